@@ -1,0 +1,83 @@
+"""ctypes binding of the C ABI declared in include/cdftools_hip.h.
+
+The library is the product: there is no Python or CPU fallback.  A missing shared object, a
+missing symbol or a missing GPU is an error the caller sees (CdftError), never a silent detour.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libcdftools_hip.so")
+
+CDFT_OK = 0
+CDFT_ERR_ARG, CDFT_ERR_HIP, CDFT_ERR_ALLOC, CDFT_ERR_STATE, CDFT_ERR_NODEVICE = 1, 2, 3, 4, 5
+MEM_HOST, MEM_DEVICE = 0, 1
+
+
+class CdftError(RuntimeError):
+    """A C-ABI call returned a non-zero status (the Fortran host turns this into STOP 98)."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libcdftools_hip status {code}: {message}")
+        self.code = code
+        self.message = message
+
+
+_vp, _i, _i64, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_size_t
+_pvp = C.POINTER(C.c_void_p)
+
+# symbol -> (restype, argtypes); must list every entry point of include/cdftools_hip.h
+SIGNATURES = {
+    "cdft_version": (_i, []),
+    "cdft_last_error": (C.c_char_p, []),
+    "cdft_device_count": (_i, [C.POINTER(_i)]),
+    "cdft_set_device": (_i, [_i]),
+    "cdft_malloc": (_i, [_pvp, _sz]),
+    "cdft_free": (_i, [_vp]),
+    "cdft_memcpy_h2d": (_i, [_vp, _vp, _sz, _vp]),
+    "cdft_memcpy_d2h": (_i, [_vp, _vp, _sz, _vp]),
+    "cdft_stream_sync": (_i, [_vp]),
+    "cdft_timer_create": (_i, [_pvp]),
+    "cdft_timer_start": (_i, [_vp, _vp]),
+    "cdft_timer_stop": (_i, [_vp, _vp]),
+    "cdft_timer_elapsed_ms": (_i, [_vp, C.POINTER(C.c_float)]),
+    "cdft_timer_destroy": (_i, [_vp]),
+    "cdft_moc_create": (_i, [_pvp, _i, _i, _i, _i]),
+    "cdft_moc_set_mesh": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
+    "cdft_moc_compute": (_i, [_vp, _vp, _i64, _i, _i, _vp, _i, _vp]),
+    "cdft_moc_set_tuning": (_i, [_vp, _i, _i, _i]),
+    "cdft_moc_describe": (_i, [_vp, C.c_char_p, _sz]),
+    "cdft_moc_profile_enable": (_i, [_vp, _i]),
+    "cdft_moc_profile_read": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(_i)]),
+    "cdft_moc_destroy": (_i, [_vp]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libcdftools_hip.so (built in-tree by __graft_entry__.build()) and type its symbols."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CdftError(
+            CDFT_ERR_STATE,
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C cdftools_amd/csrc`); there is no fallback path",
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header and library out of step
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status: int) -> None:
+    if status != CDFT_OK:
+        msg = load().cdft_last_error()
+        raise CdftError(status, msg.decode("utf-8", "replace") if msg else "(no message)")

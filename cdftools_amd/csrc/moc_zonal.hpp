@@ -1,0 +1,282 @@
+// moc_zonal.hpp -- the cdfmoc zonal kernel (gfx950), included once per basin capacity NB by
+// moc_zonal_nb{1,5,8}.hip so that the variants build in parallel.
+//
+// Replaces the reference loop src/cdfmoc.f90:355-379
+//     dmoc(jbasin,jj,jk) = dmoc(jbasin,jj,jk) - e1v(ji,jj)*e3v(ji,jj,jk)*ibmask(jbasin,ji,jj)*zv(ji,jj)*1.d0
+// Arithmetic contract (kept bit-faithful per term): the product is formed in r4, left to right,
+// then widened to r8 and accumulated in r8.  With ibmask in {0,1} the r4 product equals
+// (e1v*e3v)*zv where the basin bit is set and contributes (+/-)0 elsewhere, so the kernel keeps
+// ONE r4 weight w = e1v*e3v per cell (rounded once, as the reference's first product) plus one
+// byte of basin bits per (i,j), and selects per basin.  Only the order of the r8 additions along
+// i differs from the sequential reference (fixed tree => run-to-run deterministic).
+//
+// Work decomposition (HBM-bound, no MFMA):
+//   one workgroup            = one (jj,jk) row of npiglo cells, for ALL npt records
+//   one wave (64 lanes)      = a contiguous segment of 64*NV float4 vectors of that row
+//   weights + basin bits     = loaded once into registers, every record streams past them
+//                              => 4*(1+1/npt) algorithmic bytes per cell-record
+//   velocity                 = NV x 16-byte coalesced loads per lane per record, the next
+//                              record is in flight while the current one is reduced
+//   per-record reduction     = per-lane r8 partial sums -> one LDS transposition per wave
+//                              (8x8 lanes per basin) -> 3 cross-lane steps; waves of a row are
+//                              combined through LDS in wave order once per record chunk
+#pragma once
+#include "common.hpp"
+
+namespace cdft {
+namespace moc {
+
+constexpr int kWave      = 64;
+constexpr int kMaxNV     = 16;   // float4 vectors per lane held in registers
+constexpr int kMaxWaves  = 16;   // waves per row (1024-thread workgroup)
+constexpr int kSmallWaves = 4;   // waves per row of a 256-thread workgroup
+constexpr int kBigNV     = 6;    // vectors per lane a 1024-thread workgroup can hold unspilled
+constexpr int kTChunk    = 16;   // records combined per LDS flush
+constexpr int kScrStride = 72;   // doubles; 64 + 8 keeps the 5 basin rows on different banks
+
+enum Mode { kModeSelect = 1, kModeFma = 2 };
+
+struct ZonalArgs {
+    const float   *w;           // (npi,npj,npk) r4 weights, base 16-byte aligned, padded by 16 B
+    const uint8_t *bits;        // (npi,npj) basin bits
+    const float   *zv;          // record 0
+    int64_t        rec_stride;  // elements between records
+    int            npt;
+    double        *out;         // (nbasins,npj,npk,npt): -(zonal sum), levels 1..npk-1
+    int            npi, npj, npk, nbasins;
+};
+
+typedef int (*ZonalLauncher)(const ZonalArgs &, int nwaves, int nv, bool aligned, int mode,
+                             hipStream_t st);
+// defined by moc_zonal_nb{1,5,8}.hip
+int launch_zonal_nb1(const ZonalArgs &, int, int, bool, int, hipStream_t);
+int launch_zonal_nb5(const ZonalArgs &, int, int, bool, int, hipStream_t);
+int launch_zonal_nb8(const ZonalArgs &, int, int, bool, int, hipStream_t);
+
+#ifdef CDFT_MOC_NB
+
+__device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
+    return __shfl_xor(v, mask, kWave);
+}
+
+template <int NV, int NB, bool ALIGNED, int MODE, int LB>
+__global__ void __launch_bounds__(LB)
+moc_zonal_kernel(ZonalArgs a) {
+    extern __shared__ double smem[];
+    const int lane   = threadIdx.x & (kWave - 1);
+    const int wave   = threadIdx.x >> 6;
+    const int nwaves = blockDim.x >> 6;
+    double *scr  = smem + wave * (NB * kScrStride);              // per-wave transposition scratch
+    double *part = smem + nwaves * (NB * kScrStride);            // [kTChunk][NB][nwaves]
+
+    const int row = blockIdx.x;                                   // jk*npj + jj, jj fastest
+    const int jk  = row / a.npj;
+    const int jj  = row - jk * a.npj;
+    const int64_t g0   = (int64_t)row * a.npi;                    // first cell of the row in a 3-D field
+    const int     head = ALIGNED ? (int)(g0 & 3) : 0;             // cells before the row in its first float4
+    const int64_t a0   = g0 - head;
+    const int     v0   = wave * (kWave * NV) + lane;              // this lane's first vector
+
+    float   w[NV][4];
+    bool    ok[NV][4];
+    uint32_t bits[NV];                                            // 4 basin-bit bytes per vector
+    bool    vec_ok[NV];
+
+    // Branch-free prologue: every load uses an in-range address (clamped) and is masked
+    // afterwards, so the weight / basin-bit loads of a row are all in flight together.
+    const uint8_t *brow = a.bits + (int64_t)jj * a.npi;
+    float4   wraw[NV];
+    uint32_t braw[NV][4];
+#pragma unroll
+    for (int r = 0; r < NV; ++r) {                                // issue every load first
+        const int v  = v0 + r * kWave;
+        const int i0 = 4 * v - head;                              // column of component 0
+        vec_ok[r] = i0 < a.npi;                                   // (i0+3 >= 0 always)
+        const int vc = vec_ok[r] ? v : 0;                         // vector 0 of the row is always valid
+        if (ALIGNED) {
+            wraw[r] = *reinterpret_cast<const float4 *>(a.w + a0 + 4 * (int64_t)vc);
+        } else {                                                  // head = 0 here, so i0 >= 0
+            wraw[r].x = a.w[g0 + min(i0 + 0, a.npi - 1)];
+            wraw[r].y = a.w[g0 + min(i0 + 1, a.npi - 1)];
+            wraw[r].z = a.w[g0 + min(i0 + 2, a.npi - 1)];
+            wraw[r].w = a.w[g0 + min(i0 + 3, a.npi - 1)];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) braw[r][c] = brow[min(max(i0 + c, 0), a.npi - 1)];
+    }
+    // One record's velocity for this lane.  Lanes past the row end re-read vector 0 of the row
+    // (in range, and a cache hit); their weight is 0 and their basin bits are clear.
+    auto load_rec = [&](float (&z)[NV][4], int t) {
+        const float *zr = a.zv + (int64_t)t * a.rec_stride;
+#pragma unroll
+        for (int r = 0; r < NV; ++r) {
+            const int v  = v0 + r * kWave;
+            const int vc = vec_ok[r] ? v : 0;
+            if (ALIGNED) {
+                const float4 q = *reinterpret_cast<const float4 *>(zr + a0 + 4 * (int64_t)vc);
+                z[r][0] = q.x; z[r][1] = q.y; z[r][2] = q.z; z[r][3] = q.w;
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) z[r][c] = zr[g0 + min(4 * v + c, a.npi - 1)];
+            }
+        }
+    };
+
+    float zc[NV][4], zn[NV][4];
+    load_rec(zc, 0);                                              // first record in flight behind the weights
+
+#pragma unroll
+    for (int r = 0; r < NV; ++r) {                                // then mask what lies outside the row
+        const int i0 = 4 * (v0 + r * kWave) - head;
+        uint32_t bb = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int i = i0 + c;
+            ok[r][c] = (i >= 0) && (i < a.npi);
+            bb |= (ok[r][c] ? braw[r][c] : 0u) << (8 * c);
+        }
+        bits[r] = bb;
+        w[r][0] = ok[r][0] ? wraw[r].x : 0.f;
+        w[r][1] = ok[r][1] ? wraw[r].y : 0.f;
+        w[r][2] = ok[r][2] ? wraw[r].z : 0.f;
+        w[r][3] = ok[r][3] ? wraw[r].w : 0.f;
+    }
+
+    // MODE fma: basin masks as r8 0/1 multipliers held in registers (small NV only).
+    double m[MODE == kModeFma ? NV : 1][4][NB];
+    if (MODE == kModeFma) {
+#pragma unroll
+        for (int r = 0; r < NV; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+                    m[r][c][b] = ((bits[r] >> (8 * c + b)) & 1u) ? 1.0 : 0.0;
+    }
+
+
+    for (int t0 = 0; t0 < a.npt; t0 += kTChunk) {
+        const int tcount = min(kTChunk, a.npt - t0);
+        for (int tl = 0; tl < tcount; ++tl) {
+            const int t = t0 + tl;
+            if (t + 1 < a.npt) load_rec(zn, t + 1);               // next record in flight
+
+            double acc[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) acc[b] = 0.0;
+#pragma unroll
+            for (int r = 0; r < NV; ++r) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    // r4 product, then widen: src/cdfmoc.f90:373-374
+                    const float zf = (MODE == kModeFma) ? (ok[r][c] ? zc[r][c] : 0.f) : zc[r][c];
+                    const double pd = (double)__fmul_rn(w[r][c], zf);
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) {
+                        if (MODE == kModeFma)
+                            acc[b] = __fma_rn(pd, m[r][c][b], acc[b]);
+                        else
+                            acc[b] += ((bits[r] >> (8 * c + b)) & 1u) ? pd : 0.0;
+                    }
+                }
+            }
+
+            // wave reduction: transpose through LDS so that lane (b*8+s) sums 8 lanes' partials
+#pragma unroll
+            for (int b = 0; b < NB; ++b) scr[b * kScrStride + lane] = acc[b];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            double s = 0.0;
+            if (lane < NB * 8) {
+                const double *p = scr + (lane >> 3) * kScrStride + (lane & 7);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s += p[8 * j];
+            }
+            s += shfl_xor_f64(s, 1);
+            s += shfl_xor_f64(s, 2);
+            s += shfl_xor_f64(s, 4);
+            __builtin_amdgcn_wave_barrier();                      // scr is rewritten next record
+            if (lane < NB * 8 && (lane & 7) == 0) {
+                const int b = lane >> 3;
+                if (nwaves == 1) {
+                    if (b < a.nbasins)
+                        a.out[(((int64_t)t * a.npk + jk) * a.npj + jj) * a.nbasins + b] = -s;
+                } else {
+                    part[(tl * NB + b) * nwaves + wave] = s;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < NV; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) zc[r][c] = zn[r][c];
+        }
+        if (nwaves > 1) {
+            __syncthreads();
+            if ((int)threadIdx.x < tcount * NB) {
+                const int tl = threadIdx.x / NB, b = threadIdx.x - tl * NB;
+                double s = 0.0;
+                for (int k = 0; k < nwaves; ++k) s += part[(tl * NB + b) * nwaves + k];
+                if (b < a.nbasins)
+                    a.out[(((int64_t)(t0 + tl) * a.npk + jk) * a.npj + jj) * a.nbasins + b] = -s;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <int NV, int NB, bool ALIGNED, int MODE, int LB>
+static int launch_lb(const ZonalArgs &a, int nwaves, hipStream_t st) {
+    const size_t shmem =
+        sizeof(double) * ((size_t)nwaves * NB * kScrStride + (size_t)kTChunk * NB * nwaves);
+    const unsigned grid = (unsigned)a.npj * (unsigned)(a.npk - 1);
+    hipLaunchKernelGGL((moc_zonal_kernel<NV, NB, ALIGNED, MODE, LB>), dim3(grid),
+                       dim3(kWave * nwaves), shmem, st, a);
+    CDFT_LAUNCH_CHECK();
+    return CDFT_OK;
+}
+
+// Workgroups of up to kSmallWaves waves get the full register budget (512 VGPRs / lane at one
+// wave per SIMD); longer rows use up to kMaxWaves waves with at most kBigNV vectors per lane,
+// which fits the 128 VGPRs a 1024-thread workgroup leaves per lane.
+template <int NV, int NB, bool ALIGNED, int MODE>
+static int launch_one(const ZonalArgs &a, int nwaves, hipStream_t st) {
+    if (nwaves <= kSmallWaves) return launch_lb<NV, NB, ALIGNED, MODE, kWave * kSmallWaves>(a, nwaves, st);
+    if constexpr (NV <= kBigNV && MODE == kModeSelect)
+        return launch_lb<NV, NB, ALIGNED, MODE, kWave * kMaxWaves>(a, nwaves, st);
+    else
+        return fail(CDFT_ERR_ARG, "%d waves per row need <= %d vectors per lane (select mode), got %d",
+                    nwaves, kBigNV, NV);
+}
+
+template <int NB>
+static int launch_nb(const ZonalArgs &a, int nwaves, int nv, bool aligned, int mode,
+                     hipStream_t st) {
+    if (!aligned) {
+        if (nv != 4 || mode != kModeSelect)
+            return fail(CDFT_ERR_ARG, "unaligned zonal path supports nv=4, select mode only");
+        return launch_one<4, NB, false, kModeSelect>(a, nwaves, st);
+    }
+    if (mode == kModeFma) {
+        switch (nv) {
+            case 1: return launch_one<1, NB, true, kModeFma>(a, nwaves, st);
+            case 2: return launch_one<2, NB, true, kModeFma>(a, nwaves, st);
+            case 3: return launch_one<3, NB, true, kModeFma>(a, nwaves, st);
+            case 4: return launch_one<4, NB, true, kModeFma>(a, nwaves, st);
+            default: return fail(CDFT_ERR_ARG, "fma mode supports 1..4 vectors per lane, got %d", nv);
+        }
+    }
+    switch (nv) {
+#define CDFT_CASE(N) case N: return launch_one<N, NB, true, kModeSelect>(a, nwaves, st);
+        CDFT_CASE(1) CDFT_CASE(2) CDFT_CASE(3) CDFT_CASE(4) CDFT_CASE(5) CDFT_CASE(6)
+        CDFT_CASE(7) CDFT_CASE(8) CDFT_CASE(9) CDFT_CASE(10) CDFT_CASE(11) CDFT_CASE(12)
+        CDFT_CASE(13) CDFT_CASE(14) CDFT_CASE(15) CDFT_CASE(16)
+#undef CDFT_CASE
+        default: return fail(CDFT_ERR_ARG, "vectors per lane must be 1..16, got %d", nv);
+    }
+}
+
+#endif  // CDFT_MOC_NB
+
+}  // namespace moc
+}  // namespace cdft

@@ -1,0 +1,169 @@
+// runtime.hip -- device/runtime entry points of the C ABI (include/cdftools_hip.h, "runtime").
+#include "common.hpp"
+
+namespace cdft {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int require_device() {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(CDFT_ERR_NODEVICE,
+                    "no HIP device available (hipGetDeviceCount: %s, count %d); "
+                    "libcdftools_hip has no CPU fallback",
+                    hipGetErrorString(e), n);
+    }
+    return CDFT_OK;
+}
+
+int DevBuf::reserve(size_t n) {
+    if (n <= bytes) return CDFT_OK;
+    release();
+    if (hipMalloc(&ptr, n) != hipSuccess) {
+        (void)hipGetLastError();
+        ptr = nullptr;
+        return fail(CDFT_ERR_ALLOC, "hipMalloc of %zu bytes failed", n);
+    }
+    bytes = n;
+    return CDFT_OK;
+}
+
+void DevBuf::release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    bytes = 0;
+}
+
+int to_device(const void *src, size_t n, int memspace, DevBuf &stage, hipStream_t st,
+              const void **dev) {
+    if (memspace == CDFT_MEM_DEVICE) {
+        *dev = src;
+        return CDFT_OK;
+    }
+    if (memspace != CDFT_MEM_HOST) return fail(CDFT_ERR_ARG, "bad memory-space tag %d", memspace);
+    CDFT_TRY(stage.reserve(n));
+    CDFT_HIP(hipMemcpyAsync(stage.ptr, src, n, hipMemcpyHostToDevice, st));
+    *dev = stage.ptr;
+    return CDFT_OK;
+}
+
+struct Timer {
+    hipEvent_t t0, t1;
+};
+
+}  // namespace cdft
+
+using namespace cdft;
+
+extern "C" {
+
+int cdft_version(void) { return 100; }
+
+const char *cdft_last_error(void) { return g_err; }
+
+int cdft_device_count(int *count) {
+    if (!count) return fail(CDFT_ERR_ARG, "cdft_device_count: NULL argument");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        n = 0;
+    }
+    *count = n;
+    return CDFT_OK;
+}
+
+int cdft_set_device(int device) {
+    CDFT_TRY(require_device());
+    CDFT_HIP(hipSetDevice(device));
+    return CDFT_OK;
+}
+
+int cdft_malloc(void **ptr, size_t bytes) {
+    if (!ptr) return fail(CDFT_ERR_ARG, "cdft_malloc: NULL argument");
+    CDFT_TRY(require_device());
+    if (hipMalloc(ptr, bytes ? bytes : 1) != hipSuccess) {
+        (void)hipGetLastError();
+        *ptr = nullptr;
+        return fail(CDFT_ERR_ALLOC, "hipMalloc of %zu bytes failed", bytes);
+    }
+    return CDFT_OK;
+}
+
+int cdft_free(void *ptr) {
+    if (ptr) CDFT_HIP(hipFree(ptr));
+    return CDFT_OK;
+}
+
+int cdft_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream) {
+    CDFT_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, as_stream(stream)));
+    return CDFT_OK;
+}
+
+int cdft_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream) {
+    CDFT_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, as_stream(stream)));
+    CDFT_HIP(hipStreamSynchronize(as_stream(stream)));
+    return CDFT_OK;
+}
+
+int cdft_stream_sync(void *stream) {
+    CDFT_HIP(hipStreamSynchronize(as_stream(stream)));
+    return CDFT_OK;
+}
+
+int cdft_timer_create(void **timer) {
+    if (!timer) return fail(CDFT_ERR_ARG, "cdft_timer_create: NULL argument");
+    CDFT_TRY(require_device());
+    Timer *t = new Timer;
+    CDFT_HIP(hipEventCreate(&t->t0));
+    CDFT_HIP(hipEventCreate(&t->t1));
+    *timer = t;
+    return CDFT_OK;
+}
+
+int cdft_timer_start(void *timer, void *stream) {
+    if (!timer) return fail(CDFT_ERR_ARG, "cdft_timer_start: NULL timer");
+    CDFT_HIP(hipEventRecord(static_cast<Timer *>(timer)->t0, as_stream(stream)));
+    return CDFT_OK;
+}
+
+int cdft_timer_stop(void *timer, void *stream) {
+    if (!timer) return fail(CDFT_ERR_ARG, "cdft_timer_stop: NULL timer");
+    CDFT_HIP(hipEventRecord(static_cast<Timer *>(timer)->t1, as_stream(stream)));
+    return CDFT_OK;
+}
+
+int cdft_timer_elapsed_ms(void *timer, float *ms) {
+    if (!timer || !ms) return fail(CDFT_ERR_ARG, "cdft_timer_elapsed_ms: NULL argument");
+    Timer *t = static_cast<Timer *>(timer);
+    CDFT_HIP(hipEventSynchronize(t->t1));
+    CDFT_HIP(hipEventElapsedTime(ms, t->t0, t->t1));
+    return CDFT_OK;
+}
+
+int cdft_timer_destroy(void *timer) {
+    if (!timer) return CDFT_OK;
+    Timer *t = static_cast<Timer *>(timer);
+    (void)hipEventDestroy(t->t0);
+    (void)hipEventDestroy(t->t1);
+    delete t;
+    return CDFT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,163 @@
+"""Host-side mirror of the C ABI for Python callers (tests, bench.py, smoke).
+
+The product is libcdftools_hip.so behind include/cdftools_hip.h; the drop-in host programs are
+Fortran (cdftools_amd/fortran/).  This module only gives Python the same calls with array
+arguments, so that the parity tests read like the reference loops they check.
+
+Array convention: the reference is Fortran, column-major.  A NumPy / torch array handed to these
+wrappers is C-contiguous with the dimensions REVERSED, e.g. the reference's zv(npiglo,npjglo,npk)
+per record is shape (npt, npk, npjglo, npiglo) here, ibmask(nbasins,npiglo,npjglo) is
+(npjglo, npiglo, nbasins) and dmoc(nbasins,npjglo,npk) per record is (npt, npk, npjglo, nbasins).
+NumPy arrays are host memory (the library stages them through HBM); torch CUDA tensors are used in
+place (no copy).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import MEM_DEVICE, MEM_HOST, CdftError, check
+
+try:  # torch is plumbing for device memory / streams only
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+
+def _is_tensor(x) -> bool:
+    return torch is not None and isinstance(x, torch.Tensor)
+
+
+def _arg(x, dtype, name):
+    """-> (pointer, memspace, keepalive) for a NumPy array (host) or torch CUDA tensor (device)."""
+    if _is_tensor(x):
+        want = {np.float32: torch.float32, np.float64: torch.float64, np.int16: torch.int16,
+                np.uint8: torch.uint8, np.int8: torch.int8}[dtype]
+        if x.dtype != want:
+            raise TypeError(f"{name}: expected {want}, got {x.dtype}")
+        if not x.is_contiguous():
+            raise ValueError(f"{name}: tensor must be contiguous")
+        if x.is_cuda:
+            return C.c_void_p(x.data_ptr()), MEM_DEVICE, x
+        a = x.numpy()
+        return C.c_void_p(a.ctypes.data), MEM_HOST, a
+    a = np.ascontiguousarray(x, dtype=dtype)
+    return C.c_void_p(a.ctypes.data), MEM_HOST, a
+
+
+def current_stream_ptr():
+    """hipStream_t of torch's current stream (so torch.cuda.Event brackets see the kernels)."""
+    if torch is not None and torch.cuda.is_available():
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(0)
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    check(_lib.load().cdft_device_count(C.byref(n)))
+    return n.value
+
+
+class Timer:
+    """HIP events on a given stream (cdft_timer_*)."""
+
+    def __init__(self):
+        self._h = C.c_void_p()
+        check(_lib.load().cdft_timer_create(C.byref(self._h)))
+
+    def start(self, stream=None):
+        check(_lib.load().cdft_timer_start(self._h, stream or current_stream_ptr()))
+
+    def stop(self, stream=None):
+        check(_lib.load().cdft_timer_stop(self._h, stream or current_stream_ptr()))
+
+    def elapsed_ms(self) -> float:
+        ms = C.c_float(0)
+        check(_lib.load().cdft_timer_elapsed_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    def __del__(self):
+        try:
+            _lib.load().cdft_timer_destroy(self._h)
+        except Exception:
+            pass
+
+
+class MocPlan:
+    """cdfmoc hot path (src/cdfmoc.f90:325-388) on one GPU: cdft_moc_* of the C ABI."""
+
+    def __init__(self, npiglo: int, npjglo: int, npk: int, nbasins: int):
+        self.npi, self.npj, self.npk, self.nb = npiglo, npjglo, npk, nbasins
+        self._h = C.c_void_p()
+        check(_lib.load().cdft_moc_create(C.byref(self._h), npiglo, npjglo, npk, nbasins))
+
+    def set_mesh(self, e1v, e3v, ibmask, stream=None):
+        """e1v (npj,npi) r4; e3v (npk,npj,npi) r4 already * vmask; ibmask (npj,npi,nb) i2 in {0,1}."""
+        p1, s1, k1 = _arg(e1v, np.float32, "e1v")
+        p2, s2, k2 = _arg(e3v, np.float32, "e3v")
+        p3, s3, k3 = _arg(ibmask, np.int16, "ibmask")
+        if not (s1 == s2 == s3):
+            raise ValueError("e1v, e3v and ibmask must live in the same memory space")
+        for k, n, nm in ((k1, self.npi * self.npj, "e1v"), (k2, self.npi * self.npj * self.npk, "e3v"),
+                         (k3, self.npi * self.npj * self.nb, "ibmask")):
+            if int(np.prod(k.shape)) != n:
+                raise ValueError(f"{nm}: expected {n} elements, got shape {tuple(k.shape)}")
+        check(_lib.load().cdft_moc_set_mesh(self._h, p1, p2, p3, s1, stream or current_stream_ptr()))
+
+    def set_tuning(self, waves_per_row=0, vec_per_lane=0, mode=0):
+        check(_lib.load().cdft_moc_set_tuning(self._h, waves_per_row, vec_per_lane, mode))
+
+    def describe(self) -> str:
+        buf = C.create_string_buffer(256)
+        check(_lib.load().cdft_moc_describe(self._h, buf, 256))
+        return buf.value.decode()
+
+    def profile_enable(self, on=True):
+        check(_lib.load().cdft_moc_profile_enable(self._h, 1 if on else 0))
+
+    def profile_read(self):
+        """-> (summed zonal-kernel duration in ms, number of launches) since the last read."""
+        ms, n = C.c_double(0), C.c_int(0)
+        check(_lib.load().cdft_moc_profile_read(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def compute(self, zv, out=None, rec_stride=None, npt=None, stream=None):
+        """zv (npt,npk,npj,npi) r4 -> dmoc (npt,npk,npj,nb) r8 in Sv (same memory space as zv
+        unless `out` is given)."""
+        pz, sz, kz = _arg(zv, np.float32, "zv")
+        n3 = self.npi * self.npj * self.npk
+        if npt is None:
+            total = int(np.prod(kz.shape))
+            if total % n3:
+                raise ValueError(f"zv: {total} elements is not a whole number of records of {n3}")
+            npt = total // n3
+        if rec_stride is None:
+            rec_stride = n3
+        shape = (npt, self.npk, self.npj, self.nb)
+        if out is None:
+            if sz == MEM_DEVICE:
+                out = torch.empty(shape, dtype=torch.float64, device=zv.device)
+            else:
+                out = np.empty(shape, dtype=np.float64)
+        po, so, ko = _arg(out, np.float64, "dmoc")
+        if int(np.prod(ko.shape)) != int(np.prod(shape)):
+            raise ValueError(f"dmoc: expected shape {shape}, got {tuple(ko.shape)}")
+        check(_lib.load().cdft_moc_compute(self._h, pz, rec_stride, npt, sz, po, so,
+                                           stream or current_stream_ptr()))
+        return out
+
+    def close(self):
+        if self._h:
+            _lib.load().cdft_moc_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+__all__ = ["MocPlan", "Timer", "CdftError", "device_count", "current_stream_ptr", "MEM_HOST", "MEM_DEVICE"]

@@ -1,0 +1,113 @@
+/*
+ * cdftools_hip.h -- C ABI of the MI355X (gfx950) hot-path library libcdftools_hip.so
+ *
+ * This is the drop-in boundary between the Fortran host programs (cdfmoc, cdfmhst, cdfvT,
+ * cdfheatc, cdfpsi, cdfcurl, cdfsig0, cdfsigi) and the hand-written HIP kernels.  The reference
+ * (meom-group/CDFTOOLS) has no FFI: its numerical loops are written inline in each PROGRAM unit.
+ * Every entry point below therefore cites the reference loop (file:line under src/) that it
+ * replaces; the Fortran ISO_C_BINDING interface blocks for these symbols live in
+ * cdftools_amd/fortran/cdftools_hip.f90 and are reproduced in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C symbols, plain pointers and sizes; no C++/torch types.
+ *   - every function returns an int status: CDFT_OK (0) or a CDFT_ERR_* code; the message is
+ *     available from cdft_last_error().  The Fortran wrappers turn a non-zero status into the
+ *     reference's fatal-error convention (message + STOP 98, cf. src/cdfio.F90:2924-2940).
+ *   - arrays are Fortran column-major, first index fastest: a "slab" is (npiglo,npjglo) r4,
+ *     a 3-D field is (npiglo,npjglo,npk), records are appended as the slowest index.
+ *   - every array argument carries a memory-space tag: CDFT_MEM_HOST (the library stages it
+ *     through HBM itself) or CDFT_MEM_DEVICE (already resident in HBM; nothing is copied).
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls whose output
+ *     space is CDFT_MEM_DEVICE are asynchronous on that stream; calls that return results to
+ *     host memory synchronise the stream before returning.
+ *   - a plan owns its device memory; the caller owns every array it passes in.
+ *   - one plan must not be used from two host threads at once (the reference is single-threaded,
+ *     src/cdfio.F90:72-73 keeps module-level state).
+ *   - there is NO CPU fallback inside this library: without a usable HIP device every compute
+ *     entry point returns CDFT_ERR_NODEVICE.
+ */
+#ifndef CDFTOOLS_HIP_H
+#define CDFTOOLS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CDFT_OK            0
+#define CDFT_ERR_ARG       1   /* invalid argument (NULL pointer, bad size, bad mask value ...) */
+#define CDFT_ERR_HIP       2   /* a HIP runtime call or kernel launch failed                     */
+#define CDFT_ERR_ALLOC     3   /* device or host allocation failed                               */
+#define CDFT_ERR_STATE     4   /* call sequence error (e.g. compute before set_mesh)             */
+#define CDFT_ERR_NODEVICE  5   /* no HIP device available                                        */
+
+#define CDFT_MEM_HOST      0
+#define CDFT_MEM_DEVICE    1
+
+/* ------------------------------------------------------------------------------------------ */
+/* runtime                                                                                    */
+/* ------------------------------------------------------------------------------------------ */
+int         cdft_version(void);                       /* 100*major + minor */
+const char *cdft_last_error(void);                    /* message of the last failing call (thread-local) */
+int         cdft_device_count(int *count);            /* never fails on a box without GPU: *count = 0 */
+int         cdft_set_device(int device);
+int         cdft_malloc(void **ptr, size_t bytes);    /* HBM allocation */
+int         cdft_free(void *ptr);
+int         cdft_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream);
+int         cdft_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream); /* synchronises */
+int         cdft_stream_sync(void *stream);
+/* launch-duration probe: HIP events recorded on the stream the kernels are launched on */
+int         cdft_timer_create(void **timer);
+int         cdft_timer_start(void *timer, void *stream);
+int         cdft_timer_stop(void *timer, void *stream);
+int         cdft_timer_elapsed_ms(void *timer, float *ms); /* synchronises on the stop event */
+int         cdft_timer_destroy(void *timer);
+
+/* ------------------------------------------------------------------------------------------ */
+/* cdfmoc : meridional overturning stream function                                            */
+/*   replaces src/cdfmoc.f90:355-379 (zonal masked weighted sum, hot loop 1)                   */
+/*        and src/cdfmoc.f90:382-388 (bottom-to-surface cumulated sum, hot loop 2)             */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct cdft_moc_plan cdft_moc_plan;
+
+/* npiglo,npjglo: horizontal size of the (local row block of the) domain; npk: number of levels;
+ * nbasins: 1..8 (the reference uses 1 or 5, src/cdfmoc.f90:270-274). */
+int cdft_moc_create(cdft_moc_plan **plan, int npiglo, int npjglo, int npk, int nbasins);
+
+/* Time-invariant inputs (once per run; once per record with -vvl, src/cdfmoc.f90:343-348):
+ *   e1v    (npiglo,npjglo)         r4  src/cdfmoc.f90:306
+ *   e3v    (npiglo,npjglo,npk)     r4  already multiplied by vmask(level) as get_e3v does,
+ *                                      src/cdfmoc.f90:576-596
+ *   ibmask (nbasins,npiglo,npjglo) i2  values 0/1, basin index fastest, src/cdfmoc.f90:281,325-336
+ * The plan keeps one r4 weight e1v*e3v (rounded to r4 exactly as the reference expression's
+ * first product) and one byte of basin bits per (i,j); the inputs may be released afterwards. */
+int cdft_moc_set_mesh(cdft_moc_plan *plan, const float *e1v, const float *e3v,
+                      const int16_t *ibmask, int memspace, void *stream);
+
+/* zv   : npt records of (npiglo,npjglo,npk) r4 meridional velocity, record r starting at
+ *        zv + r*rec_stride (rec_stride in elements, >= npiglo*npjglo*npk; level npk is never
+ *        read, as in the reference loop jk=1,npk-1).
+ * dmoc : (nbasins,npjglo,npk,npt) r8, in Sverdrup, exactly the reference's dmoc(:,:,:) after
+ *        its loop 2 for each record; level npk is 0. */
+int cdft_moc_compute(cdft_moc_plan *plan, const float *zv, int64_t rec_stride, int npt,
+                     int zv_space, double *dmoc, int dmoc_space, void *stream);
+
+/* Tuning hook for the measurement harness: waves per row (0 = automatic) and float4 vectors
+ * per lane (0 = automatic), accumulate mode (0 = automatic, 1 = select, 2 = fma-with-mask). */
+int cdft_moc_set_tuning(cdft_moc_plan *plan, int waves_per_row, int vec_per_lane, int mode);
+/* name of the zonal kernel variant the next compute will launch (for profiles) */
+int cdft_moc_describe(cdft_moc_plan *plan, char *buf, size_t buflen);
+/* Launch-duration probe for the dominant (zonal) kernel: while enabled, every cdft_moc_compute
+ * brackets its zonal-kernel launch with HIP events on the launch stream.  cdft_moc_profile_read
+ * synchronises on them, returns the summed duration and the number of launches, and resets. */
+int cdft_moc_profile_enable(cdft_moc_plan *plan, int on);
+int cdft_moc_profile_read(cdft_moc_plan *plan, double *zonal_ms_total, int *launches);
+
+int cdft_moc_destroy(cdft_moc_plan *plan);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CDFTOOLS_HIP_H */

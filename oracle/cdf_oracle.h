@@ -1,0 +1,40 @@
+/*
+ * cdf_oracle.h -- CPU restatement of the CDFTOOLS hot-path loops (TEST INFRASTRUCTURE ONLY).
+ *
+ * Nothing under cdftools_amd/ may include, link or call this.  Only tests/, the smoke check in
+ * __graft_entry__.py and the cpu_baseline leg of bench.py use it, and only as the checker.
+ *
+ * Every function restates one reference loop in the reference's own evaluation order and r4/r8
+ * mixing; the reference file:line it follows is cited at each definition in cdf_oracle.c.
+ *
+ * Pinning status (see DESIGN.md "Oracle"):
+ *   - sigma0 / sigmai : PINNED.  Checked against the reference's own known-answer values
+ *     (src/eos.f90:817,:820) and against oracle/_ref (the unmodified src/eos.f90 compiled with
+ *     amdflang) through tests/golden/eos_*.npz.
+ *   - cdfmoc, cdfheatc, cdfmhst, cdfvT, cdfpsi, cdfcurl loops : PARITY UNPINNED.  The reference
+ *     holds no tests, golden files or fixtures for them, and its programs cannot be built here
+ *     (they need netcdf-fortran, which the image lacks); these restatements are pinned only by
+ *     line-by-line reading of the cited source.
+ *
+ * Arrays are Fortran column-major (first index fastest), as in include/cdftools_hip.h.
+ */
+#ifndef CDF_ORACLE_H
+#define CDF_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* src/cdfmoc.f90:352-388 for ONE record.
+ *   e1v(npi,npj) e3v(npi,npj,npk) [already * vmask(level)] ibmask(nb,npi,npj) zv(npi,npj,npk)
+ *   dmoc(nb,npj,npk) out, Sverdrup.  Levels 1..npk-1 of zv are read (jk=1,npk-1). */
+void oracle_moc(int npi, int npj, int npk, int nb, const float *e1v, const float *e3v,
+                const int16_t *ibmask, const float *zv, double *dmoc);
+/* number of OpenMP threads the oracle's parallel loops use (1 when built without OpenMP) */
+int oracle_num_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
