@@ -68,6 +68,14 @@ def load() -> C.CDLL:
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C cdftools_amd/csrc`); there is no fallback path",
         )
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.  When Python callers
+    # also use torch (device memory, streams), torch must be loaded first so that this library
+    # binds to the same runtime instance and torch's stream handles are valid here.  (The Fortran
+    # host programs link the system runtime directly and never see torch.)
+    try:
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch-less callers use the system runtime
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here = header and library out of step

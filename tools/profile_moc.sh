@@ -1,0 +1,16 @@
+#!/bin/bash
+# rocprofv3 passes for the bench workload; run on the GPU box from the repo root:
+#   bash tools/profile_moc.sh <tag>          (outputs under gpurun_out/prof_<tag>/)
+# Pass 1: --kernel-trace --stats (per-kernel durations).  Passes 2,3: PMC counters alone
+# (FETCH_SIZE and WRITE_SIZE need separate passes: TCC has 4 slots, FETCH_SIZE takes 3).
+set -u
+TAG=${1:-r01}
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$REPO/gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+ARGS="$REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline ${BENCH_ARGS:-}"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 $ARGS > "$OUT/trace.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 $ARGS > "$OUT/pmc_fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 $ARGS > "$OUT/pmc_write.log" 2>&1
+find "$OUT" -name "*.csv" | head -20
