@@ -52,6 +52,10 @@ SIGNATURES = {
     "cdft_moc_profile_enable": (_i, [_vp, _i]),
     "cdft_moc_profile_read": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(_i)]),
     "cdft_moc_destroy": (_i, [_vp]),
+    "cdft_eos_sigmai": (_i, [_vp, _vp, _i64, C.c_float, _i, _i, _vp, _i, _i, _vp]),
+    "cdft_eos_sigmai2d": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _i, _i, _vp]),
+    "cdft_eos_sig_tool": (_i, [_vp, _vp, _i64, C.c_float, C.c_float, _i, _i, _vp, _i, _i, _vp]),
+    "cdft_eos_release": (_i, []),
 }
 
 _lib = None

@@ -1,0 +1,267 @@
+// eos.hip -- pointwise equation of state: sigma0 / sigmai (C ABI section "eos").
+// Reference: src/eos.f90:601-632 (sigma0), :802-887 (sigmai_dep), :1002-1087 (sigmai_dep2d),
+// :889-1000 / :1089-1201 (Jackett-McDougall 1994 variants), coefficients from eos_init :207-598;
+// callers src/cdfsig0.f90:146-152 and src/cdfsigi.f90:131-137.
+//
+// r8 arithmetic on widened r4 inputs, ~120 r8 operations per point for 12-16 bytes of traffic:
+// without FMA contraction the kernel sits at the fp64-vector ridge, so the exact
+// variant (same operation order and rounding as the reference, bit-identical results) is offered
+// next to a contracted one (CDFT_EOS_FAST_FMA, a few ulp of r8, invisible after the r4 store).
+#include "common.hpp"
+#include "eos_coef.h"
+
+using namespace cdft;
+
+namespace {
+
+__constant__ double kC[2][CDFT_EOS_NK][CDFT_EOS_NJ][CDFT_EOS_NI] = CDFT_EOS_COEF_INIT;
+__constant__ double kR[6] = CDFT_EOS_REF_INIT;
+
+template <bool FAST>
+__device__ __forceinline__ double muladd(double a, double b, double c) {
+    return FAST ? __fma_rn(a, b, c) : __dadd_rn(__dmul_rn(a, b), c);
+}
+
+// r_k(t,s) with the reference's association (src/eos.f90:858-875): each t-level is written
+//   ( ... )*dlt + (((c_n*dls + c_{n-1})*dls + ...) + c_1)*dls + c_0  ==  (acc*t + Y*s) + c_0
+template <int SET, int K, bool FAST>
+__device__ __forceinline__ double eos_rk(double t, double s) {
+    constexpr int jmax = CDFT_EOS_JMAX(K);
+    double acc = kC[SET][K][jmax][0];
+#pragma unroll
+    for (int j = jmax - 1; j >= 0; --j) {
+        const int imax = jmax - j;
+        double y = kC[SET][K][j][imax];
+#pragma unroll
+        for (int i = imax - 1; i >= 1; --i) y = muladd<FAST>(y, s, kC[SET][K][j][i]);
+        if (FAST)
+            acc = __fma_rn(acc, t, __fma_rn(y, s, kC[SET][K][j][0]));
+        else
+            acc = __dadd_rn(__dadd_rn(__dmul_rn(acc, t), __dmul_rn(y, s)), kC[SET][K][j][0]);
+    }
+    return acc;
+}
+
+template <int SET, bool FAST>
+__device__ __forceinline__ double sigmai_point(float ptem, float psal, float pref) {
+    constexpr double rdeltas = SET ? CDFT_EOS_RDELTAS_T10 : CDFT_EOS_RDELTAS_80;
+    constexpr double r1_s0   = SET ? CDFT_EOS_R1_S0_T10 : CDFT_EOS_R1_S0_80;
+    const double h = __dmul_rn((double)pref, CDFT_EOS_R1_Z0);                       // :842 / :1046
+    double ref = kR[5];                                                             // :845 / :1050
+#pragma unroll
+    for (int q = 4; q >= 0; --q) ref = muladd<FAST>(ref, h, kR[q]);
+    ref = __dmul_rn(ref, h);
+    const double t  = __dmul_rn((double)ptem, CDFT_EOS_R1_T0);                      // :850
+    const double s  = __dsqrt_rn(__dmul_rn(fabs(__dadd_rn((double)psal, rdeltas)), r1_s0));  // :851
+    const double tm = (psal == 0.0f) ? 0.0 : 1.0;                                   // :852-856
+    const double r3 = eos_rk<SET, 3, FAST>(t, s);
+    const double r2 = eos_rk<SET, 2, FAST>(t, s);
+    const double r1 = eos_rk<SET, 1, FAST>(t, s);
+    const double r0 = eos_rk<SET, 0, FAST>(t, s);
+    const double r  = muladd<FAST>(muladd<FAST>(muladd<FAST>(r3, h, r2), h, r1), h, r0);   // :877
+    return __dmul_rn(__dadd_rn(__dadd_rn(r, ref), -CDFT_EOS_RAU0), tm);            // :880
+}
+
+template <int N>
+__device__ __forceinline__ double horner(const double (&c)[N], double t) {
+    double a = c[0];
+#pragma unroll
+    for (int i = 1; i < N; ++i) a = __dadd_rn(__dmul_rn(a, t), c[i]);
+    return a;
+}
+
+// Jackett & McDougall 1994 (src/eos.f90:936-995); note SQRT(ABS(psal)) is an r4 expression (:931).
+__device__ __forceinline__ double jmd94_point(float ptem, float psal, float pref) {
+    constexpr double c_r1[] = {6.536332e-9, -1.120083e-6, 1.001685e-4, -9.095290e-3, 6.793952e-2, 999.842594};
+    constexpr double c_r2[] = {5.3875e-9, -8.2467e-7, 7.6438e-5, -4.0899e-3, 0.824493};
+    constexpr double c_r3[] = {-1.6546e-6, 1.0227e-4, -5.72466e-3};
+    constexpr double c_e[]  = {-3.508914e-8, -1.248266e-8, -2.595994e-6};
+    constexpr double c_bw[] = {1.296821e-6, -5.782165e-9, 1.045941e-4};
+    constexpr double c_c[]  = {-7.267926e-5, 2.598241e-3, 0.1571896};
+    constexpr double c_aw[] = {5.939910e-6, 2.512549e-3, -0.1028859, -4.721788};
+    constexpr double c_b1[] = {-0.1909078, 7.390729, -55.87545};
+    constexpr double c_a1[] = {2.326469e-3, 1.553190, -65.00517, 1044.077};
+    constexpr double c_kw[] = {-1.361629e-4, -1.852732e-2, -30.41638, 2098.925, 190925.6};
+    const double ref = (double)pref;
+    const double rs  = (double)__fsqrt_rn(fabsf(psal));
+    const double t = (double)ptem, s = (double)psal;
+    const double r1 = horner(c_r1, t), r2 = horner(c_r2, t), r3 = horner(c_r3, t);
+    const double rhop = __dadd_rn(__dmul_rn(__dadd_rn(__dadd_rn(__dmul_rn(4.8314e-4, s), __dmul_rn(r3, rs)), r2), s), r1);
+    const double e = horner(c_e, t), bw = horner(c_bw, t);
+    const double b = __dadd_rn(bw, __dmul_rn(e, s));
+    const double c = horner(c_c, t), aw = horner(c_aw, t);
+    const double a = __dadd_rn(__dmul_rn(__dadd_rn(__dmul_rn(-2.042967e-2, rs), c), s), aw);
+    const double b1 = horner(c_b1, t), a1 = horner(c_a1, t), kw = horner(c_kw, t);
+    const double k0 = __dadd_rn(__dmul_rn(__dadd_rn(__dmul_rn(b1, rs), a1), s), kw);
+    const double den = __dadd_rn(1.0, -__ddiv_rn(ref, __dadd_rn(k0, -__dmul_rn(ref, __dadd_rn(a, -__dmul_rn(ref, b))))));
+    return __dadd_rn(__ddiv_rn(rhop, den), -1000.0);
+}
+
+enum Kind { kScalarRef = 0, kPointRef = 1, kTool = 2 };
+
+struct EosArgs {
+    const float *t, *s, *p2d;
+    double *out8;
+    float  *out4;
+    int64_t n;
+    float pref, spval;
+};
+
+template <int EOS, bool FAST>
+__device__ __forceinline__ double eval_point(float t, float s, float p) {
+    if (EOS == 2) return jmd94_point(t, s, p);
+    return sigmai_point<(EOS == 1 ? 1 : 0), FAST>(t, s, p);
+}
+
+// VEC = 4: every pointer 16-byte aligned, four points per lane per step (dwordx4 loads);
+// VEC = 1: scalar fallback for unaligned arrays.  Grid-stride over vectors.
+template <int EOS, bool FAST, int KIND, int VEC>
+__global__ void __launch_bounds__(256) eos_kernel(EosArgs a) {
+    const int64_t nvec = a.n / VEC;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += stride) {
+        float t[VEC], s[VEC], p[VEC];
+        if (VEC == 4) {
+            const float4 tt = reinterpret_cast<const float4 *>(a.t)[v];
+            const float4 ss = reinterpret_cast<const float4 *>(a.s)[v];
+            t[0] = tt.x; t[1] = tt.y; t[2] = tt.z; t[3] = tt.w;
+            s[0] = ss.x; s[1] = ss.y; s[2] = ss.z; s[3] = ss.w;
+            if (KIND == kPointRef) {
+                const float4 pp = reinterpret_cast<const float4 *>(a.p2d)[v];
+                p[0] = pp.x; p[1] = pp.y; p[2] = pp.z; p[3] = pp.w;
+            }
+        } else {
+            t[0] = a.t[v]; s[0] = a.s[v];
+            if (KIND == kPointRef) p[0] = a.p2d[v];
+        }
+        double r[VEC];
+#pragma unroll
+        for (int c = 0; c < VEC; ++c)
+            r[c] = eval_point<EOS, FAST>(t[c], s[c], KIND == kPointRef ? p[c] : a.pref);
+        if (KIND == kTool) {
+            float o[VEC];
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) {   // cdfsig0.f90:148-150: r8 * r4 mask, stored into r4
+                const float zmask = (s[c] == a.spval) ? 0.f : 1.f;
+                o[c] = (float)__dmul_rn(r[c], (double)zmask);
+            }
+            if (VEC == 4) reinterpret_cast<float4 *>(a.out4)[v] = make_float4(o[0], o[1], o[2], o[3]);
+            else a.out4[v] = o[0];
+        } else {
+            if (VEC == 4) {
+                reinterpret_cast<double2 *>(a.out8)[2 * v]     = make_double2(r[0], r[1]);
+                reinterpret_cast<double2 *>(a.out8)[2 * v + 1] = make_double2(r[2], r[3]);
+            } else {
+                a.out8[v] = r[0];
+            }
+        }
+    }
+    // tail of a vectorised launch: < 4 points, one lane each
+    if (VEC == 4 && blockIdx.x == 0 && threadIdx.x < (unsigned)(a.n - nvec * VEC)) {
+        const int64_t q = nvec * VEC + threadIdx.x;
+        const double r = eval_point<EOS, FAST>(a.t[q], a.s[q], KIND == kPointRef ? a.p2d[q] : a.pref);
+        if (KIND == kTool) {
+            const float zmask = (a.s[q] == a.spval) ? 0.f : 1.f;
+            a.out4[q] = (float)__dmul_rn(r, (double)zmask);
+        } else {
+            a.out8[q] = r;
+        }
+    }
+}
+
+template <int EOS, bool FAST, int KIND>
+int launch_kind(const EosArgs &a, hipStream_t st) {
+    if (a.n == 0) return CDFT_OK;
+    auto al = [](const void *p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+    const bool vec = al(a.t) && al(a.s) && al(a.p2d) && al(a.out8) && al(a.out4);
+    const int threads = 256;
+    const int64_t work = vec ? (a.n + 3) / 4 : a.n;
+    int64_t blocks = (work + threads - 1) / threads;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    if (blocks < 1) blocks = 1;
+    if (vec)
+        hipLaunchKernelGGL((eos_kernel<EOS, FAST, KIND, 4>), dim3((unsigned)blocks), dim3(threads), 0, st, a);
+    else
+        hipLaunchKernelGGL((eos_kernel<EOS, FAST, KIND, 1>), dim3((unsigned)blocks), dim3(threads), 0, st, a);
+    CDFT_LAUNCH_CHECK();
+    return CDFT_OK;
+}
+
+template <int KIND>
+int launch_eos(const EosArgs &a, int eos, int flags, hipStream_t st) {
+    const bool fast = (flags & CDFT_EOS_FAST_FMA) != 0;
+    switch (eos) {
+        case CDFT_EOS_80:     return fast ? launch_kind<0, true, KIND>(a, st) : launch_kind<0, false, KIND>(a, st);
+        case CDFT_EOS_TEOS10: return fast ? launch_kind<1, true, KIND>(a, st) : launch_kind<1, false, KIND>(a, st);
+        case CDFT_EOS_JMD94:  return launch_kind<2, false, KIND>(a, st);
+        default: return fail(CDFT_ERR_ARG, "unknown equation of state %d", eos);
+    }
+}
+
+// staging for host arrays (the Fortran tools pass getvar slabs); single host thread, as the reference
+DevBuf g_t, g_s, g_p, g_o;
+
+int run(int kind, const float *ptem, const float *psal, const float *pref2d, int64_t n, float pref,
+        float spval, int eos, int flags, void *out, size_t out_elem, int in_space, int out_space,
+        void *stream) {
+    if (!ptem || !psal || !out || (kind == kPointRef && !pref2d))
+        return fail(CDFT_ERR_ARG, "cdft_eos: NULL argument");
+    if (n < 0) return fail(CDFT_ERR_ARG, "cdft_eos: negative point count");
+    CDFT_TRY(require_device());
+    hipStream_t st = as_stream(stream);
+    const void *dt, *ds, *dp = nullptr;
+    CDFT_TRY(to_device(ptem, n * sizeof(float), in_space, g_t, st, &dt));
+    CDFT_TRY(to_device(psal, n * sizeof(float), in_space, g_s, st, &ds));
+    if (kind == kPointRef) CDFT_TRY(to_device(pref2d, n * sizeof(float), in_space, g_p, st, &dp));
+    void *dout = out;
+    if (out_space == CDFT_MEM_HOST) {
+        CDFT_TRY(g_o.reserve(n * out_elem + 16));
+        dout = g_o.ptr;
+    } else if (out_space != CDFT_MEM_DEVICE) {
+        return fail(CDFT_ERR_ARG, "cdft_eos: bad memory-space tag %d", out_space);
+    }
+    EosArgs a;
+    a.t = (const float *)dt; a.s = (const float *)ds; a.p2d = (const float *)dp;
+    a.out8 = kind == kTool ? nullptr : (double *)dout;
+    a.out4 = kind == kTool ? (float *)dout : nullptr;
+    a.n = n; a.pref = pref; a.spval = spval;
+    int rc;
+    if (kind == kScalarRef)     rc = launch_eos<kScalarRef>(a, eos, flags, st);
+    else if (kind == kPointRef) rc = launch_eos<kPointRef>(a, eos, flags, st);
+    else                        rc = launch_eos<kTool>(a, eos, flags, st);
+    CDFT_TRY(rc);
+    if (out_space == CDFT_MEM_HOST) {
+        CDFT_HIP(hipMemcpyAsync(out, dout, n * out_elem, hipMemcpyDeviceToHost, st));
+        CDFT_HIP(hipStreamSynchronize(st));
+    }
+    return CDFT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cdft_eos_sigmai(const float *ptem, const float *psal, int64_t n, float pref, int eos, int flags,
+                    double *sig, int in_space, int out_space, void *stream) {
+    return run(kScalarRef, ptem, psal, nullptr, n, pref, 0.f, eos, flags, sig, sizeof(double), in_space,
+               out_space, stream);
+}
+
+int cdft_eos_sigmai2d(const float *ptem, const float *psal, const float *pref2d, int64_t n, int eos,
+                      int flags, double *sig, int in_space, int out_space, void *stream) {
+    return run(kPointRef, ptem, psal, pref2d, n, 0.f, 0.f, eos, flags, sig, sizeof(double), in_space,
+               out_space, stream);
+}
+
+int cdft_eos_sig_tool(const float *ptem, const float *psal, int64_t n, float pref, float spval, int eos,
+                      int flags, float *sig4, int in_space, int out_space, void *stream) {
+    return run(kTool, ptem, psal, nullptr, n, pref, spval, eos, flags, sig4, sizeof(float), in_space,
+               out_space, stream);
+}
+
+int cdft_eos_release(void) {
+    g_t.release(); g_s.release(); g_p.release(); g_o.release();
+    return CDFT_OK;
+}
+
+}  // extern "C"

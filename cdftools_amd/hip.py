@@ -160,4 +160,57 @@ class MocPlan:
             pass
 
 
-__all__ = ["MocPlan", "Timer", "CdftError", "device_count", "current_stream_ptr", "MEM_HOST", "MEM_DEVICE"]
+EOS_80, EOS_TEOS10, EOS_JMD94 = 0, 1, 2
+EOS_FAST_FMA = 1
+
+
+def _out_like(x, dtype_np, dtype_t):
+    if _is_tensor(x) and x.is_cuda:
+        return torch.empty(x.shape, dtype=dtype_t, device=x.device)
+    return np.empty(tuple(x.shape), dtype=dtype_np)
+
+
+def sigmai(ptem, psal, pref=0.0, eos=EOS_80, flags=0, pref2d=None, out=None, stream=None):
+    """sigmai(ptem, psal, pref) -> r8 (src/eos.f90:802-887; pref2d: :1002-1087; sigma0 = pref 0)."""
+    pt, st_, kt = _arg(ptem, np.float32, "ptem")
+    ps, ss, ks = _arg(psal, np.float32, "psal")
+    n = int(np.prod(kt.shape))
+    if ss != st_ or int(np.prod(ks.shape)) != n:
+        raise ValueError("ptem and psal must have the same size and memory space")
+    if out is None:
+        out = _out_like(kt, np.float64, torch.float64 if torch is not None else None)
+    po, so, ko = _arg(out, np.float64, "sig")
+    if int(np.prod(ko.shape)) != n:
+        raise ValueError("sig: wrong size")
+    s = stream or current_stream_ptr()
+    if pref2d is None:
+        check(_lib.load().cdft_eos_sigmai(pt, ps, n, float(pref), eos, flags, po, st_, so, s))
+    else:
+        pp, sp, kp = _arg(pref2d, np.float32, "pref2d")
+        if sp != st_ or int(np.prod(kp.shape)) != n:
+            raise ValueError("pref2d must match ptem in size and memory space")
+        check(_lib.load().cdft_eos_sigmai2d(pt, ps, pp, n, eos, flags, po, st_, so, s))
+    return out
+
+
+def sigma0(ptem, psal, eos=EOS_80, flags=0, out=None, stream=None):
+    """sigma0 = sigmai at 0 m (src/eos.f90:601-632)."""
+    return sigmai(ptem, psal, 0.0, eos, flags, None, out, stream)
+
+
+def sig_tool(ptem, psal, pref=0.0, spval=0.0, eos=EOS_80, flags=0, out=None, stream=None):
+    """cdfsig0 / cdfsigi level loop: r4 = REAL(sigmai * (S /= spval)) (src/cdfsig0.f90:146-152)."""
+    pt, st_, kt = _arg(ptem, np.float32, "ptem")
+    ps, ss, ks = _arg(psal, np.float32, "psal")
+    n = int(np.prod(kt.shape))
+    if ss != st_ or int(np.prod(ks.shape)) != n:
+        raise ValueError("ptem and psal must have the same size and memory space")
+    if out is None:
+        out = _out_like(kt, np.float32, torch.float32 if torch is not None else None)
+    po, so, ko = _arg(out, np.float32, "sig4")
+    check(_lib.load().cdft_eos_sig_tool(pt, ps, n, float(pref), float(spval), eos, flags, po, st_, so,
+                                        stream or current_stream_ptr()))
+    return out
+
+
+__all__ = ["MocPlan", "sigmai", "sigma0", "sig_tool", "EOS_80", "EOS_TEOS10", "EOS_JMD94", "EOS_FAST_FMA", "Timer", "CdftError", "device_count", "current_stream_ptr", "MEM_HOST", "MEM_DEVICE"]

@@ -107,6 +107,30 @@ int cdft_moc_profile_read(cdft_moc_plan *plan, double *zonal_ms_total, int *laun
 
 int cdft_moc_destroy(cdft_moc_plan *plan);
 
+/* ------------------------------------------------------------------------------------------ */
+/* eos : potential density sigma0 / sigmai                                                    */
+/*   replaces src/eos.f90:601-632 (sigma0), :802-887 (sigmai_dep), :1002-1087 (sigmai_dep2d),  */
+/*   :889-1000 and :1089-1201 (Jackett-McDougall 1994 variants); the coefficient set is what   */
+/*   eos_init (:207-598) selects.  Pointwise: n = number of points (a slab or a whole field).  */
+/* ------------------------------------------------------------------------------------------ */
+#define CDFT_EOS_80        0   /* NEMO polynomial EOS-80  (eos_init(.FALSE.), the tools' default) */
+#define CDFT_EOS_TEOS10    1   /* NEMO polynomial TEOS-10 (eos_init(.TRUE.), -teos10)             */
+#define CDFT_EOS_JMD94     2   /* sigmai(..., ld_eos80=.TRUE.) legacy rational form               */
+#define CDFT_EOS_FAST_FMA  1   /* flags: allow FMA contraction (not bit-identical: few ulp of r8)  */
+
+/* sig(n) r8 = sigmai(ptem, psal, pref): density anomaly referenced to depth pref (sigma0: pref = 0),
+ * already multiplied by (psal /= 0) as the reference does (src/eos.f90:852-856,:880). */
+int cdft_eos_sigmai(const float *ptem, const float *psal, int64_t n, float pref, int eos, int flags,
+                    double *sig, int in_space, int out_space, void *stream);
+/* per-point reference depth pref2d(n) (sigmai_dep2d) */
+int cdft_eos_sigmai2d(const float *ptem, const float *psal, const float *pref2d, int64_t n, int eos,
+                      int flags, double *sig, int in_space, int out_space, void *stream);
+/* The level loop of cdfsig0 / cdfsigi fused (src/cdfsig0.f90:146-152, src/cdfsigi.f90:131-137):
+ * sig4(n) r4 = REAL( sigmai(ptem,psal,pref) * zmask ), zmask = 0 where psal == spval else 1. */
+int cdft_eos_sig_tool(const float *ptem, const float *psal, int64_t n, float pref, float spval, int eos,
+                      int flags, float *sig4, int in_space, int out_space, void *stream);
+int cdft_eos_release(void);   /* frees the staging buffers used for host arrays */
+
 #ifdef __cplusplus
 }
 #endif

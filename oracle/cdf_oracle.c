@@ -6,7 +6,9 @@
  * contraction, like the reference's plain -O/-O2 builds (Macrolib/macro.gfortran:26).
  */
 #include "cdf_oracle.h"
+#include <math.h>
 #include <stdlib.h>
+#include "eos_coef.h"
 #include <string.h>
 #ifdef _OPENMP
 #include <omp.h>
@@ -58,4 +60,97 @@ void oracle_moc(int npi, int npj, int npk, int nb, const float *e1v, const float
                 dmoc[((size_t)jk * npj + jj) * nb + jb] =
                     dmoc[((size_t)(jk + 1) * npj + jj) * nb + jb] +
                     dmoc[((size_t)jk * npj + jj) * nb + jb] / 1.0e6;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* equation of state                                                                           */
+/* ------------------------------------------------------------------------------------------ */
+static const double eos_c[2][CDFT_EOS_NK][CDFT_EOS_NJ][CDFT_EOS_NI] = CDFT_EOS_COEF_INIT;
+static const double eos_r[6] = CDFT_EOS_REF_INIT;
+
+/* r_k(t,s): the reference nests Horner in t around Horner in s and writes each t-level as
+ *   ( ... )*dlt + (((c_n*dls + c_{n-1})*dls + ...)+c_1)*dls + c_0        (src/eos.f90:858-875)
+ * i.e. acc = (acc*t + Y*s) + c_0 with Y the Horner form of c_n..c_1; the top t-level is a bare
+ * coefficient.  Reproduced with that exact association. */
+static double eos_rk(const double c[CDFT_EOS_NJ][CDFT_EOS_NI], int k, double t, double s) {
+    const int jmax = CDFT_EOS_JMAX(k);
+    double acc = c[jmax][0];
+    for (int j = jmax - 1; j >= 0; --j) {
+        const int imax = CDFT_EOS_IMAX(k, j);
+        double y = c[j][imax];
+        for (int i = imax - 1; i >= 1; --i) y = y * s + c[j][i];
+        acc = (acc * t + y * s) + c[j][0];
+    }
+    return acc;
+}
+
+void oracle_sigmai(const float *ptem, const float *psal, long n, float pref, const float *pref2d,
+                   int teos10, double *sig) {
+    const int set = teos10 ? 1 : 0;
+    const double rdeltas = teos10 ? CDFT_EOS_RDELTAS_T10 : CDFT_EOS_RDELTAS_80;
+    const double r1_s0 = teos10 ? CDFT_EOS_R1_S0_T10 : CDFT_EOS_R1_S0_80;
+    const double r1_t0 = CDFT_EOS_R1_T0, r1_z0 = CDFT_EOS_R1_Z0, rau0 = CDFT_EOS_RAU0;
+    for (long p = 0; p < n; ++p) {
+        /* :842-845 / :1046,:1062: depth and reference density at that depth */
+        const double h = (double)(pref2d ? pref2d[p] : pref) * r1_z0;
+        const double ref = (((((eos_r[5] * h + eos_r[4]) * h + eos_r[3]) * h + eos_r[2]) * h + eos_r[1]) * h + eos_r[0]) * h;
+        const double t = (double)ptem[p] * r1_t0;                              /* :850 */
+        const double s = sqrt(fabs((double)psal[p] + rdeltas) * r1_s0);        /* :851 */
+        const double tm = (psal[p] == 0.0f) ? 0.0 : 1.0;                       /* :852-856 */
+        const double r3 = eos_rk(eos_c[set][3], 3, t, s);
+        const double r2 = eos_rk(eos_c[set][2], 2, t, s);
+        const double r1 = eos_rk(eos_c[set][1], 1, t, s);
+        const double r0 = eos_rk(eos_c[set][0], 0, t, s);
+        const double r = ((r3 * h + r2) * h + r1) * h + r0;                    /* :877 */
+        sig[p] = (r + ref - rau0) * tm;                                        /* :880 */
+    }
+}
+
+void oracle_sig_tool(const float *ptem, const float *psal, long n, float pref, float spval, int teos10,
+                     float *sig4) {
+    double *tmp = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    oracle_sigmai(ptem, psal, n, pref, NULL, teos10, tmp);
+    for (long p = 0; p < n; ++p) {
+        const float zmask = (psal[p] == spval) ? 0.0f : 1.0f;                  /* cdfsig0.f90:148 */
+        sig4[p] = (float)(tmp[p] * (double)zmask);                             /* :150 r8*r4 -> r4 */
+    }
+    free(tmp);
+}
+
+/* Jackett & McDougall (1994) form: src/eos.f90:889-1000 (one reference depth) and :1089-1201
+ * (per-point depth).  Every polynomial in t is a plain Horner chain in the reference (:942-991);
+ * coefficients highest power first. */
+static double horner(const double *c, int n, double t) {
+    double a = c[0];
+    for (int i = 1; i < n; ++i) a = a * t + c[i];
+    return a;
+}
+
+void oracle_sigmai_jmd94(const float *ptem, const float *psal, long n, float pref, const float *pref2d,
+                         double *sig) {
+    static const double c_r1[] = {6.536332e-9, -1.120083e-6, 1.001685e-4, -9.095290e-3, 6.793952e-2, 999.842594};
+    static const double c_r2[] = {5.3875e-9, -8.2467e-7, 7.6438e-5, -4.0899e-3, 0.824493};
+    static const double c_r3[] = {-1.6546e-6, 1.0227e-4, -5.72466e-3};
+    static const double c_e[] = {-3.508914e-8, -1.248266e-8, -2.595994e-6};
+    static const double c_bw[] = {1.296821e-6, -5.782165e-9, 1.045941e-4};
+    static const double c_c[] = {-7.267926e-5, 2.598241e-3, 0.1571896};
+    static const double c_aw[] = {5.939910e-6, 2.512549e-3, -0.1028859, -4.721788};
+    static const double c_b1[] = {-0.1909078, 7.390729, -55.87545};
+    static const double c_a1[] = {2.326469e-3, 1.553190, -65.00517, 1044.077};
+    static const double c_kw[] = {-1.361629e-4, -1.852732e-2, -30.41638, 2098.925, 190925.6};
+    const double dpr4 = 4.8314e-4, dpd = -2.042967e-2, dprau0 = 1000.0;       /* :920 */
+    for (long p = 0; p < n; ++p) {
+        const double ref = (double)(pref2d ? pref2d[p] : pref);                /* :928 */
+        const double rs = (double)sqrtf(fabsf(psal[p]));    /* :931 SQRT(ABS(psal)) is evaluated in r4 */
+        const double t = (double)ptem[p], s = (double)psal[p];                 /* :939-940 */
+        const double r1 = horner(c_r1, 6, t), r2 = horner(c_r2, 5, t), r3 = horner(c_r3, 3, t);
+        const double rhop = (dpr4 * s + r3 * rs + r2) * s + r1;                /* :960 */
+        const double e = horner(c_e, 3, t), bw = horner(c_bw, 3, t);
+        const double b = bw + e * s;                                           /* :969 */
+        const double c = horner(c_c, 3, t), aw = horner(c_aw, 4, t);
+        const double a = (dpd * rs + c) * s + aw;                              /* :978 */
+        const double b1 = horner(c_b1, 3, t), a1 = horner(c_a1, 4, t), kw = horner(c_kw, 5, t);
+        const double k0 = (b1 * rs + a1) * s + kw;                             /* :992 */
+        sig[p] = rhop / (1.0 - ref / (k0 - ref * (a - ref * b))) - dprau0;     /* :995 */
+    }
 }

@@ -31,6 +31,18 @@ extern "C" {
  *   dmoc(nb,npj,npk) out, Sverdrup.  Levels 1..npk-1 of zv are read (jk=1,npk-1). */
 void oracle_moc(int npi, int npj, int npk, int nb, const float *e1v, const float *e3v,
                 const int16_t *ibmask, const float *zv, double *dmoc);
+/* src/eos.f90:802-887 (sigmai_dep), :1002-1087 (sigmai_dep2d), :601-632 (sigma0 = pref 0);
+ * coefficients as set by eos_init :207-598 (teos10 = 0: EOS-80 polynomial, 1: TEOS-10).
+ * ptem, psal: n r4 values; pref: one r4 depth (pref2d == NULL) or n per-point depths. */
+void oracle_sigmai(const float *ptem, const float *psal, long n, float pref, const float *pref2d,
+                   int teos10, double *sig);
+/* src/eos.f90:889-1000 (sigmai_dep_80) and :1089-1201 (sigmai_dep2d_80): Jackett-McDougall 1994 */
+void oracle_sigmai_jmd94(const float *ptem, const float *psal, long n, float pref, const float *pref2d,
+                         double *sig);
+/* callers src/cdfsig0.f90:146-152, src/cdfsigi.f90:131-137: r4 result = sigma * (S /= spval) */
+void oracle_sig_tool(const float *ptem, const float *psal, long n, float pref, float spval, int teos10,
+                     float *sig4);
+
 /* number of OpenMP threads the oracle's parallel loops use (1 when built without OpenMP) */
 int oracle_num_threads(void);
 

@@ -48,3 +48,94 @@ def moc(e1v, e3v, ibmask, zv):
 
 def num_threads():
     return load().oracle_num_threads()
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, np.float32)
+
+
+def sigmai(ptem, psal, pref=0.0, teos10=False, pref2d=None):
+    """oracle_sigmai: r8 result with the shape of ptem."""
+    lib = load()
+    t, s = _f32(ptem), _f32(psal)
+    out = np.empty(t.shape, np.float64)
+    p2 = _f32(pref2d) if pref2d is not None else None
+    lib.oracle_sigmai(_p(t), _p(s), C.c_long(t.size), C.c_float(pref), _p(p2) if p2 is not None else None,
+                      C.c_int(1 if teos10 else 0), _p(out))
+    return out
+
+
+def sigmai_jmd94(ptem, psal, pref=0.0, pref2d=None):
+    lib = load()
+    t, s = _f32(ptem), _f32(psal)
+    out = np.empty(t.shape, np.float64)
+    p2 = _f32(pref2d) if pref2d is not None else None
+    lib.oracle_sigmai_jmd94(_p(t), _p(s), C.c_long(t.size), C.c_float(pref),
+                            _p(p2) if p2 is not None else None, _p(out))
+    return out
+
+
+def sig_tool(ptem, psal, pref=0.0, spval=0.0, teos10=False):
+    """cdfsig0 / cdfsigi level loop: r4 result = sigma * (S /= spval)."""
+    lib = load()
+    t, s = _f32(ptem), _f32(psal)
+    out = np.empty(t.shape, np.float32)
+    lib.oracle_sig_tool(_p(t), _p(s), C.c_long(t.size), C.c_float(pref), C.c_float(spval),
+                        C.c_int(1 if teos10 else 0), _p(out))
+    return out
+
+
+# ------------------------------------------------------------------ oracle/_ref (the real reference)
+REF_EOS = os.path.join(ORACLE_DIR, "_ref", "libeos_ref.so")
+_ref = None
+
+
+def ref_eos_available():
+    return os.path.exists(REF_EOS)
+
+
+class RefEos:
+    """The unmodified src/eos.f90 compiled by oracle/ref_build.sh (build container only)."""
+
+    def __init__(self):
+        global _ref
+        if _ref is None:
+            _ref = C.CDLL(REF_EOS)
+        self.lib = _ref
+        self.mode = None
+
+    def init(self, teos10):
+        if self.mode != bool(teos10):
+            self.lib.ref_eos_init(C.c_int(1 if teos10 else 0))
+            self.mode = bool(teos10)
+
+    def _call(self, fn, t, s, *extra):
+        t, s = _f32(t), _f32(s)
+        t2, s2 = t.reshape(-1, t.shape[-1]) if t.ndim > 1 else t.reshape(1, -1), None
+        s2 = s.reshape(t2.shape)
+        out = np.empty(t2.shape, np.float64)
+        kpj, kpi = t2.shape
+        fn(_p(t2), _p(s2), *extra, C.c_int(kpi), C.c_int(kpj), _p(out))
+        return out.reshape(t.shape)
+
+    def sigma0(self, t, s, teos10=False):
+        self.init(teos10)
+        return self._call(self.lib.ref_sigma0, t, s)
+
+    def sigmai(self, t, s, pref, teos10=False):
+        self.init(teos10)
+        return self._call(self.lib.ref_sigmai, t, s, C.c_float(pref))
+
+    def sigmai2d(self, t, s, pref2d, teos10=False):
+        self.init(teos10)
+        p = _f32(pref2d)
+        return self._call(self.lib.ref_sigmai2d, t, s, _p(p))
+
+    def sigmai_jmd94(self, t, s, pref):
+        self.init(False)
+        return self._call(self.lib.ref_sigmai_jmd94, t, s, C.c_float(pref))
+
+    def sigmai2d_jmd94(self, t, s, pref2d):
+        self.init(False)
+        p = _f32(pref2d)
+        return self._call(self.lib.ref_sigmai2d_jmd94, t, s, _p(p))

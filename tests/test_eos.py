@@ -1,0 +1,156 @@
+"""sigma0 / sigmai (src/eos.f90): the oracle is PINNED against the real reference here --
+(a) the reference's own known-answer values (src/eos.f90:817,:820),
+(b) tests/golden/eos.npz, outputs of the unmodified eos.f90 built by oracle/ref_build.sh
+    (generator: tests/make_golden_eos.py),
+(c) oracle/_ref itself when present (build container).
+GPU: the HIP kernels must equal the oracle BIT FOR BIT in the exact mode; the FMA-contracted mode
+is held to 4 ulp of r8 (and equality after the r4 store of the tool form to 1 ulp r4).
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "eos.npz"))
+REF_PROFILE_03 = 13.486253711156655      # ref(h = 0.3): R00..R05 polynomial at 3000 m
+
+
+# ----------------------------------------------------------------------------- CPU: pin the oracle
+def test_known_answers_of_the_reference():
+    t = np.array([3.0], np.float32)
+    s = np.array([35.5], np.float32)
+    # src/eos.f90:820  EOS-80 : rho = 1028.35011066567 at z=3000, pt=3, sp=35.5
+    # src/eos.f90:817  TEOS-10: rho = 1028.21993233072 at z=3000, ct=3, sa=35.5
+    # (in-situ density; sigmai returns rho + ref(h) - 1000)
+    for teos, rho in ((False, 1028.35011066567), (True, 1028.21993233072)):
+        sig = oracle_lib.sigmai(t, s, 3000.0, teos)[0]
+        assert abs(sig + 1000.0 - REF_PROFILE_03 - rho) < 1e-10
+    # values measured with the flang-built reference
+    assert oracle_lib.sigmai(t, s, 3000.0, False)[0] == 41.83636437682958
+    assert oracle_lib.sigmai(t, s, 3000.0, True)[0] == 41.706186041879164
+    assert oracle_lib.sigmai(t, s, 0.0, False)[0] == 28.284481618400832
+    assert oracle_lib.sigmai_jmd94(t, s, 3000.0)[0] == 41.83326188211663
+
+
+@pytest.mark.parametrize("tag,teos", [("eos80", False), ("teos10", True)])
+def test_oracle_equals_golden_reference_outputs_bitwise(tag, teos):
+    T, S, D = GOLD["T"], GOLD["S"], GOLD["D"]
+    assert np.array_equal(oracle_lib.sigmai(T, S, 0.0, teos), GOLD[f"sigma0_{tag}"])
+    assert np.array_equal(oracle_lib.sigmai(T, S, 2000.0, teos), GOLD[f"sigmai2000_{tag}"])
+    assert np.array_equal(oracle_lib.sigmai(T, S, 3000.0, teos), GOLD[f"sigmai3000_{tag}"])
+    assert np.array_equal(oracle_lib.sigmai(T, S, 0.0, teos, pref2d=D), GOLD[f"sigmai2d_{tag}"])
+
+
+def test_oracle_jmd94_equals_golden_reference_outputs_bitwise():
+    T, S, D = GOLD["T"], GOLD["S"], GOLD["D"]
+    assert np.array_equal(oracle_lib.sigmai_jmd94(T, S, 2000.0), GOLD["sigmai2000_jmd94"])
+    assert np.array_equal(oracle_lib.sigmai_jmd94(T, S, 0.0, pref2d=D), GOLD["sigmai2d_jmd94"])
+
+
+def test_land_points_are_masked_on_salinity_zero():
+    T, S = GOLD["T"], GOLD["S"]
+    sig = oracle_lib.sigmai(T, S, 1000.0)
+    assert np.all(sig[S == 0] == 0.0) and np.all(sig[S != 0] != 0.0)
+
+
+@pytest.mark.skipif(not oracle_lib.ref_eos_available(), reason="oracle/_ref not built (no /root/reference)")
+def test_oracle_equals_live_reference_on_fresh_random_fields():
+    ref = oracle_lib.RefEos()
+    rng = np.random.default_rng(5)
+    T = (-2 + 34 * rng.random((33, 57))).astype(np.float32)
+    S = (38 * rng.random((33, 57))).astype(np.float32)
+    S[rng.random(S.shape) < 0.2] = 0
+    D = (6000 * rng.random(S.shape)).astype(np.float32)
+    for teos in (False, True):
+        assert np.array_equal(ref.sigma0(T, S, teos), oracle_lib.sigmai(T, S, 0.0, teos))
+        assert np.array_equal(ref.sigmai(T, S, 1234.5, teos), oracle_lib.sigmai(T, S, 1234.5, teos))
+        assert np.array_equal(ref.sigmai2d(T, S, D, teos), oracle_lib.sigmai(T, S, 0.0, teos, pref2d=D))
+    assert np.array_equal(ref.sigmai_jmd94(T, S, 1234.5), oracle_lib.sigmai_jmd94(T, S, 1234.5))
+    assert np.array_equal(ref.sigmai2d_jmd94(T, S, D), oracle_lib.sigmai_jmd94(T, S, 0.0, pref2d=D))
+
+
+def test_tool_form_matches_its_definition():
+    T, S = GOLD["T"], GOLD["S"].copy()
+    spval = np.float32(0.0)
+    got = oracle_lib.sig_tool(T, S, 2000.0, spval)
+    want = (GOLD["sigmai2000_eos80"] * (S != spval)).astype(np.float32)
+    assert np.array_equal(got, want)
+
+
+# ----------------------------------------------------------------------------- GPU: parity
+def fields(n, seed):
+    rng = np.random.default_rng(seed)
+    T = (-2 + 34 * rng.random(n)).astype(np.float32)
+    S = (38 * rng.random(n)).astype(np.float32)
+    S[rng.random(n) < 0.3] = 0
+    D = (6000 * rng.random(n)).astype(np.float32)
+    return T, S, D
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("eos", [0, 1, 2])
+def test_hip_equals_golden_reference_outputs_bitwise(gpu, eos):
+    T, S, D = GOLD["T"], GOLD["S"], GOLD["D"]
+    tag = {0: "eos80", 1: "teos10", 2: "jmd94"}[eos]
+    assert np.array_equal(gpu.sigmai(T, S, 2000.0, eos), GOLD[f"sigmai2000_{tag}"])
+    assert np.array_equal(gpu.sigmai(T, S, 0.0, eos, pref2d=D), GOLD[f"sigmai2d_{tag}"])
+    if eos < 2:
+        assert np.array_equal(gpu.sigma0(T, S, eos), GOLD[f"sigma0_{tag}"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [0, 1, 3, 4, 5, 257, 27118, 1_000_003])
+@pytest.mark.parametrize("eos", [0, 1, 2])
+def test_hip_equals_oracle_bitwise_host_and_device(gpu, n, eos):
+    import torch
+
+    T, S, D = fields(n, seed=n + eos)
+    ora = oracle_lib.sigmai_jmd94 if eos == 2 else (lambda t, s, p, pref2d=None: oracle_lib.sigmai(t, s, p, eos == 1, pref2d))
+    want = ora(T, S, 1500.0)
+    want2 = ora(T, S, 0.0, pref2d=D)
+    assert np.array_equal(gpu.sigmai(T, S, 1500.0, eos), want)                       # host arrays
+    if n:
+        dT, dS, dD = (torch.from_numpy(x).cuda() for x in (T, S, D))
+        assert np.array_equal(gpu.sigmai(dT, dS, 1500.0, eos).cpu().numpy(), want)    # resident in HBM
+        assert np.array_equal(gpu.sigmai(dT, dS, 0.0, eos, pref2d=dD).cpu().numpy(), want2)
+        # unaligned views take the scalar variant
+        assert np.array_equal(gpu.sigmai(dT[1:], dS[1:], 1500.0, eos).cpu().numpy(), want[1:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("eos", [0, 1])
+def test_hip_tool_form_and_fast_mode(gpu, eos):
+    T, S, _ = fields(182 * 149, seed=3)
+    S[::7] = np.float32(9999.0)                                  # a non-zero fill value
+    want = oracle_lib.sig_tool(T, S, 1000.0, 9999.0, eos == 1)
+    got = gpu.sig_tool(T, S, 1000.0, 9999.0, eos)
+    assert np.array_equal(got, want)                             # exact mode: bit-identical r4
+    fast8 = gpu.sigmai(T, S, 1000.0, eos, flags=gpu.EOS_FAST_FMA)
+    ref8 = oracle_lib.sigmai(T, S, 1000.0, eos == 1)
+    ulp = np.spacing(np.abs(ref8) + 1000.0)                      # ulp of rho ~ 1e3, the summed quantity
+    assert np.all(np.abs(fast8 - ref8) <= 4 * ulp)
+    fast4 = gpu.sig_tool(T, S, 1000.0, 9999.0, eos, flags=gpu.EOS_FAST_FMA)
+    assert np.all(np.abs(fast4.astype(np.float64) - want) <= np.spacing(np.abs(want)).astype(np.float64))
+
+
+@pytest.mark.gpu
+def test_hip_full_level_properties_eorca12_slab(gpu):
+    """One eORCA12 level (15.6 M points) resident in HBM: pointwise => any permutation of the points
+    permutes the result bit for bit; land (S == 0) is exactly 0."""
+    import torch
+
+    n = 4322 * 3606
+    g = torch.Generator(device="cuda").manual_seed(7)
+    T = -2 + 32 * torch.rand(n, device="cuda", generator=g)
+    S = (30 + 8 * torch.rand(n, device="cuda", generator=g)) * (torch.rand(n, device="cuda", generator=g) > 0.35)
+    a = gpu.sigmai(T, S, 2000.0)
+    perm = torch.randperm(n, device="cuda", generator=g)
+    b = gpu.sigmai(T[perm].contiguous(), S[perm].contiguous(), 2000.0)
+    torch.cuda.synchronize()
+    assert torch.equal(b, a[perm])
+    assert torch.all(a[S == 0] == 0)
+    idx = torch.randint(0, n, (4096,), device="cuda", generator=g)
+    want = oracle_lib.sigmai(T[idx].cpu().numpy(), S[idx].cpu().numpy(), 2000.0)
+    assert np.array_equal(a[idx].cpu().numpy(), want)
