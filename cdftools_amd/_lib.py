@@ -56,6 +56,10 @@ SIGNATURES = {
     "cdft_eos_sigmai2d": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _i, _i, _vp]),
     "cdft_eos_sig_tool": (_i, [_vp, _vp, _i64, C.c_float, C.c_float, _i, _i, _vp, _i, _i, _vp]),
     "cdft_eos_release": (_i, []),
+    "cdft_heatc_create": (_i, [_pvp, _i, _i, _i]),
+    "cdft_heatc_set_mesh": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "cdft_heatc_compute": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp]),
+    "cdft_heatc_destroy": (_i, [_vp]),
 }
 
 _lib = None

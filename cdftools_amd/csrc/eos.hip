@@ -83,7 +83,8 @@ __device__ __forceinline__ double jmd94_point(float ptem, float psal, float pref
     constexpr double c_a1[] = {2.326469e-3, 1.553190, -65.00517, 1044.077};
     constexpr double c_kw[] = {-1.361629e-4, -1.852732e-2, -30.41638, 2098.925, 190925.6};
     const double ref = (double)pref;
-    const double rs  = (double)__fsqrt_rn(fabsf(psal));
+    // r4 square root, correctly rounded: an r8 sqrt rounded to r4 is exact for sqrt (53 >= 2*24+2)
+    const double rs  = (double)(float)__dsqrt_rn((double)fabsf(psal));
     const double t = (double)ptem, s = (double)psal;
     const double r1 = horner(c_r1, t), r2 = horner(c_r2, t), r3 = horner(c_r3, t);
     const double rhop = __dadd_rn(__dmul_rn(__dadd_rn(__dadd_rn(__dmul_rn(4.8314e-4, s), __dmul_rn(r3, rs)), r2), s), r1);
@@ -204,9 +205,10 @@ DevBuf g_t, g_s, g_p, g_o;
 int run(int kind, const float *ptem, const float *psal, const float *pref2d, int64_t n, float pref,
         float spval, int eos, int flags, void *out, size_t out_elem, int in_space, int out_space,
         void *stream) {
+    if (n < 0) return fail(CDFT_ERR_ARG, "cdft_eos: negative point count");
+    if (n == 0) return CDFT_OK;                                   // empty slab: nothing to do
     if (!ptem || !psal || !out || (kind == kPointRef && !pref2d))
         return fail(CDFT_ERR_ARG, "cdft_eos: NULL argument");
-    if (n < 0) return fail(CDFT_ERR_ARG, "cdft_eos: negative point count");
     CDFT_TRY(require_device());
     hipStream_t st = as_stream(stream);
     const void *dt, *ds, *dp = nullptr;

@@ -1,0 +1,252 @@
+// heatc.hip -- cdfheatc masked volume integrals (C ABI section "cdfheatc").
+// Reference loop src/cdfheatc.f90:205-240, per level:
+//     dsurf  = sum(e1t * e2t       * tmask)
+//     dvol2d = sum(e1t * e2t * e3t * tmask)
+//     dsum2d = sum(e1t * e2t * e3t * temp * tmask)
+// The array expressions are r4 (left to right); the reference also SUMs in r4, which makes its own
+// answer compiler-dependent at ~1e-4.  Here every r4 product is formed exactly
+// as written and accumulated in r8 in a fixed order (more accurate, deterministic).
+//
+// HBM-bound: per cell temp 4 B + e3t 4 B + tmask 1 B (+ 8/npk) = 9.11 algorithmic bytes; the 2-D
+// area e1t*e2t is re-read from L2 / Infinity Cache for every level.
+#include "common.hpp"
+#include "reduce.hpp"
+
+using namespace cdft;
+
+struct cdft_heatc_plan {
+    int npi = 0, npj = 0, npk = 0;
+    float   *area = nullptr;   // (npi,npj) e1t*e2t in r4
+    float   *e3t  = nullptr;   // (npi,npj,npk) or null when full-step
+    float   *e31d = nullptr;   // (npk) full-step thickness, or null
+    uint8_t *mask8 = nullptr;  // (npi,npj,npk) 0/1 bytes, or
+    float   *mask4 = nullptr;  // (npi,npj,npk) r4 mask (arbitrary values, -M option)
+    float   *gdepw = nullptr;  // (npk)
+    double  *partial = nullptr;
+    int nblk = 0;
+    bool mesh_set = false;
+    DevBuf st_a, st_b, st_temp, st_mxl, st_out;
+};
+
+namespace {
+
+constexpr int kThreads = 256;
+
+struct HeatcArgs {
+    const float *area, *e3t, *e31d, *temp, *mxl, *gdepw;
+    const uint8_t *mask8;
+    const float *mask4;
+    int64_t nij;
+    int npk, mxlopt, nblk;
+    double *partial;           // [npk][nblk][3]
+};
+
+__global__ void heatc_area_kernel(const float *__restrict__ e1t, const float *__restrict__ e2t,
+                                  float *__restrict__ area, int64_t nij) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < nij) area[e] = __fmul_rn(e1t[e], e2t[e]);
+}
+
+template <int VEC>
+struct Vec;
+template <> struct Vec<4> { typedef float4 f; typedef uchar4 u; };
+template <> struct Vec<2> { typedef float2 f; typedef uchar2 u; };
+template <> struct Vec<1> { typedef float f;  typedef unsigned char u; };
+
+template <int VEC> __device__ __forceinline__ void unpack(const typename Vec<VEC>::f &v, float (&o)[VEC]);
+template <> __device__ __forceinline__ void unpack<4>(const float4 &v, float (&o)[4]) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+template <> __device__ __forceinline__ void unpack<2>(const float2 &v, float (&o)[2]) { o[0] = v.x; o[1] = v.y; }
+template <> __device__ __forceinline__ void unpack<1>(const float &v, float (&o)[1]) { o[0] = v; }
+template <int VEC> __device__ __forceinline__ void unpacku(const typename Vec<VEC>::u &v, float (&o)[VEC]);
+template <> __device__ __forceinline__ void unpacku<4>(const uchar4 &v, float (&o)[4]) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+template <> __device__ __forceinline__ void unpacku<2>(const uchar2 &v, float (&o)[2]) { o[0] = v.x; o[1] = v.y; }
+template <> __device__ __forceinline__ void unpacku<1>(const unsigned char &v, float (&o)[1]) { o[0] = v; }
+
+// grid (nblk, npk): block (b,k) strides over the VEC-vectors of level k.
+template <int VEC, bool MASK8, bool FULL>
+__global__ void __launch_bounds__(kThreads) heatc_level_kernel(HeatcArgs a) {
+    __shared__ double scratch[16];
+    const int k = blockIdx.y;
+    const int64_t nvec = a.nij / VEC;                  // nij % VEC == 0 by construction
+    const int64_t base = (int64_t)k * nvec;            // vector offset of level k in a 3-D field
+    const float e3k = FULL ? a.e31d[k] : 0.f;
+    const float dw  = a.mxlopt ? a.gdepw[k] : 0.f;
+    double s_surf = 0.0, s_vol = 0.0, s_sum = 0.0;
+    typedef typename Vec<VEC>::f FV;
+    typedef typename Vec<VEC>::u UV;
+    for (int64_t v = (int64_t)blockIdx.x * kThreads + threadIdx.x; v < nvec; v += (int64_t)a.nblk * kThreads) {
+        float ar[VEC], e3[VEC], tt[VEC], mk[VEC], mx[VEC];
+        unpack<VEC>(reinterpret_cast<const FV *>(a.area)[v], ar);
+        unpack<VEC>(reinterpret_cast<const FV *>(a.temp)[base + v], tt);
+        if (FULL) {
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) e3[c] = e3k;
+        } else {
+            unpack<VEC>(reinterpret_cast<const FV *>(a.e3t)[base + v], e3);
+        }
+        if (MASK8) unpacku<VEC>(reinterpret_cast<const UV *>(a.mask8)[base + v], mk);
+        else       unpack<VEC>(reinterpret_cast<const FV *>(a.mask4)[base + v], mk);
+        if (a.mxlopt) unpack<VEC>(reinterpret_cast<const FV *>(a.mxl)[v], mx);
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+            float e = e3[c];
+            if (a.mxlopt == 1)                        // src/cdfheatc.f90:220
+                e = fmaxf(0.f, fminf(e, __fsub_rn(mx[c], dw)));
+            else if (a.mxlopt == -1)                  // :222
+                e = fminf(e, fmaxf(0.f, __fsub_rn(__fadd_rn(dw, e), mx[c])));
+            const float pv = __fmul_rn(ar[c], e);                      // (e1t*e2t)*e3t
+            s_surf += (double)__fmul_rn(ar[c], mk[c]);                 // :225
+            s_vol  += (double)__fmul_rn(pv, mk[c]);                    // :226
+            s_sum  += (double)__fmul_rn(__fmul_rn(pv, tt[c]), mk[c]);  // :229
+        }
+    }
+    s_surf = block_sum(s_surf, scratch);
+    s_vol  = block_sum(s_vol, scratch);
+    s_sum  = block_sum(s_sum, scratch);
+    if (threadIdx.x == 0) {
+        double *p = a.partial + ((int64_t)k * a.nblk + blockIdx.x) * 3;
+        p[0] = s_surf; p[1] = s_vol; p[2] = s_sum;
+    }
+}
+
+// sums[k][3] = partials of level k added in block order
+__global__ void heatc_final_kernel(const double *__restrict__ partial, int npk, int nblk,
+                                   double *__restrict__ sums) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= npk * 3) return;
+    const int k = q / 3, c = q - 3 * k;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += partial[((int64_t)k * nblk + b) * 3 + c];
+    sums[q] = s;
+}
+
+template <int VEC>
+int launch_vec(const HeatcArgs &a, hipStream_t st) {
+    dim3 grid(a.nblk, a.npk), block(kThreads);
+    const bool m8 = a.mask8 != nullptr, full = a.e31d != nullptr;
+    if (m8 && full)        hipLaunchKernelGGL((heatc_level_kernel<VEC, true, true>), grid, block, 0, st, a);
+    else if (m8 && !full)  hipLaunchKernelGGL((heatc_level_kernel<VEC, true, false>), grid, block, 0, st, a);
+    else if (!m8 && full)  hipLaunchKernelGGL((heatc_level_kernel<VEC, false, true>), grid, block, 0, st, a);
+    else                   hipLaunchKernelGGL((heatc_level_kernel<VEC, false, false>), grid, block, 0, st, a);
+    CDFT_LAUNCH_CHECK();
+    return CDFT_OK;
+}
+
+bool aligned_to(const void *p, size_t n) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) % n) == 0; }
+
+int dev_copy(void **dst, const void *src, size_t bytes, int space, hipStream_t st) {
+    if (!*dst && hipMalloc(dst, bytes + 16) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(CDFT_ERR_ALLOC, "cdfheatc: device allocation of %zu bytes failed", bytes);
+    }
+    CDFT_HIP(hipMemcpyAsync(*dst, src, bytes, space == CDFT_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+    return CDFT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cdft_heatc_create(cdft_heatc_plan **plan, int npiglo, int npjglo, int npk) {
+    if (!plan) return fail(CDFT_ERR_ARG, "cdft_heatc_create: NULL plan pointer");
+    *plan = nullptr;
+    if (npiglo < 1 || npjglo < 1 || npk < 1)
+        return fail(CDFT_ERR_ARG, "cdft_heatc_create: bad sizes %d x %d x %d", npiglo, npjglo, npk);
+    CDFT_TRY(require_device());
+    cdft_heatc_plan *p = new cdft_heatc_plan;
+    p->npi = npiglo; p->npj = npjglo; p->npk = npk;
+    const int64_t nij = (int64_t)npiglo * npjglo;
+    int64_t nb = (nij / 4 + kThreads * 4 - 1) / (kThreads * 4);
+    p->nblk = (int)(nb < 1 ? 1 : (nb > 64 ? 64 : nb));
+    if (hipMalloc((void **)&p->area, nij * sizeof(float) + 16) != hipSuccess ||
+        hipMalloc((void **)&p->gdepw, npk * sizeof(float) + 16) != hipSuccess ||
+        hipMalloc((void **)&p->partial, (size_t)npk * p->nblk * 3 * sizeof(double)) != hipSuccess) {
+        (void)hipGetLastError();
+        cdft_heatc_destroy(p);
+        return fail(CDFT_ERR_ALLOC, "cdft_heatc_create: device allocation failed");
+    }
+    *plan = p;
+    return CDFT_OK;
+}
+
+int cdft_heatc_set_mesh(cdft_heatc_plan *p, const float *e1t, const float *e2t, const float *e3t,
+                        const float *e31d, const void *tmask, int mask_is_r4, int memspace, void *stream) {
+    if (!p || !e1t || !e2t || !tmask || (!e3t && !e31d) || (e3t && e31d))
+        return fail(CDFT_ERR_ARG, "cdft_heatc_set_mesh: need e1t, e2t, tmask and exactly one of e3t / e31d");
+    hipStream_t st = as_stream(stream);
+    const int64_t nij = (int64_t)p->npi * p->npj, n3 = nij * p->npk;
+    const void *d1, *d2;
+    CDFT_TRY(to_device(e1t, nij * sizeof(float), memspace, p->st_a, st, &d1));
+    CDFT_TRY(to_device(e2t, nij * sizeof(float), memspace, p->st_b, st, &d2));
+    hipLaunchKernelGGL(heatc_area_kernel, dim3((unsigned)((nij + 255) / 256)), dim3(256), 0, st,
+                       (const float *)d1, (const float *)d2, p->area, nij);
+    CDFT_LAUNCH_CHECK();
+    if (e3t) {
+        CDFT_TRY(dev_copy((void **)&p->e3t, e3t, n3 * sizeof(float), memspace, st));
+        if (p->e31d) { (void)hipFree(p->e31d); p->e31d = nullptr; }
+    } else {
+        CDFT_TRY(dev_copy((void **)&p->e31d, e31d, p->npk * sizeof(float), memspace, st));
+        if (p->e3t) { (void)hipFree(p->e3t); p->e3t = nullptr; }
+    }
+    if (mask_is_r4) {
+        CDFT_TRY(dev_copy((void **)&p->mask4, tmask, n3 * sizeof(float), memspace, st));
+        if (p->mask8) { (void)hipFree(p->mask8); p->mask8 = nullptr; }
+    } else {
+        CDFT_TRY(dev_copy((void **)&p->mask8, tmask, n3, memspace, st));
+        if (p->mask4) { (void)hipFree(p->mask4); p->mask4 = nullptr; }
+    }
+    CDFT_HIP(hipStreamSynchronize(st));
+    p->st_a.release(); p->st_b.release();
+    p->mesh_set = true;
+    return CDFT_OK;
+}
+
+int cdft_heatc_compute(cdft_heatc_plan *p, const float *temp, int temp_space, const float *rmxldep,
+                       const float *gdepw, int mxloption, double *sums, int out_space, void *stream) {
+    if (!p || !temp || !sums) return fail(CDFT_ERR_ARG, "cdft_heatc_compute: NULL argument");
+    if (!p->mesh_set) return fail(CDFT_ERR_STATE, "cdft_heatc_compute: cdft_heatc_set_mesh has not succeeded");
+    if (mxloption < -1 || mxloption > 1 || (mxloption != 0 && (!rmxldep || !gdepw)))
+        return fail(CDFT_ERR_ARG, "cdft_heatc_compute: mxloption %d needs rmxldep and gdepw", mxloption);
+    hipStream_t st = as_stream(stream);
+    const int64_t nij = (int64_t)p->npi * p->npj, n3 = nij * p->npk;
+    const void *dt, *dm = nullptr;
+    CDFT_TRY(to_device(temp, n3 * sizeof(float), temp_space, p->st_temp, st, &dt));
+    if (mxloption) {
+        CDFT_TRY(to_device(rmxldep, nij * sizeof(float), temp_space, p->st_mxl, st, &dm));
+        CDFT_HIP(hipMemcpyAsync(p->gdepw, gdepw, p->npk * sizeof(float), hipMemcpyHostToDevice, st));
+    }
+    double *dout = sums;
+    if (out_space == CDFT_MEM_HOST) {
+        CDFT_TRY(p->st_out.reserve((size_t)p->npk * 3 * sizeof(double)));
+        dout = (double *)p->st_out.ptr;
+    }
+    HeatcArgs a;
+    a.area = p->area; a.e3t = p->e3t; a.e31d = p->e31d; a.temp = (const float *)dt; a.mxl = (const float *)dm;
+    a.gdepw = p->gdepw; a.mask8 = p->mask8; a.mask4 = p->mask4; a.nij = nij; a.npk = p->npk;
+    a.mxlopt = mxloption; a.nblk = p->nblk; a.partial = p->partial;
+    int vec = 1;
+    if (nij % 4 == 0 && aligned_to(dt, 16) && aligned_to(dm, 16)) vec = 4;
+    else if (nij % 2 == 0 && aligned_to(dt, 8) && aligned_to(dm, 8)) vec = 2;
+    if (vec == 4)      CDFT_TRY(launch_vec<4>(a, st));
+    else if (vec == 2) CDFT_TRY(launch_vec<2>(a, st));
+    else               CDFT_TRY(launch_vec<1>(a, st));
+    hipLaunchKernelGGL(heatc_final_kernel, dim3((p->npk * 3 + 63) / 64), dim3(64), 0, st, p->partial, p->npk,
+                       p->nblk, dout);
+    CDFT_LAUNCH_CHECK();
+    if (out_space == CDFT_MEM_HOST) {
+        CDFT_HIP(hipMemcpyAsync(sums, dout, (size_t)p->npk * 3 * sizeof(double), hipMemcpyDeviceToHost, st));
+        CDFT_HIP(hipStreamSynchronize(st));
+    }
+    return CDFT_OK;
+}
+
+int cdft_heatc_destroy(cdft_heatc_plan *p) {
+    if (!p) return CDFT_OK;
+    void *ptrs[] = {p->area, p->e3t, p->e31d, p->mask8, p->mask4, p->gdepw, p->partial};
+    for (void *q : ptrs) if (q) (void)hipFree(q);
+    p->st_a.release(); p->st_b.release(); p->st_temp.release(); p->st_mxl.release(); p->st_out.release();
+    delete p;
+    return CDFT_OK;
+}
+
+}  // extern "C"

@@ -213,4 +213,62 @@ def sig_tool(ptem, psal, pref=0.0, spval=0.0, eos=EOS_80, flags=0, out=None, str
     return out
 
 
-__all__ = ["MocPlan", "sigmai", "sigma0", "sig_tool", "EOS_80", "EOS_TEOS10", "EOS_JMD94", "EOS_FAST_FMA", "Timer", "CdftError", "device_count", "current_stream_ptr", "MEM_HOST", "MEM_DEVICE"]
+class _Plan:
+    """Common life-cycle of the opaque C plans."""
+
+    _destroy = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            getattr(_lib.load(), self._destroy)(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _null():
+    return C.c_void_p(0)
+
+
+class HeatcPlan(_Plan):
+    """cdfheatc level sums (src/cdfheatc.f90:205-240): cdft_heatc_* of the C ABI."""
+
+    _destroy = "cdft_heatc_destroy"
+
+    def __init__(self, npiglo, npjglo, npk):
+        self.npi, self.npj, self.npk = npiglo, npjglo, npk
+        self._h = C.c_void_p()
+        check(_lib.load().cdft_heatc_create(C.byref(self._h), npiglo, npjglo, npk))
+
+    def set_mesh(self, e1t, e2t, tmask, e3t=None, e31d=None, stream=None):
+        """e1t,e2t (npj,npi) r4; tmask (npk,npj,npi) uint8/int8 0-1 bytes or r4; e3t (npk,npj,npi) r4
+        or e31d (npk) r4 (-full)."""
+        p1, s1, k1 = _arg(e1t, np.float32, "e1t")
+        p2, s2, k2 = _arg(e2t, np.float32, "e2t")
+        is_r4 = (tmask.dtype == np.float32) if not _is_tensor(tmask) else (tmask.dtype == torch.float32)
+        pm, sm, km = _arg(tmask, np.float32 if is_r4 else np.uint8, "tmask")
+        p3, s3, k3 = _arg(e3t, np.float32, "e3t") if e3t is not None else (_null(), s1, None)
+        p4, s4, k4 = _arg(e31d, np.float32, "e31d") if e31d is not None else (_null(), s1, None)
+        if not (s1 == s2 == sm == s3 == s4):
+            raise ValueError("all mesh arrays must live in the same memory space")
+        check(_lib.load().cdft_heatc_set_mesh(self._h, p1, p2, p3, p4, pm, 1 if is_r4 else 0, s1,
+                                              stream or current_stream_ptr()))
+
+    def compute(self, temp, rmxldep=None, gdepw=None, mxloption=0, stream=None):
+        """temp (npk,npj,npi) r4 -> sums (npk,3) r8 = dsurf, dvol2d, dsum2d per level (host array)."""
+        pt, st_, kt = _arg(temp, np.float32, "temp")
+        pm, sm, km = _arg(rmxldep, np.float32, "rmxldep") if rmxldep is not None else (_null(), st_, None)
+        pg, sg, kg = _arg(np.asarray(gdepw, np.float32), np.float32, "gdepw") if gdepw is not None else (_null(), 0, None)
+        if sm != st_:
+            raise ValueError("rmxldep must live in the same memory space as temp")
+        out = np.empty((self.npk, 3), np.float64)
+        check(_lib.load().cdft_heatc_compute(self._h, pt, st_, pm, pg, mxloption, C.c_void_p(out.ctypes.data),
+                                             MEM_HOST, stream or current_stream_ptr()))
+        return out
+
+
+__all__ = ["MocPlan", "HeatcPlan", "sigmai", "sigma0", "sig_tool", "EOS_80", "EOS_TEOS10", "EOS_JMD94", "EOS_FAST_FMA", "Timer", "CdftError", "device_count", "current_stream_ptr", "MEM_HOST", "MEM_DEVICE"]

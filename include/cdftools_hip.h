@@ -131,6 +131,29 @@ int cdft_eos_sig_tool(const float *ptem, const float *psal, int64_t n, float pre
                       int flags, float *sig4, int in_space, int out_space, void *stream);
 int cdft_eos_release(void);   /* frees the staging buffers used for host arrays */
 
+/* ------------------------------------------------------------------------------------------ */
+/* cdfheatc : heat content (masked volume integrals per level)                                */
+/*   replaces src/cdfheatc.f90:205-240 (the three SUMs of each level)                          */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct cdft_heatc_plan cdft_heatc_plan;
+
+/* sizes of the (zoomed) working window, as the reference's npiglo/npjglo/nvpk after -zoom */
+int cdft_heatc_create(cdft_heatc_plan **plan, int npiglo, int npjglo, int npk);
+/* e1t,e2t (npiglo,npjglo) r4 src/cdfheatc.f90:188-189; exactly one of
+ *   e3t  (npiglo,npjglo,npk) r4  (:216, again per record with -vvl)  or
+ *   e31d (npk) r4                (-full, :213)
+ * tmask (npiglo,npjglo,npk): bytes with values 0/1 (mask_is_r4 = 0) or r4 values (mask_is_r4 = 1,
+ * for -M masks that are not 0/1), :209.  The plan keeps its own copies. */
+int cdft_heatc_set_mesh(cdft_heatc_plan *plan, const float *e1t, const float *e2t, const float *e3t,
+                        const float *e31d, const void *tmask, int mask_is_r4, int memspace, void *stream);
+/* temp (npiglo,npjglo,npk) r4, one record (:208).  mxloption 0 | 1 | -1 with rmxldep (npiglo,npjglo)
+ * r4 in the same space as temp and gdepw (npk) r4 on the HOST (:218-223).
+ * sums (3,npk) r8 = dsurf, dvol2d, dsum2d of every level (:225-229); the caller forms
+ * heatc2d = pprho0*ppcp*dsum2d and the running dvol / dsum exactly as :227,:230,:236-247. */
+int cdft_heatc_compute(cdft_heatc_plan *plan, const float *temp, int temp_space, const float *rmxldep,
+                       const float *gdepw, int mxloption, double *sums, int out_space, void *stream);
+int cdft_heatc_destroy(cdft_heatc_plan *plan);
+
 #ifdef __cplusplus
 }
 #endif

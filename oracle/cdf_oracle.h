@@ -43,6 +43,23 @@ void oracle_sigmai_jmd94(const float *ptem, const float *psal, long n, float pre
 void oracle_sig_tool(const float *ptem, const float *psal, long n, float pref, float spval, int teos10,
                      float *sig4);
 
+/* cdf_oracle_tools.c -- see the comment at each definition for the reference lines followed */
+void oracle_heatc(int npi, int npj, int npk, const float *e1t, const float *e2t, const float *e3t,
+                  const float *e31d, const float *tmask, const float *temp, const float *mxl,
+                  const float *gdepw, int mxlopt, int r4sum, double *sums);
+void oracle_mhst(int npi, int npj, int npk, int nb, const float *e1v, const float *e3v, const float *e31d,
+                 const float *vt, const float *vs, const float *zv, const float *zt, const float *zs,
+                 const float *masks, int zdim, double *heat, double *salt);
+void oracle_psi(int npi, int npj, int npk, const float *zu, const float *e2u, const float *e3u,
+                const float *zv, const float *e1v, const float *e3v, const float *e31d, int iiref,
+                int ijref, const float *fmask, float *psi4, double *dpsi8);
+void oracle_vt(int npi, int npj, int nfr, long fstride, const float *u, const float *v, const float *t,
+               const float *s, const float *e3u, const float *e3v, double *vt, double *vs, double *ut,
+               double *us, double *e3um, double *e3vm);
+void oracle_curl(int npi, int npj, const float *un, const float *vn, const float *e1u, const float *e2v,
+                 const float *e1f, const float *e2f, int lperio, int ltpoint, const double *ff,
+                 double *rotn);
+
 /* number of OpenMP threads the oracle's parallel loops use (1 when built without OpenMP) */
 int oracle_num_threads(void);
 

@@ -1,0 +1,258 @@
+/*
+ * cdf_oracle_tools.c -- CPU restatement of the cdfheatc / cdfmhst / cdfpsi / cdfvT / cdfcurl loops.
+ * TEST INFRASTRUCTURE ONLY (see cdf_oracle.h).  PARITY UNPINNED: the reference holds no tests or
+ * fixtures for these loops and its programs need netcdf-fortran to build; each function follows the
+ * cited source line by line, in its evaluation order and r4/r8 mixing.
+ */
+#include "cdf_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define IJ(i, j) ((size_t)(j) * npi + (i))
+#define IJK(i, j, k) (((size_t)(k) * npj + (j)) * npi + (i))
+
+/* ------------------------------------------------------------------------------------------ */
+/* src/cdfheatc.f90:205-230, all levels of one record.
+ *   e3t: (npi,npj,npk) or NULL with e31d(npk) (-full, :213); tmask r4 (npi,npj,npk);
+ *   mxlopt 0/1/-1 with mxl(npi,npj), gdepw(npk) (:218-223).
+ *   r4sum = 1: the array expression AND the SUM in r4, sequentially (what flang -O1/-O2 inlines for
+ *              the reference; compiler dependent);
+ *   r4sum = 0: same r4 products, r8 sequential accumulation (comparator of the HIP path).
+ *   sums(3,npk) = dsurf, dvol2d, dsum2d. */
+void oracle_heatc(int npi, int npj, int npk, const float *e1t, const float *e2t, const float *e3t,
+                  const float *e31d, const float *tmask, const float *temp, const float *mxl,
+                  const float *gdepw, int mxlopt, int r4sum, double *sums) {
+    const size_t nij = (size_t)npi * npj;
+    for (int k = 0; k < npk; ++k) {
+        double d_surf = 0.0, d_vol = 0.0, d_sum = 0.0;
+        float f_surf = 0.f, f_vol = 0.f, f_sum = 0.f;
+        for (size_t p = 0; p < nij; ++p) {
+            float e3 = e3t ? e3t[(size_t)k * nij + p] : e31d[k];
+            if (mxlopt == 1) e3 = fmaxf(0.f, fminf(e3, mxl[p] - gdepw[k]));                 /* :220 */
+            else if (mxlopt == -1) e3 = fminf(e3, fmaxf(0.f, gdepw[k] + e3 - mxl[p]));      /* :222 */
+            const float m = tmask[(size_t)k * nij + p];
+            const float a = e1t[p] * e2t[p];
+            const float ps = a * m;                                                         /* :225 */
+            const float pv = a * e3 * m;                                                    /* :226 */
+            const float pt = a * e3 * temp[(size_t)k * nij + p] * m;                        /* :229 */
+            if (r4sum) { f_surf += ps; f_vol += pv; f_sum += pt; }
+            else { d_surf += (double)ps; d_vol += (double)pv; d_sum += (double)pt; }
+        }
+        sums[3 * k + 0] = r4sum ? (double)f_surf : d_surf;
+        sums[3 * k + 1] = r4sum ? (double)f_vol : d_vol;
+        sums[3 * k + 2] = r4sum ? (double)f_sum : d_sum;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* src/cdfmhst.f90:306-367 for one record.
+ *   vt, vs (npi,npj,npk) r4 (-vt file, :325-326); or vt == NULL and zv, zt, zs given (:312-322):
+ *       zvt(ji,jj) = 0.5*(zt(ji,jj)+zt(ji,jj+1))*zv(ji,jj) for jj < npj, 0 on the last row;
+ *   e3v (npi,npj,npk) or NULL with e31d (-full, :329); e1v (npi,npj);
+ *   masks (npi,npj,nb) r4: basin 0 is the global one (vmask level 1) and is summed over
+ *       ji = 2..npi-1 only (:343-344), the others over the whole row (:349-367);
+ *   zdim = 0: heat/salt (nb,npj) after the last level; zdim = 1: (nb,npj,npk) running totals
+ *       after every level (:389-392, -Zdim).
+ *   heat = sum dtrph*zmask with dtrph += (zvt*e1v*e3v*1.d0)*pprau0*pprcp (:332,:336),
+ *   salt = sum dtrps*zmask with dtrps += zvs*e1v*e3v*1.d0 (:333,:337). */
+void oracle_mhst(int npi, int npj, int npk, int nb, const float *e1v, const float *e3v, const float *e31d,
+                 const float *vt, const float *vs, const float *zv, const float *zt, const float *zs,
+                 const float *masks, int zdim, double *heat, double *salt) {
+    const size_t nij = (size_t)npi * npj;
+    const float pprau0 = 1000.f, pprcp = 4000.f;                  /* src/cdfmhst.f90:53-54 */
+    double *dtrph = (double *)calloc(nij, sizeof(double));
+    double *dtrps = (double *)calloc(nij, sizeof(double));
+    for (int k = 0; k < npk; ++k) {
+        for (int j = 0; j < npj; ++j)
+            for (int i = 0; i < npi; ++i) {
+                float zvt, zvs;
+                if (vt) {
+                    zvt = vt[IJK(i, j, k)];
+                    zvs = vs[IJK(i, j, k)];
+                } else if (j < npj - 1) {
+                    zvt = 0.5f * (zt[IJK(i, j, k)] + zt[IJK(i, j + 1, k)]) * zv[IJK(i, j, k)];   /* :318 */
+                    zvs = 0.5f * (zs[IJK(i, j, k)] + zs[IJK(i, j + 1, k)]) * zv[IJK(i, j, k)];
+                } else {
+                    zvt = 0.f; zvs = 0.f;                                                        /* :314-315 */
+                }
+                const float e3 = e3v ? e3v[IJK(i, j, k)] : e31d[k];
+                const double dwkh = (double)(zvt * e1v[IJ(i, j)] * e3) * 1.0;                    /* :332 */
+                const double dwks = (double)(zvs * e1v[IJ(i, j)] * e3) * 1.0;                    /* :333 */
+                dtrph[IJ(i, j)] = dtrph[IJ(i, j)] + dwkh * (double)pprau0 * (double)pprcp;       /* :336 */
+                dtrps[IJ(i, j)] = dtrps[IJ(i, j)] + dwks;                                        /* :337 */
+            }
+        if (zdim || k == npk - 1) {
+            double *oh = heat + (zdim ? (size_t)k * npj * nb : 0);
+            double *os = salt + (zdim ? (size_t)k * npj * nb : 0);
+            for (int b = 0; b < nb; ++b) {
+                const float *zm = masks + (size_t)b * nij;
+                const int i0 = (b == 0) ? 1 : 0, i1 = (b == 0) ? npi - 1 : npi;                  /* :343 */
+                for (int j = 0; j < npj; ++j) {
+                    double sh = 0.0, ss = 0.0;
+                    for (int i = i0; i < i1; ++i) {
+                        sh += dtrph[IJ(i, j)] * (double)zm[IJ(i, j)];
+                        ss += dtrps[IJ(i, j)] * (double)zm[IJ(i, j)];
+                    }
+                    oh[(size_t)j * nb + b] = sh;
+                    os[(size_t)j * nb + b] = ss;
+                }
+            }
+        }
+    }
+    free(dtrph);
+    free(dtrps);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* src/cdfpsi.f90:256-438 for one record, default / -V / -mean / -mask / -ref paths (not -open,
+ * --ssh-file, -lev).
+ *   ll_u: zu, e2u, e3u (or e31d) -> dtrpu = sum_k zu*e2u*e3u*1.d0 (:296-297), then
+ *         dpsiu(:,1) = 0 ; dpsiu(:,jj) = dpsiu(:,jj-1) - dtrpu(:,jj), jj = 2..npj (:395-398)
+ *   ll_v: zv, e1v, e3v          -> dtrpv = sum_k zv*e1v*e3v*1.d0 (:277-278), then
+ *         dpsiv(npi,:) = 0 ; dpsiv(ji,:) = dpsiv(ji+1,:) - dtrpv(ji,:), ji = npi-1..1 (:380-383)
+ *   both (-mean): dpsi = 0.5*(dpsiu + dpsiv) (:413)
+ *   dpsi = dpsi - dpsi(iiref,ijref) (:423, 1-based reference point)
+ *   psi4 = SNGL(dpsi) [* fmask] (:426,:433); dpsi8 (optional) = the r8 field before SNGL. */
+void oracle_psi(int npi, int npj, int npk, const float *zu, const float *e2u, const float *e3u,
+                const float *zv, const float *e1v, const float *e3v, const float *e31d, int iiref,
+                int ijref, const float *fmask, float *psi4, double *dpsi8) {
+    const size_t nij = (size_t)npi * npj;
+    double *dtrpu = (double *)calloc(nij, sizeof(double)), *dtrpv = (double *)calloc(nij, sizeof(double));
+    double *dpsiu = (double *)calloc(nij, sizeof(double)), *dpsiv = (double *)calloc(nij, sizeof(double));
+    for (int k = 0; k < npk; ++k)
+        for (int j = 0; j < npj; ++j)
+            for (int i = 0; i < npi; ++i) {
+                if (zv) {
+                    const float e3 = e3v ? e3v[IJK(i, j, k)] : e31d[k];
+                    dtrpv[IJ(i, j)] = dtrpv[IJ(i, j)] + (double)(zv[IJK(i, j, k)] * e1v[IJ(i, j)] * e3) * 1.0;
+                }
+                if (zu) {
+                    const float e3 = e3u ? e3u[IJK(i, j, k)] : e31d[k];
+                    dtrpu[IJ(i, j)] = dtrpu[IJ(i, j)] + (double)(zu[IJK(i, j, k)] * e2u[IJ(i, j)] * e3) * 1.0;
+                }
+            }
+    double *dpsi = NULL;
+    if (zv) {
+        for (int j = 0; j < npj; ++j) {
+            dpsiv[IJ(npi - 1, j)] = 0.0;
+            for (int i = npi - 2; i >= 0; --i) dpsiv[IJ(i, j)] = dpsiv[IJ(i + 1, j)] - dtrpv[IJ(i, j)];
+        }
+        dpsi = dpsiv;
+    }
+    if (zu) {
+        for (int j = 1; j < npj; ++j)
+            for (int i = 0; i < npi; ++i) dpsiu[IJ(i, j)] = dpsiu[IJ(i, j - 1)] - dtrpu[IJ(i, j)];
+        dpsi = dpsiu;
+    }
+    if (zu && zv) {
+        for (size_t p = 0; p < nij; ++p) dpsiu[p] = 0.5 * (dpsiu[p] + dpsiv[p]);
+        dpsi = dpsiu;
+    }
+    const double ref = dpsi[IJ(iiref - 1, ijref - 1)];
+    for (size_t p = 0; p < nij; ++p) {
+        const double d = dpsi[p] - ref;
+        if (dpsi8) dpsi8[p] = d;
+        psi4[p] = fmask ? (float)d * fmask[p] : (float)d;
+    }
+    free(dtrpu); free(dtrpv); free(dpsiu); free(dpsiv);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* src/cdfvT.f90:160-259 for ONE level over nfr time frames (all tags concatenated).
+ *   u, v, t, s: frame f of the level at ptr + f*fstride (npi,npj) r4; e3u/e3v likewise with -vvl
+ *   (else NULL).  Outputs (npi,npj) r8: vt, vs, ut, us = the values handed to putvar (:247-250,
+ *   or :240-245 with -vvl, then also e3um, e3vm). */
+void oracle_vt(int npi, int npj, int nfr, long fstride, const float *u, const float *v, const float *t,
+               const float *s, const float *e3u, const float *e3v, double *vt, double *vs, double *ut,
+               double *us, double *e3um, double *e3vm) {
+    const size_t nij = (size_t)npi * npj;
+    double *cut = (double *)calloc(nij, 8), *cvt = (double *)calloc(nij, 8), *cus = (double *)calloc(nij, 8),
+           *cvs = (double *)calloc(nij, 8), *ce3u = (double *)calloc(nij, 8), *ce3v = (double *)calloc(nij, 8);
+    float *wu = (float *)malloc(nij * 4), *wv = (float *)malloc(nij * 4);
+    for (int f = 0; f < nfr; ++f) {
+        const float *zu = u + (size_t)f * fstride, *zv = v + (size_t)f * fstride;
+        const float *e3uf = e3u ? e3u + (size_t)f * fstride : NULL, *e3vf = e3v ? e3v + (size_t)f * fstride : NULL;
+        for (int pass = 0; pass < 2; ++pass) {                       /* temperature, then salinity */
+            const float *sc = (pass ? s : t) + (size_t)f * fstride;
+            double *au = pass ? cus : cut, *av = pass ? cvs : cvt;
+            memset(wu, 0, nij * 4); memset(wv, 0, nij * 4);                                     /* :201 */
+            for (int i = 0; i < npi - 1; ++i)
+                for (int j = 0; j < npj - 1; ++j) {
+                    wu[IJ(i, j)] = 0.5f * (sc[IJ(i, j)] + sc[IJ(i + 1, j)]);                      /* :204 */
+                    wv[IJ(i, j)] = 0.5f * (sc[IJ(i, j)] + sc[IJ(i, j + 1)]);                      /* :205 */
+                }
+            for (size_t p = 0; p < nij; ++p) {
+                if (e3uf) {
+                    au[p] = au[p] + (double)(wu[p] * e3uf[p] * zu[p]) * 1.0;                      /* :209 */
+                    av[p] = av[p] + (double)(wv[p] * e3vf[p] * zv[p]) * 1.0;
+                } else {
+                    au[p] = au[p] + (double)(wu[p] * zu[p]) * 1.0;                                /* :214 */
+                    av[p] = av[p] + (double)(wv[p] * zv[p]) * 1.0;
+                }
+            }
+        }
+        if (e3uf)
+            for (size_t p = 0; p < nij; ++p) {
+                ce3u[p] = ce3u[p] + (double)e3uf[p] * 1.0;                                        /* :211 */
+                ce3v[p] = ce3v[p] + (double)e3vf[p] * 1.0;
+            }
+    }
+    for (size_t p = 0; p < nij; ++p) {
+        if (e3u) {                                                                               /* :240-245 */
+            vt[p] = cvt[p] / ce3v[p] * 1.0; vs[p] = cvs[p] / ce3v[p] * 1.0;
+            ut[p] = cut[p] / ce3u[p] * 1.0; us[p] = cus[p] / ce3u[p] * 1.0;
+            e3um[p] = ce3u[p] / (double)nfr * 1.0; e3vm[p] = ce3v[p] / (double)nfr * 1.0;
+        } else {                                                                                 /* :247-250 */
+            vt[p] = cvt[p] / (double)nfr * 1.0; vs[p] = cvs[p] / (double)nfr * 1.0;
+            ut[p] = cut[p] / (double)nfr * 1.0; us[p] = cus[p] / (double)nfr * 1.0;
+        }
+    }
+    free(cut); free(cvt); free(cus); free(cvs); free(ce3u); free(ce3v); free(wu); free(wv);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* src/cdfcurl.f90:262-301 for one level.
+ *   un, vn (npi,npj) r4 (C-grid velocities, :256-257); e1u, e2v, e1f, e2f (npi,npj) r4;
+ *   fmask = 1 where un(i,j)*un(i,j+1)*vn(i,j)*vn(i+1,j) /= 0 (:267-273);
+ *   rotn(i,j) = (e2v(i+1,j)vn(i+1,j) - e2v(i,j)vn(i,j) - e1u(i,j+1)un(i,j+1) + e1u(i,j)un(i,j))
+ *               * fmask / (e1f*e2f)   -- one r4 expression stored into r8 (:276-282), i<npi, j<npj;
+ *   lperio: rotn(npi,:) = rotn(2,:) (:285);
+ *   ltpoint (-T): 4-point mean to T points with the fmask product (:286-297); the reference never
+ *       assigns fmask(npi,:) and fmask(:,npj), they are taken as 0 here;
+ *   ff (npi,npj) r8 or NULL: -overf, rotn = rotn/ff where ff /= 0 (:299-301). */
+void oracle_curl(int npi, int npj, const float *un, const float *vn, const float *e1u, const float *e2v,
+                 const float *e1f, const float *e2f, int lperio, int ltpoint, const double *ff,
+                 double *rotn) {
+    const size_t nij = (size_t)npi * npj;
+    float *fm = (float *)calloc(nij, 4);
+    memset(rotn, 0, nij * 8);
+    for (int j = 0; j < npj - 1; ++j)
+        for (int i = 0; i < npi - 1; ++i) {
+            float f = un[IJ(i, j)] * un[IJ(i, j + 1)] * vn[IJ(i, j)] * vn[IJ(i + 1, j)];
+            if (f != 0.f) f = 1.f;
+            fm[IJ(i, j)] = f;
+            const float r = (e2v[IJ(i + 1, j)] * vn[IJ(i + 1, j)] - e2v[IJ(i, j)] * vn[IJ(i, j)] -
+                             e1u[IJ(i, j + 1)] * un[IJ(i, j + 1)] + e1u[IJ(i, j)] * un[IJ(i, j)]) *
+                            f / (e1f[IJ(i, j)] * e2f[IJ(i, j)]);
+            rotn[IJ(i, j)] = (double)r;
+        }
+    if (lperio)
+        for (int j = 0; j < npj; ++j) rotn[IJ(npi - 1, j)] = rotn[IJ(1, j)];
+    if (ltpoint) {
+        double *dl = (double *)calloc(nij, 8);
+        for (int i = 1; i < npi; ++i)
+            for (int j = 1; j < npj; ++j) {
+                const float zm = fm[IJ(i, j)] * fm[IJ(i, j - 1)] * fm[IJ(i - 1, j)] * fm[IJ(i - 1, j - 1)];
+                dl[IJ(i, j)] = 0.25 * (rotn[IJ(i, j)] + rotn[IJ(i, j - 1)] + rotn[IJ(i - 1, j)] + rotn[IJ(i - 1, j - 1)]) * (double)zm;
+            }
+        if (lperio)
+            for (int j = 0; j < npj; ++j) dl[IJ(0, j)] = dl[IJ(npi - 1, j)];
+        memcpy(rotn, dl, nij * 8);
+        free(dl);
+    }
+    if (ff)
+        for (size_t p = 0; p < nij; ++p)
+            if (ff[p] != 0.0) rotn[p] = rotn[p] / ff[p];
+    free(fm);
+}

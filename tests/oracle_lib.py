@@ -16,9 +16,7 @@ _lib = None
 def load():
     global _lib
     if _lib is None:
-        src = os.path.join(ORACLE_DIR, "cdf_oracle.c")
-        if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
-            subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle.so"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle.so"], stdout=subprocess.DEVNULL)  # no-op when fresh
         _lib = C.CDLL(LIB)
         _lib.oracle_num_threads.restype = C.c_int
     return _lib

