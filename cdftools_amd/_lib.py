@@ -60,6 +60,13 @@ SIGNATURES = {
     "cdft_heatc_set_mesh": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "cdft_heatc_compute": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp]),
     "cdft_heatc_destroy": (_i, [_vp]),
+    "cdft_mhst_create": (_i, [_pvp, _i, _i, _i, _i]),
+    "cdft_mhst_set_mesh": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "cdft_mhst_compute": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp]),
+    "cdft_mhst_destroy": (_i, [_vp]),
+    "cdft_psi_create": (_i, [_pvp, _i, _i, _i]),
+    "cdft_psi_compute": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _vp]),
+    "cdft_psi_destroy": (_i, [_vp]),
 }
 
 _lib = None

@@ -1,0 +1,441 @@
+// transport.hip -- cdfmhst and cdfpsi (C ABI sections "cdfmhst", "cdfpsi").
+//
+// Both tools integrate a metric-weighted velocity (times tracer) vertically, cell by cell, and then
+// reduce or scan the resulting 2-D r8 field:
+//   cdfmhst src/cdfmhst.f90:308-367  dtrph += (zvt*e1v*e3v*1.d0)*pprau0*pprcp ; dtrps += zvs*e1v*e3v*1.d0
+//                                    zonal SUM(dtrp*zmask) per row and basin
+//   cdfpsi  src/cdfpsi.f90:271-298   dtrpu += zu*e2u*e3u*1.d0 ; dtrpv += zv*e1v*e3v*1.d0
+//           :377-423                 running differences along j (U) or i (V), reference point, SNGL
+// The vertical sums run sequentially in k per cell with the reference's r4 product order, so the 2-D
+// transports are BIT-IDENTICAL to the reference; cdfpsi's scans are sequential too (bit-identical);
+// only cdfmhst's zonal sums use a fixed tree order (tolerance 1e-13 * sum|terms|).
+//
+// HBM-bound: the 3-D pass reads 8 B (cdfpsi: u + e3u) or 12 B (cdfmhst: vt + vs + e3v) per cell
+// once; the 2-D work is < 1 % of that.
+#include "common.hpp"
+#include "reduce.hpp"
+
+using namespace cdft;
+
+namespace {
+
+constexpr int kThreads = 256;
+
+template <int VEC> struct FV;
+template <> struct FV<4> { typedef float4 t; };
+template <> struct FV<2> { typedef float2 t; };
+template <> struct FV<1> { typedef float t; };
+template <int VEC> __device__ __forceinline__ void ld(const float *p, int64_t e, float (&o)[VEC]);
+template <> __device__ __forceinline__ void ld<4>(const float *p, int64_t e, float (&o)[4]) {
+    const float4 v = *reinterpret_cast<const float4 *>(p + e); o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+}
+template <> __device__ __forceinline__ void ld<2>(const float *p, int64_t e, float (&o)[2]) {
+    const float2 v = *reinterpret_cast<const float2 *>(p + e); o[0] = v.x; o[1] = v.y;
+}
+template <> __device__ __forceinline__ void ld<1>(const float *p, int64_t e, float (&o)[1]) { o[0] = p[e]; }
+
+enum VMode { kPsi = 0, kMhstVt = 1, kMhstSep = 2 };
+
+struct VintArgs {
+    const float *f0, *f1, *f2;   // psi: velocity ; mhst -vt: vt, vs ; mhst sep: v, t, s
+    const float *m2d;            // e2u / e1v (npi,npj)
+    const float *e3;             // (npi,npj,npk) or null
+    const float *e31d;           // (npk) or null
+    double *acc0, *acc1;         // (npi,npj) r8 accumulators (acc1: salt)
+    int64_t nij;
+    int npi, npj, k0, k1, init;
+};
+
+// One lane owns VEC consecutive cells and walks the levels k0..k1-1 in order (sequential r8 sum).
+template <int VEC, int MODE, bool FULL>
+__global__ void __launch_bounds__(kThreads) vint_kernel(VintArgs a) {
+    const int64_t p = ((int64_t)blockIdx.x * kThreads + threadIdx.x) * VEC;
+    if (p >= a.nij) return;
+    float m[VEC];
+    ld<VEC>(a.m2d, p, m);
+    double s0[VEC], s1[VEC];
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) {
+        s0[c] = a.init ? 0.0 : a.acc0[p + c];
+        s1[c] = (MODE != kPsi && !a.init) ? a.acc1[p + c] : 0.0;
+    }
+    const bool lastrow = (MODE == kMhstSep) && (p / a.npi == a.npj - 1);    // npi % VEC == 0 here
+#pragma unroll 4
+    for (int k = a.k0; k < a.k1; ++k) {
+        const int64_t e = (int64_t)k * a.nij + p;
+        float x0[VEC], x1[VEC], e3[VEC];
+        if (FULL) {
+            const float v = a.e31d[k];
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) e3[c] = v;
+        } else {
+            ld<VEC>(a.e3, e, e3);
+        }
+        if (MODE == kMhstSep) {                       // src/cdfmhst.f90:312-322
+            float v[VEC], t0[VEC], t1[VEC], q0[VEC], q1[VEC];
+            ld<VEC>(a.f0, e, v);
+            ld<VEC>(a.f1, e, t0);
+            ld<VEC>(a.f2, e, q0);
+            if (!lastrow) { ld<VEC>(a.f1, e + a.npi, t1); ld<VEC>(a.f2, e + a.npi, q1); }
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) {
+                x0[c] = lastrow ? 0.f : __fmul_rn(__fmul_rn(0.5f, __fadd_rn(t0[c], t1[c])), v[c]);
+                x1[c] = lastrow ? 0.f : __fmul_rn(__fmul_rn(0.5f, __fadd_rn(q0[c], q1[c])), v[c]);
+            }
+        } else {
+            ld<VEC>(a.f0, e, x0);
+            if (MODE == kMhstVt) ld<VEC>(a.f1, e, x1);
+        }
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+            // (field*metric)*e3 in r4, then widened: src/cdfmhst.f90:332-333, src/cdfpsi.f90:277,296
+            const double d0 = (double)__fmul_rn(__fmul_rn(x0[c], m[c]), e3[c]);
+            if (MODE == kPsi) {
+                s0[c] = __dadd_rn(s0[c], d0);
+            } else {
+                s0[c] = __dadd_rn(s0[c], __dmul_rn(__dmul_rn(d0, 1000.0), 4000.0));   // :336 pprau0, pprcp
+                s1[c] = __dadd_rn(s1[c], (double)__fmul_rn(__fmul_rn(x1[c], m[c]), e3[c]));   // :337
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) {
+        a.acc0[p + c] = s0[c];
+        if (MODE != kPsi) a.acc1[p + c] = s1[c];
+    }
+}
+
+template <int MODE>
+int launch_vint(const VintArgs &a, hipStream_t st) {
+    auto al = [](const void *p, size_t n) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) % n) == 0; };
+    auto all = [&](size_t n) {
+        return al(a.f0, n) && al(a.f1, n) && al(a.f2, n) && al(a.m2d, n) && al(a.e3, n);
+    };
+    int vec = 1;
+    const bool rowok4 = MODE != kMhstSep || a.npi % 4 == 0, rowok2 = MODE != kMhstSep || a.npi % 2 == 0;
+    if (a.nij % 4 == 0 && rowok4 && all(16)) vec = 4;
+    else if (a.nij % 2 == 0 && rowok2 && all(8)) vec = 2;
+    const bool full = a.e31d != nullptr;
+    const int64_t nthr = (a.nij + vec - 1) / vec;
+    const dim3 grid((unsigned)((nthr + kThreads - 1) / kThreads)), block(kThreads);
+#define CDFT_GO(V, F) hipLaunchKernelGGL((vint_kernel<V, MODE, F>), grid, block, 0, st, a)
+    if (vec == 4) { if (full) CDFT_GO(4, true); else CDFT_GO(4, false); }
+    else if (vec == 2) { if (full) CDFT_GO(2, true); else CDFT_GO(2, false); }
+    else { if (full) CDFT_GO(1, true); else CDFT_GO(1, false); }
+#undef CDFT_GO
+    CDFT_LAUNCH_CHECK();
+    return CDFT_OK;
+}
+
+// cdfmhst zonal sums (src/cdfmhst.f90:340-367): one workgroup per row, every basin in one pass.
+// masks (npi,npj,nb) r4; basin 0 (global) runs over ji = 2..npi-1, the others over the whole row.
+template <int NB>
+__global__ void __launch_bounds__(kThreads)
+mhst_zonal_kernel(const double *__restrict__ dtrph, const double *__restrict__ dtrps,
+                  const float *__restrict__ masks, int npi, int npj, int nb, double *__restrict__ heat,
+                  double *__restrict__ salt) {
+    __shared__ double scratch[16];
+    const int jj = blockIdx.x;
+    const int64_t nij = (int64_t)npi * npj, row = (int64_t)jj * npi;
+    double sh[NB], ss[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) { sh[b] = 0.0; ss[b] = 0.0; }
+    for (int i = threadIdx.x; i < npi; i += kThreads) {
+        const double h = dtrph[row + i], s = dtrps[row + i];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            if (b < nb && !(b == 0 && (i == 0 || i == npi - 1))) {
+                const double zm = (double)masks[(int64_t)b * nij + row + i];
+                sh[b] += h * zm;
+                ss[b] += s * zm;
+            }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        if (b < nb) {                                   // nb is uniform: no divergent barrier
+            const double th = block_sum(sh[b], scratch), ts = block_sum(ss[b], scratch);
+            if (threadIdx.x == 0) {
+                heat[(int64_t)jj * nb + b] = th;
+                salt[(int64_t)jj * nb + b] = ts;
+            }
+        }
+    }
+}
+
+// cdfpsi U path, src/cdfpsi.f90:395-398: dpsiu(:,1) = 0 ; dpsiu(:,jj) = dpsiu(:,jj-1) - dtrpu(:,jj)
+__global__ void psi_scan_j_kernel(const double *__restrict__ dtrp, double *__restrict__ dpsi, int npi, int npj) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npi) return;
+    double acc = 0.0;
+    dpsi[i] = 0.0;
+    for (int j = 1; j < npj; ++j) {
+        acc = __dadd_rn(acc, -dtrp[(int64_t)j * npi + i]);
+        dpsi[(int64_t)j * npi + i] = acc;
+    }
+}
+
+// cdfpsi V path, src/cdfpsi.f90:380-383: dpsiv(npi,:) = 0 ; dpsiv(ji,:) = dpsiv(ji+1,:) - dtrpv(ji,:),
+// ji = npi-1..1.  The scan runs along i, the contiguous axis: one wave takes 64 rows, stages a
+// 64 x 64 tile through LDS with coalesced row segments, each lane scans its own row of the tile
+// sequentially (carry in a register), and the tile is written back coalesced.
+__global__ void __launch_bounds__(64) psi_scan_i_kernel(const double *__restrict__ dtrp, double *__restrict__ dpsi,
+                                                        int npi, int npj) {
+    __shared__ double tile[64][65];
+    const int lane = threadIdx.x, j0 = blockIdx.x * 64;
+    double carry = 0.0;                                   // dpsiv(ji+1, row) entering the chunk
+    for (int c1 = npi; c1 > 0; c1 -= 64) {                // columns [c0, c1), right to left
+        const int c0 = max(c1 - 64, 0), w = c1 - c0;
+        for (int r = 0; r < 64; ++r)
+            if (j0 + r < npj && lane < w) tile[r][lane] = dtrp[(int64_t)(j0 + r) * npi + c0 + lane];
+        __syncthreads();
+        if (j0 + lane < npj) {
+            for (int c = w - 1; c >= 0; --c) {
+                if (c0 + c == npi - 1) carry = 0.0;       // the eastern column itself is 0
+                else carry = __dadd_rn(carry, -tile[lane][c]);
+                tile[lane][c] = carry;
+            }
+        }
+        __syncthreads();
+        for (int r = 0; r < 64; ++r)
+            if (j0 + r < npj && lane < w) dpsi[(int64_t)(j0 + r) * npi + c0 + lane] = tile[r][lane];
+        __syncthreads();
+    }
+}
+
+// src/cdfpsi.f90:412-438: optional mean of the two estimates, reference point, SNGL, optional mask
+__global__ void psi_final_kernel(const double *__restrict__ du, const double *__restrict__ dv, int64_t nij,
+                                 int64_t pref, const float *__restrict__ fmask, float *__restrict__ psi4,
+                                 double *__restrict__ dpsi8) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nij) return;
+    auto val = [&](int64_t q) {
+        if (du && dv) return __dmul_rn(0.5, __dadd_rn(du[q], dv[q]));
+        return du ? du[q] : dv[q];
+    };
+    const double d = __dadd_rn(val(p), -val(pref));
+    if (dpsi8) dpsi8[p] = d;
+    psi4[p] = fmask ? __fmul_rn((float)d, fmask[p]) : (float)d;
+}
+
+int dmalloc(void **p, size_t bytes) {
+    if (hipMalloc(p, bytes + 64) != hipSuccess) {
+        (void)hipGetLastError();
+        *p = nullptr;
+        return fail(CDFT_ERR_ALLOC, "device allocation of %zu bytes failed", bytes);
+    }
+    return CDFT_OK;
+}
+
+int upload(void **dst, const void *src, size_t bytes, int space, hipStream_t st) {
+    if (!*dst) CDFT_TRY(dmalloc(dst, bytes));
+    CDFT_HIP(hipMemcpyAsync(*dst, src, bytes, space == CDFT_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+    return CDFT_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------ cdfmhst
+struct cdft_mhst_plan {
+    int npi = 0, npj = 0, npk = 0, nb = 0;
+    float *e1v = nullptr, *e3v = nullptr, *e31d = nullptr, *masks = nullptr;
+    double *dtrph = nullptr, *dtrps = nullptr, *oh = nullptr, *os = nullptr;
+    bool mesh_set = false;
+    DevBuf s0, s1, s2;
+};
+
+extern "C" {
+
+int cdft_mhst_create(cdft_mhst_plan **plan, int npiglo, int npjglo, int npk, int nbasins) {
+    if (!plan) return fail(CDFT_ERR_ARG, "cdft_mhst_create: NULL plan pointer");
+    *plan = nullptr;
+    if (npiglo < 1 || npjglo < 1 || npk < 1 || nbasins < 1 || nbasins > 8)
+        return fail(CDFT_ERR_ARG, "cdft_mhst_create: bad sizes %d x %d x %d, %d basins", npiglo, npjglo, npk, nbasins);
+    CDFT_TRY(require_device());
+    cdft_mhst_plan *p = new cdft_mhst_plan;
+    p->npi = npiglo; p->npj = npjglo; p->npk = npk; p->nb = nbasins;
+    const size_t nij = (size_t)npiglo * npjglo;
+    int rc = dmalloc((void **)&p->dtrph, nij * 8);
+    if (!rc) rc = dmalloc((void **)&p->dtrps, nij * 8);
+    if (!rc) rc = dmalloc((void **)&p->oh, (size_t)nbasins * npjglo * npk * 8);
+    if (!rc) rc = dmalloc((void **)&p->os, (size_t)nbasins * npjglo * npk * 8);
+    if (rc) { cdft_mhst_destroy(p); return rc; }
+    *plan = p;
+    return CDFT_OK;
+}
+
+int cdft_mhst_set_mesh(cdft_mhst_plan *p, const float *e1v, const float *e3v, const float *e31d,
+                       const float *masks, int memspace, void *stream) {
+    if (!p || !e1v || !masks || (!e3v && !e31d) || (e3v && e31d))
+        return fail(CDFT_ERR_ARG, "cdft_mhst_set_mesh: need e1v, masks and exactly one of e3v / e31d");
+    hipStream_t st = as_stream(stream);
+    const size_t nij = (size_t)p->npi * p->npj;
+    CDFT_TRY(upload((void **)&p->e1v, e1v, nij * 4, memspace, st));
+    CDFT_TRY(upload((void **)&p->masks, masks, nij * p->nb * 4, memspace, st));
+    if (e3v) {
+        CDFT_TRY(upload((void **)&p->e3v, e3v, nij * p->npk * 4, memspace, st));
+        if (p->e31d) { (void)hipFree(p->e31d); p->e31d = nullptr; }
+    } else {
+        CDFT_TRY(upload((void **)&p->e31d, e31d, (size_t)p->npk * 4, memspace, st));
+        if (p->e3v) { (void)hipFree(p->e3v); p->e3v = nullptr; }
+    }
+    CDFT_HIP(hipStreamSynchronize(st));
+    p->mesh_set = true;
+    return CDFT_OK;
+}
+
+int cdft_mhst_compute(cdft_mhst_plan *p, const float *vt, const float *vs, const float *zv, const float *zt,
+                      const float *zs, int in_space, int zdim, double *heat, double *salt, int out_space,
+                      void *stream) {
+    if (!p || !heat || !salt) return fail(CDFT_ERR_ARG, "cdft_mhst_compute: NULL argument");
+    if (!p->mesh_set) return fail(CDFT_ERR_STATE, "cdft_mhst_compute: cdft_mhst_set_mesh has not succeeded");
+    const bool sep = (vt == nullptr);
+    if ((sep && (!zv || !zt || !zs)) || (!sep && !vs))
+        return fail(CDFT_ERR_ARG, "cdft_mhst_compute: give (vt, vs) or (zv, zt, zs)");
+    hipStream_t st = as_stream(stream);
+    const int64_t nij = (int64_t)p->npi * p->npj;
+    const size_t n3b = (size_t)nij * p->npk * 4;
+    const void *d0, *d1, *d2 = nullptr;
+    CDFT_TRY(to_device(sep ? zv : vt, n3b, in_space, p->s0, st, &d0));
+    CDFT_TRY(to_device(sep ? zt : vs, n3b, in_space, p->s1, st, &d1));
+    if (sep) CDFT_TRY(to_device(zs, n3b, in_space, p->s2, st, &d2));
+    VintArgs a;
+    a.f0 = (const float *)d0; a.f1 = (const float *)d1; a.f2 = (const float *)d2; a.m2d = p->e1v;
+    a.e3 = p->e3v; a.e31d = p->e31d; a.acc0 = p->dtrph; a.acc1 = p->dtrps; a.nij = nij; a.npi = p->npi;
+    a.npj = p->npj;
+    const int nlev_out = zdim ? p->npk : 1;
+    const size_t out_bytes = (size_t)p->nb * p->npj * nlev_out * 8;
+    double *oh = (out_space == CDFT_MEM_DEVICE) ? heat : p->oh, *os = (out_space == CDFT_MEM_DEVICE) ? salt : p->os;
+    auto zonal = [&](double *h, double *s) -> int {
+        if (p->nb == 1)
+            hipLaunchKernelGGL((mhst_zonal_kernel<1>), dim3(p->npj), dim3(kThreads), 0, st, p->dtrph, p->dtrps,
+                               p->masks, p->npi, p->npj, p->nb, h, s);
+        else
+            hipLaunchKernelGGL((mhst_zonal_kernel<8>), dim3(p->npj), dim3(kThreads), 0, st, p->dtrph, p->dtrps,
+                               p->masks, p->npi, p->npj, p->nb, h, s);
+        CDFT_LAUNCH_CHECK();
+        return CDFT_OK;
+    };
+    if (!zdim) {
+        a.k0 = 0; a.k1 = p->npk; a.init = 1;
+        CDFT_TRY(sep ? launch_vint<kMhstSep>(a, st) : launch_vint<kMhstVt>(a, st));
+        CDFT_TRY(zonal(oh, os));
+    } else {                                            // -Zdim: running totals after every level
+        for (int k = 0; k < p->npk; ++k) {
+            a.k0 = k; a.k1 = k + 1; a.init = (k == 0);
+            CDFT_TRY(sep ? launch_vint<kMhstSep>(a, st) : launch_vint<kMhstVt>(a, st));
+            CDFT_TRY(zonal(oh + (size_t)k * p->npj * p->nb, os + (size_t)k * p->npj * p->nb));
+        }
+    }
+    if (out_space == CDFT_MEM_HOST) {
+        CDFT_HIP(hipMemcpyAsync(heat, oh, out_bytes, hipMemcpyDeviceToHost, st));
+        CDFT_HIP(hipMemcpyAsync(salt, os, out_bytes, hipMemcpyDeviceToHost, st));
+        CDFT_HIP(hipStreamSynchronize(st));
+    }
+    return CDFT_OK;
+}
+
+int cdft_mhst_destroy(cdft_mhst_plan *p) {
+    if (!p) return CDFT_OK;
+    void *ptrs[] = {p->e1v, p->e3v, p->e31d, p->masks, p->dtrph, p->dtrps, p->oh, p->os};
+    for (void *q : ptrs) if (q) (void)hipFree(q);
+    p->s0.release(); p->s1.release(); p->s2.release();
+    delete p;
+    return CDFT_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------ cdfpsi
+struct cdft_psi_plan {
+    int npi = 0, npj = 0, npk = 0;
+    double *dtrpu = nullptr, *dtrpv = nullptr, *dpsiu = nullptr, *dpsiv = nullptr, *d8 = nullptr;
+    float *p4 = nullptr;
+    DevBuf su, se3u, sv, se3v, sm0, sm1, sfm, s1d;
+};
+
+extern "C" {
+
+int cdft_psi_create(cdft_psi_plan **plan, int npiglo, int npjglo, int npk) {
+    if (!plan) return fail(CDFT_ERR_ARG, "cdft_psi_create: NULL plan pointer");
+    *plan = nullptr;
+    if (npiglo < 1 || npjglo < 1 || npk < 1)
+        return fail(CDFT_ERR_ARG, "cdft_psi_create: bad sizes %d x %d x %d", npiglo, npjglo, npk);
+    CDFT_TRY(require_device());
+    cdft_psi_plan *p = new cdft_psi_plan;
+    p->npi = npiglo; p->npj = npjglo; p->npk = npk;
+    const size_t nij = (size_t)npiglo * npjglo;
+    int rc = dmalloc((void **)&p->dtrpu, nij * 8);
+    if (!rc) rc = dmalloc((void **)&p->dtrpv, nij * 8);
+    if (!rc) rc = dmalloc((void **)&p->dpsiu, nij * 8);
+    if (!rc) rc = dmalloc((void **)&p->dpsiv, nij * 8);
+    if (!rc) rc = dmalloc((void **)&p->d8, nij * 8);
+    if (!rc) rc = dmalloc((void **)&p->p4, nij * 4);
+    if (rc) { cdft_psi_destroy(p); return rc; }
+    *plan = p;
+    return CDFT_OK;
+}
+
+int cdft_psi_compute(cdft_psi_plan *p, const float *zu, const float *e2u, const float *e3u, const float *zv,
+                     const float *e1v, const float *e3v, const float *e31d, int iiref, int ijref,
+                     const float *fmask, int in_space, float *psi4, double *dpsi8, int out_space, void *stream) {
+    if (!p || !psi4) return fail(CDFT_ERR_ARG, "cdft_psi_compute: NULL argument");
+    const bool lu = zu != nullptr, lv = zv != nullptr;
+    if (!lu && !lv) return fail(CDFT_ERR_ARG, "cdft_psi_compute: give the U set, the V set, or both (-mean)");
+    if ((lu && (!e2u || (!e3u && !e31d))) || (lv && (!e1v || (!e3v && !e31d))))
+        return fail(CDFT_ERR_ARG, "cdft_psi_compute: each velocity needs its horizontal metric and e3 (or e31d)");
+    if (iiref < 1 || iiref > p->npi || ijref < 1 || ijref > p->npj)
+        return fail(CDFT_ERR_ARG, "cdft_psi_compute: reference point (%d,%d) outside the domain", iiref, ijref);
+    hipStream_t st = as_stream(stream);
+    const int64_t nij = (int64_t)p->npi * p->npj;
+    const size_t n3b = (size_t)nij * p->npk * 4, n2b = (size_t)nij * 4;
+    const void *d1d = nullptr, *dfm = nullptr;
+    if (e31d) CDFT_TRY(to_device(e31d, (size_t)p->npk * 4, in_space, p->s1d, st, &d1d));
+    if (fmask) CDFT_TRY(to_device(fmask, n2b, in_space, p->sfm, st, &dfm));
+    auto integrate = [&](const float *z, const float *m, const float *e3, DevBuf &bz, DevBuf &be, DevBuf &bm,
+                         double *acc) -> int {
+        const void *dz, *dm, *de = nullptr;
+        CDFT_TRY(to_device(z, n3b, in_space, bz, st, &dz));
+        CDFT_TRY(to_device(m, n2b, in_space, bm, st, &dm));
+        if (e3) CDFT_TRY(to_device(e3, n3b, in_space, be, st, &de));
+        VintArgs a;
+        a.f0 = (const float *)dz; a.f1 = nullptr; a.f2 = nullptr; a.m2d = (const float *)dm;
+        a.e3 = (const float *)de; a.e31d = e3 ? nullptr : (const float *)d1d; a.acc0 = acc; a.acc1 = nullptr;
+        a.nij = nij; a.npi = p->npi; a.npj = p->npj; a.k0 = 0; a.k1 = p->npk; a.init = 1;
+        return launch_vint<kPsi>(a, st);
+    };
+    if (lv) {
+        CDFT_TRY(integrate(zv, e1v, e3v, p->sv, p->se3v, p->sm1, p->dtrpv));
+        hipLaunchKernelGGL(psi_scan_i_kernel, dim3((p->npj + 63) / 64), dim3(64), 0, st, p->dtrpv, p->dpsiv, p->npi, p->npj);
+        CDFT_LAUNCH_CHECK();
+    }
+    if (lu) {
+        CDFT_TRY(integrate(zu, e2u, e3u, p->su, p->se3u, p->sm0, p->dtrpu));
+        hipLaunchKernelGGL(psi_scan_j_kernel, dim3((p->npi + 63) / 64), dim3(64), 0, st, p->dtrpu, p->dpsiu, p->npi, p->npj);
+        CDFT_LAUNCH_CHECK();
+    }
+    float *o4 = out_space == CDFT_MEM_DEVICE ? psi4 : p->p4;
+    double *o8 = dpsi8 ? (out_space == CDFT_MEM_DEVICE ? dpsi8 : p->d8) : nullptr;
+    const int64_t pref = (int64_t)(ijref - 1) * p->npi + (iiref - 1);
+    hipLaunchKernelGGL(psi_final_kernel, dim3((unsigned)((nij + 255) / 256)), dim3(256), 0, st,
+                       lu ? p->dpsiu : nullptr, lv ? p->dpsiv : nullptr, nij, pref, (const float *)dfm, o4, o8);
+    CDFT_LAUNCH_CHECK();
+    if (out_space == CDFT_MEM_HOST) {
+        CDFT_HIP(hipMemcpyAsync(psi4, o4, n2b, hipMemcpyDeviceToHost, st));
+        if (dpsi8) CDFT_HIP(hipMemcpyAsync(dpsi8, o8, (size_t)nij * 8, hipMemcpyDeviceToHost, st));
+        CDFT_HIP(hipStreamSynchronize(st));
+    }
+    return CDFT_OK;
+}
+
+int cdft_psi_destroy(cdft_psi_plan *p) {
+    if (!p) return CDFT_OK;
+    void *ptrs[] = {p->dtrpu, p->dtrpv, p->dpsiu, p->dpsiv, p->d8, p->p4};
+    for (void *q : ptrs) if (q) (void)hipFree(q);
+    DevBuf *bufs[] = {&p->su, &p->se3u, &p->sv, &p->se3v, &p->sm0, &p->sm1, &p->sfm, &p->s1d};
+    for (DevBuf *b : bufs) b->release();
+    delete p;
+    return CDFT_OK;
+}
+
+}  // extern "C"

@@ -271,4 +271,73 @@ class HeatcPlan(_Plan):
         return out
 
 
-__all__ = ["MocPlan", "HeatcPlan", "sigmai", "sigma0", "sig_tool", "EOS_80", "EOS_TEOS10", "EOS_JMD94", "EOS_FAST_FMA", "Timer", "CdftError", "device_count", "current_stream_ptr", "MEM_HOST", "MEM_DEVICE"]
+def _opt(x, name):
+    """optional r4 array -> (pointer, space or None, keepalive)"""
+    if x is None:
+        return _null(), None, None
+    return _arg(x, np.float32, name)
+
+
+def _same_space(*spaces):
+    s = {x for x in spaces if x is not None}
+    if len(s) > 1:
+        raise ValueError("all input arrays of one call must live in the same memory space")
+    return s.pop() if s else MEM_HOST
+
+
+class MhstPlan(_Plan):
+    """cdfmhst (src/cdfmhst.f90:308-367): cdft_mhst_* of the C ABI."""
+
+    _destroy = "cdft_mhst_destroy"
+
+    def __init__(self, npiglo, npjglo, npk, nbasins):
+        self.npi, self.npj, self.npk, self.nb = npiglo, npjglo, npk, nbasins
+        self._h = C.c_void_p()
+        check(_lib.load().cdft_mhst_create(C.byref(self._h), npiglo, npjglo, npk, nbasins))
+
+    def set_mesh(self, e1v, masks, e3v=None, e31d=None, stream=None):
+        """e1v (npj,npi); masks (nb,npj,npi) r4, slab 0 global; e3v (npk,npj,npi) or e31d (npk)."""
+        p1, s1, k1 = _arg(e1v, np.float32, "e1v")
+        pm, sm, km = _arg(masks, np.float32, "masks")
+        p3, s3, k3 = _opt(e3v, "e3v")
+        p4, s4, k4 = _opt(e31d, "e31d")
+        sp = _same_space(s1, sm, s3, s4)
+        check(_lib.load().cdft_mhst_set_mesh(self._h, p1, p3, p4, pm, sp, stream or current_stream_ptr()))
+
+    def compute(self, vt=None, vs=None, zv=None, zt=None, zs=None, zdim=False, stream=None):
+        """-> (heat, salt) host arrays (npj,nb) or (npk,npj,nb) with zdim: raw zonal sums."""
+        a = [_opt(x, n) for x, n in ((vt, "vt"), (vs, "vs"), (zv, "zv"), (zt, "zt"), (zs, "zs"))]
+        sp = _same_space(*[x[1] for x in a])
+        shape = (self.npk, self.npj, self.nb) if zdim else (self.npj, self.nb)
+        heat, salt = np.empty(shape, np.float64), np.empty(shape, np.float64)
+        check(_lib.load().cdft_mhst_compute(self._h, a[0][0], a[1][0], a[2][0], a[3][0], a[4][0], sp,
+                                            1 if zdim else 0, C.c_void_p(heat.ctypes.data),
+                                            C.c_void_p(salt.ctypes.data), MEM_HOST, stream or current_stream_ptr()))
+        return heat, salt
+
+
+class PsiPlan(_Plan):
+    """cdfpsi (src/cdfpsi.f90:271-438, default / -V / -mean / -mask / -ref): cdft_psi_*."""
+
+    _destroy = "cdft_psi_destroy"
+
+    def __init__(self, npiglo, npjglo, npk):
+        self.npi, self.npj, self.npk = npiglo, npjglo, npk
+        self._h = C.c_void_p()
+        check(_lib.load().cdft_psi_create(C.byref(self._h), npiglo, npjglo, npk))
+
+    def compute(self, zu=None, e2u=None, e3u=None, zv=None, e1v=None, e3v=None, e31d=None, iiref=None,
+                ijref=None, fmask=None, stream=None):
+        """-> (psi4 (npj,npi) r4, dpsi8 (npj,npi) r8) host arrays."""
+        names = ("zu", "e2u", "e3u", "zv", "e1v", "e3v", "e31d", "fmask")
+        a = [_opt(x, n) for x, n in zip((zu, e2u, e3u, zv, e1v, e3v, e31d, fmask), names)]
+        sp = _same_space(*[x[1] for x in a])
+        p4, d8 = np.empty((self.npj, self.npi), np.float32), np.empty((self.npj, self.npi), np.float64)
+        check(_lib.load().cdft_psi_compute(self._h, a[0][0], a[1][0], a[2][0], a[3][0], a[4][0], a[5][0], a[6][0],
+                                           self.npi if iiref is None else iiref, self.npj if ijref is None else ijref,
+                                           a[7][0], sp, C.c_void_p(p4.ctypes.data), C.c_void_p(d8.ctypes.data),
+                                           MEM_HOST, stream or current_stream_ptr()))
+        return p4, d8
+
+
+__all__ = ["MocPlan", "HeatcPlan", "MhstPlan", "PsiPlan", "sigmai", "sigma0", "sig_tool", "EOS_80", "EOS_TEOS10", "EOS_JMD94", "EOS_FAST_FMA", "Timer", "CdftError", "device_count", "current_stream_ptr", "MEM_HOST", "MEM_DEVICE"]

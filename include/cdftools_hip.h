@@ -154,6 +154,48 @@ int cdft_heatc_compute(cdft_heatc_plan *plan, const float *temp, int temp_space,
                        const float *gdepw, int mxloption, double *sums, int out_space, void *stream);
 int cdft_heatc_destroy(cdft_heatc_plan *plan);
 
+/* ------------------------------------------------------------------------------------------ */
+/* cdfmhst : meridional heat / salt transport                                                 */
+/*   replaces src/cdfmhst.f90:308-367 (vertical integration of vt, vs and the zonal SUMs)      */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct cdft_mhst_plan cdft_mhst_plan;
+
+int cdft_mhst_create(cdft_mhst_plan **plan, int npiglo, int npjglo, int npk, int nbasins);
+/* e1v (npiglo,npjglo) r4 :276; exactly one of e3v (npiglo,npjglo,npk) r4 (:330, again per record
+ * with -vvl) or e31d (npk) r4 (-full, :329); masks (npiglo,npjglo,nbasins) r4: slab 0 is the global
+ * mask (vmask level 1, summed over ji = 2..npiglo-1 only, :340-344), the others are the basin masks
+ * summed over the whole row (:349-367).  The plan keeps copies. */
+int cdft_mhst_set_mesh(cdft_mhst_plan *plan, const float *e1v, const float *e3v, const float *e31d,
+                       const float *masks, int memspace, void *stream);
+/* One record.  Either vt, vs (npiglo,npjglo,npk) r4 from a VT file (:325-326), or vt = vs = NULL and
+ * zv, zt, zs given: the kernel forms 0.5*(t(j)+t(j+1))*v itself (:312-322).
+ * zdim = 0: heat, salt (nbasins,npjglo) r8 = the zonal sums after the last level;
+ * zdim = 1: (nbasins,npjglo,npk) running totals after every level (-Zdim, :389-392).
+ * Raw sums: the caller divides by 1.d15 / 1.d6, forms inp / inp0 and substitutes 9999.99 (:395-443). */
+int cdft_mhst_compute(cdft_mhst_plan *plan, const float *vt, const float *vs, const float *zv,
+                      const float *zt, const float *zs, int in_space, int zdim, double *heat, double *salt,
+                      int out_space, void *stream);
+int cdft_mhst_destroy(cdft_mhst_plan *plan);
+
+/* ------------------------------------------------------------------------------------------ */
+/* cdfpsi : barotropic stream function                                                        */
+/*   replaces src/cdfpsi.f90:271-298 (vertical integration), :377-423 (scans, mean, reference  */
+/*   point) and the SNGL / mask at :426-433.  Not covered: -open, --ssh-file, -lev.            */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct cdft_psi_plan cdft_psi_plan;
+
+int cdft_psi_create(cdft_psi_plan **plan, int npiglo, int npjglo, int npk);
+/* One record.  U set (default path): zu (npiglo,npjglo,npk), e2u (npiglo,npjglo), e3u (3-D) r4;
+ * V set (-V): zv, e1v, e3v; both sets = -mean.  e31d (npk) replaces the 3-D e3 with -full.
+ * (iiref,ijref): 1-based reference point, default (npiglo,npjglo) (:203-206); fmask (npiglo,npjglo)
+ * r4 or NULL (-mask).  psi4 (npiglo,npjglo) r4 = what putvar writes; dpsi8 (optional, may be NULL)
+ * = the r8 field before SNGL. */
+int cdft_psi_compute(cdft_psi_plan *plan, const float *zu, const float *e2u, const float *e3u,
+                     const float *zv, const float *e1v, const float *e3v, const float *e31d, int iiref,
+                     int ijref, const float *fmask, int in_space, float *psi4, double *dpsi8, int out_space,
+                     void *stream);
+int cdft_psi_destroy(cdft_psi_plan *plan);
+
 #ifdef __cplusplus
 }
 #endif

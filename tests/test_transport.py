@@ -1,0 +1,153 @@
+"""cdfmhst (src/cdfmhst.f90:308-367) and cdfpsi (src/cdfpsi.f90:271-438).
+
+Stated tolerances:
+  cdfpsi  : the vertical sums and both scans are sequential in the reference's order -> the HIP result
+            must equal the oracle BIT FOR BIT (r8 field and the r4 output).
+  cdfmhst : vertical sums bit-exact; zonal sums in a fixed tree order instead of sequentially:
+            |d| <= 1e-13 * sum|terms| per output.
+"""
+import numpy as np
+import pytest
+
+import oracle_tools
+import synth
+
+
+def tracer_fields(g, seed):
+    rng = np.random.default_rng(seed)
+    npk, npj, npi = g["tmask"].shape
+    t = (-2 + 32 * rng.random((npk, npj, npi), dtype=np.float32)).astype(np.float32) * g["tmask"]
+    s = (30 + 8 * rng.random((npk, npj, npi), dtype=np.float32)).astype(np.float32) * g["tmask"]
+    v = synth.velocity(g, 1, seed + 1)[0]
+    u = synth.velocity(g, 1, seed + 2, which="u")[0]
+    return t.astype(np.float32), s.astype(np.float32), u, v
+
+
+def mhst_masks(g, nb):
+    m = np.zeros((nb,) + g["e1v"].shape, np.float32)
+    m[0] = g["vmask"][0]
+    if nb >= 4:
+        m[1], m[2], m[3] = g["tmaskatl"], g["tmaskpac"], g["tmaskind"]
+    return m
+
+
+# ----------------------------------------------------------------------------- CPU
+def test_oracle_psi_matches_numpy_restatement_bitwise():
+    g = synth.make_grid(19, 13, 5, seed=1)
+    _, _, u, v = tracer_fields(g, 3)
+    _, d8u = oracle_tools.psi(5, zu=u, e2u=g["e2u"], e3u=g["e3u_0"])
+    tr = np.cumsum(((u * g["e2u"][None]).astype(np.float32) * g["e3u_0"]).astype(np.float32).astype(np.float64), axis=0)[-1]
+    want = np.zeros_like(tr)
+    want[1:] = np.cumsum(-tr[1:], axis=0)
+    want = want - want[-1, -1]
+    assert np.array_equal(d8u, want)
+    _, d8v = oracle_tools.psi(5, zv=v, e1v=g["e1v"], e3v=g["e3v_0"])
+    trv = np.cumsum(((v * g["e1v"][None]).astype(np.float32) * g["e3v_0"]).astype(np.float32).astype(np.float64), axis=0)[-1]
+    wv = np.zeros_like(trv)
+    wv[:, :-1] = np.cumsum(-trv[:, -2::-1], axis=1)[:, ::-1]
+    assert np.array_equal(d8v, wv - wv[-1, -1])
+
+
+def test_oracle_mhst_sep_equals_vt_path_fed_with_its_own_products():
+    g = synth.make_grid(17, 11, 4, seed=2)
+    t, s, _, v = tracer_fields(g, 5)
+    vt = np.zeros_like(t)
+    vs = np.zeros_like(s)
+    vt[:, :-1] = (np.float32(0.5) * (t[:, :-1] + t[:, 1:])).astype(np.float32) * v[:, :-1]
+    vs[:, :-1] = (np.float32(0.5) * (s[:, :-1] + s[:, 1:])).astype(np.float32) * v[:, :-1]
+    m = mhst_masks(g, 4)
+    a = oracle_tools.mhst(g["e1v"], m, e3v=g["e3v_0"], vt=vt, vs=vs)
+    b = oracle_tools.mhst(g["e1v"], m, e3v=g["e3v_0"], zv=v, zt=t, zs=s)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    z = oracle_tools.mhst(g["e1v"], m, e3v=g["e3v_0"], vt=vt, vs=vs, zdim=True)
+    assert np.array_equal(z[0][-1], a[0]) and np.array_equal(z[1][-1], a[1])     # last level = total
+
+
+# ----------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("npi,npj,npk", [(24, 18, 7), (182, 149, 31), (1, 1, 1), (5, 3, 2), (130, 67, 4), (64, 64, 3)])
+def test_hip_psi_equals_oracle_bitwise(gpu, npi, npj, npk):
+    g = synth.make_grid(npi, npj, npk, seed=npi)
+    _, _, u, v = tracer_fields(g, 7)
+    plan = gpu.PsiPlan(npi, npj, npk)
+    cases = [
+        dict(zu=u, e2u=g["e2u"], e3u=g["e3u_0"]),                                         # default
+        dict(zv=v, e1v=g["e1v"], e3v=g["e3v_0"]),                                         # -V
+        dict(zu=u, e2u=g["e2u"], e3u=g["e3u_0"], zv=v, e1v=g["e1v"], e3v=g["e3v_0"]),     # -mean
+        dict(zu=u, e2u=g["e2u"], e31d=g["e3t_1d"]),                                       # -full
+        dict(zu=u, e2u=g["e2u"], e3u=g["e3u_0"], fmask=g["fmask"][0].astype(np.float32),
+             iiref=max(1, npi // 2), ijref=max(1, npj // 3)),                             # -mask -ref
+    ]
+    for kw in cases:
+        p4, d8 = plan.compute(**kw)
+        r4, r8 = oracle_tools.psi(npk, **kw)
+        assert np.array_equal(d8, r8), list(kw)
+        assert np.array_equal(p4, r4), list(kw)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("npi,npj,npk,nb", [(24, 18, 7, 4), (182, 149, 31, 4), (182, 149, 31, 1), (1, 2, 1, 1),
+                                            (7, 3, 2, 4), (1442, 9, 3, 4), (333, 5, 4, 8)])
+def test_hip_mhst_matches_oracle(gpu, npi, npj, npk, nb):
+    import torch
+
+    g = synth.make_grid(npi, npj, npk, seed=npi + 1)
+    t, s, _, v = tracer_fields(g, 9)
+    m = mhst_masks(g, nb)
+    vt = ((np.float32(0.5) * (t + np.roll(t, -1, axis=1))).astype(np.float32) * v).astype(np.float32)
+    vs = ((np.float32(0.5) * (s + np.roll(s, -1, axis=1))).astype(np.float32) * v).astype(np.float32)
+    plan = gpu.MhstPlan(npi, npj, npk, nb)
+    plan.set_mesh(g["e1v"], m, e3v=g["e3v_0"])
+
+    def check(got, ref, bound):
+        for k in (0, 1):
+            assert np.all(np.abs(got[k] - ref[k]) <= 1e-13 * bound[k] + 1e-300)
+
+    for zdim in (False, True):
+        ref = oracle_tools.mhst(g["e1v"], m, e3v=g["e3v_0"], vt=vt, vs=vs, zdim=zdim)
+        bound = oracle_tools.mhst(g["e1v"], m, e3v=g["e3v_0"], vt=np.abs(vt), vs=np.abs(vs), zdim=zdim)
+        check(plan.compute(vt=vt, vs=vs, zdim=zdim), ref, bound)
+    # separate V, T, S files; arrays resident in HBM
+    ref = oracle_tools.mhst(g["e1v"], m, e3v=g["e3v_0"], zv=v, zt=t, zs=s)
+    bound = oracle_tools.mhst(g["e1v"], m, e3v=g["e3v_0"], zv=np.abs(v), zt=np.abs(t), zs=np.abs(s))
+    dv, dt, ds = (torch.from_numpy(x).cuda() for x in (v, t, s))
+    check(plan.compute(zv=dv, zt=dt, zs=ds), ref, bound)
+    # -full
+    plan.set_mesh(g["e1v"], m, e31d=g["e3t_1d"])
+    ref = oracle_tools.mhst(g["e1v"], m, e31d=g["e3t_1d"], vt=vt, vs=vs)
+    bound = oracle_tools.mhst(g["e1v"], m, e31d=g["e3t_1d"], vt=np.abs(vt), vs=np.abs(vs))
+    check(plan.compute(vt=vt, vs=vs), ref, bound)
+
+
+@pytest.mark.gpu
+def test_hip_psi_and_mhst_at_eorca025_size(gpu):
+    """Full eORCA025 (1442x1207x75) resident in HBM: psi bit-exact on sampled columns/rows against
+    the oracle run on the sub-grids that determine them; mhst rows against the oracle."""
+    import torch
+
+    npi, npj, npk = 1442, 1207, 75
+    dev = "cuda"
+    gen = torch.Generator(device=dev).manual_seed(5)
+    e2u = 2000.0 + 26000.0 * torch.rand((npj, npi), device=dev, generator=gen)
+    e3u = torch.from_numpy(synth.e3_profile(npk)).to(dev)[:, None, None] * (0.2 + 0.8 * torch.rand((npk, npj, npi), device=dev, generator=gen))
+    u = torch.rand((npk, npj, npi), device=dev, generator=gen) - 0.5
+    plan = gpu.PsiPlan(npi, npj, npk)
+    p4, d8 = plan.compute(zu=u, e2u=e2u, e3u=e3u, iiref=1, ijref=1)   # dpsiu(:,1) = 0: no shift
+    # the U path scans along j column by column: a block of columns is an independent sub-problem
+    cols = slice(700, 732)
+    r4, r8 = oracle_tools.psi(npk, zu=u[:, :, cols].cpu().numpy(), e2u=e2u[:, cols].cpu().numpy(),
+                              e3u=e3u[:, :, cols].cpu().numpy(), iiref=1, ijref=1)
+    assert np.array_equal(d8[:, cols], r8) and np.array_equal(p4[:, cols], r4)
+    a4, a8 = plan.compute(zu=u, e2u=e2u, e3u=e3u, iiref=1, ijref=1)
+    assert np.array_equal(a8, d8) and np.array_equal(a4, p4)               # deterministic
+    # mhst on the same arrays (vt := u, vs := e3u as arbitrary fields)
+    m = (torch.rand((2, npj, npi), device=dev, generator=gen) > 0.4).float()
+    mp = gpu.MhstPlan(npi, npj, npk, 2)
+    mp.set_mesh(e2u, m, e3v=e3u)
+    heat, salt = mp.compute(vt=u, vs=e3u)
+    rows = slice(600, 606)
+    rh, rs = oracle_tools.mhst(e2u[rows].cpu().numpy(), m[:, rows].cpu().numpy(), e3v=e3u[:, rows].cpu().numpy(),
+                               vt=u[:, rows].cpu().numpy(), vs=e3u[:, rows].cpu().numpy())
+    bh, bs = oracle_tools.mhst(e2u[rows].cpu().numpy(), m[:, rows].cpu().numpy(), e3v=e3u[:, rows].cpu().numpy(),
+                               vt=np.abs(u[:, rows].cpu().numpy()), vs=e3u[:, rows].cpu().numpy())
+    assert np.all(np.abs(heat[rows] - rh) <= 1e-13 * bh) and np.all(np.abs(salt[rows] - rs) <= 1e-13 * bs)
