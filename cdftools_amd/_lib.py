@@ -67,6 +67,13 @@ SIGNATURES = {
     "cdft_psi_create": (_i, [_pvp, _i, _i, _i]),
     "cdft_psi_compute": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _vp]),
     "cdft_psi_destroy": (_i, [_vp]),
+    "cdft_vt_compute": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
+                             _i, _i, _vp]),
+    "cdft_stencil_release": (_i, []),
+    "cdft_curl_create": (_i, [_pvp, _i, _i]),
+    "cdft_curl_set_mesh": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "cdft_curl_compute": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _vp]),
+    "cdft_curl_destroy": (_i, [_vp]),
 }
 
 _lib = None

@@ -1,0 +1,419 @@
+// stencil.hip -- the two C-grid stencil tools: cdfvT and cdfcurl (C ABI sections "cdfvT", "cdfcurl").
+//
+//   cdfvT   src/cdfvT.f90:160-259   T,S interpolated to U/V points (2-point means along i / j),
+//                                   times u / v, accumulated over every time frame, per cell
+//   cdfcurl src/cdfcurl.f90:262-304 curl of (u,v) at F points from the 4 surrounding U/V points
+//
+// Both are pointwise after the stencil: every product is formed in r4 exactly as the reference
+// writes it and (cdfvT) accumulated over frames in the reference's order, so results are
+// BIT-IDENTICAL to the reference loop.
+//
+// Layout of the work: one workgroup = one 1024-cell tile of one (jj,jk) row; lanes own 4 consecutive
+// cells (one 16-byte load per field; rows are only 4-byte aligned in general, so the loads are
+// declared with 4-byte alignment).  The i+1 neighbour of a lane's last cell belongs to the next
+// lane: the first cell of every lane is staged through LDS (plus one halo cell per tile).  The j+1
+// row is a second coalesced load; the block -> tile map gives every XCD a contiguous band of rows so
+// that the row read as "j+1" is still in that XCD's L2 when it is read again as "j".
+#include "common.hpp"
+
+using namespace cdft;
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kTile    = kThreads * 4;
+
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+
+// nv valid cells (1..4) starting at p; cells beyond the row are returned as 0 and never touched
+__device__ __forceinline__ void load4(const float *p, int nv, float (&o)[4]) {
+    if (nv == 4) {
+        const f4u v = *reinterpret_cast<const f4u *>(p);
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+    } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o[c] = (c < nv) ? p[c] : 0.f;
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void store4(T *p, int nv, const double (&v)[4]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        if (c < nv) p[c] = (T)v[c];
+}
+
+// XCD-aware block -> work-item map: blocks b and b+8 share an XCD (round-robin dispatch), so XCD x
+// takes the contiguous band [x*per, (x+1)*per) and sweeps it in order.  Speed only, never correctness.
+__device__ __forceinline__ int64_t xcd_band_item(int64_t total) {
+    const int64_t b = blockIdx.x, per = (total + 7) / 8;
+    return (b & 7) * per + (b >> 3);
+}
+
+// ------------------------------------------------------------------------------------------ cdfvT
+struct VtArgs {
+    const float *u, *v, *t, *s, *e3u, *e3v;   // frame 0 of (npi,npj,npk) fields
+    int64_t fstride;                          // elements between frames
+    int nfr, npi, npj, npk, ntx;
+    void *vt, *vs, *ut, *us, *e3um, *e3vm;    // (npi,npj,npk) r8 or r4
+};
+
+template <bool VVL, typename OUT>
+__global__ void __launch_bounds__(kThreads) vt_kernel(VtArgs a) {
+    __shared__ float lt[2][kThreads + 1], ls[2][kThreads + 1];
+    const int64_t nrows = (int64_t)a.npj * a.npk, total = nrows * a.ntx;
+    const int64_t q = xcd_band_item(total);
+    if (q >= total) return;                                      // whole block: no barrier is skipped
+    const int64_t L = q / a.ntx;
+    const int tx = (int)(q - L * a.ntx), tid = threadIdx.x;
+    const int jj = (int)(L % a.npj);
+    const int i0 = tx * kTile + tid * 4;
+    const int nv = min(4, a.npi - i0);                            // <= 0: lane past the row end
+    const bool north = jj < a.npj - 1;
+    const int64_t cell = L * a.npi + i0;
+    const int ih = tx * kTile + kTile;                            // halo column of this tile
+
+    double aut[4] = {0, 0, 0, 0}, avt[4] = {0, 0, 0, 0}, aus[4] = {0, 0, 0, 0}, avs[4] = {0, 0, 0, 0};
+    double ce3u[4] = {0, 0, 0, 0}, ce3v[4] = {0, 0, 0, 0};
+    for (int f = 0; f < a.nfr; ++f) {
+        const int64_t e = (int64_t)f * a.fstride + cell;
+        float t[4] = {0, 0, 0, 0}, s[4] = {0, 0, 0, 0}, tn[4] = {0, 0, 0, 0}, sn[4] = {0, 0, 0, 0};
+        float u[4] = {0, 0, 0, 0}, v[4] = {0, 0, 0, 0}, e3u[4] = {0, 0, 0, 0}, e3v[4] = {0, 0, 0, 0};
+        if (nv > 0) {
+            load4(a.t + e, nv, t); load4(a.s + e, nv, s); load4(a.u + e, nv, u); load4(a.v + e, nv, v);
+            if (north) { load4(a.t + e + a.npi, nv, tn); load4(a.s + e + a.npi, nv, sn); }
+            if (VVL) { load4(a.e3u + e, nv, e3u); load4(a.e3v + e, nv, e3v); }
+        }
+        const int buf = f & 1;                                    // double-buffered: one barrier per frame
+        lt[buf][tid] = t[0]; ls[buf][tid] = s[0];
+        if (tid == 0) {
+            const bool has = ih < a.npi;
+            const int64_t eh = (int64_t)f * a.fstride + L * a.npi + ih;
+            lt[buf][kThreads] = has ? a.t[eh] : 0.f;
+            ls[buf][kThreads] = has ? a.s[eh] : 0.f;
+        }
+        __syncthreads();
+        const float tnx = lt[buf][tid + 1], snx = ls[buf][tid + 1];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            // zworku / zworkv are set for ji < npiglo, jj < npjglo only, 0 elsewhere (src/cdfvT.f90:201-206)
+            const bool inner = north && (i0 + c < a.npi - 1);
+            const float te = (c < 3) ? t[c < 3 ? c + 1 : 3] : tnx, se = (c < 3) ? s[c < 3 ? c + 1 : 3] : snx;
+            const float wtu = inner ? __fmul_rn(0.5f, __fadd_rn(t[c], te)) : 0.f;
+            const float wtv = inner ? __fmul_rn(0.5f, __fadd_rn(t[c], tn[c])) : 0.f;
+            const float wsu = inner ? __fmul_rn(0.5f, __fadd_rn(s[c], se)) : 0.f;
+            const float wsv = inner ? __fmul_rn(0.5f, __fadd_rn(s[c], sn[c])) : 0.f;
+            if (VVL) {                                            // :208-211, :228-229
+                aut[c] = __dadd_rn(aut[c], (double)__fmul_rn(__fmul_rn(wtu, e3u[c]), u[c]));
+                avt[c] = __dadd_rn(avt[c], (double)__fmul_rn(__fmul_rn(wtv, e3v[c]), v[c]));
+                aus[c] = __dadd_rn(aus[c], (double)__fmul_rn(__fmul_rn(wsu, e3u[c]), u[c]));
+                avs[c] = __dadd_rn(avs[c], (double)__fmul_rn(__fmul_rn(wsv, e3v[c]), v[c]));
+                ce3u[c] = __dadd_rn(ce3u[c], (double)e3u[c]);
+                ce3v[c] = __dadd_rn(ce3v[c], (double)e3v[c]);
+            } else {                                              // :214-215, :231-232
+                aut[c] = __dadd_rn(aut[c], (double)__fmul_rn(wtu, u[c]));
+                avt[c] = __dadd_rn(avt[c], (double)__fmul_rn(wtv, v[c]));
+                aus[c] = __dadd_rn(aus[c], (double)__fmul_rn(wsu, u[c]));
+                avs[c] = __dadd_rn(avs[c], (double)__fmul_rn(wsv, v[c]));
+            }
+        }
+    }
+    if (nv <= 0) return;
+    const double dn = (double)a.nfr;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (VVL) {                                                // :240-245
+            avt[c] = __ddiv_rn(avt[c], ce3v[c]); avs[c] = __ddiv_rn(avs[c], ce3v[c]);
+            aut[c] = __ddiv_rn(aut[c], ce3u[c]); aus[c] = __ddiv_rn(aus[c], ce3u[c]);
+            ce3u[c] = __ddiv_rn(ce3u[c], dn); ce3v[c] = __ddiv_rn(ce3v[c], dn);
+        } else {                                                  // :247-250
+            avt[c] = __ddiv_rn(avt[c], dn); avs[c] = __ddiv_rn(avs[c], dn);
+            aut[c] = __ddiv_rn(aut[c], dn); aus[c] = __ddiv_rn(aus[c], dn);
+        }
+    }
+    store4((OUT *)a.vt + cell, nv, avt); store4((OUT *)a.vs + cell, nv, avs);
+    store4((OUT *)a.ut + cell, nv, aut); store4((OUT *)a.us + cell, nv, aus);
+    if (VVL) { store4((OUT *)a.e3um + cell, nv, ce3u); store4((OUT *)a.e3vm + cell, nv, ce3v); }
+}
+
+// ------------------------------------------------------------------------------------------ cdfcurl
+struct CurlArgs {
+    const float *un, *vn;                     // (npi,npj,nlev)
+    const float *e1u, *e2v, *e1f, *e2f;       // (npi,npj)
+    const double *ff;                         // (npi,npj) or null
+    int npi, npj, nlev, ntx, lperio;
+    void *out;                                // (npi,npj,nlev) r8 or r4
+    double *work;                             // F-point curl for the T-point pass
+};
+
+// one F point from scalar loads (periodic column, T-point pass); un/vn point at the level
+__device__ __forceinline__ float curl_at(const CurlArgs &a, const float *un, const float *vn, int i, int j,
+                                         float *fmask) {
+    const int64_t p = (int64_t)j * a.npi + i, pe = p + 1, pn = p + a.npi;
+    float f = __fmul_rn(__fmul_rn(__fmul_rn(un[p], un[pn]), vn[p]), vn[pe]);      // src/cdfcurl.f90:270
+    f = (f != 0.f) ? 1.f : 0.f;
+    if (fmask) *fmask = f;
+    const float num = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(a.e2v[pe], vn[pe]), -__fmul_rn(a.e2v[p], vn[p])),
+                                          -__fmul_rn(a.e1u[pn], un[pn])), __fmul_rn(a.e1u[p], un[p]));
+    return __fdiv_rn(__fmul_rn(num, f), __fmul_rn(a.e1f[p], a.e2f[p]));           // :276-282
+}
+
+template <typename OUT, bool KEEP>
+__global__ void __launch_bounds__(kThreads) curl_kernel(CurlArgs a) {
+    __shared__ float lv[kThreads + 1], le[kThreads + 1];
+    const int64_t nrows = (int64_t)a.npj * a.nlev, total = nrows * a.ntx;
+    const int64_t q = xcd_band_item(total);
+    if (q >= total) return;
+    const int64_t L = q / a.ntx;
+    const int tx = (int)(q - L * a.ntx), tid = threadIdx.x;
+    const int lev = (int)(L / a.npj), jj = (int)(L - (int64_t)lev * a.npj);
+    const int i0 = tx * kTile + tid * 4, nv = min(4, a.npi - i0);
+    const bool north = jj < a.npj - 1;
+    const int64_t nij = (int64_t)a.npi * a.npj, p2 = (int64_t)jj * a.npi + i0;
+    const float *un = a.un + (int64_t)lev * nij, *vn = a.vn + (int64_t)lev * nij;
+    float u[4] = {0, 0, 0, 0}, un1[4] = {0, 0, 0, 0}, v[4] = {0, 0, 0, 0};
+    float e1u[4] = {0, 0, 0, 0}, e1un[4] = {0, 0, 0, 0}, e2v[4] = {0, 0, 0, 0}, e1f[4] = {1, 1, 1, 1}, e2f[4] = {1, 1, 1, 1};
+    if (nv > 0) {
+        load4(un + p2, nv, u); load4(vn + p2, nv, v); load4(a.e1u + p2, nv, e1u); load4(a.e2v + p2, nv, e2v);
+        load4(a.e1f + p2, nv, e1f); load4(a.e2f + p2, nv, e2f);
+        if (north) { load4(un + p2 + a.npi, nv, un1); load4(a.e1u + p2 + a.npi, nv, e1un); }
+    }
+    lv[tid] = v[0]; le[tid] = e2v[0];
+    if (tid == 0) {
+        const int ih = tx * kTile + kTile;
+        const bool has = ih < a.npi;
+        lv[kThreads] = has ? vn[(int64_t)jj * a.npi + ih] : 0.f;
+        le[kThreads] = has ? a.e2v[(int64_t)jj * a.npi + ih] : 0.f;
+    }
+    __syncthreads();
+    if (nv <= 0) return;
+    const float vnx = lv[tid + 1], enx = le[tid + 1];
+    double r[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int i = i0 + c;
+        float val = 0.f;                                              // drotn(:,:) = 0.d0, :275
+        if (c < nv && north) {
+            if (i < a.npi - 1) {
+                const float ve = (c < 3) ? v[c < 3 ? c + 1 : 3] : vnx, ee = (c < 3) ? e2v[c < 3 ? c + 1 : 3] : enx;
+                float f = __fmul_rn(__fmul_rn(__fmul_rn(u[c], un1[c]), v[c]), ve);
+                f = (f != 0.f) ? 1.f : 0.f;
+                const float num = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(ee, ve), -__fmul_rn(e2v[c], v[c])),
+                                                      -__fmul_rn(e1un[c], un1[c])), __fmul_rn(e1u[c], u[c]));
+                val = __fdiv_rn(__fmul_rn(num, f), __fmul_rn(e1f[c], e2f[c]));
+            } else if (a.lperio && a.npi > 2) {
+                val = curl_at(a, un, vn, 1, jj, nullptr);             // drotn(npiglo,:) = drotn(2,:), :285
+            }
+        }
+        r[c] = (double)val;
+        if (KEEP && c < nv) a.work[(int64_t)lev * nij + p2 + c] = r[c];
+        if (!KEEP && a.ff && c < nv) {                                // -overf, :299-301
+            const double f = a.ff[p2 + c];
+            if (f != 0.0) r[c] = __ddiv_rn(r[c], f);
+        }
+    }
+    if (!KEEP) store4((OUT *)a.out + (int64_t)lev * nij + p2, nv, r);
+}
+
+// -T: 4-point mean of the F-point curl to T points with the product of the 4 fmask (:286-297).
+// fmask(npiglo,:) and fmask(:,npjglo) are never assigned by the reference; taken as 0.
+template <typename OUT>
+__global__ void curl_tpoint_kernel(CurlArgs a) {
+    const int64_t nij = (int64_t)a.npi * a.npj;
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= nij * a.nlev) return;
+    const int lev = (int)(g / nij);
+    const int64_t p = g - (int64_t)lev * nij;
+    const int j = (int)(p / a.npi), i = (int)(p - (int64_t)j * a.npi);
+    const float *un = a.un + (int64_t)lev * nij, *vn = a.vn + (int64_t)lev * nij;
+    const double *w = a.work + (int64_t)lev * nij;
+    auto fm = [&](int ii, int jj) -> float {
+        if (ii >= a.npi - 1 || jj >= a.npj - 1) return 0.f;
+        float f;
+        (void)curl_at(a, un, vn, ii, jj, &f);
+        return f;
+    };
+    auto tval = [&](int ii, int jj) -> double {                  // dl_rotn(ii,jj), ii >= 1, jj >= 1
+        const float zm = __fmul_rn(__fmul_rn(__fmul_rn(fm(ii, jj), fm(ii, jj - 1)), fm(ii - 1, jj)), fm(ii - 1, jj - 1));
+        const double s4 = __dadd_rn(__dadd_rn(__dadd_rn(w[(int64_t)jj * a.npi + ii], w[(int64_t)(jj - 1) * a.npi + ii]),
+                                              w[(int64_t)jj * a.npi + ii - 1]), w[(int64_t)(jj - 1) * a.npi + ii - 1]);
+        return __dmul_rn(__dmul_rn(0.25, s4), (double)zm);
+    };
+    double r = 0.0;
+    if (i >= 1 && j >= 1) r = tval(i, j);
+    else if (i == 0 && a.lperio && j >= 1 && a.npi > 1) r = tval(a.npi - 1, j);   // dl_rotn(1,:) = dl_rotn(npiglo,:)
+    if (a.ff) {
+        const double f = a.ff[p];
+        if (f != 0.0) r = __ddiv_rn(r, f);
+    }
+    ((OUT *)a.out)[g] = (OUT)r;
+}
+
+DevBuf g_in[6], g_out[6];
+
+}  // namespace
+
+extern "C" {
+
+int cdft_vt_compute(const float *u, const float *v, const float *t, const float *s, const float *e3u,
+                    const float *e3v, int64_t fstride, int nframes, int npiglo, int npjglo, int npk, int in_space,
+                    void *vt, void *vs, void *ut, void *us, void *e3um, void *e3vm, int out_is_r4, int out_space,
+                    void *stream) {
+    if (!u || !v || !t || !s || !vt || !vs || !ut || !us)
+        return fail(CDFT_ERR_ARG, "cdft_vt_compute: NULL argument");
+    const bool vvl = e3u != nullptr;
+    if (vvl && (!e3v || !e3um || !e3vm)) return fail(CDFT_ERR_ARG, "cdft_vt_compute: -vvl needs e3u, e3v, e3um, e3vm");
+    const int64_t n3 = (int64_t)npiglo * npjglo * npk;
+    if (npiglo < 1 || npjglo < 1 || npk < 1 || nframes < 1 || fstride < n3)
+        return fail(CDFT_ERR_ARG, "cdft_vt_compute: bad sizes (%d,%d,%d) x %d frames, stride %lld", npiglo, npjglo, npk,
+                    nframes, (long long)fstride);
+    CDFT_TRY(require_device());
+    hipStream_t st = as_stream(stream);
+    const size_t inb = ((size_t)(nframes - 1) * fstride + n3) * 4, esz = out_is_r4 ? 4 : 8;
+    const float *src[6] = {u, v, t, s, e3u, e3v};
+    const void *din[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    for (int q = 0; q < (vvl ? 6 : 4); ++q) CDFT_TRY(to_device(src[q], inb, in_space, g_in[q], st, &din[q]));
+    void *hout[6] = {vt, vs, ut, us, e3um, e3vm}, *dout[6];
+    for (int q = 0; q < 6; ++q) {
+        dout[q] = hout[q];
+        if (out_space == CDFT_MEM_HOST && q < (vvl ? 6 : 4)) {
+            CDFT_TRY(g_out[q].reserve(n3 * esz));
+            dout[q] = g_out[q].ptr;
+        }
+    }
+    VtArgs a;
+    a.u = (const float *)din[0]; a.v = (const float *)din[1]; a.t = (const float *)din[2]; a.s = (const float *)din[3];
+    a.e3u = (const float *)din[4]; a.e3v = (const float *)din[5]; a.fstride = fstride; a.nfr = nframes;
+    a.npi = npiglo; a.npj = npjglo; a.npk = npk; a.ntx = (npiglo + kTile - 1) / kTile;
+    a.vt = dout[0]; a.vs = dout[1]; a.ut = dout[2]; a.us = dout[3]; a.e3um = dout[4]; a.e3vm = dout[5];
+    const int64_t total = (int64_t)npjglo * npk * a.ntx;
+    const dim3 grid((unsigned)(((total + 7) / 8) * 8)), block(kThreads);
+    if (vvl) {
+        if (out_is_r4) hipLaunchKernelGGL((vt_kernel<true, float>), grid, block, 0, st, a);
+        else           hipLaunchKernelGGL((vt_kernel<true, double>), grid, block, 0, st, a);
+    } else {
+        if (out_is_r4) hipLaunchKernelGGL((vt_kernel<false, float>), grid, block, 0, st, a);
+        else           hipLaunchKernelGGL((vt_kernel<false, double>), grid, block, 0, st, a);
+    }
+    CDFT_LAUNCH_CHECK();
+    if (out_space == CDFT_MEM_HOST) {
+        for (int q = 0; q < (vvl ? 6 : 4); ++q)
+            CDFT_HIP(hipMemcpyAsync(hout[q], dout[q], n3 * esz, hipMemcpyDeviceToHost, st));
+        CDFT_HIP(hipStreamSynchronize(st));
+    }
+    return CDFT_OK;
+}
+
+int cdft_stencil_release(void) {
+    for (DevBuf &b : g_in) b.release();
+    for (DevBuf &b : g_out) b.release();
+    return CDFT_OK;
+}
+
+}  // extern "C"
+
+struct cdft_curl_plan {
+    int npi = 0, npj = 0, lperio = 0;
+    float *e1u = nullptr, *e2v = nullptr, *e1f = nullptr, *e2f = nullptr;
+    double *ff = nullptr;
+    bool mesh_set = false;
+    DevBuf su, sv, sout, work;
+};
+
+extern "C" {
+
+int cdft_curl_create(cdft_curl_plan **plan, int npiglo, int npjglo) {
+    if (!plan) return fail(CDFT_ERR_ARG, "cdft_curl_create: NULL plan pointer");
+    *plan = nullptr;
+    if (npiglo < 1 || npjglo < 1) return fail(CDFT_ERR_ARG, "cdft_curl_create: bad sizes %d x %d", npiglo, npjglo);
+    CDFT_TRY(require_device());
+    cdft_curl_plan *p = new cdft_curl_plan;
+    p->npi = npiglo; p->npj = npjglo;
+    *plan = p;
+    return CDFT_OK;
+}
+
+int cdft_curl_set_mesh(cdft_curl_plan *p, const float *e1u, const float *e2v, const float *e1f, const float *e2f,
+                       const double *ff, int lperio, int memspace, void *stream) {
+    if (!p || !e1u || !e2v || !e1f || !e2f) return fail(CDFT_ERR_ARG, "cdft_curl_set_mesh: NULL argument");
+    hipStream_t st = as_stream(stream);
+    const size_t nij = (size_t)p->npi * p->npj;
+    const hipMemcpyKind kind = memspace == CDFT_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    float **dst[4] = {&p->e1u, &p->e2v, &p->e1f, &p->e2f};
+    const float *src[4] = {e1u, e2v, e1f, e2f};
+    for (int q = 0; q < 4; ++q) {
+        if (!*dst[q] && hipMalloc((void **)dst[q], nij * 4 + 64) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(CDFT_ERR_ALLOC, "cdft_curl_set_mesh: device allocation failed");
+        }
+        CDFT_HIP(hipMemcpyAsync(*dst[q], src[q], nij * 4, kind, st));
+    }
+    if (ff) {
+        if (!p->ff && hipMalloc((void **)&p->ff, nij * 8 + 64) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(CDFT_ERR_ALLOC, "cdft_curl_set_mesh: device allocation failed");
+        }
+        CDFT_HIP(hipMemcpyAsync(p->ff, ff, nij * 8, kind, st));
+    } else if (p->ff) {
+        (void)hipFree(p->ff);
+        p->ff = nullptr;
+    }
+    CDFT_HIP(hipStreamSynchronize(st));
+    p->lperio = lperio ? 1 : 0;
+    p->mesh_set = true;
+    return CDFT_OK;
+}
+
+int cdft_curl_compute(cdft_curl_plan *p, const float *un, const float *vn, int nlev, int in_space, int ltpoint,
+                      void *out, int out_is_r8, int out_space, void *stream) {
+    if (!p || !un || !vn || !out) return fail(CDFT_ERR_ARG, "cdft_curl_compute: NULL argument");
+    if (!p->mesh_set) return fail(CDFT_ERR_STATE, "cdft_curl_compute: cdft_curl_set_mesh has not succeeded");
+    if (nlev < 1) return fail(CDFT_ERR_ARG, "cdft_curl_compute: nlev = %d", nlev);
+    hipStream_t st = as_stream(stream);
+    const int64_t nij = (int64_t)p->npi * p->npj, n3 = nij * nlev;
+    const size_t esz = out_is_r8 ? 8 : 4;
+    const void *du, *dv;
+    CDFT_TRY(to_device(un, n3 * 4, in_space, p->su, st, &du));
+    CDFT_TRY(to_device(vn, n3 * 4, in_space, p->sv, st, &dv));
+    void *dout = out;
+    if (out_space == CDFT_MEM_HOST) {
+        CDFT_TRY(p->sout.reserve(n3 * esz));
+        dout = p->sout.ptr;
+    }
+    CurlArgs a;
+    a.un = (const float *)du; a.vn = (const float *)dv; a.e1u = p->e1u; a.e2v = p->e2v; a.e1f = p->e1f; a.e2f = p->e2f;
+    a.ff = p->ff; a.npi = p->npi; a.npj = p->npj; a.nlev = nlev; a.ntx = (p->npi + kTile - 1) / kTile;
+    a.lperio = p->lperio; a.out = dout; a.work = nullptr;
+    const int64_t total = (int64_t)p->npj * nlev * a.ntx;
+    const dim3 grid((unsigned)(((total + 7) / 8) * 8)), block(kThreads);
+    if (ltpoint) {
+        CDFT_TRY(p->work.reserve(n3 * 8));
+        a.work = (double *)p->work.ptr;
+        hipLaunchKernelGGL((curl_kernel<double, true>), grid, block, 0, st, a);
+        CDFT_LAUNCH_CHECK();
+        const dim3 g2((unsigned)((n3 + 255) / 256));
+        if (out_is_r8) hipLaunchKernelGGL((curl_tpoint_kernel<double>), g2, dim3(256), 0, st, a);
+        else           hipLaunchKernelGGL((curl_tpoint_kernel<float>), g2, dim3(256), 0, st, a);
+    } else {
+        if (out_is_r8) hipLaunchKernelGGL((curl_kernel<double, false>), grid, block, 0, st, a);
+        else           hipLaunchKernelGGL((curl_kernel<float, false>), grid, block, 0, st, a);
+    }
+    CDFT_LAUNCH_CHECK();
+    if (out_space == CDFT_MEM_HOST) {
+        CDFT_HIP(hipMemcpyAsync(out, dout, n3 * esz, hipMemcpyDeviceToHost, st));
+        CDFT_HIP(hipStreamSynchronize(st));
+    }
+    return CDFT_OK;
+}
+
+int cdft_curl_destroy(cdft_curl_plan *p) {
+    if (!p) return CDFT_OK;
+    void *ptrs[] = {p->e1u, p->e2v, p->e1f, p->e2f, p->ff};
+    for (void *q : ptrs) if (q) (void)hipFree(q);
+    p->su.release(); p->sv.release(); p->sout.release(); p->work.release();
+    delete p;
+    return CDFT_OK;
+}
+
+}  // extern "C"

@@ -340,4 +340,63 @@ class PsiPlan(_Plan):
         return p4, d8
 
 
-__all__ = ["MocPlan", "HeatcPlan", "MhstPlan", "PsiPlan", "sigmai", "sigma0", "sig_tool", "EOS_80", "EOS_TEOS10", "EOS_JMD94", "EOS_FAST_FMA", "Timer", "CdftError", "device_count", "current_stream_ptr", "MEM_HOST", "MEM_DEVICE"]
+def vt_compute(u, v, t, s, e3u=None, e3v=None, out_r4=False, stream=None):
+    """cdfvT (src/cdfvT.f90:160-259).  u, v, t, s: (nframes,npk,npj,npi) r4 (NumPy: host; torch CUDA:
+    resident).  -> dict of (npk,npj,npi) arrays vt, vs, ut, us (+ e3u, e3v with -vvl), r8 or r4,
+    in the memory space of the inputs."""
+    names = ("u", "v", "t", "s", "e3u", "e3v")
+    a = [_opt(x, n) for x, n in zip((u, v, t, s, e3u, e3v), names)]
+    sp = _same_space(*[x[1] for x in a])
+    nfr, npk, npj, npi = a[0][2].shape
+    vvl = e3u is not None
+    keys = ("vt", "vs", "ut", "us") + (("e3u", "e3v") if vvl else ())
+    if sp == MEM_DEVICE:
+        o = {k: torch.empty((npk, npj, npi), dtype=torch.float32 if out_r4 else torch.float64, device=u.device)
+             for k in keys}
+        ptr = {k: C.c_void_p(x.data_ptr()) for k, x in o.items()}
+    else:
+        o = {k: np.empty((npk, npj, npi), np.float32 if out_r4 else np.float64) for k in keys}
+        ptr = {k: C.c_void_p(x.ctypes.data) for k, x in o.items()}
+    check(_lib.load().cdft_vt_compute(a[0][0], a[1][0], a[2][0], a[3][0], a[4][0], a[5][0], npk * npj * npi, nfr,
+                                      npi, npj, npk, sp, ptr["vt"], ptr["vs"], ptr["ut"], ptr["us"],
+                                      ptr.get("e3u", _null()), ptr.get("e3v", _null()), 1 if out_r4 else 0, sp,
+                                      stream or current_stream_ptr()))
+    return o
+
+
+class CurlPlan(_Plan):
+    """cdfcurl (src/cdfcurl.f90:262-301): cdft_curl_* of the C ABI."""
+
+    _destroy = "cdft_curl_destroy"
+
+    def __init__(self, npiglo, npjglo):
+        self.npi, self.npj = npiglo, npjglo
+        self._h = C.c_void_p()
+        check(_lib.load().cdft_curl_create(C.byref(self._h), npiglo, npjglo))
+
+    def set_mesh(self, e1u, e2v, e1f, e2f, ff=None, lperio=False, stream=None):
+        a = [_arg(x, np.float32, n) for x, n in zip((e1u, e2v, e1f, e2f), ("e1u", "e2v", "e1f", "e2f"))]
+        pf, sf, kf = _arg(ff, np.float64, "ff") if ff is not None else (_null(), None, None)
+        sp = _same_space(*[x[1] for x in a], sf)
+        check(_lib.load().cdft_curl_set_mesh(self._h, a[0][0], a[1][0], a[2][0], a[3][0], pf, 1 if lperio else 0, sp,
+                                             stream or current_stream_ptr()))
+
+    def compute(self, un, vn, ltpoint=False, out_r8=True, stream=None):
+        """un, vn (nlev,npj,npi) r4 -> curl (nlev,npj,npi) r8 or r4 in the inputs' memory space."""
+        pu, su, ku = _arg(un, np.float32, "un")
+        pv, sv, kv = _arg(vn, np.float32, "vn")
+        sp = _same_space(su, sv)
+        nlev = int(np.prod(ku.shape)) // (self.npi * self.npj)
+        shape = (nlev, self.npj, self.npi)
+        if sp == MEM_DEVICE:
+            out = torch.empty(shape, dtype=torch.float64 if out_r8 else torch.float32, device=un.device)
+            po = C.c_void_p(out.data_ptr())
+        else:
+            out = np.empty(shape, np.float64 if out_r8 else np.float32)
+            po = C.c_void_p(out.ctypes.data)
+        check(_lib.load().cdft_curl_compute(self._h, pu, pv, nlev, sp, 1 if ltpoint else 0, po, 1 if out_r8 else 0,
+                                            sp, stream or current_stream_ptr()))
+        return out
+
+
+__all__ = ["MocPlan", "HeatcPlan", "MhstPlan", "PsiPlan", "CurlPlan", "vt_compute", "sigmai", "sigma0", "sig_tool", "EOS_80", "EOS_TEOS10", "EOS_JMD94", "EOS_FAST_FMA", "Timer", "CdftError", "device_count", "current_stream_ptr", "MEM_HOST", "MEM_DEVICE"]

@@ -196,6 +196,42 @@ int cdft_psi_compute(cdft_psi_plan *plan, const float *zu, const float *e2u, con
                      void *stream);
 int cdft_psi_destroy(cdft_psi_plan *plan);
 
+/* ------------------------------------------------------------------------------------------ */
+/* cdfvT : time-mean of u.T, v.T, u.S, v.S at U / V points                                    */
+/*   replaces src/cdfvT.f90:160-259 (all levels at once instead of the reference's level loop; */
+/*   per cell the accumulation over frames keeps the reference's order)                       */
+/* ------------------------------------------------------------------------------------------ */
+/* u, v, t, s: nframes frames of (npiglo,npjglo,npk) r4, frame f at ptr + f*fstride elements (all
+ * tags concatenated, :168-191).  e3u, e3v: same shape with -vvl, else NULL (:193-196).
+ * Outputs (npiglo,npjglo,npk), r8 (out_is_r4 = 0: the array handed to putvar, :247-250) or r4
+ * (out_is_r4 = 1: what NetCDF stores in the float variable): vt, vs, ut, us, and with -vvl the
+ * mean e3u, e3v (e3um, e3vm; NULL otherwise).  Call with npk = 1 to work level by level. */
+int cdft_vt_compute(const float *u, const float *v, const float *t, const float *s, const float *e3u,
+                    const float *e3v, int64_t fstride, int nframes, int npiglo, int npjglo, int npk,
+                    int in_space, void *vt, void *vs, void *ut, void *us, void *e3um, void *e3vm,
+                    int out_is_r4, int out_space, void *stream);
+int cdft_stencil_release(void);   /* frees the staging buffers cdft_vt_compute uses for host arrays */
+
+/* ------------------------------------------------------------------------------------------ */
+/* cdfcurl : relative vorticity at F points                                                   */
+/*   replaces src/cdfcurl.f90:262-301 (fmask, curl, E-W wrap, -T, -overf).  Not covered: the   */
+/*   A-grid averaging of forcing fields (:250-258).                                            */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct cdft_curl_plan cdft_curl_plan;
+
+int cdft_curl_create(cdft_curl_plan **plan, int npiglo, int npjglo);
+/* e1u, e2v, e1f, e2f (npiglo,npjglo) r4 (:200-203; pass arrays of 1. for -nometric);
+ * ff (npiglo,npjglo) r8 = 2*omega*sin(gphif*pi/180) for -overf (:225-227) or NULL;
+ * lperio: glamf(1,1) == glamf(npiglo-1,1) (:238). */
+int cdft_curl_set_mesh(cdft_curl_plan *plan, const float *e1u, const float *e2v, const float *e1f,
+                       const float *e2f, const double *ff, int lperio, int memspace, void *stream);
+/* un, vn (npiglo,npjglo,nlev) r4: the selected levels of one record (:247-248).
+ * out (npiglo,npjglo,nlev): r8 (drotn as handed to putvar, -8) or r4 (float variable).
+ * ltpoint: -T, 4-point mean to T points (:286-297). */
+int cdft_curl_compute(cdft_curl_plan *plan, const float *un, const float *vn, int nlev, int in_space,
+                      int ltpoint, void *out, int out_is_r8, int out_space, void *stream);
+int cdft_curl_destroy(cdft_curl_plan *plan);
+
 #ifdef __cplusplus
 }
 #endif

@@ -237,7 +237,7 @@ void oracle_curl(int npi, int npj, const float *un, const float *vn, const float
                             f / (e1f[IJ(i, j)] * e2f[IJ(i, j)]);
             rotn[IJ(i, j)] = (double)r;
         }
-    if (lperio)
+    if (lperio && npi > 2)   /* column 2 exists and is not the wrap column itself */
         for (int j = 0; j < npj; ++j) rotn[IJ(npi - 1, j)] = rotn[IJ(1, j)];
     if (ltpoint) {
         double *dl = (double *)calloc(nij, 8);
