@@ -159,61 +159,70 @@ __device__ __forceinline__ float curl_at(const CurlArgs &a, const float *un, con
     return __fdiv_rn(__fmul_rn(num, f), __fmul_rn(a.e1f[p], a.e2f[p]));           // :276-282
 }
 
+// One workgroup = one 1024-cell tile of row jj for ALL levels: the six metric vectors are loaded once
+// into registers and every level streams past them (12 algorithmic bytes per cell-level).
 template <typename OUT, bool KEEP>
 __global__ void __launch_bounds__(kThreads) curl_kernel(CurlArgs a) {
-    __shared__ float lv[kThreads + 1], le[kThreads + 1];
-    const int64_t nrows = (int64_t)a.npj * a.nlev, total = nrows * a.ntx;
+    __shared__ float lv[2][kThreads + 1], le[kThreads + 1];
+    const int64_t total = (int64_t)a.npj * a.ntx;
     const int64_t q = xcd_band_item(total);
-    if (q >= total) return;
-    const int64_t L = q / a.ntx;
-    const int tx = (int)(q - L * a.ntx), tid = threadIdx.x;
-    const int lev = (int)(L / a.npj), jj = (int)(L - (int64_t)lev * a.npj);
+    if (q >= total) return;                                       // whole block
+    const int jj = (int)(q / a.ntx), tx = (int)(q - (int64_t)jj * a.ntx), tid = threadIdx.x;
     const int i0 = tx * kTile + tid * 4, nv = min(4, a.npi - i0);
-    const bool north = jj < a.npj - 1;
+    const int ih = tx * kTile + kTile;                            // halo column of the tile
+    const bool north = jj < a.npj - 1, has_halo = ih < a.npi;
     const int64_t nij = (int64_t)a.npi * a.npj, p2 = (int64_t)jj * a.npi + i0;
-    const float *un = a.un + (int64_t)lev * nij, *vn = a.vn + (int64_t)lev * nij;
-    float u[4] = {0, 0, 0, 0}, un1[4] = {0, 0, 0, 0}, v[4] = {0, 0, 0, 0};
     float e1u[4] = {0, 0, 0, 0}, e1un[4] = {0, 0, 0, 0}, e2v[4] = {0, 0, 0, 0}, e1f[4] = {1, 1, 1, 1}, e2f[4] = {1, 1, 1, 1};
+    double ffv[4] = {0, 0, 0, 0};
     if (nv > 0) {
-        load4(un + p2, nv, u); load4(vn + p2, nv, v); load4(a.e1u + p2, nv, e1u); load4(a.e2v + p2, nv, e2v);
-        load4(a.e1f + p2, nv, e1f); load4(a.e2f + p2, nv, e2f);
-        if (north) { load4(un + p2 + a.npi, nv, un1); load4(a.e1u + p2 + a.npi, nv, e1un); }
+        load4(a.e1u + p2, nv, e1u); load4(a.e2v + p2, nv, e2v); load4(a.e1f + p2, nv, e1f); load4(a.e2f + p2, nv, e2f);
+        if (north) load4(a.e1u + p2 + a.npi, nv, e1un);
+        if (!KEEP && a.ff)
+            for (int c = 0; c < nv; ++c) ffv[c] = a.ff[p2 + c];
     }
-    lv[tid] = v[0]; le[tid] = e2v[0];
-    if (tid == 0) {
-        const int ih = tx * kTile + kTile;
-        const bool has = ih < a.npi;
-        lv[kThreads] = has ? vn[(int64_t)jj * a.npi + ih] : 0.f;
-        le[kThreads] = has ? a.e2v[(int64_t)jj * a.npi + ih] : 0.f;
-    }
+    le[tid] = e2v[0];
+    if (tid == 0) le[kThreads] = has_halo ? a.e2v[(int64_t)jj * a.npi + ih] : 0.f;
     __syncthreads();
-    if (nv <= 0) return;
-    const float vnx = lv[tid + 1], enx = le[tid + 1];
-    double r[4];
+    const float enx = le[tid + 1];
+    float den[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const int i = i0 + c;
-        float val = 0.f;                                              // drotn(:,:) = 0.d0, :275
-        if (c < nv && north) {
-            if (i < a.npi - 1) {
-                const float ve = (c < 3) ? v[c < 3 ? c + 1 : 3] : vnx, ee = (c < 3) ? e2v[c < 3 ? c + 1 : 3] : enx;
-                float f = __fmul_rn(__fmul_rn(__fmul_rn(u[c], un1[c]), v[c]), ve);
-                f = (f != 0.f) ? 1.f : 0.f;
-                const float num = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(ee, ve), -__fmul_rn(e2v[c], v[c])),
-                                                      -__fmul_rn(e1un[c], un1[c])), __fmul_rn(e1u[c], u[c]));
-                val = __fdiv_rn(__fmul_rn(num, f), __fmul_rn(e1f[c], e2f[c]));
-            } else if (a.lperio && a.npi > 2) {
-                val = curl_at(a, un, vn, 1, jj, nullptr);             // drotn(npiglo,:) = drotn(2,:), :285
+    for (int c = 0; c < 4; ++c) den[c] = __fmul_rn(e1f[c], e2f[c]);
+    for (int lev = 0; lev < a.nlev; ++lev) {
+        const float *un = a.un + (int64_t)lev * nij, *vn = a.vn + (int64_t)lev * nij;
+        float u[4] = {0, 0, 0, 0}, un1[4] = {0, 0, 0, 0}, v[4] = {0, 0, 0, 0};
+        if (nv > 0) {
+            load4(un + p2, nv, u); load4(vn + p2, nv, v);
+            if (north) load4(un + p2 + a.npi, nv, un1);
+        }
+        const int buf = lev & 1;                                  // double-buffered: one barrier per level
+        lv[buf][tid] = v[0];
+        if (tid == 0) lv[buf][kThreads] = has_halo ? vn[(int64_t)jj * a.npi + ih] : 0.f;
+        __syncthreads();
+        if (nv <= 0) continue;
+        const float vnx = lv[buf][tid + 1];
+        double r[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int i = i0 + c;
+            float val = 0.f;                                          // drotn(:,:) = 0.d0, :275
+            if (c < nv && north) {
+                if (i < a.npi - 1) {
+                    const float ve = (c < 3) ? v[c < 3 ? c + 1 : 3] : vnx, ee = (c < 3) ? e2v[c < 3 ? c + 1 : 3] : enx;
+                    float f = __fmul_rn(__fmul_rn(__fmul_rn(u[c], un1[c]), v[c]), ve);
+                    f = (f != 0.f) ? 1.f : 0.f;
+                    const float num = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(ee, ve), -__fmul_rn(e2v[c], v[c])),
+                                                          -__fmul_rn(e1un[c], un1[c])), __fmul_rn(e1u[c], u[c]));
+                    val = __fdiv_rn(__fmul_rn(num, f), den[c]);
+                } else if (a.lperio && a.npi > 2) {
+                    val = curl_at(a, un, vn, 1, jj, nullptr);         // drotn(npiglo,:) = drotn(2,:), :285
+                }
             }
+            r[c] = (double)val;
+            if (KEEP && c < nv) a.work[(int64_t)lev * nij + p2 + c] = r[c];
+            if (!KEEP && a.ff && ffv[c] != 0.0) r[c] = __ddiv_rn(r[c], ffv[c]);   // -overf, :299-301
         }
-        r[c] = (double)val;
-        if (KEEP && c < nv) a.work[(int64_t)lev * nij + p2 + c] = r[c];
-        if (!KEEP && a.ff && c < nv) {                                // -overf, :299-301
-            const double f = a.ff[p2 + c];
-            if (f != 0.0) r[c] = __ddiv_rn(r[c], f);
-        }
+        if (!KEEP) store4((OUT *)a.out + (int64_t)lev * nij + p2, nv, r);
     }
-    if (!KEEP) store4((OUT *)a.out + (int64_t)lev * nij + p2, nv, r);
 }
 
 // -T: 4-point mean of the F-point curl to T points with the product of the 4 fmask (:286-297).
@@ -385,7 +394,7 @@ int cdft_curl_compute(cdft_curl_plan *p, const float *un, const float *vn, int n
     a.un = (const float *)du; a.vn = (const float *)dv; a.e1u = p->e1u; a.e2v = p->e2v; a.e1f = p->e1f; a.e2f = p->e2f;
     a.ff = p->ff; a.npi = p->npi; a.npj = p->npj; a.nlev = nlev; a.ntx = (p->npi + kTile - 1) / kTile;
     a.lperio = p->lperio; a.out = dout; a.work = nullptr;
-    const int64_t total = (int64_t)p->npj * nlev * a.ntx;
+    const int64_t total = (int64_t)p->npj * a.ntx;
     const dim3 grid((unsigned)(((total + 7) / 8) * 8)), block(kThreads);
     if (ltpoint) {
         CDFT_TRY(p->work.reserve(n3 * 8));

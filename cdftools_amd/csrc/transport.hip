@@ -169,9 +169,18 @@ __global__ void psi_scan_j_kernel(const double *__restrict__ dtrp, double *__res
     if (i >= npi) return;
     double acc = 0.0;
     dpsi[i] = 0.0;
-    for (int j = 1; j < npj; ++j) {
-        acc = __dadd_rn(acc, -dtrp[(int64_t)j * npi + i]);
-        dpsi[(int64_t)j * npi + i] = acc;
+    constexpr int kB = 16;                               // rows fetched together: the loads are independent,
+    for (int j0 = 1; j0 < npj; j0 += kB) {               // only the additions are sequential
+        double x[kB];
+#pragma unroll
+        for (int r = 0; r < kB; ++r) x[r] = (j0 + r < npj) ? dtrp[(int64_t)(j0 + r) * npi + i] : 0.0;
+#pragma unroll
+        for (int r = 0; r < kB; ++r) {
+            if (j0 + r < npj) {
+                acc = __dadd_rn(acc, -x[r]);
+                dpsi[(int64_t)(j0 + r) * npi + i] = acc;
+            }
+        }
     }
 }
 

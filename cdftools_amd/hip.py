@@ -327,16 +327,25 @@ class PsiPlan(_Plan):
         check(_lib.load().cdft_psi_create(C.byref(self._h), npiglo, npjglo, npk))
 
     def compute(self, zu=None, e2u=None, e3u=None, zv=None, e1v=None, e3v=None, e31d=None, iiref=None,
-                ijref=None, fmask=None, stream=None):
-        """-> (psi4 (npj,npi) r4, dpsi8 (npj,npi) r8) host arrays."""
+                ijref=None, fmask=None, stream=None, host_out=True, want_r8=True):
+        """-> (psi4 (npj,npi) r4, dpsi8 (npj,npi) r8 or None): host arrays, or tensors in HBM when the
+        inputs are resident and host_out is False."""
         names = ("zu", "e2u", "e3u", "zv", "e1v", "e3v", "e31d", "fmask")
         a = [_opt(x, n) for x, n in zip((zu, e2u, e3u, zv, e1v, e3v, e31d, fmask), names)]
         sp = _same_space(*[x[1] for x in a])
-        p4, d8 = np.empty((self.npj, self.npi), np.float32), np.empty((self.npj, self.npi), np.float64)
+        shape = (self.npj, self.npi)
+        if sp == MEM_DEVICE and not host_out:
+            dev = next(x for x in (zu, zv) if x is not None).device
+            p4 = torch.empty(shape, dtype=torch.float32, device=dev)
+            d8 = torch.empty(shape, dtype=torch.float64, device=dev) if want_r8 else None
+            pp4, pd8, so = C.c_void_p(p4.data_ptr()), C.c_void_p(d8.data_ptr()) if want_r8 else _null(), MEM_DEVICE
+        else:
+            p4 = np.empty(shape, np.float32)
+            d8 = np.empty(shape, np.float64) if want_r8 else None
+            pp4, pd8, so = C.c_void_p(p4.ctypes.data), C.c_void_p(d8.ctypes.data) if want_r8 else _null(), MEM_HOST
         check(_lib.load().cdft_psi_compute(self._h, a[0][0], a[1][0], a[2][0], a[3][0], a[4][0], a[5][0], a[6][0],
                                            self.npi if iiref is None else iiref, self.npj if ijref is None else ijref,
-                                           a[7][0], sp, C.c_void_p(p4.ctypes.data), C.c_void_p(d8.ctypes.data),
-                                           MEM_HOST, stream or current_stream_ptr()))
+                                           a[7][0], sp, pp4, pd8, so, stream or current_stream_ptr()))
         return p4, d8
 
 
