@@ -1,0 +1,879 @@
+MODULE cdfio
+  !!======================================================================
+  !! cdfio : NetCDF access layer of the tools -- the module surface the PROGRAM units are written
+  !! against.  Same public names, argument lists and conventions as the reference's src/cdfio.F90
+  !! for the part of the surface the hot-path tools use (cited per routine); the implementation is
+  !! new and sits on the NF90 API (module netcdf: the bundled classic-format backend, or a real
+  !! netcdf-fortran).  Conventions kept from the reference:
+  !!   - input files are opened and closed on every read call; one output file is built at a time
+  !!     through the module-level ids set by create (not re-entrant, src/cdfio.F90:72-73);
+  !!   - getvar returns one (kpi,kpj) r4 slab, unpacking scale_factor / add_offset / savelog10;
+  !!   - chkfile / chkvar return .TRUE. when the file / variable is MISSING;
+  !!   - fatal NetCDF errors print a message and STOP 98.
+  !! Extension: getvar3d reads a whole (kpi,kpj,kpk) record in one call (what the HIP path wants).
+  !!======================================================================
+  USE netcdf
+  USE modcdfnames
+  IMPLICIT NONE
+  PRIVATE
+
+  CHARACTER(LEN=256), PUBLIC :: cg_zgr_ver = 'v3.6'     ! layout of mesh_zgr: v2.0 | v3.0 | v3.6
+  LOGICAL,            PUBLIC :: lg_vvl = .FALSE.        ! set by the tools' -vvl option
+
+  TYPE, PUBLIC :: variable                              ! descriptor of an output variable (src/cdfio.F90:87-103)
+     CHARACTER(LEN=256) :: cname
+     CHARACTER(LEN=256) :: cunits
+     REAL(KIND=4)       :: rmissing_value
+     REAL(KIND=4)       :: valid_min
+     REAL(KIND=4)       :: valid_max
+     REAL(KIND=4)       :: scale_factor = 1.
+     REAL(KIND=4)       :: add_offset = 0.
+     REAL(KIND=4)       :: savelog10 = 0.
+     INTEGER(KIND=4)    :: iwght = 1
+     INTEGER(KIND=4), DIMENSION(4) :: ichunk
+     CHARACTER(LEN=256) :: clong_name
+     CHARACTER(LEN=256) :: cshort_name
+     CHARACTER(LEN=256) :: conline_operation
+     CHARACTER(LEN=256) :: caxis
+     CHARACTER(LEN=256) :: cprecision = 'r4'            ! r4 | r8 | i2 | by
+  END TYPE variable
+
+  ! ids of the output file under construction
+  INTEGER(KIND=4) :: nid_x, nid_y, nid_z, nid_t, nid_lon, nid_lat, nid_dep, nid_tim, nid_lon1d, nid_lat1d
+  ! time / global attributes captured from the first file seen by getdim (src/cdfio.F90:939-994)
+  INTEGER(KIND=4)    :: nstart_date = -1
+  CHARACTER(LEN=256) :: ctime_units = 'seconds since 0001-01-01 00:00:00', ctime_origin = 'N/A', calendar = 'N/A'
+  CHARACTER(LEN=256) :: config = 'N/A', ccase = 'N/A'
+  CHARACTER(LEN=10)  :: cfreq = 'N/A'
+  LOGICAL            :: l_first_getdim = .TRUE.
+
+  INTERFACE putvar
+     MODULE PROCEDURE putvarr8, putvarr4, putvari2, putvarzo
+  END INTERFACE
+  INTERFACE putvar1d
+     MODULE PROCEDURE putvar1d4, putvar1d8
+  END INTERFACE
+  INTERFACE getatt
+     MODULE PROCEDURE getattr, getatti, getattc
+  END INTERFACE
+
+  PUBLIC :: chkfile, chkvar, getdim, getvdim, getspval, getatt, getvar, getvar1d, getvare3, getvar3d
+  PUBLIC :: create, createvar, putatt, putheadervar, putvar, putvar1d, closeout, ncopen, copyatt, ERR_HDL
+
+CONTAINS
+
+  SUBROUTINE ERR_HDL(kstatus)
+    INTEGER(KIND=4), INTENT(in) :: kstatus
+    IF ( kstatus /= NF90_NOERR ) THEN
+       PRINT *, 'ERROR in NETCDF routine, status=', kstatus
+       PRINT *, NF90_STRERROR(kstatus)
+       STOP 98
+    ENDIF
+  END SUBROUTINE ERR_HDL
+
+  FUNCTION iom_name(cdvar) RESULT(clvar)
+    ! name of a vertical metric in mesh_zgr for the detected layout (src/cdfio.F90:1510-1536)
+    CHARACTER(LEN=*), INTENT(in) :: cdvar
+    CHARACTER(LEN=256) :: clvar, clbase
+    clvar = cdvar
+    IF      ( cdvar == cn_ve3t ) THEN ; clbase = 'e3t'
+    ELSE IF ( cdvar == cn_ve3u ) THEN ; clbase = 'e3u'
+    ELSE IF ( cdvar == cn_ve3v ) THEN ; clbase = 'e3v'
+    ELSE IF ( cdvar == cn_ve3w ) THEN ; clbase = 'e3w'
+    ELSE ; RETURN
+    ENDIF
+    SELECT CASE ( cg_zgr_ver )
+    CASE ( 'v2.0' ) ; clvar = TRIM(clbase)//'_ps'
+    CASE ( 'v3.0' ) ; clvar = clbase
+    CASE ( 'v3.6' ) ; clvar = TRIM(clbase)//'_0'
+    END SELECT
+  END FUNCTION iom_name
+
+  FUNCTION env_value(cdname) RESULT(cl)
+    CHARACTER(LEN=*), INTENT(in) :: cdname
+    CHARACTER(LEN=256) :: cl
+    INTEGER :: istat
+    cl = ' '
+    CALL GET_ENVIRONMENT_VARIABLE(cdname, cl, STATUS=istat)
+    IF ( istat /= 0 ) cl = ' '
+  END FUNCTION env_value
+
+  ! ------------------------------------------------------------------------------------------------
+  LOGICAL FUNCTION chkfile(cd_file, ld_verbose)
+    !! .TRUE. when the file is missing; seeing mesh_zgr sets cg_zgr_ver (src/cdfio.F90:3032-3070)
+    CHARACTER(LEN=*),  INTENT(in) :: cd_file
+    LOGICAL, OPTIONAL, INTENT(in) :: ld_verbose
+    LOGICAL :: ll_exist, ll_verbose
+    ll_verbose = .TRUE. ; IF ( PRESENT(ld_verbose) ) ll_verbose = ld_verbose
+    chkfile = .FALSE.
+    IF ( TRIM(cd_file) == 'none' ) RETURN
+    INQUIRE(FILE=TRIM(cd_file), EXIST=ll_exist)
+    IF ( ll_exist ) THEN
+       IF ( cd_file == cn_fzgr ) CALL SetMeshZgrVersion
+    ELSE
+       IF ( ll_verbose ) PRINT *, ' File ', TRIM(cd_file), ' is missing '
+       chkfile = .TRUE.
+    ENDIF
+  END FUNCTION chkfile
+
+  LOGICAL FUNCTION chkvar(cd_file, cd_var, ld_verbose)
+    !! .TRUE. when the variable is missing from the file (src/cdfio.F90:3072-3112)
+    CHARACTER(LEN=*),  INTENT(in) :: cd_file, cd_var
+    LOGICAL, OPTIONAL, INTENT(in) :: ld_verbose
+    INTEGER(KIND=4) :: istatus, incid, id_var
+    LOGICAL :: ll_verbose
+    ll_verbose = .TRUE. ; IF ( PRESENT(ld_verbose) ) ll_verbose = ld_verbose
+    chkvar = .FALSE.
+    IF ( TRIM(cd_var) == 'none' ) RETURN
+    istatus = NF90_OPEN(cd_file, NF90_NOWRITE, incid)
+    IF ( istatus == NF90_NOERR ) THEN
+       istatus = NF90_INQ_VARID(incid, cd_var, id_var)
+       id_var  = NF90_CLOSE(incid)
+    ENDIF
+    IF ( istatus /= NF90_NOERR ) THEN
+       IF ( ll_verbose ) PRINT *, ' Var ', TRIM(cd_var), ' is missing in file ', TRIM(cd_file)
+       chkvar = .TRUE.
+    ENDIF
+  END FUNCTION chkvar
+
+  SUBROUTINE SetMeshZgrVersion()
+    !! e3t_0 absent: v2.0; e3t_0(t,z): v3.0; e3t_0(t,z,y,x): v3.6 (src/cdfio.F90:3310-3335)
+    CHARACTER(LEN=256) :: clvar
+    clvar = 'e3t_0'
+    IF ( chkvar(cn_fzgr, clvar, .FALSE.) ) THEN
+       cg_zgr_ver = 'v2.0'
+    ELSE IF ( getvdim(cn_fzgr, clvar) == 1 ) THEN
+       cg_zgr_ver = 'v3.0'
+    ELSE
+       cg_zgr_ver = 'v3.6'
+    ENDIF
+    PRINT *, ' mesh_zgr version is ', TRIM(cg_zgr_ver)
+  END SUBROUTINE SetMeshZgrVersion
+
+  INTEGER(KIND=4) FUNCTION getdim(cdfile, cdim_name, cdtrue, kstatus, ldexact)
+    !! Length of the first dimension whose name CONTAINS cdim_name (exact match for cn_x or with
+    !! ldexact); 0 / 'unknown' / kstatus=1 when not found.  The first call also captures the time
+    !! attributes and the global attributes that outputs re-emit (src/cdfio.F90:876-1003).
+    CHARACTER(LEN=*),             INTENT(in ) :: cdfile, cdim_name
+    CHARACTER(LEN=256), OPTIONAL, INTENT(out) :: cdtrue
+    INTEGER(KIND=4),    OPTIONAL, INTENT(out) :: kstatus
+    LOGICAL,            OPTIONAL, INTENT(in ) :: ldexact
+    INTEGER(KIND=4) :: incid, istatus, idims, jdim, id_dim, ilen
+    CHARACTER(LEN=256) :: clnam
+    LOGICAL :: ll_exact, ll_found
+    getdim = 0
+    IF ( PRESENT(kstatus) ) kstatus = 0
+    IF ( PRESENT(cdtrue) ) cdtrue = 'unknown'
+    ll_exact = ( cdim_name == cn_x )
+    IF ( PRESENT(ldexact) ) ll_exact = ll_exact .OR. ldexact
+    istatus = NF90_OPEN(cdfile, NF90_NOWRITE, incid)
+    IF ( istatus /= NF90_NOERR ) THEN
+       IF ( PRESENT(kstatus) ) kstatus = 1
+       RETURN
+    ENDIF
+    ll_found = .FALSE.
+    IF ( ll_exact ) THEN
+       istatus = NF90_INQ_DIMID(incid, cdim_name, id_dim)
+       IF ( istatus /= NF90_NOERR ) THEN
+          PRINT *, NF90_STRERROR(istatus)
+          PRINT *, ' Exact dimension name ', TRIM(cdim_name), ' not found in ', TRIM(cdfile) ; STOP 98
+       ENDIF
+       istatus = NF90_INQUIRE_DIMENSION(incid, id_dim, len=getdim)
+       IF ( PRESENT(cdtrue) ) cdtrue = cdim_name
+       ll_found = .TRUE.
+    ELSE
+       istatus = NF90_INQUIRE(incid, nDimensions=idims)
+       DO jdim = 1, idims
+          istatus = NF90_INQUIRE_DIMENSION(incid, jdim, name=clnam, len=ilen)
+          IF ( INDEX(clnam, TRIM(cdim_name)) /= 0 ) THEN
+             getdim = ilen ; ll_found = .TRUE.
+             IF ( PRESENT(cdtrue) ) cdtrue = clnam
+             EXIT
+          ENDIF
+       END DO
+    ENDIF
+    IF ( .NOT. ll_found ) THEN
+       getdim = 0
+       IF ( PRESENT(kstatus) ) kstatus = 1
+    ENDIF
+    IF ( l_first_getdim ) THEN
+       l_first_getdim = .FALSE.
+       CALL capture_file_attributes(incid)
+    ENDIF
+    istatus = NF90_CLOSE(incid)
+  END FUNCTION getdim
+
+  SUBROUTINE capture_file_attributes(kncid)
+    ! time_counter attributes and start_date / output_frequency / CONFIG / CASE: file attribute first,
+    ! then the environment variable of the same name, then the default (src/cdfio.F90:939-994)
+    INTEGER(KIND=4), INTENT(in) :: kncid
+    INTEGER(KIND=4) :: istatus, idv
+    CHARACTER(LEN=256) :: cl
+    istatus = NF90_INQ_VARID(kncid, cn_vtimec, idv)
+    IF ( istatus == NF90_NOERR ) THEN
+       istatus = NF90_GET_ATT(kncid, idv, 'units', cl)       ; IF ( istatus == NF90_NOERR ) ctime_units = cl
+       istatus = NF90_GET_ATT(kncid, idv, 'time_origin', cl) ; IF ( istatus == NF90_NOERR ) ctime_origin = cl
+       istatus = NF90_GET_ATT(kncid, idv, 'calendar', cl)    ; IF ( istatus == NF90_NOERR ) calendar = cl
+    ENDIF
+    cl = env_value('start_date')
+    IF ( NF90_INQUIRE_ATTRIBUTE(kncid, NF90_GLOBAL, 'start_date') == NF90_NOERR ) THEN
+       istatus = NF90_GET_ATT(kncid, NF90_GLOBAL, 'start_date', nstart_date)
+    ELSE IF ( cl /= ' ' ) THEN ; READ(cl, *) nstart_date
+    ELSE ; nstart_date = -1
+    ENDIF
+    cl = env_value('output_frequency')
+    IF ( NF90_INQUIRE_ATTRIBUTE(kncid, NF90_GLOBAL, 'output_frequency') == NF90_NOERR ) THEN
+       istatus = NF90_GET_ATT(kncid, NF90_GLOBAL, 'output_frequency', cfreq)
+    ELSE IF ( cl /= ' ' ) THEN ; cfreq = TRIM(cl)
+    ELSE ; cfreq = 'N/A'
+    ENDIF
+    cl = env_value('CONFIG')
+    IF ( NF90_INQUIRE_ATTRIBUTE(kncid, NF90_GLOBAL, 'CONFIG') == NF90_NOERR ) THEN
+       istatus = NF90_GET_ATT(kncid, NF90_GLOBAL, 'CONFIG', config)
+    ELSE IF ( cl /= ' ' ) THEN ; config = cl
+    ELSE ; config = 'N/A'
+    ENDIF
+    cl = env_value('CASE')
+    IF ( NF90_INQUIRE_ATTRIBUTE(kncid, NF90_GLOBAL, 'CASE') == NF90_NOERR ) THEN
+       istatus = NF90_GET_ATT(kncid, NF90_GLOBAL, 'CASE', ccase)
+    ELSE IF ( cl /= ' ' ) THEN ; ccase = cl
+    ELSE ; ccase = 'N/A'
+    ENDIF
+  END SUBROUTINE capture_file_attributes
+
+  INTEGER(KIND=4) FUNCTION getvdim(cdfile, cdvar)
+    !! number of dimensions of cdvar minus one (src/cdfio.F90:1042-1083); a missing variable is fatal
+    !! here (the reference prompts interactively for another one)
+    CHARACTER(LEN=*), INTENT(in)    :: cdfile
+    CHARACTER(LEN=*), INTENT(inout) :: cdvar
+    INTEGER(KIND=4) :: incid, id_var, idi
+    CALL ERR_HDL(NF90_OPEN(cdfile, NF90_NOWRITE, incid))
+    IF ( NF90_INQ_VARID(incid, cdvar, id_var) /= NF90_NOERR ) THEN
+       PRINT *, ' getvdim : variable ', TRIM(cdvar), ' not found in ', TRIM(cdfile) ; STOP 98
+    ENDIF
+    CALL ERR_HDL(NF90_INQUIRE_VARIABLE(incid, id_var, ndims=idi))
+    getvdim = idi - 1
+    CALL ERR_HDL(NF90_CLOSE(incid))
+  END FUNCTION getvdim
+
+  SUBROUTINE find_spval(kncid, kvar, pspval, cdmissing)
+    ! missing value of a variable: cn_missing_value, then the usual spellings (src/cdfio.F90:1022-1036)
+    INTEGER(KIND=4), INTENT(in) :: kncid, kvar
+    REAL(KIND=4), INTENT(out) :: pspval
+    CHARACTER(LEN=*), OPTIONAL, INTENT(out) :: cdmissing
+    CHARACTER(LEN=13), PARAMETER :: cl_try(3) = (/ 'missing_value', 'Fillvalue    ', '_Fillvalue   ' /)
+    INTEGER :: jt
+    IF ( PRESENT(cdmissing) ) cdmissing = cn_missing_value
+    IF ( NF90_GET_ATT(kncid, kvar, cn_missing_value, pspval) == NF90_NOERR ) RETURN
+    DO jt = 1, SIZE(cl_try)
+       IF ( NF90_GET_ATT(kncid, kvar, TRIM(cl_try(jt)), pspval) == NF90_NOERR ) THEN
+          IF ( PRESENT(cdmissing) ) cdmissing = TRIM(cl_try(jt))
+          RETURN
+       ENDIF
+    END DO
+    pspval = 0.
+  END SUBROUTINE find_spval
+
+  REAL(KIND=4) FUNCTION getspval(cdfile, cdvar, cdmissing)
+    CHARACTER(LEN=*),           INTENT(in ) :: cdfile, cdvar
+    CHARACTER(LEN=*), OPTIONAL, INTENT(out) :: cdmissing
+    INTEGER(KIND=4) :: incid, id_var, istatus
+    getspval = 0.
+    IF ( PRESENT(cdmissing) ) cdmissing = cn_missing_value
+    IF ( NF90_OPEN(cdfile, NF90_NOWRITE, incid) /= NF90_NOERR ) RETURN
+    IF ( NF90_INQ_VARID(incid, cdvar, id_var) == NF90_NOERR ) CALL find_spval(incid, id_var, getspval, cdmissing)
+    istatus = NF90_CLOSE(incid)
+  END FUNCTION getspval
+
+  SUBROUTINE att_problem(kstatus, cdfile, cdvar, cdatt, cddefault)
+    INTEGER(KIND=4), INTENT(in) :: kstatus
+    CHARACTER(LEN=*), INTENT(in) :: cdfile, cdvar, cdatt, cddefault
+    PRINT *, ' getatt problem :', NF90_STRERROR(kstatus)
+    PRINT *, ' attribute :', TRIM(cdatt)
+    PRINT *, ' variable  :', TRIM(cdvar)
+    PRINT *, ' file      :', TRIM(cdfile)
+    PRINT *, ' return default ', cddefault
+  END SUBROUTINE att_problem
+
+  REAL(KIND=4) FUNCTION getattr(cdfile, cdvar, cdatt)
+    !! r4 attribute of a variable, 0. (with a message) when absent (src/cdfio.F90:688-716)
+    CHARACTER(LEN=*), INTENT(in) :: cdfile, cdvar, cdatt
+    INTEGER(KIND=4) :: istatus, incid, idv
+    getattr = 0.
+    istatus = NF90_OPEN(cdfile, NF90_NOWRITE, incid)
+    istatus = NF90_INQ_VARID(incid, cdvar, idv)
+    IF ( istatus /= NF90_NOERR ) PRINT *, TRIM(NF90_STRERROR(istatus)), ' when looking for ', TRIM(cdvar), ' in getatt.'
+    istatus = NF90_GET_ATT(incid, idv, cdatt, getattr)
+    IF ( istatus /= NF90_NOERR ) THEN
+       CALL att_problem(istatus, cdfile, cdvar, cdatt, '0') ; getattr = 0.
+    ENDIF
+    istatus = NF90_CLOSE(incid)
+  END FUNCTION getattr
+
+  INTEGER(KIND=4) FUNCTION getatti(cdfile, cdvar, cdatt, kidum)
+    CHARACTER(LEN=*), INTENT(in) :: cdfile, cdvar, cdatt
+    INTEGER(KIND=4) :: kidum                             ! only selects this specific
+    INTEGER(KIND=4) :: istatus, incid, idv
+    getatti = 0
+    istatus = NF90_OPEN(cdfile, NF90_NOWRITE, incid)
+    istatus = NF90_INQ_VARID(incid, cdvar, idv)
+    IF ( istatus /= NF90_NOERR ) PRINT *, TRIM(NF90_STRERROR(istatus)), ' when looking for ', TRIM(cdvar), ' in getatt.'
+    istatus = NF90_GET_ATT(incid, idv, cdatt, getatti)
+    IF ( istatus /= NF90_NOERR ) THEN
+       CALL att_problem(istatus, cdfile, cdvar, cdatt, '0') ; getatti = 0
+    ENDIF
+    istatus = NF90_CLOSE(incid)
+  END FUNCTION getatti
+
+  CHARACTER(LEN=256) FUNCTION getattc(cdfile, cdvar, cdatt, cdum)
+    CHARACTER(LEN=*), INTENT(in) :: cdfile, cdvar, cdatt
+    CHARACTER(LEN=*) :: cdum                             ! only selects this specific
+    INTEGER(KIND=4) :: istatus, incid, idv
+    getattc = 'N/A'
+    istatus = NF90_OPEN(cdfile, NF90_NOWRITE, incid)
+    istatus = NF90_INQ_VARID(incid, cdvar, idv)
+    IF ( istatus /= NF90_NOERR ) PRINT *, TRIM(NF90_STRERROR(istatus)), ' when looking for ', TRIM(cdvar), ' in getatt.'
+    istatus = NF90_GET_ATT(incid, idv, cdatt, getattc)
+    IF ( istatus /= NF90_NOERR ) THEN
+       CALL att_problem(istatus, cdfile, cdvar, cdatt, 'N/A') ; getattc = 'N/A'
+    ENDIF
+    istatus = NF90_CLOSE(incid)
+  END FUNCTION getattc
+
+  ! ------------------------------------------------------------------------------------------------
+  SUBROUTINE packing(kncid, kvar, psf, pao, ldlog, ldsf, ldao)
+    ! scale_factor / add_offset / savelog10 of a variable (src/cdfio.F90:1563-1584)
+    INTEGER(KIND=4), INTENT(in) :: kncid, kvar
+    REAL(KIND=4), INTENT(out) :: psf, pao
+    LOGICAL, INTENT(out) :: ldlog, ldsf, ldao
+    INTEGER(KIND=4) :: ilog
+    psf = 1. ; pao = 0. ; ldlog = .FALSE. ; ldsf = .FALSE. ; ldao = .FALSE.
+    IF ( NF90_INQUIRE_ATTRIBUTE(kncid, kvar, 'savelog10') == NF90_NOERR ) THEN
+       IF ( NF90_GET_ATT(kncid, kvar, 'savelog10', ilog) == NF90_NOERR ) ldlog = ( ilog /= 0 )
+    ENDIF
+    IF ( NF90_INQUIRE_ATTRIBUTE(kncid, kvar, 'scale_factor') == NF90_NOERR ) THEN
+       IF ( NF90_GET_ATT(kncid, kvar, 'scale_factor', psf) == NF90_NOERR ) ldsf = ( psf /= 1. )
+    ENDIF
+    IF ( NF90_INQUIRE_ATTRIBUTE(kncid, kvar, 'add_offset') == NF90_NOERR ) THEN
+       IF ( NF90_GET_ATT(kncid, kvar, 'add_offset', pao) == NF90_NOERR ) ldao = ( pao /= 0. )
+    ENDIF
+  END SUBROUTINE packing
+
+  SUBROUTINE level_start(kncid, kvar, klev, ktime, kstart)
+    ! start vector of a (level, time) slab: a variable whose 3rd dimension is the unlimited one is
+    ! (x,y,t), anything else is read as (x,y,z,t) (src/cdfio.F90:1544-1554)
+    INTEGER(KIND=4), INTENT(in) :: kncid, kvar, klev, ktime
+    INTEGER(KIND=4), INTENT(inout) :: kstart(4)
+    INTEGER(KIND=4) :: istatus, iunlim, inb, idd(4)
+    idd = 0
+    istatus = NF90_INQUIRE(kncid, unlimitedDimId=iunlim)
+    istatus = NF90_INQUIRE_VARIABLE(kncid, kvar, ndims=inb, dimids=idd)
+    IF ( idd(3) == iunlim ) THEN
+       kstart(3) = ktime ; kstart(4) = 1
+    ELSE
+       kstart(3) = klev ; kstart(4) = ktime
+    ENDIF
+  END SUBROUTINE level_start
+
+  FUNCTION getvar(cdfile, cdvar, klev, kpi, kpj, kimin, kjmin, ktime, ldiom)
+    !! One (kpi,kpj) r4 slab of cdvar at level klev, record ktime, window origin (kimin,kjmin);
+    !! a window crossing the E-W boundary wraps skipping the overlap column; ldiom maps e3t/e3u/e3v/e3w
+    !! to their mesh_zgr names (src/cdfio.F90:1425-1609).
+    CHARACTER(LEN=*),          INTENT(in) :: cdfile, cdvar
+    INTEGER(KIND=4), OPTIONAL, INTENT(in) :: klev
+    INTEGER(KIND=4),           INTENT(in) :: kpi, kpj
+    INTEGER(KIND=4), OPTIONAL, INTENT(in) :: kimin, kjmin, ktime
+    LOGICAL,         OPTIONAL, INTENT(in) :: ldiom
+    REAL(KIND=4), DIMENSION(kpi,kpj) :: getvar
+    INTEGER(KIND=4) :: incid, id_var, istatus, ilev, imin, jmin, itime, ipiglo, ileft, istart(4), icount(4)
+    REAL(KIND=4) :: zsf, zao, zspval
+    LOGICAL :: llog, lsf, lao, llperio
+    CHARACTER(LEN=256) :: clvar
+    ilev = 1  ; IF ( PRESENT(klev ) ) ilev  = klev
+    imin = 1  ; IF ( PRESENT(kimin) ) imin  = kimin
+    jmin = 1  ; IF ( PRESENT(kjmin) ) jmin  = kjmin
+    itime = 1 ; IF ( PRESENT(ktime) ) itime = ktime
+    clvar = cdvar
+    IF ( PRESENT(ldiom) ) THEN
+       IF ( ldiom ) clvar = iom_name(cdvar)
+    ENDIF
+    llperio = .FALSE.
+    IF ( PRESENT(kimin) ) THEN
+       ipiglo = getdim(cdfile, cn_x, ldexact=.TRUE.)
+       llperio = ( imin + kpi - 1 > ipiglo )
+    ENDIF
+    CALL ERR_HDL(NF90_OPEN(cdfile, NF90_NOWRITE, incid))
+    CALL ERR_HDL(NF90_INQ_VARID(incid, clvar, id_var))
+    istart = (/ imin, jmin, 1, 1 /) ; icount = (/ kpi, kpj, 1, 1 /)
+    CALL level_start(incid, id_var, ilev, itime, istart)
+    CALL find_spval(incid, id_var, zspval)
+    CALL packing(incid, id_var, zsf, zao, llog, lsf, lao)
+    IF ( llperio ) THEN
+       ileft = ipiglo - imin                          ! columns imin .. ipiglo-1, then from column 2 on
+       istart(1) = imin ; icount(1) = ileft
+       istatus = NF90_GET_VAR(incid, id_var, getvar(1:ileft,:), start=istart, count=icount)
+       istart(1) = 2 ; icount(1) = kpi - ileft
+       IF ( istatus == NF90_NOERR ) istatus = NF90_GET_VAR(incid, id_var, getvar(ileft+1:kpi,:), start=istart, count=icount)
+    ELSE
+       istatus = NF90_GET_VAR(incid, id_var, getvar, start=istart, count=icount)
+    ENDIF
+    IF ( istatus /= NF90_NOERR ) THEN
+       PRINT *, ' Problem in getvar for ', TRIM(clvar)
+       CALL ERR_HDL(istatus)
+    ENDIF
+    IF ( lsf  ) WHERE ( getvar /= zspval ) getvar = getvar * zsf
+    IF ( lao  ) WHERE ( getvar /= zspval ) getvar = getvar + zao
+    IF ( llog ) WHERE ( getvar /= zspval ) getvar = 10**getvar
+    istatus = NF90_CLOSE(incid)
+  END FUNCTION getvar
+
+  FUNCTION getvar3d(cdfile, cdvar, kpi, kpj, kpk, ktime, ldiom)
+    !! A whole (kpi,kpj,kpk) record in one read: same unpacking as getvar level by level.
+    CHARACTER(LEN=*),          INTENT(in) :: cdfile, cdvar
+    INTEGER(KIND=4),           INTENT(in) :: kpi, kpj, kpk
+    INTEGER(KIND=4), OPTIONAL, INTENT(in) :: ktime
+    LOGICAL,         OPTIONAL, INTENT(in) :: ldiom
+    REAL(KIND=4), DIMENSION(kpi,kpj,kpk) :: getvar3d
+    INTEGER(KIND=4) :: incid, id_var, istatus, itime
+    REAL(KIND=4) :: zsf, zao, zspval
+    LOGICAL :: llog, lsf, lao
+    CHARACTER(LEN=256) :: clvar
+    itime = 1 ; IF ( PRESENT(ktime) ) itime = ktime
+    clvar = cdvar
+    IF ( PRESENT(ldiom) ) THEN
+       IF ( ldiom ) clvar = iom_name(cdvar)
+    ENDIF
+    CALL ERR_HDL(NF90_OPEN(cdfile, NF90_NOWRITE, incid))
+    CALL ERR_HDL(NF90_INQ_VARID(incid, clvar, id_var))
+    CALL find_spval(incid, id_var, zspval)
+    CALL packing(incid, id_var, zsf, zao, llog, lsf, lao)
+    istatus = NF90_GET_VAR(incid, id_var, getvar3d, start=(/ 1, 1, 1, itime /), count=(/ kpi, kpj, kpk, 1 /))
+    IF ( istatus /= NF90_NOERR ) THEN
+       PRINT *, ' Problem in getvar3d for ', TRIM(clvar)
+       CALL ERR_HDL(istatus)
+    ENDIF
+    IF ( lsf  ) WHERE ( getvar3d /= zspval ) getvar3d = getvar3d * zsf
+    IF ( lao  ) WHERE ( getvar3d /= zspval ) getvar3d = getvar3d + zao
+    IF ( llog ) WHERE ( getvar3d /= zspval ) getvar3d = 10**getvar3d
+    istatus = NF90_CLOSE(incid)
+  END FUNCTION getvar3d
+
+  FUNCTION getvar1d(cdfile, cdvar, kk, kstatus)
+    !! 1-D variable as r8 (time axes); 99999999999.d0 and kstatus /= 0 when absent (src/cdfio.F90:2151-2186)
+    CHARACTER(LEN=*),           INTENT(in) :: cdfile, cdvar
+    INTEGER(KIND=4),            INTENT(in) :: kk
+    INTEGER(KIND=4), OPTIONAL, INTENT(out) :: kstatus
+    REAL(KIND=8), DIMENSION(kk) :: getvar1d
+    INTEGER(KIND=4) :: incid, id_var, istatus
+    IF ( PRESENT(kstatus) ) kstatus = 0
+    istatus = NF90_OPEN(cdfile, NF90_NOWRITE, incid)
+    istatus = NF90_INQ_VARID(incid, cdvar, id_var)
+    IF ( istatus == NF90_NOERR ) THEN
+       istatus = NF90_GET_VAR(incid, id_var, getvar1d, start=(/ 1 /), count=(/ kk /))
+    ELSE
+       PRINT *, ' getvar1d ERROR: ', TRIM(NF90_STRERROR(istatus))
+       PRINT *, '                when reading ', TRIM(cdvar)
+       IF ( PRESENT(kstatus) ) kstatus = istatus
+       getvar1d = 99999999999.d0
+    ENDIF
+    istatus = NF90_CLOSE(incid)
+  END FUNCTION getvar1d
+
+  FUNCTION getvare3(cdfile, cdvar, kk)
+    !! 1-D vertical metric (gdept, gdepw, e3t, e3w) from mesh_zgr whatever its layout: v2.0 stores
+    !! (t,z,1,1), v3.0 'xxx_0'(t,z), v3.6 'xxx_1d'(t,z) (src/cdfio.F90:2189-2287)
+    CHARACTER(LEN=*), INTENT(in) :: cdfile, cdvar
+    INTEGER(KIND=4),  INTENT(in) :: kk
+    REAL(KIND=4), DIMENSION(kk) :: getvare3
+    INTEGER(KIND=4) :: incid, id_var, istatus, icount(4)
+    CHARACTER(LEN=256) :: clvar, clbase
+    LOGICAL :: ll_1d
+    clvar = cdvar ; clbase = ' ' ; ll_1d = .TRUE.
+    IF      ( cdvar == cn_gdept  ) THEN ; clbase = 'gdept'
+    ELSE IF ( cdvar == cn_gdepw  ) THEN ; clbase = 'gdepw'
+    ELSE IF ( cdvar == cn_ve3t1d ) THEN ; clbase = 'e3t'
+    ELSE IF ( cdvar == cn_ve3w1d ) THEN ; clbase = 'e3w'
+    ELSE ; ll_1d = .FALSE.
+    ENDIF
+    icount = (/ 1, 1, kk, 1 /)
+    IF ( ll_1d ) THEN
+       SELECT CASE ( cg_zgr_ver )
+       CASE ( 'v2.0' ) ; clvar = clbase
+       CASE ( 'v3.0' ) ; clvar = TRIM(clbase)//'_0'  ; icount = (/ kk, 1, 1, 1 /)
+       CASE ( 'v3.6' ) ; clvar = TRIM(clbase)//'_1d' ; icount = (/ kk, 1, 1, 1 /)
+       END SELECT
+    ENDIF
+    istatus = NF90_OPEN(cdfile, NF90_NOWRITE, incid)
+    IF ( istatus == NF90_NOERR ) istatus = NF90_INQ_VARID(incid, clvar, id_var)
+    IF ( istatus == NF90_NOERR ) istatus = NF90_GET_VAR(incid, id_var, getvare3, start=(/ 1, 1, 1, 1 /), count=icount)
+    IF ( istatus /= NF90_NOERR ) THEN
+       PRINT *, ' Problem in getvare3 for ', TRIM(cdvar)
+       PRINT *, TRIM(cdfile), kk
+       CALL ERR_HDL(istatus)
+    ENDIF
+    istatus = NF90_CLOSE(incid)
+  END FUNCTION getvare3
+
+  ! ------------------------------------------------------------------------------------------------
+  INTEGER(KIND=4) FUNCTION copyatt(cdvar, kidvar, kcin, kcout)
+    !! attributes of a coordinate variable: copied from the reference file when there is one
+    !! (kcin /= -9999), standard ones otherwise (src/cdfio.F90:185-258)
+    CHARACTER(LEN=*), INTENT(in) :: cdvar
+    INTEGER(KIND=4),  INTENT(in) :: kidvar, kcin, kcout
+    INTEGER(KIND=4) :: ja, idvar, iatt
+    CHARACTER(LEN=256) :: clatt
+    copyatt = NF90_NOERR
+    IF ( kcin /= -9999 ) THEN
+       IF ( NF90_INQ_VARID(kcin, cdvar, idvar) /= NF90_NOERR ) RETURN
+       copyatt = NF90_INQUIRE_VARIABLE(kcin, idvar, nAtts=iatt)
+       DO ja = 1, iatt
+          copyatt = NF90_INQ_ATTNAME(kcin, idvar, ja, clatt)
+          copyatt = NF90_COPY_ATT(kcin, idvar, TRIM(clatt), kcout, kidvar)
+       END DO
+       RETURN
+    ENDIF
+    SELECT CASE ( TRIM(cdvar) )
+    CASE ( 'nav_lon', 'lon', 'x', 'longitude' )
+       CALL coord_atts('degrees_east', -180., 180., 'Longitude', 'nav_model', 'Default grid')
+    CASE ( 'nav_lat', 'lat', 'y', 'latitude' )
+       CALL coord_atts('degrees_north', -90., 90., 'Latitude', 'nav_model', 'Default grid')
+    CASE ( 'time_counter', 'time', 't' )
+       copyatt = NF90_PUT_ATT(kcout, kidvar, 'calendar',    TRIM(calendar))
+       copyatt = NF90_PUT_ATT(kcout, kidvar, 'units',       TRIM(ctime_units))
+       copyatt = NF90_PUT_ATT(kcout, kidvar, 'time_origin', TRIM(ctime_origin))
+       copyatt = NF90_PUT_ATT(kcout, kidvar, 'title',       'Time')
+       copyatt = NF90_PUT_ATT(kcout, kidvar, 'long_name',   'Time axis')
+    CASE ( 'deptht', 'depthu', 'depthv', 'depthw', 'dep', 'gdept' )
+       copyatt = NF90_PUT_ATT(kcout, kidvar, 'units', 'm')
+       copyatt = NF90_PUT_ATT(kcout, kidvar, 'positive', 'unknown')
+       copyatt = NF90_PUT_ATT(kcout, kidvar, 'valid_min', 0.)
+       copyatt = NF90_PUT_ATT(kcout, kidvar, 'valid_max', 5875.)
+       copyatt = NF90_PUT_ATT(kcout, kidvar, 'title', TRIM(cdvar))
+       copyatt = NF90_PUT_ATT(kcout, kidvar, 'long_name', 'Vertical Levels')
+    CASE ( 'sigma', 'levels' )
+       copyatt = NF90_PUT_ATT(kcout, kidvar, 'units', 'kg/m3')
+       copyatt = NF90_PUT_ATT(kcout, kidvar, 'positive', 'unknown')
+       copyatt = NF90_PUT_ATT(kcout, kidvar, 'valid_min', 0.)
+       copyatt = NF90_PUT_ATT(kcout, kidvar, 'valid_max', 40.)
+       copyatt = NF90_PUT_ATT(kcout, kidvar, 'title', TRIM(cdvar))
+       copyatt = NF90_PUT_ATT(kcout, kidvar, 'long_name', 'Sigma bin limits')
+    END SELECT
+  CONTAINS
+    SUBROUTINE coord_atts(cdunits, pmin, pmax, cdlong, cdextra, cdextraval)
+      CHARACTER(LEN=*), INTENT(in) :: cdunits, cdlong, cdextra, cdextraval
+      REAL(KIND=4), INTENT(in) :: pmin, pmax
+      copyatt = NF90_PUT_ATT(kcout, kidvar, 'units', cdunits)
+      copyatt = NF90_PUT_ATT(kcout, kidvar, 'valid_min', pmin)
+      copyatt = NF90_PUT_ATT(kcout, kidvar, 'valid_max', pmax)
+      copyatt = NF90_PUT_ATT(kcout, kidvar, 'long_name', cdlong)
+      copyatt = NF90_PUT_ATT(kcout, kidvar, cdextra, cdextraval)
+    END SUBROUTINE coord_atts
+  END FUNCTION copyatt
+
+  INTEGER(KIND=4) FUNCTION create(cdfile, cdfilref, kx, ky, kz, cdep, cdepvar, cdlonvar, cdlatvar, ld_xycoo, ld_nc4)
+    !! New 64-bit-offset file with dims x, y, [depth], time_counter(UNLIMITED) and the coordinate
+    !! variables nav_lon, nav_lat, [depth], time_counter; returns its ncid (src/cdfio.F90:260-368).
+    !! ld_nc4 is accepted; with the bundled backend the file stays classic.
+    CHARACTER(LEN=*),           INTENT(in) :: cdfile, cdfilref
+    INTEGER(KIND=4),            INTENT(in) :: kx, ky, kz
+    CHARACTER(LEN=*), OPTIONAL, INTENT(in) :: cdep, cdepvar, cdlonvar, cdlatvar
+    LOGICAL,          OPTIONAL, INTENT(in) :: ld_xycoo, ld_nc4
+    INTEGER(KIND=4) :: istatus, icout, incid, idum, icmode
+    CHARACTER(LEN=256) :: cldep, cldepref, cldepvar
+    LOGICAL :: ll_xycoo
+    ll_xycoo = .TRUE. ; IF ( PRESENT(ld_xycoo) ) ll_xycoo = ld_xycoo
+    icmode = IOR(NF90_CLOBBER, NF90_64BIT_OFFSET)
+    ! a slab of more than 2^32-4 bytes per record does not fit the 64-bit-offset format: use CDF-5
+    IF ( REAL(kx, 8) * REAL(ky, 8) * REAL(MAX(kz, 1), 8) * 8.d0 > 4.0d9 ) icmode = IOR(NF90_CLOBBER, NF90_64BIT_DATA)
+    CALL ERR_HDL(NF90_CREATE(cdfile, icmode, icout))
+    istatus = NF90_DEF_DIM(icout, TRIM(cn_x), kx, nid_x)
+    istatus = NF90_DEF_DIM(icout, TRIM(cn_y), ky, nid_y)
+    IF ( kz /= 0 ) THEN                                  ! name of the depth dimension: from the reference file
+       IF ( PRESENT(cdep) ) THEN
+          cldep = cdep
+          idum = getdim(cdfilref, cldep, cldepref)
+          IF ( cldepref == 'unknown' ) cldepref = cdep
+       ELSE
+          idum = getdim(cdfilref, cn_z, cldep)
+          cldepref = cldep
+       ENDIF
+       cldepvar = cldep
+       IF ( PRESENT(cdepvar) ) cldepvar = cdepvar
+       istatus = NF90_DEF_DIM(icout, TRIM(cldep), kz, nid_z)
+    ENDIF
+    istatus = NF90_DEF_DIM(icout, TRIM(cn_t), NF90_UNLIMITED, nid_t)
+    incid = -9999
+    IF ( TRIM(cdfilref) /= 'none' ) istatus = NF90_OPEN(cdfilref, NF90_NOWRITE, incid)
+    IF ( ll_xycoo ) THEN
+       istatus = NF90_DEF_VAR(icout, TRIM(cn_vlon2d), NF90_FLOAT, (/ nid_x, nid_y /), nid_lon)
+       istatus = copyatt(cn_vlon2d, nid_lon, incid, icout)
+       istatus = NF90_DEF_VAR(icout, TRIM(cn_vlat2d), NF90_FLOAT, (/ nid_x, nid_y /), nid_lat)
+       istatus = copyatt(cn_vlat2d, nid_lat, incid, icout)
+    ENDIF
+    IF ( PRESENT(cdlonvar) ) istatus = NF90_DEF_VAR(icout, cdlonvar, NF90_FLOAT, (/ nid_x /), nid_lon1d)
+    IF ( PRESENT(cdlatvar) ) istatus = NF90_DEF_VAR(icout, cdlatvar, NF90_FLOAT, (/ nid_y /), nid_lat1d)
+    IF ( kz /= 0 ) THEN
+       istatus = NF90_DEF_VAR(icout, TRIM(cldepvar), NF90_FLOAT, (/ nid_z /), nid_dep)
+       istatus = copyatt(TRIM(cldepvar), nid_dep, incid, icout)
+    ENDIF
+    istatus = NF90_DEF_VAR(icout, TRIM(cn_vtimec), NF90_DOUBLE, (/ nid_t /), nid_tim)
+    istatus = copyatt(cn_vtimec, nid_tim, incid, icout)
+    istatus = NF90_PUT_ATT(icout, NF90_GLOBAL, 'start_date', nstart_date)
+    istatus = NF90_PUT_ATT(icout, NF90_GLOBAL, 'output_frequency', TRIM(cfreq))
+    istatus = NF90_PUT_ATT(icout, NF90_GLOBAL, 'CONFIG', TRIM(config))
+    istatus = NF90_PUT_ATT(icout, NF90_GLOBAL, 'CASE', TRIM(ccase))
+    IF ( incid /= -9999 ) istatus = NF90_CLOSE(incid)
+    create = icout
+  END FUNCTION create
+
+  INTEGER(KIND=4) FUNCTION createvar(kout, sdtyvar, kvar, kpk, kidvo, cdglobal, ld_nc4)
+    !! Defines the kvar output variables ('none' skipped) and leaves define mode.  kpk == 1: (x,y,t);
+    !! kpk > 1: (x,y,z,t); kpk < 0: (t).  An r4 variable with a scale factor or offset is stored as
+    !! short (src/cdfio.F90:371-459).
+    INTEGER(KIND=4),                  INTENT(in   ) :: kout, kvar
+    TYPE(variable), DIMENSION(kvar),  INTENT(inout) :: sdtyvar
+    INTEGER(KIND=4), DIMENSION(kvar), INTENT(in   ) :: kpk
+    INTEGER(KIND=4), DIMENSION(kvar), INTENT(out  ) :: kidvo
+    CHARACTER(LEN=*), OPTIONAL,       INTENT(in   ) :: cdglobal
+    LOGICAL,          OPTIONAL,       INTENT(in   ) :: ld_nc4
+    INTEGER(KIND=4) :: jv, idims, istatus, iidims(4), itype
+    createvar = NF90_NOERR
+    DO jv = 1, kvar
+       IF ( sdtyvar(jv)%cname == 'none' ) CYCLE
+       IF ( kpk(jv) == 1 ) THEN
+          idims = 3 ; iidims(1:3) = (/ nid_x, nid_y, nid_t /)
+       ELSE IF ( kpk(jv) > 1 ) THEN
+          idims = 4 ; iidims(1:4) = (/ nid_x, nid_y, nid_z, nid_t /)
+       ELSE IF ( kpk(jv) < 0 ) THEN
+          idims = 1 ; iidims(1) = nid_t
+       ELSE
+          PRINT *, ' ERROR: ipk = ', kpk(jv), jv, sdtyvar(jv)%cname
+          STOP 98
+       ENDIF
+       SELECT CASE ( sdtyvar(jv)%cprecision )
+       CASE ( 'r8' ) ; itype = NF90_DOUBLE
+       CASE ( 'i2' ) ; itype = NF90_SHORT
+       CASE ( 'by' ) ; itype = NF90_BYTE
+       CASE DEFAULT
+          itype = NF90_FLOAT
+          IF ( sdtyvar(jv)%scale_factor /= 1. .OR. sdtyvar(jv)%add_offset /= 0. ) THEN
+             itype = NF90_SHORT ; sdtyvar(jv)%cprecision = 'i2'
+          ENDIF
+       END SELECT
+       CALL ERR_HDL(NF90_DEF_VAR(kout, TRIM(sdtyvar(jv)%cname), itype, iidims(1:idims), kidvo(jv)))
+       createvar = putatt(sdtyvar(jv), kout, kidvo(jv), cdglobal=cdglobal)
+    END DO
+    istatus = NF90_ENDDEF(kout)
+    IF ( istatus /= NF90_NOERR ) THEN
+       PRINT *, ' Error in CreateVar :', TRIM(NF90_STRERROR(istatus))
+       STOP 98
+    ENDIF
+  END FUNCTION createvar
+
+  INTEGER(KIND=4) FUNCTION putatt(sdtyvar, kout, kid, cdglobal)
+    !! the 12 standard attributes of an output variable, in the reference's order
+    !! (src/cdfio.F90:629-682); any failure is fatal
+    TYPE(variable),             INTENT(in) :: sdtyvar
+    INTEGER(KIND=4),            INTENT(in) :: kout, kid
+    CHARACTER(LEN=*), OPTIONAL, INTENT(in) :: cdglobal
+    CALL must(NF90_PUT_ATT(kout, kid, 'units', TRIM(sdtyvar%cunits)), 'units')
+    SELECT CASE ( sdtyvar%cprecision )                   ! the missing value has the variable's type
+    CASE ( 'r8' ) ; putatt = NF90_PUT_ATT(kout, kid, TRIM(cn_missing_value), REAL(sdtyvar%rmissing_value, 8))
+    CASE ( 'i2' ) ; putatt = NF90_PUT_ATT(kout, kid, TRIM(cn_missing_value), INT(sdtyvar%rmissing_value, 2))
+    CASE ( 'by' ) ; putatt = NF90_PUT_ATT(kout, kid, TRIM(cn_missing_value), INT(sdtyvar%rmissing_value, 1))
+    CASE DEFAULT  ; putatt = NF90_PUT_ATT(kout, kid, TRIM(cn_missing_value), REAL(sdtyvar%rmissing_value, 4))
+    END SELECT
+    CALL must(putatt, 'missing value')
+    CALL must(NF90_PUT_ATT(kout, kid, 'valid_min', sdtyvar%valid_min), 'valid_min')
+    CALL must(NF90_PUT_ATT(kout, kid, 'valid_max', sdtyvar%valid_max), 'valid_max')
+    CALL must(NF90_PUT_ATT(kout, kid, 'long_name', TRIM(sdtyvar%clong_name)), 'long_name')
+    CALL must(NF90_PUT_ATT(kout, kid, 'short_name', TRIM(sdtyvar%cshort_name)), 'short_name')
+    CALL must(NF90_PUT_ATT(kout, kid, 'iweight', sdtyvar%iwght), 'iweight')
+    CALL must(NF90_PUT_ATT(kout, kid, 'online_operation', TRIM(sdtyvar%conline_operation)), 'online_operation')
+    CALL must(NF90_PUT_ATT(kout, kid, 'axis', TRIM(sdtyvar%caxis)), 'axis')
+    CALL must(NF90_PUT_ATT(kout, kid, 'scale_factor', sdtyvar%scale_factor), 'scale_factor')
+    CALL must(NF90_PUT_ATT(kout, kid, 'add_offset', sdtyvar%add_offset), 'add_offset')
+    CALL must(NF90_PUT_ATT(kout, kid, 'savelog10', sdtyvar%savelog10), 'savelog10')
+    IF ( PRESENT(cdglobal) ) CALL must(NF90_PUT_ATT(kout, NF90_GLOBAL, 'history', TRIM(cdglobal)), 'history')
+    putatt = NF90_NOERR
+  CONTAINS
+    SUBROUTINE must(kstatus, cdwhat)
+      INTEGER(KIND=4), INTENT(in) :: kstatus
+      CHARACTER(LEN=*), INTENT(in) :: cdwhat
+      IF ( kstatus /= NF90_NOERR ) THEN
+         PRINT *, NF90_STRERROR(kstatus) ; PRINT *, ' putatt for ', cdwhat ; STOP 98
+      ENDIF
+    END SUBROUTINE must
+  END FUNCTION putatt
+
+  INTEGER(KIND=4) FUNCTION putheadervar(kout, cdfile, kpi, kpj, kpk, pnavlon, pnavlat, pdep, cdep, ld_xycoo)
+    !! fills nav_lon / nav_lat / depth of the output file from the arrays given, else from cdfile
+    !! (2-D, then 1-D lon/lat, then zeros; depth under any of its usual names) (src/cdfio.F90:2290-2407)
+    INTEGER(KIND=4),                            INTENT(in) :: kout, kpi, kpj, kpk
+    CHARACTER(LEN=*),                           INTENT(in) :: cdfile
+    REAL(KIND=4), OPTIONAL, DIMENSION(kpi,kpj), INTENT(in) :: pnavlon, pnavlat
+    REAL(KIND=4), OPTIONAL, DIMENSION(kpk),     INTENT(in) :: pdep
+    CHARACTER(LEN=*), OPTIONAL,                 INTENT(in) :: cdep
+    LOGICAL,          OPTIONAL,                 INTENT(in) :: ld_xycoo
+    REAL(KIND=4), ALLOCATABLE :: z2d(:,:)
+    REAL(KIND=4) :: z1d(MAX(kpk, 1))
+    CHARACTER(LEN=256) :: cldept(6)
+    INTEGER(KIND=4) :: istatus, idep, jj
+    LOGICAL :: ll_xycoo
+    ll_xycoo = .TRUE. ; IF ( PRESENT(ld_xycoo) ) ll_xycoo = ld_xycoo
+    istatus = NF90_NOERR
+    IF ( ll_xycoo ) THEN
+       ALLOCATE( z2d(kpi,kpj) )
+       IF ( PRESENT(pnavlon) ) THEN ; z2d = pnavlon
+       ELSE ; CALL horizontal_coordinate(cn_vlon2d, cn_vlon1d, .TRUE.)
+       ENDIF
+       istatus = putvar(kout, nid_lon, z2d, 1, kpi, kpj)
+       IF ( PRESENT(pnavlat) ) THEN ; z2d = pnavlat
+       ELSE ; CALL horizontal_coordinate(cn_vlat2d, cn_vlat1d, .FALSE.)
+       ENDIF
+       istatus = putvar(kout, nid_lat, z2d, 1, kpi, kpj)
+       DEALLOCATE( z2d )
+    ENDIF
+    IF ( kpk /= 0 ) THEN
+       IF ( PRESENT(pdep) ) THEN
+          z1d(1:kpk) = pdep
+       ELSE
+          idep = -1
+          IF ( PRESENT(cdep) ) z1d(1:kpk) = getvar1d(cdfile, cdep, kpk, idep)
+          IF ( idep /= NF90_NOERR ) THEN
+             cldept = (/ cn_vdeptht, cn_vdepthu, cn_vdepthv, cn_vdepthw, 'nav_lev'//REPEAT(' ', 249), 'z'//REPEAT(' ', 255) /)
+             DO jj = 1, SIZE(cldept)
+                IF ( .NOT. chkvar(cdfile, cldept(jj), .FALSE.) ) THEN
+                   z1d(1:kpk) = getvar1d(cdfile, cldept(jj), kpk, idep)
+                   IF ( idep == NF90_NOERR ) EXIT
+                ENDIF
+             END DO
+             IF ( idep /= NF90_NOERR ) THEN
+                PRINT *, ' No depth variable found in ', TRIM(cdfile)
+                STOP 98
+             ENDIF
+          ENDIF
+       ENDIF
+       istatus = putvar1d(kout, z1d(1:kpk), kpk, 'D')
+    ENDIF
+    putheadervar = istatus
+  CONTAINS
+    SUBROUTINE horizontal_coordinate(cd2d, cd1d, ldlon)
+      CHARACTER(LEN=*), INTENT(in) :: cd2d, cd1d
+      LOGICAL, INTENT(in) :: ldlon
+      INTEGER(KIND=4) :: ji, ist
+      IF ( .NOT. chkvar(cdfile, cd2d, .FALSE.) ) THEN
+         z2d = getvar(cdfile, cd2d, 1, kpi, kpj)
+      ELSE IF ( .NOT. chkvar(cdfile, cd1d, .FALSE.) ) THEN
+         IF ( ldlon ) THEN
+            z2d(:,1) = REAL(getvar1d(cdfile, cd1d, kpi, ist), 4)
+            DO ji = 2, kpj ; z2d(:,ji) = z2d(:,1) ; END DO
+         ELSE
+            z2d(1,:) = REAL(getvar1d(cdfile, cd1d, kpj, ist), 4)
+            DO ji = 2, kpi ; z2d(ji,:) = z2d(1,:) ; END DO
+         ENDIF
+      ELSE
+         PRINT *, '... dummy value used!'
+         z2d = 0.
+      ENDIF
+    END SUBROUTINE horizontal_coordinate
+  END FUNCTION putheadervar
+
+  SUBROUTINE slab_start(kout, kid, klev, ktime, kstart)
+    ! where a (level, time) slab of an output variable goes: the last dimension is the record one,
+    ! a 4-D variable also has a level (src/cdfio.F90:2437-2441)
+    INTEGER(KIND=4), INTENT(in) :: kout, kid, klev, ktime
+    INTEGER(KIND=4), INTENT(out) :: kstart(4)
+    INTEGER(KIND=4) :: istatus, iunlim, inb, idd(4)
+    idd = 0 ; kstart = 1
+    istatus = NF90_INQUIRE(kout, unlimitedDimId=iunlim)
+    istatus = NF90_INQUIRE_VARIABLE(kout, kid, ndims=inb, dimids=idd)
+    IF ( inb >= 1 .AND. inb <= 4 ) THEN
+       IF ( idd(inb) == iunlim ) kstart(inb) = ktime
+    ENDIF
+    IF ( inb == 4 ) kstart(3) = klev
+  END SUBROUTINE slab_start
+
+  INTEGER(KIND=4) FUNCTION putvarr8(kout, kid, ptab, klev, kpi, kpj, ktime, kwght)
+    !! r8 slab (converted by NetCDF to the variable's type) (src/cdfio.F90:2410-2451)
+    INTEGER(KIND=4),                  INTENT(in) :: kout, kid, klev, kpi, kpj
+    REAL(KIND=8), DIMENSION(kpi,kpj), INTENT(in) :: ptab
+    INTEGER(KIND=4), OPTIONAL,        INTENT(in) :: ktime, kwght
+    INTEGER(KIND=4) :: itime, istart(4)
+    itime = 1 ; IF ( PRESENT(ktime) ) itime = ktime
+    CALL slab_start(kout, kid, klev, itime, istart)
+    putvarr8 = NF90_PUT_VAR(kout, kid, ptab, start=istart, count=(/ kpi, kpj, 1, 1 /))
+    IF ( PRESENT(kwght) ) putvarr8 = NF90_PUT_ATT(kout, kid, 'iweight', kwght)
+  END FUNCTION putvarr8
+
+  INTEGER(KIND=4) FUNCTION putvarr4(kout, kid, ptab, klev, kpi, kpj, ktime, kwght)
+    INTEGER(KIND=4),                  INTENT(in) :: kout, kid, klev, kpi, kpj
+    REAL(KIND=4), DIMENSION(kpi,kpj), INTENT(in) :: ptab
+    INTEGER(KIND=4), OPTIONAL,        INTENT(in) :: ktime, kwght
+    INTEGER(KIND=4) :: itime, istart(4)
+    itime = 1 ; IF ( PRESENT(ktime) ) itime = ktime
+    CALL slab_start(kout, kid, klev, itime, istart)
+    putvarr4 = NF90_PUT_VAR(kout, kid, ptab, start=istart, count=(/ kpi, kpj, 1, 1 /))
+    IF ( PRESENT(kwght) ) putvarr4 = NF90_PUT_ATT(kout, kid, 'iweight', kwght)
+  END FUNCTION putvarr4
+
+  INTEGER(KIND=4) FUNCTION putvari2(kout, kid, ktab, klev, kpi, kpj, ktime, kwght)
+    INTEGER(KIND=4),                     INTENT(in) :: kout, kid, klev, kpi, kpj
+    INTEGER(KIND=2), DIMENSION(kpi,kpj), INTENT(in) :: ktab
+    INTEGER(KIND=4), OPTIONAL,           INTENT(in) :: ktime, kwght
+    INTEGER(KIND=4) :: itime, istart(4)
+    itime = 1 ; IF ( PRESENT(ktime) ) itime = ktime
+    CALL slab_start(kout, kid, klev, itime, istart)
+    putvari2 = NF90_PUT_VAR(kout, kid, ktab, start=istart, count=(/ kpi, kpj, 1, 1 /))
+    IF ( PRESENT(kwght) ) putvari2 = NF90_PUT_ATT(kout, kid, 'iweight', kwght)
+  END FUNCTION putvari2
+
+  INTEGER(KIND=4) FUNCTION putvarzo(kout, kid, ptab, klev, kpi, kpj, ktime)
+    !! a zonal (kpi = 1) or meridional (kpj = 1) line given as a 1-D r4 array (src/cdfio.F90:2642-2681)
+    INTEGER(KIND=4),            INTENT(in) :: kout, kid, klev, kpi, kpj
+    REAL(KIND=4), DIMENSION(:), INTENT(in) :: ptab
+    INTEGER(KIND=4), OPTIONAL,  INTENT(in) :: ktime
+    INTEGER(KIND=4) :: itime, istart(4)
+    itime = 1 ; IF ( PRESENT(ktime) ) itime = ktime
+    CALL slab_start(kout, kid, klev, itime, istart)
+    putvarzo = NF90_PUT_VAR(kout, kid, ptab, start=istart, count=(/ kpi, kpj, 1, 1 /))
+  END FUNCTION putvarzo
+
+  INTEGER(KIND=4) FUNCTION axis_id(cdtype)
+    CHARACTER(LEN=1), INTENT(in) :: cdtype
+    SELECT CASE ( cdtype )
+    CASE ( 'T', 't' ) ; axis_id = nid_tim
+    CASE ( 'D', 'd' ) ; axis_id = nid_dep
+    CASE ( 'X', 'x' ) ; axis_id = nid_lon1d
+    CASE ( 'Y', 'y' ) ; axis_id = nid_lat1d
+    CASE DEFAULT ; axis_id = -1
+    END SELECT
+  END FUNCTION axis_id
+
+  INTEGER(KIND=4) FUNCTION putvar1d4(kout, ptab, kk, cdtype)
+    !! time ('T'), depth ('D') or 1-D lon/lat ('X','Y') axis values (src/cdfio.F90:2684-2756)
+    INTEGER(KIND=4),             INTENT(in) :: kout, kk
+    REAL(KIND=4), DIMENSION(kk), INTENT(in) :: ptab
+    CHARACTER(LEN=1),            INTENT(in) :: cdtype
+    putvar1d4 = NF90_PUT_VAR(kout, axis_id(cdtype), ptab, start=(/ 1 /), count=(/ kk /))
+  END FUNCTION putvar1d4
+
+  INTEGER(KIND=4) FUNCTION putvar1d8(kout, ddtab, kk, cdtype)
+    INTEGER(KIND=4),             INTENT(in) :: kout, kk
+    REAL(KIND=8), DIMENSION(kk), INTENT(in) :: ddtab
+    CHARACTER(LEN=1),            INTENT(in) :: cdtype
+    putvar1d8 = NF90_PUT_VAR(kout, axis_id(cdtype), ddtab, start=(/ 1 /), count=(/ kk /))
+  END FUNCTION putvar1d8
+
+  INTEGER(KIND=4) FUNCTION closeout(kout)
+    INTEGER(KIND=4), INTENT(in) :: kout
+    closeout = NF90_CLOSE(kout)
+  END FUNCTION closeout
+
+  INTEGER(KIND=4) FUNCTION ncopen(cdfile)
+    CHARACTER(LEN=*), INTENT(in) :: cdfile
+    INTEGER(KIND=4) :: istatus
+    istatus = NF90_OPEN(cdfile, NF90_WRITE, ncopen)
+  END FUNCTION ncopen
+
+END MODULE cdfio

@@ -1,0 +1,256 @@
+PROGRAM cdfmoc
+  !!======================================================================
+  !!                     ***  PROGRAM  cdfmoc  ***
+  !! Meridional overturning stream function, global and (with new_maskglo.nc) per ocean basin.
+  !!
+  !! Drop-in for the reference tool (src/cdfmoc.f90): same command line, same auxiliary files
+  !! (mesh_hgr.nc, mesh_zgr.nc, mask.nc, new_maskglo.nc through modcdfnames), same stdout lines for the
+  !! dimensions, same moc.nc (dims x=1,y,depthw,time_counter; zomsfglo [atl inp ind pac inp0] float,
+  !! units Sverdrup, :1006-1188).  The two hot loops (:355-379 zonal sum, :382-388 vertical cumulated
+  !! sum) run on the GPU through cdft_moc_* (libcdftools_hip.so); several records are sent per call so
+  !! that the time-invariant weights are read once for all of them.
+  !! -decomp and -rapid are not carried by this build: they stop with an explicit message.
+  !!======================================================================
+  USE ISO_C_BINDING
+  USE cdfio
+  USE modcdfnames
+  USE eos
+  USE cdftools_hip
+  IMPLICIT NONE
+
+  INTEGER(KIND=4) :: narg, ijarg, ierr, ii
+  INTEGER(KIND=4) :: npiglo, npjglo, npk, npt, nbasins, nbasinso, nvarout
+  INTEGER(KIND=4) :: jt, jk, jbasin, jr, it0, nrec, nbatch, ijvar, ncout
+  INTEGER(KIND=4) :: npglo = 1, npatl = 2, npinp = 3, npind = 4, nppac = 5
+  INTEGER(KIND=4), ALLOCATABLE :: ipk(:), id_varout(:)
+  INTEGER(KIND=4) :: iloc(2)
+  INTEGER(KIND=2), ALLOCATABLE :: ibmask(:,:,:)                 ! (nbasins, npiglo, npjglo)
+  REAL(KIND=4),    ALLOCATABLE :: e1v(:,:), gphiv(:,:), e3v(:,:,:), zv(:,:,:,:), zmsk(:,:)
+  REAL(KIND=4),    ALLOCATABLE :: rdumlon(:,:), rdumlat(:,:), gdepw(:), e31d(:)
+  REAL(KIND=8),    ALLOCATABLE :: dtim(:), dmoc(:,:,:,:)          ! (nbasins, npjglo, npk, nbatch)
+  REAL(KIND=8) :: dl_budget
+  CHARACTER(LEN=256) :: cf_vfil = 'none', cf_tfil = 'none', cf_sfil = 'none', cf_ufil = 'none'
+  CHARACTER(LEN=256) :: cf_moc = 'moc.nc', cglobal, cldum
+  TYPE(variable), ALLOCATABLE :: stypvar(:)
+  TYPE(C_PTR) :: plan
+  LOGICAL :: lbas, lfull = .FALSE., lchk = .FALSE., ldec = .FALSE., lrap = .FALSE., ll_teos10 = .FALSE.
+  !!----------------------------------------------------------------------
+  CALL ReadCdfNames()
+
+  narg = COMMAND_ARGUMENT_COUNT()
+  IF ( narg == 0 ) THEN
+     PRINT *, ' usage : cdfmoc  -v V-file  [-decomp] [-rapid] [-t T-file] [-s S-file] ...'
+     PRINT *, '                  ... [-u U-file] [-full] [-vvl ] [-o OUT-file] [-teos] '
+     PRINT *, '      '
+     PRINT *, '     PURPOSE :'
+     PRINT *, '       Compute the meridional overturning stream function (MOC) of the global ocean and,'
+     PRINT *, '       when the sub-basin file ', TRIM(cn_fbasins), ' is present, of the Atlantic,'
+     PRINT *, '       Indo-Pacific, Indian and Pacific basins.  MI355X build: the zonal integration and'
+     PRINT *, '       the bottom-to-surface accumulation run on the GPU.'
+     PRINT *, '      '
+     PRINT *, '     ARGUMENTS :'
+     PRINT *, '       -v V-file : file with the meridional velocity component (mandatory).'
+     PRINT *, '      '
+     PRINT *, '     OPTIONS :'
+     PRINT *, '       [-full ]      : full step instead of the default partial step'
+     PRINT *, '       [-vvl  ]      : time-varying vertical metrics (read from V-file)'
+     PRINT *, '       [-o OUT-file] : output file instead of ', TRIM(cf_moc)
+     PRINT *, '       [-decomp ], [-rapid ], [-t T-file], [-s S-file], [-u U-file], [-teos10] :'
+     PRINT *, '                       accepted for compatibility; the MOC decomposition and the RAPID'
+     PRINT *, '                       diagnostics are not available in this build.'
+     PRINT *, '      '
+     PRINT *, '     REQUIRED FILES :'
+     PRINT *, '       ', TRIM(cn_fhgr), ' ', TRIM(cn_fzgr), ' and ', TRIM(cn_fmsk)
+     PRINT *, '       ', TRIM(cn_fbasins), ' (optional): without it only the global MOC is computed'
+     PRINT *, '      '
+     PRINT *, '     OPENMP SUPPORT : not needed (GPU) '
+     PRINT *, '      '
+     PRINT *, '     OUTPUT : '
+     PRINT *, '       netcdf file : ', TRIM(cf_moc)
+     PRINT *, '       variables ', TRIM(cn_zomsfglo), ' : Global ocean '
+     PRINT *, '       variables ', TRIM(cn_zomsfatl), ' : Atlantic Ocean '
+     PRINT *, '       variables ', TRIM(cn_zomsfinp), ' : Indo Pacific '
+     PRINT *, '       variables ', TRIM(cn_zomsfind), ' : Indian Ocean alone'
+     PRINT *, '       variables ', TRIM(cn_zomsfpac), ' : Pacific Ocean alone'
+     PRINT *, '       variables ', TRIM(cn_zomsfinp0), ' : Indo Pacific Net'
+     PRINT *, '      '
+     STOP
+  ENDIF
+
+  cglobal = 'Partial step computation'
+  ijarg = 1
+  DO WHILE ( ijarg <= narg )
+     CALL GET_COMMAND_ARGUMENT(ijarg, cldum) ; ijarg = ijarg + 1
+     SELECT CASE ( cldum )
+     CASE ( '-v'      ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cf_vfil) ; ijarg = ijarg + 1
+     CASE ( '-t'      ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cf_tfil) ; ijarg = ijarg + 1
+     CASE ( '-s'      ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cf_sfil) ; ijarg = ijarg + 1
+     CASE ( '-u'      ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cf_ufil) ; ijarg = ijarg + 1
+     CASE ( '-o'      ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cf_moc ) ; ijarg = ijarg + 1
+     CASE ( '-full'   ) ; lfull  = .TRUE. ; cglobal = 'Full step computation'
+     CASE ( '-decomp' ) ; ldec   = .TRUE.
+     CASE ( '-rapid'  ) ; lrap   = .TRUE.
+     CASE ( '-vvl'    ) ; lg_vvl = .TRUE.
+     CASE ( '-teos10' ) ; ll_teos10 = .TRUE.
+     CASE DEFAULT       ; PRINT *, ' ERROR : ', TRIM(cldum), ' : unknown option.' ; STOP 99
+     END SELECT
+  END DO
+
+  CALL eos_init( ll_teos10 )
+  IF ( cf_sfil == 'none' ) cf_sfil = cf_tfil
+
+  lchk = lchk .OR. chkfile( cn_fhgr )
+  lchk = lchk .OR. chkfile( cn_fzgr )
+  lchk = lchk .OR. chkfile( cn_fmsk )
+  lchk = lchk .OR. chkfile( cf_vfil )
+  IF ( lchk ) STOP 99                                     ! missing file(s)
+  IF ( ldec .OR. lrap ) THEN
+     PRINT *, ' ERROR : options -decomp and -rapid are not available in the MI355X build of cdfmoc.'
+     STOP 99
+  ENDIF
+  IF ( lg_vvl ) THEN
+     cn_fe3v = cf_vfil
+     cn_ve3v = cn_ve3vvvl
+  ENDIF
+
+  npiglo = getdim(cf_vfil, cn_x)
+  npjglo = getdim(cf_vfil, cn_y)
+  npk    = getdim(cf_vfil, cn_z)
+  npt    = getdim(cf_vfil, cn_t)
+
+  PRINT *, 'Working with cdfmoc ...'
+  PRINT *, '  npiglo =', npiglo
+  PRINT *, '  npjglo =', npjglo
+  PRINT *, '  npk    =', npk
+  PRINT *, '  npt    =', npt
+
+  lbas = .NOT. chkfile( cn_fbasins )                      ! sub-basin file present ?
+  IF ( lbas ) THEN ; nbasins = 5 ; nbasinso = 6
+  ELSE             ; nbasins = 1 ; nbasinso = 1
+  ENDIF
+  nvarout = nbasinso
+
+  ! records sent to the GPU per call: as many as fit a host budget (default 8 GB, CDFT_HOST_GB)
+  dl_budget = 8.d0
+  CALL GET_ENVIRONMENT_VARIABLE('CDFT_HOST_GB', cldum)
+  IF ( LEN_TRIM(cldum) > 0 ) READ(cldum, *) dl_budget
+  nbatch = MAX(1, MIN(npt, INT(dl_budget * 1.d9 / (4.d0 * npiglo * npjglo * npk))))
+  IF ( lg_vvl ) nbatch = 1                                ! the metric changes with every record
+
+  ALLOCATE( ibmask(nbasins, npiglo, npjglo), zmsk(npiglo, npjglo) )
+  ALLOCATE( e1v(npiglo, npjglo), gphiv(npiglo, npjglo), e3v(npiglo, npjglo, npk) )
+  ALLOCATE( zv(npiglo, npjglo, npk, nbatch), dmoc(nbasins, npjglo, npk, nbatch) )
+  ALLOCATE( rdumlon(1, npjglo), rdumlat(1, npjglo), gdepw(npk), e31d(npk), dtim(npt) )
+  ALLOCATE( stypvar(nvarout), ipk(nvarout), id_varout(nvarout) )
+
+  e1v(:,:)   = getvar(cn_fhgr, cn_ve1v,  1, npiglo, npjglo)
+  gphiv(:,:) = getvar(cn_fhgr, cn_gphiv, 1, npiglo, npjglo)
+  gdepw(:)   = getvare3(cn_fzgr, cn_gdepw, npk)
+  gdepw(:)   = -1. * gdepw(:)
+  IF ( lfull ) e31d(:) = getvare3(cn_fzgr, cn_ve3t1d, npk)
+
+  iloc = MAXLOC(gphiv)
+  rdumlat(1,:) = gphiv(iloc(1),:)
+  rdumlon(:,:) = 0.
+
+  CALL CreateOutput
+
+  ! basin masks, basin index fastest (src/cdfmoc.f90:325-336)
+  zmsk(:,:) = getvar(cn_fmsk, cn_vmask, 1, npiglo, npjglo) ; ibmask(npglo,:,:) = INT(zmsk, 2)
+  IF ( lbas ) THEN
+     zmsk(:,:) = getvar(cn_fbasins, cn_tmaskatl, 1, npiglo, npjglo) ; ibmask(npatl,:,:) = INT(zmsk, 2)
+     zmsk(:,:) = getvar(cn_fbasins, cn_tmaskind, 1, npiglo, npjglo) ; ibmask(npind,:,:) = INT(zmsk, 2)
+     zmsk(:,:) = getvar(cn_fbasins, cn_tmaskpac, 1, npiglo, npjglo) ; ibmask(nppac,:,:) = INT(zmsk, 2)
+     ibmask(npinp,:,:) = ibmask(nppac,:,:) + ibmask(npind,:,:)
+     WHERE ( ibmask(npinp,:,:) > 0 ) ibmask(npinp,:,:) = 1
+  ENDIF
+  ibmask(npglo, 1,      :) = 0                            ! E-W periodic overlap, global basin only
+  ibmask(npglo, npiglo, :) = 0
+
+  CALL hip_check(cdft_moc_create(plan, npiglo, npjglo, npk, nbasins), 'cdft_moc_create')
+
+  it0 = 1
+  DO WHILE ( it0 <= npt )
+     nrec = MIN(nbatch, npt - it0 + 1)
+     IF ( it0 == 1 .OR. lg_vvl ) THEN                     ! e3v masked by vmask, every level (get_e3v)
+        DO jk = 1, npk
+           e3v(:,:,jk) = get_e3v(jk, it0)
+        END DO
+        CALL hip_check(cdft_moc_set_mesh(plan, e1v, e3v, ibmask, CDFT_MEM_HOST, C_NULL_PTR), 'cdft_moc_set_mesh')
+     ENDIF
+     DO jr = 1, nrec                                      ! velocities of levels 1..npk-1 are used
+        zv(:,:,:,jr) = getvar3d(cf_vfil, cn_vomecrty, npiglo, npjglo, npk, ktime=it0 + jr - 1)
+     END DO
+     CALL hip_check(cdft_moc_compute(plan, zv, INT(npiglo, C_INT64_T) * npjglo * npk, nrec, CDFT_MEM_HOST, dmoc, &
+          &                          CDFT_MEM_HOST, C_NULL_PTR), 'cdft_moc_compute')
+     DO jr = 1, nrec
+        jt = it0 + jr - 1
+        ijvar = 1
+        DO jbasin = 1, nbasins
+           DO jk = 1, npk
+              ierr = putvar(ncout, id_varout(ijvar), REAL(dmoc(jbasin,:,jk,jr)), jk, 1, npjglo, ktime=jt)
+           END DO
+           ijvar = ijvar + 1
+        END DO
+        IF ( lbas ) THEN                                  ! net Indo-Pacific = global - Atlantic
+           DO jk = 1, npk
+              ierr = putvar(ncout, id_varout(ijvar), REAL(dmoc(npglo,:,jk,jr) - dmoc(npatl,:,jk,jr)), jk, 1, npjglo, ktime=jt)
+           END DO
+        ENDIF
+     END DO
+     it0 = it0 + nrec
+  END DO
+
+  ierr = cdft_moc_destroy(plan)
+  ierr = closeout(ncout)
+
+CONTAINS
+
+  FUNCTION get_e3v(kk, kt)
+    !! e3v at level kk (or e31d with -full) times vmask of that level (src/cdfmoc.f90:576-596)
+    INTEGER(KIND=4), INTENT(in) :: kk, kt
+    REAL(KIND=4), DIMENSION(npiglo,npjglo) :: get_e3v
+    REAL(KIND=4), DIMENSION(npiglo,npjglo) :: zvm
+    INTEGER(KIND=2), DIMENSION(npiglo,npjglo) :: ivmask
+    zvm(:,:) = getvar(cn_fmsk, cn_vmask, kk, npiglo, npjglo)
+    ivmask(:,:) = INT(zvm, 2)
+    IF ( lfull ) THEN ; get_e3v(:,:) = e31d(kk)
+    ELSE              ; get_e3v(:,:) = getvar(cn_fe3v, cn_ve3v, kk, npiglo, npjglo, ktime=kt, ldiom=.NOT. lg_vvl)
+    ENDIF
+    get_e3v(:,:) = get_e3v(:,:) * ivmask(:,:)
+  END FUNCTION get_e3v
+
+  SUBROUTINE CreateOutput
+    !! moc.nc exactly as the reference builds it (src/cdfmoc.f90:1006-1188)
+    CHARACTER(LEN=256) :: cl_names(6), cl_long(6)
+    stypvar%cunits            = 'Sverdrup'
+    stypvar%rmissing_value    = 99999.
+    stypvar%valid_min         = -1000.
+    stypvar%valid_max         =  1000.
+    stypvar%scale_factor      = 1.
+    stypvar%add_offset        = 0.
+    stypvar%savelog10         = 0.
+    stypvar%conline_operation = 'N/A'
+    stypvar%caxis             = 'TZY'
+    ipk(:) = npk
+    cl_names = (/ cn_zomsfglo, cn_zomsfatl, cn_zomsfinp, cn_zomsfind, cn_zomsfpac, cn_zomsfinp0 /)
+    cl_long(1) = 'Meridional_Overt.Cell_Global'
+    cl_long(2) = 'Meridional_Overt.Cell_Atlantic'
+    cl_long(3) = 'Meridional_Overt.Cell_IndoPacif'
+    cl_long(4) = 'Meridional_Overt.Cell_Indian'
+    cl_long(5) = 'Meridional_Overt.Cell_pacif'
+    cl_long(6) = 'Meridional_Overt.Cell_IndPac0'
+    DO ii = 1, nvarout
+       PRINT *, 'Variable ', ii, ' is ', TRIM(cl_names(ii))
+       stypvar(ii)%cname       = TRIM(cl_names(ii))
+       stypvar(ii)%clong_name  = TRIM(cl_long(ii))
+       stypvar(ii)%cshort_name = TRIM(cl_names(ii))
+    END DO
+    ncout = create      (cf_moc, 'none', 1, npjglo, npk, cdep=cn_vdepthw)
+    ierr  = createvar   (ncout, stypvar, nvarout, ipk, id_varout, cdglobal=TRIM(cglobal))
+    ierr  = putheadervar(ncout, cf_vfil, 1, npjglo, npk, pnavlon=rdumlon, pnavlat=rdumlat, pdep=gdepw)
+    dtim  = getvar1d    (cf_vfil, cn_vtimec, npt)
+    ierr  = putvar1d    (ncout, dtim, npt, 'T')
+  END SUBROUTINE CreateOutput
+
+END PROGRAM cdfmoc

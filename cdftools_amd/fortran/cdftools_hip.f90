@@ -1,0 +1,160 @@
+MODULE cdftools_hip
+  !!======================================================================
+  !! cdftools_hip : the thin ISO_C_BINDING shim between the Fortran host programs and the hand-written
+  !! HIP kernels in libcdftools_hip.so.  One interface per entry point of include/cdftools_hip.h (same
+  !! names, same argument order); arrays are passed as they sit in the Fortran program (column-major,
+  !! assumed-size), plans are opaque TYPE(C_PTR).  hip_check turns a non-zero status into the
+  !! reference's fatal-error convention (message + STOP 98, src/cdfio.F90:2924-2940).
+  !!======================================================================
+  USE ISO_C_BINDING
+  IMPLICIT NONE
+  PUBLIC
+
+  INTEGER(C_INT), PARAMETER :: CDFT_OK = 0, CDFT_MEM_HOST = 0, CDFT_MEM_DEVICE = 1
+  INTEGER(C_INT), PARAMETER :: CDFT_EOS_80 = 0, CDFT_EOS_TEOS10 = 1, CDFT_EOS_JMD94 = 2, CDFT_EOS_FAST_FMA = 1
+
+  INTERFACE
+     FUNCTION cdft_last_error() BIND(C, name='cdft_last_error')
+       IMPORT ; TYPE(C_PTR) :: cdft_last_error
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_device_count(n) BIND(C, name='cdft_device_count')
+       IMPORT ; INTEGER(C_INT), INTENT(out) :: n
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_set_device(idev) BIND(C, name='cdft_set_device')
+       IMPORT ; INTEGER(C_INT), VALUE :: idev
+     END FUNCTION
+     ! ---- cdfmoc ---------------------------------------------------------------------------
+     INTEGER(C_INT) FUNCTION cdft_moc_create(plan, npiglo, npjglo, npk, nbasins) BIND(C, name='cdft_moc_create')
+       IMPORT ; TYPE(C_PTR), INTENT(out) :: plan ; INTEGER(C_INT), VALUE :: npiglo, npjglo, npk, nbasins
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_moc_set_mesh(plan, e1v, e3v, ibmask, memspace, stream) BIND(C, name='cdft_moc_set_mesh')
+       IMPORT ; TYPE(C_PTR), VALUE :: plan, stream ; REAL(C_FLOAT), INTENT(in) :: e1v(*), e3v(*)
+       INTEGER(C_INT16_T), INTENT(in) :: ibmask(*) ; INTEGER(C_INT), VALUE :: memspace
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_moc_compute(plan, zv, rec_stride, npt, zv_space, dmoc, dmoc_space, stream) &
+          &         BIND(C, name='cdft_moc_compute')
+       IMPORT ; TYPE(C_PTR), VALUE :: plan, stream ; REAL(C_FLOAT), INTENT(in) :: zv(*)
+       INTEGER(C_INT64_T), VALUE :: rec_stride ; INTEGER(C_INT), VALUE :: npt, zv_space, dmoc_space
+       REAL(C_DOUBLE), INTENT(out) :: dmoc(*)
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_moc_destroy(plan) BIND(C, name='cdft_moc_destroy')
+       IMPORT ; TYPE(C_PTR), VALUE :: plan
+     END FUNCTION
+     ! ---- eos ------------------------------------------------------------------------------
+     INTEGER(C_INT) FUNCTION cdft_eos_sigmai(ptem, psal, n, pref, keos, kflags, sig, in_space, out_space, stream) &
+          &         BIND(C, name='cdft_eos_sigmai')
+       IMPORT ; REAL(C_FLOAT), INTENT(in) :: ptem(*), psal(*) ; INTEGER(C_INT64_T), VALUE :: n
+       REAL(C_FLOAT), VALUE :: pref ; INTEGER(C_INT), VALUE :: keos, kflags, in_space, out_space
+       REAL(C_DOUBLE), INTENT(out) :: sig(*) ; TYPE(C_PTR), VALUE :: stream
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_eos_sigmai2d(ptem, psal, pref2d, n, keos, kflags, sig, in_space, out_space, stream) &
+          &         BIND(C, name='cdft_eos_sigmai2d')
+       IMPORT ; REAL(C_FLOAT), INTENT(in) :: ptem(*), psal(*), pref2d(*) ; INTEGER(C_INT64_T), VALUE :: n
+       INTEGER(C_INT), VALUE :: keos, kflags, in_space, out_space
+       REAL(C_DOUBLE), INTENT(out) :: sig(*) ; TYPE(C_PTR), VALUE :: stream
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_eos_sig_tool(ptem, psal, n, pref, spval, keos, kflags, sig4, in_space, out_space, stream) &
+          &         BIND(C, name='cdft_eos_sig_tool')
+       IMPORT ; REAL(C_FLOAT), INTENT(in) :: ptem(*), psal(*) ; INTEGER(C_INT64_T), VALUE :: n
+       REAL(C_FLOAT), VALUE :: pref, spval ; INTEGER(C_INT), VALUE :: keos, kflags, in_space, out_space
+       REAL(C_FLOAT), INTENT(out) :: sig4(*) ; TYPE(C_PTR), VALUE :: stream
+     END FUNCTION
+     ! ---- cdfheatc -------------------------------------------------------------------------
+     INTEGER(C_INT) FUNCTION cdft_heatc_create(plan, npiglo, npjglo, npk) BIND(C, name='cdft_heatc_create')
+       IMPORT ; TYPE(C_PTR), INTENT(out) :: plan ; INTEGER(C_INT), VALUE :: npiglo, npjglo, npk
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_heatc_set_mesh(plan, e1t, e2t, e3t, e31d, tmask, mask_is_r4, memspace, stream) &
+          &         BIND(C, name='cdft_heatc_set_mesh')
+       IMPORT ; TYPE(C_PTR), VALUE :: plan, stream, e3t, e31d, tmask ; REAL(C_FLOAT), INTENT(in) :: e1t(*), e2t(*)
+       INTEGER(C_INT), VALUE :: mask_is_r4, memspace
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_heatc_compute(plan, temp, temp_space, rmxldep, gdepw, mxloption, sums, out_space, stream) &
+          &         BIND(C, name='cdft_heatc_compute')
+       IMPORT ; TYPE(C_PTR), VALUE :: plan, stream, rmxldep, gdepw ; REAL(C_FLOAT), INTENT(in) :: temp(*)
+       INTEGER(C_INT), VALUE :: temp_space, mxloption, out_space ; REAL(C_DOUBLE), INTENT(out) :: sums(*)
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_heatc_destroy(plan) BIND(C, name='cdft_heatc_destroy')
+       IMPORT ; TYPE(C_PTR), VALUE :: plan
+     END FUNCTION
+     ! ---- cdfmhst --------------------------------------------------------------------------
+     INTEGER(C_INT) FUNCTION cdft_mhst_create(plan, npiglo, npjglo, npk, nbasins) BIND(C, name='cdft_mhst_create')
+       IMPORT ; TYPE(C_PTR), INTENT(out) :: plan ; INTEGER(C_INT), VALUE :: npiglo, npjglo, npk, nbasins
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_mhst_set_mesh(plan, e1v, e3v, e31d, masks, memspace, stream) BIND(C, name='cdft_mhst_set_mesh')
+       IMPORT ; TYPE(C_PTR), VALUE :: plan, stream, e3v, e31d ; REAL(C_FLOAT), INTENT(in) :: e1v(*), masks(*)
+       INTEGER(C_INT), VALUE :: memspace
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_mhst_compute(plan, vt, vs, zv, zt, zs, in_space, zdim, heat, salt, out_space, stream) &
+          &         BIND(C, name='cdft_mhst_compute')
+       IMPORT ; TYPE(C_PTR), VALUE :: plan, stream, vt, vs, zv, zt, zs ; INTEGER(C_INT), VALUE :: in_space, zdim, out_space
+       REAL(C_DOUBLE), INTENT(out) :: heat(*), salt(*)
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_mhst_destroy(plan) BIND(C, name='cdft_mhst_destroy')
+       IMPORT ; TYPE(C_PTR), VALUE :: plan
+     END FUNCTION
+     ! ---- cdfpsi ---------------------------------------------------------------------------
+     INTEGER(C_INT) FUNCTION cdft_psi_create(plan, npiglo, npjglo, npk) BIND(C, name='cdft_psi_create')
+       IMPORT ; TYPE(C_PTR), INTENT(out) :: plan ; INTEGER(C_INT), VALUE :: npiglo, npjglo, npk
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_psi_compute(plan, zu, e2u, e3u, zv, e1v, e3v, e31d, iiref, ijref, fmask, in_space, &
+          &                                   psi4, dpsi8, out_space, stream) BIND(C, name='cdft_psi_compute')
+       IMPORT ; TYPE(C_PTR), VALUE :: plan, stream, zu, e2u, e3u, zv, e1v, e3v, e31d, fmask, dpsi8
+       INTEGER(C_INT), VALUE :: iiref, ijref, in_space, out_space ; REAL(C_FLOAT), INTENT(out) :: psi4(*)
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_psi_destroy(plan) BIND(C, name='cdft_psi_destroy')
+       IMPORT ; TYPE(C_PTR), VALUE :: plan
+     END FUNCTION
+     ! ---- cdfvT ----------------------------------------------------------------------------
+     INTEGER(C_INT) FUNCTION cdft_vt_compute(u, v, t, s, e3u, e3v, fstride, nframes, npiglo, npjglo, npk, in_space, &
+          &                                  vt, vs, ut, us, e3um, e3vm, out_is_r4, out_space, stream)                &
+          &         BIND(C, name='cdft_vt_compute')
+       IMPORT ; REAL(C_FLOAT), INTENT(in) :: u(*), v(*), t(*), s(*) ; TYPE(C_PTR), VALUE :: e3u, e3v, e3um, e3vm, stream
+       INTEGER(C_INT64_T), VALUE :: fstride ; INTEGER(C_INT), VALUE :: nframes, npiglo, npjglo, npk, in_space
+       TYPE(C_PTR), VALUE :: vt, vs, ut, us ; INTEGER(C_INT), VALUE :: out_is_r4, out_space
+     END FUNCTION
+     ! ---- cdfcurl --------------------------------------------------------------------------
+     INTEGER(C_INT) FUNCTION cdft_curl_create(plan, npiglo, npjglo) BIND(C, name='cdft_curl_create')
+       IMPORT ; TYPE(C_PTR), INTENT(out) :: plan ; INTEGER(C_INT), VALUE :: npiglo, npjglo
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_curl_set_mesh(plan, e1u, e2v, e1f, e2f, ff, lperio, memspace, stream) &
+          &         BIND(C, name='cdft_curl_set_mesh')
+       IMPORT ; TYPE(C_PTR), VALUE :: plan, stream, ff ; REAL(C_FLOAT), INTENT(in) :: e1u(*), e2v(*), e1f(*), e2f(*)
+       INTEGER(C_INT), VALUE :: lperio, memspace
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_curl_compute(plan, un, vn, nlev, in_space, ltpoint, rotn, out_is_r8, out_space, stream) &
+          &         BIND(C, name='cdft_curl_compute')
+       IMPORT ; TYPE(C_PTR), VALUE :: plan, stream, rotn ; REAL(C_FLOAT), INTENT(in) :: un(*), vn(*)
+       INTEGER(C_INT), VALUE :: nlev, in_space, ltpoint, out_is_r8, out_space
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_curl_destroy(plan) BIND(C, name='cdft_curl_destroy')
+       IMPORT ; TYPE(C_PTR), VALUE :: plan
+     END FUNCTION
+     INTEGER(C_SIZE_T) FUNCTION hip_strlen(s) BIND(C, name='strlen')
+       IMPORT ; TYPE(C_PTR), VALUE :: s
+     END FUNCTION
+  END INTERFACE
+
+CONTAINS
+
+  SUBROUTINE hip_check(kstatus, cdwhere)
+    !! non-zero status of a libcdftools_hip call: print its message and stop like a NetCDF failure
+    INTEGER(C_INT),   INTENT(in) :: kstatus
+    CHARACTER(LEN=*), INTENT(in) :: cdwhere
+    TYPE(C_PTR) :: p
+    CHARACTER(KIND=C_CHAR), POINTER :: c(:)
+    CHARACTER(LEN=512) :: cl
+    INTEGER :: i, n
+    IF ( kstatus == CDFT_OK ) RETURN
+    cl = ' '
+    p = cdft_last_error()
+    IF ( C_ASSOCIATED(p) ) THEN
+       n = MIN(INT(hip_strlen(p)), LEN(cl))
+       CALL C_F_POINTER(p, c, (/ n /))
+       DO i = 1, n ; cl(i:i) = c(i) ; END DO
+    ENDIF
+    PRINT *, ' ERROR in ', TRIM(cdwhere), ' : libcdftools_hip status ', kstatus
+    PRINT *, ' ', TRIM(cl)
+    STOP 98
+  END SUBROUTINE hip_check
+
+END MODULE cdftools_hip

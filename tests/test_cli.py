@@ -1,0 +1,91 @@
+"""The Fortran drop-in programs (cdftools_amd/bin/*, built by cdftools_amd/fortran/Makefile): process
+contract of SURVEY.md 8b -- usage on no arguments, STOP 99 on an unknown option or a missing file --
+and, on the GPU, whole runs on NEMO-style NetCDF files checked against the oracle through the
+bundled NetCDF backend (files written and read back with scipy, an independent implementation)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+from scipy.io import netcdf_file
+
+import nemo_files
+import oracle_lib
+import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "cdftools_amd", "bin")
+
+
+@pytest.fixture(scope="module")
+def tools():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "cdftools_amd", "netcdf")], stdout=subprocess.DEVNULL)
+    if not os.path.exists(os.path.join(ROOT, "cdftools_amd", "lib", "libcdftools_hip.so")):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "cdftools_amd", "csrc"), "-j8"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "cdftools_amd", "fortran")], stdout=subprocess.DEVNULL)
+    return BIN
+
+
+def run(tool, args, cwd, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    p = subprocess.run([os.path.join(BIN, tool)] + args, cwd=cwd, env=e, capture_output=True, text=True, timeout=600)
+    return p.returncode, p.stdout, p.stderr
+
+
+PROGRAMS = [t for t in ("cdfmoc", "cdfheatc", "cdfcurl", "cdfsig0", "cdfsigi", "cdfpsi", "cdfmhst", "cdfvT")
+            if os.path.exists(os.path.join(ROOT, "cdftools_amd", "fortran", t + ".f90"))]
+
+
+@pytest.mark.parametrize("tool", PROGRAMS)
+def test_usage_unknown_option_and_missing_file(tools, tmp_path, tool):
+    rc, out, _ = run(tool, [], tmp_path)
+    assert rc == 0 and f"usage : {tool}" in out                     # README.md:49 of the reference
+    rc, out, _ = run(tool, ["-thisisnotanoption"], tmp_path)
+    assert rc == 99 and "unknown option" in out                      # e.g. src/cdfmoc.f90:232
+    first = {"cdfmoc": "-v", "cdfheatc": "-f", "cdfcurl": "-u", "cdfsig0": "-t", "cdfsigi": "-t", "cdfpsi": "-u",
+             "cdfmhst": "-vt", "cdfvT": "-c"}[tool]
+    extra = {"cdfcurl": ["U.nc", "vozocrtx", "-v", "V.nc", "vomecrty", "-l", "1"], "cdfvT": ["SYN", "-l", "y0001"],
+             "cdfsigi": ["T.nc", "-r", "2000"]}.get(tool, ["nothere.nc"])
+    rc, out, _ = run(tool, [first] + extra, tmp_path)
+    assert rc in (97, 99) and "missing" in out                       # src/cdfio.F90:3063, src/modutils.f90:111
+
+
+def test_names_can_be_redirected_by_environment(tools, tmp_path):
+    rc, out, _ = run("cdfmoc", ["-v", "nothere.nc"], tmp_path, env={"CDFT_MESH_HGR": "my_hgr.nc"})
+    assert rc == 99 and "my_hgr.nc is missing" in out                # src/modcdfnames.F90:376
+
+
+def read_nc(path):
+    with netcdf_file(path, "r", mmap=False) as f:
+        return {k: np.array(v[:]) for k, v in f.variables.items()}, {k: dict(v._attributes) for k, v in f.variables.items()}, dict(f.dimensions)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("basins", [True, False])
+def test_cdfmoc_end_to_end(tools, tmp_path, basins):
+    g, rec = nemo_files.make_case(str(tmp_path), basins=basins)
+    npk, npj, npi = g["tmask"].shape
+    rc, out, err = run("cdfmoc", ["-v", "SYN_y0001_gridV.nc"], tmp_path, env={"CDFT_HOST_GB": "0.000001"})
+    assert rc == 0, out + err
+    assert f"npiglo = {npi}".replace(" ", "") in out.replace(" ", "")
+    var, att, dims = read_nc(os.path.join(tmp_path, "moc.nc"))
+    assert dims["x"] == 1 and dims["y"] == npj and dims["depthw"] == npk and dims["time_counter"] is None
+    e1v, e3v, ib = synth.moc_inputs(g, nbasins=5 if basins else 1)
+    ref = oracle_lib.moc(e1v, e3v, ib, rec["v"])                       # (npt,npk,npj,nb)
+    names = ["zomsfglo", "zomsfatl", "zomsfinp", "zomsfind", "zomsfpac"] if basins else ["zomsfglo"]
+    for b, nm in enumerate(names):
+        got = var[nm][:, :, :, 0]
+        want = ref[..., b].astype(np.float32)
+        assert np.all(np.abs(got - want) <= np.spacing(np.abs(want))), nm   # r8 -> r4 on write: <= 1 ulp(r4)
+        assert att[nm]["units"] == b"Sverdrup" and att[nm]["_FillValue"] == np.float32(99999.0)
+    if basins:
+        want = (ref[..., 0] - ref[..., 1]).astype(np.float32)
+        assert np.all(np.abs(var["zomsfinp0"][:, :, :, 0] - want) <= np.spacing(np.abs(want)) + 1e-30)
+    assert np.array_equal(var["depthw"], -g["gdepw_1d"])                 # src/cdfmoc.f90:309
+    assert np.allclose(var["time_counter"], [86400.0 * 30, 86400.0 * 60])
+    # batching several records per GPU call gives the same file
+    rc, _, _ = run("cdfmoc", ["-v", "SYN_y0001_gridV.nc", "-o", "moc2.nc"], tmp_path)
+    assert rc == 0
+    var2, _, _ = read_nc(os.path.join(tmp_path, "moc2.nc"))
+    assert all(np.array_equal(var[k], var2[k]) for k in var)

@@ -1,0 +1,169 @@
+"""The bundled classic-NetCDF backend (cdftools_amd/netcdf/ncclassic.c, the layer under cdfio.F90)
+against an independent implementation, scipy.io.netcdf_file, in both directions, for CDF-1 and CDF-2;
+CDF-5 (which scipy cannot read) round-trips through the backend itself.  CPU only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+from scipy.io import netcdf_file
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "cdftools_amd", "netcdf")
+LIB = os.path.join(ROOT, "cdftools_amd", "lib", "libncclassic.so")
+BYTE, CHAR, SHORT, INT, FLOAT, DOUBLE = 1, 2, 3, 4, 5, 6
+NPT = {BYTE: np.int8, SHORT: np.int16, INT: np.int32, FLOAT: np.float32, DOUBLE: np.float64}
+
+
+@pytest.fixture(scope="module")
+def nc():
+    subprocess.check_call(["make", "-C", SRC], stdout=subprocess.DEVNULL)
+    lib = C.CDLL(LIB)
+    lib.ncc_strerror.restype = C.c_char_p
+    return lib
+
+
+def ok(lib, rc):
+    assert rc == 0, lib.ncc_strerror(rc).decode()
+
+
+def sz(*v):
+    return (C.c_size_t * len(v))(*v)
+
+
+def write_sample(lib, path, fmt):
+    ncid = C.c_int()
+    ok(lib, lib.ncc_create(path.encode(), fmt, 1, C.byref(ncid)))
+    ids = {}
+    for name, n in (("time_counter", 0), ("deptht", 3), ("y", 4), ("x", 5)):
+        d = C.c_int()
+        ok(lib, lib.ncc_def_dim(ncid, name.encode(), C.c_size_t(n), C.byref(d)))
+        ids[name] = d.value
+    v = {}
+    for name, typ, dims in (("nav_lon", FLOAT, ("y", "x")), ("deptht", FLOAT, ("deptht",)),
+                            ("time_counter", DOUBLE, ("time_counter",)),
+                            ("votemper", FLOAT, ("time_counter", "deptht", "y", "x")),
+                            ("tmask", BYTE, ("time_counter", "deptht", "y", "x")),
+                            ("sossheig", SHORT, ("time_counter", "y", "x"))):
+        vid = C.c_int()
+        di = (C.c_int * len(dims))(*[ids[d] for d in dims])
+        ok(lib, lib.ncc_def_var(ncid, name.encode(), typ, len(dims), di, C.byref(vid)))
+        v[name] = vid.value
+    ok(lib, lib.ncc_put_att(ncid, v["votemper"], b"units", CHAR, 4, CHAR, b"degC"))
+    fill = np.array([9999.0], np.float32)
+    ok(lib, lib.ncc_put_att(ncid, v["votemper"], b"_FillValue", FLOAT, 1, FLOAT, fill.ctypes.data_as(C.c_void_p)))
+    sf = np.array([0.01], np.float64)
+    ok(lib, lib.ncc_put_att(ncid, v["sossheig"], b"scale_factor", FLOAT, 1, DOUBLE, sf.ctypes.data_as(C.c_void_p)))
+    ok(lib, lib.ncc_put_att(ncid, -1, b"history", CHAR, 7, CHAR, b"created"))
+    ok(lib, lib.ncc_enddef(ncid))
+    rng = np.random.default_rng(3)
+    data = {"nav_lon": rng.random((4, 5)).astype(np.float32), "deptht": np.array([5, 15, 30], np.float32),
+            "time_counter": np.array([86400.0, 172800.0]), "votemper": rng.random((2, 3, 4, 5)).astype(np.float32),
+            "tmask": (rng.random((2, 3, 4, 5)) > 0.5).astype(np.int8),
+            "sossheig": rng.integers(-300, 300, (2, 4, 5)).astype(np.int16)}
+    mt = {np.dtype(np.float32): FLOAT, np.dtype(np.float64): DOUBLE, np.dtype(np.int8): BYTE, np.dtype(np.int16): SHORT}
+    for name, a in data.items():
+        if name in ("votemper", "tmask"):        # level by level, record by record, like cdfio's putvar
+            for t in range(2):
+                for k in range(3):
+                    sl = np.ascontiguousarray(a[t, k])
+                    ok(lib, lib.ncc_put_vara(ncid, v[name], sz(t, k, 0, 0), sz(1, 1, 4, 5), mt[a.dtype],
+                                             sl.ctypes.data_as(C.c_void_p)))
+        else:
+            ok(lib, lib.ncc_put_vara(ncid, v[name], sz(*([0] * a.ndim)), sz(*a.shape), mt[a.dtype],
+                                     a.ctypes.data_as(C.c_void_p)))
+    ok(lib, lib.ncc_close(ncid))
+    return data
+
+
+@pytest.mark.parametrize("fmt", [1, 2])
+def test_files_written_by_the_backend_are_read_by_scipy(nc, tmp_path, fmt):
+    path = str(tmp_path / "w.nc")
+    data = write_sample(nc, path, fmt)
+    with netcdf_file(path, "r", mmap=False) as f:
+        assert f.version_byte == fmt
+        assert f.dimensions["time_counter"] is None and f.dimensions["x"] == 5
+        for name, a in data.items():
+            assert np.array_equal(f.variables[name][:], a), name
+        assert f.variables["votemper"].units == b"degC"
+        assert f.variables["votemper"]._FillValue == np.float32(9999.0)
+        assert abs(f.variables["sossheig"].scale_factor - 0.01) < 1e-9
+        assert f.history == b"created"
+
+
+@pytest.mark.parametrize("fmt", [1, 2])
+def test_files_written_by_scipy_are_read_by_the_backend(nc, tmp_path, fmt):
+    path = str(tmp_path / "r.nc")
+    rng = np.random.default_rng(1)
+    want = rng.random((3, 2, 4, 6)).astype(np.float32)
+    mask = (rng.random((2, 4, 6)) > 0.4).astype(np.int8)
+    with netcdf_file(path, "w", version=fmt) as f:
+        f.createDimension("time_counter", None)
+        f.createDimension("z", 2); f.createDimension("y", 4); f.createDimension("x", 6)
+        v = f.createVariable("vomecrty", "f4", ("time_counter", "z", "y", "x"))
+        v[:] = want
+        v.missing_value = np.float32(1e20)
+        m = f.createVariable("vmask", "i1", ("z", "y", "x"))
+        m[:] = mask
+        t = f.createVariable("time_counter", "f8", ("time_counter",))
+        t[:] = [1.0, 2.0, 3.0]
+        t.units = "seconds since 1950-01-01"
+    ncid = C.c_int()
+    ok(nc, nc.ncc_open(path.encode(), 0, C.byref(ncid)))
+    nd, nv, na, un = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    ok(nc, nc.ncc_inq(ncid, C.byref(nd), C.byref(nv), C.byref(na), C.byref(un)))
+    assert (nd.value, nv.value) == (4, 3)
+    ln = C.c_size_t()
+    name = C.create_string_buffer(256)
+    ok(nc, nc.ncc_inq_dim(ncid, un.value, name, C.byref(ln)))
+    assert name.value == b"time_counter" and ln.value == 3
+    vid = C.c_int()
+    ok(nc, nc.ncc_inq_varid(ncid, b"vomecrty", C.byref(vid)))
+    slab = np.empty((4, 6), np.float32)                      # getvar: one level of one record
+    ok(nc, nc.ncc_get_vara(ncid, vid, sz(2, 1, 0, 0), sz(1, 1, 4, 6), FLOAT, slab.ctypes.data_as(C.c_void_p)))
+    assert np.array_equal(slab, want[2, 1])
+    win = np.empty((2, 3), np.float32)                       # zoom window (kimin/kjmin)
+    ok(nc, nc.ncc_get_vara(ncid, vid, sz(0, 0, 1, 2), sz(1, 1, 2, 3), FLOAT, win.ctypes.data_as(C.c_void_p)))
+    assert np.array_equal(win, want[0, 0, 1:3, 2:5])
+    mv = np.empty(1, np.float32)
+    ok(nc, nc.ncc_get_att(ncid, vid, b"missing_value", FLOAT, mv.ctypes.data_as(C.c_void_p)))
+    assert mv[0] == np.float32(1e20)
+    ok(nc, nc.ncc_inq_varid(ncid, b"vmask", C.byref(vid)))
+    asf = np.empty((4, 6), np.float32)                       # byte mask converted to r4 on read
+    ok(nc, nc.ncc_get_vara(ncid, vid, sz(1, 0, 0), sz(1, 4, 6), FLOAT, asf.ctypes.data_as(C.c_void_p)))
+    assert np.array_equal(asf, mask[1].astype(np.float32))
+    assert nc.ncc_inq_varid(ncid, b"nothere", C.byref(vid)) == -49
+    assert nc.ncc_get_vara(ncid, 0, sz(3, 0, 0, 0), sz(1, 1, 4, 6), FLOAT, slab.ctypes.data_as(C.c_void_p)) != 0
+    ok(nc, nc.ncc_close(ncid))
+    assert nc.ncc_open(str(tmp_path / "missing.nc").encode(), 0, C.byref(ncid)) == -90
+
+
+def test_cdf5_round_trip_and_redef_with_data(nc, tmp_path):
+    path = str(tmp_path / "c5.nc")
+    data = write_sample(nc, path, 5)
+    assert open(path, "rb").read(4) == b"CDF\x05"
+    ncid = C.c_int()
+    ok(nc, nc.ncc_open(path.encode(), 1, C.byref(ncid)))
+    # grow the header after data exist (cdfio re-enters define mode to add attributes, e.g. iweight)
+    ok(nc, nc.ncc_redef(ncid))
+    big = b"x" * 9000
+    ok(nc, nc.ncc_put_att(ncid, -1, b"long_history", CHAR, len(big), CHAR, big))
+    iw = np.array([12], np.int32)
+    ok(nc, nc.ncc_put_att(ncid, 3, b"iweight", INT, 1, INT, iw.ctypes.data_as(C.c_void_p)))
+    ok(nc, nc.ncc_enddef(ncid))
+    iw[0] = 24                                               # in-place overwrite in data mode
+    ok(nc, nc.ncc_put_att(ncid, 3, b"iweight", INT, 1, INT, iw.ctypes.data_as(C.c_void_p)))
+    ok(nc, nc.ncc_close(ncid))
+    ok(nc, nc.ncc_open(path.encode(), 0, C.byref(ncid)))
+    for name, a in data.items():
+        vid = C.c_int()
+        ok(nc, nc.ncc_inq_varid(ncid, name.encode(), C.byref(vid)))
+        got = np.empty_like(a)
+        mt = {np.dtype(np.float32): FLOAT, np.dtype(np.float64): DOUBLE, np.dtype(np.int8): BYTE, np.dtype(np.int16): SHORT}
+        ok(nc, nc.ncc_get_vara(ncid, vid, sz(*([0] * a.ndim)), sz(*a.shape), mt[a.dtype], got.ctypes.data_as(C.c_void_p)))
+        assert np.array_equal(got, a), name
+    out = np.zeros(1, np.int32)
+    ok(nc, nc.ncc_get_att(ncid, 3, b"iweight", INT, out.ctypes.data_as(C.c_void_p)))
+    assert out[0] == 24
+    ok(nc, nc.ncc_close(ncid))
