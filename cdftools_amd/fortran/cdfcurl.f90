@@ -1,0 +1,250 @@
+PROGRAM cdfcurl
+  !!======================================================================
+  !!                     ***  PROGRAM  cdfcurl  ***
+  !! Relative vorticity (curl of the horizontal velocity) at F points, for a list of levels.
+  !!
+  !! Drop-in for the reference tool (src/cdfcurl.f90): same options (-u file var, -v file var, -l levels,
+  !! -T, -8, -surf, -overf, -nometric, -nc4, -o), same curl.nc (socurl | socurlt | socurloverf, float or
+  !! double, :395-438).  The level loop :242-304 runs on the GPU for all selected levels of a record at
+  !! once (cdft_curl_*, bit-identical to the reference's r4 expression).
+  !! Not carried: level 0 (forcing fields on the A grid, :250-258) stops with an explicit message.
+  !!======================================================================
+  USE ISO_C_BINDING
+  USE cdfio
+  USE modcdfnames
+  USE cdftools_hip
+  IMPLICIT NONE
+
+  INTEGER(KIND=4) :: narg, ijarg, ierr, jt, jk, npiglo, npjglo, npk, npt, nlev = 0, ncout
+  INTEGER(KIND=4) :: ipk(1), id_varout(1)
+  INTEGER(KIND=4), ALLOCATABLE :: nilev(:)
+  REAL(KIND=4), ALLOCATABLE :: e1u(:,:), e1f(:,:), e2v(:,:), e2f(:,:), zlon(:,:), zlat(:,:)
+  REAL(KIND=4), ALLOCATABLE :: un(:,:,:), vn(:,:,:), gdep(:)
+  REAL(KIND=4), ALLOCATABLE, TARGET :: zrot4(:,:,:)
+  REAL(KIND=8), ALLOCATABLE, TARGET :: drotn(:,:,:), dl_ff(:,:)
+  REAL(KIND=8), ALLOCATABLE :: dtim(:), zdep(:)
+  REAL(KIND=8) :: dl_pi, dl_omega
+  CHARACTER(LEN=256) :: cf_ufil = 'none', cf_vfil = 'none', cf_out = 'curl.nc', cv_u = 'none', cv_v = 'none', cldum
+  TYPE(variable) :: stypvar(1)
+  TYPE(C_PTR) :: plan, pff
+  LOGICAL :: lchk = .FALSE., lperio = .FALSE., ldblpr = .FALSE., lnc4 = .FALSE., ltpoint = .FALSE., lsurf = .FALSE.
+  LOGICAL :: loverf = .FALSE., l_metric = .TRUE.
+  !!----------------------------------------------------------------------
+  CALL ReadCdfNames()
+  narg = COMMAND_ARGUMENT_COUNT()
+  IF ( narg == 0 ) THEN
+     PRINT *, ' usage : cdfcurl -u U-file U-var -v V-file V-var -l levlist [-T] [-8]...'
+     PRINT *, '           ... [-surf] [-overf] [-nc4] [-o OUT-file ] [-nometric]'
+     PRINT *, '      '
+     PRINT *, '     PURPOSE :'
+     PRINT *, '       Compute the curl of a vector field at the specified levels (at F points, or at T points'
+     PRINT *, '       with -T).  MI355X build: the stencil runs on the GPU.'
+     PRINT *, '      '
+     PRINT *, '     ARGUMENTS :'
+     PRINT *, '       -u U-file U-var : file and variable of the zonal component.'
+     PRINT *, '       -v V-file V-var : file and variable of the meridional component.'
+     PRINT *, '       -l levlist      : levels, e.g. 1  or  1,3,5  or  1-20  or  1-3,10-12.'
+     PRINT *, '      '
+     PRINT *, '     OPTIONS :'
+     PRINT *, '       [-T]        : curl at T points instead of F points'
+     PRINT *, '       [-8]        : double precision output'
+     PRINT *, '       [-surf]     : single-level C-grid files (no vertical dimension)'
+     PRINT *, '       [-overf]    : curl normalised by the local Coriolis parameter'
+     PRINT *, '       [-nometric] : unit metrics (output ', 'curl_grid.nc', ')'
+     PRINT *, '       [-nc4]      : accepted; the bundled NetCDF backend writes classic files'
+     PRINT *, '       [-o OUT-file] : output file instead of ', TRIM(cf_out)
+     PRINT *, '      '
+     PRINT *, '     REQUIRED FILES :'
+     PRINT *, '       ', TRIM(cn_fhgr)
+     PRINT *, '      '
+     PRINT *, '     OUTPUT : '
+     PRINT *, '       netcdf file : ', TRIM(cf_out)
+     PRINT *, '         variables : socurl or socurlt (if -T option), units : s^-1'
+     PRINT *, '            or socurloverf, no units (if -overf option)'
+     STOP
+  ENDIF
+
+  ijarg = 1
+  DO WHILE ( ijarg <= narg )
+     CALL GET_COMMAND_ARGUMENT(ijarg, cldum) ; ijarg = ijarg + 1
+     SELECT CASE ( cldum )
+     CASE ( '-u'        ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cf_ufil) ; ijarg = ijarg + 1
+        ;                   CALL GET_COMMAND_ARGUMENT(ijarg, cv_u   ) ; ijarg = ijarg + 1
+     CASE ( '-v'        ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cf_vfil) ; ijarg = ijarg + 1
+        ;                   CALL GET_COMMAND_ARGUMENT(ijarg, cv_v   ) ; ijarg = ijarg + 1
+     CASE ( '-l'        ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cldum  ) ; ijarg = ijarg + 1
+        ;                   CALL ParseLevel(cldum)
+     CASE ( '-nc4'      ) ; lnc4    = .TRUE.
+     CASE ( '-T'        ) ; ltpoint = .TRUE.
+     CASE ( '-8'        ) ; ldblpr  = .TRUE.
+     CASE ( '-surf'     ) ; lsurf   = .TRUE.
+     CASE ( '-overf'    ) ; loverf  = .TRUE.
+     CASE ( '-nometric' ) ; l_metric = .FALSE. ; cf_out = 'curl_grid.nc'
+     CASE ( '-o'        ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cf_out) ; ijarg = ijarg + 1
+     CASE DEFAULT         ; PRINT *, ' ERROR : ', TRIM(cldum), ' : unknown option.' ; STOP 99
+     END SELECT
+  END DO
+  IF ( ltpoint .AND. loverf ) THEN
+     PRINT *, ' ERROR : You might choose only one of -T or -overf option !'
+     STOP 99
+  ENDIF
+
+  IF ( l_metric ) lchk = chkfile(cn_fhgr) .OR. lchk
+  lchk = chkfile(cf_ufil) .OR. lchk
+  lchk = chkfile(cf_vfil) .OR. lchk
+  IF ( lchk ) STOP 99
+
+  npiglo = getdim(cf_ufil, cn_x)
+  npjglo = getdim(cf_ufil, cn_y)
+  npk    = getdim(cf_ufil, cn_z)
+  npt    = getdim(cf_ufil, cn_t)
+
+  PRINT *, 'npiglo = ', npiglo
+  PRINT *, 'npjglo = ', npjglo
+  PRINT *, 'npk    = ', npk
+  PRINT *, 'npt    = ', npt
+  PRINT *, 'nlev   = ', nlev
+
+  IF ( npk == 0 .AND. nlev > 0 .AND. .NOT. lsurf ) THEN
+     PRINT *, 'Problem : npk = 0 and lev > 0 STOP 99'
+     PRINT *, '  Use -surf option is dealing with single level file on C grid '
+     STOP 99
+  ENDIF
+  IF ( lsurf ) THEN
+     nlev = 1
+     IF ( ALLOCATED(nilev) ) DEALLOCATE(nilev)
+     ALLOCATE( nilev(1) )
+     npk = 1 ; nilev(1) = 1
+  ENDIF
+  IF ( .NOT. ALLOCATED(nilev) ) THEN
+     PRINT *, ' ERROR : option -l levlist is mandatory.' ; STOP 99
+  ENDIF
+  IF ( nilev(1) == 0 ) THEN
+     PRINT *, ' ERROR : level 0 (forcing fields on the A grid) is not available in the MI355X build of cdfcurl.'
+     STOP 99
+  ENDIF
+  IF ( npt == 0 ) THEN
+     PRINT *, 'npt=0, assume 1'
+     npt = 1
+  ENDIF
+  DO jk = 1, nlev                                            ! the list stops at the first level >= npk
+     IF ( nilev(jk) >= npk ) THEN
+        nlev = jk
+        EXIT
+     ENDIF
+  END DO
+  PRINT *, 'NLEV', nlev
+
+  ALLOCATE( e1u(npiglo,npjglo), e1f(npiglo,npjglo), e2v(npiglo,npjglo), e2f(npiglo,npjglo) )
+  ALLOCATE( zlon(npiglo,npjglo), zlat(npiglo,npjglo), un(npiglo,npjglo,nlev), vn(npiglo,npjglo,nlev) )
+  ALLOCATE( dtim(npt), gdep(nlev), zdep(MAX(npk, 1)) )
+  IF ( ldblpr ) THEN ; ALLOCATE( drotn(npiglo,npjglo,nlev) ) ; ELSE ; ALLOCATE( zrot4(npiglo,npjglo,nlev) ) ; ENDIF
+
+  IF ( l_metric ) THEN
+     e1u  = getvar(cn_fhgr, cn_ve1u, 1, npiglo, npjglo)
+     e1f  = getvar(cn_fhgr, cn_ve1f, 1, npiglo, npjglo)
+     e2v  = getvar(cn_fhgr, cn_ve2v, 1, npiglo, npjglo)
+     e2f  = getvar(cn_fhgr, cn_ve2f, 1, npiglo, npjglo)
+     zlon = getvar(cn_fhgr, cn_glamf, 1, npiglo, npjglo)
+     zlat = getvar(cn_fhgr, cn_gphif, 1, npiglo, npjglo)
+  ELSE
+     e1u = 1. ; e1f = 1. ; e2v = 1. ; e2f = 1. ; zlon = 10. ; zlat = 10.
+  ENDIF
+  pff = C_NULL_PTR
+  IF ( loverf ) THEN                                         ! src/cdfcurl.f90:224-227
+     ALLOCATE( dl_ff(npiglo,npjglo) )
+     dl_pi = ACOS(-1.d0)
+     dl_omega = 2 * dl_pi / 86400.d0
+     dl_ff = 2 * dl_omega * SIN( zlat * dl_pi / 180.d0 )
+     pff = C_LOC(dl_ff)
+  ENDIF
+  IF ( lsurf ) THEN
+     gdep(1) = 0.
+  ELSE
+     zdep(:) = getvar1d(cf_ufil, cn_vdepthu, npk)
+     DO jk = 1, nlev
+        gdep(jk) = REAL(zdep(nilev(jk)), 4)
+     END DO
+  ENDIF
+  IF ( zlon(1,1) == zlon(npiglo-1,1) ) lperio = .TRUE.       ! E-W periodicity, :238
+
+  CALL CreateOutput
+  CALL hip_check(cdft_curl_create(plan, npiglo, npjglo), 'cdft_curl_create')
+  CALL hip_check(cdft_curl_set_mesh(plan, e1u, e2v, e1f, e2f, pff, MERGE(1_C_INT, 0_C_INT, lperio), CDFT_MEM_HOST, &
+       &         C_NULL_PTR), 'cdft_curl_set_mesh')
+
+  DO jt = 1, npt
+     IF ( MOD(jt, 100) == 0 ) PRINT *, jt, '/', npt
+     DO jk = 1, nlev
+        PRINT *, TRIM(cf_ufil), ' ', TRIM(cv_u), ' ', jk, nilev(jk), npiglo, npjglo, jt
+        un(:,:,jk) = getvar(cf_ufil, cv_u, nilev(jk), npiglo, npjglo, ktime=jt)
+        vn(:,:,jk) = getvar(cf_vfil, cv_v, nilev(jk), npiglo, npjglo, ktime=jt)
+     END DO
+     IF ( ldblpr ) THEN
+        CALL hip_check(cdft_curl_compute(plan, un, vn, nlev, CDFT_MEM_HOST, MERGE(1_C_INT, 0_C_INT, ltpoint),        &
+             &         C_LOC(drotn), 1_C_INT, CDFT_MEM_HOST, C_NULL_PTR), 'cdft_curl_compute')
+     ELSE
+        CALL hip_check(cdft_curl_compute(plan, un, vn, nlev, CDFT_MEM_HOST, MERGE(1_C_INT, 0_C_INT, ltpoint),        &
+             &         C_LOC(zrot4), 0_C_INT, CDFT_MEM_HOST, C_NULL_PTR), 'cdft_curl_compute')
+     ENDIF
+     DO jk = 1, nlev
+        IF ( ldblpr ) THEN ; ierr = putvar(ncout, id_varout(1), drotn(:,:,jk), jk, npiglo, npjglo, ktime=jt)
+        ELSE               ; ierr = putvar(ncout, id_varout(1), zrot4(:,:,jk), jk, npiglo, npjglo, ktime=jt)
+        ENDIF
+     END DO
+  END DO
+  ierr = cdft_curl_destroy(plan)
+  ierr = closeout(ncout)
+
+CONTAINS
+
+  SUBROUTINE ParseLevel(cdum)
+    !! '5', '1,3,5', '1-20', '1-3,10-12', '10-' (open ended, capped at 300) -> nilev(1:nlev)
+    CHARACTER(LEN=*), INTENT(in) :: cdum
+    INTEGER(KIND=4) :: ilev(350), ia, ib, ic, id, i1, i2, jl
+    nlev = 0 ; ia = 1
+    DO WHILE ( ia <= LEN_TRIM(cdum) )
+       ib = INDEX(cdum(ia:), ',')
+       IF ( ib == 0 ) THEN ; ic = LEN_TRIM(cdum) ; ELSE ; ic = ia + ib - 2 ; ENDIF
+       id = INDEX(cdum(ia:ic), '-')
+       IF ( id == 0 ) THEN
+          READ(cdum(ia:ic), *) i1 ; i2 = i1
+       ELSE IF ( ia + id - 1 == ic ) THEN
+          READ(cdum(ia:ic-1), *) i1 ; i2 = 300
+       ELSE
+          READ(cdum(ia:ia+id-2), *) i1 ; READ(cdum(ia+id:ic), *) i2
+       ENDIF
+       DO jl = i1, i2
+          IF ( nlev < 350 ) THEN ; nlev = nlev + 1 ; ilev(nlev) = jl ; ENDIF
+       END DO
+       ia = ic + 2
+    END DO
+    IF ( ALLOCATED(nilev) ) DEALLOCATE(nilev)
+    ALLOCATE( nilev(nlev) )
+    nilev(:) = ilev(1:nlev)
+  END SUBROUTINE ParseLevel
+
+  SUBROUTINE CreateOutput
+    !! src/cdfcurl.f90:395-438
+    ipk(1) = nlev
+    stypvar(1)%ichunk = (/ npiglo, MAX(1, npjglo / 30), 1, 1 /)
+    IF      ( ltpoint ) THEN ; stypvar(1)%cname = 'socurlt'     ; stypvar(1)%cunits = 's-1'
+    ELSE IF ( loverf  ) THEN ; stypvar(1)%cname = 'socurloverf' ; stypvar(1)%cunits = '-'
+    ELSE                     ; stypvar(1)%cname = 'socurl'      ; stypvar(1)%cunits = 's-1'
+    ENDIF
+    stypvar(1)%cprecision = 'r4' ; IF ( ldblpr ) stypvar(1)%cprecision = 'r8'
+    stypvar(1)%rmissing_value    = 0.
+    stypvar(1)%valid_min         = -1000.
+    stypvar(1)%valid_max         =  1000.
+    stypvar(1)%clong_name        = 'Relative_Vorticity (curl)'
+    stypvar(1)%cshort_name       = 'socurl'
+    stypvar(1)%conline_operation = 'N/A'
+    stypvar(1)%caxis             = 'TYX'
+    ncout = create      (cf_out, cf_ufil, npiglo, npjglo, nlev, ld_nc4=lnc4)
+    ierr  = createvar   (ncout, stypvar, 1, ipk, id_varout, ld_nc4=lnc4)
+    ierr  = putheadervar(ncout, cf_ufil, npiglo, npjglo, nlev, pnavlon=zlon, pnavlat=zlat, pdep=gdep)
+    dtim  = getvar1d(cf_ufil, cn_vtimec, npt)
+    ierr  = putvar1d(ncout, dtim, npt, 'T')
+  END SUBROUTINE CreateOutput
+
+END PROGRAM cdfcurl

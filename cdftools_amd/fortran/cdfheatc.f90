@@ -1,0 +1,216 @@
+PROGRAM cdfheatc
+  !!======================================================================
+  !!                     ***  PROGRAM  cdfheatc  ***
+  !! Heat content of the ocean (or of a sub-domain): rho0 * cp * sum( e1t*e2t*e3t * T * tmask ).
+  !!
+  !! Drop-in for the reference tool (src/cdfheatc.f90): same options (-zoom, -full, -vvl, -mxloption,
+  !! -mxlf, -M, -o), same stdout lines per level and for the totals (:233-243), same heatc.nc
+  !! (heatc3d, heatc2d, heatc3dpervol double, :251-306).  The three SUMs of every level (:225-229) run
+  !! on the GPU for all levels of a record at once (cdft_heatc_*): r4 products as written, r8 sums.
+  !!======================================================================
+  USE ISO_C_BINDING
+  USE cdfio
+  USE modcdfnames
+  USE cdftools_hip
+  IMPLICIT NONE
+
+  INTEGER(KIND=4), PARAMETER :: jp_hc3d = 1, jp_hc2d = 2, jp_hcvol = 3
+  REAL(KIND=4),    PARAMETER :: pprho0 = 1020., ppcp = 4000.       ! src/cdfheatc.f90:39-40
+  INTEGER(KIND=4) :: narg, ijarg, ierr, jt, jk, ik, it
+  INTEGER(KIND=4) :: iimin = 0, iimax = 0, ijmin = 0, ijmax = 0, ikmin = 0, ikmax = 0, mxloption = 0
+  INTEGER(KIND=4) :: npiglo, npjglo, npk, npkk, npt, nvpk, ncout
+  INTEGER(KIND=4), ALLOCATABLE :: ipk(:), id_varout(:)
+  REAL(KIND=4), ALLOCATABLE, TARGET :: e1t(:,:), e2t(:,:), e3t(:,:,:), temp(:,:,:), tmask(:,:,:), rmxldep(:,:)
+  REAL(KIND=4), ALLOCATABLE, TARGET :: gdepw(:), e31d(:), gdepw_sel(:), e31d_sel(:)
+  REAL(KIND=8), ALLOCATABLE :: dtim(:), dsums(:,:)
+  REAL(KIND=8) :: dvol, dsum, dvol2d, dsum2d, dsurf, dl_dum(1,1)
+  CHARACTER(LEN=256) :: cf_tfil = 'none', cf_mfil = 'none', cf_out = 'heatc.nc', cv_msk = 'tmask', cldum
+  TYPE(variable), ALLOCATABLE :: stypvar(:)
+  TYPE(C_PTR) :: plan, pe3t, pe31d, pmxl, pdepw
+  LOGICAL :: lfull = .FALSE., lchk
+  !!----------------------------------------------------------------------
+  CALL ReadCdfNames()
+  narg = COMMAND_ARGUMENT_COUNT()
+  IF ( narg == 0 ) THEN
+     PRINT *, ' usage :  cdfheatc  -f T-file [-mxloption option] [-mxlf MXL-file] ...'
+     PRINT *, '     [-zoom imin imax jmin jmax kmin kmax] [-full] [-o OUT-file]'
+     PRINT *, '     [-M MSK-file VAR-mask ] [-vvl ]'
+     PRINT *, '      '
+     PRINT *, '     PURPOSE :'
+     PRINT *, '       Compute the heat content of the ocean in the specified area (global by default).'
+     PRINT *, '       MI355X build: the masked volume integrals of every level run on the GPU.'
+     PRINT *, '      '
+     PRINT *, '     ARGUMENTS :'
+     PRINT *, '       -f T-file : netcdf file with temperature.'
+     PRINT *, '      '
+     PRINT *, '     OPTIONS :'
+     PRINT *, '       [-zoom imin imax jmin jmax kmin kmax] : sub-domain; a 0 pair means the full range.'
+     PRINT *, '       [-full ]             : full step instead of the default partial step'
+     PRINT *, '       [-mxloption option]  : 1: only in the mixed layer, -1: only below it, 0: ignore (default)'
+     PRINT *, '       [-mxlf MXL-file ]    : file with the mixed layer depth when it is not in T-file'
+     PRINT *, '       [-o OUT-file ]       : output file instead of ', TRIM(cf_out)
+     PRINT *, '       [-M MSK-file VAR-mask] : mask file and variable instead of ', TRIM(cn_fmsk), ' and ', TRIM(cv_msk)
+     PRINT *, '       [-vvl ]              : time-varying vertical metrics (read from T-file)'
+     PRINT *, '      '
+     PRINT *, '     REQUIRED FILES :'
+     PRINT *, '       Files ', TRIM(cn_fhgr), ', ', TRIM(cn_fzgr), ' and ', TRIM(cn_fmsk)
+     PRINT *, '      '
+     PRINT *, '     OUTPUT : '
+     PRINT *, '       Netcdf file : ', TRIM(cf_out), ' with variables heatc3d, heatc2d and heatc3dpervol'
+     PRINT *, '       Standard output : heat content per level and total'
+     STOP
+  ENDIF
+
+  ijarg = 1
+  DO WHILE ( ijarg <= narg )
+     CALL GET_COMMAND_ARGUMENT(ijarg, cldum) ; ijarg = ijarg + 1
+     SELECT CASE ( cldum )
+     CASE ( '-f'         ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cf_tfil) ; ijarg = ijarg + 1
+     CASE ( '-full'      ) ; lfull = .TRUE.
+     CASE ( '-vvl'       ) ; lg_vvl = .TRUE.
+     CASE ( '-mxloption' ) ; mxloption = int_arg()
+     CASE ( '-mxlf'      ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cf_mfil) ; ijarg = ijarg + 1
+     CASE ( '-o'         ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cf_out ) ; ijarg = ijarg + 1
+     CASE ( '-zoom'      ) ; iimin = int_arg() ; iimax = int_arg() ; ijmin = int_arg() ; ijmax = int_arg()
+        ;                    ikmin = int_arg() ; ikmax = int_arg()
+     CASE ( '-M'         ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cn_fmsk) ; ijarg = ijarg + 1
+        ;                    CALL GET_COMMAND_ARGUMENT(ijarg, cv_msk ) ; ijarg = ijarg + 1
+     CASE DEFAULT          ; PRINT *, ' ERROR : ', TRIM(cldum), ' : unknown option.' ; STOP 99
+     END SELECT
+  END DO
+  IF ( cf_mfil == 'none' ) cf_mfil = cf_tfil
+
+  lchk = chkfile(cn_fhgr)
+  lchk = chkfile(cn_fzgr) .OR. lchk
+  lchk = chkfile(cn_fmsk) .OR. lchk
+  lchk = chkfile(cf_tfil) .OR. lchk
+  lchk = chkfile(cf_mfil) .OR. lchk
+  IF ( lchk ) STOP 99
+  IF ( lg_vvl ) THEN
+     cn_fe3t = cf_tfil
+     cn_ve3t = cn_ve3tvvl
+  ENDIF
+
+  npiglo = getdim(cf_tfil, cn_x)
+  npjglo = getdim(cf_tfil, cn_y)
+  npk    = getdim(cf_tfil, cn_z)
+  npt    = getdim(cf_tfil, cn_t)
+  npkk = npk
+  IF ( iimin /= 0 ) THEN ; npiglo = iimax - iimin + 1 ; ELSE ; iimin = 1 ; ENDIF
+  IF ( ijmin /= 0 ) THEN ; npjglo = ijmax - ijmin + 1 ; ELSE ; ijmin = 1 ; ENDIF
+  IF ( ikmin /= 0 ) THEN ; npkk   = ikmax - ikmin + 1 ; ELSE ; ikmin = 1 ; ikmax = npk ; ENDIF
+  nvpk = getvdim(cf_tfil, cn_votemper)
+  IF ( nvpk == 2 ) nvpk = 1
+  IF ( nvpk == 3 ) nvpk = npkk
+
+  PRINT *, 'npiglo = ', npiglo
+  PRINT *, 'npjglo = ', npjglo
+  PRINT *, 'npk    = ', npk
+  PRINT *, 'npt    = ', npt
+  PRINT *, 'nvpk   = ', nvpk
+
+  ALLOCATE( e1t(npiglo,npjglo), e2t(npiglo,npjglo), temp(npiglo,npjglo,nvpk), tmask(npiglo,npjglo,nvpk) )
+  ALLOCATE( gdepw(npk), gdepw_sel(nvpk), dtim(npt), dsums(3,nvpk) )
+  IF ( mxloption /= 0 ) ALLOCATE( rmxldep(npiglo,npjglo) )
+  IF ( lfull ) THEN ; ALLOCATE( e31d(npk), e31d_sel(nvpk) ) ; ELSE ; ALLOCATE( e3t(npiglo,npjglo,nvpk) ) ; ENDIF
+
+  e1t(:,:) = getvar(cn_fhgr, cn_ve1t, 1, npiglo, npjglo, kimin=iimin, kjmin=ijmin)
+  e2t(:,:) = getvar(cn_fhgr, cn_ve2t, 1, npiglo, npjglo, kimin=iimin, kjmin=ijmin)
+  gdepw(:) = getvare3(cn_fzgr, cn_gdepw, npk)
+  gdepw_sel(:) = gdepw(ikmin:ikmin + nvpk - 1)
+  IF ( lfull ) THEN
+     e31d(:) = getvare3(cn_fzgr, cn_ve3t1d, npk)
+     e31d_sel(:) = e31d(ikmin:ikmin + nvpk - 1)
+  ENDIF
+  DO jk = 1, nvpk
+     tmask(:,:,jk) = getvar(cn_fmsk, cv_msk, jk + ikmin - 1, npiglo, npjglo, kimin=iimin, kjmin=ijmin)
+  END DO
+
+  CALL CreateOutput
+  CALL hip_check(cdft_heatc_create(plan, npiglo, npjglo, nvpk), 'cdft_heatc_create')
+
+  DO jt = 1, npt
+     it = 1 ; IF ( lg_vvl ) it = jt
+     dvol = 0.d0
+     dsum = 0.d0
+     PRINT *, 'TIME : ', dtim(jt)
+     pmxl = C_NULL_PTR ; pdepw = C_NULL_PTR
+     IF ( mxloption /= 0 ) THEN
+        rmxldep(:,:) = getvar(cf_mfil, cn_somxl010, 1, npiglo, npjglo, kimin=iimin, kjmin=ijmin, ktime=jt)
+        pmxl = C_LOC(rmxldep) ; pdepw = C_LOC(gdepw_sel)
+     ENDIF
+     DO jk = 1, nvpk
+        ik = jk + ikmin - 1
+        temp(:,:,jk) = getvar(cf_tfil, cn_votemper, ik, npiglo, npjglo, kimin=iimin, kjmin=ijmin, ktime=jt)
+        IF ( .NOT. lfull .AND. (jt == 1 .OR. lg_vvl) ) &
+           &  e3t(:,:,jk) = getvar(cn_fe3t, cn_ve3t, ik, npiglo, npjglo, kimin=iimin, kjmin=ijmin, ktime=it, ldiom=.NOT. lg_vvl)
+     END DO
+     IF ( jt == 1 .OR. lg_vvl ) THEN
+        pe3t = C_NULL_PTR ; pe31d = C_NULL_PTR
+        IF ( lfull ) THEN ; pe31d = C_LOC(e31d_sel) ; ELSE ; pe3t = C_LOC(e3t) ; ENDIF
+        CALL hip_check(cdft_heatc_set_mesh(plan, e1t, e2t, pe3t, pe31d, C_LOC(tmask), 1_C_INT, CDFT_MEM_HOST, C_NULL_PTR), &
+             &         'cdft_heatc_set_mesh')
+     ENDIF
+     CALL hip_check(cdft_heatc_compute(plan, temp, CDFT_MEM_HOST, pmxl, pdepw, INT(mxloption, C_INT), dsums, CDFT_MEM_HOST, &
+          &         C_NULL_PTR), 'cdft_heatc_compute')
+
+     DO jk = 1, nvpk                                       ! src/cdfheatc.f90:225-238
+        ik = jk + ikmin - 1
+        dsurf = dsums(1,jk) ; dvol2d = dsums(2,jk) ; dsum2d = dsums(3,jk)
+        dvol = dvol + dvol2d
+        dsum = dsum + dsum2d
+        IF ( dvol2d /= 0 ) THEN
+           PRINT *, ' Heat Content  at level ', ik, '(', gdepw(ik), ' m) ', pprho0 * ppcp * dsum2d, 'surface = ', dsurf / 1.e6, ' km^2'
+        ELSE
+           PRINT *, ' No points in the water at level ', ik, '(', gdepw(ik), ' m) '
+        ENDIF
+        dl_dum(1,1) = pprho0 * ppcp * dsum2d
+        ierr = putvar(ncout, id_varout(jp_hc2d), dl_dum(:,:), jk, 1, 1, ktime=jt)
+     END DO
+     PRINT *, ' Total Heat content        : ', pprho0 * ppcp * dsum, ' Joules'
+     PRINT *, ' Total Heat content/volume : ', pprho0 * ppcp * dsum / dvol, ' Joules/m3 '
+     dl_dum(1,1) = pprho0 * ppcp * dsum
+     ierr = putvar(ncout, id_varout(jp_hc3d), dl_dum(:,:), 1, 1, 1, ktime=jt)
+     dl_dum(1,1) = dl_dum(1,1) / dvol
+     ierr = putvar(ncout, id_varout(jp_hcvol), dl_dum(:,:), 1, 1, 1, ktime=jt)
+  END DO
+  ierr = cdft_heatc_destroy(plan)
+  ierr = closeout(ncout)
+
+CONTAINS
+
+  INTEGER FUNCTION int_arg()
+    CALL GET_COMMAND_ARGUMENT(ijarg, cldum) ; ijarg = ijarg + 1
+    READ(cldum, *) int_arg
+  END FUNCTION int_arg
+
+  SUBROUTINE CreateOutput
+    !! three scalar-like variables stored as (1,1[,k],t) doubles (src/cdfheatc.f90:251-306)
+    REAL(KIND=4) :: zdumlon(1,1), zdumlat(1,1)
+    ALLOCATE( stypvar(3), ipk(3), id_varout(3) )
+    zdumlon = 0. ; zdumlat = 0.
+    ipk(:) = 1
+    stypvar%scale_factor      = 1.
+    stypvar%add_offset        = 0.
+    stypvar%savelog10         = 0.
+    stypvar%conline_operation = 'N/A'
+    stypvar%caxis             = 'T'
+    stypvar%cprecision        = 'r8'
+    stypvar%rmissing_value    = 0.                         ! left unset by the reference
+    stypvar%valid_min         = 0.
+    stypvar%valid_max         = 0.
+    stypvar(jp_hc3d)%cname  = 'heatc3d'        ; stypvar(jp_hc3d)%cunits  = 'Joules'
+    stypvar(jp_hc3d)%clong_name  = 'Total Heat Content' ; stypvar(jp_hc3d)%cshort_name = 'heatc3d'
+    stypvar(jp_hcvol)%cname = 'heatc3dpervol'  ; stypvar(jp_hcvol)%cunits = 'Joules/m3'
+    stypvar(jp_hcvol)%clong_name = 'Total Heat Content per unit volume' ; stypvar(jp_hcvol)%cshort_name = 'heatc3dpervol'
+    ipk(jp_hc2d) = npkk
+    stypvar(jp_hc2d)%cname  = 'heatc2d'        ; stypvar(jp_hc2d)%cunits  = 'Joules'
+    stypvar(jp_hc2d)%clong_name  = 'Heat Content at each selected level' ; stypvar(jp_hc2d)%cshort_name = 'heatc2d'
+    ncout = create      (cf_out, 'none', 1, 1, npkk, cdep='depthw')
+    ierr  = createvar   (ncout, stypvar, 3, ipk, id_varout)
+    ierr  = putheadervar(ncout, cf_tfil, 1, 1, npkk, pnavlon=zdumlon, pnavlat=zdumlat, pdep=gdepw(ikmin:ikmax), cdep='depthw')
+    dtim  = getvar1d(cf_tfil, cn_vtimec, npt)
+    ierr  = putvar1d(ncout, dtim, npt, 'T')
+  END SUBROUTINE CreateOutput
+
+END PROGRAM cdfheatc

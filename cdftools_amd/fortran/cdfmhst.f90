@@ -1,0 +1,292 @@
+PROGRAM cdfmhst
+  !!======================================================================
+  !!                     ***  PROGRAM  cdfmhst  ***
+  !! Meridional heat (and salt) transport, global and per basin, from V.T and V.S.
+  !!
+  !! Drop-in for the reference tool (src/cdfmhst.f90): same options (-vt | -v -t [-s], -vtvar, -MST, -full,
+  !! -Zdim, -b, -o, -vvl), same mhst.nc (zomht_* [zomst_*] float, PW / T/sec, fill 9999.99, :504-550) and
+  !! the same two ASCII files zonal_heat_trp.dat / zonal_salt_trp.dat (:449-492).  The vertical
+  !! integration and the masked zonal sums (:308-367) run on the GPU (cdft_mhst_*).
+  !!======================================================================
+  USE ISO_C_BINDING
+  USE cdfio
+  USE modcdfnames
+  USE cdftools_hip
+  IMPLICIT NONE
+
+  REAL(KIND=4), PARAMETER :: ppspval = 9999.99
+  INTEGER(KIND=4) :: narg, ijarg, ierr, jt, jk, jj, jvar, jb, it, ik0, ivar, iloc(2)
+  INTEGER(KIND=4) :: npiglo, npjglo, npk, npko, npt, nbasins, nbasinso, npvar = 1, ncout, nmask, nlevo
+  INTEGER(KIND=4) :: numouth = 10, numouts = 11
+  INTEGER(KIND=4), ALLOCATABLE :: ipk(:), id_varout(:)
+  REAL(KIND=4), ALLOCATABLE, TARGET :: e1v(:,:), e3v(:,:,:), e31d(:), zmasks(:,:,:), zvt(:,:,:), zvs(:,:,:), zt(:,:,:)
+  REAL(KIND=4), ALLOCATABLE :: gphiv(:,:), rdumlon(:,:), rdumlat(:,:), gdep(:)
+  REAL(KIND=8), ALLOCATABLE :: dtim(:), dheat(:,:,:), dsalt(:,:,:), dmtrp(:), dz(:,:)
+  CHARACTER(LEN=256) :: cf_vtfil = 'none', cf_vfil = 'none', cf_tfil = 'none', cf_sfil = 'none'
+  CHARACTER(LEN=256) :: cf_outh = 'zonal_heat_trp.dat', cf_outs = 'zonal_salt_trp.dat', cf_outnc = 'mhst.nc'
+  CHARACTER(LEN=256) :: cv_zomht = 'zomht', cv_zomst = 'zomst', cldimension, cldum
+  CHARACTER(LEN=5)   :: cbasin(6) = (/ '_glo ', '_atl ', '_inp ', '_ind ', '_pac ', '_inp0' /)
+  TYPE(variable), ALLOCATABLE :: stypvar(:)
+  TYPE(C_PTR) :: plan, pe3v, pe31d, p1, p2, p3, p4, p5
+  LOGICAL :: llglo, lchk = .FALSE., lfull = .FALSE., lsepf = .TRUE., lzdim = .FALSE.
+  !!----------------------------------------------------------------------
+  CALL ReadCdfNames()
+  narg = COMMAND_ARGUMENT_COUNT()
+  IF ( narg == 0 ) THEN
+     PRINT *, ' usage : cdfmhst  -vt VT-file | (-v V-file -t T-file [-s S-file]) [-MST] [-full] ...'
+     PRINT *, '          ... [-Zdim] [-b BASIN-file] [-o OUT-file] [-vtvar VT-var VS-var] [-vvl]'
+     PRINT *, '      '
+     PRINT *, '     PURPOSE :'
+     PRINT *, '       Compute the meridional heat transport (and, with -MST, the salt transport) as a function'
+     PRINT *, '       of latitude, for the global ocean and for the sub-basins of ', TRIM(cn_fbasins), ' when'
+     PRINT *, '       that file exists.  MI355X build: integration and zonal sums run on the GPU.'
+     PRINT *, '      '
+     PRINT *, '     ARGUMENTS :'
+     PRINT *, '       -vt VT-file : file with the mean products V.T and V.S (from cdfvT), or'
+     PRINT *, '       -v V-file -t T-file [-s S-file] : separate velocity and tracer files.'
+     PRINT *, '      '
+     PRINT *, '     OPTIONS :'
+     PRINT *, '       [-MST ]   : also output the meridional salt transport'
+     PRINT *, '       [-full ]  : full step'
+     PRINT *, '       [-Zdim ]  : output the cumulated transport of every level (variables get a depth axis)'
+     PRINT *, '       [-b BASIN-file] : sub-basin mask file instead of ', TRIM(cn_fbasins)
+     PRINT *, '       [-vtvar VT-var VS-var] : names of the product variables instead of ', TRIM(cn_vomevt), ' ', TRIM(cn_vomevs)
+     PRINT *, '       [-vvl ]   : time-varying vertical metrics'
+     PRINT *, '       [-o OUT-file ] : change name of the output file. Default:', TRIM(cf_outnc)
+     PRINT *, '      '
+     PRINT *, '     REQUIRED FILES :'
+     PRINT *, '       ', TRIM(cn_fhgr), ', ', TRIM(cn_fzgr), ' and ', TRIM(cn_fmsk)
+     PRINT *, '      '
+     PRINT *, '     OUTPUT : '
+     PRINT *, '       ASCII files : ', TRIM(cf_outh), ' : Meridional Heat Transport'
+     PRINT *, '                     ', TRIM(cf_outs), ' : Meridional Salt Transport'
+     PRINT *, '       netcdf file : ', TRIM(cf_outnc), ' unless -o option is used.'
+     PRINT *, '         variables : ', TRIM(cv_zomht), '_glo [_atl _inp _ind _pac _inp0], and ', TRIM(cv_zomst), '_* with -MST'
+     STOP
+  ENDIF
+
+  ijarg = 1
+  DO WHILE ( ijarg <= narg )
+     CALL GET_COMMAND_ARGUMENT(ijarg, cldum) ; ijarg = ijarg + 1
+     SELECT CASE ( cldum )
+     CASE ( '-vt'    ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cf_vtfil ) ; ijarg = ijarg + 1
+     CASE ( '-vtvar' ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cn_vomevt) ; ijarg = ijarg + 1
+        ;                CALL GET_COMMAND_ARGUMENT(ijarg, cn_vomevs) ; ijarg = ijarg + 1
+     CASE ( '-v'     ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cf_vfil  ) ; ijarg = ijarg + 1
+     CASE ( '-t'     ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cf_tfil  ) ; ijarg = ijarg + 1
+     CASE ( '-s'     ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cf_sfil  ) ; ijarg = ijarg + 1
+     CASE ( '-MST'   ) ; npvar = 2
+     CASE ( '-full'  ) ; lfull = .TRUE.
+     CASE ( '-Zdim'  ) ; lzdim = .TRUE.
+     CASE ( '-b'     ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cn_fbasins) ; ijarg = ijarg + 1
+     CASE ( '-o'     ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cf_outnc ) ; ijarg = ijarg + 1
+     CASE ( '-vvl'   ) ; lg_vvl = .TRUE.
+     CASE DEFAULT      ; PRINT *, ' ERROR : ', TRIM(cldum), ' : unknown option.' ; STOP 99
+     END SELECT
+  END DO
+
+  IF ( TRIM(cf_vtfil) /= 'none' ) lsepf = .FALSE.
+  IF ( lsepf ) THEN
+     lchk = chkfile(cf_vfil)
+     lchk = lchk .OR. chkfile(cf_tfil)
+     IF ( lchk ) STOP 99
+     IF ( TRIM(cf_sfil) == 'none' ) cf_sfil = cf_tfil
+  ENDIF
+  lchk = lchk .OR. chkfile(cn_fhgr)
+  lchk = lchk .OR. chkfile(cn_fzgr)
+  lchk = lchk .OR. chkfile(cn_fmsk)
+  lchk = lchk .OR. chkfile(cf_vtfil)
+  IF ( lsepf ) THEN
+     lchk = lchk .OR. chkfile(cf_tfil)
+     lchk = lchk .OR. chkfile(cf_sfil)
+  ENDIF
+  IF ( lchk ) STOP 99
+  IF ( lsepf ) cf_vtfil = cf_vfil                          ! dimensions (and e3v with -vvl) come from there
+  IF ( lg_vvl ) THEN
+     cn_fe3v = cf_vtfil
+     cn_ve3v = cn_ve3vvvl
+  ENDIF
+
+  IF ( .NOT. chkfile(cn_fbasins) ) THEN
+     llglo = .TRUE. ; nbasins = 5 ; nbasinso = 6 ; nmask = 4
+  ELSE
+     PRINT *, ' Only compute for GLOBAL basin'
+     llglo = .FALSE. ; nbasins = 1 ; nbasinso = 1 ; nmask = 1
+  ENDIF
+
+  npiglo = getdim(cf_vtfil, cn_x)
+  npjglo = getdim(cf_vtfil, cn_y)
+  npk    = getdim(cf_vtfil, cn_z)
+  npt    = getdim(cf_vtfil, cn_t)
+  PRINT *, 'npiglo = ', npiglo
+  PRINT *, 'npjglo = ', npjglo
+  PRINT *, 'npk    = ', npk
+  PRINT *, 'npt    = ', npt
+  IF ( lzdim ) THEN ; npko = npk ; cldimension = 'TZY'
+  ELSE              ; npko = 1   ; cldimension = 'TY'
+  ENDIF
+  nlevo = npko
+
+  ALLOCATE( e1v(npiglo,npjglo), gphiv(npiglo,npjglo), zmasks(npiglo,npjglo,nmask) )
+  ALLOCATE( zvt(npiglo,npjglo,npk), zvs(npiglo,npjglo,npk) )
+  IF ( lsepf ) ALLOCATE( zt(npiglo,npjglo,npk) )
+  IF ( lfull ) THEN ; ALLOCATE( e31d(npk) ) ; ELSE ; ALLOCATE( e3v(npiglo,npjglo,npk) ) ; ENDIF
+  ALLOCATE( rdumlon(1,npjglo), rdumlat(1,npjglo), gdep(npko), dtim(npt), dmtrp(npjglo), dz(npjglo,6) )
+  ALLOCATE( dheat(nmask,npjglo,nlevo), dsalt(nmask,npjglo,nlevo) )
+  ALLOCATE( stypvar(nbasinso*npvar), ipk(nbasinso*npvar), id_varout(nbasinso*npvar) )
+
+  e1v(:,:)   = getvar(cn_fhgr, cn_ve1v,  1, npiglo, npjglo)
+  gphiv(:,:) = getvar(cn_fhgr, cn_gphiv, 1, npiglo, npjglo)
+  IF ( lzdim ) THEN ; gdep(:) = getvare3(cn_fzgr, cn_gdept, npk)
+  ELSE              ; gdep(:) = 0.
+  ENDIF
+  IF ( lfull ) e31d = getvare3(cn_fzgr, cn_ve3t1d, npk)
+  iloc = MAXLOC(gphiv)
+  rdumlat(1,:) = gphiv(iloc(1),:)
+  rdumlon(:,:) = 0.
+  CALL CreateOutput
+
+  ! masks: slab 1 global (vmask level 1), then Atlantic, Pacific, Indian (src/cdfmhst.f90:340-363)
+  zmasks(:,:,1) = getvar(cn_fmsk, cn_vmask, 1, npiglo, npjglo)
+  IF ( llglo ) THEN
+     zmasks(:,:,2) = getvar(cn_fbasins, cn_tmaskatl, 1, npiglo, npjglo)
+     zmasks(:,:,3) = getvar(cn_fbasins, cn_tmaskpac, 1, npiglo, npjglo)
+     zmasks(:,:,4) = getvar(cn_fbasins, cn_tmaskind, 1, npiglo, npjglo)
+  ENDIF
+
+  OPEN(numouth, FILE=cf_outh, FORM='FORMATTED', RECL=256)
+  OPEN(numouts, FILE=cf_outs, FORM='FORMATTED', RECL=256)
+  CALL hip_check(cdft_mhst_create(plan, npiglo, npjglo, npk, nmask), 'cdft_mhst_create')
+
+  DO jt = 1, npt
+     it = 1 ; IF ( lg_vvl ) it = jt
+     IF ( jt == 1 .OR. lg_vvl ) THEN
+        pe3v = C_NULL_PTR ; pe31d = C_NULL_PTR
+        IF ( lfull ) THEN
+           pe31d = C_LOC(e31d)
+        ELSE
+           DO jk = 1, npk
+              e3v(:,:,jk) = getvar(cn_fe3v, cn_ve3v, jk, npiglo, npjglo, ktime=it, ldiom=.NOT. lg_vvl)
+           END DO
+           pe3v = C_LOC(e3v)
+        ENDIF
+        CALL hip_check(cdft_mhst_set_mesh(plan, e1v, pe3v, pe31d, zmasks, CDFT_MEM_HOST, C_NULL_PTR), 'cdft_mhst_set_mesh')
+     ENDIF
+     DO jk = 1, npk
+        PRINT *, 'level ', jk
+     END DO
+     p1 = C_NULL_PTR ; p2 = C_NULL_PTR ; p3 = C_NULL_PTR ; p4 = C_NULL_PTR ; p5 = C_NULL_PTR
+     IF ( lsepf ) THEN                                     ! V, T, S: the kernel forms 0.5*(t(j)+t(j+1))*v
+        zvt = getvar3d(cf_vfil, cn_vomecrty, npiglo, npjglo, npk, ktime=jt)
+        zt  = getvar3d(cf_tfil, cn_votemper, npiglo, npjglo, npk, ktime=jt)
+        zvs = getvar3d(cf_sfil, cn_vosaline, npiglo, npjglo, npk, ktime=jt)
+        p3 = C_LOC(zvt) ; p4 = C_LOC(zt) ; p5 = C_LOC(zvs)
+     ELSE
+        zvt = getvar3d(cf_vtfil, cn_vomevt, npiglo, npjglo, npk, ktime=jt)
+        zvs = getvar3d(cf_vtfil, cn_vomevs, npiglo, npjglo, npk, ktime=jt)
+        p1 = C_LOC(zvt) ; p2 = C_LOC(zvs)
+     ENDIF
+     CALL hip_check(cdft_mhst_compute(plan, p1, p2, p3, p4, p5, CDFT_MEM_HOST, MERGE(1_C_INT, 0_C_INT, lzdim), dheat, dsalt, &
+          &         CDFT_MEM_HOST, C_NULL_PTR), 'cdft_mhst_compute')
+
+     DO ik0 = 1, nlevo                                     ! src/cdfmhst.f90:389-445
+        DO jvar = 1, npvar
+           IF ( jvar == 1 ) THEN ; CALL basin_columns(dheat(:,:,ik0), 1.d15)
+           ELSE                  ; CALL basin_columns(dsalt(:,:,ik0), 1.d6)
+           ENDIF
+           DO jb = 1, nbasinso
+              ivar = (jvar - 1) * nbasinso + jb
+              dmtrp(:) = dz(:,jb)
+              WHERE ( dmtrp == 0 ) dmtrp = ppspval
+              ierr = putvar(ncout, id_varout(ivar), REAL(dmtrp), ik0, 1, npjglo, ktime=jt)
+           END DO
+        END DO
+     END DO
+
+     ! ASCII dumps of the totals (last level), north to south (:449-492)
+     WRITE(numouth,*) '! Zonal heat transport (integrated alon I-model coordinate) (in Pw)'
+     CALL ascii_dump(numouth, dheat(:,:,nlevo), 1.d15, 9000)
+     WRITE(numouts,*) ' ! Zonal salt transport (integrated alon I-model coordinate) (in 10^6 kg/s)'
+     CALL ascii_dump(numouts, dsalt(:,:,nlevo), 1.d6, 9001)
+  END DO
+  ierr = cdft_mhst_destroy(plan)
+  ierr = closeout(ncout)
+  CLOSE(numouth)
+  CLOSE(numouts)
+
+CONTAINS
+
+  SUBROUTINE basin_columns(dsum, ddiv)
+    !! glo, atl, inp = (ind + pac), ind, pac, inp0 = (glo - atl), each divided by ddiv (:395-443)
+    REAL(KIND=8), INTENT(in) :: dsum(:,:), ddiv
+    dz(:,1) = dsum(1,:) / ddiv
+    IF ( nbasinso == 6 ) THEN
+       dz(:,2) = dsum(2,:) / ddiv
+       dz(:,3) = (dsum(4,:) + dsum(3,:)) / ddiv
+       dz(:,4) = dsum(4,:) / ddiv
+       dz(:,5) = dsum(3,:) / ddiv
+       dz(:,6) = (dsum(1,:) - dsum(2,:)) / ddiv
+    ENDIF
+  END SUBROUTINE basin_columns
+
+  SUBROUTINE ascii_dump(knum, dsum, ddiv, kfmt)
+    INTEGER(KIND=4), INTENT(in) :: knum, kfmt
+    REAL(KIND=8), INTENT(in) :: dsum(:,:), ddiv
+    IF ( llglo ) THEN
+       WRITE(knum,*) '! J        Global          Atlantic         Pacific          Indian           Mediteranean     Austral  '
+       WRITE(knum,*) ' ! time : ', jt
+       DO jj = npjglo, 1, -1
+          IF ( kfmt == 9000 ) THEN
+             WRITE(knum, 9000) jj, rdumlat(1,jj), dsum(1,jj)/ddiv, dsum(2,jj)/ddiv, dsum(3,jj)/ddiv, dsum(4,jj)/ddiv, 0.d0, 0.d0
+          ELSE
+             WRITE(knum, 9001) jj, rdumlat(1,jj), dsum(1,jj)/ddiv, dsum(2,jj)/ddiv, dsum(3,jj)/ddiv, dsum(4,jj)/ddiv, 0.d0, 0.d0
+          ENDIF
+       END DO
+    ELSE
+       WRITE(knum,*) '! J        Global        '
+       WRITE(knum,*) ' ! time : ', jt
+       DO jj = npjglo, 1, -1
+          IF ( kfmt == 9000 ) THEN ; WRITE(knum, 9000) jj, rdumlat(1,jj), dsum(1,jj)/ddiv
+          ELSE                     ; WRITE(knum, 9001) jj, rdumlat(1,jj), dsum(1,jj)/ddiv
+          ENDIF
+       END DO
+    ENDIF
+9000 FORMAT(I4,6(1x,f9.3,1x,f8.4))
+9001 FORMAT(I4,6(1x,f9.2,1x,f9.3))
+  END SUBROUTINE ascii_dump
+
+  SUBROUTINE CreateOutput
+    !! src/cdfmhst.f90:504-550
+    INTEGER(KIND=4) :: jbasins, iv
+    ipk(:) = npko
+    DO jbasins = 1, nbasinso
+       stypvar(jbasins)%cname             = TRIM(cv_zomht)//TRIM(cbasin(jbasins))
+       stypvar(jbasins)%cunits            = 'PW'
+       stypvar(jbasins)%rmissing_value    = ppspval
+       stypvar(jbasins)%valid_min         = -10.
+       stypvar(jbasins)%valid_max         = 20
+       stypvar(jbasins)%clong_name        = 'Meridional Heat Transport '//TRIM(cbasin(jbasins))
+       stypvar(jbasins)%cshort_name       = stypvar(jbasins)%cname
+       stypvar(jbasins)%conline_operation = 'N/A'
+       stypvar(jbasins)%caxis             = cldimension
+       IF ( npvar == 2 ) THEN
+          iv = nbasinso + jbasins
+          stypvar(iv)%cname             = TRIM(cv_zomst)//TRIM(cbasin(jbasins))
+          stypvar(iv)%cunits            = 'T/sec'
+          stypvar(iv)%rmissing_value    = ppspval
+          stypvar(iv)%valid_min         = -10.e9
+          stypvar(iv)%valid_max         = 20.e9
+          stypvar(iv)%clong_name        = 'Meridional Salt Transport '//TRIM(cbasin(jbasins))
+          stypvar(iv)%cshort_name       = stypvar(iv)%cname
+          stypvar(iv)%conline_operation = 'N/A'
+          stypvar(iv)%caxis             = cldimension
+       ENDIF
+    END DO
+    ncout = create      (cf_outnc, cf_vtfil, 1, npjglo, npko, cdep='depthv')
+    ierr  = createvar   (ncout, stypvar, nbasinso*npvar, ipk, id_varout)
+    ierr  = putheadervar(ncout, cf_vtfil, 1, npjglo, npko, pnavlon=rdumlon, pnavlat=rdumlat, pdep=gdep)
+    dtim  = getvar1d(cf_vtfil, cn_vtimec, npt)
+    ierr  = putvar1d(ncout, dtim, npt, 'T')
+  END SUBROUTINE CreateOutput
+
+END PROGRAM cdfmhst

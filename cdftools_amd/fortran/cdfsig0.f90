@@ -1,0 +1,128 @@
+PROGRAM cdfsig0
+  !!======================================================================
+  !!                     ***  PROGRAM  cdfsig0  ***
+  !! Potential density sigma-0 from potential temperature and salinity.
+  !!
+  !! Drop-in for the reference tool (src/cdfsig0.f90): same options, same sig0.nc (vosigma0 float
+  !! (t,z,y,x), kg/m3, :170-185).  The level loop :139-155 -- sigma0(T,S) * (S /= spval) stored in r4 --
+  !! runs on the GPU for a whole record at once (cdft_eos_sig_tool, bit-identical to the reference's
+  !! arithmetic).
+  !!======================================================================
+  USE ISO_C_BINDING
+  USE cdfio
+  USE modcdfnames
+  USE eos
+  USE cdftools_hip
+  IMPLICIT NONE
+
+  INTEGER(KIND=4) :: narg, ijarg, ierr, jt, jk, npiglo, npjglo, npk, npkk, npt, ncout
+  INTEGER(KIND=4) :: ipk(1), id_varout(1)
+  REAL(KIND=4), ALLOCATABLE :: ztemp(:,:,:), zsal(:,:,:), zsig0(:,:,:)
+  REAL(KIND=4) :: zsps
+  REAL(KIND=8), ALLOCATABLE :: dtim(:)
+  CHARACTER(LEN=256) :: cf_tfil = 'none', cf_sfil = 'none', cf_out = 'sig0.nc', cldum, cv_sal, cv_tem
+  TYPE(variable) :: stypvar(1)
+  LOGICAL :: lnc4 = .FALSE., ll_teos10 = .FALSE.
+  !!----------------------------------------------------------------------
+  CALL ReadCdfNames()
+  narg = COMMAND_ARGUMENT_COUNT()
+  IF ( narg == 0 ) THEN
+     PRINT *, ' usage : cdfsig0 -t T-file [-s S-file] [-sal SAL-name] [-tem TEMP-name] [-nc4] ...'
+     PRINT *, '              ... [-o OUT-file] [-teos10] '
+     PRINT *, '      '
+     PRINT *, '     PURPOSE :'
+     PRINT *, '       Compute potential density (sigma-0) refered to the surface.  MI355X build: the'
+     PRINT *, '       equation of state is evaluated on the GPU.'
+     PRINT *, '      '
+     PRINT *, '     ARGUMENTS :'
+     PRINT *, '       -t T-file  : netcdf file with temperature and salinity.'
+     PRINT *, '      '
+     PRINT *, '     OPTIONS :'
+     PRINT *, '       [-s S-file ]      : salinity file if it differs from T-file.'
+     PRINT *, '       [-sal SAL-name]   : salinity variable name instead of ', TRIM(cn_vosaline)
+     PRINT *, '       [-tem TEMP-name]  : temperature variable name instead of ', TRIM(cn_votemper)
+     PRINT *, '       [-nc4]            : accepted; the bundled NetCDF backend writes classic files.'
+     PRINT *, '       [-o OUT-file]     : output file instead of ', TRIM(cf_out)
+     PRINT *, '       [-teos10]         : TEOS10 equation of state (CT, SA) instead of EOS80'
+     PRINT *, '      '
+     PRINT *, '     REQUIRED FILES :'
+     PRINT *, '       none'
+     PRINT *, '      '
+     PRINT *, '     OPENMP SUPPORT : not needed (GPU) '
+     PRINT *, '      '
+     PRINT *, '     OUTPUT : '
+     PRINT *, '       netcdf file : ', TRIM(cf_out)
+     PRINT *, '         variables : ', TRIM(cn_vosigma0), ' ( kg/m3 - 1000 )'
+     STOP
+  ENDIF
+
+  cv_sal = cn_vosaline ; cv_tem = cn_votemper
+  ijarg = 1
+  DO WHILE ( ijarg <= narg )
+     CALL GET_COMMAND_ARGUMENT(ijarg, cldum) ; ijarg = ijarg + 1
+     SELECT CASE ( cldum )
+     CASE ( '-t'      ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cf_tfil) ; ijarg = ijarg + 1
+     CASE ( '-s'      ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cf_sfil) ; ijarg = ijarg + 1
+     CASE ( '-o'      ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cf_out ) ; ijarg = ijarg + 1
+     CASE ( '-sal'    ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cv_sal ) ; ijarg = ijarg + 1
+     CASE ( '-tem'    ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cv_tem ) ; ijarg = ijarg + 1
+     CASE ( '-nc4'    ) ; lnc4 = .TRUE.
+     CASE ( '-teos10' ) ; ll_teos10 = .TRUE.
+     CASE DEFAULT       ; PRINT *, ' ERROR : ', TRIM(cldum), ' : unknown option.' ; STOP 99
+     END SELECT
+  END DO
+
+  CALL eos_init( ll_teos10 )
+  IF ( cf_sfil == 'none' ) cf_sfil = cf_tfil
+  IF ( chkfile(cf_tfil) .OR. chkfile(cf_sfil) ) STOP 99
+
+  zsps   = getspval(cf_sfil, cv_sal)                      ! salinity fill value marks land
+  npiglo = getdim(cf_tfil, cn_x)
+  npjglo = getdim(cf_tfil, cn_y)
+  npk    = getdim(cf_tfil, cn_z)
+  npt    = getdim(cf_tfil, cn_t)
+  npkk = npk ; IF ( npk == 0 ) npkk = 1
+
+  PRINT *, 'npiglo = ', npiglo
+  PRINT *, 'npjglo = ', npjglo
+  PRINT *, 'npk    = ', npk
+  PRINT *, 'npt    = ', npt
+
+  ALLOCATE( ztemp(npiglo,npjglo,npkk), zsal(npiglo,npjglo,npkk), zsig0(npiglo,npjglo,npkk), dtim(npt) )
+  CALL CreateOutput
+
+  DO jt = 1, npt
+     PRINT *, ' TIME = ', jt, dtim(jt) / 86400., ' days'
+     ztemp = getvar3d(cf_tfil, cv_tem, npiglo, npjglo, npkk, ktime=jt)
+     zsal  = getvar3d(cf_sfil, cv_sal, npiglo, npjglo, npkk, ktime=jt)
+     CALL hip_check(cdft_eos_sig_tool(ztemp, zsal, INT(npiglo, C_INT64_T) * npjglo * npkk, 0.0, zsps,            &
+          &         MERGE(CDFT_EOS_TEOS10, CDFT_EOS_80, ll_teos10), 0_C_INT, zsig0, CDFT_MEM_HOST, CDFT_MEM_HOST, &
+          &         C_NULL_PTR), 'cdft_eos_sig_tool')
+     DO jk = 1, npkk
+        ierr = putvar(ncout, id_varout(1), zsig0(:,:,jk), jk, npiglo, npjglo, ktime=jt)
+     END DO
+  END DO
+  ierr = closeout(ncout)
+
+CONTAINS
+
+  SUBROUTINE CreateOutput
+    ipk(:)                       = npkk
+    stypvar(1)%cname             = cn_vosigma0
+    stypvar(1)%cunits            = 'kg/m3'
+    stypvar(1)%rmissing_value    = 0.
+    stypvar(1)%valid_min         = 0.001
+    stypvar(1)%valid_max         = 40.
+    stypvar(1)%clong_name        = 'Potential_density:sigma-0'
+    stypvar(1)%cshort_name       = cn_vosigma0
+    stypvar(1)%conline_operation = 'N/A'
+    stypvar(1)%caxis             = 'TZYX'
+    stypvar(1)%ichunk            = (/ npiglo, MAX(1, npjglo / 30), 1, 1 /)
+    ncout = create      (cf_out, cf_tfil, npiglo, npjglo, npk, ld_nc4=lnc4)
+    ierr  = createvar   (ncout, stypvar, 1, ipk, id_varout, ld_nc4=lnc4)
+    ierr  = putheadervar(ncout, cf_tfil, npiglo, npjglo, npk)
+    dtim  = getvar1d(cf_tfil, cn_vtimec, npt)
+    ierr  = putvar1d(ncout, dtim, npt, 'T')
+  END SUBROUTINE CreateOutput
+
+END PROGRAM cdfsig0

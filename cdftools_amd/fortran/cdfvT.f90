@@ -1,0 +1,201 @@
+PROGRAM cdfvT
+  !!======================================================================
+  !!                     ***  PROGRAM  cdfvT  ***
+  !! Time-mean products U.T, U.S (at U points) and V.T, V.S (at V points) over a list of tags.
+  !!
+  !! Drop-in for the reference tool (src/cdfvT.f90): same options (-c CONFIG -l tags... [-o] [-nc4] [-vvl]
+  !! [-namT/-namU/-namV]), same file naming through SetFileName, same vt.nc (vomevt, vomevs, vozout,
+  !! vozous float (t,z,y,x), iweight = number of frames, :262-310).  Like the reference the work goes
+  !! level by level (:160); all the time frames of one level are sent to the GPU together
+  !! (cdft_vt_compute with npk = 1), which interpolates, multiplies and accumulates them in the
+  !! reference's order (bit-identical).
+  !!======================================================================
+  USE ISO_C_BINDING
+  USE cdfio
+  USE modcdfnames
+  USE modutils
+  USE cdftools_hip
+  IMPLICIT NONE
+
+  INTEGER(KIND=4) :: narg, ijarg, ierr, jk, jt, jtt, jv, npiglo, npjglo, npk, npt, ntags = 0, ntframe, nvaro, ncout, ifr
+  INTEGER(KIND=4), ALLOCATABLE :: ipk(:), id_varout(:), nptag(:)
+  REAL(KIND=4), ALLOCATABLE, TARGET :: zu(:,:,:), zv(:,:,:), zt(:,:,:), zs(:,:,:), e3u(:,:,:), e3v(:,:,:)
+  REAL(KIND=8), ALLOCATABLE, TARGET :: dvt(:,:), dvs(:,:), dut(:,:), dus(:,:), de3u(:,:), de3v(:,:)
+  REAL(KIND=8), ALLOCATABLE :: dtim(:)
+  REAL(KIND=8) :: dtotal_time, dtimean(1)
+  CHARACTER(LEN=256) :: cf_tfil, cf_sfil, cf_ufil, cf_vfil, cf_out = 'vt.nc', config = 'none', cldum
+  CHARACTER(LEN=256), ALLOCATABLE :: ctag_lst(:)
+  TYPE(variable), ALLOCATABLE :: stypvar(:)
+  TYPE(C_PTR) :: pe3u, pe3v, pe3um, pe3vm
+  LOGICAL :: lnc4 = .FALSE.
+  !!----------------------------------------------------------------------
+  CALL ReadCdfNames()
+  narg = COMMAND_ARGUMENT_COUNT()
+  IF ( narg == 0 ) THEN
+     PRINT *, ' usage : cdfvT -c CONFIG-CASE -l LST-tags [-o OUT-file ] [-nc4 ] [-vvl]'
+     PRINT *, '          ... [-namT TEMP-name] [-namU U-name] [-namV V-name]'
+     PRINT *, '      '
+     PRINT *, '     PURPOSE :'
+     PRINT *, '       Compute the time average of the products U.T, U.S, V.T and V.S over the model outputs'
+     PRINT *, '       identified by the list of tags.  MI355X build: the products are formed on the GPU.'
+     PRINT *, '      '
+     PRINT *, '     ARGUMENTS :'
+     PRINT *, '       -c CONFIG-CASE : configuration and case, e.g. ORCA025-G70'
+     PRINT *, '       -l LST-tags    : blank-separated list of time tags; files are CONFIG-CASE_tag_grid[_]{T,U,V,S}.nc'
+     PRINT *, '      '
+     PRINT *, '     OPTIONS :'
+     PRINT *, '       [-o OUT-file ] : output file instead of ', TRIM(cf_out)
+     PRINT *, '       [-nc4 ]        : accepted; the bundled NetCDF backend writes classic files'
+     PRINT *, '       [-vvl ]        : time-varying vertical metrics (e3u, e3v read from the U and V files)'
+     PRINT *, '       [-namT/-namU/-namV name] : variable names instead of the defaults'
+     PRINT *, '      '
+     PRINT *, '     OUTPUT : '
+     PRINT *, '       netcdf file : ', TRIM(cf_out)
+     PRINT *, '         variables : ', TRIM(cn_vozout), ', ', TRIM(cn_vozous), ', ', TRIM(cn_vomevt), ' and ', TRIM(cn_vomevs)
+     STOP
+  ENDIF
+
+  ijarg = 1
+  DO WHILE ( ijarg <= narg )
+     CALL GET_COMMAND_ARGUMENT(ijarg, cldum) ; ijarg = ijarg + 1
+     SELECT CASE ( cldum )
+     CASE ( '-c'    ) ; CALL GET_COMMAND_ARGUMENT(ijarg, config) ; ijarg = ijarg + 1
+     CASE ( '-l'    ) ; CALL GetTagList
+     CASE ( '-o'    ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cf_out) ; ijarg = ijarg + 1
+     CASE ( '-nc4'  ) ; lnc4   = .TRUE.
+     CASE ( '-vvl'  ) ; lg_vvl = .TRUE.
+     CASE ( '-namT' ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cn_votemper) ; ijarg = ijarg + 1
+     CASE ( '-namU' ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cn_vozocrtx) ; ijarg = ijarg + 1
+     CASE ( '-namV' ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cn_vomecrty) ; ijarg = ijarg + 1
+     CASE DEFAULT     ; PRINT *, ' ERROR : ', TRIM(cldum), ' : unknown option.' ; STOP 99
+     END SELECT
+  END DO
+  IF ( ntags == 0 ) THEN
+     PRINT *, ' ERROR : a list of tags ( -l ) is mandatory.' ; STOP 99
+  ENDIF
+
+  cf_tfil = SetFileName(config, ctag_lst(1), 'T')
+  npiglo = getdim(cf_tfil, cn_x)
+  npjglo = getdim(cf_tfil, cn_y)
+  npk    = getdim(cf_tfil, cn_z)
+  PRINT *, 'npiglo =', npiglo
+  PRINT *, 'npjglo =', npjglo
+  PRINT *, 'npk    =', npk
+
+  nvaro = 4
+  IF ( lg_vvl ) THEN
+     nvaro = 6
+     cn_ve3u = cn_ve3uvvl
+     cn_ve3v = cn_ve3vvvl
+  ENDIF
+
+  ! number of frames of every tag, and the mean time
+  ALLOCATE( nptag(ntags) )
+  ntframe = 0 ; dtotal_time = 0.d0
+  DO jt = 1, ntags
+     cf_tfil = SetFileName(config, ctag_lst(jt), 'T', ld_stop=.TRUE.)
+     npt = getdim(cf_tfil, cn_t)
+     nptag(jt) = npt
+     ALLOCATE( dtim(npt) )
+     dtim = getvar1d(cf_tfil, cn_vtimec, npt)
+     dtotal_time = dtotal_time + SUM(dtim(1:npt))
+     DEALLOCATE( dtim )
+     ntframe = ntframe + npt
+  END DO
+
+  ALLOCATE( zu(npiglo,npjglo,ntframe), zv(npiglo,npjglo,ntframe), zt(npiglo,npjglo,ntframe), zs(npiglo,npjglo,ntframe) )
+  ALLOCATE( dvt(npiglo,npjglo), dvs(npiglo,npjglo), dut(npiglo,npjglo), dus(npiglo,npjglo) )
+  ALLOCATE( stypvar(nvaro), ipk(nvaro), id_varout(nvaro) )
+  pe3u = C_NULL_PTR ; pe3v = C_NULL_PTR ; pe3um = C_NULL_PTR ; pe3vm = C_NULL_PTR
+  IF ( lg_vvl ) THEN
+     ALLOCATE( e3u(npiglo,npjglo,ntframe), e3v(npiglo,npjglo,ntframe), de3u(npiglo,npjglo), de3v(npiglo,npjglo) )
+     pe3u = C_LOC(e3u) ; pe3v = C_LOC(e3v) ; pe3um = C_LOC(de3u) ; pe3vm = C_LOC(de3v)
+  ENDIF
+  cf_tfil = SetFileName(config, ctag_lst(1), 'T')
+  CALL CreateOutput
+
+  DO jk = 1, npk
+     PRINT *, 'level ', jk
+     ifr = 0
+     DO jt = 1, ntags
+        cf_tfil = SetFileName(config, ctag_lst(jt), 'T', ld_stop=.TRUE.)
+        cf_sfil = SetFileName(config, ctag_lst(jt), 'S', ld_stop=.FALSE.)
+        IF ( chkfile(cf_sfil, ld_verbose=.FALSE.) ) cf_sfil = cf_tfil      ! salinity in the T file
+        cf_ufil = SetFileName(config, ctag_lst(jt), 'U')
+        cf_vfil = SetFileName(config, ctag_lst(jt), 'V')
+        DO jtt = 1, nptag(jt)
+           ifr = ifr + 1
+           zu(:,:,ifr) = getvar(cf_ufil, cn_vozocrtx, jk, npiglo, npjglo, ktime=jtt)
+           zv(:,:,ifr) = getvar(cf_vfil, cn_vomecrty, jk, npiglo, npjglo, ktime=jtt)
+           zt(:,:,ifr) = getvar(cf_tfil, cn_votemper, jk, npiglo, npjglo, ktime=jtt)
+           zs(:,:,ifr) = getvar(cf_sfil, cn_vosaline, jk, npiglo, npjglo, ktime=jtt)
+           IF ( lg_vvl ) THEN
+              e3u(:,:,ifr) = getvar(cf_ufil, cn_ve3u, jk, npiglo, npjglo, ktime=jtt)
+              e3v(:,:,ifr) = getvar(cf_vfil, cn_ve3v, jk, npiglo, npjglo, ktime=jtt)
+           ENDIF
+        END DO
+     END DO
+     CALL hip_check(cdft_vt_compute(zu, zv, zt, zs, pe3u, pe3v, INT(npiglo, C_INT64_T) * npjglo, ntframe, npiglo, npjglo,   &
+          &         1_C_INT, CDFT_MEM_HOST, C_LOC(dvt), C_LOC(dvs), C_LOC(dut), C_LOC(dus), pe3um, pe3vm, 0_C_INT,         &
+          &         CDFT_MEM_HOST, C_NULL_PTR), 'cdft_vt_compute')
+     ierr = putvar(ncout, id_varout(1), dvt, jk, npiglo, npjglo, kwght=ntframe)
+     ierr = putvar(ncout, id_varout(2), dvs, jk, npiglo, npjglo, kwght=ntframe)
+     ierr = putvar(ncout, id_varout(3), dut, jk, npiglo, npjglo, kwght=ntframe)
+     ierr = putvar(ncout, id_varout(4), dus, jk, npiglo, npjglo, kwght=ntframe)
+     IF ( lg_vvl ) THEN
+        ierr = putvar(ncout, id_varout(5), de3u, jk, npiglo, npjglo, kwght=ntframe)
+        ierr = putvar(ncout, id_varout(6), de3v, jk, npiglo, npjglo, kwght=ntframe)
+     ENDIF
+     IF ( jk == 1 ) THEN
+        dtimean(1) = dtotal_time / ntframe
+        ierr = putvar1d(ncout, dtimean, 1, 'T')
+     ENDIF
+  END DO
+  ierr = closeout(ncout)
+
+CONTAINS
+
+  SUBROUTINE GetTagList
+    !! every argument up to the next option is a tag (src/cdfvT.f90:312-339)
+    INTEGER(KIND=4) :: ji, icur
+    ntags = 0
+    icur = ijarg
+    DO ji = icur, narg
+       CALL GET_COMMAND_ARGUMENT(ji, cldum)
+       IF ( cldum(1:1) == '-' ) EXIT
+       ntags = ntags + 1
+    END DO
+    ALLOCATE( ctag_lst(ntags) )
+    DO ji = icur, icur + ntags - 1
+       CALL GET_COMMAND_ARGUMENT(ji, ctag_lst(ji - icur + 1)) ; ijarg = ijarg + 1
+    END DO
+  END SUBROUTINE GetTagList
+
+  SUBROUTINE CreateOutput
+    !! src/cdfvT.f90:262-310
+    ipk(:) = npk
+    stypvar%rmissing_value    = 0.
+    stypvar%valid_min         = -100.
+    stypvar%valid_max         = 100.
+    stypvar%conline_operation = 'N/A'
+    stypvar%caxis             = 'TZYX'
+    DO jv = 1, nvaro
+       stypvar(jv)%ichunk = (/ npiglo, MAX(1, npjglo / 30), 1, 1 /)
+    END DO
+    stypvar(1)%cname = cn_vomevt ; stypvar(1)%cunits = 'm.DegC.s-1' ; stypvar(1)%clong_name = 'Meridional_VT'
+    stypvar(2)%cname = cn_vomevs ; stypvar(2)%cunits = 'm.PSU.s-1'  ; stypvar(2)%clong_name = 'Meridional_VS'
+    stypvar(3)%cname = cn_vozout ; stypvar(3)%cunits = 'm.DegC.s-1' ; stypvar(3)%clong_name = 'Zonal_UT'
+    stypvar(4)%cname = cn_vozous ; stypvar(4)%cunits = 'm.PSU.s-1'  ; stypvar(4)%clong_name = 'Zonal_US'
+    IF ( lg_vvl ) THEN
+       stypvar(5)%cname = cn_ve3u ; stypvar(5)%cunits = 'm' ; stypvar(5)%clong_name = 'Mean_e3u'
+       stypvar(6)%cname = cn_ve3v ; stypvar(6)%cunits = 'm' ; stypvar(6)%clong_name = 'Mean_e3v'
+    ENDIF
+    DO jv = 1, nvaro
+       stypvar(jv)%cshort_name = stypvar(jv)%cname
+    END DO
+    ncout = create      (cf_out, cf_tfil, npiglo, npjglo, npk, ld_xycoo=.TRUE., ld_nc4=lnc4)
+    ierr  = createvar   (ncout, stypvar, nvaro, ipk, id_varout, ld_nc4=lnc4)
+    ierr  = putheadervar(ncout, cf_tfil, npiglo, npjglo, npk, ld_xycoo=.TRUE.)
+  END SUBROUTINE CreateOutput
+
+END PROGRAM cdfvT

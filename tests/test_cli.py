@@ -40,7 +40,8 @@ PROGRAMS = [t for t in ("cdfmoc", "cdfheatc", "cdfcurl", "cdfsig0", "cdfsigi", "
 @pytest.mark.parametrize("tool", PROGRAMS)
 def test_usage_unknown_option_and_missing_file(tools, tmp_path, tool):
     rc, out, _ = run(tool, [], tmp_path)
-    assert rc == 0 and f"usage : {tool}" in out                     # README.md:49 of the reference
+    first = out.strip().splitlines()[0]
+    assert rc == 0 and "usage :" in first and tool in first            # README.md:49 of the reference
     rc, out, _ = run(tool, ["-thisisnotanoption"], tmp_path)
     assert rc == 99 and "unknown option" in out                      # e.g. src/cdfmoc.f90:232
     first = {"cdfmoc": "-v", "cdfheatc": "-f", "cdfcurl": "-u", "cdfsig0": "-t", "cdfsigi": "-t", "cdfpsi": "-u",
