@@ -62,75 +62,109 @@ template <> __device__ __forceinline__ void unpacku<4>(const uchar4 &v, float (&
 template <> __device__ __forceinline__ void unpacku<2>(const uchar2 &v, float (&o)[2]) { o[0] = v.x; o[1] = v.y; }
 template <> __device__ __forceinline__ void unpacku<1>(const unsigned char &v, float (&o)[1]) { o[0] = v; }
 
-// grid (nblk, npk): block (b,k) strides over the VEC-vectors of level k.
+constexpr int kVPT = 4;   // vectors per lane: each wave reads kVPT contiguous KiB-sized runs per field and level
+
+// One workgroup owns kThreads*kVPT vectors of the horizontal plane for ALL levels: the area
+// e1t*e2t (and the mixed-layer depth) stays in registers, every level streams temp / e3t / tmask
+// past it.  Per level each wave reduces its three sums and parks them in LDS; at the end the waves
+// are combined in wave order into partial[k][block][3].
 template <int VEC, bool MASK8, bool FULL>
 __global__ void __launch_bounds__(kThreads) heatc_level_kernel(HeatcArgs a) {
-    __shared__ double scratch[16];
-    const int k = blockIdx.y;
+    extern __shared__ double wsum[];                   // [nwaves][npk][3]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = kThreads / 64;
     const int64_t nvec = a.nij / VEC;                  // nij % VEC == 0 by construction
-    const int64_t base = (int64_t)k * nvec;            // vector offset of level k in a 3-D field
-    const float e3k = FULL ? a.e31d[k] : 0.f;
-    const float dw  = a.mxlopt ? a.gdepw[k] : 0.f;
-    double s_surf = 0.0, s_vol = 0.0, s_sum = 0.0;
     typedef typename Vec<VEC>::f FV;
     typedef typename Vec<VEC>::u UV;
-    for (int64_t v = (int64_t)blockIdx.x * kThreads + threadIdx.x; v < nvec; v += (int64_t)a.nblk * kThreads) {
-        float ar[VEC], e3[VEC], tt[VEC], mk[VEC], mx[VEC];
-        unpack<VEC>(reinterpret_cast<const FV *>(a.area)[v], ar);
-        unpack<VEC>(reinterpret_cast<const FV *>(a.temp)[base + v], tt);
-        if (FULL) {
+    int64_t q[kVPT];
+    bool ok[kVPT];
+    float ar[kVPT][VEC], mx[kVPT][VEC];
 #pragma unroll
-            for (int c = 0; c < VEC; ++c) e3[c] = e3k;
-        } else {
-            unpack<VEC>(reinterpret_cast<const FV *>(a.e3t)[base + v], e3);
+    for (int v = 0; v < kVPT; ++v) {
+        q[v] = (((int64_t)blockIdx.x * nwaves + wave) * kVPT + v) * 64 + lane;
+        ok[v] = q[v] < nvec;
+        if (!ok[v]) q[v] = 0;
+        unpack<VEC>(reinterpret_cast<const FV *>(a.area)[q[v]], ar[v]);
+        if (a.mxlopt) unpack<VEC>(reinterpret_cast<const FV *>(a.mxl)[q[v]], mx[v]);
+        if (!ok[v])
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) ar[v][c] = 0.f;       // contributes exact zeros
+    }
+    for (int k = 0; k < a.npk; ++k) {
+        const int64_t base = (int64_t)k * nvec;        // vector offset of level k in a 3-D field
+        const float e3k = FULL ? a.e31d[k] : 0.f;
+        const float dw  = a.mxlopt ? a.gdepw[k] : 0.f;
+        float e3[kVPT][VEC], tt[kVPT][VEC], mk[kVPT][VEC];
+#pragma unroll
+        for (int v = 0; v < kVPT; ++v) {
+            unpack<VEC>(reinterpret_cast<const FV *>(a.temp)[base + q[v]], tt[v]);
+            if (FULL) {
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) e3[v][c] = e3k;
+            } else {
+                unpack<VEC>(reinterpret_cast<const FV *>(a.e3t)[base + q[v]], e3[v]);
+            }
+            if (MASK8) unpacku<VEC>(reinterpret_cast<const UV *>(a.mask8)[base + q[v]], mk[v]);
+            else       unpack<VEC>(reinterpret_cast<const FV *>(a.mask4)[base + q[v]], mk[v]);
         }
-        if (MASK8) unpacku<VEC>(reinterpret_cast<const UV *>(a.mask8)[base + v], mk);
-        else       unpack<VEC>(reinterpret_cast<const FV *>(a.mask4)[base + v], mk);
-        if (a.mxlopt) unpack<VEC>(reinterpret_cast<const FV *>(a.mxl)[v], mx);
+        double s_surf = 0.0, s_vol = 0.0, s_sum = 0.0;
 #pragma unroll
-        for (int c = 0; c < VEC; ++c) {
-            float e = e3[c];
-            if (a.mxlopt == 1)                        // src/cdfheatc.f90:220
-                e = fmaxf(0.f, fminf(e, __fsub_rn(mx[c], dw)));
-            else if (a.mxlopt == -1)                  // :222
-                e = fminf(e, fmaxf(0.f, __fsub_rn(__fadd_rn(dw, e), mx[c])));
-            const float pv = __fmul_rn(ar[c], e);                      // (e1t*e2t)*e3t
-            s_surf += (double)__fmul_rn(ar[c], mk[c]);                 // :225
-            s_vol  += (double)__fmul_rn(pv, mk[c]);                    // :226
-            s_sum  += (double)__fmul_rn(__fmul_rn(pv, tt[c]), mk[c]);  // :229
+        for (int v = 0; v < kVPT; ++v)
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) {
+                float e = e3[v][c];
+                if (a.mxlopt == 1)                        // src/cdfheatc.f90:220
+                    e = fmaxf(0.f, fminf(e, __fsub_rn(mx[v][c], dw)));
+                else if (a.mxlopt == -1)                  // :222
+                    e = fminf(e, fmaxf(0.f, __fsub_rn(__fadd_rn(dw, e), mx[v][c])));
+                const float mkc = ok[v] ? mk[v][c] : 0.f;
+                const float ttc = ok[v] ? tt[v][c] : 0.f;
+                const float pv = __fmul_rn(ar[v][c], e);                       // (e1t*e2t)*e3t
+                s_surf += (double)__fmul_rn(ar[v][c], mkc);                    // :225
+                s_vol  += (double)__fmul_rn(pv, mkc);                          // :226
+                s_sum  += (double)__fmul_rn(__fmul_rn(pv, ttc), mkc);          // :229
+            }
+        s_surf = wave_sum(s_surf); s_vol = wave_sum(s_vol); s_sum = wave_sum(s_sum);
+        if (lane == 0) {
+            double *w = wsum + ((int64_t)wave * a.npk + k) * 3;
+            w[0] = s_surf; w[1] = s_vol; w[2] = s_sum;
         }
     }
-    s_surf = block_sum(s_surf, scratch);
-    s_vol  = block_sum(s_vol, scratch);
-    s_sum  = block_sum(s_sum, scratch);
-    if (threadIdx.x == 0) {
-        double *p = a.partial + ((int64_t)k * a.nblk + blockIdx.x) * 3;
-        p[0] = s_surf; p[1] = s_vol; p[2] = s_sum;
+    __syncthreads();
+    for (int t = threadIdx.x; t < a.npk * 3; t += kThreads) {
+        double s = 0.0;
+        for (int w = 0; w < nwaves; ++w) s += wsum[(int64_t)w * a.npk * 3 + t];
+        const int k = t / 3, c = t - 3 * k;
+        a.partial[((int64_t)k * a.nblk + blockIdx.x) * 3 + c] = s;
     }
 }
 
-// sums[k][3] = partials of level k added in block order
-__global__ void heatc_final_kernel(const double *__restrict__ partial, int npk, int nblk,
-                                   double *__restrict__ sums) {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= npk * 3) return;
-    const int k = q / 3, c = q - 3 * k;
-    double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += partial[((int64_t)k * nblk + b) * 3 + c];
-    sums[q] = s;
+// sums[k][3] = partials of level k added over the blocks in a fixed order (one workgroup per level)
+__global__ void __launch_bounds__(kThreads) heatc_final_kernel(const double *__restrict__ partial, int npk, int nblk,
+                                                               double *__restrict__ sums) {
+    __shared__ double scratch[16];
+    const int k = blockIdx.x;
+    double s[3] = {0.0, 0.0, 0.0};
+    for (int b = threadIdx.x; b < nblk; b += kThreads)
+        for (int c = 0; c < 3; ++c) s[c] += partial[((int64_t)k * nblk + b) * 3 + c];
+    for (int c = 0; c < 3; ++c) {
+        const double t = block_sum(s[c], scratch);
+        if (threadIdx.x == 0) sums[k * 3 + c] = t;
+    }
 }
 
 template <int VEC>
 int launch_vec(const HeatcArgs &a, hipStream_t st) {
-    dim3 grid(a.nblk, a.npk), block(kThreads);
+    dim3 grid(a.nblk), block(kThreads);
+    const size_t shmem = (size_t)(kThreads / 64) * a.npk * 3 * sizeof(double);
     const bool m8 = a.mask8 != nullptr, full = a.e31d != nullptr;
-    if (m8 && full)        hipLaunchKernelGGL((heatc_level_kernel<VEC, true, true>), grid, block, 0, st, a);
-    else if (m8 && !full)  hipLaunchKernelGGL((heatc_level_kernel<VEC, true, false>), grid, block, 0, st, a);
-    else if (!m8 && full)  hipLaunchKernelGGL((heatc_level_kernel<VEC, false, true>), grid, block, 0, st, a);
-    else                   hipLaunchKernelGGL((heatc_level_kernel<VEC, false, false>), grid, block, 0, st, a);
+    if (m8 && full)        hipLaunchKernelGGL((heatc_level_kernel<VEC, true, true>), grid, block, shmem, st, a);
+    else if (m8 && !full)  hipLaunchKernelGGL((heatc_level_kernel<VEC, true, false>), grid, block, shmem, st, a);
+    else if (!m8 && full)  hipLaunchKernelGGL((heatc_level_kernel<VEC, false, true>), grid, block, shmem, st, a);
+    else                   hipLaunchKernelGGL((heatc_level_kernel<VEC, false, false>), grid, block, shmem, st, a);
     CDFT_LAUNCH_CHECK();
     return CDFT_OK;
 }
+
 
 bool aligned_to(const void *p, size_t n) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) % n) == 0; }
 
@@ -156,8 +190,7 @@ int cdft_heatc_create(cdft_heatc_plan **plan, int npiglo, int npjglo, int npk) {
     cdft_heatc_plan *p = new cdft_heatc_plan;
     p->npi = npiglo; p->npj = npjglo; p->npk = npk;
     const int64_t nij = (int64_t)npiglo * npjglo;
-    int64_t nb = (nij / 4 + kThreads * 4 - 1) / (kThreads * 4);
-    p->nblk = (int)(nb < 1 ? 1 : (nb > 64 ? 64 : nb));
+    p->nblk = (int)((nij + kThreads * 4 - 1) / (kThreads * 4));   // blocks when VEC = 1 (the most)
     if (hipMalloc((void **)&p->area, nij * sizeof(float) + 16) != hipSuccess ||
         hipMalloc((void **)&p->gdepw, npk * sizeof(float) + 16) != hipSuccess ||
         hipMalloc((void **)&p->partial, (size_t)npk * p->nblk * 3 * sizeof(double)) != hipSuccess) {
@@ -223,15 +256,15 @@ int cdft_heatc_compute(cdft_heatc_plan *p, const float *temp, int temp_space, co
     HeatcArgs a;
     a.area = p->area; a.e3t = p->e3t; a.e31d = p->e31d; a.temp = (const float *)dt; a.mxl = (const float *)dm;
     a.gdepw = p->gdepw; a.mask8 = p->mask8; a.mask4 = p->mask4; a.nij = nij; a.npk = p->npk;
-    a.mxlopt = mxloption; a.nblk = p->nblk; a.partial = p->partial;
+    a.mxlopt = mxloption; a.partial = p->partial;
     int vec = 1;
     if (nij % 4 == 0 && aligned_to(dt, 16) && aligned_to(dm, 16)) vec = 4;
     else if (nij % 2 == 0 && aligned_to(dt, 8) && aligned_to(dm, 8)) vec = 2;
+    a.nblk = (int)((nij / vec + kThreads * 4 - 1) / (kThreads * 4));   // kVPT = 4 vectors per lane
     if (vec == 4)      CDFT_TRY(launch_vec<4>(a, st));
     else if (vec == 2) CDFT_TRY(launch_vec<2>(a, st));
     else               CDFT_TRY(launch_vec<1>(a, st));
-    hipLaunchKernelGGL(heatc_final_kernel, dim3((p->npk * 3 + 63) / 64), dim3(64), 0, st, p->partial, p->npk,
-                       p->nblk, dout);
+    hipLaunchKernelGGL(heatc_final_kernel, dim3(p->npk), dim3(kThreads), 0, st, p->partial, p->npk, a.nblk, dout);
     CDFT_LAUNCH_CHECK();
     if (out_space == CDFT_MEM_HOST) {
         CDFT_HIP(hipMemcpyAsync(sums, dout, (size_t)p->npk * 3 * sizeof(double), hipMemcpyDeviceToHost, st));

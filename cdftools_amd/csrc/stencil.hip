@@ -76,23 +76,33 @@ __global__ void __launch_bounds__(kThreads) vt_kernel(VtArgs a) {
 
     double aut[4] = {0, 0, 0, 0}, avt[4] = {0, 0, 0, 0}, aus[4] = {0, 0, 0, 0}, avs[4] = {0, 0, 0, 0};
     double ce3u[4] = {0, 0, 0, 0}, ce3v[4] = {0, 0, 0, 0};
-    for (int f = 0; f < a.nfr; ++f) {
+    // Software pipeline over the frames (as in the cdfmoc kernel): the loads of frame f+1 are in
+    // flight while frame f is interpolated and accumulated.
+    struct Frame { float t[4], s[4], tn[4], sn[4], u[4], v[4], e3u[4], e3v[4], ht, hs; };
+    auto fetch = [&](Frame &r, int f) {
         const int64_t e = (int64_t)f * a.fstride + cell;
-        float t[4] = {0, 0, 0, 0}, s[4] = {0, 0, 0, 0}, tn[4] = {0, 0, 0, 0}, sn[4] = {0, 0, 0, 0};
-        float u[4] = {0, 0, 0, 0}, v[4] = {0, 0, 0, 0}, e3u[4] = {0, 0, 0, 0}, e3v[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { r.t[c] = r.s[c] = r.tn[c] = r.sn[c] = r.u[c] = r.v[c] = r.e3u[c] = r.e3v[c] = 0.f; }
+        r.ht = r.hs = 0.f;
         if (nv > 0) {
-            load4(a.t + e, nv, t); load4(a.s + e, nv, s); load4(a.u + e, nv, u); load4(a.v + e, nv, v);
-            if (north) { load4(a.t + e + a.npi, nv, tn); load4(a.s + e + a.npi, nv, sn); }
-            if (VVL) { load4(a.e3u + e, nv, e3u); load4(a.e3v + e, nv, e3v); }
+            load4(a.t + e, nv, r.t); load4(a.s + e, nv, r.s); load4(a.u + e, nv, r.u); load4(a.v + e, nv, r.v);
+            if (north) { load4(a.t + e + a.npi, nv, r.tn); load4(a.s + e + a.npi, nv, r.sn); }
+            if (VVL) { load4(a.e3u + e, nv, r.e3u); load4(a.e3v + e, nv, r.e3v); }
         }
+        if (tid == 0 && ih < a.npi) {                             // halo cell of the tile
+            const int64_t eh = (int64_t)f * a.fstride + L * a.npi + ih;
+            r.ht = a.t[eh]; r.hs = a.s[eh];
+        }
+    };
+    Frame cur, nxt;
+    fetch(cur, 0);
+    for (int f = 0; f < a.nfr; ++f) {
+        if (f + 1 < a.nfr) fetch(nxt, f + 1);
+        const float (&t)[4] = cur.t, (&s)[4] = cur.s, (&tn)[4] = cur.tn, (&sn)[4] = cur.sn;
+        const float (&u)[4] = cur.u, (&v)[4] = cur.v, (&e3u)[4] = cur.e3u, (&e3v)[4] = cur.e3v;
         const int buf = f & 1;                                    // double-buffered: one barrier per frame
         lt[buf][tid] = t[0]; ls[buf][tid] = s[0];
-        if (tid == 0) {
-            const bool has = ih < a.npi;
-            const int64_t eh = (int64_t)f * a.fstride + L * a.npi + ih;
-            lt[buf][kThreads] = has ? a.t[eh] : 0.f;
-            ls[buf][kThreads] = has ? a.s[eh] : 0.f;
-        }
+        if (tid == 0) { lt[buf][kThreads] = cur.ht; ls[buf][kThreads] = cur.hs; }
         __syncthreads();
         const float tnx = lt[buf][tid + 1], snx = ls[buf][tid + 1];
 #pragma unroll
@@ -118,6 +128,7 @@ __global__ void __launch_bounds__(kThreads) vt_kernel(VtArgs a) {
                 avs[c] = __dadd_rn(avs[c], (double)__fmul_rn(wsv, v[c]));
             }
         }
+        cur = nxt;
     }
     if (nv <= 0) return;
     const double dn = (double)a.nfr;
@@ -187,16 +198,32 @@ __global__ void __launch_bounds__(kThreads) curl_kernel(CurlArgs a) {
     float den[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) den[c] = __fmul_rn(e1f[c], e2f[c]);
+    // software pipeline over the levels: level lev+1 is in flight while level lev is differenced
+    struct Level { float u[4], un1[4], v[4], hv; };
+    auto fetch = [&](Level &r, int lev) {
+        const float *un = a.un + (int64_t)lev * nij, *vn = a.vn + (int64_t)lev * nij;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { r.u[c] = r.un1[c] = r.v[c] = 0.f; }
+        r.hv = 0.f;
+        if (nv > 0) {
+            load4(un + p2, nv, r.u); load4(vn + p2, nv, r.v);
+            if (north) load4(un + p2 + a.npi, nv, r.un1);
+        }
+        if (tid == 0 && has_halo) r.hv = vn[(int64_t)jj * a.npi + ih];
+    };
+    Level cur, nxt;
+    fetch(cur, 0);
     for (int lev = 0; lev < a.nlev; ++lev) {
         const float *un = a.un + (int64_t)lev * nij, *vn = a.vn + (int64_t)lev * nij;
-        float u[4] = {0, 0, 0, 0}, un1[4] = {0, 0, 0, 0}, v[4] = {0, 0, 0, 0};
-        if (nv > 0) {
-            load4(un + p2, nv, u); load4(vn + p2, nv, v);
-            if (north) load4(un + p2 + a.npi, nv, un1);
-        }
+        if (lev + 1 < a.nlev) fetch(nxt, lev + 1);
+        float u[4], un1[4], v[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { u[c] = cur.u[c]; un1[c] = cur.un1[c]; v[c] = cur.v[c]; }
+        const float hv = cur.hv;
+        cur = nxt;
         const int buf = lev & 1;                                  // double-buffered: one barrier per level
         lv[buf][tid] = v[0];
-        if (tid == 0) lv[buf][kThreads] = has_halo ? vn[(int64_t)jj * a.npi + ih] : 0.f;
+        if (tid == 0) lv[buf][kThreads] = hv;
         __syncthreads();
         if (nv <= 0) continue;
         const float vnx = lv[buf][tid + 1];

@@ -12,6 +12,7 @@
 //
 // HBM-bound: the 3-D pass reads 8 B (cdfpsi: u + e3u) or 12 B (cdfmhst: vt + vs + e3v) per cell
 // once; the 2-D work is < 1 % of that.
+#include <cstdlib>
 #include "common.hpp"
 #include "reduce.hpp"
 
@@ -46,64 +47,84 @@ struct VintArgs {
     int npi, npj, k0, k1, init;
 };
 
-// One lane owns VEC consecutive cells and walks the levels k0..k1-1 in order (sequential r8 sum).
-template <int VEC, int MODE, bool FULL>
+// One lane owns VPT vectors of VEC consecutive cells and walks the levels k0..k1-1 in order
+// (sequential r8 sum per cell).  The VPT vectors of a wave are 64 vectors apart, so every wave reads
+// VPT KiB-sized contiguous runs per field and level (better DRAM row locality than one run per wave).
+template <int VEC, int MODE, bool FULL, int VPT>
 __global__ void __launch_bounds__(kThreads) vint_kernel(VintArgs a) {
-    const int64_t p = ((int64_t)blockIdx.x * kThreads + threadIdx.x) * VEC;
-    if (p >= a.nij) return;
-    float m[VEC];
-    ld<VEC>(a.m2d, p, m);
-    double s0[VEC], s1[VEC];
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * kThreads + threadIdx.x) >> 6;
+    int64_t p[VPT];
+    bool ok[VPT], lastrow[VPT];
+    float m[VPT][VEC];
+    double s0[VPT][VEC], s1[VPT][VEC];
 #pragma unroll
-    for (int c = 0; c < VEC; ++c) {
-        s0[c] = a.init ? 0.0 : a.acc0[p + c];
-        s1[c] = (MODE != kPsi && !a.init) ? a.acc1[p + c] : 0.0;
-    }
-    const bool lastrow = (MODE == kMhstSep) && (p / a.npi == a.npj - 1);    // npi % VEC == 0 here
-#pragma unroll 4
-    for (int k = a.k0; k < a.k1; ++k) {
-        const int64_t e = (int64_t)k * a.nij + p;
-        float x0[VEC], x1[VEC], e3[VEC];
-        if (FULL) {
-            const float v = a.e31d[k];
-#pragma unroll
-            for (int c = 0; c < VEC; ++c) e3[c] = v;
-        } else {
-            ld<VEC>(a.e3, e, e3);
-        }
-        if (MODE == kMhstSep) {                       // src/cdfmhst.f90:312-322
-            float v[VEC], t0[VEC], t1[VEC], q0[VEC], q1[VEC];
-            ld<VEC>(a.f0, e, v);
-            ld<VEC>(a.f1, e, t0);
-            ld<VEC>(a.f2, e, q0);
-            if (!lastrow) { ld<VEC>(a.f1, e + a.npi, t1); ld<VEC>(a.f2, e + a.npi, q1); }
-#pragma unroll
-            for (int c = 0; c < VEC; ++c) {
-                x0[c] = lastrow ? 0.f : __fmul_rn(__fmul_rn(0.5f, __fadd_rn(t0[c], t1[c])), v[c]);
-                x1[c] = lastrow ? 0.f : __fmul_rn(__fmul_rn(0.5f, __fadd_rn(q0[c], q1[c])), v[c]);
-            }
-        } else {
-            ld<VEC>(a.f0, e, x0);
-            if (MODE == kMhstVt) ld<VEC>(a.f1, e, x1);
-        }
+    for (int v = 0; v < VPT; ++v) {
+        p[v] = ((wave * VPT + v) * 64 + lane) * VEC;
+        ok[v] = p[v] < a.nij;
+        if (!ok[v]) p[v] = 0;                              // harmless in-range address, never stored
+        ld<VEC>(a.m2d, p[v], m[v]);
+        lastrow[v] = (MODE == kMhstSep) && (p[v] / a.npi == a.npj - 1);    // npi % VEC == 0 here
 #pragma unroll
         for (int c = 0; c < VEC; ++c) {
-            // (field*metric)*e3 in r4, then widened: src/cdfmhst.f90:332-333, src/cdfpsi.f90:277,296
-            const double d0 = (double)__fmul_rn(__fmul_rn(x0[c], m[c]), e3[c]);
-            if (MODE == kPsi) {
-                s0[c] = __dadd_rn(s0[c], d0);
-            } else {
-                s0[c] = __dadd_rn(s0[c], __dmul_rn(__dmul_rn(d0, 1000.0), 4000.0));   // :336 pprau0, pprcp
-                s1[c] = __dadd_rn(s1[c], (double)__fmul_rn(__fmul_rn(x1[c], m[c]), e3[c]));   // :337
-            }
+            s0[v][c] = a.init ? 0.0 : a.acc0[p[v] + c];
+            s1[v][c] = (MODE != kPsi && !a.init) ? a.acc1[p[v] + c] : 0.0;
         }
     }
+    if (!ok[0]) return;
+#pragma unroll 2
+    for (int k = a.k0; k < a.k1; ++k) {
+        float x0[VPT][VEC], x1[VPT][VEC], e3[VPT][VEC];
 #pragma unroll
-    for (int c = 0; c < VEC; ++c) {
-        a.acc0[p + c] = s0[c];
-        if (MODE != kPsi) a.acc1[p + c] = s1[c];
+        for (int v = 0; v < VPT; ++v) {
+            const int64_t e = (int64_t)k * a.nij + p[v];
+            if (FULL) {
+                const float z = a.e31d[k];
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) e3[v][c] = z;
+            } else {
+                ld<VEC>(a.e3, e, e3[v]);
+            }
+            if (MODE == kMhstSep) {                       // src/cdfmhst.f90:312-322
+                float vv[VEC], t0[VEC], t1[VEC], q0[VEC], q1[VEC];
+                ld<VEC>(a.f0, e, vv);
+                ld<VEC>(a.f1, e, t0);
+                ld<VEC>(a.f2, e, q0);
+                if (!lastrow[v]) { ld<VEC>(a.f1, e + a.npi, t1); ld<VEC>(a.f2, e + a.npi, q1); }
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) {
+                    x0[v][c] = lastrow[v] ? 0.f : __fmul_rn(__fmul_rn(0.5f, __fadd_rn(t0[c], t1[c])), vv[c]);
+                    x1[v][c] = lastrow[v] ? 0.f : __fmul_rn(__fmul_rn(0.5f, __fadd_rn(q0[c], q1[c])), vv[c]);
+                }
+            } else {
+                ld<VEC>(a.f0, e, x0[v]);
+                if (MODE == kMhstVt) ld<VEC>(a.f1, e, x1[v]);
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < VPT; ++v)
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) {
+                // (field*metric)*e3 in r4, then widened: src/cdfmhst.f90:332-333, src/cdfpsi.f90:277,296
+                const double d0 = (double)__fmul_rn(__fmul_rn(x0[v][c], m[v][c]), e3[v][c]);
+                if (MODE == kPsi) {
+                    s0[v][c] = __dadd_rn(s0[v][c], d0);
+                } else {
+                    s0[v][c] = __dadd_rn(s0[v][c], __dmul_rn(__dmul_rn(d0, 1000.0), 4000.0));   // :336 pprau0, pprcp
+                    s1[v][c] = __dadd_rn(s1[v][c], (double)__fmul_rn(__fmul_rn(x1[v][c], m[v][c]), e3[v][c]));   // :337
+                }
+            }
     }
+#pragma unroll
+    for (int v = 0; v < VPT; ++v)
+        if (ok[v])
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) {
+                a.acc0[p[v] + c] = s0[v][c];
+                if (MODE != kPsi) a.acc1[p[v] + c] = s1[v][c];
+            }
 }
+
 
 template <int MODE>
 int launch_vint(const VintArgs &a, hipStream_t st) {
@@ -116,9 +137,13 @@ int launch_vint(const VintArgs &a, hipStream_t st) {
     if (a.nij % 4 == 0 && rowok4 && all(16)) vec = 4;
     else if (a.nij % 2 == 0 && rowok2 && all(8)) vec = 2;
     const bool full = a.e31d != nullptr;
-    const int64_t nthr = (a.nij + vec - 1) / vec;
+    static int vpt = 0;                                  // vectors per lane: CDFT_VINT_VPT = 1 | 2 | 4 (tuning)
+    if (!vpt) { const char *e = getenv("CDFT_VINT_VPT"); vpt = e ? atoi(e) : 4; if (vpt != 1 && vpt != 2 && vpt != 4) vpt = 4; }
+    const int64_t nvecs = (a.nij + vec - 1) / vec, nthr = (nvecs + vpt - 1) / vpt;
     const dim3 grid((unsigned)((nthr + kThreads - 1) / kThreads)), block(kThreads);
-#define CDFT_GO(V, F) hipLaunchKernelGGL((vint_kernel<V, MODE, F>), grid, block, 0, st, a)
+#define CDFT_GO(V, F) do { if (vpt == 1) hipLaunchKernelGGL((vint_kernel<V, MODE, F, 1>), grid, block, 0, st, a); \
+                           else if (vpt == 2) hipLaunchKernelGGL((vint_kernel<V, MODE, F, 2>), grid, block, 0, st, a); \
+                           else hipLaunchKernelGGL((vint_kernel<V, MODE, F, 4>), grid, block, 0, st, a); } while (0)
     if (vec == 4) { if (full) CDFT_GO(4, true); else CDFT_GO(4, false); }
     else if (vec == 2) { if (full) CDFT_GO(2, true); else CDFT_GO(2, false); }
     else { if (full) CDFT_GO(1, true); else CDFT_GO(1, false); }
@@ -169,18 +194,28 @@ __global__ void psi_scan_j_kernel(const double *__restrict__ dtrp, double *__res
     if (i >= npi) return;
     double acc = 0.0;
     dpsi[i] = 0.0;
-    constexpr int kB = 16;                               // rows fetched together: the loads are independent,
-    for (int j0 = 1; j0 < npj; j0 += kB) {               // only the additions are sequential
-        double x[kB];
+    // Only the additions are sequential: rows are fetched kB at a time, and the next batch is in
+    // flight while the current one is accumulated and stored (double buffer in registers).
+    constexpr int kB = 24;
+    double xa[kB], xb[kB];
+    auto fetch = [&](double (&x)[kB], int j0) {
 #pragma unroll
         for (int r = 0; r < kB; ++r) x[r] = (j0 + r < npj) ? dtrp[(int64_t)(j0 + r) * npi + i] : 0.0;
+    };
+    auto drain = [&](const double (&x)[kB], int j0) {
 #pragma unroll
-        for (int r = 0; r < kB; ++r) {
+        for (int r = 0; r < kB; ++r)
             if (j0 + r < npj) {
                 acc = __dadd_rn(acc, -x[r]);
                 dpsi[(int64_t)(j0 + r) * npi + i] = acc;
             }
-        }
+    };
+    fetch(xa, 1);
+    for (int j0 = 1; j0 < npj; j0 += 2 * kB) {
+        fetch(xb, j0 + kB);
+        drain(xa, j0);
+        fetch(xa, j0 + 2 * kB);
+        drain(xb, j0 + kB);
     }
 }
 
