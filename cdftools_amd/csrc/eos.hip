@@ -46,19 +46,24 @@ template <int SET, bool FAST>
 __device__ __forceinline__ double sigmai_point(float ptem, float psal, float pref) {
     constexpr double rdeltas = SET ? CDFT_EOS_RDELTAS_T10 : CDFT_EOS_RDELTAS_80;
     constexpr double r1_s0   = SET ? CDFT_EOS_R1_S0_T10 : CDFT_EOS_R1_S0_80;
-    const double h = __dmul_rn((double)pref, CDFT_EOS_R1_Z0);                       // :842 / :1046
-    double ref = kR[5];                                                             // :845 / :1050
-#pragma unroll
-    for (int q = 4; q >= 0; --q) ref = muladd<FAST>(ref, h, kR[q]);
-    ref = __dmul_rn(ref, h);
     const double t  = __dmul_rn((double)ptem, CDFT_EOS_R1_T0);                      // :850
     const double s  = __dsqrt_rn(__dmul_rn(fabs(__dadd_rn((double)psal, rdeltas)), r1_s0));  // :851
     const double tm = (psal == 0.0f) ? 0.0 : 1.0;                                   // :852-856
-    const double r3 = eos_rk<SET, 3, FAST>(t, s);
-    const double r2 = eos_rk<SET, 2, FAST>(t, s);
-    const double r1 = eos_rk<SET, 1, FAST>(t, s);
     const double r0 = eos_rk<SET, 0, FAST>(t, s);
-    const double r  = muladd<FAST>(muladd<FAST>(muladd<FAST>(r3, h, r2), h, r1), h, r0);   // :877
+    double r = r0, ref = 0.0;
+    // At the surface (sigma0: pref = 0) h = 0, so ((r3*h + r2)*h + r1)*h + r0 is r0 and the reference
+    // profile is +0 for every finite T,S: the three depth-dependent polynomials are skipped (bit-identical).
+    if (pref != 0.0f) {
+        const double h = __dmul_rn((double)pref, CDFT_EOS_R1_Z0);                   // :842 / :1046
+        ref = kR[5];                                                                // :845 / :1050
+#pragma unroll
+        for (int q = 4; q >= 0; --q) ref = muladd<FAST>(ref, h, kR[q]);
+        ref = __dmul_rn(ref, h);
+        const double r3 = eos_rk<SET, 3, FAST>(t, s);
+        const double r2 = eos_rk<SET, 2, FAST>(t, s);
+        const double r1 = eos_rk<SET, 1, FAST>(t, s);
+        r = muladd<FAST>(muladd<FAST>(muladd<FAST>(r3, h, r2), h, r1), h, r0);     // :877
+    }
     return __dmul_rn(__dadd_rn(__dadd_rn(r, ref), -CDFT_EOS_RAU0), tm);            // :880
 }
 
