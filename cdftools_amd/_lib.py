@@ -66,6 +66,10 @@ SIGNATURES = {
     "cdft_mhst_destroy": (_i, [_vp]),
     "cdft_psi_create": (_i, [_pvp, _i, _i, _i]),
     "cdft_psi_compute": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _vp]),
+    "cdft_psi_integrate": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "cdft_psi_scan_u": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp]),
+    "cdft_psi_value": (_i, [_vp, _i, _i, C.POINTER(C.c_double), _vp]),
+    "cdft_psi_finish": (_i, [_vp, _i, C.c_double, _i, _i, _vp, _i, _vp, _vp, _i, _vp]),
     "cdft_psi_destroy": (_i, [_vp]),
     "cdft_vt_compute": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                              _i, _i, _vp]),

@@ -189,11 +189,20 @@ mhst_zonal_kernel(const double *__restrict__ dtrph, const double *__restrict__ d
 }
 
 // cdfpsi U path, src/cdfpsi.f90:395-398: dpsiu(:,1) = 0 ; dpsiu(:,jj) = dpsiu(:,jj-1) - dtrpu(:,jj)
-__global__ void psi_scan_j_kernel(const double *__restrict__ dtrp, double *__restrict__ dpsi, int npi, int npj) {
+// Row-block sharding: a block that does not hold global row 1 continues the running difference of
+// the block south of it: it starts from that block's last row (carry) and its first row is an
+// ordinary row.  Chained this way the result does not depend on the number of blocks (bit for bit).
+__global__ void psi_scan_j_kernel(const double *__restrict__ dtrp, double *__restrict__ dpsi, int npi, int npj,
+                                  const double *__restrict__ carry, int first_block) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= npi) return;
-    double acc = 0.0;
-    dpsi[i] = 0.0;
+    double acc = carry ? carry[i] : 0.0;
+    if (first_block) {
+        dpsi[i] = acc;                                    // global row 1: dpsiu(:,1) = 0, its transport is not used
+    } else {
+        acc = __dadd_rn(acc, -dtrp[i]);
+        dpsi[i] = acc;
+    }
     // Only the additions are sequential: rows are fetched kB at a time, and the next batch is in
     // flight while the current one is accumulated and stored (double buffer in registers).
     constexpr int kB = 24;
@@ -249,15 +258,15 @@ __global__ void __launch_bounds__(64) psi_scan_i_kernel(const double *__restrict
 
 // src/cdfpsi.f90:412-438: optional mean of the two estimates, reference point, SNGL, optional mask
 __global__ void psi_final_kernel(const double *__restrict__ du, const double *__restrict__ dv, int64_t nij,
-                                 int64_t pref, const float *__restrict__ fmask, float *__restrict__ psi4,
-                                 double *__restrict__ dpsi8) {
+                                 int64_t pref, int use_ref, double ref_value, const float *__restrict__ fmask,
+                                 float *__restrict__ psi4, double *__restrict__ dpsi8) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= nij) return;
     auto val = [&](int64_t q) {
         if (du && dv) return __dmul_rn(0.5, __dadd_rn(du[q], dv[q]));
         return du ? du[q] : dv[q];
     };
-    const double d = __dadd_rn(val(p), -val(pref));
+    const double d = __dadd_rn(val(p), -(use_ref ? ref_value : val(pref)));
     if (dpsi8) dpsi8[p] = d;
     psi4[p] = fmask ? __fmul_rn((float)d, fmask[p]) : (float)d;
 }
@@ -395,7 +404,8 @@ struct cdft_psi_plan {
     int npi = 0, npj = 0, npk = 0;
     double *dtrpu = nullptr, *dtrpv = nullptr, *dpsiu = nullptr, *dpsiv = nullptr, *d8 = nullptr;
     float *p4 = nullptr;
-    DevBuf su, se3u, sv, se3v, sm0, sm1, sfm, s1d;
+    bool lu = false, lv = false;                       // what the last cdft_psi_integrate filled
+    DevBuf su, se3u, sv, se3v, sm0, sm1, sfm, s1d, scar;
 };
 
 extern "C" {
@@ -420,22 +430,18 @@ int cdft_psi_create(cdft_psi_plan **plan, int npiglo, int npjglo, int npk) {
     return CDFT_OK;
 }
 
-int cdft_psi_compute(cdft_psi_plan *p, const float *zu, const float *e2u, const float *e3u, const float *zv,
-                     const float *e1v, const float *e3v, const float *e31d, int iiref, int ijref,
-                     const float *fmask, int in_space, float *psi4, double *dpsi8, int out_space, void *stream) {
-    if (!p || !psi4) return fail(CDFT_ERR_ARG, "cdft_psi_compute: NULL argument");
+int cdft_psi_integrate(cdft_psi_plan *p, const float *zu, const float *e2u, const float *e3u, const float *zv,
+                       const float *e1v, const float *e3v, const float *e31d, int in_space, void *stream) {
+    if (!p) return fail(CDFT_ERR_ARG, "cdft_psi_integrate: NULL plan");
     const bool lu = zu != nullptr, lv = zv != nullptr;
-    if (!lu && !lv) return fail(CDFT_ERR_ARG, "cdft_psi_compute: give the U set, the V set, or both (-mean)");
+    if (!lu && !lv) return fail(CDFT_ERR_ARG, "cdft_psi: give the U set, the V set, or both (-mean)");
     if ((lu && (!e2u || (!e3u && !e31d))) || (lv && (!e1v || (!e3v && !e31d))))
-        return fail(CDFT_ERR_ARG, "cdft_psi_compute: each velocity needs its horizontal metric and e3 (or e31d)");
-    if (iiref < 1 || iiref > p->npi || ijref < 1 || ijref > p->npj)
-        return fail(CDFT_ERR_ARG, "cdft_psi_compute: reference point (%d,%d) outside the domain", iiref, ijref);
+        return fail(CDFT_ERR_ARG, "cdft_psi: each velocity needs its horizontal metric and e3 (or e31d)");
     hipStream_t st = as_stream(stream);
     const int64_t nij = (int64_t)p->npi * p->npj;
     const size_t n3b = (size_t)nij * p->npk * 4, n2b = (size_t)nij * 4;
-    const void *d1d = nullptr, *dfm = nullptr;
+    const void *d1d = nullptr;
     if (e31d) CDFT_TRY(to_device(e31d, (size_t)p->npk * 4, in_space, p->s1d, st, &d1d));
-    if (fmask) CDFT_TRY(to_device(fmask, n2b, in_space, p->sfm, st, &dfm));
     auto integrate = [&](const float *z, const float *m, const float *e3, DevBuf &bz, DevBuf &be, DevBuf &bm,
                          double *acc) -> int {
         const void *dz, *dm, *de = nullptr;
@@ -448,21 +454,66 @@ int cdft_psi_compute(cdft_psi_plan *p, const float *zu, const float *e2u, const 
         a.nij = nij; a.npi = p->npi; a.npj = p->npj; a.k0 = 0; a.k1 = p->npk; a.init = 1;
         return launch_vint<kPsi>(a, st);
     };
-    if (lv) {
+    if (lv) {                                            // the i-scan stays inside a row: local to a row block
         CDFT_TRY(integrate(zv, e1v, e3v, p->sv, p->se3v, p->sm1, p->dtrpv));
         hipLaunchKernelGGL(psi_scan_i_kernel, dim3((p->npj + 63) / 64), dim3(64), 0, st, p->dtrpv, p->dpsiv, p->npi, p->npj);
         CDFT_LAUNCH_CHECK();
     }
-    if (lu) {
-        CDFT_TRY(integrate(zu, e2u, e3u, p->su, p->se3u, p->sm0, p->dtrpu));
-        hipLaunchKernelGGL(psi_scan_j_kernel, dim3((p->npi + 63) / 64), dim3(64), 0, st, p->dtrpu, p->dpsiu, p->npi, p->npj);
-        CDFT_LAUNCH_CHECK();
+    if (lu) CDFT_TRY(integrate(zu, e2u, e3u, p->su, p->se3u, p->sm0, p->dtrpu));
+    p->lu = lu; p->lv = lv;
+    return CDFT_OK;
+}
+
+int cdft_psi_scan_u(cdft_psi_plan *p, const double *carry, int carry_space, int first_block, double *last_row,
+                    int last_space, void *stream) {
+    if (!p) return fail(CDFT_ERR_ARG, "cdft_psi_scan_u: NULL plan");
+    if (!p->lu) return CDFT_OK;                          // V-only: nothing runs along j
+    hipStream_t st = as_stream(stream);
+    const void *dc = nullptr;
+    if (carry) CDFT_TRY(to_device(carry, (size_t)p->npi * 8, carry_space, p->scar, st, &dc));
+    hipLaunchKernelGGL(psi_scan_j_kernel, dim3((p->npi + 63) / 64), dim3(64), 0, st, p->dtrpu, p->dpsiu, p->npi, p->npj,
+                       (const double *)dc, first_block ? 1 : 0);
+    CDFT_LAUNCH_CHECK();
+    if (last_row) {
+        const double *src = p->dpsiu + (int64_t)(p->npj - 1) * p->npi;
+        CDFT_HIP(hipMemcpyAsync(last_row, src, (size_t)p->npi * 8,
+                                last_space == CDFT_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
+        if (last_space == CDFT_MEM_HOST) CDFT_HIP(hipStreamSynchronize(st));
     }
+    return CDFT_OK;
+}
+
+int cdft_psi_value(cdft_psi_plan *p, int ii, int ij, double *value, void *stream) {
+    if (!p || !value) return fail(CDFT_ERR_ARG, "cdft_psi_value: NULL argument");
+    if (ii < 1 || ii > p->npi || ij < 1 || ij > p->npj)
+        return fail(CDFT_ERR_ARG, "cdft_psi_value: point (%d,%d) outside the local block", ii, ij);
+    hipStream_t st = as_stream(stream);
+    const int64_t q = (int64_t)(ij - 1) * p->npi + (ii - 1);
+    double u = 0.0, v = 0.0;
+    if (p->lu) CDFT_HIP(hipMemcpyAsync(&u, p->dpsiu + q, 8, hipMemcpyDeviceToHost, st));
+    if (p->lv) CDFT_HIP(hipMemcpyAsync(&v, p->dpsiv + q, 8, hipMemcpyDeviceToHost, st));
+    CDFT_HIP(hipStreamSynchronize(st));
+    *value = (p->lu && p->lv) ? 0.5 * (u + v) : (p->lu ? u : v);    // as psi_final_kernel's val()
+    return CDFT_OK;
+}
+
+int cdft_psi_finish(cdft_psi_plan *p, int use_ref, double ref_value, int iiref, int ijref, const float *fmask,
+                    int mask_space, float *psi4, double *dpsi8, int out_space, void *stream) {
+    if (!p || !psi4) return fail(CDFT_ERR_ARG, "cdft_psi_finish: NULL argument");
+    if (!p->lu && !p->lv) return fail(CDFT_ERR_STATE, "cdft_psi_finish: cdft_psi_integrate has not run");
+    if (!use_ref && (iiref < 1 || iiref > p->npi || ijref < 1 || ijref > p->npj))
+        return fail(CDFT_ERR_ARG, "cdft_psi: reference point (%d,%d) outside the domain", iiref, ijref);
+    hipStream_t st = as_stream(stream);
+    const int64_t nij = (int64_t)p->npi * p->npj;
+    const size_t n2b = (size_t)nij * 4;
+    const void *dfm = nullptr;
+    if (fmask) CDFT_TRY(to_device(fmask, n2b, mask_space, p->sfm, st, &dfm));
     float *o4 = out_space == CDFT_MEM_DEVICE ? psi4 : p->p4;
     double *o8 = dpsi8 ? (out_space == CDFT_MEM_DEVICE ? dpsi8 : p->d8) : nullptr;
-    const int64_t pref = (int64_t)(ijref - 1) * p->npi + (iiref - 1);
+    const int64_t pref = use_ref ? 0 : (int64_t)(ijref - 1) * p->npi + (iiref - 1);
     hipLaunchKernelGGL(psi_final_kernel, dim3((unsigned)((nij + 255) / 256)), dim3(256), 0, st,
-                       lu ? p->dpsiu : nullptr, lv ? p->dpsiv : nullptr, nij, pref, (const float *)dfm, o4, o8);
+                       p->lu ? p->dpsiu : nullptr, p->lv ? p->dpsiv : nullptr, nij, pref, use_ref ? 1 : 0, ref_value,
+                       (const float *)dfm, o4, o8);
     CDFT_LAUNCH_CHECK();
     if (out_space == CDFT_MEM_HOST) {
         CDFT_HIP(hipMemcpyAsync(psi4, o4, n2b, hipMemcpyDeviceToHost, st));
@@ -472,11 +523,22 @@ int cdft_psi_compute(cdft_psi_plan *p, const float *zu, const float *e2u, const 
     return CDFT_OK;
 }
 
+int cdft_psi_compute(cdft_psi_plan *p, const float *zu, const float *e2u, const float *e3u, const float *zv,
+                     const float *e1v, const float *e3v, const float *e31d, int iiref, int ijref,
+                     const float *fmask, int in_space, float *psi4, double *dpsi8, int out_space, void *stream) {
+    if (!p || !psi4) return fail(CDFT_ERR_ARG, "cdft_psi_compute: NULL argument");
+    if (iiref < 1 || iiref > p->npi || ijref < 1 || ijref > p->npj)
+        return fail(CDFT_ERR_ARG, "cdft_psi_compute: reference point (%d,%d) outside the domain", iiref, ijref);
+    CDFT_TRY(cdft_psi_integrate(p, zu, e2u, e3u, zv, e1v, e3v, e31d, in_space, stream));
+    CDFT_TRY(cdft_psi_scan_u(p, nullptr, CDFT_MEM_HOST, 1, nullptr, CDFT_MEM_HOST, stream));
+    return cdft_psi_finish(p, 0, 0.0, iiref, ijref, fmask, in_space, psi4, dpsi8, out_space, stream);
+}
+
 int cdft_psi_destroy(cdft_psi_plan *p) {
     if (!p) return CDFT_OK;
     void *ptrs[] = {p->dtrpu, p->dtrpv, p->dpsiu, p->dpsiv, p->d8, p->p4};
     for (void *q : ptrs) if (q) (void)hipFree(q);
-    DevBuf *bufs[] = {&p->su, &p->se3u, &p->sv, &p->se3v, &p->sm0, &p->sm1, &p->sfm, &p->s1d};
+    DevBuf *bufs[] = {&p->su, &p->se3u, &p->sv, &p->se3v, &p->sm0, &p->sm1, &p->sfm, &p->s1d, &p->scar};
     for (DevBuf *b : bufs) b->release();
     delete p;
     return CDFT_OK;

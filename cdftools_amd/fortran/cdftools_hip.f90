@@ -101,6 +101,23 @@ MODULE cdftools_hip
        IMPORT ; TYPE(C_PTR), VALUE :: plan, stream, zu, e2u, e3u, zv, e1v, e3v, e31d, fmask, dpsi8
        INTEGER(C_INT), VALUE :: iiref, ijref, in_space, out_space ; REAL(C_FLOAT), INTENT(out) :: psi4(*)
      END FUNCTION
+     ! staged form for a row-block partitioned domain (one plan per block, see include/cdftools_hip.h)
+     INTEGER(C_INT) FUNCTION cdft_psi_integrate(plan, zu, e2u, e3u, zv, e1v, e3v, e31d, in_space, stream) &
+          &         BIND(C, name='cdft_psi_integrate')
+       IMPORT ; TYPE(C_PTR), VALUE :: plan, stream, zu, e2u, e3u, zv, e1v, e3v, e31d ; INTEGER(C_INT), VALUE :: in_space
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_psi_scan_u(plan, carry, carry_space, first_block, last_row, last_space, stream) &
+          &         BIND(C, name='cdft_psi_scan_u')
+       IMPORT ; TYPE(C_PTR), VALUE :: plan, stream, carry, last_row ; INTEGER(C_INT), VALUE :: carry_space, first_block, last_space
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_psi_value(plan, ii, ij, dvalue, stream) BIND(C, name='cdft_psi_value')
+       IMPORT ; TYPE(C_PTR), VALUE :: plan, stream ; INTEGER(C_INT), VALUE :: ii, ij ; REAL(C_DOUBLE), INTENT(out) :: dvalue
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_psi_finish(plan, use_ref, ref_value, iiref, ijref, fmask, mask_space, psi4, dpsi8, &
+          &                                  out_space, stream) BIND(C, name='cdft_psi_finish')
+       IMPORT ; TYPE(C_PTR), VALUE :: plan, stream, fmask, dpsi8 ; REAL(C_DOUBLE), VALUE :: ref_value
+       INTEGER(C_INT), VALUE :: use_ref, iiref, ijref, mask_space, out_space ; REAL(C_FLOAT), INTENT(out) :: psi4(*)
+     END FUNCTION
      INTEGER(C_INT) FUNCTION cdft_psi_destroy(plan) BIND(C, name='cdft_psi_destroy')
        IMPORT ; TYPE(C_PTR), VALUE :: plan
      END FUNCTION

@@ -326,6 +326,41 @@ class PsiPlan(_Plan):
         self._h = C.c_void_p()
         check(_lib.load().cdft_psi_create(C.byref(self._h), npiglo, npjglo, npk))
 
+    # --- the stages used when the domain is row-block partitioned (cdftools_amd/shard.py) ---
+    def integrate(self, zu=None, e2u=None, e3u=None, zv=None, e1v=None, e3v=None, e31d=None, stream=None):
+        names = ("zu", "e2u", "e3u", "zv", "e1v", "e3v", "e31d")
+        a = [_opt(x, n) for x, n in zip((zu, e2u, e3u, zv, e1v, e3v, e31d), names)]
+        sp = _same_space(*[x[1] for x in a])
+        check(_lib.load().cdft_psi_integrate(self._h, a[0][0], a[1][0], a[2][0], a[3][0], a[4][0], a[5][0], a[6][0],
+                                             sp, stream or current_stream_ptr()))
+
+    def scan_u(self, carry=None, first_block=True, stream=None):
+        """j-scan of the U path; carry (npi,) r8 host array from the block to the south -> this block's
+        last row (npi,) r8 host array."""
+        last = np.empty(self.npi, np.float64)
+        keep = None if carry is None else np.ascontiguousarray(carry, np.float64)
+        if keep is not None and keep.shape != (self.npi,):
+            raise ValueError(f"carry has shape {keep.shape}, expected {(self.npi,)}")
+        pc = _null() if keep is None else C.c_void_p(keep.ctypes.data)
+        check(_lib.load().cdft_psi_scan_u(self._h, pc, MEM_HOST, 1 if first_block else 0, C.c_void_p(last.ctypes.data),
+                                          MEM_HOST, stream or current_stream_ptr()))
+        return last
+
+    def value(self, ii, ij, stream=None):
+        v = C.c_double(0)
+        check(_lib.load().cdft_psi_value(self._h, ii, ij, C.byref(v), stream or current_stream_ptr()))
+        return v.value
+
+    def finish(self, ref_value=None, iiref=None, ijref=None, fmask=None, stream=None):
+        pm, sm, km = _opt(fmask, "fmask")
+        p4, d8 = np.empty((self.npj, self.npi), np.float32), np.empty((self.npj, self.npi), np.float64)
+        use = ref_value is not None
+        check(_lib.load().cdft_psi_finish(self._h, 1 if use else 0, float(ref_value) if use else 0.0,
+                                          iiref or 1, ijref or 1, pm, MEM_HOST if sm is None else sm,
+                                          C.c_void_p(p4.ctypes.data), C.c_void_p(d8.ctypes.data), MEM_HOST,
+                                          stream or current_stream_ptr()))
+        return p4, d8
+
     def compute(self, zu=None, e2u=None, e3u=None, zv=None, e1v=None, e3v=None, e31d=None, iiref=None,
                 ijref=None, fmask=None, stream=None, host_out=True, want_r8=True):
         """-> (psi4 (npj,npi) r4, dpsi8 (npj,npi) r8 or None): host arrays, or tensors in HBM when the

@@ -194,6 +194,24 @@ int cdft_psi_compute(cdft_psi_plan *plan, const float *zu, const float *e2u, con
                      const float *zv, const float *e1v, const float *e3v, const float *e31d, int iiref,
                      int ijref, const float *fmask, int in_space, float *psi4, double *dpsi8, int out_space,
                      void *stream);
+/* The same computation in stages, for a domain that is row-block partitioned over several GPUs
+ * (cdftools_amd/shard.py): cdft_psi_compute == integrate + scan_u(no carry, first block) + finish.
+ *   integrate : vertical integration of the block (and the i-scan of the V path, which stays inside rows).
+ *   scan_u    : the j-scan of the U path.  A block that does not hold global row 1 passes
+ *               first_block = 0 and carry(npiglo) r8 = the last row of the block south of it; last_row
+ *               (optional) returns this block's last row for the next one.  Chained in rank order the
+ *               result is bit-identical to the single-GPU one.
+ *   value     : the (mean of the) stream function at a local point, before the reference shift
+ *               (the owner of the reference point broadcasts it).
+ *   finish    : reference shift (use_ref = 1: ref_value given; 0: local point (iiref,ijref)), SNGL, mask. */
+int cdft_psi_integrate(cdft_psi_plan *plan, const float *zu, const float *e2u, const float *e3u,
+                       const float *zv, const float *e1v, const float *e3v, const float *e31d, int in_space,
+                       void *stream);
+int cdft_psi_scan_u(cdft_psi_plan *plan, const double *carry, int carry_space, int first_block,
+                    double *last_row, int last_space, void *stream);
+int cdft_psi_value(cdft_psi_plan *plan, int ii, int ij, double *value, void *stream);
+int cdft_psi_finish(cdft_psi_plan *plan, int use_ref, double ref_value, int iiref, int ijref,
+                    const float *fmask, int mask_space, float *psi4, double *dpsi8, int out_space, void *stream);
 int cdft_psi_destroy(cdft_psi_plan *plan);
 
 /* ------------------------------------------------------------------------------------------ */

@@ -69,3 +69,156 @@ def test_two_rank_gloo_gather_matches_single_process(npj):
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=10) is True
+
+
+# ------------------------------------------------------------------ the other tools of the path
+def test_halo_windows():
+    assert shard.halo_window(19, 2, 0) == (0, 11, 0, 10)
+    assert shard.halo_window(19, 2, 1) == (10, 19, 0, 9)               # last block: no halo row to read
+    assert shard.halo_window(19, 2, 1, south=1) == (9, 19, 1, 10)
+    assert shard.halo_window(19, 1, 0, south=1) == (0, 19, 0, 19)
+
+
+class NumpyPsiStages:
+    """The three stages of cdftools_amd.hip.PsiPlan restated with numpy for ONE row block (checker
+    for shard.psi_chain; same arithmetic as oracle_psi: r4 products, r8 sums, sequential scans)."""
+
+    def __init__(self, npk, zu=None, e2u=None, e3u=None, zv=None, e1v=None, e3v=None):
+        self.lu, self.lv = zu is not None, zv is not None
+        ref = e2u if self.lu else e1v
+        self.npj, self.npi = ref.shape
+        if self.lu:
+            self.dtrpu = np.zeros(ref.shape)
+            for k in range(npk):
+                self.dtrpu += ((zu[k] * e2u) * e3u[k]).astype(np.float64)
+        if self.lv:
+            dtrpv = np.zeros(ref.shape)
+            for k in range(npk):
+                dtrpv += ((zv[k] * e1v) * e3v[k]).astype(np.float64)
+            self.dpsiv = np.zeros(ref.shape)
+            for i in range(self.npi - 2, -1, -1):
+                self.dpsiv[:, i] = self.dpsiv[:, i + 1] - dtrpv[:, i]
+
+    def scan_u(self, carry, first_block):
+        if not self.lu:
+            return np.zeros(self.npi)
+        self.dpsiu = np.zeros((self.npj, self.npi))
+        acc = np.zeros(self.npi) if carry is None else np.array(carry, np.float64)
+        for j in range(self.npj):
+            if not (first_block and j == 0):
+                acc = acc - self.dtrpu[j]
+            self.dpsiu[j] = acc
+        return self.dpsiu[-1].copy()
+
+    def _val(self):
+        if self.lu and self.lv:
+            return 0.5 * (self.dpsiu + self.dpsiv)
+        return self.dpsiu if self.lu else self.dpsiv
+
+    def value(self, ii, ij):
+        return float(self._val()[ij - 1, ii - 1])
+
+    def finish(self, ref_value=None, iiref=None, ijref=None, fmask=None):
+        v = self._val()
+        d = v - (v[ijref - 1, iiref - 1] if ref_value is None else ref_value)
+        p4 = d.astype(np.float32)
+        return (p4 * fmask if fmask is not None else p4), d
+
+
+def _tools_worker(rank, world, port, npi, npj, npk, q):
+    import oracle_tools
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ok = {}
+    try:
+        g = synth.make_grid(npi, npj, npk, seed=5)
+        rng = np.random.default_rng(11)
+        u = (rng.standard_normal((2, npk, npj, npi)) * g["umask"]).astype(np.float32)
+        v = (rng.standard_normal((2, npk, npj, npi)) * g["vmask"]).astype(np.float32)
+        t = ((10 + rng.standard_normal((2, npk, npj, npi))) * g["tmask"]).astype(np.float32)
+        s = ((35 + rng.standard_normal((2, npk, npj, npi))) * g["tmask"]).astype(np.float32)
+        j0, j1 = shard.row_block(npj, world, rank)
+
+        # cdfmhst: rows are independent with a vt file; from V,T,S each block reads T/S row j+1 too
+        masks = np.stack([g["vmask"][0], g["tmaskatl"], g["tmaskpac"]]).astype(np.float32)
+        h, sl = oracle_tools.mhst(g["e1v"][j0:j1], masks[:, j0:j1], e3v=g["e3v_0"][:, j0:j1], vt=t[0][:, j0:j1],
+                                  vs=s[0][:, j0:j1])
+        full = shard.gather_block_rows(torch.from_numpy(np.stack([h, sl])), npj, axis=1)
+        r0, r1, lo, hi = shard.halo_window(npj, world, rank)
+        h, sl = oracle_tools.mhst(g["e1v"][r0:r1], masks[:, r0:r1], e3v=g["e3v_0"][:, r0:r1], zv=v[0][:, r0:r1],
+                                  zt=t[0][:, r0:r1], zs=s[0][:, r0:r1])
+        full2 = shard.gather_block_rows(torch.from_numpy(np.stack([h[lo:hi], sl[lo:hi]])), npj, axis=1)
+        if rank == 0:
+            rh, rs = oracle_tools.mhst(g["e1v"], masks, e3v=g["e3v_0"], vt=t[0], vs=s[0])
+            ok["mhst"] = bool(np.array_equal(full.numpy(), np.stack([rh, rs])))
+            rh, rs = oracle_tools.mhst(g["e1v"], masks, e3v=g["e3v_0"], zv=v[0], zt=t[0], zs=s[0])
+            ok["mhst"] = ok["mhst"] and bool(np.array_equal(full2.numpy(), np.stack([rh, rs])))
+
+        # cdfvT and cdfcurl: one halo row read by each block but the last
+        r0, r1, lo, hi = shard.halo_window(npj, world, rank)
+        loc = oracle_tools.vt_level(u[:, 1, r0:r1], v[:, 1, r0:r1], t[:, 1, r0:r1], s[:, 1, r0:r1])
+        st = np.stack([loc[k][lo:hi] for k in ("vt", "vs", "ut", "us")])
+        full = shard.gather_block_rows(torch.from_numpy(st), npj, axis=1)
+        if rank == 0:
+            ref = oracle_tools.vt_level(u[:, 1], v[:, 1], t[:, 1], s[:, 1])
+            ok["vt"] = bool(np.array_equal(full.numpy(), np.stack([ref[k] for k in ("vt", "vs", "ut", "us")])))
+        for name, tp in (("curl", False), ("curlT", True)):
+            r0, r1, lo, hi = shard.halo_window(npj, world, rank, south=1 if tp else 0)
+            loc = oracle_tools.curl(u[0, 0, r0:r1], v[0, 0, r0:r1], g["e1u"][r0:r1], g["e2v"][r0:r1], g["e1f"][r0:r1],
+                                    g["e2f"][r0:r1], True, tp)[lo:hi]
+            full = shard.gather_block_rows(torch.from_numpy(loc), npj, axis=0)
+            if rank == 0:
+                ref = oracle_tools.curl(u[0, 0], v[0, 0], g["e1u"], g["e2v"], g["e1f"], g["e2f"], True, tp)
+                ok[name] = bool(np.array_equal(full.numpy(), ref) and np.count_nonzero(ref) > (0 if tp else 10))
+
+        # cdfheatc: per-level sums added in rank order (r8: regrouping moves the last bits only)
+        loc = oracle_tools.heatc(g["e1t"][j0:j1], g["e2t"][j0:j1], g["tmask"][:, j0:j1], t[0][:, j0:j1], e3t=g["e3t_0"][:, j0:j1])
+        tot = shard.heatc_sums(torch.from_numpy(loc)).numpy()
+        ref = oracle_tools.heatc(g["e1t"], g["e2t"], g["tmask"], t[0], e3t=g["e3t_0"])
+        ok[f"heatc{rank}"] = bool(np.allclose(tot, ref, rtol=1e-13, atol=0))
+        both = [torch.empty(tot.shape, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(both, torch.from_numpy(tot))
+        ok[f"heatc_same{rank}"] = all(torch.equal(both[0], b) for b in both)
+
+        # cdfpsi: chained scan, broadcast reference value
+        fm = np.minimum(g["fmask"][0], 1).astype(np.float32)
+        for name, kw, iiref, ijref in (("psiU", dict(u=True), npi, npj), ("psiV", dict(v=True), 3, 2),
+                                       ("psiMean", dict(u=True, v=True), 5, j1 if rank == 0 else j0)):
+            sync = torch.tensor([ijref])                                   # rank 0's choice: its own last row
+            dist.broadcast(sync, src=0)
+            ijref = int(sync.item())
+            a, full_a = {}, {}
+            if kw.get("u"):
+                a.update(zu=u[0][:, j0:j1], e2u=g["e2u"][j0:j1], e3u=g["e3u_0"][:, j0:j1])
+                full_a.update(zu=u[0], e2u=g["e2u"], e3u=g["e3u_0"])
+            if kw.get("v"):
+                a.update(zv=v[0][:, j0:j1], e1v=g["e1v"][j0:j1], e3v=g["e3v_0"][:, j0:j1])
+                full_a.update(zv=v[0], e1v=g["e1v"], e3v=g["e3v_0"])
+            p4, d8 = shard.psi_chain(NumpyPsiStages(npk, **a), npj, iiref, ijref, fmask=fm[j0:j1])
+            full4 = shard.gather_block_rows(torch.from_numpy(np.ascontiguousarray(p4)), npj, axis=0)
+            full8 = shard.gather_block_rows(torch.from_numpy(np.ascontiguousarray(d8)), npj, axis=0)
+            if rank == 0:
+                r4, r8 = oracle_tools.psi(npk, iiref=iiref, ijref=ijref, fmask=fm, **full_a)
+                ok[name] = bool(np.array_equal(full4.numpy(), r4) and np.array_equal(full8.numpy(), r8))
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,npj", [(2, 19), (3, 20)])
+def test_row_block_sharding_of_the_other_tools_matches_single_process(world, npj):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tools_worker, args=(r, world, port, 23, npj, 5, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    bad = [k for k in ("mhst", "vt", "curl", "curlT", "psiU", "psiV", "psiMean") if not res[0].get(k)]
+    assert not bad, bad
+    for r in range(world):
+        assert res[r][f"heatc{r}"] and res[r][f"heatc_same{r}"], res[r]

@@ -86,6 +86,42 @@ def test_hip_psi_equals_oracle_bitwise(gpu, npi, npj, npk):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("npi,npj,npk,blocks", [(24, 18, 7, 2), (182, 149, 5, 3), (70, 9, 2, 8), (5, 2, 1, 2)])
+def test_hip_psi_row_blocks_chained_equal_the_whole_domain_bitwise(gpu, npi, npj, npk, blocks):
+    """The staged entry points (integrate / scan_u with a carry / value / finish with a given
+    reference value) used by cdftools_amd.shard.psi_chain: any number of row blocks, chained in
+    order, reproduces the one-plan result bit for bit."""
+    from cdftools_amd import shard
+
+    g = synth.make_grid(npi, npj, npk, seed=npi + 3)
+    _, _, u, v = tracer_fields(g, 5)
+    fm = np.minimum(g["fmask"][0], 1).astype(np.float32)
+    iiref, ijref = max(1, npi // 2), max(1, (2 * npj) // 3)
+    for lu, lv in ((True, False), (False, True), (True, True)):
+        kw = {}
+        if lu:
+            kw.update(zu=u, e2u=g["e2u"], e3u=g["e3u_0"])
+        if lv:
+            kw.update(zv=v, e1v=g["e1v"], e3v=g["e3v_0"])
+        w4, w8 = gpu.PsiPlan(npi, npj, npk).compute(iiref=iiref, ijref=ijref, fmask=fm, **kw)
+        plans, carry, ref = [], None, None
+        for r in range(blocks):
+            j0, j1 = shard.row_block(npj, blocks, r)
+            p = gpu.PsiPlan(npi, j1 - j0, npk)
+            p.integrate(**{k: (x[:, j0:j1] if x.ndim == 3 else x[j0:j1]) for k, x in kw.items()})
+            carry = p.scan_u(carry, first_block=(r == 0))
+            if j0 < ijref <= j1:
+                ref = p.value(iiref, ijref - j0)
+            plans.append((p, j0, j1))
+        got4, got8 = np.empty_like(w4), np.empty_like(w8)
+        for p, j0, j1 in plans:
+            got4[j0:j1], got8[j0:j1] = p.finish(ref, fmask=fm[j0:j1])
+        assert np.array_equal(got8, w8) and np.array_equal(got4, w4), (lu, lv)
+    with pytest.raises(gpu.CdftError):
+        gpu.PsiPlan(4, 4, 2).finish(0.0)                                # nothing integrated yet
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("npi,npj,npk,nb", [(24, 18, 7, 4), (182, 149, 31, 4), (182, 149, 31, 1), (1, 2, 1, 1),
                                             (7, 3, 2, 4), (1442, 9, 3, 4), (333, 5, 4, 8)])
 def test_hip_mhst_matches_oracle(gpu, npi, npj, npk, nb):
