@@ -31,6 +31,20 @@ struct DevBuf {
 int to_device(const void *src, size_t n, int memspace, DevBuf &stage, hipStream_t st,
               const void **dev);
 
+// Streaming loads.  Every kernel of this path reads its 3-D fields exactly once; a nontemporal
+// load tells L2 / Infinity Cache not to keep those lines (measured with tools/hbm_probe.hip on
+// MI355X: 7.0-7.2 TB/s for a nontemporal read stream against 6.3-6.5 TB/s with plain loads).
+typedef float f4a __attribute__((ext_vector_type(4)));               // 16-byte aligned address
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // any r4 address
+__device__ __forceinline__ f4a ld_stream4(const float *p) {
+    return __builtin_nontemporal_load(reinterpret_cast<const f4a *>(p));
+}
+__device__ __forceinline__ f4u ld_stream4u(const float *p) {
+    return __builtin_nontemporal_load(reinterpret_cast<const f4u *>(p));
+}
+template <typename T>
+__device__ __forceinline__ T ld_stream(const T *p) { return __builtin_nontemporal_load(p); }
+
 }  // namespace cdft
 
 #define CDFT_HIP(call)                                                                     \

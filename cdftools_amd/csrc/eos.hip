@@ -128,12 +128,12 @@ __global__ void __launch_bounds__(256) eos_kernel(EosArgs a) {
     for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += stride) {
         float t[VEC], s[VEC], p[VEC];
         if (VEC == 4) {
-            const float4 tt = reinterpret_cast<const float4 *>(a.t)[v];
-            const float4 ss = reinterpret_cast<const float4 *>(a.s)[v];
+            const f4a tt = ld_stream4(a.t + 4 * (int64_t)v);
+            const f4a ss = ld_stream4(a.s + 4 * (int64_t)v);
             t[0] = tt.x; t[1] = tt.y; t[2] = tt.z; t[3] = tt.w;
             s[0] = ss.x; s[1] = ss.y; s[2] = ss.z; s[3] = ss.w;
             if (KIND == kPointRef) {
-                const float4 pp = reinterpret_cast<const float4 *>(a.p2d)[v];
+                const f4a pp = ld_stream4(a.p2d + 4 * (int64_t)v);
                 p[0] = pp.x; p[1] = pp.y; p[2] = pp.z; p[3] = pp.w;
             }
         } else {

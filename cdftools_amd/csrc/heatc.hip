@@ -49,17 +49,20 @@ __global__ void heatc_area_kernel(const float *__restrict__ e1t, const float *__
 
 template <int VEC>
 struct Vec;
-template <> struct Vec<4> { typedef float4 f; typedef uchar4 u; };
-template <> struct Vec<2> { typedef float2 f; typedef uchar2 u; };
+typedef float f2a __attribute__((ext_vector_type(2)));
+typedef unsigned char u4a __attribute__((ext_vector_type(4)));
+typedef unsigned char u2a __attribute__((ext_vector_type(2)));
+template <> struct Vec<4> { typedef f4a f; typedef u4a u; };
+template <> struct Vec<2> { typedef f2a f; typedef u2a u; };
 template <> struct Vec<1> { typedef float f;  typedef unsigned char u; };
 
 template <int VEC> __device__ __forceinline__ void unpack(const typename Vec<VEC>::f &v, float (&o)[VEC]);
-template <> __device__ __forceinline__ void unpack<4>(const float4 &v, float (&o)[4]) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
-template <> __device__ __forceinline__ void unpack<2>(const float2 &v, float (&o)[2]) { o[0] = v.x; o[1] = v.y; }
+template <> __device__ __forceinline__ void unpack<4>(const f4a &v, float (&o)[4]) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+template <> __device__ __forceinline__ void unpack<2>(const f2a &v, float (&o)[2]) { o[0] = v.x; o[1] = v.y; }
 template <> __device__ __forceinline__ void unpack<1>(const float &v, float (&o)[1]) { o[0] = v; }
 template <int VEC> __device__ __forceinline__ void unpacku(const typename Vec<VEC>::u &v, float (&o)[VEC]);
-template <> __device__ __forceinline__ void unpacku<4>(const uchar4 &v, float (&o)[4]) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
-template <> __device__ __forceinline__ void unpacku<2>(const uchar2 &v, float (&o)[2]) { o[0] = v.x; o[1] = v.y; }
+template <> __device__ __forceinline__ void unpacku<4>(const u4a &v, float (&o)[4]) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+template <> __device__ __forceinline__ void unpacku<2>(const u2a &v, float (&o)[2]) { o[0] = v.x; o[1] = v.y; }
 template <> __device__ __forceinline__ void unpacku<1>(const unsigned char &v, float (&o)[1]) { o[0] = v; }
 
 constexpr int kVPT = 4;   // vectors per lane: each wave reads kVPT contiguous KiB-sized runs per field and level
@@ -96,15 +99,15 @@ __global__ void __launch_bounds__(kThreads) heatc_level_kernel(HeatcArgs a) {
         float e3[kVPT][VEC], tt[kVPT][VEC], mk[kVPT][VEC];
 #pragma unroll
         for (int v = 0; v < kVPT; ++v) {
-            unpack<VEC>(reinterpret_cast<const FV *>(a.temp)[base + q[v]], tt[v]);
+            unpack<VEC>(ld_stream(reinterpret_cast<const FV *>(a.temp) + base + q[v]), tt[v]);
             if (FULL) {
 #pragma unroll
                 for (int c = 0; c < VEC; ++c) e3[v][c] = e3k;
             } else {
-                unpack<VEC>(reinterpret_cast<const FV *>(a.e3t)[base + q[v]], e3[v]);
+                unpack<VEC>(ld_stream(reinterpret_cast<const FV *>(a.e3t) + base + q[v]), e3[v]);
             }
-            if (MASK8) unpacku<VEC>(reinterpret_cast<const UV *>(a.mask8)[base + q[v]], mk[v]);
-            else       unpack<VEC>(reinterpret_cast<const FV *>(a.mask4)[base + q[v]], mk[v]);
+            if (MASK8) unpacku<VEC>(ld_stream(reinterpret_cast<const UV *>(a.mask8) + base + q[v]), mk[v]);
+            else       unpack<VEC>(ld_stream(reinterpret_cast<const FV *>(a.mask4) + base + q[v]), mk[v]);
         }
         double s_surf = 0.0, s_vol = 0.0, s_sum = 0.0;
 #pragma unroll

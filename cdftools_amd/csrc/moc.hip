@@ -12,7 +12,10 @@ struct cdft_moc_plan {
     int npi = 0, npj = 0, npk = 0, nbasins = 0;
     float   *w    = nullptr;   // (npi,npj,npk) r4 weight e1v*e3v
     uint8_t *bits = nullptr;   // (npi,npj) basin bits
-    int     *flag = nullptr;   // device error flag (mask value check)
+    uint8_t *cls  = nullptr;   // (npi,npj) class of the cell's bit pattern (class mode), 0xFF = none
+    int     *flag = nullptr;   // device: [0] error flag (mask value check), [1..256] pattern present
+    uint8_t pat[kMaxClass] = {0};
+    int     nclass = 0;        // distinct non-empty patterns, 0 when there are more than kMaxClass
     bool mesh_set = false;
     int  tune_waves = 0, tune_nv = 0, tune_mode = 0;
     DevBuf st_e1v, st_e3v, st_mask, st_zv, st_out;   // staging for host arrays
@@ -46,7 +49,15 @@ __global__ void moc_bits_kernel(const int16_t *__restrict__ ibmask, uint8_t *__r
         }
         bits[e] = (uint8_t)v;
         if (bad) atomicOr(flag, 1);
+        if (v && !flag[1 + v]) flag[1 + v] = 1;          // benign race: every writer stores 1
     }
+}
+
+// cls(i,j) = class index of the cell's basin-bit pattern (lut), 0xFF for a cell in no basin
+__global__ void moc_class_kernel(const uint8_t *__restrict__ bits, uint8_t *__restrict__ cls, int64_t nij,
+                                 const uint8_t *__restrict__ lut) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nij; e += stride) cls[e] = lut[bits[e]];
 }
 
 // src/cdfmoc.f90:382-388: dmoc(:,jj,jk) = dmoc(:,jj,jk+1) + dmoc(:,jj,jk)/1.d6, jk = npk-1..1;
@@ -70,7 +81,9 @@ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 // pick waves per row and float4 vectors per lane for a row of npi cells
 void choose_shape(const cdft_moc_plan *p, bool aligned, int *nwaves, int *nv, int *mode) {
     const int nvec = (p->npi + 6) / 4;             // worst-case aligned vectors covering a row
-    int md = p->tune_mode ? p->tune_mode : kModeSelect;
+    int md = p->tune_mode ? p->tune_mode : ((p->nbasins > 1 && p->nclass > 0) ? kModeClass : kModeSelect);
+    if (md == kModeClass && (!aligned || p->nbasins == 1 || p->nclass == 0 || p->nclass > kMaxClass))
+        md = kModeSelect;
     int k, v;
     if (!aligned) {
         md = kModeSelect;
@@ -81,7 +94,7 @@ void choose_shape(const cdft_moc_plan *p, bool aligned, int *nwaves, int *nv, in
         else if (p->tune_waves > 0) { k = p->tune_waves; v = ceil_div(nvec, kWave * k); }
         else { v = p->tune_nv; k = ceil_div(nvec, kWave * v); }
     } else {
-        int vmax = (md == kModeFma) ? 4 : 8;
+        int vmax = (md == kModeFma) ? 4 : (md == kModeClass ? 9 : 8);   // measured best at npiglo = 4322
         k = ceil_div(nvec, kWave * vmax);
         if (k > kSmallWaves) {          // long rows: 1024-thread workgroups, fewer registers
             vmax = (md == kModeFma) ? 2 : kBigNV;
@@ -115,7 +128,8 @@ int cdft_moc_create(cdft_moc_plan **plan, int npiglo, int npjglo, int npk, int n
     const size_t n3 = (size_t)npiglo * npjglo * npk;
     if (hipMalloc((void **)&p->w, n3 * sizeof(float) + 64) != hipSuccess ||
         hipMalloc((void **)&p->bits, (size_t)npiglo * npjglo + 64) != hipSuccess ||
-        hipMalloc((void **)&p->flag, sizeof(int)) != hipSuccess) {
+        hipMalloc((void **)&p->cls, (size_t)npiglo * npjglo + 64 + 256) != hipSuccess ||
+        hipMalloc((void **)&p->flag, 257 * sizeof(int)) != hipSuccess) {
         (void)hipGetLastError();
         cdft_moc_destroy(p);
         return fail(CDFT_ERR_ALLOC, "cdft_moc_create: device allocation of %zu bytes failed",
@@ -134,7 +148,7 @@ int cdft_moc_set_mesh(cdft_moc_plan *p, const float *e1v, const float *e3v, cons
     CDFT_TRY(to_device(e1v, nij * sizeof(float), memspace, p->st_e1v, st, &d_e1v));
     CDFT_TRY(to_device(e3v, n3 * sizeof(float), memspace, p->st_e3v, st, &d_e3v));
     CDFT_TRY(to_device(ibmask, nij * p->nbasins * sizeof(int16_t), memspace, p->st_mask, st, &d_msk));
-    CDFT_HIP(hipMemsetAsync(p->flag, 0, sizeof(int), st));
+    CDFT_HIP(hipMemsetAsync(p->flag, 0, 257 * sizeof(int), st));
     CDFT_HIP(hipMemsetAsync(p->w + n3, 0, 64, st));
     const int threads = 256;
     int blocks = (int)((n3 + threads - 1) / threads);
@@ -147,9 +161,27 @@ int cdft_moc_set_mesh(cdft_moc_plan *p, const float *e1v, const float *e3v, cons
     hipLaunchKernelGGL(moc_bits_kernel, dim3(blocks), dim3(threads), 0, st, (const int16_t *)d_msk,
                        p->bits, p->nbasins, nij, p->flag);
     CDFT_LAUNCH_CHECK();
-    int flag = 0;
-    CDFT_HIP(hipMemcpyAsync(&flag, p->flag, sizeof(int), hipMemcpyDeviceToHost, st));
+    int flags[257];
+    CDFT_HIP(hipMemcpyAsync(flags, p->flag, sizeof(flags), hipMemcpyDeviceToHost, st));
     CDFT_HIP(hipStreamSynchronize(st));
+    const int flag = flags[0];
+    // class mode: the distinct non-empty bit patterns, in increasing order
+    uint8_t lut[256];
+    p->nclass = 0;
+    for (int v = 0; v < 256; ++v) lut[v] = 0xFF;
+    for (int v = 1; v < 256; ++v)
+        if (flags[1 + v]) {
+            if (p->nclass < kMaxClass) { p->pat[p->nclass] = (uint8_t)v; lut[v] = (uint8_t)p->nclass; }
+            ++p->nclass;
+        }
+    if (p->nclass > kMaxClass) p->nclass = 0;
+    if (p->nclass > 0 && !flag) {
+        uint8_t *dlut = p->cls + nij + 64;                       // the table lives behind the map
+        CDFT_HIP(hipMemcpyAsync(dlut, lut, 256, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(moc_class_kernel, dim3(blocks), dim3(threads), 0, st, p->bits, p->cls, nij, dlut);
+        CDFT_LAUNCH_CHECK();
+        CDFT_HIP(hipStreamSynchronize(st));                      // lut[] is a stack array
+    }
     // the staged copies of host arrays are no longer needed (e3v is as large as the weight)
     p->st_e1v.release(); p->st_e3v.release(); p->st_mask.release();
     if (flag) {
@@ -163,7 +195,7 @@ int cdft_moc_set_mesh(cdft_moc_plan *p, const float *e1v, const float *e3v, cons
 int cdft_moc_set_tuning(cdft_moc_plan *p, int waves_per_row, int vec_per_lane, int mode) {
     if (!p) return fail(CDFT_ERR_ARG, "cdft_moc_set_tuning: NULL plan");
     if (waves_per_row < 0 || waves_per_row > kMaxWaves || vec_per_lane < 0 || vec_per_lane > kMaxNV ||
-        mode < 0 || mode > 2)
+        mode < 0 || mode > 3)
         return fail(CDFT_ERR_ARG, "cdft_moc_set_tuning: out of range (%d,%d,%d)", waves_per_row,
                     vec_per_lane, mode);
     if (waves_per_row > 0 && vec_per_lane > 0 &&
@@ -179,8 +211,11 @@ int cdft_moc_describe(cdft_moc_plan *p, char *buf, size_t buflen) {
     int k, v, md;
     choose_shape(p, true, &k, &v, &md);
     const int nb = p->nbasins == 1 ? 1 : (p->nbasins <= 5 ? 5 : 8);
-    snprintf(buf, buflen, "moc_zonal_kernel<NV=%d,NB=%d,ALIGNED=1,MODE=%s> waves_per_row=%d", v, nb,
-             md == kModeFma ? "fma" : "select", k);
+    if (md == kModeClass)
+        snprintf(buf, buflen, "moc_zonal_class_kernel<NV=%d,KC=%d> waves_per_row=%d basin_patterns=%d", v, kMaxClass, k, p->nclass);
+    else
+        snprintf(buf, buflen, "moc_zonal_kernel<NV=%d,NB=%d,ALIGNED=1,MODE=%s> waves_per_row=%d", v, nb,
+                 md == kModeFma ? "fma" : "select", k);
     return CDFT_OK;
 }
 
@@ -206,7 +241,9 @@ int cdft_moc_compute(cdft_moc_plan *p, const float *zv, int64_t rec_stride, int 
     }
 
     ZonalArgs a;
-    a.w = p->w; a.bits = p->bits; a.zv = (const float *)d_zv; a.rec_stride = rec_stride; a.npt = npt;
+    a.w = p->w; a.bits = p->bits; a.cls = p->cls; a.nclass = p->nclass;
+    for (int c = 0; c < kMaxClass; ++c) a.pat[c] = p->pat[c];
+    a.zv = (const float *)d_zv; a.rec_stride = rec_stride; a.npt = npt;
     a.out = d_out; a.npi = p->npi; a.npj = p->npj; a.npk = p->npk; a.nbasins = p->nbasins;
     const bool aligned = ((uintptr_t)d_zv % 16 == 0) && (rec_stride % 4 == 0);
     int k, v, md;
@@ -226,7 +263,8 @@ int cdft_moc_compute(cdft_moc_plan *p, const float *zv, int64_t rec_stride, int 
         ev1 = p->ev[p->ev_used + 1];
         p->ev_used += 2;
     }
-    if (p->nbasins == 1)      CDFT_TRY(launch_zonal_nb1(a, k, v, aligned, md, st));
+    if (md == kModeClass)     CDFT_TRY(launch_zonal_class(a, k, v, st));
+    else if (p->nbasins == 1) CDFT_TRY(launch_zonal_nb1(a, k, v, aligned, md, st));
     else if (p->nbasins <= 5) CDFT_TRY(launch_zonal_nb5(a, k, v, aligned, md, st));
     else                      CDFT_TRY(launch_zonal_nb8(a, k, v, aligned, md, st));
     if (ev1) CDFT_HIP(hipEventRecord(ev1, st));
@@ -269,6 +307,7 @@ int cdft_moc_destroy(cdft_moc_plan *p) {
     for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
     if (p->w) (void)hipFree(p->w);
     if (p->bits) (void)hipFree(p->bits);
+    if (p->cls) (void)hipFree(p->cls);
     if (p->flag) (void)hipFree(p->flag);
     p->st_e1v.release(); p->st_e3v.release(); p->st_mask.release(); p->st_zv.release(); p->st_out.release();
     delete p;

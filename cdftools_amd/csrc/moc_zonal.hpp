@@ -34,11 +34,15 @@ constexpr int kBigNV     = 6;    // vectors per lane a 1024-thread workgroup can
 constexpr int kTChunk    = 16;   // records combined per LDS flush
 constexpr int kScrStride = 72;   // doubles; 64 + 8 keeps the 5 basin rows on different banks
 
-enum Mode { kModeSelect = 1, kModeFma = 2 };
+enum Mode { kModeSelect = 1, kModeFma = 2, kModeClass = 3 };
+constexpr int kMaxClass = 8;     // distinct non-empty basin-bit patterns the class kernel can hold
 
 struct ZonalArgs {
     const float   *w;           // (npi,npj,npk) r4 weights, base 16-byte aligned, padded by 16 B
     const uint8_t *bits;        // (npi,npj) basin bits
+    const uint8_t *cls;         // (npi,npj) class of the cell's bit pattern, 0xFF = no basin (class mode)
+    uint8_t        pat[kMaxClass];  // bit pattern of each class
+    int            nclass;      // 0 = class mode unavailable (more than kMaxClass patterns)
     const float   *zv;          // record 0
     int64_t        rec_stride;  // elements between records
     int            npt;
@@ -52,6 +56,8 @@ typedef int (*ZonalLauncher)(const ZonalArgs &, int nwaves, int nv, bool aligned
 int launch_zonal_nb1(const ZonalArgs &, int, int, bool, int, hipStream_t);
 int launch_zonal_nb5(const ZonalArgs &, int, int, bool, int, hipStream_t);
 int launch_zonal_nb8(const ZonalArgs &, int, int, bool, int, hipStream_t);
+// defined by moc_zonal_class.hip (kMaxClass accumulators, 16-byte aligned records only)
+int launch_zonal_class(const ZonalArgs &, int nwaves, int nv, hipStream_t st);
 
 #ifdef CDFT_MOC_NB
 
@@ -94,7 +100,8 @@ moc_zonal_kernel(ZonalArgs a) {
         vec_ok[r] = i0 < a.npi;                                   // (i0+3 >= 0 always)
         const int vc = vec_ok[r] ? v : 0;                         // vector 0 of the row is always valid
         if (ALIGNED) {
-            wraw[r] = *reinterpret_cast<const float4 *>(a.w + a0 + 4 * (int64_t)vc);
+            const f4a q = ld_stream4(a.w + a0 + 4 * (int64_t)vc);
+            wraw[r] = make_float4(q.x, q.y, q.z, q.w);
         } else {                                                  // head = 0 here, so i0 >= 0
             wraw[r].x = a.w[g0 + min(i0 + 0, a.npi - 1)];
             wraw[r].y = a.w[g0 + min(i0 + 1, a.npi - 1)];
@@ -113,7 +120,7 @@ moc_zonal_kernel(ZonalArgs a) {
             const int v  = v0 + r * kWave;
             const int vc = vec_ok[r] ? v : 0;
             if (ALIGNED) {
-                const float4 q = *reinterpret_cast<const float4 *>(zr + a0 + 4 * (int64_t)vc);
+                const f4a q = ld_stream4(zr + a0 + 4 * (int64_t)vc);
                 z[r][0] = q.x; z[r][1] = q.y; z[r][2] = q.z; z[r][3] = q.w;
             } else {
 #pragma unroll
@@ -225,6 +232,7 @@ moc_zonal_kernel(ZonalArgs a) {
     }
 }
 
+
 template <int NV, int NB, bool ALIGNED, int MODE, int LB>
 static int launch_lb(const ZonalArgs &a, int nwaves, hipStream_t st) {
     const size_t shmem =
@@ -252,6 +260,7 @@ static int launch_one(const ZonalArgs &a, int nwaves, hipStream_t st) {
 template <int NB>
 static int launch_nb(const ZonalArgs &a, int nwaves, int nv, bool aligned, int mode,
                      hipStream_t st) {
+    if (mode == kModeClass) return fail(CDFT_ERR_ARG, "class mode is launched through launch_zonal_class");
     if (!aligned) {
         if (nv != 4 || mode != kModeSelect)
             return fail(CDFT_ERR_ARG, "unaligned zonal path supports nv=4, select mode only");
@@ -277,6 +286,157 @@ static int launch_nb(const ZonalArgs &a, int nwaves, int nv, bool aligned, int m
 }
 
 #endif  // CDFT_MOC_NB
+
+#ifdef CDFT_MOC_CLASS
+__device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
+    return __shfl_xor(v, mask, kWave);
+}
+
+// Class mode.  The select kernel above spends NB select-adds in r8 per cell; at 5 basins that is
+// as expensive as the memory stream itself.  A cell's basin membership is one of a handful of bit
+// patterns (open ocean only / Atlantic / Indian / Pacific ...), so each cell is given the CLASS of
+// its pattern once (cdft_moc_set_mesh) and its r8 term is added to exactly one accumulator: a
+// per-lane, per-class slot in LDS, updated by ds_add_f64 (one LDS instruction per cell instead of
+// ~5 x 5 VALU instructions).  A slot only ever receives the terms of its own lane, in program
+// order, so the result is run-to-run deterministic.  Basin sums are formed from the class sums at
+// the end (basin b = classes whose pattern has bit b, in class order).
+template <int NV, int KC, int LB>
+__global__ void __launch_bounds__(LB)
+moc_zonal_class_kernel(ZonalArgs a) {
+    extern __shared__ double smem[];
+    const int lane   = threadIdx.x & (kWave - 1);
+    const int wave   = threadIdx.x >> 6;
+    const int nwaves = blockDim.x >> 6;
+    double *scr  = smem + wave * ((KC + 1) * kScrStride);        // slot [class][lane]; class KC = unused cells
+    double *part = smem + nwaves * ((KC + 1) * kScrStride);      // [kTChunk][KC][nwaves]
+
+    const int row = blockIdx.x;                                   // jk*npj + jj, jj fastest
+    const int jk  = row / a.npj;
+    const int jj  = row - jk * a.npj;
+    const int64_t g0   = (int64_t)row * a.npi;
+    const int     head = (int)(g0 & 3);
+    const int64_t a0   = g0 - head;
+    const int     v0   = wave * (kWave * NV) + lane;
+
+    float   w[NV][4];
+    int     slot[NV][4];                                          // index of the cell's slot in scr
+    bool    vec_ok[NV];
+    const uint8_t *crow = a.cls + (int64_t)jj * a.npi;
+    f4a      wraw[NV];
+    uint32_t craw[NV][4];
+#pragma unroll
+    for (int r = 0; r < NV; ++r) {                                // issue every load first
+        const int v  = v0 + r * kWave;
+        const int i0 = 4 * v - head;
+        vec_ok[r] = i0 < a.npi;
+        const int vc = vec_ok[r] ? v : 0;
+        wraw[r] = ld_stream4(a.w + a0 + 4 * (int64_t)vc);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) craw[r][c] = crow[min(max(i0 + c, 0), a.npi - 1)];
+    }
+    auto load_rec = [&](f4a (&z)[NV], int t) {
+        const float *zr = a.zv + (int64_t)t * a.rec_stride;
+#pragma unroll
+        for (int r = 0; r < NV; ++r) {
+            const int vc = vec_ok[r] ? v0 + r * kWave : 0;
+            z[r] = ld_stream4(zr + a0 + 4 * (int64_t)vc);
+        }
+    };
+    f4a zc[NV], zn[NV];
+    load_rec(zc, 0);
+#pragma unroll
+    for (int s = 0; s <= KC; ++s) scr[s * kScrStride + lane] = 0.0;
+#pragma unroll
+    for (int r = 0; r < NV; ++r) {
+        const int i0 = 4 * (v0 + r * kWave) - head;
+        const float wr[4] = {wraw[r].x, wraw[r].y, wraw[r].z, wraw[r].w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const bool ok = (i0 + c >= 0) && (i0 + c < a.npi);
+            w[r][c]    = ok ? wr[c] : 0.f;
+            slot[r][c] = (ok ? min((int)craw[r][c], KC) : KC) * kScrStride + lane;
+        }
+    }
+
+    for (int t0 = 0; t0 < a.npt; t0 += kTChunk) {
+        const int tcount = min(kTChunk, a.npt - t0);
+        for (int tl = 0; tl < tcount; ++tl) {
+            const int t = t0 + tl;
+            if (t + 1 < a.npt) load_rec(zn, t + 1);               // next record in flight
+#pragma unroll
+            for (int r = 0; r < NV; ++r) {
+                const float zr[4] = {zc[r].x, zc[r].y, zc[r].z, zc[r].w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    // r4 product, then widen: src/cdfmoc.f90:373-374
+                    const double pd = (double)__fmul_rn(w[r][c], zr[c]);
+                    (void)__hip_atomic_fetch_add(&scr[slot[r][c]], pd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            double s = 0.0;
+            if (lane < KC * 8) {
+                const double *p = scr + (lane >> 3) * kScrStride + (lane & 7);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s += p[8 * j];
+            }
+            s += shfl_xor_f64(s, 1);
+            s += shfl_xor_f64(s, 2);
+            s += shfl_xor_f64(s, 4);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();                      // every lane has read before the slots are cleared
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int c = 0; c < KC; ++c) scr[c * kScrStride + lane] = 0.0;
+            if (lane < KC * 8 && (lane & 7) == 0) part[(tl * KC + (lane >> 3)) * nwaves + wave] = s;
+#pragma unroll
+            for (int r = 0; r < NV; ++r) zc[r] = zn[r];
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < tcount * a.nbasins) {
+            const int tl = threadIdx.x / a.nbasins, b = threadIdx.x - tl * a.nbasins;
+            double s = 0.0;
+            for (int c = 0; c < a.nclass; ++c)
+                if ((a.pat[c] >> b) & 1)
+                    for (int k = 0; k < nwaves; ++k) s += part[(tl * KC + c) * nwaves + k];
+            a.out[(((int64_t)(t0 + tl) * a.npk + jk) * a.npj + jj) * a.nbasins + b] = -s;
+        }
+        __syncthreads();
+    }
+}
+
+template <int NV, int KC, int LB>
+static int launch_class_lb(const ZonalArgs &a, int nwaves, hipStream_t st) {
+    const size_t shmem = sizeof(double) * ((size_t)nwaves * (KC + 1) * kScrStride + (size_t)kTChunk * KC * nwaves);
+    const unsigned grid = (unsigned)a.npj * (unsigned)(a.npk - 1);
+    hipLaunchKernelGGL((moc_zonal_class_kernel<NV, KC, LB>), dim3(grid), dim3(kWave * nwaves), shmem, st, a);
+    CDFT_LAUNCH_CHECK();
+    return CDFT_OK;
+}
+
+template <int NV, int KC>
+static int launch_class_one(const ZonalArgs &a, int nwaves, hipStream_t st) {
+    if (nwaves <= kSmallWaves) return launch_class_lb<NV, KC, kWave * kSmallWaves>(a, nwaves, st);
+    if constexpr (NV <= kBigNV) return launch_class_lb<NV, KC, kWave * kMaxWaves>(a, nwaves, st);
+    else return fail(CDFT_ERR_ARG, "%d waves per row need <= %d vectors per lane, got %d", nwaves, kBigNV, NV);
+}
+
+template <int KC>
+static int launch_class(const ZonalArgs &a, int nwaves, int nv, hipStream_t st) {
+    if (a.nclass < 1 || a.nclass > KC)
+        return fail(CDFT_ERR_ARG, "class mode holds 1..%d basin patterns, the masks have %d", KC, a.nclass);
+    switch (nv) {
+#define CDFT_CASE(N) case N: return launch_class_one<N, KC>(a, nwaves, st);
+        CDFT_CASE(1) CDFT_CASE(2) CDFT_CASE(3) CDFT_CASE(4) CDFT_CASE(5) CDFT_CASE(6)
+        CDFT_CASE(7) CDFT_CASE(8) CDFT_CASE(9) CDFT_CASE(10) CDFT_CASE(11) CDFT_CASE(12)
+#undef CDFT_CASE
+        default: return fail(CDFT_ERR_ARG, "class mode: vectors per lane must be 1..12, got %d", nv);
+    }
+}
+
+#endif  // CDFT_MOC_CLASS
 
 }  // namespace moc
 }  // namespace cdft

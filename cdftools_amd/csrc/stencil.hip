@@ -23,7 +23,6 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kTile    = kThreads * 4;
 
-typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
 
 // nv valid cells (1..4) starting at p; cells beyond the row are returned as 0 and never touched
@@ -37,11 +36,38 @@ __device__ __forceinline__ void load4(const float *p, int nv, float (&o)[4]) {
     }
 }
 
-template <typename T>
-__device__ __forceinline__ void store4(T *p, int nv, const double (&v)[4]) {
+// the same for a field no other row reads again (nontemporal, common.hpp)
+__device__ __forceinline__ void load4s(const float *p, int nv, float (&o)[4]) {
+    if (nv == 4) {
+        const f4u v = ld_stream4u(p);
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+    } else {
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
-        if (c < nv) p[c] = (T)v[c];
+        for (int c = 0; c < 4; ++c) o[c] = (c < nv) ? p[c] : 0.f;
+    }
+}
+
+// results are written once and never read back by these kernels: full vectors, nontemporal
+__device__ __forceinline__ void store4(float *p, int nv, const double (&v)[4]) {
+    if (nv == 4) {
+        const f4u q = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+        __builtin_nontemporal_store(q, reinterpret_cast<f4u *>(p));
+    } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c < nv) p[c] = (float)v[c];
+    }
+}
+__device__ __forceinline__ void store4(double *p, int nv, const double (&v)[4]) {
+    if (nv == 4) {
+        const d2u q0 = {v[0], v[1]}, q1 = {v[2], v[3]};
+        __builtin_nontemporal_store(q0, reinterpret_cast<d2u *>(p));
+        __builtin_nontemporal_store(q1, reinterpret_cast<d2u *>(p) + 1);
+    } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c < nv) p[c] = v[c];
+    }
 }
 
 // XCD-aware block -> work-item map: blocks b and b+8 share an XCD (round-robin dispatch), so XCD x
@@ -85,9 +111,9 @@ __global__ void __launch_bounds__(kThreads) vt_kernel(VtArgs a) {
         for (int c = 0; c < 4; ++c) { r.t[c] = r.s[c] = r.tn[c] = r.sn[c] = r.u[c] = r.v[c] = r.e3u[c] = r.e3v[c] = 0.f; }
         r.ht = r.hs = 0.f;
         if (nv > 0) {
-            load4(a.t + e, nv, r.t); load4(a.s + e, nv, r.s); load4(a.u + e, nv, r.u); load4(a.v + e, nv, r.v);
+            load4(a.t + e, nv, r.t); load4(a.s + e, nv, r.s); load4s(a.u + e, nv, r.u); load4s(a.v + e, nv, r.v);
             if (north) { load4(a.t + e + a.npi, nv, r.tn); load4(a.s + e + a.npi, nv, r.sn); }
-            if (VVL) { load4(a.e3u + e, nv, r.e3u); load4(a.e3v + e, nv, r.e3v); }
+            if (VVL) { load4s(a.e3u + e, nv, r.e3u); load4s(a.e3v + e, nv, r.e3v); }
         }
         if (tid == 0 && ih < a.npi) {                             // halo cell of the tile
             const int64_t eh = (int64_t)f * a.fstride + L * a.npi + ih;
@@ -206,7 +232,7 @@ __global__ void __launch_bounds__(kThreads) curl_kernel(CurlArgs a) {
         for (int c = 0; c < 4; ++c) { r.u[c] = r.un1[c] = r.v[c] = 0.f; }
         r.hv = 0.f;
         if (nv > 0) {
-            load4(un + p2, nv, r.u); load4(vn + p2, nv, r.v);
+            load4(un + p2, nv, r.u); load4s(vn + p2, nv, r.v);
             if (north) load4(un + p2 + a.npi, nv, r.un1);
         }
         if (tid == 0 && has_halo) r.hv = vn[(int64_t)jj * a.npi + ih];

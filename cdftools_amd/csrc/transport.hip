@@ -34,6 +34,16 @@ template <> __device__ __forceinline__ void ld<2>(const float *p, int64_t e, flo
     const float2 v = *reinterpret_cast<const float2 *>(p + e); o[0] = v.x; o[1] = v.y;
 }
 template <> __device__ __forceinline__ void ld<1>(const float *p, int64_t e, float (&o)[1]) { o[0] = p[e]; }
+// read-once fields: nontemporal (common.hpp)
+typedef float f2a __attribute__((ext_vector_type(2)));
+template <int VEC> __device__ __forceinline__ void lds_(const float *p, int64_t e, float (&o)[VEC]);
+template <> __device__ __forceinline__ void lds_<4>(const float *p, int64_t e, float (&o)[4]) {
+    const f4a v = ld_stream4(p + e); o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+}
+template <> __device__ __forceinline__ void lds_<2>(const float *p, int64_t e, float (&o)[2]) {
+    const f2a v = ld_stream(reinterpret_cast<const f2a *>(p + e)); o[0] = v.x; o[1] = v.y;
+}
+template <> __device__ __forceinline__ void lds_<1>(const float *p, int64_t e, float (&o)[1]) { o[0] = ld_stream(p + e); }
 
 enum VMode { kPsi = 0, kMhstVt = 1, kMhstSep = 2 };
 
@@ -72,48 +82,63 @@ __global__ void __launch_bounds__(kThreads) vint_kernel(VintArgs a) {
         }
     }
     if (!ok[0]) return;
-#pragma unroll 2
-    for (int k = a.k0; k < a.k1; ++k) {
+    // One level's operands of this lane.  Level k+1 is requested before level k is accumulated, so a
+    // wave always has a full level of loads in flight behind its arithmetic (software pipeline).
+    struct Level {
         float x0[VPT][VEC], x1[VPT][VEC], e3[VPT][VEC];
+        float tn[MODE == kMhstSep ? VPT : 1][VEC], qn[MODE == kMhstSep ? VPT : 1][VEC];   // T, S one row north
+        float vv[MODE == kMhstSep ? VPT : 1][VEC];
+    };
+    auto fetch = [&](Level &L, int k) {
 #pragma unroll
         for (int v = 0; v < VPT; ++v) {
             const int64_t e = (int64_t)k * a.nij + p[v];
             if (FULL) {
                 const float z = a.e31d[k];
 #pragma unroll
-                for (int c = 0; c < VEC; ++c) e3[v][c] = z;
+                for (int c = 0; c < VEC; ++c) L.e3[v][c] = z;
             } else {
-                ld<VEC>(a.e3, e, e3[v]);
+                lds_<VEC>(a.e3, e, L.e3[v]);
             }
-            if (MODE == kMhstSep) {                       // src/cdfmhst.f90:312-322
-                float vv[VEC], t0[VEC], t1[VEC], q0[VEC], q1[VEC];
-                ld<VEC>(a.f0, e, vv);
-                ld<VEC>(a.f1, e, t0);
-                ld<VEC>(a.f2, e, q0);
-                if (!lastrow[v]) { ld<VEC>(a.f1, e + a.npi, t1); ld<VEC>(a.f2, e + a.npi, q1); }
-#pragma unroll
-                for (int c = 0; c < VEC; ++c) {
-                    x0[v][c] = lastrow[v] ? 0.f : __fmul_rn(__fmul_rn(0.5f, __fadd_rn(t0[c], t1[c])), vv[c]);
-                    x1[v][c] = lastrow[v] ? 0.f : __fmul_rn(__fmul_rn(0.5f, __fadd_rn(q0[c], q1[c])), vv[c]);
-                }
+            if (MODE == kMhstSep) {                       // src/cdfmhst.f90:312-322: T and S are read again by row j-1
+                lds_<VEC>(a.f0, e, L.vv[v]);
+                ld<VEC>(a.f1, e, L.x0[v]);
+                ld<VEC>(a.f2, e, L.x1[v]);
+                const int64_t en = lastrow[v] ? e : e + a.npi;
+                ld<VEC>(a.f1, en, L.tn[v]);
+                ld<VEC>(a.f2, en, L.qn[v]);
             } else {
-                ld<VEC>(a.f0, e, x0[v]);
-                if (MODE == kMhstVt) ld<VEC>(a.f1, e, x1[v]);
+                lds_<VEC>(a.f0, e, L.x0[v]);
+                if (MODE == kMhstVt) lds_<VEC>(a.f1, e, L.x1[v]);
             }
         }
+    };
+    auto accumulate = [&](const Level &L) {
 #pragma unroll
         for (int v = 0; v < VPT; ++v)
 #pragma unroll
             for (int c = 0; c < VEC; ++c) {
+                float x0 = L.x0[v][c], x1 = L.x1[v][c];
+                if (MODE == kMhstSep) {
+                    x0 = lastrow[v] ? 0.f : __fmul_rn(__fmul_rn(0.5f, __fadd_rn(L.x0[v][c], L.tn[v][c])), L.vv[v][c]);
+                    x1 = lastrow[v] ? 0.f : __fmul_rn(__fmul_rn(0.5f, __fadd_rn(L.x1[v][c], L.qn[v][c])), L.vv[v][c]);
+                }
                 // (field*metric)*e3 in r4, then widened: src/cdfmhst.f90:332-333, src/cdfpsi.f90:277,296
-                const double d0 = (double)__fmul_rn(__fmul_rn(x0[v][c], m[v][c]), e3[v][c]);
+                const double d0 = (double)__fmul_rn(__fmul_rn(x0, m[v][c]), L.e3[v][c]);
                 if (MODE == kPsi) {
                     s0[v][c] = __dadd_rn(s0[v][c], d0);
                 } else {
                     s0[v][c] = __dadd_rn(s0[v][c], __dmul_rn(__dmul_rn(d0, 1000.0), 4000.0));   // :336 pprau0, pprcp
-                    s1[v][c] = __dadd_rn(s1[v][c], (double)__fmul_rn(__fmul_rn(x1[v][c], m[v][c]), e3[v][c]));   // :337
+                    s1[v][c] = __dadd_rn(s1[v][c], (double)__fmul_rn(__fmul_rn(x1, m[v][c]), L.e3[v][c]));   // :337
                 }
             }
+    };
+    Level cur, nxt;
+    if (a.k0 < a.k1) fetch(cur, a.k0);
+    for (int k = a.k0; k < a.k1; ++k) {
+        if (k + 1 < a.k1) fetch(nxt, k + 1);
+        accumulate(cur);
+        cur = nxt;
     }
 #pragma unroll
     for (int v = 0; v < VPT; ++v)

@@ -95,7 +95,11 @@ int cdft_moc_compute(cdft_moc_plan *plan, const float *zv, int64_t rec_stride, i
                      int zv_space, double *dmoc, int dmoc_space, void *stream);
 
 /* Tuning hook for the measurement harness: waves per row (0 = automatic) and float4 vectors
- * per lane (0 = automatic), accumulate mode (0 = automatic, 1 = select, 2 = fma-with-mask). */
+ * per lane (0 = automatic), accumulate mode (0 = automatic, 1 = select per basin, 2 = fma with
+ * 0/1 masks, 3 = one LDS accumulator per basin-bit pattern ("class"; needs several basins, at most
+ * 5 (nbasins <= 5) or 8 distinct non-empty patterns, 16-byte aligned records; automatic choice
+ * when those hold).  All modes form identical r8 terms; they differ in the (fixed) order of the
+ * r8 additions along i, i.e. within the stated 1e-13 * sum|terms| tolerance. */
 int cdft_moc_set_tuning(cdft_moc_plan *plan, int waves_per_row, int vec_per_lane, int mode);
 /* name of the zonal kernel variant the next compute will launch (for profiles) */
 int cdft_moc_describe(cdft_moc_plan *plan, char *buf, size_t buflen);

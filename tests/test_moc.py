@@ -99,7 +99,8 @@ def test_hip_matches_oracle_host_arrays(gpu, npi, npj, npk, nb, npt):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("waves,nv,mode", [(0, 0, 1), (0, 0, 2), (1, 5, 1), (2, 3, 1), (3, 2, 2), (4, 2, 2),
-                                           (5, 1, 1), (16, 1, 1), (2, 16, 1), (2, 4, 2)])
+                                           (5, 1, 1), (16, 1, 1), (2, 16, 1), (2, 4, 2),
+                                           (0, 0, 3), (1, 5, 3), (3, 2, 3), (5, 1, 3), (16, 1, 3), (2, 12, 3), (7, 6, 3)])
 def test_hip_kernel_variants_agree_with_oracle(gpu, waves, nv, mode):
     import torch
 
@@ -114,6 +115,35 @@ def test_hip_kernel_variants_agree_with_oracle(gpu, waves, nv, mode):
     torch.cuda.synchronize()
     ref = oracle_lib.moc(e1v, e3v, ib, zv)
     assert_moc_close(got.cpu().numpy(), ref, abs_bound(e1v, e3v, ib, zv))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nb,overlap", [(5, False), (3, False), (8, False), (8, True), (1, False)])
+def test_hip_class_mode_is_chosen_when_the_masks_have_few_bit_patterns(gpu, nb, overlap):
+    """Automatic mode: basin masks with at most 8 distinct non-empty bit patterns take the kernel
+    with one LDS accumulator per pattern; anything else (one basin, many overlapping masks) the
+    select kernel.  Both must match the oracle, 17 records span two LDS chunks."""
+    npi, npj, npk, npt = 517, 9, 5, 17
+    g = synth.make_grid(npi, npj, npk, seed=31, nbasins=nb)
+    e1v, e3v, ib = synth.moc_inputs(g)
+    if overlap:                                            # independent random masks: up to 255 patterns
+        rng = np.random.default_rng(3)
+        ib = ib.copy()
+        ib[:, :, 1:] = rng.integers(0, 2, size=ib[:, :, 1:].shape, dtype=np.int16)
+    zv = synth.velocity(g, npt, seed=6)
+    packed = (ib.astype(np.int64) << np.arange(nb)).sum(axis=2)
+    npat = len(set(np.unique(packed)) - {0})
+    kernel = "class" if nb > 1 and 1 <= npat <= 8 else "select"
+    assert (nb, overlap, kernel) in ((5, False, "class"), (3, False, "class"), (8, False, "select"), (8, True, "select"),
+                                     (1, False, "select"))
+    plan = gpu.MocPlan(npi, npj, npk, nb)
+    plan.set_mesh(e1v, e3v, ib)
+    assert kernel in plan.describe(), plan.describe()
+    got = plan.compute(zv)
+    assert_moc_close(got, oracle_lib.moc(e1v, e3v, ib, zv), abs_bound(e1v, e3v, ib, zv))
+    again = plan.compute(zv)
+    assert np.array_equal(got, again)                      # fixed summation order: run-to-run identical
+    plan.close()
 
 
 @pytest.mark.gpu

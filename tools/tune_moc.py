@@ -37,8 +37,8 @@ def main():
     else:
         nvec = (npi + 6) // 4
         variants = []
-        for mode in (1, 2):
-            for nv in ((1, 2, 3, 4, 5, 6, 8, 9, 12, 16) if mode == 1 else (1, 2, 3, 4)):
+        for mode in (1, 2, 3):
+            for nv in {1: (1, 2, 3, 4, 5, 6, 8, 9, 12, 16), 2: (1, 2, 3, 4), 3: (1, 2, 3, 4, 5, 6, 8, 9, 12)}[mode]:
                 k = -(-nvec // (64 * nv))
                 if k <= 16 and not (k > 4 and (nv > 6 or mode == 2)):
                     variants.append((k, nv, mode))
