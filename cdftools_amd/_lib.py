@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libcdftools_hip.so")
+# CDFT_LIB: another build of the same library (A/B timing of kernel variants on one GPU box)
+LIB_PATH = os.environ.get("CDFT_LIB") or os.path.join(HERE, "lib", "libcdftools_hip.so")
 
 CDFT_OK = 0
 CDFT_ERR_ARG, CDFT_ERR_HIP, CDFT_ERR_ALLOC, CDFT_ERR_STATE, CDFT_ERR_NODEVICE = 1, 2, 3, 4, 5

@@ -217,7 +217,7 @@ mhst_zonal_kernel(const double *__restrict__ dtrph, const double *__restrict__ d
 // Row-block sharding: a block that does not hold global row 1 continues the running difference of
 // the block south of it: it starts from that block's last row (carry) and its first row is an
 // ordinary row.  Chained this way the result does not depend on the number of blocks (bit for bit).
-__global__ void psi_scan_j_kernel(const double *__restrict__ dtrp, double *__restrict__ dpsi, int npi, int npj,
+__global__ void __launch_bounds__(64) psi_scan_j_kernel(const double *__restrict__ dtrp, double *__restrict__ dpsi, int npi, int npj,
                                   const double *__restrict__ carry, int first_block) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= npi) return;
@@ -229,8 +229,10 @@ __global__ void psi_scan_j_kernel(const double *__restrict__ dtrp, double *__res
         dpsi[i] = acc;
     }
     // Only the additions are sequential: rows are fetched kB at a time, and the next batch is in
-    // flight while the current one is accumulated and stored (double buffer in registers).
-    constexpr int kB = 24;
+    // flight while the current one is accumulated and stored (double buffer in registers).  Only
+    // npi/64 waves exist, so each must keep ~100 KB in flight to draw a useful share of the HBM
+    // bandwidth: one wave per SIMD with (nearly) the whole 512-VGPR file, 2 x 96 rows of r8.
+    constexpr int kB = 96;
     double xa[kB], xb[kB];
     auto fetch = [&](double (&x)[kB], int j0) {
 #pragma unroll

@@ -71,7 +71,7 @@ __global__ void __launch_bounds__(256) read2_kernel(const f4 *__restrict__ a, co
 // prefetched.  grid == nrows: one workgroup per row, dispatched as slots free up (the workgroups
 // drift apart, so all K regions are read at once at scattered rows).  grid < nrows: persistent
 // workgroups that walk the rows with a grid stride (they start each row together).
-template <int VPT>
+template <int VPT, bool NT = false>
 __global__ void __launch_bounds__(256) multi_kernel(const f4 *__restrict__ a, size_t stride, int K, size_t nrows, float *out) {
     float acc = 0.f;
     const size_t chunk = (size_t)VPT * blockDim.x;
@@ -79,11 +79,11 @@ __global__ void __launch_bounds__(256) multi_kernel(const f4 *__restrict__ a, si
         const f4 *p = a + row * chunk + threadIdx.x;
         f4 v[VPT], n[VPT];
 #pragma unroll
-        for (int r = 0; r < VPT; ++r) v[r] = p[(size_t)r * blockDim.x];
+        for (int r = 0; r < VPT; ++r) v[r] = NT ? __builtin_nontemporal_load(p + (size_t)r * blockDim.x) : p[(size_t)r * blockDim.x];
         for (int t = 0; t < K; ++t) {
             if (t + 1 < K) {
 #pragma unroll
-                for (int r = 0; r < VPT; ++r) n[r] = p[(size_t)(t + 1) * stride + (size_t)r * blockDim.x];
+                for (int r = 0; r < VPT; ++r) n[r] = NT ? __builtin_nontemporal_load(p + (size_t)(t + 1) * stride + (size_t)r * blockDim.x) : p[(size_t)(t + 1) * stride + (size_t)r * blockDim.x];
             }
 #pragma unroll
             for (int r = 0; r < VPT; ++r) acc += v[r].x + v[r].y + v[r].z + v[r].w;
@@ -152,6 +152,26 @@ int main(int argc, char **argv) {
         run(std::integral_constant<int, 6>{}, 192);     // the cdfmoc shape: 3 waves x 6 vectors = 18 KiB
         run(std::integral_constant<int, 8>{}, 256);     // 32 KiB
         run(std::integral_constant<int, 16>{}, 256);    // 64 KiB
+    }
+    // the level walk of cdfheatc / cdfmhst / cdfpsi / cdfcurl: 75 (x fields) slabs of one eORCA12 level
+    // (62 MB apart), every workgroup reads its chunk of each slab in turn
+    if (bytes >= (size_t)225 * 15585132 * 4 + (64 << 20)) {
+        const size_t stride = 15585132 / 4;                 // one level, in vectors
+        for (int K : {75, 150, 225}) {
+            auto run = [&](auto vpt_tag, int threads) {
+                constexpr int VPT = decltype(vpt_tag)::value;
+                const size_t chunk = (size_t)VPT * threads, nrows = stride / chunk;
+                float m0 = time_ms([&] { hipLaunchKernelGGL((multi_kernel<VPT, false>), dim3((unsigned)nrows), dim3(threads), 0, 0, a, stride, K, nrows, out); }, 5);
+                float m1 = time_ms([&] { hipLaunchKernelGGL((multi_kernel<VPT, true>), dim3((unsigned)nrows), dim3(threads), 0, 0, a, stride, K, nrows, out); }, 5);
+                printf("{\"pattern\": \"level walk\", \"slabs\": %d, \"chunk_KiB\": %zu, \"nwg\": %zu, \"plain_GBps\": %.0f, \"nt_GBps\": %.0f}\n", K,
+                       chunk * 16 / 1024, nrows, (double)K * nrows * chunk * 16 / m0 * 1e-6, (double)K * nrows * chunk * 16 / m1 * 1e-6);
+                fflush(stdout);
+            };
+            run(std::integral_constant<int, 1>{}, 256);      // 4 KiB  (cdfcurl / cdfvT tile)
+            run(std::integral_constant<int, 4>{}, 256);      // 16 KiB (vertical integrals, cdfheatc)
+            run(std::integral_constant<int, 8>{}, 256);      // 32 KiB
+            run(std::integral_constant<int, 16>{}, 256);     // 64 KiB
+        }
     }
     CK(hipGetLastError());
     return 0;
