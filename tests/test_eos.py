@@ -59,8 +59,8 @@ def test_land_points_are_masked_on_salinity_zero():
 def test_oracle_equals_live_reference_on_fresh_random_fields():
     ref = oracle_lib.RefEos()
     rng = np.random.default_rng(5)
-    T = (-2 + 34 * rng.random((33, 57))).astype(np.float32)
-    S = (38 * rng.random((33, 57))).astype(np.float32)
+    T = (-2 + 34 * rng.random((331, 577))).astype(np.float32)          # 190 987 points
+    S = (38 * rng.random((331, 577))).astype(np.float32)
     S[rng.random(S.shape) < 0.2] = 0
     D = (6000 * rng.random(S.shape)).astype(np.float32)
     for teos in (False, True):
