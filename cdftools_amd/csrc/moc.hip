@@ -19,6 +19,11 @@ struct cdft_moc_plan {
     bool mesh_set = false;
     int  tune_waves = 0, tune_nv = 0, tune_mode = 0;
     DevBuf st_e1v, st_e3v, st_mask, st_zv, st_out;   // staging for host arrays
+    // -decomp (cdft_moc_decomp_*): the mesh it needs beyond w / bits, and its work arrays
+    bool dec_set = false;
+    DevBuf d_e3v, d_e1u, d_zcoef, d_tmask, d_umask;  // e3v (masked) 3-D, e1u / zcoef 2-D, masks 3-D bytes
+    std::vector<float> gdept;
+    DevBuf d_t, d_s, d_zvgeo, d_sig8, d_dvbt, d_hdep, d_dvgeo, d_raw, d_o4;   // record inputs, work, results
     bool profiling = false;
     std::vector<hipEvent_t> ev;                      // (start, stop) pairs, one per profiled launch
     size_t ev_used = 0;
@@ -76,6 +81,129 @@ __global__ void moc_cumsum_kernel(double *__restrict__ dmoc, int nbj, int npk, i
     }
 }
 
+
+// ------------------------------------------------------------------------------------ cdfmoc -decomp
+// src/cdfmoc.f90:360-365 then :397-401: dvbt = sum_k e3v*zv*1.d0 (r4 product, r8 sum, k = 1..npk-1 in
+// order), hdep = sum_k e3v (r4), dvbt = dvbt / hdep where hdep /= 0, else 0.
+__global__ void dec_vmean_kernel(const float *__restrict__ e3v, const float *__restrict__ zv, int64_t nij, int npk,
+                                 double *__restrict__ dvbt, float *__restrict__ hdep) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nij) return;
+    double d = 0.0;
+    float h = 0.f;
+    for (int k = 0; k < npk - 1; ++k) {
+        const float e = e3v[(int64_t)k * nij + p];
+        d = __dadd_rn(d, (double)__fmul_rn(e, zv[(int64_t)k * nij + p]));
+        h = __fadd_rn(h, e);
+    }
+    hdep[p] = h;
+    dvbt[p] = (h != 0.f) ? __ddiv_rn(d, (double)h) : 0.0;
+}
+
+// :480-484: the same division for the mean of the geostrophic velocity accumulated by dec_shear_kernel
+__global__ void dec_divide_kernel(double *__restrict__ dvbt, const float *__restrict__ hdep, int64_t nij) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nij) return;
+    const float h = hdep[p];
+    dvbt[p] = (h != 0.f) ? __ddiv_rn(dvbt[p], (double)h) : 0.0;
+}
+
+// :403-414 and :489-502: raw(b,jj,jk) = - sum_ji (e1v*e3v*ibmask(b)) * dvbt(ji,jj): the r4 weight times
+// an r8 field that does not depend on the level.  One workgroup per (jj,jk) row, basins selected by
+// bit; level npk (index npk-1) is written as 0.  Fixed reduction order.
+template <int NB>
+__global__ void __launch_bounds__(256) dec_zonal_r8_kernel(const float *__restrict__ w, const uint8_t *__restrict__ bits,
+                                                            const double *__restrict__ field, int npi, int npj, int npk,
+                                                            int nb, double *__restrict__ raw) {
+    __shared__ double scratch[NB][4];
+    const int row = blockIdx.x, jk = row / npj, jj = row - jk * npj;
+    double acc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[b] = 0.0;
+    if (jk < npk - 1) {
+        const int64_t r2 = (int64_t)jj * npi, r3 = (int64_t)row * npi;
+        for (int i = threadIdx.x; i < npi; i += 256) {
+            const double t = __dmul_rn((double)w[r3 + i], field[r2 + i]);
+            const uint32_t bb = bits[r2 + i];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) acc[b] += ((bb >> b) & 1u) ? t : 0.0;
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        double s = acc[b];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+        if (lane == 0) scratch[b][wave] = s;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nb) {
+        const int b = threadIdx.x;
+        const double s = ((scratch[b][0] + scratch[b][1]) + scratch[b][2]) + scratch[b][3];
+        raw[((int64_t)jk * npj + jj) * nb + b] = -s;
+    }
+}
+
+// :439-466 for ONE level jk (launched from the bottom level up, in order).  sig8 = sigmai(T,S,gdept(jk))
+// of the level (r8); zsig0 = REAL(sig8 * itmask) is formed on the fly for the six points of the stencil.
+// dvgeo is updated in place (the reference's iup/ido pair collapses: each cell only reads its own
+// previous value); zvgeo(:,:,jk) receives the r4 geostrophic velocity, the border keeps the velocity of
+// level npk-1 (the reference never assigns the border of zv, see the oracle); dvbt += e3v*zv*1.d0.
+__global__ void dec_shear_kernel(const double *__restrict__ sig8, const uint8_t *__restrict__ tm,
+                                 const uint8_t *__restrict__ um, const float *__restrict__ e1u,
+                                 const float *__restrict__ zcoef, const uint8_t *__restrict__ bits,
+                                 const float *__restrict__ e3v, const float *__restrict__ zvlast, int npi, int npj,
+                                 double *__restrict__ dvgeo, float *__restrict__ zvgeo, double *__restrict__ dvbt) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= (int64_t)npi * npj) return;
+    const int jj = (int)(p / npi), ji = (int)(p - (int64_t)jj * npi);
+    float zv;
+    if (ji >= 1 && ji < npi - 1 && jj >= 1 && jj < npj - 1) {
+        auto sg = [&](int64_t q) { return (float)__dmul_rn(sig8[q], (double)tm[q]); };        // :443
+        const int64_t pn = p + npi;
+        const int isum = max(1, (int)um[pn - 1] + (int)um[pn] + (int)um[p - 1] + (int)um[p]);
+        const float zmsv = __fdiv_rn(1.f, (float)isum);                                          // :449
+        float g = __fdiv_rn(__fmul_rn(__fsub_rn(sg(pn), sg(pn - 1)), (float)um[pn - 1]), e1u[pn - 1]);
+        g = __fadd_rn(g, __fdiv_rn(__fmul_rn(__fsub_rn(sg(pn + 1), sg(pn)), (float)um[pn]), e1u[pn]));
+        g = __fadd_rn(g, __fdiv_rn(__fmul_rn(__fsub_rn(sg(p), sg(p - 1)), (float)um[p - 1]), e1u[p - 1]));
+        g = __fadd_rn(g, __fdiv_rn(__fmul_rn(__fsub_rn(sg(p + 1), sg(p)), (float)um[p]), e1u[p]));   // :450-453
+        double inc = __dmul_rn((double)zcoef[p], (double)g);
+        inc = __dmul_rn(inc, (double)zmsv);
+        inc = __dmul_rn(inc, (double)(bits[p] & 1u));                                            // ibmask(npglo,ji,jj)
+        inc = __dmul_rn(inc, (double)e3v[p]);
+        const double old = dvgeo[p], now = __dadd_rn(old, inc);                                  // :457
+        dvgeo[p] = now;
+        zv = (float)__dmul_rn(0.5, __dadd_rn(now, old));                                         // :459
+    } else {
+        zv = zvlast[p];
+    }
+    zvgeo[p] = zv;
+    dvbt[p] = __dadd_rn(dvbt[p], (double)__fmul_rn(e3v[p], zv));                                 // :466
+}
+
+// :416-419, :505-516 per (basin,jj) column: cumulated sums of the barotropic and shear parts and the
+// ageostrophic remainder.  sh is IN/OUT (the reference accumulates onto what the array holds, :471).
+__global__ void dec_finish_kernel(const double *__restrict__ tot, const double *__restrict__ raw_bt,
+                                  const double *__restrict__ raw_sh, const double *__restrict__ raw_btw,
+                                  int nbj, int npk, double *__restrict__ sh, double *__restrict__ bt,
+                                  double *__restrict__ ag) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nbj) return;
+    const int64_t top = (int64_t)(npk - 1) * nbj + q;
+    double b = 0.0;                                          // dmoc_bt(:,:,npk) stays at its initial 0
+    double s = __dadd_rn(sh[top], -raw_btw[top]);            // :505 at level npk (dmoc_btw is 0 there)
+    bt[top] = b; sh[top] = s;
+    ag[top] = __dadd_rn(__dadd_rn(tot[top], -s), -b);
+    for (int jk = npk - 2; jk >= 0; --jk) {
+        const int64_t e = (int64_t)jk * nbj + q;
+        b = __dadd_rn(b, __ddiv_rn(raw_bt[e], 1.0e6));                                           // :418
+        const double r = __dadd_rn(__dadd_rn(sh[e], raw_sh[e]), -raw_btw[e]);                    // :471, :505
+        s = __dadd_rn(s, __ddiv_rn(r, 1.0e6));                                                   // :509
+        bt[e] = b; sh[e] = s;
+        ag[e] = __dadd_rn(__dadd_rn(tot[e], -s), -b);                                            // :516
+    }
+}
+
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // pick waves per row and float4 vectors per lane for a row of npi cells
@@ -106,6 +234,42 @@ void choose_shape(const cdft_moc_plan *p, bool aligned, int *nwaves, int *nv, in
 }
 
 }  // namespace
+
+// the zonal kernel of one call: raw -(zonal sums) of npt records into d_out (nbasins,npj,npk,npt),
+// levels 1..npk-1 (level npk is left to the caller)
+static int zonal_launch(cdft_moc_plan *p, const float *d_zv, int64_t rec_stride, int npt, double *d_out,
+                        hipStream_t st, bool profile) {
+    ZonalArgs a;
+    a.w = p->w; a.bits = p->bits; a.cls = p->cls; a.nclass = p->nclass;
+    for (int c = 0; c < kMaxClass; ++c) a.pat[c] = p->pat[c];
+    a.zv = d_zv; a.rec_stride = rec_stride; a.npt = npt;
+    a.out = d_out; a.npi = p->npi; a.npj = p->npj; a.npk = p->npk; a.nbasins = p->nbasins;
+    const bool aligned = ((uintptr_t)d_zv % 16 == 0) && (rec_stride % 4 == 0);
+    int k, v, md;
+    choose_shape(p, aligned, &k, &v, &md);
+    if (k > kMaxWaves || v > kMaxNV)
+        return fail(CDFT_ERR_ARG, "cdft_moc_compute: row of %d cells needs %d waves x %d vectors", p->npi, k, v);
+    hipEvent_t ev1 = nullptr;
+    if (profile && p->profiling) {
+        if (p->ev_used + 2 > p->ev.size()) {
+            hipEvent_t e0, e1;
+            CDFT_HIP(hipEventCreate(&e0));
+            CDFT_HIP(hipEventCreate(&e1));
+            p->ev.push_back(e0);
+            p->ev.push_back(e1);
+        }
+        CDFT_HIP(hipEventRecord(p->ev[p->ev_used], st));
+        ev1 = p->ev[p->ev_used + 1];
+        p->ev_used += 2;
+    }
+    if (md == kModeClass)     CDFT_TRY(launch_zonal_class(a, k, v, st));
+    else if (p->nbasins == 1) CDFT_TRY(launch_zonal_nb1(a, k, v, aligned, md, st));
+    else if (p->nbasins <= 5) CDFT_TRY(launch_zonal_nb5(a, k, v, aligned, md, st));
+    else                      CDFT_TRY(launch_zonal_nb8(a, k, v, aligned, md, st));
+    if (ev1) CDFT_HIP(hipEventRecord(ev1, st));
+
+    return CDFT_OK;
+}
 
 extern "C" {
 
@@ -240,34 +404,7 @@ int cdft_moc_compute(cdft_moc_plan *p, const float *zv, int64_t rec_stride, int 
         return fail(CDFT_ERR_ARG, "cdft_moc_compute: bad memory-space tag %d", dmoc_space);
     }
 
-    ZonalArgs a;
-    a.w = p->w; a.bits = p->bits; a.cls = p->cls; a.nclass = p->nclass;
-    for (int c = 0; c < kMaxClass; ++c) a.pat[c] = p->pat[c];
-    a.zv = (const float *)d_zv; a.rec_stride = rec_stride; a.npt = npt;
-    a.out = d_out; a.npi = p->npi; a.npj = p->npj; a.npk = p->npk; a.nbasins = p->nbasins;
-    const bool aligned = ((uintptr_t)d_zv % 16 == 0) && (rec_stride % 4 == 0);
-    int k, v, md;
-    choose_shape(p, aligned, &k, &v, &md);
-    if (k > kMaxWaves || v > kMaxNV)
-        return fail(CDFT_ERR_ARG, "cdft_moc_compute: row of %d cells needs %d waves x %d vectors", p->npi, k, v);
-    hipEvent_t ev1 = nullptr;
-    if (p->profiling) {
-        if (p->ev_used + 2 > p->ev.size()) {
-            hipEvent_t e0, e1;
-            CDFT_HIP(hipEventCreate(&e0));
-            CDFT_HIP(hipEventCreate(&e1));
-            p->ev.push_back(e0);
-            p->ev.push_back(e1);
-        }
-        CDFT_HIP(hipEventRecord(p->ev[p->ev_used], st));
-        ev1 = p->ev[p->ev_used + 1];
-        p->ev_used += 2;
-    }
-    if (md == kModeClass)     CDFT_TRY(launch_zonal_class(a, k, v, st));
-    else if (p->nbasins == 1) CDFT_TRY(launch_zonal_nb1(a, k, v, aligned, md, st));
-    else if (p->nbasins <= 5) CDFT_TRY(launch_zonal_nb5(a, k, v, aligned, md, st));
-    else                      CDFT_TRY(launch_zonal_nb8(a, k, v, aligned, md, st));
-    if (ev1) CDFT_HIP(hipEventRecord(ev1, st));
+    CDFT_TRY(zonal_launch(p, (const float *)d_zv, rec_stride, npt, d_out, st, true));
 
     const int nbj = p->nbasins * p->npj;
     const int64_t nthr = (int64_t)nbj * npt;
@@ -276,6 +413,113 @@ int cdft_moc_compute(cdft_moc_plan *p, const float *zv, int64_t rec_stride, int 
     CDFT_LAUNCH_CHECK();
     if (dmoc_space == CDFT_MEM_HOST) {
         CDFT_HIP(hipMemcpyAsync(dmoc, d_out, out_bytes, hipMemcpyDeviceToHost, st));
+        CDFT_HIP(hipStreamSynchronize(st));
+    }
+    return CDFT_OK;
+}
+
+int cdft_moc_decomp_set_mesh(cdft_moc_plan *p, const float *e3v, const float *e1u, const float *zcoef,
+                             const float *gdept, const uint8_t *tmask, const uint8_t *umask, int memspace,
+                             void *stream) {
+    if (!p || !e3v || !e1u || !zcoef || !gdept || !tmask || !umask)
+        return fail(CDFT_ERR_ARG, "cdft_moc_decomp_set_mesh: NULL argument");
+    if (p->npi < 3 || p->npj < 3)
+        return fail(CDFT_ERR_ARG, "cdft_moc_decomp_set_mesh: the 4-point stencil needs npiglo, npjglo >= 3");
+    hipStream_t st = as_stream(stream);
+    const size_t nij = (size_t)p->npi * p->npj, n3 = nij * p->npk;
+    auto keep = [&](DevBuf &b, const void *src, size_t bytes) -> int {   // the plan owns a copy
+        CDFT_TRY(b.reserve(bytes));
+        CDFT_HIP(hipMemcpyAsync(b.ptr, src, bytes, memspace == CDFT_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+        return CDFT_OK;
+    };
+    CDFT_TRY(keep(p->d_e3v, e3v, n3 * 4));
+    CDFT_TRY(keep(p->d_e1u, e1u, nij * 4));
+    CDFT_TRY(keep(p->d_zcoef, zcoef, nij * 4));
+    CDFT_TRY(keep(p->d_tmask, tmask, n3));
+    CDFT_TRY(keep(p->d_umask, umask, n3));
+    p->gdept.assign(gdept, gdept + p->npk);                   // gdept is always a HOST array (npk values)
+    CDFT_HIP(hipStreamSynchronize(st));
+    p->dec_set = true;
+    return CDFT_OK;
+}
+
+int cdft_moc_decomp(cdft_moc_plan *p, const float *zv, const float *ztemp, const float *zsal, int eos, int in_space,
+                    double *dmoc, double *dmoc_sh, double *dmoc_bt, double *dmoc_ag, int out_space, void *stream) {
+    if (!p || !zv || !ztemp || !zsal || !dmoc || !dmoc_sh || !dmoc_bt || !dmoc_ag)
+        return fail(CDFT_ERR_ARG, "cdft_moc_decomp: NULL argument");
+    if (!p->mesh_set || !p->dec_set)
+        return fail(CDFT_ERR_STATE, "cdft_moc_decomp: cdft_moc_set_mesh and cdft_moc_decomp_set_mesh must have succeeded");
+    if (eos != CDFT_EOS_80 && eos != CDFT_EOS_TEOS10) return fail(CDFT_ERR_ARG, "cdft_moc_decomp: eos must be CDFT_EOS_80 or CDFT_EOS_TEOS10");
+    hipStream_t st = as_stream(stream);
+    const int npi = p->npi, npj = p->npj, npk = p->npk, nb = p->nbasins;
+    const int64_t nij = (int64_t)npi * npj, n3 = nij * npk;
+    const size_t ob = (size_t)nb * npj * npk * 8;
+    const void *dzv, *dt, *ds;
+    CDFT_TRY(to_device(zv, n3 * 4, in_space, p->st_zv, st, &dzv));
+    CDFT_TRY(to_device(ztemp, n3 * 4, in_space, p->d_t, st, &dt));
+    CDFT_TRY(to_device(zsal, n3 * 4, in_space, p->d_s, st, &ds));
+    CDFT_TRY(p->d_zvgeo.reserve(n3 * 4));
+    CDFT_TRY(p->d_sig8.reserve(nij * 8));
+    CDFT_TRY(p->d_dvbt.reserve(nij * 8));
+    CDFT_TRY(p->d_hdep.reserve(nij * 4));
+    CDFT_TRY(p->d_dvgeo.reserve(nij * 8));
+    CDFT_TRY(p->d_raw.reserve(3 * ob));                       // raw zonal sums: bt, sh, btw
+    double *raw_bt = (double *)p->d_raw.ptr, *raw_sh = raw_bt + ob / 8, *raw_btw = raw_sh + ob / 8;
+    double *o_tot = dmoc, *o_sh = dmoc_sh, *o_bt = dmoc_bt, *o_ag = dmoc_ag;
+    if (out_space == CDFT_MEM_HOST) {
+        CDFT_TRY(p->d_o4.reserve(4 * ob));
+        o_tot = (double *)p->d_o4.ptr; o_sh = o_tot + ob / 8; o_bt = o_sh + ob / 8; o_ag = o_bt + ob / 8;
+        CDFT_HIP(hipMemcpyAsync(o_sh, dmoc_sh, ob, hipMemcpyHostToDevice, st));   // IN/OUT
+    } else if (out_space != CDFT_MEM_DEVICE) {
+        return fail(CDFT_ERR_ARG, "cdft_moc_decomp: bad memory-space tag %d", out_space);
+    }
+    const float *e3v = (const float *)p->d_e3v.ptr, *fzv = (const float *)dzv;
+    const uint8_t *tm = (const uint8_t *)p->d_tmask.ptr, *um = (const uint8_t *)p->d_umask.ptr;
+    double *dvbt = (double *)p->d_dvbt.ptr, *dvgeo = (double *)p->d_dvgeo.ptr, *sig8 = (double *)p->d_sig8.ptr;
+    float *hdep = (float *)p->d_hdep.ptr, *zvgeo = (float *)p->d_zvgeo.ptr;
+    const dim3 g2((unsigned)((nij + 255) / 256)), b2(256), grow((unsigned)npj * (unsigned)npk);
+    auto zonal_r8 = [&](const double *field, double *raw) -> int {
+        if (nb == 1)      hipLaunchKernelGGL((dec_zonal_r8_kernel<1>), grow, b2, 0, st, p->w, p->bits, field, npi, npj, npk, nb, raw);
+        else if (nb <= 5) hipLaunchKernelGGL((dec_zonal_r8_kernel<5>), grow, b2, 0, st, p->w, p->bits, field, npi, npj, npk, nb, raw);
+        else              hipLaunchKernelGGL((dec_zonal_r8_kernel<8>), grow, b2, 0, st, p->w, p->bits, field, npi, npj, npk, nb, raw);
+        CDFT_LAUNCH_CHECK();
+        return CDFT_OK;
+    };
+    // 1) total MOC of the record (src/cdfmoc.f90:352-388)
+    CDFT_TRY(cdft_moc_compute(p, fzv, n3, 1, CDFT_MEM_DEVICE, o_tot, CDFT_MEM_DEVICE, stream));
+    // 2.1) barotropic part (:360-365, :397-419)
+    hipLaunchKernelGGL(dec_vmean_kernel, g2, b2, 0, st, e3v, fzv, nij, npk, dvbt, hdep);
+    CDFT_LAUNCH_CHECK();
+    CDFT_TRY(zonal_r8(dvbt, raw_bt));
+    // 2.2) geostrophic shear part (:435-478): levels from the bottom up
+    CDFT_HIP(hipMemsetAsync(dvgeo, 0, nij * 8, st));
+    CDFT_HIP(hipMemsetAsync(dvbt, 0, nij * 8, st));
+    CDFT_HIP(hipMemsetAsync(zvgeo + (int64_t)(npk - 1) * nij, 0, nij * 4, st));
+    for (int jk = npk - 2; jk >= 0; --jk) {
+        const int64_t o = (int64_t)jk * nij;
+        CDFT_TRY(cdft_eos_sigmai((const float *)dt + o, (const float *)ds + o, nij, p->gdept[jk], eos, 0, sig8,
+                                 CDFT_MEM_DEVICE, CDFT_MEM_DEVICE, stream));
+        hipLaunchKernelGGL(dec_shear_kernel, g2, b2, 0, st, sig8, tm + o, um + o, (const float *)p->d_e1u.ptr,
+                           (const float *)p->d_zcoef.ptr, p->bits, e3v + o, fzv + (int64_t)(npk - 2) * nij, npi, npj,
+                           dvgeo, zvgeo + o, dvbt);
+        CDFT_LAUNCH_CHECK();
+    }
+    CDFT_HIP(hipMemsetAsync(raw_sh, 0, ob, st));              // level npk of the raw sums stays 0
+    CDFT_TRY(zonal_launch(p, zvgeo, n3, 1, raw_sh, st, false));
+    // 2.2.1) its pseudo-barotropic part (:480-502)
+    hipLaunchKernelGGL(dec_divide_kernel, g2, b2, 0, st, dvbt, hdep, nij);
+    CDFT_LAUNCH_CHECK();
+    CDFT_TRY(zonal_r8(dvbt, raw_btw));
+    // :416-419, :505-516
+    const int nbj = nb * npj;
+    hipLaunchKernelGGL(dec_finish_kernel, dim3((unsigned)((nbj + 255) / 256)), b2, 0, st, o_tot, raw_bt, raw_sh, raw_btw,
+                       nbj, npk, o_sh, o_bt, o_ag);
+    CDFT_LAUNCH_CHECK();
+    if (out_space == CDFT_MEM_HOST) {
+        CDFT_HIP(hipMemcpyAsync(dmoc, o_tot, ob, hipMemcpyDeviceToHost, st));
+        CDFT_HIP(hipMemcpyAsync(dmoc_sh, o_sh, ob, hipMemcpyDeviceToHost, st));
+        CDFT_HIP(hipMemcpyAsync(dmoc_bt, o_bt, ob, hipMemcpyDeviceToHost, st));
+        CDFT_HIP(hipMemcpyAsync(dmoc_ag, o_ag, ob, hipMemcpyDeviceToHost, st));
         CDFT_HIP(hipStreamSynchronize(st));
     }
     return CDFT_OK;
@@ -310,6 +554,9 @@ int cdft_moc_destroy(cdft_moc_plan *p) {
     if (p->cls) (void)hipFree(p->cls);
     if (p->flag) (void)hipFree(p->flag);
     p->st_e1v.release(); p->st_e3v.release(); p->st_mask.release(); p->st_zv.release(); p->st_out.release();
+    DevBuf *dec[] = {&p->d_e3v, &p->d_e1u, &p->d_zcoef, &p->d_tmask, &p->d_umask, &p->d_t, &p->d_s, &p->d_zvgeo, &p->d_sig8,
+                     &p->d_dvbt, &p->d_hdep, &p->d_dvgeo, &p->d_raw, &p->d_o4};
+    for (DevBuf *b : dec) b->release();
     delete p;
     return CDFT_OK;
 }

@@ -109,6 +109,32 @@ class MocPlan:
     def set_tuning(self, waves_per_row=0, vec_per_lane=0, mode=0):
         check(_lib.load().cdft_moc_set_tuning(self._h, waves_per_row, vec_per_lane, mode))
 
+    def decomp_set_mesh(self, e3v, e1u, zcoef, gdept, tmask, umask, stream=None):
+        """-decomp mesh (host arrays): e3v (npk,npj,npi) r4 masked, e1u / zcoef (npj,npi) r4, gdept (npk) r4,
+        tmask / umask (npk,npj,npi) bytes 0/1."""
+        keep = [np.ascontiguousarray(e3v, np.float32), np.ascontiguousarray(e1u, np.float32),
+                np.ascontiguousarray(zcoef, np.float32), np.ascontiguousarray(gdept, np.float32),
+                np.ascontiguousarray(tmask, np.uint8), np.ascontiguousarray(umask, np.uint8)]
+        n2, n3 = self.npi * self.npj, self.npi * self.npj * self.npk
+        for a, n, nm in zip(keep, (n3, n2, n2, self.npk, n3, n3), ("e3v", "e1u", "zcoef", "gdept", "tmask", "umask")):
+            if a.size != n:
+                raise ValueError(f"{nm}: expected {n} elements, got shape {a.shape}")
+        check(_lib.load().cdft_moc_decomp_set_mesh(self._h, *[C.c_void_p(a.ctypes.data) for a in keep], MEM_HOST,
+                                                   stream or current_stream_ptr()))
+
+    def decomp(self, zv, ztemp, zsal, dmoc_sh=None, eos=0, stream=None):
+        """One record (host arrays (npk,npj,npi) r4) -> dict of (npk,npj,nb) r8: total, sh, bt, ag.
+        dmoc_sh: the values the shear part accumulates onto (None = zeros, i.e. the first record)."""
+        ins = [np.ascontiguousarray(x, np.float32) for x in (zv, ztemp, zsal)]
+        shape = (self.npk, self.npj, self.nb)
+        out = {k: np.zeros(shape, np.float64) for k in ("total", "sh", "bt", "ag")}
+        if dmoc_sh is not None:
+            out["sh"][...] = dmoc_sh
+        check(_lib.load().cdft_moc_decomp(self._h, *[C.c_void_p(a.ctypes.data) for a in ins], eos, MEM_HOST,
+                                          *[C.c_void_p(out[k].ctypes.data) for k in ("total", "sh", "bt", "ag")], MEM_HOST,
+                                          stream or current_stream_ptr()))
+        return out
+
     def describe(self) -> str:
         buf = C.create_string_buffer(256)
         check(_lib.load().cdft_moc_describe(self._h, buf, 256))

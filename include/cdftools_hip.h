@@ -94,6 +94,29 @@ int cdft_moc_set_mesh(cdft_moc_plan *plan, const float *e1v, const float *e3v,
 int cdft_moc_compute(cdft_moc_plan *plan, const float *zv, int64_t rec_stride, int npt,
                      int zv_space, double *dmoc, int dmoc_space, void *stream);
 
+/* cdfmoc -decomp (src/cdfmoc.f90:353, :360-365, :390-517): the total overturning of ONE record and its
+ * geostrophic-shear, barotropic and ageostrophic parts.  Needs cdft_moc_set_mesh (weights, basins)
+ * and, once per run (per record with -vvl):
+ *   e3v   (npiglo,npjglo,npk) r4, the same masked e3v handed to cdft_moc_set_mesh (:343-348)
+ *   e1u   (npiglo,npjglo) r4 (:313)
+ *   zcoef (npiglo,npjglo) r4: the reference's array after :428-433, -grav/rau0/f at V points and 0
+ *         where f = 0.  Computed by the caller: it goes through the compiler's r4 SIN.
+ *   gdept (npk) r4 on the HOST (:312)
+ *   tmask, umask (npiglo,npjglo,npk) bytes 0/1 (the reference reads them into INTEGER(2), :439-440) */
+int cdft_moc_decomp_set_mesh(cdft_moc_plan *plan, const float *e3v, const float *e1u, const float *zcoef,
+                             const float *gdept, const uint8_t *tmask, const uint8_t *umask, int memspace,
+                             void *stream);
+/* zv, ztemp, zsal (npiglo,npjglo,npk) r4 of one record; eos = CDFT_EOS_80 | CDFT_EOS_TEOS10 (-teos10).
+ * dmoc, dmoc_bt, dmoc_ag (nbasins,npjglo,npk) r8 out.
+ * dmoc_sh (nbasins,npjglo,npk) r8 IN/OUT: the reference never clears it and accumulates each record
+ * onto what the array holds (:471) -- pass zeros for the first record and the previous record's
+ * result afterwards to reproduce a multi-record run of the reference, or zeros every time for the
+ * per-record decomposition.  Another quirk kept: the border of the geostrophic velocity holds the
+ * velocity of level npk-1 (zv(:,:) is only assigned on ji=2..npiglo-1, jj=2..npjglo-1, :447-462). */
+int cdft_moc_decomp(cdft_moc_plan *plan, const float *zv, const float *ztemp, const float *zsal, int eos,
+                    int in_space, double *dmoc, double *dmoc_sh, double *dmoc_bt, double *dmoc_ag,
+                    int out_space, void *stream);
+
 /* Tuning hook for the measurement harness: waves per row (0 = automatic) and float4 vectors
  * per lane (0 = automatic), accumulate mode (0 = automatic, 1 = select per basin, 2 = fma with
  * 0/1 masks, 3 = one LDS accumulator per basin-bit pattern ("class"; needs several basins, at most

@@ -154,3 +154,96 @@ void oracle_sigmai_jmd94(const float *ptem, const float *psal, long n, float pre
         sig[p] = rhop / (1.0 - ref / (k0 - ref * (a - ref * b))) - dprau0;     /* :995 */
     }
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* cdfmoc -decomp, src/cdfmoc.f90:353,:360-365 (dvbt, hdep in the main loop) and :390-517, ONE record.
+ *   e1v,e1u,zcoef (npi,npj) r4; e3v (npi,npj,npk) r4 already * vmask(level); ibmask (nb,npi,npj) i2,
+ *   basin 0 = global; zv,ztemp,zsal (npi,npj,npk) r4; tmask,umask (npi,npj,npk) 0/1 bytes (the
+ *   reference reads them into INTEGER(2)); gdept (npk) r4.
+ *   zcoef is the reference's r4 array after :428-433 (-g/rau0/f at V points, 0 where f = 0): it is
+ *   computed by the CALLER because it goes through the compiler's r4 SIN.
+ *   dmoc (nb,npj,npk): total MOC as oracle_moc gives it (input).
+ *   dmoc_sh (nb,npj,npk): IN/OUT.  The reference never clears it (:471 accumulates onto whatever
+ *   the array holds): zeros for the first record of a run, the previous record's result afterwards.
+ *   dmoc_bt, dmoc_ag (nb,npj,npk): out.
+ * Quirk kept: zv(:,:) is only assigned for ji=2..npiglo-1, jj=2..npjglo-1 (:447-462); its border
+ * keeps the velocity of level npk-1 read last by the main loop (:358), and enters :466 and :471. */
+void oracle_moc_decomp(int npi, int npj, int npk, int nb, const float *e1v, const float *e3v,
+                       const int16_t *ibmask, const float *zv3, const float *ztemp, const float *zsal,
+                       const uint8_t *tmask, const uint8_t *umask, const float *e1u, const float *zcoef,
+                       const float *gdept, int teos10, const double *dmoc, double *dmoc_sh,
+                       double *dmoc_bt, double *dmoc_ag) {
+    const size_t nij = (size_t)npi * npj, nbj = (size_t)nb * npj;
+    double *dvbt = (double *)calloc(nij, 8), *dvgeo = (double *)calloc(2 * nij, 8);
+    double *btw = (double *)calloc(nbj * npk, 8), *sig8 = (double *)malloc(nij * 8);
+    float *hdep = (float *)calloc(nij, 4), *zv = (float *)malloc(nij * 4), *zsig0 = (float *)malloc(nij * 4);
+    /* :360-365 */
+    for (int jk = 0; jk < npk - 1; ++jk)
+        for (size_t p = 0; p < nij; ++p) {
+            dvbt[p] = dvbt[p] + (double)(e3v[jk * nij + p] * zv3[jk * nij + p]) * 1.0;
+            hdep[p] = hdep[p] + e3v[jk * nij + p];
+        }
+    memcpy(zv, zv3 + (size_t)(npk - 2) * nij, nij * 4);       /* what zv(:,:) holds when :390 is reached */
+    /* :397-401 */
+    for (size_t p = 0; p < nij; ++p) dvbt[p] = (hdep[p] != 0.f) ? dvbt[p] / (double)hdep[p] : 0.0;
+    /* :403-419 */
+    memset(dmoc_bt, 0, nbj * npk * 8);
+    for (int jk = 0; jk < npk - 1; ++jk)
+        for (int ji = 0; ji < npi; ++ji)
+            for (int jb = 0; jb < nb; ++jb)
+                for (int jj = 0; jj < npj; ++jj) {
+                    const float w = e1v[IJ(ji, jj)] * e3v[IJK(ji, jj, jk)] * (float)ibmask[IJ(ji, jj) * nb + jb];
+                    dmoc_bt[((size_t)jk * npj + jj) * nb + jb] -= (double)w * dvbt[IJ(ji, jj)];
+                }
+    for (int jk = npk - 2; jk >= 0; --jk)
+        for (size_t q = 0; q < nbj; ++q) dmoc_bt[jk * nbj + q] = dmoc_bt[(jk + 1) * nbj + q] + dmoc_bt[jk * nbj + q] / 1.0e6;
+    /* :435-482 */
+    memset(dvbt, 0, nij * 8);
+    int iup = 0, ido = 1;
+    for (int jk = npk - 2; jk >= 0; --jk) {
+        const uint8_t *ium = umask + jk * nij, *itm = tmask + jk * nij;
+        oracle_sigmai(ztemp + jk * nij, zsal + jk * nij, (long)nij, gdept[jk], NULL, teos10, sig8);
+        for (size_t p = 0; p < nij; ++p) zsig0[p] = (float)(sig8[p] * (double)(int16_t)itm[p]);          /* :443 */
+        for (int jj = 1; jj < npj - 1; ++jj)
+            for (int ji = 1; ji < npi - 1; ++ji) {
+                int16_t isum = (int16_t)(ium[IJ(ji - 1, jj + 1)] + ium[IJ(ji, jj + 1)] + ium[IJ(ji - 1, jj)] + ium[IJ(ji, jj)]);
+                if (isum < 1) isum = 1;
+                const float zmsv = 1.f / (float)isum;                                                     /* :449 */
+                float g = (zsig0[IJ(ji, jj + 1)] - zsig0[IJ(ji - 1, jj + 1)]) * (float)ium[IJ(ji - 1, jj + 1)] / e1u[IJ(ji - 1, jj + 1)];
+                g = g + (zsig0[IJ(ji + 1, jj + 1)] - zsig0[IJ(ji, jj + 1)]) * (float)ium[IJ(ji, jj + 1)] / e1u[IJ(ji, jj + 1)];
+                g = g + (zsig0[IJ(ji, jj)] - zsig0[IJ(ji - 1, jj)]) * (float)ium[IJ(ji - 1, jj)] / e1u[IJ(ji - 1, jj)];
+                g = g + (zsig0[IJ(ji + 1, jj)] - zsig0[IJ(ji, jj)]) * (float)ium[IJ(ji, jj)] / e1u[IJ(ji, jj)];
+                const double dgeo = (double)g * 1.0;                                                      /* :450-453 */
+                double inc = (double)zcoef[IJ(ji, jj)] * dgeo;
+                inc = inc * (double)zmsv;
+                inc = inc * (double)ibmask[IJ(ji, jj) * nb + 0];
+                inc = inc * (double)e3v[IJK(ji, jj, jk)];
+                dvgeo[iup * nij + IJ(ji, jj)] = dvgeo[ido * nij + IJ(ji, jj)] + inc;                      /* :457 */
+                zv[IJ(ji, jj)] = (float)(0.5 * (dvgeo[iup * nij + IJ(ji, jj)] + dvgeo[ido * nij + IJ(ji, jj)]));   /* :459 */
+            }
+        for (size_t p = 0; p < nij; ++p) dvbt[p] = dvbt[p] + (double)(e3v[jk * nij + p] * zv[p]) * 1.0;  /* :466 */
+        for (int ji = 0; ji < npi; ++ji)
+            for (int jb = 0; jb < nb; ++jb)
+                for (int jj = 0; jj < npj; ++jj) {
+                    float p = e1v[IJ(ji, jj)] * e3v[IJK(ji, jj, jk)];
+                    p = p * (float)ibmask[IJ(ji, jj) * nb + jb];
+                    p = p * zv[IJ(ji, jj)];
+                    dmoc_sh[((size_t)jk * npj + jj) * nb + jb] -= (double)p * 1.0;                        /* :471 */
+                }
+        const int t = iup; iup = ido; ido = t;
+    }
+    for (size_t p = 0; p < nij; ++p) dvbt[p] = (hdep[p] != 0.f) ? dvbt[p] / (double)hdep[p] : 0.0;        /* :480-484 */
+    /* :489-502 */
+    for (int jk = 0; jk < npk - 1; ++jk)
+        for (int ji = 0; ji < npi; ++ji)
+            for (int jb = 0; jb < nb; ++jb)
+                for (int jj = 0; jj < npj; ++jj) {
+                    const float w = e1v[IJ(ji, jj)] * e3v[IJK(ji, jj, jk)] * (float)ibmask[IJ(ji, jj) * nb + jb];
+                    btw[((size_t)jk * npj + jj) * nb + jb] -= (double)w * dvbt[IJ(ji, jj)];
+                }
+    for (size_t q = 0; q < nbj * npk; ++q) dmoc_sh[q] = dmoc_sh[q] - btw[q];                              /* :505 */
+    for (int jk = npk - 2; jk >= 0; --jk)
+        for (size_t q = 0; q < nbj; ++q) dmoc_sh[jk * nbj + q] = dmoc_sh[(jk + 1) * nbj + q] + dmoc_sh[jk * nbj + q] / (double)1.e6f;   /* :509 */
+    for (size_t q = 0; q < nbj * npk; ++q) dmoc_ag[q] = dmoc[q] - dmoc_sh[q] - dmoc_bt[q];                /* :516 */
+    free(dvbt); free(dvgeo); free(btw); free(sig8); free(hdep); free(zv); free(zsig0);
+}

@@ -31,6 +31,13 @@ extern "C" {
  *   dmoc(nb,npj,npk) out, Sverdrup.  Levels 1..npk-1 of zv are read (jk=1,npk-1). */
 void oracle_moc(int npi, int npj, int npk, int nb, const float *e1v, const float *e3v,
                 const int16_t *ibmask, const float *zv, double *dmoc);
+/* src/cdfmoc.f90:353,:360-365,:390-517 (-decomp) for ONE record; see the definition for the argument
+ * list and the two reference quirks it keeps (dmoc_sh is never cleared; the border of zv). */
+void oracle_moc_decomp(int npi, int npj, int npk, int nb, const float *e1v, const float *e3v,
+                       const int16_t *ibmask, const float *zv3, const float *ztemp, const float *zsal,
+                       const uint8_t *tmask, const uint8_t *umask, const float *e1u, const float *zcoef,
+                       const float *gdept, int teos10, const double *dmoc, double *dmoc_sh,
+                       double *dmoc_bt, double *dmoc_ag);
 /* src/eos.f90:802-887 (sigmai_dep), :1002-1087 (sigmai_dep2d), :601-632 (sigma0 = pref 0);
  * coefficients as set by eos_init :207-598 (teos10 = 0: EOS-80 polynomial, 1: TEOS-10).
  * ptem, psal: n r4 values; pref: one r4 depth (pref2d == NULL) or n per-point depths. */

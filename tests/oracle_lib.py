@@ -26,6 +26,24 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def moc_decomp(e1v, e3v, ibmask, zv, ztemp, zsal, tmask, umask, e1u, zcoef, gdept, teos10=False, dmoc_sh=None):
+    """One record of cdfmoc -decomp (oracle_moc_decomp) -> dict total / sh / bt / ag, each (npk,npj,nb) r8."""
+    lib = load()
+    f = lambda a: np.ascontiguousarray(a, np.float32)   # noqa: E731
+    e1v, e3v, zv, ztemp, zsal, e1u, zcoef, gdept = map(f, (e1v, e3v, zv, ztemp, zsal, e1u, zcoef, gdept))
+    ibmask = np.ascontiguousarray(ibmask, np.int16)
+    tmask, umask = np.ascontiguousarray(tmask, np.uint8), np.ascontiguousarray(umask, np.uint8)
+    npk, npj, npi = e3v.shape
+    nb = ibmask.shape[-1]
+    tot = moc(e1v, e3v, ibmask, zv)[0]
+    sh = np.zeros_like(tot) if dmoc_sh is None else np.array(dmoc_sh, np.float64, order="C")
+    bt, ag = np.empty_like(tot), np.empty_like(tot)
+    lib.oracle_moc_decomp(C.c_int(npi), C.c_int(npj), C.c_int(npk), C.c_int(nb), _p(e1v), _p(e3v), _p(ibmask), _p(zv),
+                          _p(ztemp), _p(zsal), _p(tmask), _p(umask), _p(e1u), _p(zcoef), _p(gdept),
+                          C.c_int(1 if teos10 else 0), _p(tot), _p(sh), _p(bt), _p(ag))
+    return {"total": tot, "sh": sh, "bt": bt, "ag": ag}
+
+
 def moc(e1v, e3v, ibmask, zv):
     """e1v (npj,npi), e3v (npk,npj,npi), ibmask (npj,npi,nb) i2, zv (npt,npk,npj,npi)
     -> dmoc (npt,npk,npj,nb) r8, one oracle_moc call per record."""
