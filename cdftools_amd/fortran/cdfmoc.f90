@@ -9,7 +9,9 @@ PROGRAM cdfmoc
   !! units Sverdrup, :1006-1188).  The two hot loops (:355-379 zonal sum, :382-388 vertical cumulated
   !! sum) run on the GPU through cdft_moc_* (libcdftools_hip.so); several records are sent per call so
   !! that the time-invariant weights are read once for all of them.
-  !! -decomp and -rapid are not carried by this build: they stop with an explicit message.
+  !! -decomp (:390-517: geostrophic-shear, barotropic and ageostrophic parts) runs on the GPU as well
+  !! (cdft_moc_decomp_*), one record per call.  -rapid is not carried by this build: it stops with an
+  !! explicit message.
   !!======================================================================
   USE ISO_C_BINDING
   USE cdfio
@@ -18,7 +20,7 @@ PROGRAM cdfmoc
   USE cdftools_hip
   IMPLICIT NONE
 
-  INTEGER(KIND=4) :: narg, ijarg, ierr, ii
+  INTEGER(KIND=4) :: narg, ijarg, ierr, ii, iv
   INTEGER(KIND=4) :: npiglo, npjglo, npk, npt, nbasins, nbasinso, nvarout
   INTEGER(KIND=4) :: jt, jk, jbasin, jr, it0, nrec, nbatch, ijvar, ncout
   INTEGER(KIND=4) :: npglo = 1, npatl = 2, npinp = 3, npind = 4, nppac = 5
@@ -29,6 +31,11 @@ PROGRAM cdfmoc
   REAL(KIND=4),    ALLOCATABLE :: rdumlon(:,:), rdumlat(:,:), gdepw(:), e31d(:)
   REAL(KIND=8),    ALLOCATABLE :: dtim(:), dmoc(:,:,:,:)          ! (nbasins, npjglo, npk, nbatch)
   REAL(KIND=8) :: dl_budget
+  ! -decomp
+  INTEGER(KIND=1), ALLOCATABLE, TARGET :: itmask(:,:,:), iumask(:,:,:)   ! (npiglo, npjglo, npk) 0/1
+  REAL(KIND=4),    ALLOCATABLE :: e1u(:,:), zcoef(:,:), gdept(:), ztemp(:,:,:), zsal(:,:,:)
+  REAL(KIND=8),    ALLOCATABLE :: dmoc_sh(:,:,:), dmoc_bt(:,:,:), dmoc_ag(:,:,:)   ! (nbasins, npjglo, npk)
+  REAL(KIND=4) :: rpi, grav = 9.81, rau0 = 1025.
   CHARACTER(LEN=256) :: cf_vfil = 'none', cf_tfil = 'none', cf_sfil = 'none', cf_ufil = 'none'
   CHARACTER(LEN=256) :: cf_moc = 'moc.nc', cglobal, cldum
   TYPE(variable), ALLOCATABLE :: stypvar(:)
@@ -55,9 +62,13 @@ PROGRAM cdfmoc
      PRINT *, '       [-full ]      : full step instead of the default partial step'
      PRINT *, '       [-vvl  ]      : time-varying vertical metrics (read from V-file)'
      PRINT *, '       [-o OUT-file] : output file instead of ', TRIM(cf_moc)
-     PRINT *, '       [-decomp ], [-rapid ], [-t T-file], [-s S-file], [-u U-file], [-teos10] :'
-     PRINT *, '                       accepted for compatibility; the MOC decomposition and the RAPID'
-     PRINT *, '                       diagnostics are not available in this build.'
+     PRINT *, '       [-decomp ]    : decompose the MOC in 3 components: geostrophic shear (_sh),'
+     PRINT *, '                       barotropic (_bt) and ageostrophic (_ag); needs -t (and -s)'
+     PRINT *, '       [-t T-file]   : temperature (and salinity) file, for -decomp'
+     PRINT *, '       [-s S-file]   : salinity file if not the T-file'
+     PRINT *, '       [-teos10]     : TEOS10 equation of state instead of the default EOS80'
+     PRINT *, '       [-rapid ], [-u U-file] : accepted for compatibility; the RAPID diagnostics are'
+     PRINT *, '                       not available in this build.'
      PRINT *, '      '
      PRINT *, '     REQUIRED FILES :'
      PRINT *, '       ', TRIM(cn_fhgr), ' ', TRIM(cn_fzgr), ' and ', TRIM(cn_fmsk)
@@ -103,9 +114,10 @@ PROGRAM cdfmoc
   lchk = lchk .OR. chkfile( cn_fzgr )
   lchk = lchk .OR. chkfile( cn_fmsk )
   lchk = lchk .OR. chkfile( cf_vfil )
+  IF ( ldec ) lchk = lchk .OR. chkfile( cf_tfil ) .OR. chkfile( cf_sfil )
   IF ( lchk ) STOP 99                                     ! missing file(s)
-  IF ( ldec .OR. lrap ) THEN
-     PRINT *, ' ERROR : options -decomp and -rapid are not available in the MI355X build of cdfmoc.'
+  IF ( lrap ) THEN
+     PRINT *, ' ERROR : option -rapid is not available in the MI355X build of cdfmoc.'
      STOP 99
   ENDIF
   IF ( lg_vvl ) THEN
@@ -129,6 +141,7 @@ PROGRAM cdfmoc
   ELSE             ; nbasins = 1 ; nbasinso = 1
   ENDIF
   nvarout = nbasinso
+  IF ( ldec ) nvarout = nbasinso * 4                      ! total, _sh, _bt, _ag (src/cdfmoc.f90:276)
 
   ! records sent to the GPU per call: as many as fit a host budget (default 8 GB, CDFT_HOST_GB)
   dl_budget = 8.d0
@@ -136,6 +149,7 @@ PROGRAM cdfmoc
   IF ( LEN_TRIM(cldum) > 0 ) READ(cldum, *) dl_budget
   nbatch = MAX(1, MIN(npt, INT(dl_budget * 1.d9 / (4.d0 * npiglo * npjglo * npk))))
   IF ( lg_vvl ) nbatch = 1                                ! the metric changes with every record
+  IF ( ldec   ) nbatch = 1                                ! cdft_moc_decomp works record by record
 
   ALLOCATE( ibmask(nbasins, npiglo, npjglo), zmsk(npiglo, npjglo) )
   ALLOCATE( e1v(npiglo, npjglo), gphiv(npiglo, npjglo), e3v(npiglo, npjglo, npk) )
@@ -148,6 +162,27 @@ PROGRAM cdfmoc
   gdepw(:)   = getvare3(cn_fzgr, cn_gdepw, npk)
   gdepw(:)   = -1. * gdepw(:)
   IF ( lfull ) e31d(:) = getvare3(cn_fzgr, cn_ve3t1d, npk)
+  IF ( ldec ) THEN
+     ALLOCATE( e1u(npiglo, npjglo), zcoef(npiglo, npjglo), gdept(npk) )
+     ALLOCATE( itmask(npiglo, npjglo, npk), iumask(npiglo, npjglo, npk) )
+     ALLOCATE( ztemp(npiglo, npjglo, npk), zsal(npiglo, npjglo, npk) )
+     ALLOCATE( dmoc_sh(nbasins, npjglo, npk), dmoc_bt(nbasins, npjglo, npk), dmoc_ag(nbasins, npjglo, npk) )
+     gdept(:) = getvare3(cn_fzgr, cn_gdept, npk)
+     e1u(:,:) = getvar(cn_fhgr, cn_ve1u, 1, npiglo, npjglo)
+     ! f at V points, then -g/rau0/f, in r4 as the reference writes it (src/cdfmoc.f90:425-433)
+     rpi = ACOS( -1. )
+     zcoef(:,:) = 2*2*rpi/( 24.0 * 3600. )* SIN ( rpi * gphiv(:,:) /180.0)
+     WHERE ( zcoef /= 0 )
+        zcoef(:,:) = -grav/ rau0 / zcoef(:,:)
+     ELSEWHERE
+        zcoef(:,:) = 0.
+     END WHERE
+     DO jk = 1, npk
+        zmsk(:,:) = getvar(cn_fmsk, cn_tmask, jk, npiglo, npjglo) ; itmask(:,:,jk) = INT(zmsk, 1)
+        zmsk(:,:) = getvar(cn_fmsk, cn_umask, jk, npiglo, npjglo) ; iumask(:,:,jk) = INT(zmsk, 1)
+     END DO
+     dmoc_sh(:,:,:) = 0.d0            ! the reference never clears it: a fresh allocation (zero pages) for
+  ENDIF                               ! the first record, then each record accumulates onto the last (:471)
 
   iloc = MAXLOC(gphiv)
   rdumlat(1,:) = gphiv(iloc(1),:)
@@ -177,6 +212,24 @@ PROGRAM cdfmoc
            e3v(:,:,jk) = get_e3v(jk, it0)
         END DO
         CALL hip_check(cdft_moc_set_mesh(plan, e1v, e3v, ibmask, CDFT_MEM_HOST, C_NULL_PTR), 'cdft_moc_set_mesh')
+        IF ( ldec ) CALL hip_check(cdft_moc_decomp_set_mesh(plan, e3v, e1u, zcoef, gdept, C_LOC(itmask), C_LOC(iumask), &
+             &                     CDFT_MEM_HOST, C_NULL_PTR), 'cdft_moc_decomp_set_mesh')
+     ENDIF
+     IF ( ldec ) THEN                                     ! one record: total + the three components
+        jt = it0
+        zv(:,:,:,1)  = getvar3d(cf_vfil, cn_vomecrty, npiglo, npjglo, npk, ktime=jt)
+        ztemp(:,:,:) = getvar3d(cf_tfil, cn_votemper, npiglo, npjglo, npk, ktime=jt)
+        zsal(:,:,:)  = getvar3d(cf_sfil, cn_vosaline, npiglo, npjglo, npk, ktime=jt)
+        CALL hip_check(cdft_moc_decomp(plan, zv, ztemp, zsal, MERGE(CDFT_EOS_TEOS10, CDFT_EOS_80, ll_teos10), CDFT_MEM_HOST, &
+             &         dmoc, dmoc_sh, dmoc_bt, dmoc_ag, CDFT_MEM_HOST, C_NULL_PTR), 'cdft_moc_decomp')
+        ijvar = 1                                         ! output order of src/cdfmoc.f90:520-569
+        DO jbasin = 1, nbasins
+           CALL put4(dmoc(jbasin,:,:,1), dmoc_sh(jbasin,:,:), dmoc_bt(jbasin,:,:), dmoc_ag(jbasin,:,:))
+        END DO
+        IF ( lbas ) CALL put4(dmoc(npglo,:,:,1) - dmoc(npatl,:,:,1), dmoc_sh(npglo,:,:) - dmoc_sh(npatl,:,:), &
+             &                dmoc_bt(npglo,:,:) - dmoc_bt(npatl,:,:), dmoc_ag(npglo,:,:) - dmoc_ag(npatl,:,:))
+        it0 = it0 + 1
+        CYCLE
      ENDIF
      DO jr = 1, nrec                                      ! velocities of levels 1..npk-1 are used
         zv(:,:,:,jr) = getvar3d(cf_vfil, cn_vomecrty, npiglo, npjglo, npk, ktime=it0 + jr - 1)
@@ -206,6 +259,20 @@ PROGRAM cdfmoc
 
 CONTAINS
 
+  SUBROUTINE put4(dd_tot, dd_sh, dd_bt, dd_ag)
+    !! one basin: total, _sh, _bt, _ag, every level, as REAL() (src/cdfmoc.f90:522-545)
+    REAL(KIND=8), DIMENSION(npjglo,npk), INTENT(in) :: dd_tot, dd_sh, dd_bt, dd_ag
+    INTEGER(KIND=4) :: ik
+    DO ik = 1, npk ; ierr = putvar(ncout, id_varout(ijvar), REAL(dd_tot(:,ik)), ik, 1, npjglo, ktime=jt) ; END DO
+    ijvar = ijvar + 1
+    DO ik = 1, npk ; ierr = putvar(ncout, id_varout(ijvar), REAL(dd_sh(:,ik)), ik, 1, npjglo, ktime=jt) ; END DO
+    ijvar = ijvar + 1
+    DO ik = 1, npk ; ierr = putvar(ncout, id_varout(ijvar), REAL(dd_bt(:,ik)), ik, 1, npjglo, ktime=jt) ; END DO
+    ijvar = ijvar + 1
+    DO ik = 1, npk ; ierr = putvar(ncout, id_varout(ijvar), REAL(dd_ag(:,ik)), ik, 1, npjglo, ktime=jt) ; END DO
+    ijvar = ijvar + 1
+  END SUBROUTINE put4
+
   FUNCTION get_e3v(kk, kt)
     !! e3v at level kk (or e31d with -full) times vmask of that level (src/cdfmoc.f90:576-596)
     INTEGER(KIND=4), INTENT(in) :: kk, kt
@@ -222,7 +289,8 @@ CONTAINS
 
   SUBROUTINE CreateOutput
     !! moc.nc exactly as the reference builds it (src/cdfmoc.f90:1006-1188)
-    CHARACTER(LEN=256) :: cl_names(6), cl_long(6)
+    CHARACTER(LEN=256) :: cl_names(6), cl_long(6), cl_tag(6), cl_ag(6)
+    INTEGER(KIND=4) :: ib
     stypvar%cunits            = 'Sverdrup'
     stypvar%rmissing_value    = 99999.
     stypvar%valid_min         = -1000.
@@ -240,11 +308,19 @@ CONTAINS
     cl_long(4) = 'Meridional_Overt.Cell_Indian'
     cl_long(5) = 'Meridional_Overt.Cell_pacif'
     cl_long(6) = 'Meridional_Overt.Cell_IndPac0'
-    DO ii = 1, nvarout
-       PRINT *, 'Variable ', ii, ' is ', TRIM(cl_names(ii))
-       stypvar(ii)%cname       = TRIM(cl_names(ii))
-       stypvar(ii)%clong_name  = TRIM(cl_long(ii))
-       stypvar(ii)%cshort_name = TRIM(cl_names(ii))
+    ! long-name suffix of the decomposition variables, and the reference's spelling of the
+    ! ageostrophic one (src/cdfmoc.f90:1041, :1061: 'Ageostoph' for the global basin only)
+    cl_tag = (/ '          ', '_Atlantic ', '_IndoPacif', '_Indian   ', '_Pacif    ', '_IndPac0  ' /)
+    cl_ag(:)  = 'Ageostroph_Merid_StreamFunction'
+    cl_ag(1)  = 'Ageostoph_Merid_StreamFunction'
+    iv = 1
+    DO ib = 1, nbasinso
+       CALL setvar(TRIM(cl_names(ib)), TRIM(cl_long(ib)))
+       IF ( ldec ) THEN
+          CALL setvar(TRIM(cl_names(ib))//'_sh', 'GeoShear_Merid_StreamFunction'//TRIM(cl_tag(ib)))
+          CALL setvar(TRIM(cl_names(ib))//'_bt', 'Barotropic_Merid_StreamFunction'//TRIM(cl_tag(ib)))
+          CALL setvar(TRIM(cl_names(ib))//'_ag', TRIM(cl_ag(ib))//TRIM(cl_tag(ib)))
+       ENDIF
     END DO
     ncout = create      (cf_moc, 'none', 1, npjglo, npk, cdep=cn_vdepthw)
     ierr  = createvar   (ncout, stypvar, nvarout, ipk, id_varout, cdglobal=TRIM(cglobal))
@@ -252,5 +328,15 @@ CONTAINS
     dtim  = getvar1d    (cf_vfil, cn_vtimec, npt)
     ierr  = putvar1d    (ncout, dtim, npt, 'T')
   END SUBROUTINE CreateOutput
+
+  SUBROUTINE setvar(cd_name, cd_long)
+    !! next output variable (iv is the program's variable counter)
+    CHARACTER(LEN=*), INTENT(in) :: cd_name, cd_long
+    PRINT *, 'Variable ', iv, ' is ', cd_name
+    stypvar(iv)%cname       = cd_name
+    stypvar(iv)%clong_name  = cd_long
+    stypvar(iv)%cshort_name = cd_name
+    iv = iv + 1
+  END SUBROUTINE setvar
 
 END PROGRAM cdfmoc

@@ -37,6 +37,17 @@ MODULE cdftools_hip
        INTEGER(C_INT64_T), VALUE :: rec_stride ; INTEGER(C_INT), VALUE :: npt, zv_space, dmoc_space
        REAL(C_DOUBLE), INTENT(out) :: dmoc(*)
      END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_moc_decomp_set_mesh(plan, e3v, e1u, zcoef, gdept, tmask, umask, memspace, stream) &
+          &         BIND(C, name='cdft_moc_decomp_set_mesh')
+       IMPORT ; TYPE(C_PTR), VALUE :: plan, stream, tmask, umask
+       REAL(C_FLOAT), INTENT(in) :: e3v(*), e1u(*), zcoef(*), gdept(*) ; INTEGER(C_INT), VALUE :: memspace
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_moc_decomp(plan, zv, ztemp, zsal, eos, in_space, dmoc, dmoc_sh, dmoc_bt, dmoc_ag, &
+          &                                  out_space, stream) BIND(C, name='cdft_moc_decomp')
+       IMPORT ; TYPE(C_PTR), VALUE :: plan, stream ; REAL(C_FLOAT), INTENT(in) :: zv(*), ztemp(*), zsal(*)
+       INTEGER(C_INT), VALUE :: eos, in_space, out_space
+       REAL(C_DOUBLE), INTENT(inout) :: dmoc(*), dmoc_sh(*), dmoc_bt(*), dmoc_ag(*)
+     END FUNCTION
      INTEGER(C_INT) FUNCTION cdft_moc_destroy(plan) BIND(C, name='cdft_moc_destroy')
        IMPORT ; TYPE(C_PTR), VALUE :: plan
      END FUNCTION

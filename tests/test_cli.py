@@ -90,3 +90,42 @@ def test_cdfmoc_end_to_end(tools, tmp_path, basins):
     assert rc == 0
     var2, _, _ = read_nc(os.path.join(tmp_path, "moc2.nc"))
     assert all(np.array_equal(var[k], var2[k]) for k in var)
+
+
+@pytest.mark.gpu
+def test_cdfmoc_decomp_end_to_end(tools, tmp_path):
+    """cdfmoc -v V -t T -decomp: 4 variables per basin (total, _sh, _bt, _ag), 24 in all, in the
+    reference's order; record 2 accumulates its shear part onto record 1's (src/cdfmoc.f90:471)."""
+    from test_moc_decomp import decomp_inputs
+
+    g, rec = nemo_files.make_case(str(tmp_path))
+    npk, npj, npi = g["tmask"].shape
+    rc, out, err = run("cdfmoc", ["-v", "SYN_y0001_gridV.nc", "-t", "SYN_y0001_gridT.nc", "-decomp", "-o", "dec.nc"], tmp_path)
+    assert rc == 0, out + err
+    assert "Variable            2  is zomsfglo_sh".replace(" ", "") in out.replace(" ", "")
+    var, att, dims = read_nc(os.path.join(tmp_path, "dec.nc"))
+    names = [n for n in var if n.startswith("zomsf")]
+    assert len(names) == 24
+    assert att["zomsfglo_ag"]["long_name"] == b"Ageostoph_Merid_StreamFunction"        # the reference's spelling
+    assert att["zomsfatl_ag"]["long_name"] == b"Ageostroph_Merid_StreamFunction_Atlantic"
+    a = decomp_inputs(npi, npj, npk, 5, seed=1)                          # only for zcoef: same gphiv for every seed
+    e1v, e3v, ib = synth.moc_inputs(g, nbasins=5)
+    sh = None
+    for t in range(2):
+        ref = oracle_lib.moc_decomp(e1v, e3v, ib, rec["v"][t], rec["t"][t], rec["s"][t], g["tmask"].astype(np.uint8),
+                                    g["umask"].astype(np.uint8), g["e1u"], a["zcoef"], g["gdept_1d"], dmoc_sh=sh)
+        sh = ref["sh"]
+        for b, nm in enumerate(["zomsfglo", "zomsfatl", "zomsfinp", "zomsfind", "zomsfpac"]):
+            for suffix, key in (("", "total"), ("_sh", "sh"), ("_bt", "bt"), ("_ag", "ag")):
+                got = var[nm + suffix][t, :, :, 0]
+                want = ref[key][..., b]
+                tol = 2e-6 * np.abs(ref[key]).max() + 1e-30             # r4 store + the host's own r4 SIN in zcoef
+                assert np.all(np.abs(got - want) <= tol), (nm + suffix, t)
+        want = ref["sh"][..., 0] - ref["sh"][..., 1]
+        assert np.all(np.abs(var["zomsfinp0_sh"][t, :, :, 0] - want) <= 2e-6 * np.abs(ref["sh"]).max() + 1e-30)
+    assert np.abs(var["zomsfglo_sh"]).max() > 0 and np.abs(var["zomsfglo_bt"]).max() > 0
+    # missing T file -> the reference's message and STOP 99
+    rc, out, _ = run("cdfmoc", ["-v", "SYN_y0001_gridV.nc", "-t", "nothere.nc", "-decomp"], tmp_path)
+    assert rc == 99 and "nothere.nc is missing" in out
+    rc, out, _ = run("cdfmoc", ["-v", "SYN_y0001_gridV.nc", "-rapid"], tmp_path)
+    assert rc == 99 and "-rapid" in out
