@@ -137,17 +137,35 @@ def main():
     del e3v
     torch.cuda.empty_cache()
 
-    dmoc = torch.empty((npt, npk, nloc, nb), dtype=torch.float64, device=device)
+    # Two result buffers: the gather of step i (RCCL, communication stream) overlaps the kernels of
+    # step i+1; a buffer is reused only after its gather has been waited for and assembled.
+    nbuf = 2 if world > 1 else 1
+    dmoc = [torch.empty((npt, npk, nloc, nb), dtype=torch.float64, device=device) for _ in range(nbuf)]
     nmax = shard.max_rows(npj, world)
-    pad = torch.zeros((npt, npk, nmax, nb), dtype=torch.float64, device=device) if world > 1 else None
-    recv = [torch.empty((npt, npk, nmax, nb), dtype=torch.float64, device=device) for _ in range(world)] \
-        if (world > 1 and rank == 0) else None
+    pad = [torch.zeros((npt, npk, nmax, nb), dtype=torch.float64, device=device) if world > 1 else None for _ in range(nbuf)]
+    recv = [[torch.empty((npt, npk, nmax, nb), dtype=torch.float64, device=device) for _ in range(world)]
+            if (world > 1 and rank == 0) else None for _ in range(nbuf)]
+    pending = [None] * nbuf
+    state = {"i": 0, "result": None}
 
     def step():
-        plan.compute(zv, out=dmoc)
+        b = state["i"] % nbuf
+        state["i"] += 1
+        if pending[b] is not None:                            # step i-2: gathered -> assembled on rank 0
+            state["result"] = shard.gather_rows_finish(pending[b])
+            pending[b] = None
+        plan.compute(zv, out=dmoc[b])
         if world > 1:
-            return shard.gather_rows(dmoc, npj, pad_buf=pad, recv_bufs=recv)
-        return dmoc
+            pending[b] = shard.gather_rows_start(dmoc[b], npj, pad_buf=pad[b], recv_bufs=recv[b])
+        else:
+            state["result"] = dmoc[b]
+
+    def drain():
+        order = [(state["i"] + k) % nbuf for k in range(nbuf)]    # oldest first
+        for b in order:
+            if pending[b] is not None:
+                state["result"] = shard.gather_rows_finish(pending[b])
+                pending[b] = None
 
     def fence():
         torch.cuda.synchronize()
@@ -157,13 +175,16 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    drain()
     fence()
     plan.profile_enable(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        result = step()
+        step()
+    drain()                                                   # every step's result is gathered and assembled
     fence()
     elapsed = time.perf_counter() - t0
+    result = state["result"]
     plan.profile_enable(False)
     zonal_ms, launches = plan.profile_read()
     if world > 1:

@@ -39,12 +39,14 @@ def max_rows(npjglo: int, world: int) -> int:
     return -(-npjglo // world)
 
 
-def gather_rows(local: torch.Tensor, npjglo: int, group=None, dst: int = 0, pad_buf=None, recv_bufs=None):
-    """Collect per-rank results (npt,npk,npj_loc,nb) on rank `dst` -> (npt,npk,npjglo,nb) there,
-    None elsewhere.  Blocks are padded to the largest block so that one gather moves them all."""
+def gather_rows_start(local: torch.Tensor, npjglo: int, group=None, dst: int = 0, pad_buf=None, recv_bufs=None):
+    """Start collecting per-rank results (npt,npk,npj_loc,nb) on rank `dst` without blocking: the
+    gather runs on the communication stream while the caller computes the next step.  Blocks are
+    padded to the largest block so that one gather moves them all.  -> handle for gather_rows_finish.
+    The buffers (local, pad_buf, recv_bufs) must not be touched until gather_rows_finish returned."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
-        return local
+        return (None, local, None, npjglo, world, dst)
     rank = dist.get_rank(group)
     npt, npk, nloc, nb = local.shape
     j0, j1 = row_block(npjglo, world, rank)
@@ -56,16 +58,33 @@ def gather_rows(local: torch.Tensor, npjglo: int, group=None, dst: int = 0, pad_
     else:
         send = pad_buf if pad_buf is not None else local.new_zeros((npt, npk, nmax, nb))
         send[:, :, :nloc] = local
+    bufs = None
     if rank == dst:
         bufs = recv_bufs if recv_bufs is not None else [torch.empty_like(send) for _ in range(world)]
-        dist.gather(send, bufs, dst=dst, group=group)
-        out = local.new_empty((npt, npk, npjglo, nb))
-        for r in range(world):
-            a, b = row_block(npjglo, world, r)
-            out[:, :, a:b] = bufs[r][:, :, : b - a]
-        return out
-    dist.gather(send, None, dst=dst, group=group)
-    return None
+    work = dist.gather(send, bufs, dst=dst, group=group, async_op=True)
+    return (work, local, bufs, npjglo, world, dst, send)
+
+
+def gather_rows_finish(handle):
+    """Wait for a gather started by gather_rows_start; -> (npt,npk,npjglo,nb) on rank dst, None elsewhere."""
+    work, local, bufs, npjglo, world, dst = handle[:6]
+    if world == 1:
+        return local
+    work.wait()                                   # the current stream now waits for the gather
+    if bufs is None:
+        return None
+    npt, npk, _, nb = local.shape
+    out = local.new_empty((npt, npk, npjglo, nb))
+    for r in range(world):
+        a, b = row_block(npjglo, world, r)
+        out[:, :, a:b] = bufs[r][:, :, : b - a]
+    return out
+
+
+def gather_rows(local: torch.Tensor, npjglo: int, group=None, dst: int = 0, pad_buf=None, recv_bufs=None):
+    """Collect per-rank results (npt,npk,npj_loc,nb) on rank `dst` -> (npt,npk,npjglo,nb) there,
+    None elsewhere (gather_rows_start + gather_rows_finish)."""
+    return gather_rows_finish(gather_rows_start(local, npjglo, group=group, dst=dst, pad_buf=pad_buf, recv_bufs=recv_bufs))
 
 
 def halo_window(npjglo: int, world: int, rank: int, north: int = 1, south: int = 0):

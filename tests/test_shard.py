@@ -48,11 +48,17 @@ def _worker(rank, world, port, npi, npj, npk, nb, npt, q):
         j0, j1 = shard.row_block(npj, world, rank)
         loc = oracle_lib.moc(e1v[j0:j1], e3v[:, j0:j1], ib[j0:j1], zv[:, :, j0:j1])
         full = shard.gather_rows(torch.from_numpy(loc), npj)
+        # two gathers in flight (bench.py overlaps the gather of step i with the kernels of step i+1)
+        t1, t2 = torch.from_numpy(loc), torch.from_numpy(loc) * 2.0
+        h1 = shard.gather_rows_start(t1, npj)
+        h2 = shard.gather_rows_start(t2, npj)
+        f1, f2 = shard.gather_rows_finish(h1), shard.gather_rows_finish(h2)
         if rank == 0:
             ref = oracle_lib.moc(e1v, e3v, ib, zv)
-            q.put(bool(np.array_equal(full.numpy(), ref)))
+            q.put(bool(np.array_equal(full.numpy(), ref) and np.array_equal(f1.numpy(), ref)
+                       and np.array_equal(f2.numpy(), 2.0 * ref)))
         else:
-            assert full is None
+            assert full is None and f1 is None and f2 is None
     finally:
         dist.destroy_process_group()
 
