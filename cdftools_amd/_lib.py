@@ -71,6 +71,7 @@ SIGNATURES = {
     "cdft_psi_compute": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _vp]),
     "cdft_psi_integrate": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "cdft_psi_scan_u": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp]),
+    "cdft_psi_scan_open": (_i, [_vp, _i, _vp]),
     "cdft_psi_value": (_i, [_vp, _i, _i, C.POINTER(C.c_double), _vp]),
     "cdft_psi_finish": (_i, [_vp, _i, C.c_double, _i, _i, _vp, _i, _vp, _vp, _i, _vp]),
     "cdft_psi_destroy": (_i, [_vp]),

@@ -298,6 +298,52 @@ __global__ void psi_final_kernel(const double *__restrict__ du, const double *__
     psi4[p] = fmask ? __fmul_rn((float)d, fmask[p]) : (float)d;
 }
 
+// cdfpsi -open, src/cdfpsi.f90:335-356: psi started from a line inside the domain.
+// line kernels: one thread walks the starting line (npi or npj sequential additions).
+__global__ void psi_open_line_u_kernel(const double *__restrict__ dtrpv, double *__restrict__ dpsiu, int npi, int J) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    double acc = dtrpv[(int64_t)J * npi];                    // dpsiu(1,J) = dtrpv(1,J)
+    dpsiu[(int64_t)J * npi] = acc;
+    for (int i = 1; i < npi; ++i) {
+        acc = __dadd_rn(acc, dtrpv[(int64_t)J * npi + i]);   // dpsiu(ji,J) = dpsiu(ji-1,J) + dtrpv(ji,J)
+        dpsiu[(int64_t)J * npi + i] = acc;
+    }
+}
+// southwards from row J: dpsiu(ji,jj) = dpsiu(ji,jj+1) + dtrpu(ji,jj+1); rows north of J are 0 (:259)
+__global__ void psi_open_march_u_kernel(const double *__restrict__ dtrpu, double *__restrict__ dpsiu, int npi, int npj, int J) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npi) return;
+    for (int j = npj - 1; j > J; --j) dpsiu[(int64_t)j * npi + i] = 0.0;
+    double acc = dpsiu[(int64_t)J * npi + i];
+    for (int j = J - 1; j >= 0; --j) {
+        acc = __dadd_rn(acc, dtrpu[(int64_t)(j + 1) * npi + i]);
+        dpsiu[(int64_t)j * npi + i] = acc;
+    }
+}
+// the other estimate (-mean): column I from the north, dpsiv(I,npj) = dtrpu(I,npj), then + dtrpu(I,jj+1)
+__global__ void psi_open_line_v_kernel(const double *__restrict__ dtrpu, double *__restrict__ dpsiv, int npi, int npj, int I) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    double acc = dtrpu[(int64_t)(npj - 1) * npi + I];
+    dpsiv[(int64_t)(npj - 1) * npi + I] = acc;
+    for (int j = npj - 2; j >= 0; --j) {
+        acc = __dadd_rn(acc, dtrpu[(int64_t)(j + 1) * npi + I]);
+        dpsiv[(int64_t)j * npi + I] = acc;
+    }
+}
+// westwards from column I: dpsiv(ji,jj) = dpsiv(ji+1,jj) - dtrpv(ji+1,jj); columns east of I are 0
+__global__ void psi_open_march_v_kernel(const double *__restrict__ dtrpv, double *__restrict__ dpsiv, int npi, int npj, int I) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= npj) return;
+    double *row = dpsiv + (int64_t)j * npi;
+    const double *tr = dtrpv + (int64_t)j * npi;
+    for (int i = npi - 1; i > I; --i) row[i] = 0.0;
+    double acc = row[I];
+    for (int i = I - 1; i >= 0; --i) {
+        acc = __dadd_rn(acc, -tr[i + 1]);
+        row[i] = acc;
+    }
+}
+
 int dmalloc(void **p, size_t bytes) {
     if (hipMalloc(p, bytes + 64) != hipSuccess) {
         (void)hipGetLastError();
@@ -432,6 +478,7 @@ struct cdft_psi_plan {
     double *dtrpu = nullptr, *dtrpv = nullptr, *dpsiu = nullptr, *dpsiv = nullptr, *d8 = nullptr;
     float *p4 = nullptr;
     bool lu = false, lv = false;                       // what the last cdft_psi_integrate filled
+    bool use_u = false, use_v = false;                 // which estimates cdft_psi_finish combines
     DevBuf su, se3u, sv, se3v, sm0, sm1, sfm, s1d, scar;
 };
 
@@ -488,6 +535,7 @@ int cdft_psi_integrate(cdft_psi_plan *p, const float *zu, const float *e2u, cons
     }
     if (lu) CDFT_TRY(integrate(zu, e2u, e3u, p->su, p->se3u, p->sm0, p->dtrpu));
     p->lu = lu; p->lv = lv;
+    p->use_u = lu; p->use_v = lv;
     return CDFT_OK;
 }
 
@@ -510,6 +558,24 @@ int cdft_psi_scan_u(cdft_psi_plan *p, const double *carry, int carry_space, int 
     return CDFT_OK;
 }
 
+int cdft_psi_scan_open(cdft_psi_plan *p, int lmean, void *stream) {
+    if (!p) return fail(CDFT_ERR_ARG, "cdft_psi_scan_open: NULL plan");
+    if (!p->lu || !p->lv) return fail(CDFT_ERR_STATE, "cdft_psi_scan_open: -open needs both transports (cdft_psi_integrate with U and V)");
+    if (p->npi < 3 || p->npj < 3) return fail(CDFT_ERR_ARG, "cdft_psi_scan_open: npiglo, npjglo >= 3 required");
+    hipStream_t st = as_stream(stream);
+    const int J = p->npj - 3, I = p->npi - 3;               // row npjglo-2 / column npiglo-2, 0-based
+    hipLaunchKernelGGL(psi_open_line_u_kernel, dim3(1), dim3(64), 0, st, p->dtrpv, p->dpsiu, p->npi, J);
+    hipLaunchKernelGGL(psi_open_march_u_kernel, dim3((p->npi + 63) / 64), dim3(64), 0, st, p->dtrpu, p->dpsiu, p->npi, p->npj, J);
+    CDFT_LAUNCH_CHECK();
+    if (lmean) {
+        hipLaunchKernelGGL(psi_open_line_v_kernel, dim3(1), dim3(64), 0, st, p->dtrpu, p->dpsiv, p->npi, p->npj, I);
+        hipLaunchKernelGGL(psi_open_march_v_kernel, dim3((p->npj + 63) / 64), dim3(64), 0, st, p->dtrpv, p->dpsiv, p->npi, p->npj, I);
+        CDFT_LAUNCH_CHECK();
+    }
+    p->use_u = true; p->use_v = lmean != 0;
+    return CDFT_OK;
+}
+
 int cdft_psi_value(cdft_psi_plan *p, int ii, int ij, double *value, void *stream) {
     if (!p || !value) return fail(CDFT_ERR_ARG, "cdft_psi_value: NULL argument");
     if (ii < 1 || ii > p->npi || ij < 1 || ij > p->npj)
@@ -517,10 +583,10 @@ int cdft_psi_value(cdft_psi_plan *p, int ii, int ij, double *value, void *stream
     hipStream_t st = as_stream(stream);
     const int64_t q = (int64_t)(ij - 1) * p->npi + (ii - 1);
     double u = 0.0, v = 0.0;
-    if (p->lu) CDFT_HIP(hipMemcpyAsync(&u, p->dpsiu + q, 8, hipMemcpyDeviceToHost, st));
-    if (p->lv) CDFT_HIP(hipMemcpyAsync(&v, p->dpsiv + q, 8, hipMemcpyDeviceToHost, st));
+    if (p->use_u) CDFT_HIP(hipMemcpyAsync(&u, p->dpsiu + q, 8, hipMemcpyDeviceToHost, st));
+    if (p->use_v) CDFT_HIP(hipMemcpyAsync(&v, p->dpsiv + q, 8, hipMemcpyDeviceToHost, st));
     CDFT_HIP(hipStreamSynchronize(st));
-    *value = (p->lu && p->lv) ? 0.5 * (u + v) : (p->lu ? u : v);    // as psi_final_kernel's val()
+    *value = (p->use_u && p->use_v) ? 0.5 * (u + v) : (p->use_u ? u : v);    // as psi_final_kernel's val()
     return CDFT_OK;
 }
 
@@ -539,7 +605,7 @@ int cdft_psi_finish(cdft_psi_plan *p, int use_ref, double ref_value, int iiref, 
     double *o8 = dpsi8 ? (out_space == CDFT_MEM_DEVICE ? dpsi8 : p->d8) : nullptr;
     const int64_t pref = use_ref ? 0 : (int64_t)(ijref - 1) * p->npi + (iiref - 1);
     hipLaunchKernelGGL(psi_final_kernel, dim3((unsigned)((nij + 255) / 256)), dim3(256), 0, st,
-                       p->lu ? p->dpsiu : nullptr, p->lv ? p->dpsiv : nullptr, nij, pref, use_ref ? 1 : 0, ref_value,
+                       p->use_u ? p->dpsiu : nullptr, p->use_v ? p->dpsiv : nullptr, nij, pref, use_ref ? 1 : 0, ref_value,
                        (const float *)dfm, o4, o8);
     CDFT_LAUNCH_CHECK();
     if (out_space == CDFT_MEM_HOST) {

@@ -7,7 +7,8 @@ PROGRAM cdfcurl
   !! -T, -8, -surf, -overf, -nometric, -nc4, -o), same curl.nc (socurl | socurlt | socurloverf, float or
   !! double, :395-438).  The level loop :242-304 runs on the GPU for all selected levels of a record at
   !! once (cdft_curl_*, bit-identical to the reference's r4 expression).
-  !! Not carried: level 0 (forcing fields on the A grid, :250-258) stops with an explicit message.
+  !! Level 0 (forcing fields on the A grid, :250-258): the 2-point averages to U / V points are host work,
+  !! the curl itself is the same kernel.
   !!======================================================================
   USE ISO_C_BINDING
   USE cdfio
@@ -15,7 +16,7 @@ PROGRAM cdfcurl
   USE cdftools_hip
   IMPLICIT NONE
 
-  INTEGER(KIND=4) :: narg, ijarg, ierr, jt, jk, npiglo, npjglo, npk, npt, nlev = 0, ncout
+  INTEGER(KIND=4) :: narg, ijarg, ierr, jt, jk, ji, jj, npiglo, npjglo, npk, npt, nlev = 0, ncout
   INTEGER(KIND=4) :: ipk(1), id_varout(1)
   INTEGER(KIND=4), ALLOCATABLE :: nilev(:)
   REAL(KIND=4), ALLOCATABLE :: e1u(:,:), e1f(:,:), e2v(:,:), e2f(:,:), zlon(:,:), zlat(:,:)
@@ -28,7 +29,7 @@ PROGRAM cdfcurl
   TYPE(variable) :: stypvar(1)
   TYPE(C_PTR) :: plan, pff
   LOGICAL :: lchk = .FALSE., lperio = .FALSE., ldblpr = .FALSE., lnc4 = .FALSE., ltpoint = .FALSE., lsurf = .FALSE.
-  LOGICAL :: loverf = .FALSE., l_metric = .TRUE.
+  LOGICAL :: loverf = .FALSE., l_metric = .TRUE., lforcing = .FALSE.
   !!----------------------------------------------------------------------
   CALL ReadCdfNames()
   narg = COMMAND_ARGUMENT_COUNT()
@@ -119,9 +120,10 @@ PROGRAM cdfcurl
   IF ( .NOT. ALLOCATED(nilev) ) THEN
      PRINT *, ' ERROR : option -l levlist is mandatory.' ; STOP 99
   ENDIF
-  IF ( nilev(1) == 0 ) THEN
-     PRINT *, ' ERROR : level 0 (forcing fields on the A grid) is not available in the MI355X build of cdfcurl.'
-     STOP 99
+  IF ( nilev(1) == 0 ) THEN                                  ! forcing fields (A grid, no depth), :170-174
+     lforcing = .TRUE.
+     npk = 1 ; nilev(1) = 1
+     PRINT *, 'npk =0, assume 1'
   ENDIF
   IF ( npt == 0 ) THEN
      PRINT *, 'npt=0, assume 1'
@@ -158,7 +160,7 @@ PROGRAM cdfcurl
      dl_ff = 2 * dl_omega * SIN( zlat * dl_pi / 180.d0 )
      pff = C_LOC(dl_ff)
   ENDIF
-  IF ( lsurf ) THEN
+  IF ( lforcing .OR. lsurf ) THEN
      gdep(1) = 0.
   ELSE
      zdep(:) = getvar1d(cf_ufil, cn_vdepthu, npk)
@@ -179,6 +181,14 @@ PROGRAM cdfcurl
         PRINT *, TRIM(cf_ufil), ' ', TRIM(cv_u), ' ', jk, nilev(jk), npiglo, npjglo, jt
         un(:,:,jk) = getvar(cf_ufil, cv_u, nilev(jk), npiglo, npjglo, ktime=jt)
         vn(:,:,jk) = getvar(cf_vfil, cv_v, nilev(jk), npiglo, npjglo, ktime=jt)
+        IF ( lforcing ) THEN                                 ! A grid -> U and V points (:250-258); the last
+           DO ji = 1, npiglo - 1                             ! column of un / row of vn is not used by the stencil
+              un(ji,:,jk) = 0.5*( un(ji,:,jk) + un(ji+1,:,jk) )
+           END DO
+           DO jj = 1, npjglo - 1
+              vn(:,jj,jk) = 0.5*( vn(:,jj,jk) + vn(:,jj+1,jk) )
+           END DO
+        ENDIF
      END DO
      IF ( ldblpr ) THEN
         CALL hip_check(cdft_curl_compute(plan, un, vn, nlev, CDFT_MEM_HOST, MERGE(1_C_INT, 0_C_INT, ltpoint),        &

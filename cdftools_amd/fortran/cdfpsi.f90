@@ -8,7 +8,9 @@ PROGRAM cdfpsi
   !! vertical integration (:271-298), the integration along j or i (:377-402), -mean, the reference point
   !! and the SNGL/mask at output (:412-438) run on the GPU (cdft_psi_*, bit-identical: every sum keeps the
   !! reference's sequential order).
-  !! Not carried: -open, --ssh-file and -lev stop with an explicit message.
+  !! -open (:316-366, psi started from a line inside the domain), --ssh-file (:260-267, :280, :299: the SSH
+  !! contribution, same scans on other operands) and -lev (:282-307: one psi per level) use the staged
+  !! entry points cdft_psi_integrate / _scan_u / _scan_open / _finish, the last two with a 1-level plan.
   !!======================================================================
   USE ISO_C_BINDING
   USE cdfio
@@ -18,13 +20,16 @@ PROGRAM cdfpsi
   IMPLICIT NONE
 
   INTEGER(KIND=4) :: narg, ijarg, ierr, jt, jk, it, npiglo, npjglo, npk, npt, ncout, iiref = -1, ijref = -1
-  INTEGER(KIND=4) :: ipk(1), id_varout(1)
+  INTEGER(KIND=4) :: ipk(3), id_varout(3), nvout = 1
   REAL(KIND=4), ALLOCATABLE, TARGET :: zu(:,:,:), zv(:,:,:), e3u(:,:,:), e3v(:,:,:), e1v(:,:), e2u(:,:), zmask(:,:), e31d(:)
   REAL(KIND=4), ALLOCATABLE :: glamf(:,:), gphif(:,:), zpsi(:,:)
+  REAL(KIND=4), ALLOCATABLE, TARGET :: zssh(:,:), zsshu(:,:), zsshv(:,:), zvel1(:,:), zlev(:,:), ze3(:,:)
+  REAL(KIND=8), ALLOCATABLE, TARGET :: dpsi(:,:), dpsissh(:,:)
   REAL(KIND=8), ALLOCATABLE :: dtim(:)
   CHARACTER(LEN=256) :: cf_ufil = 'none', cf_vfil = 'none', cf_out = 'psi.nc', cv_out = 'sobarstf', cglobal, cldum
-  TYPE(variable) :: stypvar(1)
-  TYPE(C_PTR) :: plan, pzu, pe2u, pe3u, pzv, pe1v, pe3v, pe31d, pmask
+  CHARACTER(LEN=256) :: cf_sshfil = 'none', cv_outssh = 'sobarstfssh', cv_outotal = 'sobarstftotal'
+  TYPE(variable) :: stypvar(3)
+  TYPE(C_PTR) :: plan, plan1, pzu, pe2u, pe3u, pzv, pe1v, pe3v, pe31d, pmask, pdpsi
   LOGICAL :: lchk = .FALSE., lfull = .FALSE., lmask = .FALSE., lmean = .FALSE., lopen = .FALSE., lssh = .FALSE.
   LOGICAL :: llev = .FALSE., lnc4 = .FALSE., ll_u = .TRUE., ll_v = .FALSE.
   !!----------------------------------------------------------------------
@@ -52,7 +57,9 @@ PROGRAM cdfpsi
      PRINT *, '       [-vvl ]    : time-varying vertical metrics'
      PRINT *, '       [-nc4 ]    : accepted; the bundled NetCDF backend writes classic files'
      PRINT *, '       [-o OUT-file] : output file instead of ', TRIM(cf_out)
-     PRINT *, '       [-open ] [--ssh-file SSH-file] [-lev] : accepted for compatibility, not available in this build'
+     PRINT *, '       [-open ]   : open domain: psi is built from the row npjglo-2 (implies both components)'
+     PRINT *, '       [--ssh-file SSH-file] : add the contribution of the SSH (2 more variables)'
+     PRINT *, '       [-lev ]    : psi of each level instead of the vertical integral (variable vobarstf)'
      PRINT *, '      '
      PRINT *, '     REQUIRED FILES :'
      PRINT *, '       ', TRIM(cn_fhgr), ' and ', TRIM(cn_fzgr), ' (', TRIM(cn_fmsk), ' with -mask)'
@@ -74,14 +81,15 @@ PROGRAM cdfpsi
      CASE ( '-full'      ) ; lfull = .TRUE.
      CASE ( '-mask'      ) ; lmask = .TRUE.
      CASE ( '-mean'      ) ; lmean = .TRUE. ; ll_v = .TRUE. ; ll_u = .TRUE.
-     CASE ( '--ssh-file' ) ; lssh  = .TRUE. ; ijarg = ijarg + 1
-     CASE ( '-open'      ) ; lopen = .TRUE.
+     CASE ( '--ssh-file' ) ; lssh  = .TRUE. ; nvout = 3
+        ;                    CALL GET_COMMAND_ARGUMENT(ijarg, cf_sshfil) ; ijarg = ijarg + 1
+     CASE ( '-open'      ) ; lopen = .TRUE. ; ll_v = .TRUE. ; ll_u = .TRUE.
      CASE ( '-o'         ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cf_out) ; ijarg = ijarg + 1
      CASE ( '-nc4'       ) ; lnc4  = .TRUE.
      CASE ( '-ref'       ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cldum) ; ijarg = ijarg + 1 ; READ(cldum, *) iiref
         ;                    CALL GET_COMMAND_ARGUMENT(ijarg, cldum) ; ijarg = ijarg + 1 ; READ(cldum, *) ijref
      CASE ( '-vvl'       ) ; lg_vvl = .TRUE.
-     CASE ( '-lev'       ) ; llev  = .TRUE.
+     CASE ( '-lev'       ) ; llev  = .TRUE. ; cv_out = 'vobarstf'
      CASE DEFAULT          ; PRINT *, ' ERROR : ', TRIM(cldum), ' : unknown option.' ; STOP 99
      END SELECT
   END DO
@@ -91,10 +99,19 @@ PROGRAM cdfpsi
   IF ( lmask ) lchk = lchk .OR. chkfile(cn_fmsk)
   lchk = lchk .OR. chkfile(cf_ufil)
   lchk = lchk .OR. chkfile(cf_vfil)
+  IF ( lssh ) lchk = lchk .OR. chkfile(cf_sshfil)
   IF ( lchk ) STOP 99
-  IF ( lopen .OR. lssh .OR. llev ) THEN
-     PRINT *, ' ERROR : options -open, --ssh-file and -lev are not available in the MI355X build of cdfpsi.'
-     STOP 99
+  IF ( llev .AND. lopen ) THEN
+     PRINT *, ' +++ error : cannot use both -lev and -open options.' ; STOP 99
+  ENDIF
+  IF ( llev .AND. lssh ) THEN
+     PRINT *, ' +++ error : cannot use both -lev and -ssh options.' ; STOP 99
+  ENDIF
+  IF ( llev .AND. lmean ) THEN
+     PRINT *, ' +++ error : cannot use both -lev and -mean options.' ; STOP 99
+  ENDIF
+  IF ( llev .AND. lmask ) THEN
+     PRINT *, ' +++ error : cannot use both -lev and -mask options.' ; STOP 99
   ENDIF
   IF ( lg_vvl ) THEN
      cn_fe3u = cf_ufil ; cn_fe3v = cf_vfil
@@ -129,10 +146,10 @@ PROGRAM cdfpsi
 
   ALLOCATE( glamf(npiglo,npjglo), gphif(npiglo,npjglo), zpsi(npiglo,npjglo), dtim(npt) )
   ALLOCATE( e1v(npiglo,npjglo), e2u(npiglo,npjglo) )
-  IF ( ll_u ) ALLOCATE( zu(npiglo,npjglo,npk) )
-  IF ( ll_v ) ALLOCATE( zv(npiglo,npjglo,npk) )
+  IF ( ll_u .AND. .NOT. llev ) ALLOCATE( zu(npiglo,npjglo,npk) )      ! -lev works level by level
+  IF ( ll_v .AND. .NOT. llev ) ALLOCATE( zv(npiglo,npjglo,npk) )
   IF ( lfull ) THEN ; ALLOCATE( e31d(npk) )
-  ELSE
+  ELSE IF ( .NOT. llev ) THEN
      IF ( ll_u ) ALLOCATE( e3u(npiglo,npjglo,npk) )
      IF ( ll_v ) ALLOCATE( e3v(npiglo,npjglo,npk) )
   ENDIF
@@ -156,8 +173,23 @@ PROGRAM cdfpsi
   ENDIF
 
   CALL hip_check(cdft_psi_create(plan, npiglo, npjglo, npk), 'cdft_psi_create')
+  IF ( lssh .OR. llev ) CALL hip_check(cdft_psi_create(plan1, npiglo, npjglo, 1), 'cdft_psi_create')
+  IF ( lssh ) THEN
+     ALLOCATE( zssh(npiglo,npjglo), zsshu(npiglo,npjglo), zsshv(npiglo,npjglo), zvel1(npiglo,npjglo) )
+     ALLOCATE( dpsi(npiglo,npjglo), dpsissh(npiglo,npjglo) )
+  ENDIF
+  IF ( llev ) ALLOCATE( zlev(npiglo,npjglo), ze3(npiglo,npjglo) )
   DO jt = 1, npt
      it = 1 ; IF ( lg_vvl ) it = jt
+     IF ( llev ) THEN                                     ! src/cdfpsi.f90:282-315: one psi per level, first record only
+        DO jk = 1, npk
+           IF ( ll_v ) CALL level_psi(cf_vfil, cn_vomecrty, cn_fe3v, cn_ve3v, .FALSE.)
+           IF ( ll_u ) CALL level_psi(cf_ufil, cn_vozocrtx, cn_fe3u, cn_ve3u, .TRUE. )
+        END DO
+        ierr = closeout(ncout)
+        PRINT *, ' cdfpsi_level completed.'
+        STOP 0
+     ENDIF
      pzu = C_NULL_PTR ; pe2u = C_NULL_PTR ; pe3u = C_NULL_PTR ; pzv = C_NULL_PTR ; pe1v = C_NULL_PTR ; pe3v = C_NULL_PTR
      IF ( ll_v ) THEN
         zv = getvar3d(cf_vfil, cn_vomecrty, npiglo, npjglo, npk, ktime=jt)
@@ -183,33 +215,109 @@ PROGRAM cdfpsi
            pe3u = C_LOC(e3u)
         ENDIF
      ENDIF
-     CALL hip_check(cdft_psi_compute(plan, pzu, pe2u, pe3u, pzv, pe1v, pe3v, pe31d, INT(iiref, C_INT), INT(ijref, C_INT), &
-          &         pmask, CDFT_MEM_HOST, zpsi, C_NULL_PTR, CDFT_MEM_HOST, C_NULL_PTR), 'cdft_psi_compute')
+     pdpsi = C_NULL_PTR ; IF ( lssh ) pdpsi = C_LOC(dpsi)
+     CALL hip_check(cdft_psi_integrate(plan, pzu, pe2u, pe3u, pzv, pe1v, pe3v, pe31d, CDFT_MEM_HOST, C_NULL_PTR), &
+          &         'cdft_psi_integrate')
+     CALL scan_and_finish(plan, 0_C_INT, pdpsi)           ! dpsi = dpsi - dpsi(iiref,ijref), SNGL, mask (:423-438)
      IF ( lmask ) THEN ; PRINT *, ' Write masked BSF'
      ELSE              ; PRINT *, ' Write BSF'
      ENDIF
      ierr = putvar(ncout, id_varout(1), zpsi, 1, npiglo, npjglo, ktime=jt)
+     IF ( lssh ) THEN                                     ! :260-267, :280, :299, :323-333, :386-408
+        zssh(:,:) = getvar(cf_sshfil, cn_sossheig, 1, npiglo, npjglo, ktime=jt)
+        zsshu(:,:) = 0.0 ; zsshv(:,:) = 0.0
+        zsshu(1:npiglo-1, :) = 0.5*( zssh(2:npiglo,:) + zssh(1:npiglo-1,:) )
+        zsshv(:, 1:npjglo-1) = 0.5*( zssh(:,2:npjglo) + zssh(:,1:npjglo-1) )
+        ! the reference multiplies BOTH contributions by zv(:,:), the meridional velocity of level 1
+        ! (:299 uses zv where zu was meant); zv is never assigned without the V component: taken as 0
+        zvel1(:,:) = 0.0 ; IF ( ll_v ) zvel1(:,:) = zv(:,:,1)
+        pzu = C_NULL_PTR ; pe2u = C_NULL_PTR ; pe3u = C_NULL_PTR ; pzv = C_NULL_PTR ; pe1v = C_NULL_PTR ; pe3v = C_NULL_PTR
+        IF ( ll_u ) THEN ; pzu = C_LOC(zvel1) ; pe2u = C_LOC(e2u) ; pe3u = C_LOC(zsshu) ; ENDIF
+        IF ( ll_v ) THEN ; pzv = C_LOC(zvel1) ; pe1v = C_LOC(e1v) ; pe3v = C_LOC(zsshv) ; ENDIF
+        CALL hip_check(cdft_psi_integrate(plan1, pzu, pe2u, pe3u, pzv, pe1v, pe3v, C_NULL_PTR, CDFT_MEM_HOST, C_NULL_PTR), &
+             &         'cdft_psi_integrate')
+        CALL scan_and_finish(plan1, 1_C_INT, C_LOC(dpsissh))   ! the SSH part is not referenced to (iiref,ijref)
+        ierr = putvar(ncout, id_varout(2), zpsi, 1, npiglo, npjglo, ktime=jt)
+        IF ( lmask ) THEN ; zpsi(:,:) = SNGL(dpsissh + dpsi) * zmask(:,:)
+        ELSE              ; zpsi(:,:) = SNGL(dpsissh + dpsi)
+        ENDIF
+        ierr = putvar(ncout, id_varout(3), zpsi, 1, npiglo, npjglo, ktime=jt)
+     ENDIF
   END DO
+  IF ( lssh .OR. llev ) ierr = cdft_psi_destroy(plan1)
   ierr = cdft_psi_destroy(plan)
   ierr = closeout(ncout)
 
 CONTAINS
 
+  SUBROUTINE scan_and_finish(kplan, knoref, pd8)
+    !! scans of the transports held by kplan (closed domain or -open), then reference point, SNGL and mask
+    !! into zpsi; knoref = 1: no reference point (value 0 is subtracted); pd8: optional r8 copy of psi
+    TYPE(C_PTR),    INTENT(in) :: kplan, pd8
+    INTEGER(C_INT), INTENT(in) :: knoref
+    IF ( lopen ) THEN
+       CALL hip_check(cdft_psi_scan_open(kplan, MERGE(1_C_INT, 0_C_INT, lmean), C_NULL_PTR), 'cdft_psi_scan_open')
+    ELSE
+       CALL hip_check(cdft_psi_scan_u(kplan, C_NULL_PTR, CDFT_MEM_HOST, 1_C_INT, C_NULL_PTR, CDFT_MEM_HOST, C_NULL_PTR), &
+            &         'cdft_psi_scan_u')
+    ENDIF
+    CALL hip_check(cdft_psi_finish(kplan, knoref, 0.d0, INT(iiref, C_INT), INT(ijref, C_INT), pmask, CDFT_MEM_HOST, zpsi, &
+         &         pd8, CDFT_MEM_HOST, C_NULL_PTR), 'cdft_psi_finish')
+  END SUBROUTINE scan_and_finish
+
+  SUBROUTINE level_psi(cd_file, cd_var, cd_fe3, cd_ve3, ld_u)
+    !! -lev: transport of level jk alone, scanned and written without reference point (:275-307)
+    CHARACTER(LEN=*), INTENT(in) :: cd_file, cd_var, cd_fe3, cd_ve3
+    LOGICAL,          INTENT(in) :: ld_u
+    TYPE(C_PTR) :: pl_e3, pl_1d
+    zlev(:,:) = getvar(cd_file, cd_var, jk, npiglo, npjglo, ktime=jt)
+    pl_e3 = C_NULL_PTR ; pl_1d = C_NULL_PTR
+    IF ( lfull ) THEN ; pl_1d = C_LOC(e31d(jk))
+    ELSE
+       ze3(:,:) = getvar(cd_fe3, cd_ve3, jk, npiglo, npjglo, ktime=it, ldiom=.NOT. lg_vvl)
+       pl_e3 = C_LOC(ze3)
+    ENDIF
+    IF ( ld_u ) THEN
+       CALL hip_check(cdft_psi_integrate(plan1, C_LOC(zlev), C_LOC(e2u), pl_e3, C_NULL_PTR, C_NULL_PTR, C_NULL_PTR, pl_1d, &
+            &         CDFT_MEM_HOST, C_NULL_PTR), 'cdft_psi_integrate')
+    ELSE
+       CALL hip_check(cdft_psi_integrate(plan1, C_NULL_PTR, C_NULL_PTR, C_NULL_PTR, C_LOC(zlev), C_LOC(e1v), pl_e3, pl_1d, &
+            &         CDFT_MEM_HOST, C_NULL_PTR), 'cdft_psi_integrate')
+    ENDIF
+    CALL scan_and_finish(plan1, 1_C_INT, C_NULL_PTR)
+    ! the reference creates the file with ONE level (:497) and ignores the status of the writes that
+    ! do not fit: only level 1 reaches the file there, and here
+    ierr = putvar(ncout, id_varout(1), zpsi, jk, npiglo, npjglo, ktime=jt)
+  END SUBROUTINE level_psi
+
   SUBROUTINE CreateOutput
-    !! src/cdfpsi.f90:444-505 (single variable: no --ssh-file, no -lev)
+    !! src/cdfpsi.f90:444-505
+    INTEGER(KIND=4) :: ji
     ipk(:) = 1
-    stypvar(1)%cunits            = 'm3/s'
-    stypvar(1)%valid_min         = -300.e6
-    stypvar(1)%valid_max         = 300.e6
-    stypvar(1)%conline_operation = 'N/A'
-    stypvar(1)%caxis             = 'TYX'
-    stypvar(1)%ichunk            = (/ npiglo, MAX(1, npjglo / 30), 1, 1 /)
+    IF ( llev ) ipk(1) = npk
+    stypvar(:)%cunits            = 'm3/s'
+    stypvar(:)%valid_min         = -300.e6
+    stypvar(:)%valid_max         = 300.e6
+    stypvar(:)%conline_operation = 'N/A'
+    stypvar(:)%caxis             = 'TYX'
+    DO ji = 1, 3
+       stypvar(ji)%ichunk        = (/ npiglo, MAX(1, npjglo / 30), 1, 1 /)
+    END DO
     stypvar(1)%cname             = cv_out
     stypvar(1)%rmissing_value    = 0.
     stypvar(1)%clong_name        = 'Barotropic_Stream_Function'
+    IF ( llev ) stypvar(1)%clong_name = 'Barotropic_Stream_Function_per_level'
     stypvar(1)%cshort_name       = cv_out
+    stypvar(2)%cname             = cv_outssh
+    stypvar(2)%rmissing_value    = 0.
+    stypvar(2)%clong_name        = 'Barotropic_Stream_Function SSH contribution'
+    stypvar(2)%cshort_name       = cv_outssh
+    stypvar(3)%cname             = cv_outotal
+    stypvar(3)%rmissing_value    = 0.
+    stypvar(3)%clong_name        = 'Barotropic_Stream_Function SSH total'
+    stypvar(3)%cshort_name       = cv_outotal
     ncout = create      (cf_out, cf_ufil, npiglo, npjglo, 1, ld_nc4=lnc4)
-    ierr  = createvar   (ncout, stypvar, 1, ipk, id_varout, cdglobal=TRIM(cglobal), ld_nc4=lnc4)
+    ierr  = createvar   (ncout, stypvar, nvout, ipk, id_varout, cdglobal=TRIM(cglobal), ld_nc4=lnc4)
     ierr  = putheadervar(ncout, cf_ufil, npiglo, npjglo, 1, glamf, gphif)
     dtim  = getvar1d(cf_ufil, cn_vtimec, npt)
     ierr  = putvar1d(ncout, dtim, npt, 'T')

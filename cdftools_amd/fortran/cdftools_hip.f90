@@ -121,6 +121,9 @@ MODULE cdftools_hip
           &         BIND(C, name='cdft_psi_scan_u')
        IMPORT ; TYPE(C_PTR), VALUE :: plan, stream, carry, last_row ; INTEGER(C_INT), VALUE :: carry_space, first_block, last_space
      END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_psi_scan_open(plan, lmean, stream) BIND(C, name='cdft_psi_scan_open')
+       IMPORT ; TYPE(C_PTR), VALUE :: plan, stream ; INTEGER(C_INT), VALUE :: lmean
+     END FUNCTION
      INTEGER(C_INT) FUNCTION cdft_psi_value(plan, ii, ij, dvalue, stream) BIND(C, name='cdft_psi_value')
        IMPORT ; TYPE(C_PTR), VALUE :: plan, stream ; INTEGER(C_INT), VALUE :: ii, ij ; REAL(C_DOUBLE), INTENT(out) :: dvalue
      END FUNCTION

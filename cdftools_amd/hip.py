@@ -372,6 +372,10 @@ class PsiPlan(_Plan):
                                           MEM_HOST, stream or current_stream_ptr()))
         return last
 
+    def scan_open(self, lmean=False, stream=None):
+        """-open: psi from the row npjglo-2 / column npiglo-2 (needs integrate() with both velocity sets)."""
+        check(_lib.load().cdft_psi_scan_open(self._h, 1 if lmean else 0, stream or current_stream_ptr()))
+
     def value(self, ii, ij, stream=None):
         v = C.c_double(0)
         check(_lib.load().cdft_psi_value(self._h, ii, ij, C.byref(v), stream or current_stream_ptr()))

@@ -236,6 +236,11 @@ int cdft_psi_integrate(cdft_psi_plan *plan, const float *zu, const float *e2u, c
                        void *stream);
 int cdft_psi_scan_u(cdft_psi_plan *plan, const double *carry, int carry_space, int first_block,
                     double *last_row, int last_space, void *stream);
+/* -open (src/cdfpsi.f90:316-366): after cdft_psi_integrate with BOTH velocity sets, psi is built from
+ * the row npjglo-2 (line integral of the V transport, then southwards with the U transport) instead
+ * of cdft_psi_scan_u; lmean adds the estimate from the column npiglo-2 and averages (-open -mean).
+ * Follow with cdft_psi_finish as usual.  (The whole domain: not for row-block partitioned runs.) */
+int cdft_psi_scan_open(cdft_psi_plan *plan, int lmean, void *stream);
 int cdft_psi_value(cdft_psi_plan *plan, int ii, int ij, double *value, void *stream);
 int cdft_psi_finish(cdft_psi_plan *plan, int use_ref, double ref_value, int iiref, int ijref,
                     const float *fmask, int mask_space, float *psi4, double *dpsi8, int out_space, void *stream);

@@ -60,6 +60,9 @@ void oracle_mhst(int npi, int npj, int npk, int nb, const float *e1v, const floa
 void oracle_psi(int npi, int npj, int npk, const float *zu, const float *e2u, const float *e3u,
                 const float *zv, const float *e1v, const float *e3v, const float *e31d, int iiref,
                 int ijref, const float *fmask, float *psi4, double *dpsi8);
+void oracle_psi_open(int npi, int npj, int npk, const float *zu, const float *e2u, const float *e3u,
+                     const float *zv, const float *e1v, const float *e3v, const float *e31d, int lmean,
+                     int iiref, int ijref, int noref, const float *fmask, float *psi4, double *dpsi8);
 void oracle_vt(int npi, int npj, int nfr, long fstride, const float *u, const float *v, const float *t,
                const float *s, const float *e3u, const float *e3v, double *vt, double *vs, double *ut,
                double *us, double *e3um, double *e3vm);

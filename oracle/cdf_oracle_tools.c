@@ -105,8 +105,8 @@ void oracle_mhst(int npi, int npj, int npk, int nb, const float *e1v, const floa
 }
 
 /* ------------------------------------------------------------------------------------------ */
-/* src/cdfpsi.f90:256-438 for one record, default / -V / -mean / -mask / -ref paths (not -open,
- * --ssh-file, -lev).
+/* src/cdfpsi.f90:256-438 for one record, default / -V / -mean / -mask / -ref paths (-open: see
+ * oracle_psi_open below; --ssh-file and -lev are these same functions applied to other operands).
  *   ll_u: zu, e2u, e3u (or e31d) -> dtrpu = sum_k zu*e2u*e3u*1.d0 (:296-297), then
  *         dpsiu(:,1) = 0 ; dpsiu(:,jj) = dpsiu(:,jj-1) - dtrpu(:,jj), jj = 2..npj (:395-398)
  *   ll_v: zv, e1v, e3v          -> dtrpv = sum_k zv*e1v*e3v*1.d0 (:277-278), then
@@ -152,6 +152,52 @@ void oracle_psi(int npi, int npj, int npk, const float *zu, const float *e2u, co
     const double ref = dpsi[IJ(iiref - 1, ijref - 1)];
     for (size_t p = 0; p < nij; ++p) {
         const double d = dpsi[p] - ref;
+        if (dpsi8) dpsi8[p] = d;
+        psi4[p] = fmask ? (float)d * fmask[p] : (float)d;
+    }
+    free(dtrpu); free(dtrpv); free(dpsiu); free(dpsiv);
+}
+
+/* src/cdfpsi.f90:316-366, the -open path (implies both transports): psi from a first line inside the
+ * domain instead of a closed boundary.
+ *   dpsiu(1,J) = dtrpv(1,J), dpsiu(ji,J) = dpsiu(ji-1,J) + dtrpv(ji,J) on the row J = npjglo-2 (:335-338),
+ *   then southwards dpsiu(ji,jj) = dpsiu(ji,jj+1) + dtrpu(ji,jj+1), jj = npjglo-3..1 (:340-344); rows
+ *   north of J keep the 0 of :259.
+ *   lmean (:346-356): the other estimate from the column I = npiglo-2,
+ *   dpsiv(I,npjglo) = dtrpu(I,npjglo), dpsiv(I,jj) = dpsiv(I,jj+1) + dtrpu(I,jj+1), jj = npjglo-1..1, then
+ *   westwards dpsiv(ji,jj) = dpsiv(ji+1,jj) - dtrpv(ji+1,jj), ji = npiglo-3..1; columns east of I stay 0;
+ *   dpsi = 0.5*(dpsiu + dpsiv).
+ *   Then dpsi = dpsi - dpsi(iiref,ijref) unless noref (the ssh part is never normalised, :423),
+ *   psi4 = SNGL(dpsi) [* fmask]. */
+void oracle_psi_open(int npi, int npj, int npk, const float *zu, const float *e2u, const float *e3u,
+                     const float *zv, const float *e1v, const float *e3v, const float *e31d, int lmean,
+                     int iiref, int ijref, int noref, const float *fmask, float *psi4, double *dpsi8) {
+    const size_t nij = (size_t)npi * npj;
+    double *dtrpu = (double *)calloc(nij, 8), *dtrpv = (double *)calloc(nij, 8);
+    double *dpsiu = (double *)calloc(nij, 8), *dpsiv = (double *)calloc(nij, 8);
+    for (int k = 0; k < npk; ++k)
+        for (int j = 0; j < npj; ++j)
+            for (int i = 0; i < npi; ++i) {
+                const float ev = e3v ? e3v[IJK(i, j, k)] : e31d[k], eu = e3u ? e3u[IJK(i, j, k)] : e31d[k];
+                dtrpv[IJ(i, j)] = dtrpv[IJ(i, j)] + (double)(zv[IJK(i, j, k)] * e1v[IJ(i, j)] * ev) * 1.0;
+                dtrpu[IJ(i, j)] = dtrpu[IJ(i, j)] + (double)(zu[IJK(i, j, k)] * e2u[IJ(i, j)] * eu) * 1.0;
+            }
+    const int J = npj - 3;                                   /* row npjglo-2, 0-based */
+    dpsiu[IJ(0, J)] = dtrpv[IJ(0, J)];
+    for (int i = 1; i < npi; ++i) dpsiu[IJ(i, J)] = dpsiu[IJ(i - 1, J)] + dtrpv[IJ(i, J)];
+    for (int j = J - 1; j >= 0; --j)
+        for (int i = 0; i < npi; ++i) dpsiu[IJ(i, j)] = dpsiu[IJ(i, j + 1)] + dtrpu[IJ(i, j + 1)];
+    if (lmean) {
+        const int I = npi - 3;                               /* column npiglo-2, 0-based */
+        dpsiv[IJ(I, npj - 1)] = dtrpu[IJ(I, npj - 1)];
+        for (int j = npj - 2; j >= 0; --j) dpsiv[IJ(I, j)] = dpsiv[IJ(I, j + 1)] + dtrpu[IJ(I, j + 1)];
+        for (int j = npj - 1; j >= 0; --j)
+            for (int i = I - 1; i >= 0; --i) dpsiv[IJ(i, j)] = dpsiv[IJ(i + 1, j)] - dtrpv[IJ(i + 1, j)];
+        for (size_t p = 0; p < nij; ++p) dpsiu[p] = 0.5 * (dpsiu[p] + dpsiv[p]);
+    }
+    const double ref = noref ? 0.0 : dpsiu[IJ(iiref - 1, ijref - 1)];
+    for (size_t p = 0; p < nij; ++p) {
+        const double d = noref ? dpsiu[p] : dpsiu[p] - ref;
         if (dpsi8) dpsi8[p] = d;
         psi4[p] = fmask ? (float)d * fmask[p] : (float)d;
     }

@@ -56,6 +56,20 @@ def psi(npk, zu=None, e2u=None, e3u=None, zv=None, e1v=None, e3v=None, e31d=None
     return p4, d8
 
 
+def psi_open(npk, zu, e2u, e3u, zv, e1v, e3v, lmean=False, e31d=None, iiref=None, ijref=None, noref=False, fmask=None):
+    """-open path (src/cdfpsi.f90:316-366) -> (psi4, dpsi8)."""
+    lib = load()
+    zu, e2u, e3u, zv, e1v, e3v, e31d, fmask = map(_f, (zu, e2u, e3u, zv, e1v, e3v, e31d, fmask))
+    npj, npi = e2u.shape
+    iiref = npi if iiref is None else iiref
+    ijref = npj if ijref is None else ijref
+    p4, d8 = np.empty((npj, npi), np.float32), np.empty((npj, npi), np.float64)
+    lib.oracle_psi_open(C.c_int(npi), C.c_int(npj), C.c_int(npk), _p(zu), _p(e2u), _pp(e3u), _p(zv), _p(e1v), _pp(e3v),
+                        _pp(e31d), C.c_int(1 if lmean else 0), C.c_int(iiref), C.c_int(ijref), C.c_int(1 if noref else 0),
+                        _pp(fmask), _p(p4), _p(d8))
+    return p4, d8
+
+
 def vt_level(u, v, t, s, e3u=None, e3v=None):
     """u,v,t,s (nfr,npj,npi) r4 for ONE level -> dict of (npj,npi) r8 means (src/cdfvT.f90:160-259)."""
     lib = load()

@@ -143,3 +143,96 @@ def test_cdfvT_then_cdfmhst_end_to_end(case):
     assert ma["zomht_glo"]["units"] == b"PW" and md["depthv"] == 1
     txt = open(os.path.join(d, "zonal_heat_trp.dat")).read().splitlines()
     assert len(txt) == 3 + g["e1v"].shape[0] and "Atlantic" in txt[1]
+
+
+@pytest.mark.gpu
+def test_cdfpsi_open_ssh_and_lev_options(case):
+    """-open [-mean], --ssh-file (with the reference's zv-for-zu operand, src/cdfpsi.f90:299) and -lev
+    (first record, one-level file as the reference creates it, :311-315 and :497)."""
+    d, g, rec = case
+    npk, npj, npi = g["tmask"].shape
+    rng = np.random.default_rng(77)
+    ssh = (rng.standard_normal((2, npj, npi)) * g["tmask"][0]).astype(np.float32)
+    nemo_files.write_data(os.path.join(d, "SYN_y0001_grid2D.nc"), g, "deptht", {"sossheig": ssh})
+    uv = ["-u", "SYN_y0001_gridU.nc", "-v", "SYN_y0001_gridV.nc"]
+    fm = np.minimum(g["fmask"][0], 1).astype(np.float32)
+
+    def transports(t):
+        return dict(zu=rec["u"][t], e2u=g["e2u"], e3u=g["e3u_0"], zv=rec["v"][t], e1v=g["e1v"], e3v=g["e3v_0"])
+
+    for extra, lmean in ((["-open"], False), (["-open", "-mean"], True)):
+        rc, out, err = run("cdfpsi", uv + extra + ["-ref", "5", "4", "-mask", "-o", "po.nc"], d)
+        assert rc == 0, out + err
+        var, _, _ = read_nc(os.path.join(d, "po.nc"))
+        for t in range(2):
+            want, _ = oracle_tools.psi_open(npk, **transports(t), lmean=lmean, iiref=5, ijref=4, fmask=fm)
+            assert np.array_equal(var["sobarstf"][t], want), extra
+    # --ssh-file with -mean: three variables
+    rc, out, err = run("cdfpsi", uv + ["-mean", "--ssh-file", "SYN_y0001_grid2D.nc", "-o", "ps.nc"], d)
+    assert rc == 0, out + err
+    var, att, _ = read_nc(os.path.join(d, "ps.nc"))
+    assert att["sobarstfssh"]["long_name"] == b"Barotropic_Stream_Function SSH contribution"
+    for t in range(2):
+        sshu, sshv = np.zeros((npj, npi), np.float32), np.zeros((npj, npi), np.float32)
+        sshu[:, :-1] = np.float32(0.5) * (ssh[t][:, 1:] + ssh[t][:, :-1])
+        sshv[:-1, :] = np.float32(0.5) * (ssh[t][1:, :] + ssh[t][:-1, :])
+        v1 = rec["v"][t][0:1]                                             # level-1 v multiplies BOTH parts (:280, :299)
+        _, d8 = oracle_tools.psi(npk, **transports(t))
+        p4s, d8s = oracle_tools.psi(1, zu=v1, e2u=g["e2u"], e3u=sshu[None], zv=v1, e1v=g["e1v"], e3v=sshv[None])
+        # the SSH part is not referenced: undo the oracle's subtraction of its value at (npi,npj)
+        _, d8s0 = oracle_tools.psi(1, zu=v1, e2u=g["e2u"], e3u=sshu[None], zv=v1, e1v=g["e1v"], e3v=sshv[None], iiref=npi, ijref=1)
+        assert np.array_equal(var["sobarstf"][t], d8.astype(np.float32))
+        got_ssh = var["sobarstfssh"][t]
+        # reconstruct the unreferenced field from two differently referenced oracle runs: both are dpsi - const
+        assert np.allclose(got_ssh - got_ssh[-1, -1], d8s.astype(np.float32), rtol=0, atol=np.abs(d8s).max() * 3e-7)
+        assert np.allclose(var["sobarstftotal"][t], got_ssh.astype(np.float64) + d8, rtol=0, atol=np.abs(d8).max() * 2e-7)
+        assert np.abs(got_ssh).max() > 0
+    # without the V component the reference's zv is never assigned: the SSH part is 0 there and here
+    rc, out, err = run("cdfpsi", uv + ["--ssh-file", "SYN_y0001_grid2D.nc", "-o", "ps0.nc"], d)
+    assert rc == 0, out + err
+    var, _, _ = read_nc(os.path.join(d, "ps0.nc"))
+    assert np.all(var["sobarstfssh"] == 0) and np.array_equal(var["sobarstftotal"], var["sobarstf"])
+    # -lev
+    rc, out, err = run("cdfpsi", uv + ["-lev", "-o", "pl.nc"], d)
+    assert rc == 0 and "cdfpsi_level completed." in out, out + err
+    var, att, dims = read_nc(os.path.join(d, "pl.nc"))
+    assert att["vobarstf"]["long_name"] == b"Barotropic_Stream_Function_per_level"
+    lev = var["vobarstf"]
+    lev = lev.reshape(lev.shape[0], -1, npj, npi)                      # (t, 1, y, x): the file holds one level
+    assert lev.shape[1] == 1
+    _, want = oracle_tools.psi(1, zu=rec["u"][0][0:1], e2u=g["e2u"], e3u=g["e3u_0"][0:1], iiref=1, ijref=1)
+    assert np.array_equal(lev[0, 0], want.astype(np.float32))
+    rc, out, _ = run("cdfpsi", uv + ["-lev", "-open"], d)
+    assert rc == 99 and "cannot use both -lev and -open" in out
+
+
+@pytest.mark.gpu
+def test_cdfcurl_level_0_forcing_fields_on_the_a_grid(case):
+    """-l 0: the fields are taken as A-grid forcing, averaged to U / V points (src/cdfcurl.f90:250-258), then
+    the same stencil.  As in the reference the test ':154' comes first: a file without depth stops with
+    'Use -surf option', so level 0 is only reachable on a file that has a depth dimension."""
+    d, g, rec = case
+    npk, npj, npi = g["tmask"].shape
+    rc, out, err = run("cdfcurl", ["-u", "SYN_y0001_gridU.nc", "vozocrtx", "-v", "SYN_y0001_gridV.nc", "vomecrty", "-l", "0",
+                                   "-o", "cf.nc"], d)
+    assert rc == 0 and "npk =0, assume 1" in out, out + err
+    var, _, _ = read_nc(os.path.join(d, "cf.nc"))
+    for t in range(2):
+        tx, ty = rec["u"][t, 0], rec["v"][t, 0]
+        un, vn = tx.copy(), ty.copy()
+        un[:, :-1] = np.float32(0.5) * (tx[:, :-1] + tx[:, 1:])
+        vn[:-1, :] = np.float32(0.5) * (ty[:-1, :] + ty[1:, :])
+        want = oracle_tools.curl(un, vn, g["e1u"], g["e2v"], g["e1f"], g["e2f"], True).astype(np.float32)
+        assert np.array_equal(var["socurl"][t].reshape(npj, npi), want)
+        assert np.count_nonzero(want) > 20
+    with netcdf_file(os.path.join(d, "flx.nc"), "w", version=2) as f:       # no depth dimension at all
+        f.createDimension("time_counter", None)
+        f.createDimension("y", npj)
+        f.createDimension("x", npi)
+        for nm in ("sozotaux", "sometauy"):
+            v = f.createVariable(nm, "f4", ("time_counter", "y", "x"))
+            v[:] = np.zeros((1, npj, npi), np.float32)
+        v = f.createVariable("time_counter", "f8", ("time_counter",))
+        v[:] = [86400.0]
+    rc, out, _ = run("cdfcurl", ["-u", "flx.nc", "sozotaux", "-v", "flx.nc", "sometauy", "-l", "0"], d)
+    assert rc == 99 and "Use -surf option" in out

@@ -121,6 +121,61 @@ def test_hip_psi_row_blocks_chained_equal_the_whole_domain_bitwise(gpu, npi, npj
         gpu.PsiPlan(4, 4, 2).finish(0.0)                                # nothing integrated yet
 
 
+def test_oracle_psi_open_matches_numpy_restatement_bitwise():
+    g = synth.make_grid(24, 18, 5, seed=6)
+    _, _, u, v = tracer_fields(g, 2)
+    npk, npj, npi = u.shape
+    dtu, dtv = np.zeros((npj, npi)), np.zeros((npj, npi))
+    for k in range(npk):
+        dtu += ((u[k] * g["e2u"]) * g["e3u_0"][k]).astype(np.float64)
+        dtv += ((v[k] * g["e1v"]) * g["e3v_0"][k]).astype(np.float64)
+    J, I = npj - 3, npi - 3
+    pu = np.zeros((npj, npi))
+    pu[J] = np.cumsum(dtv[J])                                   # sequential prefix along i (np.cumsum adds in order)
+    for j in range(J - 1, -1, -1):
+        pu[j] = pu[j + 1] + dtu[j + 1]
+    pv = np.zeros((npj, npi))
+    acc = dtu[npj - 1, I]
+    pv[npj - 1, I] = acc
+    for j in range(npj - 2, -1, -1):
+        acc = acc + dtu[j + 1, I]
+        pv[j, I] = acc
+    for i in range(I - 1, -1, -1):
+        pv[:, i] = pv[:, i + 1] - dtv[:, i + 1]
+    kw = dict(zu=u, e2u=g["e2u"], e3u=g["e3u_0"], zv=v, e1v=g["e1v"], e3v=g["e3v_0"])
+    _, d8 = oracle_tools.psi_open(npk, **kw, noref=True)
+    assert np.array_equal(d8, pu)
+    _, d8m = oracle_tools.psi_open(npk, **kw, lmean=True, noref=True)
+    assert np.array_equal(d8m, 0.5 * (pu + pv))
+    p4, d8r = oracle_tools.psi_open(npk, **kw, iiref=4, ijref=3)
+    assert np.array_equal(d8r, pu - pu[2, 3]) and np.array_equal(p4, (pu - pu[2, 3]).astype(np.float32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("npi,npj,npk", [(24, 18, 7), (182, 149, 5), (3, 3, 2), (130, 67, 3)])
+def test_hip_psi_open_equals_oracle_bitwise(gpu, npi, npj, npk):
+    g = synth.make_grid(npi, npj, npk, seed=npi + 11)
+    _, _, u, v = tracer_fields(g, 3)
+    fm = np.minimum(g["fmask"][0], 1).astype(np.float32)
+    kw = dict(zu=u, e2u=g["e2u"], e3u=g["e3u_0"], zv=v, e1v=g["e1v"], e3v=g["e3v_0"])
+    plan = gpu.PsiPlan(npi, npj, npk)
+    for lmean in (False, True):
+        plan.integrate(**kw)
+        plan.scan_open(lmean)
+        g4, g8 = plan.finish(None, max(1, npi // 2), max(1, npj // 3), fm)
+        r4, r8 = oracle_tools.psi_open(npk, **kw, lmean=lmean, iiref=max(1, npi // 2), ijref=max(1, npj // 3), fmask=fm)
+        assert np.array_equal(g8, r8) and np.array_equal(g4, r4), lmean
+        plan.integrate(**kw)
+        plan.scan_open(lmean)
+        g4, g8 = plan.finish(0.0)                                # the SSH part: no reference point
+        r4, r8 = oracle_tools.psi_open(npk, **kw, lmean=lmean, noref=True)
+        assert np.array_equal(g8, r8) and np.array_equal(g4, r4), lmean
+    only_u = gpu.PsiPlan(npi, npj, npk)
+    only_u.integrate(zu=u, e2u=g["e2u"], e3u=g["e3u_0"])
+    with pytest.raises(gpu.CdftError):
+        only_u.scan_open()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("npi,npj,npk,nb", [(24, 18, 7, 4), (182, 149, 31, 4), (182, 149, 31, 1), (1, 2, 1, 1),
                                             (7, 3, 2, 4), (1442, 9, 3, 4), (333, 5, 4, 8)])
