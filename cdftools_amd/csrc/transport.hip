@@ -45,7 +45,7 @@ template <> __device__ __forceinline__ void lds_<2>(const float *p, int64_t e, f
 }
 template <> __device__ __forceinline__ void lds_<1>(const float *p, int64_t e, float (&o)[1]) { o[0] = ld_stream(p + e); }
 
-enum VMode { kPsi = 0, kMhstVt = 1, kMhstSep = 2 };
+enum VMode { kPsi = 0, kMhstVt = 1, kMhstSep = 2, kVhst = 3 };
 
 struct VintArgs {
     const float *f0, *f1, *f2;   // psi: velocity ; mhst -vt: vt, vs ; mhst sep: v, t, s
@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(kThreads) vint_kernel(VintArgs a) {
                 ld<VEC>(a.f2, en, L.qn[v]);
             } else {
                 lds_<VEC>(a.f0, e, L.x0[v]);
-                if (MODE == kMhstVt) lds_<VEC>(a.f1, e, L.x1[v]);
+                if (MODE == kMhstVt || MODE == kVhst) lds_<VEC>(a.f1, e, L.x1[v]);
             }
         }
     };
@@ -122,6 +122,13 @@ __global__ void __launch_bounds__(kThreads) vint_kernel(VintArgs a) {
                 if (MODE == kMhstSep) {
                     x0 = lastrow[v] ? 0.f : __fmul_rn(__fmul_rn(0.5f, __fadd_rn(L.x0[v][c], L.tn[v][c])), L.vv[v][c]);
                     x1 = lastrow[v] ? 0.f : __fmul_rn(__fmul_rn(0.5f, __fadd_rn(L.x1[v][c], L.qn[v][c])), L.vv[v][c]);
+                }
+                if (MODE == kVhst) {
+                    // src/cdfvhst.f90:167-178: e3v = e3v*e1v first, then zvt*e3v*pp_rau0*pp_rcp*1.d0, all r4
+                    const float em = __fmul_rn(L.e3[v][c], m[v][c]);
+                    s0[v][c] = __dadd_rn(s0[v][c], (double)__fmul_rn(__fmul_rn(__fmul_rn(x0, em), 1000.f), 4000.f));
+                    s1[v][c] = __dadd_rn(s1[v][c], (double)__fmul_rn(x1, em));
+                    continue;
                 }
                 // (field*metric)*e3 in r4, then widened: src/cdfmhst.f90:332-333, src/cdfpsi.f90:277,296
                 const double d0 = (double)__fmul_rn(__fmul_rn(x0, m[v][c]), L.e3[v][c]);
@@ -467,6 +474,78 @@ int cdft_mhst_destroy(cdft_mhst_plan *p) {
     for (void *q : ptrs) if (q) (void)hipFree(q);
     p->s0.release(); p->s1.release(); p->s2.release();
     delete p;
+    return CDFT_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------- cdfvtrp / cdfvhst
+namespace { DevBuf g_vi[4], g_vo[2]; }
+
+extern "C" {
+
+int cdft_vint_transport(const float *vel, const float *m2d, const float *e3, const float *e31d, int npiglo,
+                        int npjglo, int npk, int in_space, double *dtrp, int out_space, void *stream) {
+    if (!vel || !m2d || !dtrp || (!e3 && !e31d)) return fail(CDFT_ERR_ARG, "cdft_vint_transport: NULL argument");
+    if (npiglo < 1 || npjglo < 1 || npk < 1) return fail(CDFT_ERR_ARG, "cdft_vint_transport: bad sizes");
+    CDFT_TRY(require_device());
+    hipStream_t st = as_stream(stream);
+    const int64_t nij = (int64_t)npiglo * npjglo;
+    const void *dv, *dm, *de = nullptr, *d1 = nullptr;
+    CDFT_TRY(to_device(vel, (size_t)nij * npk * 4, in_space, g_vi[0], st, &dv));
+    CDFT_TRY(to_device(m2d, (size_t)nij * 4, in_space, g_vi[1], st, &dm));
+    if (e3) CDFT_TRY(to_device(e3, (size_t)nij * npk * 4, in_space, g_vi[2], st, &de));
+    else    CDFT_TRY(to_device(e31d, (size_t)npk * 4, in_space, g_vi[3], st, &d1));
+    double *out = dtrp;
+    if (out_space == CDFT_MEM_HOST) { CDFT_TRY(g_vo[0].reserve((size_t)nij * 8)); out = (double *)g_vo[0].ptr; }
+    VintArgs a;
+    a.f0 = (const float *)dv; a.f1 = nullptr; a.f2 = nullptr; a.m2d = (const float *)dm; a.e3 = (const float *)de;
+    a.e31d = (const float *)d1; a.acc0 = out; a.acc1 = nullptr; a.nij = nij; a.npi = npiglo; a.npj = npjglo;
+    a.k0 = 0; a.k1 = npk; a.init = 1;
+    CDFT_TRY(launch_vint<kPsi>(a, st));
+    if (out_space == CDFT_MEM_HOST) {
+        CDFT_HIP(hipMemcpyAsync(dtrp, out, (size_t)nij * 8, hipMemcpyDeviceToHost, st));
+        CDFT_HIP(hipStreamSynchronize(st));
+    }
+    return CDFT_OK;
+}
+
+int cdft_vhst_transport(const float *xt, const float *xs, const float *m2d, const float *e3, const float *e31d,
+                        int npiglo, int npjglo, int npk, int in_space, double *dheat, double *dsalt, int out_space,
+                        void *stream) {
+    if (!xt || !xs || !m2d || !dheat || !dsalt || (!e3 && !e31d)) return fail(CDFT_ERR_ARG, "cdft_vhst_transport: NULL argument");
+    if (npiglo < 1 || npjglo < 1 || npk < 1) return fail(CDFT_ERR_ARG, "cdft_vhst_transport: bad sizes");
+    CDFT_TRY(require_device());
+    hipStream_t st = as_stream(stream);
+    const int64_t nij = (int64_t)npiglo * npjglo;
+    static DevBuf sxs;
+    const void *dt, *dsx, *dm, *de = nullptr, *d1 = nullptr;
+    CDFT_TRY(to_device(xt, (size_t)nij * npk * 4, in_space, g_vi[0], st, &dt));
+    CDFT_TRY(to_device(xs, (size_t)nij * npk * 4, in_space, sxs, st, &dsx));
+    CDFT_TRY(to_device(m2d, (size_t)nij * 4, in_space, g_vi[1], st, &dm));
+    if (e3) CDFT_TRY(to_device(e3, (size_t)nij * npk * 4, in_space, g_vi[2], st, &de));
+    else    CDFT_TRY(to_device(e31d, (size_t)npk * 4, in_space, g_vi[3], st, &d1));
+    double *oh = dheat, *os = dsalt;
+    if (out_space == CDFT_MEM_HOST) {
+        CDFT_TRY(g_vo[0].reserve((size_t)nij * 8)); CDFT_TRY(g_vo[1].reserve((size_t)nij * 8));
+        oh = (double *)g_vo[0].ptr; os = (double *)g_vo[1].ptr;
+    }
+    VintArgs a;
+    a.f0 = (const float *)dt; a.f1 = (const float *)dsx; a.f2 = nullptr; a.m2d = (const float *)dm;
+    a.e3 = (const float *)de; a.e31d = (const float *)d1; a.acc0 = oh; a.acc1 = os; a.nij = nij; a.npi = npiglo;
+    a.npj = npjglo; a.k0 = 0; a.k1 = npk; a.init = 1;
+    CDFT_TRY(launch_vint<kVhst>(a, st));
+    if (out_space == CDFT_MEM_HOST) {
+        CDFT_HIP(hipMemcpyAsync(dheat, oh, (size_t)nij * 8, hipMemcpyDeviceToHost, st));
+        CDFT_HIP(hipMemcpyAsync(dsalt, os, (size_t)nij * 8, hipMemcpyDeviceToHost, st));
+        CDFT_HIP(hipStreamSynchronize(st));
+    }
+    return CDFT_OK;
+}
+
+int cdft_vint_release(void) {
+    for (DevBuf &b : g_vi) b.release();
+    for (DevBuf &b : g_vo) b.release();
     return CDFT_OK;
 }
 

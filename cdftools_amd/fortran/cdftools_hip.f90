@@ -103,6 +103,17 @@ MODULE cdftools_hip
      INTEGER(C_INT) FUNCTION cdft_mhst_destroy(plan) BIND(C, name='cdft_mhst_destroy')
        IMPORT ; TYPE(C_PTR), VALUE :: plan
      END FUNCTION
+     ! ---- cdfvtrp, cdfvhst -----------------------------------------------------------------
+     INTEGER(C_INT) FUNCTION cdft_vint_transport(vel, m2d, e3, e31d, npiglo, npjglo, npk, in_space, dtrp, out_space, stream) &
+          &         BIND(C, name='cdft_vint_transport')
+       IMPORT ; REAL(C_FLOAT), INTENT(in) :: vel(*), m2d(*) ; TYPE(C_PTR), VALUE :: e3, e31d, stream
+       INTEGER(C_INT), VALUE :: npiglo, npjglo, npk, in_space, out_space ; REAL(C_DOUBLE), INTENT(out) :: dtrp(*)
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_vhst_transport(xt, xs, m2d, e3, e31d, npiglo, npjglo, npk, in_space, dheat, dsalt, &
+          &                                      out_space, stream) BIND(C, name='cdft_vhst_transport')
+       IMPORT ; REAL(C_FLOAT), INTENT(in) :: xt(*), xs(*), m2d(*) ; TYPE(C_PTR), VALUE :: e3, e31d, stream
+       INTEGER(C_INT), VALUE :: npiglo, npjglo, npk, in_space, out_space ; REAL(C_DOUBLE), INTENT(out) :: dheat(*), dsalt(*)
+     END FUNCTION
      ! ---- cdfpsi ---------------------------------------------------------------------------
      INTEGER(C_INT) FUNCTION cdft_psi_create(plan, npiglo, npjglo, npk) BIND(C, name='cdft_psi_create')
        IMPORT ; TYPE(C_PTR), INTENT(out) :: plan ; INTEGER(C_INT), VALUE :: npiglo, npjglo, npk

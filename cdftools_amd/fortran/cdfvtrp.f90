@@ -1,0 +1,211 @@
+PROGRAM cdfvtrp
+  !!======================================================================
+  !!                     ***  PROGRAM  cdfvtrp  ***
+  !! Vertically integrated transports at each grid cell, optionally rotated along / across the
+  !! bathymetric slope.
+  !!
+  !! Drop-in for the reference tool (src/cdfvtrp.f90): same options, same trp.nc (sozoutrp, somevtrp
+  !! [soastrp, socstrp] float (t,y,x), :262-291).  The level loop (:196-219) runs on the GPU for all levels
+  !! of a record at once (cdft_vint_transport, bit-identical); the -bathy rotation (:224-259) is 2-D work
+  !! through the compiler's ATAN2 / COS / SIN and stays in the program, as written in the reference.
+  !!======================================================================
+  USE ISO_C_BINDING
+  USE cdfio
+  USE modcdfnames
+  USE cdftools_hip
+  IMPLICIT NONE
+
+  INTEGER(KIND=4) :: narg, ijarg, ierr, ji, jj, jk, jt, it, npiglo, npjglo, npk, npt, ncout, nvarout = 2
+  INTEGER(KIND=4), ALLOCATABLE :: ipk(:), id_varout(:)
+  REAL(KIND=4), ALLOCATABLE, TARGET :: e1v(:,:), e2u(:,:), e3u(:,:,:), e3v(:,:,:), e31d(:)
+  REAL(KIND=4), ALLOCATABLE :: zu(:,:,:), zv(:,:,:)
+  REAL(KIND=4), ALLOCATABLE :: e1u(:,:), e2v(:,:), tmask(:,:), hdepw(:,:), zdhdx(:,:), zdhdy(:,:), zalpha(:,:)
+  REAL(KIND=8), ALLOCATABLE :: dtim(:), dwku(:,:), dwkv(:,:), dtrpu(:,:), dtrpv(:,:)
+  TYPE(variable), ALLOCATABLE :: stypvar(:)
+  TYPE(C_PTR) :: pe3u, pe3v, pe31d
+  CHARACTER(LEN=256) :: cf_ufil = 'none', cf_vfil = 'none', cf_out = 'trp.nc', cldum
+  CHARACTER(LEN=256) :: cv_soastrp = 'soastrp', cv_socstrp = 'socstrp'
+  LOGICAL :: lfull = .FALSE., lbathy = .FALSE., lchk = .FALSE., lnc4 = .FALSE.
+  !!----------------------------------------------------------------------
+  CALL ReadCdfNames()
+  narg = COMMAND_ARGUMENT_COUNT()
+  IF ( narg == 0 ) THEN
+     PRINT *, ' usage : cdfvtrp -u U-file -v V-file [-full] [-bathy] [-vvl] ...'
+     PRINT *, '               ... [-o OUT-file] [-nc4]'
+     PRINT *, '      '
+     PRINT *, '     PURPOSE :'
+     PRINT *, '       Compute the vertically integrated transports at each grid cell.'
+     PRINT *, '       MI355X build: the integration runs on the GPU.'
+     PRINT *, '      '
+     PRINT *, '     ARGUMENTS :'
+     PRINT *, '       -u U-file : netcdf gridU file'
+     PRINT *, '       -v V-file : netcdf gridV file'
+     PRINT *, '      '
+     PRINT *, '     OPTIONS :'
+     PRINT *, '       [-full ]  : full step configuration (default is partial steps).'
+     PRINT *, '       [-bathy ] : also compute the along slope and cross slope transport components;'
+     PRINT *, '                bathymetry is read from ', TRIM(cn_fzgr), ' file.'
+     PRINT *, '       [-vvl  ] : time-varying vertical metrics'
+     PRINT *, '       [-o OUT-file  ] : output file name instead of ', TRIM(cf_out)
+     PRINT *, '       [-nc4 ]     : accepted; the bundled NetCDF backend writes classic files.'
+     PRINT *, '      '
+     PRINT *, '     REQUIRED FILES :'
+     PRINT *, '        ', TRIM(cn_fhgr), ' and ', TRIM(cn_fzgr)
+     PRINT *, '        ', TRIM(cn_fmsk), ' is required only with -bathy option.'
+     PRINT *, '      '
+     PRINT *, '     OUTPUT : '
+     PRINT *, '       netcdf file : ', TRIM(cf_out)
+     PRINT *, '       variables : '
+     PRINT *, '           ', TRIM(cn_sozoutrp), ' : zonal transport.'
+     PRINT *, '           ', TRIM(cn_somevtrp), ' : meridional transport.'
+     PRINT *, '          If option -bathy is used :'
+     PRINT *, '           ', TRIM(cv_soastrp), ' : along slope transport'
+     PRINT *, '           ', TRIM(cv_socstrp), ' : cross slope transport'
+     PRINT *, '      '
+     STOP
+  ENDIF
+
+  ijarg = 1
+  DO WHILE ( ijarg <= narg )
+     CALL GET_COMMAND_ARGUMENT(ijarg, cldum) ; ijarg = ijarg + 1
+     SELECT CASE ( cldum )
+     CASE ( '-u'     ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cf_ufil) ; ijarg = ijarg + 1
+     CASE ( '-v'     ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cf_vfil) ; ijarg = ijarg + 1
+     CASE ( '-full'  ) ; lfull  = .TRUE.
+     CASE ( '-vvl'   ) ; lg_vvl = .TRUE.
+     CASE ( '-o'     ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cf_out) ; ijarg = ijarg + 1
+     CASE ( '-nc4'   ) ; lnc4   = .TRUE.
+     CASE ( '-bathy' ) ; lbathy = .TRUE. ; nvarout = 4
+     CASE DEFAULT      ; PRINT *, ' ERROR : ', TRIM(cldum), ' : unknown option.' ; STOP 99
+     END SELECT
+  END DO
+
+  lchk = lchk .OR. chkfile(cn_fzgr)
+  lchk = lchk .OR. chkfile(cn_fhgr)
+  lchk = lchk .OR. chkfile(cf_ufil)
+  lchk = lchk .OR. chkfile(cf_vfil)
+  IF ( lbathy ) lchk = lchk .OR. chkfile(cn_fmsk)
+  IF ( lchk ) STOP 99
+  IF ( lg_vvl ) THEN
+     cn_fe3u = cf_ufil ; cn_fe3v = cf_vfil
+     cn_ve3u = cn_ve3uvvl ; cn_ve3v = cn_ve3vvvl
+  ENDIF
+  ALLOCATE( ipk(nvarout), id_varout(nvarout), stypvar(nvarout) )
+
+  npiglo = getdim(cf_ufil, cn_x)
+  npjglo = getdim(cf_ufil, cn_y)
+  npk    = getdim(cf_ufil, cn_z)
+  npt    = getdim(cf_ufil, cn_t)
+  PRINT *, 'npiglo = ', npiglo
+  PRINT *, 'npjglo = ', npjglo
+  PRINT *, 'npk    = ', npk
+  PRINT *, 'npt    = ', npt
+
+  ALLOCATE( e1v(npiglo,npjglo), e2u(npiglo,npjglo), zu(npiglo,npjglo,npk), zv(npiglo,npjglo,npk) )
+  ALLOCATE( dwku(npiglo,npjglo), dwkv(npiglo,npjglo), dtrpu(npiglo,npjglo), dtrpv(npiglo,npjglo), e31d(npk), dtim(npt) )
+  IF ( .NOT. lfull ) ALLOCATE( e3u(npiglo,npjglo,npk), e3v(npiglo,npjglo,npk) )
+  IF ( lbathy ) THEN
+     ALLOCATE( e1u(npiglo,npjglo), e2v(npiglo,npjglo), tmask(npiglo,npjglo), hdepw(npiglo,npjglo) )
+     ALLOCATE( zdhdx(npiglo,npjglo), zdhdy(npiglo,npjglo), zalpha(npiglo,npjglo) )
+  ENDIF
+  CALL CreateOutput
+  e1v(:,:) = getvar(cn_fhgr, cn_ve1v, 1, npiglo, npjglo)
+  e2u(:,:) = getvar(cn_fhgr, cn_ve2u, 1, npiglo, npjglo)
+  IF ( lfull ) e31d(:) = getvare3(cn_fzgr, cn_ve3t1d, npk)
+  IF ( lbathy ) THEN
+     e1u(:,:)   = getvar(cn_fhgr, cn_ve1u,  1, npiglo, npjglo)
+     e2v(:,:)   = getvar(cn_fhgr, cn_ve2v,  1, npiglo, npjglo)
+     tmask(:,:) = getvar(cn_fmsk, cn_tmask, 1, npiglo, npjglo)
+     hdepw(:,:) = getvar(cn_fzgr, cn_hdepw, 1, npiglo, npjglo)
+  ENDIF
+
+  DO jt = 1, npt
+     it = 1 ; IF ( lg_vvl ) it = jt
+     pe3u = C_NULL_PTR ; pe3v = C_NULL_PTR ; pe31d = C_NULL_PTR
+     IF ( lfull ) THEN
+        pe31d = C_LOC(e31d)
+     ELSE
+        IF ( jt == 1 .OR. lg_vvl ) THEN
+           DO jk = 1, npk
+              e3v(:,:,jk) = getvar(cn_fe3v, cn_ve3v, jk, npiglo, npjglo, ktime=it, ldiom=.NOT. lg_vvl)
+              e3u(:,:,jk) = getvar(cn_fe3u, cn_ve3u, jk, npiglo, npjglo, ktime=it, ldiom=.NOT. lg_vvl)
+           END DO
+        ENDIF
+        pe3u = C_LOC(e3u) ; pe3v = C_LOC(e3v)
+     ENDIF
+     DO jk = 1, npk
+        PRINT *, 'level ', jk
+     END DO
+     zu = getvar3d(cf_ufil, cn_vozocrtx, npiglo, npjglo, npk, ktime=jt)
+     zv = getvar3d(cf_vfil, cn_vomecrty, npiglo, npjglo, npk, ktime=jt)
+     CALL hip_check(cdft_vint_transport(zu, e2u, pe3u, pe31d, npiglo, npjglo, npk, CDFT_MEM_HOST, dtrpu, CDFT_MEM_HOST, &
+          &         C_NULL_PTR), 'cdft_vint_transport')
+     CALL hip_check(cdft_vint_transport(zv, e1v, pe3v, pe31d, npiglo, npjglo, npk, CDFT_MEM_HOST, dtrpv, CDFT_MEM_HOST, &
+          &         C_NULL_PTR), 'cdft_vint_transport')
+     ierr = putvar(ncout, id_varout(1), REAL(dtrpu(:,:)), 1, npiglo, npjglo, ktime=jt)
+     ierr = putvar(ncout, id_varout(2), REAL(dtrpv(:,:)), 1, npiglo, npjglo, ktime=jt)
+
+     IF ( lbathy ) THEN                                   ! src/cdfvtrp.f90:224-259, as written there
+        dwku(:,:) = 0.d0
+        DO jj = 1, npjglo
+           DO ji = 2, npiglo
+              dwku(ji,jj) = 0.5 * ( dtrpu(ji,jj) + dtrpu(ji-1,jj) )
+           END DO
+           dwku(1,jj) = dwku(npiglo-1, jj)
+        END DO
+        dwkv(:,:) = 0.d0
+        DO jj = 2, npjglo
+           DO ji = 1, npiglo
+              dwkv(ji,jj) = 0.5 * ( dtrpv(ji,jj) + dtrpv(ji,jj-1) )
+           END DO
+        END DO
+        zdhdx = 0.e0
+        DO jj = 1, npjglo
+           DO ji = 2, npiglo-1
+              zdhdx(ji,jj) = ( hdepw(ji+1,jj) - hdepw(ji-1,jj) ) / ( e1u(ji,jj) + e1u(ji-1,jj) ) * tmask(ji,jj)
+           END DO
+        END DO
+        zdhdy = 0.e0
+        DO jj = 2, npjglo-1
+           DO ji = 1, npiglo
+              zdhdy(ji,jj) = ( hdepw(ji,jj+1) - hdepw(ji,jj-1) ) / ( e2v(ji,jj) + e2v(ji,jj-1) ) * tmask(ji,jj)
+           END DO
+        END DO
+        zalpha(:,:) = ATAN2( zdhdx, zdhdy ) * tmask(:,:)
+        dtrpu(:,:) = (  dwku(:,:) * COS(zalpha) + dwkv(:,:) * SIN(zalpha) ) * tmask(:,:)
+        dtrpv(:,:) = ( -dwku(:,:) * SIN(zalpha) + dwkv(:,:) * COS(zalpha) ) * tmask(:,:)
+        ierr = putvar(ncout, id_varout(3), REAL(dtrpu(:,:)), 1, npiglo, npjglo, ktime=jt)
+        ierr = putvar(ncout, id_varout(4), REAL(dtrpv(:,:)), 1, npiglo, npjglo, ktime=jt)
+     ENDIF
+  END DO
+  ierr = closeout(ncout)
+
+CONTAINS
+
+  SUBROUTINE CreateOutput
+    !! src/cdfvtrp.f90:262-291
+    ipk(:) = 1
+    stypvar%rmissing_value    = 0.
+    stypvar%valid_min         = -100.
+    stypvar%valid_max         = 100.
+    stypvar%cunits            = 'm3/s'
+    stypvar%conline_operation = 'N/A'
+    stypvar%caxis             = 'TYX'
+    stypvar(1)%ichunk = (/ npiglo, MAX(1, npjglo / 30), 1, 1 /) ; stypvar(2)%ichunk = (/ npiglo, MAX(1, npjglo / 30), 1, 1 /)
+    stypvar(1)%cname       = cn_sozoutrp                  ; stypvar(2)%cname       = cn_somevtrp
+    stypvar(1)%clong_name  = 'Zonal_barotropic_transport' ; stypvar(2)%clong_name  = 'Meridional_barotropic_transport'
+    stypvar(1)%cshort_name = cn_sozoutrp                  ; stypvar(2)%cshort_name = cn_somevtrp
+    IF ( lbathy ) THEN
+       stypvar(3)%ichunk = (/ npiglo, MAX(1, npjglo / 30), 1, 1 /) ; stypvar(4)%ichunk = (/ npiglo, MAX(1, npjglo / 30), 1, 1 /)
+       stypvar(3)%cname       = cv_soastrp                      ; stypvar(4)%cname       = cv_socstrp
+       stypvar(3)%clong_name  = 'Along_Slope_Barotropic_Transp' ; stypvar(4)%clong_name  = 'Cross_Slope_Barotropic_Transp'
+       stypvar(3)%cshort_name = cv_soastrp                      ; stypvar(4)%cshort_name = cv_socstrp
+    ENDIF
+    ncout = create      (cf_out, cf_ufil, npiglo, npjglo, 1, ld_nc4=lnc4)
+    ierr  = createvar   (ncout, stypvar, nvarout, ipk, id_varout, ld_nc4=lnc4)
+    ierr  = putheadervar(ncout, cf_ufil, npiglo, npjglo, 1)
+    dtim  = getvar1d(cf_ufil, cn_vtimec, npt)
+    ierr  = putvar1d(ncout, dtim, npt, 'T')
+  END SUBROUTINE CreateOutput
+
+END PROGRAM cdfvtrp

@@ -438,6 +438,44 @@ def vt_compute(u, v, t, s, e3u=None, e3v=None, out_r4=False, stream=None):
     return o
 
 
+def vint_transport(vel, m2d, e3=None, e31d=None, stream=None):
+    """cdft_vint_transport: vel (npk,npj,npi) r4 -> (npj,npi) r8 (host arrays or CUDA tensors)."""
+    pv, sv, kv = _arg(vel, np.float32, "vel")
+    pm, sm, km = _arg(m2d, np.float32, "m2d")
+    pe, se, ke = _opt(e3, "e3")
+    p1, s1, k1 = _opt(e31d, "e31d")
+    sp = _same_space(sv, sm, se, s1)
+    npk, npj, npi = kv.shape
+    if sp == MEM_DEVICE:
+        out = torch.empty((npj, npi), dtype=torch.float64, device=kv.device)
+        po = C.c_void_p(out.data_ptr())
+    else:
+        out = np.empty((npj, npi), np.float64)
+        po = C.c_void_p(out.ctypes.data)
+    check(_lib.load().cdft_vint_transport(pv, pm, pe, p1, npi, npj, npk, sp, po, sp, stream or current_stream_ptr()))
+    return out
+
+
+def vhst_transport(xt, xs, m2d, e3=None, e31d=None, stream=None):
+    """cdft_vhst_transport: one pair of VT-file variables -> (heat, salt), each (npj,npi) r8."""
+    pt, st_, kt = _arg(xt, np.float32, "xt")
+    ps, ss, ks = _arg(xs, np.float32, "xs")
+    pm, sm, km = _arg(m2d, np.float32, "m2d")
+    pe, se, ke = _opt(e3, "e3")
+    p1, s1, k1 = _opt(e31d, "e31d")
+    sp = _same_space(st_, ss, sm, se, s1)
+    npk, npj, npi = kt.shape
+    if sp == MEM_DEVICE:
+        h = torch.empty((npj, npi), dtype=torch.float64, device=kt.device)
+        s = torch.empty_like(h)
+        ph, pss = C.c_void_p(h.data_ptr()), C.c_void_p(s.data_ptr())
+    else:
+        h, s = np.empty((npj, npi), np.float64), np.empty((npj, npi), np.float64)
+        ph, pss = C.c_void_p(h.ctypes.data), C.c_void_p(s.ctypes.data)
+    check(_lib.load().cdft_vhst_transport(pt, ps, pm, pe, p1, npi, npj, npk, sp, ph, pss, sp, stream or current_stream_ptr()))
+    return h, s
+
+
 class CurlPlan(_Plan):
     """cdfcurl (src/cdfcurl.f90:262-301): cdft_curl_* of the C ABI."""
 
@@ -473,4 +511,4 @@ class CurlPlan(_Plan):
         return out
 
 
-__all__ = ["MocPlan", "HeatcPlan", "MhstPlan", "PsiPlan", "CurlPlan", "vt_compute", "sigmai", "sigma0", "sig_tool", "EOS_80", "EOS_TEOS10", "EOS_JMD94", "EOS_FAST_FMA", "Timer", "CdftError", "device_count", "current_stream_ptr", "MEM_HOST", "MEM_DEVICE"]
+__all__ = ["MocPlan", "HeatcPlan", "MhstPlan", "PsiPlan", "CurlPlan", "vt_compute", "vint_transport", "vhst_transport", "sigmai", "sigma0", "sig_tool", "EOS_80", "EOS_TEOS10", "EOS_JMD94", "EOS_FAST_FMA", "Timer", "CdftError", "device_count", "current_stream_ptr", "MEM_HOST", "MEM_DEVICE"]

@@ -205,6 +205,23 @@ int cdft_mhst_compute(cdft_mhst_plan *plan, const float *vt, const float *vs, co
 int cdft_mhst_destroy(cdft_mhst_plan *plan);
 
 /* ------------------------------------------------------------------------------------------ */
+/* cdfvtrp, cdfvhst : vertically integrated transports per grid cell     */
+/*   the same vertical integral as cdfpsi / cdfmhst, handed back as a 2-D r8 field               */
+/* ------------------------------------------------------------------------------------------ */
+/* src/cdfvtrp.f90:211-218: dtrp(ji,jj) = sum_k vel*m2d*e3*1.d0 (r4 product left to right, r8 sum in
+ * level order).  vel (npiglo,npjglo,npk) r4, m2d (npiglo,npjglo) r4 (e2u or e1v), e3 (npiglo,npjglo,npk)
+ * r4 or NULL with e31d (npk) r4 (-full).  dtrp (npiglo,npjglo) r8: the caller stores REAL(dtrp). */
+int cdft_vint_transport(const float *vel, const float *m2d, const float *e3, const float *e31d, int npiglo,
+                        int npjglo, int npk, int in_space, double *dtrp, int out_space, void *stream);
+/* src/cdfvhst.f90:167-178 for one pair of VT-file variables (vomevt, vomevs with e1v, e3v; vozout,
+ * vozous with e2u, e3u): e3m = e3*m2d in r4 first, then
+ *   dheat += xt*e3m*pp_rau0*pp_rcp*1.d0 (1000., 4000., r4 chain), dsalt += xs*e3m*1.d0. */
+int cdft_vhst_transport(const float *xt, const float *xs, const float *m2d, const float *e3, const float *e31d,
+                        int npiglo, int npjglo, int npk, int in_space, double *dheat, double *dsalt, int out_space,
+                        void *stream);
+int cdft_vint_release(void);   /* frees the staging buffers of the two calls above */
+
+/* ------------------------------------------------------------------------------------------ */
 /* cdfpsi : barotropic stream function                                                        */
 /*   replaces src/cdfpsi.f90:271-298 (vertical integration), :377-423 (scans, mean, reference  */
 /*   point) and the SNGL / mask at :426-433.  Not covered: -open, --ssh-file, -lev.            */

@@ -302,3 +302,32 @@ void oracle_curl(int npi, int npj, const float *un, const float *vn, const float
             if (ff[p] != 0.0) rotn[p] = rotn[p] / ff[p];
     free(fm);
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* src/cdfvtrp.f90:211-218: dtrp = sum_k vel*m2d*e3*1.d0 (the product in r4, left to right) */
+void oracle_vint_transport(int npi, int npj, int npk, const float *vel, const float *m2d, const float *e3,
+                           const float *e31d, double *dtrp) {
+    const size_t nij = (size_t)npi * npj;
+    memset(dtrp, 0, nij * 8);
+    for (int k = 0; k < npk; ++k)
+        for (size_t p = 0; p < nij; ++p) {
+            const float e = e3 ? e3[k * nij + p] : e31d[k];
+            dtrp[p] = dtrp[p] + (double)(vel[k * nij + p] * m2d[p] * e) * 1.0;
+        }
+}
+
+/* src/cdfvhst.f90:167-178: e3m = e3*m2d (r4, :170-171), then
+ *   dheat += xt*e3m*pp_rau0*pp_rcp*1.d0 ; dsalt += xs*e3m*1.d0   (pp_rau0 = 1000., pp_rcp = 4000., r4) */
+void oracle_vhst_transport(int npi, int npj, int npk, const float *xt, const float *xs, const float *m2d,
+                           const float *e3, const float *e31d, double *dheat, double *dsalt) {
+    const size_t nij = (size_t)npi * npj;
+    const float pp_rau0 = 1000.f, pp_rcp = 4000.f;
+    memset(dheat, 0, nij * 8);
+    memset(dsalt, 0, nij * 8);
+    for (int k = 0; k < npk; ++k)
+        for (size_t p = 0; p < nij; ++p) {
+            const float e3m = (e3 ? e3[k * nij + p] : e31d[k]) * m2d[p];
+            dheat[p] = dheat[p] + (double)(xt[k * nij + p] * e3m * pp_rau0 * pp_rcp) * 1.0;
+            dsalt[p] = dsalt[p] + (double)(xs[k * nij + p] * e3m) * 1.0;
+        }
+}

@@ -37,6 +37,8 @@ def write_mesh(d, g):
         _var(f, "gdepw_1d", "f4", ("t", "z"), g["gdepw_1d"][None])
         _var(f, "gdept_1d", "f4", ("t", "z"), g["gdept_1d"][None])
         _var(f, "e3t_1d", "f4", ("t", "z"), g["e3t_1d"][None])
+        hdepw = (g["e3t_0"] * g["tmask"]).sum(axis=0).astype(np.float32)          # depth of the sea floor
+        _var(f, "hdepw", "f4", ("t", "y", "x"), hdepw[None])
     with _new(os.path.join(d, "mask.nc"), dims) as f:
         for nm in ("tmask", "umask", "vmask", "fmask"):
             _var(f, nm, "i1", ("t", "z", "y", "x"), g[nm][None].astype(np.int8))

@@ -93,3 +93,23 @@ def curl(un, vn, e1u, e2v, e1f, e2f, lperio=False, ltpoint=False, ff=None):
     lib.oracle_curl(C.c_int(npi), C.c_int(npj), _p(un), _p(vn), _p(e1u), _p(e2v), _p(e1f), _p(e2f),
                     C.c_int(1 if lperio else 0), C.c_int(1 if ltpoint else 0), _pp(ffc), _p(out))
     return out
+
+
+def vint_transport(vel, m2d, e3=None, e31d=None):
+    """sum_k vel*m2d*e3*1.d0 (src/cdfvtrp.f90:211-218) -> (npj,npi) r8."""
+    lib = load()
+    vel, m2d, e3, e31d = map(_f, (vel, m2d, e3, e31d))
+    npk, npj, npi = vel.shape
+    out = np.empty((npj, npi), np.float64)
+    lib.oracle_vint_transport(C.c_int(npi), C.c_int(npj), C.c_int(npk), _p(vel), _p(m2d), _pp(e3), _pp(e31d), _p(out))
+    return out
+
+
+def vhst_transport(xt, xs, m2d, e3=None, e31d=None):
+    """src/cdfvhst.f90:167-178 for one pair -> (heat, salt), each (npj,npi) r8."""
+    lib = load()
+    xt, xs, m2d, e3, e31d = map(_f, (xt, xs, m2d, e3, e31d))
+    npk, npj, npi = xt.shape
+    h, s = np.empty((npj, npi), np.float64), np.empty((npj, npi), np.float64)
+    lib.oracle_vhst_transport(C.c_int(npi), C.c_int(npj), C.c_int(npk), _p(xt), _p(xs), _p(m2d), _pp(e3), _pp(e31d), _p(h), _p(s))
+    return h, s

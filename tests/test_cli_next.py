@@ -1,0 +1,107 @@
+"""The first 'next' tools of SURVEY.md 8f rank 2, vertically integrated transports per grid cell:
+cdfvhst (src/cdfvhst.f90) and cdfvtrp (src/cdfvtrp.f90).  Kernel parity through the C ABI (bit-exact:
+r4 products as written, r8 sums in level order) and whole runs of the Fortran programs."""
+import os
+
+import numpy as np
+import pytest
+
+import nemo_files
+import oracle_tools
+import synth
+from test_cli import read_nc, run, tools  # noqa: F401
+from test_transport import tracer_fields
+
+
+def test_oracle_vint_and_vhst_match_numpy_restatement_bitwise():
+    g = synth.make_grid(19, 13, 5, seed=4)
+    t, s, u, v = tracer_fields(g, 1)
+    want = np.zeros(g["e2u"].shape)
+    for k in range(5):
+        want += ((u[k] * g["e2u"]) * g["e3u_0"][k]).astype(np.float64)
+    assert np.array_equal(oracle_tools.vint_transport(u, g["e2u"], e3=g["e3u_0"]), want)
+    wh, ws = np.zeros(g["e1v"].shape), np.zeros(g["e1v"].shape)
+    for k in range(5):
+        em = (g["e3v_0"][k] * g["e1v"]).astype(np.float32)
+        wh += (((t[k] * em).astype(np.float32) * np.float32(1000)).astype(np.float32) * np.float32(4000)).astype(np.float64)
+        ws += (s[k] * em).astype(np.float64)
+    h, sl = oracle_tools.vhst_transport(t, s, g["e1v"], e3=g["e3v_0"])
+    assert np.array_equal(h, wh) and np.array_equal(sl, ws)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("npi,npj,npk", [(24, 18, 7), (182, 149, 31), (1, 1, 1), (5, 3, 2), (1023, 7, 3)])
+def test_hip_vint_and_vhst_equal_oracle_bitwise(gpu, npi, npj, npk):
+    import torch
+
+    g = synth.make_grid(npi, npj, npk, seed=npi + 2)
+    t, s, u, v = tracer_fields(g, 3)
+    assert np.array_equal(gpu.vint_transport(u, g["e2u"], e3=g["e3u_0"]), oracle_tools.vint_transport(u, g["e2u"], e3=g["e3u_0"]))
+    assert np.array_equal(gpu.vint_transport(v, g["e1v"], e31d=g["e3t_1d"]), oracle_tools.vint_transport(v, g["e1v"], e31d=g["e3t_1d"]))
+    for kw in (dict(e3=g["e3v_0"]), dict(e31d=g["e3t_1d"])):
+        gh, gs = gpu.vhst_transport(t, s, g["e1v"], **kw)
+        rh, rs = oracle_tools.vhst_transport(t, s, g["e1v"], **kw)
+        assert np.array_equal(gh, rh) and np.array_equal(gs, rs)
+    dev = [torch.from_numpy(x).cuda() for x in (t, s, g["e1v"], g["e3v_0"])]
+    dh, ds = gpu.vhst_transport(dev[0], dev[1], dev[2], e3=dev[3])            # resident arrays
+    rh, rs = oracle_tools.vhst_transport(t, s, g["e1v"], e3=g["e3v_0"])
+    assert np.array_equal(dh.cpu().numpy(), rh) and np.array_equal(ds.cpu().numpy(), rs)
+
+
+@pytest.mark.parametrize("tool,flag", [("cdfvhst", "-f"), ("cdfvtrp", "-u")])
+def test_usage_and_unknown_option(tools, tmp_path, tool, flag):  # noqa: F811
+    rc, out, _ = run(tool, [], tmp_path)
+    assert rc == 0 and "usage :" in out.splitlines()[0] and tool in out.splitlines()[0]
+    rc, out, _ = run(tool, ["-thisisnotanoption"], tmp_path)
+    assert rc == 99 and "unknown option" in out
+    if tool == "cdfvtrp":
+        rc, out, _ = run(tool, ["-u", "U.nc", "-v", "V.nc"], tmp_path)
+        assert rc == 99 and "missing" in out
+
+
+@pytest.mark.gpu
+def test_cdfvhst_and_cdfvtrp_end_to_end(tools, tmp_path):  # noqa: F811
+    d = str(tmp_path)
+    g, rec = nemo_files.make_case(d, npi=26, npj=19, npk=6, npt=2)
+    npk = 6
+    rc, out, err = run("cdfvT", ["-c", "SYN", "-l", "y0001"], d)
+    assert rc == 0, out + err
+    vt, _, _ = read_nc(os.path.join(d, "vt.nc"))
+    rc, out, err = run("cdfvhst", ["-f", "vt.nc", "-o", "vh.nc"], d)
+    assert rc == 0, out + err
+    var, att, _ = read_nc(os.path.join(d, "vh.nc"))
+    h, s = oracle_tools.vhst_transport(vt["vomevt"][0], vt["vomevs"][0], g["e1v"], e3=g["e3v_0"])
+    assert np.array_equal(var["somevt"][0], h.astype(np.float32)) and np.array_equal(var["somevs"][0], s.astype(np.float32))
+    h, s = oracle_tools.vhst_transport(vt["vozout"][0], vt["vozous"][0], g["e2u"], e3=g["e3u_0"])
+    assert np.array_equal(var["sozout"][0], h.astype(np.float32)) and np.array_equal(var["sozous"][0], s.astype(np.float32))
+    assert att["somevt"]["units"] == b"W" and att["sozous"]["long_name"] == b"Zonal_salt_transport"
+    rc, out, err = run("cdfvhst", ["-f", "vt.nc", "-full", "-o", "vhf.nc"], d)
+    assert rc == 0, out + err
+    varf, _, _ = read_nc(os.path.join(d, "vhf.nc"))
+    h, _ = oracle_tools.vhst_transport(vt["vomevt"][0], vt["vomevs"][0], g["e1v"], e31d=g["e3t_1d"])
+    assert np.array_equal(varf["somevt"][0], h.astype(np.float32))
+
+    rc, out, err = run("cdfvtrp", ["-u", "SYN_y0001_gridU.nc", "-v", "SYN_y0001_gridV.nc", "-bathy", "-o", "tr.nc"], d)
+    assert rc == 0, out + err
+    var, att, _ = read_nc(os.path.join(d, "tr.nc"))
+    tm = g["tmask"][0].astype(np.float32)
+    hdepw = (g["e3t_0"] * g["tmask"]).sum(axis=0).astype(np.float32)
+    for t in range(2):
+        du = oracle_tools.vint_transport(rec["u"][t], g["e2u"], e3=g["e3u_0"])
+        dv = oracle_tools.vint_transport(rec["v"][t], g["e1v"], e3=g["e3v_0"])
+        assert np.array_equal(var["sozoutrp"][t], du.astype(np.float32)) and np.array_equal(var["somevtrp"][t], dv.astype(np.float32))
+        # -bathy (src/cdfvtrp.f90:224-259): rotation onto the bathymetric slope, through the host's libm
+        wu, wv = np.zeros_like(du), np.zeros_like(dv)
+        wu[:, 1:] = 0.5 * (du[:, 1:] + du[:, :-1])
+        wu[:, 0] = wu[:, -2]
+        wv[1:, :] = 0.5 * (dv[1:, :] + dv[:-1, :])
+        dhdx, dhdy = np.zeros_like(tm), np.zeros_like(tm)
+        dhdx[:, 1:-1] = (hdepw[:, 2:] - hdepw[:, :-2]) / (g["e1u"][:, 1:-1] + g["e1u"][:, :-2]) * tm[:, 1:-1]
+        dhdy[1:-1, :] = (hdepw[2:, :] - hdepw[:-2, :]) / (g["e2v"][1:-1, :] + g["e2v"][:-2, :]) * tm[1:-1, :]
+        al = (np.arctan2(dhdx, dhdy) * tm).astype(np.float32)
+        along = (wu * np.cos(al) + wv * np.sin(al)) * tm
+        cross = (-wu * np.sin(al) + wv * np.cos(al)) * tm
+        scale = np.abs(along).max()
+        assert np.allclose(var["soastrp"][t], along, rtol=0, atol=2e-6 * scale)
+        assert np.allclose(var["socstrp"][t], cross, rtol=0, atol=2e-6 * scale)
+    assert att["soastrp"]["long_name"] == b"Along_Slope_Barotropic_Transp"
