@@ -1,0 +1,254 @@
+// mean.hip -- cdfmean weighted sums per level and sub-basin (C ABI section "cdfmean").
+// Reference loop src/cdfmean.f90:415-431, per level and basin:
+//     zv     = zv * zmask                                                   (:410)
+//     dsurf  = SUM(DBLE(          e1 * e2      * zmask * ibmask(b,:,:)))
+//     dvol2d = SUM(DBLE(          e1 * e2 * e3 * zmask * ibmask(b,:,:)))
+//     dsum2d = SUM(DBLE(zv      * e1 * e2 * e3         * ibmask(b,:,:)))
+//     dvar2d = SUM(DBLE(zv * zv * e1 * e2 * e3         * ibmask(b,:,:)))
+// Every product is formed in r4, left to right, exactly as written, then widened; the r8 SUMs are
+// regrouped in a fixed order (|d| <= 1e-13 * sum|terms|).  Same layout of the work as cdfheatc: one
+// workgroup owns a set of cells of the horizontal plane for ALL levels, keeps e1, e2 and the basin
+// values in registers and streams zv / e3 / mask past them (12 bytes per cell and level).
+#include "common.hpp"
+#include "reduce.hpp"
+
+using namespace cdft;
+
+struct cdft_mean_plan {
+    int npi = 0, npj = 0, npk = 0, nb = 0;
+    float *e1 = nullptr, *e2 = nullptr, *e3 = nullptr, *e31d = nullptr, *mask = nullptr;
+    int16_t *ib = nullptr;          // (nb,npi,npj), basin index fastest
+    double *partial = nullptr;      // [npk][nblk][nb][4]
+    int nblk = 0;
+    bool mesh_set = false;
+    DevBuf st_zv, st_out;
+};
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kVPT     = 2;     // vectors per lane
+constexpr int kMaxNB   = 8;
+
+struct MeanArgs {
+    const float *e1, *e2, *e3, *e31d, *mask, *zv;
+    const int16_t *ib;
+    int64_t nij;
+    int npk, nb, nblk;
+    double *partial;
+};
+
+// NB: basin capacity of the instantiation (1, 2, 4 or 8): every loop over basins is unrolled so that the
+// accumulators stay in registers (a run-time bound put them in scratch memory: 6x slower)
+template <int VEC, bool FULL, int NB>
+__global__ void __launch_bounds__(kThreads) mean_level_kernel(MeanArgs a) {
+    extern __shared__ double wsum[];                   // [nwaves][nb*4]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = kThreads / 64;
+    int64_t q[kVPT];
+    float e1[kVPT][VEC], e2[kVPT][VEC], fb[kVPT][VEC][NB];
+    bool ok[kVPT][VEC];
+#pragma unroll
+    for (int v = 0; v < kVPT; ++v) {
+        q[v] = ((((int64_t)blockIdx.x * nwaves + wave) * kVPT + v) * 64 + lane) * VEC;   // first cell of the vector
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+            const int64_t p = q[v] + c;
+            ok[v][c] = p < a.nij;
+            const int64_t pc = ok[v][c] ? p : 0;
+            e1[v][c] = ok[v][c] ? a.e1[pc] : 0.f;      // cells past the plane contribute exact zeros
+            e2[v][c] = a.e2[pc];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) fb[v][c][b] = (b < a.nb) ? (float)a.ib[pc * a.nb + min(b, a.nb - 1)] : 0.f;
+        }
+    }
+    for (int k = 0; k < a.npk; ++k) {
+        const int64_t base = (int64_t)k * a.nij;
+        float zv[kVPT][VEC], e3[kVPT][VEC], mk[kVPT][VEC];
+#pragma unroll
+        for (int v = 0; v < kVPT; ++v) {
+            if constexpr (VEC == 4) {                  // nij % 4 == 0 and 16-byte aligned bases on this path
+                const int64_t qc = ok[v][0] ? q[v] : 0;
+                const f4a z = ld_stream4(a.zv + base + qc), m = ld_stream4(a.mask + base + qc);
+                zv[v][0] = z.x; zv[v][1] = z.y; zv[v][2] = z.z; zv[v][3] = z.w;
+                mk[v][0] = m.x; mk[v][1] = m.y; mk[v][2] = m.z; mk[v][3] = m.w;
+                if (!FULL) {
+                    const f4a e = ld_stream4(a.e3 + base + qc);
+                    e3[v][0] = e.x; e3[v][1] = e.y; e3[v][2] = e.z; e3[v][3] = e.w;
+                }
+                if (!ok[v][0]) { zv[v][0] = zv[v][1] = zv[v][2] = zv[v][3] = 0.f; }
+            } else {
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) {
+                    const int64_t pc = ok[v][c] ? q[v] + c : 0;
+                    zv[v][c] = ok[v][c] ? a.zv[base + pc] : 0.f;
+                    mk[v][c] = a.mask[base + pc];
+                    if (!FULL) e3[v][c] = a.e3[base + pc];
+                }
+            }
+            if (FULL) {
+                const float z = a.e31d[k];
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) e3[v][c] = z;
+            }
+        }
+        double s[NB][4];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) { s[b][0] = s[b][1] = s[b][2] = s[b][3] = 0.0; }
+#pragma unroll
+        for (int v = 0; v < kVPT; ++v)
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) {
+                const float m = mk[v][c];
+                const float zm = __fmul_rn(zv[v][c], m);                                  // :410
+                const float ar = __fmul_rn(e1[v][c], e2[v][c]);
+                const float t_surf = __fmul_rn(ar, m);                                     // e1*e2*zmask
+                const float t_vol  = __fmul_rn(__fmul_rn(ar, e3[v][c]), m);                // e1*e2*e3*zmask
+                const float t_sum  = __fmul_rn(__fmul_rn(__fmul_rn(zm, e1[v][c]), e2[v][c]), e3[v][c]);
+                const float t_var  = __fmul_rn(__fmul_rn(__fmul_rn(__fmul_rn(zm, zm), e1[v][c]), e2[v][c]), e3[v][c]);
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {                 // basins past nb have f = 0: they add exact zeros
+                    const float f = fb[v][c][b];
+                    s[b][0] += (double)__fmul_rn(t_surf, f);
+                    s[b][1] += (double)__fmul_rn(t_vol, f);
+                    s[b][2] += (double)__fmul_rn(t_sum, f);
+                    s[b][3] += (double)__fmul_rn(t_var, f);
+                }
+            }
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const double t = wave_sum(s[b][c]);
+                if (lane == 0 && b < a.nb) wsum[(wave * a.nb + b) * 4 + c] = t;
+            }
+        __syncthreads();
+        if ((int)threadIdx.x < a.nb * 4) {
+            double t = 0.0;
+            for (int w = 0; w < nwaves; ++w) t += wsum[w * a.nb * 4 + threadIdx.x];
+            a.partial[((int64_t)k * a.nblk + blockIdx.x) * a.nb * 4 + threadIdx.x] = t;
+        }
+        __syncthreads();
+    }
+}
+
+// sums[k][nb][4] = the partials of level k added over the blocks in block order
+__global__ void __launch_bounds__(kThreads) mean_final_kernel(const double *__restrict__ partial, int nblk, int nq,
+                                                              double *__restrict__ sums) {
+    __shared__ double scratch[16];
+    const int k = blockIdx.x;
+    for (int c = 0; c < nq; ++c) {
+        double s = 0.0;
+        for (int b = threadIdx.x; b < nblk; b += kThreads) s += partial[((int64_t)k * nblk + b) * nq + c];
+        const double t = block_sum(s, scratch);
+        if (threadIdx.x == 0) sums[(int64_t)k * nq + c] = t;
+        __syncthreads();
+    }
+}
+
+int keep(void **dst, const void *src, size_t bytes, int space, hipStream_t st) {
+    if (!*dst && hipMalloc(dst, bytes + 64) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(CDFT_ERR_ALLOC, "cdfmean: device allocation of %zu bytes failed", bytes);
+    }
+    CDFT_HIP(hipMemcpyAsync(*dst, src, bytes, space == CDFT_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+    return CDFT_OK;
+}
+
+bool al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) % 16) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+int cdft_mean_create(cdft_mean_plan **plan, int npiglo, int npjglo, int npk, int nbasins) {
+    if (!plan) return fail(CDFT_ERR_ARG, "cdft_mean_create: NULL plan pointer");
+    *plan = nullptr;
+    if (npiglo < 1 || npjglo < 1 || npk < 1 || nbasins < 1 || nbasins > kMaxNB)
+        return fail(CDFT_ERR_ARG, "cdft_mean_create: bad sizes %d x %d x %d, %d basins (1..%d)", npiglo, npjglo, npk,
+                    nbasins, kMaxNB);
+    CDFT_TRY(require_device());
+    cdft_mean_plan *p = new cdft_mean_plan;
+    p->npi = npiglo; p->npj = npjglo; p->npk = npk; p->nb = nbasins;
+    const int64_t nij = (int64_t)npiglo * npjglo;
+    p->nblk = (int)((nij + kThreads * kVPT - 1) / (kThreads * kVPT));            // blocks when VEC = 1 (the most)
+    if (hipMalloc((void **)&p->partial, (size_t)npk * p->nblk * nbasins * 4 * sizeof(double)) != hipSuccess) {
+        (void)hipGetLastError();
+        delete p;
+        return fail(CDFT_ERR_ALLOC, "cdft_mean_create: device allocation failed");
+    }
+    *plan = p;
+    return CDFT_OK;
+}
+
+int cdft_mean_set_mesh(cdft_mean_plan *p, const float *e1, const float *e2, const float *e3, const float *e31d,
+                       const float *zmask, const int16_t *ibmask, int memspace, void *stream) {
+    if (!p || !e1 || !e2 || !zmask || !ibmask || (!e3 && !e31d) || (e3 && e31d))
+        return fail(CDFT_ERR_ARG, "cdft_mean_set_mesh: need e1, e2, zmask, ibmask and exactly one of e3 / e31d");
+    hipStream_t st = as_stream(stream);
+    const size_t nij = (size_t)p->npi * p->npj, n3 = nij * p->npk;
+    CDFT_TRY(keep((void **)&p->e1, e1, nij * 4, memspace, st));
+    CDFT_TRY(keep((void **)&p->e2, e2, nij * 4, memspace, st));
+    if (e3) {
+        CDFT_TRY(keep((void **)&p->e3, e3, n3 * 4, memspace, st));
+        if (p->e31d) { (void)hipFree(p->e31d); p->e31d = nullptr; }
+    } else {
+        CDFT_TRY(keep((void **)&p->e31d, e31d, (size_t)p->npk * 4, memspace, st));
+        if (p->e3) { (void)hipFree(p->e3); p->e3 = nullptr; }
+    }
+    CDFT_TRY(keep((void **)&p->mask, zmask, n3 * 4, memspace, st));
+    CDFT_TRY(keep((void **)&p->ib, ibmask, nij * p->nb * 2, memspace, st));
+    CDFT_HIP(hipStreamSynchronize(st));
+    p->mesh_set = true;
+    return CDFT_OK;
+}
+
+int cdft_mean_compute(cdft_mean_plan *p, const float *zv, int in_space, double *sums, int out_space, void *stream) {
+    if (!p || !zv || !sums) return fail(CDFT_ERR_ARG, "cdft_mean_compute: NULL argument");
+    if (!p->mesh_set) return fail(CDFT_ERR_STATE, "cdft_mean_compute: cdft_mean_set_mesh has not succeeded");
+    hipStream_t st = as_stream(stream);
+    const int64_t nij = (int64_t)p->npi * p->npj;
+    const void *dz;
+    CDFT_TRY(to_device(zv, (size_t)nij * p->npk * 4, in_space, p->st_zv, st, &dz));
+    const int nq = p->nb * 4;
+    const size_t ob = (size_t)p->npk * nq * 8;
+    double *dout = sums;
+    if (out_space == CDFT_MEM_HOST) { CDFT_TRY(p->st_out.reserve(ob)); dout = (double *)p->st_out.ptr; }
+    MeanArgs a;
+    a.e1 = p->e1; a.e2 = p->e2; a.e3 = p->e3; a.e31d = p->e31d; a.mask = p->mask; a.zv = (const float *)dz; a.ib = p->ib;
+    a.nij = nij; a.npk = p->npk; a.nb = p->nb; a.partial = p->partial;
+    const bool vec4 = (nij % 4 == 0) && al16(dz) && al16(p->mask) && (!p->e3 || al16(p->e3));
+    const int vec = vec4 ? 4 : 1;
+    a.nblk = (int)(((nij + vec - 1) / vec + kThreads * kVPT - 1) / (kThreads * kVPT));
+    const dim3 grid(a.nblk), block(kThreads);
+    const size_t shmem = (size_t)(kThreads / 64) * nq * sizeof(double);
+    const bool full = p->e31d != nullptr;
+#define CDFT_MEAN(NBC) do { \
+        if (vec4 && full)       hipLaunchKernelGGL((mean_level_kernel<4, true, NBC>), grid, block, shmem, st, a); \
+        else if (vec4)          hipLaunchKernelGGL((mean_level_kernel<4, false, NBC>), grid, block, shmem, st, a); \
+        else if (full)          hipLaunchKernelGGL((mean_level_kernel<1, true, NBC>), grid, block, shmem, st, a); \
+        else                    hipLaunchKernelGGL((mean_level_kernel<1, false, NBC>), grid, block, shmem, st, a); } while (0)
+    if (p->nb == 1)      CDFT_MEAN(1);
+    else if (p->nb == 2) CDFT_MEAN(2);
+    else if (p->nb <= 4) CDFT_MEAN(4);
+    else                 CDFT_MEAN(8);
+#undef CDFT_MEAN
+    CDFT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(mean_final_kernel, dim3(p->npk), dim3(kThreads), 0, st, p->partial, a.nblk, nq, dout);
+    CDFT_LAUNCH_CHECK();
+    if (out_space == CDFT_MEM_HOST) {
+        CDFT_HIP(hipMemcpyAsync(sums, dout, ob, hipMemcpyDeviceToHost, st));
+        CDFT_HIP(hipStreamSynchronize(st));
+    }
+    return CDFT_OK;
+}
+
+int cdft_mean_destroy(cdft_mean_plan *p) {
+    if (!p) return CDFT_OK;
+    void *ptrs[] = {p->e1, p->e2, p->e3, p->e31d, p->mask, p->ib, p->partial};
+    for (void *q : ptrs) if (q) (void)hipFree(q);
+    p->st_zv.release(); p->st_out.release();
+    delete p;
+    return CDFT_OK;
+}
+
+}  // extern "C"

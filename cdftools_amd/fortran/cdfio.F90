@@ -53,12 +53,16 @@ MODULE cdfio
   INTERFACE putvar1d
      MODULE PROCEDURE putvar1d4, putvar1d8
   END INTERFACE
+  INTERFACE putvar0d
+     MODULE PROCEDURE putvar0dt, putvar0ds
+  END INTERFACE
   INTERFACE getatt
      MODULE PROCEDURE getattr, getatti, getattc
   END INTERFACE
 
+  PUBLIC :: getvaratt
   PUBLIC :: chkfile, chkvar, getdim, getvdim, getspval, getatt, getvar, getvar1d, getvare3, getvar3d
-  PUBLIC :: create, createvar, putatt, putheadervar, putvar, putvar1d, closeout, ncopen, copyatt, ERR_HDL
+  PUBLIC :: create, createvar, putatt, putheadervar, putvar, putvar1d, putvar0d, closeout, ncopen, copyatt, ERR_HDL
 
 CONTAINS
 
@@ -324,6 +328,23 @@ CONTAINS
     ENDIF
     istatus = NF90_CLOSE(incid)
   END FUNCTION getatti
+
+  INTEGER(KIND=4) FUNCTION getvaratt(cdfile, cdvar, cdunits, pmissing_value, cdlong_name, cdshort_name)
+    !! units, missing value, long and short name of a variable; an absent attribute leaves its argument
+    !! untouched and only the status of the last lookup is returned (src/cdfio.F90:488-514)
+    CHARACTER(LEN=*), INTENT(in)    :: cdfile, cdvar
+    REAL(KIND=4),     INTENT(out)   :: pmissing_value
+    CHARACTER(LEN=*), INTENT(inout) :: cdunits, cdlong_name, cdshort_name
+    INTEGER(KIND=4) :: istatus, incid, idv
+    istatus = NF90_OPEN(cdfile, NF90_NOWRITE, incid)
+    istatus = NF90_INQ_VARID(incid, cdvar, idv)
+    IF ( NF90_INQUIRE_ATTRIBUTE(incid, idv, 'units') == NF90_NOERR ) istatus = NF90_GET_ATT(incid, idv, 'units', cdunits)
+    pmissing_value = getspval(cdfile, cdvar)
+    IF ( NF90_INQUIRE_ATTRIBUTE(incid, idv, 'long_name') == NF90_NOERR ) istatus = NF90_GET_ATT(incid, idv, 'long_name', cdlong_name)
+    getvaratt = NF90_INQUIRE_ATTRIBUTE(incid, idv, 'short_name')
+    IF ( getvaratt == NF90_NOERR ) getvaratt = NF90_GET_ATT(incid, idv, 'short_name', cdshort_name)
+    istatus = NF90_CLOSE(incid)
+  END FUNCTION getvaratt
 
   CHARACTER(LEN=256) FUNCTION getattc(cdfile, cdvar, cdatt, cdum)
     CHARACTER(LEN=*), INTENT(in) :: cdfile, cdvar, cdatt
@@ -838,6 +859,29 @@ CONTAINS
     CALL slab_start(kout, kid, klev, itime, istart)
     putvarzo = NF90_PUT_VAR(kout, kid, ptab, start=istart, count=(/ kpi, kpj, 1, 1 /))
   END FUNCTION putvarzo
+
+  INTEGER(KIND=4) FUNCTION putvar0dt(kout, kid, pvalue, ktime)
+    !! one value, given as a (1,1) array, at record ktime (src/cdfio.F90:2809-2848)
+    INTEGER(KIND=4),              INTENT(in) :: kout, kid
+    REAL(KIND=4), DIMENSION(1,1), INTENT(in) :: pvalue
+    INTEGER(KIND=4), OPTIONAL,    INTENT(in) :: ktime
+    INTEGER(KIND=4) :: itime, istart(4)
+    itime = 1 ; IF ( PRESENT(ktime) ) itime = ktime
+    CALL slab_start(kout, kid, 1, itime, istart)
+    putvar0dt = NF90_PUT_VAR(kout, kid, pvalue, start=istart, count=(/ 1, 1, 1, 1 /))
+  END FUNCTION putvar0dt
+
+  INTEGER(KIND=4) FUNCTION putvar0ds(kout, kid, pvalue, ktime)
+    !! the same for a scalar argument (src/cdfio.F90:2850-2892)
+    INTEGER(KIND=4),           INTENT(in) :: kout, kid
+    REAL(KIND=4),              INTENT(in) :: pvalue
+    INTEGER(KIND=4), OPTIONAL, INTENT(in) :: ktime
+    REAL(KIND=4) :: ztab(1,1)
+    ztab = pvalue
+    IF ( PRESENT(ktime) ) THEN ; putvar0ds = putvar0dt(kout, kid, ztab, ktime)
+    ELSE                       ; putvar0ds = putvar0dt(kout, kid, ztab)
+    ENDIF
+  END FUNCTION putvar0ds
 
   INTEGER(KIND=4) FUNCTION axis_id(cdtype)
     CHARACTER(LEN=1), INTENT(in) :: cdtype

@@ -1,0 +1,403 @@
+PROGRAM cdfmean
+  !!======================================================================
+  !!                     ***  PROGRAM  cdfmean  ***
+  !! Weighted mean (and variance, sum) of a field, per level and over the volume, in a window and / or
+  !! per sub-basin.
+  !!
+  !! Drop-in for the reference tool (src/cdfmean.f90): same options, same text on stdout and in
+  !! cdfmean.txt [cdfvar.txt, cdfsum.txt], same cdfmean.nc (mean_<var>, mean_3D<var> [var_, var_3D, sum_,
+  !! sum_3D] [_<basin>], :556-625).  The four weighted sums of every level and basin (:405-424) run on the
+  !! GPU for all levels of a record at once (cdft_mean_*: r4 products as written, r8 sums).
+  !! -zeromean (a second pass that rewrites the whole field, :500-527) is not carried: explicit STOP 99.
+  !!======================================================================
+  USE ISO_C_BINDING
+  USE cdfio
+  USE modcdfnames
+  USE cdftools_hip
+  IMPLICIT NONE
+
+  INTEGER(KIND=4) :: jk, jt, it, ik, jbasin, ivarb, narg, ijarg, ierr, idep, idep_max
+  INTEGER(KIND=4) :: iimin = 0, iimax = 0, ijmin = 0, ijmax = 0, ikmin = 0, ikmax = 0
+  INTEGER(KIND=4) :: npiglo, npjglo, npk, npt, npiglo_fi, npjglo_fi, npk_fi, nvpk, nbasin = 1
+  INTEGER(KIND=4) :: numout = 10, numvar = 11, numsum = 12, ikx = 1, iky = 1, nvars, nvars_bas, ncout
+  INTEGER(KIND=4), ALLOCATABLE :: n_sum(:), n_sum3d(:), n_mean(:), n_mean3d(:), n_var(:), n_var3d(:), ipk(:), id_varout(:)
+  INTEGER(KIND=2), ALLOCATABLE :: ibmask(:,:,:)                    ! (nbasin, npiglo, npjglo)
+  REAL(KIND=4) :: zspval, rdummy(1,1)
+  REAL(KIND=4), ALLOCATABLE, TARGET :: e3(:,:,:), e31d(:)
+  REAL(KIND=4), ALLOCATABLE :: gdep(:), zdep(:), e1(:,:), e2(:,:), zv(:,:,:), zmask(:,:,:), zwk(:,:)
+  REAL(KIND=4), ALLOCATABLE :: rdumlon(:,:), rdumlat(:,:), rdummymean(:,:)
+  REAL(KIND=8) :: dsurf, dvol2d, dsum2d, dvar2d
+  REAL(KIND=8), ALLOCATABLE :: dtim(:), dvmeanout(:), dvariance(:), dvol(:), dsum(:), dvar(:)
+  REAL(KIND=8), ALLOCATABLE :: dvmeanout3d(:,:), dvariance3d(:,:), dsums(:,:,:)      ! dsums(4, nbasin, nvpk)
+  CHARACTER(LEN=256) :: cv_nam, cv_dep, cf_e3, cf_in = 'none', cf_out = 'cdfmean.txt', cf_var = 'cdfvar.txt'
+  CHARACTER(LEN=256) :: cf_sum = 'cdfsum.txt', cf_ncout = 'cdfmean.nc', cf_zerom = 'zeromean.nc', clbas = ''
+  CHARACTER(LEN=256) :: cl_prefix = '', ctype = ' ', clunits = ' ', cllong_name = ' ', clshort_name = ' ', cglobal, cldum
+  CHARACTER(LEN=20)  :: cv_e1, cv_e2, cv_e3, cv_e31d, cv_msk = ''
+  CHARACTER(LEN=256), ALLOCATABLE :: clv_dep(:), cbasins(:)
+  TYPE(variable), ALLOCATABLE :: stypvar(:)
+  TYPE(C_PTR) :: plan, pe3, pe31d
+  LOGICAL :: lbas = .FALSE., lfull = .FALSE., lvar = .FALSE., lsum = .FALSE., lzeromean = .FALSE., lnodep = .FALSE., lchk
+  !!----------------------------------------------------------------------
+  CALL ReadCdfNames()
+  narg = COMMAND_ARGUMENT_COUNT()
+  IF ( narg == 0 ) THEN
+     PRINT *, ' usage : cdfmean -f IN-file -v IN-var -p C-point  ...'
+     PRINT *, '       ... [-w imin imax jmin jmax kmin kmax] [-full] [-var] [-zeromean]...'
+     PRINT *, '       ... [-M MSK-file VAR-mask ] [-B BASIN-mask LST-basins] [-P OUT-prefix]'
+     PRINT *, '       ... [-o OUT-file] [ -ot OUTASCII-file] [-oz ZEROMEAN-file] '
+     PRINT *, '       ... [-ov VAR-file] [-os SUM-file][ -vvl ] [-S]'
+     PRINT *, '      '
+     PRINT *, '     PURPOSE :'
+     PRINT *, '        Compute the weighted mean value of the field: a horizontal mean for each level and'
+     PRINT *, '        the mean over the volume, optionally in a window, with a non standard mask or per'
+     PRINT *, '        sub-basin.  MI355X build: the weighted sums run on the GPU.'
+     PRINT *, '      '
+     PRINT *, '     ARGUMENTS :'
+     PRINT *, '       -f IN-file : input netcdf file.'
+     PRINT *, '       -v IN-var  : name of netcdf variable to work with.'
+     PRINT *, '       -p C-point : one of T|U|V|F|W, the position of IN-var on the C-grid.'
+     PRINT *, '      '
+     PRINT *, '     OPTIONS :'
+     PRINT *, '       [-w imin imax jmin jmax kmin kmax] : spatial window (0 for a whole direction)'
+     PRINT *, '       [-full ] : full steps instead of partial steps.'
+     PRINT *, '       [-var ]  : also compute the spatial variance of IN-var.'
+     PRINT *, '       [-S ]    : also save the weighted sums.'
+     PRINT *, '       [-M MSK-file VAR-mask] : non standard mask file and variable'
+     PRINT *, '       [-B BASIN-mask LST-basins] : means for the sub-basins of the blank separated list'
+     PRINT *, '       [-P OUT-prefix] : prepended to every output file name.'
+     PRINT *, '       [-o OUT-file] [-ot OUTASCII-file] [-ov VAR-file] [-os SUM-file] : output names instead of'
+     PRINT *, '              ', TRIM(cf_ncout), ' ', TRIM(cf_out), ' ', TRIM(cf_var), ' ', TRIM(cf_sum)
+     PRINT *, '       [-vvl ] : time-varying vertical metrics.'
+     PRINT *, '       [-zeromean ] [-oz ZEROMEAN-file] : accepted for compatibility, not available in this build.'
+     PRINT *, '      '
+     PRINT *, '     REQUIRED FILES :'
+     PRINT *, '       Files ', TRIM(cn_fhgr), ', ', TRIM(cn_fzgr), ', ', TRIM(cn_fmsk)
+     PRINT *, '      '
+     PRINT *, '     OUTPUT : '
+     PRINT *, '       - netcdf file : ', TRIM(cf_ncout)
+     PRINT *, '           variables : mean_<IN-var>, mean_3D_<IN-var> [var_, var_3D with -var] [sum_, sum_3D with -S]'
+     PRINT *, '       - ASCII files : ', TRIM(cf_out), ' [', TRIM(cf_var), '] [', TRIM(cf_sum), '], also sent to standard output.'
+     STOP
+  ENDIF
+
+  cglobal = 'Partial step computation'
+  ijarg = 1
+  DO WHILE ( ijarg <= narg )
+     CALL GET_COMMAND_ARGUMENT(ijarg, cldum) ; ijarg = ijarg + 1
+     SELECT CASE ( cldum )
+     CASE ( '-f'        ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cf_in ) ; ijarg = ijarg + 1
+     CASE ( '-v'        ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cv_nam) ; ijarg = ijarg + 1
+     CASE ( '-p'        ) ; CALL GET_COMMAND_ARGUMENT(ijarg, ctype ) ; ijarg = ijarg + 1
+     CASE ( '-full'     ) ; lfull     = .TRUE. ; cglobal = 'full step computation'
+     CASE ( '-var'      ) ; lvar      = .TRUE.
+     CASE ( '-zeromean' ) ; lzeromean = .TRUE.
+     CASE ( '-vvl'      ) ; lg_vvl    = .TRUE.
+     CASE ( '-w'        ) ; CALL geti(iimin) ; CALL geti(iimax) ; CALL geti(ijmin) ; CALL geti(ijmax) ; CALL geti(ikmin) ; CALL geti(ikmax)
+     CASE ( '-o'        ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cf_ncout) ; ijarg = ijarg + 1
+     CASE ( '-oz'       ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cf_zerom) ; ijarg = ijarg + 1
+     CASE ( '-ov'       ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cf_var  ) ; ijarg = ijarg + 1
+     CASE ( '-os'       ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cf_sum  ) ; ijarg = ijarg + 1
+     CASE ( '-ot'       ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cf_out  ) ; ijarg = ijarg + 1
+     CASE ( '-M'        ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cn_fmsk ) ; ijarg = ijarg + 1
+        ;                   CALL GET_COMMAND_ARGUMENT(ijarg, cv_msk  ) ; ijarg = ijarg + 1
+     CASE ( '-S'        ) ; lsum = .TRUE.
+     CASE ( '-B'        ) ; lbas = .TRUE.
+        ;                   CALL GET_COMMAND_ARGUMENT(ijarg, cn_fbasins) ; ijarg = ijarg + 1
+        ;                   CALL GetLstMask
+     CASE ( '-P'        ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cl_prefix) ; ijarg = ijarg + 1
+     CASE DEFAULT         ; PRINT *, ' ERROR : ', TRIM(cldum), ' : unknown option.' ; STOP 99
+     END SELECT
+  END DO
+  cf_ncout = TRIM(cl_prefix)//TRIM(cf_ncout)
+  cf_out   = TRIM(cl_prefix)//TRIM(cf_out  )
+  cf_var   = TRIM(cl_prefix)//TRIM(cf_var  )
+  cf_sum   = TRIM(cl_prefix)//TRIM(cf_sum  )
+
+  lchk = chkfile(cn_fhgr)
+  lchk = chkfile(cn_fzgr) .OR. lchk
+  lchk = chkfile(cn_fmsk) .OR. lchk
+  lchk = chkfile(cf_in  ) .OR. lchk
+  IF ( lbas ) lchk = chkfile(cn_fbasins) .OR. lchk
+  IF ( lchk ) STOP 99
+  IF ( lzeromean ) THEN
+     PRINT *, ' ERROR : option -zeromean is not available in the MI355X build of cdfmean.'
+     STOP 99
+  ENDIF
+  IF ( .NOT. ALLOCATED(cbasins) ) ALLOCATE( cbasins(1) )
+
+  cv_dep = 'none'
+  npiglo = getdim(cf_in, cn_x)
+  npjglo = getdim(cf_in, cn_y)
+  idep_max = 8
+  ALLOCATE( clv_dep(idep_max) )
+  clv_dep(1) = cn_z ; clv_dep(2) = 'z' ; clv_dep(3) = 'sigma' ; clv_dep(4) = 'nav_lev' ; clv_dep(5) = 'levels'
+  clv_dep(6) = 'ncatice' ; clv_dep(7) = 'icbcla' ; clv_dep(8) = 'icbsect'
+  idep = 1 ; ierr = 1000
+  DO WHILE ( ierr /= 0 .AND. idep <= idep_max )
+     npk  = getdim(cf_in, clv_dep(idep), cdtrue=cv_dep, kstatus=ierr)
+     idep = idep + 1
+  END DO
+  IF ( ierr /= 0 ) THEN
+     PRINT *, ' assume file with no depth'
+     npk = 0
+  ENDIF
+  npt  = getdim(cf_in, cn_t)
+  nvpk = getvdim(cf_in, cv_nam)
+  npiglo_fi = npiglo ; npjglo_fi = npjglo ; npk_fi = npk
+  IF ( npk == 0 ) THEN ; lnodep = .TRUE. ; npk = 1 ; npk_fi = 1
+  ENDIF
+  IF ( iimin /= 0 ) THEN ; npiglo = iimax - iimin + 1 ; ELSE ; iimin = 1
+  ENDIF
+  IF ( ijmin /= 0 ) THEN ; npjglo = ijmax - ijmin + 1 ; ELSE ; ijmin = 1
+  ENDIF
+  IF ( ikmin /= 0 ) THEN ; npk    = ikmax - ikmin + 1 ; ELSE ; ikmin = 1
+  ENDIF
+  IF ( nvpk == 2 ) nvpk = 1
+  IF ( nvpk == 3 ) nvpk = npk
+
+  WRITE(6, *) 'npiglo = ', npiglo
+  WRITE(6, *) 'npjglo = ', npjglo
+  WRITE(6, *) 'npk    = ', npk
+  WRITE(6, *) 'npt    = ', npt
+  WRITE(6, *) 'nvpk   = ', nvpk
+  WRITE(6, *) 'depth dim name is ', TRIM(cv_dep)
+
+  ALLOCATE( ibmask(nbasin,npiglo,npjglo), zmask(npiglo,npjglo,nvpk), zv(npiglo,npjglo,nvpk), zwk(npiglo,npjglo) )
+  ALLOCATE( e1(npiglo,npjglo), e2(npiglo,npjglo), dvariance3d(nbasin,npt), dvmeanout3d(nbasin,npt) )
+  ALLOCATE( gdep(npk), e31d(npk), dtim(npt), dvol(nbasin), dsum(nbasin), dvar(nbasin), zdep(npk_fi) )
+  ALLOCATE( n_mean(nbasin), n_mean3d(nbasin), n_var(nbasin), n_var3d(nbasin), n_sum(nbasin), n_sum3d(nbasin) )
+  ALLOCATE( dsums(4, nbasin, nvpk) )
+
+  SELECT CASE ( TRIM(ctype) )                                ! metrics, mask and depth of each C-grid point (:296-355)
+  CASE ( 'T' ) ; CALL setgrid(cn_ve1t, cn_ve2t, cn_fe3t, cn_ve3t, cn_ve3t1d, cn_ve3tvvl, cn_tmask, cn_gdept)
+  CASE ( 'U' ) ; CALL setgrid(cn_ve1u, cn_ve2u, cn_fe3u, cn_ve3u, cn_ve3t1d, cn_ve3uvvl, cn_umask, cn_gdept)
+  CASE ( 'V' ) ; CALL setgrid(cn_ve1v, cn_ve2v, cn_fe3v, cn_ve3v, cn_ve3t1d, cn_ve3vvvl, cn_vmask, cn_gdept)
+  CASE ( 'F' ) ; CALL setgrid(cn_ve1f, cn_ve2f, cn_fe3t, cn_ve3t, cn_ve3t1d, cn_ve3tvvl, cn_fmask, cn_gdept)
+  CASE ( 'W' ) ; CALL setgrid(cn_ve1t, cn_ve2t, cn_fe3t, cn_ve3w, cn_ve3w1d, cn_ve3wvvl, cn_tmask, cn_gdepw)
+  CASE DEFAULT
+     PRINT *, 'this type of variable is not known :', TRIM(ctype)
+     STOP 99
+  END SELECT
+
+  e1(:,:) = getvar(cn_fhgr, cv_e1, 1, npiglo, npjglo, kimin=iimin, kjmin=ijmin)
+  e2(:,:) = getvar(cn_fhgr, cv_e2, 1, npiglo, npjglo, kimin=iimin, kjmin=ijmin)
+  IF ( lfull ) e31d(:) = getvare3(cn_fzgr, cv_e31d, npk)
+  zdep(:) = getvare3(cn_fzgr, cv_dep, npk_fi)
+  gdep(:) = zdep(ikmin:npk - ikmin + 1)
+
+  IF ( lvar ) THEN ; nvars_bas = 4
+  ELSE             ; nvars_bas = 2
+  ENDIF
+  IF ( lsum ) nvars_bas = nvars_bas + 2
+  nvars = nvars_bas * nbasin
+  ALLOCATE( stypvar(nvars), ipk(nvars), id_varout(nvars) )
+  ALLOCATE( rdumlon(ikx,iky), rdumlat(ikx,iky), rdummymean(ikx,iky), dvmeanout(npk) )
+  IF ( lvar ) ALLOCATE( dvariance(npk) )
+  CALL CreateOutput
+
+  IF ( lbas ) THEN
+     DO jbasin = 1, nbasin
+        zwk(:,:) = getvar(cn_fbasins, cbasins(jbasin), 1, npiglo, npjglo, kimin=iimin, kjmin=ijmin)
+        ibmask(jbasin,:,:) = INT(zwk(:,:), 2)
+     END DO
+  ELSE
+     ibmask(1,:,:) = 1
+  ENDIF
+
+  OPEN(numout, FILE=cf_out)
+  IF ( lvar ) OPEN(numvar, FILE=cf_var)
+  IF ( lsum ) OPEN(numsum, FILE=cf_sum)
+  IF ( lg_vvl ) cf_e3 = cf_in
+
+  ! the mask of the working levels is the same for every record
+  DO jk = 1, nvpk
+     ik = jk + ikmin - 1
+     zmask(:,:,jk) = getvar(cn_fmsk, cv_msk, ik, npiglo, npjglo, kimin=iimin, kjmin=ijmin)
+  END DO
+  IF ( .NOT. lfull ) ALLOCATE( e3(npiglo,npjglo,nvpk) )
+  CALL hip_check(cdft_mean_create(plan, npiglo, npjglo, nvpk, nbasin), 'cdft_mean_create')
+
+  DO jt = 1, npt
+     it = 1 ; IF ( lg_vvl ) it = jt
+     dvol(:) = 0.d0 ; dsum(:) = 0.d0 ; dvar(:) = 0.d0
+     IF ( jt == 1 .OR. lg_vvl ) THEN
+        pe3 = C_NULL_PTR ; pe31d = C_NULL_PTR
+        IF ( lfull ) THEN
+           pe31d = C_LOC(e31d)                               ! e3(:,:) = e31d(jk), with jk the working-level index (:412)
+        ELSE
+           DO jk = 1, nvpk
+              ik = jk + ikmin - 1
+              e3(:,:,jk) = getvar(cf_e3, cv_e3, ik, npiglo, npjglo, kimin=iimin, kjmin=ijmin, ktime=it, ldiom=.NOT. lg_vvl)
+           END DO
+           pe3 = C_LOC(e3)
+        ENDIF
+        CALL hip_check(cdft_mean_set_mesh(plan, e1, e2, pe3, pe31d, zmask, ibmask, CDFT_MEM_HOST, C_NULL_PTR), 'cdft_mean_set_mesh')
+     ENDIF
+     DO jk = 1, nvpk
+        ik = jk + ikmin - 1
+        zv(:,:,jk) = getvar(cf_in, cv_nam, ik, npiglo, npjglo, kimin=iimin, kjmin=ijmin, ktime=jt)
+     END DO
+     CALL hip_check(cdft_mean_compute(plan, zv, CDFT_MEM_HOST, dsums, CDFT_MEM_HOST, C_NULL_PTR), 'cdft_mean_compute')
+
+     DO jk = 1, nvpk
+        ik = jk + ikmin - 1
+        DO jbasin = 1, nbasin
+           ivarb = nvars_bas * (jbasin - 1)
+           dsurf  = dsums(1, jbasin, jk) ; dvol2d = dsums(2, jbasin, jk)
+           dsum2d = dsums(3, jbasin, jk) ; dvar2d = dsums(4, jbasin, jk)
+           dvol(jbasin) = dvol(jbasin) + dvol2d
+           dsum(jbasin) = dsum(jbasin) + dsum2d
+           dvar(jbasin) = dvar(jbasin) + dvar2d
+           IF ( lbas ) clbas = ' for basin '//cbasins(jbasin)
+           IF ( dvol2d /= 0 ) THEN
+              dvmeanout(jk) = dsum2d / dvol2d
+              WRITE(6,*) ' Mean value', TRIM(clbas), ' at level ', ik, '(', gdep(jk), ' m) ', dvmeanout(jk), 'surface = ', dsurf/1.e6, ' km^2'
+              WRITE(numout, 9004) gdep(jk), ik, dvmeanout(jk)
+              IF ( lvar ) THEN
+                 dvariance(jk) = dvar2d / dvol2d - dvmeanout(jk) * dvmeanout(jk)
+                 WRITE(6,*) ' Variance value', TRIM(clbas), ' at level ', ik, '(', gdep(jk), ' m) ', dvariance(jk), 'surface = ', dsurf/1.e6, ' km^2'
+                 WRITE(numvar, 9004) gdep(jk), ik, dvariance(jk)
+              ENDIF
+              IF ( lsum ) WRITE(numsum, 9004) gdep(jk), ik, dvol2d
+           ELSE
+              WRITE(6,*) ' No points in the water at level ', ik, '(', gdep(jk), ' m) '
+              dvmeanout(jk) = 99999.
+              IF ( lvar ) dvariance(jk) = 99999.
+           ENDIF
+           rdummymean(1,1) = dvmeanout(jk)
+           ierr = putvar(ncout, id_varout(n_mean(jbasin)), rdummymean, jk, ikx, iky, ktime=jt)
+           IF ( lvar ) THEN
+              rdummymean(1,1) = dvariance(jk)
+              ierr = putvar(ncout, id_varout(n_var(jbasin)), rdummymean, jk, ikx, iky, ktime=jt)
+           ENDIF
+           IF ( lsum ) THEN
+              rdummymean(1,1) = dsum2d
+              ierr = putvar(ncout, id_varout(n_sum(jbasin)), rdummymean, jk, ikx, iky, ktime=jt)
+           ENDIF
+        END DO
+     END DO
+
+     DO jbasin = 1, nbasin
+        dvmeanout3d(jbasin,jt) = dsum(jbasin) / dvol(jbasin)
+        WRITE(6,*) ' Mean value over the ocean: ', dvmeanout3d(jbasin,jt), jt
+        WRITE(numout,*) ' Mean value over the ocean ', TRIM(clbas), ': ', dvmeanout3d(jbasin,jt), jt
+        rdummy(:,:) = dvmeanout3d(jbasin,jt)
+        ierr = putvar0d(ncout, id_varout(n_mean3d(jbasin)), rdummy, ktime=jt)
+        IF ( lvar ) THEN
+           dvariance3d(jbasin,jt) = dvar(jbasin)/dvol(jbasin) - dsum(jbasin) / dvol(jbasin) * dsum(jbasin) / dvol(jbasin)
+           WRITE(6,*) ' Variance over the ocean: ', dvariance3d(jbasin,jt), jt
+           WRITE(numvar,*) ' Variance over the ocean ', TRIM(clbas), ': ', dvariance3d(jbasin,jt), jt
+           rdummy(:,:) = dvariance3d(jbasin,jt)
+           ierr = putvar0d(ncout, id_varout(n_var3d(jbasin)), rdummy, ktime=jt)
+        ENDIF
+        IF ( lsum ) THEN
+           WRITE(6,*) ' Sum over the ocean: ', dsum, jt
+           WRITE(numsum,*) ' Sum over the ocean:  ', TRIM(clbas), '', dsum, jt
+           rdummy(:,:) = dsum(jbasin)
+           ierr = putvar0d(ncout, id_varout(n_sum3d(jbasin)), rdummy, ktime=jt)
+        ENDIF
+     END DO
+  END DO
+
+  CLOSE(numout)
+  IF ( lvar ) CLOSE(numvar)
+  ierr = cdft_mean_destroy(plan)
+  ierr = closeout(ncout)
+9004 FORMAT(f9.2,' ',i2,' ',f9.2)
+
+CONTAINS
+
+  SUBROUTINE geti(kval)
+    INTEGER(KIND=4), INTENT(out) :: kval
+    CALL GET_COMMAND_ARGUMENT(ijarg, cldum) ; ijarg = ijarg + 1 ; READ(cldum, *) kval
+  END SUBROUTINE geti
+
+  SUBROUTINE setgrid(cd_e1, cd_e2, cd_fe3, cd_e3, cd_e31d, cd_e3vvl, cd_msk, cd_dep)
+    CHARACTER(LEN=*), INTENT(in) :: cd_e1, cd_e2, cd_fe3, cd_e3, cd_e31d, cd_e3vvl, cd_msk, cd_dep
+    cv_e1 = cd_e1 ; cv_e2 = cd_e2 ; cf_e3 = cd_fe3 ; cv_e3 = cd_e3 ; cv_e31d = cd_e31d
+    IF ( lg_vvl ) cv_e3 = cd_e3vvl
+    IF ( cv_msk == '' ) cv_msk = cd_msk
+    cv_dep = cd_dep
+  END SUBROUTINE setgrid
+
+  SUBROUTINE CreateOutput
+    !! src/cdfmean.f90:530-632
+    INTEGER(KIND=4) :: ivar
+    CHARACTER(LEN=80) :: cl_suffix
+    rdumlon(:,:) = 0. ; rdumlat(:,:) = 0.
+    ivar = 0
+    ierr = getvaratt(cf_in, cv_nam, clunits, zspval, cllong_name, clshort_name)
+    stypvar%cunits            = TRIM(clunits)
+    stypvar%rmissing_value    = 99999.
+    stypvar%valid_min         = -1000.
+    stypvar%valid_max         = 1000.
+    stypvar%scale_factor      = 1.
+    stypvar%add_offset        = 0.
+    stypvar%savelog10         = 0.
+    stypvar%conline_operation = 'N/A'
+    DO jbasin = 1, nbasin
+       IF ( lbas ) THEN ; cl_suffix = '_'//TRIM(cbasins(jbasin))
+       ELSE             ; cl_suffix = ''
+       ENDIF
+       ivar = ivar + 1 ; n_mean(jbasin) = ivar
+       CALL defvar(ivar, nvpk, 'mean_', TRIM(clunits), 'ZT', cl_suffix)
+       ivar = ivar + 1 ; n_mean3d(jbasin) = ivar
+       CALL defvar(ivar, 1, 'mean_3D', TRIM(clunits), 'T', cl_suffix)
+       IF ( lvar ) THEN
+          ivar = ivar + 1 ; n_var(jbasin) = ivar
+          CALL defvar(ivar, nvpk, 'var_', TRIM(clunits)//'^2', 'ZT', cl_suffix)
+          ivar = ivar + 1 ; n_var3d(jbasin) = ivar
+          CALL defvar(ivar, 1, 'var_3D', TRIM(clunits)//'^2', 'T', cl_suffix)
+       ENDIF
+       IF ( lsum ) THEN
+          ivar = ivar + 1 ; n_sum(jbasin) = ivar
+          CALL defvar(ivar, nvpk, 'sum_', TRIM(clunits)//'.m^3', 'ZT', cl_suffix)
+          ivar = ivar + 1 ; n_sum3d(jbasin) = ivar
+          CALL defvar(ivar, 1, 'sum_3D', TRIM(clunits)//'.m^3', 'T', cl_suffix)
+       ENDIF
+    END DO
+    ncout = create      (cf_ncout, 'none', ikx, iky, nvpk, cdep=cv_dep)
+    ierr  = createvar   (ncout, stypvar, nvars, ipk, id_varout, cdglobal=TRIM(cglobal))
+    ierr  = putheadervar(ncout, cf_in, ikx, iky, npk, pnavlon=rdumlon, pnavlat=rdumlat, pdep=gdep(1:nvpk), cdep=cv_dep)
+    dtim  = getvar1d(cf_in, cn_vtimec, npt)
+    ierr  = putvar1d(ncout, dtim, npt, 'T')
+  END SUBROUTINE CreateOutput
+
+  SUBROUTINE defvar(kv, kpk, cd_pre, cd_units, cd_axis, cd_suffix)
+    INTEGER(KIND=4),  INTENT(in) :: kv, kpk
+    CHARACTER(LEN=*), INTENT(in) :: cd_pre, cd_units, cd_axis, cd_suffix
+    ipk(kv)                 = kpk
+    stypvar(kv)%cunits      = cd_units
+    stypvar(kv)%cname       = cd_pre//TRIM(cv_nam)//TRIM(cd_suffix)
+    stypvar(kv)%clong_name  = cd_pre//TRIM(cllong_name)//TRIM(cd_suffix)
+    stypvar(kv)%cshort_name = cd_pre//TRIM(clshort_name)//TRIM(cd_suffix)
+    stypvar(kv)%caxis       = cd_axis
+  END SUBROUTINE defvar
+
+  SUBROUTINE GetLstMask
+    !! -B BASIN-file name1 name2 ... : the names up to the next option (src/cdfmean.f90:670-699)
+    INTEGER(KIND=4) :: iiarg
+    LOGICAL :: lchkv = .FALSE.
+    iiarg = ijarg
+    cldum = 'xxxx'
+    DO WHILE ( cldum(1:1) /= '-' .AND. iiarg <= narg )
+       CALL GET_COMMAND_ARGUMENT(iiarg, cldum) ; iiarg = iiarg + 1
+    END DO
+    nbasin = iiarg - ijarg - 1                             ! as the reference: a list that runs to the end of the
+    !                                                        command line loses its last name (put -B before another option)
+    ALLOCATE( cbasins(nbasin) )
+    DO jbasin = 1, nbasin
+       CALL GET_COMMAND_ARGUMENT(ijarg, cbasins(jbasin)) ; ijarg = ijarg + 1
+    END DO
+    PRINT *, 'Basin File : ', TRIM(cn_fbasins)
+    PRINT *, '  nbasin : ', nbasin
+    DO jbasin = 1, nbasin
+       PRINT *, '  basin ', jbasin, ' : ', TRIM(cbasins(jbasin))
+    END DO
+    DO jbasin = 1, nbasin
+       lchkv = lchkv .OR. chkvar(cn_fbasins, cbasins(jbasin))
+    END DO
+    IF ( lchkv ) STOP 99
+  END SUBROUTINE GetLstMask
+
+END PROGRAM cdfmean

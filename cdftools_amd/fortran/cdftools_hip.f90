@@ -114,6 +114,22 @@ MODULE cdftools_hip
        IMPORT ; REAL(C_FLOAT), INTENT(in) :: xt(*), xs(*), m2d(*) ; TYPE(C_PTR), VALUE :: e3, e31d, stream
        INTEGER(C_INT), VALUE :: npiglo, npjglo, npk, in_space, out_space ; REAL(C_DOUBLE), INTENT(out) :: dheat(*), dsalt(*)
      END FUNCTION
+     ! ---- cdfmean --------------------------------------------------------------------------
+     INTEGER(C_INT) FUNCTION cdft_mean_create(plan, npiglo, npjglo, npk, nbasins) BIND(C, name='cdft_mean_create')
+       IMPORT ; TYPE(C_PTR), INTENT(out) :: plan ; INTEGER(C_INT), VALUE :: npiglo, npjglo, npk, nbasins
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_mean_set_mesh(plan, e1, e2, e3, e31d, zmask, ibmask, memspace, stream) &
+          &         BIND(C, name='cdft_mean_set_mesh')
+       IMPORT ; TYPE(C_PTR), VALUE :: plan, stream, e3, e31d ; REAL(C_FLOAT), INTENT(in) :: e1(*), e2(*), zmask(*)
+       INTEGER(C_INT16_T), INTENT(in) :: ibmask(*) ; INTEGER(C_INT), VALUE :: memspace
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_mean_compute(plan, zv, in_space, sums, out_space, stream) BIND(C, name='cdft_mean_compute')
+       IMPORT ; TYPE(C_PTR), VALUE :: plan, stream ; REAL(C_FLOAT), INTENT(in) :: zv(*)
+       INTEGER(C_INT), VALUE :: in_space, out_space ; REAL(C_DOUBLE), INTENT(out) :: sums(*)
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_mean_destroy(plan) BIND(C, name='cdft_mean_destroy')
+       IMPORT ; TYPE(C_PTR), VALUE :: plan
+     END FUNCTION
      ! ---- cdfpsi ---------------------------------------------------------------------------
      INTEGER(C_INT) FUNCTION cdft_psi_create(plan, npiglo, npjglo, npk) BIND(C, name='cdft_psi_create')
        IMPORT ; TYPE(C_PTR), INTENT(out) :: plan ; INTEGER(C_INT), VALUE :: npiglo, npjglo, npk

@@ -438,6 +438,33 @@ def vt_compute(u, v, t, s, e3u=None, e3v=None, out_r4=False, stream=None):
     return o
 
 
+class MeanPlan(_Plan):
+    """cdfmean (src/cdfmean.f90:405-431): cdft_mean_*; host arrays."""
+
+    _destroy = "cdft_mean_destroy"
+
+    def __init__(self, npiglo, npjglo, npk, nbasins=1):
+        self.npi, self.npj, self.npk, self.nb = npiglo, npjglo, npk, nbasins
+        self._h = C.c_void_p()
+        check(_lib.load().cdft_mean_create(C.byref(self._h), npiglo, npjglo, npk, nbasins))
+
+    def set_mesh(self, e1, e2, zmask, ibmask, e3=None, e31d=None, stream=None):
+        """e1, e2 (npj,npi); zmask (npk,npj,npi) r4; ibmask (npj,npi,nb) i2; e3 (npk,npj,npi) or e31d (npk)."""
+        k = [np.ascontiguousarray(e1, np.float32), np.ascontiguousarray(e2, np.float32),
+             None if e3 is None else np.ascontiguousarray(e3, np.float32),
+             None if e31d is None else np.ascontiguousarray(e31d, np.float32),
+             np.ascontiguousarray(zmask, np.float32), np.ascontiguousarray(ibmask, np.int16)]
+        ptr = [_null() if a is None else C.c_void_p(a.ctypes.data) for a in k]
+        check(_lib.load().cdft_mean_set_mesh(self._h, *ptr, MEM_HOST, stream or current_stream_ptr()))
+
+    def compute(self, zv, stream=None):
+        """zv (npk,npj,npi) r4 -> sums (npk,nb,4) r8: dsurf, dvol2d, dsum2d, dvar2d."""
+        pz, sz, kz = _arg(zv, np.float32, "zv")
+        out = np.empty((self.npk, self.nb, 4), np.float64)
+        check(_lib.load().cdft_mean_compute(self._h, pz, sz, C.c_void_p(out.ctypes.data), MEM_HOST, stream or current_stream_ptr()))
+        return out
+
+
 def vint_transport(vel, m2d, e3=None, e31d=None, stream=None):
     """cdft_vint_transport: vel (npk,npj,npi) r4 -> (npj,npi) r8 (host arrays or CUDA tensors)."""
     pv, sv, kv = _arg(vel, np.float32, "vel")
@@ -511,4 +538,4 @@ class CurlPlan(_Plan):
         return out
 
 
-__all__ = ["MocPlan", "HeatcPlan", "MhstPlan", "PsiPlan", "CurlPlan", "vt_compute", "vint_transport", "vhst_transport", "sigmai", "sigma0", "sig_tool", "EOS_80", "EOS_TEOS10", "EOS_JMD94", "EOS_FAST_FMA", "Timer", "CdftError", "device_count", "current_stream_ptr", "MEM_HOST", "MEM_DEVICE"]
+__all__ = ["MocPlan", "HeatcPlan", "MeanPlan", "MhstPlan", "PsiPlan", "CurlPlan", "vt_compute", "vint_transport", "vhst_transport", "sigmai", "sigma0", "sig_tool", "EOS_80", "EOS_TEOS10", "EOS_JMD94", "EOS_FAST_FMA", "Timer", "CdftError", "device_count", "current_stream_ptr", "MEM_HOST", "MEM_DEVICE"]

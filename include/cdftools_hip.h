@@ -222,6 +222,24 @@ int cdft_vhst_transport(const float *xt, const float *xs, const float *m2d, cons
 int cdft_vint_release(void);   /* frees the staging buffers of the two calls above */
 
 /* ------------------------------------------------------------------------------------------ */
+/* cdfmean : weighted mean / variance / sum per level and sub-basin      */
+/*   replaces src/cdfmean.f90:405-431 (the four SUMs of each level and basin)                   */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct cdft_mean_plan cdft_mean_plan;
+int cdft_mean_create(cdft_mean_plan **plan, int npiglo, int npjglo, int npk, int nbasins /* 1..8 */);
+/* e1, e2 (npiglo,npjglo) r4 (:363-364); exactly one of e3 (npiglo,npjglo,npk) r4 (:414, again per record
+ * with -vvl) or e31d (npk) r4 (-full, :412); zmask (npiglo,npjglo,npk) r4 as getvar returns it (:409; any
+ * values, e.g. a -M mask); ibmask (nbasins,npiglo,npjglo) i2, basin index fastest (:385-391; all 1
+ * without -B).  (npiglo,npjglo,npk) is the -w window the caller read. */
+int cdft_mean_set_mesh(cdft_mean_plan *plan, const float *e1, const float *e2, const float *e3, const float *e31d,
+                       const float *zmask, const int16_t *ibmask, int memspace, void *stream);
+/* zv (npiglo,npjglo,npk) r4, one record (:408; NOT yet multiplied by zmask: the kernel does :410).
+ * sums (4,nbasins,npk) r8: dsurf, dvol2d, dsum2d, dvar2d of every level and basin (:419-424); the
+ * caller forms the means, variances and 3-D totals (:425-499). */
+int cdft_mean_compute(cdft_mean_plan *plan, const float *zv, int in_space, double *sums, int out_space, void *stream);
+int cdft_mean_destroy(cdft_mean_plan *plan);
+
+/* ------------------------------------------------------------------------------------------ */
 /* cdfpsi : barotropic stream function                                                        */
 /*   replaces src/cdfpsi.f90:271-298 (vertical integration), :377-423 (scans, mean, reference  */
 /*   point) and the SNGL / mask at :426-433.  Not covered: -open, --ssh-file, -lev.            */

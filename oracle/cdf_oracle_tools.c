@@ -331,3 +331,29 @@ void oracle_vhst_transport(int npi, int npj, int npk, const float *xt, const flo
             dsalt[p] = dsalt[p] + (double)(xs[k * nij + p] * e3m) * 1.0;
         }
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* src/cdfmean.f90:405-431 for one record: zv = zv*zmask (:410), then per level and basin
+ *   dsurf  = SUM(DBLE(e1*e2*zmask*ibmask)), dvol2d = SUM(DBLE(e1*e2*e3*zmask*ibmask)),
+ *   dsum2d = SUM(DBLE(zv*e1*e2*e3*ibmask)), dvar2d = SUM(DBLE(zv*zv*e1*e2*e3*ibmask))
+ * with every product in r4, left to right (ibmask is INTEGER(2): converted to r4 by the multiply).
+ * sums (4,nb,npk).  The SUM is taken sequentially here (its order is the compiler's in the reference). */
+void oracle_mean(int npi, int npj, int npk, int nb, const float *e1, const float *e2, const float *e3,
+                 const float *e31d, const float *zmask, const int16_t *ibmask, const float *zv, double *sums) {
+    const size_t nij = (size_t)npi * npj;
+    for (int k = 0; k < npk; ++k)
+        for (int b = 0; b < nb; ++b) {
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            for (size_t p = 0; p < nij; ++p) {
+                const float m = zmask[k * nij + p], fb = (float)ibmask[p * nb + b];
+                const float e = e3 ? e3[k * nij + p] : e31d[k];
+                const float z = zv[k * nij + p] * m;
+                s0 += (double)(e1[p] * e2[p] * m * fb);
+                s1 += (double)(e1[p] * e2[p] * e * m * fb);
+                s2 += (double)(z * e1[p] * e2[p] * e * fb);
+                s3 += (double)(z * z * e1[p] * e2[p] * e * fb);
+            }
+            double *o = sums + ((size_t)k * nb + b) * 4;
+            o[0] = s0; o[1] = s1; o[2] = s2; o[3] = s3;
+        }
+}

@@ -105,3 +105,103 @@ def test_cdfvhst_and_cdfvtrp_end_to_end(tools, tmp_path):  # noqa: F811
         assert np.allclose(var["soastrp"][t], along, rtol=0, atol=2e-6 * scale)
         assert np.allclose(var["socstrp"][t], cross, rtol=0, atol=2e-6 * scale)
     assert att["soastrp"]["long_name"] == b"Along_Slope_Barotropic_Transp"
+
+
+# ------------------------------------------------------------------------------------------- cdfmean
+def mean_inputs(npi, npj, npk, nb, seed):
+    g = synth.make_grid(npi, npj, npk, seed=seed)
+    rng = np.random.default_rng(seed + 3)
+    zv = ((-2 + 30 * rng.random((npk, npj, npi), dtype=np.float32)) * g["tmask"]).astype(np.float32)
+    zv[g["tmask"] == 0] = 1.0e20                                           # funny fill values on land (:410)
+    ib = np.zeros((npj, npi, nb), np.int16)
+    ib[:, :, 0] = 1
+    for b, nm in zip(range(1, nb), ("tmaskatl", "tmaskpac", "tmaskind")):
+        ib[:, :, b] = g[nm]
+    return g, zv, ib
+
+
+def test_oracle_mean_matches_numpy_restatement():
+    g, zv, ib = mean_inputs(19, 13, 5, 3, seed=2)
+    tm = g["tmask"].astype(np.float32)
+    got = oracle_tools.mean(g["e1t"], g["e2t"], tm, ib, zv, e3=g["e3t_0"])
+    f32 = np.float32
+    zm = (zv * tm).astype(f32)
+    for b in range(3):
+        fb = ib[:, :, b].astype(f32)
+        a = (g["e1t"] * g["e2t"]).astype(f32)
+        want = np.stack([((a * tm).astype(f32) * fb).astype(np.float64).sum(axis=(1, 2)),
+                         (((a * g["e3t_0"]).astype(f32) * tm).astype(f32) * fb).astype(np.float64).sum(axis=(1, 2)),
+                         ((((zm * g["e1t"]).astype(f32) * g["e2t"]).astype(f32) * g["e3t_0"]).astype(f32) * fb).astype(np.float64).sum(axis=(1, 2)),
+                         (((((zm * zm).astype(f32) * g["e1t"]).astype(f32) * g["e2t"]).astype(f32) * g["e3t_0"]).astype(f32) * fb)
+                         .astype(np.float64).sum(axis=(1, 2))], axis=1)
+        assert np.allclose(got[:, b, :], want, rtol=1e-13, atol=0)
+    assert np.all(np.isfinite(got))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("npi,npj,npk,nb", [(24, 18, 7, 4), (182, 149, 31, 1), (1, 1, 1, 1), (5, 3, 2, 8), (1023, 7, 3, 3), (64, 64, 2, 2)])
+def test_hip_mean_matches_oracle(gpu, npi, npj, npk, nb):
+    g, zv, ib = mean_inputs(npi, npj, npk, min(nb, 4), seed=npi + 1)
+    if nb > 4:
+        ib = np.concatenate([ib, ib[:, :, :nb - 4] * 2], axis=2)                      # values other than 0/1 are allowed
+    tm = g["tmask"].astype(np.float32)
+    plan = gpu.MeanPlan(npi, npj, npk, nb)
+    for kw in (dict(e3=g["e3t_0"]), dict(e31d=g["e3t_1d"])):
+        plan.set_mesh(g["e1t"], g["e2t"], tm, ib, **kw)
+        got = plan.compute(zv)
+        ref = oracle_tools.mean(g["e1t"], g["e2t"], tm, ib, zv, **kw)
+        bound = oracle_tools.mean(g["e1t"], g["e2t"], tm, ib, np.abs(zv), **kw)
+        assert np.all(np.abs(got - ref) <= 1e-13 * bound + 1e-300), float(np.abs(got - ref).max())
+        assert np.array_equal(plan.compute(zv), got)                                    # run-to-run identical
+
+
+@pytest.mark.gpu
+def test_cdfmean_end_to_end(tools, tmp_path):  # noqa: F811
+    d = str(tmp_path)
+    g, rec = nemo_files.make_case(d, npi=26, npj=19, npk=6, npt=2)
+    npk, npj, npi = g["tmask"].shape
+    tm = g["tmask"].astype(np.float32)
+    one = np.ones((npj, npi, 1), np.int16)
+
+    def nc(name):
+        return read_nc(os.path.join(d, name))
+
+    rc, out, err = run("cdfmean", ["-f", "SYN_y0001_gridT.nc", "-v", "votemper", "-p", "T", "-var", "-S"], d)
+    assert rc == 0, out + err
+    var, att, dims = nc("cdfmean.nc")
+    assert dims["x"] == 1 and dims["y"] == 1
+    for t in range(2):
+        s = oracle_tools.mean(g["e1t"], g["e2t"], tm, one, rec["t"][t], e3=g["e3t_0"])[:, 0, :]
+        mean = np.where(s[:, 1] != 0, s[:, 2] / np.where(s[:, 1] != 0, s[:, 1], 1), 99999.0)
+        vari = np.where(s[:, 1] != 0, s[:, 3] / np.where(s[:, 1] != 0, s[:, 1], 1) - mean * mean, 99999.0)
+        assert np.allclose(var["mean_votemper"][t].ravel(), mean, rtol=2e-7, atol=0)
+        assert np.allclose(var["var_votemper"][t].ravel(), vari, rtol=1e-5, atol=1e-6)
+        assert np.allclose(var["sum_votemper"][t].ravel(), s[:, 2], rtol=2e-7, atol=0)
+        assert np.allclose(var["mean_3Dvotemper"][t].ravel(), s[:, 2].sum() / s[:, 1].sum(), rtol=2e-7)
+        assert np.allclose(var["sum_3Dvotemper"][t].ravel(), s[:, 2].sum(), rtol=2e-7)
+    assert "Mean value over the ocean:" in out and os.path.exists(os.path.join(d, "cdfvar.txt"))
+    txt = open(os.path.join(d, "cdfmean.txt")).read().splitlines()
+    assert len(txt) == 2 * (npk + 1) - 2 * int((g["tmask"][-1] == 0).all())          # a level without water writes no line
+    # window, full step, sub-basins (followed by another option, as the reference's list parser needs)
+    rc, out, err = run("cdfmean", ["-f", "SYN_y0001_gridT.nc", "-v", "vosaline", "-p", "T", "-w", "3", "20", "2", "15", "2", "4",
+                                   "-B", "new_maskglo.nc", "tmaskatl", "tmaskpac", "-full", "-o", "mw.nc", "-P", "pre_"], d)
+    assert rc == 0, out + err
+    var, att, dims = nc("pre_mw.nc")
+    ib = np.stack([g["tmaskatl"], g["tmaskpac"]], axis=2).astype(np.int16)[1:15, 2:20]
+    s = oracle_tools.mean(g["e1t"][1:15, 2:20], g["e2t"][1:15, 2:20], tm[1:4, 1:15, 2:20], ib, rec["s"][0][1:4, 1:15, 2:20],
+                          e31d=g["e3t_1d"][0:3])                                       # e31d(jk), jk = 1.. (:412)
+    for b, nm in enumerate(("tmaskatl", "tmaskpac")):
+        mean = np.where(s[:, b, 1] != 0, s[:, b, 2] / np.where(s[:, b, 1] != 0, s[:, b, 1], 1), 99999.0)
+        assert np.allclose(var["mean_vosaline_" + nm][0].ravel(), mean, rtol=2e-7), nm
+    assert os.path.exists(os.path.join(d, "pre_cdfmean.txt"))
+    # another mask file and variable (-M), V point
+    rc, out, err = run("cdfmean", ["-f", "SYN_y0001_gridV.nc", "-v", "vomecrty", "-p", "V", "-M", "mask.nc", "umask", "-o", "mm.nc"], d)
+    assert rc == 0, out + err
+    var, _, _ = nc("mm.nc")
+    s = oracle_tools.mean(g["e1v"], g["e2v"], g["umask"].astype(np.float32), one, rec["v"][1], e3=g["e3v_0"])[:, 0, :]
+    good = s[:, 1] != 0
+    assert np.allclose(var["mean_vomecrty"][1].ravel()[good], (s[:, 2] / np.where(good, s[:, 1], 1))[good], rtol=5e-6, atol=1e-9)
+    rc, out, _ = run("cdfmean", ["-f", "SYN_y0001_gridT.nc", "-v", "votemper", "-p", "T", "-zeromean"], d)
+    assert rc == 99 and "-zeromean" in out
+    rc, out, _ = run("cdfmean", ["-f", "SYN_y0001_gridT.nc", "-v", "votemper", "-p", "Q"], d)
+    assert rc == 99 and "not known" in out

@@ -43,7 +43,7 @@ def main():
     ap.add_argument("--grid", default="eorca025", choices=sorted(GRIDS))
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--frames", type=int, default=6)
-    ap.add_argument("--tools", default="heatc,mhst,psi,vt,curl,eos")
+    ap.add_argument("--tools", default="heatc,mean,mhst,psi,vt,curl,eos")
     args = ap.parse_args()
     npi, npj, npk = GRIDS[args.grid]
     dev = torch.device("cuda", 0)
@@ -62,6 +62,16 @@ def main():
         ms = timed(lambda: p.compute(temp), args.reps)
         report("cdfheatc", args.grid, n3, 9.0 + 8.0 / npk, ms, "T 4 + e3t 4 + tmask 1 B per cell; includes the D2H of 3*npk sums")
         del p, tmask, temp
+
+    if "mean" in tools:
+        tm = (rnd(npk, npj, npi) > 0.35).float().cpu().numpy()
+        zv = (-2 + 32 * rnd(npk, npj, npi))
+        p = hip.MeanPlan(npi, npj, npk, 1)
+        p.set_mesh(e1.cpu().numpy(), e2.cpu().numpy(), tm, np.ones((npj, npi, 1), np.int16), e3=e3.cpu().numpy())
+        del tm
+        ms = timed(lambda: p.compute(zv), args.reps)
+        report("cdfmean (1 basin)", args.grid, n3, 12.0, ms, "field 4 + e3 4 + r4 mask 4 B per cell; includes the D2H of 4*npk sums")
+        del p, zv
 
     if "mhst" in tools:
         vt, vs = rnd(npk, npj, npi) - 0.5, rnd(npk, npj, npi) - 0.5
