@@ -225,7 +225,7 @@ void choose_shape(const cdft_moc_plan *p, bool aligned, int *nwaves, int *nv, in
         int vmax = (md == kModeFma) ? 4 : (md == kModeClass ? 9 : 8);   // measured best at npiglo = 4322
         k = ceil_div(nvec, kWave * vmax);
         if (k > kSmallWaves) {          // long rows: 1024-thread workgroups, fewer registers
-            vmax = (md == kModeFma) ? 2 : kBigNV;
+            vmax = (md == kModeFma) ? 2 : (md == kModeClass ? kBigNVClass : kBigNV);
             k = ceil_div(nvec, kWave * vmax);
         }
         v = ceil_div(nvec, kWave * k);

@@ -31,6 +31,7 @@ constexpr int kMaxNV     = 16;   // float4 vectors per lane held in registers
 constexpr int kMaxWaves  = 16;   // waves per row (1024-thread workgroup)
 constexpr int kSmallWaves = 4;   // waves per row of a 256-thread workgroup
 constexpr int kBigNV     = 6;    // vectors per lane a 1024-thread workgroup can hold unspilled
+constexpr int kBigNVClass = 5;   // the same for the class kernel (one slot index per cell on top)
 constexpr int kTChunk    = 16;   // records combined per LDS flush
 constexpr int kScrStride = 72;   // doubles; 64 + 8 keeps the 5 basin rows on different banks
 
@@ -419,8 +420,8 @@ static int launch_class_lb(const ZonalArgs &a, int nwaves, hipStream_t st) {
 template <int NV, int KC>
 static int launch_class_one(const ZonalArgs &a, int nwaves, hipStream_t st) {
     if (nwaves <= kSmallWaves) return launch_class_lb<NV, KC, kWave * kSmallWaves>(a, nwaves, st);
-    if constexpr (NV <= kBigNV) return launch_class_lb<NV, KC, kWave * kMaxWaves>(a, nwaves, st);
-    else return fail(CDFT_ERR_ARG, "%d waves per row need <= %d vectors per lane, got %d", nwaves, kBigNV, NV);
+    if constexpr (NV <= kBigNVClass) return launch_class_lb<NV, KC, kWave * kMaxWaves>(a, nwaves, st);
+    else return fail(CDFT_ERR_ARG, "%d waves per row need <= %d vectors per lane, got %d", nwaves, kBigNVClass, NV);
 }
 
 template <int KC>
