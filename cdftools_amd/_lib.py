@@ -74,6 +74,10 @@ SIGNATURES = {
     "cdft_mean_set_mesh": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "cdft_mean_compute": (_i, [_vp, _vp, _i, _vp, _i, _vp]),
     "cdft_mean_destroy": (_i, [_vp]),
+    "cdft_zonal_create": (_i, [_pvp, _i, _i, _i, _i]),
+    "cdft_zonal_set_mesh": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "cdft_zonal_compute": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
+    "cdft_zonal_destroy": (_i, [_vp]),
     "cdft_psi_create": (_i, [_pvp, _i, _i, _i]),
     "cdft_psi_compute": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _vp]),
     "cdft_psi_integrate": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),

@@ -1,0 +1,366 @@
+// zonal.hip -- cdfzonalsum / cdfzonalmean: zonal (along i) integral or mean of any field, per level, row
+// and sub-basin (C ABI section "cdfzonal").
+// Reference loops: src/cdfzonalsum.f90:302-310 and src/cdfzonalmean.f90:319-327, per (variable, record, level, basin):
+//     sum  form  dtmp = zmask(b,ji,jj)*zmaskvar(ji,jj)*zv(ji,jj)*1.d0          (r4 product, then widened)
+//     mean form  dtmp = 1.d0*zmask(b,ji,jj)*zmaskvar(ji,jj)*zv(ji,jj)          (every product in r8)
+//     dzo(jj,jk)   += dl_surf(ji,jj)*dtmp                     with dl_surf = 1.d0*e1*e2 (r8)
+//     darea(jj,jk) += dl_surf(ji,jj)*zmask(b,ji,jj)*zmaskvar(ji,jj)             (mean form)
+//     rzomax / rzomin = MAX / MIN of dtmp (min over dtmp /= 0) stored in r4     (mean form, -max)
+// Per-term values are formed exactly as written; the r8 additions along i are regrouped in a fixed order
+// (|d| <= 1e-13 * sum|terms|).  One workgroup owns a row jj for ALL levels of the variable: the 2-D
+// operands of the row (surface, basin masks) are re-read per level from L2 / Infinity Cache, the field
+// and its 3-D mask stream from HBM once (8 bytes per cell and level).
+#include <cstdlib>
+#include "common.hpp"
+#include "reduce.hpp"
+
+using namespace cdft;
+
+struct cdft_zonal_plan {
+    int npi = 0, npj = 0, npk = 0, nb = 0;
+    double *surf = nullptr;       // (npi,npj) 1.d0*e1*e2
+    float  *mask3 = nullptr;      // (npi,npj,npk) mask of the variable's grid point
+    float  *bmask = nullptr;      // (nb,npi,npj) basin masks, basin index fastest
+    uint8_t *bits = nullptr;      // (npi,npj) basin bits when every basin mask is 0/1 (fast kernel)
+    int *flag = nullptr;          // device: 1 when a basin-mask value is neither 0 nor 1
+    bool binary = false;
+    bool mesh_set = false;
+    DevBuf st_a, st_b, st_zv, st_o[4];
+};
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxNB   = 8;
+
+__global__ void zonal_surf_kernel(const float *__restrict__ e1, const float *__restrict__ e2, double *__restrict__ surf, int64_t nij) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < nij) surf[p] = __dmul_rn(__dmul_rn(1.0, (double)e1[p]), (double)e2[p]);      // dl_surf = 1.d0 * e1 * e2
+}
+
+struct ZonalArgs2 {
+    const double *surf;
+    const float *mask3, *bmask, *zv;
+    int npi, npj, nlev, nb;
+    double *dsum, *darea;      // (npj,nlev,nb)
+    float *rmax, *rmin;        // (npj,nlev,nb) or null
+};
+
+template <int NB, bool MEAN, bool MINMAX>
+__global__ void __launch_bounds__(kThreads) zonal_row_kernel(ZonalArgs2 a) {
+    extern __shared__ double lds[];                     // [nlev][nwaves][NB][4]: sum, area, max, min
+    const int jj = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = kThreads / 64;
+    const int64_t nij = (int64_t)a.npi * a.npj, r2 = (int64_t)jj * a.npi;
+    for (int k = 0; k < a.nlev; ++k) {
+        const float *zv = a.zv + (int64_t)k * nij + r2, *mv = a.mask3 + (int64_t)k * nij + r2;
+        double s[NB], ar[NB], mx[NB], mn[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) { s[b] = 0.0; ar[b] = 0.0; mx[b] = -1.e20f; mn[b] = 1.e20f; }
+        for (int i = threadIdx.x; i < a.npi; i += kThreads) {
+            const float z = ld_stream(zv + i), m = ld_stream(mv + i);
+            const double sf = a.surf[r2 + i];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                if (b < a.nb) {
+                    const float zb = a.bmask[(r2 + i) * a.nb + b];
+                    double dtmp;
+                    if (MEAN) dtmp = __dmul_rn(__dmul_rn(__dmul_rn(1.0, (double)zb), (double)m), (double)z);
+                    else      dtmp = (double)__fmul_rn(__fmul_rn(zb, m), z);
+                    s[b] += __dmul_rn(sf, dtmp);
+                    if (MEAN) ar[b] += __dmul_rn(__dmul_rn(sf, (double)zb), (double)m);
+                    if (MINMAX) {
+                        mx[b] = fmax(mx[b], dtmp);
+                        if (dtmp != 0.0) mn[b] = fmin(mn[b], dtmp);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const double ts = wave_sum(s[b]);
+            double ta = 0.0, tx = 0.0, tn = 0.0;
+            if (MEAN) ta = wave_sum(ar[b]);
+            if (MINMAX) {
+                tx = mx[b]; tn = mn[b];
+                for (int o = 32; o > 0; o >>= 1) { tx = fmax(tx, __shfl_xor(tx, o, 64)); tn = fmin(tn, __shfl_xor(tn, o, 64)); }
+            }
+            if (lane == 0) {
+                double *w = lds + (((int64_t)k * nwaves + wave) * NB + b) * 4;
+                w[0] = ts; w[1] = ta; w[2] = tx; w[3] = tn;
+            }
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < a.nlev * a.nb; t += kThreads) {
+        const int k = t / a.nb, b = t - k * a.nb;
+        double ts = 0.0, ta = 0.0, tx = -1.e20f, tn = 1.e20f;
+        for (int w = 0; w < nwaves; ++w) {
+            const double *q = lds + (((int64_t)k * nwaves + w) * NB + b) * 4;
+            ts += q[0]; ta += q[1]; tx = fmax(tx, q[2]); tn = fmin(tn, q[3]);
+        }
+        const int64_t o = ((int64_t)b * a.nlev + k) * a.npj + jj;
+        a.dsum[o] = ts;
+        if (MEAN) a.darea[o] = ta;
+        if (MINMAX) { a.rmax[o] = (float)tx; a.rmin[o] = (float)tn; }
+    }
+}
+
+// bits(i,j) = basin membership bits; flag raised when a mask value is neither 0 nor 1
+__global__ void zonal_bits_kernel(const float *__restrict__ bmask, uint8_t *__restrict__ bits, int nb, int64_t nij, int *flag) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nij) return;
+    uint32_t v = 0;
+    bool bad = false;
+    for (int b = 0; b < nb; ++b) {
+        const float x = bmask[p * nb + b];
+        bad |= (x != 0.f && x != 1.f);
+        v |= (x != 0.f ? 1u : 0u) << b;
+    }
+    bits[p] = (uint8_t)v;
+    if (bad) atomicOr(flag, 1);
+}
+
+// Fast path for 0/1 basin masks (the usual case).  zmask*zmaskvar*zv is then (zmaskvar*zv) or an exact
+// zero, and dl_surf*zmask*zmaskvar is (dl_surf*zmaskvar) or zero, so the per-cell work is done once and
+// each basin only selects: bit-identical terms to the general kernel.  A workgroup owns a row jj for all
+// levels; every thread keeps the surface and the basin bits of its M cells (i = tid, tid+T, ...) in
+// registers and streams the field and its mask past them: 8 bytes per cell and level from HBM.
+template <int NB, int M, bool MEAN, bool MINMAX, int T>
+__global__ void __launch_bounds__(T) zonal_row_fast_kernel(ZonalArgs2 a, const uint8_t *__restrict__ bits) {
+    extern __shared__ double lds[];                     // [nlev][nwaves][NB][4]
+    const int jj = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = T / 64;
+    const int64_t nij = (int64_t)a.npi * a.npj, r2 = (int64_t)jj * a.npi;
+    double sf[M];
+    uint32_t bb[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        const int i = threadIdx.x + m * T;
+        const bool ok = i < a.npi;
+        sf[m] = ok ? a.surf[r2 + i] : 0.0;
+        bb[m] = ok ? bits[r2 + i] : 0u;
+    }
+    float zc[M], mc[M], zn[M], mn_[M];
+    auto fetch = [&](float (&z)[M], float (&mk)[M], int k) {
+        const float *zv = a.zv + (int64_t)k * nij + r2, *mv = a.mask3 + (int64_t)k * nij + r2;
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const int i = min((int)threadIdx.x + m * T, a.npi - 1);   // clamped: cells past the row have no bit set
+            z[m] = ld_stream(zv + i); mk[m] = ld_stream(mv + i);
+        }
+    };
+    fetch(zc, mc, 0);
+    for (int k = 0; k < a.nlev; ++k) {
+        if (k + 1 < a.nlev) fetch(zn, mn_, k + 1);      // next level in flight
+        double s[NB], ar[NB], mx[NB], mi[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) { s[b] = 0.0; ar[b] = 0.0; mx[b] = -1.e20f; mi[b] = 1.e20f; }
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            // zmask = 1: sum form (1.f*m)*z = m*z in r4; mean form ((1.d0*1)*m)*z = m*z in r8
+            const double dt = MEAN ? __dmul_rn((double)mc[m], (double)zc[m]) : (double)__fmul_rn(mc[m], zc[m]);
+            const double u = __dmul_rn(sf[m], dt);
+            const double w = MEAN ? __dmul_rn(sf[m], (double)mc[m]) : 0.0;     // (dl_surf*1)*zmaskvar
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const bool in = (bb[m] >> b) & 1u;
+                // zmask = 0: the reference's term is an exact (signed) zero, which never changes an r8 sum
+                // that already holds a value; and its dtmp = 0 never enters the minimum
+                s[b] += in ? u : 0.0;
+                if (MEAN) ar[b] += in ? w : 0.0;
+                if (MINMAX) {
+                    const double d = in ? dt : 0.0;
+                    mx[b] = fmax(mx[b], ((int)threadIdx.x + m * T < a.npi) ? d : mx[b]);
+                    if (in && dt != 0.0) mi[b] = fmin(mi[b], dt);
+                }
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const double ts = wave_sum(s[b]);
+            double ta = 0.0, tx = 0.0, tn = 0.0;
+            if (MEAN) ta = wave_sum(ar[b]);
+            if (MINMAX) {
+                tx = mx[b]; tn = mi[b];
+                for (int o = 32; o > 0; o >>= 1) { tx = fmax(tx, __shfl_xor(tx, o, 64)); tn = fmin(tn, __shfl_xor(tn, o, 64)); }
+            }
+            if (lane == 0) {
+                double *q = lds + (((int64_t)k * nwaves + wave) * NB + b) * 4;
+                q[0] = ts; q[1] = ta; q[2] = tx; q[3] = tn;
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < M; ++m) { zc[m] = zn[m]; mc[m] = mn_[m]; }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < a.nlev * a.nb; t += T) {
+        const int k = t / a.nb, b = t - k * a.nb;
+        double ts = 0.0, ta = 0.0, tx = -1.e20f, tn = 1.e20f;
+        for (int w = 0; w < nwaves; ++w) {
+            const double *q = lds + (((int64_t)k * nwaves + w) * NB + b) * 4;
+            ts += q[0]; ta += q[1]; tx = fmax(tx, q[2]); tn = fmin(tn, q[3]);
+        }
+        const int64_t o = ((int64_t)b * a.nlev + k) * a.npj + jj;
+        a.dsum[o] = ts;
+        if (MEAN) a.darea[o] = ta;
+        if (MINMAX) { a.rmax[o] = (float)tx; a.rmin[o] = (float)tn; }
+    }
+}
+
+template <int NB, int M, int T>
+int launch_fast(const ZonalArgs2 &a, const uint8_t *bits, bool mean, bool minmax, hipStream_t st) {
+    const size_t shmem = (size_t)a.nlev * (T / 64) * NB * 4 * sizeof(double);
+    const dim3 grid(a.npj), block(T);
+    if (mean && minmax)  hipLaunchKernelGGL((zonal_row_fast_kernel<NB, M, true, true, T>), grid, block, shmem, st, a, bits);
+    else if (mean)       hipLaunchKernelGGL((zonal_row_fast_kernel<NB, M, true, false, T>), grid, block, shmem, st, a, bits);
+    else                 hipLaunchKernelGGL((zonal_row_fast_kernel<NB, M, false, false, T>), grid, block, shmem, st, a, bits);
+    CDFT_LAUNCH_CHECK();
+    return CDFT_OK;
+}
+
+// rows up to 1536 / 4352 cells with 256 threads; longer rows would need more registers per thread than
+// pay off: they take the general kernel
+template <int NB>
+int launch_fast_nb(const ZonalArgs2 &a, const uint8_t *bits, bool mean, bool minmax, hipStream_t st, bool *done) {
+    *done = true;
+    if (a.npi <= 256 * 6)  return launch_fast<NB, 6, 256>(a, bits, mean, minmax, st);
+    if (a.npi <= 256 * 17) return launch_fast<NB, 17, 256>(a, bits, mean, minmax, st);
+    *done = false;
+    return CDFT_OK;
+}
+
+int keepz(void **dst, const void *src, size_t bytes, int space, hipStream_t st) {
+    if (!*dst && hipMalloc(dst, bytes + 64) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(CDFT_ERR_ALLOC, "cdfzonal: device allocation of %zu bytes failed", bytes);
+    }
+    CDFT_HIP(hipMemcpyAsync(*dst, src, bytes, space == CDFT_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+    return CDFT_OK;
+}
+
+template <int NB>
+int launch_rows(const ZonalArgs2 &a, bool mean, bool minmax, hipStream_t st) {
+    const size_t shmem = (size_t)a.nlev * (kThreads / 64) * NB * 4 * sizeof(double);
+    const dim3 grid(a.npj), block(kThreads);
+    if (mean && minmax)  hipLaunchKernelGGL((zonal_row_kernel<NB, true, true>), grid, block, shmem, st, a);
+    else if (mean)       hipLaunchKernelGGL((zonal_row_kernel<NB, true, false>), grid, block, shmem, st, a);
+    else                 hipLaunchKernelGGL((zonal_row_kernel<NB, false, false>), grid, block, shmem, st, a);
+    CDFT_LAUNCH_CHECK();
+    return CDFT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cdft_zonal_create(cdft_zonal_plan **plan, int npiglo, int npjglo, int npk, int nbasins) {
+    if (!plan) return fail(CDFT_ERR_ARG, "cdft_zonal_create: NULL plan pointer");
+    *plan = nullptr;
+    if (npiglo < 1 || npjglo < 1 || npk < 1 || nbasins < 1 || nbasins > kMaxNB)
+        return fail(CDFT_ERR_ARG, "cdft_zonal_create: bad sizes %d x %d x %d, %d basins (1..%d)", npiglo, npjglo, npk,
+                    nbasins, kMaxNB);
+    // the per-level partials of a row live in LDS (64 KB without opting in to more): 5 basins x 4 waves x 4
+    // values x 8 bytes = 640 bytes per level, i.e. up to 102 levels
+    if ((size_t)npk * 4 * (nbasins <= 1 ? 1 : (nbasins <= 5 ? 5 : 8)) * 4 * 8 > 64 * 1024)
+        return fail(CDFT_ERR_ARG, "cdft_zonal_create: %d levels x %d basins exceed the LDS budget of a row", npk, nbasins);
+    CDFT_TRY(require_device());
+    cdft_zonal_plan *p = new cdft_zonal_plan;
+    p->npi = npiglo; p->npj = npjglo; p->npk = npk; p->nb = nbasins;
+    *plan = p;
+    return CDFT_OK;
+}
+
+int cdft_zonal_set_mesh(cdft_zonal_plan *p, const float *e1, const float *e2, const float *zmaskvar, const float *zmask,
+                        int memspace, void *stream) {
+    if (!p || !e1 || !e2 || !zmaskvar || !zmask) return fail(CDFT_ERR_ARG, "cdft_zonal_set_mesh: NULL argument");
+    hipStream_t st = as_stream(stream);
+    const size_t nij = (size_t)p->npi * p->npj;
+    const void *d1, *d2;
+    CDFT_TRY(to_device(e1, nij * 4, memspace, p->st_a, st, &d1));
+    CDFT_TRY(to_device(e2, nij * 4, memspace, p->st_b, st, &d2));
+    if (!p->surf && hipMalloc((void **)&p->surf, nij * 8 + 64) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(CDFT_ERR_ALLOC, "cdft_zonal_set_mesh: device allocation failed");
+    }
+    hipLaunchKernelGGL(zonal_surf_kernel, dim3((unsigned)((nij + 255) / 256)), dim3(256), 0, st, (const float *)d1,
+                       (const float *)d2, p->surf, (int64_t)nij);
+    CDFT_LAUNCH_CHECK();
+    CDFT_TRY(keepz((void **)&p->mask3, zmaskvar, nij * p->npk * 4, memspace, st));
+    CDFT_TRY(keepz((void **)&p->bmask, zmask, nij * p->nb * 4, memspace, st));
+    if (!p->bits && (hipMalloc((void **)&p->bits, nij + 64) != hipSuccess || hipMalloc((void **)&p->flag, sizeof(int)) != hipSuccess)) {
+        (void)hipGetLastError();
+        return fail(CDFT_ERR_ALLOC, "cdft_zonal_set_mesh: device allocation failed");
+    }
+    CDFT_HIP(hipMemsetAsync(p->flag, 0, sizeof(int), st));
+    hipLaunchKernelGGL(zonal_bits_kernel, dim3((unsigned)((nij + 255) / 256)), dim3(256), 0, st, p->bmask, p->bits, p->nb,
+                       (int64_t)nij, p->flag);
+    CDFT_LAUNCH_CHECK();
+    int flag = 0;
+    CDFT_HIP(hipMemcpyAsync(&flag, p->flag, sizeof(int), hipMemcpyDeviceToHost, st));
+    CDFT_HIP(hipStreamSynchronize(st));
+    p->binary = (flag == 0);
+    p->st_a.release(); p->st_b.release();
+    p->mesh_set = true;
+    return CDFT_OK;
+}
+
+int cdft_zonal_compute(cdft_zonal_plan *p, const float *zv, int nlev, int in_space, int mean_form, double *dzo,
+                       double *darea, float *rzomax, float *rzomin, int out_space, void *stream) {
+    if (!p || !zv || !dzo) return fail(CDFT_ERR_ARG, "cdft_zonal_compute: NULL argument");
+    if (!p->mesh_set) return fail(CDFT_ERR_STATE, "cdft_zonal_compute: cdft_zonal_set_mesh has not succeeded");
+    if (nlev < 1 || nlev > p->npk) return fail(CDFT_ERR_ARG, "cdft_zonal_compute: nlev = %d outside 1..%d", nlev, p->npk);
+    if (mean_form && !darea) return fail(CDFT_ERR_ARG, "cdft_zonal_compute: the mean form needs darea");
+    const bool minmax = rzomax != nullptr || rzomin != nullptr;
+    if (minmax && (!rzomax || !rzomin || !mean_form))
+        return fail(CDFT_ERR_ARG, "cdft_zonal_compute: rzomax and rzomin go together, with the mean form");
+    hipStream_t st = as_stream(stream);
+    const int64_t nij = (int64_t)p->npi * p->npj;
+    const void *dz;
+    CDFT_TRY(to_device(zv, (size_t)nij * nlev * 4, in_space, p->st_zv, st, &dz));
+    const size_t n = (size_t)p->npj * nlev * p->nb;
+    ZonalArgs2 a;
+    a.surf = p->surf; a.mask3 = p->mask3; a.bmask = p->bmask; a.zv = (const float *)dz;
+    a.npi = p->npi; a.npj = p->npj; a.nlev = nlev; a.nb = p->nb;
+    a.dsum = dzo; a.darea = darea; a.rmax = rzomax; a.rmin = rzomin;
+    if (out_space == CDFT_MEM_HOST) {
+        CDFT_TRY(p->st_o[0].reserve(n * 8)); a.dsum = (double *)p->st_o[0].ptr;
+        if (mean_form) { CDFT_TRY(p->st_o[1].reserve(n * 8)); a.darea = (double *)p->st_o[1].ptr; }
+        if (minmax) {
+            CDFT_TRY(p->st_o[2].reserve(n * 4)); CDFT_TRY(p->st_o[3].reserve(n * 4));
+            a.rmax = (float *)p->st_o[2].ptr; a.rmin = (float *)p->st_o[3].ptr;
+        }
+    }
+    bool done = false;
+    static const bool force_general = getenv("CDFT_ZONAL_GENERAL") != nullptr;     // A/B and test hook
+    if (p->binary && !force_general) {
+        if (p->nb == 1)      CDFT_TRY(launch_fast_nb<1>(a, p->bits, mean_form != 0, minmax, st, &done));
+        else if (p->nb <= 5) CDFT_TRY(launch_fast_nb<5>(a, p->bits, mean_form != 0, minmax, st, &done));
+        else                 CDFT_TRY(launch_fast_nb<8>(a, p->bits, mean_form != 0, minmax, st, &done));
+    }
+    if (!done) {
+        if (p->nb == 1)      CDFT_TRY(launch_rows<1>(a, mean_form != 0, minmax, st));
+        else if (p->nb <= 5) CDFT_TRY(launch_rows<5>(a, mean_form != 0, minmax, st));
+        else                 CDFT_TRY(launch_rows<8>(a, mean_form != 0, minmax, st));
+    }
+    if (out_space == CDFT_MEM_HOST) {
+        CDFT_HIP(hipMemcpyAsync(dzo, a.dsum, n * 8, hipMemcpyDeviceToHost, st));
+        if (mean_form) CDFT_HIP(hipMemcpyAsync(darea, a.darea, n * 8, hipMemcpyDeviceToHost, st));
+        if (minmax) {
+            CDFT_HIP(hipMemcpyAsync(rzomax, a.rmax, n * 4, hipMemcpyDeviceToHost, st));
+            CDFT_HIP(hipMemcpyAsync(rzomin, a.rmin, n * 4, hipMemcpyDeviceToHost, st));
+        }
+        CDFT_HIP(hipStreamSynchronize(st));
+    }
+    return CDFT_OK;
+}
+
+int cdft_zonal_destroy(cdft_zonal_plan *p) {
+    if (!p) return CDFT_OK;
+    void *ptrs[] = {p->surf, p->mask3, p->bmask, p->bits, p->flag};
+    for (void *q : ptrs) if (q) (void)hipFree(q);
+    p->st_a.release(); p->st_b.release(); p->st_zv.release();
+    for (DevBuf &b : p->st_o) b.release();
+    delete p;
+    return CDFT_OK;
+}
+
+}  // extern "C"

@@ -60,7 +60,7 @@ MODULE cdfio
      MODULE PROCEDURE getattr, getatti, getattc
   END INTERFACE
 
-  PUBLIC :: getvaratt
+  PUBLIC :: getvaratt, getnvar, getvarname, getipk
   PUBLIC :: chkfile, chkvar, getdim, getvdim, getspval, getatt, getvar, getvar1d, getvare3, getvar3d
   PUBLIC :: create, createvar, putatt, putheadervar, putvar, putvar1d, putvar0d, closeout, ncopen, copyatt, ERR_HDL
 
@@ -328,6 +328,83 @@ CONTAINS
     ENDIF
     istatus = NF90_CLOSE(incid)
   END FUNCTION getatti
+
+  INTEGER(KIND=4) FUNCTION getnvar(cdfile)
+    !! number of variables of a file (src/cdfio.F90:1127-1145)
+    CHARACTER(LEN=*), INTENT(in) :: cdfile
+    INTEGER(KIND=4) :: incid, istatus
+    getnvar = 0
+    istatus = NF90_OPEN(cdfile, NF90_NOWRITE, incid)
+    istatus = NF90_INQUIRE(incid, nvariables=getnvar)
+    istatus = NF90_CLOSE(incid)
+  END FUNCTION getnvar
+
+  FUNCTION getipk(cdfile, knvars, cdep)
+    !! levels of every variable: 4-D -> size of the depth dimension, 3-D -> 1, else 0 (src/cdfio.F90:1148-1194)
+    CHARACTER(LEN=*),           INTENT(in) :: cdfile
+    INTEGER(KIND=4),            INTENT(in) :: knvars
+    CHARACTER(LEN=*), OPTIONAL, INTENT(in) :: cdep
+    INTEGER(KIND=4), DIMENSION(knvars) :: getipk
+    INTEGER(KIND=4) :: incid, inb, jv, iipk, istatus
+    CHARACTER(LEN=256) :: cldep
+    cldep = 'dep' ; IF ( PRESENT(cdep) ) cldep = cdep
+    iipk = getdim(cdfile, TRIM(cldep), kstatus=istatus)
+    IF ( istatus /= 0 ) THEN
+       PRINT *, ' getipk : vertical dim not found ...assume 1'
+       iipk = 1
+    ENDIF
+    istatus = NF90_OPEN(cdfile, NF90_NOWRITE, incid)
+    DO jv = 1, knvars
+       istatus = NF90_INQUIRE_VARIABLE(incid, jv, ndims=inb)
+       IF ( inb == 4 ) THEN ; getipk(jv) = iipk
+       ELSE IF ( inb == 3 ) THEN ; getipk(jv) = 1
+       ELSE ; getipk(jv) = 0
+       ENDIF
+    END DO
+    istatus = NF90_CLOSE(incid)
+  END FUNCTION getipk
+
+  FUNCTION getvarname(cdfile, knvars, sdtypvar)
+    !! names of the variables of a file, and their standard attributes into sdtypvar (src/cdfio.F90:1197-1290)
+    CHARACTER(LEN=*), INTENT(in) :: cdfile
+    INTEGER(KIND=4),  INTENT(in) :: knvars
+    TYPE(variable), DIMENSION(knvars) :: sdtypvar
+    CHARACTER(LEN=256), DIMENSION(knvars) :: getvarname
+    INTEGER(KIND=4) :: incid, jv, istatus, iatt
+    REAL(KIND=4) :: zatt
+    istatus = NF90_OPEN(cdfile, NF90_NOWRITE, incid)
+    DO jv = 1, knvars
+       istatus = NF90_INQUIRE_VARIABLE(incid, jv, name=getvarname(jv))
+       sdtypvar(jv)%cname = getvarname(jv)
+       sdtypvar(jv)%cunits            = catt('units')
+       sdtypvar(jv)%rmissing_value    = getspval(cdfile, sdtypvar(jv)%cname)
+       sdtypvar(jv)%valid_min = 0. ; sdtypvar(jv)%valid_max = 0. ; sdtypvar(jv)%iwght = 1
+       IF ( NF90_INQUIRE_ATTRIBUTE(incid, jv, 'valid_min') == NF90_NOERR ) THEN
+          istatus = NF90_GET_ATT(incid, jv, 'valid_min', zatt) ; sdtypvar(jv)%valid_min = zatt
+       ENDIF
+       IF ( NF90_INQUIRE_ATTRIBUTE(incid, jv, 'valid_max') == NF90_NOERR ) THEN
+          istatus = NF90_GET_ATT(incid, jv, 'valid_max', zatt) ; sdtypvar(jv)%valid_max = zatt
+       ENDIF
+       IF ( NF90_INQUIRE_ATTRIBUTE(incid, jv, 'iweight') == NF90_NOERR ) THEN
+          istatus = NF90_GET_ATT(incid, jv, 'iweight', iatt) ; sdtypvar(jv)%iwght = iatt
+       ENDIF
+       sdtypvar(jv)%clong_name        = catt('long_name')
+       sdtypvar(jv)%cshort_name       = catt('short_name')
+       sdtypvar(jv)%conline_operation = catt('online_operation')
+       sdtypvar(jv)%caxis             = catt('axis')
+    END DO
+    istatus = NF90_CLOSE(incid)
+  CONTAINS
+    CHARACTER(LEN=256) FUNCTION catt(cdatt)
+      CHARACTER(LEN=*), INTENT(in) :: cdatt
+      INTEGER(KIND=4) :: ilen
+      catt = 'N/A'
+      IF ( NF90_INQUIRE_ATTRIBUTE(incid, jv, cdatt, len=ilen) == NF90_NOERR ) THEN
+         catt = ' '
+         istatus = NF90_GET_ATT(incid, jv, cdatt, catt)
+      ENDIF
+    END FUNCTION catt
+  END FUNCTION getvarname
 
   INTEGER(KIND=4) FUNCTION getvaratt(cdfile, cdvar, cdunits, pmissing_value, cdlong_name, cdshort_name)
     !! units, missing value, long and short name of a variable; an absent attribute leaves its argument

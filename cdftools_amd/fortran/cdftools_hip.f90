@@ -130,6 +130,22 @@ MODULE cdftools_hip
      INTEGER(C_INT) FUNCTION cdft_mean_destroy(plan) BIND(C, name='cdft_mean_destroy')
        IMPORT ; TYPE(C_PTR), VALUE :: plan
      END FUNCTION
+     ! ---- cdfzonalsum, cdfzonalmean --------------------------------------------------------
+     INTEGER(C_INT) FUNCTION cdft_zonal_create(plan, npiglo, npjglo, npk, nbasins) BIND(C, name='cdft_zonal_create')
+       IMPORT ; TYPE(C_PTR), INTENT(out) :: plan ; INTEGER(C_INT), VALUE :: npiglo, npjglo, npk, nbasins
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_zonal_set_mesh(plan, e1, e2, zmaskvar, zmask, memspace, stream) BIND(C, name='cdft_zonal_set_mesh')
+       IMPORT ; TYPE(C_PTR), VALUE :: plan, stream ; REAL(C_FLOAT), INTENT(in) :: e1(*), e2(*), zmaskvar(*), zmask(*)
+       INTEGER(C_INT), VALUE :: memspace
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_zonal_compute(plan, zv, nlev, in_space, mean_form, dzo, darea, rzomax, rzomin, out_space, &
+          &                                     stream) BIND(C, name='cdft_zonal_compute')
+       IMPORT ; TYPE(C_PTR), VALUE :: plan, stream, darea, rzomax, rzomin ; REAL(C_FLOAT), INTENT(in) :: zv(*)
+       INTEGER(C_INT), VALUE :: nlev, in_space, mean_form, out_space ; REAL(C_DOUBLE), INTENT(out) :: dzo(*)
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_zonal_destroy(plan) BIND(C, name='cdft_zonal_destroy')
+       IMPORT ; TYPE(C_PTR), VALUE :: plan
+     END FUNCTION
      ! ---- cdfpsi ---------------------------------------------------------------------------
      INTEGER(C_INT) FUNCTION cdft_psi_create(plan, npiglo, npjglo, npk) BIND(C, name='cdft_psi_create')
        IMPORT ; TYPE(C_PTR), INTENT(out) :: plan ; INTEGER(C_INT), VALUE :: npiglo, npjglo, npk

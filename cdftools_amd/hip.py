@@ -465,6 +465,40 @@ class MeanPlan(_Plan):
         return out
 
 
+class ZonalPlan(_Plan):
+    """cdfzonalsum / cdfzonalmean (src/cdfzonalsum.f90:296-313, src/cdfzonalmean.f90:313-330): cdft_zonal_*."""
+
+    _destroy = "cdft_zonal_destroy"
+
+    def __init__(self, npiglo, npjglo, npk, nbasins=1):
+        self.npi, self.npj, self.npk, self.nb = npiglo, npjglo, npk, nbasins
+        self._h = C.c_void_p()
+        check(_lib.load().cdft_zonal_create(C.byref(self._h), npiglo, npjglo, npk, nbasins))
+
+    def set_mesh(self, e1, e2, zmaskvar, zmask, stream=None):
+        """e1, e2 (npj,npi); zmaskvar (npk,npj,npi) r4; zmask (npj,npi,nb) r4 (host arrays)."""
+        k = [np.ascontiguousarray(x, np.float32) for x in (e1, e2, zmaskvar, zmask)]
+        check(_lib.load().cdft_zonal_set_mesh(self._h, *[C.c_void_p(a.ctypes.data) for a in k], MEM_HOST,
+                                              stream or current_stream_ptr()))
+
+    def compute(self, zv, mean_form=False, minmax=False, stream=None):
+        """zv (nlev,npj,npi) r4 -> dict of (nb,nlev,npj) arrays: 'sum' [, 'area', 'max', 'min']."""
+        pz, sz, kz = _arg(zv, np.float32, "zv")
+        nlev = kz.shape[0]
+        shape = (self.nb, nlev, self.npj)
+        out = {"sum": np.empty(shape, np.float64)}
+        pa = px = pn = _null()
+        if mean_form:
+            out["area"] = np.empty(shape, np.float64)
+            pa = C.c_void_p(out["area"].ctypes.data)
+        if minmax:
+            out["max"], out["min"] = np.empty(shape, np.float32), np.empty(shape, np.float32)
+            px, pn = C.c_void_p(out["max"].ctypes.data), C.c_void_p(out["min"].ctypes.data)
+        check(_lib.load().cdft_zonal_compute(self._h, pz, nlev, sz, 1 if mean_form else 0, C.c_void_p(out["sum"].ctypes.data),
+                                             pa, px, pn, MEM_HOST, stream or current_stream_ptr()))
+        return out
+
+
 def vint_transport(vel, m2d, e3=None, e31d=None, stream=None):
     """cdft_vint_transport: vel (npk,npj,npi) r4 -> (npj,npi) r8 (host arrays or CUDA tensors)."""
     pv, sv, kv = _arg(vel, np.float32, "vel")
@@ -538,4 +572,4 @@ class CurlPlan(_Plan):
         return out
 
 
-__all__ = ["MocPlan", "HeatcPlan", "MeanPlan", "MhstPlan", "PsiPlan", "CurlPlan", "vt_compute", "vint_transport", "vhst_transport", "sigmai", "sigma0", "sig_tool", "EOS_80", "EOS_TEOS10", "EOS_JMD94", "EOS_FAST_FMA", "Timer", "CdftError", "device_count", "current_stream_ptr", "MEM_HOST", "MEM_DEVICE"]
+__all__ = ["MocPlan", "HeatcPlan", "MeanPlan", "ZonalPlan", "MhstPlan", "PsiPlan", "CurlPlan", "vt_compute", "vint_transport", "vhst_transport", "sigmai", "sigma0", "sig_tool", "EOS_80", "EOS_TEOS10", "EOS_JMD94", "EOS_FAST_FMA", "Timer", "CdftError", "device_count", "current_stream_ptr", "MEM_HOST", "MEM_DEVICE"]

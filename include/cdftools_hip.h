@@ -240,6 +240,27 @@ int cdft_mean_compute(cdft_mean_plan *plan, const float *zv, int in_space, doubl
 int cdft_mean_destroy(cdft_mean_plan *plan);
 
 /* ------------------------------------------------------------------------------------------ */
+/* cdfzonalsum, cdfzonalmean : zonal integral / mean of any field        */
+/*   replaces src/cdfzonalsum.f90:296-313 and src/cdfzonalmean.f90:313-330                      */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct cdft_zonal_plan cdft_zonal_plan;
+int cdft_zonal_create(cdft_zonal_plan **plan, int npiglo, int npjglo, int npk, int nbasins /* 1..8 */);
+/* e1, e2 (npiglo,npjglo) r4 of the variable's grid point (dl_surf = 1.d0*e1*e2); zmaskvar (npiglo,npjglo,npk)
+ * r4, the mask of that grid point at every level; zmask (nbasins,npiglo,npjglo) r4, basin index fastest,
+ * the reference's zmask array (global, then the sub-basins). */
+int cdft_zonal_set_mesh(cdft_zonal_plan *plan, const float *e1, const float *e2, const float *zmaskvar,
+                        const float *zmask, int memspace, void *stream);
+/* zv (npiglo,npjglo,nlev) r4: the nlev levels (1 for a 2-D variable) of one variable and record.
+ * mean_form = 0 (cdfzonalsum): dzo (npjglo,nlev,nbasins) r8 = the integral along i, BEFORE the optional
+ *   division by alpha(jj) (-pdeg), which the caller applies.
+ * mean_form = 1 (cdfzonalmean): dzo = sum of dl_surf*dtmp, darea = sum of dl_surf*zmask*zmaskvar, both
+ *   (npjglo,nlev,nbasins) r8; the caller divides where darea /= 0.  rzomax, rzomin (npjglo,nlev,nbasins) r4
+ *   or NULL: the -max option (extrema of dtmp, the minimum over dtmp /= 0, start values -1.e20 / 1.e20). */
+int cdft_zonal_compute(cdft_zonal_plan *plan, const float *zv, int nlev, int in_space, int mean_form, double *dzo,
+                       double *darea, float *rzomax, float *rzomin, int out_space, void *stream);
+int cdft_zonal_destroy(cdft_zonal_plan *plan);
+
+/* ------------------------------------------------------------------------------------------ */
 /* cdfpsi : barotropic stream function                                                        */
 /*   replaces src/cdfpsi.f90:271-298 (vertical integration), :377-423 (scans, mean, reference  */
 /*   point) and the SNGL / mask at :426-433.  Not covered: -open, --ssh-file, -lev.            */

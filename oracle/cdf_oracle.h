@@ -66,6 +66,9 @@ void oracle_vhst_transport(int npi, int npj, int npk, const float *xt, const flo
                            const float *e3, const float *e31d, double *dheat, double *dsalt);
 void oracle_mean(int npi, int npj, int npk, int nb, const float *e1, const float *e2, const float *e3,
                  const float *e31d, const float *zmask, const int16_t *ibmask, const float *zv, double *sums);
+void oracle_zonal(int npi, int npj, int nlev, int nb, const float *e1, const float *e2, const float *zmaskvar,
+                  const float *zmask, const float *zv, int mean_form, double *dzo, double *darea, float *rmax,
+                  float *rmin);
 void oracle_psi_open(int npi, int npj, int npk, const float *zu, const float *e2u, const float *e3u,
                      const float *zv, const float *e1v, const float *e3v, const float *e31d, int lmean,
                      int iiref, int ijref, int noref, const float *fmask, float *psi4, double *dpsi8);

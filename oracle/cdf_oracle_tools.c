@@ -357,3 +357,38 @@ void oracle_mean(int npi, int npj, int npk, int nb, const float *e1, const float
             o[0] = s0; o[1] = s1; o[2] = s2; o[3] = s3;
         }
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* src/cdfzonalsum.f90:296-313 (mean_form = 0) and src/cdfzonalmean.f90:313-330 (mean_form = 1) for one
+ * variable and record of nlev levels.  e1,e2 (npi,npj); zmaskvar (npi,npj,nlev); zmask (nb,npi,npj) r4;
+ * outputs (npj,nlev,nb): dzo, darea (mean form) r8, rmax / rmin r4 (mean form, may be NULL).
+ *   sum  form: dtmp = zmask*zmaskvar*zv*1.d0 (r4 product) ; dzo += dl_surf*dtmp
+ *   mean form: dtmp = 1.d0*zmask*zmaskvar*zv (r8 products); dzo += dl_surf*dtmp ;
+ *              darea += dl_surf*zmask*zmaskvar ; rzomax = MAX(rzomax,dtmp) ; dtmp /= 0: rzomin = MIN(rzomin,dtmp)
+ *   dl_surf = 1.d0*e1*e2 */
+void oracle_zonal(int npi, int npj, int nlev, int nb, const float *e1, const float *e2, const float *zmaskvar,
+                  const float *zmask, const float *zv, int mean_form, double *dzo, double *darea, float *rmax,
+                  float *rmin) {
+    const size_t nij = (size_t)npi * npj;
+    for (int b = 0; b < nb; ++b)
+        for (int k = 0; k < nlev; ++k)
+            for (int j = 0; j < npj; ++j) {
+                double s = 0.0, a = 0.0;
+                float mx = -1.e20f, mn = 1.e20f;
+                for (int i = 0; i < npi; ++i) {
+                    const size_t p = IJ(i, j);
+                    const float zb = zmask[p * nb + b], m = zmaskvar[k * nij + p], z = zv[k * nij + p];
+                    const double surf = 1.0 * (double)e1[p] * (double)e2[p];
+                    const double dtmp = mean_form ? 1.0 * (double)zb * (double)m * (double)z : (double)(zb * m * z) * 1.0;
+                    s = s + surf * dtmp;
+                    if (mean_form) {
+                        a = a + surf * (double)zb * (double)m;
+                        mx = (float)((double)mx > dtmp ? (double)mx : dtmp);
+                        if (dtmp != 0.0) mn = (float)((double)mn < dtmp ? (double)mn : dtmp);
+                    }
+                }
+                const size_t o = ((size_t)b * nlev + k) * npj + j;
+                dzo[o] = s;
+                if (mean_form) { darea[o] = a; if (rmax) rmax[o] = mx; if (rmin) rmin[o] = mn; }
+            }
+}

@@ -31,6 +31,8 @@ def write_mesh(d, g):
     with _new(os.path.join(d, "mesh_hgr.nc"), dims) as f:
         for nm in ("e1t", "e2t", "e1u", "e2u", "e1v", "e2v", "e1f", "e2f", "glamf", "gphif", "gphiv"):
             _var(f, nm, "f4", ("t", "y", "x"), g[nm][None])
+        for nm in ("gphit", "gphiu"):                                    # same latitudes on this synthetic grid
+            _var(f, nm, "f4", ("t", "y", "x"), g["gphif"][None])
     with _new(os.path.join(d, "mesh_zgr.nc"), dims) as f:
         for nm in ("e3t_0", "e3u_0", "e3v_0"):
             _var(f, nm, "f4", ("t", "z", "y", "x"), g[nm][None])

@@ -126,3 +126,20 @@ def mean(e1, e2, zmask, ibmask, zv, e3=None, e31d=None):
     lib.oracle_mean(C.c_int(npi), C.c_int(npj), C.c_int(npk), C.c_int(nb), _p(e1), _p(e2), _pp(e3), _pp(e31d), _p(zmask),
                     _p(ib), _p(zv), _p(out))
     return out
+
+
+def zonal(e1, e2, zmaskvar, zmask, zv, mean_form=False):
+    """cdfzonalsum / cdfzonalmean loops -> dict of (nb,nlev,npj): sum [, area, max, min]."""
+    lib = load()
+    e1, e2, zmaskvar, zmask, zv = map(_f, (e1, e2, zmaskvar, zmask, zv))
+    nlev, npj, npi = zv.shape
+    nb = zmask.shape[-1]
+    out = {"sum": np.empty((nb, nlev, npj), np.float64)}
+    pa = px = pn = None
+    if mean_form:
+        out["area"] = np.empty((nb, nlev, npj), np.float64)
+        out["max"], out["min"] = np.empty((nb, nlev, npj), np.float32), np.empty((nb, nlev, npj), np.float32)
+        pa, px, pn = _p(out["area"]), _p(out["max"]), _p(out["min"])
+    lib.oracle_zonal(C.c_int(npi), C.c_int(npj), C.c_int(nlev), C.c_int(nb), _p(e1), _p(e2), _p(zmaskvar), _p(zmask), _p(zv),
+                     C.c_int(1 if mean_form else 0), _p(out["sum"]), pa, px, pn)
+    return out

@@ -205,3 +205,109 @@ def test_cdfmean_end_to_end(tools, tmp_path):  # noqa: F811
     assert rc == 99 and "-zeromean" in out
     rc, out, _ = run("cdfmean", ["-f", "SYN_y0001_gridT.nc", "-v", "votemper", "-p", "Q"], d)
     assert rc == 99 and "not known" in out
+
+
+# ------------------------------------------------------------------------------ cdfzonalsum / cdfzonalmean
+def zonal_inputs(npi, npj, npk, nb, seed):
+    g = synth.make_grid(npi, npj, npk, seed=seed)
+    rng = np.random.default_rng(seed + 5)
+    zv = ((-2 + 30 * rng.random((npk, npj, npi), dtype=np.float32)) * g["tmask"]).astype(np.float32)
+    zm = np.zeros((npj, npi, nb), np.float32)
+    zm[:, :, 0] = g["tmask"][0]
+    if nb >= 5:
+        zm[:, :, 1], zm[:, :, 3], zm[:, :, 4] = g["tmaskatl"], g["tmaskind"], g["tmaskpac"]
+        zm[:, :, 2] = np.minimum(zm[:, :, 4] + zm[:, :, 3], 1)
+    return g, zv, zm
+
+
+def test_oracle_zonal_matches_numpy_restatement():
+    g, zv, zm = zonal_inputs(19, 13, 5, 5, seed=8)
+    tm = g["tmask"].astype(np.float32)
+    surf = g["e1t"].astype(np.float64) * g["e2t"].astype(np.float64)
+    s = oracle_tools.zonal(g["e1t"], g["e2t"], tm, zm, zv)
+    m = oracle_tools.zonal(g["e1t"], g["e2t"], tm, zm, zv, mean_form=True)
+    for b in range(5):
+        d4 = ((zm[None, :, :, b] * tm).astype(np.float32) * zv).astype(np.float32).astype(np.float64)
+        assert np.allclose(s["sum"][b], (surf[None] * d4).sum(axis=2), rtol=1e-13, atol=0)
+        d8 = zm[None, :, :, b].astype(np.float64) * tm * zv
+        assert np.allclose(m["sum"][b], (surf[None] * d8).sum(axis=2), rtol=1e-13, atol=0)
+        assert np.allclose(m["area"][b], (surf[None] * zm[None, :, :, b] * tm).sum(axis=2), rtol=1e-13, atol=0)
+        assert np.array_equal(m["max"][b], np.maximum(d8.max(axis=2), np.float32(-1e20)).astype(np.float32))
+        mn = np.where(d8 != 0, d8, np.inf).min(axis=2)
+        assert np.array_equal(m["min"][b], np.minimum(mn, np.float32(1e20)).astype(np.float32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("npi,npj,npk,nb", [(24, 18, 7, 5), (182, 149, 31, 5), (1, 1, 1, 1), (300, 5, 2, 1), (1031, 4, 3, 5)])
+def test_hip_zonal_matches_oracle(gpu, npi, npj, npk, nb):
+    g, zv, zm = zonal_inputs(npi, npj, npk, nb, seed=npi + 9)
+    tm = g["tmask"].astype(np.float32)
+    plan = gpu.ZonalPlan(npi, npj, npk, nb)
+    plan.set_mesh(g["e1t"], g["e2t"], tm, zm)
+    for mean_form in (False, True):
+        got = plan.compute(zv, mean_form=mean_form, minmax=mean_form)
+        ref = oracle_tools.zonal(g["e1t"], g["e2t"], tm, zm, zv, mean_form=mean_form)
+        bound = oracle_tools.zonal(g["e1t"], g["e2t"], tm, zm, np.abs(zv), mean_form=mean_form)["sum"]
+        assert np.all(np.abs(got["sum"] - ref["sum"]) <= 1e-13 * bound + 1e-300)
+        if mean_form:
+            assert np.all(np.abs(got["area"] - ref["area"]) <= 1e-13 * ref["area"] + 1e-300)
+            assert np.array_equal(got["max"], ref["max"]) and np.array_equal(got["min"], ref["min"])
+    two = plan.compute(zv[:2] if npk > 1 else zv)                          # a variable with fewer levels
+    ref = oracle_tools.zonal(g["e1t"], g["e2t"], tm[:2], zm, zv[:2] if npk > 1 else zv)
+    assert np.allclose(two["sum"], ref["sum"], rtol=1e-12, atol=1e-6)
+
+
+@pytest.mark.parametrize("tool", ["cdfzonalsum", "cdfzonalmean", "cdfmean"])
+def test_usage_of_the_reduction_tools(tools, tmp_path, tool):  # noqa: F811
+    rc, out, _ = run(tool, [], tmp_path)
+    assert rc == 0 and "usage :" in out.splitlines()[0] and tool in out.splitlines()[0]
+    rc, out, _ = run(tool, ["-thisisnotanoption"], tmp_path)
+    assert rc == 99 and "unknown option" in out
+    rc, out, _ = run(tool, ["-f", "nothere.nc", "-p", "T"] + (["-v", "votemper"] if tool == "cdfmean" else []), tmp_path)
+    assert rc == 99 and "missing" in out
+
+
+@pytest.mark.gpu
+def test_cdfzonalsum_and_cdfzonalmean_end_to_end(tools, tmp_path):  # noqa: F811
+    d = str(tmp_path)
+    g, rec = nemo_files.make_case(d, npi=26, npj=19, npk=6, npt=2)
+    npk, npj, npi = g["tmask"].shape
+    tm = g["tmask"].astype(np.float32)
+    zm = np.zeros((npj, npi, 5), np.float32)
+    zm[:, :, 0] = g["tmask"][0]
+    zm[:, :, 1], zm[:, :, 3], zm[:, :, 4] = g["tmaskatl"], g["tmaskind"], g["tmaskpac"]
+    zm[:, :, 2] = np.minimum(zm[:, :, 4] + zm[:, :, 3], 1)
+    sfx = ["_glo", "_atl", "_inp", "_ind", "_pac"]
+
+    rc, out, err = run("cdfzonalsum", ["-f", "SYN_y0001_gridT.nc", "-p", "T", "-b", "new_maskglo.nc"], d)
+    assert rc == 0, out + err
+    var, att, dims = read_nc(os.path.join(d, "zonalsum.nc"))
+    assert dims["x"] == 1 and dims["y"] == npj and att["zoitemper_atl"]["long_name"].startswith(b"Zonal_Integral_")
+    for nm, key in (("zoitemper", "t"), ("zoisaline", "s")):
+        for t in range(2):
+            ref = oracle_tools.zonal(g["e1t"], g["e2t"], tm, zm, rec[key][t])["sum"]
+            for b in range(5):
+                got = var[nm + sfx[b]][t, :, :, 0]
+                assert np.allclose(got, ref[b], rtol=2e-7, atol=0), (nm, b)
+    assert np.array_equal(var["deptht"], -g["gdept_1d"])
+    # one variable, per degree of latitude, positive depths
+    rc, out, err = run("cdfzonalsum", ["-f", "SYN_y0001_gridT.nc", "-p", "T", "-l", "vosaline", "-pdeg", "-pdep"], d)
+    assert rc == 0, out + err
+    var, att, _ = read_nc(os.path.join(d, "zonalintdeg.nc"))
+    assert [n for n in var if n.startswith("zoi")] == ["zoisaline_glo"] and np.array_equal(var["deptht"], g["gdept_1d"])
+    alpha = (g["e2t"][:, 0] * np.float32(360.) / (np.float32(2.0) * np.arccos(np.float32(-1.))) / np.float32(6371229.)).astype(np.float32)
+    ref = oracle_tools.zonal(g["e1t"], g["e2t"], tm, zm[:, :, :1], rec["s"][0])["sum"][0] / alpha[None, :]
+    assert np.allclose(var["zoisaline_glo"][0, :, :, 0], ref, rtol=3e-7)
+
+    rc, out, err = run("cdfzonalmean", ["-f", "SYN_y0001_gridT.nc", "-p", "T", "-b", "new_maskglo.nc", "-max", "-l", "votemper"], d)
+    assert rc == 0, out + err
+    var, att, _ = read_nc(os.path.join(d, "zonalmean.nc"))
+    assert att["zotemper_pac_max"]["long_name"].startswith(b"Zonal_Max_")
+    for t in range(2):
+        ref = oracle_tools.zonal(g["e1t"], g["e2t"], tm, zm, rec["t"][t], mean_form=True)
+        ok = ref["area"] != 0
+        mean = np.where(ok, ref["sum"] / np.where(ok, ref["area"], 1), 0.0)
+        for b in range(5):
+            assert np.allclose(var["zotemper" + sfx[b]][t, :, :, 0], mean[b], rtol=2e-7, atol=0)
+            assert np.array_equal(var["zotemper" + sfx[b] + "_max"][t, :, :, 0], np.where(ok[b], ref["max"][b], 0).astype(np.float32))
+            assert np.array_equal(var["zotemper" + sfx[b] + "_min"][t, :, :, 0], np.where(ok[b], ref["min"][b], 0).astype(np.float32))

@@ -43,7 +43,7 @@ def main():
     ap.add_argument("--grid", default="eorca025", choices=sorted(GRIDS))
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--frames", type=int, default=6)
-    ap.add_argument("--tools", default="heatc,mean,mhst,psi,vt,curl,eos")
+    ap.add_argument("--tools", default="heatc,mean,zonal,mhst,psi,vt,curl,eos")
     args = ap.parse_args()
     npi, npj, npk = GRIDS[args.grid]
     dev = torch.device("cuda", 0)
@@ -71,6 +71,18 @@ def main():
         del tm
         ms = timed(lambda: p.compute(zv), args.reps)
         report("cdfmean (1 basin)", args.grid, n3, 12.0, ms, "field 4 + e3 4 + r4 mask 4 B per cell; includes the D2H of 4*npk sums")
+        del p, zv
+
+    if "zonal" in tools:
+        tm = (rnd(npk, npj, npi) > 0.35).float().cpu().numpy()
+        zm = (rnd(npj, npi, 5) > 0.4).float().cpu().numpy()
+        zv = (-2 + 32 * rnd(npk, npj, npi))
+        p = hip.ZonalPlan(npi, npj, npk, 5)
+        p.set_mesh(e1.cpu().numpy(), e2.cpu().numpy(), tm, zm)
+        del tm, zm
+        for name, mf in (("cdfzonalsum (5 basins)", False), ("cdfzonalmean (5 basins)", True)):
+            ms = timed(lambda: p.compute(zv, mean_form=mf), args.reps)
+            report(name, args.grid, n3, 8.0, ms, "field 4 + mask 4 B per cell (2-D surface and basin masks from cache); D2H of the result included")
         del p, zv
 
     if "mhst" in tools:
