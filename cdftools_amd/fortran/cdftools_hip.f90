@@ -146,6 +146,19 @@ MODULE cdftools_hip
      INTEGER(C_INT) FUNCTION cdft_zonal_destroy(plan) BIND(C, name='cdft_zonal_destroy')
        IMPORT ; TYPE(C_PTR), VALUE :: plan
      END FUNCTION
+     ! ---- cdfvint, cdfvertmean -------------------------------------------------------------
+     INTEGER(C_INT) FUNCTION cdft_vint_cumul(zt, e3t, e31d, tmask, npiglo, npjglo, npk, kout, khit, clip, rdep2, npko, sclf, &
+          &                                  mean, in_space, zout, out_space, stream) BIND(C, name='cdft_vint_cumul')
+       IMPORT ; REAL(C_FLOAT), INTENT(in) :: zt(*), tmask(*), clip(*), rdep2(*) ; TYPE(C_PTR), VALUE :: e3t, e31d, stream
+       INTEGER(C_INT), INTENT(in) :: kout(*), khit(*) ; INTEGER(C_INT), VALUE :: npiglo, npjglo, npk, npko, mean, in_space, out_space
+       REAL(C_FLOAT), VALUE :: sclf ; REAL(C_FLOAT), INTENT(out) :: zout(*)
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_vertmean(zv, e3, e31d, zmask, npiglo, npjglo, nlev, gdep_first, gdep_last, rdep_up, rdep_down, &
+          &                                in_space, dvertmean, out_space, stream) BIND(C, name='cdft_vertmean')
+       IMPORT ; REAL(C_FLOAT), INTENT(in) :: zv(*), zmask(*) ; TYPE(C_PTR), VALUE :: e3, e31d, stream
+       INTEGER(C_INT), VALUE :: npiglo, npjglo, nlev, in_space, out_space
+       REAL(C_FLOAT), VALUE :: gdep_first, gdep_last, rdep_up, rdep_down ; REAL(C_DOUBLE), INTENT(out) :: dvertmean(*)
+     END FUNCTION
      ! ---- cdfpsi ---------------------------------------------------------------------------
      INTEGER(C_INT) FUNCTION cdft_psi_create(plan, npiglo, npjglo, npk) BIND(C, name='cdft_psi_create')
        IMPORT ; TYPE(C_PTR), INTENT(out) :: plan ; INTEGER(C_INT), VALUE :: npiglo, npjglo, npk

@@ -1,0 +1,241 @@
+PROGRAM cdfvint
+  !!======================================================================
+  !!                     ***  PROGRAM  cdfvint  ***
+  !! Vertical integral of temperature (heat content) or salinity from the surface down, cumulated and
+  !! written at every output depth (model levels, -GSOP or -OCCI depths).
+  !!
+  !! Drop-in for the reference tool (src/cdfvint.f90): same options, same <var>.nc (voheatc | vohsalt |
+  !! votemper | vosaline float (t,depthw,y,x), :318-346).  The column integration (:266-311) runs on the GPU
+  !! for all levels of a record at once (cdft_vint_cumul, bit-identical); the scalar bookkeeping of the level
+  !! loop (depth counters, which level is written, clipping depth) is done here exactly as the reference does.
+  !!======================================================================
+  USE ISO_C_BINDING
+  USE cdfio
+  USE modcdfnames
+  USE cdftools_hip
+  IMPLICIT NONE
+
+  INTEGER(KIND=4) :: narg, ijarg, ierr, jk, jt, it, iko, npiglo, npjglo, npk, npko, npt, ncout
+  INTEGER(KIND=4) :: iimin = 0, iimax = 0, ijmin = 0, ijmax = 0, ipk(1), id_varout(1)
+  INTEGER(C_INT), ALLOCATABLE :: kout(:), khit(:)
+  REAL(KIND=4), PARAMETER :: pprho0 = 1020., ppcp = 4000.
+  REAL(KIND=4) :: rdep1, rdep2, tol = 1.0, sclf = 1.0
+  REAL(KIND=4), ALLOCATABLE, TARGET :: e3t(:,:,:), e31d(:)
+  REAL(KIND=4), ALLOCATABLE :: gdepw(:), gdepo(:), zt(:,:,:), tmask(:,:,:), rlon(:,:), rlat(:,:), zout(:,:,:), zclip(:), zdiv(:)
+  REAL(KIND=8), ALLOCATABLE :: dtim(:)
+  CHARACTER(LEN=256) :: cf_in = 'none', cf_out, cv_in, cv_out, cunits, clongname, cldum
+  TYPE(variable) :: stypvar(1)
+  TYPE(C_PTR) :: pe3, pe31d
+  LOGICAL :: lfull = .FALSE., lgsop = .FALSE., locci = .FALSE., lchk, lout, ltmean = .FALSE., lsmean = .FALSE.
+  LOGICAL :: lnc4 = .FALSE., lfout = .FALSE.
+  !!----------------------------------------------------------------------
+  CALL ReadCdfNames()
+  cv_in = cn_votemper
+  narg = COMMAND_ARGUMENT_COUNT()
+  IF ( narg == 0 ) THEN
+     PRINT *, ' usage : cdfvint -f T-file [-v IN-var] [-GSOP] [-OCCI] [-full] [-vvl] ...'
+     PRINT *, '              ... [-w imin imax jmin jmax ] ...'
+     PRINT *, '              ... [-tmean] [-smean] [-o OUT-file] [-nc4]'
+     PRINT *, '      '
+     PRINT *, '     PURPOSE :'
+     PRINT *, '       Compute the vertical integral of the variable from top to bottom and save the cumulated'
+     PRINT *, '       values level by level: heat content (10^6 J/m2) for temperature, PSU.m for salinity.'
+     PRINT *, '       MI355X build: the integration runs on the GPU.'
+     PRINT *, '      '
+     PRINT *, '     ARGUMENTS :'
+     PRINT *, '         -f T-file : gridT file holding either temperature or salinity '
+     PRINT *, '      '
+     PRINT *, '     OPTIONS :'
+     PRINT *, '        [-v IN-var ] : input variable, default ', TRIM(cn_votemper), ', or ', TRIM(cn_vosaline)
+     PRINT *, '        [-GSOP] : 7 GSOP standard levels for the output (default: the model levels)'
+     PRINT *, '        [-OCCI] : 3 levels for the output: 700m, 2000m and bottom'
+     PRINT *, '        [-full] : full step computation '
+     PRINT *, '        [-vvl]  : time-varying vertical metrics'
+     PRINT *, '        [-w imin imax jmin jmax ] : limit the computation to a subdomain'
+     PRINT *, '        [-tmean] : output mean temperature instead of heat content'
+     PRINT *, '        [-smean] : output mean salinity instead of PSU.m'
+     PRINT *, '        [-o OUT-file] : output file instead of <IN-var>.nc'
+     PRINT *, '        [-nc4]  : accepted; the bundled NetCDF backend writes classic files'
+     PRINT *, '      '
+     PRINT *, '     REQUIRED FILES :'
+     PRINT *, '       ', TRIM(cn_fmsk), ', ', TRIM(cn_fhgr), ' and ', TRIM(cn_fzgr)
+     PRINT *, '      '
+     PRINT *, '     OUTPUT : '
+     PRINT *, '       netcdf file :  VAR-name.nc (or specified with -o option)'
+     PRINT *, '         variables :  voheatc or vohsalt, ', TRIM(cn_votemper), ' or ', TRIM(cn_vosaline), ' with -tmean / -smean'
+     STOP
+  ENDIF
+
+  ijarg = 1
+  DO WHILE ( ijarg <= narg )
+     CALL GET_COMMAND_ARGUMENT(ijarg, cldum) ; ijarg = ijarg + 1
+     SELECT CASE ( cldum )
+     CASE ( '-f'     ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cf_in) ; ijarg = ijarg + 1
+     CASE ( '-v'     ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cv_in) ; ijarg = ijarg + 1
+     CASE ( '-GSOP'  ) ; lgsop  = .TRUE.
+     CASE ( '-OCCI'  ) ; locci  = .TRUE.
+     CASE ( '-full'  ) ; lfull  = .TRUE.
+     CASE ( '-tmean' ) ; ltmean = .TRUE.
+     CASE ( '-smean' ) ; lsmean = .TRUE.
+     CASE ( '-vvl'   ) ; lg_vvl = .TRUE.
+     CASE ( '-w'     ) ; CALL geti(iimin) ; CALL geti(iimax) ; CALL geti(ijmin) ; CALL geti(ijmax)
+     CASE ( '-nc4'   ) ; lnc4   = .TRUE.
+     CASE ( '-o'     ) ; lfout  = .TRUE. ; CALL GET_COMMAND_ARGUMENT(ijarg, cf_out) ; ijarg = ijarg + 1
+     CASE DEFAULT      ; PRINT *, ' ERROR : ', TRIM(cldum), ' : unknown option.' ; STOP 99
+     END SELECT
+  END DO
+
+  lchk = chkfile(cf_in)
+  lchk = chkfile(cn_fmsk) .OR. lchk
+  lchk = chkfile(cn_fhgr) .OR. lchk
+  lchk = chkfile(cn_fzgr) .OR. lchk
+  IF ( lchk ) STOP 99
+  IF ( lg_vvl ) THEN
+     cn_fe3t = cf_in
+     cn_ve3t = cn_ve3tvvl
+  ENDIF
+  IF ( ltmean .AND. cv_in == cn_vosaline ) THEN
+     PRINT *, ' WARNING : flag -tmean is useless with variable', TRIM(cv_in)
+     ltmean = .FALSE.
+  ENDIF
+  IF ( lsmean .AND. cv_in == cn_votemper ) THEN
+     PRINT *, ' WARNING : flag -smean is useless with variable', TRIM(cv_in)
+     lsmean = .FALSE.
+  ENDIF
+  IF ( cv_in == cn_votemper ) THEN
+     IF ( ltmean ) THEN
+        cv_out = cn_votemper ; clongname = 'Mean temperature ' ; cunits = 'Deg Celsius' ; sclf = 1.
+     ELSE
+        cv_out = 'voheatc' ; clongname = 'Heat Content per unit area' ; cunits = '10^6 J/m2' ; sclf = pprho0*ppcp/1.e6
+     ENDIF
+  ELSEIF ( cv_in == cn_vosaline ) THEN
+     IF ( lsmean ) THEN
+        cv_out = cn_vosaline ; clongname = 'Mean salinity' ; cunits = 'psu'
+     ELSE
+        cv_out = 'vohsalt' ; clongname = 'Vertically Integrated Salinity' ; cunits = 'psu.m'
+     ENDIF
+     sclf = 1.
+  ELSE
+     PRINT *, '  ERROR: Variable ', TRIM(cv_in), ' not pre-defined ...'
+     PRINT *, '     Accepted variables are ', TRIM(cn_votemper), ' and ', TRIM(cn_vosaline)
+     STOP 99
+  ENDIF
+  IF ( .NOT. lfout ) cf_out = TRIM(cv_out)//'.nc'
+  PRINT *, ' INPUT VARIABLE  : ', TRIM(cv_in)
+  PRINT *, ' OUTPUT VARIABLE : ', TRIM(cv_out)
+  PRINT *, ' OUTPUT FILE     : ', TRIM(cf_out)
+
+  npiglo = getdim(cf_in, cn_x)
+  npjglo = getdim(cf_in, cn_y)
+  npk    = getdim(cf_in, cn_z)
+  npt    = getdim(cf_in, cn_t)
+  IF ( iimin /= 0 ) THEN ; npiglo = iimax - iimin + 1 ; ELSE ; iimin = 1
+  ENDIF
+  IF ( ijmin /= 0 ) THEN ; npjglo = ijmax - ijmin + 1 ; ELSE ; ijmin = 1
+  ENDIF
+  IF ( lgsop ) THEN ; PRINT *, ' using GSOP depths' ; npko = 7
+  ENDIF
+  IF ( locci ) THEN ; PRINT *, ' using OCCIPUT depths' ; npko = 3
+  ENDIF
+  IF ( (.NOT. lgsop) .AND. (.NOT. locci) ) THEN ; PRINT *, ' using model depths' ; npko = npk
+  ENDIF
+  PRINT *, ' NPIGLO = ', npiglo
+  PRINT *, ' NPJGLO = ', npjglo
+  PRINT *, ' NPK    = ', npk
+  PRINT *, ' NPKO   = ', npko
+  PRINT *, ' NPT    = ', npt
+
+  ALLOCATE( dtim(npt), tmask(npiglo,npjglo,npk), rlon(npiglo,npjglo), rlat(npiglo,npjglo), zt(npiglo,npjglo,npk) )
+  ALLOCATE( e31d(npk), gdepw(npk), gdepo(npko), zout(npiglo,npjglo,npko), kout(npk), khit(npk), zclip(npk), zdiv(npk) )
+  IF ( .NOT. lfull ) ALLOCATE( e3t(npiglo,npjglo,npk) )
+  gdepw(:) = getvare3(cn_fzgr, cn_gdepw, npk)
+  e31d(:)  = getvare3(cn_fzgr, cn_ve3t1d, npk)
+  IF ( lgsop ) gdepo(:) = (/ 100., 300., 500., 700., 800., 2000., 6000. /)
+  IF ( locci ) gdepo(:) = (/ 700., 2000., 6000. /)
+  IF ( (.NOT. lgsop) .AND. (.NOT. locci) ) THEN
+     gdepo(1:npk-1) = gdepw(2:npk)
+     gdepo(npk)     = 6000.
+  ENDIF
+  rlon = getvar(cf_in, cn_vlon2d, 1, npiglo, npjglo, kimin=iimin, kjmin=ijmin)
+  rlat = getvar(cf_in, cn_vlat2d, 1, npiglo, npjglo, kimin=iimin, kjmin=ijmin)
+  CALL CreateOutput
+  PRINT *, 'OUTPUT DEPTHS ARE : ', gdepo
+
+  DO jk = 1, npk
+     tmask(:,:,jk) = getvar(cn_fmsk, cn_tmask, jk, npiglo, npjglo, kimin=iimin, kjmin=ijmin)
+  END DO
+
+  DO jt = 1, npt
+     it = 1 ; IF ( lg_vvl ) it = jt
+     ! the scalar part of the reference's level loop (:266-311): which levels are written, and clipped where
+     iko = 1 ; rdep1 = 0.0 ; rdep2 = 0.0 ; lout = .TRUE.
+     DO jk = 1, npk
+        IF ( lgsop .OR. locci ) lout = .FALSE.
+        rdep1 = rdep2
+        rdep2 = rdep1 + e31d(jk)
+        khit(jk) = 0 ; kout(jk) = -1 ; zclip(jk) = 0. ; zdiv(jk) = rdep2
+        IF ( iko <= npko ) THEN
+           IF ( rdep2 >= (gdepo(iko) - tol) ) THEN
+              lout = .TRUE.
+              khit(jk) = 1 ; zclip(jk) = gdepo(iko) - rdep1
+           ENDIF
+           IF ( lout ) THEN
+              IF ( jt == 1 ) THEN
+                 PRINT *, 'Output for level ', iko
+                 PRINT *, 'rdep1, rdep2, depo ', rdep1, rdep2, gdepo(iko)
+              ENDIF
+              kout(jk) = iko - 1
+              iko = iko + 1
+           ENDIF
+        ENDIF
+     END DO
+     pe3 = C_NULL_PTR ; pe31d = C_NULL_PTR
+     IF ( lfull ) THEN
+        pe31d = C_LOC(e31d)
+     ELSE
+        IF ( jt == 1 .OR. lg_vvl ) THEN
+           DO jk = 1, npk
+              e3t(:,:,jk) = getvar(cn_fe3t, cn_ve3t, jk, npiglo, npjglo, kimin=iimin, kjmin=ijmin, ktime=it, ldiom=.NOT. lg_vvl)
+           END DO
+        ENDIF
+        pe3 = C_LOC(e3t)
+     ENDIF
+     DO jk = 1, npk
+        zt(:,:,jk) = getvar(cf_in, cv_in, jk, npiglo, npjglo, kimin=iimin, kjmin=ijmin, ktime=jt)
+     END DO
+     CALL hip_check(cdft_vint_cumul(zt, pe3, pe31d, tmask, npiglo, npjglo, npk, kout, khit, zclip, zdiv, npko, sclf, &
+          &         MERGE(1_C_INT, 0_C_INT, ltmean .OR. lsmean), CDFT_MEM_HOST, zout, CDFT_MEM_HOST, C_NULL_PTR), 'cdft_vint_cumul')
+     DO jk = 1, npk
+        IF ( kout(jk) >= 0 ) ierr = putvar(ncout, id_varout(1), zout(:,:,kout(jk)+1), kout(jk)+1, npiglo, npjglo, ktime=jt)
+     END DO
+  END DO
+  ierr = closeout(ncout)
+
+CONTAINS
+
+  SUBROUTINE geti(kval)
+    INTEGER(KIND=4), INTENT(out) :: kval
+    CALL GET_COMMAND_ARGUMENT(ijarg, cldum) ; ijarg = ijarg + 1 ; READ(cldum, *) kval
+  END SUBROUTINE geti
+
+  SUBROUTINE CreateOutput
+    !! src/cdfvint.f90:318-346
+    ipk(:)                       = npko
+    stypvar(1)%ichunk            = (/ npiglo, MAX(1, npjglo / 30), 1, 1 /)
+    stypvar(1)%cname             = TRIM(cv_out)
+    stypvar(1)%cunits            = TRIM(cunits)
+    stypvar(1)%rmissing_value    = 0.
+    stypvar(1)%valid_min         = -1.e15
+    stypvar(1)%valid_max         =  1.e15
+    stypvar(1)%clong_name        = TRIM(clongname)
+    stypvar(1)%cshort_name       = TRIM(cv_out)
+    stypvar(1)%conline_operation = 'N/A'
+    stypvar(1)%caxis             = 'TZYX'
+    ncout = create      (cf_out, 'none', npiglo, npjglo, npko, cdep=cn_vdepthw, ld_xycoo=.FALSE., ld_nc4=lnc4)
+    ierr  = createvar   (ncout, stypvar, 1, ipk, id_varout, ld_nc4=lnc4)
+    ierr  = putheadervar(ncout, cf_in, npiglo, npjglo, npko, pnavlon=rlon, pnavlat=rlat, pdep=gdepo, ld_xycoo=.FALSE.)
+    dtim  = getvar1d(cf_in, cn_vtimec, npt)
+    ierr  = putvar1d(ncout, dtim, npt, 'T')
+  END SUBROUTINE CreateOutput
+
+END PROGRAM cdfvint

@@ -499,6 +499,33 @@ class ZonalPlan(_Plan):
         return out
 
 
+def vint_cumul(zt, tmask, kout, hit, clip, rdep2, npko, sclf=1.0, mean=False, e3t=None, e31d=None, stream=None):
+    """cdft_vint_cumul (host arrays): zt, tmask (npk,npj,npi) r4 -> (npko,npj,npi) r4."""
+    a = [np.ascontiguousarray(zt, np.float32), None if e3t is None else np.ascontiguousarray(e3t, np.float32),
+         None if e31d is None else np.ascontiguousarray(e31d, np.float32), np.ascontiguousarray(tmask, np.float32)]
+    sch = [np.ascontiguousarray(kout, np.int32), np.ascontiguousarray(hit, np.int32), np.ascontiguousarray(clip, np.float32),
+           np.ascontiguousarray(rdep2, np.float32)]
+    npk, npj, npi = a[0].shape
+    out = np.empty((npko, npj, npi), np.float32)
+    ptr = [_null() if x is None else C.c_void_p(x.ctypes.data) for x in a]
+    check(_lib.load().cdft_vint_cumul(*ptr, npi, npj, npk, *[C.c_void_p(x.ctypes.data) for x in sch], npko, float(sclf),
+                                      1 if mean else 0, MEM_HOST, C.c_void_p(out.ctypes.data), MEM_HOST,
+                                      stream or current_stream_ptr()))
+    return out
+
+
+def vertmean(zv, zmask, gdep_first, gdep_last, rdep_up, rdep_down, e3=None, e31d=None, stream=None):
+    """cdft_vertmean (host arrays): the levels ik1..ik2 stacked (nlev,npj,npi) -> (npj,npi) r8."""
+    a = [np.ascontiguousarray(zv, np.float32), None if e3 is None else np.ascontiguousarray(e3, np.float32),
+         None if e31d is None else np.ascontiguousarray(e31d, np.float32), np.ascontiguousarray(zmask, np.float32)]
+    nlev, npj, npi = a[0].shape
+    out = np.empty((npj, npi), np.float64)
+    ptr = [_null() if x is None else C.c_void_p(x.ctypes.data) for x in a]
+    check(_lib.load().cdft_vertmean(*ptr, npi, npj, nlev, float(gdep_first), float(gdep_last), float(rdep_up), float(rdep_down),
+                                    MEM_HOST, C.c_void_p(out.ctypes.data), MEM_HOST, stream or current_stream_ptr()))
+    return out
+
+
 def vint_transport(vel, m2d, e3=None, e31d=None, stream=None):
     """cdft_vint_transport: vel (npk,npj,npi) r4 -> (npj,npi) r8 (host arrays or CUDA tensors)."""
     pv, sv, kv = _arg(vel, np.float32, "vel")
@@ -572,4 +599,4 @@ class CurlPlan(_Plan):
         return out
 
 
-__all__ = ["MocPlan", "HeatcPlan", "MeanPlan", "ZonalPlan", "MhstPlan", "PsiPlan", "CurlPlan", "vt_compute", "vint_transport", "vhst_transport", "sigmai", "sigma0", "sig_tool", "EOS_80", "EOS_TEOS10", "EOS_JMD94", "EOS_FAST_FMA", "Timer", "CdftError", "device_count", "current_stream_ptr", "MEM_HOST", "MEM_DEVICE"]
+__all__ = ["MocPlan", "HeatcPlan", "MeanPlan", "ZonalPlan", "MhstPlan", "PsiPlan", "CurlPlan", "vt_compute", "vint_cumul", "vertmean", "vint_transport", "vhst_transport", "sigmai", "sigma0", "sig_tool", "EOS_80", "EOS_TEOS10", "EOS_JMD94", "EOS_FAST_FMA", "Timer", "CdftError", "device_count", "current_stream_ptr", "MEM_HOST", "MEM_DEVICE"]

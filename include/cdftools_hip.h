@@ -261,6 +261,28 @@ int cdft_zonal_compute(cdft_zonal_plan *plan, const float *zv, int nlev, int in_
 int cdft_zonal_destroy(cdft_zonal_plan *plan);
 
 /* ------------------------------------------------------------------------------------------ */
+/* cdfvint, cdfvertmean : per-column vertical integrals                  */
+/* ------------------------------------------------------------------------------------------ */
+/* src/cdfvint.f90:266-311 for one record.  zt, tmask (npiglo,npjglo,npk) r4 (the mask as getvar returns
+ * it), e3t (npiglo,npjglo,npk) r4 or NULL with e31d (npk) r4 (-full).  The level schedule is the
+ * reference's scalar logic (:271-292), computed by the caller, npk HOST values each:
+ *   kout(k)  0-based index of the output depth written after level k, -1 for none (lout, iko)
+ *   hit(k)   1 when rdep2 >= gdepo(iko) - tol (:285): the level is clipped to clip(k) = gdepo(iko) - rdep1
+ *   rdep2(k) the divisor of -tmean / -smean (mean = 1), unused otherwise
+ * out (npiglo,npjglo,npko) r4 = REAL(dl_vint2*sclf) [/ rdep2]; depths never reached stay 0. */
+int cdft_vint_cumul(const float *zt, const float *e3t, const float *e31d, const float *tmask, int npiglo, int npjglo,
+                    int npk, const int *kout, const int *hit, const float *clip, const float *rdep2, int npko, float sclf,
+                    int mean, int in_space, float *out, int out_space, void *stream);
+/* src/cdfvertmean.f90:236-270 for one variable and record: the nlev levels ik1..ik2 of zv, zmask and e3
+ * (or e31d(ik1:ik2), -full); gdep_first = gdep(ik1), gdep_last = gdep(ik2); dvertmean (npiglo,npjglo) r8,
+ * divided by the integrated thickness where that is not 0.  (The reference leaves the level loop when a
+ * level has no wet point in the window: such a level adds exact zeros, so it is not special-cased.) */
+int cdft_vertmean(const float *zv, const float *e3, const float *e31d, const float *zmask, int npiglo, int npjglo, int nlev,
+                  float gdep_first, float gdep_last, float rdep_up, float rdep_down, int in_space, double *dvertmean,
+                  int out_space, void *stream);
+int cdft_column_release(void);   /* frees the staging buffers of the two calls above */
+
+/* ------------------------------------------------------------------------------------------ */
 /* cdfpsi : barotropic stream function                                                        */
 /*   replaces src/cdfpsi.f90:271-298 (vertical integration), :377-423 (scans, mean, reference  */
 /*   point) and the SNGL / mask at :426-433.  Not covered: -open, --ssh-file, -lev.            */

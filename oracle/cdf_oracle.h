@@ -69,6 +69,11 @@ void oracle_mean(int npi, int npj, int npk, int nb, const float *e1, const float
 void oracle_zonal(int npi, int npj, int nlev, int nb, const float *e1, const float *e2, const float *zmaskvar,
                   const float *zmask, const float *zv, int mean_form, double *dzo, double *darea, float *rmax,
                   float *rmin);
+void oracle_vint_cumul(int npi, int npj, int npk, int npko, const float *zt, const float *e3t, const float *e31d_full,
+                       const float *tmask, const float *e31d, const float *gdepo, int lstd, float sclf, int mean,
+                       float *out);
+void oracle_vertmean(int npi, int npj, int nlev, const float *zv, const float *e3, const float *e31d, const float *zmask,
+                     float gdep_first, float gdep_last, float rdep_up, float rdep_down, double *dmean);
 void oracle_psi_open(int npi, int npj, int npk, const float *zu, const float *e2u, const float *e3u,
                      const float *zv, const float *e1v, const float *e3v, const float *e31d, int lmean,
                      int iiref, int ijref, int noref, const float *fmask, float *psi4, double *dpsi8);

@@ -392,3 +392,61 @@ void oracle_zonal(int npi, int npj, int nlev, int nb, const float *e1, const flo
                 if (mean_form) { darea[o] = a; if (rmax) rmax[o] = mx; if (rmin) rmin[o] = mn; }
             }
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* src/cdfvint.f90:266-311 for one record, with the reference's own scalar schedule inside:
+ *   gdepo (npko) output depths, e31d (npk) the 1-D thickness (rdep2 = rdep1 + e31d(jk), :282),
+ *   lstd = 1 with -GSOP / -OCCI (lout starts .FALSE. at each level, :273), tol = 1.0.
+ * out (npi,npj,npko) r4, zero where an output depth is never reached. */
+void oracle_vint_cumul(int npi, int npj, int npk, int npko, const float *zt, const float *e3t, const float *e31d_full,
+                       const float *tmask, const float *e31d, const float *gdepo, int lstd, float sclf, int mean,
+                       float *out) {
+    const size_t nij = (size_t)npi * npj;
+    const float tol = 1.0f;
+    double *v1 = (double *)calloc(nij, 8), *v2 = (double *)calloc(nij, 8);
+    memset(out, 0, nij * npko * 4);
+    int iko = 0, lout = 1;
+    float rdep1 = 0.f, rdep2 = 0.f;
+    for (int jk = 0; jk < npk; ++jk) {
+        if (lstd) lout = 0;
+        rdep1 = rdep2;
+        memcpy(v2, v1, nij * 8);
+        rdep2 = rdep1 + e31d[jk];
+        const int hit = (iko < npko) && (rdep2 >= (gdepo[iko] - tol));
+        for (size_t p = 0; p < nij; ++p) {
+            float e = e3t ? e3t[jk * nij + p] : e31d_full[jk];
+            const float t = zt[jk * nij + p], m = tmask[jk * nij + p];
+            v1[p] = v1[p] + (double)(t * e * m) * 1.0;
+            if (hit) {
+                if (e > gdepo[iko] - rdep1) e = gdepo[iko] - rdep1;
+                v2[p] = v2[p] + (double)(t * e * m) * 1.0;
+            }
+        }
+        if (hit) lout = 1;
+        if (lout && iko < npko) {
+            for (size_t p = 0; p < nij; ++p) {
+                v2[p] = v2[p] * (double)sclf;
+                out[(size_t)iko * nij + p] = mean ? (float)v2[p] / rdep2 : (float)v2[p];
+            }
+            iko = iko + 1;
+        }
+    }
+    free(v1); free(v2);
+}
+
+/* src/cdfvertmean.f90:236-270 for one variable and record; the levels ik1..ik2 are passed stacked. */
+void oracle_vertmean(int npi, int npj, int nlev, const float *zv, const float *e3, const float *e31d, const float *zmask,
+                     float gdep_first, float gdep_last, float rdep_up, float rdep_down, double *dmean) {
+    const size_t nij = (size_t)npi * npj;
+    for (size_t p = 0; p < nij; ++p) {
+        double dvol = 0.0, ds = 0.0;
+        for (int k = 0; k < nlev; ++k) {
+            float e = e3 ? e3[k * nij + p] : e31d[k];
+            if (k == 0) { const float hdep = gdep_first + e; const float c = hdep - rdep_up; if (c < e) e = c; }
+            if (k == nlev - 1) { const float c = rdep_down - gdep_last; if (c < e) e = c; }
+            dvol = (double)(e * zmask[k * nij + p]) * 1.0 + dvol;
+            ds   = (double)(zv[k * nij + p] * e * zmask[k * nij + p]) * 1.0 + ds;
+        }
+        dmean[p] = (dvol != 0.0) ? ds / dvol : ds;
+    }
+}

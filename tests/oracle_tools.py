@@ -143,3 +143,26 @@ def zonal(e1, e2, zmaskvar, zmask, zv, mean_form=False):
     lib.oracle_zonal(C.c_int(npi), C.c_int(npj), C.c_int(nlev), C.c_int(nb), _p(e1), _p(e2), _p(zmaskvar), _p(zmask), _p(zv),
                      C.c_int(1 if mean_form else 0), _p(out["sum"]), pa, px, pn)
     return out
+
+
+def vint_cumul(zt, tmask, e31d, gdepo, lstd=False, sclf=1.0, mean=False, e3t=None, full=False):
+    """src/cdfvint.f90:266-311 -> (npko,npj,npi) r4.  e31d (npk) always drives the depth counters; with
+    full=True it is also the thickness."""
+    lib = load()
+    zt, tmask, e31d, gdepo, e3t = map(_f, (zt, tmask, e31d, gdepo, e3t))
+    npk, npj, npi = zt.shape
+    out = np.empty((len(gdepo), npj, npi), np.float32)
+    lib.oracle_vint_cumul(C.c_int(npi), C.c_int(npj), C.c_int(npk), C.c_int(len(gdepo)), _p(zt), _pp(e3t),
+                          _p(e31d) if full else None, _p(tmask), _p(e31d), _p(gdepo), C.c_int(1 if lstd else 0),
+                          C.c_float(sclf), C.c_int(1 if mean else 0), _p(out))
+    return out
+
+
+def vertmean(zv, zmask, gdep_first, gdep_last, rdep_up, rdep_down, e3=None, e31d=None):
+    lib = load()
+    zv, zmask, e3, e31d = map(_f, (zv, zmask, e3, e31d))
+    nlev, npj, npi = zv.shape
+    out = np.empty((npj, npi), np.float64)
+    lib.oracle_vertmean(C.c_int(npi), C.c_int(npj), C.c_int(nlev), _p(zv), _pp(e3), _pp(e31d), _p(zmask), C.c_float(gdep_first),
+                        C.c_float(gdep_last), C.c_float(rdep_up), C.c_float(rdep_down), _p(out))
+    return out

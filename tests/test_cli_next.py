@@ -311,3 +311,132 @@ def test_cdfzonalsum_and_cdfzonalmean_end_to_end(tools, tmp_path):  # noqa: F811
             assert np.allclose(var["zotemper" + sfx[b]][t, :, :, 0], mean[b], rtol=2e-7, atol=0)
             assert np.array_equal(var["zotemper" + sfx[b] + "_max"][t, :, :, 0], np.where(ok[b], ref["max"][b], 0).astype(np.float32))
             assert np.array_equal(var["zotemper" + sfx[b] + "_min"][t, :, :, 0], np.where(ok[b], ref["min"][b], 0).astype(np.float32))
+
+
+# ------------------------------------------------------------------------------------ cdfvint / cdfvertmean
+def vint_schedule(e31d, gdepo, lstd):
+    """The scalar bookkeeping of src/cdfvint.f90:266-311 in r4, as the Fortran host program does it."""
+    npk = len(e31d)
+    kout, hit = -np.ones(npk, np.int32), np.zeros(npk, np.int32)
+    clip, rdep = np.zeros(npk, np.float32), np.zeros(npk, np.float32)
+    iko, r1, r2, lout = 0, np.float32(0), np.float32(0), True
+    for k in range(npk):
+        if lstd:
+            lout = False
+        r1 = r2
+        r2 = np.float32(r1 + np.float32(e31d[k]))
+        rdep[k] = r2
+        if iko < len(gdepo):
+            if r2 >= np.float32(np.float32(gdepo[iko]) - np.float32(1.0)):
+                lout, hit[k], clip[k] = True, 1, np.float32(np.float32(gdepo[iko]) - r1)
+            if lout:
+                kout[k] = iko
+                iko += 1
+    return kout, hit, clip, rdep
+
+
+def column_inputs(npi, npj, npk, seed):
+    g = synth.make_grid(npi, npj, npk, seed=seed)
+    rng = np.random.default_rng(seed + 4)
+    zt = ((-2 + 30 * rng.random((npk, npj, npi), dtype=np.float32)) * g["tmask"]).astype(np.float32)
+    return g, zt, g["tmask"].astype(np.float32)
+
+
+def test_oracle_vint_and_vertmean_match_numpy_restatement_bitwise():
+    g, zt, tm = column_inputs(17, 11, 7, seed=3)
+    e31d = g["e3t_1d"]
+    gdepo = np.append(g["gdepw_1d"][1:], np.float32(6000.0)).astype(np.float32)
+    sclf = np.float32(np.float32(1020.) * np.float32(4000.) / np.float32(1.e6))
+    got = oracle_tools.vint_cumul(zt, tm, e31d, gdepo, sclf=sclf, e3t=g["e3t_0"])
+    kout, hit, clip, _ = vint_schedule(e31d, gdepo, False)
+    v1 = np.zeros(zt.shape[1:])
+    want = np.zeros_like(got)
+    for k in range(7):
+        v2 = v1.copy()
+        v1 = v1 + ((zt[k] * g["e3t_0"][k]).astype(np.float32) * tm[k]).astype(np.float64)
+        if hit[k]:
+            e = np.minimum(g["e3t_0"][k], clip[k]).astype(np.float32)
+            v2 = v2 + ((zt[k] * e).astype(np.float32) * tm[k]).astype(np.float64)
+        if kout[k] >= 0:
+            want[kout[k]] = (v2 * np.float64(sclf)).astype(np.float32)
+    assert np.array_equal(got, want) and np.abs(got).max() > 0
+    # vertical mean between 15 m and 120 m
+    gdep = g["gdepw_1d"]
+    ik1 = int(np.nonzero(gdep <= 15.0)[0].max())
+    ik2 = int(np.nonzero(gdep <= 120.0)[0].max())
+    sl = slice(ik1, ik2 + 1)
+    m = oracle_tools.vertmean(zt[sl], tm[sl], gdep[ik1], gdep[ik2], 15.0, 120.0, e3=g["e3t_0"][sl])
+    dvol, ds = np.zeros(zt.shape[1:]), np.zeros(zt.shape[1:])
+    for n, k in enumerate(range(ik1, ik2 + 1)):
+        e = g["e3t_0"][k].copy()
+        if n == 0:
+            e = np.minimum(e, (np.float32(gdep[ik1]) + e).astype(np.float32) - np.float32(15.0)).astype(np.float32)
+        if k == ik2:
+            e = np.minimum(e, np.float32(np.float32(120.0) - np.float32(gdep[ik2]))).astype(np.float32)
+        dvol = (e * tm[k]).astype(np.float64) + dvol
+        ds = ((zt[k] * e).astype(np.float32) * tm[k]).astype(np.float64) + ds
+    assert np.array_equal(m, np.where(dvol != 0, ds / np.where(dvol != 0, dvol, 1), ds))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("npi,npj,npk", [(24, 18, 7), (182, 149, 31), (1, 1, 2), (130, 5, 4)])
+def test_hip_vint_and_vertmean_equal_oracle_bitwise(gpu, npi, npj, npk):
+    g, zt, tm = column_inputs(npi, npj, npk, seed=npi + 6)
+    e31d = g["e3t_1d"]
+    sclf = np.float32(np.float32(1020.) * np.float32(4000.) / np.float32(1.e6))
+    for gdepo, lstd in ((np.append(g["gdepw_1d"][1:], np.float32(6000.0)).astype(np.float32), False),
+                        (np.array([100., 300., 500., 700., 800., 2000., 6000.], np.float32), True),
+                        (np.array([700., 2000., 6000.], np.float32), True)):
+        kout, hit, clip, rdep = vint_schedule(e31d, gdepo, lstd)
+        for mean in (False, True):
+            for kw, okw in ((dict(e3t=g["e3t_0"]), dict(e3t=g["e3t_0"])), (dict(e31d=e31d), dict(full=True))):
+                got = gpu.vint_cumul(zt, tm, kout, hit, clip, rdep, len(gdepo), sclf=sclf, mean=mean, **kw)
+                ref = oracle_tools.vint_cumul(zt, tm, e31d, gdepo, lstd=lstd, sclf=sclf, mean=mean, **okw)
+                assert np.array_equal(got, ref), (lstd, mean, list(kw))
+    gdep = g["gdepw_1d"]
+    for up, down in ((0.0, 50.0), (15.0, 120.0), (30.0, 30.0), (0.0, 1.0e4)):
+        ik1 = int(np.nonzero(gdep <= up)[0].max())
+        ik2 = int(np.nonzero(gdep <= down)[0].max())
+        sl = slice(ik1, ik2 + 1)
+        for kw in (dict(e3=g["e3t_0"][sl]), dict(e31d=e31d[sl])):
+            got = gpu.vertmean(zt[sl], tm[sl], gdep[ik1], gdep[ik2], up, down, **kw)
+            assert np.array_equal(got, oracle_tools.vertmean(zt[sl], tm[sl], gdep[ik1], gdep[ik2], up, down, **kw)), (up, down)
+
+
+@pytest.mark.gpu
+def test_cdfvint_and_cdfvertmean_end_to_end(tools, tmp_path):  # noqa: F811
+    d = str(tmp_path)
+    g, rec = nemo_files.make_case(d, npi=26, npj=19, npk=6, npt=2)
+    tm = g["tmask"].astype(np.float32)
+    e31d = g["e3t_1d"]
+    sclf = np.float32(np.float32(1020.) * np.float32(4000.) / np.float32(1.e6))
+    rc, out, err = run("cdfvint", ["-f", "SYN_y0001_gridT.nc"], d)
+    assert rc == 0 and "using model depths" in out, out + err
+    var, att, dims = read_nc(os.path.join(d, "voheatc.nc"))
+    gdepo = np.append(g["gdepw_1d"][1:], np.float32(6000.0)).astype(np.float32)
+    for t in range(2):
+        assert np.array_equal(var["voheatc"][t], oracle_tools.vint_cumul(rec["t"][t], tm, e31d, gdepo, sclf=sclf, e3t=g["e3t_0"]))
+    assert att["voheatc"]["units"] == b"10^6 J/m2" and np.array_equal(var["depthw"], gdepo)
+    rc, out, err = run("cdfvint", ["-f", "SYN_y0001_gridT.nc", "-v", "vosaline", "-OCCI", "-smean", "-full", "-w", "3", "20", "2", "15",
+                                   "-o", "sm.nc"], d)
+    assert rc == 0, out + err
+    var, att, dims = read_nc(os.path.join(d, "sm.nc"))
+    occi = np.array([700., 2000., 6000.], np.float32)
+    ref = oracle_tools.vint_cumul(rec["s"][1][:, 1:15, 2:20], tm[:, 1:15, 2:20], e31d, occi, lstd=True, mean=True, full=True)
+    assert dims["depthw"] == 3 and np.array_equal(var["vosaline"][1], ref)
+    rc, out, _ = run("cdfvint", ["-f", "SYN_y0001_gridT.nc", "-v", "sossheig"], d)
+    assert rc == 99 and "not pre-defined" in out
+
+    rc, out, err = run("cdfvertmean", ["-f", "SYN_y0001_gridT.nc", "-l", "votemper,vosaline", "-p", "T", "-zlim", "15", "120"], d)
+    assert rc == 0, out + err
+    var, att, _ = read_nc(os.path.join(d, "vertmean.nc"))
+    gdep = g["gdepw_1d"]
+    ik1 = int(np.nonzero(gdep <= 15.0)[0].max())
+    ik2 = int(np.nonzero(gdep <= 120.0)[0].max())
+    sl = slice(ik1, ik2 + 1)
+    for nm, key in (("votemper", "t"), ("vosaline", "s")):
+        for t in range(2):
+            ref = oracle_tools.vertmean(rec[key][t][sl], tm[sl], gdep[ik1], gdep[ik2], 15.0, 120.0, e3=g["e3t_0"][sl])
+            assert np.array_equal(var[nm + "_vert_mean"][t], ref.astype(np.float32)), nm
+    rc, out, _ = run("cdfvertmean", ["-f", "SYN_y0001_gridT.nc", "-l", "votemper", "-p", "T", "-zlim", "100", "10"], d)
+    assert rc == 99 and "increasing order" in out
