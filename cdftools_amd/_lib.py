@@ -81,6 +81,9 @@ SIGNATURES = {
     "cdft_vint_cumul": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, C.c_float, _i, _i, _vp, _i, _vp]),
     "cdft_vertmean": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, C.c_float, C.c_float, C.c_float, C.c_float, _i, _vp, _i, _vp]),
     "cdft_column_release": (_i, []),
+    "cdft_mocsig_compute": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, C.c_float, C.c_float, C.c_float,
+                                 C.c_float, _i, _i, C.c_float, C.c_float, _i, _vp, _vp, _i, _vp]),
+    "cdft_mocsig_release": (_i, []),
     "cdft_psi_create": (_i, [_pvp, _i, _i, _i]),
     "cdft_psi_compute": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _vp]),
     "cdft_psi_integrate": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),

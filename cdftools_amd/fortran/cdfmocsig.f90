@@ -1,0 +1,265 @@
+PROGRAM cdfmocsig
+  !!======================================================================
+  !!                     ***  PROGRAM  cdfmocsig  ***
+  !! Meridional overturning stream function in density classes (sigma coordinates).
+  !!
+  !! Drop-in for the reference tool (src/cdfmocsig.f90): same options, same mocsig.nc (x=1, y, sigma, time;
+  !! zomsfglo [atl inp ind pac] [zoisoglo ...] float, Sverdrup / m, :490-586).  The level loop, the density
+  !! binning, the zonal sums and the cumulation over the density classes (:368-470) run on the GPU for a whole
+  !! record at once (cdft_mocsig_compute).  -ntr (neutral density) is not carried: explicit STOP 99.
+  !!======================================================================
+  USE ISO_C_BINDING
+  USE cdfio
+  USE modcdfnames
+  USE modutils
+  USE eos
+  USE cdftools_hip
+  IMPLICIT NONE
+
+  INTEGER(KIND=4) :: ji, jt, jbasin, jbin, it, npiglo, npjglo, npk, npt, nbins, narg, ijarg, ii, ncout, nbasins, nvaro, ierr
+  INTEGER(KIND=4) :: npglo = 1, npatl = 2, npinp = 3, npind = 4, nppac = 5, iloc(2)
+  INTEGER(KIND=4), ALLOCATABLE :: ipk(:), id_varout(:)
+  INTEGER(KIND=2), ALLOCATABLE :: ibmask(:,:,:)
+  REAL(KIND=4) :: pref = 0., sigmin, sigstp, zsps, zspt, zspv, rp_spval = 99999.
+  REAL(KIND=4), ALLOCATABLE, TARGET :: e3v(:,:,:), e31d(:), gdep(:), zveiv(:,:,:)
+  REAL(KIND=4), ALLOCATABLE :: e1v(:,:), gphiv(:,:), zv(:,:,:), zt(:,:,:), zs(:,:,:), rdumlon(:,:), rdumlat(:,:), sigma(:), zwk(:,:)
+  REAL(KIND=8), ALLOCATABLE :: dtim(:)
+  REAL(KIND=8), ALLOCATABLE, TARGET :: dmoc(:,:,:), depi(:,:,:)            ! (nbasins, nbins, npjglo)
+  CHARACTER(LEN=256) :: cf_vfil, cf_tfil, cf_sfil, cf_moc = 'mocsig.nc', cldum, cglobal
+  TYPE(variable), ALLOCATABLE :: stypvar(:)
+  TYPE(C_PTR) :: pe3, pe31d, peiv, pgdep, pdepi
+  LOGICAL :: lfull = .FALSE., lchk = .FALSE., lbas, lbin(3), lisodep = .FALSE., lprint = .FALSE., leiv = .FALSE.
+  LOGICAL :: lntr = .FALSE., ll_teos10 = .FALSE.
+  !!----------------------------------------------------------------------
+  CALL ReadCdfNames()
+  narg = COMMAND_ARGUMENT_COUNT()
+  IF ( narg == 0 ) THEN
+     PRINT *, ' usage : cdfmocsig  -v V-file -t T-file -r REF-depth | -ntr [-s S-file] [-eiv] [-full] ...'
+     PRINT *, '         ...  [-sigmin sigmin] [-sigstp sigstp] [-nbins nbins] [-isodep] [-o OUT-file]...'
+     PRINT *, '         ...  [-vvl] [-verbose] [-teos10]'
+     PRINT *, '      '
+     PRINT *, '     PURPOSE :'
+     PRINT *, '       Compute the MOC in density-latitude coordinates: the meridional transport of each cell is'
+     PRINT *, '       binned by its potential density referred to REF-depth and integrated zonally, then'
+     PRINT *, '       cumulated from the densest class up.  MI355X build: all of it runs on the GPU.'
+     PRINT *, '      '
+     PRINT *, '     ARGUMENTS :'
+     PRINT *, '        -v V-file  : Netcdf gridV file.'
+     PRINT *, '        -t T-file  : Netcdf gridT file with temperature and salinity (else -s).'
+     PRINT *, '        -r ref-depth : reference depth for density; 0, 1000 and 2000 m have pre-defined classes,'
+     PRINT *, '            other depths need -sigmin, -sigstp and -nbins.'
+     PRINT *, '        or -ntr : neutral density; not available in this build.'
+     PRINT *, '      '
+     PRINT *, '     OPTIONS :'
+     PRINT *, '       [-s S-file   ] : salinity file if not T-file.'
+     PRINT *, '       [-eiv ] : add the meridional eddy induced velocity.'
+     PRINT *, '       [-full       ] : full step instead of partial steps.'
+     PRINT *, '       [-sigmin     ] : minimum of density for bining.'
+     PRINT *, '       [-sigstp     ] : density step for bining.'
+     PRINT *, '       [-nbins      ] : number of density bins.'
+     PRINT *, '       [-isodep     ] : also the zonal mean of the isopycnal depths.'
+     PRINT *, '       [-o OUT-file ] : output file name instead of ', TRIM(cf_moc)
+     PRINT *, '       [-vvl        ] : time-varying vertical metrics.'
+     PRINT *, '       [-verbose    ] : more info during execution.'
+     PRINT *, '       [-teos10     ] : TEOS10 equation of state instead of default EOS80'
+     PRINT *, '      '
+     PRINT *, '     REQUIRED FILES :'
+     PRINT *, '        Files ', TRIM(cn_fzgr), ', ', TRIM(cn_fhgr), ', ', TRIM(cn_fmsk)
+     PRINT *, '        File ', TRIM(cn_fbasins), ' is optional [sub basins masks]'
+     PRINT *, '      '
+     PRINT *, '     OUTPUT : '
+     PRINT *, '       netcdf file : ', TRIM(cf_moc)
+     PRINT *, '       variables ', TRIM(cn_zomsfglo), ' [', TRIM(cn_zomsfatl), ' ', TRIM(cn_zomsfinp), ' ', TRIM(cn_zomsfind), ' ', &
+          &   TRIM(cn_zomsfpac), '] and with -isodep ', TRIM(cn_zoisoglo), ' ...'
+     STOP
+  ENDIF
+
+  cglobal = 'Partial step computation'
+  lbin = (/ .TRUE., .TRUE., .TRUE. /)
+  ijarg = 1 ; ii = 0
+  cf_sfil = 'none'
+  DO WHILE ( ijarg <= narg )
+     CALL GET_COMMAND_ARGUMENT(ijarg, cldum) ; ijarg = ijarg + 1
+     SELECT CASE ( cldum )
+     CASE ( '-v'       ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cf_vfil) ; ijarg = ijarg + 1 ; ii = ii + 1
+     CASE ( '-t'       ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cf_tfil) ; ijarg = ijarg + 1 ; ii = ii + 1
+     CASE ( '-r'       ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cldum  ) ; ijarg = ijarg + 1 ; ii = ii + 1 ; READ(cldum, *) pref
+     CASE ( '-ntr'     ) ; lntr = .TRUE. ; ii = ii + 1
+     CASE ( '-s'       ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cf_sfil) ; ijarg = ijarg + 1
+     CASE ( '-full'    ) ; lfull   = .TRUE. ; cglobal = 'Full step computation'
+     CASE ( '-eiv'     ) ; leiv    = .TRUE.
+     CASE ( '-sigmin'  ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cldum) ; ijarg = ijarg + 1 ; READ(cldum, *) sigmin ; lbin(1) = .FALSE.
+     CASE ( '-nbins'   ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cldum) ; ijarg = ijarg + 1 ; READ(cldum, *) nbins  ; lbin(2) = .FALSE.
+     CASE ( '-sigstp'  ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cldum) ; ijarg = ijarg + 1 ; READ(cldum, *) sigstp ; lbin(3) = .FALSE.
+     CASE ( '-o'       ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cf_moc) ; ijarg = ijarg + 1
+     CASE ( '-vvl'     ) ; lg_vvl  = .TRUE.
+     CASE ( '-teos10'  ) ; ll_teos10 = .TRUE.
+     CASE ( '-isodep'  ) ; lisodep = .TRUE.
+     CASE ( '-verbose' ) ; lprint  = .TRUE.
+     CASE DEFAULT        ; PRINT *, ' ERROR : ', TRIM(cldum), ' : unknown option.' ; STOP 99
+     END SELECT
+  END DO
+  CALL eos_init( ll_teos10 )
+  IF ( ii /= 3 ) THEN ; PRINT *, ' ERROR : mandatory arguments missing, see usage please !' ; STOP 99
+  ENDIF
+  IF ( lntr ) THEN
+     PRINT *, ' ERROR : option -ntr (neutral density) is not available in the MI355X build of cdfmocsig.'
+     STOP 99
+  ENDIF
+  IF ( cf_sfil == 'none' ) cf_sfil = cf_tfil
+  lchk = lchk .OR. chkfile(cn_fhgr)
+  lchk = lchk .OR. chkfile(cn_fzgr)
+  lchk = lchk .OR. chkfile(cn_fmsk)
+  lchk = lchk .OR. chkfile(cf_vfil)
+  lchk = lchk .OR. chkfile(cf_tfil)
+  lchk = lchk .OR. chkfile(cf_sfil)
+  IF ( lchk ) STOP 99
+  zsps = getspval(cf_sfil, cn_vosaline)
+  zspt = getspval(cf_tfil, cn_votemper)
+  zspv = getspval(cf_vfil, cn_vomecrty)
+  IF ( lg_vvl ) THEN
+     cn_fe3v = cf_vfil
+     cn_ve3v = cn_ve3vvvl
+  ENDIF
+  lchk = lbin(1) .OR. lbin(2) .OR. lbin(3)                  ! TRUE if no particular binning specified
+
+  npiglo = getdim(cf_vfil, cn_x)
+  npjglo = getdim(cf_vfil, cn_y)
+  npk    = getdim(cf_vfil, cn_z)
+  npt    = getdim(cf_vfil, cn_t)
+  PRINT *, 'npiglo = ', npiglo
+  PRINT *, 'npjglo = ', npjglo
+  PRINT *, 'npk    = ', npk
+  PRINT *, 'npt    = ', npt
+  CALL SetGlobalAtt(cglobal, 'A')
+  lbas = .NOT. chkfile(cn_fbasins)
+  IF ( lbas ) THEN ; nbasins = 5
+  ELSE             ; nbasins = 1
+  ENDIF
+  IF ( lisodep ) THEN ; nvaro = 2 * nbasins
+  ELSE                ; nvaro =     nbasins
+  ENDIF
+  ALLOCATE( stypvar(nvaro), ipk(nvaro), id_varout(nvaro) )
+  IF ( lchk ) THEN                                          ! default classes of the reference depth (:282-318)
+     SELECT CASE ( INT(pref) )
+     CASE ( 0 )    ; nbins = 52  ; sigmin = 23. ; sigstp = 0.1
+     CASE ( 1000 ) ; nbins = 88  ; sigmin = 24. ; sigstp = 0.1
+     CASE ( 2000 ) ; nbins = 158 ; sigmin = 30. ; sigstp = 0.05
+     CASE DEFAULT
+        PRINT *, ' This value of depth_ref (', pref, ') is not implemented as standard'
+        PRINT *, ' You must use the -sigmin, -sigstp and -nbins options to precise'
+        PRINT *, ' the density bining you want to use.'
+        STOP 99
+     END SELECT
+  ENDIF
+  PRINT '(a,f6.1,a)', '  For reference depth ', pref, ' m, '
+  PRINT '(a,f5.2,a,f5.2,a,i3)', '  You are using -sigmin ', sigmin, ' -sigstp ', sigstp, ' -nbins ', nbins
+  ALLOCATE( sigma(nbins) )
+  DO ji = 1, nbins
+     sigma(ji) = sigmin + (ji-0.5)*sigstp
+  END DO
+  IF ( lprint ) PRINT *, ' min density:', sigma(1), ' max density:', sigma(nbins)
+
+  ALLOCATE( ibmask(nbasins,npiglo,npjglo), zv(npiglo,npjglo,npk), zt(npiglo,npjglo,npk), zs(npiglo,npjglo,npk) )
+  ALLOCATE( e1v(npiglo,npjglo), gphiv(npiglo,npjglo), zwk(npiglo,npjglo), dmoc(nbasins,nbins,npjglo) )
+  ALLOCATE( rdumlon(1,npjglo), rdumlat(1,npjglo), dtim(npt), e31d(npk), gdep(npk) )
+  IF ( lisodep ) ALLOCATE( depi(nbasins,nbins,npjglo) )
+  IF ( leiv ) ALLOCATE( zveiv(npiglo,npjglo,npk) )
+  IF ( .NOT. lfull ) ALLOCATE( e3v(npiglo,npjglo,npk) )
+  e1v(:,:) = getvar(cn_fhgr, cn_ve1v, 1, npiglo, npjglo)
+  IF ( lfull   ) e31d(:) = getvare3(cn_fzgr, cn_ve3t1d, npk)
+  IF ( lisodep ) gdep(:) = -getvare3(cn_fzgr, cn_gdept, npk)
+  IF ( npjglo > 1 ) THEN
+     gphiv(:,:)   = getvar(cn_fhgr, cn_gphiv, 1, npiglo, npjglo)
+     iloc         = MAXLOC(gphiv)
+     rdumlat(1,:) = gphiv(iloc(1),:)
+  ELSE
+     rdumlat(1,:) = 0.
+  ENDIF
+  rdumlon(:,:) = 0.
+  CALL CreateOutputFile
+
+  zwk(:,:) = getvar(cn_fmsk, cn_vmask, 1, npiglo, npjglo) ; ibmask(npglo,:,:) = INT(zwk, 2)
+  IF ( lbas ) THEN
+     zwk(:,:) = getvar(cn_fbasins, cn_tmaskatl, 1, npiglo, npjglo) ; ibmask(npatl,:,:) = INT(zwk, 2)
+     zwk(:,:) = getvar(cn_fbasins, cn_tmaskind, 1, npiglo, npjglo) ; ibmask(npind,:,:) = INT(zwk, 2)
+     zwk(:,:) = getvar(cn_fbasins, cn_tmaskpac, 1, npiglo, npjglo) ; ibmask(nppac,:,:) = INT(zwk, 2)
+     ibmask(npinp,:,:) = ibmask(nppac,:,:) + ibmask(npind,:,:)
+     WHERE ( ibmask(npinp,:,:) > 0 ) ibmask(npinp,:,:) = 1
+     ibmask(1,1,     :) = 0                                 ! global periodic condition (only with the basin file, :357-358)
+     ibmask(1,npiglo,:) = 0
+  ENDIF
+
+  DO jt = 1, npt
+     it = 1 ; IF ( lg_vvl ) it = jt
+     zv = getvar3d(cf_vfil, cn_vomecrty, npiglo, npjglo, npk, ktime=jt)
+     zt = getvar3d(cf_tfil, cn_votemper, npiglo, npjglo, npk, ktime=jt)
+     zs = getvar3d(cf_sfil, cn_vosaline, npiglo, npjglo, npk, ktime=jt)
+     pe3 = C_NULL_PTR ; pe31d = C_NULL_PTR ; peiv = C_NULL_PTR ; pgdep = C_NULL_PTR ; pdepi = C_NULL_PTR
+     IF ( leiv ) THEN
+        zveiv = getvar3d(cf_vfil, cn_vomeeivv, npiglo, npjglo, npk, ktime=jt)
+        peiv = C_LOC(zveiv)
+     ENDIF
+     IF ( lfull ) THEN
+        pe31d = C_LOC(e31d)
+     ELSE
+        IF ( jt == 1 .OR. lg_vvl ) THEN
+           DO ji = 1, npk
+              e3v(:,:,ji) = getvar(cn_fe3v, cn_ve3v, ji, npiglo, npjglo, ktime=it, ldiom=.NOT. lg_vvl)
+           END DO
+        ENDIF
+        pe3 = C_LOC(e3v)
+     ENDIF
+     IF ( lisodep ) THEN ; pgdep = C_LOC(gdep) ; pdepi = C_LOC(depi) ; ENDIF
+     CALL hip_check(cdft_mocsig_compute(zv, peiv, zt, zs, e1v, pe3, pe31d, ibmask, pgdep, npiglo, npjglo, npk, nbasins, zspv, zspt, &
+          &         zsps, pref, MERGE(CDFT_EOS_TEOS10, CDFT_EOS_80, ll_teos10), nbins, sigmin, sigstp, CDFT_MEM_HOST, dmoc, pdepi,  &
+          &         CDFT_MEM_HOST, C_NULL_PTR), 'cdft_mocsig_compute')
+     DO jbasin = 1, nbasins
+        DO jbin = 1, nbins
+           ierr = putvar(ncout, id_varout(jbasin), REAL(dmoc(jbasin,jbin,:)), jbin, 1, npjglo, ktime=jt)
+           IF ( lisodep ) ierr = putvar(ncout, id_varout(jbasin+nbasins), REAL(depi(jbasin,jbin,:)), jbin, 1, npjglo, ktime=jt)
+        END DO
+     END DO
+  END DO
+  ierr = closeout(ncout)
+
+CONTAINS
+
+  SUBROUTINE CreateOutputFile
+    !! src/cdfmocsig.f90:490-586
+    CHARACTER(LEN=256) :: cl_moc(5), cl_iso(5), cl_tag(5)
+    INTEGER(KIND=4) :: jb
+    stypvar%cunits            = 'Sverdrup'
+    stypvar%rmissing_value    = rp_spval
+    stypvar%valid_min         = -1000.
+    stypvar%valid_max         =  1000.
+    stypvar%scale_factor      = 1.
+    stypvar%add_offset        = 0.
+    stypvar%savelog10         = 0.
+    stypvar%conline_operation = 'N/A'
+    stypvar%caxis             = 'TZY'
+    ipk(:) = nbins
+    cl_moc = (/ cn_zomsfglo, cn_zomsfatl, cn_zomsfinp, cn_zomsfind, cn_zomsfpac /)
+    cl_iso = (/ cn_zoisoglo, cn_zoisoatl, cn_zoisoinp, cn_zoisoind, cn_zoisopac /)
+    cl_tag(1) = 'Global' ; cl_tag(2) = 'Atlantic' ; cl_tag(3) = 'IndoPacif' ; cl_tag(4) = 'Indian' ; cl_tag(5) = 'pacif'
+    DO jb = 1, nbasins
+       stypvar(jb)%cname       = cl_moc(jb)
+       stypvar(jb)%clong_name  = 'Meridional_Overt.Cell_'//TRIM(cl_tag(jb))
+       stypvar(jb)%cshort_name = cl_moc(jb)
+       IF ( lisodep ) THEN
+          stypvar(jb+nbasins)%cunits      = 'm'
+          stypvar(jb+nbasins)%cname       = cl_iso(jb)
+          stypvar(jb+nbasins)%clong_name  = 'Zonal_mean_isopycnal_depth_'//TRIM(cl_tag(jb))
+          stypvar(jb+nbasins)%cshort_name = cl_iso(jb)
+          stypvar(jb+nbasins)%valid_min   = 0.
+          stypvar(jb+nbasins)%valid_max   = 8000.
+       ENDIF
+    END DO
+    ncout = create      (cf_moc, 'none', 1, npjglo, nbins, cdep='sigma')
+    ierr  = createvar   (ncout, stypvar, nvaro, ipk, id_varout, cdglobal=cglobal)
+    ierr  = putheadervar(ncout, cf_vfil, 1, npjglo, nbins, pnavlon=rdumlon, pnavlat=rdumlat, pdep=sigma)
+    dtim  = getvar1d(cf_vfil, cn_vtimec, npt)
+    ierr  = putvar1d(ncout, dtim, npt, 'T')
+  END SUBROUTINE CreateOutputFile
+
+END PROGRAM cdfmocsig

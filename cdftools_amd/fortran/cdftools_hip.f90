@@ -159,6 +159,14 @@ MODULE cdftools_hip
        INTEGER(C_INT), VALUE :: npiglo, npjglo, nlev, in_space, out_space
        REAL(C_FLOAT), VALUE :: gdep_first, gdep_last, rdep_up, rdep_down ; REAL(C_DOUBLE), INTENT(out) :: dvertmean(*)
      END FUNCTION
+     ! ---- cdfmocsig ------------------------------------------------------------------------
+     INTEGER(C_INT) FUNCTION cdft_mocsig_compute(zv, zveiv, zt, zs, e1v, e3v, e31d, ibmask, gdep, npiglo, npjglo, npk, nbasins,  &
+          &         zspv, zspt, zsps, pref, keos, nbins, sigmin, sigstp, in_space, dmoc, depi, out_space, stream)              &
+          &         BIND(C, name='cdft_mocsig_compute')
+       IMPORT ; REAL(C_FLOAT), INTENT(in) :: zv(*), zt(*), zs(*), e1v(*) ; TYPE(C_PTR), VALUE :: zveiv, e3v, e31d, gdep, depi, stream
+       INTEGER(C_INT16_T), INTENT(in) :: ibmask(*) ; INTEGER(C_INT), VALUE :: npiglo, npjglo, npk, nbasins, keos, nbins, in_space, out_space
+       REAL(C_FLOAT), VALUE :: zspv, zspt, zsps, pref, sigmin, sigstp ; REAL(C_DOUBLE), INTENT(out) :: dmoc(*)
+     END FUNCTION
      ! ---- cdfpsi ---------------------------------------------------------------------------
      INTEGER(C_INT) FUNCTION cdft_psi_create(plan, npiglo, npjglo, npk) BIND(C, name='cdft_psi_create')
        IMPORT ; TYPE(C_PTR), INTENT(out) :: plan ; INTEGER(C_INT), VALUE :: npiglo, npjglo, npk

@@ -499,6 +499,24 @@ class ZonalPlan(_Plan):
         return out
 
 
+def mocsig(zv, zt, zs, e1v, ibmask, nbins, sigmin, sigstp, pref=0.0, eos=0, e3v=None, e31d=None, zveiv=None, gdep=None,
+           spv=(0.0, 0.0, 0.0), isodep=False, stream=None):
+    """cdft_mocsig_compute (host arrays) -> dmoc (npj,nbins,nb) r8 [, depi the same shape with isodep]."""
+    f = lambda x: None if x is None else np.ascontiguousarray(x, np.float32)   # noqa: E731
+    zv, zt, zs, e1v, e3v, e31d, zveiv, gdep = map(f, (zv, zt, zs, e1v, e3v, e31d, zveiv, gdep))
+    ib = np.ascontiguousarray(ibmask, np.int16)
+    npk, npj, npi = zv.shape
+    nb = ib.shape[-1]
+    dmoc = np.empty((npj, nbins, nb), np.float64)
+    depi = np.empty((npj, nbins, nb), np.float64) if isodep else None
+    P = lambda x: _null() if x is None else C.c_void_p(x.ctypes.data)   # noqa: E731
+    check(_lib.load().cdft_mocsig_compute(P(zv), P(zveiv), P(zt), P(zs), P(e1v), P(e3v), P(e31d), P(ib), P(gdep), npi, npj, npk,
+                                          nb, float(spv[0]), float(spv[1]), float(spv[2]), float(pref), eos, nbins,
+                                          float(sigmin), float(sigstp), MEM_HOST, P(dmoc), P(depi), MEM_HOST,
+                                          stream or current_stream_ptr()))
+    return (dmoc, depi) if isodep else dmoc
+
+
 def vint_cumul(zt, tmask, kout, hit, clip, rdep2, npko, sclf=1.0, mean=False, e3t=None, e31d=None, stream=None):
     """cdft_vint_cumul (host arrays): zt, tmask (npk,npj,npi) r4 -> (npko,npj,npi) r4."""
     a = [np.ascontiguousarray(zt, np.float32), None if e3t is None else np.ascontiguousarray(e3t, np.float32),
@@ -599,4 +617,4 @@ class CurlPlan(_Plan):
         return out
 
 
-__all__ = ["MocPlan", "HeatcPlan", "MeanPlan", "ZonalPlan", "MhstPlan", "PsiPlan", "CurlPlan", "vt_compute", "vint_cumul", "vertmean", "vint_transport", "vhst_transport", "sigmai", "sigma0", "sig_tool", "EOS_80", "EOS_TEOS10", "EOS_JMD94", "EOS_FAST_FMA", "Timer", "CdftError", "device_count", "current_stream_ptr", "MEM_HOST", "MEM_DEVICE"]
+__all__ = ["MocPlan", "HeatcPlan", "MeanPlan", "ZonalPlan", "MhstPlan", "PsiPlan", "CurlPlan", "vt_compute", "mocsig", "vint_cumul", "vertmean", "vint_transport", "vhst_transport", "sigmai", "sigma0", "sig_tool", "EOS_80", "EOS_TEOS10", "EOS_JMD94", "EOS_FAST_FMA", "Timer", "CdftError", "device_count", "current_stream_ptr", "MEM_HOST", "MEM_DEVICE"]

@@ -283,6 +283,26 @@ int cdft_vertmean(const float *zv, const float *e3, const float *e31d, const flo
 int cdft_column_release(void);   /* frees the staging buffers of the two calls above */
 
 /* ------------------------------------------------------------------------------------------ */
+/* cdfmocsig : meridional overturning in density classes                 */
+/*   replaces src/cdfmocsig.f90:368-470 (level loop, density binning, zonal sums, bin cumulation) */
+/* ------------------------------------------------------------------------------------------ */
+/* One record.  zv, zt, zs (npiglo,npjglo,npk) r4 as read from the files (fill values are replaced by 0
+ * here, :374,:382-383, with the spvals given); zveiv the eddy-induced velocity or NULL (-eiv); e1v
+ * (npiglo,npjglo); e3v (npiglo,npjglo,npk) or NULL with e31d (npk) (-full); ibmask (nbasins,npiglo,npjglo)
+ * i2, basin index fastest, the global one already cleared on columns 1 and npiglo (:357-358);
+ * pref, eos: the density is sigmai(zt,zs,pref) (-r, -teos10; -ntr is not carried);
+ * nbins, sigmin, sigstp: the density classes (:282-318).
+ * dmoc (nbasins,nbins,npjglo) r8 in Sv, cumulated from the highest density class down (:463-467).
+ * depi (nbasins,nbins,npjglo) r8 or NULL: -isodep, the transport-weighted mean depth of each class,
+ *   99999. where the class is empty; needs gdep (npk) r4 on the HOST, the NEGATIVE depths of :336. */
+int cdft_mocsig_compute(const float *zv, const float *zveiv, const float *zt, const float *zs, const float *e1v,
+                        const float *e3v, const float *e31d, const int16_t *ibmask, const float *gdep, int npiglo,
+                        int npjglo, int npk, int nbasins, float zspv, float zspt, float zsps, float pref, int eos,
+                        int nbins, float sigmin, float sigstp, int in_space, double *dmoc, double *depi, int out_space,
+                        void *stream);
+int cdft_mocsig_release(void);   /* frees the staging buffers of cdft_mocsig_compute */
+
+/* ------------------------------------------------------------------------------------------ */
 /* cdfpsi : barotropic stream function                                                        */
 /*   replaces src/cdfpsi.f90:271-298 (vertical integration), :377-423 (scans, mean, reference  */
 /*   point) and the SNGL / mask at :426-433.  Not covered: -open, --ssh-file, -lev.            */

@@ -247,3 +247,72 @@ void oracle_moc_decomp(int npi, int npj, int npk, int nb, const float *e1v, cons
     for (size_t q = 0; q < nbj * npk; ++q) dmoc_ag[q] = dmoc[q] - dmoc_sh[q] - dmoc_bt[q];                /* :516 */
     free(dvbt); free(dvgeo); free(btw); free(sig8); free(hdep); free(zv); free(zsig0);
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* cdfmocsig, src/cdfmocsig.f90:368-470 for ONE record (sigmai density, not -ntr).
+ *   zv, zt, zs (npi,npj,npk) r4 as read (fill values -> 0 with zspv, zspt, zsps, :374,:382-383); zveiv or
+ *   NULL (-eiv, :375-378); e1v (npi,npj); e3v (npi,npj,npk) or NULL with e31d (-full); ibmask (nb,npi,npj)
+ *   i2; gdep (npk) the negative depths of :336, or NULL without -isodep.
+ *   dmoc (nb,nbins,npj) r8; depi (nb,nbins,npj) r8 or NULL. */
+void oracle_mocsig(int npi, int npj, int npk, int nb, const float *zv3, const float *zveiv, const float *zt3,
+                   const float *zs3, const float *e1v, const float *e3v, const float *e31d, const int16_t *ibmask,
+                   const float *gdep, float zspv, float zspt, float zsps, float pref, int teos10, int nbins,
+                   float sigmin, float sigstp, double *dmoc, double *depi) {
+    const size_t nij = (size_t)npi * npj, nout = (size_t)nb * nbins * npj;
+    double *dens = (double *)malloc(nij * 8), *wdep = depi ? (double *)calloc(nout, 8) : NULL;
+    double *tmp = (double *)malloc((size_t)nbins * npi * 8), *dtmp = NULL, *wtmp = NULL;
+    float *zv = (float *)malloc(nij * 4), *zt = (float *)malloc(nij * 4), *zs = (float *)malloc(nij * 4);
+    int *ibin = (int *)malloc(nij * sizeof(int)), *itm = (int *)malloc(nij * sizeof(int));
+    if (depi) { dtmp = (double *)malloc((size_t)nbins * npi * 8); wtmp = (double *)malloc((size_t)nbins * npi * 8); memset(depi, 0, nout * 8); }
+    memset(dmoc, 0, nout * 8);
+    const int j0 = npj > 1 ? 1 : 0, j1 = npj > 1 ? npj - 2 : 0;                                    /* :405-407 */
+    for (int jk = 0; jk < npk - 1; ++jk) {
+        for (size_t p = 0; p < nij; ++p) {
+            zv[p] = zv3[jk * nij + p]; if (zv[p] == zspv) zv[p] = 0.f;
+            if (zveiv) zv[p] = zv[p] + zveiv[jk * nij + p];
+            zt[p] = zt3[jk * nij + p]; if (zt[p] == zspt) zt[p] = 0.f;
+            zs[p] = zs3[jk * nij + p]; if (zs[p] == zsps) zs[p] = 0.f;
+            itm[p] = (zs[p] == zsps) ? 0 : 1;                                                      /* :392-393 */
+        }
+        oracle_sigmai(zt, zs, (long)nij, pref, NULL, teos10, dens);
+        for (size_t p = 0; p < nij; ++p) {
+            const float zttmp = (float)(dens[p] * (double)itm[p]);                                 /* :398 */
+            int ib = (int)((zttmp - sigmin) / sigstp);
+            if (ib < 1) ib = 1;
+            if (ib > nbins) ib = nbins;
+            ibin[p] = ib - 1;
+        }
+        for (int jj = j0; jj <= j1; ++jj) {
+            memset(tmp, 0, (size_t)nbins * npi * 8);
+            if (depi) { memset(dtmp, 0, (size_t)nbins * npi * 8); memset(wtmp, 0, (size_t)nbins * npi * 8); }
+            for (int ji = 1; ji < npi - 1; ++ji) {
+                const size_t p = IJ(ji, jj);
+                const float zarea = e1v[p] * (e3v ? e3v[IJK(ji, jj, jk)] : e31d[jk]);              /* :389 */
+                const size_t q = (size_t)ibin[p] + (size_t)nbins * ji;
+                tmp[q] = tmp[q] - (double)(zv[p] * zarea);                                         /* :417 */
+                if (depi) {
+                    dtmp[q] = dtmp[q] + (double)(gdep[jk] * (float)itm[p] * zarea);                /* :424 */
+                    wtmp[q] = wtmp[q] + (double)((float)itm[p] * zarea);                           /* :425 */
+                }
+            }
+            for (int jb = 0; jb < nb; ++jb)
+                for (int jbin = 0; jbin < nbins; ++jbin)
+                    for (int ji = 1; ji < npi - 1; ++ji) {
+                        const double m = (double)ibmask[IJ(ji, jj) * nb + jb];
+                        const size_t o = ((size_t)jj * nbins + jbin) * nb + jb, q = (size_t)jbin + (size_t)nbins * ji;
+                        dmoc[o] = dmoc[o] + tmp[q] * m;                                            /* :435 */
+                        if (depi) { depi[o] = depi[o] + dtmp[q] * m; wdep[o] = wdep[o] + wtmp[q] * m; }
+                    }
+        }
+    }
+    if (depi)
+        for (size_t o = 0; o < nout; ++o) depi[o] = (wdep[o] != 0.0) ? depi[o] / wdep[o] : 99999.0;   /* :454-460 */
+    for (int jj = 0; jj < npj; ++jj)
+        for (int jb = 0; jb < nb; ++jb) {
+            double *col = dmoc + (size_t)jj * nbins * nb + jb;
+            col[(size_t)(nbins - 1) * nb] = col[(size_t)(nbins - 1) * nb] / (double)1.e6f;          /* :463 */
+            for (int n = nbins - 2; n >= 0; --n) col[(size_t)n * nb] = col[(size_t)(n + 1) * nb] + col[(size_t)n * nb] / (double)1.e6f;
+        }
+    free(dens); free(tmp); free(zv); free(zt); free(zs); free(ibin); free(itm);
+    if (depi) { free(dtmp); free(wtmp); free(wdep); }
+}

@@ -38,6 +38,11 @@ void oracle_moc_decomp(int npi, int npj, int npk, int nb, const float *e1v, cons
                        const uint8_t *tmask, const uint8_t *umask, const float *e1u, const float *zcoef,
                        const float *gdept, int teos10, const double *dmoc, double *dmoc_sh,
                        double *dmoc_bt, double *dmoc_ag);
+/* cdfmocsig, src/cdfmocsig.f90:368-470 for ONE record; see the definition for the arguments */
+void oracle_mocsig(int npi, int npj, int npk, int nb, const float *zv3, const float *zveiv, const float *zt3,
+                   const float *zs3, const float *e1v, const float *e3v, const float *e31d, const int16_t *ibmask,
+                   const float *gdep, float zspv, float zspt, float zsps, float pref, int teos10, int nbins,
+                   float sigmin, float sigstp, double *dmoc, double *depi);
 /* src/eos.f90:802-887 (sigmai_dep), :1002-1087 (sigmai_dep2d), :601-632 (sigma0 = pref 0);
  * coefficients as set by eos_init :207-598 (teos10 = 0: EOS-80 polynomial, 1: TEOS-10).
  * ptem, psal: n r4 values; pref: one r4 depth (pref2d == NULL) or n per-point depths. */

@@ -44,6 +44,24 @@ def moc_decomp(e1v, e3v, ibmask, zv, ztemp, zsal, tmask, umask, e1u, zcoef, gdep
     return {"total": tot, "sh": sh, "bt": bt, "ag": ag}
 
 
+def mocsig(zv, zt, zs, e1v, ibmask, nbins, sigmin, sigstp, pref=0.0, teos10=False, e3v=None, e31d=None, zveiv=None, gdep=None,
+           spv=(0.0, 0.0, 0.0), isodep=False):
+    """oracle_mocsig -> dmoc (npj,nbins,nb) r8 [, depi]."""
+    lib = load()
+    f = lambda a: None if a is None else np.ascontiguousarray(a, np.float32)   # noqa: E731
+    zv, zt, zs, e1v, e3v, e31d, zveiv, gdep = map(f, (zv, zt, zs, e1v, e3v, e31d, zveiv, gdep))
+    ib = np.ascontiguousarray(ibmask, np.int16)
+    npk, npj, npi = zv.shape
+    nb = ib.shape[-1]
+    dmoc = np.empty((npj, nbins, nb), np.float64)
+    depi = np.empty((npj, nbins, nb), np.float64) if isodep else None
+    P = lambda a: None if a is None else _p(a)   # noqa: E731
+    lib.oracle_mocsig(C.c_int(npi), C.c_int(npj), C.c_int(npk), C.c_int(nb), P(zv), P(zveiv), P(zt), P(zs), P(e1v), P(e3v), P(e31d),
+                      P(ib), P(gdep), C.c_float(spv[0]), C.c_float(spv[1]), C.c_float(spv[2]), C.c_float(pref),
+                      C.c_int(1 if teos10 else 0), C.c_int(nbins), C.c_float(sigmin), C.c_float(sigstp), P(dmoc), P(depi))
+    return (dmoc, depi) if isodep else dmoc
+
+
 def moc(e1v, e3v, ibmask, zv):
     """e1v (npj,npi), e3v (npk,npj,npi), ibmask (npj,npi,nb) i2, zv (npt,npk,npj,npi)
     -> dmoc (npt,npk,npj,nb) r8, one oracle_moc call per record."""

@@ -440,3 +440,96 @@ def test_cdfvint_and_cdfvertmean_end_to_end(tools, tmp_path):  # noqa: F811
             assert np.array_equal(var[nm + "_vert_mean"][t], ref.astype(np.float32)), nm
     rc, out, _ = run("cdfvertmean", ["-f", "SYN_y0001_gridT.nc", "-l", "votemper", "-p", "T", "-zlim", "100", "10"], d)
     assert rc == 99 and "increasing order" in out
+
+
+# ------------------------------------------------------------------------------------------- cdfmocsig
+import oracle_lib  # noqa: E402
+
+
+def mocsig_inputs(npi, npj, npk, nb, seed):
+    g = synth.make_grid(npi, npj, npk, seed=seed, nbasins=nb if nb > 1 else 5)
+    e1v, e3v, ib = synth.moc_inputs(g, nbasins=nb)
+    rng = np.random.default_rng(seed + 2)
+    zv = ((rng.random((npk, npj, npi), dtype=np.float32) - np.float32(0.5)) * g["vmask"]).astype(np.float32)
+    zt = ((np.float32(-2) + np.float32(30) * rng.random((npk, npj, npi), dtype=np.float32)) * g["tmask"]).astype(np.float32)
+    zs = ((np.float32(33) + np.float32(4) * rng.random((npk, npj, npi), dtype=np.float32)) * g["tmask"]).astype(np.float32)
+    return g, e1v, e3v, ib, zv, zt, zs
+
+
+def test_oracle_mocsig_matches_numpy_restatement():
+    g, e1v, e3v, ib, zv, zt, zs = mocsig_inputs(21, 12, 5, 5, seed=4)
+    nbins, sigmin, sigstp = 52, np.float32(23.0), np.float32(0.1)
+    gdep = -g["gdept_1d"]
+    got, depi = oracle_lib.mocsig(zv, zt, zs, e1v, ib, nbins, sigmin, sigstp, e3v=e3v, gdep=gdep, isodep=True)
+    npk, npj, npi = zv.shape
+    raw = np.zeros((npj, nbins, 5))
+    dd, ww = np.zeros((npj, nbins, 5)), np.zeros((npj, nbins, 5))
+    for k in range(npk - 1):
+        itm = (zs[k] != 0).astype(np.float32)                                      # zsps = 0: S = 0 is land
+        dens = oracle_lib.sigmai(zt[k], zs[k], 0.0)
+        ztt = (dens * itm).astype(np.float32)
+        ibin = np.clip(((ztt - sigmin) / sigstp).astype(np.float32).astype(np.int64), 1, nbins) - 1
+        zarea = (e1v * e3v[k]).astype(np.float32)
+        term = -(zv[k] * zarea).astype(np.float32).astype(np.float64)
+        tdep = ((np.float32(gdep[k]) * itm).astype(np.float32) * zarea).astype(np.float32).astype(np.float64)
+        twei = (itm * zarea).astype(np.float32).astype(np.float64)
+        for j in range(1, npj - 1):
+            for i in range(1, npi - 1):
+                raw[j, ibin[j, i]] += term[j, i] * ib[j, i]
+                dd[j, ibin[j, i]] += tdep[j, i] * ib[j, i]
+                ww[j, ibin[j, i]] += twei[j, i] * ib[j, i]
+    want = np.zeros_like(raw)
+    want[:, nbins - 1] = raw[:, nbins - 1] / 1e6
+    for n in range(nbins - 2, -1, -1):
+        want[:, n] = want[:, n + 1] + raw[:, n] / 1e6
+    assert np.allclose(got, want, rtol=0, atol=1e-12 * np.abs(want).max()) and np.abs(want).max() > 0
+    wd = np.where(ww != 0, dd / np.where(ww != 0, ww, 1), 99999.0)
+    assert np.allclose(depi, wd, rtol=1e-12, atol=0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("npi,npj,npk,nb,pref,teos", [(24, 18, 7, 5, 0.0, False), (182, 149, 31, 5, 2000.0, False),
+                                                      (40, 1, 4, 1, 1000.0, True), (700, 6, 5, 5, 0.0, True)])
+def test_hip_mocsig_matches_oracle(gpu, npi, npj, npk, nb, pref, teos):
+    g, e1v, e3v, ib, zv, zt, zs = mocsig_inputs(npi, npj, npk, nb, seed=npi + 1)
+    nbins, sigmin, sigstp = {0.0: (52, 23.0, 0.1), 1000.0: (88, 24.0, 0.1), 2000.0: (158, 30.0, 0.05)}[pref]
+    gdep = -g["gdept_1d"]
+    eiv = (zv * np.float32(0.1)).astype(np.float32)
+    for kw in (dict(e3v=e3v), dict(e31d=g["e3t_1d"], zveiv=eiv)):
+        ref, rdep = oracle_lib.mocsig(zv, zt, zs, e1v, ib, nbins, sigmin, sigstp, pref=pref, teos10=teos, gdep=gdep, isodep=True, **kw)
+        got, gdp = gpu.mocsig(zv, zt, zs, e1v, ib, nbins, sigmin, sigstp, pref=pref, eos=gpu.EOS_TEOS10 if teos else gpu.EOS_80,
+                              gdep=gdep, isodep=True, **kw)
+        assert np.all(np.abs(got - ref) <= 1e-10 * np.abs(ref).max() + 1e-300), float(np.abs(got - ref).max())
+        assert np.allclose(gdp, rdep, rtol=1e-10, atol=0)
+        only = gpu.mocsig(zv, zt, zs, e1v, ib, nbins, sigmin, sigstp, pref=pref, eos=gpu.EOS_TEOS10 if teos else gpu.EOS_80, **kw)
+        assert np.all(np.abs(only - ref) <= 1e-10 * np.abs(ref).max() + 1e-300)
+        again = gpu.mocsig(zv, zt, zs, e1v, ib, nbins, sigmin, sigstp, pref=pref, eos=gpu.EOS_TEOS10 if teos else gpu.EOS_80, **kw)
+        assert np.array_equal(only, again)                                   # per-wave histograms: run-to-run identical
+
+
+@pytest.mark.gpu
+def test_cdfmocsig_end_to_end(tools, tmp_path):  # noqa: F811
+    d = str(tmp_path)
+    g, rec = nemo_files.make_case(d, npi=26, npj=19, npk=6, npt=2)
+    e1v, e3v, ib = synth.moc_inputs(g, nbasins=5)
+    rc, out, err = run("cdfmocsig", ["-v", "SYN_y0001_gridV.nc", "-t", "SYN_y0001_gridT.nc", "-r", "2000", "-isodep"], d)
+    assert rc == 0 and "-nbins 158" in out, out + err
+    var, att, dims = read_nc(os.path.join(d, "mocsig.nc"))
+    assert dims["sigma"] == 158 and att["zoisoatl"]["units"] == b"m"
+    assert np.allclose(var["sigma"], np.float32(30.0) + (np.arange(1, 159) - 0.5).astype(np.float32) * np.float32(0.05), rtol=1e-6)
+    gdep = -g["gdept_1d"]
+    names = ["glo", "atl", "inp", "ind", "pac"]
+    for t in range(2):
+        ref, rdep = oracle_lib.mocsig(rec["v"][t], rec["t"][t], rec["s"][t], e1v, ib, 158, 30.0, 0.05, pref=2000.0, e3v=g["e3v_0"],
+                                      gdep=gdep, isodep=True, spv=(0.0, 0.0, 0.0))
+        for b, nm in enumerate(names):
+            got = var["zomsf" + nm][t, :, :, 0]                               # (sigma, y)
+            assert np.allclose(got, ref[:, :, b].T, rtol=0, atol=2e-7 * np.abs(ref).max()), nm
+            assert np.allclose(var["zoiso" + nm][t, :, :, 0], rdep[:, :, b].T, rtol=3e-7, atol=0), nm
+    assert np.abs(var["zomsfglo"]).max() > 0
+    rc, out, _ = run("cdfmocsig", ["-v", "SYN_y0001_gridV.nc", "-t", "SYN_y0001_gridT.nc", "-r", "500"], d)
+    assert rc == 99 and "not implemented as standard" in out
+    rc, out, _ = run("cdfmocsig", ["-v", "SYN_y0001_gridV.nc", "-t", "SYN_y0001_gridT.nc", "-ntr"], d)
+    assert rc == 99 and "-ntr" in out
+    rc, out, _ = run("cdfmocsig", ["-v", "SYN_y0001_gridV.nc", "-t", "SYN_y0001_gridT.nc"], d)
+    assert rc == 99 and "mandatory arguments missing" in out

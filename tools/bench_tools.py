@@ -85,6 +85,20 @@ def main():
             report(name, args.grid, n3, 8.0, ms, "field 4 + mask 4 B per cell (2-D surface and basin masks from cache); D2H of the result included")
         del p, zv
 
+    if "mocsig" in tools:
+        import time
+        ib = (rnd(npj, npi, 5) > 0.4).to(torch.int16).cpu().numpy()
+        zv, zt, zs = (rnd(npk, npj, npi) - 0.5).cpu().numpy(), (-2 + 30 * rnd(npk, npj, npi)).cpu().numpy(), (33 + 4 * rnd(npk, npj, npi)).cpu().numpy()
+        e1n, e3n = e1.cpu().numpy(), e3.cpu().numpy()
+        hip.mocsig(zv, zt, zs, e1n, ib, 158, 30.0, 0.05, pref=2000.0, e3v=e3n)
+        tm = hip.Timer()
+        t0 = time.perf_counter()
+        hip.mocsig(zv, zt, zs, e1n, ib, 158, 30.0, 0.05, pref=2000.0, e3v=e3n)
+        ms = (time.perf_counter() - t0) * 1e3
+        report("cdfmocsig (host arrays, 158 classes, 5 basins)", args.grid, n3, 16.0, ms,
+               "v,T,S,e3v 16 B per cell; the time includes the H2D copy of the four fields (PCIe-bound)")
+        del zv, zt, zs, e3n
+
     if "mhst" in tools:
         vt, vs = rnd(npk, npj, npi) - 0.5, rnd(npk, npj, npi) - 0.5
         m = (rnd(5, npj, npi) > 0.4).float()
