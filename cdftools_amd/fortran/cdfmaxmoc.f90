@@ -1,0 +1,144 @@
+PROGRAM cdfmaxmoc
+  !!======================================================================
+  !!                     ***  PROGRAM  cdfmaxmoc  ***
+  !! Maximum and minimum of the overturning of a moc.nc file in a latitude / depth window, and where they
+  !! are found.
+  !!
+  !! Drop-in for the reference tool (src/cdfmaxmoc.f90): a consumer of the file cdfmoc writes (one
+  !! (y,depthw) slice of the first record): no grid-sized work, so nothing here runs on the GPU; it is part of
+  !! the tool set because it checks the moc.nc produced by this build end to end.
+  !!======================================================================
+  USE cdfio
+  USE modcdfnames
+  IMPLICIT NONE
+
+  INTEGER(KIND=4) :: jj, jk, npjglo, npk, narg, ijarg, ijmin = 1, ijmax = 1, ikmin = 1, ikmax = 1
+  INTEGER(KIND=4) :: ilatmin, ilatmax, idepmin, idepmax, nx = 1, ny = 1, nz = 1, nvarout = 6, ncout, ierr
+  INTEGER(KIND=4) :: iminloc(3), imaxloc(3)
+  INTEGER(KIND=4), ALLOCATABLE :: ipk(:), id_varout(:)
+  REAL(KIND=4) :: ovtmax, ovtmin, rlatmin = 0., rlatmax = 0., rdepmin = 0., rdepmax = 0.
+  REAL(KIND=4), ALLOCATABLE :: gdepw(:), rdumlon(:,:), rdumlat(:,:), rlat(:,:), rmoc(:,:,:)
+  REAL(KIND=8) :: dtim(1)
+  TYPE(variable), ALLOCATABLE :: stypvar(:)
+  CHARACTER(LEN=256) :: cf_moc = 'none', cf_ncout = 'maxmoc.nc', cldum, cbasin = ' ', cv_in
+  !!----------------------------------------------------------------------
+  CALL ReadCdfNames()
+  narg = COMMAND_ARGUMENT_COUNT()
+  IF ( narg == 0 ) THEN
+     PRINT *, ' usage : cdfmaxmoc -f OVT-file -b BASIN-name -w latmin latmax depmin depmax ...'
+     PRINT *, '                 ... [-o OUT-file]'
+     PRINT *, '      '
+     PRINT *, '     PURPOSE :'
+     PRINT *, '        Compute the maximum and minimum of the overturning, from OVT-file, for the specified'
+     PRINT *, '        oceanic basin, in the window given by a range of latitudes and depths.'
+     PRINT *, '      '
+     PRINT *, '     ARGUMENTS :'
+     PRINT *, '        -f OVT-file   : overturning file from cdfmoc, with or w/o sub basins.'
+     PRINT *, '        -b BASIN-name : one of atl, glo, inp, ind or pac (glo: no subbasins).'
+     PRINT *, '        -w latmin latmax depmin depmax : limits in latitude (deg N) and depth (meters).'
+     PRINT *, '      '
+     PRINT *, '     OPTIONS :'
+     PRINT *, '        [-o OUT-file] : output file name instead of ', TRIM(cf_ncout)
+     PRINT *, '      '
+     PRINT *, '     REQUIRED FILES :'
+     PRINT *, '        none'
+     PRINT *, '      '
+     PRINT *, '     OUTPUT : '
+     PRINT *, '       netcdf file : ', TRIM(cf_ncout)
+     PRINT *, '         6 variables : maxmoc, minmoc (Sv), latmaxmoc, latminmoc (deg), depthmaxmoc, depthminmoc (m)'
+     STOP
+  ENDIF
+
+  ijarg = 1
+  DO WHILE ( ijarg <= narg )
+     CALL GET_COMMAND_ARGUMENT(ijarg, cldum) ; ijarg = ijarg + 1
+     SELECT CASE ( cldum )
+     CASE ( '-f' ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cf_moc) ; ijarg = ijarg + 1
+     CASE ( '-b' ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cbasin) ; ijarg = ijarg + 1
+     CASE ( '-w' ) ; CALL getr(rlatmin) ; CALL getr(rlatmax) ; CALL getr(rdepmin) ; CALL getr(rdepmax)
+     CASE ( '-o' ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cf_ncout) ; ijarg = ijarg + 1
+     CASE DEFAULT  ; PRINT *, ' ERROR : ', TRIM(cldum), ' : unknown option.' ; STOP 99
+     END SELECT
+  END DO
+  IF ( chkfile(cf_moc) ) STOP 99
+
+  npjglo = getdim(cf_moc, cn_y)
+  npk    = getdim(cf_moc, cn_z)
+  ALLOCATE( rmoc(1,npjglo,npk), gdepw(npk), rlat(1,npjglo) )
+  gdepw(:)  = -getvar1d(cf_moc, cn_vdepthw, npk)
+  rlat(:,:) =  getvar  (cf_moc, cn_vlat2d, 1, 1, npjglo)
+  SELECT CASE ( cbasin )
+  CASE ( 'atl' ) ; cv_in = cn_zomsfatl
+  CASE ( 'glo' ) ; cv_in = cn_zomsfglo
+  CASE ( 'pac' ) ; cv_in = cn_zomsfpac
+  CASE ( 'inp' ) ; cv_in = cn_zomsfinp
+  CASE ( 'ind' ) ; cv_in = cn_zomsfind
+  CASE DEFAULT   ; PRINT *, ' basin not found !' ; STOP 99
+  END SELECT
+  ALLOCATE( stypvar(nvarout), ipk(nvarout), id_varout(nvarout), rdumlon(1,1), rdumlat(1,1) )
+  CALL CreateOutput
+
+  DO jk = 1, npk
+     rmoc(:,:,jk) = getvar(cf_moc, cv_in, jk, 1, npjglo)
+  END DO
+  DO jj = 1, npjglo                                         ! window in index space (src/cdfmaxmoc.f90:162-173)
+     IF ( rlat(1,jj) <= rlatmin ) ijmin = jj
+     IF ( rlat(1,jj) <= rlatmax ) ijmax = jj
+  END DO
+  DO jk = 1, npk
+     IF ( gdepw(jk) <= rdepmin ) ikmin = jk
+     IF ( gdepw(jk) <= rdepmax ) ikmax = jk
+  END DO
+  ovtmax  = MAXVAL(rmoc(1,ijmin:ijmax,ikmin:ikmax))
+  ovtmin  = MINVAL(rmoc(1,ijmin:ijmax,ikmin:ikmax))
+  iminloc = MINLOC(rmoc(:,ijmin:ijmax,ikmin:ikmax))
+  imaxloc = MAXLOC(rmoc(:,ijmin:ijmax,ikmin:ikmax))
+  ilatmin = iminloc(2) + ijmin - 1 ; ilatmax = imaxloc(2) + ijmin - 1
+  idepmin = iminloc(3) + ikmin - 1 ; idepmax = imaxloc(3) + ikmin - 1
+  PRINT *, ' Maximum ', ovtmax, ' Sv latitude ', rlat(1,ilatmax), ' depth = ', gdepw(idepmax)
+  PRINT *, ' Minimum ', ovtmin, ' Sv latitude ', rlat(1,ilatmin), ' depth = ', gdepw(idepmin)
+  ierr = putvar0d(ncout, id_varout(1), REAL(ovtmax))
+  ierr = putvar0d(ncout, id_varout(2), REAL(ovtmin))
+  ierr = putvar0d(ncout, id_varout(3), REAL(rlat(1,ilatmax)))
+  ierr = putvar0d(ncout, id_varout(4), REAL(rlat(1,ilatmin)))
+  ierr = putvar0d(ncout, id_varout(5), REAL(gdepw(idepmax)))
+  ierr = putvar0d(ncout, id_varout(6), REAL(gdepw(idepmin)))
+  ierr = closeout(ncout)
+
+CONTAINS
+
+  SUBROUTINE getr(pval)
+    REAL(KIND=4), INTENT(out) :: pval
+    CALL GET_COMMAND_ARGUMENT(ijarg, cldum) ; ijarg = ijarg + 1 ; READ(cldum, *) pval
+  END SUBROUTINE getr
+
+  SUBROUTINE CreateOutput
+    !! src/cdfmaxmoc.f90:196-241
+    rdumlon(:,:) = 0. ; rdumlat(:,:) = 0.
+    ipk(:) = 1
+    stypvar%rmissing_value    = 99999.
+    stypvar%scale_factor      = 1.
+    stypvar%add_offset        = 0.
+    stypvar%savelog10         = 0.
+    stypvar%conline_operation = 'N/A'
+    stypvar%caxis             = 'T'
+    stypvar(1)%cname = 'maxmoc'      ; stypvar(1)%clong_name = 'Maximum_Overturing'
+    stypvar(2)%cname = 'minmoc'      ; stypvar(2)%clong_name = 'Minimum_Overtuning'
+    stypvar(3)%cname = 'latmaxmoc'   ; stypvar(3)%clong_name = 'Latitude_of_Maximum_Overturing'
+    stypvar(4)%cname = 'latminmoc'   ; stypvar(4)%clong_name = 'Latitude_of_Minimum_Overtuning'
+    stypvar(5)%cname = 'depthmaxmoc' ; stypvar(5)%clong_name = 'Depth_of_Maximum_Overturing'
+    stypvar(6)%cname = 'depthminmoc' ; stypvar(6)%clong_name = 'Depth_of_Minimum_Overtuning'
+    DO jj = 1, nvarout
+       stypvar(jj)%cshort_name = stypvar(jj)%cname
+    END DO
+    stypvar(1:2)%cunits = 'Sverdrup' ; stypvar(1:2)%valid_min = -1000.  ; stypvar(1:2)%valid_max = 1000.
+    stypvar(3:4)%cunits = 'Degrees'  ; stypvar(3:4)%valid_min = -90.    ; stypvar(3:4)%valid_max = 90.
+    stypvar(5:6)%cunits = 'Meters'   ; stypvar(5:6)%valid_min = -10000. ; stypvar(5:6)%valid_max = 0.
+    ncout = create      (cf_ncout, 'none', nx, ny, nz, cdep=cn_vdepthw)
+    ierr  = createvar   (ncout, stypvar, nvarout, ipk, id_varout)
+    ierr  = putheadervar(ncout, cf_moc, nx, ny, nz, pnavlon=rdumlon, pnavlat=rdumlat, pdep=gdepw)
+    dtim  = getvar1d(cf_moc, cn_vtimec, 1)
+    ierr  = putvar1d(ncout, dtim, 1, 'T')
+  END SUBROUTINE CreateOutput
+
+END PROGRAM cdfmaxmoc

@@ -129,3 +129,27 @@ def test_cdfmoc_decomp_end_to_end(tools, tmp_path):
     assert rc == 99 and "nothere.nc is missing" in out
     rc, out, _ = run("cdfmoc", ["-v", "SYN_y0001_gridV.nc", "-rapid"], tmp_path)
     assert rc == 99 and "-rapid" in out
+
+
+@pytest.mark.gpu
+def test_cdfmaxmoc_reads_the_moc_file_of_this_build(tools, tmp_path):
+    """cdfmoc -> moc.nc -> cdfmaxmoc: the consumer of the file format (src/cdfmaxmoc.f90)."""
+    g, rec = nemo_files.make_case(str(tmp_path))
+    rc, out, err = run("cdfmoc", ["-v", "SYN_y0001_gridV.nc"], tmp_path)
+    assert rc == 0, out + err
+    moc, _, _ = read_nc(os.path.join(tmp_path, "moc.nc"))
+    lat, dep = moc["nav_lat"][:, 0], moc["depthw"]                       # depthw is stored negative
+    rc, out, err = run("cdfmaxmoc", ["-f", "moc.nc", "-b", "atl", "-w", "-30", "60", "-5000", "-20"], tmp_path)
+    assert rc == 0 and "Maximum" in out, out + err
+    var, att, _ = read_nc(os.path.join(tmp_path, "maxmoc.nc"))
+    gdepw = -dep
+    jmin = max(int(np.nonzero(lat <= -30)[0].max()) if (lat <= -30).any() else 0, 0)
+    jmax = int(np.nonzero(lat <= 60)[0].max())
+    kmin = int(np.nonzero(gdepw <= -5000)[0].max()) if (gdepw <= -5000).any() else 0
+    kmax = int(np.nonzero(gdepw <= -20)[0].max()) if (gdepw <= -20).any() else 0
+    sub = moc["zomsfatl"][0, kmin:kmax + 1, jmin:jmax + 1, 0]
+    assert np.isclose(var["maxmoc"].ravel()[0], sub.max()) and np.isclose(var["minmoc"].ravel()[0], sub.min())
+    k, j = np.unravel_index(np.argmax(sub), sub.shape)
+    assert np.isclose(var["latmaxmoc"].ravel()[0], lat[jmin + j]) and att["maxmoc"]["units"] == b"Sverdrup"
+    rc, out, _ = run("cdfmaxmoc", ["-f", "moc.nc", "-b", "xyz", "-w", "0", "60", "-5000", "0"], tmp_path)
+    assert rc == 99 and "basin not found" in out
