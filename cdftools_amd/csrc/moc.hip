@@ -12,10 +12,10 @@ struct cdft_moc_plan {
     int npi = 0, npj = 0, npk = 0, nbasins = 0;
     float   *w    = nullptr;   // (npi,npj,npk) r4 weight e1v*e3v
     uint8_t *bits = nullptr;   // (npi,npj) basin bits
-    uint8_t *cls  = nullptr;   // (npi,npj) class of the cell's bit pattern (class mode), 0xFF = none
+    uint8_t *cls  = nullptr;   // (npi,npj) class of the cell's bit pattern (class mode)
     int     *flag = nullptr;   // device: [0] error flag (mask value check), [1..256] pattern present
     uint8_t pat[kMaxClass] = {0};
-    int     nclass = 0;        // distinct non-empty patterns, 0 when there are more than kMaxClass
+    int     nclass = 0;        // distinct patterns (the empty one included), 0 when there are more than kMaxClass
     bool mesh_set = false;
     int  tune_waves = 0, tune_nv = 0, tune_mode = 0;
     DevBuf st_e1v, st_e3v, st_mask, st_zv, st_out;   // staging for host arrays
@@ -54,11 +54,11 @@ __global__ void moc_bits_kernel(const int16_t *__restrict__ ibmask, uint8_t *__r
         }
         bits[e] = (uint8_t)v;
         if (bad) atomicOr(flag, 1);
-        if (v && !flag[1 + v]) flag[1 + v] = 1;          // benign race: every writer stores 1
+        if (!flag[1 + v]) flag[1 + v] = 1;               // benign race: every writer stores 1
     }
 }
 
-// cls(i,j) = class index of the cell's basin-bit pattern (lut), 0xFF for a cell in no basin
+// cls(i,j) = class index of the cell's basin-bit pattern (lut)
 __global__ void moc_class_kernel(const uint8_t *__restrict__ bits, uint8_t *__restrict__ cls, int64_t nij,
                                  const uint8_t *__restrict__ lut) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -124,9 +124,10 @@ __global__ void __launch_bounds__(256) dec_zonal_r8_kernel(const float *__restri
         const int64_t r2 = (int64_t)jj * npi, r3 = (int64_t)row * npi;
         for (int i = threadIdx.x; i < npi; i += 256) {
             const double t = __dmul_rn((double)w[r3 + i], field[r2 + i]);
+            const double tz = __dmul_rn(t, 0.0);          // ibmask = 0: a zero, or the NaN of 0*NaN / 0*Inf
             const uint32_t bb = bits[r2 + i];
 #pragma unroll
-            for (int b = 0; b < NB; ++b) acc[b] += ((bb >> b) & 1u) ? t : 0.0;
+            for (int b = 0; b < NB; ++b) acc[b] += ((bb >> b) & 1u) ? t : tz;
         }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -225,7 +226,8 @@ void choose_shape(const cdft_moc_plan *p, bool aligned, int *nwaves, int *nv, in
         int vmax = (md == kModeFma) ? 4 : (md == kModeClass ? 9 : 8);   // measured best at npiglo = 4322
         k = ceil_div(nvec, kWave * vmax);
         if (k > kSmallWaves) {          // long rows: 1024-thread workgroups, fewer registers
-            vmax = (md == kModeFma) ? 2 : (md == kModeClass ? kBigNVClass : kBigNV);
+            // (several basin accumulators leave room for one vector less than a single one does)
+            vmax = (md == kModeFma) ? 2 : (md == kModeClass ? kBigNVClass : (p->nbasins > 1 ? kBigNV - 1 : kBigNV));
             k = ceil_div(nvec, kWave * vmax);
         }
         v = ceil_div(nvec, kWave * k);
@@ -329,11 +331,12 @@ int cdft_moc_set_mesh(cdft_moc_plan *p, const float *e1v, const float *e3v, cons
     CDFT_HIP(hipMemcpyAsync(flags, p->flag, sizeof(flags), hipMemcpyDeviceToHost, st));
     CDFT_HIP(hipStreamSynchronize(st));
     const int flag = flags[0];
-    // class mode: the distinct non-empty bit patterns, in increasing order
+    // class mode: the distinct bit patterns, in increasing order (the empty pattern included: its cells
+    // still contribute the reference's 0*zv terms, see moc_zonal.hpp)
     uint8_t lut[256];
     p->nclass = 0;
     for (int v = 0; v < 256; ++v) lut[v] = 0xFF;
-    for (int v = 1; v < 256; ++v)
+    for (int v = 0; v < 256; ++v)
         if (flags[1 + v]) {
             if (p->nclass < kMaxClass) { p->pat[p->nclass] = (uint8_t)v; lut[v] = (uint8_t)p->nclass; }
             ++p->nclass;

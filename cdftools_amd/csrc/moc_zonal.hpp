@@ -5,10 +5,11 @@
 //     dmoc(jbasin,jj,jk) = dmoc(jbasin,jj,jk) - e1v(ji,jj)*e3v(ji,jj,jk)*ibmask(jbasin,ji,jj)*zv(ji,jj)*1.d0
 // Arithmetic contract (kept bit-faithful per term): the product is formed in r4, left to right,
 // then widened to r8 and accumulated in r8.  With ibmask in {0,1} the r4 product equals
-// (e1v*e3v)*zv where the basin bit is set and contributes (+/-)0 elsewhere, so the kernel keeps
-// ONE r4 weight w = e1v*e3v per cell (rounded once, as the reference's first product) plus one
-// byte of basin bits per (i,j), and selects per basin.  Only the order of the r8 additions along
-// i differs from the sequential reference (fixed tree => run-to-run deterministic).
+// (e1v*e3v)*zv where the basin bit is set and contributes (+/-)0 elsewhere (NaN when zv is NaN or
+// Inf there: 0*NaN, kept), so the kernel keeps ONE r4 weight w = e1v*e3v per cell (rounded once,
+// as the reference's first product) plus one byte of basin bits per (i,j), and selects per basin.
+// Only the order of the r8 additions along i differs from the sequential reference (fixed tree =>
+// run-to-run deterministic).
 //
 // Work decomposition (HBM-bound, no MFMA):
 //   one workgroup            = one (jj,jk) row of npiglo cells, for ALL npt records
@@ -21,6 +22,7 @@
 //                              (8x8 lanes per basin) -> 3 cross-lane steps; waves of a row are
 //                              combined through LDS in wave order once per record chunk
 #pragma once
+#include <type_traits>
 #include "common.hpp"
 
 namespace cdft {
@@ -36,14 +38,14 @@ constexpr int kTChunk    = 16;   // records combined per LDS flush
 constexpr int kScrStride = 72;   // doubles; 64 + 8 keeps the 5 basin rows on different banks
 
 enum Mode { kModeSelect = 1, kModeFma = 2, kModeClass = 3 };
-constexpr int kMaxClass = 8;     // distinct non-empty basin-bit patterns the class kernel can hold
+constexpr int kMaxClass = 8;     // distinct basin-bit patterns (the empty one included) the class kernel can hold
 
 struct ZonalArgs {
     const float   *w;           // (npi,npj,npk) r4 weights, base 16-byte aligned, padded by 16 B
     const uint8_t *bits;        // (npi,npj) basin bits
-    const uint8_t *cls;         // (npi,npj) class of the cell's bit pattern, 0xFF = no basin (class mode)
+    const uint8_t *cls;         // (npi,npj) class of the cell's bit pattern (class mode)
     uint8_t        pat[kMaxClass];  // bit pattern of each class
-    int            nclass;      // 0 = class mode unavailable (more than kMaxClass patterns)
+    int            nclass;      // patterns in use; 0 = class mode unavailable (more than kMaxClass)
     const float   *zv;          // record 0
     int64_t        rec_stride;  // elements between records
     int            npt;
@@ -169,25 +171,39 @@ moc_zonal_kernel(ZonalArgs a) {
             const int t = t0 + tl;
             if (t + 1 < a.npt) load_rec(zn, t + 1);               // next record in flight
 
+            // ibmask = 0: the reference's term is ((e1v*e3v)*0)*zv, a signed zero that never changes the
+            // r8 sum -- unless zv is NaN/Inf there (a fill value on land), when it is NaN and the sum must
+            // keep it.  The usual all-finite record selects pd or 0; a record in which any r4 product of
+            // the wave is not finite is accumulated again with 0*pd in place of the 0 (EXACT).
             double acc[NB];
+            float nonfinite = 0.f;                                // sum of 0*pf: 0, or NaN once a product is NaN/Inf
+            auto accumulate = [&](auto exact) {
+                constexpr bool EXACT = decltype(exact)::value;
 #pragma unroll
-            for (int b = 0; b < NB; ++b) acc[b] = 0.0;
+                for (int b = 0; b < NB; ++b) acc[b] = 0.0;
 #pragma unroll
-            for (int r = 0; r < NV; ++r) {
+                for (int r = 0; r < NV; ++r) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    // r4 product, then widen: src/cdfmoc.f90:373-374
-                    const float zf = (MODE == kModeFma) ? (ok[r][c] ? zc[r][c] : 0.f) : zc[r][c];
-                    const double pd = (double)__fmul_rn(w[r][c], zf);
+                    for (int c = 0; c < 4; ++c) {
+                        // r4 product, then widen: src/cdfmoc.f90:373-374.  Lanes past the row end re-read
+                        // a real cell with weight 0: harmless unless that cell is not finite
+                        const float zf = (MODE == kModeFma || EXACT) ? (ok[r][c] ? zc[r][c] : 0.f) : zc[r][c];
+                        const float pf = __fmul_rn(w[r][c], zf);
+                        const double pd = (double)pf;
+                        if (MODE == kModeSelect && !EXACT) nonfinite = __fmaf_rn(pf, 0.f, nonfinite);
+                        const double pz = EXACT ? __dmul_rn(pd, 0.0) : 0.0;
 #pragma unroll
-                    for (int b = 0; b < NB; ++b) {
-                        if (MODE == kModeFma)
-                            acc[b] = __fma_rn(pd, m[r][c][b], acc[b]);
-                        else
-                            acc[b] += ((bits[r] >> (8 * c + b)) & 1u) ? pd : 0.0;
+                        for (int b = 0; b < NB; ++b) {
+                            if (MODE == kModeFma)
+                                acc[b] = __fma_rn(pd, m[r][c][b], acc[b]);
+                            else
+                                acc[b] += ((bits[r] >> (8 * c + b)) & 1u) ? pd : pz;
+                        }
                     }
                 }
-            }
+            };
+            accumulate(std::false_type{});
+            if (MODE == kModeSelect && __builtin_amdgcn_ballot_w64(nonfinite != 0.f) != 0) accumulate(std::true_type{});
 
             // wave reduction: transpose through LDS so that lane (b*8+s) sums 8 lanes' partials
 #pragma unroll
@@ -300,7 +316,9 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
 // per-lane, per-class slot in LDS, updated by ds_add_f64 (one LDS instruction per cell instead of
 // ~5 x 5 VALU instructions).  A slot only ever receives the terms of its own lane, in program
 // order, so the result is run-to-run deterministic.  Basin sums are formed from the class sums at
-// the end (basin b = classes whose pattern has bit b, in class order).
+// the end (basin b = classes whose pattern has bit b, in class order).  The empty pattern (a cell in
+// no basin) is a class like the others: its sum is finite unless a NaN/Inf sits on such a cell, and
+// 0 * (the sums of the classes outside b) restores the NaN the reference's 0*zv products give.
 template <int NV, int KC, int LB>
 __global__ void __launch_bounds__(LB)
 moc_zonal_class_kernel(ZonalArgs a) {
@@ -308,7 +326,7 @@ moc_zonal_class_kernel(ZonalArgs a) {
     const int lane   = threadIdx.x & (kWave - 1);
     const int wave   = threadIdx.x >> 6;
     const int nwaves = blockDim.x >> 6;
-    double *scr  = smem + wave * ((KC + 1) * kScrStride);        // slot [class][lane]; class KC = unused cells
+    double *scr  = smem + wave * ((KC + 1) * kScrStride);        // slot [class][lane]; class KC = lanes past the row end
     double *part = smem + nwaves * ((KC + 1) * kScrStride);      // [kTChunk][KC][nwaves]
 
     const int row = blockIdx.x;                                   // jk*npj + jj, jj fastest
@@ -355,7 +373,7 @@ moc_zonal_class_kernel(ZonalArgs a) {
         for (int c = 0; c < 4; ++c) {
             const bool ok = (i0 + c >= 0) && (i0 + c < a.npi);
             w[r][c]    = ok ? wr[c] : 0.f;
-            slot[r][c] = (ok ? min((int)craw[r][c], KC) : KC) * kScrStride + lane;
+            slot[r][c] = (ok ? min((int)craw[r][c], KC) : KC) * kScrStride + lane;   // slot KC is never read
         }
     }
 
@@ -398,10 +416,17 @@ moc_zonal_class_kernel(ZonalArgs a) {
         __syncthreads();
         if ((int)threadIdx.x < tcount * a.nbasins) {
             const int tl = threadIdx.x / a.nbasins, b = threadIdx.x - tl * a.nbasins;
-            double s = 0.0;
-            for (int c = 0; c < a.nclass; ++c)
-                if ((a.pat[c] >> b) & 1)
-                    for (int k = 0; k < nwaves; ++k) s += part[(tl * KC + c) * nwaves + k];
+            double s = 0.0, z = 0.0;
+            for (int c = 0; c < a.nclass; ++c) {
+                const bool in = (a.pat[c] >> b) & 1;
+                for (int k = 0; k < nwaves; ++k) {
+                    const double v = part[(tl * KC + c) * nwaves + k];
+                    if (in) s += v;
+                    else    z += v;
+                }
+            }
+            // cells outside basin b: the reference adds ((e1v*e3v)*0)*zv, a zero unless zv is NaN/Inf
+            s += __dmul_rn(z, 0.0);
             a.out[(((int64_t)(t0 + tl) * a.npk + jk) * a.npj + jj) * a.nbasins + b] = -s;
         }
         __syncthreads();

@@ -23,6 +23,7 @@ struct cdft_zonal_plan {
     float  *bmask = nullptr;      // (nb,npi,npj) basin masks, basin index fastest
     uint8_t *bits = nullptr;      // (npi,npj) basin bits when every basin mask is 0/1 (fast kernel)
     int *flag = nullptr;          // device: 1 when a basin-mask value is neither 0 nor 1
+    int *rowflag = nullptr;       // device (npj): rows of the last fast-kernel launch that met a NaN/Inf
     bool binary = false;
     bool mesh_set = false;
     DevBuf st_a, st_b, st_zv, st_o[4];
@@ -47,9 +48,10 @@ struct ZonalArgs2 {
 };
 
 template <int NB, bool MEAN, bool MINMAX>
-__global__ void __launch_bounds__(kThreads) zonal_row_kernel(ZonalArgs2 a) {
+__global__ void __launch_bounds__(kThreads) zonal_row_kernel(ZonalArgs2 a, const int *__restrict__ rowflag) {
     extern __shared__ double lds[];                     // [nlev][nwaves][NB][4]: sum, area, max, min
     const int jj = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = kThreads / 64;
+    if (rowflag && !rowflag[jj]) return;                // second pass behind the fast kernel: flagged rows only
     const int64_t nij = (int64_t)a.npi * a.npj, r2 = (int64_t)jj * a.npi;
     for (int k = 0; k < a.nlev; ++k) {
         const float *zv = a.zv + (int64_t)k * nij + r2, *mv = a.mask3 + (int64_t)k * nij + r2;
@@ -126,7 +128,8 @@ __global__ void zonal_bits_kernel(const float *__restrict__ bmask, uint8_t *__re
 // levels; every thread keeps the surface and the basin bits of its M cells (i = tid, tid+T, ...) in
 // registers and streams the field and its mask past them: 8 bytes per cell and level from HBM.
 template <int NB, int M, bool MEAN, bool MINMAX, int T>
-__global__ void __launch_bounds__(T) zonal_row_fast_kernel(ZonalArgs2 a, const uint8_t *__restrict__ bits) {
+__global__ void __launch_bounds__(T) zonal_row_fast_kernel(ZonalArgs2 a, const uint8_t *__restrict__ bits,
+                                                            int *__restrict__ rowflag) {
     extern __shared__ double lds[];                     // [nlev][nwaves][NB][4]
     const int jj = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = T / 64;
     const int64_t nij = (int64_t)a.npi * a.npj, r2 = (int64_t)jj * a.npi;
@@ -140,6 +143,7 @@ __global__ void __launch_bounds__(T) zonal_row_fast_kernel(ZonalArgs2 a, const u
         bb[m] = ok ? bits[r2 + i] : 0u;
     }
     float zc[M], mc[M], zn[M], mn_[M];
+    float nonfinite = 0.f;                              // sum of 0*z over every value this thread reads: 0 or NaN
     auto fetch = [&](float (&z)[M], float (&mk)[M], int k) {
         const float *zv = a.zv + (int64_t)k * nij + r2, *mv = a.mask3 + (int64_t)k * nij + r2;
 #pragma unroll
@@ -156,6 +160,7 @@ __global__ void __launch_bounds__(T) zonal_row_fast_kernel(ZonalArgs2 a, const u
         for (int b = 0; b < NB; ++b) { s[b] = 0.0; ar[b] = 0.0; mx[b] = -1.e20f; mi[b] = 1.e20f; }
 #pragma unroll
         for (int m = 0; m < M; ++m) {
+            nonfinite = __fmaf_rn(zc[m], 0.f, nonfinite);      // 0*NaN = 0*Inf = NaN sticks (see below)
             // zmask = 1: sum form (1.f*m)*z = m*z in r4; mean form ((1.d0*1)*m)*z = m*z in r8
             const double dt = MEAN ? __dmul_rn((double)mc[m], (double)zc[m]) : (double)__fmul_rn(mc[m], zc[m]);
             const double u = __dmul_rn(sf[m], dt);
@@ -191,7 +196,11 @@ __global__ void __launch_bounds__(T) zonal_row_fast_kernel(ZonalArgs2 a, const u
 #pragma unroll
         for (int m = 0; m < M; ++m) { zc[m] = zn[m]; mc[m] = mn_[m]; }
     }
-    __syncthreads();
+    // A NaN/Inf in the row (a fill value on land): where zmask = 0 the reference's term is 0*NaN = NaN, not the
+    // zero selected above.  The row is flagged and zonal_row_kernel, which multiplies as the reference does,
+    // recomputes it.
+    const int redo = __syncthreads_or(!__builtin_isfinite(nonfinite));
+    if (threadIdx.x == 0) rowflag[jj] = redo;
     for (int t = threadIdx.x; t < a.nlev * a.nb; t += T) {
         const int k = t / a.nb, b = t - k * a.nb;
         double ts = 0.0, ta = 0.0, tx = -1.e20f, tn = 1.e20f;
@@ -207,12 +216,12 @@ __global__ void __launch_bounds__(T) zonal_row_fast_kernel(ZonalArgs2 a, const u
 }
 
 template <int NB, int M, int T>
-int launch_fast(const ZonalArgs2 &a, const uint8_t *bits, bool mean, bool minmax, hipStream_t st) {
+int launch_fast(const ZonalArgs2 &a, const uint8_t *bits, int *rowflag, bool mean, bool minmax, hipStream_t st) {
     const size_t shmem = (size_t)a.nlev * (T / 64) * NB * 4 * sizeof(double);
     const dim3 grid(a.npj), block(T);
-    if (mean && minmax)  hipLaunchKernelGGL((zonal_row_fast_kernel<NB, M, true, true, T>), grid, block, shmem, st, a, bits);
-    else if (mean)       hipLaunchKernelGGL((zonal_row_fast_kernel<NB, M, true, false, T>), grid, block, shmem, st, a, bits);
-    else                 hipLaunchKernelGGL((zonal_row_fast_kernel<NB, M, false, false, T>), grid, block, shmem, st, a, bits);
+    if (mean && minmax)  hipLaunchKernelGGL((zonal_row_fast_kernel<NB, M, true, true, T>), grid, block, shmem, st, a, bits, rowflag);
+    else if (mean)       hipLaunchKernelGGL((zonal_row_fast_kernel<NB, M, true, false, T>), grid, block, shmem, st, a, bits, rowflag);
+    else                 hipLaunchKernelGGL((zonal_row_fast_kernel<NB, M, false, false, T>), grid, block, shmem, st, a, bits, rowflag);
     CDFT_LAUNCH_CHECK();
     return CDFT_OK;
 }
@@ -220,10 +229,10 @@ int launch_fast(const ZonalArgs2 &a, const uint8_t *bits, bool mean, bool minmax
 // rows up to 1536 / 4352 cells with 256 threads; longer rows would need more registers per thread than
 // pay off: they take the general kernel
 template <int NB>
-int launch_fast_nb(const ZonalArgs2 &a, const uint8_t *bits, bool mean, bool minmax, hipStream_t st, bool *done) {
+int launch_fast_nb(const ZonalArgs2 &a, const uint8_t *bits, int *rowflag, bool mean, bool minmax, hipStream_t st, bool *done) {
     *done = true;
-    if (a.npi <= 256 * 6)  return launch_fast<NB, 6, 256>(a, bits, mean, minmax, st);
-    if (a.npi <= 256 * 17) return launch_fast<NB, 17, 256>(a, bits, mean, minmax, st);
+    if (a.npi <= 256 * 6)  return launch_fast<NB, 6, 256>(a, bits, rowflag, mean, minmax, st);
+    if (a.npi <= 256 * 17) return launch_fast<NB, 17, 256>(a, bits, rowflag, mean, minmax, st);
     *done = false;
     return CDFT_OK;
 }
@@ -238,12 +247,12 @@ int keepz(void **dst, const void *src, size_t bytes, int space, hipStream_t st) 
 }
 
 template <int NB>
-int launch_rows(const ZonalArgs2 &a, bool mean, bool minmax, hipStream_t st) {
+int launch_rows(const ZonalArgs2 &a, const int *rowflag, bool mean, bool minmax, hipStream_t st) {
     const size_t shmem = (size_t)a.nlev * (kThreads / 64) * NB * 4 * sizeof(double);
     const dim3 grid(a.npj), block(kThreads);
-    if (mean && minmax)  hipLaunchKernelGGL((zonal_row_kernel<NB, true, true>), grid, block, shmem, st, a);
-    else if (mean)       hipLaunchKernelGGL((zonal_row_kernel<NB, true, false>), grid, block, shmem, st, a);
-    else                 hipLaunchKernelGGL((zonal_row_kernel<NB, false, false>), grid, block, shmem, st, a);
+    if (mean && minmax)  hipLaunchKernelGGL((zonal_row_kernel<NB, true, true>), grid, block, shmem, st, a, rowflag);
+    else if (mean)       hipLaunchKernelGGL((zonal_row_kernel<NB, true, false>), grid, block, shmem, st, a, rowflag);
+    else                 hipLaunchKernelGGL((zonal_row_kernel<NB, false, false>), grid, block, shmem, st, a, rowflag);
     CDFT_LAUNCH_CHECK();
     return CDFT_OK;
 }
@@ -286,7 +295,8 @@ int cdft_zonal_set_mesh(cdft_zonal_plan *p, const float *e1, const float *e2, co
     CDFT_LAUNCH_CHECK();
     CDFT_TRY(keepz((void **)&p->mask3, zmaskvar, nij * p->npk * 4, memspace, st));
     CDFT_TRY(keepz((void **)&p->bmask, zmask, nij * p->nb * 4, memspace, st));
-    if (!p->bits && (hipMalloc((void **)&p->bits, nij + 64) != hipSuccess || hipMalloc((void **)&p->flag, sizeof(int)) != hipSuccess)) {
+    if (!p->bits && (hipMalloc((void **)&p->bits, nij + 64) != hipSuccess || hipMalloc((void **)&p->flag, sizeof(int)) != hipSuccess ||
+                     hipMalloc((void **)&p->rowflag, (size_t)p->npj * sizeof(int)) != hipSuccess)) {
         (void)hipGetLastError();
         return fail(CDFT_ERR_ALLOC, "cdft_zonal_set_mesh: device allocation failed");
     }
@@ -330,17 +340,17 @@ int cdft_zonal_compute(cdft_zonal_plan *p, const float *zv, int nlev, int in_spa
         }
     }
     bool done = false;
-    static const bool force_general = getenv("CDFT_ZONAL_GENERAL") != nullptr;     // A/B and test hook
+    const bool force_general = getenv("CDFT_ZONAL_GENERAL") != nullptr;            // A/B and test hook
     if (p->binary && !force_general) {
-        if (p->nb == 1)      CDFT_TRY(launch_fast_nb<1>(a, p->bits, mean_form != 0, minmax, st, &done));
-        else if (p->nb <= 5) CDFT_TRY(launch_fast_nb<5>(a, p->bits, mean_form != 0, minmax, st, &done));
-        else                 CDFT_TRY(launch_fast_nb<8>(a, p->bits, mean_form != 0, minmax, st, &done));
+        if (p->nb == 1)      CDFT_TRY(launch_fast_nb<1>(a, p->bits, p->rowflag, mean_form != 0, minmax, st, &done));
+        else if (p->nb <= 5) CDFT_TRY(launch_fast_nb<5>(a, p->bits, p->rowflag, mean_form != 0, minmax, st, &done));
+        else                 CDFT_TRY(launch_fast_nb<8>(a, p->bits, p->rowflag, mean_form != 0, minmax, st, &done));
     }
-    if (!done) {
-        if (p->nb == 1)      CDFT_TRY(launch_rows<1>(a, mean_form != 0, minmax, st));
-        else if (p->nb <= 5) CDFT_TRY(launch_rows<5>(a, mean_form != 0, minmax, st));
-        else                 CDFT_TRY(launch_rows<8>(a, mean_form != 0, minmax, st));
-    }
+    // the general kernel: every row when the fast one did not run, else the rows it flagged (NaN/Inf met)
+    const int *only = done ? p->rowflag : nullptr;
+    if (p->nb == 1)      CDFT_TRY(launch_rows<1>(a, only, mean_form != 0, minmax, st));
+    else if (p->nb <= 5) CDFT_TRY(launch_rows<5>(a, only, mean_form != 0, minmax, st));
+    else                 CDFT_TRY(launch_rows<8>(a, only, mean_form != 0, minmax, st));
     if (out_space == CDFT_MEM_HOST) {
         CDFT_HIP(hipMemcpyAsync(dzo, a.dsum, n * 8, hipMemcpyDeviceToHost, st));
         if (mean_form) CDFT_HIP(hipMemcpyAsync(darea, a.darea, n * 8, hipMemcpyDeviceToHost, st));
@@ -355,7 +365,7 @@ int cdft_zonal_compute(cdft_zonal_plan *p, const float *zv, int nlev, int in_spa
 
 int cdft_zonal_destroy(cdft_zonal_plan *p) {
     if (!p) return CDFT_OK;
-    void *ptrs[] = {p->surf, p->mask3, p->bmask, p->bits, p->flag};
+    void *ptrs[] = {p->surf, p->mask3, p->bmask, p->bits, p->flag, p->rowflag};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     p->st_a.release(); p->st_b.release(); p->st_zv.release();
     for (DevBuf &b : p->st_o) b.release();

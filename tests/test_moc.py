@@ -120,9 +120,10 @@ def test_hip_kernel_variants_agree_with_oracle(gpu, waves, nv, mode):
 @pytest.mark.gpu
 @pytest.mark.parametrize("nb,overlap", [(5, False), (3, False), (8, False), (8, True), (1, False)])
 def test_hip_class_mode_is_chosen_when_the_masks_have_few_bit_patterns(gpu, nb, overlap):
-    """Automatic mode: basin masks with at most 8 distinct non-empty bit patterns take the kernel
-    with one LDS accumulator per pattern; anything else (one basin, many overlapping masks) the
-    select kernel.  Both must match the oracle, 17 records span two LDS chunks."""
+    """Automatic mode: basin masks with at most 8 distinct bit patterns (the empty one, a cell in no
+    basin, included) take the kernel with one LDS accumulator per pattern; anything else (one basin,
+    many overlapping masks) the select kernel.  Both must match the oracle, 17 records span two LDS
+    chunks."""
     npi, npj, npk, npt = 517, 9, 5, 17
     g = synth.make_grid(npi, npj, npk, seed=31, nbasins=nb)
     e1v, e3v, ib = synth.moc_inputs(g)
@@ -132,7 +133,7 @@ def test_hip_class_mode_is_chosen_when_the_masks_have_few_bit_patterns(gpu, nb, 
         ib[:, :, 1:] = rng.integers(0, 2, size=ib[:, :, 1:].shape, dtype=np.int16)
     zv = synth.velocity(g, npt, seed=6)
     packed = (ib.astype(np.int64) << np.arange(nb)).sum(axis=2)
-    npat = len(set(np.unique(packed)) - {0})
+    npat = len(np.unique(packed))
     kernel = "class" if nb > 1 and 1 <= npat <= 8 else "select"
     assert (nb, overlap, kernel) in ((5, False, "class"), (3, False, "class"), (8, False, "select"), (8, True, "select"),
                                      (1, False, "select"))
@@ -185,12 +186,14 @@ def test_hip_rejects_bad_masks_and_call_order(gpu):
 
 
 @pytest.mark.gpu
-def test_hip_properties_at_eorca025_size(gpu):
-    """BASELINE config 2 size (1442x1207x75, 12 records, 5 basins): size-independent properties
-    plus a sampled-row comparison with the oracle (rows are independent in cdfmoc)."""
+@pytest.mark.parametrize("npi,npj,npk,nb,npt", [(1442, 1207, 75, 5, 12), (4322, 3606, 75, 5, 4)],
+                         ids=["eorca025", "eorca12"])
+def test_hip_properties_at_full_size(gpu, npi, npj, npk, nb, npt):
+    """BASELINE config sizes (eORCA025 1442x1207x75 with 12 records; eORCA12 4322x3606x75, the grid
+    the metric is quoted on, with 4 records to bound the test's memory): size-independent
+    properties plus a sampled-row comparison with the oracle (rows are independent in cdfmoc)."""
     import torch
 
-    npi, npj, npk, nb, npt = 1442, 1207, 75, 5, 12
     gen = torch.Generator(device="cuda").manual_seed(1234)
     dev = "cuda"
     e1v = 2000.0 + 26000.0 * torch.rand((npj, npi), device=dev, generator=gen)
@@ -225,7 +228,7 @@ def test_hip_properties_at_eorca025_size(gpu):
     d4 = plan.compute(zv * 4.0)
     assert torch.equal(d4, d1 * 4.0)
     # records are independent: permuting them permutes the output bit for bit
-    perm = torch.tensor([5, 0, 11, 3, 7, 1, 9, 2, 10, 4, 8, 6], device=dev)
+    perm = torch.from_numpy(np.random.default_rng(5).permutation(npt)).to(dev)
     dp = plan.compute(zv[perm].contiguous())
     assert torch.equal(dp, d1[perm])
     # sampled rows against the oracle

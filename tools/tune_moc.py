@@ -21,10 +21,13 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--variants", default="")
     ap.add_argument("--npt", type=int, default=0)
+    ap.add_argument("--nb", type=int, default=0, help="number of basins (default: the workload's)")
     args = ap.parse_args()
     npi, npj, npk, npt, nb = bench.WORKLOADS[args.workload]
     if args.npt:
         npt = args.npt
+    if args.nb:
+        nb = args.nb
     dev = torch.device("cuda", 0)
     e1v, e3v, ib, zv = bench.build_inputs(npi, npj, npk, npt, nb, 0, npj, dev)
     plan = hip.MocPlan(npi, npj, npk, nb)
