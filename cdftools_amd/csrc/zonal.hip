@@ -9,7 +9,8 @@
 // Per-term values are formed exactly as written; the r8 additions along i are regrouped in a fixed order
 // (|d| <= 1e-13 * sum|terms|).  One workgroup owns a row jj for ALL levels of the variable: the 2-D
 // operands of the row (surface, basin masks) are re-read per level from L2 / Infinity Cache, the field
-// and its 3-D mask stream from HBM once (8 bytes per cell and level).
+// and its 3-D mask stream from HBM once (8 bytes per cell and level).  darea does not depend on the field: it is
+// summed once per mesh (cdft_zonal_set_mesh) and copied out by every mean-form call.
 #include <cstdlib>
 #include "common.hpp"
 #include "reduce.hpp"
@@ -24,6 +25,11 @@ struct cdft_zonal_plan {
     uint8_t *bits = nullptr;      // (npi,npj) basin bits when every basin mask is 0/1 (fast kernel)
     int *flag = nullptr;          // device: 1 when a basin-mask value is neither 0 nor 1
     int *rowflag = nullptr;       // device (npj): rows of the last fast-kernel launch that met a NaN/Inf
+    double *area = nullptr;       // device (nb,npk,npj): masked area of every row, level and basin
+    uint8_t *cls = nullptr;       // device (npi,npj) + 256: class of the cell's bit pattern, then the lookup table
+    int *seen = nullptr;          // device (256): bit patterns present
+    uint8_t pat[8] = {0};
+    int nclass = 0;               // distinct bit patterns, 0 when the class kernel cannot be used
     bool binary = false;
     bool mesh_set = false;
     DevBuf st_a, st_b, st_zv, st_o[4];
@@ -47,7 +53,7 @@ struct ZonalArgs2 {
     float *rmax, *rmin;        // (npj,nlev,nb) or null
 };
 
-template <int NB, bool MEAN, bool MINMAX>
+template <int NB, bool MEAN, bool MINMAX, bool AREA>
 __global__ void __launch_bounds__(kThreads) zonal_row_kernel(ZonalArgs2 a, const int *__restrict__ rowflag) {
     extern __shared__ double lds[];                     // [nlev][nwaves][NB][4]: sum, area, max, min
     const int jj = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = kThreads / 64;
@@ -69,7 +75,7 @@ __global__ void __launch_bounds__(kThreads) zonal_row_kernel(ZonalArgs2 a, const
                     if (MEAN) dtmp = __dmul_rn(__dmul_rn(__dmul_rn(1.0, (double)zb), (double)m), (double)z);
                     else      dtmp = (double)__fmul_rn(__fmul_rn(zb, m), z);
                     s[b] += __dmul_rn(sf, dtmp);
-                    if (MEAN) ar[b] += __dmul_rn(__dmul_rn(sf, (double)zb), (double)m);
+                    if (AREA) ar[b] += __dmul_rn(__dmul_rn(sf, (double)zb), (double)m);
                     if (MINMAX) {
                         mx[b] = fmax(mx[b], dtmp);
                         if (dtmp != 0.0) mn[b] = fmin(mn[b], dtmp);
@@ -81,7 +87,7 @@ __global__ void __launch_bounds__(kThreads) zonal_row_kernel(ZonalArgs2 a, const
         for (int b = 0; b < NB; ++b) {
             const double ts = wave_sum(s[b]);
             double ta = 0.0, tx = 0.0, tn = 0.0;
-            if (MEAN) ta = wave_sum(ar[b]);
+            if (AREA) ta = wave_sum(ar[b]);
             if (MINMAX) {
                 tx = mx[b]; tn = mn[b];
                 for (int o = 32; o > 0; o >>= 1) { tx = fmax(tx, __shfl_xor(tx, o, 64)); tn = fmin(tn, __shfl_xor(tn, o, 64)); }
@@ -101,8 +107,8 @@ __global__ void __launch_bounds__(kThreads) zonal_row_kernel(ZonalArgs2 a, const
             ts += q[0]; ta += q[1]; tx = fmax(tx, q[2]); tn = fmin(tn, q[3]);
         }
         const int64_t o = ((int64_t)b * a.nlev + k) * a.npj + jj;
-        a.dsum[o] = ts;
-        if (MEAN) a.darea[o] = ta;
+        if (AREA) a.darea[o] = ta;
+        else      a.dsum[o] = ts;
         if (MINMAX) { a.rmax[o] = (float)tx; a.rmin[o] = (float)tn; }
     }
 }
@@ -155,23 +161,21 @@ __global__ void __launch_bounds__(T) zonal_row_fast_kernel(ZonalArgs2 a, const u
     fetch(zc, mc, 0);
     for (int k = 0; k < a.nlev; ++k) {
         if (k + 1 < a.nlev) fetch(zn, mn_, k + 1);      // next level in flight
-        double s[NB], ar[NB], mx[NB], mi[NB];
+        double s[NB], mx[NB], mi[NB];
 #pragma unroll
-        for (int b = 0; b < NB; ++b) { s[b] = 0.0; ar[b] = 0.0; mx[b] = -1.e20f; mi[b] = 1.e20f; }
+        for (int b = 0; b < NB; ++b) { s[b] = 0.0; mx[b] = -1.e20f; mi[b] = 1.e20f; }
 #pragma unroll
         for (int m = 0; m < M; ++m) {
             nonfinite = __fmaf_rn(zc[m], 0.f, nonfinite);      // 0*NaN = 0*Inf = NaN sticks (see below)
             // zmask = 1: sum form (1.f*m)*z = m*z in r4; mean form ((1.d0*1)*m)*z = m*z in r8
             const double dt = MEAN ? __dmul_rn((double)mc[m], (double)zc[m]) : (double)__fmul_rn(mc[m], zc[m]);
             const double u = __dmul_rn(sf[m], dt);
-            const double w = MEAN ? __dmul_rn(sf[m], (double)mc[m]) : 0.0;     // (dl_surf*1)*zmaskvar
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
                 const bool in = (bb[m] >> b) & 1u;
                 // zmask = 0: the reference's term is an exact (signed) zero, which never changes an r8 sum
                 // that already holds a value; and its dtmp = 0 never enters the minimum
                 s[b] += in ? u : 0.0;
-                if (MEAN) ar[b] += in ? w : 0.0;
                 if (MINMAX) {
                     const double d = in ? dt : 0.0;
                     mx[b] = fmax(mx[b], ((int)threadIdx.x + m * T < a.npi) ? d : mx[b]);
@@ -182,15 +186,14 @@ __global__ void __launch_bounds__(T) zonal_row_fast_kernel(ZonalArgs2 a, const u
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             const double ts = wave_sum(s[b]);
-            double ta = 0.0, tx = 0.0, tn = 0.0;
-            if (MEAN) ta = wave_sum(ar[b]);
+            double tx = 0.0, tn = 0.0;
             if (MINMAX) {
                 tx = mx[b]; tn = mi[b];
                 for (int o = 32; o > 0; o >>= 1) { tx = fmax(tx, __shfl_xor(tx, o, 64)); tn = fmin(tn, __shfl_xor(tn, o, 64)); }
             }
             if (lane == 0) {
                 double *q = lds + (((int64_t)k * nwaves + wave) * NB + b) * 4;
-                q[0] = ts; q[1] = ta; q[2] = tx; q[3] = tn;
+                q[0] = ts; q[1] = 0.0; q[2] = tx; q[3] = tn;
             }
         }
 #pragma unroll
@@ -203,14 +206,13 @@ __global__ void __launch_bounds__(T) zonal_row_fast_kernel(ZonalArgs2 a, const u
     if (threadIdx.x == 0) rowflag[jj] = redo;
     for (int t = threadIdx.x; t < a.nlev * a.nb; t += T) {
         const int k = t / a.nb, b = t - k * a.nb;
-        double ts = 0.0, ta = 0.0, tx = -1.e20f, tn = 1.e20f;
+        double ts = 0.0, tx = -1.e20f, tn = 1.e20f;
         for (int w = 0; w < nwaves; ++w) {
             const double *q = lds + (((int64_t)k * nwaves + w) * NB + b) * 4;
-            ts += q[0]; ta += q[1]; tx = fmax(tx, q[2]); tn = fmin(tn, q[3]);
+            ts += q[0]; tx = fmax(tx, q[2]); tn = fmin(tn, q[3]);
         }
         const int64_t o = ((int64_t)b * a.nlev + k) * a.npj + jj;
         a.dsum[o] = ts;
-        if (MEAN) a.darea[o] = ta;
         if (MINMAX) { a.rmax[o] = (float)tx; a.rmin[o] = (float)tn; }
     }
 }
@@ -237,6 +239,142 @@ int launch_fast_nb(const ZonalArgs2 &a, const uint8_t *bits, int *rowflag, bool 
     return CDFT_OK;
 }
 
+// Class kernel for 0/1 basin masks without -max.  The fast kernel above spends NB r8 select-adds per cell, as much as
+// the memory stream costs at 5 basins.  A cell's basin membership is one of a few bit patterns, so each cell is given
+// the class of its pattern once (cdft_zonal_set_mesh) and its term goes to ONE accumulator: a per-lane, per-class slot
+// in LDS, updated by ds_add_f64 (same scheme as cdfmoc's class kernel, moc_zonal.hpp).  A slot only receives its own
+// lane's terms in program order => run-to-run identical results.  Basin sums are formed from the class sums at the
+// end: basin b = the classes whose pattern has bit b, plus 0 * (the sums of the other classes), which is the NaN the
+// reference's 0*zv gives when a NaN/Inf sits on a point outside b, and a zero otherwise.
+constexpr int kZC = 8;            // bit patterns the class kernel holds (the empty pattern included)
+constexpr int kZStride = 72;      // doubles between the slot rows of two classes (64 lanes + 8: different banks)
+
+struct ZonalClassArgs {
+    const uint8_t *cls;           // (npi,npj) class of the cell's basin bit pattern
+    uint8_t pat[kZC];
+    int nclass;
+};
+
+// Loads: the row is covered by 16-byte vectors starting at cells 0, 4, 8, ... (r4-aligned only: rows start anywhere),
+// and, when npiglo is not a multiple of 4, one more vector anchored at npiglo-4 whose leading cells repeat the previous
+// vector's and are sent to an unread slot -- so every load is a full vector inside the row, without a branch.
+template <int NV, bool MEAN, int T>
+__global__ void __launch_bounds__(T) zonal_row_class_kernel(ZonalArgs2 a, ZonalClassArgs ca) {
+    extern __shared__ double lds[];
+    constexpr int nwaves = T / 64;
+    const int jj = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double *scr  = lds + wave * ((kZC + 1) * kZStride);              // slot [class][lane]; class kZC = cells not owned
+    double *part = lds + nwaves * ((kZC + 1) * kZStride);            // [nlev][kZC][nwaves]
+    const int64_t nij = (int64_t)a.npi * a.npj, r2 = (int64_t)jj * a.npi;
+    const int nfull = a.npi >> 2;                                    // vectors 0..nfull-1 start at 4v
+    double sf[NV][4];
+    int slot[NV][4], i0[NV];
+#pragma unroll
+    for (int r = 0; r < NV; ++r) {
+        const int v = threadIdx.x + r * T;
+        i0[r] = min(4 * v, a.npi - 4);                                // anchored vector for v >= nfull
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int i = i0[r] + c;
+            const bool own = v < nfull || (v == nfull && i >= 4 * nfull);
+            sf[r][c]   = a.surf[r2 + i];
+            slot[r][c] = (own ? min((int)ca.cls[r2 + i], kZC) : kZC) * kZStride + lane;      // slot kZC is never read
+        }
+    }
+#pragma unroll
+    for (int c = 0; c <= kZC; ++c) scr[c * kZStride + lane] = 0.0;
+    f4u zc[NV], mc[NV], zn[NV], mn_[NV];
+    auto fetch = [&](f4u (&z)[NV], f4u (&mk)[NV], int k) {
+        const float *zv = a.zv + (int64_t)k * nij + r2, *mv = a.mask3 + (int64_t)k * nij + r2;
+#pragma unroll
+        for (int r = 0; r < NV; ++r) { z[r] = ld_stream4u(zv + i0[r]); mk[r] = ld_stream4u(mv + i0[r]); }
+    };
+    fetch(zc, mc, 0);
+    for (int k = 0; k < a.nlev; ++k) {
+        if (k + 1 < a.nlev) fetch(zn, mn_, k + 1);      // next level in flight
+#pragma unroll
+        for (int r = 0; r < NV; ++r) {
+            const float z4[4] = {zc[r].x, zc[r].y, zc[r].z, zc[r].w}, m4[4] = {mc[r].x, mc[r].y, mc[r].z, mc[r].w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                // zmask = 1: sum form (1.f*m)*z = m*z in r4; mean form ((1.d0*1)*m)*z = m*z in r8
+                const double dt = MEAN ? __dmul_rn((double)m4[c], (double)z4[c]) : (double)__fmul_rn(m4[c], z4[c]);
+                (void)__hip_atomic_fetch_add(&scr[slot[r][c]], __dmul_rn(sf[r][c], dt), __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        double s = 0.0;
+        {                                               // lane c*8+q sums 8 lanes of class c, then 3 cross-lane steps
+            const double *q = scr + (lane >> 3) * kZStride + (lane & 7);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += q[8 * j];
+        }
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 4, 64);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                // every lane has read before the slots are cleared
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int c = 0; c < kZC; ++c) scr[c * kZStride + lane] = 0.0;
+        if ((lane & 7) == 0) part[((int64_t)k * kZC + (lane >> 3)) * nwaves + wave] = s;
+#pragma unroll
+        for (int r = 0; r < NV; ++r) { zc[r] = zn[r]; mc[r] = mn_[r]; }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < a.nlev * a.nb; t += T) {
+        const int k = t / a.nb, b = t - k * a.nb;
+        double s = 0.0, z = 0.0;
+        for (int c = 0; c < ca.nclass; ++c) {
+            const bool in = (ca.pat[c] >> b) & 1;
+            for (int w = 0; w < nwaves; ++w) {
+                const double v = part[((int64_t)k * kZC + c) * nwaves + w];
+                if (in) s += v;
+                else    z += v;
+            }
+        }
+        a.dsum[((int64_t)b * a.nlev + k) * a.npj + jj] = s + __dmul_rn(z, 0.0);
+    }
+}
+
+constexpr int kClassT = 256, kClassMaxNV = 5;
+
+template <int NV>
+int launch_class_nv(const ZonalArgs2 &a, const ZonalClassArgs &ca, bool mean, hipStream_t st) {
+    constexpr int T = kClassT;
+    const size_t shmem = ((size_t)(T / 64) * (kZC + 1) * kZStride + (size_t)a.nlev * kZC * (T / 64)) * sizeof(double);
+    if (mean) hipLaunchKernelGGL((zonal_row_class_kernel<NV, true, T>), dim3(a.npj), dim3(T), shmem, st, a, ca);
+    else      hipLaunchKernelGGL((zonal_row_class_kernel<NV, false, T>), dim3(a.npj), dim3(T), shmem, st, a, ca);
+    CDFT_LAUNCH_CHECK();
+    return CDFT_OK;
+}
+
+// rows of 4 .. 5116 cells
+inline bool class_fits(int npi) { return npi >= 4 && (npi / 4 + 1 + kClassT - 1) / kClassT <= kClassMaxNV; }
+
+int launch_class(const ZonalArgs2 &a, const ZonalClassArgs &ca, bool mean, hipStream_t st) {
+    switch ((a.npi / 4 + 1 + kClassT - 1) / kClassT) {
+        case 1: return launch_class_nv<1>(a, ca, mean, st);
+        case 2: return launch_class_nv<2>(a, ca, mean, st);
+        case 3: return launch_class_nv<3>(a, ca, mean, st);
+        case 4: return launch_class_nv<4>(a, ca, mean, st);
+        default: return launch_class_nv<5>(a, ca, mean, st);
+    }
+}
+
+// cls(i,j) = lut[bits(i,j)]; seen[v] = 1 for every bit pattern v present
+__global__ void zonal_seen_kernel(const uint8_t *__restrict__ bits, int64_t nij, int *__restrict__ seen) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < nij && !seen[bits[p]]) seen[bits[p]] = 1;              // benign race: every writer stores 1
+}
+__global__ void zonal_cls_kernel(const uint8_t *__restrict__ bits, int64_t nij, const uint8_t *__restrict__ lut, uint8_t *__restrict__ cls) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < nij) cls[p] = lut[bits[p]];
+}
+
 int keepz(void **dst, const void *src, size_t bytes, int space, hipStream_t st) {
     if (!*dst && hipMalloc(dst, bytes + 64) != hipSuccess) {
         (void)hipGetLastError();
@@ -250,9 +388,19 @@ template <int NB>
 int launch_rows(const ZonalArgs2 &a, const int *rowflag, bool mean, bool minmax, hipStream_t st) {
     const size_t shmem = (size_t)a.nlev * (kThreads / 64) * NB * 4 * sizeof(double);
     const dim3 grid(a.npj), block(kThreads);
-    if (mean && minmax)  hipLaunchKernelGGL((zonal_row_kernel<NB, true, true>), grid, block, shmem, st, a, rowflag);
-    else if (mean)       hipLaunchKernelGGL((zonal_row_kernel<NB, true, false>), grid, block, shmem, st, a, rowflag);
-    else                 hipLaunchKernelGGL((zonal_row_kernel<NB, false, false>), grid, block, shmem, st, a, rowflag);
+    if (mean && minmax)  hipLaunchKernelGGL((zonal_row_kernel<NB, true, true, false>), grid, block, shmem, st, a, rowflag);
+    else if (mean)       hipLaunchKernelGGL((zonal_row_kernel<NB, true, false, false>), grid, block, shmem, st, a, rowflag);
+    else                 hipLaunchKernelGGL((zonal_row_kernel<NB, false, false, false>), grid, block, shmem, st, a, rowflag);
+    CDFT_LAUNCH_CHECK();
+    return CDFT_OK;
+}
+
+// darea(b,jj,jk) = sum_i dl_surf*zmask(b)*zmaskvar(jk) (src/cdfzonalmean.f90:326): it does not depend on the field, so it
+// is summed once per mesh, for every level, in the order the field sums use
+template <int NB>
+int launch_area(const ZonalArgs2 &a, hipStream_t st) {
+    const size_t shmem = (size_t)a.nlev * (kThreads / 64) * NB * 4 * sizeof(double);
+    hipLaunchKernelGGL((zonal_row_kernel<NB, true, false, true>), dim3(a.npj), dim3(kThreads), shmem, st, a, nullptr);
     CDFT_LAUNCH_CHECK();
     return CDFT_OK;
 }
@@ -308,6 +456,47 @@ int cdft_zonal_set_mesh(cdft_zonal_plan *p, const float *e1, const float *e2, co
     CDFT_HIP(hipMemcpyAsync(&flag, p->flag, sizeof(int), hipMemcpyDeviceToHost, st));
     CDFT_HIP(hipStreamSynchronize(st));
     p->binary = (flag == 0);
+    // class kernel: number the bit patterns present (the empty one included), at most kZC of them
+    p->nclass = 0;
+    if (p->binary && p->nb > 1) {
+        if (!p->cls && (hipMalloc((void **)&p->cls, nij + 64 + 256) != hipSuccess || hipMalloc((void **)&p->seen, 256 * sizeof(int)) != hipSuccess)) {
+            (void)hipGetLastError();
+            return fail(CDFT_ERR_ALLOC, "cdft_zonal_set_mesh: device allocation failed");
+        }
+        CDFT_HIP(hipMemsetAsync(p->seen, 0, 256 * sizeof(int), st));
+        hipLaunchKernelGGL(zonal_seen_kernel, dim3((unsigned)((nij + 255) / 256)), dim3(256), 0, st, p->bits, (int64_t)nij, p->seen);
+        CDFT_LAUNCH_CHECK();
+        int seen[256];
+        CDFT_HIP(hipMemcpyAsync(seen, p->seen, sizeof(seen), hipMemcpyDeviceToHost, st));
+        CDFT_HIP(hipStreamSynchronize(st));
+        uint8_t lut[256];
+        for (int v = 0; v < 256; ++v) {
+            lut[v] = 0xFF;
+            if (seen[v]) {
+                if (p->nclass < kZC) { p->pat[p->nclass] = (uint8_t)v; lut[v] = (uint8_t)p->nclass; }
+                ++p->nclass;
+            }
+        }
+        if (p->nclass > kZC) p->nclass = 0;
+        if (p->nclass > 0) {
+            uint8_t *dlut = p->cls + nij + 64;
+            CDFT_HIP(hipMemcpyAsync(dlut, lut, 256, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(zonal_cls_kernel, dim3((unsigned)((nij + 255) / 256)), dim3(256), 0, st, p->bits, (int64_t)nij, dlut, p->cls);
+            CDFT_LAUNCH_CHECK();
+            CDFT_HIP(hipStreamSynchronize(st));                  // lut[] is a stack array
+        }
+    }
+    if (!p->area && hipMalloc((void **)&p->area, nij / p->npi * p->npk * p->nb * sizeof(double) + 64) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(CDFT_ERR_ALLOC, "cdft_zonal_set_mesh: device allocation failed");
+    }
+    ZonalArgs2 a;
+    a.surf = p->surf; a.mask3 = p->mask3; a.bmask = p->bmask; a.zv = p->mask3;      // any finite field: only darea is kept
+    a.npi = p->npi; a.npj = p->npj; a.nlev = p->npk; a.nb = p->nb;
+    a.dsum = nullptr; a.darea = p->area; a.rmax = nullptr; a.rmin = nullptr;
+    if (p->nb == 1)      CDFT_TRY(launch_area<1>(a, st));
+    else if (p->nb <= 5) CDFT_TRY(launch_area<5>(a, st));
+    else                 CDFT_TRY(launch_area<8>(a, st));
     p->st_a.release(); p->st_b.release();
     p->mesh_set = true;
     return CDFT_OK;
@@ -333,14 +522,20 @@ int cdft_zonal_compute(cdft_zonal_plan *p, const float *zv, int nlev, int in_spa
     a.dsum = dzo; a.darea = darea; a.rmax = rzomax; a.rmin = rzomin;
     if (out_space == CDFT_MEM_HOST) {
         CDFT_TRY(p->st_o[0].reserve(n * 8)); a.dsum = (double *)p->st_o[0].ptr;
-        if (mean_form) { CDFT_TRY(p->st_o[1].reserve(n * 8)); a.darea = (double *)p->st_o[1].ptr; }
         if (minmax) {
             CDFT_TRY(p->st_o[2].reserve(n * 4)); CDFT_TRY(p->st_o[3].reserve(n * 4));
             a.rmax = (float *)p->st_o[2].ptr; a.rmin = (float *)p->st_o[3].ptr;
         }
     }
     bool done = false;
-    const bool force_general = getenv("CDFT_ZONAL_GENERAL") != nullptr;            // A/B and test hook
+    const bool force_general = getenv("CDFT_ZONAL_GENERAL") != nullptr;            // A/B and test hooks
+    const bool no_class = getenv("CDFT_ZONAL_NOCLASS") != nullptr;
+    if (p->binary && !force_general && !no_class && !minmax && p->nclass > 0 && class_fits(p->npi)) {
+        ZonalClassArgs ca;
+        ca.cls = p->cls; ca.nclass = p->nclass;
+        for (int c = 0; c < kZC; ++c) ca.pat[c] = p->pat[c];
+        CDFT_TRY(launch_class(a, ca, mean_form != 0, st));
+    } else {
     if (p->binary && !force_general) {
         if (p->nb == 1)      CDFT_TRY(launch_fast_nb<1>(a, p->bits, p->rowflag, mean_form != 0, minmax, st, &done));
         else if (p->nb <= 5) CDFT_TRY(launch_fast_nb<5>(a, p->bits, p->rowflag, mean_form != 0, minmax, st, &done));
@@ -351,9 +546,12 @@ int cdft_zonal_compute(cdft_zonal_plan *p, const float *zv, int nlev, int in_spa
     if (p->nb == 1)      CDFT_TRY(launch_rows<1>(a, only, mean_form != 0, minmax, st));
     else if (p->nb <= 5) CDFT_TRY(launch_rows<5>(a, only, mean_form != 0, minmax, st));
     else                 CDFT_TRY(launch_rows<8>(a, only, mean_form != 0, minmax, st));
+    }
+    if (mean_form)      // the first nlev levels of every basin's precomputed area
+        CDFT_HIP(hipMemcpy2DAsync(darea, (size_t)nlev * p->npj * 8, p->area, (size_t)p->npk * p->npj * 8, (size_t)nlev * p->npj * 8,
+                                  p->nb, out_space == CDFT_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, st));
     if (out_space == CDFT_MEM_HOST) {
         CDFT_HIP(hipMemcpyAsync(dzo, a.dsum, n * 8, hipMemcpyDeviceToHost, st));
-        if (mean_form) CDFT_HIP(hipMemcpyAsync(darea, a.darea, n * 8, hipMemcpyDeviceToHost, st));
         if (minmax) {
             CDFT_HIP(hipMemcpyAsync(rzomax, a.rmax, n * 4, hipMemcpyDeviceToHost, st));
             CDFT_HIP(hipMemcpyAsync(rzomin, a.rmin, n * 4, hipMemcpyDeviceToHost, st));
@@ -365,7 +563,7 @@ int cdft_zonal_compute(cdft_zonal_plan *p, const float *zv, int nlev, int in_spa
 
 int cdft_zonal_destroy(cdft_zonal_plan *p) {
     if (!p) return CDFT_OK;
-    void *ptrs[] = {p->surf, p->mask3, p->bmask, p->bits, p->flag, p->rowflag};
+    void *ptrs[] = {p->surf, p->mask3, p->bmask, p->bits, p->flag, p->rowflag, p->area, p->cls, p->seen};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     p->st_a.release(); p->st_b.release(); p->st_zv.release();
     for (DevBuf &b : p->st_o) b.release();

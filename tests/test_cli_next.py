@@ -238,19 +238,27 @@ def test_oracle_zonal_matches_numpy_restatement():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("npi,npj,npk,nb", [(24, 18, 7, 5), (182, 149, 31, 5), (1, 1, 1, 1), (300, 5, 2, 1), (1031, 4, 3, 5)])
-def test_hip_zonal_matches_oracle(gpu, npi, npj, npk, nb):
+@pytest.mark.parametrize("kernel", ["class", "fast", "general"])
+@pytest.mark.parametrize("npi,npj,npk,nb", [(24, 18, 7, 5), (182, 149, 31, 5), (1, 1, 1, 1), (300, 5, 2, 1), (1031, 4, 3, 5),
+                                            (1537, 3, 2, 5), (4322, 2, 3, 5)])
+def test_hip_zonal_matches_oracle(gpu, monkeypatch, npi, npj, npk, nb, kernel):
+    """The three kernels behind cdft_zonal_compute: LDS class accumulators (0/1 masks, several basins, no -max), the
+    select kernel (0/1 masks) and the general one (any mask values); the environment hooks force the latter two."""
+    if kernel != "class":
+        monkeypatch.setenv("CDFT_ZONAL_GENERAL" if kernel == "general" else "CDFT_ZONAL_NOCLASS", "1")
     g, zv, zm = zonal_inputs(npi, npj, npk, nb, seed=npi + 9)
     tm = g["tmask"].astype(np.float32)
     plan = gpu.ZonalPlan(npi, npj, npk, nb)
     plan.set_mesh(g["e1t"], g["e2t"], tm, zm)
-    for mean_form in (False, True):
-        got = plan.compute(zv, mean_form=mean_form, minmax=mean_form)
+    for mean_form, minmax in ((False, False), (True, True), (True, False)):      # -max keeps the select kernel
+        got = plan.compute(zv, mean_form=mean_form, minmax=minmax)
         ref = oracle_tools.zonal(g["e1t"], g["e2t"], tm, zm, zv, mean_form=mean_form)
         bound = oracle_tools.zonal(g["e1t"], g["e2t"], tm, zm, np.abs(zv), mean_form=mean_form)["sum"]
         assert np.all(np.abs(got["sum"] - ref["sum"]) <= 1e-13 * bound + 1e-300)
+        assert np.array_equal(plan.compute(zv, mean_form=mean_form, minmax=minmax)["sum"], got["sum"])   # run-to-run identical
         if mean_form:
             assert np.all(np.abs(got["area"] - ref["area"]) <= 1e-13 * ref["area"] + 1e-300)
+        if minmax:
             assert np.array_equal(got["max"], ref["max"]) and np.array_equal(got["min"], ref["min"])
     two = plan.compute(zv[:2] if npk > 1 else zv)                          # a variable with fewer levels
     ref = oracle_tools.zonal(g["e1t"], g["e2t"], tm[:2], zm, zv[:2] if npk > 1 else zv)

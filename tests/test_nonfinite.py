@@ -112,13 +112,13 @@ def test_mean(gpu, npi, npj, npk, nb):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("general", [False, True])
-@pytest.mark.parametrize("npi,npj,npk,nb", [(24, 18, 7, 5), (182, 149, 5, 5), (1031, 4, 3, 1)])
-def test_zonal(gpu, monkeypatch, npi, npj, npk, nb, general):
+@pytest.mark.parametrize("kernel", ["class", "fast", "general"])
+@pytest.mark.parametrize("npi,npj,npk,nb", [(24, 18, 7, 5), (182, 149, 5, 5), (1031, 4, 3, 1), (1600, 3, 2, 5)])
+def test_zonal(gpu, monkeypatch, npi, npj, npk, nb, kernel):
     from test_cli_next import zonal_inputs
 
-    if general:
-        monkeypatch.setenv("CDFT_ZONAL_GENERAL", "1")
+    if kernel != "class":
+        monkeypatch.setenv("CDFT_ZONAL_GENERAL" if kernel == "general" else "CDFT_ZONAL_NOCLASS", "1")
     g, zv, zm = zonal_inputs(npi, npj, npk, nb, seed=npi + 9)
     tm = g["tmask"].astype(np.float32)
     plan = gpu.ZonalPlan(npi, npj, npk, nb)

@@ -75,7 +75,10 @@ def main():
 
     if "zonal" in tools:
         tm = (rnd(npk, npj, npi) > 0.35).float().cpu().numpy()
-        zm = (rnd(npj, npi, 5) > 0.4).float().cpu().numpy()
+        # NEMO-style sub-basins: global, Atlantic, Indo-Pacific = Indian + Pacific (three bands of i over the ocean)
+        band = ((torch.arange(npi, device=dev) * 3) // npi)[None, :]
+        sea = torch.from_numpy(tm[0]).to(dev) > 0
+        zm = torch.stack([sea, sea & (band == 0), sea & (band > 0), sea & (band == 2), sea & (band == 1)], dim=2).float().cpu().numpy()
         zv = (-2 + 32 * rnd(npk, npj, npi))
         p = hip.ZonalPlan(npi, npj, npk, 5)
         p.set_mesh(e1.cpu().numpy(), e2.cpu().numpy(), tm, zm)
