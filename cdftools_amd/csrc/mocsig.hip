@@ -9,6 +9,7 @@
 // its own (basin, bin) accumulators in LDS and adds with ds_add_f64 (an LDS atomic: one instruction per
 // cell and basin).  The waves' histograms are added in wave order at the end.  Terms are formed exactly
 // as the reference writes them; the r8 additions along i are regrouped (|d| <= 1e-13 * sum|terms|).
+#include <cstdlib>
 #include "eos_dev.hpp"
 
 using namespace cdft;
@@ -57,9 +58,9 @@ __global__ void mocsig_row_kernel(SigArgs a) {
                 const double dw = ISODEP ? (double)__fmul_rn((float)itm, zarea) : 0.0;                   // :425
                 for (int b = 0; b < a.nb; ++b) {
                     const int16_t m = a.ib[p * a.nb + b];
-                    if (m == 0) continue;                                                  // adds an exact zero
-                    const double fm = (double)m;
-                    (void)__hip_atomic_fetch_add(&h[b * a.nbins + ibin], __dmul_rn(term, fm), __ATOMIC_RELAXED,
+                    const double fm = (double)m, add = __dmul_rn(term, fm);
+                    if (m == 0 && add == 0.0) continue;                                    // an exact zero (0*NaN is not: kept)
+                    (void)__hip_atomic_fetch_add(&h[b * a.nbins + ibin], add, __ATOMIC_RELAXED,
                                                  __HIP_MEMORY_SCOPE_WORKGROUP);            // :435
                     if (ISODEP) {
                         (void)__hip_atomic_fetch_add(&h[(a.nb + b) * a.nbins + ibin], __dmul_rn(dd, fm), __ATOMIC_RELAXED,
@@ -95,6 +96,160 @@ __global__ void mocsig_row_kernel(SigArgs a) {
             a.depi[((int64_t)jj * a.nbins + n) * a.nb + b] = (w != 0.0) ? __ddiv_rn(d, w) : 99999.0;
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Class kernel (0/1 basin masks with at most kSC bit patterns, no -isodep / -eiv / -full; rows of 4..5116 cells).
+// The loop above spends a scalar load per operand and cell, re-reads e1v and the basin masks at every level and
+// issues one LDS atomic per cell AND basin.  Here a thread owns NV 16-byte vectors of the row for all levels: e1v
+// and the class of each cell's basin bit pattern (see cdfmoc's class kernel, moc_zonal.hpp) stay in registers,
+// v / T / S / e3v arrive as nontemporal 16-byte loads, and a cell's term goes to ONE (class, bin) accumulator of the
+// wave's LDS histogram.  Neighbouring cells mostly fall into the same density bin: the four cells of a vector are
+// merged in registers first (left to right), so real fields issue one atomic per vector, and the conflicts of a
+// whole wave adding into one bin stay hidden behind the equation of state.  A term that is an exact zero (land:
+// v = 0) is not added -- it could not change the sum -- which keeps the land cells out of bin 1 (:401) altogether.
+// Basin b = the classes whose pattern has bit b, + 0 * (the other classes): the NaN of the reference's 0*NaN, or 0.
+constexpr int kSC = 8;
+
+struct SigClassArgs {
+    const uint8_t *cls;            // (npi,npj) class of the cell's basin bit pattern
+    uint8_t pat[kSC];
+    int nclass;
+};
+
+template <int NV, int TEOS, int T>
+__global__ void __launch_bounds__(T) mocsig_class_kernel(SigArgs a, SigClassArgs ca) {
+    extern __shared__ double hist[];                    // [nwaves][nclass][nbins], then raw [nb][nbins]
+    constexpr int nwaves = T / 64;
+    const int jj = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hsz = ca.nclass * a.nbins;
+    double *h = hist + (int64_t)wave * hsz, *raw = hist + (int64_t)nwaves * hsz;
+    for (int t = lane; t < hsz; t += 64) h[t] = 0.0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int64_t nij = (int64_t)a.npi * a.npj, r2 = (int64_t)jj * a.npi;
+    if (jj >= a.j0 && jj <= a.j1) {                     // rows ij1..ij2 (:405-407); the others stay 0
+        const int nfull = a.npi >> 2;
+        int i0[NV];
+        float e1[NV][4];
+        int hoff[NV][4];                                // class * nbins, or -1 for a cell this lane does not own
+#pragma unroll
+        for (int r = 0; r < NV; ++r) {
+            const int v = threadIdx.x + r * T;
+            i0[r] = min(4 * v, a.npi - 4);              // vectors 0..nfull-1 start at 4v, one more is anchored at npi-4
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int i = i0[r] + c;
+                const bool own = (v < nfull || (v == nfull && i >= 4 * nfull)) && i >= 1 && i < a.npi - 1;   // ji = 2..npiglo-1
+                e1[r][c]   = a.e1v[r2 + i];
+                hoff[r][c] = own ? (int)ca.cls[r2 + i] * a.nbins : -1;
+            }
+        }
+        for (int k = 0; k < a.npk - 1; ++k) {
+            const int64_t e = (int64_t)k * nij + r2;
+            f4u qv[NV], qt[NV], qs[NV], qe[NV];
+#pragma unroll
+            for (int r = 0; r < NV; ++r) {
+                qv[r] = ld_stream4u(a.zv + e + i0[r]); qt[r] = ld_stream4u(a.zt + e + i0[r]);
+                qs[r] = ld_stream4u(a.zs + e + i0[r]); qe[r] = ld_stream4u(a.e3v + e + i0[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < NV; ++r) {
+                const float v4[4] = {qv[r].x, qv[r].y, qv[r].z, qv[r].w}, t4[4] = {qt[r].x, qt[r].y, qt[r].z, qt[r].w};
+                const float s4[4] = {qs[r].x, qs[r].y, qs[r].z, qs[r].w}, e4[4] = {qe[r].x, qe[r].y, qe[r].z, qe[r].w};
+                int key[4];
+                double val[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float v = v4[c], t = t4[c], s = s4[c];
+                    if (v == a.zspv) v = 0.f;                                                  // :374
+                    if (t == a.zspt) t = 0.f;                                                  // :382
+                    if (s == a.zsps) s = 0.f;                                                  // :383
+                    const float zarea = __fmul_rn(e1[r][c], e4[c]);                            // :389
+                    const int itm = (s == a.zsps) ? 0 : 1;                                     // :392-393
+                    const double dens = sigmai_point<TEOS, false>(t, s, a.pref);               // :395
+                    const float zttmp = (float)__dmul_rn(dens, (double)itm);                   // :398
+                    int ibin = (int)__fdiv_rn(__fsub_rn(zttmp, a.sigmin), a.sigstp);           // :400
+                    ibin = min(max(ibin, 1), a.nbins) - 1;                                     // :401-402
+                    val[c] = -(double)__fmul_rn(v, zarea);                                     // :417
+                    key[c] = (hoff[r][c] >= 0 && val[c] != 0.0) ? hoff[r][c] + ibin : -1;      // (NaN != 0: kept)
+                }
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    if (key[c] >= 0 && key[c] == key[c + 1]) { val[c + 1] = __dadd_rn(val[c + 1], val[c]); key[c] = -1; }
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (key[c] >= 0)
+                        (void)__hip_atomic_fetch_add(&h[key[c]], val[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // :435
+            }
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < hsz; t += T) {                // waves added in wave order
+        double s = 0.0;
+        for (int w = 0; w < nwaves; ++w) s += hist[(int64_t)w * hsz + t];
+        hist[t] = s;                                            // wave 0's slot t is only read by this thread
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < a.nb * a.nbins; t += T) {    // class sums -> basin sums
+        const int b = t / a.nbins, n = t - b * a.nbins;
+        double s = 0.0, z = 0.0;
+        for (int c = 0; c < ca.nclass; ++c) {
+            const double v = hist[c * a.nbins + n];
+            if ((ca.pat[c] >> b) & 1) s += v;
+            else                      z += v;
+        }
+        raw[t] = s + __dmul_rn(z, 0.0);
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < a.nb) {                              // :463-467: from the highest density down
+        const int b = threadIdx.x;
+        const double *hm = raw + b * a.nbins;
+        double acc = __ddiv_rn(hm[a.nbins - 1], (double)1.e6f);
+        a.dmoc[((int64_t)jj * a.nbins + (a.nbins - 1)) * a.nb + b] = acc;
+        for (int n = a.nbins - 2; n >= 0; --n) {
+            acc = __dadd_rn(acc, __ddiv_rn(hm[n], (double)1.e6f));
+            a.dmoc[((int64_t)jj * a.nbins + n) * a.nb + b] = acc;
+        }
+    }
+}
+
+// bits(i,j) = basin membership bits; seen[1+v] = 1 for every pattern v present; seen[0] raised by a value outside {0,1}
+__global__ void sig_bits_kernel(const int16_t *__restrict__ ib, int nb, int64_t nij, uint8_t *__restrict__ bits, int *__restrict__ seen) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nij) return;
+    uint32_t v = 0;
+    bool bad = false;
+    for (int b = 0; b < nb; ++b) {
+        const int16_t m = ib[p * nb + b];
+        bad |= (m != 0 && m != 1);
+        v |= (m != 0 ? 1u : 0u) << b;
+    }
+    bits[p] = (uint8_t)v;
+    if (bad) atomicOr(seen, 1);
+    if (!seen[1 + v]) seen[1 + v] = 1;                   // benign race: every writer stores 1
+}
+__global__ void sig_cls_kernel(uint8_t *__restrict__ bits, int64_t nij, const uint8_t *__restrict__ lut) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < nij) bits[p] = lut[bits[p]];                 // in place: pattern -> class
+}
+
+constexpr int kSigT = 256;
+
+template <int NV>
+int launch_sig_class(const SigArgs &a, const SigClassArgs &ca, int eos, size_t shmem, hipStream_t st) {
+    if (eos == CDFT_EOS_TEOS10) {
+        if (shmem > 64 * 1024)
+            CDFT_HIP(hipFuncSetAttribute((const void *)mocsig_class_kernel<NV, 1, kSigT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL((mocsig_class_kernel<NV, 1, kSigT>), dim3(a.npj), dim3(kSigT), shmem, st, a, ca);
+    } else {
+        if (shmem > 64 * 1024)
+            CDFT_HIP(hipFuncSetAttribute((const void *)mocsig_class_kernel<NV, 0, kSigT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL((mocsig_class_kernel<NV, 0, kSigT>), dim3(a.npj), dim3(kSigT), shmem, st, a, ca);
+    }
+    CDFT_LAUNCH_CHECK();
+    return CDFT_OK;
 }
 
 }  // namespace
@@ -139,6 +294,46 @@ int cdft_mocsig_compute(const float *zv, const float *zveiv, const float *zt, co
     a.j0 = npjglo > 1 ? 1 : 0; a.j1 = npjglo > 1 ? npjglo - 2 : 0;                         // :405-407
     a.zspv = zspv; a.zspt = zspt; a.zsps = zsps; a.pref = pref; a.sigmin = sigmin; a.sigstp = sigstp;
     a.dmoc = om; a.depi = od;
+    // class kernel when it applies (see above); CDFT_MOCSIG_NOCLASS=1 keeps the general kernel (A/B and test hook)
+    bool done = false;
+    const int nvec = npiglo / 4 + 1, nv = (nvec + kSigT - 1) / kSigT;
+    if (!depi && !zveiv && e3v && npiglo >= 4 && nv <= 5 && !getenv("CDFT_MOCSIG_NOCLASS")) {
+        static DevBuf sbits, sseen;
+        CDFT_TRY(sbits.reserve(nij + 64 + 256));
+        CDFT_TRY(sseen.reserve(257 * sizeof(int)));
+        uint8_t *bits = (uint8_t *)sbits.ptr;
+        int *seen = (int *)sseen.ptr;
+        CDFT_HIP(hipMemsetAsync(seen, 0, 257 * sizeof(int), st));
+        hipLaunchKernelGGL(sig_bits_kernel, dim3((unsigned)((nij + 255) / 256)), dim3(256), 0, st, (const int16_t *)dib, nbasins,
+                           (int64_t)nij, bits, seen);
+        CDFT_LAUNCH_CHECK();
+        int hseen[257];
+        CDFT_HIP(hipMemcpyAsync(hseen, seen, sizeof(hseen), hipMemcpyDeviceToHost, st));
+        CDFT_HIP(hipStreamSynchronize(st));
+        SigClassArgs ca;
+        ca.nclass = 0;
+        uint8_t lut[256];
+        for (int v = 0; v < 256; ++v) {
+            lut[v] = 0;
+            if (hseen[1 + v]) {
+                if (ca.nclass < kSC) { ca.pat[ca.nclass] = (uint8_t)v; lut[v] = (uint8_t)ca.nclass; }
+                ++ca.nclass;
+            }
+        }
+        const size_t shmem = ((size_t)(kSigT / 64) * ca.nclass + nbasins) * nbins * 8;
+        if (!hseen[0] && ca.nclass <= kSC && shmem <= 150 * 1024) {
+            uint8_t *dlut = bits + nij + 64;
+            CDFT_HIP(hipMemcpyAsync(dlut, lut, 256, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(sig_cls_kernel, dim3((unsigned)((nij + 255) / 256)), dim3(256), 0, st, bits, (int64_t)nij, dlut);
+            CDFT_LAUNCH_CHECK();
+            CDFT_HIP(hipStreamSynchronize(st));                  // lut[] is a stack array
+            ca.cls = bits;
+            if (nv <= 2) CDFT_TRY(launch_sig_class<2>(a, ca, eos, shmem, st));
+            else         CDFT_TRY(launch_sig_class<5>(a, ca, eos, shmem, st));
+            done = true;
+        }
+    }
+    if (!done) {
     const int nq = depi ? 3 : 1;
     const size_t per_wave = (size_t)nq * nbasins * nbins * 8;
     int nwaves = 4;
@@ -155,6 +350,7 @@ int cdft_mocsig_compute(const float *zv, const float *zveiv, const float *zt, co
         else      hipLaunchKernelGGL((mocsig_row_kernel<0, false>), grid, block, shmem, st, a);
     }
     CDFT_LAUNCH_CHECK();
+    }
     if (out_space == CDFT_MEM_HOST) {
         CDFT_HIP(hipMemcpyAsync(dmoc, om, ob, hipMemcpyDeviceToHost, st));
         if (depi) CDFT_HIP(hipMemcpyAsync(depi, od, ob, hipMemcpyDeviceToHost, st));

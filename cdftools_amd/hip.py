@@ -501,7 +501,27 @@ class ZonalPlan(_Plan):
 
 def mocsig(zv, zt, zs, e1v, ibmask, nbins, sigmin, sigstp, pref=0.0, eos=0, e3v=None, e31d=None, zveiv=None, gdep=None,
            spv=(0.0, 0.0, 0.0), isodep=False, stream=None):
-    """cdft_mocsig_compute (host arrays) -> dmoc (npj,nbins,nb) r8 [, depi the same shape with isodep]."""
+    """cdft_mocsig_compute -> dmoc (npj,nbins,nb) r8 [, depi the same shape with isodep].  Host arrays, or CUDA tensors
+    for every field (gdep stays a host array): the result is then a CUDA tensor too."""
+    P = lambda x: _null() if x is None else C.c_void_p(x.ctypes.data)   # noqa: E731
+    if _is_tensor(zv) and zv.is_cuda:
+        keep = [_arg(x, np.float32, n) if x is not None else (_null(), MEM_DEVICE, None)
+                for x, n in ((zv, "zv"), (zveiv, "zveiv"), (zt, "zt"), (zs, "zs"), (e1v, "e1v"), (e3v, "e3v"), (e31d, "e31d"))]
+        pib, sib, kib = _arg(ibmask, np.int16, "ibmask")
+        if any(sp != MEM_DEVICE for _, sp, _ in keep) or sib != MEM_DEVICE:
+            raise ValueError("mocsig: every field must live in the same memory space")
+        npk, npj, npi = zv.shape
+        nb = ibmask.shape[-1]
+        dmoc = torch.empty((npj, nbins, nb), dtype=torch.float64, device=zv.device)
+        depi = torch.empty((npj, nbins, nb), dtype=torch.float64, device=zv.device) if isodep else None
+        gd = None if gdep is None else np.ascontiguousarray(gdep, np.float32)
+        ptr = [k[0] for k in keep]
+        check(_lib.load().cdft_mocsig_compute(ptr[0], ptr[1], ptr[2], ptr[3], ptr[4], ptr[5], ptr[6], pib, P(gd), npi, npj, npk, nb,
+                                              float(spv[0]), float(spv[1]), float(spv[2]), float(pref), eos, nbins, float(sigmin),
+                                              float(sigstp), MEM_DEVICE, C.c_void_p(dmoc.data_ptr()),
+                                              _null() if depi is None else C.c_void_p(depi.data_ptr()), MEM_DEVICE,
+                                              stream or current_stream_ptr()))
+        return (dmoc, depi) if isodep else dmoc
     f = lambda x: None if x is None else np.ascontiguousarray(x, np.float32)   # noqa: E731
     zv, zt, zs, e1v, e3v, e31d, zveiv, gdep = map(f, (zv, zt, zs, e1v, e3v, e31d, zveiv, gdep))
     ib = np.ascontiguousarray(ibmask, np.int16)
@@ -509,7 +529,6 @@ def mocsig(zv, zt, zs, e1v, ibmask, nbins, sigmin, sigstp, pref=0.0, eos=0, e3v=
     nb = ib.shape[-1]
     dmoc = np.empty((npj, nbins, nb), np.float64)
     depi = np.empty((npj, nbins, nb), np.float64) if isodep else None
-    P = lambda x: _null() if x is None else C.c_void_p(x.ctypes.data)   # noqa: E731
     check(_lib.load().cdft_mocsig_compute(P(zv), P(zveiv), P(zt), P(zs), P(e1v), P(e3v), P(e31d), P(ib), P(gdep), npi, npj, npk,
                                           nb, float(spv[0]), float(spv[1]), float(spv[2]), float(pref), eos, nbins,
                                           float(sigmin), float(sigstp), MEM_HOST, P(dmoc), P(depi), MEM_HOST,

@@ -516,6 +516,45 @@ def test_hip_mocsig_matches_oracle(gpu, npi, npj, npk, nb, pref, teos):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kernel", ["class", "general"])
+@pytest.mark.parametrize("npi,npj,npk,nb,smooth", [(24, 18, 7, 5, False), (182, 149, 9, 5, True), (1031, 5, 4, 5, True),
+                                                   (2045, 4, 3, 8, False), (4322, 3, 3, 5, True), (5, 4, 3, 5, False)])
+def test_hip_mocsig_kernels(gpu, monkeypatch, npi, npj, npk, nb, smooth, kernel):
+    """The class kernel (0/1 masks, <= 8 bit patterns: vector loads, one LDS accumulator per pattern and bin, the cells
+    of a vector merged in registers) and the general kernel (CDFT_MOCSIG_NOCLASS=1) against the oracle, with white-noise
+    or smooth T,S (neighbours in one bin), host arrays and arrays resident in HBM, a NaN on a cell outside a basin."""
+    import torch
+
+    if kernel == "general":
+        monkeypatch.setenv("CDFT_MOCSIG_NOCLASS", "1")
+    g, e1v, e3v, ib, zv, zt, zs = mocsig_inputs(npi, npj, npk, nb, seed=npi + 3)
+    if smooth:
+        x = np.linspace(0, 1, npi, dtype=np.float32)[None, None, :]
+        z = np.linspace(0, 1, npk, dtype=np.float32)[:, None, None]
+        zt = ((np.float32(25) * (1 - z) ** 2 + np.float32(2) * x) * g["tmask"]).astype(np.float32)
+        zs = ((np.float32(34) + z + np.float32(0.5) * x) * g["tmask"]).astype(np.float32)
+    nbins, sigmin, sigstp = 158, 30.0, 0.05
+    for poison in (False, True):
+        v = zv.copy()
+        if poison:
+            out = np.argwhere(ib[1:-1, 1:-1, min(1, nb - 1)] == 0)
+            if len(out) == 0:
+                continue
+            j, i = out[len(out) // 2] + 1
+            v[0, j, i] = np.nan
+        ref = oracle_lib.mocsig(v, zt, zs, e1v, ib, nbins, sigmin, sigstp, pref=2000.0, e3v=e3v)
+        bound = np.abs(oracle_lib.mocsig(np.abs(np.nan_to_num(v)), zt, zs, e1v, ib, nbins, sigmin, sigstp, pref=2000.0, e3v=e3v))
+        got = gpu.mocsig(v, zt, zs, e1v, ib, nbins, sigmin, sigstp, pref=2000.0, e3v=e3v)
+        assert np.array_equal(np.isnan(got), np.isnan(ref)) and (not poison or np.isnan(ref).any())
+        ok = ~np.isnan(ref)
+        lim = 1e-13 * bound.max(axis=1, keepdims=True) + 1e-300          # the cumulated sums of a row share its largest
+        assert np.all(np.abs(got - ref)[ok] <= np.broadcast_to(lim, ref.shape)[ok]), float(np.nanmax(np.abs(got - ref)))
+        dev = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (v, zt, zs, e1v, ib, e3v)]
+        res = gpu.mocsig(dev[0], dev[1], dev[2], dev[3], dev[4], nbins, sigmin, sigstp, pref=2000.0, e3v=dev[5])
+        assert np.array_equal(res.cpu().numpy(), got, equal_nan=True)       # same kernel, same order: identical
+
+
+@pytest.mark.gpu
 def test_cdfmocsig_end_to_end(tools, tmp_path):  # noqa: F811
     d = str(tmp_path)
     g, rec = nemo_files.make_case(d, npi=26, npj=19, npk=6, npt=2)

@@ -89,18 +89,26 @@ def main():
         del p, zv
 
     if "mocsig" in tools:
-        import time
-        ib = (rnd(npj, npi, 5) > 0.4).to(torch.int16).cpu().numpy()
-        zv, zt, zs = (rnd(npk, npj, npi) - 0.5).cpu().numpy(), (-2 + 30 * rnd(npk, npj, npi)).cpu().numpy(), (33 + 4 * rnd(npk, npj, npi)).cpu().numpy()
-        e1n, e3n = e1.cpu().numpy(), e3.cpu().numpy()
-        hip.mocsig(zv, zt, zs, e1n, ib, 158, 30.0, 0.05, pref=2000.0, e3v=e3n)
-        tm = hip.Timer()
-        t0 = time.perf_counter()
-        hip.mocsig(zv, zt, zs, e1n, ib, 158, 30.0, 0.05, pref=2000.0, e3v=e3n)
-        ms = (time.perf_counter() - t0) * 1e3
-        report("cdfmocsig (host arrays, 158 classes, 5 basins)", args.grid, n3, 16.0, ms,
-               "v,T,S,e3v 16 B per cell; the time includes the H2D copy of the four fields (PCIe-bound)")
-        del zv, zt, zs, e3n
+        # fields resident in HBM; T,S either white noise (every cell its own density bin: few LDS conflicts, no merging)
+        # or smooth in i (neighbouring cells share a bin, as in an ocean: merged in registers, conflicts between lanes)
+        band = ((torch.arange(npi, device=dev) * 3) // npi)[None, :]
+        sea = rnd(npj, npi) > 0.35
+        ib = torch.stack([sea, sea & (band == 0), sea & (band > 0), sea & (band == 2), sea & (band == 1)], dim=2).to(torch.int16).contiguous()
+        zv = ((rnd(npk, npj, npi) - 0.5) * sea[None]).contiguous()
+        for kind in ("white-noise T,S", "smooth T,S"):
+            if kind.startswith("white"):
+                zt, zs = (-2 + 30 * rnd(npk, npj, npi)), ((33 + 4 * rnd(npk, npj, npi)) * sea[None]).contiguous()
+            else:
+                x = torch.linspace(0, 1, npi, device=dev)[None, None, :]
+                z = torch.linspace(0, 1, npk, device=dev)[:, None, None]
+                y = torch.linspace(0, 1, npj, device=dev)[None, :, None]
+                zt = (25 * (1 - z) ** 2 * (1 - 0.5 * y) + 2 * x).contiguous()
+                zs = ((34 + z + 0.5 * x + 0 * y) * sea[None]).contiguous()
+            ms = timed(lambda: hip.mocsig(zv, zt, zs, e1, ib, 158, 30.0, 0.05, pref=2000.0, e3v=e3), args.reps)
+            report("cdfmocsig (158 classes, 5 basins, %s)" % kind, args.grid, n3, 16.0, ms,
+                   "v,T,S,e3v 16 B per cell; ~130 r8 operations per cell for sigma2 (fp64-bound: see the eos line)")
+            del zt, zs
+        del zv
 
     if "mhst" in tools:
         vt, vs = rnd(npk, npj, npi) - 0.5, rnd(npk, npj, npi) - 0.5
@@ -157,7 +165,9 @@ def main():
         for name, eos, flags in (("sigma0 tool form, exact", 0, 0), ("sigma0 tool form, FMA", 0, 1),
                                  ("sigmai TEOS-10 tool form, exact", 1, 0)):
             ms = timed(lambda: hip.sig_tool(t, s, 0.0, 0.0, eos, flags, out=o4), args.reps)
-            report(name, args.grid, n3, 12.0, ms, "T 4 + S 4 + out 4 B per point; ~120 r8 operations per point")
+            report(name, args.grid, n3, 12.0, ms, "T 4 + S 4 + out 4 B per point; surface reference: one of the four polynomials")
+        ms = timed(lambda: hip.sig_tool(t, s, 2000.0, 0.0, 0, 0, out=o4), args.reps)
+        report("sigma2 (sigmai at 2000 m) tool form, exact", args.grid, n3, 12.0, ms, "all four polynomials of the EOS: the r8 work of cdfmocsig")
 
 
 if __name__ == "__main__":
