@@ -73,6 +73,7 @@ SIGNATURES = {
     "cdft_mean_create": (_i, [_pvp, _i, _i, _i, _i]),
     "cdft_mean_set_mesh": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "cdft_mean_compute": (_i, [_vp, _vp, _i, _vp, _i, _vp]),
+    "cdft_mean_set_form": (_i, [_vp, _i]),
     "cdft_mean_destroy": (_i, [_vp]),
     "cdft_zonal_create": (_i, [_pvp, _i, _i, _i, _i]),
     "cdft_zonal_set_mesh": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),

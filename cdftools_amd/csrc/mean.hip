@@ -1,4 +1,4 @@
-// mean.hip -- cdfmean weighted sums per level and sub-basin (C ABI section "cdfmean").
+// mean.hip -- cdfmean / cdfsum weighted sums per level and sub-basin (C ABI section "cdfmean").
 // Reference loop src/cdfmean.f90:415-431, per level and basin:
 //     zv     = zv * zmask                                                   (:410)
 //     dsurf  = SUM(DBLE(          e1 * e2      * zmask * ibmask(b,:,:)))
@@ -20,6 +20,7 @@ struct cdft_mean_plan {
     int16_t *ib = nullptr;          // (nb,npi,npj), basin index fastest
     double *partial = nullptr;      // [npk][nblk][nb][4]
     int nblk = 0;
+    int form = 0;                   // CDFT_MEAN_FORM_*
     bool mesh_set = false;
     DevBuf st_zv, st_out;
 };
@@ -34,7 +35,7 @@ struct MeanArgs {
     const float *e1, *e2, *e3, *e31d, *mask, *zv;
     const int16_t *ib;
     int64_t nij;
-    int npk, nb, nblk;
+    int npk, nb, nblk, form;
     double *partial;
 };
 
@@ -103,8 +104,10 @@ __global__ void __launch_bounds__(kThreads) mean_level_kernel(MeanArgs a) {
                 const float ar = __fmul_rn(e1[v][c], e2[v][c]);
                 const float t_surf = __fmul_rn(ar, m);                                     // e1*e2*zmask
                 const float t_vol  = __fmul_rn(__fmul_rn(ar, e3[v][c]), m);                // e1*e2*e3*zmask
-                const float t_sum  = __fmul_rn(__fmul_rn(__fmul_rn(zm, e1[v][c]), e2[v][c]), e3[v][c]);
-                const float t_var  = __fmul_rn(__fmul_rn(__fmul_rn(__fmul_rn(zm, zm), e1[v][c]), e2[v][c]), e3[v][c]);
+                const float zee = __fmul_rn(__fmul_rn(zm, e1[v][c]), e2[v][c]);            // zv*e1*e2
+                // cdfmean: zv*e1*e2*e3 (:421); cdfsum: zv*e1*e2 (src/cdfsum.f90:309), forcing field: zv*e1*e2*zmask (:320)
+                const float t_sum  = a.form == 0 ? __fmul_rn(zee, e3[v][c]) : (a.form == 1 ? zee : __fmul_rn(zee, m));
+                const float t_var  = a.form == 0 ? __fmul_rn(__fmul_rn(__fmul_rn(__fmul_rn(zm, zm), e1[v][c]), e2[v][c]), e3[v][c]) : 0.f;
 #pragma unroll
                 for (int b = 0; b < NB; ++b) {                 // basins past nb have f = 0: they add exact zeros
                     const float f = fb[v][c][b];
@@ -202,6 +205,14 @@ int cdft_mean_set_mesh(cdft_mean_plan *p, const float *e1, const float *e2, cons
     return CDFT_OK;
 }
 
+int cdft_mean_set_form(cdft_mean_plan *p, int form) {
+    if (!p) return fail(CDFT_ERR_ARG, "cdft_mean_set_form: NULL plan");
+    if (form < CDFT_MEAN_FORM_MEAN || form > CDFT_MEAN_FORM_SUM_FORCING)
+        return fail(CDFT_ERR_ARG, "cdft_mean_set_form: form %d outside 0..2", form);
+    p->form = form;
+    return CDFT_OK;
+}
+
 int cdft_mean_compute(cdft_mean_plan *p, const float *zv, int in_space, double *sums, int out_space, void *stream) {
     if (!p || !zv || !sums) return fail(CDFT_ERR_ARG, "cdft_mean_compute: NULL argument");
     if (!p->mesh_set) return fail(CDFT_ERR_STATE, "cdft_mean_compute: cdft_mean_set_mesh has not succeeded");
@@ -215,7 +226,7 @@ int cdft_mean_compute(cdft_mean_plan *p, const float *zv, int in_space, double *
     if (out_space == CDFT_MEM_HOST) { CDFT_TRY(p->st_out.reserve(ob)); dout = (double *)p->st_out.ptr; }
     MeanArgs a;
     a.e1 = p->e1; a.e2 = p->e2; a.e3 = p->e3; a.e31d = p->e31d; a.mask = p->mask; a.zv = (const float *)dz; a.ib = p->ib;
-    a.nij = nij; a.npk = p->npk; a.nb = p->nb; a.partial = p->partial;
+    a.nij = nij; a.npk = p->npk; a.nb = p->nb; a.partial = p->partial; a.form = p->form;
     const bool vec4 = (nij % 4 == 0) && al16(dz) && al16(p->mask) && (!p->e3 || al16(p->e3));
     const int vec = vec4 ? 4 : 1;
     a.nblk = (int)(((nij + vec - 1) / vec + kThreads * kVPT - 1) / (kThreads * kVPT));

@@ -11,6 +11,7 @@ MODULE cdftools_hip
   PUBLIC
 
   INTEGER(C_INT), PARAMETER :: CDFT_OK = 0, CDFT_MEM_HOST = 0, CDFT_MEM_DEVICE = 1
+  INTEGER(C_INT), PARAMETER :: CDFT_MEAN_FORM_MEAN = 0, CDFT_MEAN_FORM_SUM = 1, CDFT_MEAN_FORM_SUM_FORCING = 2
   INTEGER(C_INT), PARAMETER :: CDFT_EOS_80 = 0, CDFT_EOS_TEOS10 = 1, CDFT_EOS_JMD94 = 2, CDFT_EOS_FAST_FMA = 1
 
   INTERFACE
@@ -126,6 +127,9 @@ MODULE cdftools_hip
      INTEGER(C_INT) FUNCTION cdft_mean_compute(plan, zv, in_space, sums, out_space, stream) BIND(C, name='cdft_mean_compute')
        IMPORT ; TYPE(C_PTR), VALUE :: plan, stream ; REAL(C_FLOAT), INTENT(in) :: zv(*)
        INTEGER(C_INT), VALUE :: in_space, out_space ; REAL(C_DOUBLE), INTENT(out) :: sums(*)
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_mean_set_form(plan, form) BIND(C, name='cdft_mean_set_form')
+       IMPORT ; TYPE(C_PTR), VALUE :: plan ; INTEGER(C_INT), VALUE :: form
      END FUNCTION
      INTEGER(C_INT) FUNCTION cdft_mean_destroy(plan) BIND(C, name='cdft_mean_destroy')
        IMPORT ; TYPE(C_PTR), VALUE :: plan

@@ -457,6 +457,10 @@ class MeanPlan(_Plan):
         ptr = [_null() if a is None else C.c_void_p(a.ctypes.data) for a in k]
         check(_lib.load().cdft_mean_set_mesh(self._h, *ptr, MEM_HOST, stream or current_stream_ptr()))
 
+    def set_form(self, form):
+        """0 = cdfmean, 1 = cdfsum, 2 = cdfsum on a file without depth (cdft_mean_set_form)."""
+        check(_lib.load().cdft_mean_set_form(self._h, int(form)))
+
     def compute(self, zv, stream=None):
         """zv (npk,npj,npi) r4 -> sums (npk,nb,4) r8: dsurf, dvol2d, dsum2d, dvar2d."""
         pz, sz, kz = _arg(zv, np.float32, "zv")

@@ -222,7 +222,7 @@ int cdft_vhst_transport(const float *xt, const float *xs, const float *m2d, cons
 int cdft_vint_release(void);   /* frees the staging buffers of the two calls above */
 
 /* ------------------------------------------------------------------------------------------ */
-/* cdfmean : weighted mean / variance / sum per level and sub-basin      */
+/* cdfmean, cdfsum : weighted mean / variance / sum per level and sub-basin */
 /*   replaces src/cdfmean.f90:405-431 (the four SUMs of each level and basin)                   */
 /* ------------------------------------------------------------------------------------------ */
 typedef struct cdft_mean_plan cdft_mean_plan;
@@ -237,6 +237,15 @@ int cdft_mean_set_mesh(cdft_mean_plan *plan, const float *e1, const float *e2, c
  * sums (4,nbasins,npk) r8: dsurf, dvol2d, dsum2d, dvar2d of every level and basin (:419-424); the
  * caller forms the means, variances and 3-D totals (:425-499). */
 int cdft_mean_compute(cdft_mean_plan *plan, const float *zv, int in_space, double *sums, int out_space, void *stream);
+/* cdfsum (src/cdfsum.f90:303-327) forms the same dsurf and dvol2d but a different third sum, and no fourth:
+ *   CDFT_MEAN_FORM_MEAN (default)  dsum2d = SUM(DBLE(zv*e1*e2*e3)),  dvar2d = SUM(DBLE(zv*zv*e1*e2*e3))   (cdfmean)
+ *   CDFT_MEAN_FORM_SUM             dsum2d = SUM(DBLE(zv*e1*e2)),     dvar2d = 0          (cdfsum :309, model field)
+ *   CDFT_MEAN_FORM_SUM_FORCING     dsum2d = SUM(DBLE(zv*e1*e2*zmask)), dvar2d = 0        (cdfsum :320, file without depth)
+ * with zv = zv*zmask first in every form (:299).  Applies to the following cdft_mean_compute calls. */
+#define CDFT_MEAN_FORM_MEAN        0
+#define CDFT_MEAN_FORM_SUM         1
+#define CDFT_MEAN_FORM_SUM_FORCING 2
+int cdft_mean_set_form(cdft_mean_plan *plan, int form);
 int cdft_mean_destroy(cdft_mean_plan *plan);
 
 /* ------------------------------------------------------------------------------------------ */

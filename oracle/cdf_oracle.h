@@ -71,6 +71,9 @@ void oracle_vhst_transport(int npi, int npj, int npk, const float *xt, const flo
                            const float *e3, const float *e31d, double *dheat, double *dsalt);
 void oracle_mean(int npi, int npj, int npk, int nb, const float *e1, const float *e2, const float *e3,
                  const float *e31d, const float *zmask, const int16_t *ibmask, const float *zv, double *sums);
+void oracle_mean_form(int npi, int npj, int npk, int nb, const float *e1, const float *e2, const float *e3,
+                      const float *e31d, const float *zmask, const int16_t *ibmask, const float *zv, int form,
+                      double *sums);
 void oracle_zonal(int npi, int npj, int nlev, int nb, const float *e1, const float *e2, const float *zmaskvar,
                   const float *zmask, const float *zv, int mean_form, double *dzo, double *darea, float *rmax,
                   float *rmin);

@@ -338,8 +338,20 @@ void oracle_vhst_transport(int npi, int npj, int npk, const float *xt, const flo
  *   dsum2d = SUM(DBLE(zv*e1*e2*e3*ibmask)), dvar2d = SUM(DBLE(zv*zv*e1*e2*e3*ibmask))
  * with every product in r4, left to right (ibmask is INTEGER(2): converted to r4 by the multiply).
  * sums (4,nb,npk).  The SUM is taken sequentially here (its order is the compiler's in the reference). */
+void oracle_mean_form(int npi, int npj, int npk, int nb, const float *e1, const float *e2, const float *e3,
+                      const float *e31d, const float *zmask, const int16_t *ibmask, const float *zv, int form,
+                      double *sums);
+
 void oracle_mean(int npi, int npj, int npk, int nb, const float *e1, const float *e2, const float *e3,
                  const float *e31d, const float *zmask, const int16_t *ibmask, const float *zv, double *sums) {
+    oracle_mean_form(npi, npj, npk, nb, e1, e2, e3, e31d, zmask, ibmask, zv, 0, sums);
+}
+
+/* form 0: src/cdfmean.f90:415-431.  form 1: src/cdfsum.f90:306-309 (dsum2d = SUM(DBLE(zv*e1*e2)), no variance);
+ * form 2: src/cdfsum.f90:319-320, a file without depth (dsum2d = SUM(DBLE(zv*e1*e2*zmask))).  zv = zv*zmask first. */
+void oracle_mean_form(int npi, int npj, int npk, int nb, const float *e1, const float *e2, const float *e3,
+                      const float *e31d, const float *zmask, const int16_t *ibmask, const float *zv, int form,
+                      double *sums) {
     const size_t nij = (size_t)npi * npj;
     for (int k = 0; k < npk; ++k)
         for (int b = 0; b < nb; ++b) {
@@ -350,8 +362,14 @@ void oracle_mean(int npi, int npj, int npk, int nb, const float *e1, const float
                 const float z = zv[k * nij + p] * m;
                 s0 += (double)(e1[p] * e2[p] * m * fb);
                 s1 += (double)(e1[p] * e2[p] * e * m * fb);
-                s2 += (double)(z * e1[p] * e2[p] * e * fb);
-                s3 += (double)(z * z * e1[p] * e2[p] * e * fb);
+                if (form == 0) {
+                    s2 += (double)(z * e1[p] * e2[p] * e * fb);
+                    s3 += (double)(z * z * e1[p] * e2[p] * e * fb);
+                } else if (form == 1) {
+                    s2 += (double)(z * e1[p] * e2[p] * fb);
+                } else {
+                    s2 += (double)(z * e1[p] * e2[p] * m * fb);
+                }
             }
             double *o = sums + ((size_t)k * nb + b) * 4;
             o[0] = s0; o[1] = s1; o[2] = s2; o[3] = s3;

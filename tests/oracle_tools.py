@@ -115,16 +115,17 @@ def vhst_transport(xt, xs, m2d, e3=None, e31d=None):
     return h, s
 
 
-def mean(e1, e2, zmask, ibmask, zv, e3=None, e31d=None):
-    """src/cdfmean.f90:405-431 -> sums (npk,nb,4) r8: dsurf, dvol2d, dsum2d, dvar2d."""
+def mean(e1, e2, zmask, ibmask, zv, e3=None, e31d=None, form=0):
+    """src/cdfmean.f90:405-431 (form 0) or src/cdfsum.f90:303-327 (form 1; 2 for a file without depth)
+    -> sums (npk,nb,4) r8: dsurf, dvol2d, dsum2d, dvar2d."""
     lib = load()
     e1, e2, zmask, zv, e3, e31d = map(_f, (e1, e2, zmask, zv, e3, e31d))
     ib = np.ascontiguousarray(ibmask, np.int16)
     npk, npj, npi = zv.shape
     nb = ib.shape[-1]
     out = np.empty((npk, nb, 4), np.float64)
-    lib.oracle_mean(C.c_int(npi), C.c_int(npj), C.c_int(npk), C.c_int(nb), _p(e1), _p(e2), _pp(e3), _pp(e31d), _p(zmask),
-                    _p(ib), _p(zv), _p(out))
+    lib.oracle_mean_form(C.c_int(npi), C.c_int(npj), C.c_int(npk), C.c_int(nb), _p(e1), _p(e2), _pp(e3), _pp(e31d), _p(zmask),
+                         _p(ib), _p(zv), C.c_int(form), _p(out))
     return out
 
 

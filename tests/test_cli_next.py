@@ -207,6 +207,109 @@ def test_cdfmean_end_to_end(tools, tmp_path):  # noqa: F811
     assert rc == 99 and "not known" in out
 
 
+# ------------------------------------------------------------------------------------------------ cdfsum
+def test_oracle_sum_forms_match_numpy_restatement():
+    g, zv, ib = mean_inputs(19, 13, 5, 1, seed=2)
+    tm = (g["tmask"] * np.float32(0.5)).astype(np.float32)                 # a -M mask with values other than 0/1
+    f32 = np.float32
+    zm = (zv * tm).astype(f32)
+    zee = ((zm * g["e1t"]).astype(f32) * g["e2t"]).astype(f32)
+    want = {1: zee, 2: (zee * tm).astype(f32)}
+    for form in (1, 2):
+        got = oracle_tools.mean(g["e1t"], g["e2t"], tm, ib, zv, e3=g["e3t_0"], form=form)[:, 0, :]
+        ref = oracle_tools.mean(g["e1t"], g["e2t"], tm, ib, zv, e3=g["e3t_0"])[:, 0, :]
+        assert np.array_equal(got[:, :2], ref[:, :2]) and np.all(got[:, 3] == 0)
+        assert np.allclose(got[:, 2], want[form].astype(np.float64).sum(axis=(1, 2)), rtol=1e-13, atol=0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("npi,npj,npk", [(24, 18, 7), (182, 149, 5), (1, 1, 1), (1023, 7, 3), (64, 64, 2)])
+def test_hip_sum_forms_match_oracle(gpu, npi, npj, npk):
+    g, zv, ib = mean_inputs(npi, npj, npk, 1, seed=npi + 4)
+    tm = (g["tmask"] * np.float32(0.5)).astype(np.float32)
+    plan = gpu.MeanPlan(npi, npj, npk, 1)
+    plan.set_mesh(g["e1t"], g["e2t"], tm, ib, e3=g["e3t_0"])
+    for form in (1, 2, 0):
+        plan.set_form(form)
+        got = plan.compute(zv)
+        ref = oracle_tools.mean(g["e1t"], g["e2t"], tm, ib, zv, e3=g["e3t_0"], form=form)
+        bound = oracle_tools.mean(g["e1t"], g["e2t"], tm, ib, np.abs(zv), e3=g["e3t_0"], form=form)
+        assert np.all(np.abs(got - ref) <= 1e-13 * bound + 1e-300), form
+    with pytest.raises(gpu.CdftError):
+        plan.set_form(3)
+
+
+def test_cdfsum_usage_and_option_errors(tools, tmp_path):  # noqa: F811
+    rc, out, _ = run("cdfsum", [], tmp_path)
+    assert rc == 0 and "usage : cdfsum" in out.splitlines()[0]
+    rc, out, _ = run("cdfsum", ["-full"], tmp_path)                        # announced by the usage, unknown to the parser
+    assert rc == 99 and "unknown option" in out
+    rc, out, _ = run("cdfsum", ["-f", "x.nc"], tmp_path)
+    assert rc == 99 and "-v option" in out and "-p option" in out
+    rc, out, _ = run("cdfsum", ["-f", "nothere.nc", "-v", "votemper", "-p", "T"], tmp_path)
+    assert rc == 99 and "missing" in out
+
+
+@pytest.mark.gpu
+def test_cdfsum_end_to_end(tools, tmp_path):  # noqa: F811
+    d = str(tmp_path)
+    g, rec = nemo_files.make_case(d, npi=26, npj=19, npk=6, npt=2)
+    npk, npj, npi = g["tmask"].shape
+    tm = g["tmask"].astype(np.float32)
+    one = np.ones((npj, npi, 1), np.int16)
+
+    rc, out, err = run("cdfsum", ["-f", "SYN_y0001_gridT.nc", "-v", "votemper", "-p", "T"], d)
+    assert rc == 0, out + err
+    var, att, dims = read_nc(os.path.join(d, "cdfsum.nc"))
+    assert dims["x"] == 1 and dims["y"] == 1 and dims["deptht"] == npk
+    cum = 0.0
+    for t in range(2):
+        s = oracle_tools.mean(g["e1t"], g["e2t"], tm, one, rec["t"][t], e3=g["e3t_0"], form=1)[:, 0, :]
+        want = np.where(s[:, 1] != 0, s[:, 2], 99999.0)
+        assert np.allclose(var["sum_votemper"][t].ravel(), want, rtol=2e-7, atol=0)
+        cum += s[:, 2].sum()
+        assert np.allclose(var["sum_3D_tvotemper"][t].ravel(), s[:, 2].sum(), rtol=2e-7)
+        assert np.allclose(var["sum_3Dvotemper"][t].ravel(), cum, rtol=2e-7)
+    assert att["sum_votemper"]["units"].endswith(b".m2") and att["sum_3Dvotemper"]["units"].endswith(b".m3")
+    assert "Sum value over the ocean: (cumulated in time)" in out and " mean Sum over time " in out
+
+    # a 3-D window, the U mask given with -M on the V point, unweighted
+    rc, out, err = run("cdfsum", ["-f", "SYN_y0001_gridV.nc", "-v", "vomecrty", "-p", "V", "-w", "3", "20", "2", "15", "2", "4",
+                                  "-M", "mask.nc", "umask", "-nowght", "-o", "w.nc"], d)
+    assert rc == 0, out + err
+    var, att, dims = read_nc(os.path.join(d, "w.nc"))
+    assert dims["depthv"] == 3 and not att["sum_vomecrty"]["units"].endswith(b".m2")
+    sl = (slice(1, 4), slice(1, 15), slice(2, 20))
+    ones2 = np.ones((14, 18), np.float32)
+    s = oracle_tools.mean(ones2, ones2, g["umask"].astype(np.float32)[sl], one[1:15, 2:20], rec["v"][1][sl],
+                          e3=np.ones((3, 14, 18), np.float32), form=1)[:, 0, :]
+    assert np.allclose(var["sum_vomecrty"][1].ravel(), np.where(s[:, 1] != 0, s[:, 2], 99999.0), rtol=2e-7, atol=1e-9)
+    # -nomsk
+    rc, out, err = run("cdfsum", ["-f", "SYN_y0001_gridT.nc", "-v", "vosaline", "-p", "T", "-nomsk", "-o", "n.nc"], d)
+    assert rc == 0, out + err
+    var, _, _ = read_nc(os.path.join(d, "n.nc"))
+    s = oracle_tools.mean(g["e1t"], g["e2t"], np.ones_like(tm), one, rec["s"][0], e3=g["e3t_0"], form=1)[:, 0, :]
+    assert np.allclose(var["sum_vosaline"][0].ravel(), s[:, 2], rtol=2e-7, atol=0)
+
+    # a file without depth (a forcing field): the other expression, and cdfsum.txt
+    flx = (100 * np.random.default_rng(3).random((2, npj, npi), dtype=np.float32)).astype(np.float32)
+    with nemo_files._new(os.path.join(d, "flx.nc"), [("time_counter", None), ("y", npj), ("x", npi)]) as f:
+        nemo_files._var(f, "nav_lon", "f4", ("y", "x"), g["glamf"])
+        nemo_files._var(f, "nav_lat", "f4", ("y", "x"), g["gphif"])
+        nemo_files._var(f, "time_counter", "f8", ("time_counter",), np.array([1.0, 2.0]), units="seconds since 1950-01-01 00:00:00",
+                        calendar="noleap", time_origin="1950-JAN-01 00:00:00")
+        nemo_files._var(f, "sohefldo", "f4", ("time_counter", "y", "x"), flx, units="W/m2")
+    rc, out, err = run("cdfsum", ["-f", "flx.nc", "-v", "sohefldo", "-p", "T", "-o", "f.nc"], d)
+    assert rc == 0, out + err
+    assert "W A R N I N G : you used a forcing field" in out
+    var, _, _ = read_nc(os.path.join(d, "f.nc"))
+    for t in range(2):
+        s = oracle_tools.mean(g["e1t"], g["e2t"], tm[:1], one, flx[t][None], e3=g["e3t_0"][:1], form=2)[:, 0, :]
+        assert np.allclose(var["sum_sohefldo"][t].ravel(), s[0, 2], rtol=2e-7)
+    lines = open(os.path.join(d, "cdfsum.txt")).read().splitlines()
+    assert len(lines) == 2 and lines[0].split()[0] == "1"
+
+
 # ------------------------------------------------------------------------------ cdfzonalsum / cdfzonalmean
 def zonal_inputs(npi, npj, npk, nb, seed):
     g = synth.make_grid(npi, npj, npk, seed=seed)
