@@ -10,14 +10,16 @@ PROGRAM cdfmoc
   !! sum) run on the GPU through cdft_moc_* (libcdftools_hip.so); several records are sent per call so
   !! that the time-invariant weights are read once for all of them.
   !! -decomp (:390-517: geostrophic-shear, barotropic and ageostrophic parts) runs on the GPU as well
-  !! (cdft_moc_decomp_*), one record per call.  -rapid is not carried by this build: it stops with an
-  !! explicit message.
+  !! (cdft_moc_decomp_*), one record per call.  -rapid (:598-1004: the RAPID-MOCHA diagnostics of one (i,k)
+  !! section at 26.5 N) has nothing data-parallel in it and is host code as in the reference
+  !! (module cdfmoc_rapid, cdf_findij from module cdftools).
   !!======================================================================
   USE ISO_C_BINDING
   USE cdfio
   USE modcdfnames
   USE eos
   USE cdftools_hip
+  USE cdfmoc_rapid
   IMPLICIT NONE
 
   INTEGER(KIND=4) :: narg, ijarg, ierr, ii, iv
@@ -67,8 +69,9 @@ PROGRAM cdfmoc
      PRINT *, '       [-t T-file]   : temperature (and salinity) file, for -decomp'
      PRINT *, '       [-s S-file]   : salinity file if not the T-file'
      PRINT *, '       [-teos10]     : TEOS10 equation of state instead of the default EOS80'
-     PRINT *, '       [-rapid ], [-u U-file] : accepted for compatibility; the RAPID diagnostics are'
-     PRINT *, '                       not available in this build.'
+     PRINT *, '       [-rapid ]     : the AMOC at 26.5 N and its components as the RAPID-MOCHA array gives'
+     PRINT *, '                       them (output rapid_', TRIM(cf_moc), '); needs -t, (-s) and -u'
+     PRINT *, '       [-u U-file]   : file with the zonal wind stress, for the Ekman transport of -rapid'
      PRINT *, '      '
      PRINT *, '     REQUIRED FILES :'
      PRINT *, '       ', TRIM(cn_fhgr), ' ', TRIM(cn_fzgr), ' and ', TRIM(cn_fmsk)
@@ -115,14 +118,15 @@ PROGRAM cdfmoc
   lchk = lchk .OR. chkfile( cn_fmsk )
   lchk = lchk .OR. chkfile( cf_vfil )
   IF ( ldec ) lchk = lchk .OR. chkfile( cf_tfil ) .OR. chkfile( cf_sfil )
+  IF ( lrap ) lchk = lchk .OR. chkfile( cf_tfil ) .OR. chkfile( cf_sfil ) .OR. chkfile( cf_ufil )
   IF ( lchk ) STOP 99                                     ! missing file(s)
-  IF ( lrap ) THEN
-     PRINT *, ' ERROR : option -rapid is not available in the MI355X build of cdfmoc.'
-     STOP 99
-  ENDIF
   IF ( lg_vvl ) THEN
      cn_fe3v = cf_vfil
      cn_ve3v = cn_ve3vvvl
+  ENDIF
+  IF ( lrap ) THEN
+     CALL rapid_amoc(cf_vfil, cf_tfil, cf_sfil, cf_ufil, cf_moc, lfull)      ! all of it in a separate routine
+     STOP 99                                              ! the reference ends here, with this code (:255)
   ENDIF
 
   npiglo = getdim(cf_vfil, cn_x)

@@ -127,8 +127,9 @@ def test_cdfmoc_decomp_end_to_end(tools, tmp_path):
     # missing T file -> the reference's message and STOP 99
     rc, out, _ = run("cdfmoc", ["-v", "SYN_y0001_gridV.nc", "-t", "nothere.nc", "-decomp"], tmp_path)
     assert rc == 99 and "nothere.nc is missing" in out
-    rc, out, _ = run("cdfmoc", ["-v", "SYN_y0001_gridV.nc", "-rapid"], tmp_path)
-    assert rc == 99 and "-rapid" in out
+    # -rapid checks its three other files before anything else (tests/test_cli_rapid.py has the option itself)
+    rc, out, _ = run("cdfmoc", ["-v", "SYN_y0001_gridV.nc", "-t", "nothere.nc", "-u", "nothere2.nc", "-rapid"], tmp_path)
+    assert rc == 99 and "nothere2.nc is missing" in out
 
 
 @pytest.mark.gpu
