@@ -6,6 +6,8 @@
 #define _FILE_OFFSET_BITS 64
 #define _GNU_SOURCE
 #include "ncclassic.h"
+#include "ncmodel.h"
+#include <dlfcn.h>
 #include <errno.h>
 #include <fcntl.h>
 #include <stdint.h>
@@ -21,27 +23,6 @@
 #define MAX_FILES 64
 
 typedef struct {
-    char name[NCC_MAX_NAME];
-    int type;
-    size_t nelems;
-    void *data; /* native byte order, packed array of `type` */
-} Att;
-
-typedef struct {
-    char name[NCC_MAX_NAME];
-    uint64_t len; /* 0 = unlimited */
-} Dim;
-
-typedef struct {
-    char name[NCC_MAX_NAME];
-    int ndims, dimids[NCC_MAX_DIMS];
-    int natts;
-    Att *atts;
-    int type, isrec;
-    uint64_t vsize, begin;
-} Var;
-
-typedef struct {
     int used, fd, format, writable, indef, has_data, hdr_dirty, nrec_dirty;
     uint64_t numrecs, recsize, hdr_size; /* hdr_size: bytes reserved for the header in the file */
     int ndims, nvars, ngatts, unlim;
@@ -50,6 +31,7 @@ typedef struct {
     Att *gatts;
     uint64_t *old_begin; /* begins before the current redef (NULL outside redef of a file with data) */
     uint64_t old_recsize;
+    NcH5 *h5;            /* a NetCDF-4 file, read through the HDF5 plug-in (read only) */
 } File;
 
 static File g_files[MAX_FILES];
@@ -436,6 +418,42 @@ int ncc_create(const char *path, int format, int clobber, int *ncid) {
     return 0;
 }
 
+/* The HDF5 plug-in lives next to this library (libnch5.so; CDFT_NCH5_LIB overrides) and is only loaded when a
+ * NetCDF-4 file is opened, so that the classic path does not depend on an HDF5 installation. */
+static nch5_open_fn g_h5_open;
+static nch5_get_vara_fn g_h5_get;
+static nch5_close_fn g_h5_close;
+static char g_h5_msg[512] = "NetCDF: HDF5 error";
+
+static int h5_load(void) {
+    if (g_h5_open) return 0;
+    char path[4096] = "libnch5.so";
+    const char *env = getenv("CDFT_NCH5_LIB");
+    Dl_info info;
+    if (env && *env) snprintf(path, sizeof path, "%s", env);
+    else if (dladdr((void *)&h5_load, &info) && info.dli_fname) {
+        snprintf(path, sizeof path, "%s", info.dli_fname);
+        char *slash = strrchr(path, '/');
+        if (slash) snprintf(slash + 1, sizeof path - (size_t)(slash + 1 - path), "libnch5.so");
+        else snprintf(path, sizeof path, "libnch5.so");
+    }
+    void *lib = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+    if (!lib) {
+        snprintf(g_h5_msg, sizeof g_h5_msg, "NetCDF: a NetCDF-4/HDF5 file needs the HDF5 plug-in, which could not be loaded (%s)",
+                 dlerror());
+        return NCC_EHDFERR;
+    }
+    g_h5_open  = (nch5_open_fn)dlsym(lib, "nch5_open");
+    g_h5_get   = (nch5_get_vara_fn)dlsym(lib, "nch5_get_vara");
+    g_h5_close = (nch5_close_fn)dlsym(lib, "nch5_close");
+    if (!g_h5_open || !g_h5_get || !g_h5_close) {
+        g_h5_open = NULL;
+        snprintf(g_h5_msg, sizeof g_h5_msg, "NetCDF: %s is not the HDF5 plug-in of this build", path);
+        return NCC_EHDFERR;
+    }
+    return 0;
+}
+
 int ncc_open(const char *path, int writable, int *ncid) {
     if (!path || !ncid) return NCC_EINVAL;
     const int s = new_slot();
@@ -445,6 +463,18 @@ int ncc_open(const char *path, int writable, int *ncid) {
     File *f = &g_files[s];
     memset(f, 0, sizeof *f);
     f->used = 1; f->fd = fd; f->writable = writable; f->has_data = 1;
+    unsigned char sig[8] = {0};
+    if (pread(fd, sig, 8, 0) == 8 && memcmp(sig, "\211HDF\r\n\032\n", 8) == 0) {      /* NetCDF-4 = HDF5 */
+        close(fd);
+        f->fd = -1;
+        int rc4 = writable ? NCC_EPERM : h5_load();
+        if (!rc4) rc4 = g_h5_open(path, &f->h5, &f->ndims, &f->dims, &f->nvars, &f->vars, &f->ngatts, &f->gatts, &f->unlim,
+                                  &f->numrecs);
+        if (rc4) { f->used = 0; return rc4; }
+        f->format = NCC_FORMAT_NETCDF4;
+        *ncid = s;
+        return 0;
+    }
     const int rc = parse_header(f);
     if (rc) { close(fd); f->used = 0; return rc; }
     if (f->recsize && f->numrecs == 0) {           /* numrecs not flushed (or STREAMING): derive from the size */
@@ -494,6 +524,11 @@ int ncc_close(int ncid) {
     File *f = getf(ncid);
     if (!f) return NCC_EBADID;
     int rc = 0;
+    if (f->h5) {
+        g_h5_close(f->h5);
+        free_file(f);
+        return 0;
+    }
     if (f->writable) {
         if (f->indef) rc = ncc_enddef(ncid);
         else if (f->hdr_dirty || f->nrec_dirty) rc = write_header(f);
@@ -746,6 +781,7 @@ static int vara(int ncid, int varid, const size_t *start, const size_t *count, i
         total *= ct[d];
     }
     if (total == 0) return 0;
+    if (f->h5) return writing ? NCC_EPERM : g_h5_get(f->h5, varid, nd, st, ct, memtype, data);
     /* byte strides of the file layout */
     uint64_t stride[NCC_MAX_DIMS + 1];
     uint64_t s = xs;
@@ -824,13 +860,14 @@ const char *ncc_strerror(int status) {
         case NCC_EBADDIM: return "NetCDF: Invalid dimension ID or name";
         case NCC_EUNLIMIT: return "NetCDF: NC_UNLIMITED size already in use";
         case NCC_ENOTVAR: return "NetCDF: Variable not found";
-        case NCC_ENOTNC: return "NetCDF: Unknown file format (only classic CDF-1/2/5 is read by this build)";
+        case NCC_ENOTNC: return "NetCDF: Unknown file format (not CDF-1/2/5 and not NetCDF-4/HDF5)";
         case NCC_ECHAR: return "NetCDF: Attempt to convert between text & numbers";
         case NCC_EEDGE: return "NetCDF: Start+count exceeds dimension bound";
         case NCC_ERANGE: return "NetCDF: Numeric conversion not representable";
         case NCC_ENOMEM: return "NetCDF: Memory allocation (malloc) failure";
         case NCC_EIO: return "NetCDF: I/O failure";
         case NCC_ENOENT: return "No such file or directory";
+        case NCC_EHDFERR: return g_h5_msg;
         default: return "NetCDF: Unknown Error";
     }
 }

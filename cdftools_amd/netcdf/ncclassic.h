@@ -1,6 +1,8 @@
 /*
  * ncclassic.h -- a small, self-contained reader/writer of the NetCDF classic formats
- * (CDF-1, CDF-2 "64-bit offset", CDF-5 "64-bit data"), the I/O layer under cdfio.F90.
+ * (CDF-1, CDF-2 "64-bit offset", CDF-5 "64-bit data"), the I/O layer under cdfio.F90.  NetCDF-4 files
+ * (HDF5) are READ through an optional plug-in, libnch5.so (nch5.c, needs an HDF5 C library >= 1.10), loaded
+ * when the first such file is opened; they are never written.
  *
  * Why it exists: neither the build container nor the GPU box has libnetcdf / netcdf-fortran, and
  * the CDFTOOLS programs read and write NetCDF (src/cdfio.F90 is written on the NF90 API).  The
@@ -20,7 +22,7 @@ extern "C" {
 
 enum { NCC_BYTE = 1, NCC_CHAR = 2, NCC_SHORT = 3, NCC_INT = 4, NCC_FLOAT = 5, NCC_DOUBLE = 6,
        NCC_UBYTE = 7, NCC_USHORT = 8, NCC_UINT = 9, NCC_INT64 = 10, NCC_UINT64 = 11 };
-enum { NCC_FORMAT_CLASSIC = 1, NCC_FORMAT_64BIT_OFFSET = 2, NCC_FORMAT_64BIT_DATA = 5 };
+enum { NCC_FORMAT_CLASSIC = 1, NCC_FORMAT_64BIT_OFFSET = 2, NCC_FORMAT_NETCDF4 = 3, NCC_FORMAT_64BIT_DATA = 5 };
 enum { NCC_GLOBAL = -1, NCC_MAX_NAME = 256, NCC_MAX_DIMS = 16 };
 
 #define NCC_NOERR        0
@@ -44,6 +46,7 @@ enum { NCC_GLOBAL = -1, NCC_MAX_NAME = 256, NCC_MAX_DIMS = 16 };
 #define NCC_ENOMEM     (-61)
 #define NCC_EIO        (-68)
 #define NCC_ENOENT     (-90)   /* file does not exist / cannot be opened */
+#define NCC_EHDFERR   (-101)   /* NetCDF-4 file: HDF5 plug-in missing, or an HDF5 call failed */
 
 int ncc_create(const char *path, int format, int clobber, int *ncid);
 int ncc_open(const char *path, int writable, int *ncid);

@@ -1,0 +1,400 @@
+/*
+ * nch5.c -- read-only NetCDF-4 support: maps the HDF5 layout netCDF-4 uses onto the classic data model of
+ * ncclassic.c (dimensions, variables, attributes), so that cdfio reads a NetCDF-4 file like a classic one.
+ * Built as a plug-in (libnch5.so, linked against the HDF5 C library >= 1.10) that libncclassic.so loads when
+ * it first meets an HDF5 signature; written from the published netCDF-4 format description ("NetCDF-4 Format"
+ * appendix of the NetCDF User's Guide), no code from libnetcdf.
+ *
+ * What is understood (the root group only, which is what NEMO / XIOS write):
+ *   - a dataset with CLASS = "DIMENSION_SCALE" is a dimension: its name, its extent, unlimited when its
+ *     maximum extent is; `_Netcdf4Dimid` gives the dimension id when present.  A scale whose NAME starts with
+ *     "This is a netCDF dimension but not a netCDF variable." is a dimension only, any other one is also the
+ *     coordinate variable of that dimension;
+ *   - every other dataset is a variable; its dimensions are the scales referenced by DIMENSION_LIST (object
+ *     references), a dataset without them gets anonymous "phony_dim_<n>" dimensions by extent;
+ *     the prefix "_nc4_non_coord_" of a variable named like a dimension is dropped;
+ *   - integer and floating-point types of 1, 2, 4, 8 bytes; chunked / deflated / shuffled storage is HDF5's
+ *     business; values are converted to the requested memory type by H5Dread;
+ *   - attributes: numeric arrays, and strings (fixed or variable length) as NC_CHAR; the bookkeeping
+ *     attributes of the format itself are hidden.
+ * Not understood: groups, user-defined / compound / enum / opaque / vlen types, string variables.
+ */
+#define _GNU_SOURCE
+#include <hdf5.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "ncmodel.h"
+
+#if H5_VERS_MAJOR == 1 && H5_VERS_MINOR < 10
+#error "HDF5 1.10 or later is needed (hid_t is 64 bits, H5Rdereference2)"
+#endif
+
+struct NcH5 {
+    hid_t file;
+    int nvars;
+    hid_t *dset;      /* one per variable */
+};
+
+typedef struct {
+    char name[NCC_MAX_NAME];
+    hid_t id;
+    int rank;
+    hsize_t ext[NCC_MAX_DIMS], maxext[NCC_MAX_DIMS];
+    int is_scale, dim_only, dimid_att;     /* dimid_att: _Netcdf4Dimid or -1 */
+    int dim_index;                         /* index of the dimension this scale defines */
+} Obj;
+
+typedef struct {
+    Obj *o;
+    int n, cap;
+    hid_t file;
+} Scan;
+
+static const char *const kDimOnly = "This is a netCDF dimension but not a netCDF variable.";
+static const char *const kNonCoord = "_nc4_non_coord_";
+
+/* ---- small helpers ---------------------------------------------------------------------------------------- */
+static int read_string_att(hid_t obj, const char *name, char *out, size_t cap) {
+    if (H5Aexists(obj, name) <= 0) return -1;
+    hid_t a = H5Aopen(obj, name, H5P_DEFAULT);
+    if (a < 0) return -1;
+    hid_t t = H5Aget_type(a);
+    int rc = -1;
+    out[0] = 0;
+    if (H5Tget_class(t) == H5T_STRING) {
+        hid_t mt = H5Tcopy(H5T_C_S1);
+        if (H5Tis_variable_str(t) > 0) {
+            char *p = NULL;
+            H5Tset_size(mt, H5T_VARIABLE);
+            if (H5Aread(a, mt, &p) >= 0 && p) { snprintf(out, cap, "%s", p); H5free_memory(p); rc = 0; }
+        } else {
+            const size_t n = H5Tget_size(t);
+            char *buf = (char *)calloc(n + 1, 1);
+            H5Tset_size(mt, n + 1);
+            if (buf && H5Aread(a, mt, buf) >= 0) { snprintf(out, cap, "%s", buf); rc = 0; }
+            free(buf);
+        }
+        H5Tclose(mt);
+    }
+    H5Tclose(t);
+    H5Aclose(a);
+    return rc;
+}
+
+static int nc_type_of(hid_t t) {
+    const size_t sz = H5Tget_size(t);
+    switch (H5Tget_class(t)) {
+        case H5T_INTEGER: {
+            const int sgn = H5Tget_sign(t) != H5T_SGN_NONE;
+            if (sz == 1) return sgn ? NCC_BYTE : NCC_UBYTE;
+            if (sz == 2) return sgn ? NCC_SHORT : NCC_USHORT;
+            if (sz == 4) return sgn ? NCC_INT : NCC_UINT;
+            if (sz == 8) return sgn ? NCC_INT64 : NCC_UINT64;
+            return 0;
+        }
+        case H5T_FLOAT:
+            return sz == 4 ? NCC_FLOAT : (sz == 8 ? NCC_DOUBLE : 0);
+        default:
+            return 0;
+    }
+}
+
+static hid_t mem_type(int t) {
+    switch (t) {
+        case NCC_BYTE: return H5T_NATIVE_SCHAR;
+        case NCC_UBYTE: return H5T_NATIVE_UCHAR;
+        case NCC_SHORT: return H5T_NATIVE_SHORT;
+        case NCC_USHORT: return H5T_NATIVE_USHORT;
+        case NCC_INT: return H5T_NATIVE_INT;
+        case NCC_UINT: return H5T_NATIVE_UINT;
+        case NCC_INT64: return H5T_NATIVE_LLONG;
+        case NCC_UINT64: return H5T_NATIVE_ULLONG;
+        case NCC_FLOAT: return H5T_NATIVE_FLOAT;
+        case NCC_DOUBLE: return H5T_NATIVE_DOUBLE;
+        default: return -1;
+    }
+}
+
+static size_t mem_size(int t) {
+    switch (t) {
+        case NCC_BYTE: case NCC_UBYTE: case NCC_CHAR: return 1;
+        case NCC_SHORT: case NCC_USHORT: return 2;
+        case NCC_INT: case NCC_UINT: case NCC_FLOAT: return 4;
+        default: return 8;
+    }
+}
+
+/* ---- attributes -------------------------------------------------------------------------------------------- */
+typedef struct { Att *a; int n, cap; } AttList;
+
+static int hidden_att(const char *name) {
+    static const char *const k[] = {"DIMENSION_LIST", "REFERENCE_LIST", "CLASS", "NAME", "_Netcdf4Dimid", "_Netcdf4Coordinates",
+                                    "_NCProperties", "_nc3_strict", "_NetCDF4Dimid"};
+    for (size_t i = 0; i < sizeof k / sizeof k[0]; ++i) if (!strcmp(name, k[i])) return 1;
+    return 0;
+}
+
+static herr_t att_cb(hid_t obj, const char *name, const H5A_info_t *info, void *ctx) {
+    (void)info;
+    AttList *l = (AttList *)ctx;
+    if (hidden_att(name)) return 0;
+    hid_t a = H5Aopen(obj, name, H5P_DEFAULT);
+    if (a < 0) return 0;
+    hid_t t = H5Aget_type(a), sp = H5Aget_space(a);
+    Att at;
+    memset(&at, 0, sizeof at);
+    snprintf(at.name, sizeof at.name, "%s", name);
+    const hssize_t npts = H5Sget_simple_extent_npoints(sp);
+    int keep = 0;
+    if (H5Tget_class(t) == H5T_STRING) {
+        char *text = NULL;
+        hid_t mt = H5Tcopy(H5T_C_S1);
+        if (H5Tis_variable_str(t) > 0) {
+            char **p = (char **)calloc((size_t)(npts > 0 ? npts : 1), sizeof *p);
+            H5Tset_size(mt, H5T_VARIABLE);
+            if (p && H5Aread(a, mt, p) >= 0 && p[0]) text = strdup(p[0]);
+            if (p) { for (hssize_t i = 0; i < npts; ++i) if (p[i]) H5free_memory(p[i]); free(p); }
+        } else {
+            const size_t n = H5Tget_size(t);
+            char *buf = (char *)calloc((size_t)(npts > 0 ? npts : 1) * (n + 1) + 1, 1);
+            H5Tset_size(mt, n + 1);
+            if (buf && H5Aread(a, mt, buf) >= 0) text = buf; else free(buf);
+        }
+        H5Tclose(mt);
+        if (text) {
+            at.type = NCC_CHAR;
+            at.nelems = strlen(text);
+            at.data = text;
+            keep = 1;
+        }
+    } else {
+        at.type = nc_type_of(t);
+        if (at.type && npts > 0) {
+            at.nelems = (size_t)npts;
+            at.data = malloc(at.nelems * mem_size(at.type));
+            if (at.data && H5Aread(a, mem_type(at.type), at.data) >= 0) keep = 1;
+            else free(at.data);
+        }
+    }
+    if (keep) {
+        if (l->n == l->cap) {
+            l->cap = l->cap ? 2 * l->cap : 8;
+            l->a = (Att *)realloc(l->a, (size_t)l->cap * sizeof(Att));
+        }
+        l->a[l->n++] = at;
+    }
+    H5Sclose(sp);
+    H5Tclose(t);
+    H5Aclose(a);
+    return 0;
+}
+
+static void read_atts(hid_t obj, Att **out, int *n) {
+    AttList l = {NULL, 0, 0};
+    hsize_t idx = 0;
+    if (H5Aiterate2(obj, H5_INDEX_CRT_ORDER, H5_ITER_INC, &idx, att_cb, &l) < 0) {      /* creation order not tracked */
+        idx = 0;
+        for (int i = 0; i < l.n; ++i) free(l.a[i].data);
+        l.n = 0;
+        H5Aiterate2(obj, H5_INDEX_NAME, H5_ITER_INC, &idx, att_cb, &l);
+    }
+    *out = l.a;
+    *n = l.n;
+}
+
+/* ---- objects of the root group ----------------------------------------------------------------------------- */
+static herr_t link_cb(hid_t grp, const char *name, const H5L_info_t *info, void *ctx) {
+    (void)info;
+    Scan *s = (Scan *)ctx;
+    hid_t d = H5Dopen2(grp, name, H5P_DEFAULT);
+    if (d < 0) return 0;                                         /* a group, a named type, ...: not ours */
+    if (s->n == s->cap) {
+        s->cap = s->cap ? 2 * s->cap : 32;
+        s->o = (Obj *)realloc(s->o, (size_t)s->cap * sizeof(Obj));
+    }
+    Obj *o = &s->o[s->n];
+    memset(o, 0, sizeof *o);
+    snprintf(o->name, sizeof o->name, "%s", name);
+    o->id = d;
+    o->dimid_att = -1;
+    o->dim_index = -1;
+    hid_t sp = H5Dget_space(d);
+    o->rank = H5Sget_simple_extent_ndims(sp);
+    if (o->rank < 0 || o->rank > NCC_MAX_DIMS) { H5Sclose(sp); H5Dclose(d); return 0; }
+    if (o->rank > 0) H5Sget_simple_extent_dims(sp, o->ext, o->maxext);
+    H5Sclose(sp);
+    char cls[64];
+    if (read_string_att(d, "CLASS", cls, sizeof cls) == 0 && !strcmp(cls, "DIMENSION_SCALE")) {
+        char nm[NCC_MAX_NAME];
+        o->is_scale = 1;
+        if (read_string_att(d, "NAME", nm, sizeof nm) == 0 && !strncmp(nm, kDimOnly, strlen(kDimOnly))) o->dim_only = 1;
+        if (H5Aexists(d, "_Netcdf4Dimid") > 0) {
+            hid_t a = H5Aopen(d, "_Netcdf4Dimid", H5P_DEFAULT);
+            int v = -1;
+            if (a >= 0 && H5Aread(a, H5T_NATIVE_INT, &v) >= 0) o->dimid_att = v;
+            if (a >= 0) H5Aclose(a);
+        }
+    }
+    ++s->n;
+    return 0;
+}
+
+static int find_dim(const Dim *dims, int nd, const char *name) {
+    for (int i = 0; i < nd; ++i) if (!strcmp(dims[i].name, name)) return i;
+    return -1;
+}
+
+int nch5_open(const char *path, NcH5 **hout, int *ndims, Dim **dims_out, int *nvars, Var **vars_out, int *ngatts, Att **gatts,
+              int *unlim, uint64_t *numrecs) {
+    H5Eset_auto2(H5E_DEFAULT, NULL, NULL);                       /* failures are reported through return codes */
+    hid_t file = H5Fopen(path, H5F_ACC_RDONLY, H5P_DEFAULT);
+    if (file < 0) return NCC_EHDFERR;
+    Scan s = {NULL, 0, 0, file};
+    hsize_t idx = 0;
+    if (H5Literate(file, H5_INDEX_CRT_ORDER, H5_ITER_INC, &idx, link_cb, &s) < 0) {     /* creation order not tracked */
+        for (int i = 0; i < s.n; ++i) H5Dclose(s.o[i].id);
+        s.n = 0; idx = 0;
+        H5Literate(file, H5_INDEX_NAME, H5_ITER_INC, &idx, link_cb, &s);
+    }
+    /* dimensions: the scales, ordered by _Netcdf4Dimid when every scale has one */
+    int nscale = 0, all_ids = 1;
+    for (int i = 0; i < s.n; ++i) if (s.o[i].is_scale && s.o[i].rank >= 1) { ++nscale; if (s.o[i].dimid_att < 0) all_ids = 0; }
+    int cap = nscale + s.n * NCC_MAX_DIMS + 1;
+    Dim *dims = (Dim *)calloc((size_t)cap, sizeof(Dim));
+    uint64_t *dlen = (uint64_t *)calloc((size_t)cap, sizeof(uint64_t));            /* current lengths */
+    int nd = 0;
+    *unlim = -1; *numrecs = 0;
+    for (int pass = 0; pass < nscale; ++pass) {
+        int pick = -1;
+        for (int i = 0; i < s.n; ++i) {
+            Obj *o = &s.o[i];
+            if (!o->is_scale || o->rank < 1 || o->dim_index >= 0) continue;
+            if (!all_ids) { pick = i; break; }
+            if (pick < 0 || o->dimid_att < s.o[pick].dimid_att) pick = i;
+        }
+        if (pick < 0) break;
+        Obj *o = &s.o[pick];
+        o->dim_index = nd;
+        snprintf(dims[nd].name, sizeof dims[nd].name, "%s", o->name);
+        dlen[nd] = o->ext[0];
+        const int is_unlim = o->maxext[0] == H5S_UNLIMITED;
+        if (is_unlim && *unlim < 0) { *unlim = nd; *numrecs = o->ext[0]; dims[nd].len = 0; }
+        else dims[nd].len = o->ext[0];
+        ++nd;
+    }
+    /* variables */
+    const size_t nobj = s.n > 0 ? (size_t)s.n : 1;
+    Var *vars = (Var *)calloc(nobj, sizeof(Var));
+    hid_t *dset = (hid_t *)calloc(nobj, sizeof(hid_t));
+    int nv = 0, nphony = 0;
+    for (int i = 0; i < s.n; ++i) {
+        Obj *o = &s.o[i];
+        if (o->is_scale && o->dim_only) { H5Dclose(o->id); continue; }
+        hid_t t = H5Dget_type(o->id);
+        const int xtype = nc_type_of(t);
+        H5Tclose(t);
+        if (!xtype) { H5Dclose(o->id); continue; }               /* strings, compounds, ...: not carried */
+        Var *v = &vars[nv];
+        const char *nm = o->name;
+        if (!strncmp(nm, kNonCoord, strlen(kNonCoord))) nm += strlen(kNonCoord);
+        snprintf(v->name, sizeof v->name, "%s", nm);
+        v->type = xtype;
+        v->ndims = o->rank;
+        int have = 0;
+        if (o->rank > 0 && H5Aexists(o->id, "DIMENSION_LIST") > 0) {
+            hid_t a = H5Aopen(o->id, "DIMENSION_LIST", H5P_DEFAULT);
+            hid_t at = H5Aget_type(a), asp = H5Aget_space(a);
+            hvl_t *vl = (hvl_t *)calloc((size_t)o->rank, sizeof *vl);
+            if (H5Sget_simple_extent_npoints(asp) == o->rank && H5Aread(a, at, vl) >= 0) {
+                have = 1;
+                for (int r = 0; r < o->rank; ++r) {
+                    int di = -1;
+                    if (vl[r].len >= 1 && vl[r].p) {
+                        hobj_ref_t ref = ((hobj_ref_t *)vl[r].p)[0];
+                        hid_t so = H5Rdereference2(o->id, H5P_DEFAULT, H5R_OBJECT, &ref);
+                        if (so >= 0) {
+                            char full[NCC_MAX_NAME + 2];
+                            if (H5Iget_name(so, full, sizeof full) > 0) {
+                                const char *base = strrchr(full, '/');
+                                di = find_dim(dims, nd, base ? base + 1 : full);
+                            }
+                            H5Oclose(so);
+                        }
+                    }
+                    if (di < 0) have = 0;
+                    v->dimids[r] = di;
+                }
+                H5Dvlen_reclaim(at, asp, H5P_DEFAULT, vl);
+            }
+            free(vl);
+            H5Sclose(asp); H5Tclose(at); H5Aclose(a);
+        }
+        if (!have && o->is_scale && o->rank == 1 && o->dim_index >= 0) { v->dimids[0] = o->dim_index; have = 1; }
+        if (!have && o->rank > 0) {                              /* plain HDF5 dataset: anonymous dimensions by extent */
+            for (int r = 0; r < o->rank; ++r) {
+                int di = -1;
+                for (int k = 0; k < nd; ++k)
+                    if (!strncmp(dims[k].name, "phony_dim_", 10) && dlen[k] == o->ext[r]) { di = k; break; }
+                if (di < 0) {
+                    di = nd++;
+                    snprintf(dims[di].name, sizeof dims[di].name, "phony_dim_%d", nphony++);
+                    dims[di].len = dlen[di] = o->ext[r];
+                }
+                v->dimids[r] = di;
+            }
+        }
+        v->isrec = (o->rank > 0 && v->dimids[0] == *unlim);
+        read_atts(o->id, &v->atts, &v->natts);
+        dset[nv] = o->id;
+        ++nv;
+    }
+    hid_t root = H5Gopen2(file, "/", H5P_DEFAULT);
+    *gatts = NULL; *ngatts = 0;
+    if (root >= 0) { read_atts(root, gatts, ngatts); H5Gclose(root); }
+    free(s.o);
+    free(dlen);
+    NcH5 *h = (NcH5 *)calloc(1, sizeof *h);
+    h->file = file; h->nvars = nv; h->dset = dset;
+    *hout = h; *ndims = nd; *dims_out = dims; *nvars = nv; *vars_out = vars;
+    return 0;
+}
+
+int nch5_get_vara(NcH5 *h, int varid, int nd, const uint64_t *start, const uint64_t *count, int memtype, void *data) {
+    if (!h || varid < 0 || varid >= h->nvars) return NCC_ENOTVAR;
+    const hid_t mt = mem_type(memtype);
+    if (mt < 0) return NCC_EBADTYPE;
+    const hid_t d = h->dset[varid];
+    hid_t fs = H5Dget_space(d);
+    if (fs < 0) return NCC_EHDFERR;
+    int rc = 0;
+    if (H5Sget_simple_extent_ndims(fs) != nd) rc = NCC_EINVALCOORDS;
+    if (!rc && nd == 0) {
+        if (H5Dread(d, mt, H5S_ALL, H5S_ALL, H5P_DEFAULT, data) < 0) rc = NCC_EHDFERR;
+    } else if (!rc) {
+        hsize_t st[NCC_MAX_DIMS], ct[NCC_MAX_DIMS], ext[NCC_MAX_DIMS];
+        H5Sget_simple_extent_dims(fs, ext, NULL);
+        for (int i = 0; i < nd; ++i) {
+            st[i] = start[i]; ct[i] = count[i];
+            if (st[i] + ct[i] > ext[i]) rc = NCC_EEDGE;          /* a variable shorter than its unlimited dimension */
+        }
+        if (!rc) {
+            hid_t ms = H5Screate_simple(nd, ct, NULL);
+            if (ms < 0 || H5Sselect_hyperslab(fs, H5S_SELECT_SET, st, NULL, ct, NULL) < 0 ||
+                H5Dread(d, mt, ms, fs, H5P_DEFAULT, data) < 0)
+                rc = NCC_EHDFERR;
+            if (ms >= 0) H5Sclose(ms);
+        }
+    }
+    H5Sclose(fs);
+    return rc;
+}
+
+void nch5_close(NcH5 *h) {
+    if (!h) return;
+    for (int i = 0; i < h->nvars; ++i) H5Dclose(h->dset[i]);
+    H5Fclose(h->file);
+    free(h->dset);
+    free(h);
+}

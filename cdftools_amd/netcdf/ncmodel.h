@@ -1,0 +1,41 @@
+/*
+ * ncmodel.h -- the in-memory description of an open file, shared by the classic reader/writer
+ * (ncclassic.c) and the NetCDF-4/HDF5 read plug-in (nch5.c).  Internal: not part of the API.
+ */
+#ifndef NCMODEL_H
+#define NCMODEL_H
+#include <stdint.h>
+#include "ncclassic.h"
+
+typedef struct {
+    char name[NCC_MAX_NAME];
+    int type;
+    size_t nelems;
+    void *data; /* native byte order, packed array of `type` */
+} Att;
+
+typedef struct {
+    char name[NCC_MAX_NAME];
+    uint64_t len; /* 0 = unlimited */
+} Dim;
+
+typedef struct {
+    char name[NCC_MAX_NAME];
+    int ndims, dimids[NCC_MAX_DIMS];
+    int natts;
+    Att *atts;
+    int type, isrec;
+    uint64_t vsize, begin;
+} Var;
+
+/* What the HDF5 plug-in (libnch5.so, loaded on the first NetCDF-4 file) exports.  nch5_open fills malloc'ed
+ * arrays that the caller frees like its own; *unlim is the id of the (first) unlimited dimension or -1 and
+ * *numrecs its current length. */
+typedef struct NcH5 NcH5;
+typedef int (*nch5_open_fn)(const char *path, NcH5 **h, int *ndims, Dim **dims, int *nvars, Var **vars, int *ngatts,
+                            Att **gatts, int *unlim, uint64_t *numrecs);
+typedef int (*nch5_get_vara_fn)(NcH5 *h, int varid, int nd, const uint64_t *start, const uint64_t *count, int memtype,
+                                void *data);
+typedef void (*nch5_close_fn)(NcH5 *h);
+
+#endif
