@@ -8,7 +8,8 @@ PROGRAM cdfmean
   !! cdfmean.txt [cdfvar.txt, cdfsum.txt], same cdfmean.nc (mean_<var>, mean_3D<var> [var_, var_3D, sum_,
   !! sum_3D] [_<basin>], :556-625).  The four weighted sums of every level and basin (:405-424) run on the
   !! GPU for all levels of a record at once (cdft_mean_*: r4 products as written, r8 sums).
-  !! -zeromean (a second pass that rewrites the whole field, :500-527) is not carried: explicit STOP 99.
+  !! -zeromean (:490-527) is a second, pointwise pass over the whole field that is bound by reading and writing the
+  !! file: it stays on the host, as in the reference.
   !!======================================================================
   USE ISO_C_BINDING
   USE cdfio
@@ -68,7 +69,8 @@ PROGRAM cdfmean
      PRINT *, '       [-o OUT-file] [-ot OUTASCII-file] [-ov VAR-file] [-os SUM-file] : output names instead of'
      PRINT *, '              ', TRIM(cf_ncout), ' ', TRIM(cf_out), ' ', TRIM(cf_var), ' ', TRIM(cf_sum)
      PRINT *, '       [-vvl ] : time-varying vertical metrics.'
-     PRINT *, '       [-zeromean ] [-oz ZEROMEAN-file] : accepted for compatibility, not available in this build.'
+     PRINT *, '       [-zeromean ] : also write the field minus its 3-D mean (per basin), masked, to ', TRIM(cf_zerom)
+     PRINT *, '       [-oz ZEROMEAN-file] : name of that file'
      PRINT *, '      '
      PRINT *, '     REQUIRED FILES :'
      PRINT *, '       Files ', TRIM(cn_fhgr), ', ', TRIM(cn_fzgr), ', ', TRIM(cn_fmsk)
@@ -112,6 +114,7 @@ PROGRAM cdfmean
   cf_out   = TRIM(cl_prefix)//TRIM(cf_out  )
   cf_var   = TRIM(cl_prefix)//TRIM(cf_var  )
   cf_sum   = TRIM(cl_prefix)//TRIM(cf_sum  )
+  cf_zerom = TRIM(cl_prefix)//TRIM(cf_zerom)
 
   lchk = chkfile(cn_fhgr)
   lchk = chkfile(cn_fzgr) .OR. lchk
@@ -119,10 +122,6 @@ PROGRAM cdfmean
   lchk = chkfile(cf_in  ) .OR. lchk
   IF ( lbas ) lchk = chkfile(cn_fbasins) .OR. lchk
   IF ( lchk ) STOP 99
-  IF ( lzeromean ) THEN
-     PRINT *, ' ERROR : option -zeromean is not available in the MI355X build of cdfmean.'
-     STOP 99
-  ENDIF
   IF ( .NOT. ALLOCATED(cbasins) ) ALLOCATE( cbasins(1) )
 
   cv_dep = 'none'
@@ -305,6 +304,10 @@ PROGRAM cdfmean
   ierr = closeout(ncout)
 9004 FORMAT(f9.2,' ',i2,' ',f9.2)
 
+  ! -zeromean (:490-527): the field of the WHOLE domain minus the 3-D mean found above (possibly that of a window),
+  ! times the masks, level by level into zeromean.nc -- a read-modify-write stream at the speed of the files
+  IF ( lzeromean ) CALL ZeroMean
+
 CONTAINS
 
   SUBROUTINE geti(kval)
@@ -362,6 +365,70 @@ CONTAINS
     dtim  = getvar1d(cf_in, cn_vtimec, npt)
     ierr  = putvar1d(ncout, dtim, npt, 'T')
   END SUBROUTINE CreateOutput
+
+  SUBROUTINE ZeroMean
+    INTEGER(KIND=4) :: ivin, ivar0, jv
+    INTEGER(KIND=4), ALLOCATABLE :: ipkz(:), id_varz(:)
+    INTEGER(KIND=2), ALLOCATABLE :: ibfull(:,:,:)
+    REAL(KIND=4),    ALLOCATABLE :: zvf(:,:), zmf(:,:), zvzm(:,:)
+    CHARACTER(LEN=256), ALLOCATABLE :: cv_names(:)
+    CHARACTER(LEN=80) :: cl_suffix
+    TYPE(variable), ALLOCATABLE :: stypvarin(:), stypvarzero(:)
+    npiglo = npiglo_fi ; npjglo = npjglo_fi
+    ALLOCATE( zvf(npiglo,npjglo), zmf(npiglo,npjglo), zvzm(npiglo,npjglo), ibfull(nbasin,npiglo,npjglo) )
+    ivin = getnvar(cf_in)
+    ALLOCATE( stypvarin(ivin), cv_names(ivin), id_varz(nbasin), ipkz(nbasin), stypvarzero(nbasin) )
+    cv_names(:) = getvarname(cf_in, ivin, stypvarin)
+    ivar0 = ivin + 1
+    DO jv = 1, ivin
+       IF ( TRIM(cv_names(jv)) == TRIM(cv_nam) ) THEN
+          ivar0 = jv ; EXIT
+       ENDIF
+    END DO
+    IF ( ivar0 > ivin ) RETURN
+    DO jbasin = 1, nbasin
+       cl_suffix = '' ; IF ( lbas ) cl_suffix = '_'//TRIM(cbasins(jbasin))
+       ipkz(jbasin)                          = nvpk
+       stypvarzero(jbasin)%cname             = TRIM(cv_nam)//TRIM(cl_suffix)
+       stypvarzero(jbasin)%cunits            = stypvarin(ivar0)%cunits
+       stypvarzero(jbasin)%rmissing_value    = stypvarin(ivar0)%rmissing_value
+       stypvarzero(jbasin)%valid_min         = stypvarin(ivar0)%valid_min - MAXVAL(dvmeanout3d)
+       stypvarzero(jbasin)%valid_max         = stypvarin(ivar0)%valid_max - MINVAL(dvmeanout3d)
+       stypvarzero(jbasin)%clong_name        = TRIM(stypvarin(ivar0)%clong_name)//TRIM(cl_suffix)//' zero mean '
+       stypvarzero(jbasin)%cshort_name       = TRIM(cv_nam)//TRIM(cl_suffix)
+       stypvarzero(jbasin)%conline_operation = 'N/A'
+       stypvarzero(jbasin)%caxis             = stypvarin(ivar0)%caxis
+       stypvarzero(jbasin)%scale_factor      = 1.
+       stypvarzero(jbasin)%add_offset        = 0.
+       stypvarzero(jbasin)%savelog10         = 0.
+    END DO
+    ik = nvpk ; IF ( lnodep ) ik = 0                         ! no depth in the input file: none in the output
+    ncout = create      (cf_zerom, cf_in, npiglo, npjglo, ik)
+    ierr  = createvar   (ncout, stypvarzero, nbasin, ipkz, id_varz)
+    ierr  = putheadervar(ncout, cf_in, npiglo, npjglo, ik, pdep=zdep)
+    dtim  = getvar1d(cf_in, cn_vtimec, npt)
+    ierr  = putvar1d(ncout, dtim, npt, 'T')
+    IF ( lbas ) THEN
+       DO jbasin = 1, nbasin
+          zvf(:,:) = getvar(cn_fbasins, cbasins(jbasin), 1, npiglo, npjglo)
+          ibfull(jbasin,:,:) = INT(zvf(:,:), 2)
+       END DO
+    ELSE
+       ibfull(1,:,:) = 1
+    ENDIF
+    DO jt = 1, npt
+       DO jk = 1, nvpk
+          ik = jk + ikmin - 1
+          zvf(:,:) = getvar(cf_in,   cv_nam, ik, npiglo, npjglo, ktime=jt)
+          zmf(:,:) = getvar(cn_fmsk, cv_msk, ik, npiglo, npjglo)
+          DO jbasin = 1, nbasin
+             zvzm(:,:) = (zvf(:,:) - dvmeanout3d(jbasin,jt)) * zmf(:,:) * ibfull(jbasin,:,:)
+             ierr = putvar(ncout, id_varz(jbasin), zvzm, ik, npiglo, npjglo, ktime=jt)
+          END DO
+       END DO
+    END DO
+    ierr = closeout(ncout)
+  END SUBROUTINE ZeroMean
 
   SUBROUTINE defvar(kv, kpk, cd_pre, cd_units, cd_axis, cd_suffix)
     INTEGER(KIND=4),  INTENT(in) :: kv, kpk

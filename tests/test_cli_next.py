@@ -201,8 +201,22 @@ def test_cdfmean_end_to_end(tools, tmp_path):  # noqa: F811
     s = oracle_tools.mean(g["e1v"], g["e2v"], g["umask"].astype(np.float32), one, rec["v"][1], e3=g["e3v_0"])[:, 0, :]
     good = s[:, 1] != 0
     assert np.allclose(var["mean_vomecrty"][1].ravel()[good], (s[:, 2] / np.where(good, s[:, 1], 1))[good], rtol=5e-6, atol=1e-9)
-    rc, out, _ = run("cdfmean", ["-f", "SYN_y0001_gridT.nc", "-v", "votemper", "-p", "T", "-zeromean"], d)
-    assert rc == 99 and "-zeromean" in out
+    # -zeromean: the field minus the 3-D mean of each record, masked, for the global domain and per basin
+    rc, out, err = run("cdfmean", ["-f", "SYN_y0001_gridT.nc", "-v", "votemper", "-p", "T", "-zeromean", "-oz", "zm.nc",
+                                   "-B", "new_maskglo.nc", "tmaskatl", "tmaskind", "-o", "mz.nc"], d)
+    assert rc == 0, out + err
+    var, att, dims = nc("zm.nc")
+    mvar, _, _ = nc("mz.nc")
+    assert dims["x"] == npi and dims["y"] == npj and dims["deptht"] == npk
+    for nm in ("tmaskatl", "tmaskind"):
+        ibm = g[nm].astype(np.float64)
+        for t in range(2):
+            s = oracle_tools.mean(g["e1t"], g["e2t"], tm, g[nm][:, :, None].astype(np.int16), rec["t"][t], e3=g["e3t_0"])[:, 0, :]
+            m3 = s[:, 2].sum() / s[:, 1].sum()
+            assert np.allclose(mvar["mean_3Dvotemper_" + nm][t].ravel(), m3, rtol=2e-7)
+            want = ((rec["t"][t].astype(np.float64) - m3) * tm * ibm[None]).astype(np.float32)
+            assert np.allclose(var["votemper_" + nm][t], want, rtol=0, atol=4e-6), nm
+            assert np.abs(var["votemper_" + nm][t]).max() > 1
     rc, out, _ = run("cdfmean", ["-f", "SYN_y0001_gridT.nc", "-v", "votemper", "-p", "Q"], d)
     assert rc == 99 and "not known" in out
 
