@@ -62,6 +62,7 @@ struct EosArgs {
 template <int EOS, bool FAST>
 __device__ __forceinline__ double eval_point(float t, float s, float p) {
     if (EOS == 2) return jmd94_point(t, s, p);
+    if (EOS == 3) return sigmantr_point(t, s);                     // neutral density: no reference depth, no mask
     return sigmai_point<(EOS == 1 ? 1 : 0), FAST>(t, s, p);
 }
 
@@ -146,6 +147,7 @@ int launch_eos(const EosArgs &a, int eos, int flags, hipStream_t st) {
         case CDFT_EOS_80:     return fast ? launch_kind<0, true, KIND>(a, st) : launch_kind<0, false, KIND>(a, st);
         case CDFT_EOS_TEOS10: return fast ? launch_kind<1, true, KIND>(a, st) : launch_kind<1, false, KIND>(a, st);
         case CDFT_EOS_JMD94:  return launch_kind<2, false, KIND>(a, st);
+        case CDFT_EOS_NTR:    return launch_kind<3, false, KIND>(a, st);
         default: return fail(CDFT_ERR_ARG, "unknown equation of state %d", eos);
     }
 }

@@ -61,4 +61,27 @@ __device__ __forceinline__ double sigmai_point(float ptem, float psal, float pre
     return __dmul_rn(__dadd_rn(__dadd_rn(r, ref), -CDFT_EOS_RAU0), tm);            // :880
 }
 
+// Neutral density of McDougall and Jackett (2005) as src/eos.f90:634-687 writes it: every product and sum in r8, in
+// the written order (no contraction); rho - 1000, not masked.  rho(20,35) - 1000 = 24.59416751197 (:646).
+__device__ __forceinline__ double sigmantr_point(float ptem, float psal) {
+    const double t = (double)ptem, s = (double)psal, sr = __dsqrt_rn(fabs(s));
+    auto mul = [](double a, double b) { return __dmul_rn(a, b); };
+    auto add = [](double a, double b) { return __dadd_rn(a, b); };
+    const double r1 = add(mul(add(mul(add(mul(-4.3159255086706703e-4, t), 8.1157118782170051e-2), t), 2.2280832068441331e-1), t),
+                          1002.3063688892480);
+    const double r2 = mul(add(add(mul(-1.7052298331414675e-7, s), -mul(3.1710675488863952e-3, t)), -1.0304537539692924e-4), s);
+    const double r3 = add(mul(add(mul(add(mul(add(mul(-2.3850178558212048e-9, t), -1.6212552470310961e-7), t), 7.8717799560577725e-5), t),
+                                  4.3907692647825900e-5), t), 1.0);
+    const double r4 = mul(add(mul(add(mul(mul(-2.2744455733317707e-9, t), t), 6.0399864718597388e-6), t), -5.1268124398160734e-4), s);
+    const double r5 = mul(mul(add(mul(mul(-1.3409379420216683e-9, t), t), -3.6138532339703262e-5), s), sr);
+    return add(__ddiv_rn(add(r1, r2), add(add(r3, r4), r5)), -1000.0);
+}
+
+// the density cdfmocsig bins: sigmai (KIND 0 EOS-80, 1 TEOS-10) or the neutral density (KIND 2, -ntr)
+template <int KIND>
+__device__ __forceinline__ double mocsig_density(float t, float s, float pref) {
+    if constexpr (KIND == 2) return sigmantr_point(t, s);
+    else return sigmai_point<KIND, false>(t, s, pref);
+}
+
 }  // namespace

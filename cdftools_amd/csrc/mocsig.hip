@@ -49,7 +49,7 @@ __global__ void mocsig_row_kernel(SigArgs a) {
                 const float ez = a.e3v ? ld_stream(a.e3v + e) : e31;
                 const float zarea = __fmul_rn(a.e1v[p], ez);                               // :389
                 const int itm = (s == a.zsps) ? 0 : 1;                                     // :392-393
-                const double dens = sigmai_point<TEOS, false>(t, s, a.pref);               // :395
+                const double dens = mocsig_density<TEOS>(t, s, a.pref);                    // :395
                 const float zttmp = (float)__dmul_rn(dens, (double)itm);                   // :398
                 int ibin = (int)__fdiv_rn(__fsub_rn(zttmp, a.sigmin), a.sigstp);           // :400
                 ibin = min(max(ibin, 1), a.nbins) - 1;                                     // :401-402
@@ -168,7 +168,7 @@ __global__ void __launch_bounds__(T) mocsig_class_kernel(SigArgs a, SigClassArgs
                     if (s == a.zsps) s = 0.f;                                                  // :383
                     const float zarea = __fmul_rn(e1[r][c], e4[c]);                            // :389
                     const int itm = (s == a.zsps) ? 0 : 1;                                     // :392-393
-                    const double dens = sigmai_point<TEOS, false>(t, s, a.pref);               // :395
+                    const double dens = mocsig_density<TEOS>(t, s, a.pref);                    // :395
                     const float zttmp = (float)__dmul_rn(dens, (double)itm);                   // :398
                     int ibin = (int)__fdiv_rn(__fsub_rn(zttmp, a.sigmin), a.sigstp);           // :400
                     ibin = min(max(ibin, 1), a.nbins) - 1;                                     // :401-402
@@ -237,19 +237,21 @@ __global__ void sig_cls_kernel(uint8_t *__restrict__ bits, int64_t nij, const ui
 
 constexpr int kSigT = 256;
 
-template <int NV>
-int launch_sig_class(const SigArgs &a, const SigClassArgs &ca, int eos, size_t shmem, hipStream_t st) {
-    if (eos == CDFT_EOS_TEOS10) {
-        if (shmem > 64 * 1024)
-            CDFT_HIP(hipFuncSetAttribute((const void *)mocsig_class_kernel<NV, 1, kSigT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        hipLaunchKernelGGL((mocsig_class_kernel<NV, 1, kSigT>), dim3(a.npj), dim3(kSigT), shmem, st, a, ca);
-    } else {
-        if (shmem > 64 * 1024)
-            CDFT_HIP(hipFuncSetAttribute((const void *)mocsig_class_kernel<NV, 0, kSigT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        hipLaunchKernelGGL((mocsig_class_kernel<NV, 0, kSigT>), dim3(a.npj), dim3(kSigT), shmem, st, a, ca);
-    }
+template <int NV, int KIND>
+int launch_sig_class_kind(const SigArgs &a, const SigClassArgs &ca, size_t shmem, hipStream_t st) {
+    if (shmem > 64 * 1024)
+        CDFT_HIP(hipFuncSetAttribute((const void *)mocsig_class_kernel<NV, KIND, kSigT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)shmem));
+    hipLaunchKernelGGL((mocsig_class_kernel<NV, KIND, kSigT>), dim3(a.npj), dim3(kSigT), shmem, st, a, ca);
     CDFT_LAUNCH_CHECK();
     return CDFT_OK;
+}
+
+template <int NV>
+int launch_sig_class(const SigArgs &a, const SigClassArgs &ca, int eos, size_t shmem, hipStream_t st) {
+    if (eos == CDFT_EOS_TEOS10) return launch_sig_class_kind<NV, 1>(a, ca, shmem, st);
+    if (eos == CDFT_EOS_NTR)    return launch_sig_class_kind<NV, 2>(a, ca, shmem, st);
+    return launch_sig_class_kind<NV, 0>(a, ca, shmem, st);
 }
 
 }  // namespace
@@ -266,7 +268,8 @@ int cdft_mocsig_compute(const float *zv, const float *zveiv, const float *zt, co
         return fail(CDFT_ERR_ARG, "cdft_mocsig_compute: bad sizes or binning (%d x %d x %d, %d basins, %d bins)", npiglo, npjglo,
                     npk, nbasins, nbins);
     if (depi && !gdep) return fail(CDFT_ERR_ARG, "cdft_mocsig_compute: -isodep needs gdep");
-    if (eos != CDFT_EOS_80 && eos != CDFT_EOS_TEOS10) return fail(CDFT_ERR_ARG, "cdft_mocsig_compute: eos must be CDFT_EOS_80 or CDFT_EOS_TEOS10");
+    if (eos != CDFT_EOS_80 && eos != CDFT_EOS_TEOS10 && eos != CDFT_EOS_NTR)
+        return fail(CDFT_ERR_ARG, "cdft_mocsig_compute: eos must be CDFT_EOS_80, CDFT_EOS_TEOS10 or CDFT_EOS_NTR");
     CDFT_TRY(require_device());
     hipStream_t st = as_stream(stream);
     const size_t nij = (size_t)npiglo * npjglo, n3 = nij * npk;
@@ -345,6 +348,9 @@ int cdft_mocsig_compute(const float *zv, const float *zveiv, const float *zt, co
     if (eos == CDFT_EOS_TEOS10) {
         if (depi) hipLaunchKernelGGL((mocsig_row_kernel<1, true>), grid, block, shmem, st, a);
         else      hipLaunchKernelGGL((mocsig_row_kernel<1, false>), grid, block, shmem, st, a);
+    } else if (eos == CDFT_EOS_NTR) {
+        if (depi) hipLaunchKernelGGL((mocsig_row_kernel<2, true>), grid, block, shmem, st, a);
+        else      hipLaunchKernelGGL((mocsig_row_kernel<2, false>), grid, block, shmem, st, a);
     } else {
         if (depi) hipLaunchKernelGGL((mocsig_row_kernel<0, true>), grid, block, shmem, st, a);
         else      hipLaunchKernelGGL((mocsig_row_kernel<0, false>), grid, block, shmem, st, a);

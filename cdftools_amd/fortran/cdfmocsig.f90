@@ -6,7 +6,7 @@ PROGRAM cdfmocsig
   !! Drop-in for the reference tool (src/cdfmocsig.f90): same options, same mocsig.nc (x=1, y, sigma, time;
   !! zomsfglo [atl inp ind pac] [zoisoglo ...] float, Sverdrup / m, :490-586).  The level loop, the density
   !! binning, the zonal sums and the cumulation over the density classes (:368-470) run on the GPU for a whole
-  !! record at once (cdft_mocsig_compute).  -ntr (neutral density) is not carried: explicit STOP 99.
+  !! record at once (cdft_mocsig_compute); -ntr bins the neutral density (CDFT_EOS_NTR) the same way.
   !!======================================================================
   USE ISO_C_BINDING
   USE cdfio
@@ -30,6 +30,7 @@ PROGRAM cdfmocsig
   TYPE(C_PTR) :: pe3, pe31d, peiv, pgdep, pdepi
   LOGICAL :: lfull = .FALSE., lchk = .FALSE., lbas, lbin(3), lisodep = .FALSE., lprint = .FALSE., leiv = .FALSE.
   LOGICAL :: lntr = .FALSE., ll_teos10 = .FALSE.
+  INTEGER(C_INT) :: ieos
   !!----------------------------------------------------------------------
   CALL ReadCdfNames()
   narg = COMMAND_ARGUMENT_COUNT()
@@ -48,7 +49,7 @@ PROGRAM cdfmocsig
      PRINT *, '        -t T-file  : Netcdf gridT file with temperature and salinity (else -s).'
      PRINT *, '        -r ref-depth : reference depth for density; 0, 1000 and 2000 m have pre-defined classes,'
      PRINT *, '            other depths need -sigmin, -sigstp and -nbins.'
-     PRINT *, '        or -ntr : neutral density; not available in this build.'
+     PRINT *, '        or -ntr : neutral density (McDougall and Jackett, 2005) instead of a reference depth.'
      PRINT *, '      '
      PRINT *, '     OPTIONS :'
      PRINT *, '       [-s S-file   ] : salinity file if not T-file.'
@@ -102,11 +103,9 @@ PROGRAM cdfmocsig
   CALL eos_init( ll_teos10 )
   IF ( ii /= 3 ) THEN ; PRINT *, ' ERROR : mandatory arguments missing, see usage please !' ; STOP 99
   ENDIF
-  IF ( lntr ) THEN
-     PRINT *, ' ERROR : option -ntr (neutral density) is not available in the MI355X build of cdfmocsig.'
-     STOP 99
-  ENDIF
   IF ( cf_sfil == 'none' ) cf_sfil = cf_tfil
+  ieos = MERGE(CDFT_EOS_TEOS10, CDFT_EOS_80, ll_teos10)
+  IF ( lntr ) ieos = CDFT_EOS_NTR
   lchk = lchk .OR. chkfile(cn_fhgr)
   lchk = lchk .OR. chkfile(cn_fzgr)
   lchk = lchk .OR. chkfile(cn_fmsk)
@@ -140,7 +139,9 @@ PROGRAM cdfmocsig
   ELSE                ; nvaro =     nbasins
   ENDIF
   ALLOCATE( stypvar(nvaro), ipk(nvaro), id_varout(nvaro) )
-  IF ( lchk ) THEN                                          ! default classes of the reference depth (:282-318)
+  IF ( lchk .AND. lntr ) THEN                               ! (:267-270, "to be confirmed": sigmantr is rho - 1000)
+     nbins = 52 ; sigmin = 1023. ; sigstp = 0.1
+  ELSE IF ( lchk ) THEN                                     ! default classes of the reference depth (:282-318)
      SELECT CASE ( INT(pref) )
      CASE ( 0 )    ; nbins = 52  ; sigmin = 23. ; sigstp = 0.1
      CASE ( 1000 ) ; nbins = 88  ; sigmin = 24. ; sigstp = 0.1
@@ -152,7 +153,9 @@ PROGRAM cdfmocsig
         STOP 99
      END SELECT
   ENDIF
-  PRINT '(a,f6.1,a)', '  For reference depth ', pref, ' m, '
+  IF ( lntr ) THEN ; PRINT '(a)',         '  For Neutral density MOC'
+  ELSE             ; PRINT '(a,f6.1,a)', '  For reference depth ', pref, ' m, '
+  ENDIF
   PRINT '(a,f5.2,a,f5.2,a,i3)', '  You are using -sigmin ', sigmin, ' -sigstp ', sigstp, ' -nbins ', nbins
   ALLOCATE( sigma(nbins) )
   DO ji = 1, nbins
@@ -212,7 +215,7 @@ PROGRAM cdfmocsig
      ENDIF
      IF ( lisodep ) THEN ; pgdep = C_LOC(gdep) ; pdepi = C_LOC(depi) ; ENDIF
      CALL hip_check(cdft_mocsig_compute(zv, peiv, zt, zs, e1v, pe3, pe31d, ibmask, pgdep, npiglo, npjglo, npk, nbasins, zspv, zspt, &
-          &         zsps, pref, MERGE(CDFT_EOS_TEOS10, CDFT_EOS_80, ll_teos10), nbins, sigmin, sigstp, CDFT_MEM_HOST, dmoc, pdepi,  &
+          &         zsps, pref, ieos, nbins, sigmin, sigstp, CDFT_MEM_HOST, dmoc, pdepi,  &
           &         CDFT_MEM_HOST, C_NULL_PTR), 'cdft_mocsig_compute')
      DO jbasin = 1, nbasins
         DO jbin = 1, nbins

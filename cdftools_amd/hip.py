@@ -186,7 +186,7 @@ class MocPlan:
             pass
 
 
-EOS_80, EOS_TEOS10, EOS_JMD94 = 0, 1, 2
+EOS_80, EOS_TEOS10, EOS_JMD94, EOS_NTR = 0, 1, 2, 3
 EOS_FAST_FMA = 1
 
 

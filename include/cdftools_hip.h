@@ -143,6 +143,8 @@ int cdft_moc_destroy(cdft_moc_plan *plan);
 #define CDFT_EOS_80        0   /* NEMO polynomial EOS-80  (eos_init(.FALSE.), the tools' default) */
 #define CDFT_EOS_TEOS10    1   /* NEMO polynomial TEOS-10 (eos_init(.TRUE.), -teos10)             */
 #define CDFT_EOS_JMD94     2   /* sigmai(..., ld_eos80=.TRUE.) legacy rational form               */
+#define CDFT_EOS_NTR       3   /* sigmantr: neutral density of McDougall & Jackett 2005 (src/eos.f90:634-687);
+                                * pref is ignored and the result is NOT multiplied by (psal /= 0)        */
 #define CDFT_EOS_FAST_FMA  1   /* flags: allow FMA contraction (not bit-identical: few ulp of r8)  */
 
 /* sig(n) r8 = sigmai(ptem, psal, pref): density anomaly referenced to depth pref (sigma0: pref = 0),
@@ -299,7 +301,7 @@ int cdft_column_release(void);   /* frees the staging buffers of the two calls a
  * here, :374,:382-383, with the spvals given); zveiv the eddy-induced velocity or NULL (-eiv); e1v
  * (npiglo,npjglo); e3v (npiglo,npjglo,npk) or NULL with e31d (npk) (-full); ibmask (nbasins,npiglo,npjglo)
  * i2, basin index fastest, the global one already cleared on columns 1 and npiglo (:357-358);
- * pref, eos: the density is sigmai(zt,zs,pref) (-r, -teos10; -ntr is not carried);
+ * pref, eos: the density is sigmai(zt,zs,pref) (-r, -teos10) or, with eos = CDFT_EOS_NTR, sigmantr(zt,zs) (-ntr, :395);
  * nbins, sigmin, sigstp: the density classes (:282-318).
  * dmoc (nbasins,nbins,npjglo) r8 in Sv, cumulated from the highest density class down (:463-467).
  * depi (nbasins,nbins,npjglo) r8 or NULL: -isodep, the transport-weighted mean depth of each class,

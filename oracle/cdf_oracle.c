@@ -155,6 +155,21 @@ void oracle_sigmai_jmd94(const float *ptem, const float *psal, long n, float pre
     }
 }
 
+/* Neutral density, McDougall and Jackett (2005) as the reference writes it (src/eos.f90:634-687), each
+ * product and sum in r8 in the written order; result rho - 1000, NOT masked.
+ * Check value of the reference's comment (:646): rho(20,35) - 1000 = 24.59416751197. */
+void oracle_sigmantr(const float *ptem, const float *psal, long n, double *out) {
+    for (long p = 0; p < n; ++p) {
+        const double t = (double)ptem[p], s = (double)psal[p], sr = sqrt(fabs(s));
+        const double r1 = ((-4.3159255086706703e-4 * t + 8.1157118782170051e-2) * t + 2.2280832068441331e-1) * t + 1002.3063688892480;
+        const double r2 = (-1.7052298331414675e-7 * s - 3.1710675488863952e-3 * t - 1.0304537539692924e-4) * s;
+        const double r3 = (((-2.3850178558212048e-9 * t - 1.6212552470310961e-7) * t + 7.8717799560577725e-5) * t + 4.3907692647825900e-5) * t + 1.0;
+        const double r4 = ((-2.2744455733317707e-9 * t * t + 6.0399864718597388e-6) * t - 5.1268124398160734e-4) * s;
+        const double r5 = (-1.3409379420216683e-9 * t * t - 3.6138532339703262e-5) * s * sr;
+        out[p] = (r1 + r2) / (r3 + r4 + r5) - 1000.0;
+    }
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* cdfmoc -decomp, src/cdfmoc.f90:353,:360-365 (dvbt, hdep in the main loop) and :390-517, ONE record.
  *   e1v,e1u,zcoef (npi,npj) r4; e3v (npi,npj,npk) r4 already * vmask(level); ibmask (nb,npi,npj) i2,
@@ -274,7 +289,8 @@ void oracle_mocsig(int npi, int npj, int npk, int nb, const float *zv3, const fl
             zs[p] = zs3[jk * nij + p]; if (zs[p] == zsps) zs[p] = 0.f;
             itm[p] = (zs[p] == zsps) ? 0 : 1;                                                      /* :392-393 */
         }
-        oracle_sigmai(zt, zs, (long)nij, pref, NULL, teos10, dens);
+        if (teos10 == 2) oracle_sigmantr(zt, zs, (long)nij, dens);                  /* -ntr (:395) */
+        else oracle_sigmai(zt, zs, (long)nij, pref, NULL, teos10, dens);
         for (size_t p = 0; p < nij; ++p) {
             const float zttmp = (float)(dens[p] * (double)itm[p]);                                 /* :398 */
             int ib = (int)((zttmp - sigmin) / sigstp);

@@ -51,6 +51,7 @@ void oracle_sigmai(const float *ptem, const float *psal, long n, float pref, con
 /* src/eos.f90:889-1000 (sigmai_dep_80) and :1089-1201 (sigmai_dep2d_80): Jackett-McDougall 1994 */
 void oracle_sigmai_jmd94(const float *ptem, const float *psal, long n, float pref, const float *pref2d,
                          double *sig);
+void oracle_sigmantr(const float *ptem, const float *psal, long n, double *out);   /* src/eos.f90:634-687 */
 /* callers src/cdfsig0.f90:146-152, src/cdfsigi.f90:131-137: r4 result = sigma * (S /= spval) */
 void oracle_sig_tool(const float *ptem, const float *psal, long n, float pref, float spval, int teos10,
                      float *sig4);

@@ -55,3 +55,12 @@ SUBROUTINE ref_sigmai2d_jmd94(ptem, psal, pref, kpi, kpj, dout) BIND(C, name='re
   REAL(C_DOUBLE), INTENT(out) :: dout(kpi,kpj)
   dout(:,:) = sigmai(ptem, psal, pref, kpi, kpj, .TRUE.)
 END SUBROUTINE ref_sigmai2d_jmd94
+
+SUBROUTINE ref_sigmantr(ptem, psal, kpi, kpj, dout) BIND(C, name='ref_sigmantr')
+  USE ISO_C_BINDING
+  USE eos
+  INTEGER(C_INT), VALUE :: kpi, kpj
+  REAL(C_FLOAT),  INTENT(in)  :: ptem(kpi,kpj), psal(kpi,kpj)
+  REAL(C_DOUBLE), INTENT(out) :: dout(kpi,kpj)
+  dout(:,:) = sigmantr(ptem, psal, kpi, kpj)
+END SUBROUTINE ref_sigmantr

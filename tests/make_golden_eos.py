@@ -32,6 +32,7 @@ def main():
         out[f"sigmai2000_{tag}"] = ref.sigmai(T, S, 2000.0, teos)
         out[f"sigmai3000_{tag}"] = ref.sigmai(T, S, 3000.0, teos)
         out[f"sigmai2d_{tag}"] = ref.sigmai2d(T, S, D, teos)
+    out["sigmantr"] = ref.sigmantr(T, S)
     out["sigmai2000_jmd94"] = ref.sigmai_jmd94(T, S, 2000.0)
     out["sigmai2d_jmd94"] = ref.sigmai2d_jmd94(T, S, D)
     path = os.path.join(HERE, "golden", "eos.npz")

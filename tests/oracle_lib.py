@@ -45,8 +45,8 @@ def moc_decomp(e1v, e3v, ibmask, zv, ztemp, zsal, tmask, umask, e1u, zcoef, gdep
 
 
 def mocsig(zv, zt, zs, e1v, ibmask, nbins, sigmin, sigstp, pref=0.0, teos10=False, e3v=None, e31d=None, zveiv=None, gdep=None,
-           spv=(0.0, 0.0, 0.0), isodep=False):
-    """oracle_mocsig -> dmoc (npj,nbins,nb) r8 [, depi]."""
+           spv=(0.0, 0.0, 0.0), isodep=False, ntr=False):
+    """oracle_mocsig -> dmoc (npj,nbins,nb) r8 [, depi]; ntr: neutral density instead of sigmai (-ntr)."""
     lib = load()
     f = lambda a: None if a is None else np.ascontiguousarray(a, np.float32)   # noqa: E731
     zv, zt, zs, e1v, e3v, e31d, zveiv, gdep = map(f, (zv, zt, zs, e1v, e3v, e31d, zveiv, gdep))
@@ -58,7 +58,7 @@ def mocsig(zv, zt, zs, e1v, ibmask, nbins, sigmin, sigstp, pref=0.0, teos10=Fals
     P = lambda a: None if a is None else _p(a)   # noqa: E731
     lib.oracle_mocsig(C.c_int(npi), C.c_int(npj), C.c_int(npk), C.c_int(nb), P(zv), P(zveiv), P(zt), P(zs), P(e1v), P(e3v), P(e31d),
                       P(ib), P(gdep), C.c_float(spv[0]), C.c_float(spv[1]), C.c_float(spv[2]), C.c_float(pref),
-                      C.c_int(1 if teos10 else 0), C.c_int(nbins), C.c_float(sigmin), C.c_float(sigstp), P(dmoc), P(depi))
+                      C.c_int(2 if ntr else (1 if teos10 else 0)), C.c_int(nbins), C.c_float(sigmin), C.c_float(sigstp), P(dmoc), P(depi))
     return (dmoc, depi) if isodep else dmoc
 
 
@@ -106,6 +106,15 @@ def sigmai_jmd94(ptem, psal, pref=0.0, pref2d=None):
     p2 = _f32(pref2d) if pref2d is not None else None
     lib.oracle_sigmai_jmd94(_p(t), _p(s), C.c_long(t.size), C.c_float(pref),
                             _p(p2) if p2 is not None else None, _p(out))
+    return out
+
+
+def sigmantr(ptem, psal):
+    """oracle_sigmantr: neutral density - 1000 (src/eos.f90:634-687), r8, not masked."""
+    lib = load()
+    t, s = _f32(ptem), _f32(psal)
+    out = np.empty(t.shape, np.float64)
+    lib.oracle_sigmantr(_p(t), _p(s), C.c_long(t.size), _p(out))
     return out
 
 
@@ -159,6 +168,9 @@ class RefEos:
     def sigmai(self, t, s, pref, teos10=False):
         self.init(teos10)
         return self._call(self.lib.ref_sigmai, t, s, C.c_float(pref))
+
+    def sigmantr(self, t, s):
+        return self._call(self.lib.ref_sigmantr, t, s)
 
     def sigmai2d(self, t, s, pref2d, teos10=False):
         self.init(teos10)

@@ -669,6 +669,11 @@ def test_hip_mocsig_kernels(gpu, monkeypatch, npi, npj, npk, nb, smooth, kernel)
         dev = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (v, zt, zs, e1v, ib, e3v)]
         res = gpu.mocsig(dev[0], dev[1], dev[2], dev[3], dev[4], nbins, sigmin, sigstp, pref=2000.0, e3v=dev[5])
         assert np.array_equal(res.cpu().numpy(), got, equal_nan=True)       # same kernel, same order: identical
+    # -ntr: the neutral density in the same classes
+    ref = oracle_lib.mocsig(zv, zt, zs, e1v, ib, 80, 18.0, 0.2, e3v=e3v, ntr=True)
+    bound = np.abs(oracle_lib.mocsig(np.abs(zv), zt, zs, e1v, ib, 80, 18.0, 0.2, e3v=e3v, ntr=True))
+    got = gpu.mocsig(zv, zt, zs, e1v, ib, 80, 18.0, 0.2, eos=gpu.EOS_NTR, e3v=e3v)
+    assert np.all(np.abs(got - ref) <= 1e-13 * bound.max(axis=1, keepdims=True) + 1e-300)
 
 
 @pytest.mark.gpu
@@ -693,7 +698,19 @@ def test_cdfmocsig_end_to_end(tools, tmp_path):  # noqa: F811
     assert np.abs(var["zomsfglo"]).max() > 0
     rc, out, _ = run("cdfmocsig", ["-v", "SYN_y0001_gridV.nc", "-t", "SYN_y0001_gridT.nc", "-r", "500"], d)
     assert rc == 99 and "not implemented as standard" in out
-    rc, out, _ = run("cdfmocsig", ["-v", "SYN_y0001_gridV.nc", "-t", "SYN_y0001_gridT.nc", "-ntr"], d)
-    assert rc == 99 and "-ntr" in out
+    # -ntr: the neutral density binned in classes the user gives (the reference's default ones start at 1023 while
+    # sigmantr returns rho - 1000: kept, everything then falls in the first class)
+    rc, out, err = run("cdfmocsig", ["-v", "SYN_y0001_gridV.nc", "-t", "SYN_y0001_gridT.nc", "-ntr", "-sigmin", "19", "-sigstp",
+                                     "0.25", "-nbins", "60", "-o", "ntr.nc"], d)
+    assert rc == 0 and "For Neutral density MOC" in out, out + err
+    var, _, dims = read_nc(os.path.join(d, "ntr.nc"))
+    assert dims["sigma"] == 60
+    for t in range(2):
+        ref = oracle_lib.mocsig(rec["v"][t], rec["t"][t], rec["s"][t], e1v, ib, 60, 19.0, 0.25, e3v=g["e3v_0"], ntr=True)
+        for b, nm in enumerate(names):
+            assert np.allclose(var["zomsf" + nm][t, :, :, 0], ref[:, :, b].T, rtol=0, atol=2e-7 * np.abs(ref).max()), nm
+        assert len(np.unique(np.round(ref[:, :, 0], 6))) > 20                  # spread over many classes
+    rc, out, err = run("cdfmocsig", ["-v", "SYN_y0001_gridV.nc", "-t", "SYN_y0001_gridT.nc", "-ntr", "-o", "ntr0.nc"], d)
+    assert rc == 0 and "-nbins  52" in out, out + err                        # the default classes of -ntr (:267-270)
     rc, out, _ = run("cdfmocsig", ["-v", "SYN_y0001_gridV.nc", "-t", "SYN_y0001_gridT.nc"], d)
     assert rc == 99 and "mandatory arguments missing" in out

@@ -49,6 +49,14 @@ def test_oracle_jmd94_equals_golden_reference_outputs_bitwise():
     assert np.array_equal(oracle_lib.sigmai_jmd94(T, S, 0.0, pref2d=D), GOLD["sigmai2d_jmd94"])
 
 
+def test_neutral_density_known_answer_and_golden_reference_outputs_bitwise():
+    # src/eos.f90:646  rho(20,35) = 1024.59416751197 kg/m3; sigmantr returns rho - 1000 and does not mask
+    assert abs(oracle_lib.sigmantr(np.float32([20.0]), np.float32([35.0]))[0] - 24.59416751197) < 1e-11
+    T, S = GOLD["T"], GOLD["S"]
+    got = oracle_lib.sigmantr(T, S)
+    assert np.array_equal(got, GOLD["sigmantr"]) and np.all(got[S == 0] != 0.0)
+
+
 def test_land_points_are_masked_on_salinity_zero():
     T, S = GOLD["T"], GOLD["S"]
     sig = oracle_lib.sigmai(T, S, 1000.0)
@@ -69,6 +77,7 @@ def test_oracle_equals_live_reference_on_fresh_random_fields():
         assert np.array_equal(ref.sigmai2d(T, S, D, teos), oracle_lib.sigmai(T, S, 0.0, teos, pref2d=D))
     assert np.array_equal(ref.sigmai_jmd94(T, S, 1234.5), oracle_lib.sigmai_jmd94(T, S, 1234.5))
     assert np.array_equal(ref.sigmai2d_jmd94(T, S, D), oracle_lib.sigmai_jmd94(T, S, 0.0, pref2d=D))
+    assert np.array_equal(ref.sigmantr(T, S), oracle_lib.sigmantr(T, S))
 
 
 def test_tool_form_matches_its_definition():
@@ -87,6 +96,16 @@ def fields(n, seed):
     S[rng.random(n) < 0.3] = 0
     D = (6000 * rng.random(n)).astype(np.float32)
     return T, S, D
+
+
+@pytest.mark.gpu
+def test_hip_neutral_density_equals_golden_reference_outputs_bitwise(gpu):
+    T, S = GOLD["T"], GOLD["S"]
+    assert np.array_equal(gpu.sigmai(T, S, 0.0, gpu.EOS_NTR), GOLD["sigmantr"])
+    assert np.array_equal(gpu.sigmai(T, S, 2000.0, gpu.EOS_NTR), GOLD["sigmantr"])          # no reference depth in it
+    rng = np.random.default_rng(7)
+    t, s = (-2 + 32 * rng.random(100_003)).astype(np.float32), (38 * rng.random(100_003)).astype(np.float32)
+    assert np.array_equal(gpu.sigmai(t, s, 0.0, gpu.EOS_NTR), oracle_lib.sigmantr(t, s))
 
 
 @pytest.mark.gpu
