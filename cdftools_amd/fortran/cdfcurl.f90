@@ -52,7 +52,7 @@ PROGRAM cdfcurl
      PRINT *, '       [-surf]     : single-level C-grid files (no vertical dimension)'
      PRINT *, '       [-overf]    : curl normalised by the local Coriolis parameter'
      PRINT *, '       [-nometric] : unit metrics (output ', 'curl_grid.nc', ')'
-     PRINT *, '       [-nc4]      : accepted; the bundled NetCDF backend writes classic files'
+     PRINT *, '       [-nc4]      : NetCDF-4 output with chunking and deflation (needs the HDF5 plug-in)'
      PRINT *, '       [-o OUT-file] : output file instead of ', TRIM(cf_out)
      PRINT *, '      '
      PRINT *, '     REQUIRED FILES :'

@@ -30,7 +30,7 @@ MODULE cdfio
      REAL(KIND=4)       :: add_offset = 0.
      REAL(KIND=4)       :: savelog10 = 0.
      INTEGER(KIND=4)    :: iwght = 1
-     INTEGER(KIND=4), DIMENSION(4) :: ichunk
+     INTEGER(KIND=4), DIMENSION(4) :: ichunk = 0        ! NetCDF-4 chunk sizes (x,y,z,t); 0 = the backend chooses
      CHARACTER(LEN=256) :: clong_name
      CHARACTER(LEN=256) :: cshort_name
      CHARACTER(LEN=256) :: conline_operation
@@ -671,7 +671,8 @@ CONTAINS
   INTEGER(KIND=4) FUNCTION create(cdfile, cdfilref, kx, ky, kz, cdep, cdepvar, cdlonvar, cdlatvar, ld_xycoo, ld_nc4)
     !! New 64-bit-offset file with dims x, y, [depth], time_counter(UNLIMITED) and the coordinate
     !! variables nav_lon, nav_lat, [depth], time_counter; returns its ncid (src/cdfio.F90:260-368).
-    !! ld_nc4 is accepted; with the bundled backend the file stays classic.
+    !! ld_nc4: a NetCDF-4 file (src/cdfio.F90:291-299) through the HDF5 plug-in of the bundled backend; where no
+    !! HDF5 library is found the file is classic, as with a reference built without key_netcdf4.
     CHARACTER(LEN=*),           INTENT(in) :: cdfile, cdfilref
     INTEGER(KIND=4),            INTENT(in) :: kx, ky, kz
     CHARACTER(LEN=*), OPTIONAL, INTENT(in) :: cdep, cdepvar, cdlonvar, cdlatvar
@@ -683,6 +684,9 @@ CONTAINS
     icmode = IOR(NF90_CLOBBER, NF90_64BIT_OFFSET)
     ! a slab of more than 2^32-4 bytes per record does not fit the 64-bit-offset format: use CDF-5
     IF ( REAL(kx, 8) * REAL(ky, 8) * REAL(MAX(kz, 1), 8) * 8.d0 > 4.0d9 ) icmode = IOR(NF90_CLOBBER, NF90_64BIT_DATA)
+    IF ( PRESENT(ld_nc4) ) THEN
+       IF ( ld_nc4 ) icmode = IOR(NF90_CLOBBER, NF90_NETCDF4)
+    ENDIF
     CALL ERR_HDL(NF90_CREATE(cdfile, icmode, icout))
     istatus = NF90_DEF_DIM(icout, TRIM(cn_x), kx, nid_x)
     istatus = NF90_DEF_DIM(icout, TRIM(cn_y), ky, nid_y)
@@ -735,6 +739,8 @@ CONTAINS
     CHARACTER(LEN=*), OPTIONAL,       INTENT(in   ) :: cdglobal
     LOGICAL,          OPTIONAL,       INTENT(in   ) :: ld_nc4
     INTEGER(KIND=4) :: jv, idims, istatus, iidims(4), itype
+    LOGICAL :: ll_nc4
+    ll_nc4 = .FALSE. ; IF ( PRESENT(ld_nc4) ) ll_nc4 = ld_nc4
     createvar = NF90_NOERR
     DO jv = 1, kvar
        IF ( sdtyvar(jv)%cname == 'none' ) CYCLE
@@ -758,7 +764,12 @@ CONTAINS
              itype = NF90_SHORT ; sdtyvar(jv)%cprecision = 'i2'
           ENDIF
        END SELECT
-       CALL ERR_HDL(NF90_DEF_VAR(kout, TRIM(sdtyvar(jv)%cname), itype, iidims(1:idims), kidvo(jv)))
+       IF ( ll_nc4 ) THEN                                  ! chunked and deflated (src/cdfio.F90:438-441)
+          CALL ERR_HDL(NF90_DEF_VAR(kout, TRIM(sdtyvar(jv)%cname), itype, iidims(1:idims), kidvo(jv), &
+               &                    chunksizes=sdtyvar(jv)%ichunk(1:idims), deflate_level=1))
+       ELSE
+          CALL ERR_HDL(NF90_DEF_VAR(kout, TRIM(sdtyvar(jv)%cname), itype, iidims(1:idims), kidvo(jv)))
+       ENDIF
        createvar = putatt(sdtyvar(jv), kout, kidvo(jv), cdglobal=cdglobal)
     END DO
     istatus = NF90_ENDDEF(kout)

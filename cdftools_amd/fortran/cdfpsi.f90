@@ -55,7 +55,7 @@ PROGRAM cdfpsi
      PRINT *, '       [-mean ]   : average of the U and V estimates'
      PRINT *, '       [-ref iref jref] : point where psi is set to 0 (default: upper right corner)'
      PRINT *, '       [-vvl ]    : time-varying vertical metrics'
-     PRINT *, '       [-nc4 ]    : accepted; the bundled NetCDF backend writes classic files'
+     PRINT *, '       [-nc4 ]    : NetCDF-4 output with chunking and deflation (needs the HDF5 plug-in)'
      PRINT *, '       [-o OUT-file] : output file instead of ', TRIM(cf_out)
      PRINT *, '       [-open ]   : open domain: psi is built from the row npjglo-2 (implies both components)'
      PRINT *, '       [--ssh-file SSH-file] : add the contribution of the SSH (2 more variables)'

@@ -40,7 +40,7 @@ PROGRAM cdfsigi
      PRINT *, '      '
      PRINT *, '     OPTIONS :'
      PRINT *, '       [-s S-file ]      : salinity file if it differs from T-file.'
-     PRINT *, '       [-nc4]            : accepted; the bundled NetCDF backend writes classic files.'
+     PRINT *, '       [-nc4]            : NetCDF-4 output with chunking and deflation (needs the HDF5 plug-in)'
      PRINT *, '       [-o OUT-file]     : output file instead of ', TRIM(cf_out)
      PRINT *, '       [-teos10]         : TEOS10 equation of state (CT, SA) instead of EOS80'
      PRINT *, '      '

@@ -56,7 +56,7 @@ PROGRAM cdfsum
      PRINT *, '       [-full ]:  Use full steps instead of default partial steps'
      PRINT *, '       [-vvl  ]:  use time -varying  vertical metrics'
      PRINT *, '       [-o OUT-file ] : name of the output file instead of ', TRIM(cf_out)
-     PRINT *, '       [-nc4 ] : accepted; the output stays a classic netcdf file in this build.'
+     PRINT *, '       [-nc4 ] : NetCDF-4 output with chunking and deflation (needs the HDF5 plug-in)'
      PRINT *, '       [-M MSK-file VAR-mask] : non standard mask file and variable, instead of ', TRIM(cn_fmsk)
      PRINT *, '      '
      PRINT *, '     REQUIRED FILES :'
@@ -281,8 +281,8 @@ CONTAINS
     CALL defvar(3, 'sum_3D_t', 'T')
     stypvar(3)%cunits = TRIM(clunits)//'.m3'
 
-    ncout = create      (cf_out, 'none', 1, 1, nvpk, cdep=cdep)
-    ierr  = createvar   (ncout, stypvar, 3, ipk, id_varout)
+    ncout = create      (cf_out, 'none', 1, 1, nvpk, cdep=cdep, ld_nc4=lnc4)
+    ierr  = createvar   (ncout, stypvar, 3, ipk, id_varout, ld_nc4=lnc4)
     ierr  = putheadervar(ncout, cf_in, 1, 1, npkk, pnavlon=zdumlon, pnavlat=zdumlat, pdep=gdep(ikmin:ikmax), cdep=cdep)
     dtim  = getvar1d(cf_in, cn_vtimec, npt)
     ierr  = putvar1d(ncout, dtim, npt, 'T')

@@ -45,7 +45,7 @@ PROGRAM cdfvT
      PRINT *, '      '
      PRINT *, '     OPTIONS :'
      PRINT *, '       [-o OUT-file ] : output file instead of ', TRIM(cf_out)
-     PRINT *, '       [-nc4 ]        : accepted; the bundled NetCDF backend writes classic files'
+     PRINT *, '       [-nc4 ]        : NetCDF-4 output with chunking and deflation (needs the HDF5 plug-in)'
      PRINT *, '       [-vvl ]        : time-varying vertical metrics (e3u, e3v read from the U and V files)'
      PRINT *, '       [-namT/-namU/-namV name] : variable names instead of the defaults'
      PRINT *, '      '

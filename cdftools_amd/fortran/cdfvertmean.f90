@@ -51,7 +51,7 @@ PROGRAM cdfvertmean
      PRINT *, '       [-debug ] : print some extra informations.'
      PRINT *, '       [-vvl ] : time-varying vertical metrics.'
      PRINT *, '       [-o OUT-file ] : output file instead of ', TRIM(cf_out)
-     PRINT *, '       [-nc4 ]: accepted; the bundled NetCDF backend writes classic files.'
+     PRINT *, '       [-nc4 ]: NetCDF-4 output with chunking and deflation (needs the HDF5 plug-in)'
      PRINT *, '      '
      PRINT *, '     REQUIRED FILES :'
      PRINT *, '       ', TRIM(cn_fzgr), ' and ', TRIM(cn_fmsk)

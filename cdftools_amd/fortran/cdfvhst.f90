@@ -39,7 +39,7 @@ PROGRAM cdfvhst
      PRINT *, '         [-full ] : full step computation (default is partial steps).'
      PRINT *, '         [-vvl  ] : time-varying vertical metrics.'
      PRINT *, '         [-o OUT-file ] : output file name instead of ', TRIM(cf_out)
-     PRINT *, '         [-nc4  ] : accepted; the bundled NetCDF backend writes classic files.'
+     PRINT *, '         [-nc4  ] : NetCDF-4 output with chunking and deflation (needs the HDF5 plug-in)'
      PRINT *, '      '
      PRINT *, '     REQUIRED FILES :'
      PRINT *, '         Files ', TRIM(cn_fhgr), ', ', TRIM(cn_fzgr)

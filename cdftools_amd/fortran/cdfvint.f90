@@ -55,7 +55,7 @@ PROGRAM cdfvint
      PRINT *, '        [-tmean] : output mean temperature instead of heat content'
      PRINT *, '        [-smean] : output mean salinity instead of PSU.m'
      PRINT *, '        [-o OUT-file] : output file instead of <IN-var>.nc'
-     PRINT *, '        [-nc4]  : accepted; the bundled NetCDF backend writes classic files'
+     PRINT *, '        [-nc4]  : NetCDF-4 output with chunking and deflation (needs the HDF5 plug-in)'
      PRINT *, '      '
      PRINT *, '     REQUIRED FILES :'
      PRINT *, '       ', TRIM(cn_fmsk), ', ', TRIM(cn_fhgr), ' and ', TRIM(cn_fzgr)

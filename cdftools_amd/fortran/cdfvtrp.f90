@@ -47,7 +47,7 @@ PROGRAM cdfvtrp
      PRINT *, '                bathymetry is read from ', TRIM(cn_fzgr), ' file.'
      PRINT *, '       [-vvl  ] : time-varying vertical metrics'
      PRINT *, '       [-o OUT-file  ] : output file name instead of ', TRIM(cf_out)
-     PRINT *, '       [-nc4 ]     : accepted; the bundled NetCDF backend writes classic files.'
+     PRINT *, '       [-nc4 ]     : NetCDF-4 output with chunking and deflation (needs the HDF5 plug-in)'
      PRINT *, '      '
      PRINT *, '     REQUIRED FILES :'
      PRINT *, '        ', TRIM(cn_fhgr), ' and ', TRIM(cn_fzgr)

@@ -31,7 +31,9 @@ typedef struct {
     Att *gatts;
     uint64_t *old_begin; /* begins before the current redef (NULL outside redef of a file with data) */
     uint64_t old_recsize;
-    NcH5 *h5;            /* a NetCDF-4 file, read through the HDF5 plug-in (read only) */
+    NcH5 *h5;            /* a NetCDF-4 file, read or written through the HDF5 plug-in */
+    int nc4w;            /* NetCDF-4 output: the HDF5 file is created from the model at the first enddef */
+    char path[4096];
 } File;
 
 static File g_files[MAX_FILES];
@@ -405,10 +407,24 @@ static int new_slot(void) {
     return -1;
 }
 
+static int h5_load(void);
+
 int ncc_create(const char *path, int format, int clobber, int *ncid) {
-    if (!path || !ncid || (format != 1 && format != 2 && format != 5)) return NCC_EINVAL;
+    if (!path || !ncid || (format != 1 && format != 2 && format != 3 && format != 5)) return NCC_EINVAL;
     const int s = new_slot();
     if (s < 0) return NCC_ENOMEM;
+    if (format == NCC_FORMAT_NETCDF4) {                /* the HDF5 file itself is created at the first enddef */
+        if (strlen(path) >= sizeof g_files[s].path) return NCC_EINVAL;
+        const int rc4 = h5_load();
+        if (rc4) return rc4;
+        if (!clobber && access(path, F_OK) == 0) return NCC_EEXIST;
+        File *f4 = &g_files[s];
+        memset(f4, 0, sizeof *f4);
+        f4->used = 1; f4->fd = -1; f4->format = format; f4->writable = 1; f4->indef = 1; f4->unlim = -1; f4->nc4w = 1;
+        strcpy(f4->path, path);
+        *ncid = s;
+        return 0;
+    }
     const int fd = open(path, O_RDWR | O_CREAT | (clobber ? O_TRUNC : O_EXCL), 0644);
     if (fd < 0) return errno == EEXIST ? NCC_EEXIST : NCC_ENOENT;
     File *f = &g_files[s];
@@ -423,6 +439,10 @@ int ncc_create(const char *path, int format, int clobber, int *ncid) {
 static nch5_open_fn g_h5_open;
 static nch5_get_vara_fn g_h5_get;
 static nch5_close_fn g_h5_close;
+static nch5_create_fn g_h5_create;
+static nch5_put_vara_fn g_h5_put;
+static nch5_put_atts_fn g_h5_put_atts;
+static nch5_finish_fn g_h5_finish;
 static char g_h5_msg[512] = "NetCDF: HDF5 error";
 
 static int h5_load(void) {
@@ -446,7 +466,11 @@ static int h5_load(void) {
     g_h5_open  = (nch5_open_fn)dlsym(lib, "nch5_open");
     g_h5_get   = (nch5_get_vara_fn)dlsym(lib, "nch5_get_vara");
     g_h5_close = (nch5_close_fn)dlsym(lib, "nch5_close");
-    if (!g_h5_open || !g_h5_get || !g_h5_close) {
+    g_h5_create = (nch5_create_fn)dlsym(lib, "nch5_create");
+    g_h5_put = (nch5_put_vara_fn)dlsym(lib, "nch5_put_vara");
+    g_h5_put_atts = (nch5_put_atts_fn)dlsym(lib, "nch5_put_atts");
+    g_h5_finish = (nch5_finish_fn)dlsym(lib, "nch5_finish");
+    if (!g_h5_open || !g_h5_get || !g_h5_close || !g_h5_create || !g_h5_put || !g_h5_put_atts || !g_h5_finish) {
         g_h5_open = NULL;
         snprintf(g_h5_msg, sizeof g_h5_msg, "NetCDF: %s is not the HDF5 plug-in of this build", path);
         return NCC_EHDFERR;
@@ -499,6 +523,18 @@ int ncc_enddef(int ncid) {
     File *f = getf(ncid);
     if (!f) return NCC_EBADID;
     if (!f->indef) return NCC_ENOTINDEFINE;
+    if (f->nc4w) {
+        int rc4 = 0;
+        if (!f->h5) {
+            for (int i = 0; i < f->nvars; ++i) f->vars[i].isrec = (f->vars[i].ndims > 0 && f->vars[i].dimids[0] == f->unlim);
+            rc4 = g_h5_create(f->path, &f->h5, f->ndims, f->dims, f->nvars, f->vars, f->ngatts, f->gatts, f->unlim);
+        } else {                                       /* attributes added or changed in this define mode */
+            rc4 = g_h5_put_atts(f->h5, NCC_GLOBAL, f->ngatts, f->gatts);
+            for (int i = 0; i < f->nvars && !rc4; ++i) rc4 = g_h5_put_atts(f->h5, i, f->vars[i].natts, f->vars[i].atts);
+        }
+        f->indef = 0;
+        return rc4;
+    }
     int rc = layout(f);
     if (!rc) rc = write_header(f);
     free(f->old_begin);
@@ -513,6 +549,7 @@ int ncc_redef(int ncid) {
     if (!f->writable) return NCC_EPERM;
     if (f->indef) return NCC_EINDEFINE;
     f->indef = 1;
+    if (f->nc4w) return 0;
     free(f->old_begin);
     f->old_begin = (uint64_t *)calloc(f->nvars + 1024, sizeof(uint64_t));
     for (int i = 0; i < f->nvars + 1024; ++i) f->old_begin[i] = i < f->nvars ? f->vars[i].begin : UINT64_MAX;
@@ -524,6 +561,12 @@ int ncc_close(int ncid) {
     File *f = getf(ncid);
     if (!f) return NCC_EBADID;
     int rc = 0;
+    if (f->nc4w) {
+        int rc4 = f->indef ? ncc_enddef(ncid) : 0;     /* a file that never left define mode is still created */
+        if (f->h5) { const int r2 = g_h5_finish(f->h5, f->numrecs); if (!rc4) rc4 = r2; }
+        free_file(f);
+        return rc4;
+    }
     if (f->h5) {
         g_h5_close(f->h5);
         free_file(f);
@@ -561,6 +604,7 @@ int ncc_def_dim(int ncid, const char *name, size_t len, int *dimid) {
     File *f = getf(ncid);
     if (!f) return NCC_EBADID;
     if (!f->indef) return NCC_ENOTINDEFINE;
+    if (f->nc4w && f->h5) return NCC_EPERM;            /* NetCDF-4 output: everything is defined before the first enddef */
     if (!name || strlen(name) >= NCC_MAX_NAME) return NCC_EINVAL;
     for (int i = 0; i < f->ndims; ++i) if (!strcmp(f->dims[i].name, name)) return NCC_ENAMEINUSE;
     if (len == 0 && f->unlim >= 0) return NCC_EUNLIMIT;
@@ -581,8 +625,10 @@ int ncc_def_var(int ncid, const char *name, int xtype, int ndims, const int *dim
     File *f = getf(ncid);
     if (!f) return NCC_EBADID;
     if (!f->indef) return NCC_ENOTINDEFINE;
+    if (f->nc4w && f->h5) return NCC_EPERM;
     if (!name || strlen(name) >= NCC_MAX_NAME || ndims < 0 || ndims > NCC_MAX_DIMS) return NCC_EINVAL;
-    if (tsize(xtype) == 0 || (xtype > NCC_DOUBLE && f->format != 5)) return NCC_EBADTYPE;
+    if (tsize(xtype) == 0 || (xtype > NCC_DOUBLE && f->format != 5 && !f->nc4w)) return NCC_EBADTYPE;
+    if (f->nc4w && xtype == NCC_CHAR) return NCC_EBADTYPE;       /* text variables are not written to NetCDF-4 */
     for (int i = 0; i < f->nvars; ++i) if (!strcmp(f->vars[i].name, name)) return NCC_ENAMEINUSE;
     for (int d = 0; d < ndims; ++d) {
         if (dimids[d] < 0 || dimids[d] >= f->ndims) return NCC_EBADDIM;
@@ -601,6 +647,29 @@ int ncc_def_var(int ncid, const char *name, int xtype, int ndims, const int *dim
     if (varid) *varid = f->nvars;
     f->nvars++;
     f->hdr_dirty = 1;
+    return 0;
+}
+
+/* NetCDF-4 output only (ignored for the classic formats, like a libnetcdf call on a classic file would fail) */
+int ncc_def_var_chunking(int ncid, int varid, const size_t *chunks) {
+    File *f = getf(ncid);
+    if (!f) return NCC_EBADID;
+    if (!f->indef) return NCC_ENOTINDEFINE;
+    if (varid < 0 || varid >= f->nvars) return NCC_ENOTVAR;
+    if (!f->nc4w) return 0;
+    for (int d = 0; d < f->vars[varid].ndims; ++d) f->vars[varid].chunk[d] = chunks ? chunks[d] : 0;
+    return 0;
+}
+
+int ncc_def_var_deflate(int ncid, int varid, int shuffle, int level) {
+    File *f = getf(ncid);
+    if (!f) return NCC_EBADID;
+    if (!f->indef) return NCC_ENOTINDEFINE;
+    if (varid < 0 || varid >= f->nvars) return NCC_ENOTVAR;
+    if (level < 0 || level > 9) return NCC_EINVAL;
+    if (!f->nc4w) return 0;
+    f->vars[varid].deflate = level;
+    f->vars[varid].shuffle = shuffle != 0;
     return 0;
 }
 
@@ -700,7 +769,7 @@ int ncc_put_att(int ncid, int varid, const char *name, int xtype, size_t len, in
     const int rc = att_list(f, varid, &l, &n);
     if (rc) return rc;
     Att *a = find_att(f, varid, name);
-    if (!f->indef) {   /* outside define mode an attribute may only be overwritten in place */
+    if (!f->indef && !f->nc4w) {   /* outside define mode an attribute may only be overwritten in place */
         if (!a || pad4(a->nelems * tsize(a->type)) < pad4(len * tsize(xtype))) return NCC_ENOTINDEFINE;
     }
     if (!a) {
@@ -718,6 +787,12 @@ int ncc_put_att(int ncid, int varid, const char *name, int xtype, size_t len, in
     free(a->data);
     a->data = d; a->type = xtype; a->nelems = len;
     f->hdr_dirty = 1;
+    if (f->nc4w) {                                     /* after the file exists an attribute goes straight to it */
+        if (!f->h5 || f->indef) return 0;
+        Att **l2; int *n2;
+        att_list(f, varid, &l2, &n2);
+        return g_h5_put_atts(f->h5, varid, *n2, *l2);
+    }
     if (!f->indef) return write_header(f);
     return 0;
 }
@@ -781,6 +856,12 @@ static int vara(int ncid, int varid, const size_t *start, const size_t *count, i
         total *= ct[d];
     }
     if (total == 0) return 0;
+    if (f->nc4w) {
+        if (!f->h5) return NCC_EINDEFINE;
+        const int rc4 = writing ? g_h5_put(f->h5, varid, nd, st, ct, memtype, data) : g_h5_get(f->h5, varid, nd, st, ct, memtype, data);
+        if (!rc4 && writing && v->isrec && st[0] + ct[0] > f->numrecs) f->numrecs = st[0] + ct[0];
+        return rc4;
+    }
     if (f->h5) return writing ? NCC_EPERM : g_h5_get(f->h5, varid, nd, st, ct, memtype, data);
     /* byte strides of the file layout */
     uint64_t stride[NCC_MAX_DIMS + 1];

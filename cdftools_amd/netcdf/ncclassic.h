@@ -2,7 +2,8 @@
  * ncclassic.h -- a small, self-contained reader/writer of the NetCDF classic formats
  * (CDF-1, CDF-2 "64-bit offset", CDF-5 "64-bit data"), the I/O layer under cdfio.F90.  NetCDF-4 files
  * (HDF5) are READ through an optional plug-in, libnch5.so (nch5.c, needs an HDF5 C library >= 1.10), loaded
- * when the first such file is opened; they are never written.
+ * when the first such file is opened or created; NetCDF-4 files are written whole (ncc_create ... ncc_close), an
+ * existing one cannot be opened for writing.
  *
  * Why it exists: neither the build container nor the GPU box has libnetcdf / netcdf-fortran, and
  * the CDFTOOLS programs read and write NetCDF (src/cdfio.F90 is written on the NF90 API).  The
@@ -57,6 +58,11 @@ int ncc_inq_format(int ncid, int *format);
 
 int ncc_def_dim(int ncid, const char *name, size_t len, int *dimid);   /* len 0 = unlimited */
 int ncc_def_var(int ncid, const char *name, int xtype, int ndims, const int *dimids, int *varid);
+
+/* NetCDF-4 output (ncc_create with NCC_FORMAT_NETCDF4): chunk extents, slowest dimension first (0 or out of range =
+ * chosen by the library), byte shuffle and deflate level 0..9.  No effect on the classic formats. */
+int ncc_def_var_chunking(int ncid, int varid, const size_t *chunks);
+int ncc_def_var_deflate(int ncid, int varid, int shuffle, int level);
 
 int ncc_inq(int ncid, int *ndims, int *nvars, int *ngatts, int *unlimdimid);
 int ncc_inq_dimid(int ncid, const char *name, int *dimid);

@@ -18,9 +18,15 @@
  *   - attributes: numeric arrays, and strings (fixed or variable length) as NC_CHAR; the bookkeeping
  *     attributes of the format itself are hidden.
  * Not understood: groups, user-defined / compound / enum / opaque / vlen types, string variables.
+ *
+ * Output (nch5_create ...): the same layout written from a complete model -- dimension scales made by HDF5's
+ * High-Level library (H5DSset_scale / H5DSattach_scale, as libnetcdf does), `_Netcdf4Dimid`, `_NCProperties`, creation
+ * order tracked, chunked storage with optional shuffle + deflate, an unlimited record dimension that grows with the
+ * data, fill value taken from `_FillValue`.
  */
 #define _GNU_SOURCE
 #include <hdf5.h>
+#include <hdf5_hl.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -35,6 +41,10 @@ struct NcH5 {
     hid_t file;
     int nvars;
     hid_t *dset;      /* one per variable */
+    /* output only */
+    int ndims, unlim;
+    hid_t *scale;     /* one per dimension: the coordinate variable's dataset or a dimension-only scale */
+    int *own_scale;   /* 1 when the scale is a dimension-only dataset (closed here, extended at the end) */
 };
 
 typedef struct {
@@ -397,4 +407,232 @@ void nch5_close(NcH5 *h) {
     H5Fclose(h->file);
     free(h->dset);
     free(h);
+}
+
+int nch5_finish(NcH5 *h, uint64_t numrecs);
+
+/* ---- output ------------------------------------------------------------------------------------------------ */
+static hid_t file_type(int t) {
+    switch (t) {
+        case NCC_BYTE: return H5T_STD_I8LE;
+        case NCC_UBYTE: return H5T_STD_U8LE;
+        case NCC_SHORT: return H5T_STD_I16LE;
+        case NCC_USHORT: return H5T_STD_U16LE;
+        case NCC_INT: return H5T_STD_I32LE;
+        case NCC_UINT: return H5T_STD_U32LE;
+        case NCC_INT64: return H5T_STD_I64LE;
+        case NCC_UINT64: return H5T_STD_U64LE;
+        case NCC_FLOAT: return H5T_IEEE_F32LE;
+        case NCC_DOUBLE: return H5T_IEEE_F64LE;
+        default: return -1;
+    }
+}
+
+static int write_att(hid_t obj, const Att *a) {
+    if (H5Aexists(obj, a->name) > 0) H5Adelete(obj, a->name);
+    hid_t sp, id;
+    int rc = 0;
+    if (a->type == NCC_CHAR) {                             /* as libnetcdf: a fixed-length string, scalar space */
+        hid_t at = H5Tcopy(H5T_C_S1);
+        H5Tset_size(at, a->nelems ? a->nelems : 1);
+        H5Tset_strpad(at, H5T_STR_NULLTERM);
+        sp = H5Screate(H5S_SCALAR);
+        id = H5Acreate2(obj, a->name, at, sp, H5P_DEFAULT, H5P_DEFAULT);
+        if (id < 0 || H5Awrite(id, at, a->nelems ? a->data : "") < 0) rc = NCC_EHDFERR;
+        H5Tclose(at);
+    } else {
+        hsize_t n = a->nelems;
+        if (file_type(a->type) < 0 || n == 0) return 0;
+        sp = H5Screate_simple(1, &n, NULL);
+        id = H5Acreate2(obj, a->name, file_type(a->type), sp, H5P_DEFAULT, H5P_DEFAULT);
+        if (id < 0 || H5Awrite(id, mem_type(a->type), a->data) < 0) rc = NCC_EHDFERR;
+    }
+    if (id >= 0) H5Aclose(id);
+    H5Sclose(sp);
+    return rc;
+}
+
+int nch5_put_atts(NcH5 *h, int varid, int natts, const Att *atts) {
+    if (!h) return NCC_EBADID;
+    hid_t obj, root = -1;
+    if (varid == NCC_GLOBAL) obj = root = H5Gopen2(h->file, "/", H5P_DEFAULT);
+    else if (varid >= 0 && varid < h->nvars) obj = h->dset[varid];
+    else return NCC_ENOTVAR;
+    int rc = 0;
+    for (int a = 0; a < natts && !rc; ++a) rc = write_att(obj, &atts[a]);
+    if (root >= 0) H5Gclose(root);
+    return rc;
+}
+
+int nch5_create(const char *path, NcH5 **hout, int ndims, const Dim *dims, int nvars, const Var *vars, int ngatts, const Att *gatts,
+                int unlim) {
+    H5Eset_auto2(H5E_DEFAULT, NULL, NULL);
+    hid_t fcpl = H5Pcreate(H5P_FILE_CREATE);
+    H5Pset_link_creation_order(fcpl, H5P_CRT_ORDER_TRACKED | H5P_CRT_ORDER_INDEXED);
+    H5Pset_attr_creation_order(fcpl, H5P_CRT_ORDER_TRACKED | H5P_CRT_ORDER_INDEXED);
+    hid_t file = H5Fcreate(path, H5F_ACC_TRUNC, fcpl, H5P_DEFAULT);
+    H5Pclose(fcpl);
+    if (file < 0) return NCC_EHDFERR;
+    NcH5 *h = (NcH5 *)calloc(1, sizeof *h);
+    h->file = file; h->nvars = nvars; h->ndims = ndims; h->unlim = unlim;
+    h->dset = (hid_t *)calloc((size_t)(nvars > 0 ? nvars : 1), sizeof(hid_t));
+    h->scale = (hid_t *)calloc((size_t)(ndims > 0 ? ndims : 1), sizeof(hid_t));
+    h->own_scale = (int *)calloc((size_t)(ndims > 0 ? ndims : 1), sizeof(int));
+    int rc = 0;
+    {                                                      /* what libnetcdf stamps on every file */
+        char props[128];
+        unsigned maj, min, rel;
+        H5get_libversion(&maj, &min, &rel);
+        snprintf(props, sizeof props, "version=2,cdftools_amd=1,hdf5=%u.%u.%u", maj, min, rel);
+        Att a;
+        memset(&a, 0, sizeof a);
+        strcpy(a.name, "_NCProperties"); a.type = NCC_CHAR; a.nelems = strlen(props); a.data = props;
+        hid_t root = H5Gopen2(file, "/", H5P_DEFAULT);
+        rc = write_att(root, &a);
+        for (int i = 0; i < ngatts && !rc; ++i) rc = write_att(root, &gatts[i]);
+        H5Gclose(root);
+    }
+    /* the coordinate variable of a dimension: 1-D, same name, on that dimension */
+    int *coord = (int *)calloc((size_t)(ndims > 0 ? ndims : 1), sizeof(int));
+    for (int d = 0; d < ndims; ++d) {
+        coord[d] = -1;
+        h->scale[d] = -1;
+        for (int v = 0; v < nvars; ++v)
+            if (vars[v].ndims == 1 && vars[v].dimids[0] == d && !strcmp(vars[v].name, dims[d].name)) coord[d] = v;
+    }
+    for (int v = 0; v < nvars && !rc; ++v) {
+        const Var *x = &vars[v];
+        char h5name[NCC_MAX_NAME + 16];
+        int clash = 0;
+        for (int d = 0; d < ndims; ++d) if (!strcmp(x->name, dims[d].name) && coord[d] != v) clash = 1;
+        snprintf(h5name, sizeof h5name, "%s%s", clash ? kNonCoord : "", x->name);
+        hsize_t ext[NCC_MAX_DIMS], mx[NCC_MAX_DIMS], chunk[NCC_MAX_DIMS];
+        int has_unlim = 0;
+        for (int r = 0; r < x->ndims; ++r) {
+            const int d = x->dimids[r];
+            ext[r] = dims[d].len; mx[r] = ext[r];
+            if (d == unlim) { ext[r] = 0; mx[r] = H5S_UNLIMITED; has_unlim = 1; }
+            hsize_t c = x->chunk[r];
+            if (d == unlim) c = (c >= 1 && c <= 1024) ? c : 1;
+            else if (c < 1 || c > dims[d].len) c = dims[d].len ? dims[d].len : 1;      /* unset or out of range: whole dimension */
+            chunk[r] = c;
+        }
+        if (x->ndims >= 3 && !(x->chunk[x->ndims - 1] >= 1))        /* nothing asked for: one horizontal slab per chunk */
+            for (int r = 0; r < x->ndims - 2; ++r) chunk[r] = 1;
+        hid_t sp = x->ndims ? H5Screate_simple(x->ndims, ext, mx) : H5Screate(H5S_SCALAR);
+        hid_t dcpl = H5Pcreate(H5P_DATASET_CREATE);
+        H5Pset_attr_creation_order(dcpl, H5P_CRT_ORDER_TRACKED | H5P_CRT_ORDER_INDEXED);
+        if (x->ndims && (has_unlim || x->deflate > 0 || x->chunk[x->ndims - 1] >= 1)) {
+            H5Pset_chunk(dcpl, x->ndims, chunk);
+            if (x->deflate > 0) {
+                if (x->shuffle) H5Pset_shuffle(dcpl);
+                H5Pset_deflate(dcpl, (unsigned)x->deflate);
+            }
+        }
+        for (int a = 0; a < x->natts; ++a)                  /* never-written cells read back as the fill value */
+            if (!strcmp(x->atts[a].name, "_FillValue") && x->atts[a].type == x->type && x->atts[a].nelems == 1)
+                H5Pset_fill_value(dcpl, mem_type(x->type), x->atts[a].data);
+        h->dset[v] = H5Dcreate2(file, h5name, file_type(x->type), sp, H5P_DEFAULT, dcpl, H5P_DEFAULT);
+        H5Pclose(dcpl);
+        H5Sclose(sp);
+        if (h->dset[v] < 0) { rc = NCC_EHDFERR; break; }
+        for (int a = 0; a < x->natts && !rc; ++a) rc = write_att(h->dset[v], &x->atts[a]);
+        for (int d = 0; d < ndims; ++d)
+            if (coord[d] == v) { h->scale[d] = h->dset[v]; if (H5DSset_scale(h->dset[v], NULL) < 0) rc = NCC_EHDFERR; }
+    }
+    for (int d = 0; d < ndims && !rc; ++d) {               /* dimensions without a coordinate variable */
+        if (h->scale[d] >= 0) continue;
+        hsize_t ext = (d == unlim) ? 0 : dims[d].len, mx = (d == unlim) ? H5S_UNLIMITED : ext, chunk = 512;
+        hid_t sp = H5Screate_simple(1, &ext, &mx);
+        hid_t dcpl = H5Pcreate(H5P_DATASET_CREATE);
+        if (d == unlim) H5Pset_chunk(dcpl, 1, &chunk);
+        h->scale[d] = H5Dcreate2(file, dims[d].name, H5T_IEEE_F32BE, sp, H5P_DEFAULT, dcpl, H5P_DEFAULT);
+        H5Pclose(dcpl);
+        H5Sclose(sp);
+        h->own_scale[d] = 1;
+        char nm[128];
+        snprintf(nm, sizeof nm, "%s%10d", kDimOnly, (int)dims[d].len);
+        if (h->scale[d] < 0 || H5DSset_scale(h->scale[d], nm) < 0) rc = NCC_EHDFERR;
+    }
+    for (int d = 0; d < ndims && !rc; ++d) {
+        Att a;
+        memset(&a, 0, sizeof a);
+        strcpy(a.name, "_Netcdf4Dimid"); a.type = NCC_INT; a.nelems = 1; a.data = &d;
+        rc = write_att(h->scale[d], &a);
+    }
+    for (int v = 0; v < nvars && !rc; ++v) {
+        int is_coord = 0;
+        for (int d = 0; d < ndims; ++d) if (coord[d] == v) is_coord = 1;
+        if (is_coord) continue;
+        for (int r = 0; r < vars[v].ndims; ++r)
+            if (H5DSattach_scale(h->dset[v], h->scale[vars[v].dimids[r]], (unsigned)r) < 0) rc = NCC_EHDFERR;
+    }
+    free(coord);
+    if (rc) { nch5_finish(h, 0); return rc; }
+    *hout = h;
+    return 0;
+}
+
+int nch5_put_vara(NcH5 *h, int varid, int nd, const uint64_t *start, const uint64_t *count, int memtype, const void *data) {
+    if (!h || varid < 0 || varid >= h->nvars) return NCC_ENOTVAR;
+    const hid_t mt = mem_type(memtype);
+    if (mt < 0) return NCC_EBADTYPE;
+    const hid_t d = h->dset[varid];
+    if (nd == 0) return H5Dwrite(d, mt, H5S_ALL, H5S_ALL, H5P_DEFAULT, data) < 0 ? NCC_EHDFERR : 0;
+    hid_t fs = H5Dget_space(d);
+    if (fs < 0) return NCC_EHDFERR;
+    hsize_t st[NCC_MAX_DIMS], ct[NCC_MAX_DIMS], ext[NCC_MAX_DIMS], mx[NCC_MAX_DIMS];
+    int rc = 0, grow = 0;
+    if (H5Sget_simple_extent_ndims(fs) != nd) rc = NCC_EINVALCOORDS;
+    if (!rc) {
+        H5Sget_simple_extent_dims(fs, ext, mx);
+        for (int i = 0; i < nd; ++i) {
+            st[i] = start[i]; ct[i] = count[i];
+            if (st[i] + ct[i] > ext[i]) {
+                if (mx[i] == H5S_UNLIMITED) { ext[i] = st[i] + ct[i]; grow = 1; }
+                else rc = NCC_EEDGE;
+            }
+        }
+    }
+    if (!rc && grow) {
+        H5Sclose(fs);
+        if (H5Dset_extent(d, ext) < 0) return NCC_EHDFERR;
+        fs = H5Dget_space(d);
+    }
+    if (!rc) {
+        hid_t ms = H5Screate_simple(nd, ct, NULL);
+        if (ms < 0 || H5Sselect_hyperslab(fs, H5S_SELECT_SET, st, NULL, ct, NULL) < 0 ||
+            H5Dwrite(d, mt, ms, fs, H5P_DEFAULT, data) < 0)
+            rc = NCC_EHDFERR;
+        if (ms >= 0) H5Sclose(ms);
+    }
+    H5Sclose(fs);
+    return rc;
+}
+
+int nch5_finish(NcH5 *h, uint64_t numrecs) {
+    if (!h) return 0;
+    int rc = 0;
+    /* every dataset on the record dimension gets its final length (a variable never written reads as fill values) */
+    for (int pass = 0; pass < 2; ++pass) {
+        const int n = pass ? h->ndims : h->nvars;
+        for (int i = 0; i < n; ++i) {
+            const hid_t d = pass ? (h->own_scale[i] ? h->scale[i] : -1) : h->dset[i];
+            if (d < 0) continue;
+            hid_t fs = H5Dget_space(d);
+            hsize_t ext[NCC_MAX_DIMS], mx[NCC_MAX_DIMS];
+            const int nd = H5Sget_simple_extent_ndims(fs);
+            if (nd >= 1) {
+                H5Sget_simple_extent_dims(fs, ext, mx);
+                if (mx[0] == H5S_UNLIMITED && ext[0] < numrecs) { ext[0] = numrecs; if (H5Dset_extent(d, ext) < 0) rc = NCC_EHDFERR; }
+            }
+            H5Sclose(fs);
+        }
+    }
+    for (int i = 0; i < h->nvars; ++i) if (h->dset[i] >= 0) H5Dclose(h->dset[i]);
+    for (int i = 0; i < h->ndims; ++i) if (h->own_scale[i] && h->scale[i] >= 0) H5Dclose(h->scale[i]);
+    if (H5Fclose(h->file) < 0) rc = NCC_EHDFERR;
+    free(h->dset); free(h->scale); free(h->own_scale);
+    free(h);
+    return rc;
 }

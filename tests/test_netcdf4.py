@@ -175,3 +175,36 @@ def test_programs_give_identical_results_on_netcdf4_inputs(libs, tools, tmp_path
         assert d1 == d2 and list(v1) == list(v2), tool
         for nm in v1:
             assert np.array_equal(v1[nm], v2[nm], equal_nan=True), (tool, nm)
+
+
+@pytest.mark.gpu
+def test_nc4_option_writes_netcdf4_with_the_same_content(libs, tools, tmp_path):  # noqa: F811
+    """-nc4 (src/cdfio.F90:291-299, :438-441): a NetCDF-4 file, chunked and deflated, whose content seen through the
+    reader equals the classic output of the same command; the HDF5 side is checked with h5dump where it exists."""
+    nc, w4 = libs
+    d = str(tmp_path)
+    nemo_files.make_case(d, npi=40, npj=62, npk=6, npt=3)
+    for tool, args, outfile in (("cdfsig0", ["-t", "SYN_y0001_gridT.nc"], "sig0.nc"),
+                                ("cdfvT", ["-c", "SYN", "-l", "y0001"], "vt.nc"),
+                                ("cdfsum", ["-f", "SYN_y0001_gridT.nc", "-v", "votemper", "-p", "T"], "cdfsum.nc")):
+        rc, out, err = run(tool, args + ["-o", "classic_" + outfile], d)
+        assert rc == 0, (tool, out + err)
+        rc, out, err = run(tool, args + ["-nc4", "-o", "nc4_" + outfile], d)
+        assert rc == 0, (tool, out + err)
+        p3, p4 = os.path.join(d, "classic_" + outfile), os.path.join(d, "nc4_" + outfile)
+        with open(p4, "rb") as f:
+            assert f.read(8) == b"\x89HDF\r\n\x1a\n", tool
+        a, b = model(nc, p3), model(nc, p4)
+        same_model(a, b)
+        assert a["dims"] == b["dims"] and list(a["vars"]) == list(b["vars"])
+        for k in a["gatts"]:
+            assert a["gatts"][k] == b["gatts"][k] if isinstance(a["gatts"][k], bytes) else np.array_equal(a["gatts"][k], b["gatts"][k])
+        fmt = C.c_int()
+        assert nc.ncc_inq_format(b["ncid"], C.byref(fmt)) == 0 and fmt.value == 3
+        nc.ncc_close(a["ncid"]); nc.ncc_close(b["ncid"])
+    h5dump = "/opt/conda/bin/h5dump"
+    if os.path.exists(h5dump):
+        txt = subprocess.run([h5dump, "-H", "-p", os.path.join(d, "nc4_sig0.nc")], capture_output=True, text=True).stdout
+        blk = txt[txt.index('DATASET "vosigma0"'):]
+        assert "CHUNKED ( 1, 1, 2, 40 )" in blk and "COMPRESSION DEFLATE { LEVEL 1 }" in blk       # (t,z,y/30,x)
+        assert "DIMENSION_LIST" in blk and "H5S_UNLIMITED" in blk
