@@ -10,7 +10,7 @@ MODULE cdfio
   !!   - getvar returns one (kpi,kpj) r4 slab, unpacking scale_factor / add_offset / savelog10;
   !!   - chkfile / chkvar return .TRUE. when the file / variable is MISSING;
   !!   - fatal NetCDF errors print a message and STOP 98.
-  !! Extension: getvar3d reads a whole (kpi,kpj,kpk) record in one call (what the HIP path wants).
+  !! Extension: getvar3d / readvar3d read a whole (kpi,kpj,kpk) record in one call (what the HIP path wants).
   !!======================================================================
   USE netcdf
   USE modcdfnames
@@ -61,7 +61,7 @@ MODULE cdfio
   END INTERFACE
 
   PUBLIC :: getvaratt, getnvar, getvarname, getipk
-  PUBLIC :: chkfile, chkvar, getdim, getvdim, getspval, getatt, getvar, getvar1d, getvare3, getvar3d
+  PUBLIC :: chkfile, chkvar, getdim, getvdim, getspval, getatt, getvar, getvar1d, getvare3, getvar3d, readvar3d
   PUBLIC :: create, createvar, putatt, putheadervar, putvar, putvar1d, putvar0d, closeout, ncopen, copyatt, ERR_HDL
 
 CONTAINS
@@ -555,6 +555,37 @@ CONTAINS
     IF ( llog ) WHERE ( getvar3d /= zspval ) getvar3d = 10**getvar3d
     istatus = NF90_CLOSE(incid)
   END FUNCTION getvar3d
+
+  SUBROUTINE readvar3d(cdfile, cdvar, ptab, ktime, ldiom)
+    !! getvar3d without the function result: the (kpi,kpj,kpk) record is read straight into ptab (no copy of
+    !! hundreds of MB), same unpacking.  Not in the reference's cdfio: used by the programs of this build only.
+    CHARACTER(LEN=*),          INTENT(in)  :: cdfile, cdvar
+    REAL(KIND=4), CONTIGUOUS,  INTENT(out) :: ptab(:,:,:)
+    INTEGER(KIND=4), OPTIONAL, INTENT(in)  :: ktime
+    LOGICAL,         OPTIONAL, INTENT(in)  :: ldiom
+    INTEGER(KIND=4) :: incid, id_var, istatus, itime
+    REAL(KIND=4) :: zsf, zao, zspval
+    LOGICAL :: llog, lsf, lao
+    CHARACTER(LEN=256) :: clvar
+    itime = 1 ; IF ( PRESENT(ktime) ) itime = ktime
+    clvar = cdvar
+    IF ( PRESENT(ldiom) ) THEN
+       IF ( ldiom ) clvar = iom_name(cdvar)
+    ENDIF
+    CALL ERR_HDL(NF90_OPEN(cdfile, NF90_NOWRITE, incid))
+    CALL ERR_HDL(NF90_INQ_VARID(incid, clvar, id_var))
+    CALL find_spval(incid, id_var, zspval)
+    CALL packing(incid, id_var, zsf, zao, llog, lsf, lao)
+    istatus = NF90_GET_VAR(incid, id_var, ptab, start=(/ 1, 1, 1, itime /), count=(/ SIZE(ptab,1), SIZE(ptab,2), SIZE(ptab,3), 1 /))
+    IF ( istatus /= NF90_NOERR ) THEN
+       PRINT *, ' Problem in readvar3d for ', TRIM(clvar)
+       CALL ERR_HDL(istatus)
+    ENDIF
+    IF ( lsf  ) WHERE ( ptab /= zspval ) ptab = ptab * zsf
+    IF ( lao  ) WHERE ( ptab /= zspval ) ptab = ptab + zao
+    IF ( llog ) WHERE ( ptab /= zspval ) ptab = 10**ptab
+    istatus = NF90_CLOSE(incid)
+  END SUBROUTINE readvar3d
 
   FUNCTION getvar1d(cdfile, cdvar, kk, kstatus)
     !! 1-D variable as r8 (time axes); 99999999999.d0 and kstatus /= 0 when absent (src/cdfio.F90:2151-2186)

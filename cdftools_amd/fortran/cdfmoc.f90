@@ -32,7 +32,9 @@ PROGRAM cdfmoc
   REAL(KIND=4),    ALLOCATABLE :: e1v(:,:), gphiv(:,:), e3v(:,:,:), zv(:,:,:,:), zmsk(:,:)
   REAL(KIND=4),    ALLOCATABLE :: rdumlon(:,:), rdumlat(:,:), gdepw(:), e31d(:)
   REAL(KIND=8),    ALLOCATABLE :: dtim(:), dmoc(:,:,:,:)          ! (nbasins, npjglo, npk, nbatch)
-  REAL(KIND=8) :: dl_budget
+  REAL(KIND=8) :: dl_budget, dl_t(5) = 0.d0                     ! CDFT_TIMING: mesh reads, data reads, GPU calls, output
+  INTEGER(KIND=8) :: iclk0, iclk1, iclk_rate
+  LOGICAL :: ltiming = .FALSE.
   ! -decomp
   INTEGER(KIND=1), ALLOCATABLE, TARGET :: itmask(:,:,:), iumask(:,:,:)   ! (npiglo, npjglo, npk) 0/1
   REAL(KIND=4),    ALLOCATABLE :: e1u(:,:), zcoef(:,:), gdept(:), ztemp(:,:,:), zsal(:,:,:)
@@ -152,6 +154,9 @@ PROGRAM cdfmoc
   CALL GET_ENVIRONMENT_VARIABLE('CDFT_HOST_GB', cldum)
   IF ( LEN_TRIM(cldum) > 0 ) READ(cldum, *) dl_budget
   nbatch = MAX(1, MIN(npt, INT(dl_budget * 1.d9 / (4.d0 * npiglo * npjglo * npk))))
+  CALL GET_ENVIRONMENT_VARIABLE('CDFT_TIMING', cldum)
+  ltiming = LEN_TRIM(cldum) > 0
+  CALL SYSTEM_CLOCK(iclk0, iclk_rate)
   IF ( lg_vvl ) nbatch = 1                                ! the metric changes with every record
   IF ( ldec   ) nbatch = 1                                ! cdft_moc_decomp works record by record
 
@@ -212,10 +217,11 @@ PROGRAM cdfmoc
   DO WHILE ( it0 <= npt )
      nrec = MIN(nbatch, npt - it0 + 1)
      IF ( it0 == 1 .OR. lg_vvl ) THEN                     ! e3v masked by vmask, every level (get_e3v)
-        DO jk = 1, npk
-           e3v(:,:,jk) = get_e3v(jk, it0)
-        END DO
+        CALL tick(1)                                         ! what came before: coordinates, masks, output file
+        CALL get_e3v_all(it0)
+        CALL tick(2)
         CALL hip_check(cdft_moc_set_mesh(plan, e1v, e3v, ibmask, CDFT_MEM_HOST, C_NULL_PTR), 'cdft_moc_set_mesh')
+        CALL tick(4)
         IF ( ldec ) CALL hip_check(cdft_moc_decomp_set_mesh(plan, e3v, e1u, zcoef, gdept, C_LOC(itmask), C_LOC(iumask), &
              &                     CDFT_MEM_HOST, C_NULL_PTR), 'cdft_moc_decomp_set_mesh')
      ENDIF
@@ -235,11 +241,14 @@ PROGRAM cdfmoc
         it0 = it0 + 1
         CYCLE
      ENDIF
+     CALL tick(5)
      DO jr = 1, nrec                                      ! velocities of levels 1..npk-1 are used
-        zv(:,:,:,jr) = getvar3d(cf_vfil, cn_vomecrty, npiglo, npjglo, npk, ktime=it0 + jr - 1)
+        CALL readvar3d(cf_vfil, cn_vomecrty, zv(:,:,:,jr), ktime=it0 + jr - 1)
      END DO
+     CALL tick(3)
      CALL hip_check(cdft_moc_compute(plan, zv, INT(npiglo, C_INT64_T) * npjglo * npk, nrec, CDFT_MEM_HOST, dmoc, &
           &                          CDFT_MEM_HOST, C_NULL_PTR), 'cdft_moc_compute')
+     CALL tick(4)
      DO jr = 1, nrec
         jt = it0 + jr - 1
         ijvar = 1
@@ -260,8 +269,19 @@ PROGRAM cdfmoc
 
   ierr = cdft_moc_destroy(plan)
   ierr = closeout(ncout)
+  CALL tick(5)
+  IF ( ltiming ) PRINT '(a,5(a,f8.3))', ' CDFT_TIMING (s):', ' setup', dl_t(1), '  mesh reads', dl_t(2), '  data reads', dl_t(3), &
+       &                                 '  GPU calls (H2D + kernels + D2H)', dl_t(4), '  output', dl_t(5)
 
 CONTAINS
+
+  SUBROUTINE tick(kphase)
+    !! the time since the last call goes to phase kphase
+    INTEGER(KIND=4), INTENT(in) :: kphase
+    CALL SYSTEM_CLOCK(iclk1)
+    dl_t(kphase) = dl_t(kphase) + REAL(iclk1 - iclk0, 8) / REAL(iclk_rate, 8)
+    iclk0 = iclk1
+  END SUBROUTINE tick
 
   SUBROUTINE put4(dd_tot, dd_sh, dd_bt, dd_ag)
     !! one basin: total, _sh, _bt, _ag, every level, as REAL() (src/cdfmoc.f90:522-545)
@@ -277,19 +297,21 @@ CONTAINS
     ijvar = ijvar + 1
   END SUBROUTINE put4
 
-  FUNCTION get_e3v(kk, kt)
-    !! e3v at level kk (or e31d with -full) times vmask of that level (src/cdfmoc.f90:576-596)
-    INTEGER(KIND=4), INTENT(in) :: kk, kt
-    REAL(KIND=4), DIMENSION(npiglo,npjglo) :: get_e3v
-    REAL(KIND=4), DIMENSION(npiglo,npjglo) :: zvm
-    INTEGER(KIND=2), DIMENSION(npiglo,npjglo) :: ivmask
-    zvm(:,:) = getvar(cn_fmsk, cn_vmask, kk, npiglo, npjglo)
-    ivmask(:,:) = INT(zvm, 2)
-    IF ( lfull ) THEN ; get_e3v(:,:) = e31d(kk)
-    ELSE              ; get_e3v(:,:) = getvar(cn_fe3v, cn_ve3v, kk, npiglo, npjglo, ktime=kt, ldiom=.NOT. lg_vvl)
+  SUBROUTINE get_e3v_all(kt)
+    !! e3v of every level (or e31d with -full) times vmask of that level (src/cdfmoc.f90:576-596, get_e3v), read as
+    !! two whole fields: the mask goes through zv, which is free at that point
+    INTEGER(KIND=4), INTENT(in) :: kt
+    INTEGER(KIND=4) :: ik
+    CALL readvar3d(cn_fmsk, cn_vmask, zv(:,:,:,1))
+    IF ( lfull ) THEN
+       DO ik = 1, npk ; e3v(:,:,ik) = e31d(ik) ; END DO
+    ELSE
+       CALL readvar3d(cn_fe3v, cn_ve3v, e3v, ktime=kt, ldiom=.NOT. lg_vvl)
     ENDIF
-    get_e3v(:,:) = get_e3v(:,:) * ivmask(:,:)
-  END FUNCTION get_e3v
+    DO ik = 1, npk
+       e3v(:,:,ik) = e3v(:,:,ik) * INT(zv(:,:,ik,1), 2)        ! the reference's INTEGER*2 mask (:581-593)
+    END DO
+  END SUBROUTINE get_e3v_all
 
   SUBROUTINE CreateOutput
     !! moc.nc exactly as the reference builds it (src/cdfmoc.f90:1006-1188)

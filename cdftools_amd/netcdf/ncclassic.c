@@ -56,10 +56,29 @@ static size_t tsize(int t) {
 static uint64_t pad4(uint64_t n) { return (n + 3u) & ~(uint64_t)3u; }
 
 /* ------------------------------------------------------------------ byte order + conversion */
+/* n elements of w bytes, byte order reversed; dst may be src.  The fixed-width loops vectorise (file built -O3). */
 static void bswap_copy(void *dst, const void *src, size_t n, size_t w) {
+    if (w == 1) { if (dst != src) memcpy(dst, src, n); return; }
+    if (w == 4) {
+        const unsigned char *s = (const unsigned char *)src;
+        unsigned char *d = (unsigned char *)dst;
+        for (size_t i = 0; i < n; ++i) { uint32_t v; memcpy(&v, s + 4 * i, 4); v = __builtin_bswap32(v); memcpy(d + 4 * i, &v, 4); }
+        return;
+    }
+    if (w == 8) {
+        const unsigned char *s = (const unsigned char *)src;
+        unsigned char *d = (unsigned char *)dst;
+        for (size_t i = 0; i < n; ++i) { uint64_t v; memcpy(&v, s + 8 * i, 8); v = __builtin_bswap64(v); memcpy(d + 8 * i, &v, 8); }
+        return;
+    }
+    if (w == 2) {
+        const unsigned char *s = (const unsigned char *)src;
+        unsigned char *d = (unsigned char *)dst;
+        for (size_t i = 0; i < n; ++i) { uint16_t v; memcpy(&v, s + 2 * i, 2); v = __builtin_bswap16(v); memcpy(d + 2 * i, &v, 2); }
+        return;
+    }
     const unsigned char *s = (const unsigned char *)src;
     unsigned char *d = (unsigned char *)dst;
-    if (w == 1) { memcpy(dst, src, n); return; }
     for (size_t i = 0; i < n; ++i, s += w, d += w)
         for (size_t b = 0; b < w; ++b) d[b] = s[w - 1 - b];
 }
@@ -98,6 +117,19 @@ static void store_from_double(void *p, int t, size_t i, double v) {
 /* native array of type `from` -> native array of type `to` */
 static void convert(void *dst, int to, const void *src, int from, size_t n) {
     if (to == from || (tsize(to) == 1 && tsize(from) == 1)) { memcpy(dst, src, n * tsize(to)); return; }
+    /* the conversions getvar meets all the time (masks as bytes, r8 or i2 variables read as r4), as plain loops */
+    if (to == NCC_FLOAT) {
+        float *d = (float *)dst;
+        if (from == NCC_BYTE)   { const signed char *q = (const signed char *)src; for (size_t i = 0; i < n; ++i) d[i] = (float)q[i]; return; }
+        if (from == NCC_SHORT)  { const int16_t *q = (const int16_t *)src;         for (size_t i = 0; i < n; ++i) d[i] = (float)q[i]; return; }
+        if (from == NCC_INT)    { const int32_t *q = (const int32_t *)src;         for (size_t i = 0; i < n; ++i) d[i] = (float)(double)q[i]; return; }
+        if (from == NCC_DOUBLE) { const double *q = (const double *)src;           for (size_t i = 0; i < n; ++i) d[i] = (float)q[i]; return; }
+    }
+    if (to == NCC_DOUBLE && from == NCC_FLOAT) {
+        const float *q = (const float *)src; double *d = (double *)dst;
+        for (size_t i = 0; i < n; ++i) d[i] = (double)q[i];
+        return;
+    }
     for (size_t i = 0; i < n; ++i) store_from_double(dst, to, i, load_as_double(src, from, i));
 }
 
@@ -831,6 +863,64 @@ int ncc_copy_att(int ncid_in, int varid_in, const char *name, int ncid_out, int 
 }
 
 /* ------------------------------------------------------------------ hyperslab I/O */
+/* pread until n bytes or end of file (a single pread stops at 2 GiB - 4 KiB on Linux) */
+static ssize_t pread_all(int fd, void *buf, size_t n, off_t off) {
+    size_t got = 0;
+    while (got < n) {
+        const ssize_t g = pread(fd, (char *)buf + got, n - got, off + (off_t)got);
+        if (g < 0) { if (errno == EINTR) continue; return -1; }
+        if (g == 0) break;
+        got += (size_t)g;
+    }
+    return (ssize_t)got;
+}
+
+/* A large same-type read is split over a few threads, each reading and byte-swapping its own part: one thread
+ * moves ~2 GB/s out of the page cache, and the tools read whole records (hundreds of MB) at a time. */
+#include <pthread.h>
+typedef struct { int fd; unsigned char *mem; size_t bytes, xs; off_t off; ssize_t got; } ReadJob;
+
+static void *read_job(void *arg) {
+    ReadJob *j = (ReadJob *)arg;
+    j->got = pread_all(j->fd, j->mem, j->bytes, j->off);
+    if (j->got >= 0) {
+        if ((size_t)j->got < j->bytes) memset(j->mem + j->got, 0, j->bytes - (size_t)j->got);
+        bswap_copy(j->mem, j->mem, j->bytes / j->xs, j->xs);
+    }
+    return NULL;
+}
+
+static int read_run_parallel(int fd, unsigned char *mem, size_t bytes, size_t xs, off_t off) {
+    enum { kMaxThreads = 8 };
+    const size_t kMinPart = (size_t)16 << 20;
+    int nt = (int)(bytes / kMinPart);
+    if (nt > kMaxThreads) nt = kMaxThreads;
+    const char *env = getenv("CDFT_IO_THREADS");
+    if (env && *env) { const int e = atoi(env); if (e >= 1 && e < nt) nt = e; }
+    if (nt < 2) {
+        ReadJob j = {fd, mem, bytes, xs, off, 0};
+        read_job(&j);
+        return j.got < 0 ? NCC_EIO : 0;
+    }
+    ReadJob jobs[kMaxThreads];
+    pthread_t th[kMaxThreads];
+    int started[kMaxThreads] = {0};
+    const size_t nel = bytes / xs, per = (nel + (size_t)nt - 1) / (size_t)nt;
+    int rc = 0;
+    for (int t = 0; t < nt; ++t) {
+        const size_t e0 = per * (size_t)t, e1 = e0 + per < nel ? e0 + per : nel;
+        jobs[t] = (ReadJob){fd, mem + e0 * xs, e0 < e1 ? (e1 - e0) * xs : 0, xs, off + (off_t)(e0 * xs), 0};
+        if (jobs[t].bytes == 0) continue;
+        if (t == nt - 1 || pthread_create(&th[t], NULL, read_job, &jobs[t]) != 0) read_job(&jobs[t]);   /* inline */
+        else started[t] = 1;
+    }
+    for (int t = 0; t < nt; ++t) {
+        if (started[t]) pthread_join(th[t], NULL);
+        if (jobs[t].got < 0) rc = NCC_EIO;
+    }
+    return rc;
+}
+
 static int vara(int ncid, int varid, const size_t *start, const size_t *count, int memtype, void *data, int writing) {
     File *f = getf(ncid);
     if (!f) return NCC_EBADID;
@@ -896,13 +986,23 @@ static int vara(int ncid, int varid, const size_t *start, const size_t *count, i
             const void *src = mem;
             if (conv) { convert(conv, v->type, mem, memtype, (size_t)run); src = conv; }
             bswap_copy(tmp, src, (size_t)run, xs);
-            if (pwrite(f->fd, tmp, tmpn, (off_t)off) != (ssize_t)tmpn) { rc = NCC_EIO; break; }
+            size_t put = 0;                                          /* (a single pwrite stops near 2 GiB) */
+            while (put < tmpn) {
+                const ssize_t g = pwrite(f->fd, tmp + put, tmpn - put, (off_t)(off + put));
+                if (g < 0 && errno == EINTR) continue;
+                if (g <= 0) break;
+                put += (size_t)g;
+            }
+            if (put != tmpn) { rc = NCC_EIO; break; }
+        } else if (!conv) {                     /* same type: read in place, then swap; a never-written tail reads as 0 */
+            rc = read_run_parallel(f->fd, mem, tmpn, xs, (off_t)off);
+            if (rc) break;
         } else {
-            ssize_t g = pread(f->fd, tmp, tmpn, (off_t)off);
+            ssize_t g = pread_all(f->fd, tmp, tmpn, (off_t)off);
             if (g < 0) { rc = NCC_EIO; break; }
-            if ((size_t)g < tmpn) memset(tmp + g, 0, tmpn - g);       /* never-written tail reads as 0 */
-            if (conv) { bswap_copy(conv, tmp, (size_t)run, xs); convert(mem, memtype, conv, v->type, (size_t)run); }
-            else bswap_copy(mem, tmp, (size_t)run, xs);
+            if ((size_t)g < tmpn) memset(tmp + g, 0, tmpn - g);
+            bswap_copy(conv, tmp, (size_t)run, xs);
+            convert(mem, memtype, conv, v->type, (size_t)run);
         }
         mem += (size_t)run * ms;
         int d = nouter - 1;
