@@ -47,6 +47,7 @@ SIGNATURES = {
     "cdft_timer_destroy": (_i, [_vp]),
     "cdft_moc_create": (_i, [_pvp, _i, _i, _i, _i]),
     "cdft_moc_set_mesh": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
+    "cdft_moc_set_mesh_vmask": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "cdft_moc_compute": (_i, [_vp, _vp, _i64, _i, _i, _vp, _i, _vp]),
     "cdft_moc_decomp_set_mesh": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "cdft_moc_decomp": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),

@@ -18,7 +18,8 @@ struct cdft_moc_plan {
     int     nclass = 0;        // distinct patterns (the empty one included), 0 when there are more than kMaxClass
     bool mesh_set = false;
     int  tune_waves = 0, tune_nv = 0, tune_mode = 0;
-    DevBuf st_e1v, st_e3v, st_mask, st_zv, st_out;   // staging for host arrays
+    DevBuf st_e1v, st_e3v, st_mask, st_zv, st_out;
+    DevBuf st_vm;   // staging for host arrays
     // -decomp (cdft_moc_decomp_*): the mesh it needs beyond w / bits, and its work arrays
     bool dec_set = false;
     DevBuf d_e3v, d_e1u, d_zcoef, d_tmask, d_umask;  // e3v (masked) 3-D, e1u / zcoef 2-D, masks 3-D bytes
@@ -33,11 +34,15 @@ namespace {
 
 // w(i,j,k) = e1v(i,j) * e3v(i,j,k), rounded to r4 like the reference's first product
 // (src/cdfmoc.f90:374: e1v(ji,jj)*e3v(ji,jj,jk) is evaluated first, in r4).
+// With vm (the level's vmask as the reference's INTEGER*2 ivmask, here a byte): e3v is the raw metric and
+// get_e3v's  e3v * ivmask  (:581-593) is formed here, in r4, before the product with e1v.
 __global__ void moc_weight_kernel(const float *__restrict__ e1v, const float *__restrict__ e3v,
-                                  float *__restrict__ w, int64_t nij, int64_t n) {
+                                  const int8_t *__restrict__ vm, float *__restrict__ w, int64_t nij, int64_t n) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride)
-        w[e] = __fmul_rn(e1v[e % nij], e3v[e]);
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
+        const float e3 = vm ? __fmul_rn(e3v[e], (float)vm[e]) : e3v[e];
+        w[e] = __fmul_rn(e1v[e % nij], e3);
+    }
 }
 
 // bits(i,j) = sum_b (ibmask(b,i,j) != 0) << b ; any value outside {0,1} raises the flag.
@@ -307,12 +312,18 @@ int cdft_moc_create(cdft_moc_plan **plan, int npiglo, int npjglo, int npk, int n
 
 int cdft_moc_set_mesh(cdft_moc_plan *p, const float *e1v, const float *e3v, const int16_t *ibmask,
                       int memspace, void *stream) {
+    return cdft_moc_set_mesh_vmask(p, e1v, e3v, nullptr, ibmask, memspace, stream);
+}
+
+int cdft_moc_set_mesh_vmask(cdft_moc_plan *p, const float *e1v, const float *e3v, const int8_t *vmask,
+                            const int16_t *ibmask, int memspace, void *stream) {
     if (!p || !e1v || !e3v || !ibmask) return fail(CDFT_ERR_ARG, "cdft_moc_set_mesh: NULL argument");
     hipStream_t st = as_stream(stream);
     const int64_t nij = (int64_t)p->npi * p->npj, n3 = nij * p->npk;
-    const void *d_e1v, *d_e3v, *d_msk;
+    const void *d_e1v, *d_e3v, *d_msk, *d_vm = nullptr;
     CDFT_TRY(to_device(e1v, nij * sizeof(float), memspace, p->st_e1v, st, &d_e1v));
     CDFT_TRY(to_device(e3v, n3 * sizeof(float), memspace, p->st_e3v, st, &d_e3v));
+    if (vmask) CDFT_TRY(to_device(vmask, (size_t)n3, memspace, p->st_vm, st, &d_vm));
     CDFT_TRY(to_device(ibmask, nij * p->nbasins * sizeof(int16_t), memspace, p->st_mask, st, &d_msk));
     CDFT_HIP(hipMemsetAsync(p->flag, 0, 257 * sizeof(int), st));
     CDFT_HIP(hipMemsetAsync(p->w + n3, 0, 64, st));
@@ -320,7 +331,7 @@ int cdft_moc_set_mesh(cdft_moc_plan *p, const float *e1v, const float *e3v, cons
     int blocks = (int)((n3 + threads - 1) / threads);
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(moc_weight_kernel, dim3(blocks), dim3(threads), 0, st, (const float *)d_e1v,
-                       (const float *)d_e3v, p->w, nij, n3);
+                       (const float *)d_e3v, (const int8_t *)d_vm, p->w, nij, n3);
     CDFT_LAUNCH_CHECK();
     blocks = (int)((nij + threads - 1) / threads);
     if (blocks > 256 * 16) blocks = 256 * 16;
@@ -350,7 +361,7 @@ int cdft_moc_set_mesh(cdft_moc_plan *p, const float *e1v, const float *e3v, cons
         CDFT_HIP(hipStreamSynchronize(st));                      // lut[] is a stack array
     }
     // the staged copies of host arrays are no longer needed (e3v is as large as the weight)
-    p->st_e1v.release(); p->st_e3v.release(); p->st_mask.release();
+    p->st_e1v.release(); p->st_e3v.release(); p->st_mask.release(); p->st_vm.release();
     if (flag) {
         p->mesh_set = false;
         return fail(CDFT_ERR_ARG, "cdft_moc_set_mesh: ibmask holds values other than 0/1");
@@ -556,7 +567,7 @@ int cdft_moc_destroy(cdft_moc_plan *p) {
     if (p->bits) (void)hipFree(p->bits);
     if (p->cls) (void)hipFree(p->cls);
     if (p->flag) (void)hipFree(p->flag);
-    p->st_e1v.release(); p->st_e3v.release(); p->st_mask.release(); p->st_zv.release(); p->st_out.release();
+    p->st_e1v.release(); p->st_e3v.release(); p->st_mask.release(); p->st_vm.release(); p->st_zv.release(); p->st_out.release();
     DevBuf *dec[] = {&p->d_e3v, &p->d_e1u, &p->d_zcoef, &p->d_tmask, &p->d_umask, &p->d_t, &p->d_s, &p->d_zvgeo, &p->d_sig8,
                      &p->d_dvbt, &p->d_hdep, &p->d_dvgeo, &p->d_raw, &p->d_o4};
     for (DevBuf *b : dec) b->release();

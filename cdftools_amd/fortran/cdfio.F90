@@ -61,7 +61,7 @@ MODULE cdfio
   END INTERFACE
 
   PUBLIC :: getvaratt, getnvar, getvarname, getipk
-  PUBLIC :: chkfile, chkvar, getdim, getvdim, getspval, getatt, getvar, getvar1d, getvare3, getvar3d, readvar3d
+  PUBLIC :: chkfile, chkvar, getdim, getvdim, getspval, getatt, getvar, getvar1d, getvare3, getvar3d, readvar3d, readvar3d_i1
   PUBLIC :: create, createvar, putatt, putheadervar, putvar, putvar1d, putvar0d, closeout, ncopen, copyatt, ERR_HDL
 
 CONTAINS
@@ -586,6 +586,23 @@ CONTAINS
     IF ( llog ) WHERE ( ptab /= zspval ) ptab = 10**ptab
     istatus = NF90_CLOSE(incid)
   END SUBROUTINE readvar3d
+
+  SUBROUTINE readvar3d_i1(cdfile, cdvar, ktab, ktime)
+    !! a whole 3-D mask as bytes (values converted by the backend when the file holds another type)
+    CHARACTER(LEN=*),          INTENT(in)  :: cdfile, cdvar
+    INTEGER(KIND=1), CONTIGUOUS, INTENT(out) :: ktab(:,:,:)
+    INTEGER(KIND=4), OPTIONAL, INTENT(in)  :: ktime
+    INTEGER(KIND=4) :: incid, id_var, istatus, itime
+    itime = 1 ; IF ( PRESENT(ktime) ) itime = ktime
+    CALL ERR_HDL(NF90_OPEN(cdfile, NF90_NOWRITE, incid))
+    CALL ERR_HDL(NF90_INQ_VARID(incid, cdvar, id_var))
+    istatus = NF90_GET_VAR(incid, id_var, ktab, start=(/ 1, 1, 1, itime /), count=(/ SIZE(ktab,1), SIZE(ktab,2), SIZE(ktab,3), 1 /))
+    IF ( istatus /= NF90_NOERR ) THEN
+       PRINT *, ' Problem in readvar3d for ', TRIM(cdvar)
+       CALL ERR_HDL(istatus)
+    ENDIF
+    istatus = NF90_CLOSE(incid)
+  END SUBROUTINE readvar3d_i1
 
   FUNCTION getvar1d(cdfile, cdvar, kk, kstatus)
     !! 1-D variable as r8 (time axes); 99999999999.d0 and kstatus /= 0 when absent (src/cdfio.F90:2151-2186)

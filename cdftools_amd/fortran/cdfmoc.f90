@@ -29,6 +29,7 @@ PROGRAM cdfmoc
   INTEGER(KIND=4), ALLOCATABLE :: ipk(:), id_varout(:)
   INTEGER(KIND=4) :: iloc(2)
   INTEGER(KIND=2), ALLOCATABLE :: ibmask(:,:,:)                 ! (nbasins, npiglo, npjglo)
+  INTEGER(KIND=1), ALLOCATABLE :: ivmask(:,:,:)                 ! vmask of every level, as bytes
   REAL(KIND=4),    ALLOCATABLE :: e1v(:,:), gphiv(:,:), e3v(:,:,:), zv(:,:,:,:), zmsk(:,:)
   REAL(KIND=4),    ALLOCATABLE :: rdumlon(:,:), rdumlat(:,:), gdepw(:), e31d(:)
   REAL(KIND=8),    ALLOCATABLE :: dtim(:), dmoc(:,:,:,:)          ! (nbasins, npjglo, npk, nbatch)
@@ -218,9 +219,18 @@ PROGRAM cdfmoc
      nrec = MIN(nbatch, npt - it0 + 1)
      IF ( it0 == 1 .OR. lg_vvl ) THEN                     ! e3v masked by vmask, every level (get_e3v)
         CALL tick(1)                                         ! what came before: coordinates, masks, output file
-        CALL get_e3v_all(it0)
-        CALL tick(2)
-        CALL hip_check(cdft_moc_set_mesh(plan, e1v, e3v, ibmask, CDFT_MEM_HOST, C_NULL_PTR), 'cdft_moc_set_mesh')
+        IF ( ldec .OR. lfull ) THEN                      ! the masked metric is needed on the host as well
+           CALL get_e3v_all(it0)
+           CALL tick(2)
+           CALL hip_check(cdft_moc_set_mesh(plan, e1v, e3v, ibmask, CDFT_MEM_HOST, C_NULL_PTR), 'cdft_moc_set_mesh')
+        ELSE                                              ! raw metric + byte mask: get_e3v's product on the device
+           IF ( .NOT. ALLOCATED(ivmask) ) ALLOCATE( ivmask(npiglo, npjglo, npk) )
+           CALL readvar3d_i1(cn_fmsk, cn_vmask, ivmask)
+           CALL readvar3d(cn_fe3v, cn_ve3v, e3v, ktime=it0, ldiom=.NOT. lg_vvl)
+           CALL tick(2)
+           CALL hip_check(cdft_moc_set_mesh_vmask(plan, e1v, e3v, ivmask, ibmask, CDFT_MEM_HOST, C_NULL_PTR), &
+                &         'cdft_moc_set_mesh_vmask')
+        ENDIF
         CALL tick(4)
         IF ( ldec ) CALL hip_check(cdft_moc_decomp_set_mesh(plan, e3v, e1u, zcoef, gdept, C_LOC(itmask), C_LOC(iumask), &
              &                     CDFT_MEM_HOST, C_NULL_PTR), 'cdft_moc_decomp_set_mesh')

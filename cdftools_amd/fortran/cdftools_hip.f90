@@ -32,6 +32,11 @@ MODULE cdftools_hip
        IMPORT ; TYPE(C_PTR), VALUE :: plan, stream ; REAL(C_FLOAT), INTENT(in) :: e1v(*), e3v(*)
        INTEGER(C_INT16_T), INTENT(in) :: ibmask(*) ; INTEGER(C_INT), VALUE :: memspace
      END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_moc_set_mesh_vmask(plan, e1v, e3v, vmask, ibmask, memspace, stream) &
+          &         BIND(C, name='cdft_moc_set_mesh_vmask')
+       IMPORT ; TYPE(C_PTR), VALUE :: plan, stream ; REAL(C_FLOAT), INTENT(in) :: e1v(*), e3v(*)
+       INTEGER(C_INT8_T), INTENT(in) :: vmask(*) ; INTEGER(C_INT16_T), INTENT(in) :: ibmask(*) ; INTEGER(C_INT), VALUE :: memspace
+     END FUNCTION
      INTEGER(C_INT) FUNCTION cdft_moc_compute(plan, zv, rec_stride, npt, zv_space, dmoc, dmoc_space, stream) &
           &         BIND(C, name='cdft_moc_compute')
        IMPORT ; TYPE(C_PTR), VALUE :: plan, stream ; REAL(C_FLOAT), INTENT(in) :: zv(*)

@@ -93,8 +93,18 @@ class MocPlan:
         self._h = C.c_void_p()
         check(_lib.load().cdft_moc_create(C.byref(self._h), npiglo, npjglo, npk, nbasins))
 
-    def set_mesh(self, e1v, e3v, ibmask, stream=None):
-        """e1v (npj,npi) r4; e3v (npk,npj,npi) r4 already * vmask; ibmask (npj,npi,nb) i2 in {0,1}."""
+    def set_mesh(self, e1v, e3v, ibmask, vmask=None, stream=None):
+        """e1v (npj,npi) r4; e3v (npk,npj,npi) r4 already * vmask -- or the raw metric with vmask (npk,npj,npi) i1 given,
+        the product then being formed on the device; ibmask (npj,npi,nb) i2 in {0,1}."""
+        if vmask is not None:
+            p1, s1, k1 = _arg(e1v, np.float32, "e1v")
+            p2, s2, k2 = _arg(e3v, np.float32, "e3v")
+            p3, s3, k3 = _arg(ibmask, np.int16, "ibmask")
+            p4, s4, k4 = _arg(vmask, np.int8, "vmask")
+            if not (s1 == s2 == s3 == s4):
+                raise ValueError("e1v, e3v, vmask and ibmask must live in the same memory space")
+            check(_lib.load().cdft_moc_set_mesh_vmask(self._h, p1, p2, p4, p3, s1, stream or current_stream_ptr()))
+            return
         p1, s1, k1 = _arg(e1v, np.float32, "e1v")
         p2, s2, k2 = _arg(e3v, np.float32, "e3v")
         p3, s3, k3 = _arg(ibmask, np.int16, "ibmask")

@@ -85,6 +85,12 @@ int cdft_moc_create(cdft_moc_plan **plan, int npiglo, int npjglo, int npk, int n
  * first product) and one byte of basin bits per (i,j); the inputs may be released afterwards. */
 int cdft_moc_set_mesh(cdft_moc_plan *plan, const float *e1v, const float *e3v,
                       const int16_t *ibmask, int memspace, void *stream);
+/* The same with get_e3v's mask product (src/cdfmoc.f90:581-593: e3v = e3v * ivmask, ivmask the level's vmask as
+ * INTEGER*2) done on the device: e3v is the raw metric as read from the file and vmask (npiglo,npjglo,npk) its 0/1
+ * mask as bytes.  Saves the host a conversion of the mask to r4 and a pass over the metric (two passes over a
+ * 4.68 GB field at eORCA12).  vmask = NULL is cdft_moc_set_mesh. */
+int cdft_moc_set_mesh_vmask(cdft_moc_plan *plan, const float *e1v, const float *e3v, const int8_t *vmask,
+                            const int16_t *ibmask, int memspace, void *stream);
 
 /* zv   : npt records of (npiglo,npjglo,npk) r4 meridional velocity, record r starting at
  *        zv + r*rec_stride (rec_stride in elements, >= npiglo*npjglo*npk; level npk is never

@@ -148,6 +148,28 @@ def test_hip_class_mode_is_chosen_when_the_masks_have_few_bit_patterns(gpu, nb, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("npi,npj,npk,nb", [(24, 18, 7, 5), (182, 149, 31, 5), (67, 5, 3, 1)])
+def test_hip_mask_product_of_get_e3v_on_the_device(gpu, npi, npj, npk, nb):
+    """cdft_moc_set_mesh_vmask: the raw metric and the byte mask give bit for bit what the host-masked metric gives."""
+    import torch
+
+    g = synth.make_grid(npi, npj, npk, seed=npi + 11, nbasins=nb)
+    e1v, e3v, ib = synth.moc_inputs(g)
+    zv = synth.velocity(g, 3, seed=5)
+    a = gpu.MocPlan(npi, npj, npk, nb)
+    a.set_mesh(e1v, e3v, ib)
+    want = a.compute(zv)
+    b = gpu.MocPlan(npi, npj, npk, nb)
+    raw = (g["e3v_0"] + np.float32(0.25) * (1 - g["vmask"])).astype(np.float32)      # something on the masked points too
+    b.set_mesh(e1v, raw, ib, vmask=g["vmask"].astype(np.int8))
+    assert np.array_equal(b.compute(zv), want)
+    dev = [torch.from_numpy(np.ascontiguousarray(x)).cuda() for x in (e1v, raw, ib, g["vmask"].astype(np.int8))]
+    b.set_mesh(dev[0], dev[1], dev[2], vmask=dev[3])
+    assert np.array_equal(b.compute(zv), want)
+    a.close(); b.close()
+
+
+@pytest.mark.gpu
 def test_hip_unaligned_records_take_the_scalar_path(gpu):
     import torch
 

@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""cdfmoc (the program) on FILES of the headline grid, eORCA12 4322 x 3606 x 75: one 3-D field is 4.68 GB, more than
+the 64-bit-offset format holds per record, so the files are CDF-5 written through the bundled backend (ncc_* over
+ctypes; scipy cannot write them), level by level to keep the generator's memory small.  Only what cdfmoc reads is
+written: mesh_hgr.nc (e1v, gphiv), mesh_zgr.nc (e3v_0, gdepw_1d; e3t_0 defined, not written), mask.nc (vmask),
+new_maskglo.nc, V.nc (--npt records).  Sampled rows of moc.nc are checked against the oracle.
+
+    python tools/e2e_cdfmoc_big.py [--grid eorca12] [--npt 2]      # on the GPU box; ~25 GB of scratch files
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_lib  # noqa: E402
+import synth  # noqa: E402
+from test_cli import read_nc  # noqa: E402
+
+GRIDS = {"tiny": (64, 40, 7), "eorca025": (1442, 1207, 75), "eorca12": (4322, 3606, 75)}
+BYTE, CHAR, FLOAT, DOUBLE = 1, 2, 5, 6
+nc = C.CDLL(os.path.join(ROOT, "cdftools_amd", "lib", "libncclassic.so"))
+nc.ncc_strerror.restype = C.c_char_p
+
+
+def ok(rc):
+    if rc != 0:
+        raise RuntimeError(nc.ncc_strerror(rc).decode())
+
+
+class Writer:
+    def __init__(self, path, dims):
+        self.id = C.c_int()
+        ok(nc.ncc_create(path.encode(), 5, 1, C.byref(self.id)))
+        self.dim = {}
+        for name, n in dims:
+            d = C.c_int()
+            ok(nc.ncc_def_dim(self.id, name.encode(), C.c_size_t(n or 0), C.byref(d)))
+            self.dim[name] = d.value
+        self.var = {}
+
+    def define(self, name, xtype, dims, **atts):
+        ids = (C.c_int * len(dims))(*[self.dim[d] for d in dims])
+        v = C.c_int()
+        ok(nc.ncc_def_var(self.id, name.encode(), xtype, len(dims), ids, C.byref(v)))
+        for k, val in atts.items():
+            b = val.encode()
+            ok(nc.ncc_put_att(self.id, v, k.encode(), CHAR, C.c_size_t(len(b)), CHAR, b))
+        self.var[name] = (v.value, xtype, len(dims))
+
+    def enddef(self):
+        ok(nc.ncc_enddef(self.id))
+
+    def put(self, name, start, a):
+        v, xtype, nd = self.var[name]
+        a = np.ascontiguousarray(a)
+        mt = {np.dtype(np.int8): BYTE, np.dtype(np.float32): FLOAT, np.dtype(np.float64): DOUBLE}[a.dtype]
+        st = (C.c_size_t * nd)(*start)
+        ct = (C.c_size_t * nd)(*([1] * (nd - a.ndim) + list(a.shape)))
+        ok(nc.ncc_put_vara(self.id, v, st, ct, mt, a.ctypes.data_as(C.c_void_p)))
+
+    def close(self):
+        ok(nc.ncc_close(self.id))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--grid", default="eorca12", choices=sorted(GRIDS))
+    ap.add_argument("--npt", type=int, default=2)
+    ap.add_argument("--rows", type=int, default=5)
+    ap.add_argument("--keep", action="store_true")
+    args = ap.parse_args()
+    npi, npj, npk = GRIDS[args.grid]
+    npt = args.npt
+    d = tempfile.mkdtemp(prefix="cdfmoc_big_", dir=os.environ.get("TMPDIR", "/tmp"))
+    rng = np.random.default_rng(20240601)
+    f32 = np.float32
+    t0 = time.perf_counter()
+    rows = np.sort(rng.choice(np.arange(1, npj - 1), args.rows, replace=False))
+
+    e1v = (2000 + 26000 * rng.random((npj, npi), dtype=f32)).astype(f32)
+    gphiv = np.broadcast_to(np.linspace(-78.0, 89.9, npj, dtype=f32)[:, None], (npj, npi)).copy()
+    e31d = synth.e3_profile(npk)
+    gdepw = np.concatenate([[0.0], np.cumsum(e31d[:-1], dtype=np.float64)]).astype(f32)
+    mbathy = np.where(rng.random((npj, npi)) < 0.35, 0, 1 + np.floor((npk - 1) * rng.random((npj, npi))).astype(np.int32))
+    mbathy = np.minimum(mbathy, npk - 1).astype(np.int32)
+    mbathy[0, :] = 0
+    band = (np.arange(npi) * 3) // npi
+
+    def tmask(k):
+        return (k < mbathy).astype(np.int8)
+
+    def vmask(k):
+        t = tmask(k)
+        v = np.zeros_like(t)
+        v[:-1] = t[:-1] * t[1:]
+        return v
+
+    w = Writer(os.path.join(d, "mesh_hgr.nc"), [("t", None), ("y", npj), ("x", npi)])
+    for nm in ("e1v", "gphiv"):
+        w.define(nm, FLOAT, ("t", "y", "x"))
+    w.enddef()
+    w.put("e1v", (0, 0, 0), e1v)
+    w.put("gphiv", (0, 0, 0), gphiv)
+    w.close()
+
+    t1 = tmask(0)
+    w = Writer(os.path.join(d, "new_maskglo.nc"), [("y", npj), ("x", npi)])
+    for nm in ("tmaskatl", "tmaskpac", "tmaskind"):
+        w.define(nm, BYTE, ("y", "x"))
+    w.enddef()
+    basin = {"tmaskatl": t1 * (band == 0)[None], "tmaskpac": t1 * (band == 1)[None], "tmaskind": t1 * (band == 2)[None]}
+    for nm, a in basin.items():
+        w.put(nm, (0, 0), a.astype(np.int8))
+    w.close()
+
+    wz = Writer(os.path.join(d, "mesh_zgr.nc"), [("t", None), ("z", npk), ("y", npj), ("x", npi)])
+    wz.define("e3t_0", FLOAT, ("t", "z", "y", "x"))          # present (it selects the v3.6 layout), never read by cdfmoc
+    wz.define("e3v_0", FLOAT, ("t", "z", "y", "x"))
+    wz.define("gdepw_1d", FLOAT, ("t", "z"))
+    wz.enddef()
+    wz.put("gdepw_1d", (0, 0), gdepw)
+    wm = Writer(os.path.join(d, "mask.nc"), [("t", None), ("z", npk), ("y", npj), ("x", npi)])
+    wm.define("vmask", BYTE, ("t", "z", "y", "x"))
+    wm.enddef()
+    wv = Writer(os.path.join(d, "V.nc"), [("time_counter", None), ("depthv", npk), ("y", npj), ("x", npi)])
+    wv.define("vomecrty", FLOAT, ("time_counter", "depthv", "y", "x"), units="m/s")
+    wv.define("time_counter", DOUBLE, ("time_counter",), units="seconds since 1950-01-01 00:00:00", calendar="noleap",
+              time_origin="1950-JAN-01 00:00:00")
+    wv.define("depthv", FLOAT, ("depthv",), units="m")
+    wv.enddef()
+    wv.put("depthv", (0,), (gdepw + 0.5 * e31d).astype(f32))
+    wv.put("time_counter", (0,), np.arange(1, npt + 1, dtype=np.float64) * 86400.0 * 30)
+    e3v_rows = np.zeros((npk, args.rows, npi), f32)
+    v_rows = np.zeros((npt, npk, args.rows, npi), f32)
+    vm0 = None
+    for k in range(npk):
+        vm = vmask(k)
+        if k == 0:
+            vm0 = vm
+        e3 = np.full((npj, npi), e31d[k], f32)
+        bottom = mbathy == k + 1                                  # partial step: the last wet cell is thinner
+        e3[bottom] *= (f32(0.2) + f32(0.8) * rng.random(int(bottom.sum()), dtype=f32)).astype(f32)
+        e3v = e3.copy()
+        e3v[:-1] = np.minimum(e3[:-1], e3[1:])
+        wz.put("e3v_0", (0, k, 0, 0), e3v)
+        wm.put("vmask", (0, k, 0, 0), vm)
+        e3v_rows[k] = (e3v[rows] * vm[rows].astype(f32)).astype(f32)          # get_e3v: e3v * vmask
+        for t in range(npt):
+            v = ((rng.random((npj, npi), dtype=f32) - f32(0.5)) * vm).astype(f32)
+            wv.put("vomecrty", (t, k, 0, 0), v)
+            v_rows[t, k] = v[rows]
+    wz.close(); wm.close(); wv.close()
+    gen = time.perf_counter() - t0
+    sizes = {f: round(os.path.getsize(os.path.join(d, f)) / 1e9, 2) for f in sorted(os.listdir(d))}
+
+    exe = os.path.join(ROOT, "cdftools_amd", "bin", "cdfmoc")
+    env = dict(os.environ, CDFT_TIMING="1")
+    walls, phases = [], ""
+    for i in range(2):
+        t0 = time.perf_counter()
+        r = subprocess.run([exe, "-v", "V.nc"], cwd=d, env=env, capture_output=True, text=True)
+        walls.append(round(time.perf_counter() - t0, 2))
+        if r.returncode != 0:
+            print("cdfmoc failed with code", r.returncode)
+            print(r.stdout[-3000:], r.stderr[-2000:])
+            sys.exit(1)
+        phases = [ln.strip() for ln in r.stdout.splitlines() if "CDFT_TIMING" in ln][0]
+
+    ib = np.zeros((args.rows, npi, 5), np.int16)                  # src/cdfmoc.f90:325-336
+    ib[:, :, 0] = vm0[rows]
+    ib[:, :, 1], ib[:, :, 3], ib[:, :, 4] = basin["tmaskatl"][rows], basin["tmaskind"][rows], basin["tmaskpac"][rows]
+    ib[:, :, 2] = np.minimum(ib[:, :, 4] + ib[:, :, 3], 1)
+    ib[:, 0, 0] = 0
+    ib[:, npi - 1, 0] = 0
+    ref = oracle_lib.moc(e1v[rows], e3v_rows, ib, v_rows)         # (npt,npk,rows,nb)
+    var, _, dims = read_nc(os.path.join(d, "moc.nc"))
+    worst, ident = 0.0, 0
+    for b, nm in enumerate(("zomsfglo", "zomsfatl", "zomsfinp", "zomsfind", "zomsfpac")):
+        got = var[nm][:, :, rows, 0]
+        want = ref[..., b].astype(f32)
+        ident += int(np.array_equal(got, want))
+        worst = max(worst, float(np.abs(got - want).max() / (np.abs(want).max() + 1e-30)))
+    print(json.dumps({"tool": "cdfmoc (program, CDF-5 files)", "grid": args.grid, "npt": npt, "files_GB": sizes, "generate_s": round(gen, 1),
+                      "wall_s": walls, "phases_last": phases, "grid_cells_per_s": npi * npj * npk * npt / walls[-1],
+                      "rows_checked": [int(x) for x in rows], "basins_bit_identical_after_r4_store": ident,
+                      "max_rel_diff_vs_oracle": worst, "moc_dims": {k: (int(v) if v is not None else None) for k, v in dims.items()}}))
+    if not args.keep:
+        shutil.rmtree(d, ignore_errors=True)
+    sys.exit(0 if worst < 1e-6 else 2)
+
+
+if __name__ == "__main__":
+    main()
