@@ -9,6 +9,7 @@
 //
 // HBM-bound: per cell temp 4 B + e3t 4 B + tmask 1 B (+ 8/npk) = 9.11 algorithmic bytes; the 2-D
 // area e1t*e2t is re-read from L2 / Infinity Cache for every level.
+#include <cstdlib>
 #include "common.hpp"
 #include "reduce.hpp"
 
@@ -141,6 +142,103 @@ __global__ void __launch_bounds__(kThreads) heatc_level_kernel(HeatcArgs a) {
     }
 }
 
+// The same for planes whose size is not a multiple of 4 cells (eORCA025: 1442 x 1207) or whose arrays are not
+// 16-byte aligned: 16-byte loads at r4 alignment (a level then starts anywhere), the plane covered by vectors at cells
+// 0, 4, 8, ... plus, when nij is not a multiple of 4, one vector anchored at nij-4 whose leading cells repeat the
+// previous vector's and count as zeros -- every load is a full vector inside the level, without a branch.
+typedef unsigned char u4u __attribute__((ext_vector_type(4), aligned(1)));
+
+template <bool MASK8, bool FULL>
+__global__ void __launch_bounds__(kThreads) heatc_level_u4_kernel(HeatcArgs a) {
+    extern __shared__ double wsum[];                   // [nwaves][npk][3]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = kThreads / 64;
+    const int64_t nfull = a.nij >> 2;                  // vectors 0..nfull-1 start at 4v
+    int64_t e0[kVPT];
+    bool own[kVPT][4];
+    float ar[kVPT][4], mx[kVPT][4];
+#pragma unroll
+    for (int v = 0; v < kVPT; ++v) {
+        const int64_t q = (((int64_t)blockIdx.x * nwaves + wave) * kVPT + v) * 64 + lane;
+        e0[v] = min(4 * q, a.nij - 4);
+        const f4u av = *reinterpret_cast<const f4u *>(a.area + e0[v]);
+        const float a4[4] = {av.x, av.y, av.z, av.w};
+        float m4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (a.mxlopt) { const f4u mv = *reinterpret_cast<const f4u *>(a.mxl + e0[v]); m4[0] = mv.x; m4[1] = mv.y; m4[2] = mv.z; m4[3] = mv.w; }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            own[v][c] = q < nfull || (q == nfull && e0[v] + c >= 4 * nfull);
+            ar[v][c] = own[v][c] ? a4[c] : 0.f;          // contributes exact zeros
+            mx[v][c] = m4[c];
+        }
+    }
+    for (int k = 0; k < a.npk; ++k) {
+        const int64_t base = (int64_t)k * a.nij;
+        const float e3k = FULL ? a.e31d[k] : 0.f;
+        const float dw  = a.mxlopt ? a.gdepw[k] : 0.f;
+        float e3[kVPT][4], tt[kVPT][4], mk[kVPT][4];
+#pragma unroll
+        for (int v = 0; v < kVPT; ++v) {
+            const f4u t4 = ld_stream4u(a.temp + base + e0[v]);
+            tt[v][0] = t4.x; tt[v][1] = t4.y; tt[v][2] = t4.z; tt[v][3] = t4.w;
+            if (FULL) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) e3[v][c] = e3k;
+            } else {
+                const f4u e4 = ld_stream4u(a.e3t + base + e0[v]);
+                e3[v][0] = e4.x; e3[v][1] = e4.y; e3[v][2] = e4.z; e3[v][3] = e4.w;
+            }
+            if (MASK8) {
+                const u4u m = __builtin_nontemporal_load(reinterpret_cast<const u4u *>(a.mask8 + base + e0[v]));
+                mk[v][0] = m.x; mk[v][1] = m.y; mk[v][2] = m.z; mk[v][3] = m.w;
+            } else {
+                const f4u m = ld_stream4u(a.mask4 + base + e0[v]);
+                mk[v][0] = m.x; mk[v][1] = m.y; mk[v][2] = m.z; mk[v][3] = m.w;
+            }
+        }
+        double s_surf = 0.0, s_vol = 0.0, s_sum = 0.0;
+#pragma unroll
+        for (int v = 0; v < kVPT; ++v)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float e = e3[v][c];
+                if (a.mxlopt == 1)                        // src/cdfheatc.f90:220
+                    e = fmaxf(0.f, fminf(e, __fsub_rn(mx[v][c], dw)));
+                else if (a.mxlopt == -1)                  // :222
+                    e = fminf(e, fmaxf(0.f, __fsub_rn(__fadd_rn(dw, e), mx[v][c])));
+                const float mkc = own[v][c] ? mk[v][c] : 0.f;
+                const float ttc = own[v][c] ? tt[v][c] : 0.f;
+                const float pv = __fmul_rn(ar[v][c], e);                       // (e1t*e2t)*e3t
+                s_surf += (double)__fmul_rn(ar[v][c], mkc);                    // :225
+                s_vol  += (double)__fmul_rn(pv, mkc);                          // :226
+                s_sum  += (double)__fmul_rn(__fmul_rn(pv, ttc), mkc);          // :229
+            }
+        s_surf = wave_sum(s_surf); s_vol = wave_sum(s_vol); s_sum = wave_sum(s_sum);
+        if (lane == 0) {
+            double *w = wsum + ((int64_t)wave * a.npk + k) * 3;
+            w[0] = s_surf; w[1] = s_vol; w[2] = s_sum;
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < a.npk * 3; t += kThreads) {
+        double s = 0.0;
+        for (int w = 0; w < nwaves; ++w) s += wsum[(int64_t)w * a.npk * 3 + t];
+        const int k = t / 3, c = t - 3 * k;
+        a.partial[((int64_t)k * a.nblk + blockIdx.x) * 3 + c] = s;
+    }
+}
+
+int launch_u4(const HeatcArgs &a, hipStream_t st) {
+    dim3 grid(a.nblk), block(kThreads);
+    const size_t shmem = (size_t)(kThreads / 64) * a.npk * 3 * sizeof(double);
+    const bool m8 = a.mask8 != nullptr, full = a.e31d != nullptr;
+    if (m8 && full)        hipLaunchKernelGGL((heatc_level_u4_kernel<true, true>), grid, block, shmem, st, a);
+    else if (m8 && !full)  hipLaunchKernelGGL((heatc_level_u4_kernel<true, false>), grid, block, shmem, st, a);
+    else if (!m8 && full)  hipLaunchKernelGGL((heatc_level_u4_kernel<false, true>), grid, block, shmem, st, a);
+    else                   hipLaunchKernelGGL((heatc_level_u4_kernel<false, false>), grid, block, shmem, st, a);
+    CDFT_LAUNCH_CHECK();
+    return CDFT_OK;
+}
+
 // sums[k][3] = partials of level k added over the blocks in a fixed order (one workgroup per level)
 __global__ void __launch_bounds__(kThreads) heatc_final_kernel(const double *__restrict__ partial, int npk, int nblk,
                                                                double *__restrict__ sums) {
@@ -262,9 +360,12 @@ int cdft_heatc_compute(cdft_heatc_plan *p, const float *temp, int temp_space, co
     a.mxlopt = mxloption; a.partial = p->partial;
     int vec = 1;
     if (nij % 4 == 0 && aligned_to(dt, 16) && aligned_to(dm, 16)) vec = 4;
+    else if (nij >= 4 && !getenv("CDFT_HEATC_NOU4")) vec = -4;           // 16-byte loads at r4 alignment (A/B hook: the old paths)
     else if (nij % 2 == 0 && aligned_to(dt, 8) && aligned_to(dm, 8)) vec = 2;
-    a.nblk = (int)((nij / vec + kThreads * 4 - 1) / (kThreads * 4));   // kVPT = 4 vectors per lane
-    if (vec == 4)      CDFT_TRY(launch_vec<4>(a, st));
+    a.nblk = vec == -4 ? (int)(((nij + 3) / 4 + 1 + kThreads * 4 - 1) / (kThreads * 4))
+                       : (int)((nij / vec + kThreads * 4 - 1) / (kThreads * 4));   // kVPT = 4 vectors per lane
+    if (vec == -4)     CDFT_TRY(launch_u4(a, st));
+    else if (vec == 4) CDFT_TRY(launch_vec<4>(a, st));
     else if (vec == 2) CDFT_TRY(launch_vec<2>(a, st));
     else               CDFT_TRY(launch_vec<1>(a, st));
     hipLaunchKernelGGL(heatc_final_kernel, dim3(p->npk), dim3(kThreads), 0, st, p->partial, p->npk, a.nblk, dout);

@@ -9,6 +9,7 @@
 // regrouped in a fixed order (|d| <= 1e-13 * sum|terms|).  Same layout of the work as cdfheatc: one
 // workgroup owns a set of cells of the horizontal plane for ALL levels, keeps e1, e2 and the basin
 // values in registers and streams zv / e3 / mask past them (12 bytes per cell and level).
+#include <cstdlib>
 #include "common.hpp"
 #include "reduce.hpp"
 
@@ -48,13 +49,17 @@ __global__ void __launch_bounds__(kThreads) mean_level_kernel(MeanArgs a) {
     int64_t q[kVPT];
     float e1[kVPT][VEC], e2[kVPT][VEC], fb[kVPT][VEC][NB];
     bool ok[kVPT][VEC];
+    // VEC = 4: vectors at cells 0, 4, 8, ... and, when the plane is not a multiple of 4 cells, one more anchored at
+    // nij-4 whose leading cells belong to the previous vector and count as zeros here: no partial vector, no branch
+    const int64_t nfull = a.nij / VEC, nvtot = nfull + ((VEC == 4 && (a.nij & 3)) ? 1 : 0);
 #pragma unroll
     for (int v = 0; v < kVPT; ++v) {
-        q[v] = ((((int64_t)blockIdx.x * nwaves + wave) * kVPT + v) * 64 + lane) * VEC;   // first cell of the vector
+        const int64_t iv = (((int64_t)blockIdx.x * nwaves + wave) * kVPT + v) * 64 + lane;     // vector index
+        q[v] = iv < nvtot ? (VEC == 4 ? min(iv * 4, a.nij - 4) : iv * VEC) : 0;                  // its first cell
 #pragma unroll
         for (int c = 0; c < VEC; ++c) {
             const int64_t p = q[v] + c;
-            ok[v][c] = p < a.nij;
+            ok[v][c] = iv < nvtot && (iv < nfull || p >= nfull * VEC);
             const int64_t pc = ok[v][c] ? p : 0;
             e1[v][c] = ok[v][c] ? a.e1[pc] : 0.f;      // cells past the plane contribute exact zeros
             e2[v][c] = a.e2[pc];
@@ -67,16 +72,16 @@ __global__ void __launch_bounds__(kThreads) mean_level_kernel(MeanArgs a) {
         float zv[kVPT][VEC], e3[kVPT][VEC], mk[kVPT][VEC];
 #pragma unroll
         for (int v = 0; v < kVPT; ++v) {
-            if constexpr (VEC == 4) {                  // nij % 4 == 0 and 16-byte aligned bases on this path
-                const int64_t qc = ok[v][0] ? q[v] : 0;
-                const f4a z = ld_stream4(a.zv + base + qc), m = ld_stream4(a.mask + base + qc);
+            if constexpr (VEC == 4) {                  // 16-byte loads at r4 alignment, always inside the level
+                const f4u z = ld_stream4u(a.zv + base + q[v]), m = ld_stream4u(a.mask + base + q[v]);
                 zv[v][0] = z.x; zv[v][1] = z.y; zv[v][2] = z.z; zv[v][3] = z.w;
                 mk[v][0] = m.x; mk[v][1] = m.y; mk[v][2] = m.z; mk[v][3] = m.w;
                 if (!FULL) {
-                    const f4a e = ld_stream4(a.e3 + base + qc);
+                    const f4u e = ld_stream4u(a.e3 + base + q[v]);
                     e3[v][0] = e.x; e3[v][1] = e.y; e3[v][2] = e.z; e3[v][3] = e.w;
                 }
-                if (!ok[v][0]) { zv[v][0] = zv[v][1] = zv[v][2] = zv[v][3] = 0.f; }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) if (!ok[v][c]) zv[v][c] = 0.f;      // not this lane's cell: an exact zero
             } else {
 #pragma unroll
                 for (int c = 0; c < VEC; ++c) {
@@ -227,7 +232,7 @@ int cdft_mean_compute(cdft_mean_plan *p, const float *zv, int in_space, double *
     MeanArgs a;
     a.e1 = p->e1; a.e2 = p->e2; a.e3 = p->e3; a.e31d = p->e31d; a.mask = p->mask; a.zv = (const float *)dz; a.ib = p->ib;
     a.nij = nij; a.npk = p->npk; a.nb = p->nb; a.partial = p->partial; a.form = p->form;
-    const bool vec4 = (nij % 4 == 0) && al16(dz) && al16(p->mask) && (!p->e3 || al16(p->e3));
+    const bool vec4 = nij >= 4 && !getenv("CDFT_MEAN_SCALAR");         // (A/B hook: the scalar path)
     const int vec = vec4 ? 4 : 1;
     a.nblk = (int)(((nij + vec - 1) / vec + kThreads * kVPT - 1) / (kThreads * kVPT));
     const dim3 grid(a.nblk), block(kThreads);

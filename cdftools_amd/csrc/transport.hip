@@ -27,8 +27,9 @@ template <> struct FV<4> { typedef float4 t; };
 template <> struct FV<2> { typedef float2 t; };
 template <> struct FV<1> { typedef float t; };
 template <int VEC> __device__ __forceinline__ void ld(const float *p, int64_t e, float (&o)[VEC]);
+// (16-byte loads at r4 alignment: a level of a plane that is not a multiple of 4 cells starts anywhere)
 template <> __device__ __forceinline__ void ld<4>(const float *p, int64_t e, float (&o)[4]) {
-    const float4 v = *reinterpret_cast<const float4 *>(p + e); o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+    const f4u v = *reinterpret_cast<const f4u *>(p + e); o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
 }
 template <> __device__ __forceinline__ void ld<2>(const float *p, int64_t e, float (&o)[2]) {
     const float2 v = *reinterpret_cast<const float2 *>(p + e); o[0] = v.x; o[1] = v.y;
@@ -38,7 +39,7 @@ template <> __device__ __forceinline__ void ld<1>(const float *p, int64_t e, flo
 typedef float f2a __attribute__((ext_vector_type(2)));
 template <int VEC> __device__ __forceinline__ void lds_(const float *p, int64_t e, float (&o)[VEC]);
 template <> __device__ __forceinline__ void lds_<4>(const float *p, int64_t e, float (&o)[4]) {
-    const f4a v = ld_stream4(p + e); o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+    const f4u v = ld_stream4u(p + e); o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
 }
 template <> __device__ __forceinline__ void lds_<2>(const float *p, int64_t e, float (&o)[2]) {
     const f2a v = ld_stream(reinterpret_cast<const f2a *>(p + e)); o[0] = v.x; o[1] = v.y;
@@ -65,18 +66,22 @@ __global__ void __launch_bounds__(kThreads) vint_kernel(VintArgs a) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * kThreads + threadIdx.x) >> 6;
     int64_t p[VPT];
-    bool ok[VPT], lastrow[VPT];
+    bool ok[VPT], lastrow[VPT], own[VPT][VEC];
     float m[VPT][VEC];
     double s0[VPT][VEC], s1[VPT][VEC];
+    // VEC = 4: vectors at cells 0, 4, 8, ... and, when the plane is not a multiple of 4 cells, one more anchored at
+    // nij-4 whose leading cells belong to the previous vector (computed twice, stored once): no partial vector
+    const int64_t nfull = a.nij / VEC, nvtot = nfull + ((VEC == 4 && (a.nij & 3)) ? 1 : 0);
 #pragma unroll
     for (int v = 0; v < VPT; ++v) {
-        p[v] = ((wave * VPT + v) * 64 + lane) * VEC;
-        ok[v] = p[v] < a.nij;
-        if (!ok[v]) p[v] = 0;                              // harmless in-range address, never stored
+        const int64_t q = (wave * VPT + v) * 64 + lane;
+        ok[v] = q < nvtot;
+        p[v] = ok[v] ? (VEC == 4 ? min(q * 4, a.nij - 4) : q * VEC) : 0;      // (not ok: a harmless in-range address)
         ld<VEC>(a.m2d, p[v], m[v]);
-        lastrow[v] = (MODE == kMhstSep) && (p[v] / a.npi == a.npj - 1);    // npi % VEC == 0 here
+        lastrow[v] = (MODE == kMhstSep) && (p[v] / a.npi == a.npj - 1);    // npi % VEC == 0 in this mode
 #pragma unroll
         for (int c = 0; c < VEC; ++c) {
+            own[v][c] = ok[v] && (q < nfull || p[v] + c >= nfull * VEC);
             s0[v][c] = a.init ? 0.0 : a.acc0[p[v] + c];
             s1[v][c] = (MODE != kPsi && !a.init) ? a.acc1[p[v] + c] : 0.0;
         }
@@ -149,9 +154,9 @@ __global__ void __launch_bounds__(kThreads) vint_kernel(VintArgs a) {
     }
 #pragma unroll
     for (int v = 0; v < VPT; ++v)
-        if (ok[v])
 #pragma unroll
-            for (int c = 0; c < VEC; ++c) {
+        for (int c = 0; c < VEC; ++c)
+            if (own[v][c]) {
                 a.acc0[p[v] + c] = s0[v][c];
                 if (MODE != kPsi) a.acc1[p[v] + c] = s1[v][c];
             }
@@ -166,7 +171,8 @@ int launch_vint(const VintArgs &a, hipStream_t st) {
     };
     int vec = 1;
     const bool rowok4 = MODE != kMhstSep || a.npi % 4 == 0, rowok2 = MODE != kMhstSep || a.npi % 2 == 0;
-    if (a.nij % 4 == 0 && rowok4 && all(16)) vec = 4;
+    if (a.nij >= 4 && rowok4 && !getenv("CDFT_VINT_ALIGNED_ONLY")) vec = 4;      // r4-aligned 16-byte loads, any plane size
+    else if (a.nij % 4 == 0 && rowok4 && all(16)) vec = 4;
     else if (a.nij % 2 == 0 && rowok2 && all(8)) vec = 2;
     const bool full = a.e31d != nullptr;
     static int vpt = 0;                                  // vectors per lane: CDFT_VINT_VPT = 1 | 2 | 4 (tuning)

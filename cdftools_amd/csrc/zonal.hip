@@ -547,7 +547,7 @@ int cdft_zonal_compute(cdft_zonal_plan *p, const float *zv, int nlev, int in_spa
     else if (p->nb <= 5) CDFT_TRY(launch_rows<5>(a, only, mean_form != 0, minmax, st));
     else                 CDFT_TRY(launch_rows<8>(a, only, mean_form != 0, minmax, st));
     }
-    if (mean_form)      // the first nlev levels of every basin's precomputed area
+    if (mean_form)      // the first nlev levels of every basin's precomputed area (a pitched copy: measured faster than plain ones)
         CDFT_HIP(hipMemcpy2DAsync(darea, (size_t)nlev * p->npj * 8, p->area, (size_t)p->npk * p->npj * 8, (size_t)nlev * p->npj * 8,
                                   p->nb, out_space == CDFT_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, st));
     if (out_space == CDFT_MEM_HOST) {
