@@ -19,7 +19,8 @@ struct cdft_moc_plan {
     bool mesh_set = false;
     int  tune_waves = 0, tune_nv = 0, tune_mode = 0;
     DevBuf st_e1v, st_e3v, st_mask, st_zv, st_out;
-    DevBuf st_vm;   // staging for host arrays
+    DevBuf st_vm;
+    bool last_aligned = true;  // alignment of the records of the last launch (cdft_moc_describe)   // staging for host arrays
     // -decomp (cdft_moc_decomp_*): the mesh it needs beyond w / bits, and its work arrays
     bool dec_set = false;
     DevBuf d_e3v, d_e1u, d_zcoef, d_tmask, d_umask;  // e3v (masked) 3-D, e1u / zcoef 2-D, masks 3-D bytes
@@ -215,11 +216,15 @@ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 // pick waves per row and float4 vectors per lane for a row of npi cells
 void choose_shape(const cdft_moc_plan *p, bool aligned, int *nwaves, int *nv, int *mode) {
     const int nvec = (p->npi + 6) / 4;             // worst-case aligned vectors covering a row
-    int md = p->tune_mode ? p->tune_mode : ((p->nbasins > 1 && p->nclass > 0) ? kModeClass : kModeSelect);
-    if (md == kModeClass && (!aligned || p->nbasins == 1 || p->nclass == 0 || p->nclass > kMaxClass))
-        md = kModeSelect;
+    const bool class_ok = p->nclass > 0 && p->nclass <= kMaxClass;
+    int md = p->tune_mode ? p->tune_mode : ((p->nbasins > 1 && class_ok) ? kModeClass : kModeSelect);
+    if (md == kModeClass && (p->nbasins == 1 || !class_ok)) md = kModeSelect;
+    // records whose base or stride is not a multiple of 16 bytes (eORCA025: 130 537 050 cells per record): the class
+    // kernel reads them with 16-byte loads at r4 alignment, whatever the number of basins; the select kernel would
+    // fall back to scalar loads
+    if (!aligned) md = (class_ok && p->npi >= 4 && p->tune_mode != kModeSelect) ? kModeClass : kModeSelect;
     int k, v;
-    if (!aligned) {
+    if (!aligned && md != kModeClass) {
         md = kModeSelect;
         v  = 4;
         k  = ceil_div(nvec, kWave * v);
@@ -251,9 +256,13 @@ static int zonal_launch(cdft_moc_plan *p, const float *d_zv, int64_t rec_stride,
     for (int c = 0; c < kMaxClass; ++c) a.pat[c] = p->pat[c];
     a.zv = d_zv; a.rec_stride = rec_stride; a.npt = npt;
     a.out = d_out; a.npi = p->npi; a.npj = p->npj; a.npk = p->npk; a.nbasins = p->nbasins;
+    a.rows_per_wg = 1;
+    a.aligned = ((uintptr_t)d_zv % 16 == 0) && (rec_stride % 4 == 0);
+    { const char *e = getenv("CDFT_MOC_ROWS"); if (e && atoi(e) >= 1) a.rows_per_wg = atoi(e); }
     const bool aligned = ((uintptr_t)d_zv % 16 == 0) && (rec_stride % 4 == 0);
     int k, v, md;
     choose_shape(p, aligned, &k, &v, &md);
+    p->last_aligned = aligned;
     if (k > kMaxWaves || v > kMaxNV)
         return fail(CDFT_ERR_ARG, "cdft_moc_compute: row of %d cells needs %d waves x %d vectors", p->npi, k, v);
     hipEvent_t ev1 = nullptr;
@@ -387,12 +396,13 @@ int cdft_moc_set_tuning(cdft_moc_plan *p, int waves_per_row, int vec_per_lane, i
 int cdft_moc_describe(cdft_moc_plan *p, char *buf, size_t buflen) {
     if (!p || !buf) return fail(CDFT_ERR_ARG, "cdft_moc_describe: NULL argument");
     int k, v, md;
-    choose_shape(p, true, &k, &v, &md);
+    choose_shape(p, p->last_aligned, &k, &v, &md);       // the shape of the last launch (16-byte aligned records before any)
     const int nb = p->nbasins == 1 ? 1 : (p->nbasins <= 5 ? 5 : 8);
     if (md == kModeClass)
-        snprintf(buf, buflen, "moc_zonal_class_kernel<NV=%d,KC=%d> waves_per_row=%d basin_patterns=%d", v, kMaxClass, k, p->nclass);
+        snprintf(buf, buflen, "moc_zonal_class_kernel<NV=%d,KC=%d,ALIGNED=%d> waves_per_row=%d basin_patterns=%d", v, kMaxClass,
+                 p->last_aligned ? 1 : 0, k, p->nclass);
     else
-        snprintf(buf, buflen, "moc_zonal_kernel<NV=%d,NB=%d,ALIGNED=1,MODE=%s> waves_per_row=%d", v, nb,
+        snprintf(buf, buflen, "moc_zonal_kernel<NV=%d,NB=%d,ALIGNED=%d,MODE=%s> waves_per_row=%d", v, nb, p->last_aligned ? 1 : 0,
                  md == kModeFma ? "fma" : "select", k);
     return CDFT_OK;
 }

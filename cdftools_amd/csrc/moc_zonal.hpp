@@ -51,6 +51,8 @@ struct ZonalArgs {
     int            npt;
     double        *out;         // (nbasins,npj,npk,npt): -(zonal sum), levels 1..npk-1
     int            npi, npj, npk, nbasins;
+    int            rows_per_wg; // class kernel: consecutive rows one workgroup works through (>= 1)
+    int            aligned;     // class kernel: record base and stride are multiples of 16 bytes
 };
 
 typedef int (*ZonalLauncher)(const ZonalArgs &, int nwaves, int nv, bool aligned, int mode,
@@ -319,59 +321,69 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
 // the end (basin b = classes whose pattern has bit b, in class order).  The empty pattern (a cell in
 // no basin) is a class like the others: its sum is finite unless a NaN/Inf sits on such a cell, and
 // 0 * (the sums of the classes outside b) restores the NaN the reference's 0*zv products give.
-template <int NV, int KC, int LB>
-__global__ void __launch_bounds__(LB)
-moc_zonal_class_kernel(ZonalArgs a) {
-    extern __shared__ double smem[];
+// ALIGNED: records whose base and stride are multiples of 16 bytes: the row is covered by vectors aligned to the
+// ARRAY and its first / last vector is shared with the neighbouring rows (masked).  Otherwise (eORCA025: 1442 x 1207 x 75
+// cells per record, not a multiple of 4): 16-byte loads at r4 alignment, vectors at cells 0, 4, 8, ... of the ROW plus
+// one anchored at npiglo-4 whose leading cells repeat the previous vector's and go to the unread slot.
+template <bool ALIGNED> struct ZVec;
+template <> struct ZVec<true>  { typedef f4a T; static __device__ __forceinline__ f4a ld(const float *p) { return ld_stream4(p); } };
+template <> struct ZVec<false> { typedef f4u T; static __device__ __forceinline__ f4u ld(const float *p) { return ld_stream4u(p); } };
+
+template <int NV, int KC, bool ALIGNED>
+__device__ __forceinline__ void moc_zonal_class_row(const ZonalArgs &a, const int row, double *smem) {
+    typedef typename ZVec<ALIGNED>::T V4;
     const int lane   = threadIdx.x & (kWave - 1);
     const int wave   = threadIdx.x >> 6;
     const int nwaves = blockDim.x >> 6;
     double *scr  = smem + wave * ((KC + 1) * kScrStride);        // slot [class][lane]; class KC = lanes past the row end
     double *part = smem + nwaves * ((KC + 1) * kScrStride);      // [kTChunk][KC][nwaves]
 
-    const int row = blockIdx.x;                                   // jk*npj + jj, jj fastest
-    const int jk  = row / a.npj;
+    const int jk  = row / a.npj;                                  // row = jk*npj + jj, jj fastest
     const int jj  = row - jk * a.npj;
     const int64_t g0   = (int64_t)row * a.npi;
-    const int     head = (int)(g0 & 3);
-    const int64_t a0   = g0 - head;
+    const int     head = ALIGNED ? (int)(g0 & 3) : 0;
     const int     v0   = wave * (kWave * NV) + lane;
+    const int     nfull = a.npi >> 2;                             // (not ALIGNED) vectors 0..nfull-1 start at cell 4v
 
     float   w[NV][4];
     int     slot[NV][4];                                          // index of the cell's slot in scr
-    bool    vec_ok[NV];
+    int     i0[NV];                                               // column of component 0 (ALIGNED: -head .. )
+    int64_t off[NV];                                              // element offset of the vector in a 3-D field
     const uint8_t *crow = a.cls + (int64_t)jj * a.npi;
-    f4a      wraw[NV];
+    V4       wraw[NV];
     uint32_t craw[NV][4];
 #pragma unroll
     for (int r = 0; r < NV; ++r) {                                // issue every load first
         const int v  = v0 + r * kWave;
-        const int i0 = 4 * v - head;
-        vec_ok[r] = i0 < a.npi;
-        const int vc = vec_ok[r] ? v : 0;
-        wraw[r] = ld_stream4(a.w + a0 + 4 * (int64_t)vc);
+        if (ALIGNED) {
+            i0[r] = 4 * v - head;
+            off[r] = g0 + (i0[r] < a.npi ? i0[r] : -head);        // lanes past the row end re-read its first vector
+        } else {
+            i0[r] = min(4 * v, a.npi - 4);                        // v >= nfull: the anchored vector (in range for every lane)
+            off[r] = g0 + i0[r];
+        }
+        wraw[r] = ZVec<ALIGNED>::ld(a.w + off[r]);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) craw[r][c] = crow[min(max(i0 + c, 0), a.npi - 1)];
+        for (int c = 0; c < 4; ++c) craw[r][c] = crow[min(max(i0[r] + c, 0), a.npi - 1)];
     }
-    auto load_rec = [&](f4a (&z)[NV], int t) {
+    auto load_rec = [&](V4 (&z)[NV], int t) {
         const float *zr = a.zv + (int64_t)t * a.rec_stride;
 #pragma unroll
-        for (int r = 0; r < NV; ++r) {
-            const int vc = vec_ok[r] ? v0 + r * kWave : 0;
-            z[r] = ld_stream4(zr + a0 + 4 * (int64_t)vc);
-        }
+        for (int r = 0; r < NV; ++r) z[r] = ZVec<ALIGNED>::ld(zr + off[r]);
     };
-    f4a zc[NV], zn[NV];
+    V4 zc[NV], zn[NV];
     load_rec(zc, 0);
 #pragma unroll
     for (int s = 0; s <= KC; ++s) scr[s * kScrStride + lane] = 0.0;
 #pragma unroll
     for (int r = 0; r < NV; ++r) {
-        const int i0 = 4 * (v0 + r * kWave) - head;
+        const int v = v0 + r * kWave;
         const float wr[4] = {wraw[r].x, wraw[r].y, wraw[r].z, wraw[r].w};
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const bool ok = (i0 + c >= 0) && (i0 + c < a.npi);
+            const int i = i0[r] + c;
+            const bool ok = ALIGNED ? (i >= 0 && i < a.npi && 4 * v - head < a.npi)
+                                    : (v < nfull || (v == nfull && i >= 4 * nfull));
             w[r][c]    = ok ? wr[c] : 0.f;
             slot[r][c] = (ok ? min((int)craw[r][c], KC) : KC) * kScrStride + lane;   // slot KC is never read
         }
@@ -414,8 +426,8 @@ moc_zonal_class_kernel(ZonalArgs a) {
             for (int r = 0; r < NV; ++r) zc[r] = zn[r];
         }
         __syncthreads();
-        if ((int)threadIdx.x < tcount * a.nbasins) {
-            const int tl = threadIdx.x / a.nbasins, b = threadIdx.x - tl * a.nbasins;
+        for (int q = threadIdx.x; q < tcount * a.nbasins; q += blockDim.x) {     // (one wave holds 64 < 16 records x 5 basins)
+            const int tl = q / a.nbasins, b = q - tl * a.nbasins;
             double s = 0.0, z = 0.0;
             for (int c = 0; c < a.nclass; ++c) {
                 const bool in = (a.pat[c] >> b) & 1;
@@ -433,11 +445,24 @@ moc_zonal_class_kernel(ZonalArgs a) {
     }
 }
 
+// A workgroup takes rows_per_wg consecutive rows: short rows (eORCA025: 5.8 KB per record) are otherwise bound by the
+// rate at which workgroups can be started, not by memory (measured: the same 1.77 ms whatever the kernel shape).
+template <int NV, int KC, int LB, bool ALIGNED>
+__global__ void __launch_bounds__(LB)
+moc_zonal_class_kernel(ZonalArgs a) {
+    extern __shared__ double smem[];
+    const int nrows = a.npj * (a.npk - 1);
+    const int r0 = blockIdx.x * a.rows_per_wg, r1 = min(nrows, r0 + a.rows_per_wg);
+    for (int row = r0; row < r1; ++row) moc_zonal_class_row<NV, KC, ALIGNED>(a, row, smem);
+}
+
 template <int NV, int KC, int LB>
 static int launch_class_lb(const ZonalArgs &a, int nwaves, hipStream_t st) {
     const size_t shmem = sizeof(double) * ((size_t)nwaves * (KC + 1) * kScrStride + (size_t)kTChunk * KC * nwaves);
-    const unsigned grid = (unsigned)a.npj * (unsigned)(a.npk - 1);
-    hipLaunchKernelGGL((moc_zonal_class_kernel<NV, KC, LB>), dim3(grid), dim3(kWave * nwaves), shmem, st, a);
+    const unsigned nrows = (unsigned)a.npj * (unsigned)(a.npk - 1);
+    const unsigned grid = (nrows + (unsigned)a.rows_per_wg - 1) / (unsigned)a.rows_per_wg;
+    if (a.aligned) hipLaunchKernelGGL((moc_zonal_class_kernel<NV, KC, LB, true>), dim3(grid), dim3(kWave * nwaves), shmem, st, a);
+    else           hipLaunchKernelGGL((moc_zonal_class_kernel<NV, KC, LB, false>), dim3(grid), dim3(kWave * nwaves), shmem, st, a);
     CDFT_LAUNCH_CHECK();
     return CDFT_OK;
 }

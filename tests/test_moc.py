@@ -170,10 +170,16 @@ def test_hip_mask_product_of_get_e3v_on_the_device(gpu, npi, npj, npk, nb):
 
 
 @pytest.mark.gpu
-def test_hip_unaligned_records_take_the_scalar_path(gpu):
+@pytest.mark.parametrize("npi,nb,mode,kernel", [(333, 5, 0, "class_kernel<NV=2,KC=8,ALIGNED=0>"), (1442, 5, 0, "ALIGNED=0"),
+                                                (334, 1, 0, "class_kernel"), (6, 5, 0, "class_kernel"), (4, 3, 0, "class_kernel"),
+                                                (3, 5, 0, "MODE=select"), (333, 5, 1, "MODE=select")])
+def test_hip_records_that_are_not_16_byte_aligned(gpu, npi, nb, mode, kernel):
+    """A record base / stride that is not a multiple of 16 bytes (eORCA025: 130 537 050 cells per record): the class
+    kernel reads with 16-byte loads at r4 alignment and an anchored tail vector; rows shorter than one vector, or the
+    select mode when asked for, take the scalar-load variant."""
     import torch
 
-    npi, npj, npk, nb, npt = 333, 5, 4, 5, 3
+    npj, npk, npt = 5, 4, 3
     g = synth.make_grid(npi, npj, npk, seed=5, nbasins=nb)
     e1v, e3v, ib = synth.moc_inputs(g)
     zv = synth.velocity(g, npt, seed=8)
@@ -185,11 +191,16 @@ def test_hip_unaligned_records_take_the_scalar_path(gpu):
         view[t * stride: t * stride + n3] = torch.from_numpy(zv[t].ravel()).cuda()
     plan = gpu.MocPlan(npi, npj, npk, nb)
     plan.set_mesh(e1v, e3v, ib)
+    plan.set_tuning(mode=mode)
     out = torch.empty((npt, npk, npj, nb), dtype=torch.float64, device="cuda")
     plan.compute(view, out=out, rec_stride=stride, npt=npt)
     torch.cuda.synchronize()
+    assert kernel in plan.describe(), plan.describe()
     ref = oracle_lib.moc(e1v, e3v, ib, zv)
     assert_moc_close(out.cpu().numpy(), ref, abs_bound(e1v, e3v, ib, zv))
+    again = torch.empty_like(out)
+    plan.compute(view, out=again, rec_stride=stride, npt=npt)
+    assert torch.equal(out, again)
 
 
 @pytest.mark.gpu
