@@ -73,6 +73,7 @@ CASES = [
     (3, 2, 2, 5, 3),         # shorter than one float4
     (63, 5, 4, 5, 1), (64, 5, 4, 5, 1), (65, 5, 4, 5, 1), (255, 3, 3, 8, 2), (257, 3, 3, 3, 2),
     (1031, 7, 5, 5, 17),     # ragged row, more records than one LDS chunk
+    (1032, 4, 5, 5, 16),     # 16-byte aligned records, one wave per row, 16 records x 5 basins > 64 lanes in the epilogue
     (4322, 3, 4, 5, 2),      # eORCA12 row length
     (12960, 2, 3, 5, 1),     # eORCA36 row length (1024-thread workgroups)
 ]
