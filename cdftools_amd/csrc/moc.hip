@@ -233,12 +233,23 @@ void choose_shape(const cdft_moc_plan *p, bool aligned, int *nwaves, int *nv, in
         else if (p->tune_waves > 0) { k = p->tune_waves; v = ceil_div(nvec, kWave * k); }
         else { v = p->tune_nv; k = ceil_div(nvec, kWave * v); }
     } else {
-        int vmax = (md == kModeFma) ? 4 : (md == kModeClass ? 9 : 8);   // measured best at npiglo = 4322
-        k = ceil_div(nvec, kWave * vmax);
-        if (k > kSmallWaves) {          // long rows: 1024-thread workgroups, fewer registers
-            // (several basin accumulators leave room for one vector less than a single one does)
-            vmax = (md == kModeFma) ? 2 : (md == kModeClass ? kBigNVClass : (p->nbasins > 1 ? kBigNV - 1 : kBigNV));
+        if (md == kModeClass) {
+            // vectors per lane by workgroup size (256 / 512 / 1024 threads leave 512 / 256 / 128 VGPRs per lane); records
+            // that are not 16-byte aligned cost more registers per vector (measured: no spill with these)
+            const int v_small = aligned ? 9 : 6, v_mid = aligned ? 9 : 8, v_big = aligned ? kBigNVClass : 4;
+            k = ceil_div(nvec, kWave * v_small);                   // 9: measured best at npiglo = 4322
+            if (k > kSmallWaves) {
+                k = ceil_div(nvec, kWave * v_mid);                 // rows of 4.6k .. 18k cells (eORCA36): 512 threads
+                if (k > kMidWaves || ceil_div(nvec, kWave * k) <= kBigNVClass) k = ceil_div(nvec, kWave * v_big);
+            }
+        } else {
+            int vmax = (md == kModeFma) ? 4 : 8;
             k = ceil_div(nvec, kWave * vmax);
+            if (k > kSmallWaves) {          // long rows: 1024-thread workgroups, fewer registers
+                // (several basin accumulators leave room for one vector less than a single one does)
+                vmax = (md == kModeFma) ? 2 : (p->nbasins > 1 ? kBigNV - 1 : kBigNV);
+                k = ceil_div(nvec, kWave * vmax);
+            }
         }
         v = ceil_div(nvec, kWave * k);
     }

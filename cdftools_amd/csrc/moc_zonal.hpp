@@ -32,6 +32,7 @@ constexpr int kWave      = 64;
 constexpr int kMaxNV     = 16;   // float4 vectors per lane held in registers
 constexpr int kMaxWaves  = 16;   // waves per row (1024-thread workgroup)
 constexpr int kSmallWaves = 4;   // waves per row of a 256-thread workgroup
+constexpr int kMidWaves  = 8;    // waves per row of a 512-thread workgroup (class kernel, 6..9 vectors per lane)
 constexpr int kBigNV     = 6;    // vectors per lane a 1024-thread workgroup can hold unspilled
 constexpr int kBigNVClass = 5;   // the same for the class kernel (one slot index per cell on top)
 constexpr int kTChunk    = 16;   // records combined per LDS flush
@@ -347,29 +348,29 @@ __device__ __forceinline__ void moc_zonal_class_row(const ZonalArgs &a, const in
 
     float   w[NV][4];
     int     slot[NV][4];                                          // index of the cell's slot in scr
-    int     i0[NV];                                               // column of component 0 (ALIGNED: -head .. )
-    int64_t off[NV];                                              // element offset of the vector in a 3-D field
+    int     ioff[NV];                                             // column the lane's vector is loaded from (ALIGNED: -head ..)
     const uint8_t *crow = a.cls + (int64_t)jj * a.npi;
     V4       wraw[NV];
     uint32_t craw[NV][4];
 #pragma unroll
     for (int r = 0; r < NV; ++r) {                                // issue every load first
         const int v  = v0 + r * kWave;
+        int i0;                                                   // column of component 0
         if (ALIGNED) {
-            i0[r] = 4 * v - head;
-            off[r] = g0 + (i0[r] < a.npi ? i0[r] : -head);        // lanes past the row end re-read its first vector
+            i0 = 4 * v - head;
+            ioff[r] = i0 < a.npi ? i0 : -head;                    // lanes past the row end re-read its first vector
         } else {
-            i0[r] = min(4 * v, a.npi - 4);                        // v >= nfull: the anchored vector (in range for every lane)
-            off[r] = g0 + i0[r];
+            i0 = min(4 * v, a.npi - 4);                           // v >= nfull: the anchored vector (in range for every lane)
+            ioff[r] = i0;
         }
-        wraw[r] = ZVec<ALIGNED>::ld(a.w + off[r]);
+        wraw[r] = ZVec<ALIGNED>::ld(a.w + g0 + ioff[r]);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) craw[r][c] = crow[min(max(i0[r] + c, 0), a.npi - 1)];
+        for (int c = 0; c < 4; ++c) craw[r][c] = crow[min(max(i0 + c, 0), a.npi - 1)];
     }
     auto load_rec = [&](V4 (&z)[NV], int t) {
-        const float *zr = a.zv + (int64_t)t * a.rec_stride;
+        const float *zr = a.zv + (int64_t)t * a.rec_stride + g0;
 #pragma unroll
-        for (int r = 0; r < NV; ++r) z[r] = ZVec<ALIGNED>::ld(zr + off[r]);
+        for (int r = 0; r < NV; ++r) z[r] = ZVec<ALIGNED>::ld(zr + ioff[r]);
     };
     V4 zc[NV], zn[NV];
     load_rec(zc, 0);
@@ -381,8 +382,8 @@ __device__ __forceinline__ void moc_zonal_class_row(const ZonalArgs &a, const in
         const float wr[4] = {wraw[r].x, wraw[r].y, wraw[r].z, wraw[r].w};
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const int i = i0[r] + c;
-            const bool ok = ALIGNED ? (i >= 0 && i < a.npi && 4 * v - head < a.npi)
+            const int i = (ALIGNED ? 4 * v - head : min(4 * v, a.npi - 4)) + c;
+            const bool ok = ALIGNED ? (i >= 0 && i < a.npi)
                                     : (v < nfull || (v == nfull && i >= 4 * nfull));
             w[r][c]    = ok ? wr[c] : 0.f;
             slot[r][c] = (ok ? min((int)craw[r][c], KC) : KC) * kScrStride + lane;   // slot KC is never read
@@ -469,6 +470,11 @@ static int launch_class_lb(const ZonalArgs &a, int nwaves, hipStream_t st) {
 template <int NV, int KC>
 static int launch_class_one(const ZonalArgs &a, int nwaves, hipStream_t st) {
     if (nwaves <= kSmallWaves) return launch_class_lb<NV, KC, kWave * kSmallWaves>(a, nwaves, st);
+    // 5..8 waves (rows of 4.6k .. 18k cells, eORCA36): 512-thread workgroups keep 256 VGPRs per lane, i.e. the 9
+    // vectors per lane that stream best; 1024-thread workgroups only have room for kBigNVClass
+    if constexpr (NV > kBigNVClass && NV <= 9) {
+        if (nwaves <= kMidWaves) return launch_class_lb<NV, KC, kWave * kMidWaves>(a, nwaves, st);
+    }
     if constexpr (NV <= kBigNVClass) return launch_class_lb<NV, KC, kWave * kMaxWaves>(a, nwaves, st);
     else return fail(CDFT_ERR_ARG, "%d waves per row need <= %d vectors per lane, got %d", nwaves, kBigNVClass, NV);
 }
