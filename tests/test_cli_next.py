@@ -504,8 +504,13 @@ def test_oracle_vint_and_vertmean_match_numpy_restatement_bitwise():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("npi,npj,npk", [(24, 18, 7), (182, 149, 31), (1, 1, 2), (130, 5, 4)])
-def test_hip_vint_and_vertmean_equal_oracle_bitwise(gpu, npi, npj, npk):
+@pytest.mark.parametrize("kernel", ["vec4", "scalar"])
+@pytest.mark.parametrize("npi,npj,npk", [(24, 18, 7), (182, 149, 31), (1, 1, 2), (130, 5, 4), (3, 1, 3), (5, 1, 9), (7, 3, 5),
+                                         (1027, 3, 6)])
+def test_hip_vint_and_vertmean_equal_oracle_bitwise(gpu, monkeypatch, kernel, npi, npj, npk):
+    # vec4: 4 cells per thread with the last vector anchored at nij-4 (nij % 4 of every kind, nij < 4 falls back);
+    # scalar: one cell per thread
+    monkeypatch.setenv("CDFT_COLUMN_SCALAR", "1" if kernel == "scalar" else "0")
     g, zt, tm = column_inputs(npi, npj, npk, seed=npi + 6)
     e31d = g["e3t_1d"]
     sclf = np.float32(np.float32(1020.) * np.float32(4000.) / np.float32(1.e6))
