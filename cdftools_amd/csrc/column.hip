@@ -25,6 +25,17 @@ struct VintSched { const int *kout; const int *hit; const float *clip; const flo
 // last one is anchored at nij-4, so its first cells repeat the previous thread's and both store the same values), KU
 // levels of loads issued before the sums that use them.
 constexpr int kColKU = 4;
+#ifndef CDFT_COL_THREADS
+#define CDFT_COL_THREADS 1024
+#endif
+constexpr int kColThreads = CDFT_COL_THREADS;
+// Nothing is shared between threads; the barrier keeps the waves of a workgroup on the same levels, so that their
+// loads form one contiguous run per field and level.
+#ifndef CDFT_COL_NOSYNC
+#define COL_SYNC() __syncthreads()
+#else
+#define COL_SYNC() (void)0
+#endif
 
 template <int VEC> struct ColVec;
 template <> struct ColVec<1> {
@@ -42,28 +53,27 @@ template <> struct ColVec<4> {
     }
 };
 
+// First cell of this thread's vector; threads past the end repeat the last vector (same loads, same values stored), so
+// every thread of a workgroup runs the same loop and meets the same barriers.
 template <int VEC>
 __device__ __forceinline__ int64_t col_first_cell(int64_t nij) {
-    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (VEC == 1) return g < nij ? g : -1;
-    const int64_t p = g * VEC;
-    if (p >= nij) return -1;
+    const int64_t p = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
     return p + VEC <= nij ? p : nij - VEC;
 }
 
 template <int VEC, bool E3D>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(kColThreads)
 vint_cumul_kernel(const float *__restrict__ zt, const float *__restrict__ e3, const float *__restrict__ e31d,
                   const float *__restrict__ tmask, int64_t nij, int npk, const int *__restrict__ kout,
                   const int *__restrict__ hit, const float *__restrict__ clip, const float *__restrict__ dv,
                   float sclf, int mean, float *__restrict__ out) {
     const int64_t p = col_first_cell<VEC>(nij);
-    if (p < 0) return;
     double v1[VEC];                                             // dl_vint1
 #pragma unroll
     for (int c = 0; c < VEC; ++c) v1[c] = 0.0;
     for (int k0 = 0; k0 < npk; k0 += kColKU) {
         float t[kColKU][VEC], m[kColKU][VEC], ez[kColKU][VEC];
+        COL_SYNC();
 #pragma unroll
         for (int u = 0; u < kColKU; ++u) {
             if (k0 + u < npk) {
@@ -99,17 +109,17 @@ vint_cumul_kernel(const float *__restrict__ zt, const float *__restrict__ e3, co
 }
 
 template <int VEC, bool E3D>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(kColThreads)
 vertmean_kernel(const float *__restrict__ zv, const float *__restrict__ e3, const float *__restrict__ e31d,
                 const float *__restrict__ zmask, int64_t nij, int nlev, float gdep_first, float gdep_last,
                 float rdep_up, float rdep_down, double *__restrict__ dmean) {
     const int64_t p = col_first_cell<VEC>(nij);
-    if (p < 0) return;
     double dvol[VEC], dsum[VEC];
 #pragma unroll
     for (int c = 0; c < VEC; ++c) { dvol[c] = 0.0; dsum[c] = 0.0; }
     for (int k0 = 0; k0 < nlev; k0 += kColKU) {
         float v[kColKU][VEC], m[kColKU][VEC], ez[kColKU][VEC];
+        COL_SYNC();
 #pragma unroll
         for (int u = 0; u < kColKU; ++u) {
             if (k0 + u < nlev) {
@@ -185,9 +195,9 @@ int cdft_vint_cumul(const float *zt, const float *e3t, const float *e31d, const 
             if (!written[(size_t)q]) CDFT_HIP(hipMemsetAsync(o + (size_t)q * nij, 0, (size_t)nij * 4, st));
     }
     const int vec = column_vec(nij);
-    const dim3 grid((unsigned)(((nij + vec - 1) / vec + 255) / 256));
+    const dim3 grid((unsigned)(((nij + vec - 1) / vec + kColThreads - 1) / kColThreads));
 #define CDFT_VINT_LAUNCH(V, E)                                                                                         \
-    hipLaunchKernelGGL((vint_cumul_kernel<V, E>), grid, dim3(256), 0, st, (const float *)dz, (const float *)de,        \
+    hipLaunchKernelGGL((vint_cumul_kernel<V, E>), grid, dim3(kColThreads), 0, st, (const float *)dz, (const float *)de,        \
                        (const float *)d1, (const float *)dm, nij, npk, (const int *)sb,                                \
                        (const int *)(sb + (size_t)npk * 4), (const float *)(sb + (size_t)npk * 8),                     \
                        (const float *)(sb + (size_t)npk * 12), sclf, mean, o)
@@ -218,9 +228,9 @@ int cdft_vertmean(const float *zv, const float *e3, const float *e31d, const flo
     double *o = dvertmean;
     if (out_space == CDFT_MEM_HOST) { CDFT_TRY(g_co.reserve((size_t)nij * 8)); o = (double *)g_co.ptr; }
     const int vec = column_vec(nij);
-    const dim3 grid((unsigned)(((nij + vec - 1) / vec + 255) / 256));
+    const dim3 grid((unsigned)(((nij + vec - 1) / vec + kColThreads - 1) / kColThreads));
 #define CDFT_VERTMEAN_LAUNCH(V, E)                                                                                     \
-    hipLaunchKernelGGL((vertmean_kernel<V, E>), grid, dim3(256), 0, st, (const float *)dz, (const float *)de,          \
+    hipLaunchKernelGGL((vertmean_kernel<V, E>), grid, dim3(kColThreads), 0, st, (const float *)dz, (const float *)de,          \
                        (const float *)d1, (const float *)dm, nij, nlev, gdep_first, gdep_last, rdep_up, rdep_down, o)
     if (vec == 4) { if (de) CDFT_VERTMEAN_LAUNCH(4, true); else CDFT_VERTMEAN_LAUNCH(4, false); }
     else          { if (de) CDFT_VERTMEAN_LAUNCH(1, true); else CDFT_VERTMEAN_LAUNCH(1, false); }

@@ -16,6 +16,10 @@
 // that the row read as "j+1" is still in that XCD's L2 when it is read again as "j".
 #include "common.hpp"
 
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+
 using namespace cdft;
 
 namespace {
@@ -278,6 +282,151 @@ __global__ void __launch_bounds__(kThreads) curl_kernel(CurlArgs a) {
     }
 }
 
+// The kernel that runs (npiglo >= 4).  A tile is `tw` columns of one row, 4 per lane, for a range of levels; tw and
+// the workgroup size are chosen so that nearly every lane has cells (1024-column tiles left 30 % of the lanes idle
+// at npiglo = 1442).  Waves share nothing: the east neighbour of a lane's last cell is the next lane's first one
+// (a ds_bpermute; the last lane of a wave or tile loads it), the last vector of the row is anchored at npiglo-4 (its
+// repeated cells compute and store what their owner does).  Workgroups are handed out in (level chunk, row, tile)
+// order, so the ones running together sweep neighbouring rows through the same levels: that keeps the u(j+1) row in
+// L2 for the row above and the DRAM accesses in long runs (a persistent grid with equal shares of (tile, level)
+// units, each workgroup somewhere else in the levels, ran 50 % slower).  The levels are cut into `lc` chunks only
+// when one chunk would leave the chip half empty in its last round (eORCA025: 1.2 rounds).
+#ifndef CDFT_CURL_PF
+#define CDFT_CURL_PF 2
+#endif
+constexpr int kCurlPF = CDFT_CURL_PF;                             // level buffers in registers (kCurlPF-1 in flight)
+
+template <typename OUT, bool KEEP>
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 8))) curl_tile_kernel(CurlArgs a, int tw, int lc) {
+    const int lane = threadIdx.x & 63;
+    const int64_t tiles = (int64_t)a.ntx * a.npj, total = tiles * lc;
+    const int64_t job = xcd_band_item(total);
+    if (job >= total) return;                                     // whole block
+    const int64_t nij = (int64_t)a.npi * a.npj;
+    {
+        const int chunk = (int)(job / tiles);
+        const int64_t tile = job - chunk * tiles;
+        const int lev0 = (int)((int64_t)chunk * a.nlev / lc), lev1 = (int)((int64_t)(chunk + 1) * a.nlev / lc);
+        const int jj = (int)(tile / a.ntx), tx = (int)(tile - (int64_t)jj * a.ntx);
+        const bool north = jj < a.npj - 1;
+        const int it = (int)threadIdx.x * 4, ic = tx * tw + it;   // first column before anchoring
+        const bool act = it < tw && ic < a.npi;                   // lanes past the tile or the row do nothing
+        const int i0 = min(ic, a.npi - 4);
+        const int sh = act ? ic - i0 : 0;                         // cells of this vector that repeat the previous lane's
+        const bool halo = act && (lane == 63 || it + 4 >= tw) && ic + 4 < a.npi;   // east neighbour: next wave / tile
+        const int64_t p2 = (int64_t)jj * a.npi + i0;
+        float e1u[4] = {0, 0, 0, 0}, e1un[4] = {0, 0, 0, 0}, e2v[4] = {0, 0, 0, 0}, den[4] = {1, 1, 1, 1}, enx = 0.f;
+        if (act) {
+            float e1f[4], e2f[4];
+            load4(a.e1u + p2, 4, e1u); load4(a.e2v + p2, 4, e2v); load4(a.e1f + p2, 4, e1f); load4(a.e2f + p2, 4, e2f);
+            if (north) load4(a.e1u + p2 + a.npi, 4, e1un);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) den[c] = __fmul_rn(e1f[c], e2f[c]);
+            if (i0 + 4 < a.npi) enx = a.e2v[p2 + 4];
+        }
+        struct Level { float u[4], v[4], un1[4], hv; };
+        auto fetch = [&](Level &x, int lev) {
+            const float *un = a.un + (int64_t)lev * nij, *vn = a.vn + (int64_t)lev * nij;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { x.u[c] = x.v[c] = x.un1[c] = 0.f; }
+            if (act) {
+                load4(un + p2, 4, x.u); load4s(vn + p2, 4, x.v);
+                if (north) load4(un + p2 + a.npi, 4, x.un1);
+            }
+            x.hv = halo ? vn[p2 + 4] : 0.f;
+        };
+        Level q[kCurlPF];
+#pragma unroll
+        for (int k = 0; k < kCurlPF - 1; ++k)
+            if (lev0 + k < lev1) fetch(q[k], lev0 + k);
+        for (int levb = lev0; levb < lev1; levb += kCurlPF) {
+#pragma unroll
+            for (int k = 0; k < kCurlPF; ++k) {
+                const int lev = levb + k;
+                if (lev >= lev1) break;
+                if (lev + kCurlPF - 1 < lev1) fetch(q[(k + kCurlPF - 1) % kCurlPF], lev + kCurlPF - 1);
+                float u[4], un1[4], v[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { u[c] = q[k].u[c]; un1[c] = q[k].un1[c]; v[c] = q[k].v[c]; }
+                const float mine = sh == 0 ? v[0] : sh == 1 ? v[1] : sh == 2 ? v[2] : v[3];   // column ic of this row
+                __syncthreads();            // nothing is shared: it keeps the waves of the tile at the same level, and their
+                                            // loads one contiguous run (measured: 8 % faster at eORCA12 than free-running waves)
+                float vnx = __shfl_down(mine, 1);
+                if (halo) vnx = q[k].hv;
+                if (act) {
+                    double res[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int i = i0 + c;
+                        float val = 0.f;                                          // drotn(:,:) = 0.d0, :275
+                        if (north) {
+                            if (i < a.npi - 1) {
+                                const float ve = (c < 3) ? v[c < 3 ? c + 1 : 3] : vnx, ee = (c < 3) ? e2v[c < 3 ? c + 1 : 3] : enx;
+                                float f = __fmul_rn(__fmul_rn(__fmul_rn(u[c], un1[c]), v[c]), ve);
+                                f = (f != 0.f) ? 1.f : 0.f;
+                                const float num = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(ee, ve), -__fmul_rn(e2v[c], v[c])),
+                                                                      -__fmul_rn(e1un[c], un1[c])), __fmul_rn(e1u[c], u[c]));
+                                val = __fdiv_rn(__fmul_rn(num, f), den[c]);
+                            } else if (a.lperio && a.npi > 2) {                   // drotn(npiglo,:) = drotn(2,:), :285
+                                val = curl_at(a, a.un + (int64_t)lev * nij, a.vn + (int64_t)lev * nij, 1, jj, nullptr);
+                            }
+                        }
+                        res[c] = (double)val;
+                        if (KEEP) a.work[(int64_t)lev * nij + p2 + c] = res[c];
+                        if (!KEEP && a.ff) {                                          // -overf, :299-301 (ff re-read per level:
+                            const double f = a.ff[p2 + c];                            // 8 registers fewer for every other run)
+                            if (f != 0.0) res[c] = __ddiv_rn(res[c], f);
+                        }
+                    }
+                    if (!KEEP) store4((OUT *)a.out + (int64_t)lev * nij + p2, 4, res);
+                }
+            }
+        }
+    }
+}
+
+// Level chunks: the fewest that fill the last round of workgroups (slots = what the chip holds at once); a chunk
+// reloads the tile's metrics, 20 bytes per cell against 12 per cell and level.
+inline int curl_level_chunks(int64_t tiles, int nlev, int slots) {
+    int best = 1;
+    double best_cost = 1e30;
+    for (int lc = 1; lc <= std::min(nlev, 8); ++lc) {
+        const double rounds = (double)tiles * lc / slots;
+        const double cost = std::ceil(rounds) / rounds * (1.0 + 20.0 * lc / (12.0 * nlev));
+        if (cost < best_cost - 0.02) { best_cost = cost; best = lc; }
+    }
+    return best;
+}
+
+// Tiles per row, tile width (a multiple of 4) and workgroup size (a multiple of 64, <= kThreads) that leave the
+// fewest lanes without cells; fewer, wider tiles on a tie.
+struct CurlShape { int ntx, tw, threads; };
+inline CurlShape curl_shape(int npi) {
+    CurlShape best{1, 4, 64};
+    double best_eff = -1.0;
+    const int n0 = (npi + kTile - 1) / kTile;
+    for (int ntx = n0; ntx <= n0 + 4; ++ntx) {
+        const int tw = (((npi + ntx - 1) / ntx + 3) / 4) * 4, threads = ((tw / 4 + 63) / 64) * 64;
+        if (threads > kThreads) continue;
+        const double eff = (double)npi / ((double)ntx * threads * 4);
+        if (eff > best_eff + 1e-9) { best_eff = eff; best = CurlShape{ntx, tw, threads}; }
+    }
+    return best;
+}
+
+// Workgroups of `kernel` the device holds at once (the persistent grid), a multiple of 8 for the XCD band map.
+template <typename K>
+int resident_workgroups(K kernel, int threads) {
+    int dev = 0, per_cu = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) != hipSuccess || per_cu < 1) {
+        (void)hipGetLastError();
+        return 2048;
+    }
+    return ((prop.multiProcessorCount * per_cu + 7) / 8) * 8;
+}
+
 // -T: 4-point mean of the F-point curl to T points with the product of the 4 fmask (:286-297).
 // fmask(npiglo,:) and fmask(:,npjglo) are never assigned by the reference; taken as 0.
 template <typename OUT>
@@ -445,21 +594,46 @@ int cdft_curl_compute(cdft_curl_plan *p, const float *un, const float *vn, int n
     }
     CurlArgs a;
     a.un = (const float *)du; a.vn = (const float *)dv; a.e1u = p->e1u; a.e2v = p->e2v; a.e1f = p->e1f; a.e2f = p->e2f;
-    a.ff = p->ff; a.npi = p->npi; a.npj = p->npj; a.nlev = nlev; a.ntx = (p->npi + kTile - 1) / kTile;
+    a.ff = p->ff; a.npi = p->npi; a.npj = p->npj; a.nlev = nlev;
     a.lperio = p->lperio; a.out = dout; a.work = nullptr;
-    const int64_t total = (int64_t)p->npj * a.ntx;
-    const dim3 grid((unsigned)(((total + 7) / 8) * 8)), block(kThreads);
     if (ltpoint) {
         CDFT_TRY(p->work.reserve(n3 * 8));
         a.work = (double *)p->work.ptr;
-        hipLaunchKernelGGL((curl_kernel<double, true>), grid, block, 0, st, a);
+    }
+    const char *env = getenv("CDFT_CURL_ROWTILE");                // the one-row-tile kernel (tests compare the two)
+    if (p->npi >= 4 && !(env && env[0] == '1')) {
+        CurlShape sh = curl_shape(p->npi);
+        if (const char *etw = getenv("CDFT_CURL_TW")) {           // A/B hook: tile width, a multiple of 4 in 4..1024
+            const int tw = std::max(4, std::min(kTile, atoi(etw) / 4 * 4));
+            sh = CurlShape{(p->npi + tw - 1) / tw, tw, ((tw / 4 + 63) / 64) * 64};
+        }
+        a.ntx = sh.ntx;
+        const int64_t tiles = (int64_t)a.ntx * p->npj;
+        static int resident[3][kThreads / 64];                    // per kernel variant and workgroup size; 0 = not asked yet
+        int &res = resident[ltpoint ? 0 : out_is_r8 ? 1 : 2][sh.threads / 64 - 1];
+        if (res == 0)
+            res = ltpoint     ? resident_workgroups(curl_tile_kernel<double, true>, sh.threads)
+                  : out_is_r8 ? resident_workgroups(curl_tile_kernel<double, false>, sh.threads)
+                              : resident_workgroups(curl_tile_kernel<float, false>, sh.threads);
+        const char *elc = getenv("CDFT_CURL_CHUNKS");             // A/B hook
+        const int lc = elc ? std::max(1, std::min(nlev, atoi(elc))) : curl_level_chunks(tiles, nlev, res);
+        const dim3 grid((unsigned)(((tiles * lc + 7) / 8) * 8)), block(sh.threads);
+        if (ltpoint)        hipLaunchKernelGGL((curl_tile_kernel<double, true>), grid, block, 0, st, a, sh.tw, lc);
+        else if (out_is_r8) hipLaunchKernelGGL((curl_tile_kernel<double, false>), grid, block, 0, st, a, sh.tw, lc);
+        else                hipLaunchKernelGGL((curl_tile_kernel<float, false>), grid, block, 0, st, a, sh.tw, lc);
+    } else {
+        a.ntx = (p->npi + kTile - 1) / kTile;
+        const int64_t total = (int64_t)p->npj * a.ntx;
+        const dim3 grid((unsigned)(((total + 7) / 8) * 8)), block(kThreads);
+        if (ltpoint)        hipLaunchKernelGGL((curl_kernel<double, true>), grid, block, 0, st, a);
+        else if (out_is_r8) hipLaunchKernelGGL((curl_kernel<double, false>), grid, block, 0, st, a);
+        else                hipLaunchKernelGGL((curl_kernel<float, false>), grid, block, 0, st, a);
+    }
+    if (ltpoint) {
         CDFT_LAUNCH_CHECK();
         const dim3 g2((unsigned)((n3 + 255) / 256));
         if (out_is_r8) hipLaunchKernelGGL((curl_tpoint_kernel<double>), g2, dim3(256), 0, st, a);
         else           hipLaunchKernelGGL((curl_tpoint_kernel<float>), g2, dim3(256), 0, st, a);
-    } else {
-        if (out_is_r8) hipLaunchKernelGGL((curl_kernel<double, false>), grid, block, 0, st, a);
-        else           hipLaunchKernelGGL((curl_kernel<float, false>), grid, block, 0, st, a);
     }
     CDFT_LAUNCH_CHECK();
     if (out_space == CDFT_MEM_HOST) {

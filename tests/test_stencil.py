@@ -2,6 +2,8 @@
 stencil, every r4 product formed as the reference writes it, cdfvT accumulated over frames in the
 reference's order  =>  the HIP results must equal the oracle BIT FOR BIT (stated tolerance: none).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -84,11 +86,16 @@ def test_hip_vt_equals_oracle_bitwise(gpu, npi, npj, npk, nfr):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kernel", ["tile", "rowtile"])
 @pytest.mark.parametrize("npi,npj,nlev", [(24, 18, 3), (182, 149, 2), (1, 1, 1), (2, 2, 1), (3, 3, 2), (1023, 5, 1),
-                                          (1025, 5, 2), (4322, 4, 1)])
-def test_hip_curl_equals_oracle_bitwise(gpu, npi, npj, nlev):
+                                          (1025, 5, 2), (4322, 4, 1), (4, 4, 1), (5, 7, 3), (255, 6, 2), (257, 9, 3),
+                                          (258, 5, 2), (513, 11, 7)])
+def test_hip_curl_equals_oracle_bitwise(gpu, monkeypatch, kernel, npi, npj, nlev):
+    # tile: 4 rows x 256 columns per workgroup, persistent grid (npiglo >= 4); rowtile: one 1024-cell row tile per
+    # workgroup (the only one for npiglo < 4)
     import torch
 
+    monkeypatch.setenv("CDFT_CURL_ROWTILE", "1" if kernel == "rowtile" else "0")
     g = synth.make_grid(npi, npj, max(nlev, 2), seed=npi + 5)
     u, v, _, _, _, _ = frames(g, 1, seed=8)
     un, vn = u[0, :nlev], v[0, :nlev]
@@ -107,6 +114,26 @@ def test_hip_curl_equals_oracle_bitwise(gpu, npi, npj, nlev):
     d = plan.compute(torch.from_numpy(un).cuda(), torch.from_numpy(vn).cuda(), out_r8=False)
     ref = np.stack([oracle_tools.curl(un[k], vn[k], g["e1u"], g["e2v"], g["e1f"], g["e2f"], True) for k in range(nlev)])
     assert np.array_equal(d.cpu().numpy(), ref.astype(np.float32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ltpoint", [False, True])
+def test_hip_curl_persistent_grid_shares_cross_tiles(gpu, ltpoint):
+    """More tiles than the chip holds workgroups (1812 x 5 levels here): a workgroup's share of the (tile, level) units
+    starts and ends inside a tile's levels and spans several tiles.  Bitwise against the oracle and the row-tile kernel."""
+    npi, npj, nlev = 1442, 1207, 5
+    g = synth.make_grid(npi, npj, nlev, seed=31)
+    u, v, _, _, _, _ = frames(g, 1, seed=9)
+    plan = gpu.CurlPlan(npi, npj)
+    plan.set_mesh(g["e1u"], g["e2v"], g["e1f"], g["e2f"], lperio=True)
+    got = plan.compute(u[0], v[0], ltpoint=ltpoint)
+    ref = np.stack([oracle_tools.curl(u[0, k], v[0, k], g["e1u"], g["e2v"], g["e1f"], g["e2f"], True, ltpoint) for k in range(nlev)])
+    assert np.array_equal(got, ref) and np.count_nonzero(got) > 3e4
+    os.environ["CDFT_CURL_ROWTILE"] = "1"
+    try:
+        assert np.array_equal(plan.compute(u[0], v[0], ltpoint=ltpoint), got)
+    finally:
+        del os.environ["CDFT_CURL_ROWTILE"]
 
 
 @pytest.mark.gpu
