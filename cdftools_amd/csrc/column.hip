@@ -152,6 +152,16 @@ vertmean_kernel(const float *__restrict__ zv, const float *__restrict__ e3, cons
 }
 
 // CDFT_COLUMN_SCALAR=1 keeps one cell per thread (tests compare the two).
+// Workgroup size: 1024 threads (16 waves in step, the longest runs); 256 measured the same or slower at eORCA025 and
+// eORCA12.  CDFT_COLUMN_THREADS overrides (A/B hook).
+inline int column_threads() {
+    if (const char *e = getenv("CDFT_COLUMN_THREADS")) {
+        const int t = atoi(e);
+        if (t == 256 || t == 512 || t == 1024) return t;
+    }
+    return kColThreads;
+}
+
 inline int column_vec(int64_t nij) {
     const char *e = getenv("CDFT_COLUMN_SCALAR");
     return (nij >= 4 && !(e && e[0] == '1')) ? 4 : 1;
@@ -195,9 +205,11 @@ int cdft_vint_cumul(const float *zt, const float *e3t, const float *e31d, const 
             if (!written[(size_t)q]) CDFT_HIP(hipMemsetAsync(o + (size_t)q * nij, 0, (size_t)nij * 4, st));
     }
     const int vec = column_vec(nij);
-    const dim3 grid((unsigned)(((nij + vec - 1) / vec + kColThreads - 1) / kColThreads));
+    const int64_t nth = (nij + vec - 1) / vec;
+    const int threads = column_threads();
+    const dim3 grid((unsigned)((nth + threads - 1) / threads));
 #define CDFT_VINT_LAUNCH(V, E)                                                                                         \
-    hipLaunchKernelGGL((vint_cumul_kernel<V, E>), grid, dim3(kColThreads), 0, st, (const float *)dz, (const float *)de,        \
+    hipLaunchKernelGGL((vint_cumul_kernel<V, E>), grid, dim3(threads), 0, st, (const float *)dz, (const float *)de,        \
                        (const float *)d1, (const float *)dm, nij, npk, (const int *)sb,                                \
                        (const int *)(sb + (size_t)npk * 4), (const float *)(sb + (size_t)npk * 8),                     \
                        (const float *)(sb + (size_t)npk * 12), sclf, mean, o)
@@ -228,9 +240,11 @@ int cdft_vertmean(const float *zv, const float *e3, const float *e31d, const flo
     double *o = dvertmean;
     if (out_space == CDFT_MEM_HOST) { CDFT_TRY(g_co.reserve((size_t)nij * 8)); o = (double *)g_co.ptr; }
     const int vec = column_vec(nij);
-    const dim3 grid((unsigned)(((nij + vec - 1) / vec + kColThreads - 1) / kColThreads));
+    const int64_t nth = (nij + vec - 1) / vec;
+    const int threads = column_threads();
+    const dim3 grid((unsigned)((nth + threads - 1) / threads));
 #define CDFT_VERTMEAN_LAUNCH(V, E)                                                                                     \
-    hipLaunchKernelGGL((vertmean_kernel<V, E>), grid, dim3(kColThreads), 0, st, (const float *)dz, (const float *)de,          \
+    hipLaunchKernelGGL((vertmean_kernel<V, E>), grid, dim3(threads), 0, st, (const float *)dz, (const float *)de,          \
                        (const float *)d1, (const float *)dm, nij, nlev, gdep_first, gdep_last, rdep_up, rdep_down, o)
     if (vec == 4) { if (de) CDFT_VERTMEAN_LAUNCH(4, true); else CDFT_VERTMEAN_LAUNCH(4, false); }
     else          { if (de) CDFT_VERTMEAN_LAUNCH(1, true); else CDFT_VERTMEAN_LAUNCH(1, false); }
