@@ -268,6 +268,68 @@ __global__ void __launch_bounds__(64) psi_scan_j_kernel(const double *__restrict
     }
 }
 
+// The same scan with a workgroup per 32 columns (the kernel that runs): the column chain of additions is sequential,
+// the loads and stores around it are not.  16 waves bring 128 rows x 32 columns into LDS (a load instruction covers 2
+// rows of 256 bytes; the next 128 rows are already on their way into registers), the first 32 lanes of wave 0 run the
+// chain through LDS in place, 8 rows read ahead of the additions, and all 16 waves store the result.  One wave per 64
+// columns (above) has npiglo/64 waves on the whole chip: 0.25 ms at eORCA12, latency-bound; this one 0.085 ms
+// (16 / 64 columns and 32 .. 512 rows per pass were measured too: 0.09 .. 0.15 ms).
+constexpr int kScanWaves = 16, kScanRW = 4, kScanCW = 32, kScanRPI = 64 / kScanCW;
+constexpr int kScanRows = kScanWaves * kScanRW * kScanRPI;
+
+__global__ void __launch_bounds__(kScanWaves * 64)
+psi_scan_j_wg_kernel(const double *__restrict__ dtrp, double *__restrict__ dpsi, int npi, int npj,
+                     const double *__restrict__ carry, int first_block) {
+    __shared__ double rows[kScanRows][kScanCW];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane % kScanCW, sub = lane / kScanCW;
+    const int i = blockIdx.x * kScanCW + c;
+    const bool col = i < npi;
+    double acc = (carry && col) ? carry[i] : 0.0;                 // used by the chain lanes only
+    double x[kScanRW];
+    auto row_of = [&](int r) { return (wave * kScanRW + r) * kScanRPI + sub; };
+    auto fetch = [&](int j0) {
+#pragma unroll
+        for (int r = 0; r < kScanRW; ++r) {
+            const int j = j0 + row_of(r);
+            x[r] = (col && j < npj) ? __builtin_nontemporal_load(dtrp + (int64_t)j * npi + i) : 0.0;
+        }
+    };
+    fetch(0);
+    for (int j0 = 0; j0 < npj; j0 += kScanRows) {
+#pragma unroll
+        for (int r = 0; r < kScanRW; ++r) rows[row_of(r)][c] = x[r];
+        if (j0 + kScanRows < npj) fetch(j0 + kScanRows);
+        __syncthreads();
+        if (threadIdx.x < kScanCW) {                              // rows past the end hold 0: the chain passes through them
+            double t[8], tn[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) t[r] = rows[r][c];
+            // global row 1 of the first block: dpsiu(:,1) = 0 (or the carry), its transport is not used
+            if (first_block && j0 == 0) t[0] = 0.0;
+            for (int r0 = 0; r0 < kScanRows; r0 += 8) {
+                if (r0 + 8 < kScanRows) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) tn[r] = rows[r0 + 8 + r][c];
+                }
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    acc = __dadd_rn(acc, -t[r]);
+                    rows[r0 + r][c] = acc;
+                }
+#pragma unroll
+                for (int r = 0; r < 8; ++r) t[r] = tn[r];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < kScanRW; ++r) {
+            const int j = j0 + row_of(r);
+            if (col && j < npj) dpsi[(int64_t)j * npi + i] = rows[row_of(r)][c];
+        }
+    }
+}
+
 // cdfpsi V path, src/cdfpsi.f90:380-383: dpsiv(npi,:) = 0 ; dpsiv(ji,:) = dpsiv(ji+1,:) - dtrpv(ji,:),
 // ji = npi-1..1.  The scan runs along i, the contiguous axis: one wave takes 64 rows, stages a
 // 64 x 64 tile through LDS with coalesced row segments, each lane scans its own row of the tile
@@ -631,8 +693,13 @@ int cdft_psi_scan_u(cdft_psi_plan *p, const double *carry, int carry_space, int 
     hipStream_t st = as_stream(stream);
     const void *dc = nullptr;
     if (carry) CDFT_TRY(to_device(carry, (size_t)p->npi * 8, carry_space, p->scar, st, &dc));
-    hipLaunchKernelGGL(psi_scan_j_kernel, dim3((p->npi + 63) / 64), dim3(64), 0, st, p->dtrpu, p->dpsiu, p->npi, p->npj,
-                       (const double *)dc, first_block ? 1 : 0);
+    const char *ew = getenv("CDFT_PSI_SCAN_WAVE");                // the one-wave-per-64-columns scan (tests compare the two)
+    if (ew && ew[0] == '1')
+        hipLaunchKernelGGL(psi_scan_j_kernel, dim3((p->npi + 63) / 64), dim3(64), 0, st, p->dtrpu, p->dpsiu, p->npi, p->npj,
+                           (const double *)dc, first_block ? 1 : 0);
+    else
+        hipLaunchKernelGGL(psi_scan_j_wg_kernel, dim3((p->npi + kScanCW - 1) / kScanCW), dim3(kScanWaves * 64), 0, st, p->dtrpu, p->dpsiu,
+                           p->npi, p->npj, (const double *)dc, first_block ? 1 : 0);
     CDFT_LAUNCH_CHECK();
     if (last_row) {
         const double *src = p->dpsiu + (int64_t)(p->npj - 1) * p->npi;

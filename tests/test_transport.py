@@ -65,8 +65,12 @@ def test_oracle_mhst_sep_equals_vt_path_fed_with_its_own_products():
 
 # ----------------------------------------------------------------------------- GPU
 @pytest.mark.gpu
-@pytest.mark.parametrize("npi,npj,npk", [(24, 18, 7), (182, 149, 31), (1, 1, 1), (5, 3, 2), (130, 67, 4), (64, 64, 3)])
-def test_hip_psi_equals_oracle_bitwise(gpu, npi, npj, npk):
+@pytest.mark.parametrize("scan", ["workgroup", "wave"])
+@pytest.mark.parametrize("npi,npj,npk", [(24, 18, 7), (182, 149, 31), (1, 1, 1), (5, 3, 2), (130, 67, 4), (64, 64, 3),
+                                         (70, 300, 2), (129, 257, 1), (65, 128, 1), (3, 129, 2), (17, 1100, 1), (33, 513, 2)])
+def test_hip_psi_equals_oracle_bitwise(gpu, monkeypatch, scan, npi, npj, npk):
+    # the j scan: 16 waves per 64 columns with the chain run through LDS (128 rows a time), or one wave per 64 columns
+    monkeypatch.setenv("CDFT_PSI_SCAN_WAVE", "1" if scan == "wave" else "0")
     g = synth.make_grid(npi, npj, npk, seed=npi)
     _, _, u, v = tracer_fields(g, 7)
     plan = gpu.PsiPlan(npi, npj, npk)
@@ -86,7 +90,7 @@ def test_hip_psi_equals_oracle_bitwise(gpu, npi, npj, npk):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("npi,npj,npk,blocks", [(24, 18, 7, 2), (182, 149, 5, 3), (70, 9, 2, 8), (5, 2, 1, 2)])
+@pytest.mark.parametrize("npi,npj,npk,blocks", [(24, 18, 7, 2), (182, 149, 5, 3), (70, 9, 2, 8), (5, 2, 1, 2), (66, 700, 1, 3)])
 def test_hip_psi_row_blocks_chained_equal_the_whole_domain_bitwise(gpu, npi, npj, npk, blocks):
     """The staged entry points (integrate / scan_u with a carry / value / finish with a given
     reference value) used by cdftools_amd.shard.psi_chain: any number of row blocks, chained in
