@@ -11,6 +11,7 @@
 // operands of the row (surface, basin masks) are re-read per level from L2 / Infinity Cache, the field
 // and its 3-D mask stream from HBM once (8 bytes per cell and level).  darea does not depend on the field: it is
 // summed once per mesh (cdft_zonal_set_mesh) and copied out by every mean-form call.
+#include <algorithm>
 #include <cstdlib>
 #include "common.hpp"
 #include "reduce.hpp"
@@ -249,10 +250,14 @@ int launch_fast_nb(const ZonalArgs2 &a, const uint8_t *bits, int *rowflag, bool 
 constexpr int kZC = 8;            // bit patterns the class kernel holds (the empty pattern included)
 constexpr int kZStride = 72;      // doubles between the slot rows of two classes (64 lanes + 8: different banks)
 
+#ifndef ZONAL_STEP
+#define ZONAL_STEP 1
+#endif
 struct ZonalClassArgs {
     const uint8_t *cls;           // (npi,npj) class of the cell's basin bit pattern
     uint8_t pat[kZC];
     int nclass;
+    int lc;                       // level chunks: workgroup = (chunk, row)
 };
 
 // Loads: the row is covered by 16-byte vectors starting at cells 0, 4, 8, ... (r4-aligned only: rows start anywhere),
@@ -262,9 +267,10 @@ template <int NV, bool MEAN, int T>
 __global__ void __launch_bounds__(T) zonal_row_class_kernel(ZonalArgs2 a, ZonalClassArgs ca) {
     extern __shared__ double lds[];
     constexpr int nwaves = T / 64;
-    const int jj = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int chunk = blockIdx.x / a.npj, jj = blockIdx.x - chunk * a.npj, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k0 = (int)((int64_t)chunk * a.nlev / ca.lc), k1 = (int)((int64_t)(chunk + 1) * a.nlev / ca.lc);
     double *scr  = lds + wave * ((kZC + 1) * kZStride);              // slot [class][lane]; class kZC = cells not owned
-    double *part = lds + nwaves * ((kZC + 1) * kZStride);            // [nlev][kZC][nwaves]
+    double *part = lds + nwaves * ((kZC + 1) * kZStride);            // [k1-k0][kZC][nwaves]
     const int64_t nij = (int64_t)a.npi * a.npj, r2 = (int64_t)jj * a.npi;
     const int nfull = a.npi >> 2;                                    // vectors 0..nfull-1 start at 4v
     double sf[NV][4];
@@ -289,9 +295,10 @@ __global__ void __launch_bounds__(T) zonal_row_class_kernel(ZonalArgs2 a, ZonalC
 #pragma unroll
         for (int r = 0; r < NV; ++r) { z[r] = ld_stream4u(zv + i0[r]); mk[r] = ld_stream4u(mv + i0[r]); }
     };
-    fetch(zc, mc, 0);
-    for (int k = 0; k < a.nlev; ++k) {
-        if (k + 1 < a.nlev) fetch(zn, mn_, k + 1);      // next level in flight
+    fetch(zc, mc, k0);
+    for (int k = k0; k < k1; ++k) {
+        if (k + 1 < k1) fetch(zn, mn_, k + 1);          // next level in flight
+        if (ZONAL_STEP) __syncthreads();                // nothing shared here: keeps the waves of the row on one level
 #pragma unroll
         for (int r = 0; r < NV; ++r) {
             const float z4[4] = {zc[r].x, zc[r].y, zc[r].z, zc[r].w}, m4[4] = {mc[r].x, mc[r].y, mc[r].z, mc[r].w};
@@ -320,18 +327,18 @@ __global__ void __launch_bounds__(T) zonal_row_class_kernel(ZonalArgs2 a, ZonalC
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
         for (int c = 0; c < kZC; ++c) scr[c * kZStride + lane] = 0.0;
-        if ((lane & 7) == 0) part[((int64_t)k * kZC + (lane >> 3)) * nwaves + wave] = s;
+        if ((lane & 7) == 0) part[((int64_t)(k - k0) * kZC + (lane >> 3)) * nwaves + wave] = s;
 #pragma unroll
         for (int r = 0; r < NV; ++r) { zc[r] = zn[r]; mc[r] = mn_[r]; }
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < a.nlev * a.nb; t += T) {
-        const int k = t / a.nb, b = t - k * a.nb;
+    for (int t = threadIdx.x; t < (k1 - k0) * a.nb; t += T) {
+        const int kk = t / a.nb, b = t - kk * a.nb, k = k0 + kk;
         double s = 0.0, z = 0.0;
         for (int c = 0; c < ca.nclass; ++c) {
             const bool in = (ca.pat[c] >> b) & 1;
             for (int w = 0; w < nwaves; ++w) {
-                const double v = part[((int64_t)k * kZC + c) * nwaves + w];
+                const double v = part[((int64_t)kk * kZC + c) * nwaves + w];
                 if (in) s += v;
                 else    z += v;
             }
@@ -346,8 +353,8 @@ template <int NV>
 int launch_class_nv(const ZonalArgs2 &a, const ZonalClassArgs &ca, bool mean, hipStream_t st) {
     constexpr int T = kClassT;
     const size_t shmem = ((size_t)(T / 64) * (kZC + 1) * kZStride + (size_t)a.nlev * kZC * (T / 64)) * sizeof(double);
-    if (mean) hipLaunchKernelGGL((zonal_row_class_kernel<NV, true, T>), dim3(a.npj), dim3(T), shmem, st, a, ca);
-    else      hipLaunchKernelGGL((zonal_row_class_kernel<NV, false, T>), dim3(a.npj), dim3(T), shmem, st, a, ca);
+    if (mean) hipLaunchKernelGGL((zonal_row_class_kernel<NV, true, T>), dim3(a.npj * ca.lc), dim3(T), shmem, st, a, ca);
+    else      hipLaunchKernelGGL((zonal_row_class_kernel<NV, false, T>), dim3(a.npj * ca.lc), dim3(T), shmem, st, a, ca);
     CDFT_LAUNCH_CHECK();
     return CDFT_OK;
 }
@@ -355,7 +362,11 @@ int launch_class_nv(const ZonalArgs2 &a, const ZonalClassArgs &ca, bool mean, hi
 // rows of 4 .. 5116 cells
 inline bool class_fits(int npi) { return npi >= 4 && (npi / 4 + 1 + kClassT - 1) / kClassT <= kClassMaxNV; }
 
-int launch_class(const ZonalArgs2 &a, const ZonalClassArgs &ca, bool mean, hipStream_t st) {
+int launch_class(const ZonalArgs2 &a, ZonalClassArgs ca, bool mean, hipStream_t st) {
+    const char *e = getenv("CDFT_ZONAL_CHUNKS");                  // A/B hook
+    // one workgroup per row for all levels is 1207 workgroups at eORCA025, less than the chip holds: the levels are cut
+    // so that there are about 4096 (measured: 238 -> 209 us there, nothing lost at eORCA12)
+    ca.lc = e ? std::max(1, std::min(a.nlev, atoi(e))) : std::max(1, std::min(std::min(a.nlev, 8), (4096 + a.npj - 1) / a.npj));
     switch ((a.npi / 4 + 1 + kClassT - 1) / kClassT) {
         case 1: return launch_class_nv<1>(a, ca, mean, st);
         case 2: return launch_class_nv<2>(a, ca, mean, st);

@@ -495,21 +495,31 @@ class ZonalPlan(_Plan):
         check(_lib.load().cdft_zonal_set_mesh(self._h, *[C.c_void_p(a.ctypes.data) for a in k], MEM_HOST,
                                               stream or current_stream_ptr()))
 
-    def compute(self, zv, mean_form=False, minmax=False, stream=None):
-        """zv (nlev,npj,npi) r4 -> dict of (nb,nlev,npj) arrays: 'sum' [, 'area', 'max', 'min']."""
+    def compute(self, zv, mean_form=False, minmax=False, stream=None, device_out=False):
+        """zv (nlev,npj,npi) r4 -> dict of (nb,nlev,npj) arrays: 'sum' [, 'area', 'max', 'min']; numpy arrays, or
+        torch tensors left on the GPU with device_out=True."""
         pz, sz, kz = _arg(zv, np.float32, "zv")
         nlev = kz.shape[0]
         shape = (self.nb, nlev, self.npj)
-        out = {"sum": np.empty(shape, np.float64)}
+        if device_out:
+            import torch
+            new = lambda dt: torch.empty(shape, dtype=dt, device="cuda")            # noqa: E731
+            ptr = lambda t: C.c_void_p(t.data_ptr())                                 # noqa: E731
+            r8, r4, space = torch.float64, torch.float32, MEM_DEVICE
+        else:
+            new = lambda dt: np.empty(shape, dt)                                     # noqa: E731
+            ptr = lambda a: C.c_void_p(a.ctypes.data)                                # noqa: E731
+            r8, r4, space = np.float64, np.float32, MEM_HOST
+        out = {"sum": new(r8)}
         pa = px = pn = _null()
         if mean_form:
-            out["area"] = np.empty(shape, np.float64)
-            pa = C.c_void_p(out["area"].ctypes.data)
+            out["area"] = new(r8)
+            pa = ptr(out["area"])
         if minmax:
-            out["max"], out["min"] = np.empty(shape, np.float32), np.empty(shape, np.float32)
-            px, pn = C.c_void_p(out["max"].ctypes.data), C.c_void_p(out["min"].ctypes.data)
-        check(_lib.load().cdft_zonal_compute(self._h, pz, nlev, sz, 1 if mean_form else 0, C.c_void_p(out["sum"].ctypes.data),
-                                             pa, px, pn, MEM_HOST, stream or current_stream_ptr()))
+            out["max"], out["min"] = new(r4), new(r4)
+            px, pn = ptr(out["max"]), ptr(out["min"])
+        check(_lib.load().cdft_zonal_compute(self._h, pz, nlev, sz, 1 if mean_form else 0, ptr(out["sum"]),
+                                             pa, px, pn, space, stream or current_stream_ptr()))
         return out
 
 

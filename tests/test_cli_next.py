@@ -373,6 +373,8 @@ def test_hip_zonal_matches_oracle(gpu, monkeypatch, npi, npj, npk, nb, kernel):
         bound = oracle_tools.zonal(g["e1t"], g["e2t"], tm, zm, np.abs(zv), mean_form=mean_form)["sum"]
         assert np.all(np.abs(got["sum"] - ref["sum"]) <= 1e-13 * bound + 1e-300)
         assert np.array_equal(plan.compute(zv, mean_form=mean_form, minmax=minmax)["sum"], got["sum"])   # run-to-run identical
+        dev = plan.compute(zv, mean_form=mean_form, minmax=minmax, device_out=True)                       # results left in HBM
+        assert sorted(dev) == sorted(got) and all(np.array_equal(dev[k].cpu().numpy(), got[k]) for k in got)
         if mean_form:
             assert np.all(np.abs(got["area"] - ref["area"]) <= 1e-13 * ref["area"] + 1e-300)
         if minmax:
