@@ -208,3 +208,97 @@ def test_nc4_option_writes_netcdf4_with_the_same_content(libs, tools, tmp_path):
         blk = txt[txt.index('DATASET "vosigma0"'):]
         assert "CHUNKED ( 1, 1, 2, 40 )" in blk and "COMPRESSION DEFLATE { LEVEL 1 }" in blk       # (t,z,y/30,x)
         assert "DIMENSION_LIST" in blk and "H5S_UNLIMITED" in blk
+
+
+@pytest.mark.parametrize("dtype,xtype,shuffle", [(np.float32, 5, 1), (np.float64, 6, 1), (np.int16, 3, 0)])
+def test_whole_chunk_writes_are_deflated_in_parallel_and_read_back(libs, tmp_path, monkeypatch, dtype, xtype, shuffle):
+    """A put_vara that covers whole chunks of a deflated variable is shuffled and deflated by several threads and handed
+    to HDF5 chunk by chunk (H5Dwrite_chunk); the library's own filters inflate it on the way back.  23 rows in chunks of
+    5: the last chunk of every level is an edge chunk.  CDFT_NC4_SERIAL=1 (the library's filter pipeline) must give a
+    file with the same content, and a write that does not start on a chunk boundary takes that route by itself."""
+    nc, _ = libs
+    npt, npk, npj, npi = 2, 3, 23, 17
+    rng = np.random.default_rng(5)
+    ref = (rng.standard_normal((npt, npk, npj, npi)) * 100).astype(dtype)
+
+    def write(path, serial, rows_at_a_time=None):
+        monkeypatch.setenv("CDFT_NC4_SERIAL", "1" if serial else "0")
+        ncid, v = C.c_int(), C.c_int()
+        assert nc.ncc_create(path.encode(), 3, 1, C.byref(ncid)) == 0
+        ids = []
+        for name, n in (("time_counter", 0), ("z", npk), ("y", npj), ("x", npi)):
+            d = C.c_int()
+            assert nc.ncc_def_dim(ncid, name.encode(), C.c_size_t(n), C.byref(d)) == 0
+            ids.append(d.value)
+        assert nc.ncc_def_var(ncid, b"field", xtype, 4, (C.c_int * 4)(*ids), C.byref(v)) == 0
+        assert nc.ncc_def_var_chunking(ncid, v, (C.c_size_t * 4)(1, 1, 5, npi)) == 0
+        assert nc.ncc_def_var_deflate(ncid, v, shuffle, 1) == 0
+        assert nc.ncc_enddef(ncid) == 0
+        mt = xtype
+        for t in range(npt):
+            for k in range(npk):
+                if rows_at_a_time is None:
+                    a = np.ascontiguousarray(ref[t, k])
+                    rc = nc.ncc_put_vara(ncid, v, (C.c_size_t * 4)(t, k, 0, 0), (C.c_size_t * 4)(1, 1, npj, npi), mt,
+                                         a.ctypes.data_as(C.c_void_p))
+                    assert rc == 0, nc.ncc_strerror(rc).decode()
+                else:                                   # 3 rows a call: not whole chunks
+                    for j0 in range(0, npj, rows_at_a_time):
+                        a = np.ascontiguousarray(ref[t, k, j0:j0 + rows_at_a_time])
+                        rc = nc.ncc_put_vara(ncid, v, (C.c_size_t * 4)(t, k, j0, 0), (C.c_size_t * 4)(1, 1, a.shape[0], npi),
+                                             mt, a.ctypes.data_as(C.c_void_p))
+                        assert rc == 0, nc.ncc_strerror(rc).decode()
+        assert nc.ncc_close(ncid) == 0
+
+    def read(path):
+        ncid, v = C.c_int(), C.c_int()
+        assert nc.ncc_open(path.encode(), 0, C.byref(ncid)) == 0
+        assert nc.ncc_inq_varid(ncid, b"field", C.byref(v)) == 0
+        out = np.empty((npt, npk, npj, npi), dtype)
+        assert nc.ncc_get_vara(ncid, v, (C.c_size_t * 4)(0, 0, 0, 0), (C.c_size_t * 4)(npt, npk, npj, npi), xtype,
+                               out.ctypes.data_as(C.c_void_p)) == 0
+        nc.ncc_close(ncid)
+        return out
+
+    def read_block(path, st, ct, serial):
+        monkeypatch.setenv("CDFT_NC4_SERIAL", "1" if serial else "0")
+        ncid, v = C.c_int(), C.c_int()
+        assert nc.ncc_open(path.encode(), 0, C.byref(ncid)) == 0
+        assert nc.ncc_inq_varid(ncid, b"field", C.byref(v)) == 0
+        out = np.empty(ct, dtype)
+        assert nc.ncc_get_vara(ncid, v, (C.c_size_t * 4)(*st), (C.c_size_t * 4)(*ct), xtype, out.ctypes.data_as(C.c_void_p)) == 0
+        nc.ncc_close(ncid)
+        return out
+
+    plug = C.CDLL(PLUG)                                # the instance libncclassic has loaded: its counters
+    plug.nch5_chunks_inflated.restype = plug.nch5_chunks_deflated.restype = C.c_ulong
+    par, ser, rag = (str(tmp_path / n) for n in ("par.nc", "ser.nc", "rag.nc"))
+    w0 = plug.nch5_chunks_deflated()
+    write(par, serial=False)
+    assert plug.nch5_chunks_deflated() - w0 == npt * npk * 5              # 5 chunks a level, all by the threaded route
+    w0 = plug.nch5_chunks_deflated()
+    write(ser, serial=True)
+    assert plug.nch5_chunks_deflated() == w0
+    write(rag, serial=False, rows_at_a_time=3)
+    for p in (par, ser, rag):
+        for serial in (False, True):                  # chunks inflated by threads here / by the library
+            monkeypatch.setenv("CDFT_NC4_SERIAL", "1" if serial else "0")
+            r0 = plug.nch5_chunks_inflated()
+            assert np.array_equal(read(p), ref), (p, serial)
+            assert plug.nch5_chunks_inflated() - r0 == (0 if serial else npt * npk * 5)
+            # requests that cut through chunks, start inside one, or lie in a single chunk
+            for st, ct in (((1, 0, 3, 2), (1, 3, 17, 13)), ((0, 1, 5, 0), (2, 1, 10, 17)), ((1, 2, 21, 4), (1, 1, 2, 6)),
+                           ((0, 0, 0, 0), (1, 1, 23, 17)), ((0, 2, 7, 16), (2, 1, 9, 1))):
+                want = ref[st[0]:st[0] + ct[0], st[1]:st[1] + ct[1], st[2]:st[2] + ct[2], st[3]:st[3] + ct[3]]
+                assert np.array_equal(read_block(p, st, ct, serial), want), (p, serial, st, ct)
+    monkeypatch.setenv("CDFT_NC4_SERIAL", "0")
+    assert abs(os.path.getsize(par) - os.path.getsize(ser)) <= 0.02 * os.path.getsize(ser)       # the same deflate, chunk for chunk
+    h5dump = "/opt/conda/bin/h5dump"
+    if os.path.exists(h5dump):                                           # the HDF5 tool inflates every chunk too
+        r = subprocess.run([h5dump, "-d", "/field", "-y", "-w", "0", par], capture_output=True, text=True)
+        assert r.returncode == 0 and "error" not in r.stderr.lower() and "unable" not in r.stderr.lower(), r.stderr[-400:]
+        body = r.stdout[r.stdout.index("DATA {") + 6:]
+        body = body[:body.index("}")]
+        nums = np.array([float(x) for x in body.replace("}", " ").replace(",", " ").split()
+                         if x[0].isdigit() or (x[0] == "-" and len(x) > 1 and x[1].isdigit())])
+        assert nums.size == ref.size and np.allclose(nums, ref.ravel().astype(np.float64), rtol=1e-5, atol=1e-30)
