@@ -226,6 +226,57 @@ mhst_zonal_kernel(const double *__restrict__ dtrph, const double *__restrict__ d
     }
 }
 
+// Basin masks that hold only 0 and 1 (the usual case) are packed to one byte per cell at set_mesh: the zonal kernel
+// then reads 17 bytes per cell instead of 16 + 4*nb, and multiplies by the same 0.d0 / 1.d0.  flag[0] is raised by any
+// other value: the r4 masks are used as they are.
+__global__ void mhst_mask_bits_kernel(const float *__restrict__ masks, int64_t nij, int nb, uint8_t *__restrict__ bits,
+                                      int *__restrict__ flag) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nij) return;
+    unsigned v = 0;
+    for (int b = 0; b < nb; ++b) {
+        const float m = masks[(int64_t)b * nij + p];
+        if (m == 1.f) v |= 1u << b;
+        else if (!(m == 0.f) || signbit(m)) flag[0] = 1;         // -0. would flip the sign of a product: not packed either
+    }
+    bits[p] = (uint8_t)v;
+}
+
+template <int NB>
+__global__ void __launch_bounds__(kThreads)
+mhst_zonal_bits_kernel(const double *__restrict__ dtrph, const double *__restrict__ dtrps,
+                       const uint8_t *__restrict__ bits, int npi, int npj, int nb, double *__restrict__ heat,
+                       double *__restrict__ salt) {
+    __shared__ double scratch[16];
+    const int jj = blockIdx.x;
+    const int64_t row = (int64_t)jj * npi;
+    double sh[NB], ss[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) { sh[b] = 0.0; ss[b] = 0.0; }
+    for (int i = threadIdx.x; i < npi; i += kThreads) {
+        const double h = dtrph[row + i], s = dtrps[row + i];
+        const unsigned v = bits[row + i];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            if (b < nb && !(b == 0 && (i == 0 || i == npi - 1))) {
+                const double zm = ((v >> b) & 1u) ? 1.0 : 0.0;
+                sh[b] += h * zm;
+                ss[b] += s * zm;
+            }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        if (b < nb) {
+            const double th = block_sum(sh[b], scratch), ts = block_sum(ss[b], scratch);
+            if (threadIdx.x == 0) {
+                heat[(int64_t)jj * nb + b] = th;
+                salt[(int64_t)jj * nb + b] = ts;
+            }
+        }
+    }
+}
+
 // cdfpsi U path, src/cdfpsi.f90:395-398: dpsiu(:,1) = 0 ; dpsiu(:,jj) = dpsiu(:,jj-1) - dtrpu(:,jj)
 // Row-block sharding: a block that does not hold global row 1 continues the running difference of
 // the block south of it: it starts from that block's last row (carry) and its first row is an
@@ -440,6 +491,8 @@ int upload(void **dst, const void *src, size_t bytes, int space, hipStream_t st)
 struct cdft_mhst_plan {
     int npi = 0, npj = 0, npk = 0, nb = 0;
     float *e1v = nullptr, *e3v = nullptr, *e31d = nullptr, *masks = nullptr;
+    uint8_t *mbits = nullptr;                            // masks packed to a byte per cell when they are all 0 / 1
+    bool use_bits = false;
     double *dtrph = nullptr, *dtrps = nullptr, *oh = nullptr, *os = nullptr;
     bool mesh_set = false;
     DevBuf s0, s1, s2;
@@ -480,7 +533,19 @@ int cdft_mhst_set_mesh(cdft_mhst_plan *p, const float *e1v, const float *e3v, co
         CDFT_TRY(upload((void **)&p->e31d, e31d, (size_t)p->npk * 4, memspace, st));
         if (p->e3v) { (void)hipFree(p->e3v); p->e3v = nullptr; }
     }
+    if (!p->mbits && hipMalloc((void **)&p->mbits, nij + 64) != hipSuccess) {     // the flag sits behind the bytes, 16-aligned
+        (void)hipGetLastError();
+        return fail(CDFT_ERR_ALLOC, "cdft_mhst_set_mesh: device allocation failed");
+    }
+    int *flag = (int *)(p->mbits + ((nij + 15) / 16) * 16);
+    int not01 = 0;
+    CDFT_HIP(hipMemsetAsync(flag, 0, 4, st));
+    hipLaunchKernelGGL(mhst_mask_bits_kernel, dim3((unsigned)((nij + 255) / 256)), dim3(256), 0, st, p->masks, (int64_t)nij,
+                       p->nb, p->mbits, flag);
+    CDFT_LAUNCH_CHECK();
+    CDFT_HIP(hipMemcpyAsync(&not01, flag, 4, hipMemcpyDeviceToHost, st));
     CDFT_HIP(hipStreamSynchronize(st));
+    p->use_bits = not01 == 0;
     p->mesh_set = true;
     return CDFT_OK;
 }
@@ -508,7 +573,15 @@ int cdft_mhst_compute(cdft_mhst_plan *p, const float *vt, const float *vs, const
     const size_t out_bytes = (size_t)p->nb * p->npj * nlev_out * 8;
     double *oh = (out_space == CDFT_MEM_DEVICE) ? heat : p->oh, *os = (out_space == CDFT_MEM_DEVICE) ? salt : p->os;
     auto zonal = [&](double *h, double *s) -> int {
-        if (p->nb == 1)
+        const char *e = getenv("CDFT_MHST_R4MASKS");             // test hook: the unpacked masks
+        const bool bits = p->use_bits && !(e && e[0] == '1');
+        if (bits && p->nb == 1)
+            hipLaunchKernelGGL((mhst_zonal_bits_kernel<1>), dim3(p->npj), dim3(kThreads), 0, st, p->dtrph, p->dtrps,
+                               p->mbits, p->npi, p->npj, p->nb, h, s);
+        else if (bits)
+            hipLaunchKernelGGL((mhst_zonal_bits_kernel<8>), dim3(p->npj), dim3(kThreads), 0, st, p->dtrph, p->dtrps,
+                               p->mbits, p->npi, p->npj, p->nb, h, s);
+        else if (p->nb == 1)
             hipLaunchKernelGGL((mhst_zonal_kernel<1>), dim3(p->npj), dim3(kThreads), 0, st, p->dtrph, p->dtrps,
                                p->masks, p->npi, p->npj, p->nb, h, s);
         else
@@ -538,7 +611,7 @@ int cdft_mhst_compute(cdft_mhst_plan *p, const float *vt, const float *vs, const
 
 int cdft_mhst_destroy(cdft_mhst_plan *p) {
     if (!p) return CDFT_OK;
-    void *ptrs[] = {p->e1v, p->e3v, p->e31d, p->masks, p->dtrph, p->dtrps, p->oh, p->os};
+    void *ptrs[] = {p->e1v, p->e3v, p->e31d, p->masks, p->mbits, p->dtrph, p->dtrps, p->oh, p->os};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     p->s0.release(); p->s1.release(); p->s2.release();
     delete p;

@@ -215,6 +215,38 @@ def test_hip_mhst_matches_oracle(gpu, npi, npj, npk, nb):
 
 
 @pytest.mark.gpu
+def test_hip_mhst_packed_masks_equal_the_r4_masks_bitwise(gpu, monkeypatch):
+    """0/1 basin masks are packed to a byte per cell for the zonal sums; CDFT_MHST_R4MASKS=1 keeps the r4 masks.  Same
+    products (x*1.d0, x*0.d0), same order: identical bits, a NaN under a zero mask included (0*NaN = NaN in the reference's
+    masked sum too).  Masks with other values are never packed."""
+    npi, npj, npk, nb = 130, 21, 4, 5
+    g = synth.make_grid(npi, npj, npk, seed=12)
+    t, s, _, v = tracer_fields(g, 3)
+    m = mhst_masks(g, nb)
+    vt = (t * v).astype(np.float32)
+    vs = (s * v).astype(np.float32)
+    vt[1, 7, 9] = np.nan                                     # wherever it falls: every basin sum of row 7 sees it
+    plan = gpu.MhstPlan(npi, npj, npk, nb)
+    plan.set_mesh(g["e1v"], m, e3v=g["e3v_0"])
+    a = plan.compute(vt=vt, vs=vs)
+    monkeypatch.setenv("CDFT_MHST_R4MASKS", "1")
+    b = plan.compute(vt=vt, vs=vs)
+    monkeypatch.delenv("CDFT_MHST_R4MASKS")
+    for k in (0, 1):
+        assert np.array_equal(a[k], b[k], equal_nan=True)
+    assert np.isnan(a[0]).sum() == nb                        # row 7 of every basin, nothing else
+    m2 = m.copy()
+    m2[1] *= np.float32(0.5)                                 # not a 0/1 mask: the r4 values are used
+    plan.set_mesh(g["e1v"], m2, e3v=g["e3v_0"])
+    vt[1, 7, 9] = 0.0
+    got = plan.compute(vt=vt, vs=vs)
+    ref = oracle_tools.mhst(g["e1v"], m2, e3v=g["e3v_0"], vt=vt, vs=vs)
+    bound = oracle_tools.mhst(g["e1v"], m2, e3v=g["e3v_0"], vt=np.abs(vt), vs=np.abs(vs))
+    for k in (0, 1):
+        assert np.all(np.abs(got[k] - ref[k]) <= 1e-13 * bound[k] + 1e-300)
+
+
+@pytest.mark.gpu
 def test_hip_psi_and_mhst_at_eorca025_size(gpu):
     """Full eORCA025 (1442x1207x75) resident in HBM: psi bit-exact on sampled columns/rows against
     the oracle run on the sub-grids that determine them; mhst rows against the oracle."""
