@@ -22,6 +22,8 @@ struct cdft_zonal_plan {
     int npi = 0, npj = 0, npk = 0, nb = 0;
     double *surf = nullptr;       // (npi,npj) 1.d0*e1*e2
     float  *mask3 = nullptr;      // (npi,npj,npk) mask of the variable's grid point
+    uint8_t *mask8 = nullptr;     // the same as bytes when every value is 0 or 1 (class kernel: 1 byte per cell instead of 4)
+    bool mask01 = false;
     float  *bmask = nullptr;      // (nb,npi,npj) basin masks, basin index fastest
     uint8_t *bits = nullptr;      // (npi,npj) basin bits when every basin mask is 0/1 (fast kernel)
     int *flag = nullptr;          // device: 1 when a basin-mask value is neither 0 nor 1
@@ -49,6 +51,7 @@ __global__ void zonal_surf_kernel(const float *__restrict__ e1, const float *__r
 struct ZonalArgs2 {
     const double *surf;
     const float *mask3, *bmask, *zv;
+    const uint8_t *mask8;      // or null
     int npi, npj, nlev, nb;
     double *dsum, *darea;      // (npj,nlev,nb)
     float *rmax, *rmin;        // (npj,nlev,nb) or null
@@ -263,7 +266,9 @@ struct ZonalClassArgs {
 // Loads: the row is covered by 16-byte vectors starting at cells 0, 4, 8, ... (r4-aligned only: rows start anywhere),
 // and, when npiglo is not a multiple of 4, one more vector anchored at npiglo-4 whose leading cells repeat the previous
 // vector's and are sent to an unread slot -- so every load is a full vector inside the row, without a branch.
-template <int NV, bool MEAN, int T>
+typedef uint32_t u32u __attribute__((aligned(1)));               // 4 mask bytes at any address
+
+template <int NV, bool MEAN, int T, bool M8>
 __global__ void __launch_bounds__(T) zonal_row_class_kernel(ZonalArgs2 a, ZonalClassArgs ca) {
     extern __shared__ double lds[];
     constexpr int nwaves = T / 64;
@@ -289,11 +294,18 @@ __global__ void __launch_bounds__(T) zonal_row_class_kernel(ZonalArgs2 a, ZonalC
     }
 #pragma unroll
     for (int c = 0; c <= kZC; ++c) scr[c * kZStride + lane] = 0.0;
-    f4u zc[NV], mc[NV], zn[NV], mn_[NV];
-    auto fetch = [&](f4u (&z)[NV], f4u (&mk)[NV], int k) {
-        const float *zv = a.zv + (int64_t)k * nij + r2, *mv = a.mask3 + (int64_t)k * nij + r2;
+    // the level mask: r4 as given (M8 = false), or one byte per cell when it holds only 0 and 1 (the same m*z products)
+    struct Mask { f4u v; uint32_t b; };
+    f4u zc[NV], zn[NV];
+    Mask mc[NV], mn_[NV];
+    auto fetch = [&](f4u (&z)[NV], Mask (&mk)[NV], int k) {
+        const float *zv = a.zv + (int64_t)k * nij + r2;
 #pragma unroll
-        for (int r = 0; r < NV; ++r) { z[r] = ld_stream4u(zv + i0[r]); mk[r] = ld_stream4u(mv + i0[r]); }
+        for (int r = 0; r < NV; ++r) {
+            z[r] = ld_stream4u(zv + i0[r]);
+            if (M8) mk[r].b = __builtin_nontemporal_load(reinterpret_cast<const u32u *>(a.mask8 + (int64_t)k * nij + r2 + i0[r]));
+            else    mk[r].v = ld_stream4u(a.mask3 + (int64_t)k * nij + r2 + i0[r]);
+        }
     };
     fetch(zc, mc, k0);
     for (int k = k0; k < k1; ++k) {
@@ -301,7 +313,14 @@ __global__ void __launch_bounds__(T) zonal_row_class_kernel(ZonalArgs2 a, ZonalC
         if (ZONAL_STEP) __syncthreads();                // nothing shared here: keeps the waves of the row on one level
 #pragma unroll
         for (int r = 0; r < NV; ++r) {
-            const float z4[4] = {zc[r].x, zc[r].y, zc[r].z, zc[r].w}, m4[4] = {mc[r].x, mc[r].y, mc[r].z, mc[r].w};
+            const float z4[4] = {zc[r].x, zc[r].y, zc[r].z, zc[r].w};
+            float m4[4];
+            if (M8) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) m4[c] = (float)((mc[r].b >> (8 * c)) & 0xffu);
+            } else {
+                m4[0] = mc[r].v.x; m4[1] = mc[r].v.y; m4[2] = mc[r].v.z; m4[3] = mc[r].v.w;
+            }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 // zmask = 1: sum form (1.f*m)*z = m*z in r4; mean form ((1.d0*1)*m)*z = m*z in r8
@@ -353,8 +372,14 @@ template <int NV>
 int launch_class_nv(const ZonalArgs2 &a, const ZonalClassArgs &ca, bool mean, hipStream_t st) {
     constexpr int T = kClassT;
     const size_t shmem = ((size_t)(T / 64) * (kZC + 1) * kZStride + (size_t)a.nlev * kZC * (T / 64)) * sizeof(double);
-    if (mean) hipLaunchKernelGGL((zonal_row_class_kernel<NV, true, T>), dim3(a.npj * ca.lc), dim3(T), shmem, st, a, ca);
-    else      hipLaunchKernelGGL((zonal_row_class_kernel<NV, false, T>), dim3(a.npj * ca.lc), dim3(T), shmem, st, a, ca);
+    const dim3 grid(a.npj * ca.lc);
+    if (a.mask8) {
+        if (mean) hipLaunchKernelGGL((zonal_row_class_kernel<NV, true, T, true>), grid, dim3(T), shmem, st, a, ca);
+        else      hipLaunchKernelGGL((zonal_row_class_kernel<NV, false, T, true>), grid, dim3(T), shmem, st, a, ca);
+    } else {
+        if (mean) hipLaunchKernelGGL((zonal_row_class_kernel<NV, true, T, false>), grid, dim3(T), shmem, st, a, ca);
+        else      hipLaunchKernelGGL((zonal_row_class_kernel<NV, false, T, false>), grid, dim3(T), shmem, st, a, ca);
+    }
     CDFT_LAUNCH_CHECK();
     return CDFT_OK;
 }
@@ -374,6 +399,15 @@ int launch_class(const ZonalArgs2 &a, ZonalClassArgs ca, bool mean, hipStream_t 
         case 4: return launch_class_nv<4>(a, ca, mean, st);
         default: return launch_class_nv<5>(a, ca, mean, st);
     }
+}
+
+// mask8 = mask3 as bytes; flag[0] is raised by a value that is neither +0 nor 1
+__global__ void zonal_mask8_kernel(const float *__restrict__ m, int64_t n, uint8_t *__restrict__ m8, int *__restrict__ flag) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const float v = m[p];
+    if (v == 1.f) m8[p] = 1;
+    else { m8[p] = 0; if (!(v == 0.f) || signbit(v)) flag[0] = 1; }
 }
 
 // cls(i,j) = lut[bits(i,j)]; seen[v] = 1 for every bit pattern v present
@@ -454,6 +488,10 @@ int cdft_zonal_set_mesh(cdft_zonal_plan *p, const float *e1, const float *e2, co
     CDFT_LAUNCH_CHECK();
     CDFT_TRY(keepz((void **)&p->mask3, zmaskvar, nij * p->npk * 4, memspace, st));
     CDFT_TRY(keepz((void **)&p->bmask, zmask, nij * p->nb * 4, memspace, st));
+    if (!p->mask8 && hipMalloc((void **)&p->mask8, nij * p->npk + 64) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(CDFT_ERR_ALLOC, "cdft_zonal_set_mesh: device allocation failed");
+    }
     if (!p->bits && (hipMalloc((void **)&p->bits, nij + 64) != hipSuccess || hipMalloc((void **)&p->flag, sizeof(int)) != hipSuccess ||
                      hipMalloc((void **)&p->rowflag, (size_t)p->npj * sizeof(int)) != hipSuccess)) {
         (void)hipGetLastError();
@@ -467,6 +505,16 @@ int cdft_zonal_set_mesh(cdft_zonal_plan *p, const float *e1, const float *e2, co
     CDFT_HIP(hipMemcpyAsync(&flag, p->flag, sizeof(int), hipMemcpyDeviceToHost, st));
     CDFT_HIP(hipStreamSynchronize(st));
     p->binary = (flag == 0);
+    {                                                            // the level masks as bytes, when they are 0 / 1
+        const int64_t n3 = (int64_t)nij * p->npk;
+        int f8 = 0;
+        CDFT_HIP(hipMemsetAsync(p->flag, 0, sizeof(int), st));
+        hipLaunchKernelGGL(zonal_mask8_kernel, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, st, p->mask3, n3, p->mask8, p->flag);
+        CDFT_LAUNCH_CHECK();
+        CDFT_HIP(hipMemcpyAsync(&f8, p->flag, sizeof(int), hipMemcpyDeviceToHost, st));
+        CDFT_HIP(hipStreamSynchronize(st));
+        p->mask01 = (f8 == 0);
+    }
     // class kernel: number the bit patterns present (the empty one included), at most kZC of them
     p->nclass = 0;
     if (p->binary && p->nb > 1) {
@@ -502,7 +550,7 @@ int cdft_zonal_set_mesh(cdft_zonal_plan *p, const float *e1, const float *e2, co
         return fail(CDFT_ERR_ALLOC, "cdft_zonal_set_mesh: device allocation failed");
     }
     ZonalArgs2 a;
-    a.surf = p->surf; a.mask3 = p->mask3; a.bmask = p->bmask; a.zv = p->mask3;      // any finite field: only darea is kept
+    a.surf = p->surf; a.mask3 = p->mask3; a.mask8 = nullptr; a.bmask = p->bmask; a.zv = p->mask3;      // any finite field: only darea is kept
     a.npi = p->npi; a.npj = p->npj; a.nlev = p->npk; a.nb = p->nb;
     a.dsum = nullptr; a.darea = p->area; a.rmax = nullptr; a.rmin = nullptr;
     if (p->nb == 1)      CDFT_TRY(launch_area<1>(a, st));
@@ -529,6 +577,10 @@ int cdft_zonal_compute(cdft_zonal_plan *p, const float *zv, int nlev, int in_spa
     const size_t n = (size_t)p->npj * nlev * p->nb;
     ZonalArgs2 a;
     a.surf = p->surf; a.mask3 = p->mask3; a.bmask = p->bmask; a.zv = (const float *)dz;
+    {
+        const char *e = getenv("CDFT_ZONAL_R4MASK");             // test hook: the class kernel on the r4 level masks
+        a.mask8 = (p->mask01 && !(e && e[0] == '1')) ? p->mask8 : nullptr;
+    }
     a.npi = p->npi; a.npj = p->npj; a.nlev = nlev; a.nb = p->nb;
     a.dsum = dzo; a.darea = darea; a.rmax = rzomax; a.rmin = rzomin;
     if (out_space == CDFT_MEM_HOST) {
@@ -574,7 +626,7 @@ int cdft_zonal_compute(cdft_zonal_plan *p, const float *zv, int nlev, int in_spa
 
 int cdft_zonal_destroy(cdft_zonal_plan *p) {
     if (!p) return CDFT_OK;
-    void *ptrs[] = {p->surf, p->mask3, p->bmask, p->bits, p->flag, p->rowflag, p->area, p->cls, p->seen};
+    void *ptrs[] = {p->surf, p->mask3, p->mask8, p->bmask, p->bits, p->flag, p->rowflag, p->area, p->cls, p->seen};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     p->st_a.release(); p->st_b.release(); p->st_zv.release();
     for (DevBuf &b : p->st_o) b.release();

@@ -373,6 +373,11 @@ def test_hip_zonal_matches_oracle(gpu, monkeypatch, npi, npj, npk, nb, kernel):
         bound = oracle_tools.zonal(g["e1t"], g["e2t"], tm, zm, np.abs(zv), mean_form=mean_form)["sum"]
         assert np.all(np.abs(got["sum"] - ref["sum"]) <= 1e-13 * bound + 1e-300)
         assert np.array_equal(plan.compute(zv, mean_form=mean_form, minmax=minmax)["sum"], got["sum"])   # run-to-run identical
+        if kernel == "class":                     # the level masks as bytes (0/1 masks) against the r4 masks: same bits
+            monkeypatch.setenv("CDFT_ZONAL_R4MASK", "1")
+            r4 = plan.compute(zv, mean_form=mean_form, minmax=minmax)
+            monkeypatch.delenv("CDFT_ZONAL_R4MASK")
+            assert all(np.array_equal(r4[k], got[k]) for k in got)
         dev = plan.compute(zv, mean_form=mean_form, minmax=minmax, device_out=True)                       # results left in HBM
         assert sorted(dev) == sorted(got) and all(np.array_equal(dev[k].cpu().numpy(), got[k]) for k in got)
         if mean_form:

@@ -85,9 +85,9 @@ def main():
         del tm, zm
         for name, mf in (("cdfzonalsum (5 basins)", False), ("cdfzonalmean (5 basins)", True)):
             ms = timed(lambda: p.compute(zv, mean_form=mf, device_out=True), args.reps)
-            report(name, args.grid, n3, 8.0, ms, "field 4 + mask 4 B per cell (2-D surface and basin masks from cache); result left in HBM")
+            report(name, args.grid, n3, 5.0, ms, "field 4 + level mask 1 B per cell (a 0/1 mask is kept as bytes; 2-D surface and basin classes from cache); result left in HBM")
             ms = timed(lambda: p.compute(zv, mean_form=mf), args.reps)
-            report(name + ", result to the host", args.grid, n3, 8.0, ms, "the same with the D2H copy of the (5,npk,npj) r8 result"
+            report(name + ", result to the host", args.grid, n3, 5.0, ms, "the same with the D2H copy of the (5,npk,npj) r8 result"
                    " (and the area, mean form) into fresh pageable arrays: PCIe and page faults, not the kernel")
         del p, zv
 
