@@ -18,6 +18,8 @@ using namespace cdft;
 struct cdft_mean_plan {
     int npi = 0, npj = 0, npk = 0, nb = 0;
     float *e1 = nullptr, *e2 = nullptr, *e3 = nullptr, *e31d = nullptr, *mask = nullptr;
+    uint8_t *mask8 = nullptr;      // zmask as bytes when it holds only +0 and 1 (9 bytes per cell and level instead of 12)
+    bool mask01 = false;
     int16_t *ib = nullptr;          // (nb,npi,npj), basin index fastest
     double *partial = nullptr;      // [npk][nblk][nb][4]
     int nblk = 0;
@@ -34,6 +36,7 @@ constexpr int kMaxNB   = 8;
 
 struct MeanArgs {
     const float *e1, *e2, *e3, *e31d, *mask, *zv;
+    const uint8_t *mask8;          // or null
     const int16_t *ib;
     int64_t nij;
     int npk, nb, nblk, form;
@@ -42,6 +45,15 @@ struct MeanArgs {
 
 // NB: basin capacity of the instantiation (1, 2, 4 or 8): every loop over basins is unrolled so that the
 // accumulators stay in registers (a run-time bound put them in scratch memory: 6x slower)
+// mask8 = zmask as bytes; flag[0] is raised by a value that is neither +0 nor 1
+__global__ void mean_mask8_kernel(const float *__restrict__ m, int64_t n, uint8_t *__restrict__ m8, int *__restrict__ flag) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const float v = m[p];
+    if (v == 1.f) m8[p] = 1;
+    else { m8[p] = 0; if (!(v == 0.f) || signbit(v)) flag[0] = 1; }
+}
+
 template <int VEC, bool FULL, int NB>
 __global__ void __launch_bounds__(kThreads) mean_level_kernel(MeanArgs a) {
     extern __shared__ double wsum[];                   // [nwaves][nb*4]
@@ -73,9 +85,17 @@ __global__ void __launch_bounds__(kThreads) mean_level_kernel(MeanArgs a) {
 #pragma unroll
         for (int v = 0; v < kVPT; ++v) {
             if constexpr (VEC == 4) {                  // 16-byte loads at r4 alignment, always inside the level
-                const f4u z = ld_stream4u(a.zv + base + q[v]), m = ld_stream4u(a.mask + base + q[v]);
+                const f4u z = ld_stream4u(a.zv + base + q[v]);
                 zv[v][0] = z.x; zv[v][1] = z.y; zv[v][2] = z.z; zv[v][3] = z.w;
-                mk[v][0] = m.x; mk[v][1] = m.y; mk[v][2] = m.z; mk[v][3] = m.w;
+                if (a.mask8) {                         // 4 mask bytes (an unaligned dword): the same 0.f / 1.f
+                    typedef uint32_t u32u __attribute__((aligned(1)));
+                    const uint32_t m = __builtin_nontemporal_load(reinterpret_cast<const u32u *>(a.mask8 + base + q[v]));
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) mk[v][c] = (float)((m >> (8 * c)) & 0xffu);
+                } else {
+                    const f4u m = ld_stream4u(a.mask + base + q[v]);
+                    mk[v][0] = m.x; mk[v][1] = m.y; mk[v][2] = m.z; mk[v][3] = m.w;
+                }
                 if (!FULL) {
                     const f4u e = ld_stream4u(a.e3 + base + q[v]);
                     e3[v][0] = e.x; e3[v][1] = e.y; e3[v][2] = e.z; e3[v][3] = e.w;
@@ -205,7 +225,18 @@ int cdft_mean_set_mesh(cdft_mean_plan *p, const float *e1, const float *e2, cons
     }
     CDFT_TRY(keep((void **)&p->mask, zmask, n3 * 4, memspace, st));
     CDFT_TRY(keep((void **)&p->ib, ibmask, nij * p->nb * 2, memspace, st));
+    if (!p->mask8 && hipMalloc((void **)&p->mask8, n3 + 64) != hipSuccess) {       // the flag sits behind the bytes
+        (void)hipGetLastError();
+        return fail(CDFT_ERR_ALLOC, "cdft_mean_set_mesh: device allocation failed");
+    }
+    int *flag = (int *)(p->mask8 + ((n3 + 15) / 16) * 16);
+    int not01 = 0;
+    CDFT_HIP(hipMemsetAsync(flag, 0, 4, st));
+    hipLaunchKernelGGL(mean_mask8_kernel, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, st, p->mask, (int64_t)n3, p->mask8, flag);
+    CDFT_LAUNCH_CHECK();
+    CDFT_HIP(hipMemcpyAsync(&not01, flag, 4, hipMemcpyDeviceToHost, st));
     CDFT_HIP(hipStreamSynchronize(st));
+    p->mask01 = not01 == 0;
     p->mesh_set = true;
     return CDFT_OK;
 }
@@ -232,6 +263,10 @@ int cdft_mean_compute(cdft_mean_plan *p, const float *zv, int in_space, double *
     MeanArgs a;
     a.e1 = p->e1; a.e2 = p->e2; a.e3 = p->e3; a.e31d = p->e31d; a.mask = p->mask; a.zv = (const float *)dz; a.ib = p->ib;
     a.nij = nij; a.npk = p->npk; a.nb = p->nb; a.partial = p->partial; a.form = p->form;
+    {
+        const char *e = getenv("CDFT_MEAN_R4MASK");              // test hook: the r4 mask
+        a.mask8 = (p->mask01 && !(e && e[0] == '1')) ? p->mask8 : nullptr;
+    }
     const bool vec4 = nij >= 4 && !getenv("CDFT_MEAN_SCALAR");         // (A/B hook: the scalar path)
     const int vec = vec4 ? 4 : 1;
     a.nblk = (int)(((nij + vec - 1) / vec + kThreads * kVPT - 1) / (kThreads * kVPT));
@@ -260,7 +295,7 @@ int cdft_mean_compute(cdft_mean_plan *p, const float *zv, int in_space, double *
 
 int cdft_mean_destroy(cdft_mean_plan *p) {
     if (!p) return CDFT_OK;
-    void *ptrs[] = {p->e1, p->e2, p->e3, p->e31d, p->mask, p->ib, p->partial};
+    void *ptrs[] = {p->e1, p->e2, p->e3, p->e31d, p->mask, p->mask8, p->ib, p->partial};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     p->st_zv.release(); p->st_out.release();
     delete p;

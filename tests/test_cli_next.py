@@ -140,7 +140,7 @@ def test_oracle_mean_matches_numpy_restatement():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("npi,npj,npk,nb", [(24, 18, 7, 4), (182, 149, 31, 1), (1, 1, 1, 1), (5, 3, 2, 8), (1023, 7, 3, 3), (64, 64, 2, 2)])
-def test_hip_mean_matches_oracle(gpu, npi, npj, npk, nb):
+def test_hip_mean_matches_oracle(gpu, monkeypatch, npi, npj, npk, nb):
     g, zv, ib = mean_inputs(npi, npj, npk, min(nb, 4), seed=npi + 1)
     if nb > 4:
         ib = np.concatenate([ib, ib[:, :, :nb - 4] * 2], axis=2)                      # values other than 0/1 are allowed
@@ -153,6 +153,15 @@ def test_hip_mean_matches_oracle(gpu, npi, npj, npk, nb):
         bound = oracle_tools.mean(g["e1t"], g["e2t"], tm, ib, np.abs(zv), **kw)
         assert np.all(np.abs(got - ref) <= 1e-13 * bound + 1e-300), float(np.abs(got - ref).max())
         assert np.array_equal(plan.compute(zv), got)                                    # run-to-run identical
+        monkeypatch.setenv("CDFT_MEAN_R4MASK", "1")                                     # the 0/1 mask as r4 instead of bytes
+        assert np.array_equal(plan.compute(zv), got)
+        monkeypatch.delenv("CDFT_MEAN_R4MASK")
+    tm2 = tm * np.float32(0.5)                                                          # not 0/1: never packed
+    plan.set_mesh(g["e1t"], g["e2t"], tm2, ib, e3=g["e3t_0"])
+    got = plan.compute(zv)
+    ref = oracle_tools.mean(g["e1t"], g["e2t"], tm2, ib, zv, e3=g["e3t_0"])
+    bound = oracle_tools.mean(g["e1t"], g["e2t"], tm2, ib, np.abs(zv), e3=g["e3t_0"])
+    assert np.all(np.abs(got - ref) <= 1e-13 * bound + 1e-300)
 
 
 @pytest.mark.gpu

@@ -70,7 +70,7 @@ def main():
         p.set_mesh(e1.cpu().numpy(), e2.cpu().numpy(), tm, np.ones((npj, npi, 1), np.int16), e3=e3.cpu().numpy())
         del tm
         ms = timed(lambda: p.compute(zv), args.reps)
-        report("cdfmean (1 basin)", args.grid, n3, 12.0, ms, "field 4 + e3 4 + r4 mask 4 B per cell; includes the D2H of 4*npk sums")
+        report("cdfmean (1 basin)", args.grid, n3, 9.0, ms, "field 4 + e3 4 + mask 1 B per cell (a 0/1 mask is kept as bytes); includes the D2H of 4*npk sums")
         del p, zv
 
     if "zonal" in tools:
