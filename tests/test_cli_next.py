@@ -396,6 +396,13 @@ def test_hip_zonal_matches_oracle(gpu, monkeypatch, npi, npj, npk, nb, kernel):
     two = plan.compute(zv[:2] if npk > 1 else zv)                          # a variable with fewer levels
     ref = oracle_tools.zonal(g["e1t"], g["e2t"], tm[:2], zm, zv[:2] if npk > 1 else zv)
     assert np.allclose(two["sum"], ref["sum"], rtol=1e-12, atol=1e-6)
+    tm2 = (tm * np.float32(0.5)).astype(np.float32)                        # a level mask that is not 0/1 is never packed to bytes
+    plan.set_mesh(g["e1t"], g["e2t"], tm2, zm)
+    for mean_form in (False, True):
+        got = plan.compute(zv, mean_form=mean_form)
+        ref = oracle_tools.zonal(g["e1t"], g["e2t"], tm2, zm, zv, mean_form=mean_form)
+        bound = oracle_tools.zonal(g["e1t"], g["e2t"], tm2, zm, np.abs(zv), mean_form=mean_form)["sum"]
+        assert np.all(np.abs(got["sum"] - ref["sum"]) <= 1e-13 * bound + 1e-300)
 
 
 @pytest.mark.parametrize("tool", ["cdfzonalsum", "cdfzonalmean", "cdfmean"])
