@@ -8,13 +8,18 @@
  * mixing; the reference file:line it follows is cited at each definition in cdf_oracle.c.
  *
  * Pinning status (see DESIGN.md "Oracle"):
- *   - sigma0 / sigmai : PINNED.  Checked against the reference's own known-answer values
- *     (src/eos.f90:817,:820) and against oracle/_ref (the unmodified src/eos.f90 compiled with
- *     amdflang) through tests/golden/eos_*.npz.
- *   - cdfmoc, cdfheatc, cdfmhst, cdfvT, cdfpsi, cdfcurl loops : PARITY UNPINNED.  The reference
- *     holds no tests, golden files or fixtures for them, and its programs cannot be built here
- *     (they need netcdf-fortran, which the image lacks); these restatements are pinned only by
- *     line-by-line reading of the cited source.
+ *   - sigma0 / sigmai / sigmantr : PINNED bit for bit to the reference's src/eos.f90 compiled where it lies
+ *     (oracle/_ref/libeos_ref.so; tests/golden/eos.npz) and to its known-answer values (src/eos.f90:817,:820).
+ *   - cdfmoc (+ -decomp, -full), cdfheatc (r4sum mode, + -full, -mxloption), cdfmhst (-vt / V,T,S / -Zdim / -full),
+ *     cdfpsi (default, -V, -mean, -mask, -ref, -full, -open, --ssh-file, -lev), cdfvT (+ -vvl), cdfcurl (+ -T,
+ *     -overf, level 0) : PINNED bit for bit to the reference's own STATEMENTS.  The programs cannot be built here
+ *     (netcdf-fortran is absent), so oracle/ref_lift.py lifts their declaration blocks, ALLOCATEs and whole time
+ *     loops by line range into harnesses with plain array arguments (only I/O statements are rewritten), compiled
+ *     with amdflang -O1 -ffp-contract=off into oracle/_ref/liblift_ref.so; tests/golden/lift_*.npz hold the
+ *     harness outputs and tests/test_lift.py compares.  That pins evaluation order, r4/r8 mixing and index ranges
+ *     -- what a transcription can get wrong -- not cdfio, the option parsers or the file layouts.
+ *   - cdfmocsig, cdfmean, cdfsum, cdfzonal*, cdfvint, cdfvertmean, cdfvhst, cdfvtrp loops : unpinned,
+ *     read line by line from the cited source.
  *
  * Arrays are Fortran column-major (first index fastest), as in include/cdftools_hip.h.
  */

@@ -1,8 +1,8 @@
 /*
  * cdf_oracle_tools.c -- CPU restatement of the cdfheatc / cdfmhst / cdfpsi / cdfvT / cdfcurl loops.
- * TEST INFRASTRUCTURE ONLY (see cdf_oracle.h).  PARITY UNPINNED: the reference holds no tests or
- * fixtures for these loops and its programs need netcdf-fortran to build; each function follows the
- * cited source line by line, in its evaluation order and r4/r8 mixing.
+ * TEST INFRASTRUCTURE ONLY (see cdf_oracle.h).  These five are pinned bit for bit to harnesses built from the
+ * reference's own statements (oracle/ref_lift.py, tests/golden/lift_*.npz, tests/test_lift.py); each function follows
+ * the cited source line by line, in its evaluation order and r4/r8 mixing.
  */
 #include "cdf_oracle.h"
 #include <math.h>

@@ -1,0 +1,496 @@
+#!/usr/bin/env python3
+"""oracle/ref_lift.py -- harnesses around LITERAL statements of the reference programs (TEST INFRASTRUCTURE).
+
+What this is.  The eight cdf*.f90 programs of the reference cannot be built in this image: they reach NetCDF
+through cdfio.F90 and netcdf-fortran is absent.  Their ARITHMETIC, however, is plain
+Fortran.  This script reads /root/reference/src/<tool>.f90 where it lies and writes, into the git-ignored
+oracle/_ref/, one Fortran subroutine per tool made of
+
+  * the program's own declaration block, lifted verbatim (only `TYPE(variable)` lines, which need cdfio, are
+    dropped), so every variable has the reference's type, kind and rank;
+  * the program's own ALLOCATE statements and its whole time loop, lifted verbatim by line range;
+  * harness glue written here: a BIND(C) argument list of plain arrays, flag assignments that stand for the
+    command-line parser, and captures of results.
+
+The only lines of a lifted range that are altered are I/O statements, and only in these mechanical ways:
+  `getvar(file, var, lev, npiglo, npjglo [, ktime=t] ...)`  ->  `h_<array>(:,:,lev,t)`  (a plain array argument)
+  `getvare3(file, var, n)` / `getvar1d(file, var, n)`        ->  `h_<array>(:)`
+  `ierr = putvar(ncout, id_varout(n), EXPR, lev, ...)`       ->  `o_<array>(..) = EXPR`  (EXPR untouched)
+  `PRINT ...` / `WRITE(...)`                                  ->  dropped (or, where the tool spec says so, a capture of
+                                                                 the printed variables)
+  `ierr = closeout(..)`, `STOP n`                             ->  `ierr = 0`, `RETURN`
+Every other line reaches the compiler byte for byte; `lift()` asserts that a line it alters holds one of those
+I/O tokens, and each lifted range is pinned by the SHA-256 of its text so that a different reference revision is
+refused instead of silently shifting line numbers.
+
+What this is NOT.  It is not the reference program and not a build of it: no cdfio, no files, no option parser.
+It pins the evaluation order, the r4/r8 mixing and the index ranges of the loops -- the part a transcription can
+get wrong -- because the compiler sees the reference's own text.  The generated sources and the shared object
+stay in oracle/_ref/ (git-ignored): reference text never enters the repository.  Only outputs of the harness run
+on synthetic inputs are committed (tests/golden/lift_*.npz, made by tests/make_golden_lift.py).
+
+Usage: python3 oracle/ref_lift.py [--out DIR] [--shas]     (called by oracle/ref_build.sh; needs /root/reference)
+"""
+import hashlib
+import os
+import re
+import sys
+
+REF = os.environ.get("CDFT_REFERENCE_SRC", "/root/reference/src")
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(HERE, "_ref")
+
+IO_TOKEN = re.compile(r"\b(getvar|getvare3|getvar1d|putvar|putvar1d|closeout|PRINT|WRITE|STOP)\b", re.I)
+
+
+# SHA-256 (first 16 hex digits) of every lifted range at the reference revision this was written for
+# (`python3 oracle/ref_lift.py --shas` prints the current ones).
+SHAS = {
+    "cdfmoc.f90": {'49-125': '3fefe705db05454d', '236-236': '75b30441aecc08bb', '272-278': '105e320aa63f3b97',
+                   '281-304': 'e8ff1410b994b5fb', '306-314': '5c9fb47f8397cf47', '325-336': 'b805d15787c1cb5d',
+                   '338-518': '93b908f104591dd7', '519-570': '30dc9880c21c4367', '576-596': '4dddff438b339b54'},
+    "cdfheatc.f90": {'24-67': 'f588c6224654319f', '177-186': '4e0de2a06c88c8d6', '188-192': 'b770d4ce667f8e40',
+                     '196-248': '1c9fc2a727732949'},
+    "cdfmhst.f90": {'34-103': '7ef454039bb47b19', '256-274': 'c4130977d91a663b', '276-277': 'f20e8805749476d9',
+                    '285-285': '0c09e2d78019206d', '302-446': 'dd7740ee803f57b3'},
+    "cdfpsi.f90": {'34-88': '59db5ae980e25bce', '228-239': 'c25b3e7e171a1692', '246-253': '3cdebe7afb78924e',
+                   '256-423': 'faea68189a77a289', '424-439': '54abc3e06a253c80'},
+    "cdfvT.f90": {'29-66': '01a91a9f11bdef51', '146-150': 'be34dddcb49a65d7', '152-155': '1ceb1ad495d85ecd',
+                  '159-159': '355959c032428590', '160-168': 'e7924de889e9fd84', '186-259': '190b74a4951ddade'},
+    "cdfcurl.f90": {'26-64': '2e0ba28c42a38070', '190-198': '1cf01aed8a82cb4b', '200-225': 'b703bc172976af47',
+                    '238-238': '1e01b69985fc68f0', '242-304': '436d55fbb38c6d62'},
+}
+
+
+def split_args(s):
+    """Split a Fortran argument list at top-level commas."""
+    out, depth, cur = [], 0, ""
+    for ch in s:
+        if ch in "([":
+            depth += 1
+        elif ch in ")]":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur.strip())
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur.strip())
+    return out
+
+
+def find_call(line, name):
+    """-> (start, end, args) of the first `name ( ... )` call in line, or None."""
+    m = re.search(r"\b%s\s*\(" % name, line)
+    if not m:
+        return None
+    i = m.end()
+    depth = 1
+    while i < len(line) and depth:
+        if line[i] == "(":
+            depth += 1
+        elif line[i] == ")":
+            depth -= 1
+        i += 1
+    if depth:
+        raise ValueError("unbalanced call in: " + line)
+    return m.start(), i, split_args(line[m.end():i - 1])
+
+
+def varidx(tok):
+    """`id_varout(n)` -> `n`"""
+    return re.sub(r"id_varout\s*\((.*)\)", r"\1", tok)
+
+
+class Tool:
+    def __init__(self, fname, varmap, putvar=None, capture=None, shas=None):
+        self.fname = fname
+        with open(os.path.join(REF, fname)) as f:
+            self.src = f.read().split("\n")
+        self.varmap = varmap            # reference variable-name token -> harness array
+        self.putvar = putvar            # callable(args, kw) -> statement text
+        self.capture = capture or {}    # line number -> replacement for a PRINT / WRITE line
+        self.shas = shas if shas is not None else SHAS.get(fname, {})
+        self.report = []
+
+    def text(self, a, b):
+        return [ln.rstrip() for ln in self.src[a - 1:b]]
+
+    def check_sha(self, a, b):
+        h = hashlib.sha256("\n".join(self.text(a, b)).encode()).hexdigest()[:16]
+        key = f"{a}-{b}"
+        want = self.shas.get(key)
+        self.report.append((key, h))
+        if want is None and "--shas" not in sys.argv:
+            raise SystemExit(f"{self.fname}:{key}: range has no pinned SHA")
+        if want is not None and want != h:
+            raise SystemExit(f"{self.fname}:{key}: reference text differs from the revision this harness was written "
+                             f"for (sha {h}, expected {want})")
+
+    def decls(self, a, b):
+        """The declaration block, verbatim, minus TYPE(variable) lines (need cdfio)."""
+        self.check_sha(a, b)
+        out = []
+        for ln in self.text(a, b):
+            if re.match(r"\s*TYPE\s*\(\s*variable\s*\)", ln, re.I):
+                out.append("  ! [lift] dropped: " + ln.strip())
+            else:
+                out.append(ln)
+        return out
+
+    def raw(self, a, b):
+        """Lines a..b verbatim; refuses ranges that hold I/O."""
+        self.check_sha(a, b)
+        for n, ln in enumerate(self.text(a, b), a):
+            code = ln.split("!")[0]
+            if IO_TOKEN.search(code):
+                raise SystemExit(f"{self.fname}:{n}: raw() range holds an I/O statement: {ln}")
+        return self.text(a, b)
+
+    def _kw(self, args):
+        pos, kw = [], {}
+        for a in args:
+            m = re.match(r"^(\w+)\s*=\s*(.*)$", a)
+            if m and not a.startswith(("'", '"')):
+                kw[m.group(1).lower()] = m.group(2)
+            else:
+                pos.append(a)
+        return pos, kw
+
+    def rewrite(self, n, ln):
+        code = ln.split("!")[0] if "'" not in ln and '"' not in ln else ln
+        if not IO_TOKEN.search(code):
+            return ln                                           # arithmetic / control flow: byte for byte
+        if n in self.capture:
+            return self.capture[n]
+        s = ln
+        if re.match(r"\s*(PRINT|WRITE)\b", s, re.I) or re.search(r"\)\s*(PRINT|WRITE)\b", code, re.I):
+            return "  ! [lift] I/O dropped: " + s.strip()
+        for name in ("getvare3", "getvar1d"):
+            c = find_call(s, name)
+            if c:
+                pos, kw = self._kw(c[2])
+                arr = self.varmap[pos[1]]
+                return s[:c[0]] + f"{arr}(:)" + s[c[1]:]
+        c = find_call(s, "getvar")
+        if c:
+            pos, kw = self._kw(c[2])
+            arr = self.varmap[pos[1]]
+            lev = pos[2]
+            t = kw.get("ktime", "1")
+            return s[:c[0]] + f"{arr}(:,:,{lev},{t})" + s[c[1]:]
+        c = find_call(s, "putvar1d")
+        if c:
+            m = re.search(r"\bierr\s*=\s*$", s[:c[0]])
+            return s[:m.start()] + "ierr = 0" + s[c[1]:]
+        c = find_call(s, "putvar")
+        if c:
+            pos, kw = self._kw(c[2])
+            m = re.search(r"\bierr\s*=\s*$", s[:c[0]])
+            if not m:
+                raise SystemExit(f"{self.fname}:{n}: putvar not of the form `ierr = putvar(...)`: {ln}")
+            return s[:m.start()] + self.putvar(pos, kw) + s[c[1]:]
+        c = find_call(s, "closeout")
+        if c:
+            m = re.search(r"\bierr\s*=\s*$", s[:c[0]])
+            return s[:m.start()] + "ierr = 0" + s[c[1]:]
+        m = re.search(r"\bSTOP\b\s*\d*", s)
+        if m:
+            return s[:m.start()] + "RETURN" + s[m.end():]
+        raise SystemExit(f"{self.fname}:{n}: I/O token without a rewrite rule: {ln}")
+
+    def lift(self, a, b):
+        self.check_sha(a, b)
+        return [self.rewrite(n, ln) for n, ln in enumerate(self.text(a, b), a)]
+
+    def expand(self, template):
+        out = []
+        for ln in template.split("\n"):
+            m = re.match(r"\s*!@(DECLS|LIFT|RAW)\s+(\d+)\s+(\d+)", ln)
+            if not m:
+                out.append(ln)
+                continue
+            a, b = int(m.group(2)), int(m.group(3))
+            out.append(f"  ! ---- {m.group(1).lower()} {self.fname}:{a}-{b}")
+            out += {"DECLS": self.decls, "LIFT": self.lift, "RAW": self.raw}[m.group(1)](a, b)
+            out.append(f"  ! ---- end {self.fname}:{a}-{b}")
+        return "\n".join(out) + "\n"
+
+
+# =============================================================================================== cdfmoc
+# src/cdfmoc.f90: declarations :49-125, eos_init :236, sizes :272-278, ALLOCATE :281-304, metrics :306-314,
+# masks :325-336, the whole time loop :338-570 (zonal sums, cumulated sums, -decomp, output), get_e3v :576-596.
+CDFMOC = r"""
+SUBROUTINE lift_cdfmoc(kpi, kpj, kpk, kpt, kbas, kdec, kfull, kteos10, knvar, h_e1v, h_e1u, h_gphiv, h_gdepw, h_gdept, &
+     &  h_e31d, h_vmask, h_umask, h_tmask, h_e3v, h_atl, h_ind, h_pac, h_v, h_t, h_s, o_var, o_dmoc, o_dec) &
+     &  BIND(C, name='lift_cdfmoc')
+  USE ISO_C_BINDING
+  USE eos                      ! the reference's src/eos.f90, compiled where it lies (ref_build.sh)
+  IMPLICIT NONE
+  INTEGER(C_INT), VALUE :: kpi, kpj, kpk, kpt, kbas, kdec, kfull, kteos10, knvar
+  REAL(C_FLOAT), INTENT(in) :: h_e1v(kpi,kpj,1,1), h_e1u(kpi,kpj,1,1), h_gphiv(kpi,kpj,1,1)
+  REAL(C_FLOAT), INTENT(in) :: h_gdepw(kpk), h_gdept(kpk), h_e31d(kpk)
+  REAL(C_FLOAT), INTENT(in) :: h_vmask(kpi,kpj,kpk,1), h_umask(kpi,kpj,kpk,1), h_tmask(kpi,kpj,kpk,1), h_e3v(kpi,kpj,kpk,1)
+  REAL(C_FLOAT), INTENT(in) :: h_atl(kpi,kpj,1,1), h_ind(kpi,kpj,1,1), h_pac(kpi,kpj,1,1)
+  REAL(C_FLOAT), INTENT(in) :: h_v(kpi,kpj,kpk,kpt), h_t(kpi,kpj,kpk,kpt), h_s(kpi,kpj,kpk,kpt)
+  REAL(C_FLOAT),  INTENT(out) :: o_var(kpj,kpk,knvar,kpt)       ! what putvar is handed: REAL(...) rows
+  REAL(C_DOUBLE), INTENT(out) :: o_dmoc(kbas,kpj,kpk,kpt)       ! dmoc after the cumulated sum
+  REAL(C_DOUBLE), INTENT(out) :: o_dec(kbas,kpj,kpk,3,kpt)      ! dmoc_sh, dmoc_bt, dmoc_ag (-decomp)
+  LOGICAL :: lg_vvl = .FALSE.      ! modcdfnames variable; the vvl branch only changes which file is read
+!@DECLS 49 125
+  npiglo = kpi ; npjglo = kpj ; npk = kpk ; npt = kpt
+  lbas = ( kbas == 5 ) ; ldec = ( kdec /= 0 ) ; lfull = ( kfull /= 0 ) ; ll_teos10 = ( kteos10 /= 0 )
+  lg_vvl = .FALSE.
+!@RAW 236 236
+!@RAW 272 278
+  ! basin indices as CreateOutput numbers them (src/cdfmoc.f90:1032,:1057,:1081,:1106,:1131,:1156)
+  npglo = 1 ; npatl = 2 ; npinp = 3 ; npind = 4 ; nppac = 5 ; npinp0 = 6
+!@RAW 281 304
+!@LIFT 306 314
+!@LIFT 325 336
+  IF ( ldec ) dmoc_sh = 0.d0     ! ALLOCATE leaves it undefined and the reference never clears it (:471); start from 0
+!@LIFT 338 518
+     o_dmoc(:,:,:,jt) = dmoc(:,:,:)
+     IF ( ldec ) THEN
+        o_dec(:,:,:,1,jt) = dmoc_sh ; o_dec(:,:,:,2,jt) = dmoc_bt ; o_dec(:,:,:,3,jt) = dmoc_ag
+     ENDIF
+!@LIFT 519 570
+CONTAINS
+!@LIFT 576 596
+END SUBROUTINE lift_cdfmoc
+"""
+
+
+def gen_cdfmoc():
+    t = Tool("cdfmoc.f90",
+             {"cn_ve1v": "h_e1v", "cn_gphiv": "h_gphiv", "cn_gdepw": "h_gdepw", "cn_gdept": "h_gdept", "cn_ve1u": "h_e1u",
+              "cn_ve3t1d": "h_e31d", "cn_vmask": "h_vmask", "cn_tmaskatl": "h_atl", "cn_tmaskind": "h_ind",
+              "cn_tmaskpac": "h_pac", "cn_vomecrty": "h_v", "cn_umask": "h_umask", "cn_tmask": "h_tmask",
+              "cn_votemper": "h_t", "cn_vosaline": "h_s", "cn_ve3v": "h_e3v"},
+             putvar=lambda pos, kw: f"o_var(:,{pos[3]},{varidx(pos[1])},{kw.get('ktime', '1')}) = {pos[2]}")
+    return t, t.expand(CDFMOC)
+
+
+# =============================================================================================== cdfheatc
+# src/cdfheatc.f90: declarations :24-67, ALLOCATE :177-186, metrics :188-192, time loop :196-248.
+# The PRINT of :233 / :235 shows dsurf, dsum2d per level: those two lines become the capture of the level sums.
+CDFHEATC = r"""
+SUBROUTINE lift_cdfheatc(kpi, kpj, kpk, kpt, kfull, kmxl, h_e1t, h_e2t, h_gdepw, h_e31d, h_tmask, h_e3t, h_t, h_mxl, &
+     &  o_var, o_sums) BIND(C, name='lift_cdfheatc')
+  USE ISO_C_BINDING
+  IMPLICIT NONE
+  INTEGER(C_INT), VALUE :: kpi, kpj, kpk, kpt, kfull, kmxl
+  REAL(C_FLOAT), INTENT(in) :: h_e1t(kpi,kpj,1,1), h_e2t(kpi,kpj,1,1), h_gdepw(kpk), h_e31d(kpk)
+  REAL(C_FLOAT), INTENT(in) :: h_tmask(kpi,kpj,kpk,1), h_e3t(kpi,kpj,kpk,1), h_t(kpi,kpj,kpk,kpt), h_mxl(kpi,kpj,1,kpt)
+  REAL(C_DOUBLE), INTENT(out) :: o_var(kpk,3,kpt)       ! what putvar is handed: heatc3d, heatc2d(k), heatc3dpervol
+  REAL(C_DOUBLE), INTENT(out) :: o_sums(3,kpk,kpt)      ! dsurf, dvol2d, dsum2d of each level
+  LOGICAL :: lg_vvl = .FALSE.
+!@DECLS 24 67
+  npiglo = kpi ; npjglo = kpj ; npk = kpk ; npt = kpt ; npkk = kpk ; nvpk = kpk
+  iimin = 1 ; ijmin = 1 ; ikmin = 1 ; ikmax = kpk          ! no -zoom: src/cdfheatc.f90:162-164
+  lfull = ( kfull /= 0 ) ; mxloption = kmxl ; lg_vvl = .FALSE.
+!@RAW 177 186
+!@LIFT 188 192
+!@LIFT 196 248
+END SUBROUTINE lift_cdfheatc
+"""
+
+
+def gen_cdfheatc():
+    cap = "           o_sums(1,ik,jt) = dsurf ; o_sums(2,ik,jt) = dvol2d ; o_sums(3,ik,jt) = dsum2d   ! [lift] capture of the PRINT"
+    t = Tool("cdfheatc.f90",
+             {"cn_ve1t": "h_e1t", "cn_ve2t": "h_e2t", "cn_gdepw": "h_gdepw", "cn_ve3t1d": "h_e31d", "cn_somxl010": "h_mxl",
+              "cn_votemper": "h_t", "cv_msk": "h_tmask", "cn_ve3t": "h_e3t"},
+             putvar=lambda pos, kw: f"o_var({pos[3]}:{pos[3]},{varidx(pos[1])}:{varidx(pos[1])},{kw.get('ktime', '1')}) = {pos[2]}",
+             capture={233: cap, 235: cap})
+    return t, t.expand(CDFHEATC)
+
+
+# =============================================================================================== cdfmhst
+# src/cdfmhst.f90: declarations :34-103, ALLOCATE :256-274, metrics :276-277,:285, time loop :302-446 (the .dat dumps
+# that follow, :449-492, are formatted WRITEs of the same dzonal_* arrays and are not lifted).
+CDFMHST = r"""
+SUBROUTINE lift_cdfmhst(kpi, kpj, kpk, kpt, kbas, ksepf, kfull, kzdim, kmst, h_e1v, h_gphiv, h_gdept, h_e31d, h_e3v, h_vmask, &
+     &  h_atl, h_pac, h_ind, h_vt, h_vs, h_v, h_t, h_s, o_var, o_zon) BIND(C, name='lift_cdfmhst')
+  USE ISO_C_BINDING
+  IMPLICIT NONE
+  INTEGER(C_INT), VALUE :: kpi, kpj, kpk, kpt, kbas, ksepf, kfull, kzdim, kmst
+  REAL(C_FLOAT), INTENT(in) :: h_e1v(kpi,kpj,1,1), h_gphiv(kpi,kpj,1,1), h_gdept(kpk), h_e31d(kpk), h_e3v(kpi,kpj,kpk,1)
+  REAL(C_FLOAT), INTENT(in) :: h_vmask(kpi,kpj,1,1), h_atl(kpi,kpj,1,1), h_pac(kpi,kpj,1,1), h_ind(kpi,kpj,1,1)
+  REAL(C_FLOAT), INTENT(in) :: h_vt(kpi,kpj,kpk,kpt), h_vs(kpi,kpj,kpk,kpt), h_v(kpi,kpj,kpk,kpt), h_t(kpi,kpj,kpk,kpt)
+  REAL(C_FLOAT), INTENT(in) :: h_s(kpi,kpj,kpk,kpt)
+  REAL(C_FLOAT),  INTENT(out) :: o_var(kpj,kpk,12,kpt)   ! REAL(dmtrp) as handed to putvar (level 1 only without -Zdim)
+  REAL(C_DOUBLE), INTENT(out) :: o_zon(kpj,8,kpt)        ! dzonal_{heat,salt}_{glo,atl,pac,ind} after the last level
+  LOGICAL :: lg_vvl = .FALSE.
+!@DECLS 34 103
+  npiglo = kpi ; npjglo = kpj ; npk = kpk ; npt = kpt
+  lsepf = ( ksepf /= 0 ) ; lfull = ( kfull /= 0 ) ; lzdim = ( kzdim /= 0 ) ; lg_vvl = .FALSE.
+  llglo = ( kbas == 5 ) ; nbasins = kbas ; nbasinso = 1 ; IF ( llglo ) nbasinso = 6     ! src/cdfmhst.f90:219-226
+  npvar = 1 ; IF ( kmst /= 0 ) npvar = 2                                                ! -MST
+  npko = 1 ; IF ( lzdim ) npko = npk                                                    ! :247-253
+  o_var = 0. ; o_zon = 0.d0
+!@RAW 256 274
+!@LIFT 276 277
+!@LIFT 285 285
+!@LIFT 302 446
+     o_zon(:,1,jt) = dzonal_heat_glo ; o_zon(:,5,jt) = dzonal_salt_glo
+     IF ( llglo ) THEN
+        o_zon(:,2,jt) = dzonal_heat_atl ; o_zon(:,3,jt) = dzonal_heat_pac ; o_zon(:,4,jt) = dzonal_heat_ind
+        o_zon(:,6,jt) = dzonal_salt_atl ; o_zon(:,7,jt) = dzonal_salt_pac ; o_zon(:,8,jt) = dzonal_salt_ind
+     ENDIF
+  END DO
+END SUBROUTINE lift_cdfmhst
+"""
+
+
+def gen_cdfmhst():
+    t = Tool("cdfmhst.f90",
+             {"cn_vomecrty": "h_v", "cn_votemper": "h_t", "cn_vosaline": "h_s", "cn_vomevt": "h_vt", "cn_vomevs": "h_vs",
+              "cn_ve3v": "h_e3v", "cn_vmask": "h_vmask", "cn_tmaskatl": "h_atl", "cn_tmaskpac": "h_pac", "cn_tmaskind": "h_ind",
+              "cn_ve1v": "h_e1v", "cn_gphiv": "h_gphiv", "cn_ve3t1d": "h_e31d", "cn_gdept": "h_gdept"},
+             putvar=lambda pos, kw: f"o_var(:,{pos[3]},{varidx(pos[1])},{kw.get('ktime', '1')}) = {pos[2]}")
+    return t, t.expand(CDFMHST)
+
+
+# =============================================================================================== cdfpsi
+# src/cdfpsi.f90: declarations :34-88, ALLOCATE :228-239, metrics and mask :246-253, the whole time loop :256-439.
+CDFPSI = r"""
+SUBROUTINE lift_cdfpsi(kpi, kpj, kpk, kpt, ku, kv, kfull, kmask, kmean, kopen, kssh, klev, kiref, kjref, h_e1v, h_e2u, h_fmask, &
+     &  h_e31d, h_e3u, h_e3v, h_u, h_v, h_ssh, knlo, o_var, o_dpsi) BIND(C, name='lift_cdfpsi')
+  USE ISO_C_BINDING
+  IMPLICIT NONE
+  INTEGER(C_INT), VALUE :: kpi, kpj, kpk, kpt, ku, kv, kfull, kmask, kmean, kopen, kssh, klev, kiref, kjref, knlo
+  REAL(C_FLOAT), INTENT(in) :: h_e1v(kpi,kpj,1,1), h_e2u(kpi,kpj,1,1), h_fmask(kpi,kpj,1,1), h_e31d(kpk)
+  REAL(C_FLOAT), INTENT(in) :: h_e3u(kpi,kpj,kpk,1), h_e3v(kpi,kpj,kpk,1), h_u(kpi,kpj,kpk,kpt), h_v(kpi,kpj,kpk,kpt)
+  REAL(C_FLOAT), INTENT(in) :: h_ssh(kpi,kpj,1,kpt)
+  REAL(C_FLOAT),  INTENT(out) :: o_var(kpi,kpj,knlo,3,kpt)   ! what putvar is handed (SNGL(...) fields)
+  REAL(C_DOUBLE), INTENT(out) :: o_dpsi(kpi,kpj,kpt)         ! dpsi after the normalisation, before SNGL
+  LOGICAL :: lg_vvl = .FALSE.
+!@DECLS 34 88
+  npiglo = kpi ; npjglo = kpj ; npk = kpk ; npt = kpt
+  ll_u = ( ku /= 0 ) ; ll_v = ( kv /= 0 ) ; lfull = ( kfull /= 0 ) ; lmask = ( kmask /= 0 ) ; lmean = ( kmean /= 0 )
+  lopen = ( kopen /= 0 ) ; lssh = ( kssh /= 0 ) ; llev = ( klev /= 0 ) ; lg_vvl = .FALSE.
+  iiref = kiref ; ijref = kjref
+  o_var = 0. ; o_dpsi = 0.d0
+!@RAW 228 239
+!@LIFT 246 253
+!@LIFT 256 423
+     o_dpsi(:,:,jt) = dpsi(:,:)
+!@LIFT 424 439
+END SUBROUTINE lift_cdfpsi
+"""
+
+
+def gen_cdfpsi():
+    t = Tool("cdfpsi.f90",
+             {"cn_sossheig": "h_ssh", "cn_vomecrty": "h_v", "cn_ve3v": "h_e3v", "cn_vozocrtx": "h_u", "cn_ve3u": "h_e3u",
+              "cn_ve1v": "h_e1v", "cn_ve2u": "h_e2u", "cn_fmask": "h_fmask", "cn_ve3t1d": "h_e31d"},
+             putvar=lambda pos, kw: f"o_var(:,:,{pos[3]},{varidx(pos[1])},{kw.get('ktime', '1')}) = {pos[2]}")
+    return t, t.expand(CDFPSI)
+
+
+# =============================================================================================== cdfvT
+# src/cdfvT.f90: declarations :29-66, ALLOCATE :146-150,:152-155, level loop :159-168 and :186-259.  Lines :169-185 resolve the
+# file names of a tag and read its frame count and time axis (SetFileName / getdim / getvar1d): the harness feeds the
+# frames of all tags as one array, ntags tags of kfr frames each, so those lines are replaced by `npt = kfr`.
+CDFVT = r"""
+SUBROUTINE lift_cdfvt(kpi, kpj, kpk, ktags, kfr, kvvl, h_u, h_v, h_t, h_s, h_e3u, h_e3v, o_var) BIND(C, name='lift_cdfvt')
+  USE ISO_C_BINDING
+  IMPLICIT NONE
+  INTEGER(C_INT), VALUE :: kpi, kpj, kpk, ktags, kfr, kvvl
+  REAL(C_FLOAT), INTENT(in) :: h_u(kpi,kpj,kpk,kfr,ktags), h_v(kpi,kpj,kpk,kfr,ktags), h_t(kpi,kpj,kpk,kfr,ktags)
+  REAL(C_FLOAT), INTENT(in) :: h_s(kpi,kpj,kpk,kfr,ktags), h_e3u(kpi,kpj,kpk,kfr,ktags), h_e3v(kpi,kpj,kpk,kfr,ktags)
+  REAL(C_DOUBLE), INTENT(out) :: o_var(kpi,kpj,kpk,6)      ! the r8 arrays handed to putvar: vt, vs, ut, us [, e3u, e3v]
+  LOGICAL :: lg_vvl = .FALSE.
+!@DECLS 29 66
+  npiglo = kpi ; npjglo = kpj ; npk = kpk ; ntags = ktags ; lg_vvl = ( kvvl /= 0 )
+  o_var = 0.d0
+  ALLOCATE ( ctag_lst(ntags) )
+!@RAW 146 150
+!@RAW 152 155
+!@RAW 159 159
+!@LIFT 160 168
+        npt = kfr                                           ! [lift] stands for :169-185 (file names, getdim, time axis)
+!@LIFT 186 259
+END SUBROUTINE lift_cdfvt
+"""
+
+
+def gen_cdfvt():
+    t = Tool("cdfvT.f90", {})
+    # getvar(file, var, jk, npiglo, npjglo, ktime=jtt) -> frame jtt of tag jt
+    names = {"cn_vozocrtx": "h_u", "cn_vomecrty": "h_v", "cn_votemper": "h_t", "cn_vosaline": "h_s", "cn_ve3u": "h_e3u",
+             "cn_ve3v": "h_e3v"}
+
+    class VM(dict):
+        def __getitem__(self, k):
+            return names[k]
+    t.varmap = VM()
+    orig = t.rewrite
+
+    def rewrite(n, ln):
+        out = orig(n, ln)
+        return re.sub(r"(h_\w+)\(:,:,(\w+),(\w+)\)", r"\1(:,:,\2,\3,jt)", out) if out is not ln else out
+    t.rewrite = rewrite
+    t.putvar = lambda pos, kw: f"o_var(:,:,{pos[3]},{varidx(pos[1])}) = {pos[2]}"
+    return t, t.expand(CDFVT)
+
+
+# =============================================================================================== cdfcurl
+# src/cdfcurl.f90: declarations :26-64, ALLOCATE :190-198, metrics and Coriolis :200-225, periodicity :238, time loop
+# :242-304.  fmask is only assigned for ji < npiglo, jj < npjglo (:267-273) while -T reads its last row and column
+# (:290): the reference leaves them as ALLOCATE found them; the harness clears the array once, as a zeroed heap would.
+CDFCURL = r"""
+SUBROUTINE lift_cdfcurl(kpi, kpj, kpk, kpt, knlev, kforcing, ktpoint, koverf, h_e1u, h_e1f, h_e2v, h_e2f, h_glamf, h_gphif, &
+     &  h_u, h_v, o_var) BIND(C, name='lift_cdfcurl')
+  USE ISO_C_BINDING
+  IMPLICIT NONE
+  INTEGER(C_INT), VALUE :: kpi, kpj, kpk, kpt, knlev, kforcing, ktpoint, koverf
+  REAL(C_FLOAT), INTENT(in) :: h_e1u(kpi,kpj,1,1), h_e1f(kpi,kpj,1,1), h_e2v(kpi,kpj,1,1), h_e2f(kpi,kpj,1,1)
+  REAL(C_FLOAT), INTENT(in) :: h_glamf(kpi,kpj,1,1), h_gphif(kpi,kpj,1,1), h_u(kpi,kpj,kpk,kpt), h_v(kpi,kpj,kpk,kpt)
+  REAL(C_DOUBLE), INTENT(out) :: o_var(kpi,kpj,knlev,kpt)   ! drotn as handed to putvar
+!@DECLS 26 64
+  npiglo = kpi ; npjglo = kpj ; npk = kpk ; npt = kpt ; nlev = knlev
+  lforcing = ( kforcing /= 0 ) ; ltpoint = ( ktpoint /= 0 ) ; loverf = ( koverf /= 0 ) ; l_metric = .TRUE. ; lperio = .FALSE.
+  ALLOCATE ( nilev(nlev) )
+  DO jk = 1, nlev ; nilev(jk) = jk ; ENDDO               ! -l 1 2 ... nlev
+!@RAW 190 198
+  fmask(:,:) = 0.
+!@LIFT 200 225
+!@RAW 238 238
+!@LIFT 242 304
+END SUBROUTINE lift_cdfcurl
+"""
+
+
+def gen_cdfcurl():
+    t = Tool("cdfcurl.f90",
+             {"cn_ve1u": "h_e1u", "cn_ve1f": "h_e1f", "cn_ve2v": "h_e2v", "cn_ve2f": "h_e2f", "cn_glamf": "h_glamf",
+              "cn_gphif": "h_gphif", "cv_u": "h_u", "cv_v": "h_v"},
+             putvar=lambda pos, kw: f"o_var(:,:,{pos[3]},{kw.get('ktime', '1')}) = {pos[2]}")
+    return t, t.expand(CDFCURL)
+
+
+TOOLS = {"cdfmoc": gen_cdfmoc, "cdfheatc": gen_cdfheatc, "cdfmhst": gen_cdfmhst, "cdfpsi": gen_cdfpsi, "cdfvt": gen_cdfvt,
+         "cdfcurl": gen_cdfcurl}
+
+
+def main():
+    global OUT
+    if "--out" in sys.argv:
+        OUT = sys.argv[sys.argv.index("--out") + 1]
+    os.makedirs(OUT, exist_ok=True)
+    for name, gen in TOOLS.items():
+        tool, text = gen()
+        path = os.path.join(OUT, f"lift_{name}.f90")
+        with open(path, "w") as f:
+            f.write(f"! GENERATED by oracle/ref_lift.py from {REF}/{tool.fname} -- never committed (oracle/_ref is git-ignored)\n")
+            f.write(text)
+        if "--shas" in sys.argv:
+            print(name, {k: v for k, v in tool.report})
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
