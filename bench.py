@@ -4,8 +4,10 @@
 One "step" = one full pass of the cdfmoc hot path (src/cdfmoc.f90:352-388: zonal masked weighted
 sum + bottom-to-surface cumulated sum, 5 basins) over all 12 records, inputs resident in HBM.
 With N > 1 (one process per GPU, torch.distributed over RCCL) the horizontal domain is row-block
-partitioned (cdftools_amd/shard.py); ranks are independent and rank 0 gathers the (nbasins,npj,npk,
-npt) result once per step.  The grid is fixed as N grows => "scaling": "strong".
+partitioned (cdftools_amd/shard.py); ranks are independent and rank 0 collects the (nbasins,npj,npk,
+npt) result of every step (exact-size point-to-point transfers under the next step's kernels).  The
+grid is fixed as N grows => "scaling": "strong".  `python bench.py --gpus N` starts its own N ranks
+(a torch.distributed.run child process) when it is not already running under a launcher.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
   roofline     -- HBM roofline of the dominant kernel (moc_zonal_kernel): algorithmic bytes per
@@ -27,7 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-from cdftools_amd import hip, shard  # noqa: E402
+hip = shard = None          # cdftools_amd.hip / .shard, imported by main() once it knows it is a rank and not the launcher
 
 WORKLOADS = {
     # name: (npiglo, npjglo, npk, npt, nbasins)
@@ -102,28 +104,64 @@ def cpu_baseline(e1v, e3v, ib, zv, npi, npk, npt, target_s=12.0):
                       f"{reps} passes in {total:.1f} s, OpenMP over jj as src/cdfmoc.f90:369,382"}, rows, out
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: this process -- which has not touched the GPU
+    (no torch.cuda / HIP call so far) -- starts `python -m torch.distributed.run` with N ranks as a CHILD process,
+    relays its output (rank 0's JSON line) and exits with its code.  Never an exec: a process that has initialised
+    the GPU must not be replaced, and this one stays a plain parent anyway."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC, the only kind the host driver supports
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=0, help="timed steps (default: 250 per GPU, a timed region of about 2.5 s)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="eorca12", choices=sorted(WORKLOADS))
     ap.add_argument("--tune", default="", help="waves,vectors,mode for the zonal kernel (0 = automatic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.steps <= 0:
+        args.steps = 250 * max(args.gpus, 1)
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
+    global hip, shard
+    from cdftools_amd import hip, shard
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libcdftools_hip has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # Test hooks for a 1-GPU box (tests/test_bench_gpu.py): CDFT_BENCH_ONE_GPU=1 puts every rank on cuda:0 and
+    # CDFT_BENCH_BACKEND=gloo moves the transfers through the host (RCCL refuses two ranks on one device), so that
+    # the N > 1 code path -- launcher, row blocks, pipeline, streams, checks -- runs where only one GPU exists.
+    # Lines produced that way carry "test_hooks" and are not measurements.
+    one_gpu = os.environ.get("CDFT_BENCH_ONE_GPU") == "1"
+    backend = os.environ.get("CDFT_BENCH_BACKEND", "nccl")
+    dev_index = 0 if one_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     npi, npj, npk, npt, nb = WORKLOADS[args.workload]
     j0, j1 = shard.row_block(npj, world, rank)
@@ -138,35 +176,9 @@ def main():
     del e3v
     torch.cuda.empty_cache()
 
-    # Two result buffers: the gather of step i (RCCL, communication stream) overlaps the kernels of
-    # step i+1; a buffer is reused only after its gather has been waited for and assembled.
-    nbuf = 2 if world > 1 else 1
-    dmoc = [torch.empty((npt, npk, nloc, nb), dtype=torch.float64, device=device) for _ in range(nbuf)]
-    nmax = shard.max_rows(npj, world)
-    pad = [torch.zeros((npt, npk, nmax, nb), dtype=torch.float64, device=device) if world > 1 else None for _ in range(nbuf)]
-    recv = [[torch.empty((npt, npk, nmax, nb), dtype=torch.float64, device=device) for _ in range(world)]
-            if (world > 1 and rank == 0) else None for _ in range(nbuf)]
-    pending = [None] * nbuf
-    state = {"i": 0, "result": None}
-
-    def step():
-        b = state["i"] % nbuf
-        state["i"] += 1
-        if pending[b] is not None:                            # step i-2: gathered -> assembled on rank 0
-            state["result"] = shard.gather_rows_finish(pending[b])
-            pending[b] = None
-        plan.compute(zv, out=dmoc[b])
-        if world > 1:
-            pending[b] = shard.gather_rows_start(dmoc[b], npj, pad_buf=pad[b], recv_bufs=recv[b])
-        else:
-            state["result"] = dmoc[b]
-
-    def drain():
-        order = [(state["i"] + k) % nbuf for k in range(nbuf)]    # oldest first
-        for b in order:
-            if pending[b] is not None:
-                state["result"] = shard.gather_rows_finish(pending[b])
-                pending[b] = None
+    # The step loop (cdftools_amd/shard.py): two result buffers, rank 0 collects every step's blocks with exact-size
+    # point-to-point transfers on the communication stream under the kernels of the next step.
+    pipe = shard.StepPipeline(lambda out: plan.compute(zv, out=out), npj, (npt, npk, nloc, nb), device=device)
 
     def fence():
         torch.cuda.synchronize()
@@ -175,19 +187,21 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step()
-    drain()
+        pipe.step()
+    pipe.drain()
     fence()
     plan.profile_enable(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
-    drain()                                                   # every step's result is gathered and assembled
+        pipe.step()
+    pipe.drain()                                              # every step's result is gathered and assembled
     fence()
     elapsed = time.perf_counter() - t0
-    result = state["result"]
+    result = pipe.result
     plan.profile_enable(False)
-    zonal_ms, launches = plan.profile_read()
+    each = plan.profile_read_each()
+    launches = int(each.size)
+    zonal_ms = float(each.sum())
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -209,12 +223,20 @@ def main():
             traffic = tj.get("hbm_bytes_per_launch")
     roofline = {"bound": "hbm", "kernel": plan.describe(), "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms, "launches": launches}
+                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms, "launches": launches,
+                "min_launch_ms": float(each.min()) if launches else None,
+                "median_launch_ms": float(np.median(each)) if launches else None,
+                "max_launch_ms": float(each.max()) if launches else None,
+                "rank": rank, "rows": nloc}
 
     cpu = None
     check = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu, rows, ref = cpu_baseline(e1v[:keep_rows], e3v_s, ib[:keep_rows], zv[:, :, :keep_rows], npi, npk, npt)
+    if rank == 0 and not args.no_cpu_baseline:
+        # rank 0's first rows are rows 1..keep_rows of the global result for any N: the same check at every N
+        target = 12.0 if world == 1 else 0.0                         # the timed CPU baseline is an N = 1 item
+        cpu, rows, ref = cpu_baseline(e1v[:keep_rows], e3v_s, ib[:keep_rows], zv[:, :, :keep_rows], npi, npk, npt, target_s=target)
+        if world > 1:
+            cpu = None
         got = result[:, :, :rows].cpu().numpy()
         bound = np.abs(ref).max() + 1e-300
         check = float(np.abs(got - ref).max() / bound)
@@ -226,16 +248,20 @@ def main():
             "metric": "grid-cells/s for cdfmoc on eORCA12 75L 12t" if args.workload == "eorca12"
             else f"grid-cells/s for cdfmoc on {args.workload}",
             "value": value, "unit": "grid-cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong",
+            "ms_per_step": 1e3 * elapsed / args.steps, "timed_region_s": elapsed, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"cdfmoc {args.workload} {npi}x{npj}x{npk}, {npt} records, {nb} basins",
                        "arithmetic": "r4 products widened to r8, r8 sums (src/cdfmoc.f90:373-374)",
                        "parallelism": f"row-block x{world}", "rows_per_rank": nloc,
-                       "cells_per_step": cells_per_step},
+                       "cells_per_step": cells_per_step,
+                       "result_gathers": pipe.gathers if world > 1 else 0},
             "roofline": roofline, "cpu_baseline": cpu, "oracle_check_rel_err": check,
         }
-        print(json.dumps(line))
+        if one_gpu or backend != "nccl":
+            line["test_hooks"] = {"one_gpu": one_gpu, "backend": backend}
+        print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -55,6 +55,7 @@ SIGNATURES = {
     "cdft_moc_describe": (_i, [_vp, C.c_char_p, _sz]),
     "cdft_moc_profile_enable": (_i, [_vp, _i]),
     "cdft_moc_profile_read": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(_i)]),
+    "cdft_moc_profile_read_each": (_i, [_vp, C.POINTER(C.c_float), _i, C.POINTER(_i)]),
     "cdft_moc_destroy": (_i, [_vp]),
     "cdft_eos_sigmai": (_i, [_vp, _vp, _i64, C.c_float, _i, _i, _vp, _i, _i, _vp]),
     "cdft_eos_sigmai2d": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _i, _i, _vp]),

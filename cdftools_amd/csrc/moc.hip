@@ -580,6 +580,21 @@ int cdft_moc_profile_read(cdft_moc_plan *p, double *zonal_ms_total, int *launche
     return CDFT_OK;
 }
 
+int cdft_moc_profile_read_each(cdft_moc_plan *p, float *ms_each, int capacity, int *launches) {
+    if (!p || !ms_each || !launches || capacity < 0)
+        return fail(CDFT_ERR_ARG, "cdft_moc_profile_read_each: bad argument");
+    const int n = (int)(p->ev_used / 2);
+    for (int i = 0; i < n; ++i) {
+        float ms = 0.f;
+        CDFT_HIP(hipEventSynchronize(p->ev[2 * i + 1]));
+        CDFT_HIP(hipEventElapsedTime(&ms, p->ev[2 * i], p->ev[2 * i + 1]));
+        if (i < capacity) ms_each[i] = ms;
+    }
+    *launches = n;
+    p->ev_used = 0;
+    return CDFT_OK;
+}
+
 int cdft_moc_destroy(cdft_moc_plan *p) {
     if (!p) return CDFT_OK;
     for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);

@@ -159,6 +159,13 @@ class MocPlan:
         check(_lib.load().cdft_moc_profile_read(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def profile_read_each(self, capacity=65536):
+        """-> array of the zonal-kernel durations (ms) of every launch since the last read."""
+        buf = (C.c_float * capacity)()
+        n = C.c_int(0)
+        check(_lib.load().cdft_moc_profile_read_each(self._h, buf, capacity, C.byref(n)))
+        return np.frombuffer(buf, dtype=np.float32, count=min(n.value, capacity)).astype(np.float64)
+
     def compute(self, zv, out=None, rec_stride=None, npt=None, stream=None):
         """zv (npt,npk,npj,npi) r4 -> dmoc (npt,npk,npj,nb) r8 in Sv (same memory space as zv
         unless `out` is given)."""
@@ -370,16 +377,23 @@ class PsiPlan(_Plan):
         check(_lib.load().cdft_psi_integrate(self._h, a[0][0], a[1][0], a[2][0], a[3][0], a[4][0], a[5][0], a[6][0],
                                              sp, stream or current_stream_ptr()))
 
-    def scan_u(self, carry=None, first_block=True, stream=None):
-        """j-scan of the U path; carry (npi,) r8 host array from the block to the south -> this block's
-        last row (npi,) r8 host array."""
-        last = np.empty(self.npi, np.float64)
-        keep = None if carry is None else np.ascontiguousarray(carry, np.float64)
-        if keep is not None and keep.shape != (self.npi,):
-            raise ValueError(f"carry has shape {keep.shape}, expected {(self.npi,)}")
-        pc = _null() if keep is None else C.c_void_p(keep.ctypes.data)
-        check(_lib.load().cdft_psi_scan_u(self._h, pc, MEM_HOST, 1 if first_block else 0, C.c_void_p(last.ctypes.data),
-                                          MEM_HOST, stream or current_stream_ptr()))
+    def scan_u(self, carry=None, first_block=True, stream=None, device_out=False):
+        """j-scan of the U path; carry (npi,) r8 (host array or CUDA tensor) from the block to the south -> this
+        block's last row (npi,) r8: a host array, or a CUDA tensor with device_out (the multi-GPU chain keeps both
+        in HBM)."""
+        if carry is None:
+            pc, sc, keep = _null(), MEM_HOST, None
+        else:
+            pc, sc, keep = _arg(carry, np.float64, "carry")
+            if int(np.prod(keep.shape)) != self.npi:
+                raise ValueError(f"carry has shape {tuple(keep.shape)}, expected {(self.npi,)}")
+        if device_out:
+            last = torch.empty(self.npi, dtype=torch.float64, device="cuda")
+            pl, sl = C.c_void_p(last.data_ptr()), MEM_DEVICE
+        else:
+            last = np.empty(self.npi, np.float64)
+            pl, sl = C.c_void_p(last.ctypes.data), MEM_HOST
+        check(_lib.load().cdft_psi_scan_u(self._h, pc, sc, 1 if first_block else 0, pl, sl, stream or current_stream_ptr()))
         return last
 
     def scan_open(self, lmean=False, stream=None):

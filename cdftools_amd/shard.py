@@ -39,11 +39,13 @@ def max_rows(npjglo: int, world: int) -> int:
     return -(-npjglo // world)
 
 
-def gather_rows_start(local: torch.Tensor, npjglo: int, group=None, dst: int = 0, pad_buf=None, recv_bufs=None):
-    """Start collecting per-rank results (npt,npk,npj_loc,nb) on rank `dst` without blocking: the
-    gather runs on the communication stream while the caller computes the next step.  Blocks are
-    padded to the largest block so that one gather moves them all.  -> handle for gather_rows_finish.
-    The buffers (local, pad_buf, recv_bufs) must not be touched until gather_rows_finish returned."""
+def gather_rows_start(local: torch.Tensor, npjglo: int, group=None, dst: int = 0, recv_bufs=None):
+    """Start collecting per-rank results (npt,npk,npj_loc,nb) on rank `dst` without blocking: point-to-point
+    transfers of each block's exact size straight into per-rank receive buffers (no padding copy, nothing sent by
+    `dst` to itself), batched so that RCCL runs them side by side -- they arrive over different xGMI links -- on the
+    communication stream while the caller computes the next step.  -> handle for gather_rows_finish.
+    `local` and `recv_bufs` must not be touched until gather_rows_finish returned.
+    recv_bufs: on `dst`, a list of world tensors (npt,npk,rows_of_rank_r,nb) to reuse (entry `dst` is ignored)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         return (None, local, None, npjglo, world, dst)
@@ -52,39 +54,100 @@ def gather_rows_start(local: torch.Tensor, npjglo: int, group=None, dst: int = 0
     j0, j1 = row_block(npjglo, world, rank)
     if nloc != j1 - j0:
         raise ValueError(f"rank {rank}: local block has {nloc} rows, partition says {j1 - j0}")
-    nmax = max_rows(npjglo, world)
-    if nloc == nmax:
-        send = local.contiguous()
-    else:
-        send = pad_buf if pad_buf is not None else local.new_zeros((npt, npk, nmax, nb))
-        send[:, :, :nloc] = local
-    bufs = None
-    if rank == dst:
-        bufs = recv_bufs if recv_bufs is not None else [torch.empty_like(send) for _ in range(world)]
-    work = dist.gather(send, bufs, dst=dst, group=group, async_op=True)
-    return (work, local, bufs, npjglo, world, dst, send)
+    local = local.contiguous()
+    peer = (lambda r: r) if group is None else (lambda r: dist.get_global_rank(group, r))
+    if rank != dst:
+        works = dist.batch_isend_irecv([dist.P2POp(dist.isend, local, peer(dst), group)])
+        return (works, local, None, npjglo, world, dst)
+    bufs = list(recv_bufs) if recv_bufs is not None else [None] * world
+    ops = []
+    for r in range(world):
+        if r == dst:
+            bufs[r] = local
+            continue
+        a, b = row_block(npjglo, world, r)
+        if bufs[r] is None:
+            bufs[r] = local.new_empty((npt, npk, b - a, nb))
+        elif tuple(bufs[r].shape) != (npt, npk, b - a, nb):
+            raise ValueError(f"recv_bufs[{r}] has shape {tuple(bufs[r].shape)}, expected {(npt, npk, b - a, nb)}")
+        ops.append(dist.P2POp(dist.irecv, bufs[r], peer(r), group))
+    works = dist.batch_isend_irecv(ops)
+    return (works, local, bufs, npjglo, world, dst)
 
 
-def gather_rows_finish(handle):
-    """Wait for a gather started by gather_rows_start; -> (npt,npk,npjglo,nb) on rank dst, None elsewhere."""
-    work, local, bufs, npjglo, world, dst = handle[:6]
+def gather_rows_finish(handle, out=None):
+    """Wait for a gather started by gather_rows_start; -> (npt,npk,npjglo,nb) on rank dst (written into `out` when
+    given), None elsewhere."""
+    works, local, bufs, npjglo, world, dst = handle[:6]
     if world == 1:
         return local
-    work.wait()                                   # the current stream now waits for the gather
+    for w in works:
+        w.wait()                                  # the current stream now waits for the transfers
     if bufs is None:
         return None
     npt, npk, _, nb = local.shape
-    out = local.new_empty((npt, npk, npjglo, nb))
+    if out is None:
+        out = local.new_empty((npt, npk, npjglo, nb))
     for r in range(world):
         a, b = row_block(npjglo, world, r)
-        out[:, :, a:b] = bufs[r][:, :, : b - a]
+        out[:, :, a:b] = bufs[r]
     return out
 
 
-def gather_rows(local: torch.Tensor, npjglo: int, group=None, dst: int = 0, pad_buf=None, recv_bufs=None):
+def gather_rows(local: torch.Tensor, npjglo: int, group=None, dst: int = 0, recv_bufs=None):
     """Collect per-rank results (npt,npk,npj_loc,nb) on rank `dst` -> (npt,npk,npjglo,nb) there,
     None elsewhere (gather_rows_start + gather_rows_finish)."""
-    return gather_rows_finish(gather_rows_start(local, npjglo, group=group, dst=dst, pad_buf=pad_buf, recv_bufs=recv_bufs))
+    return gather_rows_finish(gather_rows_start(local, npjglo, group=group, dst=dst, recv_bufs=recv_bufs))
+
+
+class StepPipeline:
+    """The step loop of bench.py: `compute(out)` fills this rank's (npt,npk,npj_loc,nb) block of one step; with N > 1
+    rank 0 collects every step's blocks.  Two result buffers: the gather of step i (communication stream) runs under
+    the kernels of step i+1, and a buffer is handed to compute() again only after its gather has been waited for and
+    assembled.  `result` is the last assembled (npt,npk,npjglo,nb) array on rank 0 (the local block when N = 1).
+    The same class is driven on 2 gloo ranks with the oracle as `compute` by tests/test_shard.py."""
+
+    def __init__(self, compute, npjglo, local_shape, dtype=torch.float64, device=None, group=None, nbuf=2):
+        self.compute, self.npj, self.group = compute, npjglo, group
+        self.world, self.rank = _world_rank(group)
+        self.nbuf = nbuf if self.world > 1 else 1
+        npt, npk, nloc, nb = local_shape
+        self.local = [torch.empty(local_shape, dtype=dtype, device=device) for _ in range(self.nbuf)]
+        self.recv = [None] * self.nbuf
+        self.out = None
+        if self.world > 1 and self.rank == 0:
+            for b in range(self.nbuf):
+                self.recv[b] = [None if r == 0 else torch.empty((npt, npk, row_block(npjglo, self.world, r)[1] -
+                                                                  row_block(npjglo, self.world, r)[0], nb), dtype=dtype, device=device)
+                                for r in range(self.world)]
+            self.out = torch.empty((npt, npk, npjglo, nb), dtype=dtype, device=device)
+        self.pending = [None] * self.nbuf
+        self.i = 0
+        self.gathers = 0
+        self.result = None
+
+    def _finish(self, b):
+        if self.pending[b] is not None:
+            res = gather_rows_finish(self.pending[b], out=self.out)
+            self.pending[b] = None
+            self.gathers += 1
+            if res is not None:
+                self.result = res
+
+    def step(self):
+        b = self.i % self.nbuf
+        self.i += 1
+        self._finish(b)                                   # step i - nbuf: gathered -> assembled on rank 0
+        self.compute(self.local[b])
+        if self.world > 1:
+            self.pending[b] = gather_rows_start(self.local[b], self.npj, group=self.group, recv_bufs=self.recv[b])
+        else:
+            self.result = self.local[b]
+
+    def drain(self):
+        """Every started gather is waited for and assembled, oldest first."""
+        for k in range(self.nbuf):
+            self._finish((self.i + k) % self.nbuf)
 
 
 def halo_window(npjglo: int, world: int, rank: int, north: int = 1, south: int = 0):
@@ -151,14 +214,18 @@ def psi_chain(stages, npjglo: int, iiref: int, ijref: int, fmask=None, group=Non
         return stages.finish(None, iiref, ijref, fmask)
     if not (1 <= ijref <= npjglo):
         raise ValueError(f"reference row {ijref} outside 1..{npjglo}")
+    on_gpu = device is not None and torch.device(device).type == "cuda"
     carry = None
     if rank > 0:
-        buf = torch.empty(stages.npi, dtype=torch.float64, device=device)
-        dist.recv(buf, src=rank - 1, group=group)
-        carry = buf.cpu().numpy()
-    last = stages.scan_u(carry, rank == 0)
+        carry = torch.empty(stages.npi, dtype=torch.float64, device=device)
+        dist.recv(carry, src=rank - 1, group=group)
+        if not on_gpu:
+            carry = carry.numpy()
+    # on a GPU the carry and the last row stay in HBM: scan_u takes and returns device arrays through the C ABI
+    # (memory-space tags of cdft_psi_scan_u), so a hop is one xGMI transfer of 8*npiglo bytes, no PCIe round trip
+    last = stages.scan_u(carry, rank == 0, device_out=True) if on_gpu else stages.scan_u(carry, rank == 0)
     if rank < world - 1:
-        dist.send(torch.as_tensor(last, dtype=torch.float64, device=device), dst=rank + 1, group=group)
+        dist.send(last if on_gpu else torch.as_tensor(last, dtype=torch.float64), dst=rank + 1, group=group)
     owner = next(r for r in range(world) if row_block(npjglo, world, r)[0] < ijref <= row_block(npjglo, world, r)[1])
     ref = torch.zeros(1, dtype=torch.float64, device=device)
     if rank == owner:

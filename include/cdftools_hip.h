@@ -137,6 +137,9 @@ int cdft_moc_describe(cdft_moc_plan *plan, char *buf, size_t buflen);
  * synchronises on them, returns the summed duration and the number of launches, and resets. */
 int cdft_moc_profile_enable(cdft_moc_plan *plan, int on);
 int cdft_moc_profile_read(cdft_moc_plan *plan, double *zonal_ms_total, int *launches);
+/* The same probe, one duration per launch (ms_each[0..min(launches,capacity)-1]) so that the harness can report the
+ * minimum, median and maximum beside the mean; synchronises and resets like cdft_moc_profile_read. */
+int cdft_moc_profile_read_each(cdft_moc_plan *plan, float *ms_each, int capacity, int *launches);
 
 int cdft_moc_destroy(cdft_moc_plan *plan);
 

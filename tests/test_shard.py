@@ -77,6 +77,95 @@ def test_two_rank_gloo_gather_matches_single_process(npj):
     assert q.get(timeout=10) is True
 
 
+def _pipeline_worker(rank, world, port, npi, npj, npk, nb, npt, steps, q):
+    """bench.py's step loop (shard.StepPipeline: double-buffered results, exact-size gather of every step on rank 0,
+    drain) on gloo ranks with the oracle standing in for plan.compute; step s scales the velocity by s+1 so that every
+    step has its own answer."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = synth.make_grid(npi, npj, npk, seed=4, nbasins=nb)
+        e1v, e3v, ib = synth.moc_inputs(g)
+        zv = synth.velocity(g, npt, seed=10)
+        j0, j1 = shard.row_block(npj, world, rank)
+        state = {"s": 0}
+
+        def compute(out):
+            state["s"] += 1
+            z = (zv[:, :, j0:j1] * np.float32(state["s"])).astype(np.float32)
+            out.copy_(torch.from_numpy(oracle_lib.moc(e1v[j0:j1], e3v[:, j0:j1], ib[j0:j1], z)))
+        pipe = shard.StepPipeline(compute, npj, (npt, npk, j1 - j0, nb))
+        seen = []
+        for _ in range(steps):
+            pipe.step()
+            seen.append(None if pipe.result is None else pipe.result.clone())
+        pipe.drain()
+        if rank == 0:
+            ref = [oracle_lib.moc(e1v, e3v, ib, (zv * np.float32(k + 1)).astype(np.float32)) for k in range(steps)]
+            ok = pipe.gathers == steps and np.array_equal(pipe.result.numpy(), ref[-1])
+            for k in range(steps):                       # after step k the newest ASSEMBLED result is step k - nbuf
+                want = k - pipe.nbuf
+                ok = ok and ((seen[k] is None) if want < 0 else np.array_equal(seen[k].numpy(), ref[want]))
+            q.put(bool(ok))
+        else:
+            assert pipe.result is None and pipe.gathers == steps
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,npj,steps", [(2, 19, 5), (3, 20, 4), (2, 18, 1)])
+def test_bench_step_pipeline_on_gloo_ranks_collects_every_step(world, npj, steps):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, world, port, 24, npj, 6, 5, 2, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=10) is True
+
+
+def test_bench_step_pipeline_single_process():
+    g = synth.make_grid(24, 9, 4, seed=4)
+    e1v, e3v, ib = synth.moc_inputs(g)
+    zv = synth.velocity(g, 2, seed=10)
+    ref = oracle_lib.moc(e1v, e3v, ib, zv)
+    pipe = shard.StepPipeline(lambda out: out.copy_(torch.from_numpy(ref)), 9, ref.shape)
+    for _ in range(3):
+        pipe.step()
+    pipe.drain()
+    assert pipe.nbuf == 1 and pipe.gathers == 0 and np.array_equal(pipe.result.numpy(), ref)
+
+
+def test_bench_self_launch_builds_a_child_command(monkeypatch):
+    """`python bench.py --gpus N` without a launcher starts a torch.distributed.run CHILD (never an exec of a process
+    that may have touched the GPU) and relays its exit code."""
+    import importlib.util
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "127.0.0.1" in cmd
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "3"] and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
 # ------------------------------------------------------------------ the other tools of the path
 def test_halo_windows():
     assert shard.halo_window(19, 2, 0) == (0, 11, 0, 10)
