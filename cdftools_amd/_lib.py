@@ -46,6 +46,8 @@ SIGNATURES = {
     "cdft_timer_elapsed_ms": (_i, [_vp, C.POINTER(C.c_float)]),
     "cdft_timer_destroy": (_i, [_vp]),
     "cdft_moc_create": (_i, [_pvp, _i, _i, _i, _i]),
+    "cdft_shard_from_env": (_i, [C.POINTER(_i), C.POINTER(_i), _i]),
+    "cdft_moc_create_sharded": (_i, [_pvp, _i, _i, _i, _i, _i, C.POINTER(_i)]),
     "cdft_moc_set_mesh": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
     "cdft_moc_set_mesh_vmask": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "cdft_moc_compute": (_i, [_vp, _vp, _i64, _i, _i, _vp, _i, _vp]),
@@ -62,10 +64,12 @@ SIGNATURES = {
     "cdft_eos_sig_tool": (_i, [_vp, _vp, _i64, C.c_float, C.c_float, _i, _i, _vp, _i, _i, _vp]),
     "cdft_eos_release": (_i, []),
     "cdft_heatc_create": (_i, [_pvp, _i, _i, _i]),
+    "cdft_heatc_create_sharded": (_i, [_pvp, _i, _i, _i, _i, C.POINTER(_i)]),
     "cdft_heatc_set_mesh": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "cdft_heatc_compute": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp]),
     "cdft_heatc_destroy": (_i, [_vp]),
     "cdft_mhst_create": (_i, [_pvp, _i, _i, _i, _i]),
+    "cdft_mhst_create_sharded": (_i, [_pvp, _i, _i, _i, _i, _i, C.POINTER(_i)]),
     "cdft_mhst_set_mesh": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "cdft_mhst_compute": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp]),
     "cdft_mhst_destroy": (_i, [_vp]),
@@ -88,6 +92,7 @@ SIGNATURES = {
                                  C.c_float, _i, _i, C.c_float, C.c_float, _i, _vp, _vp, _i, _vp]),
     "cdft_mocsig_release": (_i, []),
     "cdft_psi_create": (_i, [_pvp, _i, _i, _i]),
+    "cdft_psi_create_sharded": (_i, [_pvp, _i, _i, _i, _i, C.POINTER(_i)]),
     "cdft_psi_compute": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _vp]),
     "cdft_psi_integrate": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "cdft_psi_scan_u": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp]),
@@ -98,6 +103,7 @@ SIGNATURES = {
     "cdft_vt_compute": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                              _i, _i, _vp]),
     "cdft_stencil_release": (_i, []),
+    "cdft_vt_compute_sharded": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, C.POINTER(_i)]),
     "cdft_curl_create": (_i, [_pvp, _i, _i]),
     "cdft_curl_set_mesh": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "cdft_curl_compute": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _vp]),

@@ -12,10 +12,20 @@
 #include <cstdlib>
 #include "common.hpp"
 #include "reduce.hpp"
+#include "shard.hpp"
 
 using namespace cdft;
 
+namespace cdft { namespace shard {
+int heatc_parts(ShardSet &sh);
+int heatc_set_mesh(ShardSet &sh, const float *e1t, const float *e2t, const float *e3t, const float *e31d, const void *tmask,
+                   int mask_is_r4);
+int heatc_compute(ShardSet &sh, const float *temp, const float *rmxldep, const float *gdepw, int mxloption, double *sums,
+                  int out_space, hipStream_t out_stream);
+} }
+
 struct cdft_heatc_plan {
+    cdft::ShardSet *sh = nullptr;   // set: a shell over one plan per row block (shard.hpp)
     int npi = 0, npj = 0, npk = 0;
     float   *area = nullptr;   // (npi,npj) e1t*e2t in r4
     float   *e3t  = nullptr;   // (npi,npj,npk) or null when full-step
@@ -303,10 +313,30 @@ int cdft_heatc_create(cdft_heatc_plan **plan, int npiglo, int npjglo, int npk) {
     return CDFT_OK;
 }
 
+int cdft_heatc_create_sharded(cdft_heatc_plan **plan, int npiglo, int npjglo, int npk, int ndev, const int *devices) {
+    if (!plan) return fail(CDFT_ERR_ARG, "cdft_heatc_create_sharded: NULL plan pointer");
+    *plan = nullptr;
+    if (npiglo < 1 || npjglo < 1 || npk < 1)
+        return fail(CDFT_ERR_ARG, "cdft_heatc_create_sharded: bad sizes %d x %d x %d", npiglo, npjglo, npk);
+    cdft_heatc_plan *p = new cdft_heatc_plan;
+    p->npi = npiglo; p->npj = npjglo; p->npk = npk;
+    int rc = shard::make(&p->sh, npiglo, npjglo, npk, 0, ndev, devices, 0, 7);
+    if (rc == CDFT_OK) rc = shard::heatc_parts(*p->sh);
+    if (rc != CDFT_OK) { cdft_heatc_destroy(p); return rc; }
+    *plan = p;
+    return CDFT_OK;
+}
+
 int cdft_heatc_set_mesh(cdft_heatc_plan *p, const float *e1t, const float *e2t, const float *e3t,
                         const float *e31d, const void *tmask, int mask_is_r4, int memspace, void *stream) {
     if (!p || !e1t || !e2t || !tmask || (!e3t && !e31d) || (e3t && e31d))
         return fail(CDFT_ERR_ARG, "cdft_heatc_set_mesh: need e1t, e2t, tmask and exactly one of e3t / e31d");
+    if (p->sh) {
+        if (memspace == CDFT_MEM_DEVICE) CDFT_HIP(hipStreamSynchronize(as_stream(stream)));
+        CDFT_TRY(shard::heatc_set_mesh(*p->sh, e1t, e2t, e3t, e31d, tmask, mask_is_r4));
+        p->mesh_set = true;
+        return CDFT_OK;
+    }
     hipStream_t st = as_stream(stream);
     const int64_t nij = (int64_t)p->npi * p->npj, n3 = nij * p->npk;
     const void *d1, *d2;
@@ -341,6 +371,10 @@ int cdft_heatc_compute(cdft_heatc_plan *p, const float *temp, int temp_space, co
     if (!p->mesh_set) return fail(CDFT_ERR_STATE, "cdft_heatc_compute: cdft_heatc_set_mesh has not succeeded");
     if (mxloption < -1 || mxloption > 1 || (mxloption != 0 && (!rmxldep || !gdepw)))
         return fail(CDFT_ERR_ARG, "cdft_heatc_compute: mxloption %d needs rmxldep and gdepw", mxloption);
+    if (p->sh) {
+        if (temp_space == CDFT_MEM_DEVICE) CDFT_HIP(hipStreamSynchronize(as_stream(stream)));
+        return shard::heatc_compute(*p->sh, temp, rmxldep, gdepw, mxloption, sums, out_space, as_stream(stream));
+    }
     hipStream_t st = as_stream(stream);
     const int64_t nij = (int64_t)p->npi * p->npj, n3 = nij * p->npk;
     const void *dt, *dm = nullptr;
@@ -379,6 +413,12 @@ int cdft_heatc_compute(cdft_heatc_plan *p, const float *temp, int temp_space, co
 
 int cdft_heatc_destroy(cdft_heatc_plan *p) {
     if (!p) return CDFT_OK;
+    if (p->sh) {
+        (void)shard::for_blocks(*p->sh, [&](int b) { return cdft_heatc_destroy((cdft_heatc_plan *)p->sh->part[b]); });
+        shard::destroy(p->sh);
+        delete p;
+        return CDFT_OK;
+    }
     void *ptrs[] = {p->area, p->e3t, p->e31d, p->mask8, p->mask4, p->gdepw, p->partial};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     p->st_a.release(); p->st_b.release(); p->st_temp.release(); p->st_mxl.release(); p->st_out.release();

@@ -4,11 +4,19 @@
 #include <cstdlib>
 #include <vector>
 #include "moc_zonal.hpp"
+#include "shard.hpp"
 
 using namespace cdft;
 using namespace cdft::moc;
 
+namespace cdft { namespace shard {
+int moc_parts(ShardSet &sh);
+int moc_set_mesh(ShardSet &sh, const float *e1v, const float *e3v, const int8_t *vmask, const int16_t *ibmask);
+int moc_compute(ShardSet &sh, const float *zv, int64_t rec_stride, int npt, double *dmoc);
+} }
+
 struct cdft_moc_plan {
+    cdft::ShardSet *sh = nullptr;   // set: a shell over one plan per row block (shard.hpp); the fields below are unused
     int npi = 0, npj = 0, npk = 0, nbasins = 0;
     float   *w    = nullptr;   // (npi,npj,npk) r4 weight e1v*e3v
     uint8_t *bits = nullptr;   // (npi,npj) basin bits
@@ -329,6 +337,20 @@ int cdft_moc_create(cdft_moc_plan **plan, int npiglo, int npjglo, int npk, int n
     return CDFT_OK;
 }
 
+int cdft_moc_create_sharded(cdft_moc_plan **plan, int npiglo, int npjglo, int npk, int nbasins, int ndev, const int *devices) {
+    if (!plan) return fail(CDFT_ERR_ARG, "cdft_moc_create_sharded: NULL plan pointer");
+    *plan = nullptr;
+    if (npiglo < 1 || npjglo < 1 || npk < 2 || nbasins < 1 || nbasins > 8)
+        return fail(CDFT_ERR_ARG, "cdft_moc_create_sharded: bad sizes %d x %d x %d, %d basins", npiglo, npjglo, npk, nbasins);
+    cdft_moc_plan *p = new cdft_moc_plan;
+    p->npi = npiglo; p->npj = npjglo; p->npk = npk; p->nbasins = nbasins;
+    int rc = shard::make(&p->sh, npiglo, npjglo, npk, nbasins, ndev, devices, 0, 6);
+    if (rc == CDFT_OK) rc = shard::moc_parts(*p->sh);
+    if (rc != CDFT_OK) { cdft_moc_destroy(p); return rc; }
+    *plan = p;
+    return CDFT_OK;
+}
+
 int cdft_moc_set_mesh(cdft_moc_plan *p, const float *e1v, const float *e3v, const int16_t *ibmask,
                       int memspace, void *stream) {
     return cdft_moc_set_mesh_vmask(p, e1v, e3v, nullptr, ibmask, memspace, stream);
@@ -337,6 +359,12 @@ int cdft_moc_set_mesh(cdft_moc_plan *p, const float *e1v, const float *e3v, cons
 int cdft_moc_set_mesh_vmask(cdft_moc_plan *p, const float *e1v, const float *e3v, const int8_t *vmask,
                             const int16_t *ibmask, int memspace, void *stream) {
     if (!p || !e1v || !e3v || !ibmask) return fail(CDFT_ERR_ARG, "cdft_moc_set_mesh: NULL argument");
+    if (p->sh) {
+        if (memspace == CDFT_MEM_DEVICE) CDFT_HIP(hipStreamSynchronize(as_stream(stream)));   // the blocks use their own streams
+        CDFT_TRY(shard::moc_set_mesh(*p->sh, e1v, e3v, vmask, ibmask));
+        p->mesh_set = true;
+        return CDFT_OK;
+    }
     hipStream_t st = as_stream(stream);
     const int64_t nij = (int64_t)p->npi * p->npj, n3 = nij * p->npk;
     const void *d_e1v, *d_e3v, *d_msk, *d_vm = nullptr;
@@ -391,6 +419,10 @@ int cdft_moc_set_mesh_vmask(cdft_moc_plan *p, const float *e1v, const float *e3v
 
 int cdft_moc_set_tuning(cdft_moc_plan *p, int waves_per_row, int vec_per_lane, int mode) {
     if (!p) return fail(CDFT_ERR_ARG, "cdft_moc_set_tuning: NULL plan");
+    if (p->sh) {
+        for (void *q : p->sh->part) CDFT_TRY(cdft_moc_set_tuning((cdft_moc_plan *)q, waves_per_row, vec_per_lane, mode));
+        return CDFT_OK;
+    }
     if (waves_per_row < 0 || waves_per_row > kMaxWaves || vec_per_lane < 0 || vec_per_lane > kMaxNV ||
         mode < 0 || mode > 3)
         return fail(CDFT_ERR_ARG, "cdft_moc_set_tuning: out of range (%d,%d,%d)", waves_per_row,
@@ -405,6 +437,7 @@ int cdft_moc_set_tuning(cdft_moc_plan *p, int waves_per_row, int vec_per_lane, i
 
 int cdft_moc_describe(cdft_moc_plan *p, char *buf, size_t buflen) {
     if (!p || !buf) return fail(CDFT_ERR_ARG, "cdft_moc_describe: NULL argument");
+    if (p->sh) return cdft_moc_describe((cdft_moc_plan *)p->sh->part[0], buf, buflen);
     int k, v, md;
     choose_shape(p, p->last_aligned, &k, &v, &md);       // the shape of the last launch (16-byte aligned records before any)
     const int nb = p->nbasins == 1 ? 1 : (p->nbasins <= 5 ? 5 : 8);
@@ -425,6 +458,10 @@ int cdft_moc_compute(cdft_moc_plan *p, const float *zv, int64_t rec_stride, int 
     if (npt < 1 || rec_stride < n3)
         return fail(CDFT_ERR_ARG, "cdft_moc_compute: npt=%d rec_stride=%lld (need npt>=1, stride>=%lld)",
                     npt, (long long)rec_stride, (long long)n3);
+    if (p->sh) {                                                                 // any memory spaces; returns when done
+        if (zv_space == CDFT_MEM_DEVICE) CDFT_HIP(hipStreamSynchronize(as_stream(stream)));
+        return shard::moc_compute(*p->sh, zv, rec_stride, npt, dmoc);
+    }
     hipStream_t st = as_stream(stream);
     const void *d_zv;
     CDFT_TRY(to_device(zv, ((size_t)(npt - 1) * rec_stride + n3) * sizeof(float), zv_space, p->st_zv,
@@ -457,6 +494,8 @@ int cdft_moc_decomp_set_mesh(cdft_moc_plan *p, const float *e3v, const float *e1
                              void *stream) {
     if (!p || !e3v || !e1u || !zcoef || !gdept || !tmask || !umask)
         return fail(CDFT_ERR_ARG, "cdft_moc_decomp_set_mesh: NULL argument");
+    if (p->sh) return fail(CDFT_ERR_STATE, "cdft_moc_decomp_set_mesh: -decomp runs on one device (its U-point stencil and depth "
+                                           "means cross rows); create the plan with cdft_moc_create");
     if (p->npi < 3 || p->npj < 3)
         return fail(CDFT_ERR_ARG, "cdft_moc_decomp_set_mesh: the 4-point stencil needs npiglo, npjglo >= 3");
     hipStream_t st = as_stream(stream);
@@ -561,12 +600,17 @@ int cdft_moc_decomp(cdft_moc_plan *p, const float *zv, const float *ztemp, const
 
 int cdft_moc_profile_enable(cdft_moc_plan *p, int on) {
     if (!p) return fail(CDFT_ERR_ARG, "cdft_moc_profile_enable: NULL plan");
+    if (p->sh) {
+        for (void *q : p->sh->part) CDFT_TRY(cdft_moc_profile_enable((cdft_moc_plan *)q, on));
+        return CDFT_OK;
+    }
     p->profiling = on != 0;
     return CDFT_OK;
 }
 
 int cdft_moc_profile_read(cdft_moc_plan *p, double *zonal_ms_total, int *launches) {
     if (!p || !zonal_ms_total || !launches) return fail(CDFT_ERR_ARG, "cdft_moc_profile_read: NULL argument");
+    if (p->sh) return cdft_moc_profile_read((cdft_moc_plan *)p->sh->part[0], zonal_ms_total, launches);   // block 0 speaks for all
     double tot = 0.0;
     for (size_t i = 0; i + 1 < p->ev_used; i += 2) {
         float ms = 0.f;
@@ -583,6 +627,7 @@ int cdft_moc_profile_read(cdft_moc_plan *p, double *zonal_ms_total, int *launche
 int cdft_moc_profile_read_each(cdft_moc_plan *p, float *ms_each, int capacity, int *launches) {
     if (!p || !ms_each || !launches || capacity < 0)
         return fail(CDFT_ERR_ARG, "cdft_moc_profile_read_each: bad argument");
+    if (p->sh) return cdft_moc_profile_read_each((cdft_moc_plan *)p->sh->part[0], ms_each, capacity, launches);
     const int n = (int)(p->ev_used / 2);
     for (int i = 0; i < n; ++i) {
         float ms = 0.f;
@@ -597,6 +642,12 @@ int cdft_moc_profile_read_each(cdft_moc_plan *p, float *ms_each, int capacity, i
 
 int cdft_moc_destroy(cdft_moc_plan *p) {
     if (!p) return CDFT_OK;
+    if (p->sh) {
+        (void)shard::for_blocks(*p->sh, [&](int b) { return cdft_moc_destroy((cdft_moc_plan *)p->sh->part[b]); });
+        shard::destroy(p->sh);
+        delete p;
+        return CDFT_OK;
+    }
     for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
     if (p->w) (void)hipFree(p->w);
     if (p->bits) (void)hipFree(p->bits);

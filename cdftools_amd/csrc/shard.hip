@@ -1,0 +1,491 @@
+// shard.hip -- row-block sharded plans over several GPUs of one node, driven by one process (see shard.hpp).
+// Host code only: every kernel launch goes through the ordinary single-device entry points of the C ABI.
+#include "shard.hpp"
+#include <cstdlib>
+#include <thread>
+
+using namespace cdft;
+
+namespace cdft {
+namespace shard {
+
+int from_env(int *ndev, int *devices, int capacity) {
+    if (!ndev || !devices || capacity < 1) return fail(CDFT_ERR_ARG, "cdft_shard_from_env: bad argument");
+    int n = 0;
+    const char *map = getenv("CDFT_GPU_MAP");
+    const char *cnt = getenv("CDFT_GPUS");
+    if (map && *map) {
+        const char *p = map;
+        while (*p) {
+            char *end = nullptr;
+            long v = strtol(p, &end, 10);
+            if (end == p || v < 0) return fail(CDFT_ERR_ARG, "CDFT_GPU_MAP=\"%s\": expected a comma-separated list of device numbers", map);
+            if (n >= capacity) return fail(CDFT_ERR_ARG, "CDFT_GPU_MAP lists more than %d blocks", capacity);
+            devices[n++] = (int)v;
+            p = end;
+            while (*p == ',' || *p == ' ') ++p;
+        }
+    } else if (cnt && *cnt) {
+        char *end = nullptr;
+        long v = strtol(cnt, &end, 10);
+        if (end == cnt || v < 1 || v > capacity) return fail(CDFT_ERR_ARG, "CDFT_GPUS=\"%s\": expected 1..%d", cnt, capacity);
+        for (n = 0; n < (int)v; ++n) devices[n] = n;
+    }
+    if (n == 0) { n = 1; devices[0] = -1; }          // -1: whatever device is current (the unsharded default)
+    if (n > 1 || devices[0] >= 0) {
+        int have = 0;
+        if (hipGetDeviceCount(&have) != hipSuccess) { (void)hipGetLastError(); have = 0; }
+        for (int b = 0; b < n; ++b)
+            if (devices[b] >= have)
+                return fail(have ? CDFT_ERR_ARG : CDFT_ERR_NODEVICE, "block %d asks for HIP device %d, the node has %d", b, devices[b], have);
+    }
+    *ndev = n;
+    return CDFT_OK;
+}
+
+void row_block(int npj, int n, int b, int *j0, int *j1) {
+    const int base = npj / n, extra = npj % n;
+    *j0 = b * base + (b < extra ? b : extra);
+    *j1 = *j0 + base + (b < extra ? 1 : 0);
+}
+
+int make(ShardSet **out, int npi, int npj, int npk, int nb, int ndev, const int *devices, int halo_north, int nbuf) {
+    *out = nullptr;
+    if (ndev < 1 || !devices) return fail(CDFT_ERR_ARG, "sharded plan: no devices");
+    if (ndev > npj) return fail(CDFT_ERR_ARG, "sharded plan: %d blocks for %d rows", ndev, npj);
+    CDFT_TRY(require_device());
+    int have = 0;
+    CDFT_HIP(hipGetDeviceCount(&have));
+    for (int b = 0; b < ndev; ++b)
+        if (devices[b] >= have) return fail(CDFT_ERR_ARG, "sharded plan: block %d asks for HIP device %d, the node has %d", b, devices[b], have);
+    ShardSet *sh = new ShardSet;
+    sh->npi = npi; sh->npj = npj; sh->npk = npk; sh->nb = nb;
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (int b = 0; b < ndev; ++b) {
+        int j0, j1;
+        row_block(npj, ndev, b, &j0, &j1);
+        sh->dev.push_back(devices[b] < 0 ? cur : devices[b]);
+        sh->j0.push_back(j0);
+        sh->j1.push_back(j1);
+        sh->r1.push_back((halo_north && j1 < npj) ? j1 + 1 : j1);
+        sh->part.push_back(nullptr);
+        sh->st.push_back(nullptr);
+        sh->buf.emplace_back((size_t)nbuf);
+    }
+    for (int b = 0; b < ndev; ++b) {
+        hipError_t e = hipSetDevice(sh->dev[b]);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&sh->st[b], hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipSetDevice(cur);
+            destroy(sh);
+            return fail(CDFT_ERR_HIP, "sharded plan: stream on device %d -> %s", devices[b], hipGetErrorString(e));
+        }
+    }
+    (void)hipSetDevice(cur);
+    *out = sh;
+    return CDFT_OK;
+}
+
+void destroy(ShardSet *sh) {
+    if (!sh) return;
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (int b = 0; b < sh->nblk(); ++b) {
+        (void)hipSetDevice(sh->dev[b]);
+        for (DevBuf &d : sh->buf[b]) d.release();
+        if (sh->st[b]) (void)hipStreamDestroy(sh->st[b]);
+    }
+    (void)hipSetDevice(cur);
+    (void)hipGetLastError();            // nothing sticky may outlive a plan (CDFT_LAUNCH_CHECK reads the last error)
+    delete sh;
+}
+
+int for_blocks(ShardSet &sh, const std::function<int(int)> &fn) {
+    const int n = sh.nblk();
+    std::vector<int> rc(n, CDFT_OK);
+    std::vector<std::string> msg(n);
+    auto body = [&](int b) {
+        if (hipSetDevice(sh.dev[b]) != hipSuccess) {
+            (void)hipGetLastError();
+            rc[b] = CDFT_ERR_HIP;
+            msg[b] = "hipSetDevice failed";
+            return;
+        }
+        rc[b] = fn(b);
+        if (rc[b] != CDFT_OK) msg[b] = cdft_last_error();       // the message is thread-local: carry it over
+    };
+    if (n == 1) {
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        body(0);
+        (void)hipSetDevice(cur);
+    } else {
+        std::vector<std::thread> th;
+        for (int b = 0; b < n; ++b) th.emplace_back(body, b);
+        for (auto &t : th) t.join();
+    }
+    for (int b = 0; b < n; ++b)
+        if (rc[b] != CDFT_OK) return fail(rc[b], "row block %d (device %d): %s", b, sh.dev[b], msg[b].c_str());
+    return CDFT_OK;
+}
+
+static int rows_copy(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t height, hipStream_t st) {
+    if (width == 0 || height == 0) return CDFT_OK;
+    if (dpitch == width && spitch == width) {
+        CDFT_HIP(hipMemcpyAsync(dst, src, width * height, hipMemcpyDefault, st));
+    } else {
+        CDFT_HIP(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyDefault, st));
+    }
+    return CDFT_OK;
+}
+
+int rows_in(void *blk, const void *full, size_t rowbytes, int npj, int j0, int j1, size_t nslab, size_t slab_stride,
+            hipStream_t st) {
+    const size_t width = rowbytes * (size_t)(j1 - j0);
+    const size_t spitch = slab_stride ? slab_stride : rowbytes * (size_t)npj;
+    return rows_copy(blk, width, (const char *)full + rowbytes * (size_t)j0, spitch, width, nslab, st);
+}
+
+int rows_out(void *full, const void *blk, size_t rowbytes, int npj, int j0, int j1, size_t nslab, size_t slab_stride,
+             hipStream_t st) {
+    const size_t width = rowbytes * (size_t)(j1 - j0);
+    const size_t dpitch = slab_stride ? slab_stride : rowbytes * (size_t)npj;
+    return rows_copy((char *)full + rowbytes * (size_t)j0, dpitch, blk, width, width, nslab, st);
+}
+
+}  // namespace shard
+}  // namespace cdft
+
+extern "C" int cdft_shard_from_env(int *ndev, int *devices, int capacity) { return shard::from_env(ndev, devices, capacity); }
+
+// =================================================================================================== cdfmoc
+namespace cdft {
+namespace shard {
+
+int moc_parts(ShardSet &sh) {
+    return for_blocks(sh, [&](int b) {
+        cdft_moc_plan *p = nullptr;
+        CDFT_TRY(cdft_moc_create(&p, sh.npi, sh.j1[b] - sh.j0[b], sh.npk, sh.nb));
+        sh.part[b] = p;
+        return CDFT_OK;
+    });
+}
+
+int moc_set_mesh(ShardSet &sh, const float *e1v, const float *e3v, const int8_t *vmask, const int16_t *ibmask) {
+    return for_blocks(sh, [&](int b) {
+        const int j0 = sh.j0[b], j1 = sh.j1[b], nloc = j1 - j0;
+        const size_t nij = (size_t)sh.npi * nloc, n3 = nij * sh.npk;
+        hipStream_t st = sh.st[b];
+        DevBuf *B = sh.buf[b].data();            // 0: e1v, 1: e3v, 2: vmask, 3: ibmask, (4: zv, 5: out)
+        CDFT_TRY(B[0].reserve(nij * 4));
+        CDFT_TRY(B[1].reserve(n3 * 4));
+        CDFT_TRY(B[3].reserve(nij * sh.nb * 2));
+        CDFT_TRY(rows_in(B[0].ptr, e1v, (size_t)sh.npi * 4, sh.npj, j0, j1, 1, 0, st));
+        CDFT_TRY(rows_in(B[1].ptr, e3v, (size_t)sh.npi * 4, sh.npj, j0, j1, sh.npk, 0, st));
+        CDFT_TRY(rows_in(B[3].ptr, ibmask, (size_t)sh.npi * sh.nb * 2, sh.npj, j0, j1, 1, 0, st));
+        if (vmask) {
+            CDFT_TRY(B[2].reserve(n3));
+            CDFT_TRY(rows_in(B[2].ptr, vmask, (size_t)sh.npi, sh.npj, j0, j1, sh.npk, 0, st));
+        }
+        int rc = cdft_moc_set_mesh_vmask((cdft_moc_plan *)sh.part[b], (const float *)B[0].ptr, (const float *)B[1].ptr,
+                                         vmask ? (const int8_t *)B[2].ptr : nullptr, (const int16_t *)B[3].ptr, CDFT_MEM_DEVICE, st);
+        (void)hipStreamSynchronize(st);
+        for (int i = 0; i < 4; ++i) B[i].release();
+        return rc;
+    });
+}
+
+int moc_compute(ShardSet &sh, const float *zv, int64_t rec_stride, int npt, double *dmoc) {
+    return for_blocks(sh, [&](int b) {
+        const int j0 = sh.j0[b], j1 = sh.j1[b], nloc = j1 - j0;
+        const size_t n3 = (size_t)sh.npi * nloc * sh.npk;
+        hipStream_t st = sh.st[b];
+        DevBuf *B = sh.buf[b].data();
+        CDFT_TRY(B[4].reserve(n3 * npt * 4));
+        CDFT_TRY(B[5].reserve((size_t)sh.nb * nloc * sh.npk * npt * 8));
+        for (int t = 0; t < npt; ++t)
+            CDFT_TRY(rows_in((float *)B[4].ptr + (size_t)t * n3, zv + (size_t)t * rec_stride, (size_t)sh.npi * 4, sh.npj, j0, j1,
+                             sh.npk, 0, st));
+        CDFT_TRY(cdft_moc_compute((cdft_moc_plan *)sh.part[b], (const float *)B[4].ptr, (int64_t)n3, npt, CDFT_MEM_DEVICE,
+                                  (double *)B[5].ptr, CDFT_MEM_DEVICE, st));
+        // dmoc(nbasins,npjglo,npk,npt): the rows of this block, every level and record, in place
+        CDFT_TRY(rows_out(dmoc, B[5].ptr, (size_t)sh.nb * 8, sh.npj, j0, j1, (size_t)sh.npk * npt, 0, st));
+        CDFT_HIP(hipStreamSynchronize(st));
+        return CDFT_OK;
+    });
+}
+
+// =================================================================================================== cdfheatc
+int heatc_parts(ShardSet &sh) {
+    return for_blocks(sh, [&](int b) {
+        cdft_heatc_plan *p = nullptr;
+        CDFT_TRY(cdft_heatc_create(&p, sh.npi, sh.j1[b] - sh.j0[b], sh.npk));
+        sh.part[b] = p;
+        return CDFT_OK;
+    });
+}
+
+int heatc_set_mesh(ShardSet &sh, const float *e1t, const float *e2t, const float *e3t, const float *e31d, const void *tmask,
+                   int mask_is_r4) {
+    return for_blocks(sh, [&](int b) {
+        const int j0 = sh.j0[b], j1 = sh.j1[b], nloc = j1 - j0;
+        const size_t nij = (size_t)sh.npi * nloc, n3 = nij * sh.npk, ms = mask_is_r4 ? 4 : 1;
+        hipStream_t st = sh.st[b];
+        DevBuf *B = sh.buf[b].data();            // 0: e1t, 1: e2t, 2: e3t, 3: tmask, 4: e31d (5: temp, 6: mxl)
+        CDFT_TRY(B[0].reserve(nij * 4));
+        CDFT_TRY(B[1].reserve(nij * 4));
+        CDFT_TRY(B[3].reserve(n3 * ms));
+        CDFT_TRY(rows_in(B[0].ptr, e1t, (size_t)sh.npi * 4, sh.npj, j0, j1, 1, 0, st));
+        CDFT_TRY(rows_in(B[1].ptr, e2t, (size_t)sh.npi * 4, sh.npj, j0, j1, 1, 0, st));
+        CDFT_TRY(rows_in(B[3].ptr, tmask, (size_t)sh.npi * ms, sh.npj, j0, j1, sh.npk, 0, st));
+        if (e3t) {
+            CDFT_TRY(B[2].reserve(n3 * 4));
+            CDFT_TRY(rows_in(B[2].ptr, e3t, (size_t)sh.npi * 4, sh.npj, j0, j1, sh.npk, 0, st));
+        } else {
+            CDFT_TRY(B[4].reserve((size_t)sh.npk * 4));
+            CDFT_HIP(hipMemcpyAsync(B[4].ptr, e31d, (size_t)sh.npk * 4, hipMemcpyDefault, st));
+        }
+        int rc = cdft_heatc_set_mesh((cdft_heatc_plan *)sh.part[b], (const float *)B[0].ptr, (const float *)B[1].ptr,
+                                     e3t ? (const float *)B[2].ptr : nullptr, e3t ? nullptr : (const float *)B[4].ptr, B[3].ptr,
+                                     mask_is_r4, CDFT_MEM_DEVICE, st);
+        (void)hipStreamSynchronize(st);
+        for (int i = 0; i < 5; ++i) B[i].release();
+        return rc;
+    });
+}
+
+int heatc_compute(ShardSet &sh, const float *temp, const float *rmxldep, const float *gdepw, int mxloption, double *sums,
+                  int out_space, hipStream_t out_stream) {
+    const int n = sh.nblk();
+    std::vector<std::vector<double>> part(n, std::vector<double>((size_t)3 * sh.npk));
+    CDFT_TRY(for_blocks(sh, [&](int b) {
+        const int j0 = sh.j0[b], j1 = sh.j1[b], nloc = j1 - j0;
+        const size_t nij = (size_t)sh.npi * nloc;
+        hipStream_t st = sh.st[b];
+        DevBuf *B = sh.buf[b].data();
+        CDFT_TRY(B[5].reserve(nij * sh.npk * 4));
+        CDFT_TRY(rows_in(B[5].ptr, temp, (size_t)sh.npi * 4, sh.npj, j0, j1, sh.npk, 0, st));
+        if (mxloption != 0) {
+            CDFT_TRY(B[6].reserve(nij * 4));
+            CDFT_TRY(rows_in(B[6].ptr, rmxldep, (size_t)sh.npi * 4, sh.npj, j0, j1, 1, 0, st));
+        }
+        return cdft_heatc_compute((cdft_heatc_plan *)sh.part[b], (const float *)B[5].ptr, CDFT_MEM_DEVICE,
+                                  mxloption ? (const float *)B[6].ptr : nullptr, gdepw, mxloption, part[b].data(), CDFT_MEM_HOST, st);
+    }));
+    // src/cdfheatc.f90:225-229 sums the whole level; here the blocks' r8 sums are added in block order
+    std::vector<double> tot(part[0]);
+    for (int b = 1; b < n; ++b)
+        for (size_t i = 0; i < tot.size(); ++i) tot[i] += part[b][i];
+    if (out_space == CDFT_MEM_HOST) {
+        memcpy(sums, tot.data(), tot.size() * 8);
+    } else {
+        CDFT_HIP(hipMemcpyAsync(sums, tot.data(), tot.size() * 8, hipMemcpyHostToDevice, out_stream));
+        CDFT_HIP(hipStreamSynchronize(out_stream));
+    }
+    return CDFT_OK;
+}
+
+// =================================================================================================== cdfmhst
+int mhst_parts(ShardSet &sh) {
+    return for_blocks(sh, [&](int b) {
+        cdft_mhst_plan *p = nullptr;
+        CDFT_TRY(cdft_mhst_create(&p, sh.npi, sh.r1[b] - sh.j0[b], sh.npk, sh.nb));     // with the halo row to the north
+        sh.part[b] = p;
+        return CDFT_OK;
+    });
+}
+
+int mhst_set_mesh(ShardSet &sh, const float *e1v, const float *e3v, const float *e31d, const float *masks) {
+    return for_blocks(sh, [&](int b) {
+        const int j0 = sh.j0[b], r1 = sh.r1[b], nrd = r1 - j0;
+        const size_t nij = (size_t)sh.npi * nrd;
+        hipStream_t st = sh.st[b];
+        DevBuf *B = sh.buf[b].data();            // 0: e1v, 1: e3v, 2: masks, 3: e31d (4..6: fields, 7..8: out)
+        CDFT_TRY(B[0].reserve(nij * 4));
+        CDFT_TRY(B[2].reserve(nij * sh.nb * 4));
+        CDFT_TRY(rows_in(B[0].ptr, e1v, (size_t)sh.npi * 4, sh.npj, j0, r1, 1, 0, st));
+        CDFT_TRY(rows_in(B[2].ptr, masks, (size_t)sh.npi * 4, sh.npj, j0, r1, sh.nb, 0, st));
+        if (e3v) {
+            CDFT_TRY(B[1].reserve(nij * sh.npk * 4));
+            CDFT_TRY(rows_in(B[1].ptr, e3v, (size_t)sh.npi * 4, sh.npj, j0, r1, sh.npk, 0, st));
+        } else {
+            CDFT_TRY(B[3].reserve((size_t)sh.npk * 4));
+            CDFT_HIP(hipMemcpyAsync(B[3].ptr, e31d, (size_t)sh.npk * 4, hipMemcpyDefault, st));
+        }
+        int rc = cdft_mhst_set_mesh((cdft_mhst_plan *)sh.part[b], (const float *)B[0].ptr, e3v ? (const float *)B[1].ptr : nullptr,
+                                    e3v ? nullptr : (const float *)B[3].ptr, (const float *)B[2].ptr, CDFT_MEM_DEVICE, st);
+        (void)hipStreamSynchronize(st);
+        for (int i = 0; i < 4; ++i) B[i].release();
+        return rc;
+    });
+}
+
+int mhst_compute(ShardSet &sh, const float *vt, const float *vs, const float *zv, const float *zt, const float *zs, int zdim,
+                 double *heat, double *salt) {
+    return for_blocks(sh, [&](int b) {
+        const int j0 = sh.j0[b], j1 = sh.j1[b], r1 = sh.r1[b], nrd = r1 - j0;
+        const size_t n3 = (size_t)sh.npi * nrd * sh.npk;
+        const int nlo = zdim ? sh.npk : 1;
+        hipStream_t st = sh.st[b];
+        DevBuf *B = sh.buf[b].data();
+        const float *in[3] = {vt ? vt : zv, vt ? vs : zt, vt ? nullptr : zs};
+        for (int i = 0; i < 3; ++i)
+            if (in[i]) {
+                CDFT_TRY(B[4 + i].reserve(n3 * 4));
+                CDFT_TRY(rows_in(B[4 + i].ptr, in[i], (size_t)sh.npi * 4, sh.npj, j0, r1, sh.npk, 0, st));
+            }
+        const size_t ob = (size_t)sh.nb * nrd * nlo * 8;
+        CDFT_TRY(B[7].reserve(ob));
+        CDFT_TRY(B[8].reserve(ob));
+        const float *a = (const float *)B[4].ptr, *c = (const float *)B[5].ptr, *d = (const float *)B[6].ptr;
+        CDFT_TRY(cdft_mhst_compute((cdft_mhst_plan *)sh.part[b], vt ? a : nullptr, vt ? c : nullptr, vt ? nullptr : a,
+                                   vt ? nullptr : c, vt ? nullptr : d, CDFT_MEM_DEVICE, zdim, (double *)B[7].ptr, (double *)B[8].ptr,
+                                   CDFT_MEM_DEVICE, st));
+        // heat, salt (nbasins,npjglo[,npk]): keep the rows this block owns (its halo row belongs to the next block)
+        for (int k = 0; k < nlo; ++k) {
+            const size_t so = (size_t)k * sh.nb * nrd * 8, fo = (size_t)k * sh.nb * sh.npj * 8;
+            CDFT_TRY(rows_out((char *)heat + fo, (char *)B[7].ptr + so, (size_t)sh.nb * 8, sh.npj, j0, j1, 1, 0, st));
+            CDFT_TRY(rows_out((char *)salt + fo, (char *)B[8].ptr + so, (size_t)sh.nb * 8, sh.npj, j0, j1, 1, 0, st));
+        }
+        CDFT_HIP(hipStreamSynchronize(st));
+        return CDFT_OK;
+    });
+}
+
+// =================================================================================================== cdfpsi
+int psi_parts(ShardSet &sh) {
+    return for_blocks(sh, [&](int b) {
+        cdft_psi_plan *p = nullptr;
+        CDFT_TRY(cdft_psi_create(&p, sh.npi, sh.j1[b] - sh.j0[b], sh.npk));
+        sh.part[b] = p;
+        return CDFT_OK;
+    });
+}
+
+int psi_compute(ShardSet &sh, const float *zu, const float *e2u, const float *e3u, const float *zv, const float *e1v,
+                const float *e3v, const float *e31d, int iiref, int ijref, const float *fmask, float *psi4, double *dpsi8) {
+    const int n = sh.nblk();
+    if (iiref < 1 || iiref > sh.npi || ijref < 1 || ijref > sh.npj)
+        return fail(CDFT_ERR_ARG, "cdft_psi_compute: reference point (%d,%d) outside the domain", iiref, ijref);
+    // 1. the vertical integrals (and the i-scan of the V path, local to a row): all blocks at once
+    CDFT_TRY(for_blocks(sh, [&](int b) {
+        const int j0 = sh.j0[b], j1 = sh.j1[b], nloc = j1 - j0;
+        const size_t nij = (size_t)sh.npi * nloc, n3 = nij * sh.npk;
+        hipStream_t st = sh.st[b];
+        DevBuf *B = sh.buf[b].data();            // 0: zu 1: e2u 2: e3u 3: zv 4: e1v 5: e3v 6: e31d 7: fmask 8: carry 9: last
+        const float *src3[2][2] = {{zu, e3u}, {zv, e3v}};
+        const float *src2[2] = {e2u, e1v};
+        for (int c = 0; c < 2; ++c) {
+            if (!src3[c][0]) continue;
+            CDFT_TRY(B[3 * c].reserve(n3 * 4));
+            CDFT_TRY(rows_in(B[3 * c].ptr, src3[c][0], (size_t)sh.npi * 4, sh.npj, j0, j1, sh.npk, 0, st));
+            CDFT_TRY(B[3 * c + 1].reserve(nij * 4));
+            CDFT_TRY(rows_in(B[3 * c + 1].ptr, src2[c], (size_t)sh.npi * 4, sh.npj, j0, j1, 1, 0, st));
+            if (src3[c][1]) {
+                CDFT_TRY(B[3 * c + 2].reserve(n3 * 4));
+                CDFT_TRY(rows_in(B[3 * c + 2].ptr, src3[c][1], (size_t)sh.npi * 4, sh.npj, j0, j1, sh.npk, 0, st));
+            }
+        }
+        if (e31d) {
+            CDFT_TRY(B[6].reserve((size_t)sh.npk * 4));
+            CDFT_HIP(hipMemcpyAsync(B[6].ptr, e31d, (size_t)sh.npk * 4, hipMemcpyDefault, st));
+        }
+        if (fmask) {
+            CDFT_TRY(B[7].reserve(nij * 4));
+            CDFT_TRY(rows_in(B[7].ptr, fmask, (size_t)sh.npi * 4, sh.npj, j0, j1, 1, 0, st));
+        }
+        CDFT_TRY(B[8].reserve((size_t)sh.npi * 8));
+        CDFT_TRY(B[9].reserve((size_t)sh.npi * 8));
+        auto f = [&](int i, const float *given) { return given ? (const float *)B[i].ptr : nullptr; };
+        CDFT_TRY(cdft_psi_integrate((cdft_psi_plan *)sh.part[b], f(0, zu), f(1, zu ? e2u : nullptr), f(2, zu ? e3u : nullptr), f(3, zv),
+                                    f(4, zv ? e1v : nullptr), f(5, zv ? e3v : nullptr), f(6, e31d), CDFT_MEM_DEVICE, st));
+        CDFT_HIP(hipStreamSynchronize(st));
+        return CDFT_OK;
+    }));
+    // 2. the running difference along j crosses the blocks (src/cdfpsi.f90:395-398): visit them south to north, the
+    //    last row of one is the carry of the next -- 8*npiglo bytes from HBM to HBM
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (int b = 0; b < n; ++b) {
+        CDFT_HIP(hipSetDevice(sh.dev[b]));
+        DevBuf *B = sh.buf[b].data();
+        if (b > 0) {
+            CDFT_HIP(hipMemcpyPeerAsync(B[8].ptr, sh.dev[b], sh.buf[b - 1][9].ptr, sh.dev[b - 1], (size_t)sh.npi * 8, sh.st[b]));
+        }
+        int rc = cdft_psi_scan_u((cdft_psi_plan *)sh.part[b], b > 0 ? (const double *)B[8].ptr : nullptr, CDFT_MEM_DEVICE, b == 0 ? 1 : 0,
+                                 (double *)B[9].ptr, CDFT_MEM_DEVICE, sh.st[b]);
+        if (rc == CDFT_OK && hipStreamSynchronize(sh.st[b]) != hipSuccess) rc = fail(CDFT_ERR_HIP, "cdft_psi_compute: scan of block %d failed", b);
+        if (rc != CDFT_OK) { (void)hipSetDevice(cur); return rc; }
+    }
+    // 3. the value at the reference point (:423) from the block that owns it
+    double ref = 0.0;
+    for (int b = 0; b < n; ++b)
+        if (ijref > sh.j0[b] && ijref <= sh.j1[b]) {
+            CDFT_HIP(hipSetDevice(sh.dev[b]));
+            int rc = cdft_psi_value((cdft_psi_plan *)sh.part[b], iiref, ijref - sh.j0[b], &ref, sh.st[b]);
+            if (rc != CDFT_OK) { (void)hipSetDevice(cur); return rc; }
+        }
+    (void)hipSetDevice(cur);
+    // 4. normalisation, mask, SNGL: every block writes its rows of the caller's arrays
+    return for_blocks(sh, [&](int b) {
+        const size_t off = (size_t)sh.npi * sh.j0[b], nij = (size_t)sh.npi * (sh.j1[b] - sh.j0[b]);
+        DevBuf *B = sh.buf[b].data();
+        hipStream_t st = sh.st[b];
+        CDFT_TRY(B[10].reserve(nij * 4));
+        if (dpsi8) CDFT_TRY(B[11].reserve(nij * 8));
+        CDFT_TRY(cdft_psi_finish((cdft_psi_plan *)sh.part[b], 1, ref, 1, 1, fmask ? (const float *)B[7].ptr : nullptr, CDFT_MEM_DEVICE,
+                                 (float *)B[10].ptr, dpsi8 ? (double *)B[11].ptr : nullptr, CDFT_MEM_DEVICE, st));
+        CDFT_HIP(hipMemcpyAsync(psi4 + off, B[10].ptr, nij * 4, hipMemcpyDefault, st));        // rows of a 2-D array: contiguous
+        if (dpsi8) CDFT_HIP(hipMemcpyAsync(dpsi8 + off, B[11].ptr, nij * 8, hipMemcpyDefault, st));
+        CDFT_HIP(hipStreamSynchronize(st));
+        return CDFT_OK;
+    });
+}
+
+// =================================================================================================== cdfvT
+int vt_compute(int ndev, const int *devices, const float *u, const float *v, const float *t, const float *s, const float *e3u,
+               const float *e3v, int64_t fstride, int nfr, int npi, int npj, int npk, void *vt, void *vs, void *ut, void *us,
+               void *e3um, void *e3vm, int out_r4) {
+    ShardSet *shp = nullptr;
+    CDFT_TRY(make(&shp, npi, npj, npk, 0, ndev, devices, 1, 12));
+    ShardSet &sh = *shp;
+    const size_t os = out_r4 ? 4 : 8;
+    int rc = for_blocks(sh, [&](int b) {
+        const int j0 = sh.j0[b], j1 = sh.j1[b], r1 = sh.r1[b], nrd = r1 - j0;
+        const size_t n3 = (size_t)npi * nrd * npk;
+        hipStream_t st = sh.st[b];
+        DevBuf *B = sh.buf[b].data();            // 0..5: u v t s e3u e3v (all frames), 6..11: results
+        const float *in[6] = {u, v, t, s, e3u, e3v};
+        void *out[6] = {vt, vs, ut, us, e3um, e3vm};
+        for (int i = 0; i < 6; ++i) {
+            if (!in[i]) continue;
+            CDFT_TRY(B[i].reserve(n3 * nfr * 4));
+            for (int f = 0; f < nfr; ++f)
+                CDFT_TRY(rows_in((float *)B[i].ptr + (size_t)f * n3, in[i] + (size_t)f * fstride, (size_t)npi * 4, npj, j0, r1, npk, 0, st));
+        }
+        for (int i = 0; i < 6; ++i)
+            if (out[i] && (i < 4 || e3u)) CDFT_TRY(B[6 + i].reserve(n3 * os));
+        auto o = [&](int i) { return (out[i] && (i < 4 || e3u)) ? B[6 + i].ptr : nullptr; };
+        CDFT_TRY(cdft_vt_compute((const float *)B[0].ptr, (const float *)B[1].ptr, (const float *)B[2].ptr, (const float *)B[3].ptr,
+                                 e3u ? (const float *)B[4].ptr : nullptr, e3u ? (const float *)B[5].ptr : nullptr, (int64_t)n3, nfr, npi, nrd,
+                                 npk, CDFT_MEM_DEVICE, o(0), o(1), o(2), o(3), o(4), o(5), out_r4, CDFT_MEM_DEVICE, st));
+        // the rows this block owns: its north halo row was only read (src/cdfvT.f90:200-206 look at jj+1); the global
+        // last row stays 0 as in the reference, and the kernel leaves the last row of whatever block it is given at 0,
+        // which for an interior block is the halo row that is dropped here
+        for (int i = 0; i < 6; ++i)
+            if (o(i)) {
+                for (int k = 0; k < npk; ++k)
+                    CDFT_TRY(rows_out((char *)out[i] + (size_t)k * npi * npj * os, (char *)B[6 + i].ptr + (size_t)k * npi * nrd * os,
+                                      (size_t)npi * os, npj, j0, j1, 1, 0, st));
+            }
+        CDFT_HIP(hipStreamSynchronize(st));
+        return CDFT_OK;
+    });
+    destroy(shp);
+    return rc;
+}
+
+}  // namespace shard
+}  // namespace cdft

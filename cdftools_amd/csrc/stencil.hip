@@ -15,6 +15,7 @@
 // row is a second coalesced load; the block -> tile map gives every XCD a contiguous band of rows so
 // that the row read as "j+1" is still in that XCD's L2 when it is read again as "j".
 #include "common.hpp"
+#include "shard.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -465,7 +466,26 @@ DevBuf g_in[6], g_out[6];
 
 }  // namespace
 
+namespace cdft { namespace shard {
+int vt_compute(int ndev, const int *devices, const float *u, const float *v, const float *t, const float *s, const float *e3u,
+               const float *e3v, int64_t fstride, int nfr, int npi, int npj, int npk, void *vt, void *vs, void *ut, void *us,
+               void *e3um, void *e3vm, int out_r4);
+} }
+
 extern "C" {
+
+int cdft_vt_compute_sharded(const float *u, const float *v, const float *t, const float *s, const float *e3u,
+                            const float *e3v, int64_t fstride, int nframes, int npiglo, int npjglo, int npk,
+                            void *vt, void *vs, void *ut, void *us, void *e3um, void *e3vm, int out_is_r4, int ndev,
+                            const int *devices) {
+    if (!u || !v || !t || !s || !vt || !vs || !ut || !us)
+        return fail(CDFT_ERR_ARG, "cdft_vt_compute_sharded: NULL argument");
+    if (e3u && (!e3v || !e3um || !e3vm)) return fail(CDFT_ERR_ARG, "cdft_vt_compute_sharded: -vvl needs e3u, e3v, e3um, e3vm");
+    if (npiglo < 1 || npjglo < 1 || npk < 1 || nframes < 1 || fstride < (int64_t)npiglo * npjglo * npk)
+        return fail(CDFT_ERR_ARG, "cdft_vt_compute_sharded: bad sizes (%d,%d,%d) x %d frames", npiglo, npjglo, npk, nframes);
+    return cdft::shard::vt_compute(ndev, devices, u, v, t, s, e3u, e3v, fstride, nframes, npiglo, npjglo, npk, vt, vs, ut, us,
+                                   e3um, e3vm, out_is_r4);
+}
 
 int cdft_vt_compute(const float *u, const float *v, const float *t, const float *s, const float *e3u,
                     const float *e3v, int64_t fstride, int nframes, int npiglo, int npjglo, int npk, int in_space,

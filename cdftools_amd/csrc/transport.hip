@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include "common.hpp"
 #include "reduce.hpp"
+#include "shard.hpp"
 
 using namespace cdft;
 
@@ -488,7 +489,18 @@ int upload(void **dst, const void *src, size_t bytes, int space, hipStream_t st)
 }  // namespace
 
 // ------------------------------------------------------------------------------------------ cdfmhst
+namespace cdft { namespace shard {
+int mhst_parts(ShardSet &sh);
+int mhst_set_mesh(ShardSet &sh, const float *e1v, const float *e3v, const float *e31d, const float *masks);
+int mhst_compute(ShardSet &sh, const float *vt, const float *vs, const float *zv, const float *zt, const float *zs, int zdim,
+                 double *heat, double *salt);
+int psi_parts(ShardSet &sh);
+int psi_compute(ShardSet &sh, const float *zu, const float *e2u, const float *e3u, const float *zv, const float *e1v,
+                const float *e3v, const float *e31d, int iiref, int ijref, const float *fmask, float *psi4, double *dpsi8);
+} }
+
 struct cdft_mhst_plan {
+    cdft::ShardSet *sh = nullptr;   // set: a shell over one plan per row block (shard.hpp)
     int npi = 0, npj = 0, npk = 0, nb = 0;
     float *e1v = nullptr, *e3v = nullptr, *e31d = nullptr, *masks = nullptr;
     uint8_t *mbits = nullptr;                            // masks packed to a byte per cell when they are all 0 / 1
@@ -518,10 +530,30 @@ int cdft_mhst_create(cdft_mhst_plan **plan, int npiglo, int npjglo, int npk, int
     return CDFT_OK;
 }
 
+int cdft_mhst_create_sharded(cdft_mhst_plan **plan, int npiglo, int npjglo, int npk, int nbasins, int ndev, const int *devices) {
+    if (!plan) return fail(CDFT_ERR_ARG, "cdft_mhst_create_sharded: NULL plan pointer");
+    *plan = nullptr;
+    if (npiglo < 1 || npjglo < 1 || npk < 1 || nbasins < 1 || nbasins > 8)
+        return fail(CDFT_ERR_ARG, "cdft_mhst_create_sharded: bad sizes %d x %d x %d, %d basins", npiglo, npjglo, npk, nbasins);
+    cdft_mhst_plan *p = new cdft_mhst_plan;
+    p->npi = npiglo; p->npj = npjglo; p->npk = npk; p->nb = nbasins;
+    int rc = shard::make(&p->sh, npiglo, npjglo, npk, nbasins, ndev, devices, 1, 9);     // one halo row to the north (:318)
+    if (rc == CDFT_OK) rc = shard::mhst_parts(*p->sh);
+    if (rc != CDFT_OK) { cdft_mhst_destroy(p); return rc; }
+    *plan = p;
+    return CDFT_OK;
+}
+
 int cdft_mhst_set_mesh(cdft_mhst_plan *p, const float *e1v, const float *e3v, const float *e31d,
                        const float *masks, int memspace, void *stream) {
     if (!p || !e1v || !masks || (!e3v && !e31d) || (e3v && e31d))
         return fail(CDFT_ERR_ARG, "cdft_mhst_set_mesh: need e1v, masks and exactly one of e3v / e31d");
+    if (p->sh) {
+        if (memspace == CDFT_MEM_DEVICE) CDFT_HIP(hipStreamSynchronize(as_stream(stream)));
+        CDFT_TRY(shard::mhst_set_mesh(*p->sh, e1v, e3v, e31d, masks));
+        p->mesh_set = true;
+        return CDFT_OK;
+    }
     hipStream_t st = as_stream(stream);
     const size_t nij = (size_t)p->npi * p->npj;
     CDFT_TRY(upload((void **)&p->e1v, e1v, nij * 4, memspace, st));
@@ -558,6 +590,10 @@ int cdft_mhst_compute(cdft_mhst_plan *p, const float *vt, const float *vs, const
     const bool sep = (vt == nullptr);
     if ((sep && (!zv || !zt || !zs)) || (!sep && !vs))
         return fail(CDFT_ERR_ARG, "cdft_mhst_compute: give (vt, vs) or (zv, zt, zs)");
+    if (p->sh) {
+        if (in_space == CDFT_MEM_DEVICE) CDFT_HIP(hipStreamSynchronize(as_stream(stream)));
+        return shard::mhst_compute(*p->sh, vt, vs, zv, zt, zs, zdim, heat, salt);
+    }
     hipStream_t st = as_stream(stream);
     const int64_t nij = (int64_t)p->npi * p->npj;
     const size_t n3b = (size_t)nij * p->npk * 4;
@@ -611,6 +647,12 @@ int cdft_mhst_compute(cdft_mhst_plan *p, const float *vt, const float *vs, const
 
 int cdft_mhst_destroy(cdft_mhst_plan *p) {
     if (!p) return CDFT_OK;
+    if (p->sh) {
+        (void)shard::for_blocks(*p->sh, [&](int b) { return cdft_mhst_destroy((cdft_mhst_plan *)p->sh->part[b]); });
+        shard::destroy(p->sh);
+        delete p;
+        return CDFT_OK;
+    }
     void *ptrs[] = {p->e1v, p->e3v, p->e31d, p->masks, p->mbits, p->dtrph, p->dtrps, p->oh, p->os};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     p->s0.release(); p->s1.release(); p->s2.release();
@@ -694,6 +736,7 @@ int cdft_vint_release(void) {
 
 // ------------------------------------------------------------------------------------------ cdfpsi
 struct cdft_psi_plan {
+    cdft::ShardSet *sh = nullptr;   // set: a shell over one plan per row block (shard.hpp)
     int npi = 0, npj = 0, npk = 0;
     double *dtrpu = nullptr, *dtrpv = nullptr, *dpsiu = nullptr, *dpsiv = nullptr, *d8 = nullptr;
     float *p4 = nullptr;
@@ -724,9 +767,29 @@ int cdft_psi_create(cdft_psi_plan **plan, int npiglo, int npjglo, int npk) {
     return CDFT_OK;
 }
 
+int cdft_psi_create_sharded(cdft_psi_plan **plan, int npiglo, int npjglo, int npk, int ndev, const int *devices) {
+    if (!plan) return fail(CDFT_ERR_ARG, "cdft_psi_create_sharded: NULL plan pointer");
+    *plan = nullptr;
+    if (npiglo < 1 || npjglo < 1 || npk < 1)
+        return fail(CDFT_ERR_ARG, "cdft_psi_create_sharded: bad sizes %d x %d x %d", npiglo, npjglo, npk);
+    cdft_psi_plan *p = new cdft_psi_plan;
+    p->npi = npiglo; p->npj = npjglo; p->npk = npk;
+    int rc = shard::make(&p->sh, npiglo, npjglo, npk, 0, ndev, devices, 0, 12);
+    if (rc == CDFT_OK) rc = shard::psi_parts(*p->sh);
+    if (rc != CDFT_OK) { cdft_psi_destroy(p); return rc; }
+    *plan = p;
+    return CDFT_OK;
+}
+
+#define CDFT_PSI_ONE_DEVICE(p, name)                                                                                  \
+    if ((p) && (p)->sh)                                                                                               \
+        return fail(CDFT_ERR_STATE, name ": a sharded plan offers cdft_psi_compute only (the staged entry points and " \
+                                         "-open work on one device's plan)")
+
 int cdft_psi_integrate(cdft_psi_plan *p, const float *zu, const float *e2u, const float *e3u, const float *zv,
                        const float *e1v, const float *e3v, const float *e31d, int in_space, void *stream) {
     if (!p) return fail(CDFT_ERR_ARG, "cdft_psi_integrate: NULL plan");
+    CDFT_PSI_ONE_DEVICE(p, "cdft_psi_integrate");
     const bool lu = zu != nullptr, lv = zv != nullptr;
     if (!lu && !lv) return fail(CDFT_ERR_ARG, "cdft_psi: give the U set, the V set, or both (-mean)");
     if ((lu && (!e2u || (!e3u && !e31d))) || (lv && (!e1v || (!e3v && !e31d))))
@@ -762,6 +825,7 @@ int cdft_psi_integrate(cdft_psi_plan *p, const float *zu, const float *e2u, cons
 int cdft_psi_scan_u(cdft_psi_plan *p, const double *carry, int carry_space, int first_block, double *last_row,
                     int last_space, void *stream) {
     if (!p) return fail(CDFT_ERR_ARG, "cdft_psi_scan_u: NULL plan");
+    CDFT_PSI_ONE_DEVICE(p, "cdft_psi_scan_u");
     if (!p->lu) return CDFT_OK;                          // V-only: nothing runs along j
     hipStream_t st = as_stream(stream);
     const void *dc = nullptr;
@@ -785,6 +849,7 @@ int cdft_psi_scan_u(cdft_psi_plan *p, const double *carry, int carry_space, int 
 
 int cdft_psi_scan_open(cdft_psi_plan *p, int lmean, void *stream) {
     if (!p) return fail(CDFT_ERR_ARG, "cdft_psi_scan_open: NULL plan");
+    CDFT_PSI_ONE_DEVICE(p, "cdft_psi_scan_open");
     if (!p->lu || !p->lv) return fail(CDFT_ERR_STATE, "cdft_psi_scan_open: -open needs both transports (cdft_psi_integrate with U and V)");
     if (p->npi < 3 || p->npj < 3) return fail(CDFT_ERR_ARG, "cdft_psi_scan_open: npiglo, npjglo >= 3 required");
     hipStream_t st = as_stream(stream);
@@ -803,6 +868,7 @@ int cdft_psi_scan_open(cdft_psi_plan *p, int lmean, void *stream) {
 
 int cdft_psi_value(cdft_psi_plan *p, int ii, int ij, double *value, void *stream) {
     if (!p || !value) return fail(CDFT_ERR_ARG, "cdft_psi_value: NULL argument");
+    CDFT_PSI_ONE_DEVICE(p, "cdft_psi_value");
     if (ii < 1 || ii > p->npi || ij < 1 || ij > p->npj)
         return fail(CDFT_ERR_ARG, "cdft_psi_value: point (%d,%d) outside the local block", ii, ij);
     hipStream_t st = as_stream(stream);
@@ -818,6 +884,7 @@ int cdft_psi_value(cdft_psi_plan *p, int ii, int ij, double *value, void *stream
 int cdft_psi_finish(cdft_psi_plan *p, int use_ref, double ref_value, int iiref, int ijref, const float *fmask,
                     int mask_space, float *psi4, double *dpsi8, int out_space, void *stream) {
     if (!p || !psi4) return fail(CDFT_ERR_ARG, "cdft_psi_finish: NULL argument");
+    CDFT_PSI_ONE_DEVICE(p, "cdft_psi_finish");
     if (!p->lu && !p->lv) return fail(CDFT_ERR_STATE, "cdft_psi_finish: cdft_psi_integrate has not run");
     if (!use_ref && (iiref < 1 || iiref > p->npi || ijref < 1 || ijref > p->npj))
         return fail(CDFT_ERR_ARG, "cdft_psi: reference point (%d,%d) outside the domain", iiref, ijref);
@@ -845,6 +912,10 @@ int cdft_psi_compute(cdft_psi_plan *p, const float *zu, const float *e2u, const 
                      const float *e1v, const float *e3v, const float *e31d, int iiref, int ijref,
                      const float *fmask, int in_space, float *psi4, double *dpsi8, int out_space, void *stream) {
     if (!p || !psi4) return fail(CDFT_ERR_ARG, "cdft_psi_compute: NULL argument");
+    if (p->sh) {
+        if (in_space == CDFT_MEM_DEVICE) CDFT_HIP(hipStreamSynchronize(as_stream(stream)));
+        return shard::psi_compute(*p->sh, zu, e2u, e3u, zv, e1v, e3v, e31d, iiref, ijref, fmask, psi4, dpsi8);
+    }
     if (iiref < 1 || iiref > p->npi || ijref < 1 || ijref > p->npj)
         return fail(CDFT_ERR_ARG, "cdft_psi_compute: reference point (%d,%d) outside the domain", iiref, ijref);
     CDFT_TRY(cdft_psi_integrate(p, zu, e2u, e3u, zv, e1v, e3v, e31d, in_space, stream));
@@ -854,6 +925,12 @@ int cdft_psi_compute(cdft_psi_plan *p, const float *zu, const float *e2u, const 
 
 int cdft_psi_destroy(cdft_psi_plan *p) {
     if (!p) return CDFT_OK;
+    if (p->sh) {
+        (void)shard::for_blocks(*p->sh, [&](int b) { return cdft_psi_destroy((cdft_psi_plan *)p->sh->part[b]); });
+        shard::destroy(p->sh);
+        delete p;
+        return CDFT_OK;
+    }
     void *ptrs[] = {p->dtrpu, p->dtrpv, p->dpsiu, p->dpsiv, p->d8, p->p4};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     DevBuf *bufs[] = {&p->su, &p->se3u, &p->sv, &p->se3v, &p->sm0, &p->sm1, &p->sfm, &p->s1d, &p->scar};

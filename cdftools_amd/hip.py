@@ -85,13 +85,31 @@ class Timer:
             pass
 
 
-class MocPlan:
-    """cdfmoc hot path (src/cdfmoc.f90:325-388) on one GPU: cdft_moc_* of the C ABI."""
+def shard_from_env():
+    """CDFT_GPU_MAP / CDFT_GPUS as the drop-in programs read them (cdft_shard_from_env) -> list of device numbers,
+    one per row block ([-1] = one block on the current device: no sharding)."""
+    n = C.c_int(0)
+    dev = (C.c_int * 64)()
+    check(_lib.load().cdft_shard_from_env(C.byref(n), dev, 64))
+    return [dev[i] for i in range(n.value)]
 
-    def __init__(self, npiglo: int, npjglo: int, npk: int, nbasins: int):
+
+def _devs(devices):
+    arr = (C.c_int * len(devices))(*[int(d) for d in devices])
+    return len(devices), arr
+
+
+class MocPlan:
+    """cdfmoc hot path (src/cdfmoc.f90:325-388): cdft_moc_* of the C ABI.  devices=[d0, d1, ..]: a sharded plan, one
+    row block per entry (block b on HIP device d_b); the arrays handed to it are the full domain's."""
+
+    def __init__(self, npiglo: int, npjglo: int, npk: int, nbasins: int, devices=None):
         self.npi, self.npj, self.npk, self.nb = npiglo, npjglo, npk, nbasins
         self._h = C.c_void_p()
-        check(_lib.load().cdft_moc_create(C.byref(self._h), npiglo, npjglo, npk, nbasins))
+        if devices is None:
+            check(_lib.load().cdft_moc_create(C.byref(self._h), npiglo, npjglo, npk, nbasins))
+        else:
+            check(_lib.load().cdft_moc_create_sharded(C.byref(self._h), npiglo, npjglo, npk, nbasins, *_devs(devices)))
 
     def set_mesh(self, e1v, e3v, ibmask, vmask=None, stream=None):
         """e1v (npj,npi) r4; e3v (npk,npj,npi) r4 already * vmask -- or the raw metric with vmask (npk,npj,npi) i1 given,
@@ -282,10 +300,13 @@ class HeatcPlan(_Plan):
 
     _destroy = "cdft_heatc_destroy"
 
-    def __init__(self, npiglo, npjglo, npk):
+    def __init__(self, npiglo, npjglo, npk, devices=None):
         self.npi, self.npj, self.npk = npiglo, npjglo, npk
         self._h = C.c_void_p()
-        check(_lib.load().cdft_heatc_create(C.byref(self._h), npiglo, npjglo, npk))
+        if devices is None:
+            check(_lib.load().cdft_heatc_create(C.byref(self._h), npiglo, npjglo, npk))
+        else:
+            check(_lib.load().cdft_heatc_create_sharded(C.byref(self._h), npiglo, npjglo, npk, *_devs(devices)))
 
     def set_mesh(self, e1t, e2t, tmask, e3t=None, e31d=None, stream=None):
         """e1t,e2t (npj,npi) r4; tmask (npk,npj,npi) uint8/int8 0-1 bytes or r4; e3t (npk,npj,npi) r4
@@ -333,10 +354,13 @@ class MhstPlan(_Plan):
 
     _destroy = "cdft_mhst_destroy"
 
-    def __init__(self, npiglo, npjglo, npk, nbasins):
+    def __init__(self, npiglo, npjglo, npk, nbasins, devices=None):
         self.npi, self.npj, self.npk, self.nb = npiglo, npjglo, npk, nbasins
         self._h = C.c_void_p()
-        check(_lib.load().cdft_mhst_create(C.byref(self._h), npiglo, npjglo, npk, nbasins))
+        if devices is None:
+            check(_lib.load().cdft_mhst_create(C.byref(self._h), npiglo, npjglo, npk, nbasins))
+        else:
+            check(_lib.load().cdft_mhst_create_sharded(C.byref(self._h), npiglo, npjglo, npk, nbasins, *_devs(devices)))
 
     def set_mesh(self, e1v, masks, e3v=None, e31d=None, stream=None):
         """e1v (npj,npi); masks (nb,npj,npi) r4, slab 0 global; e3v (npk,npj,npi) or e31d (npk)."""
@@ -364,10 +388,13 @@ class PsiPlan(_Plan):
 
     _destroy = "cdft_psi_destroy"
 
-    def __init__(self, npiglo, npjglo, npk):
+    def __init__(self, npiglo, npjglo, npk, devices=None):
         self.npi, self.npj, self.npk = npiglo, npjglo, npk
         self._h = C.c_void_p()
-        check(_lib.load().cdft_psi_create(C.byref(self._h), npiglo, npjglo, npk))
+        if devices is None:
+            check(_lib.load().cdft_psi_create(C.byref(self._h), npiglo, npjglo, npk))
+        else:
+            check(_lib.load().cdft_psi_create_sharded(C.byref(self._h), npiglo, npjglo, npk, *_devs(devices)))
 
     # --- the stages used when the domain is row-block partitioned (cdftools_amd/shard.py) ---
     def integrate(self, zu=None, e2u=None, e3u=None, zv=None, e1v=None, e3v=None, e31d=None, stream=None):
@@ -438,10 +465,10 @@ class PsiPlan(_Plan):
         return p4, d8
 
 
-def vt_compute(u, v, t, s, e3u=None, e3v=None, out_r4=False, stream=None):
+def vt_compute(u, v, t, s, e3u=None, e3v=None, out_r4=False, stream=None, devices=None):
     """cdfvT (src/cdfvT.f90:160-259).  u, v, t, s: (nframes,npk,npj,npi) r4 (NumPy: host; torch CUDA:
     resident).  -> dict of (npk,npj,npi) arrays vt, vs, ut, us (+ e3u, e3v with -vvl), r8 or r4,
-    in the memory space of the inputs."""
+    in the memory space of the inputs.  devices=[..]: row blocks on those devices (cdft_vt_compute_sharded)."""
     names = ("u", "v", "t", "s", "e3u", "e3v")
     a = [_opt(x, n) for x, n in zip((u, v, t, s, e3u, e3v), names)]
     sp = _same_space(*[x[1] for x in a])
@@ -455,6 +482,14 @@ def vt_compute(u, v, t, s, e3u=None, e3v=None, out_r4=False, stream=None):
     else:
         o = {k: np.empty((npk, npj, npi), np.float32 if out_r4 else np.float64) for k in keys}
         ptr = {k: C.c_void_p(x.ctypes.data) for k, x in o.items()}
+    if devices is not None:
+        if sp == MEM_DEVICE:
+            torch.cuda.synchronize()              # the blocks run on their own streams: the inputs must be complete
+        check(_lib.load().cdft_vt_compute_sharded(a[0][0], a[1][0], a[2][0], a[3][0], a[4][0], a[5][0], npk * npj * npi, nfr,
+                                                  npi, npj, npk, ptr["vt"], ptr["vs"], ptr["ut"], ptr["us"],
+                                                  ptr.get("e3u", _null()), ptr.get("e3v", _null()), 1 if out_r4 else 0,
+                                                  *_devs(devices)))
+        return o
     check(_lib.load().cdft_vt_compute(a[0][0], a[1][0], a[2][0], a[3][0], a[4][0], a[5][0], npk * npj * npi, nfr,
                                       npi, npj, npk, sp, ptr["vt"], ptr["vs"], ptr["ut"], ptr["us"],
                                       ptr.get("e3u", _null()), ptr.get("e3v", _null()), 1 if out_r4 else 0, sp,

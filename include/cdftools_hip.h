@@ -66,6 +66,30 @@ int         cdft_timer_elapsed_ms(void *timer, float *ms); /* synchronises on th
 int         cdft_timer_destroy(void *timer);
 
 /* ------------------------------------------------------------------------------------------ */
+/* sharded plans : ONE process, several GPUs of the node, row-block (j) partition              */
+/*   The reference's only parallel split of these loops is OpenMP over jj                      */
+/*   (src/cdfmoc.f90:369-377, :382-388); this is its analogue on a multi-GPU node, behind the  */
+/*   same boundary.  A plan made by cdft_<tool>_create_sharded owns one single-device plan per */
+/*   row block (block b on devices[b], rows split as evenly as possible, south to north) and   */
+/*   is then used through the SAME entry points as a plan of cdft_<tool>_create:               */
+/*     - array arguments are the caller's FULL-DOMAIN arrays, host or device memory alike;     */
+/*       each block's rows are moved with strided copies (blocks in parallel, one host thread  */
+/*       and one stream per block), results land in place in the caller's arrays;              */
+/*     - the calls return when every block is done (the `stream` argument is not used);        */
+/*     - cdfmoc, cdfmhst, cdfvT: rows are independent, results are bit-identical to one device;*/
+/*       cdfpsi: the running difference along j (src/cdfpsi.f90:395-398) is chained through   */
+/*       the blocks in order, 8*npiglo bytes from HBM to HBM per hop, bit-identical as well;   */
+/*       cdfheatc: the blocks' (npk,3) r8 sums are added in block order (1e-15 relative to one */
+/*       device: the r8 additions are regrouped, as between any two launch shapes).            */
+/*   cdft_shard_from_env reads what the drop-in programs honour:                               */
+/*     CDFT_GPU_MAP="a,b,.."  block b on HIP device map[b] (a device may appear twice: that is */
+/*                            how the path is tested on a 1-GPU box), else                     */
+/*     CDFT_GPUS=n            devices 0..n-1, else one block on the current device             */
+/*   (*ndev = 1, devices[0] = -1).                                                             */
+/* ------------------------------------------------------------------------------------------ */
+int cdft_shard_from_env(int *ndev, int *devices, int capacity);
+
+/* ------------------------------------------------------------------------------------------ */
 /* cdfmoc : meridional overturning stream function                                            */
 /*   replaces src/cdfmoc.f90:355-379 (zonal masked weighted sum, hot loop 1)                   */
 /*        and src/cdfmoc.f90:382-388 (bottom-to-surface cumulated sum, hot loop 2)             */
@@ -75,6 +99,11 @@ typedef struct cdft_moc_plan cdft_moc_plan;
 /* npiglo,npjglo: horizontal size of the (local row block of the) domain; npk: number of levels;
  * nbasins: 1..8 (the reference uses 1 or 5, src/cdfmoc.f90:270-274). */
 int cdft_moc_create(cdft_moc_plan **plan, int npiglo, int npjglo, int npk, int nbasins);
+
+/* The same plan over ndev row blocks, block b on HIP device devices[b] (see "sharded plans" above).  -decomp
+ * (cdft_moc_decomp_*) is not offered on it: its U-point stencil and depth means cross rows. */
+int cdft_moc_create_sharded(cdft_moc_plan **plan, int npiglo, int npjglo, int npk, int nbasins, int ndev,
+                            const int *devices);
 
 /* Time-invariant inputs (once per run; once per record with -vvl, src/cdfmoc.f90:343-348):
  *   e1v    (npiglo,npjglo)         r4  src/cdfmoc.f90:306
@@ -177,6 +206,7 @@ typedef struct cdft_heatc_plan cdft_heatc_plan;
 
 /* sizes of the (zoomed) working window, as the reference's npiglo/npjglo/nvpk after -zoom */
 int cdft_heatc_create(cdft_heatc_plan **plan, int npiglo, int npjglo, int npk);
+int cdft_heatc_create_sharded(cdft_heatc_plan **plan, int npiglo, int npjglo, int npk, int ndev, const int *devices);
 /* e1t,e2t (npiglo,npjglo) r4 src/cdfheatc.f90:188-189; exactly one of
  *   e3t  (npiglo,npjglo,npk) r4  (:216, again per record with -vvl)  or
  *   e31d (npk) r4                (-full, :213)
@@ -199,6 +229,8 @@ int cdft_heatc_destroy(cdft_heatc_plan *plan);
 typedef struct cdft_mhst_plan cdft_mhst_plan;
 
 int cdft_mhst_create(cdft_mhst_plan **plan, int npiglo, int npjglo, int npk, int nbasins);
+/* sharded: every block but the last also reads the row north of it (the V,T,S form looks at T, S of row j+1, :318) */
+int cdft_mhst_create_sharded(cdft_mhst_plan **plan, int npiglo, int npjglo, int npk, int nbasins, int ndev, const int *devices);
 /* e1v (npiglo,npjglo) r4 :276; exactly one of e3v (npiglo,npjglo,npk) r4 (:330, again per record
  * with -vvl) or e31d (npk) r4 (-full, :329); masks (npiglo,npjglo,nbasins) r4: slab 0 is the global
  * mask (vmask level 1, summed over ji = 2..npiglo-1 only, :340-344), the others are the basin masks
@@ -330,6 +362,9 @@ int cdft_mocsig_release(void);   /* frees the staging buffers of cdft_mocsig_com
 typedef struct cdft_psi_plan cdft_psi_plan;
 
 int cdft_psi_create(cdft_psi_plan **plan, int npiglo, int npjglo, int npk);
+/* sharded ("sharded plans" above): offers cdft_psi_compute (default, -V, -mean, -mask, -ref, -full); the staged entry
+ * points below and -open belong to one device's plan (-open integrates along the row npjglo-2 of the whole domain). */
+int cdft_psi_create_sharded(cdft_psi_plan **plan, int npiglo, int npjglo, int npk, int ndev, const int *devices);
 /* One record.  U set (default path): zu (npiglo,npjglo,npk), e2u (npiglo,npjglo), e3u (3-D) r4;
  * V set (-V): zv, e1v, e3v; both sets = -mean.  e31d (npk) replaces the 3-D e3 with -full.
  * (iiref,ijref): 1-based reference point, default (npiglo,npjglo) (:203-206); fmask (npiglo,npjglo)
@@ -378,6 +413,12 @@ int cdft_vt_compute(const float *u, const float *v, const float *t, const float 
                     const float *e3v, int64_t fstride, int nframes, int npiglo, int npjglo, int npk,
                     int in_space, void *vt, void *vs, void *ut, void *us, void *e3um, void *e3vm,
                     int out_is_r4, int out_space, void *stream);
+/* The same over ndev row blocks, block b on HIP device devices[b] ("sharded plans" above): every block but the last also
+ * reads the row north of it (T_v looks at jj+1, :205); arrays in any memory space, returns when all blocks are done. */
+int cdft_vt_compute_sharded(const float *u, const float *v, const float *t, const float *s, const float *e3u,
+                            const float *e3v, int64_t fstride, int nframes, int npiglo, int npjglo, int npk,
+                            void *vt, void *vs, void *ut, void *us, void *e3um, void *e3vm, int out_is_r4, int ndev,
+                            const int *devices);
 int cdft_stencil_release(void);   /* frees the staging buffers cdft_vt_compute uses for host arrays */
 
 /* ------------------------------------------------------------------------------------------ */

@@ -1,0 +1,196 @@
+"""Row-block sharded plans behind the C ABI (include/cdftools_hip.h "sharded plans", cdftools_amd/csrc/shard.hip): one
+process, one single-device plan per row block, the caller's full-domain arrays scattered and the results landed in
+place.  On this 1-GPU box every block is mapped to device 0 (devices=[0,0,..] == CDFT_GPU_MAP=0,0,..): the code path --
+threads, streams, strided copies, the halo rows, the carry of cdfpsi handed from block to block -- is the one a
+multi-GPU node runs, only the peer copies stay inside one HBM.
+
+Stated results: cdfmoc, cdfmhst, cdfvT, cdfpsi BIT-IDENTICAL to the one-device plan (rows are independent; the psi scan
+is chained in order); cdfheatc within 1e-13 * sum|terms| (block sums added in block order)."""
+import numpy as np
+import pytest
+
+import lift_cases as lc
+import oracle_tools as ot
+import synth
+
+f32 = np.float32
+BLOCKS = [[0, 0], [0, 0, 0], [0] * 5]
+
+
+def test_shard_from_env_parsing(monkeypatch):
+    from cdftools_amd import hip
+    monkeypatch.delenv("CDFT_GPUS", raising=False)
+    monkeypatch.delenv("CDFT_GPU_MAP", raising=False)
+    assert hip.shard_from_env() == [-1]
+    monkeypatch.setenv("CDFT_GPUS", "1")
+    for bad in ("x", "0", "-2"):
+        monkeypatch.setenv("CDFT_GPUS", bad)
+        with pytest.raises(hip.CdftError):
+            hip.shard_from_env()
+    monkeypatch.setenv("CDFT_GPU_MAP", "0,,a")
+    with pytest.raises(hip.CdftError):
+        hip.shard_from_env()
+    # more devices than the box has (none here, one on the GPU box) is refused with a message, not a crash
+    monkeypatch.setenv("CDFT_GPU_MAP", "0,63")
+    with pytest.raises(hip.CdftError) as e:
+        hip.shard_from_env()
+    assert "device 63" in str(e.value) or "device 0" in str(e.value)
+
+
+@pytest.mark.gpu
+def test_shard_from_env_on_the_gpu_box(gpu, monkeypatch):
+    monkeypatch.setenv("CDFT_GPU_MAP", "0, 0,0")
+    assert gpu.shard_from_env() == [0, 0, 0]
+    monkeypatch.delenv("CDFT_GPU_MAP")
+    monkeypatch.setenv("CDFT_GPUS", "1")
+    assert gpu.shard_from_env() == [0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices", BLOCKS)
+@pytest.mark.parametrize("npi,npj,npk,nb", [(37, 29, 9, 5), (182, 149, 31, 5), (130, 11, 4, 1)])
+def test_sharded_moc_is_bit_identical_to_one_device(gpu, devices, npi, npj, npk, nb):
+    import torch
+    g = synth.make_grid(npi, npj, npk, seed=npi, nbasins=nb)
+    e1v, e3v, ib = synth.moc_inputs(g, nb)
+    zv = synth.velocity(g, 3, seed=5)
+    one = gpu.MocPlan(npi, npj, npk, nb)
+    one.set_mesh(e1v, e3v, ib)
+    ref = one.compute(zv)
+    sh = gpu.MocPlan(npi, npj, npk, nb, devices=devices)
+    sh.set_mesh(e1v, e3v, ib)
+    assert np.array_equal(sh.compute(zv), ref)
+    # raw metric + byte mask (cdft_moc_set_mesh_vmask), arrays resident in HBM, result in HBM
+    sh.set_mesh(torch.from_numpy(e1v).cuda(), torch.from_numpy(g["e3v_0"]).cuda(), torch.from_numpy(ib).cuda(),
+                vmask=torch.from_numpy(g["vmask"].astype(np.int8)).cuda())
+    got = sh.compute(torch.from_numpy(zv).cuda())
+    assert np.array_equal(got.cpu().numpy(), ref)
+    # a record stride larger than a record
+    pad = np.zeros((3, npk * npj * npi + 7), f32)
+    pad[:, : npk * npj * npi] = zv.reshape(3, -1)
+    assert np.array_equal(sh.compute(pad, rec_stride=pad.shape[1], npt=3), ref)
+    with pytest.raises(gpu.CdftError):
+        sh.decomp_set_mesh(e3v, g["e1u"], g["e1u"], g["gdept_1d"], g["tmask"], g["umask"])
+    assert "moc_zonal" in sh.describe()
+
+
+@pytest.mark.gpu
+def test_sharded_moc_rejects_bad_masks_and_too_many_blocks(gpu):
+    g = synth.make_grid(24, 6, 4, seed=1)
+    e1v, e3v, ib = synth.moc_inputs(g)
+    with pytest.raises(gpu.CdftError):
+        gpu.MocPlan(24, 6, 4, 5, devices=[0] * 7)                 # more blocks than rows
+    with pytest.raises(gpu.CdftError):
+        gpu.MocPlan(24, 6, 4, 5, devices=[0, 99])
+    sh = gpu.MocPlan(24, 6, 4, 5, devices=[0, 0])
+    bad = ib.copy()
+    bad[5, 3, 1] = 2                                              # in the second block
+    with pytest.raises(gpu.CdftError) as e:
+        sh.set_mesh(e1v, e3v, bad)
+    assert "row block 1" in str(e.value)
+    with pytest.raises(gpu.CdftError):
+        sh.compute(synth.velocity(g, 1))                         # no mesh
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices", BLOCKS)
+def test_sharded_heatc_matches_one_device(gpu, devices):
+    for name in ("default", "full", "mxl_in", "mxl_out"):
+        g, temp, full, mxlopt, mxl = lc.heatc_case(name)
+        npk, npj, npi = g["tmask"].shape
+        mesh = dict(e31d=g["e3t_1d"]) if full else dict(e3t=g["e3t_0"])
+        one = gpu.HeatcPlan(npi, npj, npk)
+        one.set_mesh(g["e1t"], g["e2t"], g["tmask"].astype(np.uint8), **mesh)
+        sh = gpu.HeatcPlan(npi, npj, npk, devices=devices)
+        sh.set_mesh(g["e1t"], g["e2t"], g["tmask"].astype(np.uint8), **mesh)
+        for t in range(temp.shape[0]):
+            kw = dict(rmxldep=None if mxl is None else mxl[t], gdepw=g["gdepw_1d"], mxloption=mxlopt)
+            ref, got = one.compute(temp[t], **kw), sh.compute(temp[t], **kw)
+            bound = ot.heatc(g["e1t"], g["e2t"], g["tmask"], np.abs(temp[t]), mxl=kw["rmxldep"], gdepw=g["gdepw_1d"], mxlopt=mxlopt, **mesh)
+            assert np.all(np.abs(got - ref) <= 1e-13 * bound + 1e-300), name
+    # an r4 mask that is not 0/1 (-M)
+    g, temp, *_ = lc.heatc_case("default")
+    npk, npj, npi = g["tmask"].shape
+    m4 = (g["tmask"] * f32(0.5)).astype(f32)
+    one, sh = gpu.HeatcPlan(npi, npj, npk), gpu.HeatcPlan(npi, npj, npk, devices=devices)
+    for p in (one, sh):
+        p.set_mesh(g["e1t"], g["e2t"], m4, e3t=g["e3t_0"])
+    ref, got = one.compute(temp[0]), sh.compute(temp[0])
+    assert np.allclose(got, ref, rtol=1e-13, atol=0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices", BLOCKS)
+def test_sharded_mhst_is_bit_identical_to_one_device(gpu, devices):
+    for name in lc.MHST_CASES:
+        g, nb, kw = lc.mhst_case(name)
+        npk, npj, npi = g["tmask"].shape
+        m = np.zeros((4 if nb == 5 else 1, npj, npi), f32)
+        m[0] = g["vmask"][0]
+        if nb == 5:
+            m[1], m[2], m[3] = g["tmaskatl"], g["tmaskpac"], g["tmaskind"]
+        mesh = dict(e31d=g["e3t_1d"]) if kw["full"] else dict(e3v=g["e3v_0"])
+        one, sh = gpu.MhstPlan(npi, npj, npk, m.shape[0]), gpu.MhstPlan(npi, npj, npk, m.shape[0], devices=devices)
+        for p in (one, sh):
+            p.set_mesh(g["e1v"], m, **mesh)
+        fields = {k: kw[k] for k in ("vt", "vs", "zv", "zt", "zs") if k in kw}
+        for t in range(next(iter(fields.values())).shape[0]):
+            rec = {k: v[t] for k, v in fields.items()}
+            rh, rs = one.compute(zdim=kw["zdim"], **rec)
+            gh, gs = sh.compute(zdim=kw["zdim"], **rec)
+            assert np.array_equal(gh, rh) and np.array_equal(gs, rs), name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices", BLOCKS)
+def test_sharded_psi_is_bit_identical_to_one_device(gpu, devices):
+    import torch
+    for name in ("u", "v", "mean_mask_ref", "u_full"):
+        g, kw = lc.psi_case(name)
+        npk, npj, npi = g["tmask"].shape
+        one, sh = gpu.PsiPlan(npi, npj, npk), gpu.PsiPlan(npi, npj, npk, devices=devices)
+        fm = g["fmask"][0].astype(f32) if kw.get("mask") else None
+        for t in range(2):
+            a = {}
+            if kw["zu"] is not None:
+                a.update(zu=kw["zu"][t], e2u=g["e2u"], **({} if kw.get("full") else dict(e3u=g["e3u_0"])))
+            if kw["zv"] is not None:
+                a.update(zv=kw["zv"][t], e1v=g["e1v"], **({} if kw.get("full") else dict(e3v=g["e3v_0"])))
+            if kw.get("full"):
+                a["e31d"] = g["e3t_1d"]
+            r4, r8 = one.compute(iiref=kw.get("iiref"), ijref=kw.get("ijref"), fmask=fm, **a)
+            g4, g8 = sh.compute(iiref=kw.get("iiref"), ijref=kw.get("ijref"), fmask=fm, **a)
+            assert np.array_equal(g4, r4) and np.array_equal(g8, r8), name
+            # the reference point in every block in turn
+            for ij in (1, npj // 2, npj):
+                r4, r8 = one.compute(iiref=3, ijref=ij, **a)
+                g4, g8 = sh.compute(iiref=3, ijref=ij, **a)
+                assert np.array_equal(g4, r4) and np.array_equal(g8, r8), (name, ij)
+            # arrays and results resident in HBM
+            d = {k: torch.from_numpy(np.ascontiguousarray(v, f32)).cuda() for k, v in a.items()}
+            g4, g8 = sh.compute(host_out=False, **d)
+            r4, r8 = one.compute(**a)
+            assert np.array_equal(g4.cpu().numpy(), r4) and np.array_equal(g8.cpu().numpy(), r8)
+    with pytest.raises(gpu.CdftError):
+        sh.scan_open()                                            # staged entry points: one device's plan only
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices", BLOCKS)
+def test_sharded_vt_is_bit_identical_to_one_device(gpu, devices):
+    import torch
+    for name in ("tags2x3", "vvl"):
+        u, v, t, s, e3u, e3v = lc.vt_case(name)
+        fl = lambda x: None if x is None else np.ascontiguousarray(x.reshape((-1,) + x.shape[2:]))     # noqa: E731
+        a = [fl(x) for x in (u, v, t, s)]
+        for out_r4 in (False, True):
+            ref = gpu.vt_compute(*a, e3u=fl(e3u), e3v=fl(e3v), out_r4=out_r4)
+            got = gpu.vt_compute(*a, e3u=fl(e3u), e3v=fl(e3v), out_r4=out_r4, devices=devices)
+            assert set(ref) == set(got)
+            for k in ref:
+                assert np.array_equal(got[k], ref[k], equal_nan=True), (name, k)
+        d = [torch.from_numpy(x).cuda() for x in a]
+        got = gpu.vt_compute(*d, devices=devices)
+        ref = gpu.vt_compute(*a)
+        for k in ("vt", "vs", "ut", "us"):
+            assert np.array_equal(got[k].cpu().numpy(), ref[k])
