@@ -364,17 +364,15 @@ int psi_parts(ShardSet &sh) {
     });
 }
 
-int psi_compute(ShardSet &sh, const float *zu, const float *e2u, const float *e3u, const float *zv, const float *e1v,
-                const float *e3v, const float *e31d, int iiref, int ijref, const float *fmask, float *psi4, double *dpsi8) {
-    const int n = sh.nblk();
-    if (iiref < 1 || iiref > sh.npi || ijref < 1 || ijref > sh.npj)
-        return fail(CDFT_ERR_ARG, "cdft_psi_compute: reference point (%d,%d) outside the domain", iiref, ijref);
-    // 1. the vertical integrals (and the i-scan of the V path, local to a row): all blocks at once
-    CDFT_TRY(for_blocks(sh, [&](int b) {
+// the three stages of cdft_psi_* on row blocks: the staged entry points of a sharded plan land here
+int psi_integrate(ShardSet &sh, const float *zu, const float *e2u, const float *e3u, const float *zv, const float *e1v,
+                  const float *e3v, const float *e31d) {
+    // the vertical integrals (and the i-scan of the V path, local to a row): all blocks at once
+    return for_blocks(sh, [&](int b) {
         const int j0 = sh.j0[b], j1 = sh.j1[b], nloc = j1 - j0;
         const size_t nij = (size_t)sh.npi * nloc, n3 = nij * sh.npk;
         hipStream_t st = sh.st[b];
-        DevBuf *B = sh.buf[b].data();            // 0: zu 1: e2u 2: e3u 3: zv 4: e1v 5: e3v 6: e31d 7: fmask 8: carry 9: last
+        DevBuf *B = sh.buf[b].data();            // 0: zu 1: e2u 2: e3u 3: zv 4: e1v 5: e3v 6: e31d 7: fmask 8: carry 9: last 10: psi4 11: dpsi8
         const float *src3[2][2] = {{zu, e3u}, {zv, e3v}};
         const float *src2[2] = {e2u, e1v};
         for (int c = 0; c < 2; ++c) {
@@ -392,10 +390,6 @@ int psi_compute(ShardSet &sh, const float *zu, const float *e2u, const float *e3
             CDFT_TRY(B[6].reserve((size_t)sh.npk * 4));
             CDFT_HIP(hipMemcpyAsync(B[6].ptr, e31d, (size_t)sh.npk * 4, hipMemcpyDefault, st));
         }
-        if (fmask) {
-            CDFT_TRY(B[7].reserve(nij * 4));
-            CDFT_TRY(rows_in(B[7].ptr, fmask, (size_t)sh.npi * 4, sh.npj, j0, j1, 1, 0, st));
-        }
         CDFT_TRY(B[8].reserve((size_t)sh.npi * 8));
         CDFT_TRY(B[9].reserve((size_t)sh.npi * 8));
         auto f = [&](int i, const float *given) { return given ? (const float *)B[i].ptr : nullptr; };
@@ -403,36 +397,59 @@ int psi_compute(ShardSet &sh, const float *zu, const float *e2u, const float *e3
                                     f(4, zv ? e1v : nullptr), f(5, zv ? e3v : nullptr), f(6, e31d), CDFT_MEM_DEVICE, st));
         CDFT_HIP(hipStreamSynchronize(st));
         return CDFT_OK;
-    }));
-    // 2. the running difference along j crosses the blocks (src/cdfpsi.f90:395-398): visit them south to north, the
-    //    last row of one is the carry of the next -- 8*npiglo bytes from HBM to HBM
+    });
+}
+
+int psi_scan_u(ShardSet &sh) {
+    // the running difference along j crosses the blocks (src/cdfpsi.f90:395-398): visit them south to north, the
+    // last row of one is the carry of the next -- 8*npiglo bytes from HBM to HBM
+    const int n = sh.nblk();
     int cur = 0;
     (void)hipGetDevice(&cur);
     for (int b = 0; b < n; ++b) {
         CDFT_HIP(hipSetDevice(sh.dev[b]));
         DevBuf *B = sh.buf[b].data();
+        if (!B[8].ptr || !B[9].ptr) { (void)hipSetDevice(cur); return fail(CDFT_ERR_STATE, "cdft_psi_scan_u: cdft_psi_integrate has not run"); }
         if (b > 0) {
             CDFT_HIP(hipMemcpyPeerAsync(B[8].ptr, sh.dev[b], sh.buf[b - 1][9].ptr, sh.dev[b - 1], (size_t)sh.npi * 8, sh.st[b]));
         }
         int rc = cdft_psi_scan_u((cdft_psi_plan *)sh.part[b], b > 0 ? (const double *)B[8].ptr : nullptr, CDFT_MEM_DEVICE, b == 0 ? 1 : 0,
                                  (double *)B[9].ptr, CDFT_MEM_DEVICE, sh.st[b]);
-        if (rc == CDFT_OK && hipStreamSynchronize(sh.st[b]) != hipSuccess) rc = fail(CDFT_ERR_HIP, "cdft_psi_compute: scan of block %d failed", b);
+        if (rc == CDFT_OK && hipStreamSynchronize(sh.st[b]) != hipSuccess) rc = fail(CDFT_ERR_HIP, "cdft_psi_scan_u: scan of block %d failed", b);
         if (rc != CDFT_OK) { (void)hipSetDevice(cur); return rc; }
     }
-    // 3. the value at the reference point (:423) from the block that owns it
-    double ref = 0.0;
-    for (int b = 0; b < n; ++b)
-        if (ijref > sh.j0[b] && ijref <= sh.j1[b]) {
+    (void)hipSetDevice(cur);
+    return CDFT_OK;
+}
+
+int psi_value(ShardSet &sh, int ii, int ij, double *value) {
+    if (ii < 1 || ii > sh.npi || ij < 1 || ij > sh.npj)
+        return fail(CDFT_ERR_ARG, "cdft_psi_value: point (%d,%d) outside the domain", ii, ij);
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    int rc = CDFT_OK;
+    for (int b = 0; b < sh.nblk(); ++b)
+        if (ij > sh.j0[b] && ij <= sh.j1[b]) {                  // the block that owns the row
             CDFT_HIP(hipSetDevice(sh.dev[b]));
-            int rc = cdft_psi_value((cdft_psi_plan *)sh.part[b], iiref, ijref - sh.j0[b], &ref, sh.st[b]);
-            if (rc != CDFT_OK) { (void)hipSetDevice(cur); return rc; }
+            rc = cdft_psi_value((cdft_psi_plan *)sh.part[b], ii, ij - sh.j0[b], value, sh.st[b]);
         }
     (void)hipSetDevice(cur);
-    // 4. normalisation, mask, SNGL: every block writes its rows of the caller's arrays
+    return rc;
+}
+
+int psi_finish(ShardSet &sh, int use_ref, double ref_value, int iiref, int ijref, const float *fmask, float *psi4, double *dpsi8) {
+    double ref = ref_value;
+    if (!use_ref) CDFT_TRY(psi_value(sh, iiref, ijref, &ref));      // :423, from the block that owns the point
+    // normalisation, mask, SNGL: every block writes its rows of the caller's arrays
     return for_blocks(sh, [&](int b) {
-        const size_t off = (size_t)sh.npi * sh.j0[b], nij = (size_t)sh.npi * (sh.j1[b] - sh.j0[b]);
+        const int j0 = sh.j0[b], j1 = sh.j1[b];
+        const size_t off = (size_t)sh.npi * j0, nij = (size_t)sh.npi * (j1 - j0);
         DevBuf *B = sh.buf[b].data();
         hipStream_t st = sh.st[b];
+        if (fmask) {
+            CDFT_TRY(B[7].reserve(nij * 4));
+            CDFT_TRY(rows_in(B[7].ptr, fmask, (size_t)sh.npi * 4, sh.npj, j0, j1, 1, 0, st));
+        }
         CDFT_TRY(B[10].reserve(nij * 4));
         if (dpsi8) CDFT_TRY(B[11].reserve(nij * 8));
         CDFT_TRY(cdft_psi_finish((cdft_psi_plan *)sh.part[b], 1, ref, 1, 1, fmask ? (const float *)B[7].ptr : nullptr, CDFT_MEM_DEVICE,

@@ -495,8 +495,11 @@ int mhst_set_mesh(ShardSet &sh, const float *e1v, const float *e3v, const float 
 int mhst_compute(ShardSet &sh, const float *vt, const float *vs, const float *zv, const float *zt, const float *zs, int zdim,
                  double *heat, double *salt);
 int psi_parts(ShardSet &sh);
-int psi_compute(ShardSet &sh, const float *zu, const float *e2u, const float *e3u, const float *zv, const float *e1v,
-                const float *e3v, const float *e31d, int iiref, int ijref, const float *fmask, float *psi4, double *dpsi8);
+int psi_integrate(ShardSet &sh, const float *zu, const float *e2u, const float *e3u, const float *zv, const float *e1v,
+                  const float *e3v, const float *e31d);
+int psi_scan_u(ShardSet &sh);
+int psi_value(ShardSet &sh, int ii, int ij, double *value);
+int psi_finish(ShardSet &sh, int use_ref, double ref_value, int iiref, int ijref, const float *fmask, float *psi4, double *dpsi8);
 } }
 
 struct cdft_mhst_plan {
@@ -781,15 +784,14 @@ int cdft_psi_create_sharded(cdft_psi_plan **plan, int npiglo, int npjglo, int np
     return CDFT_OK;
 }
 
-#define CDFT_PSI_ONE_DEVICE(p, name)                                                                                  \
-    if ((p) && (p)->sh)                                                                                               \
-        return fail(CDFT_ERR_STATE, name ": a sharded plan offers cdft_psi_compute only (the staged entry points and " \
-                                         "-open work on one device's plan)")
-
 int cdft_psi_integrate(cdft_psi_plan *p, const float *zu, const float *e2u, const float *e3u, const float *zv,
                        const float *e1v, const float *e3v, const float *e31d, int in_space, void *stream) {
     if (!p) return fail(CDFT_ERR_ARG, "cdft_psi_integrate: NULL plan");
-    CDFT_PSI_ONE_DEVICE(p, "cdft_psi_integrate");
+    if (p->sh) {
+        if ((zu && !e2u) || (zv && !e1v) || (!zu && !zv)) return fail(CDFT_ERR_ARG, "cdft_psi: each velocity needs its horizontal metric");
+        if (in_space == CDFT_MEM_DEVICE) CDFT_HIP(hipStreamSynchronize(as_stream(stream)));
+        return shard::psi_integrate(*p->sh, zu, e2u, e3u, zv, e1v, e3v, e31d);
+    }
     const bool lu = zu != nullptr, lv = zv != nullptr;
     if (!lu && !lv) return fail(CDFT_ERR_ARG, "cdft_psi: give the U set, the V set, or both (-mean)");
     if ((lu && (!e2u || (!e3u && !e31d))) || (lv && (!e1v || (!e3v && !e31d))))
@@ -825,7 +827,11 @@ int cdft_psi_integrate(cdft_psi_plan *p, const float *zu, const float *e2u, cons
 int cdft_psi_scan_u(cdft_psi_plan *p, const double *carry, int carry_space, int first_block, double *last_row,
                     int last_space, void *stream) {
     if (!p) return fail(CDFT_ERR_ARG, "cdft_psi_scan_u: NULL plan");
-    CDFT_PSI_ONE_DEVICE(p, "cdft_psi_scan_u");
+    if (p->sh) {
+        if (carry || last_row || !first_block)
+            return fail(CDFT_ERR_ARG, "cdft_psi_scan_u: a sharded plan chains its own blocks; it takes no carry and returns no row");
+        return shard::psi_scan_u(*p->sh);
+    }
     if (!p->lu) return CDFT_OK;                          // V-only: nothing runs along j
     hipStream_t st = as_stream(stream);
     const void *dc = nullptr;
@@ -849,7 +855,8 @@ int cdft_psi_scan_u(cdft_psi_plan *p, const double *carry, int carry_space, int 
 
 int cdft_psi_scan_open(cdft_psi_plan *p, int lmean, void *stream) {
     if (!p) return fail(CDFT_ERR_ARG, "cdft_psi_scan_open: NULL plan");
-    CDFT_PSI_ONE_DEVICE(p, "cdft_psi_scan_open");
+    if (p->sh)
+        return fail(CDFT_ERR_STATE, "cdft_psi_scan_open: -open integrates along one row of the whole domain; use a plan of cdft_psi_create");
     if (!p->lu || !p->lv) return fail(CDFT_ERR_STATE, "cdft_psi_scan_open: -open needs both transports (cdft_psi_integrate with U and V)");
     if (p->npi < 3 || p->npj < 3) return fail(CDFT_ERR_ARG, "cdft_psi_scan_open: npiglo, npjglo >= 3 required");
     hipStream_t st = as_stream(stream);
@@ -868,7 +875,7 @@ int cdft_psi_scan_open(cdft_psi_plan *p, int lmean, void *stream) {
 
 int cdft_psi_value(cdft_psi_plan *p, int ii, int ij, double *value, void *stream) {
     if (!p || !value) return fail(CDFT_ERR_ARG, "cdft_psi_value: NULL argument");
-    CDFT_PSI_ONE_DEVICE(p, "cdft_psi_value");
+    if (p->sh) return shard::psi_value(*p->sh, ii, ij, value);
     if (ii < 1 || ii > p->npi || ij < 1 || ij > p->npj)
         return fail(CDFT_ERR_ARG, "cdft_psi_value: point (%d,%d) outside the local block", ii, ij);
     hipStream_t st = as_stream(stream);
@@ -884,7 +891,10 @@ int cdft_psi_value(cdft_psi_plan *p, int ii, int ij, double *value, void *stream
 int cdft_psi_finish(cdft_psi_plan *p, int use_ref, double ref_value, int iiref, int ijref, const float *fmask,
                     int mask_space, float *psi4, double *dpsi8, int out_space, void *stream) {
     if (!p || !psi4) return fail(CDFT_ERR_ARG, "cdft_psi_finish: NULL argument");
-    CDFT_PSI_ONE_DEVICE(p, "cdft_psi_finish");
+    if (p->sh) {
+        if (fmask && mask_space == CDFT_MEM_DEVICE) CDFT_HIP(hipStreamSynchronize(as_stream(stream)));
+        return shard::psi_finish(*p->sh, use_ref, ref_value, iiref, ijref, fmask, psi4, dpsi8);
+    }
     if (!p->lu && !p->lv) return fail(CDFT_ERR_STATE, "cdft_psi_finish: cdft_psi_integrate has not run");
     if (!use_ref && (iiref < 1 || iiref > p->npi || ijref < 1 || ijref > p->npj))
         return fail(CDFT_ERR_ARG, "cdft_psi: reference point (%d,%d) outside the domain", iiref, ijref);
@@ -912,10 +922,6 @@ int cdft_psi_compute(cdft_psi_plan *p, const float *zu, const float *e2u, const 
                      const float *e1v, const float *e3v, const float *e31d, int iiref, int ijref,
                      const float *fmask, int in_space, float *psi4, double *dpsi8, int out_space, void *stream) {
     if (!p || !psi4) return fail(CDFT_ERR_ARG, "cdft_psi_compute: NULL argument");
-    if (p->sh) {
-        if (in_space == CDFT_MEM_DEVICE) CDFT_HIP(hipStreamSynchronize(as_stream(stream)));
-        return shard::psi_compute(*p->sh, zu, e2u, e3u, zv, e1v, e3v, e31d, iiref, ijref, fmask, psi4, dpsi8);
-    }
     if (iiref < 1 || iiref > p->npi || ijref < 1 || ijref > p->npj)
         return fail(CDFT_ERR_ARG, "cdft_psi_compute: reference point (%d,%d) outside the domain", iiref, ijref);
     CDFT_TRY(cdft_psi_integrate(p, zu, e2u, e3u, zv, e1v, e3v, e31d, in_space, stream));

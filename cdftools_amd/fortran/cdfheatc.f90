@@ -16,6 +16,7 @@ PROGRAM cdfheatc
 
   INTEGER(KIND=4), PARAMETER :: jp_hc3d = 1, jp_hc2d = 2, jp_hcvol = 3
   REAL(KIND=4),    PARAMETER :: pprho0 = 1020., ppcp = 4000.       ! src/cdfheatc.f90:39-40
+  INTEGER(C_INT)  :: ngpu, igpus(64)                          ! row blocks and their HIP devices (CDFT_GPUS, CDFT_GPU_MAP)
   INTEGER(KIND=4) :: narg, ijarg, ierr, jt, jk, ik, it
   INTEGER(KIND=4) :: iimin = 0, iimax = 0, ijmin = 0, ijmax = 0, ikmin = 0, ikmax = 0, mxloption = 0
   INTEGER(KIND=4) :: npiglo, npjglo, npk, npkk, npt, nvpk, ncout
@@ -127,7 +128,12 @@ PROGRAM cdfheatc
   END DO
 
   CALL CreateOutput
-  CALL hip_check(cdft_heatc_create(plan, npiglo, npjglo, nvpk), 'cdft_heatc_create')
+  CALL hip_shard(ngpu, igpus)                                ! CDFT_GPUS / CDFT_GPU_MAP: row blocks over the node's GPUs
+  IF ( ngpu > 1 ) THEN
+     CALL hip_check(cdft_heatc_create_sharded(plan, npiglo, npjglo, nvpk, ngpu, igpus), 'cdft_heatc_create_sharded')
+  ELSE
+     CALL hip_check(cdft_heatc_create(plan, npiglo, npjglo, nvpk), 'cdft_heatc_create')
+  ENDIF
 
   DO jt = 1, npt
      it = 1 ; IF ( lg_vvl ) it = jt

@@ -15,6 +15,7 @@ PROGRAM cdfmhst
   IMPLICIT NONE
 
   REAL(KIND=4), PARAMETER :: ppspval = 9999.99
+  INTEGER(C_INT)  :: ngpu, igpus(64)                          ! row blocks and their HIP devices (CDFT_GPUS, CDFT_GPU_MAP)
   INTEGER(KIND=4) :: narg, ijarg, ierr, jt, jk, jj, jvar, jb, it, ik0, ivar, iloc(2)
   INTEGER(KIND=4) :: npiglo, npjglo, npk, npko, npt, nbasins, nbasinso, npvar = 1, ncout, nmask, nlevo
   INTEGER(KIND=4) :: numouth = 10, numouts = 11
@@ -156,7 +157,12 @@ PROGRAM cdfmhst
 
   OPEN(numouth, FILE=cf_outh, FORM='FORMATTED', RECL=256)
   OPEN(numouts, FILE=cf_outs, FORM='FORMATTED', RECL=256)
-  CALL hip_check(cdft_mhst_create(plan, npiglo, npjglo, npk, nmask), 'cdft_mhst_create')
+  CALL hip_shard(ngpu, igpus)                                ! CDFT_GPUS / CDFT_GPU_MAP: row blocks over the node's GPUs
+  IF ( ngpu > 1 ) THEN
+     CALL hip_check(cdft_mhst_create_sharded(plan, npiglo, npjglo, npk, nmask, ngpu, igpus), 'cdft_mhst_create_sharded')
+  ELSE
+     CALL hip_check(cdft_mhst_create(plan, npiglo, npjglo, npk, nmask), 'cdft_mhst_create')
+  ENDIF
 
   DO jt = 1, npt
      it = 1 ; IF ( lg_vvl ) it = jt

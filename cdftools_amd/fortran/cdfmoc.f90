@@ -22,6 +22,7 @@ PROGRAM cdfmoc
   USE cdfmoc_rapid
   IMPLICIT NONE
 
+  INTEGER(C_INT)  :: ngpu, igpus(64)                          ! row blocks and their HIP devices (CDFT_GPUS, CDFT_GPU_MAP)
   INTEGER(KIND=4) :: narg, ijarg, ierr, ii, iv
   INTEGER(KIND=4) :: npiglo, npjglo, npk, npt, nbasins, nbasinso, nvarout
   INTEGER(KIND=4) :: jt, jk, jbasin, jr, it0, nrec, nbatch, ijvar, ncout
@@ -212,7 +213,12 @@ PROGRAM cdfmoc
   ibmask(npglo, 1,      :) = 0                            ! E-W periodic overlap, global basin only
   ibmask(npglo, npiglo, :) = 0
 
-  CALL hip_check(cdft_moc_create(plan, npiglo, npjglo, npk, nbasins), 'cdft_moc_create')
+  CALL hip_shard(ngpu, igpus)                                ! CDFT_GPUS / CDFT_GPU_MAP: row blocks over the node's GPUs
+  IF ( ngpu > 1 .AND. .NOT. ldec ) THEN                      ! (-decomp stays on one device: its stencil crosses rows)
+     CALL hip_check(cdft_moc_create_sharded(plan, npiglo, npjglo, npk, nbasins, ngpu, igpus), 'cdft_moc_create_sharded')
+  ELSE
+     CALL hip_check(cdft_moc_create(plan, npiglo, npjglo, npk, nbasins), 'cdft_moc_create')
+  ENDIF
 
   it0 = 1
   DO WHILE ( it0 <= npt )

@@ -19,6 +19,7 @@ PROGRAM cdfpsi
   USE cdftools_hip
   IMPLICIT NONE
 
+  INTEGER(C_INT)  :: ngpu, igpus(64)                          ! row blocks and their HIP devices (CDFT_GPUS, CDFT_GPU_MAP)
   INTEGER(KIND=4) :: narg, ijarg, ierr, jt, jk, it, npiglo, npjglo, npk, npt, ncout, iiref = -1, ijref = -1
   INTEGER(KIND=4) :: ipk(3), id_varout(3), nvout = 1
   REAL(KIND=4), ALLOCATABLE, TARGET :: zu(:,:,:), zv(:,:,:), e3u(:,:,:), e3v(:,:,:), e1v(:,:), e2u(:,:), zmask(:,:), e31d(:)
@@ -172,7 +173,12 @@ PROGRAM cdfpsi
      pe31d = C_LOC(e31d)
   ENDIF
 
-  CALL hip_check(cdft_psi_create(plan, npiglo, npjglo, npk), 'cdft_psi_create')
+  CALL hip_shard(ngpu, igpus)                                ! CDFT_GPUS / CDFT_GPU_MAP: row blocks over the node's GPUs
+  IF ( ngpu > 1 .AND. .NOT. lopen ) THEN                     ! (-open integrates along one row of the whole domain)
+     CALL hip_check(cdft_psi_create_sharded(plan, npiglo, npjglo, npk, ngpu, igpus), 'cdft_psi_create_sharded')
+  ELSE
+     CALL hip_check(cdft_psi_create(plan, npiglo, npjglo, npk), 'cdft_psi_create')
+  ENDIF
   IF ( lssh .OR. llev ) CALL hip_check(cdft_psi_create(plan1, npiglo, npjglo, 1), 'cdft_psi_create')
   IF ( lssh ) THEN
      ALLOCATE( zssh(npiglo,npjglo), zsshu(npiglo,npjglo), zsshv(npiglo,npjglo), zvel1(npiglo,npjglo) )

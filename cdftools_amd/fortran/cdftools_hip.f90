@@ -24,6 +24,37 @@ MODULE cdftools_hip
      INTEGER(C_INT) FUNCTION cdft_set_device(idev) BIND(C, name='cdft_set_device')
        IMPORT ; INTEGER(C_INT), VALUE :: idev
      END FUNCTION
+     ! ---- sharded plans: one process, several GPUs, row blocks (include/cdftools_hip.h "sharded plans") ------
+     INTEGER(C_INT) FUNCTION cdft_shard_from_env(ndev, devices, capacity) BIND(C, name='cdft_shard_from_env')
+       IMPORT ; INTEGER(C_INT), INTENT(out) :: ndev, devices(*) ; INTEGER(C_INT), VALUE :: capacity
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_moc_create_sharded(plan, npiglo, npjglo, npk, nbasins, ndev, devices) &
+          &         BIND(C, name='cdft_moc_create_sharded')
+       IMPORT ; TYPE(C_PTR), INTENT(out) :: plan ; INTEGER(C_INT), VALUE :: npiglo, npjglo, npk, nbasins, ndev
+       INTEGER(C_INT), INTENT(in) :: devices(*)
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_heatc_create_sharded(plan, npiglo, npjglo, npk, ndev, devices) &
+          &         BIND(C, name='cdft_heatc_create_sharded')
+       IMPORT ; TYPE(C_PTR), INTENT(out) :: plan ; INTEGER(C_INT), VALUE :: npiglo, npjglo, npk, ndev
+       INTEGER(C_INT), INTENT(in) :: devices(*)
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_mhst_create_sharded(plan, npiglo, npjglo, npk, nbasins, ndev, devices) &
+          &         BIND(C, name='cdft_mhst_create_sharded')
+       IMPORT ; TYPE(C_PTR), INTENT(out) :: plan ; INTEGER(C_INT), VALUE :: npiglo, npjglo, npk, nbasins, ndev
+       INTEGER(C_INT), INTENT(in) :: devices(*)
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_psi_create_sharded(plan, npiglo, npjglo, npk, ndev, devices) &
+          &         BIND(C, name='cdft_psi_create_sharded')
+       IMPORT ; TYPE(C_PTR), INTENT(out) :: plan ; INTEGER(C_INT), VALUE :: npiglo, npjglo, npk, ndev
+       INTEGER(C_INT), INTENT(in) :: devices(*)
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_vt_compute_sharded(u, v, t, s, e3u, e3v, fstride, nframes, npiglo, npjglo, npk, &
+          &                                  vt, vs, ut, us, e3um, e3vm, out_is_r4, ndev, devices)               &
+          &         BIND(C, name='cdft_vt_compute_sharded')
+       IMPORT ; REAL(C_FLOAT), INTENT(in) :: u(*), v(*), t(*), s(*) ; TYPE(C_PTR), VALUE :: e3u, e3v, e3um, e3vm
+       INTEGER(C_INT64_T), VALUE :: fstride ; INTEGER(C_INT), VALUE :: nframes, npiglo, npjglo, npk
+       TYPE(C_PTR), VALUE :: vt, vs, ut, us ; INTEGER(C_INT), VALUE :: out_is_r4, ndev ; INTEGER(C_INT), INTENT(in) :: devices(*)
+     END FUNCTION
      ! ---- cdfmoc ---------------------------------------------------------------------------
      INTEGER(C_INT) FUNCTION cdft_moc_create(plan, npiglo, npjglo, npk, nbasins) BIND(C, name='cdft_moc_create')
        IMPORT ; TYPE(C_PTR), INTENT(out) :: plan ; INTEGER(C_INT), VALUE :: npiglo, npjglo, npk, nbasins
@@ -239,6 +270,14 @@ MODULE cdftools_hip
   END INTERFACE
 
 CONTAINS
+
+  SUBROUTINE hip_shard(kgpu, kdev)
+    !! The row blocks the run is split into: CDFT_GPU_MAP="a,b,.." (block b on HIP device map(b)) or CDFT_GPUS=n
+    !! (devices 0..n-1); kgpu = 1 without either.  With one block on a named device that device becomes current.
+    INTEGER(C_INT), INTENT(out) :: kgpu, kdev(64)
+    CALL hip_check(cdft_shard_from_env(kgpu, kdev, 64_C_INT), 'cdft_shard_from_env')
+    IF ( kgpu == 1 .AND. kdev(1) >= 0 ) CALL hip_check(cdft_set_device(kdev(1)), 'cdft_set_device')
+  END SUBROUTINE hip_shard
 
   SUBROUTINE hip_check(kstatus, cdwhere)
     !! non-zero status of a libcdftools_hip call: print its message and stop like a NetCDF failure

@@ -17,6 +17,7 @@ PROGRAM cdfvT
   USE cdftools_hip
   IMPLICIT NONE
 
+  INTEGER(C_INT)  :: ngpu, igpus(64)                          ! row blocks and their HIP devices (CDFT_GPUS, CDFT_GPU_MAP)
   INTEGER(KIND=4) :: narg, ijarg, ierr, jk, jt, jtt, jv, npiglo, npjglo, npk, npt, ntags = 0, ntframe, nvaro, ncout, ifr
   INTEGER(KIND=4), ALLOCATABLE :: ipk(:), id_varout(:), nptag(:)
   REAL(KIND=4), ALLOCATABLE, TARGET :: zu(:,:,:), zv(:,:,:), zt(:,:,:), zs(:,:,:), e3u(:,:,:), e3v(:,:,:)
@@ -112,6 +113,7 @@ PROGRAM cdfvT
      pe3u = C_LOC(e3u) ; pe3v = C_LOC(e3v) ; pe3um = C_LOC(de3u) ; pe3vm = C_LOC(de3v)
   ENDIF
   cf_tfil = SetFileName(config, ctag_lst(1), 'T')
+  CALL hip_shard(ngpu, igpus)                                ! CDFT_GPUS / CDFT_GPU_MAP
   CALL CreateOutput
 
   DO jk = 1, npk
@@ -135,9 +137,15 @@ PROGRAM cdfvT
            ENDIF
         END DO
      END DO
+     IF ( ngpu > 1 ) THEN                                    ! CDFT_GPUS / CDFT_GPU_MAP: row blocks over the node's GPUs
+        CALL hip_check(cdft_vt_compute_sharded(zu, zv, zt, zs, pe3u, pe3v, INT(npiglo, C_INT64_T) * npjglo, ntframe, npiglo,  &
+             &         npjglo, 1_C_INT, C_LOC(dvt), C_LOC(dvs), C_LOC(dut), C_LOC(dus), pe3um, pe3vm, 0_C_INT, ngpu, igpus),  &
+             &         'cdft_vt_compute_sharded')
+     ELSE
      CALL hip_check(cdft_vt_compute(zu, zv, zt, zs, pe3u, pe3v, INT(npiglo, C_INT64_T) * npjglo, ntframe, npiglo, npjglo,   &
           &         1_C_INT, CDFT_MEM_HOST, C_LOC(dvt), C_LOC(dvs), C_LOC(dut), C_LOC(dus), pe3um, pe3vm, 0_C_INT,         &
           &         CDFT_MEM_HOST, C_NULL_PTR), 'cdft_vt_compute')
+     ENDIF
      ierr = putvar(ncout, id_varout(1), dvt, jk, npiglo, npjglo, kwght=ntframe)
      ierr = putvar(ncout, id_varout(2), dvs, jk, npiglo, npjglo, kwght=ntframe)
      ierr = putvar(ncout, id_varout(3), dut, jk, npiglo, npjglo, kwght=ntframe)

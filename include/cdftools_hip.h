@@ -362,8 +362,9 @@ int cdft_mocsig_release(void);   /* frees the staging buffers of cdft_mocsig_com
 typedef struct cdft_psi_plan cdft_psi_plan;
 
 int cdft_psi_create(cdft_psi_plan **plan, int npiglo, int npjglo, int npk);
-/* sharded ("sharded plans" above): offers cdft_psi_compute (default, -V, -mean, -mask, -ref, -full); the staged entry
- * points below and -open belong to one device's plan (-open integrates along the row npjglo-2 of the whole domain). */
+/* sharded ("sharded plans" above): cdft_psi_compute and the staged entry points below all work on it (cdft_psi_scan_u
+ * then takes no carry and returns no row: the plan chains its own blocks); only cdft_psi_scan_open (-open, a line
+ * integral along the row npjglo-2 of the whole domain) needs a plan of cdft_psi_create. */
 int cdft_psi_create_sharded(cdft_psi_plan **plan, int npiglo, int npjglo, int npk, int ndev, const int *devices);
 /* One record.  U set (default path): zu (npiglo,npjglo,npk), e2u (npiglo,npjglo), e3u (3-D) r4;
  * V set (-V): zv, e1v, e3v; both sets = -mean.  e31d (npk) replaces the 3-D e3 with -full.

@@ -172,7 +172,7 @@ def test_sharded_psi_is_bit_identical_to_one_device(gpu, devices):
             r4, r8 = one.compute(**a)
             assert np.array_equal(g4.cpu().numpy(), r4) and np.array_equal(g8.cpu().numpy(), r8)
     with pytest.raises(gpu.CdftError):
-        sh.scan_open()                                            # staged entry points: one device's plan only
+        sh.scan_open()                                            # -open: one device only
 
 
 @pytest.mark.gpu
