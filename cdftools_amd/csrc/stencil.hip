@@ -629,18 +629,16 @@ int cdft_curl_compute(cdft_curl_plan *p, const float *un, const float *vn, int n
         }
         a.ntx = sh.ntx;
         const int64_t tiles = (int64_t)a.ntx * p->npj;
+        const int variant = ltpoint ? 0 : out_is_r8 ? 1 : 2;
+        typedef void (*CurlKernel)(CurlArgs, int, int);
+        static const CurlKernel table[3] = {curl_tile_kernel<double, true>, curl_tile_kernel<double, false>, curl_tile_kernel<float, false>};
         static int resident[3][kThreads / 64];                    // per kernel variant and workgroup size; 0 = not asked yet
-        int &res = resident[ltpoint ? 0 : out_is_r8 ? 1 : 2][sh.threads / 64 - 1];
-        if (res == 0)
-            res = ltpoint     ? resident_workgroups(curl_tile_kernel<double, true>, sh.threads)
-                  : out_is_r8 ? resident_workgroups(curl_tile_kernel<double, false>, sh.threads)
-                              : resident_workgroups(curl_tile_kernel<float, false>, sh.threads);
+        int &res = resident[variant][sh.threads / 64 - 1];
+        if (res == 0) res = resident_workgroups(table[variant], sh.threads);
         const char *elc = getenv("CDFT_CURL_CHUNKS");             // A/B hook
         const int lc = elc ? std::max(1, std::min(nlev, atoi(elc))) : curl_level_chunks(tiles, nlev, res);
         const dim3 grid((unsigned)(((tiles * lc + 7) / 8) * 8)), block(sh.threads);
-        if (ltpoint)        hipLaunchKernelGGL((curl_tile_kernel<double, true>), grid, block, 0, st, a, sh.tw, lc);
-        else if (out_is_r8) hipLaunchKernelGGL((curl_tile_kernel<double, false>), grid, block, 0, st, a, sh.tw, lc);
-        else                hipLaunchKernelGGL((curl_tile_kernel<float, false>), grid, block, 0, st, a, sh.tw, lc);
+        hipLaunchKernelGGL(table[variant], grid, block, 0, st, a, sh.tw, lc);
     } else {
         a.ntx = (p->npi + kTile - 1) / kTile;
         const int64_t total = (int64_t)p->npj * a.ntx;
