@@ -67,6 +67,8 @@ SIGNATURES = {
     "cdft_heatc_create_sharded": (_i, [_pvp, _i, _i, _i, _i, C.POINTER(_i)]),
     "cdft_heatc_set_mesh": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "cdft_heatc_compute": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp]),
+    "cdft_heatc_set_sum_mode": (_i, [_vp, _i]),
+    "cdft_heatc_chain": (_i, [_vp, _vp, _vp]),
     "cdft_heatc_destroy": (_i, [_vp]),
     "cdft_mhst_create": (_i, [_pvp, _i, _i, _i, _i]),
     "cdft_mhst_create_sharded": (_i, [_pvp, _i, _i, _i, _i, _i, C.POINTER(_i)]),

@@ -10,6 +10,7 @@
 // HBM-bound: per cell temp 4 B + e3t 4 B + tmask 1 B (+ 8/npk) = 9.11 algorithmic bytes; the 2-D
 // area e1t*e2t is re-read from L2 / Infinity Cache for every level.
 #include <cstdlib>
+#include <vector>
 #include "common.hpp"
 #include "reduce.hpp"
 #include "shard.hpp"
@@ -21,7 +22,7 @@ int heatc_parts(ShardSet &sh);
 int heatc_set_mesh(ShardSet &sh, const float *e1t, const float *e2t, const float *e3t, const float *e31d, const void *tmask,
                    int mask_is_r4);
 int heatc_compute(ShardSet &sh, const float *temp, const float *rmxldep, const float *gdepw, int mxloption, double *sums,
-                  int out_space, hipStream_t out_stream);
+                  int out_space, hipStream_t out_stream, int sum_mode);
 } }
 
 struct cdft_heatc_plan {
@@ -36,7 +37,10 @@ struct cdft_heatc_plan {
     double  *partial = nullptr;
     int nblk = 0;
     bool mesh_set = false;
-    DevBuf st_a, st_b, st_temp, st_mxl, st_out;
+    int sum_mode = 0;          // CDFT_HEATC_SUM_R8 | CDFT_HEATC_SUM_R4SEQ
+    std::vector<float> carry;  // r4seq: the chains' start values (3*npk), empty = zeros; consumed by the next compute
+    std::vector<float> last4;  // r4seq: the r4 sums of the last compute (what the next row block starts from)
+    DevBuf st_a, st_b, st_temp, st_mxl, st_out, st_c4, st_s4;
 };
 
 namespace {
@@ -249,6 +253,90 @@ int launch_u4(const HeatcArgs &a, hipStream_t st) {
     return CDFT_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The reference's own order.  src/cdfheatc.f90:225-229 forms  SUM(e1t*e2t*tmask), SUM(e1t*e2t*e3t*tmask),
+// SUM(e1t*e2t*e3t*temp*tmask)  in REAL(KIND=4): gfortran -O and flang -O1 compile that SUM into one sequential r4
+// loop over the array in memory order, so the value a reference build returns is  s = 0; s = s + x(p), p = 1..n,
+// rounded to r4 at every step (9e-5 away from the r8 sum at eORCA025).  A sequential rounding
+// chain cannot be regrouped, so it is reproduced as it is: one wave per level; the 64 lanes form the three r4
+// products of 256 cells at a time in parallel (coalesced 16-byte loads, the next batch already requested) and park
+// them in LDS, then lanes 0..2 -- one per sum -- add their 256 values in order.  1.74e6 dependent v_add_f32 per chain
+// at eORCA025: a few milliseconds for all 225 chains, which run side by side on 75 CUs.  `carry` (3*npk r4, or NULL)
+// continues the chains of the row block to the south (sharded plans): the result does not depend on the partition.
+template <bool MASK8, bool FULL>
+__global__ void __launch_bounds__(64) heatc_seq_kernel(HeatcArgs a, const float *__restrict__ carry, float *__restrict__ sums4) {
+    __shared__ float lds[3][256];
+    const int k = blockIdx.x, lane = threadIdx.x, ch = lane < 3 ? lane : 2;
+    const int64_t base = (int64_t)k * a.nij;
+    const float e3k = FULL ? a.e31d[k] : 0.f;
+    const float dw  = a.mxlopt ? a.gdepw[k] : 0.f;
+    float s = carry ? carry[k * 3 + ch] : 0.f;
+    struct Batch { float ar[4], e3[4], tt[4], mk[4], mx[4]; };
+    auto fetch = [&](Batch &x, int64_t p0) {
+        const int64_t p = p0 + 4 * lane;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { x.ar[c] = x.e3[c] = x.tt[c] = x.mk[c] = x.mx[c] = 0.f; }
+        if (p + 3 < a.nij) {
+            const f4u av = *reinterpret_cast<const f4u *>(a.area + p);
+            x.ar[0] = av.x; x.ar[1] = av.y; x.ar[2] = av.z; x.ar[3] = av.w;
+            const f4u tv = ld_stream4u(a.temp + base + p);
+            x.tt[0] = tv.x; x.tt[1] = tv.y; x.tt[2] = tv.z; x.tt[3] = tv.w;
+            if (!FULL) { const f4u ev = ld_stream4u(a.e3t + base + p); x.e3[0] = ev.x; x.e3[1] = ev.y; x.e3[2] = ev.z; x.e3[3] = ev.w; }
+            if (MASK8) { const u4u m = __builtin_nontemporal_load(reinterpret_cast<const u4u *>(a.mask8 + base + p)); x.mk[0] = m.x; x.mk[1] = m.y; x.mk[2] = m.z; x.mk[3] = m.w; }
+            else       { const f4u m = ld_stream4u(a.mask4 + base + p); x.mk[0] = m.x; x.mk[1] = m.y; x.mk[2] = m.z; x.mk[3] = m.w; }
+            if (a.mxlopt) { const f4u mv = *reinterpret_cast<const f4u *>(a.mxl + p); x.mx[0] = mv.x; x.mx[1] = mv.y; x.mx[2] = mv.z; x.mx[3] = mv.w; }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (p + c < a.nij) {
+                    x.ar[c] = a.area[p + c];
+                    x.tt[c] = a.temp[base + p + c];
+                    if (!FULL) x.e3[c] = a.e3t[base + p + c];
+                    x.mk[c] = MASK8 ? (float)a.mask8[base + p + c] : a.mask4[base + p + c];
+                    if (a.mxlopt) x.mx[c] = a.mxl[p + c];
+                }
+        }
+    };
+    Batch cur, nxt;
+    fetch(cur, 0);
+    for (int64_t p0 = 0; p0 < a.nij; p0 += 256) {
+        if (p0 + 256 < a.nij) fetch(nxt, p0 + 256);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float e = FULL ? e3k : cur.e3[c];
+            if (a.mxlopt == 1)       e = fmaxf(0.f, fminf(e, __fsub_rn(cur.mx[c], dw)));                 // :220
+            else if (a.mxlopt == -1) e = fminf(e, fmaxf(0.f, __fsub_rn(__fadd_rn(dw, e), cur.mx[c])));   // :222
+            const float pv = __fmul_rn(cur.ar[c], e);
+            lds[0][4 * lane + c] = __fmul_rn(cur.ar[c], cur.mk[c]);                                   // :225
+            lds[1][4 * lane + c] = __fmul_rn(pv, cur.mk[c]);                                          // :226
+            lds[2][4 * lane + c] = __fmul_rn(__fmul_rn(pv, cur.tt[c]), cur.mk[c]);                    // :229
+        }
+        __syncthreads();
+        const int n = (int)min((int64_t)256, a.nij - p0);
+        const float *x = lds[ch];
+        int i = 0;
+        for (; i + 4 <= n; i += 4) {
+            const f4a v = *reinterpret_cast<const f4a *>(x + i);
+            s = __fadd_rn(s, v.x); s = __fadd_rn(s, v.y); s = __fadd_rn(s, v.z); s = __fadd_rn(s, v.w);
+        }
+        for (; i < n; ++i) s = __fadd_rn(s, x[i]);
+        __syncthreads();
+        cur = nxt;
+    }
+    if (lane < 3) sums4[k * 3 + lane] = s;
+}
+
+int launch_seq(const HeatcArgs &a, const float *carry, float *sums4, hipStream_t st) {
+    dim3 grid(a.npk), block(64);
+    const bool m8 = a.mask8 != nullptr, full = a.e31d != nullptr;
+    if (m8 && full)        hipLaunchKernelGGL((heatc_seq_kernel<true, true>), grid, block, 0, st, a, carry, sums4);
+    else if (m8 && !full)  hipLaunchKernelGGL((heatc_seq_kernel<true, false>), grid, block, 0, st, a, carry, sums4);
+    else if (!m8 && full)  hipLaunchKernelGGL((heatc_seq_kernel<false, true>), grid, block, 0, st, a, carry, sums4);
+    else                   hipLaunchKernelGGL((heatc_seq_kernel<false, false>), grid, block, 0, st, a, carry, sums4);
+    CDFT_LAUNCH_CHECK();
+    return CDFT_OK;
+}
+
 // sums[k][3] = partials of level k added over the blocks in a fixed order (one workgroup per level)
 __global__ void __launch_bounds__(kThreads) heatc_final_kernel(const double *__restrict__ partial, int npk, int nblk,
                                                                double *__restrict__ sums) {
@@ -373,7 +461,7 @@ int cdft_heatc_compute(cdft_heatc_plan *p, const float *temp, int temp_space, co
         return fail(CDFT_ERR_ARG, "cdft_heatc_compute: mxloption %d needs rmxldep and gdepw", mxloption);
     if (p->sh) {
         if (temp_space == CDFT_MEM_DEVICE) CDFT_HIP(hipStreamSynchronize(as_stream(stream)));
-        return shard::heatc_compute(*p->sh, temp, rmxldep, gdepw, mxloption, sums, out_space, as_stream(stream));
+        return shard::heatc_compute(*p->sh, temp, rmxldep, gdepw, mxloption, sums, out_space, as_stream(stream), p->sum_mode);
     }
     hipStream_t st = as_stream(stream);
     const int64_t nij = (int64_t)p->npi * p->npj, n3 = nij * p->npk;
@@ -392,6 +480,31 @@ int cdft_heatc_compute(cdft_heatc_plan *p, const float *temp, int temp_space, co
     a.area = p->area; a.e3t = p->e3t; a.e31d = p->e31d; a.temp = (const float *)dt; a.mxl = (const float *)dm;
     a.gdepw = p->gdepw; a.mask8 = p->mask8; a.mask4 = p->mask4; a.nij = nij; a.npk = p->npk;
     a.mxlopt = mxloption; a.partial = p->partial;
+    if (p->sum_mode == CDFT_HEATC_SUM_R4SEQ) {
+        // the reference's sequential r4 sums, bit for bit (heatc_seq_kernel); the r4 results are widened exactly
+        const size_t n = (size_t)p->npk * 3;
+        CDFT_TRY(p->st_s4.reserve(n * sizeof(float)));
+        const float *dcarry = nullptr;
+        if (!p->carry.empty()) {
+            CDFT_TRY(p->st_c4.reserve(n * sizeof(float)));
+            CDFT_HIP(hipMemcpyAsync(p->st_c4.ptr, p->carry.data(), n * sizeof(float), hipMemcpyHostToDevice, st));
+            dcarry = (const float *)p->st_c4.ptr;
+        }
+        CDFT_TRY(launch_seq(a, dcarry, (float *)p->st_s4.ptr, st));
+        p->last4.resize(n);
+        CDFT_HIP(hipMemcpyAsync(p->last4.data(), p->st_s4.ptr, n * sizeof(float), hipMemcpyDeviceToHost, st));
+        CDFT_HIP(hipStreamSynchronize(st));
+        p->carry.clear();
+        std::vector<double> s8(n);
+        for (size_t i = 0; i < n; ++i) s8[i] = (double)p->last4[i];
+        if (out_space == CDFT_MEM_HOST) {
+            memcpy(sums, s8.data(), n * sizeof(double));
+        } else {
+            CDFT_HIP(hipMemcpyAsync(sums, s8.data(), n * sizeof(double), hipMemcpyHostToDevice, st));
+            CDFT_HIP(hipStreamSynchronize(st));
+        }
+        return CDFT_OK;
+    }
     int vec = 1;
     if (nij % 4 == 0 && aligned_to(dt, 16) && aligned_to(dm, 16)) vec = 4;
     else if (nij >= 4 && !getenv("CDFT_HEATC_NOU4")) vec = -4;           // 16-byte loads at r4 alignment (A/B hook: the old paths)
@@ -411,6 +524,27 @@ int cdft_heatc_compute(cdft_heatc_plan *p, const float *temp, int temp_space, co
     return CDFT_OK;
 }
 
+int cdft_heatc_set_sum_mode(cdft_heatc_plan *p, int mode) {
+    if (!p) return fail(CDFT_ERR_ARG, "cdft_heatc_set_sum_mode: NULL plan");
+    if (mode != CDFT_HEATC_SUM_R8 && mode != CDFT_HEATC_SUM_R4SEQ) return fail(CDFT_ERR_ARG, "cdft_heatc_set_sum_mode: mode %d", mode);
+    p->sum_mode = mode;
+    if (p->sh)
+        for (void *q : p->sh->part) CDFT_TRY(cdft_heatc_set_sum_mode((cdft_heatc_plan *)q, mode));
+    return CDFT_OK;
+}
+
+int cdft_heatc_chain(cdft_heatc_plan *p, const float *carry_in, float *last_out) {
+    if (!p) return fail(CDFT_ERR_ARG, "cdft_heatc_chain: NULL plan");
+    if (p->sh) return fail(CDFT_ERR_STATE, "cdft_heatc_chain: a sharded plan chains its own blocks");
+    const size_t n = (size_t)p->npk * 3;
+    if (last_out) {
+        if (p->last4.size() != n) return fail(CDFT_ERR_STATE, "cdft_heatc_chain: no CDFT_HEATC_SUM_R4SEQ result to hand on");
+        memcpy(last_out, p->last4.data(), n * sizeof(float));
+    }
+    if (carry_in) p->carry.assign(carry_in, carry_in + n);
+    return CDFT_OK;
+}
+
 int cdft_heatc_destroy(cdft_heatc_plan *p) {
     if (!p) return CDFT_OK;
     if (p->sh) {
@@ -422,6 +556,7 @@ int cdft_heatc_destroy(cdft_heatc_plan *p) {
     void *ptrs[] = {p->area, p->e3t, p->e31d, p->mask8, p->mask4, p->gdepw, p->partial};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     p->st_a.release(); p->st_b.release(); p->st_temp.release(); p->st_mxl.release(); p->st_out.release();
+    p->st_c4.release(); p->st_s4.release();
     delete p;
     return CDFT_OK;
 }

@@ -257,9 +257,50 @@ int heatc_set_mesh(ShardSet &sh, const float *e1t, const float *e2t, const float
 }
 
 int heatc_compute(ShardSet &sh, const float *temp, const float *rmxldep, const float *gdepw, int mxloption, double *sums,
-                  int out_space, hipStream_t out_stream) {
+                  int out_space, hipStream_t out_stream, int sum_mode) {
     const int n = sh.nblk();
     std::vector<std::vector<double>> part(n, std::vector<double>((size_t)3 * sh.npk));
+    if (sum_mode == CDFT_HEATC_SUM_R4SEQ) {
+        // The reference's sequential r4 sums run through the rows in memory order, i.e. through the blocks south to
+        // north: stage every block's rows (in parallel), then run the chains block after block, each starting from the
+        // r4 values the previous one ended with -- the same additions in the same order as on one device.
+        CDFT_TRY(for_blocks(sh, [&](int b) {
+            const int j0 = sh.j0[b], j1 = sh.j1[b];
+            const size_t nij = (size_t)sh.npi * (j1 - j0);
+            DevBuf *B = sh.buf[b].data();
+            CDFT_TRY(B[5].reserve(nij * sh.npk * 4));
+            CDFT_TRY(rows_in(B[5].ptr, temp, (size_t)sh.npi * 4, sh.npj, j0, j1, sh.npk, 0, sh.st[b]));
+            if (mxloption != 0) {
+                CDFT_TRY(B[6].reserve(nij * 4));
+                CDFT_TRY(rows_in(B[6].ptr, rmxldep, (size_t)sh.npi * 4, sh.npj, j0, j1, 1, 0, sh.st[b]));
+            }
+            CDFT_HIP(hipStreamSynchronize(sh.st[b]));
+            return CDFT_OK;
+        }));
+        std::vector<float> carry((size_t)3 * sh.npk);
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        int rc = CDFT_OK;
+        for (int b = 0; b < n && rc == CDFT_OK; ++b) {
+            if (hipSetDevice(sh.dev[b]) != hipSuccess) { rc = fail(CDFT_ERR_HIP, "cdft_heatc_compute: hipSetDevice(%d) failed", sh.dev[b]); break; }
+            cdft_heatc_plan *p = (cdft_heatc_plan *)sh.part[b];
+            if (b > 0) rc = cdft_heatc_chain(p, carry.data(), nullptr);
+            if (rc == CDFT_OK)
+                rc = cdft_heatc_compute(p, (const float *)sh.buf[b][5].ptr, CDFT_MEM_DEVICE, mxloption ? (const float *)sh.buf[b][6].ptr : nullptr,
+                                        gdepw, mxloption, part[b].data(), CDFT_MEM_HOST, sh.st[b]);
+            if (rc == CDFT_OK) rc = cdft_heatc_chain(p, nullptr, carry.data());
+        }
+        (void)hipSetDevice(cur);
+        CDFT_TRY(rc);
+        const std::vector<double> &tot = part[n - 1];
+        if (out_space == CDFT_MEM_HOST) {
+            memcpy(sums, tot.data(), tot.size() * 8);
+        } else {
+            CDFT_HIP(hipMemcpyAsync(sums, tot.data(), tot.size() * 8, hipMemcpyHostToDevice, out_stream));
+            CDFT_HIP(hipStreamSynchronize(out_stream));
+        }
+        return CDFT_OK;
+    }
     CDFT_TRY(for_blocks(sh, [&](int b) {
         const int j0 = sh.j0[b], j1 = sh.j1[b], nloc = j1 - j0;
         const size_t nij = (size_t)sh.npi * nloc;

@@ -6,7 +6,9 @@ PROGRAM cdfheatc
   !! Drop-in for the reference tool (src/cdfheatc.f90): same options (-zoom, -full, -vvl, -mxloption,
   !! -mxlf, -M, -o), same stdout lines per level and for the totals (:233-243), same heatc.nc
   !! (heatc3d, heatc2d, heatc3dpervol double, :251-306).  The three SUMs of every level (:225-229) run
-  !! on the GPU for all levels of a record at once (cdft_heatc_*): r4 products as written, r8 sums.
+  !! on the GPU for all levels of a record at once (cdft_heatc_*): r4 products as written, summed in r4 in the
+  !! reference's sequential order (bit-identical to a gfortran -O / flang -O1 build of the reference), or in r8 with
+  !! CDFT_HEATC_SUM=r8 (the more accurate value, at the HBM roofline).
   !!======================================================================
   USE ISO_C_BINDING
   USE cdfio
@@ -134,6 +136,11 @@ PROGRAM cdfheatc
   ELSE
      CALL hip_check(cdft_heatc_create(plan, npiglo, npjglo, nvpk), 'cdft_heatc_create')
   ENDIF
+  ! The reference's SUMs are REAL(KIND=4), added sequentially in memory order (src/cdfheatc.f90:225-229 as gfortran -O and
+  ! flang -O1 compile them): the program returns exactly those values.  CDFT_HEATC_SUM=r8 asks for r8 sums instead -- the
+  ! more accurate number (the two differ by 1e-4 relative at eORCA025) at the HBM roofline.
+  CALL GET_ENVIRONMENT_VARIABLE('CDFT_HEATC_SUM', cldum)
+  IF ( TRIM(cldum) /= 'r8' ) CALL hip_check(cdft_heatc_set_sum_mode(plan, CDFT_HEATC_SUM_R4SEQ), 'cdft_heatc_set_sum_mode')
 
   DO jt = 1, npt
      it = 1 ; IF ( lg_vvl ) it = jt

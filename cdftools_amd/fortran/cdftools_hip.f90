@@ -11,6 +11,7 @@ MODULE cdftools_hip
   PUBLIC
 
   INTEGER(C_INT), PARAMETER :: CDFT_OK = 0, CDFT_MEM_HOST = 0, CDFT_MEM_DEVICE = 1
+  INTEGER(C_INT), PARAMETER :: CDFT_HEATC_SUM_R8 = 0, CDFT_HEATC_SUM_R4SEQ = 1
   INTEGER(C_INT), PARAMETER :: CDFT_MEAN_FORM_MEAN = 0, CDFT_MEAN_FORM_SUM = 1, CDFT_MEAN_FORM_SUM_FORCING = 2
   INTEGER(C_INT), PARAMETER :: CDFT_EOS_80 = 0, CDFT_EOS_TEOS10 = 1, CDFT_EOS_JMD94 = 2, CDFT_EOS_NTR = 3, CDFT_EOS_FAST_FMA = 1
 
@@ -110,6 +111,9 @@ MODULE cdftools_hip
      ! ---- cdfheatc -------------------------------------------------------------------------
      INTEGER(C_INT) FUNCTION cdft_heatc_create(plan, npiglo, npjglo, npk) BIND(C, name='cdft_heatc_create')
        IMPORT ; TYPE(C_PTR), INTENT(out) :: plan ; INTEGER(C_INT), VALUE :: npiglo, npjglo, npk
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_heatc_set_sum_mode(plan, mode) BIND(C, name='cdft_heatc_set_sum_mode')
+       IMPORT ; TYPE(C_PTR), VALUE :: plan ; INTEGER(C_INT), VALUE :: mode
      END FUNCTION
      INTEGER(C_INT) FUNCTION cdft_heatc_set_mesh(plan, e1t, e2t, e3t, e31d, tmask, mask_is_r4, memspace, stream) &
           &         BIND(C, name='cdft_heatc_set_mesh')

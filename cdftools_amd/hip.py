@@ -322,6 +322,19 @@ class HeatcPlan(_Plan):
         check(_lib.load().cdft_heatc_set_mesh(self._h, p1, p2, p3, p4, pm, 1 if is_r4 else 0, s1,
                                               stream or current_stream_ptr()))
 
+    def set_sum_mode(self, r4seq):
+        """r4seq=True: the reference's sequential r4 SUMs, bit for bit (CDFT_HEATC_SUM_R4SEQ); False: r8 sums (default)."""
+        check(_lib.load().cdft_heatc_set_sum_mode(self._h, 1 if r4seq else 0))
+
+    def chain(self, carry_in=None, want_last=False):
+        """row blocks in separate plans (r4seq): carry_in (npk,3) r4 starts the next compute's chains; want_last returns
+        the (npk,3) r4 sums the last compute ended with."""
+        last = np.empty((self.npk, 3), np.float32) if want_last else None
+        keep = None if carry_in is None else np.ascontiguousarray(carry_in, np.float32)
+        check(_lib.load().cdft_heatc_chain(self._h, None if keep is None else C.c_void_p(keep.ctypes.data),
+                                           None if last is None else C.c_void_p(last.ctypes.data)))
+        return last
+
     def compute(self, temp, rmxldep=None, gdepw=None, mxloption=0, stream=None):
         """temp (npk,npj,npi) r4 -> sums (npk,3) r8 = dsurf, dvol2d, dsum2d per level (host array)."""
         pt, st_, kt = _arg(temp, np.float32, "temp")

@@ -220,6 +220,21 @@ int cdft_heatc_set_mesh(cdft_heatc_plan *plan, const float *e1t, const float *e2
  * heatc2d = pprho0*ppcp*dsum2d and the running dvol / dsum exactly as :227,:230,:236-247. */
 int cdft_heatc_compute(cdft_heatc_plan *plan, const float *temp, int temp_space, const float *rmxldep,
                        const float *gdepw, int mxloption, double *sums, int out_space, void *stream);
+/* How the three SUMs of a level are accumulated:
+ *   CDFT_HEATC_SUM_R8     (default) r4 products as written, r8 sums in a fixed parallel order: the accurate value,
+ *                         at the HBM roofline; 1e-13 from a sequential r8 sum.
+ *   CDFT_HEATC_SUM_R4SEQ  the reference's own arithmetic: its SUM is REAL(KIND=4) (:225-229), compiled by gfortran -O /
+ *                         flang -O1 into one sequential r4 loop in memory order.  Reproduced bit for bit (one wave per
+ *                         level adds the products in order; milliseconds instead of a fraction of one), so that the
+ *                         drop-in program returns what a reference build returns (9e-5 from the r8 value at eORCA025).
+ *                         The r4 results are widened exactly into `sums`.  Sharded plans chain the blocks in order. */
+#define CDFT_HEATC_SUM_R8     0
+#define CDFT_HEATC_SUM_R4SEQ  1
+int cdft_heatc_set_sum_mode(cdft_heatc_plan *plan, int mode);
+/* CDFT_HEATC_SUM_R4SEQ over row blocks held by separate plans (what a sharded plan does internally, and what ranks
+ * of cdftools_amd/shard.py do across processes): last_out (3*npk r4, may be NULL) receives the r4 sums the last
+ * compute ended with; carry_in (3*npk r4, may be NULL) makes the NEXT compute start its chains there instead of 0. */
+int cdft_heatc_chain(cdft_heatc_plan *plan, const float *carry_in, float *last_out);
 int cdft_heatc_destroy(cdft_heatc_plan *plan);
 
 /* ------------------------------------------------------------------------------------------ */

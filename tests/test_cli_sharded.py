@@ -1,7 +1,8 @@
 """The drop-in programs on several row blocks: CDFT_GPU_MAP / CDFT_GPUS (read by hip_shard in cdftools_hip.f90 through
 cdft_shard_from_env) make cdfmoc, cdfheatc, cdfpsi, cdfvT and cdfmhst create sharded plans.  On this 1-GPU box the
 blocks are mapped to device 0 (CDFT_GPU_MAP=0,0 and 0,0,0).  Every output file must be IDENTICAL to the one-device run (bytes of every
-variable; the whole file where the command line is not recorded in it), except cdfheatc's r8 sums, which regroup their additions (block order): 1e-13 relative."""
+variable; the whole file where the command line is not recorded in it) -- cdfheatc included, whose reference-order r4
+sums are chained through the blocks; only its optional r8 sums (CDFT_HEATC_SUM=r8) regroup their additions: 1e-13."""
 import filecmp
 import os
 
@@ -64,7 +65,13 @@ def test_programs_on_row_blocks_write_identical_files(case, gmap):
                       (["-v", "SYN_y0001_gridV.nc", "-t", "SYN_y0001_gridT.nc", "-MST"], "mhst_sep")):
         a, b = pair("cdfmhst", args, d, out, gmap)
         assert same_file(a, b), args
-    a, b = pair("cdfheatc", ["-f", "SYN_y0001_gridT.nc"], d, "heatc", gmap)
+    a, b = pair("cdfheatc", ["-f", "SYN_y0001_gridT.nc"], d, "heatc", gmap)       # the reference's r4 sums, chained through the blocks
+    assert same_file(a, b)
+    os.environ["CDFT_HEATC_SUM"] = "r8"
+    try:
+        a, b = pair("cdfheatc", ["-f", "SYN_y0001_gridT.nc"], d, "heatc8", gmap)  # r8 sums: block sums added in block order
+    finally:
+        del os.environ["CDFT_HEATC_SUM"]
     va, _, _ = read_nc(a)
     vb, _, _ = read_nc(b)
     for k in ("heatc2d", "heatc3d", "heatc3dpervol"):

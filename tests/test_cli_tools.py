@@ -34,18 +34,30 @@ def test_cdfheatc_end_to_end(case):
     var, att, dims = read_nc(os.path.join(d, "heatc.nc"))
     scale = np.float64(np.float32(1020.0) * np.float32(4000.0))
     for t in range(2):
+        # the program returns the reference's own r4 sequential SUMs (src/cdfheatc.f90:225-229), bit for bit
+        ref = oracle_tools.heatc(g["e1t"], g["e2t"], g["tmask"], rec["t"][t], e3t=g["e3t_0"], r4sum=True)
+        dvol = dsum = 0.0
+        for k in range(ref.shape[0]):
+            dvol, dsum = dvol + ref[k, 1], dsum + ref[k, 2]
+        assert np.array_equal(var["heatc2d"][t, :, 0, 0], scale * ref[:, 2])
+        assert var["heatc3d"][t, 0, 0] == scale * dsum and var["heatc3dpervol"][t, 0, 0] == scale * dsum / dvol
+    rc, out, err = run("cdfheatc", ["-f", "SYN_y0001_gridT.nc", "-o", "heatc_r8.nc"], d, env={"CDFT_HEATC_SUM": "r8"})
+    assert rc == 0, out + err
+    v8, _, _ = read_nc(os.path.join(d, "heatc_r8.nc"))
+    for t in range(2):                                   # CDFT_HEATC_SUM=r8: r8 sums of the same r4 products
         ref = oracle_tools.heatc(g["e1t"], g["e2t"], g["tmask"], rec["t"][t], e3t=g["e3t_0"])
-        assert np.allclose(var["heatc2d"][t, :, 0, 0], scale * ref[:, 2], rtol=1e-12, atol=0)
-        assert np.isclose(var["heatc3d"][t, 0, 0], scale * ref[:, 2].sum(), rtol=1e-12)
-        assert np.isclose(var["heatc3dpervol"][t, 0, 0], scale * ref[:, 2].sum() / ref[:, 1].sum(), rtol=1e-12)
+        assert np.allclose(v8["heatc2d"][t, :, 0, 0], scale * ref[:, 2], rtol=1e-12, atol=0)
+        assert np.isclose(v8["heatc3d"][t, 0, 0], scale * ref[:, 2].sum(), rtol=1e-12)
+        assert np.isclose(v8["heatc3dpervol"][t, 0, 0], scale * ref[:, 2].sum() / ref[:, 1].sum(), rtol=1e-12)
     assert var["heatc2d"].dtype == np.dtype(">f8") and att["heatc3d"]["units"] == b"Joules"
     # zoom window + full step
     rc, out, _ = run("cdfheatc", ["-f", "SYN_y0001_gridT.nc", "-zoom", "3", "12", "2", "9", "2", "4", "-full", "-o", "hz.nc"], d)
     assert rc == 0, out
     vz, _, dz = read_nc(os.path.join(d, "hz.nc"))
-    ref = oracle_tools.heatc(g["e1t"][1:9, 2:12], g["e2t"][1:9, 2:12], g["tmask"][1:4, 1:9, 2:12], rec["t"][0][1:4, 1:9, 2:12],
-                             e31d=g["e3t_1d"][1:4])
-    assert dz["depthw"] == 3 and np.allclose(vz["heatc2d"][0, :, 0, 0], scale * ref[:, 2], rtol=1e-12)
+    c = np.ascontiguousarray
+    ref = oracle_tools.heatc(c(g["e1t"][1:9, 2:12]), c(g["e2t"][1:9, 2:12]), c(g["tmask"][1:4, 1:9, 2:12]), c(rec["t"][0][1:4, 1:9, 2:12]),
+                             e31d=g["e3t_1d"][1:4], r4sum=True)
+    assert dz["depthw"] == 3 and np.array_equal(vz["heatc2d"][0, :, 0, 0], scale * ref[:, 2])
 
 
 @pytest.mark.gpu

@@ -375,6 +375,16 @@ def test_hip_heatc_against_reference_statements(gpu, name):
         absb = ot.heatc(g["e1t"], g["e2t"], g["tmask"], np.abs(temp[t]), mxl=None if mxl is None else mxl[t], gdepw=g["gdepw_1d"],
                         mxlopt=mxlopt, **kw)
         assert np.all(np.abs(got - G[f"{name}.sums"][t]) <= n * 2.0 ** -24 * absb + 1e-300)
+    # the reference-order mode (sequential r4 sums): what the reference's statements return, bit for bit -- on one
+    # device and chained through 2 and 3 row blocks
+    for devices in (None, [0, 0], [0, 0, 0]):
+        seq = gpu.HeatcPlan(npi, npj, npk, devices=devices)
+        seq.set_mesh(g["e1t"], g["e2t"], g["tmask"].astype(np.uint8), **(dict(e31d=g["e3t_1d"]) if full else dict(e3t=g["e3t_0"])))
+        seq.set_sum_mode(True)
+        got = np.stack([seq.compute(temp[t], rmxldep=None if mxl is None else mxl[t], gdepw=g["gdepw_1d"], mxloption=mxlopt)
+                        for t in range(temp.shape[0])])
+        assert same(got, G[f"{name}.sums"]), devices
+        assert same(heatc_vars(got), G[f"{name}.var"]), devices
 
 
 @pytest.mark.gpu
