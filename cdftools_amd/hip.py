@@ -335,13 +335,18 @@ class HeatcPlan(_Plan):
                                            None if last is None else C.c_void_p(last.ctypes.data)))
         return last
 
-    def compute(self, temp, rmxldep=None, gdepw=None, mxloption=0, stream=None):
-        """temp (npk,npj,npi) r4 -> sums (npk,3) r8 = dsurf, dvol2d, dsum2d per level (host array)."""
+    def compute(self, temp, rmxldep=None, gdepw=None, mxloption=0, stream=None, device_out=None):
+        """temp (npk,npj,npi) r4 -> sums (npk,3) r8 = dsurf, dvol2d, dsum2d per level: a host array (the call returns
+        when it is there), or -- device_out = a CUDA r8 tensor of 3*npk elements -- left in HBM, asynchronously."""
         pt, st_, kt = _arg(temp, np.float32, "temp")
         pm, sm, km = _arg(rmxldep, np.float32, "rmxldep") if rmxldep is not None else (_null(), st_, None)
         pg, sg, kg = _arg(np.asarray(gdepw, np.float32), np.float32, "gdepw") if gdepw is not None else (_null(), 0, None)
         if sm != st_:
             raise ValueError("rmxldep must live in the same memory space as temp")
+        if device_out is not None:
+            po, so, ko = _arg(device_out, np.float64, "sums")
+            check(_lib.load().cdft_heatc_compute(self._h, pt, st_, pm, pg, mxloption, po, so, stream or current_stream_ptr()))
+            return device_out
         out = np.empty((self.npk, 3), np.float64)
         check(_lib.load().cdft_heatc_compute(self._h, pt, st_, pm, pg, mxloption, C.c_void_p(out.ctypes.data),
                                              MEM_HOST, stream or current_stream_ptr()))
