@@ -504,7 +504,7 @@ static int h5_load(void) {
     g_h5_finish = (nch5_finish_fn)dlsym(lib, "nch5_finish");
     if (!g_h5_open || !g_h5_get || !g_h5_close || !g_h5_create || !g_h5_put || !g_h5_put_atts || !g_h5_finish) {
         g_h5_open = NULL;
-        snprintf(g_h5_msg, sizeof g_h5_msg, "NetCDF: %s is not the HDF5 plug-in of this build", path);
+        snprintf(g_h5_msg, sizeof g_h5_msg, "NetCDF: %.400s is not the HDF5 plug-in of this build", path);
         return NCC_EHDFERR;
     }
     return 0;

@@ -11,7 +11,7 @@ from scipy.io import netcdf_file
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "cdftools_amd", "netcdf")
-LIB = os.path.join(ROOT, "cdftools_amd", "lib", "libncclassic.so")
+LIB = os.environ.get("CDFT_NCCLASSIC_LIB") or os.path.join(ROOT, "cdftools_amd", "lib", "libncclassic.so")   # (sanitizer build: test_netcdf_asan.py)
 BYTE, CHAR, SHORT, INT, FLOAT, DOUBLE = 1, 2, 3, 4, 5, 6
 NPT = {BYTE: np.int8, SHORT: np.int16, INT: np.int32, FLOAT: np.float32, DOUBLE: np.float64}
 

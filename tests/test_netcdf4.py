@@ -19,8 +19,8 @@ from test_cli import read_nc, run, tools  # noqa: F401
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "cdftools_amd", "netcdf")
-LIB = os.path.join(ROOT, "cdftools_amd", "lib", "libncclassic.so")
-PLUG = os.path.join(ROOT, "cdftools_amd", "lib", "libnch5.so")
+LIB = os.environ.get("CDFT_NCCLASSIC_LIB") or os.path.join(ROOT, "cdftools_amd", "lib", "libncclassic.so")   # (sanitizer build: test_netcdf_asan.py)
+PLUG = os.environ.get("CDFT_NCH5_LIB") or os.path.join(ROOT, "cdftools_amd", "lib", "libnch5.so")
 W4 = os.path.join(ROOT, "tools", "bin", "libnc4write.so")
 NPT = {1: np.int8, 3: np.int16, 4: np.int32, 5: np.float32, 6: np.float64}
 
