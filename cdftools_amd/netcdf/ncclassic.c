@@ -417,6 +417,23 @@ static int layout(File *f) {
     const uint64_t rec0 = off;
     for (int i = 0; i < f->nvars; ++i) if (f->vars[i].isrec) { nb[i] = off; off += f->vars[i].vsize; }
     int rc = 0;
+    /* The classic formats' size rules (NetCDF User's Guide, "Large File Support"): the header stores vsize in 32 bits
+     * (CDF-1, CDF-2) and begin in 32 bits (CDF-1).  A fixed-size variable, or one record of a record variable, must
+     * fit 2^31 - 4 (CDF-1) / 2^32 - 4 (CDF-2) bytes unless it is the LAST fixed-size variable of a file without record
+     * variables, or the last record variable; every begin of a CDF-1 file must fit 31 bits.  Anything else would be
+     * written with a clamped vsize or a truncated offset that other readers misinterpret: refuse it here (cdfio's
+     * create() switches to CDF-5 before that happens). */
+    if (f->format != 5) {
+        const uint64_t vmax = f->format == 1 ? 0x7FFFFFFCull : 0xFFFFFFFCull;
+        int last_fix = -1, last_rec = -1;
+        for (int i = 0; i < f->nvars; ++i) { if (f->vars[i].isrec) last_rec = i; else last_fix = i; }
+        for (int i = 0; i < f->nvars && !rc; ++i) {
+            const int may_be_big = f->vars[i].isrec ? (i == last_rec) : (i == last_fix && last_rec < 0);
+            if (f->vars[i].vsize > vmax && !may_be_big) rc = NCC_EVARSIZE;
+            if (f->format == 1 && nb[i] > 0x7FFFFFFFull) rc = NCC_EVARSIZE;
+        }
+        if (rc) { free(nb); return rc; }
+    }
     if (f->has_data) {
         /* only layouts that keep the record structure can be moved in place */
         if (f->numrecs > 0 && f->recsize != f->old_recsize) rc = NCC_EINVAL;
@@ -1046,6 +1063,7 @@ const char *ncc_strerror(int status) {
         case NCC_EEDGE: return "NetCDF: Start+count exceeds dimension bound";
         case NCC_ERANGE: return "NetCDF: Numeric conversion not representable";
         case NCC_ENOMEM: return "NetCDF: Memory allocation (malloc) failure";
+        case NCC_EVARSIZE: return "NetCDF: One or more variable sizes violate format constraints";
         case NCC_EIO: return "NetCDF: I/O failure";
         case NCC_ENOENT: return "No such file or directory";
         case NCC_EHDFERR: return g_h5_msg;

@@ -45,6 +45,7 @@ enum { NCC_GLOBAL = -1, NCC_MAX_NAME = 256, NCC_MAX_DIMS = 16 };
 #define NCC_EEDGE      (-57)
 #define NCC_ERANGE     (-60)
 #define NCC_ENOMEM     (-61)
+#define NCC_EVARSIZE   (-62)   /* a variable or an offset does not fit the format (CDF-1 / CDF-2 limits) */
 #define NCC_EIO        (-68)
 #define NCC_ENOENT     (-90)   /* file does not exist / cannot be opened */
 #define NCC_EHDFERR   (-101)   /* NetCDF-4 file: HDF5 plug-in missing, or an HDF5 call failed */

@@ -167,3 +167,56 @@ def test_cdf5_round_trip_and_redef_with_data(nc, tmp_path):
     ok(nc, nc.ncc_get_att(ncid, 3, b"iweight", INT, out.ctypes.data_as(C.c_void_p)))
     assert out[0] == 24
     ok(nc, nc.ncc_close(ncid))
+
+
+def _define(lib, path, fmt, variables, dims):
+    """create `path`, define dims {name: len} and variables [(name, dims)] as floats -> (ncid, status of enddef)"""
+    ncid = C.c_int()
+    ok(lib, lib.ncc_create(path.encode(), fmt, 1, C.byref(ncid)))
+    ids = {}
+    for name, n in dims.items():
+        d = C.c_int()
+        ok(lib, lib.ncc_def_dim(ncid, name.encode(), C.c_size_t(n), C.byref(d)))
+        ids[name] = d.value
+    for name, vd in variables:
+        vid = C.c_int()
+        di = (C.c_int * len(vd))(*[ids[d] for d in vd])
+        ok(lib, lib.ncc_def_var(ncid, name.encode(), FLOAT, len(vd), di, C.byref(vid)))
+    return ncid, lib.ncc_enddef(ncid)
+
+
+def test_classic_formats_refuse_variables_and_offsets_that_do_not_fit(nc, tmp_path):
+    """CDF-1 / CDF-2 store vsize (and CDF-1: begin) in 32 bits.  A layout that does not fit is refused with NC_EVARSIZE
+    instead of being written with a clamped size or a truncated offset; the one exception of the format -- the last
+    fixed-size variable of a file without record variables, or the last record variable -- and CDF-5 are accepted.
+    (Headers only: no data is written, the files stay a few hundred bytes.)"""
+    big = {"t": 0, "y": 40000, "x": 40000}                       # 40000 x 40000 floats = 6.4 GB
+    EVARSIZE = -62
+    p = str(tmp_path / "v.nc")
+    for fmt in (1, 2):
+        ncid, rc = _define(nc, p, fmt, [("a", ("y", "x")), ("b", ("y", "x"))], big)          # a big variable that is not the last
+        assert rc == EVARSIZE and b"variable sizes" in nc.ncc_strerror(rc)
+        nc.ncc_close(ncid)
+        ncid, rc = _define(nc, p, fmt, [("a", ("y", "x")), ("r", ("t", "x"))], big)          # big fixed variable + a record variable
+        assert rc == EVARSIZE
+        nc.ncc_close(ncid)
+        ncid, rc = _define(nc, p, fmt, [("r", ("t", "y", "x")), ("s", ("t", "x"))], big)     # a big record that is not the last
+        assert rc == EVARSIZE
+        nc.ncc_close(ncid)
+    ncid, rc = _define(nc, p, 2, [("small", ("x",)), ("a", ("y", "x"))], big)                # the exception: last fixed variable
+    ok(nc, rc)
+    nc.ncc_close(ncid)
+    ncid, rc = _define(nc, p, 2, [("s", ("t", "x")), ("r", ("t", "y", "x"))], big)           # the exception: last record variable
+    ok(nc, rc)
+    nc.ncc_close(ncid)
+    # CDF-1: three 1.2 GB variables fit one by one, but the third one begins beyond 2^31
+    mid = {"y": 17500, "x": 17500}
+    ncid, rc = _define(nc, p, 1, [("a", ("y", "x")), ("b", ("y", "x")), ("c", ("y", "x"))], mid)
+    assert rc == EVARSIZE
+    nc.ncc_close(ncid)
+    ncid, rc = _define(nc, p, 2, [("a", ("y", "x")), ("b", ("y", "x")), ("c", ("y", "x"))], mid)   # 64-bit offsets: fine
+    ok(nc, rc)
+    nc.ncc_close(ncid)
+    ncid, rc = _define(nc, p, 5, [("a", ("y", "x")), ("b", ("y", "x"))], big)                # CDF-5: 64-bit sizes
+    ok(nc, rc)
+    nc.ncc_close(ncid)
