@@ -18,8 +18,9 @@
  *     with amdflang -O1 -ffp-contract=off into oracle/_ref/liblift_ref.so; tests/golden/lift_*.npz hold the
  *     harness outputs and tests/test_lift.py compares.  That pins evaluation order, r4/r8 mixing and index ranges
  *     -- what a transcription can get wrong -- not cdfio, the option parsers or the file layouts.
- *   - cdfmocsig, cdfmean, cdfsum, cdfzonal*, cdfvint, cdfvertmean, cdfvhst, cdfvtrp loops : unpinned,
- *     read line by line from the cited source.
+ *   - cdfmocsig (+ -isodep, -eiv, -full, -ntr, TEOS-10), cdfmean (+ basins, -var, -S, -full), cdfsum (model / forcing
+ *     form, -nowght -nomsk), cdfzonalsum (+ -pdeg), cdfzonalmean (+ -max), cdfvint (model / GSOP / OCCIPUT depths, means,
+ *     -full), cdfvertmean, cdfvhst, cdfvtrp : PINNED the same way (tests/test_lift_next.py).
  *
  * Arrays are Fortran column-major (first index fastest), as in include/cdftools_hip.h.
  */

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """oracle/ref_lift.py -- harnesses around LITERAL statements of the reference programs (TEST INFRASTRUCTURE).
 
-What this is.  The eight cdf*.f90 programs of the reference cannot be built in this image: they reach NetCDF
+What this is.  The cdf*.f90 programs of the reference cannot be built in this image: they reach NetCDF
 through cdfio.F90 and netcdf-fortran is absent.  Their ARITHMETIC, however, is plain
 Fortran.  This script reads /root/reference/src/<tool>.f90 where it lies and writes, into the git-ignored
 oracle/_ref/, one Fortran subroutine per tool made of
@@ -40,7 +40,7 @@ REF = os.environ.get("CDFT_REFERENCE_SRC", "/root/reference/src")
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(HERE, "_ref")
 
-IO_TOKEN = re.compile(r"\b(getvar|getvare3|getvar1d|putvar|putvar1d|closeout|PRINT|WRITE|STOP)\b", re.I)
+IO_TOKEN = re.compile(r"\b(getvar|getvare3|getvar1d|putvar|putvar1d|putvar0d|closeout|PRINT|WRITE|STOP|OPEN|CLOSE)\b", re.I)
 
 
 # SHA-256 (first 16 hex digits) of every lifted range at the reference revision this was written for
@@ -59,6 +59,26 @@ SHAS = {
                   '159-159': '355959c032428590', '160-168': 'e7924de889e9fd84', '186-259': '190b74a4951ddade'},
     "cdfcurl.f90": {'26-64': '2e0ba28c42a38070', '190-198': '1cf01aed8a82cb4b', '200-225': 'b703bc172976af47',
                     '238-238': '1e01b69985fc68f0', '242-304': '436d55fbb38c6d62'},
+    "cdfvhst.f90": {'25-56': '3fabc6e253b698e3', '129-135': 'b79d5deead59e1a4', '140-142': '09aecf481b63a53f',
+                    '144-181': 'dc19234ad642a260'},
+    "cdfvtrp.f90": {'27-62': '3a1911d6740770e8', '151-163': 'abe836d83ab5b2a5', '167-176': '2982ef76148e7ef4',
+                    '178-252': 'aa4ef0b140e159e0'},
+    "cdfsum.f90": {'29-79': '70fa8b3dc7293818', '214-217': 'a237d141ae03476c', '275-286': '9eef53076f4ffe91',
+                   '290-349': 'c55d0345bfb35f54'},
+    "cdfmean.f90": {'27-109': '2afc692c05a8c49c', '294-303': '3810e05a885119c3', '361-366': '30c75f9da2454881',
+                    '368-373': '2d3f4324de749945', '376-378': '16a1fb636762cdc2', '383-389': '25303bff04b9110c',
+                    '396-482': 'd620d6b665ebeee5'},
+    "cdfvertmean.f90": {'28-79': 'c8171621ff04d256', '183-188': '0df32f3e32228af5', '210-218': '733b29a12144d7b3',
+                        '224-269': '168e09af6bf3b12c'},
+    "cdfvint.f90": {'28-68': 'bd62e334b804c648', '234-242': 'dc6d815578f78f00', '245-259': '8cc915212078de44',
+                    '268-313': 'b699a0f2a22070ff'},
+    "cdfzonalsum.f90": {'27-83': 'ad0b9842a9a961ac', '246-252': '0882565e17aedd7e', '255-280': '6fa18a4d6c72f75a',
+                        '286-294': 'dcf9e73016b19a2c', '297-326': '9bd815763a8a2722'},
+    "cdfzonalmean.f90": {'27-84': 'a13dce4e4fd7aad5', '248-256': '1a4ec079c4829d95', '259-278': '150e86ef5d5a1311',
+                         '287-297': '73cf4242f36fa74f', '300-350': '2349b9d6ecf65284'},
+    "cdfmocsig.f90": {'40-108': '9b8d04603f1640c1', '255-261': '37870c2cf98ed885', '299-304': '24fccd9c0d50516c',
+                      '308-323': 'd5334578d236b66e', '325-328': 'ab5348a0318ad2fd', '342-342': 'bc3b9905f14f22c2',
+                      '347-359': 'bda9394497041e7f', '361-476': '2a40e249c283bba6', '477-485': '1a302182f99b7d53'},
 }
 
 
@@ -165,7 +185,7 @@ class Tool:
         if n in self.capture:
             return self.capture[n]
         s = ln
-        if re.match(r"\s*(PRINT|WRITE)\b", s, re.I) or re.search(r"\)\s*(PRINT|WRITE)\b", code, re.I):
+        if re.match(r"\s*(PRINT|WRITE|OPEN|CLOSE)\b", s, re.I) or re.search(r"\)\s*(PRINT|WRITE|OPEN|CLOSE)\b", code, re.I):
             return "  ! [lift] I/O dropped: " + s.strip()
         for name in ("getvare3", "getvar1d"):
             c = find_call(s, name)
@@ -179,11 +199,18 @@ class Tool:
             arr = self.varmap[pos[1]]
             lev = pos[2]
             t = kw.get("ktime", "1")
+            if "(" in arr:                                      # the tool spec gives the whole array section
+                return s[:c[0]] + arr.format(lev=lev, t=t) + s[c[1]:]
             return s[:c[0]] + f"{arr}(:,:,{lev},{t})" + s[c[1]:]
         c = find_call(s, "putvar1d")
         if c:
             m = re.search(r"\bierr\s*=\s*$", s[:c[0]])
             return s[:m.start()] + "ierr = 0" + s[c[1]:]
+        c = find_call(s, "putvar0d")
+        if c:
+            pos, kw = self._kw(c[2])
+            m = re.search(r"\bierr\s*=\s*$", s[:c[0]])
+            return s[:m.start()] + self.putvar0d(pos, kw) + s[c[1]:]
         c = find_call(s, "putvar")
         if c:
             pos, kw = self._kw(c[2])
@@ -202,7 +229,19 @@ class Tool:
 
     def lift(self, a, b):
         self.check_sha(a, b)
-        return [self.rewrite(n, ln) for n, ln in enumerate(self.text(a, b), a)]
+        out, lines, i = [], self.text(a, b), 0
+        while i < len(lines):
+            n, ln = a + i, lines[i]
+            code = ln.split("!")[0]
+            # an I/O call continued over several lines (`getvar(... , &` / `& ktime=it ...)`) is joined before it is rewritten
+            while IO_TOKEN.search(code) and code.rstrip().endswith("&") and i + 1 < len(lines):
+                i += 1
+                nxt = lines[i].split("!")[0].strip()
+                ln = code.rstrip()[:-1].rstrip() + " " + (nxt[1:].lstrip() if nxt.startswith("&") else nxt)
+                code = ln
+            out.append(self.rewrite(n, ln))
+            i += 1
+        return out
 
     def expand(self, template):
         out = []
@@ -472,8 +511,350 @@ def gen_cdfcurl():
     return t, t.expand(CDFCURL)
 
 
+# =============================================================================================== cdfvhst
+# src/cdfvhst.f90: declarations :25-56, ALLOCATE :129-135, metrics :140-142, time loop :144-181.
+CDFVHST = r"""
+SUBROUTINE lift_cdfvhst(kpi, kpj, kpk, kpt, kfull, h_e1v, h_e2u, h_e31d, h_e3v, h_e3u, h_vt, h_vs, h_ut, h_us, o_var) &
+     &  BIND(C, name='lift_cdfvhst')
+  USE ISO_C_BINDING
+  IMPLICIT NONE
+  INTEGER(C_INT), VALUE :: kpi, kpj, kpk, kpt, kfull
+  REAL(C_FLOAT), INTENT(in) :: h_e1v(kpi,kpj,1,1), h_e2u(kpi,kpj,1,1), h_e31d(kpk), h_e3v(kpi,kpj,kpk,1), h_e3u(kpi,kpj,kpk,1)
+  REAL(C_FLOAT), INTENT(in) :: h_vt(kpi,kpj,kpk,kpt), h_vs(kpi,kpj,kpk,kpt), h_ut(kpi,kpj,kpk,kpt), h_us(kpi,kpj,kpk,kpt)
+  REAL(C_FLOAT), INTENT(out) :: o_var(kpi,kpj,4,kpt)          ! SNGL(dtrpvt), SNGL(dtrpvs), SNGL(dtrput), SNGL(dtrpus)
+  LOGICAL :: lg_vvl = .FALSE.
+!@DECLS 25 56
+  npiglo = kpi ; npjglo = kpj ; npk = kpk ; npt = kpt ; lfull = ( kfull /= 0 ) ; lg_vvl = .FALSE.
+!@RAW 129 135
+!@LIFT 140 142
+!@LIFT 144 181
+END SUBROUTINE lift_cdfvhst
+"""
+
+
+def gen_cdfvhst():
+    t = Tool("cdfvhst.f90",
+             {"cn_ve1v": "h_e1v", "cn_ve2u": "h_e2u", "cn_ve3t1d": "h_e31d", "cn_vomevt": "h_vt", "cn_vomevs": "h_vs",
+              "cn_vozout": "h_ut", "cn_vozous": "h_us", "cn_ve3v": "h_e3v", "cn_ve3u": "h_e3u"},
+             putvar=lambda pos, kw: f"o_var(:,:,{varidx(pos[1])},{kw.get('ktime', '1')}) = {pos[2]}")
+    return t, t.expand(CDFVHST)
+
+
+# =============================================================================================== cdfvtrp (SURVEY 8f)
+# src/cdfvtrp.f90: declarations :27-62, ALLOCATE :151-163, metrics :167-176, time loop :178-252 (with -bathy: the slope
+# rotation through the compiler's ATAN2 / COS / SIN).
+CDFVTRP = r"""
+SUBROUTINE lift_cdfvtrp(kpi, kpj, kpk, kpt, kfull, kbathy, h_e1v, h_e2u, h_e1u, h_e2v, h_tmask, h_hdepw, h_e31d, h_e3v, h_e3u, &
+     &  h_u, h_v, o_var) BIND(C, name='lift_cdfvtrp')
+  USE ISO_C_BINDING
+  IMPLICIT NONE
+  INTEGER(C_INT), VALUE :: kpi, kpj, kpk, kpt, kfull, kbathy
+  REAL(C_FLOAT), INTENT(in) :: h_e1v(kpi,kpj,1,1), h_e2u(kpi,kpj,1,1), h_e1u(kpi,kpj,1,1), h_e2v(kpi,kpj,1,1)
+  REAL(C_FLOAT), INTENT(in) :: h_tmask(kpi,kpj,1,1), h_hdepw(kpi,kpj,1,1), h_e31d(kpk), h_e3v(kpi,kpj,kpk,1), h_e3u(kpi,kpj,kpk,1)
+  REAL(C_FLOAT), INTENT(in) :: h_u(kpi,kpj,kpk,kpt), h_v(kpi,kpj,kpk,kpt)
+  REAL(C_FLOAT), INTENT(out) :: o_var(kpi,kpj,4,kpt)          ! REAL(dtrpu), REAL(dtrpv) [, along-slope, cross-slope]
+  LOGICAL :: lg_vvl = .FALSE.
+!@DECLS 27 62
+  npiglo = kpi ; npjglo = kpj ; npk = kpk ; npt = kpt ; lfull = ( kfull /= 0 ) ; lbathy = ( kbathy /= 0 ) ; lg_vvl = .FALSE.
+  o_var = 0.
+!@RAW 151 163
+!@LIFT 167 176
+!@LIFT 178 252
+END SUBROUTINE lift_cdfvtrp
+"""
+
+
+def gen_cdfvtrp():
+    t = Tool("cdfvtrp.f90",
+             {"cn_ve1v": "h_e1v", "cn_ve2u": "h_e2u", "cn_ve1u": "h_e1u", "cn_ve2v": "h_e2v", "cn_tmask": "h_tmask",
+              "cn_hdepw": "h_hdepw", "cn_ve3t1d": "h_e31d", "cn_vozocrtx": "h_u", "cn_vomecrty": "h_v", "cn_ve3v": "h_e3v",
+              "cn_ve3u": "h_e3u"},
+             putvar=lambda pos, kw: f"o_var(:,:,{varidx(pos[1])},{kw.get('ktime', '1')}) = {pos[2]}")
+    return t, t.expand(CDFVTRP)
+
+
+# =============================================================================================== cdfsum (SURVEY 8f)
+# src/cdfsum.f90: declarations :29-79, ALLOCATE :214-217, metrics :275-286, time loop :290-349.  The PRINTs of the level
+# sums (:324 / :327, forcing form :334) become the capture of dsurf, dvol2d, dsum2d.
+CDFSUM = r"""
+SUBROUTINE lift_cdfsum(kpi, kpj, kpk, kpt, kforcing, knwgh, knmsk, h_e1, h_e2, h_dep, h_e3, h_msk, h_in, o_var, o_sums) &
+     &  BIND(C, name='lift_cdfsum')
+  USE ISO_C_BINDING
+  IMPLICIT NONE
+  INTEGER(C_INT), VALUE :: kpi, kpj, kpk, kpt, kforcing, knwgh, knmsk
+  REAL(C_FLOAT), INTENT(in) :: h_e1(kpi,kpj,1,1), h_e2(kpi,kpj,1,1), h_dep(kpk), h_e3(kpi,kpj,kpk,1), h_msk(kpi,kpj,kpk,1)
+  REAL(C_FLOAT), INTENT(in) :: h_in(kpi,kpj,kpk,kpt)
+  REAL(C_FLOAT),  INTENT(out) :: o_var(kpk,3,kpt)            ! rdummy as handed to putvar: level sums, cumulated, per record
+  REAL(C_DOUBLE), INTENT(out) :: o_sums(3,kpk,kpt)           ! dsurf, dvol2d, dsum2d of each level
+  LOGICAL :: lg_vvl = .FALSE.
+!@DECLS 29 79
+  npiglo = kpi ; npjglo = kpj ; npk = kpk ; npt = kpt ; npkk = kpk ; nvpk = kpk
+  iimin = 1 ; ijmin = 1 ; ikmin = 1 ; ikmax = kpk             ! no -w window: src/cdfsum.f90:190-192
+  lforcing = ( kforcing /= 0 ) ; lnwgh = ( knwgh /= 0 ) ; lnmsk = ( knmsk /= 0 ) ; lg_vvl = .FALSE.
+  o_var = 0. ; o_sums = 0.d0
+!@RAW 214 217
+!@LIFT 275 286
+!@LIFT 290 349
+END SUBROUTINE lift_cdfsum
+"""
+
+
+def gen_cdfsum():
+    cap = "           o_sums(1,ik,jt) = dsurf ; o_sums(2,ik,jt) = dvol2d ; o_sums(3,ik,jt) = dsum2d   ! [lift] capture of the PRINT"
+    capf = "           o_sums(1,ik,jt) = dsurf ; o_sums(3,ik,jt) = dsum2d   ! [lift] capture of the PRINT"
+    t = Tool("cdfsum.f90",
+             {"cv_e1": "h_e1", "cv_e2": "h_e2", "cv_dep": "h_dep", "cv_in": "h_in", "cv_msk": "h_msk", "cv_e3": "h_e3"},
+             putvar=lambda pos, kw: f"o_var({pos[3]}:{pos[3]},{varidx(pos[1])}:{varidx(pos[1])},{kw.get('ktime', '1')}) = {pos[2]}",
+             capture={324: cap, 327: cap, 334: capf})
+    return t, t.expand(CDFSUM)
+
+
+# =============================================================================================== cdfmean (SURVEY 8f)
+# src/cdfmean.f90: declarations :27-109, ALLOCATE :294-303, metrics :361-366, :376-378, basin masks :383-389, time loop
+# :396-482.  The WRITEs of the level values (:429 / :440) become the capture of dsurf, dvol2d, dsum2d, dvar2d.
+CDFMEAN = r"""
+SUBROUTINE lift_cdfmean(kpi, kpj, kpk, kpt, kbasin, kfull, kvar, ksum, h_e1, h_e2, h_e31d, h_dep, h_e3, h_msk, h_bas, h_in, &
+     &  knv, o_var, o_var0, o_sums) BIND(C, name='lift_cdfmean')
+  USE ISO_C_BINDING
+  IMPLICIT NONE
+  INTEGER(C_INT), VALUE :: kpi, kpj, kpk, kpt, kbasin, kfull, kvar, ksum, knv
+  REAL(C_FLOAT), INTENT(in) :: h_e1(kpi,kpj,1,1), h_e2(kpi,kpj,1,1), h_e31d(kpk), h_dep(kpk), h_e3(kpi,kpj,kpk,1), h_msk(kpi,kpj,kpk,1)
+  REAL(C_FLOAT), INTENT(in) :: h_bas(kpi,kpj,kbasin,1), h_in(kpi,kpj,kpk,kpt)
+  REAL(C_FLOAT),  INTENT(out) :: o_var(kpk,knv,kpt)          ! rdummymean as handed to putvar, per output variable index
+  REAL(C_FLOAT),  INTENT(out) :: o_var0(knv,kpt)             ! rdummy as handed to putvar0d
+  REAL(C_DOUBLE), INTENT(out) :: o_sums(4,kbasin,kpk,kpt)    ! dsurf, dvol2d, dsum2d, dvar2d of each level and basin
+  LOGICAL :: lg_vvl = .FALSE.
+  INTEGER :: jb_
+!@DECLS 27 109
+  npiglo = kpi ; npjglo = kpj ; npk = kpk ; npt = kpt ; nvpk = kpk ; npk_fi = kpk ; nbasin = kbasin
+  iimin = 1 ; ijmin = 1 ; ikmin = 1 ; ikmax = kpk             ! no -w window: src/cdfmean.f90:268-270
+  lbas = ( kbasin > 1 ) ; lfull = ( kfull /= 0 ) ; lvar = ( kvar /= 0 ) ; lsum = ( ksum /= 0 ) ; lg_vvl = .FALSE.
+  o_var = 0. ; o_var0 = 0. ; o_sums = 0.d0
+!@RAW 294 303
+!@LIFT 361 366
+!@RAW 368 373
+  ALLOCATE ( ipk(nvars), id_varout(nvars) )
+!@RAW 376 378
+  ! output variable numbers as CreateOutput hands them out (src/cdfmean.f90:556-620): per basin mean, mean3d [, var, var3d] [, sum, sum3d]
+  DO jb_ = 1, nbasin
+     ivarb = nvars_bas * (jb_ - 1)
+     n_mean(jb_) = ivarb + 1 ; n_mean3d(jb_) = ivarb + 2
+     ivar = 2
+     IF ( lvar ) THEN ; n_var(jb_) = ivarb + ivar + 1 ; n_var3d(jb_) = ivarb + ivar + 2 ; ivar = ivar + 2 ; ENDIF
+     IF ( lsum ) THEN ; n_sum(jb_) = ivarb + ivar + 1 ; n_sum3d(jb_) = ivarb + ivar + 2 ; ENDIF
+  ENDDO
+  ALLOCATE ( cbasins(nbasin) ) ; cbasins = 'basin'
+!@LIFT 383 389
+!@LIFT 396 482
+END SUBROUTINE lift_cdfmean
+"""
+
+
+def gen_cdfmean():
+    cap = ("              o_sums(1,jbasin,jk,jt) = dsurf ; o_sums(2,jbasin,jk,jt) = dvol2d ; o_sums(3,jbasin,jk,jt) = dsum2d ; "
+           "o_sums(4,jbasin,jk,jt) = dvar2d   ! [lift] capture of the WRITE")
+    t = Tool("cdfmean.f90",
+             {"cv_e1": "h_e1", "cv_e2": "h_e2", "cv_e31d": "h_e31d", "cv_dep": "h_dep", "cv_nam": "h_in", "cv_msk": "h_msk",
+              "cv_e3": "h_e3", "cbasins(jbasin)": "h_bas(:,:,jbasin,1)"},
+             putvar=lambda pos, kw: f"o_var({pos[3]}:{pos[3]},{varidx(pos[1])}:{varidx(pos[1])},{kw.get('ktime', '1')}) = {pos[2]}",
+             capture={429: cap, 440: cap})
+    t.putvar0d = lambda pos, kw: f"o_var0({varidx(pos[1])}:{varidx(pos[1])},{kw.get('ktime', '1')}:{kw.get('ktime', '1')}) = {pos[2]}"
+    return t, t.expand(CDFMEAN)
+
+
+# =============================================================================================== cdfvertmean (SURVEY 8f)
+# src/cdfvertmean.f90: declarations :28-79, ALLOCATE :183-188, depths :210-218, time loop :224-269.
+CDFVERTMEAN = r"""
+SUBROUTINE lift_cdfvertmean(kpi, kpj, kpk, kpt, kfull, pup, pdown, h_dep, h_e31d, h_e3, h_msk, h_in, o_var) &
+     &  BIND(C, name='lift_cdfvertmean')
+  USE ISO_C_BINDING
+  IMPLICIT NONE
+  INTEGER(C_INT), VALUE :: kpi, kpj, kpk, kpt, kfull
+  REAL(C_FLOAT), VALUE :: pup, pdown
+  REAL(C_FLOAT), INTENT(in) :: h_dep(kpk), h_e31d(kpk), h_e3(kpi,kpj,kpk,1), h_msk(kpi,kpj,kpk,1), h_in(kpi,kpj,kpk,kpt)
+  REAL(C_FLOAT), INTENT(out) :: o_var(kpi,kpj,1,kpt)          ! REAL(dvertmean) as handed to putvar
+  LOGICAL :: lg_vvl = .FALSE.
+!@DECLS 28 79
+  npiglo = kpi ; npjglo = kpj ; npk = kpk ; npt = kpt ; nvaro = 1 ; iimin = 1 ; ijmin = 1
+  lfull = ( kfull /= 0 ) ; lg_vvl = .FALSE. ; rdep_up = pup ; rdep_down = pdown
+  ALLOCATE ( cv_in(1), ipk(1), id_varout(1) ) ; cv_in(1) = 'field'
+!@RAW 183 188
+!@LIFT 210 218
+!@LIFT 224 269
+END SUBROUTINE lift_cdfvertmean
+"""
+
+
+def gen_cdfvertmean():
+    t = Tool("cdfvertmean.f90",
+             {"cv_dep": "h_dep", "cv_e31d": "h_e31d", "cv_cur": "h_in", "cv_msk": "h_msk", "cv_e3": "h_e3"},
+             putvar=lambda pos, kw: f"o_var(:,:,{varidx(pos[1])},{kw.get('ktime', '1')}) = {pos[2]}")
+    return t, t.expand(CDFVERTMEAN)
+
+
+# =============================================================================================== cdfvint (SURVEY 8f)
+# src/cdfvint.f90: declarations :28-68, ALLOCATE :234-242, depths :245-259, time loop :268-313.
+CDFVINT = r"""
+SUBROUTINE lift_cdfvint(kpi, kpj, kpk, kpt, kfull, kgsop, kocci, kmean, psclf, h_gdepw, h_e31d, h_tmask, h_e3t, h_in, knpko, o_var) &
+     &  BIND(C, name='lift_cdfvint')
+  USE ISO_C_BINDING
+  IMPLICIT NONE
+  INTEGER(C_INT), VALUE :: kpi, kpj, kpk, kpt, kfull, kgsop, kocci, kmean, knpko
+  REAL(C_FLOAT), VALUE :: psclf
+  REAL(C_FLOAT), INTENT(in) :: h_gdepw(kpk), h_e31d(kpk), h_tmask(kpi,kpj,kpk,1), h_e3t(kpi,kpj,kpk,1), h_in(kpi,kpj,kpk,kpt)
+  REAL(C_FLOAT), INTENT(out) :: o_var(kpi,kpj,knpko+1,kpt)    ! REAL(dl_vint2) [/rdep2] as handed to putvar, per output depth
+  LOGICAL :: lg_vvl = .FALSE.
+!@DECLS 28 68
+  npiglo = kpi ; npjglo = kpj ; npk = kpk ; npt = kpt ; npko = knpko ; iimin = 1 ; ijmin = 1
+  lfull = ( kfull /= 0 ) ; lgsop = ( kgsop /= 0 ) ; locci = ( kocci /= 0 ) ; ltmean = ( kmean /= 0 ) ; lsmean = .FALSE.
+  sclf = psclf ; lg_vvl = .FALSE.
+  o_var = 0.
+!@RAW 234 242
+!@LIFT 245 259
+!@LIFT 268 313
+END SUBROUTINE lift_cdfvint
+"""
+
+
+def gen_cdfvint():
+    t = Tool("cdfvint.f90",
+             {"cn_gdepw": "h_gdepw", "cn_ve3t1d": "h_e31d", "cn_tmask": "h_tmask", "cv_in": "h_in", "cn_ve3t": "h_e3t"},
+             putvar=lambda pos, kw: f"o_var(:,:,{pos[3]},{kw.get('ktime', '1')}) = {pos[2]}")
+    return t, t.expand(CDFVINT)
+
+
+# =============================================================================================== cdfzonalsum (SURVEY 8f)
+# src/cdfzonalsum.f90: declarations :27-83, ALLOCATE :246-252, metrics / alpha / depths :255-280, basin masks :286-294,
+# main loop :297-326 (one variable of npk levels).
+CDFZONALSUM = r"""
+SUBROUTINE lift_cdfzonalsum(kpi, kpj, kpk, kpt, kbas, kpdeg, h_e1, h_e2, h_phi, h_dep, h_msk, h_atl, h_ind, h_pac, h_in, o_var, o_r8) &
+     &  BIND(C, name='lift_cdfzonalsum')
+  USE ISO_C_BINDING
+  IMPLICIT NONE
+  INTEGER(C_INT), VALUE :: kpi, kpj, kpk, kpt, kbas, kpdeg
+  REAL(C_FLOAT), INTENT(in) :: h_e1(kpi,kpj,1,1), h_e2(kpi,kpj,1,1), h_phi(kpi,kpj,1,1), h_dep(kpk), h_msk(kpi,kpj,kpk,1)
+  REAL(C_FLOAT), INTENT(in) :: h_atl(kpi,kpj,1,1), h_ind(kpi,kpj,1,1), h_pac(kpi,kpj,1,1), h_in(kpi,kpj,kpk,kpt)
+  REAL(C_FLOAT),  INTENT(out) :: o_var(kpj,kpk,kbas,kpt)     ! REAL(dzosum(:,jk)) as handed to putvar
+  REAL(C_DOUBLE), INTENT(out) :: o_r8(kpj,kpk,kbas,kpt)      ! dzosum(:,jk) itself
+!@DECLS 27 83
+  npiglo = kpi ; npjglo = kpj ; npk = kpk ; npt = kpt ; npbasins = kbas ; lpdeg = ( kpdeg /= 0 ) ; l2d = .FALSE.
+  nvar = 1 ; nvaro = 1 ; nvarin = 1 ; nvarmx = npbasins
+  cf_basins = 'none' ; IF ( kbas == 5 ) cf_basins = 'yes'        ! (initialised variables are SAVEd: set both ways)
+  ALLOCATE ( cv_namesi(1), ipki(1), id_varin(1), ipko(nvarmx), id_varout(nvarmx) )
+  cv_namesi(1) = 'field' ; ipki(1) = npk ; id_varin(1) = 1
+!@RAW 246 252
+!@LIFT 255 280
+!@LIFT 286 294
+!@LIFT 297 326
+END SUBROUTINE lift_cdfzonalsum
+"""
+
+
+def gen_cdfzonalsum():
+    t = Tool("cdfzonalsum.f90",
+             {"cv_e1": "h_e1", "cv_e2": "h_e2", "cv_phi": "h_phi", "cv_depi": "h_dep", "cv_msk": "h_msk", "cn_tmaskatl": "h_atl",
+              "cn_tmaskind": "h_ind", "cn_tmaskpac": "h_pac", "cv_namesi(ijvar)": "h_in"},
+             putvar=lambda pos, kw: (f"o_var(:,{pos[3]},{varidx(pos[1])},{kw.get('ktime', '1')}) = {pos[2]} ; "
+                                     f"o_r8(:,{pos[3]},{varidx(pos[1])},{kw.get('ktime', '1')}) = dzosum(:,jk)"))
+    return t, t.expand(CDFZONALSUM)
+
+
+# =============================================================================================== cdfzonalmean (SURVEY 8f)
+# src/cdfzonalmean.f90: declarations :27-84, ALLOCATE :248-256, metrics / depths :259-278, basin masks :287-297, main loop
+# :300-350 (one variable of npk levels; -max: extrema).
+CDFZONALMEAN = r"""
+SUBROUTINE lift_cdfzonalmean(kpi, kpj, kpk, kpt, kbas, kmax, h_e1, h_e2, h_phi, h_dep, h_msk, h_atl, h_ind, h_pac, h_in, o_var, o_r8, &
+     &  o_area) BIND(C, name='lift_cdfzonalmean')
+  USE ISO_C_BINDING
+  IMPLICIT NONE
+  INTEGER(C_INT), VALUE :: kpi, kpj, kpk, kpt, kbas, kmax
+  REAL(C_FLOAT), INTENT(in) :: h_e1(kpi,kpj,1,1), h_e2(kpi,kpj,1,1), h_phi(kpi,kpj,1,1), h_dep(kpk), h_msk(kpi,kpj,kpk,1)
+  REAL(C_FLOAT), INTENT(in) :: h_atl(kpi,kpj,1,1), h_ind(kpi,kpj,1,1), h_pac(kpi,kpj,1,1), h_in(kpi,kpj,kpk,kpt)
+  REAL(C_FLOAT),  INTENT(out) :: o_var(kpj,kpk,3*kbas,kpt)   ! REAL(dzomean(:,jk)) [, rzomax, rzomin] as handed to putvar
+  REAL(C_DOUBLE), INTENT(out) :: o_r8(kpj,kpk,kbas,kpt)      ! dzomean(:,jk) after the division
+  REAL(C_DOUBLE), INTENT(out) :: o_area(kpj,kpk,kbas,kpt)    ! darea(:,jk)
+!@DECLS 27 84
+  npiglo = kpi ; npjglo = kpj ; npk = kpk ; npt = kpt ; npbasins = kbas ; lmax = ( kmax /= 0 ) ; l2d = .FALSE.
+  nvar = 1 ; nvarin = 1 ; nvaro = npbasins ; nvarmx = 3 * npbasins          ! nvaro as CreateOutput leaves it (the count of mean variables): src/cdfzonalmean.f90:448
+  cf_basins = 'none' ; IF ( kbas == 5 ) cf_basins = 'yes'        ! (initialised variables are SAVEd: set both ways)
+  ALLOCATE ( cv_namesi(1), ipki(1), id_varin(1), ipko(nvarmx), id_varout(nvarmx) )
+  cv_namesi(1) = 'field' ; ipki(1) = npk ; id_varin(1) = 1
+  o_var = 0.
+!@RAW 248 256
+!@LIFT 259 278
+!@LIFT 287 297
+!@LIFT 300 350
+END SUBROUTINE lift_cdfzonalmean
+"""
+
+
+def gen_cdfzonalmean():
+    def put(pos, kw):
+        base = f"o_var(:,{pos[3]},{varidx(pos[1])},{kw.get('ktime', '1')}) = {pos[2]}"
+        if "dzomean" in pos[2]:
+            base += (f" ; o_r8(:,{pos[3]},{varidx(pos[1])},{kw.get('ktime', '1')}) = dzomean(:,jk)"
+                     f" ; o_area(:,{pos[3]},{varidx(pos[1])},{kw.get('ktime', '1')}) = darea(:,jk)")
+        return base
+    t = Tool("cdfzonalmean.f90",
+             {"cv_e1": "h_e1", "cv_e2": "h_e2", "cv_phi": "h_phi", "cv_depi": "h_dep", "cv_msk": "h_msk", "cn_tmaskatl": "h_atl",
+              "cn_tmaskind": "h_ind", "cn_tmaskpac": "h_pac", "cv_namesi(ijvar)": "h_in"},
+             putvar=put)
+    return t, t.expand(CDFZONALMEAN)
+
+
+# =============================================================================================== cdfmocsig (SURVEY 8f)
+# src/cdfmocsig.f90: declarations :40-108, sizes :255-261, bins :299-304, ALLOCATE :308-323, metrics :325-328, basin numbers
+# :342, masks :347-359, the whole time loop :361-485 (density through the reference's eos module; -isodep, -eiv, -full, -ntr).
+CDFMOCSIG = r"""
+SUBROUTINE lift_cdfmocsig(kpi, kpj, kpk, kpt, kbas, kfull, kisodep, keiv, kntr, kteos10, knbins, psigmin, psigstp, ppref, pspv, &
+     &  pspt, psps, h_e1v, h_e31d, h_gdept, h_vmask, h_atl, h_ind, h_pac, h_e3v, h_v, h_veiv, h_t, h_s, o_var, o_dmoc, o_depi) &
+     &  BIND(C, name='lift_cdfmocsig')
+  USE ISO_C_BINDING
+  USE eos                      ! the reference's src/eos.f90, compiled where it lies
+  IMPLICIT NONE
+  INTEGER(C_INT), VALUE :: kpi, kpj, kpk, kpt, kbas, kfull, kisodep, keiv, kntr, kteos10, knbins
+  REAL(C_FLOAT), VALUE :: psigmin, psigstp, ppref, pspv, pspt, psps
+  REAL(C_FLOAT), INTENT(in) :: h_e1v(kpi,kpj,1,1), h_e31d(kpk), h_gdept(kpk), h_vmask(kpi,kpj,1,1), h_atl(kpi,kpj,1,1)
+  REAL(C_FLOAT), INTENT(in) :: h_ind(kpi,kpj,1,1), h_pac(kpi,kpj,1,1), h_e3v(kpi,kpj,kpk,1), h_v(kpi,kpj,kpk,kpt)
+  REAL(C_FLOAT), INTENT(in) :: h_veiv(kpi,kpj,kpk,kpt), h_t(kpi,kpj,kpk,kpt), h_s(kpi,kpj,kpk,kpt)
+  REAL(C_FLOAT),  INTENT(out) :: o_var(kpj,knbins,2*kbas,kpt)     ! REAL(dmoc(basin,bin,:)) [, REAL(depi(..))] as handed to putvar
+  REAL(C_DOUBLE), INTENT(out) :: o_dmoc(kbas,knbins,kpj,kpt), o_depi(kbas,knbins,kpj,kpt)
+  LOGICAL :: lg_vvl = .FALSE.
+!@DECLS 40 108
+  npiglo = kpi ; npjglo = kpj ; npk = kpk ; npt = kpt
+  lbas = ( kbas == 5 ) ; lfull = ( kfull /= 0 ) ; lisodep = ( kisodep /= 0 ) ; leiv = ( keiv /= 0 ) ; lntr = ( kntr /= 0 )
+  ll_teos10 = ( kteos10 /= 0 ) ; lprint = .FALSE. ; lg_vvl = .FALSE.
+  nbins = knbins ; sigmin = psigmin ; sigstp = psigstp ; pref = ppref ; zspv = pspv ; zspt = pspt ; zsps = psps
+  CALL eos_init ( ll_teos10 )                              ! src/cdfmocsig.f90:210
+  o_var = 0. ; o_dmoc = 0.d0 ; o_depi = 0.d0
+!@RAW 255 261
+  ALLOCATE ( ipk(nvaro), id_varout(nvaro) )
+!@RAW 299 304
+!@RAW 308 323
+!@LIFT 325 328
+!@RAW 342 342
+!@LIFT 347 359
+!@LIFT 361 476
+     o_dmoc(:,:,:,jt) = dmoc(1:nbasins,:,:)
+     IF ( lisodep ) o_depi(:,:,:,jt) = depi(1:nbasins,:,:)
+!@LIFT 477 485
+END SUBROUTINE lift_cdfmocsig
+"""
+
+
+def gen_cdfmocsig():
+    t = Tool("cdfmocsig.f90",
+             {"cn_ve1v": "h_e1v", "cn_ve3t1d": "h_e31d", "cn_gdept": "h_gdept", "cn_gphiv": "h_e1v", "cn_vmask": "h_vmask",
+              "cn_tmaskatl": "h_atl", "cn_tmaskind": "h_ind", "cn_tmaskpac": "h_pac", "cn_vomecrty": "h_v", "cn_vomeeivv": "h_veiv",
+              "cn_votemper": "h_t", "cn_vosaline": "h_s", "cn_ve3v": "h_e3v"},
+             putvar=lambda pos, kw: f"o_var(:,{pos[3]},{varidx(pos[1])},{kw.get('ktime', '1')}) = {pos[2]}")
+    return t, t.expand(CDFMOCSIG)
+
+
 TOOLS = {"cdfmoc": gen_cdfmoc, "cdfheatc": gen_cdfheatc, "cdfmhst": gen_cdfmhst, "cdfpsi": gen_cdfpsi, "cdfvt": gen_cdfvt,
-         "cdfcurl": gen_cdfcurl}
+         "cdfcurl": gen_cdfcurl, "cdfvhst": gen_cdfvhst, "cdfvtrp": gen_cdfvtrp, "cdfsum": gen_cdfsum,
+         "cdfmean": gen_cdfmean, "cdfvertmean": gen_cdfvertmean, "cdfvint": gen_cdfvint,
+         "cdfzonalsum": gen_cdfzonalsum, "cdfzonalmean": gen_cdfzonalmean, "cdfmocsig": gen_cdfmocsig}
 
 
 def main():

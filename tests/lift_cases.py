@@ -142,3 +142,70 @@ def curl_ff(g):
     """dl_ff of src/cdfcurl.f90:220-224: r8, from the r4 latitude."""
     pi = np.arccos(-1.0)
     return 2 * (2 * pi / 86400.0) * np.sin(g["gphif"].astype(np.float64) * pi / 180.0)
+
+
+# ------------------------------------------------------------------------------------------ SURVEY 8f tools
+def grid8f():
+    g = synth.make_grid(29, 23, 8, seed=808)
+    t, s, u, v = tracers(g, 2, 81)
+    return g, t, s, u, v
+
+
+def vhst_case(name):
+    """-> g, vt, vs, ut, us (npt,npk,npj,npi), full"""
+    g, t, s, u, v = grid8f()
+    return g, (t * v).astype(f32), (s * v).astype(f32), (t * u).astype(f32), (s * u).astype(f32), name == "full"
+
+
+VHST_CASES = ["default", "full"]
+VTRP_CASES = ["default", "full"]
+
+
+def mean_case(name):
+    """-> g, field (npt,npk,npj,npi), basins (nb,npj,npi) r4, full, point type"""
+    g, t, s, u, v = grid8f()
+    nb, full = {"one": (1, False), "basins3_var_sum": (3, False), "full": (1, True)}[name]
+    bas = np.stack([np.ones_like(g["tmaskatl"]), g["tmaskatl"], g["tmaskpac"]]).astype(f32)[:nb]
+    return g, t, bas, full
+
+
+MEAN_CASES = ["one", "basins3_var_sum", "full"]
+SUM_CASES = ["model", "forcing", "nowght_nomsk"]
+VERTMEAN_CASES = [("15_120", 15.0, 120.0, False), ("all", 0.0, 1.0e4, False), ("thin", 30.0, 31.0, False), ("full", 15.0, 120.0, True)]
+VINT_CASES = [("model", False, False, False, False), ("gsop", False, True, False, False), ("occi_mean", False, False, True, True),
+              ("full_mean", True, False, False, True)]
+ZONAL_CASES = [("b5", 5, False), ("b1", 1, False), ("b1_opt", 1, True)]       # opt: -pdeg (sum) / -max (mean)
+
+
+def vint_gdepo(g, gsop, occi):
+    if gsop:
+        return np.array([100., 300., 500., 700., 800., 2000., 6000.], f32)
+    if occi:
+        return np.array([700., 2000., 6000.], f32)
+    return np.append(g["gdepw_1d"][1:], f32(6000.)).astype(f32)
+
+
+def vint_sclf(mean):
+    return f32(1.0) if mean else f32(f32(1020.) * f32(4000.) / f32(1e6))
+
+
+def zonal_masks(g, nb):
+    zm = np.zeros(g["e1t"].shape + (nb,), f32)
+    zm[:, :, 0] = g["tmask"][0]
+    if nb >= 5:
+        zm[:, :, 1], zm[:, :, 3], zm[:, :, 4] = g["tmaskatl"], g["tmaskind"], g["tmaskpac"]
+        zm[:, :, 2] = np.minimum(zm[:, :, 4] + zm[:, :, 3], 1)
+    return zm
+
+
+MOCSIG_CASES = [("sigma0", 0.0, (52, 23.0, 0.1), False, False, False, False), ("sigma2_teos10", 2000.0, (158, 30.0, 0.05), True, False, False, False),
+                ("sigma1_full_eiv", 1000.0, (88, 24.0, 0.1), False, True, True, False), ("ntr", 0.0, (52, 1023.0, 0.1), False, False, False, True)]
+
+
+def mocsig_fields():
+    g = synth.make_grid(25, 17, 7, seed=909)
+    sh = (2,) + g["tmask"].shape
+    zv = synth.velocity(g, 2, seed=91)
+    zt = (rnd(92, sh, -2, 28) * g["tmask"][None]).astype(f32)
+    zs = (rnd(93, sh, 33, 37) * g["tmask"][None]).astype(f32)
+    return g, zv, zt, zs

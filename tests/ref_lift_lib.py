@@ -137,3 +137,116 @@ def cdfcurl(g, u, v, forcing=False, tpoint=False, overf=False):
     o = np.zeros((npt, nlev, npj, npi), np.float64)
     load().lift_cdfcurl(*_i(npi, npj, nlev, npt, nlev, forcing, tpoint, overf), *[_p(x) for x in a], _p(o))
     return o
+
+
+# ------------------------------------------------------------------------------------------ SURVEY 8f tools
+def _m(a):
+    return _f(np.asarray(a).astype(np.float32))
+
+
+def cdfvhst(g, vt, vs, ut, us, full=False):
+    """vt, vs, ut, us (npt,npk,npj,npi) -> (npt,4,npj,npi) r4: SNGL of the four vertical integrals (vt, vs, ut, us)."""
+    vt = _f(vt)
+    npt, npk, npj, npi = vt.shape
+    o = np.zeros((npt, 4, npj, npi), np.float32)
+    a = [_f(g["e1v"]), _f(g["e2u"]), _f(g["e3t_1d"]), _f(g["e3v_0"]), _f(g["e3u_0"]), vt, _f(vs), _f(ut), _f(us)]
+    load().lift_cdfvhst(*_i(npi, npj, npk, npt, full), *[_p(x) for x in a], _p(o))
+    return o
+
+
+def cdfvtrp(g, u, v, full=False, bathy=None):
+    """u, v (npt,npk,npj,npi) -> (npt,4,npj,npi) r4: REAL(dtrpu), REAL(dtrpv) [, along- and cross-slope with bathy=hdepw]."""
+    u = _f(u)
+    npt, npk, npj, npi = u.shape
+    o = np.zeros((npt, 4, npj, npi), np.float32)
+    hd = _f(bathy) if bathy is not None else _dummy(npj, npi)
+    a = [_f(g["e1v"]), _f(g["e2u"]), _f(g["e1u"]), _f(g["e2v"]), _m(g["tmask"][0]), hd, _f(g["e3t_1d"]), _f(g["e3v_0"]), _f(g["e3u_0"]),
+         u, _f(v)]
+    load().lift_cdfvtrp(*_i(npi, npj, npk, npt, full, bathy is not None), *[_p(x) for x in a], _p(o))
+    return o
+
+
+def cdfsum(e1, e2, e3, mask, field, dep, forcing=False, nowght=False, nomsk=False):
+    """field (npt,npk,npj,npi) -> var (npt,3,npk) r4, sums (npt,npk,3) r8 (dsurf, dvol2d, dsum2d)."""
+    field = _f(field)
+    npt, npk, npj, npi = field.shape
+    o_var, o_sums = np.zeros((npt, 3, npk), np.float32), np.zeros((npt, npk, 3), np.float64)
+    a = [_f(e1), _f(e2), _f(dep), _f(e3), _m(mask), field]
+    load().lift_cdfsum(*_i(npi, npj, npk, npt, forcing, nowght, nomsk), *[_p(x) for x in a], _p(o_var), _p(o_sums))
+    return {"var": o_var, "sums": o_sums}
+
+
+def cdfmean(e1, e2, e3, e31d, mask, basins, field, dep, full=False, var=False, lsum=False):
+    """basins (nb,npj,npi) r4 0/1; field (npt,npk,npj,npi) -> var (npt,nv,npk) r4, var0 (npt,nv) r4, sums (npt,npk,nb,4) r8."""
+    field = _f(field)
+    npt, npk, npj, npi = field.shape
+    basins = _m(basins)
+    nb = basins.shape[0]
+    nv = (2 + (2 if var else 0) + (2 if lsum else 0)) * nb
+    o_var, o_var0 = np.zeros((npt, nv, npk), np.float32), np.zeros((npt, nv), np.float32)
+    o_sums = np.zeros((npt, npk, nb, 4), np.float64)
+    a = [_f(e1), _f(e2), _f(e31d), _f(dep), _f(e3), _m(mask), basins, field]
+    load().lift_cdfmean(*_i(npi, npj, npk, npt, nb, full, var, lsum), *[_p(x) for x in a], C.c_int(nv), _p(o_var), _p(o_var0), _p(o_sums))
+    return {"var": o_var, "var0": o_var0, "sums": o_sums}
+
+
+def cdfvertmean(dep, e31d, e3, mask, field, up, down, full=False):
+    """field (npt,npk,npj,npi) -> (npt,npj,npi) r4 REAL(dvertmean)."""
+    field = _f(field)
+    npt, npk, npj, npi = field.shape
+    o = np.zeros((npt, 1, npj, npi), np.float32)
+    a = [_f(dep), _f(e31d), _f(e3), _m(mask), field]
+    load().lift_cdfvertmean(*_i(npi, npj, npk, npt, full), C.c_float(up), C.c_float(down), *[_p(x) for x in a], _p(o))
+    return o[:, 0]
+
+
+def cdfvint(gdepw, e31d, tmask, e3t, field, full=False, gsop=False, occi=False, mean=False, sclf=1.0):
+    """field (npt,npk,npj,npi) -> (npt,npko,npj,npi) r4 as handed to putvar per output depth."""
+    field = _f(field)
+    npt, npk, npj, npi = field.shape
+    npko = 7 if gsop else 3 if occi else npk
+    o = np.zeros((npt, npko + 1, npj, npi), np.float32)
+    a = [_f(gdepw), _f(e31d), _m(tmask), _f(e3t), field]
+    load().lift_cdfvint(*_i(npi, npj, npk, npt, full, gsop, occi, mean), C.c_float(sclf), *[_p(x) for x in a], C.c_int(npko), _p(o))
+    return o[:, :npko]
+
+
+def _zonal_args(g, e1, e2, phi, dep, mask, field):
+    return [_f(e1), _f(e2), _f(phi), _f(dep), _m(mask), _m(g["tmaskatl"]), _m(g["tmaskind"]), _m(g["tmaskpac"]), field]
+
+
+def cdfzonalsum(g, e1, e2, phi, dep, mask, field, nb=5, pdeg=False):
+    """field (npt,npk,npj,npi) -> var (npt,nb,npk,npj) r4, r8 (npt,nb,npk,npj)."""
+    field = _f(field)
+    npt, npk, npj, npi = field.shape
+    o_var, o_r8 = np.zeros((npt, nb, npk, npj), np.float32), np.zeros((npt, nb, npk, npj), np.float64)
+    load().lift_cdfzonalsum(*_i(npi, npj, npk, npt, nb, pdeg), *[_p(x) for x in _zonal_args(g, e1, e2, phi, dep, mask, field)],
+                            _p(o_var), _p(o_r8))
+    return {"var": o_var, "r8": o_r8}
+
+
+def cdfzonalmean(g, e1, e2, phi, dep, mask, field, nb=5, lmax=False):
+    """-> var (npt,3*nb,npk,npj) r4 [mean, max, min blocks of nb], r8 mean and area (npt,nb,npk,npj)."""
+    field = _f(field)
+    npt, npk, npj, npi = field.shape
+    o_var = np.zeros((npt, 3 * nb, npk, npj), np.float32)
+    o_r8, o_area = np.zeros((npt, nb, npk, npj), np.float64), np.zeros((npt, nb, npk, npj), np.float64)
+    load().lift_cdfzonalmean(*_i(npi, npj, npk, npt, nb, lmax), *[_p(x) for x in _zonal_args(g, e1, e2, phi, dep, mask, field)],
+                             _p(o_var), _p(o_r8), _p(o_area))
+    return {"var": o_var, "r8": o_r8, "area": o_area}
+
+
+def cdfmocsig(g, zv, zt, zs, nbins, sigmin, sigstp, pref=0.0, nb=5, full=False, isodep=False, eiv=None, ntr=False, teos10=False,
+              spv=(0.0, 0.0, 0.0)):
+    """zv, zt, zs (npt,npk,npj,npi) -> var (npt,2*nb,nbins,npj) r4, dmoc and depi (npt,npj,nbins,nb) r8."""
+    zv = _f(zv)
+    npt, npk, npj, npi = zv.shape
+    o_var = np.zeros((npt, 2 * nb, nbins, npj), np.float32)
+    o_dmoc, o_depi = np.zeros((npt, npj, nbins, nb), np.float64), np.zeros((npt, npj, nbins, nb), np.float64)
+    ve = _f(eiv) if eiv is not None else _dummy(*zv.shape)
+    a = [_f(g["e1v"]), _f(g["e3t_1d"]), _f(g["gdept_1d"]), _m(g["vmask"][0]), _m(g["tmaskatl"]), _m(g["tmaskind"]), _m(g["tmaskpac"]),
+         _f(g["e3v_0"]), zv, ve, _f(zt), _f(zs)]
+    load().lift_cdfmocsig(*_i(npi, npj, npk, npt, nb, full, isodep, eiv is not None, ntr, teos10, nbins), C.c_float(sigmin), C.c_float(sigstp),
+                          C.c_float(pref), C.c_float(spv[0]), C.c_float(spv[1]), C.c_float(spv[2]), *[_p(x) for x in a], _p(o_var), _p(o_dmoc),
+                          _p(o_depi))
+    return {"var": o_var, "dmoc": o_dmoc, "depi": o_depi}
