@@ -63,6 +63,10 @@ SIGNATURES = {
     "cdft_eos_sigmai2d": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _i, _i, _vp]),
     "cdft_eos_sig_tool": (_i, [_vp, _vp, _i64, C.c_float, C.c_float, _i, _i, _vp, _i, _i, _vp]),
     "cdft_eos_release": (_i, []),
+    "cdft_eos_field": (_i, [_i, _vp, _vp, _vp, C.c_float, _i64, _i, _vp, _i, _i, _vp]),
+    "cdft_eos_bn2": (_i, [_vp, _vp, _vp, _vp, _vp, C.c_float, _i64, _i, _vp, _i, _i, _vp]),
+    "cdft_eos_point": (_i, [_i, C.c_double, C.c_double, C.c_double, _i, C.POINTER(C.c_double)]),
+    "cdft_eos_more_release": (_i, []),
     "cdft_heatc_create": (_i, [_pvp, _i, _i, _i]),
     "cdft_heatc_create_sharded": (_i, [_pvp, _i, _i, _i, _i, C.POINTER(_i)]),
     "cdft_heatc_set_mesh": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),

@@ -48,10 +48,13 @@ MODULE cdfio
   LOGICAL            :: l_first_getdim = .TRUE.
 
   INTERFACE putvar
-     MODULE PROCEDURE putvarr8, putvarr4, putvari2, putvarzo
+     MODULE PROCEDURE putvarr8, putvarr4, putvari2, putvarzo, reputvarr4, putvare3
   END INTERFACE
   INTERFACE putvar1d
-     MODULE PROCEDURE putvar1d4, putvar1d8
+     MODULE PROCEDURE putvar1d4, putvar1d8, reputvar1d4, reputvar1d8
+  END INTERFACE
+  INTERFACE atted
+     MODULE PROCEDURE atted_char, atted_r4
   END INTERFACE
   INTERFACE putvar0d
      MODULE PROCEDURE putvar0dt, putvar0ds
@@ -60,7 +63,8 @@ MODULE cdfio
      MODULE PROCEDURE getattr, getatti, getattc
   END INTERFACE
 
-  PUBLIC :: getvaratt, getnvar, getvarname, getipk
+  PUBLIC :: getvaratt, getnvar, getvarname, getipk, getvarid, getdimvar, cvaratt, gettimeatt, puttimeatt, atted
+  PUBLIC :: getvarxz, getvaryz, getvar3dt, getvar4d, gettimeseries
   PUBLIC :: chkfile, chkvar, getdim, getvdim, getspval, getatt, getvar, getvar1d, getvare3, getvar3d, readvar3d, readvar3d_i1
   PUBLIC :: create, createvar, putatt, putheadervar, putvar, putvar1d, putvar0d, closeout, ncopen, copyatt, ERR_HDL
 
@@ -525,18 +529,22 @@ CONTAINS
     istatus = NF90_CLOSE(incid)
   END FUNCTION getvar
 
-  FUNCTION getvar3d(cdfile, cdvar, kpi, kpj, kpk, ktime, ldiom)
-    !! A whole (kpi,kpj,kpk) record in one read: same unpacking as getvar level by level.
+  FUNCTION getvar3d(cdfile, cdvar, kpi, kpj, kpk, kimin, kjmin, kkmin, ktime, ldiom)
+    !! A (kpi,kpj,kpk) block of one record in one read, window origin (kimin,kjmin,kkmin) (src/cdfio.F90:1611-1715; ldiom
+    !! as in getvar): same unpacking as getvar level by level.
     CHARACTER(LEN=*),          INTENT(in) :: cdfile, cdvar
     INTEGER(KIND=4),           INTENT(in) :: kpi, kpj, kpk
-    INTEGER(KIND=4), OPTIONAL, INTENT(in) :: ktime
+    INTEGER(KIND=4), OPTIONAL, INTENT(in) :: kimin, kjmin, kkmin, ktime
     LOGICAL,         OPTIONAL, INTENT(in) :: ldiom
     REAL(KIND=4), DIMENSION(kpi,kpj,kpk) :: getvar3d
-    INTEGER(KIND=4) :: incid, id_var, istatus, itime
+    INTEGER(KIND=4) :: incid, id_var, istatus, itime, iimin, ijmin, ikmin
     REAL(KIND=4) :: zsf, zao, zspval
     LOGICAL :: llog, lsf, lao
     CHARACTER(LEN=256) :: clvar
     itime = 1 ; IF ( PRESENT(ktime) ) itime = ktime
+    iimin = 1 ; IF ( PRESENT(kimin) ) iimin = kimin
+    ijmin = 1 ; IF ( PRESENT(kjmin) ) ijmin = kjmin
+    ikmin = 1 ; IF ( PRESENT(kkmin) ) ikmin = kkmin
     clvar = cdvar
     IF ( PRESENT(ldiom) ) THEN
        IF ( ldiom ) clvar = iom_name(cdvar)
@@ -545,7 +553,7 @@ CONTAINS
     CALL ERR_HDL(NF90_INQ_VARID(incid, clvar, id_var))
     CALL find_spval(incid, id_var, zspval)
     CALL packing(incid, id_var, zsf, zao, llog, lsf, lao)
-    istatus = NF90_GET_VAR(incid, id_var, getvar3d, start=(/ 1, 1, 1, itime /), count=(/ kpi, kpj, kpk, 1 /))
+    istatus = NF90_GET_VAR(incid, id_var, getvar3d, start=(/ iimin, ijmin, ikmin, itime /), count=(/ kpi, kpj, kpk, 1 /))
     IF ( istatus /= NF90_NOERR ) THEN
        PRINT *, ' Problem in getvar3d for ', TRIM(clvar)
        CALL ERR_HDL(istatus)
@@ -1044,6 +1052,432 @@ CONTAINS
     CHARACTER(LEN=1),            INTENT(in) :: cdtype
     putvar1d8 = NF90_PUT_VAR(kout, axis_id(cdtype), ddtab, start=(/ 1 /), count=(/ kk /))
   END FUNCTION putvar1d8
+
+  ! ------------------------------------------------------------------------------------------------------------------
+  ! The rest of the reference's public list (src/cdfio.F90:173-180).  No program of the hot path calls these; they are
+  ! here so that any reference program compiles against this module set unchanged.  Same argument lists, same defaults,
+  ! same messages and STOP codes; reading goes through the helpers above (find_spval, packing), writing through the
+  ! bundled backend's redef (attributes may be added to a file that already holds data).
+  ! ------------------------------------------------------------------------------------------------------------------
+  FUNCTION getvarid(cdfile, knvars)
+    !! the variable ids of cdfile, in file order (src/cdfio.F90:462-485)
+    CHARACTER(LEN=*), INTENT(in) :: cdfile
+    INTEGER(KIND=4),  INTENT(in) :: knvars
+    INTEGER(KIND=4), DIMENSION(knvars) :: getvarid
+    INTEGER(KIND=4) :: jv, incid, istatus
+    CHARACTER(LEN=256) :: clvar
+    getvarid(:) = 0
+    istatus = NF90_OPEN(cdfile, NF90_NOWRITE, incid)
+    DO jv = 1, knvars
+       istatus = NF90_INQUIRE_VARIABLE(incid, jv, clvar)
+       IF ( istatus == NF90_NOERR ) istatus = NF90_INQ_VARID(incid, clvar, getvarid(jv))
+    END DO
+    istatus = NF90_CLOSE(incid)
+  END FUNCTION getvarid
+
+  INTEGER(KIND=4) FUNCTION gettimeatt(cdfile, cdvartime, ctcalendar, cttitle, ctlong_name, ctaxis, ctunits, cttime_origin)
+    !! the six attributes of the time variable, 'unknown' where absent (src/cdfio.F90:517-552)
+    CHARACTER(LEN=*), INTENT(in)  :: cdfile, cdvartime
+    CHARACTER(LEN=*), INTENT(out) :: ctcalendar, cttitle, ctlong_name, ctaxis, ctunits, cttime_origin
+    INTEGER(KIND=4) :: istatus, incid, ivarid
+    ctcalendar = 'unknown' ; cttitle = 'unknown' ; ctlong_name = 'unknown'
+    ctaxis = 'unknown' ; ctunits = 'unknown' ; cttime_origin = 'unknown'
+    istatus = NF90_OPEN(cdfile, NF90_NOWRITE, incid)
+    istatus = NF90_INQ_VARID(incid, cdvartime, ivarid)
+    istatus = NF90_GET_ATT(incid, ivarid, 'calendar',    ctcalendar)
+    istatus = NF90_GET_ATT(incid, ivarid, 'title',       cttitle)
+    istatus = NF90_GET_ATT(incid, ivarid, 'long_name',   ctlong_name)
+    istatus = NF90_GET_ATT(incid, ivarid, 'axis',        ctaxis)
+    istatus = NF90_GET_ATT(incid, ivarid, 'units',       ctunits)
+    istatus = NF90_GET_ATT(incid, ivarid, 'time_origin', cttime_origin)
+    gettimeatt = istatus                                   ! the status of the last attribute, as in the reference
+    istatus = NF90_CLOSE(incid)
+  END FUNCTION gettimeatt
+
+  INTEGER(KIND=4) FUNCTION puttimeatt(kout, cdvartime, ctcalendar, cttitle, ctlong_name, ctaxis, ctunits, cttime_origin)
+    !! the same six attributes onto the time variable of an output file in data mode (src/cdfio.F90:554-593)
+    INTEGER(KIND=4),    INTENT(in) :: kout
+    CHARACTER(LEN=20),  INTENT(in) :: cdvartime
+    CHARACTER(LEN=256), INTENT(in) :: ctcalendar, cttitle, ctlong_name, ctaxis, ctunits, cttime_origin
+    INTEGER(KIND=4) :: ivarid
+    puttimeatt = NF90_INQ_VARID(kout, cdvartime, ivarid)
+    IF ( puttimeatt /= 0 ) THEN
+       PRINT *, TRIM(NF90_STRERROR(puttimeatt))
+       PRINT *, 'puttimeatt : ', TRIM(cdvartime), ' does not exist'
+       STOP 98
+    ENDIF
+    puttimeatt = NF90_REDEF(kout)
+    CALL one('calendar', ctcalendar) ; CALL one('title', cttitle) ; CALL one('long_name', ctlong_name)
+    CALL one('axis', ctaxis) ; CALL one('units', ctunits) ; CALL one('time_origin', cttime_origin)
+    puttimeatt = NF90_ENDDEF(kout)
+  CONTAINS
+    SUBROUTINE one(cdatt, cdval)
+      CHARACTER(LEN=*), INTENT(in) :: cdatt, cdval
+      puttimeatt = NF90_PUT_ATT(kout, ivarid, cdatt, cdval)
+      IF ( puttimeatt /= 0 ) THEN
+         PRINT *, NF90_STRERROR(puttimeatt) ; PRINT *, ' in puttimeatt ', cdatt ; STOP 98
+      ENDIF
+    END SUBROUTINE one
+  END FUNCTION puttimeatt
+
+  INTEGER(KIND=4) FUNCTION cvaratt(cdfile, cdvar, cdunits, pmissing_value, cdlong_name, cdshort_name)
+    !! change units, the missing-value attribute (under whichever name the file uses), long_name and short_name of a
+    !! variable of an existing file (src/cdfio.F90:595-627)
+    CHARACTER(LEN=256), INTENT(in) :: cdfile, cdvar, cdunits, cdlong_name, cdshort_name
+    REAL(KIND=4),       INTENT(in) :: pmissing_value
+    INTEGER(KIND=4) :: istatus, incid, ivarid
+    REAL(KIND=4) :: zspval
+    CHARACTER(LEN=256) :: clmissing
+    zspval = getspval(cdfile, cdvar, clmissing)              ! (read before the file is opened for writing)
+    istatus = NF90_OPEN(cdfile, NF90_WRITE, incid)
+    istatus = NF90_REDEF(incid)
+    istatus = NF90_INQ_VARID(incid, cdvar, ivarid)
+    istatus = NF90_PUT_ATT(incid, ivarid, 'units',      cdunits)
+    istatus = NF90_PUT_ATT(incid, ivarid, clmissing,    pmissing_value)
+    istatus = NF90_PUT_ATT(incid, ivarid, 'long_name',  cdlong_name)
+    istatus = NF90_PUT_ATT(incid, ivarid, 'short_name', cdshort_name)
+    istatus = NF90_ENDDEF(incid)
+    cvaratt = istatus
+    istatus = NF90_CLOSE(incid)
+  END FUNCTION cvaratt
+
+  INTEGER(KIND=4) FUNCTION atted_char(cdfile, cdvar, cdatt, cdvalue)
+    !! attribute editor, text value: create the attribute or overwrite one of the same type (src/cdfio.F90:790-830)
+    CHARACTER(LEN=*), INTENT(in) :: cdfile, cdvar, cdatt, cdvalue
+    INTEGER(KIND=4) :: incid, istatus, idvar, ityp
+    istatus = NF90_OPEN(cdfile, NF90_WRITE, incid)
+    istatus = NF90_INQ_VARID(incid, cdvar, idvar)
+    IF ( istatus /= NF90_NOERR ) THEN
+       PRINT *, NF90_STRERROR(istatus), ' in atted ( inq_varid)'
+       STOP 98
+    ENDIF
+    istatus = NF90_INQUIRE_ATTRIBUTE(incid, idvar, cdatt, xtype=ityp)
+    IF ( istatus /= NF90_NOERR ) THEN
+       PRINT *, ' Attribute does not exist. Create it'
+    ELSE IF ( ityp /= NF90_CHAR ) THEN
+       PRINT *, ' Mismatch in attribute type in atted_char'
+       STOP 98
+    ENDIF
+    istatus = NF90_REDEF(incid)
+    atted_char = NF90_PUT_ATT(incid, idvar, cdatt, cdvalue)
+    istatus = NF90_CLOSE(incid)
+  END FUNCTION atted_char
+
+  INTEGER(KIND=4) FUNCTION atted_r4(cdfile, cdvar, cdatt, pvalue)
+    !! attribute editor, REAL*4 value (src/cdfio.F90:833-873)
+    CHARACTER(LEN=*), INTENT(in) :: cdfile, cdvar, cdatt
+    REAL(KIND=4),     INTENT(in) :: pvalue
+    INTEGER(KIND=4) :: incid, istatus, idvar, ityp
+    istatus = NF90_OPEN(cdfile, NF90_WRITE, incid)
+    istatus = NF90_INQ_VARID(incid, cdvar, idvar)
+    IF ( istatus /= NF90_NOERR ) THEN
+       PRINT *, NF90_STRERROR(istatus), ' in atted ( inq_varid)'
+       STOP 98
+    ENDIF
+    istatus = NF90_INQUIRE_ATTRIBUTE(incid, idvar, cdatt, xtype=ityp)
+    IF ( istatus /= NF90_NOERR ) THEN
+       PRINT *, ' Attribute does not exist. Create it'
+    ELSE IF ( ityp /= NF90_FLOAT ) THEN
+       PRINT *, ' Mismatch in attribute type in atted_r4'
+       STOP 98
+    ENDIF
+    istatus = NF90_REDEF(incid)
+    atted_r4 = NF90_PUT_ATT(incid, idvar, cdatt, pvalue)
+    istatus = NF90_CLOSE(incid)
+  END FUNCTION atted_r4
+
+  FUNCTION getdimvar(cdfile, kpk, cd_depnam)
+    !! the values of the first 1-D variable that does not run along the unlimited dimension: the vertical axis of a
+    !! file whose depth variable has an unknown name (src/cdfio.F90:1085-1127)
+    CHARACTER(LEN=*), INTENT(in) :: cdfile
+    INTEGER(KIND=4),  INTENT(in) :: kpk
+    REAL(KIND=4), DIMENSION(kpk) :: getdimvar
+    CHARACTER(LEN=*), OPTIONAL, INTENT(out) :: cd_depnam
+    INTEGER(KIND=4) :: ji, incid, idims, iuldid, idimv, ivars, istatus, idimt(4)
+    CHARACTER(LEN=80) :: clvar
+    LOGICAL :: llfound
+    clvar = 'none' ; llfound = .FALSE.
+    istatus = NF90_OPEN(cdfile, NF90_NOWRITE, incid)
+    istatus = NF90_INQUIRE(incid, nDimensions=idims, unlimitedDimId=iuldid, nVariables=ivars)
+    DO ji = 1, ivars
+       istatus = NF90_INQUIRE_VARIABLE(incid, ji, name=clvar, ndims=idimv, dimids=idimt)
+       IF ( idimv == 1 ) THEN
+          IF ( idimt(1) /= iuldid ) THEN
+             PRINT *, ' Found vertical variable :', TRIM(clvar)
+             istatus = NF90_GET_VAR(incid, ji, getdimvar(:))
+             llfound = .TRUE.
+             EXIT
+          ENDIF
+       ENDIF
+    END DO
+    IF ( PRESENT(cd_depnam) ) cd_depnam = TRIM(clvar)
+    IF ( .NOT. llfound ) THEN
+       PRINT *, 'Sorry, no vertical dim variables inferred ...'
+       getdimvar = 0.
+    ENDIF
+    istatus = NF90_CLOSE(incid)
+  END FUNCTION getdimvar
+
+  SUBROUTINE unpack_in_place(kncid, kvar, cdfile, cdvar, ptab, kn)
+    ! scale_factor, add_offset, savelog10 applied to the kn values just read, missing values left alone -- the order
+    ! matters (src/cdfio.F90:1806-1808)
+    INTEGER(KIND=4),  INTENT(in) :: kncid, kvar, kn
+    CHARACTER(LEN=*), INTENT(in) :: cdfile, cdvar
+    REAL(KIND=4), INTENT(inout) :: ptab(kn)
+    REAL(KIND=4) :: zsf, zao, zspval
+    LOGICAL :: llog, lsf, lao
+    CALL find_spval(kncid, kvar, zspval)
+    CALL packing(kncid, kvar, zsf, zao, llog, lsf, lao)
+    IF ( lsf  ) WHERE ( ptab /= zspval ) ptab = ptab * zsf
+    IF ( lao  ) WHERE ( ptab /= zspval ) ptab = ptab + zao
+    IF ( llog ) WHERE ( ptab /= zspval ) ptab = 10**ptab
+  END SUBROUTINE unpack_in_place
+
+  FUNCTION getvar3dt(cdfile, cdvar, kk, kpi, kpj, kpt, kimin, kjmin, ktmin)
+    !! kpt records of level kk: (kpi,kpj,kpt) (src/cdfio.F90:1717-1820; a 3-D variable is taken as x, y, t)
+    CHARACTER(LEN=*),          INTENT(in) :: cdfile, cdvar
+    INTEGER(KIND=4),           INTENT(in) :: kpi, kpj, kk, kpt
+    INTEGER(KIND=4), OPTIONAL, INTENT(in) :: kimin, kjmin, ktmin
+    REAL(KIND=4), DIMENSION(kpi,kpj,kpt) :: getvar3dt
+    INTEGER(KIND=4) :: istart(4), icount(4), incid, id_var, iid, istatus, iimin, ijmin, itmin
+    iimin = 1 ; IF ( PRESENT(kimin) ) iimin = kimin
+    ijmin = 1 ; IF ( PRESENT(kjmin) ) ijmin = kjmin
+    itmin = 1 ; IF ( PRESENT(ktmin) ) itmin = ktmin
+    PRINT *, ' GETVAR3DT '
+    PRINT *, '  ', TRIM(cdfile)
+    PRINT *, '  ', TRIM(cdvar)
+    PRINT *, '    KPI KPJ KPT, KK ', kpi, kpj, kpt, kk
+    CALL ERR_HDL(NF90_OPEN(cdfile, NF90_NOWRITE, incid))
+    CALL ERR_HDL(NF90_INQ_VARID(incid, cdvar, id_var))
+    istatus = NF90_INQUIRE_VARIABLE(incid, id_var, ndims=iid)
+    istart = (/ iimin, ijmin, kk, itmin /) ; icount = (/ kpi, kpj, 1, kpt /)
+    IF ( iid == 3 ) THEN
+       istart = (/ iimin, ijmin, itmin, 1 /) ; icount = (/ kpi, kpj, kpt, 1 /)
+    ENDIF
+    istatus = NF90_GET_VAR(incid, id_var, getvar3dt, start=istart, count=icount)
+    IF ( istatus /= NF90_NOERR ) THEN
+       PRINT *, ' Problem in getvar3dt for ', TRIM(cdvar)
+       CALL ERR_HDL(istatus)
+       STOP 98
+    ENDIF
+    CALL unpack_in_place(incid, id_var, cdfile, cdvar, getvar3dt, kpi * kpj * kpt)
+    istatus = NF90_CLOSE(incid)
+  END FUNCTION getvar3dt
+
+  FUNCTION getvar4d(cdfile, cdvar, kpi, kpj, kpz, kpt, kimin, kjmin, kkmin, ktmin)
+    !! a (kpi,kpj,kpz,kpt) block (src/cdfio.F90:1822-1931)
+    CHARACTER(LEN=*),          INTENT(in) :: cdfile, cdvar
+    INTEGER(KIND=4),           INTENT(in) :: kpi, kpj, kpz, kpt
+    INTEGER(KIND=4), OPTIONAL, INTENT(in) :: kimin, kjmin, kkmin, ktmin
+    REAL(KIND=4), DIMENSION(kpi,kpj,kpz,kpt) :: getvar4d
+    INTEGER(KIND=4) :: istart(4), icount(4), incid, id_var, iid, istatus, iimin, ijmin, ikmin, itmin
+    iimin = 1 ; IF ( PRESENT(kimin) ) iimin = kimin
+    ijmin = 1 ; IF ( PRESENT(kjmin) ) ijmin = kjmin
+    ikmin = 1 ; IF ( PRESENT(kkmin) ) ikmin = kkmin
+    itmin = 1 ; IF ( PRESENT(ktmin) ) itmin = ktmin
+    PRINT *, ' GETVAR4D '
+    PRINT *, '  ', TRIM(cdfile)
+    PRINT *, '  ', TRIM(cdvar)
+    PRINT *, '    KPI KPJ KPZ, KPT ', kpi, kpj, kpz, kpt
+    CALL ERR_HDL(NF90_OPEN(cdfile, NF90_NOWRITE, incid))
+    CALL ERR_HDL(NF90_INQ_VARID(incid, cdvar, id_var))
+    istatus = NF90_INQUIRE_VARIABLE(incid, id_var, ndims=iid)
+    istart = (/ iimin, ijmin, ikmin, itmin /) ; icount = (/ kpi, kpj, kpz, kpt /)
+    IF ( iid == 3 ) THEN
+       istart = (/ iimin, ijmin, itmin, 1 /) ; icount = (/ kpi, kpj, kpt, 1 /)
+    ENDIF
+    istatus = NF90_GET_VAR(incid, id_var, getvar4d, start=istart, count=icount)
+    IF ( istatus /= NF90_NOERR ) THEN
+       PRINT *, ' Problem in getvar4d for ', TRIM(cdvar)
+       CALL ERR_HDL(istatus)
+       STOP 98
+    ENDIF
+    CALL unpack_in_place(incid, id_var, cdfile, cdvar, getvar4d, kpi * kpj * kpz * kpt)
+    istatus = NF90_CLOSE(incid)
+  END FUNCTION getvar4d
+
+  FUNCTION getvarxz(cdfile, cdvar, kj, kpi, kpz, kimin, kkmin, ktime)
+    !! the x-z section at row kj (src/cdfio.F90:1933-2044; cn_ve3v is mapped to the mesh_zgr name of the layout; a file
+    !! without a y dimension is read as x, z, t)
+    CHARACTER(LEN=*),          INTENT(in) :: cdfile, cdvar
+    INTEGER(KIND=4),           INTENT(in) :: kj, kpi, kpz
+    INTEGER(KIND=4), OPTIONAL, INTENT(in) :: kimin, kkmin, ktime
+    REAL(KIND=4), DIMENSION(kpi,kpz) :: getvarxz
+    INTEGER(KIND=4) :: istart(4), icount(4), incid, id_var, istatus, imin, kmin, itime, idum
+    CHARACTER(LEN=256) :: clvar
+    imin = 1  ; IF ( PRESENT(kimin) ) imin  = kimin
+    kmin = 1  ; IF ( PRESENT(kkmin) ) kmin  = kkmin
+    itime = 1 ; IF ( PRESENT(ktime) ) itime = ktime
+    clvar = cdvar
+    IF ( clvar == cn_ve3v ) clvar = iom_name(cdvar)
+    CALL ERR_HDL(NF90_OPEN(cdfile, NF90_NOWRITE, incid))
+    CALL ERR_HDL(NF90_INQ_VARID(incid, clvar, id_var))
+    IF ( NF90_INQ_DIMID(incid, 'y', idum) == NF90_NOERR ) THEN
+       istart = (/ imin, kj, kmin, itime /) ; icount = (/ kpi, 1, kpz, 1 /)
+    ELSE
+       istart = (/ imin, kmin, itime, 1 /)  ; icount = (/ kpi, kpz, 1, 1 /)
+    ENDIF
+    istatus = NF90_GET_VAR(incid, id_var, getvarxz, start=istart, count=icount)
+    IF ( istatus /= NF90_NOERR ) THEN
+       PRINT *, ' Problem in getvarxz for ', TRIM(clvar)
+       CALL ERR_HDL(istatus)
+       STOP 98
+    ENDIF
+    CALL unpack_in_place(incid, id_var, cdfile, clvar, getvarxz, kpi * kpz)
+    istatus = NF90_CLOSE(incid)
+  END FUNCTION getvarxz
+
+  FUNCTION getvaryz(cdfile, cdvar, ki, kpj, kpz, kjmin, kkmin, ktime)
+    !! the y-z section at column ki (src/cdfio.F90:2046-2149; cn_ve3u mapped like getvarxz's cn_ve3v; a file without an
+    !! x dimension is read as y, z, t)
+    CHARACTER(LEN=*),          INTENT(in) :: cdfile, cdvar
+    INTEGER(KIND=4),           INTENT(in) :: ki, kpj, kpz
+    INTEGER(KIND=4), OPTIONAL, INTENT(in) :: kjmin, kkmin, ktime
+    REAL(KIND=4), DIMENSION(kpj,kpz) :: getvaryz
+    INTEGER(KIND=4) :: istart(4), icount(4), incid, id_var, istatus, jmin, kmin, itime, idum
+    CHARACTER(LEN=256) :: clvar
+    jmin = 1  ; IF ( PRESENT(kjmin) ) jmin  = kjmin
+    kmin = 1  ; IF ( PRESENT(kkmin) ) kmin  = kkmin
+    itime = 1 ; IF ( PRESENT(ktime) ) itime = ktime
+    clvar = cdvar
+    IF ( clvar == cn_ve3u ) clvar = iom_name(cdvar)
+    CALL ERR_HDL(NF90_OPEN(cdfile, NF90_NOWRITE, incid))
+    CALL ERR_HDL(NF90_INQ_VARID(incid, clvar, id_var))
+    IF ( NF90_INQ_DIMID(incid, 'x', idum) == NF90_NOERR ) THEN
+       istart = (/ ki, jmin, kmin, itime /) ; icount = (/ 1, kpj, kpz, 1 /)
+    ELSE
+       istart = (/ jmin, kmin, itime, 1 /)  ; icount = (/ kpj, kpz, 1, 1 /)
+    ENDIF
+    istatus = NF90_GET_VAR(incid, id_var, getvaryz, start=istart, count=icount)
+    IF ( istatus /= NF90_NOERR ) THEN
+       PRINT *, ' Problem in getvaryz for ', TRIM(clvar)
+       CALL ERR_HDL(istatus)
+       STOP 98
+    ENDIF
+    CALL unpack_in_place(incid, id_var, cdfile, clvar, getvaryz, kpj * kpz)
+    istatus = NF90_CLOSE(incid)
+  END FUNCTION getvaryz
+
+  SUBROUTINE gettimeseries(cdfile, cdvar, kilook, kjlook, klev, ldncdf)
+    !! prints the time series of cdvar at (kilook,kjlook[,klev]): days, value (src/cdfio.F90:2943-3029; the ldncdf
+    !! branch only builds a file name in the reference -- "not finished" -- and does the same here)
+    CHARACTER(LEN=*),          INTENT(in) :: cdfile, cdvar
+    INTEGER(KIND=4),           INTENT(in) :: kilook, kjlook
+    INTEGER(KIND=4), OPTIONAL, INTENT(in) :: klev
+    LOGICAL,         OPTIONAL, INTENT(in) :: ldncdf
+    INTEGER(KIND=4) :: jt, jk, iint, istatus, incid, id_t, id_var, indim
+    REAL(KIND=4), DIMENSION(:), ALLOCATABLE :: ztime, zval
+    REAL(KIND=4) :: ztmp, zao, zsf
+    CHARACTER(LEN=256) :: clname
+    jk = 1 ; IF ( PRESENT(klev) ) jk = klev
+    zao = 0. ; zsf = 1.0
+    istatus = NF90_OPEN(cdfile, NF90_NOWRITE, incid)
+    istatus = NF90_INQ_DIMID(incid, cn_t, id_t)
+    istatus = NF90_INQUIRE_DIMENSION(incid, id_t, len=iint)
+    ALLOCATE ( ztime(iint), zval(iint) )
+    istatus = NF90_INQ_VARID(incid, cn_vtimec, id_var)
+    istatus = NF90_GET_VAR(incid, id_var, ztime, (/ 1 /), (/ iint /))
+    istatus = NF90_INQ_VARID(incid, cdvar, id_var)
+    IF ( NF90_GET_ATT(incid, id_var, 'add_offset', ztmp) == NF90_NOERR ) zao = ztmp
+    IF ( NF90_GET_ATT(incid, id_var, 'scale_factor', ztmp) == NF90_NOERR ) zsf = ztmp
+    istatus = NF90_INQUIRE_VARIABLE(incid, id_var, ndims=indim)
+    IF ( indim == 3 ) THEN
+       istatus = NF90_GET_VAR(incid, id_var, zval, (/ kilook, kjlook, 1 /), (/ 1, 1, iint /))
+    ELSE IF ( indim == 4 ) THEN
+       istatus = NF90_GET_VAR(incid, id_var, zval, (/ kilook, kjlook, jk, 1 /), (/ 1, 1, 1, iint /))
+    ELSE
+       PRINT *, '  ERROR : variable ', TRIM(cdvar), ' has ', indim, ' dimensions !. Only 3 or 4 supported'
+       STOP 98
+    ENDIF
+    zval = zval * zsf + zao
+    DO jt = 1, iint
+       PRINT *, ztime(jt) / 86400., zval(jt)
+    END DO
+    istatus = NF90_CLOSE(incid)
+    IF ( PRESENT(ldncdf) ) THEN
+       IF ( ldncdf ) WRITE (clname, '("probe_",i4.4,"_",i4.4,"_",a,".nc")') kilook, kjlook, TRIM(cdvar)
+    ENDIF
+    DEALLOCATE ( ztime, zval )
+  END SUBROUTINE gettimeseries
+
+  INTEGER(KIND=4) FUNCTION putvare3(kout, kid, ptab, kmax, cd_vert, ktime, kwght)
+    !! a vertical profile of kmax values into variable kid, record ktime (src/cdfio.F90:2501-2543; cd_vert only selects
+    !! this member of the generic putvar)
+    INTEGER(KIND=4),               INTENT(in) :: kout, kid, kmax
+    REAL(KIND=4), DIMENSION(kmax), INTENT(in) :: ptab
+    CHARACTER(LEN=*),              INTENT(in) :: cd_vert
+    INTEGER(KIND=4), OPTIONAL,     INTENT(in) :: ktime, kwght
+    INTEGER(KIND=4) :: istatus, itime, id_dimunlim, inbdim, istart(4), icount(4), inldim(4)
+    itime = 1 ; IF ( PRESENT(ktime) ) itime = ktime
+    inldim = 0
+    istatus = NF90_INQUIRE(kout, unlimitedDimId=id_dimunlim)
+    istatus = NF90_INQUIRE_VARIABLE(kout, kid, ndims=inbdim, dimids=inldim)
+    istart(:) = 1 ; icount(:) = 1
+    icount(3) = kmax
+    IF ( inldim(inbdim) == id_dimunlim ) istart(inbdim) = itime
+    istatus = NF90_PUT_VAR(kout, kid, ptab, start=istart, count=icount)
+    IF ( PRESENT(kwght) ) istatus = NF90_PUT_ATT(kout, kid, 'iweight', kwght)
+    putvare3 = istatus
+  END FUNCTION putvare3
+
+  INTEGER(KIND=4) FUNCTION reputvarr4(cdfile, cdvar, klev, kpi, kpj, kimin, kjmin, ktime, ptab, kwght)
+    !! overwrite a (kpi,kpj) window of level klev, record ktime of a variable of an EXISTING file
+    !! (src/cdfio.F90:2591-2640)
+    CHARACTER(LEN=*),                 INTENT(in) :: cdfile, cdvar
+    INTEGER(KIND=4), OPTIONAL,        INTENT(in) :: klev
+    INTEGER(KIND=4),                  INTENT(in) :: kpi, kpj
+    INTEGER(KIND=4), OPTIONAL,        INTENT(in) :: kimin, kjmin, ktime
+    REAL(KIND=4), DIMENSION(kpi,kpj), INTENT(in) :: ptab
+    INTEGER(KIND=4), OPTIONAL,        INTENT(in) :: kwght
+    INTEGER(KIND=4) :: incid, id_var, id_dimunlim, inbdim, istatus, ilev, iimin, ijmin, itime, istart(4), icount(4), inldim(4)
+    ilev  = 1 ; IF ( PRESENT(klev ) ) ilev  = klev
+    iimin = 1 ; IF ( PRESENT(kimin) ) iimin = kimin
+    ijmin = 1 ; IF ( PRESENT(kjmin) ) ijmin = kjmin
+    itime = 1 ; IF ( PRESENT(ktime) ) itime = ktime
+    inldim = 0
+    istatus = NF90_OPEN(cdfile, NF90_WRITE, incid)
+    istatus = NF90_INQ_VARID(incid, cdvar, id_var)
+    istatus = NF90_INQUIRE(incid, unlimitedDimId=id_dimunlim)
+    istatus = NF90_INQUIRE_VARIABLE(incid, id_var, ndims=inbdim, dimids=inldim)
+    istart(:) = 1 ; icount(:) = 1
+    istart(1) = iimin ; istart(2) = ijmin
+    icount(1) = kpi   ; icount(2) = kpj
+    IF ( inldim(inbdim) == id_dimunlim ) istart(inbdim) = itime
+    IF ( inbdim == 4 ) istart(3) = ilev
+    istatus = NF90_PUT_VAR(incid, id_var, ptab, start=istart, count=icount)
+    IF ( PRESENT(kwght) ) THEN
+       istatus = NF90_REDEF(incid)
+       istatus = NF90_PUT_ATT(incid, id_var, 'iweight', kwght)
+       istatus = NF90_ENDDEF(incid)
+    ENDIF
+    reputvarr4 = istatus
+    istatus = NF90_CLOSE(incid)
+  END FUNCTION reputvarr4
+
+  INTEGER(KIND=4) FUNCTION reputvar1d4(cdfile, cdvar, ptab, kk)
+    !! overwrite a 1-D variable of an existing file (src/cdfio.F90:2758-2781)
+    CHARACTER(LEN=*),            INTENT(in) :: cdfile, cdvar
+    REAL(KIND=4), DIMENSION(kk), INTENT(in) :: ptab
+    INTEGER(KIND=4),             INTENT(in) :: kk
+    INTEGER :: istatus, incid, id
+    istatus = NF90_OPEN(cdfile, NF90_WRITE, incid)
+    istatus = NF90_INQ_VARID(incid, cdvar, id)
+    istatus = NF90_PUT_VAR(incid, id, ptab, start=(/ 1 /), count=(/ kk /))
+    reputvar1d4 = istatus
+    istatus = NF90_CLOSE(incid)
+  END FUNCTION reputvar1d4
+
+  INTEGER(KIND=4) FUNCTION reputvar1d8(cdfile, cdvar, ddtab, kk)
+    CHARACTER(LEN=*),            INTENT(in) :: cdfile, cdvar
+    REAL(KIND=8), DIMENSION(kk), INTENT(in) :: ddtab
+    INTEGER(KIND=4),             INTENT(in) :: kk
+    INTEGER :: istatus, incid, id
+    istatus = NF90_OPEN(cdfile, NF90_WRITE, incid)
+    istatus = NF90_INQ_VARID(incid, cdvar, id)
+    istatus = NF90_PUT_VAR(incid, id, ddtab, start=(/ 1 /), count=(/ kk /))
+    reputvar1d8 = istatus
+    istatus = NF90_CLOSE(incid)
+  END FUNCTION reputvar1d8
 
   INTEGER(KIND=4) FUNCTION closeout(kout)
     INTEGER(KIND=4), INTENT(in) :: kout

@@ -17,7 +17,7 @@ MODULE cdftools
   USE modcdfnames
   IMPLICIT NONE
   PRIVATE
-  PUBLIC :: cdf_findij
+  PUBLIC :: cdf_findij, dist
 
   INTEGER(KIND=4), PARAMETER :: jp_halfblock = 10, jp_restarts = 15
   INTEGER(KIND=4), SAVE :: nxg = 0, nyg = 0
@@ -123,7 +123,7 @@ CONTAINS
       ki = nxg/2 ; kj = nyg/2
       DO
          CALL walk(ddx, ddy, ki, kj, ld_bnd)
-         dldis  = gcdist(ddx, dlam(ki,kj), ddy, dphi(ki,kj))                      ! km
+         dldis  = dist(ddx, dlam(ki,kj), ddy, dphi(ki,kj))                      ! km
          dldiag = MAX(dsc1(ki,kj), dsc2(ki,kj))/1000.*SQRT(2.)                    ! km
          IF ( dldis <= dldiag ) THEN
             IF ( lverbose ) PRINT '("#  dl_dis= ",f8.3," km")', dldis
@@ -160,7 +160,7 @@ CONTAINS
        IF ( j1 > nyg ) j1 = nyg - 1
        DO jj = j0, j1
           DO ji = i0, i1
-             zd    = gcdist(ddlon, dlam(ji,jj), ddlat, dphi(ji,jj))
+             zd    = dist(ddlon, dlam(ji,jj), ddlat, dphi(ji,jj))
              zbest = MIN(zbest, zd)
              IF ( zbest /= zprev ) THEN
                 ki = ji ; kj = jj
@@ -173,7 +173,7 @@ CONTAINS
     END DO
   END SUBROUTINE walk
 
-  REAL(KIND=8) FUNCTION gcdist(ddlona, ddlonb, ddlata, ddlatb)
+  REAL(KIND=8) FUNCTION dist(ddlona, ddlonb, ddlata, ddlatb)
     !! great-circle distance in km between A and B (degrees), src/cdftools.f90:498-556
     REAL(KIND=8), INTENT(in) :: ddlona, ddlonb, ddlata, ddlatb
     REAL(KIND=8) :: dlpi, dlconv, dlr, dlux, dluy, dluz, dlvx, dlvy, dlvz, dlpds
@@ -188,10 +188,10 @@ CONTAINS
     dlvz = SIN(ddlatb*dlconv)
     dlpds = dlux*dlvx + dluy*dlvy + dluz*dlvz
     IF ( dlpds >= 1. ) THEN
-       gcdist = 0.
+       dist = 0.
     ELSE
-       gcdist = dlr*ACOS(dlpds)
+       dist = dlr*ACOS(dlpds)
     ENDIF
-  END FUNCTION gcdist
+  END FUNCTION dist
 
 END MODULE cdftools

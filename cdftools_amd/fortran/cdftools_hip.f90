@@ -14,6 +14,9 @@ MODULE cdftools_hip
   INTEGER(C_INT), PARAMETER :: CDFT_HEATC_SUM_R8 = 0, CDFT_HEATC_SUM_R4SEQ = 1
   INTEGER(C_INT), PARAMETER :: CDFT_MEAN_FORM_MEAN = 0, CDFT_MEAN_FORM_SUM = 1, CDFT_MEAN_FORM_SUM_FORCING = 2
   INTEGER(C_INT), PARAMETER :: CDFT_EOS_80 = 0, CDFT_EOS_TEOS10 = 1, CDFT_EOS_JMD94 = 2, CDFT_EOS_NTR = 3, CDFT_EOS_FAST_FMA = 1
+  INTEGER(C_INT), PARAMETER :: CDFT_EOS_MCD87 = 4
+  INTEGER(C_INT), PARAMETER :: CDFT_EOSQ_ALPHA = 0, CDFT_EOSQ_BETA = 1, CDFT_EOSQ_ALBET_MCD87 = 2, CDFT_EOSQ_BETA_MCD87 = 3
+  INTEGER(C_INT), PARAMETER :: CDFT_EOSQ_SPICE_POL = 4, CDFT_EOSQ_SPICE_F02 = 5
 
   INTERFACE
      FUNCTION cdft_last_error() BIND(C, name='cdft_last_error')
@@ -107,6 +110,22 @@ MODULE cdftools_hip
        IMPORT ; REAL(C_FLOAT), INTENT(in) :: ptem(*), psal(*) ; INTEGER(C_INT64_T), VALUE :: n
        REAL(C_FLOAT), VALUE :: pref, spval ; INTEGER(C_INT), VALUE :: keos, kflags, in_space, out_space
        REAL(C_FLOAT), INTENT(out) :: sig4(*) ; TYPE(C_PTR), VALUE :: stream
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_eos_field(kquantity, ptem, psal, pdep_n, pdep, n, keos, dout, in_space, out_space, stream) &
+          &         BIND(C, name='cdft_eos_field')
+       IMPORT ; INTEGER(C_INT), VALUE :: kquantity, keos, in_space, out_space ; REAL(C_FLOAT), INTENT(in) :: ptem(*), psal(*)
+       TYPE(C_PTR), VALUE :: pdep_n, stream ; REAL(C_FLOAT), VALUE :: pdep ; INTEGER(C_INT64_T), VALUE :: n
+       REAL(C_DOUBLE), INTENT(out) :: dout(*)
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_eos_bn2(ptem_up, ptem_down, psal_up, psal_down, pe3w, pdep, n, keos, pbn2, in_space,     &
+          &         out_space, stream) BIND(C, name='cdft_eos_bn2')
+       IMPORT ; REAL(C_FLOAT), INTENT(in) :: ptem_up(*), ptem_down(*), psal_up(*), psal_down(*), pe3w(*)
+       REAL(C_FLOAT), VALUE :: pdep ; INTEGER(C_INT64_T), VALUE :: n ; INTEGER(C_INT), VALUE :: keos, in_space, out_space
+       REAL(C_FLOAT), INTENT(out) :: pbn2(*) ; TYPE(C_PTR), VALUE :: stream
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_eos_point(kquantity, dtem, dsal, ddep, keos, dout) BIND(C, name='cdft_eos_point')
+       IMPORT ; INTEGER(C_INT), VALUE :: kquantity, keos ; REAL(C_DOUBLE), VALUE :: dtem, dsal, ddep
+       REAL(C_DOUBLE), INTENT(out) :: dout
      END FUNCTION
      ! ---- cdfheatc -------------------------------------------------------------------------
      INTEGER(C_INT) FUNCTION cdft_heatc_create(plan, npiglo, npjglo, npk) BIND(C, name='cdft_heatc_create')

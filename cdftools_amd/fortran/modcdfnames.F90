@@ -8,11 +8,22 @@ MODULE modcdfnames
   !! lookup order (./nam_cdf_names or $NAM_CDF_NAMES, then $HOME/CDFTOOLS_cfg/), same CDFT_* overrides.
   !! Only the implementation is new.
   !!======================================================================
+  !!
+  !! Compiled with -Dkey_CMIP6 the twenty names whose CMIP6 spelling differs take the defaults of the reference's
+  !! src/modcdfnames_CMIP6.h90 (thetao, so, uo, vo, wo, zos, thkcello ...) and the seven names only that header has
+  !! (cn_votemper2 ... cn_somxldep) exist; every other name keeps its default and stays declared, so a program written
+  !! against either name set compiles against this module.
+  !!======================================================================
+#if defined key_CMIP6
+#  define CMIP6_(std, cmip) cmip
+#else
+#  define CMIP6_(std, cmip) std
+#endif
   IMPLICIT NONE
   PUBLIC
   INTEGER, PARAMETER, PRIVATE :: lc = 256
 
-  CHARACTER(LEN=lc) :: cn_output = 'default'
+  CHARACTER(LEN=lc) :: cn_output = CMIP6_('default', 'CMIP6')
 
   ! --- dimensions and their coordinate variables -------------------------------------------
   CHARACTER(LEN=lc) :: cn_x = 'x', cn_y = 'y', cn_z = 'depth', cn_t = 'time_counter'
@@ -21,12 +32,18 @@ MODULE modcdfnames
   CHARACTER(LEN=lc) :: cn_vtimec = 'time_counter'
   CHARACTER(LEN=lc) :: cn_missing_value = '_FillValue'
 
+#if defined key_CMIP6
+  ! --- the names only the CMIP6 set has (src/modcdfnames_CMIP6.h90:74-85) -----------------------
+  CHARACTER(LEN=lc) :: cn_votemper2 = 'thetao_sqd', cn_vosaline2 = 'so_sqd', cn_vozocrtx2 = 'u2o', cn_vomecrty2 = 'v2o'
+  CHARACTER(LEN=lc) :: cn_vovecrtz2 = 'w2o', cn_sossheig2 = 'zossq', cn_somxldep = 'mlotst'
+#endif
+
   ! --- metrics ---------------------------------------------------------------------------------
   CHARACTER(LEN=lc) :: cn_ve1t = 'e1t', cn_ve2t = 'e2t', cn_ve1u = 'e1u', cn_ve2u = 'e2u'
   CHARACTER(LEN=lc) :: cn_ve1v = 'e1v', cn_ve2v = 'e2v', cn_ve1f = 'e1f', cn_ve2f = 'e2f'
   CHARACTER(LEN=lc) :: cn_ve3t1d = 'e3t', cn_ve3t = 'e3t', cn_ve3w = 'e3w', cn_ve3u = 'e3u', cn_ve3v = 'e3v'
   CHARACTER(LEN=255) :: cn_ve3w1d = 'e3w'
-  CHARACTER(LEN=lc) :: cn_ve3tvvl = 'e3t', cn_ve3wvvl = 'e3w', cn_ve3uvvl = 'e3u', cn_ve3vvvl = 'e3v'
+  CHARACTER(LEN=lc) :: cn_ve3tvvl = CMIP6_('e3t', 'thkcello'), cn_ve3wvvl = CMIP6_('e3w', 'thkcello'), cn_ve3uvvl = CMIP6_('e3u', 'thkcello'), cn_ve3vvvl = CMIP6_('e3v', 'thkcello')
   CHARACTER(LEN=lc) :: cn_ve3t0 = 'e3t_0', cn_ve3w0 = 'e3w_0', cn_ve3u0 = 'e3u_0', cn_ve3v0 = 'e3v_0'
   CHARACTER(LEN=lc) :: cn_vff = 'ff'
   CHARACTER(LEN=lc) :: cn_gdept = 'gdept', cn_gdepw = 'gdepw', cn_hdept = 'hdept', cn_hdepw = 'hdepw'
@@ -46,11 +63,11 @@ MODULE modcdfnames
   CHARACTER(LEN=lc) :: cn_fcoo = 'coordinates.nc', cn_fbasins = 'new_maskglo.nc'
 
   ! --- model variables ---------------------------------------------------------------------
-  CHARACTER(LEN=lc) :: cn_votemper = 'votemper', cn_vosaline = 'vosaline', cn_vozocrtx = 'vozocrtx'
-  CHARACTER(LEN=lc) :: cn_vomecrty = 'vomecrty', cn_vomeeivv = 'vomeeivv', cn_vovecrtz = 'vovecrtz'
-  CHARACTER(LEN=lc) :: cn_sossheig = 'sossheig', cn_somxl010 = 'somxl010', cn_somxlt02 = 'somxlt02'
-  CHARACTER(LEN=lc) :: cn_sozotaux = 'sozotaux'
-  CHARACTER(LEN=lc) :: cn_sohefldo = 'sohefldo', cn_solhflup = 'solhflup', cn_sosbhfup = 'sosbhfup'
+  CHARACTER(LEN=lc) :: cn_votemper = CMIP6_('votemper', 'thetao'), cn_vosaline = CMIP6_('vosaline', 'so'), cn_vozocrtx = CMIP6_('vozocrtx', 'uo')
+  CHARACTER(LEN=lc) :: cn_vomecrty = CMIP6_('vomecrty', 'vo'), cn_vomeeivv = 'vomeeivv', cn_vovecrtz = CMIP6_('vovecrtz', 'wo')
+  CHARACTER(LEN=lc) :: cn_sossheig = CMIP6_('sossheig', 'zos'), cn_somxl010 = 'somxl010', cn_somxlt02 = 'somxlt02'
+  CHARACTER(LEN=lc) :: cn_sozotaux = CMIP6_('sozotaux', 'tauuo')
+  CHARACTER(LEN=lc) :: cn_sohefldo = CMIP6_('sohefldo', 'hfds'), cn_solhflup = 'solhflup', cn_sosbhfup = 'sosbhfup'
   CHARACTER(LEN=lc) :: cn_solwfldo = 'solwfldo', cn_soshfldo = 'soshfldo'
   CHARACTER(LEN=lc) :: cn_sowaflup = 'sowaflup', cn_sowaflcd = 'sowaflcd', cn_sowafldp = 'sowafldp'
   CHARACTER(LEN=lc) :: cn_sorunoff = 'sorunoff', cn_iowaflup = 'iowaflup', cn_soicecov = 'soicecov'
@@ -61,16 +78,16 @@ MODULE modcdfnames
   CHARACTER(LEN=lc) :: cn_zoisoatl = 'zoisoatl', cn_zoisoglo = 'zoisoglo', cn_zoisopac = 'zoisopac'
   CHARACTER(LEN=lc) :: cn_zoisoinp = 'zoisoinp', cn_zoisoind = 'zoisoind', cn_zoisoinp0 = 'zoisoinp0'
   ! transports
-  CHARACTER(LEN=lc) :: cn_vozout = 'vozout', cn_vomevt = 'vomevt', cn_vozous = 'vozous', cn_vomevs = 'vomevs'
+  CHARACTER(LEN=lc) :: cn_vozout = CMIP6_('vozout', 'uto'), cn_vomevt = CMIP6_('vomevt', 'vto'), cn_vozous = CMIP6_('vozous', 'uso'), cn_vomevs = CMIP6_('vomevs', 'vso')
   CHARACTER(LEN=lc) :: cn_sozout = 'sozout', cn_somevt = 'somevt', cn_sozous = 'sozous', cn_somevs = 'somevs'
-  CHARACTER(LEN=lc) :: cn_sozoutrp = 'sozoutrp', cn_somevtrp = 'somevtrp', cn_vouv = 'vouv'
+  CHARACTER(LEN=lc) :: cn_sozoutrp = CMIP6_('sozoutrp', 'umo_vint'), cn_somevtrp = 'somevtrp', cn_vouv = 'vouv'
   ! density
   CHARACTER(LEN=lc) :: cn_vosigma0 = 'vosigma0', cn_vosigmai = 'vosigmai', cn_vosigntr = 'vosigntr'
   CHARACTER(LEN=lc) :: cn_vodepiso = 'vodepiso', cn_isothick = 'isothick'
   ! passive tracers, ice
   CHARACTER(LEN=lc) :: cn_invcfc = 'INVCFC', cn_cfc11 = 'CFC11', cn_pendep = 'pendep'
   CHARACTER(LEN=lc) :: cn_iicethic = 'iicethic', cn_ileadfra = 'ileadfra', cn_iicevelu = 'iicevelu', cn_iicevelv = 'iicevelv'
-  CHARACTER(LEN=lc) :: cn_iicethic3 = 'sivolu', cn_ileadfra3 = 'siconc', cn_iicevelu3 = 'sivelu', cn_iicevelv3 = 'sivelv'
+  CHARACTER(LEN=lc) :: cn_iicethic3 = CMIP6_('sivolu', 'iicethic'), cn_ileadfra3 = CMIP6_('siconc', 'iiceconc'), cn_iicevelu3 = 'sivelu', cn_iicevelv3 = 'sivelv'
   ! bathymetry
   CHARACTER(LEN=lc) :: cn_fbathymet = 'bathy_meter.nc', cn_fbathylev = 'bathy_level.nc'
   CHARACTER(LEN=lc) :: cn_bathymet = 'Bathymetry', cn_bathylev = 'bathy_level', cn_mbathy = 'mbathy'

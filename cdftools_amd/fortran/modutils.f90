@@ -4,11 +4,13 @@ MODULE modutils
   !!   SetGlobalAtt (:45-83)   command line -> 'history' attribute text
   !!   SetFileName  (:85-114)  <CONF>_<TAG>_grid<X>.nc or <CONF>_<TAG>_grid_<X>.nc, STOP 97 when neither exists
   !!   GetList      (:116-169) '1-3,6,10-12' -> integer list
+  !! and heading (:934-973), the rhumb-line bearing the section tools use.  The pool-filling and Shapiro routines of
+  !! the reference's module (:171-932) belong to tools outside the hot path and are not provided.
   !!======================================================================
   USE cdfio, ONLY : chkfile
   IMPLICIT NONE
   PRIVATE
-  PUBLIC :: SetGlobalAtt, SetFileName, GetList
+  PUBLIC :: SetGlobalAtt, SetFileName, GetList, heading
 
 CONTAINS
 
@@ -67,5 +69,22 @@ CONTAINS
     ALLOCATE( klist(ksiz) )
     klist(:) = itmp(1:ksiz)
   END SUBROUTINE GetList
+
+  REAL(KIND=8) FUNCTION heading(dplona, dplonb, dplata, dplatb)
+    !! true heading (degrees, 0..360) from A to B along the rhumb line: the bearing of the segment on a Mercator map
+    !! (src/modutils.f90:934-973).  The longitude difference is folded into (-pi, pi) so that a segment crossing the
+    !! date line is measured the short way.
+    REAL(KIND=8), INTENT(in) :: dplona, dplonb, dplata, dplatb
+    REAL(KIND=8) :: dlpi, dlrad, dldx, dlya, dlyb
+    dlpi  = ACOS(-1.d0)
+    dlrad = dlpi/180.d0
+    dlya  = -LOG(TAN(dlpi/4. - dlrad*dplata/2.d0))          ! Mercator ordinates
+    dlyb  = -LOG(TAN(dlpi/4. - dlrad*dplatb/2.d0))
+    dldx  = MOD(dplonb*dlrad - dplona*dlrad, 2*dlpi)
+    IF ( dldx >=  dlpi ) dldx = dldx - 2*dlpi
+    IF ( dldx <= -dlpi ) dldx = dldx + 2*dlpi
+    heading = ATAN2(dldx, dlyb - dlya)*180.d0/dlpi
+    IF ( heading < 0 ) heading = heading + 360.d0
+  END FUNCTION heading
 
 END MODULE modutils

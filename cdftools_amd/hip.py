@@ -259,6 +259,75 @@ def sigma0(ptem, psal, eos=EOS_80, flags=0, out=None, stream=None):
     return sigmai(ptem, psal, 0.0, eos, flags, None, out, stream)
 
 
+EOS_MCD87 = 4
+EOSQ_ALPHA, EOSQ_BETA, EOSQ_ALBET_MCD87, EOSQ_BETA_MCD87, EOSQ_SPICE_POL, EOSQ_SPICE_F02 = range(6)
+
+
+def eos_field(quantity, ptem, psal, pdep=0.0, eos=EOS_80, out=None, stream=None):
+    """cdft_eos_field: alpha, beta, albet, beta (McDougall 1987) or spiciness at every point -> r8 (src/eos.f90:1315-1775,
+    :689-800).  pdep: one depth, or an array like ptem with a depth per point (the profile members of the generics)."""
+    pt, st_, kt = _arg(ptem, np.float32, "ptem")
+    ps, ss, ks = _arg(psal, np.float32, "psal")
+    n = int(np.prod(kt.shape))
+    if ss != st_ or int(np.prod(ks.shape)) != n:
+        raise ValueError("ptem and psal must have the same size and memory space")
+    pp, dep = None, 0.0
+    if np.ndim(pdep) == 0:
+        dep = float(pdep)
+    else:
+        pp, sp, kp = _arg(pdep, np.float32, "pdep")
+        if sp != st_ or int(np.prod(kp.shape)) != n:
+            raise ValueError("pdep must match ptem in size and memory space")
+    if out is None:
+        out = _out_like(kt, np.float64, torch.float64 if torch is not None else None)
+    po, so, ko = _arg(out, np.float64, "out")
+    if int(np.prod(ko.shape)) != n:
+        raise ValueError("out: wrong size")
+    check(_lib.load().cdft_eos_field(int(quantity), pt, ps, pp, dep, n, eos, po, st_, so, stream or current_stream_ptr()))
+    return out
+
+
+def eos_point(quantity, ptem, psal, pdep, eos=EOS_80):
+    """alpha_0d / beta_0d: one point, r8 arguments (src/eos.f90:1505-1543, :1596-1641)."""
+    import ctypes
+    out = ctypes.c_double()
+    check(_lib.load().cdft_eos_point(int(quantity), float(ptem), float(psal), float(pdep), eos, ctypes.byref(out)))
+    return out.value
+
+
+def alpha(ptem, psal, pdep=0.0, eos=EOS_80, **kw):
+    return eos_field(EOSQ_ALPHA, ptem, psal, pdep, eos, **kw)
+
+
+def beta(ptem, psal, pdep=0.0, eos=EOS_80, **kw):
+    """eos = EOS_MCD87: beta(..., ld_eos80=.TRUE.) (src/eos.f90:1693-1775)."""
+    return eos_field(EOSQ_BETA_MCD87 if eos == EOS_MCD87 else EOSQ_BETA, ptem, psal, pdep, EOS_80 if eos == EOS_MCD87 else eos, **kw)
+
+
+def albet(ptem, psal, pdep=0.0, **kw):
+    return eos_field(EOSQ_ALBET_MCD87, ptem, psal, pdep, **kw)
+
+
+def spice(ptem, psal, flament=False, **kw):
+    """spice(ptem, psal, kpi, kpj, ld_teos10) -- the GSW fit -- or, flament=True, spice(ptem, psal, kpi, kpj)."""
+    return eos_field(EOSQ_SPICE_F02 if flament else EOSQ_SPICE_POL, ptem, psal, 0.0, **kw)
+
+
+def eosbn2(ptem_up, ptem_down, psal_up, psal_down, pe3w, pdep, eos=EOS_80, out=None, stream=None):
+    """cdft_eos_bn2: N^2 between two T levels -> r4 (src/eos.f90:1203-1312); eos = EOS_MCD87 for the ld_eos80 member."""
+    a = [_arg(x, np.float32, nm) for x, nm in zip((ptem_up, ptem_down, psal_up, psal_down, pe3w), ("ptem_up", "ptem_down", "psal_up", "psal_down", "pe3w"))]
+    n = int(np.prod(a[0][2].shape))
+    if any(sp != a[0][1] or int(np.prod(k.shape)) != n for _, sp, k in a):
+        raise ValueError("the five arrays must have the same size and memory space")
+    if out is None:
+        out = _out_like(a[0][2], np.float32, torch.float32 if torch is not None else None)
+    po, so, ko = _arg(out, np.float32, "bn2")
+    if int(np.prod(ko.shape)) != n:
+        raise ValueError("bn2: wrong size")
+    check(_lib.load().cdft_eos_bn2(*[p for p, _, _ in a], float(pdep), n, eos, po, a[0][1], so, stream or current_stream_ptr()))
+    return out
+
+
 def sig_tool(ptem, psal, pref=0.0, spval=0.0, eos=EOS_80, flags=0, out=None, stream=None):
     """cdfsig0 / cdfsigi level loop: r4 = REAL(sigmai * (S /= spval)) (src/cdfsig0.f90:146-152)."""
     pt, st_, kt = _arg(ptem, np.float32, "ptem")
@@ -727,4 +796,4 @@ class CurlPlan(_Plan):
         return out
 
 
-__all__ = ["MocPlan", "HeatcPlan", "MeanPlan", "ZonalPlan", "MhstPlan", "PsiPlan", "CurlPlan", "vt_compute", "mocsig", "vint_cumul", "vertmean", "vint_transport", "vhst_transport", "sigmai", "sigma0", "sig_tool", "EOS_80", "EOS_TEOS10", "EOS_JMD94", "EOS_FAST_FMA", "Timer", "CdftError", "device_count", "current_stream_ptr", "MEM_HOST", "MEM_DEVICE"]
+__all__ = ["MocPlan", "HeatcPlan", "MeanPlan", "ZonalPlan", "MhstPlan", "PsiPlan", "CurlPlan", "vt_compute", "mocsig", "vint_cumul", "vertmean", "vint_transport", "vhst_transport", "sigmai", "sigma0", "sig_tool", "eos_field", "eos_point", "alpha", "beta", "albet", "spice", "eosbn2", "EOS_80", "EOS_TEOS10", "EOS_JMD94", "EOS_NTR", "EOS_MCD87", "EOS_FAST_FMA", "Timer", "CdftError", "device_count", "current_stream_ptr", "MEM_HOST", "MEM_DEVICE"]

@@ -199,6 +199,34 @@ int cdft_eos_sig_tool(const float *ptem, const float *psal, int64_t n, float pre
 int cdft_eos_release(void);   /* frees the staging buffers used for host arrays */
 
 /* ------------------------------------------------------------------------------------------ */
+/* eos, the other members of the module's public list (src/eos.f90:24-32): alpha, beta, albet, */
+/*   spice, eosbn2.  Pointwise like sigmai; the same evaluation order and r4/r8 mixing as the  */
+/*   reference, bit-identical results.  (sigmantr is cdft_eos_sigmai with CDFT_EOS_NTR.)       */
+/* ------------------------------------------------------------------------------------------ */
+#define CDFT_EOSQ_ALPHA        0   /* alpha_2d / alpha_z  (src/eos.f90:1452-1503, :1545-1594), eos = 80 | TEOS10        */
+#define CDFT_EOSQ_BETA         1   /* beta_2d / beta_z    (:1400-1450, :1643-1691),            eos = 80 | TEOS10        */
+#define CDFT_EOSQ_ALBET_MCD87  2   /* albet_2d / albet_z  (:1315-1398): alpha/beta of McDougall (1987); eos ignored     */
+#define CDFT_EOSQ_BETA_MCD87   3   /* beta_2d_80 / beta_z_80 (:1693-1775): beta(..., ld_eos80=.TRUE.); eos ignored      */
+#define CDFT_EOSQ_SPICE_POL    4   /* spice_pol (:755-800): spiciness-0 fit of the GSW toolbox; depth and eos ignored   */
+#define CDFT_EOSQ_SPICE_F02    5   /* spice_80  (:689-753): Flament (2002); depth and eos ignored                       */
+#define CDFT_EOS_MCD87         4   /* cdft_eos_bn2 only: eosbn2(..., ld_eos80=.TRUE.), McDougall (1987) alpha/beta, beta */
+
+/* out(n) r8 = the quantity at every point.  pdep_n == NULL: one depth pdep for all points (the 2-D members of the
+ * generics); else pdep_n(n) holds a depth per point (the profile members, which take pdep(kpk)) and pdep is ignored.
+ * alpha and beta are multiplied by (psal /= 0) as the reference does (:1419-1423); the other four are not masked. */
+int cdft_eos_field(int quantity, const float *ptem, const float *psal, const float *pdep_n, float pdep, int64_t n, int eos,
+                   double *out, int in_space, int out_space, void *stream);
+/* bn2(n) r4 = eosbn2(ptem, psal, pdep, pe3w, kpi, kpj, kup, kdown): N^2 at the w level between the T levels "up" and
+ * "down" (the reference's ptem(:,:,kup), ptem(:,:,kdown) planes are passed as separate arrays).  eos = CDFT_EOS_80 or
+ * CDFT_EOS_TEOS10: eosbn2_pol (:1203-1244) with that coefficient set -- including its habit of handing alpha and beta
+ * the salinity anomaly s-35 (:1231-1235); CDFT_EOS_MCD87: eosbn2_80 (:1246-1312).  Not masked. */
+int cdft_eos_bn2(const float *ptem_up, const float *ptem_down, const float *psal_up, const float *psal_down, const float *pe3w,
+                 float pdep, int64_t n, int eos, float *bn2, int in_space, int out_space, void *stream);
+/* alpha_0d / beta_0d (:1505-1543, :1596-1641): one point, r8 arguments, r8 result in host memory (synchronous) */
+int cdft_eos_point(int quantity, double ptem, double psal, double pdep, int eos, double *out);
+int cdft_eos_more_release(void);   /* frees the staging buffers of the two entries above */
+
+/* ------------------------------------------------------------------------------------------ */
 /* cdfheatc : heat content (masked volume integrals per level)                                */
 /*   replaces src/cdfheatc.f90:205-240 (the three SUMs of each level)                          */
 /* ------------------------------------------------------------------------------------------ */

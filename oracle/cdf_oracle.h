@@ -8,7 +8,7 @@
  * mixing; the reference file:line it follows is cited at each definition in cdf_oracle.c.
  *
  * Pinning status (see DESIGN.md "Oracle"):
- *   - sigma0 / sigmai / sigmantr : PINNED bit for bit to the reference's src/eos.f90 compiled where it lies
+ *   - sigma0 / sigmai / sigmantr, and spice / alpha / beta / albet / eosbn2 (every generic member) : PINNED bit for bit to the reference's src/eos.f90 compiled where it lies
  *     (oracle/_ref/libeos_ref.so; tests/golden/eos.npz) and to its known-answer values (src/eos.f90:817,:820).
  *   - cdfmoc (+ -decomp, -full), cdfheatc (r4sum mode, + -full, -mxloption), cdfmhst (-vt / V,T,S / -Zdim / -full),
  *     cdfpsi (default, -V, -mean, -mask, -ref, -full, -open, --ssh-file, -lev), cdfvT (+ -vvl), cdfcurl (+ -T,
@@ -58,6 +58,15 @@ void oracle_sigmai(const float *ptem, const float *psal, long n, float pref, con
 void oracle_sigmai_jmd94(const float *ptem, const float *psal, long n, float pref, const float *pref2d,
                          double *sig);
 void oracle_sigmantr(const float *ptem, const float *psal, long n, double *out);   /* src/eos.f90:634-687 */
+/* the rest of the eos module's public list (cdf_oracle_eos2.c): which = 0 alpha, 1 beta (polynomial, src/eos.f90:1400-1691),
+ * 2 alpha/beta, 3 beta (McDougall 1987, :1315-1398, :1693-1775); one depth, or a depth per point (the profile members) */
+void oracle_eos_coef(int which, const float *ptem, const float *psal, long n, float pdep, const float *pdep2d,
+                     int teos10, double *out);
+/* spice_pol (flament = 0, :755-800) and spice_80 (flament = 1, :689-753) */
+void oracle_spice(int flament, const float *ptem, const float *psal, long n, double *out);
+/* eosbn2_pol (form 0, :1203-1244) and eosbn2_80 (form 1, :1246-1312); r4 result */
+void oracle_bn2(int form, const float *t_up, const float *t_dn, const float *s_up, const float *s_dn, const float *e3w,
+                long n, float pdep, int teos10, float *bn2);
 /* callers src/cdfsig0.f90:146-152, src/cdfsigi.f90:131-137: r4 result = sigma * (S /= spval) */
 void oracle_sig_tool(const float *ptem, const float *psal, long n, float pref, float spval, int teos10,
                      float *sig4);

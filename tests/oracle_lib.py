@@ -118,6 +118,35 @@ def sigmantr(ptem, psal):
     return out
 
 
+def eos_coef(which, ptem, psal, pdep=0.0, teos10=False, pdep2d=None):
+    """oracle_eos_coef: which 0 alpha, 1 beta (polynomial), 2 alpha/beta, 3 beta (McDougall 1987); r8."""
+    lib = load()
+    t, s = _f32(ptem), _f32(psal)
+    out = np.empty(t.shape, np.float64)
+    p2 = _f32(pdep2d) if pdep2d is not None else None
+    lib.oracle_eos_coef(C.c_int(which), _p(t), _p(s), C.c_long(t.size), C.c_float(pdep), _p(p2) if p2 is not None else None,
+                        C.c_int(1 if teos10 else 0), _p(out))
+    return out
+
+
+def spice(ptem, psal, flament=False):
+    lib = load()
+    t, s = _f32(ptem), _f32(psal)
+    out = np.empty(t.shape, np.float64)
+    lib.oracle_spice(C.c_int(1 if flament else 0), _p(t), _p(s), C.c_long(t.size), _p(out))
+    return out
+
+
+def bn2(t_up, t_dn, s_up, s_dn, e3w, pdep, teos10=False, mcd87=False):
+    """oracle_bn2: N^2 between two T levels, r4."""
+    lib = load()
+    a = [_f32(x) for x in (t_up, t_dn, s_up, s_dn, e3w)]
+    out = np.empty(a[0].shape, np.float32)
+    lib.oracle_bn2(C.c_int(1 if mcd87 else 0), *[_p(x) for x in a], C.c_long(a[0].size), C.c_float(pdep),
+                   C.c_int(1 if teos10 else 0), _p(out))
+    return out
+
+
 def sig_tool(ptem, psal, pref=0.0, spval=0.0, teos10=False):
     """cdfsig0 / cdfsigi level loop: r4 result = sigma * (S /= spval)."""
     lib = load()
@@ -171,6 +200,42 @@ class RefEos:
 
     def sigmantr(self, t, s):
         return self._call(self.lib.ref_sigmantr, t, s)
+
+    def spice(self, t, s, flament=False):
+        t, s = _f32(t), _f32(s)
+        out = np.empty(t.shape, np.float64)
+        self.lib.ref_spice(_p(t), _p(s), C.c_int(t.shape[-1]), C.c_int(t.size // t.shape[-1]), C.c_int(1 if flament else 0), _p(out))
+        return out
+
+    def coef(self, which, t, s, pdep, teos10=False):
+        """pdep a number: the 2-D members; an array like t: the profile members (one call over the raveled points)."""
+        self.init(teos10)
+        t, s = _f32(t), _f32(s)
+        out = np.empty(t.shape, np.float64)
+        if np.ndim(pdep) == 0:
+            self.lib.ref_coef2d(C.c_int(which), _p(t), _p(s), C.c_float(pdep), C.c_int(t.shape[-1]), C.c_int(t.size // t.shape[-1]), _p(out))
+        else:
+            p = _f32(pdep)
+            self.lib.ref_coefz(C.c_int(which), _p(t), _p(s), _p(p), C.c_int(t.size), _p(out))
+        return out
+
+    def coef0d(self, which, t, s, dep, teos10=False):
+        self.init(teos10)
+        out = C.c_double()
+        self.lib.ref_coef0d(C.c_int(which), C.c_double(t), C.c_double(s), C.c_double(dep), C.byref(out))
+        return out.value
+
+    def bn2(self, t_up, t_dn, s_up, s_dn, e3w, pdep, teos10=False, mcd87=False, up_plane=1):
+        """t_up .. e3w (npj,npi); the two levels are stacked as the reference's (kpi,kpj,2) with the upper one in plane
+        up_plane (1 or 2), as cdfbn2's swapping iup / idown do."""
+        self.init(teos10)
+        tt = np.stack([_f32(t_up), _f32(t_dn)] if up_plane == 1 else [_f32(t_dn), _f32(t_up)])
+        ss = np.stack([_f32(s_up), _f32(s_dn)] if up_plane == 1 else [_f32(s_dn), _f32(s_up)])
+        e = _f32(e3w)
+        out = np.empty(e.shape, np.float32)
+        self.lib.ref_bn2(C.c_int(1 if mcd87 else 0), _p(tt), _p(ss), C.c_float(pdep), _p(e), C.c_int(e.shape[-1]), C.c_int(e.size // e.shape[-1]),
+                         C.c_int(up_plane), C.c_int(3 - up_plane), _p(out))
+        return out
 
     def sigmai2d(self, t, s, pref2d, teos10=False):
         self.init(teos10)
