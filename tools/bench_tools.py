@@ -183,6 +183,17 @@ def main():
             report(name, args.grid, n3, 12.0, ms, "T 4 + S 4 + out 4 B per point; surface reference: one of the four polynomials")
         ms = timed(lambda: hip.sig_tool(t, s, 2000.0, 0.0, 0, 0, out=o4), args.reps)
         report("sigma2 (sigmai at 2000 m) tool form, exact", args.grid, n3, 12.0, ms, "all four polynomials of the EOS: the r8 work of cdfmocsig")
+        # the other members of the eos module (eos_more.hip); r8 results: T 4 + S 4 + out 8 B per point
+        o8 = torch.empty(n3, dtype=torch.float64, device=dev)
+        for name, fn in (("alpha (2000 m)", lambda: hip.alpha(t, s, 2000.0, out=o8)), ("beta (2000 m)", lambda: hip.beta(t, s, 2000.0, out=o8)),
+                         ("albet, McDougall 1987", lambda: hip.albet(t, s, 2000.0, out=o8)), ("spice, GSW fit", lambda: hip.spice(t, s, out=o8)),
+                         ("spice, Flament 2002", lambda: hip.spice(t, s, flament=True, out=o8))):
+            report(name, args.grid, n3, 16.0, timed(fn, args.reps), "T 4 + S 4 + out 8 B per point")
+        t2, s2 = t + 0.5, s * 1.01
+        ms = timed(lambda: hip.eosbn2(t, t2, s, s2, e3.reshape(-1), 2000.0, out=o4), args.reps)
+        report("eosbn2, polynomial alpha and beta", args.grid, n3, 24.0, ms, "two levels of T and S 16 + e3w 4 + out 4 B per point; alpha AND beta evaluated at every point")
+        ms = timed(lambda: hip.eosbn2(t, t2, s, s2, e3.reshape(-1), 2000.0, eos=hip.EOS_MCD87, out=o4), args.reps)
+        report("eosbn2, McDougall 1987", args.grid, n3, 24.0, ms, "")
 
 
 if __name__ == "__main__":
