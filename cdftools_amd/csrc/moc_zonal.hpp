@@ -176,8 +176,10 @@ moc_zonal_kernel(ZonalArgs a) {
 
             // ibmask = 0: the reference's term is ((e1v*e3v)*0)*zv, a signed zero that never changes the
             // r8 sum -- unless zv is NaN/Inf there (a fill value on land), when it is NaN and the sum must
-            // keep it.  The usual all-finite record selects pd or 0; a record in which any r4 product of
-            // the wave is not finite is accumulated again with 0*pd in place of the 0 (EXACT).
+            // keep it.  The usual all-finite record selects pd or 0 (or multiplies by the 0/1 mask); a record
+            // in which any r4 product of the wave is not finite -- a NaN/Inf velocity, or a finite one large
+            // enough to overflow the r4 product -- is accumulated again with the reference's own zero term
+            // (w*0)*zv in place of the 0 (EXACT): NaN for a NaN/Inf velocity, 0 for an overflow.
             double acc[NB];
             float nonfinite = 0.f;                                // sum of 0*pf: 0, or NaN once a product is NaN/Inf
             auto accumulate = [&](auto exact) {
@@ -193,11 +195,11 @@ moc_zonal_kernel(ZonalArgs a) {
                         const float zf = (MODE == kModeFma || EXACT) ? (ok[r][c] ? zc[r][c] : 0.f) : zc[r][c];
                         const float pf = __fmul_rn(w[r][c], zf);
                         const double pd = (double)pf;
-                        if (MODE == kModeSelect && !EXACT) nonfinite = __fmaf_rn(pf, 0.f, nonfinite);
-                        const double pz = EXACT ? __dmul_rn(pd, 0.0) : 0.0;
+                        if (!EXACT) nonfinite = __fmaf_rn(pf, 0.f, nonfinite);
+                        const double pz = EXACT ? (double)__fmul_rn(__fmul_rn(w[r][c], 0.f), zf) : 0.0;
 #pragma unroll
                         for (int b = 0; b < NB; ++b) {
-                            if (MODE == kModeFma)
+                            if (MODE == kModeFma && !EXACT)
                                 acc[b] = __fma_rn(pd, m[r][c][b], acc[b]);
                             else
                                 acc[b] += ((bits[r] >> (8 * c + b)) & 1u) ? pd : pz;
@@ -206,7 +208,7 @@ moc_zonal_kernel(ZonalArgs a) {
                 }
             };
             accumulate(std::false_type{});
-            if (MODE == kModeSelect && __builtin_amdgcn_ballot_w64(nonfinite != 0.f) != 0) accumulate(std::true_type{});
+            if (__builtin_amdgcn_ballot_w64(nonfinite != 0.f) != 0) accumulate(std::true_type{});
 
             // wave reduction: transpose through LDS so that lane (b*8+s) sums 8 lanes' partials
 #pragma unroll
@@ -320,8 +322,10 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
 // ~5 x 5 VALU instructions).  A slot only ever receives the terms of its own lane, in program
 // order, so the result is run-to-run deterministic.  Basin sums are formed from the class sums at
 // the end (basin b = classes whose pattern has bit b, in class order).  The empty pattern (a cell in
-// no basin) is a class like the others: its sum is finite unless a NaN/Inf sits on such a cell, and
-// 0 * (the sums of the classes outside b) restores the NaN the reference's 0*zv products give.
+// no basin) is a class like the others.  The zero terms ((e1v*e3v)*0)*zv the reference adds for the cells outside a
+// basin matter only when a velocity there is NaN/Inf: as long as the sum of those classes is finite nothing is added;
+// when it is not, the row's velocities are read again to tell a NaN/Inf (the term is NaN) from a finite velocity whose
+// r4 product overflowed (the term is 0) -- a slow path no sane record takes.
 // ALIGNED: records whose base and stride are multiples of 16 bytes: the row is covered by vectors aligned to the
 // ARRAY and its first / last vector is shared with the neighbouring rows (masked).  Otherwise (eORCA025: 1442 x 1207 x 75
 // cells per record, not a multiple of 4): 16-byte loads at r4 alignment, vectors at cells 0, 4, 8, ... of the ROW plus
@@ -338,6 +342,8 @@ __device__ __forceinline__ void moc_zonal_class_row(const ZonalArgs &a, const in
     const int nwaves = blockDim.x >> 6;
     double *scr  = smem + wave * ((KC + 1) * kScrStride);        // slot [class][lane]; class KC = lanes past the row end
     double *part = smem + nwaves * ((KC + 1) * kScrStride);      // [kTChunk][KC][nwaves]
+    // [0]: records of the chunk whose zero term needs the velocities again; [1+tl]: classes holding a NaN/Inf velocity
+    uint32_t *flag = reinterpret_cast<uint32_t *>(part + kTChunk * KC * nwaves);
 
     const int jk  = row / a.npj;                                  // row = jk*npj + jj, jj fastest
     const int jj  = row - jk * a.npj;
@@ -392,6 +398,7 @@ __device__ __forceinline__ void moc_zonal_class_row(const ZonalArgs &a, const in
 
     for (int t0 = 0; t0 < a.npt; t0 += kTChunk) {
         const int tcount = min(kTChunk, a.npt - t0);
+        if (threadIdx.x <= kTChunk) flag[threadIdx.x] = 0u;       // (ordered before its use by the barrier after the records)
         for (int tl = 0; tl < tcount; ++tl) {
             const int t = t0 + tl;
             if (t + 1 < a.npt) load_rec(zn, t + 1);               // next record in flight
@@ -427,20 +434,53 @@ __device__ __forceinline__ void moc_zonal_class_row(const ZonalArgs &a, const in
             for (int r = 0; r < NV; ++r) zc[r] = zn[r];
         }
         __syncthreads();
-        for (int q = threadIdx.x; q < tcount * a.nbasins; q += blockDim.x) {     // (one wave holds 64 < 16 records x 5 basins)
-            const int tl = q / a.nbasins, b = q - tl * a.nbasins;
-            double s = 0.0, z = 0.0;
+        // basin b of record tl: s = the classes whose pattern has bit b, z = the others, nm = which those are
+        auto basin_sums = [&](int tl, int b, double &s, double &z, uint32_t &nm) {
+            s = 0.0; z = 0.0; nm = 0u;
             for (int c = 0; c < a.nclass; ++c) {
                 const bool in = (a.pat[c] >> b) & 1;
+                if (!in) nm |= 1u << c;
                 for (int k = 0; k < nwaves; ++k) {
                     const double v = part[(tl * KC + c) * nwaves + k];
                     if (in) s += v;
                     else    z += v;
                 }
             }
-            // cells outside basin b: the reference adds ((e1v*e3v)*0)*zv, a zero unless zv is NaN/Inf
-            s += __dmul_rn(z, 0.0);
-            a.out[(((int64_t)(t0 + tl) * a.npk + jk) * a.npj + jj) * a.nbasins + b] = -s;
+        };
+        for (int q = threadIdx.x; q < tcount * a.nbasins; q += blockDim.x) {     // (one wave holds 64 < 16 records x 5 basins)
+            const int tl = q / a.nbasins, b = q - tl * a.nbasins;
+            double s, z; uint32_t nm;
+            basin_sums(tl, b, s, z, nm);
+            // cells outside basin b: the reference adds ((e1v*e3v)*0)*zv, a zero unless zv is NaN/Inf.  While the sum
+            // of their products is finite every one of them is: the zero term is a zero.
+            if (__builtin_isfinite(z)) {
+                s += __dmul_rn(z, 0.0);
+                a.out[(((int64_t)(t0 + tl) * a.npk + jk) * a.npj + jj) * a.nbasins + b] = -s;
+            } else {
+                atomicOr(&flag[0], 1u << tl);
+            }
+        }
+        __syncthreads();
+        if (flag[0] != 0u) {                                      // (the same word for every lane of the workgroup)
+            // A product outside some basin is not finite: a NaN/Inf velocity (the reference's zero term is NaN) or a
+            // finite one that overflowed the r4 product (the zero term is 0).  Only the velocities tell: read the
+            // row of those records again and note the classes that hold a NaN/Inf.
+            const uint32_t need = flag[0];
+            for (int tl = 0; tl < tcount; ++tl) {
+                if (!((need >> tl) & 1u)) continue;
+                const float *zr = a.zv + (int64_t)(t0 + tl) * a.rec_stride + g0;
+                for (int i = threadIdx.x; i < a.npi; i += blockDim.x)
+                    if (!__builtin_isfinite(zr[i])) atomicOr(&flag[1 + tl], 1u << crow[i]);
+            }
+            __syncthreads();
+            for (int q = threadIdx.x; q < tcount * a.nbasins; q += blockDim.x) {
+                const int tl = q / a.nbasins, b = q - tl * a.nbasins;
+                double s, z; uint32_t nm;
+                basin_sums(tl, b, s, z, nm);
+                if (__builtin_isfinite(z)) continue;             // written above
+                if (flag[1 + tl] & nm) s += __builtin_nan("");
+                a.out[(((int64_t)(t0 + tl) * a.npk + jk) * a.npj + jj) * a.nbasins + b] = -s;
+            }
         }
         __syncthreads();
     }
@@ -458,7 +498,7 @@ moc_zonal_class_kernel(ZonalArgs a) {
 
 template <int NV, int KC, int LB>
 static int launch_class_lb(const ZonalArgs &a, int nwaves, hipStream_t st) {
-    const size_t shmem = sizeof(double) * ((size_t)nwaves * (KC + 1) * kScrStride + (size_t)kTChunk * KC * nwaves);
+    const size_t shmem = sizeof(double) * ((size_t)nwaves * (KC + 1) * kScrStride + (size_t)kTChunk * KC * nwaves + (kTChunk + 2) / 2 + 1);
     const unsigned nrows = (unsigned)a.npj * (unsigned)(a.npk - 1);
     const unsigned grid = (nrows + (unsigned)a.rows_per_wg - 1) / (unsigned)a.rows_per_wg;
     if (a.aligned) hipLaunchKernelGGL((moc_zonal_class_kernel<NV, KC, LB, true>), dim3(grid), dim3(kWave * nwaves), shmem, st, a);

@@ -55,6 +55,72 @@ def test_oracle_propagates_a_masked_nan_like_the_reference_expression():
 
 
 # ----------------------------------------------------------------------------- GPU
+def overflowing(zv, e1v, e3v, ib, seed, with_nan=False):
+    """Copy of zv with huge FINITE values on a few ocean cells that lie in the global basin but outside at least one
+    sub-basin: the r4 product (e1v*e3v)*zv overflows to +-Inf there.  The reference forms ((e1v*e3v)*ibmask)*zv, so the
+    basins the cell is not in get (w*0)*zv = 0, not 0*Inf = NaN (cdfmoc.f90:373-374).  with_nan: a NaN on a cell outside
+    every basin of the SAME rows as well, which must still reach every basin."""
+    zv = zv.copy()
+    rng = np.random.default_rng(seed)
+    w = e1v[None] * e3v                                                  # (npk, npj, npi)
+    nb = ib.shape[2]
+    partial = (ib[:, :, 0] == 1) & (ib[:, :, 1:].sum(axis=2) < max(nb - 1, 1)) if nb > 1 else (ib[:, :, 0] == 1)
+    cand = np.argwhere((w[:-1] > 1.0) & partial[None])
+    pick = cand[rng.choice(len(cand), min(4, len(cand)), replace=False)]
+    rows = []
+    for n, (k, j, i) in enumerate(pick):
+        zv[:, k, j, i] = np.float32(3.0e38) * (1 if n % 2 == 0 else -1)
+        rows.append((k, j))
+    if with_nan:
+        nowhere = np.argwhere(ib.max(axis=2) == 0)
+        for k, j in rows[:2]:
+            on_row = nowhere[nowhere[:, 0] == j]
+            if len(on_row):
+                zv[1 % zv.shape[0], k, j, on_row[0, 1]] = np.nan
+    return zv, rows
+
+
+def test_oracle_gives_zero_not_nan_for_an_overflowed_product_outside_a_basin():
+    g = synth.make_grid(24, 18, 7, seed=24, nbasins=5)
+    e1v, e3v, ib = synth.moc_inputs(g)
+    zv, rows = overflowing(synth.velocity(g, 2, seed=4), e1v, e3v, ib, seed=1)
+    d = oracle_lib.moc(e1v, e3v, ib, zv)                         # (npt, npk, npj, nb)
+    assert rows and np.isinf(d[..., 0]).any() and not np.isnan(d).any()
+    # at the poisoned level itself (before the cumulation spreads it upwards... the cumulation runs upwards from the
+    # bottom, so the levels BELOW k never see it): a basin the cell is not in keeps a finite value on that row
+    checked = 0
+    for k, j in rows:
+        i = np.flatnonzero(np.abs(zv[0, k, j]) > 1e38)
+        for b in range(5):
+            if ib[j, i, b].sum() == 0:
+                assert np.isfinite(d[:, :, j, b]).all()
+                checked += 1
+            else:
+                assert np.isinf(d[:, k, j, b]).all()
+    assert checked
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+@pytest.mark.parametrize("npi,npj,npk,nb", [(24, 18, 7, 5), (182, 149, 31, 5), (259, 6, 4, 8), (67, 5, 3, 1), (1442, 9, 4, 5)])
+def test_moc_finite_overflow_is_not_a_nan_outside_the_basin(gpu, npi, npj, npk, nb, mode):
+    """the zero term is (w*0)*zv, keyed on the velocity, not 0*(w*zv)."""
+    g = synth.make_grid(npi, npj, npk, seed=npi, nbasins=nb)
+    e1v, e3v, ib = synth.moc_inputs(g)
+    plan = gpu.MocPlan(npi, npj, npk, nb)
+    plan.set_mesh(e1v, e3v, ib)
+    plan.set_tuning(mode=mode)
+    for with_nan in (False, True):
+        zv, rows = overflowing(synth.velocity(g, 3, seed=4), e1v, e3v, ib, seed=npi, with_nan=with_nan)
+        assert rows
+        ref = oracle_lib.moc(e1v, e3v, ib, zv)
+        clean = np.where(np.abs(zv) < 1e38, zv, 0).astype(np.float32)
+        clean[~np.isfinite(clean)] = 0
+        lim = 1e-13 * np.abs(oracle_lib.moc(e1v, e3v, ib, np.abs(clean))).max() + 1e-300
+        same(plan.compute(zv), ref, lim)
+    plan.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", [0, 1, 2, 3])
 @pytest.mark.parametrize("npi,npj,npk,nb", [(24, 18, 7, 5), (182, 149, 31, 5), (259, 6, 4, 8), (67, 5, 3, 1)])
