@@ -9,7 +9,10 @@
 //
 // HBM-bound: per cell temp 4 B + e3t 4 B + tmask 1 B (+ 8/npk) = 9.11 algorithmic bytes; the 2-D
 // area e1t*e2t is re-read from L2 / Infinity Cache for every level.
+#include <algorithm>
+#include <cstddef>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 #include "common.hpp"
 #include "reduce.hpp"
@@ -42,7 +45,7 @@ struct cdft_heatc_plan {
     int sum_mode = 0;          // CDFT_HEATC_SUM_R8 | CDFT_HEATC_SUM_R4SEQ
     std::vector<float> carry;  // r4seq: the chains' start values (3*npk), empty = zeros; consumed by the next compute
     std::vector<float> last4;  // r4seq: the r4 sums of the last compute (what the next row block starts from)
-    DevBuf st_a, st_b, st_temp, st_mxl, st_out, st_c4, st_s4;
+    DevBuf st_a, st_b, st_temp, st_mxl, st_out, st_c4, st_s4, st_scan;
 };
 
 namespace {
@@ -328,13 +331,455 @@ __global__ void __launch_bounds__(64) heatc_seq_kernel(HeatcArgs a, const float 
     if (lane < 3) sums4[k * 3 + lane] = s;
 }
 
-int launch_seq(const HeatcArgs &a, const float *carry, float *sums4, hipStream_t st) {
-    dim3 grid(a.npk), block(64);
+// ---------------------------------------------------------------------------------------------------------------
+// The same chains at memory speed.  A sequential r4 sum cannot be regrouped -- but while the running sum s stays
+// inside one binade [2^e, 2^(e+1)) it IS an integer sum: s = S * 2^(e-23) with S a 24-bit integer, and
+//     RN(s + x) = (S + k(x)) * 2^(e-23),   k(x) = x / 2^(e-23) rounded to the nearest integer,
+// as long as the result stays in the binade (the spacing of the floats around s + x is then 2^(e-23) whatever x is;
+// negative s: the mirror image).  k does not depend on S unless x / 2^(e-23) falls exactly half way between two
+// integers (then RN picks the even S + k: a "tie").  So a chunk of cells with no tie and no binade change moves S
+// by the plain sum of its k's: order-free, computed by every lane of every wave at once.
+//
+// Which binade?  The r8 sums of the level kernel above (one partial per block of 4096 cells, formed anyway by the r8
+// mode), added to the last exact value the level has published, estimate the chain's value at every block boundary:
+// the binade of the estimate where a block starts and, when different, where it ends are the two HYPOTHESES (sign, e)
+// for the block's chunks of 512 cells.  Work is dealt in tickets of 64 chunks of one level from an atomic counter (ticket = step * npk
+// + level: the workgroups in flight spread over all levels and a few consecutive steps of each).  A workgroup forms,
+// for each chunk, chain and hypothesis,  K = sum k,  pos = sum max(k,0)  and flags (a cell that is not 0; a tie / NaN
+// / Inf / |k| >= 2^20; a negative x); then waits for the step before it to publish the chains' exact values.  One
+// wave per chain takes the 64 chunks, one per lane: with S_before from a prefix sum of the K's,
+//     S_before + neg >= 2^23 (+1 when an x was negative)   and   S_before + pos < 2^24
+// prove that no prefix of the chunk left the binade, and S += K is exactly what 512 sequential v_add_f32 would have
+// produced; the first chunk that fails the proof, or whose hypotheses do not name the chain's binade, stops the walk.
+// That chunk -- the sum crosses a power of two (some 25 times per chain), a tie (about as rare on real fields), the
+// first cells of the chain (s = 0, or smaller than x) -- is read again and resolved cell by cell, still in parallel:
+// per-cell prefix sums find the first cell that breaks the rule, the cells before it are added as integers, that one
+// cell with a v_add_f32, and the rest again under the new binade (a chunk that keeps breaking -- every cell a tie --
+// is finished by a plain sequential loop).  A chunk of zeros (land) is the identity under any state.  Since the step
+// a workgroup waits for was dealt before its own, it is held by a workgroup that already runs: no deadlock whatever
+// else shares the GPU; a wait that lasts over a second raises an error flag instead of hanging.  Bit-identical to
+// heatc_seq_kernel (tests/test_heatc.py compares the two on adversarial fields and at size).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kScanWaves = 4, kScanNV = 2, kScanChunk = kScanNV * 256, kScanSub = kScanWaves * kScanChunk;
+constexpr int kScanMaxChunks = 256;                               // chunks per ticket: 64, 128 or 256 (32768 .. 131072 cells)
+
+__device__ __forceinline__ int wave_isum(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ int wave_imin(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_iscan_incl(int v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(v, o, 64); if (lane >= o) v += t; }
+    return v;
+}
+
+// What a level has published: word[ch] = (number of tickets done) << 32 | bits of chain ch's value there -- tag and
+// value in ONE 64-bit atomic word, so a reader never sees a value that does not belong to the step it read.
+struct ScanLevel { unsigned long long word[3]; unsigned long long pad; };
+__device__ __forceinline__ unsigned long long scan_word(int step, float s) { return ((unsigned long long)(uint32_t)step << 32) | __float_as_uint(s); }
+struct ScanCtl   { int ticket; int error; int nfallback, nunguessed, nslow, pad; };   // (the last three: statistics)
+
+// the binade of a chain value: sign and exponent, or -1 when the integer picture does not apply (0, denormal, Inf, NaN,
+// or an exponent whose ulp does not scale exactly)
+__device__ __forceinline__ int scan_key(float s) {
+    const uint32_t b = __float_as_uint(s);
+    const int ex = (int)((b >> 23) & 0xffu);
+    return (ex >= 27 && ex <= 247) ? (int)(b >> 23) : -1;
+}
+__device__ __forceinline__ int   scan_mant(float s)         { return (int)((__float_as_uint(s) & 0x7fffffu) | 0x800000u); }
+__device__ __forceinline__ float scan_value(int key, int S) { return __uint_as_float(((uint32_t)key << 23) | ((uint32_t)S & 0x7fffffu)); }
+__device__ __forceinline__ float scan_scale(int key) {            // +-2^(23-e): x * scale = x / ulp(s), with the sign of s folded in
+    return __uint_as_float(((uint32_t)(key & 0x100) << 23) | ((uint32_t)(23 + 254 - (key & 0xff)) << 23));
+}
+
+// est[k][b][ch], b = 0..nblk: the r8 value of chain ch of level k where block b of the level kernel starts (b = nblk:
+// where the level ends), from its partials and the carry.  One wave per level.
+__global__ void __launch_bounds__(64) heatc_scan_est_kernel(const double *__restrict__ partial, int nblk, const float *__restrict__ carry,
+                                                            double *__restrict__ est, ScanLevel *lev, ScanCtl *ctl) {
+    const int k = blockIdx.x, lane = threadIdx.x;
+    double *ek = est + (int64_t)k * (nblk + 1) * 3;
+    const double *pk = partial + (int64_t)k * nblk * 3;
+    const int seg = (nblk + 63) / 64, b0 = min(nblk, lane * seg), b1 = min(nblk, b0 + seg);   // this lane's blocks
+    double sum[3] = {0.0, 0.0, 0.0};
+    for (int b = b0; b < b1; ++b)
+        for (int c = 0; c < 3; ++c) sum[c] += pk[(int64_t)b * 3 + c];
+    for (int c = 0; c < 3; ++c) {
+        double incl = sum[c];                                     // the sums of the lanes before this one
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const double t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+        double run = (double)(carry ? carry[k * 3 + c] : 0.f) + (incl - sum[c]);
+        if (lane == 0) ek[c] = run;
+        for (int b = b0; b < b1; ++b) { run += pk[(int64_t)b * 3 + c]; ek[(int64_t)(b + 1) * 3 + c] = run; }
+    }
+    if (lane < 3) lev[k].word[lane] = scan_word(0, carry ? carry[k * 3 + lane] : 0.f);
+    if (k == 0 && lane == 0) { ctl->ticket = 0; ctl->error = 0; ctl->nfallback = 0; ctl->nunguessed = 0; ctl->nslow = 0; }
+}
+
+template <bool MASK8, bool FULL, bool MXL>
+__global__ void __launch_bounds__(64 * kScanWaves, 3) heatc_scan_kernel(HeatcArgs a, ScanLevel *__restrict__ lev, ScanCtl *__restrict__ ctl,
+                                                                     const double *__restrict__ est, int block_cells, int nchunk, int nsteps,
+                                                                     float *__restrict__ sums4) {
+    __shared__ int sm_K[2][kScanMaxChunks][3], sm_pos[2][kScanMaxChunks][3], sm_flag[2][kScanMaxChunks][3], sm_key[2][kScanMaxChunks][3];
+    __shared__ float st_s[3];
+    __shared__ int pos_[3], fb[3], tick;
+    __shared__ __attribute__((aligned(16))) float xs[3][kScanChunk];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t ticket_cells = (int64_t)nchunk * kScanChunk;
+
+    struct Raw { float ar[4], e3[4], tt[4], mk[4], mx[4]; };
+    for (;;) {
+        if (threadIdx.x == 0) tick = __hip_atomic_fetch_add(&ctl->ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const int ticket = tick;
+        if (ticket >= nsteps * a.npk) break;                      // (uniform)
+        const int step = ticket / a.npk, k = ticket - step * a.npk;
+        const int64_t base = (int64_t)k * a.nij, t0 = (int64_t)step * ticket_cells;
+        const float e3k = FULL ? a.e31d[k] : 0.f;
+        const float dw  = MXL ? a.gdepw[k] : 0.f;
+        if (w < 3) {
+            // The hypotheses of chunk `lane`, chain w: the binades of the chain's estimated value at both ends of the
+            // level-kernel block the chunk lies in.  Estimated = the last EXACT value the level has published (a few
+            // tickets back) + the r8 sum of the blocks since: the r4 chain drifts away from the r8 sums (by 1e-4 at
+            // eORCA025, by per cents at eORCA12 where x is of the order of ulp(s)), but not over a handful of tickets.
+            const unsigned long long pub = __hip_atomic_load(&lev[k].word[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int sp = min(step, (int)(pub >> 32));
+            const float sv = __uint_as_float((uint32_t)pub);
+            const double *el = est + (int64_t)k * (a.nblk + 1) * 3 + w;
+            const int64_t ab = min((int64_t)a.nblk, (int64_t)sp * ticket_cells / block_cells);
+            for (int q = lane; q < nchunk; q += 64) {
+                const int64_t c0 = t0 + (int64_t)q * kScanChunk;
+                int k0 = -1, k1 = -1;
+                if (c0 < a.nij) {
+                    const int64_t cb = c0 / block_cells;
+                    const double d0 = (double)sv + (el[cb * 3] - el[ab * 3]), d1 = (double)sv + (el[(cb + 1) * 3] - el[ab * 3]);
+                    k0 = scan_key((float)d0); k1 = scan_key((float)d1);
+                    if (k0 < 0) { k0 = k1; k1 = -1; }
+                    if (k1 == k0) k1 = -1;
+                }
+                sm_key[0][q][w] = k0; sm_key[1][q][w] = k1;
+            }
+            if (lane == 0) pos_[w] = 0;
+        }
+        __syncthreads();
+
+        auto fetch = [&](Raw (&raw)[kScanNV], int64_t c0) {       // 512 cells from c0 on: lane l takes cells 4l..4l+3 of each 256
+#pragma unroll
+            for (int v = 0; v < kScanNV; ++v) {
+                Raw &x = raw[v];
+                const int64_t p = c0 + v * 256 + 4 * lane;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { x.ar[c] = x.e3[c] = x.tt[c] = x.mk[c] = x.mx[c] = 0.f; }
+                if (p + 3 < a.nij) {
+                    const f4u av = *reinterpret_cast<const f4u *>(a.area + p);
+                    x.ar[0] = av.x; x.ar[1] = av.y; x.ar[2] = av.z; x.ar[3] = av.w;
+                    const f4u tv = ld_stream4u(a.temp + base + p);
+                    x.tt[0] = tv.x; x.tt[1] = tv.y; x.tt[2] = tv.z; x.tt[3] = tv.w;
+                    if (!FULL) { const f4u ev = ld_stream4u(a.e3t + base + p); x.e3[0] = ev.x; x.e3[1] = ev.y; x.e3[2] = ev.z; x.e3[3] = ev.w; }
+                    if (MASK8) { const u4u m = __builtin_nontemporal_load(reinterpret_cast<const u4u *>(a.mask8 + base + p)); x.mk[0] = m.x; x.mk[1] = m.y; x.mk[2] = m.z; x.mk[3] = m.w; }
+                    else       { const f4u m = ld_stream4u(a.mask4 + base + p); x.mk[0] = m.x; x.mk[1] = m.y; x.mk[2] = m.z; x.mk[3] = m.w; }
+                    if (MXL) { const f4u mv = *reinterpret_cast<const f4u *>(a.mxl + p); x.mx[0] = mv.x; x.mx[1] = mv.y; x.mx[2] = mv.z; x.mx[3] = mv.w; }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (p + c < a.nij) {
+                            x.ar[c] = a.area[p + c];
+                            x.tt[c] = a.temp[base + p + c];
+                            if (!FULL) x.e3[c] = a.e3t[base + p + c];
+                            x.mk[c] = MASK8 ? (float)a.mask8[base + p + c] : a.mask4[base + p + c];
+                            if (MXL) x.mx[c] = a.mxl[p + c];
+                        }
+                }
+            }
+        };
+        // the three r4 products of every cell in `raw`, exactly as the reference forms them (:225-229); zeros past the end
+        auto products = [&](const Raw (&raw)[kScanNV], int64_t c0, float (&x)[3][kScanNV][4]) {
+            const bool whole = c0 + kScanChunk <= a.nij;          // (uniform) every cell of the chunk exists
+#pragma unroll
+            for (int v = 0; v < kScanNV; ++v) {
+                const int left = whole ? 4 : (int)max((int64_t)0, min((int64_t)4, a.nij - (c0 + v * 256 + 4 * lane)));
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const Raw &r = raw[v];
+                    float e = FULL ? e3k : r.e3[c];
+                    if (MXL) {
+                        if (a.mxlopt == 1) e = fmaxf(0.f, fminf(e, __fsub_rn(r.mx[c], dw)));                   // :220
+                        else               e = fminf(e, fmaxf(0.f, __fsub_rn(__fadd_rn(dw, e), r.mx[c])));     // :222
+                    }
+                    const float pv = __fmul_rn(r.ar[c], e);
+                    x[0][v][c] = __fmul_rn(r.ar[c], r.mk[c]);
+                    x[1][v][c] = __fmul_rn(pv, r.mk[c]);
+                    x[2][v][c] = __fmul_rn(__fmul_rn(pv, r.tt[c]), r.mk[c]);
+                    if (!whole && c >= left) x[0][v][c] = x[1][v][c] = x[2][v][c] = 0.f;
+                }
+            }
+        };
+        // sums of chunk q under the hypotheses of each chain
+        auto summarize = [&](const float (&x)[3][kScanNV][4], int q) {
+            uint32_t any = 0u;                                    // is there a cell with a term that is not 0?  (one answer for the three
+#pragma unroll                                                    // chains: "yes" for a chain of zeros only costs it the integer checks)
+            for (int v = 0; v < kScanNV; ++v)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) any |= __float_as_uint(x[0][v][c]) | __float_as_uint(x[1][v][c]) | __float_as_uint(x[2][v][c]);
+            const bool anz = __builtin_amdgcn_ballot_w64((any & 0x7fffffffu) != 0u) != 0;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                for (int h = 0; h < 2; ++h) {
+                    const int key = sm_key[h][q][ch];
+                    if (h == 1 && key < 0) break;                 // (uniform)
+                    int K = 0, pos = 0;
+                    uint32_t sgn = 0u, big = 0u;
+                    bool tie = false;
+                    if (key >= 0 && anz) {
+                        const float scale = scan_scale(key);
+#pragma unroll
+                        for (int v = 0; v < kScanNV; ++v)
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                const float qq = __fmul_rn(x[ch][v][c], scale);               // exact (a power of two), or Inf / NaN
+                                const float kf = rintf(qq);
+                                const int   ki = (int)kf;                                     // (saturating conversion; guarded by `big`)
+                                K += ki; pos += max(ki, 0);
+                                tie |= fabsf(__fsub_rn(qq, kf)) == 0.5f;                      // the difference is exact
+                                sgn |= __float_as_uint(qq);
+                                big = max(big, __float_as_uint(qq) & 0x7fffffffu);            // NaN > Inf > every finite |q|
+                            }
+                        K = wave_isum(K); pos = wave_isum(pos);
+                    }
+                    const bool bad = tie || big >= 0x49800000u;   // a tie; NaN, Inf, or |k| >= 2^20 (x not well below s; and the
+                                                                  // sums of 512 k's stay inside 32 bits)
+                    const bool abad = __builtin_amdgcn_ballot_w64(bad) != 0, ang = __builtin_amdgcn_ballot_w64((sgn >> 31) != 0u) != 0;
+                    if (lane == 0) {
+                        sm_K[h][q][ch] = K; sm_pos[h][q][ch] = pos;
+                        sm_flag[h][q][ch] = (anz ? 1 : 0) | ((abad || key < 0) ? 2 : 0) | (ang ? 4 : 0);
+                    }
+                }
+            }
+        };
+        {                                                         // every chunk of the ticket: the loads run one sub-block ahead
+            Raw raw[kScanNV];
+            float x[3][kScanNV][4];
+            fetch(raw, t0 + (int64_t)w * kScanChunk);
+#pragma clang loop unroll(disable)
+            for (int q = w; q < nchunk; q += kScanWaves) {
+                const int64_t c0 = t0 + (int64_t)q * kScanChunk;
+                if (c0 >= a.nij) {                                // past the end of the level: nothing there
+                    if (lane == 0) for (int ch = 0; ch < 3; ++ch) sm_flag[0][q][ch] = sm_flag[1][q][ch] = 0;
+                    continue;
+                }
+                products(raw, c0, x);
+                if (q + kScanWaves < nchunk && c0 + kScanSub < a.nij) fetch(raw, c0 + kScanSub);
+                summarize(x, q);
+            }
+        }
+        // the exact values of the chains where this ticket starts: published by the step before (tag == step)
+        if (threadIdx.x < 3) {
+            int spins = 0;
+            unsigned long long pub;
+            while ((int)((pub = __hip_atomic_load(&lev[k].word[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != step) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1 << 24)) { __hip_atomic_store(&ctl->error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+            st_s[threadIdx.x] = __uint_as_float((uint32_t)pub);
+        }
+        __syncthreads();
+        for (;;) {
+            // ---- wave ch walks the chunks of chain ch, one per lane
+            if (w < 3) {
+                const int ch = w, from = pos_[ch];
+                const float s = st_s[ch];
+                const int ks = scan_key(s);
+                int S0 = scan_mant(s), stop = -1, hstop = 0;
+                for (int g = from & ~63; g < nchunk && stop < 0; g += 64) {      // 64 chunks at a time, one per lane
+                    const int q = g + lane;
+                    const int f0 = sm_flag[0][q][ch];
+                    const bool live = q >= from && (f0 & 1);      // zeros: s + 0 = s in every state
+                    const int h = (ks >= 0 && ks == sm_key[0][q][ch]) ? 0 : (ks >= 0 && ks == sm_key[1][q][ch]) ? 1 : -1;
+                    const int hh = h < 0 ? 0 : h;
+                    const int f = sm_flag[hh][q][ch];
+                    const int K = (live && h >= 0) ? sm_K[hh][q][ch] : 0, pos = (live && h >= 0) ? sm_pos[hh][q][ch] : 0;
+                    const int incl = wave_iscan_incl(K, lane), Sb = S0 + incl - K;
+                    const bool stopq = live && (h < 0 || (f & 2) || Sb + pos > (1 << 24) - 1 || Sb + (K - pos) < (1 << 23) + ((f & 4) ? 1 : 0));
+                    const uint64_t m = __builtin_amdgcn_ballot_w64(stopq);
+                    const int sl = m ? (int)__builtin_ctzll(m) : 64;             // (uniform)
+                    S0 += sl == 0 ? 0 : __shfl(incl, sl - 1, 64);
+                    if (sl < 64) { stop = g + sl; hstop = __shfl(h, sl, 64); }
+                }
+                if (lane == 0) {
+                    if (ks >= 0) st_s[ch] = scan_value(ks, S0);
+                    fb[ch] = stop;
+                    pos_[ch] = stop < 0 ? nchunk : stop;
+                    if (stop >= 0 && ks >= 0 && hstop < 0) atomicAdd(&ctl->nunguessed, 1);
+                }
+            }
+            __syncthreads();
+            if (fb[0] < 0 && fb[1] < 0 && fb[2] < 0) break;
+            // ---- the chunk that stopped the walk: read again and resolved cell by cell, by wave ch for chain ch
+            if (w < 3 && fb[w] >= 0) {
+                const int ch = w, q = fb[ch];
+                const int64_t c0 = t0 + (int64_t)q * kScanChunk;
+                const int nvalid = (int)max((int64_t)0, min((int64_t)kScanChunk, a.nij - c0));
+                Raw raw[kScanNV];
+                float x3[3][kScanNV][4];
+                fetch(raw, c0);
+                products(raw, c0, x3);
+                float xv[kScanNV][4];
+#pragma unroll
+                for (int v = 0; v < kScanNV; ++v)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) xv[v][c] = ch == 0 ? x3[0][v][c] : ch == 1 ? x3[1][v][c] : x3[2][v][c];
+                if (lane == 0) atomicAdd(&ctl->nfallback, 1);
+                float s = st_s[ch];
+                int next = 0, rounds = 0;                         // cells [0, next) of the chunk are in s
+                while (next < nvalid && rounds < 6) {
+                    ++rounds;
+                    const int ks = scan_key(s);
+                    int first;                                    // the first cell >= next that cannot be added as an integer
+                    int incl[kScanNV][4];
+                    if (ks < 0) {
+                        // no binade (s = 0, ...): the next cell that is not 0 is added with v_add_f32
+                        int mine = kScanChunk;
+#pragma unroll
+                        for (int v = kScanNV - 1; v >= 0; --v)
+#pragma unroll
+                            for (int c = 3; c >= 0; --c) { const int id = v * 256 + 4 * lane + c; if (id >= next && xv[v][c] != 0.f) mine = id; }
+                        first = wave_imin(mine);
+                    } else {
+                        const float scale = scan_scale(ks);
+                        const int S0 = scan_mant(s);
+                        int run = 0, mine = kScanChunk;
+#pragma unroll
+                        for (int v = 0; v < kScanNV; ++v) {
+                            int kk[4], loc = 0;
+                            bool bad[4], ngq[4];
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                const int id = v * 256 + 4 * lane + c;
+                                const float qq = __fmul_rn(xv[v][c], scale), kf = rintf(qq);
+                                kk[c] = id >= next ? (int)kf : 0;
+                                bad[c] = id >= next && (fabsf(__fsub_rn(qq, kf)) == 0.5f || !(fabsf(qq) < 1048576.f));
+                                ngq[c] = qq < 0.f;
+                                if (bad[c]) kk[c] = 0;
+                                loc += kk[c];
+                            }
+                            const int lincl = wave_iscan_incl(loc, lane);
+                            int before = run + lincl - loc;       // sum of the k's of every cell before this lane's four, from `next` on
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                const int id = v * 256 + 4 * lane + c, after = S0 + before + kk[c];
+                                const bool ok = !bad[c] && after <= (1 << 24) - 1 && after >= (1 << 23) + (ngq[c] ? 1 : 0);
+                                if (id >= next && !ok && id < mine) mine = id;
+                                before += kk[c];
+                                incl[v][c] = before;
+                            }
+                            run += __shfl(lincl, 63, 64);
+                        }
+                        first = wave_imin(mine);
+                        // the cells [next, first) as integers: the prefix sum just before `first`
+                        const int upto = min(first, nvalid);
+                        if (upto > next) {
+                            const int id = upto - 1, v = id >> 8, l = (id & 255) >> 2, c = id & 3;
+                            int val = 0;
+#pragma unroll
+                            for (int vv = 0; vv < kScanNV; ++vv)
+#pragma unroll
+                                for (int cc = 0; cc < 4; ++cc) if (vv == v && cc == c) val = incl[vv][cc];
+                            s = scan_value(ks, S0 + __shfl(val, l, 64));
+                        }
+                    }
+                    if (first < nvalid) {                         // that one cell: a plain r4 add
+                        const int v = first >> 8, l = (first & 255) >> 2, c = first & 3;
+                        float val = 0.f;
+#pragma unroll
+                        for (int vv = 0; vv < kScanNV; ++vv)
+#pragma unroll
+                            for (int cc = 0; cc < 4; ++cc) if (vv == v && cc == c) val = xv[vv][cc];
+                        s = __fadd_rn(s, __shfl(val, l, 64));
+                        next = first + 1;
+                    } else {
+                        next = nvalid;
+                    }
+                }
+                if (next < nvalid) {                              // a chunk that keeps breaking (every cell a tie ...): the plain loop
+#pragma unroll
+                    for (int v = 0; v < kScanNV; ++v)
+                        *reinterpret_cast<f4a *>(&xs[ch][v * 256 + 4 * lane]) = f4a{xv[v][0], xv[v][1], xv[v][2], xv[v][3]};
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    if (lane == 0) {
+                        atomicAdd(&ctl->nslow, 1);
+                        const float *xp = xs[ch];
+                        int i = next;
+                        for (; i < nvalid && (i & 3); ++i) s = __fadd_rn(s, xp[i]);
+                        for (; i + 16 <= nvalid; i += 16) {       // 16 values on their way from LDS while 16 are added
+                            const f4a q0 = *reinterpret_cast<const f4a *>(xp + i),     q1 = *reinterpret_cast<const f4a *>(xp + i + 4),
+                                      q2 = *reinterpret_cast<const f4a *>(xp + i + 8), q3 = *reinterpret_cast<const f4a *>(xp + i + 12);
+                            s = __fadd_rn(s, q0.x); s = __fadd_rn(s, q0.y); s = __fadd_rn(s, q0.z); s = __fadd_rn(s, q0.w);
+                            s = __fadd_rn(s, q1.x); s = __fadd_rn(s, q1.y); s = __fadd_rn(s, q1.z); s = __fadd_rn(s, q1.w);
+                            s = __fadd_rn(s, q2.x); s = __fadd_rn(s, q2.y); s = __fadd_rn(s, q2.z); s = __fadd_rn(s, q2.w);
+                            s = __fadd_rn(s, q3.x); s = __fadd_rn(s, q3.y); s = __fadd_rn(s, q3.z); s = __fadd_rn(s, q3.w);
+                        }
+                        for (; i < nvalid; ++i) s = __fadd_rn(s, xp[i]);
+                    }
+                    s = __shfl(s, 0, 64);
+                    __builtin_amdgcn_wave_barrier();
+                }
+                if (lane == 0) { st_s[ch] = s; pos_[ch] = q + 1; }
+            }
+            __syncthreads();
+        }
+        // ---- publish: the values where the next step of this level starts (the barrier of the loop above ordered st_s)
+        if (threadIdx.x < 3) {
+            __hip_atomic_store(&lev[k].word[threadIdx.x], scan_word(step + 1, st_s[threadIdx.x]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (step == nsteps - 1) sums4[k * 3 + threadIdx.x] = st_s[threadIdx.x];
+        }
+        __syncthreads();                                          // (st_s is written again by the next ticket)
+    }
+}
+
+// the plain chain of v_add_f32 (CDFT_HEATC_SEQ=chain: what heatc_scan_kernel is checked against)
+int launch_seq_chain(const HeatcArgs &a, const float *carry, float *sums4, hipStream_t st) {
     const bool m8 = a.mask8 != nullptr, full = a.e31d != nullptr;
+    dim3 grid(a.npk), block(64);
     if (m8 && full)        hipLaunchKernelGGL((heatc_seq_kernel<true, true>), grid, block, 0, st, a, carry, sums4);
     else if (m8 && !full)  hipLaunchKernelGGL((heatc_seq_kernel<true, false>), grid, block, 0, st, a, carry, sums4);
     else if (!m8 && full)  hipLaunchKernelGGL((heatc_seq_kernel<false, true>), grid, block, 0, st, a, carry, sums4);
     else                   hipLaunchKernelGGL((heatc_seq_kernel<false, false>), grid, block, 0, st, a, carry, sums4);
+    CDFT_LAUNCH_CHECK();
+    return CDFT_OK;
+}
+
+// a.partial holds the r8 sums of the level kernel over blocks of `block_cells` cells (a multiple of a chunk, a divisor of a ticket)
+int launch_seq_scan(const HeatcArgs &a, int block_cells, const float *carry, float *sums4, DevBuf &work, hipStream_t st) {
+    const bool m8 = a.mask8 != nullptr, full = a.e31d != nullptr;
+    // about 32 tickets per level: enough of them in flight for every CU, few enough steps in a level's chain of waits
+    int nchunk = 64;
+    while (nchunk < kScanMaxChunks && a.nij > (int64_t)nchunk * kScanChunk * 32) nchunk *= 2;
+    const int64_t ticket_cells = (int64_t)nchunk * kScanChunk;
+    const int nsteps = (int)((a.nij + ticket_cells - 1) / ticket_cells);
+    const size_t head = (sizeof(ScanLevel) * (size_t)a.npk + sizeof(ScanCtl) + 15) / 16 * 16;
+    CDFT_TRY(work.reserve(head + sizeof(double) * (size_t)a.npk * (a.nblk + 1) * 3));
+    ScanLevel *lev = (ScanLevel *)work.ptr;
+    ScanCtl *ctl = (ScanCtl *)(lev + a.npk);
+    double *est = (double *)((char *)work.ptr + head);
+    hipLaunchKernelGGL(heatc_scan_est_kernel, dim3(a.npk), dim3(64), 0, st, a.partial, a.nblk, carry, est, lev, ctl);
+    int dev = 0, ncu = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    const int64_t tickets = (int64_t)nsteps * a.npk;
+    dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>(tickets, 3 * (int64_t)ncu))), block(64 * kScanWaves);
+#define CDFT_SCAN_LAUNCH(M8, FU, MX) hipLaunchKernelGGL((heatc_scan_kernel<M8, FU, MX>), grid, block, 0, st, a, lev, ctl, est, block_cells, nchunk, nsteps, sums4)
+    const bool mx = a.mxlopt != 0;
+    if (m8 && full)        { if (mx) CDFT_SCAN_LAUNCH(true, true, true);   else CDFT_SCAN_LAUNCH(true, true, false); }
+    else if (m8 && !full)  { if (mx) CDFT_SCAN_LAUNCH(true, false, true);  else CDFT_SCAN_LAUNCH(true, false, false); }
+    else if (!m8 && full)  { if (mx) CDFT_SCAN_LAUNCH(false, true, true);  else CDFT_SCAN_LAUNCH(false, true, false); }
+    else                   { if (mx) CDFT_SCAN_LAUNCH(false, false, true); else CDFT_SCAN_LAUNCH(false, false, false); }
+#undef CDFT_SCAN_LAUNCH
     CDFT_LAUNCH_CHECK();
     return CDFT_OK;
 }
@@ -480,8 +925,22 @@ int cdft_heatc_compute(cdft_heatc_plan *p, const float *temp, int temp_space, co
     a.area = p->area; a.e3t = p->e3t; a.e31d = p->e31d; a.temp = (const float *)dt; a.mxl = (const float *)dm;
     a.gdepw = p->gdepw; a.mask8 = p->mask8; a.mask4 = p->mask4; a.nij = nij; a.npk = p->npk;
     a.mxlopt = mxloption; a.partial = p->partial;
-    if (p->sum_mode == CDFT_HEATC_SUM_R4SEQ) {
-        // the reference's sequential r4 sums, bit for bit (heatc_seq_kernel); the r4 results are widened exactly
+    const char *seq_env = getenv("CDFT_HEATC_SEQ");
+    const bool r4seq = p->sum_mode == CDFT_HEATC_SUM_R4SEQ, chain = r4seq && seq_env && !strcmp(seq_env, "chain");
+    int vec = 1;
+    if (nij % 4 == 0 && aligned_to(dt, 16) && aligned_to(dm, 16)) vec = 4;
+    else if (nij >= 4 && !getenv("CDFT_HEATC_NOU4")) vec = -4;           // 16-byte loads at r4 alignment (A/B hook: the old paths)
+    else if (nij % 2 == 0 && aligned_to(dt, 8) && aligned_to(dm, 8)) vec = 2;
+    a.nblk = vec == -4 ? (int)(((nij + 3) / 4 + 1 + kThreads * 4 - 1) / (kThreads * 4))
+                       : (int)((nij / vec + kThreads * 4 - 1) / (kThreads * 4));   // kVPT = 4 vectors per lane
+    if (!chain) {                                         // the r8 sums per block: the result (r8 mode), or the estimates of the r4 chains
+        if (vec == -4)     CDFT_TRY(launch_u4(a, st));
+        else if (vec == 4) CDFT_TRY(launch_vec<4>(a, st));
+        else if (vec == 2) CDFT_TRY(launch_vec<2>(a, st));
+        else               CDFT_TRY(launch_vec<1>(a, st));
+    }
+    if (r4seq) {
+        // the reference's sequential r4 sums, bit for bit (heatc_scan_kernel / heatc_seq_kernel); the r4 results are widened exactly
         const size_t n = (size_t)p->npk * 3;
         CDFT_TRY(p->st_s4.reserve(n * sizeof(float)));
         const float *dcarry = nullptr;
@@ -490,10 +949,19 @@ int cdft_heatc_compute(cdft_heatc_plan *p, const float *temp, int temp_space, co
             CDFT_HIP(hipMemcpyAsync(p->st_c4.ptr, p->carry.data(), n * sizeof(float), hipMemcpyHostToDevice, st));
             dcarry = (const float *)p->st_c4.ptr;
         }
-        CDFT_TRY(launch_seq(a, dcarry, (float *)p->st_s4.ptr, st));
+        if (chain) CDFT_TRY(launch_seq_chain(a, dcarry, (float *)p->st_s4.ptr, st));
+        else       CDFT_TRY(launch_seq_scan(a, kThreads * 4 * (vec < 0 ? -vec : vec), dcarry, (float *)p->st_s4.ptr, p->st_scan, st));
         p->last4.resize(n);
         CDFT_HIP(hipMemcpyAsync(p->last4.data(), p->st_s4.ptr, n * sizeof(float), hipMemcpyDeviceToHost, st));
+        ScanCtl ctl = {};
+        if (!chain)
+            CDFT_HIP(hipMemcpyAsync(&ctl, (char *)p->st_scan.ptr + sizeof(ScanLevel) * (size_t)p->npk, sizeof(ctl), hipMemcpyDeviceToHost, st));
         CDFT_HIP(hipStreamSynchronize(st));
+        if (!chain && getenv("CDFT_HEATC_SCAN_STATS"))
+            fprintf(stderr, "heatc_scan_kernel: %d tickets, %d chunks resolved cell by cell (%d of them finished by the sequential loop), "
+                    "%d times in a binade neither estimate named\n", ctl.ticket, ctl.nfallback, ctl.nslow, ctl.nunguessed);
+        if (ctl.error)
+            return fail(CDFT_ERR_HIP, "cdfheatc: a workgroup of heatc_scan_kernel waited over a second for the step before it (results discarded)");
         p->carry.clear();
         std::vector<double> s8(n);
         for (size_t i = 0; i < n; ++i) s8[i] = (double)p->last4[i];
@@ -505,16 +973,6 @@ int cdft_heatc_compute(cdft_heatc_plan *p, const float *temp, int temp_space, co
         }
         return CDFT_OK;
     }
-    int vec = 1;
-    if (nij % 4 == 0 && aligned_to(dt, 16) && aligned_to(dm, 16)) vec = 4;
-    else if (nij >= 4 && !getenv("CDFT_HEATC_NOU4")) vec = -4;           // 16-byte loads at r4 alignment (A/B hook: the old paths)
-    else if (nij % 2 == 0 && aligned_to(dt, 8) && aligned_to(dm, 8)) vec = 2;
-    a.nblk = vec == -4 ? (int)(((nij + 3) / 4 + 1 + kThreads * 4 - 1) / (kThreads * 4))
-                       : (int)((nij / vec + kThreads * 4 - 1) / (kThreads * 4));   // kVPT = 4 vectors per lane
-    if (vec == -4)     CDFT_TRY(launch_u4(a, st));
-    else if (vec == 4) CDFT_TRY(launch_vec<4>(a, st));
-    else if (vec == 2) CDFT_TRY(launch_vec<2>(a, st));
-    else               CDFT_TRY(launch_vec<1>(a, st));
     hipLaunchKernelGGL(heatc_final_kernel, dim3(p->npk), dim3(kThreads), 0, st, p->partial, p->npk, a.nblk, dout);
     CDFT_LAUNCH_CHECK();
     if (out_space == CDFT_MEM_HOST) {
@@ -557,7 +1015,7 @@ int cdft_heatc_destroy(cdft_heatc_plan *p) {
     for (void *q : ptrs) if (q) (void)hipFree(q);
     if (p->hsums) (void)hipHostFree(p->hsums);
     p->st_a.release(); p->st_b.release(); p->st_temp.release(); p->st_mxl.release(); p->st_out.release();
-    p->st_c4.release(); p->st_s4.release();
+    p->st_c4.release(); p->st_s4.release(); p->st_scan.release();
     delete p;
     return CDFT_OK;
 }

@@ -12,6 +12,8 @@ import pytest
 import oracle_tools
 import synth
 
+f32 = np.float32
+
 
 def fields(npi, npj, npk, seed):
     g = synth.make_grid(npi, npj, npk, seed=seed)
@@ -113,6 +115,111 @@ def test_hip_reference_order_sums_at_eorca025_size(gpu):
     sh.set_mesh(g["e1t"], g["e2t"], g["tmask"].astype(np.uint8), e3t=g["e3t_0"])
     sh.set_sum_mode(True)
     assert np.array_equal(sh.compute(t), ref)
+
+
+def both_kernels(gpu, plan, temp, monkeypatch, **kw):
+    """The level-parallel integer kernel (default) and the plain chain of v_add_f32 (CDFT_HEATC_SEQ=chain), as bits."""
+    monkeypatch.delenv("CDFT_HEATC_SEQ", raising=False)
+    a = plan.compute(temp, **kw)
+    monkeypatch.setenv("CDFT_HEATC_SEQ", "chain")
+    b = plan.compute(temp, **kw)
+    monkeypatch.delenv("CDFT_HEATC_SEQ")
+    return a.view(np.uint64), b.view(np.uint64)
+
+
+ADVERSARIAL = ["ones", "powers_of_two", "sign_changes", "mostly_land", "huge_range", "nonfinite", "tiny_sum", "negative_mask", "constant_rows"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ADVERSARIAL)
+def test_hip_reference_order_kernels_agree_on_adversarial_fields(gpu, case, monkeypatch):
+    """heatc_scan_kernel replaces a chain of sequential r4 adds by integer sums inside a binade; everything that can break
+    that -- ties on every cell, sums that cross powers of two or zero over and over, a sum smaller than its terms, Inf and
+    NaN, negative weights, long stretches of land -- must come out bit-identical to the plain chain and to the oracle."""
+    rng = np.random.default_rng(len(case))
+    npi, npj, npk = 1442, 211, 3
+    shape = (npk, npj, npi)
+    e1t = (2000 + 26000 * rng.random((npj, npi))).astype(f32)
+    e2t = (2000 + 26000 * rng.random((npj, npi))).astype(f32)
+    e3t = (1 + 199 * rng.random(shape)).astype(f32)
+    mask = (rng.random(shape) > 0.35).astype(f32)
+    temp = (-2 + 32 * rng.random(shape)).astype(f32)
+    if case == "ones":                                   # s counts 1, 2, 3, ...: a tie on every cell once s >= 2^24 would need 16.7e6 cells;
+        e1t[:], e2t[:], e3t[:], mask[:], temp[:] = 1, 1, 1, 1, 1      # here: every chunk boundary is a power of two early on
+    elif case == "powers_of_two":                        # x = 2^k: x / ulp(s) is a half-integer again and again
+        e1t[:] = 2.0 ** rng.integers(0, 4, (npj, npi)); e2t[:] = 1
+        e3t[:] = 2.0 ** rng.integers(-3, 3, shape); temp[:] = 2.0 ** rng.integers(-2, 3, shape) * rng.choice([-1, 1], shape)
+    elif case == "sign_changes":                         # the heat sum hovers around zero
+        temp[:] = rng.normal(0, 1, shape)
+    elif case == "mostly_land":
+        mask[:] = rng.random(shape) > 0.97
+        mask[:, : npj // 2] = 0                          # and the first half of every level is land: s = 0 for 150 000 cells
+    elif case == "huge_range":
+        temp[:] *= 10.0 ** rng.integers(-20, 20, shape)
+        e3t[:] *= 10.0 ** rng.integers(-3, 3, shape)
+    elif case == "nonfinite":
+        temp[0, 100, 7] = np.inf; temp[1, 50, 700] = np.nan; temp[2, 200, 1000] = -np.inf; temp[2, 205, 3] = 3e38
+    elif case == "tiny_sum":
+        e1t[:] = 1e-18; e2t[:] = 1e-18; e3t[:] = 1e-6    # surfaces of 1e-36: denormal sums
+    elif case == "negative_mask":                        # -M with an arbitrary r4 mask: the "surface" chain sees negative terms
+        mask[:] = rng.normal(0, 1, shape)
+    elif case == "constant_rows":                        # a regular grid: e1t constant along i, the same x thousands of times
+        e1t[:] = (1000 * (1 + np.arange(npj)))[:, None]; e2t[:] = 2500; e3t[:] = 10; temp[:] = 4
+    plan = gpu.HeatcPlan(npi, npj, npk)
+    m = mask if case == "negative_mask" else mask.astype(np.uint8)
+    plan.set_mesh(e1t, e2t, m, e3t=e3t)
+    plan.set_sum_mode(True)
+    a, b = both_kernels(gpu, plan, temp, monkeypatch)
+    assert np.array_equal(a, b), case
+    with np.errstate(all="ignore"):
+        ref = oracle_tools.heatc(e1t, e2t, mask, temp, e3t=e3t, r4sum=True)
+    assert np.array_equal(a, ref.view(np.uint64)), case
+    # chained row blocks: the chains start from a carry in the middle of a binade
+    sh = gpu.HeatcPlan(npi, npj, npk, devices=[0, 0, 0])
+    sh.set_mesh(e1t, e2t, m, e3t=e3t)
+    sh.set_sum_mode(True)
+    assert np.array_equal(sh.compute(temp).view(np.uint64), a), case
+
+
+@pytest.mark.gpu
+def test_hip_reference_order_sum_saturates_like_the_chain(gpu, monkeypatch):
+    """One level of 4322 x 3900 ones: the r4 count stops at 2^24 = 16 777 216 of 16 855 800 cells (s + 1 is a tie that goes
+    back to the even s, on every cell from there on) -- in both kernels."""
+    npi, npj, npk = 4322, 3900, 1
+    one = np.ones((npj, npi), f32)
+    plan = gpu.HeatcPlan(npi, npj, npk)
+    plan.set_mesh(one, one, np.ones((npk, npj, npi), np.uint8), e3t=np.ones((npk, npj, npi), f32))
+    plan.set_sum_mode(True)
+    a, b = both_kernels(gpu, plan, np.ones((npk, npj, npi), f32), monkeypatch)
+    assert np.array_equal(a, b) and np.all(a.view(np.float64) == 16777216.0)
+
+
+@pytest.mark.gpu
+def test_hip_reference_order_kernels_agree_on_eorca12_levels(gpu, monkeypatch):
+    """Two levels of 4322 x 3606 = 15.6e6 cells: 119 tickets of 131072 cells per level, sums that reach 2e15 where a term is of
+    the order of ulp(s) (the r4 chain then runs per cents away from the r8 sums the hypotheses start from): both kernels and
+    the oracle, bit for bit; and with the chains carried over three row blocks."""
+    rng = np.random.default_rng(12)
+    npi, npj, npk = 4322, 3606, 2
+    shape = (npk, npj, npi)
+    e1t = (2000 + 26000 * rng.random((npj, npi), dtype=f32)).astype(f32)
+    e2t = (2000 + 26000 * rng.random((npj, npi), dtype=f32)).astype(f32)
+    e3t = (1 + 199 * rng.random(shape, dtype=f32)).astype(f32)
+    mask = (rng.random(shape, dtype=f32) > 0.35).astype(np.uint8)
+    temp = (-2 + 32 * rng.random(shape, dtype=f32)).astype(f32)
+    plan = gpu.HeatcPlan(npi, npj, npk)
+    plan.set_mesh(e1t, e2t, mask, e3t=e3t)
+    r8 = plan.compute(temp)
+    plan.set_sum_mode(True)
+    a, b = both_kernels(gpu, plan, temp, monkeypatch)
+    assert np.array_equal(a, b)
+    ref = oracle_tools.heatc(e1t, e2t, mask, temp, e3t=e3t, r4sum=True)
+    assert np.array_equal(a, ref.view(np.uint64))
+    assert (np.abs(ref - r8) / np.abs(r8)).max() > 1e-3            # the reference's own r4 SUM is this far from the sum here
+    sh = gpu.HeatcPlan(npi, npj, npk, devices=[0, 0, 0])
+    sh.set_mesh(e1t, e2t, mask, e3t=e3t)
+    sh.set_sum_mode(True)
+    assert np.array_equal(sh.compute(temp).view(np.uint64), a)
 
 
 def abs_terms(g, temp, e3t=None, e31d=None, **kw):
