@@ -363,10 +363,16 @@ __global__ void __launch_bounds__(64) heatc_seq_kernel(HeatcArgs a, const float 
 constexpr int kScanWaves = 4, kScanNV = 2, kScanChunk = kScanNV * 256, kScanSub = kScanWaves * kScanChunk;
 constexpr int kScanMaxChunks = 256;                               // chunks per ticket: 64, 128 or 256 (32768 .. 131072 cells)
 
+// the sum over the 64 lanes, in every lane: six DPP adds in the vector pipeline (quad swaps, half-row and row mirrors give
+// every lane its row of 16; row_bcast:15 and :31 carry the rows forward to lane 63), not six ds_bpermute round trips
 __device__ __forceinline__ int wave_isum(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += __builtin_amdgcn_update_dpp(0, v, 0xb1, 0xf, 0xf, true);      // quad_perm:[1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4e, 0xf, 0xf, true);      // quad_perm:[2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true);     // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true);     // row_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);     // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);     // row_bcast:31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(v, 63);
 }
 __device__ __forceinline__ int wave_imin(int v) {
 #pragma unroll
@@ -426,8 +432,7 @@ __global__ void __launch_bounds__(64 * kScanWaves, 3) heatc_scan_kernel(HeatcArg
                                                                      const double *__restrict__ est, int block_cells, int nchunk, int nsteps,
                                                                      float *__restrict__ sums4) {
     __shared__ int sm_K[2][kScanMaxChunks][3], sm_pos[2][kScanMaxChunks][3], sm_flag[2][kScanMaxChunks][3], sm_key[2][kScanMaxChunks][3];
-    __shared__ float st_s[3];
-    __shared__ int pos_[3], fb[3], tick;
+    __shared__ int tick;
     __shared__ __attribute__((aligned(16))) float xs[3][kScanChunk];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t ticket_cells = (int64_t)nchunk * kScanChunk;
@@ -464,7 +469,6 @@ __global__ void __launch_bounds__(64 * kScanWaves, 3) heatc_scan_kernel(HeatcArg
                 }
                 sm_key[0][q][w] = k0; sm_key[1][q][w] = k1;
             }
-            if (lane == 0) pos_[w] = 0;
         }
         __syncthreads();
 
@@ -534,7 +538,7 @@ __global__ void __launch_bounds__(64 * kScanWaves, 3) heatc_scan_kernel(HeatcArg
                     if (h == 1 && key < 0) break;                 // (uniform)
                     int K = 0, pos = 0;
                     uint32_t sgn = 0u, big = 0u;
-                    bool tie = false;
+                    float far = 0.f;                              // the largest |q - rint(q)|: 0.5 exactly = a tie
                     if (key >= 0 && anz) {
                         const float scale = scan_scale(key);
 #pragma unroll
@@ -545,14 +549,14 @@ __global__ void __launch_bounds__(64 * kScanWaves, 3) heatc_scan_kernel(HeatcArg
                                 const float kf = rintf(qq);
                                 const int   ki = (int)kf;                                     // (saturating conversion; guarded by `big`)
                                 K += ki; pos += max(ki, 0);
-                                tie |= fabsf(__fsub_rn(qq, kf)) == 0.5f;                      // the difference is exact
+                                far = fmaxf(far, fabsf(__fsub_rn(qq, kf)));                   // the difference is exact
                                 sgn |= __float_as_uint(qq);
                                 big = max(big, __float_as_uint(qq) & 0x7fffffffu);            // NaN > Inf > every finite |q|
                             }
                         K = wave_isum(K); pos = wave_isum(pos);
                     }
-                    const bool bad = tie || big >= 0x49800000u;   // a tie; NaN, Inf, or |k| >= 2^20 (x not well below s; and the
-                                                                  // sums of 512 k's stay inside 32 bits)
+                    const bool bad = far == 0.5f || big >= 0x49800000u;   // a tie; NaN, Inf, or |k| >= 2^20 (x not well below s; and
+                                                                          // the sums of 512 k's stay inside 32 bits)
                     const bool abad = __builtin_amdgcn_ballot_w64(bad) != 0, ang = __builtin_amdgcn_ballot_w64((sgn >> 31) != 0u) != 0;
                     if (lane == 0) {
                         sm_K[h][q][ch] = K; sm_pos[h][q][ch] = pos;
@@ -577,25 +581,26 @@ __global__ void __launch_bounds__(64 * kScanWaves, 3) heatc_scan_kernel(HeatcArg
                 summarize(x, q);
             }
         }
-        // the exact values of the chains where this ticket starts: published by the step before (tag == step)
-        if (threadIdx.x < 3) {
-            int spins = 0;
-            unsigned long long pub;
-            while ((int)((pub = __hip_atomic_load(&lev[k].word[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != step) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1 << 24)) { __hip_atomic_store(&ctl->error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        __syncthreads();                                          // the sums of every chunk are in LDS
+        // ---- wave ch takes chain ch through the ticket on its own: no workgroup barrier, no other chain waited for
+        if (w < 3) {
+            const int ch = w;
+            // the exact value where this ticket starts: published by the step before (tag == step)
+            unsigned long long pub = 0;
+            if (lane == 0) {
+                int spins = 0;
+                while ((int)((pub = __hip_atomic_load(&lev[k].word[ch], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != step) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1 << 24)) { __hip_atomic_store(&ctl->error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                }
             }
-            st_s[threadIdx.x] = __uint_as_float((uint32_t)pub);
-        }
-        __syncthreads();
-        for (;;) {
-            // ---- wave ch walks the chunks of chain ch, one per lane
-            if (w < 3) {
-                const int ch = w, from = pos_[ch];
-                const float s = st_s[ch];
+            float s = __uint_as_float((uint32_t)__shfl((int)(uint32_t)pub, 0, 64));
+            int from = 0;
+            for (;;) {
+                // the chunks in order, 64 at a time, one per lane
                 const int ks = scan_key(s);
                 int S0 = scan_mant(s), stop = -1, hstop = 0;
-                for (int g = from & ~63; g < nchunk && stop < 0; g += 64) {      // 64 chunks at a time, one per lane
+                for (int g = from & ~63; g < nchunk && stop < 0; g += 64) {
                     const int q = g + lane;
                     const int f0 = sm_flag[0][q][ch];
                     const bool live = q >= from && (f0 & 1);      // zeros: s + 0 = s in every state
@@ -610,18 +615,11 @@ __global__ void __launch_bounds__(64 * kScanWaves, 3) heatc_scan_kernel(HeatcArg
                     S0 += sl == 0 ? 0 : __shfl(incl, sl - 1, 64);
                     if (sl < 64) { stop = g + sl; hstop = __shfl(h, sl, 64); }
                 }
-                if (lane == 0) {
-                    if (ks >= 0) st_s[ch] = scan_value(ks, S0);
-                    fb[ch] = stop;
-                    pos_[ch] = stop < 0 ? nchunk : stop;
-                    if (stop >= 0 && ks >= 0 && hstop < 0) atomicAdd(&ctl->nunguessed, 1);
-                }
-            }
-            __syncthreads();
-            if (fb[0] < 0 && fb[1] < 0 && fb[2] < 0) break;
-            // ---- the chunk that stopped the walk: read again and resolved cell by cell, by wave ch for chain ch
-            if (w < 3 && fb[w] >= 0) {
-                const int ch = w, q = fb[ch];
+                if (ks >= 0) s = scan_value(ks, S0);
+                if (stop < 0) break;
+                if (lane == 0 && ks >= 0 && hstop < 0) atomicAdd(&ctl->nunguessed, 1);
+                // the chunk that stopped the walk: read again and resolved cell by cell
+                const int q = stop;
                 const int64_t c0 = t0 + (int64_t)q * kScanChunk;
                 const int nvalid = (int)max((int64_t)0, min((int64_t)kScanChunk, a.nij - c0));
                 Raw raw[kScanNV];
@@ -634,7 +632,6 @@ __global__ void __launch_bounds__(64 * kScanWaves, 3) heatc_scan_kernel(HeatcArg
 #pragma unroll
                     for (int c = 0; c < 4; ++c) xv[v][c] = ch == 0 ? x3[0][v][c] : ch == 1 ? x3[1][v][c] : x3[2][v][c];
                 if (lane == 0) atomicAdd(&ctl->nfallback, 1);
-                float s = st_s[ch];
                 int next = 0, rounds = 0;                         // cells [0, next) of the chunk are in s
                 while (next < nvalid && rounds < 6) {
                     ++rounds;
@@ -730,16 +727,15 @@ __global__ void __launch_bounds__(64 * kScanWaves, 3) heatc_scan_kernel(HeatcArg
                     s = __shfl(s, 0, 64);
                     __builtin_amdgcn_wave_barrier();
                 }
-                if (lane == 0) { st_s[ch] = s; pos_[ch] = q + 1; }
+                from = q + 1;
             }
-            __syncthreads();
+            // publish: the value where the next step of this level starts
+            if (lane == 0) {
+                __hip_atomic_store(&lev[k].word[ch], scan_word(step + 1, s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (step == nsteps - 1) sums4[k * 3 + ch] = s;
+            }
         }
-        // ---- publish: the values where the next step of this level starts (the barrier of the loop above ordered st_s)
-        if (threadIdx.x < 3) {
-            __hip_atomic_store(&lev[k].word[threadIdx.x], scan_word(step + 1, st_s[threadIdx.x]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (step == nsteps - 1) sums4[k * 3 + threadIdx.x] = st_s[threadIdx.x];
-        }
-        __syncthreads();                                          // (st_s is written again by the next ticket)
+        __syncthreads();                                          // (the LDS arrays are written again by the next ticket)
     }
 }
 
@@ -761,6 +757,7 @@ int launch_seq_scan(const HeatcArgs &a, int block_cells, const float *carry, flo
     // about 32 tickets per level: enough of them in flight for every CU, few enough steps in a level's chain of waits
     int nchunk = 64;
     while (nchunk < kScanMaxChunks && a.nij > (int64_t)nchunk * kScanChunk * 32) nchunk *= 2;
+    if (const char *e = getenv("CDFT_HEATC_SCAN_CHUNKS")) { const int v = atoi(e); if (v == 64 || v == 128 || v == 256) nchunk = v; }   // (tuning hook)
     const int64_t ticket_cells = (int64_t)nchunk * kScanChunk;
     const int nsteps = (int)((a.nij + ticket_cells - 1) / ticket_cells);
     const size_t head = (sizeof(ScanLevel) * (size_t)a.npk + sizeof(ScanCtl) + 15) / 16 * 16;
