@@ -252,10 +252,13 @@ int cdft_heatc_compute(cdft_heatc_plan *plan, const float *temp, int temp_space,
  *   CDFT_HEATC_SUM_R8     (default) r4 products as written, r8 sums in a fixed parallel order: the accurate value,
  *                         at the HBM roofline; 1e-13 from a sequential r8 sum.
  *   CDFT_HEATC_SUM_R4SEQ  the reference's own arithmetic: its SUM is REAL(KIND=4) (:225-229), compiled by gfortran -O /
- *                         flang -O1 into one sequential r4 loop in memory order.  Reproduced bit for bit (one wave per
- *                         level adds the products in order; milliseconds instead of a fraction of one), so that the
- *                         drop-in program returns what a reference build returns (9e-5 from the r8 value at eORCA025).
- *                         The r4 results are widened exactly into `sums`.  Sharded plans chain the blocks in order. */
+ *                         flang -O1 into one sequential r4 loop in memory order.  Reproduced bit for bit, so that the
+ *                         drop-in program returns what a reference build returns (9e-5 from the r8 value at eORCA025,
+ *                         per cents at eORCA12): inside a binade of the running sum the chain is an integer sum, formed
+ *                         in parallel; crossings of a power of two and ties are resolved cell by cell (heatc_scan_kernel,
+ *                         2.7-4 times the r8 mode's time; CDFT_HEATC_SEQ=chain in the environment selects the plain chain
+ *                         of v_add_f32 it is checked against, 14-23 times slower).  The r4 results are widened exactly
+ *                         into `sums`.  Sharded plans chain the blocks in order. */
 #define CDFT_HEATC_SUM_R8     0
 #define CDFT_HEATC_SUM_R4SEQ  1
 int cdft_heatc_set_sum_mode(cdft_heatc_plan *plan, int mode);
