@@ -31,7 +31,7 @@ struct cdft_mean_plan {
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kVPT     = 2;     // vectors per lane
+constexpr int kVPT     = 2;     // vectors per lane (4: slower at both grids, measured)
 constexpr int kMaxNB   = 8;
 
 struct MeanArgs {
@@ -54,9 +54,12 @@ __global__ void mean_mask8_kernel(const float *__restrict__ m, int64_t n, uint8_
     else { m8[p] = 0; if (!(v == 0.f) || signbit(v)) flag[0] = 1; }
 }
 
-template <int VEC, bool FULL, int NB>
+// PARK: the wave sums of every level stay in LDS [wave][level][nb*4] and the four waves are combined once, after the
+// last level -- no workgroup barrier inside the level loop (the layout of cdfheatc's level kernel).  Without it (when
+// npk * nb * 4 sums per wave do not fit): two barriers per level.
+template <int VEC, bool FULL, int NB, bool PARK>
 __global__ void __launch_bounds__(kThreads) mean_level_kernel(MeanArgs a) {
-    extern __shared__ double wsum[];                   // [nwaves][nb*4]
+    extern __shared__ double wsum[];                   // PARK: [nwaves][npk][nb*4], else [nwaves][nb*4]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = kThreads / 64;
     int64_t q[kVPT];
     float e1[kVPT][VEC], e2[kVPT][VEC], fb[kVPT][VEC][NB];
@@ -147,15 +150,27 @@ __global__ void __launch_bounds__(kThreads) mean_level_kernel(MeanArgs a) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const double t = wave_sum(s[b][c]);
-                if (lane == 0 && b < a.nb) wsum[(wave * a.nb + b) * 4 + c] = t;
+                if (lane == 0 && b < a.nb) wsum[((PARK ? wave * a.npk + k : wave) * a.nb + b) * 4 + c] = t;
             }
-        __syncthreads();
-        if ((int)threadIdx.x < a.nb * 4) {
-            double t = 0.0;
-            for (int w = 0; w < nwaves; ++w) t += wsum[w * a.nb * 4 + threadIdx.x];
-            a.partial[((int64_t)k * a.nblk + blockIdx.x) * a.nb * 4 + threadIdx.x] = t;
+        if (!PARK) {
+            __syncthreads();
+            if ((int)threadIdx.x < a.nb * 4) {
+                double t = 0.0;
+                for (int w = 0; w < nwaves; ++w) t += wsum[w * a.nb * 4 + threadIdx.x];
+                a.partial[((int64_t)k * a.nblk + blockIdx.x) * a.nb * 4 + threadIdx.x] = t;
+            }
+            __syncthreads();
         }
+    }
+    if (PARK) {
         __syncthreads();
+        const int nq = a.nb * 4;
+        for (int t = threadIdx.x; t < a.npk * nq; t += kThreads) {
+            double sum = 0.0;
+            for (int w = 0; w < nwaves; ++w) sum += wsum[(int64_t)w * a.npk * nq + t];     // waves in order, as above
+            const int k = t / nq, qq = t - k * nq;
+            a.partial[((int64_t)k * a.nblk + blockIdx.x) * nq + qq] = sum;
+        }
     }
 }
 
@@ -271,17 +286,21 @@ int cdft_mean_compute(cdft_mean_plan *p, const float *zv, int in_space, double *
     const int vec = vec4 ? 4 : 1;
     a.nblk = (int)(((nij + vec - 1) / vec + kThreads * kVPT - 1) / (kThreads * kVPT));
     const dim3 grid(a.nblk), block(kThreads);
-    const size_t shmem = (size_t)(kThreads / 64) * nq * sizeof(double);
+    const size_t park_bytes = (size_t)(kThreads / 64) * p->npk * nq * sizeof(double);
+    const bool park = park_bytes <= 48 * 1024 && !getenv("CDFT_MEAN_NOPARK");     // (A/B hook: a barrier pair per level)
+    const size_t shmem = park ? park_bytes : (size_t)(kThreads / 64) * nq * sizeof(double);
     const bool full = p->e31d != nullptr;
-#define CDFT_MEAN(NBC) do { \
-        if (vec4 && full)       hipLaunchKernelGGL((mean_level_kernel<4, true, NBC>), grid, block, shmem, st, a); \
-        else if (vec4)          hipLaunchKernelGGL((mean_level_kernel<4, false, NBC>), grid, block, shmem, st, a); \
-        else if (full)          hipLaunchKernelGGL((mean_level_kernel<1, true, NBC>), grid, block, shmem, st, a); \
-        else                    hipLaunchKernelGGL((mean_level_kernel<1, false, NBC>), grid, block, shmem, st, a); } while (0)
+#define CDFT_MEAN2(NBC, PK) do { \
+        if (vec4 && full)       hipLaunchKernelGGL((mean_level_kernel<4, true, NBC, PK>), grid, block, shmem, st, a); \
+        else if (vec4)          hipLaunchKernelGGL((mean_level_kernel<4, false, NBC, PK>), grid, block, shmem, st, a); \
+        else if (full)          hipLaunchKernelGGL((mean_level_kernel<1, true, NBC, PK>), grid, block, shmem, st, a); \
+        else                    hipLaunchKernelGGL((mean_level_kernel<1, false, NBC, PK>), grid, block, shmem, st, a); } while (0)
+#define CDFT_MEAN(NBC) do { if (park) CDFT_MEAN2(NBC, true); else CDFT_MEAN2(NBC, false); } while (0)
     if (p->nb == 1)      CDFT_MEAN(1);
     else if (p->nb == 2) CDFT_MEAN(2);
     else if (p->nb <= 4) CDFT_MEAN(4);
     else                 CDFT_MEAN(8);
+#undef CDFT_MEAN2
 #undef CDFT_MEAN
     CDFT_LAUNCH_CHECK();
     hipLaunchKernelGGL(mean_final_kernel, dim3(p->npk), dim3(kThreads), 0, st, p->partial, a.nblk, nq, dout);

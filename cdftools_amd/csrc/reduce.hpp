@@ -5,10 +5,26 @@
 
 namespace cdft {
 
+// One step of the reduction: v + (v moved across lanes by the DPP control word).  Data-parallel primitives run in the
+// vector pipeline (two v_mov_dpp and a v_add_f64), where a __shfl_xor of a double is two ds_bpermute round trips
+// through the LDS crossbar -- the level kernels do several of these per level and wave.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
+    return v + __hiloint2double(hi, lo);          // (rows outside ROW_MASK add +0.0)
+}
+
+// Fixed order: quads, half rows, rows of 16, then the four rows in order -- the same tree on every call.
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;                                     // every lane holds the wave total
+    v = dpp_add<0xb1, 0xf>(v);                    // quad_perm:[1,0,3,2]
+    v = dpp_add<0x4e, 0xf>(v);                    // quad_perm:[2,3,0,1]
+    v = dpp_add<0x141, 0xf>(v);                   // row_half_mirror
+    v = dpp_add<0x140, 0xf>(v);                   // row_mirror: every lane holds its row of 16
+    v = dpp_add<0x142, 0xa>(v);                   // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xc>(v);                   // row_bcast:31 into rows 2 and 3: lane 63 holds the wave total
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);              // every lane holds the wave total
 }
 
 // Sum of `v` over the workgroup (blockDim.x a multiple of 64, <= 1024), combined in wave order.
