@@ -60,6 +60,23 @@ __global__ void __launch_bounds__(256) triad_kernel(const f4 *__restrict__ a, co
     }
 }
 
+// flat sweep in address order, one 4 KB chunk per workgroup, where every level ALSO reads NM 2-D planes (cdfcurl's
+// metrics) at the same horizontal position: plain loads, so they can stay in L2 / Infinity Cache from one level to the next
+// (NM planes of 62 MB against 256 MB of Infinity Cache); HALO: one more read of `a` a row (1081 vectors) ahead
+template <int NM, int HALO>
+__global__ void __launch_bounds__(256) flat_metric_kernel(const f4 *__restrict__ a, const f4 *__restrict__ b, f4 *__restrict__ c,
+                                                          const f4 *__restrict__ m, size_t stride, size_t nvec) {
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= nvec) return;
+    const size_t pp = p % stride;
+    f4 va = __builtin_nontemporal_load(a + p), vb = __builtin_nontemporal_load(b + p);
+    f4 acc = va * vb;
+    if (HALO) acc += a[min(p + 1081, nvec - 1)];
+#pragma unroll
+    for (int q = 0; q < NM; ++q) acc += m[(size_t)q * stride + pp] * va;
+    __builtin_nontemporal_store(acc, c + p);
+}
+
 // short-lived workgroups, one (tile, level) item each, handed out TILE-major: the K levels of a tile are consecutive
 // blocks (XCD = 0: blocks b..b+K-1 on whatever XCD they land; XCD = 1: all K levels of a tile on one XCD, tiles dealt
 // round-robin to the 8 XCDs) -- what a cdfcurl with per-tile metrics in L2 would look like
@@ -170,6 +187,20 @@ int main() {
             fflush(stdout);
         };
         item(I1{}, M0{}); item(I1{}, M1{}); item(I2{}, M0{}); item(I2{}, M1{}); item(I4{}, M0{}); item(I4{}, M1{});
+    }
+    {
+        f4 *m;
+        CK(hipMalloc(&m, stride * 16 * 4 + 65536)); CK(hipMemset(m, 3, stride * 16 * 4));
+        auto fm = [&](auto nm_tag, auto halo_tag) {
+            constexpr int NM = decltype(nm_tag)::value, HALO = decltype(halo_tag)::value;
+            float t = time_ms([&] { hipLaunchKernelGGL((flat_metric_kernel<NM, HALO>), dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, 0, a, b, c, m, stride, nvec); }, 5);
+            printf("{\"pattern\": \"flat sweep, level-major, 2 reads + 1 write + metric planes per level\", \"metric_planes\": %d, \"halo_row\": %d, \"ms\": %.3f, \"GBps_of_the_3_streams\": %.0f}\n",
+                   NM, HALO, t, 3.0 * nvec * 16 / t * 1e-6);
+            fflush(stdout);
+        };
+        using I0 = std::integral_constant<int, 0>; using I3 = std::integral_constant<int, 3>;
+        fm(I0{}, I0{}); fm(I1{}, I0{}); fm(I2{}, I0{}); fm(I3{}, I0{}); fm(I4{}, I0{}); fm(I3{}, I1{}); fm(I4{}, I1{});
+        CK(hipFree(m));
     }
     for (int threads : {512, 1024}) {
         auto big = [&](auto vpt_tag) {
