@@ -125,9 +125,7 @@ PROGRAM cdfheatc
      e31d(:) = getvare3(cn_fzgr, cn_ve3t1d, npk)
      e31d_sel(:) = e31d(ikmin:ikmin + nvpk - 1)
   ENDIF
-  DO jk = 1, nvpk
-     tmask(:,:,jk) = getvar(cn_fmsk, cv_msk, jk + ikmin - 1, npiglo, npjglo, kimin=iimin, kjmin=ijmin)
-  END DO
+  CALL readvar3d(cn_fmsk, cv_msk, tmask, kimin=iimin, kjmin=ijmin, kkmin=ikmin)      ! (every level in one read)
 
   CALL CreateOutput
   CALL hip_shard(ngpu, igpus)                                ! CDFT_GPUS / CDFT_GPU_MAP: row blocks over the node's GPUs
@@ -152,12 +150,9 @@ PROGRAM cdfheatc
         rmxldep(:,:) = getvar(cf_mfil, cn_somxl010, 1, npiglo, npjglo, kimin=iimin, kjmin=ijmin, ktime=jt)
         pmxl = C_LOC(rmxldep) ; pdepw = C_LOC(gdepw_sel)
      ENDIF
-     DO jk = 1, nvpk
-        ik = jk + ikmin - 1
-        temp(:,:,jk) = getvar(cf_tfil, cn_votemper, ik, npiglo, npjglo, kimin=iimin, kjmin=ijmin, ktime=jt)
-        IF ( .NOT. lfull .AND. (jt == 1 .OR. lg_vvl) ) &
-           &  e3t(:,:,jk) = getvar(cn_fe3t, cn_ve3t, ik, npiglo, npjglo, kimin=iimin, kjmin=ijmin, ktime=it, ldiom=.NOT. lg_vvl)
-     END DO
+     CALL readvar3d(cf_tfil, cn_votemper, temp, kimin=iimin, kjmin=ijmin, kkmin=ikmin, ktime=jt)
+     IF ( .NOT. lfull .AND. (jt == 1 .OR. lg_vvl) ) &
+        &  CALL readvar3d(cn_fe3t, cn_ve3t, e3t, kimin=iimin, kjmin=ijmin, kkmin=ikmin, ktime=it, ldiom=.NOT. lg_vvl)
      IF ( jt == 1 .OR. lg_vvl ) THEN
         pe3t = C_NULL_PTR ; pe31d = C_NULL_PTR
         IF ( lfull ) THEN ; pe31d = C_LOC(e31d_sel) ; ELSE ; pe3t = C_LOC(e3t) ; ENDIF

@@ -564,27 +564,45 @@ CONTAINS
     istatus = NF90_CLOSE(incid)
   END FUNCTION getvar3d
 
-  SUBROUTINE readvar3d(cdfile, cdvar, ptab, ktime, ldiom)
-    !! getvar3d without the function result: the (kpi,kpj,kpk) record is read straight into ptab (no copy of
-    !! hundreds of MB), same unpacking.  Not in the reference's cdfio: used by the programs of this build only.
+  SUBROUTINE readvar3d(cdfile, cdvar, ptab, ktime, ldiom, kimin, kjmin, kkmin)
+    !! getvar3d without the function result: the (kpi,kpj,kpk) block of one record, window origin (kimin,kjmin,kkmin), is
+    !! read straight into ptab in ONE call (no copy of hundreds of MB, none of the per-level open / inquire / close of a
+    !! getvar loop), same unpacking.  A (x,y,t) variable gives its one slab; a window that crosses the E-W boundary is
+    !! read level by level through getvar, which knows how to wrap.  Not in the reference's cdfio: used by the programs
+    !! of this build only.
     CHARACTER(LEN=*),          INTENT(in)  :: cdfile, cdvar
     REAL(KIND=4), CONTIGUOUS,  INTENT(out) :: ptab(:,:,:)
-    INTEGER(KIND=4), OPTIONAL, INTENT(in)  :: ktime
+    INTEGER(KIND=4), OPTIONAL, INTENT(in)  :: ktime, kimin, kjmin, kkmin
     LOGICAL,         OPTIONAL, INTENT(in)  :: ldiom
-    INTEGER(KIND=4) :: incid, id_var, istatus, itime
+    INTEGER(KIND=4) :: incid, id_var, istatus, itime, iimin, ijmin, ikmin, jk, indim, istart(4), icount(4)
     REAL(KIND=4) :: zsf, zao, zspval
-    LOGICAL :: llog, lsf, lao
+    LOGICAL :: llog, lsf, lao, lliom
     CHARACTER(LEN=256) :: clvar
     itime = 1 ; IF ( PRESENT(ktime) ) itime = ktime
+    iimin = 1 ; IF ( PRESENT(kimin) ) iimin = kimin
+    ijmin = 1 ; IF ( PRESENT(kjmin) ) ijmin = kjmin
+    ikmin = 1 ; IF ( PRESENT(kkmin) ) ikmin = kkmin
+    lliom = .FALSE. ; IF ( PRESENT(ldiom) ) lliom = ldiom
     clvar = cdvar
-    IF ( PRESENT(ldiom) ) THEN
-       IF ( ldiom ) clvar = iom_name(cdvar)
+    IF ( lliom ) clvar = iom_name(cdvar)
+    IF ( PRESENT(kimin) ) THEN
+       IF ( iimin + SIZE(ptab,1) - 1 > getdim(cdfile, cn_x, ldexact=.TRUE.) ) THEN       ! wraps: getvar's business
+          DO jk = 1, SIZE(ptab,3)
+             ptab(:,:,jk) = getvar(cdfile, cdvar, jk + ikmin - 1, SIZE(ptab,1), SIZE(ptab,2), kimin=iimin, kjmin=ijmin, &
+                  &                ktime=itime, ldiom=lliom)
+          END DO
+          RETURN
+       ENDIF
     ENDIF
     CALL ERR_HDL(NF90_OPEN(cdfile, NF90_NOWRITE, incid))
     CALL ERR_HDL(NF90_INQ_VARID(incid, clvar, id_var))
     CALL find_spval(incid, id_var, zspval)
     CALL packing(incid, id_var, zsf, zao, llog, lsf, lao)
-    istatus = NF90_GET_VAR(incid, id_var, ptab, start=(/ 1, 1, 1, itime /), count=(/ SIZE(ptab,1), SIZE(ptab,2), SIZE(ptab,3), 1 /))
+    istart = (/ iimin, ijmin, 1, 1 /) ; icount = (/ SIZE(ptab,1), SIZE(ptab,2), 1, 1 /)
+    CALL level_start(incid, id_var, ikmin, itime, istart)                    ! (x,y,t): istart(3) = the record
+    istatus = NF90_INQUIRE_VARIABLE(incid, id_var, ndims=indim)
+    IF ( indim == 4 ) icount(3) = SIZE(ptab,3)                                ! (x,y,z,t): all the levels at once
+    istatus = NF90_GET_VAR(incid, id_var, ptab, start=istart, count=icount)
     IF ( istatus /= NF90_NOERR ) THEN
        PRINT *, ' Problem in readvar3d for ', TRIM(clvar)
        CALL ERR_HDL(istatus)

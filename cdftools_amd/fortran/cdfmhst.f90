@@ -171,9 +171,7 @@ PROGRAM cdfmhst
         IF ( lfull ) THEN
            pe31d = C_LOC(e31d)
         ELSE
-           DO jk = 1, npk
-              e3v(:,:,jk) = getvar(cn_fe3v, cn_ve3v, jk, npiglo, npjglo, ktime=it, ldiom=.NOT. lg_vvl)
-           END DO
+           CALL readvar3d(cn_fe3v, cn_ve3v, e3v, ktime=it, ldiom=.NOT. lg_vvl)      ! (every level in one read)
            pe3v = C_LOC(e3v)
         ENDIF
         CALL hip_check(cdft_mhst_set_mesh(plan, e1v, pe3v, pe31d, zmasks, CDFT_MEM_HOST, C_NULL_PTR), 'cdft_mhst_set_mesh')

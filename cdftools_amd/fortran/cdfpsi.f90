@@ -202,9 +202,7 @@ PROGRAM cdfpsi
         pzv = C_LOC(zv) ; pe1v = C_LOC(e1v)
         IF ( .NOT. lfull ) THEN
            IF ( jt == 1 .OR. lg_vvl ) THEN
-              DO jk = 1, npk
-                 e3v(:,:,jk) = getvar(cn_fe3v, cn_ve3v, jk, npiglo, npjglo, ktime=it, ldiom=.NOT. lg_vvl)
-              END DO
+              CALL readvar3d(cn_fe3v, cn_ve3v, e3v, ktime=it, ldiom=.NOT. lg_vvl)      ! (every level in one read)
            ENDIF
            pe3v = C_LOC(e3v)
         ENDIF
@@ -214,9 +212,7 @@ PROGRAM cdfpsi
         pzu = C_LOC(zu) ; pe2u = C_LOC(e2u)
         IF ( .NOT. lfull ) THEN
            IF ( jt == 1 .OR. lg_vvl ) THEN
-              DO jk = 1, npk
-                 e3u(:,:,jk) = getvar(cn_fe3u, cn_ve3u, jk, npiglo, npjglo, ktime=it, ldiom=.NOT. lg_vvl)
-              END DO
+              CALL readvar3d(cn_fe3u, cn_ve3u, e3u, ktime=it, ldiom=.NOT. lg_vvl)
            ENDIF
            pe3u = C_LOC(e3u)
         ENDIF
