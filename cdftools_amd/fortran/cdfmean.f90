@@ -209,10 +209,7 @@ PROGRAM cdfmean
   IF ( lg_vvl ) cf_e3 = cf_in
 
   ! the mask of the working levels is the same for every record
-  DO jk = 1, nvpk
-     ik = jk + ikmin - 1
-     zmask(:,:,jk) = getvar(cn_fmsk, cv_msk, ik, npiglo, npjglo, kimin=iimin, kjmin=ijmin)
-  END DO
+  CALL readvar3d(cn_fmsk, cv_msk, zmask, kimin=iimin, kjmin=ijmin, kkmin=ikmin)      ! (every level in one read)
   IF ( .NOT. lfull ) ALLOCATE( e3(npiglo,npjglo,nvpk) )
   CALL hip_check(cdft_mean_create(plan, npiglo, npjglo, nvpk, nbasin), 'cdft_mean_create')
 
@@ -224,18 +221,12 @@ PROGRAM cdfmean
         IF ( lfull ) THEN
            pe31d = C_LOC(e31d)                               ! e3(:,:) = e31d(jk), with jk the working-level index (:412)
         ELSE
-           DO jk = 1, nvpk
-              ik = jk + ikmin - 1
-              e3(:,:,jk) = getvar(cf_e3, cv_e3, ik, npiglo, npjglo, kimin=iimin, kjmin=ijmin, ktime=it, ldiom=.NOT. lg_vvl)
-           END DO
+           CALL readvar3d(cf_e3, cv_e3, e3, kimin=iimin, kjmin=ijmin, kkmin=ikmin, ktime=it, ldiom=.NOT. lg_vvl)
            pe3 = C_LOC(e3)
         ENDIF
         CALL hip_check(cdft_mean_set_mesh(plan, e1, e2, pe3, pe31d, zmask, ibmask, CDFT_MEM_HOST, C_NULL_PTR), 'cdft_mean_set_mesh')
      ENDIF
-     DO jk = 1, nvpk
-        ik = jk + ikmin - 1
-        zv(:,:,jk) = getvar(cf_in, cv_nam, ik, npiglo, npjglo, kimin=iimin, kjmin=ijmin, ktime=jt)
-     END DO
+     CALL readvar3d(cf_in, cv_nam, zv, kimin=iimin, kjmin=ijmin, kkmin=ikmin, ktime=jt)
      CALL hip_check(cdft_mean_compute(plan, zv, CDFT_MEM_HOST, dsums, CDFT_MEM_HOST, C_NULL_PTR), 'cdft_mean_compute')
 
      DO jk = 1, nvpk

@@ -168,12 +168,9 @@ PROGRAM cdfsum
   CALL CreateOutput
 
   ! the mask of the working levels does not change with the record
-  DO jk = 1, nvpk
-     ik = jk + ikmin - 1
-     IF ( lnmsk ) THEN ; zmask(:,:,jk) = 1
-     ELSE              ; zmask(:,:,jk) = getvar(cn_fmsk, cv_msk, ik, npiglo, npjglo, kimin=iimin, kjmin=ijmin)
-     ENDIF
-  END DO
+  IF ( lnmsk ) THEN ; zmask(:,:,:) = 1
+  ELSE IF ( nvpk >= 1 ) THEN ; CALL readvar3d(cn_fmsk, cv_msk, zmask, kimin=iimin, kjmin=ijmin, kkmin=ikmin)      ! (every level in one read)
+  ENDIF
   ibmask(:,:,:) = 1
   IF ( nvpk >= 1 ) THEN
      CALL hip_check(cdft_mean_create(plan, npiglo, npjglo, nvpk, 1), 'cdft_mean_create')
@@ -187,19 +184,13 @@ PROGRAM cdfsum
      it = 1 ; IF ( lg_vvl ) it = jt
      dvol = 0.d0 ; dsum = 0.d0
      IF ( nvpk >= 1 .AND. ( jt == 1 .OR. lg_vvl ) ) THEN
-        DO jk = 1, nvpk
-           ik = jk + ikmin - 1
-           IF ( lnwgh ) THEN ; e3(:,:,jk) = 1.
-           ELSE ; e3(:,:,jk) = getvar(cf_e3, cv_e3, ik, npiglo, npjglo, kimin=iimin, kjmin=ijmin, ktime=it, ldiom=.NOT. lg_vvl)
-           ENDIF
-        END DO
+        IF ( lnwgh ) THEN ; e3(:,:,:) = 1.
+        ELSE ; CALL readvar3d(cf_e3, cv_e3, e3, kimin=iimin, kjmin=ijmin, kkmin=ikmin, ktime=it, ldiom=.NOT. lg_vvl)
+        ENDIF
         CALL hip_check(cdft_mean_set_mesh(plan, e1, e2, C_LOC(e3), C_NULL_PTR, zmask, ibmask, CDFT_MEM_HOST, C_NULL_PTR), &
              &         'cdft_mean_set_mesh')
      ENDIF
-     DO jk = 1, nvpk
-        ik = jk + ikmin - 1
-        zv(:,:,jk) = getvar(cf_in, cv_in, ik, npiglo, npjglo, ktime=jt, kimin=iimin, kjmin=ijmin)
-     END DO
+     IF ( nvpk >= 1 ) CALL readvar3d(cf_in, cv_in, zv, kimin=iimin, kjmin=ijmin, kkmin=ikmin, ktime=jt)
      IF ( nvpk >= 1 ) CALL hip_check(cdft_mean_compute(plan, zv, CDFT_MEM_HOST, dsums, CDFT_MEM_HOST, C_NULL_PTR), 'cdft_mean_compute')
 
      DO jk = 1, nvpk

@@ -102,10 +102,8 @@ PROGRAM cdfvhst
         pe31d = C_LOC(e31d)
      ELSE
         IF ( jt == 1 .OR. lg_vvl ) THEN
-           DO jk = 1, npk
-              e3v(:,:,jk) = getvar(cn_fe3v, cn_ve3v, jk, npiglo, npjglo, ktime=it, ldiom=.NOT. lg_vvl)
-              e3u(:,:,jk) = getvar(cn_fe3u, cn_ve3u, jk, npiglo, npjglo, ktime=it, ldiom=.NOT. lg_vvl)
-           END DO
+           CALL readvar3d(cn_fe3v, cn_ve3v, e3v, ktime=it, ldiom=.NOT. lg_vvl)      ! (every level in one read)
+           CALL readvar3d(cn_fe3u, cn_ve3u, e3u, ktime=it, ldiom=.NOT. lg_vvl)
         ENDIF
         pe3u = C_LOC(e3u) ; pe3v = C_LOC(e3v)
      ENDIF

@@ -161,9 +161,7 @@ PROGRAM cdfvint
   CALL CreateOutput
   PRINT *, 'OUTPUT DEPTHS ARE : ', gdepo
 
-  DO jk = 1, npk
-     tmask(:,:,jk) = getvar(cn_fmsk, cn_tmask, jk, npiglo, npjglo, kimin=iimin, kjmin=ijmin)
-  END DO
+  CALL readvar3d(cn_fmsk, cn_tmask, tmask, kimin=iimin, kjmin=ijmin)      ! (every level in one read)
 
   DO jt = 1, npt
      it = 1 ; IF ( lg_vvl ) it = jt
@@ -194,15 +192,11 @@ PROGRAM cdfvint
         pe31d = C_LOC(e31d)
      ELSE
         IF ( jt == 1 .OR. lg_vvl ) THEN
-           DO jk = 1, npk
-              e3t(:,:,jk) = getvar(cn_fe3t, cn_ve3t, jk, npiglo, npjglo, kimin=iimin, kjmin=ijmin, ktime=it, ldiom=.NOT. lg_vvl)
-           END DO
+           CALL readvar3d(cn_fe3t, cn_ve3t, e3t, kimin=iimin, kjmin=ijmin, ktime=it, ldiom=.NOT. lg_vvl)
         ENDIF
         pe3 = C_LOC(e3t)
      ENDIF
-     DO jk = 1, npk
-        zt(:,:,jk) = getvar(cf_in, cv_in, jk, npiglo, npjglo, kimin=iimin, kjmin=ijmin, ktime=jt)
-     END DO
+     CALL readvar3d(cf_in, cv_in, zt, kimin=iimin, kjmin=ijmin, ktime=jt)
      CALL hip_check(cdft_vint_cumul(zt, pe3, pe31d, tmask, npiglo, npjglo, npk, kout, khit, zclip, zdiv, npko, sclf, &
           &         MERGE(1_C_INT, 0_C_INT, ltmean .OR. lsmean), CDFT_MEM_HOST, zout, CDFT_MEM_HOST, C_NULL_PTR), 'cdft_vint_cumul')
      DO jk = 1, npk
