@@ -343,11 +343,12 @@ __global__ void __launch_bounds__(64) heatc_seq_kernel(HeatcArgs a, const float 
 // Which binade?  The r8 sums of the level kernel above (one partial per block of 4096 cells, formed anyway by the r8
 // mode), added to the last exact value the level has published, estimate the chain's value at every block boundary:
 // the binade of the estimate where a block starts and, when different, where it ends are the two HYPOTHESES (sign, e)
-// for the block's chunks of 512 cells.  Work is dealt in tickets of 64 chunks of one level from an atomic counter (ticket = step * npk
-// + level: the workgroups in flight spread over all levels and a few consecutive steps of each).  A workgroup forms,
+// for the block's chunks of 512 cells.  Work is dealt in tickets of 64 to 256 chunks of one level from an atomic counter
+// (ticket = step * npk + level: the workgroups in flight spread over all levels and a few consecutive steps of each;
+// about 32 steps per level).  A workgroup forms,
 // for each chunk, chain and hypothesis,  K = sum k,  pos = sum max(k,0)  and flags (a cell that is not 0; a tie / NaN
 // / Inf / |k| >= 2^20; a negative x); then waits for the step before it to publish the chains' exact values.  One
-// wave per chain takes the 64 chunks, one per lane: with S_before from a prefix sum of the K's,
+// wave per chain takes the chunks 64 at a time, one per lane: with S_before from a prefix sum of the K's,
 //     S_before + neg >= 2^23 (+1 when an x was negative)   and   S_before + pos < 2^24
 // prove that no prefix of the chunk left the binade, and S += K is exactly what 512 sequential v_add_f32 would have
 // produced; the first chunk that fails the proof, or whose hypotheses do not name the chain's binade, stops the walk.
