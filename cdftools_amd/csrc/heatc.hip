@@ -600,11 +600,14 @@ __global__ void __launch_bounds__(64 * kScanWaves, 3) heatc_scan_kernel(HeatcArg
             for (;;) {
                 // the chunks in order, 64 at a time, one per lane
                 const int ks = scan_key(s);
+                // (-0) + (+0) = +0: a chain handed a start value of -0.0 is the one state a zero term can change; it looks
+                // at every chunk until a term that is not -0.0 has made it +0.0 or a number (no chain gets back to -0.0)
+                const bool minus0 = __float_as_uint(s) == 0x80000000u;
                 int S0 = scan_mant(s), stop = -1, hstop = 0;
                 for (int g = from & ~63; g < nchunk && stop < 0; g += 64) {
                     const int q = g + lane;
                     const int f0 = sm_flag[0][q][ch];
-                    const bool live = q >= from && (f0 & 1);      // zeros: s + 0 = s in every state
+                    const bool live = q >= from && ((f0 & 1) || (minus0 && t0 + (int64_t)q * kScanChunk < a.nij));   // zeros: s + 0 = s
                     const int h = (ks >= 0 && ks == sm_key[0][q][ch]) ? 0 : (ks >= 0 && ks == sm_key[1][q][ch]) ? 1 : -1;
                     const int hh = h < 0 ? 0 : h;
                     const int f = sm_flag[hh][q][ch];
@@ -640,12 +643,16 @@ __global__ void __launch_bounds__(64 * kScanWaves, 3) heatc_scan_kernel(HeatcArg
                     int first;                                    // the first cell >= next that cannot be added as an integer
                     int incl[kScanNV][4];
                     if (ks < 0) {
-                        // no binade (s = 0, ...): the next cell that is not 0 is added with v_add_f32
+                        // no binade (s = 0, ...): the next cell that is not 0 (s = -0.0: that is not -0.0) is added with v_add_f32
+                        const bool m0 = __float_as_uint(s) == 0x80000000u;
                         int mine = kScanChunk;
 #pragma unroll
                         for (int v = kScanNV - 1; v >= 0; --v)
 #pragma unroll
-                            for (int c = 3; c >= 0; --c) { const int id = v * 256 + 4 * lane + c; if (id >= next && xv[v][c] != 0.f) mine = id; }
+                            for (int c = 3; c >= 0; --c) {
+                                const int id = v * 256 + 4 * lane + c;
+                                if (id >= next && (m0 ? __float_as_uint(xv[v][c]) != 0x80000000u : xv[v][c] != 0.f)) mine = id;
+                            }
                         first = wave_imin(mine);
                     } else {
                         const float scale = scan_scale(ks);

@@ -222,6 +222,43 @@ def test_hip_reference_order_kernels_agree_on_eorca12_levels(gpu, monkeypatch):
     assert np.array_equal(sh.compute(temp).view(np.uint64), a)
 
 
+FUZZ_SHAPES = [(1, 1, 1), (511, 1, 2), (512, 1, 1), (513, 1, 3), (4, 127, 2), (4096, 8, 1), (4097, 8, 2), (257, 255, 3), (1023, 33, 2),
+               (32768, 1, 2), (32769, 1, 1), (181, 181, 5), (65536, 2, 1), (1442, 91, 2), (977, 269, 4), (3, 3, 7)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("npi,npj,npk", FUZZ_SHAPES)
+def test_hip_reference_order_kernels_agree_on_random_shapes_and_options(gpu, npi, npj, npk, monkeypatch):
+    """Sizes around the chunk (512), block (4096) and ticket (32768) boundaries, every combination of byte / r4 mask, e3t /
+    -full, -mxloption 0 / 1 / -1, magnitudes from 1e-12 to 1e12, and a start value handed in (cdft_heatc_chain)."""
+    rng = np.random.default_rng(npi * 7 + npj * 3 + npk)
+    shape = (npk, npj, npi)
+    for trial in range(4):
+        scale = 10.0 ** rng.integers(-6, 7)
+        e1t = (scale * (0.5 + rng.random((npj, npi)))).astype(f32)
+        e2t = (scale * (0.5 + rng.random((npj, npi)))).astype(f32)
+        e3t = (1 + 199 * rng.random(shape)).astype(f32)
+        e31d = (1 + 199 * rng.random(npk)).astype(f32)
+        mask = (rng.random(shape) > rng.choice([0.1, 0.5, 0.95])).astype(f32)
+        temp = (rng.normal(rng.choice([0.0, 10.0]), 8, shape)).astype(f32)
+        mxl = (10 + 300 * rng.random((npj, npi))).astype(f32)
+        gdepw = np.cumsum(np.concatenate([[0], e31d[:-1]])).astype(f32)
+        full, m8, opt = bool(trial & 1), bool(trial & 2), int(rng.integers(-1, 2))
+        plan = gpu.HeatcPlan(npi, npj, npk)
+        plan.set_mesh(e1t, e2t, mask.astype(np.uint8) if m8 else (mask * f32(0.75)).astype(f32), **(dict(e31d=e31d) if full else dict(e3t=e3t)))
+        plan.set_sum_mode(True)
+        kw = dict(rmxldep=mxl if opt else None, gdepw=gdepw, mxloption=opt)
+        carry = (rng.normal(0, 1, (npk, 3)) * scale * scale * rng.choice([0.0, 1.0, 1e3])).astype(f32)
+        monkeypatch.delenv("CDFT_HEATC_SEQ", raising=False)
+        plan.chain(carry_in=carry)
+        a = plan.compute(temp, **kw).view(np.uint64)
+        monkeypatch.setenv("CDFT_HEATC_SEQ", "chain")
+        plan.chain(carry_in=carry)
+        b = plan.compute(temp, **kw).view(np.uint64)
+        monkeypatch.delenv("CDFT_HEATC_SEQ")
+        assert np.array_equal(a, b), (trial, full, m8, opt)
+
+
 def abs_terms(g, temp, e3t=None, e31d=None, **kw):
     return oracle_tools.heatc(g["e1t"], g["e2t"], g["tmask"], np.abs(temp), e3t=e3t, e31d=e31d, **kw)
 
