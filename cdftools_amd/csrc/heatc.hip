@@ -549,15 +549,19 @@ __global__ void __launch_bounds__(64 * kScanWaves, 3) heatc_scan_kernel(HeatcArg
                                 const float qq = __fmul_rn(x[ch][v][c], scale);               // exact (a power of two), or Inf / NaN
                                 const float kf = rintf(qq);
                                 const int   ki = (int)kf;                                     // (saturating conversion; guarded by `big`)
-                                K += ki; pos += max(ki, 0);
+                                K += ki;
+                                if (ch == 2) pos += max(ki, 0);                               // (surface and volume: see below)
                                 far = fmaxf(far, fabsf(__fsub_rn(qq, kf)));                   // the difference is exact
                                 sgn |= __float_as_uint(qq);
                                 big = max(big, __float_as_uint(qq) & 0x7fffffffu);            // NaN > Inf > every finite |q|
                             }
-                        K = wave_isum(K); pos = wave_isum(pos);
+                        K = wave_isum(K);
+                        pos = ch == 2 ? wave_isum(pos) : K;
                     }
-                    const bool bad = far == 0.5f || big >= 0x49800000u;   // a tie; NaN, Inf, or |k| >= 2^20 (x not well below s; and
-                                                                          // the sums of 512 k's stay inside 32 bits)
+                    // a tie; NaN, Inf, or |k| >= 2^20 (x not well below s; and the sums of 512 k's stay inside 32 bits); and for
+                    // the surface and the volume, whose terms are never negative on a real mesh (pos = K, one sum less to
+                    // form): a sign bit anywhere (a negative weight of -M, a negative start value) sends the chunk to the cells
+                    const bool bad = far == 0.5f || big >= 0x49800000u || (ch != 2 && (sgn >> 31) != 0u);
                     const bool abad = __builtin_amdgcn_ballot_w64(bad) != 0, ang = __builtin_amdgcn_ballot_w64((sgn >> 31) != 0u) != 0;
                     if (lane == 0) {
                         sm_K[h][q][ch] = K; sm_pos[h][q][ch] = pos;
