@@ -259,6 +259,19 @@ def test_hip_reference_order_kernels_agree_on_random_shapes_and_options(gpu, npi
         assert np.array_equal(a, b), (trial, full, m8, opt)
 
 
+@pytest.mark.gpu
+def test_hip_reference_order_kernel_next_to_another_kernel_on_another_stream(gpu):
+    """tools/stress_scan_concurrent.py for two seconds: heatc_scan_kernel (whose workgroups wait for earlier tickets) on one
+    stream, cdfmoc's zonal kernel filling the CUs on another, from two host threads -- same sums every time, no hang."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_scan_concurrent.py")], capture_output=True, text=True,
+                       env=dict(os.environ, STRESS_SECONDS="2"), timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-1500:] + r.stderr[-1500:]
+
+
 def abs_terms(g, temp, e3t=None, e31d=None, **kw):
     return oracle_tools.heatc(g["e1t"], g["e2t"], g["tmask"], np.abs(temp), e3t=e3t, e31d=e31d, **kw)
 
