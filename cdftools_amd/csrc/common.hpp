@@ -31,6 +31,14 @@ struct DevBuf {
 int to_device(const void *src, size_t n, int memspace, DevBuf &stage, hipStream_t st,
               const void **dev);
 
+// A named range around a C-ABI call for rocprofv3 --marker-trace (roctx).  Off unless CDFT_ROCTX=1 is in the environment
+// when the first range is made; the roctx library is looked up at run time (no link dependency, nothing when it is absent).
+struct TraceRange {
+    explicit TraceRange(const char *name);
+    ~TraceRange();
+    bool on;
+};
+
 // Streaming loads.  Every kernel of this path reads its 3-D fields exactly once; a nontemporal
 // load tells L2 / Infinity Cache not to keep those lines (measured with tools/hbm_probe.hip on
 // MI355X: 7.0-7.2 TB/s for a nontemporal read stream against 6.3-6.5 TB/s with plain loads).

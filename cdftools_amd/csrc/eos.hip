@@ -198,6 +198,7 @@ extern "C" {
 
 int cdft_eos_sigmai(const float *ptem, const float *psal, int64_t n, float pref, int eos, int flags,
                     double *sig, int in_space, int out_space, void *stream) {
+    TraceRange trace_("cdft_eos_sigmai");
     return run(kScalarRef, ptem, psal, nullptr, n, pref, 0.f, eos, flags, sig, sizeof(double), in_space,
                out_space, stream);
 }
@@ -210,6 +211,7 @@ int cdft_eos_sigmai2d(const float *ptem, const float *psal, const float *pref2d,
 
 int cdft_eos_sig_tool(const float *ptem, const float *psal, int64_t n, float pref, float spval, int eos,
                       int flags, float *sig4, int in_space, int out_space, void *stream) {
+    TraceRange trace_("cdft_eos_sig_tool");
     return run(kTool, ptem, psal, nullptr, n, pref, spval, eos, flags, sig4, sizeof(float), in_space,
                out_space, stream);
 }

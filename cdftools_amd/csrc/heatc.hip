@@ -875,6 +875,7 @@ int cdft_heatc_create_sharded(cdft_heatc_plan **plan, int npiglo, int npjglo, in
 
 int cdft_heatc_set_mesh(cdft_heatc_plan *p, const float *e1t, const float *e2t, const float *e3t,
                         const float *e31d, const void *tmask, int mask_is_r4, int memspace, void *stream) {
+    TraceRange trace_("cdft_heatc_set_mesh");
     if (!p || !e1t || !e2t || !tmask || (!e3t && !e31d) || (e3t && e31d))
         return fail(CDFT_ERR_ARG, "cdft_heatc_set_mesh: need e1t, e2t, tmask and exactly one of e3t / e31d");
     if (p->sh) {
@@ -913,6 +914,7 @@ int cdft_heatc_set_mesh(cdft_heatc_plan *p, const float *e1t, const float *e2t, 
 
 int cdft_heatc_compute(cdft_heatc_plan *p, const float *temp, int temp_space, const float *rmxldep,
                        const float *gdepw, int mxloption, double *sums, int out_space, void *stream) {
+    TraceRange trace_("cdft_heatc_compute");
     if (!p || !temp || !sums) return fail(CDFT_ERR_ARG, "cdft_heatc_compute: NULL argument");
     if (!p->mesh_set) return fail(CDFT_ERR_STATE, "cdft_heatc_compute: cdft_heatc_set_mesh has not succeeded");
     if (mxloption < -1 || mxloption > 1 || (mxloption != 0 && (!rmxldep || !gdepw)))

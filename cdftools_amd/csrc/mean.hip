@@ -265,6 +265,7 @@ int cdft_mean_set_form(cdft_mean_plan *p, int form) {
 }
 
 int cdft_mean_compute(cdft_mean_plan *p, const float *zv, int in_space, double *sums, int out_space, void *stream) {
+    TraceRange trace_("cdft_mean_compute");
     if (!p || !zv || !sums) return fail(CDFT_ERR_ARG, "cdft_mean_compute: NULL argument");
     if (!p->mesh_set) return fail(CDFT_ERR_STATE, "cdft_mean_compute: cdft_mean_set_mesh has not succeeded");
     hipStream_t st = as_stream(stream);

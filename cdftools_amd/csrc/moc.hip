@@ -353,6 +353,7 @@ int cdft_moc_create_sharded(cdft_moc_plan **plan, int npiglo, int npjglo, int np
 
 int cdft_moc_set_mesh(cdft_moc_plan *p, const float *e1v, const float *e3v, const int16_t *ibmask,
                       int memspace, void *stream) {
+    TraceRange trace_("cdft_moc_set_mesh");
     return cdft_moc_set_mesh_vmask(p, e1v, e3v, nullptr, ibmask, memspace, stream);
 }
 
@@ -452,6 +453,7 @@ int cdft_moc_describe(cdft_moc_plan *p, char *buf, size_t buflen) {
 
 int cdft_moc_compute(cdft_moc_plan *p, const float *zv, int64_t rec_stride, int npt, int zv_space,
                      double *dmoc, int dmoc_space, void *stream) {
+    TraceRange trace_("cdft_moc_compute");
     if (!p || !zv || !dmoc) return fail(CDFT_ERR_ARG, "cdft_moc_compute: NULL argument");
     if (!p->mesh_set) return fail(CDFT_ERR_STATE, "cdft_moc_compute: cdft_moc_set_mesh has not succeeded");
     const int64_t n3 = (int64_t)p->npi * p->npj * p->npk;
@@ -518,6 +520,7 @@ int cdft_moc_decomp_set_mesh(cdft_moc_plan *p, const float *e3v, const float *e1
 
 int cdft_moc_decomp(cdft_moc_plan *p, const float *zv, const float *ztemp, const float *zsal, int eos, int in_space,
                     double *dmoc, double *dmoc_sh, double *dmoc_bt, double *dmoc_ag, int out_space, void *stream) {
+    TraceRange trace_("cdft_moc_decomp");
     if (!p || !zv || !ztemp || !zsal || !dmoc || !dmoc_sh || !dmoc_bt || !dmoc_ag)
         return fail(CDFT_ERR_ARG, "cdft_moc_decomp: NULL argument");
     if (!p->mesh_set || !p->dec_set)

@@ -263,6 +263,7 @@ int cdft_mocsig_compute(const float *zv, const float *zveiv, const float *zt, co
                         int npjglo, int npk, int nbasins, float zspv, float zspt, float zsps, float pref, int eos,
                         int nbins, float sigmin, float sigstp, int in_space, double *dmoc, double *depi, int out_space,
                         void *stream) {
+    TraceRange trace_("cdft_mocsig_compute");
     if (!zv || !zt || !zs || !e1v || (!e3v && !e31d) || !ibmask || !dmoc) return fail(CDFT_ERR_ARG, "cdft_mocsig_compute: NULL argument");
     if (npiglo < 1 || npjglo < 1 || npk < 2 || nbasins < 1 || nbasins > 8 || nbins < 1 || nbins > 2048 || !(sigstp > 0.f))
         return fail(CDFT_ERR_ARG, "cdft_mocsig_compute: bad sizes or binning (%d x %d x %d, %d basins, %d bins)", npiglo, npjglo,

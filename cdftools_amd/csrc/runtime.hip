@@ -1,4 +1,6 @@
 // runtime.hip -- device/runtime entry points of the C ABI (include/cdftools_hip.h, "runtime").
+#include <dlfcn.h>
+#include <cstdlib>
 #include "common.hpp"
 
 namespace cdft {
@@ -67,6 +69,30 @@ int to_device(const void *src, size_t n, int memspace, DevBuf &stage, hipStream_
 struct Timer {
     hipEvent_t t0, t1;
 };
+
+namespace {
+typedef int (*roctx_push_t)(const char *);
+typedef int (*roctx_pop_t)(void);
+roctx_push_t g_push = nullptr;
+roctx_pop_t  g_pop = nullptr;
+bool roctx_ready() {
+    static const bool ok = [] {
+        const char *e = getenv("CDFT_ROCTX");
+        if (!e || e[0] != '1') return false;
+        void *h = nullptr;
+        for (const char *lib : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"})
+            if ((h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL)) != nullptr) break;
+        if (!h) return false;
+        g_push = (roctx_push_t)dlsym(h, "roctxRangePushA");
+        g_pop  = (roctx_pop_t)dlsym(h, "roctxRangePop");
+        return g_push && g_pop;
+    }();
+    return ok;
+}
+}  // namespace
+
+TraceRange::TraceRange(const char *name) : on(roctx_ready()) { if (on) (void)g_push(name); }
+TraceRange::~TraceRange() { if (on) (void)g_pop(); }
 
 }  // namespace cdft
 

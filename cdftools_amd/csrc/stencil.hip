@@ -491,6 +491,7 @@ int cdft_vt_compute(const float *u, const float *v, const float *t, const float 
                     const float *e3v, int64_t fstride, int nframes, int npiglo, int npjglo, int npk, int in_space,
                     void *vt, void *vs, void *ut, void *us, void *e3um, void *e3vm, int out_is_r4, int out_space,
                     void *stream) {
+    TraceRange trace_("cdft_vt_compute");
     if (!u || !v || !t || !s || !vt || !vs || !ut || !us)
         return fail(CDFT_ERR_ARG, "cdft_vt_compute: NULL argument");
     const bool vvl = e3u != nullptr;
@@ -598,6 +599,7 @@ int cdft_curl_set_mesh(cdft_curl_plan *p, const float *e1u, const float *e2v, co
 
 int cdft_curl_compute(cdft_curl_plan *p, const float *un, const float *vn, int nlev, int in_space, int ltpoint,
                       void *out, int out_is_r8, int out_space, void *stream) {
+    TraceRange trace_("cdft_curl_compute");
     if (!p || !un || !vn || !out) return fail(CDFT_ERR_ARG, "cdft_curl_compute: NULL argument");
     if (!p->mesh_set) return fail(CDFT_ERR_STATE, "cdft_curl_compute: cdft_curl_set_mesh has not succeeded");
     if (nlev < 1) return fail(CDFT_ERR_ARG, "cdft_curl_compute: nlev = %d", nlev);

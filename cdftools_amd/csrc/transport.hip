@@ -588,6 +588,7 @@ int cdft_mhst_set_mesh(cdft_mhst_plan *p, const float *e1v, const float *e3v, co
 int cdft_mhst_compute(cdft_mhst_plan *p, const float *vt, const float *vs, const float *zv, const float *zt,
                       const float *zs, int in_space, int zdim, double *heat, double *salt, int out_space,
                       void *stream) {
+    TraceRange trace_("cdft_mhst_compute");
     if (!p || !heat || !salt) return fail(CDFT_ERR_ARG, "cdft_mhst_compute: NULL argument");
     if (!p->mesh_set) return fail(CDFT_ERR_STATE, "cdft_mhst_compute: cdft_mhst_set_mesh has not succeeded");
     const bool sep = (vt == nullptr);
@@ -921,6 +922,7 @@ int cdft_psi_finish(cdft_psi_plan *p, int use_ref, double ref_value, int iiref, 
 int cdft_psi_compute(cdft_psi_plan *p, const float *zu, const float *e2u, const float *e3u, const float *zv,
                      const float *e1v, const float *e3v, const float *e31d, int iiref, int ijref,
                      const float *fmask, int in_space, float *psi4, double *dpsi8, int out_space, void *stream) {
+    TraceRange trace_("cdft_psi_compute");
     if (!p || !psi4) return fail(CDFT_ERR_ARG, "cdft_psi_compute: NULL argument");
     if (iiref < 1 || iiref > p->npi || ijref < 1 || ijref > p->npj)
         return fail(CDFT_ERR_ARG, "cdft_psi_compute: reference point (%d,%d) outside the domain", iiref, ijref);

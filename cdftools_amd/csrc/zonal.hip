@@ -563,6 +563,7 @@ int cdft_zonal_set_mesh(cdft_zonal_plan *p, const float *e1, const float *e2, co
 
 int cdft_zonal_compute(cdft_zonal_plan *p, const float *zv, int nlev, int in_space, int mean_form, double *dzo,
                        double *darea, float *rzomax, float *rzomin, int out_space, void *stream) {
+    TraceRange trace_("cdft_zonal_compute");
     if (!p || !zv || !dzo) return fail(CDFT_ERR_ARG, "cdft_zonal_compute: NULL argument");
     if (!p->mesh_set) return fail(CDFT_ERR_STATE, "cdft_zonal_compute: cdft_zonal_set_mesh has not succeeded");
     if (nlev < 1 || nlev > p->npk) return fail(CDFT_ERR_ARG, "cdft_zonal_compute: nlev = %d outside 1..%d", nlev, p->npk);
