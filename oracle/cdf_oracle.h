@@ -21,6 +21,7 @@
  *   - cdfmocsig (+ -isodep, -eiv, -full, -ntr, TEOS-10), cdfmean (+ basins, -var, -S, -full), cdfsum (model / forcing
  *     form, -nowght -nomsk), cdfzonalsum (+ -pdeg), cdfzonalmean (+ -max), cdfvint (model / GSOP / OCCIPUT depths, means,
  *     -full), cdfvertmean, cdfvhst, cdfvtrp : PINNED the same way (tests/test_lift_next.py).
+ *   - the level loops of cdfsig0 / cdfsigi (oracle_sig_tool) : PINNED the same way (tests/golden/lift_cdfsig.npz).
  *
  * Arrays are Fortran column-major (first index fastest), as in include/cdftools_hip.h.
  */

@@ -79,6 +79,8 @@ SHAS = {
     "cdfmocsig.f90": {'40-108': '9b8d04603f1640c1', '255-261': '37870c2cf98ed885', '299-304': '24fccd9c0d50516c',
                       '308-323': 'd5334578d236b66e', '325-328': 'ab5348a0318ad2fd', '342-342': 'bc3b9905f14f22c2',
                       '347-359': 'bda9394497041e7f', '361-476': '2a40e249c283bba6', '477-485': '1a302182f99b7d53'},
+    "cdfsig0.f90": {'25-51': '70cc5ee89f5abbd9', '132-134': 'd7f186c3f2f1c40e', '139-155': 'e6971df41b8c61f4'},
+    "cdfsigi.f90": {'26-52': '9e777513b6fb83e8', '124-126': '6a9aca4456a24830', '130-145': '40727884d7f41266'},
 }
 
 
@@ -851,10 +853,64 @@ def gen_cdfmocsig():
     return t, t.expand(CDFMOCSIG)
 
 
+# =============================================================================================== cdfsig0, cdfsigi
+# The two thin callers of the EOS: src/cdfsig0.f90 declarations :25-51, ALLOCATE :132-134, the
+# time loop :139-155; src/cdfsigi.f90 declarations :26-52, ALLOCATE :124-126, the time loop :130-145.  Density through the
+# reference's eos module, as compiled where it lies.
+CDFSIG0 = r"""
+SUBROUTINE lift_cdfsig0(kpi, kpj, kpk, kpt, kteos10, psps, h_t, h_s, o_var) BIND(C, name='lift_cdfsig0')
+  USE ISO_C_BINDING
+  USE eos                      ! the reference's src/eos.f90, compiled where it lies
+  IMPLICIT NONE
+  INTEGER(C_INT), VALUE :: kpi, kpj, kpk, kpt, kteos10
+  REAL(C_FLOAT), VALUE :: psps
+  REAL(C_FLOAT), INTENT(in) :: h_t(kpi,kpj,kpk,kpt), h_s(kpi,kpj,kpk,kpt)
+  REAL(C_FLOAT), INTENT(out) :: o_var(kpi,kpj,kpk,kpt)        ! zsig0 as handed to putvar
+!@DECLS 25 51
+  npiglo = kpi ; npjglo = kpj ; npk = kpk ; npkk = kpk ; npt = kpt ; ll_teos10 = ( kteos10 /= 0 ) ; zsps = psps
+  CALL eos_init ( ll_teos10 )                              ! src/cdfsig0.f90:110
+!@RAW 132 134
+  dtim(:) = 0.d0
+!@LIFT 139 155
+END SUBROUTINE lift_cdfsig0
+"""
+
+
+def gen_cdfsig0():
+    t = Tool("cdfsig0.f90", {"cv_tem": "h_t", "cv_sal": "h_s"},
+             putvar=lambda pos, kw: f"o_var(:,:,{pos[3]},{kw.get('ktime', '1')}) = {pos[2]}")
+    return t, t.expand(CDFSIG0)
+
+
+CDFSIGI = r"""
+SUBROUTINE lift_cdfsigi(kpi, kpj, kpk, kpt, kteos10, pref, pspval, h_t, h_s, o_var) BIND(C, name='lift_cdfsigi')
+  USE ISO_C_BINDING
+  USE eos                      ! the reference's src/eos.f90, compiled where it lies
+  IMPLICIT NONE
+  INTEGER(C_INT), VALUE :: kpi, kpj, kpk, kpt, kteos10
+  REAL(C_FLOAT), VALUE :: pref, pspval
+  REAL(C_FLOAT), INTENT(in) :: h_t(kpi,kpj,kpk,kpt), h_s(kpi,kpj,kpk,kpt)
+  REAL(C_FLOAT), INTENT(out) :: o_var(kpi,kpj,kpk,kpt)        ! zsigi as handed to putvar
+!@DECLS 26 52
+  npiglo = kpi ; npjglo = kpj ; npk = kpk ; npt = kpt ; ll_teos10 = ( kteos10 /= 0 ) ; ref_dep = pref ; zspval = pspval
+  CALL eos_init ( ll_teos10 )                              ! src/cdfsigi.f90:108
+!@RAW 124 126
+!@LIFT 130 145
+END SUBROUTINE lift_cdfsigi
+"""
+
+
+def gen_cdfsigi():
+    t = Tool("cdfsigi.f90", {"cn_votemper": "h_t", "cn_vosaline": "h_s"},
+             putvar=lambda pos, kw: f"o_var(:,:,{pos[3]},{kw.get('ktime', '1')}) = {pos[2]}")
+    return t, t.expand(CDFSIGI)
+
+
 TOOLS = {"cdfmoc": gen_cdfmoc, "cdfheatc": gen_cdfheatc, "cdfmhst": gen_cdfmhst, "cdfpsi": gen_cdfpsi, "cdfvt": gen_cdfvt,
          "cdfcurl": gen_cdfcurl, "cdfvhst": gen_cdfvhst, "cdfvtrp": gen_cdfvtrp, "cdfsum": gen_cdfsum,
          "cdfmean": gen_cdfmean, "cdfvertmean": gen_cdfvertmean, "cdfvint": gen_cdfvint,
-         "cdfzonalsum": gen_cdfzonalsum, "cdfzonalmean": gen_cdfzonalmean, "cdfmocsig": gen_cdfmocsig}
+         "cdfzonalsum": gen_cdfzonalsum, "cdfzonalmean": gen_cdfzonalmean, "cdfmocsig": gen_cdfmocsig,
+         "cdfsig0": gen_cdfsig0, "cdfsigi": gen_cdfsigi}
 
 
 def main():

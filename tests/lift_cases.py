@@ -209,3 +209,21 @@ def mocsig_fields():
     zt = (rnd(92, sh, -2, 28) * g["tmask"][None]).astype(f32)
     zs = (rnd(93, sh, 33, 37) * g["tmask"][None]).astype(f32)
     return g, zv, zt, zs
+
+
+# ---- cdfsig0 / cdfsigi (the two thin callers of the EOS): name, reference depth (None: cdfsig0), TEOS-10, missing value of S
+SIG_CASES = [("sig0", None, False, 0.0), ("sig0_teos10", None, True, 0.0), ("sig0_spval", None, False, -999.0),
+             ("sigi_2000", 2000.0, False, 0.0), ("sigi_3000_teos10", 3000.0, True, 0.0), ("sigi_1000_spval", 1000.0, False, -999.0)]
+
+
+def sig_fields(spval):
+    """T, S (npt,npk,npj,npi) r4: S = spval on land (also 0 on a few ocean-less points when spval is not 0: sigmai masks
+    on S == 0 by itself, the programs on S == spval)."""
+    g = synth.make_grid(26, 15, 6, seed=515)
+    sh = (2,) + g["tmask"].shape
+    zt = rnd(516, sh, -2, 30).astype(f32)
+    zs = rnd(517, sh, 30, 38).astype(f32)
+    land = np.broadcast_to(g["tmask"][None] == 0, sh)
+    zs = np.where(land, f32(spval), zs).astype(f32)
+    zs[0, 0, 0, :3] = 0.0
+    return zt, zs

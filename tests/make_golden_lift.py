@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Makes tests/golden/lift_*.npz: OUTPUTS of the reference-statement harness (oracle/_ref/liblift_ref.so, built by
-oracle/ref_build.sh from literal statements of the 15 loop programs under /root/reference/src with
+oracle/ref_build.sh from literal statements of the 17 loop programs under /root/reference/src with
 amdflang -O1 -ffp-contract=off; oracle/ref_lift.py says exactly what is lifted and what is harness) on the seeded
 cases of tests/lift_cases.py.  Run in the build container only; the .npz files travel, the reference does not.
 
@@ -103,6 +103,11 @@ def main():
                          eiv=(zv * np.float32(0.1)).astype(np.float32) if eiv else None, ntr=ntr, teos10=teos)
         d[f"{name}.var"], d[f"{name}.dmoc"], d[f"{name}.depi"] = r["var"], r["dmoc"], r["depi"]
     np.savez_compressed(os.path.join(out, "lift_cdfmocsig.npz"), **d)
+    d = {}
+    for name, pref, teos, spval in lc.SIG_CASES:
+        zt, zs = lc.sig_fields(spval)
+        d[name] = rl.cdfsig0(zt, zs, sps=spval, teos10=teos) if pref is None else rl.cdfsigi(zt, zs, pref, spval=spval, teos10=teos)
+    np.savez_compressed(os.path.join(out, "lift_cdfsig.npz"), **d)
     for f in sorted(os.listdir(out)):
         if f.startswith("lift_"):
             print(f, os.path.getsize(os.path.join(out, f)))

@@ -250,3 +250,21 @@ def cdfmocsig(g, zv, zt, zs, nbins, sigmin, sigstp, pref=0.0, nb=5, full=False, 
                           C.c_float(pref), C.c_float(spv[0]), C.c_float(spv[1]), C.c_float(spv[2]), *[_p(x) for x in a], _p(o_var), _p(o_dmoc),
                           _p(o_depi))
     return {"var": o_var, "dmoc": o_dmoc, "depi": o_depi}
+
+
+def cdfsig0(zt, zs, sps=0.0, teos10=False):
+    """zt, zs (npt,npk,npj,npi) r4 -> zsig0 (npt,npk,npj,npi) r4 as handed to putvar (src/cdfsig0.f90:139-155)."""
+    zt, zs = _f(zt), _f(zs)
+    npt, npk, npj, npi = zt.shape
+    o = np.zeros(zt.shape, np.float32)
+    load().lift_cdfsig0(*_i(npi, npj, npk, npt, teos10), C.c_float(sps), _p(zt), _p(zs), _p(o))
+    return o
+
+
+def cdfsigi(zt, zs, pref, spval=0.0, teos10=False):
+    """-> zsigi (npt,npk,npj,npi) r4 as handed to putvar (src/cdfsigi.f90:130-145)."""
+    zt, zs = _f(zt), _f(zs)
+    npt, npk, npj, npi = zt.shape
+    o = np.zeros(zt.shape, np.float32)
+    load().lift_cdfsigi(*_i(npi, npj, npk, npt, teos10), C.c_float(pref), C.c_float(spval), _p(zt), _p(zs), _p(o))
+    return o

@@ -297,6 +297,26 @@ def test_hip_mocsig_against_reference_statements(gpu, case):
     assert np.allclose(depi, G[f"{case[0]}.depi"], rtol=1e-10, atol=0)
 
 
+# ================================================================================================ cdfsig0, cdfsigi
+@pytest.mark.parametrize("case", lc.SIG_CASES, ids=[c[0] for c in lc.SIG_CASES])
+def test_oracle_sig_tool_equals_reference_statements(case):
+    """The level loops of cdfsig0 (src/cdfsig0.f90:139-155) and cdfsigi (src/cdfsigi.f90:130-145) -- mask on S == spval,
+    sigma0 / sigmai of the reference's compiled eos module, times the mask, stored in r4 -- against oracle_sig_tool."""
+    name, pref, teos, spval = case
+    zt, zs = lc.sig_fields(spval)
+    got = oracle_lib.sig_tool(zt, zs, pref=0.0 if pref is None else pref, spval=spval, teos10=teos)
+    assert got.dtype == f32 and same(got, gold("cdfsig")[name])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", lc.SIG_CASES, ids=[c[0] for c in lc.SIG_CASES])
+def test_hip_sig_tool_against_reference_statements(gpu, case):
+    name, pref, teos, spval = case
+    zt, zs = lc.sig_fields(spval)
+    got = gpu.sig_tool(zt, zs, pref=0.0 if pref is None else pref, spval=spval, eos=gpu.EOS_TEOS10 if teos else gpu.EOS_80)
+    assert got.dtype == f32 and same(got, gold("cdfsig")[name])
+
+
 # ================================================================================================ live pin
 @pytest.mark.skipif(not rl.available(), reason="oracle/_ref/liblift_ref.so is only built where /root/reference exists")
 def test_goldens_of_the_8f_tools_are_what_the_harness_returns_now():
