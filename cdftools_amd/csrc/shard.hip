@@ -83,6 +83,20 @@ int make(ShardSet **out, int npi, int npj, int npk, int nb, int ndev, const int 
             return fail(CDFT_ERR_HIP, "sharded plan: stream on device %d -> %s", devices[b], hipGetErrorString(e));
         }
     }
+    // Blocks on distinct devices exchange rows of resident arrays and cdfpsi's carry directly: let every device of the set,
+    // and the caller's current device (where a resident full-domain array lives), map the others' memory where the node
+    // allows it (xGMI / PCIe peer-to-peer).  Where it does not, the runtime stages the copies; "already enabled" is fine.
+    {
+        std::vector<int> ds(sh->dev);
+        ds.push_back(cur);
+        for (int a : ds)
+            for (int b : ds) {
+                int can = 0;
+                if (a == b || hipDeviceCanAccessPeer(&can, a, b) != hipSuccess || !can) { (void)hipGetLastError(); continue; }
+                if (hipSetDevice(a) == hipSuccess) (void)hipDeviceEnablePeerAccess(b, 0);
+                (void)hipGetLastError();
+            }
+    }
     (void)hipSetDevice(cur);
     *out = sh;
     return CDFT_OK;
