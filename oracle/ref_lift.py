@@ -48,7 +48,9 @@ IO_TOKEN = re.compile(r"\b(getvar|getvare3|getvar1d|putvar|putvar1d|putvar0d|clo
 SHAS = {
     "cdfmoc.f90": {'49-125': '3fefe705db05454d', '236-236': '75b30441aecc08bb', '272-278': '105e320aa63f3b97',
                    '281-304': 'e8ff1410b994b5fb', '306-314': '5c9fb47f8397cf47', '325-336': 'b805d15787c1cb5d',
-                   '338-518': '93b908f104591dd7', '519-570': '30dc9880c21c4367', '576-596': '4dddff438b339b54'},
+                   '338-518': '93b908f104591dd7', '519-570': '30dc9880c21c4367', '576-596': '4dddff438b339b54',
+                   '618-653': '254e9a3188c2bfa2', '683-690': 'be10b9f6d92d9d34', '692-705': 'bbcc7224fd6d58c3',
+                   '709-998': '7b7fa589a3f32135'},
     "cdfheatc.f90": {'24-67': 'f588c6224654319f', '177-186': '4e0de2a06c88c8d6', '188-192': 'b770d4ce667f8e40',
                      '196-248': '1c9fc2a727732949'},
     "cdfmhst.f90": {'34-103': '7ef454039bb47b19', '256-274': 'c4130977d91a663b', '276-277': 'f20e8805749476d9',
@@ -853,6 +855,48 @@ def gen_cdfmocsig():
     return t, t.expand(CDFMOCSIG)
 
 
+# =============================================================================================== cdfmoc -rapid
+# src/cdfmoc.f90, SUBROUTINE rapid_amoc (:598-1004), contained in the program: its own declarations :618-653 (the USE of
+# cdftools, :617, is for cdf_findij, which the harness replaces by the section's indices), ALLOCATE :683-690, the metric /
+# mask reads :692-705, the whole time loop :709-998 (33 output variables).  Kept as an internal subroutine of the harness so
+# that its local gdept hides the program's, as in the reference.
+CDFMOC_RAPID = r"""
+SUBROUTINE lift_cdfmoc_rapid(kpi, kpigs, kpk, kpt, kfull, h_gphiv, h_e31d, h_e1v, h_gdepw, h_tmask, h_gdept, h_e3v, h_v, h_taux, &
+     &  h_t, h_s, o_var) BIND(C, name='lift_cdfmoc_rapid')
+  USE ISO_C_BINDING
+  IMPLICIT NONE
+  INTEGER(C_INT), VALUE :: kpi, kpigs, kpk, kpt, kfull          ! kpi: cells of the section (iiw..iie), kpigs: of its Gulf Stream part
+  REAL(C_FLOAT), INTENT(in) :: h_gphiv(kpi,1,1,1), h_e31d(kpk), h_e1v(kpi,1,1,1), h_gdepw(kpk), h_tmask(kpi,1,kpk,1), h_gdept(kpk)
+  REAL(C_FLOAT), INTENT(in) :: h_e3v(kpi,1,kpk,1), h_v(kpi,1,kpk,kpt), h_taux(kpi,1,1,kpt), h_t(kpi,1,kpk,kpt), h_s(kpi,1,kpk,kpt)
+  REAL(C_FLOAT), INTENT(out) :: o_var(33,kpk,kpt)                ! what putvar is handed, by output variable and level
+  LOGICAL :: lg_vvl = .FALSE.
+!@DECLS 49 125
+  npk = kpk ; npt = kpt ; lfull = ( kfull /= 0 ) ; lg_vvl = .FALSE.
+  o_var = 0.
+  CALL rapid_amoc
+CONTAINS
+  SUBROUTINE rapid_amoc
+!@DECLS 618 653
+    npiglo = kpi ; npigs = kpigs
+!@RAW 683 690
+!@LIFT 692 705
+!@LIFT 709 998
+  END SUBROUTINE rapid_amoc
+END SUBROUTINE lift_cdfmoc_rapid
+"""
+
+
+def gen_cdfmoc_rapid():
+    def put(pos, kw):
+        idx, lev = varidx(pos[1]), pos[3]
+        return f"o_var({idx}:{idx},{lev}:{lev},{kw.get('ktime', '1')}) = {pos[2]}"
+    t = Tool("cdfmoc.f90",
+             {"cn_gphiv": "h_gphiv", "cn_ve3t1d": "h_e31d", "cn_ve1v": "h_e1v", "cn_gdepw": "h_gdepw", "cn_tmask": "h_tmask",
+              "cn_gdept": "h_gdept", "cn_ve3v": "h_e3v", "cn_vomecrty": "h_v", "cn_sozotaux": "h_taux", "cn_votemper": "h_t",
+              "cn_vosaline": "h_s"}, putvar=put)
+    return t, t.expand(CDFMOC_RAPID)
+
+
 # =============================================================================================== cdfsig0, cdfsigi
 # The two thin callers of the EOS (SURVEY 8a rows a12 / a13): src/cdfsig0.f90 declarations :25-51, ALLOCATE :132-134, the
 # time loop :139-155; src/cdfsigi.f90 declarations :26-52, ALLOCATE :124-126, the time loop :130-145.  Density through the
@@ -910,7 +954,7 @@ TOOLS = {"cdfmoc": gen_cdfmoc, "cdfheatc": gen_cdfheatc, "cdfmhst": gen_cdfmhst,
          "cdfcurl": gen_cdfcurl, "cdfvhst": gen_cdfvhst, "cdfvtrp": gen_cdfvtrp, "cdfsum": gen_cdfsum,
          "cdfmean": gen_cdfmean, "cdfvertmean": gen_cdfvertmean, "cdfvint": gen_cdfvint,
          "cdfzonalsum": gen_cdfzonalsum, "cdfzonalmean": gen_cdfzonalmean, "cdfmocsig": gen_cdfmocsig,
-         "cdfsig0": gen_cdfsig0, "cdfsigi": gen_cdfsigi}
+         "cdfsig0": gen_cdfsig0, "cdfsigi": gen_cdfsigi, "cdfmoc_rapid": gen_cdfmoc_rapid}
 
 
 def main():

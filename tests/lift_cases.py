@@ -227,3 +227,28 @@ def sig_fields(spval):
     zs = np.where(land, f32(spval), zs).astype(f32)
     zs[0, 0, 0, :3] = 0.0
     return zt, zs
+
+
+# ---- cdfmoc -rapid: one section of ni cells, the first npigs of them the Gulf Stream part
+RAPID_NAMES = ["amoc_rapid", "tr_GS", "tr_THERM", "tr_AIW", "tr_UNADW", "tr_LNADW", "tr_BW", "Total_max_amoc_rapid", "tr_EKMAN", "tr_TOTAL",
+               "mean_v_total_section", "mean_v_Florida_section", "mean_v_MidOcean_section", "mean_T_total_section", "mean_T_Florida_section",
+               "mean_T_MidOcean_section", "mean_S_total_section", "mean_S_Florida_section", "mean_S_MidOcean_section", "MO_meanVtimesmeanT",
+               "MO_meanVtimesmeanS", "Total_temp_transport", "Florida_temp_transport", "MidOcean_temp_transport", "Ekman_temp_transport_SST",
+               "Ekman_temp_transport_T100", "Total_salt_transport", "Florida_salt_transport", "MidOcean_salt_transport",
+               "Ekman_salt_transport_SSS", "Ekman_salt_transport_S100", "Total_meanVtimesmeanT", "Total_meanVtimesmeanS"]
+RAPID_CASES = [("partial", False), ("full", True)]
+
+
+def rapid_case(name):
+    """A synthetic grid and the row / columns of a section across it (1-based iiw, iie, iigs, ij as cdf_findij would return
+    them): the fields of 2 records, with deep levels (gdept reaches 100 m and every depth class is met)."""
+    g = synth.make_grid(46, 9, 14, seed=2626)
+    scale = f32(5500.0) / f32(g["gdepw_1d"][-1] + g["e3t_1d"][-1])          # stretch the column to 5500 m
+    for k in ("gdepw_1d", "gdept_1d", "e3t_1d", "e3v_0", "e3t_0", "e3u_0"):
+        g[k] = (g[k] * scale).astype(f32)
+    sh = (2,) + g["tmask"].shape
+    v = rnd(27, sh, -0.5, 0.5).astype(f32)                                   # (not masked: the section code masks with tmask itself)
+    t = (rnd(28, sh, -2, 30) * g["tmask"][None]).astype(f32)
+    s = (rnd(29, sh, 30, 38) * g["tmask"][None]).astype(f32)
+    taux = (rnd(30, (2,) + g["e1v"].shape, -0.1, 0.1)).astype(f32)
+    return g, v, t, s, taux, (4, 41, 12, 5), dict(RAPID_CASES)[name]

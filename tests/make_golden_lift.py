@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Makes tests/golden/lift_*.npz: OUTPUTS of the reference-statement harness (oracle/_ref/liblift_ref.so, built by
-oracle/ref_build.sh from literal statements of the 17 loop programs under /root/reference/src with
+oracle/ref_build.sh from literal statements of 17 programs (18 harnesses) under /root/reference/src with
 amdflang -O1 -ffp-contract=off; oracle/ref_lift.py says exactly what is lifted and what is harness) on the seeded
 cases of tests/lift_cases.py.  Run in the build container only; the .npz files travel, the reference does not.
 
@@ -108,6 +108,13 @@ def main():
         zt, zs = lc.sig_fields(spval)
         d[name] = rl.cdfsig0(zt, zs, sps=spval, teos10=teos) if pref is None else rl.cdfsigi(zt, zs, pref, spval=spval, teos10=teos)
     np.savez_compressed(os.path.join(out, "lift_cdfsig.npz"), **d)
+    d = {}
+    for name, _ in lc.RAPID_CASES:
+        g, v, t, s, taux, (iiw, iie, iigs, ij), full = lc.rapid_case(name)
+        sl, j = slice(iiw - 1, iie), ij - 1
+        d[name] = rl.cdfmoc_rapid(g["gphiv"][j, sl], g["e1v"][j, sl], g["gdepw_1d"], g["gdept_1d"], g["e3t_1d"], g["tmask"][:, j, sl],
+                                  g["e3v_0"][:, j, sl], v[:, :, j, sl], taux[:, j, sl], t[:, :, j, sl], s[:, :, j, sl], iigs - iiw + 1, full=full)
+    np.savez_compressed(os.path.join(out, "lift_cdfmoc_rapid.npz"), **d)
     for f in sorted(os.listdir(out)):
         if f.startswith("lift_"):
             print(f, os.path.getsize(os.path.join(out, f)))

@@ -268,3 +268,14 @@ def cdfsigi(zt, zs, pref, spval=0.0, teos10=False):
     o = np.zeros(zt.shape, np.float32)
     load().lift_cdfsigi(*_i(npi, npj, npk, npt, teos10), C.c_float(pref), C.c_float(spval), _p(zt), _p(zs), _p(o))
     return o
+
+
+def cdfmoc_rapid(gphiv, e1v, gdepw, gdept, e31d, tmask, e3v, v, taux, t, s, npigs, full=False):
+    """The Rapid section alone (src/cdfmoc.f90:598-1004): gphiv, e1v (ni); tmask, e3v (npk,ni); v, t, s (npt,npk,ni); taux (npt,ni)
+    -> what putvar is handed, (npt,npk,33) r4 (variable 1 has every level, the others level 1)."""
+    v = _f(v)
+    npt, npk, ni = v.shape
+    o = np.zeros((npt, npk, 33), np.float32)
+    a = [_f(gphiv), _f(e31d), _f(e1v), _f(gdepw), _f(np.asarray(tmask, np.float32)), _f(gdept), _f(e3v), v, _f(taux), _f(t), _f(s)]
+    load().lift_cdfmoc_rapid(*_i(ni, npigs, npk, npt, full), *[_p(x) for x in a], _p(o))
+    return o

@@ -208,3 +208,36 @@ def test_cdfmoc_rapid_full_step_and_missing_files(tools, tmp_path):  # noqa: F81
     ref = numpy_rapid(g2, v[0], t[0], s[0], taux[0], iiw, iie, iigs, ij)
     for nm in ("amoc_rapid", "tr_GS", "tr_TOTAL", "mean_S_MidOcean_section", "Total_meanVtimesmeanT"):
         assert np.array_equal(var[nm][0].ravel(), np.atleast_1d(ref[nm])), nm
+
+
+# ---------------------------------------------------------------------------------------------- the pin of numpy_rapid
+import lift_cases as lc  # noqa: E402
+
+WIND = ("tr_EKMAN", "Ekman_temp_transport_SST", "Ekman_temp_transport_T100", "Ekman_salt_transport_SSS", "Ekman_salt_transport_S100")
+
+
+@pytest.mark.parametrize("name", [c[0] for c in lc.RAPID_CASES])
+def test_numpy_rapid_equals_the_reference_statements(name):
+    """numpy_rapid above is what the cdfmoc -rapid program is held to; here it is held itself to the reference's own
+    statements: SUBROUTINE rapid_amoc of src/cdfmoc.f90 (:598-1004), lifted by oracle/ref_lift.py into a harness whose outputs
+    on a seeded section are tests/golden/lift_cdfmoc_rapid.npz.  Bit for bit, except the five wind-driven numbers, which go
+    through an r4 SIN / ATAN of the Fortran runtime (2e-6)."""
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lift_cdfmoc_rapid.npz"))[name]   # (npt,npk,33)
+    g, v, t, s, taux, (iiw, iie, iigs, ij), full = lc.rapid_case(name)
+    if full:                                                        # -full: e3v(:,jk) = e31d(jk) on the section
+        g = dict(g)
+        g["e3v_0"] = np.broadcast_to(g["e3t_1d"][:, None, None], g["e3v_0"].shape).astype(f32).copy()
+    met = set()
+    for rec in range(2):
+        ref = numpy_rapid(g, v[rec], t[rec], s[rec], taux[rec], iiw, iie, iigs, ij)
+        assert list(ref) and set(ref) == set(lc.RAPID_NAMES)
+        for n, nm in enumerate(lc.RAPID_NAMES):
+            want = gold[rec, :, n] if nm == "amoc_rapid" else gold[rec, 0, n]
+            got = ref[nm]
+            if nm in WIND:
+                assert np.allclose(got, want, rtol=2e-6, atol=0), (nm, got, want)
+            else:
+                assert np.array_equal(np.asarray(got, f32), np.asarray(want, f32)), (nm, got, want)
+            if nm.startswith("tr_") and float(np.ravel(want)[0]) != 0.0:
+                met.add(nm)
+    assert {"tr_THERM", "tr_AIW", "tr_UNADW", "tr_LNADW"} <= met      # the depth classes of the section are not empty
