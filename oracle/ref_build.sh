@@ -27,13 +27,13 @@ if [ ! -f _ref/liblift_ref.so ] || [ ref_lift.py -nt _ref/liblift_ref.so ] || [ 
   if [ -n "$KEEP_LIFT_SRC" ]; then gen=_ref; else gen=$(mktemp -d /tmp/cdft_lift.XXXXXX); fi
   python3 ref_lift.py --out "$gen"
   objs=""
-  for t in cdfmoc cdfheatc cdfmhst cdfpsi cdfvt cdfcurl cdfvhst cdfvtrp cdfsum cdfmean cdfvertmean cdfvint cdfzonalsum cdfzonalmean cdfmocsig cdfsig0 cdfsigi cdfmoc_rapid; do
+  for t in cdfmoc cdfheatc cdfmhst cdfpsi cdfvt cdfcurl cdfvhst cdfvtrp cdfsum cdfmean cdfvertmean cdfvint cdfzonalsum cdfzonalmean cdfmocsig cdfsig0 cdfsigi cdfmoc_rapid cdfmaxmoc; do
     $FC -O1 -fPIC -ffp-contract=off -module-dir _ref -I_ref -c "$gen"/lift_$t.f90 -o _ref/lift_$t.o
     objs="$objs _ref/lift_$t.o"
   done
   $FC -shared _ref/eos.o $objs -o _ref/liblift_ref.so
   [ -n "$KEEP_LIFT_SRC" ] || rm -rf "$gen"
-  echo "oracle/_ref/liblift_ref.so built from literal statements of 17 programs (18 harnesses: cdfmoc also gives its -rapid branch) under $REF"
+  echo "oracle/_ref/liblift_ref.so built from literal statements of 18 programs (19 harnesses: cdfmoc also gives its -rapid branch) under $REF"
 else
   echo "oracle/_ref/liblift_ref.so up to date"
 fi

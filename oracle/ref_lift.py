@@ -81,6 +81,8 @@ SHAS = {
     "cdfmocsig.f90": {'40-108': '9b8d04603f1640c1', '255-261': '37870c2cf98ed885', '299-304': '24fccd9c0d50516c',
                       '308-323': 'd5334578d236b66e', '325-328': 'ab5348a0318ad2fd', '342-342': 'bc3b9905f14f22c2',
                       '347-359': 'bda9394497041e7f', '361-476': '2a40e249c283bba6', '477-485': '1a302182f99b7d53'},
+    "cdfmaxmoc.f90": {'28-59': 'b55b09bb29db5292', '122-122': '8aa24a0caec32bf0', '123-124': '347ce8e20ebb08e9',
+                      '140-178': '195ad4300d453a07'},
     "cdfsig0.f90": {'25-51': '70cc5ee89f5abbd9', '132-134': 'd7f186c3f2f1c40e', '139-155': 'e6971df41b8c61f4'},
     "cdfsigi.f90": {'26-52': '9e777513b6fb83e8', '124-126': '6a9aca4456a24830', '130-145': '40727884d7f41266'},
 }
@@ -897,6 +899,33 @@ def gen_cdfmoc_rapid():
     return t, t.expand(CDFMOC_RAPID)
 
 
+# =============================================================================================== cdfmaxmoc
+# src/cdfmaxmoc.f90 (the consumer of moc.nc): declarations :28-59, ALLOCATE :122, depths and latitudes :123-124, the read of
+# the overturning and the window search :140-178 (six scalars to putvar0d).
+CDFMAXMOC = r"""
+SUBROUTINE lift_cdfmaxmoc(kpj, kpk, platmin, platmax, pdepmin, pdepmax, h_depw, h_lat, h_moc, o_var) BIND(C, name='lift_cdfmaxmoc')
+  USE ISO_C_BINDING
+  IMPLICIT NONE
+  INTEGER(C_INT), VALUE :: kpj, kpk
+  REAL(C_FLOAT), VALUE :: platmin, platmax, pdepmin, pdepmax
+  REAL(C_DOUBLE), INTENT(in) :: h_depw(kpk)                     ! depthw of moc.nc as getvar1d returns it (r8, negative downwards)
+  REAL(C_FLOAT), INTENT(in) :: h_lat(1,kpj,1,1), h_moc(1,kpj,kpk,1)
+  REAL(C_FLOAT), INTENT(out) :: o_var(6)                        ! maxmoc, minmoc, their latitudes, their depths
+!@DECLS 28 59
+  npjglo = kpj ; npk = kpk ; rlatmin = platmin ; rlatmax = platmax ; rdepmin = pdepmin ; rdepmax = pdepmax
+!@RAW 122 122
+!@LIFT 123 124
+!@LIFT 140 178
+END SUBROUTINE lift_cdfmaxmoc
+"""
+
+
+def gen_cdfmaxmoc():
+    t = Tool("cdfmaxmoc.f90", {"cn_vdepthw": "h_depw", "cn_vlat2d": "h_lat", "cv_in": "h_moc"})
+    t.putvar0d = lambda pos, kw: f"o_var({varidx(pos[1])}) = {pos[2]}"
+    return t, t.expand(CDFMAXMOC)
+
+
 # =============================================================================================== cdfsig0, cdfsigi
 # The two thin callers of the EOS (SURVEY 8a rows a12 / a13): src/cdfsig0.f90 declarations :25-51, ALLOCATE :132-134, the
 # time loop :139-155; src/cdfsigi.f90 declarations :26-52, ALLOCATE :124-126, the time loop :130-145.  Density through the
@@ -954,7 +983,8 @@ TOOLS = {"cdfmoc": gen_cdfmoc, "cdfheatc": gen_cdfheatc, "cdfmhst": gen_cdfmhst,
          "cdfcurl": gen_cdfcurl, "cdfvhst": gen_cdfvhst, "cdfvtrp": gen_cdfvtrp, "cdfsum": gen_cdfsum,
          "cdfmean": gen_cdfmean, "cdfvertmean": gen_cdfvertmean, "cdfvint": gen_cdfvint,
          "cdfzonalsum": gen_cdfzonalsum, "cdfzonalmean": gen_cdfzonalmean, "cdfmocsig": gen_cdfmocsig,
-         "cdfsig0": gen_cdfsig0, "cdfsigi": gen_cdfsigi, "cdfmoc_rapid": gen_cdfmoc_rapid}
+         "cdfsig0": gen_cdfsig0, "cdfsigi": gen_cdfsigi, "cdfmoc_rapid": gen_cdfmoc_rapid,
+         "cdfmaxmoc": gen_cdfmaxmoc}
 
 
 def main():

@@ -252,3 +252,18 @@ def rapid_case(name):
     s = (rnd(29, sh, 30, 38) * g["tmask"][None]).astype(f32)
     taux = (rnd(30, (2,) + g["e1v"].shape, -0.1, 0.1)).astype(f32)
     return g, v, t, s, taux, (4, 41, 12, 5), dict(RAPID_CASES)[name]
+
+
+# ---- cdfmaxmoc: windows (latmin, latmax, depmin, depmax) over one synthetic overturning
+# (depths positive downwards: the program reads depthw, stored negative in moc.nc, as gdepw = -depthw, src/cdfmaxmoc.f90:123)
+MAXMOC_WINDOWS = [(-30.0, 60.0, 20.0, 5000.0), (0.0, 60.0, 0.0, 5000.0), (20.0, 30.0, 300.0, 1200.0), (-70.0, -35.0, 2000.0, 6000.0)]
+
+
+def maxmoc_fields():
+    """depthw (npk) r8, negative as cdfmoc writes it; nav_lat (npj) r4 increasing; zomsfatl (npk,npj) r4."""
+    npk, npj = 14, 41
+    depw = -np.concatenate([[0.0], np.cumsum(np.linspace(10, 900, npk - 1))])
+    lat = np.linspace(-77.5, 88.0, npj).astype(f32)
+    moc = (rnd(4141, (npk, npj), -12, 22)).astype(f32)
+    moc[0] = 0
+    return depw, lat, moc

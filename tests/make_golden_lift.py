@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Makes tests/golden/lift_*.npz: OUTPUTS of the reference-statement harness (oracle/_ref/liblift_ref.so, built by
-oracle/ref_build.sh from literal statements of 17 programs (18 harnesses) under /root/reference/src with
+oracle/ref_build.sh from literal statements of 18 programs (19 harnesses) under /root/reference/src with
 amdflang -O1 -ffp-contract=off; oracle/ref_lift.py says exactly what is lifted and what is harness) on the seeded
 cases of tests/lift_cases.py.  Run in the build container only; the .npz files travel, the reference does not.
 
@@ -115,6 +115,8 @@ def main():
         d[name] = rl.cdfmoc_rapid(g["gphiv"][j, sl], g["e1v"][j, sl], g["gdepw_1d"], g["gdept_1d"], g["e3t_1d"], g["tmask"][:, j, sl],
                                   g["e3v_0"][:, j, sl], v[:, :, j, sl], taux[:, j, sl], t[:, :, j, sl], s[:, :, j, sl], iigs - iiw + 1, full=full)
     np.savez_compressed(os.path.join(out, "lift_cdfmoc_rapid.npz"), **d)
+    depw, lat, moc = lc.maxmoc_fields()
+    np.savez_compressed(os.path.join(out, "lift_cdfmaxmoc.npz"), six=np.stack([rl.cdfmaxmoc(depw, lat, moc, *w) for w in lc.MAXMOC_WINDOWS]))
     for f in sorted(os.listdir(out)):
         if f.startswith("lift_"):
             print(f, os.path.getsize(os.path.join(out, f)))

@@ -279,3 +279,14 @@ def cdfmoc_rapid(gphiv, e1v, gdepw, gdept, e31d, tmask, e3v, v, taux, t, s, npig
     a = [_f(gphiv), _f(e31d), _f(e1v), _f(gdepw), _f(np.asarray(tmask, np.float32)), _f(gdept), _f(e3v), v, _f(taux), _f(t), _f(s)]
     load().lift_cdfmoc_rapid(*_i(ni, npigs, npk, npt, full), *[_p(x) for x in a], _p(o))
     return o
+
+
+def cdfmaxmoc(depw8, lat, moc, latmin, latmax, depmin, depmax):
+    """depw8 (npk) r8 as stored in moc.nc (negative), lat (npj), moc (npk,npj) r4 -> the six numbers handed to putvar0d."""
+    moc = _f(moc)
+    npk, npj = moc.shape
+    d8 = np.ascontiguousarray(depw8, np.float64)
+    o = np.zeros(6, np.float32)
+    load().lift_cdfmaxmoc(*_i(npj, npk), C.c_float(latmin), C.c_float(latmax), C.c_float(depmin), C.c_float(depmax), _p(d8), _p(_f(lat)),
+                          _p(moc), _p(o))
+    return o

@@ -325,3 +325,38 @@ def test_goldens_of_the_8f_tools_are_what_the_harness_returns_now():
     assert same(rl.cdfvtrp(g, u, v)[:, :2], gold("cdfvhst_cdfvtrp")["vtrp.default"])
     assert same(rl.cdfzonalsum(g, g["e1t"], g["e2t"], g["gphiv"], g["gdept_1d"], tm, t, nb=5)["r8"], gold("cdfzonal")["sum.b5.r8"])
     assert same(rl.cdfvertmean(g["gdepw_1d"], g["e3t_1d"], g["e3t_0"], tm, t, 15.0, 120.0), gold("cdfvint_cdfvertmean")["vertmean.15_120"])
+
+
+# ================================================================================================ cdfmaxmoc (host program)
+def test_cdfmaxmoc_program_equals_reference_statements(tmp_path):
+    """cdfmaxmoc is host code (it reads a moc.nc and searches a window): the program itself runs here, on a moc.nc written by
+    scipy, and its six numbers equal those of the harness around the reference's own statements (src/cdfmaxmoc.f90:122-178)."""
+    import os
+    import subprocess
+    from scipy.io import netcdf_file
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "cdftools_amd", "bin", "cdfmaxmoc")
+    if not os.path.exists(exe):
+        pytest.skip("cdftools_amd/bin/cdfmaxmoc is not built")
+    depw, lat, moc = lc.maxmoc_fields()
+    npk, npj = moc.shape
+    d = str(tmp_path)
+    f = netcdf_file(os.path.join(d, "moc.nc"), "w", version=2)
+    f.createDimension("time_counter", None)
+    f.createDimension("depthw", npk)
+    f.createDimension("y", npj)
+    f.createDimension("x", 1)
+    for nm, vals in (("nav_lon", np.zeros((npj, 1), f32)), ("nav_lat", lat[:, None])):
+        v = f.createVariable(nm, "f4", ("y", "x")); v[:] = vals
+    v = f.createVariable("depthw", "f4", ("depthw",)); v[:] = depw.astype(f32)
+    v = f.createVariable("time_counter", "f8", ("time_counter",)); v[:] = np.array([86400.0])
+    v = f.createVariable("zomsfatl", "f4", ("time_counter", "depthw", "y", "x")); v[:] = moc[None, :, :, None]
+    f.close()
+    want = gold("cdfmaxmoc")["six"]
+    for n, w in enumerate(lc.MAXMOC_WINDOWS):
+        r = subprocess.run([exe, "-f", "moc.nc", "-b", "atl", "-w"] + [repr(x) for x in w] + ["-o", f"max{n}.nc"], cwd=d, capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        o = netcdf_file(os.path.join(d, f"max{n}.nc"), "r", mmap=False)
+        got = np.array([o.variables[k][:].ravel()[0] for k in ("maxmoc", "minmoc", "latmaxmoc", "latminmoc", "depthmaxmoc", "depthminmoc")], f32)
+        o.close()
+        assert same(got, want[n]), (w, got, want[n])
