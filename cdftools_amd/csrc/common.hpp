@@ -31,12 +31,16 @@ struct DevBuf {
 int to_device(const void *src, size_t n, int memspace, DevBuf &stage, hipStream_t st,
               const void **dev);
 
-// A named range around a C-ABI call for rocprofv3 --marker-trace (roctx).  Off unless CDFT_ROCTX=1 is in the environment
-// when the first range is made; the roctx library is looked up at run time (no link dependency, nothing when it is absent).
+// A named range around a C-ABI call.  CDFT_ROCTX=1: a roctx range for rocprofv3 --marker-trace (the roctx library is looked
+// up at run time: no link dependency, nothing when it is absent).  CDFT_TIMING=1: the wall time of the call (as the caller
+// sees it: a call that returns host results includes its stream synchronisation) is added to a per-entry total, printed
+// on stderr when the process ends.  Both are read from the environment when the first range is made; neither touches stdout.
 struct TraceRange {
     explicit TraceRange(const char *name);
     ~TraceRange();
-    bool on;
+    const char *name;
+    bool on, timed;
+    double t0;
 };
 
 // Streaming loads.  Every kernel of this path reads its 3-D fields exactly once; a nontemporal

@@ -1,6 +1,8 @@
 // runtime.hip -- device/runtime entry points of the C ABI (include/cdftools_hip.h, "runtime").
 #include <dlfcn.h>
+#include <chrono>
 #include <cstdlib>
+#include <mutex>
 #include "common.hpp"
 
 namespace cdft {
@@ -91,8 +93,43 @@ bool roctx_ready() {
 }
 }  // namespace
 
-TraceRange::TraceRange(const char *name) : on(roctx_ready()) { if (on) (void)g_push(name); }
-TraceRange::~TraceRange() { if (on) (void)g_pop(); }
+namespace {
+struct TimingRow { const char *name; long calls; double seconds; };
+TimingRow g_rows[32];
+int g_nrows = 0;
+std::mutex g_timing_mutex;
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+void timing_report() {
+    for (int i = 0; i < g_nrows; ++i)
+        fprintf(stderr, " CDFT_TIMING library: %-24s %6ld call%s %10.3f ms\n", g_rows[i].name, g_rows[i].calls, g_rows[i].calls == 1 ? " " : "s",
+                g_rows[i].seconds * 1e3);
+}
+bool timing_ready() {
+    static const bool ok = [] {
+        const char *e = getenv("CDFT_TIMING");
+        if (!e || e[0] != '1') return false;
+        atexit(timing_report);
+        return true;
+    }();
+    return ok;
+}
+}  // namespace
+
+TraceRange::TraceRange(const char *nm) : name(nm), on(roctx_ready()), timed(timing_ready()), t0(0.0) {
+    if (on) (void)g_push(name);
+    if (timed) t0 = now_s();
+}
+TraceRange::~TraceRange() {
+    if (timed) {
+        const double dt = now_s() - t0;
+        std::lock_guard<std::mutex> lock(g_timing_mutex);
+        int i = 0;
+        while (i < g_nrows && g_rows[i].name != name) ++i;       // (the names are string literals: one address each)
+        if (i == g_nrows && g_nrows < 32) g_rows[g_nrows++] = TimingRow{name, 0, 0.0};
+        if (i < g_nrows) { g_rows[i].calls += 1; g_rows[i].seconds += dt; }
+    }
+    if (on) (void)g_pop();
+}
 
 }  // namespace cdft
 

@@ -46,6 +46,11 @@ MODULE cdfio
   CHARACTER(LEN=256) :: config = 'N/A', ccase = 'N/A'
   CHARACTER(LEN=10)  :: cfreq = 'N/A'
   LOGICAL            :: l_first_getdim = .TRUE.
+  ! CDFT_TIMING=1: wall time of the bulk reads (getvar, getvar3d, readvar3d) and slab writes (putvar), summed over the
+  ! run and printed on stderr by closeout (stdout stays what the reference prints)
+  INTEGER(KIND=4)    :: ntiming = -1                    ! -1 not asked yet, 0 off, 1 on
+  INTEGER(KIND=8)    :: nclock0
+  REAL(KIND=8)       :: dtime_read = 0.d0, dtime_write = 0.d0
 
   INTERFACE putvar
      MODULE PROCEDURE putvarr8, putvarr4, putvari2, putvarzo, reputvarr4, putvare3
@@ -78,6 +83,23 @@ CONTAINS
        STOP 98
     ENDIF
   END SUBROUTINE ERR_HDL
+
+  SUBROUTINE tic()
+    CHARACTER(LEN=8) :: cl
+    IF ( ntiming < 0 ) THEN
+       CALL GET_ENVIRONMENT_VARIABLE('CDFT_TIMING', cl)
+       ntiming = MERGE(1, 0, cl(1:1) == '1')
+    ENDIF
+    IF ( ntiming == 1 ) CALL SYSTEM_CLOCK(nclock0)
+  END SUBROUTINE tic
+
+  SUBROUTINE toc(dtotal)
+    REAL(KIND=8), INTENT(inout) :: dtotal
+    INTEGER(KIND=8) :: iclock, irate
+    IF ( ntiming /= 1 ) RETURN
+    CALL SYSTEM_CLOCK(iclock, irate)
+    dtotal = dtotal + DBLE(iclock - nclock0) / DBLE(irate)
+  END SUBROUTINE toc
 
   FUNCTION iom_name(cdvar) RESULT(clvar)
     ! name of a vertical metric in mesh_zgr for the detected layout (src/cdfio.F90:1510-1536)
@@ -504,6 +526,7 @@ CONTAINS
        ipiglo = getdim(cdfile, cn_x, ldexact=.TRUE.)
        llperio = ( imin + kpi - 1 > ipiglo )
     ENDIF
+    CALL tic()
     CALL ERR_HDL(NF90_OPEN(cdfile, NF90_NOWRITE, incid))
     CALL ERR_HDL(NF90_INQ_VARID(incid, clvar, id_var))
     istart = (/ imin, jmin, 1, 1 /) ; icount = (/ kpi, kpj, 1, 1 /)
@@ -527,6 +550,7 @@ CONTAINS
     IF ( lao  ) WHERE ( getvar /= zspval ) getvar = getvar + zao
     IF ( llog ) WHERE ( getvar /= zspval ) getvar = 10**getvar
     istatus = NF90_CLOSE(incid)
+    CALL toc(dtime_read)
   END FUNCTION getvar
 
   FUNCTION getvar3d(cdfile, cdvar, kpi, kpj, kpk, kimin, kjmin, kkmin, ktime, ldiom)
@@ -549,6 +573,7 @@ CONTAINS
     IF ( PRESENT(ldiom) ) THEN
        IF ( ldiom ) clvar = iom_name(cdvar)
     ENDIF
+    CALL tic()
     CALL ERR_HDL(NF90_OPEN(cdfile, NF90_NOWRITE, incid))
     CALL ERR_HDL(NF90_INQ_VARID(incid, clvar, id_var))
     CALL find_spval(incid, id_var, zspval)
@@ -562,6 +587,7 @@ CONTAINS
     IF ( lao  ) WHERE ( getvar3d /= zspval ) getvar3d = getvar3d + zao
     IF ( llog ) WHERE ( getvar3d /= zspval ) getvar3d = 10**getvar3d
     istatus = NF90_CLOSE(incid)
+    CALL toc(dtime_read)
   END FUNCTION getvar3d
 
   SUBROUTINE readvar3d(cdfile, cdvar, ptab, ktime, ldiom, kimin, kjmin, kkmin)
@@ -594,6 +620,7 @@ CONTAINS
           RETURN
        ENDIF
     ENDIF
+    CALL tic()
     CALL ERR_HDL(NF90_OPEN(cdfile, NF90_NOWRITE, incid))
     CALL ERR_HDL(NF90_INQ_VARID(incid, clvar, id_var))
     CALL find_spval(incid, id_var, zspval)
@@ -611,6 +638,7 @@ CONTAINS
     IF ( lao  ) WHERE ( ptab /= zspval ) ptab = ptab + zao
     IF ( llog ) WHERE ( ptab /= zspval ) ptab = 10**ptab
     istatus = NF90_CLOSE(incid)
+    CALL toc(dtime_read)
   END SUBROUTINE readvar3d
 
   SUBROUTINE readvar3d_i1(cdfile, cdvar, ktab, ktime)
@@ -620,6 +648,7 @@ CONTAINS
     INTEGER(KIND=4), OPTIONAL, INTENT(in)  :: ktime
     INTEGER(KIND=4) :: incid, id_var, istatus, itime
     itime = 1 ; IF ( PRESENT(ktime) ) itime = ktime
+    CALL tic()
     CALL ERR_HDL(NF90_OPEN(cdfile, NF90_NOWRITE, incid))
     CALL ERR_HDL(NF90_INQ_VARID(incid, cdvar, id_var))
     istatus = NF90_GET_VAR(incid, id_var, ktab, start=(/ 1, 1, 1, itime /), count=(/ SIZE(ktab,1), SIZE(ktab,2), SIZE(ktab,3), 1 /))
@@ -628,6 +657,7 @@ CONTAINS
        CALL ERR_HDL(istatus)
     ENDIF
     istatus = NF90_CLOSE(incid)
+    CALL toc(dtime_read)
   END SUBROUTINE readvar3d_i1
 
   FUNCTION getvar1d(cdfile, cdvar, kk, kstatus)
@@ -984,9 +1014,11 @@ CONTAINS
     INTEGER(KIND=4), OPTIONAL,        INTENT(in) :: ktime, kwght
     INTEGER(KIND=4) :: itime, istart(4)
     itime = 1 ; IF ( PRESENT(ktime) ) itime = ktime
+    CALL tic()
     CALL slab_start(kout, kid, klev, itime, istart)
     putvarr8 = NF90_PUT_VAR(kout, kid, ptab, start=istart, count=(/ kpi, kpj, 1, 1 /))
     IF ( PRESENT(kwght) ) putvarr8 = NF90_PUT_ATT(kout, kid, 'iweight', kwght)
+    CALL toc(dtime_write)
   END FUNCTION putvarr8
 
   INTEGER(KIND=4) FUNCTION putvarr4(kout, kid, ptab, klev, kpi, kpj, ktime, kwght)
@@ -995,9 +1027,11 @@ CONTAINS
     INTEGER(KIND=4), OPTIONAL,        INTENT(in) :: ktime, kwght
     INTEGER(KIND=4) :: itime, istart(4)
     itime = 1 ; IF ( PRESENT(ktime) ) itime = ktime
+    CALL tic()
     CALL slab_start(kout, kid, klev, itime, istart)
     putvarr4 = NF90_PUT_VAR(kout, kid, ptab, start=istart, count=(/ kpi, kpj, 1, 1 /))
     IF ( PRESENT(kwght) ) putvarr4 = NF90_PUT_ATT(kout, kid, 'iweight', kwght)
+    CALL toc(dtime_write)
   END FUNCTION putvarr4
 
   INTEGER(KIND=4) FUNCTION putvari2(kout, kid, ktab, klev, kpi, kpj, ktime, kwght)
@@ -1006,9 +1040,11 @@ CONTAINS
     INTEGER(KIND=4), OPTIONAL,           INTENT(in) :: ktime, kwght
     INTEGER(KIND=4) :: itime, istart(4)
     itime = 1 ; IF ( PRESENT(ktime) ) itime = ktime
+    CALL tic()
     CALL slab_start(kout, kid, klev, itime, istart)
     putvari2 = NF90_PUT_VAR(kout, kid, ktab, start=istart, count=(/ kpi, kpj, 1, 1 /))
     IF ( PRESENT(kwght) ) putvari2 = NF90_PUT_ATT(kout, kid, 'iweight', kwght)
+    CALL toc(dtime_write)
   END FUNCTION putvari2
 
   INTEGER(KIND=4) FUNCTION putvarzo(kout, kid, ptab, klev, kpi, kpj, ktime)
@@ -1018,8 +1054,10 @@ CONTAINS
     INTEGER(KIND=4), OPTIONAL,  INTENT(in) :: ktime
     INTEGER(KIND=4) :: itime, istart(4)
     itime = 1 ; IF ( PRESENT(ktime) ) itime = ktime
+    CALL tic()
     CALL slab_start(kout, kid, klev, itime, istart)
     putvarzo = NF90_PUT_VAR(kout, kid, ptab, start=istart, count=(/ kpi, kpj, 1, 1 /))
+    CALL toc(dtime_write)
   END FUNCTION putvarzo
 
   INTEGER(KIND=4) FUNCTION putvar0dt(kout, kid, pvalue, ktime)
@@ -1499,7 +1537,10 @@ CONTAINS
 
   INTEGER(KIND=4) FUNCTION closeout(kout)
     INTEGER(KIND=4), INTENT(in) :: kout
+    CALL tic()
     closeout = NF90_CLOSE(kout)
+    CALL toc(dtime_write)
+    IF ( ntiming == 1 ) WRITE(0,'(a,f9.3,a,f9.3)') ' CDFT_TIMING cdfio (s): reads', dtime_read, '  writes', dtime_write
   END FUNCTION closeout
 
   INTEGER(KIND=4) FUNCTION ncopen(cdfile)

@@ -93,6 +93,21 @@ def run(tmp_path_factory):
     return d, out, (t, ssh, pk)
 
 
+def test_timing_switch_of_cdfio(run):
+    """CDFT_TIMING=1: the read / write wall-time totals on stderr at closeout, nothing else changes"""
+    d, _, _ = run
+    for f in ("new.nc",):
+        if os.path.exists(os.path.join(d, f)):
+            os.remove(os.path.join(d, f))
+    shutil.copy(os.path.join(d, "T.nc"), os.path.join(d, "edit.nc"))
+    r0 = subprocess.run([os.path.join(d, "cdfio_public"), d], capture_output=True, text=True, cwd=d)
+    shutil.copy(os.path.join(d, "T.nc"), os.path.join(d, "edit.nc"))
+    r1 = subprocess.run([os.path.join(d, "cdfio_public"), d], capture_output=True, text=True, cwd=d, env=dict(os.environ, CDFT_TIMING="1"))
+    assert r0.returncode == 0 and r1.returncode == 0
+    assert r1.stdout == r0.stdout and "CDFT_TIMING" not in r0.stderr
+    assert "CDFT_TIMING cdfio (s): reads" in r1.stderr and "writes" in r1.stderr
+
+
 def nums(s, shape=None):
     a = np.array(s.split(), dtype=np.float64).astype(f32)
     return a if shape is None else a.reshape(shape)          # Fortran order printed = reversed C shape

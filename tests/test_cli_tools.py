@@ -61,6 +61,29 @@ def test_cdfheatc_end_to_end(case):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("tool,args", [("cdfheatc", ["-f", "SYN_y0001_gridT.nc", "-o", "ht.nc"]), ("cdfsig0", ["-t", "SYN_y0001_gridT.nc", "-o", "s0t.nc"]),
+                                       ("cdfcurl", ["-u", "SYN_y0001_gridU.nc", "vozocrtx", "-v", "SYN_y0001_gridV.nc", "vomecrty", "-l", "1", "-o", "ct.nc"])])
+def test_timing_switch_reports_on_stderr_only(case, tool, args):
+    """CDFT_TIMING=1 (a phase-time switch that must not change stdout): cdfio's read / write totals and the library's
+    per-entry wall times go to stderr; stdout and the output file are those of a run without the switch."""
+    d, g, rec = case
+    rc0, out0, err0 = run(tool, args, d)
+    before = open(os.path.join(d, args[-1]), "rb").read()
+    rc1, out1, err1 = run(tool, args, d, env={"CDFT_TIMING": "1"})
+    assert rc0 == 0 and rc1 == 0, out1 + err1
+    assert out1 == out0 and "CDFT_TIMING" not in err0
+    assert "CDFT_TIMING cdfio (s): reads" in err1 and "CDFT_TIMING library: cdft_" in err1, err1
+    var0, var1 = read_nc_bytes(before, d), read_nc(os.path.join(d, args[-1]))[0]
+    assert all(np.array_equal(var0[k], var1[k], equal_nan=True) for k in var0)
+
+
+def read_nc_bytes(blob, d):
+    path = os.path.join(d, "_before.nc")
+    open(path, "wb").write(blob)
+    return read_nc(path)[0]
+
+
+@pytest.mark.gpu
 def test_cdfsig0_and_cdfsigi_end_to_end(case):
     d, g, rec = case
     rc, out, err = run("cdfsig0", ["-t", "SYN_y0001_gridT.nc"], d)
