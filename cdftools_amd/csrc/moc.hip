@@ -27,6 +27,7 @@ struct cdft_moc_plan {
     bool mesh_set = false;
     int  tune_waves = 0, tune_nv = 0, tune_mode = 0;
     DevBuf st_e1v, st_e3v, st_mask, st_zv, st_out;
+    DevBuf seg_out;            // class kernel, rows cut into segments: the segments' sums (nseg x the size of the result)
     DevBuf st_vm;
     bool last_aligned = true;  // alignment of the records of the last launch (cdft_moc_describe)   // staging for host arrays
     // -decomp (cdft_moc_decomp_*): the mesh it needs beyond w / bits, and its work arrays
@@ -222,6 +223,12 @@ __global__ void dec_finish_kernel(const double *__restrict__ tot, const double *
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // pick waves per row and float4 vectors per lane for a row of npi cells
+// class mode: *nwaves waves x *nv vectors make a SEGMENT of the row (one workgroup); the row has ceil(nvec / segment) of them
+int row_segments(const cdft_moc_plan *p, int nwaves, int nv, int mode) {
+    const int nvec = (p->npi + 6) / 4;
+    return mode == kModeClass ? (nvec + kWave * nwaves * nv - 1) / (kWave * nwaves * nv) : 1;
+}
+
 void choose_shape(const cdft_moc_plan *p, bool aligned, int *nwaves, int *nv, int *mode) {
     const int nvec = (p->npi + 6) / 4;             // worst-case aligned vectors covering a row
     const bool class_ok = p->nclass > 0 && p->nclass <= kMaxClass;
@@ -244,12 +251,12 @@ void choose_shape(const cdft_moc_plan *p, bool aligned, int *nwaves, int *nv, in
         if (md == kModeClass) {
             // vectors per lane by workgroup size (256 / 512 / 1024 threads leave 512 / 256 / 128 VGPRs per lane); records
             // that are not 16-byte aligned cost more registers per vector (measured: no spill with these)
-            const int v_small = aligned ? 9 : 6, v_mid = aligned ? 9 : 8, v_big = aligned ? kBigNVClass : 4;
+            const int v_small = aligned ? 9 : 6;
             k = ceil_div(nvec, kWave * v_small);                   // 9: measured best at npiglo = 4322
-            if (k > kSmallWaves) {
-                k = ceil_div(nvec, kWave * v_mid);                 // rows of 4.6k .. 18k cells (eORCA36): 512 threads
-                if (k > kMidWaves || ceil_div(nvec, kWave * k) <= kBigNVClass) k = ceil_div(nvec, kWave * v_big);
-            }
+            // rows no 256-thread workgroup covers (> 9.2k cells, eORCA36): segments of kSegWaves waves x 9 vectors, the
+            // shape that streams best, one workgroup each (6 waves x 9 in one 512-thread workgroup: 70 % of the HBM
+            // peak at npiglo = 12960, segments: see DESIGN 4.1)
+            if (k > kSmallWaves) { k = kSegWaves; v = v_small; *nwaves = k; *nv = v; *mode = md; return; }
         } else {
             int vmax = (md == kModeFma) ? 4 : 8;
             k = ceil_div(nvec, kWave * vmax);
@@ -283,6 +290,16 @@ static int zonal_launch(cdft_moc_plan *p, const float *d_zv, int64_t rec_stride,
     p->last_aligned = aligned;
     if (k > kMaxWaves || v > kMaxNV)
         return fail(CDFT_ERR_ARG, "cdft_moc_compute: row of %d cells needs %d waves x %d vectors", p->npi, k, v);
+    if (md != kModeClass && k * v * kWave < (p->npi + 6) / 4)
+        return fail(CDFT_ERR_ARG, "cdft_moc_compute: %d waves x %d vectors do not cover a row of %d (only the class kernel cuts rows)", k, v,
+                    p->npi);
+    a.nseg = row_segments(p, k, v, md);
+    a.seg_out = nullptr;
+    a.seg_stride = (int64_t)p->nbasins * p->npj * p->npk * npt;
+    if (a.nseg > 1) {
+        CDFT_TRY(p->seg_out.reserve((size_t)a.nseg * a.seg_stride * sizeof(double)));
+        a.seg_out = (double *)p->seg_out.ptr;
+    }
     hipEvent_t ev1 = nullptr;
     if (profile && p->profiling) {
         if (p->ev_used + 2 > p->ev.size()) {
@@ -428,8 +445,8 @@ int cdft_moc_set_tuning(cdft_moc_plan *p, int waves_per_row, int vec_per_lane, i
         mode < 0 || mode > 3)
         return fail(CDFT_ERR_ARG, "cdft_moc_set_tuning: out of range (%d,%d,%d)", waves_per_row,
                     vec_per_lane, mode);
-    if (waves_per_row > 0 && vec_per_lane > 0 &&
-        waves_per_row * vec_per_lane * kWave < (p->npi + 6) / 4)
+    if (waves_per_row > 0 && vec_per_lane > 0 && mode != kModeClass && !(mode == 0 && p->nbasins > 1 && p->nclass > 0) &&
+        waves_per_row * vec_per_lane * kWave < (p->npi + 6) / 4)                    // (the class kernel cuts the row into segments)
         return fail(CDFT_ERR_ARG, "cdft_moc_set_tuning: %d waves x %d vectors do not cover a row of %d",
                     waves_per_row, vec_per_lane, p->npi);
     p->tune_waves = waves_per_row; p->tune_nv = vec_per_lane; p->tune_mode = mode;
@@ -442,7 +459,11 @@ int cdft_moc_describe(cdft_moc_plan *p, char *buf, size_t buflen) {
     int k, v, md;
     choose_shape(p, p->last_aligned, &k, &v, &md);       // the shape of the last launch (16-byte aligned records before any)
     const int nb = p->nbasins == 1 ? 1 : (p->nbasins <= 5 ? 5 : 8);
-    if (md == kModeClass)
+    const int nseg = row_segments(p, k, v, md);
+    if (md == kModeClass && nseg > 1)
+        snprintf(buf, buflen, "moc_zonal_class_kernel<NV=%d,KC=%d,ALIGNED=%d> row_segments=%d waves_per_segment=%d basin_patterns=%d", v,
+                 kMaxClass, p->last_aligned ? 1 : 0, nseg, k, p->nclass);
+    else if (md == kModeClass)
         snprintf(buf, buflen, "moc_zonal_class_kernel<NV=%d,KC=%d,ALIGNED=%d> waves_per_row=%d basin_patterns=%d", v, kMaxClass,
                  p->last_aligned ? 1 : 0, k, p->nclass);
     else
@@ -656,7 +677,7 @@ int cdft_moc_destroy(cdft_moc_plan *p) {
     if (p->bits) (void)hipFree(p->bits);
     if (p->cls) (void)hipFree(p->cls);
     if (p->flag) (void)hipFree(p->flag);
-    p->st_e1v.release(); p->st_e3v.release(); p->st_mask.release(); p->st_vm.release(); p->st_zv.release(); p->st_out.release();
+    p->st_e1v.release(); p->st_e3v.release(); p->st_mask.release(); p->st_vm.release(); p->st_zv.release(); p->st_out.release(); p->seg_out.release();
     DevBuf *dec[] = {&p->d_e3v, &p->d_e1u, &p->d_zcoef, &p->d_tmask, &p->d_umask, &p->d_t, &p->d_s, &p->d_zvgeo, &p->d_sig8,
                      &p->d_dvbt, &p->d_hdep, &p->d_dvgeo, &p->d_raw, &p->d_o4};
     for (DevBuf *b : dec) b->release();

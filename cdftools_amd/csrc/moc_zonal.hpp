@@ -32,6 +32,7 @@ constexpr int kWave      = 64;
 constexpr int kMaxNV     = 16;   // float4 vectors per lane held in registers
 constexpr int kMaxWaves  = 16;   // waves per row (1024-thread workgroup)
 constexpr int kSmallWaves = 4;   // waves per row of a 256-thread workgroup
+constexpr int kSegWaves  = 2;    // class kernel, rows longer than a 256-thread workgroup covers: waves per row segment
 constexpr int kMidWaves  = 8;    // waves per row of a 512-thread workgroup (class kernel, 6..9 vectors per lane)
 constexpr int kBigNV     = 6;    // vectors per lane a 1024-thread workgroup can hold unspilled
 constexpr int kBigNVClass = 5;   // the same for the class kernel (one slot index per cell on top)
@@ -54,6 +55,12 @@ struct ZonalArgs {
     int            npi, npj, npk, nbasins;
     int            rows_per_wg; // class kernel: consecutive rows one workgroup works through (>= 1)
     int            aligned;     // class kernel: record base and stride are multiples of 16 bytes
+    // class kernel, long rows: a row is cut into nseg segments of nwaves*64*NV vectors, one workgroup each (segments of a
+    // row are consecutive workgroups); segment s writes its sums to seg_out + s*seg_stride (laid out like out), and
+    // moc_seg_sum_kernel adds the segments in order into out.  nseg = 1: straight into out.
+    int            nseg;
+    double        *seg_out;
+    int64_t        seg_stride;
 };
 
 typedef int (*ZonalLauncher)(const ZonalArgs &, int nwaves, int nv, bool aligned, int mode,
@@ -335,7 +342,7 @@ template <> struct ZVec<true>  { typedef f4a T; static __device__ __forceinline_
 template <> struct ZVec<false> { typedef f4u T; static __device__ __forceinline__ f4u ld(const float *p) { return ld_stream4u(p); } };
 
 template <int NV, int KC, bool ALIGNED>
-__device__ __forceinline__ void moc_zonal_class_row(const ZonalArgs &a, const int row, double *smem) {
+__device__ __forceinline__ void moc_zonal_class_row(const ZonalArgs &a, const int row, const int seg, double *smem) {
     typedef typename ZVec<ALIGNED>::T V4;
     const int lane   = threadIdx.x & (kWave - 1);
     const int wave   = threadIdx.x >> 6;
@@ -349,8 +356,10 @@ __device__ __forceinline__ void moc_zonal_class_row(const ZonalArgs &a, const in
     const int jj  = row - jk * a.npj;
     const int64_t g0   = (int64_t)row * a.npi;
     const int     head = ALIGNED ? (int)(g0 & 3) : 0;
-    const int     v0   = wave * (kWave * NV) + lane;
-    const int     nfull = a.npi >> 2;                             // (not ALIGNED) vectors 0..nfull-1 start at cell 4v
+    const int     segv = nwaves * (kWave * NV);                   // vectors of a segment
+    const int     v0   = seg * segv + wave * (kWave * NV) + lane;
+    const int     nfull = a.npi >> 2;
+    double *const outp = a.nseg > 1 ? a.seg_out + (int64_t)seg * a.seg_stride : a.out;                             // (not ALIGNED) vectors 0..nfull-1 start at cell 4v
 
     float   w[NV][4];
     int     slot[NV][4];                                          // index of the cell's slot in scr
@@ -455,7 +464,7 @@ __device__ __forceinline__ void moc_zonal_class_row(const ZonalArgs &a, const in
             // of their products is finite every one of them is: the zero term is a zero.
             if (__builtin_isfinite(z)) {
                 s += __dmul_rn(z, 0.0);
-                a.out[(((int64_t)(t0 + tl) * a.npk + jk) * a.npj + jj) * a.nbasins + b] = -s;
+                outp[(((int64_t)(t0 + tl) * a.npk + jk) * a.npj + jj) * a.nbasins + b] = -s;
             } else {
                 atomicOr(&flag[0], 1u << tl);
             }
@@ -466,10 +475,13 @@ __device__ __forceinline__ void moc_zonal_class_row(const ZonalArgs &a, const in
             // finite one that overflowed the r4 product (the zero term is 0).  Only the velocities tell: read the
             // row of those records again and note the classes that hold a NaN/Inf.
             const uint32_t need = flag[0];
+            // the cells of this segment: those of its vectors (cell i lies in vector (i + head) >> 2; not ALIGNED: head = 0
+            // and the anchored vector nfull owns the cells from 4*nfull on)
+            const int ifirst = max(0, 4 * seg * segv - head), ilast = (int)min((int64_t)a.npi, (int64_t)4 * (seg + 1) * segv - head);
             for (int tl = 0; tl < tcount; ++tl) {
                 if (!((need >> tl) & 1u)) continue;
                 const float *zr = a.zv + (int64_t)(t0 + tl) * a.rec_stride + g0;
-                for (int i = threadIdx.x; i < a.npi; i += blockDim.x)
+                for (int i = ifirst + threadIdx.x; i < ilast; i += blockDim.x)
                     if (!__builtin_isfinite(zr[i])) atomicOr(&flag[1 + tl], 1u << crow[i]);
             }
             __syncthreads();
@@ -479,7 +491,7 @@ __device__ __forceinline__ void moc_zonal_class_row(const ZonalArgs &a, const in
                 basin_sums(tl, b, s, z, nm);
                 if (__builtin_isfinite(z)) continue;             // written above
                 if (flag[1 + tl] & nm) s += __builtin_nan("");
-                a.out[(((int64_t)(t0 + tl) * a.npk + jk) * a.npj + jj) * a.nbasins + b] = -s;
+                outp[(((int64_t)(t0 + tl) * a.npk + jk) * a.npj + jj) * a.nbasins + b] = -s;
             }
         }
         __syncthreads();
@@ -491,19 +503,38 @@ template <int NV, int KC, int LB, bool ALIGNED>
 __global__ void __launch_bounds__(LB)
 moc_zonal_class_kernel(ZonalArgs a) {
     extern __shared__ double smem[];
-    const int nrows = a.npj * (a.npk - 1);
-    const int r0 = blockIdx.x * a.rows_per_wg, r1 = min(nrows, r0 + a.rows_per_wg);
-    for (int row = r0; row < r1; ++row) moc_zonal_class_row<NV, KC, ALIGNED>(a, row, smem);
+    const int nitems = a.npj * (a.npk - 1) * a.nseg;              // item = row * nseg + segment
+    const int r0 = blockIdx.x * a.rows_per_wg, r1 = min(nitems, r0 + a.rows_per_wg);
+    for (int item = r0; item < r1; ++item) {
+        const int row = item / a.nseg;
+        moc_zonal_class_row<NV, KC, ALIGNED>(a, row, item - row * a.nseg, smem);
+    }
+}
+
+// out = the segments' sums added in segment order (levels 1..npk-1 of every record; level npk is not theirs)
+__global__ void moc_seg_sum_kernel(ZonalArgs a) {
+    const int64_t per_level = (int64_t)a.npj * a.nbasins, per_rec = per_level * a.npk;
+    const int64_t n = (int64_t)a.npt * (a.npk - 1) * per_level;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t t = q / ((a.npk - 1) * per_level), e = t * per_rec + (q - t * (a.npk - 1) * per_level);
+        double s = a.seg_out[e];
+        for (int g = 1; g < a.nseg; ++g) s += a.seg_out[(int64_t)g * a.seg_stride + e];
+        a.out[e] = s;
+    }
 }
 
 template <int NV, int KC, int LB>
 static int launch_class_lb(const ZonalArgs &a, int nwaves, hipStream_t st) {
     const size_t shmem = sizeof(double) * ((size_t)nwaves * (KC + 1) * kScrStride + (size_t)kTChunk * KC * nwaves + (kTChunk + 2) / 2 + 1);
-    const unsigned nrows = (unsigned)a.npj * (unsigned)(a.npk - 1);
+    const unsigned nrows = (unsigned)a.npj * (unsigned)(a.npk - 1) * (unsigned)a.nseg;
     const unsigned grid = (nrows + (unsigned)a.rows_per_wg - 1) / (unsigned)a.rows_per_wg;
     if (a.aligned) hipLaunchKernelGGL((moc_zonal_class_kernel<NV, KC, LB, true>), dim3(grid), dim3(kWave * nwaves), shmem, st, a);
     else           hipLaunchKernelGGL((moc_zonal_class_kernel<NV, KC, LB, false>), dim3(grid), dim3(kWave * nwaves), shmem, st, a);
     CDFT_LAUNCH_CHECK();
+    if (a.nseg > 1) {
+        hipLaunchKernelGGL(moc_seg_sum_kernel, dim3(2048), dim3(256), 0, st, a);
+        CDFT_LAUNCH_CHECK();
+    }
     return CDFT_OK;
 }
 

@@ -75,7 +75,7 @@ CASES = [
     (1031, 7, 5, 5, 17),     # ragged row, more records than one LDS chunk
     (1032, 4, 5, 5, 16),     # 16-byte aligned records, one wave per row, 16 records x 5 basins > 64 lanes in the epilogue
     (4322, 3, 4, 5, 2),      # eORCA12 row length
-    (12960, 2, 3, 5, 1),     # eORCA36 row length (1024-thread workgroups)
+    (12960, 2, 3, 5, 1),     # eORCA36 row length (three row segments)
 ]
 
 
@@ -101,7 +101,8 @@ def test_hip_matches_oracle_host_arrays(gpu, npi, npj, npk, nb, npt):
 @pytest.mark.gpu
 @pytest.mark.parametrize("waves,nv,mode", [(0, 0, 1), (0, 0, 2), (1, 5, 1), (2, 3, 1), (3, 2, 2), (4, 2, 2),
                                            (5, 1, 1), (16, 1, 1), (2, 16, 1), (2, 4, 2),
-                                           (0, 0, 3), (1, 5, 3), (3, 2, 3), (5, 1, 3), (16, 1, 3), (2, 12, 3), (7, 5, 3)])
+                                           (0, 0, 3), (1, 5, 3), (3, 2, 3), (5, 1, 3), (16, 1, 3), (2, 12, 3), (7, 5, 3),
+                                           (1, 1, 3), (1, 2, 3), (2, 1, 3), (3, 1, 3), (2, 2, 3)])   # class kernel, 5 / 3 / 3 / 2 / 2 row segments
 def test_hip_kernel_variants_agree_with_oracle(gpu, waves, nv, mode):
     import torch
 
@@ -116,6 +117,43 @@ def test_hip_kernel_variants_agree_with_oracle(gpu, waves, nv, mode):
     torch.cuda.synchronize()
     ref = oracle_lib.moc(e1v, e3v, ib, zv)
     assert_moc_close(got.cpu().numpy(), ref, abs_bound(e1v, e3v, ib, zv))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("npi,aligned,tune,segments", [(12960, True, (0, 0), 3), (12962, False, (0, 0), 5), (1190, True, (1, 1), 5),
+                                                       (1191, False, (1, 1), 5), (333, False, (1, 1), 2), (9300, True, (0, 0), 3),
+                                                       (9208, True, (0, 0), 0)])
+def test_hip_class_kernel_cuts_long_rows_into_segments(gpu, npi, aligned, tune, segments):
+    """Rows longer than a 256-thread workgroup covers (> 9.2k cells: eORCA36), or a tuning that asks for it: the class kernel
+    gives each SEGMENT of the row to its own workgroup and adds the segments' sums in order -- same tolerance, run-to-run
+    identical, for 16-byte aligned records and for records that are not."""
+    import torch
+
+    npj, npk, nb, npt = 3, 4, 5, 3
+    g = synth.make_grid(npi, npj, npk, seed=npi, nbasins=nb)
+    e1v, e3v, ib = synth.moc_inputs(g)
+    zv = synth.velocity(g, npt, seed=8)
+    n3 = npi * npj * npk
+    stride = n3 if aligned else n3 + 3
+    assert aligned == (stride % 4 == 0)
+    buf = torch.zeros(4 + npt * stride, dtype=torch.float32, device="cuda")
+    view = buf[4:] if aligned else buf[1:]
+    for t in range(npt):
+        view[t * stride: t * stride + n3] = torch.from_numpy(zv[t].ravel()).cuda()
+    plan = gpu.MocPlan(npi, npj, npk, nb)
+    plan.set_mesh(e1v, e3v, ib)
+    plan.set_tuning(tune[0], tune[1], 0)
+    out = torch.empty((npt, npk, npj, nb), dtype=torch.float64, device="cuda")
+    plan.compute(view, out=out, rec_stride=stride, npt=npt)
+    torch.cuda.synchronize()
+    d = plan.describe()
+    assert (f"row_segments={segments} " in d) if segments else ("row_segments" not in d), d
+    assert f"ALIGNED={int(aligned)}" in d, d
+    ref = oracle_lib.moc(e1v, e3v, ib, zv)
+    assert_moc_close(out.cpu().numpy(), ref, abs_bound(e1v, e3v, ib, zv))
+    again = torch.empty_like(out)
+    plan.compute(view, out=again, rec_stride=stride, npt=npt)
+    assert torch.equal(out, again)
 
 
 @pytest.mark.gpu

@@ -144,6 +144,38 @@ def test_moc(gpu, npi, npj, npk, nb, mode):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("npi,npj,npk,nb", [(1442, 9, 4, 5), (259, 6, 4, 5), (1190, 5, 3, 3)])
+def test_moc_row_segments(gpu, npi, npj, npk, nb):
+    """The class kernel with its rows cut into segments (one vector per lane, one wave per segment: 6 / 2 / 5 of them): a
+    segment settles its own zero terms -- a NaN/Inf velocity outside a basin in ANY segment reaches the basin, an overflowed
+    product does not."""
+    g = synth.make_grid(npi, npj, npk, seed=npi, nbasins=nb)
+    e1v, e3v, ib = synth.moc_inputs(g)
+    zv = synth.velocity(g, 3, seed=4)
+    outside_every_basin = (ib.max(axis=2) == 0)[None, None]
+    outside_global = (ib[:, :, 0] == 0)[None, None]
+    plan = gpu.MocPlan(npi, npj, npk, nb)
+    plan.set_mesh(e1v, e3v, ib)
+    plan.set_tuning(1, 1, 3)
+    for land, n_ocean in ((outside_every_basin, 0), (outside_global, 0), (outside_global, 2)):
+        bad = poison(zv, land, seed=npi + n_ocean, n_land=6, n_ocean=n_ocean)
+        ref = oracle_lib.moc(e1v, e3v, ib, bad)
+        clean = np.where(np.isfinite(bad), bad, 0).astype(np.float32)
+        lim = 1e-13 * np.abs(oracle_lib.moc(e1v, e3v, ib, np.abs(clean))).max() + 1e-300
+        same(plan.compute(bad), ref, lim)
+    assert "row_segments" in plan.describe()
+    for with_nan in (False, True):
+        big, rows = overflowing(zv, e1v, e3v, ib, seed=npi, with_nan=with_nan)
+        assert rows
+        ref = oracle_lib.moc(e1v, e3v, ib, big)
+        clean = np.where(np.abs(big) < 1e38, big, 0).astype(np.float32)
+        clean[~np.isfinite(clean)] = 0
+        lim = 1e-13 * np.abs(oracle_lib.moc(e1v, e3v, ib, np.abs(clean))).max() + 1e-300
+        same(plan.compute(big), ref, lim)
+    plan.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("npi,npj,npk", [(24, 18, 7), (182, 149, 5), (1031, 7, 3)])
 def test_heatc(gpu, npi, npj, npk):
     g = synth.make_grid(npi, npj, npk, seed=npi)

@@ -50,8 +50,13 @@ def main():
     ref = None
     for rnd in range(args.rounds):
         for v in variants:
-            plan.set_tuning(*v)
-            plan.compute(zv, out=out)          # warm
+            try:
+                plan.set_tuning(*v)
+                plan.compute(zv, out=out)          # warm
+            except Exception as e:                 # a shape this row length or mode does not allow
+                if rnd == 0:
+                    print(json.dumps({"variant": v, "refused": str(e)}), flush=True)
+                continue
             plan.profile_enable(True)
             for _ in range(3):
                 plan.compute(zv, out=out)
