@@ -256,7 +256,22 @@ void choose_shape(const cdft_moc_plan *p, bool aligned, int *nwaves, int *nv, in
             // rows no 256-thread workgroup covers (> 9.2k cells, eORCA36): segments of kSegWaves waves x 9 vectors, the
             // shape that streams best, one workgroup each (6 waves x 9 in one 512-thread workgroup: 70 % of the HBM
             // peak at npiglo = 12960, segments: see DESIGN 4.1)
-            if (k > kSmallWaves) { k = kSegWaves; v = v_small; *nwaves = k; *nv = v; *mode = md; return; }
+            if (k > kSmallWaves) {
+                // ... with the vectors per lane (9, 10 or 8; 6 or 5 for unaligned records) that leave the fewest idle
+                // lanes in the last segment: 12960 cells = 3 x 2 x 64 x 9 at 94 %, 10000 cells = 2 x 2 x 64 x 10 at 98 %
+                const int cand_a[3] = {9, 10, 8}, cand_u[2] = {6, 5};
+                const int *cand = aligned ? cand_a : cand_u;
+                const int ncand = aligned ? 3 : 2;
+                double best = 0.0;
+                v = cand[0];
+                for (int c = 0; c < ncand; ++c) {
+                    const int cap = kWave * kSegWaves * cand[c], ns = ceil_div(nvec, cap);
+                    const double fill = (double)nvec / ((double)ns * cap);
+                    if (fill > best + 1e-9) { best = fill; v = cand[c]; }
+                }
+                *nwaves = kSegWaves; *nv = v; *mode = md;
+                return;
+            }
         } else {
             int vmax = (md == kModeFma) ? 4 : 8;
             k = ceil_div(nvec, kWave * vmax);

@@ -121,7 +121,7 @@ def test_hip_kernel_variants_agree_with_oracle(gpu, waves, nv, mode):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("npi,aligned,tune,segments", [(12960, True, (0, 0), 3), (12962, False, (0, 0), 5), (1190, True, (1, 1), 5),
-                                                       (1191, False, (1, 1), 5), (333, False, (1, 1), 2), (9300, True, (0, 0), 3),
+                                                       (1191, False, (1, 1), 5), (333, False, (1, 1), 2), (9300, True, (0, 0), 2), (16000, True, (0, 0), 4),
                                                        (9208, True, (0, 0), 0)])
 def test_hip_class_kernel_cuts_long_rows_into_segments(gpu, npi, aligned, tune, segments):
     """Rows longer than a 256-thread workgroup covers (> 9.2k cells: eORCA36), or a tuning that asks for it: the class kernel
