@@ -22,6 +22,15 @@ int oracle_num_threads(void) {
 #endif
 }
 
+/* threads of the following parallel loops (bench.py picks the count that serves the sample best) */
+void oracle_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n >= 1) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 /* Fortran (ji,jj[,jk]) -> C offset, 0-based indices */
 #define IJ(i, j) ((size_t)(j) * npi + (i))
 #define IJK(i, j, k) (((size_t)(k) * npj + (j)) * npi + (i))

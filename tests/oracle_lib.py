@@ -84,6 +84,10 @@ def num_threads():
     return load().oracle_num_threads()
 
 
+def set_num_threads(n):
+    load().oracle_set_num_threads(C.c_int(int(n)))
+
+
 def _f32(a):
     return np.ascontiguousarray(a, np.float32)
 
