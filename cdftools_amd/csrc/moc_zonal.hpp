@@ -361,9 +361,15 @@ __device__ __forceinline__ void moc_zonal_class_row(const ZonalArgs &a, const in
     const int     nfull = a.npi >> 2;
     double *const outp = a.nseg > 1 ? a.seg_out + (int64_t)seg * a.seg_stride : a.out;                             // (not ALIGNED) vectors 0..nfull-1 start at cell 4v
 
-    float   w[NV][4];
-    int     slot[NV][4];                                          // index of the cell's slot in scr
-    int     ioff[NV];                                             // column the lane's vector is loaded from (ALIGNED: -head ..)
+    float    w[NV][4];
+    uint32_t cpk[NV];                                             // the 4 cells' classes, a byte each (their slots: cls*kScrStride + lane)
+    // column a lane's vector r is loaded from (ALIGNED: -head ..): formed again at every use (two VALU operations) rather
+    // than kept in NV registers -- with the packed classes that brings 9 vectors per lane under 168 VGPRs, three waves a SIMD
+    auto ioff_of = [&](int r, int base) -> int {
+        const int i0 = base + 4 * kWave * r;
+        return ALIGNED ? (i0 < a.npi ? i0 : -head) : min(i0, a.npi - 4);
+    };
+    const int ibase = 4 * v0 - (ALIGNED ? head : 0);
     const uint8_t *crow = a.cls + (int64_t)jj * a.npi;
     V4       wraw[NV];
     uint32_t craw[NV][4];
@@ -373,19 +379,20 @@ __device__ __forceinline__ void moc_zonal_class_row(const ZonalArgs &a, const in
         int i0;                                                   // column of component 0
         if (ALIGNED) {
             i0 = 4 * v - head;
-            ioff[r] = i0 < a.npi ? i0 : -head;                    // lanes past the row end re-read its first vector
+            // (lanes past the row end re-read its first vector)
         } else {
             i0 = min(4 * v, a.npi - 4);                           // v >= nfull: the anchored vector (in range for every lane)
-            ioff[r] = i0;
         }
-        wraw[r] = ZVec<ALIGNED>::ld(a.w + g0 + ioff[r]);
+        wraw[r] = ZVec<ALIGNED>::ld(a.w + g0 + ioff_of(r, ibase));
 #pragma unroll
         for (int c = 0; c < 4; ++c) craw[r][c] = crow[min(max(i0 + c, 0), a.npi - 1)];
     }
     auto load_rec = [&](V4 (&z)[NV], int t) {
         const float *zr = a.zv + (int64_t)t * a.rec_stride + g0;
+        int base = ibase;
+        asm volatile("" : "+v"(base));                            // (or the NV offsets are hoisted into registers again)
 #pragma unroll
-        for (int r = 0; r < NV; ++r) z[r] = ZVec<ALIGNED>::ld(zr + ioff[r]);
+        for (int r = 0; r < NV; ++r) z[r] = ZVec<ALIGNED>::ld(zr + ioff_of(r, base));
     };
     V4 zc[NV], zn[NV];
     load_rec(zc, 0);
@@ -395,13 +402,14 @@ __device__ __forceinline__ void moc_zonal_class_row(const ZonalArgs &a, const in
     for (int r = 0; r < NV; ++r) {
         const int v = v0 + r * kWave;
         const float wr[4] = {wraw[r].x, wraw[r].y, wraw[r].z, wraw[r].w};
+        cpk[r] = 0u;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int i = (ALIGNED ? 4 * v - head : min(4 * v, a.npi - 4)) + c;
             const bool ok = ALIGNED ? (i >= 0 && i < a.npi)
                                     : (v < nfull || (v == nfull && i >= 4 * nfull));
-            w[r][c]    = ok ? wr[c] : 0.f;
-            slot[r][c] = (ok ? min((int)craw[r][c], KC) : KC) * kScrStride + lane;   // slot KC is never read
+            w[r][c] = ok ? wr[c] : 0.f;
+            cpk[r] |= (uint32_t)(ok ? min((int)craw[r][c], KC) : KC) << (8 * c);     // slot KC is never read
         }
     }
 
@@ -414,11 +422,14 @@ __device__ __forceinline__ void moc_zonal_class_row(const ZonalArgs &a, const in
 #pragma unroll
             for (int r = 0; r < NV; ++r) {
                 const float zr[4] = {zc[r].x, zc[r].y, zc[r].z, zc[r].w};
+                uint32_t pk = cpk[r];
+                asm volatile("" : "+v"(pk));                       // (keeps the 36 slot addresses from being hoisted into registers)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     // r4 product, then widen: src/cdfmoc.f90:373-374
                     const double pd = (double)__fmul_rn(w[r][c], zr[c]);
-                    (void)__hip_atomic_fetch_add(&scr[slot[r][c]], pd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const uint32_t cl = (pk >> (8 * c)) & 0xffu;
+                    (void)__hip_atomic_fetch_add(&scr[cl * kScrStride + lane], pd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
