@@ -146,18 +146,25 @@ __global__ void __launch_bounds__(T) mocsig_class_kernel(SigArgs a, SigClassArgs
                 hoff[r][c] = own ? (int)ca.cls[r2 + i] * a.nbins : -1;
             }
         }
+        // one vector (v, T, S, e3v: four 16-byte loads) is in flight while the previous one goes through the equation of
+        // state: 32 registers of loads instead of 16*NV, which keeps the kernel at three waves per SIMD (it is bound by the
+        // r8 issue rate and the latency of its Horner chains, not by HBM: more waves, not more bytes in flight)
+        f4u cv, ct, cs, ce;
+        {
+            const int64_t e = r2 + i0[0];
+            cv = ld_stream4u(a.zv + e); ct = ld_stream4u(a.zt + e); cs = ld_stream4u(a.zs + e); ce = ld_stream4u(a.e3v + e);
+        }
         for (int k = 0; k < a.npk - 1; ++k) {
             const int64_t e = (int64_t)k * nij + r2;
-            f4u qv[NV], qt[NV], qs[NV], qe[NV];
 #pragma unroll
             for (int r = 0; r < NV; ++r) {
-                qv[r] = ld_stream4u(a.zv + e + i0[r]); qt[r] = ld_stream4u(a.zt + e + i0[r]);
-                qs[r] = ld_stream4u(a.zs + e + i0[r]); qe[r] = ld_stream4u(a.e3v + e + i0[r]);
-            }
-#pragma unroll
-            for (int r = 0; r < NV; ++r) {
-                const float v4[4] = {qv[r].x, qv[r].y, qv[r].z, qv[r].w}, t4[4] = {qt[r].x, qt[r].y, qt[r].z, qt[r].w};
-                const float s4[4] = {qs[r].x, qs[r].y, qs[r].z, qs[r].w}, e4[4] = {qe[r].x, qe[r].y, qe[r].z, qe[r].w};
+                f4u nv_ = cv, nt_ = ct, ns_ = cs, ne_ = ce;
+                if (r + 1 < NV || k + 1 < a.npk - 1) {
+                    const int64_t en = (r + 1 < NV ? e : e + nij) + i0[r + 1 < NV ? r + 1 : 0];
+                    nv_ = ld_stream4u(a.zv + en); nt_ = ld_stream4u(a.zt + en); ns_ = ld_stream4u(a.zs + en); ne_ = ld_stream4u(a.e3v + en);
+                }
+                const float v4[4] = {cv.x, cv.y, cv.z, cv.w}, t4[4] = {ct.x, ct.y, ct.z, ct.w};
+                const float s4[4] = {cs.x, cs.y, cs.z, cs.w}, e4[4] = {ce.x, ce.y, ce.z, ce.w};
                 int key[4];
                 double val[4];
 #pragma unroll
@@ -182,6 +189,7 @@ __global__ void __launch_bounds__(T) mocsig_class_kernel(SigArgs a, SigClassArgs
                 for (int c = 0; c < 4; ++c)
                     if (key[c] >= 0)
                         (void)__hip_atomic_fetch_add(&h[key[c]], val[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // :435
+                cv = nv_; ct = nt_; cs = ns_; ce = ne_;
             }
         }
     }
