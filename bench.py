@@ -20,6 +20,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement), including
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -124,7 +125,7 @@ def cpu_baseline(e1v, e3v, ib, zv, npi, npk, npt, target_s=12.0):
                       f"five thread counts up to {nmax if target_s > 0 else oracle_lib.num_threads()}"}, rows, out
 
 
-def reference_baseline(e1v, e3v, ib, zv, npi, npk, npt, got, rows=64, target_s=6.0):
+def reference_baseline(e1v, e3v, ib, zv, npi, npk, npt, got, rows=32, target_s=6.0):
     """The reference's OWN statements for this path (src/cdfmoc.f90 main loop and cumulation, lifted verbatim into
     oracle/_ref/liblift_ref.so by oracle/ref_lift.py and compiled there by amdflang -O1 -ffp-contract=off; built where
     /root/reference exists, it travels as a binary) on the first `rows` rows of the sample: timed on one host thread -- the
@@ -149,7 +150,7 @@ def reference_baseline(e1v, e3v, ib, zv, npi, npk, npt, got, rows=64, target_s=6
         code = f"import sys; sys.path.insert(0, {ROOT!r}); import bench; bench.reference_child({d!r}, {float(target_s)!r})"
         r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=600)
         if r.returncode != 0:
-            raise SystemExit("bench: the reference-statement baseline failed:\n" + r.stderr[-2000:])
+            raise ValueError("the reference-statement child failed: " + r.stderr[-300:])
         out = np.load(os.path.join(d, "dmoc.npy"))
         reps, total = json.load(open(os.path.join(d, "time.json")))
     finally:
@@ -325,8 +326,11 @@ def main():
         if not check < 1e-11:
             raise SystemExit(f"bench: HIP result differs from the oracle on the sampled rows (rel {check:.3e})")
         if world == 1 and nb == 5:
-            cpu_ref = reference_baseline(e1v[:keep_rows], e3v_s, ib[:keep_rows], zv[:, :, :keep_rows], npi, npk, npt, got)
-            if cpu_ref is not None and not cpu_ref["hip_vs_reference_rel_err"] < 1e-11:
+            try:
+                cpu_ref = reference_baseline(e1v[:keep_rows], e3v_s, ib[:keep_rows], zv[:, :, :keep_rows], npi, npk, npt, got)
+            except (OSError, subprocess.SubprocessError, ValueError) as exc:        # no room in the temporary directory, ...:
+                cpu_ref = {"kind": "reference", "error": str(exc)[:300]}               # an optional leg, never the bench's failure
+            if cpu_ref is not None and "error" not in cpu_ref and not cpu_ref["hip_vs_reference_rel_err"] < 1e-11:
                 raise SystemExit(f"bench: HIP result differs from the reference's statements (rel {cpu_ref['hip_vs_reference_rel_err']:.3e})")
 
     if rank == 0:
