@@ -279,17 +279,21 @@ __global__ void __launch_bounds__(T) zonal_row_class_kernel(ZonalArgs2 a, ZonalC
     const int64_t nij = (int64_t)a.npi * a.npj, r2 = (int64_t)jj * a.npi;
     const int nfull = a.npi >> 2;                                    // vectors 0..nfull-1 start at 4v
     double sf[NV][4];
-    int slot[NV][4], i0[NV];
+    // the classes of a vector's four cells, a byte each, and the column it is loaded from are formed again at every use
+    // (a bit-field extract and a multiply-add; min) instead of living in 5 * NV registers: one more wave per SIMD
+    uint32_t cpk[NV];
+    auto i0_of = [&](int r, int tx) -> int { return min(4 * (tx + r * T), a.npi - 4); };   // anchored vector for v >= nfull
 #pragma unroll
     for (int r = 0; r < NV; ++r) {
         const int v = threadIdx.x + r * T;
-        i0[r] = min(4 * v, a.npi - 4);                                // anchored vector for v >= nfull
+        const int i0 = i0_of(r, threadIdx.x);
+        cpk[r] = 0u;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const int i = i0[r] + c;
+            const int i = i0 + c;
             const bool own = v < nfull || (v == nfull && i >= 4 * nfull);
-            sf[r][c]   = a.surf[r2 + i];
-            slot[r][c] = (own ? min((int)ca.cls[r2 + i], kZC) : kZC) * kZStride + lane;      // slot kZC is never read
+            sf[r][c] = a.surf[r2 + i];
+            cpk[r] |= (uint32_t)(own ? min((int)ca.cls[r2 + i], kZC) : kZC) << (8 * c);      // slot kZC is never read
         }
     }
 #pragma unroll
@@ -300,11 +304,14 @@ __global__ void __launch_bounds__(T) zonal_row_class_kernel(ZonalArgs2 a, ZonalC
     Mask mc[NV], mn_[NV];
     auto fetch = [&](f4u (&z)[NV], Mask (&mk)[NV], int k) {
         const float *zv = a.zv + (int64_t)k * nij + r2;
+        int tx = threadIdx.x;
+        asm volatile("" : "+v"(tx));                    // (or the NV offsets are hoisted into registers)
 #pragma unroll
         for (int r = 0; r < NV; ++r) {
-            z[r] = ld_stream4u(zv + i0[r]);
-            if (M8) mk[r].b = __builtin_nontemporal_load(reinterpret_cast<const u32u *>(a.mask8 + (int64_t)k * nij + r2 + i0[r]));
-            else    mk[r].v = ld_stream4u(a.mask3 + (int64_t)k * nij + r2 + i0[r]);
+            const int i0 = i0_of(r, tx);
+            z[r] = ld_stream4u(zv + i0);
+            if (M8) mk[r].b = __builtin_nontemporal_load(reinterpret_cast<const u32u *>(a.mask8 + (int64_t)k * nij + r2 + i0));
+            else    mk[r].v = ld_stream4u(a.mask3 + (int64_t)k * nij + r2 + i0);
         }
     };
     fetch(zc, mc, k0);
@@ -314,6 +321,8 @@ __global__ void __launch_bounds__(T) zonal_row_class_kernel(ZonalArgs2 a, ZonalC
 #pragma unroll
         for (int r = 0; r < NV; ++r) {
             const float z4[4] = {zc[r].x, zc[r].y, zc[r].z, zc[r].w};
+            uint32_t pk = cpk[r];
+            asm volatile("" : "+v"(pk));                // (or the 4 * NV slot addresses are hoisted into registers)
             float m4[4];
             if (M8) {
 #pragma unroll
@@ -325,7 +334,7 @@ __global__ void __launch_bounds__(T) zonal_row_class_kernel(ZonalArgs2 a, ZonalC
             for (int c = 0; c < 4; ++c) {
                 // zmask = 1: sum form (1.f*m)*z = m*z in r4; mean form ((1.d0*1)*m)*z = m*z in r8
                 const double dt = MEAN ? __dmul_rn((double)m4[c], (double)z4[c]) : (double)__fmul_rn(m4[c], z4[c]);
-                (void)__hip_atomic_fetch_add(&scr[slot[r][c]], __dmul_rn(sf[r][c], dt), __ATOMIC_RELAXED,
+                (void)__hip_atomic_fetch_add(&scr[((pk >> (8 * c)) & 0xffu) * kZStride + lane], __dmul_rn(sf[r][c], dt), __ATOMIC_RELAXED,
                                              __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
