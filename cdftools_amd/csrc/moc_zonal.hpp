@@ -372,7 +372,8 @@ __device__ __forceinline__ void moc_zonal_class_row(const ZonalArgs &a, const in
     const int ibase = 4 * v0 - (ALIGNED ? head : 0);
     const uint8_t *crow = a.cls + (int64_t)jj * a.npi;
     V4       wraw[NV];
-    uint32_t craw[NV][4];
+    typedef uint32_t u32u __attribute__((aligned(1)));
+    uint32_t craw[NV];                                            // the classes of columns cfirst .. cfirst+3: ONE unaligned dword per vector
 #pragma unroll
     for (int r = 0; r < NV; ++r) {                                // issue every load first
         const int v  = v0 + r * kWave;
@@ -384,8 +385,7 @@ __device__ __forceinline__ void moc_zonal_class_row(const ZonalArgs &a, const in
             i0 = min(4 * v, a.npi - 4);                           // v >= nfull: the anchored vector (in range for every lane)
         }
         wraw[r] = ZVec<ALIGNED>::ld(a.w + g0 + ioff_of(r, ibase));
-#pragma unroll
-        for (int c = 0; c < 4; ++c) craw[r][c] = crow[min(max(i0 + c, 0), a.npi - 1)];
+        craw[r] = *reinterpret_cast<const u32u *>(crow + max(0, min(i0, a.npi - 4)));      // (the array is padded past its last row)
     }
     auto load_rec = [&](V4 (&z)[NV], int t) {
         const float *zr = a.zv + (int64_t)t * a.rec_stride + g0;
@@ -402,14 +402,17 @@ __device__ __forceinline__ void moc_zonal_class_row(const ZonalArgs &a, const in
     for (int r = 0; r < NV; ++r) {
         const int v = v0 + r * kWave;
         const float wr[4] = {wraw[r].x, wraw[r].y, wraw[r].z, wraw[r].w};
+        const int ifirst = ALIGNED ? 4 * v - head : min(4 * v, a.npi - 4);
+        const int cfirst = max(0, min(ifirst, a.npi - 4));        // the column the class dword was read at
         cpk[r] = 0u;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const int i = (ALIGNED ? 4 * v - head : min(4 * v, a.npi - 4)) + c;
+            const int i = ifirst + c;
             const bool ok = ALIGNED ? (i >= 0 && i < a.npi)
                                     : (v < nfull || (v == nfull && i >= 4 * nfull));
             w[r][c] = ok ? wr[c] : 0.f;
-            cpk[r] |= (uint32_t)(ok ? min((int)craw[r][c], KC) : KC) << (8 * c);     // slot KC is never read
+            const uint32_t cl = (craw[r] >> ((8 * (i - cfirst)) & 31)) & 0xffu;     // (an owned cell lies in cfirst .. cfirst+3)
+            cpk[r] |= (ok ? min(cl, (uint32_t)KC) : (uint32_t)KC) << (8 * c);       // slot KC is never read
         }
     }
 
