@@ -29,6 +29,12 @@ def test_bench_n1_line_small_workload(gpu):
     rf = r["roofline"]
     assert rf["launches"] == 20 and rf["min_launch_ms"] <= rf["median_launch_ms"] <= rf["max_launch_ms"]
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and r["cpu_baseline"]["cores"] >= 1
+    assert r["cpu_baseline"]["kind"] == "port" and r["cpu_baseline"]["value"] > 0
+    ref = r["cpu_baseline_reference"]                # the reference's own statements, when oracle/_ref travelled with the snapshot
+    if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "liblift_ref.so")):
+        assert ref["kind"] == "reference" and ref["cores"] == 1 and ref["value"] > 0 and ref["hip_vs_reference_rel_err"] < 1e-11, ref
+    else:
+        assert ref is None
 
 
 @pytest.mark.gpu
