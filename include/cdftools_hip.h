@@ -157,7 +157,10 @@ int cdft_moc_decomp(cdft_moc_plan *plan, const float *zv, const float *ztemp, co
  * 0/1 masks, 3 = one LDS accumulator per basin-bit pattern ("class"; needs several basins, at most
  * 5 (nbasins <= 5) or 8 distinct non-empty patterns, 16-byte aligned records; automatic choice
  * when those hold).  All modes form identical r8 terms; they differ in the (fixed) order of the
- * r8 additions along i, i.e. within the stated 1e-13 * sum|terms| tolerance. */
+ * r8 additions along i, i.e. within the stated 1e-13 * sum|terms| tolerance.
+ * In class mode waves_per_row x vec_per_lane need not cover a row: they make a SEGMENT of it (one workgroup), the row is
+ * cut into as many as it takes and the segments' sums are added in order (the automatic choice for rows longer than
+ * 9.2k cells: 2 waves x 8..10 vectors).  The other modes refuse a shape that does not cover the row. */
 int cdft_moc_set_tuning(cdft_moc_plan *plan, int waves_per_row, int vec_per_lane, int mode);
 /* name of the zonal kernel variant the next compute will launch (for profiles) */
 int cdft_moc_describe(cdft_moc_plan *plan, char *buf, size_t buflen);
