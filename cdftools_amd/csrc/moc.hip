@@ -238,6 +238,13 @@ void choose_shape(const cdft_moc_plan *p, bool aligned, int *nwaves, int *nv, in
     // kernel reads them with 16-byte loads at r4 alignment, whatever the number of basins; the select kernel would
     // fall back to scalar loads
     if (!aligned) md = (class_ok && p->npi >= 4 && p->tune_mode != kModeSelect) ? kModeClass : kModeSelect;
+    // rows longer than one workgroup of the select / fma kernel covers (16 waves x 6, 5 or 2 vectors; 4 for unaligned
+    // records: 16k .. 24k cells): only the class kernel cuts a row into segments -- it takes them whatever the number of
+    // basins, as long as the masks have at most kMaxClass bit patterns
+    {
+        const int vcap = !aligned ? 4 : (md == kModeFma ? 2 : (p->nbasins > 1 ? kBigNV - 1 : kBigNV));
+        if (md != kModeClass && p->tune_mode == 0 && nvec > kWave * kMaxWaves * vcap && class_ok && p->npi >= 4) md = kModeClass;
+    }
     int k, v;
     if (!aligned && md != kModeClass) {
         md = kModeSelect;
@@ -304,7 +311,9 @@ static int zonal_launch(cdft_moc_plan *p, const float *d_zv, int64_t rec_stride,
     choose_shape(p, aligned, &k, &v, &md);
     p->last_aligned = aligned;
     if (k > kMaxWaves || v > kMaxNV)
-        return fail(CDFT_ERR_ARG, "cdft_moc_compute: row of %d cells needs %d waves x %d vectors", p->npi, k, v);
+        return fail(CDFT_ERR_ARG, "cdft_moc_compute: a row of %d cells needs %d waves x %d vectors of the %s kernel (rows this long "
+                    "take basin masks with at most %d bit patterns: the class kernel)", p->npi, k, v, md == kModeFma ? "fma" : "select",
+                    kMaxClass);
     if (md != kModeClass && k * v * kWave < (p->npi + 6) / 4)
         return fail(CDFT_ERR_ARG, "cdft_moc_compute: %d waves x %d vectors do not cover a row of %d (only the class kernel cuts rows)", k, v,
                     p->npi);
@@ -347,9 +356,8 @@ int cdft_moc_create(cdft_moc_plan **plan, int npiglo, int npjglo, int npk, int n
                     npiglo, npjglo, npk);
     if (nbasins < 1 || nbasins > 8)
         return fail(CDFT_ERR_ARG, "cdft_moc_create: nbasins=%d outside 1..8", nbasins);
-    if ((npiglo + 6) / 4 > kWave * 4 * kMaxWaves)   // the unaligned path holds 4 vectors per lane
-        return fail(CDFT_ERR_ARG, "cdft_moc_create: npiglo=%d exceeds the supported row length %d",
-                    npiglo, 4 * kWave * 4 * kMaxWaves - 6);
+    if (npiglo > (1 << 24))                         // (rows of any length: the class kernel cuts them into segments)
+        return fail(CDFT_ERR_ARG, "cdft_moc_create: npiglo=%d exceeds the supported row length %d", npiglo, 1 << 24);
     if ((int64_t)npjglo * (npk - 1) > 0x7fffffffLL)
         return fail(CDFT_ERR_ARG, "cdft_moc_create: npjglo*(npk-1) exceeds the grid limit");
     CDFT_TRY(require_device());

@@ -157,6 +157,40 @@ def test_hip_class_kernel_cuts_long_rows_into_segments(gpu, npi, aligned, tune, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("npi,nb,aligned", [(30000, 5, True), (30001, 5, False), (30000, 1, True), (24577, 1, True), (16385, 1, False), (70000, 3, True)])
+def test_hip_rows_longer_than_any_workgroup(gpu, npi, nb, aligned):
+    """Rows no single workgroup of the select kernel covers (16k .. 24k cells): the class kernel takes them in segments,
+    one basin or several; basin masks with more than 8 bit patterns have no such kernel and are refused with a message."""
+    import torch
+    from cdftools_amd._lib import CdftError
+
+    npj, npk, npt = 2, 3, 2
+    g = synth.make_grid(npi, npj, npk, seed=npi, nbasins=nb)
+    e1v, e3v, ib = synth.moc_inputs(g)
+    zv = synth.velocity(g, npt, seed=3)
+    n3 = npi * npj * npk
+    stride = n3 if aligned else n3 + 1
+    if aligned and stride % 4:
+        stride += 4 - stride % 4
+    buf = torch.zeros(4 + npt * stride, dtype=torch.float32, device="cuda")
+    view = buf[4:] if aligned else buf[1:]
+    for t in range(npt):
+        view[t * stride: t * stride + n3] = torch.from_numpy(zv[t].ravel()).cuda()
+    plan = gpu.MocPlan(npi, npj, npk, nb)
+    plan.set_mesh(e1v, e3v, ib)
+    out = torch.empty((npt, npk, npj, nb), dtype=torch.float64, device="cuda")
+    plan.compute(view, out=out, rec_stride=stride, npt=npt)
+    torch.cuda.synchronize()
+    assert "class_kernel" in plan.describe() and "row_segments=" in plan.describe(), plan.describe()
+    assert_moc_close(out.cpu().numpy(), oracle_lib.moc(e1v, e3v, ib, zv), abs_bound(e1v, e3v, ib, zv))
+    if nb == 5:
+        many = gpu.MocPlan(npi, npj, npk, 8)
+        many.set_mesh(e1v, e3v, (np.random.default_rng(1).random((npj, npi, 8)) < 0.5).astype(np.int16))     # ~256 bit patterns
+        with pytest.raises(CdftError, match="at most 8 bit patterns"):
+            many.compute(view, out=torch.empty((npt, npk, npj, 8), dtype=torch.float64, device="cuda"), rec_stride=stride, npt=npt)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("nb,overlap", [(5, False), (3, False), (8, False), (8, True), (1, False)])
 def test_hip_class_mode_is_chosen_when_the_masks_have_few_bit_patterns(gpu, nb, overlap):
     """Automatic mode: basin masks with at most 8 distinct bit patterns (the empty one, a cell in no
