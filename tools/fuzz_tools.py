@@ -6,6 +6,9 @@
   cdfcurl  (E-W wrap, -T, -overf, r4 out)               bit for bit
   cdfmhst  (-vt, V/T/S, -Zdim, -full, 1..8 masks)       1e-13 of the integral over |terms|
   cdfheatc (r8 sums; byte / r4 mask, -full, -mxloption) 1e-13
+  cdfmean / cdfsum (1..4 basins, three forms, -full)     1e-13
+  cdfzonalsum / cdfzonalmean (class / fast / general kernels; extrema bit for bit)   1e-13
+  cdfvtrp / cdfvhst vertical integrals                   bit for bit
 tests/ run fixed shapes; this draws new ones for FUZZ_SECONDS (default 300) and stops at the first failure.
 Run on the GPU box:  FUZZ_SECONDS=300 python tools/fuzz_tools.py [seed]"""
 import os
@@ -42,7 +45,7 @@ while time.time() < stop:
     npk = int(rng.integers(1, 6))
     while npi * npj * npk > 1_500_000:
         npj = max(1, npj // 2)
-    tool = ["psi", "vt", "curl", "mhst", "heatc"][int(rng.integers(5))]
+    tool = ["psi", "vt", "curl", "mhst", "heatc", "mean", "zonal", "vint"][int(rng.integers(8))]
     g = synth.make_grid(npi, npj, max(npk, 2) if tool == "curl" else npk, seed=int(rng.integers(1 << 30)), land=float(rng.choice([0.0, 0.35, 0.8])))
     shp = dict(npi=npi, npj=npj, npk=npk)
     count[tool] = count.get(tool, 0) + 1
@@ -109,6 +112,59 @@ while time.time() < stop:
             if not np.all(np.abs(got[q] - ref[q]) <= 1e-13 * bound[q] + 1e-300):
                 fail(tool, q, nb=nb, full=full, zdim=zdim, sep=sep, **shp)
         plan.close()
+    elif tool == "mean":                                   # cdfmean / cdfsum (src/cdfmean.f90:405-431, src/cdfsum.f90:303-327)
+        from test_cli_next import mean_inputs
+        nb = int(rng.choice([1, 2, 3, 4]))
+        g, zv, ib = mean_inputs(npi, npj, npk, nb, seed=int(rng.integers(1 << 20)))
+        tm = g["tmask"].astype(f32)
+        form, full = int(rng.integers(3)), bool(rng.integers(2))
+        e3 = dict(e31d=g["e3t_1d"]) if full else dict(e3=g["e3t_0"])
+        plan = hip.MeanPlan(npi, npj, npk, nb)
+        plan.set_mesh(g["e1t"], g["e2t"], tm, ib, **e3)
+        plan.set_form(form)
+        zc = np.where(tm == 0, f32(0), zv).astype(f32) if form else zv      # (the 1e20 fill of land survives only cdfmean's zv*zmask)
+        got = plan.compute(zc)
+        ref = oracle_tools.mean(g["e1t"], g["e2t"], tm, ib, zc, form=form, **e3)
+        bound = oracle_tools.mean(g["e1t"], g["e2t"], tm, ib, np.abs(zc), form=form, **e3)
+        if not np.all(np.abs(got - ref) <= 1e-13 * np.abs(bound) + 1e-300):
+            fail(tool, "", nb=nb, form=form, full=full, **shp)
+        plan.close()
+    elif tool == "zonal":                                  # cdfzonalsum / cdfzonalmean
+        from test_cli_next import zonal_inputs
+        nb = int(rng.choice([1, 3, 5]))
+        g, zv, zm = zonal_inputs(npi, npj, npk, nb, seed=int(rng.integers(1 << 20)))
+        tm = g["tmask"].astype(f32)
+        fam = int(rng.integers(3))
+        for key in ("CDFT_ZONAL_GENERAL", "CDFT_ZONAL_NOCLASS"):
+            os.environ.pop(key, None)
+        if fam:
+            os.environ["CDFT_ZONAL_GENERAL" if fam == 2 else "CDFT_ZONAL_NOCLASS"] = "1"
+        mean_form = bool(rng.integers(2))
+        plan = hip.ZonalPlan(npi, npj, npk, nb)
+        plan.set_mesh(g["e1t"], g["e2t"], tm, zm)
+        got = plan.compute(zv, mean_form=mean_form, minmax=mean_form)
+        ref = oracle_tools.zonal(g["e1t"], g["e2t"], tm, zm, zv, mean_form=mean_form)
+        bound = oracle_tools.zonal(g["e1t"], g["e2t"], tm, zm, np.abs(zv), mean_form=mean_form)["sum"]
+        ok = np.all(np.abs(got["sum"] - ref["sum"]) <= 1e-13 * bound + 1e-300)
+        if mean_form:
+            ok = ok and np.all(np.abs(got["area"] - ref["area"]) <= 1e-13 * np.abs(ref["area"]) + 1e-300)
+            ok = ok and np.array_equal(got["max"], ref["max"]) and np.array_equal(got["min"], ref["min"])
+        if not ok:
+            fail(tool, "", nb=nb, family=fam, mean_form=mean_form, **shp)
+        plan.close()
+    elif tool == "vint":                                   # cdfvtrp / cdfvhst: every cell walks its levels in order: bit for bit
+        t, s, u, v = tracer_fields(g, int(rng.integers(1 << 20)))
+        full = bool(rng.integers(2))
+        e3 = dict(e31d=g["e3t_1d"]) if full else dict(e3=g["e3v_0"])
+        if rng.integers(2):
+            got, ref = hip.vint_transport(v, g["e1v"], **e3), oracle_tools.vint_transport(v, g["e1v"], **e3)
+            ok = np.array_equal(got, ref)
+        else:
+            vt, vs = (t * v).astype(f32), (s * v).astype(f32)
+            got, ref = hip.vhst_transport(vt, vs, g["e1v"], **e3), oracle_tools.vhst_transport(vt, vs, g["e1v"], **e3)
+            ok = np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+        if not ok:
+            fail(tool, "", full=full, **shp)
     else:
         shape = (npk, npj, npi)
         e3t = (1 + 199 * rng.random(shape)).astype(f32)
@@ -130,4 +186,4 @@ while time.time() < stop:
         if not np.all(np.abs(got - ref) <= 1e-13 * np.abs(bound) + 1e-300):
             fail(tool, "", full=full, m8=m8, opt=opt, **shp)
         plan.close()
-print(f"fuzz_tools: seed {seed}: {sum(count.values())} cases {count}: every result equal to the oracle (psi, vt, curl: bit for bit; mhst, heatc: 1e-13)")
+print(f"fuzz_tools: seed {seed}: {sum(count.values())} cases {count}: every result equal to the oracle (psi, vt, curl, vint: bit for bit; mhst, heatc, mean, zonal: 1e-13)")
