@@ -9,6 +9,7 @@
   cdfmean / cdfsum (1..4 basins, three forms, -full)     1e-13
   cdfzonalsum / cdfzonalmean (class / fast / general kernels; extrema bit for bit)   1e-13
   cdfvtrp / cdfvhst vertical integrals                   bit for bit
+  cdfmocsig (three equations of state, -full, -eiv, -isodep, class / general kernel)   1e-13
 tests/ run fixed shapes; this draws new ones for FUZZ_SECONDS (default 300) and stops at the first failure.
 Run on the GPU box:  FUZZ_SECONDS=300 python tools/fuzz_tools.py [seed]"""
 import os
@@ -45,7 +46,9 @@ while time.time() < stop:
     npk = int(rng.integers(1, 6))
     while npi * npj * npk > 1_500_000:
         npj = max(1, npj // 2)
-    tool = ["psi", "vt", "curl", "mhst", "heatc", "mean", "zonal", "vint"][int(rng.integers(8))]
+    tool = ["psi", "vt", "curl", "mhst", "heatc", "mean", "zonal", "vint", "mocsig"][int(rng.integers(9))]
+    if tool == "mocsig":
+        npk = max(npk, 2)
     g = synth.make_grid(npi, npj, max(npk, 2) if tool == "curl" else npk, seed=int(rng.integers(1 << 30)), land=float(rng.choice([0.0, 0.35, 0.8])))
     shp = dict(npi=npi, npj=npj, npk=npk)
     count[tool] = count.get(tool, 0) + 1
@@ -152,6 +155,35 @@ while time.time() < stop:
         if not ok:
             fail(tool, "", nb=nb, family=fam, mean_form=mean_form, **shp)
         plan.close()
+    elif tool == "mocsig":                                 # cdfmocsig (src/cdfmocsig.f90:368-470): class and general kernels
+        import oracle_lib
+        nb = int(rng.choice([1, 3, 5]))
+        t, s, _, v = tracer_fields(g, int(rng.integers(1 << 20)))
+        if rng.integers(2):                                # smooth fields: neighbours share a density class
+            t = (t * 0 + (20 - 18 * np.linspace(0, 1, npj, dtype=f32))[None, :, None]).astype(f32) * g["tmask"]
+        e1v, e3v, ib = synth.moc_inputs(g, nbasins=nb)
+        eos, pref = int(rng.integers(3)), float(rng.choice([0.0, 1000.0, 2000.0]))
+        sigmin, sigstp, nbins = {0.0: (20.0, 0.1, 100), 1000.0: (24.0, 0.1, 101), 2000.0: (30.0, 0.05, 158)}[pref]
+        if eos == 2:
+            pref = 0.0
+        full, eiv, isodep = bool(rng.integers(2)), bool(rng.integers(2)), bool(rng.integers(2))
+        if rng.integers(4) == 0:
+            os.environ["CDFT_MOCSIG_NOCLASS"] = "1"
+        else:
+            os.environ.pop("CDFT_MOCSIG_NOCLASS", None)
+        kw = dict(pref=pref, zveiv=(v * f32(0.1)).astype(f32) if eiv else None, gdep=g["gdept_1d"] if isodep else None, isodep=isodep,
+                  **(dict(e31d=g["e3t_1d"]) if full else dict(e3v=e3v)))
+        got = hip.mocsig(v, t, s, e1v, ib, nbins, sigmin, sigstp, eos=(hip.EOS_80, hip.EOS_TEOS10, hip.EOS_NTR)[eos], **kw)
+        ref = oracle_lib.mocsig(v, t, s, e1v, ib, nbins, sigmin, sigstp, teos10=eos == 1, ntr=eos == 2, **kw)
+        kwb = dict(kw, zveiv=None if not eiv else np.abs(kw["zveiv"]))
+        bound = oracle_lib.mocsig(np.abs(v), t, s, e1v, ib, nbins, sigmin, sigstp, teos10=eos == 1, ntr=eos == 2, **kwb)
+        gd, rd = (got[0], ref[0]) if isodep else (got, ref)
+        bd = bound[0] if isodep else bound
+        ok = np.all(np.abs(gd - rd) <= 1e-13 * np.abs(bd) + 1e-300)
+        if isodep:
+            ok = ok and np.allclose(got[1], ref[1], rtol=1e-12, atol=0)
+        if not ok:
+            fail(tool, "", nb=nb, eos=eos, pref=pref, full=full, eiv=eiv, isodep=isodep, noclass=os.environ.get("CDFT_MOCSIG_NOCLASS"), **shp)
     elif tool == "vint":                                   # cdfvtrp / cdfvhst: every cell walks its levels in order: bit for bit
         t, s, u, v = tracer_fields(g, int(rng.integers(1 << 20)))
         full = bool(rng.integers(2))
@@ -186,4 +218,4 @@ while time.time() < stop:
         if not np.all(np.abs(got - ref) <= 1e-13 * np.abs(bound) + 1e-300):
             fail(tool, "", full=full, m8=m8, opt=opt, **shp)
         plan.close()
-print(f"fuzz_tools: seed {seed}: {sum(count.values())} cases {count}: every result equal to the oracle (psi, vt, curl, vint: bit for bit; mhst, heatc, mean, zonal: 1e-13)")
+print(f"fuzz_tools: seed {seed}: {sum(count.values())} cases {count}: every result equal to the oracle (psi, vt, curl, vint: bit for bit; mhst, heatc, mean, zonal, mocsig: 1e-13)")
