@@ -10,6 +10,7 @@
   cdfzonalsum / cdfzonalmean (class / fast / general kernels; extrema bit for bit)   1e-13
   cdfvtrp / cdfvhst vertical integrals                   bit for bit
   cdfmocsig (three equations of state, -full, -eiv, -isodep, class / general kernel)   1e-13
+  sharded plans of cdfmoc / cdfpsi / cdfmhst / cdfvT / cdfheatc (reference-order sums), 2..6 row blocks   the bits of one plan
 tests/ run fixed shapes; this draws new ones for FUZZ_SECONDS (default 300) and stops at the first failure.
 Run on the GPU box:  FUZZ_SECONDS=300 python tools/fuzz_tools.py [seed]"""
 import os
@@ -46,7 +47,7 @@ while time.time() < stop:
     npk = int(rng.integers(1, 6))
     while npi * npj * npk > 1_500_000:
         npj = max(1, npj // 2)
-    tool = ["psi", "vt", "curl", "mhst", "heatc", "mean", "zonal", "vint", "mocsig"][int(rng.integers(9))]
+    tool = ["psi", "vt", "curl", "mhst", "heatc", "mean", "zonal", "vint", "mocsig", "sharded"][int(rng.integers(10))]
     if tool == "mocsig":
         npk = max(npk, 2)
     g = synth.make_grid(npi, npj, max(npk, 2) if tool == "curl" else npk, seed=int(rng.integers(1 << 30)), land=float(rng.choice([0.0, 0.35, 0.8])))
@@ -155,6 +156,53 @@ while time.time() < stop:
         if not ok:
             fail(tool, "", nb=nb, family=fam, mean_form=mean_form, **shp)
         plan.close()
+    elif tool == "sharded":                                # row-block sharded plans (every block on this device) == one plan
+        import oracle_lib
+        nd = int(rng.integers(2, 7))
+        if npj < nd:
+            npj = nd + int(rng.integers(0, 4))
+            g = synth.make_grid(npi, npj, npk, seed=int(rng.integers(1 << 30)))
+            shp = dict(npi=npi, npj=npj, npk=npk)
+        dev = [0] * nd
+        t, s, u, v = tracer_fields(g, int(rng.integers(1 << 20)))
+        which = ["moc", "psi", "mhst", "vt", "heatc_r4seq"][int(rng.integers(5))]
+        ok = True
+        if which == "moc" and npk >= 2:
+            nb = int(rng.choice([1, 5]))
+            e1v, e3v, ib = synth.moc_inputs(g, nbasins=nb)
+            zv = synth.velocity(g, int(rng.integers(1, 4)), seed=int(rng.integers(1 << 20)))
+            one, sh = hip.MocPlan(npi, npj, npk, nb), hip.MocPlan(npi, npj, npk, nb, devices=dev)
+            for pl in (one, sh):
+                pl.set_mesh(e1v, e3v, ib)
+            ok = np.array_equal(sh.compute(zv), one.compute(zv))
+        elif which == "psi":
+            kw = [dict(zu=u, e2u=g["e2u"], e3u=g["e3u_0"]), dict(zv=v, e1v=g["e1v"], e3v=g["e3v_0"]),
+                  dict(zu=u, e2u=g["e2u"], e3u=g["e3u_0"], zv=v, e1v=g["e1v"], e3v=g["e3v_0"])][int(rng.integers(3))]
+            kw.update(iiref=int(rng.integers(1, npi + 1)), ijref=int(rng.integers(1, npj + 1)))
+            a, b = hip.PsiPlan(npi, npj, npk).compute(**kw), hip.PsiPlan(npi, npj, npk, devices=dev).compute(**kw)
+            ok = np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        elif which == "mhst":
+            m = mhst_masks(g, 4)
+            vt_, vs_ = (t * v).astype(f32), (s * v).astype(f32)
+            one, sh = hip.MhstPlan(npi, npj, npk, 4), hip.MhstPlan(npi, npj, npk, 4, devices=dev)
+            for pl in (one, sh):
+                pl.set_mesh(g["e1v"], m, e3v=g["e3v_0"])
+            fld = dict(zv=v, zt=t, zs=s) if rng.integers(2) else dict(vt=vt_, vs=vs_)
+            a, b = one.compute(**fld), sh.compute(**fld)
+            ok = np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        elif which == "vt":
+            fr = frames(g, int(rng.integers(1, 4)), seed=int(rng.integers(1 << 20)))
+            a, b = hip.vt_compute(*fr[:4]), hip.vt_compute(*fr[:4], devices=dev)
+            ok = all(np.array_equal(a[k], b[k]) for k in a)
+        elif which == "heatc_r4seq":                       # the chains carried from block to block: the same bits
+            temp = (-2 + 32 * rng.random((npk, npj, npi))).astype(f32)
+            one, sh = hip.HeatcPlan(npi, npj, npk), hip.HeatcPlan(npi, npj, npk, devices=dev)
+            for pl in (one, sh):
+                pl.set_mesh(g["e1t"], g["e2t"], g["tmask"].astype(np.uint8), e3t=g["e3t_0"])
+                pl.set_sum_mode(True)
+            ok = np.array_equal(one.compute(temp).view(np.uint64), sh.compute(temp).view(np.uint64))
+        if not ok:
+            fail(tool, which, blocks=nd, **shp)
     elif tool == "mocsig":                                 # cdfmocsig (src/cdfmocsig.f90:368-470): class and general kernels
         import oracle_lib
         nb = int(rng.choice([1, 3, 5]))
