@@ -76,7 +76,13 @@ def write_data(path, g, depname, fields, times=None, fill=None):
 
 
 def make_case(d, npi=24, npj=18, npk=7, npt=2, seed=20240601, basins=True):
-    """-> (grid dict, {'v','u','t','s'} records) with every file written under directory d."""
+    """-> (grid dict, {'v','u','t','s'} records) with every file written under directory d.
+    CDFT_TEST_SHAPE="npi,npj,npk" in the environment replaces the grid size every end-to-end test asks for: the program
+    tests then run on other shapes (plane sizes that are not multiples of 4, rows longer than a tile, ...) unchanged
+    (at least 20 x 15 x 4: some of them pass zoom windows).  Run on the GPU box, e.g.
+    CDFT_TEST_SHAPE=1443,37,4 python -m pytest tests/test_cli.py tests/test_cli_tools.py tests/test_cli_next.py tests/test_cli_sharded.py -m gpu"""
+    if os.environ.get("CDFT_TEST_SHAPE") and (npi, npj, npk) in ((24, 18, 7), (26, 19, 6)):     # (the end-to-end tests' two grids)
+        npi, npj, npk = (int(x) for x in os.environ["CDFT_TEST_SHAPE"].split(","))
     g = synth.make_grid(npi, npj, npk, seed=seed)
     write_mesh(d, g)
     if basins:

@@ -37,14 +37,15 @@ def same_file(a, b):
     return True
 
 
-def pair(tool, args, d, out, gmap):
+def pair(tool, args, d, out, gmap, same_stdout=True):
     """run `tool args -o <out>` on one device and on the row blocks of `gmap`; -> the two output paths"""
     a, b = f"{out}_1.nc", f"{out}_n.nc"
     rc, o1, e1 = run(tool, args + ["-o", a], d)
     assert rc == 0, o1 + e1
     rc, o2, e2 = run(tool, args + ["-o", b], d, env={"CDFT_GPU_MAP": gmap})
     assert rc == 0, o2 + e2
-    assert o1.replace(a, "X") == o2.replace(b, "X")                      # the same standard output
+    if same_stdout:
+        assert o1.replace(a, "X") == o2.replace(b, "X")                  # the same standard output
     return os.path.join(d, a), os.path.join(d, b)
 
 
@@ -69,7 +70,8 @@ def test_programs_on_row_blocks_write_identical_files(case, gmap):
     assert same_file(a, b)
     os.environ["CDFT_HEATC_SUM"] = "r8"
     try:
-        a, b = pair("cdfheatc", ["-f", "SYN_y0001_gridT.nc"], d, "heatc8", gmap)  # r8 sums: block sums added in block order
+        # r8 sums: block sums added in block order -- 1e-13, so the last printed digit may differ (it does at 1443 x 37 x 4)
+        a, b = pair("cdfheatc", ["-f", "SYN_y0001_gridT.nc"], d, "heatc8", gmap, same_stdout=False)
     finally:
         del os.environ["CDFT_HEATC_SUM"]
     va, _, _ = read_nc(a)
