@@ -507,7 +507,6 @@ __global__ void __launch_bounds__(64 * kScanWaves, 3) heatc_scan_kernel(HeatcArg
             const bool whole = c0 + kScanChunk <= a.nij;          // (uniform) every cell of the chunk exists
 #pragma unroll
             for (int v = 0; v < kScanNV; ++v) {
-                const int left = whole ? 4 : (int)max((int64_t)0, min((int64_t)4, a.nij - (c0 + v * 256 + 4 * lane)));
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const Raw &r = raw[v];
@@ -520,7 +519,15 @@ __global__ void __launch_bounds__(64 * kScanWaves, 3) heatc_scan_kernel(HeatcArg
                     x[0][v][c] = __fmul_rn(r.ar[c], r.mk[c]);
                     x[1][v][c] = __fmul_rn(pv, r.mk[c]);
                     x[2][v][c] = __fmul_rn(__fmul_rn(pv, r.tt[c]), r.mk[c]);
-                    if (!whole && c >= left) x[0][v][c] = x[1][v][c] = x[2][v][c] = 0.f;
+                }
+            }
+            if (!whole) {                                         // (uniform: only the last chunk of a level takes this branch)
+#pragma unroll
+                for (int v = 0; v < kScanNV; ++v) {
+                    const int left = (int)max((int64_t)0, min((int64_t)4, a.nij - (c0 + v * 256 + 4 * lane)));
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (c >= left) x[0][v][c] = x[1][v][c] = x[2][v][c] = 0.f;
                 }
             }
         };
@@ -542,21 +549,23 @@ __global__ void __launch_bounds__(64 * kScanWaves, 3) heatc_scan_kernel(HeatcArg
                     float far = 0.f;                              // the largest |q - rint(q)|: 0.5 exactly = a tie
                     if (key >= 0 && anz) {
                         const float scale = scan_scale(key);
+                        // a lane's eight k's are added as floats: exact, each |k| < 2^20 (or the chunk is `big` and its sums
+                        // are not used) -- one conversion per lane instead of one per cell
+                        float Kf = 0.f, posf = 0.f;
 #pragma unroll
                         for (int v = 0; v < kScanNV; ++v)
 #pragma unroll
                             for (int c = 0; c < 4; ++c) {
                                 const float qq = __fmul_rn(x[ch][v][c], scale);               // exact (a power of two), or Inf / NaN
                                 const float kf = rintf(qq);
-                                const int   ki = (int)kf;                                     // (saturating conversion; guarded by `big`)
-                                K += ki;
-                                if (ch == 2) pos += max(ki, 0);                               // (surface and volume: see below)
+                                Kf = __fadd_rn(Kf, kf);
+                                if (ch == 2) posf = __fadd_rn(posf, fmaxf(kf, 0.f));          // (surface and volume: see below)
                                 far = fmaxf(far, fabsf(__fsub_rn(qq, kf)));                   // the difference is exact
                                 sgn |= __float_as_uint(qq);
                                 big = max(big, __float_as_uint(qq) & 0x7fffffffu);            // NaN > Inf > every finite |q|
                             }
-                        K = wave_isum(K);
-                        pos = ch == 2 ? wave_isum(pos) : K;
+                        K = wave_isum((int)Kf);                                               // (saturating conversions; guarded by `big`)
+                        pos = ch == 2 ? wave_isum((int)posf) : K;
                     }
                     // a tie; NaN, Inf, or |k| >= 2^20 (x not well below s; and the sums of 512 k's stay inside 32 bits); and for
                     // the surface and the volume, whose terms are never negative on a real mesh (pos = K, one sum less to
