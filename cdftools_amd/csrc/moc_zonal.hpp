@@ -358,8 +358,8 @@ __device__ __forceinline__ void moc_zonal_class_row(const ZonalArgs &a, const in
     const int     head = ALIGNED ? (int)(g0 & 3) : 0;
     const int     segv = nwaves * (kWave * NV);                   // vectors of a segment
     const int     v0   = seg * segv + wave * (kWave * NV) + lane;
-    const int     nfull = a.npi >> 2;
-    double *const outp = a.nseg > 1 ? a.seg_out + (int64_t)seg * a.seg_stride : a.out;                             // (not ALIGNED) vectors 0..nfull-1 start at cell 4v
+    const int     nfull = a.npi >> 2;                             // (not ALIGNED) vectors 0..nfull-1 start at cell 4v
+    double *const outp = a.nseg > 1 ? a.seg_out + (int64_t)seg * a.seg_stride : a.out;
 
     float    w[NV][4];
     uint32_t cpk[NV];                                             // the 4 cells' classes, a byte each (their slots: cls*kScrStride + lane)
