@@ -11,6 +11,7 @@
 // values in registers and streams zv / e3 / mask past them (12 bytes per cell and level).
 #include <cstdlib>
 #include "common.hpp"
+#include <type_traits>
 #include "reduce.hpp"
 
 using namespace cdft;
@@ -82,6 +83,7 @@ __global__ void __launch_bounds__(kThreads) mean_level_kernel(MeanArgs a) {
             for (int b = 0; b < NB; ++b) fb[v][c][b] = (b < a.nb) ? (float)a.ib[pc * a.nb + min(b, a.nb - 1)] : 0.f;
         }
     }
+    const int sumform = a.form == CDFT_MEAN_FORM_MEAN_NOVAR ? CDFT_MEAN_FORM_MEAN : a.form;
     for (int k = 0; k < a.npk; ++k) {
         const int64_t base = (int64_t)k * a.nij;
         float zv[kVPT][VEC], e3[kVPT][VEC], mk[kVPT][VEC];
@@ -123,33 +125,40 @@ __global__ void __launch_bounds__(kThreads) mean_level_kernel(MeanArgs a) {
         double s[NB][4];
 #pragma unroll
         for (int b = 0; b < NB; ++b) { s[b][0] = s[b][1] = s[b][2] = s[b][3] = 0.0; }
+        // the variance sum only where it is asked for (cdfmean -var): a uniform branch around two copies of the cell loop,
+        // not a select per cell -- 4 products, a conversion, an r8 add and a wave sum less per cell otherwise
+        auto cells = [&](auto want_var) {
 #pragma unroll
-        for (int v = 0; v < kVPT; ++v)
+            for (int v = 0; v < kVPT; ++v)
 #pragma unroll
-            for (int c = 0; c < VEC; ++c) {
-                const float m = mk[v][c];
-                const float zm = __fmul_rn(zv[v][c], m);                                  // :410
-                const float ar = __fmul_rn(e1[v][c], e2[v][c]);
-                const float t_surf = __fmul_rn(ar, m);                                     // e1*e2*zmask
-                const float t_vol  = __fmul_rn(__fmul_rn(ar, e3[v][c]), m);                // e1*e2*e3*zmask
-                const float zee = __fmul_rn(__fmul_rn(zm, e1[v][c]), e2[v][c]);            // zv*e1*e2
-                // cdfmean: zv*e1*e2*e3 (:421); cdfsum: zv*e1*e2 (src/cdfsum.f90:309), forcing field: zv*e1*e2*zmask (:320)
-                const float t_sum  = a.form == 0 ? __fmul_rn(zee, e3[v][c]) : (a.form == 1 ? zee : __fmul_rn(zee, m));
-                const float t_var  = a.form == 0 ? __fmul_rn(__fmul_rn(__fmul_rn(__fmul_rn(zm, zm), e1[v][c]), e2[v][c]), e3[v][c]) : 0.f;
+                for (int c = 0; c < VEC; ++c) {
+                    const float m = mk[v][c];
+                    const float zm = __fmul_rn(zv[v][c], m);                                  // :410
+                    const float ar = __fmul_rn(e1[v][c], e2[v][c]);
+                    const float t_surf = __fmul_rn(ar, m);                                     // e1*e2*zmask
+                    const float t_vol  = __fmul_rn(__fmul_rn(ar, e3[v][c]), m);                // e1*e2*e3*zmask
+                    const float zee = __fmul_rn(__fmul_rn(zm, e1[v][c]), e2[v][c]);            // zv*e1*e2
+                    // cdfmean: zv*e1*e2*e3 (:421); cdfsum: zv*e1*e2 (src/cdfsum.f90:309), forcing field: zv*e1*e2*zmask (:320)
+                    const float t_sum  = sumform == 0 ? __fmul_rn(zee, e3[v][c]) : (sumform == 1 ? zee : __fmul_rn(zee, m));
+                    float t_var = 0.f;
+                    if (decltype(want_var)::value) t_var = __fmul_rn(__fmul_rn(__fmul_rn(__fmul_rn(zm, zm), e1[v][c]), e2[v][c]), e3[v][c]);
 #pragma unroll
-                for (int b = 0; b < NB; ++b) {                 // basins past nb have f = 0: they add exact zeros
-                    const float f = fb[v][c][b];
-                    s[b][0] += (double)__fmul_rn(t_surf, f);
-                    s[b][1] += (double)__fmul_rn(t_vol, f);
-                    s[b][2] += (double)__fmul_rn(t_sum, f);
-                    s[b][3] += (double)__fmul_rn(t_var, f);
+                    for (int b = 0; b < NB; ++b) {             // basins past nb have f = 0: they add exact zeros
+                        const float f = fb[v][c][b];
+                        s[b][0] += (double)__fmul_rn(t_surf, f);
+                        s[b][1] += (double)__fmul_rn(t_vol, f);
+                        s[b][2] += (double)__fmul_rn(t_sum, f);
+                        if (decltype(want_var)::value) s[b][3] += (double)__fmul_rn(t_var, f);
+                    }
                 }
-            }
+        };
+        if (a.form == CDFT_MEAN_FORM_MEAN) cells(std::true_type{});
+        else                               cells(std::false_type{});
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const double t = wave_sum(s[b][c]);
+                const double t = (c < 3 || a.form == CDFT_MEAN_FORM_MEAN) ? wave_sum(s[b][c]) : 0.0;       // (uniform)
                 if (lane == 0 && b < a.nb) wsum[((PARK ? wave * a.npk + k : wave) * a.nb + b) * 4 + c] = t;
             }
         if (!PARK) {
@@ -258,8 +267,8 @@ int cdft_mean_set_mesh(cdft_mean_plan *p, const float *e1, const float *e2, cons
 
 int cdft_mean_set_form(cdft_mean_plan *p, int form) {
     if (!p) return fail(CDFT_ERR_ARG, "cdft_mean_set_form: NULL plan");
-    if (form < CDFT_MEAN_FORM_MEAN || form > CDFT_MEAN_FORM_SUM_FORCING)
-        return fail(CDFT_ERR_ARG, "cdft_mean_set_form: form %d outside 0..2", form);
+    if (form < CDFT_MEAN_FORM_MEAN || form > CDFT_MEAN_FORM_MEAN_NOVAR)
+        return fail(CDFT_ERR_ARG, "cdft_mean_set_form: form %d outside 0..3", form);
     p->form = form;
     return CDFT_OK;
 }

@@ -212,6 +212,8 @@ PROGRAM cdfmean
   CALL readvar3d(cn_fmsk, cv_msk, zmask, kimin=iimin, kjmin=ijmin, kkmin=ikmin)      ! (every level in one read)
   IF ( .NOT. lfull ) ALLOCATE( e3(npiglo,npjglo,nvpk) )
   CALL hip_check(cdft_mean_create(plan, npiglo, npjglo, nvpk, nbasin), 'cdft_mean_create')
+  ! without -var nothing reads dvar2d: the kernel then leaves its four products per cell out (the slot comes back 0)
+  IF ( .NOT. lvar ) CALL hip_check(cdft_mean_set_form(plan, CDFT_MEAN_FORM_MEAN_NOVAR), 'cdft_mean_set_form')
 
   DO jt = 1, npt
      it = 1 ; IF ( lg_vvl ) it = jt

@@ -12,7 +12,8 @@ MODULE cdftools_hip
 
   INTEGER(C_INT), PARAMETER :: CDFT_OK = 0, CDFT_MEM_HOST = 0, CDFT_MEM_DEVICE = 1
   INTEGER(C_INT), PARAMETER :: CDFT_HEATC_SUM_R8 = 0, CDFT_HEATC_SUM_R4SEQ = 1
-  INTEGER(C_INT), PARAMETER :: CDFT_MEAN_FORM_MEAN = 0, CDFT_MEAN_FORM_SUM = 1, CDFT_MEAN_FORM_SUM_FORCING = 2
+  INTEGER(C_INT), PARAMETER :: CDFT_MEAN_FORM_MEAN = 0, CDFT_MEAN_FORM_SUM = 1, CDFT_MEAN_FORM_SUM_FORCING = 2, &
+       &                       CDFT_MEAN_FORM_MEAN_NOVAR = 3
   INTEGER(C_INT), PARAMETER :: CDFT_EOS_80 = 0, CDFT_EOS_TEOS10 = 1, CDFT_EOS_JMD94 = 2, CDFT_EOS_NTR = 3, CDFT_EOS_FAST_FMA = 1
   INTEGER(C_INT), PARAMETER :: CDFT_EOS_MCD87 = 4
   INTEGER(C_INT), PARAMETER :: CDFT_EOSQ_ALPHA = 0, CDFT_EOSQ_BETA = 1, CDFT_EOSQ_ALBET_MCD87 = 2, CDFT_EOSQ_BETA_MCD87 = 3

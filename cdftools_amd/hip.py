@@ -604,7 +604,7 @@ class MeanPlan(_Plan):
         check(_lib.load().cdft_mean_set_mesh(self._h, *ptr, MEM_HOST, stream or current_stream_ptr()))
 
     def set_form(self, form):
-        """0 = cdfmean, 1 = cdfsum, 2 = cdfsum on a file without depth (cdft_mean_set_form)."""
+        """0 = cdfmean, 1 = cdfsum, 2 = cdfsum on a file without depth, 3 = cdfmean without the variance sum (cdft_mean_set_form)."""
         check(_lib.load().cdft_mean_set_form(self._h, int(form)))
 
     def compute(self, zv, stream=None):

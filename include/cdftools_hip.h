@@ -337,6 +337,7 @@ int cdft_mean_compute(cdft_mean_plan *plan, const float *zv, int in_space, doubl
 #define CDFT_MEAN_FORM_MEAN        0
 #define CDFT_MEAN_FORM_SUM         1
 #define CDFT_MEAN_FORM_SUM_FORCING 2
+#define CDFT_MEAN_FORM_MEAN_NOVAR  3   /* cdfmean without -var: the three sums of FORM_MEAN, dvar2d = 0 (its products are not formed) */
 int cdft_mean_set_form(cdft_mean_plan *plan, int form);
 int cdft_mean_destroy(cdft_mean_plan *plan);
 

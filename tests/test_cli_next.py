@@ -259,7 +259,7 @@ def test_hip_sum_forms_match_oracle(gpu, npi, npj, npk):
         bound = oracle_tools.mean(g["e1t"], g["e2t"], tm, ib, np.abs(zv), e3=g["e3t_0"], form=form)
         assert np.all(np.abs(got - ref) <= 1e-13 * bound + 1e-300), form
     with pytest.raises(gpu.CdftError):
-        plan.set_form(3)
+        plan.set_form(4)                                                  # (3 = cdfmean without the variance sum)
 
 
 def test_cdfsum_usage_and_option_errors(tools, tmp_path):  # noqa: F811

@@ -163,6 +163,13 @@ def test_hip_mean_and_sum_against_reference_statements(gpu, name):
         got = p.compute(field[t])
         bound = ot.mean(g["e1t"], g["e2t"], tm, ib, np.abs(field[t]), **e3kw(g, full))
         assert np.all(np.abs(got - G[f"mean.{name}.sums"][t]) <= 1e-13 * bound + 1e-300)
+        # cdfmean without -var (CDFT_MEAN_FORM_MEAN_NOVAR): the same three sums, bit for bit, and no variance sum
+        p.set_form(3)
+        nov = p.compute(field[t])
+        p.set_form(0)
+        assert np.array_equal(nov[..., :3], got[..., :3]) and not nov[..., 3].any()
+    with pytest.raises(gpu.CdftError):
+        p.set_form(4)
 
 
 # ================================================================================================ cdfvertmean / cdfvint

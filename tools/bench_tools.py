@@ -83,7 +83,14 @@ def main():
         p.set_mesh(e1.cpu().numpy(), e2.cpu().numpy(), tm, np.ones((npj, npi, 1), np.int16), e3=e3.cpu().numpy())
         del tm
         ms = timed(lambda: p.compute(zv), args.reps)
-        report("cdfmean (1 basin)", args.grid, n3, 9.0, ms, "field 4 + e3 4 + mask 1 B per cell (a 0/1 mask is kept as bytes); includes the D2H of 4*npk sums")
+        report("cdfmean -var (1 basin)", args.grid, n3, 9.0, ms, "field 4 + e3 4 + mask 1 B per cell (a 0/1 mask is kept as bytes); includes the D2H of 4*npk sums; "
+               "with the variance sum (zv*zv*e1*e2*e3)")
+        p.set_form(3)
+        ms = timed(lambda: p.compute(zv), args.reps)
+        report("cdfmean (1 basin)", args.grid, n3, 9.0, ms, "the same without the variance sum (CDFT_MEAN_FORM_MEAN_NOVAR: what the program asks for without -var)")
+        p.set_form(1)
+        ms = timed(lambda: p.compute(zv), args.reps)
+        report("cdfsum (1 basin)", args.grid, n3, 9.0, ms, "cdfsum's form: SUM(zv*e1*e2), no variance")
         del p, zv
 
     if "zonal" in tools:
