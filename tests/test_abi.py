@@ -23,6 +23,30 @@ def test_header_and_binding_agree():
     assert sorted(_lib.SIGNATURES) == syms
 
 
+def test_fortran_binding_constants_equal_the_header():
+    """cdftools_hip.f90 repeats the header's integer constants (Fortran cannot include a C header): every CDFT_* parameter
+    of the module has the value of the header's #define, and every entry point of the header has its BIND(C) interface."""
+    hdr = open(os.path.join(ROOT, "include", "cdftools_hip.h")).read()
+    defs = {m.group(1): int(m.group(2), 0) for m in re.finditer(r"^#define\s+(CDFT_[A-Z0-9_]+)\s+(-?(?:0x[0-9a-fA-F]+|\d+))\b", hdr, flags=re.M)}
+    f90 = open(os.path.join(ROOT, "cdftools_amd", "fortran", "cdftools_hip.f90")).read()
+    f90 = re.sub(r"&\s*\n\s*&", " ", f90)                                   # continuation lines
+    pars = {}
+    for line in re.findall(r"INTEGER\(C_INT\),\s*PARAMETER\s*::\s*(.*)", f90):
+        for name, val in re.findall(r"(CDFT_[A-Z0-9_]+)\s*=\s*(-?\d+)", line):
+            pars[name] = int(val)
+    assert len(pars) >= 15
+    for name, val in pars.items():
+        assert name in defs, f"{name} is not a #define of the header"
+        assert defs[name] == val, f"{name}: {val} in cdftools_hip.f90, {defs[name]} in the header"
+    bound = set(re.findall(r"BIND\(C,\s*name='(cdft_[a-z0-9_]+)'\)", f90))
+    syms = header_symbols()
+    assert bound and not [x for x in bound if x not in syms], "an interface of cdftools_hip.f90 binds a name the header does not declare"
+    # the entries a program needs (plans and computations); the harness hooks (timers, tuning, cdft_malloc, ...) stay C-only
+    needed = [x for x in syms if re.search(r"_(create|create_sharded|set_mesh|compute|destroy)$", x) and not x.startswith("cdft_timer_")]
+    missing = [x for x in needed if x not in bound]
+    assert not missing, f"no Fortran interface for {missing}"
+
+
 def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in header_symbols():
