@@ -47,6 +47,20 @@ def test_fortran_binding_constants_equal_the_header():
     assert not missing, f"no Fortran interface for {missing}"
 
 
+def test_python_mirror_constants_equal_the_header():
+    from cdftools_amd import hip
+    hdr = open(os.path.join(ROOT, "include", "cdftools_hip.h")).read()
+    defs = {m.group(1): int(m.group(2), 0) for m in re.finditer(r"^#define\s+(CDFT_[A-Z0-9_]+)\s+(-?(?:0x[0-9a-fA-F]+|\d+))\b", hdr, flags=re.M)}
+    seen = 0
+    for mod in (hip, _lib):
+        for name, val in vars(mod).items():
+            key = name if name.startswith("CDFT_") else "CDFT_" + name
+            if isinstance(val, int) and not isinstance(val, bool) and name.isupper() and key in defs:
+                assert defs[key] == val, f"{mod.__name__}.{name} = {val}, the header says {defs[key]}"
+                seen += 1
+    assert seen >= 15
+
+
 def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in header_symbols():
