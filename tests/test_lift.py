@@ -367,7 +367,8 @@ def test_hip_heatc_against_reference_statements(gpu, name):
     G = gold("cdfheatc")
     npk, npj, npi = g["tmask"].shape
     plan = gpu.HeatcPlan(npi, npj, npk)
-    plan.set_mesh(g["e1t"], g["e2t"], g["tmask"].astype(np.uint8), **(dict(e31d=g["e3t_1d"]) if full else dict(e3t=g["e3t_0"])))
+    hmask = g["tmask"] if name == "rmask" else g["tmask"].astype(np.uint8)      # "rmask": an r4 mask that is not 0/1 (-M)
+    plan.set_mesh(g["e1t"], g["e2t"], hmask, **(dict(e31d=g["e3t_1d"]) if full else dict(e3t=g["e3t_0"])))
     n = npi * npj
     for t in range(temp.shape[0]):
         got = plan.compute(temp[t], rmxldep=None if mxl is None else mxl[t], gdepw=g["gdepw_1d"], mxloption=mxlopt)
@@ -379,7 +380,7 @@ def test_hip_heatc_against_reference_statements(gpu, name):
     # device and chained through 2 and 3 row blocks
     for devices in (None, [0, 0], [0, 0, 0]):
         seq = gpu.HeatcPlan(npi, npj, npk, devices=devices)
-        seq.set_mesh(g["e1t"], g["e2t"], g["tmask"].astype(np.uint8), **(dict(e31d=g["e3t_1d"]) if full else dict(e3t=g["e3t_0"])))
+        seq.set_mesh(g["e1t"], g["e2t"], hmask, **(dict(e31d=g["e3t_1d"]) if full else dict(e3t=g["e3t_0"])))
         seq.set_sum_mode(True)
         got = np.stack([seq.compute(temp[t], rmxldep=None if mxl is None else mxl[t], gdepw=g["gdepw_1d"], mxloption=mxlopt)
                         for t in range(temp.shape[0])])
