@@ -267,26 +267,26 @@ class Tool:
 # src/cdfmoc.f90: declarations :49-125, eos_init :236, sizes :272-278, ALLOCATE :281-304, metrics :306-314,
 # masks :325-336, the whole time loop :338-570 (zonal sums, cumulated sums, -decomp, output), get_e3v :576-596.
 CDFMOC = r"""
-SUBROUTINE lift_cdfmoc(kpi, kpj, kpk, kpt, kbas, kdec, kfull, kteos10, knvar, h_e1v, h_e1u, h_gphiv, h_gdepw, h_gdept, &
+SUBROUTINE lift_cdfmoc(kpi, kpj, kpk, kpt, kbas, kdec, kfull, kteos10, knvar, kvvl, h_e1v, h_e1u, h_gphiv, h_gdepw, h_gdept, &
      &  h_e31d, h_vmask, h_umask, h_tmask, h_e3v, h_atl, h_ind, h_pac, h_v, h_t, h_s, o_var, o_dmoc, o_dec) &
      &  BIND(C, name='lift_cdfmoc')
   USE ISO_C_BINDING
   USE eos                      ! the reference's src/eos.f90, compiled where it lies (ref_build.sh)
   IMPLICIT NONE
-  INTEGER(C_INT), VALUE :: kpi, kpj, kpk, kpt, kbas, kdec, kfull, kteos10, knvar
+  INTEGER(C_INT), VALUE :: kpi, kpj, kpk, kpt, kbas, kdec, kfull, kteos10, knvar, kvvl   ! kvvl 0 / 1: -vvl, e3v of every record
   REAL(C_FLOAT), INTENT(in) :: h_e1v(kpi,kpj,1,1), h_e1u(kpi,kpj,1,1), h_gphiv(kpi,kpj,1,1)
   REAL(C_FLOAT), INTENT(in) :: h_gdepw(kpk), h_gdept(kpk), h_e31d(kpk)
-  REAL(C_FLOAT), INTENT(in) :: h_vmask(kpi,kpj,kpk,1), h_umask(kpi,kpj,kpk,1), h_tmask(kpi,kpj,kpk,1), h_e3v(kpi,kpj,kpk,1)
+  REAL(C_FLOAT), INTENT(in) :: h_vmask(kpi,kpj,kpk,1), h_umask(kpi,kpj,kpk,1), h_tmask(kpi,kpj,kpk,1), h_e3v(kpi,kpj,kpk,1+(kpt-1)*kvvl)
   REAL(C_FLOAT), INTENT(in) :: h_atl(kpi,kpj,1,1), h_ind(kpi,kpj,1,1), h_pac(kpi,kpj,1,1)
   REAL(C_FLOAT), INTENT(in) :: h_v(kpi,kpj,kpk,kpt), h_t(kpi,kpj,kpk,kpt), h_s(kpi,kpj,kpk,kpt)
   REAL(C_FLOAT),  INTENT(out) :: o_var(kpj,kpk,knvar,kpt)       ! what putvar is handed: REAL(...) rows
   REAL(C_DOUBLE), INTENT(out) :: o_dmoc(kbas,kpj,kpk,kpt)       ! dmoc after the cumulated sum
   REAL(C_DOUBLE), INTENT(out) :: o_dec(kbas,kpj,kpk,3,kpt)      ! dmoc_sh, dmoc_bt, dmoc_ag (-decomp)
-  LOGICAL :: lg_vvl = .FALSE.      ! modcdfnames variable; the vvl branch only changes which file is read
+  LOGICAL :: lg_vvl = .FALSE.      ! modcdfnames variable; -vvl changes the file e3v is read from and reads it at every record
 !@DECLS 49 125
   npiglo = kpi ; npjglo = kpj ; npk = kpk ; npt = kpt
   lbas = ( kbas == 5 ) ; ldec = ( kdec /= 0 ) ; lfull = ( kfull /= 0 ) ; ll_teos10 = ( kteos10 /= 0 )
-  lg_vvl = .FALSE.
+  lg_vvl = ( kvvl /= 0 )
 !@RAW 236 236
 !@RAW 272 278
   ! basin indices as CreateOutput numbers them (src/cdfmoc.f90:1032,:1057,:1081,:1106,:1131,:1156)
@@ -321,20 +321,20 @@ def gen_cdfmoc():
 # src/cdfheatc.f90: declarations :24-67, ALLOCATE :177-186, metrics :188-192, time loop :196-248.
 # The PRINT of :233 / :235 shows dsurf, dsum2d per level: those two lines become the capture of the level sums.
 CDFHEATC = r"""
-SUBROUTINE lift_cdfheatc(kpi, kpj, kpk, kpt, kfull, kmxl, h_e1t, h_e2t, h_gdepw, h_e31d, h_tmask, h_e3t, h_t, h_mxl, &
+SUBROUTINE lift_cdfheatc(kpi, kpj, kpk, kpt, kfull, kmxl, kvvl, h_e1t, h_e2t, h_gdepw, h_e31d, h_tmask, h_e3t, h_t, h_mxl, &
      &  o_var, o_sums) BIND(C, name='lift_cdfheatc')
   USE ISO_C_BINDING
   IMPLICIT NONE
-  INTEGER(C_INT), VALUE :: kpi, kpj, kpk, kpt, kfull, kmxl
+  INTEGER(C_INT), VALUE :: kpi, kpj, kpk, kpt, kfull, kmxl, kvvl
   REAL(C_FLOAT), INTENT(in) :: h_e1t(kpi,kpj,1,1), h_e2t(kpi,kpj,1,1), h_gdepw(kpk), h_e31d(kpk)
-  REAL(C_FLOAT), INTENT(in) :: h_tmask(kpi,kpj,kpk,1), h_e3t(kpi,kpj,kpk,1), h_t(kpi,kpj,kpk,kpt), h_mxl(kpi,kpj,1,kpt)
+  REAL(C_FLOAT), INTENT(in) :: h_tmask(kpi,kpj,kpk,1), h_e3t(kpi,kpj,kpk,1+(kpt-1)*kvvl), h_t(kpi,kpj,kpk,kpt), h_mxl(kpi,kpj,1,kpt)
   REAL(C_DOUBLE), INTENT(out) :: o_var(kpk,3,kpt)       ! what putvar is handed: heatc3d, heatc2d(k), heatc3dpervol
   REAL(C_DOUBLE), INTENT(out) :: o_sums(3,kpk,kpt)      ! dsurf, dvol2d, dsum2d of each level
   LOGICAL :: lg_vvl = .FALSE.
 !@DECLS 24 67
   npiglo = kpi ; npjglo = kpj ; npk = kpk ; npt = kpt ; npkk = kpk ; nvpk = kpk
   iimin = 1 ; ijmin = 1 ; ikmin = 1 ; ikmax = kpk          ! no -zoom: src/cdfheatc.f90:162-164
-  lfull = ( kfull /= 0 ) ; mxloption = kmxl ; lg_vvl = .FALSE.
+  lfull = ( kfull /= 0 ) ; mxloption = kmxl ; lg_vvl = ( kvvl /= 0 )
 !@RAW 177 186
 !@LIFT 188 192
 !@LIFT 196 248
@@ -356,12 +356,12 @@ def gen_cdfheatc():
 # src/cdfmhst.f90: declarations :34-103, ALLOCATE :256-274, metrics :276-277,:285, time loop :302-446 (the .dat dumps
 # that follow, :449-492, are formatted WRITEs of the same dzonal_* arrays and are not lifted).
 CDFMHST = r"""
-SUBROUTINE lift_cdfmhst(kpi, kpj, kpk, kpt, kbas, ksepf, kfull, kzdim, kmst, h_e1v, h_gphiv, h_gdept, h_e31d, h_e3v, h_vmask, &
+SUBROUTINE lift_cdfmhst(kpi, kpj, kpk, kpt, kbas, ksepf, kfull, kzdim, kmst, kvvl, h_e1v, h_gphiv, h_gdept, h_e31d, h_e3v, h_vmask, &
      &  h_atl, h_pac, h_ind, h_vt, h_vs, h_v, h_t, h_s, o_var, o_zon) BIND(C, name='lift_cdfmhst')
   USE ISO_C_BINDING
   IMPLICIT NONE
-  INTEGER(C_INT), VALUE :: kpi, kpj, kpk, kpt, kbas, ksepf, kfull, kzdim, kmst
-  REAL(C_FLOAT), INTENT(in) :: h_e1v(kpi,kpj,1,1), h_gphiv(kpi,kpj,1,1), h_gdept(kpk), h_e31d(kpk), h_e3v(kpi,kpj,kpk,1)
+  INTEGER(C_INT), VALUE :: kpi, kpj, kpk, kpt, kbas, ksepf, kfull, kzdim, kmst, kvvl
+  REAL(C_FLOAT), INTENT(in) :: h_e1v(kpi,kpj,1,1), h_gphiv(kpi,kpj,1,1), h_gdept(kpk), h_e31d(kpk), h_e3v(kpi,kpj,kpk,1+(kpt-1)*kvvl)
   REAL(C_FLOAT), INTENT(in) :: h_vmask(kpi,kpj,1,1), h_atl(kpi,kpj,1,1), h_pac(kpi,kpj,1,1), h_ind(kpi,kpj,1,1)
   REAL(C_FLOAT), INTENT(in) :: h_vt(kpi,kpj,kpk,kpt), h_vs(kpi,kpj,kpk,kpt), h_v(kpi,kpj,kpk,kpt), h_t(kpi,kpj,kpk,kpt)
   REAL(C_FLOAT), INTENT(in) :: h_s(kpi,kpj,kpk,kpt)
@@ -370,7 +370,7 @@ SUBROUTINE lift_cdfmhst(kpi, kpj, kpk, kpt, kbas, ksepf, kfull, kzdim, kmst, h_e
   LOGICAL :: lg_vvl = .FALSE.
 !@DECLS 34 103
   npiglo = kpi ; npjglo = kpj ; npk = kpk ; npt = kpt
-  lsepf = ( ksepf /= 0 ) ; lfull = ( kfull /= 0 ) ; lzdim = ( kzdim /= 0 ) ; lg_vvl = .FALSE.
+  lsepf = ( ksepf /= 0 ) ; lfull = ( kfull /= 0 ) ; lzdim = ( kzdim /= 0 ) ; lg_vvl = ( kvvl /= 0 )
   llglo = ( kbas == 5 ) ; nbasins = kbas ; nbasinso = 1 ; IF ( llglo ) nbasinso = 6     ! src/cdfmhst.f90:219-226
   npvar = 1 ; IF ( kmst /= 0 ) npvar = 2                                                ! -MST
   npko = 1 ; IF ( lzdim ) npko = npk                                                    ! :247-253
@@ -402,12 +402,12 @@ def gen_cdfmhst():
 # src/cdfpsi.f90: declarations :34-88, ALLOCATE :228-239, metrics and mask :246-253, the whole time loop :256-439.
 CDFPSI = r"""
 SUBROUTINE lift_cdfpsi(kpi, kpj, kpk, kpt, ku, kv, kfull, kmask, kmean, kopen, kssh, klev, kiref, kjref, h_e1v, h_e2u, h_fmask, &
-     &  h_e31d, h_e3u, h_e3v, h_u, h_v, h_ssh, knlo, o_var, o_dpsi) BIND(C, name='lift_cdfpsi')
+     &  h_e31d, h_e3u, h_e3v, h_u, h_v, h_ssh, knlo, kvvl, o_var, o_dpsi) BIND(C, name='lift_cdfpsi')
   USE ISO_C_BINDING
   IMPLICIT NONE
-  INTEGER(C_INT), VALUE :: kpi, kpj, kpk, kpt, ku, kv, kfull, kmask, kmean, kopen, kssh, klev, kiref, kjref, knlo
+  INTEGER(C_INT), VALUE :: kpi, kpj, kpk, kpt, ku, kv, kfull, kmask, kmean, kopen, kssh, klev, kiref, kjref, knlo, kvvl
   REAL(C_FLOAT), INTENT(in) :: h_e1v(kpi,kpj,1,1), h_e2u(kpi,kpj,1,1), h_fmask(kpi,kpj,1,1), h_e31d(kpk)
-  REAL(C_FLOAT), INTENT(in) :: h_e3u(kpi,kpj,kpk,1), h_e3v(kpi,kpj,kpk,1), h_u(kpi,kpj,kpk,kpt), h_v(kpi,kpj,kpk,kpt)
+  REAL(C_FLOAT), INTENT(in) :: h_e3u(kpi,kpj,kpk,1+(kpt-1)*kvvl), h_e3v(kpi,kpj,kpk,1+(kpt-1)*kvvl), h_u(kpi,kpj,kpk,kpt), h_v(kpi,kpj,kpk,kpt)
   REAL(C_FLOAT), INTENT(in) :: h_ssh(kpi,kpj,1,kpt)
   REAL(C_FLOAT),  INTENT(out) :: o_var(kpi,kpj,knlo,3,kpt)   ! what putvar is handed (SNGL(...) fields)
   REAL(C_DOUBLE), INTENT(out) :: o_dpsi(kpi,kpj,kpt)         ! dpsi after the normalisation, before SNGL
@@ -415,7 +415,7 @@ SUBROUTINE lift_cdfpsi(kpi, kpj, kpk, kpt, ku, kv, kfull, kmask, kmean, kopen, k
 !@DECLS 34 88
   npiglo = kpi ; npjglo = kpj ; npk = kpk ; npt = kpt
   ll_u = ( ku /= 0 ) ; ll_v = ( kv /= 0 ) ; lfull = ( kfull /= 0 ) ; lmask = ( kmask /= 0 ) ; lmean = ( kmean /= 0 )
-  lopen = ( kopen /= 0 ) ; lssh = ( kssh /= 0 ) ; llev = ( klev /= 0 ) ; lg_vvl = .FALSE.
+  lopen = ( kopen /= 0 ) ; lssh = ( kssh /= 0 ) ; llev = ( klev /= 0 ) ; lg_vvl = ( kvvl /= 0 )
   iiref = kiref ; ijref = kjref
   o_var = 0. ; o_dpsi = 0.d0
 !@RAW 228 239
@@ -520,17 +520,17 @@ def gen_cdfcurl():
 # =============================================================================================== cdfvhst
 # src/cdfvhst.f90: declarations :25-56, ALLOCATE :129-135, metrics :140-142, time loop :144-181.
 CDFVHST = r"""
-SUBROUTINE lift_cdfvhst(kpi, kpj, kpk, kpt, kfull, h_e1v, h_e2u, h_e31d, h_e3v, h_e3u, h_vt, h_vs, h_ut, h_us, o_var) &
+SUBROUTINE lift_cdfvhst(kpi, kpj, kpk, kpt, kfull, kvvl, h_e1v, h_e2u, h_e31d, h_e3v, h_e3u, h_vt, h_vs, h_ut, h_us, o_var) &
      &  BIND(C, name='lift_cdfvhst')
   USE ISO_C_BINDING
   IMPLICIT NONE
-  INTEGER(C_INT), VALUE :: kpi, kpj, kpk, kpt, kfull
-  REAL(C_FLOAT), INTENT(in) :: h_e1v(kpi,kpj,1,1), h_e2u(kpi,kpj,1,1), h_e31d(kpk), h_e3v(kpi,kpj,kpk,1), h_e3u(kpi,kpj,kpk,1)
+  INTEGER(C_INT), VALUE :: kpi, kpj, kpk, kpt, kfull, kvvl
+  REAL(C_FLOAT), INTENT(in) :: h_e1v(kpi,kpj,1,1), h_e2u(kpi,kpj,1,1), h_e31d(kpk), h_e3v(kpi,kpj,kpk,1+(kpt-1)*kvvl), h_e3u(kpi,kpj,kpk,1+(kpt-1)*kvvl)
   REAL(C_FLOAT), INTENT(in) :: h_vt(kpi,kpj,kpk,kpt), h_vs(kpi,kpj,kpk,kpt), h_ut(kpi,kpj,kpk,kpt), h_us(kpi,kpj,kpk,kpt)
   REAL(C_FLOAT), INTENT(out) :: o_var(kpi,kpj,4,kpt)          ! SNGL(dtrpvt), SNGL(dtrpvs), SNGL(dtrput), SNGL(dtrpus)
   LOGICAL :: lg_vvl = .FALSE.
 !@DECLS 25 56
-  npiglo = kpi ; npjglo = kpj ; npk = kpk ; npt = kpt ; lfull = ( kfull /= 0 ) ; lg_vvl = .FALSE.
+  npiglo = kpi ; npjglo = kpj ; npk = kpk ; npt = kpt ; lfull = ( kfull /= 0 ) ; lg_vvl = ( kvvl /= 0 )
 !@RAW 129 135
 !@LIFT 140 142
 !@LIFT 144 181
@@ -550,18 +550,18 @@ def gen_cdfvhst():
 # src/cdfvtrp.f90: declarations :27-62, ALLOCATE :151-163, metrics :167-176, time loop :178-252 (with -bathy: the slope
 # rotation through the compiler's ATAN2 / COS / SIN).
 CDFVTRP = r"""
-SUBROUTINE lift_cdfvtrp(kpi, kpj, kpk, kpt, kfull, kbathy, h_e1v, h_e2u, h_e1u, h_e2v, h_tmask, h_hdepw, h_e31d, h_e3v, h_e3u, &
+SUBROUTINE lift_cdfvtrp(kpi, kpj, kpk, kpt, kfull, kbathy, kvvl, h_e1v, h_e2u, h_e1u, h_e2v, h_tmask, h_hdepw, h_e31d, h_e3v, h_e3u, &
      &  h_u, h_v, o_var) BIND(C, name='lift_cdfvtrp')
   USE ISO_C_BINDING
   IMPLICIT NONE
-  INTEGER(C_INT), VALUE :: kpi, kpj, kpk, kpt, kfull, kbathy
+  INTEGER(C_INT), VALUE :: kpi, kpj, kpk, kpt, kfull, kbathy, kvvl
   REAL(C_FLOAT), INTENT(in) :: h_e1v(kpi,kpj,1,1), h_e2u(kpi,kpj,1,1), h_e1u(kpi,kpj,1,1), h_e2v(kpi,kpj,1,1)
-  REAL(C_FLOAT), INTENT(in) :: h_tmask(kpi,kpj,1,1), h_hdepw(kpi,kpj,1,1), h_e31d(kpk), h_e3v(kpi,kpj,kpk,1), h_e3u(kpi,kpj,kpk,1)
+  REAL(C_FLOAT), INTENT(in) :: h_tmask(kpi,kpj,1,1), h_hdepw(kpi,kpj,1,1), h_e31d(kpk), h_e3v(kpi,kpj,kpk,1+(kpt-1)*kvvl), h_e3u(kpi,kpj,kpk,1+(kpt-1)*kvvl)
   REAL(C_FLOAT), INTENT(in) :: h_u(kpi,kpj,kpk,kpt), h_v(kpi,kpj,kpk,kpt)
   REAL(C_FLOAT), INTENT(out) :: o_var(kpi,kpj,4,kpt)          ! REAL(dtrpu), REAL(dtrpv) [, along-slope, cross-slope]
   LOGICAL :: lg_vvl = .FALSE.
 !@DECLS 27 62
-  npiglo = kpi ; npjglo = kpj ; npk = kpk ; npt = kpt ; lfull = ( kfull /= 0 ) ; lbathy = ( kbathy /= 0 ) ; lg_vvl = .FALSE.
+  npiglo = kpi ; npjglo = kpj ; npk = kpk ; npt = kpt ; lfull = ( kfull /= 0 ) ; lbathy = ( kbathy /= 0 ) ; lg_vvl = ( kvvl /= 0 )
   o_var = 0.
 !@RAW 151 163
 !@LIFT 167 176
@@ -583,12 +583,12 @@ def gen_cdfvtrp():
 # src/cdfsum.f90: declarations :29-79, ALLOCATE :214-217, metrics :275-286, time loop :290-349.  The PRINTs of the level
 # sums (:324 / :327, forcing form :334) become the capture of dsurf, dvol2d, dsum2d.
 CDFSUM = r"""
-SUBROUTINE lift_cdfsum(kpi, kpj, kpk, kpt, kforcing, knwgh, knmsk, h_e1, h_e2, h_dep, h_e3, h_msk, h_in, o_var, o_sums) &
+SUBROUTINE lift_cdfsum(kpi, kpj, kpk, kpt, kforcing, knwgh, knmsk, kvvl, h_e1, h_e2, h_dep, h_e3, h_msk, h_in, o_var, o_sums) &
      &  BIND(C, name='lift_cdfsum')
   USE ISO_C_BINDING
   IMPLICIT NONE
-  INTEGER(C_INT), VALUE :: kpi, kpj, kpk, kpt, kforcing, knwgh, knmsk
-  REAL(C_FLOAT), INTENT(in) :: h_e1(kpi,kpj,1,1), h_e2(kpi,kpj,1,1), h_dep(kpk), h_e3(kpi,kpj,kpk,1), h_msk(kpi,kpj,kpk,1)
+  INTEGER(C_INT), VALUE :: kpi, kpj, kpk, kpt, kforcing, knwgh, knmsk, kvvl
+  REAL(C_FLOAT), INTENT(in) :: h_e1(kpi,kpj,1,1), h_e2(kpi,kpj,1,1), h_dep(kpk), h_e3(kpi,kpj,kpk,1+(kpt-1)*kvvl), h_msk(kpi,kpj,kpk,1)
   REAL(C_FLOAT), INTENT(in) :: h_in(kpi,kpj,kpk,kpt)
   REAL(C_FLOAT),  INTENT(out) :: o_var(kpk,3,kpt)            ! rdummy as handed to putvar: level sums, cumulated, per record
   REAL(C_DOUBLE), INTENT(out) :: o_sums(3,kpk,kpt)           ! dsurf, dvol2d, dsum2d of each level
@@ -596,7 +596,7 @@ SUBROUTINE lift_cdfsum(kpi, kpj, kpk, kpt, kforcing, knwgh, knmsk, h_e1, h_e2, h
 !@DECLS 29 79
   npiglo = kpi ; npjglo = kpj ; npk = kpk ; npt = kpt ; npkk = kpk ; nvpk = kpk
   iimin = 1 ; ijmin = 1 ; ikmin = 1 ; ikmax = kpk             ! no -w window: src/cdfsum.f90:190-192
-  lforcing = ( kforcing /= 0 ) ; lnwgh = ( knwgh /= 0 ) ; lnmsk = ( knmsk /= 0 ) ; lg_vvl = .FALSE.
+  lforcing = ( kforcing /= 0 ) ; lnwgh = ( knwgh /= 0 ) ; lnmsk = ( knmsk /= 0 ) ; lg_vvl = ( kvvl /= 0 )
   o_var = 0. ; o_sums = 0.d0
 !@RAW 214 217
 !@LIFT 275 286
@@ -619,12 +619,12 @@ def gen_cdfsum():
 # src/cdfmean.f90: declarations :27-109, ALLOCATE :294-303, metrics :361-366, :376-378, basin masks :383-389, time loop
 # :396-482.  The WRITEs of the level values (:429 / :440) become the capture of dsurf, dvol2d, dsum2d, dvar2d.
 CDFMEAN = r"""
-SUBROUTINE lift_cdfmean(kpi, kpj, kpk, kpt, kbasin, kfull, kvar, ksum, h_e1, h_e2, h_e31d, h_dep, h_e3, h_msk, h_bas, h_in, &
+SUBROUTINE lift_cdfmean(kpi, kpj, kpk, kpt, kbasin, kfull, kvar, ksum, kvvl, h_e1, h_e2, h_e31d, h_dep, h_e3, h_msk, h_bas, h_in, &
      &  knv, o_var, o_var0, o_sums) BIND(C, name='lift_cdfmean')
   USE ISO_C_BINDING
   IMPLICIT NONE
-  INTEGER(C_INT), VALUE :: kpi, kpj, kpk, kpt, kbasin, kfull, kvar, ksum, knv
-  REAL(C_FLOAT), INTENT(in) :: h_e1(kpi,kpj,1,1), h_e2(kpi,kpj,1,1), h_e31d(kpk), h_dep(kpk), h_e3(kpi,kpj,kpk,1), h_msk(kpi,kpj,kpk,1)
+  INTEGER(C_INT), VALUE :: kpi, kpj, kpk, kpt, kbasin, kfull, kvar, ksum, knv, kvvl
+  REAL(C_FLOAT), INTENT(in) :: h_e1(kpi,kpj,1,1), h_e2(kpi,kpj,1,1), h_e31d(kpk), h_dep(kpk), h_e3(kpi,kpj,kpk,1+(kpt-1)*kvvl), h_msk(kpi,kpj,kpk,1)
   REAL(C_FLOAT), INTENT(in) :: h_bas(kpi,kpj,kbasin,1), h_in(kpi,kpj,kpk,kpt)
   REAL(C_FLOAT),  INTENT(out) :: o_var(kpk,knv,kpt)          ! rdummymean as handed to putvar, per output variable index
   REAL(C_FLOAT),  INTENT(out) :: o_var0(knv,kpt)             ! rdummy as handed to putvar0d
@@ -634,7 +634,7 @@ SUBROUTINE lift_cdfmean(kpi, kpj, kpk, kpt, kbasin, kfull, kvar, ksum, h_e1, h_e
 !@DECLS 27 109
   npiglo = kpi ; npjglo = kpj ; npk = kpk ; npt = kpt ; nvpk = kpk ; npk_fi = kpk ; nbasin = kbasin
   iimin = 1 ; ijmin = 1 ; ikmin = 1 ; ikmax = kpk             ! no -w window: src/cdfmean.f90:268-270
-  lbas = ( kbasin > 1 ) ; lfull = ( kfull /= 0 ) ; lvar = ( kvar /= 0 ) ; lsum = ( ksum /= 0 ) ; lg_vvl = .FALSE.
+  lbas = ( kbasin > 1 ) ; lfull = ( kfull /= 0 ) ; lvar = ( kvar /= 0 ) ; lsum = ( ksum /= 0 ) ; lg_vvl = ( kvvl /= 0 )
   o_var = 0. ; o_var0 = 0. ; o_sums = 0.d0
 !@RAW 294 303
 !@LIFT 361 366
@@ -671,18 +671,18 @@ def gen_cdfmean():
 # =============================================================================================== cdfvertmean
 # src/cdfvertmean.f90: declarations :28-79, ALLOCATE :183-188, depths :210-218, time loop :224-269.
 CDFVERTMEAN = r"""
-SUBROUTINE lift_cdfvertmean(kpi, kpj, kpk, kpt, kfull, pup, pdown, h_dep, h_e31d, h_e3, h_msk, h_in, o_var) &
+SUBROUTINE lift_cdfvertmean(kpi, kpj, kpk, kpt, kfull, kvvl, pup, pdown, h_dep, h_e31d, h_e3, h_msk, h_in, o_var) &
      &  BIND(C, name='lift_cdfvertmean')
   USE ISO_C_BINDING
   IMPLICIT NONE
-  INTEGER(C_INT), VALUE :: kpi, kpj, kpk, kpt, kfull
+  INTEGER(C_INT), VALUE :: kpi, kpj, kpk, kpt, kfull, kvvl
   REAL(C_FLOAT), VALUE :: pup, pdown
-  REAL(C_FLOAT), INTENT(in) :: h_dep(kpk), h_e31d(kpk), h_e3(kpi,kpj,kpk,1), h_msk(kpi,kpj,kpk,1), h_in(kpi,kpj,kpk,kpt)
+  REAL(C_FLOAT), INTENT(in) :: h_dep(kpk), h_e31d(kpk), h_e3(kpi,kpj,kpk,1+(kpt-1)*kvvl), h_msk(kpi,kpj,kpk,1), h_in(kpi,kpj,kpk,kpt)
   REAL(C_FLOAT), INTENT(out) :: o_var(kpi,kpj,1,kpt)          ! REAL(dvertmean) as handed to putvar
   LOGICAL :: lg_vvl = .FALSE.
 !@DECLS 28 79
   npiglo = kpi ; npjglo = kpj ; npk = kpk ; npt = kpt ; nvaro = 1 ; iimin = 1 ; ijmin = 1
-  lfull = ( kfull /= 0 ) ; lg_vvl = .FALSE. ; rdep_up = pup ; rdep_down = pdown
+  lfull = ( kfull /= 0 ) ; lg_vvl = ( kvvl /= 0 ) ; rdep_up = pup ; rdep_down = pdown
   ALLOCATE ( cv_in(1), ipk(1), id_varout(1) ) ; cv_in(1) = 'field'
 !@RAW 183 188
 !@LIFT 210 218
@@ -701,19 +701,19 @@ def gen_cdfvertmean():
 # =============================================================================================== cdfvint
 # src/cdfvint.f90: declarations :28-68, ALLOCATE :234-242, depths :245-259, time loop :268-313.
 CDFVINT = r"""
-SUBROUTINE lift_cdfvint(kpi, kpj, kpk, kpt, kfull, kgsop, kocci, kmean, psclf, h_gdepw, h_e31d, h_tmask, h_e3t, h_in, knpko, o_var) &
+SUBROUTINE lift_cdfvint(kpi, kpj, kpk, kpt, kfull, kgsop, kocci, kmean, kvvl, psclf, h_gdepw, h_e31d, h_tmask, h_e3t, h_in, knpko, o_var) &
      &  BIND(C, name='lift_cdfvint')
   USE ISO_C_BINDING
   IMPLICIT NONE
-  INTEGER(C_INT), VALUE :: kpi, kpj, kpk, kpt, kfull, kgsop, kocci, kmean, knpko
+  INTEGER(C_INT), VALUE :: kpi, kpj, kpk, kpt, kfull, kgsop, kocci, kmean, knpko, kvvl
   REAL(C_FLOAT), VALUE :: psclf
-  REAL(C_FLOAT), INTENT(in) :: h_gdepw(kpk), h_e31d(kpk), h_tmask(kpi,kpj,kpk,1), h_e3t(kpi,kpj,kpk,1), h_in(kpi,kpj,kpk,kpt)
+  REAL(C_FLOAT), INTENT(in) :: h_gdepw(kpk), h_e31d(kpk), h_tmask(kpi,kpj,kpk,1), h_e3t(kpi,kpj,kpk,1+(kpt-1)*kvvl), h_in(kpi,kpj,kpk,kpt)
   REAL(C_FLOAT), INTENT(out) :: o_var(kpi,kpj,knpko+1,kpt)    ! REAL(dl_vint2) [/rdep2] as handed to putvar, per output depth
   LOGICAL :: lg_vvl = .FALSE.
 !@DECLS 28 68
   npiglo = kpi ; npjglo = kpj ; npk = kpk ; npt = kpt ; npko = knpko ; iimin = 1 ; ijmin = 1
   lfull = ( kfull /= 0 ) ; lgsop = ( kgsop /= 0 ) ; locci = ( kocci /= 0 ) ; ltmean = ( kmean /= 0 ) ; lsmean = .FALSE.
-  sclf = psclf ; lg_vvl = .FALSE.
+  sclf = psclf ; lg_vvl = ( kvvl /= 0 )
   o_var = 0.
 !@RAW 234 242
 !@LIFT 245 259
@@ -812,16 +812,16 @@ def gen_cdfzonalmean():
 # src/cdfmocsig.f90: declarations :40-108, sizes :255-261, bins :299-304, ALLOCATE :308-323, metrics :325-328, basin numbers
 # :342, masks :347-359, the whole time loop :361-485 (density through the reference's eos module; -isodep, -eiv, -full, -ntr).
 CDFMOCSIG = r"""
-SUBROUTINE lift_cdfmocsig(kpi, kpj, kpk, kpt, kbas, kfull, kisodep, keiv, kntr, kteos10, knbins, psigmin, psigstp, ppref, pspv, &
+SUBROUTINE lift_cdfmocsig(kpi, kpj, kpk, kpt, kbas, kfull, kisodep, keiv, kntr, kteos10, knbins, kvvl, psigmin, psigstp, ppref, pspv, &
      &  pspt, psps, h_e1v, h_e31d, h_gdept, h_vmask, h_atl, h_ind, h_pac, h_e3v, h_v, h_veiv, h_t, h_s, o_var, o_dmoc, o_depi) &
      &  BIND(C, name='lift_cdfmocsig')
   USE ISO_C_BINDING
   USE eos                      ! the reference's src/eos.f90, compiled where it lies
   IMPLICIT NONE
-  INTEGER(C_INT), VALUE :: kpi, kpj, kpk, kpt, kbas, kfull, kisodep, keiv, kntr, kteos10, knbins
+  INTEGER(C_INT), VALUE :: kpi, kpj, kpk, kpt, kbas, kfull, kisodep, keiv, kntr, kteos10, knbins, kvvl
   REAL(C_FLOAT), VALUE :: psigmin, psigstp, ppref, pspv, pspt, psps
   REAL(C_FLOAT), INTENT(in) :: h_e1v(kpi,kpj,1,1), h_e31d(kpk), h_gdept(kpk), h_vmask(kpi,kpj,1,1), h_atl(kpi,kpj,1,1)
-  REAL(C_FLOAT), INTENT(in) :: h_ind(kpi,kpj,1,1), h_pac(kpi,kpj,1,1), h_e3v(kpi,kpj,kpk,1), h_v(kpi,kpj,kpk,kpt)
+  REAL(C_FLOAT), INTENT(in) :: h_ind(kpi,kpj,1,1), h_pac(kpi,kpj,1,1), h_e3v(kpi,kpj,kpk,1+(kpt-1)*kvvl), h_v(kpi,kpj,kpk,kpt)
   REAL(C_FLOAT), INTENT(in) :: h_veiv(kpi,kpj,kpk,kpt), h_t(kpi,kpj,kpk,kpt), h_s(kpi,kpj,kpk,kpt)
   REAL(C_FLOAT),  INTENT(out) :: o_var(kpj,knbins,2*kbas,kpt)     ! REAL(dmoc(basin,bin,:)) [, REAL(depi(..))] as handed to putvar
   REAL(C_DOUBLE), INTENT(out) :: o_dmoc(kbas,knbins,kpj,kpt), o_depi(kbas,knbins,kpj,kpt)
@@ -829,7 +829,7 @@ SUBROUTINE lift_cdfmocsig(kpi, kpj, kpk, kpt, kbas, kfull, kisodep, keiv, kntr, 
 !@DECLS 40 108
   npiglo = kpi ; npjglo = kpj ; npk = kpk ; npt = kpt
   lbas = ( kbas == 5 ) ; lfull = ( kfull /= 0 ) ; lisodep = ( kisodep /= 0 ) ; leiv = ( keiv /= 0 ) ; lntr = ( kntr /= 0 )
-  ll_teos10 = ( kteos10 /= 0 ) ; lprint = .FALSE. ; lg_vvl = .FALSE.
+  ll_teos10 = ( kteos10 /= 0 ) ; lprint = .FALSE. ; lg_vvl = ( kvvl /= 0 )
   nbins = knbins ; sigmin = psigmin ; sigstp = psigstp ; pref = ppref ; zspv = pspv ; zspt = pspt ; zsps = psps
   CALL eos_init ( ll_teos10 )                              ! src/cdfmocsig.f90:210
   o_var = 0. ; o_dmoc = 0.d0 ; o_depi = 0.d0
@@ -863,17 +863,17 @@ def gen_cdfmocsig():
 # mask reads :692-705, the whole time loop :709-998 (33 output variables).  Kept as an internal subroutine of the harness so
 # that its local gdept hides the program's, as in the reference.
 CDFMOC_RAPID = r"""
-SUBROUTINE lift_cdfmoc_rapid(kpi, kpigs, kpk, kpt, kfull, h_gphiv, h_e31d, h_e1v, h_gdepw, h_tmask, h_gdept, h_e3v, h_v, h_taux, &
+SUBROUTINE lift_cdfmoc_rapid(kpi, kpigs, kpk, kpt, kfull, kvvl, h_gphiv, h_e31d, h_e1v, h_gdepw, h_tmask, h_gdept, h_e3v, h_v, h_taux, &
      &  h_t, h_s, o_var) BIND(C, name='lift_cdfmoc_rapid')
   USE ISO_C_BINDING
   IMPLICIT NONE
-  INTEGER(C_INT), VALUE :: kpi, kpigs, kpk, kpt, kfull          ! kpi: cells of the section (iiw..iie), kpigs: of its Gulf Stream part
+  INTEGER(C_INT), VALUE :: kpi, kpigs, kpk, kpt, kfull, kvvl    ! kpi: cells of the section (iiw..iie), kpigs: of its Gulf Stream part
   REAL(C_FLOAT), INTENT(in) :: h_gphiv(kpi,1,1,1), h_e31d(kpk), h_e1v(kpi,1,1,1), h_gdepw(kpk), h_tmask(kpi,1,kpk,1), h_gdept(kpk)
-  REAL(C_FLOAT), INTENT(in) :: h_e3v(kpi,1,kpk,1), h_v(kpi,1,kpk,kpt), h_taux(kpi,1,1,kpt), h_t(kpi,1,kpk,kpt), h_s(kpi,1,kpk,kpt)
+  REAL(C_FLOAT), INTENT(in) :: h_e3v(kpi,1,kpk,1+(kpt-1)*kvvl), h_v(kpi,1,kpk,kpt), h_taux(kpi,1,1,kpt), h_t(kpi,1,kpk,kpt), h_s(kpi,1,kpk,kpt)
   REAL(C_FLOAT), INTENT(out) :: o_var(33,kpk,kpt)                ! what putvar is handed, by output variable and level
   LOGICAL :: lg_vvl = .FALSE.
 !@DECLS 49 125
-  npk = kpk ; npt = kpt ; lfull = ( kfull /= 0 ) ; lg_vvl = .FALSE.
+  npk = kpk ; npt = kpt ; lfull = ( kfull /= 0 ) ; lg_vvl = ( kvvl /= 0 )
   o_var = 0.
   CALL rapid_amoc
 CONTAINS

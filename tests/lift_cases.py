@@ -269,3 +269,72 @@ def maxmoc_fields():
     moc = (rnd(4141, (npk, npj), -12, 22)).astype(f32)
     moc[0] = 0
     return depw, lat, moc
+
+
+# ------------------------------------------------------------------------------------------ -vvl (time-varying vertical metrics)
+# Every program that parses -vvl reads its e3 at the record's time index instead of once (src/cdfmoc.f90:339-348,
+# cdfheatc.f90:197-215, cdfmhst.f90:303-330, cdfpsi.f90:257-294, cdfmean.f90:397-412, cdfsum.f90:292-314, cdfmocsig.f90:362-388,
+# cdfvertmean.f90:225-243, cdfvhst.f90:145-165, cdfvint.f90:269-285, cdfvtrp.f90:181-197, cdfmoc.f90:710-719 for -rapid).
+# The cases below give each of them a metric that differs from record to record (the static one times 0.9 .. 1.1).
+def e3_records(e3, npt, seed):
+    """(npt,) + e3.shape r4: the static metric scaled cell by cell and record by record."""
+    return (np.asarray(e3, f32)[None] * rnd(seed, (npt,) + np.shape(e3), 0.9, 1.1)).astype(f32)
+
+
+def moc_vvl_case(name):
+    """-> g, zv, nbasins, decomp inputs or None, teos10, e3v_t (npt,npk,npj,npi)"""
+    base = {"vvl5": "small5", "vvl1": "one_basin", "vvl_decomp": "decomp"}[name]
+    g, zv, nb, full, d, teos = moc_case(base)
+    return g, zv, nb, d, teos, e3_records(g["e3v_0"], zv.shape[0], 7001)
+
+
+MOC_VVL_CASES = ["vvl5", "vvl1", "vvl_decomp"]
+
+
+def heatc_vvl_case(name):
+    """-> g, temp, mxlopt, mxl, e3t_t"""
+    g, temp, full, mxlopt, mxl = heatc_case({"vvl": "default", "vvl_mxl": "mxl_in"}[name])
+    return g, temp, mxlopt, mxl, e3_records(g["e3t_0"], temp.shape[0], 7002)
+
+
+HEATC_VVL_CASES = ["vvl", "vvl_mxl"]
+
+
+def mhst_vvl_case(name):
+    """-> g, nbasins, harness keyword arguments (with e3v_t)"""
+    g, nb, kw = mhst_case({"vvl_vt5": "vt5", "vvl_sep5": "sep5"}[name])
+    npt = next(v for k, v in kw.items() if k in ("vt", "zv")).shape[0]
+    kw["e3v_t"] = e3_records(g["e3v_0"], npt, 7003)
+    return g, nb, kw
+
+
+MHST_VVL_CASES = ["vvl_vt5", "vvl_sep5"]
+
+
+def psi_vvl_case(name):
+    """-> g, harness keyword arguments (with e3u_t, e3v_t)"""
+    g, kw = psi_case({"vvl_u": "u", "vvl_v": "v", "vvl_mean_mask_ref": "mean_mask_ref", "vvl_open": "open"}[name])
+    kw["e3u_t"], kw["e3v_t"] = e3_records(g["e3u_0"], 2, 7004), e3_records(g["e3v_0"], 2, 7005)
+    return g, kw
+
+
+PSI_VVL_CASES = ["vvl_u", "vvl_v", "vvl_mean_mask_ref", "vvl_open"]
+
+
+def e3_8f():
+    """The record-varying e3t, e3u, e3v of the 8f grid (2 records)."""
+    g, t, s, u, v = grid8f()
+    return e3_records(g["e3t_0"], 2, 7006), e3_records(g["e3u_0"], 2, 7007), e3_records(g["e3v_0"], 2, 7008)
+
+
+def mocsig_e3v():
+    g, zv, zt, zs = mocsig_fields()
+    return e3_records(g["e3v_0"], 2, 7009)
+
+
+MOCSIG_VVL_CASE = ("vvl_sigma0", 0.0, (52, 23.0, 0.1), False, False, False, False)
+
+
+def rapid_e3v():
+    g = rapid_case("partial")[0]
+    return e3_records(g["e3v_0"], 2, 7010)

@@ -194,10 +194,11 @@ def test_oracle_mhst_equals_reference_statements(name):
 
 
 # ================================================================================================ cdfpsi
-def psi_by(psi, psi_open, name):
+def psi_by(psi, psi_open, name, case=lc.psi_case):
     """The record loop of src/cdfpsi.f90:256-439 written over a psi(...) / psi_open(...) pair (the oracle's or the
-    HIP path's): -> var (npt,3,nlo,npj,npi) r4 and dpsi (npt,npj,npi) r8 laid out like the harness outputs."""
-    g, kw = lc.psi_case(name)
+    HIP path's): -> var (npt,3,nlo,npj,npi) r4 and dpsi (npt,npj,npi) r8 laid out like the harness outputs.
+    With `e3u_t` / `e3v_t` in the case (-vvl) record t takes the metrics of record t (:257-262, :275, :294)."""
+    g, kw = case(name)
     npk, npj, npi = g["tmask"].shape
     zu, zv = kw.get("zu"), kw.get("zv")
     npt = (zu if zu is not None else zv).shape[0]
@@ -211,11 +212,11 @@ def psi_by(psi, psi_open, name):
         if zu is not None:
             a.update(zu=zu[t], e2u=g["e2u"])
             if not kw.get("full"):
-                a["e3u"] = g["e3u_0"]
+                a["e3u"] = g["e3u_0"] if kw.get("e3u_t") is None else kw["e3u_t"][t]
         if zv is not None:
             a.update(zv=zv[t], e1v=g["e1v"])
             if not kw.get("full"):
-                a["e3v"] = g["e3v_0"]
+                a["e3v"] = g["e3v_0"] if kw.get("e3v_t") is None else kw["e3v_t"][t]
         if lev:                                   # -lev: one scan per level, no reference point, first record only (:311-315)
             if t > 0:
                 break
