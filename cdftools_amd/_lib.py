@@ -80,6 +80,7 @@ SIGNATURES = {
     "cdft_mhst_compute": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp]),
     "cdft_mhst_destroy": (_i, [_vp]),
     "cdft_vint_transport": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
+    "cdft_vint_slope_rotate": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp]),
     "cdft_vhst_transport": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "cdft_vint_release": (_i, []),
     "cdft_mean_create": (_i, [_pvp, _i, _i, _i, _i]),

@@ -667,7 +667,36 @@ int cdft_mhst_destroy(cdft_mhst_plan *p) {
 }  // extern "C"
 
 // ------------------------------------------------------------- cdfvtrp / cdfvhst
-namespace { DevBuf g_vi[4], g_vo[2]; }
+namespace { DevBuf g_vi[4], g_vo[2], g_sl[6]; }
+
+// cdfvtrp -bathy (src/cdfvtrp.f90:210-252): the vertically integrated transports brought to the T point and rotated onto
+// the direction of the bathymetric slope.  One thread per (i,j) of the plane; every operand is 2-D, so the whole option is
+// 40 B per cell read once -- its cost is the launch.  Arithmetic as the reference writes it: the means in r8 (0.5 is
+// exact), the slopes, their angle and its cosine / sine in r4, the rotation in r8 with the r4 factors widened.  The three
+// transcendental results are formed in r8 and rounded to r4 -- the correctly rounded r4 value except on near-ties -- so the
+// result does not depend on the accuracy of a single-precision device routine (the host libraries the reference meets are
+// themselves within an ulp of that value: tolerance in tests/test_vtrp_bathy.py).
+__global__ void __launch_bounds__(256)
+slope_rotate_kernel(const double *__restrict__ dtrpu, const double *__restrict__ dtrpv, const float *__restrict__ hdepw,
+                    const float *__restrict__ e1u, const float *__restrict__ e2v, const float *__restrict__ tmask,
+                    int npi, int npj, double *__restrict__ dalong, double *__restrict__ dcross) {
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
+    if (i >= npi || j >= npj) return;
+    const size_t p = (size_t)j * npi + i;
+    // dwku(1,jj) = dwku(npiglo-1,jj): the E-W overlap column takes the mean of columns npiglo-2, npiglo-1 (:218)
+    const int iu = (i == 0) ? npi - 2 : i;
+    double dwku = 0.0, dwkv = 0.0;
+    if (iu >= 1) dwku = 0.5 * (dtrpu[(size_t)j * npi + iu] + dtrpu[(size_t)j * npi + iu - 1]);
+    if (j >= 1) dwkv = 0.5 * (dtrpv[p] + dtrpv[p - npi]);
+    const float tm = tmask[p];
+    float zdhdx = 0.f, zdhdy = 0.f;
+    if (i >= 1 && i <= npi - 2) zdhdx = __fmul_rn(__fdiv_rn(__fsub_rn(hdepw[p + 1], hdepw[p - 1]), __fadd_rn(e1u[p], e1u[p - 1])), tm);
+    if (j >= 1 && j <= npj - 2) zdhdy = __fmul_rn(__fdiv_rn(__fsub_rn(hdepw[p + npi], hdepw[p - npi]), __fadd_rn(e2v[p], e2v[p - npi])), tm);
+    const float zalpha = __fmul_rn((float)atan2((double)zdhdx, (double)zdhdy), tm);
+    const double c = (double)(float)cos((double)zalpha), sn = (double)(float)sin((double)zalpha);
+    dalong[p] = __dmul_rn(__dadd_rn(__dmul_rn(dwku, c), __dmul_rn(dwkv, sn)), (double)tm);
+    dcross[p] = __dmul_rn(__dadd_rn(__dmul_rn(-dwku, sn), __dmul_rn(dwkv, c)), (double)tm);
+}
 
 extern "C" {
 
@@ -730,9 +759,43 @@ int cdft_vhst_transport(const float *xt, const float *xs, const float *m2d, cons
     return CDFT_OK;
 }
 
+int cdft_vint_slope_rotate(const double *dtrpu, const double *dtrpv, const float *hdepw, const float *e1u,
+                           const float *e2v, const float *tmask, int npiglo, int npjglo, int in_space, double *dalong,
+                           double *dcross, int out_space, void *stream) {
+    if (!dtrpu || !dtrpv || !hdepw || !e1u || !e2v || !tmask || !dalong || !dcross)
+        return fail(CDFT_ERR_ARG, "cdft_vint_slope_rotate: NULL argument");
+    if (npiglo < 1 || npjglo < 1) return fail(CDFT_ERR_ARG, "cdft_vint_slope_rotate: bad sizes");
+    CDFT_TRY(require_device());
+    hipStream_t st = as_stream(stream);
+    const size_t nij = (size_t)npiglo * npjglo;
+    const void *du, *dv, *dh, *d1, *d2, *dm;
+    CDFT_TRY(to_device(dtrpu, nij * 8, in_space, g_sl[0], st, &du));
+    CDFT_TRY(to_device(dtrpv, nij * 8, in_space, g_sl[1], st, &dv));
+    CDFT_TRY(to_device(hdepw, nij * 4, in_space, g_sl[2], st, &dh));
+    CDFT_TRY(to_device(e1u, nij * 4, in_space, g_sl[3], st, &d1));
+    CDFT_TRY(to_device(e2v, nij * 4, in_space, g_sl[4], st, &d2));
+    CDFT_TRY(to_device(tmask, nij * 4, in_space, g_sl[5], st, &dm));
+    double *oa = dalong, *oc = dcross;
+    if (out_space == CDFT_MEM_HOST) {
+        CDFT_TRY(g_vo[0].reserve(nij * 8)); CDFT_TRY(g_vo[1].reserve(nij * 8));
+        oa = (double *)g_vo[0].ptr; oc = (double *)g_vo[1].ptr;
+    }
+    const dim3 block(64, 4), grid((unsigned)((npiglo + 63) / 64), (unsigned)((npjglo + 3) / 4));
+    hipLaunchKernelGGL(slope_rotate_kernel, grid, block, 0, st, (const double *)du, (const double *)dv, (const float *)dh,
+                       (const float *)d1, (const float *)d2, (const float *)dm, npiglo, npjglo, oa, oc);
+    CDFT_LAUNCH_CHECK();
+    if (out_space == CDFT_MEM_HOST) {
+        CDFT_HIP(hipMemcpyAsync(dalong, oa, nij * 8, hipMemcpyDeviceToHost, st));
+        CDFT_HIP(hipMemcpyAsync(dcross, oc, nij * 8, hipMemcpyDeviceToHost, st));
+        CDFT_HIP(hipStreamSynchronize(st));
+    }
+    return CDFT_OK;
+}
+
 int cdft_vint_release(void) {
     for (DevBuf &b : g_vi) b.release();
     for (DevBuf &b : g_vo) b.release();
+    for (DevBuf &b : g_sl) b.release();
     return CDFT_OK;
 }
 

@@ -170,6 +170,12 @@ MODULE cdftools_hip
        IMPORT ; REAL(C_FLOAT), INTENT(in) :: vel(*), m2d(*) ; TYPE(C_PTR), VALUE :: e3, e31d, stream
        INTEGER(C_INT), VALUE :: npiglo, npjglo, npk, in_space, out_space ; REAL(C_DOUBLE), INTENT(out) :: dtrp(*)
      END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_vint_slope_rotate(dtrpu, dtrpv, hdepw, e1u, e2v, tmask, npiglo, npjglo, in_space, dalong, &
+          &                                         dcross, out_space, stream) BIND(C, name='cdft_vint_slope_rotate')
+       IMPORT ; REAL(C_DOUBLE), INTENT(in) :: dtrpu(*), dtrpv(*) ; REAL(C_FLOAT), INTENT(in) :: hdepw(*), e1u(*), e2v(*), tmask(*)
+       INTEGER(C_INT), VALUE :: npiglo, npjglo, in_space, out_space ; TYPE(C_PTR), VALUE :: stream
+       REAL(C_DOUBLE), INTENT(out) :: dalong(*), dcross(*)
+     END FUNCTION
      INTEGER(C_INT) FUNCTION cdft_vhst_transport(xt, xs, m2d, e3, e31d, npiglo, npjglo, npk, in_space, dheat, dsalt, &
           &                                      out_space, stream) BIND(C, name='cdft_vhst_transport')
        IMPORT ; REAL(C_FLOAT), INTENT(in) :: xt(*), xs(*), m2d(*) ; TYPE(C_PTR), VALUE :: e3, e31d, stream

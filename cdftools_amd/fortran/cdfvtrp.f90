@@ -15,11 +15,11 @@ PROGRAM cdfvtrp
   USE cdftools_hip
   IMPLICIT NONE
 
-  INTEGER(KIND=4) :: narg, ijarg, ierr, ji, jj, jk, jt, it, npiglo, npjglo, npk, npt, ncout, nvarout = 2
+  INTEGER(KIND=4) :: narg, ijarg, ierr, jk, jt, it, npiglo, npjglo, npk, npt, ncout, nvarout = 2
   INTEGER(KIND=4), ALLOCATABLE :: ipk(:), id_varout(:)
   REAL(KIND=4), ALLOCATABLE, TARGET :: e1v(:,:), e2u(:,:), e3u(:,:,:), e3v(:,:,:), e31d(:)
   REAL(KIND=4), ALLOCATABLE :: zu(:,:,:), zv(:,:,:)
-  REAL(KIND=4), ALLOCATABLE :: e1u(:,:), e2v(:,:), tmask(:,:), hdepw(:,:), zdhdx(:,:), zdhdy(:,:), zalpha(:,:)
+  REAL(KIND=4), ALLOCATABLE :: e1u(:,:), e2v(:,:), tmask(:,:), hdepw(:,:)
   REAL(KIND=8), ALLOCATABLE :: dtim(:), dwku(:,:), dwkv(:,:), dtrpu(:,:), dtrpv(:,:)
   TYPE(variable), ALLOCATABLE :: stypvar(:)
   TYPE(C_PTR) :: pe3u, pe3v, pe31d
@@ -106,7 +106,6 @@ PROGRAM cdfvtrp
   IF ( .NOT. lfull ) ALLOCATE( e3u(npiglo,npjglo,npk), e3v(npiglo,npjglo,npk) )
   IF ( lbathy ) THEN
      ALLOCATE( e1u(npiglo,npjglo), e2v(npiglo,npjglo), tmask(npiglo,npjglo), hdepw(npiglo,npjglo) )
-     ALLOCATE( zdhdx(npiglo,npjglo), zdhdy(npiglo,npjglo), zalpha(npiglo,npjglo) )
   ENDIF
   CALL CreateOutput
   e1v(:,:) = getvar(cn_fhgr, cn_ve1v, 1, npiglo, npjglo)
@@ -143,37 +142,11 @@ PROGRAM cdfvtrp
      ierr = putvar(ncout, id_varout(1), REAL(dtrpu(:,:)), 1, npiglo, npjglo, ktime=jt)
      ierr = putvar(ncout, id_varout(2), REAL(dtrpv(:,:)), 1, npiglo, npjglo, ktime=jt)
 
-     IF ( lbathy ) THEN                                   ! src/cdfvtrp.f90:224-259, as written there
-        dwku(:,:) = 0.d0
-        DO jj = 1, npjglo
-           DO ji = 2, npiglo
-              dwku(ji,jj) = 0.5 * ( dtrpu(ji,jj) + dtrpu(ji-1,jj) )
-           END DO
-           dwku(1,jj) = dwku(npiglo-1, jj)
-        END DO
-        dwkv(:,:) = 0.d0
-        DO jj = 2, npjglo
-           DO ji = 1, npiglo
-              dwkv(ji,jj) = 0.5 * ( dtrpv(ji,jj) + dtrpv(ji,jj-1) )
-           END DO
-        END DO
-        zdhdx = 0.e0
-        DO jj = 1, npjglo
-           DO ji = 2, npiglo-1
-              zdhdx(ji,jj) = ( hdepw(ji+1,jj) - hdepw(ji-1,jj) ) / ( e1u(ji,jj) + e1u(ji-1,jj) ) * tmask(ji,jj)
-           END DO
-        END DO
-        zdhdy = 0.e0
-        DO jj = 2, npjglo-1
-           DO ji = 1, npiglo
-              zdhdy(ji,jj) = ( hdepw(ji,jj+1) - hdepw(ji,jj-1) ) / ( e2v(ji,jj) + e2v(ji,jj-1) ) * tmask(ji,jj)
-           END DO
-        END DO
-        zalpha(:,:) = ATAN2( zdhdx, zdhdy ) * tmask(:,:)
-        dtrpu(:,:) = (  dwku(:,:) * COS(zalpha) + dwkv(:,:) * SIN(zalpha) ) * tmask(:,:)
-        dtrpv(:,:) = ( -dwku(:,:) * SIN(zalpha) + dwkv(:,:) * COS(zalpha) ) * tmask(:,:)
-        ierr = putvar(ncout, id_varout(3), REAL(dtrpu(:,:)), 1, npiglo, npjglo, ktime=jt)
-        ierr = putvar(ncout, id_varout(4), REAL(dtrpv(:,:)), 1, npiglo, npjglo, ktime=jt)
+     IF ( lbathy ) THEN                                   ! along- and cross-slope components (src/cdfvtrp.f90:210-252): on the GPU
+        CALL hip_check(cdft_vint_slope_rotate(dtrpu, dtrpv, hdepw, e1u, e2v, tmask, npiglo, npjglo, CDFT_MEM_HOST, dwku, dwkv, &
+             &         CDFT_MEM_HOST, C_NULL_PTR), 'cdft_vint_slope_rotate')
+        ierr = putvar(ncout, id_varout(3), REAL(dwku(:,:)), 1, npiglo, npjglo, ktime=jt)
+        ierr = putvar(ncout, id_varout(4), REAL(dwkv(:,:)), 1, npiglo, npjglo, ktime=jt)
      ENDIF
   END DO
   ierr = closeout(ncout)

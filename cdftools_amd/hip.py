@@ -741,6 +741,27 @@ def vint_transport(vel, m2d, e3=None, e31d=None, stream=None):
     return out
 
 
+def vint_slope_rotate(dtrpu, dtrpv, hdepw, e1u, e2v, tmask, stream=None):
+    """cdft_vint_slope_rotate (cdfvtrp -bathy): (npj,npi) r8 transports + r4 planes -> (along, cross) r8."""
+    pu, su, ku = _arg(dtrpu, np.float64, "dtrpu")
+    pv, sv, kv = _arg(dtrpv, np.float64, "dtrpv")
+    ph, sh, kh = _arg(hdepw, np.float32, "hdepw")
+    p1, s1, k1 = _arg(e1u, np.float32, "e1u")
+    p2, s2, k2 = _arg(e2v, np.float32, "e2v")
+    pm, sm, km = _arg(tmask, np.float32, "tmask")
+    sp = _same_space(su, sv, sh, s1, s2, sm)
+    npj, npi = ku.shape
+    if sp == MEM_DEVICE:
+        a = torch.empty((npj, npi), dtype=torch.float64, device=ku.device)
+        c = torch.empty_like(a)
+        pa, pc = C.c_void_p(a.data_ptr()), C.c_void_p(c.data_ptr())
+    else:
+        a, c = np.empty((npj, npi), np.float64), np.empty((npj, npi), np.float64)
+        pa, pc = C.c_void_p(a.ctypes.data), C.c_void_p(c.ctypes.data)
+    check(_lib.load().cdft_vint_slope_rotate(pu, pv, ph, p1, p2, pm, npi, npj, sp, pa, pc, sp, stream or current_stream_ptr()))
+    return a, c
+
+
 def vhst_transport(xt, xs, m2d, e3=None, e31d=None, stream=None):
     """cdft_vhst_transport: one pair of VT-file variables -> (heat, salt), each (npj,npi) r8."""
     pt, st_, kt = _arg(xt, np.float32, "xt")

@@ -305,6 +305,16 @@ int cdft_mhst_destroy(cdft_mhst_plan *plan);
  * r4 or NULL with e31d (npk) r4 (-full).  dtrp (npiglo,npjglo) r8: the caller stores REAL(dtrp). */
 int cdft_vint_transport(const float *vel, const float *m2d, const float *e3, const float *e31d, int npiglo,
                         int npjglo, int npk, int in_space, double *dtrp, int out_space, void *stream);
+/* cdfvtrp -bathy, src/cdfvtrp.f90:210-252: along- and cross-slope components of the two vertically integrated
+ * transports.  dtrpu, dtrpv (npiglo,npjglo) r8 as cdft_vint_transport returns them; hdepw (sea-floor depth), e1u, e2v,
+ * tmask (level 1) (npiglo,npjglo) r4.  dwku = 0.5*(dtrpu(i)+dtrpu(i-1)) with dwku(1,:) = dwku(npiglo-1,:), dwkv likewise
+ * in j with row 1 = 0; slopes zdhdx, zdhdy by centred r4 differences (0 on the border), zalpha = ATAN2(zdhdx,zdhdy)*tmask;
+ *   dalong = ( dwku*COS(zalpha) + dwkv*SIN(zalpha)) * tmask      dcross = (-dwku*SIN(zalpha) + dwkv*COS(zalpha)) * tmask
+ * both (npiglo,npjglo) r8; the caller stores REAL(.).  Pointwise r8 arithmetic on r4 ATAN2 / COS / SIN values: equal to the
+ * reference up to the last bit of those three library results (|d| <= 3 ulp(r4) * (|dwku| + |dwkv|)). */
+int cdft_vint_slope_rotate(const double *dtrpu, const double *dtrpv, const float *hdepw, const float *e1u,
+                           const float *e2v, const float *tmask, int npiglo, int npjglo, int in_space, double *dalong,
+                           double *dcross, int out_space, void *stream);
 /* src/cdfvhst.f90:167-178 for one pair of VT-file variables (vomevt, vomevs with e1v, e3v; vozout,
  * vozous with e2u, e3u): e3m = e3*m2d in r4 first, then
  *   dheat += xt*e3m*pp_rau0*pp_rcp*1.d0 (1000., 4000., r4 chain), dsalt += xs*e3m*1.d0. */

@@ -84,6 +84,8 @@ void oracle_psi(int npi, int npj, int npk, const float *zu, const float *e2u, co
                 int ijref, const float *fmask, float *psi4, double *dpsi8);
 void oracle_vint_transport(int npi, int npj, int npk, const float *vel, const float *m2d, const float *e3,
                            const float *e31d, double *dtrp);
+void oracle_vtrp_slope(int npi, int npj, const double *dtrpu, const double *dtrpv, const float *hdepw, const float *e1u,
+                       const float *e2v, const float *tmask, double *along, double *cross);
 void oracle_vhst_transport(int npi, int npj, int npk, const float *xt, const float *xs, const float *m2d,
                            const float *e3, const float *e31d, double *dheat, double *dsalt);
 void oracle_mean(int npi, int npj, int npk, int nb, const float *e1, const float *e2, const float *e3,

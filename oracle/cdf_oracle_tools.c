@@ -316,6 +316,40 @@ void oracle_vint_transport(int npi, int npj, int npk, const float *vel, const fl
         }
 }
 
+/* src/cdfvtrp.f90:210-252 (-bathy): the transports brought to the T point, rotated onto the bathymetric slope.
+ *   dwku(i,j) = 0.5*(dtrpu(i,j) + dtrpu(i-1,j)), i >= 2; dwku(1,j) = dwku(npi-1,j)          (:213-219)
+ *   dwkv(i,j) = 0.5*(dtrpv(i,j) + dtrpv(i,j-1)), j >= 2; row 1 = 0                           (:220-225)
+ *   zdhdx = (hdepw(i+1,j) - hdepw(i-1,j)) / (e1u(i,j) + e1u(i-1,j)) * tmask, 2 <= i <= npi-1, else 0   (r4, :228-233)
+ *   zdhdy = (hdepw(i,j+1) - hdepw(i,j-1)) / (e2v(i,j) + e2v(i,j-1)) * tmask, 2 <= j <= npj-1, else 0   (r4, :235-240)
+ *   zalpha = ATAN2(zdhdx, zdhdy) * tmask                                                      (r4, :243)
+ *   along = ( dwku*COS(zalpha) + dwkv*SIN(zalpha)) * tmask ; cross = (-dwku*SIN(zalpha) + dwkv*COS(zalpha)) * tmask
+ * (r4 COS / SIN widened, r8 arithmetic, :246-247).  ATAN2 / COS / SIN are the C library's single precision functions. */
+void oracle_vtrp_slope(int npi, int npj, const double *dtrpu, const double *dtrpv, const float *hdepw, const float *e1u,
+                       const float *e2v, const float *tmask, double *along, double *cross) {
+#define AT(a, i, j) (a)[(size_t)(j) * npi + (i)]
+    const size_t nij = (size_t)npi * npj;
+    double *dwku = (double *)calloc(nij, 8), *dwkv = (double *)calloc(nij, 8);
+    for (int j = 0; j < npj; ++j) {
+        for (int i = 1; i < npi; ++i) AT(dwku, i, j) = 0.5f * (AT(dtrpu, i, j) + AT(dtrpu, i - 1, j));
+        if (npi >= 2) AT(dwku, 0, j) = AT(dwku, npi - 2, j);
+    }
+    for (int j = 1; j < npj; ++j)
+        for (int i = 0; i < npi; ++i) AT(dwkv, i, j) = 0.5f * (AT(dtrpv, i, j) + AT(dtrpv, i, j - 1));
+    for (int j = 0; j < npj; ++j)
+        for (int i = 0; i < npi; ++i) {
+            float zdhdx = 0.f, zdhdy = 0.f;
+            const float tm = AT(tmask, i, j);
+            if (i >= 1 && i <= npi - 2) zdhdx = (AT(hdepw, i + 1, j) - AT(hdepw, i - 1, j)) / (AT(e1u, i, j) + AT(e1u, i - 1, j)) * tm;
+            if (j >= 1 && j <= npj - 2) zdhdy = (AT(hdepw, i, j + 1) - AT(hdepw, i, j - 1)) / (AT(e2v, i, j) + AT(e2v, i, j - 1)) * tm;
+            const float zalpha = atan2f(zdhdx, zdhdy) * tm;
+            const double c = (double)cosf(zalpha), sn = (double)sinf(zalpha);
+            AT(along, i, j) = (AT(dwku, i, j) * c + AT(dwkv, i, j) * sn) * (double)tm;
+            AT(cross, i, j) = (-AT(dwku, i, j) * sn + AT(dwkv, i, j) * c) * (double)tm;
+        }
+    free(dwku); free(dwkv);
+#undef AT
+}
+
 /* src/cdfvhst.f90:167-178: e3m = e3*m2d (r4, :170-171), then
  *   dheat += xt*e3m*pp_rau0*pp_rcp*1.d0 ; dsalt += xs*e3m*1.d0   (pp_rau0 = 1000., pp_rcp = 4000., r4) */
 void oracle_vhst_transport(int npi, int npj, int npk, const float *xt, const float *xs, const float *m2d,

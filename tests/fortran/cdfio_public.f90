@@ -1,87 +1,113 @@
 PROGRAM cdfio_public
-  ! Test driver (tests/test_cdfio_public.py): calls every routine of cdfio's public list that no tool of the hot path
-  ! uses, the way a reference program would (argument order and keywords of src/cdfio.F90), on the files the Python
-  ! side wrote into the directory given as argument; prints "key values" lines the test compares with NumPy.
+  ! Test driver (tests/test_cdfio_public.py): calls the routines of cdfio the tools of this build rely on, with the
+  ! reference's argument order and keywords (src/cdfio.F90), on the files the Python side wrote into the directory given
+  ! as argument; prints "key values" lines the test compares with NumPy.
   USE cdfio
   USE modcdfnames
   IMPLICIT NONE
   INTEGER(KIND=4), PARAMETER :: npi = 6, npj = 5, npk = 4, npt = 3
-  CHARACTER(LEN=256) :: cdir, cf_t, cf_e, cf_xz, cf_o, cldep, cl1, cl2, cl3, cl4, cl5, cl6, clvar, clunits, cllong, clshort
-  CHARACTER(LEN=20)  :: cltime
-  INTEGER(KIND=4) :: ierr, ncout, ipk(2), id_varout(2), ivid(5)
-  REAL(KIND=4) :: v3(npi-1,npj-2,npk-1), v3t(npi,npj,npt), v4(npi-2,npj-1,npk,npt-1), vxz(npi-1,npk-1), vyz(npj-1,npk), vx2(npi,npk)
-  REAL(KIND=4) :: zdep(npk), zwin(3,2), zprof(npk), z1d(npk), zlon(npi,npj), zlat(npi,npj)
-  REAL(KIND=8) :: d1d(npk)
-  TYPE(variable) :: stypvar(2)
+  CHARACTER(LEN=256) :: cdir, cf_t, cf_m, cf_o, cltrue, clvar, clunits, cllong, clshort, clmiss
+  CHARACTER(LEN=256), ALLOCATABLE :: clnames(:)
+  INTEGER(KIND=4) :: ierr, ncout, ipk(4), id_varout(4), nvars, istat
+  INTEGER(KIND=4), ALLOCATABLE :: ipkin(:)
+  REAL(KIND=4) :: v3(npi-1,npj-2,npk-1), w3(npi,npj,npk), vw(4,npj), zspv, z2(npi,npj), zline(npj)
+  REAL(KIND=8) :: d2(npi,npj), d1d(2)
+  INTEGER(KIND=1) :: m3(npi,npj,npk)
+  INTEGER(KIND=2) :: i2(npi,npj)
+  TYPE(variable) :: stypvar(4)
+  TYPE(variable), ALLOCATABLE :: stypin(:)
 
   CALL getarg(1, cdir)
-  cf_t  = TRIM(cdir)//'/T.nc'
-  cf_e  = TRIM(cdir)//'/edit.nc'
-  cf_xz = TRIM(cdir)//'/xz.nc'
-  cf_o  = TRIM(cdir)//'/out.nc'
+  cf_t = TRIM(cdir)//'/T.nc'
+  cf_m = TRIM(cdir)//'/mesh.nc'
+  cf_o = TRIM(cdir)//'/out.nc'
 
-  ivid = getvarid(cf_t, 5)
-  PRINT '(a,5i4)', 'getvarid', ivid
-  zdep = getdimvar(cf_t, npk, cd_depnam=cldep)
-  PRINT '(a,1x,a)', 'getdimvar_name', TRIM(cldep)
-  PRINT '(a,4es16.8)', 'getdimvar', zdep
-  ierr = gettimeatt(cf_t, cn_vtimec, cl1, cl2, cl3, cl4, cl5, cl6)
-  PRINT '(13a)', 'gettimeatt |', TRIM(cl1), '|', TRIM(cl2), '|', TRIM(cl3), '|', TRIM(cl4), '|', TRIM(cl5), '|', TRIM(cl6), '|'
+  ! ---- inquiries
+  PRINT '(a,4i6)', 'getdim', getdim(cf_t, cn_x), getdim(cf_t, cn_y), getdim(cf_t, 'dep', cdtrue=cltrue), getdim(cf_t, cn_t)
+  PRINT '(a,1x,a)', 'getdim_true', TRIM(cltrue)
+  ierr = getdim(cf_t, 'nosuchdim', cdtrue=cltrue, kstatus=istat)
+  PRINT '(a,2i4,1x,a)', 'getdim_absent', ierr, istat, TRIM(cltrue)
+  clvar = 'votemper'
+  PRINT '(a,2i4)', 'getvdim', getvdim(cf_t, clvar), MERGE(1, 0, chkvar(cf_t, 'nosuchvar', .FALSE.))
+  zspv = getspval(cf_t, 'sossheig', clmiss)
+  PRINT '(a,es16.8,1x,a)', 'getspval', zspv, TRIM(clmiss)
+  PRINT '(a,es16.8,i6,1x,a)', 'getatt', getatt(cf_t, 'votemper', 'valid_max'), getatt(cf_t, 'votemper', 'iweight', 1), &
+       &  TRIM(getatt(cf_t, 'votemper', 'units', 'c'))
+  clunits = 'keep' ; cllong = 'keep' ; clshort = 'keep'
+  ierr = getvaratt(cf_t, 'votemper', clunits, zspv, cllong, clshort)
+  PRINT '(a,es16.8,7a)', 'getvaratt', zspv, ' |', TRIM(clunits), '|', TRIM(cllong), '|', TRIM(clshort), '|'
+  nvars = getnvar(cf_t)
+  ALLOCATE( clnames(nvars), stypin(nvars), ipkin(nvars) )
+  clnames = getvarname(cf_t, nvars, stypin)
+  ipkin = getipk(cf_t, nvars)
+  PRINT '(a,i4)', 'getnvar', nvars
+  PRINT '(a,99(1x,a))', 'getvarname', (TRIM(clnames(ierr)), ierr = 1, nvars)
+  PRINT '(a,99i4)', 'getipk', ipkin
+  PRINT '(a,es16.8,3a)', 'stypin_votemper', stypin(5)%valid_max, ' |', TRIM(stypin(5)%cunits), '|'
 
+  ! ---- slab and block reads
+  z2 = getvar(cf_t, 'packed', 2, npi, npj, ktime=2)
+  PRINT '(a,999es16.8)', 'getvar_packed', z2
+  vw = getvar(cf_t, cn_votemper, 3, 4, npj, kimin=4, ktime=1)            ! columns 4 5, then 2 3 (the wrap skips column 1 = 6)
+  PRINT '(a,999es16.8)', 'getvar_wrap', vw
+  vw = getvar(cf_t, cn_votemper, 3, 4, npj, kimin=3, ktime=1)            ! ends on the last column: no wrap
+  PRINT '(a,999es16.8)', 'getvar_edge', vw
   v3 = getvar3d(cf_t, cn_votemper, npi-1, npj-2, npk-1, kimin=2, kjmin=3, kkmin=2, ktime=2)
   PRINT '(a,999es16.8)', 'getvar3d', v3
-  v3t = getvar3dt(cf_t, cn_votemper, 3, npi, npj, npt)
-  PRINT '(a,999es16.8)', 'getvar3dt', v3t
-  v3t(:,:,1:2) = getvar3dt(cf_t, cn_sossheig, 1, npi, npj, 2, ktmin=2)
-  PRINT '(a,999es16.8)', 'getvar3dt_2d', v3t(:,:,1:2)
-  v4 = getvar4d(cf_t, 'packed', npi-2, npj-1, npk, npt-1, kimin=3, kjmin=2, ktmin=2)
-  PRINT '(a,999es16.8)', 'getvar4d', v4
-  vxz = getvarxz(cf_t, cn_votemper, 4, npi-1, npk-1, kimin=2, kkmin=2, ktime=3)
-  PRINT '(a,999es16.8)', 'getvarxz', vxz
-  vyz = getvaryz(cf_t, 'packed', 5, npj-1, npk, kjmin=2, ktime=2)
-  PRINT '(a,999es16.8)', 'getvaryz', vyz
-  vx2 = getvarxz(cf_xz, 'sec', 1, npi, npk, ktime=2)
-  PRINT '(a,999es16.8)', 'getvarxz_noy', vx2
-  PRINT '(a)', 'gettimeseries_begin'
-  CALL gettimeseries(cf_t, cn_votemper, 2, 3, klev=4)
-  CALL gettimeseries(cf_t, cn_sossheig, 6, 1)
-  PRINT '(a)', 'gettimeseries_end'
+  CALL readvar3d(cf_t, 'packed', w3, ktime=3)
+  PRINT '(a,999es16.8)', 'readvar3d_packed', w3
+  CALL readvar3d(cf_t, cn_sossheig, w3, ktime=2)                           ! (x,y,t): the slab on every level
+  PRINT '(a,999es16.8)', 'readvar3d_xyt', w3
+  CALL readvar3d(cf_m, 'e3static', w3)                                     ! (x,y,z) without a time axis
+  PRINT '(a,999es16.8)', 'readvar3d_xyz', w3
+  CALL readvar3d(cf_m, 'e3static', v3, kimin=2, kjmin=3, kkmin=2)
+  PRINT '(a,999es16.8)', 'readvar3d_xyz_window', v3
+  CALL readvar3d(cf_m, 'area', w3)                                         ! (x,y)
+  PRINT '(a,999es16.8)', 'readvar3d_xy', w3
+  CALL readvar3d(cf_t, cn_votemper, w3(1:4,:,:), ktime=2, kimin=4)         ! over the eastern edge
+  PRINT '(a,999es16.8)', 'readvar3d_wrap', w3(1:4,:,:)
+  CALL readvar3d_i1(cf_m, 'tmaskstatic', m3)
+  PRINT '(a,999i3)', 'readvar3d_i1_xyz', m3
+  CALL readvar3d_i1(cf_t, 'tmask4d', m3, ktime=2)
+  PRINT '(a,999i3)', 'readvar3d_i1_xyzt', m3
+  d1d = getvar1d(cf_t, cn_vtimec, 2)
+  PRINT '(a,2es24.16)', 'getvar1d', d1d
+  d1d = getvar1d(cf_t, 'nosuchvar', 2, istat)
+  PRINT '(a,es24.16,i4)', 'getvar1d_absent', d1d(1), MERGE(1, 0, istat /= 0)
 
-  ! ---- editing an existing file
-  ierr = atted(cf_e, 'votemper', 'units', 'degC')                  ! overwrite, longer than before
-  ierr = atted(cf_e, 'votemper', 'a_new_text_attribute', 'made by atted_char, long enough to move the data section')
-  ierr = atted(cf_e, 'votemper', 'valid_max', 41.5)               ! overwrite r4
-  ierr = atted(cf_e, 'sossheig', 'new_r4', -2.25)
-  clvar = 'sossheig' ; clunits = 'metres' ; cllong = 'sea surface height' ; clshort = 'ssh'
-  ierr = cvaratt(cf_e, clvar, clunits, -9999., cllong, clshort)
-  PRINT '(a,i4)', 'cvaratt', ierr
-  zwin = RESHAPE((/ 1., 2., 3., 4., 5., 6. /), (/ 3, 2 /))
-  ierr = putvar(cf_e, 'votemper', 2, 3, 2, kimin=2, kjmin=4, ktime=3, ptab=zwin, kwght=7)
-  PRINT '(a,i4)', 'reputvarr4', ierr
-  ierr = putvar(cf_e, 'sossheig', 1, 3, 2, kimin=4, kjmin=1, ktime=2, ptab=-zwin)
-  z1d = (/ 10., 20., 30., 40. /) ; d1d = (/ 1.5d0, 2.5d0, 3.5d0, 4.5d0 /)
-  ierr = putvar1d(cf_e, 'deptht', z1d, npk)
-  ierr = putvar1d(cf_e, 'dprof', d1d, npk)
-
-  ! ---- a new file: puttimeatt, putvare3
-  ipk = (/ npk, 1 /)
-  stypvar(1)%cname = 'prof' ; stypvar(1)%cunits = 'm' ; stypvar(1)%clong_name = 'a profile' ; stypvar(1)%cshort_name = 'prof'
-  stypvar(2)%cname = 'flat' ; stypvar(2)%cunits = 'm' ; stypvar(2)%clong_name = 'a map'     ; stypvar(2)%cshort_name = 'flat'
-  ncout = create(cf_o, cf_t, 1, 1, npk)
-  ierr  = createvar(ncout, stypvar, 2, ipk, id_varout)
-  zlon = 0. ; zlat = 0.
-  ierr  = putheadervar(ncout, cf_t, 1, 1, npk, pnavlon=zlon(1:1,1:1), pnavlat=zlat(1:1,1:1))
-  zprof = (/ 4., 3., 2., 1. /)
-  ierr = putvar(ncout, id_varout(1), zprof, npk, 'vert', ktime=1)
-  ierr = putvar(ncout, id_varout(1), 2. * zprof, npk, 'vert', ktime=2, kwght=3)
-  ierr = putvar0d(ncout, id_varout(2), 5.5, ktime=1)
-  ierr = putvar0d(ncout, id_varout(2), 6.5, ktime=2)
-  d1d(1:2) = (/ 86400.d0, 172800.d0 /)
-  ierr = putvar1d(ncout, d1d(1:2), 2, 'T')
-  cltime = cn_vtimec
-  cl1 = 'gregorian' ; cl2 = 'Time' ; cl3 = 'Time axis' ; cl4 = 'T' ; cl5 = 'seconds since 1958-01-01 00:00:00' ; cl6 = '1958-JAN-01 00:00:00'
-  ierr = puttimeatt(ncout, cltime, cl1, cl2, cl3, cl4, cl5, cl6)
-  PRINT '(a,i4)', 'puttimeatt', ierr
+  ! ---- a new file: every kind of putvar
+  ipk = (/ npk, 1, 1, -1 /)
+  stypvar(:)%cunits = 'm' ; stypvar(:)%rmissing_value = -1. ; stypvar(:)%valid_min = 0. ; stypvar(:)%valid_max = 9.
+  stypvar(:)%clong_name = 'long' ; stypvar(:)%cshort_name = 'short' ; stypvar(:)%conline_operation = 'N/A' ; stypvar(:)%caxis = 'TZYX'
+  stypvar(1)%cname = 'cube'  ; stypvar(1)%cprecision = 'r8'
+  stypvar(2)%cname = 'plane' ; stypvar(2)%scale_factor = 0.5                ! becomes a short
+  stypvar(3)%cname = 'count' ; stypvar(3)%cprecision = 'i2'
+  stypvar(4)%cname = 'scalar'
+  ncout = create(cf_o, cf_t, npi, npj, npk, cdep='deptht')
+  ierr  = createvar(ncout, stypvar, 4, ipk, id_varout, cdglobal='made by the test')
+  ierr  = putheadervar(ncout, cf_t, npi, npj, npk)
+  d2 = RESHAPE((/ (DBLE(ierr) * 0.25d0, ierr = 1, npi*npj) /), (/ npi, npj /))
+  DO ierr = 1, npk
+     istat = putvar(ncout, id_varout(1), d2 * ierr, ierr, npi, npj, ktime=2)
+  END DO
+  z2 = REAL(d2, 4)
+  istat = putvar(ncout, id_varout(2), z2, 1, npi, npj, ktime=1, kwght=5)
+  i2 = INT(4.d0 * d2, 2)
+  istat = putvar(ncout, id_varout(3), i2, 1, npi, npj, ktime=2)
+  istat = putvar0d(ncout, id_varout(4), 5.5, ktime=1)
+  istat = putvar0d(ncout, id_varout(4), RESHAPE((/ 6.5 /), (/ 1, 1 /)), ktime=2)
+  d1d = (/ 86400.d0, 172800.d0 /)
+  istat = putvar1d(ncout, d1d, 2, 'T')
+  ierr = closeout(ncout)
+  ! a zonal line (1-D r4) into a (1,npj) file, with the coordinates given
+  cf_o = TRIM(cdir)//'/zonal.nc'
+  stypvar(1)%cname = 'line' ; stypvar(1)%cprecision = 'r4'
+  ncout = create(cf_o, 'none', 1, npj, npk, cdep='depthw')
+  ierr  = createvar(ncout, stypvar, 1, ipk, id_varout)
+  z2 = 0.
+  ierr  = putheadervar(ncout, 'none', 1, npj, npk, pnavlon=z2(1:1,:), pnavlat=z2(1:1,:) + 2., pdep=(/ 1., 2., 3., 4. /))
+  zline = (/ 1., 2., 3., 4., 5. /)
+  istat = putvar(ncout, id_varout(1), zline, 3, 1, npj, ktime=1)
   ierr = closeout(ncout)
   PRINT '(a)', 'done'
 END PROGRAM cdfio_public

@@ -163,6 +163,11 @@ VHST_CASES = ["default", "full"]
 VTRP_CASES = ["default", "full"]
 
 
+def vtrp_hdepw(g):
+    """the depth of the sea floor of a synthetic grid (hdepw of mesh_zgr), as tests/nemo_files.py writes it"""
+    return (g["e3t_0"] * g["tmask"]).sum(axis=0).astype(f32)
+
+
 def mean_case(name):
     """-> g, field (npt,npk,npj,npi), basins (nb,npj,npi) r4, full, point type"""
     g, t, s, u, v = grid8f()

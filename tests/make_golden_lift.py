@@ -87,6 +87,12 @@ def g_cdfvhst_cdfvtrp():
     return d
 
 
+def g_cdfvtrp_bathy():
+    """cdfvtrp -bathy (src/cdfvtrp.f90:210-252): REAL(dtrpu), REAL(dtrpv), then the along- and cross-slope components."""
+    g, t, s, u, v = lc.grid8f()
+    return {"default": rl.cdfvtrp(g, u, v, bathy=lc.vtrp_hdepw(g)), "full": rl.cdfvtrp(g, u, v, full=True, bathy=lc.vtrp_hdepw(g))}
+
+
 def g_cdfmean_cdfsum():
     d = {}
     g, t, s, u, v = lc.grid8f()
@@ -216,7 +222,7 @@ def g_vvl():
     return d
 
 
-FILES = {"cdfmoc": g_cdfmoc, "cdfheatc": g_cdfheatc, "cdfmhst": g_cdfmhst, "cdfpsi": g_cdfpsi, "cdfvt": g_cdfvt, "cdfcurl": g_cdfcurl,
+FILES = {"cdfvtrp_bathy": g_cdfvtrp_bathy, "cdfmoc": g_cdfmoc, "cdfheatc": g_cdfheatc, "cdfmhst": g_cdfmhst, "cdfpsi": g_cdfpsi, "cdfvt": g_cdfvt, "cdfcurl": g_cdfcurl,
          "cdfvhst_cdfvtrp": g_cdfvhst_cdfvtrp, "cdfmean_cdfsum": g_cdfmean_cdfsum, "cdfvint_cdfvertmean": g_cdfvint_cdfvertmean,
          "cdfzonal": g_cdfzonal, "cdfmocsig": g_cdfmocsig, "cdfsig": g_cdfsig, "cdfmoc_rapid": g_cdfmoc_rapid, "cdfmaxmoc": g_cdfmaxmoc,
          "vvl": g_vvl}

@@ -105,6 +105,17 @@ def vint_transport(vel, m2d, e3=None, e31d=None):
     return out
 
 
+def vtrp_slope(dtrpu, dtrpv, hdepw, e1u, e2v, tmask):
+    """src/cdfvtrp.f90:210-252 (-bathy) -> (along, cross), each (npj,npi) r8."""
+    lib = load()
+    du, dv = np.ascontiguousarray(dtrpu, np.float64), np.ascontiguousarray(dtrpv, np.float64)
+    hdepw, e1u, e2v, tmask = map(_f, (hdepw, e1u, e2v, tmask))
+    npj, npi = du.shape
+    a, c = np.empty((npj, npi), np.float64), np.empty((npj, npi), np.float64)
+    lib.oracle_vtrp_slope(C.c_int(npi), C.c_int(npj), _p(du), _p(dv), _p(hdepw), _p(e1u), _p(e2v), _p(tmask), _p(a), _p(c))
+    return a, c
+
+
 def vhst_transport(xt, xs, m2d, e3=None, e31d=None):
     """src/cdfvhst.f90:167-178 for one pair -> (heat, salt), each (npj,npi) r8."""
     lib = load()
