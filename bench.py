@@ -9,6 +9,16 @@ npt) result of every step (exact-size point-to-point transfers under the next st
 grid is fixed as N grows => "scaling": "strong".  `python bench.py --gpus N` starts its own N ranks
 (a torch.distributed.run child process) when it is not already running under a launcher.
 
+Two ways of using N GPUs are measured, because the product has two:
+  --mode ranks (default, the contract above)  one process per GPU over RCCL, plans of cdft_moc_create on row blocks;
+  --mode inprocess                            ONE process, N devices: the sharded plan of cdft_moc_create_sharded, which is
+      what the drop-in programs use under CDFT_GPUS=N.  The full-domain records are handed over once (cdft_moc_stage: each
+      block's rows go to its own HBM) and every step is cdft_moc_compute_staged into a full-domain result on device 0.
+After its own measurement, rank 0 of a `ranks` run starts the in-process one as a child process on the same N devices
+(the other ranks wait, their memory released) and carries its line as the object "inprocess": both scaling curves come
+out of the one command the driver runs.  The child also runs cdfheatc and cdfpsi on sharded plans with their exchanges
+as peer copies and as RCCL collectives (cdft_shard_set_collective) and reports whether the results are the same bits.
+
 Prints ONE JSON line on rank 0 (contract in the task statement), including
   roofline     -- HBM roofline of the dominant kernel (moc_zonal_kernel): algorithmic bytes per
                   launch / its mean launch duration from HIP events on the launch stream;
@@ -186,6 +196,189 @@ def reference_child(d, target_s):
     json.dump([reps, total], open(os.path.join(d, "time.json"), "w"))
 
 
+def pmc_traffic(describe, npi, rows, npk, npt):
+    """HBM bytes per launch from the committed PMC passes (profiles/moc_zonal_traffic.json, made by tools/profile_moc.sh as
+    MI355X_MICROARCH.md prescribes) -- but only for the very kernel that ran: the file records plan.describe() and the
+    block shape of its measurement, and anything else (another kernel variant after a code change, another row block) gets
+    null and the reason.  -> (bytes or None, note)"""
+    tpath = os.path.join(ROOT, "profiles", "moc_zonal_traffic.json")
+    if not os.path.exists(tpath):
+        return None, "no profiles/moc_zonal_traffic.json"
+    tj = json.load(open(tpath))
+    shape = [npi, rows, npk, npt]
+    if tj.get("describe") != describe:
+        return None, f"the PMC passes of {os.path.basename(tpath)} measured '{tj.get('describe')}', this run launched '{describe}'"
+    if tj.get("block_shape") != shape:
+        return None, f"the PMC passes measured a block of {tj.get('block_shape')}, this rank's is {shape}"
+    return tj.get("hbm_bytes_per_launch"), tj.get("source")
+
+
+def all_devices_sync(devices):
+    for d in sorted(set(devices)):
+        torch.cuda.synchronize(d)
+
+
+def collective_check(devices):
+    """cdfheatc (r8 sums) and cdfpsi on sharded plans over `devices`, their exchanges once as peer copies / a host sum
+    (CDFT_COLLECTIVE_PEER, the default) and once as RCCL collectives inside the library (ncclAllGather of the block sums,
+    ncclSend / ncclRecv of the carry, ncclBroadcast of the reference value): the same bits?  And against one device."""
+    import synth
+    n = len(devices)
+    if len(set(devices)) != n:
+        return {"skipped": "two blocks on one device (test hook): RCCL takes one rank per device"}
+    npi, npj, npk = 362, 48 * n + 5, 31
+    g = synth.make_grid(npi, npj, npk, seed=77)
+    rng = np.random.default_rng(78)
+    temp = ((-2 + 30 * rng.random((npk, npj, npi), dtype=np.float32)) * g["tmask"]).astype(np.float32)
+    u = synth.velocity(g, 1, 79, which="u")[0]
+    tm = g["tmask"].astype(np.uint8)
+    out = {}
+
+    def heatc(devs):
+        p = hip.HeatcPlan(npi, npj, npk, devices=devs)
+        p.set_sum_mode(False)
+        p.set_mesh(g["e1t"], g["e2t"], tm, e3t=g["e3t_0"])
+        t0 = time.perf_counter()
+        r = p.compute(temp)
+        return r, 1e3 * (time.perf_counter() - t0)
+
+    def psi(devs):
+        p = hip.PsiPlan(npi, npj, npk, devices=devs)
+        t0 = time.perf_counter()
+        r = p.compute(zu=u, e2u=g["e2u"], e3u=g["e3u_0"], iiref=npi // 3, ijref=(2 * npj) // 3)
+        return r, 1e3 * (time.perf_counter() - t0)
+    res = {}
+    for name, mode in (("peer", hip.COLLECTIVE_PEER), ("rccl", hip.COLLECTIVE_RCCL)):
+        hip.set_collective(mode)
+        try:
+            heatc(devices), psi(devices)                          # first call: communicators, staging buffers
+            res[name] = (heatc(devices), psi(devices))
+        finally:
+            hip.set_collective(hip.COLLECTIVE_PEER)
+    one = (heatc(None), psi(None))
+    hp, hr, h1 = res["peer"][0][0], res["rccl"][0][0], one[0][0]
+    pp, pr, p1 = res["peer"][1][0], res["rccl"][1][0], one[1][0]
+    out["heatc_rccl_equals_peer_bits"] = bool(np.array_equal(hp, hr))
+    out["heatc_vs_one_device_rel"] = float(np.abs(hr - h1).max() / np.abs(h1).max())
+    out["psi_rccl_equals_peer_bits"] = bool(np.array_equal(pp[0], pr[0]) and np.array_equal(pp[1], pr[1]))
+    out["psi_equals_one_device_bits"] = bool(np.array_equal(pr[0], p1[0]) and np.array_equal(pr[1], p1[1]))
+    out["ms_per_call"] = {"heatc_peer": res["peer"][0][1], "heatc_rccl": res["rccl"][0][1], "psi_peer": res["peer"][1][1],
+                          "psi_rccl": res["rccl"][1][1]}
+    out["grid"] = [npi, npj, npk]
+    out["blocks"] = n
+    return out
+
+
+def main_inprocess(args):
+    """--mode inprocess: one process, N devices, the sharded plan behind the drop-in boundary (CDFT_GPUS=N)."""
+    global hip, shard
+    from cdftools_amd import hip, shard
+    n = args.gpus
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: libcdftools_hip has no CPU fallback")
+    one_gpu = os.environ.get("CDFT_BENCH_ONE_GPU") == "1"
+    devices = [0] * n if one_gpu else list(range(n))
+    if not one_gpu and torch.cuda.device_count() < n:
+        raise SystemExit(f"--gpus {n} but the node has {torch.cuda.device_count()} devices")
+    torch.cuda.set_device(0)
+    device = torch.device("cuda", 0)
+    npi, npj, npk, npt, nb = WORKLOADS[args.workload]
+    e1v, e3v, ib, zv = build_inputs(npi, npj, npk, npt, nb, 0, npj, device)
+    plan = hip.MocPlan(npi, npj, npk, nb, devices=devices)
+    if args.tune:
+        plan.set_tuning(*[int(x) for x in args.tune.split(",")])
+    plan.set_mesh(e1v, e3v, ib)
+    keep_rows = min(shard.row_block(npj, n, 0)[1], 192)
+    e3v_s = e3v[:, :keep_rows].clone()
+    zv_s = zv[:, :, :keep_rows].clone()
+    del e3v
+    torch.cuda.empty_cache()
+    t0 = time.perf_counter()
+    plan.stage(zv)                                             # every block's rows into its own HBM, once
+    all_devices_sync(devices)
+    stage_s = time.perf_counter() - t0
+    del zv
+    plan._staged = None
+    torch.cuda.empty_cache()
+    outs = [torch.empty((npt, npk, npj, nb), dtype=torch.float64, device=device) for _ in range(2)]
+    for i in range(args.warmup):
+        plan.compute_staged(outs[i % 2])
+    all_devices_sync(devices)
+    plan.profile_enable(True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        plan.compute_staged(outs[i % 2])                       # returns when every block's rows are in outs[..]
+    all_devices_sync(devices)
+    elapsed = time.perf_counter() - t0
+    plan.profile_enable(False)
+    result = outs[(args.steps - 1) % 2]
+    blocks = []
+    for b in range(n):
+        dev, j0, j1 = plan.block_info(b)
+        each = plan.profile_read_block(b)
+        rows = j1 - j0
+        alg = 4.0 * (1.0 + 1.0 / npt) * float(npi) * rows * (npk - 1) * npt
+        avg = float(each.mean()) if each.size else None
+        blocks.append({"block": b, "device": dev, "rows": rows, "launches": int(each.size), "avg_launch_ms": avg,
+                       "algorithmic_bytes_per_launch": alg, "achieved": alg / (avg * 1e-3) / 1e9 if avg else None,
+                       "frac": alg / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS if avg else None})
+    cells_per_step = float(npi) * npj * npk * npt
+    slow = max(blocks, key=lambda x: x["avg_launch_ms"] or 0.0)
+    desc = plan.describe()
+    tr, note = pmc_traffic(desc, npi, slow["rows"], npk, npt)
+    check = None
+    if not args.no_cpu_baseline:
+        _, rows, ref = cpu_baseline(e1v[:keep_rows], e3v_s, ib[:keep_rows], zv_s, npi, npk, npt, target_s=0.0)
+        got = result[:, :, :rows].cpu().numpy()
+        check = float(np.abs(got - ref).max() / (np.abs(ref).max() + 1e-300))
+        if not check < 1e-11:
+            raise SystemExit(f"bench: the sharded plan's result differs from the oracle on the sampled rows (rel {check:.3e})")
+    del plan, outs, result
+    torch.cuda.empty_cache()
+    try:
+        coll = collective_check(devices)
+    except Exception as exc:                                   # an extra: reported, never the failure of the measurement
+        coll = {"error": f"{type(exc).__name__}: {exc}"[:400]}
+    line = {"metric": "grid-cells/s for cdfmoc on eORCA12 75L 12t" if args.workload == "eorca12" else f"grid-cells/s for cdfmoc on {args.workload}",
+            "mode": "inprocess", "value": cells_per_step * args.steps / elapsed, "unit": "grid-cells/s", "n_gpus": n, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "timed_region_s": elapsed, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"cdfmoc {args.workload} {npi}x{npj}x{npk}, {npt} records, {nb} basins",
+                       "parallelism": f"one process, sharded plan over {n} row block(s) on devices {devices}",
+                       "stage_s": stage_s, "cells_per_step": cells_per_step},
+            "roofline": {"bound": "hbm", "kernel": desc, "achieved": slow["achieved"], "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": slow["frac"], "traffic": tr, "traffic_source": note, "avg_launch_ms": slow["avg_launch_ms"],
+                         "block": slow["block"], "note": "the slowest block; every block under per_block"},
+            "per_block": blocks, "oracle_check_rel_err": check, "collectives": coll}
+    if one_gpu:
+        line["test_hooks"] = {"one_gpu": True}
+    print(json.dumps(line), flush=True)
+
+
+def inprocess_leg(args):
+    """rank 0, after its own measurement: the in-process mode on the same devices, as a child process with a time limit (a
+    failure or a hang there must not cost the main line)."""
+    steps = max(10, min(100, args.steps // max(args.gpus, 1) // 2))
+    cmd = [sys.executable, os.path.abspath(__file__), "--mode", "inprocess", "--gpus", str(args.gpus), "--workload", args.workload,
+           "--steps", str(steps), "--warmup", "3"]
+    if args.no_cpu_baseline:
+        cmd.append("--no-cpu-baseline")
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE",
+              "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=args.inprocess_timeout, env=env)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or len(lines) != 1:
+            return {"error": f"rc {r.returncode}: " + (r.stderr or r.stdout)[-400:]}
+        return json.loads(lines[0])
+    except subprocess.TimeoutExpired:
+        return {"error": f"no result within {args.inprocess_timeout} s"}
+    except (OSError, ValueError) as exc:
+        return {"error": str(exc)[:400]}
+
+
 def self_launch(args):
     """`python bench.py --gpus N` with N > 1 and no launcher around it: this process -- which has not touched the GPU
     (no torch.cuda / HIP call so far) -- starts `python -m torch.distributed.run` with N ranks as a CHILD process,
@@ -214,10 +407,16 @@ def main():
     ap.add_argument("--workload", default="eorca12", choices=sorted(WORKLOADS))
     ap.add_argument("--tune", default="", help="waves,vectors,mode for the zonal kernel (0 = automatic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="ranks", choices=["ranks", "inprocess"],
+                    help="ranks: one process per GPU over RCCL (the contract); inprocess: one process, the sharded plan over N devices")
+    ap.add_argument("--no-inprocess", action="store_true", help="ranks mode: do not run the in-process leg afterwards")
+    ap.add_argument("--inprocess-timeout", type=int, default=240)
     args = ap.parse_args()
     if args.steps <= 0:
-        args.steps = 250 * max(args.gpus, 1)
+        args.steps = 250 * max(args.gpus, 1) if args.mode == "ranks" else 50
 
+    if args.mode == "inprocess":
+        return main_inprocess(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args))
     global hip, shard
@@ -284,10 +483,25 @@ def main():
     each = plan.profile_read_each()
     launches = int(each.size)
     zonal_ms = float(each.sum())
+    comm = None
+    per_rank = None
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        # what the collective library saw: a sum of ones over the ranks, and every rank's device and launch times
+        cdev = device if backend == "nccl" else torch.device("cpu")     # (gloo gathers host tensors only)
+        ones = torch.ones(1, dtype=torch.float64, device=cdev)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        mine = torch.tensor([rank, dev_index, nloc, zonal_ms / max(launches, 1), float(each.min()) if launches else 0.0,
+                             float(each.max()) if launches else 0.0], dtype=torch.float64, device=cdev)
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [{"rank": int(x[0]), "device": int(x[1]), "rows": int(x[2]), "avg_launch_ms": float(x[3]), "min_launch_ms": float(x[4]),
+                     "max_launch_ms": float(x[5])} for x in (y.cpu().tolist() for y in allr)]
+        comm = {"backend": dist.get_backend(), "library": "RCCL" if dist.get_backend() == "nccl" else dist.get_backend(),
+                "ranks_seen_by_allreduce": int(round(float(ones.item()))), "world_size": world,
+                "distinct_devices": len({(r["device"]) for r in per_rank})}
 
     cells_per_step = float(npi) * npj * npk * npt
     value = cells_per_step * args.steps / elapsed
@@ -297,19 +511,21 @@ def main():
     alg_bytes = 4.0 * (1.0 + 1.0 / npt) * touched                    # 4*(1+1/npt) B per cell-record
     avg_ms = zonal_ms / max(launches, 1)
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "moc_zonal_traffic.json")
-    if os.path.exists(tpath):
-        tj = json.load(open(tpath))
-        if tj.get("workload") == args.workload and tj.get("n_gpus") == world:
-            traffic = tj.get("hbm_bytes_per_launch")
+    traffic, traffic_note = pmc_traffic(plan.describe(), npi, nloc, npk, npt)
     roofline = {"bound": "hbm", "kernel": plan.describe(), "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms, "launches": launches,
                 "min_launch_ms": float(each.min()) if launches else None,
                 "median_launch_ms": float(np.median(each)) if launches else None,
                 "max_launch_ms": float(each.max()) if launches else None,
                 "rank": rank, "rows": nloc}
+    if per_rank:
+        for r in per_rank:                                          # every rank's own roofline fraction (its rows, its launches)
+            alg_r = 4.0 * (1.0 + 1.0 / npt) * float(npi) * r["rows"] * (npk - 1) * npt
+            r["frac"] = alg_r / (r["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS if r["avg_launch_ms"] > 0 else None
+        roofline["avg_launch_ms_min_over_ranks"] = min(r["avg_launch_ms"] for r in per_rank)
+        roofline["avg_launch_ms_max_over_ranks"] = max(r["avg_launch_ms"] for r in per_rank)
+        roofline["frac_min_over_ranks"] = min(r["frac"] for r in per_rank if r["frac"] is not None)
 
     cpu = None
     cpu_ref = None
@@ -333,6 +549,17 @@ def main():
             if cpu_ref is not None and "error" not in cpu_ref and not cpu_ref["hip_vs_reference_rel_err"] < 1e-11:
                 raise SystemExit(f"bench: HIP result differs from the reference's statements (rel {cpu_ref['hip_vs_reference_rel_err']:.3e})")
 
+    inproc = None
+    gathers = pipe.gathers
+    if not args.no_inprocess:
+        # the in-process leg: every rank lets go of its memory, rank 0's child uses the N devices, the others wait
+        del pipe, plan, zv, e1v, ib, result
+        torch.cuda.empty_cache()
+        if world > 1:
+            dist.barrier()
+        if rank == 0:
+            inproc = inprocess_leg(args)
+
     if rank == 0:
         line = {
             "metric": "grid-cells/s for cdfmoc on eORCA12 75L 12t" if args.workload == "eorca12"
@@ -344,8 +571,9 @@ def main():
                        "arithmetic": "r4 products widened to r8, r8 sums (src/cdfmoc.f90:373-374)",
                        "parallelism": f"row-block x{world}", "rows_per_rank": nloc,
                        "cells_per_step": cells_per_step,
-                       "result_gathers": pipe.gathers if world > 1 else 0},
+                       "result_gathers": gathers if world > 1 else 0},
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_reference": cpu_ref, "oracle_check_rel_err": check,
+            "comm": comm, "per_rank": per_rank, "inprocess": inproc,
         }
         if one_gpu or backend != "nccl":
             line["test_hooks"] = {"one_gpu": one_gpu, "backend": backend}

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("CDFT_LIB") or os.path.join(HERE, "lib", "libcdftools_
 
 CDFT_OK = 0
 CDFT_ERR_ARG, CDFT_ERR_HIP, CDFT_ERR_ALLOC, CDFT_ERR_STATE, CDFT_ERR_NODEVICE = 1, 2, 3, 4, 5
-MEM_HOST, MEM_DEVICE = 0, 1
+MEM_HOST, MEM_DEVICE, MEM_PINNED = 0, 1, 2
 
 
 class CdftError(RuntimeError):
@@ -47,6 +47,10 @@ SIGNATURES = {
     "cdft_timer_destroy": (_i, [_vp]),
     "cdft_moc_create": (_i, [_pvp, _i, _i, _i, _i]),
     "cdft_shard_from_env": (_i, [C.POINTER(_i), C.POINTER(_i), _i]),
+    "cdft_shard_set_collective": (_i, [_i]),
+    "cdft_shard_get_collective": (_i, [C.POINTER(_i)]),
+    "cdft_host_alloc": (_i, [_pvp, _sz]),
+    "cdft_host_free": (_i, [_vp]),
     "cdft_moc_create_sharded": (_i, [_pvp, _i, _i, _i, _i, _i, C.POINTER(_i)]),
     "cdft_moc_set_mesh": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
     "cdft_moc_set_mesh_vmask": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),
@@ -58,6 +62,10 @@ SIGNATURES = {
     "cdft_moc_profile_enable": (_i, [_vp, _i]),
     "cdft_moc_profile_read": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(_i)]),
     "cdft_moc_profile_read_each": (_i, [_vp, C.POINTER(C.c_float), _i, C.POINTER(_i)]),
+    "cdft_moc_profile_read_block": (_i, [_vp, _i, C.POINTER(C.c_float), _i, C.POINTER(_i)]),
+    "cdft_moc_block_info": (_i, [_vp, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "cdft_moc_stage": (_i, [_vp, _vp, _i64, _i, _i, _vp]),
+    "cdft_moc_compute_staged": (_i, [_vp, _vp, _i, _vp]),
     "cdft_moc_destroy": (_i, [_vp]),
     "cdft_eos_sigmai": (_i, [_vp, _vp, _i64, C.c_float, _i, _i, _vp, _i, _i, _vp]),
     "cdft_eos_sigmai2d": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _i, _i, _vp]),

@@ -875,7 +875,7 @@ int cdft_heatc_create_sharded(cdft_heatc_plan **plan, int npiglo, int npjglo, in
         return fail(CDFT_ERR_ARG, "cdft_heatc_create_sharded: bad sizes %d x %d x %d", npiglo, npjglo, npk);
     cdft_heatc_plan *p = new cdft_heatc_plan;
     p->npi = npiglo; p->npj = npjglo; p->npk = npk;
-    int rc = shard::make(&p->sh, npiglo, npjglo, npk, 0, ndev, devices, 0, 7);
+    int rc = shard::make(&p->sh, npiglo, npjglo, npk, 0, ndev, devices, 0, 9);
     if (rc == CDFT_OK) rc = shard::heatc_parts(*p->sh);
     if (rc != CDFT_OK) { cdft_heatc_destroy(p); return rc; }
     *plan = p;

@@ -13,6 +13,8 @@ namespace cdft { namespace shard {
 int moc_parts(ShardSet &sh);
 int moc_set_mesh(ShardSet &sh, const float *e1v, const float *e3v, const int8_t *vmask, const int16_t *ibmask);
 int moc_compute(ShardSet &sh, const float *zv, int64_t rec_stride, int npt, double *dmoc);
+int moc_stage(ShardSet &sh, const float *zv, int64_t rec_stride, int npt);
+int moc_run(ShardSet &sh, int npt, double *dmoc);
 } }
 
 struct cdft_moc_plan {
@@ -38,7 +40,14 @@ struct cdft_moc_plan {
     bool profiling = false;
     std::vector<hipEvent_t> ev;                      // (start, stop) pairs, one per profiled launch
     size_t ev_used = 0;
+    // records handed over once by cdft_moc_stage (in HBM: the caller's own array, or st_zv for a host array)
+    const float *staged = nullptr;
+    int64_t staged_stride = 0;
+    int staged_npt = 0;
 };
+
+static int moc_compute_on(cdft_moc_plan *p, const float *d_zv, int64_t rec_stride, int npt, double *dmoc, int dmoc_space,
+                          hipStream_t st);
 
 namespace {
 
@@ -506,34 +515,74 @@ int cdft_moc_compute(cdft_moc_plan *p, const float *zv, int64_t rec_stride, int 
                     npt, (long long)rec_stride, (long long)n3);
     if (p->sh) {                                                                 // any memory spaces; returns when done
         if (zv_space == CDFT_MEM_DEVICE) CDFT_HIP(hipStreamSynchronize(as_stream(stream)));
+        p->staged_npt = 0;
         return shard::moc_compute(*p->sh, zv, rec_stride, npt, dmoc);
     }
     hipStream_t st = as_stream(stream);
     const void *d_zv;
     CDFT_TRY(to_device(zv, ((size_t)(npt - 1) * rec_stride + n3) * sizeof(float), zv_space, p->st_zv,
                        st, &d_zv));
+    p->staged = nullptr; p->staged_npt = 0;            // (st_zv may just have been overwritten)
+    return moc_compute_on(p, (const float *)d_zv, rec_stride, npt, dmoc, dmoc_space, st);
+}
+
+// zonal sums + cumulated sums of npt records that are in HBM, result to host or HBM
+static int moc_compute_on(cdft_moc_plan *p, const float *d_zv, int64_t rec_stride, int npt, double *dmoc, int dmoc_space,
+                          hipStream_t st) {
     const size_t out_bytes = (size_t)p->nbasins * p->npj * p->npk * npt * sizeof(double);
     double *d_out = dmoc;
-    if (dmoc_space == CDFT_MEM_HOST) {
+    if (dmoc_space == CDFT_MEM_HOST || dmoc_space == CDFT_MEM_PINNED) {
         CDFT_TRY(p->st_out.reserve(out_bytes));
         d_out = (double *)p->st_out.ptr;
     } else if (dmoc_space != CDFT_MEM_DEVICE) {
         return fail(CDFT_ERR_ARG, "cdft_moc_compute: bad memory-space tag %d", dmoc_space);
     }
 
-    CDFT_TRY(zonal_launch(p, (const float *)d_zv, rec_stride, npt, d_out, st, true));
+    CDFT_TRY(zonal_launch(p, d_zv, rec_stride, npt, d_out, st, true));
 
     const int nbj = p->nbasins * p->npj;
     const int64_t nthr = (int64_t)nbj * npt;
     hipLaunchKernelGGL(moc_cumsum_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, d_out,
                        nbj, p->npk, npt);
     CDFT_LAUNCH_CHECK();
-    if (dmoc_space == CDFT_MEM_HOST) {
+    if (dmoc_space != CDFT_MEM_DEVICE) {
         CDFT_HIP(hipMemcpyAsync(dmoc, d_out, out_bytes, hipMemcpyDeviceToHost, st));
-        CDFT_HIP(hipStreamSynchronize(st));
+        if (dmoc_space == CDFT_MEM_HOST) CDFT_HIP(hipStreamSynchronize(st));     // (pinned: the caller synchronises)
     }
     return CDFT_OK;
 }
+
+extern "C" {
+
+int cdft_moc_stage(cdft_moc_plan *p, const float *zv, int64_t rec_stride, int npt, int zv_space, void *stream) {
+    TraceRange trace_("cdft_moc_stage");
+    if (!p || !zv) return fail(CDFT_ERR_ARG, "cdft_moc_stage: NULL argument");
+    const int64_t n3 = (int64_t)p->npi * p->npj * p->npk;
+    if (npt < 1 || rec_stride < n3)
+        return fail(CDFT_ERR_ARG, "cdft_moc_stage: npt=%d rec_stride=%lld (need npt>=1, stride>=%lld)", npt, (long long)rec_stride, (long long)n3);
+    if (p->sh) {
+        if (zv_space == CDFT_MEM_DEVICE) CDFT_HIP(hipStreamSynchronize(as_stream(stream)));
+        CDFT_TRY(shard::moc_stage(*p->sh, zv, rec_stride, npt));
+        p->staged_npt = npt;
+        return CDFT_OK;
+    }
+    hipStream_t st = as_stream(stream);
+    const void *d_zv;
+    CDFT_TRY(to_device(zv, ((size_t)(npt - 1) * rec_stride + n3) * sizeof(float), zv_space, p->st_zv, st, &d_zv));
+    p->staged = (const float *)d_zv; p->staged_stride = rec_stride; p->staged_npt = npt;
+    return CDFT_OK;
+}
+
+int cdft_moc_compute_staged(cdft_moc_plan *p, double *dmoc, int dmoc_space, void *stream) {
+    TraceRange trace_("cdft_moc_compute_staged");
+    if (!p || !dmoc) return fail(CDFT_ERR_ARG, "cdft_moc_compute_staged: NULL argument");
+    if (!p->mesh_set) return fail(CDFT_ERR_STATE, "cdft_moc_compute_staged: cdft_moc_set_mesh has not succeeded");
+    if (p->staged_npt < 1) return fail(CDFT_ERR_STATE, "cdft_moc_compute_staged: cdft_moc_stage has not run (or a cdft_moc_compute since)");
+    if (p->sh) return shard::moc_run(*p->sh, p->staged_npt, dmoc);
+    return moc_compute_on(p, p->staged, p->staged_stride, p->staged_npt, dmoc, dmoc_space, as_stream(stream));
+}
+
+}  // extern "C"
 
 int cdft_moc_decomp_set_mesh(cdft_moc_plan *p, const float *e3v, const float *e1u, const float *zcoef,
                              const float *gdept, const uint8_t *tmask, const uint8_t *umask, int memspace,
@@ -657,7 +706,16 @@ int cdft_moc_profile_enable(cdft_moc_plan *p, int on) {
 
 int cdft_moc_profile_read(cdft_moc_plan *p, double *zonal_ms_total, int *launches) {
     if (!p || !zonal_ms_total || !launches) return fail(CDFT_ERR_ARG, "cdft_moc_profile_read: NULL argument");
-    if (p->sh) return cdft_moc_profile_read((cdft_moc_plan *)p->sh->part[0], zonal_ms_total, launches);   // block 0 speaks for all
+    if (p->sh) {                                         // per launch the slowest block: that is what the call waited for
+        std::vector<float> each(65536);
+        int n = 0;
+        CDFT_TRY(cdft_moc_profile_read_each(p, each.data(), (int)each.size(), &n));
+        double tot = 0.0;
+        for (int i = 0; i < n && i < (int)each.size(); ++i) tot += each[i];
+        *zonal_ms_total = tot;
+        *launches = n;
+        return CDFT_OK;
+    }
     double tot = 0.0;
     for (size_t i = 0; i + 1 < p->ev_used; i += 2) {
         float ms = 0.f;
@@ -674,7 +732,24 @@ int cdft_moc_profile_read(cdft_moc_plan *p, double *zonal_ms_total, int *launche
 int cdft_moc_profile_read_each(cdft_moc_plan *p, float *ms_each, int capacity, int *launches) {
     if (!p || !ms_each || !launches || capacity < 0)
         return fail(CDFT_ERR_ARG, "cdft_moc_profile_read_each: bad argument");
-    if (p->sh) return cdft_moc_profile_read_each((cdft_moc_plan *)p->sh->part[0], ms_each, capacity, launches);
+    if (p->sh) {                                         // per launch the slowest block (cdft_moc_profile_read_block: one block)
+        const int nblk = p->sh->nblk();
+        std::vector<float> one((size_t)(capacity > 0 ? capacity : 1));
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        int rc = CDFT_OK, nmin = -1;
+        for (int b = 0; b < nblk && rc == CDFT_OK; ++b) {
+            int n = 0;
+            if (hipSetDevice(p->sh->dev[b]) != hipSuccess) { rc = fail(CDFT_ERR_HIP, "cdft_moc_profile_read_each: hipSetDevice(%d) failed", p->sh->dev[b]); break; }
+            rc = cdft_moc_profile_read_each((cdft_moc_plan *)p->sh->part[b], one.data(), capacity, &n);
+            for (int i = 0; rc == CDFT_OK && i < n && i < capacity; ++i) ms_each[i] = (b == 0 || one[i] > ms_each[i]) ? one[i] : ms_each[i];
+            if (nmin < 0 || n < nmin) nmin = n;
+        }
+        (void)hipSetDevice(cur);
+        CDFT_TRY(rc);
+        *launches = nmin < 0 ? 0 : nmin;
+        return CDFT_OK;
+    }
     const int n = (int)(p->ev_used / 2);
     for (int i = 0; i < n; ++i) {
         float ms = 0.f;
@@ -684,6 +759,34 @@ int cdft_moc_profile_read_each(cdft_moc_plan *p, float *ms_each, int capacity, i
     }
     *launches = n;
     p->ev_used = 0;
+    return CDFT_OK;
+}
+
+int cdft_moc_profile_read_block(cdft_moc_plan *p, int block, float *ms_each, int capacity, int *launches) {
+    if (!p || !ms_each || !launches || capacity < 0) return fail(CDFT_ERR_ARG, "cdft_moc_profile_read_block: bad argument");
+    if (!p->sh) {
+        if (block != 0) return fail(CDFT_ERR_ARG, "cdft_moc_profile_read_block: block %d of a plan with one block", block);
+        return cdft_moc_profile_read_each(p, ms_each, capacity, launches);
+    }
+    if (block < 0 || block >= p->sh->nblk()) return fail(CDFT_ERR_ARG, "cdft_moc_profile_read_block: block %d of %d", block, p->sh->nblk());
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    CDFT_HIP(hipSetDevice(p->sh->dev[block]));
+    int rc = cdft_moc_profile_read_each((cdft_moc_plan *)p->sh->part[block], ms_each, capacity, launches);
+    (void)hipSetDevice(cur);
+    return rc;
+}
+
+int cdft_moc_block_info(cdft_moc_plan *p, int block, int *device, int *j0, int *j1) {
+    if (!p || !device || !j0 || !j1) return fail(CDFT_ERR_ARG, "cdft_moc_block_info: NULL argument");
+    if (!p->sh) {
+        if (block != 0) return fail(CDFT_ERR_ARG, "cdft_moc_block_info: block %d of a plan with one block", block);
+        *device = -1; *j0 = 0; *j1 = p->npj;
+        (void)hipGetDevice(device);
+        return CDFT_OK;
+    }
+    if (block < 0 || block >= p->sh->nblk()) return fail(CDFT_ERR_ARG, "cdft_moc_block_info: block %d of %d", block, p->sh->nblk());
+    *device = p->sh->dev[block]; *j0 = p->sh->j0[block]; *j1 = p->sh->j1[block];
     return CDFT_OK;
 }
 

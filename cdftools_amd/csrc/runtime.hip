@@ -61,7 +61,7 @@ int to_device(const void *src, size_t n, int memspace, DevBuf &stage, hipStream_
         *dev = src;
         return CDFT_OK;
     }
-    if (memspace != CDFT_MEM_HOST) return fail(CDFT_ERR_ARG, "bad memory-space tag %d", memspace);
+    if (memspace != CDFT_MEM_HOST && memspace != CDFT_MEM_PINNED) return fail(CDFT_ERR_ARG, "bad memory-space tag %d", memspace);
     CDFT_TRY(stage.reserve(n));
     CDFT_HIP(hipMemcpyAsync(stage.ptr, src, n, hipMemcpyHostToDevice, st));
     *dev = stage.ptr;
@@ -171,6 +171,22 @@ int cdft_malloc(void **ptr, size_t bytes) {
 
 int cdft_free(void *ptr) {
     if (ptr) CDFT_HIP(hipFree(ptr));
+    return CDFT_OK;
+}
+
+int cdft_host_alloc(void **ptr, size_t bytes) {
+    if (!ptr) return fail(CDFT_ERR_ARG, "cdft_host_alloc: NULL argument");
+    CDFT_TRY(require_device());
+    if (hipHostMalloc(ptr, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        *ptr = nullptr;
+        return fail(CDFT_ERR_ALLOC, "hipHostMalloc of %zu bytes failed", bytes);
+    }
+    return CDFT_OK;
+}
+
+int cdft_host_free(void *ptr) {
+    if (ptr) CDFT_HIP(hipHostFree(ptr));
     return CDFT_OK;
 }
 

@@ -1,10 +1,77 @@
 // shard.hip -- row-block sharded plans over several GPUs of one node, driven by one process (see shard.hpp).
 // Host code only: every kernel launch goes through the ordinary single-device entry points of the C ABI.
 #include "shard.hpp"
+#include "rccl_dl.hpp"
+#include <dlfcn.h>
+#include <atomic>
 #include <cstdlib>
+#include <mutex>
 #include <thread>
 
 using namespace cdft;
+
+// ------------------------------------------------------------------------------------------ RCCL, looked up at run time
+namespace cdft {
+namespace rccl {
+
+const Api *api() {
+    static Api a;
+    static int state = 0;                                // 0 not tried, 1 ready, -1 failed
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    if (state == 1) return &a;
+    if (state == -1) { set_error("RCCL is not available on this machine (librccl.so.1 or one of its entry points was not found)"); return nullptr; }
+    void *h = nullptr;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *n : names) {
+        h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+    }
+    bool ok = h != nullptr;
+    auto take = [&](const char *name) -> void * {
+        void *f = ok ? dlsym(h, name) : nullptr;
+        if (!f) ok = false;
+        return f;
+    };
+    a.CommInitAll = (int (*)(comm_t *, int, const int *))take("ncclCommInitAll");
+    a.CommDestroy = (int (*)(comm_t))take("ncclCommDestroy");
+    a.AllGather = (int (*)(const void *, void *, size_t, int, comm_t, hipStream_t))take("ncclAllGather");
+    a.Broadcast = (int (*)(const void *, void *, size_t, int, int, comm_t, hipStream_t))take("ncclBroadcast");
+    a.Send = (int (*)(const void *, size_t, int, int, comm_t, hipStream_t))take("ncclSend");
+    a.Recv = (int (*)(void *, size_t, int, int, comm_t, hipStream_t))take("ncclRecv");
+    a.GroupStart = (int (*)())take("ncclGroupStart");
+    a.GroupEnd = (int (*)())take("ncclGroupEnd");
+    a.GetErrorString = (const char *(*)(int))take("ncclGetErrorString");
+    state = ok ? 1 : -1;
+    if (!ok) { set_error("RCCL is not available on this machine (%s)", h ? "an entry point is missing" : dlerror()); return nullptr; }
+    return &a;
+}
+
+}  // namespace rccl
+}  // namespace cdft
+
+namespace {
+std::atomic<int> g_collective{-1};                       // -1: not asked yet (CDFT_SHARD_COLLECTIVE decides)
+int collective_mode() {
+    int m = g_collective.load();
+    if (m >= 0) return m;
+    const char *e = getenv("CDFT_SHARD_COLLECTIVE");
+    m = (e && (!strcmp(e, "rccl") || !strcmp(e, "RCCL") || !strcmp(e, "nccl"))) ? CDFT_COLLECTIVE_RCCL : CDFT_COLLECTIVE_PEER;
+    g_collective.store(m);
+    return m;
+}
+}  // namespace
+
+extern "C" int cdft_shard_set_collective(int mode) {
+    if (mode != CDFT_COLLECTIVE_PEER && mode != CDFT_COLLECTIVE_RCCL) return fail(CDFT_ERR_ARG, "cdft_shard_set_collective: mode %d", mode);
+    g_collective.store(mode);
+    return CDFT_OK;
+}
+extern "C" int cdft_shard_get_collective(int *mode) {
+    if (!mode) return fail(CDFT_ERR_ARG, "cdft_shard_get_collective: NULL argument");
+    *mode = collective_mode();
+    return CDFT_OK;
+}
 
 namespace cdft {
 namespace shard {
@@ -98,6 +165,22 @@ int make(ShardSet **out, int npi, int npj, int npk, int nb, int ndev, const int 
             }
     }
     (void)hipSetDevice(cur);
+    if (collective_mode() == CDFT_COLLECTIVE_RCCL) {
+        for (int a = 0; a < ndev; ++a)
+            for (int b = a + 1; b < ndev; ++b)
+                if (sh->dev[a] == sh->dev[b]) {
+                    destroy(sh);
+                    return fail(CDFT_ERR_ARG, "sharded plan: blocks %d and %d are both on device %d -- RCCL takes one rank per device "
+                                "(CDFT_SHARD_COLLECTIVE=peer, the default, does not mind)", a, b, devices[a]);
+                }
+        const rccl::Api *api = rccl::api();
+        if (!api) { destroy(sh); return CDFT_ERR_HIP; }
+        std::vector<rccl::comm_t> comms((size_t)ndev, nullptr);
+        int r = api->CommInitAll(comms.data(), ndev, sh->dev.data());
+        (void)hipSetDevice(cur);
+        if (r != 0) { destroy(sh); return fail(CDFT_ERR_HIP, "sharded plan: ncclCommInitAll over %d devices -> %s", ndev, api->GetErrorString(r)); }
+        sh->comm.assign(comms.begin(), comms.end());
+    }
     *out = sh;
     return CDFT_OK;
 }
@@ -106,6 +189,9 @@ void destroy(ShardSet *sh) {
     if (!sh) return;
     int cur = 0;
     (void)hipGetDevice(&cur);
+    if (sh->rccl() && rccl::api())
+        for (void *c : sh->comm) if (c) (void)rccl::api()->CommDestroy(c);
+    sh->comm.clear();
     for (int b = 0; b < sh->nblk(); ++b) {
         (void)hipSetDevice(sh->dev[b]);
         for (DevBuf &d : sh->buf[b]) d.release();
@@ -211,24 +297,49 @@ int moc_set_mesh(ShardSet &sh, const float *e1v, const float *e3v, const int8_t 
     });
 }
 
+// the records of a call, or of cdft_moc_stage, in each block's HBM (B[4], kept until the next one)
+static int moc_rows_to_block(ShardSet &sh, int b, const float *zv, int64_t rec_stride, int npt) {
+    const int j0 = sh.j0[b], j1 = sh.j1[b], nloc = j1 - j0;
+    const size_t n3 = (size_t)sh.npi * nloc * sh.npk;
+    DevBuf *B = sh.buf[b].data();
+    CDFT_TRY(B[4].reserve(n3 * npt * 4));
+    for (int t = 0; t < npt; ++t)
+        CDFT_TRY(rows_in((float *)B[4].ptr + (size_t)t * n3, zv + (size_t)t * rec_stride, (size_t)sh.npi * 4, sh.npj, j0, j1,
+                         sh.npk, 0, sh.st[b]));
+    return CDFT_OK;
+}
+
+static int moc_block_run(ShardSet &sh, int b, int npt, double *dmoc) {
+    const int j0 = sh.j0[b], j1 = sh.j1[b], nloc = j1 - j0;
+    const size_t n3 = (size_t)sh.npi * nloc * sh.npk;
+    hipStream_t st = sh.st[b];
+    DevBuf *B = sh.buf[b].data();
+    CDFT_TRY(B[5].reserve((size_t)sh.nb * nloc * sh.npk * npt * 8));
+    CDFT_TRY(cdft_moc_compute((cdft_moc_plan *)sh.part[b], (const float *)B[4].ptr, (int64_t)n3, npt, CDFT_MEM_DEVICE,
+                              (double *)B[5].ptr, CDFT_MEM_DEVICE, st));
+    // dmoc(nbasins,npjglo,npk,npt): the rows of this block, every level and record, in place
+    CDFT_TRY(rows_out(dmoc, B[5].ptr, (size_t)sh.nb * 8, sh.npj, j0, j1, (size_t)sh.npk * npt, 0, st));
+    CDFT_HIP(hipStreamSynchronize(st));
+    return CDFT_OK;
+}
+
 int moc_compute(ShardSet &sh, const float *zv, int64_t rec_stride, int npt, double *dmoc) {
     return for_blocks(sh, [&](int b) {
-        const int j0 = sh.j0[b], j1 = sh.j1[b], nloc = j1 - j0;
-        const size_t n3 = (size_t)sh.npi * nloc * sh.npk;
-        hipStream_t st = sh.st[b];
-        DevBuf *B = sh.buf[b].data();
-        CDFT_TRY(B[4].reserve(n3 * npt * 4));
-        CDFT_TRY(B[5].reserve((size_t)sh.nb * nloc * sh.npk * npt * 8));
-        for (int t = 0; t < npt; ++t)
-            CDFT_TRY(rows_in((float *)B[4].ptr + (size_t)t * n3, zv + (size_t)t * rec_stride, (size_t)sh.npi * 4, sh.npj, j0, j1,
-                             sh.npk, 0, st));
-        CDFT_TRY(cdft_moc_compute((cdft_moc_plan *)sh.part[b], (const float *)B[4].ptr, (int64_t)n3, npt, CDFT_MEM_DEVICE,
-                                  (double *)B[5].ptr, CDFT_MEM_DEVICE, st));
-        // dmoc(nbasins,npjglo,npk,npt): the rows of this block, every level and record, in place
-        CDFT_TRY(rows_out(dmoc, B[5].ptr, (size_t)sh.nb * 8, sh.npj, j0, j1, (size_t)sh.npk * npt, 0, st));
-        CDFT_HIP(hipStreamSynchronize(st));
+        CDFT_TRY(moc_rows_to_block(sh, b, zv, rec_stride, npt));
+        return moc_block_run(sh, b, npt, dmoc);
+    });
+}
+
+int moc_stage(ShardSet &sh, const float *zv, int64_t rec_stride, int npt) {
+    return for_blocks(sh, [&](int b) {
+        CDFT_TRY(moc_rows_to_block(sh, b, zv, rec_stride, npt));
+        CDFT_HIP(hipStreamSynchronize(sh.st[b]));
         return CDFT_OK;
     });
+}
+
+int moc_run(ShardSet &sh, int npt, double *dmoc) {
+    return for_blocks(sh, [&](int b) { return moc_block_run(sh, b, npt, dmoc); });
 }
 
 // =================================================================================================== cdfheatc
@@ -315,6 +426,8 @@ int heatc_compute(ShardSet &sh, const float *temp, const float *rmxldep, const f
         }
         return CDFT_OK;
     }
+    const size_t nsum = (size_t)3 * sh.npk;
+    std::vector<double> gathered(sh.rccl() ? nsum * n : 0);
     CDFT_TRY(for_blocks(sh, [&](int b) {
         const int j0 = sh.j0[b], j1 = sh.j1[b], nloc = j1 - j0;
         const size_t nij = (size_t)sh.npi * nloc;
@@ -326,9 +439,22 @@ int heatc_compute(ShardSet &sh, const float *temp, const float *rmxldep, const f
             CDFT_TRY(B[6].reserve(nij * 4));
             CDFT_TRY(rows_in(B[6].ptr, rmxldep, (size_t)sh.npi * 4, sh.npj, j0, j1, 1, 0, st));
         }
-        return cdft_heatc_compute((cdft_heatc_plan *)sh.part[b], (const float *)B[5].ptr, CDFT_MEM_DEVICE,
-                                  mxloption ? (const float *)B[6].ptr : nullptr, gdepw, mxloption, part[b].data(), CDFT_MEM_HOST, st);
+        if (!sh.rccl())
+            return cdft_heatc_compute((cdft_heatc_plan *)sh.part[b], (const float *)B[5].ptr, CDFT_MEM_DEVICE,
+                                      mxloption ? (const float *)B[6].ptr : nullptr, gdepw, mxloption, part[b].data(), CDFT_MEM_HOST, st);
+        // RCCL: the block's sums stay in its HBM, ONE all-gather hands every block the (npk,3) sums of all of them in block
+        // order (1.8 KB per block at 75 levels); block 0's copy comes to the host, where they are added as below
+        CDFT_TRY(B[7].reserve(nsum * 8));
+        CDFT_TRY(B[8].reserve(nsum * 8 * n));
+        CDFT_TRY(cdft_heatc_compute((cdft_heatc_plan *)sh.part[b], (const float *)B[5].ptr, CDFT_MEM_DEVICE,
+                                    mxloption ? (const float *)B[6].ptr : nullptr, gdepw, mxloption, (double *)B[7].ptr, CDFT_MEM_DEVICE, st));
+        CDFT_RCCL(rccl::api()->AllGather(B[7].ptr, B[8].ptr, nsum, rccl::kDouble, sh.comm[b], st));
+        if (b == 0) CDFT_HIP(hipMemcpyAsync(gathered.data(), B[8].ptr, nsum * 8 * n, hipMemcpyDeviceToHost, st));
+        CDFT_HIP(hipStreamSynchronize(st));
+        return CDFT_OK;
     }));
+    if (sh.rccl())
+        for (int b = 0; b < n; ++b) memcpy(part[b].data(), gathered.data() + (size_t)b * nsum, nsum * 8);
     // src/cdfheatc.f90:225-229 sums the whole level; here the blocks' r8 sums are added in block order
     std::vector<double> tot(part[0]);
     for (int b = 1; b < n; ++b)
@@ -455,52 +581,82 @@ int psi_integrate(ShardSet &sh, const float *zu, const float *e2u, const float *
     });
 }
 
+namespace {
+// the caller's current device, put back however the function is left (the loops below switch devices and may return early)
+struct DeviceGuard {
+    int cur = 0;
+    DeviceGuard() { (void)hipGetDevice(&cur); }
+    ~DeviceGuard() { (void)hipSetDevice(cur); }
+};
+}  // namespace
+
 int psi_scan_u(ShardSet &sh) {
     // the running difference along j crosses the blocks (src/cdfpsi.f90:395-398): visit them south to north, the
-    // last row of one is the carry of the next -- 8*npiglo bytes from HBM to HBM
+    // last row of one is the carry of the next -- 8*npiglo bytes from HBM to HBM, by a peer copy or, in RCCL mode, by an
+    // ncclSend / ncclRecv pair (one host thread, two devices: inside a group)
     const int n = sh.nblk();
-    int cur = 0;
-    (void)hipGetDevice(&cur);
+    DeviceGuard guard;
     for (int b = 0; b < n; ++b) {
         CDFT_HIP(hipSetDevice(sh.dev[b]));
         DevBuf *B = sh.buf[b].data();
-        if (!B[8].ptr || !B[9].ptr) { (void)hipSetDevice(cur); return fail(CDFT_ERR_STATE, "cdft_psi_scan_u: cdft_psi_integrate has not run"); }
-        if (b > 0) {
+        if (!B[8].ptr || !B[9].ptr) return fail(CDFT_ERR_STATE, "cdft_psi_scan_u: cdft_psi_integrate has not run");
+        if (b > 0 && sh.rccl()) {
+            const rccl::Api *api = rccl::api();
+            CDFT_RCCL(api->GroupStart());
+            CDFT_RCCL(api->Send(sh.buf[b - 1][9].ptr, (size_t)sh.npi, rccl::kDouble, b, sh.comm[b - 1], sh.st[b - 1]));
+            CDFT_RCCL(api->Recv(B[8].ptr, (size_t)sh.npi, rccl::kDouble, b - 1, sh.comm[b], sh.st[b]));
+            CDFT_RCCL(api->GroupEnd());
+        } else if (b > 0) {
             CDFT_HIP(hipMemcpyPeerAsync(B[8].ptr, sh.dev[b], sh.buf[b - 1][9].ptr, sh.dev[b - 1], (size_t)sh.npi * 8, sh.st[b]));
         }
-        int rc = cdft_psi_scan_u((cdft_psi_plan *)sh.part[b], b > 0 ? (const double *)B[8].ptr : nullptr, CDFT_MEM_DEVICE, b == 0 ? 1 : 0,
-                                 (double *)B[9].ptr, CDFT_MEM_DEVICE, sh.st[b]);
-        if (rc == CDFT_OK && hipStreamSynchronize(sh.st[b]) != hipSuccess) rc = fail(CDFT_ERR_HIP, "cdft_psi_scan_u: scan of block %d failed", b);
-        if (rc != CDFT_OK) { (void)hipSetDevice(cur); return rc; }
+        CDFT_TRY(cdft_psi_scan_u((cdft_psi_plan *)sh.part[b], b > 0 ? (const double *)B[8].ptr : nullptr, CDFT_MEM_DEVICE, b == 0 ? 1 : 0,
+                                 (double *)B[9].ptr, CDFT_MEM_DEVICE, sh.st[b]));
+        if (hipStreamSynchronize(sh.st[b]) != hipSuccess) return fail(CDFT_ERR_HIP, "cdft_psi_scan_u: scan of block %d failed", b);
     }
-    (void)hipSetDevice(cur);
     return CDFT_OK;
+}
+
+static int owner_of_row(const ShardSet &sh, int ij) {
+    for (int b = 0; b < sh.nblk(); ++b)
+        if (ij > sh.j0[b] && ij <= sh.j1[b]) return b;
+    return -1;
 }
 
 int psi_value(ShardSet &sh, int ii, int ij, double *value) {
     if (ii < 1 || ii > sh.npi || ij < 1 || ij > sh.npj)
         return fail(CDFT_ERR_ARG, "cdft_psi_value: point (%d,%d) outside the domain", ii, ij);
-    int cur = 0;
-    (void)hipGetDevice(&cur);
-    int rc = CDFT_OK;
-    for (int b = 0; b < sh.nblk(); ++b)
-        if (ij > sh.j0[b] && ij <= sh.j1[b]) {                  // the block that owns the row
-            CDFT_HIP(hipSetDevice(sh.dev[b]));
-            rc = cdft_psi_value((cdft_psi_plan *)sh.part[b], ii, ij - sh.j0[b], value, sh.st[b]);
-        }
-    (void)hipSetDevice(cur);
-    return rc;
+    DeviceGuard guard;
+    const int b = owner_of_row(sh, ij);                     // the block that owns the row
+    CDFT_HIP(hipSetDevice(sh.dev[b]));
+    return cdft_psi_value((cdft_psi_plan *)sh.part[b], ii, ij - sh.j0[b], value, sh.st[b]);
 }
 
 int psi_finish(ShardSet &sh, int use_ref, double ref_value, int iiref, int ijref, const float *fmask, float *psi4, double *dpsi8) {
-    double ref = ref_value;
-    if (!use_ref) CDFT_TRY(psi_value(sh, iiref, ijref, &ref));      // :423, from the block that owns the point
+    double ref0 = ref_value;
+    const bool bcast = !use_ref && sh.rccl();
+    if (!use_ref && !bcast) CDFT_TRY(psi_value(sh, iiref, ijref, &ref0));     // :423, from the block that owns the point
+    if (bcast && (iiref < 1 || iiref > sh.npi || ijref < 1 || ijref > sh.npj))
+        return fail(CDFT_ERR_ARG, "cdft_psi_value: point (%d,%d) outside the domain", iiref, ijref);
+    const int owner = bcast ? owner_of_row(sh, ijref) : -1;
     // normalisation, mask, SNGL: every block writes its rows of the caller's arrays
     return for_blocks(sh, [&](int b) {
         const int j0 = sh.j0[b], j1 = sh.j1[b];
         const size_t off = (size_t)sh.npi * j0, nij = (size_t)sh.npi * (j1 - j0);
         DevBuf *B = sh.buf[b].data();
         hipStream_t st = sh.st[b];
+        double ref = ref0;
+        if (bcast) {                                           // RCCL mode: the owner's value reaches every block by ncclBroadcast
+            CDFT_TRY(B[12].reserve(8));
+            if (b == owner) {
+                double v = 0.0;
+                CDFT_TRY(cdft_psi_value((cdft_psi_plan *)sh.part[b], iiref, ijref - sh.j0[b], &v, st));
+                CDFT_HIP(hipMemcpyAsync(B[12].ptr, &v, 8, hipMemcpyHostToDevice, st));
+                CDFT_HIP(hipStreamSynchronize(st));
+            }
+            CDFT_RCCL(rccl::api()->Broadcast(B[12].ptr, B[12].ptr, 1, rccl::kDouble, owner, sh.comm[b], st));
+            CDFT_HIP(hipMemcpyAsync(&ref, B[12].ptr, 8, hipMemcpyDeviceToHost, st));
+            CDFT_HIP(hipStreamSynchronize(st));
+        }
         if (fmask) {
             CDFT_TRY(B[7].reserve(nij * 4));
             CDFT_TRY(rows_in(B[7].ptr, fmask, (size_t)sh.npi * 4, sh.npj, j0, j1, 1, 0, st));

@@ -14,9 +14,16 @@
 //             (hipMemcpyPeerAsync, xGMI between distinct GPUs), blocks visited in order -- the additions and their
 //             order are those of one device, so the result is bit-identical for any number of blocks;
 //             the owner of (iiref,ijref) hands its value to the others through the host (one r8).
-// Peer copies, not RCCL: within one process the devices address each other directly, the payloads are KBs, and RCCL
-// refuses two ranks on one device, which is how the path is tested on a 1-GPU box (CDFT_GPU_MAP=0,0).  RCCL is the
-// transport where the ranks are separate processes (cdftools_amd/shard.py, bench.py).
+// Two transports for these exchanges (cdft_shard_set_collective / CDFT_SHARD_COLLECTIVE):
+//   peer (default)  what is described above: within one process the devices address each other directly, the payloads
+//                   are KBs, and it also runs with two blocks on one device -- which is how the path is tested on a 1-GPU
+//                   box (CDFT_GPU_MAP=0,0);
+//   rccl            the same exchanges as RCCL collectives over xGMI (rccl_dl.hpp): cdfheatc's block sums by ONE
+//                   ncclAllGather of (npk,3) r8 per block, added in block order by every block -- the additions of the
+//                   default, bit for bit; cdfpsi's carry hop as an ncclSend / ncclRecv pair and its reference value by
+//                   ncclBroadcast from the block that owns the point.  RCCL refuses two ranks on one device, so this mode
+//                   needs distinct devices.
+// RCCL is also the transport where the ranks are separate processes (cdftools_amd/shard.py, bench.py).
 #pragma once
 #include <functional>
 #include <string>
@@ -32,7 +39,9 @@ struct ShardSet {
     std::vector<hipStream_t> st;           // one stream per block, created on its device
     std::vector<void *> part;              // the single-device plans (opaque: cdft_moc_plan*, ...)
     std::vector<std::vector<DevBuf>> buf;  // per block: staging buffers in that device's HBM
+    std::vector<void *> comm;              // CDFT_COLLECTIVE_RCCL: one RCCL communicator per block (ncclCommInitAll), else empty
     int nblk() const { return (int)dev.size(); }
+    bool rccl() const { return !comm.empty(); }
 };
 
 namespace shard {

@@ -841,7 +841,7 @@ int cdft_psi_create_sharded(cdft_psi_plan **plan, int npiglo, int npjglo, int np
         return fail(CDFT_ERR_ARG, "cdft_psi_create_sharded: bad sizes %d x %d x %d", npiglo, npjglo, npk);
     cdft_psi_plan *p = new cdft_psi_plan;
     p->npi = npiglo; p->npj = npjglo; p->npk = npk;
-    int rc = shard::make(&p->sh, npiglo, npjglo, npk, 0, ndev, devices, 0, 12);
+    int rc = shard::make(&p->sh, npiglo, npjglo, npk, 0, ndev, devices, 0, 13);
     if (rc == CDFT_OK) rc = shard::psi_parts(*p->sh);
     if (rc != CDFT_OK) { cdft_psi_destroy(p); return rc; }
     *plan = p;

@@ -10,7 +10,8 @@ MODULE cdftools_hip
   IMPLICIT NONE
   PUBLIC
 
-  INTEGER(C_INT), PARAMETER :: CDFT_OK = 0, CDFT_MEM_HOST = 0, CDFT_MEM_DEVICE = 1
+  INTEGER(C_INT), PARAMETER :: CDFT_OK = 0, CDFT_MEM_HOST = 0, CDFT_MEM_DEVICE = 1, CDFT_MEM_PINNED = 2
+  INTEGER(C_INT), PARAMETER :: CDFT_COLLECTIVE_PEER = 0, CDFT_COLLECTIVE_RCCL = 1
   INTEGER(C_INT), PARAMETER :: CDFT_HEATC_SUM_R8 = 0, CDFT_HEATC_SUM_R4SEQ = 1
   INTEGER(C_INT), PARAMETER :: CDFT_MEAN_FORM_MEAN = 0, CDFT_MEAN_FORM_SUM = 1, CDFT_MEAN_FORM_SUM_FORCING = 2, &
        &                       CDFT_MEAN_FORM_MEAN_NOVAR = 3
@@ -32,6 +33,18 @@ MODULE cdftools_hip
      ! ---- sharded plans: one process, several GPUs, row blocks (include/cdftools_hip.h "sharded plans") ------
      INTEGER(C_INT) FUNCTION cdft_shard_from_env(ndev, devices, capacity) BIND(C, name='cdft_shard_from_env')
        IMPORT ; INTEGER(C_INT), INTENT(out) :: ndev, devices(*) ; INTEGER(C_INT), VALUE :: capacity
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_shard_set_collective(mode) BIND(C, name='cdft_shard_set_collective')
+       IMPORT ; INTEGER(C_INT), VALUE :: mode
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_shard_get_collective(mode) BIND(C, name='cdft_shard_get_collective')
+       IMPORT ; INTEGER(C_INT), INTENT(out) :: mode
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_host_alloc(ptr, bytes) BIND(C, name='cdft_host_alloc')
+       IMPORT ; TYPE(C_PTR), INTENT(out) :: ptr ; INTEGER(C_SIZE_T), VALUE :: bytes
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_host_free(ptr) BIND(C, name='cdft_host_free')
+       IMPORT ; TYPE(C_PTR), VALUE :: ptr
      END FUNCTION
      INTEGER(C_INT) FUNCTION cdft_moc_create_sharded(plan, npiglo, npjglo, npk, nbasins, ndev, devices) &
           &         BIND(C, name='cdft_moc_create_sharded')
@@ -78,6 +91,21 @@ MODULE cdftools_hip
        IMPORT ; TYPE(C_PTR), VALUE :: plan, stream ; REAL(C_FLOAT), INTENT(in) :: zv(*)
        INTEGER(C_INT64_T), VALUE :: rec_stride ; INTEGER(C_INT), VALUE :: npt, zv_space, dmoc_space
        REAL(C_DOUBLE), INTENT(out) :: dmoc(*)
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_moc_stage(plan, zv, rec_stride, npt, zv_space, stream) BIND(C, name='cdft_moc_stage')
+       IMPORT ; TYPE(C_PTR), VALUE :: plan, stream ; REAL(C_FLOAT), INTENT(in) :: zv(*)
+       INTEGER(C_INT64_T), VALUE :: rec_stride ; INTEGER(C_INT), VALUE :: npt, zv_space
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_moc_compute_staged(plan, dmoc, dmoc_space, stream) BIND(C, name='cdft_moc_compute_staged')
+       IMPORT ; TYPE(C_PTR), VALUE :: plan, stream ; INTEGER(C_INT), VALUE :: dmoc_space ; REAL(C_DOUBLE), INTENT(out) :: dmoc(*)
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_moc_profile_read_block(plan, block, ms_each, capacity, launches) &
+          &         BIND(C, name='cdft_moc_profile_read_block')
+       IMPORT ; TYPE(C_PTR), VALUE :: plan ; INTEGER(C_INT), VALUE :: block, capacity
+       REAL(C_FLOAT), INTENT(out) :: ms_each(*) ; INTEGER(C_INT), INTENT(out) :: launches
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_moc_block_info(plan, block, device, j0, j1) BIND(C, name='cdft_moc_block_info')
+       IMPORT ; TYPE(C_PTR), VALUE :: plan ; INTEGER(C_INT), VALUE :: block ; INTEGER(C_INT), INTENT(out) :: device, j0, j1
      END FUNCTION
      INTEGER(C_INT) FUNCTION cdft_moc_decomp_set_mesh(plan, e3v, e1u, zcoef, gdept, tmask, umask, memspace, stream) &
           &         BIND(C, name='cdft_moc_decomp_set_mesh')

@@ -18,7 +18,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import MEM_DEVICE, MEM_HOST, CdftError, check
+from ._lib import MEM_DEVICE, MEM_HOST, MEM_PINNED, CdftError, check
 
 try:  # torch is plumbing for device memory / streams only
     import torch
@@ -81,6 +81,42 @@ class Timer:
     def __del__(self):
         try:
             _lib.load().cdft_timer_destroy(self._h)
+        except Exception:
+            pass
+
+
+COLLECTIVE_PEER, COLLECTIVE_RCCL = 0, 1
+
+
+def set_collective(mode):
+    """How the blocks of the sharded plans made from now on exchange data: COLLECTIVE_PEER (default) or COLLECTIVE_RCCL."""
+    check(_lib.load().cdft_shard_set_collective(int(mode)))
+
+
+def get_collective():
+    m = C.c_int(0)
+    check(_lib.load().cdft_shard_get_collective(C.byref(m)))
+    return m.value
+
+
+class PinnedArray:
+    """Page-locked host memory from cdft_host_alloc seen as a NumPy array (`.a`); copies from / to it are asynchronous."""
+
+    def __init__(self, shape, dtype):
+        self._p = C.c_void_p()
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        check(_lib.load().cdft_host_alloc(C.byref(self._p), n))
+        self.a = np.frombuffer((C.c_char * n).from_address(self._p.value), dtype=dtype).reshape(shape)
+
+    def close(self):
+        if self._p:
+            self.a = None
+            _lib.load().cdft_host_free(self._p)
+            self._p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
         except Exception:
             pass
 
@@ -183,6 +219,36 @@ class MocPlan:
         n = C.c_int(0)
         check(_lib.load().cdft_moc_profile_read_each(self._h, buf, capacity, C.byref(n)))
         return np.frombuffer(buf, dtype=np.float32, count=min(n.value, capacity)).astype(np.float64)
+
+    def profile_read_block(self, block, capacity=65536):
+        """-> the zonal-kernel durations (ms) of the launches of ONE row block since the last read (a sharded plan's
+        profile_read / profile_read_each give the slowest block of every launch)."""
+        buf = (C.c_float * capacity)()
+        n = C.c_int(0)
+        check(_lib.load().cdft_moc_profile_read_block(self._h, block, buf, capacity, C.byref(n)))
+        return np.frombuffer(buf, dtype=np.float32, count=min(n.value, capacity)).astype(np.float64)
+
+    def block_info(self, block):
+        """-> (device, j0, j1): the device of a row block and the rows [j0,j1) of the domain it owns."""
+        d, j0, j1 = C.c_int(0), C.c_int(0), C.c_int(0)
+        check(_lib.load().cdft_moc_block_info(self._h, block, C.byref(d), C.byref(j0), C.byref(j1)))
+        return d.value, j0.value, j1.value
+
+    def stage(self, zv, rec_stride=None, npt=None, stream=None):
+        """Hand the records over once (cdft_moc_stage): a sharded plan moves every block's rows into that block's HBM;
+        compute_staged then runs on them any number of times without touching the inputs again."""
+        pz, sz, kz = _arg(zv, np.float32, "zv")
+        n3 = self.npi * self.npj * self.npk
+        if npt is None:
+            npt = int(np.prod(kz.shape)) // n3
+        self._staged = (kz, npt)                          # a single-device plan borrows a device array: keep it alive
+        check(_lib.load().cdft_moc_stage(self._h, pz, rec_stride or n3, npt, sz, stream or current_stream_ptr()))
+
+    def compute_staged(self, out, stream=None):
+        """dmoc (npt,npk,npj,nb) r8 of the staged records into `out` (NumPy array or CUDA tensor)."""
+        po, so, ko = _arg(out, np.float64, "dmoc")
+        check(_lib.load().cdft_moc_compute_staged(self._h, po, so, stream or current_stream_ptr()))
+        return out
 
     def compute(self, zv, out=None, rec_stride=None, npt=None, stream=None):
         """zv (npt,npk,npj,npi) r4 -> dmoc (npt,npk,npj,nb) r8 in Sv (same memory space as zv

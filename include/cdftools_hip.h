@@ -45,6 +45,7 @@ extern "C" {
 
 #define CDFT_MEM_HOST      0
 #define CDFT_MEM_DEVICE    1
+#define CDFT_MEM_PINNED    2   /* host memory from cdft_host_alloc: transfers are asynchronous (see "host feed" below)   */
 
 /* ------------------------------------------------------------------------------------------ */
 /* runtime                                                                                    */
@@ -55,6 +56,15 @@ int         cdft_device_count(int *count);            /* never fails on a box wi
 int         cdft_set_device(int device);
 int         cdft_malloc(void **ptr, size_t bytes);    /* HBM allocation */
 int         cdft_free(void *ptr);
+/* Host feed without stalls.  The reference reads a slab and consumes it (src/cdfmoc.f90:355-379: getvar, then the loops);
+ * a GPU is fed through PCIe, and a program that reads record t+1 while record t travels needs (a) page-locked memory, so
+ * that the copy is a DMA the host does not take part in, and (b) calls that return once their work is QUEUED:
+ *   - cdft_host_alloc gives such memory (hipHostMalloc); arrays in it may be passed under CDFT_MEM_HOST like any host array;
+ *   - an OUTPUT array tagged CDFT_MEM_PINNED (it must come from cdft_host_alloc) is filled asynchronously: the call returns
+ *     without synchronising the stream, and the caller reads the result after cdft_stream_sync(stream).  Inputs tagged
+ *     CDFT_MEM_PINNED are host arrays whose copy is known to be asynchronous.  Entry points that take the tag say so. */
+int         cdft_host_alloc(void **ptr, size_t bytes);
+int         cdft_host_free(void *ptr);
 int         cdft_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream);
 int         cdft_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream); /* synchronises */
 int         cdft_stream_sync(void *stream);
@@ -88,6 +98,19 @@ int         cdft_timer_destroy(void *timer);
 /*   (*ndev = 1, devices[0] = -1).                                                             */
 /* ------------------------------------------------------------------------------------------ */
 int cdft_shard_from_env(int *ndev, int *devices, int capacity);
+/* How the blocks of the sharded plans made FROM NOW ON exchange what crosses them (cdfheatc's level sums, cdfpsi's carry and
+ * reference value -- src/cdfheatc.f90:225-229, src/cdfpsi.f90:395-398, :423):
+ *   CDFT_COLLECTIVE_PEER (default)  device-to-device copies and a host sum, as described above;
+ *   CDFT_COLLECTIVE_RCCL            RCCL over xGMI: one ncclAllGather of the blocks' (npk,3) r8 sums, added in block order
+ *                                   (the same additions: bit-identical to the default), ncclSend / ncclRecv for the carry
+ *                                   hop, ncclBroadcast of the reference value.  One communicator per block from
+ *                                   ncclCommInitAll; librccl is opened at run time, only in this mode; two blocks on one
+ *                                   device are refused (RCCL takes one rank per device).
+ * The environment variable CDFT_SHARD_COLLECTIVE=rccl|peer sets the initial mode (what the drop-in programs honour). */
+#define CDFT_COLLECTIVE_PEER 0
+#define CDFT_COLLECTIVE_RCCL 1
+int cdft_shard_set_collective(int mode);
+int cdft_shard_get_collective(int *mode);
 
 /* ------------------------------------------------------------------------------------------ */
 /* cdfmoc : meridional overturning stream function                                            */
@@ -128,6 +151,15 @@ int cdft_moc_set_mesh_vmask(cdft_moc_plan *plan, const float *e1v, const float *
  *        its loop 2 for each record; level npk is 0. */
 int cdft_moc_compute(cdft_moc_plan *plan, const float *zv, int64_t rec_stride, int npt,
                      int zv_space, double *dmoc, int dmoc_space, void *stream);
+/* (dmoc_space = CDFT_MEM_PINNED: the result is on its way when the call returns; cdft_stream_sync(stream) before reading.) */
+
+/* The records handed over ONCE and used by any number of cdft_moc_compute_staged calls: the equivalent of the program
+ * having read its velocity records (src/cdfmoc.f90:355-358) before the loops run.  A single-device plan keeps a device
+ * array as it is (the caller keeps it alive) and copies a host array to HBM; a sharded plan moves every block's rows into
+ * that block's HBM, so that the compute calls that follow involve no transfer of inputs at all -- what a resident multi-GPU
+ * run is.  cdft_moc_compute forgets the staged records (it may reuse their staging memory). */
+int cdft_moc_stage(cdft_moc_plan *plan, const float *zv, int64_t rec_stride, int npt, int zv_space, void *stream);
+int cdft_moc_compute_staged(cdft_moc_plan *plan, double *dmoc, int dmoc_space, void *stream);
 
 /* cdfmoc -decomp (src/cdfmoc.f90:353, :360-365, :390-517): the total overturning of ONE record and its
  * geostrophic-shear, barotropic and ageostrophic parts.  Needs cdft_moc_set_mesh (weights, basins)
@@ -172,6 +204,11 @@ int cdft_moc_profile_read(cdft_moc_plan *plan, double *zonal_ms_total, int *laun
 /* The same probe, one duration per launch (ms_each[0..min(launches,capacity)-1]) so that the harness can report the
  * minimum, median and maximum beside the mean; synchronises and resets like cdft_moc_profile_read. */
 int cdft_moc_profile_read_each(cdft_moc_plan *plan, float *ms_each, int capacity, int *launches);
+/* On a sharded plan the two readers above give, launch by launch, the duration of the SLOWEST block (what the call waited
+ * for); this one gives the launches of one block (and resets that block only), cdft_moc_block_info its device and its
+ * rows [j0,j1) of the domain (0-based, j1 exclusive).  Block 0 of an ordinary plan is the plan itself. */
+int cdft_moc_profile_read_block(cdft_moc_plan *plan, int block, float *ms_each, int capacity, int *launches);
+int cdft_moc_block_info(cdft_moc_plan *plan, int block, int *device, int *j0, int *j1);
 
 int cdft_moc_destroy(cdft_moc_plan *plan);
 

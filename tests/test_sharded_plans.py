@@ -194,3 +194,117 @@ def test_sharded_vt_is_bit_identical_to_one_device(gpu, devices):
         ref = gpu.vt_compute(*a)
         for k in ("vt", "vs", "ut", "us"):
             assert np.array_equal(got[k].cpu().numpy(), ref[k])
+
+
+# ------------------------------------------------------------------------------------------ staged records, per-block probes
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices", [None, [0], [0, 0, 0]])
+def test_staged_records_and_per_block_probes(gpu, devices):
+    """cdft_moc_stage + cdft_moc_compute_staged (what bench.py --mode inprocess times): the records are handed over once, every
+    later call gives the bits of cdft_moc_compute; the launch probe of a sharded plan speaks per block."""
+    import torch
+    npi, npj, npk, nb = 182, 149, 31, 5
+    g = synth.make_grid(npi, npj, npk, seed=3, nbasins=nb)
+    e1v, e3v, ib = synth.moc_inputs(g, nb)
+    zv = synth.velocity(g, 3, seed=5)
+    p = gpu.MocPlan(npi, npj, npk, nb, devices=devices)
+    p.set_mesh(e1v, e3v, ib)
+    ref = p.compute(zv)
+    with pytest.raises(gpu.CdftError):                              # nothing staged (and compute forgets what was)
+        p.compute_staged(np.empty_like(ref))
+    for src in (zv, torch.from_numpy(zv).cuda()):
+        p.stage(src)
+        p.profile_enable(True)
+        for _ in range(3):
+            out = p.compute_staged(np.zeros_like(ref))
+            assert np.array_equal(out, ref)
+        dout = p.compute_staged(torch.zeros(ref.shape, dtype=torch.float64, device="cuda"))
+        assert np.array_equal(dout.cpu().numpy(), ref)
+        p.profile_enable(False)
+        nblk = 1 if devices is None else len(devices)
+        rows = 0
+        for b in range(nblk):
+            dev, j0, j1 = p.block_info(b)
+            assert dev == 0 and j0 == rows and j1 > j0
+            rows = j1
+        assert rows == npj
+        each = p.profile_read_each()                              # the slowest block of every launch (and a reset of every block)
+        assert each.size == 4 and np.all(each > 0)
+        p.profile_enable(True)
+        p.compute_staged(np.zeros_like(ref))
+        p.compute_staged(np.zeros_like(ref))
+        p.profile_enable(False)
+        one = p.profile_read_block(nblk - 1)
+        assert one.size == 2 and np.all(one > 0)
+        assert p.profile_read_block(nblk - 1).size == 0           # read and reset
+        if nblk > 1:
+            assert p.profile_read_block(0).size == 2              # (the other blocks keep theirs)
+    with pytest.raises(gpu.CdftError):
+        p.block_info(7)
+    with pytest.raises(gpu.CdftError):
+        p.profile_read_block(-1)
+
+
+# ------------------------------------------------------------------------------------------ RCCL inside the library
+@pytest.mark.gpu
+def test_rccl_collectives_inside_the_library_on_one_device(gpu):
+    """CDFT_COLLECTIVE_RCCL on the one GPU there is: librccl opened at run time, ncclCommInitAll over one device, the
+    all-gather / broadcast entry points called for real (a communicator of one rank) -- the results are the bits of the
+    default transport.  Two blocks on one device are refused with a message (RCCL takes one rank per device); the
+    multi-device case is what bench.py's in-process leg reports from the driver's multi-GPU runs ("collectives")."""
+    npi, npj, npk = 97, 53, 11
+    g = synth.make_grid(npi, npj, npk, seed=9)
+    rng = np.random.default_rng(10)
+    temp = ((-2 + 30 * rng.random((npk, npj, npi), dtype=f32)) * g["tmask"]).astype(f32)
+    u = synth.velocity(g, 1, 11, which="u")[0]
+    tm = g["tmask"].astype(np.uint8)
+
+    def run():
+        h = gpu.HeatcPlan(npi, npj, npk, devices=[0])
+        h.set_sum_mode(False)
+        h.set_mesh(g["e1t"], g["e2t"], tm, e3t=g["e3t_0"])
+        p = gpu.PsiPlan(npi, npj, npk, devices=[0])
+        return h.compute(temp), p.compute(zu=u, e2u=g["e2u"], e3u=g["e3u_0"], iiref=30, ijref=20)
+    assert gpu.get_collective() == gpu.COLLECTIVE_PEER
+    hs, (p4, p8) = run()
+    gpu.set_collective(gpu.COLLECTIVE_RCCL)
+    try:
+        assert gpu.get_collective() == gpu.COLLECTIVE_RCCL
+        hr, (r4, r8) = run()
+        with pytest.raises(gpu.CdftError) as e:
+            gpu.HeatcPlan(npi, npj, npk, devices=[0, 0])
+        assert "one rank per device" in str(e.value)
+    finally:
+        gpu.set_collective(gpu.COLLECTIVE_PEER)
+    assert np.array_equal(hs, hr) and np.array_equal(p4, r4) and np.array_equal(p8, r8)
+    one = gpu.PsiPlan(npi, npj, npk).compute(zu=u, e2u=g["e2u"], e3u=g["e3u_0"], iiref=30, ijref=20)
+    assert np.array_equal(one[0], r4) and np.array_equal(one[1], r8)
+    with pytest.raises(gpu.CdftError):
+        gpu.set_collective(7)
+
+
+@pytest.mark.gpu
+def test_pinned_output_is_asynchronous_and_equal(gpu):
+    """CDFT_MEM_PINNED: the result of cdft_moc_compute lands in page-locked memory without the call synchronising; after
+    cdft_stream_sync it holds the bits of the synchronous call."""
+    import ctypes as C
+    from cdftools_amd import _lib
+    npi, npj, npk, nb = 182, 149, 31, 5
+    g = synth.make_grid(npi, npj, npk, seed=3, nbasins=nb)
+    e1v, e3v, ib = synth.moc_inputs(g, nb)
+    zv = synth.velocity(g, 2, seed=5)
+    p = gpu.MocPlan(npi, npj, npk, nb)
+    p.set_mesh(e1v, e3v, ib)
+    ref = p.compute(zv)
+    zin = gpu.PinnedArray(zv.shape, np.float32)
+    zin.a[...] = zv
+    out = gpu.PinnedArray(ref.shape, np.float64)
+    out.a[...] = -1.0
+    lib = _lib.load()
+    st = gpu.current_stream_ptr()
+    gpu.check(lib.cdft_moc_compute(p._h, C.c_void_p(zin.a.ctypes.data), npi * npj * npk, 2, gpu.MEM_HOST, C.c_void_p(out.a.ctypes.data),
+                                   _lib.MEM_PINNED, st))
+    gpu.check(lib.cdft_stream_sync(st))
+    assert np.array_equal(out.a, ref)
+    zin.close()
+    out.close()
