@@ -51,6 +51,12 @@ SIGNATURES = {
     "cdft_shard_get_collective": (_i, [C.POINTER(_i)]),
     "cdft_host_alloc": (_i, [_pvp, _sz]),
     "cdft_host_free": (_i, [_vp]),
+    "cdft_feed_create": (_i, [_pvp, _sz, _i]),
+    "cdft_feed_slot": (_i, [_vp, _pvp, C.POINTER(_sz)]),
+    "cdft_feed_push": (_i, [_vp, _vp, _sz, _sz]),
+    "cdft_feed_stream": (_i, [_vp, _pvp]),
+    "cdft_feed_wait": (_i, [_vp]),
+    "cdft_feed_destroy": (_i, [_vp]),
     "cdft_moc_create_sharded": (_i, [_pvp, _i, _i, _i, _i, _i, C.POINTER(_i)]),
     "cdft_moc_set_mesh": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
     "cdft_moc_set_mesh_vmask": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),

@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include <mutex>
 #include "common.hpp"
+#include <vector>
 
 namespace cdft {
 
@@ -187,6 +188,89 @@ int cdft_host_alloc(void **ptr, size_t bytes) {
 
 int cdft_host_free(void *ptr) {
     if (ptr) CDFT_HIP(hipHostFree(ptr));
+    return CDFT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ host feed
+// A ring of page-locked slots and a stream: the host fills a slot (a file read), queues its copy to HBM and goes on
+// filling the next one while the DMA runs.  A slot is handed out again only when the copy that last used it is done.
+struct cdft_feed {
+    std::vector<void *> slot;
+    std::vector<hipEvent_t> done;
+    std::vector<char> busy;
+    size_t slot_bytes = 0;
+    int cur = 0;                  // the slot being filled
+    hipStream_t st = nullptr;
+};
+
+int cdft_feed_create(cdft_feed **feed, size_t slot_bytes, int nslots) {
+    if (!feed) return fail(CDFT_ERR_ARG, "cdft_feed_create: NULL argument");
+    *feed = nullptr;
+    if (slot_bytes < 1 || nslots < 2 || nslots > 64) return fail(CDFT_ERR_ARG, "cdft_feed_create: %zu bytes x %d slots", slot_bytes, nslots);
+    CDFT_TRY(require_device());
+    cdft_feed *f = new cdft_feed;
+    f->slot_bytes = slot_bytes;
+    hipError_t e = hipStreamCreateWithFlags(&f->st, hipStreamNonBlocking);
+    for (int i = 0; i < nslots && e == hipSuccess; ++i) {
+        void *h = nullptr;
+        hipEvent_t ev = nullptr;
+        e = hipHostMalloc(&h, slot_bytes, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (h) f->slot.push_back(h);
+        if (ev) f->done.push_back(ev);
+        f->busy.push_back(0);
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        (void)cdft_feed_destroy(f);
+        return fail(CDFT_ERR_ALLOC, "cdft_feed_create: %d page-locked slots of %zu bytes -> %s", nslots, slot_bytes, hipGetErrorString(e));
+    }
+    *feed = f;
+    return CDFT_OK;
+}
+
+int cdft_feed_slot(cdft_feed *f, void **host, size_t *bytes) {
+    if (!f || !host) return fail(CDFT_ERR_ARG, "cdft_feed_slot: NULL argument");
+    if (f->busy[f->cur]) {
+        CDFT_HIP(hipEventSynchronize(f->done[f->cur]));
+        f->busy[f->cur] = 0;
+    }
+    *host = f->slot[f->cur];
+    if (bytes) *bytes = f->slot_bytes;
+    return CDFT_OK;
+}
+
+int cdft_feed_push(cdft_feed *f, void *dst, size_t dst_offset, size_t bytes) {
+    if (!f || !dst) return fail(CDFT_ERR_ARG, "cdft_feed_push: NULL argument");
+    if (bytes > f->slot_bytes) return fail(CDFT_ERR_ARG, "cdft_feed_push: %zu bytes from a slot of %zu", bytes, f->slot_bytes);
+    CDFT_HIP(hipMemcpyAsync((char *)dst + dst_offset, f->slot[f->cur], bytes, hipMemcpyHostToDevice, f->st));
+    CDFT_HIP(hipEventRecord(f->done[f->cur], f->st));
+    f->busy[f->cur] = 1;
+    f->cur = (f->cur + 1) % (int)f->slot.size();
+    return CDFT_OK;
+}
+
+int cdft_feed_stream(cdft_feed *f, void **stream) {
+    if (!f || !stream) return fail(CDFT_ERR_ARG, "cdft_feed_stream: NULL argument");
+    *stream = (void *)f->st;
+    return CDFT_OK;
+}
+
+int cdft_feed_wait(cdft_feed *f) {
+    if (!f) return fail(CDFT_ERR_ARG, "cdft_feed_wait: NULL argument");
+    CDFT_HIP(hipStreamSynchronize(f->st));
+    for (char &b : f->busy) b = 0;
+    return CDFT_OK;
+}
+
+int cdft_feed_destroy(cdft_feed *f) {
+    if (!f) return CDFT_OK;
+    if (f->st) (void)hipStreamSynchronize(f->st);
+    for (hipEvent_t e : f->done) (void)hipEventDestroy(e);
+    for (void *h : f->slot) (void)hipHostFree(h);
+    if (f->st) (void)hipStreamDestroy(f->st);
+    (void)hipGetLastError();
+    delete f;
     return CDFT_OK;
 }
 

@@ -707,18 +707,18 @@ CONTAINS
     CALL toc(dtime_read)
   END SUBROUTINE readvar3d
 
-  SUBROUTINE readvar3d_i1(cdfile, cdvar, ktab, ktime)
-    !! a whole 3-D mask as bytes (the backend converts when the file holds another type); a time-less (x,y,z) mask is
-    !! read the same way, a mask without levels fills every level of ktab
+  SUBROUTINE readvar3d_i1(cdfile, cdvar, ktab, ktime, kkmin)
+    !! a whole 3-D mask (or its levels from kkmin on) as bytes (the backend converts when the file holds another type); a
+    !! time-less (x,y,z) mask is read the same way, a mask without levels fills every level of ktab
     CHARACTER(LEN=*),            INTENT(in)  :: cdfile, cdvar
     INTEGER(KIND=1), CONTIGUOUS, INTENT(out) :: ktab(:,:,:)
-    INTEGER(KIND=4), OPTIONAL,   INTENT(in)  :: ktime
+    INTEGER(KIND=4), OPTIONAL,   INTENT(in)  :: ktime, kkmin
     INTEGER(KIND=4) :: ncid, ivar, ierr, jk, ifirst(4), ishape(4)
     LOGICAL :: ll_levels
     CALL tic()
     CALL src_variable(cdfile, cdvar, ncid, ivar)
     ifirst = 1 ; ishape = (/ SIZE(ktab, 1), SIZE(ktab, 2), 1, 1 /)
-    CALL place_slab(ncid, ivar, 1, oint(ktime, 1), ifirst, ll_levels)
+    CALL place_slab(ncid, ivar, oint(kkmin, 1), oint(ktime, 1), ifirst, ll_levels)
     IF ( ll_levels ) THEN
        ishape(3) = SIZE(ktab, 3)
        ierr = NF90_GET_VAR(ncid, ivar, ktab, start=ifirst, count=ishape)

@@ -13,12 +13,16 @@ PROGRAM cdfmoc
   !! (cdft_moc_decomp_*), one record per call.  -rapid (:598-1004: the RAPID-MOCHA diagnostics of one (i,k)
   !! section at 26.5 N) has nothing data-parallel in it and is host code as in the reference
   !! (module cdfmoc_rapid, cdf_findij from module cdftools).
+  !! Host feed (module cdffeed): on one device, without -decomp / -full, nothing 3-D is held in host memory -- the metric,
+  !! its mask and every velocity record go from the file to HBM slab by slab through a page-locked ring, the copy of one
+  !! slab under the read of the next, so a record costs its read, not its read plus its transfer (CDFT_FEED=0: the old way).
   !!======================================================================
   USE ISO_C_BINDING
   USE cdfio
   USE modcdfnames
   USE eos
   USE cdftools_hip
+  USE cdffeed
   USE cdfmoc_rapid
   IMPLICIT NONE
 
@@ -29,9 +33,10 @@ PROGRAM cdfmoc
   INTEGER(KIND=4) :: npglo = 1, npatl = 2, npinp = 3, npind = 4, nppac = 5
   INTEGER(KIND=4), ALLOCATABLE :: ipk(:), id_varout(:)
   INTEGER(KIND=4) :: iloc(2)
-  INTEGER(KIND=2), ALLOCATABLE :: ibmask(:,:,:)                 ! (nbasins, npiglo, npjglo)
+  INTEGER(KIND=2), ALLOCATABLE, TARGET :: ibmask(:,:,:)         ! (nbasins, npiglo, npjglo)
   INTEGER(KIND=1), ALLOCATABLE :: ivmask(:,:,:)                 ! vmask of every level, as bytes
-  REAL(KIND=4),    ALLOCATABLE :: e1v(:,:), gphiv(:,:), e3v(:,:,:), zv(:,:,:,:), zmsk(:,:)
+  REAL(KIND=4),    ALLOCATABLE, TARGET :: e1v(:,:)
+  REAL(KIND=4),    ALLOCATABLE :: gphiv(:,:), e3v(:,:,:), zv(:,:,:,:), zmsk(:,:)
   REAL(KIND=4),    ALLOCATABLE :: rdumlon(:,:), rdumlat(:,:), gdepw(:), e31d(:)
   REAL(KIND=8),    ALLOCATABLE :: dtim(:), dmoc(:,:,:,:)          ! (nbasins, npjglo, npk, nbatch)
   REAL(KIND=8) :: dl_budget, dl_t(5) = 0.d0                     ! CDFT_TIMING: mesh reads, data reads, GPU calls, output
@@ -46,6 +51,12 @@ PROGRAM cdfmoc
   CHARACTER(LEN=256) :: cf_moc = 'moc.nc', cglobal, cldum
   TYPE(variable), ALLOCATABLE :: stypvar(:)
   TYPE(C_PTR) :: plan
+  TYPE(C_PTR) :: pd_zv = C_NULL_PTR, pd_e3v = C_NULL_PTR, pd_vm = C_NULL_PTR, pd_e1v = C_NULL_PTR, pd_ib = C_NULL_PTR
+  REAL(KIND=4), POINTER :: zv_d(:), e3v_d(:), e1v_d(:)       ! the same device arrays seen as arrays (never touched by the host)
+  INTEGER(KIND=1), POINTER :: ivm_d(:)
+  INTEGER(KIND=2), POINTER :: ib_d(:)
+  INTEGER(KIND=8) :: nij8, n38
+  LOGICAL :: lfeed
   LOGICAL :: lbas, lfull = .FALSE., lchk = .FALSE., ldec = .FALSE., lrap = .FALSE., ll_teos10 = .FALSE.
   !!----------------------------------------------------------------------
   CALL ReadCdfNames()
@@ -162,9 +173,14 @@ PROGRAM cdfmoc
   IF ( lg_vvl ) nbatch = 1                                ! the metric changes with every record
   IF ( ldec   ) nbatch = 1                                ! cdft_moc_decomp works record by record
 
+  CALL hip_shard(ngpu, igpus)                                ! CDFT_GPUS / CDFT_GPU_MAP: row blocks over the node's GPUs
+  lfeed = feed_wanted() .AND. ngpu == 1 .AND. .NOT. ( ldec .OR. lfull )
+  IF ( lfeed ) nbatch = 1                                 ! a record is computed on as soon as its last slab has left
+  nij8 = INT(npiglo, 8) * npjglo ; n38 = nij8 * npk
+
   ALLOCATE( ibmask(nbasins, npiglo, npjglo), zmsk(npiglo, npjglo) )
-  ALLOCATE( e1v(npiglo, npjglo), gphiv(npiglo, npjglo), e3v(npiglo, npjglo, npk) )
-  ALLOCATE( zv(npiglo, npjglo, npk, nbatch), dmoc(nbasins, npjglo, npk, nbatch) )
+  ALLOCATE( e1v(npiglo, npjglo), gphiv(npiglo, npjglo), dmoc(nbasins, npjglo, npk, nbatch) )
+  IF ( .NOT. lfeed ) ALLOCATE( e3v(npiglo, npjglo, npk), zv(npiglo, npjglo, npk, nbatch) )
   ALLOCATE( rdumlon(1, npjglo), rdumlat(1, npjglo), gdepw(npk), e31d(npk), dtim(npt) )
   ALLOCATE( stypvar(nvarout), ipk(nvarout), id_varout(nvarout) )
 
@@ -213,7 +229,6 @@ PROGRAM cdfmoc
   ibmask(npglo, 1,      :) = 0                            ! E-W periodic overlap, global basin only
   ibmask(npglo, npiglo, :) = 0
 
-  CALL hip_shard(ngpu, igpus)                                ! CDFT_GPUS / CDFT_GPU_MAP: row blocks over the node's GPUs
   IF ( ngpu > 1 .AND. .NOT. ldec ) THEN                      ! (-decomp stays on one device: its stencil crosses rows)
      CALL hip_check(cdft_moc_create_sharded(plan, npiglo, npjglo, npk, nbasins, ngpu, igpus), 'cdft_moc_create_sharded')
   ELSE
@@ -225,7 +240,26 @@ PROGRAM cdfmoc
      nrec = MIN(nbatch, npt - it0 + 1)
      IF ( it0 == 1 .OR. lg_vvl ) THEN                     ! e3v masked by vmask, every level (get_e3v)
         CALL tick(1)                                         ! what came before: coordinates, masks, output file
-        IF ( ldec .OR. lfull ) THEN                      ! the masked metric is needed on the host as well
+        IF ( lfeed ) THEN                                ! file -> HBM through the ring, get_e3v's product on the device
+           IF ( it0 == 1 ) THEN
+              pd_e1v = feed_device(4 * nij8) ; pd_ib = feed_device(2 * nbasins * nij8)
+              pd_vm  = feed_device(n38)      ; pd_e3v = feed_device(4 * n38) ; pd_zv = feed_device(4 * n38)
+              CALL C_F_POINTER(pd_e1v, e1v_d, (/ nij8 /))   ; CALL C_F_POINTER(pd_ib, ib_d, (/ nbasins * nij8 /))
+              CALL C_F_POINTER(pd_vm, ivm_d, (/ n38 /))     ; CALL C_F_POINTER(pd_e3v, e3v_d, (/ n38 /))
+              CALL C_F_POINTER(pd_zv, zv_d, (/ n38 /))
+              CALL feed_host(C_LOC(e1v), 4 * nij8, pd_e1v)
+              CALL feed_host(C_LOC(ibmask), 2 * nbasins * nij8, pd_ib)
+              CALL feed_mask(cn_fmsk, cn_vmask, pd_vm, npiglo, npjglo, npk)
+           ENDIF
+           CALL feed_field(cn_fe3v, cn_ve3v, pd_e3v, npiglo, npjglo, npk, ktime=it0, ldiom=.NOT. lg_vvl)
+           CALL tick(2)
+           CALL hip_check(cdft_moc_set_mesh_vmask(plan, e1v_d, e3v_d, ivm_d, ib_d, CDFT_MEM_DEVICE, feed_stream), &
+                &         'cdft_moc_set_mesh_vmask')
+           CALL hip_check(cdft_stream_sync(feed_stream), 'cdft_stream_sync')
+           IF ( .NOT. lg_vvl ) THEN                       ! the plan keeps its own weights and classes: these can go
+              CALL feed_release(pd_e3v) ; CALL feed_release(pd_vm) ; CALL feed_release(pd_e1v) ; CALL feed_release(pd_ib)
+           ENDIF
+        ELSE IF ( ldec .OR. lfull ) THEN                 ! the masked metric is needed on the host as well
            CALL get_e3v_all(it0)
            CALL tick(2)
            CALL hip_check(cdft_moc_set_mesh(plan, e1v, e3v, ibmask, CDFT_MEM_HOST, C_NULL_PTR), 'cdft_moc_set_mesh')
@@ -258,12 +292,19 @@ PROGRAM cdfmoc
         CYCLE
      ENDIF
      CALL tick(5)
-     DO jr = 1, nrec                                      ! velocities of levels 1..npk-1 are used
-        CALL readvar3d(cf_vfil, cn_vomecrty, zv(:,:,:,jr), ktime=it0 + jr - 1)
-     END DO
-     CALL tick(3)
-     CALL hip_check(cdft_moc_compute(plan, zv, INT(npiglo, C_INT64_T) * npjglo * npk, nrec, CDFT_MEM_HOST, dmoc, &
-          &                          CDFT_MEM_HOST, C_NULL_PTR), 'cdft_moc_compute')
+     IF ( lfeed ) THEN                                    ! the record's slabs leave for HBM as they are read
+        CALL feed_field(cf_vfil, cn_vomecrty, pd_zv, npiglo, npjglo, npk, ktime=it0)
+        CALL tick(3)
+        CALL hip_check(cdft_moc_compute(plan, zv_d, INT(n38, C_INT64_T), 1, CDFT_MEM_DEVICE, dmoc, CDFT_MEM_HOST, feed_stream), &
+             &         'cdft_moc_compute')
+     ELSE
+        DO jr = 1, nrec                                   ! velocities of levels 1..npk-1 are used
+           CALL readvar3d(cf_vfil, cn_vomecrty, zv(:,:,:,jr), ktime=it0 + jr - 1)
+        END DO
+        CALL tick(3)
+        CALL hip_check(cdft_moc_compute(plan, zv, INT(npiglo, C_INT64_T) * npjglo * npk, nrec, CDFT_MEM_HOST, dmoc, &
+             &                          CDFT_MEM_HOST, C_NULL_PTR), 'cdft_moc_compute')
+     ENDIF
      CALL tick(4)
      DO jr = 1, nrec
         jt = it0 + jr - 1
@@ -284,6 +325,10 @@ PROGRAM cdfmoc
   END DO
 
   ierr = cdft_moc_destroy(plan)
+  IF ( lfeed ) THEN
+     CALL feed_release(pd_zv) ; CALL feed_release(pd_e3v) ; CALL feed_release(pd_vm) ; CALL feed_release(pd_e1v) ; CALL feed_release(pd_ib)
+     CALL feed_close()
+  ENDIF
   ierr = closeout(ncout)
   CALL tick(5)
   IF ( ltiming ) PRINT '(a,5(a,f8.3))', ' CDFT_TIMING (s):', ' setup', dl_t(1), '  mesh reads', dl_t(2), '  data reads', dl_t(3), &

@@ -30,6 +30,18 @@ MODULE cdftools_hip
      INTEGER(C_INT) FUNCTION cdft_set_device(idev) BIND(C, name='cdft_set_device')
        IMPORT ; INTEGER(C_INT), VALUE :: idev
      END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_malloc(ptr, bytes) BIND(C, name='cdft_malloc')
+       IMPORT ; TYPE(C_PTR), INTENT(out) :: ptr ; INTEGER(C_SIZE_T), VALUE :: bytes
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_free(ptr) BIND(C, name='cdft_free')
+       IMPORT ; TYPE(C_PTR), VALUE :: ptr
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_memcpy_h2d(dst, src, bytes, stream) BIND(C, name='cdft_memcpy_h2d')
+       IMPORT ; TYPE(C_PTR), VALUE :: dst, src, stream ; INTEGER(C_SIZE_T), VALUE :: bytes
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_stream_sync(stream) BIND(C, name='cdft_stream_sync')
+       IMPORT ; TYPE(C_PTR), VALUE :: stream
+     END FUNCTION
      ! ---- sharded plans: one process, several GPUs, row blocks (include/cdftools_hip.h "sharded plans") ------
      INTEGER(C_INT) FUNCTION cdft_shard_from_env(ndev, devices, capacity) BIND(C, name='cdft_shard_from_env')
        IMPORT ; INTEGER(C_INT), INTENT(out) :: ndev, devices(*) ; INTEGER(C_INT), VALUE :: capacity
@@ -45,6 +57,24 @@ MODULE cdftools_hip
      END FUNCTION
      INTEGER(C_INT) FUNCTION cdft_host_free(ptr) BIND(C, name='cdft_host_free')
        IMPORT ; TYPE(C_PTR), VALUE :: ptr
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_feed_create(feed, slot_bytes, nslots) BIND(C, name='cdft_feed_create')
+       IMPORT ; TYPE(C_PTR), INTENT(out) :: feed ; INTEGER(C_SIZE_T), VALUE :: slot_bytes ; INTEGER(C_INT), VALUE :: nslots
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_feed_slot(feed, host, slot_bytes) BIND(C, name='cdft_feed_slot')
+       IMPORT ; TYPE(C_PTR), VALUE :: feed ; TYPE(C_PTR), INTENT(out) :: host ; INTEGER(C_SIZE_T), INTENT(out) :: slot_bytes
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_feed_push(feed, dst, dst_offset, bytes) BIND(C, name='cdft_feed_push')
+       IMPORT ; TYPE(C_PTR), VALUE :: feed, dst ; INTEGER(C_SIZE_T), VALUE :: dst_offset, bytes
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_feed_stream(feed, stream) BIND(C, name='cdft_feed_stream')
+       IMPORT ; TYPE(C_PTR), VALUE :: feed ; TYPE(C_PTR), INTENT(out) :: stream
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_feed_wait(feed) BIND(C, name='cdft_feed_wait')
+       IMPORT ; TYPE(C_PTR), VALUE :: feed
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_feed_destroy(feed) BIND(C, name='cdft_feed_destroy')
+       IMPORT ; TYPE(C_PTR), VALUE :: feed
      END FUNCTION
      INTEGER(C_INT) FUNCTION cdft_moc_create_sharded(plan, npiglo, npjglo, npk, nbasins, ndev, devices) &
           &         BIND(C, name='cdft_moc_create_sharded')

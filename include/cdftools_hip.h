@@ -65,6 +65,20 @@ int         cdft_free(void *ptr);
  *     CDFT_MEM_PINNED are host arrays whose copy is known to be asynchronous.  Entry points that take the tag say so. */
 int         cdft_host_alloc(void **ptr, size_t bytes);
 int         cdft_host_free(void *ptr);
+/* The feed: a ring of page-locked slots with a stream of its own, for a host that produces its input piece by piece (a
+ * file read per slab of levels).  cdft_feed_slot gives the slot to fill (waiting, if need be, for the copy that last used
+ * it); cdft_feed_push queues the copy of its first `bytes` to dst + dst_offset in HBM and moves to the next slot, so the
+ * next read runs while the DMA does; work given cdft_feed_stream's stream afterwards (a compute call on the record just
+ * pushed) runs after the copies.  What this replaces is the time, not an interface: the reference reads a slab, then
+ * computes on it (src/cdfmoc.f90:355-379).  Measured on this pool: a pageable first touch or hipHostMalloc cost 0.17-0.19 s
+ * per GB and a copy runs at 57 GB/s either way (tools/pin_probe.hip) -- hence a small ring, not page-locked records. */
+typedef struct cdft_feed cdft_feed;
+int         cdft_feed_create(cdft_feed **feed, size_t slot_bytes, int nslots);
+int         cdft_feed_slot(cdft_feed *feed, void **host, size_t *slot_bytes);
+int         cdft_feed_push(cdft_feed *feed, void *dst, size_t dst_offset, size_t bytes);
+int         cdft_feed_stream(cdft_feed *feed, void **stream);
+int         cdft_feed_wait(cdft_feed *feed);
+int         cdft_feed_destroy(cdft_feed *feed);
 int         cdft_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream);
 int         cdft_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream); /* synchronises */
 int         cdft_stream_sync(void *stream);

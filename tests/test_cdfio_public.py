@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FDIR = os.path.join(ROOT, "cdftools_amd", "fortran")
 BUILD = os.path.join(FDIR, "build")
 LIBDIR = os.path.join(ROOT, "cdftools_amd", "lib")
-MODS = ["netcdf", "modcdfnames", "cdftools_hip", "cdfio", "eos", "modutils", "cdftools", "cdfmoc_rapid"]
+MODS = ["netcdf", "modcdfnames", "cdftools_hip", "cdfio", "cdffeed", "eos", "modutils", "cdftools", "cdfmoc_rapid"]
 FFLAGS = ["-O1", "-fPIC", "-cpp", "-ffp-contract=off"]
 f32 = np.float32
 NPI, NPJ, NPK, NPT = 6, 5, 4, 3

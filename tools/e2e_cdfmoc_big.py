@@ -163,17 +163,40 @@ def main():
     sizes = {f: round(os.path.getsize(os.path.join(d, f)) / 1e9, 2) for f in sorted(os.listdir(d))}
 
     exe = os.path.join(ROOT, "cdftools_amd", "bin", "cdfmoc")
-    env = dict(os.environ, CDFT_TIMING="1")
-    walls, phases = [], ""
-    for i in range(2):
+
+    def run_program(feed, out):
+        """-> wall time, the phases line, stdout without it, the phases as numbers"""
+        env = dict(os.environ, CDFT_TIMING="1", CDFT_FEED="1" if feed else "0")
         t0 = time.perf_counter()
-        r = subprocess.run([exe, "-v", "V.nc"], cwd=d, env=env, capture_output=True, text=True)
-        walls.append(round(time.perf_counter() - t0, 2))
+        r = subprocess.run([exe, "-v", "V.nc", "-o", out], cwd=d, env=env, capture_output=True, text=True)
+        wall = time.perf_counter() - t0
         if r.returncode != 0:
             print("cdfmoc failed with code", r.returncode)
             print(r.stdout[-3000:], r.stderr[-2000:])
             sys.exit(1)
-        phases = [ln.strip() for ln in r.stdout.splitlines() if "CDFT_TIMING" in ln][0]
+        line = [ln.strip() for ln in r.stdout.splitlines() if "CDFT_TIMING" in ln][0]
+        rest = "\n".join(ln for ln in r.stdout.splitlines() if "CDFT_TIMING" not in ln)
+        nums = [float(x) for x in line.replace("(H2D + kernels + D2H)", "").split() if x.replace(".", "", 1).isdigit()]
+        return round(wall, 3), line, rest, dict(zip(("setup", "mesh_reads", "data_reads", "gpu_calls", "output"), nums))
+
+    # the old way (whole records in pageable memory, read THEN transferred) and the feed (slabs through the page-locked ring,
+    # the transfer of one under the read of the next), each twice (the second run has every file in the page cache)
+    e2e = {}
+    outs = {}
+    for feed in (False, True):
+        best = None
+        for i in range(2):
+            wall, line, rest, ph = run_program(feed, "moc_feed.nc" if feed else "moc.nc")
+            if best is None or wall < best[0]:
+                best = (wall, line, ph)
+        outs[feed] = rest
+        wall, line, ph = best
+        e2e["feed" if feed else "whole_records"] = {
+            "wall_s": wall, "phases_s": ph, "per_record_s": round((ph["data_reads"] + ph["gpu_calls"] - (0 if feed else 0)) / npt, 4),
+            "grid_cells_per_s": npi * npj * npk * npt / wall, "phases_line": line}
+    e2e["stdout_identical"] = outs[False] == outs[True].replace("moc_feed.nc", "moc.nc")
+    e2e["moc_files_identical"] = open(os.path.join(d, "moc.nc"), "rb").read() == open(os.path.join(d, "moc_feed.nc"), "rb").read()
+    walls, phases = [e2e["whole_records"]["wall_s"], e2e["feed"]["wall_s"]], e2e["feed"]["phases_line"]
 
     ib = np.zeros((args.rows, npi, 5), np.int16)                  # src/cdfmoc.f90:325-336
     ib[:, :, 0] = vm0[rows]
@@ -182,7 +205,7 @@ def main():
     ib[:, 0, 0] = 0
     ib[:, npi - 1, 0] = 0
     ref = oracle_lib.moc(e1v[rows], e3v_rows, ib, v_rows)         # (npt,npk,rows,nb)
-    var, _, dims = read_nc(os.path.join(d, "moc.nc"))
+    var, _, dims = read_nc(os.path.join(d, "moc_feed.nc"))
     worst, ident = 0.0, 0
     for b, nm in enumerate(("zomsfglo", "zomsfatl", "zomsfinp", "zomsfind", "zomsfpac")):
         got = var[nm][:, :, rows, 0]
@@ -190,7 +213,7 @@ def main():
         ident += int(np.array_equal(got, want))
         worst = max(worst, float(np.abs(got - want).max() / (np.abs(want).max() + 1e-30)))
     print(json.dumps({"tool": "cdfmoc (program, CDF-5 files)", "grid": args.grid, "npt": npt, "files_GB": sizes, "generate_s": round(gen, 1),
-                      "wall_s": walls, "phases_last": phases, "grid_cells_per_s": npi * npj * npk * npt / walls[-1],
+                      "wall_s": walls, "phases_last": phases, "grid_cells_per_s": npi * npj * npk * npt / walls[-1], "e2e": e2e,
                       "rows_checked": [int(x) for x in rows], "basins_bit_identical_after_r4_store": ident,
                       "max_rel_diff_vs_oracle": worst, "moc_dims": {k: (int(v) if v is not None else None) for k, v in dims.items()}}))
     if not args.keep:
