@@ -52,6 +52,7 @@ SIGNATURES = {
     "cdft_host_alloc": (_i, [_pvp, _sz]),
     "cdft_host_free": (_i, [_vp]),
     "cdft_feed_create": (_i, [_pvp, _sz, _i]),
+    "cdft_feed_resize": (_i, [_vp, _sz, _i]),
     "cdft_feed_slot": (_i, [_vp, _pvp, C.POINTER(_sz)]),
     "cdft_feed_push": (_i, [_vp, _vp, _sz, _sz]),
     "cdft_feed_stream": (_i, [_vp, _pvp]),

@@ -229,6 +229,31 @@ int cdft_feed_create(cdft_feed **feed, size_t slot_bytes, int nslots) {
     return CDFT_OK;
 }
 
+int cdft_feed_resize(cdft_feed *f, size_t slot_bytes, int nslots) {
+    if (!f) return fail(CDFT_ERR_ARG, "cdft_feed_resize: NULL argument");
+    if (slot_bytes < 1 || nslots < 2 || nslots > 64) return fail(CDFT_ERR_ARG, "cdft_feed_resize: %zu bytes x %d slots", slot_bytes, nslots);
+    CDFT_HIP(hipStreamSynchronize(f->st));                      // nothing in flight: the slots can go
+    for (void *h : f->slot) (void)hipHostFree(h);
+    f->slot.clear();
+    f->busy.assign((size_t)nslots, 0);
+    while ((int)f->done.size() < nslots) {
+        hipEvent_t ev = nullptr;
+        CDFT_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        f->done.push_back(ev);
+    }
+    f->slot_bytes = slot_bytes;
+    f->cur = 0;
+    for (int i = 0; i < nslots; ++i) {
+        void *h = nullptr;
+        if (hipHostMalloc(&h, slot_bytes, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(CDFT_ERR_ALLOC, "cdft_feed_resize: %d page-locked slots of %zu bytes", nslots, slot_bytes);
+        }
+        f->slot.push_back(h);
+    }
+    return CDFT_OK;
+}
+
 int cdft_feed_slot(cdft_feed *f, void **host, size_t *bytes) {
     if (!f || !host) return fail(CDFT_ERR_ARG, "cdft_feed_slot: NULL argument");
     if (f->busy[f->cur]) {

@@ -7,8 +7,10 @@ MODULE cdffeed
   !! in a device array as soon as it is read: the DMA of slab s runs while the file read of slab s+1 does, so a record
   !! costs the longer of the two.  The compute call on that device array is then given feed_stream, which orders it after
   !! the copies.  Unpacking (scale_factor ...), windows and the mesh_zgr names are readvar3d's, unchanged.
-  !! CDFT_FEED_MB (slot size, default 128) and CDFT_FEED_SLOTS (default 4) size the ring; CDFT_FEED=0 switches the programs
-  !! back to whole records in pageable memory.
+  !! The ring is made when the first field goes through it, sized for that field: page-locked memory costs 0.17 s per GB to
+  !! get and 0.10 s per GB to give back on this pool (tools/pin_probe.hip), so the slots hold a sixteenth of the field, at
+  !! least one plane and at most CDFT_FEED_MB (default 128) MB, CDFT_FEED_SLOTS (default 4) of them.  A program takes this
+  !! route when its fields are large enough for it to pay (feed_wanted: CDFT_FEED=0 / 1 decide for it).
   !!======================================================================
   USE ISO_C_BINDING
   USE cdfio
@@ -24,24 +26,49 @@ MODULE cdffeed
 
 CONTAINS
 
-  LOGICAL FUNCTION feed_wanted()
-    !! .FALSE. with CDFT_FEED=0 in the environment
-    CHARACTER(LEN=8) :: cl
+  LOGICAL FUNCTION feed_wanted(kfield)
+    !! whether a program whose 3-D fields hold kfield bytes goes through the ring: CDFT_FEED=1 always, CDFT_FEED=0 never;
+    !! left alone, from CDFT_FEED_MIN_MB (default 1024) on -- below that a transfer takes a few milliseconds and the ring's
+    !! page-locked memory costs as much as it hides (measured at eORCA025, 0.5 GB fields: +- 0.05 s either way on 0.5 s runs)
+    INTEGER(KIND=8), INTENT(in) :: kfield
+    CHARACTER(LEN=16) :: cl
+    INTEGER(KIND=4) :: imin
     CALL GET_ENVIRONMENT_VARIABLE('CDFT_FEED', cl)
-    feed_wanted = ( cl(1:1) /= '0' )
+    IF ( cl(1:1) == '0' .OR. cl(1:1) == '1' ) THEN
+       feed_wanted = ( cl(1:1) == '1' )
+       RETURN
+    ENDIF
+    imin = 1024
+    CALL GET_ENVIRONMENT_VARIABLE('CDFT_FEED_MIN_MB', cl) ; IF ( LEN_TRIM(cl) > 0 ) READ(cl, *) imin
+    feed_wanted = ( kfield >= INT(imin, 8) * 1048576_8 )
   END FUNCTION feed_wanted
 
   SUBROUTINE feed_open()
-    INTEGER(KIND=4) :: imb, islots
-    CHARACTER(LEN=16) :: cl
+    !! the feed's stream, with a ring of token size: the slots proper come with the first field (feed_size)
     IF ( C_ASSOCIATED(hfeed) ) RETURN
-    imb = 128 ; islots = 4
-    CALL GET_ENVIRONMENT_VARIABLE('CDFT_FEED_MB', cl)    ; IF ( LEN_TRIM(cl) > 0 ) READ(cl, *) imb
-    CALL GET_ENVIRONMENT_VARIABLE('CDFT_FEED_SLOTS', cl) ; IF ( LEN_TRIM(cl) > 0 ) READ(cl, *) islots
-    nslot_bytes = INT(MAX(imb, 1), 8) * 1048576_8
-    CALL hip_check(cdft_feed_create(hfeed, INT(nslot_bytes, C_SIZE_T), MAX(2, islots)), 'cdft_feed_create')
+    nslot_bytes = 0
+    CALL hip_check(cdft_feed_create(hfeed, 4096_C_SIZE_T, 2), 'cdft_feed_create')
     CALL hip_check(cdft_feed_stream(hfeed, feed_stream), 'cdft_feed_stream')
   END SUBROUTINE feed_open
+
+  SUBROUTINE feed_size(kplane, kfield)
+    ! slots for fields of kfield bytes made of planes of kplane bytes: a sixteenth of the field, whole planes, at least one,
+    ! at most CDFT_FEED_MB; a ring that already holds a plane is kept
+    INTEGER(KIND=8), INTENT(in) :: kplane, kfield
+    INTEGER(KIND=4) :: islots
+    INTEGER(KIND=8) :: iwant
+    REAL(KIND=8)    :: dl_mb
+    CHARACTER(LEN=16) :: cl
+    CALL feed_open()
+    IF ( nslot_bytes >= kplane ) RETURN
+    dl_mb = 128.d0 ; islots = 4
+    CALL GET_ENVIRONMENT_VARIABLE('CDFT_FEED_MB', cl)    ; IF ( LEN_TRIM(cl) > 0 ) READ(cl, *) dl_mb
+    CALL GET_ENVIRONMENT_VARIABLE('CDFT_FEED_SLOTS', cl) ; IF ( LEN_TRIM(cl) > 0 ) READ(cl, *) islots
+    iwant = MIN(INT(dl_mb * 1048576.d0, 8), MAX(kfield / 16, 4194304_8))
+    iwant = MAX(( iwant / kplane ) * kplane, kplane)
+    CALL hip_check(cdft_feed_resize(hfeed, INT(iwant, C_SIZE_T), MAX(2, islots)), 'cdft_feed_resize')
+    nslot_bytes = iwant
+  END SUBROUTINE feed_size
 
   SUBROUTINE feed_close()
     IF ( C_ASSOCIATED(hfeed) ) CALL hip_check(cdft_feed_destroy(hfeed), 'cdft_feed_destroy')
@@ -52,6 +79,7 @@ CONTAINS
     !! kbytes of HBM (the destination of feed_field / feed_mask / feed_host)
     INTEGER(KIND=8), INTENT(in) :: kbytes
     TYPE(C_PTR) :: pdev
+    CALL feed_open()
     CALL hip_check(cdft_malloc(pdev, INT(kbytes, C_SIZE_T)), 'cdft_malloc')
   END FUNCTION feed_device
 
@@ -62,30 +90,32 @@ CONTAINS
     pdev = C_NULL_PTR
   END SUBROUTINE feed_release
 
-  SUBROUTINE feed_field(cdfile, cdvar, pdev, kpi, kpj, kpk, ktime, ldiom, kimin, kjmin, kkmin)
+  SUBROUTINE feed_field(cdfile, cdvar, pdev, kpi, kpj, kpk, ktime, ldiom, kimin, kjmin, kkmin, kplane)
     !! the (kpi,kpj,kpk) r4 block of record ktime (window origin kimin, kjmin, kkmin; ldiom as in getvar) into the device
-    !! array pdev, slab by slab through the ring.  Returns when the last slab is QUEUED.
+    !! array pdev -- from its plane number kplane on (default 1: the start) -- slab by slab through the ring.  Returns when
+    !! the last slab is QUEUED.
     CHARACTER(LEN=*),          INTENT(in) :: cdfile, cdvar
     TYPE(C_PTR),               INTENT(in) :: pdev
     INTEGER(KIND=4),           INTENT(in) :: kpi, kpj, kpk
-    INTEGER(KIND=4), OPTIONAL, INTENT(in) :: ktime, kimin, kjmin, kkmin
+    INTEGER(KIND=4), OPTIONAL, INTENT(in) :: ktime, kimin, kjmin, kkmin, kplane
     LOGICAL,         OPTIONAL, INTENT(in) :: ldiom
-    INTEGER(KIND=4) :: ik0, inl, inlmax, ikfirst
+    INTEGER(KIND=4) :: ik0, inl, inlmax, ikfirst, iplane
     INTEGER(KIND=8) :: islab
     INTEGER(C_SIZE_T) :: ibytes
     TYPE(C_PTR) :: pslot
     REAL(KIND=4), POINTER :: zslab(:,:,:)
-    CALL feed_open()
     islab = 4_8 * kpi * kpj
-    IF ( islab > nslot_bytes ) CALL feed_resize(islab)
+    CALL feed_size(islab, islab * kpk)
     inlmax = INT(MAX(1_8, nslot_bytes / islab), 4)
     ikfirst = 1 ; IF ( PRESENT(kkmin) ) ikfirst = kkmin
+    iplane = 1  ; IF ( PRESENT(kplane) ) iplane = kplane
     DO ik0 = 1, kpk, inlmax
        inl = MIN(inlmax, kpk - ik0 + 1)
        CALL hip_check(cdft_feed_slot(hfeed, pslot, ibytes), 'cdft_feed_slot')
        CALL C_F_POINTER(pslot, zslab, (/ kpi, kpj, inl /))
        CALL readvar3d(cdfile, cdvar, zslab, ktime=ktime, ldiom=ldiom, kimin=kimin, kjmin=kjmin, kkmin=ikfirst + ik0 - 1)
-       CALL hip_check(cdft_feed_push(hfeed, pdev, INT(islab * (ik0 - 1), C_SIZE_T), INT(islab * inl, C_SIZE_T)), 'cdft_feed_push')
+       CALL hip_check(cdft_feed_push(hfeed, pdev, INT(islab * (iplane + ik0 - 2), C_SIZE_T), INT(islab * inl, C_SIZE_T)), &
+            &         'cdft_feed_push')
     END DO
   END SUBROUTINE feed_field
 
@@ -100,9 +130,8 @@ CONTAINS
     INTEGER(C_SIZE_T) :: ibytes
     TYPE(C_PTR) :: pslot
     INTEGER(KIND=1), POINTER :: islabs(:,:,:)
-    CALL feed_open()
     islab = 1_8 * kpi * kpj
-    IF ( islab > nslot_bytes ) CALL feed_resize(islab)
+    CALL feed_size(islab, 4 * islab * kpk)
     inlmax = INT(MAX(1_8, nslot_bytes / islab), 4)
     DO ik0 = 1, kpk, inlmax
        inl = MIN(inlmax, kpk - ik0 + 1)
@@ -114,33 +143,12 @@ CONTAINS
   END SUBROUTINE feed_mask
 
   SUBROUTINE feed_host(psrc, kbytes, pdev)
-    !! kbytes of a host array (C_LOC of it) into the device array pdev through the ring
+    !! kbytes of a host array (C_LOC of it: a 2-D metric, a mask, a profile) into the device array pdev, there when the
+    !! call returns.  Small arrays: a plain copy from pageable memory, no ring.
     TYPE(C_PTR),     INTENT(in) :: psrc, pdev
     INTEGER(KIND=8), INTENT(in) :: kbytes
-    INTEGER(KIND=8) :: ioff, in
-    INTEGER(C_SIZE_T) :: ibytes
-    TYPE(C_PTR) :: pslot
-    INTEGER(KIND=1), POINTER :: isrc(:), idst(:)
-    CALL feed_open()
-    CALL C_F_POINTER(psrc, isrc, (/ kbytes /))
-    ioff = 0
-    DO WHILE ( ioff < kbytes )
-       in = MIN(nslot_bytes, kbytes - ioff)
-       CALL hip_check(cdft_feed_slot(hfeed, pslot, ibytes), 'cdft_feed_slot')
-       CALL C_F_POINTER(pslot, idst, (/ in /))
-       idst(1:in) = isrc(ioff+1:ioff+in)
-       CALL hip_check(cdft_feed_push(hfeed, pdev, INT(ioff, C_SIZE_T), INT(in, C_SIZE_T)), 'cdft_feed_push')
-       ioff = ioff + in
-    END DO
+    CALL hip_check(cdft_memcpy_h2d(pdev, psrc, INT(kbytes, C_SIZE_T), C_NULL_PTR), 'cdft_memcpy_h2d')
+    CALL hip_check(cdft_stream_sync(C_NULL_PTR), 'cdft_stream_sync')
   END SUBROUTINE feed_host
-
-  SUBROUTINE feed_resize(kbytes)
-    ! one level does not fit a slot (a very large plane): a new ring whose slots hold one
-    INTEGER(KIND=8), INTENT(in) :: kbytes
-    CALL hip_check(cdft_feed_destroy(hfeed), 'cdft_feed_destroy')
-    nslot_bytes = kbytes
-    CALL hip_check(cdft_feed_create(hfeed, INT(nslot_bytes, C_SIZE_T), 3), 'cdft_feed_create')
-    CALL hip_check(cdft_feed_stream(hfeed, feed_stream), 'cdft_feed_stream')
-  END SUBROUTINE feed_resize
 
 END MODULE cdffeed

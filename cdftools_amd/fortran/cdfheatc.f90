@@ -14,6 +14,7 @@ PROGRAM cdfheatc
   USE cdfio
   USE modcdfnames
   USE cdftools_hip
+  USE cdffeed
   IMPLICIT NONE
 
   INTEGER(KIND=4), PARAMETER :: jp_hc3d = 1, jp_hc2d = 2, jp_hcvol = 3
@@ -30,7 +31,12 @@ PROGRAM cdfheatc
   CHARACTER(LEN=256) :: cf_tfil = 'none', cf_mfil = 'none', cf_out = 'heatc.nc', cv_msk = 'tmask', cldum
   TYPE(variable), ALLOCATABLE :: stypvar(:)
   TYPE(C_PTR) :: plan, pe3t, pe31d, pmxl, pdepw
-  LOGICAL :: lfull = .FALSE., lchk
+  ! the same arrays in HBM when they are fed there through the ring (module cdffeed): never touched by the host
+  TYPE(C_PTR) :: pd_e1 = C_NULL_PTR, pd_e2 = C_NULL_PTR, pd_e3 = C_NULL_PTR, pd_e31d = C_NULL_PTR, pd_msk = C_NULL_PTR
+  TYPE(C_PTR) :: pd_t = C_NULL_PTR, pd_mxl = C_NULL_PTR
+  REAL(KIND=4), POINTER :: e1_d(:), e2_d(:), temp_d(:)
+  INTEGER(KIND=8) :: nij8, n38
+  LOGICAL :: lfull = .FALSE., lchk, lfeed
   !!----------------------------------------------------------------------
   CALL ReadCdfNames()
   narg = COMMAND_ARGUMENT_COUNT()
@@ -112,10 +118,13 @@ PROGRAM cdfheatc
   PRINT *, 'npt    = ', npt
   PRINT *, 'nvpk   = ', nvpk
 
-  ALLOCATE( e1t(npiglo,npjglo), e2t(npiglo,npjglo), temp(npiglo,npjglo,nvpk), tmask(npiglo,npjglo,nvpk) )
-  ALLOCATE( gdepw(npk), gdepw_sel(nvpk), dtim(npt), dsums(3,nvpk) )
+  CALL hip_shard(ngpu, igpus)                                ! CDFT_GPUS / CDFT_GPU_MAP: row blocks over the node's GPUs
+  lfeed = feed_wanted(4_8 * npiglo * npjglo * nvpk) .AND. ngpu == 1                      ! one device: file -> HBM through the ring (module cdffeed)
+  nij8 = INT(npiglo, 8) * npjglo ; n38 = nij8 * nvpk
+  ALLOCATE( e1t(npiglo,npjglo), e2t(npiglo,npjglo), gdepw(npk), gdepw_sel(nvpk), dtim(npt), dsums(3,nvpk) )
+  IF ( .NOT. lfeed ) ALLOCATE( temp(npiglo,npjglo,nvpk), tmask(npiglo,npjglo,nvpk) )
   IF ( mxloption /= 0 ) ALLOCATE( rmxldep(npiglo,npjglo) )
-  IF ( lfull ) THEN ; ALLOCATE( e31d(npk), e31d_sel(nvpk) ) ; ELSE ; ALLOCATE( e3t(npiglo,npjglo,nvpk) ) ; ENDIF
+  IF ( lfull ) THEN ; ALLOCATE( e31d(npk), e31d_sel(nvpk) ) ; ELSE IF ( .NOT. lfeed ) THEN ; ALLOCATE( e3t(npiglo,npjglo,nvpk) ) ; ENDIF
 
   e1t(:,:) = getvar(cn_fhgr, cn_ve1t, 1, npiglo, npjglo, kimin=iimin, kjmin=ijmin)
   e2t(:,:) = getvar(cn_fhgr, cn_ve2t, 1, npiglo, npjglo, kimin=iimin, kjmin=ijmin)
@@ -125,10 +134,22 @@ PROGRAM cdfheatc
      e31d(:) = getvare3(cn_fzgr, cn_ve3t1d, npk)
      e31d_sel(:) = e31d(ikmin:ikmin + nvpk - 1)
   ENDIF
-  CALL readvar3d(cn_fmsk, cv_msk, tmask, kimin=iimin, kjmin=ijmin, kkmin=ikmin)      ! (every level in one read)
+  IF ( lfeed ) THEN
+     pd_e1 = feed_device(4 * nij8) ; pd_e2 = feed_device(4 * nij8) ; pd_msk = feed_device(4 * n38) ; pd_t = feed_device(4 * n38)
+     CALL C_F_POINTER(pd_e1, e1_d, (/ nij8 /)) ; CALL C_F_POINTER(pd_e2, e2_d, (/ nij8 /)) ; CALL C_F_POINTER(pd_t, temp_d, (/ n38 /))
+     CALL feed_host(C_LOC(e1t), 4 * nij8, pd_e1) ; CALL feed_host(C_LOC(e2t), 4 * nij8, pd_e2)
+     CALL feed_field(cn_fmsk, cv_msk, pd_msk, npiglo, npjglo, nvpk, kimin=iimin, kjmin=ijmin, kkmin=ikmin)
+     IF ( lfull ) THEN
+        pd_e31d = feed_device(4_8 * nvpk) ; CALL feed_host(C_LOC(e31d_sel), 4_8 * nvpk, pd_e31d)
+     ELSE
+        pd_e3 = feed_device(4 * n38)
+     ENDIF
+     IF ( mxloption /= 0 ) pd_mxl = feed_device(4 * nij8)
+  ELSE
+     CALL readvar3d(cn_fmsk, cv_msk, tmask, kimin=iimin, kjmin=ijmin, kkmin=ikmin)      ! (every level in one read)
+  ENDIF
 
   CALL CreateOutput
-  CALL hip_shard(ngpu, igpus)                                ! CDFT_GPUS / CDFT_GPU_MAP: row blocks over the node's GPUs
   IF ( ngpu > 1 ) THEN
      CALL hip_check(cdft_heatc_create_sharded(plan, npiglo, npjglo, nvpk, ngpu, igpus), 'cdft_heatc_create_sharded')
   ELSE
@@ -149,18 +170,31 @@ PROGRAM cdfheatc
      IF ( mxloption /= 0 ) THEN
         rmxldep(:,:) = getvar(cf_mfil, cn_somxl010, 1, npiglo, npjglo, kimin=iimin, kjmin=ijmin, ktime=jt)
         pmxl = C_LOC(rmxldep) ; pdepw = C_LOC(gdepw_sel)
+        IF ( lfeed ) THEN ; CALL feed_host(pmxl, 4 * nij8, pd_mxl) ; pmxl = pd_mxl ; ENDIF
      ENDIF
-     CALL readvar3d(cf_tfil, cn_votemper, temp, kimin=iimin, kjmin=ijmin, kkmin=ikmin, ktime=jt)
-     IF ( .NOT. lfull .AND. (jt == 1 .OR. lg_vvl) ) &
-        &  CALL readvar3d(cn_fe3t, cn_ve3t, e3t, kimin=iimin, kjmin=ijmin, kkmin=ikmin, ktime=it, ldiom=.NOT. lg_vvl)
-     IF ( jt == 1 .OR. lg_vvl ) THEN
-        pe3t = C_NULL_PTR ; pe31d = C_NULL_PTR
-        IF ( lfull ) THEN ; pe31d = C_LOC(e31d_sel) ; ELSE ; pe3t = C_LOC(e3t) ; ENDIF
-        CALL hip_check(cdft_heatc_set_mesh(plan, e1t, e2t, pe3t, pe31d, C_LOC(tmask), 1_C_INT, CDFT_MEM_HOST, C_NULL_PTR), &
-             &         'cdft_heatc_set_mesh')
+     IF ( lfeed ) THEN                                    ! the record, and the metric when it is due, slab by slab into HBM
+        CALL feed_field(cf_tfil, cn_votemper, pd_t, npiglo, npjglo, nvpk, kimin=iimin, kjmin=ijmin, kkmin=ikmin, ktime=jt)
+        IF ( jt == 1 .OR. lg_vvl ) THEN
+           IF ( .NOT. lfull ) CALL feed_field(cn_fe3t, cn_ve3t, pd_e3, npiglo, npjglo, nvpk, kimin=iimin, kjmin=ijmin, &
+                &                              kkmin=ikmin, ktime=it, ldiom=.NOT. lg_vvl)
+           CALL hip_check(cdft_heatc_set_mesh(plan, e1_d, e2_d, pd_e3, pd_e31d, pd_msk, 1_C_INT, CDFT_MEM_DEVICE, feed_stream), &
+                &         'cdft_heatc_set_mesh')
+        ENDIF
+        CALL hip_check(cdft_heatc_compute(plan, temp_d, CDFT_MEM_DEVICE, pmxl, pdepw, INT(mxloption, C_INT), dsums, CDFT_MEM_HOST, &
+             &         feed_stream), 'cdft_heatc_compute')
+     ELSE
+        CALL readvar3d(cf_tfil, cn_votemper, temp, kimin=iimin, kjmin=ijmin, kkmin=ikmin, ktime=jt)
+        IF ( .NOT. lfull .AND. (jt == 1 .OR. lg_vvl) ) &
+           &  CALL readvar3d(cn_fe3t, cn_ve3t, e3t, kimin=iimin, kjmin=ijmin, kkmin=ikmin, ktime=it, ldiom=.NOT. lg_vvl)
+        IF ( jt == 1 .OR. lg_vvl ) THEN
+           pe3t = C_NULL_PTR ; pe31d = C_NULL_PTR
+           IF ( lfull ) THEN ; pe31d = C_LOC(e31d_sel) ; ELSE ; pe3t = C_LOC(e3t) ; ENDIF
+           CALL hip_check(cdft_heatc_set_mesh(plan, e1t, e2t, pe3t, pe31d, C_LOC(tmask), 1_C_INT, CDFT_MEM_HOST, C_NULL_PTR), &
+                &         'cdft_heatc_set_mesh')
+        ENDIF
+        CALL hip_check(cdft_heatc_compute(plan, temp, CDFT_MEM_HOST, pmxl, pdepw, INT(mxloption, C_INT), dsums, CDFT_MEM_HOST, &
+             &         C_NULL_PTR), 'cdft_heatc_compute')
      ENDIF
-     CALL hip_check(cdft_heatc_compute(plan, temp, CDFT_MEM_HOST, pmxl, pdepw, INT(mxloption, C_INT), dsums, CDFT_MEM_HOST, &
-          &         C_NULL_PTR), 'cdft_heatc_compute')
 
      DO jk = 1, nvpk                                       ! src/cdfheatc.f90:225-238
         ik = jk + ikmin - 1
@@ -183,6 +217,11 @@ PROGRAM cdfheatc
      ierr = putvar(ncout, id_varout(jp_hcvol), dl_dum(:,:), 1, 1, 1, ktime=jt)
   END DO
   ierr = cdft_heatc_destroy(plan)
+  IF ( lfeed ) THEN
+     CALL feed_release(pd_e1) ; CALL feed_release(pd_e2) ; CALL feed_release(pd_msk) ; CALL feed_release(pd_t)
+     CALL feed_release(pd_e3) ; CALL feed_release(pd_e31d) ; CALL feed_release(pd_mxl)
+     CALL feed_close()
+  ENDIF
   ierr = closeout(ncout)
 
 CONTAINS

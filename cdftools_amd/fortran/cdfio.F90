@@ -56,7 +56,7 @@ MODULE cdfio
   INTEGER(KIND=8)    :: nclock0
   REAL(KIND=8)       :: dtime_read = 0.d0, dtime_write = 0.d0
   ! ---- read handles kept open (least recently used one gives way)
-  INTEGER(KIND=4), PARAMETER :: jpsrc = 8
+  INTEGER(KIND=4), PARAMETER :: jpsrc = 16
   CHARACTER(LEN=1024) :: csrc_name(jpsrc) = ' '
   INTEGER(KIND=4)     :: nsrc_ncid(jpsrc) = -1, nsrc_used(jpsrc) = 0, nsrc_clock = 0
   INTEGER(KIND=4)     :: nsrc_keep = -1                 ! -1 not asked yet, 0 open / close per call, 1 keep open

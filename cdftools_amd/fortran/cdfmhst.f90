@@ -12,6 +12,7 @@ PROGRAM cdfmhst
   USE cdfio
   USE modcdfnames
   USE cdftools_hip
+  USE cdffeed
   IMPLICIT NONE
 
   REAL(KIND=4), PARAMETER :: ppspval = 9999.99
@@ -30,6 +31,13 @@ PROGRAM cdfmhst
   TYPE(variable), ALLOCATABLE :: stypvar(:)
   TYPE(C_PTR) :: plan, pe3v, pe31d, p1, p2, p3, p4, p5
   LOGICAL :: llglo, lchk = .FALSE., lfull = .FALSE., lsepf = .TRUE., lzdim = .FALSE.
+  ! the operands in HBM when they are fed there through the ring (module cdffeed): never touched by the host
+  TYPE(C_PTR) :: pd_a = C_NULL_PTR, pd_b = C_NULL_PTR, pd_c = C_NULL_PTR, pd_e3 = C_NULL_PTR, pd_e31d = C_NULL_PTR
+  TYPE(C_PTR) :: pd_e1 = C_NULL_PTR, pd_msk = C_NULL_PTR
+  REAL(KIND=4), POINTER :: e1_d(:), msk_d(:)
+  INTEGER(KIND=8) :: nij8, n38
+  TYPE(C_PTR) :: pstream = C_NULL_PTR
+  LOGICAL :: lfeed = .FALSE.
   !!----------------------------------------------------------------------
   CALL ReadCdfNames()
   narg = COMMAND_ARGUMENT_COUNT()
@@ -128,10 +136,16 @@ PROGRAM cdfmhst
   ENDIF
   nlevo = npko
 
+  CALL hip_shard(ngpu, igpus)                                ! CDFT_GPUS / CDFT_GPU_MAP: row blocks over the node's GPUs
+  lfeed = feed_wanted(4_8 * npiglo * npjglo * npk) .AND. ngpu == 1                      ! one device: file -> HBM through the ring (module cdffeed)
+  nij8 = INT(npiglo, 8) * npjglo ; n38 = nij8 * npk
   ALLOCATE( e1v(npiglo,npjglo), gphiv(npiglo,npjglo), zmasks(npiglo,npjglo,nmask) )
-  ALLOCATE( zvt(npiglo,npjglo,npk), zvs(npiglo,npjglo,npk) )
-  IF ( lsepf ) ALLOCATE( zt(npiglo,npjglo,npk) )
-  IF ( lfull ) THEN ; ALLOCATE( e31d(npk) ) ; ELSE ; ALLOCATE( e3v(npiglo,npjglo,npk) ) ; ENDIF
+  IF ( lfull ) ALLOCATE( e31d(npk) )
+  IF ( .NOT. lfeed ) THEN
+     ALLOCATE( zvt(npiglo,npjglo,npk), zvs(npiglo,npjglo,npk) )
+     IF ( lsepf ) ALLOCATE( zt(npiglo,npjglo,npk) )
+     IF ( .NOT. lfull ) ALLOCATE( e3v(npiglo,npjglo,npk) )
+  ENDIF
   ALLOCATE( rdumlon(1,npjglo), rdumlat(1,npjglo), gdep(npko), dtim(npt), dmtrp(npjglo), dz(npjglo,6) )
   ALLOCATE( dheat(nmask,npjglo,nlevo), dsalt(nmask,npjglo,nlevo) )
   ALLOCATE( stypvar(nbasinso*npvar), ipk(nbasinso*npvar), id_varout(nbasinso*npvar) )
@@ -157,7 +171,15 @@ PROGRAM cdfmhst
 
   OPEN(numouth, FILE=cf_outh, FORM='FORMATTED', RECL=256)
   OPEN(numouts, FILE=cf_outs, FORM='FORMATTED', RECL=256)
-  CALL hip_shard(ngpu, igpus)                                ! CDFT_GPUS / CDFT_GPU_MAP: row blocks over the node's GPUs
+  IF ( lfeed ) THEN
+     pd_e1 = feed_device(4 * nij8) ; pd_msk = feed_device(4 * nij8 * nmask) ; pd_a = feed_device(4 * n38) ; pd_b = feed_device(4 * n38)
+     IF ( lsepf ) pd_c = feed_device(4 * n38)
+     CALL C_F_POINTER(pd_e1, e1_d, (/ nij8 /)) ; CALL C_F_POINTER(pd_msk, msk_d, (/ nij8 * nmask /))
+     CALL feed_host(C_LOC(e1v), 4 * nij8, pd_e1) ; CALL feed_host(C_LOC(zmasks), 4 * nij8 * nmask, pd_msk)
+     IF ( lfull ) THEN ; pd_e31d = feed_device(4_8 * npk) ; CALL feed_host(C_LOC(e31d), 4_8 * npk, pd_e31d)
+     ELSE              ; pd_e3 = feed_device(4 * n38)
+     ENDIF
+  ENDIF
   IF ( ngpu > 1 ) THEN
      CALL hip_check(cdft_mhst_create_sharded(plan, npiglo, npjglo, npk, nmask, ngpu, igpus), 'cdft_mhst_create_sharded')
   ELSE
@@ -166,7 +188,10 @@ PROGRAM cdfmhst
 
   DO jt = 1, npt
      it = 1 ; IF ( lg_vvl ) it = jt
-     IF ( jt == 1 .OR. lg_vvl ) THEN
+     IF ( lfeed .AND. ( jt == 1 .OR. lg_vvl ) ) THEN     ! the metric slab by slab into HBM, the mesh set from there
+        IF ( .NOT. lfull ) CALL feed_field(cn_fe3v, cn_ve3v, pd_e3, npiglo, npjglo, npk, ktime=it, ldiom=.NOT. lg_vvl)
+        CALL hip_check(cdft_mhst_set_mesh(plan, e1_d, pd_e3, pd_e31d, msk_d, CDFT_MEM_DEVICE, feed_stream), 'cdft_mhst_set_mesh')
+     ELSE IF ( jt == 1 .OR. lg_vvl ) THEN
         pe3v = C_NULL_PTR ; pe31d = C_NULL_PTR
         IF ( lfull ) THEN
            pe31d = C_LOC(e31d)
@@ -180,18 +205,30 @@ PROGRAM cdfmhst
         PRINT *, 'level ', jk
      END DO
      p1 = C_NULL_PTR ; p2 = C_NULL_PTR ; p3 = C_NULL_PTR ; p4 = C_NULL_PTR ; p5 = C_NULL_PTR
-     IF ( lsepf ) THEN                                     ! V, T, S: the kernel forms 0.5*(t(j)+t(j+1))*v
-        zvt = getvar3d(cf_vfil, cn_vomecrty, npiglo, npjglo, npk, ktime=jt)
-        zt  = getvar3d(cf_tfil, cn_votemper, npiglo, npjglo, npk, ktime=jt)
-        zvs = getvar3d(cf_sfil, cn_vosaline, npiglo, npjglo, npk, ktime=jt)
+     IF ( lfeed ) pstream = feed_stream
+     IF ( lfeed ) THEN                                     ! the records slab by slab into HBM
+        IF ( lsepf ) THEN
+           CALL feed_field(cf_vfil, cn_vomecrty, pd_a, npiglo, npjglo, npk, ktime=jt)
+           CALL feed_field(cf_tfil, cn_votemper, pd_b, npiglo, npjglo, npk, ktime=jt)
+           CALL feed_field(cf_sfil, cn_vosaline, pd_c, npiglo, npjglo, npk, ktime=jt)
+           p3 = pd_a ; p4 = pd_b ; p5 = pd_c
+        ELSE
+           CALL feed_field(cf_vtfil, cn_vomevt, pd_a, npiglo, npjglo, npk, ktime=jt)
+           CALL feed_field(cf_vtfil, cn_vomevs, pd_b, npiglo, npjglo, npk, ktime=jt)
+           p1 = pd_a ; p2 = pd_b
+        ENDIF
+     ELSE IF ( lsepf ) THEN                                ! V, T, S: the kernel forms 0.5*(t(j)+t(j+1))*v
+        CALL readvar3d(cf_vfil, cn_vomecrty, zvt, ktime=jt)
+        CALL readvar3d(cf_tfil, cn_votemper, zt, ktime=jt)
+        CALL readvar3d(cf_sfil, cn_vosaline, zvs, ktime=jt)
         p3 = C_LOC(zvt) ; p4 = C_LOC(zt) ; p5 = C_LOC(zvs)
      ELSE
-        zvt = getvar3d(cf_vtfil, cn_vomevt, npiglo, npjglo, npk, ktime=jt)
-        zvs = getvar3d(cf_vtfil, cn_vomevs, npiglo, npjglo, npk, ktime=jt)
+        CALL readvar3d(cf_vtfil, cn_vomevt, zvt, ktime=jt)
+        CALL readvar3d(cf_vtfil, cn_vomevs, zvs, ktime=jt)
         p1 = C_LOC(zvt) ; p2 = C_LOC(zvs)
      ENDIF
-     CALL hip_check(cdft_mhst_compute(plan, p1, p2, p3, p4, p5, CDFT_MEM_HOST, MERGE(1_C_INT, 0_C_INT, lzdim), dheat, dsalt, &
-          &         CDFT_MEM_HOST, C_NULL_PTR), 'cdft_mhst_compute')
+     CALL hip_check(cdft_mhst_compute(plan, p1, p2, p3, p4, p5, MERGE(CDFT_MEM_DEVICE, CDFT_MEM_HOST, lfeed),                &
+          &         MERGE(1_C_INT, 0_C_INT, lzdim), dheat, dsalt, CDFT_MEM_HOST, pstream), 'cdft_mhst_compute')
 
      DO ik0 = 1, nlevo                                     ! src/cdfmhst.f90:389-445
         DO jvar = 1, npvar
@@ -214,6 +251,11 @@ PROGRAM cdfmhst
      CALL ascii_dump(numouts, dsalt(:,:,nlevo), 1.d6, 9001)
   END DO
   ierr = cdft_mhst_destroy(plan)
+  IF ( lfeed ) THEN
+     CALL feed_release(pd_a) ; CALL feed_release(pd_b) ; CALL feed_release(pd_c) ; CALL feed_release(pd_e3)
+     CALL feed_release(pd_e31d) ; CALL feed_release(pd_e1) ; CALL feed_release(pd_msk)
+     CALL feed_close()
+  ENDIF
   ierr = closeout(ncout)
   CLOSE(numouth)
   CLOSE(numouts)

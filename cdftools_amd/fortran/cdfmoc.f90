@@ -174,7 +174,7 @@ PROGRAM cdfmoc
   IF ( ldec   ) nbatch = 1                                ! cdft_moc_decomp works record by record
 
   CALL hip_shard(ngpu, igpus)                                ! CDFT_GPUS / CDFT_GPU_MAP: row blocks over the node's GPUs
-  lfeed = feed_wanted() .AND. ngpu == 1 .AND. .NOT. ( ldec .OR. lfull )
+  lfeed = feed_wanted(4_8 * npiglo * npjglo * npk) .AND. ngpu == 1 .AND. .NOT. ( ldec .OR. lfull )
   IF ( lfeed ) nbatch = 1                                 ! a record is computed on as soon as its last slab has left
   nij8 = INT(npiglo, 8) * npjglo ; n38 = nij8 * npk
 
@@ -277,9 +277,9 @@ PROGRAM cdfmoc
      ENDIF
      IF ( ldec ) THEN                                     ! one record: total + the three components
         jt = it0
-        zv(:,:,:,1)  = getvar3d(cf_vfil, cn_vomecrty, npiglo, npjglo, npk, ktime=jt)
-        ztemp(:,:,:) = getvar3d(cf_tfil, cn_votemper, npiglo, npjglo, npk, ktime=jt)
-        zsal(:,:,:)  = getvar3d(cf_sfil, cn_vosaline, npiglo, npjglo, npk, ktime=jt)
+        CALL readvar3d(cf_vfil, cn_vomecrty, zv(:,:,:,1), ktime=jt)
+        CALL readvar3d(cf_tfil, cn_votemper, ztemp(:,:,:), ktime=jt)
+        CALL readvar3d(cf_sfil, cn_vosaline, zsal(:,:,:), ktime=jt)
         CALL hip_check(cdft_moc_decomp(plan, zv, ztemp, zsal, MERGE(CDFT_EOS_TEOS10, CDFT_EOS_80, ll_teos10), CDFT_MEM_HOST, &
              &         dmoc, dmoc_sh, dmoc_bt, dmoc_ag, CDFT_MEM_HOST, C_NULL_PTR), 'cdft_moc_decomp')
         ijvar = 1                                         ! output order of src/cdfmoc.f90:520-569

@@ -195,12 +195,12 @@ PROGRAM cdfmocsig
 
   DO jt = 1, npt
      it = 1 ; IF ( lg_vvl ) it = jt
-     zv = getvar3d(cf_vfil, cn_vomecrty, npiglo, npjglo, npk, ktime=jt)
-     zt = getvar3d(cf_tfil, cn_votemper, npiglo, npjglo, npk, ktime=jt)
-     zs = getvar3d(cf_sfil, cn_vosaline, npiglo, npjglo, npk, ktime=jt)
+     CALL readvar3d(cf_vfil, cn_vomecrty, zv, ktime=jt)
+     CALL readvar3d(cf_tfil, cn_votemper, zt, ktime=jt)
+     CALL readvar3d(cf_sfil, cn_vosaline, zs, ktime=jt)
      pe3 = C_NULL_PTR ; pe31d = C_NULL_PTR ; peiv = C_NULL_PTR ; pgdep = C_NULL_PTR ; pdepi = C_NULL_PTR
      IF ( leiv ) THEN
-        zveiv = getvar3d(cf_vfil, cn_vomeeivv, npiglo, npjglo, npk, ktime=jt)
+        CALL readvar3d(cf_vfil, cn_vomeeivv, zveiv, ktime=jt)
         peiv = C_LOC(zveiv)
      ENDIF
      IF ( lfull ) THEN

@@ -17,6 +17,7 @@ PROGRAM cdfpsi
   USE modcdfnames
   USE modutils
   USE cdftools_hip
+  USE cdffeed
   IMPLICIT NONE
 
   INTEGER(C_INT)  :: ngpu, igpus(64)                          ! row blocks and their HIP devices (CDFT_GPUS, CDFT_GPU_MAP)
@@ -30,9 +31,16 @@ PROGRAM cdfpsi
   CHARACTER(LEN=256) :: cf_ufil = 'none', cf_vfil = 'none', cf_out = 'psi.nc', cv_out = 'sobarstf', cglobal, cldum
   CHARACTER(LEN=256) :: cf_sshfil = 'none', cv_outssh = 'sobarstfssh', cv_outotal = 'sobarstftotal'
   TYPE(variable) :: stypvar(3)
-  TYPE(C_PTR) :: plan, plan1, pzu, pe2u, pe3u, pzv, pe1v, pe3v, pe31d, pmask, pdpsi
+  TYPE(C_PTR) :: plan, plan1, pzu, pe2u, pe3u, pzv, pe1v, pe3v, pe31d, pmask, pmask1, pdpsi
   LOGICAL :: lchk = .FALSE., lfull = .FALSE., lmask = .FALSE., lmean = .FALSE., lopen = .FALSE., lssh = .FALSE.
   LOGICAL :: llev = .FALSE., lnc4 = .FALSE., ll_u = .TRUE., ll_v = .FALSE.
+  ! the 3-D operands in HBM when they are fed there through the ring (module cdffeed); pstream: the stream the plan's calls
+  ! are queued on (the feed's, so that they follow the copies)
+  TYPE(C_PTR) :: pd_zu = C_NULL_PTR, pd_zv = C_NULL_PTR, pd_e3u = C_NULL_PTR, pd_e3v = C_NULL_PTR, pd_e2u = C_NULL_PTR
+  TYPE(C_PTR) :: pd_e1v = C_NULL_PTR, pd_e31d = C_NULL_PTR, pd_mask = C_NULL_PTR, pstream = C_NULL_PTR
+  INTEGER(C_INT)  :: nspace = CDFT_MEM_HOST
+  INTEGER(KIND=8) :: nij8, n38
+  LOGICAL :: lfeed = .FALSE.
   !!----------------------------------------------------------------------
   CALL ReadCdfNames()
   narg = COMMAND_ARGUMENT_COUNT()
@@ -147,10 +155,13 @@ PROGRAM cdfpsi
 
   ALLOCATE( glamf(npiglo,npjglo), gphif(npiglo,npjglo), zpsi(npiglo,npjglo), dtim(npt) )
   ALLOCATE( e1v(npiglo,npjglo), e2u(npiglo,npjglo) )
-  IF ( ll_u .AND. .NOT. llev ) ALLOCATE( zu(npiglo,npjglo,npk) )      ! -lev works level by level
-  IF ( ll_v .AND. .NOT. llev ) ALLOCATE( zv(npiglo,npjglo,npk) )
+  CALL hip_shard(ngpu, igpus)                                ! CDFT_GPUS / CDFT_GPU_MAP: row blocks over the node's GPUs
+  lfeed = feed_wanted(4_8 * npiglo * npjglo * npk) .AND. ngpu == 1 .AND. .NOT. llev     ! one device: file -> HBM through the ring (module cdffeed)
+  nij8 = INT(npiglo, 8) * npjglo ; n38 = nij8 * npk
+  IF ( ll_u .AND. .NOT. ( llev .OR. lfeed ) ) ALLOCATE( zu(npiglo,npjglo,npk) )      ! -lev works level by level
+  IF ( ll_v .AND. .NOT. ( llev .OR. lfeed ) ) ALLOCATE( zv(npiglo,npjglo,npk) )
   IF ( lfull ) THEN ; ALLOCATE( e31d(npk) )
-  ELSE IF ( .NOT. llev ) THEN
+  ELSE IF ( .NOT. ( llev .OR. lfeed ) ) THEN
      IF ( ll_u ) ALLOCATE( e3u(npiglo,npjglo,npk) )
      IF ( ll_v ) ALLOCATE( e3v(npiglo,npjglo,npk) )
   ENDIF
@@ -173,7 +184,20 @@ PROGRAM cdfpsi
      pe31d = C_LOC(e31d)
   ENDIF
 
-  CALL hip_shard(ngpu, igpus)                                ! CDFT_GPUS / CDFT_GPU_MAP: row blocks over the node's GPUs
+  IF ( lfeed ) THEN                                          ! the 2-D operands and the 3-D buffers, in HBM
+     nspace = CDFT_MEM_DEVICE
+     IF ( ll_u ) THEN
+        pd_e2u = feed_device(4 * nij8) ; CALL feed_host(C_LOC(e2u), 4 * nij8, pd_e2u) ; pd_zu = feed_device(4 * n38)
+        IF ( .NOT. lfull ) pd_e3u = feed_device(4 * n38)
+     ENDIF
+     IF ( ll_v ) THEN
+        pd_e1v = feed_device(4 * nij8) ; CALL feed_host(C_LOC(e1v), 4 * nij8, pd_e1v) ; pd_zv = feed_device(4 * n38)
+        IF ( .NOT. lfull ) pd_e3v = feed_device(4 * n38)
+     ENDIF
+     IF ( lfull ) THEN ; pd_e31d = feed_device(4_8 * npk) ; CALL feed_host(pe31d, 4_8 * npk, pd_e31d) ; pe31d = pd_e31d ; ENDIF
+     IF ( lmask ) THEN ; pd_mask = feed_device(4 * nij8) ; CALL feed_host(pmask, 4 * nij8, pd_mask) ; pmask = pd_mask ; ENDIF
+     pstream = feed_stream
+  ENDIF
   IF ( ngpu > 1 .AND. .NOT. lopen ) THEN                     ! (-open integrates along one row of the whole domain)
      CALL hip_check(cdft_psi_create_sharded(plan, npiglo, npjglo, npk, ngpu, igpus), 'cdft_psi_create_sharded')
   ELSE
@@ -197,8 +221,13 @@ PROGRAM cdfpsi
         STOP 0
      ENDIF
      pzu = C_NULL_PTR ; pe2u = C_NULL_PTR ; pe3u = C_NULL_PTR ; pzv = C_NULL_PTR ; pe1v = C_NULL_PTR ; pe3v = C_NULL_PTR
-     IF ( ll_v ) THEN
-        zv = getvar3d(cf_vfil, cn_vomecrty, npiglo, npjglo, npk, ktime=jt)
+     IF ( ll_v .AND. lfeed ) THEN                         ! slab by slab into HBM, the copy of one under the read of the next
+        CALL feed_field(cf_vfil, cn_vomecrty, pd_zv, npiglo, npjglo, npk, ktime=jt)
+        IF ( .NOT. lfull .AND. ( jt == 1 .OR. lg_vvl ) ) CALL feed_field(cn_fe3v, cn_ve3v, pd_e3v, npiglo, npjglo, npk, ktime=it, &
+             &                                                             ldiom=.NOT. lg_vvl)
+        pzv = pd_zv ; pe1v = pd_e1v ; pe3v = pd_e3v
+     ELSE IF ( ll_v ) THEN
+        CALL readvar3d(cf_vfil, cn_vomecrty, zv, ktime=jt)
         pzv = C_LOC(zv) ; pe1v = C_LOC(e1v)
         IF ( .NOT. lfull ) THEN
            IF ( jt == 1 .OR. lg_vvl ) THEN
@@ -207,8 +236,13 @@ PROGRAM cdfpsi
            pe3v = C_LOC(e3v)
         ENDIF
      ENDIF
-     IF ( ll_u ) THEN
-        zu = getvar3d(cf_ufil, cn_vozocrtx, npiglo, npjglo, npk, ktime=jt)
+     IF ( ll_u .AND. lfeed ) THEN
+        CALL feed_field(cf_ufil, cn_vozocrtx, pd_zu, npiglo, npjglo, npk, ktime=jt)
+        IF ( .NOT. lfull .AND. ( jt == 1 .OR. lg_vvl ) ) CALL feed_field(cn_fe3u, cn_ve3u, pd_e3u, npiglo, npjglo, npk, ktime=it, &
+             &                                                             ldiom=.NOT. lg_vvl)
+        pzu = pd_zu ; pe2u = pd_e2u ; pe3u = pd_e3u
+     ELSE IF ( ll_u ) THEN
+        CALL readvar3d(cf_ufil, cn_vozocrtx, zu, ktime=jt)
         pzu = C_LOC(zu) ; pe2u = C_LOC(e2u)
         IF ( .NOT. lfull ) THEN
            IF ( jt == 1 .OR. lg_vvl ) THEN
@@ -218,9 +252,8 @@ PROGRAM cdfpsi
         ENDIF
      ENDIF
      pdpsi = C_NULL_PTR ; IF ( lssh ) pdpsi = C_LOC(dpsi)
-     CALL hip_check(cdft_psi_integrate(plan, pzu, pe2u, pe3u, pzv, pe1v, pe3v, pe31d, CDFT_MEM_HOST, C_NULL_PTR), &
-          &         'cdft_psi_integrate')
-     CALL scan_and_finish(plan, 0_C_INT, pdpsi)           ! dpsi = dpsi - dpsi(iiref,ijref), SNGL, mask (:423-438)
+     CALL hip_check(cdft_psi_integrate(plan, pzu, pe2u, pe3u, pzv, pe1v, pe3v, pe31d, nspace, pstream), 'cdft_psi_integrate')
+     CALL scan_and_finish(plan, 0_C_INT, pdpsi, pmask, nspace, pstream)   ! dpsi = dpsi - dpsi(iiref,ijref), SNGL, mask (:423-438)
      IF ( lmask ) THEN ; PRINT *, ' Write masked BSF'
      ELSE              ; PRINT *, ' Write BSF'
      ENDIF
@@ -232,13 +265,17 @@ PROGRAM cdfpsi
         zsshv(:, 1:npjglo-1) = 0.5*( zssh(:,2:npjglo) + zssh(:,1:npjglo-1) )
         ! the reference multiplies BOTH contributions by zv(:,:), the meridional velocity of level 1
         ! (:299 uses zv where zu was meant); zv is never assigned without the V component: taken as 0
-        zvel1(:,:) = 0.0 ; IF ( ll_v ) zvel1(:,:) = zv(:,:,1)
+        zvel1(:,:) = 0.0
+        IF ( ll_v .AND. lfeed ) THEN ; zvel1(:,:) = getvar(cf_vfil, cn_vomecrty, 1, npiglo, npjglo, ktime=jt)
+        ELSE IF ( ll_v )        THEN ; zvel1(:,:) = zv(:,:,1)
+        ENDIF
         pzu = C_NULL_PTR ; pe2u = C_NULL_PTR ; pe3u = C_NULL_PTR ; pzv = C_NULL_PTR ; pe1v = C_NULL_PTR ; pe3v = C_NULL_PTR
         IF ( ll_u ) THEN ; pzu = C_LOC(zvel1) ; pe2u = C_LOC(e2u) ; pe3u = C_LOC(zsshu) ; ENDIF
         IF ( ll_v ) THEN ; pzv = C_LOC(zvel1) ; pe1v = C_LOC(e1v) ; pe3v = C_LOC(zsshv) ; ENDIF
         CALL hip_check(cdft_psi_integrate(plan1, pzu, pe2u, pe3u, pzv, pe1v, pe3v, C_NULL_PTR, CDFT_MEM_HOST, C_NULL_PTR), &
              &         'cdft_psi_integrate')
-        CALL scan_and_finish(plan1, 1_C_INT, C_LOC(dpsissh))   ! the SSH part is not referenced to (iiref,ijref)
+        pmask1 = C_NULL_PTR ; IF ( lmask ) pmask1 = C_LOC(zmask)
+        CALL scan_and_finish(plan1, 1_C_INT, C_LOC(dpsissh), pmask1, CDFT_MEM_HOST, C_NULL_PTR)   ! the SSH part is not referenced to (iiref,ijref)
         ierr = putvar(ncout, id_varout(2), zpsi, 1, npiglo, npjglo, ktime=jt)
         IF ( lmask ) THEN ; zpsi(:,:) = SNGL(dpsissh + dpsi) * zmask(:,:)
         ELSE              ; zpsi(:,:) = SNGL(dpsissh + dpsi)
@@ -248,23 +285,29 @@ PROGRAM cdfpsi
   END DO
   IF ( lssh .OR. llev ) ierr = cdft_psi_destroy(plan1)
   ierr = cdft_psi_destroy(plan)
+  IF ( lfeed ) THEN
+     CALL feed_release(pd_zu) ; CALL feed_release(pd_zv) ; CALL feed_release(pd_e3u) ; CALL feed_release(pd_e3v)
+     CALL feed_release(pd_e2u) ; CALL feed_release(pd_e1v) ; CALL feed_release(pd_e31d) ; CALL feed_release(pd_mask)
+     CALL feed_close()
+  ENDIF
   ierr = closeout(ncout)
 
 CONTAINS
 
-  SUBROUTINE scan_and_finish(kplan, knoref, pd8)
+  SUBROUTINE scan_and_finish(kplan, knoref, pd8, pd_msk, kmskspace, pd_stream)
     !! scans of the transports held by kplan (closed domain or -open), then reference point, SNGL and mask
-    !! into zpsi; knoref = 1: no reference point (value 0 is subtracted); pd8: optional r8 copy of psi
-    TYPE(C_PTR),    INTENT(in) :: kplan, pd8
-    INTEGER(C_INT), INTENT(in) :: knoref
+    !! into zpsi; knoref = 1: no reference point (value 0 is subtracted); pd8: optional r8 copy of psi; pd_msk: the mask
+    !! (NULL: none) in memory space kmskspace; pd_stream: the stream of this plan's calls
+    TYPE(C_PTR),    INTENT(in) :: kplan, pd8, pd_msk, pd_stream
+    INTEGER(C_INT), INTENT(in) :: knoref, kmskspace
     IF ( lopen ) THEN
-       CALL hip_check(cdft_psi_scan_open(kplan, MERGE(1_C_INT, 0_C_INT, lmean), C_NULL_PTR), 'cdft_psi_scan_open')
+       CALL hip_check(cdft_psi_scan_open(kplan, MERGE(1_C_INT, 0_C_INT, lmean), pd_stream), 'cdft_psi_scan_open')
     ELSE
-       CALL hip_check(cdft_psi_scan_u(kplan, C_NULL_PTR, CDFT_MEM_HOST, 1_C_INT, C_NULL_PTR, CDFT_MEM_HOST, C_NULL_PTR), &
+       CALL hip_check(cdft_psi_scan_u(kplan, C_NULL_PTR, CDFT_MEM_HOST, 1_C_INT, C_NULL_PTR, CDFT_MEM_HOST, pd_stream), &
             &         'cdft_psi_scan_u')
     ENDIF
-    CALL hip_check(cdft_psi_finish(kplan, knoref, 0.d0, INT(iiref, C_INT), INT(ijref, C_INT), pmask, CDFT_MEM_HOST, zpsi, &
-         &         pd8, CDFT_MEM_HOST, C_NULL_PTR), 'cdft_psi_finish')
+    CALL hip_check(cdft_psi_finish(kplan, knoref, 0.d0, INT(iiref, C_INT), INT(ijref, C_INT), pd_msk, kmskspace, zpsi, &
+         &         pd8, CDFT_MEM_HOST, pd_stream), 'cdft_psi_finish')
   END SUBROUTINE scan_and_finish
 
   SUBROUTINE level_psi(cd_file, cd_var, cd_fe3, cd_ve3, ld_u)
@@ -286,7 +329,8 @@ CONTAINS
        CALL hip_check(cdft_psi_integrate(plan1, C_NULL_PTR, C_NULL_PTR, C_NULL_PTR, C_LOC(zlev), C_LOC(e1v), pl_e3, pl_1d, &
             &         CDFT_MEM_HOST, C_NULL_PTR), 'cdft_psi_integrate')
     ENDIF
-    CALL scan_and_finish(plan1, 1_C_INT, C_NULL_PTR)
+    pmask1 = C_NULL_PTR ; IF ( lmask ) pmask1 = C_LOC(zmask)
+    CALL scan_and_finish(plan1, 1_C_INT, C_NULL_PTR, pmask1, CDFT_MEM_HOST, C_NULL_PTR)
     ! the reference creates the file with ONE level (:497) and ignores the status of the writes that
     ! do not fit: only level 1 reaches the file there, and here
     ierr = putvar(ncout, id_varout(1), zpsi, jk, npiglo, npjglo, ktime=jt)

@@ -93,8 +93,8 @@ PROGRAM cdfsig0
 
   DO jt = 1, npt
      PRINT *, ' TIME = ', jt, dtim(jt) / 86400., ' days'
-     ztemp = getvar3d(cf_tfil, cv_tem, npiglo, npjglo, npkk, ktime=jt)
-     zsal  = getvar3d(cf_sfil, cv_sal, npiglo, npjglo, npkk, ktime=jt)
+     CALL readvar3d(cf_tfil, cv_tem, ztemp, ktime=jt)
+     CALL readvar3d(cf_sfil, cv_sal, zsal, ktime=jt)
      CALL hip_check(cdft_eos_sig_tool(ztemp, zsal, INT(npiglo, C_INT64_T) * npjglo * npkk, 0.0, zsps,            &
           &         MERGE(CDFT_EOS_TEOS10, CDFT_EOS_80, ll_teos10), 0_C_INT, zsig0, CDFT_MEM_HOST, CDFT_MEM_HOST, &
           &         C_NULL_PTR), 'cdft_eos_sig_tool')

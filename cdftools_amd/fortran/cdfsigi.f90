@@ -91,8 +91,8 @@ PROGRAM cdfsigi
 
   DO jt = 1, npt
      PRINT *, 'time: ', jt
-     ztemp = getvar3d(cf_tfil, cv_tem, npiglo, npjglo, npkk, ktime=jt)
-     zsal  = getvar3d(cf_sfil, cv_sal, npiglo, npjglo, npkk, ktime=jt)
+     CALL readvar3d(cf_tfil, cv_tem, ztemp, ktime=jt)
+     CALL readvar3d(cf_sfil, cv_sal, zsal, ktime=jt)
      CALL hip_check(cdft_eos_sig_tool(ztemp, zsal, INT(npiglo, C_INT64_T) * npjglo * npkk, ref_dep, zsps,           &
           &         MERGE(CDFT_EOS_TEOS10, CDFT_EOS_80, ll_teos10), 0_C_INT, zsigi, CDFT_MEM_HOST, CDFT_MEM_HOST, &
           &         C_NULL_PTR), 'cdft_eos_sig_tool')

@@ -61,6 +61,9 @@ MODULE cdftools_hip
      INTEGER(C_INT) FUNCTION cdft_feed_create(feed, slot_bytes, nslots) BIND(C, name='cdft_feed_create')
        IMPORT ; TYPE(C_PTR), INTENT(out) :: feed ; INTEGER(C_SIZE_T), VALUE :: slot_bytes ; INTEGER(C_INT), VALUE :: nslots
      END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_feed_resize(feed, slot_bytes, nslots) BIND(C, name='cdft_feed_resize')
+       IMPORT ; TYPE(C_PTR), VALUE :: feed ; INTEGER(C_SIZE_T), VALUE :: slot_bytes ; INTEGER(C_INT), VALUE :: nslots
+     END FUNCTION
      INTEGER(C_INT) FUNCTION cdft_feed_slot(feed, host, slot_bytes) BIND(C, name='cdft_feed_slot')
        IMPORT ; TYPE(C_PTR), VALUE :: feed ; TYPE(C_PTR), INTENT(out) :: host ; INTEGER(C_SIZE_T), INTENT(out) :: slot_bytes
      END FUNCTION

@@ -15,6 +15,7 @@ PROGRAM cdfvT
   USE modcdfnames
   USE modutils
   USE cdftools_hip
+  USE cdffeed
   IMPLICIT NONE
 
   INTEGER(C_INT)  :: ngpu, igpus(64)                          ! row blocks and their HIP devices (CDFT_GPUS, CDFT_GPU_MAP)
@@ -28,7 +29,11 @@ PROGRAM cdfvT
   CHARACTER(LEN=256), ALLOCATABLE :: ctag_lst(:)
   TYPE(variable), ALLOCATABLE :: stypvar(:)
   TYPE(C_PTR) :: pe3u, pe3v, pe3um, pe3vm
-  LOGICAL :: lnc4 = .FALSE.
+  ! the frames of one level in HBM when they are fed there through the ring (module cdffeed): never touched by the host
+  TYPE(C_PTR) :: pd_u = C_NULL_PTR, pd_v = C_NULL_PTR, pd_t = C_NULL_PTR, pd_s = C_NULL_PTR, pd_e3u = C_NULL_PTR, pd_e3v = C_NULL_PTR
+  REAL(KIND=4), POINTER :: zu_d(:), zv_d(:), zt_d(:), zs_d(:)
+  INTEGER(KIND=8) :: nfr8
+  LOGICAL :: lnc4 = .FALSE., lfeed = .FALSE.
   !!----------------------------------------------------------------------
   CALL ReadCdfNames()
   narg = COMMAND_ARGUMENT_COUNT()
@@ -104,16 +109,31 @@ PROGRAM cdfvT
      ntframe = ntframe + npt
   END DO
 
-  ALLOCATE( zu(npiglo,npjglo,ntframe), zv(npiglo,npjglo,ntframe), zt(npiglo,npjglo,ntframe), zs(npiglo,npjglo,ntframe) )
+  CALL hip_shard(ngpu, igpus)                                ! CDFT_GPUS / CDFT_GPU_MAP
+  lfeed = feed_wanted(4_8 * npiglo * npjglo * ntframe) .AND. ngpu == 1                      ! one device: every slab file -> HBM through the ring (module cdffeed)
+  nfr8 = 4_8 * npiglo * npjglo * ntframe
+  IF ( lfeed ) THEN
+     pd_u = feed_device(nfr8) ; pd_v = feed_device(nfr8) ; pd_t = feed_device(nfr8) ; pd_s = feed_device(nfr8)
+     CALL C_F_POINTER(pd_u, zu_d, (/ nfr8 / 4 /)) ; CALL C_F_POINTER(pd_v, zv_d, (/ nfr8 / 4 /))
+     CALL C_F_POINTER(pd_t, zt_d, (/ nfr8 / 4 /)) ; CALL C_F_POINTER(pd_s, zs_d, (/ nfr8 / 4 /))
+  ELSE
+     ALLOCATE( zu(npiglo,npjglo,ntframe), zv(npiglo,npjglo,ntframe), zt(npiglo,npjglo,ntframe), zs(npiglo,npjglo,ntframe) )
+  ENDIF
   ALLOCATE( dvt(npiglo,npjglo), dvs(npiglo,npjglo), dut(npiglo,npjglo), dus(npiglo,npjglo) )
   ALLOCATE( stypvar(nvaro), ipk(nvaro), id_varout(nvaro) )
   pe3u = C_NULL_PTR ; pe3v = C_NULL_PTR ; pe3um = C_NULL_PTR ; pe3vm = C_NULL_PTR
   IF ( lg_vvl ) THEN
-     ALLOCATE( e3u(npiglo,npjglo,ntframe), e3v(npiglo,npjglo,ntframe), de3u(npiglo,npjglo), de3v(npiglo,npjglo) )
-     pe3u = C_LOC(e3u) ; pe3v = C_LOC(e3v) ; pe3um = C_LOC(de3u) ; pe3vm = C_LOC(de3v)
+     ALLOCATE( de3u(npiglo,npjglo), de3v(npiglo,npjglo) )
+     pe3um = C_LOC(de3u) ; pe3vm = C_LOC(de3v)
+     IF ( lfeed ) THEN
+        pd_e3u = feed_device(nfr8) ; pd_e3v = feed_device(nfr8)
+        pe3u = pd_e3u ; pe3v = pd_e3v
+     ELSE
+        ALLOCATE( e3u(npiglo,npjglo,ntframe), e3v(npiglo,npjglo,ntframe) )
+        pe3u = C_LOC(e3u) ; pe3v = C_LOC(e3v)
+     ENDIF
   ENDIF
   cf_tfil = SetFileName(config, ctag_lst(1), 'T')
-  CALL hip_shard(ngpu, igpus)                                ! CDFT_GPUS / CDFT_GPU_MAP
   CALL CreateOutput
 
   DO jk = 1, npk
@@ -127,6 +147,17 @@ PROGRAM cdfvT
         cf_vfil = SetFileName(config, ctag_lst(jt), 'V')
         DO jtt = 1, nptag(jt)
            ifr = ifr + 1
+           IF ( lfeed ) THEN                              ! the slab leaves for HBM while the next one is read
+              CALL feed_field(cf_ufil, cn_vozocrtx, pd_u, npiglo, npjglo, 1, ktime=jtt, kkmin=jk, kplane=ifr)
+              CALL feed_field(cf_vfil, cn_vomecrty, pd_v, npiglo, npjglo, 1, ktime=jtt, kkmin=jk, kplane=ifr)
+              CALL feed_field(cf_tfil, cn_votemper, pd_t, npiglo, npjglo, 1, ktime=jtt, kkmin=jk, kplane=ifr)
+              CALL feed_field(cf_sfil, cn_vosaline, pd_s, npiglo, npjglo, 1, ktime=jtt, kkmin=jk, kplane=ifr)
+              IF ( lg_vvl ) THEN
+                 CALL feed_field(cf_ufil, cn_ve3u, pd_e3u, npiglo, npjglo, 1, ktime=jtt, kkmin=jk, kplane=ifr)
+                 CALL feed_field(cf_vfil, cn_ve3v, pd_e3v, npiglo, npjglo, 1, ktime=jtt, kkmin=jk, kplane=ifr)
+              ENDIF
+              CYCLE
+           ENDIF
            zu(:,:,ifr) = getvar(cf_ufil, cn_vozocrtx, jk, npiglo, npjglo, ktime=jtt)
            zv(:,:,ifr) = getvar(cf_vfil, cn_vomecrty, jk, npiglo, npjglo, ktime=jtt)
            zt(:,:,ifr) = getvar(cf_tfil, cn_votemper, jk, npiglo, npjglo, ktime=jtt)
@@ -141,6 +172,10 @@ PROGRAM cdfvT
         CALL hip_check(cdft_vt_compute_sharded(zu, zv, zt, zs, pe3u, pe3v, INT(npiglo, C_INT64_T) * npjglo, ntframe, npiglo,  &
              &         npjglo, 1_C_INT, C_LOC(dvt), C_LOC(dvs), C_LOC(dut), C_LOC(dus), pe3um, pe3vm, 0_C_INT, ngpu, igpus),  &
              &         'cdft_vt_compute_sharded')
+     ELSE IF ( lfeed ) THEN
+        CALL hip_check(cdft_vt_compute(zu_d, zv_d, zt_d, zs_d, pe3u, pe3v, INT(npiglo, C_INT64_T) * npjglo, ntframe, npiglo, npjglo, &
+             &         1_C_INT, CDFT_MEM_DEVICE, C_LOC(dvt), C_LOC(dvs), C_LOC(dut), C_LOC(dus), pe3um, pe3vm, 0_C_INT,              &
+             &         CDFT_MEM_HOST, feed_stream), 'cdft_vt_compute')
      ELSE
      CALL hip_check(cdft_vt_compute(zu, zv, zt, zs, pe3u, pe3v, INT(npiglo, C_INT64_T) * npjglo, ntframe, npiglo, npjglo,   &
           &         1_C_INT, CDFT_MEM_HOST, C_LOC(dvt), C_LOC(dvs), C_LOC(dut), C_LOC(dus), pe3um, pe3vm, 0_C_INT,         &
@@ -159,6 +194,11 @@ PROGRAM cdfvT
         ierr = putvar1d(ncout, dtimean, 1, 'T')
      ENDIF
   END DO
+  IF ( lfeed ) THEN
+     CALL feed_release(pd_u) ; CALL feed_release(pd_v) ; CALL feed_release(pd_t) ; CALL feed_release(pd_s)
+     CALL feed_release(pd_e3u) ; CALL feed_release(pd_e3v)
+     CALL feed_close()
+  ENDIF
   ierr = closeout(ncout)
 
 CONTAINS

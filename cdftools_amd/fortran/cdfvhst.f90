@@ -111,15 +111,15 @@ PROGRAM cdfvhst
         PRINT *, 'level ', jk, ' time ', jt
      END DO
      ! meridional components with e1v, e3v
-     zt = getvar3d(cf_vtfil, cn_vomevt, npiglo, npjglo, npk, ktime=jt)
-     zs = getvar3d(cf_vtfil, cn_vomevs, npiglo, npjglo, npk, ktime=jt)
+     CALL readvar3d(cf_vtfil, cn_vomevt, zt, ktime=jt)
+     CALL readvar3d(cf_vtfil, cn_vomevs, zs, ktime=jt)
      CALL hip_check(cdft_vhst_transport(zt, zs, e1v, pe3v, pe31d, npiglo, npjglo, npk, CDFT_MEM_HOST, dtrpt, dtrps, &
           &         CDFT_MEM_HOST, C_NULL_PTR), 'cdft_vhst_transport')
      ierr = putvar(ncout, id_varout(1), SNGL(dtrpt), 1, npiglo, npjglo, ktime=jt)
      ierr = putvar(ncout, id_varout(2), SNGL(dtrps), 1, npiglo, npjglo, ktime=jt)
      ! zonal components with e2u, e3u
-     zt = getvar3d(cf_vtfil, cn_vozout, npiglo, npjglo, npk, ktime=jt)
-     zs = getvar3d(cf_vtfil, cn_vozous, npiglo, npjglo, npk, ktime=jt)
+     CALL readvar3d(cf_vtfil, cn_vozout, zt, ktime=jt)
+     CALL readvar3d(cf_vtfil, cn_vozous, zs, ktime=jt)
      CALL hip_check(cdft_vhst_transport(zt, zs, e2u, pe3u, pe31d, npiglo, npjglo, npk, CDFT_MEM_HOST, dtrpt, dtrps, &
           &         CDFT_MEM_HOST, C_NULL_PTR), 'cdft_vhst_transport')
      ierr = putvar(ncout, id_varout(3), SNGL(dtrpt), 1, npiglo, npjglo, ktime=jt)

@@ -133,8 +133,8 @@ PROGRAM cdfvtrp
      DO jk = 1, npk
         PRINT *, 'level ', jk
      END DO
-     zu = getvar3d(cf_ufil, cn_vozocrtx, npiglo, npjglo, npk, ktime=jt)
-     zv = getvar3d(cf_vfil, cn_vomecrty, npiglo, npjglo, npk, ktime=jt)
+     CALL readvar3d(cf_ufil, cn_vozocrtx, zu, ktime=jt)
+     CALL readvar3d(cf_vfil, cn_vomecrty, zv, ktime=jt)
      CALL hip_check(cdft_vint_transport(zu, e2u, pe3u, pe31d, npiglo, npjglo, npk, CDFT_MEM_HOST, dtrpu, CDFT_MEM_HOST, &
           &         C_NULL_PTR), 'cdft_vint_transport')
      CALL hip_check(cdft_vint_transport(zv, e1v, pe3v, pe31d, npiglo, npjglo, npk, CDFT_MEM_HOST, dtrpv, CDFT_MEM_HOST, &

@@ -74,6 +74,7 @@ int         cdft_host_free(void *ptr);
  * per GB and a copy runs at 57 GB/s either way (tools/pin_probe.hip) -- hence a small ring, not page-locked records. */
 typedef struct cdft_feed cdft_feed;
 int         cdft_feed_create(cdft_feed **feed, size_t slot_bytes, int nslots);
+int         cdft_feed_resize(cdft_feed *feed, size_t slot_bytes, int nslots);   /* other slots, the same stream (waits for it) */
 int         cdft_feed_slot(cdft_feed *feed, void **host, size_t *slot_bytes);
 int         cdft_feed_push(cdft_feed *feed, void *dst, size_t dst_offset, size_t bytes);
 int         cdft_feed_stream(cdft_feed *feed, void **stream);

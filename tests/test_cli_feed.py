@@ -1,0 +1,108 @@
+"""The host feed (module cdffeed, cdft_feed_* of the C ABI): the programs that have it -- cdfmoc, cdfheatc, cdfpsi, cdfvT,
+cdfmhst -- send their 3-D fields from the file to HBM slab by slab through a page-locked ring when the fields are large
+(from 1 GiB on) and as whole records in pageable memory otherwise.  The route must not show: for every option that
+touches it, CDFT_FEED=1 and CDFT_FEED=0 give the same stdout and byte-identical files (the pageable route is the one the
+other program tests hold against the oracle).  A ring with one plane per slot and two slots (CDFT_FEED_MB / _SLOTS) makes
+every slot wrap around many times per field."""
+import os
+
+import pytest
+
+import lift_cases as lc
+import nemo_files
+from test_cli import run, tools  # noqa: F401  (tools is a fixture)
+
+
+@pytest.fixture(scope="module")
+def case(tools, tmp_path_factory):  # noqa: F811
+    d = str(tmp_path_factory.mktemp("feed"))
+    g, rec = nemo_files.make_case(d, npi=26, npj=19, npk=6, npt=3)
+    e3 = {p: lc.e3_records(g[f"e3{p}_0"], 3, 8100 + i) for i, p in enumerate("tuv")}
+    nemo_files.write_data(os.path.join(d, "VVL_y0001_gridV.nc"), g, "depthv", {"vomecrty": rec["v"], "e3v": e3["v"]})
+    nemo_files.write_data(os.path.join(d, "VVL_y0001_gridU.nc"), g, "depthu", {"vozocrtx": rec["u"], "e3u": e3["u"]})
+    nemo_files.write_data(os.path.join(d, "VVL_y0001_gridT.nc"), g, "deptht", {"votemper": rec["t"], "vosaline": rec["s"], "e3t": e3["t"]},
+                          fill=0.0)
+    mxl = (5 + 200 * abs(rec["t"][:, 0]) / 30).astype("float32")
+    nemo_files.write_data(os.path.join(d, "mxl.nc"), g, "deptht", {"somxl010": mxl})
+    nemo_files.write_data(os.path.join(d, "ssh.nc"), g, "deptht", {"sossheig": (rec["t"][:, 0] / 30 - 0.5).astype("float32")})
+    return d
+
+
+V, U, T = "SYN_y0001_gridV.nc", "SYN_y0001_gridU.nc", "SYN_y0001_gridT.nc"
+RUNS = [
+    ("cdfmoc", ["-v", V], ["moc.nc"]),
+    ("cdfmoc", ["-v", "VVL_y0001_gridV.nc", "-vvl"], ["moc.nc"]),
+    ("cdfheatc", ["-f", T], ["heatc.nc"]),
+    ("cdfheatc", ["-f", T, "-full"], ["heatc.nc"]),
+    ("cdfheatc", ["-f", "VVL_y0001_gridT.nc", "-vvl"], ["heatc.nc"]),
+    ("cdfheatc", ["-f", T, "-zoom", "20", "30", "2", "9", "2", "4"], ["heatc.nc"]),          # a window over the eastern edge
+    ("cdfheatc", ["-f", T, "-mxloption", "1", "-mxlf", "mxl.nc"], ["heatc.nc"]),
+    ("cdfpsi", ["-u", U, "-v", V], ["psi.nc"]),
+    ("cdfpsi", ["-u", U, "-v", V, "-V"], ["psi.nc"]),
+    ("cdfpsi", ["-u", U, "-v", V, "-mean", "-mask", "-ref", "5", "4"], ["psi.nc"]),
+    ("cdfpsi", ["-u", U, "-v", V, "-full"], ["psi.nc"]),
+    ("cdfpsi", ["-u", U, "-v", V, "-open"], ["psi.nc"]),
+    ("cdfpsi", ["-u", U, "-v", V, "-mean", "--ssh-file", "ssh.nc"], ["psi.nc"]),
+    ("cdfpsi", ["-u", U, "-v", V, "-mean", "--ssh-file", "nothere.nc"], None),                   # both routes stop alike
+    ("cdfpsi", ["-u", "VVL_y0001_gridU.nc", "-v", "VVL_y0001_gridV.nc", "-vvl", "-mean"], ["psi.nc"]),
+    ("cdfvT", ["-c", "SYN", "-l", "y0001"], ["vt.nc"]),
+    ("cdfvT", ["-c", "VVL", "-l", "y0001", "-vvl"], ["vt.nc"]),
+    ("cdfmhst", ["-vt", "vt_keep.nc", "-MST"], ["mhst.nc", "zonal_heat_trp.dat", "zonal_salt_trp.dat"]),
+    ("cdfmhst", ["-vt", "vt_keep.nc", "-MST", "-Zdim", "-full"], ["mhst.nc"]),
+    ("cdfmhst", ["-v", V, "-t", T, "-MST"], ["mhst.nc"]),
+    ("cdfmhst", ["-v", "VVL_y0001_gridV.nc", "-t", "VVL_y0001_gridT.nc", "-vvl"], ["mhst.nc"]),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ring", [{}, {"CDFT_FEED_MB": "0.0001", "CDFT_FEED_SLOTS": "2"}], ids=["default_ring", "one_plane_two_slots"])
+def test_both_routes_give_the_same_stdout_and_files(case, ring):
+    d = case
+    rc, out, err = run("cdfvT", ["-c", "SYN", "-l", "y0001", "-o", "vt_keep.nc"], d, env={"CDFT_FEED": "0"})
+    assert rc == 0, out + err
+    for tool, args, files in RUNS:
+        res = {}
+        for feed in ("0", "1"):
+            rc, out, err = run(tool, args, d, env=dict(ring, CDFT_FEED=feed))
+            data = {f: open(os.path.join(d, f), "rb").read() for f in (files or [])} if rc == 0 else {}
+            for f in data:
+                os.remove(os.path.join(d, f))
+            res[feed] = (rc, out, data)
+        assert res["0"][0] == res["1"][0] and (files is None or res["1"][0] == 0), (tool, args, res["1"][1][-400:])
+        assert res["0"][1] == res["1"][1], (tool, args)
+        assert res["0"][2] == res["1"][2], (tool, args)
+
+
+@pytest.mark.gpu
+def test_the_feed_ring_of_the_c_abi(gpu):
+    """cdft_feed_*: slots handed out in turn, a slot reused only after its copy has left it, copies ordered before work queued
+    on the feed's stream; resize keeps the stream"""
+    import ctypes as C
+
+    import numpy as np
+    import torch
+    from cdftools_amd import _lib
+    lib = _lib.load()
+    feed, st, st2 = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    gpu.check(lib.cdft_feed_create(C.byref(feed), 4096, 2))
+    gpu.check(lib.cdft_feed_stream(feed, C.byref(st)))
+    gpu.check(lib.cdft_feed_resize(feed, 1 << 20, 3))
+    gpu.check(lib.cdft_feed_stream(feed, C.byref(st2)))
+    assert st.value == st2.value
+    n = 37
+    want = np.arange(n * (1 << 18), dtype=np.float32)
+    dst = torch.zeros(want.size, dtype=torch.float32, device="cuda")
+    seen = []
+    for i in range(n):
+        host, nb = C.c_void_p(), C.c_size_t()
+        gpu.check(lib.cdft_feed_slot(feed, C.byref(host), C.byref(nb)))
+        assert nb.value == 1 << 20
+        seen.append(host.value)
+        np.frombuffer((C.c_char * (1 << 20)).from_address(host.value), dtype=np.float32)[:] = want[i << 18:(i + 1) << 18]
+        gpu.check(lib.cdft_feed_push(feed, C.c_void_p(dst.data_ptr()), i << 20, 1 << 20))
+    assert seen[:3] == seen[3:6] and len(set(seen)) == 3
+    gpu.check(lib.cdft_feed_wait(feed))
+    assert np.array_equal(dst.cpu().numpy(), want)
+    with pytest.raises(gpu.CdftError):
+        gpu.check(lib.cdft_feed_push(feed, C.c_void_p(dst.data_ptr()), 0, (1 << 20) + 1))
+    gpu.check(lib.cdft_feed_destroy(feed))

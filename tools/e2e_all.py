@@ -55,13 +55,33 @@ def main():
     nemo_files.make_case(d, npi=npi, npj=npj, npk=npk, npt=args.npt)
     gen = time.perf_counter() - t0
     bad = 0
-    for tool, a in RUNS:
+
+    def once(tool, a, env, keep):
+        """-> (completed process, wall, {file: sha1} of what the run wrote); the files are removed again unless keep"""
+        import hashlib
+        before = {f: os.path.getmtime(os.path.join(d, f)) for f in os.listdir(d)}
         t0 = time.perf_counter()
-        r = subprocess.run([os.path.join(ROOT, "cdftools_amd", "bin", tool)] + a, cwd=d, capture_output=True, text=True)
+        r = subprocess.run([os.path.join(ROOT, "cdftools_amd", "bin", tool)] + a, cwd=d, capture_output=True, text=True, env=env)
         wall = time.perf_counter() - t0
-        ok = r.returncode == 0
+        wrote = {}
+        for f in sorted(os.listdir(d)):
+            p = os.path.join(d, f)
+            if os.path.isfile(p) and before.get(f) != os.path.getmtime(p):
+                wrote[f] = hashlib.sha1(open(p, "rb").read()).hexdigest()
+                if not keep:
+                    os.remove(p)
+        return r, wall, wrote
+
+    for tool, a in RUNS:
+        # CDFT_FEED=0: whole records in pageable host memory, read THEN transferred (the way of rounds 1-2); default: slabs
+        # through the page-locked ring of module cdffeed where the program has it.  Same stdout, same files?  (Each run
+        # creates its output files: the first run's are removed before the second.)
+        r0, w0, f0 = once(tool, a, dict(os.environ, CDFT_FEED="0"), False)
+        r, wall, f1 = once(tool, a, dict(os.environ), True)
+        ok = r.returncode == 0 and r0.returncode == 0
         bad += not ok
-        line = {"tool": tool, "args": " ".join(a), "grid": args.grid, "rc": r.returncode, "wall_s": round(wall, 3)}
+        line = {"tool": tool, "args": " ".join(a), "grid": args.grid, "rc": r.returncode, "wall_s": round(wall, 3),
+                "wall_s_feed_off": round(w0, 3), "same_stdout": r.stdout == r0.stdout, "same_files": f0 == f1, "files": sorted(f1)}
         if not ok:
             line["tail"] = (r.stdout[-600:] + r.stderr[-300:])
         print(json.dumps(line), flush=True)
