@@ -106,6 +106,7 @@ SIGNATURES = {
     "cdft_zonal_create": (_i, [_pvp, _i, _i, _i, _i]),
     "cdft_zonal_set_mesh": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "cdft_zonal_compute": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
+    "cdft_zonal_area": (_i, [_vp, _i, _vp, _i, _vp]),
     "cdft_zonal_destroy": (_i, [_vp]),
     "cdft_vint_cumul": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, C.c_float, _i, _i, _vp, _i, _vp]),
     "cdft_vertmean": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, C.c_float, C.c_float, C.c_float, C.c_float, _i, _vp, _i, _vp]),

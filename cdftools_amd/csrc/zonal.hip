@@ -576,7 +576,9 @@ int cdft_zonal_compute(cdft_zonal_plan *p, const float *zv, int nlev, int in_spa
     if (!p || !zv || !dzo) return fail(CDFT_ERR_ARG, "cdft_zonal_compute: NULL argument");
     if (!p->mesh_set) return fail(CDFT_ERR_STATE, "cdft_zonal_compute: cdft_zonal_set_mesh has not succeeded");
     if (nlev < 1 || nlev > p->npk) return fail(CDFT_ERR_ARG, "cdft_zonal_compute: nlev = %d outside 1..%d", nlev, p->npk);
-    if (mean_form && !darea) return fail(CDFT_ERR_ARG, "cdft_zonal_compute: the mean form needs darea");
+    if (out_space != CDFT_MEM_HOST && out_space != CDFT_MEM_DEVICE && out_space != CDFT_MEM_PINNED)
+        return fail(CDFT_ERR_ARG, "cdft_zonal_compute: bad memory-space tag %d", out_space);
+    const bool to_host = out_space != CDFT_MEM_DEVICE;
     const bool minmax = rzomax != nullptr || rzomin != nullptr;
     if (minmax && (!rzomax || !rzomin || !mean_form))
         return fail(CDFT_ERR_ARG, "cdft_zonal_compute: rzomax and rzomin go together, with the mean form");
@@ -593,7 +595,7 @@ int cdft_zonal_compute(cdft_zonal_plan *p, const float *zv, int nlev, int in_spa
     }
     a.npi = p->npi; a.npj = p->npj; a.nlev = nlev; a.nb = p->nb;
     a.dsum = dzo; a.darea = darea; a.rmax = rzomax; a.rmin = rzomin;
-    if (out_space == CDFT_MEM_HOST) {
+    if (to_host) {
         CDFT_TRY(p->st_o[0].reserve(n * 8)); a.dsum = (double *)p->st_o[0].ptr;
         if (minmax) {
             CDFT_TRY(p->st_o[2].reserve(n * 4)); CDFT_TRY(p->st_o[3].reserve(n * 4));
@@ -620,17 +622,28 @@ int cdft_zonal_compute(cdft_zonal_plan *p, const float *zv, int nlev, int in_spa
     else if (p->nb <= 5) CDFT_TRY(launch_rows<5>(a, only, mean_form != 0, minmax, st));
     else                 CDFT_TRY(launch_rows<8>(a, only, mean_form != 0, minmax, st));
     }
-    if (mean_form)      // the first nlev levels of every basin's precomputed area (a pitched copy: measured faster than plain ones)
+    if (mean_form && darea)      // the first nlev levels of every basin's precomputed area (a pitched copy: measured faster than plain ones)
         CDFT_HIP(hipMemcpy2DAsync(darea, (size_t)nlev * p->npj * 8, p->area, (size_t)p->npk * p->npj * 8, (size_t)nlev * p->npj * 8,
-                                  p->nb, out_space == CDFT_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, st));
-    if (out_space == CDFT_MEM_HOST) {
+                                  p->nb, to_host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, st));
+    if (to_host) {
         CDFT_HIP(hipMemcpyAsync(dzo, a.dsum, n * 8, hipMemcpyDeviceToHost, st));
         if (minmax) {
             CDFT_HIP(hipMemcpyAsync(rzomax, a.rmax, n * 4, hipMemcpyDeviceToHost, st));
             CDFT_HIP(hipMemcpyAsync(rzomin, a.rmin, n * 4, hipMemcpyDeviceToHost, st));
         }
-        CDFT_HIP(hipStreamSynchronize(st));
+        if (out_space == CDFT_MEM_HOST) CDFT_HIP(hipStreamSynchronize(st));      // (page-locked results: the caller synchronises)
     }
+    return CDFT_OK;
+}
+
+int cdft_zonal_area(cdft_zonal_plan *p, int nlev, double *darea, int out_space, void *stream) {
+    if (!p || !darea) return fail(CDFT_ERR_ARG, "cdft_zonal_area: NULL argument");
+    if (!p->mesh_set) return fail(CDFT_ERR_STATE, "cdft_zonal_area: cdft_zonal_set_mesh has not succeeded");
+    if (nlev < 1 || nlev > p->npk) return fail(CDFT_ERR_ARG, "cdft_zonal_area: nlev = %d outside 1..%d", nlev, p->npk);
+    hipStream_t st = as_stream(stream);
+    CDFT_HIP(hipMemcpy2DAsync(darea, (size_t)nlev * p->npj * 8, p->area, (size_t)p->npk * p->npj * 8, (size_t)nlev * p->npj * 8, p->nb,
+                              out_space == CDFT_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
+    if (out_space != CDFT_MEM_DEVICE) CDFT_HIP(hipStreamSynchronize(st));
     return CDFT_OK;
 }
 

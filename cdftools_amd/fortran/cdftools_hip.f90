@@ -274,6 +274,9 @@ MODULE cdftools_hip
        IMPORT ; TYPE(C_PTR), VALUE :: plan, stream, darea, rzomax, rzomin ; REAL(C_FLOAT), INTENT(in) :: zv(*)
        INTEGER(C_INT), VALUE :: nlev, in_space, mean_form, out_space ; REAL(C_DOUBLE), INTENT(out) :: dzo(*)
      END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_zonal_area(plan, nlev, darea, out_space, stream) BIND(C, name='cdft_zonal_area')
+       IMPORT ; TYPE(C_PTR), VALUE :: plan, stream ; INTEGER(C_INT), VALUE :: nlev, out_space ; REAL(C_DOUBLE), INTENT(out) :: darea(*)
+     END FUNCTION
      INTEGER(C_INT) FUNCTION cdft_zonal_destroy(plan) BIND(C, name='cdft_zonal_destroy')
        IMPORT ; TYPE(C_PTR), VALUE :: plan
      END FUNCTION

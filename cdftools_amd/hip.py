@@ -697,31 +697,53 @@ class ZonalPlan(_Plan):
         check(_lib.load().cdft_zonal_set_mesh(self._h, *[C.c_void_p(a.ctypes.data) for a in k], MEM_HOST,
                                               stream or current_stream_ptr()))
 
-    def compute(self, zv, mean_form=False, minmax=False, stream=None, device_out=False):
+    def area(self, nlev=None):
+        """darea (nb,nlev,npj) r8 of the mesh: it does not depend on the field (cdft_zonal_area)."""
+        nlev = self.npk if nlev is None else nlev
+        out = np.empty((self.nb, nlev, self.npj), np.float64)
+        check(_lib.load().cdft_zonal_area(self._h, nlev, C.c_void_p(out.ctypes.data), MEM_HOST, current_stream_ptr()))
+        return out
+
+    def compute(self, zv, mean_form=False, minmax=False, stream=None, device_out=False, pinned=False, want_area=True):
         """zv (nlev,npj,npi) r4 -> dict of (nb,nlev,npj) arrays: 'sum' [, 'area', 'max', 'min']; numpy arrays, or
-        torch tensors left on the GPU with device_out=True."""
+        torch tensors left on the GPU with device_out=True.  pinned=True: the results land in page-locked arrays the plan
+        keeps and hands out again at every call (CDFT_MEM_PINNED: no staging, no fresh pages); want_area=False: the mean
+        form without its area, which area() gives once per mesh."""
         pz, sz, kz = _arg(zv, np.float32, "zv")
         nlev = kz.shape[0]
         shape = (self.nb, nlev, self.npj)
         if device_out:
             import torch
-            new = lambda dt: torch.empty(shape, dtype=dt, device="cuda")            # noqa: E731
+            new = lambda dt, k: torch.empty(shape, dtype=dt, device="cuda")         # noqa: E731
             ptr = lambda t: C.c_void_p(t.data_ptr())                                 # noqa: E731
             r8, r4, space = torch.float64, torch.float32, MEM_DEVICE
+        elif pinned:
+            if getattr(self, "_pin_shape", None) != shape:
+                self._pin = {}
+                self._pin_shape = shape
+
+            def new(dt, k):
+                if k not in self._pin:
+                    self._pin[k] = PinnedArray(shape, dt)
+                return self._pin[k].a
+            ptr = lambda a: C.c_void_p(a.ctypes.data)                                # noqa: E731
+            r8, r4, space = np.float64, np.float32, MEM_PINNED
         else:
-            new = lambda dt: np.empty(shape, dt)                                     # noqa: E731
+            new = lambda dt, k: np.empty(shape, dt)                                  # noqa: E731
             ptr = lambda a: C.c_void_p(a.ctypes.data)                                # noqa: E731
             r8, r4, space = np.float64, np.float32, MEM_HOST
-        out = {"sum": new(r8)}
+        out = {"sum": new(r8, "sum")}
         pa = px = pn = _null()
-        if mean_form:
-            out["area"] = new(r8)
+        if mean_form and want_area:
+            out["area"] = new(r8, "area")
             pa = ptr(out["area"])
         if minmax:
-            out["max"], out["min"] = new(r4), new(r4)
+            out["max"], out["min"] = new(r4, "max"), new(r4, "min")
             px, pn = ptr(out["max"]), ptr(out["min"])
-        check(_lib.load().cdft_zonal_compute(self._h, pz, nlev, sz, 1 if mean_form else 0, ptr(out["sum"]),
-                                             pa, px, pn, space, stream or current_stream_ptr()))
+        st = stream or current_stream_ptr()
+        check(_lib.load().cdft_zonal_compute(self._h, pz, nlev, sz, 1 if mean_form else 0, ptr(out["sum"]), pa, px, pn, space, st))
+        if pinned:
+            check(_lib.load().cdft_stream_sync(st))
         return out
 
 

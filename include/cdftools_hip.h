@@ -422,6 +422,11 @@ int cdft_zonal_set_mesh(cdft_zonal_plan *plan, const float *e1, const float *e2,
  *   or NULL: the -max option (extrema of dtmp, the minimum over dtmp /= 0, start values -1.e20 / 1.e20). */
 int cdft_zonal_compute(cdft_zonal_plan *plan, const float *zv, int nlev, int in_space, int mean_form, double *dzo,
                        double *darea, float *rzomax, float *rzomin, int out_space, void *stream);
+/* darea does not depend on the field: it is formed once by cdft_zonal_set_mesh.  A caller that takes it from here (once per
+ * mesh) may pass darea = NULL to the mean form of cdft_zonal_compute, which then returns one array instead of two.
+ * out_space = CDFT_MEM_PINNED in cdft_zonal_compute: results into page-locked arrays of the caller (cdft_host_alloc) without
+ * a closing synchronisation -- cdft_stream_sync(stream) before reading them. */
+int cdft_zonal_area(cdft_zonal_plan *plan, int nlev, double *darea, int out_space, void *stream);
 int cdft_zonal_destroy(cdft_zonal_plan *plan);
 
 /* ------------------------------------------------------------------------------------------ */

@@ -461,6 +461,38 @@ def test_cdfzonalsum_and_cdfzonalmean_end_to_end(tools, tmp_path):  # noqa: F811
             assert np.array_equal(var["zotemper" + sfx[b] + "_min"][t, :, :, 0], np.where(ok[b], ref["min"][b], 0).astype(np.float32))
 
 
+@pytest.mark.gpu
+def test_cdfzonal_file_with_2d_and_3d_variables(tools, tmp_path):  # noqa: F811
+    """A file that holds a 2-D variable beside a 3-D one: the results of a call are packed for the levels of THAT variable
+    ((npjglo, 1, nbasins) for the 2-D one), and every basin of both must land in its own output variable."""
+    d = str(tmp_path)
+    g, rec = nemo_files.make_case(d, npi=26, npj=19, npk=6, npt=2)
+    npk, npj, npi = g["tmask"].shape
+    ssh = (np.random.default_rng(5).random((2, npj, npi), dtype=np.float32) - np.float32(0.5)) * g["tmask"][0]
+    nemo_files.write_data(os.path.join(d, "mix.nc"), g, "deptht", {"sossheig": ssh.astype(np.float32), "votemper": rec["t"]}, fill=0.0)
+    tm = g["tmask"].astype(np.float32)
+    zm = np.zeros((npj, npi, 5), np.float32)
+    zm[:, :, 0] = g["tmask"][0]
+    zm[:, :, 1], zm[:, :, 3], zm[:, :, 4] = g["tmaskatl"], g["tmaskind"], g["tmaskpac"]
+    zm[:, :, 2] = np.minimum(zm[:, :, 4] + zm[:, :, 3], 1)
+    sfx = ["_glo", "_atl", "_inp", "_ind", "_pac"]
+    for tool, out_name, pre in (("cdfzonalsum", "zonalsum.nc", "zoi"), ("cdfzonalmean", "zonalmean.nc", "zo")):
+        rc, out, err = run(tool, ["-f", "mix.nc", "-p", "T", "-b", "new_maskglo.nc"], d)
+        assert rc == 0, out + err
+        var, _, _ = read_nc(os.path.join(d, out_name))
+        for t in range(2):
+            for nm, fld, msk in ((pre + "ssheig", ssh[t][None], tm[:1]), (pre + "temper", rec["t"][t], tm)):
+                ref = oracle_tools.zonal(g["e1t"], g["e2t"], msk, zm, fld, mean_form=tool == "cdfzonalmean")
+                want = ref["sum"]
+                if tool == "cdfzonalmean":
+                    ok = ref["area"] != 0
+                    want = np.where(ok, ref["sum"] / np.where(ok, ref["area"], 1), 0.0)
+                for b in range(5):
+                    got = var[nm + sfx[b]][t]
+                    got = got[:, :, 0] if got.ndim == 3 else got[None, :, 0]
+                    assert np.allclose(got, want[b], rtol=2e-7, atol=1e-30), (tool, nm, b, t)
+
+
 # ------------------------------------------------------------------------------------ cdfvint / cdfvertmean
 def vint_schedule(e31d, gdepo, lstd):
     """The scalar bookkeeping of src/cdfvint.f90:266-311 in r4, as the Fortran host program does it."""
