@@ -8,6 +8,7 @@
 // variant (same operation order and rounding as the reference, bit-identical results) is offered
 // next to a contracted one (CDFT_EOS_FAST_FMA, a few ulp of r8, invisible after the r4 store).
 #include "eos_dev.hpp"
+#include <cstdlib>
 
 using namespace cdft;
 
@@ -57,6 +58,7 @@ struct EosArgs {
     float  *out4;
     int64_t n;
     float pref, spval;
+    int no_land_shortcut;      // CDFT_EOS_NOLAND=1 (A/B and test hook): every point through the polynomials
 };
 
 template <int EOS, bool FAST>
@@ -68,24 +70,75 @@ __device__ __forceinline__ double eval_point(float t, float s, float p) {
 
 // VEC = 4: every pointer 16-byte aligned, four points per lane per step (dwordx4 loads);
 // VEC = 1: scalar fallback for unaligned arrays.  Grid-stride over vectors.
+//
+// Land.  NEMO writes T = S = 0 on land, and land comes in large pieces: a wave (256 consecutive points) that finds +0 in every
+// T and S it loaded stores sigma(0, 0, pref) -- evaluated ONCE per lane before the loop by the same code, so the stored bits
+// are those the full evaluation gives (for sigma0 that is -0.0: the reference's r * tmask with r = -0.16, src/eos.f90:630,
+// and the tools' zsig * zmask, src/cdfsig0.f90:150) -- and moves on without touching the polynomials.  The branch is uniform
+// over the wave (a ballot), so an ocean wave pays two OR / compare instructions per point.  A wave holding any other bit
+// pattern -- an ocean point, a fill value, -0.0, NaN -- takes the full path.  Not for per-point reference depths (kPointRef).
 template <int EOS, bool FAST, int KIND, int VEC>
 __global__ void __launch_bounds__(256) eos_kernel(EosArgs a) {
     const int64_t nvec = a.n / VEC;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += stride) {
+    double r_land = 0.0;
+    float  o_land = 0.f;
+    if (KIND != kPointRef && !a.no_land_shortcut) {
+        r_land = eval_point<EOS, FAST>(0.f, 0.f, a.pref);
+        o_land = (float)__dmul_rn(r_land, (double)((0.f == a.spval) ? 0.f : 1.f));
+    }
+    // the loads of the NEXT vector are issued before the current one is evaluated (3 % at eORCA12: the kernel is bound by
+    // the vector pipeline -- counters: VALU busy 96 % of the time for sigma2, ~141 vector instructions per point of which 119
+    // are r8 -- so a load that is not waited for is all there is to gain; writing the four points' Horner chains side by
+    // side in the source changed nothing, the scheduler interleaves them by itself)
+    f4a nt = {0.f, 0.f, 0.f, 0.f}, ns = nt, np_ = nt;
+    float nt1 = 0.f, ns1 = 0.f, np1 = 0.f;
+    const int64_t v0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v0 < nvec) {
+        if (VEC == 4) {
+            nt = ld_stream4(a.t + 4 * v0); ns = ld_stream4(a.s + 4 * v0);
+            if (KIND == kPointRef) np_ = ld_stream4(a.p2d + 4 * v0);
+        } else {
+            nt1 = a.t[v0]; ns1 = a.s[v0];
+            if (KIND == kPointRef) np1 = a.p2d[v0];
+        }
+    }
+    for (int64_t v = v0; v < nvec; v += stride) {
         float t[VEC], s[VEC], p[VEC];
         if (VEC == 4) {
-            const f4a tt = ld_stream4(a.t + 4 * (int64_t)v);
-            const f4a ss = ld_stream4(a.s + 4 * (int64_t)v);
-            t[0] = tt.x; t[1] = tt.y; t[2] = tt.z; t[3] = tt.w;
-            s[0] = ss.x; s[1] = ss.y; s[2] = ss.z; s[3] = ss.w;
-            if (KIND == kPointRef) {
-                const f4a pp = ld_stream4(a.p2d + 4 * (int64_t)v);
-                p[0] = pp.x; p[1] = pp.y; p[2] = pp.z; p[3] = pp.w;
-            }
+            t[0] = nt.x; t[1] = nt.y; t[2] = nt.z; t[3] = nt.w;
+            s[0] = ns.x; s[1] = ns.y; s[2] = ns.z; s[3] = ns.w;
+            if (KIND == kPointRef) { p[0] = np_.x; p[1] = np_.y; p[2] = np_.z; p[3] = np_.w; }
         } else {
-            t[0] = a.t[v]; s[0] = a.s[v];
-            if (KIND == kPointRef) p[0] = a.p2d[v];
+            t[0] = nt1; s[0] = ns1;
+            if (KIND == kPointRef) p[0] = np1;
+        }
+        if (v + stride < nvec) {
+            const int64_t w = v + stride;
+            if (VEC == 4) {
+                nt = ld_stream4(a.t + 4 * w); ns = ld_stream4(a.s + 4 * w);
+                if (KIND == kPointRef) np_ = ld_stream4(a.p2d + 4 * w);
+            } else {
+                nt1 = a.t[w]; ns1 = a.s[w];
+                if (KIND == kPointRef) np1 = a.p2d[w];
+            }
+        }
+        if (KIND != kPointRef && !a.no_land_shortcut) {
+            uint32_t bits = 0;
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) bits |= __float_as_uint(t[c]) | __float_as_uint(s[c]);
+            if (!__any(bits != 0u)) {                    // every lane of the wave: T = S = +0 on all its points
+                if (KIND == kTool) {
+                    if (VEC == 4) reinterpret_cast<float4 *>(a.out4)[v] = make_float4(o_land, o_land, o_land, o_land);
+                    else a.out4[v] = o_land;
+                } else if (VEC == 4) {
+                    reinterpret_cast<double2 *>(a.out8)[2 * v]     = make_double2(r_land, r_land);
+                    reinterpret_cast<double2 *>(a.out8)[2 * v + 1] = make_double2(r_land, r_land);
+                } else {
+                    a.out8[v] = r_land;
+                }
+                continue;
+            }
         }
         double r[VEC];
 #pragma unroll
@@ -98,7 +151,7 @@ __global__ void __launch_bounds__(256) eos_kernel(EosArgs a) {
                 const float zmask = (s[c] == a.spval) ? 0.f : 1.f;
                 o[c] = (float)__dmul_rn(r[c], (double)zmask);
             }
-            if (VEC == 4) reinterpret_cast<float4 *>(a.out4)[v] = make_float4(o[0], o[1], o[2], o[3]);
+            if (VEC == 4) { f4a ov = {o[0], o[1], o[2], o[3]}; __builtin_nontemporal_store(ov, reinterpret_cast<f4a *>(a.out4) + v); }
             else a.out4[v] = o[0];
         } else {
             if (VEC == 4) {
@@ -180,6 +233,7 @@ int run(int kind, const float *ptem, const float *psal, const float *pref2d, int
     a.out8 = kind == kTool ? nullptr : (double *)dout;
     a.out4 = kind == kTool ? (float *)dout : nullptr;
     a.n = n; a.pref = pref; a.spval = spval;
+    { const char *e = getenv("CDFT_EOS_NOLAND"); a.no_land_shortcut = (e && e[0] == '1') ? 1 : 0; }
     int rc;
     if (kind == kScalarRef)     rc = launch_eos<kScalarRef>(a, eos, flags, st);
     else if (kind == kPointRef) rc = launch_eos<kPointRef>(a, eos, flags, st);

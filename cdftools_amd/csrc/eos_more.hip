@@ -11,16 +11,21 @@
 // 8-20 bytes of traffic per point for 60-250 r8 operations: these sit at or beyond the fp64-vector ridge of the chip
 // (like sigmai); one lane per point, four points per lane when the arrays are 16-byte aligned.
 #include "common.hpp"
+#include <type_traits>
 #include "eos_coef.h"
 
 using namespace cdft;
 
 namespace {
 
-__constant__ double kAlp[2][CDFT_EOS_NK][CDFT_EOS_DNJ][CDFT_EOS_DNI] = CDFT_EOS_ALP_INIT;
-__constant__ double kBet[2][CDFT_EOS_NK][CDFT_EOS_DNJ][CDFT_EOS_DNI] = CDFT_EOS_BET_INIT;
-__constant__ double kSpice[49] = CDFT_SPICE_POL_INIT;
-__constant__ double kF02[6][5] = CDFT_SPICE_F02_INIT;
+// constexpr, not __constant__: with every index known after unrolling the coefficients become literals of the instruction
+// stream.  As __constant__ arrays they were fetched into ~180 scalar registers ahead of the loop, more than a wave has,
+// and came back through v_readlane / v_writelane: 180 of the 402 vector instructions per point of eosbn2 (counters,
+// profiles/r03/fp64_ops_pmc.json: 298 per point issued, 170 of them r8).
+constexpr double kAlp[2][CDFT_EOS_NK][CDFT_EOS_DNJ][CDFT_EOS_DNI] = CDFT_EOS_ALP_INIT;
+constexpr double kBet[2][CDFT_EOS_NK][CDFT_EOS_DNJ][CDFT_EOS_DNI] = CDFT_EOS_BET_INIT;
+constexpr double kSpice[49] = CDFT_SPICE_POL_INIT;
+constexpr double kF02[6][5] = CDFT_SPICE_F02_INIT;
 
 // n_k(t,s): Horner in t around Horner in s, each t-level written ( .. )*t + ( .. )*s + c0 (src/eos.f90:1424-1441)
 template <bool BETA, int SET, int K>
@@ -176,13 +181,30 @@ __device__ __forceinline__ float bn2_point(float tu, float td, float su, float s
     }
 }
 
-template <int FORM, int SET>
+template <int FORM, int SET, int VEC>
 __global__ void __launch_bounds__(256) eos_bn2_kernel(Bn2Args a) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const double zh = (double)a.dep;
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < a.n; p += stride)
-        a.out[p] = bn2_point<FORM, SET>(ld_stream(a.tu + p), ld_stream(a.td + p), ld_stream(a.su + p), ld_stream(a.sd + p),
-                                        ld_stream(a.e3w + p), zh);
+    const int64_t nvec = a.n / VEC;
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += stride) {
+        if constexpr (VEC == 4) {               // four independent points per lane: their chains fill one another's latency
+            const f4a tu = ld_stream4(a.tu + 4 * v), td = ld_stream4(a.td + 4 * v), su = ld_stream4(a.su + 4 * v);
+            const f4a sd = ld_stream4(a.sd + 4 * v), e3 = ld_stream4(a.e3w + 4 * v);
+            f4a r;
+            r.x = bn2_point<FORM, SET>(tu.x, td.x, su.x, sd.x, e3.x, zh);
+            r.y = bn2_point<FORM, SET>(tu.y, td.y, su.y, sd.y, e3.y, zh);
+            r.z = bn2_point<FORM, SET>(tu.z, td.z, su.z, sd.z, e3.z, zh);
+            r.w = bn2_point<FORM, SET>(tu.w, td.w, su.w, sd.w, e3.w, zh);
+            *reinterpret_cast<f4a *>(a.out + 4 * v) = r;
+        } else {
+            a.out[v] = bn2_point<FORM, SET>(ld_stream(a.tu + v), ld_stream(a.td + v), ld_stream(a.su + v), ld_stream(a.sd + v),
+                                            ld_stream(a.e3w + v), zh);
+        }
+    }
+    if (VEC == 4 && blockIdx.x == 0 && threadIdx.x < (unsigned)(a.n - nvec * VEC)) {
+        const int64_t q = nvec * VEC + threadIdx.x;
+        a.out[q] = bn2_point<FORM, SET>(a.tu[q], a.td[q], a.su[q], a.sd[q], a.e3w[q], zh);
+    }
 }
 
 inline unsigned grid_for(int64_t work) {
@@ -275,10 +297,18 @@ int cdft_eos_bn2(const float *ptem_up, const float *ptem_down, const float *psal
     }
     Bn2Args a{(const float *)dev[0], (const float *)dev[1], (const float *)dev[2], (const float *)dev[3], (const float *)dev[4],
               (float *)dout, n, pdep};
-    const unsigned g = grid_for(n);
-    if (eos == CDFT_EOS_MCD87)       hipLaunchKernelGGL((eos_bn2_kernel<1, 0>), dim3(g), dim3(256), 0, st, a);
-    else if (eos == CDFT_EOS_TEOS10) hipLaunchKernelGGL((eos_bn2_kernel<0, 1>), dim3(g), dim3(256), 0, st, a);
-    else                             hipLaunchKernelGGL((eos_bn2_kernel<0, 0>), dim3(g), dim3(256), 0, st, a);
+    bool vec = (reinterpret_cast<uintptr_t>(dout) & 15u) == 0;
+    for (int q = 0; q < 5; ++q) vec = vec && (reinterpret_cast<uintptr_t>(dev[q]) & 15u) == 0;
+    const unsigned g = grid_for(vec ? (n + 3) / 4 : n);
+    auto launch = [&](auto form, auto set) {
+        if (vec) hipLaunchKernelGGL((eos_bn2_kernel<decltype(form)::value, decltype(set)::value, 4>), dim3(g), dim3(256), 0, st, a);
+        else     hipLaunchKernelGGL((eos_bn2_kernel<decltype(form)::value, decltype(set)::value, 1>), dim3(g), dim3(256), 0, st, a);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    if (eos == CDFT_EOS_MCD87)       launch(I1{}, I0{});
+    else if (eos == CDFT_EOS_TEOS10) launch(I0{}, I1{});
+    else                             launch(I0{}, I0{});
     CDFT_LAUNCH_CHECK();
     if (out_space == CDFT_MEM_HOST) {
         CDFT_HIP(hipMemcpyAsync(bn2, dout, n * sizeof(float), hipMemcpyDeviceToHost, st));

@@ -24,6 +24,7 @@ struct SigArgs {
     int npi, npj, npk, nb, nbins, j0, j1;
     float zspv, zspt, zsps, pref, sigmin, sigstp;
     double *dmoc, *depi;               // (nb,nbins,npj)
+    int no_land_shortcut;              // CDFT_MOCSIG_NOLAND=1: the equation of state on every cell (A/B and test hook)
 };
 
 template <int TEOS, bool ISODEP>
@@ -167,6 +168,19 @@ __global__ void __launch_bounds__(T) mocsig_class_kernel(SigArgs a, SigClassArgs
                 const float s4[4] = {cs.x, cs.y, cs.z, cs.w}, e4[4] = {ce.x, ce.y, ce.z, ce.w};
                 int key[4];
                 double val[4];
+                // Land.  A term that is exactly zero (v = 0 or e3v = 0: land, and it comes in large pieces) is never added
+                // (below), so its density class is never looked at: a wave whose 256 cells all have such a term skips the
+                // equation of state altogether -- ~115 r8 operations per cell.  Uniform over the wave (a ballot); a NaN
+                // term is not zero and takes the full path.  CDFT_MOCSIG_NOLAND=1: A/B and test hook.
+                {
+                    bool live = false;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float v = (v4[c] == a.zspv) ? 0.f : v4[c];
+                        live |= (hoff[r][c] >= 0) && (__fmul_rn(v, __fmul_rn(e1[r][c], e4[c])) != 0.f);
+                    }
+                    if (!a.no_land_shortcut && !__any(live)) { cv = nv_; ct = nt_; cs = ns_; ce = ne_; continue; }
+                }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     float v = v4[c], t = t4[c], s = s4[c];
@@ -306,6 +320,7 @@ int cdft_mocsig_compute(const float *zv, const float *zveiv, const float *zt, co
     a.j0 = npjglo > 1 ? 1 : 0; a.j1 = npjglo > 1 ? npjglo - 2 : 0;                         // :405-407
     a.zspv = zspv; a.zspt = zspt; a.zsps = zsps; a.pref = pref; a.sigmin = sigmin; a.sigstp = sigstp;
     a.dmoc = om; a.depi = od;
+    { const char *e = getenv("CDFT_MOCSIG_NOLAND"); a.no_land_shortcut = (e && e[0] == '1') ? 1 : 0; }
     // class kernel when it applies (see above); CDFT_MOCSIG_NOCLASS=1 keeps the general kernel (A/B and test hook)
     bool done = false;
     const int nvec = npiglo / 4 + 1, nv = (nvec + kSigT - 1) / kSigT;

@@ -774,3 +774,30 @@ def test_cdfmocsig_end_to_end(tools, tmp_path):  # noqa: F811
     assert rc == 0 and "-nbins  52" in out, out + err                        # the default classes of -ntr (:267-270)
     rc, out, _ = run("cdfmocsig", ["-v", "SYN_y0001_gridV.nc", "-t", "SYN_y0001_gridT.nc"], d)
     assert rc == 99 and "mandatory arguments missing" in out
+
+
+@pytest.mark.gpu
+def test_hip_mocsig_land_shortcut_is_bit_identical(gpu, monkeypatch):
+    """cdfmocsig's class kernel skips the equation of state for a wave whose 256 cells all have an exactly zero transport
+    (land in large pieces): the histogram is the one of the run that evaluates every cell (CDFT_MOCSIG_NOLAND=1), bit for bit
+    -- with a NaN velocity inside the land (not a zero: it must be binned), and with land pieces that end inside a wave."""
+    npi, npj, npk, nb = 1031, 6, 5, 5
+    g, e1v, _, ib, zv, zt, zs = mocsig_inputs(npi, npj, npk, nb, seed=31)
+    land = np.zeros((npj, npi), bool)
+    land[:, 100:700] = True
+    land[2, :] = True
+    land[4, 900:] = True
+    zv = zv.copy()
+    zv[:, land] = 0.0
+    zv[1, 3, 350] = np.nan
+    zt[:, land] = 0.0
+    zs[:, land] = 0.0
+    kw = dict(pref=2000.0, e3v=g["e3v_0"])
+    monkeypatch.delenv("CDFT_MOCSIG_NOLAND", raising=False)
+    got = gpu.mocsig(zv, zt, zs, e1v, ib, 158, np.float32(30.0), np.float32(0.05), **kw)
+    monkeypatch.setenv("CDFT_MOCSIG_NOLAND", "1")
+    full = gpu.mocsig(zv, zt, zs, e1v, ib, 158, np.float32(30.0), np.float32(0.05), **kw)
+    assert got.tobytes() == full.tobytes() and np.isnan(got[3]).any() and np.isfinite(got[0]).all()
+    ref = oracle_lib.mocsig(zv, zt, zs, e1v, ib, 158, np.float32(30.0), np.float32(0.05), **kw)
+    ok = np.isfinite(ref)
+    assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.all(np.abs(got[ok] - ref[ok]) <= 1e-10 * np.abs(ref[ok]).max())

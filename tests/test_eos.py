@@ -174,3 +174,41 @@ def test_hip_full_level_properties_eorca12_slab(gpu):
     idx = torch.randint(0, n, (4096,), device="cuda", generator=g)
     want = oracle_lib.sigmai(T[idx].cpu().numpy(), S[idx].cpu().numpy(), 2000.0)
     assert np.array_equal(a[idx].cpu().numpy(), want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("eos,pref", [(0, 0.0), (0, 2000.0), (1, 1000.0), (2, 0.0), (3, 0.0)])
+def test_hip_land_shortcut_stores_the_bits_of_the_full_evaluation(gpu, monkeypatch, eos, pref):
+    """A wave that finds T = S = +0 on all its 256 points stores sigma(0,0,pref) without evaluating the polynomials.  Fields
+    with land in large pieces -- and, inside the land, everything that must NOT take the shortcut: -0.0, a NaN, a fill
+    value, a single ocean point, pieces shorter than a wave and pieces that end in the middle of one -- give the bits of the
+    run that evaluates every point (CDFT_EOS_NOLAND=1), which are the oracle's."""
+    import torch
+    rng = np.random.default_rng(5)
+    n = 64 * 4 * 40 + 3
+    t = (-2 + 32 * rng.random(n)).astype(np.float32)
+    s = (30 + 8 * rng.random(n)).astype(np.float32)
+    land = np.zeros(n, bool)
+    for a, b in ((0, 1024), (1500, 1500 + 256), (2048 + 13, 2048 + 13 + 700), (4096, 4096 + 255), (6000, 8200), (n - 300, n)):
+        land[a:b] = True
+    t[land] = 0
+    s[land] = 0
+    t[100] = -0.0                     # not +0: no shortcut for its wave
+    t[6100] = np.nan
+    s[6500] = -0.0
+    t[7000] = 1.0e20                  # a fill value on land
+    t[7600], s[7600] = 3.0, 35.0      # one ocean point in the middle of land
+    for spval in (0.0, -999.0):
+        monkeypatch.delenv("CDFT_EOS_NOLAND", raising=False)
+        got = gpu.sigmai(t, s, pref, eos=eos)
+        tool = gpu.sig_tool(t, s, pref=pref, spval=spval, eos=eos)
+        dev = gpu.sig_tool(torch.from_numpy(t).cuda(), torch.from_numpy(s).cuda(), pref=pref, spval=spval, eos=eos).cpu().numpy()
+        monkeypatch.setenv("CDFT_EOS_NOLAND", "1")
+        full = gpu.sigmai(t, s, pref, eos=eos)
+        tool_full = gpu.sig_tool(t, s, pref=pref, spval=spval, eos=eos)
+        for x, y in ((got, full), (tool, tool_full), (dev, tool_full)):
+            assert x.tobytes() == y.tobytes()          # the sign of a zero included
+    if eos in (0, 1):
+        ref = oracle_lib.sigmai(t, s, pref, teos10=eos == 1)
+        assert np.array_equal(got, ref, equal_nan=True)
+        assert np.signbit(got[5]) == np.signbit(ref[5])

@@ -162,6 +162,12 @@ def test_hip_eos_more_against_the_oracle_at_a_level_of_eORCA025(gpu):
     assert np.array_equal(gpu.albet(dT, dS, 10.0).cpu().numpy(), ol.eos_coef(2, T, S, 10.0))
     assert np.array_equal(gpu.beta(dT, dS, dD, eos=gpu.EOS_MCD87).cpu().numpy(), ol.eos_coef(3, T, S, 0, pdep2d=D))
     assert np.array_equal(gpu.eosbn2(T, T2, S, S2, E, 55.0, eos=gpu.EOS_MCD87), ol.bn2(T, T2, S, S2, E, 55.0, mcd87=True))
+    # device arrays: four points per lane when every address is 16-byte aligned (with a ragged tail), one point per lane when
+    # one is not -- the same bits either way
+    dev = [torch.from_numpy(x).cuda() for x in (T, T2, S, S2, E)]
+    for lo, hi in ((0, n - 3), (1, n), (1, 4099), (0, 3)):
+        want = ol.bn2(*(x[lo:hi] for x in (T, T2, S, S2, E)), 55.0, False)
+        assert np.array_equal(gpu.eosbn2(*(x[lo:hi] for x in dev), 55.0).cpu().numpy(), want), (lo, hi)
 
 
 @pytest.mark.gpu
