@@ -340,10 +340,16 @@ __global__ void __launch_bounds__(64) heatc_seq_kernel(HeatcArgs a, const float 
 // integers (then RN picks the even S + k: a "tie").  So a chunk of cells with no tie and no binade change moves S
 // by the plain sum of its k's: order-free, computed by every lane of every wave at once.
 //
-// Which binade?  The r8 sums of the level kernel above (one partial per block of 4096 cells, formed anyway by the r8
-// mode), added to the last exact value the level has published, estimate the chain's value at every block boundary:
-// the binade of the estimate where a block starts and, when different, where it ends are the two HYPOTHESES (sign, e)
-// for the block's chunks of 512 cells.  Work is dealt in tickets of 64 to 256 chunks of one level from an atomic counter
+// Which binade?  An ESTIMATE of the chain's value is enough to name it, and the walk below checks the name against the
+// exact value before it uses a sum formed under it -- so the estimate costs correctness nothing, only a chunk resolved
+// the slow way when it is wrong.  heatc_sample_kernel reads one 64-cell run of every block of 4096 cells (1/64 of the
+// fields; the first 32768 cells of a level in full, where the chain grows from nothing and a crossing comes every
+// few cells) and scales it to the block: r8 block sums that, added to the last exact value the level has published,
+// estimate the chain at every block boundary.  The binade of the estimate where a chunk starts and, when different,
+// where it ends -- or the neighbouring binade when the estimate is within a quarter of its growth since the published
+// value of a power of two -- are the two HYPOTHESES (sign, e) for a chunk of 512 cells.  (Rounds 1-2 took the estimates
+// from a full r8 pass of heatc_level_kernel: every field read twice.)
+// Work is dealt in tickets of 64 to 256 chunks of one level from an atomic counter
 // (ticket = step * npk + level: the workgroups in flight spread over all levels and a few consecutive steps of each;
 // about 32 steps per level).  A workgroup forms,
 // for each chunk, chain and hypothesis,  K = sum k,  pos = sum max(k,0)  and flags (a cell that is not 0; a tie / NaN
@@ -390,7 +396,8 @@ __device__ __forceinline__ int wave_iscan_incl(int v, int lane) {
 // value in ONE 64-bit atomic word, so a reader never sees a value that does not belong to the step it read.
 struct ScanLevel { unsigned long long word[3]; unsigned long long pad; };
 __device__ __forceinline__ unsigned long long scan_word(int step, float s) { return ((unsigned long long)(uint32_t)step << 32) | __float_as_uint(s); }
-struct ScanCtl   { int ticket; int error; int nfallback, nunguessed, nslow, pad; };   // (the last three: statistics)
+constexpr int kScanMaxLanes = 8;
+struct ScanCtl   { int ticket; int error; int nfallback, nunguessed, nslow, nstolen; int lane_next[kScanMaxLanes]; };   // (nfallback ...: statistics)
 
 // the binade of a chain value: sign and exponent, or -1 when the integer picture does not apply (0, denormal, Inf, NaN,
 // or an exponent whose ulp does not scale exactly)
@@ -403,6 +410,45 @@ __device__ __forceinline__ int   scan_mant(float s)         { return (int)((__fl
 __device__ __forceinline__ float scan_value(int key, int S) { return __uint_as_float(((uint32_t)key << 23) | ((uint32_t)S & 0x7fffffu)); }
 __device__ __forceinline__ float scan_scale(int key) {            // +-2^(23-e): x * scale = x / ulp(s), with the sign of s folded in
     return __uint_as_float(((uint32_t)(key & 0x100) << 23) | ((uint32_t)(23 + 254 - (key & 0xff)) << 23));
+}
+
+// partial[k][b][ch], b over blocks of kSampleBlock cells: r8 sum of the chain's terms over the block -- of all its cells when the
+// block lies in the level's first `dense_cells` cells, else of its first 64 cells scaled by (cells of the block) / 64.
+// One wave per block.
+constexpr int kSampleBlock = 4096;
+template <bool MASK8, bool FULL, bool MXL>
+__global__ void __launch_bounds__(256) heatc_sample_kernel(HeatcArgs a, int64_t dense_cells) {
+    const int lane = threadIdx.x & 63, k = blockIdx.y;
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= a.nblk) return;
+    const int64_t c0 = b * kSampleBlock, c1 = min(a.nij, c0 + kSampleBlock), base = (int64_t)k * a.nij;
+    const bool dense = c0 < dense_cells;
+    const int64_t cend = dense ? c1 : min(c1, c0 + 64);
+    const float e3k = FULL ? a.e31d[k] : 0.f;
+    const float dw  = MXL ? a.gdepw[k] : 0.f;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll 4
+    for (int64_t p = c0 + lane; p < cend; p += 64) {
+        const float ar = a.area[p], tt = ld_stream(a.temp + base + p);
+        const float mk = MASK8 ? (float)ld_stream(a.mask8 + base + p) : ld_stream(a.mask4 + base + p);
+        float e = FULL ? e3k : ld_stream(a.e3t + base + p);
+        if (MXL) {
+            if (a.mxlopt == 1) e = fmaxf(0.f, fminf(e, __fsub_rn(a.mxl[p], dw)));
+            else               e = fminf(e, fmaxf(0.f, __fsub_rn(__fadd_rn(dw, e), a.mxl[p])));
+        }
+        const float pv = __fmul_rn(ar, e);
+        s0 += (double)__fmul_rn(ar, mk);
+        s1 += (double)__fmul_rn(pv, mk);
+        s2 += (double)__fmul_rn(__fmul_rn(pv, tt), mk);
+    }
+    s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if (lane == 0) {
+        const double f = dense ? 1.0 : (double)(c1 - c0) / (double)(cend - c0);
+        double *o = a.partial + ((int64_t)k * a.nblk + b) * 3;
+        // (a NaN or Inf in the sample would poison every estimate after it: such a block counts as 0 -- its chunks are
+        // resolved cell by cell whatever the hypotheses say)
+        o[0] = isfinite(s0) ? s0 * f : 0.0; o[1] = isfinite(s1) ? s1 * f : 0.0; o[2] = isfinite(s2) ? s2 * f : 0.0;
+    }
 }
 
 // est[k][b][ch], b = 0..nblk: the r8 value of chain ch of level k where block b of the level kernel starts (b = nblk:
@@ -425,27 +471,60 @@ __global__ void __launch_bounds__(64) heatc_scan_est_kernel(const double *__rest
         for (int b = b0; b < b1; ++b) { run += pk[(int64_t)b * 3 + c]; ek[(int64_t)(b + 1) * 3 + c] = run; }
     }
     if (lane < 3) lev[k].word[lane] = scan_word(0, carry ? carry[k * 3 + lane] : 0.f);
-    if (k == 0 && lane == 0) { ctl->ticket = 0; ctl->error = 0; ctl->nfallback = 0; ctl->nunguessed = 0; ctl->nslow = 0; }
+    if (k == 0 && lane == 0) {
+        ctl->ticket = 0; ctl->error = 0; ctl->nfallback = 0; ctl->nunguessed = 0; ctl->nslow = 0; ctl->nstolen = 0;
+        for (int x = 0; x < kScanMaxLanes; ++x) ctl->lane_next[x] = 0;
+    }
 }
 
 template <bool MASK8, bool FULL, bool MXL>
 __global__ void __launch_bounds__(64 * kScanWaves, 3) heatc_scan_kernel(HeatcArgs a, ScanLevel *__restrict__ lev, ScanCtl *__restrict__ ctl,
                                                                      const double *__restrict__ est, int block_cells, int nchunk, int nsteps,
-                                                                     float *__restrict__ sums4) {
+                                                                     float *__restrict__ sums4, long long scan_wait_ticks, int nlanes, int align) {
     __shared__ int sm_K[2][kScanMaxChunks][3], sm_pos[2][kScanMaxChunks][3], sm_flag[2][kScanMaxChunks][3], sm_key[2][kScanMaxChunks][3];
     __shared__ int tick;
     __shared__ __attribute__((aligned(16))) float xs[3][kScanChunk];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t ticket_cells = (int64_t)nchunk * kScanChunk;
 
+    // the XCD this workgroup runs on (HW_REG_XCC_ID, bits 3:0)
+    const int my_lane = nlanes > 1 ? (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u) % nlanes : 0;
+
     struct Raw { float ar[4], e3[4], tt[4], mk[4], mx[4]; };
     for (;;) {
-        if (threadIdx.x == 0) tick = __hip_atomic_fetch_add(&ctl->ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // Dealing.  Lane x of `nlanes` holds the steps x, x + nlanes, ... of every level, in that order; a workgroup draws from
+        // the lane of the XCD it runs on, and from the next lanes once its own is empty.  The 75 levels of a step multiply
+        // the SAME 131072 values of e1t*e2t: drawn by one XCD they find them in its L2 after the first (dealt from one
+        // counter the levels of a step spread over the eight L2s and the plane was fetched eight times, 0.4 B per cell).
+        // No deadlock: every lane deals in increasing order, so the smallest ticket not yet finished is either held by a
+        // workgroup that runs (all it waits for is finished) or the next one of its lane, whose workgroups all hold
+        // finished-or-running smaller tickets and come back for it.
+        if (threadIdx.x == 0) {
+            int t = -1;
+            for (int o = 0; o < nlanes && t < 0; ++o) {
+                const int x = (my_lane + o) % nlanes;
+                const int steps_x = (nsteps - x + nlanes - 1) / nlanes;            // steps x, x + nlanes, ... < nsteps
+                if (steps_x <= 0 || __hip_atomic_load(&ctl->lane_next[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= steps_x * a.npk) continue;
+                const int i = __hip_atomic_fetch_add(&ctl->lane_next[x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (i < steps_x * a.npk) {
+                    t = (x + nlanes * (i / a.npk)) * a.npk + i % a.npk;
+                    if (o) atomicAdd(&ctl->nstolen, 1);
+                }
+            }
+            if (t >= 0) atomicAdd(&ctl->ticket, 1);
+            tick = t;
+        }
         __syncthreads();
         const int ticket = tick;
-        if (ticket >= nsteps * a.npk) break;                      // (uniform)
+        if (ticket < 0) break;                                    // (uniform)
         const int step = ticket / a.npk, k = ticket - step * a.npk;
+        // A level is walked in VIRTUAL cells: `pad` cells that do not exist (terms of -0.0, the one value that changes no sum,
+        // not even a sum of -0.0) stand before its first one, so that every chunk of 512 starts on a 128-byte line of temp,
+        // e3t and the byte mask alike whatever k * nij is -- a line split between two chunks is fetched by both (two waves,
+        // two moments): 0.35 B per cell of 9.1 at eORCA12, where a level starts 48 bytes into a line.
         const int64_t base = (int64_t)k * a.nij, t0 = (int64_t)step * ticket_cells;
+        const int pad = align ? (int)((base + (int64_t)((reinterpret_cast<uintptr_t>(a.temp) >> 2) & 127u)) & 127) : 0;
+        const int64_t nijv = a.nij + pad;
         const float e3k = FULL ? a.e31d[k] : 0.f;
         const float dw  = MXL ? a.gdepw[k] : 0.f;
         if (w < 3) {
@@ -457,16 +536,24 @@ __global__ void __launch_bounds__(64 * kScanWaves, 3) heatc_scan_kernel(HeatcArg
             const int sp = min(step, (int)(pub >> 32));
             const float sv = __uint_as_float((uint32_t)pub);
             const double *el = est + (int64_t)k * (a.nblk + 1) * 3 + w;
-            const int64_t ab = min((int64_t)a.nblk, (int64_t)sp * ticket_cells / block_cells);
+            const int64_t ab = min((int64_t)a.nblk, max((int64_t)0, (int64_t)sp * ticket_cells - pad) / block_cells);
             for (int q = lane; q < nchunk; q += 64) {
                 const int64_t c0 = t0 + (int64_t)q * kScanChunk;
                 int k0 = -1, k1 = -1;
-                if (c0 < a.nij) {
-                    const int64_t cb = c0 / block_cells;
-                    const double d0 = (double)sv + (el[cb * 3] - el[ab * 3]), d1 = (double)sv + (el[(cb + 1) * 3] - el[ab * 3]);
+                if (c0 < nijv) {
+                    const int64_t c0r = max((int64_t)0, c0 - pad), cb = c0r / block_cells;
+                    const double b0 = el[cb * 3] - el[ab * 3], b1 = el[(cb + 1) * 3] - el[ab * 3];      // growth since the published value
+                    const double per = (b1 - b0) / (double)block_cells;
+                    const double g0 = b0 + per * (double)(c0r - cb * block_cells), g1 = g0 + per * (double)kScanChunk;
+                    const double d0 = (double)sv + g0, d1 = (double)sv + g1;
                     k0 = scan_key((float)d0); k1 = scan_key((float)d1);
                     if (k0 < 0) { k0 = k1; k1 = -1; }
                     if (k1 == k0) k1 = -1;
+                    if (k1 < 0 && k0 >= 0) {                      // the estimate may be off by a share of what it added to the exact value
+                        const double u = 0.25 * fabs(g0);
+                        const int ku = scan_key((float)(d0 + u)), kd = scan_key((float)(d0 - u));
+                        k1 = (ku >= 0 && ku != k0) ? ku : (kd >= 0 && kd != k0) ? kd : -1;
+                    }
                 }
                 sm_key[0][q][w] = k0; sm_key[1][q][w] = k1;
             }
@@ -474,37 +561,44 @@ __global__ void __launch_bounds__(64 * kScanWaves, 3) heatc_scan_kernel(HeatcArg
         __syncthreads();
 
         auto fetch = [&](Raw (&raw)[kScanNV], int64_t c0) {       // 512 cells from c0 on: lane l takes cells 4l..4l+3 of each 256
+            if (c0 >= pad && c0 + kScanChunk <= nijv) {           // (uniform) every cell exists: four 16-byte loads per field and lane, nothing else
 #pragma unroll
-            for (int v = 0; v < kScanNV; ++v) {
-                Raw &x = raw[v];
-                const int64_t p = c0 + v * 256 + 4 * lane;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) { x.ar[c] = x.e3[c] = x.tt[c] = x.mk[c] = x.mx[c] = 0.f; }
-                if (p + 3 < a.nij) {
+                for (int v = 0; v < kScanNV; ++v) {
+                    Raw &x = raw[v];
+                    const int64_t p = c0 + v * 256 + 4 * lane - pad;
                     const f4u av = *reinterpret_cast<const f4u *>(a.area + p);
                     x.ar[0] = av.x; x.ar[1] = av.y; x.ar[2] = av.z; x.ar[3] = av.w;
                     const f4u tv = ld_stream4u(a.temp + base + p);
                     x.tt[0] = tv.x; x.tt[1] = tv.y; x.tt[2] = tv.z; x.tt[3] = tv.w;
                     if (!FULL) { const f4u ev = ld_stream4u(a.e3t + base + p); x.e3[0] = ev.x; x.e3[1] = ev.y; x.e3[2] = ev.z; x.e3[3] = ev.w; }
+                    else       { x.e3[0] = x.e3[1] = x.e3[2] = x.e3[3] = 0.f; }
                     if (MASK8) { const u4u m = __builtin_nontemporal_load(reinterpret_cast<const u4u *>(a.mask8 + base + p)); x.mk[0] = m.x; x.mk[1] = m.y; x.mk[2] = m.z; x.mk[3] = m.w; }
                     else       { const f4u m = ld_stream4u(a.mask4 + base + p); x.mk[0] = m.x; x.mk[1] = m.y; x.mk[2] = m.z; x.mk[3] = m.w; }
                     if (MXL) { const f4u mv = *reinterpret_cast<const f4u *>(a.mxl + p); x.mx[0] = mv.x; x.mx[1] = mv.y; x.mx[2] = mv.z; x.mx[3] = mv.w; }
-                } else {
+                    else     { x.mx[0] = x.mx[1] = x.mx[2] = x.mx[3] = 0.f; }
+                }
+                return;
+            }
 #pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        if (p + c < a.nij) {
-                            x.ar[c] = a.area[p + c];
-                            x.tt[c] = a.temp[base + p + c];
-                            if (!FULL) x.e3[c] = a.e3t[base + p + c];
-                            x.mk[c] = MASK8 ? (float)a.mask8[base + p + c] : a.mask4[base + p + c];
-                            if (MXL) x.mx[c] = a.mxl[p + c];
-                        }
+            for (int v = 0; v < kScanNV; ++v) {                   // the first and the last chunk of a level: cell by cell, zeros where there is none
+                Raw &x = raw[v];
+                const int64_t p = c0 + v * 256 + 4 * lane - pad;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    x.ar[c] = x.e3[c] = x.tt[c] = x.mk[c] = x.mx[c] = 0.f;
+                    if (p + c >= 0 && p + c < a.nij) {
+                        x.ar[c] = a.area[p + c];
+                        x.tt[c] = a.temp[base + p + c];
+                        if (!FULL) x.e3[c] = a.e3t[base + p + c];
+                        x.mk[c] = MASK8 ? (float)a.mask8[base + p + c] : a.mask4[base + p + c];
+                        if (MXL) x.mx[c] = a.mxl[p + c];
+                    }
                 }
             }
         };
         // the three r4 products of every cell in `raw`, exactly as the reference forms them (:225-229); zeros past the end
         auto products = [&](const Raw (&raw)[kScanNV], int64_t c0, float (&x)[3][kScanNV][4]) {
-            const bool whole = c0 + kScanChunk <= a.nij;          // (uniform) every cell of the chunk exists
+            const bool whole = c0 >= pad && c0 + kScanChunk <= nijv;     // (uniform) every cell of the chunk exists
 #pragma unroll
             for (int v = 0; v < kScanNV; ++v) {
 #pragma unroll
@@ -521,14 +615,14 @@ __global__ void __launch_bounds__(64 * kScanWaves, 3) heatc_scan_kernel(HeatcArg
                     x[2][v][c] = __fmul_rn(__fmul_rn(pv, r.tt[c]), r.mk[c]);
                 }
             }
-            if (!whole) {                                         // (uniform: only the last chunk of a level takes this branch)
+            if (!whole) {                                         // (uniform: only the first and the last chunk of a level take this branch)
 #pragma unroll
-                for (int v = 0; v < kScanNV; ++v) {
-                    const int left = (int)max((int64_t)0, min((int64_t)4, a.nij - (c0 + v * 256 + 4 * lane)));
+                for (int v = 0; v < kScanNV; ++v)
 #pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        if (c >= left) x[0][v][c] = x[1][v][c] = x[2][v][c] = 0.f;
-                }
+                    for (int c = 0; c < 4; ++c) {
+                        const int64_t id = c0 + v * 256 + 4 * lane + c;
+                        if (id < pad || id >= nijv) x[0][v][c] = x[1][v][c] = x[2][v][c] = -0.f;
+                    }
             }
         };
         // sums of chunk q under the hypotheses of each chain
@@ -586,12 +680,12 @@ __global__ void __launch_bounds__(64 * kScanWaves, 3) heatc_scan_kernel(HeatcArg
 #pragma clang loop unroll(disable)
             for (int q = w; q < nchunk; q += kScanWaves) {
                 const int64_t c0 = t0 + (int64_t)q * kScanChunk;
-                if (c0 >= a.nij) {                                // past the end of the level: nothing there
+                if (c0 >= nijv) {                                 // past the end of the level: nothing there
                     if (lane == 0) for (int ch = 0; ch < 3; ++ch) sm_flag[0][q][ch] = sm_flag[1][q][ch] = 0;
                     continue;
                 }
                 products(raw, c0, x);
-                if (q + kScanWaves < nchunk && c0 + kScanSub < a.nij) fetch(raw, c0 + kScanSub);
+                if (q + kScanWaves < nchunk && c0 + kScanSub < nijv) fetch(raw, c0 + kScanSub);
                 summarize(x, q);
             }
         }
@@ -602,10 +696,21 @@ __global__ void __launch_bounds__(64 * kScanWaves, 3) heatc_scan_kernel(HeatcArg
             // the exact value where this ticket starts: published by the step before (tag == step)
             unsigned long long pub = 0;
             if (lane == 0) {
+                // (the step waited for was dealt before this one: it is held by a workgroup that runs.  Two seconds of the
+                // 100 MHz wall clock without it -- a preempted queue, a fault -- raise the error flag; every other wait sees the
+                // flag and gives up too, the kernel ends and the host takes the plain chain instead)
+                long long t_start = 0;
                 int spins = 0;
                 while ((int)((pub = __hip_atomic_load(&lev[k].word[ch], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != step) {
                     __builtin_amdgcn_s_sleep(1);
-                    if (++spins > (1 << 24)) { __hip_atomic_store(&ctl->error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                    if ((++spins & 1023) == 0 || scan_wait_ticks == 0) {
+                        const long long now = wall_clock64();
+                        if (!t_start) t_start = now;
+                        if (now - t_start >= scan_wait_ticks || __hip_atomic_load(&ctl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                            __hip_atomic_store(&ctl->error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            break;
+                        }
+                    }
                 }
             }
             float s = __uint_as_float((uint32_t)__shfl((int)(uint32_t)pub, 0, 64));
@@ -620,7 +725,7 @@ __global__ void __launch_bounds__(64 * kScanWaves, 3) heatc_scan_kernel(HeatcArg
                 for (int g = from & ~63; g < nchunk && stop < 0; g += 64) {
                     const int q = g + lane;
                     const int f0 = sm_flag[0][q][ch];
-                    const bool live = q >= from && ((f0 & 1) || (minus0 && t0 + (int64_t)q * kScanChunk < a.nij));   // zeros: s + 0 = s
+                    const bool live = q >= from && ((f0 & 1) || (minus0 && t0 + (int64_t)q * kScanChunk < nijv));   // zeros: s + 0 = s
                     const int h = (ks >= 0 && ks == sm_key[0][q][ch]) ? 0 : (ks >= 0 && ks == sm_key[1][q][ch]) ? 1 : -1;
                     const int hh = h < 0 ? 0 : h;
                     const int f = sm_flag[hh][q][ch];
@@ -638,7 +743,7 @@ __global__ void __launch_bounds__(64 * kScanWaves, 3) heatc_scan_kernel(HeatcArg
                 // the chunk that stopped the walk: read again and resolved cell by cell
                 const int q = stop;
                 const int64_t c0 = t0 + (int64_t)q * kScanChunk;
-                const int nvalid = (int)max((int64_t)0, min((int64_t)kScanChunk, a.nij - c0));
+                const int nvalid = (int)max((int64_t)0, min((int64_t)kScanChunk, nijv - c0));
                 Raw raw[kScanNV];
                 float x3[3][kScanNV][4];
                 fetch(raw, c0);
@@ -772,27 +877,73 @@ int launch_seq_chain(const HeatcArgs &a, const float *carry, float *sums4, hipSt
     return CDFT_OK;
 }
 
-// a.partial holds the r8 sums of the level kernel over blocks of `block_cells` cells (a multiple of a chunk, a divisor of a ticket)
-int launch_seq_scan(const HeatcArgs &a, int block_cells, const float *carry, float *sums4, DevBuf &work, hipStream_t st) {
-    const bool m8 = a.mask8 != nullptr, full = a.e31d != nullptr;
+// How many XCDs the workgroups of a launch land on (HW_REG_XCC_ID): 8 on an MI355X in SPX mode.  Asked once per device; the
+// scan deals its tickets XCD by XCD only when the ids seen are exactly 0 .. n-1 (else from one counter, as before).
+__global__ void heatc_xcc_probe_kernel(unsigned *seen) {
+    if (threadIdx.x == 0) atomicOr(seen, 1u << (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u));
+}
+int scan_lanes(hipStream_t st) {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 1;
+    if (const char *e = getenv("CDFT_HEATC_SCAN_LANES")) return std::min(std::max(atoi(e), 1), kScanMaxLanes);   // (A/B and test hook: 1 = one counter)
+    if (cached[dev]) return cached[dev];
+    int n = 1;
+    {
+        unsigned *d = nullptr, h = 0;
+        if (hipMalloc((void **)&d, sizeof(unsigned)) == hipSuccess) {
+            if (hipMemsetAsync(d, 0, sizeof(unsigned), st) == hipSuccess) {
+                hipLaunchKernelGGL(heatc_xcc_probe_kernel, dim3(4096), dim3(64), 0, st, d);
+                if (hipMemcpyAsync(&h, d, sizeof(unsigned), hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess)
+                    for (int c = 2; c <= kScanMaxLanes; ++c)
+                        if (h == (1u << c) - 1u) n = c;
+            }
+            (void)hipFree(d);
+        }
+        (void)hipGetLastError();
+    }
+    return cached[dev] = n;
+}
+
+// the sampled estimates (heatc_sample_kernel: blocks of kSampleBlock cells -- a multiple of a chunk, a divisor of a ticket), then the scan
+int launch_seq_scan(HeatcArgs a, const float *carry, float *sums4, DevBuf &work, hipStream_t st) {
+    const bool m8 = a.mask8 != nullptr, full = a.e31d != nullptr, mx = a.mxlopt != 0;
+    const int block_cells = kSampleBlock;
+    a.nblk = (int)((a.nij + kSampleBlock - 1) / kSampleBlock);
+    // two seconds of the 100 MHz clock (CDFT_HEATC_SCAN_WAIT_US: test hook -- 0 makes the first wait that is not over at once give up)
+    long long wait_ticks = 200000000LL;
+    if (const char *e = getenv("CDFT_HEATC_SCAN_WAIT_US")) wait_ticks = std::max(0LL, atoll(e)) * 100LL;
     // about 32 tickets per level: enough of them in flight for every CU, few enough steps in a level's chain of waits
     int nchunk = 64;
     while (nchunk < kScanMaxChunks && a.nij > (int64_t)nchunk * kScanChunk * 32) nchunk *= 2;
     if (const char *e = getenv("CDFT_HEATC_SCAN_CHUNKS")) { const int v = atoi(e); if (v == 64 || v == 128 || v == 256) nchunk = v; }   // (tuning hook)
     const int64_t ticket_cells = (int64_t)nchunk * kScanChunk;
-    const int nsteps = (int)((a.nij + ticket_cells - 1) / ticket_cells);
+    const int nsteps = (int)((a.nij + 127 + ticket_cells - 1) / ticket_cells);   // (a level is walked with up to 127 cells of padding in front)
+    const int nlanes = scan_lanes(st);
+    const int align = getenv("CDFT_HEATC_SCAN_NOALIGN") ? 0 : 1;          // (A/B hook)
     const size_t head = (sizeof(ScanLevel) * (size_t)a.npk + sizeof(ScanCtl) + 15) / 16 * 16;
     CDFT_TRY(work.reserve(head + sizeof(double) * (size_t)a.npk * (a.nblk + 1) * 3));
     ScanLevel *lev = (ScanLevel *)work.ptr;
     ScanCtl *ctl = (ScanCtl *)(lev + a.npk);
     double *est = (double *)((char *)work.ptr + head);
+    {
+        int64_t dense_cells = 32768;                              // read in full: where a chain grows from nothing
+        if (const char *e = getenv("CDFT_HEATC_SCAN_DENSE")) dense_cells = std::max(0LL, atoll(e));           // (tuning hook)
+        const dim3 sgrid((unsigned)((a.nblk + 3) / 4), (unsigned)a.npk), sblock(256);
+#define CDFT_SAMPLE_LAUNCH(M8, FU, MX) hipLaunchKernelGGL((heatc_sample_kernel<M8, FU, MX>), sgrid, sblock, 0, st, a, dense_cells)
+        if (m8 && full)        { if (mx) CDFT_SAMPLE_LAUNCH(true, true, true);   else CDFT_SAMPLE_LAUNCH(true, true, false); }
+        else if (m8 && !full)  { if (mx) CDFT_SAMPLE_LAUNCH(true, false, true);  else CDFT_SAMPLE_LAUNCH(true, false, false); }
+        else if (!m8 && full)  { if (mx) CDFT_SAMPLE_LAUNCH(false, true, true);  else CDFT_SAMPLE_LAUNCH(false, true, false); }
+        else                   { if (mx) CDFT_SAMPLE_LAUNCH(false, false, true); else CDFT_SAMPLE_LAUNCH(false, false, false); }
+#undef CDFT_SAMPLE_LAUNCH
+        CDFT_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(heatc_scan_est_kernel, dim3(a.npk), dim3(64), 0, st, a.partial, a.nblk, carry, est, lev, ctl);
     int dev = 0, ncu = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
     const int64_t tickets = (int64_t)nsteps * a.npk;
     dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>(tickets, 3 * (int64_t)ncu))), block(64 * kScanWaves);
-#define CDFT_SCAN_LAUNCH(M8, FU, MX) hipLaunchKernelGGL((heatc_scan_kernel<M8, FU, MX>), grid, block, 0, st, a, lev, ctl, est, block_cells, nchunk, nsteps, sums4)
-    const bool mx = a.mxlopt != 0;
+#define CDFT_SCAN_LAUNCH(M8, FU, MX) hipLaunchKernelGGL((heatc_scan_kernel<M8, FU, MX>), grid, block, 0, st, a, lev, ctl, est, block_cells, nchunk, nsteps, sums4, wait_ticks, nlanes, align)
     if (m8 && full)        { if (mx) CDFT_SCAN_LAUNCH(true, true, true);   else CDFT_SCAN_LAUNCH(true, true, false); }
     else if (m8 && !full)  { if (mx) CDFT_SCAN_LAUNCH(true, false, true);  else CDFT_SCAN_LAUNCH(true, false, false); }
     else if (!m8 && full)  { if (mx) CDFT_SCAN_LAUNCH(false, true, true);  else CDFT_SCAN_LAUNCH(false, true, false); }
@@ -953,7 +1104,7 @@ int cdft_heatc_compute(cdft_heatc_plan *p, const float *temp, int temp_space, co
     else if (nij % 2 == 0 && aligned_to(dt, 8) && aligned_to(dm, 8)) vec = 2;
     a.nblk = vec == -4 ? (int)(((nij + 3) / 4 + 1 + kThreads * 4 - 1) / (kThreads * 4))
                        : (int)((nij / vec + kThreads * 4 - 1) / (kThreads * 4));   // kVPT = 4 vectors per lane
-    if (!chain) {                                         // the r8 sums per block: the result (r8 mode), or the estimates of the r4 chains
+    if (!r4seq) {                                         // the r8 sums per block
         if (vec == -4)     CDFT_TRY(launch_u4(a, st));
         else if (vec == 4) CDFT_TRY(launch_vec<4>(a, st));
         else if (vec == 2) CDFT_TRY(launch_vec<2>(a, st));
@@ -970,7 +1121,7 @@ int cdft_heatc_compute(cdft_heatc_plan *p, const float *temp, int temp_space, co
             dcarry = (const float *)p->st_c4.ptr;
         }
         if (chain) CDFT_TRY(launch_seq_chain(a, dcarry, (float *)p->st_s4.ptr, st));
-        else       CDFT_TRY(launch_seq_scan(a, kThreads * 4 * (vec < 0 ? -vec : vec), dcarry, (float *)p->st_s4.ptr, p->st_scan, st));
+        else       CDFT_TRY(launch_seq_scan(a, dcarry, (float *)p->st_s4.ptr, p->st_scan, st));
         p->last4.resize(n);
         CDFT_HIP(hipMemcpyAsync(p->last4.data(), p->st_s4.ptr, n * sizeof(float), hipMemcpyDeviceToHost, st));
         ScanCtl ctl = {};
@@ -979,9 +1130,16 @@ int cdft_heatc_compute(cdft_heatc_plan *p, const float *temp, int temp_space, co
         CDFT_HIP(hipStreamSynchronize(st));
         if (!chain && getenv("CDFT_HEATC_SCAN_STATS"))
             fprintf(stderr, "heatc_scan_kernel: %d tickets, %d chunks resolved cell by cell (%d of them finished by the sequential loop), "
-                    "%d times in a binade neither estimate named\n", ctl.ticket, ctl.nfallback, ctl.nslow, ctl.nunguessed);
-        if (ctl.error)
-            return fail(CDFT_ERR_HIP, "cdfheatc: a workgroup of heatc_scan_kernel waited over a second for the step before it (results discarded)");
+                    "%d times in a binade neither estimate named; %d tickets drawn from another XCD's lane\n", ctl.ticket, ctl.nfallback, ctl.nslow,
+                    ctl.nunguessed, ctl.nstolen);
+        if (ctl.error) {
+            // a wait that did not end (heatc_scan_kernel): its results are discarded and the plain chain of v_add_f32 --
+            // no workgroup waits for another there -- gives the same bits, 25 times slower
+            fprintf(stderr, "cdfheatc: heatc_scan_kernel gave up waiting for a step of its chains; the sums are formed by the plain chain instead\n");
+            CDFT_TRY(launch_seq_chain(a, dcarry, (float *)p->st_s4.ptr, st));
+            CDFT_HIP(hipMemcpyAsync(p->last4.data(), p->st_s4.ptr, n * sizeof(float), hipMemcpyDeviceToHost, st));
+            CDFT_HIP(hipStreamSynchronize(st));
+        }
         p->carry.clear();
         std::vector<double> s8(n);
         for (size_t i = 0; i < n; ++i) s8[i] = (double)p->last4[i];

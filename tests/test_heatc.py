@@ -222,11 +222,40 @@ def test_hip_reference_order_kernels_agree_on_eorca12_levels(gpu, monkeypatch):
     assert np.array_equal(a, b)
     ref = oracle_tools.heatc(e1t, e2t, mask, temp, e3t=e3t, r4sum=True)
     assert np.array_equal(a, ref.view(np.uint64))
+    # the tickets dealt from one counter, from three lanes (a lane count the XCDs do not divide into: tickets get stolen) and
+    # with no cell read in full by the sampling pass (the first hypotheses all wrong): the same bits
+    for var, val in (("CDFT_HEATC_SCAN_LANES", "1"), ("CDFT_HEATC_SCAN_LANES", "3"), ("CDFT_HEATC_SCAN_DENSE", "0")):
+        monkeypatch.setenv(var, val)
+        assert np.array_equal(plan.compute(temp).view(np.uint64), a), (var, val)
+        monkeypatch.delenv(var)
     assert (np.abs(ref - r8) / np.abs(r8)).max() > 1e-3            # the reference's own r4 SUM is this far from the sum here
     sh = gpu.HeatcPlan(npi, npj, npk, devices=[0, 0, 0])
     sh.set_mesh(e1t, e2t, mask, e3t=e3t)
     sh.set_sum_mode(True)
     assert np.array_equal(sh.compute(temp).view(np.uint64), a)
+
+
+@pytest.mark.gpu
+def test_hip_reference_order_scan_that_gives_up_hands_over_to_the_chain(gpu, monkeypatch, capfd):
+    """A wait of heatc_scan_kernel that does not end (a preempted queue, a fault) raises a flag instead of hanging; the
+    host then forms the sums with the plain chain and says so.  CDFT_HEATC_SCAN_WAIT_US=0: the first wait that is not
+    over at once gives up."""
+    npi, npj, npk = 1442, 400, 6
+    g, temp, _ = fields(npi, npj, npk, seed=31)
+    plan = gpu.HeatcPlan(npi, npj, npk)
+    plan.set_mesh(g["e1t"], g["e2t"], g["tmask"].astype(np.uint8), e3t=g["e3t_0"])
+    plan.set_sum_mode(True)
+    ref = oracle_tools.heatc(g["e1t"], g["e2t"], g["tmask"], temp, e3t=g["e3t_0"], r4sum=True)
+    monkeypatch.delenv("CDFT_HEATC_SEQ", raising=False)
+    capfd.readouterr()
+    monkeypatch.setenv("CDFT_HEATC_SCAN_WAIT_US", "0")
+    got = plan.compute(temp)
+    monkeypatch.delenv("CDFT_HEATC_SCAN_WAIT_US")
+    err = capfd.readouterr().err
+    assert np.array_equal(got, ref)
+    assert "plain chain" in err, err                   # (18 tickets of 6 levels: some workgroup gets there before its predecessor)
+    assert np.array_equal(plan.compute(temp), ref)     # and the plan is as good as before
+    assert "plain chain" not in capfd.readouterr().err
 
 
 FUZZ_SHAPES = [(1, 1, 1), (511, 1, 2), (512, 1, 1), (513, 1, 3), (4, 127, 2), (4096, 8, 1), (4097, 8, 2), (257, 255, 3), (1023, 33, 2),

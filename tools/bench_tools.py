@@ -183,8 +183,9 @@ def main():
         p.set_sum_mode(True)
         ms = timed(lambda: p.compute(temp), max(3, args.reps // 4))
         report("cdfheatc, reference-order r4 sums", args.grid, n3, 9.0 + 8.0 / npk, ms,
-               "CDFT_HEATC_SUM_R4SEQ: bit-identical to the reference's sequential REAL*4 SUM (heatc_scan_kernel: integer sums inside a binade, "
-               "after the r8 level kernel whose block sums name the binades; CDFT_HEATC_SEQ=chain times the plain chain of v_add_f32 instead)")
+               "CDFT_HEATC_SUM_R4SEQ: bit-identical to the reference's sequential REAL*4 SUM.  One pass over the fields (heatc_scan_kernel: "
+               "integer sums inside a binade) after heatc_sample_kernel has read 1/64 of them to name the binades; "
+               "CDFT_HEATC_SEQ=chain times the plain chain of v_add_f32 instead")
         del p, tmask, temp
 
     if "mean" in tools:
