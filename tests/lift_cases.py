@@ -30,6 +30,16 @@ def moc_case(name):
 
 MOC_CASES = ["small5", "one_basin", "full", "decomp", "decomp_teos10", "tiny"]
 
+# cdfmoc -decomp as a PROGRAM, on files: the grid and the records tests/nemo_files.make_case writes (not the 24 x 18 x 7 of
+# the other end-to-end tests) -- the program forms zcoef itself from gphiv with its runtime's r4 SIN (src/cdfmoc.f90:427-433)
+MOC_PROG = dict(npi=90, npj=61, npk=15, npt=2)
+
+
+def moc_prog_case(d):
+    """-> g, records {'v','t','s',..}; every file of the case written under directory d"""
+    import nemo_files
+    return nemo_files.make_case(d, **MOC_PROG)
+
 
 def moc_zcoef(g):
     """src/cdfmoc.f90:427-433 with a correctly rounded r4 SIN (what amdflang's runtime returns on these arguments;

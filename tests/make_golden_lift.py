@@ -34,6 +34,15 @@ def g_cdfmoc():
     return d
 
 
+def g_cdfmoc_decomp_prog():
+    """what the reference's statements make of the files of lc.moc_prog_case: the 24 variables -decomp writes, as r4"""
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        g, rec = lc.moc_prog_case(tmp)
+    r = rl.cdfmoc(g, rec["v"], nbasins=5, decomp=dict(t=rec["t"], s=rec["s"]))
+    return {"var": r["var"], "dmoc": r["dmoc"], "dec": r["dec"]}
+
+
 def g_cdfheatc():
     d = {}
     for name in lc.HEATC_CASES:
@@ -222,7 +231,7 @@ def g_vvl():
     return d
 
 
-FILES = {"cdfvtrp_bathy": g_cdfvtrp_bathy, "cdfmoc": g_cdfmoc, "cdfheatc": g_cdfheatc, "cdfmhst": g_cdfmhst, "cdfpsi": g_cdfpsi, "cdfvt": g_cdfvt, "cdfcurl": g_cdfcurl,
+FILES = {"cdfmoc_decomp_prog": g_cdfmoc_decomp_prog, "cdfvtrp_bathy": g_cdfvtrp_bathy, "cdfmoc": g_cdfmoc, "cdfheatc": g_cdfheatc, "cdfmhst": g_cdfmhst, "cdfpsi": g_cdfpsi, "cdfvt": g_cdfvt, "cdfcurl": g_cdfcurl,
          "cdfvhst_cdfvtrp": g_cdfvhst_cdfvtrp, "cdfmean_cdfsum": g_cdfmean_cdfsum, "cdfvint_cdfvertmean": g_cdfvint_cdfvertmean,
          "cdfzonal": g_cdfzonal, "cdfmocsig": g_cdfmocsig, "cdfsig": g_cdfsig, "cdfmoc_rapid": g_cdfmoc_rapid, "cdfmaxmoc": g_cdfmaxmoc,
          "vvl": g_vvl}

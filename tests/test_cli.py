@@ -93,6 +93,46 @@ def test_cdfmoc_end_to_end(tools, tmp_path, basins):
 
 
 @pytest.mark.gpu
+def test_cdfmoc_decomp_program_against_reference_statements_at_another_size(tools, tmp_path):
+    """The PROGRAM on files of a 90 x 61 x 15 grid, two records: it forms zcoef itself (fortran/cdfmoc.f90: 2*2*rpi/86400 *
+    SIN(rpi*gphiv/180) in r4, as src/cdfmoc.f90:427-433) -- every one of the 24 variables it writes against what the
+    reference's own statements return on the same arrays (tests/golden/lift_cdfmoc_decomp_prog.npz): one r4 ulp for the
+    rounding of the stored value, plus 1e-13 of the sum of the absolute values of the terms of the element."""
+    import lift_cases as lc
+    from test_lift import decomp_vars, gold, moc_mesh, ulp4
+    from test_moc_decomp import decomp_bounds
+    g, rec = lc.moc_prog_case(str(tmp_path))
+    npk, npj, npi = g["tmask"].shape
+    rc, out, err = run("cdfmoc", ["-v", "SYN_y0001_gridV.nc", "-t", "SYN_y0001_gridT.nc", "-decomp", "-o", "dec.nc"], tmp_path)
+    assert rc == 0, out + err
+    var, _, _ = read_nc(os.path.join(tmp_path, "dec.nc"))
+    G = gold("cdfmoc_decomp_prog")
+    e1v, e3v, ib = moc_mesh(g, 5, False)
+    names = [b + sfx for b in ("zomsfglo", "zomsfatl", "zomsfinp", "zomsfind", "zomsfpac", "zomsfinp0") for sfx in ("", "_sh", "_bt", "_ag")]
+    assert G["var"].shape == (2, 24, npk, npj)
+    shb = None
+    worst = 0.0
+    for t in range(2):
+        a = dict(e1v=e1v, e3v=e3v, ibmask=ib, zv=rec["v"][t], ztemp=rec["t"][t], zsal=rec["s"][t], tmask=g["tmask"].astype(np.uint8),
+                 umask=g["umask"].astype(np.uint8), e1u=g["e1u"], zcoef=lc.moc_zcoef(g), gdept=g["gdept_1d"].astype(np.float32))
+        b = decomp_bounds(a, prior_bound=shb)
+        shb = b["sh"]
+        # the bounds in the order of the variables: basin by basin total, sh, bt, ag; glo - atl: the terms of both
+        bt = np.stack([b["total"]])
+        bp = np.stack([np.stack([b["sh"], b["bt"], b["ag"]])])
+        bv = decomp_vars(bt, bp, 5).astype(np.float64)[0]
+        for q, kk in zip(range(20, 24), ("total", "sh", "bt", "ag")):
+            bv[q] = b[kk][..., 0] + b[kk][..., 1]
+        for q, nm in enumerate(names):
+            got, want = var[nm][t, :, :, 0].astype(np.float64), G["var"][t, q].astype(np.float64)
+            tol = ulp4(G["var"][t, q]) + 1e-13 * bv[q] + 1e-30
+            assert np.all(np.abs(got - want) <= tol), (nm, t, float((np.abs(got - want) / tol).max()))
+            worst = max(worst, float((np.abs(got - want) / tol).max()))
+    assert np.abs(G["var"][:, 1]).max() > 0 and np.abs(G["var"][:, 2]).max() > 0       # shear and barotropic parts are there
+    print("worst |got - want| / tol:", worst)
+
+
+@pytest.mark.gpu
 def test_cdfmoc_decomp_end_to_end(tools, tmp_path):
     """cdfmoc -v V -t T -decomp: 4 variables per basin (total, _sh, _bt, _ag), 24 in all, in the
     reference's order; record 2 accumulates its shear part onto record 1's (src/cdfmoc.f90:471)."""

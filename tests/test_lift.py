@@ -84,6 +84,17 @@ def oracle_decomp_records(g, zv, dec, teos, e1v, e3v, ib):
     return np.stack(tot), np.stack(parts)
 
 
+def test_oracle_decomp_on_the_program_case_equals_reference_statements(tmp_path):
+    """cdfmoc -decomp on the 90 x 61 x 15 grid of lc.moc_prog_case (two records): the reference's statements formed zcoef from
+    gphiv themselves with the r4 SIN of amdflang's runtime (src/cdfmoc.f90:427-433); the oracle is handed lc.moc_zcoef's."""
+    g, rec = lc.moc_prog_case(str(tmp_path))
+    e1v, e3v, ib = moc_mesh(g, 5, False)
+    G = gold("cdfmoc_decomp_prog")
+    tot, parts = oracle_decomp_records(g, rec["v"], dict(t=rec["t"], s=rec["s"]), False, e1v, e3v, ib)
+    assert same(tot, G["dmoc"]) and same(parts, G["dec"])
+    assert same(decomp_vars(tot, parts, 5), G["var"])
+
+
 @pytest.mark.parametrize("name", lc.MOC_CASES)
 def test_oracle_moc_equals_reference_statements(name):
     g, zv, nb, full, dec, teos, e1v, e3v, ib = moc_oracle(name)
@@ -351,14 +362,20 @@ def test_hip_moc_against_reference_statements(gpu, name):
         assert np.all(np.abs(got - G[f"{name}.dmoc"]) <= 1e-13 * bound + 1e-300)
         assert np.all(np.abs(moc_vars(got, nb).astype(np.float64) - G[f"{name}.var"]) <= ulp4(G[f"{name}.var"]))
         return
+    from test_moc_decomp import decomp_bounds, within_bounds
     plan.decomp_set_mesh(e3v, g["e1u"], lc.moc_zcoef(g), g["gdept_1d"], g["tmask"], g["umask"])
-    sh = None
+    sh = shb = None
     for t in range(zv.shape[0]):
         o = plan.decomp(zv[t], dec["t"][t], dec["s"][t], dmoc_sh=sh, eos=gpu.EOS_TEOS10 if teos else gpu.EOS_80)
-        sh = o["sh"]
         ref = {"total": G[f"{name}.dmoc"][t], "sh": G[f"{name}.dec"][t, 0], "bt": G[f"{name}.dec"][t, 1], "ag": G[f"{name}.dec"][t, 2]}
-        for k in ref:                       # the tolerance stated in tests/test_moc_decomp.py
-            assert np.all(np.abs(o[k] - ref[k]) <= 1e-10 * (np.abs(ref[k]).max() + 1e-300)), (k, t)
+        a = dict(e1v=e1v, e3v=e3v, ibmask=ib, zv=zv[t], ztemp=dec["t"][t], zsal=dec["s"][t], tmask=g["tmask"].astype(np.uint8),
+                 umask=g["umask"].astype(np.uint8), e1u=g["e1u"], zcoef=lc.moc_zcoef(g), gdept=g["gdept_1d"].astype(np.float32))
+        # element by element, 1e-13 of the sum of the absolute values of its terms (tests/test_moc_decomp.py); the shear part
+        # is accumulated onto the one of the record before (:471) -- the GPU's onto its own, the reference's onto its own:
+        # that one's terms count too
+        b = decomp_bounds(a, teos, prior_bound=shb)
+        within_bounds(o, ref, b)
+        sh, shb = o["sh"], b["sh"]
 
 
 @pytest.mark.gpu

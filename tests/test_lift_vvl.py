@@ -90,9 +90,15 @@ def test_hip_moc_vvl(gpu, name):
         plan.set_mesh(e1v, e3v, ib)                      # the program's -vvl path: the mesh again at every record
         return plan.compute(zv[None])[0]
 
+    from test_moc_decomp import decomp_bounds
+    bounds = []
+
     def decomp(g, e1v, e3v, ib, zv, zt, zs, teos, sh):
         plan.set_mesh(e1v, e3v, ib)
         plan.decomp_set_mesh(e3v, g["e1u"], lc.moc_zcoef(g), g["gdept_1d"], g["tmask"], g["umask"])
+        a = dict(e1v=e1v, e3v=e3v, ibmask=ib, zv=zv, ztemp=zt, zsal=zs, tmask=g["tmask"].astype(np.uint8), umask=g["umask"].astype(np.uint8),
+                 e1u=g["e1u"], zcoef=lc.moc_zcoef(g), gdept=g["gdept_1d"].astype(f32))
+        bounds.append(decomp_bounds(a, teos, prior_bound=bounds[-1]["sh"] if bounds else None))
         return plan.decomp(zv, zt, zs, dmoc_sh=sh, eos=gpu.EOS_TEOS10 if teos else gpu.EOS_80)
     g, nb, dec, tot, parts, e1v, ib, zv, e3v_t = moc_records(name, moc, decomp)
     gd = G()
@@ -102,9 +108,10 @@ def test_hip_moc_vvl(gpu, name):
     if dec is None:
         assert np.all(np.abs(tot - want) <= 1e-13 * bound + 1e-300)
         assert np.all(np.abs(moc_vars(tot, nb).astype(np.float64) - gd[f"moc.{name}.var"]) <= ulp4(gd[f"moc.{name}.var"]))
-    else:                                                # the tolerance of tests/test_lift.py's -decomp cases
-        for got, ref in [(tot, want)] + [(parts[:, c], gd[f"moc.{name}.dec"][:, c]) for c in range(3)]:
-            assert np.all(np.abs(got - ref) <= 1e-10 * (np.abs(ref).max() + 1e-300))
+    else:                                                # the tolerance of tests/test_lift.py's -decomp cases: 1e-13 of the sum of |terms|
+        for t in range(zv.shape[0]):
+            for got, ref, key in [(tot[t], want[t], "total")] + [(parts[t, c], gd[f"moc.{name}.dec"][t, c], k) for c, k in enumerate(("sh", "bt", "ag"))]:
+                assert np.all(np.abs(got - ref) <= 1e-13 * bounds[t][key] + 1e-300), (t, key)
 
 
 # ================================================================================================ cdfheatc
