@@ -42,6 +42,13 @@ struct TraceRange {
     bool on, timed;
     double t0;
 };
+// While one is alive on a thread, the ranges made on that thread are not added to the CDFT_TIMING totals (they still
+// show as roctx ranges): the row blocks of a sharded plan call the very entry points the caller's range already times,
+// side by side on their own threads -- counted too, a call on four devices read as five calls and five times its wall time.
+struct TraceMute {
+    TraceMute();
+    ~TraceMute();
+};
 
 // Streaming loads.  Every kernel of this path reads its 3-D fields exactly once; a nontemporal
 // load tells L2 / Infinity Cache not to keep those lines (measured with tools/hbm_probe.hip on

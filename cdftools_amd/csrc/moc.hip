@@ -614,6 +614,7 @@ int cdft_moc_decomp_set_mesh(cdft_moc_plan *p, const float *e3v, const float *e1
 int cdft_moc_decomp(cdft_moc_plan *p, const float *zv, const float *ztemp, const float *zsal, int eos, int in_space,
                     double *dmoc, double *dmoc_sh, double *dmoc_bt, double *dmoc_ag, int out_space, void *stream) {
     TraceRange trace_("cdft_moc_decomp");
+    TraceMute mute_;                                             // (the sigmai calls below are part of this one)
     if (!p || !zv || !ztemp || !zsal || !dmoc || !dmoc_sh || !dmoc_bt || !dmoc_ag)
         return fail(CDFT_ERR_ARG, "cdft_moc_decomp: NULL argument");
     if (!p->mesh_set || !p->dec_set)

@@ -3,6 +3,13 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// The DPP control words below (row_bcast:15 / :31, row mirrors) are those of the GCN / CDNA wave64 encoding; this library
+// is built for gfx950 alone (csrc/Makefile) and says so here rather than miscompiling quietly elsewhere (RDNA has no
+// row_bcast).  Device passes only: the host pass of hipcc defines no __gfx*__ macro.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__) && !defined(__gfx90a__)
+#error "cdftools_amd/csrc/reduce.hpp: the DPP wave reductions are written for CDNA (gfx950); build with --offload-arch=gfx950"
+#endif
+
 namespace cdft {
 
 // One step of the reduction: v + (v moved across lanes by the DPP control word).  Data-parallel primitives run in the
@@ -16,6 +23,8 @@ __device__ __forceinline__ double dpp_add(double v) {
 }
 
 // Fixed order: quads, half rows, rows of 16, then the four rows in order -- the same tree on every call.
+// (Round 1 reduced with __shfl_xor butterflies: another tree, so r8 sums formed since differ from round-1 output in the
+// last bits -- inside the 1e-13 * sum|terms| every regrouped sum is held to, and identical from run to run as before.)
 __device__ __forceinline__ double wave_sum(double v) {
     v = dpp_add<0xb1, 0xf>(v);                    // quad_perm:[1,0,3,2]
     v = dpp_add<0x4e, 0xf>(v);                    // quad_perm:[2,3,0,1]

@@ -116,7 +116,11 @@ bool timing_ready() {
 }
 }  // namespace
 
-TraceRange::TraceRange(const char *nm) : name(nm), on(roctx_ready()), timed(timing_ready()), t0(0.0) {
+static thread_local int g_trace_mute = 0;
+TraceMute::TraceMute() { ++g_trace_mute; }
+TraceMute::~TraceMute() { --g_trace_mute; }
+
+TraceRange::TraceRange(const char *nm) : name(nm), on(roctx_ready()), timed(timing_ready() && g_trace_mute == 0), t0(0.0) {
     if (on) (void)g_push(name);
     if (timed) t0 = now_s();
 }

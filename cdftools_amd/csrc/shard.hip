@@ -207,6 +207,7 @@ int for_blocks(ShardSet &sh, const std::function<int(int)> &fn) {
     std::vector<int> rc(n, CDFT_OK);
     std::vector<std::string> msg(n);
     auto body = [&](int b) {
+        TraceMute mute_;                                         // (the caller's range times the whole call: common.hpp)
         if (hipSetDevice(sh.dev[b]) != hipSuccess) {
             (void)hipGetLastError();
             rc[b] = CDFT_ERR_HIP;
@@ -406,6 +407,7 @@ int heatc_compute(ShardSet &sh, const float *temp, const float *rmxldep, const f
         int cur = 0;
         (void)hipGetDevice(&cur);
         int rc = CDFT_OK;
+        TraceMute mute_;                                         // (the blocks' calls below are inside the caller's: common.hpp)
         for (int b = 0; b < n && rc == CDFT_OK; ++b) {
             if (hipSetDevice(sh.dev[b]) != hipSuccess) { rc = fail(CDFT_ERR_HIP, "cdft_heatc_compute: hipSetDevice(%d) failed", sh.dev[b]); break; }
             cdft_heatc_plan *p = (cdft_heatc_plan *)sh.part[b];

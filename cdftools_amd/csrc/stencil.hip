@@ -478,6 +478,7 @@ int cdft_vt_compute_sharded(const float *u, const float *v, const float *t, cons
                             const float *e3v, int64_t fstride, int nframes, int npiglo, int npjglo, int npk,
                             void *vt, void *vs, void *ut, void *us, void *e3um, void *e3vm, int out_is_r4, int ndev,
                             const int *devices) {
+    TraceRange trace_("cdft_vt_compute_sharded");
     if (!u || !v || !t || !s || !vt || !vs || !ut || !us)
         return fail(CDFT_ERR_ARG, "cdft_vt_compute_sharded: NULL argument");
     if (e3u && (!e3v || !e3um || !e3vm)) return fail(CDFT_ERR_ARG, "cdft_vt_compute_sharded: -vvl needs e3u, e3v, e3um, e3vm");

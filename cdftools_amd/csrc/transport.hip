@@ -850,6 +850,7 @@ int cdft_psi_create_sharded(cdft_psi_plan **plan, int npiglo, int npjglo, int np
 
 int cdft_psi_integrate(cdft_psi_plan *p, const float *zu, const float *e2u, const float *e3u, const float *zv,
                        const float *e1v, const float *e3v, const float *e31d, int in_space, void *stream) {
+    TraceRange trace_("cdft_psi_integrate");
     if (!p) return fail(CDFT_ERR_ARG, "cdft_psi_integrate: NULL plan");
     if (p->sh) {
         if ((zu && !e2u) || (zv && !e1v) || (!zu && !zv)) return fail(CDFT_ERR_ARG, "cdft_psi: each velocity needs its horizontal metric");
@@ -918,6 +919,7 @@ int cdft_psi_scan_u(cdft_psi_plan *p, const double *carry, int carry_space, int 
 }
 
 int cdft_psi_scan_open(cdft_psi_plan *p, int lmean, void *stream) {
+    TraceRange trace_("cdft_psi_scan_open");
     if (!p) return fail(CDFT_ERR_ARG, "cdft_psi_scan_open: NULL plan");
     if (p->sh)
         return fail(CDFT_ERR_STATE, "cdft_psi_scan_open: -open integrates along one row of the whole domain; use a plan of cdft_psi_create");
@@ -954,6 +956,7 @@ int cdft_psi_value(cdft_psi_plan *p, int ii, int ij, double *value, void *stream
 
 int cdft_psi_finish(cdft_psi_plan *p, int use_ref, double ref_value, int iiref, int ijref, const float *fmask,
                     int mask_space, float *psi4, double *dpsi8, int out_space, void *stream) {
+    TraceRange trace_("cdft_psi_finish");
     if (!p || !psi4) return fail(CDFT_ERR_ARG, "cdft_psi_finish: NULL argument");
     if (p->sh) {
         if (fmask && mask_space == CDFT_MEM_DEVICE) CDFT_HIP(hipStreamSynchronize(as_stream(stream)));

@@ -310,10 +310,15 @@ int cdft_heatc_compute(cdft_heatc_plan *plan, const float *temp, int temp_space,
  *                         flang -O1 into one sequential r4 loop in memory order.  Reproduced bit for bit, so that the
  *                         drop-in program returns what a reference build returns (9e-5 from the r8 value at eORCA025,
  *                         per cents at eORCA12): inside a binade of the running sum the chain is an integer sum, formed
- *                         in parallel; crossings of a power of two and ties are resolved cell by cell (heatc_scan_kernel,
- *                         2.7-4 times the r8 mode's time; CDFT_HEATC_SEQ=chain in the environment selects the plain chain
- *                         of v_add_f32 it is checked against, 14-23 times slower).  The r4 results are widened exactly
- *                         into `sums`.  Sharded plans chain the blocks in order. */
+ *                         in parallel; crossings of a power of two and ties are resolved cell by cell (heatc_scan_kernel:
+ *                         one pass over the fields after a 1/64 sample that names the binades, 1.6-3 times the r8 mode's
+ *                         time; CDFT_HEATC_SEQ=chain in the environment selects the plain chain of v_add_f32 it is checked
+ *                         against, 25-40 times slower; a wait of the scan that does not end within 2 s makes the call fall
+ *                         back to that chain, with a line on stderr).  The r4 results are widened exactly into `sums`.
+ *                         Sharded plans: a sequential sum has no parallel form across row blocks -- block b starts where
+ *                         block b-1 ended -- so the blocks' rows are staged side by side but their chains run ONE BLOCK
+ *                         AFTER THE OTHER, south to north: N devices take as long as one in this mode (and hold 1/N of
+ *                         the fields each); the r8 mode is the one that scales. */
 #define CDFT_HEATC_SUM_R8     0
 #define CDFT_HEATC_SUM_R4SEQ  1
 int cdft_heatc_set_sum_mode(cdft_heatc_plan *plan, int mode);

@@ -89,3 +89,26 @@ def test_cdft_gpus_count_form_and_bad_values(case):
     assert rc == 98 and "HIP device" in out                              # more GPUs than the box has: message + STOP 98
     rc, out, err = run("cdfmoc", ["-v", "SYN_y0001_gridV.nc", "-o", "moc_bad.nc"], d, env={"CDFT_GPU_MAP": "zero"})
     assert rc == 98 and "CDFT_GPU_MAP" in out
+
+
+@pytest.mark.gpu
+def test_timing_totals_count_a_sharded_call_once(case):
+    """CDFT_TIMING=1 with the plan on three row blocks: the blocks run the same entry points on their own threads, inside the
+    caller's call -- the totals count the caller's calls, as many as on one device (they used to count the blocks' too)."""
+    import re
+    d, g, rec = case
+
+    def calls(tool, args, env):
+        rc, out, err = run(tool, args, d, env=dict(env, CDFT_TIMING="1"))
+        assert rc == 0, out + err
+        return {m.group(1): int(m.group(2)) for m in re.finditer(r"CDFT_TIMING library: (\S+)\s+(\d+) call", err)}
+    for tool, args in (("cdfheatc", ["-f", "SYN_y0001_gridT.nc", "-o", "ht_timing.nc"]), ("cdfmoc", ["-v", "SYN_y0001_gridV.nc", "-o", "moc_timing.nc"]),
+                       ("cdfpsi", ["-u", "SYN_y0001_gridU.nc", "-v", "SYN_y0001_gridV.nc", "-o", "psi_timing.nc"]),
+                       ("cdfmhst", ["-v", "SYN_y0001_gridV.nc", "-t", "SYN_y0001_gridT.nc", "-o", "mhst_timing.nc"]),
+                       ("cdfvT", ["-c", "SYN", "-l", "y0001", "-o", "vt_timing.nc"])):
+        one, three = calls(tool, args, {}), calls(tool, args, {"CDFT_GPU_MAP": "0,0,0"})
+        assert one, tool
+        three = {k.replace("_sharded", ""): v for k, v in three.items()}        # (cdfvT's sharded entry has its own name)
+        assert {k: three.get(k) for k in one} == one, (tool, one, three)
+        if tool == "cdfheatc":
+            assert one.get("cdft_heatc_compute") == 2               # two records

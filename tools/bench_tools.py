@@ -246,7 +246,7 @@ def main():
         p = hip.MhstPlan(npi, npj, npk, 5)
         p.set_mesh(e1, m, e3v=e3)
         ms = timed(lambda: p.compute(vt=vt, vs=vs), args.reps)
-        report("cdfmhst -vt", args.grid, n3, 12.0, ms, "vt 4 + vs 4 + e3v 4 B per cell (one record: e3v counted in full)")
+        report("cdfmhst -vt", args.grid, n3, 12.0, ms, "vt 4 + vs 4 + e3v 4 B per cell: one record per launch, e3v read in full by each (BASELINE.md section 3)")
         del p, vt, vs, m
 
     if "psi" in tools:
