@@ -490,7 +490,7 @@ __global__ void __launch_bounds__(64 * kScanWaves, 3) heatc_scan_kernel(HeatcArg
     // the XCD this workgroup runs on (HW_REG_XCC_ID, bits 3:0)
     const int my_lane = nlanes > 1 ? (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u) % nlanes : 0;
 
-    struct Raw { float ar[4], e3[4], tt[4], mk[4], mx[4]; };
+    struct Raw { float ar[4], e3[4], tt[4], mk[4], mx[4]; uint32_t mkb; };      // (mkb: the four mask bytes as loaded, MASK8)
     for (;;) {
         // Dealing.  Lane x of `nlanes` holds the steps x, x + nlanes, ... of every level, in that order; a workgroup draws from
         // the lane of the XCD it runs on, and from the next lanes once its own is empty.  The 75 levels of a step multiply
@@ -572,7 +572,7 @@ __global__ void __launch_bounds__(64 * kScanWaves, 3) heatc_scan_kernel(HeatcArg
                     x.tt[0] = tv.x; x.tt[1] = tv.y; x.tt[2] = tv.z; x.tt[3] = tv.w;
                     if (!FULL) { const f4u ev = ld_stream4u(a.e3t + base + p); x.e3[0] = ev.x; x.e3[1] = ev.y; x.e3[2] = ev.z; x.e3[3] = ev.w; }
                     else       { x.e3[0] = x.e3[1] = x.e3[2] = x.e3[3] = 0.f; }
-                    if (MASK8) { const u4u m = __builtin_nontemporal_load(reinterpret_cast<const u4u *>(a.mask8 + base + p)); x.mk[0] = m.x; x.mk[1] = m.y; x.mk[2] = m.z; x.mk[3] = m.w; }
+                    if (MASK8) { typedef uint32_t u32u __attribute__((aligned(1))); x.mkb = __builtin_nontemporal_load(reinterpret_cast<const u32u *>(a.mask8 + base + p)); }
                     else       { const f4u m = ld_stream4u(a.mask4 + base + p); x.mk[0] = m.x; x.mk[1] = m.y; x.mk[2] = m.z; x.mk[3] = m.w; }
                     if (MXL) { const f4u mv = *reinterpret_cast<const f4u *>(a.mxl + p); x.mx[0] = mv.x; x.mx[1] = mv.y; x.mx[2] = mv.z; x.mx[3] = mv.w; }
                     else     { x.mx[0] = x.mx[1] = x.mx[2] = x.mx[3] = 0.f; }
@@ -583,6 +583,7 @@ __global__ void __launch_bounds__(64 * kScanWaves, 3) heatc_scan_kernel(HeatcArg
             for (int v = 0; v < kScanNV; ++v) {                   // the first and the last chunk of a level: cell by cell, zeros where there is none
                 Raw &x = raw[v];
                 const int64_t p = c0 + v * 256 + 4 * lane - pad;
+                x.mkb = 0u;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     x.ar[c] = x.e3[c] = x.tt[c] = x.mk[c] = x.mx[c] = 0.f;
@@ -590,7 +591,8 @@ __global__ void __launch_bounds__(64 * kScanWaves, 3) heatc_scan_kernel(HeatcArg
                         x.ar[c] = a.area[p + c];
                         x.tt[c] = a.temp[base + p + c];
                         if (!FULL) x.e3[c] = a.e3t[base + p + c];
-                        x.mk[c] = MASK8 ? (float)a.mask8[base + p + c] : a.mask4[base + p + c];
+                        if (MASK8) x.mkb |= (uint32_t)a.mask8[base + p + c] << (8 * c);
+                        else       x.mk[c] = a.mask4[base + p + c];
                         if (MXL) x.mx[c] = a.mxl[p + c];
                     }
                 }
@@ -610,9 +612,10 @@ __global__ void __launch_bounds__(64 * kScanWaves, 3) heatc_scan_kernel(HeatcArg
                         else               e = fminf(e, fmaxf(0.f, __fsub_rn(__fadd_rn(dw, e), r.mx[c])));     // :222
                     }
                     const float pv = __fmul_rn(r.ar[c], e);
-                    x[0][v][c] = __fmul_rn(r.ar[c], r.mk[c]);
-                    x[1][v][c] = __fmul_rn(pv, r.mk[c]);
-                    x[2][v][c] = __fmul_rn(__fmul_rn(pv, r.tt[c]), r.mk[c]);
+                    const float mk = MASK8 ? (float)((r.mkb >> (8 * c)) & 0xffu) : r.mk[c];
+                    x[0][v][c] = __fmul_rn(r.ar[c], mk);
+                    x[1][v][c] = __fmul_rn(pv, mk);
+                    x[2][v][c] = __fmul_rn(__fmul_rn(pv, r.tt[c]), mk);
                 }
             }
             if (!whole) {                                         // (uniform: only the first and the last chunk of a level take this branch)
@@ -673,20 +676,27 @@ __global__ void __launch_bounds__(64 * kScanWaves, 3) heatc_scan_kernel(HeatcArg
                 }
             }
         };
-        {                                                         // every chunk of the ticket: the loads run one sub-block ahead
-            Raw raw[kScanNV];
+        {   // Every chunk of the ticket; the loads run TWO sub-blocks ahead (two register sets, the loop unrolled by two so that
+            // neither is ever copied): counters showed the waves waiting for memory 61 % of their time with one sub-block ahead
+            // -- a chunk's vector work (~2 us with three waves on the SIMD) is about the latency of its loads under load.
+            Raw rawA[kScanNV], rawB[kScanNV];
             float x[3][kScanNV][4];
-            fetch(raw, t0 + (int64_t)w * kScanChunk);
-#pragma clang loop unroll(disable)
-            for (int q = w; q < nchunk; q += kScanWaves) {
+            auto chunk = [&](Raw (&raw)[kScanNV], int q) {        // sums chunk q from `raw`, then asks for chunk q + 2 * kScanWaves into it
                 const int64_t c0 = t0 + (int64_t)q * kScanChunk;
                 if (c0 >= nijv) {                                 // past the end of the level: nothing there
                     if (lane == 0) for (int ch = 0; ch < 3; ++ch) sm_flag[0][q][ch] = sm_flag[1][q][ch] = 0;
-                    continue;
+                    return;
                 }
                 products(raw, c0, x);
-                if (q + kScanWaves < nchunk && c0 + kScanSub < nijv) fetch(raw, c0 + kScanSub);
+                if (q + 2 * kScanWaves < nchunk && c0 + 2 * kScanSub < nijv) fetch(raw, c0 + 2 * kScanSub);
                 summarize(x, q);
+            };
+            fetch(rawA, t0 + (int64_t)w * kScanChunk);
+            if (w + kScanWaves < nchunk && t0 + (int64_t)(w + kScanWaves) * kScanChunk < nijv) fetch(rawB, t0 + (int64_t)(w + kScanWaves) * kScanChunk);
+#pragma clang loop unroll(disable)
+            for (int q = w; q < nchunk; q += 2 * kScanWaves) {    // (nchunk is a multiple of 2 * kScanWaves: 64, 128 or 256)
+                chunk(rawA, q);
+                chunk(rawB, q + kScanWaves);
             }
         }
         __syncthreads();                                          // the sums of every chunk are in LDS
