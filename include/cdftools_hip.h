@@ -311,7 +311,7 @@ int cdft_heatc_compute(cdft_heatc_plan *plan, const float *temp, int temp_space,
  *                         drop-in program returns what a reference build returns (9e-5 from the r8 value at eORCA025,
  *                         per cents at eORCA12): inside a binade of the running sum the chain is an integer sum, formed
  *                         in parallel; crossings of a power of two and ties are resolved cell by cell (heatc_scan_kernel:
- *                         one pass over the fields after a 1/64 sample that names the binades, 1.6-3 times the r8 mode's
+ *                         one pass over the fields after a 1/64 sample that names the binades, 1.4-3 times the r8 mode's
  *                         time; CDFT_HEATC_SEQ=chain in the environment selects the plain chain of v_add_f32 it is checked
  *                         against, 25-40 times slower; a wait of the scan that does not end within 2 s makes the call fall
  *                         back to that chain, with a line on stderr).  The r4 results are widened exactly into `sums`.
