@@ -19,7 +19,8 @@ template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_add(double v) {
     const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
-    return v + __hiloint2double(hi, lo);          // (rows outside ROW_MASK add +0.0)
+    return v + __hiloint2double(hi, lo);          // (rows outside ROW_MASK add +0.0: a total of -0.0 terms comes out +0.0 -- as a
+                                                  //  Fortran SUM, which starts from +0, returns it)
 }
 
 // Fixed order: quads, half rows, rows of 16, then the four rows in order -- the same tree on every call.
