@@ -61,11 +61,11 @@ struct EosArgs {
     int no_land_shortcut;      // CDFT_EOS_NOLAND=1 (A/B and test hook): every point through the polynomials
 };
 
-template <int EOS, bool FAST>
+template <int EOS, bool FAST, int DEPTH = 0>
 __device__ __forceinline__ double eval_point(float t, float s, float p) {
     if (EOS == 2) return jmd94_point(t, s, p);
     if (EOS == 3) return sigmantr_point(t, s);                     // neutral density: no reference depth, no mask
-    return sigmai_point<(EOS == 1 ? 1 : 0), FAST>(t, s, p);
+    return sigmai_point<(EOS == 1 ? 1 : 0), FAST, DEPTH>(t, s, p);
 }
 
 // VEC = 4: every pointer 16-byte aligned, four points per lane per step (dwordx4 loads);
@@ -77,14 +77,16 @@ __device__ __forceinline__ double eval_point(float t, float s, float p) {
 // and the tools' zsig * zmask, src/cdfsig0.f90:150) -- and moves on without touching the polynomials.  The branch is uniform
 // over the wave (a ballot), so an ocean wave pays two OR / compare instructions per point.  A wave holding any other bit
 // pattern -- an ocean point, a fill value, -0.0, NaN -- takes the full path.  Not for per-point reference depths (kPointRef).
-template <int EOS, bool FAST, int KIND, int VEC>
+// DEPTH 1 / 2: one reference depth for the launch, known to be 0 / not 0 (eos_dev.hpp: the same arithmetic without the joins
+// of the branch on it); 0: looked at per point.
+template <int EOS, bool FAST, int KIND, int VEC, int DEPTH>
 __global__ void __launch_bounds__(256) eos_kernel(EosArgs a) {
     const int64_t nvec = a.n / VEC;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     double r_land = 0.0;
     float  o_land = 0.f;
     if (KIND != kPointRef && !a.no_land_shortcut) {
-        r_land = eval_point<EOS, FAST>(0.f, 0.f, a.pref);
+        r_land = eval_point<EOS, FAST, DEPTH>(0.f, 0.f, a.pref);
         o_land = (float)__dmul_rn(r_land, (double)((0.f == a.spval) ? 0.f : 1.f));
     }
     // the loads of the NEXT vector are issued before the current one is evaluated (3 % at eORCA12: the kernel is bound by
@@ -143,7 +145,7 @@ __global__ void __launch_bounds__(256) eos_kernel(EosArgs a) {
         double r[VEC];
 #pragma unroll
         for (int c = 0; c < VEC; ++c)
-            r[c] = eval_point<EOS, FAST>(t[c], s[c], KIND == kPointRef ? p[c] : a.pref);
+            r[c] = eval_point<EOS, FAST, DEPTH>(t[c], s[c], KIND == kPointRef ? p[c] : a.pref);
         if (KIND == kTool) {
             float o[VEC];
 #pragma unroll
@@ -165,7 +167,7 @@ __global__ void __launch_bounds__(256) eos_kernel(EosArgs a) {
     // tail of a vectorised launch: < 4 points, one lane each
     if (VEC == 4 && blockIdx.x == 0 && threadIdx.x < (unsigned)(a.n - nvec * VEC)) {
         const int64_t q = nvec * VEC + threadIdx.x;
-        const double r = eval_point<EOS, FAST>(a.t[q], a.s[q], KIND == kPointRef ? a.p2d[q] : a.pref);
+        const double r = eval_point<EOS, FAST, DEPTH>(a.t[q], a.s[q], KIND == kPointRef ? a.p2d[q] : a.pref);
         if (KIND == kTool) {
             const float zmask = (a.s[q] == a.spval) ? 0.f : 1.f;
             a.out4[q] = (float)__dmul_rn(r, (double)zmask);
@@ -185,10 +187,15 @@ int launch_kind(const EosArgs &a, hipStream_t st) {
     int64_t blocks = (work + threads - 1) / threads;
     if (blocks > 256 * 8) blocks = 256 * 8;
     if (blocks < 1) blocks = 1;
-    if (vec)
-        hipLaunchKernelGGL((eos_kernel<EOS, FAST, KIND, 4>), dim3((unsigned)blocks), dim3(threads), 0, st, a);
-    else
-        hipLaunchKernelGGL((eos_kernel<EOS, FAST, KIND, 1>), dim3((unsigned)blocks), dim3(threads), 0, st, a);
+    // the surface form as its own kernel (sigma0: 94 -> 90 vector instructions per point, 3.85 -> 3.6 ms at eORCA12); the deep
+    // form keeps the uniform branch: specialised too it came out at 146 instructions per point instead of 143 (measured)
+    if (vec && KIND != kPointRef && (EOS == 0 || EOS == 1) && a.pref == 0.f) {
+        hipLaunchKernelGGL((eos_kernel<EOS, FAST, KIND, 4, 1>), dim3((unsigned)blocks), dim3(threads), 0, st, a);
+    } else if (vec) {
+        hipLaunchKernelGGL((eos_kernel<EOS, FAST, KIND, 4, 0>), dim3((unsigned)blocks), dim3(threads), 0, st, a);
+    } else {
+        hipLaunchKernelGGL((eos_kernel<EOS, FAST, KIND, 1, 0>), dim3((unsigned)blocks), dim3(threads), 0, st, a);
+    }
     CDFT_LAUNCH_CHECK();
     return CDFT_OK;
 }

@@ -36,7 +36,9 @@ __device__ __forceinline__ double eos_rk(double t, double s) {
     return acc;
 }
 
-template <int SET, bool FAST>
+// DEPTH: 0 = pref looked at here (a uniform branch), 1 = the caller knows pref == 0 (surface form), 2 = the caller knows
+// pref != 0 -- the same arithmetic, without the branch's joins (moves and selects of r8 pairs around it)
+template <int SET, bool FAST, int DEPTH = 0>
 __device__ __forceinline__ double sigmai_point(float ptem, float psal, float pref) {
     constexpr double rdeltas = SET ? CDFT_EOS_RDELTAS_T10 : CDFT_EOS_RDELTAS_80;
     constexpr double r1_s0   = SET ? CDFT_EOS_R1_S0_T10 : CDFT_EOS_R1_S0_80;
@@ -47,7 +49,7 @@ __device__ __forceinline__ double sigmai_point(float ptem, float psal, float pre
     double r = r0, ref = 0.0;
     // At the surface (sigma0: pref = 0) h = 0, so ((r3*h + r2)*h + r1)*h + r0 is r0 and the reference
     // profile is +0 for every finite T,S: the three depth-dependent polynomials are skipped (bit-identical).
-    if (pref != 0.0f) {
+    if (DEPTH == 2 || (DEPTH == 0 && pref != 0.0f)) {
         const double h = __dmul_rn((double)pref, CDFT_EOS_R1_Z0);                   // :842 / :1046
         ref = kR[5];                                                                // :845 / :1050
 #pragma unroll
@@ -78,10 +80,10 @@ __device__ __forceinline__ double sigmantr_point(float ptem, float psal) {
 }
 
 // the density cdfmocsig bins: sigmai (KIND 0 EOS-80, 1 TEOS-10) or the neutral density (KIND 2, -ntr)
-template <int KIND>
+template <int KIND, int DEPTH = 0>
 __device__ __forceinline__ double mocsig_density(float t, float s, float pref) {
     if constexpr (KIND == 2) return sigmantr_point(t, s);
-    else return sigmai_point<KIND, false>(t, s, pref);
+    else return sigmai_point<KIND, false, DEPTH>(t, s, pref);
 }
 
 }  // namespace

@@ -23,6 +23,7 @@ struct SigArgs {
     const int16_t *ib;                 // (nb,npi,npj)
     int npi, npj, npk, nb, nbins, j0, j1;
     float zspv, zspt, zsps, pref, sigmin, sigstp;
+    double rsigstp;                    // 1 / sigstp in r8 (class kernel: the r4 division by sigstp as an r8 product)
     double *dmoc, *depi;               // (nb,nbins,npj)
     int no_land_shortcut;              // CDFT_MOCSIG_NOLAND=1: the equation of state on every cell (A/B and test hook)
 };
@@ -118,7 +119,7 @@ struct SigClassArgs {
     int nclass;
 };
 
-template <int NV, int TEOS, int T>
+template <int NV, int TEOS, int T, int DEPTH>
 __global__ void __launch_bounds__(T) mocsig_class_kernel(SigArgs a, SigClassArgs ca) {
     extern __shared__ double hist[];                    // [nwaves][nclass][nbins], then raw [nb][nbins]
     constexpr int nwaves = T / 64;
@@ -168,33 +169,35 @@ __global__ void __launch_bounds__(T) mocsig_class_kernel(SigArgs a, SigClassArgs
                 const float s4[4] = {cs.x, cs.y, cs.z, cs.w}, e4[4] = {ce.x, ce.y, ce.z, ce.w};
                 int key[4];
                 double val[4];
+                float vz[4];
+                // The term of every cell first (:374, :389, :417): -(v * (e1v * e3v)) in r4, widened.
+                bool live = false;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    vz[c] = (v4[c] == a.zspv) ? 0.f : v4[c];                                   // :374
+                    val[c] = -(double)__fmul_rn(vz[c], __fmul_rn(e1[r][c], e4[c]));            // :389, :417
+                    live |= (hoff[r][c] >= 0) && (val[c] != 0.0);                              // (NaN != 0: kept)
+                }
                 // Land.  A term that is exactly zero (v = 0 or e3v = 0: land, and it comes in large pieces) is never added
                 // (below), so its density class is never looked at: a wave whose 256 cells all have such a term skips the
                 // equation of state altogether -- ~115 r8 operations per cell.  Uniform over the wave (a ballot); a NaN
                 // term is not zero and takes the full path.  CDFT_MOCSIG_NOLAND=1: A/B and test hook.
-                {
-                    bool live = false;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const float v = (v4[c] == a.zspv) ? 0.f : v4[c];
-                        live |= (hoff[r][c] >= 0) && (__fmul_rn(v, __fmul_rn(e1[r][c], e4[c])) != 0.f);
-                    }
-                    if (!a.no_land_shortcut && !__any(live)) { cv = nv_; ct = nt_; cs = ns_; ce = ne_; continue; }
-                }
+                if (!a.no_land_shortcut && !__any(live)) { cv = nv_; ct = nt_; cs = ns_; ce = ne_; continue; }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    float v = v4[c], t = t4[c], s = s4[c];
-                    if (v == a.zspv) v = 0.f;                                                  // :374
+                    float t = t4[c], s = s4[c];
                     if (t == a.zspt) t = 0.f;                                                  // :382
                     if (s == a.zsps) s = 0.f;                                                  // :383
-                    const float zarea = __fmul_rn(e1[r][c], e4[c]);                            // :389
                     const int itm = (s == a.zsps) ? 0 : 1;                                     // :392-393
-                    const double dens = mocsig_density<TEOS>(t, s, a.pref);                    // :395
+                    const double dens = mocsig_density<TEOS, DEPTH>(t, s, a.pref);             // :395
                     const float zttmp = (float)__dmul_rn(dens, (double)itm);                   // :398
-                    int ibin = (int)__fdiv_rn(__fsub_rn(zttmp, a.sigmin), a.sigstp);           // :400
+                    // :400  (zttmp - sigmin) / sigstp in r4, correctly rounded: the quotient of two r4 numbers is never closer
+                    // than 2^-49 (relative) to the middle between two r4 numbers unless it is one, so the r8 product with the r8
+                    // reciprocal of sigstp (error < 2^-52) rounds to the same r4 as the division -- three instructions, not ten
+                    const float zq = (float)__dmul_rn((double)__fsub_rn(zttmp, a.sigmin), a.rsigstp);
+                    int ibin = (int)zq;
                     ibin = min(max(ibin, 1), a.nbins) - 1;                                     // :401-402
-                    val[c] = -(double)__fmul_rn(v, zarea);                                     // :417
-                    key[c] = (hoff[r][c] >= 0 && val[c] != 0.0) ? hoff[r][c] + ibin : -1;      // (NaN != 0: kept)
+                    key[c] = (hoff[r][c] >= 0 && val[c] != 0.0) ? hoff[r][c] + ibin : -1;
                 }
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
@@ -259,14 +262,21 @@ __global__ void sig_cls_kernel(uint8_t *__restrict__ bits, int64_t nij, const ui
 
 constexpr int kSigT = 256;
 
-template <int NV, int KIND>
-int launch_sig_class_kind(const SigArgs &a, const SigClassArgs &ca, size_t shmem, hipStream_t st) {
+template <int NV, int KIND, int DEPTH>
+int launch_sig_class_depth(const SigArgs &a, const SigClassArgs &ca, size_t shmem, hipStream_t st) {
     if (shmem > 64 * 1024)
-        CDFT_HIP(hipFuncSetAttribute((const void *)mocsig_class_kernel<NV, KIND, kSigT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        CDFT_HIP(hipFuncSetAttribute((const void *)mocsig_class_kernel<NV, KIND, kSigT, DEPTH>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)shmem));
-    hipLaunchKernelGGL((mocsig_class_kernel<NV, KIND, kSigT>), dim3(a.npj), dim3(kSigT), shmem, st, a, ca);
+    hipLaunchKernelGGL((mocsig_class_kernel<NV, KIND, kSigT, DEPTH>), dim3(a.npj), dim3(kSigT), shmem, st, a, ca);
     CDFT_LAUNCH_CHECK();
     return CDFT_OK;
+}
+
+template <int NV, int KIND>
+int launch_sig_class_kind(const SigArgs &a, const SigClassArgs &ca, size_t shmem, hipStream_t st) {
+    if (KIND == 2) return launch_sig_class_depth<NV, KIND, 0>(a, ca, shmem, st);            // (the neutral density has no depth)
+    if (getenv("CDFT_MOCSIG_DEPTH0")) return launch_sig_class_depth<NV, KIND, 0>(a, ca, shmem, st);      // (A/B hook: the uniform branch)
+    return a.pref == 0.f ? launch_sig_class_depth<NV, KIND, 1>(a, ca, shmem, st) : launch_sig_class_depth<NV, KIND, 2>(a, ca, shmem, st);
 }
 
 template <int NV>
@@ -319,6 +329,7 @@ int cdft_mocsig_compute(const float *zv, const float *zveiv, const float *zt, co
     a.ib = (const int16_t *)dib; a.npi = npiglo; a.npj = npjglo; a.npk = npk; a.nb = nbasins; a.nbins = nbins;
     a.j0 = npjglo > 1 ? 1 : 0; a.j1 = npjglo > 1 ? npjglo - 2 : 0;                         // :405-407
     a.zspv = zspv; a.zspt = zspt; a.zsps = zsps; a.pref = pref; a.sigmin = sigmin; a.sigstp = sigstp;
+    a.rsigstp = 1.0 / (double)sigstp;
     a.dmoc = om; a.depi = od;
     { const char *e = getenv("CDFT_MOCSIG_NOLAND"); a.no_land_shortcut = (e && e[0] == '1') ? 1 : 0; }
     // class kernel when it applies (see above); CDFT_MOCSIG_NOCLASS=1 keeps the general kernel (A/B and test hook)

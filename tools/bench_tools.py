@@ -237,7 +237,7 @@ def main():
                 ms = timed(lambda: hip.mocsig(f["zv"], f["zt"], f["zs"], f["e1"], f["ib"], 158, 30.0, 0.05, pref=2000.0, e3v=f["e3"]), args.reps)
                 report("cdfmocsig (158 classes, 5 basins, %s T,S, %s land)" % ("smooth" if smooth else "white-noise", land), args.grid, n3, 16.0, ms,
                        "v,T,S,e3v 16 B per cell; sigma2 needs all four polynomials of the EOS; a wave whose 256 cells all carry a zero transport skips it",
-                       fp64=fp64_ops("mocsig_" + land, args.grid, "mocsig_class_kernel<5, 0, 256>" if npi > 2048 else "mocsig_class_kernel<2, 0, 256>") if smooth else None)
+                       fp64=fp64_ops("mocsig_" + land, args.grid, "mocsig_class_kernel<5, 0, 256, 2>" if npi > 2048 else "mocsig_class_kernel<2, 0, 256, 2>") if smooth else None)
                 del f
 
     if "mhst" in tools:
@@ -293,10 +293,10 @@ def main():
         o4 = torch.empty(n3, dtype=torch.float32, device=dev)
         for land in ["none"] + [x for x in args.land.split(",") if x != "none"]:
             t, s = eos_fields(npi, npj, npk, dev, land)
-            for name, case, pref, eos, flags, kern in (("sigma0 tool form, exact", "sigma0", 0.0, 0, 0, "eos_kernel<0, false, 2, 4>"),
-                                                       ("sigma0 tool form, FMA", "sigma0_fma", 0.0, 0, 1, "eos_kernel<0, true, 2, 4>"),
-                                                       ("sigmai TEOS-10 tool form, exact", "sigma0_teos10", 0.0, 1, 0, "eos_kernel<1, false, 2, 4>"),
-                                                       ("sigma2 (sigmai at 2000 m) tool form, exact", "sigma2", 2000.0, 0, 0, "eos_kernel<0, false, 2, 4>")):
+            for name, case, pref, eos, flags, kern in (("sigma0 tool form, exact", "sigma0", 0.0, 0, 0, "eos_kernel<0, false, 2, 4, 0>"),
+                                                       ("sigma0 tool form, FMA", "sigma0_fma", 0.0, 0, 1, "eos_kernel<0, true, 2, 4, 0>"),
+                                                       ("sigmai TEOS-10 tool form, exact", "sigma0_teos10", 0.0, 1, 0, "eos_kernel<1, false, 2, 4, 0>"),
+                                                       ("sigma2 (sigmai at 2000 m) tool form, exact", "sigma2", 2000.0, 0, 0, "eos_kernel<0, false, 2, 4, 0>")):
                 if land != "none" and case not in ("sigma0", "sigma2"):
                     continue
                 ms = timed(lambda: hip.sig_tool(t, s, pref, 0.0, eos, flags, out=o4), args.reps)
@@ -314,7 +314,7 @@ def main():
         t2, s2 = t + 0.5, s * 1.01
         ms = timed(lambda: hip.eosbn2(t, t2, s, s2, e3.reshape(-1), 2000.0, out=o4), args.reps)
         report("eosbn2, polynomial alpha and beta", args.grid, n3, 24.0, ms, "two levels of T and S 16 + e3w 4 + out 4 B per point; alpha AND beta evaluated at every point",
-               fp64=fp64_ops("bn2_none", args.grid, "eos_bn2_kernel<0, 0>"))
+               fp64=fp64_ops("bn2_none", args.grid, "eos_bn2_kernel<0, 0, 4>"))
         ms = timed(lambda: hip.eosbn2(t, t2, s, s2, e3.reshape(-1), 2000.0, eos=hip.EOS_MCD87, out=o4), args.reps)
         report("eosbn2, McDougall 1987", args.grid, n3, 24.0, ms, "")
 
