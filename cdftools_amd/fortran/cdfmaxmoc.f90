@@ -12,11 +12,11 @@ PROGRAM cdfmaxmoc
   USE modcdfnames
   IMPLICIT NONE
 
-  INTEGER(KIND=4) :: jj, jk, npjglo, npk, narg, ijarg, ijmin = 1, ijmax = 1, ikmin = 1, ikmax = 1
-  INTEGER(KIND=4) :: ilatmin, ilatmax, idepmin, idepmax, nx = 1, ny = 1, nz = 1, nvarout = 6, ncout, ierr
-  INTEGER(KIND=4) :: iminloc(3), imaxloc(3)
+  INTEGER(KIND=4) :: jk, jv, npjglo, npk, narg, ijarg, nx = 1, ny = 1, nz = 1, nvarout = 6, ncout, ierr
+  INTEGER(KIND=4) :: iwin(4)                   ! the window: first row, last row, first level, last level
+  INTEGER(KIND=4) :: iat(2,2)                  ! (row, level) of the maximum, of the minimum
   INTEGER(KIND=4), ALLOCATABLE :: ipk(:), id_varout(:)
-  REAL(KIND=4) :: ovtmax, ovtmin, rlatmin = 0., rlatmax = 0., rdepmin = 0., rdepmax = 0.
+  REAL(KIND=4) :: zext(2), zout(6), rlatmin = 0., rlatmax = 0., rdepmin = 0., rdepmax = 0.
   REAL(KIND=4), ALLOCATABLE :: gdepw(:), rdumlon(:,:), rdumlat(:,:), rlat(:,:), rmoc(:,:,:)
   REAL(KIND=8) :: dtim(1)
   TYPE(variable), ALLOCATABLE :: stypvar(:)
@@ -78,31 +78,23 @@ PROGRAM cdfmaxmoc
   ALLOCATE( stypvar(nvarout), ipk(nvarout), id_varout(nvarout), rdumlon(1,1), rdumlat(1,1) )
   CALL CreateOutput
 
-  DO jk = 1, npk
+  DO jk = 1, npk                                            ! one (y) row of the first record per level
      rmoc(:,:,jk) = getvar(cf_moc, cv_in, jk, 1, npjglo)
   END DO
-  DO jj = 1, npjglo                                         ! window in index space (src/cdfmaxmoc.f90:162-173)
-     IF ( rlat(1,jj) <= rlatmin ) ijmin = jj
-     IF ( rlat(1,jj) <= rlatmax ) ijmax = jj
+  ! The window in index space: the LAST row / level whose latitude / depth is at or below each limit, 1 when none is
+  ! (what the reference's four IF-in-a-loop statements leave behind, src/cdfmaxmoc.f90:162-173).
+  iwin(:) = (/ last_at_or_below(rlat(1,:), rlatmin), last_at_or_below(rlat(1,:), rlatmax), &
+       &       last_at_or_below(gdepw,     rdepmin), last_at_or_below(gdepw,     rdepmax) /)
+  ! The extrema and where they are: the first one met going through the window row by row, level after level -- the order
+  ! in which MAXLOC / MINLOC of the (1, y, z) section look (:175-183).
+  CALL first_extreme( 1., zext(1), iat(1,1), iat(2,1))
+  CALL first_extreme(-1., zext(2), iat(1,2), iat(2,2))
+  PRINT *, ' Maximum ', zext(1), ' Sv latitude ', rlat(1,iat(1,1)), ' depth = ', gdepw(iat(2,1))
+  PRINT *, ' Minimum ', zext(2), ' Sv latitude ', rlat(1,iat(1,2)), ' depth = ', gdepw(iat(2,2))
+  zout(:) = (/ zext(1), zext(2), rlat(1,iat(1,1)), rlat(1,iat(1,2)), gdepw(iat(2,1)), gdepw(iat(2,2)) /)
+  DO jv = 1, nvarout                                        ! maxmoc, minmoc, latmaxmoc, latminmoc, depthmaxmoc, depthminmoc
+     ierr = putvar0d(ncout, id_varout(jv), zout(jv))
   END DO
-  DO jk = 1, npk
-     IF ( gdepw(jk) <= rdepmin ) ikmin = jk
-     IF ( gdepw(jk) <= rdepmax ) ikmax = jk
-  END DO
-  ovtmax  = MAXVAL(rmoc(1,ijmin:ijmax,ikmin:ikmax))
-  ovtmin  = MINVAL(rmoc(1,ijmin:ijmax,ikmin:ikmax))
-  iminloc = MINLOC(rmoc(:,ijmin:ijmax,ikmin:ikmax))
-  imaxloc = MAXLOC(rmoc(:,ijmin:ijmax,ikmin:ikmax))
-  ilatmin = iminloc(2) + ijmin - 1 ; ilatmax = imaxloc(2) + ijmin - 1
-  idepmin = iminloc(3) + ikmin - 1 ; idepmax = imaxloc(3) + ikmin - 1
-  PRINT *, ' Maximum ', ovtmax, ' Sv latitude ', rlat(1,ilatmax), ' depth = ', gdepw(idepmax)
-  PRINT *, ' Minimum ', ovtmin, ' Sv latitude ', rlat(1,ilatmin), ' depth = ', gdepw(idepmin)
-  ierr = putvar0d(ncout, id_varout(1), REAL(ovtmax))
-  ierr = putvar0d(ncout, id_varout(2), REAL(ovtmin))
-  ierr = putvar0d(ncout, id_varout(3), REAL(rlat(1,ilatmax)))
-  ierr = putvar0d(ncout, id_varout(4), REAL(rlat(1,ilatmin)))
-  ierr = putvar0d(ncout, id_varout(5), REAL(gdepw(idepmax)))
-  ierr = putvar0d(ncout, id_varout(6), REAL(gdepw(idepmin)))
   ierr = closeout(ncout)
 
 CONTAINS
@@ -111,6 +103,31 @@ CONTAINS
     REAL(KIND=4), INTENT(out) :: pval
     CALL GET_COMMAND_ARGUMENT(ijarg, cldum) ; ijarg = ijarg + 1 ; READ(cldum, *) pval
   END SUBROUTINE getr
+
+  INTEGER(KIND=4) FUNCTION last_at_or_below(pval, plim)
+    REAL(KIND=4), INTENT(in) :: pval(:), plim
+    INTEGER(KIND=4) :: ji
+    last_at_or_below = 1
+    DO ji = 1, SIZE(pval)
+       IF ( pval(ji) <= plim ) last_at_or_below = ji
+    END DO
+  END FUNCTION last_at_or_below
+
+  SUBROUTINE first_extreme(psign, pext, kj, kk)
+    !! psign = 1.: the maximum of rmoc over the window, -1.: the minimum; (kj, kk): its row and level in the file
+    REAL(KIND=4),    INTENT(in)  :: psign
+    REAL(KIND=4),    INTENT(out) :: pext
+    INTEGER(KIND=4), INTENT(out) :: kj, kk
+    INTEGER(KIND=4) :: ij, ik
+    kj = iwin(1) ; kk = iwin(3) ; pext = rmoc(1,kj,kk)
+    DO ik = iwin(3), iwin(4)
+       DO ij = iwin(1), iwin(2)
+          IF ( psign * rmoc(1,ij,ik) > psign * pext ) THEN
+             pext = rmoc(1,ij,ik) ; kj = ij ; kk = ik
+          ENDIF
+       END DO
+    END DO
+  END SUBROUTINE first_extreme
 
   SUBROUTINE CreateOutput
     !! src/cdfmaxmoc.f90:196-241
@@ -128,8 +145,8 @@ CONTAINS
     stypvar(4)%cname = 'latminmoc'   ; stypvar(4)%clong_name = 'Latitude_of_Minimum_Overtuning'
     stypvar(5)%cname = 'depthmaxmoc' ; stypvar(5)%clong_name = 'Depth_of_Maximum_Overturing'
     stypvar(6)%cname = 'depthminmoc' ; stypvar(6)%clong_name = 'Depth_of_Minimum_Overtuning'
-    DO jj = 1, nvarout
-       stypvar(jj)%cshort_name = stypvar(jj)%cname
+    DO jv = 1, nvarout
+       stypvar(jv)%cshort_name = stypvar(jv)%cname
     END DO
     stypvar(1:2)%cunits = 'Sverdrup' ; stypvar(1:2)%valid_min = -1000.  ; stypvar(1:2)%valid_max = 1000.
     stypvar(3:4)%cunits = 'Degrees'  ; stypvar(3:4)%valid_min = -90.    ; stypvar(3:4)%valid_max = 90.
