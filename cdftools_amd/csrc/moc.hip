@@ -314,6 +314,7 @@ static int zonal_launch(cdft_moc_plan *p, const float *d_zv, int64_t rec_stride,
     a.zv = d_zv; a.rec_stride = rec_stride; a.npt = npt;
     a.out = d_out; a.npi = p->npi; a.npj = p->npj; a.npk = p->npk; a.nbasins = p->nbasins;
     a.rows_per_wg = 1;            // (2, 4, 8, 16 measured at eORCA025 and eORCA12: no gain, the kernel is not launch-bound)
+    { const char *e = getenv("CDFT_MOC_XCDMAP"); a.xcd_map = (e && e[0] == '0') ? 0 : 1; }      // (CDFT_MOC_XCDMAP=0: launch order = row order, A/B hook)
     const bool aligned = ((uintptr_t)d_zv % 16 == 0) && (rec_stride % 4 == 0);
     a.aligned = aligned ? 1 : 0;
     int k, v, md;
@@ -327,6 +328,7 @@ static int zonal_launch(cdft_moc_plan *p, const float *d_zv, int64_t rec_stride,
         return fail(CDFT_ERR_ARG, "cdft_moc_compute: %d waves x %d vectors do not cover a row of %d (only the class kernel cuts rows)", k, v,
                     p->npi);
     a.nseg = row_segments(p, k, v, md);
+    if (a.nseg > 1 || a.rows_per_wg != 1 || md != kModeClass || p->npj < 64) a.xcd_map = 0;
     a.seg_out = nullptr;
     a.seg_stride = (int64_t)p->nbasins * p->npj * p->npk * npt;
     if (a.nseg > 1) {
