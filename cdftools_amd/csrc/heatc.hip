@@ -57,7 +57,7 @@ struct HeatcArgs {
     const uint8_t *mask8;
     const float *mask4;
     int64_t nij;
-    int npk, mxlopt, nblk;
+    int npk, mxlopt, nblk, band;
     double *partial;           // [npk][nblk][3]
 };
 
@@ -94,6 +94,7 @@ constexpr int kVPT = 4;   // vectors per lane: each wave reads kVPT contiguous K
 template <int VEC, bool MASK8, bool FULL>
 __global__ void __launch_bounds__(kThreads) heatc_level_kernel(HeatcArgs a) {
     extern __shared__ double wsum[];                   // [nwaves][npk][3]
+    const int64_t blk = xcd_band(a.band);              // (common.hpp)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = kThreads / 64;
     const int64_t nvec = a.nij / VEC;                  // nij % VEC == 0 by construction
     typedef typename Vec<VEC>::f FV;
@@ -103,7 +104,7 @@ __global__ void __launch_bounds__(kThreads) heatc_level_kernel(HeatcArgs a) {
     float ar[kVPT][VEC], mx[kVPT][VEC];
 #pragma unroll
     for (int v = 0; v < kVPT; ++v) {
-        q[v] = (((int64_t)blockIdx.x * nwaves + wave) * kVPT + v) * 64 + lane;
+        q[v] = ((blk * nwaves + wave) * kVPT + v) * 64 + lane;
         ok[v] = q[v] < nvec;
         if (!ok[v]) q[v] = 0;
         unpack<VEC>(reinterpret_cast<const FV *>(a.area)[q[v]], ar[v]);
@@ -157,7 +158,7 @@ __global__ void __launch_bounds__(kThreads) heatc_level_kernel(HeatcArgs a) {
         double s = 0.0;
         for (int w = 0; w < nwaves; ++w) s += wsum[(int64_t)w * a.npk * 3 + t];
         const int k = t / 3, c = t - 3 * k;
-        a.partial[((int64_t)k * a.nblk + blockIdx.x) * 3 + c] = s;
+        if (blk < a.nblk) a.partial[((int64_t)k * a.nblk + blk) * 3 + c] = s;
     }
 }
 
@@ -172,12 +173,13 @@ __global__ void __launch_bounds__(kThreads) heatc_level_u4_kernel(HeatcArgs a) {
     extern __shared__ double wsum[];                   // [nwaves][npk][3]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = kThreads / 64;
     const int64_t nfull = a.nij >> 2;                  // vectors 0..nfull-1 start at 4v
+    const int64_t blk = xcd_band(a.band);
     int64_t e0[kVPT];
     bool own[kVPT][4];
     float ar[kVPT][4], mx[kVPT][4];
 #pragma unroll
     for (int v = 0; v < kVPT; ++v) {
-        const int64_t q = (((int64_t)blockIdx.x * nwaves + wave) * kVPT + v) * 64 + lane;
+        const int64_t q = ((blk * nwaves + wave) * kVPT + v) * 64 + lane;
         e0[v] = min(4 * q, a.nij - 4);
         const f4u av = *reinterpret_cast<const f4u *>(a.area + e0[v]);
         const float a4[4] = {av.x, av.y, av.z, av.w};
@@ -242,12 +244,12 @@ __global__ void __launch_bounds__(kThreads) heatc_level_u4_kernel(HeatcArgs a) {
         double s = 0.0;
         for (int w = 0; w < nwaves; ++w) s += wsum[(int64_t)w * a.npk * 3 + t];
         const int k = t / 3, c = t - 3 * k;
-        a.partial[((int64_t)k * a.nblk + blockIdx.x) * 3 + c] = s;
+        if (blk < a.nblk) a.partial[((int64_t)k * a.nblk + blk) * 3 + c] = s;
     }
 }
 
 int launch_u4(const HeatcArgs &a, hipStream_t st) {
-    dim3 grid(a.nblk), block(kThreads);
+    dim3 grid(xcd_band_grid(a.nblk, a.band)), block(kThreads);
     const size_t shmem = (size_t)(kThreads / 64) * a.npk * 3 * sizeof(double);
     const bool m8 = a.mask8 != nullptr, full = a.e31d != nullptr;
     if (m8 && full)        hipLaunchKernelGGL((heatc_level_u4_kernel<true, true>), grid, block, shmem, st, a);
@@ -979,7 +981,7 @@ __global__ void __launch_bounds__(kThreads) heatc_final_kernel(const double *__r
 
 template <int VEC>
 int launch_vec(const HeatcArgs &a, hipStream_t st) {
-    dim3 grid(a.nblk), block(kThreads);
+    dim3 grid(xcd_band_grid(a.nblk, a.band)), block(kThreads);
     const size_t shmem = (size_t)(kThreads / 64) * a.npk * 3 * sizeof(double);
     const bool m8 = a.mask8 != nullptr, full = a.e31d != nullptr;
     if (m8 && full)        hipLaunchKernelGGL((heatc_level_kernel<VEC, true, true>), grid, block, shmem, st, a);
@@ -1106,6 +1108,7 @@ int cdft_heatc_compute(cdft_heatc_plan *p, const float *temp, int temp_space, co
     a.area = p->area; a.e3t = p->e3t; a.e31d = p->e31d; a.temp = (const float *)dt; a.mxl = (const float *)dm;
     a.gdepw = p->gdepw; a.mask8 = p->mask8; a.mask4 = p->mask4; a.nij = nij; a.npk = p->npk;
     a.mxlopt = mxloption; a.partial = p->partial;
+    a.band = xcd_bands_on();
     const char *seq_env = getenv("CDFT_HEATC_SEQ");
     const bool r4seq = p->sum_mode == CDFT_HEATC_SUM_R4SEQ, chain = r4seq && seq_env && !strcmp(seq_env, "chain");
     int vec = 1;

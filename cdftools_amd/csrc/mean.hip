@@ -40,7 +40,7 @@ struct MeanArgs {
     const uint8_t *mask8;          // or null
     const int16_t *ib;
     int64_t nij;
-    int npk, nb, nblk, form;
+    int npk, nb, nblk, form, band;
     double *partial;
 };
 
@@ -62,6 +62,7 @@ template <int VEC, bool FULL, int NB, bool PARK>
 __global__ void __launch_bounds__(kThreads) mean_level_kernel(MeanArgs a) {
     extern __shared__ double wsum[];                   // PARK: [nwaves][npk][nb*4], else [nwaves][nb*4]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = kThreads / 64;
+    const int64_t blk = xcd_band(a.band);              // (common.hpp)
     int64_t q[kVPT];
     float e1[kVPT][VEC], e2[kVPT][VEC], fb[kVPT][VEC][NB];
     bool ok[kVPT][VEC];
@@ -70,7 +71,7 @@ __global__ void __launch_bounds__(kThreads) mean_level_kernel(MeanArgs a) {
     const int64_t nfull = a.nij / VEC, nvtot = nfull + ((VEC == 4 && (a.nij & 3)) ? 1 : 0);
 #pragma unroll
     for (int v = 0; v < kVPT; ++v) {
-        const int64_t iv = (((int64_t)blockIdx.x * nwaves + wave) * kVPT + v) * 64 + lane;     // vector index
+        const int64_t iv = ((blk * nwaves + wave) * kVPT + v) * 64 + lane;                     // vector index
         q[v] = iv < nvtot ? (VEC == 4 ? min(iv * 4, a.nij - 4) : iv * VEC) : 0;                  // its first cell
 #pragma unroll
         for (int c = 0; c < VEC; ++c) {
@@ -166,7 +167,7 @@ __global__ void __launch_bounds__(kThreads) mean_level_kernel(MeanArgs a) {
             if ((int)threadIdx.x < a.nb * 4) {
                 double t = 0.0;
                 for (int w = 0; w < nwaves; ++w) t += wsum[w * a.nb * 4 + threadIdx.x];
-                a.partial[((int64_t)k * a.nblk + blockIdx.x) * a.nb * 4 + threadIdx.x] = t;
+                if (blk < a.nblk) a.partial[((int64_t)k * a.nblk + blk) * a.nb * 4 + threadIdx.x] = t;
             }
             __syncthreads();
         }
@@ -178,7 +179,7 @@ __global__ void __launch_bounds__(kThreads) mean_level_kernel(MeanArgs a) {
             double sum = 0.0;
             for (int w = 0; w < nwaves; ++w) sum += wsum[(int64_t)w * a.npk * nq + t];     // waves in order, as above
             const int k = t / nq, qq = t - k * nq;
-            a.partial[((int64_t)k * a.nblk + blockIdx.x) * nq + qq] = sum;
+            if (blk < a.nblk) a.partial[((int64_t)k * a.nblk + blk) * nq + qq] = sum;
         }
     }
 }
@@ -295,7 +296,8 @@ int cdft_mean_compute(cdft_mean_plan *p, const float *zv, int in_space, double *
     const bool vec4 = nij >= 4 && !getenv("CDFT_MEAN_SCALAR");         // (A/B hook: the scalar path)
     const int vec = vec4 ? 4 : 1;
     a.nblk = (int)(((nij + vec - 1) / vec + kThreads * kVPT - 1) / (kThreads * kVPT));
-    const dim3 grid(a.nblk), block(kThreads);
+    a.band = xcd_bands_on();
+    const dim3 grid(xcd_band_grid(a.nblk, a.band)), block(kThreads);
     const size_t park_bytes = (size_t)(kThreads / 64) * p->npk * nq * sizeof(double);
     const bool park = park_bytes <= 48 * 1024 && !getenv("CDFT_MEAN_NOPARK");     // (A/B hook: a barrier pair per level)
     const size_t shmem = park ? park_bytes : (size_t)(kThreads / 64) * nq * sizeof(double);

@@ -524,7 +524,7 @@ moc_zonal_class_kernel(ZonalArgs a) {
         // Workgroups go round the 8 XCDs in launch order (workgroup b runs on XCD b % 8).  Mapped like this, XCD x takes the
         // x-th eighth of the rows jj of every level, in row order: two consecutive rows share a 128-byte line (a row of 4322
         // cells is 135.06 lines; 13 such lines per row and launch), and it is now asked for twice from the SAME L2, a few
-        // microseconds apart, instead of from two.  Measured in one process on one set of records (tools/ab_moc_env.py):
+        // microseconds apart, instead of from two.  Measured in one process on one set of records (tools/ab_env.py):
         // 9.86 -> 9.52 ms at eORCA12, the same bits.  (Tiles of rows x all levels per XCD, so that a row's class bytes -- the
         // same for its 74 levels -- would stay in that L2 too, were slower the smaller the tile: 9.59 ms at 128 rows, 9.80
         // at 4; the jumps between levels cost more than the class bytes.)

@@ -56,7 +56,7 @@ struct VintArgs {
     const float *e31d;           // (npk) or null
     double *acc0, *acc1;         // (npi,npj) r8 accumulators (acc1: salt)
     int64_t nij;
-    int npi, npj, k0, k1, init;
+    int npi, npj, k0, k1, init, band;
 };
 
 // One lane owns VPT vectors of VEC consecutive cells and walks the levels k0..k1-1 in order
@@ -65,7 +65,7 @@ struct VintArgs {
 template <int VEC, int MODE, bool FULL, int VPT>
 __global__ void __launch_bounds__(kThreads) vint_kernel(VintArgs a) {
     const int lane = threadIdx.x & 63;
-    const int64_t wave = ((int64_t)blockIdx.x * kThreads + threadIdx.x) >> 6;
+    const int64_t wave = (xcd_band(a.band) * kThreads + threadIdx.x) >> 6;      // (common.hpp: XCD bands)
     int64_t p[VPT];
     bool ok[VPT], lastrow[VPT], own[VPT][VEC];
     float m[VPT][VEC];
@@ -165,7 +165,8 @@ __global__ void __launch_bounds__(kThreads) vint_kernel(VintArgs a) {
 
 
 template <int MODE>
-int launch_vint(const VintArgs &a, hipStream_t st) {
+int launch_vint(const VintArgs &a_in, hipStream_t st) {
+    VintArgs a = a_in;
     auto al = [](const void *p, size_t n) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) % n) == 0; };
     auto all = [&](size_t n) {
         return al(a.f0, n) && al(a.f1, n) && al(a.f2, n) && al(a.m2d, n) && al(a.e3, n);
@@ -179,7 +180,8 @@ int launch_vint(const VintArgs &a, hipStream_t st) {
     static int vpt = 0;                                  // vectors per lane: CDFT_VINT_VPT = 1 | 2 | 4 (tuning)
     if (!vpt) { const char *e = getenv("CDFT_VINT_VPT"); vpt = e ? atoi(e) : 4; if (vpt != 1 && vpt != 2 && vpt != 4) vpt = 4; }
     const int64_t nvecs = (a.nij + vec - 1) / vec, nthr = (nvecs + vpt - 1) / vpt;
-    const dim3 grid((unsigned)((nthr + kThreads - 1) / kThreads)), block(kThreads);
+    a.band = xcd_bands_on();
+    const dim3 grid(xcd_band_grid((nthr + kThreads - 1) / kThreads, a.band)), block(kThreads);
 #define CDFT_GO(V, F) do { if (vpt == 1) hipLaunchKernelGGL((vint_kernel<V, MODE, F, 1>), grid, block, 0, st, a); \
                            else if (vpt == 2) hipLaunchKernelGGL((vint_kernel<V, MODE, F, 2>), grid, block, 0, st, a); \
                            else hipLaunchKernelGGL((vint_kernel<V, MODE, F, 4>), grid, block, 0, st, a); } while (0)

@@ -261,6 +261,7 @@ struct ZonalClassArgs {
     uint8_t pat[kZC];
     int nclass;
     int lc;                       // level chunks: workgroup = (chunk, row)
+    int xcd_map;                  // workgroup -> (chunk, row) so that each XCD takes an eighth of the rows
 };
 
 // Loads: the row is covered by 16-byte vectors starting at cells 0, 4, 8, ... (r4-aligned only: rows start anywhere),
@@ -272,7 +273,19 @@ template <int NV, bool MEAN, int T, bool M8>
 __global__ void __launch_bounds__(T) zonal_row_class_kernel(ZonalArgs2 a, ZonalClassArgs ca) {
     extern __shared__ double lds[];
     constexpr int nwaves = T / 64;
-    const int chunk = blockIdx.x / a.npj, jj = blockIdx.x - chunk * a.npj, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int chunk = blockIdx.x / a.npj, jj = blockIdx.x - chunk * a.npj;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (ca.xcd_map) {
+        // workgroup b runs on XCD b % 8: XCD x takes the x-th eighth of the rows of every level chunk, in row order, so that
+        // the 128-byte lines two consecutive rows share (field and byte mask) are asked for twice from the same L2
+        // (moc_zonal.hpp has the measurement this follows; CDFT_ZONAL_XCDMAP=0: launch order = row order)
+        const int x = blockIdx.x & 7, s = blockIdx.x >> 3;
+        const int j0 = (int)((int64_t)x * a.npj / 8), nrows = (int)((int64_t)(x + 1) * a.npj / 8) - j0;
+        if (nrows <= 0) return;
+        chunk = s / nrows;
+        if (chunk >= ca.lc) return;                                  // (uniform: before any barrier)
+        jj = j0 + s - chunk * nrows;
+    }
     const int k0 = (int)((int64_t)chunk * a.nlev / ca.lc), k1 = (int)((int64_t)(chunk + 1) * a.nlev / ca.lc);
     double *scr  = lds + wave * ((kZC + 1) * kZStride);              // slot [class][lane]; class kZC = cells not owned
     double *part = lds + nwaves * ((kZC + 1) * kZStride);            // [k1-k0][kZC][nwaves]
@@ -381,7 +394,7 @@ template <int NV>
 int launch_class_nv(const ZonalArgs2 &a, const ZonalClassArgs &ca, bool mean, hipStream_t st) {
     constexpr int T = kClassT;
     const size_t shmem = ((size_t)(T / 64) * (kZC + 1) * kZStride + (size_t)a.nlev * kZC * (T / 64)) * sizeof(double);
-    const dim3 grid(a.npj * ca.lc);
+    const dim3 grid(ca.xcd_map ? 8 * ((a.npj + 7) / 8) * ca.lc : a.npj * ca.lc);
     if (a.mask8) {
         if (mean) hipLaunchKernelGGL((zonal_row_class_kernel<NV, true, T, true>), grid, dim3(T), shmem, st, a, ca);
         else      hipLaunchKernelGGL((zonal_row_class_kernel<NV, false, T, true>), grid, dim3(T), shmem, st, a, ca);
@@ -401,6 +414,7 @@ int launch_class(const ZonalArgs2 &a, ZonalClassArgs ca, bool mean, hipStream_t 
     // one workgroup per row for all levels is 1207 workgroups at eORCA025, less than the chip holds: the levels are cut
     // so that there are about 4096 (measured: 238 -> 209 us there, nothing lost at eORCA12)
     ca.lc = e ? std::max(1, std::min(a.nlev, atoi(e))) : std::max(1, std::min(std::min(a.nlev, 8), (4096 + a.npj - 1) / a.npj));
+    { const char *x = getenv("CDFT_ZONAL_XCDMAP"); ca.xcd_map = (a.npj >= 64 && !(x && x[0] == '0')) ? 1 : 0; }
     switch ((a.npi / 4 + 1 + kClassT - 1) / kClassT) {
         case 1: return launch_class_nv<1>(a, ca, mean, st);
         case 2: return launch_class_nv<2>(a, ca, mean, st);
