@@ -305,6 +305,12 @@ void choose_shape(const cdft_moc_plan *p, bool aligned, int *nwaves, int *nv, in
 }  // namespace
 
 // the zonal kernel of one call: raw -(zonal sums) of npt records into d_out (nbasins,npj,npk,npt),
+// the class kernel's workgroup -> row map (moc_zonal.hpp): on unless CDFT_MOC_XCDMAP=0 or CDFT_XCD_BANDS=0 (A/B hooks) or the rows are few
+static int zonal_xcd_map(int npj) {
+    const char *e = getenv("CDFT_MOC_XCDMAP");
+    return (npj >= 64 && !(e && e[0] == '0') && xcd_bands_on()) ? 1 : 0;
+}
+
 // levels 1..npk-1 (level npk is left to the caller)
 static int zonal_launch(cdft_moc_plan *p, const float *d_zv, int64_t rec_stride, int npt, double *d_out,
                         hipStream_t st, bool profile) {
@@ -314,7 +320,7 @@ static int zonal_launch(cdft_moc_plan *p, const float *d_zv, int64_t rec_stride,
     a.zv = d_zv; a.rec_stride = rec_stride; a.npt = npt;
     a.out = d_out; a.npi = p->npi; a.npj = p->npj; a.npk = p->npk; a.nbasins = p->nbasins;
     a.rows_per_wg = 1;            // (2, 4, 8, 16 measured at eORCA025 and eORCA12: no gain, the kernel is not launch-bound)
-    { const char *e = getenv("CDFT_MOC_XCDMAP"); a.xcd_map = (e && e[0] == '0') ? 0 : 1; }      // (CDFT_MOC_XCDMAP=0: launch order = row order, A/B hook)
+    a.xcd_map = zonal_xcd_map(p->npj);
     const bool aligned = ((uintptr_t)d_zv % 16 == 0) && (rec_stride % 4 == 0);
     a.aligned = aligned ? 1 : 0;
     int k, v, md;
@@ -328,7 +334,7 @@ static int zonal_launch(cdft_moc_plan *p, const float *d_zv, int64_t rec_stride,
         return fail(CDFT_ERR_ARG, "cdft_moc_compute: %d waves x %d vectors do not cover a row of %d (only the class kernel cuts rows)", k, v,
                     p->npi);
     a.nseg = row_segments(p, k, v, md);
-    if (a.nseg > 1 || a.rows_per_wg != 1 || md != kModeClass || p->npj < 64) a.xcd_map = 0;
+    if (a.nseg > 1 || a.rows_per_wg != 1 || md != kModeClass) a.xcd_map = 0;
     a.seg_out = nullptr;
     a.seg_stride = (int64_t)p->nbasins * p->npj * p->npk * npt;
     if (a.nseg > 1) {
@@ -498,8 +504,8 @@ int cdft_moc_describe(cdft_moc_plan *p, char *buf, size_t buflen) {
         snprintf(buf, buflen, "moc_zonal_class_kernel<NV=%d,KC=%d,ALIGNED=%d> row_segments=%d waves_per_segment=%d basin_patterns=%d", v,
                  kMaxClass, p->last_aligned ? 1 : 0, nseg, k, p->nclass);
     else if (md == kModeClass)
-        snprintf(buf, buflen, "moc_zonal_class_kernel<NV=%d,KC=%d,ALIGNED=%d> waves_per_row=%d basin_patterns=%d", v, kMaxClass,
-                 p->last_aligned ? 1 : 0, k, p->nclass);
+        snprintf(buf, buflen, "moc_zonal_class_kernel<NV=%d,KC=%d,ALIGNED=%d> waves_per_row=%d basin_patterns=%d xcd_bands=%d", v, kMaxClass,
+                 p->last_aligned ? 1 : 0, k, p->nclass, zonal_xcd_map(p->npj) ? 1 : 0);
     else
         snprintf(buf, buflen, "moc_zonal_kernel<NV=%d,NB=%d,ALIGNED=%d,MODE=%s> waves_per_row=%d", v, nb, p->last_aligned ? 1 : 0,
                  md == kModeFma ? "fma" : "select", k);
