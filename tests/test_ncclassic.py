@@ -220,3 +220,34 @@ def test_classic_formats_refuse_variables_and_offsets_that_do_not_fit(nc, tmp_pa
     ncid, rc = _define(nc, p, 5, [("a", ("y", "x")), ("b", ("y", "x"))], big)                # CDF-5: 64-bit sizes
     ok(nc, rc)
     nc.ncc_close(ncid)
+
+
+@pytest.mark.parametrize("threads", ["1", "3", "16"])
+def test_large_reads_split_over_threads_and_swapped_through_a_buffer(nc, tmp_path, monkeypatch, threads):
+    """Reads of tens of MB are cut into parts for CDFT_IO_THREADS threads, each reading through a 256 KiB buffer and
+    byte-swapping from it into place: r4, r8, i2 and bytes, sizes that are no multiple of the buffer or of the thread
+    count, a window that starts inside the variable -- against scipy's reading of the same file."""
+    monkeypatch.setenv("CDFT_IO_THREADS", threads)
+    path = str(tmp_path / "big.nc")
+    rng = np.random.default_rng(17)
+    n4, n8, n2, n1 = 9_000_037, 4_400_013, 17_000_003, 34_000_001          # 36 MB, 35 MB, 34 MB, 34 MB
+    arrays = {"a4": rng.random(n4, dtype=np.float32), "a8": rng.random(n8), "a2": rng.integers(-30000, 30000, n2).astype(np.int16),
+              "a1": rng.integers(-100, 100, n1).astype(np.int8)}
+    with netcdf_file(path, "w", version=2) as f:
+        for name, a in arrays.items():
+            f.createDimension("d" + name, a.size)
+            f.createVariable(name, a.dtype.newbyteorder(">") if a.dtype.itemsize > 1 else a.dtype, ("d" + name,))[:] = a
+    ncid = C.c_int()
+    ok(nc, nc.ncc_open(path.encode(), 0, C.byref(ncid)))
+    mt = {"a4": FLOAT, "a8": DOUBLE, "a2": SHORT, "a1": BYTE}
+    for name, a in arrays.items():
+        vid = C.c_int()
+        ok(nc, nc.ncc_inq_varid(ncid, name.encode(), C.byref(vid)))
+        got = np.empty_like(a)
+        ok(nc, nc.ncc_get_vara(ncid, vid, sz(0), sz(a.size), mt[name], got.ctypes.data_as(C.c_void_p)))
+        assert np.array_equal(got, a), name
+        lo = 1_000_003                                                    # a window: neither end on a buffer boundary
+        part = np.empty(a.size - lo - 5, a.dtype)
+        ok(nc, nc.ncc_get_vara(ncid, vid, sz(lo), sz(part.size), mt[name], part.ctypes.data_as(C.c_void_p)))
+        assert np.array_equal(part, a[lo:lo + part.size]), name
+    ok(nc, nc.ncc_close(ncid))
