@@ -177,12 +177,27 @@ int launch_vint(const VintArgs &a_in, hipStream_t st) {
     else if (a.nij % 4 == 0 && rowok4 && all(16)) vec = 4;
     else if (a.nij % 2 == 0 && rowok2 && all(8)) vec = 2;
     const bool full = a.e31d != nullptr;
-    static int vpt = 0;                                  // vectors per lane: CDFT_VINT_VPT = 1 | 2 | 4 (tuning)
-    if (!vpt) { const char *e = getenv("CDFT_VINT_VPT"); vpt = e ? atoi(e) : 4; if (vpt != 1 && vpt != 2 && vpt != 4) vpt = 4; }
+    // vectors per lane.  The more bytes a wave has in flight the better these streams run, down to two waves per SIMD:
+    // cdfpsi's form (one r8 sum per cell, two fields) 1.92 / 1.83 / 1.71 / 1.63 ms at eORCA12 with 1 / 2 / 4 / 8 vectors
+    // (36 / 70 / 138 / 256 VGPRs); cdfmhst -vt (two sums, three fields) 2.45 -> 2.34 ms with 6 instead of 4 (256 VGPRs);
+    // the other forms keep 4.  CDFT_VINT_VPT = 1 | 2 | 4 | 6 | 8: tuning and test hook (6 and 8 only where they fit).
+    int vpt_env = 0;                                     // (read at every launch: tools/ab_env.py switches it inside one process)
+    { const char *e = getenv("CDFT_VINT_VPT"); vpt_env = e ? atoi(e) : 0; if (vpt_env != 1 && vpt_env != 2 && vpt_env != 4 && vpt_env != 6 && vpt_env != 8) vpt_env = 0; }
+    const int64_t nv4 = (a.nij + vec - 1) / vec;
+    auto blocks_with = [&](int v) { return (nv4 + (int64_t)v * kThreads - 1) / ((int64_t)v * kThreads); };
+    int vpt = vpt_env ? vpt_env : 4;
+    if (!vpt_env && vec == 4) {                          // the larger shapes only where they leave four workgroups per CU (eORCA025: 6 is 20 % slower for cdfmhst)
+        if (MODE == kPsi && blocks_with(8) >= 1024) vpt = 8;
+        if (MODE == kMhstVt && blocks_with(6) >= 1024) vpt = 6;
+    }
+    if (vpt == 8 && !(MODE == kPsi && vec == 4)) vpt = 4;
+    if (vpt == 6 && !(MODE == kMhstVt && vec == 4)) vpt = 4;
     const int64_t nvecs = (a.nij + vec - 1) / vec, nthr = (nvecs + vpt - 1) / vpt;
     a.band = xcd_bands_on();
     const dim3 grid(xcd_band_grid((nthr + kThreads - 1) / kThreads, a.band)), block(kThreads);
 #define CDFT_GO(V, F) do { if (vpt == 1) hipLaunchKernelGGL((vint_kernel<V, MODE, F, 1>), grid, block, 0, st, a); \
+                           else if (vpt == 8 && MODE == kPsi && V == 4) hipLaunchKernelGGL((vint_kernel<4, kPsi, F, 8>), grid, block, 0, st, a); \
+                           else if (vpt == 6 && MODE == kMhstVt && V == 4) hipLaunchKernelGGL((vint_kernel<4, kMhstVt, F, 6>), grid, block, 0, st, a); \
                            else if (vpt == 2) hipLaunchKernelGGL((vint_kernel<V, MODE, F, 2>), grid, block, 0, st, a); \
                            else hipLaunchKernelGGL((vint_kernel<V, MODE, F, 4>), grid, block, 0, st, a); } while (0)
     if (vec == 4) { if (full) CDFT_GO(4, true); else CDFT_GO(4, false); }
