@@ -2,7 +2,7 @@
 """One plan, one set of fields, one process: a kernel timed with an environment hook of the library at several values,
 alternating (a kernel's time moves by 3 % with where its inputs were allocated, so two processes cannot be compared; the
 hooks are read at every launch).
-    python tools/ab_env.py CDFT_MOC_XCDMAP [--tool moc|heatc|mean|mhst|psi|zonal] [--values 0,1] [--rounds 3] [--steps 30] [--grid eorca12]"""
+    python tools/ab_env.py CDFT_MOC_XCDMAP [--tool moc|heatc|heatc_r4|mean|mhst|psi|vt] [--values 0,1] [--rounds 3] [--steps 30] [--grid eorca12]"""
 import argparse
 import os
 import sys
@@ -81,6 +81,18 @@ def make(tool, grid, dev):
             r = keep["r"]
             r = r[0] if isinstance(r, (tuple, list)) else r
             return r if torch.is_tensor(r) else torch.from_numpy(np.ascontiguousarray(np.asarray(r)))
+        return call, res
+    if tool == "vt":
+        nfr = 6
+        u, v = rnd(nfr, npk, npj, npi) - 0.5, rnd(nfr, npk, npj, npi) - 0.5
+        t, s = -2 + 32 * rnd(nfr, npk, npj, npi), 30 + 8 * rnd(nfr, npk, npj, npi)
+        keep = {}
+        def call():
+            keep["r"] = hip.vt_compute(u, v, t, s, out_r4=True)
+        def res():
+            r = keep["r"]
+            r = r if isinstance(r, (tuple, list)) else (list(r.values()) if isinstance(r, dict) else [r])
+            return torch.cat([x.reshape(-1) if torch.is_tensor(x) else torch.from_numpy(np.ascontiguousarray(np.asarray(x))).reshape(-1) for x in r])
         return call, res
     raise SystemExit(f"tool {tool}?")
 
