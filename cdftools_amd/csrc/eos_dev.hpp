@@ -16,6 +16,24 @@ __device__ __forceinline__ double muladd(double a, double b, double c) {
     return FAST ? __fma_rn(a, b, c) : __dadd_rn(__dmul_rn(a, b), c);
 }
 
+// sqrt of the scaled salinity, correctly rounded like __dsqrt_rn, without the range scaling the general routine wraps around
+// its iteration (a compare, two selects and two ldexp per point that only matter below 2^-767): the argument here is
+// |S + deltaS| * r1_s0 with S an r4 number, i.e. 0, at least 1e-7, at most 1e37, Inf or NaN.  The iteration is the
+// library's own (v_rsq_f64, one joint refinement of g = sqrt and h = 1 / (2 sqrt), two corrections of g by its residual);
+// 0 and Inf pass through.  A correctly rounded result is one number: the tests hold it to the oracle's sqrt bit for bit.
+__device__ __forceinline__ double eos_sqrt(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = __dmul_rn(x, y), h = __dmul_rn(y, 0.5);
+    const double r = __fma_rn(-h, g, 0.5);
+    g = __fma_rn(g, r, g);
+    h = __fma_rn(h, r, h);
+    double d = __fma_rn(-g, g, x);
+    g = __fma_rn(d, h, g);
+    d = __fma_rn(-g, g, x);
+    g = __fma_rn(d, h, g);
+    return (x == 0.0 || x == __builtin_inf()) ? x : g;
+}
+
 // r_k(t,s) with the reference's association (src/eos.f90:858-875): each t-level is written
 //   ( ... )*dlt + (((c_n*dls + c_{n-1})*dls + ...) + c_1)*dls + c_0  ==  (acc*t + Y*s) + c_0
 template <int SET, int K, bool FAST>
@@ -43,7 +61,7 @@ __device__ __forceinline__ double sigmai_point(float ptem, float psal, float pre
     constexpr double rdeltas = SET ? CDFT_EOS_RDELTAS_T10 : CDFT_EOS_RDELTAS_80;
     constexpr double r1_s0   = SET ? CDFT_EOS_R1_S0_T10 : CDFT_EOS_R1_S0_80;
     const double t  = __dmul_rn((double)ptem, CDFT_EOS_R1_T0);                      // :850
-    const double s  = __dsqrt_rn(__dmul_rn(fabs(__dadd_rn((double)psal, rdeltas)), r1_s0));  // :851
+    const double s  = eos_sqrt(__dmul_rn(fabs(__dadd_rn((double)psal, rdeltas)), r1_s0));    // :851
     const double tm = (psal == 0.0f) ? 0.0 : 1.0;                                   // :852-856
     const double r0 = eos_rk<SET, 0, FAST>(t, s);
     double r = r0, ref = 0.0;
