@@ -37,6 +37,34 @@ def _free_port():
     return p
 
 
+def _run_ranks(target, world, args, results=1, timeout=420):
+    """Start `world` processes of target(rank, world, port, *args, q) and return the `results` objects they put on q.  The
+    port is found by binding and closing, so another process can take it in between, and on a busy machine the first
+    `import torch` of a spawned process alone can take a minute: one more attempt, on another port, before failing."""
+    ctx = mp.get_context("spawn")
+    last = None
+    for attempt in range(2):
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=target, args=(r, world, port) + tuple(args) + (q,)) for r in range(world)]
+        for p in procs:
+            p.start()
+        try:
+            out = [q.get(timeout=timeout) for _ in range(results)]
+            for p in procs:
+                p.join(timeout)
+            if all(p.exitcode == 0 for p in procs):
+                return out
+            last = "exit codes %s" % [p.exitcode for p in procs]
+        except Exception as exc:                                   # queue.Empty: a rank never got there
+            last = repr(exc)
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+            p.join(30)
+    raise AssertionError("the ranks did not finish in two attempts: " + str(last))
+
+
 def _worker(rank, world, port, npi, npj, npk, nb, npt, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -65,16 +93,7 @@ def _worker(rank, world, port, npi, npj, npk, nb, npt, q):
 
 @pytest.mark.parametrize("npj", [18, 19])            # even and ragged split
 def test_two_rank_gloo_gather_matches_single_process(npj):
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, 24, npj, 7, 5, 2, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(120)
-        assert p.exitcode == 0
-    assert q.get(timeout=10) is True
+    assert _run_ranks(_worker, 2, (24, npj, 7, 5, 2)) == [True]
 
 
 def _pipeline_worker(rank, world, port, npi, npj, npk, nb, npt, steps, q):
@@ -116,16 +135,7 @@ def _pipeline_worker(rank, world, port, npi, npj, npk, nb, npt, steps, q):
 
 @pytest.mark.parametrize("world,npj,steps", [(2, 19, 5), (3, 20, 4), (2, 18, 1)])
 def test_bench_step_pipeline_on_gloo_ranks_collects_every_step(world, npj, steps):
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_pipeline_worker, args=(r, world, port, 24, npj, 6, 5, 2, steps, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(120)
-        assert p.exitcode == 0
-    assert q.get(timeout=10) is True
+    assert _run_ranks(_pipeline_worker, world, (24, npj, 6, 5, 2, steps)) == [True]
 
 
 def test_bench_step_pipeline_single_process():
@@ -303,16 +313,7 @@ def _tools_worker(rank, world, port, npi, npj, npk, q):
 
 @pytest.mark.parametrize("world,npj", [(2, 19), (3, 20)])
 def test_row_block_sharding_of_the_other_tools_matches_single_process(world, npj):
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_tools_worker, args=(r, world, port, 23, npj, 5, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = dict(q.get(timeout=120) for _ in range(world))
-    for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
+    res = dict(_run_ranks(_tools_worker, world, (23, npj, 5), results=world))
     bad = [k for k in ("mhst", "vt", "curl", "curlT", "psiU", "psiV", "psiMean") if not res[0].get(k)]
     assert not bad, bad
     for r in range(world):
