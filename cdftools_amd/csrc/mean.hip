@@ -10,6 +10,7 @@
 // workgroup owns a set of cells of the horizontal plane for ALL levels, keeps e1, e2 and the basin
 // values in registers and streams zv / e3 / mask past them (12 bytes per cell and level).
 #include <cstdlib>
+#include <cstring>
 #include "common.hpp"
 #include <type_traits>
 #include "reduce.hpp"
@@ -26,6 +27,8 @@ struct cdft_mean_plan {
     int nblk = 0;
     int form = 0;                   // CDFT_MEAN_FORM_*
     bool mesh_set = false;
+    double *hsums = nullptr, *hsums_dev = nullptr;   // page-locked, device-mapped: the final kernel writes host results where the host reads them (as cdfheatc)
+    size_t hsums_bytes = 0;
     DevBuf st_zv, st_out;
 };
 
@@ -285,7 +288,17 @@ int cdft_mean_compute(cdft_mean_plan *p, const float *zv, int in_space, double *
     const int nq = p->nb * 4;
     const size_t ob = (size_t)p->npk * nq * 8;
     double *dout = sums;
-    if (out_space == CDFT_MEM_HOST) { CDFT_TRY(p->st_out.reserve(ob)); dout = (double *)p->st_out.ptr; }
+    bool mapped = false;
+    if (out_space == CDFT_MEM_HOST) {
+        if (p->hsums_bytes < ob) {                                 // (once per plan: nb and npk are the plan's)
+            if (p->hsums) { (void)hipHostFree(p->hsums); p->hsums = nullptr; p->hsums_bytes = 0; }
+            if (hipHostMalloc((void **)&p->hsums, ob, hipHostMallocMapped) == hipSuccess &&
+                hipHostGetDevicePointer((void **)&p->hsums_dev, p->hsums, 0) == hipSuccess) p->hsums_bytes = ob;
+            else { (void)hipGetLastError(); if (p->hsums) { (void)hipHostFree(p->hsums); p->hsums = nullptr; } }
+        }
+        if (p->hsums_bytes >= ob) { dout = p->hsums_dev; mapped = true; }
+        else { CDFT_TRY(p->st_out.reserve(ob)); dout = (double *)p->st_out.ptr; }
+    }
     MeanArgs a;
     a.e1 = p->e1; a.e2 = p->e2; a.e3 = p->e3; a.e31d = p->e31d; a.mask = p->mask; a.zv = (const float *)dz; a.ib = p->ib;
     a.nij = nij; a.npk = p->npk; a.nb = p->nb; a.partial = p->partial; a.form = p->form;
@@ -318,8 +331,13 @@ int cdft_mean_compute(cdft_mean_plan *p, const float *zv, int in_space, double *
     hipLaunchKernelGGL(mean_final_kernel, dim3(p->npk), dim3(kThreads), 0, st, p->partial, a.nblk, nq, dout);
     CDFT_LAUNCH_CHECK();
     if (out_space == CDFT_MEM_HOST) {
-        CDFT_HIP(hipMemcpyAsync(sums, dout, ob, hipMemcpyDeviceToHost, st));
-        CDFT_HIP(hipStreamSynchronize(st));
+        if (mapped) {
+            CDFT_HIP(hipStreamSynchronize(st));
+            memcpy(sums, p->hsums, ob);
+        } else {
+            CDFT_HIP(hipMemcpyAsync(sums, dout, ob, hipMemcpyDeviceToHost, st));
+            CDFT_HIP(hipStreamSynchronize(st));
+        }
     }
     return CDFT_OK;
 }
@@ -328,6 +346,7 @@ int cdft_mean_destroy(cdft_mean_plan *p) {
     if (!p) return CDFT_OK;
     void *ptrs[] = {p->e1, p->e2, p->e3, p->e31d, p->mask, p->mask8, p->ib, p->partial};
     for (void *q : ptrs) if (q) (void)hipFree(q);
+    if (p->hsums) (void)hipHostFree(p->hsums);
     p->st_zv.release(); p->st_out.release();
     delete p;
     return CDFT_OK;
