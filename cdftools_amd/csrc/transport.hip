@@ -527,6 +527,8 @@ struct cdft_mhst_plan {
     bool use_bits = false;
     double *dtrph = nullptr, *dtrps = nullptr, *oh = nullptr, *os = nullptr;
     bool mesh_set = false;
+    double *hout = nullptr, *hout_dev = nullptr;         // page-locked, device-mapped (heat, salt) of a host call: the zonal kernel
+    size_t hout_bytes = 0;                               // writes the result where the host reads it (as cdfheatc)
     DevBuf s0, s1, s2;
 };
 
@@ -629,6 +631,16 @@ int cdft_mhst_compute(cdft_mhst_plan *p, const float *vt, const float *vs, const
     const int nlev_out = zdim ? p->npk : 1;
     const size_t out_bytes = (size_t)p->nb * p->npj * nlev_out * 8;
     double *oh = (out_space == CDFT_MEM_DEVICE) ? heat : p->oh, *os = (out_space == CDFT_MEM_DEVICE) ? salt : p->os;
+    bool mapped = false;
+    if (out_space == CDFT_MEM_HOST) {
+        if (p->hout_bytes < 2 * out_bytes) {
+            if (p->hout) { (void)hipHostFree(p->hout); p->hout = nullptr; p->hout_bytes = 0; }
+            if (hipHostMalloc((void **)&p->hout, 2 * out_bytes, hipHostMallocMapped) == hipSuccess &&
+                hipHostGetDevicePointer((void **)&p->hout_dev, p->hout, 0) == hipSuccess) p->hout_bytes = 2 * out_bytes;
+            else { (void)hipGetLastError(); if (p->hout) { (void)hipHostFree(p->hout); p->hout = nullptr; } }
+        }
+        if (p->hout_bytes >= 2 * out_bytes) { oh = p->hout_dev; os = p->hout_dev + out_bytes / 8; mapped = true; }
+    }
     auto zonal = [&](double *h, double *s) -> int {
         const char *e = getenv("CDFT_MHST_R4MASKS");             // test hook: the unpacked masks
         const bool bits = p->use_bits && !(e && e[0] == '1');
@@ -659,9 +671,15 @@ int cdft_mhst_compute(cdft_mhst_plan *p, const float *vt, const float *vs, const
         }
     }
     if (out_space == CDFT_MEM_HOST) {
-        CDFT_HIP(hipMemcpyAsync(heat, oh, out_bytes, hipMemcpyDeviceToHost, st));
-        CDFT_HIP(hipMemcpyAsync(salt, os, out_bytes, hipMemcpyDeviceToHost, st));
-        CDFT_HIP(hipStreamSynchronize(st));
+        if (mapped) {
+            CDFT_HIP(hipStreamSynchronize(st));
+            memcpy(heat, p->hout, out_bytes);
+            memcpy(salt, p->hout + out_bytes / 8, out_bytes);
+        } else {
+            CDFT_HIP(hipMemcpyAsync(heat, oh, out_bytes, hipMemcpyDeviceToHost, st));
+            CDFT_HIP(hipMemcpyAsync(salt, os, out_bytes, hipMemcpyDeviceToHost, st));
+            CDFT_HIP(hipStreamSynchronize(st));
+        }
     }
     return CDFT_OK;
 }
@@ -676,6 +694,7 @@ int cdft_mhst_destroy(cdft_mhst_plan *p) {
     }
     void *ptrs[] = {p->e1v, p->e3v, p->e31d, p->masks, p->mbits, p->dtrph, p->dtrps, p->oh, p->os};
     for (void *q : ptrs) if (q) (void)hipFree(q);
+    if (p->hout) (void)hipHostFree(p->hout);
     p->s0.release(); p->s1.release(); p->s2.release();
     delete p;
     return CDFT_OK;
