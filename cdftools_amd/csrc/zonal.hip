@@ -390,9 +390,8 @@ __global__ void __launch_bounds__(T) zonal_row_class_kernel(ZonalArgs2 a, ZonalC
 
 constexpr int kClassT = 256, kClassMaxNV = 5;
 
-template <int NV>
+template <int NV, int T = kClassT>
 int launch_class_nv(const ZonalArgs2 &a, const ZonalClassArgs &ca, bool mean, hipStream_t st) {
-    constexpr int T = kClassT;
     const size_t shmem = ((size_t)(T / 64) * (kZC + 1) * kZStride + (size_t)a.nlev * kZC * (T / 64)) * sizeof(double);
     const dim3 grid(ca.xcd_map ? 8 * ((a.npj + 7) / 8) * ca.lc : a.npj * ca.lc);
     if (a.mask8) {
@@ -415,6 +414,21 @@ int launch_class(const ZonalArgs2 &a, ZonalClassArgs ca, bool mean, hipStream_t 
     // so that there are about 4096 (measured: 238 -> 209 us there, nothing lost at eORCA12)
     ca.lc = e ? std::max(1, std::min(a.nlev, atoi(e))) : std::max(1, std::min(std::min(a.nlev, 8), (4096 + a.npj - 1) / a.npj));
     { const char *x = getenv("CDFT_ZONAL_XCDMAP"); ca.xcd_map = (a.npj >= 64 && !(x && x[0] == '0')) ? 1 : 0; }
+    // Workgroups of 128 lanes where they waste fewer lanes on the end of the row than 256 do (a row of 1442 cells is 362
+    // vectors: 2 x 256 slots leave 29 % of the lanes idle, 3 x 128 leave 6 %); CDFT_ZONAL_T = 128 | 256: A/B hook
+    {
+        const int nvec = a.npi / 4 + 1, nv128 = (nvec + 127) / 128, nv256 = (nvec + 255) / 256;
+        const char *t = getenv("CDFT_ZONAL_T");
+        const bool small = t ? atoi(t) == 128 : nv128 * 128 < nv256 * 256;
+        if (small && nv128 <= kClassMaxNV)                        // (rows of up to 2556 cells; at 4322 cells 9 x 128 was measured: 3 % slower than 5 x 256)
+            switch (nv128) {
+                case 1: return launch_class_nv<1, 128>(a, ca, mean, st);
+                case 2: return launch_class_nv<2, 128>(a, ca, mean, st);
+                case 3: return launch_class_nv<3, 128>(a, ca, mean, st);
+                case 4: return launch_class_nv<4, 128>(a, ca, mean, st);
+                default: return launch_class_nv<5, 128>(a, ca, mean, st);
+            }
+    }
     switch ((a.npi / 4 + 1 + kClassT - 1) / kClassT) {
         case 1: return launch_class_nv<1>(a, ca, mean, st);
         case 2: return launch_class_nv<2>(a, ca, mean, st);
