@@ -523,6 +523,11 @@ int cdft_vt_compute(const float *u, const float *v, const float *t, const float 
     // tiles of equal width chosen so that few lanes hang over the row's end (cdfcurl's rule: a row of 4322 cells in six tiles
     // of 724 on 192 lanes, 94 % of the lanes at work, instead of four of 1024 and one of 226, 84 %); CDFT_VT_TW: A/B hook
     CurlShape sh = curl_shape(npiglo);
+    {   // ... where that buys something: at 4322 cells (84 -> 94 % of the lanes) the two were measured equal, at 1442 (70 -> 94 %) 7 % apart
+        const int n0 = (npiglo + kTile - 1) / kTile;
+        const double eff0 = (double)npiglo / ((double)n0 * kTile), eff1 = (double)npiglo / ((double)sh.ntx * sh.threads * 4);
+        if (eff1 - eff0 < 0.1) sh = CurlShape{n0, kTile, kThreads};
+    }
     if (const char *etw = getenv("CDFT_VT_TW")) {
         const int tw = std::min(kTile, atoi(etw) / 4 * 4);
         if (tw >= 4) sh = CurlShape{(npiglo + tw - 1) / tw, tw, ((tw / 4 + 63) / 64) * 64};      // (0: the default)
