@@ -969,6 +969,73 @@ static int read_run_parallel(int fd, unsigned char *mem, size_t bytes, size_t xs
     return rc;
 }
 
+/* The same for writes of the external type: each thread swaps its part through a cache-resident buffer and writes it at its
+ * place (before: one thread, a temporary as large as the slab allocated and faulted in at every call, 1.6 GB/s into the page
+ * cache -- 12 of the 13.6 s cdfvT took on an eORCA12 record were its four 4.7 GB outputs). */
+typedef struct { int fd; const unsigned char *mem; size_t bytes, xs; off_t off; int rc; } WriteJob;
+
+static int pwrite_all(int fd, const void *buf, size_t n, off_t off) {
+    size_t put = 0;                                      /* (a single pwrite stops near 2 GiB) */
+    while (put < n) {
+        const ssize_t g = pwrite(fd, (const char *)buf + put, n - put, off + (off_t)put);
+        if (g < 0 && errno == EINTR) continue;
+        if (g <= 0) return -1;
+        put += (size_t)g;
+    }
+    return 0;
+}
+
+static void *write_job(void *arg) {
+    WriteJob *j = (WriteJob *)arg;
+    j->rc = 0;
+    if (j->xs == 1) { if (pwrite_all(j->fd, j->mem, j->bytes, j->off)) j->rc = NCC_EIO; return NULL; }
+    enum { kBuf = 256 * 1024 };
+    unsigned char *buf = (unsigned char *)malloc(kBuf);
+    if (!buf) { j->rc = NCC_ENOMEM; return NULL; }
+    const size_t step = (size_t)kBuf / j->xs * j->xs;
+    for (size_t done = 0; done < j->bytes; done += step) {
+        const size_t n = j->bytes - done < step ? j->bytes - done : step;
+        bswap_copy(buf, j->mem + done, n / j->xs, j->xs);
+        if (pwrite_all(j->fd, buf, n, j->off + (off_t)done)) { j->rc = NCC_EIO; break; }
+    }
+    free(buf);
+    return NULL;
+}
+
+static int write_run_parallel(int fd, const unsigned char *mem, size_t bytes, size_t xs, off_t off) {
+    enum { kMaxThreads = 32 };
+    const size_t kMinPart = (size_t)8 << 20;
+    int nt = (int)(bytes / kMinPart);
+    int cap = 16;
+    const long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+    if (ncpu >= 1 && ncpu < cap) cap = (int)ncpu;
+    const char *env = getenv("CDFT_IO_THREADS");
+    if (env && *env) { const int e = atoi(env); if (e >= 1) cap = e < kMaxThreads ? e : kMaxThreads; }
+    if (nt > cap) nt = cap;
+    if (nt < 2) {
+        WriteJob j = {fd, mem, bytes, xs, off, 0};
+        write_job(&j);
+        return j.rc;
+    }
+    WriteJob jobs[kMaxThreads];
+    pthread_t th[kMaxThreads];
+    int started[kMaxThreads] = {0};
+    const size_t nel = bytes / xs, per = (nel + (size_t)nt - 1) / (size_t)nt;
+    int rc = 0;
+    for (int t = 0; t < nt; ++t) {
+        const size_t e0 = per * (size_t)t, e1 = e0 + per < nel ? e0 + per : nel;
+        jobs[t] = (WriteJob){fd, mem + e0 * xs, e0 < e1 ? (e1 - e0) * xs : 0, xs, off + (off_t)(e0 * xs), 0};
+        if (jobs[t].bytes == 0) continue;
+        if (t == nt - 1 || pthread_create(&th[t], NULL, write_job, &jobs[t]) != 0) write_job(&jobs[t]);   /* inline */
+        else started[t] = 1;
+    }
+    for (int t = 0; t < nt; ++t) {
+        if (started[t]) pthread_join(th[t], NULL);
+        if (jobs[t].rc) rc = jobs[t].rc;
+    }
+    return rc;
+}
+
 static int vara(int ncid, int varid, const size_t *start, const size_t *count, int memtype, void *data, int writing) {
     File *f = getf(ncid);
     if (!f) return NCC_EBADID;
@@ -1022,17 +1089,23 @@ static int vara(int ncid, int varid, const size_t *start, const size_t *count, i
     const int nouter = last;
     uint64_t idx[NCC_MAX_DIMS + 1] = {0};
     const size_t tmpn = (size_t)run * xs;
-    unsigned char *tmp = (unsigned char *)malloc(tmpn ? tmpn : 1), *conv = NULL;
-    if (!tmp) return NCC_ENOMEM;
-    if (v->type != memtype && !(xs == 1 && ms == 1)) { conv = (unsigned char *)malloc((size_t)run * (xs > ms ? xs : ms)); if (!conv) { free(tmp); return NCC_ENOMEM; } }
+    unsigned char *tmp = NULL, *conv = NULL;
+    if (v->type != memtype && !(xs == 1 && ms == 1)) {       /* a conversion: the slab goes through two temporaries */
+        tmp = (unsigned char *)malloc(tmpn ? tmpn : 1);
+        if (!tmp) return NCC_ENOMEM;
+        conv = (unsigned char *)malloc((size_t)run * (xs > ms ? xs : ms)); if (!conv) { free(tmp); return NCC_ENOMEM; }
+    }
     unsigned char *mem = (unsigned char *)data;
     int rc = 0;
     for (;;) {
         uint64_t off = v->begin + (last < nd ? st[last] * stride[last] : 0);
         for (int d = 0; d < nouter; ++d) off += (st[d] + idx[d]) * stride[d];
-        if (writing) {
+        if (writing && !conv) {                 /* the external type: swapped and written by parts, no temporary */
+            rc = write_run_parallel(f->fd, mem, tmpn, xs, (off_t)off);
+            if (rc) break;
+        } else if (writing) {
             const void *src = mem;
-            if (conv) { convert(conv, v->type, mem, memtype, (size_t)run); src = conv; }
+            convert(conv, v->type, mem, memtype, (size_t)run); src = conv;
             bswap_copy(tmp, src, (size_t)run, xs);
             size_t put = 0;                                          /* (a single pwrite stops near 2 GiB) */
             while (put < tmpn) {

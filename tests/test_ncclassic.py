@@ -251,3 +251,33 @@ def test_large_reads_split_over_threads_and_swapped_through_a_buffer(nc, tmp_pat
         ok(nc, nc.ncc_get_vara(ncid, vid, sz(lo), sz(part.size), mt[name], part.ctypes.data_as(C.c_void_p)))
         assert np.array_equal(part, a[lo:lo + part.size]), name
     ok(nc, nc.ncc_close(ncid))
+
+
+@pytest.mark.parametrize("threads", ["1", "5"])
+def test_large_writes_split_over_threads_are_what_scipy_reads(nc, tmp_path, monkeypatch, threads):
+    """Writes of the external type are cut into parts for CDFT_IO_THREADS threads, each swapping through a 256 KiB buffer and
+    writing at its own offset: a 36 MB r4 variable and a 35 MB r8 one (sizes no multiple of anything), a byte variable, and
+    a window written into the middle of a variable -- read back by scipy."""
+    monkeypatch.setenv("CDFT_IO_THREADS", threads)
+    path = str(tmp_path / "bigw.nc")
+    rng = np.random.default_rng(23)
+    arrays = {"a4": rng.random(9_000_037, dtype=np.float32), "a8": rng.random(4_400_013), "a1": rng.integers(-100, 100, 20_000_003).astype(np.int8)}
+    mt = {"a4": FLOAT, "a8": DOUBLE, "a1": BYTE}
+    ncid = C.c_int()
+    ok(nc, nc.ncc_create(path.encode(), 2, 1, C.byref(ncid)))
+    vid = {}
+    for name, a in arrays.items():
+        d, v = C.c_int(), C.c_int()
+        ok(nc, nc.ncc_def_dim(ncid, ("d" + name).encode(), C.c_size_t(a.size), C.byref(d)))
+        ok(nc, nc.ncc_def_var(ncid, name.encode(), mt[name], 1, (C.c_int * 1)(d.value), C.byref(v)))
+        vid[name] = v.value
+    ok(nc, nc.ncc_enddef(ncid))
+    for name, a in arrays.items():
+        ok(nc, nc.ncc_put_vara(ncid, vid[name], sz(0), sz(a.size), mt[name], a.ctypes.data_as(C.c_void_p)))
+    patch = np.arange(8_500_001, dtype=np.float32)                         # a second write over the middle of a4
+    ok(nc, nc.ncc_put_vara(ncid, vid["a4"], sz(123_457), sz(patch.size), FLOAT, patch.ctypes.data_as(C.c_void_p)))
+    ok(nc, nc.ncc_close(ncid))
+    arrays["a4"][123_457:123_457 + patch.size] = patch
+    with netcdf_file(path, "r", mmap=False) as f:
+        for name, a in arrays.items():
+            assert np.array_equal(f.variables[name][:], a), name

@@ -5,7 +5,7 @@ same file, at sizes where a record is 4.68 GB -- slab sizes, offsets and counts 
 level through the bundled backend; only what the program reads.  (cdfmoc and cdfheatc have their own tools, which also hold
 the result against the oracle.)
 
-    python tools/e2e_feed_big.py --tool psi|mhst [--grid eorca12] [--npt 2]      # on the GPU box; 20-30 GB of scratch files
+    python tools/e2e_feed_big.py --tool psi|mhst|vt [--grid eorca12] [--npt 2]      # on the GPU box; 20-30 GB of scratch files
 """
 import argparse
 import hashlib
@@ -28,7 +28,8 @@ from e2e_cdfmoc_big import BYTE, DOUBLE, FLOAT, GRIDS, Writer  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--tool", required=True, choices=["psi", "mhst"])
+    ap.add_argument("--tool", required=True, choices=["psi", "mhst", "vt"])
+    ap.add_argument("--runs", type=int, default=2, help="runs per route (the first warms the page cache)")
     ap.add_argument("--grid", default="eorca12", choices=sorted(GRIDS))
     ap.add_argument("--npt", type=int, default=2)
     ap.add_argument("--keep", action="store_true")
@@ -91,6 +92,13 @@ def main():
         files = {"U.nc": data_file("U.nc", "depthu", ["vozocrtx"]), "V.nc": data_file("V.nc", "depthv", ["vomecrty"])}
         fields = [("U.nc", "vozocrtx")]                          # the default path reads U alone; V.nc has to exist
         cmd = ["cdfpsi", "-u", "U.nc", "-v", "V.nc"]
+    elif args.tool == "vt":                                       # one frame per file, --npt records: cdfvT averages over them
+        files = {"SYN_y0001_gridT.nc": data_file("SYN_y0001_gridT.nc", "deptht", ["votemper", "vosaline"]),
+                 "SYN_y0001_gridU.nc": data_file("SYN_y0001_gridU.nc", "depthu", ["vozocrtx"]),
+                 "SYN_y0001_gridV.nc": data_file("SYN_y0001_gridV.nc", "depthv", ["vomecrty"])}
+        fields = [("SYN_y0001_gridT.nc", "votemper"), ("SYN_y0001_gridT.nc", "vosaline"), ("SYN_y0001_gridU.nc", "vozocrtx"),
+                  ("SYN_y0001_gridV.nc", "vomecrty")]
+        cmd = ["cdfvT", "-c", "SYN", "-l", "y0001"]
     else:
         files = {"vt.nc": data_file("vt.nc", "depthv", ["vomevt", "vomevs"])}
         fields = [("vt.nc", "vomevt"), ("vt.nc", "vomevs")]
@@ -132,7 +140,7 @@ def main():
     e2e, outs, wrote = {}, {}, {}
     for feed in (False, True):
         best = None
-        for i in range(2):                                        # (the second run has every file in the page cache)
+        for i in range(args.runs):                                # (the second run has every file in the page cache)
             wall, stdout, timing, w_ = run_program(feed, "out.nc")      # (the same name both ways: cdfpsi writes its command line into the file)
             if best is None or wall < best[0]:
                 best = (wall, timing)
