@@ -52,6 +52,9 @@ PROGRAM cdfmoc
   TYPE(variable), ALLOCATABLE :: stypvar(:)
   TYPE(C_PTR) :: plan
   TYPE(C_PTR) :: pd_zv = C_NULL_PTR, pd_e3v = C_NULL_PTR, pd_vm = C_NULL_PTR, pd_e1v = C_NULL_PTR, pd_ib = C_NULL_PTR
+  TYPE(C_PTR) :: pd_t = C_NULL_PTR, pd_s = C_NULL_PTR     ! -decomp: T and S of the record in HBM
+  REAL(KIND=4), POINTER :: zt_d(:), zs_d(:)
+  LOGICAL :: lfeed_dec
   REAL(KIND=4), POINTER :: zv_d(:), e3v_d(:), e1v_d(:)       ! the same device arrays seen as arrays (never touched by the host)
   INTEGER(KIND=1), POINTER :: ivm_d(:)
   INTEGER(KIND=2), POINTER :: ib_d(:)
@@ -176,6 +179,8 @@ PROGRAM cdfmoc
   CALL hip_shard(ngpu, igpus)                                ! CDFT_GPUS / CDFT_GPU_MAP: row blocks over the node's GPUs
   lfeed = feed_wanted(4_8 * npiglo * npjglo * npk) .AND. ngpu == 1 .AND. .NOT. ( ldec .OR. lfull )
   IF ( lfeed ) nbatch = 1                                 ! a record is computed on as soon as its last slab has left
+  ! -decomp: V, T and S of a record go through the ring too (the mesh of the decomposition stays a host array: once per run)
+  lfeed_dec = ldec .AND. .NOT. lfull .AND. ngpu == 1 .AND. feed_wanted(4_8 * npiglo * npjglo * npk)
   nij8 = INT(npiglo, 8) * npjglo ; n38 = nij8 * npk
 
   ALLOCATE( ibmask(nbasins, npiglo, npjglo), zmsk(npiglo, npjglo) )
@@ -192,7 +197,7 @@ PROGRAM cdfmoc
   IF ( ldec ) THEN
      ALLOCATE( e1u(npiglo, npjglo), zcoef(npiglo, npjglo), gdept(npk) )
      ALLOCATE( itmask(npiglo, npjglo, npk), iumask(npiglo, npjglo, npk) )
-     ALLOCATE( ztemp(npiglo, npjglo, npk), zsal(npiglo, npjglo, npk) )
+     IF ( .NOT. lfeed_dec ) ALLOCATE( ztemp(npiglo, npjglo, npk), zsal(npiglo, npjglo, npk) )
      ALLOCATE( dmoc_sh(nbasins, npjglo, npk), dmoc_bt(nbasins, npjglo, npk), dmoc_ag(nbasins, npjglo, npk) )
      gdept(:) = getvare3(cn_fzgr, cn_gdept, npk)
      e1u(:,:) = getvar(cn_fhgr, cn_ve1u, 1, npiglo, npjglo)
@@ -277,11 +282,23 @@ PROGRAM cdfmoc
      ENDIF
      IF ( ldec ) THEN                                     ! one record: total + the three components
         jt = it0
+        IF ( lfeed_dec ) THEN                             ! the three fields leave for HBM slab by slab as they are read
+           IF ( .NOT. C_ASSOCIATED(pd_t) ) THEN
+              pd_zv = feed_device(4 * n38) ; pd_t = feed_device(4 * n38) ; pd_s = feed_device(4 * n38)
+              CALL C_F_POINTER(pd_zv, zv_d, (/ n38 /)) ; CALL C_F_POINTER(pd_t, zt_d, (/ n38 /)) ; CALL C_F_POINTER(pd_s, zs_d, (/ n38 /))
+           ENDIF
+           CALL feed_field(cf_vfil, cn_vomecrty, pd_zv, npiglo, npjglo, npk, ktime=jt)
+           CALL feed_field(cf_tfil, cn_votemper, pd_t,  npiglo, npjglo, npk, ktime=jt)
+           CALL feed_field(cf_sfil, cn_vosaline, pd_s,  npiglo, npjglo, npk, ktime=jt)
+           CALL hip_check(cdft_moc_decomp(plan, zv_d, zt_d, zs_d, MERGE(CDFT_EOS_TEOS10, CDFT_EOS_80, ll_teos10), CDFT_MEM_DEVICE, &
+                &         dmoc, dmoc_sh, dmoc_bt, dmoc_ag, CDFT_MEM_HOST, feed_stream), 'cdft_moc_decomp')
+        ELSE
         CALL readvar3d(cf_vfil, cn_vomecrty, zv(:,:,:,1), ktime=jt)
         CALL readvar3d(cf_tfil, cn_votemper, ztemp(:,:,:), ktime=jt)
         CALL readvar3d(cf_sfil, cn_vosaline, zsal(:,:,:), ktime=jt)
         CALL hip_check(cdft_moc_decomp(plan, zv, ztemp, zsal, MERGE(CDFT_EOS_TEOS10, CDFT_EOS_80, ll_teos10), CDFT_MEM_HOST, &
              &         dmoc, dmoc_sh, dmoc_bt, dmoc_ag, CDFT_MEM_HOST, C_NULL_PTR), 'cdft_moc_decomp')
+        ENDIF
         ijvar = 1                                         ! output order of src/cdfmoc.f90:520-569
         DO jbasin = 1, nbasins
            CALL put4(dmoc(jbasin,:,:,1), dmoc_sh(jbasin,:,:), dmoc_bt(jbasin,:,:), dmoc_ag(jbasin,:,:))
@@ -325,6 +342,9 @@ PROGRAM cdfmoc
   END DO
 
   ierr = cdft_moc_destroy(plan)
+  IF ( lfeed_dec .AND. C_ASSOCIATED(pd_t) ) THEN
+     CALL feed_release(pd_zv) ; CALL feed_release(pd_t) ; CALL feed_release(pd_s) ; CALL feed_close()
+  ENDIF
   IF ( lfeed ) THEN
      CALL feed_release(pd_zv) ; CALL feed_release(pd_e3v) ; CALL feed_release(pd_vm) ; CALL feed_release(pd_e1v) ; CALL feed_release(pd_ib)
      CALL feed_close()

@@ -37,6 +37,8 @@ RUNS = [
     ("cdfheatc", ["-f", "VVL_y0001_gridT.nc", "-vvl"], ["heatc.nc"]),
     ("cdfheatc", ["-f", T, "-zoom", "20", "30", "2", "9", "2", "4"], ["heatc.nc"]),          # a window over the eastern edge
     ("cdfheatc", ["-f", T, "-mxloption", "1", "-mxlf", "mxl.nc"], ["heatc.nc"]),
+    ("cdfmoc", ["-v", V, "-t", T, "-decomp", "-o", "dec.nc"], ["dec.nc"]),                        # V, T and S of a record through the ring
+    ("cdfmoc", ["-v", V, "-t", T, "-decomp", "-teos10", "-o", "dec.nc"], ["dec.nc"]),
     ("cdfpsi", ["-u", U, "-v", V], ["psi.nc"]),
     ("cdfpsi", ["-u", U, "-v", V, "-V"], ["psi.nc"]),
     ("cdfpsi", ["-u", U, "-v", V, "-mean", "-mask", "-ref", "5", "4"], ["psi.nc"]),
