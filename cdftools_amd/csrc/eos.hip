@@ -83,6 +83,7 @@ template <int EOS, bool FAST, int KIND, int VEC, int DEPTH>
 __global__ void __launch_bounds__(256) eos_kernel(EosArgs a) {
     const int64_t nvec = a.n / VEC;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const bool same_mask = (EOS == 0 || EOS == 1) && KIND == kTool && a.spval == 0.f && !a.no_land_shortcut;   // (uniform; the hook keeps the written-out form too)
     double r_land = 0.0;
     float  o_land = 0.f;
     if (KIND != kPointRef && !a.no_land_shortcut) {
@@ -148,10 +149,19 @@ __global__ void __launch_bounds__(256) eos_kernel(EosArgs a) {
             r[c] = eval_point<EOS, FAST, DEPTH>(t[c], s[c], KIND == kPointRef ? p[c] : a.pref);
         if (KIND == kTool) {
             float o[VEC];
+            if (same_mask) {
+                // spval = 0 (the usual missing value of S): the tool's mask (S == spval ? 0 : 1, cdfsig0.f90:148-150) is the 0 / 1
+                // sigmai has already multiplied by (S == 0 ? 0 : 1, eos.f90:852-856, :880).  (x * m) * m = x * m bit for bit for
+                // m = 1 (exact) and m = 0 (the zero, or the NaN of a non-finite x, keeps its sign through the second product):
+                // the second product, its compare, select and conversion are left out -- 4 of ~86 instructions per point
 #pragma unroll
-            for (int c = 0; c < VEC; ++c) {   // cdfsig0.f90:148-150: r8 * r4 mask, stored into r4
-                const float zmask = (s[c] == a.spval) ? 0.f : 1.f;
-                o[c] = (float)__dmul_rn(r[c], (double)zmask);
+                for (int c = 0; c < VEC; ++c) o[c] = (float)r[c];
+            } else {
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) {   // cdfsig0.f90:148-150: r8 * r4 mask, stored into r4
+                    const float zmask = (s[c] == a.spval) ? 0.f : 1.f;
+                    o[c] = (float)__dmul_rn(r[c], (double)zmask);
+                }
             }
             if (VEC == 4) { f4a ov = {o[0], o[1], o[2], o[3]}; __builtin_nontemporal_store(ov, reinterpret_cast<f4a *>(a.out4) + v); }
             else a.out4[v] = o[0];
