@@ -57,7 +57,7 @@ struct HeatcArgs {
     const uint8_t *mask8;
     const float *mask4;
     int64_t nij;
-    int npk, mxlopt, nblk, band;
+    int npk, mxlopt, nblk, band, vpt;
     double *partial;           // [npk][nblk][3]
 };
 
@@ -85,13 +85,13 @@ template <> __device__ __forceinline__ void unpacku<4>(const u4a &v, float (&o)[
 template <> __device__ __forceinline__ void unpacku<2>(const u2a &v, float (&o)[2]) { o[0] = v.x; o[1] = v.y; }
 template <> __device__ __forceinline__ void unpacku<1>(const unsigned char &v, float (&o)[1]) { o[0] = v; }
 
-constexpr int kVPT = 4;   // vectors per lane: each wave reads kVPT contiguous KiB-sized runs per field and level
+constexpr int kVPT = 4;   // vectors per lane (the smaller of the two shapes): each wave reads VPT contiguous KiB-sized runs per field and level
 
 // One workgroup owns kThreads*kVPT vectors of the horizontal plane for ALL levels: the area
 // e1t*e2t (and the mixed-layer depth) stays in registers, every level streams temp / e3t / tmask
 // past it.  Per level each wave reduces its three sums and parks them in LDS; at the end the waves
 // are combined in wave order into partial[k][block][3].
-template <int VEC, bool MASK8, bool FULL>
+template <int VEC, bool MASK8, bool FULL, int VPT>
 __global__ void __launch_bounds__(kThreads) heatc_level_kernel(HeatcArgs a) {
     extern __shared__ double wsum[];                   // [nwaves][npk][3]
     const int64_t blk = xcd_band(a.band);              // (common.hpp)
@@ -99,12 +99,12 @@ __global__ void __launch_bounds__(kThreads) heatc_level_kernel(HeatcArgs a) {
     const int64_t nvec = a.nij / VEC;                  // nij % VEC == 0 by construction
     typedef typename Vec<VEC>::f FV;
     typedef typename Vec<VEC>::u UV;
-    int64_t q[kVPT];
-    bool ok[kVPT];
-    float ar[kVPT][VEC], mx[kVPT][VEC];
+    int64_t q[VPT];
+    bool ok[VPT];
+    float ar[VPT][VEC], mx[VPT][VEC];
 #pragma unroll
-    for (int v = 0; v < kVPT; ++v) {
-        q[v] = ((blk * nwaves + wave) * kVPT + v) * 64 + lane;
+    for (int v = 0; v < VPT; ++v) {
+        q[v] = ((blk * nwaves + wave) * VPT + v) * 64 + lane;
         ok[v] = q[v] < nvec;
         if (!ok[v]) q[v] = 0;
         unpack<VEC>(reinterpret_cast<const FV *>(a.area)[q[v]], ar[v]);
@@ -117,9 +117,9 @@ __global__ void __launch_bounds__(kThreads) heatc_level_kernel(HeatcArgs a) {
         const int64_t base = (int64_t)k * nvec;        // vector offset of level k in a 3-D field
         const float e3k = FULL ? a.e31d[k] : 0.f;
         const float dw  = a.mxlopt ? a.gdepw[k] : 0.f;
-        float e3[kVPT][VEC], tt[kVPT][VEC], mk[kVPT][VEC];
+        float e3[VPT][VEC], tt[VPT][VEC], mk[VPT][VEC];
 #pragma unroll
-        for (int v = 0; v < kVPT; ++v) {
+        for (int v = 0; v < VPT; ++v) {
             unpack<VEC>(ld_stream(reinterpret_cast<const FV *>(a.temp) + base + q[v]), tt[v]);
             if (FULL) {
 #pragma unroll
@@ -132,7 +132,7 @@ __global__ void __launch_bounds__(kThreads) heatc_level_kernel(HeatcArgs a) {
         }
         double s_surf = 0.0, s_vol = 0.0, s_sum = 0.0;
 #pragma unroll
-        for (int v = 0; v < kVPT; ++v)
+        for (int v = 0; v < VPT; ++v)
 #pragma unroll
             for (int c = 0; c < VEC; ++c) {
                 float e = e3[v][c];
@@ -168,18 +168,18 @@ __global__ void __launch_bounds__(kThreads) heatc_level_kernel(HeatcArgs a) {
 // previous vector's and count as zeros -- every load is a full vector inside the level, without a branch.
 typedef unsigned char u4u __attribute__((ext_vector_type(4), aligned(1)));
 
-template <bool MASK8, bool FULL>
+template <bool MASK8, bool FULL, int VPT>
 __global__ void __launch_bounds__(kThreads) heatc_level_u4_kernel(HeatcArgs a) {
     extern __shared__ double wsum[];                   // [nwaves][npk][3]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = kThreads / 64;
     const int64_t nfull = a.nij >> 2;                  // vectors 0..nfull-1 start at 4v
     const int64_t blk = xcd_band(a.band);
-    int64_t e0[kVPT];
-    bool own[kVPT][4];
-    float ar[kVPT][4], mx[kVPT][4];
+    int64_t e0[VPT];
+    bool own[VPT][4];
+    float ar[VPT][4], mx[VPT][4];
 #pragma unroll
-    for (int v = 0; v < kVPT; ++v) {
-        const int64_t q = ((blk * nwaves + wave) * kVPT + v) * 64 + lane;
+    for (int v = 0; v < VPT; ++v) {
+        const int64_t q = ((blk * nwaves + wave) * VPT + v) * 64 + lane;
         e0[v] = min(4 * q, a.nij - 4);
         const f4u av = *reinterpret_cast<const f4u *>(a.area + e0[v]);
         const float a4[4] = {av.x, av.y, av.z, av.w};
@@ -196,9 +196,9 @@ __global__ void __launch_bounds__(kThreads) heatc_level_u4_kernel(HeatcArgs a) {
         const int64_t base = (int64_t)k * a.nij;
         const float e3k = FULL ? a.e31d[k] : 0.f;
         const float dw  = a.mxlopt ? a.gdepw[k] : 0.f;
-        float e3[kVPT][4], tt[kVPT][4], mk[kVPT][4];
+        float e3[VPT][4], tt[VPT][4], mk[VPT][4];
 #pragma unroll
-        for (int v = 0; v < kVPT; ++v) {
+        for (int v = 0; v < VPT; ++v) {
             const f4u t4 = ld_stream4u(a.temp + base + e0[v]);
             tt[v][0] = t4.x; tt[v][1] = t4.y; tt[v][2] = t4.z; tt[v][3] = t4.w;
             if (FULL) {
@@ -218,7 +218,7 @@ __global__ void __launch_bounds__(kThreads) heatc_level_u4_kernel(HeatcArgs a) {
         }
         double s_surf = 0.0, s_vol = 0.0, s_sum = 0.0;
 #pragma unroll
-        for (int v = 0; v < kVPT; ++v)
+        for (int v = 0; v < VPT; ++v)
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 float e = e3[v][c];
@@ -248,17 +248,19 @@ __global__ void __launch_bounds__(kThreads) heatc_level_u4_kernel(HeatcArgs a) {
     }
 }
 
-int launch_u4(const HeatcArgs &a, hipStream_t st) {
+template <int VPT>
+int launch_u4_vpt(const HeatcArgs &a, hipStream_t st) {
     dim3 grid(xcd_band_grid(a.nblk, a.band)), block(kThreads);
     const size_t shmem = (size_t)(kThreads / 64) * a.npk * 3 * sizeof(double);
     const bool m8 = a.mask8 != nullptr, full = a.e31d != nullptr;
-    if (m8 && full)        hipLaunchKernelGGL((heatc_level_u4_kernel<true, true>), grid, block, shmem, st, a);
-    else if (m8 && !full)  hipLaunchKernelGGL((heatc_level_u4_kernel<true, false>), grid, block, shmem, st, a);
-    else if (!m8 && full)  hipLaunchKernelGGL((heatc_level_u4_kernel<false, true>), grid, block, shmem, st, a);
-    else                   hipLaunchKernelGGL((heatc_level_u4_kernel<false, false>), grid, block, shmem, st, a);
+    if (m8 && full)        hipLaunchKernelGGL((heatc_level_u4_kernel<true, true, VPT>), grid, block, shmem, st, a);
+    else if (m8 && !full)  hipLaunchKernelGGL((heatc_level_u4_kernel<true, false, VPT>), grid, block, shmem, st, a);
+    else if (!m8 && full)  hipLaunchKernelGGL((heatc_level_u4_kernel<false, true, VPT>), grid, block, shmem, st, a);
+    else                   hipLaunchKernelGGL((heatc_level_u4_kernel<false, false, VPT>), grid, block, shmem, st, a);
     CDFT_LAUNCH_CHECK();
     return CDFT_OK;
 }
+int launch_u4(const HeatcArgs &a, hipStream_t st) { return a.vpt == 8 ? launch_u4_vpt<8>(a, st) : launch_u4_vpt<kVPT>(a, st); }
 
 // ---------------------------------------------------------------------------------------------------------------
 // The reference's own order.  src/cdfheatc.f90:225-229 forms  SUM(e1t*e2t*tmask), SUM(e1t*e2t*e3t*tmask),
@@ -979,18 +981,20 @@ __global__ void __launch_bounds__(kThreads) heatc_final_kernel(const double *__r
     }
 }
 
-template <int VEC>
-int launch_vec(const HeatcArgs &a, hipStream_t st) {
+template <int VEC, int VPT>
+int launch_vec_vpt(const HeatcArgs &a, hipStream_t st) {
     dim3 grid(xcd_band_grid(a.nblk, a.band)), block(kThreads);
     const size_t shmem = (size_t)(kThreads / 64) * a.npk * 3 * sizeof(double);
     const bool m8 = a.mask8 != nullptr, full = a.e31d != nullptr;
-    if (m8 && full)        hipLaunchKernelGGL((heatc_level_kernel<VEC, true, true>), grid, block, shmem, st, a);
-    else if (m8 && !full)  hipLaunchKernelGGL((heatc_level_kernel<VEC, true, false>), grid, block, shmem, st, a);
-    else if (!m8 && full)  hipLaunchKernelGGL((heatc_level_kernel<VEC, false, true>), grid, block, shmem, st, a);
-    else                   hipLaunchKernelGGL((heatc_level_kernel<VEC, false, false>), grid, block, shmem, st, a);
+    if (m8 && full)        hipLaunchKernelGGL((heatc_level_kernel<VEC, true, true, VPT>), grid, block, shmem, st, a);
+    else if (m8 && !full)  hipLaunchKernelGGL((heatc_level_kernel<VEC, true, false, VPT>), grid, block, shmem, st, a);
+    else if (!m8 && full)  hipLaunchKernelGGL((heatc_level_kernel<VEC, false, true, VPT>), grid, block, shmem, st, a);
+    else                   hipLaunchKernelGGL((heatc_level_kernel<VEC, false, false, VPT>), grid, block, shmem, st, a);
     CDFT_LAUNCH_CHECK();
     return CDFT_OK;
 }
+template <int VEC>
+int launch_vec(const HeatcArgs &a, hipStream_t st) { return (a.vpt == 8 && VEC == 4) ? launch_vec_vpt<4, 8>(a, st) : launch_vec_vpt<VEC, kVPT>(a, st); }
 
 
 bool aligned_to(const void *p, size_t n) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) % n) == 0; }
@@ -1115,8 +1119,13 @@ int cdft_heatc_compute(cdft_heatc_plan *p, const float *temp, int temp_space, co
     if (nij % 4 == 0 && aligned_to(dt, 16) && aligned_to(dm, 16)) vec = 4;
     else if (nij >= 4 && !getenv("CDFT_HEATC_NOU4")) vec = -4;           // 16-byte loads at r4 alignment (A/B hook: the old paths)
     else if (nij % 2 == 0 && aligned_to(dt, 8) && aligned_to(dm, 8)) vec = 2;
-    a.nblk = vec == -4 ? (int)(((nij + 3) / 4 + 1 + kThreads * 4 - 1) / (kThreads * 4))
-                       : (int)((nij / vec + kThreads * 4 - 1) / (kThreads * 4));   // kVPT = 4 vectors per lane
+    // vectors per lane: 8 where that leaves four workgroups per CU (1.68 -> 1.65 ms at eORCA12; at eORCA025 there would be 212
+    // workgroups for 256 CUs), else 4; CDFT_HEATC_VPT = 4 | 8: A/B hook
+    auto blocks_with = [&](int v) { return vec == -4 ? (int)(((nij + 3) / 4 + 1 + kThreads * v - 1) / (kThreads * v))
+                                                     : (int)((nij / vec + kThreads * v - 1) / (kThreads * v)); };
+    a.vpt = ((vec == 4 || vec == -4) && blocks_with(8) >= 1024) ? 8 : kVPT;
+    if (const char *e = getenv("CDFT_HEATC_VPT")) { const int v = atoi(e); if ((v == 8 && (vec == 4 || vec == -4)) || v == 4) a.vpt = v; }
+    a.nblk = blocks_with(a.vpt);
     if (!r4seq) {                                         // the r8 sums per block
         if (vec == -4)     CDFT_TRY(launch_u4(a, st));
         else if (vec == 4) CDFT_TRY(launch_vec<4>(a, st));
