@@ -101,7 +101,7 @@ __global__ void mocsig_row_kernel(SigArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Class kernel (0/1 basin masks with at most kSC bit patterns, no -isodep / -eiv / -full; rows of 4..5116 cells).
+// Class kernel (0/1 basin masks with at most kSC bit patterns, no -isodep / -full; -eiv as a fifth stream; rows of 4..5116 cells).
 // The loop above spends a scalar load per operand and cell, re-reads e1v and the basin masks at every level and
 // issues one LDS atomic per cell AND basin.  Here a thread owns NV 16-byte vectors of the row for all levels: e1v
 // and the class of each cell's basin bit pattern (see cdfmoc's class kernel, moc_zonal.hpp) stay in registers,
@@ -151,19 +151,21 @@ __global__ void __launch_bounds__(T) mocsig_class_kernel(SigArgs a, SigClassArgs
         // one vector (v, T, S, e3v: four 16-byte loads) is in flight while the previous one goes through the equation of
         // state: 32 registers of loads instead of 16*NV, which keeps the kernel at three waves per SIMD (it is bound by the
         // r8 issue rate and the latency of its Horner chains, not by HBM: more waves, not more bytes in flight)
-        f4u cv, ct, cs, ce;
+        f4u cv, ct, cs, ce, cei = {0.f, 0.f, 0.f, 0.f};         // (cei: the eddy-induced velocity of -eiv, a.zeiv != NULL: uniform)
         {
             const int64_t e = r2 + i0[0];
             cv = ld_stream4u(a.zv + e); ct = ld_stream4u(a.zt + e); cs = ld_stream4u(a.zs + e); ce = ld_stream4u(a.e3v + e);
+            if (a.zeiv) cei = ld_stream4u(a.zeiv + e);
         }
         for (int k = 0; k < a.npk - 1; ++k) {
             const int64_t e = (int64_t)k * nij + r2;
 #pragma unroll
             for (int r = 0; r < NV; ++r) {
-                f4u nv_ = cv, nt_ = ct, ns_ = cs, ne_ = ce;
+                f4u nv_ = cv, nt_ = ct, ns_ = cs, ne_ = ce, nei_ = cei;
                 if (r + 1 < NV || k + 1 < a.npk - 1) {
                     const int64_t en = (r + 1 < NV ? e : e + nij) + i0[r + 1 < NV ? r + 1 : 0];
                     nv_ = ld_stream4u(a.zv + en); nt_ = ld_stream4u(a.zt + en); ns_ = ld_stream4u(a.zs + en); ne_ = ld_stream4u(a.e3v + en);
+                    if (a.zeiv) nei_ = ld_stream4u(a.zeiv + en);
                 }
                 const float v4[4] = {cv.x, cv.y, cv.z, cv.w}, t4[4] = {ct.x, ct.y, ct.z, ct.w};
                 const float s4[4] = {cs.x, cs.y, cs.z, cs.w}, e4[4] = {ce.x, ce.y, ce.z, ce.w};
@@ -175,6 +177,7 @@ __global__ void __launch_bounds__(T) mocsig_class_kernel(SigArgs a, SigClassArgs
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     vz[c] = (v4[c] == a.zspv) ? 0.f : v4[c];                                   // :374
+                    if (a.zeiv) vz[c] = __fadd_rn(vz[c], c == 0 ? cei.x : c == 1 ? cei.y : c == 2 ? cei.z : cei.w);   // :375-378
                     val[c] = -(double)__fmul_rn(vz[c], __fmul_rn(e1[r][c], e4[c]));            // :389, :417
                     live |= (hoff[r][c] >= 0) && (val[c] != 0.0);                              // (NaN != 0: kept)
                 }
@@ -182,7 +185,7 @@ __global__ void __launch_bounds__(T) mocsig_class_kernel(SigArgs a, SigClassArgs
                 // (below), so its density class is never looked at: a wave whose 256 cells all have such a term skips the
                 // equation of state altogether -- ~115 r8 operations per cell.  Uniform over the wave (a ballot); a NaN
                 // term is not zero and takes the full path.  CDFT_MOCSIG_NOLAND=1: A/B and test hook.
-                if (!a.no_land_shortcut && !__any(live)) { cv = nv_; ct = nt_; cs = ns_; ce = ne_; continue; }
+                if (!a.no_land_shortcut && !__any(live)) { cv = nv_; ct = nt_; cs = ns_; ce = ne_; cei = nei_; continue; }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     float t = t4[c], s = s4[c];
@@ -206,7 +209,7 @@ __global__ void __launch_bounds__(T) mocsig_class_kernel(SigArgs a, SigClassArgs
                 for (int c = 0; c < 4; ++c)
                     if (key[c] >= 0)
                         (void)__hip_atomic_fetch_add(&h[key[c]], val[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // :435
-                cv = nv_; ct = nt_; cs = ns_; ce = ne_;
+                cv = nv_; ct = nt_; cs = ns_; ce = ne_; cei = nei_;
             }
         }
     }
@@ -335,7 +338,7 @@ int cdft_mocsig_compute(const float *zv, const float *zveiv, const float *zt, co
     // class kernel when it applies (see above); CDFT_MOCSIG_NOCLASS=1 keeps the general kernel (A/B and test hook)
     bool done = false;
     const int nvec = npiglo / 4 + 1, nv = (nvec + kSigT - 1) / kSigT;
-    if (!depi && !zveiv && e3v && npiglo >= 4 && nv <= 5 && !getenv("CDFT_MOCSIG_NOCLASS")) {
+    if (!depi && e3v && npiglo >= 4 && nv <= 5 && !getenv("CDFT_MOCSIG_NOCLASS")) {
         static DevBuf sbits, sseen;
         CDFT_TRY(sbits.reserve(nij + 64 + 256));
         CDFT_TRY(sseen.reserve(257 * sizeof(int)));

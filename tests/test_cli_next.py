@@ -729,6 +729,16 @@ def test_hip_mocsig_kernels(gpu, monkeypatch, npi, npj, npk, nb, smooth, kernel)
         dev = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (v, zt, zs, e1v, ib, e3v)]
         res = gpu.mocsig(dev[0], dev[1], dev[2], dev[3], dev[4], nbins, sigmin, sigstp, pref=2000.0, e3v=dev[5])
         assert np.array_equal(res.cpu().numpy(), got, equal_nan=True)       # same kernel, same order: identical
+    # -eiv: the eddy-induced velocity added in r4 after the missing-value select (a fifth stream of the class kernel);
+    # a missing value in v still takes the eiv term (cdfmocsig.f90:374-378)
+    eiv = (zv[::-1] * np.float32(0.3)).astype(np.float32)
+    v = zv.copy()
+    v[0, 1, 1:3] = np.float32(-9999.0)
+    ref = oracle_lib.mocsig(v, zt, zs, e1v, ib, nbins, sigmin, sigstp, pref=2000.0, e3v=e3v, zveiv=eiv, spv=(-9999.0, 0.0, 0.0))
+    bound = np.abs(oracle_lib.mocsig(np.abs(v) + np.abs(eiv), zt, zs, e1v, ib, nbins, sigmin, sigstp, pref=2000.0, e3v=e3v))
+    got = gpu.mocsig(v, zt, zs, e1v, ib, nbins, sigmin, sigstp, pref=2000.0, e3v=e3v, zveiv=eiv, spv=(-9999.0, 0.0, 0.0))
+    assert np.all(np.abs(got - ref) <= 1e-13 * bound.max(axis=1, keepdims=True) + 1e-300), float(np.abs(got - ref).max())
+    assert npi == 5 or not np.array_equal(got, gpu.mocsig(v, zt, zs, e1v, ib, nbins, sigmin, sigstp, pref=2000.0, e3v=e3v, spv=(-9999.0, 0.0, 0.0)))
     # -ntr: the neutral density in the same classes
     ref = oracle_lib.mocsig(zv, zt, zs, e1v, ib, 80, 18.0, 0.2, e3v=e3v, ntr=True)
     bound = np.abs(oracle_lib.mocsig(np.abs(zv), zt, zs, e1v, ib, 80, 18.0, 0.2, e3v=e3v, ntr=True))
