@@ -101,7 +101,7 @@ __global__ void mocsig_row_kernel(SigArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Class kernel (0/1 basin masks with at most kSC bit patterns, no -isodep / -full; -eiv as a fifth stream; rows of 4..5116 cells).
+// Class kernel (0/1 basin masks with at most kSC bit patterns, no -isodep; -eiv as a fifth stream, -full's e3t_1d in place of e3v; rows of 4..5116 cells).
 // The loop above spends a scalar load per operand and cell, re-reads e1v and the basin masks at every level and
 // issues one LDS atomic per cell AND basin.  Here a thread owns NV 16-byte vectors of the row for all levels: e1v
 // and the class of each cell's basin bit pattern (see cdfmoc's class kernel, moc_zonal.hpp) stay in registers,
@@ -154,7 +154,9 @@ __global__ void __launch_bounds__(T) mocsig_class_kernel(SigArgs a, SigClassArgs
         f4u cv, ct, cs, ce, cei = {0.f, 0.f, 0.f, 0.f};         // (cei: the eddy-induced velocity of -eiv, a.zeiv != NULL: uniform)
         {
             const int64_t e = r2 + i0[0];
-            cv = ld_stream4u(a.zv + e); ct = ld_stream4u(a.zt + e); cs = ld_stream4u(a.zs + e); ce = ld_stream4u(a.e3v + e);
+            cv = ld_stream4u(a.zv + e); ct = ld_stream4u(a.zt + e); cs = ld_stream4u(a.zs + e);
+            if (a.e3v) ce = ld_stream4u(a.e3v + e);
+            else { const float z = a.e31d[0]; ce = f4u{z, z, z, z}; }          // -full: the level's thickness (:389), uniform
             if (a.zeiv) cei = ld_stream4u(a.zeiv + e);
         }
         for (int k = 0; k < a.npk - 1; ++k) {
@@ -164,7 +166,9 @@ __global__ void __launch_bounds__(T) mocsig_class_kernel(SigArgs a, SigClassArgs
                 f4u nv_ = cv, nt_ = ct, ns_ = cs, ne_ = ce, nei_ = cei;
                 if (r + 1 < NV || k + 1 < a.npk - 1) {
                     const int64_t en = (r + 1 < NV ? e : e + nij) + i0[r + 1 < NV ? r + 1 : 0];
-                    nv_ = ld_stream4u(a.zv + en); nt_ = ld_stream4u(a.zt + en); ns_ = ld_stream4u(a.zs + en); ne_ = ld_stream4u(a.e3v + en);
+                    nv_ = ld_stream4u(a.zv + en); nt_ = ld_stream4u(a.zt + en); ns_ = ld_stream4u(a.zs + en);
+                    if (a.e3v) ne_ = ld_stream4u(a.e3v + en);
+                    else if (r + 1 == NV) { const float z = a.e31d[k + 1]; ne_ = f4u{z, z, z, z}; }
                     if (a.zeiv) nei_ = ld_stream4u(a.zeiv + en);
                 }
                 const float v4[4] = {cv.x, cv.y, cv.z, cv.w}, t4[4] = {ct.x, ct.y, ct.z, ct.w};
@@ -338,7 +342,7 @@ int cdft_mocsig_compute(const float *zv, const float *zveiv, const float *zt, co
     // class kernel when it applies (see above); CDFT_MOCSIG_NOCLASS=1 keeps the general kernel (A/B and test hook)
     bool done = false;
     const int nvec = npiglo / 4 + 1, nv = (nvec + kSigT - 1) / kSigT;
-    if (!depi && e3v && npiglo >= 4 && nv <= 5 && !getenv("CDFT_MOCSIG_NOCLASS")) {
+    if (!depi && npiglo >= 4 && nv <= 5 && !getenv("CDFT_MOCSIG_NOCLASS")) {
         static DevBuf sbits, sseen;
         CDFT_TRY(sbits.reserve(nij + 64 + 256));
         CDFT_TRY(sseen.reserve(257 * sizeof(int)));

@@ -739,6 +739,11 @@ def test_hip_mocsig_kernels(gpu, monkeypatch, npi, npj, npk, nb, smooth, kernel)
     got = gpu.mocsig(v, zt, zs, e1v, ib, nbins, sigmin, sigstp, pref=2000.0, e3v=e3v, zveiv=eiv, spv=(-9999.0, 0.0, 0.0))
     assert np.all(np.abs(got - ref) <= 1e-13 * bound.max(axis=1, keepdims=True) + 1e-300), float(np.abs(got - ref).max())
     assert npi == 5 or not np.array_equal(got, gpu.mocsig(v, zt, zs, e1v, ib, nbins, sigmin, sigstp, pref=2000.0, e3v=e3v, spv=(-9999.0, 0.0, 0.0)))
+    # -full with -eiv: the level's e3t_1d in place of e3v (cdfmocsig.f90:389)
+    ref = oracle_lib.mocsig(v, zt, zs, e1v, ib, nbins, sigmin, sigstp, pref=2000.0, e31d=g["e3t_1d"], zveiv=eiv, spv=(-9999.0, 0.0, 0.0))
+    bound = np.abs(oracle_lib.mocsig(np.abs(v) + np.abs(eiv), zt, zs, e1v, ib, nbins, sigmin, sigstp, pref=2000.0, e31d=g["e3t_1d"]))
+    got = gpu.mocsig(v, zt, zs, e1v, ib, nbins, sigmin, sigstp, pref=2000.0, e31d=g["e3t_1d"], zveiv=eiv, spv=(-9999.0, 0.0, 0.0))
+    assert np.all(np.abs(got - ref) <= 1e-13 * bound.max(axis=1, keepdims=True) + 1e-300), float(np.abs(got - ref).max())
     # -ntr: the neutral density in the same classes
     ref = oracle_lib.mocsig(zv, zt, zs, e1v, ib, 80, 18.0, 0.2, e3v=e3v, ntr=True)
     bound = np.abs(oracle_lib.mocsig(np.abs(zv), zt, zs, e1v, ib, 80, 18.0, 0.2, e3v=e3v, ntr=True))
