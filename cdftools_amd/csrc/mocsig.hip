@@ -101,7 +101,7 @@ __global__ void mocsig_row_kernel(SigArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Class kernel (0/1 basin masks with at most kSC bit patterns, no -isodep; -eiv as a fifth stream, -full's e3t_1d in place of e3v; rows of 4..5116 cells).
+// Class kernel (0/1 basin masks with at most kSC bit patterns, -eiv as a fifth stream, -full's e3t_1d in place of e3v, -isodep as two more histograms; rows of 4..5116 cells).
 // The loop above spends a scalar load per operand and cell, re-reads e1v and the basin masks at every level and
 // issues one LDS atomic per cell AND basin.  Here a thread owns NV 16-byte vectors of the row for all levels: e1v
 // and the class of each cell's basin bit pattern (see cdfmoc's class kernel, moc_zonal.hpp) stay in registers,
@@ -119,13 +119,16 @@ struct SigClassArgs {
     int nclass;
 };
 
-template <int NV, int TEOS, int T, int DEPTH>
+template <int NV, int TEOS, int T, int DEPTH, bool ISODEP>
 __global__ void __launch_bounds__(T) mocsig_class_kernel(SigArgs a, SigClassArgs ca) {
-    extern __shared__ double hist[];                    // [nwaves][nclass][nbins], then raw [nb][nbins]
-    constexpr int nwaves = T / 64;
+    // [nwaves][nq][nclass][nbins]; the basin sums raw [nq][nb][nbins] are formed in the place of wave 1's histogram (after
+    // the waves have been added into wave 0's), see sig_class_shmem().  nq = 3 with -isodep: the transport, depth * weight
+    // and weight sums of :435, :444-445.
+    extern __shared__ double hist[];
+    constexpr int nwaves = T / 64, nq = ISODEP ? 3 : 1;
     const int jj = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int hsz = ca.nclass * a.nbins;
-    double *h = hist + (int64_t)wave * hsz, *raw = hist + (int64_t)nwaves * hsz;
+    const int hq = ca.nclass * a.nbins, hsz = nq * hq;
+    double *h = hist + (int64_t)wave * hsz, *raw = hist + hsz;
     for (int t = lane; t < hsz; t += 64) h[t] = 0.0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -174,16 +177,25 @@ __global__ void __launch_bounds__(T) mocsig_class_kernel(SigArgs a, SigClassArgs
                 const float v4[4] = {cv.x, cv.y, cv.z, cv.w}, t4[4] = {ct.x, ct.y, ct.z, ct.w};
                 const float s4[4] = {cs.x, cs.y, cs.z, cs.w}, e4[4] = {ce.x, ce.y, ce.z, ce.w};
                 int key[4];
-                double val[4];
+                double val[4], vdd[4], vdw[4];                  // (vdd, vdw: -isodep only)
                 float vz[4];
+                const float gd = ISODEP ? a.gdep[k] : 0.f;
                 // The term of every cell first (:374, :389, :417): -(v * (e1v * e3v)) in r4, widened.
                 bool live = false;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     vz[c] = (v4[c] == a.zspv) ? 0.f : v4[c];                                   // :374
                     if (a.zeiv) vz[c] = __fadd_rn(vz[c], c == 0 ? cei.x : c == 1 ? cei.y : c == 2 ? cei.z : cei.w);   // :375-378
-                    val[c] = -(double)__fmul_rn(vz[c], __fmul_rn(e1[r][c], e4[c]));            // :389, :417
-                    live |= (hoff[r][c] >= 0) && (val[c] != 0.0);                              // (NaN != 0: kept)
+                    const float zarea = __fmul_rn(e1[r][c], e4[c]);                            // :389
+                    val[c] = -(double)__fmul_rn(vz[c], zarea);                                 // :417
+                    if (ISODEP) {                                                              // :392-393 with :382-383, :424-425
+                        const float fitm = ((s4[c] == a.zsps ? 0.f : s4[c]) == a.zsps) ? 0.f : 1.f;
+                        vdd[c] = (double)__fmul_rn(__fmul_rn(gd, fitm), zarea);
+                        vdw[c] = (double)__fmul_rn(fitm, zarea);
+                        live |= (hoff[r][c] >= 0) && (val[c] != 0.0 || vdd[c] != 0.0 || vdw[c] != 0.0);
+                    } else {
+                        live |= (hoff[r][c] >= 0) && (val[c] != 0.0);                          // (NaN != 0: kept)
+                    }
                 }
                 // Land.  A term that is exactly zero (v = 0 or e3v = 0: land, and it comes in large pieces) is never added
                 // (below), so its density class is never looked at: a wave whose 256 cells all have such a term skips the
@@ -204,15 +216,26 @@ __global__ void __launch_bounds__(T) mocsig_class_kernel(SigArgs a, SigClassArgs
                     const float zq = (float)__dmul_rn((double)__fsub_rn(zttmp, a.sigmin), a.rsigstp);
                     int ibin = (int)zq;
                     ibin = min(max(ibin, 1), a.nbins) - 1;                                     // :401-402
-                    key[c] = (hoff[r][c] >= 0 && val[c] != 0.0) ? hoff[r][c] + ibin : -1;
+                    const bool some = ISODEP ? (val[c] != 0.0 || vdd[c] != 0.0 || vdw[c] != 0.0) : (val[c] != 0.0);
+                    key[c] = (hoff[r][c] >= 0 && some) ? hoff[r][c] + ibin : -1;
                 }
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
-                    if (key[c] >= 0 && key[c] == key[c + 1]) { val[c + 1] = __dadd_rn(val[c + 1], val[c]); key[c] = -1; }
+                    if (key[c] >= 0 && key[c] == key[c + 1]) {
+                        val[c + 1] = __dadd_rn(val[c + 1], val[c]);
+                        if (ISODEP) { vdd[c + 1] = __dadd_rn(vdd[c + 1], vdd[c]); vdw[c + 1] = __dadd_rn(vdw[c + 1], vdw[c]); }
+                        key[c] = -1;
+                    }
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
-                    if (key[c] >= 0)
-                        (void)__hip_atomic_fetch_add(&h[key[c]], val[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // :435
+                    if (key[c] >= 0) {                  // (an exact zero is not added: it could not change a sum that starts at +0)
+                        if (!ISODEP || val[c] != 0.0)
+                            (void)__hip_atomic_fetch_add(&h[key[c]], val[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // :435
+                        if (ISODEP && vdd[c] != 0.0)
+                            (void)__hip_atomic_fetch_add(&h[hq + key[c]], vdd[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // :444
+                        if (ISODEP && vdw[c] != 0.0)
+                            (void)__hip_atomic_fetch_add(&h[2 * hq + key[c]], vdw[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // :445
+                    }
                 cv = nv_; ct = nt_; cs = ns_; ce = ne_; cei = nei_;
             }
         }
@@ -224,11 +247,12 @@ __global__ void __launch_bounds__(T) mocsig_class_kernel(SigArgs a, SigClassArgs
         hist[t] = s;                                            // wave 0's slot t is only read by this thread
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < a.nb * a.nbins; t += T) {    // class sums -> basin sums
-        const int b = t / a.nbins, n = t - b * a.nbins;
+    const int rq = a.nb * a.nbins;
+    for (int t = threadIdx.x; t < nq * rq; t += T) {           // class sums -> basin sums
+        const int q = t / rq, u = t - q * rq, b = u / a.nbins, n = u - b * a.nbins;
         double s = 0.0, z = 0.0;
         for (int c = 0; c < ca.nclass; ++c) {
-            const double v = hist[c * a.nbins + n];
+            const double v = hist[q * hq + c * a.nbins + n];
             if ((ca.pat[c] >> b) & 1) s += v;
             else                      z += v;
         }
@@ -243,6 +267,13 @@ __global__ void __launch_bounds__(T) mocsig_class_kernel(SigArgs a, SigClassArgs
         for (int n = a.nbins - 2; n >= 0; --n) {
             acc = __dadd_rn(acc, __ddiv_rn(hm[n], (double)1.e6f));
             a.dmoc[((int64_t)jj * a.nbins + n) * a.nb + b] = acc;
+        }
+    }
+    if (ISODEP) {                                               // :454-460
+        for (int t = threadIdx.x; t < rq; t += T) {
+            const int b = t / a.nbins, n = t - b * a.nbins;
+            const double d = raw[rq + t], w = raw[2 * rq + t];
+            a.depi[((int64_t)jj * a.nbins + n) * a.nb + b] = (w != 0.0) ? __ddiv_rn(d, w) : 99999.0;
         }
     }
 }
@@ -269,14 +300,25 @@ __global__ void sig_cls_kernel(uint8_t *__restrict__ bits, int64_t nij, const ui
 
 constexpr int kSigT = 256;
 
-template <int NV, int KIND, int DEPTH>
-int launch_sig_class_depth(const SigArgs &a, const SigClassArgs &ca, size_t shmem, hipStream_t st) {
+// LDS of the class kernel: the waves' histograms, or wave 0's + the basin sums formed in the place of wave 1's
+size_t sig_class_shmem(int nq, int nclass, int nb, int nbins) {
+    const size_t hsz = (size_t)nq * nclass * nbins * 8, rawsz = (size_t)nq * nb * nbins * 8;
+    return std::max((size_t)(kSigT / 64) * hsz, hsz + rawsz);
+}
+
+template <int NV, int KIND, int DEPTH, bool ISODEP>
+int launch_sig_class_iso(const SigArgs &a, const SigClassArgs &ca, size_t shmem, hipStream_t st) {
     if (shmem > 64 * 1024)
-        CDFT_HIP(hipFuncSetAttribute((const void *)mocsig_class_kernel<NV, KIND, kSigT, DEPTH>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)shmem));
-    hipLaunchKernelGGL((mocsig_class_kernel<NV, KIND, kSigT, DEPTH>), dim3(a.npj), dim3(kSigT), shmem, st, a, ca);
+        CDFT_HIP(hipFuncSetAttribute((const void *)mocsig_class_kernel<NV, KIND, kSigT, DEPTH, ISODEP>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    hipLaunchKernelGGL((mocsig_class_kernel<NV, KIND, kSigT, DEPTH, ISODEP>), dim3(a.npj), dim3(kSigT), shmem, st, a, ca);
     CDFT_LAUNCH_CHECK();
     return CDFT_OK;
+}
+
+template <int NV, int KIND, int DEPTH>
+int launch_sig_class_depth(const SigArgs &a, const SigClassArgs &ca, size_t shmem, hipStream_t st) {
+    return a.depi ? launch_sig_class_iso<NV, KIND, DEPTH, true>(a, ca, shmem, st) : launch_sig_class_iso<NV, KIND, DEPTH, false>(a, ca, shmem, st);
 }
 
 template <int NV, int KIND>
@@ -342,7 +384,7 @@ int cdft_mocsig_compute(const float *zv, const float *zveiv, const float *zt, co
     // class kernel when it applies (see above); CDFT_MOCSIG_NOCLASS=1 keeps the general kernel (A/B and test hook)
     bool done = false;
     const int nvec = npiglo / 4 + 1, nv = (nvec + kSigT - 1) / kSigT;
-    if (!depi && npiglo >= 4 && nv <= 5 && !getenv("CDFT_MOCSIG_NOCLASS")) {
+    if (npiglo >= 4 && nv <= 5 && !getenv("CDFT_MOCSIG_NOCLASS")) {
         static DevBuf sbits, sseen;
         CDFT_TRY(sbits.reserve(nij + 64 + 256));
         CDFT_TRY(sseen.reserve(257 * sizeof(int)));
@@ -365,7 +407,7 @@ int cdft_mocsig_compute(const float *zv, const float *zveiv, const float *zt, co
                 ++ca.nclass;
             }
         }
-        const size_t shmem = ((size_t)(kSigT / 64) * ca.nclass + nbasins) * nbins * 8;
+        const size_t shmem = sig_class_shmem(depi ? 3 : 1, std::min(ca.nclass, kSC), nbasins, nbins);
         if (!hseen[0] && ca.nclass <= kSC && shmem <= 150 * 1024) {
             uint8_t *dlut = bits + nij + 64;
             CDFT_HIP(hipMemcpyAsync(dlut, lut, 256, hipMemcpyHostToDevice, st));

@@ -744,6 +744,20 @@ def test_hip_mocsig_kernels(gpu, monkeypatch, npi, npj, npk, nb, smooth, kernel)
     bound = np.abs(oracle_lib.mocsig(np.abs(v) + np.abs(eiv), zt, zs, e1v, ib, nbins, sigmin, sigstp, pref=2000.0, e31d=g["e3t_1d"]))
     got = gpu.mocsig(v, zt, zs, e1v, ib, nbins, sigmin, sigstp, pref=2000.0, e31d=g["e3t_1d"], zveiv=eiv, spv=(-9999.0, 0.0, 0.0))
     assert np.all(np.abs(got - ref) <= 1e-13 * bound.max(axis=1, keepdims=True) + 1e-300), float(np.abs(got - ref).max())
+    # -isodep: depth * weight and weight sums in two more histograms of the class kernel; a cell with v = 0 still counts
+    gdep = -g["gdept_1d"]
+    v[0, 2, 1:] = 0
+    ref, rdep = oracle_lib.mocsig(v, zt, zs, e1v, ib, nbins, sigmin, sigstp, pref=2000.0, e3v=e3v, zveiv=eiv, spv=(-9999.0, 0.0, 0.0),
+                                  gdep=gdep, isodep=True)
+    bound = np.abs(oracle_lib.mocsig(np.abs(v) + np.abs(eiv), zt, zs, e1v, ib, nbins, sigmin, sigstp, pref=2000.0, e3v=e3v))
+    got, gdp = gpu.mocsig(v, zt, zs, e1v, ib, nbins, sigmin, sigstp, pref=2000.0, e3v=e3v, zveiv=eiv, spv=(-9999.0, 0.0, 0.0),
+                          gdep=gdep, isodep=True)
+    assert np.all(np.abs(got - ref) <= 1e-13 * bound.max(axis=1, keepdims=True) + 1e-300), float(np.abs(got - ref).max())
+    assert np.array_equal(gdp == 99999.0, rdep == 99999.0) and np.allclose(gdp, rdep, rtol=1e-12, atol=0)
+    assert npi == 5 or (rdep != 99999.0).any()
+    got2, gdp2 = gpu.mocsig(v, zt, zs, e1v, ib, nbins, sigmin, sigstp, pref=2000.0, e3v=e3v, zveiv=eiv, spv=(-9999.0, 0.0, 0.0),
+                            gdep=gdep, isodep=True)
+    assert np.array_equal(got, got2) and np.array_equal(gdp, gdp2)            # per-wave histograms: run-to-run identical
     # -ntr: the neutral density in the same classes
     ref = oracle_lib.mocsig(zv, zt, zs, e1v, ib, 80, 18.0, 0.2, e3v=e3v, ntr=True)
     bound = np.abs(oracle_lib.mocsig(np.abs(zv), zt, zs, e1v, ib, 80, 18.0, 0.2, e3v=e3v, ntr=True))
