@@ -119,16 +119,19 @@ struct SigClassArgs {
     int nclass;
 };
 
-template <int NV, int TEOS, int T, int DEPTH, bool ISODEP>
+// OPT: 0 = v, T, S, e3v and nothing else (the plain kernel: every option below costs it 1-6 % even as a uniform branch, measured);
+//      1 = -eiv and / or -full (uniform branches on a.zeiv, a.e3v);  2 = the same with -isodep
+template <int NV, int TEOS, int T, int DEPTH, int OPT>
 __global__ void __launch_bounds__(T) mocsig_class_kernel(SigArgs a, SigClassArgs ca) {
-    // [nwaves][nq][nclass][nbins]; the basin sums raw [nq][nb][nbins] are formed in the place of wave 1's histogram (after
-    // the waves have been added into wave 0's), see sig_class_shmem().  nq = 3 with -isodep: the transport, depth * weight
-    // and weight sums of :435, :444-445.
+    // [nwaves][nq][nclass][nbins], then the basin sums raw [nb][nbins]; with -isodep (nq = 3: the transport, depth * weight
+    // and weight sums of :435, :444-445) raw [nq][nb][nbins] is formed in the place of wave 1's histogram, after the waves
+    // have been added into wave 0's: see sig_class_shmem()
     extern __shared__ double hist[];
+    constexpr bool EXTRA = OPT >= 1, ISODEP = OPT == 2;
     constexpr int nwaves = T / 64, nq = ISODEP ? 3 : 1;
     const int jj = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int hq = ca.nclass * a.nbins, hsz = nq * hq;
-    double *h = hist + (int64_t)wave * hsz, *raw = hist + hsz;
+    double *h = hist + (int64_t)wave * hsz, *raw = hist + (ISODEP ? (int64_t)hsz : (int64_t)nwaves * hsz);
     for (int t = lane; t < hsz; t += 64) h[t] = 0.0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -158,9 +161,9 @@ __global__ void __launch_bounds__(T) mocsig_class_kernel(SigArgs a, SigClassArgs
         {
             const int64_t e = r2 + i0[0];
             cv = ld_stream4u(a.zv + e); ct = ld_stream4u(a.zt + e); cs = ld_stream4u(a.zs + e);
-            if (a.e3v) ce = ld_stream4u(a.e3v + e);
+            if (!EXTRA || a.e3v) ce = ld_stream4u(a.e3v + e);
             else { const float z = a.e31d[0]; ce = f4u{z, z, z, z}; }          // -full: the level's thickness (:389), uniform
-            if (a.zeiv) cei = ld_stream4u(a.zeiv + e);
+            if (EXTRA && a.zeiv) cei = ld_stream4u(a.zeiv + e);
         }
         for (int k = 0; k < a.npk - 1; ++k) {
             const int64_t e = (int64_t)k * nij + r2;
@@ -170,9 +173,9 @@ __global__ void __launch_bounds__(T) mocsig_class_kernel(SigArgs a, SigClassArgs
                 if (r + 1 < NV || k + 1 < a.npk - 1) {
                     const int64_t en = (r + 1 < NV ? e : e + nij) + i0[r + 1 < NV ? r + 1 : 0];
                     nv_ = ld_stream4u(a.zv + en); nt_ = ld_stream4u(a.zt + en); ns_ = ld_stream4u(a.zs + en);
-                    if (a.e3v) ne_ = ld_stream4u(a.e3v + en);
+                    if (!EXTRA || a.e3v) ne_ = ld_stream4u(a.e3v + en);
                     else if (r + 1 == NV) { const float z = a.e31d[k + 1]; ne_ = f4u{z, z, z, z}; }
-                    if (a.zeiv) nei_ = ld_stream4u(a.zeiv + en);
+                    if (EXTRA && a.zeiv) nei_ = ld_stream4u(a.zeiv + en);
                 }
                 const float v4[4] = {cv.x, cv.y, cv.z, cv.w}, t4[4] = {ct.x, ct.y, ct.z, ct.w};
                 const float s4[4] = {cs.x, cs.y, cs.z, cs.w}, e4[4] = {ce.x, ce.y, ce.z, ce.w};
@@ -185,7 +188,7 @@ __global__ void __launch_bounds__(T) mocsig_class_kernel(SigArgs a, SigClassArgs
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     vz[c] = (v4[c] == a.zspv) ? 0.f : v4[c];                                   // :374
-                    if (a.zeiv) vz[c] = __fadd_rn(vz[c], c == 0 ? cei.x : c == 1 ? cei.y : c == 2 ? cei.z : cei.w);   // :375-378
+                    if (EXTRA && a.zeiv) vz[c] = __fadd_rn(vz[c], c == 0 ? cei.x : c == 1 ? cei.y : c == 2 ? cei.z : cei.w);   // :375-378
                     const float zarea = __fmul_rn(e1[r][c], e4[c]);                            // :389
                     val[c] = -(double)__fmul_rn(vz[c], zarea);                                 // :417
                     if (ISODEP) {                                                              // :392-393 with :382-383, :424-425
@@ -216,8 +219,9 @@ __global__ void __launch_bounds__(T) mocsig_class_kernel(SigArgs a, SigClassArgs
                     const float zq = (float)__dmul_rn((double)__fsub_rn(zttmp, a.sigmin), a.rsigstp);
                     int ibin = (int)zq;
                     ibin = min(max(ibin, 1), a.nbins) - 1;                                     // :401-402
-                    const bool some = ISODEP ? (val[c] != 0.0 || vdd[c] != 0.0 || vdw[c] != 0.0) : (val[c] != 0.0);
-                    key[c] = (hoff[r][c] >= 0 && some) ? hoff[r][c] + ibin : -1;
+                    // (written as one short-circuit expression: with the test of val[c] hoisted into a variable the compiler
+                    // emits 8 % more instructions for this loop and spills more scalars -- measured, 6.9 -> 7.5 ms)
+                    key[c] = (hoff[r][c] >= 0 && (val[c] != 0.0 || (ISODEP && (vdd[c] != 0.0 || vdw[c] != 0.0)))) ? hoff[r][c] + ibin : -1;
                 }
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
@@ -303,22 +307,24 @@ constexpr int kSigT = 256;
 // LDS of the class kernel: the waves' histograms, or wave 0's + the basin sums formed in the place of wave 1's
 size_t sig_class_shmem(int nq, int nclass, int nb, int nbins) {
     const size_t hsz = (size_t)nq * nclass * nbins * 8, rawsz = (size_t)nq * nb * nbins * 8;
-    return std::max((size_t)(kSigT / 64) * hsz, hsz + rawsz);
+    return nq == 1 ? (size_t)(kSigT / 64) * hsz + rawsz : std::max((size_t)(kSigT / 64) * hsz, hsz + rawsz);
 }
 
-template <int NV, int KIND, int DEPTH, bool ISODEP>
-int launch_sig_class_iso(const SigArgs &a, const SigClassArgs &ca, size_t shmem, hipStream_t st) {
+template <int NV, int KIND, int DEPTH, int OPT>
+int launch_sig_class_opt(const SigArgs &a, const SigClassArgs &ca, size_t shmem, hipStream_t st) {
     if (shmem > 64 * 1024)
-        CDFT_HIP(hipFuncSetAttribute((const void *)mocsig_class_kernel<NV, KIND, kSigT, DEPTH, ISODEP>,
+        CDFT_HIP(hipFuncSetAttribute((const void *)mocsig_class_kernel<NV, KIND, kSigT, DEPTH, OPT>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    hipLaunchKernelGGL((mocsig_class_kernel<NV, KIND, kSigT, DEPTH, ISODEP>), dim3(a.npj), dim3(kSigT), shmem, st, a, ca);
+    hipLaunchKernelGGL((mocsig_class_kernel<NV, KIND, kSigT, DEPTH, OPT>), dim3(a.npj), dim3(kSigT), shmem, st, a, ca);
     CDFT_LAUNCH_CHECK();
     return CDFT_OK;
 }
 
 template <int NV, int KIND, int DEPTH>
 int launch_sig_class_depth(const SigArgs &a, const SigClassArgs &ca, size_t shmem, hipStream_t st) {
-    return a.depi ? launch_sig_class_iso<NV, KIND, DEPTH, true>(a, ca, shmem, st) : launch_sig_class_iso<NV, KIND, DEPTH, false>(a, ca, shmem, st);
+    if (a.depi) return launch_sig_class_opt<NV, KIND, DEPTH, 2>(a, ca, shmem, st);
+    if (a.zeiv || !a.e3v) return launch_sig_class_opt<NV, KIND, DEPTH, 1>(a, ca, shmem, st);
+    return launch_sig_class_opt<NV, KIND, DEPTH, 0>(a, ca, shmem, st);
 }
 
 template <int NV, int KIND>

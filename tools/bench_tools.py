@@ -237,7 +237,7 @@ def main():
                 ms = timed(lambda: hip.mocsig(f["zv"], f["zt"], f["zs"], f["e1"], f["ib"], 158, 30.0, 0.05, pref=2000.0, e3v=f["e3"]), args.reps)
                 report("cdfmocsig (158 classes, 5 basins, %s T,S, %s land)" % ("smooth" if smooth else "white-noise", land), args.grid, n3, 16.0, ms,
                        "v,T,S,e3v 16 B per cell; sigma2 needs all four polynomials of the EOS; a wave whose 256 cells all carry a zero transport skips it",
-                       fp64=fp64_ops("mocsig_" + land, args.grid, "mocsig_class_kernel<5, 0, 256, 2>" if npi > 2048 else "mocsig_class_kernel<2, 0, 256, 2>") if smooth else None)
+                       fp64=fp64_ops("mocsig_" + land, args.grid, "mocsig_class_kernel<5, 0, 256, 2, 0>" if npi > 2048 else "mocsig_class_kernel<2, 0, 256, 2, 0>") if smooth else None)
                 del f
 
     if "mhst" in tools:
