@@ -7,6 +7,9 @@ PROGRAM cdfmocsig
   !! zomsfglo [atl inp ind pac] [zoisoglo ...] float, Sverdrup / m, :490-586).  The level loop, the density
   !! binning, the zonal sums and the cumulation over the density classes (:368-470) run on the GPU for a whole
   !! record at once (cdft_mocsig_compute); -ntr bins the neutral density (CDFT_EOS_NTR) the same way.
+  !! Host feed (module cdffeed): when the fields are large (feed_wanted) nothing 3-D is held in host memory -- V, T, S [, the
+  !! eddy-induced velocity, e3v] go from the file to HBM slab by slab through the page-locked ring, the transfer of a slab
+  !! under the read of the next, so a record costs its read, not its read plus its transfer (CDFT_FEED=0: the old way).
   !!======================================================================
   USE ISO_C_BINDING
   USE cdfio
@@ -14,20 +17,28 @@ PROGRAM cdfmocsig
   USE modutils
   USE eos
   USE cdftools_hip
+  USE cdffeed
   IMPLICIT NONE
 
   INTEGER(KIND=4) :: ji, jt, jbasin, jbin, it, npiglo, npjglo, npk, npt, nbins, narg, ijarg, ii, ncout, nbasins, nvaro, ierr
   INTEGER(KIND=4) :: npglo = 1, npatl = 2, npinp = 3, npind = 4, nppac = 5, iloc(2)
   INTEGER(KIND=4), ALLOCATABLE :: ipk(:), id_varout(:)
-  INTEGER(KIND=2), ALLOCATABLE :: ibmask(:,:,:)
+  INTEGER(KIND=2), ALLOCATABLE, TARGET :: ibmask(:,:,:)
   REAL(KIND=4) :: pref = 0., sigmin, sigstp, zsps, zspt, zspv, rp_spval = 99999.
   REAL(KIND=4), ALLOCATABLE, TARGET :: e3v(:,:,:), e31d(:), gdep(:), zveiv(:,:,:)
-  REAL(KIND=4), ALLOCATABLE :: e1v(:,:), gphiv(:,:), zv(:,:,:), zt(:,:,:), zs(:,:,:), rdumlon(:,:), rdumlat(:,:), sigma(:), zwk(:,:)
+  REAL(KIND=4), ALLOCATABLE, TARGET :: e1v(:,:)
+  REAL(KIND=4), ALLOCATABLE :: gphiv(:,:), zv(:,:,:), zt(:,:,:), zs(:,:,:), rdumlon(:,:), rdumlat(:,:), sigma(:), zwk(:,:)
   REAL(KIND=8), ALLOCATABLE :: dtim(:)
   REAL(KIND=8), ALLOCATABLE, TARGET :: dmoc(:,:,:), depi(:,:,:)            ! (nbasins, nbins, npjglo)
   CHARACTER(LEN=256) :: cf_vfil, cf_tfil, cf_sfil, cf_moc = 'mocsig.nc', cldum, cglobal
   TYPE(variable), ALLOCATABLE :: stypvar(:)
   TYPE(C_PTR) :: pe3, pe31d, peiv, pgdep, pdepi
+  TYPE(C_PTR) :: pd_zv = C_NULL_PTR, pd_t = C_NULL_PTR, pd_s = C_NULL_PTR, pd_eiv = C_NULL_PTR, pd_e3v = C_NULL_PTR
+  TYPE(C_PTR) :: pd_e1v = C_NULL_PTR, pd_ib = C_NULL_PTR, pd_e31 = C_NULL_PTR
+  REAL(KIND=4), POINTER :: zv_d(:), zt_d(:), zs_d(:), e1v_d(:)          ! device arrays seen as arrays (never touched by the host)
+  INTEGER(KIND=2), POINTER :: ib_d(:)
+  INTEGER(KIND=8) :: nij8, n38
+  LOGICAL :: lfeed
   LOGICAL :: lfull = .FALSE., lchk = .FALSE., lbas, lbin(3), lisodep = .FALSE., lprint = .FALSE., leiv = .FALSE.
   LOGICAL :: lntr = .FALSE., ll_teos10 = .FALSE.
   INTEGER(C_INT) :: ieos
@@ -163,12 +174,15 @@ PROGRAM cdfmocsig
   END DO
   IF ( lprint ) PRINT *, ' min density:', sigma(1), ' max density:', sigma(nbins)
 
-  ALLOCATE( ibmask(nbasins,npiglo,npjglo), zv(npiglo,npjglo,npk), zt(npiglo,npjglo,npk), zs(npiglo,npjglo,npk) )
+  nij8 = INT(npiglo, 8) * npjglo ; n38 = nij8 * npk
+  lfeed = feed_wanted(4 * n38)
+  ALLOCATE( ibmask(nbasins,npiglo,npjglo) )
+  IF ( .NOT. lfeed ) ALLOCATE( zv(npiglo,npjglo,npk), zt(npiglo,npjglo,npk), zs(npiglo,npjglo,npk) )
   ALLOCATE( e1v(npiglo,npjglo), gphiv(npiglo,npjglo), zwk(npiglo,npjglo), dmoc(nbasins,nbins,npjglo) )
   ALLOCATE( rdumlon(1,npjglo), rdumlat(1,npjglo), dtim(npt), e31d(npk), gdep(npk) )
   IF ( lisodep ) ALLOCATE( depi(nbasins,nbins,npjglo) )
-  IF ( leiv ) ALLOCATE( zveiv(npiglo,npjglo,npk) )
-  IF ( .NOT. lfull ) ALLOCATE( e3v(npiglo,npjglo,npk) )
+  IF ( leiv .AND. .NOT. lfeed ) ALLOCATE( zveiv(npiglo,npjglo,npk) )
+  IF ( .NOT. ( lfull .OR. lfeed ) ) ALLOCATE( e3v(npiglo,npjglo,npk) )
   e1v(:,:) = getvar(cn_fhgr, cn_ve1v, 1, npiglo, npjglo)
   IF ( lfull   ) e31d(:) = getvare3(cn_fzgr, cn_ve3t1d, npk)
   IF ( lisodep ) gdep(:) = -getvare3(cn_fzgr, cn_gdept, npk)
@@ -195,6 +209,33 @@ PROGRAM cdfmocsig
 
   DO jt = 1, npt
      it = 1 ; IF ( lg_vvl ) it = jt
+     IF ( lfeed ) THEN                                      ! file -> HBM through the ring, the compute call ordered behind it
+        pe3 = C_NULL_PTR ; pe31d = C_NULL_PTR ; peiv = C_NULL_PTR ; pgdep = C_NULL_PTR ; pdepi = C_NULL_PTR
+        IF ( jt == 1 ) THEN
+           pd_e1v = feed_device(4 * nij8) ; pd_ib = feed_device(2 * nbasins * nij8)
+           pd_zv  = feed_device(4 * n38)  ; pd_t  = feed_device(4 * n38) ; pd_s = feed_device(4 * n38)
+           CALL C_F_POINTER(pd_e1v, e1v_d, (/ nij8 /)) ; CALL C_F_POINTER(pd_ib, ib_d, (/ nbasins * nij8 /))
+           CALL C_F_POINTER(pd_zv, zv_d, (/ n38 /)) ; CALL C_F_POINTER(pd_t, zt_d, (/ n38 /)) ; CALL C_F_POINTER(pd_s, zs_d, (/ n38 /))
+           CALL feed_host(C_LOC(e1v), 4 * nij8, pd_e1v)
+           CALL feed_host(C_LOC(ibmask), 2 * nbasins * nij8, pd_ib)
+           IF ( leiv ) pd_eiv = feed_device(4 * n38)
+           IF ( lfull ) THEN
+              pd_e31 = feed_device(4_8 * npk) ; CALL feed_host(C_LOC(e31d), 4_8 * npk, pd_e31)
+           ELSE
+              pd_e3v = feed_device(4 * n38)
+           ENDIF
+        ENDIF
+        IF ( .NOT. lfull .AND. ( jt == 1 .OR. lg_vvl ) )  &
+             &  CALL feed_field(cn_fe3v, cn_ve3v, pd_e3v, npiglo, npjglo, npk, ktime=it, ldiom=.NOT. lg_vvl)
+        CALL feed_field(cf_vfil, cn_vomecrty, pd_zv, npiglo, npjglo, npk, ktime=jt)
+        CALL feed_field(cf_tfil, cn_votemper, pd_t,  npiglo, npjglo, npk, ktime=jt)
+        CALL feed_field(cf_sfil, cn_vosaline, pd_s,  npiglo, npjglo, npk, ktime=jt)
+        IF ( leiv ) CALL feed_field(cf_vfil, cn_vomeeivv, pd_eiv, npiglo, npjglo, npk, ktime=jt)
+        IF ( lisodep ) THEN ; pgdep = C_LOC(gdep) ; pdepi = C_LOC(depi) ; ENDIF         ! (gdep: npk host values in every case)
+        CALL hip_check(cdft_mocsig_compute(zv_d, pd_eiv, zt_d, zs_d, e1v_d, pd_e3v, pd_e31, ib_d, pgdep, npiglo, npjglo, npk, nbasins, &
+             &         zspv, zspt, zsps, pref, ieos, nbins, sigmin, sigstp, CDFT_MEM_DEVICE, dmoc, pdepi, CDFT_MEM_HOST,               &
+             &         feed_stream), 'cdft_mocsig_compute')
+     ELSE
      CALL readvar3d(cf_vfil, cn_vomecrty, zv, ktime=jt)
      CALL readvar3d(cf_tfil, cn_votemper, zt, ktime=jt)
      CALL readvar3d(cf_sfil, cn_vosaline, zs, ktime=jt)
@@ -217,6 +258,7 @@ PROGRAM cdfmocsig
      CALL hip_check(cdft_mocsig_compute(zv, peiv, zt, zs, e1v, pe3, pe31d, ibmask, pgdep, npiglo, npjglo, npk, nbasins, zspv, zspt, &
           &         zsps, pref, ieos, nbins, sigmin, sigstp, CDFT_MEM_HOST, dmoc, pdepi,  &
           &         CDFT_MEM_HOST, C_NULL_PTR), 'cdft_mocsig_compute')
+     ENDIF
      DO jbasin = 1, nbasins
         DO jbin = 1, nbins
            ierr = putvar(ncout, id_varout(jbasin), REAL(dmoc(jbasin,jbin,:)), jbin, 1, npjglo, ktime=jt)
@@ -225,6 +267,11 @@ PROGRAM cdfmocsig
      END DO
   END DO
   ierr = closeout(ncout)
+  IF ( lfeed ) THEN
+     CALL feed_release(pd_zv) ; CALL feed_release(pd_t) ; CALL feed_release(pd_s) ; CALL feed_release(pd_eiv)
+     CALL feed_release(pd_e3v) ; CALL feed_release(pd_e31) ; CALL feed_release(pd_e1v) ; CALL feed_release(pd_ib)
+     CALL feed_close()
+  ENDIF
 
 CONTAINS
 

@@ -1,5 +1,5 @@
 """The host feed (module cdffeed, cdft_feed_* of the C ABI): the programs that have it -- cdfmoc, cdfheatc, cdfpsi, cdfvT,
-cdfmhst -- send their 3-D fields from the file to HBM slab by slab through a page-locked ring when the fields are large
+cdfmhst, cdfmocsig -- send their 3-D fields from the file to HBM slab by slab through a page-locked ring when the fields are large
 (from 1 GiB on) and as whole records in pageable memory otherwise.  The route must not show: for every option that
 touches it, CDFT_FEED=1 and CDFT_FEED=0 give the same stdout and byte-identical files (the pageable route is the one the
 other program tests hold against the oracle).  A ring with one plane per slot and two slots (CDFT_FEED_MB / _SLOTS) makes
@@ -22,6 +22,7 @@ def case(tools, tmp_path_factory):  # noqa: F811
     nemo_files.write_data(os.path.join(d, "VVL_y0001_gridU.nc"), g, "depthu", {"vozocrtx": rec["u"], "e3u": e3["u"]})
     nemo_files.write_data(os.path.join(d, "VVL_y0001_gridT.nc"), g, "deptht", {"votemper": rec["t"], "vosaline": rec["s"], "e3t": e3["t"]},
                           fill=0.0)
+    nemo_files.write_data(os.path.join(d, "EIV_y0001_gridV.nc"), g, "depthv", {"vomecrty": rec["v"], "vomeeivv": (rec["v"][::-1] * 0.3).astype("float32")})
     mxl = (5 + 200 * abs(rec["t"][:, 0]) / 30).astype("float32")
     nemo_files.write_data(os.path.join(d, "mxl.nc"), g, "deptht", {"somxl010": mxl})
     nemo_files.write_data(os.path.join(d, "ssh.nc"), g, "deptht", {"sossheig": (rec["t"][:, 0] / 30 - 0.5).astype("float32")})
@@ -53,6 +54,10 @@ RUNS = [
     ("cdfmhst", ["-vt", "vt_keep.nc", "-MST", "-Zdim", "-full"], ["mhst.nc"]),
     ("cdfmhst", ["-v", V, "-t", T, "-MST"], ["mhst.nc"]),
     ("cdfmhst", ["-v", "VVL_y0001_gridV.nc", "-t", "VVL_y0001_gridT.nc", "-vvl"], ["mhst.nc"]),
+    ("cdfmocsig", ["-v", V, "-t", T, "-r", "2000"], ["mocsig.nc"]),                               # V, T, S and e3v through the ring
+    ("cdfmocsig", ["-v", V, "-t", T, "-r", "0", "-isodep", "-teos10"], ["mocsig.nc"]),
+    ("cdfmocsig", ["-v", "EIV_y0001_gridV.nc", "-t", T, "-r", "1000", "-eiv", "-full"], ["mocsig.nc"]),
+    ("cdfmocsig", ["-v", "VVL_y0001_gridV.nc", "-t", "VVL_y0001_gridT.nc", "-ntr", "-vvl"], ["mocsig.nc"]),
 ]
 
 

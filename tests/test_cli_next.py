@@ -787,6 +787,20 @@ def test_cdfmocsig_end_to_end(tools, tmp_path):  # noqa: F811
     assert np.abs(var["zomsfglo"]).max() > 0
     rc, out, _ = run("cdfmocsig", ["-v", "SYN_y0001_gridV.nc", "-t", "SYN_y0001_gridT.nc", "-r", "500"], d)
     assert rc == 99 and "not implemented as standard" in out
+    # -eiv -full, by either route to the GPU: the eddy-induced velocity of the V file added, e3t_1d for the thickness
+    eiv = (rec["v"][::-1] * np.float32(0.3)).astype(np.float32)
+    nemo_files.write_data(os.path.join(d, "EIV_y0001_gridV.nc"), g, "depthv", {"vomecrty": rec["v"], "vomeeivv": eiv})
+    for feed in ("0", "1"):
+        rc, out, err = run("cdfmocsig", ["-v", "EIV_y0001_gridV.nc", "-t", "SYN_y0001_gridT.nc", "-r", "1000", "-eiv", "-full", "-o", "eiv.nc"], d,
+                           env={"CDFT_FEED": feed})
+        assert rc == 0 and "-nbins  88" in out.replace("-nbins 88", "-nbins  88"), out + err
+        var, att, dims = read_nc(os.path.join(d, "eiv.nc"))
+        for t in range(2):
+            ref = oracle_lib.mocsig(rec["v"][t], rec["t"][t], rec["s"][t], e1v, ib, 88, 24.0, 0.1, pref=1000.0, e31d=g["e3t_1d"], zveiv=eiv[t],
+                                    spv=(0.0, 0.0, 0.0))
+            for b, nm in enumerate(names):
+                assert np.allclose(var["zomsf" + nm][t, :, :, 0], ref[:, :, b].T, rtol=0, atol=2e-7 * np.abs(ref).max()), (feed, nm)
+        assert np.abs(var["zomsfglo"]).max() > 0
     # -ntr: the neutral density binned in classes the user gives (the reference's default ones start at 1023 while
     # sigmantr returns rho - 1000: kept, everything then falls in the first class)
     rc, out, err = run("cdfmocsig", ["-v", "SYN_y0001_gridV.nc", "-t", "SYN_y0001_gridT.nc", "-ntr", "-sigmin", "19", "-sigstp",

@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""cdfpsi or cdfmhst (the programs) on FILES of the eORCA12 grid with and without the host feed: the two routes to the GPU
+"""cdfpsi, cdfmhst, cdfvT or cdfmocsig (the programs) on FILES of the eORCA12 grid with and without the host feed: the two routes to the GPU
 (whole records in pageable memory, read THEN copied; slabs through the page-locked ring) must print the same and write the
 same file, at sizes where a record is 4.68 GB -- slab sizes, offsets and counts beyond 2^31.  CDF-5 files written level by
 level through the bundled backend; only what the program reads.  (cdfmoc and cdfheatc have their own tools, which also hold
 the result against the oracle.)
 
-    python tools/e2e_feed_big.py --tool psi|mhst|vt [--grid eorca12] [--npt 2]      # on the GPU box; 20-30 GB of scratch files
+    python tools/e2e_feed_big.py --tool psi|mhst|vt|mocsig [--grid eorca12] [--npt 2]      # on the GPU box; 20-30 GB of scratch files
 """
 import argparse
 import hashlib
@@ -28,7 +28,7 @@ from e2e_cdfmoc_big import BYTE, DOUBLE, FLOAT, GRIDS, Writer  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--tool", required=True, choices=["psi", "mhst", "vt"])
+    ap.add_argument("--tool", required=True, choices=["psi", "mhst", "vt", "mocsig"])
     ap.add_argument("--runs", type=int, default=2, help="runs per route (the first warms the page cache)")
     ap.add_argument("--grid", default="eorca12", choices=sorted(GRIDS))
     ap.add_argument("--npt", type=int, default=2)
@@ -99,6 +99,19 @@ def main():
         fields = [("SYN_y0001_gridT.nc", "votemper"), ("SYN_y0001_gridT.nc", "vosaline"), ("SYN_y0001_gridU.nc", "vozocrtx"),
                   ("SYN_y0001_gridV.nc", "vomecrty")]
         cmd = ["cdfvT", "-c", "SYN", "-l", "y0001"]
+    elif args.tool == "mocsig":                                   # -isodep: the three-histogram kernel; 5 basins in i-bands
+        files = {"T.nc": data_file("T.nc", "deptht", ["votemper", "vosaline"]), "V.nc": data_file("V.nc", "depthv", ["vomecrty"])}
+        fields = [("V.nc", "vomecrty")]
+        cmd = ["cdfmocsig", "-v", "V.nc", "-t", "T.nc", "-r", "2000", "-isodep"]
+        band = (np.arange(npi) * 3 // npi)[None, :]
+        sea1 = mbathy > 0
+        wb = Writer(os.path.join(d, "new_maskglo.nc"), [("y", npj), ("x", npi)])
+        for nm in ("tmaskatl", "tmaskind", "tmaskpac"):
+            wb.define(nm, BYTE, ("y", "x"))
+        wb.enddef()
+        for b, nm in enumerate(("tmaskatl", "tmaskind", "tmaskpac")):
+            wb.put(nm, (0, 0), (sea1 & (band == b)).astype(np.int8))
+        wb.close()
     else:
         files = {"vt.nc": data_file("vt.nc", "depthv", ["vomevt", "vomevs"])}
         fields = [("vt.nc", "vomevt"), ("vt.nc", "vomevs")]
@@ -115,6 +128,12 @@ def main():
         for fn, v in fields:
             for t in range(npt):
                 files[fn].put(v, (t, k, 0, 0), ((rng.random((npj, npi), dtype=f32) - f32(0.5)) * m).astype(f32))
+        if args.tool == "mocsig":                                 # T, S smooth in i and z, as an ocean's
+            x = np.linspace(0, 1, npi, dtype=f32)[None, :]
+            z = f32(k / max(npk - 1, 1))
+            for t in range(npt):
+                files["T.nc"].put("votemper", (t, k, 0, 0), ((f32(25) * (1 - z) ** 2 + f32(2) * x + f32(0.1 * t)) * m).astype(f32))
+                files["T.nc"].put("vosaline", (t, k, 0, 0), ((f32(34) + z + f32(0.5) * x) * m).astype(f32))
     wz.close(); wm.close()
     for wf in files.values():
         wf.close()
