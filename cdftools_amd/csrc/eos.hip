@@ -239,7 +239,7 @@ int run(int kind, const float *ptem, const float *psal, const float *pref2d, int
     CDFT_TRY(to_device(psal, n * sizeof(float), in_space, g_s, st, &ds));
     if (kind == kPointRef) CDFT_TRY(to_device(pref2d, n * sizeof(float), in_space, g_p, st, &dp));
     void *dout = out;
-    if (out_space == CDFT_MEM_HOST) {
+    if (out_space == CDFT_MEM_HOST || out_space == CDFT_MEM_PINNED) {
         CDFT_TRY(g_o.reserve(n * out_elem + 16));
         dout = g_o.ptr;
     } else if (out_space != CDFT_MEM_DEVICE) {
@@ -259,6 +259,8 @@ int run(int kind, const float *ptem, const float *psal, const float *pref2d, int
     if (out_space == CDFT_MEM_HOST) {
         CDFT_HIP(hipMemcpyAsync(out, dout, n * out_elem, hipMemcpyDeviceToHost, st));
         CDFT_HIP(hipStreamSynchronize(st));
+    } else if (out_space == CDFT_MEM_PINNED) {                    // on its way when the call returns (stream order keeps the
+        CDFT_HIP(hipMemcpyAsync(out, dout, n * out_elem, hipMemcpyDeviceToHost, st));   // staging buffer safe from the next call)
     }
     return CDFT_OK;
 }

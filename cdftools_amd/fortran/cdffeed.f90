@@ -22,7 +22,11 @@ MODULE cdffeed
   TYPE(C_PTR)         :: hfeed = C_NULL_PTR
   INTEGER(KIND=8)     :: nslot_bytes = 0
 
-  PUBLIC :: feed_wanted, feed_open, feed_close, feed_field, feed_mask, feed_host, feed_device, feed_release
+  PUBLIC :: feed_wanted, feed_open, feed_close, feed_field, feed_mask, feed_host, feed_device, feed_release, feed_sig_record
+
+  ! feed_sig_record's slab buffers (kept from record to record): T and S of a slab in HBM, two page-locked result slabs
+  TYPE(C_PTR)     :: pd_slab(2) = C_NULL_PTR, ph_slab(2) = C_NULL_PTR
+  INTEGER(KIND=8) :: nslab_bytes = 0
 
 CONTAINS
 
@@ -71,6 +75,13 @@ CONTAINS
   END SUBROUTINE feed_size
 
   SUBROUTINE feed_close()
+    INTEGER(KIND=4) :: ierr, jb
+    DO jb = 1, 2
+       IF ( C_ASSOCIATED(pd_slab(jb)) ) ierr = cdft_free(pd_slab(jb))
+       IF ( C_ASSOCIATED(ph_slab(jb)) ) ierr = cdft_host_free(ph_slab(jb))
+       pd_slab(jb) = C_NULL_PTR ; ph_slab(jb) = C_NULL_PTR
+    END DO
+    nslab_bytes = 0
     IF ( C_ASSOCIATED(hfeed) ) CALL hip_check(cdft_feed_destroy(hfeed), 'cdft_feed_destroy')
     hfeed = C_NULL_PTR ; feed_stream = C_NULL_PTR
   END SUBROUTINE feed_close
@@ -150,5 +161,65 @@ CONTAINS
     CALL hip_check(cdft_memcpy_h2d(pdev, psrc, INT(kbytes, C_SIZE_T), C_NULL_PTR), 'cdft_memcpy_h2d')
     CALL hip_check(cdft_stream_sync(C_NULL_PTR), 'cdft_stream_sync')
   END SUBROUTINE feed_host
+
+  SUBROUTINE feed_sig_record(cdtfil, cdtem, cdsfil, cdsal, kpi, kpj, kpk, ktime, pref, pspval, keos, kout, kidvar)
+    !! One record of cdfsig0 / cdfsigi (the level loop of src/cdfsig0.f90:139-155, src/cdfsigi.f90:131-137) a slab of levels at
+    !! a time: T and S of slab s+1 go from the file to HBM through the ring while the GPU works on slab s and sends its
+    !! result to a page-locked array; slab s is written to the file kout while slab s+1 is computed.  Nothing of the size of
+    !! a record is held in host memory, and the host waits for its file reads and writes only.
+    CHARACTER(LEN=*), INTENT(in) :: cdtfil, cdtem, cdsfil, cdsal
+    INTEGER(KIND=4),  INTENT(in) :: kpi, kpj, kpk, ktime, kout, kidvar
+    REAL(KIND=4),     INTENT(in) :: pref, pspval
+    INTEGER(C_INT),   INTENT(in) :: keos
+    INTEGER(KIND=4) :: inl, ins, js, jk, ib, ierr
+    INTEGER(KIND=8) :: islab
+    REAL(KIND=4), POINTER :: zt_d(:), zs_d(:), zout(:,:,:)
+    islab = 4_8 * kpi * kpj
+    CALL feed_size(islab, islab * kpk)
+    inl = INT(MAX(1_8, MIN(INT(kpk, 8), nslot_bytes / islab)), 4)        ! levels per slab: what a slot of the ring holds
+    IF ( nslab_bytes < islab * inl ) THEN
+       DO ib = 1, 2
+          IF ( C_ASSOCIATED(pd_slab(ib)) ) ierr = cdft_free(pd_slab(ib))
+          IF ( C_ASSOCIATED(ph_slab(ib)) ) ierr = cdft_host_free(ph_slab(ib))
+          CALL hip_check(cdft_malloc(pd_slab(ib), INT(islab * inl, C_SIZE_T)), 'cdft_malloc')
+          CALL hip_check(cdft_host_alloc(ph_slab(ib), INT(islab * inl, C_SIZE_T)), 'cdft_host_alloc')
+       END DO
+       nslab_bytes = islab * inl
+    ENDIF
+    CALL C_F_POINTER(pd_slab(1), zt_d, (/ islab / 4 * inl /)) ; CALL C_F_POINTER(pd_slab(2), zs_d, (/ islab / 4 * inl /))
+    ins = ( kpk + inl - 1 ) / inl
+    CALL load_slab(1) ; CALL compute_slab(1)
+    DO js = 1, ins
+       IF ( js < ins ) CALL load_slab(js + 1)                  ! queued behind the kernel of slab js, read while it runs
+       CALL hip_check(cdft_stream_sync(feed_stream), 'cdft_stream_sync')      ! the result of slab js is in its host array
+       IF ( js < ins ) CALL compute_slab(js + 1)               ! into the other host array, while slab js is written
+       ib = 1 + MOD(js - 1, 2)
+       CALL C_F_POINTER(ph_slab(ib), zout, (/ kpi, kpj, inl /))
+       DO jk = ( js - 1 ) * inl + 1, MIN(js * inl, kpk)
+          ierr = putvar(kout, kidvar, zout(:,:,jk - ( js - 1 ) * inl), jk, kpi, kpj, ktime=ktime)
+       END DO
+    END DO
+
+  CONTAINS
+
+    SUBROUTINE load_slab(ks)
+      INTEGER(KIND=4), INTENT(in) :: ks
+      INTEGER(KIND=4) :: ik0, il
+      ik0 = ( ks - 1 ) * inl + 1 ; il = MIN(inl, kpk - ik0 + 1)
+      CALL feed_field(cdtfil, cdtem, pd_slab(1), kpi, kpj, il, ktime=ktime, kkmin=ik0)
+      CALL feed_field(cdsfil, cdsal, pd_slab(2), kpi, kpj, il, ktime=ktime, kkmin=ik0)
+    END SUBROUTINE load_slab
+
+    SUBROUTINE compute_slab(ks)
+      INTEGER(KIND=4), INTENT(in) :: ks
+      INTEGER(KIND=4) :: ik0, il
+      REAL(KIND=4), POINTER :: zres(:)
+      ik0 = ( ks - 1 ) * inl + 1 ; il = MIN(inl, kpk - ik0 + 1)
+      CALL C_F_POINTER(ph_slab(1 + MOD(ks - 1, 2)), zres, (/ islab / 4 * il /))
+      CALL hip_check(cdft_eos_sig_tool(zt_d, zs_d, INT(islab / 4 * il, C_INT64_T), pref, pspval, keos, 0_C_INT, zres,  &
+           &         CDFT_MEM_DEVICE, CDFT_MEM_PINNED, feed_stream), 'cdft_eos_sig_tool')
+    END SUBROUTINE compute_slab
+
+  END SUBROUTINE feed_sig_record
 
 END MODULE cdffeed

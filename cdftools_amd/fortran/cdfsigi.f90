@@ -13,6 +13,7 @@ PROGRAM cdfsigi
   USE modcdfnames
   USE eos
   USE cdftools_hip
+  USE cdffeed
   IMPLICIT NONE
 
   INTEGER(KIND=4) :: narg, ijarg, ierr, jt, jk, npiglo, npjglo, npk, npkk, npt, ncout
@@ -22,7 +23,7 @@ PROGRAM cdfsigi
   REAL(KIND=8), ALLOCATABLE :: dtim(:)
   CHARACTER(LEN=256) :: cf_tfil = 'none', cf_sfil = 'none', cf_out = 'sigi.nc', cldum, cv_sal, cv_tem, cl_ref = ' '
   TYPE(variable) :: stypvar(1)
-  LOGICAL :: lnc4 = .FALSE., ll_teos10 = .FALSE.
+  LOGICAL :: lnc4 = .FALSE., ll_teos10 = .FALSE., lfeed
   !!----------------------------------------------------------------------
   CALL ReadCdfNames()
   narg = COMMAND_ARGUMENT_COUNT()
@@ -86,11 +87,19 @@ PROGRAM cdfsigi
   PRINT *, 'npk    = ', npk
   PRINT *, 'npt    = ', npt
 
-  ALLOCATE( ztemp(npiglo,npjglo,npkk), zsal(npiglo,npjglo,npkk), zsigi(npiglo,npjglo,npkk), dtim(npt) )
+  ! large fields: a slab of levels at a time through the page-locked ring (module cdffeed), nothing record-sized on the host
+  lfeed = npk > 0 .AND. feed_wanted(4_8 * npiglo * npjglo * npkk)
+  ALLOCATE( dtim(npt) )
+  IF ( .NOT. lfeed ) ALLOCATE( ztemp(npiglo,npjglo,npkk), zsal(npiglo,npjglo,npkk), zsigi(npiglo,npjglo,npkk) )
   CALL CreateOutput
 
   DO jt = 1, npt
      PRINT *, 'time: ', jt
+     IF ( lfeed ) THEN
+        CALL feed_sig_record(cf_tfil, cv_tem, cf_sfil, cv_sal, npiglo, npjglo, npkk, jt, ref_dep, zsps,  &
+             &               MERGE(CDFT_EOS_TEOS10, CDFT_EOS_80, ll_teos10), ncout, id_varout(1))
+        CYCLE
+     ENDIF
      CALL readvar3d(cf_tfil, cv_tem, ztemp, ktime=jt)
      CALL readvar3d(cf_sfil, cv_sal, zsal, ktime=jt)
      CALL hip_check(cdft_eos_sig_tool(ztemp, zsal, INT(npiglo, C_INT64_T) * npjglo * npkk, ref_dep, zsps,           &
@@ -101,6 +110,7 @@ PROGRAM cdfsigi
      END DO
   END DO
   ierr = closeout(ncout)
+  IF ( lfeed ) CALL feed_close()
 
 CONTAINS
 

@@ -248,7 +248,9 @@ int cdft_eos_sigmai(const float *ptem, const float *psal, int64_t n, float pref,
 int cdft_eos_sigmai2d(const float *ptem, const float *psal, const float *pref2d, int64_t n, int eos,
                       int flags, double *sig, int in_space, int out_space, void *stream);
 /* The level loop of cdfsig0 / cdfsigi fused (src/cdfsig0.f90:146-152, src/cdfsigi.f90:131-137):
- * sig4(n) r4 = REAL( sigmai(ptem,psal,pref) * zmask ), zmask = 0 where psal == spval else 1. */
+ * sig4(n) r4 = REAL( sigmai(ptem,psal,pref) * zmask ), zmask = 0 where psal == spval else 1.
+ * The three entries take out_space = CDFT_MEM_PINNED (a result array from cdft_host_alloc): the result is on its way when the
+ * call returns, cdft_stream_sync(stream) before reading it -- the programs compute slab s+1 while they write slab s. */
 int cdft_eos_sig_tool(const float *ptem, const float *psal, int64_t n, float pref, float spval, int eos,
                       int flags, float *sig4, int in_space, int out_space, void *stream);
 int cdft_eos_release(void);   /* frees the staging buffers used for host arrays */

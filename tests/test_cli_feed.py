@@ -1,5 +1,5 @@
 """The host feed (module cdffeed, cdft_feed_* of the C ABI): the programs that have it -- cdfmoc, cdfheatc, cdfpsi, cdfvT,
-cdfmhst, cdfmocsig -- send their 3-D fields from the file to HBM slab by slab through a page-locked ring when the fields are large
+cdfmhst, cdfmocsig, cdfsig0, cdfsigi -- send their 3-D fields from the file to HBM slab by slab through a page-locked ring when the fields are large
 (from 1 GiB on) and as whole records in pageable memory otherwise.  The route must not show: for every option that
 touches it, CDFT_FEED=1 and CDFT_FEED=0 give the same stdout and byte-identical files (the pageable route is the one the
 other program tests hold against the oracle).  A ring with one plane per slot and two slots (CDFT_FEED_MB / _SLOTS) makes
@@ -54,6 +54,9 @@ RUNS = [
     ("cdfmhst", ["-vt", "vt_keep.nc", "-MST", "-Zdim", "-full"], ["mhst.nc"]),
     ("cdfmhst", ["-v", V, "-t", T, "-MST"], ["mhst.nc"]),
     ("cdfmhst", ["-v", "VVL_y0001_gridV.nc", "-t", "VVL_y0001_gridT.nc", "-vvl"], ["mhst.nc"]),
+    ("cdfsig0", ["-t", T], ["sig0.nc"]),                                                          # slabs in through the ring, out through page-locked arrays
+    ("cdfsig0", ["-t", T, "-teos10"], ["sig0.nc"]),
+    ("cdfsigi", ["-t", T, "-r", "2000"], ["sigi.nc"]),
     ("cdfmocsig", ["-v", V, "-t", T, "-r", "2000"], ["mocsig.nc"]),                               # V, T, S and e3v through the ring
     ("cdfmocsig", ["-v", V, "-t", T, "-r", "0", "-isodep", "-teos10"], ["mocsig.nc"]),
     ("cdfmocsig", ["-v", "EIV_y0001_gridV.nc", "-t", T, "-r", "1000", "-eiv", "-full"], ["mocsig.nc"]),
@@ -113,3 +116,33 @@ def test_the_feed_ring_of_the_c_abi(gpu):
     with pytest.raises(gpu.CdftError):
         gpu.check(lib.cdft_feed_push(feed, C.c_void_p(dst.data_ptr()), 0, (1 << 20) + 1))
     gpu.check(lib.cdft_feed_destroy(feed))
+
+
+@pytest.mark.gpu
+def test_eos_results_into_page_locked_arrays(gpu):
+    """out_space = CDFT_MEM_PINNED of the cdft_eos_* entries: the result is on its way when the call returns and there after
+    cdft_stream_sync; two calls in a row share the staging buffer in stream order"""
+    import ctypes as C
+
+    import numpy as np
+    from cdftools_amd import _lib
+    lib = _lib.load()
+    n = 300_001
+    rng = np.random.default_rng(5)
+    t = (-2 + 32 * rng.random(n)).astype(np.float32)
+    s = np.where(rng.random(n) < 0.3, 0, 30 + 8 * rng.random(n)).astype(np.float32)
+    want = gpu.sig_tool(t, s, pref=2000.0, spval=0.0)
+    want0 = gpu.sig_tool(t, s, pref=0.0, spval=0.0)
+    bufs = []
+    for _ in range(2):
+        p = C.c_void_p()
+        gpu.check(lib.cdft_host_alloc(C.byref(p), 4 * n))
+        bufs.append(p)
+    for p, pref in zip(bufs, (2000.0, 0.0)):
+        gpu.check(lib.cdft_eos_sig_tool(t.ctypes.data, s.ctypes.data, n, C.c_float(pref), C.c_float(0.0), gpu.EOS_80, 0, p,
+                                        _lib.MEM_HOST, _lib.MEM_PINNED, None))
+    gpu.check(lib.cdft_stream_sync(None))
+    got = [np.frombuffer((C.c_char * (4 * n)).from_address(p.value), dtype=np.float32).copy() for p in bufs]
+    assert np.array_equal(got[0], want) and np.array_equal(got[1], want0) and not np.array_equal(want, want0)
+    for p in bufs:
+        gpu.check(lib.cdft_host_free(p))

@@ -5,7 +5,7 @@ same file, at sizes where a record is 4.68 GB -- slab sizes, offsets and counts 
 level through the bundled backend; only what the program reads.  (cdfmoc and cdfheatc have their own tools, which also hold
 the result against the oracle.)
 
-    python tools/e2e_feed_big.py --tool psi|mhst|vt|mocsig [--grid eorca12] [--npt 2]      # on the GPU box; 20-30 GB of scratch files
+    python tools/e2e_feed_big.py --tool psi|mhst|vt|mocsig|sig0|sigi [--grid eorca12] [--npt 2]      # on the GPU box; 20-30 GB of scratch files
 """
 import argparse
 import hashlib
@@ -28,7 +28,7 @@ from e2e_cdfmoc_big import BYTE, DOUBLE, FLOAT, GRIDS, Writer  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--tool", required=True, choices=["psi", "mhst", "vt", "mocsig"])
+    ap.add_argument("--tool", required=True, choices=["psi", "mhst", "vt", "mocsig", "sig0", "sigi"])
     ap.add_argument("--runs", type=int, default=2, help="runs per route (the first warms the page cache)")
     ap.add_argument("--grid", default="eorca12", choices=sorted(GRIDS))
     ap.add_argument("--npt", type=int, default=2)
@@ -99,6 +99,10 @@ def main():
         fields = [("SYN_y0001_gridT.nc", "votemper"), ("SYN_y0001_gridT.nc", "vosaline"), ("SYN_y0001_gridU.nc", "vozocrtx"),
                   ("SYN_y0001_gridV.nc", "vomecrty")]
         cmd = ["cdfvT", "-c", "SYN", "-l", "y0001"]
+    elif args.tool in ("sig0", "sigi"):
+        files = {"T.nc": data_file("T.nc", "deptht", ["votemper", "vosaline"])}
+        fields = []
+        cmd = ["cdfsig0", "-t", "T.nc"] if args.tool == "sig0" else ["cdfsigi", "-t", "T.nc", "-r", "2000"]
     elif args.tool == "mocsig":                                   # -isodep: the three-histogram kernel; 5 basins in i-bands
         files = {"T.nc": data_file("T.nc", "deptht", ["votemper", "vosaline"]), "V.nc": data_file("V.nc", "depthv", ["vomecrty"])}
         fields = [("V.nc", "vomecrty")]
@@ -128,7 +132,7 @@ def main():
         for fn, v in fields:
             for t in range(npt):
                 files[fn].put(v, (t, k, 0, 0), ((rng.random((npj, npi), dtype=f32) - f32(0.5)) * m).astype(f32))
-        if args.tool == "mocsig":                                 # T, S smooth in i and z, as an ocean's
+        if args.tool in ("mocsig", "sig0", "sigi"):               # T, S smooth in i and z, as an ocean's
             x = np.linspace(0, 1, npi, dtype=f32)[None, :]
             z = f32(k / max(npk - 1, 1))
             for t in range(npt):
