@@ -625,7 +625,7 @@ int cdft_curl_compute(cdft_curl_plan *p, const float *un, const float *vn, int n
     CDFT_TRY(to_device(un, n3 * 4, in_space, p->su, st, &du));
     CDFT_TRY(to_device(vn, n3 * 4, in_space, p->sv, st, &dv));
     void *dout = out;
-    if (out_space == CDFT_MEM_HOST) {
+    if (out_space == CDFT_MEM_HOST || out_space == CDFT_MEM_PINNED) {
         CDFT_TRY(p->sout.reserve(n3 * esz));
         dout = p->sout.ptr;
     }
@@ -674,6 +674,8 @@ int cdft_curl_compute(cdft_curl_plan *p, const float *un, const float *vn, int n
     if (out_space == CDFT_MEM_HOST) {
         CDFT_HIP(hipMemcpyAsync(out, dout, n3 * esz, hipMemcpyDeviceToHost, st));
         CDFT_HIP(hipStreamSynchronize(st));
+    } else if (out_space == CDFT_MEM_PINNED) {                    // on its way when the call returns; the next call's kernel
+        CDFT_HIP(hipMemcpyAsync(out, dout, n3 * esz, hipMemcpyDeviceToHost, st));   // follows it in stream order
     }
     return CDFT_OK;
 }

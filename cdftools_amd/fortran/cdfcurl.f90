@@ -14,6 +14,7 @@ PROGRAM cdfcurl
   USE cdfio
   USE modcdfnames
   USE cdftools_hip
+  USE cdffeed
   IMPLICIT NONE
 
   INTEGER(KIND=4) :: narg, ijarg, ierr, jt, jk, ji, jj, npiglo, npjglo, npk, npt, nlev = 0, ncout
@@ -28,6 +29,11 @@ PROGRAM cdfcurl
   CHARACTER(LEN=256) :: cf_ufil = 'none', cf_vfil = 'none', cf_out = 'curl.nc', cv_u = 'none', cv_v = 'none', cldum
   TYPE(variable) :: stypvar(1)
   TYPE(C_PTR) :: plan, pff
+  TYPE(C_PTR) :: pd_u = C_NULL_PTR, pd_v = C_NULL_PTR, ph_rot(2) = C_NULL_PTR      ! the host feed's level in HBM, two page-locked result levels
+  REAL(KIND=4), POINTER :: un_d(:), vn_d(:), zrot_h(:,:)
+  REAL(KIND=8), POINTER :: drot_h(:,:)
+  INTEGER(KIND=8) :: nij8
+  LOGICAL :: lfeed
   LOGICAL :: lchk = .FALSE., lperio = .FALSE., ldblpr = .FALSE., lnc4 = .FALSE., ltpoint = .FALSE., lsurf = .FALSE.
   LOGICAL :: loverf = .FALSE., l_metric = .TRUE., lforcing = .FALSE.
   !!----------------------------------------------------------------------
@@ -138,9 +144,14 @@ PROGRAM cdfcurl
   PRINT *, 'NLEV', nlev
 
   ALLOCATE( e1u(npiglo,npjglo), e1f(npiglo,npjglo), e2v(npiglo,npjglo), e2f(npiglo,npjglo) )
-  ALLOCATE( zlon(npiglo,npjglo), zlat(npiglo,npjglo), un(npiglo,npjglo,nlev), vn(npiglo,npjglo,nlev) )
-  ALLOCATE( dtim(npt), gdep(nlev), zdep(MAX(npk, 1)) )
-  IF ( ldblpr ) THEN ; ALLOCATE( drotn(npiglo,npjglo,nlev) ) ; ELSE ; ALLOCATE( zrot4(npiglo,npjglo,nlev) ) ; ENDIF
+  ! large fields: a level at a time through the page-locked ring (module cdffeed), nothing of nlev levels on the host
+  nij8 = INT(npiglo, 8) * npjglo
+  lfeed = feed_wanted(4 * nij8 * nlev) .AND. .NOT. ( lforcing .OR. lsurf )
+  ALLOCATE( zlon(npiglo,npjglo), zlat(npiglo,npjglo), dtim(npt), gdep(nlev), zdep(MAX(npk, 1)) )
+  IF ( .NOT. lfeed ) THEN
+     ALLOCATE( un(npiglo,npjglo,nlev), vn(npiglo,npjglo,nlev) )
+     IF ( ldblpr ) THEN ; ALLOCATE( drotn(npiglo,npjglo,nlev) ) ; ELSE ; ALLOCATE( zrot4(npiglo,npjglo,nlev) ) ; ENDIF
+  ENDIF
 
   IF ( l_metric ) THEN
      e1u  = getvar(cn_fhgr, cn_ve1u, 1, npiglo, npjglo)
@@ -175,8 +186,31 @@ PROGRAM cdfcurl
   CALL hip_check(cdft_curl_set_mesh(plan, e1u, e2v, e1f, e2f, pff, MERGE(1_C_INT, 0_C_INT, lperio), CDFT_MEM_HOST, &
        &         C_NULL_PTR), 'cdft_curl_set_mesh')
 
+  IF ( lfeed ) THEN
+     pd_u = feed_device(4 * nij8) ; pd_v = feed_device(4 * nij8)
+     CALL C_F_POINTER(pd_u, un_d, (/ nij8 /)) ; CALL C_F_POINTER(pd_v, vn_d, (/ nij8 /))
+     CALL hip_check(cdft_host_alloc(ph_rot(1), INT(MERGE(8, 4, ldblpr) * nij8, C_SIZE_T)), 'cdft_host_alloc')
+     CALL hip_check(cdft_host_alloc(ph_rot(2), INT(MERGE(8, 4, ldblpr) * nij8, C_SIZE_T)), 'cdft_host_alloc')
+  ENDIF
+
   DO jt = 1, npt
      IF ( MOD(jt, 100) == 0 ) PRINT *, jt, '/', npt
+     IF ( lfeed ) THEN      ! level jk+1 is read and computed while level jk is on its way to the host and to the file
+        CALL load_level(1) ; CALL compute_level(1)
+        DO jk = 1, nlev
+           IF ( jk < nlev ) CALL load_level(jk + 1)
+           CALL hip_check(cdft_stream_sync(feed_stream), 'cdft_stream_sync')
+           IF ( jk < nlev ) CALL compute_level(jk + 1)
+           IF ( ldblpr ) THEN
+              CALL C_F_POINTER(ph_rot(1 + MOD(jk - 1, 2)), drot_h, (/ npiglo, npjglo /))
+              ierr = putvar(ncout, id_varout(1), drot_h, jk, npiglo, npjglo, ktime=jt)
+           ELSE
+              CALL C_F_POINTER(ph_rot(1 + MOD(jk - 1, 2)), zrot_h, (/ npiglo, npjglo /))
+              ierr = putvar(ncout, id_varout(1), zrot_h, jk, npiglo, npjglo, ktime=jt)
+           ENDIF
+        END DO
+        CYCLE
+     ENDIF
      DO jk = 1, nlev
         PRINT *, TRIM(cf_ufil), ' ', TRIM(cv_u), ' ', jk, nilev(jk), npiglo, npjglo, jt
         un(:,:,jk) = getvar(cf_ufil, cv_u, nilev(jk), npiglo, npjglo, ktime=jt)
@@ -205,8 +239,28 @@ PROGRAM cdfcurl
   END DO
   ierr = cdft_curl_destroy(plan)
   ierr = closeout(ncout)
+  IF ( lfeed ) THEN
+     CALL feed_release(pd_u) ; CALL feed_release(pd_v)
+     ierr = cdft_host_free(ph_rot(1)) ; ierr = cdft_host_free(ph_rot(2))
+     CALL feed_close()
+  ENDIF
 
 CONTAINS
+
+  SUBROUTINE load_level(kk)
+    !! u and v of level nilev(kk) of record jt from the file to HBM through the ring (the line the reference prints, :246)
+    INTEGER(KIND=4), INTENT(in) :: kk
+    PRINT *, TRIM(cf_ufil), ' ', TRIM(cv_u), ' ', kk, nilev(kk), npiglo, npjglo, jt
+    CALL feed_field(cf_ufil, cv_u, pd_u, npiglo, npjglo, 1, ktime=jt, kkmin=nilev(kk))
+    CALL feed_field(cf_vfil, cv_v, pd_v, npiglo, npjglo, 1, ktime=jt, kkmin=nilev(kk))
+  END SUBROUTINE load_level
+
+  SUBROUTINE compute_level(kk)
+    !! queued behind the copies of load_level(kk); the result on its way to the page-locked array of kk's parity
+    INTEGER(KIND=4), INTENT(in) :: kk
+    CALL hip_check(cdft_curl_compute(plan, un_d, vn_d, 1, CDFT_MEM_DEVICE, MERGE(1_C_INT, 0_C_INT, ltpoint),            &
+         &         ph_rot(1 + MOD(kk - 1, 2)), MERGE(1_C_INT, 0_C_INT, ldblpr), CDFT_MEM_PINNED, feed_stream), 'cdft_curl_compute')
+  END SUBROUTINE compute_level
 
   SUBROUTINE ParseLevel(cdum)
     !! '5', '1,3,5', '1-20', '1-3,10-12', '10-' (open ended, capped at 300) -> nilev(1:nlev)

@@ -561,7 +561,9 @@ int cdft_curl_set_mesh(cdft_curl_plan *plan, const float *e1u, const float *e2v,
                        const float *e2f, const double *ff, int lperio, int memspace, void *stream);
 /* un, vn (npiglo,npjglo,nlev) r4: the selected levels of one record (:247-248).
  * out (npiglo,npjglo,nlev): r8 (drotn as handed to putvar, -8) or r4 (float variable).
- * ltpoint: -T, 4-point mean to T points (:286-297). */
+ * ltpoint: -T, 4-point mean to T points (:286-297).
+ * out_space = CDFT_MEM_PINNED (out from cdft_host_alloc): the result is on its way when the call returns,
+ * cdft_stream_sync(stream) before reading it -- the program computes level k+1 while it writes level k. */
 int cdft_curl_compute(cdft_curl_plan *plan, const float *un, const float *vn, int nlev, int in_space,
                       int ltpoint, void *out, int out_is_r8, int out_space, void *stream);
 int cdft_curl_destroy(cdft_curl_plan *plan);

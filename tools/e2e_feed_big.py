@@ -5,7 +5,7 @@ same file, at sizes where a record is 4.68 GB -- slab sizes, offsets and counts 
 level through the bundled backend; only what the program reads.  (cdfmoc and cdfheatc have their own tools, which also hold
 the result against the oracle.)
 
-    python tools/e2e_feed_big.py --tool psi|mhst|vt|mocsig|sig0|sigi [--grid eorca12] [--npt 2]      # on the GPU box; 20-30 GB of scratch files
+    python tools/e2e_feed_big.py --tool psi|mhst|vt|mocsig|sig0|sigi|curl [--grid eorca12] [--npt 2]      # on the GPU box; 20-30 GB of scratch files
 """
 import argparse
 import hashlib
@@ -28,7 +28,7 @@ from e2e_cdfmoc_big import BYTE, DOUBLE, FLOAT, GRIDS, Writer  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--tool", required=True, choices=["psi", "mhst", "vt", "mocsig", "sig0", "sigi"])
+    ap.add_argument("--tool", required=True, choices=["psi", "mhst", "vt", "mocsig", "sig0", "sigi", "curl"])
     ap.add_argument("--runs", type=int, default=2, help="runs per route (the first warms the page cache)")
     ap.add_argument("--grid", default="eorca12", choices=sorted(GRIDS))
     ap.add_argument("--npt", type=int, default=2)
@@ -49,7 +49,7 @@ def main():
     metric = lambda: (2000 + 26000 * rng.random((npj, npi), dtype=f32)).astype(f32)   # noqa: E731
 
     w = Writer(os.path.join(d, "mesh_hgr.nc"), [("t", None), ("y", npj), ("x", npi)])
-    names = ("e1v", "e2u", "glamf", "gphif", "gphiv")
+    names = ("e1v", "e2u", "glamf", "gphif", "gphiv") + (("e1u", "e2v", "e1f", "e2f") if args.tool == "curl" else ())
     for nm in names:
         w.define(nm, FLOAT, ("t", "y", "x"))
     w.enddef()
@@ -99,6 +99,10 @@ def main():
         fields = [("SYN_y0001_gridT.nc", "votemper"), ("SYN_y0001_gridT.nc", "vosaline"), ("SYN_y0001_gridU.nc", "vozocrtx"),
                   ("SYN_y0001_gridV.nc", "vomecrty")]
         cmd = ["cdfvT", "-c", "SYN", "-l", "y0001"]
+    elif args.tool == "curl":                                     # every level of the record
+        files = {"U.nc": data_file("U.nc", "depthu", ["vozocrtx"]), "V.nc": data_file("V.nc", "depthv", ["vomecrty"])}
+        fields = [("U.nc", "vozocrtx"), ("V.nc", "vomecrty")]
+        cmd = ["cdfcurl", "-u", "U.nc", "vozocrtx", "-v", "V.nc", "vomecrty", "-l", "1-%d" % (npk - 1)]
     elif args.tool in ("sig0", "sigi"):
         files = {"T.nc": data_file("T.nc", "deptht", ["votemper", "vosaline"])}
         fields = []
