@@ -22,7 +22,7 @@ MODULE cdffeed
   TYPE(C_PTR)         :: hfeed = C_NULL_PTR
   INTEGER(KIND=8)     :: nslot_bytes = 0
 
-  PUBLIC :: feed_wanted, feed_open, feed_close, feed_field, feed_mask, feed_host, feed_device, feed_release, feed_sig_record
+  PUBLIC :: feed_wanted, feed_open, feed_close, feed_field, feed_mask, feed_host, feed_device, feed_release, feed_sig_record, feed_mean_mesh
 
   ! feed_sig_record's slab buffers (kept from record to record): T and S of a slab in HBM, two page-locked result slabs
   TYPE(C_PTR)     :: pd_slab(2) = C_NULL_PTR, ph_slab(2) = C_NULL_PTR
@@ -161,6 +161,38 @@ CONTAINS
     CALL hip_check(cdft_memcpy_h2d(pdev, psrc, INT(kbytes, C_SIZE_T), C_NULL_PTR), 'cdft_memcpy_h2d')
     CALL hip_check(cdft_stream_sync(C_NULL_PTR), 'cdft_stream_sync')
   END SUBROUTINE feed_host
+
+  SUBROUTINE feed_mean_mesh(plan, pe1, pe2, pe31d, cde3fil, cde3var, cdmskfil, cdmskvar, pib, kpi, kpj, kpk, knb, kimin, kjmin, kkmin, &
+       &                    ktime, ldiom)
+    !! cdft_mean_set_mesh (cdfmean, cdfsum) with nothing 3-D in host memory: the mask of the working levels and e3 go from
+    !! their files to HBM through the ring; e1, e2, the basin masks (and e31d with -full: pe31d associated, e3 not read) are
+    !! the caller's host arrays (C_LOC).  The plan keeps its own copies: everything fed here is released on return.
+    TYPE(C_PTR),      INTENT(in) :: plan, pe1, pe2, pe31d, pib
+    CHARACTER(LEN=*), INTENT(in) :: cde3fil, cde3var, cdmskfil, cdmskvar
+    INTEGER(KIND=4),  INTENT(in) :: kpi, kpj, kpk, knb, kimin, kjmin, kkmin, ktime
+    LOGICAL,          INTENT(in) :: ldiom
+    TYPE(C_PTR) :: pd1, pd2, pdib, pdm, pde3, pd31
+    INTEGER(KIND=8) :: inij, in3
+    REAL(KIND=4), POINTER :: z1(:), z2(:), zm(:)
+    INTEGER(KIND=2), POINTER :: ib(:)
+    inij = INT(kpi, 8) * kpj ; in3 = inij * kpk
+    pd1 = feed_device(4 * inij) ; pd2 = feed_device(4 * inij) ; pdib = feed_device(2 * knb * inij) ; pdm = feed_device(4 * in3)
+    pde3 = C_NULL_PTR ; pd31 = C_NULL_PTR
+    CALL feed_host(pe1, 4 * inij, pd1) ; CALL feed_host(pe2, 4 * inij, pd2) ; CALL feed_host(pib, 2 * knb * inij, pdib)
+    CALL feed_field(cdmskfil, cdmskvar, pdm, kpi, kpj, kpk, kimin=kimin, kjmin=kjmin, kkmin=kkmin)
+    IF ( C_ASSOCIATED(pe31d) ) THEN
+       pd31 = feed_device(4_8 * kpk) ; CALL feed_host(pe31d, 4_8 * kpk, pd31)
+    ELSE
+       pde3 = feed_device(4 * in3)
+       CALL feed_field(cde3fil, cde3var, pde3, kpi, kpj, kpk, ktime=ktime, ldiom=ldiom, kimin=kimin, kjmin=kjmin, kkmin=kkmin)
+    ENDIF
+    CALL C_F_POINTER(pd1, z1, (/ inij /)) ; CALL C_F_POINTER(pd2, z2, (/ inij /)) ; CALL C_F_POINTER(pdm, zm, (/ in3 /))
+    CALL C_F_POINTER(pdib, ib, (/ knb * inij /))
+    CALL hip_check(cdft_mean_set_mesh(plan, z1, z2, pde3, pd31, zm, ib, CDFT_MEM_DEVICE, feed_stream), 'cdft_mean_set_mesh')
+    CALL hip_check(cdft_stream_sync(feed_stream), 'cdft_stream_sync')
+    CALL feed_release(pd1) ; CALL feed_release(pd2) ; CALL feed_release(pdib) ; CALL feed_release(pdm)
+    CALL feed_release(pde3) ; CALL feed_release(pd31)
+  END SUBROUTINE feed_mean_mesh
 
   SUBROUTINE feed_sig_record(cdtfil, cdtem, cdsfil, cdsal, kpi, kpj, kpk, ktime, pref, pspval, keos, kout, kidvar)
     !! One record of cdfsig0 / cdfsigi (the level loop of src/cdfsig0.f90:139-155, src/cdfsigi.f90:131-137) a slab of levels at

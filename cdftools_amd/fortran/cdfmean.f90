@@ -15,6 +15,7 @@ PROGRAM cdfmean
   USE cdfio
   USE modcdfnames
   USE cdftools_hip
+  USE cdffeed
   IMPLICIT NONE
 
   INTEGER(KIND=4) :: jk, jt, it, ik, jbasin, ivarb, narg, ijarg, ierr, idep, idep_max
@@ -22,10 +23,12 @@ PROGRAM cdfmean
   INTEGER(KIND=4) :: npiglo, npjglo, npk, npt, npiglo_fi, npjglo_fi, npk_fi, nvpk, nbasin = 1
   INTEGER(KIND=4) :: numout = 10, numvar = 11, numsum = 12, ikx = 1, iky = 1, nvars, nvars_bas, ncout
   INTEGER(KIND=4), ALLOCATABLE :: n_sum(:), n_sum3d(:), n_mean(:), n_mean3d(:), n_var(:), n_var3d(:), ipk(:), id_varout(:)
-  INTEGER(KIND=2), ALLOCATABLE :: ibmask(:,:,:)                    ! (nbasin, npiglo, npjglo)
+  INTEGER(KIND=2), ALLOCATABLE, TARGET :: ibmask(:,:,:)            ! (nbasin, npiglo, npjglo)
   REAL(KIND=4) :: zspval, rdummy(1,1)
   REAL(KIND=4), ALLOCATABLE, TARGET :: e3(:,:,:), e31d(:)
-  REAL(KIND=4), ALLOCATABLE :: gdep(:), zdep(:), e1(:,:), e2(:,:), zv(:,:,:), zmask(:,:,:), zwk(:,:)
+  REAL(KIND=4), ALLOCATABLE, TARGET :: e1(:,:), e2(:,:)
+  REAL(KIND=4), ALLOCATABLE :: gdep(:), zdep(:), zv(:,:,:), zmask(:,:,:), zwk(:,:)
+  REAL(KIND=4), POINTER :: zv_d(:)                                 ! the record in HBM (host feed), never touched by the host
   REAL(KIND=4), ALLOCATABLE :: rdumlon(:,:), rdumlat(:,:), rdummymean(:,:)
   REAL(KIND=8) :: dsurf, dvol2d, dsum2d, dvar2d
   REAL(KIND=8), ALLOCATABLE :: dtim(:), dvmeanout(:), dvariance(:), dvol(:), dsum(:), dvar(:)
@@ -36,7 +39,8 @@ PROGRAM cdfmean
   CHARACTER(LEN=20)  :: cv_e1, cv_e2, cv_e3, cv_e31d, cv_msk = ''
   CHARACTER(LEN=256), ALLOCATABLE :: clv_dep(:), cbasins(:)
   TYPE(variable), ALLOCATABLE :: stypvar(:)
-  TYPE(C_PTR) :: plan, pe3, pe31d
+  TYPE(C_PTR) :: plan, pe3, pe31d, pd_zv = C_NULL_PTR
+  LOGICAL :: lfeed
   LOGICAL :: lbas = .FALSE., lfull = .FALSE., lvar = .FALSE., lsum = .FALSE., lzeromean = .FALSE., lnodep = .FALSE., lchk
   !!----------------------------------------------------------------------
   CALL ReadCdfNames()
@@ -161,7 +165,10 @@ PROGRAM cdfmean
   WRITE(6, *) 'nvpk   = ', nvpk
   WRITE(6, *) 'depth dim name is ', TRIM(cv_dep)
 
-  ALLOCATE( ibmask(nbasin,npiglo,npjglo), zmask(npiglo,npjglo,nvpk), zv(npiglo,npjglo,nvpk), zwk(npiglo,npjglo) )
+  ! large fields: the mask, e3 and every record go from the file to HBM through the page-locked ring (module cdffeed)
+  lfeed = feed_wanted(4_8 * npiglo * npjglo * nvpk)
+  ALLOCATE( ibmask(nbasin,npiglo,npjglo), zwk(npiglo,npjglo) )
+  IF ( .NOT. lfeed ) ALLOCATE( zmask(npiglo,npjglo,nvpk), zv(npiglo,npjglo,nvpk) )
   ALLOCATE( e1(npiglo,npjglo), e2(npiglo,npjglo), dvariance3d(nbasin,npt), dvmeanout3d(nbasin,npt) )
   ALLOCATE( gdep(npk), e31d(npk), dtim(npt), dvol(nbasin), dsum(nbasin), dvar(nbasin), zdep(npk_fi) )
   ALLOCATE( n_mean(nbasin), n_mean3d(nbasin), n_var(nbasin), n_var3d(nbasin), n_sum(nbasin), n_sum3d(nbasin) )
@@ -209,8 +216,8 @@ PROGRAM cdfmean
   IF ( lg_vvl ) cf_e3 = cf_in
 
   ! the mask of the working levels is the same for every record
-  CALL readvar3d(cn_fmsk, cv_msk, zmask, kimin=iimin, kjmin=ijmin, kkmin=ikmin)      ! (every level in one read)
-  IF ( .NOT. lfull ) ALLOCATE( e3(npiglo,npjglo,nvpk) )
+  IF ( .NOT. lfeed ) CALL readvar3d(cn_fmsk, cv_msk, zmask, kimin=iimin, kjmin=ijmin, kkmin=ikmin)      ! (every level in one read)
+  IF ( .NOT. ( lfull .OR. lfeed ) ) ALLOCATE( e3(npiglo,npjglo,nvpk) )
   CALL hip_check(cdft_mean_create(plan, npiglo, npjglo, nvpk, nbasin), 'cdft_mean_create')
   ! without -var nothing reads dvar2d: the kernel then leaves its four products per cell out (the slot comes back 0)
   IF ( .NOT. lvar ) CALL hip_check(cdft_mean_set_form(plan, CDFT_MEAN_FORM_MEAN_NOVAR), 'cdft_mean_set_form')
@@ -218,6 +225,19 @@ PROGRAM cdfmean
   DO jt = 1, npt
      it = 1 ; IF ( lg_vvl ) it = jt
      dvol(:) = 0.d0 ; dsum(:) = 0.d0 ; dvar(:) = 0.d0
+     IF ( lfeed ) THEN
+        IF ( jt == 1 .OR. lg_vvl ) THEN
+           pe31d = C_NULL_PTR ; IF ( lfull ) pe31d = C_LOC(e31d)
+           CALL feed_mean_mesh(plan, C_LOC(e1), C_LOC(e2), pe31d, cf_e3, cv_e3, cn_fmsk, cv_msk, C_LOC(ibmask), npiglo, npjglo, nvpk, &
+                &              nbasin, iimin, ijmin, ikmin, it, .NOT. lg_vvl)
+        ENDIF
+        IF ( jt == 1 ) THEN
+           pd_zv = feed_device(4_8 * npiglo * npjglo * nvpk)
+           CALL C_F_POINTER(pd_zv, zv_d, (/ INT(npiglo, 8) * npjglo * nvpk /))
+        ENDIF
+        CALL feed_field(cf_in, cv_nam, pd_zv, npiglo, npjglo, nvpk, ktime=jt, kimin=iimin, kjmin=ijmin, kkmin=ikmin)
+        CALL hip_check(cdft_mean_compute(plan, zv_d, CDFT_MEM_DEVICE, dsums, CDFT_MEM_HOST, feed_stream), 'cdft_mean_compute')
+     ELSE
      IF ( jt == 1 .OR. lg_vvl ) THEN
         pe3 = C_NULL_PTR ; pe31d = C_NULL_PTR
         IF ( lfull ) THEN
@@ -230,6 +250,7 @@ PROGRAM cdfmean
      ENDIF
      CALL readvar3d(cf_in, cv_nam, zv, kimin=iimin, kjmin=ijmin, kkmin=ikmin, ktime=jt)
      CALL hip_check(cdft_mean_compute(plan, zv, CDFT_MEM_HOST, dsums, CDFT_MEM_HOST, C_NULL_PTR), 'cdft_mean_compute')
+     ENDIF
 
      DO jk = 1, nvpk
         ik = jk + ikmin - 1
@@ -295,6 +316,9 @@ PROGRAM cdfmean
   IF ( lvar ) CLOSE(numvar)
   ierr = cdft_mean_destroy(plan)
   ierr = closeout(ncout)
+  IF ( lfeed ) THEN
+     CALL feed_release(pd_zv) ; CALL feed_close()
+  ENDIF
 9004 FORMAT(f9.2,' ',i2,' ',f9.2)
 
   ! -zeromean (:490-527): the field of the WHOLE domain minus the 3-D mean found above (possibly that of a window),

@@ -14,15 +14,18 @@ PROGRAM cdfsum
   USE cdfio
   USE modcdfnames
   USE cdftools_hip
+  USE cdffeed
   IMPLICIT NONE
 
   INTEGER(KIND=4) :: jk, jt, it, ik, narg, ijarg, ierr, ncout, numout = 10
   INTEGER(KIND=4) :: iimin = 0, iimax = 0, ijmin = 0, ijmax = 0, ikmin = 0, ikmax = 0
   INTEGER(KIND=4) :: npiglo, npjglo, npk, npkk, npt, nvpk, nlev
   INTEGER(KIND=4) :: ipk(3), id_varout(3)
-  INTEGER(KIND=2), ALLOCATABLE :: ibmask(:,:,:)
+  INTEGER(KIND=2), ALLOCATABLE, TARGET :: ibmask(:,:,:)
   REAL(KIND=4) :: zspval, rdummy(1,1)
-  REAL(KIND=4), ALLOCATABLE :: gdep(:), e1(:,:), e2(:,:), zv(:,:,:), zmask(:,:,:)
+  REAL(KIND=4), ALLOCATABLE, TARGET :: e1(:,:), e2(:,:)
+  REAL(KIND=4), ALLOCATABLE :: gdep(:), zv(:,:,:), zmask(:,:,:)
+  REAL(KIND=4), POINTER :: zv_d(:)                                 ! the record in HBM (host feed), never touched by the host
   REAL(KIND=4), ALLOCATABLE, TARGET :: e3(:,:,:)
   REAL(KIND=8) :: dvol, dvol2d, dsurf, dsum, dsum2d, dsumt
   REAL(KIND=8), ALLOCATABLE :: dtim(:), dsums(:,:,:)               ! dsums(4, 1, nlev)
@@ -30,7 +33,8 @@ PROGRAM cdfsum
   CHARACTER(LEN=256) :: clunits = ' ', cllong_name = ' ', clshort_name = ' '
   CHARACTER(LEN=20)  :: cv_e1, cv_e2, cv_e3, cv_msk, cl_vmsk, cvartype = 'none'
   TYPE(variable) :: stypvar(3)
-  TYPE(C_PTR) :: plan
+  TYPE(C_PTR) :: plan, pd_zv = C_NULL_PTR
+  LOGICAL :: lfeed
   LOGICAL :: lforcing, lchk = .FALSE., lnc4 = .FALSE., lerror = .FALSE., lfmsk = .FALSE., lnwgh = .FALSE., lnmsk = .FALSE.
   !!----------------------------------------------------------------------
   CALL ReadCdfNames()
@@ -140,7 +144,10 @@ PROGRAM cdfsum
   IF ( lforcing ) OPEN(UNIT=numout, FILE='cdfsum.txt', FORM='formatted', STATUS='new', IOSTAT=ierr)
 
   nlev = MAX(nvpk, 1)
-  ALLOCATE( zmask(npiglo,npjglo,nlev), zv(npiglo,npjglo,nlev), e3(npiglo,npjglo,nlev), ibmask(1,npiglo,npjglo) )
+  ! large fields with the file's mask and weights: mask, e3 and every record from the file to HBM through the ring (cdffeed)
+  lfeed = nvpk >= 1 .AND. .NOT. ( lnmsk .OR. lnwgh ) .AND. feed_wanted(4_8 * npiglo * npjglo * nlev)
+  ALLOCATE( ibmask(1,npiglo,npjglo) )
+  IF ( .NOT. lfeed ) ALLOCATE( zmask(npiglo,npjglo,nlev), zv(npiglo,npjglo,nlev), e3(npiglo,npjglo,nlev) )
   ALLOCATE( e1(npiglo,npjglo), e2(npiglo,npjglo), gdep(npk), dtim(npt), dsums(4,1,nlev) )
 
   SELECT CASE ( TRIM(cvartype) )                               ! metrics, mask and depth of each C-grid point (:209-258)
@@ -169,7 +176,7 @@ PROGRAM cdfsum
 
   ! the mask of the working levels does not change with the record
   IF ( lnmsk ) THEN ; zmask(:,:,:) = 1
-  ELSE IF ( nvpk >= 1 ) THEN ; CALL readvar3d(cn_fmsk, cv_msk, zmask, kimin=iimin, kjmin=ijmin, kkmin=ikmin)      ! (every level in one read)
+  ELSE IF ( nvpk >= 1 .AND. .NOT. lfeed ) THEN ; CALL readvar3d(cn_fmsk, cv_msk, zmask, kimin=iimin, kjmin=ijmin, kkmin=ikmin)      ! (every level in one read)
   ENDIF
   ibmask(:,:,:) = 1
   IF ( nvpk >= 1 ) THEN
@@ -183,15 +190,25 @@ PROGRAM cdfsum
   DO jt = 1, npt
      it = 1 ; IF ( lg_vvl ) it = jt
      dvol = 0.d0 ; dsum = 0.d0
-     IF ( nvpk >= 1 .AND. ( jt == 1 .OR. lg_vvl ) ) THEN
+     IF ( lfeed ) THEN
+        IF ( jt == 1 .OR. lg_vvl ) CALL feed_mean_mesh(plan, C_LOC(e1), C_LOC(e2), C_NULL_PTR, cf_e3, cv_e3, cn_fmsk, cv_msk, C_LOC(ibmask), &
+             &                                         npiglo, npjglo, nvpk, 1, iimin, ijmin, ikmin, it, .NOT. lg_vvl)
+        IF ( jt == 1 ) THEN
+           pd_zv = feed_device(4_8 * npiglo * npjglo * nvpk)
+           CALL C_F_POINTER(pd_zv, zv_d, (/ INT(npiglo, 8) * npjglo * nvpk /))
+        ENDIF
+        CALL feed_field(cf_in, cv_in, pd_zv, npiglo, npjglo, nvpk, ktime=jt, kimin=iimin, kjmin=ijmin, kkmin=ikmin)
+        CALL hip_check(cdft_mean_compute(plan, zv_d, CDFT_MEM_DEVICE, dsums, CDFT_MEM_HOST, feed_stream), 'cdft_mean_compute')
+     ENDIF
+     IF ( nvpk >= 1 .AND. ( jt == 1 .OR. lg_vvl ) .AND. .NOT. lfeed ) THEN
         IF ( lnwgh ) THEN ; e3(:,:,:) = 1.
         ELSE ; CALL readvar3d(cf_e3, cv_e3, e3, kimin=iimin, kjmin=ijmin, kkmin=ikmin, ktime=it, ldiom=.NOT. lg_vvl)
         ENDIF
         CALL hip_check(cdft_mean_set_mesh(plan, e1, e2, C_LOC(e3), C_NULL_PTR, zmask, ibmask, CDFT_MEM_HOST, C_NULL_PTR), &
              &         'cdft_mean_set_mesh')
      ENDIF
-     IF ( nvpk >= 1 ) CALL readvar3d(cf_in, cv_in, zv, kimin=iimin, kjmin=ijmin, kkmin=ikmin, ktime=jt)
-     IF ( nvpk >= 1 ) CALL hip_check(cdft_mean_compute(plan, zv, CDFT_MEM_HOST, dsums, CDFT_MEM_HOST, C_NULL_PTR), 'cdft_mean_compute')
+     IF ( nvpk >= 1 .AND. .NOT. lfeed ) CALL readvar3d(cf_in, cv_in, zv, kimin=iimin, kjmin=ijmin, kkmin=ikmin, ktime=jt)
+     IF ( nvpk >= 1 .AND. .NOT. lfeed ) CALL hip_check(cdft_mean_compute(plan, zv, CDFT_MEM_HOST, dsums, CDFT_MEM_HOST, C_NULL_PTR), 'cdft_mean_compute')
 
      DO jk = 1, nvpk
         ik = jk + ikmin - 1
@@ -230,6 +247,9 @@ PROGRAM cdfsum
   CLOSE(numout)
   IF ( nvpk >= 1 ) ierr = cdft_mean_destroy(plan)
   ierr = closeout(ncout)
+  IF ( lfeed ) THEN
+     CALL feed_release(pd_zv) ; CALL feed_close()
+  ENDIF
 
 CONTAINS
 
