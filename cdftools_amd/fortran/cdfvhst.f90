@@ -11,6 +11,7 @@ PROGRAM cdfvhst
   USE cdfio
   USE modcdfnames
   USE cdftools_hip
+  USE cdffeed
   IMPLICIT NONE
 
   INTEGER(KIND=4) :: narg, ijarg, ierr, jt, jk, it, npiglo, npjglo, npk, npt, ncout
@@ -20,6 +21,11 @@ PROGRAM cdfvhst
   REAL(KIND=8), ALLOCATABLE :: dtim(:), dtrpt(:,:), dtrps(:,:)
   TYPE(variable) :: stypvar(4)
   TYPE(C_PTR) :: pe3u, pe3v, pe31d
+  TYPE(C_PTR) :: pd_t = C_NULL_PTR, pd_s = C_NULL_PTR, pd_e1v = C_NULL_PTR, pd_e2u = C_NULL_PTR, pd_e3u = C_NULL_PTR, pd_e3v = C_NULL_PTR
+  TYPE(C_PTR) :: pd_e31 = C_NULL_PTR
+  REAL(KIND=4), POINTER :: zt_d(:), zs_d(:), e1v_d(:), e2u_d(:)       ! device arrays of the host feed, never touched by the host
+  INTEGER(KIND=8) :: nij8, n38
+  LOGICAL :: lfeed
   CHARACTER(LEN=256) :: cf_vtfil = 'none', cf_out = 'trp.nc', cldum
   LOGICAL :: lfull = .FALSE., lnc4 = .FALSE., lchk = .FALSE., lchkvar = .FALSE.
   !!----------------------------------------------------------------------
@@ -87,16 +93,54 @@ PROGRAM cdfvhst
   PRINT *, 'npk    = ', npk
   PRINT *, 'npt    = ', npt
 
-  ALLOCATE( zt(npiglo,npjglo,npk), zs(npiglo,npjglo,npk), e1v(npiglo,npjglo), e2u(npiglo,npjglo) )
+  ! large fields: everything 3-D goes from the file to HBM through the page-locked ring (module cdffeed)
+  nij8 = INT(npiglo, 8) * npjglo ; n38 = nij8 * npk
+  lfeed = feed_wanted(4 * n38)
+  ALLOCATE( e1v(npiglo,npjglo), e2u(npiglo,npjglo) )
+  IF ( .NOT. lfeed ) ALLOCATE( zt(npiglo,npjglo,npk), zs(npiglo,npjglo,npk) )
   ALLOCATE( dtrpt(npiglo,npjglo), dtrps(npiglo,npjglo), dtim(npt), e31d(npk) )
-  IF ( .NOT. lfull ) ALLOCATE( e3u(npiglo,npjglo,npk), e3v(npiglo,npjglo,npk) )
+  IF ( .NOT. ( lfull .OR. lfeed ) ) ALLOCATE( e3u(npiglo,npjglo,npk), e3v(npiglo,npjglo,npk) )
   CALL CreateOutput
   e1v(:,:) = getvar(cn_fhgr, cn_ve1v, 1, npiglo, npjglo)
   e2u(:,:) = getvar(cn_fhgr, cn_ve2u, 1, npiglo, npjglo)
   e31d(:)  = getvare3(cn_fzgr, cn_ve3t1d, npk)
 
+  IF ( lfeed ) THEN
+     pd_t = feed_device(4 * n38) ; pd_s = feed_device(4 * n38) ; pd_e1v = feed_device(4 * nij8) ; pd_e2u = feed_device(4 * nij8)
+     CALL C_F_POINTER(pd_t, zt_d, (/ n38 /)) ; CALL C_F_POINTER(pd_s, zs_d, (/ n38 /))
+     CALL C_F_POINTER(pd_e1v, e1v_d, (/ nij8 /)) ; CALL C_F_POINTER(pd_e2u, e2u_d, (/ nij8 /))
+     CALL feed_host(C_LOC(e1v), 4 * nij8, pd_e1v) ; CALL feed_host(C_LOC(e2u), 4 * nij8, pd_e2u)
+     IF ( lfull ) THEN
+        pd_e31 = feed_device(4_8 * npk) ; CALL feed_host(C_LOC(e31d), 4_8 * npk, pd_e31)
+     ELSE
+        pd_e3u = feed_device(4 * n38) ; pd_e3v = feed_device(4 * n38)
+     ENDIF
+  ENDIF
+
   DO jt = 1, npt
      it = 1 ; IF ( lg_vvl ) it = jt
+     IF ( lfeed ) THEN
+        IF ( .NOT. lfull .AND. ( jt == 1 .OR. lg_vvl ) ) THEN
+           CALL feed_field(cn_fe3v, cn_ve3v, pd_e3v, npiglo, npjglo, npk, ktime=it, ldiom=.NOT. lg_vvl)
+           CALL feed_field(cn_fe3u, cn_ve3u, pd_e3u, npiglo, npjglo, npk, ktime=it, ldiom=.NOT. lg_vvl)
+        ENDIF
+        DO jk = 1, npk
+           PRINT *, 'level ', jk, ' time ', jt
+        END DO
+        CALL feed_field(cf_vtfil, cn_vomevt, pd_t, npiglo, npjglo, npk, ktime=jt)
+        CALL feed_field(cf_vtfil, cn_vomevs, pd_s, npiglo, npjglo, npk, ktime=jt)
+        CALL hip_check(cdft_vhst_transport(zt_d, zs_d, e1v_d, pd_e3v, pd_e31, npiglo, npjglo, npk, CDFT_MEM_DEVICE, dtrpt, dtrps, &
+             &         CDFT_MEM_HOST, feed_stream), 'cdft_vhst_transport')
+        ierr = putvar(ncout, id_varout(1), SNGL(dtrpt), 1, npiglo, npjglo, ktime=jt)
+        ierr = putvar(ncout, id_varout(2), SNGL(dtrps), 1, npiglo, npjglo, ktime=jt)
+        CALL feed_field(cf_vtfil, cn_vozout, pd_t, npiglo, npjglo, npk, ktime=jt)
+        CALL feed_field(cf_vtfil, cn_vozous, pd_s, npiglo, npjglo, npk, ktime=jt)
+        CALL hip_check(cdft_vhst_transport(zt_d, zs_d, e2u_d, pd_e3u, pd_e31, npiglo, npjglo, npk, CDFT_MEM_DEVICE, dtrpt, dtrps, &
+             &         CDFT_MEM_HOST, feed_stream), 'cdft_vhst_transport')
+        ierr = putvar(ncout, id_varout(3), SNGL(dtrpt), 1, npiglo, npjglo, ktime=jt)
+        ierr = putvar(ncout, id_varout(4), SNGL(dtrps), 1, npiglo, npjglo, ktime=jt)
+        CYCLE
+     ENDIF
      pe3u = C_NULL_PTR ; pe3v = C_NULL_PTR ; pe31d = C_NULL_PTR
      IF ( lfull ) THEN
         pe31d = C_LOC(e31d)
@@ -126,6 +170,10 @@ PROGRAM cdfvhst
      ierr = putvar(ncout, id_varout(4), SNGL(dtrps), 1, npiglo, npjglo, ktime=jt)
   END DO
   ierr = closeout(ncout)
+  IF ( lfeed ) THEN
+     CALL feed_release(pd_t) ; CALL feed_release(pd_s) ; CALL feed_release(pd_e1v) ; CALL feed_release(pd_e2u)
+     CALL feed_release(pd_e3u) ; CALL feed_release(pd_e3v) ; CALL feed_release(pd_e31) ; CALL feed_close()
+  ENDIF
 
 CONTAINS
 

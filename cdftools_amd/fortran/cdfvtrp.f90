@@ -13,6 +13,7 @@ PROGRAM cdfvtrp
   USE cdfio
   USE modcdfnames
   USE cdftools_hip
+  USE cdffeed
   IMPLICIT NONE
 
   INTEGER(KIND=4) :: narg, ijarg, ierr, jk, jt, it, npiglo, npjglo, npk, npt, ncout, nvarout = 2
@@ -23,6 +24,11 @@ PROGRAM cdfvtrp
   REAL(KIND=8), ALLOCATABLE :: dtim(:), dwku(:,:), dwkv(:,:), dtrpu(:,:), dtrpv(:,:)
   TYPE(variable), ALLOCATABLE :: stypvar(:)
   TYPE(C_PTR) :: pe3u, pe3v, pe31d
+  TYPE(C_PTR) :: pd_u = C_NULL_PTR, pd_v = C_NULL_PTR, pd_e1v = C_NULL_PTR, pd_e2u = C_NULL_PTR, pd_e3u = C_NULL_PTR, pd_e3v = C_NULL_PTR
+  TYPE(C_PTR) :: pd_e31 = C_NULL_PTR
+  REAL(KIND=4), POINTER :: zu_d(:), zv_d(:), e1v_d(:), e2u_d(:)       ! device arrays of the host feed, never touched by the host
+  INTEGER(KIND=8) :: nij8, n38
+  LOGICAL :: lfeed
   CHARACTER(LEN=256) :: cf_ufil = 'none', cf_vfil = 'none', cf_out = 'trp.nc', cldum
   CHARACTER(LEN=256) :: cv_soastrp = 'soastrp', cv_socstrp = 'socstrp'
   LOGICAL :: lfull = .FALSE., lbathy = .FALSE., lchk = .FALSE., lnc4 = .FALSE.
@@ -101,9 +107,13 @@ PROGRAM cdfvtrp
   PRINT *, 'npk    = ', npk
   PRINT *, 'npt    = ', npt
 
-  ALLOCATE( e1v(npiglo,npjglo), e2u(npiglo,npjglo), zu(npiglo,npjglo,npk), zv(npiglo,npjglo,npk) )
+  ! large fields: everything 3-D goes from the file to HBM through the page-locked ring (module cdffeed)
+  nij8 = INT(npiglo, 8) * npjglo ; n38 = nij8 * npk
+  lfeed = feed_wanted(4 * n38)
+  ALLOCATE( e1v(npiglo,npjglo), e2u(npiglo,npjglo) )
+  IF ( .NOT. lfeed ) ALLOCATE( zu(npiglo,npjglo,npk), zv(npiglo,npjglo,npk) )
   ALLOCATE( dwku(npiglo,npjglo), dwkv(npiglo,npjglo), dtrpu(npiglo,npjglo), dtrpv(npiglo,npjglo), e31d(npk), dtim(npt) )
-  IF ( .NOT. lfull ) ALLOCATE( e3u(npiglo,npjglo,npk), e3v(npiglo,npjglo,npk) )
+  IF ( .NOT. ( lfull .OR. lfeed ) ) ALLOCATE( e3u(npiglo,npjglo,npk), e3v(npiglo,npjglo,npk) )
   IF ( lbathy ) THEN
      ALLOCATE( e1u(npiglo,npjglo), e2v(npiglo,npjglo), tmask(npiglo,npjglo), hdepw(npiglo,npjglo) )
   ENDIF
@@ -118,10 +128,27 @@ PROGRAM cdfvtrp
      hdepw(:,:) = getvar(cn_fzgr, cn_hdepw, 1, npiglo, npjglo)
   ENDIF
 
+  IF ( lfeed ) THEN
+     pd_u = feed_device(4 * n38) ; pd_v = feed_device(4 * n38) ; pd_e1v = feed_device(4 * nij8) ; pd_e2u = feed_device(4 * nij8)
+     CALL C_F_POINTER(pd_u, zu_d, (/ n38 /)) ; CALL C_F_POINTER(pd_v, zv_d, (/ n38 /))
+     CALL C_F_POINTER(pd_e1v, e1v_d, (/ nij8 /)) ; CALL C_F_POINTER(pd_e2u, e2u_d, (/ nij8 /))
+     CALL feed_host(C_LOC(e1v), 4 * nij8, pd_e1v) ; CALL feed_host(C_LOC(e2u), 4 * nij8, pd_e2u)
+     IF ( lfull ) THEN
+        pd_e31 = feed_device(4_8 * npk) ; CALL feed_host(C_LOC(e31d), 4_8 * npk, pd_e31)
+     ELSE
+        pd_e3u = feed_device(4 * n38) ; pd_e3v = feed_device(4 * n38)
+     ENDIF
+  ENDIF
+
   DO jt = 1, npt
      it = 1 ; IF ( lg_vvl ) it = jt
      pe3u = C_NULL_PTR ; pe3v = C_NULL_PTR ; pe31d = C_NULL_PTR
-     IF ( lfull ) THEN
+     IF ( lfeed ) THEN
+        IF ( .NOT. lfull .AND. ( jt == 1 .OR. lg_vvl ) ) THEN
+           CALL feed_field(cn_fe3v, cn_ve3v, pd_e3v, npiglo, npjglo, npk, ktime=it, ldiom=.NOT. lg_vvl)
+           CALL feed_field(cn_fe3u, cn_ve3u, pd_e3u, npiglo, npjglo, npk, ktime=it, ldiom=.NOT. lg_vvl)
+        ENDIF
+     ELSE IF ( lfull ) THEN
         pe31d = C_LOC(e31d)
      ELSE
         IF ( jt == 1 .OR. lg_vvl ) THEN
@@ -133,12 +160,21 @@ PROGRAM cdfvtrp
      DO jk = 1, npk
         PRINT *, 'level ', jk
      END DO
+     IF ( lfeed ) THEN
+        CALL feed_field(cf_ufil, cn_vozocrtx, pd_u, npiglo, npjglo, npk, ktime=jt)
+        CALL hip_check(cdft_vint_transport(zu_d, e2u_d, pd_e3u, pd_e31, npiglo, npjglo, npk, CDFT_MEM_DEVICE, dtrpu, CDFT_MEM_HOST, &
+             &         feed_stream), 'cdft_vint_transport')
+        CALL feed_field(cf_vfil, cn_vomecrty, pd_v, npiglo, npjglo, npk, ktime=jt)
+        CALL hip_check(cdft_vint_transport(zv_d, e1v_d, pd_e3v, pd_e31, npiglo, npjglo, npk, CDFT_MEM_DEVICE, dtrpv, CDFT_MEM_HOST, &
+             &         feed_stream), 'cdft_vint_transport')
+     ELSE
      CALL readvar3d(cf_ufil, cn_vozocrtx, zu, ktime=jt)
      CALL readvar3d(cf_vfil, cn_vomecrty, zv, ktime=jt)
      CALL hip_check(cdft_vint_transport(zu, e2u, pe3u, pe31d, npiglo, npjglo, npk, CDFT_MEM_HOST, dtrpu, CDFT_MEM_HOST, &
           &         C_NULL_PTR), 'cdft_vint_transport')
      CALL hip_check(cdft_vint_transport(zv, e1v, pe3v, pe31d, npiglo, npjglo, npk, CDFT_MEM_HOST, dtrpv, CDFT_MEM_HOST, &
           &         C_NULL_PTR), 'cdft_vint_transport')
+     ENDIF
      ierr = putvar(ncout, id_varout(1), REAL(dtrpu(:,:)), 1, npiglo, npjglo, ktime=jt)
      ierr = putvar(ncout, id_varout(2), REAL(dtrpv(:,:)), 1, npiglo, npjglo, ktime=jt)
 
@@ -150,6 +186,10 @@ PROGRAM cdfvtrp
      ENDIF
   END DO
   ierr = closeout(ncout)
+  IF ( lfeed ) THEN
+     CALL feed_release(pd_u) ; CALL feed_release(pd_v) ; CALL feed_release(pd_e1v) ; CALL feed_release(pd_e2u)
+     CALL feed_release(pd_e3u) ; CALL feed_release(pd_e3v) ; CALL feed_release(pd_e31) ; CALL feed_close()
+  ENDIF
 
 CONTAINS
 

@@ -1,5 +1,5 @@
 """The host feed (module cdffeed, cdft_feed_* of the C ABI): the programs that have it -- cdfmoc, cdfheatc, cdfpsi, cdfvT,
-cdfmhst, cdfmocsig, cdfsig0, cdfsigi, cdfcurl, cdfmean, cdfsum -- send their 3-D fields from the file to HBM slab by slab through a page-locked ring when the fields are large
+cdfmhst, cdfmocsig, cdfsig0, cdfsigi, cdfcurl, cdfmean, cdfsum, cdfzonalsum, cdfzonalmean, cdfvhst, cdfvtrp -- send their 3-D fields from the file to HBM slab by slab through a page-locked ring when the fields are large
 (from 1 GiB on) and as whole records in pageable memory otherwise.  The route must not show: for every option that
 touches it, CDFT_FEED=1 and CDFT_FEED=0 give the same stdout and byte-identical files (the pageable route is the one the
 other program tests hold against the oracle).  A ring with one plane per slot and two slots (CDFT_FEED_MB / _SLOTS) makes
@@ -64,6 +64,13 @@ RUNS = [
     ("cdfmean", ["-f", T, "-v", "votemper", "-p", "T", "-zeromean", "-oz", "zm.nc"], ["cdfmean.nc", "zm.nc"]),
     ("cdfsum", ["-f", T, "-v", "votemper", "-p", "T"], ["cdfsum.nc"]),
     ("cdfsum", ["-f", V, "-v", "vomecrty", "-p", "V", "-w", "3", "20", "2", "15", "2", "4", "-M", "mask.nc", "umask", "-o", "w.nc"], ["w.nc"]),
+    ("cdfzonalsum", ["-f", T, "-p", "T", "-b", "new_maskglo.nc"], ["zonalsum.nc"]),
+    ("cdfzonalsum", ["-f", T, "-p", "T", "-l", "vosaline", "-pdeg", "-pdep"], ["zonalintdeg.nc"]),
+    ("cdfzonalmean", ["-f", T, "-p", "T", "-b", "new_maskglo.nc", "-max", "-l", "votemper"], ["zonalmean.nc"]),
+    ("cdfvhst", ["-f", "vt_keep.nc", "-o", "vh.nc"], ["vh.nc"]),
+    ("cdfvhst", ["-f", "vt_keep.nc", "-full", "-o", "vh.nc"], ["vh.nc"]),
+    ("cdfvtrp", ["-u", U, "-v", V, "-bathy", "-o", "tr.nc"], ["tr.nc"]),
+    ("cdfvtrp", ["-u", "VVL_y0001_gridU.nc", "-v", "VVL_y0001_gridV.nc", "-vvl", "-o", "tr.nc"], ["tr.nc"]),
     ("cdfsig0", ["-t", T], ["sig0.nc"]),                                                          # slabs in through the ring, out through page-locked arrays
     ("cdfsig0", ["-t", T, "-teos10"], ["sig0.nc"]),
     ("cdfsigi", ["-t", T, "-r", "2000"], ["sigi.nc"]),

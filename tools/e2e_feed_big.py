@@ -5,7 +5,7 @@ same file, at sizes where a record is 4.68 GB -- slab sizes, offsets and counts 
 level through the bundled backend; only what the program reads.  (cdfmoc and cdfheatc have their own tools, which also hold
 the result against the oracle.)
 
-    python tools/e2e_feed_big.py --tool psi|mhst|vt|mocsig|sig0|sigi|curl|mean [--grid eorca12] [--npt 2]      # on the GPU box; 20-30 GB of scratch files
+    python tools/e2e_feed_big.py --tool psi|mhst|vt|mocsig|sig0|sigi|curl|mean|zonal [--grid eorca12] [--npt 2]      # on the GPU box; 20-30 GB of scratch files
 """
 import argparse
 import hashlib
@@ -28,7 +28,7 @@ from e2e_cdfmoc_big import BYTE, DOUBLE, FLOAT, GRIDS, Writer  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--tool", required=True, choices=["psi", "mhst", "vt", "mocsig", "sig0", "sigi", "curl", "mean"])
+    ap.add_argument("--tool", required=True, choices=["psi", "mhst", "vt", "mocsig", "sig0", "sigi", "curl", "mean", "zonal"])
     ap.add_argument("--runs", type=int, default=2, help="runs per route (the first warms the page cache)")
     ap.add_argument("--grid", default="eorca12", choices=sorted(GRIDS))
     ap.add_argument("--npt", type=int, default=2)
@@ -49,14 +49,14 @@ def main():
     metric = lambda: (2000 + 26000 * rng.random((npj, npi), dtype=f32)).astype(f32)   # noqa: E731
 
     w = Writer(os.path.join(d, "mesh_hgr.nc"), [("t", None), ("y", npj), ("x", npi)])
-    names = ("e1v", "e2u", "glamf", "gphif", "gphiv") + (("e1u", "e2v", "e1f", "e2f") if args.tool == "curl" else ()) + (("e1t", "e2t") if args.tool == "mean" else ())
+    names = ("e1v", "e2u", "glamf", "gphif", "gphiv") + (("e1u", "e2v", "e1f", "e2f") if args.tool == "curl" else ()) + (("e1t", "e2t") if args.tool in ("mean", "zonal") else ()) + (("gphit",) if args.tool == "zonal" else ())
     for nm in names:
         w.define(nm, FLOAT, ("t", "y", "x"))
     w.enddef()
     for nm in names:
         w.put(nm, (0, 0, 0), lon if nm == "glamf" else lat if nm.startswith("gphi") else metric())
     w.close()
-    e3name = "e3u_0" if args.tool == "psi" else "e3t_0" if args.tool == "mean" else "e3v_0"
+    e3name = "e3u_0" if args.tool == "psi" else "e3t_0" if args.tool in ("mean", "zonal") else "e3v_0"
     wz = Writer(os.path.join(d, "mesh_zgr.nc"), [("t", None), ("z", npk), ("y", npj), ("x", npi)])
     wz.define("e3t_0", FLOAT, ("t", "z", "y", "x"))              # present (it selects the v3.6 layout), never read here
     if e3name != "e3t_0":
@@ -69,7 +69,7 @@ def main():
     wz.put("gdepw_1d", (0, 0), gdepw)
     wz.put("gdept_1d", (0, 0), (gdepw + 0.5 * e31d).astype(f32))
     wm = Writer(os.path.join(d, "mask.nc"), [("t", None), ("z", npk), ("y", npj), ("x", npi)])
-    masks = ("vmask", "fmask") + (("tmask",) if args.tool == "mean" else ())
+    masks = ("vmask", "fmask") + (("tmask",) if args.tool in ("mean", "zonal") else ())
     for nm in masks:
         wm.define(nm, BYTE, ("t", "z", "y", "x"))
     wm.enddef()
@@ -113,10 +113,15 @@ def main():
         files = {"T.nc": data_file("T.nc", "deptht", ["votemper", "vosaline"])}
         fields = []
         cmd = ["cdfsig0", "-t", "T.nc"] if args.tool == "sig0" else ["cdfsigi", "-t", "T.nc", "-r", "2000"]
-    elif args.tool == "mocsig":                                   # -isodep: the three-histogram kernel; 5 basins in i-bands
-        files = {"T.nc": data_file("T.nc", "deptht", ["votemper", "vosaline"]), "V.nc": data_file("V.nc", "depthv", ["vomecrty"])}
-        fields = [("V.nc", "vomecrty")]
-        cmd = ["cdfmocsig", "-v", "V.nc", "-t", "T.nc", "-r", "2000", "-isodep"]
+    elif args.tool in ("mocsig", "zonal"):                        # (mocsig -isodep: the three-histogram kernel); 5 basins in i-bands
+        if args.tool == "zonal":
+            files = {"T.nc": data_file("T.nc", "deptht", ["votemper"])}
+            fields = [("T.nc", "votemper")]
+            cmd = ["cdfzonalmean", "-f", "T.nc", "-p", "T", "-b", "new_maskglo.nc"]
+        else:
+            files = {"T.nc": data_file("T.nc", "deptht", ["votemper", "vosaline"]), "V.nc": data_file("V.nc", "depthv", ["vomecrty"])}
+            fields = [("V.nc", "vomecrty")]
+            cmd = ["cdfmocsig", "-v", "V.nc", "-t", "T.nc", "-r", "2000", "-isodep"]
         band = (np.arange(npi) * 3 // npi)[None, :]
         sea1 = mbathy > 0
         wb = Writer(os.path.join(d, "new_maskglo.nc"), [("y", npj), ("x", npi)])
