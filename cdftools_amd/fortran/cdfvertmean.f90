@@ -12,6 +12,7 @@ PROGRAM cdfvertmean
   USE modcdfnames
   USE modutils
   USE cdftools_hip
+  USE cdffeed
   IMPLICIT NONE
 
   INTEGER(KIND=4) :: jk, jvar, jvarin, jt, it, ik1, ik2, nlev, narg, ijarg, ierr, ncout, nvars, nvaro = 1
@@ -26,6 +27,10 @@ PROGRAM cdfvertmean
   CHARACTER(LEN=256), ALLOCATABLE :: cv_names(:), cv_in(:)
   TYPE(variable), ALLOCATABLE :: stypvarin(:), stypvar(:)
   TYPE(C_PTR) :: pe3, pe31d
+  TYPE(C_PTR) :: pd_zv = C_NULL_PTR, pd_msk = C_NULL_PTR, pd_e3 = C_NULL_PTR, pd_e31 = C_NULL_PTR
+  REAL(KIND=4), POINTER :: zv_d(:), zmask_d(:)                        ! device arrays of the host feed, never touched by the host
+  INTEGER(KIND=8) :: n38
+  LOGICAL :: lfeed
   LOGICAL :: lfull = .FALSE., ldebug = .FALSE., lnc4 = .FALSE., lchk
   !!----------------------------------------------------------------------
   CALL ReadCdfNames()
@@ -142,15 +147,40 @@ PROGRAM cdfvertmean
   PRINT '(a,2i10  )', 'nearest level found        : ', ik1, ik2
   PRINT '(a,2f10.3)', 'corresponding depth        : ', gdep(ik1), gdep(MIN(ik2+1, npk))
   nlev = ik2 - ik1 + 1
+  ! large fields: the levels ik1..ik2 of mask, e3 and every field from the file to HBM through the page-locked ring (cdffeed)
+  n38 = INT(npiglo, 8) * npjglo * nlev
+  lfeed = feed_wanted(4 * n38)
+  IF ( lfeed ) THEN
+     pd_zv = feed_device(4 * n38) ; pd_msk = feed_device(4 * n38)
+     CALL C_F_POINTER(pd_zv, zv_d, (/ n38 /)) ; CALL C_F_POINTER(pd_msk, zmask_d, (/ n38 /))
+     CALL feed_field(cn_fmsk, cv_msk, pd_msk, npiglo, npjglo, nlev, kimin=iimin, kjmin=ijmin, kkmin=ik1)
+     IF ( lfull ) THEN
+        pd_e31 = feed_device(4_8 * nlev) ; CALL feed_host(C_LOC(e31d(ik1)), 4_8 * nlev, pd_e31)
+     ELSE
+        pd_e3 = feed_device(4 * n38)
+     ENDIF
+  ELSE
   ALLOCATE( zv(npiglo,npjglo,nlev), zmask(npiglo,npjglo,nlev) )
   IF ( .NOT. lfull ) ALLOCATE( e3(npiglo,npjglo,nlev) )
   DO jk = ik1, ik2
      zmask(:,:,jk-ik1+1) = getvar(cn_fmsk, cv_msk, jk, npiglo, npjglo, kimin=iimin, kjmin=ijmin)
   END DO
+  ENDIF
 
   DO jt = 1, npt
      it = 1 ; IF ( lg_vvl ) it = jt
      pe3 = C_NULL_PTR ; pe31d = C_NULL_PTR
+     IF ( lfeed ) THEN
+        IF ( .NOT. lfull .AND. ( jt == 1 .OR. lg_vvl ) )  &
+             &  CALL feed_field(cf_e3, cv_e3, pd_e3, npiglo, npjglo, nlev, ktime=it, ldiom=.NOT. lg_vvl, kimin=iimin, kjmin=ijmin, kkmin=ik1)
+        DO jvar = 1, nvaro
+           CALL feed_field(cf_in, cv_in(jvar), pd_zv, npiglo, npjglo, nlev, ktime=jt, kimin=iimin, kjmin=ijmin, kkmin=ik1)
+           CALL hip_check(cdft_vertmean(zv_d, pd_e3, pd_e31, zmask_d, npiglo, npjglo, nlev, gdep(ik1), gdep(ik2), rdep_up, rdep_down, &
+                &         CDFT_MEM_DEVICE, dvertmean, CDFT_MEM_HOST, feed_stream), 'cdft_vertmean')
+           ierr = putvar(ncout, id_varout(jvar), REAL(dvertmean), 1, npiglo, npjglo, ktime=jt)
+        END DO
+        CYCLE
+     ENDIF
      IF ( lfull ) THEN
         pe31d = C_LOC(e31d(ik1))
      ELSE
@@ -172,6 +202,9 @@ PROGRAM cdfvertmean
      END DO
   END DO
   ierr = closeout(ncout)
+  IF ( lfeed ) THEN
+     CALL feed_release(pd_zv) ; CALL feed_release(pd_msk) ; CALL feed_release(pd_e3) ; CALL feed_release(pd_e31) ; CALL feed_close()
+  ENDIF
 
 CONTAINS
 

@@ -13,6 +13,7 @@ PROGRAM cdfvint
   USE cdfio
   USE modcdfnames
   USE cdftools_hip
+  USE cdffeed
   IMPLICIT NONE
 
   INTEGER(KIND=4) :: narg, ijarg, ierr, jk, jt, it, iko, npiglo, npjglo, npk, npko, npt, ncout
@@ -26,6 +27,10 @@ PROGRAM cdfvint
   CHARACTER(LEN=256) :: cf_in = 'none', cf_out, cv_in, cv_out, cunits, clongname, cldum
   TYPE(variable) :: stypvar(1)
   TYPE(C_PTR) :: pe3, pe31d
+  TYPE(C_PTR) :: pd_zt = C_NULL_PTR, pd_msk = C_NULL_PTR, pd_e3 = C_NULL_PTR, pd_e31 = C_NULL_PTR
+  REAL(KIND=4), POINTER :: zt_d(:), tmask_d(:)                        ! device arrays of the host feed, never touched by the host
+  INTEGER(KIND=8) :: n38
+  LOGICAL :: lfeed
   LOGICAL :: lfull = .FALSE., lgsop = .FALSE., locci = .FALSE., lchk, lout, ltmean = .FALSE., lsmean = .FALSE.
   LOGICAL :: lnc4 = .FALSE., lfout = .FALSE.
   !!----------------------------------------------------------------------
@@ -145,9 +150,14 @@ PROGRAM cdfvint
   PRINT *, ' NPKO   = ', npko
   PRINT *, ' NPT    = ', npt
 
-  ALLOCATE( dtim(npt), tmask(npiglo,npjglo,npk), rlon(npiglo,npjglo), rlat(npiglo,npjglo), zt(npiglo,npjglo,npk) )
+  ! large fields: mask, e3t and every record from the file to HBM through the page-locked ring (module cdffeed); the result
+  ! (npko levels) comes back as a host array
+  n38 = INT(npiglo, 8) * npjglo * npk
+  lfeed = feed_wanted(4 * n38)
+  ALLOCATE( dtim(npt), rlon(npiglo,npjglo), rlat(npiglo,npjglo) )
+  IF ( .NOT. lfeed ) ALLOCATE( tmask(npiglo,npjglo,npk), zt(npiglo,npjglo,npk) )
   ALLOCATE( e31d(npk), gdepw(npk), gdepo(npko), zout(npiglo,npjglo,npko), kout(npk), khit(npk), zclip(npk), zdiv(npk) )
-  IF ( .NOT. lfull ) ALLOCATE( e3t(npiglo,npjglo,npk) )
+  IF ( .NOT. ( lfull .OR. lfeed ) ) ALLOCATE( e3t(npiglo,npjglo,npk) )
   gdepw(:) = getvare3(cn_fzgr, cn_gdepw, npk)
   e31d(:)  = getvare3(cn_fzgr, cn_ve3t1d, npk)
   IF ( lgsop ) gdepo(:) = (/ 100., 300., 500., 700., 800., 2000., 6000. /)
@@ -161,7 +171,18 @@ PROGRAM cdfvint
   CALL CreateOutput
   PRINT *, 'OUTPUT DEPTHS ARE : ', gdepo
 
-  CALL readvar3d(cn_fmsk, cn_tmask, tmask, kimin=iimin, kjmin=ijmin)      ! (every level in one read)
+  IF ( lfeed ) THEN
+     pd_zt = feed_device(4 * n38) ; pd_msk = feed_device(4 * n38)
+     CALL C_F_POINTER(pd_zt, zt_d, (/ n38 /)) ; CALL C_F_POINTER(pd_msk, tmask_d, (/ n38 /))
+     CALL feed_field(cn_fmsk, cn_tmask, pd_msk, npiglo, npjglo, npk, kimin=iimin, kjmin=ijmin)
+     IF ( lfull ) THEN
+        pd_e31 = feed_device(4_8 * npk) ; CALL feed_host(C_LOC(e31d), 4_8 * npk, pd_e31)
+     ELSE
+        pd_e3 = feed_device(4 * n38)
+     ENDIF
+  ELSE
+     CALL readvar3d(cn_fmsk, cn_tmask, tmask, kimin=iimin, kjmin=ijmin)      ! (every level in one read)
+  ENDIF
 
   DO jt = 1, npt
      it = 1 ; IF ( lg_vvl ) it = jt
@@ -188,7 +209,13 @@ PROGRAM cdfvint
         ENDIF
      END DO
      pe3 = C_NULL_PTR ; pe31d = C_NULL_PTR
-     IF ( lfull ) THEN
+     IF ( lfeed ) THEN
+        IF ( .NOT. lfull .AND. ( jt == 1 .OR. lg_vvl ) )  &
+             &  CALL feed_field(cn_fe3t, cn_ve3t, pd_e3, npiglo, npjglo, npk, ktime=it, ldiom=.NOT. lg_vvl, kimin=iimin, kjmin=ijmin)
+        CALL feed_field(cf_in, cv_in, pd_zt, npiglo, npjglo, npk, ktime=jt, kimin=iimin, kjmin=ijmin)
+        CALL hip_check(cdft_vint_cumul(zt_d, pd_e3, pd_e31, tmask_d, npiglo, npjglo, npk, kout, khit, zclip, zdiv, npko, sclf, &
+             &         MERGE(1_C_INT, 0_C_INT, ltmean .OR. lsmean), CDFT_MEM_DEVICE, zout, CDFT_MEM_HOST, feed_stream), 'cdft_vint_cumul')
+     ELSE IF ( lfull ) THEN
         pe31d = C_LOC(e31d)
      ELSE
         IF ( jt == 1 .OR. lg_vvl ) THEN
@@ -196,14 +223,17 @@ PROGRAM cdfvint
         ENDIF
         pe3 = C_LOC(e3t)
      ENDIF
-     CALL readvar3d(cf_in, cv_in, zt, kimin=iimin, kjmin=ijmin, ktime=jt)
-     CALL hip_check(cdft_vint_cumul(zt, pe3, pe31d, tmask, npiglo, npjglo, npk, kout, khit, zclip, zdiv, npko, sclf, &
+     IF ( .NOT. lfeed ) CALL readvar3d(cf_in, cv_in, zt, kimin=iimin, kjmin=ijmin, ktime=jt)
+     IF ( .NOT. lfeed ) CALL hip_check(cdft_vint_cumul(zt, pe3, pe31d, tmask, npiglo, npjglo, npk, kout, khit, zclip, zdiv, npko, sclf, &
           &         MERGE(1_C_INT, 0_C_INT, ltmean .OR. lsmean), CDFT_MEM_HOST, zout, CDFT_MEM_HOST, C_NULL_PTR), 'cdft_vint_cumul')
      DO jk = 1, npk
         IF ( kout(jk) >= 0 ) ierr = putvar(ncout, id_varout(1), zout(:,:,kout(jk)+1), kout(jk)+1, npiglo, npjglo, ktime=jt)
      END DO
   END DO
   ierr = closeout(ncout)
+  IF ( lfeed ) THEN
+     CALL feed_release(pd_zt) ; CALL feed_release(pd_msk) ; CALL feed_release(pd_e3) ; CALL feed_release(pd_e31) ; CALL feed_close()
+  ENDIF
 
 CONTAINS
 

@@ -1,5 +1,5 @@
 """The host feed (module cdffeed, cdft_feed_* of the C ABI): the programs that have it -- cdfmoc, cdfheatc, cdfpsi, cdfvT,
-cdfmhst, cdfmocsig, cdfsig0, cdfsigi, cdfcurl, cdfmean, cdfsum, cdfzonalsum, cdfzonalmean, cdfvhst, cdfvtrp -- send their 3-D fields from the file to HBM slab by slab through a page-locked ring when the fields are large
+cdfmhst, cdfmocsig, cdfsig0, cdfsigi, cdfcurl, cdfmean, cdfsum, cdfzonalsum, cdfzonalmean, cdfvhst, cdfvtrp, cdfvint, cdfvertmean -- send their 3-D fields from the file to HBM slab by slab through a page-locked ring when the fields are large
 (from 1 GiB on) and as whole records in pageable memory otherwise.  The route must not show: for every option that
 touches it, CDFT_FEED=1 and CDFT_FEED=0 give the same stdout and byte-identical files (the pageable route is the one the
 other program tests hold against the oracle).  A ring with one plane per slot and two slots (CDFT_FEED_MB / _SLOTS) makes
@@ -71,6 +71,11 @@ RUNS = [
     ("cdfvhst", ["-f", "vt_keep.nc", "-full", "-o", "vh.nc"], ["vh.nc"]),
     ("cdfvtrp", ["-u", U, "-v", V, "-bathy", "-o", "tr.nc"], ["tr.nc"]),
     ("cdfvtrp", ["-u", "VVL_y0001_gridU.nc", "-v", "VVL_y0001_gridV.nc", "-vvl", "-o", "tr.nc"], ["tr.nc"]),
+    ("cdfvint", ["-f", T, "-o", "vi.nc"], ["vi.nc"]),
+    ("cdfvint", ["-f", T, "-v", "vosaline", "-OCCI", "-smean", "-full", "-w", "3", "20", "2", "15", "-o", "sm.nc"], ["sm.nc"]),
+    ("cdfvint", ["-f", "VVL_y0001_gridT.nc", "-vvl", "-o", "vi.nc"], ["vi.nc"]),
+    ("cdfvertmean", ["-f", T, "-l", "votemper,vosaline", "-p", "T", "-zlim", "15", "120"], ["vertmean.nc"]),
+    ("cdfvertmean", ["-f", T, "-l", "votemper", "-p", "T", "-zlim", "15", "120", "-full"], ["vertmean.nc"]),
     ("cdfsig0", ["-t", T], ["sig0.nc"]),                                                          # slabs in through the ring, out through page-locked arrays
     ("cdfsig0", ["-t", T, "-teos10"], ["sig0.nc"]),
     ("cdfsigi", ["-t", T, "-r", "2000"], ["sigi.nc"]),
