@@ -511,7 +511,7 @@ int cdft_vt_compute(const float *u, const float *v, const float *t, const float 
     void *hout[6] = {vt, vs, ut, us, e3um, e3vm}, *dout[6];
     for (int q = 0; q < 6; ++q) {
         dout[q] = hout[q];
-        if (out_space == CDFT_MEM_HOST && q < (vvl ? 6 : 4)) {
+        if ((out_space == CDFT_MEM_HOST || out_space == CDFT_MEM_PINNED) && q < (vvl ? 6 : 4)) {
             CDFT_TRY(g_out[q].reserve(n3 * esz));
             dout[q] = g_out[q].ptr;
         }
@@ -544,10 +544,10 @@ int cdft_vt_compute(const float *u, const float *v, const float *t, const float 
         else           hipLaunchKernelGGL((vt_kernel<false, double>), grid, block, 0, st, a);
     }
     CDFT_LAUNCH_CHECK();
-    if (out_space == CDFT_MEM_HOST) {
+    if (out_space == CDFT_MEM_HOST || out_space == CDFT_MEM_PINNED) {
         for (int q = 0; q < (vvl ? 6 : 4); ++q)
             CDFT_HIP(hipMemcpyAsync(hout[q], dout[q], n3 * esz, hipMemcpyDeviceToHost, st));
-        CDFT_HIP(hipStreamSynchronize(st));
+        if (out_space == CDFT_MEM_HOST) CDFT_HIP(hipStreamSynchronize(st));      // (page-locked: on their way when the call returns)
     }
     return CDFT_OK;
 }

@@ -29,6 +29,9 @@ PROGRAM cdfvT
   CHARACTER(LEN=256), ALLOCATABLE :: ctag_lst(:)
   TYPE(variable), ALLOCATABLE :: stypvar(:)
   TYPE(C_PTR) :: pe3u, pe3v, pe3um, pe3vm
+  TYPE(C_PTR) :: ph_out(6,2) = C_NULL_PTR                        ! the host feed's two sets of page-locked r4 results
+  REAL(KIND=4), POINTER :: zout_h(:,:)
+  INTEGER(KIND=4) :: nqo
   ! the frames of one level in HBM when they are fed there through the ring (module cdffeed): never touched by the host
   TYPE(C_PTR) :: pd_u = C_NULL_PTR, pd_v = C_NULL_PTR, pd_t = C_NULL_PTR, pd_s = C_NULL_PTR, pd_e3u = C_NULL_PTR, pd_e3v = C_NULL_PTR
   REAL(KIND=4), POINTER :: zu_d(:), zv_d(:), zt_d(:), zs_d(:)
@@ -136,7 +139,37 @@ PROGRAM cdfvT
   cf_tfil = SetFileName(config, ctag_lst(1), 'T')
   CALL CreateOutput
 
+  IF ( lfeed ) THEN
+     ! Level k+1 is read (its frames leave for HBM slab by slab) and computed while level k is on its way to the host and to
+     ! the file.  The means come back as r4 -- what NetCDF stores in the float variables when the reference hands it the r8
+     ! arrays (the same rounding, done on the GPU: half the bytes over PCIe, no conversion in the writer) -- into two sets of
+     ! page-locked arrays.
+     nqo = 4 ; IF ( lg_vvl ) nqo = 6
+     DO jt = 1, nqo
+        CALL hip_check(cdft_host_alloc(ph_out(jt,1), INT(4_8 * npiglo * npjglo, C_SIZE_T)), 'cdft_host_alloc')
+        CALL hip_check(cdft_host_alloc(ph_out(jt,2), INT(4_8 * npiglo * npjglo, C_SIZE_T)), 'cdft_host_alloc')
+     END DO
+     CALL load_level(1) ; CALL compute_level(1)
+     DO jk = 1, npk
+        IF ( jk < npk ) CALL load_level(jk + 1)
+        CALL hip_check(cdft_stream_sync(feed_stream), 'cdft_stream_sync')
+        IF ( jk < npk ) CALL compute_level(jk + 1)
+        DO jt = 1, nqo
+           CALL C_F_POINTER(ph_out(jt, 1 + MOD(jk - 1, 2)), zout_h, (/ npiglo, npjglo /))
+           ierr = putvar(ncout, id_varout(jt), zout_h, jk, npiglo, npjglo, kwght=ntframe)
+        END DO
+        IF ( jk == 1 ) THEN
+           dtimean(1) = dtotal_time / ntframe
+           ierr = putvar1d(ncout, dtimean, 1, 'T')
+        ENDIF
+     END DO
+     DO jt = 1, nqo
+        ierr = cdft_host_free(ph_out(jt,1)) ; ierr = cdft_host_free(ph_out(jt,2))
+     END DO
+  ENDIF
+
   DO jk = 1, npk
+     IF ( lfeed ) EXIT
      PRINT *, 'level ', jk
      ifr = 0
      DO jt = 1, ntags
@@ -147,17 +180,6 @@ PROGRAM cdfvT
         cf_vfil = SetFileName(config, ctag_lst(jt), 'V')
         DO jtt = 1, nptag(jt)
            ifr = ifr + 1
-           IF ( lfeed ) THEN                              ! the slab leaves for HBM while the next one is read
-              CALL feed_field(cf_ufil, cn_vozocrtx, pd_u, npiglo, npjglo, 1, ktime=jtt, kkmin=jk, kplane=ifr)
-              CALL feed_field(cf_vfil, cn_vomecrty, pd_v, npiglo, npjglo, 1, ktime=jtt, kkmin=jk, kplane=ifr)
-              CALL feed_field(cf_tfil, cn_votemper, pd_t, npiglo, npjglo, 1, ktime=jtt, kkmin=jk, kplane=ifr)
-              CALL feed_field(cf_sfil, cn_vosaline, pd_s, npiglo, npjglo, 1, ktime=jtt, kkmin=jk, kplane=ifr)
-              IF ( lg_vvl ) THEN
-                 CALL feed_field(cf_ufil, cn_ve3u, pd_e3u, npiglo, npjglo, 1, ktime=jtt, kkmin=jk, kplane=ifr)
-                 CALL feed_field(cf_vfil, cn_ve3v, pd_e3v, npiglo, npjglo, 1, ktime=jtt, kkmin=jk, kplane=ifr)
-              ENDIF
-              CYCLE
-           ENDIF
            zu(:,:,ifr) = getvar(cf_ufil, cn_vozocrtx, jk, npiglo, npjglo, ktime=jtt)
            zv(:,:,ifr) = getvar(cf_vfil, cn_vomecrty, jk, npiglo, npjglo, ktime=jtt)
            zt(:,:,ifr) = getvar(cf_tfil, cn_votemper, jk, npiglo, npjglo, ktime=jtt)
@@ -172,10 +194,6 @@ PROGRAM cdfvT
         CALL hip_check(cdft_vt_compute_sharded(zu, zv, zt, zs, pe3u, pe3v, INT(npiglo, C_INT64_T) * npjglo, ntframe, npiglo,  &
              &         npjglo, 1_C_INT, C_LOC(dvt), C_LOC(dvs), C_LOC(dut), C_LOC(dus), pe3um, pe3vm, 0_C_INT, ngpu, igpus),  &
              &         'cdft_vt_compute_sharded')
-     ELSE IF ( lfeed ) THEN
-        CALL hip_check(cdft_vt_compute(zu_d, zv_d, zt_d, zs_d, pe3u, pe3v, INT(npiglo, C_INT64_T) * npjglo, ntframe, npiglo, npjglo, &
-             &         1_C_INT, CDFT_MEM_DEVICE, C_LOC(dvt), C_LOC(dvs), C_LOC(dut), C_LOC(dus), pe3um, pe3vm, 0_C_INT,              &
-             &         CDFT_MEM_HOST, feed_stream), 'cdft_vt_compute')
      ELSE
      CALL hip_check(cdft_vt_compute(zu, zv, zt, zs, pe3u, pe3v, INT(npiglo, C_INT64_T) * npjglo, ntframe, npiglo, npjglo,   &
           &         1_C_INT, CDFT_MEM_HOST, C_LOC(dvt), C_LOC(dvs), C_LOC(dut), C_LOC(dus), pe3um, pe3vm, 0_C_INT,         &
@@ -202,6 +220,45 @@ PROGRAM cdfvT
   ierr = closeout(ncout)
 
 CONTAINS
+
+  SUBROUTINE load_level(kk)
+    !! every frame of level kk (all tags, src/cdfvT.f90:168-196) from the files to HBM through the ring
+    INTEGER(KIND=4), INTENT(in) :: kk
+    INTEGER(KIND=4) :: jtg, jfr, ifrm
+    PRINT *, 'level ', kk
+    ifrm = 0
+    DO jtg = 1, ntags
+       cf_tfil = SetFileName(config, ctag_lst(jtg), 'T', ld_stop=.TRUE.)
+       cf_sfil = SetFileName(config, ctag_lst(jtg), 'S', ld_stop=.FALSE.)
+       IF ( chkfile(cf_sfil, ld_verbose=.FALSE.) ) cf_sfil = cf_tfil      ! salinity in the T file
+       cf_ufil = SetFileName(config, ctag_lst(jtg), 'U')
+       cf_vfil = SetFileName(config, ctag_lst(jtg), 'V')
+       DO jfr = 1, nptag(jtg)
+          ifrm = ifrm + 1
+          CALL feed_field(cf_ufil, cn_vozocrtx, pd_u, npiglo, npjglo, 1, ktime=jfr, kkmin=kk, kplane=ifrm)
+          CALL feed_field(cf_vfil, cn_vomecrty, pd_v, npiglo, npjglo, 1, ktime=jfr, kkmin=kk, kplane=ifrm)
+          CALL feed_field(cf_tfil, cn_votemper, pd_t, npiglo, npjglo, 1, ktime=jfr, kkmin=kk, kplane=ifrm)
+          CALL feed_field(cf_sfil, cn_vosaline, pd_s, npiglo, npjglo, 1, ktime=jfr, kkmin=kk, kplane=ifrm)
+          IF ( lg_vvl ) THEN
+             CALL feed_field(cf_ufil, cn_ve3u, pd_e3u, npiglo, npjglo, 1, ktime=jfr, kkmin=kk, kplane=ifrm)
+             CALL feed_field(cf_vfil, cn_ve3v, pd_e3v, npiglo, npjglo, 1, ktime=jfr, kkmin=kk, kplane=ifrm)
+          ENDIF
+       END DO
+    END DO
+  END SUBROUTINE load_level
+
+  SUBROUTINE compute_level(kk)
+    !! queued behind the copies of load_level(kk); the r4 means on their way to the page-locked arrays of kk's parity
+    INTEGER(KIND=4), INTENT(in) :: kk
+    INTEGER(KIND=4) :: ib
+    TYPE(C_PTR) :: pm5, pm6
+    ib = 1 + MOD(kk - 1, 2)
+    pm5 = C_NULL_PTR ; pm6 = C_NULL_PTR
+    IF ( lg_vvl ) THEN ; pm5 = ph_out(5,ib) ; pm6 = ph_out(6,ib) ; ENDIF
+    CALL hip_check(cdft_vt_compute(zu_d, zv_d, zt_d, zs_d, pe3u, pe3v, INT(npiglo, C_INT64_T) * npjglo, ntframe, npiglo, npjglo, &
+         &         1_C_INT, CDFT_MEM_DEVICE, ph_out(1,ib), ph_out(2,ib), ph_out(3,ib), ph_out(4,ib), pm5, pm6, 1_C_INT,           &
+         &         CDFT_MEM_PINNED, feed_stream), 'cdft_vt_compute')
+  END SUBROUTINE compute_level
 
   SUBROUTINE GetTagList
     !! every argument up to the next option is a tag (src/cdfvT.f90:312-339)

@@ -895,10 +895,30 @@ static ssize_t pread_all(int fd, void *buf, size_t n, off_t off) {
 /* A large same-type read is split over a few threads, each reading and byte-swapping its own part: one thread
  * moves ~2 GB/s out of the page cache, and the tools read whole records (hundreds of MB) at a time. */
 #include <pthread.h>
-typedef struct { int fd; unsigned char *mem; size_t bytes, xs; off_t off; ssize_t got; } ReadJob;
+/* (xtype != memtype: a conversion on the way -- a byte mask read as r4, an r8 variable as r4 -- done from the same cache-resident
+ * buffer, so a mask read as r4 costs its bytes read and its floats written, on every thread; ms = size of the memory type) */
+typedef struct { int fd; unsigned char *mem; size_t bytes, xs; off_t off; ssize_t got; int xtype, memtype; size_t ms; } ReadJob;
 
 static void *read_job(void *arg) {
     ReadJob *j = (ReadJob *)arg;
+    if (j->xtype != j->memtype) {                        /* read, swap in the buffer, convert into place */
+        enum { kCBuf = 256 * 1024 };
+        unsigned char *cb = (unsigned char *)malloc(kCBuf);
+        j->got = 0;
+        if (!cb) { j->got = -1; return NULL; }
+        const size_t step = (size_t)kCBuf / j->xs * j->xs;
+        for (size_t done = 0; done < j->bytes; done += step) {
+            const size_t n = j->bytes - done < step ? j->bytes - done : step;
+            const ssize_t g = pread_all(j->fd, cb, n, j->off + (off_t)done);
+            if (g < 0) { j->got = -1; break; }
+            if ((size_t)g < n) memset(cb + g, 0, n - (size_t)g);
+            if (j->xs > 1) bswap_copy(cb, cb, n / j->xs, j->xs);
+            convert(j->mem + done / j->xs * j->ms, j->memtype, cb, j->xtype, n / j->xs);
+            j->got += g;
+        }
+        free(cb);
+        return NULL;
+    }
     if (j->xs == 1) {                                    /* bytes: straight into place */
         j->got = pread_all(j->fd, j->mem, j->bytes, j->off);
         if (j->got >= 0 && (size_t)j->got < j->bytes) memset(j->mem + j->got, 0, j->bytes - (size_t)j->got);
@@ -933,9 +953,9 @@ static void *read_job(void *arg) {
     return NULL;
 }
 
-static int read_run_parallel(int fd, unsigned char *mem, size_t bytes, size_t xs, off_t off) {
+static int read_run_parallel(int fd, unsigned char *mem, size_t bytes, size_t xs, off_t off, int xtype, int memtype, size_t ms) {
     enum { kMaxThreads = 32 };
-    const size_t kMinPart = (size_t)16 << 20;
+    const size_t kMinPart = (size_t)(xtype != memtype && xs < ms ? 4 : 16) << 20;        /* (file bytes per thread) */
     int nt = (int)(bytes / kMinPart);
     /* default: up to 16 threads, not more than the processors that are online (8 moved 28 GB/s out of the page cache on the
      * 128-core host of the GPU box -- less than the 57 GB/s the copy to the GPU takes them at); CDFT_IO_THREADS = 1 .. 32 */
@@ -946,7 +966,7 @@ static int read_run_parallel(int fd, unsigned char *mem, size_t bytes, size_t xs
     if (env && *env) { const int e = atoi(env); if (e >= 1) cap = e < kMaxThreads ? e : kMaxThreads; }
     if (nt > cap) nt = cap;
     if (nt < 2) {
-        ReadJob j = {fd, mem, bytes, xs, off, 0};
+        ReadJob j = {fd, mem, bytes, xs, off, 0, xtype, memtype, ms};
         read_job(&j);
         return j.got < 0 ? NCC_EIO : 0;
     }
@@ -957,7 +977,7 @@ static int read_run_parallel(int fd, unsigned char *mem, size_t bytes, size_t xs
     int rc = 0;
     for (int t = 0; t < nt; ++t) {
         const size_t e0 = per * (size_t)t, e1 = e0 + per < nel ? e0 + per : nel;
-        jobs[t] = (ReadJob){fd, mem + e0 * xs, e0 < e1 ? (e1 - e0) * xs : 0, xs, off + (off_t)(e0 * xs), 0};
+        jobs[t] = (ReadJob){fd, mem + e0 * (xtype != memtype ? ms : xs), e0 < e1 ? (e1 - e0) * xs : 0, xs, off + (off_t)(e0 * xs), 0, xtype, memtype, ms};
         if (jobs[t].bytes == 0) continue;
         if (t == nt - 1 || pthread_create(&th[t], NULL, read_job, &jobs[t]) != 0) read_job(&jobs[t]);   /* inline */
         else started[t] = 1;
@@ -972,7 +992,7 @@ static int read_run_parallel(int fd, unsigned char *mem, size_t bytes, size_t xs
 /* The same for writes of the external type: each thread swaps its part through a cache-resident buffer and writes it at its
  * place (before: one thread, a temporary as large as the slab allocated and faulted in at every call, 1.6 GB/s into the page
  * cache -- 12 of the 13.6 s cdfvT took on an eORCA12 record were its four 4.7 GB outputs). */
-typedef struct { int fd; const unsigned char *mem; size_t bytes, xs; off_t off; int rc; } WriteJob;
+typedef struct { int fd; const unsigned char *mem; size_t bytes, xs; off_t off; int rc; int xtype, memtype; size_t ms; } WriteJob;   /* bytes: of the file */
 
 static int pwrite_all(int fd, const void *buf, size_t n, off_t off) {
     size_t put = 0;                                      /* (a single pwrite stops near 2 GiB) */
@@ -988,6 +1008,20 @@ static int pwrite_all(int fd, const void *buf, size_t n, off_t off) {
 static void *write_job(void *arg) {
     WriteJob *j = (WriteJob *)arg;
     j->rc = 0;
+    if (j->xtype != j->memtype) {                        /* convert into the buffer, swap there, write (r8 results into float variables) */
+        enum { kCBuf = 256 * 1024 };
+        unsigned char *cb = (unsigned char *)malloc(kCBuf);
+        if (!cb) { j->rc = NCC_ENOMEM; return NULL; }
+        const size_t step = (size_t)kCBuf / j->xs * j->xs;
+        for (size_t done = 0; done < j->bytes; done += step) {
+            const size_t n = j->bytes - done < step ? j->bytes - done : step;
+            convert(cb, j->xtype, j->mem + done / j->xs * j->ms, j->memtype, n / j->xs);
+            if (j->xs > 1) bswap_copy(cb, cb, n / j->xs, j->xs);
+            if (pwrite_all(j->fd, cb, n, j->off + (off_t)done)) { j->rc = NCC_EIO; break; }
+        }
+        free(cb);
+        return NULL;
+    }
     if (j->xs == 1) { if (pwrite_all(j->fd, j->mem, j->bytes, j->off)) j->rc = NCC_EIO; return NULL; }
     enum { kBuf = 256 * 1024 };
     unsigned char *buf = (unsigned char *)malloc(kBuf);
@@ -1002,7 +1036,7 @@ static void *write_job(void *arg) {
     return NULL;
 }
 
-static int write_run_parallel(int fd, const unsigned char *mem, size_t bytes, size_t xs, off_t off) {
+static int write_run_parallel(int fd, const unsigned char *mem, size_t bytes, size_t xs, off_t off, int xtype, int memtype, size_t ms) {
     enum { kMaxThreads = 32 };
     const size_t kMinPart = (size_t)8 << 20;
     int nt = (int)(bytes / kMinPart);
@@ -1013,7 +1047,7 @@ static int write_run_parallel(int fd, const unsigned char *mem, size_t bytes, si
     if (env && *env) { const int e = atoi(env); if (e >= 1) cap = e < kMaxThreads ? e : kMaxThreads; }
     if (nt > cap) nt = cap;
     if (nt < 2) {
-        WriteJob j = {fd, mem, bytes, xs, off, 0};
+        WriteJob j = {fd, mem, bytes, xs, off, 0, xtype, memtype, ms};
         write_job(&j);
         return j.rc;
     }
@@ -1024,7 +1058,7 @@ static int write_run_parallel(int fd, const unsigned char *mem, size_t bytes, si
     int rc = 0;
     for (int t = 0; t < nt; ++t) {
         const size_t e0 = per * (size_t)t, e1 = e0 + per < nel ? e0 + per : nel;
-        jobs[t] = (WriteJob){fd, mem + e0 * xs, e0 < e1 ? (e1 - e0) * xs : 0, xs, off + (off_t)(e0 * xs), 0};
+        jobs[t] = (WriteJob){fd, mem + e0 * (xtype != memtype ? ms : xs), e0 < e1 ? (e1 - e0) * xs : 0, xs, off + (off_t)(e0 * xs), 0, xtype, memtype, ms};
         if (jobs[t].bytes == 0) continue;
         if (t == nt - 1 || pthread_create(&th[t], NULL, write_job, &jobs[t]) != 0) write_job(&jobs[t]);   /* inline */
         else started[t] = 1;
@@ -1089,48 +1123,22 @@ static int vara(int ncid, int varid, const size_t *start, const size_t *count, i
     const int nouter = last;
     uint64_t idx[NCC_MAX_DIMS + 1] = {0};
     const size_t tmpn = (size_t)run * xs;
-    unsigned char *tmp = NULL, *conv = NULL;
-    if (v->type != memtype && !(xs == 1 && ms == 1)) {       /* a conversion: the slab goes through two temporaries */
-        tmp = (unsigned char *)malloc(tmpn ? tmpn : 1);
-        if (!tmp) return NCC_ENOMEM;
-        conv = (unsigned char *)malloc((size_t)run * (xs > ms ? xs : ms)); if (!conv) { free(tmp); return NCC_ENOMEM; }
-    }
+    /* a conversion (v->type != memtype, other than between the two byte types): done by the threads that read or write, each
+     * through its cache-resident buffer -- no slab-sized temporaries (there were two, allocated and faulted in at every call) */
+    const int xt = (xs == 1 && ms == 1) ? memtype : v->type;
     unsigned char *mem = (unsigned char *)data;
     int rc = 0;
     for (;;) {
         uint64_t off = v->begin + (last < nd ? st[last] * stride[last] : 0);
         for (int d = 0; d < nouter; ++d) off += (st[d] + idx[d]) * stride[d];
-        if (writing && !conv) {                 /* the external type: swapped and written by parts, no temporary */
-            rc = write_run_parallel(f->fd, mem, tmpn, xs, (off_t)off);
-            if (rc) break;
-        } else if (writing) {
-            const void *src = mem;
-            convert(conv, v->type, mem, memtype, (size_t)run); src = conv;
-            bswap_copy(tmp, src, (size_t)run, xs);
-            size_t put = 0;                                          /* (a single pwrite stops near 2 GiB) */
-            while (put < tmpn) {
-                const ssize_t g = pwrite(f->fd, tmp + put, tmpn - put, (off_t)(off + put));
-                if (g < 0 && errno == EINTR) continue;
-                if (g <= 0) break;
-                put += (size_t)g;
-            }
-            if (put != tmpn) { rc = NCC_EIO; break; }
-        } else if (!conv) {                     /* same type: read in place, then swap; a never-written tail reads as 0 */
-            rc = read_run_parallel(f->fd, mem, tmpn, xs, (off_t)off);
-            if (rc) break;
-        } else {
-            ssize_t g = pread_all(f->fd, tmp, tmpn, (off_t)off);
-            if (g < 0) { rc = NCC_EIO; break; }
-            if ((size_t)g < tmpn) memset(tmp + g, 0, tmpn - g);
-            bswap_copy(conv, tmp, (size_t)run, xs);
-            convert(mem, memtype, conv, v->type, (size_t)run);
-        }
+        if (writing) rc = write_run_parallel(f->fd, mem, tmpn, xs, (off_t)off, xt, memtype, ms);   /* swapped [converted] and written by parts */
+        else         rc = read_run_parallel(f->fd, mem, tmpn, xs, (off_t)off, xt, memtype, ms);    /* a never-written tail reads as 0 */
+        if (rc) break;
         mem += (size_t)run * ms;
         int d = nouter - 1;
         while (d >= 0 && ++idx[d] == ct[d]) { idx[d] = 0; --d; }
         if (d < 0) break;
     }
-    free(tmp); free(conv);
     if (!rc && writing) {
         f->has_data = 1;
         if (v->isrec && st[0] + ct[0] > f->numrecs) { f->numrecs = st[0] + ct[0]; f->nrec_dirty = 1; }

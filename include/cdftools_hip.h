@@ -533,7 +533,9 @@ int cdft_psi_destroy(cdft_psi_plan *plan);
  * tags concatenated, :168-191).  e3u, e3v: same shape with -vvl, else NULL (:193-196).
  * Outputs (npiglo,npjglo,npk), r8 (out_is_r4 = 0: the array handed to putvar, :247-250) or r4
  * (out_is_r4 = 1: what NetCDF stores in the float variable): vt, vs, ut, us, and with -vvl the
- * mean e3u, e3v (e3um, e3vm; NULL otherwise).  Call with npk = 1 to work level by level. */
+ * mean e3u, e3v (e3um, e3vm; NULL otherwise).  Call with npk = 1 to work level by level.
+ * out_space = CDFT_MEM_PINNED (outputs from cdft_host_alloc): on their way when the call returns, cdft_stream_sync(stream)
+ * before reading them -- the program writes level k while level k+1 is read and computed. */
 int cdft_vt_compute(const float *u, const float *v, const float *t, const float *s, const float *e3u,
                     const float *e3v, int64_t fstride, int nframes, int npiglo, int npjglo, int npk,
                     int in_space, void *vt, void *vs, void *ut, void *us, void *e3um, void *e3vm,

@@ -250,6 +250,19 @@ def test_large_reads_split_over_threads_and_swapped_through_a_buffer(nc, tmp_pat
         part = np.empty(a.size - lo - 5, a.dtype)
         ok(nc, nc.ncc_get_vara(ncid, vid, sz(lo), sz(part.size), mt[name], part.ctypes.data_as(C.c_void_p)))
         assert np.array_equal(part, a[lo:lo + part.size]), name
+    # conversions on the way, done by the same threads from the same buffers: a byte mask and an i2 variable read as r4, r8 as
+    # r4 (rounded as the C cast rounds), r4 as r8; whole and from inside the variable
+    for name, memtype, dt in (("a1", FLOAT, np.float32), ("a2", FLOAT, np.float32), ("a8", FLOAT, np.float32), ("a4", DOUBLE, np.float64)):
+        a = arrays[name]
+        vid = C.c_int()
+        ok(nc, nc.ncc_inq_varid(ncid, name.encode(), C.byref(vid)))
+        got = np.empty(a.size, dt)
+        ok(nc, nc.ncc_get_vara(ncid, vid, sz(0), sz(a.size), memtype, got.ctypes.data_as(C.c_void_p)))
+        assert np.array_equal(got, a.astype(dt)), name
+        lo = 777_777
+        part = np.empty(a.size - lo - 3, dt)
+        ok(nc, nc.ncc_get_vara(ncid, vid, sz(lo), sz(part.size), memtype, part.ctypes.data_as(C.c_void_p)))
+        assert np.array_equal(part, a[lo:lo + part.size].astype(dt)), name
     ok(nc, nc.ncc_close(ncid))
 
 
@@ -262,7 +275,10 @@ def test_large_writes_split_over_threads_are_what_scipy_reads(nc, tmp_path, monk
     path = str(tmp_path / "bigw.nc")
     rng = np.random.default_rng(23)
     arrays = {"a4": rng.random(9_000_037, dtype=np.float32), "a8": rng.random(4_400_013), "a1": rng.integers(-100, 100, 20_000_003).astype(np.int8)}
-    mt = {"a4": FLOAT, "a8": DOUBLE, "a1": BYTE}
+    mt = {"a4": FLOAT, "a8": DOUBLE, "a1": BYTE, "c4": FLOAT, "c2": SHORT}
+    # conversions on the way out: r8 results into a float variable (what the programs' putvar of an r8 array does), r4 into i2
+    given = {"c4": (rng.random(9_100_019) * 1e3, DOUBLE), "c2": (rng.integers(-30000, 30000, 17_000_005).astype(np.float32), FLOAT)}
+    arrays.update({"c4": given["c4"][0].astype(np.float32), "c2": given["c2"][0].astype(np.int16)})
     ncid = C.c_int()
     ok(nc, nc.ncc_create(path.encode(), 2, 1, C.byref(ncid)))
     vid = {}
@@ -273,7 +289,11 @@ def test_large_writes_split_over_threads_are_what_scipy_reads(nc, tmp_path, monk
         vid[name] = v.value
     ok(nc, nc.ncc_enddef(ncid))
     for name, a in arrays.items():
-        ok(nc, nc.ncc_put_vara(ncid, vid[name], sz(0), sz(a.size), mt[name], a.ctypes.data_as(C.c_void_p)))
+        src, memtype = given.get(name, (a, mt[name]))
+        ok(nc, nc.ncc_put_vara(ncid, vid[name], sz(0), sz(a.size), memtype, src.ctypes.data_as(C.c_void_p)))
+    patch8 = np.arange(8_400_003, dtype=np.float64) / 7                    # an r8 window into the middle of the float variable
+    ok(nc, nc.ncc_put_vara(ncid, vid["c4"], sz(54_321), sz(patch8.size), DOUBLE, patch8.ctypes.data_as(C.c_void_p)))
+    arrays["c4"][54_321:54_321 + patch8.size] = patch8.astype(np.float32)
     patch = np.arange(8_500_001, dtype=np.float32)                         # a second write over the middle of a4
     ok(nc, nc.ncc_put_vara(ncid, vid["a4"], sz(123_457), sz(patch.size), FLOAT, patch.ctypes.data_as(C.c_void_p)))
     ok(nc, nc.ncc_close(ncid))
