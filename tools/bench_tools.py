@@ -238,6 +238,17 @@ def main():
                 report("cdfmocsig (158 classes, 5 basins, %s T,S, %s land)" % ("smooth" if smooth else "white-noise", land), args.grid, n3, 16.0, ms,
                        "v,T,S,e3v 16 B per cell; sigma2 needs all four polynomials of the EOS; a wave whose 256 cells all carry a zero transport skips it",
                        fp64=fp64_ops("mocsig_" + land, args.grid, "mocsig_class_kernel<5, 0, 256, 2, 0>" if npi > 2048 else "mocsig_class_kernel<2, 0, 256, 2, 0>") if smooth else None)
+                if smooth and land == "noise":      # the options that used to leave the vector-load kernel: -eiv (a fifth stream), -isodep
+                    eiv = (f["zv"] * 0.1).contiguous()
+                    ms = timed(lambda: hip.mocsig(f["zv"], f["zt"], f["zs"], f["e1"], f["ib"], 158, 30.0, 0.05, pref=2000.0, e3v=f["e3"], zveiv=eiv), args.reps)
+                    report("cdfmocsig -eiv (158 classes, 5 basins, smooth T,S, noise land)", args.grid, n3, 20.0, ms,
+                           "v,veiv,T,S,e3v 20 B per cell; the class kernel with the eddy-induced velocity as a fifth vector stream")
+                    del eiv
+                    gdep = -np.linspace(0.5, 5800.0, npk).astype(np.float32)
+                    ms = timed(lambda: hip.mocsig(f["zv"], f["zt"], f["zs"], f["e1"], f["ib"], 158, 30.0, 0.05, pref=2000.0, e3v=f["e3"], gdep=gdep, isodep=True),
+                               args.reps)
+                    report("cdfmocsig -isodep (158 classes, 5 basins, smooth T,S, noise land)", args.grid, n3, 16.0, ms,
+                           "the class kernel with the depth * weight and weight sums as two more per-wave LDS histograms (two workgroups per CU)")
                 del f
 
     if "mhst" in tools:
