@@ -30,8 +30,7 @@ PROGRAM cdfcurl
   TYPE(variable) :: stypvar(1)
   TYPE(C_PTR) :: plan, pff
   TYPE(C_PTR) :: pd_u = C_NULL_PTR, pd_v = C_NULL_PTR, ph_rot(2) = C_NULL_PTR      ! the host feed's level in HBM, two page-locked result levels
-  REAL(KIND=4), POINTER :: un_d(:), vn_d(:), zrot_h(:,:)
-  REAL(KIND=8), POINTER :: drot_h(:,:)
+  REAL(KIND=4), POINTER :: un_d(:), vn_d(:)
   INTEGER(KIND=8) :: nij8
   LOGICAL :: lfeed
   LOGICAL :: lchk = .FALSE., lperio = .FALSE., ldblpr = .FALSE., lnc4 = .FALSE., ltpoint = .FALSE., lsurf = .FALSE.
@@ -198,17 +197,13 @@ PROGRAM cdfcurl
      IF ( lfeed ) THEN      ! level jk+1 is read and computed while level jk is on its way to the host and to the file
         CALL load_level(1) ; CALL compute_level(1)
         DO jk = 1, nlev
-           IF ( jk < nlev ) CALL load_level(jk + 1)
+           IF ( jk < nlev ) CALL load_level(jk + 1)       ! (level jk-1 is being written by the output file's thread meanwhile)
            CALL hip_check(cdft_stream_sync(feed_stream), 'cdft_stream_sync')
+           CALL wait_writes(ncout)                        ! level jk-1 is in the file: its array takes level jk+1
            IF ( jk < nlev ) CALL compute_level(jk + 1)
-           IF ( ldblpr ) THEN
-              CALL C_F_POINTER(ph_rot(1 + MOD(jk - 1, 2)), drot_h, (/ npiglo, npjglo /))
-              ierr = putvar(ncout, id_varout(1), drot_h, jk, npiglo, npjglo, ktime=jt)
-           ELSE
-              CALL C_F_POINTER(ph_rot(1 + MOD(jk - 1, 2)), zrot_h, (/ npiglo, npjglo /))
-              ierr = putvar(ncout, id_varout(1), zrot_h, jk, npiglo, npjglo, ktime=jt)
-           ENDIF
+           ierr = putvar_behind(ncout, id_varout(1), ph_rot(1 + MOD(jk - 1, 2)), ldblpr, jk, npiglo, npjglo, ktime=jt)
         END DO
+        CALL wait_writes(ncout)
         CYCLE
      ENDIF
      DO jk = 1, nlev

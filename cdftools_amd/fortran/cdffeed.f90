@@ -205,7 +205,7 @@ CONTAINS
     INTEGER(C_INT),   INTENT(in) :: keos
     INTEGER(KIND=4) :: inl, ins, js, jk, ib, ierr
     INTEGER(KIND=8) :: islab
-    REAL(KIND=4), POINTER :: zt_d(:), zs_d(:), zout(:,:,:)
+    REAL(KIND=4), POINTER :: zt_d(:), zs_d(:)
     islab = 4_8 * kpi * kpj
     CALL feed_size(islab, islab * kpk)
     inl = INT(MAX(1_8, MIN(INT(kpk, 8), nslot_bytes / islab)), 4)        ! levels per slab: what a slot of the ring holds
@@ -222,15 +222,17 @@ CONTAINS
     ins = ( kpk + inl - 1 ) / inl
     CALL load_slab(1) ; CALL compute_slab(1)
     DO js = 1, ins
-       IF ( js < ins ) CALL load_slab(js + 1)                  ! queued behind the kernel of slab js, read while it runs
+       IF ( js < ins ) CALL load_slab(js + 1)                  ! queued behind the kernel of slab js, read while it runs -- and
+       !                                                         while slab js-1 is written by the file's own thread
        CALL hip_check(cdft_stream_sync(feed_stream), 'cdft_stream_sync')      ! the result of slab js is in its host array
-       IF ( js < ins ) CALL compute_slab(js + 1)               ! into the other host array, while slab js is written
+       CALL wait_writes(kout)                                  ! slab js-1 is in the file: its host array is free again ...
+       IF ( js < ins ) CALL compute_slab(js + 1)               ! ... for the result of slab js+1
        ib = 1 + MOD(js - 1, 2)
-       CALL C_F_POINTER(ph_slab(ib), zout, (/ kpi, kpj, inl /))
-       DO jk = ( js - 1 ) * inl + 1, MIN(js * inl, kpk)
-          ierr = putvar(kout, kidvar, zout(:,:,jk - ( js - 1 ) * inl), jk, kpi, kpj, ktime=ktime)
+       DO jk = ( js - 1 ) * inl + 1, MIN(js * inl, kpk)        ! queued: written while slab js+2 is read
+          ierr = putvar_behind(kout, kidvar, slab_level(ph_slab(ib), jk - ( js - 1 ) * inl), .FALSE., jk, kpi, kpj, ktime=ktime)
        END DO
     END DO
+    CALL wait_writes(kout)
 
   CONTAINS
 
@@ -241,6 +243,16 @@ CONTAINS
       CALL feed_field(cdtfil, cdtem, pd_slab(1), kpi, kpj, il, ktime=ktime, kkmin=ik0)
       CALL feed_field(cdsfil, cdsal, pd_slab(2), kpi, kpj, il, ktime=ktime, kkmin=ik0)
     END SUBROUTINE load_slab
+
+    FUNCTION slab_level(pbase, kl) RESULT(plev)
+      ! the address of level kl of a page-locked slab
+      TYPE(C_PTR), INTENT(in) :: pbase
+      INTEGER(KIND=4), INTENT(in) :: kl
+      TYPE(C_PTR) :: plev
+      REAL(KIND=4), POINTER :: zall(:,:,:)
+      CALL C_F_POINTER(pbase, zall, (/ kpi, kpj, inl /))
+      plev = C_LOC(zall(1,1,kl))
+    END FUNCTION slab_level
 
     SUBROUTINE compute_slab(ks)
       INTEGER(KIND=4), INTENT(in) :: ks

@@ -17,6 +17,7 @@ MODULE cdfio
   !! Not provided (no tool of this build calls them): the reference's atted, cvaratt, gettimeatt, puttimeatt, getvarid,
   !! getdimvar, getvarxz / yz, getvar3dt, getvar4d, gettimeseries, reputvar*, putvare3, ncopen.
   !!======================================================================
+  USE, INTRINSIC :: ISO_C_BINDING, ONLY : C_PTR
   USE netcdf
   USE modcdfnames
   IMPLICIT NONE
@@ -82,6 +83,7 @@ MODULE cdfio
   PUBLIC :: chkfile, chkvar, getdim, getvdim, getspval, getatt, getvaratt, getnvar, getvarname, getipk
   PUBLIC :: getvar, getvar1d, getvare3, getvar3d, readvar3d, readvar3d_i1
   PUBLIC :: create, createvar, putatt, putheadervar, putvar, putvar1d, putvar0d, closeout, ERR_HDL
+  PUBLIC :: putvar_behind, wait_writes                  ! (not in the reference: the host feed's write-behind)
 
 CONTAINS
 
@@ -1069,6 +1071,37 @@ CONTAINS
     IF ( PRESENT(kwght) ) putvarr8 = NF90_PUT_ATT(kout, kid, 'iweight', kwght)
     CALL toc(dtime_write)
   END FUNCTION putvarr8
+
+  ! putvar of the (kpi,kpj) slab at the ADDRESS pdata (r4, or r8 with ld_r8 -- a page-locked array the GPU filled) that returns
+  ! before the slab is in the file: a thread of the output file writes the queued slabs in order while the program goes on
+  ! READING the next ones (the NetCDF layer's write-behind, ncclassic.h).  The memory at pdata must not be touched before
+  ! wait_writes(kout) -- or any other call on kout, which all wait -- has returned.  (Not in the reference, whose level loops
+  ! read, compute and write in turn; the programs of the host feed use it where the result is as large as the input.)
+  INTEGER(KIND=4) FUNCTION putvar_behind(kout, kid, pdata, ld_r8, klev, kpi, kpj, ktime, kwght)
+    INTEGER(KIND=4),           INTENT(in) :: kout, kid, klev, kpi, kpj
+    TYPE(C_PTR),               INTENT(in) :: pdata
+    LOGICAL,                   INTENT(in) :: ld_r8
+    INTEGER(KIND=4), OPTIONAL, INTENT(in) :: ktime, kwght
+    CALL tic()
+    IF ( PRESENT(kwght) ) putvar_behind = NF90_PUT_ATT(kout, kid, 'iweight', kwght)      ! (waits for the queue: give it once)
+    putvar_behind = nf90x_put_var_behind(kout, kid, pdata, ld_r8, (/ kpi, kpj /), start=slab_origin(kout, kid, klev, ktime), &
+         &                                count=(/ kpi, kpj, 1, 1 /))
+    CALL toc(dtime_write)
+  END FUNCTION putvar_behind
+
+  SUBROUTINE wait_writes(kout)
+    !! every slab queued by putvar_behind is in the file (the time spent waiting counts as write time); a failed write stops
+    !! the program as a failed putvar's NetCDF error would
+    INTEGER(KIND=4), INTENT(in) :: kout
+    INTEGER(KIND=4) :: ierr
+    CALL tic()
+    ierr = nf90x_wait_writes(kout)
+    CALL toc(dtime_write)
+    IF ( ierr /= NF90_NOERR ) THEN
+       PRINT *, ' ERROR in a queued write : ', TRIM(NF90_STRERROR(ierr))
+       STOP 98
+    ENDIF
+  END SUBROUTINE wait_writes
 
   INTEGER(KIND=4) FUNCTION putvarr4(kout, kid, ptab, klev, kpi, kpj, ktime, kwght)
     INTEGER(KIND=4),                  INTENT(in) :: kout, kid, klev, kpi, kpj

@@ -30,7 +30,6 @@ PROGRAM cdfvT
   TYPE(variable), ALLOCATABLE :: stypvar(:)
   TYPE(C_PTR) :: pe3u, pe3v, pe3um, pe3vm
   TYPE(C_PTR) :: ph_out(6,2) = C_NULL_PTR                        ! the host feed's two sets of page-locked r4 results
-  REAL(KIND=4), POINTER :: zout_h(:,:)
   INTEGER(KIND=4) :: nqo
   ! the frames of one level in HBM when they are fed there through the ring (module cdffeed): never touched by the host
   TYPE(C_PTR) :: pd_u = C_NULL_PTR, pd_v = C_NULL_PTR, pd_t = C_NULL_PTR, pd_s = C_NULL_PTR, pd_e3u = C_NULL_PTR, pd_e3v = C_NULL_PTR
@@ -151,18 +150,21 @@ PROGRAM cdfvT
      END DO
      CALL load_level(1) ; CALL compute_level(1)
      DO jk = 1, npk
-        IF ( jk < npk ) CALL load_level(jk + 1)
+        IF ( jk < npk ) CALL load_level(jk + 1)            ! (level jk-1 is being written by the output file's thread meanwhile)
         CALL hip_check(cdft_stream_sync(feed_stream), 'cdft_stream_sync')
+        CALL wait_writes(ncout)                            ! level jk-1 is in the file: its arrays take level jk+1
         IF ( jk < npk ) CALL compute_level(jk + 1)
-        DO jt = 1, nqo
-           CALL C_F_POINTER(ph_out(jt, 1 + MOD(jk - 1, 2)), zout_h, (/ npiglo, npjglo /))
-           ierr = putvar(ncout, id_varout(jt), zout_h, jk, npiglo, npjglo, kwght=ntframe)
-        END DO
         IF ( jk == 1 ) THEN
            dtimean(1) = dtotal_time / ntframe
            ierr = putvar1d(ncout, dtimean, 1, 'T')
         ENDIF
+        DO jt = 1, nqo            ! (the reference rewrites iweight = ntframe at every level: written once it is the same file)
+           IF ( jk == 1 ) THEN ; ierr = putvar_behind(ncout, id_varout(jt), ph_out(jt,1), .FALSE., jk, npiglo, npjglo, kwght=ntframe)
+           ELSE ; ierr = putvar_behind(ncout, id_varout(jt), ph_out(jt, 1 + MOD(jk - 1, 2)), .FALSE., jk, npiglo, npjglo)
+           ENDIF
+        END DO
      END DO
+     CALL wait_writes(ncout)
      DO jt = 1, nqo
         ierr = cdft_host_free(ph_out(jt,1)) ; ierr = cdft_host_free(ph_out(jt,2))
      END DO

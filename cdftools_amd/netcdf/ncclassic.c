@@ -33,14 +33,48 @@ typedef struct {
     uint64_t old_recsize;
     NcH5 *h5;            /* a NetCDF-4 file, read or written through the HDF5 plug-in */
     int nc4w;            /* NetCDF-4 output: the HDF5 file is created from the model at the first enddef */
+    struct Behind *wb;   /* writes queued by ncc_put_vara_behind and the thread that carries them out (NULL: never used) */
     char path[4096];
 } File;
 
 static File g_files[MAX_FILES];
 
-static File *getf(int ncid) {
+/* Write-behind (ncc_put_vara_behind / ncc_wait_writes): a program that computes slab s+1 while slab s goes to the file queues
+ * the writes of slab s and goes on READING; one thread per file carries the queue out in order (each write still split over
+ * the writing threads).  Every other entry point on that file first waits for the queue to empty (getf), so nothing else
+ * ever sees the file while the thread works on it; the data must stay untouched until ncc_wait_writes (or any other call on
+ * the file) returns. */
+#include <pthread.h>
+typedef struct { int varid, memtype, has_start, has_count; size_t start[NCC_MAX_DIMS + 1], count[NCC_MAX_DIMS + 1]; const void *data; } BehindReq;
+enum { kBehindQueue = 64 };
+typedef struct Behind {
+    pthread_t th;
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
+    BehindReq q[kBehindQueue];
+    int head, n, busy, stop, rc;
+    File *f;
+} Behind;
+
+static void behind_stop(File *f);
+
+static void behind_drain(File *f) {
+    Behind *b = f->wb;
+    if (!b) return;
+    pthread_mutex_lock(&b->mu);
+    while (b->n > 0 || b->busy) pthread_cond_wait(&b->cv, &b->mu);
+    pthread_mutex_unlock(&b->mu);
+}
+
+static File *getf_nowait(int ncid) {
     if (ncid < 0 || ncid >= MAX_FILES || !g_files[ncid].used) return NULL;
     return &g_files[ncid];
+}
+
+static File *getf(int ncid) {
+    File *f = getf_nowait(ncid);
+    if (f && f->wb) behind_drain(f);
+    return f;
 }
 
 static size_t tsize(int t) {
@@ -562,6 +596,7 @@ int ncc_open(const char *path, int writable, int *ncid) {
 }
 
 static void free_file(File *f) {
+    behind_stop(f);
     for (int i = 0; i < f->nvars; ++i) { for (int a = 0; a < f->vars[i].natts; ++a) free(f->vars[i].atts[a].data); free(f->vars[i].atts); }
     for (int a = 0; a < f->ngatts; ++a) free(f->gatts[a].data);
     free(f->vars); free(f->gatts); free(f->dims); free(f->old_begin);
@@ -724,7 +759,7 @@ int ncc_def_var_deflate(int ncid, int varid, int shuffle, int level) {
 
 /* ------------------------------------------------------------------ inquire */
 int ncc_inq(int ncid, int *ndims, int *nvars, int *ngatts, int *unlimdimid) {
-    File *f = getf(ncid);
+    File *f = getf_nowait(ncid);                       /* (as ncc_inq_var) */
     if (!f) return NCC_EBADID;
     if (ndims) *ndims = f->ndims;
     if (nvars) *nvars = f->nvars;
@@ -759,7 +794,7 @@ int ncc_inq_varid(int ncid, const char *name, int *varid) {
 }
 
 int ncc_inq_var(int ncid, int varid, char *name, int *xtype, int *ndims, int *dimids, int *natts) {
-    File *f = getf(ncid);
+    File *f = getf_nowait(ncid);                       /* (what the queued writes never change: asked for between two of them) */
     if (!f) return NCC_EBADID;
     if (varid < 0 || varid >= f->nvars) return NCC_ENOTVAR;
     const Var *v = &f->vars[varid];
@@ -1070,9 +1105,7 @@ static int write_run_parallel(int fd, const unsigned char *mem, size_t bytes, si
     return rc;
 }
 
-static int vara(int ncid, int varid, const size_t *start, const size_t *count, int memtype, void *data, int writing) {
-    File *f = getf(ncid);
-    if (!f) return NCC_EBADID;
+static int vara_f(File *f, int varid, const size_t *start, const size_t *count, int memtype, void *data, int writing) {
     if (f->indef) return NCC_EINDEFINE;
     if (writing && !f->writable) return NCC_EPERM;
     if (varid < 0 || varid >= f->nvars) return NCC_ENOTVAR;
@@ -1146,8 +1179,94 @@ static int vara(int ncid, int varid, const size_t *start, const size_t *count, i
     return rc;
 }
 
+static int vara(int ncid, int varid, const size_t *start, const size_t *count, int memtype, void *data, int writing) {
+    File *f = getf(ncid);
+    if (!f) return NCC_EBADID;
+    return vara_f(f, varid, start, count, memtype, data, writing);
+}
+
 int ncc_put_vara(int ncid, int varid, const size_t *start, const size_t *count, int memtype, const void *data) {
     return vara(ncid, varid, start, count, memtype, (void *)data, 1);
+}
+
+static void *behind_worker(void *arg) {
+    Behind *b = (Behind *)arg;
+    pthread_mutex_lock(&b->mu);
+    for (;;) {
+        while (b->n == 0 && !b->stop) pthread_cond_wait(&b->cv, &b->mu);
+        if (b->n == 0 && b->stop) break;
+        const BehindReq r = b->q[b->head];
+        b->head = (b->head + 1) % kBehindQueue;
+        --b->n;
+        b->busy = 1;
+        pthread_cond_broadcast(&b->cv);                    /* (a slot is free) */
+        pthread_mutex_unlock(&b->mu);
+        const int rc = vara_f(b->f, r.varid, r.has_start ? r.start : NULL, r.has_count ? r.count : NULL, r.memtype, (void *)r.data, 1);
+        pthread_mutex_lock(&b->mu);
+        b->busy = 0;
+        if (rc && !b->rc) b->rc = rc;                      /* the first error is what ncc_wait_writes returns */
+        pthread_cond_broadcast(&b->cv);
+    }
+    pthread_mutex_unlock(&b->mu);
+    return NULL;
+}
+
+static void behind_stop(File *f) {                          /* (the queue is empty: every caller came through getf) */
+    Behind *b = f->wb;
+    if (!b) return;
+    pthread_mutex_lock(&b->mu);
+    b->stop = 1;
+    pthread_cond_broadcast(&b->cv);
+    pthread_mutex_unlock(&b->mu);
+    pthread_join(b->th, NULL);
+    pthread_mutex_destroy(&b->mu);
+    pthread_cond_destroy(&b->cv);
+    free(b);
+    f->wb = NULL;
+}
+
+/* ncc_put_vara that returns before the data is in the file: see "Write-behind" above.  Errors come back from ncc_wait_writes
+ * (NetCDF-4 output and files in define mode are written at once, as by ncc_put_vara). */
+int ncc_put_vara_behind(int ncid, int varid, const size_t *start, const size_t *count, int memtype, const void *data) {
+    File *f = getf_nowait(ncid);
+    if (!f) return NCC_EBADID;
+    if (f->nc4w || f->h5 || f->indef || !f->writable || varid < 0 || varid >= f->nvars)
+        return vara(ncid, varid, start, count, memtype, (void *)data, 1);
+    if (!f->wb) {
+        Behind *b = (Behind *)calloc(1, sizeof(Behind));
+        if (!b) return NCC_ENOMEM;
+        b->f = f;
+        pthread_mutex_init(&b->mu, NULL);
+        pthread_cond_init(&b->cv, NULL);
+        if (pthread_create(&b->th, NULL, behind_worker, b) != 0) {       /* no thread: at once */
+            pthread_mutex_destroy(&b->mu); pthread_cond_destroy(&b->cv); free(b);
+            return vara(ncid, varid, start, count, memtype, (void *)data, 1);
+        }
+        f->wb = b;
+    }
+    Behind *b = f->wb;
+    BehindReq r;
+    memset(&r, 0, sizeof r);
+    r.varid = varid; r.memtype = memtype; r.data = data;
+    const int nd = f->vars[varid].ndims;
+    if (start) { r.has_start = 1; for (int d = 0; d < nd; ++d) r.start[d] = start[d]; }
+    if (count) { r.has_count = 1; for (int d = 0; d < nd; ++d) r.count[d] = count[d]; }
+    pthread_mutex_lock(&b->mu);
+    while (b->n == kBehindQueue) pthread_cond_wait(&b->cv, &b->mu);
+    b->q[(b->head + b->n) % kBehindQueue] = r;
+    ++b->n;
+    pthread_cond_broadcast(&b->cv);
+    pthread_mutex_unlock(&b->mu);
+    return 0;
+}
+
+int ncc_wait_writes(int ncid) {
+    File *f = getf(ncid);                                   /* (waits) */
+    if (!f) return NCC_EBADID;
+    if (!f->wb) return 0;
+    const int rc = f->wb->rc;
+    f->wb->rc = 0;
+    return rc;
 }
 
 int ncc_get_vara(int ncid, int varid, const size_t *start, const size_t *count, int memtype, void *data) {

@@ -81,6 +81,11 @@ int ncc_copy_att(int ncid_in, int varid_in, const char *name, int ncid_out, int 
 
 /* hyperslab I/O with conversion between the variable's external type and memtype */
 int ncc_put_vara(int ncid, int varid, const size_t *start, const size_t *count, int memtype, const void *data);
+/* Write-behind: the write is queued and carried out in order by one thread of the file while the caller goes on (reading other
+ * files, computing); data must stay untouched until ncc_wait_writes -- or any other call on this file, every one of which waits
+ * for the queue first -- returns.  ncc_wait_writes returns the first error of the writes queued since the last call. */
+int ncc_put_vara_behind(int ncid, int varid, const size_t *start, const size_t *count, int memtype, const void *data);
+int ncc_wait_writes(int ncid);
 int ncc_get_vara(int ncid, int varid, const size_t *start, const size_t *count, int memtype, void *data);
 
 const char *ncc_strerror(int status);

@@ -301,3 +301,54 @@ def test_large_writes_split_over_threads_are_what_scipy_reads(nc, tmp_path, monk
     with netcdf_file(path, "r", mmap=False) as f:
         for name, a in arrays.items():
             assert np.array_equal(f.variables[name][:], a), name
+
+
+@pytest.mark.parametrize("threads", ["1", "5"])
+def test_writes_queued_behind_are_in_the_file_in_order(nc, tmp_path, monkeypatch, threads):
+    """ncc_put_vara_behind: the levels of a record variable queued one after the other (more requests than the queue holds, r4
+    and r8 -> float, a later write over an earlier one), reads of ANOTHER file in between, then ncc_wait_writes; a read of the
+    same file waits for the queue by itself; an error of a queued write comes back from ncc_wait_writes; close drains."""
+    monkeypatch.setenv("CDFT_IO_THREADS", threads)
+    path, other = str(tmp_path / "behind.nc"), str(tmp_path / "other.nc")
+    with netcdf_file(other, "w", version=2) as f:
+        f.createDimension("n", 1000)
+        f.createVariable("a", np.dtype(">f4"), ("n",))[:] = np.arange(1000, dtype=np.float32)
+    nlev, nij = 150, 300_007
+    rng = np.random.default_rng(41)
+    ncid, dt, dz, dx, v4, v8 = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    ok(nc, nc.ncc_create(path.encode(), 2, 1, C.byref(ncid)))
+    ok(nc, nc.ncc_def_dim(ncid, b"t", C.c_size_t(0), C.byref(dt)))
+    ok(nc, nc.ncc_def_dim(ncid, b"z", C.c_size_t(nlev), C.byref(dz)))
+    ok(nc, nc.ncc_def_dim(ncid, b"x", C.c_size_t(nij), C.byref(dx)))
+    ok(nc, nc.ncc_def_var(ncid, b"v4", FLOAT, 3, (C.c_int * 3)(dt.value, dz.value, dx.value), C.byref(v4)))
+    ok(nc, nc.ncc_def_var(ncid, b"v8", FLOAT, 3, (C.c_int * 3)(dt.value, dz.value, dx.value), C.byref(v8)))
+    ok(nc, nc.ncc_enddef(ncid))
+    a4 = rng.random((nlev, nij), dtype=np.float32)
+    a8 = rng.random((nlev, nij)) * 100
+    oid, ovid = C.c_int(), C.c_int()
+    ok(nc, nc.ncc_open(other.encode(), 0, C.byref(oid)))
+    ok(nc, nc.ncc_inq_varid(oid, b"a", C.byref(ovid)))
+    for k in range(nlev):
+        ok(nc, nc.ncc_put_vara_behind(ncid, v4, sz(0, k, 0), sz(1, 1, nij), FLOAT, a4[k].ctypes.data_as(C.c_void_p)))
+        ok(nc, nc.ncc_put_vara_behind(ncid, v8, sz(0, k, 0), sz(1, 1, nij), DOUBLE, a8[k].ctypes.data_as(C.c_void_p)))
+        if k % 40 == 0:                                                   # the caller goes on reading another file
+            got = np.empty(1000, np.float32)
+            ok(nc, nc.ncc_get_vara(oid, ovid, sz(0), sz(1000), FLOAT, got.ctypes.data_as(C.c_void_p)))
+            assert got[999] == 999
+    patch = np.full(nij, -7.5, np.float32)
+    ok(nc, nc.ncc_put_vara_behind(ncid, v4, sz(0, 3, 0), sz(1, 1, nij), FLOAT, patch.ctypes.data_as(C.c_void_p)))   # after level 3's first write
+    a4[3] = patch
+    back = np.empty(nij, np.float32)                                      # a read of the same file: waits for the queue
+    ok(nc, nc.ncc_get_vara(ncid, v4, sz(0, nlev - 1, 0), sz(1, 1, nij), FLOAT, back.ctypes.data_as(C.c_void_p)))
+    assert np.array_equal(back, a4[nlev - 1])
+    ok(nc, nc.ncc_wait_writes(ncid))
+    ok(nc, nc.ncc_put_vara_behind(ncid, v4, sz(0, nlev, 0), sz(1, 1, nij), FLOAT, patch.ctypes.data_as(C.c_void_p)))   # outside the z dimension
+    assert nc.ncc_wait_writes(ncid) != 0 and nc.ncc_wait_writes(ncid) == 0
+    ok(nc, nc.ncc_put_vara_behind(ncid, v8, sz(1, 0, 0), sz(1, 1, nij), DOUBLE, a8[0].ctypes.data_as(C.c_void_p)))  # a second record, left to close
+    ok(nc, nc.ncc_close(ncid))
+    ok(nc, nc.ncc_close(oid))
+    with netcdf_file(path, "r", mmap=False) as f:
+        assert f.variables["v4"].shape[0] == 2
+        assert np.array_equal(f.variables["v4"][0], a4)
+        assert np.array_equal(f.variables["v8"][0], a8.astype(np.float32))
+        assert np.array_equal(f.variables["v8"][1, 0], a8[0].astype(np.float32))
