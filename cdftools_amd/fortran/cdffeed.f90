@@ -11,6 +11,9 @@ MODULE cdffeed
   !! get and 0.10 s per GB to give back on this pool (tools/pin_probe.hip), so the slots hold a sixteenth of the field, at
   !! least one plane and at most CDFT_FEED_MB (default 128) MB, CDFT_FEED_SLOTS (default 4) of them.  A program takes this
   !! route when its fields are large enough for it to pay (feed_wanted: CDFT_FEED=0 / 1 decide for it).
+  !! Beyond feed_field: feed_mean_mesh (the mesh of cdfmean / cdfsum without a 3-D host array) and feed_sig_record (cdfsig0 /
+  !! cdfsigi, whose result is as large as their input: slabs in through the ring, results out through two page-locked arrays,
+  !! slab s queued for the output file's writing thread -- cdfio's putvar_behind -- while slab s+1 is read and computed).
   !!======================================================================
   USE ISO_C_BINDING
   USE cdfio
