@@ -189,8 +189,16 @@ def test_nc4_option_writes_netcdf4_with_the_same_content(libs, tools, tmp_path):
                                 ("cdfsum", ["-f", "SYN_y0001_gridT.nc", "-v", "votemper", "-p", "T"], "cdfsum.nc")):
         rc, out, err = run(tool, args + ["-o", "classic_" + outfile], d)
         assert rc == 0, (tool, out + err)
-        rc, out, err = run(tool, args + ["-nc4", "-o", "nc4_" + outfile], d)
-        assert rc == 0, (tool, out + err)
+        # (with the host feed forced on as well: cdfsig0 and cdfvT then queue their slabs behind, which a NetCDF-4 output
+        # takes at once -- the HDF5 library is not entered from a second thread)
+        for feed in ("1", "0"):
+            rc, out, err = run(tool, args + ["-nc4", "-o", "nc4_" + outfile], d, env={"CDFT_FEED": feed})
+            assert rc == 0, (tool, feed, out + err)
+            if feed == "1":
+                os.replace(os.path.join(d, "nc4_" + outfile), os.path.join(d, "nc4feed_" + outfile))
+        a, b = model(nc, os.path.join(d, "nc4feed_" + outfile)), model(nc, os.path.join(d, "nc4_" + outfile))
+        same_model(a, b)
+        nc.ncc_close(a["ncid"]); nc.ncc_close(b["ncid"])
         p3, p4 = os.path.join(d, "classic_" + outfile), os.path.join(d, "nc4_" + outfile)
         with open(p4, "rb") as f:
             assert f.read(8) == b"\x89HDF\r\n\x1a\n", tool
