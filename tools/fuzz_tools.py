@@ -12,7 +12,7 @@
   cdfmocsig (three equations of state, -full, -eiv, -isodep, class / general kernel)   1e-13
   sharded plans of cdfmoc / cdfpsi / cdfmhst / cdfvT / cdfheatc (reference-order sums), 2..6 row blocks   the bits of one plan
 tests/ run fixed shapes; this draws new ones for FUZZ_SECONDS (default 300) and stops at the first failure.
-Run on the GPU box:  FUZZ_SECONDS=300 python tools/fuzz_tools.py [seed]"""
+Run on the GPU box:  FUZZ_SECONDS=300 [FUZZ_ONLY=mocsig] python tools/fuzz_tools.py [seed]"""
 import os
 import sys
 import time
@@ -48,6 +48,8 @@ while time.time() < stop:
     while npi * npj * npk > 1_500_000:
         npj = max(1, npj // 2)
     tool = ["psi", "vt", "curl", "mhst", "heatc", "mean", "zonal", "vint", "mocsig", "sharded"][int(rng.integers(10))]
+    if os.environ.get("FUZZ_ONLY"):                        # FUZZ_ONLY=mocsig: every case of one tool
+        tool = os.environ["FUZZ_ONLY"]
     if tool == "mocsig":
         npk = max(npk, 2)
     g = synth.make_grid(npi, npj, max(npk, 2) if tool == "curl" else npk, seed=int(rng.integers(1 << 30)), land=float(rng.choice([0.0, 0.35, 0.8])))
