@@ -170,8 +170,7 @@ PROGRAM cdfvT
      END DO
   ENDIF
 
-  DO jk = 1, npk
-     IF ( lfeed ) EXIT
+  DO jk = 1, MERGE(0, npk, lfeed)                            ! (the reference's level loop: read, compute, write in turn)
      PRINT *, 'level ', jk
      ifr = 0
      DO jt = 1, ntags
