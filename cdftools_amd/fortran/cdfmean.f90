@@ -238,18 +238,18 @@ PROGRAM cdfmean
         CALL feed_field(cf_in, cv_nam, pd_zv, npiglo, npjglo, nvpk, ktime=jt, kimin=iimin, kjmin=ijmin, kkmin=ikmin)
         CALL hip_check(cdft_mean_compute(plan, zv_d, CDFT_MEM_DEVICE, dsums, CDFT_MEM_HOST, feed_stream), 'cdft_mean_compute')
      ELSE
-     IF ( jt == 1 .OR. lg_vvl ) THEN
-        pe3 = C_NULL_PTR ; pe31d = C_NULL_PTR
-        IF ( lfull ) THEN
-           pe31d = C_LOC(e31d)                               ! e3(:,:) = e31d(jk), with jk the working-level index (:412)
-        ELSE
-           CALL readvar3d(cf_e3, cv_e3, e3, kimin=iimin, kjmin=ijmin, kkmin=ikmin, ktime=it, ldiom=.NOT. lg_vvl)
-           pe3 = C_LOC(e3)
+        IF ( jt == 1 .OR. lg_vvl ) THEN
+           pe3 = C_NULL_PTR ; pe31d = C_NULL_PTR
+           IF ( lfull ) THEN
+              pe31d = C_LOC(e31d)                               ! e3(:,:) = e31d(jk), with jk the working-level index (:412)
+           ELSE
+              CALL readvar3d(cf_e3, cv_e3, e3, kimin=iimin, kjmin=ijmin, kkmin=ikmin, ktime=it, ldiom=.NOT. lg_vvl)
+              pe3 = C_LOC(e3)
+           ENDIF
+           CALL hip_check(cdft_mean_set_mesh(plan, e1, e2, pe3, pe31d, zmask, ibmask, CDFT_MEM_HOST, C_NULL_PTR), 'cdft_mean_set_mesh')
         ENDIF
-        CALL hip_check(cdft_mean_set_mesh(plan, e1, e2, pe3, pe31d, zmask, ibmask, CDFT_MEM_HOST, C_NULL_PTR), 'cdft_mean_set_mesh')
-     ENDIF
-     CALL readvar3d(cf_in, cv_nam, zv, kimin=iimin, kjmin=ijmin, kkmin=ikmin, ktime=jt)
-     CALL hip_check(cdft_mean_compute(plan, zv, CDFT_MEM_HOST, dsums, CDFT_MEM_HOST, C_NULL_PTR), 'cdft_mean_compute')
+        CALL readvar3d(cf_in, cv_nam, zv, kimin=iimin, kjmin=ijmin, kkmin=ikmin, ktime=jt)
+        CALL hip_check(cdft_mean_compute(plan, zv, CDFT_MEM_HOST, dsums, CDFT_MEM_HOST, C_NULL_PTR), 'cdft_mean_compute')
      ENDIF
 
      DO jk = 1, nvpk

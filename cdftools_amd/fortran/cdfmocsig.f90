@@ -236,28 +236,28 @@ PROGRAM cdfmocsig
              &         zspv, zspt, zsps, pref, ieos, nbins, sigmin, sigstp, CDFT_MEM_DEVICE, dmoc, pdepi, CDFT_MEM_HOST,               &
              &         feed_stream), 'cdft_mocsig_compute')
      ELSE
-     CALL readvar3d(cf_vfil, cn_vomecrty, zv, ktime=jt)
-     CALL readvar3d(cf_tfil, cn_votemper, zt, ktime=jt)
-     CALL readvar3d(cf_sfil, cn_vosaline, zs, ktime=jt)
-     pe3 = C_NULL_PTR ; pe31d = C_NULL_PTR ; peiv = C_NULL_PTR ; pgdep = C_NULL_PTR ; pdepi = C_NULL_PTR
-     IF ( leiv ) THEN
-        CALL readvar3d(cf_vfil, cn_vomeeivv, zveiv, ktime=jt)
-        peiv = C_LOC(zveiv)
-     ENDIF
-     IF ( lfull ) THEN
-        pe31d = C_LOC(e31d)
-     ELSE
-        IF ( jt == 1 .OR. lg_vvl ) THEN
-           DO ji = 1, npk
-              e3v(:,:,ji) = getvar(cn_fe3v, cn_ve3v, ji, npiglo, npjglo, ktime=it, ldiom=.NOT. lg_vvl)
-           END DO
+        CALL readvar3d(cf_vfil, cn_vomecrty, zv, ktime=jt)
+        CALL readvar3d(cf_tfil, cn_votemper, zt, ktime=jt)
+        CALL readvar3d(cf_sfil, cn_vosaline, zs, ktime=jt)
+        pe3 = C_NULL_PTR ; pe31d = C_NULL_PTR ; peiv = C_NULL_PTR ; pgdep = C_NULL_PTR ; pdepi = C_NULL_PTR
+        IF ( leiv ) THEN
+           CALL readvar3d(cf_vfil, cn_vomeeivv, zveiv, ktime=jt)
+           peiv = C_LOC(zveiv)
         ENDIF
-        pe3 = C_LOC(e3v)
-     ENDIF
-     IF ( lisodep ) THEN ; pgdep = C_LOC(gdep) ; pdepi = C_LOC(depi) ; ENDIF
-     CALL hip_check(cdft_mocsig_compute(zv, peiv, zt, zs, e1v, pe3, pe31d, ibmask, pgdep, npiglo, npjglo, npk, nbasins, zspv, zspt, &
-          &         zsps, pref, ieos, nbins, sigmin, sigstp, CDFT_MEM_HOST, dmoc, pdepi,  &
-          &         CDFT_MEM_HOST, C_NULL_PTR), 'cdft_mocsig_compute')
+        IF ( lfull ) THEN
+           pe31d = C_LOC(e31d)
+        ELSE
+           IF ( jt == 1 .OR. lg_vvl ) THEN
+              DO ji = 1, npk
+                 e3v(:,:,ji) = getvar(cn_fe3v, cn_ve3v, ji, npiglo, npjglo, ktime=it, ldiom=.NOT. lg_vvl)
+              END DO
+           ENDIF
+           pe3 = C_LOC(e3v)
+        ENDIF
+        IF ( lisodep ) THEN ; pgdep = C_LOC(gdep) ; pdepi = C_LOC(depi) ; ENDIF
+        CALL hip_check(cdft_mocsig_compute(zv, peiv, zt, zs, e1v, pe3, pe31d, ibmask, pgdep, npiglo, npjglo, npk, nbasins, zspv, zspt, &
+             &         zsps, pref, ieos, nbins, sigmin, sigstp, CDFT_MEM_HOST, dmoc, pdepi,  &
+             &         CDFT_MEM_HOST, C_NULL_PTR), 'cdft_mocsig_compute')
      ENDIF
      DO jbasin = 1, nbasins
         DO jbin = 1, nbins

@@ -160,11 +160,11 @@ PROGRAM cdfvertmean
         pd_e3 = feed_device(4 * n38)
      ENDIF
   ELSE
-  ALLOCATE( zv(npiglo,npjglo,nlev), zmask(npiglo,npjglo,nlev) )
-  IF ( .NOT. lfull ) ALLOCATE( e3(npiglo,npjglo,nlev) )
-  DO jk = ik1, ik2
-     zmask(:,:,jk-ik1+1) = getvar(cn_fmsk, cv_msk, jk, npiglo, npjglo, kimin=iimin, kjmin=ijmin)
-  END DO
+     ALLOCATE( zv(npiglo,npjglo,nlev), zmask(npiglo,npjglo,nlev) )
+     IF ( .NOT. lfull ) ALLOCATE( e3(npiglo,npjglo,nlev) )
+     DO jk = ik1, ik2
+        zmask(:,:,jk-ik1+1) = getvar(cn_fmsk, cv_msk, jk, npiglo, npjglo, kimin=iimin, kjmin=ijmin)
+     END DO
   ENDIF
 
   DO jt = 1, npt

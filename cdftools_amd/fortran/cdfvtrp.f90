@@ -168,12 +168,12 @@ PROGRAM cdfvtrp
         CALL hip_check(cdft_vint_transport(zv_d, e1v_d, pd_e3v, pd_e31, npiglo, npjglo, npk, CDFT_MEM_DEVICE, dtrpv, CDFT_MEM_HOST, &
              &         feed_stream), 'cdft_vint_transport')
      ELSE
-     CALL readvar3d(cf_ufil, cn_vozocrtx, zu, ktime=jt)
-     CALL readvar3d(cf_vfil, cn_vomecrty, zv, ktime=jt)
-     CALL hip_check(cdft_vint_transport(zu, e2u, pe3u, pe31d, npiglo, npjglo, npk, CDFT_MEM_HOST, dtrpu, CDFT_MEM_HOST, &
-          &         C_NULL_PTR), 'cdft_vint_transport')
-     CALL hip_check(cdft_vint_transport(zv, e1v, pe3v, pe31d, npiglo, npjglo, npk, CDFT_MEM_HOST, dtrpv, CDFT_MEM_HOST, &
-          &         C_NULL_PTR), 'cdft_vint_transport')
+        CALL readvar3d(cf_ufil, cn_vozocrtx, zu, ktime=jt)
+        CALL readvar3d(cf_vfil, cn_vomecrty, zv, ktime=jt)
+        CALL hip_check(cdft_vint_transport(zu, e2u, pe3u, pe31d, npiglo, npjglo, npk, CDFT_MEM_HOST, dtrpu, CDFT_MEM_HOST, &
+             &         C_NULL_PTR), 'cdft_vint_transport')
+        CALL hip_check(cdft_vint_transport(zv, e1v, pe3v, pe31d, npiglo, npjglo, npk, CDFT_MEM_HOST, dtrpv, CDFT_MEM_HOST, &
+             &         C_NULL_PTR), 'cdft_vint_transport')
      ENDIF
      ierr = putvar(ncout, id_varout(1), REAL(dtrpu(:,:)), 1, npiglo, npjglo, ktime=jt)
      ierr = putvar(ncout, id_varout(2), REAL(dtrpv(:,:)), 1, npiglo, npjglo, ktime=jt)
