@@ -39,6 +39,9 @@ MODULE cdftools_hip
      INTEGER(C_INT) FUNCTION cdft_memcpy_h2d(dst, src, bytes, stream) BIND(C, name='cdft_memcpy_h2d')
        IMPORT ; TYPE(C_PTR), VALUE :: dst, src, stream ; INTEGER(C_SIZE_T), VALUE :: bytes
      END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_memcpy_d2h(dst, src, bytes, stream) BIND(C, name='cdft_memcpy_d2h')     ! (synchronises)
+       IMPORT ; TYPE(C_PTR), VALUE :: dst, src, stream ; INTEGER(C_SIZE_T), VALUE :: bytes
+     END FUNCTION
      INTEGER(C_INT) FUNCTION cdft_stream_sync(stream) BIND(C, name='cdft_stream_sync')
        IMPORT ; TYPE(C_PTR), VALUE :: stream
      END FUNCTION

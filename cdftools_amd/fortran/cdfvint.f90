@@ -28,7 +28,9 @@ PROGRAM cdfvint
   TYPE(variable) :: stypvar(1)
   TYPE(C_PTR) :: pe3, pe31d
   TYPE(C_PTR) :: pd_zt = C_NULL_PTR, pd_msk = C_NULL_PTR, pd_e3 = C_NULL_PTR, pd_e31 = C_NULL_PTR
-  REAL(KIND=4), POINTER :: zt_d(:), tmask_d(:)                        ! device arrays of the host feed, never touched by the host
+  REAL(KIND=4), POINTER :: zt_d(:), tmask_d(:), zout_d(:)             ! device arrays of the host feed, never touched by the host
+  TYPE(C_PTR) :: pd_out = C_NULL_PTR, ph_lev(2) = C_NULL_PTR          ! the result in HBM, two page-locked levels on its way to the file
+  INTEGER(KIND=4) :: il, ib
   INTEGER(KIND=8) :: n38
   LOGICAL :: lfeed
   LOGICAL :: lfull = .FALSE., lgsop = .FALSE., locci = .FALSE., lchk, lout, ltmean = .FALSE., lsmean = .FALSE.
@@ -151,12 +153,14 @@ PROGRAM cdfvint
   PRINT *, ' NPT    = ', npt
 
   ! large fields: mask, e3t and every record from the file to HBM through the page-locked ring (module cdffeed); the result
-  ! (npko levels) comes back as a host array
+  ! (npko levels) stays in HBM and leaves level by level through two page-locked arrays, each queued for the output file's
+  ! writing thread (putvar_behind) -- the last levels are written while the next record is read
   n38 = INT(npiglo, 8) * npjglo * npk
   lfeed = feed_wanted(4 * n38)
   ALLOCATE( dtim(npt), rlon(npiglo,npjglo), rlat(npiglo,npjglo) )
   IF ( .NOT. lfeed ) ALLOCATE( tmask(npiglo,npjglo,npk), zt(npiglo,npjglo,npk) )
-  ALLOCATE( e31d(npk), gdepw(npk), gdepo(npko), zout(npiglo,npjglo,npko), kout(npk), khit(npk), zclip(npk), zdiv(npk) )
+  ALLOCATE( e31d(npk), gdepw(npk), gdepo(npko), kout(npk), khit(npk), zclip(npk), zdiv(npk) )
+  IF ( .NOT. lfeed ) ALLOCATE( zout(npiglo,npjglo,npko) )
   IF ( .NOT. ( lfull .OR. lfeed ) ) ALLOCATE( e3t(npiglo,npjglo,npk) )
   gdepw(:) = getvare3(cn_fzgr, cn_gdepw, npk)
   e31d(:)  = getvare3(cn_fzgr, cn_ve3t1d, npk)
@@ -172,8 +176,11 @@ PROGRAM cdfvint
   PRINT *, 'OUTPUT DEPTHS ARE : ', gdepo
 
   IF ( lfeed ) THEN
-     pd_zt = feed_device(4 * n38) ; pd_msk = feed_device(4 * n38)
+     pd_zt = feed_device(4 * n38) ; pd_msk = feed_device(4 * n38) ; pd_out = feed_device(4_8 * npiglo * npjglo * npko)
      CALL C_F_POINTER(pd_zt, zt_d, (/ n38 /)) ; CALL C_F_POINTER(pd_msk, tmask_d, (/ n38 /))
+     CALL C_F_POINTER(pd_out, zout_d, (/ INT(npiglo, 8) * npjglo * npko /))
+     CALL hip_check(cdft_host_alloc(ph_lev(1), INT(4_8 * npiglo * npjglo, C_SIZE_T)), 'cdft_host_alloc')
+     CALL hip_check(cdft_host_alloc(ph_lev(2), INT(4_8 * npiglo * npjglo, C_SIZE_T)), 'cdft_host_alloc')
      CALL feed_field(cn_fmsk, cn_tmask, pd_msk, npiglo, npjglo, npk, kimin=iimin, kjmin=ijmin)
      IF ( lfull ) THEN
         pd_e31 = feed_device(4_8 * npk) ; CALL feed_host(C_LOC(e31d), 4_8 * npk, pd_e31)
@@ -214,7 +221,17 @@ PROGRAM cdfvint
              &  CALL feed_field(cn_fe3t, cn_ve3t, pd_e3, npiglo, npjglo, npk, ktime=it, ldiom=.NOT. lg_vvl, kimin=iimin, kjmin=ijmin)
         CALL feed_field(cf_in, cv_in, pd_zt, npiglo, npjglo, npk, ktime=jt, kimin=iimin, kjmin=ijmin)
         CALL hip_check(cdft_vint_cumul(zt_d, pd_e3, pd_e31, tmask_d, npiglo, npjglo, npk, kout, khit, zclip, zdiv, npko, sclf, &
-             &         MERGE(1_C_INT, 0_C_INT, ltmean .OR. lsmean), CDFT_MEM_DEVICE, zout, CDFT_MEM_HOST, feed_stream), 'cdft_vint_cumul')
+             &         MERGE(1_C_INT, 0_C_INT, ltmean .OR. lsmean), CDFT_MEM_DEVICE, zout_d, CDFT_MEM_DEVICE, feed_stream), 'cdft_vint_cumul')
+        il = 0
+        DO jk = 1, npk
+           IF ( kout(jk) < 0 ) CYCLE
+           il = il + 1 ; ib = 1 + MOD(il - 1, 2)
+           CALL wait_writes(ncout)                        ! (the page-locked array of this parity is in the file)
+           CALL hip_check(cdft_memcpy_d2h(ph_lev(ib), C_LOC(zout_d(1 + INT(kout(jk), 8) * npiglo * npjglo)),  &
+                &         INT(4_8 * npiglo * npjglo, C_SIZE_T), feed_stream), 'cdft_memcpy_d2h')
+           ierr = putvar_behind(ncout, id_varout(1), ph_lev(ib), .FALSE., kout(jk) + 1, npiglo, npjglo, ktime=jt)
+        END DO
+        CYCLE
      ELSE IF ( lfull ) THEN
         pe31d = C_LOC(e31d)
      ELSE
@@ -232,7 +249,9 @@ PROGRAM cdfvint
   END DO
   ierr = closeout(ncout)
   IF ( lfeed ) THEN
-     CALL feed_release(pd_zt) ; CALL feed_release(pd_msk) ; CALL feed_release(pd_e3) ; CALL feed_release(pd_e31) ; CALL feed_close()
+     CALL feed_release(pd_zt) ; CALL feed_release(pd_msk) ; CALL feed_release(pd_e3) ; CALL feed_release(pd_e31) ; CALL feed_release(pd_out)
+     ierr = cdft_host_free(ph_lev(1)) ; ierr = cdft_host_free(ph_lev(2))
+     CALL feed_close()
   ENDIF
 
 CONTAINS

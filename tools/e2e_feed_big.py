@@ -5,7 +5,7 @@ same file, at sizes where a record is 4.68 GB -- slab sizes, offsets and counts 
 level through the bundled backend; only what the program reads.  (cdfmoc and cdfheatc have their own tools, which also hold
 the result against the oracle.)
 
-    python tools/e2e_feed_big.py --tool psi|mhst|vt|mocsig|sig0|sigi|curl|mean|zonal [--grid eorca12] [--npt 2]      # on the GPU box; 20-30 GB of scratch files
+    python tools/e2e_feed_big.py --tool psi|mhst|vt|mocsig|sig0|sigi|curl|mean|zonal|vint|vertmean [--grid eorca12] [--npt 2]      # on the GPU box; 20-30 GB of scratch files
 """
 import argparse
 import hashlib
@@ -28,7 +28,7 @@ from e2e_cdfmoc_big import BYTE, DOUBLE, FLOAT, GRIDS, Writer  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--tool", required=True, choices=["psi", "mhst", "vt", "mocsig", "sig0", "sigi", "curl", "mean", "zonal"])
+    ap.add_argument("--tool", required=True, choices=["psi", "mhst", "vt", "mocsig", "sig0", "sigi", "curl", "mean", "zonal", "vint", "vertmean"])
     ap.add_argument("--runs", type=int, default=2, help="runs per route (the first warms the page cache)")
     ap.add_argument("--grid", default="eorca12", choices=sorted(GRIDS))
     ap.add_argument("--npt", type=int, default=2)
@@ -49,14 +49,14 @@ def main():
     metric = lambda: (2000 + 26000 * rng.random((npj, npi), dtype=f32)).astype(f32)   # noqa: E731
 
     w = Writer(os.path.join(d, "mesh_hgr.nc"), [("t", None), ("y", npj), ("x", npi)])
-    names = ("e1v", "e2u", "glamf", "gphif", "gphiv") + (("e1u", "e2v", "e1f", "e2f") if args.tool == "curl" else ()) + (("e1t", "e2t") if args.tool in ("mean", "zonal") else ()) + (("gphit",) if args.tool == "zonal" else ())
+    names = ("e1v", "e2u", "glamf", "gphif", "gphiv") + (("e1u", "e2v", "e1f", "e2f") if args.tool == "curl" else ()) + (("e1t", "e2t") if args.tool in ("mean", "zonal", "vint", "vertmean") else ()) + (("gphit",) if args.tool == "zonal" else ())
     for nm in names:
         w.define(nm, FLOAT, ("t", "y", "x"))
     w.enddef()
     for nm in names:
         w.put(nm, (0, 0, 0), lon if nm == "glamf" else lat if nm.startswith("gphi") else metric())
     w.close()
-    e3name = "e3u_0" if args.tool == "psi" else "e3t_0" if args.tool in ("mean", "zonal") else "e3v_0"
+    e3name = "e3u_0" if args.tool == "psi" else "e3t_0" if args.tool in ("mean", "zonal", "vint", "vertmean") else "e3v_0"
     wz = Writer(os.path.join(d, "mesh_zgr.nc"), [("t", None), ("z", npk), ("y", npj), ("x", npi)])
     wz.define("e3t_0", FLOAT, ("t", "z", "y", "x"))              # present (it selects the v3.6 layout), never read here
     if e3name != "e3t_0":
@@ -69,7 +69,7 @@ def main():
     wz.put("gdepw_1d", (0, 0), gdepw)
     wz.put("gdept_1d", (0, 0), (gdepw + 0.5 * e31d).astype(f32))
     wm = Writer(os.path.join(d, "mask.nc"), [("t", None), ("z", npk), ("y", npj), ("x", npi)])
-    masks = ("vmask", "fmask") + (("tmask",) if args.tool in ("mean", "zonal") else ())
+    masks = ("vmask", "fmask") + (("tmask",) if args.tool in ("mean", "zonal", "vint", "vertmean") else ())
     for nm in masks:
         wm.define(nm, BYTE, ("t", "z", "y", "x"))
     wm.enddef()
@@ -101,10 +101,11 @@ def main():
         fields = [("SYN_y0001_gridT.nc", "votemper"), ("SYN_y0001_gridT.nc", "vosaline"), ("SYN_y0001_gridU.nc", "vozocrtx"),
                   ("SYN_y0001_gridV.nc", "vomecrty")]
         cmd = ["cdfvT", "-c", "SYN", "-l", "y0001"]
-    elif args.tool == "mean":
+    elif args.tool in ("mean", "vint", "vertmean"):
         files = {"T.nc": data_file("T.nc", "deptht", ["votemper"])}
         fields = [("T.nc", "votemper")]
-        cmd = ["cdfmean", "-f", "T.nc", "-v", "votemper", "-p", "T", "-var"]
+        cmd = {"mean": ["cdfmean", "-f", "T.nc", "-v", "votemper", "-p", "T", "-var"], "vint": ["cdfvint", "-f", "T.nc"],
+               "vertmean": ["cdfvertmean", "-f", "T.nc", "-l", "votemper", "-p", "T", "-zlim", "100", "1500"]}[args.tool]
     elif args.tool == "curl":                                     # every level of the record
         files = {"U.nc": data_file("U.nc", "depthu", ["vozocrtx"]), "V.nc": data_file("V.nc", "depthv", ["vomecrty"])}
         fields = [("U.nc", "vozocrtx"), ("V.nc", "vomecrty")]
