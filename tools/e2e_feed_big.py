@@ -5,7 +5,7 @@ same file, at sizes where a record is 4.68 GB -- slab sizes, offsets and counts 
 level through the bundled backend; only what the program reads.  (cdfmoc and cdfheatc have their own tools, which also hold
 the result against the oracle.)
 
-    python tools/e2e_feed_big.py --tool psi|mhst|vt|mocsig|sig0|sigi|curl|mean|zonal|vint|vertmean [--grid eorca12] [--npt 2]      # on the GPU box; 20-30 GB of scratch files
+    python tools/e2e_feed_big.py --tool psi|mhst|vt|mocsig|sig0|sigi|curl|mean|zonal|vint|vertmean|vhst|vtrp [--grid eorca12] [--npt 2]      # on the GPU box; 20-30 GB of scratch files
 """
 import argparse
 import hashlib
@@ -28,7 +28,7 @@ from e2e_cdfmoc_big import BYTE, DOUBLE, FLOAT, GRIDS, Writer  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--tool", required=True, choices=["psi", "mhst", "vt", "mocsig", "sig0", "sigi", "curl", "mean", "zonal", "vint", "vertmean"])
+    ap.add_argument("--tool", required=True, choices=["psi", "mhst", "vt", "mocsig", "sig0", "sigi", "curl", "mean", "zonal", "vint", "vertmean", "vhst", "vtrp"])
     ap.add_argument("--runs", type=int, default=2, help="runs per route (the first warms the page cache)")
     ap.add_argument("--grid", default="eorca12", choices=sorted(GRIDS))
     ap.add_argument("--npt", type=int, default=2)
@@ -56,11 +56,13 @@ def main():
     for nm in names:
         w.put(nm, (0, 0, 0), lon if nm == "glamf" else lat if nm.startswith("gphi") else metric())
     w.close()
-    e3name = "e3u_0" if args.tool == "psi" else "e3t_0" if args.tool in ("mean", "zonal", "vint", "vertmean") else "e3v_0"
+    e3names = (["e3u_0"] if args.tool == "psi" else ["e3t_0"] if args.tool in ("mean", "zonal", "vint", "vertmean") else
+               ["e3u_0", "e3v_0"] if args.tool in ("vhst", "vtrp") else ["e3v_0"])
     wz = Writer(os.path.join(d, "mesh_zgr.nc"), [("t", None), ("z", npk), ("y", npj), ("x", npi)])
     wz.define("e3t_0", FLOAT, ("t", "z", "y", "x"))              # present (it selects the v3.6 layout), never read here
-    if e3name != "e3t_0":
-        wz.define(e3name, FLOAT, ("t", "z", "y", "x"))
+    for e3name in e3names:
+        if e3name != "e3t_0":
+            wz.define(e3name, FLOAT, ("t", "z", "y", "x"))
     wz.define("e3t_1d", FLOAT, ("t", "z"))
     wz.define("gdepw_1d", FLOAT, ("t", "z"))
     wz.define("gdept_1d", FLOAT, ("t", "z"))
@@ -90,7 +92,15 @@ def main():
         wf.put("nav_lat", (0, 0), lat)
         return wf
 
-    if args.tool == "psi":
+    if args.tool == "vhst":                                       # the four products of cdfvT in one file
+        files = {"vt.nc": data_file("vt.nc", "depthv", ["vomevt", "vomevs", "vozout", "vozous"])}
+        fields = [("vt.nc", v) for v in ("vomevt", "vomevs", "vozout", "vozous")]
+        cmd = ["cdfvhst", "-f", "vt.nc"]
+    elif args.tool == "vtrp":
+        files = {"U.nc": data_file("U.nc", "depthu", ["vozocrtx"]), "V.nc": data_file("V.nc", "depthv", ["vomecrty"])}
+        fields = [("U.nc", "vozocrtx"), ("V.nc", "vomecrty")]
+        cmd = ["cdfvtrp", "-u", "U.nc", "-v", "V.nc"]
+    elif args.tool == "psi":
         files = {"U.nc": data_file("U.nc", "depthu", ["vozocrtx"]), "V.nc": data_file("V.nc", "depthv", ["vomecrty"])}
         fields = [("U.nc", "vozocrtx")]                          # the default path reads U alone; V.nc has to exist
         cmd = ["cdfpsi", "-u", "U.nc", "-v", "V.nc"]
@@ -142,7 +152,8 @@ def main():
         e3 = np.full((npj, npi), e31d[k], f32)
         bottom = mbathy == k + 1
         e3[bottom] *= (f32(0.2) + f32(0.8) * rng.random(int(bottom.sum()), dtype=f32)).astype(f32)
-        wz.put(e3name, (0, k, 0, 0), e3)
+        for e3name in e3names:
+            wz.put(e3name, (0, k, 0, 0), e3)
         for nm in masks:
             wm.put(nm, (0, k, 0, 0), m)
         for fn, v in fields:
