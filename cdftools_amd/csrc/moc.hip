@@ -31,7 +31,8 @@ struct cdft_moc_plan {
     DevBuf st_e1v, st_e3v, st_mask, st_zv, st_out;
     DevBuf seg_out;            // class kernel, rows cut into segments: the segments' sums (nseg x the size of the result)
     DevBuf st_vm;
-    bool last_aligned = true;  // alignment of the records of the last launch (cdft_moc_describe)   // staging for host arrays
+    bool last_aligned = true;  // alignment of the records of the last launch (cdft_moc_describe)
+    bool last_pool = false;    // the last launch read the pool (staged records)   // staging for host arrays
     // -decomp (cdft_moc_decomp_*): the mesh it needs beyond w / bits, and its work arrays
     bool dec_set = false;
     DevBuf d_e3v, d_e1u, d_zcoef, d_tmask, d_umask;  // e3v (masked) 3-D, e1u / zcoef 2-D, masks 3-D bytes
@@ -40,14 +41,23 @@ struct cdft_moc_plan {
     bool profiling = false;
     std::vector<hipEvent_t> ev;                      // (start, stop) pairs, one per profiled launch
     size_t ev_used = 0;
-    // records handed over once by cdft_moc_stage (in HBM: the caller's own array, or st_zv for a host array)
+    // records handed over once by cdft_moc_stage: re-laid out in `pool` (below); with CDFT_MOC_POOL=0 (A/B hook) kept as they
+    // came (in HBM: the caller's own array, or st_zv for a host array)
     const float *staged = nullptr;
     int64_t staged_stride = 0;
     int staged_npt = 0;
+    // The pool: the plan's own layout of staged records.  Row (jj,jk) of the domain owns ONE contiguous run of (1+npt) slots
+    // of pool_P r4 (pool_P = npi rounded up to 4): its weights, then its npt records -- what the workgroup of that row reads,
+    // front to back, instead of 1+npt runs 4.7 GB apart (eORCA12).  Measured (tools/layout_probe.py, profiles/r04): 8.7-9.0 ms
+    // per launch wherever the allocator put the pool, against 9.1-9.7 ms for the dense arrays depending on where they lay.
+    DevBuf pool;
+    int64_t pool_P = 0;        // slot length (elements)
+    int pool_npt = 0;          // records the pool is laid out for (0: nothing staged in it)
+    bool pool_w = false;       // the weights of the current mesh are in the pool
 };
 
 static int moc_compute_on(cdft_moc_plan *p, const float *d_zv, int64_t rec_stride, int npt, double *dmoc, int dmoc_space,
-                          hipStream_t st);
+                          hipStream_t st, int64_t z_row = 0, const float *w = nullptr, int64_t w_row = 0);
 
 namespace {
 
@@ -55,12 +65,15 @@ namespace {
 // (src/cdfmoc.f90:374: e1v(ji,jj)*e3v(ji,jj,jk) is evaluated first, in r4).
 // With vm (the level's vmask as the reference's INTEGER*2 ivmask, here a byte): e3v is the raw metric and
 // get_e3v's  e3v * ivmask  (:581-593) is formed here, in r4, before the product with e1v.
+// Rows of w are w_row elements apart (npi: dense).
 __global__ void moc_weight_kernel(const float *__restrict__ e1v, const float *__restrict__ e3v,
-                                  const int8_t *__restrict__ vm, float *__restrict__ w, int64_t nij, int64_t n) {
+                                  const int8_t *__restrict__ vm, float *__restrict__ w, int64_t nij, int64_t n, int npi,
+                                  int64_t w_row) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
         const float e3 = vm ? __fmul_rn(e3v[e], (float)vm[e]) : e3v[e];
-        w[e] = __fmul_rn(e1v[e % nij], e3);
+        const int64_t row = e / npi;
+        w[row * w_row + (e - row * npi)] = __fmul_rn(e1v[e % nij], e3);
     }
 }
 
@@ -138,14 +151,14 @@ __global__ void dec_divide_kernel(double *__restrict__ dvbt, const float *__rest
 template <int NB>
 __global__ void __launch_bounds__(256) dec_zonal_r8_kernel(const float *__restrict__ w, const uint8_t *__restrict__ bits,
                                                             const double *__restrict__ field, int npi, int npj, int npk,
-                                                            int nb, double *__restrict__ raw) {
+                                                            int nb, double *__restrict__ raw, int64_t w_row) {
     __shared__ double scratch[NB][4];
     const int row = blockIdx.x, jk = row / npj, jj = row - jk * npj;
     double acc[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) acc[b] = 0.0;
     if (jk < npk - 1) {
-        const int64_t r2 = (int64_t)jj * npi, r3 = (int64_t)row * npi;
+        const int64_t r2 = (int64_t)jj * npi, r3 = (int64_t)row * w_row;
         for (int i = threadIdx.x; i < npi; i += 256) {
             const double t = __dmul_rn((double)w[r3 + i], field[r2 + i]);
             const double tz = __dmul_rn(t, 0.0);          // ibmask = 0: a zero, or the NaN of 0*NaN / 0*Inf
@@ -312,20 +325,26 @@ static int zonal_xcd_map(int npj) {
 }
 
 // levels 1..npk-1 (level npk is left to the caller)
-static int zonal_launch(cdft_moc_plan *p, const float *d_zv, int64_t rec_stride, int npt, double *d_out,
-                        hipStream_t st, bool profile) {
+// w_row / z_row: elements between consecutive (jj,jk) rows of the weights / of a record (npi: dense arrays)
+static int zonal_launch(cdft_moc_plan *p, const float *w, int64_t w_row, const float *d_zv, int64_t rec_stride, int64_t z_row, int npt,
+                        double *d_out, hipStream_t st, bool profile) {
     ZonalArgs a;
-    a.w = p->w; a.bits = p->bits; a.cls = p->cls; a.nclass = p->nclass;
+    a.w = w; a.bits = p->bits; a.cls = p->cls; a.nclass = p->nclass;
     for (int c = 0; c < kMaxClass; ++c) a.pat[c] = p->pat[c];
     a.zv = d_zv; a.rec_stride = rec_stride; a.npt = npt;
+    a.w_row = w_row; a.z_row = z_row;
     a.out = d_out; a.npi = p->npi; a.npj = p->npj; a.npk = p->npk; a.nbasins = p->nbasins;
     a.rows_per_wg = 1;            // (2, 4, 8, 16 measured at eORCA025 and eORCA12: no gain, the kernel is not launch-bound)
     a.xcd_map = zonal_xcd_map(p->npj);
-    const bool aligned = ((uintptr_t)d_zv % 16 == 0) && (rec_stride % 4 == 0);
+    // vectors aligned to the arrays: every record 16-byte aligned, and a row begins the same number of cells past a
+    // 16-byte boundary in w and in the records
+    const bool aligned = ((uintptr_t)d_zv % 16 == 0) && (rec_stride % 4 == 0) && ((z_row - w_row) % 4 == 0) &&
+                         ((uintptr_t)w % 16 == 0);
     a.aligned = aligned ? 1 : 0;
     int k, v, md;
     choose_shape(p, aligned, &k, &v, &md);
     p->last_aligned = aligned;
+    p->last_pool = (w != p->w);
     if (k > kMaxWaves || v > kMaxNV)
         return fail(CDFT_ERR_ARG, "cdft_moc_compute: a row of %d cells needs %d waves x %d vectors of the %s kernel (rows this long "
                     "take basin masks with at most %d bit patterns: the class kernel)", p->npi, k, v, md == kModeFma ? "fma" : "select",
@@ -432,11 +451,12 @@ int cdft_moc_set_mesh_vmask(cdft_moc_plan *p, const float *e1v, const float *e3v
     CDFT_TRY(to_device(ibmask, nij * p->nbasins * sizeof(int16_t), memspace, p->st_mask, st, &d_msk));
     CDFT_HIP(hipMemsetAsync(p->flag, 0, 257 * sizeof(int), st));
     CDFT_HIP(hipMemsetAsync(p->w + n3, 0, 64, st));
+    p->pool_w = false;                                    // (the pool's copy of the weights is the old mesh's)
     const int threads = 256;
     int blocks = (int)((n3 + threads - 1) / threads);
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(moc_weight_kernel, dim3(blocks), dim3(threads), 0, st, (const float *)d_e1v,
-                       (const float *)d_e3v, (const int8_t *)d_vm, p->w, nij, n3);
+                       (const float *)d_e3v, (const int8_t *)d_vm, p->w, nij, n3, p->npi, (int64_t)p->npi);
     CDFT_LAUNCH_CHECK();
     blocks = (int)((nij + threads - 1) / threads);
     if (blocks > 256 * 16) blocks = 256 * 16;
@@ -509,6 +529,10 @@ int cdft_moc_describe(cdft_moc_plan *p, char *buf, size_t buflen) {
     else
         snprintf(buf, buflen, "moc_zonal_kernel<NV=%d,NB=%d,ALIGNED=%d,MODE=%s> waves_per_row=%d", v, nb, p->last_aligned ? 1 : 0,
                  md == kModeFma ? "fma" : "select", k);
+    if (p->last_pool) {                                   // the layout the launch read: dense arrays (nothing said) or the pool
+        const size_t n = strlen(buf);
+        if (n + 1 < buflen) snprintf(buf + n, buflen - n, " layout=pool(slot=%lld)", (long long)p->pool_P);
+    }
     return CDFT_OK;
 }
 
@@ -523,20 +547,20 @@ int cdft_moc_compute(cdft_moc_plan *p, const float *zv, int64_t rec_stride, int 
                     npt, (long long)rec_stride, (long long)n3);
     if (p->sh) {                                                                 // any memory spaces; returns when done
         if (zv_space == CDFT_MEM_DEVICE) CDFT_HIP(hipStreamSynchronize(as_stream(stream)));
-        p->staged_npt = 0;
+        p->staged_npt = 0;                                   // (the blocks' pools now hold THIS call's records)
         return shard::moc_compute(*p->sh, zv, rec_stride, npt, dmoc);
     }
     hipStream_t st = as_stream(stream);
     const void *d_zv;
     CDFT_TRY(to_device(zv, ((size_t)(npt - 1) * rec_stride + n3) * sizeof(float), zv_space, p->st_zv,
                        st, &d_zv));
-    p->staged = nullptr; p->staged_npt = 0;            // (st_zv may just have been overwritten)
+    if (p->staged) { p->staged = nullptr; p->staged_npt = 0; }     // (records kept as they came, CDFT_MOC_POOL=0: st_zv may just have been overwritten)
     return moc_compute_on(p, (const float *)d_zv, rec_stride, npt, dmoc, dmoc_space, st);
 }
 
 // zonal sums + cumulated sums of npt records that are in HBM, result to host or HBM
 static int moc_compute_on(cdft_moc_plan *p, const float *d_zv, int64_t rec_stride, int npt, double *dmoc, int dmoc_space,
-                          hipStream_t st) {
+                          hipStream_t st, int64_t z_row, const float *w, int64_t w_row) {
     const size_t out_bytes = (size_t)p->nbasins * p->npj * p->npk * npt * sizeof(double);
     double *d_out = dmoc;
     if (dmoc_space == CDFT_MEM_HOST || dmoc_space == CDFT_MEM_PINNED) {
@@ -546,7 +570,7 @@ static int moc_compute_on(cdft_moc_plan *p, const float *d_zv, int64_t rec_strid
         return fail(CDFT_ERR_ARG, "cdft_moc_compute: bad memory-space tag %d", dmoc_space);
     }
 
-    CDFT_TRY(zonal_launch(p, d_zv, rec_stride, npt, d_out, st, true));
+    CDFT_TRY(zonal_launch(p, w ? w : p->w, w ? w_row : (int64_t)p->npi, d_zv, rec_stride, z_row > 0 ? z_row : (int64_t)p->npi, npt, d_out, st, true));
 
     const int nbj = p->nbasins * p->npj;
     const int64_t nthr = (int64_t)nbj * npt;
@@ -562,6 +586,56 @@ static int moc_compute_on(cdft_moc_plan *p, const float *d_zv, int64_t rec_strid
 
 extern "C" {
 
+// CDFT_MOC_POOL=0: cdft_moc_stage keeps the records as they came (A/B hook, read at every call)
+static bool pool_wanted() { const char *e = getenv("CDFT_MOC_POOL"); return !(e && e[0] == '0'); }
+
+// rows of npi r4, src_row elements apart, into rows dst_row apart (16 KB rows at eORCA12: a workgroup per row)
+__global__ void __launch_bounds__(256) moc_pool_put_kernel(const float *__restrict__ src, int64_t src_row, float *__restrict__ dst,
+                                                           int64_t dst_row, int npi, int64_t nrows) {
+    for (int64_t r = blockIdx.x; r < nrows; r += gridDim.x) {
+        const float *s = src + r * src_row;
+        float *d = dst + r * dst_row;
+        for (int i = threadIdx.x; i < npi; i += 256) d[i] = s[i];
+    }
+}
+
+// The (jj,jk) rows of one field -- nrows of them, src_row elements apart -- into slot `slot` of the pool's rows first_row...
+// A source in this device's HBM is read by a kernel; anything else (host memory, another device's HBM) by a strided copy.
+static int pool_put(cdft_moc_plan *p, int slot, int64_t first_row, const float *src, int64_t src_row, int64_t nrows, hipStream_t st) {
+    const int64_t R = (int64_t)(p->pool_npt + 1) * p->pool_P;
+    float *dst = (float *)p->pool.ptr + first_row * R + (int64_t)slot * p->pool_P;
+    hipPointerAttribute_t at;
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    if (hipPointerGetAttributes(&at, src) == hipSuccess && at.type == hipMemoryTypeDevice && at.device == cur) {
+        const unsigned grid = (unsigned)(nrows < 65536 ? nrows : 65536);
+        hipLaunchKernelGGL(moc_pool_put_kernel, dim3(grid), dim3(256), 0, st, src, src_row, dst, R, p->npi, nrows);
+        CDFT_LAUNCH_CHECK();
+        return CDFT_OK;
+    }
+    (void)hipGetLastError();
+    CDFT_HIP(hipMemcpy2DAsync(dst, (size_t)R * 4, src, (size_t)src_row * 4, (size_t)p->npi * 4, (size_t)nrows, hipMemcpyDefault, st));
+    return CDFT_OK;
+}
+
+// Lay the pool out for npt records (contents lost when the layout changes) and bring the current weights in.
+static int pool_prepare(cdft_moc_plan *p, int npt, hipStream_t st) {
+    const int64_t P = ((int64_t)p->npi + 3) & ~(int64_t)3, rows = (int64_t)p->npj * p->npk;
+    const size_t bytes = (size_t)(rows * (npt + 1) * P) * 4 + 64;
+    if (p->pool_npt != npt || p->pool_P != P || p->pool.bytes < bytes) {
+        p->pool_npt = 0; p->pool_w = false;
+        CDFT_TRY(p->pool.reserve(bytes));
+        // the cells between npi and P and the 64 bytes behind the last row are read (and masked): never uninitialised memory
+        CDFT_HIP(hipMemsetAsync(p->pool.ptr, 0, bytes, st));
+        p->pool_npt = npt; p->pool_P = P;
+    }
+    if (!p->pool_w) {
+        CDFT_TRY(pool_put(p, 0, 0, p->w, p->npi, rows, st));
+        p->pool_w = true;
+    }
+    return CDFT_OK;
+}
+
 int cdft_moc_stage(cdft_moc_plan *p, const float *zv, int64_t rec_stride, int npt, int zv_space, void *stream) {
     TraceRange trace_("cdft_moc_stage");
     if (!p || !zv) return fail(CDFT_ERR_ARG, "cdft_moc_stage: NULL argument");
@@ -574,10 +648,42 @@ int cdft_moc_stage(cdft_moc_plan *p, const float *zv, int64_t rec_stride, int np
         p->staged_npt = npt;
         return CDFT_OK;
     }
+    if (!p->mesh_set) return fail(CDFT_ERR_STATE, "cdft_moc_stage: cdft_moc_set_mesh has not succeeded (the weights are staged with the records)");
     hipStream_t st = as_stream(stream);
-    const void *d_zv;
-    CDFT_TRY(to_device(zv, ((size_t)(npt - 1) * rec_stride + n3) * sizeof(float), zv_space, p->st_zv, st, &d_zv));
-    p->staged = (const float *)d_zv; p->staged_stride = rec_stride; p->staged_npt = npt;
+    p->staged = nullptr; p->staged_npt = 0;
+    if (!pool_wanted()) {
+        const void *d_zv;
+        CDFT_TRY(to_device(zv, ((size_t)(npt - 1) * rec_stride + n3) * sizeof(float), zv_space, p->st_zv, st, &d_zv));
+        p->staged = (const float *)d_zv; p->staged_stride = rec_stride; p->staged_npt = npt;
+        return CDFT_OK;
+    }
+    if (zv_space != CDFT_MEM_DEVICE && zv_space != CDFT_MEM_HOST && zv_space != CDFT_MEM_PINNED)
+        return fail(CDFT_ERR_ARG, "cdft_moc_stage: bad memory-space tag %d", zv_space);
+    CDFT_TRY(pool_prepare(p, npt, st));
+    for (int t = 0; t < npt; ++t)
+        CDFT_TRY(pool_put(p, 1 + t, 0, zv + (int64_t)t * rec_stride, p->npi, (int64_t)p->npj * p->npk, st));
+    if (zv_space == CDFT_MEM_HOST) CDFT_HIP(hipStreamSynchronize(st));            // (a pageable array may change once the call is back)
+    p->staged_npt = npt;
+    return CDFT_OK;
+}
+
+int cdft_moc_stage_rows(cdft_moc_plan *p, const float *zv, int64_t rec_stride, int64_t lev_stride, int npt, int zv_space, void *stream) {
+    TraceRange trace_("cdft_moc_stage_rows");
+    if (!p || !zv) return fail(CDFT_ERR_ARG, "cdft_moc_stage_rows: NULL argument");
+    if (p->sh) return fail(CDFT_ERR_STATE, "cdft_moc_stage_rows: single-device plans only (a sharded plan cuts the domain itself: cdft_moc_stage)");
+    if (!p->mesh_set) return fail(CDFT_ERR_STATE, "cdft_moc_stage_rows: cdft_moc_set_mesh has not succeeded");
+    const int64_t nij = (int64_t)p->npi * p->npj;
+    if (npt < 1 || lev_stride < nij || rec_stride < (int64_t)(p->npk - 1) * lev_stride + nij)
+        return fail(CDFT_ERR_ARG, "cdft_moc_stage_rows: npt=%d rec_stride=%lld lev_stride=%lld for levels of %lld cells", npt,
+                    (long long)rec_stride, (long long)lev_stride, (long long)nij);
+    hipStream_t st = as_stream(stream);
+    p->staged = nullptr; p->staged_npt = 0;
+    CDFT_TRY(pool_prepare(p, npt, st));
+    for (int t = 0; t < npt; ++t)
+        for (int k = 0; k < p->npk; ++k)
+            CDFT_TRY(pool_put(p, 1 + t, (int64_t)k * p->npj, zv + (int64_t)t * rec_stride + (int64_t)k * lev_stride, p->npi, p->npj, st));
+    if (zv_space == CDFT_MEM_HOST) CDFT_HIP(hipStreamSynchronize(st));
+    p->staged_npt = npt;
     return CDFT_OK;
 }
 
@@ -587,7 +693,35 @@ int cdft_moc_compute_staged(cdft_moc_plan *p, double *dmoc, int dmoc_space, void
     if (!p->mesh_set) return fail(CDFT_ERR_STATE, "cdft_moc_compute_staged: cdft_moc_set_mesh has not succeeded");
     if (p->staged_npt < 1) return fail(CDFT_ERR_STATE, "cdft_moc_compute_staged: cdft_moc_stage has not run (or a cdft_moc_compute since)");
     if (p->sh) return shard::moc_run(*p->sh, p->staged_npt, dmoc);
-    return moc_compute_on(p, p->staged, p->staged_stride, p->staged_npt, dmoc, dmoc_space, as_stream(stream));
+    if (p->staged) return moc_compute_on(p, p->staged, p->staged_stride, p->staged_npt, dmoc, dmoc_space, as_stream(stream));
+    if (!p->pool_w) CDFT_TRY(pool_prepare(p, p->pool_npt, as_stream(stream)));   // a new mesh since the records were staged: its weights
+    const float *pool = (const float *)p->pool.ptr;
+    const int64_t R = (int64_t)(p->pool_npt + 1) * p->pool_P;
+    return moc_compute_on(p, pool + p->pool_P, p->pool_P, p->staged_npt, dmoc, dmoc_space, as_stream(stream), R, pool, R);
+}
+
+int cdft_moc_compute_pitched(cdft_moc_plan *p, const float *zv, int64_t rec_stride, int64_t row_stride, int npt, double *dmoc,
+                             int dmoc_space, void *stream) {
+    TraceRange trace_("cdft_moc_compute_pitched");
+    if (!p || !zv || !dmoc) return fail(CDFT_ERR_ARG, "cdft_moc_compute_pitched: NULL argument");
+    if (!p->mesh_set) return fail(CDFT_ERR_STATE, "cdft_moc_compute_pitched: cdft_moc_set_mesh has not succeeded");
+    if (p->sh) return fail(CDFT_ERR_STATE, "cdft_moc_compute_pitched: single-device plans only (a sharded plan lays its blocks out itself: cdft_moc_stage)");
+    if (npt < 1 || row_stride < p->npi || rec_stride < 1)
+        return fail(CDFT_ERR_ARG, "cdft_moc_compute_pitched: npt=%d rec_stride=%lld row_stride=%lld (rows of %d cells)", npt,
+                    (long long)rec_stride, (long long)row_stride, p->npi);
+    // records and rows must not overlap: either the records are the outer dimension, or the rows are
+    const int64_t rows = (int64_t)p->npj * p->npk;
+    const bool rec_outer = rec_stride >= (rows - 1) * row_stride + p->npi;
+    const bool row_outer = row_stride >= (int64_t)(npt - 1) * rec_stride + p->npi && rec_stride >= p->npi;
+    if (!rec_outer && !row_outer)
+        return fail(CDFT_ERR_ARG, "cdft_moc_compute_pitched: rec_stride=%lld and row_stride=%lld make rows of %d cells overlap",
+                    (long long)rec_stride, (long long)row_stride, p->npi);
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, zv) != hipSuccess || at.type != hipMemoryTypeDevice) {
+        (void)hipGetLastError();
+        return fail(CDFT_ERR_ARG, "cdft_moc_compute_pitched: zv must be device memory (host records go through cdft_moc_stage)");
+    }
+    return moc_compute_on(p, zv, rec_stride, npt, dmoc, dmoc_space, as_stream(stream), row_stride);
 }
 
 }  // extern "C"
@@ -633,6 +767,7 @@ int cdft_moc_decomp(cdft_moc_plan *p, const float *zv, const float *ztemp, const
     const int64_t nij = (int64_t)npi * npj, n3 = nij * npk;
     const size_t ob = (size_t)nb * npj * npk * 8;
     const void *dzv, *dt, *ds;
+    if (p->staged) { p->staged = nullptr; p->staged_npt = 0; }   // (records kept as they came may live in st_zv, reused here)
     CDFT_TRY(to_device(zv, n3 * 4, in_space, p->st_zv, st, &dzv));
     CDFT_TRY(to_device(ztemp, n3 * 4, in_space, p->d_t, st, &dt));
     CDFT_TRY(to_device(zsal, n3 * 4, in_space, p->d_s, st, &ds));
@@ -657,9 +792,9 @@ int cdft_moc_decomp(cdft_moc_plan *p, const float *zv, const float *ztemp, const
     float *hdep = (float *)p->d_hdep.ptr, *zvgeo = (float *)p->d_zvgeo.ptr;
     const dim3 g2((unsigned)((nij + 255) / 256)), b2(256), grow((unsigned)npj * (unsigned)npk);
     auto zonal_r8 = [&](const double *field, double *raw) -> int {
-        if (nb == 1)      hipLaunchKernelGGL((dec_zonal_r8_kernel<1>), grow, b2, 0, st, p->w, p->bits, field, npi, npj, npk, nb, raw);
-        else if (nb <= 5) hipLaunchKernelGGL((dec_zonal_r8_kernel<5>), grow, b2, 0, st, p->w, p->bits, field, npi, npj, npk, nb, raw);
-        else              hipLaunchKernelGGL((dec_zonal_r8_kernel<8>), grow, b2, 0, st, p->w, p->bits, field, npi, npj, npk, nb, raw);
+        if (nb == 1)      hipLaunchKernelGGL((dec_zonal_r8_kernel<1>), grow, b2, 0, st, p->w, p->bits, field, npi, npj, npk, nb, raw, (int64_t)npi);
+        else if (nb <= 5) hipLaunchKernelGGL((dec_zonal_r8_kernel<5>), grow, b2, 0, st, p->w, p->bits, field, npi, npj, npk, nb, raw, (int64_t)npi);
+        else              hipLaunchKernelGGL((dec_zonal_r8_kernel<8>), grow, b2, 0, st, p->w, p->bits, field, npi, npj, npk, nb, raw, (int64_t)npi);
         CDFT_LAUNCH_CHECK();
         return CDFT_OK;
     };
@@ -683,7 +818,7 @@ int cdft_moc_decomp(cdft_moc_plan *p, const float *zv, const float *ztemp, const
         CDFT_LAUNCH_CHECK();
     }
     CDFT_HIP(hipMemsetAsync(raw_sh, 0, ob, st));              // level npk of the raw sums stays 0
-    CDFT_TRY(zonal_launch(p, zvgeo, n3, 1, raw_sh, st, false));
+    CDFT_TRY(zonal_launch(p, p->w, (int64_t)npi, zvgeo, n3, (int64_t)npi, 1, raw_sh, st, false));
     // 2.2.1) its pseudo-barotropic part (:480-502)
     hipLaunchKernelGGL(dec_divide_kernel, g2, b2, 0, st, dvbt, hdep, nij);
     CDFT_LAUNCH_CHECK();

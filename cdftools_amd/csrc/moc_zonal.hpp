@@ -50,6 +50,8 @@ struct ZonalArgs {
     int            nclass;      // patterns in use; 0 = class mode unavailable (more than kMaxClass)
     const float   *zv;          // record 0
     int64_t        rec_stride;  // elements between records
+    int64_t        w_row;       // elements between consecutive (jj,jk) rows of w   (npi: the reference's dense arrays)
+    int64_t        z_row;       // the same for every record of zv (aligned kernels: w_row and z_row equal modulo 4)
     int            npt;
     double        *out;         // (nbasins,npj,npk,npt): -(zonal sum), levels 1..npk-1
     int            npi, npj, npk, nbasins;
@@ -92,9 +94,10 @@ moc_zonal_kernel(ZonalArgs a) {
     const int row = blockIdx.x;                                   // jk*npj + jj, jj fastest
     const int jk  = row / a.npj;
     const int jj  = row - jk * a.npj;
-    const int64_t g0   = (int64_t)row * a.npi;                    // first cell of the row in a 3-D field
-    const int     head = ALIGNED ? (int)(g0 & 3) : 0;             // cells before the row in its first float4
-    const int64_t a0   = g0 - head;
+    const int64_t g0w  = (int64_t)row * a.w_row;                  // first cell of the row in the weights
+    const int64_t g0   = (int64_t)row * a.z_row;                  // ... and in a record
+    const int     head = ALIGNED ? (int)(g0 & 3) : 0;             // cells before the row in its first float4 (the same for w)
+    const int64_t a0   = g0 - head, a0w = g0w - head;
     const int     v0   = wave * (kWave * NV) + lane;              // this lane's first vector
 
     float   w[NV][4];
@@ -114,13 +117,13 @@ moc_zonal_kernel(ZonalArgs a) {
         vec_ok[r] = i0 < a.npi;                                   // (i0+3 >= 0 always)
         const int vc = vec_ok[r] ? v : 0;                         // vector 0 of the row is always valid
         if (ALIGNED) {
-            const f4a q = ld_stream4(a.w + a0 + 4 * (int64_t)vc);
+            const f4a q = ld_stream4(a.w + a0w + 4 * (int64_t)vc);
             wraw[r] = make_float4(q.x, q.y, q.z, q.w);
         } else {                                                  // head = 0 here, so i0 >= 0
-            wraw[r].x = a.w[g0 + min(i0 + 0, a.npi - 1)];
-            wraw[r].y = a.w[g0 + min(i0 + 1, a.npi - 1)];
-            wraw[r].z = a.w[g0 + min(i0 + 2, a.npi - 1)];
-            wraw[r].w = a.w[g0 + min(i0 + 3, a.npi - 1)];
+            wraw[r].x = a.w[g0w + min(i0 + 0, a.npi - 1)];
+            wraw[r].y = a.w[g0w + min(i0 + 1, a.npi - 1)];
+            wraw[r].z = a.w[g0w + min(i0 + 2, a.npi - 1)];
+            wraw[r].w = a.w[g0w + min(i0 + 3, a.npi - 1)];
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) braw[r][c] = brow[min(max(i0 + c, 0), a.npi - 1)];
@@ -355,7 +358,8 @@ __device__ __forceinline__ void moc_zonal_class_row(const ZonalArgs &a, const in
 
     const int jk  = row / a.npj;                                  // row = jk*npj + jj, jj fastest
     const int jj  = row - jk * a.npj;
-    const int64_t g0   = (int64_t)row * a.npi;
+    const int64_t g0w  = (int64_t)row * a.w_row;                  // the row in the weights
+    const int64_t g0   = (int64_t)row * a.z_row;                  // ... and in a record (ALIGNED: the same modulo 4)
     const int     head = ALIGNED ? (int)(g0 & 3) : 0;
     const int     segv = nwaves * (kWave * NV);                   // vectors of a segment
     const int     v0   = seg * segv + wave * (kWave * NV) + lane;
@@ -385,7 +389,7 @@ __device__ __forceinline__ void moc_zonal_class_row(const ZonalArgs &a, const in
         } else {
             i0 = min(4 * v, a.npi - 4);                           // v >= nfull: the anchored vector (in range for every lane)
         }
-        wraw[r] = ZVec<ALIGNED>::ld(a.w + g0 + ioff_of(r, ibase));
+        wraw[r] = ZVec<ALIGNED>::ld(a.w + g0w + ioff_of(r, ibase));
         craw[r] = *reinterpret_cast<const u32u *>(crow + max(0, min(i0, a.npi - 4)));      // (the array is padded past its last row)
     }
     auto load_rec = [&](V4 (&z)[NV], int t) {

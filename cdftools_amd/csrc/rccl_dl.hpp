@@ -2,7 +2,7 @@
 //
 // The library has no link dependency on librccl (a 570 MB shared object that every tool would map at start-up for the sake
 // of one option): the first sharded plan made while the collective mode is CDFT_COLLECTIVE_RCCL opens it (dlopen of
-// librccl.so.1, or the copy a host program such as PyTorch has already mapped) and takes the eight entry points it uses.
+// librccl.so.1, or the copy a host program such as PyTorch has already mapped) and takes the entry points it uses.
 // One process drives all the devices of a ShardSet, so the communicators come from ncclCommInitAll; a collective is issued
 // either from the per-block host threads of shard::for_blocks (one thread per device, no group needed) or, where one thread
 // talks to two devices (the carry hop of cdfpsi), inside ncclGroupStart / ncclGroupEnd.
@@ -19,6 +19,7 @@ enum { kDouble = 8 };                                    // ncclDouble / ncclFlo
 struct Api {
     int (*CommInitAll)(comm_t *, int, const int *);
     int (*CommDestroy)(comm_t);
+    int (*CommAbort)(comm_t);
     int (*AllGather)(const void *, void *, size_t, int, comm_t, hipStream_t);
     int (*Broadcast)(const void *, void *, size_t, int, int, comm_t, hipStream_t);
     int (*Send)(const void *, size_t, int, int, comm_t, hipStream_t);

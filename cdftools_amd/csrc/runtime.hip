@@ -237,29 +237,39 @@ int cdft_feed_resize(cdft_feed *f, size_t slot_bytes, int nslots) {
     if (!f) return fail(CDFT_ERR_ARG, "cdft_feed_resize: NULL argument");
     if (slot_bytes < 1 || nslots < 2 || nslots > 64) return fail(CDFT_ERR_ARG, "cdft_feed_resize: %zu bytes x %d slots", slot_bytes, nslots);
     CDFT_HIP(hipStreamSynchronize(f->st));                      // nothing in flight: the slots can go
-    for (void *h : f->slot) (void)hipHostFree(h);
-    f->slot.clear();
-    f->busy.assign((size_t)nslots, 0);
-    while ((int)f->done.size() < nslots) {
+    // the new ring is built beside the old one and swapped in only when it is complete: a failure leaves the old ring as it was
+    std::vector<hipEvent_t> more;
+    std::vector<void *> fresh;
+    hipError_t e = hipSuccess;
+    while (e == hipSuccess && (int)(f->done.size() + more.size()) < nslots) {
         hipEvent_t ev = nullptr;
-        CDFT_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        f->done.push_back(ev);
+        e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (e == hipSuccess) more.push_back(ev);
     }
+    for (int i = 0; i < nslots && e == hipSuccess; ++i) {
+        void *h = nullptr;
+        e = hipHostMalloc(&h, slot_bytes, hipHostMallocDefault);
+        if (e == hipSuccess) fresh.push_back(h);
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        for (void *h : fresh) (void)hipHostFree(h);
+        for (hipEvent_t ev : more) (void)hipEventDestroy(ev);
+        return fail(CDFT_ERR_ALLOC, "cdft_feed_resize: %d page-locked slots of %zu bytes -> %s (the ring is unchanged)", nslots, slot_bytes,
+                    hipGetErrorString(e));
+    }
+    for (void *h : f->slot) (void)hipHostFree(h);
+    f->slot.swap(fresh);
+    f->done.insert(f->done.end(), more.begin(), more.end());
+    f->busy.assign((size_t)nslots, 0);
     f->slot_bytes = slot_bytes;
     f->cur = 0;
-    for (int i = 0; i < nslots; ++i) {
-        void *h = nullptr;
-        if (hipHostMalloc(&h, slot_bytes, hipHostMallocDefault) != hipSuccess) {
-            (void)hipGetLastError();
-            return fail(CDFT_ERR_ALLOC, "cdft_feed_resize: %d page-locked slots of %zu bytes", nslots, slot_bytes);
-        }
-        f->slot.push_back(h);
-    }
     return CDFT_OK;
 }
 
 int cdft_feed_slot(cdft_feed *f, void **host, size_t *bytes) {
     if (!f || !host) return fail(CDFT_ERR_ARG, "cdft_feed_slot: NULL argument");
+    if (f->slot.empty()) return fail(CDFT_ERR_STATE, "cdft_feed_slot: the ring has no slots");
     if (f->busy[f->cur]) {
         CDFT_HIP(hipEventSynchronize(f->done[f->cur]));
         f->busy[f->cur] = 0;
@@ -271,6 +281,7 @@ int cdft_feed_slot(cdft_feed *f, void **host, size_t *bytes) {
 
 int cdft_feed_push(cdft_feed *f, void *dst, size_t dst_offset, size_t bytes) {
     if (!f || !dst) return fail(CDFT_ERR_ARG, "cdft_feed_push: NULL argument");
+    if (f->slot.empty()) return fail(CDFT_ERR_STATE, "cdft_feed_push: the ring has no slots");
     if (bytes > f->slot_bytes) return fail(CDFT_ERR_ARG, "cdft_feed_push: %zu bytes from a slot of %zu", bytes, f->slot_bytes);
     CDFT_HIP(hipMemcpyAsync((char *)dst + dst_offset, f->slot[f->cur], bytes, hipMemcpyHostToDevice, f->st));
     CDFT_HIP(hipEventRecord(f->done[f->cur], f->st));

@@ -35,6 +35,7 @@ const Api *api() {
     };
     a.CommInitAll = (int (*)(comm_t *, int, const int *))take("ncclCommInitAll");
     a.CommDestroy = (int (*)(comm_t))take("ncclCommDestroy");
+    a.CommAbort = (int (*)(comm_t))take("ncclCommAbort");
     a.AllGather = (int (*)(const void *, void *, size_t, int, comm_t, hipStream_t))take("ncclAllGather");
     a.Broadcast = (int (*)(const void *, void *, size_t, int, int, comm_t, hipStream_t))take("ncclBroadcast");
     a.Send = (int (*)(const void *, size_t, int, int, comm_t, hipStream_t))take("ncclSend");
@@ -232,6 +233,28 @@ int for_blocks(ShardSet &sh, const std::function<int(int)> &fn) {
     return CDFT_OK;
 }
 
+// The collectives of an operation, issued from the blocks' threads: every block must reach its call, or the others wait for
+// the missing rank for ever.  So (1) the fallible per-block work -- reserves, copies, kernels -- runs in a for_blocks pass of
+// its own whose status is checked BEFORE this one starts, and (2) if a block fails here all the same (the enqueue itself, or
+// what follows it on the stream), every communicator is aborted: the blocks already waiting come back with an error instead
+// of hanging, the set is left without communicators and the next sharded RCCL call reports that.
+static int for_blocks_collective(ShardSet &sh, const std::function<int(int)> &fn) {
+    std::atomic<int> failed{0};
+    const int rc = for_blocks(sh, [&](int b) {
+        const int r = fn(b);
+        if (r != CDFT_OK && !failed.exchange(1) && rccl::api())
+            for (void *c : sh.comm) if (c) (void)rccl::api()->CommAbort(c);
+        return r;
+    });
+    if (failed.load()) sh.comm.assign(sh.comm.size(), nullptr);
+    return rc;
+}
+static int comms_alive(const ShardSet &sh, const char *who) {
+    for (void *c : sh.comm)
+        if (!c) return fail(CDFT_ERR_STATE, "%s: the plan's RCCL communicators were aborted by an earlier failure; make a new plan", who);
+    return CDFT_OK;
+}
+
 static int rows_copy(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t height, hipStream_t st) {
     if (width == 0 || height == 0) return CDFT_OK;
     if (dpitch == width && spitch == width) {
@@ -298,7 +321,7 @@ int moc_set_mesh(ShardSet &sh, const float *e1v, const float *e3v, const int8_t 
     });
 }
 
-// the records of a call, or of cdft_moc_stage, in each block's HBM (B[4], kept until the next one)
+// the records of a call in each block's HBM (B[4], dense, kept until the next call)
 static int moc_rows_to_block(ShardSet &sh, int b, const float *zv, int64_t rec_stride, int npt) {
     const int j0 = sh.j0[b], j1 = sh.j1[b], nloc = j1 - j0;
     const size_t n3 = (size_t)sh.npi * nloc * sh.npk;
@@ -310,37 +333,49 @@ static int moc_rows_to_block(ShardSet &sh, int b, const float *zv, int64_t rec_s
     return CDFT_OK;
 }
 
-static int moc_block_run(ShardSet &sh, int b, int npt, double *dmoc) {
-    const int j0 = sh.j0[b], j1 = sh.j1[b], nloc = j1 - j0;
-    const size_t n3 = (size_t)sh.npi * nloc * sh.npk;
+// dmoc(nbasins,npjglo,npk,npt): the rows of this block, every level and record, in place
+static int moc_block_out(ShardSet &sh, int b, int npt, double *dmoc) {
     hipStream_t st = sh.st[b];
-    DevBuf *B = sh.buf[b].data();
-    CDFT_TRY(B[5].reserve((size_t)sh.nb * nloc * sh.npk * npt * 8));
-    CDFT_TRY(cdft_moc_compute((cdft_moc_plan *)sh.part[b], (const float *)B[4].ptr, (int64_t)n3, npt, CDFT_MEM_DEVICE,
-                              (double *)B[5].ptr, CDFT_MEM_DEVICE, st));
-    // dmoc(nbasins,npjglo,npk,npt): the rows of this block, every level and record, in place
-    CDFT_TRY(rows_out(dmoc, B[5].ptr, (size_t)sh.nb * 8, sh.npj, j0, j1, (size_t)sh.npk * npt, 0, st));
+    CDFT_TRY(rows_out(dmoc, sh.buf[b][5].ptr, (size_t)sh.nb * 8, sh.npj, sh.j0[b], sh.j1[b], (size_t)sh.npk * npt, 0, st));
     CDFT_HIP(hipStreamSynchronize(st));
     return CDFT_OK;
 }
 
 int moc_compute(ShardSet &sh, const float *zv, int64_t rec_stride, int npt, double *dmoc) {
     return for_blocks(sh, [&](int b) {
+        const int nloc = sh.j1[b] - sh.j0[b];
+        DevBuf *B = sh.buf[b].data();
         CDFT_TRY(moc_rows_to_block(sh, b, zv, rec_stride, npt));
-        return moc_block_run(sh, b, npt, dmoc);
+        CDFT_TRY(B[5].reserve((size_t)sh.nb * nloc * sh.npk * npt * 8));
+        CDFT_TRY(cdft_moc_compute((cdft_moc_plan *)sh.part[b], (const float *)B[4].ptr, (int64_t)sh.npi * nloc * sh.npk, npt, CDFT_MEM_DEVICE,
+                                  (double *)B[5].ptr, CDFT_MEM_DEVICE, sh.st[b]));
+        return moc_block_out(sh, b, npt, dmoc);
     });
 }
 
+// cdft_moc_stage: every block takes its rows [j0,j1) of every level of every record where they lie, straight into the pool
+// of its plan (moc.hip: a row's weights and records in one run)
 int moc_stage(ShardSet &sh, const float *zv, int64_t rec_stride, int npt) {
+    hipPointerAttribute_t at;
+    const bool dev = hipPointerGetAttributes(&at, zv) == hipSuccess && at.type == hipMemoryTypeDevice;
+    if (!dev) (void)hipGetLastError();
     return for_blocks(sh, [&](int b) {
-        CDFT_TRY(moc_rows_to_block(sh, b, zv, rec_stride, npt));
+        sh.buf[b][4].release();                                  // (the dense records of an earlier cdft_moc_compute)
+        CDFT_TRY(cdft_moc_stage_rows((cdft_moc_plan *)sh.part[b], zv + (size_t)sh.npi * sh.j0[b], rec_stride, (int64_t)sh.npi * sh.npj, npt,
+                                     dev ? CDFT_MEM_DEVICE : CDFT_MEM_HOST, sh.st[b]));
         CDFT_HIP(hipStreamSynchronize(sh.st[b]));
         return CDFT_OK;
     });
 }
 
 int moc_run(ShardSet &sh, int npt, double *dmoc) {
-    return for_blocks(sh, [&](int b) { return moc_block_run(sh, b, npt, dmoc); });
+    return for_blocks(sh, [&](int b) {
+        const int nloc = sh.j1[b] - sh.j0[b];
+        DevBuf *B = sh.buf[b].data();
+        CDFT_TRY(B[5].reserve((size_t)sh.nb * nloc * sh.npk * npt * 8));
+        CDFT_TRY(cdft_moc_compute_staged((cdft_moc_plan *)sh.part[b], (double *)B[5].ptr, CDFT_MEM_DEVICE, sh.st[b]));
+        return moc_block_out(sh, b, npt, dmoc);
+    });
 }
 
 // =================================================================================================== cdfheatc
@@ -430,6 +465,8 @@ int heatc_compute(ShardSet &sh, const float *temp, const float *rmxldep, const f
     }
     const size_t nsum = (size_t)3 * sh.npk;
     std::vector<double> gathered(sh.rccl() ? nsum * n : 0);
+    if (sh.rccl()) CDFT_TRY(comms_alive(sh, "cdft_heatc_compute"));
+    // pass 1: everything that can fail on one block alone (status checked before any collective is issued)
     CDFT_TRY(for_blocks(sh, [&](int b) {
         const int j0 = sh.j0[b], j1 = sh.j1[b], nloc = j1 - j0;
         const size_t nij = (size_t)sh.npi * nloc;
@@ -444,17 +481,25 @@ int heatc_compute(ShardSet &sh, const float *temp, const float *rmxldep, const f
         if (!sh.rccl())
             return cdft_heatc_compute((cdft_heatc_plan *)sh.part[b], (const float *)B[5].ptr, CDFT_MEM_DEVICE,
                                       mxloption ? (const float *)B[6].ptr : nullptr, gdepw, mxloption, part[b].data(), CDFT_MEM_HOST, st);
-        // RCCL: the block's sums stay in its HBM, ONE all-gather hands every block the (npk,3) sums of all of them in block
-        // order (1.8 KB per block at 75 levels); block 0's copy comes to the host, where they are added as below
+        // RCCL: the block's sums stay in its HBM for the all-gather of pass 2
         CDFT_TRY(B[7].reserve(nsum * 8));
         CDFT_TRY(B[8].reserve(nsum * 8 * n));
         CDFT_TRY(cdft_heatc_compute((cdft_heatc_plan *)sh.part[b], (const float *)B[5].ptr, CDFT_MEM_DEVICE,
                                     mxloption ? (const float *)B[6].ptr : nullptr, gdepw, mxloption, (double *)B[7].ptr, CDFT_MEM_DEVICE, st));
-        CDFT_RCCL(rccl::api()->AllGather(B[7].ptr, B[8].ptr, nsum, rccl::kDouble, sh.comm[b], st));
-        if (b == 0) CDFT_HIP(hipMemcpyAsync(gathered.data(), B[8].ptr, nsum * 8 * n, hipMemcpyDeviceToHost, st));
-        CDFT_HIP(hipStreamSynchronize(st));
+        CDFT_HIP(hipStreamSynchronize(st));                       // (a failed kernel shows here, not behind the collective)
         return CDFT_OK;
     }));
+    // pass 2 (RCCL): ONE all-gather hands every block the (npk,3) sums of all of them in block order (1.8 KB per block at 75
+    // levels); block 0's copy comes to the host, where they are added as below
+    if (sh.rccl())
+        CDFT_TRY(for_blocks_collective(sh, [&](int b) {
+            hipStream_t st = sh.st[b];
+            DevBuf *B = sh.buf[b].data();
+            CDFT_RCCL(rccl::api()->AllGather(B[7].ptr, B[8].ptr, nsum, rccl::kDouble, sh.comm[b], st));
+            if (b == 0) CDFT_HIP(hipMemcpyAsync(gathered.data(), B[8].ptr, nsum * 8 * n, hipMemcpyDeviceToHost, st));
+            CDFT_HIP(hipStreamSynchronize(st));
+            return CDFT_OK;
+        }));
     if (sh.rccl())
         for (int b = 0; b < n; ++b) memcpy(part[b].data(), gathered.data() + (size_t)b * nsum, nsum * 8);
     // src/cdfheatc.f90:225-229 sums the whole level; here the blocks' r8 sums are added in block order
@@ -598,6 +643,7 @@ int psi_scan_u(ShardSet &sh) {
     // ncclSend / ncclRecv pair (one host thread, two devices: inside a group)
     const int n = sh.nblk();
     DeviceGuard guard;
+    if (sh.rccl()) CDFT_TRY(comms_alive(sh, "cdft_psi_scan_u"));
     for (int b = 0; b < n; ++b) {
         CDFT_HIP(hipSetDevice(sh.dev[b]));
         DevBuf *B = sh.buf[b].data();
@@ -640,14 +686,13 @@ int psi_finish(ShardSet &sh, int use_ref, double ref_value, int iiref, int ijref
     if (bcast && (iiref < 1 || iiref > sh.npi || ijref < 1 || ijref > sh.npj))
         return fail(CDFT_ERR_ARG, "cdft_psi_value: point (%d,%d) outside the domain", iiref, ijref);
     const int owner = bcast ? owner_of_row(sh, ijref) : -1;
-    // normalisation, mask, SNGL: every block writes its rows of the caller's arrays
-    return for_blocks(sh, [&](int b) {
-        const int j0 = sh.j0[b], j1 = sh.j1[b];
-        const size_t off = (size_t)sh.npi * j0, nij = (size_t)sh.npi * (j1 - j0);
-        DevBuf *B = sh.buf[b].data();
-        hipStream_t st = sh.st[b];
-        double ref = ref0;
-        if (bcast) {                                           // RCCL mode: the owner's value reaches every block by ncclBroadcast
+    if (bcast) {
+        // RCCL mode: the owner's value reaches every block by ncclBroadcast.  First what can fail on one block alone (the
+        // one-word buffers, the owner reading its value), checked; then the collective, every block reaching its call.
+        CDFT_TRY(comms_alive(sh, "cdft_psi_finish"));
+        CDFT_TRY(for_blocks(sh, [&](int b) {
+            DevBuf *B = sh.buf[b].data();
+            hipStream_t st = sh.st[b];
             CDFT_TRY(B[12].reserve(8));
             if (b == owner) {
                 double v = 0.0;
@@ -655,10 +700,28 @@ int psi_finish(ShardSet &sh, int use_ref, double ref_value, int iiref, int ijref
                 CDFT_HIP(hipMemcpyAsync(B[12].ptr, &v, 8, hipMemcpyHostToDevice, st));
                 CDFT_HIP(hipStreamSynchronize(st));
             }
+            return CDFT_OK;
+        }));
+        std::vector<double> refs((size_t)sh.nblk(), 0.0);
+        CDFT_TRY(for_blocks_collective(sh, [&](int b) {
+            DevBuf *B = sh.buf[b].data();
+            hipStream_t st = sh.st[b];
             CDFT_RCCL(rccl::api()->Broadcast(B[12].ptr, B[12].ptr, 1, rccl::kDouble, owner, sh.comm[b], st));
-            CDFT_HIP(hipMemcpyAsync(&ref, B[12].ptr, 8, hipMemcpyDeviceToHost, st));
+            CDFT_HIP(hipMemcpyAsync(&refs[b], B[12].ptr, 8, hipMemcpyDeviceToHost, st));
             CDFT_HIP(hipStreamSynchronize(st));
-        }
+            return CDFT_OK;
+        }));
+        ref0 = refs[0];                                           // (every block received the owner's word: the same bits)
+        for (int b = 1; b < sh.nblk(); ++b)
+            if (memcmp(&refs[b], &ref0, 8) != 0) return fail(CDFT_ERR_HIP, "cdft_psi_finish: block %d received another reference value than block 0", b);
+    }
+    // normalisation, mask, SNGL: every block writes its rows of the caller's arrays
+    return for_blocks(sh, [&](int b) {
+        const int j0 = sh.j0[b], j1 = sh.j1[b];
+        const size_t off = (size_t)sh.npi * j0, nij = (size_t)sh.npi * (j1 - j0);
+        DevBuf *B = sh.buf[b].data();
+        hipStream_t st = sh.st[b];
+        const double ref = ref0;
         if (fmask) {
             CDFT_TRY(B[7].reserve(nij * 4));
             CDFT_TRY(rows_in(B[7].ptr, fmask, (size_t)sh.npi * 4, sh.npj, j0, j1, 1, 0, st));

@@ -1180,6 +1180,12 @@ CONTAINS
     CALL tic()
     closeout = NF90_CLOSE(kout)
     CALL toc(dtime_write)
+    ! the close waits for the slabs putvar_behind queued and reports a failed one: stop as the synchronous putvar's
+    ! NetCDF error would have (no program looks at closeout's value, the reference's included)
+    IF ( closeout /= NF90_NOERR ) THEN
+       PRINT *, ' ERROR while closing the output file : ', TRIM(NF90_STRERROR(closeout))
+       STOP 98
+    ENDIF
     CALL src_forget()
     IF ( ntiming == 1 ) WRITE(0,'(a,f9.3,a,f9.3)') ' CDFT_TIMING cdfio (s): reads', dtime_read, '  writes', dtime_write
   END FUNCTION closeout

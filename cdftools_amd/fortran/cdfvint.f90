@@ -247,6 +247,7 @@ PROGRAM cdfvint
         IF ( kout(jk) >= 0 ) ierr = putvar(ncout, id_varout(1), zout(:,:,kout(jk)+1), kout(jk)+1, npiglo, npjglo, ktime=jt)
      END DO
   END DO
+  IF ( lfeed ) CALL wait_writes(ncout)                    ! the last levels of the last record (a failed write stops here)
   ierr = closeout(ncout)
   IF ( lfeed ) THEN
      CALL feed_release(pd_zt) ; CALL feed_release(pd_msk) ; CALL feed_release(pd_e3) ; CALL feed_release(pd_e31) ; CALL feed_release(pd_out)

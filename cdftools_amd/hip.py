@@ -244,6 +244,22 @@ class MocPlan:
         self._staged = (kz, npt)                          # a single-device plan borrows a device array: keep it alive
         check(_lib.load().cdft_moc_stage(self._h, pz, rec_stride or n3, npt, sz, stream or current_stream_ptr()))
 
+    def stage_rows(self, zv, j0, npj_full, stream=None):
+        """cdft_moc_stage_rows: zv (npt,npk,npj_full,npi) r4 of a LARGER domain, this plan's rows being [j0, j0+npj) of it."""
+        pz, sz, kz = _arg(zv, np.float32, "zv")
+        lev = self.npi * npj_full
+        npt = int(np.prod(kz.shape)) // (lev * self.npk)
+        self._staged = (kz, npt)
+        base = C.c_void_p(pz.value + 4 * self.npi * j0)
+        check(_lib.load().cdft_moc_stage_rows(self._h, base, lev * self.npk, lev, npt, sz, stream or current_stream_ptr()))
+
+    def compute_pitched(self, zv_ptr, rec_stride, row_stride, npt, out, stream=None):
+        """Records in a pitched layout in HBM (cdft_moc_compute_pitched): zv_ptr a device address (int), strides in elements."""
+        po, so, ko = _arg(out, np.float64, "dmoc")
+        check(_lib.load().cdft_moc_compute_pitched(self._h, C.c_void_p(int(zv_ptr)), int(rec_stride), int(row_stride), int(npt), po, so,
+                                                   stream or current_stream_ptr()))
+        return out
+
     def compute_staged(self, out, stream=None):
         """dmoc (npt,npk,npj,nb) r8 of the staged records into `out` (NumPy array or CUDA tensor)."""
         po, so, ko = _arg(out, np.float64, "dmoc")

@@ -642,9 +642,11 @@ int ncc_redef(int ncid) {
 }
 
 int ncc_close(int ncid) {
-    File *f = getf(ncid);
+    File *f = getf(ncid);                               /* (waits for the queued writes) */
     if (!f) return NCC_EBADID;
-    int rc = 0;
+    /* a queued write that failed and that no ncc_wait_writes has reported yet: the close reports it, as the synchronous
+     * ncc_put_vara would have */
+    int rc = f->wb ? f->wb->rc : 0;
     if (f->nc4w) {
         int rc4 = f->indef ? ncc_enddef(ncid) : 0;     /* a file that never left define mode is still created */
         if (f->h5) { const int r2 = g_h5_finish(f->h5, f->numrecs); if (!rc4) rc4 = r2; }
@@ -657,8 +659,10 @@ int ncc_close(int ncid) {
         return 0;
     }
     if (f->writable) {
-        if (f->indef) rc = ncc_enddef(ncid);
-        else if (f->hdr_dirty || f->nrec_dirty) rc = write_header(f);
+        int rh = 0;
+        if (f->indef) rh = ncc_enddef(ncid);
+        else if (f->hdr_dirty || f->nrec_dirty) rh = write_header(f);
+        if (!rc) rc = rh;
         /* the file must extend over every fixed variable and every complete record */
         uint64_t end = f->hdr_size;
         for (int i = 0; i < f->nvars; ++i) {

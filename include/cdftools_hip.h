@@ -169,12 +169,31 @@ int cdft_moc_compute(cdft_moc_plan *plan, const float *zv, int64_t rec_stride, i
 /* (dmoc_space = CDFT_MEM_PINNED: the result is on its way when the call returns; cdft_stream_sync(stream) before reading.) */
 
 /* The records handed over ONCE and used by any number of cdft_moc_compute_staged calls: the equivalent of the program
- * having read its velocity records (src/cdfmoc.f90:355-358) before the loops run.  A single-device plan keeps a device
- * array as it is (the caller keeps it alive) and copies a host array to HBM; a sharded plan moves every block's rows into
- * that block's HBM, so that the compute calls that follow involve no transfer of inputs at all -- what a resident multi-GPU
- * run is.  cdft_moc_compute forgets the staged records (it may reuse their staging memory). */
+ * having read its velocity records (src/cdfmoc.f90:355-358) before the loops run.  The plan copies them (host or device
+ * arrays, dense like cdft_moc_compute's) into its own layout in HBM, the POOL: row (jj,jk) of the domain owns one contiguous
+ * run of 1+npt slots of P r4 (P = npiglo rounded up to a multiple of 4) -- the row's weights e1v*e3v (src/cdfmoc.f90:374),
+ * then the row of record 1, of record 2, ... -- which is what the workgroup of that row reads, front to back, instead of
+ * 1+npt runs a whole field (4.7 GB at eORCA12) apart.  The caller's array is free again when the stream has passed the call
+ * (at once for pageable host memory).  A sharded plan moves every block's rows into that block's pool, so that the compute
+ * calls that follow involve no transfer of inputs at all -- what a resident multi-GPU run is.  A new mesh
+ * (cdft_moc_set_mesh) keeps the staged records and brings its weights into the pool at the next cdft_moc_compute_staged.
+ * cdft_moc_stage_rows: the same for records whose LEVELS are lev_stride elements apart (>= npiglo*npjglo; rows dense): a
+ * row block of a larger domain, taken where it lies (single-device plans).
+ * CDFT_MOC_POOL=0 (A/B hook): keep the records as they came instead (a device array is then borrowed, not copied). */
 int cdft_moc_stage(cdft_moc_plan *plan, const float *zv, int64_t rec_stride, int npt, int zv_space, void *stream);
+int cdft_moc_stage_rows(cdft_moc_plan *plan, const float *zv, int64_t rec_stride, int64_t lev_stride, int npt, int zv_space,
+                        void *stream);
 int cdft_moc_compute_staged(cdft_moc_plan *plan, double *dmoc, int dmoc_space, void *stream);
+
+/* Records the CALLER keeps in a pitched layout in HBM.  The reference's zv(npiglo,npjglo) slab per (level, record) is
+ * dense (src/cdfmoc.f90:357 getvar); in HBM the rows of a field need not be: element (ji,jj,jk) of record t lies at
+ *     zv[t * rec_stride + ((jk-1) * npjglo + (jj-1)) * row_stride + (ji-1)]          (elements, r4)
+ * with row_stride >= npiglo.  Either the records are the outer dimension (rec_stride >= the span of a record) or the rows
+ * are (row_stride >= the span of the npt records of a row).  The weights stay the plan's dense array: 16-byte vector loads
+ * need every record base 16-byte aligned and row_stride = npiglo modulo 4; anything else is read through the (slower)
+ * unaligned path, with the same results up to the order of the r8 additions.  Device memory, single-device plans. */
+int cdft_moc_compute_pitched(cdft_moc_plan *plan, const float *zv, int64_t rec_stride, int64_t row_stride, int npt,
+                             double *dmoc, int dmoc_space, void *stream);
 
 /* cdfmoc -decomp (src/cdfmoc.f90:353, :360-365, :390-517): the total overturning of ONE record and its
  * geostrophic-shear, barotropic and ageostrophic parts.  Needs cdft_moc_set_mesh (weights, basins)

@@ -31,7 +31,7 @@ def test_bench_n1_line_small_workload(gpu):
     assert rf["launches"] == 20 and rf["min_launch_ms"] <= rf["median_launch_ms"] <= rf["max_launch_ms"]
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and r["cpu_baseline"]["cores"] >= 1
     assert r["cpu_baseline"]["kind"] == "port" and r["cpu_baseline"]["value"] > 0
-    assert rf["traffic"] is None and "measured" in rf["traffic_source"]       # the PMC passes are another kernel shape's (eORCA12), not this run's
+    assert rf["traffic"] is None and "measured" in rf["traffic_source_builders_pmc_run"]       # the PMC passes are another kernel shape's (eORCA12), not this run's
     assert r["comm"] is None and r["per_rank"] is None
     ip = r["inprocess"]                              # the in-process leg: the sharded plan (one block here) in a child process
     assert ip["mode"] == "inprocess" and ip["n_gpus"] == 1 and ip["oracle_check_rel_err"] < 1e-11, ip

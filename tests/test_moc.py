@@ -276,6 +276,131 @@ def test_hip_records_that_are_not_16_byte_aligned(gpu, npi, nb, mode, kernel):
     assert torch.equal(out, again)
 
 
+# ----------------------------------------------------------------------------- GPU: staged records (the pool layout)
+POOL_CASES = [
+    # npi, npj, npk, nb, npt
+    (24, 18, 7, 5, 2), (182, 149, 31, 5, 3), (182, 149, 31, 1, 2), (1, 3, 2, 1, 1), (3, 2, 2, 5, 3),
+    (63, 5, 4, 5, 1), (64, 5, 4, 5, 2), (65, 5, 4, 5, 1), (66, 5, 4, 5, 2), (255, 3, 3, 8, 2), (257, 3, 3, 3, 2),
+    (1031, 7, 5, 5, 17), (1032, 4, 5, 5, 16), (4322, 3, 4, 5, 12), (1442, 4, 3, 5, 12), (12960, 2, 3, 5, 2), (12962, 2, 3, 1, 2),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("npi,npj,npk,nb,npt", POOL_CASES)
+def test_hip_staged_records_in_the_pool_layout(gpu, npi, npj, npk, nb, npt):
+    """cdft_moc_stage lays the records out in the plan's pool -- every (jj,jk) row's weights and its npt records in ONE run,
+    slots of npiglo rounded up to 4 -- and cdft_moc_compute_staged reads that: the same tolerance against the oracle as the
+    dense arrays, the same bits from a host and from a device source and from call to call, level npk zero; a new mesh
+    keeps the staged records and brings its own weights; CDFT_MOC_POOL=0 keeps the records as they came (= cdft_moc_compute)."""
+    import torch
+    g = synth.make_grid(npi, npj, npk, seed=npi + 3 * npj, nbasins=nb)
+    e1v, e3v, ib = synth.moc_inputs(g)
+    zv = synth.velocity(g, npt, seed=6)
+    ref = oracle_lib.moc(e1v, e3v, ib, zv)
+    bound = abs_bound(e1v, e3v, ib, zv)
+    plan = gpu.MocPlan(npi, npj, npk, nb)
+    plan.set_mesh(e1v, e3v, ib)
+    plan.stage(zv)
+    a = plan.compute_staged(np.full(ref.shape, np.nan))
+    assert_moc_close(a, ref, bound)
+    assert np.all(a[:, npk - 1] == 0.0)
+    assert np.array_equal(plan.compute_staged(np.zeros_like(ref)), a)
+    dense = plan.compute(zv)                                           # (does not disturb the pool)
+    assert_moc_close(dense, ref, bound)
+    assert np.array_equal(plan.compute_staged(np.zeros_like(ref)), a)
+    plan.stage(torch.from_numpy(zv).cuda())
+    dout = plan.compute_staged(torch.zeros(ref.shape, dtype=torch.float64, device="cuda"))
+    assert np.array_equal(dout.cpu().numpy(), a)
+    # what lands in moc.nc is REAL(dmoc): within one r4 ulp of the oracle's
+    r32 = ref.astype(np.float32)
+    assert np.all(np.abs(a.astype(np.float32).astype(np.float64) - r32) <= np.spacing(np.abs(r32)).astype(np.float64))
+    # another mesh, the same staged records
+    e3v2 = (e3v * np.float32(0.5)).astype(np.float32)
+    plan.set_mesh(e1v, e3v2, ib)
+    b = plan.compute_staged(np.zeros_like(ref))
+    assert_moc_close(b, oracle_lib.moc(e1v, e3v2, ib, zv), abs_bound(e1v, e3v2, ib, zv))
+    plan.close()
+
+
+@pytest.mark.gpu
+def test_hip_pool_switch_keeps_the_records_as_they_came(gpu, monkeypatch):
+    npi, npj, npk, nb, npt = 182, 40, 9, 5, 3
+    g = synth.make_grid(npi, npj, npk, seed=11, nbasins=nb)
+    e1v, e3v, ib = synth.moc_inputs(g)
+    zv = synth.velocity(g, npt, seed=12)
+    plan = gpu.MocPlan(npi, npj, npk, nb)
+    plan.set_mesh(e1v, e3v, ib)
+    dense = plan.compute(zv)
+    monkeypatch.setenv("CDFT_MOC_POOL", "0")
+    plan.stage(zv)
+    assert np.array_equal(plan.compute_staged(np.zeros_like(dense)), dense)
+    plan.compute(zv)                                                    # the staging memory is reused: the records are forgotten
+    with pytest.raises(gpu.CdftError):
+        plan.compute_staged(np.zeros_like(dense))
+    plan.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("npi,nb", [(182, 5), (333, 5), (64, 1), (1190, 5), (5, 3)])
+@pytest.mark.parametrize("layout", ["records outer, padded rows (aligned)", "records outer, padded rows (unaligned)",
+                                    "rows outer", "rows outer, odd slot"])
+def test_hip_records_in_a_pitched_layout_of_the_callers(gpu, npi, nb, layout):
+    """cdft_moc_compute_pitched: the caller's records with rows row_stride apart, records outer or rows outer; 16-byte loads
+    when row_stride = npiglo modulo 4 and the bases are aligned, the unaligned path otherwise; overlapping strides refused."""
+    import torch
+    npj, npk, npt = 6, 4, 3
+    rows = npj * npk
+    g = synth.make_grid(npi, npj, npk, seed=21, nbasins=nb)
+    e1v, e3v, ib = synth.moc_inputs(g)
+    zv = synth.velocity(g, npt, seed=22)
+    ref = oracle_lib.moc(e1v, e3v, ib, zv)
+    if layout.startswith("records outer"):
+        rs = npi + (8 if "(aligned)" in layout else 7)
+        rec = rows * rs + 12
+        strides = (rec, npj * rs, rs, 1)
+    else:
+        slot = ((npi + 3) // 4 * 4) if layout == "rows outer" else npi + 1
+        rs, rec = npt * slot + 4, slot
+        strides = (rec, npj * rs, rs, 1)
+    span = (npt - 1) * strides[0] + (rows - 1) * rs + npi
+    buf = torch.full((span + 64,), float("nan"), dtype=torch.float32, device="cuda")   # what lies between the rows is never used
+    buf.as_strided((npt, npk, npj, npi), strides).copy_(torch.from_numpy(zv).cuda())
+    plan = gpu.MocPlan(npi, npj, npk, nb)
+    plan.set_mesh(e1v, e3v, ib)
+    out = torch.zeros((npt, npk, npj, nb), dtype=torch.float64, device="cuda")
+    plan.compute_pitched(buf.data_ptr(), rec, rs, npt, out)
+    torch.cuda.synchronize()
+    assert_moc_close(out.cpu().numpy(), ref, abs_bound(e1v, e3v, ib, zv))
+    again = torch.zeros_like(out)
+    plan.compute_pitched(buf.data_ptr(), rec, rs, npt, again)
+    assert torch.equal(out, again)
+    with pytest.raises(gpu.CdftError):                                  # rows of a record overlap the next record
+        plan.compute_pitched(buf.data_ptr(), npi + 1, npi + 2, 2, again)
+    with pytest.raises(gpu.CdftError):
+        plan.compute_pitched(buf.data_ptr(), rec, npi - 1, npt, again)
+    plan.close()
+
+
+@pytest.mark.gpu
+def test_hip_stage_rows_takes_a_row_block_where_it_lies(gpu):
+    """cdft_moc_stage_rows: the rows [j0,j1) of a larger domain's records (levels lev_stride apart) into the pool of a plan
+    made for those rows = the plan given the extracted block."""
+    import torch
+    npi, npj, npk, nb, npt = 182, 60, 7, 5, 3
+    j0, j1 = 17, 41
+    g = synth.make_grid(npi, npj, npk, seed=31, nbasins=nb)
+    e1v, e3v, ib = synth.moc_inputs(g)
+    zv = synth.velocity(g, npt, seed=32)
+    blk = gpu.MocPlan(npi, j1 - j0, npk, nb)
+    blk.set_mesh(np.ascontiguousarray(e1v[j0:j1]), np.ascontiguousarray(e3v[:, j0:j1]), np.ascontiguousarray(ib[j0:j1]))
+    blk.stage(np.ascontiguousarray(zv[:, :, j0:j1]))
+    want = blk.compute_staged(np.zeros((npt, npk, j1 - j0, nb)))
+    for src in (zv, torch.from_numpy(zv).cuda()):
+        blk.stage_rows(src, j0, npj)
+        assert np.array_equal(blk.compute_staged(np.zeros_like(want)), want)
+    blk.close()
+
+
 @pytest.mark.gpu
 def test_hip_rejects_bad_masks_and_call_order(gpu):
     g = synth.make_grid(16, 4, 3, seed=1, nbasins=1)

@@ -303,6 +303,32 @@ def test_large_writes_split_over_threads_are_what_scipy_reads(nc, tmp_path, monk
             assert np.array_equal(f.variables[name][:], a), name
 
 
+def test_close_reports_a_failed_queued_write(nc, tmp_path):
+    """A write queued by ncc_put_vara_behind that fails and that no ncc_wait_writes has collected: ncc_close -- which drains the
+    queue -- returns its error instead of 0 (a program that goes from its last putvar_behind straight to closeout must not
+    leave a short file behind with exit status 0); a close after a collected error, or with nothing queued, returns 0."""
+    nij = 1000
+    for collect in (False, True):
+        path = str(tmp_path / f"fail{int(collect)}.nc")
+        ncid, dt, dz, dx, v4 = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        ok(nc, nc.ncc_create(path.encode(), 2, 1, C.byref(ncid)))
+        ok(nc, nc.ncc_def_dim(ncid, b"t", C.c_size_t(0), C.byref(dt)))
+        ok(nc, nc.ncc_def_dim(ncid, b"z", C.c_size_t(3), C.byref(dz)))
+        ok(nc, nc.ncc_def_dim(ncid, b"x", C.c_size_t(nij), C.byref(dx)))
+        ok(nc, nc.ncc_def_var(ncid, b"v4", FLOAT, 3, (C.c_int * 3)(dt.value, dz.value, dx.value), C.byref(v4)))
+        ok(nc, nc.ncc_enddef(ncid))
+        a = np.arange(nij, dtype=np.float32)
+        ok(nc, nc.ncc_put_vara_behind(ncid, v4, sz(0, 0, 0), sz(1, 1, nij), FLOAT, a.ctypes.data_as(C.c_void_p)))
+        ok(nc, nc.ncc_put_vara_behind(ncid, v4, sz(0, 3, 0), sz(1, 1, nij), FLOAT, a.ctypes.data_as(C.c_void_p)))   # outside z
+        if collect:
+            assert nc.ncc_wait_writes(ncid) != 0
+            ok(nc, nc.ncc_close(ncid))
+        else:
+            assert nc.ncc_close(ncid) != 0
+        with netcdf_file(path, "r", mmap=False) as f:                          # the good write is in the file either way
+            assert np.array_equal(f.variables["v4"][0, 0], a)
+
+
 @pytest.mark.parametrize("threads", ["1", "5"])
 def test_writes_queued_behind_are_in_the_file_in_order(nc, tmp_path, monkeypatch, threads):
     """ncc_put_vara_behind: the levels of a record variable queued one after the other (more requests than the queue holds, r4

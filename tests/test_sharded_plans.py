@@ -200,8 +200,10 @@ def test_sharded_vt_is_bit_identical_to_one_device(gpu, devices):
 @pytest.mark.gpu
 @pytest.mark.parametrize("devices", [None, [0], [0, 0, 0]])
 def test_staged_records_and_per_block_probes(gpu, devices):
-    """cdft_moc_stage + cdft_moc_compute_staged (what bench.py --mode inprocess times): the records are handed over once, every
-    later call gives the bits of cdft_moc_compute; the launch probe of a sharded plan speaks per block."""
+    """cdft_moc_stage + cdft_moc_compute_staged (what bench.py times): the records are handed over once into the plan's pool
+    layout (every row's weights and records in one run), every later call gives the same bits -- for any number of row
+    blocks, since a row's sums depend on nothing but the row in that layout -- within the stated tolerance of the oracle;
+    the launch probe of a sharded plan speaks per block."""
     import torch
     npi, npj, npk, nb = 182, 149, 31, 5
     g = synth.make_grid(npi, npj, npk, seed=3, nbasins=nb)
@@ -209,9 +211,17 @@ def test_staged_records_and_per_block_probes(gpu, devices):
     zv = synth.velocity(g, 3, seed=5)
     p = gpu.MocPlan(npi, npj, npk, nb, devices=devices)
     p.set_mesh(e1v, e3v, ib)
-    ref = p.compute(zv)
-    with pytest.raises(gpu.CdftError):                              # nothing staged (and compute forgets what was)
-        p.compute_staged(np.empty_like(ref))
+    import oracle_lib
+    dense = p.compute(zv)
+    with pytest.raises(gpu.CdftError):                              # nothing staged
+        p.compute_staged(np.empty_like(dense))
+    one = gpu.MocPlan(npi, npj, npk, nb)
+    one.set_mesh(e1v, e3v, ib)
+    one.stage(zv)
+    ref = one.compute_staged(np.zeros_like(dense))                   # one device, the pool layout
+    want = oracle_lib.moc(e1v, e3v, ib, zv)
+    lim = 1e-13 * -oracle_lib.moc(e1v, e3v, ib, np.abs(zv)) + 1e-300
+    assert np.all(np.abs(ref - want) <= lim) and np.all(np.abs(dense - want) <= lim)
     for src in (zv, torch.from_numpy(zv).cuda()):
         p.stage(src)
         p.profile_enable(True)
