@@ -1,0 +1,38 @@
+#!/bin/sh
+# The reference's own PROGRAMS, unmodified, compiled where they lie under /root/reference/src into oracle/_ref/prog/
+# (git-ignored, never pushed to the GPU box: .gpurunignore).  Build container only.
+#
+# What this is, and is not.  The reference programs need netcdf-fortran, which the image lacks; here they are linked against
+# the NetCDF layer this repository ships for its own programs (cdftools_amd/fortran/netcdf.f90 over libncclassic.so) -- a
+# product component that exists whatever the reference does, not something written to make the reference build.  The
+# result is a DIFFERENTIAL of the program level (option parsing, CreateOutput, the cdfio calls, the order of variables and
+# attributes, stdout), used by tests/make_golden_prog.py to write tests/golden/prog_*.npz.  It is NOT a parity pin: both
+# sides read and write through the same NetCDF backend, whose own check is scipy.io.netcdf_file (tests/test_ncclassic.py).
+# The arithmetic pins stay oracle/ref_lift.py (statements) and src/eos.f90 (ref_build.sh).
+# Flags as ref_build.sh: -O1 (the reference's plain -O), no FMA contraction; -Dkey_netcdf4 as the reference's Makefile.
+set -e
+cd "$(dirname "$0")"
+REF=/root/reference/src
+FC=${FC:-amdflang}
+FB=../cdftools_amd/fortran/build
+LIBDIR=$(cd ../cdftools_amd/lib && pwd)
+[ -f $FB/netcdf.o ] || { echo "oracle/_ref/prog: build cdftools_amd/fortran first (its netcdf module is linked)"; exit 1; }
+mkdir -p _ref/prog/obj
+O=_ref/prog/obj
+FLAGS="-O1 -ffp-contract=off -cpp -Dkey_netcdf4 -w"
+new=0
+for f in modcdfnames.F90 cdfio.F90 modutils.f90 eos.f90 cdftools.f90; do
+  o=$O/${f%.*}.o
+  if [ ! -f $o ] || [ $REF/$f -nt $o ] || [ $FB/netcdf.o -nt $o ]; then
+    $FC $FLAGS -I$FB -I$O -module-dir $O -c $REF/$f -o $o
+    new=1
+  fi
+done
+for p in cdfmoc cdfmhst cdfvT cdfheatc cdfpsi cdfcurl cdfsig0 cdfsigi; do
+  if [ $new = 1 ] || [ ! -f _ref/prog/$p ] || [ $REF/$p.f90 -nt _ref/prog/$p ]; then
+    $FC $FLAGS -I$FB -I$O -module-dir $O -c $REF/$p.f90 -o $O/$p.prog.o
+    $FC $O/$p.prog.o $O/modcdfnames.o $O/cdfio.o $O/modutils.o $O/eos.o $O/cdftools.o $FB/netcdf.o -o _ref/prog/$p \
+        -L$LIBDIR -lncclassic -Wl,-rpath,$LIBDIR
+  fi
+done
+echo "oracle/_ref/prog: the 8 reference programs of SURVEY 8(a), unmodified, over this repository's NetCDF layer (a differential, not a pin)"

@@ -1,0 +1,97 @@
+"""The program-level differential (tests/make_golden_prog.py writes, tests/test_prog_diff.py reads): the cases -- the eight
+programs of SURVEY 8(a), each with its default call and with one option -- and the dump of everything a run leaves behind
+(exit status, stdout, every output file's dimensions, variables, attributes in file order, data, text dumps).
+
+A case runs in a directory holding the files of nemo_files.make_case (24 x 18 x 7, two records, five basins); cases run in
+the order listed, in ONE directory, because cdfmhst reads the vt.nc that cdfvT wrote."""
+import json
+import os
+import subprocess
+
+import numpy as np
+from scipy.io import netcdf_file
+
+UV = ["-u", "SYN_y0001_gridU.nc", "-v", "SYN_y0001_gridV.nc"]
+
+# (case name, program, arguments, output files)
+CASES = [
+    ("cdfmoc_default", "cdfmoc", ["-v", "SYN_y0001_gridV.nc"], ["moc.nc"]),
+    ("cdfmoc_full", "cdfmoc", ["-v", "SYN_y0001_gridV.nc", "-full", "-o", "moc_full.nc"], ["moc_full.nc"]),
+    ("cdfheatc_default", "cdfheatc", ["-f", "SYN_y0001_gridT.nc"], ["heatc.nc"]),
+    ("cdfheatc_zoom_full", "cdfheatc", ["-f", "SYN_y0001_gridT.nc", "-zoom", "3", "12", "2", "9", "2", "4", "-full", "-o", "heatc_z.nc"], ["heatc_z.nc"]),
+    ("cdfcurl_default", "cdfcurl", ["-u", "SYN_y0001_gridU.nc", "vozocrtx", "-v", "SYN_y0001_gridV.nc", "vomecrty", "-l", "1"], ["curl.nc"]),
+    ("cdfcurl_levels_T", "cdfcurl", ["-u", "SYN_y0001_gridU.nc", "vozocrtx", "-v", "SYN_y0001_gridV.nc", "vomecrty", "-l", "2-4", "-T",
+                          "-o", "curl_t.nc"], ["curl_t.nc"]),
+    ("cdfcurl_overf_8", "cdfcurl", ["-u", "SYN_y0001_gridU.nc", "vozocrtx", "-v", "SYN_y0001_gridV.nc", "vomecrty", "-l", "1,3", "-overf", "-8",
+                         "-o", "curl_f.nc"], ["curl_f.nc"]),
+    ("cdfsig0_default", "cdfsig0", ["-t", "SYN_y0001_gridT.nc"], ["sig0.nc"]),
+    ("cdfsig0_teos10", "cdfsig0", ["-t", "SYN_y0001_gridT.nc", "-teos10", "-o", "sig0_teos.nc"], ["sig0_teos.nc"]),
+    ("cdfsigi_default", "cdfsigi", ["-t", "SYN_y0001_gridT.nc", "-r", "2000"], ["sigi.nc"]),
+    ("cdfsigi_teos10", "cdfsigi", ["-t", "SYN_y0001_gridT.nc", "-r", "1000", "-teos10", "-o", "sigi_teos.nc"], ["sigi_teos.nc"]),
+    ("cdfpsi_default", "cdfpsi", UV, ["psi.nc"]),
+    ("cdfpsi_V_mask_ref", "cdfpsi", UV + ["-V", "-mask", "-ref", "5", "4", "-o", "psi_v.nc"], ["psi_v.nc"]),
+    ("cdfvT_default", "cdfvT", ["-c", "SYN", "-l", "y0001"], ["vt.nc"]),
+    ("cdfvT_named_output", "cdfvT", ["-c", "SYN", "-l", "y0001", "-namT", "votemper", "-o", "vt_named.nc"], ["vt_named.nc"]),
+    ("cdfmhst_default", "cdfmhst", ["-vt", "vt.nc"], ["mhst.nc", "zonal_heat_trp.dat", "zonal_salt_trp.dat"]),
+    ("cdfmhst_MST_Zdim", "cdfmhst", ["-vt", "vt.nc", "-MST", "-Zdim", "-o", "mhst_z.nc"], ["mhst_z.nc", "zonal_heat_trp.dat", "zonal_salt_trp.dat"]),
+]
+
+
+def _att(v):
+    """an attribute value -> JSON-able [type, value]"""
+    if isinstance(v, bytes):
+        return ["char", v.decode("latin-1")]
+    a = np.asarray(v)
+    return [a.dtype.str.lstrip("<>=|"), a.ravel().tolist()]
+
+
+def dump_nc(path):
+    """-> (schema dict (JSON-able: dimensions, variables and attributes in file order), {variable: data})"""
+    with netcdf_file(path, "r", mmap=False) as f:
+        schema = {"version_byte": int(f.version_byte),
+                  "dimensions": [[nm, (None if f.dimensions[nm] is None else int(f.dimensions[nm]))] for nm in f._dims],
+                  "global": [[k, _att(v)] for k, v in f._attributes.items()],
+                  "variables": []}
+        data = {}
+        for nm, v in f.variables.items():
+            schema["variables"].append({"name": nm, "type": v.data.dtype.str.lstrip("<>=|"), "dims": list(v.dimensions),
+                                        "shape": [int(x) for x in v.shape], "atts": [[k, _att(a)] for k, a in v._attributes.items()]})
+            data[nm] = np.array(v[:]).astype(v.data.dtype.newbyteorder("="))
+    return schema, data
+
+
+def run_case(bindir, case, cwd, env=None):
+    """run one case -> dict(rc, stdout, files={name: schema or text}), {file::var: array}"""
+    name, prog, args, outs = case
+    for o in outs:
+        if os.path.exists(os.path.join(cwd, o)):
+            os.remove(os.path.join(cwd, o))
+    e = dict(os.environ)
+    e.update(env or {})
+    # argv[0] is the bare program name (it goes into the `history` attribute, src/modutils.f90 SetGlobalAtt): the same text
+    # whichever directory the binary lies in
+    p = subprocess.run([prog] + args, executable=os.path.join(bindir, prog), cwd=cwd, env=e, capture_output=True, text=True, timeout=600)
+    meta = {"case": name, "program": prog, "args": args, "rc": p.returncode, "stdout": p.stdout, "files": {}}
+    arrays = {}
+    for o in outs:
+        path = os.path.join(cwd, o)
+        if not os.path.exists(path):
+            meta["files"][o] = None
+        elif o.endswith(".nc"):
+            schema, data = dump_nc(path)
+            meta["files"][o] = schema
+            for k, a in data.items():
+                arrays[f"{o}::{k}"] = a
+        else:
+            meta["files"][o] = open(path).read()
+    return meta, arrays
+
+
+def save_golden(path, meta, arrays):
+    np.savez_compressed(path, __meta__=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8), **arrays)
+
+
+def load_golden(path):
+    z = np.load(path)
+    meta = json.loads(bytes(z["__meta__"]).decode())
+    return meta, {k: z[k] for k in z.files if k != "__meta__"}

@@ -1,0 +1,145 @@
+"""Program-level differential: this build's programs against what the reference's OWN PROGRAMS left behind on the same files
+(tests/golden/prog_*.npz, written in the build container by tests/make_golden_prog.py from the unmodified reference sources
+linked over this repository's NetCDF layer -- oracle/ref_prog_build.sh).
+
+What it is worth: both sides went through the same NetCDF backend, so this pins nothing about that backend (scipy does:
+tests/test_ncclassic.py); it is a DIAGNOSTIC of everything above it -- option parsers, CreateOutput (dimension and variable
+order, every attribute and its type and order), cdfio's getvar / putvar conventions, the text on stdout, the .dat dumps --
+and of the arithmetic end to end through the real programs.  Every difference found is either fixed or listed in EXPLAINED
+with its reason; anything else fails.
+
+Tolerances on data: cdfcurl, cdfsig0, cdfsigi, cdfvT, cdfpsi: the same bits.  cdfheatc (whose default sums are
+the reference's sequential r4 sums): the same bits.  cdfmoc: written floats within 1 ulp(r4); cdfmhst: within 2 ulp(r4)
+(r8 sums regrouped along i, then the r4 rounding of the store)."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import nemo_files
+import prog_cases as pc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "cdftools_amd", "bin")
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+ULPS = {"cdfmoc": 1, "cdfmhst": 2}                      # float data of these programs: within n ulp(r4) of the reference program's
+
+# Differences that are known and explained: (case regex, kind, item regex) -> reason.
+#   kind "att": item = "<file>:<variable or GLOBAL>:<attribute>"; "stdout": item = the reference's line; "data": "<file>::<var>"
+EXPLAINED = [
+    (r"cdfheatc_.*", "att", r".*:(heatc3d|heatc2d|heatc3dpervol):(_FillValue|valid_min|valid_max)$",
+     "the reference never sets rmissing_value / valid_min / valid_max of these descriptors (src/cdfheatc.f90:271-292): it writes "
+     "whatever the uninitialised TYPE(variable) holds; this build writes the defaults of its descriptor"),
+]
+
+
+def explained(case, kind, item):
+    return any(re.fullmatch(c, case) and k == kind and re.fullmatch(i, item) for c, k, i, _ in EXPLAINED)
+
+
+def ulp4(x):
+    return np.spacing(np.abs(x.astype(np.float32))).astype(np.float64)
+
+
+def numbers(text):
+    return [float(t) for t in re.findall(r"[-+]?(?:\d+\.\d*|\.\d+|\d+)(?:[eE][-+]?\d+)?", text)]
+
+
+def diff_case(case, ref, ref_arr, got, got_arr):
+    """-> list of (kind, item, detail) for everything that differs"""
+    name, prog = case[0], case[1]
+    out = []
+    if ref["rc"] != got["rc"]:
+        out.append(("rc", "rc", f"reference {ref['rc']}, here {got['rc']}"))
+    rl, gl = ref["stdout"].splitlines(), got["stdout"].splitlines()
+    for i in range(max(len(rl), len(gl))):
+        a = rl[i] if i < len(rl) else "<nothing>"
+        b = gl[i] if i < len(gl) else "<nothing>"
+        if a != b:
+            out.append(("stdout", a, f"line {i + 1}: reference {a!r} / here {b!r}"))
+    for fname, rs in ref["files"].items():
+        gs = got["files"].get(fname)
+        if gs is None:
+            out.append(("file", fname, "not written"))
+            continue
+        if isinstance(rs, str):                                      # a text dump: the same layout, numbers within 2 ulp(r4)
+            ra, ga = numbers(rs), numbers(gs)
+            skel = lambda t: re.sub(r"[-+]?(?:\d+\.\d*|\.\d+|\d+)(?:[eE][-+]?\d+)?", "#", t)      # noqa: E731
+            if skel(rs) != skel(gs) or len(ra) != len(ga):
+                out.append(("text", fname, "layout differs"))
+            elif ra:
+                ra, ga = np.array(ra), np.array(ga)
+                if not np.all(np.abs(ra - ga) <= 2 * ulp4(ra) + 1e-5 * np.abs(ra)):   # (printed with ~6 digits)
+                    out.append(("text", fname, f"numbers differ by up to {np.abs(ra - ga).max():.3e}"))
+            continue
+        for key in ("version_byte", "dimensions"):
+            if rs[key] != gs[key]:
+                out.append(("schema", f"{fname}:{key}", f"reference {rs[key]} / here {gs[key]}"))
+
+        def atts(where, ra, ga):
+            rn, gn = [k for k, _ in ra], [k for k, _ in ga]
+            if rn != gn:
+                out.append(("att", f"{fname}:{where}:<names>", f"reference {rn} / here {gn}"))
+            gd = dict((k, v) for k, v in ga)
+            for k, v in ra:
+                if k in gd and gd[k] != v:
+                    out.append(("att", f"{fname}:{where}:{k}", f"reference {v} / here {gd[k]}"))
+        atts("GLOBAL", rs["global"], gs["global"])
+        rv, gv = [v["name"] for v in rs["variables"]], [v["name"] for v in gs["variables"]]
+        if rv != gv:
+            out.append(("schema", f"{fname}:<variables>", f"reference {rv} / here {gv}"))
+        gby = {v["name"]: v for v in gs["variables"]}
+        for v in rs["variables"]:
+            g = gby.get(v["name"])
+            if g is None:
+                continue
+            for key in ("type", "dims", "shape"):
+                if v[key] != g[key]:
+                    out.append(("schema", f"{fname}:{v['name']}:{key}", f"reference {v[key]} / here {g[key]}"))
+            atts(v["name"], v["atts"], g["atts"])
+            k = f"{fname}::{v['name']}"
+            a, b = ref_arr[k], got_arr.get(k)
+            if b is None or a.shape != b.shape:
+                continue
+            if np.array_equal(a, b, equal_nan=True):
+                continue
+            n = ULPS.get(prog, 0) if a.dtype == np.float32 else 0
+            if n and np.all(np.abs(a.astype(np.float64) - b.astype(np.float64)) <= n * ulp4(a)):
+                continue
+            with np.errstate(invalid="ignore"):
+                worst = np.nanmax(np.abs(a.astype(np.float64) - b.astype(np.float64)) / np.maximum(ulp4(a), 1e-300)) if a.dtype.kind == "f" else -1
+            out.append(("data", k, f"{int((a != b).sum())} of {a.size} values differ, worst {worst:.3g} ulp(r4)"))
+    return out
+
+
+@pytest.mark.gpu
+def test_programs_against_the_reference_programs(tmp_path):
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "cdftools_amd", "fortran")], stdout=subprocess.DEVNULL)
+    d = str(tmp_path)
+    nemo_files.make_case(d)
+    report, unexplained = [], []
+    for case in pc.CASES:
+        ref, ref_arr = pc.load_golden(os.path.join(GOLD, f"prog_{case[0]}.npz"))
+        got, got_arr = pc.run_case(BIN, case, d)
+        for kind, item, detail in diff_case(case, ref, ref_arr, got, got_arr):
+            ok = explained(case[0], kind, item)
+            report.append(f"{case[0]:24s} {'explained' if ok else 'UNEXPLAINED':11s} {kind:7s} {item}: {detail}")
+            if not ok:
+                unexplained.append(report[-1])
+    out = os.path.join(ROOT, "gpurun_out", "r04")
+    try:
+        os.makedirs(out, exist_ok=True)
+        open(os.path.join(out, "prog_diff_report.txt"), "w").write("\n".join(report) + "\n")
+    except OSError:
+        pass
+    assert not unexplained, "\n".join(unexplained[:60])
+
+
+def test_goldens_are_there_for_every_case():
+    for case in pc.CASES:
+        meta, arrays = pc.load_golden(os.path.join(GOLD, f"prog_{case[0]}.npz"))
+        assert meta["rc"] == 0 and meta["program"] == case[1] and meta["args"] == case[2]
+        assert all(v is not None for v in meta["files"].values()) and arrays
