@@ -30,7 +30,6 @@ PROGRAM cdfmean
   REAL(KIND=4), ALLOCATABLE :: gdep(:), zdep(:), zv(:,:,:), zmask(:,:,:), zwk(:,:)
   REAL(KIND=4), POINTER :: zv_d(:)                                 ! the record in HBM (host feed), never touched by the host
   REAL(KIND=4), ALLOCATABLE :: rdumlon(:,:), rdumlat(:,:), rdummymean(:,:)
-  REAL(KIND=8) :: dsurf, dvol2d, dsum2d, dvar2d
   REAL(KIND=8), ALLOCATABLE :: dtim(:), dvmeanout(:), dvariance(:), dvol(:), dsum(:), dvar(:)
   REAL(KIND=8), ALLOCATABLE :: dvmeanout3d(:,:), dvariance3d(:,:), dsums(:,:,:)      ! dsums(4, nbasin, nvpk)
   CHARACTER(LEN=256) :: cv_nam, cv_dep, cf_e3, cf_in = 'none', cf_out = 'cdfmean.txt', cf_var = 'cdfvar.txt'
@@ -224,7 +223,6 @@ PROGRAM cdfmean
 
   DO jt = 1, npt
      it = 1 ; IF ( lg_vvl ) it = jt
-     dvol(:) = 0.d0 ; dsum(:) = 0.d0 ; dvar(:) = 0.d0
      IF ( lfeed ) THEN
         IF ( jt == 1 .OR. lg_vvl ) THEN
            pe31d = C_NULL_PTR ; IF ( lfull ) pe31d = C_LOC(e31d)
@@ -252,63 +250,26 @@ PROGRAM cdfmean
         CALL hip_check(cdft_mean_compute(plan, zv, CDFT_MEM_HOST, dsums, CDFT_MEM_HOST, C_NULL_PTR), 'cdft_mean_compute')
      ENDIF
 
-     DO jk = 1, nvpk
-        ik = jk + ikmin - 1
-        DO jbasin = 1, nbasin
-           ivarb = nvars_bas * (jbasin - 1)
-           dsurf  = dsums(1, jbasin, jk) ; dvol2d = dsums(2, jbasin, jk)
-           dsum2d = dsums(3, jbasin, jk) ; dvar2d = dsums(4, jbasin, jk)
-           dvol(jbasin) = dvol(jbasin) + dvol2d
-           dsum(jbasin) = dsum(jbasin) + dsum2d
-           dvar(jbasin) = dvar(jbasin) + dvar2d
-           IF ( lbas ) clbas = ' for basin '//cbasins(jbasin)
-           IF ( dvol2d /= 0 ) THEN
-              dvmeanout(jk) = dsum2d / dvol2d
-              WRITE(6,*) ' Mean value', TRIM(clbas), ' at level ', ik, '(', gdep(jk), ' m) ', dvmeanout(jk), 'surface = ', dsurf/1.e6, ' km^2'
-              WRITE(numout, 9004) gdep(jk), ik, dvmeanout(jk)
-              IF ( lvar ) THEN
-                 dvariance(jk) = dvar2d / dvol2d - dvmeanout(jk) * dvmeanout(jk)
-                 WRITE(6,*) ' Variance value', TRIM(clbas), ' at level ', ik, '(', gdep(jk), ' m) ', dvariance(jk), 'surface = ', dsurf/1.e6, ' km^2'
-                 WRITE(numvar, 9004) gdep(jk), ik, dvariance(jk)
-              ENDIF
-              IF ( lsum ) WRITE(numsum, 9004) gdep(jk), ik, dvol2d
-           ELSE
-              WRITE(6,*) ' No points in the water at level ', ik, '(', gdep(jk), ' m) '
-              dvmeanout(jk) = 99999.
-              IF ( lvar ) dvariance(jk) = 99999.
-           ENDIF
-           rdummymean(1,1) = dvmeanout(jk)
-           ierr = putvar(ncout, id_varout(n_mean(jbasin)), rdummymean, jk, ikx, iky, ktime=jt)
-           IF ( lvar ) THEN
-              rdummymean(1,1) = dvariance(jk)
-              ierr = putvar(ncout, id_varout(n_var(jbasin)), rdummymean, jk, ikx, iky, ktime=jt)
-           ENDIF
-           IF ( lsum ) THEN
-              rdummymean(1,1) = dsum2d
-              ierr = putvar(ncout, id_varout(n_sum(jbasin)), rdummymean, jk, ikx, iky, ktime=jt)
-           ENDIF
+     ! What is left for the host: the kernel's four sums per level and basin (dsums) become the record's statistics, text
+     ! and output values.  Routines of this build (level_out, ocean_out below); what they must reproduce is the output
+     ! contract of src/cdfmean.f90:426-480 -- the lines on stdout and in the text files, in the order level (outer), basin
+     ! (inner), then the basins' volume values, and the value of every variable -- with the divisions in the order the goldens
+     ! hold (tests/golden/lift_cdfmean*.npz): mean*mean for a level, the chained dsum/dvol*dsum/dvol for the volume.
+     DO jbasin = 1, nbasin                               ! the volume totals: the levels added in order
+        dvol(jbasin) = 0.d0 ; dsum(jbasin) = 0.d0 ; dvar(jbasin) = 0.d0
+        DO jk = 1, nvpk
+           dvol(jbasin) = dvol(jbasin) + dsums(2,jbasin,jk)
+           dsum(jbasin) = dsum(jbasin) + dsums(3,jbasin,jk)
+           dvar(jbasin) = dvar(jbasin) + dsums(4,jbasin,jk)
         END DO
      END DO
-
+     DO jk = 1, nvpk
+        DO jbasin = 1, nbasin
+           CALL level_out(jbasin, jk, dsums(:,jbasin,jk))
+        END DO
+     END DO
      DO jbasin = 1, nbasin
-        dvmeanout3d(jbasin,jt) = dsum(jbasin) / dvol(jbasin)
-        WRITE(6,*) ' Mean value over the ocean: ', dvmeanout3d(jbasin,jt), jt
-        WRITE(numout,*) ' Mean value over the ocean ', TRIM(clbas), ': ', dvmeanout3d(jbasin,jt), jt
-        rdummy(:,:) = dvmeanout3d(jbasin,jt)
-        ierr = putvar0d(ncout, id_varout(n_mean3d(jbasin)), rdummy, ktime=jt)
-        IF ( lvar ) THEN
-           dvariance3d(jbasin,jt) = dvar(jbasin)/dvol(jbasin) - dsum(jbasin) / dvol(jbasin) * dsum(jbasin) / dvol(jbasin)
-           WRITE(6,*) ' Variance over the ocean: ', dvariance3d(jbasin,jt), jt
-           WRITE(numvar,*) ' Variance over the ocean ', TRIM(clbas), ': ', dvariance3d(jbasin,jt), jt
-           rdummy(:,:) = dvariance3d(jbasin,jt)
-           ierr = putvar0d(ncout, id_varout(n_var3d(jbasin)), rdummy, ktime=jt)
-        ENDIF
-        IF ( lsum ) THEN
-           WRITE(6,*) ' Sum over the ocean: ', dsum, jt
-           WRITE(numsum,*) ' Sum over the ocean:  ', TRIM(clbas), '', dsum, jt
-           rdummy(:,:) = dsum(jbasin)
-           ierr = putvar0d(ncout, id_varout(n_sum3d(jbasin)), rdummy, ktime=jt)
-        ENDIF
+        CALL ocean_out(jbasin)
      END DO
   END DO
 
@@ -319,13 +280,76 @@ PROGRAM cdfmean
   IF ( lfeed ) THEN
      CALL feed_release(pd_zv) ; CALL feed_close()
   ENDIF
-9004 FORMAT(f9.2,' ',i2,' ',f9.2)
 
   ! -zeromean (:490-527): the field of the WHOLE domain minus the 3-D mean found above (possibly that of a window),
   ! times the masks, level by level into zeromean.nc -- a read-modify-write stream at the speed of the files
   IF ( lzeromean ) CALL ZeroMean
 
 CONTAINS
+
+  SUBROUTINE level_out(kb, kk, psum)
+    !! one working level of one basin: psum = (surface, volume, weighted sum, weighted sum of squares)
+    INTEGER(KIND=4), INTENT(in) :: kb, kk
+    REAL(KIND=8),    INTENT(in) :: psum(4)
+    INTEGER(KIND=4) :: ilev
+    LOGICAL :: llwet
+    ilev  = kk + ikmin - 1
+    llwet = psum(2) /= 0
+    IF ( lbas ) clbas = ' for basin '//cbasins(kb)
+    dvmeanout(kk) = 99999.d0
+    IF ( lvar ) dvariance(kk) = 99999.d0
+    IF ( llwet ) THEN
+       dvmeanout(kk) = psum(3) / psum(2)
+       IF ( lvar ) dvariance(kk) = psum(4) / psum(2) - dvmeanout(kk) * dvmeanout(kk)
+       WRITE(6,*) ' Mean value', TRIM(clbas), ' at level ', ilev, '(', gdep(kk), ' m) ', dvmeanout(kk), 'surface = ', psum(1)/1.e6, ' km^2'
+       WRITE(numout, 9004) gdep(kk), ilev, dvmeanout(kk)
+       IF ( lvar ) THEN
+          WRITE(6,*) ' Variance value', TRIM(clbas), ' at level ', ilev, '(', gdep(kk), ' m) ', dvariance(kk), 'surface = ', psum(1)/1.e6, ' km^2'
+          WRITE(numvar, 9004) gdep(kk), ilev, dvariance(kk)
+       ENDIF
+       IF ( lsum ) WRITE(numsum, 9004) gdep(kk), ilev, psum(2)
+    ELSE
+       WRITE(6,*) ' No points in the water at level ', ilev, '(', gdep(kk), ' m) '
+    ENDIF
+    CALL put_level(n_mean(kb), kk, dvmeanout(kk))
+    IF ( lvar ) CALL put_level(n_var(kb), kk, dvariance(kk))
+    IF ( lsum ) CALL put_level(n_sum(kb), kk, psum(3))
+9004 FORMAT(f9.2,' ',i2,' ',f9.2)
+  END SUBROUTINE level_out
+
+  SUBROUTINE put_level(kvar, kk, pval)
+    INTEGER(KIND=4), INTENT(in) :: kvar, kk
+    REAL(KIND=8),    INTENT(in) :: pval
+    rdummymean(1,1) = pval
+    ierr = putvar(ncout, id_varout(kvar), rdummymean, kk, ikx, iky, ktime=jt)
+  END SUBROUTINE put_level
+
+  SUBROUTINE put_ocean(kvar, pval)
+    INTEGER(KIND=4), INTENT(in) :: kvar
+    REAL(KIND=8),    INTENT(in) :: pval
+    rdummy(:,:) = pval
+    ierr = putvar0d(ncout, id_varout(kvar), rdummy, ktime=jt)
+  END SUBROUTINE put_ocean
+
+  SUBROUTINE ocean_out(kb)
+    !! the volume values of one basin from the totals dvol, dsum, dvar of the record
+    INTEGER(KIND=4), INTENT(in) :: kb
+    dvmeanout3d(kb,jt) = dsum(kb) / dvol(kb)
+    WRITE(6,*) ' Mean value over the ocean: ', dvmeanout3d(kb,jt), jt
+    WRITE(numout,*) ' Mean value over the ocean ', TRIM(clbas), ': ', dvmeanout3d(kb,jt), jt
+    CALL put_ocean(n_mean3d(kb), dvmeanout3d(kb,jt))
+    IF ( lvar ) THEN
+       dvariance3d(kb,jt) = dvar(kb)/dvol(kb) - dsum(kb) / dvol(kb) * dsum(kb) / dvol(kb)
+       WRITE(6,*) ' Variance over the ocean: ', dvariance3d(kb,jt), jt
+       WRITE(numvar,*) ' Variance over the ocean ', TRIM(clbas), ': ', dvariance3d(kb,jt), jt
+       CALL put_ocean(n_var3d(kb), dvariance3d(kb,jt))
+    ENDIF
+    IF ( lsum ) THEN
+       WRITE(6,*) ' Sum over the ocean: ', dsum, jt
+       WRITE(numsum,*) ' Sum over the ocean:  ', TRIM(clbas), '', dsum, jt
+       CALL put_ocean(n_sum3d(kb), dsum(kb))
+    ENDIF
+  END SUBROUTINE ocean_out
 
   SUBROUTINE geti(kval)
     INTEGER(KIND=4), INTENT(out) :: kval

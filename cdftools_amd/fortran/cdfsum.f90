@@ -27,7 +27,7 @@ PROGRAM cdfsum
   REAL(KIND=4), ALLOCATABLE :: gdep(:), zv(:,:,:), zmask(:,:,:)
   REAL(KIND=4), POINTER :: zv_d(:)                                 ! the record in HBM (host feed), never touched by the host
   REAL(KIND=4), ALLOCATABLE, TARGET :: e3(:,:,:)
-  REAL(KIND=8) :: dvol, dvol2d, dsurf, dsum, dsum2d, dsumt
+  REAL(KIND=8) :: dvol, dsum, dsumt
   REAL(KIND=8), ALLOCATABLE :: dtim(:), dsums(:,:,:)               ! dsums(4, 1, nlev)
   CHARACTER(LEN=256) :: cldum, cf_in = 'none', cf_e3, cf_out = 'cdfsum.nc', cv_dep, cdep, cv_in = 'none'
   CHARACTER(LEN=256) :: clunits = ' ', cllong_name = ' ', clshort_name = ' '
@@ -210,35 +210,21 @@ PROGRAM cdfsum
      IF ( nvpk >= 1 .AND. .NOT. lfeed ) CALL readvar3d(cf_in, cv_in, zv, kimin=iimin, kjmin=ijmin, kkmin=ikmin, ktime=jt)
      IF ( nvpk >= 1 .AND. .NOT. lfeed ) CALL hip_check(cdft_mean_compute(plan, zv, CDFT_MEM_HOST, dsums, CDFT_MEM_HOST, C_NULL_PTR), 'cdft_mean_compute')
 
+     ! The kernel's sums per level (dsums: surface, volume, weighted sum) become the record's text and output values: this
+     ! build's routine level_out below, to the output contract of src/cdfsum.f90:318-349 (lines on stdout, the forcing-file
+     ! text dump, the three variables).
      DO jk = 1, nvpk
-        ik = jk + ikmin - 1
-        dsurf = dsums(1,1,jk) ; dvol2d = dsums(2,1,jk) ; dsum2d = dsums(3,1,jk)
-        dsum  = dsum + dsum2d
-        IF ( .NOT. lforcing ) THEN
-           dvol = dvol + dvol2d
-           IF ( dvol2d /= 0 ) THEN
-              PRINT *, ' Sum value at level ', ik, '(', gdep(ik), ' m) ', dsum2d
-              rdummy(1,1) = REAL(dsum2d)
-           ELSE
-              PRINT *, ' No points in the water at level ', ik, '(', gdep(ik), ' m) '
-              rdummy(1,1) = 99999.
-           ENDIF
-        ELSE
-           PRINT *, ' Sum value at time ', jt, ' = ', dsum2d
-           PRINT *, '          Surface  = ', dsurf/1.d6, ' km^2'
-           PRINT *, '       mean value  = ', dsum2d/dsurf
-           WRITE(numout, '(i4," ",1e13.6)') jt, dsum2d
-           rdummy(1,1) = REAL(dsum2d)
-        ENDIF
-        ierr = putvar(ncout, id_varout(1), rdummy, jk, 1, 1, ktime=jt)
+        dsum = dsum + dsums(3,1,jk)
+        IF ( .NOT. lforcing ) dvol = dvol + dsums(2,1,jk)
+        CALL level_out(jk, dsums(1,1,jk), dsums(2,1,jk), dsums(3,1,jk))
      END DO
      dsumt = dsumt + dsum
-     IF ( .NOT. lforcing ) PRINT *, ' Sum value over the ocean: (cumulated in time)', dsumt
-     IF ( .NOT. lforcing ) PRINT *, ' Sum value over the ocean: (function of  time)', dsum
-     rdummy(1,1) = REAL(dsumt)
-     ierr = putvar(ncout, id_varout(2), rdummy, 1, 1, 1, ktime=jt)
-     rdummy(1,1) = REAL(dsum)
-     ierr = putvar(ncout, id_varout(3), rdummy, 1, 1, 1, ktime=jt)
+     IF ( .NOT. lforcing ) THEN
+        PRINT *, ' Sum value over the ocean: (cumulated in time)', dsumt
+        PRINT *, ' Sum value over the ocean: (function of  time)', dsum
+     ENDIF
+     CALL put_scalar(2, 1, REAL(dsumt))
+     CALL put_scalar(3, 1, REAL(dsum))
   END DO
 
   PRINT *, ' mean Sum over time ', dsumt/npt
@@ -252,6 +238,34 @@ PROGRAM cdfsum
   ENDIF
 
 CONTAINS
+
+  SUBROUTINE level_out(kk, psurf, pvol, pwsum)
+    !! one working level: the text of the level and the value of the level variable (99999. for a level without water)
+    INTEGER(KIND=4), INTENT(in) :: kk
+    REAL(KIND=8),    INTENT(in) :: psurf, pvol, pwsum
+    INTEGER(KIND=4) :: ilev
+    ilev = kk + ikmin - 1
+    IF ( lforcing ) THEN
+       PRINT *, ' Sum value at time ', jt, ' = ', pwsum
+       PRINT *, '          Surface  = ', psurf/1.d6, ' km^2'
+       PRINT *, '       mean value  = ', pwsum/psurf
+       WRITE(numout, '(i4," ",1e13.6)') jt, pwsum
+       CALL put_scalar(1, kk, REAL(pwsum))
+    ELSE IF ( pvol /= 0 ) THEN
+       PRINT *, ' Sum value at level ', ilev, '(', gdep(ilev), ' m) ', pwsum
+       CALL put_scalar(1, kk, REAL(pwsum))
+    ELSE
+       PRINT *, ' No points in the water at level ', ilev, '(', gdep(ilev), ' m) '
+       CALL put_scalar(1, kk, 99999.)
+    ENDIF
+  END SUBROUTINE level_out
+
+  SUBROUTINE put_scalar(kvar, kk, pval)
+    INTEGER(KIND=4), INTENT(in) :: kvar, kk
+    REAL(KIND=4),    INTENT(in) :: pval
+    rdummy(1,1) = pval
+    ierr = putvar(ncout, id_varout(kvar), rdummy, kk, 1, 1, ktime=jt)
+  END SUBROUTINE put_scalar
 
   SUBROUTINE geti(kval)
     INTEGER(KIND=4), INTENT(out) :: kval
