@@ -385,6 +385,21 @@ __device__ __forceinline__ int wave_isum(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);     // row_bcast:31 into rows 2 and 3
     return __builtin_amdgcn_readlane(v, 63);
 }
+// the same sum, valid in lane 63 only (what a lane that stores it needs: no v_readlane / v_mov round trip)
+__device__ __forceinline__ int wave_isum_top(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xb1, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4e, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);
+    return v;
+}
+// two r4 operations per instruction (v_pk_mul_f32 / v_pk_add_f32: each half the plain IEEE operation, no contraction)
+typedef float f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2v pk_mul(f2v a, f2v b) { return a * b; }
+__device__ __forceinline__ f2v pk_add(f2v a, f2v b) { return a + b; }
+__device__ __forceinline__ f2v pk_sub(f2v a, f2v b) { return a - b; }
 __device__ __forceinline__ int wave_imin(int v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
@@ -488,7 +503,7 @@ __global__ void __launch_bounds__(64 * kScanWaves, 3) heatc_scan_kernel(HeatcArg
     __shared__ int sm_K[2][kScanMaxChunks][3], sm_pos[2][kScanMaxChunks][3], sm_flag[2][kScanMaxChunks][3], sm_key[2][kScanMaxChunks][3];
     __shared__ int tick;
     __shared__ __attribute__((aligned(16))) float xs[3][kScanChunk];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // (w in a scalar register: what depends on it alone stays scalar)
     const int64_t ticket_cells = (int64_t)nchunk * kScanChunk;
 
     // the XCD this workgroup runs on (HW_REG_XCC_ID, bits 3:0)
@@ -566,19 +581,24 @@ __global__ void __launch_bounds__(64 * kScanWaves, 3) heatc_scan_kernel(HeatcArg
 
         auto fetch = [&](Raw (&raw)[kScanNV], int64_t c0) {       // 512 cells from c0 on: lane l takes cells 4l..4l+3 of each 256
             if (c0 >= pad && c0 + kScanChunk <= nijv) {           // (uniform) every cell exists: four 16-byte loads per field and lane, nothing else
+                // wave-uniform bases (scalar registers) + one 32-bit lane offset: the loads need no 64-bit vector address arithmetic
+                const int64_t u0 = c0 - pad;
+                const float *ap = a.area + u0, *tp = a.temp + base + u0, *ep = FULL ? nullptr : a.e3t + base + u0;
+                const float *mp4 = MASK8 ? nullptr : a.mask4 + base + u0, *xp = MXL ? a.mxl + u0 : nullptr;
+                const uint8_t *mp8 = MASK8 ? a.mask8 + base + u0 : nullptr;
 #pragma unroll
                 for (int v = 0; v < kScanNV; ++v) {
                     Raw &x = raw[v];
-                    const int64_t p = c0 + v * 256 + 4 * lane - pad;
-                    const f4u av = *reinterpret_cast<const f4u *>(a.area + p);
+                    const unsigned p = (unsigned)(v * 256 + 4 * lane);
+                    const f4u av = *reinterpret_cast<const f4u *>(ap + p);
                     x.ar[0] = av.x; x.ar[1] = av.y; x.ar[2] = av.z; x.ar[3] = av.w;
-                    const f4u tv = ld_stream4u(a.temp + base + p);
+                    const f4u tv = ld_stream4u(tp + p);
                     x.tt[0] = tv.x; x.tt[1] = tv.y; x.tt[2] = tv.z; x.tt[3] = tv.w;
-                    if (!FULL) { const f4u ev = ld_stream4u(a.e3t + base + p); x.e3[0] = ev.x; x.e3[1] = ev.y; x.e3[2] = ev.z; x.e3[3] = ev.w; }
+                    if (!FULL) { const f4u ev = ld_stream4u(ep + p); x.e3[0] = ev.x; x.e3[1] = ev.y; x.e3[2] = ev.z; x.e3[3] = ev.w; }
                     else       { x.e3[0] = x.e3[1] = x.e3[2] = x.e3[3] = 0.f; }
-                    if (MASK8) { typedef uint32_t u32u __attribute__((aligned(1))); x.mkb = __builtin_nontemporal_load(reinterpret_cast<const u32u *>(a.mask8 + base + p)); }
-                    else       { const f4u m = ld_stream4u(a.mask4 + base + p); x.mk[0] = m.x; x.mk[1] = m.y; x.mk[2] = m.z; x.mk[3] = m.w; }
-                    if (MXL) { const f4u mv = *reinterpret_cast<const f4u *>(a.mxl + p); x.mx[0] = mv.x; x.mx[1] = mv.y; x.mx[2] = mv.z; x.mx[3] = mv.w; }
+                    if (MASK8) { typedef uint32_t u32u __attribute__((aligned(1))); x.mkb = __builtin_nontemporal_load(reinterpret_cast<const u32u *>(mp8 + p)); }
+                    else       { const f4u m = ld_stream4u(mp4 + p); x.mk[0] = m.x; x.mk[1] = m.y; x.mk[2] = m.z; x.mk[3] = m.w; }
+                    if (MXL) { const f4u mv = *reinterpret_cast<const f4u *>(xp + p); x.mx[0] = mv.x; x.mx[1] = mv.y; x.mx[2] = mv.z; x.mx[3] = mv.w; }
                     else     { x.mx[0] = x.mx[1] = x.mx[2] = x.mx[3] = 0.f; }
                 }
                 return;
@@ -602,24 +622,32 @@ __global__ void __launch_bounds__(64 * kScanWaves, 3) heatc_scan_kernel(HeatcArg
                 }
             }
         };
-        // the three r4 products of every cell in `raw`, exactly as the reference forms them (:225-229); zeros past the end
-        auto products = [&](const Raw (&raw)[kScanNV], int64_t c0, float (&x)[3][kScanNV][4]) {
+        // the three r4 products of every cell in `raw`, exactly as the reference forms them (:225-229); zeros past the end.
+        // Two cells per instruction (v_pk_mul_f32: the same IEEE r4 product in each half): x[chain][vector][pair]
+        auto products = [&](const Raw (&raw)[kScanNV], int64_t c0, f2v (&x)[3][kScanNV][2]) {
             const bool whole = c0 >= pad && c0 + kScanChunk <= nijv;     // (uniform) every cell of the chunk exists
 #pragma unroll
             for (int v = 0; v < kScanNV; ++v) {
+                const Raw &r = raw[v];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const Raw &r = raw[v];
-                    float e = FULL ? e3k : r.e3[c];
-                    if (MXL) {
-                        if (a.mxlopt == 1) e = fmaxf(0.f, fminf(e, __fsub_rn(r.mx[c], dw)));                   // :220
-                        else               e = fminf(e, fmaxf(0.f, __fsub_rn(__fadd_rn(dw, e), r.mx[c])));     // :222
+                for (int p = 0; p < 2; ++p) {
+                    float e[2], mk[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int c = 2 * p + h;
+                        e[h] = FULL ? e3k : r.e3[c];
+                        if (MXL) {
+                            if (a.mxlopt == 1) e[h] = fmaxf(0.f, fminf(e[h], __fsub_rn(r.mx[c], dw)));                   // :220
+                            else               e[h] = fminf(e[h], fmaxf(0.f, __fsub_rn(__fadd_rn(dw, e[h]), r.mx[c])));  // :222
+                        }
+                        mk[h] = MASK8 ? (float)((r.mkb >> (8 * c)) & 0xffu) : r.mk[c];
                     }
-                    const float pv = __fmul_rn(r.ar[c], e);
-                    const float mk = MASK8 ? (float)((r.mkb >> (8 * c)) & 0xffu) : r.mk[c];
-                    x[0][v][c] = __fmul_rn(r.ar[c], mk);
-                    x[1][v][c] = __fmul_rn(pv, mk);
-                    x[2][v][c] = __fmul_rn(__fmul_rn(pv, r.tt[c]), mk);
+                    const f2v ar = {r.ar[2 * p], r.ar[2 * p + 1]}, tt = {r.tt[2 * p], r.tt[2 * p + 1]};
+                    const f2v e2 = {e[0], e[1]}, mk2 = {mk[0], mk[1]};
+                    const f2v pv = pk_mul(ar, e2);
+                    x[0][v][p] = pk_mul(ar, mk2);
+                    x[1][v][p] = pk_mul(pv, mk2);
+                    x[2][v][p] = pk_mul(pk_mul(pv, tt), mk2);
                 }
             }
             if (!whole) {                                         // (uniform: only the first and the last chunk of a level take this branch)
@@ -628,54 +656,66 @@ __global__ void __launch_bounds__(64 * kScanWaves, 3) heatc_scan_kernel(HeatcArg
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         const int64_t id = c0 + v * 256 + 4 * lane + c;
-                        if (id < pad || id >= nijv) x[0][v][c] = x[1][v][c] = x[2][v][c] = -0.f;
+                        if (id < pad || id >= nijv)
+#pragma unroll
+                            for (int ch = 0; ch < 3; ++ch) { if (c & 1) x[ch][v][c >> 1].y = -0.f; else x[ch][v][c >> 1].x = -0.f; }
                     }
             }
         };
         // sums of chunk q under the hypotheses of each chain
-        auto summarize = [&](const float (&x)[3][kScanNV][4], int q) {
+        auto summarize = [&](const f2v (&x)[3][kScanNV][2], int q) {
             uint32_t any = 0u;                                    // is there a cell with a term that is not 0?  (one answer for the three
 #pragma unroll                                                    // chains: "yes" for a chain of zeros only costs it the integer checks)
             for (int v = 0; v < kScanNV; ++v)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) any |= __float_as_uint(x[0][v][c]) | __float_as_uint(x[1][v][c]) | __float_as_uint(x[2][v][c]);
+                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) any |= __float_as_uint(x[ch][v][p].x) | __float_as_uint(x[ch][v][p].y);
             const bool anz = __builtin_amdgcn_ballot_w64((any & 0x7fffffffu) != 0u) != 0;
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) {
                 for (int h = 0; h < 2; ++h) {
                     const int key = sm_key[h][q][ch];
                     if (h == 1 && key < 0) break;                 // (uniform)
-                    int K = 0, pos = 0;
-                    uint32_t sgn = 0u, big = 0u;
-                    float far = 0.f;                              // the largest |q - rint(q)|: 0.5 exactly = a tie
+                    int Kl = 0, Al = 0;                           // this lane's sum of k and of |k| (chain 2; the others: Al = Kl)
+                    bool bad = key < 0;
+                    uint32_t sgn = 0u;
                     if (key >= 0 && anz) {
                         const float scale = scan_scale(key);
-                        // a lane's eight k's are added as floats: exact, each |k| < 2^20 (or the chunk is `big` and its sums
-                        // are not used) -- one conversion per lane instead of one per cell
-                        float Kf = 0.f, posf = 0.f;
+                        const f2v sc = {scale, scale};
+                        // A lane's eight k's are added as floats, two at a time (v_pk_add_f32).  The guard is the lane's sum of
+                        // |k|: while it stays below 2^23 every partial sum is an integer below 2^24, hence exact, and the chunk's
+                        // 64 lane sums fit 32 bits with room for the walk's prefix sums; a sum that reaches 2^23 or is not a
+                        // number (a NaN / Inf term, or an x far above the chain's ulp) sends the chunk to the cells.  The surface
+                        // and the volume have no negative term on a real mesh: their sum of |k| IS their sum of k, and a sign
+                        // bit anywhere (a negative weight of -M, a negative start value) sends the chunk to the cells as well.
+                        f2v Kf = {0.f, 0.f};
+                        float Af = 0.f, far = 0.f;                // far: the largest |q - rint(q)|, 0.5 exactly = a tie
 #pragma unroll
                         for (int v = 0; v < kScanNV; ++v)
 #pragma unroll
-                            for (int c = 0; c < 4; ++c) {
-                                const float qq = __fmul_rn(x[ch][v][c], scale);               // exact (a power of two), or Inf / NaN
-                                const float kf = rintf(qq);
-                                Kf = __fadd_rn(Kf, kf);
-                                if (ch == 2) posf = __fadd_rn(posf, fmaxf(kf, 0.f));          // (surface and volume: see below)
-                                far = fmaxf(far, fabsf(__fsub_rn(qq, kf)));                   // the difference is exact
-                                sgn |= __float_as_uint(qq);
-                                big = max(big, __float_as_uint(qq) & 0x7fffffffu);            // NaN > Inf > every finite |q|
+                            for (int p = 0; p < 2; ++p) {
+                                const f2v qq = pk_mul(x[ch][v][p], sc);                       // exact (a power of two), or Inf / NaN
+                                const f2v kf = {rintf(qq.x), rintf(qq.y)};
+                                Kf = pk_add(Kf, kf);
+                                const f2v d = pk_sub(qq, kf);                                 // exact
+                                far = fmaxf(far, fmaxf(fabsf(d.x), fabsf(d.y)));              // (v_max3_f32)
+                                sgn |= __float_as_uint(qq.x) | __float_as_uint(qq.y);         // (v_or3_b32)
+                                if (ch == 2) { Af = __fadd_rn(Af, fabsf(kf.x)); Af = __fadd_rn(Af, fabsf(kf.y)); }
                             }
-                        K = wave_isum((int)Kf);                                               // (saturating conversions; guarded by `big`)
-                        pos = ch == 2 ? wave_isum((int)posf) : K;
+                        const float Ks = __fadd_rn(Kf.x, Kf.y);
+                        if (ch != 2) Af = Ks;
+                        bad = far == 0.5f || !(Af < 8388608.f) || (ch != 2 && (sgn >> 31) != 0u);
+                        Kl = bad ? 0 : (int)Ks;
+                        Al = bad ? 0 : (int)Af;
                     }
-                    // a tie; NaN, Inf, or |k| >= 2^20 (x not well below s; and the sums of 512 k's stay inside 32 bits); and for
-                    // the surface and the volume, whose terms are never negative on a real mesh (pos = K, one sum less to
-                    // form): a sign bit anywhere (a negative weight of -M, a negative start value) sends the chunk to the cells
-                    const bool bad = far == 0.5f || big >= 0x49800000u || (ch != 2 && (sgn >> 31) != 0u);
+                    // the chunk's sums: in lane 63 of the accumulating registers, which writes them (no trip through a scalar)
+                    const int Kw = wave_isum_top(Kl);
+                    const int Aw = ch == 2 ? wave_isum_top(Al) : Kw;
                     const bool abad = __builtin_amdgcn_ballot_w64(bad) != 0, ang = __builtin_amdgcn_ballot_w64((sgn >> 31) != 0u) != 0;
-                    if (lane == 0) {
-                        sm_K[h][q][ch] = K; sm_pos[h][q][ch] = pos;
-                        sm_flag[h][q][ch] = (anz ? 1 : 0) | ((abad || key < 0) ? 2 : 0) | (ang ? 4 : 0);
+                    if (lane == 63) {
+                        sm_K[h][q][ch] = Kw; sm_pos[h][q][ch] = ch == 2 ? (Aw + Kw) / 2 : Kw;      // pos = sum of max(k,0) = (sum|k| + sum k) / 2
+                        sm_flag[h][q][ch] = (anz ? 1 : 0) | (abad ? 2 : 0) | (ang ? 4 : 0);
                     }
                 }
             }
@@ -684,11 +724,11 @@ __global__ void __launch_bounds__(64 * kScanWaves, 3) heatc_scan_kernel(HeatcArg
             // neither is ever copied): counters showed the waves waiting for memory 61 % of their time with one sub-block ahead
             // -- a chunk's vector work (~2 us with three waves on the SIMD) is about the latency of its loads under load.
             Raw rawA[kScanNV], rawB[kScanNV];
-            float x[3][kScanNV][4];
+            f2v x[3][kScanNV][2];
             auto chunk = [&](Raw (&raw)[kScanNV], int q) {        // sums chunk q from `raw`, then asks for chunk q + 2 * kScanWaves into it
                 const int64_t c0 = t0 + (int64_t)q * kScanChunk;
                 if (c0 >= nijv) {                                 // past the end of the level: nothing there
-                    if (lane == 0) for (int ch = 0; ch < 3; ++ch) sm_flag[0][q][ch] = sm_flag[1][q][ch] = 0;
+                    if (lane == 63) for (int ch = 0; ch < 3; ++ch) sm_flag[0][q][ch] = sm_flag[1][q][ch] = 0;
                     return;
                 }
                 products(raw, c0, x);
@@ -759,14 +799,17 @@ __global__ void __launch_bounds__(64 * kScanWaves, 3) heatc_scan_kernel(HeatcArg
                 const int64_t c0 = t0 + (int64_t)q * kScanChunk;
                 const int nvalid = (int)max((int64_t)0, min((int64_t)kScanChunk, nijv - c0));
                 Raw raw[kScanNV];
-                float x3[3][kScanNV][4];
+                f2v x3[3][kScanNV][2];
                 fetch(raw, c0);
                 products(raw, c0, x3);
                 float xv[kScanNV][4];
 #pragma unroll
                 for (int v = 0; v < kScanNV; ++v)
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) xv[v][c] = ch == 0 ? x3[0][v][c] : ch == 1 ? x3[1][v][c] : x3[2][v][c];
+                    for (int c = 0; c < 4; ++c) {
+                        const f2v t = ch == 0 ? x3[0][v][c >> 1] : ch == 1 ? x3[1][v][c >> 1] : x3[2][v][c >> 1];
+                        xv[v][c] = (c & 1) ? t.y : t.x;
+                    }
                 if (lane == 0) atomicAdd(&ctl->nfallback, 1);
                 int next = 0, rounds = 0;                         // cells [0, next) of the chunk are in s
                 while (next < nvalid && rounds < 6) {

@@ -186,6 +186,7 @@ struct CurlArgs {
     const float *e1u, *e2v, *e1f, *e2f;       // (npi,npj)
     const double *ff;                         // (npi,npj) or null
     int npi, npj, nlev, ntx, lperio;
+    int band;                                 // curl_tile_kernel: rows of a band (0: the whole eighth of an XCD), see there
     void *out;                                // (npi,npj,nlev) r8 or r4
     double *work;                             // F-point curl for the T-point pass
 };
@@ -302,14 +303,34 @@ template <typename OUT, bool KEEP>
 __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 8))) curl_tile_kernel(CurlArgs a, int tw, int lc) {
     const int lane = threadIdx.x & 63;
     const int64_t tiles = (int64_t)a.ntx * a.npj, total = tiles * lc;
-    const int64_t job = xcd_band_item(total);
-    if (job >= total) return;                                     // whole block
+    int chunk, jj, tx;
+    if (a.band > 0) {
+        // Row bands (A/B hook CDFT_CURL_BAND): XCD x owns the x-th eighth of the rows and works through it band by band --
+        // a band = a.band rows, all their level chunks (chunk-major), then the next band -- so that the metric planes of a
+        // band (3 x 17 KB per row) are asked for again while they are still in L2 / Infinity Cache, with short level chunks.
+        const int x = blockIdx.x & 7;
+        const int64_t s = blockIdx.x >> 3;
+        const int j0 = (int)((int64_t)x * a.npj / 8), nrows = (int)((int64_t)(x + 1) * a.npj / 8) - j0;
+        const int64_t per_band = (int64_t)a.band * a.ntx * lc;
+        const int b = (int)(s / per_band);
+        const int r0 = b * a.band, rb = min(a.band, nrows - r0);                 // rows of this band
+        if (rb <= 0) return;
+        const int64_t l = s - (int64_t)b * per_band;
+        if (l >= (int64_t)rb * a.ntx * lc) return;
+        chunk = (int)(l / ((int64_t)rb * a.ntx));
+        const int64_t t = l - (int64_t)chunk * rb * a.ntx;
+        jj = j0 + r0 + (int)(t / a.ntx);
+        tx = (int)(t - (int64_t)(t / a.ntx) * a.ntx);
+    } else {
+        const int64_t job = xcd_band_item(total);
+        if (job >= total) return;                                 // whole block
+        chunk = (int)(job / tiles);
+        const int64_t tile = job - chunk * tiles;
+        jj = (int)(tile / a.ntx); tx = (int)(tile - (int64_t)jj * a.ntx);
+    }
     const int64_t nij = (int64_t)a.npi * a.npj;
     {
-        const int chunk = (int)(job / tiles);
-        const int64_t tile = job - chunk * tiles;
         const int lev0 = (int)((int64_t)chunk * a.nlev / lc), lev1 = (int)((int64_t)(chunk + 1) * a.nlev / lc);
-        const int jj = (int)(tile / a.ntx), tx = (int)(tile - (int64_t)jj * a.ntx);
         const bool north = jj < a.npj - 1;
         const int it = (int)threadIdx.x * 4, ic = tx * tw + it;   // first column before anchoring
         const bool act = it < tw && ic < a.npi;                   // lanes past the tile or the row do nothing
@@ -632,7 +653,7 @@ int cdft_curl_compute(cdft_curl_plan *p, const float *un, const float *vn, int n
     CurlArgs a;
     a.un = (const float *)du; a.vn = (const float *)dv; a.e1u = p->e1u; a.e2v = p->e2v; a.e1f = p->e1f; a.e2f = p->e2f;
     a.ff = p->ff; a.npi = p->npi; a.npj = p->npj; a.nlev = nlev;
-    a.lperio = p->lperio; a.out = dout; a.work = nullptr;
+    a.lperio = p->lperio; a.out = dout; a.work = nullptr; a.band = 0;
     if (ltpoint) {
         CDFT_TRY(p->work.reserve(n3 * 8));
         a.work = (double *)p->work.ptr;
@@ -654,7 +675,15 @@ int cdft_curl_compute(cdft_curl_plan *p, const float *un, const float *vn, int n
         if (res == 0) res = resident_workgroups(table[variant], sh.threads);
         const char *elc = getenv("CDFT_CURL_CHUNKS");             // A/B hook
         const int lc = elc ? std::max(1, std::min(nlev, atoi(elc))) : curl_level_chunks(tiles, nlev, res);
-        const dim3 grid((unsigned)(((tiles * lc + 7) / 8) * 8)), block(sh.threads);
+        dim3 grid((unsigned)(((tiles * lc + 7) / 8) * 8)), block(sh.threads);
+        a.band = 0;
+        if (const char *eb = getenv("CDFT_CURL_BAND")) {          // A/B hook: rows per band (see the kernel)
+            a.band = std::max(0, atoi(eb));
+            if (a.band > 0) {
+                const int rows_x = (p->npj + 7) / 8, nb = (rows_x + a.band - 1) / a.band;
+                grid = dim3((unsigned)(8 * (int64_t)nb * a.band * a.ntx * lc));
+            }
+        }
         hipLaunchKernelGGL(table[variant], grid, block, 0, st, a, sh.tw, lc);
     } else {
         a.ntx = (p->npi + kTile - 1) / kTile;

@@ -279,7 +279,12 @@ CONTAINS
     INTEGER(KIND=4), INTENT(in) :: knum, kfmt
     REAL(KIND=8), INTENT(in) :: dsum(:,:), ddiv
     IF ( llglo ) THEN
-       WRITE(knum,*) '! J        Global          Atlantic         Pacific          Indian           Mediteranean     Austral  '
+       ! (the two files differ by a blank in front of the column titles: src/cdfmhst.f90:451 and :474)
+       IF ( kfmt == 9000 ) THEN
+          WRITE(knum,*) '! J        Global          Atlantic         Pacific          Indian           Mediteranean     Austral  '
+       ELSE
+          WRITE(knum,*) ' ! J        Global          Atlantic         Pacific          Indian           Mediteranean     Austral  '
+       ENDIF
        WRITE(knum,*) ' ! time : ', jt
        DO jj = npjglo, 1, -1
           IF ( kfmt == 9000 ) THEN
@@ -289,7 +294,9 @@ CONTAINS
           ENDIF
        END DO
     ELSE
-       WRITE(knum,*) '! J        Global        '
+       IF ( kfmt == 9000 ) THEN ; WRITE(knum,*) '! J        Global        '          ! (:464)
+       ELSE                     ; WRITE(knum,*) ' J        Global  '                 ! (:487)
+       ENDIF
        WRITE(knum,*) ' ! time : ', jt
        DO jj = npjglo, 1, -1
           IF ( kfmt == 9000 ) THEN ; WRITE(knum, 9000) jj, rdumlat(1,jj), dsum(1,jj)/ddiv

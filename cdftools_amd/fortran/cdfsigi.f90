@@ -64,7 +64,7 @@ PROGRAM cdfsigi
      CASE ( '-t'      ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cf_tfil) ; ijarg = ijarg + 1
      CASE ( '-s'      ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cf_sfil) ; ijarg = ijarg + 1
      CASE ( '-o'      ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cf_out ) ; ijarg = ijarg + 1
-     CASE ( '-r'      ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cl_ref ) ; ijarg = ijarg + 1 ; READ(cl_ref, *) ref_dep
+     CASE ( '-r'      ) ; CALL GET_COMMAND_ARGUMENT(ijarg, cl_ref ) ; ijarg = ijarg + 1 ; READ(cl_ref, *) ref_dep ; cldum = cl_ref
      CASE ( '-nc4'    ) ; lnc4 = .TRUE.
      CASE ( '-teos10' ) ; ll_teos10 = .TRUE.
      CASE DEFAULT       ; PRINT *, ' ERROR : ', TRIM(cldum), ' : unknown option.' ; STOP 99
@@ -121,7 +121,9 @@ CONTAINS
     stypvar(1)%rmissing_value    = 0.
     stypvar(1)%valid_min         = 0.001
     stypvar(1)%valid_max         = 45.
-    stypvar(1)%clong_name        = 'Potential_density:refered to '//TRIM(cl_ref)//' m'
+    ! the reference names the depth by its parser's scratch string (src/cdfsigi.f90:98, :166): the value of -r when nothing
+    ! but value-less options follow it on the command line, else the last option the parser looked at -- kept, file for file
+    stypvar(1)%clong_name        = 'Potential_density:refered to '//TRIM(cldum)//' m'
     stypvar(1)%cshort_name       = cn_vosigmai
     stypvar(1)%conline_operation = 'N/A'
     stypvar(1)%caxis             = 'TZYX'
