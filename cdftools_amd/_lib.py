@@ -71,6 +71,7 @@ SIGNATURES = {
     "cdft_moc_profile_read_each": (_i, [_vp, C.POINTER(C.c_float), _i, C.POINTER(_i)]),
     "cdft_moc_profile_read_block": (_i, [_vp, _i, C.POINTER(C.c_float), _i, C.POINTER(_i)]),
     "cdft_moc_block_info": (_i, [_vp, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "cdft_moc_reserve": (_i, [_vp, _i, _vp]),
     "cdft_moc_stage": (_i, [_vp, _vp, _i64, _i, _i, _vp]),
     "cdft_moc_compute_staged": (_i, [_vp, _vp, _i, _vp]),
     "cdft_moc_stage_rows": (_i, [_vp, _vp, _i64, _i64, _i, _i, _vp]),

@@ -618,22 +618,42 @@ static int pool_put(cdft_moc_plan *p, int slot, int64_t first_row, const float *
     return CDFT_OK;
 }
 
-// Lay the pool out for npt records (contents lost when the layout changes) and bring the current weights in.
-static int pool_prepare(cdft_moc_plan *p, int npt, hipStream_t st) {
+// Lay the pool out for npt records (contents lost when the layout changes).
+static int pool_layout(cdft_moc_plan *p, int npt, hipStream_t st) {
     const int64_t P = ((int64_t)p->npi + 3) & ~(int64_t)3, rows = (int64_t)p->npj * p->npk;
     const size_t bytes = (size_t)(rows * (npt + 1) * P) * 4 + 64;
     if (p->pool_npt != npt || p->pool_P != P || p->pool.bytes < bytes) {
         p->pool_npt = 0; p->pool_w = false;
+        p->staged = nullptr; p->staged_npt = 0;
         CDFT_TRY(p->pool.reserve(bytes));
         // the cells between npi and P and the 64 bytes behind the last row are read (and masked): never uninitialised memory
         CDFT_HIP(hipMemsetAsync(p->pool.ptr, 0, bytes, st));
         p->pool_npt = npt; p->pool_P = P;
     }
+    return CDFT_OK;
+}
+// ... and bring the current weights in
+static int pool_prepare(cdft_moc_plan *p, int npt, hipStream_t st) {
+    CDFT_TRY(pool_layout(p, npt, st));
     if (!p->pool_w) {
-        CDFT_TRY(pool_put(p, 0, 0, p->w, p->npi, rows, st));
+        CDFT_TRY(pool_put(p, 0, 0, p->w, p->npi, (int64_t)p->npj * p->npk, st));
         p->pool_w = true;
     }
     return CDFT_OK;
+}
+
+int cdft_moc_reserve(cdft_moc_plan *p, int npt, void *stream) {
+    if (!p || npt < 1) return fail(CDFT_ERR_ARG, "cdft_moc_reserve: bad argument");
+    if (p->sh) {
+        for (size_t b = 0; b < p->sh->part.size(); ++b) {
+            CDFT_HIP(hipSetDevice(p->sh->dev[b]));
+            CDFT_TRY(cdft_moc_reserve((cdft_moc_plan *)p->sh->part[b], npt, p->sh->st[b]));
+            CDFT_HIP(hipStreamSynchronize(p->sh->st[b]));
+        }
+        return CDFT_OK;
+    }
+    if (!pool_wanted()) return CDFT_OK;
+    return pool_layout(p, npt, as_stream(stream));
 }
 
 int cdft_moc_stage(cdft_moc_plan *p, const float *zv, int64_t rec_stride, int npt, int zv_space, void *stream) {

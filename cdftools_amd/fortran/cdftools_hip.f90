@@ -135,6 +135,17 @@ MODULE cdftools_hip
      INTEGER(C_INT) FUNCTION cdft_moc_compute_staged(plan, dmoc, dmoc_space, stream) BIND(C, name='cdft_moc_compute_staged')
        IMPORT ; TYPE(C_PTR), VALUE :: plan, stream ; INTEGER(C_INT), VALUE :: dmoc_space ; REAL(C_DOUBLE), INTENT(out) :: dmoc(*)
      END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_moc_stage_rows(plan, zv, rec_stride, lev_stride, npt, zv_space, stream) &
+          &         BIND(C, name='cdft_moc_stage_rows')
+       IMPORT ; TYPE(C_PTR), VALUE :: plan, stream ; REAL(C_FLOAT), INTENT(in) :: zv(*)
+       INTEGER(C_INT64_T), VALUE :: rec_stride, lev_stride ; INTEGER(C_INT), VALUE :: npt, zv_space
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_moc_compute_pitched(plan, zv, rec_stride, row_stride, npt, dmoc, dmoc_space, stream) &
+          &         BIND(C, name='cdft_moc_compute_pitched')
+       IMPORT ; TYPE(C_PTR), VALUE :: plan, stream ; REAL(C_FLOAT), INTENT(in) :: zv(*)
+       INTEGER(C_INT64_T), VALUE :: rec_stride, row_stride ; INTEGER(C_INT), VALUE :: npt, dmoc_space
+       REAL(C_DOUBLE), INTENT(out) :: dmoc(*)
+     END FUNCTION
      INTEGER(C_INT) FUNCTION cdft_moc_profile_read_block(plan, block, ms_each, capacity, launches) &
           &         BIND(C, name='cdft_moc_profile_read_block')
        IMPORT ; TYPE(C_PTR), VALUE :: plan ; INTEGER(C_INT), VALUE :: block, capacity

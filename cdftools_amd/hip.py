@@ -234,6 +234,10 @@ class MocPlan:
         check(_lib.load().cdft_moc_block_info(self._h, block, C.byref(d), C.byref(j0), C.byref(j1)))
         return d.value, j0.value, j1.value
 
+    def reserve(self, npt, stream=None):
+        """cdft_moc_reserve: the pool for npt staged records, made now (before anything else is allocated in HBM)."""
+        check(_lib.load().cdft_moc_reserve(self._h, int(npt), stream or current_stream_ptr()))
+
     def stage(self, zv, rec_stride=None, npt=None, stream=None):
         """Hand the records over once (cdft_moc_stage): a sharded plan moves every block's rows into that block's HBM;
         compute_staged then runs on them any number of times without touching the inputs again."""

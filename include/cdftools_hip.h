@@ -179,7 +179,11 @@ int cdft_moc_compute(cdft_moc_plan *plan, const float *zv, int64_t rec_stride, i
  * (cdft_moc_set_mesh) keeps the staged records and brings its weights into the pool at the next cdft_moc_compute_staged.
  * cdft_moc_stage_rows: the same for records whose LEVELS are lev_stride elements apart (>= npiglo*npjglo; rows dense): a
  * row block of a larger domain, taken where it lies (single-device plans).
- * CDFT_MOC_POOL=0 (A/B hook): keep the records as they came instead (a device array is then borrowed, not copied). */
+ * CDFT_MOC_POOL=0 (A/B hook): keep the records as they came instead (a device array is then borrowed, not copied).
+ * cdft_moc_reserve: make the pool for npt records now (optional: cdft_moc_stage makes it when it is not there).  A program
+ * that knows its record count asks for the pool before it allocates anything else in HBM: the one large allocation then gets
+ * the device's memory while it is still in one piece. */
+int cdft_moc_reserve(cdft_moc_plan *plan, int npt, void *stream);
 int cdft_moc_stage(cdft_moc_plan *plan, const float *zv, int64_t rec_stride, int npt, int zv_space, void *stream);
 int cdft_moc_stage_rows(cdft_moc_plan *plan, const float *zv, int64_t rec_stride, int64_t lev_stride, int npt, int zv_space,
                         void *stream);

@@ -21,7 +21,8 @@ CSRC = os.path.join(ROOT, "cdftools_amd", "csrc")
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "--cuda-device-only", "-S"]
 # kernel name pattern (demangled) -> points handled by one iteration of its main loop
 WANT = [
-    ("eos.hip", r"eos_kernel<0, false, 2, 4, 0>", 4, "sigma0 / sigmai EOS-80, exact, tool form"),
+    ("eos.hip", r"eos_kernel<0, false, 2, 4, 1>", 4, "sigma0 EOS-80, exact, tool form (the surface: r0 alone)"),
+    ("eos.hip", r"eos_kernel<0, false, 2, 4, 0>", 4, "sigmai EOS-80, exact, tool form (a reference depth: four polynomials)"),
     ("eos.hip", r"eos_kernel<0, true, 2, 4, 0>", 4, "the same with FMA contraction (CDFT_EOS_FAST_FMA)"),
     ("eos.hip", r"eos_kernel<1, false, 2, 4, 0>", 4, "TEOS-10, exact, tool form"),
     ("eos_more.hip", r"eos_bn2_kernel<0, 0, 4>", 4, "eosbn2, polynomial alpha and beta"),
@@ -73,12 +74,17 @@ def main_loop(lines):
                     kinds[k.group(1)] = kinds.get(k.group(1), 0) + 1
             n = sum(kinds.values())
             if best is None or n > best[0]:
-                best = (n, kinds, sum(1 for b in body if re.match(r"^\s+[vs]_", b)))
+                other = {}
+                for b in body:                                    # the vector instructions that are not r8 arithmetic, by mnemonic
+                    k = re.match(r"^\s+(v_[a-z0-9_]+)", b)
+                    if k and "f64" not in k.group(1):
+                        other[k.group(1)] = other.get(k.group(1), 0) + 1
+                best = (n, kinds, sum(1 for b in body if re.match(r"^\s+[vs]_", b)), other)
     return best
 
 
 def main():
-    out = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else os.path.join(ROOT, "profiles", "r03", "isa_fp64_ops.json")
+    out = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else os.path.join(ROOT, "profiles", "r04", "isa_fp64_ops.json")
     asm, res = {}, {}
     for src, pat, points, what in WANT:
         if src not in asm:
@@ -89,7 +95,7 @@ def main():
         if not hit:
             print("not found:", pat, file=sys.stderr)
             continue
-        n, kinds, ninstr = main_loop(asm[src][hit[0]])
+        n, kinds, ninstr, nonr8 = main_loop(asm[src][hit[0]])
         mul = sum(v for k, v in kinds.items() if k.startswith("v_mul_f64"))
         add = sum(v for k, v in kinds.items() if k.startswith("v_add_f64"))
         fma = sum(v for k, v in kinds.items() if k.startswith("v_fma_f64"))
@@ -97,9 +103,10 @@ def main():
         if points is None:                                # one point per lane and iteration
             points = 1
         res[pat] = {"what": what, "source": src, "points_per_iteration": points, "loop_instructions": ninstr,
-                    "f64_instructions_per_iteration": kinds,
+                    "f64_instructions_per_iteration": kinds, "vector_instructions_not_f64_per_iteration": nonr8,
                     "per_point": {"mul": mul / points, "add": add / points, "fma": fma / points, "other_f64": other / points,
-                                  "issue_slots": n / points, "flops": (mul + add + 2 * fma) / points}}
+                                  "issue_slots": n / points, "flops": (mul + add + 2 * fma) / points,
+                                  "vector_not_f64": sum(nonr8.values()) / points, "vector_all": (n + sum(nonr8.values())) / points}}
     os.makedirs(os.path.dirname(out), exist_ok=True)
     json.dump(res, open(out, "w"), indent=1)
     for k, v in res.items():

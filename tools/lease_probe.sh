@@ -5,6 +5,8 @@ tag=${1:-lease}; shift
 d=gpurun_out/r04/lease_$tag
 mkdir -p $d
 { rocm-smi --showclocks --showpower --showmaxpower --showperflevel --showtemp --showmemuse 2>&1 || true; } > $d/smi_before.txt
+# what the box streams: the read-only ceiling of tools/hbm_probe.hip (best of its shapes), beside the kernel's own figure
+if [ -x tools/bin/hbm_probe ]; then tools/bin/hbm_probe 16 > $d/hbm_probe.jsonl 2>&1; fi
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $d/bench.json 2> $d/bench.err
 echo "bench rc=$?" >> $d/bench.err
 { rocm-smi --showclocks --showpower --showtemp 2>&1 || true; } > $d/smi_after.txt
