@@ -673,16 +673,25 @@ int cdft_curl_compute(cdft_curl_plan *p, const float *un, const float *vn, int n
         static int resident[3][kThreads / 64];                    // per kernel variant and workgroup size; 0 = not asked yet
         int &res = resident[variant][sh.threads / 64 - 1];
         if (res == 0) res = resident_workgroups(table[variant], sh.threads);
-        const char *elc = getenv("CDFT_CURL_CHUNKS");             // A/B hook
-        const int lc = elc ? std::max(1, std::min(nlev, atoi(elc))) : curl_level_chunks(tiles, nlev, res);
+        // Row bands (round 4): each XCD works through its eighth of the rows in bands of 128, a band's level chunks one after
+        // the other, a chunk sized so that a (band, chunk) moves about 33 MB of u, v and result -- 5 levels at eORCA12, 15 at
+        // eORCA025 (measured over bands of 16..256 rows x 1..25 chunks at both grids, profiles/r04/curl_band_*.txt: 3.05 -> 2.82 ms
+        // at eORCA12, 0.338 -> 0.334 at eORCA025).  Grids with fewer than 128 rows per XCD keep the plain (chunk, row, tile) order.
+        // CDFT_CURL_BAND (0: off) and CDFT_CURL_CHUNKS are A/B hooks.
+        const int rows_x = (p->npj + 7) / 8;
+        a.band = rows_x >= 128 ? 128 : 0;
+        if (const char *eb = getenv("CDFT_CURL_BAND")) a.band = std::max(0, atoi(eb));
+        int lc = curl_level_chunks(tiles, nlev, res);
+        if (a.band > 0) {
+            const double per_level = (double)a.band * p->npi * 12.0;
+            const int levs = std::max(1, (int)(33.0e6 / per_level + 0.5));
+            lc = std::max(1, std::min(nlev, (nlev + levs - 1) / levs));
+        }
+        if (const char *elc = getenv("CDFT_CURL_CHUNKS")) lc = std::max(1, std::min(nlev, atoi(elc)));
         dim3 grid((unsigned)(((tiles * lc + 7) / 8) * 8)), block(sh.threads);
-        a.band = 0;
-        if (const char *eb = getenv("CDFT_CURL_BAND")) {          // A/B hook: rows per band (see the kernel)
-            a.band = std::max(0, atoi(eb));
-            if (a.band > 0) {
-                const int rows_x = (p->npj + 7) / 8, nb = (rows_x + a.band - 1) / a.band;
-                grid = dim3((unsigned)(8 * (int64_t)nb * a.band * a.ntx * lc));
-            }
+        if (a.band > 0) {
+            const int nb = (rows_x + a.band - 1) / a.band;
+            grid = dim3((unsigned)(8 * (int64_t)nb * a.band * a.ntx * lc));
         }
         hipLaunchKernelGGL(table[variant], grid, block, 0, st, a, sh.tw, lc);
     } else {

@@ -117,6 +117,26 @@ def test_hip_curl_equals_oracle_bitwise(gpu, monkeypatch, kernel, npi, npj, nlev
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("band,chunks", [(1, 1), (3, 2), (7, 5), (64, 3), (5, 7)])
+@pytest.mark.parametrize("npi,npj,nlev", [(70, 37, 7), (1025, 9, 3), (24, 8, 2)])
+def test_hip_curl_row_bands_any_band_and_chunk_count(gpu, monkeypatch, band, chunks, npi, npj, nlev):
+    """The row-band order of curl_tile_kernel (each XCD works through its eighth of the rows band by band, a band's level
+    chunks one after the other; the default on grids with 128 rows per XCD) with bands and chunk counts that do not divide
+    anything: last bands shorter than the others, XCDs without rows, more chunks than levels.  Bitwise against the oracle."""
+    monkeypatch.setenv("CDFT_CURL_BAND", str(band))
+    monkeypatch.setenv("CDFT_CURL_CHUNKS", str(chunks))
+    g = synth.make_grid(npi, npj, max(nlev, 2), seed=npi + band)
+    u, v, _, _, _, _ = frames(g, 1, seed=18)
+    un, vn = u[0, :nlev], v[0, :nlev]
+    plan = gpu.CurlPlan(npi, npj)
+    for lperio, ltpoint in ((False, False), (True, True)):
+        plan.set_mesh(g["e1u"], g["e2v"], g["e1f"], g["e2f"], lperio=lperio)
+        got = plan.compute(un, vn, ltpoint=ltpoint)
+        ref = np.stack([oracle_tools.curl(un[k], vn[k], g["e1u"], g["e2v"], g["e1f"], g["e2f"], lperio, ltpoint) for k in range(nlev)])
+        assert np.array_equal(got, ref), (lperio, ltpoint)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("ltpoint", [False, True])
 def test_hip_curl_persistent_grid_shares_cross_tiles(gpu, ltpoint):
     """More tiles than the chip holds workgroups (1812 x 5 levels here): a workgroup's share of the (tile, level) units
