@@ -292,7 +292,8 @@ def main_inprocess(args):
     device = torch.device("cuda", 0)
     npi, npj, npk, npt, nb = WORKLOADS[args.workload]
     plan = hip.MocPlan(npi, npj, npk, nb, devices=devices)
-    if os.environ.get("CDFT_BENCH_RESERVE", "1") != "0":
+    reserve_first = os.environ.get("CDFT_BENCH_RESERVE", "1") != "0"
+    if reserve_first:
         plan.reserve(npt)                                      # every block's pool before anything else is allocated
     e1v, e3v, ib, zv = build_inputs(npi, npj, npk, npt, nb, 0, npj, device)
     if args.tune:
