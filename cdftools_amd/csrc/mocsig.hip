@@ -120,14 +120,18 @@ struct SigClassArgs {
 };
 
 // OPT: 0 = v, T, S, e3v and nothing else (the plain kernel: every option below costs it 1-6 % even as a uniform branch, measured);
-//      1 = -eiv and / or -full (uniform branches on a.zeiv, a.e3v);  2 = the same with -isodep
+//      1 = -eiv and / or -full (uniform branches on a.zeiv, a.e3v);  2 = the same with -isodep;
+//      3 = the plain kernel when the three missing values zspv, zspt, zsps are all 0 (what NEMO files carry) and the density is
+//          sigmai: "v == 0 ? 0 : v" and "S == 0 ? 0 : S" only turn -0.0 into +0.0, which changes nothing downstream (a zero term
+//          is never added; sigmai takes |S + dS| and tests S == 0), and the mask (S == 0 ? 0 : 1) is the one sigmai has
+//          already multiplied by -- (x*m)*m = x*m bit for bit for m in {0,1}: eight vector instructions per cell fewer
 template <int NV, int TEOS, int T, int DEPTH, int OPT>
 __global__ void __launch_bounds__(T) mocsig_class_kernel(SigArgs a, SigClassArgs ca) {
     // [nwaves][nq][nclass][nbins], then the basin sums raw [nb][nbins]; with -isodep (nq = 3: the transport, depth * weight
     // and weight sums of :435, :444-445) raw [nq][nb][nbins] is formed in the place of wave 1's histogram, after the waves
     // have been added into wave 0's: see sig_class_shmem()
     extern __shared__ double hist[];
-    constexpr bool EXTRA = OPT >= 1, ISODEP = OPT == 2;
+    constexpr bool EXTRA = OPT == 1 || OPT == 2, ISODEP = OPT == 2, Z0 = OPT == 3;
     constexpr int nwaves = T / 64, nq = ISODEP ? 3 : 1;
     const int jj = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int hq = ca.nclass * a.nbins, hsz = nq * hq;
@@ -187,7 +191,7 @@ __global__ void __launch_bounds__(T) mocsig_class_kernel(SigArgs a, SigClassArgs
                 bool live = false;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    vz[c] = (v4[c] == a.zspv) ? 0.f : v4[c];                                   // :374
+                    vz[c] = Z0 ? v4[c] : ((v4[c] == a.zspv) ? 0.f : v4[c]);                    // :374
                     if (EXTRA && a.zeiv) vz[c] = __fadd_rn(vz[c], c == 0 ? cei.x : c == 1 ? cei.y : c == 2 ? cei.z : cei.w);   // :375-378
                     const float zarea = __fmul_rn(e1[r][c], e4[c]);                            // :389
                     val[c] = -(double)__fmul_rn(vz[c], zarea);                                 // :417
@@ -209,10 +213,10 @@ __global__ void __launch_bounds__(T) mocsig_class_kernel(SigArgs a, SigClassArgs
                 for (int c = 0; c < 4; ++c) {
                     float t = t4[c], s = s4[c];
                     if (t == a.zspt) t = 0.f;                                                  // :382
-                    if (s == a.zsps) s = 0.f;                                                  // :383
+                    if (!Z0 && s == a.zsps) s = 0.f;                                           // :383
                     const int itm = (s == a.zsps) ? 0 : 1;                                     // :392-393
                     const double dens = mocsig_density<TEOS, DEPTH>(t, s, a.pref);             // :395
-                    const float zttmp = (float)__dmul_rn(dens, (double)itm);                   // :398
+                    const float zttmp = Z0 ? (float)dens : (float)__dmul_rn(dens, (double)itm);   // :398
                     // :400  (zttmp - sigmin) / sigstp in r4, correctly rounded: the quotient of two r4 numbers is never closer
                     // than 2^-49 (relative) to the middle between two r4 numbers unless it is one, so the r8 product with the r8
                     // reciprocal of sigstp (error < 2^-52) rounds to the same r4 as the division -- three instructions, not ten
@@ -324,6 +328,10 @@ template <int NV, int KIND, int DEPTH>
 int launch_sig_class_depth(const SigArgs &a, const SigClassArgs &ca, size_t shmem, hipStream_t st) {
     if (a.depi) return launch_sig_class_opt<NV, KIND, DEPTH, 2>(a, ca, shmem, st);
     if (a.zeiv || !a.e3v) return launch_sig_class_opt<NV, KIND, DEPTH, 1>(a, ca, shmem, st);
+    if constexpr (KIND != 2) {                                    // (sigmantr applies no mask of its own)
+        if (a.zspv == 0.f && a.zspt == 0.f && a.zsps == 0.f && !getenv("CDFT_MOCSIG_SPVAL_GENERAL"))     // (A/B and test hook)
+            return launch_sig_class_opt<NV, KIND, DEPTH, 3>(a, ca, shmem, st);
+    }
     return launch_sig_class_opt<NV, KIND, DEPTH, 0>(a, ca, shmem, st);
 }
 

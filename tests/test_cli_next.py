@@ -844,3 +844,28 @@ def test_hip_mocsig_land_shortcut_is_bit_identical(gpu, monkeypatch):
     ref = oracle_lib.mocsig(zv, zt, zs, e1v, ib, 158, np.float32(30.0), np.float32(0.05), **kw)
     ok = np.isfinite(ref)
     assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.all(np.abs(got[ok] - ref[ok]) <= 1e-10 * np.abs(ref[ok]).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("teos,pref", [(False, 2000.0), (True, 0.0), (False, 0.0)])
+def test_hip_mocsig_zero_missing_values_form_is_bit_identical(gpu, monkeypatch, teos, pref):
+    """With zspv = zspt = zsps = 0 (NEMO files) the class kernel leaves out the compares against the missing values and the
+    second mask product (mocsig.hip, OPT = 3): the same histogram, bit for bit, as the general form (CDFT_MOCSIG_SPVAL_GENERAL=1)
+    -- with -0.0 velocities and salinities, zeros in T and S, a NaN, and land."""
+    npi, npj, npk, nb = 1031, 6, 5, 5
+    g, e1v, _, ib, zv, zt, zs = mocsig_inputs(npi, npj, npk, nb, seed=41)
+    zv, zt, zs = zv.copy(), zt.copy(), zs.copy()
+    zv[:, 1, 200:260] = -0.0
+    zs[:, 2, 300:420] = -0.0
+    zs[:, 3, 500:600] = 0.0
+    zt[:, 3, 550:650] = 0.0
+    zt[:, 4, 10:40] = -0.0
+    zv[1, 4, 700] = np.nan
+    zs[2, 0, 800] = np.nan
+    kw = dict(pref=pref, e3v=g["e3v_0"], eos=1 if teos else 0)
+    monkeypatch.delenv("CDFT_MOCSIG_SPVAL_GENERAL", raising=False)
+    got = gpu.mocsig(zv, zt, zs, e1v, ib, 158, np.float32(30.0 if pref else 20.0), np.float32(0.05), **kw)
+    monkeypatch.setenv("CDFT_MOCSIG_SPVAL_GENERAL", "1")
+    gen = gpu.mocsig(zv, zt, zs, e1v, ib, 158, np.float32(30.0 if pref else 20.0), np.float32(0.05), **kw)
+    assert got.tobytes() == gen.tobytes()
+    assert np.isnan(got).any() and np.isfinite(got).any()

@@ -27,6 +27,7 @@ WANT = [
     ("eos.hip", r"eos_kernel<1, false, 2, 4, 0>", 4, "TEOS-10, exact, tool form"),
     ("eos_more.hip", r"eos_bn2_kernel<0, 0, 4>", 4, "eosbn2, polynomial alpha and beta"),
     ("mocsig.hip", r"mocsig_class_kernel<5, 0, 256, 2, 0>", 20, "cdfmocsig class kernel, EOS-80, 5 vectors per lane (eORCA12 rows)"),
+    ("mocsig.hip", r"mocsig_class_kernel<5, 0, 256, 2, 3>", 20, "the same when the three missing values are 0 (NEMO files)"),
     ("mocsig.hip", r"mocsig_class_kernel<2, 0, 256, 2, 0>", 8, "cdfmocsig class kernel, EOS-80, 2 vectors per lane (eORCA025 rows)"),
 ]
 F64 = re.compile(r"^\s+(v_[a-z0-9_]*f64[a-z0-9_]*)\b")
