@@ -184,6 +184,7 @@ __global__ void __launch_bounds__(kThreads) vt_kernel(VtArgs a) {
 struct CurlArgs {
     const float *un, *vn;                     // (npi,npj,nlev)
     const float *e1u, *e2v, *e1f, *e2f;       // (npi,npj)
+    const float *den;                         // (npi,npj) e1f*e2f in r4 (the tile kernel reads one plane instead of two)
     const double *ff;                         // (npi,npj) or null
     int npi, npj, nlev, ntx, lperio;
     int band;                                 // curl_tile_kernel: rows of a band (0: the whole eighth of an XCD), see there
@@ -340,11 +341,8 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6
         const int64_t p2 = (int64_t)jj * a.npi + i0;
         float e1u[4] = {0, 0, 0, 0}, e1un[4] = {0, 0, 0, 0}, e2v[4] = {0, 0, 0, 0}, den[4] = {1, 1, 1, 1}, enx = 0.f;
         if (act) {
-            float e1f[4], e2f[4];
-            load4(a.e1u + p2, 4, e1u); load4(a.e2v + p2, 4, e2v); load4(a.e1f + p2, 4, e1f); load4(a.e2f + p2, 4, e2f);
+            load4(a.e1u + p2, 4, e1u); load4(a.e2v + p2, 4, e2v); load4(a.den + p2, 4, den);     // den = e1f*e2f, formed once per mesh
             if (north) load4(a.e1u + p2 + a.npi, 4, e1un);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) den[c] = __fmul_rn(e1f[c], e2f[c]);
             if (i0 + 4 < a.npi) enx = a.e2v[p2 + 4];
         }
         struct Level { float u[4], v[4], un1[4], hv; };
@@ -484,6 +482,12 @@ __global__ void curl_tpoint_kernel(CurlArgs a) {
     ((OUT *)a.out)[g] = (OUT)r;
 }
 
+// e1f*e2f in r4, the divisor of src/cdfcurl.f90:276-282, once per mesh
+__global__ void curl_den_kernel(const float *__restrict__ e1f, const float *__restrict__ e2f, float *__restrict__ den, int64_t n) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) den[p] = __fmul_rn(e1f[p], e2f[p]);
+}
+
 DevBuf g_in[6], g_out[6];
 
 }  // namespace
@@ -583,7 +587,7 @@ int cdft_stencil_release(void) {
 
 struct cdft_curl_plan {
     int npi = 0, npj = 0, lperio = 0;
-    float *e1u = nullptr, *e2v = nullptr, *e1f = nullptr, *e2f = nullptr;
+    float *e1u = nullptr, *e2v = nullptr, *e1f = nullptr, *e2f = nullptr, *den = nullptr;
     double *ff = nullptr;
     bool mesh_set = false;
     DevBuf su, sv, sout, work;
@@ -627,6 +631,12 @@ int cdft_curl_set_mesh(cdft_curl_plan *p, const float *e1u, const float *e2v, co
         (void)hipFree(p->ff);
         p->ff = nullptr;
     }
+    if (!p->den && hipMalloc((void **)&p->den, nij * 4 + 64) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(CDFT_ERR_ALLOC, "cdft_curl_set_mesh: device allocation failed");
+    }
+    hipLaunchKernelGGL(curl_den_kernel, dim3((unsigned)((nij + 255) / 256)), dim3(256), 0, st, p->e1f, p->e2f, p->den, (int64_t)nij);
+    CDFT_LAUNCH_CHECK();
     CDFT_HIP(hipStreamSynchronize(st));
     p->lperio = lperio ? 1 : 0;
     p->mesh_set = true;
@@ -651,7 +661,7 @@ int cdft_curl_compute(cdft_curl_plan *p, const float *un, const float *vn, int n
         dout = p->sout.ptr;
     }
     CurlArgs a;
-    a.un = (const float *)du; a.vn = (const float *)dv; a.e1u = p->e1u; a.e2v = p->e2v; a.e1f = p->e1f; a.e2f = p->e2f;
+    a.un = (const float *)du; a.vn = (const float *)dv; a.e1u = p->e1u; a.e2v = p->e2v; a.e1f = p->e1f; a.e2f = p->e2f; a.den = p->den;
     a.ff = p->ff; a.npi = p->npi; a.npj = p->npj; a.nlev = nlev;
     a.lperio = p->lperio; a.out = dout; a.work = nullptr; a.band = 0;
     if (ltpoint) {
@@ -720,7 +730,7 @@ int cdft_curl_compute(cdft_curl_plan *p, const float *un, const float *vn, int n
 
 int cdft_curl_destroy(cdft_curl_plan *p) {
     if (!p) return CDFT_OK;
-    void *ptrs[] = {p->e1u, p->e2v, p->e1f, p->e2f, p->ff};
+    void *ptrs[] = {p->e1u, p->e2v, p->e1f, p->e2f, p->den, p->ff};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     p->su.release(); p->sv.release(); p->sout.release(); p->work.release();
     delete p;

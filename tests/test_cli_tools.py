@@ -97,6 +97,13 @@ def test_cdfsig0_and_cdfsigi_end_to_end(case):
     assert rc == 0, out + err
     var, att, _ = read_nc(os.path.join(d, "sigi.nc"))
     assert np.array_equal(var["vosigmai"], oracle_lib.sig_tool(rec["t"], rec["s"], 2000.0, 0.0, teos10=True))
+    # the reference names the depth by its option parser's scratch string (src/cdfsigi.f90:98, :166): the value of -r only when
+    # no value-less option follows it -- kept file for file (the reference's own program writes the same:
+    # tests/golden/prog_cdfsigi_teos10.npz)
+    assert att["vosigmai"]["long_name"] == b"Potential_density:refered to -teos10 m"
+    rc, out, err = run("cdfsigi", ["-teos10", "-o", "sigi_b.nc", "-t", "SYN_y0001_gridT.nc", "-r", "2000"], d)
+    assert rc == 0, out + err
+    _, att, _ = read_nc(os.path.join(d, "sigi_b.nc"))
     assert att["vosigmai"]["long_name"] == b"Potential_density:refered to 2000 m"
 
 
