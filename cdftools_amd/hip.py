@@ -544,11 +544,18 @@ class MhstPlan(_Plan):
         sp = _same_space(s1, sm, s3, s4)
         check(_lib.load().cdft_mhst_set_mesh(self._h, p1, p3, p4, pm, sp, stream or current_stream_ptr()))
 
-    def compute(self, vt=None, vs=None, zv=None, zt=None, zs=None, zdim=False, stream=None):
-        """-> (heat, salt) host arrays (npj,nb) or (npk,npj,nb) with zdim: raw zonal sums."""
+    def compute(self, vt=None, vs=None, zv=None, zt=None, zs=None, zdim=False, stream=None, device_out=None):
+        """-> (heat, salt) host arrays (npj,nb) or (npk,npj,nb) with zdim: raw zonal sums.  device_out = (heat, salt) CUDA
+        tensors of that shape: the results stay in HBM and the call does not wait for them (the kernels alone)."""
         a = [_opt(x, n) for x, n in ((vt, "vt"), (vs, "vs"), (zv, "zv"), (zt, "zt"), (zs, "zs"))]
         sp = _same_space(*[x[1] for x in a])
         shape = (self.npk, self.npj, self.nb) if zdim else (self.npj, self.nb)
+        if device_out is not None:
+            dh, dsl = device_out
+            check(_lib.load().cdft_mhst_compute(self._h, a[0][0], a[1][0], a[2][0], a[3][0], a[4][0], sp, 1 if zdim else 0,
+                                                C.c_void_p(dh.data_ptr()), C.c_void_p(dsl.data_ptr()), MEM_DEVICE,
+                                                stream or current_stream_ptr()))
+            return dh, dsl
         heat, salt = np.empty(shape, np.float64), np.empty(shape, np.float64)
         check(_lib.load().cdft_mhst_compute(self._h, a[0][0], a[1][0], a[2][0], a[3][0], a[4][0], sp,
                                             1 if zdim else 0, C.c_void_p(heat.ctypes.data),
@@ -693,9 +700,13 @@ class MeanPlan(_Plan):
         """0 = cdfmean, 1 = cdfsum, 2 = cdfsum on a file without depth, 3 = cdfmean without the variance sum (cdft_mean_set_form)."""
         check(_lib.load().cdft_mean_set_form(self._h, int(form)))
 
-    def compute(self, zv, stream=None):
-        """zv (npk,npj,npi) r4 -> sums (npk,nb,4) r8: dsurf, dvol2d, dsum2d, dvar2d."""
+    def compute(self, zv, stream=None, device_out=None):
+        """zv (npk,npj,npi) r4 -> sums (npk,nb,4) r8: dsurf, dvol2d, dsum2d, dvar2d.  device_out: a CUDA tensor of that shape --
+        the sums stay in HBM and the call does not wait for them (the kernels alone)."""
         pz, sz, kz = _arg(zv, np.float32, "zv")
+        if device_out is not None:
+            check(_lib.load().cdft_mean_compute(self._h, pz, sz, C.c_void_p(device_out.data_ptr()), MEM_DEVICE, stream or current_stream_ptr()))
+            return device_out
         out = np.empty((self.npk, self.nb, 4), np.float64)
         check(_lib.load().cdft_mean_compute(self._h, pz, sz, C.c_void_p(out.ctypes.data), MEM_HOST, stream or current_stream_ptr()))
         return out

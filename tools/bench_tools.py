@@ -194,12 +194,15 @@ def main():
         p = hip.MeanPlan(npi, npj, npk, 1)
         p.set_mesh(e1.cpu().numpy(), e2.cpu().numpy(), tm, np.ones((npj, npi, 1), np.int16), e3=e3.cpu().numpy())
         del tm
+        dsum = torch.empty((npk, 1, 4), dtype=torch.float64, device=dev)
         ms = timed(lambda: p.compute(zv), args.reps)
+        ms_res = timed(lambda: p.compute(zv, device_out=dsum), args.reps)
         report("cdfmean -var (1 basin)", args.grid, n3, 9.0, ms, "field 4 + e3 4 + mask 1 B per cell (a 0/1 mask is kept as bytes); includes the D2H of 4*npk sums; "
-               "with the variance sum (zv*zv*e1*e2*e3)")
+               "with the variance sum (zv*zv*e1*e2*e3)", ms_res)
         p.set_form(3)
         ms = timed(lambda: p.compute(zv), args.reps)
-        report("cdfmean (1 basin)", args.grid, n3, 9.0, ms, "the same without the variance sum (CDFT_MEAN_FORM_MEAN_NOVAR: what the program asks for without -var)")
+        ms_res = timed(lambda: p.compute(zv, device_out=dsum), args.reps)
+        report("cdfmean (1 basin)", args.grid, n3, 9.0, ms, "the same without the variance sum (CDFT_MEAN_FORM_MEAN_NOVAR: what the program asks for without -var)", ms_res)
         p.set_form(1)
         ms = timed(lambda: p.compute(zv), args.reps)
         report("cdfsum (1 basin)", args.grid, n3, 9.0, ms, "cdfsum's form: SUM(zv*e1*e2), no variance")
@@ -257,7 +260,9 @@ def main():
         p = hip.MhstPlan(npi, npj, npk, 5)
         p.set_mesh(e1, m, e3v=e3)
         ms = timed(lambda: p.compute(vt=vt, vs=vs), args.reps)
-        report("cdfmhst -vt", args.grid, n3, 12.0, ms, "vt 4 + vs 4 + e3v 4 B per cell: one record per launch, e3v read in full by each (BASELINE.md section 3)")
+        dhs = (torch.empty((npj, 5), dtype=torch.float64, device=dev), torch.empty((npj, 5), dtype=torch.float64, device=dev))
+        ms_res = timed(lambda: p.compute(vt=vt, vs=vs, device_out=dhs), args.reps)
+        report("cdfmhst -vt", args.grid, n3, 12.0, ms, "vt 4 + vs 4 + e3v 4 B per cell: one record per launch, e3v read in full by each (BASELINE.md section 3)", ms_res)
         del p, vt, vs, m
 
     if "psi" in tools:
