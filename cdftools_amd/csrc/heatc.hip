@@ -500,7 +500,7 @@ template <bool MASK8, bool FULL, bool MXL>
 // (four workgroups per CU -- 128 VGPRs, no spill in the byte-mask form -- were measured in round 4: no faster, 2.27 against 2.20 ms)
 __global__ void __launch_bounds__(64 * kScanWaves, 3) heatc_scan_kernel(HeatcArgs a, ScanLevel *__restrict__ lev, ScanCtl *__restrict__ ctl,
                                                                      const double *__restrict__ est, int block_cells, int nchunk, int nsteps,
-                                                                     float *__restrict__ sums4, long long scan_wait_ticks, int nlanes, int align) {
+                                                                     float *__restrict__ sums4, long long scan_wait_ticks, int nlanes, int align, int dbg) {
     __shared__ int sm_K[2][kScanMaxChunks][3], sm_pos[2][kScanMaxChunks][3], sm_flag[2][kScanMaxChunks][3], sm_key[2][kScanMaxChunks][3];
     __shared__ int tick;
     __shared__ __attribute__((aligned(16))) float xs[3][kScanChunk];
@@ -734,7 +734,7 @@ __global__ void __launch_bounds__(64 * kScanWaves, 3) heatc_scan_kernel(HeatcArg
                 }
                 products(raw, c0, x);
                 if (q + 2 * kScanWaves < nchunk && c0 + 2 * kScanSub < nijv) fetch(raw, c0 + 2 * kScanSub);
-                summarize(x, q);
+                if (!(dbg & 2)) summarize(x, q);      // (dbg: timing experiments of tools/, results then meaningless)
             };
             fetch(rawA, t0 + (int64_t)w * kScanChunk);
             if (w + kScanWaves < nchunk && t0 + (int64_t)(w + kScanWaves) * kScanChunk < nijv) fetch(rawB, t0 + (int64_t)(w + kScanWaves) * kScanChunk);
@@ -756,7 +756,7 @@ __global__ void __launch_bounds__(64 * kScanWaves, 3) heatc_scan_kernel(HeatcArg
                 // flag and gives up too, the kernel ends and the host takes the plain chain instead)
                 long long t_start = 0;
                 int spins = 0;
-                while ((int)((pub = __hip_atomic_load(&lev[k].word[ch], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != step) {
+                while (!(dbg & 1) && (int)((pub = __hip_atomic_load(&lev[k].word[ch], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != step) {
                     __builtin_amdgcn_s_sleep(1);
                     if ((++spins & 1023) == 0 || scan_wait_ticks == 0) {
                         const long long now = wall_clock64();
@@ -793,7 +793,7 @@ __global__ void __launch_bounds__(64 * kScanWaves, 3) heatc_scan_kernel(HeatcArg
                     if (sl < 64) { stop = g + sl; hstop = __shfl(h, sl, 64); }
                 }
                 if (ks >= 0) s = scan_value(ks, S0);
-                if (stop < 0) break;
+                if (stop < 0 || (dbg & 4)) break;
                 if (lane == 0 && ks >= 0 && hstop < 0) atomicAdd(&ctl->nunguessed, 1);
                 // the chunk that stopped the walk: read again and resolved cell by cell
                 const int q = stop;
@@ -979,6 +979,8 @@ int launch_seq_scan(HeatcArgs a, const float *carry, float *sums4, DevBuf &work,
     const int nsteps = (int)((a.nij + 127 + ticket_cells - 1) / ticket_cells);   // (a level is walked with up to 127 cells of padding in front)
     const int nlanes = scan_lanes(st);
     const int align = getenv("CDFT_HEATC_SCAN_NOALIGN") ? 0 : 1;          // (A/B hook)
+    // timing experiments only (the sums are then wrong): 1 = no chain waits, 2 = no chunk sums, 4 = no cell-by-cell resolution
+    const int dbg = getenv("CDFT_HEATC_SCAN_DEBUG") ? atoi(getenv("CDFT_HEATC_SCAN_DEBUG")) : 0;
     const size_t head = (sizeof(ScanLevel) * (size_t)a.npk + sizeof(ScanCtl) + 15) / 16 * 16;
     CDFT_TRY(work.reserve(head + sizeof(double) * (size_t)a.npk * (a.nblk + 1) * 3));
     ScanLevel *lev = (ScanLevel *)work.ptr;
@@ -1002,7 +1004,7 @@ int launch_seq_scan(HeatcArgs a, const float *carry, float *sums4, DevBuf &work,
     const int64_t tickets = (int64_t)nsteps * a.npk;
     const int per_cu = 3;                                       // (the kernel's launch bounds)
     dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>(tickets, per_cu * (int64_t)ncu))), block(64 * kScanWaves);
-#define CDFT_SCAN_LAUNCH(M8, FU, MX) hipLaunchKernelGGL((heatc_scan_kernel<M8, FU, MX>), grid, block, 0, st, a, lev, ctl, est, block_cells, nchunk, nsteps, sums4, wait_ticks, nlanes, align)
+#define CDFT_SCAN_LAUNCH(M8, FU, MX) hipLaunchKernelGGL((heatc_scan_kernel<M8, FU, MX>), grid, block, 0, st, a, lev, ctl, est, block_cells, nchunk, nsteps, sums4, wait_ticks, nlanes, align, dbg)
     if (m8 && full)        { if (mx) CDFT_SCAN_LAUNCH(true, true, true);   else CDFT_SCAN_LAUNCH(true, true, false); }
     else if (m8 && !full)  { if (mx) CDFT_SCAN_LAUNCH(true, false, true);  else CDFT_SCAN_LAUNCH(true, false, false); }
     else if (!m8 && full)  { if (mx) CDFT_SCAN_LAUNCH(false, true, true);  else CDFT_SCAN_LAUNCH(false, true, false); }

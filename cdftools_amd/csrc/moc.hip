@@ -968,6 +968,7 @@ int cdft_moc_destroy(cdft_moc_plan *p) {
     if (p->cls) (void)hipFree(p->cls);
     if (p->flag) (void)hipFree(p->flag);
     p->st_e1v.release(); p->st_e3v.release(); p->st_mask.release(); p->st_vm.release(); p->st_zv.release(); p->st_out.release(); p->seg_out.release();
+    p->pool.release();
     DevBuf *dec[] = {&p->d_e3v, &p->d_e1u, &p->d_zcoef, &p->d_tmask, &p->d_umask, &p->d_t, &p->d_s, &p->d_zvgeo, &p->d_sig8,
                      &p->d_dvbt, &p->d_hdep, &p->d_dvgeo, &p->d_raw, &p->d_o4};
     for (DevBuf *b : dec) b->release();

@@ -43,6 +43,8 @@ def moc(devices=None):
     p = hip.MocPlan(npi, npj, npk, 5, devices=devices)
     p.set_mesh(e1v, e3v, ib)
     p.compute(zv)
+    p.stage(zv)                                   # the pool of staged records (round 4) goes with the plan too
+    p.compute_staged(np.zeros((2, npk, npj, 5)))
     p.close()
 
 
