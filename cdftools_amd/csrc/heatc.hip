@@ -400,14 +400,28 @@ typedef float f2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2v pk_mul(f2v a, f2v b) { return a * b; }
 __device__ __forceinline__ f2v pk_add(f2v a, f2v b) { return a + b; }
 __device__ __forceinline__ f2v pk_sub(f2v a, f2v b) { return a - b; }
+// the minimum over the 64 lanes, in every lane: the same six DPP steps as wave_isum (INT_MAX where a step brings nothing)
 __device__ __forceinline__ int wave_imin(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
-    return v;
+    const int big = 0x7fffffff;
+    v = min(v, __builtin_amdgcn_update_dpp(big, v, 0xb1, 0xf, 0xf, false));     // quad_perm:[1,0,3,2]
+    v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x4e, 0xf, 0xf, false));     // quad_perm:[2,3,0,1]
+    v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x141, 0xf, 0xf, false));    // row_half_mirror
+    v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x140, 0xf, 0xf, false));    // row_mirror
+    v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x142, 0xa, 0xf, false));    // row_bcast:15 into rows 1 and 3
+    v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x143, 0xc, 0xf, false));    // row_bcast:31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(v, 63);
 }
+// inclusive prefix sum over the lanes: row_shr:1,2,4,8 inside the rows of 16 (a lane without a source adds 0), then the
+// rows' totals carried forward by row_bcast:15 and :31 -- six vector instructions instead of six ds_bpermute round trips
+// (the walk does one of these per 64 chunks, the cell-by-cell resolution two per round)
 __device__ __forceinline__ int wave_iscan_incl(int v, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(v, o, 64); if (lane >= o) v += t; }
+    (void)lane;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);             // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);             // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);             // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);             // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);             // row_bcast:15: rows 1 and 3 take the total of the row before
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);             // row_bcast:31: rows 2 and 3 take the total of rows 0-1
     return v;
 }
 
