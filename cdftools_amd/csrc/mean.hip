@@ -88,52 +88,42 @@ __global__ void __launch_bounds__(kThreads) mean_level_kernel(MeanArgs a) {
         }
     }
     const int sumform = a.form == CDFT_MEAN_FORM_MEAN_NOVAR ? CDFT_MEAN_FORM_MEAN : a.form;
-    // One level's operands of this lane, as loaded (the byte mask still packed).  Level k+1 is requested before level k is
-    // summed (round 4): a wave walks 75 levels, and without it each level was one exposed round trip to memory -- at eORCA025,
-    // where every workgroup of the grid is resident at once, that was the kernel's whole time (0.22 ms for 0.18 ms of traffic).
-    struct Level { float zv[kVPT][VEC], e3[kVPT][VEC], mk[kVPT][VEC]; uint32_t m8[kVPT]; };
-    auto fetch = [&](Level &L, int k) {
+    for (int k = 0; k < a.npk; ++k) {
         const int64_t base = (int64_t)k * a.nij;
+        float zv[kVPT][VEC], e3[kVPT][VEC], mk[kVPT][VEC];
 #pragma unroll
         for (int v = 0; v < kVPT; ++v) {
-            L.m8[v] = 0u;
             if constexpr (VEC == 4) {                  // 16-byte loads at r4 alignment, always inside the level
                 const f4u z = ld_stream4u(a.zv + base + q[v]);
-                L.zv[v][0] = z.x; L.zv[v][1] = z.y; L.zv[v][2] = z.z; L.zv[v][3] = z.w;
+                zv[v][0] = z.x; zv[v][1] = z.y; zv[v][2] = z.z; zv[v][3] = z.w;
                 if (a.mask8) {                         // 4 mask bytes (an unaligned dword): the same 0.f / 1.f
                     typedef uint32_t u32u __attribute__((aligned(1)));
-                    L.m8[v] = __builtin_nontemporal_load(reinterpret_cast<const u32u *>(a.mask8 + base + q[v]));
+                    const uint32_t m = __builtin_nontemporal_load(reinterpret_cast<const u32u *>(a.mask8 + base + q[v]));
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) mk[v][c] = (float)((m >> (8 * c)) & 0xffu);
                 } else {
                     const f4u m = ld_stream4u(a.mask + base + q[v]);
-                    L.mk[v][0] = m.x; L.mk[v][1] = m.y; L.mk[v][2] = m.z; L.mk[v][3] = m.w;
+                    mk[v][0] = m.x; mk[v][1] = m.y; mk[v][2] = m.z; mk[v][3] = m.w;
                 }
                 if (!FULL) {
                     const f4u e = ld_stream4u(a.e3 + base + q[v]);
-                    L.e3[v][0] = e.x; L.e3[v][1] = e.y; L.e3[v][2] = e.z; L.e3[v][3] = e.w;
+                    e3[v][0] = e.x; e3[v][1] = e.y; e3[v][2] = e.z; e3[v][3] = e.w;
                 }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) if (!ok[v][c]) zv[v][c] = 0.f;      // not this lane's cell: an exact zero
             } else {
 #pragma unroll
                 for (int c = 0; c < VEC; ++c) {
                     const int64_t pc = ok[v][c] ? q[v] + c : 0;
-                    L.zv[v][c] = ok[v][c] ? a.zv[base + pc] : 0.f;
-                    L.mk[v][c] = a.mask[base + pc];
-                    if (!FULL) L.e3[v][c] = a.e3[base + pc];
+                    zv[v][c] = ok[v][c] ? a.zv[base + pc] : 0.f;
+                    mk[v][c] = a.mask[base + pc];
+                    if (!FULL) e3[v][c] = a.e3[base + pc];
                 }
             }
-        }
-    };
-    Level cur, nxt;
-    if (a.npk > 0) fetch(cur, 0);
-    for (int k = 0; k < a.npk; ++k) {
-        if (k + 1 < a.npk) fetch(nxt, k + 1);
-        float zv[kVPT][VEC], e3[kVPT][VEC], mk[kVPT][VEC];
+            if (FULL) {
+                const float z = a.e31d[k];
 #pragma unroll
-        for (int v = 0; v < kVPT; ++v) {
-#pragma unroll
-            for (int c = 0; c < VEC; ++c) {
-                zv[v][c] = (VEC == 4 && !ok[v][c]) ? 0.f : cur.zv[v][c];          // not this lane's cell: an exact zero
-                mk[v][c] = (VEC == 4 && a.mask8) ? (float)((cur.m8[v] >> (8 * c)) & 0xffu) : cur.mk[v][c];
-                e3[v][c] = FULL ? a.e31d[k] : cur.e3[v][c];
+                for (int c = 0; c < VEC; ++c) e3[v][c] = z;
             }
         }
         double s[NB][4];
@@ -175,7 +165,6 @@ __global__ void __launch_bounds__(kThreads) mean_level_kernel(MeanArgs a) {
                 const double t = (c < 3 || a.form == CDFT_MEAN_FORM_MEAN) ? wave_sum(s[b][c]) : 0.0;       // (uniform)
                 if (lane == 0 && b < a.nb) wsum[((PARK ? wave * a.npk + k : wave) * a.nb + b) * 4 + c] = t;
             }
-        cur = nxt;
         if (!PARK) {
             __syncthreads();
             if ((int)threadIdx.x < a.nb * 4) {
