@@ -1,5 +1,5 @@
 #!/bin/sh
-# The reference's own PROGRAMS, unmodified, compiled where they lie under /root/reference/src into oracle/_ref/prog/
+# The reference's own PROGRAMS (the eight of SURVEY 8a and the ten of 8f), unmodified, compiled where they lie under /root/reference/src into oracle/_ref/prog/
 # (git-ignored, never pushed to the GPU box: .gpurunignore).  Build container only.
 #
 # What this is, and is not.  The reference programs need netcdf-fortran, which the image lacks; here they are linked against
@@ -28,11 +28,12 @@ for f in modcdfnames.F90 cdfio.F90 modutils.f90 eos.f90 cdftools.f90; do
     new=1
   fi
 done
-for p in cdfmoc cdfmhst cdfvT cdfheatc cdfpsi cdfcurl cdfsig0 cdfsigi; do
+for p in cdfmoc cdfmhst cdfvT cdfheatc cdfpsi cdfcurl cdfsig0 cdfsigi \
+         cdfvhst cdfvtrp cdfmean cdfsum cdfzonalsum cdfzonalmean cdfvint cdfvertmean cdfmocsig cdfmaxmoc; do
   if [ $new = 1 ] || [ ! -f _ref/prog/$p ] || [ $REF/$p.f90 -nt _ref/prog/$p ]; then
     $FC $FLAGS -I$FB -I$O -module-dir $O -c $REF/$p.f90 -o $O/$p.prog.o
     $FC $O/$p.prog.o $O/modcdfnames.o $O/cdfio.o $O/modutils.o $O/eos.o $O/cdftools.o $FB/netcdf.o -o _ref/prog/$p \
         -L$LIBDIR -lncclassic -Wl,-rpath,$LIBDIR
   fi
 done
-echo "oracle/_ref/prog: the 8 reference programs of SURVEY 8(a), unmodified, over this repository's NetCDF layer (a differential, not a pin)"
+echo "oracle/_ref/prog: the 18 reference programs of SURVEY 8(a) and 8(f), unmodified, over this repository's NetCDF layer (a differential, not a pin)"

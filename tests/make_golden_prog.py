@@ -30,6 +30,7 @@ def main():
     bindir = os.path.join(ROOT, "oracle", "_ref", "prog")
     gold = os.path.join(HERE, "golden")
     bad = 0
+    skipped = {}
     with tempfile.TemporaryDirectory(prefix="cdft_prog_") as d:
         nemo_files.make_case(d)
         for case in pc.CASES:
@@ -37,9 +38,15 @@ def main():
             path = os.path.join(gold, f"prog_{case[0]}.npz")
             missing = [o for o, s in meta["files"].items() if s is None]
             print(f"{case[0]:28s} rc={meta['rc']} files={list(meta['files'])} missing={missing} stdout={len(meta['stdout'].splitlines())} lines")
-            if meta["rc"] != 0 or missing:
-                print(meta["stdout"][-2000:])
-                raise SystemExit(f"the reference program failed on case {case[0]}")
+            if (meta["rc"] != 0 and not (meta["rc"] in (97, 98, 99) and not case[3])) or missing:      # (a STOP code a case expects is an outcome)
+                # a reference program that does not run here AS IT IS (e.g. cdfmean opens unit 6 with RECL=, an ifort idiom
+                # its own comment flags, which the flang runtime refuses) is left out of the differential, with the reason
+                skipped[case[0]] = {"rc": meta["rc"], "missing": missing, "stderr_tail": meta.get("stderr", "")[-400:],
+                                    "stdout_tail": meta["stdout"][-400:]}
+                print("    -> left out:", (meta.get("stderr", "") or meta["stdout"]).strip().splitlines()[-1:] )
+                if os.path.exists(path) and not check:
+                    os.remove(path)
+                continue
             if check:
                 m0, a0 = pc.load_golden(path)
                 same = m0 == meta and sorted(a0) == sorted(arrays) and all(np.array_equal(a0[k], arrays[k], equal_nan=True) for k in a0)
@@ -47,9 +54,14 @@ def main():
                 bad += not same
             else:
                 pc.save_golden(path, meta, arrays)
+    import json
+    spath = os.path.join(gold, "prog_left_out.json")
     if check:
-        print("all equal" if not bad else f"{bad} case(s) differ")
-        raise SystemExit(1 if bad else 0)
+        same = json.load(open(spath)) == skipped if os.path.exists(spath) else not skipped
+        print("all equal" if not bad and same else f"{bad} case(s) differ" + ("" if same else "; the list of cases left out differs"))
+        raise SystemExit(1 if bad or not same else 0)
+    json.dump(skipped, open(spath, "w"), indent=1)
+    print(f"{len(pc.CASES) - len(skipped)} goldens written, {len(skipped)} cases left out ({', '.join(skipped) or 'none'})")
 
 
 if __name__ == "__main__":

@@ -125,7 +125,11 @@ def test_programs_against_the_reference_programs(tmp_path):
     d = str(tmp_path)
     nemo_files.make_case(d)
     report, unexplained = [], []
+    out_of_it = pc.left_out()
     for case in pc.CASES:
+        if case[0] in out_of_it:                                       # the reference program does not run as it is: no golden
+            pc.run_case(BIN, case, d)                                  # (still run here: a later case may read its output)
+            continue
         ref, ref_arr = pc.load_golden(os.path.join(GOLD, f"prog_{case[0]}.npz"))
         got, got_arr = pc.run_case(BIN, case, d)
         for kind, item, detail in diff_case(case, ref, ref_arr, got, got_arr):
@@ -143,7 +147,11 @@ def test_programs_against_the_reference_programs(tmp_path):
 
 
 def test_goldens_are_there_for_every_case():
+    out_of_it = pc.left_out()
+    assert set(out_of_it) <= {c[0] for c in pc.CASES} and len(out_of_it) <= 4
     for case in pc.CASES:
+        if case[0] in out_of_it:
+            continue
         meta, arrays = pc.load_golden(os.path.join(GOLD, f"prog_{case[0]}.npz"))
-        assert meta["rc"] == 0 and meta["program"] == case[1] and meta["args"] == case[2]
-        assert all(v is not None for v in meta["files"].values()) and arrays
+        assert (meta["rc"] == 0 or not case[3]) and meta["program"] == case[1] and meta["args"] == case[2]
+        assert all(v is not None for v in meta["files"].values()) and (arrays or not case[3])
