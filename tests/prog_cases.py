@@ -55,7 +55,9 @@ CASES = [
                                         "-o", "sm.nc"], ["sm.nc"]),
     ("cdfvertmean_default", "cdfvertmean", ["-f", "SYN_y0001_gridT.nc", "-l", "votemper,vosaline", "-p", "T", "-zlim", "15", "120"], ["vertmean.nc"]),
     ("cdfvertmean_reversed_limits", "cdfvertmean", ["-f", "SYN_y0001_gridT.nc", "-l", "votemper", "-p", "T", "-zlim", "100", "10", "-o", "vm2.nc"], []),     # (refused: STOP 99 and a message)
-    ("cdfmocsig_sigma2_isodep", "cdfmocsig", ["-v", "SYN_y0001_gridV.nc", "-t", "SYN_y0001_gridT.nc", "-r", "2000", "-isodep"], ["mocsig.nc"]),
+    # (cdfmocsig only with -ntr: the reference never initialises its lntr (src/cdfmocsig.f90:101) and this build of it takes the
+    #  neutral-density branch whatever the options say; with -ntr both sides mean the same)
+    ("cdfmocsig_ntr_isodep", "cdfmocsig", ["-v", "SYN_y0001_gridV.nc", "-t", "SYN_y0001_gridT.nc", "-ntr", "-isodep"], ["mocsig.nc"]),
     ("cdfmocsig_ntr", "cdfmocsig", ["-v", "SYN_y0001_gridV.nc", "-t", "SYN_y0001_gridT.nc", "-ntr", "-sigmin", "19", "-sigstp", "0.25", "-nbins", "60",
                        "-o", "ntr.nc"], ["ntr.nc"]),
     ("cdfmaxmoc_atl", "cdfmaxmoc", ["-f", "moc.nc", "-b", "atl", "-w", "-30", "60", "-5000", "-20"], ["maxmoc.nc"]),

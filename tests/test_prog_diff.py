@@ -33,7 +33,7 @@ EXPLAINED = [
     (r"cdfheatc_.*", "att", r".*:(heatc3d|heatc2d|heatc3dpervol):(_FillValue|valid_min|valid_max)$",
      "the reference never sets rmissing_value / valid_min / valid_max of these descriptors (src/cdfheatc.f90:271-292): it writes "
      "whatever the uninitialised TYPE(variable) holds; this build writes the defaults of its descriptor"),
-    (r"cdfpsi_.*", "data", r".*::depthu$",
+    (r"cdf(psi|vtrp)_.*", "data", r".*::depthu$",
      "putheadervar's search for a depth variable (src/cdfio.F90 putheadervar) leaves its loop at the FIRST name whether the file "
      "holds it or not (idep starts as NF90_NOERR and only getvar1d changes it): a U file has no deptht, so the reference writes "
      "the never-assigned z1d (0.0 in this build of it); this build writes the file's depthu"),
