@@ -32,7 +32,8 @@ def main():
     bad = 0
     skipped = {}
     with tempfile.TemporaryDirectory(prefix="cdft_prog_") as d:
-        nemo_files.make_case(d)
+        g_, rec_ = nemo_files.make_case(d)
+        pc.extra_files(d, g_, rec_)
         for case in pc.CASES:
             meta, arrays = pc.run_case(bindir, case, d)
             path = os.path.join(gold, f"prog_{case[0]}.npz")

@@ -34,6 +34,26 @@ CASES = [
     ("cdfvT_named_output", "cdfvT", ["-c", "SYN", "-l", "y0001", "-namT", "votemper", "-o", "vt_named.nc"], ["vt_named.nc"]),
     ("cdfmhst_default", "cdfmhst", ["-vt", "vt.nc"], ["mhst.nc", "zonal_heat_trp.dat", "zonal_salt_trp.dat"]),
     ("cdfmhst_MST_Zdim", "cdfmhst", ["-vt", "vt.nc", "-MST", "-Zdim", "-o", "mhst_z.nc"], ["mhst_z.nc", "zonal_heat_trp.dat", "zonal_salt_trp.dat"]),
+    # more options of the eight (round 4, second tier); extra_files() writes mxl.nc and SYN_y0001_grid2D.nc
+    ("cdfmoc_decomp", "cdfmoc", ["-v", "SYN_y0001_gridV.nc", "-t", "SYN_y0001_gridT.nc", "-decomp", "-o", "moc_dec.nc"], ["moc_dec.nc"]),
+    ("cdfmoc_teos10_decomp", "cdfmoc", ["-v", "SYN_y0001_gridV.nc", "-t", "SYN_y0001_gridT.nc", "-decomp", "-teos10", "-o", "moc_dect.nc"], ["moc_dect.nc"]),
+    ("cdfmoc_teos_as_the_usage_spells_it", "cdfmoc", ["-v", "SYN_y0001_gridV.nc", "-t", "SYN_y0001_gridT.nc", "-decomp", "-teos"], []),   # (the parser knows -teos10: STOP 99)
+    ("cdfheatc_mxl_in", "cdfheatc", ["-f", "SYN_y0001_gridT.nc", "-mxloption", "1", "-mxlf", "mxl.nc", "-o", "heatc_m.nc"], ["heatc_m.nc"]),
+    ("cdfheatc_mxl_out_M", "cdfheatc", ["-f", "SYN_y0001_gridT.nc", "-mxloption", "-1", "-mxlf", "mxl.nc", "-M", "mask.nc", "umask", "-o", "heatc_mo.nc"],
+     ["heatc_mo.nc"]),
+    ("cdfcurl_surf", "cdfcurl", ["-u", "SYN_y0001_gridU.nc", "vozocrtx", "-v", "SYN_y0001_gridV.nc", "vomecrty", "-l", "1", "-surf", "-o", "curl_s.nc"],
+     ["curl_s.nc"]),
+    ("cdfpsi_mean", "cdfpsi", UV + ["-mean", "-o", "psi_m.nc"], ["psi_m.nc"]),
+    ("cdfpsi_open_ref_mask", "cdfpsi", UV + ["-open", "-ref", "5", "4", "-mask", "-o", "psi_o.nc"], ["psi_o.nc"]),
+    ("cdfpsi_ssh", "cdfpsi", UV + ["--ssh-file", "SYN_y0001_grid2D.nc", "-o", "psi_s.nc"], ["psi_s.nc"]),
+    ("cdfpsi_lev", "cdfpsi", UV + ["-lev", "-o", "psi_l.nc"], ["psi_l.nc"]),
+    ("cdfpsi_full", "cdfpsi", UV + ["-full", "-o", "psi_f.nc"], ["psi_f.nc"]),
+    ("cdfmhst_VTS_files", "cdfmhst", ["-v", "SYN_y0001_gridV.nc", "-t", "SYN_y0001_gridT.nc", "-MST", "-o", "mhst_s.nc"],
+     ["mhst_s.nc", "zonal_heat_trp.dat", "zonal_salt_trp.dat"]),
+    ("cdfmhst_full", "cdfmhst", ["-vt", "vt.nc", "-full", "-o", "mhst_f.nc"], ["mhst_f.nc"]),
+    ("cdfsig0_named", "cdfsig0", ["-t", "SYN_y0001_gridT.nc", "-s", "SYN_y0001_gridT.nc", "-sal", "vosaline", "-tem", "votemper", "-o", "sig0_n.nc"],
+     ["sig0_n.nc"]),
+    ("cdfsigi_sfile_r_last", "cdfsigi", ["-t", "SYN_y0001_gridT.nc", "-s", "SYN_y0001_gridT.nc", "-o", "sigi_s.nc", "-r", "500"], ["sigi_s.nc"]),
     # the ten programs of SURVEY 8f
     ("cdfvhst_default", "cdfvhst", ["-f", "vt.nc", "-o", "vh.nc"], ["vh.nc"]),
     ("cdfvhst_full", "cdfvhst", ["-f", "vt.nc", "-full", "-o", "vhf.nc"], ["vhf.nc"]),
@@ -63,6 +83,17 @@ CASES = [
     ("cdfmaxmoc_atl", "cdfmaxmoc", ["-f", "moc.nc", "-b", "atl", "-w", "-30", "60", "-5000", "-20"], ["maxmoc.nc"]),
     ("cdfmaxmoc_glo_other_window", "cdfmaxmoc", ["-f", "moc.nc", "-b", "glo", "-w", "-60", "20", "-3000", "-100", "-o", "maxmoc2.nc"], ["maxmoc2.nc"]),
 ]
+
+
+def extra_files(d, g, rec):
+    """the files the second-tier cases need beside those of nemo_files.make_case: a mixed-layer depth and a sea-surface height"""
+    import nemo_files
+    mxl = (5 + 200 * np.abs(rec["t"][:, 0]) / 30).astype("float32")
+    nemo_files.write_data(os.path.join(d, "mxl.nc"), g, "deptht", {"somxl010": mxl})
+    rng = np.random.default_rng(77)
+    npk, npj, npi = g["tmask"].shape
+    ssh = (rng.standard_normal((rec["t"].shape[0], npj, npi)) * g["tmask"][0]).astype(np.float32)
+    nemo_files.write_data(os.path.join(d, "SYN_y0001_grid2D.nc"), g, "deptht", {"sossheig": ssh})
 
 
 def _att(v):

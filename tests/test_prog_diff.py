@@ -123,7 +123,8 @@ def diff_case(case, ref, ref_arr, got, got_arr):
 def test_programs_against_the_reference_programs(tmp_path):
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "cdftools_amd", "fortran")], stdout=subprocess.DEVNULL)
     d = str(tmp_path)
-    nemo_files.make_case(d)
+    g_, rec_ = nemo_files.make_case(d)
+    pc.extra_files(d, g_, rec_)
     report, unexplained = [], []
     out_of_it = pc.left_out()
     for case in pc.CASES:
