@@ -46,6 +46,7 @@ CASES = [
     ("cdfpsi_mean", "cdfpsi", UV + ["-mean", "-o", "psi_m.nc"], ["psi_m.nc"]),
     ("cdfpsi_open_ref_mask", "cdfpsi", UV + ["-open", "-ref", "5", "4", "-mask", "-o", "psi_o.nc"], ["psi_o.nc"]),
     ("cdfpsi_ssh", "cdfpsi", UV + ["--ssh-file", "SYN_y0001_grid2D.nc", "-o", "psi_s.nc"], ["psi_s.nc"]),
+    ("cdfpsi_ssh_mean", "cdfpsi", UV + ["-mean", "--ssh-file", "SYN_y0001_grid2D.nc", "-o", "psi_sm.nc"], ["psi_sm.nc"]),
     ("cdfpsi_lev", "cdfpsi", UV + ["-lev", "-o", "psi_l.nc"], ["psi_l.nc"]),
     ("cdfpsi_full", "cdfpsi", UV + ["-full", "-o", "psi_f.nc"], ["psi_f.nc"]),
     ("cdfmhst_VTS_files", "cdfmhst", ["-v", "SYN_y0001_gridV.nc", "-t", "SYN_y0001_gridT.nc", "-MST", "-o", "mhst_s.nc"],
