@@ -69,6 +69,14 @@ while time.time() < stop:
     torch.cuda.synchronize()
     got = out.cpu().numpy()
     desc = plan.describe()
+    # the same records staged into the plan's pool (a row's weights and records in one run): cdft_moc_compute_staged
+    got_pool = None
+    try:
+        plan.stage(zv if rng.random() < 0.5 else torch.from_numpy(zv).cuda())
+        got_pool = plan.compute_staged(np.zeros(got.shape))
+        desc_pool = plan.describe()
+    except CdftError:                                          # (the tuned shape may not cover a pool row either)
+        pass
     plan.close()
     with np.errstate(all="ignore"):
         ref = oracle_lib.moc(e1v, e3v, ib, zv)
@@ -83,6 +91,17 @@ while time.time() < stop:
         # with poisoned records the bound of a row that holds an overflow is not the clean one: compare the clean rows strictly
         err = np.abs(got[fin] - ref[fin])
         ok = bool(np.all(err <= (lim[fin] if not poisoned else np.maximum(lim[fin], 1e-13 * np.abs(ref[fin])))))
+    if ok and got_pool is not None:                            # the staged path: the same checks
+        ok = np.array_equal(np.isnan(got_pool), np.isnan(ref))
+        if ok:
+            inf = np.isinf(ref)
+            ok = np.array_equal(np.isinf(got_pool), inf) and np.array_equal(got_pool[inf], ref[inf])
+        if ok:
+            fin = np.isfinite(ref)
+            err = np.abs(got_pool[fin] - ref[fin])
+            ok = bool(np.all(err <= (lim[fin] if not poisoned else np.maximum(lim[fin], 1e-13 * np.abs(ref[fin])))))
+        if not ok:
+            desc = desc_pool + "  [staged records]"
     n += 1
     cells += n3 * npt
     if not ok:
