@@ -55,6 +55,23 @@ CASES = [
     ("cdfsig0_named", "cdfsig0", ["-t", "SYN_y0001_gridT.nc", "-s", "SYN_y0001_gridT.nc", "-sal", "vosaline", "-tem", "votemper", "-o", "sig0_n.nc"],
      ["sig0_n.nc"]),
     ("cdfsigi_sfile_r_last", "cdfsigi", ["-t", "SYN_y0001_gridT.nc", "-s", "SYN_y0001_gridT.nc", "-o", "sigi_s.nc", "-r", "500"], ["sigi_s.nc"]),
+    # third tier: -vvl (per-record vertical metrics read from the data files) and more options of the 8f programs
+    ("cdfmoc_vvl", "cdfmoc", ["-v", "VVL_y0001_gridV.nc", "-vvl", "-o", "moc_vvl.nc"], ["moc_vvl.nc"]),
+    ("cdfheatc_vvl", "cdfheatc", ["-f", "VVL_y0001_gridT.nc", "-vvl", "-o", "heatc_vvl.nc"], ["heatc_vvl.nc"]),
+    ("cdfmhst_vvl", "cdfmhst", ["-vt", "VVL_vt.nc", "-MST", "-vvl", "-o", "mhst_vvl.nc"], ["mhst_vvl.nc"]),
+    ("cdfpsi_vvl", "cdfpsi", ["-u", "VVL_y0001_gridU.nc", "-v", "VVL_y0001_gridV.nc", "-vvl", "-o", "psi_vvl.nc"], ["psi_vvl.nc"]),
+    ("cdfvhst_vvl", "cdfvhst", ["-f", "VVL_vt.nc", "-vvl", "-o", "vh_vvl.nc"], ["vh_vvl.nc"]),
+    ("cdfvtrp_vvl", "cdfvtrp", ["-u", "VVL_y0001_gridU.nc", "-v", "VVL_y0001_gridV.nc", "-vvl", "-o", "tr_vvl.nc"], ["tr_vvl.nc"]),
+    ("cdfvtrp_bathy", "cdfvtrp", UV + ["-bathy", "-o", "tr_b.nc"], ["tr_b.nc"]),
+    ("cdfsum_vvl", "cdfsum", ["-f", "VVL_y0001_gridT.nc", "-v", "votemper", "-p", "T", "-vvl", "-o", "sum_vvl.nc"], ["sum_vvl.nc"]),
+    ("cdfsum_nomsk", "cdfsum", ["-f", "SYN_y0001_gridT.nc", "-v", "vosaline", "-p", "T", "-nomsk", "-o", "n.nc"], ["n.nc"]),
+    ("cdfvint_vvl", "cdfvint", ["-f", "VVL_y0001_gridT.nc", "-vvl", "-o", "vint_vvl.nc"], ["vint_vvl.nc"]),
+    ("cdfvint_GSOP_tmean", "cdfvint", ["-f", "SYN_y0001_gridT.nc", "-GSOP", "-tmean", "-o", "vint_g.nc"], ["vint_g.nc"]),
+    ("cdfvertmean_vvl", "cdfvertmean", ["-f", "VVL_y0001_gridT.nc", "-l", "votemper", "-p", "T", "-zlim", "15", "120", "-vvl", "-o", "vm_vvl.nc"],
+     ["vm_vvl.nc"]),
+    ("cdfvertmean_full", "cdfvertmean", ["-f", "SYN_y0001_gridT.nc", "-l", "vosaline", "-p", "T", "-zlim", "0", "300", "-full", "-o", "vm_f.nc"], ["vm_f.nc"]),
+    ("cdfmocsig_ntr_vvl", "cdfmocsig", ["-v", "VVL_y0001_gridV.nc", "-t", "VVL_y0001_gridT.nc", "-ntr", "-vvl", "-o", "ms_vvl.nc"], ["ms_vvl.nc"]),
+    ("cdfmocsig_ntr_full", "cdfmocsig", ["-v", "SYN_y0001_gridV.nc", "-t", "SYN_y0001_gridT.nc", "-ntr", "-full", "-o", "ms_f.nc"], ["ms_f.nc"]),
     # the ten programs of SURVEY 8f
     ("cdfvhst_default", "cdfvhst", ["-f", "vt.nc", "-o", "vh.nc"], ["vh.nc"]),
     ("cdfvhst_full", "cdfvhst", ["-f", "vt.nc", "-full", "-o", "vhf.nc"], ["vhf.nc"]),
@@ -95,6 +112,17 @@ def extra_files(d, g, rec):
     npk, npj, npi = g["tmask"].shape
     ssh = (rng.standard_normal((rec["t"].shape[0], npj, npi)) * g["tmask"][0]).astype(np.float32)
     nemo_files.write_data(os.path.join(d, "SYN_y0001_grid2D.nc"), g, "deptht", {"sossheig": ssh})
+    # third tier: files whose vertical metric differs from record to record (-vvl), as tests/test_cli_vvl.py writes them
+    import lift_cases as lc
+    f32 = np.float32
+    e3 = {p: lc.e3_records(g[f"e3{p}_0"], rec["t"].shape[0], 8000 + i) for i, p in enumerate("tuv")}
+    nemo_files.write_data(os.path.join(d, "VVL_y0001_gridV.nc"), g, "depthv", {"vomecrty": rec["v"], "e3v": e3["v"]})
+    nemo_files.write_data(os.path.join(d, "VVL_y0001_gridU.nc"), g, "depthu", {"vozocrtx": rec["u"], "e3u": e3["u"]})
+    nemo_files.write_data(os.path.join(d, "VVL_y0001_gridT.nc"), g, "deptht", {"votemper": rec["t"], "vosaline": rec["s"], "e3t": e3["t"]},
+                          fill=0.0)
+    vt = {"vomevt": (rec["t"] * rec["v"]).astype(f32), "vomevs": (rec["s"] * rec["v"]).astype(f32),
+          "vozout": (rec["t"] * rec["u"]).astype(f32), "vozous": (rec["s"] * rec["u"]).astype(f32)}
+    nemo_files.write_data(os.path.join(d, "VVL_vt.nc"), g, "deptht", dict(vt, e3u=e3["u"], e3v=e3["v"]))
 
 
 def _att(v):
