@@ -124,7 +124,12 @@ def diff_case(case, ref, ref_arr, got, got_arr):
             if prog == "cdfvtrp" and v["name"] in ("soastrp", "socstrp"):
                 # -bathy rotates the transports by the bottom slope's angle through the runtime's r4 ATAN2 / COS / SIN, which are not
                 # correctly rounded: the tolerance of tests/test_vtrp_bathy.py, 3 * 2^-23 * (|utrp| + |vtrp|) (+ the stored value's ulp)
-                lim = 3 * 2.0 ** -23 * (np.abs(ref_arr[f"{fname}::sozoutrp"].astype(np.float64)) + np.abs(ref_arr[f"{fname}::somevtrp"].astype(np.float64)))
+                du = np.abs(ref_arr[f"{fname}::sozoutrp"].astype(np.float64))        # (t,y,x): the transports at U and V points ...
+                dv = np.abs(ref_arr[f"{fname}::somevtrp"].astype(np.float64))
+                wu, wv = np.zeros_like(du), np.zeros_like(dv)                        # ... brought to the T point as :215-221 does
+                wu[..., 1:] = 0.5 * (du[..., 1:] + du[..., :-1]); wu[..., 0] = wu[..., -2]
+                wv[..., 1:, :] = 0.5 * (dv[..., 1:, :] + dv[..., :-1, :])
+                lim = 3 * 2.0 ** -23 * (wu + wv)
                 if np.all(np.abs(a.astype(np.float64) - b.astype(np.float64)) <= lim + ulp4(a)):
                     continue
             if prog == "cdfmoc" and "-decomp" in case[2] and a.dtype == np.float32:
