@@ -191,13 +191,14 @@ int launch_vint(const VintArgs &a_in, hipStream_t st) {
         if (MODE == kMhstVt && blocks_with(6) >= 1024) vpt = 6;
     }
     if (vpt == 8 && !(MODE == kPsi && vec == 4)) vpt = 4;
-    if (vpt == 6 && !(MODE == kMhstVt && vec == 4)) vpt = 4;
+    if (vpt == 6 && !((MODE == kMhstVt || MODE == kPsi) && vec == 4)) vpt = 4;
     const int64_t nvecs = (a.nij + vec - 1) / vec, nthr = (nvecs + vpt - 1) / vpt;
     a.band = xcd_bands_on();
     const dim3 grid(xcd_band_grid((nthr + kThreads - 1) / kThreads, a.band)), block(kThreads);
 #define CDFT_GO(V, F) do { if (vpt == 1) hipLaunchKernelGGL((vint_kernel<V, MODE, F, 1>), grid, block, 0, st, a); \
                            else if (vpt == 8 && MODE == kPsi && V == 4) hipLaunchKernelGGL((vint_kernel<4, kPsi, F, 8>), grid, block, 0, st, a); \
                            else if (vpt == 6 && MODE == kMhstVt && V == 4) hipLaunchKernelGGL((vint_kernel<4, kMhstVt, F, 6>), grid, block, 0, st, a); \
+                           else if (vpt == 6 && MODE == kPsi && V == 4) hipLaunchKernelGGL((vint_kernel<4, kPsi, F, 6>), grid, block, 0, st, a); \
                            else if (vpt == 2) hipLaunchKernelGGL((vint_kernel<V, MODE, F, 2>), grid, block, 0, st, a); \
                            else hipLaunchKernelGGL((vint_kernel<V, MODE, F, 4>), grid, block, 0, st, a); } while (0)
     if (vec == 4) { if (full) CDFT_GO(4, true); else CDFT_GO(4, false); }
