@@ -135,6 +135,9 @@ MODULE cdftools_hip
      INTEGER(C_INT) FUNCTION cdft_moc_compute_staged(plan, dmoc, dmoc_space, stream) BIND(C, name='cdft_moc_compute_staged')
        IMPORT ; TYPE(C_PTR), VALUE :: plan, stream ; INTEGER(C_INT), VALUE :: dmoc_space ; REAL(C_DOUBLE), INTENT(out) :: dmoc(*)
      END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_moc_reserve(plan, npt, stream) BIND(C, name='cdft_moc_reserve')
+       IMPORT ; TYPE(C_PTR), VALUE :: plan, stream ; INTEGER(C_INT), VALUE :: npt
+     END FUNCTION
      INTEGER(C_INT) FUNCTION cdft_moc_stage_rows(plan, zv, rec_stride, lev_stride, npt, zv_space, stream) &
           &         BIND(C, name='cdft_moc_stage_rows')
        IMPORT ; TYPE(C_PTR), VALUE :: plan, stream ; REAL(C_FLOAT), INTENT(in) :: zv(*)

@@ -320,8 +320,11 @@ def main():
                        "T 4 + S 4 + out 4 B per point; the surface form evaluates one of the four polynomials, sigma2 all four (the r8 work "
                        "of cdfmocsig); a wave whose 256 points are all T = S = 0 stores sigma(0,0) and skips them",
                        fp64=fp64_ops(case + "_" + land, args.grid, kern if pref != 0.0 else None))
+    if "eosmore" in tools:
+        # the other members of the eos module (eos_more.hip: outside SURVEY 8, not in the default set since round 4); r8 results:
+        # T 4 + S 4 + out 8 B per point
         t, s = eos_fields(npi, npj, npk, dev, "none")
-        # the other members of the eos module (eos_more.hip); r8 results: T 4 + S 4 + out 8 B per point
+        o4 = torch.empty(n3, dtype=torch.float32, device=dev)
         o8 = torch.empty(n3, dtype=torch.float64, device=dev)
         for name, fn in (("alpha (2000 m)", lambda: hip.alpha(t, s, 2000.0, out=o8)), ("beta (2000 m)", lambda: hip.beta(t, s, 2000.0, out=o8)),
                          ("albet, McDougall 1987", lambda: hip.albet(t, s, 2000.0, out=o8)), ("spice, GSW fit", lambda: hip.spice(t, s, out=o8)),
