@@ -372,6 +372,10 @@ __global__ void __launch_bounds__(64) heatc_seq_kernel(HeatcArgs a, const float 
 // heatc_seq_kernel (tests/test_heatc.py compares the two on adversarial fields and at size).
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kScanWaves = 4, kScanNV = 2, kScanChunk = kScanNV * 256, kScanSub = kScanWaves * kScanChunk;
+#ifndef CDFT_SCAN_AHEAD
+#define CDFT_SCAN_AHEAD 3
+#endif
+constexpr int kScanAhead = CDFT_SCAN_AHEAD;                       // sub-blocks of loads in flight ahead of the one being summed: 2 or 3
 constexpr int kScanMaxChunks = 256;                               // chunks per ticket: 64, 128 or 256 (32768 .. 131072 cells)
 
 // the sum over the 64 lanes, in every lane: six DPP adds in the vector pipeline (quad swaps, half-row and row mirrors give
@@ -738,24 +742,33 @@ __global__ void __launch_bounds__(64 * kScanWaves, 3) heatc_scan_kernel(HeatcArg
         {   // Every chunk of the ticket; the loads run TWO sub-blocks ahead (two register sets, the loop unrolled by two so that
             // neither is ever copied): counters showed the waves waiting for memory 61 % of their time with one sub-block ahead
             // -- a chunk's vector work (~2 us with three waves on the SIMD) is about the latency of its loads under load.
-            Raw rawA[kScanNV], rawB[kScanNV];
+            // Round 4: THREE sub-blocks ahead (AHEAD register sets, the loop unrolled by as many): the skeleton alone -- loads and
+            // products, no sums -- ran at the pace of a wave's load round trips, not of HBM.
+            constexpr int AHEAD = (MASK8 && !MXL) ? kScanAhead : 2;       // (the r4-mask and mixed-layer forms would spill with three sets)
+            Raw rawA[kScanNV], rawB[kScanNV], rawC[kScanNV];
             f2v x[3][kScanNV][2];
-            auto chunk = [&](Raw (&raw)[kScanNV], int q) {        // sums chunk q from `raw`, then asks for chunk q + 2 * kScanWaves into it
+            auto chunk = [&](Raw (&raw)[kScanNV], int q) {        // sums chunk q from `raw`, then asks for chunk q + AHEAD * kScanWaves into it
+                if (q >= nchunk) return;                          // (AHEAD = 3 does not divide the chunks of a wave)
                 const int64_t c0 = t0 + (int64_t)q * kScanChunk;
                 if (c0 >= nijv) {                                 // past the end of the level: nothing there
                     if (lane == 63) for (int ch = 0; ch < 3; ++ch) sm_flag[0][q][ch] = sm_flag[1][q][ch] = 0;
                     return;
                 }
                 products(raw, c0, x);
-                if (q + 2 * kScanWaves < nchunk && c0 + 2 * kScanSub < nijv) fetch(raw, c0 + 2 * kScanSub);
+                if (q + AHEAD * kScanWaves < nchunk && c0 + (int64_t)AHEAD * kScanSub < nijv) fetch(raw, c0 + (int64_t)AHEAD * kScanSub);
                 if (!(dbg & 2)) summarize(x, q);      // (dbg: timing experiments of tools/, results then meaningless)
             };
-            fetch(rawA, t0 + (int64_t)w * kScanChunk);
-            if (w + kScanWaves < nchunk && t0 + (int64_t)(w + kScanWaves) * kScanChunk < nijv) fetch(rawB, t0 + (int64_t)(w + kScanWaves) * kScanChunk);
+            auto first = [&](Raw (&raw)[kScanNV], int q) {
+                if (q < nchunk && t0 + (int64_t)q * kScanChunk < nijv) fetch(raw, t0 + (int64_t)q * kScanChunk);
+            };
+            first(rawA, w);
+            first(rawB, w + kScanWaves);
+            if (AHEAD == 3) first(rawC, w + 2 * kScanWaves);
 #pragma clang loop unroll(disable)
-            for (int q = w; q < nchunk; q += 2 * kScanWaves) {    // (nchunk is a multiple of 2 * kScanWaves: 64, 128 or 256)
+            for (int q = w; q < nchunk; q += AHEAD * kScanWaves) {
                 chunk(rawA, q);
                 chunk(rawB, q + kScanWaves);
+                if (AHEAD == 3) chunk(rawC, q + 2 * kScanWaves);
             }
         }
         __syncthreads();                                          // the sums of every chunk are in LDS
