@@ -35,7 +35,7 @@ struct cdft_mean_plan {
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kVPT     = 2;     // vectors per lane (4: slower at both grids, measured)
+constexpr int kVPT     = 2;     // vectors per lane of the scalar path; the 16-byte path takes 4.  The plan's partial sums are sized for 2
 constexpr int kMaxNB   = 8;
 
 struct MeanArgs {
@@ -58,106 +58,144 @@ __global__ void mean_mask8_kernel(const float *__restrict__ m, int64_t n, uint8_
     else { m8[p] = 0; if (!(v == 0.f) || signbit(v)) flag[0] = 1; }
 }
 
+// Two cells per vector instruction where the cells come four at a time (v_pk_mul_f32: each half the plain IEEE r4 product):
+// Lanes<4> works on pairs, Lanes<1> on single cells; the r8 sums take the cells in the same order either way.
+typedef float f2v __attribute__((ext_vector_type(2)));
+template <int VEC> struct Lanes;
+template <> struct Lanes<4> {
+    typedef f2v T; static constexpr int G = 2, W = 2;
+    static __device__ __forceinline__ T mk(float a, float b) { return T{a, b}; }
+    static __device__ __forceinline__ void add(double &s, T t) { s += (double)t.x; s += (double)t.y; }
+};
+template <> struct Lanes<1> {
+    typedef float T; static constexpr int G = 1, W = 1;
+    static __device__ __forceinline__ T mk(float a, float) { return a; }
+    static __device__ __forceinline__ void add(double &s, T t) { s += (double)t; }
+};
+
 // PARK: the wave sums of every level stay in LDS [wave][level][nb*4] and the four waves are combined once, after the
 // last level -- no workgroup barrier inside the level loop (the layout of cdfheatc's level kernel).  Without it (when
 // npk * nb * 4 sums per wave do not fit): two barriers per level.
-template <int VEC, bool FULL, int NB, bool PARK>
+// The form of the sums (cdfmean with / without the variance, cdfsum's two) picks one of four straight-line copies of the
+// cell loop by a uniform branch per level: no select and no scalar branch per cell.
+template <int VEC, bool FULL, int NB, bool PARK, int VPT, bool MASK8>
 __global__ void __launch_bounds__(kThreads) mean_level_kernel(MeanArgs a) {
     extern __shared__ double wsum[];                   // PARK: [nwaves][npk][nb*4], else [nwaves][nb*4]
+    typedef Lanes<VEC> LN;
+    typedef typename LN::T T;
+    constexpr int G = LN::G, W = LN::W;                // groups per vector, cells per group
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = kThreads / 64;
     const int64_t blk = xcd_band(a.band);              // (common.hpp)
-    int64_t q[kVPT];
-    float e1[kVPT][VEC], e2[kVPT][VEC], fb[kVPT][VEC][NB];
-    bool ok[kVPT][VEC];
+    int64_t q[VPT];
+    T e1[VPT][G], e2[VPT][G], ar[VPT][G], fb[VPT][G][NB];
+    bool ok[VPT][VEC];
+    bool edge = false;                                 // a lane of this wave holds a cell that is not its own
     // VEC = 4: vectors at cells 0, 4, 8, ... and, when the plane is not a multiple of 4 cells, one more anchored at
     // nij-4 whose leading cells belong to the previous vector and count as zeros here: no partial vector, no branch
     const int64_t nfull = a.nij / VEC, nvtot = nfull + ((VEC == 4 && (a.nij & 3)) ? 1 : 0);
 #pragma unroll
-    for (int v = 0; v < kVPT; ++v) {
-        const int64_t iv = ((blk * nwaves + wave) * kVPT + v) * 64 + lane;                     // vector index
+    for (int v = 0; v < VPT; ++v) {
+        const int64_t iv = ((blk * nwaves + wave) * VPT + v) * 64 + lane;                     // vector index
         q[v] = iv < nvtot ? (VEC == 4 ? min(iv * 4, a.nij - 4) : iv * VEC) : 0;                  // its first cell
+        float x1[VEC], x2[VEC], xf[VEC][NB];
 #pragma unroll
         for (int c = 0; c < VEC; ++c) {
             const int64_t p = q[v] + c;
             ok[v][c] = iv < nvtot && (iv < nfull || p >= nfull * VEC);
+            edge = edge || !ok[v][c];
             const int64_t pc = ok[v][c] ? p : 0;
-            e1[v][c] = ok[v][c] ? a.e1[pc] : 0.f;      // cells past the plane contribute exact zeros
-            e2[v][c] = a.e2[pc];
+            x1[c] = ok[v][c] ? a.e1[pc] : 0.f;         // cells past the plane contribute exact zeros
+            x2[c] = a.e2[pc];
 #pragma unroll
-            for (int b = 0; b < NB; ++b) fb[v][c][b] = (b < a.nb) ? (float)a.ib[pc * a.nb + min(b, a.nb - 1)] : 0.f;
+            for (int b = 0; b < NB; ++b) xf[c][b] = (b < a.nb) ? (float)a.ib[pc * a.nb + min(b, a.nb - 1)] : 0.f;
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            e1[v][g] = LN::mk(x1[W * g], x1[W * g + W - 1]);
+            e2[v][g] = LN::mk(x2[W * g], x2[W * g + W - 1]);
+            ar[v][g] = e1[v][g] * e2[v][g];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) fb[v][g][b] = LN::mk(xf[W * g][b], xf[W * g + W - 1][b]);
         }
     }
-    const int sumform = a.form == CDFT_MEAN_FORM_MEAN_NOVAR ? CDFT_MEAN_FORM_MEAN : a.form;
+    edge = __any(edge);                                // (wave-uniform)
     for (int k = 0; k < a.npk; ++k) {
         const int64_t base = (int64_t)k * a.nij;
-        float zv[kVPT][VEC], e3[kVPT][VEC], mk[kVPT][VEC];
+        T zv[VPT][G], e3[VPT][G], mk[VPT][G];
 #pragma unroll
-        for (int v = 0; v < kVPT; ++v) {
+        for (int v = 0; v < VPT; ++v) {
             if constexpr (VEC == 4) {                  // 16-byte loads at r4 alignment, always inside the level
                 const f4u z = ld_stream4u(a.zv + base + q[v]);
-                zv[v][0] = z.x; zv[v][1] = z.y; zv[v][2] = z.z; zv[v][3] = z.w;
-                if (a.mask8) {                         // 4 mask bytes (an unaligned dword): the same 0.f / 1.f
+                zv[v][0] = T{z.x, z.y}; zv[v][1] = T{z.z, z.w};
+                if (MASK8) {                           // 4 mask bytes (an unaligned dword): the same 0.f / 1.f.  (A template
+                                                       // parameter: as a run-time branch every mask load was followed by a wait for
+                                                       // all loads issued so far -- one round trip per vector instead of per level)
                     typedef uint32_t u32u __attribute__((aligned(1)));
                     const uint32_t m = __builtin_nontemporal_load(reinterpret_cast<const u32u *>(a.mask8 + base + q[v]));
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) mk[v][c] = (float)((m >> (8 * c)) & 0xffu);
+                    mk[v][0] = T{(float)(m & 0xffu), (float)((m >> 8) & 0xffu)};
+                    mk[v][1] = T{(float)((m >> 16) & 0xffu), (float)(m >> 24)};
                 } else {
                     const f4u m = ld_stream4u(a.mask + base + q[v]);
-                    mk[v][0] = m.x; mk[v][1] = m.y; mk[v][2] = m.z; mk[v][3] = m.w;
+                    mk[v][0] = T{m.x, m.y}; mk[v][1] = T{m.z, m.w};
                 }
                 if (!FULL) {
                     const f4u e = ld_stream4u(a.e3 + base + q[v]);
-                    e3[v][0] = e.x; e3[v][1] = e.y; e3[v][2] = e.z; e3[v][3] = e.w;
+                    e3[v][0] = T{e.x, e.y}; e3[v][1] = T{e.z, e.w};
                 }
-#pragma unroll
-                for (int c = 0; c < 4; ++c) if (!ok[v][c]) zv[v][c] = 0.f;      // not this lane's cell: an exact zero
+                if (edge) {                            // not this lane's cell: an exact zero
+                    if (!ok[v][0]) zv[v][0].x = 0.f;
+                    if (!ok[v][1]) zv[v][0].y = 0.f;
+                    if (!ok[v][2]) zv[v][1].x = 0.f;
+                    if (!ok[v][3]) zv[v][1].y = 0.f;
+                }
             } else {
-#pragma unroll
-                for (int c = 0; c < VEC; ++c) {
-                    const int64_t pc = ok[v][c] ? q[v] + c : 0;
-                    zv[v][c] = ok[v][c] ? a.zv[base + pc] : 0.f;
-                    mk[v][c] = a.mask[base + pc];
-                    if (!FULL) e3[v][c] = a.e3[base + pc];
-                }
+                const int64_t pc = ok[v][0] ? q[v] : 0;
+                zv[v][0] = LN::mk(ok[v][0] ? a.zv[base + pc] : 0.f, 0.f);
+                mk[v][0] = LN::mk(a.mask[base + pc], 0.f);
+                if (!FULL) e3[v][0] = LN::mk(a.e3[base + pc], 0.f);
             }
             if (FULL) {
                 const float z = a.e31d[k];
 #pragma unroll
-                for (int c = 0; c < VEC; ++c) e3[v][c] = z;
+                for (int g = 0; g < G; ++g) e3[v][g] = LN::mk(z, z);
             }
         }
         double s[NB][4];
 #pragma unroll
         for (int b = 0; b < NB; ++b) { s[b][0] = s[b][1] = s[b][2] = s[b][3] = 0.0; }
-        // the variance sum only where it is asked for (cdfmean -var): a uniform branch around two copies of the cell loop,
-        // not a select per cell -- 4 products, a conversion, an r8 add and a wave sum less per cell otherwise
-        auto cells = [&](auto want_var) {
+        auto cells = [&](auto sumform, auto want_var) {
+            constexpr int SF = decltype(sumform)::value;
+            constexpr bool VAR = decltype(want_var)::value;
 #pragma unroll
-            for (int v = 0; v < kVPT; ++v)
+            for (int v = 0; v < VPT; ++v)
 #pragma unroll
-                for (int c = 0; c < VEC; ++c) {
-                    const float m = mk[v][c];
-                    const float zm = __fmul_rn(zv[v][c], m);                                  // :410
-                    const float ar = __fmul_rn(e1[v][c], e2[v][c]);
-                    const float t_surf = __fmul_rn(ar, m);                                     // e1*e2*zmask
-                    const float t_vol  = __fmul_rn(__fmul_rn(ar, e3[v][c]), m);                // e1*e2*e3*zmask
-                    const float zee = __fmul_rn(__fmul_rn(zm, e1[v][c]), e2[v][c]);            // zv*e1*e2
+                for (int g = 0; g < G; ++g) {
+                    const T m = mk[v][g];
+                    const T zm = zv[v][g] * m;                                                 // :410
+                    const T t_surf = ar[v][g] * m;                                             // e1*e2*zmask
+                    const T t_vol  = (ar[v][g] * e3[v][g]) * m;                                // e1*e2*e3*zmask
+                    const T zee = (zm * e1[v][g]) * e2[v][g];                                  // zv*e1*e2
                     // cdfmean: zv*e1*e2*e3 (:421); cdfsum: zv*e1*e2 (src/cdfsum.f90:309), forcing field: zv*e1*e2*zmask (:320)
-                    const float t_sum  = sumform == 0 ? __fmul_rn(zee, e3[v][c]) : (sumform == 1 ? zee : __fmul_rn(zee, m));
-                    float t_var = 0.f;
-                    if (decltype(want_var)::value) t_var = __fmul_rn(__fmul_rn(__fmul_rn(__fmul_rn(zm, zm), e1[v][c]), e2[v][c]), e3[v][c]);
+                    const T t_sum  = SF == 0 ? zee * e3[v][g] : (SF == 1 ? zee : zee * m);
+                    T t_var = t_sum;
+                    if (VAR) t_var = (((zm * zm) * e1[v][g]) * e2[v][g]) * e3[v][g];
 #pragma unroll
                     for (int b = 0; b < NB; ++b) {             // basins past nb have f = 0: they add exact zeros
-                        const float f = fb[v][c][b];
-                        s[b][0] += (double)__fmul_rn(t_surf, f);
-                        s[b][1] += (double)__fmul_rn(t_vol, f);
-                        s[b][2] += (double)__fmul_rn(t_sum, f);
-                        if (decltype(want_var)::value) s[b][3] += (double)__fmul_rn(t_var, f);
+                        const T f = fb[v][g][b];
+                        LN::add(s[b][0], t_surf * f);
+                        LN::add(s[b][1], t_vol * f);
+                        LN::add(s[b][2], t_sum * f);
+                        if (VAR) LN::add(s[b][3], t_var * f);
                     }
                 }
         };
-        if (a.form == CDFT_MEAN_FORM_MEAN) cells(std::true_type{});
-        else                               cells(std::false_type{});
+        typedef std::integral_constant<int, 0> F0;
+        typedef std::integral_constant<int, 1> F1;
+        typedef std::integral_constant<int, 2> F2;
+        if (a.form == CDFT_MEAN_FORM_MEAN)            cells(F0{}, std::true_type{});
+        else if (a.form == CDFT_MEAN_FORM_MEAN_NOVAR) cells(F0{}, std::false_type{});
+        else if (a.form == 1)                         cells(F1{}, std::false_type{});
+        else                                          cells(F2{}, std::false_type{});
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
@@ -308,24 +346,33 @@ int cdft_mean_compute(cdft_mean_plan *p, const float *zv, int in_space, double *
     }
     const bool vec4 = nij >= 4 && !getenv("CDFT_MEAN_SCALAR");         // (A/B hook: the scalar path)
     const int vec = vec4 ? 4 : 1;
-    a.nblk = (int)(((nij + vec - 1) / vec + kThreads * kVPT - 1) / (kThreads * kVPT));
+    // vectors per lane: 4 (190 against 210 us at eORCA025, 1.72 against 1.73 ms at eORCA12); CDFT_MEAN_VPT = 2 | 4: A/B hook
+    int vpt = vec4 ? 4 : kVPT;
+    { const char *e = getenv("CDFT_MEAN_VPT"); if (e && atoi(e) == 2) vpt = 2; }
+    a.nblk = (int)(((nij + vec - 1) / vec + kThreads * vpt - 1) / (kThreads * vpt));
     a.band = xcd_bands_on();
     const dim3 grid(xcd_band_grid(a.nblk, a.band)), block(kThreads);
     const size_t park_bytes = (size_t)(kThreads / 64) * p->npk * nq * sizeof(double);
     const bool park = park_bytes <= 48 * 1024 && !getenv("CDFT_MEAN_NOPARK");     // (A/B hook: a barrier pair per level)
     const size_t shmem = park ? park_bytes : (size_t)(kThreads / 64) * nq * sizeof(double);
     const bool full = p->e31d != nullptr;
+#define CDFT_MEAN3(NBC, PK, M8) do { \
+        if (vec4 && full && vpt == 4) hipLaunchKernelGGL((mean_level_kernel<4, true, NBC, PK, 4, M8>), grid, block, shmem, st, a); \
+        else if (vec4 && vpt == 4)    hipLaunchKernelGGL((mean_level_kernel<4, false, NBC, PK, 4, M8>), grid, block, shmem, st, a); \
+        else if (vec4 && full)  hipLaunchKernelGGL((mean_level_kernel<4, true, NBC, PK, kVPT, M8>), grid, block, shmem, st, a); \
+        else                    hipLaunchKernelGGL((mean_level_kernel<4, false, NBC, PK, kVPT, M8>), grid, block, shmem, st, a); } while (0)
 #define CDFT_MEAN2(NBC, PK) do { \
-        if (vec4 && full)       hipLaunchKernelGGL((mean_level_kernel<4, true, NBC, PK>), grid, block, shmem, st, a); \
-        else if (vec4)          hipLaunchKernelGGL((mean_level_kernel<4, false, NBC, PK>), grid, block, shmem, st, a); \
-        else if (full)          hipLaunchKernelGGL((mean_level_kernel<1, true, NBC, PK>), grid, block, shmem, st, a); \
-        else                    hipLaunchKernelGGL((mean_level_kernel<1, false, NBC, PK>), grid, block, shmem, st, a); } while (0)
+        if (vec4 && a.mask8)    CDFT_MEAN3(NBC, PK, true); \
+        else if (vec4)          CDFT_MEAN3(NBC, PK, false); \
+        else if (full)          hipLaunchKernelGGL((mean_level_kernel<1, true, NBC, PK, kVPT, false>), grid, block, shmem, st, a); \
+        else                    hipLaunchKernelGGL((mean_level_kernel<1, false, NBC, PK, kVPT, false>), grid, block, shmem, st, a); } while (0)
 #define CDFT_MEAN(NBC) do { if (park) CDFT_MEAN2(NBC, true); else CDFT_MEAN2(NBC, false); } while (0)
     if (p->nb == 1)      CDFT_MEAN(1);
     else if (p->nb == 2) CDFT_MEAN(2);
     else if (p->nb <= 4) CDFT_MEAN(4);
     else                 CDFT_MEAN(8);
 #undef CDFT_MEAN2
+#undef CDFT_MEAN3
 #undef CDFT_MEAN
     CDFT_LAUNCH_CHECK();
     hipLaunchKernelGGL(mean_final_kernel, dim3(p->npk), dim3(kThreads), 0, st, p->partial, a.nblk, nq, dout);
