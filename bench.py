@@ -57,6 +57,7 @@ WORKLOADS = {
     # one rank's row block of the eORCA12 metric run at N = 2 / 4 / 8, as a single-GPU workload: what a rank's kernel costs
     # (the expected SCALE line of DESIGN 6 is built from these)
     "eorca12_half": (4322, 1803, 75, 12, 5), "eorca12_quarter": (4322, 902, 75, 12, 5), "eorca12_eighth": (4322, 451, 75, 12, 5),
+    "eorca12_1basin": (4322, 3606, 75, 12, 1),      # cdfmoc without a sub-basin file: the global basin alone
     "eorca36_eighth": (12960, 1356, 75, 12, 5),     # one GPU's row block of config 5 (12960 x 10842 x 75 over 8 GPUs)
     "eorca36": (12960, 10842, 75, 2, 5),            # the whole config-5 grid on ONE GPU: 2 records (84 GB) + 42 GB of weights
 }

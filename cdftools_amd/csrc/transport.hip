@@ -400,6 +400,137 @@ psi_scan_j_wg_kernel(const double *__restrict__ dtrp, double *__restrict__ dpsi,
     }
 }
 
+// The scan that runs since round 4: the chain wave waits for nothing but its terms.  Wave 0 (32 lanes, one per column) only
+// walks the chain, in place, through a ring of four LDS slots (112 rows x 32 columns each); waves 1..7 only load (pass q
+// travels in register set q % 6, requested six passes before it is written to its slot; every load is unconditional, at a
+// clamped address, so that the waits count loads instead of waiting for all); waves 8..15 only store.  No workgroup barrier
+// after the first: three sets of LDS counters say which pass has been written, walked and stored, and a wave sleeps on the
+// one it needs.  Measured (profiles/r04/psi_scan_*.txt): 25.2 us at eORCA025 (27.6 with the round-3 kernel), 78.6 at eORCA12
+// (84).  Where it goes at eORCA025: 4.7 us launching 46 workgroups of 1024 threads and 114 KB, 9.7 us the chain itself
+// (7.9 ns per row: tools/chain_probe.hip has 2.4 ns for the additions alone and 3.7 when a whole pass is held in registers,
+// which 1024-thread workgroups have no room for), 3.7 us the counters, 7 us the first loads and the last stores.  What was
+// tried on the way: one barrier per pass (every interval costs the slowest of the three roles: 26 us); loading and storing in
+// the same waves (with both in flight every wait is for everything: one counter, no order between the two kinds); the chain
+// wave storing its own results, a 256-byte store per row (a wave has 64 memory operations in flight at most: 35 ns per row).
+constexpr int kRingCW = 32, kRingSub = 64 / kRingCW, kRingFeed = 7, kRingDrain = 8, kRingRW = 8, kRingDW = 7;   // 7 x 8 = 8 x 7 rows per half wave
+constexpr int kRingRows = kRingFeed * kRingRW * kRingSub, kRingSlots = 4, kRingAhead = 6, kRingCnt = 8;
+static_assert(kRingRows == kRingDrain * kRingDW * kRingSub && kRingRows % 8 == 0, "loaders and storers cover the same rows");
+
+// (workgroup-scope acquire / release on LDS: the wave's own LDS operations are complete before the count moves, and the
+// count is read before the data it guards)
+__device__ __forceinline__ void ring_wait(int *ctr, int need) {
+    while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
+}
+__device__ __forceinline__ void ring_bump(int *ctr) { (void)__hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+__global__ void __launch_bounds__((1 + kRingFeed + kRingDrain) * 64)
+psi_scan_j_ring_kernel(const double *__restrict__ dtrp, double *__restrict__ dpsi, int npi, int npj,
+                       const double *__restrict__ carry, int first_block) {
+    extern __shared__ double ring[];                              // [kRingSlots][kRingRows][kRingCW], then the counters
+    // filled[q % 8]: loader waves that have written pass q (and the passes q-8, q-16, ... before it); walked: passes the chain
+    // has left; stored[q % 8]: storer waves that have stored pass q (...)
+    int *filled = reinterpret_cast<int *>(ring + (size_t)kRingSlots * kRingRows * kRingCW);
+    int *stored = filled + kRingCnt, *walked = stored + kRingCnt;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane % kRingCW, sub = lane / kRingCW;
+    const int i = blockIdx.x * kRingCW + c;
+    const bool col = i < npi;
+    const int ic = min(i, npi - 1);
+    const int npass = (npj + kRingRows - 1) / kRingRows;
+    if (threadIdx.x < 2 * kRingCnt + 1) filled[threadIdx.x] = 0;
+    __syncthreads();                                              // (the only one)
+    auto slot = [&](int p) { return ring + (size_t)(p % kRingSlots) * kRingRows * kRingCW; };
+    if (wave == 0) {
+        // ---- the chain ----
+        __builtin_amdgcn_s_setprio(3);                            // (it shares its SIMD with three of the other waves)
+        double acc = (carry && col && lane < kRingCW) ? carry[i] : 0.0;
+        for (int p = 0; p < npass; ++p) {
+            ring_wait(filled + p % kRingCnt, (p / kRingCnt + 1) * kRingFeed);       // pass p is in its slot
+            if (lane < kRingCW) {
+                double *rows = slot(p);
+                // Batches of 14 rows (7 + 7 two-row LDS operations behind the reads a batch waits for: the counter holds 15): the
+                // terms of a batch arrive in registers a batch ahead, its 14 additions run back to back
+                // (2.4 ns each, tools/chain_probe.hip), then its 14 results go to LDS in one run.  With every pair of additions
+                // followed by its own ds_write -- the compiler's schedule of the plain loop -- a row cost 8.5 ns.
+                constexpr int BR = 14, NB = kRingRows / BR;
+                static_assert(kRingRows % BR == 0, "whole batches");
+                double t[2][BR];
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+#pragma unroll
+                    for (int r = 0; r < BR; ++r) t[g][r] = rows[(g * BR + r) * kRingCW + c];
+                // global row 1 of the first block: dpsiu(:,1) = 0 (or the carry), its transport is not used
+                if (first_block && p == 0) t[0][0] = 0.0;
+#pragma unroll
+                for (int g = 0; g < NB; ++g) {
+#pragma unroll
+                    for (int r = 0; r < BR; ++r) {
+                        acc = __dadd_rn(acc, -t[g % 2][r]);         // rows past the end hold 0: the chain passes through them
+                        t[g % 2][r] = acc;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);              // (keep the additions together)
+#pragma unroll
+                    for (int r = 0; r < BR; ++r) rows[(g * BR + r) * kRingCW + c] = t[g % 2][r];
+                    if (g + 2 < NB) {
+#pragma unroll
+                        for (int r = 0; r < BR; ++r) t[g % 2][r] = rows[((g + 2) * BR + r) * kRingCW + c];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (lane == 0) ring_bump(walked);                     // (release: the results are in LDS before the count says so)
+        }
+        return;
+    }
+    if (wave <= kRingFeed) {
+        // ---- the loaders ----
+        const int lw = wave - 1;
+        auto row_of = [&](int r) { return (lw * kRingRW + r) * kRingSub + sub; };
+        auto fetch = [&](double (&x)[kRingRW], int p) {           // (branch-free: a clamped address, the value dropped in put)
+#pragma unroll
+            for (int r = 0; r < kRingRW; ++r) {
+                const int j = min(p * kRingRows + row_of(r), npj - 1);
+                x[r] = __builtin_nontemporal_load(dtrp + (int64_t)j * npi + ic);
+            }
+        };
+        auto put = [&](const double (&x)[kRingRW], int p) {
+            if (p >= npass) return;
+            if (p >= kRingSlots) ring_wait(stored + (p - kRingSlots) % kRingCnt, ((p - kRingSlots) / kRingCnt + 1) * kRingDrain);   // the slot is free
+            double *rows = slot(p);
+#pragma unroll
+            for (int r = 0; r < kRingRW; ++r) {
+                const int j = p * kRingRows + row_of(r);
+                rows[row_of(r) * kRingCW + c] = (col && j < npj) ? x[r] : 0.0;
+            }
+            if (lane == 0) ring_bump(filled + p % kRingCnt);
+        };
+        double x[kRingAhead][kRingRW];
+#pragma unroll
+        for (int q = 0; q < kRingAhead; ++q) fetch(x[q], q);
+        for (int p = 0; p < npass; p += kRingAhead) {
+#pragma unroll
+            for (int d = 0; d < kRingAhead; ++d) { put(x[d], p + d); fetch(x[d], p + d + kRingAhead); }
+        }
+        return;
+    }
+    // ---- the storers ----
+    const int dw = wave - 1 - kRingFeed;
+    for (int p = 0; p < npass; ++p) {
+        ring_wait(walked, p + 1);                                 // the chain has left pass p
+        const double *rows = slot(p);
+        double y[kRingDW];
+#pragma unroll
+        for (int r = 0; r < kRingDW; ++r) y[r] = rows[((dw * kRingDW + r) * kRingSub + sub) * kRingCW + c];
+        __builtin_amdgcn_s_waitcnt(0xc07f);                       // lgkmcnt(0): the slot has been read into registers ...
+        if (lane == 0) ring_bump(stored + p % kRingCnt);          // ... and may be written again
+#pragma unroll
+        for (int r = 0; r < kRingDW; ++r) {
+            const int j = p * kRingRows + (dw * kRingDW + r) * kRingSub + sub;
+            if (col && j < npj) dpsi[(int64_t)j * npi + i] = y[r];
+        }
+    }
+}
+
 // cdfpsi V path, src/cdfpsi.f90:380-383: dpsiv(npi,:) = 0 ; dpsiv(ji,:) = dpsiv(ji+1,:) - dtrpv(ji,:),
 // ji = npi-1..1.  The scan runs along i, the contiguous axis: one wave takes 64 rows, stages a
 // 64 x 64 tile through LDS with coalesced row segments, each lane scans its own row of the tile
@@ -942,9 +1073,16 @@ int cdft_psi_scan_u(cdft_psi_plan *p, const double *carry, int carry_space, int 
     if (ew && ew[0] == '1')
         hipLaunchKernelGGL(psi_scan_j_kernel, dim3((p->npi + 63) / 64), dim3(64), 0, st, p->dtrpu, p->dpsiu, p->npi, p->npj,
                            (const double *)dc, first_block ? 1 : 0);
-    else
+    else if (ew && ew[0] == '2')                                  // the round-3 scan: 128 rows staged, walked and stored in turn
         hipLaunchKernelGGL(psi_scan_j_wg_kernel, dim3((p->npi + kScanCW - 1) / kScanCW), dim3(kScanWaves * 64), 0, st, p->dtrpu, p->dpsiu,
                            p->npi, p->npj, (const double *)dc, first_block ? 1 : 0);
+    else {
+        const size_t shmem = sizeof(double) * kRingSlots * kRingRows * kRingCW + sizeof(int) * (2 * kRingCnt + 2);
+        // (more than 64 KB of dynamic LDS has to be asked for, on the device the plan lives on)
+        CDFT_HIP(hipFuncSetAttribute((const void *)psi_scan_j_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL(psi_scan_j_ring_kernel, dim3((p->npi + kRingCW - 1) / kRingCW), dim3((1 + kRingFeed + kRingDrain) * 64), shmem, st,
+                           p->dtrpu, p->dpsiu, p->npi, p->npj, (const double *)dc, first_block ? 1 : 0);
+    }
     CDFT_LAUNCH_CHECK();
     if (last_row) {
         const double *src = p->dpsiu + (int64_t)(p->npj - 1) * p->npi;

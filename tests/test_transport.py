@@ -65,12 +65,14 @@ def test_oracle_mhst_sep_equals_vt_path_fed_with_its_own_products():
 
 # ----------------------------------------------------------------------------- GPU
 @pytest.mark.gpu
-@pytest.mark.parametrize("scan", ["workgroup", "wave"])
+@pytest.mark.parametrize("scan", ["ring", "workgroup", "wave"])
 @pytest.mark.parametrize("npi,npj,npk", [(24, 18, 7), (182, 149, 31), (1, 1, 1), (5, 3, 2), (130, 67, 4), (64, 64, 3),
-                                         (70, 300, 2), (129, 257, 1), (65, 128, 1), (3, 129, 2), (17, 1100, 1), (33, 513, 2)])
+                                         (70, 300, 2), (129, 257, 1), (65, 128, 1), (3, 129, 2), (17, 1100, 1), (33, 513, 2),
+                                         (40, 120, 1), (40, 121, 2), (31, 239, 1), (32, 240, 1), (33, 241, 1), (100, 481, 1)])
 def test_hip_psi_equals_oracle_bitwise(gpu, monkeypatch, scan, npi, npj, npk):
-    # the j scan: 16 waves per 64 columns with the chain run through LDS (128 rows a time), or one wave per 64 columns
-    monkeypatch.setenv("CDFT_PSI_SCAN_WAVE", "1" if scan == "wave" else "0")
+    # the j scan: one chain wave fed through a ring of LDS slots by 15 others (what runs), 16 waves that stage, walk and store 128
+    # rows in turn (round 3), or one wave per 64 columns
+    monkeypatch.setenv("CDFT_PSI_SCAN_WAVE", {"ring": "0", "wave": "1", "workgroup": "2"}[scan])
     g = synth.make_grid(npi, npj, npk, seed=npi)
     _, _, u, v = tracer_fields(g, 7)
     plan = gpu.PsiPlan(npi, npj, npk)
