@@ -454,11 +454,12 @@ __device__ __forceinline__ float scan_scale(int key) {            // +-2^(23-e):
 // block lies in the level's first `dense_cells` cells, else of its first 64 cells scaled by (cells of the block) / 64.
 // One wave per block.
 constexpr int kSampleBlock = 4096;
+// One wave per block: the blocks that are read in full (the grid covers the first `nb` blocks of every level).
 template <bool MASK8, bool FULL, bool MXL>
-__global__ void __launch_bounds__(256) heatc_sample_kernel(HeatcArgs a, int64_t dense_cells) {
+__global__ void __launch_bounds__(256) heatc_sample_kernel(HeatcArgs a, int64_t dense_cells, int nb) {
     const int lane = threadIdx.x & 63, k = blockIdx.y;
     const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= a.nblk) return;
+    if (b >= nb) return;
     const int64_t c0 = b * kSampleBlock, c1 = min(a.nij, c0 + kSampleBlock), base = (int64_t)k * a.nij;
     const bool dense = c0 < dense_cells;
     const int64_t cend = dense ? c1 : min(c1, c0 + 64);
@@ -489,27 +490,107 @@ __global__ void __launch_bounds__(256) heatc_sample_kernel(HeatcArgs a, int64_t 
     }
 }
 
+// The blocks read in full (b < b0: one workgroup each, 16 cells per thread) and the sampled ones (b >= b0): four lanes per block, each 16 of its first 64 cells as four 16-byte loads per field (a load
+// instruction takes 64 contiguous bytes of a block), a wave
+// 16 blocks -- one wave per block (above) was 286 000 waves of one load each at eORCA12: 92 us, bound by their number.
+// The order of a block's 64 terms differs from the kernel above (4 lanes x 16 cells, then across the lanes): an estimate
+// either way, fixed for a given grid.
+template <bool MASK8, bool FULL, bool MXL>
+__global__ void __launch_bounds__(256) heatc_sample16_kernel(HeatcArgs a, int b0) {
+    __shared__ double scratch[16];
+    const int lane = threadIdx.x & 63, k = blockIdx.y, sub = lane & 3;
+    // workgroups 0 .. b0-1: one each for the blocks read in full (16 cells per thread); the others: 64 sampled blocks each
+    const bool dense = (int)blockIdx.x < b0;
+    const int64_t b = dense ? blockIdx.x : b0 + ((int64_t)(blockIdx.x - b0) * 4 + (threadIdx.x >> 6)) * 16 + (lane >> 2);
+    const bool live = b < a.nblk;
+    const int64_t bc = live ? b : a.nblk - 1;
+    const int64_t c0 = bc * kSampleBlock, c1 = min(a.nij, c0 + kSampleBlock), cend = dense ? c1 : min(c1, c0 + 64), base = (int64_t)k * a.nij;
+    const float e3k = FULL ? a.e31d[k] : 0.f;
+    const float dw  = MXL ? a.gdepw[k] : 0.f;
+    f4u ar[4], tt[4], e3[4], mx[4];
+    uint32_t mb[4];
+    f4u mf[4];
+    int64_t q[4];
+    typedef uint32_t u32u __attribute__((aligned(1)));
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {                      // every load at an address inside the level (clamped), masked afterwards
+        q[v] = min(c0 + (dense ? (int64_t)(v * 256 + threadIdx.x) * 4 : v * 16 + sub * 4), a.nij - 4);    // (contiguous bytes per load: 4 KB of a whole block, 64 of a sampled one)
+        if (a.nij < 4) q[v] = 0;
+        ar[v] = *reinterpret_cast<const f4u *>(a.area + q[v]);
+        tt[v] = ld_stream4u(a.temp + base + q[v]);
+        if (!FULL) e3[v] = ld_stream4u(a.e3t + base + q[v]);
+        if (MXL) mx[v] = *reinterpret_cast<const f4u *>(a.mxl + q[v]);
+        if (MASK8) mb[v] = __builtin_nontemporal_load(reinterpret_cast<const u32u *>(a.mask8 + base + q[v]));
+        else       mf[v] = ld_stream4u(a.mask4 + base + q[v]);
+    }
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int64_t want = c0 + (dense ? (int64_t)(v * 256 + threadIdx.x) * 4 : v * 16 + sub * 4);    // the first cell this vector stands for (its address may have been clamped below it)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int64_t p = q[v] + c;
+            const bool mine = p >= want && p < cend;
+            const float arc = ar[v][c], ttc = tt[v][c];
+            const float mk = MASK8 ? (float)((mb[v] >> (8 * c)) & 0xffu) : mf[v][c];
+            float e = FULL ? e3k : e3[v][c];
+            if (MXL) {
+                if (a.mxlopt == 1) e = fmaxf(0.f, fminf(e, __fsub_rn(mx[v][c], dw)));
+                else               e = fminf(e, fmaxf(0.f, __fsub_rn(__fadd_rn(dw, e), mx[v][c])));
+            }
+            const float pv = __fmul_rn(arc, e);
+            const double t0 = (double)__fmul_rn(arc, mk), t1 = (double)__fmul_rn(pv, mk), t2 = (double)__fmul_rn(__fmul_rn(pv, ttc), mk);
+            s0 += mine ? t0 : 0.0; s1 += mine ? t1 : 0.0; s2 += mine ? t2 : 0.0;
+        }
+    }
+    if (dense) {                                       // (uniform over the workgroup)
+        s0 = block_sum(s0, scratch); s1 = block_sum(s1, scratch); s2 = block_sum(s2, scratch);
+    } else {                                           // the four lanes of a block (a quad)
+        s0 = dpp_add<0xb1, 0xf>(s0); s0 = dpp_add<0x4e, 0xf>(s0);
+        s1 = dpp_add<0xb1, 0xf>(s1); s1 = dpp_add<0x4e, 0xf>(s1);
+        s2 = dpp_add<0xb1, 0xf>(s2); s2 = dpp_add<0x4e, 0xf>(s2);
+    }
+    if (live && (dense ? threadIdx.x == 0 : sub == 0)) {
+        const double f = (double)(c1 - c0) / (double)(cend - c0);
+        double *o = a.partial + ((int64_t)k * a.nblk + b) * 3;
+        // (a NaN or Inf in the sample would poison every estimate after it: such a block counts as 0 -- its chunks are
+        // resolved cell by cell whatever the hypotheses say)
+        o[0] = isfinite(s0) ? s0 * f : 0.0; o[1] = isfinite(s1) ? s1 * f : 0.0; o[2] = isfinite(s2) ? s2 * f : 0.0;
+    }
+}
+
 // est[k][b][ch], b = 0..nblk: the r8 value of chain ch of level k where block b of the level kernel starts (b = nblk:
-// where the level ends), from its partials and the carry.  One wave per level.
-__global__ void __launch_bounds__(64) heatc_scan_est_kernel(const double *__restrict__ partial, int nblk, const float *__restrict__ carry,
-                                                            double *__restrict__ est, ScanLevel *lev, ScanCtl *ctl) {
-    const int k = blockIdx.x, lane = threadIdx.x;
+// where the level ends), from its partials and the carry.  One workgroup of kEstThreads per level: a thread adds up a run
+// of blocks, the runs are scanned across the workgroup, the thread walks its run again (one wave per level walked runs of
+// 60 blocks at eORCA12: 48 us).
+constexpr int kEstThreads = 1024;
+__global__ void __launch_bounds__(kEstThreads) heatc_scan_est_kernel(const double *__restrict__ partial, int nblk, const float *__restrict__ carry,
+                                                                     double *__restrict__ est, ScanLevel *lev, ScanCtl *ctl) {
+    __shared__ double wtot[3][kEstThreads / 64];
+    const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double *ek = est + (int64_t)k * (nblk + 1) * 3;
     const double *pk = partial + (int64_t)k * nblk * 3;
-    const int seg = (nblk + 63) / 64, b0 = min(nblk, lane * seg), b1 = min(nblk, b0 + seg);   // this lane's blocks
-    double sum[3] = {0.0, 0.0, 0.0};
+    const int seg = (nblk + kEstThreads - 1) / kEstThreads, b0 = min(nblk, tid * seg), b1 = min(nblk, b0 + seg);   // this thread's blocks
+    double sum[3] = {0.0, 0.0, 0.0}, excl[3];
     for (int b = b0; b < b1; ++b)
         for (int c = 0; c < 3; ++c) sum[c] += pk[(int64_t)b * 3 + c];
     for (int c = 0; c < 3; ++c) {
         double incl = sum[c];                                     // the sums of the lanes before this one
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const double t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
-        double run = (double)(carry ? carry[k * 3 + c] : 0.f) + (incl - sum[c]);
-        if (lane == 0) ek[c] = run;
+        excl[c] = incl - sum[c];
+        if (lane == 63) wtot[c][wave] = incl;
+    }
+    __syncthreads();
+    for (int c = 0; c < 3; ++c) {
+        double run = (double)(carry ? carry[k * 3 + c] : 0.f);
+        for (int w = 0; w < wave; ++w) run += wtot[c][w];         // the waves before this one, in order
+        run += excl[c];
+        if (tid == 0) ek[c] = run;
         for (int b = b0; b < b1; ++b) { run += pk[(int64_t)b * 3 + c]; ek[(int64_t)(b + 1) * 3 + c] = run; }
     }
-    if (lane < 3) lev[k].word[lane] = scan_word(0, carry ? carry[k * 3 + lane] : 0.f);
-    if (k == 0 && lane == 0) {
+    if (tid < 3) lev[k].word[tid] = scan_word(0, carry ? carry[k * 3 + tid] : 0.f);
+    if (k == 0 && tid == 0) {
         ctl->ticket = 0; ctl->error = 0; ctl->nfallback = 0; ctl->nunguessed = 0; ctl->nslow = 0; ctl->nstolen = 0;
         for (int x = 0; x < kScanMaxLanes; ++x) ctl->lane_next[x] = 0;
     }
@@ -1030,8 +1111,14 @@ int launch_seq_scan(HeatcArgs a, const float *carry, float *sums4, DevBuf &work,
     {
         int64_t dense_cells = 32768;                              // read in full: where a chain grows from nothing
         if (const char *e = getenv("CDFT_HEATC_SCAN_DENSE")) dense_cells = std::max(0LL, atoll(e));           // (tuning hook)
-        const dim3 sgrid((unsigned)((a.nblk + 3) / 4), (unsigned)a.npk), sblock(256);
-#define CDFT_SAMPLE_LAUNCH(M8, FU, MX) hipLaunchKernelGGL((heatc_sample_kernel<M8, FU, MX>), sgrid, sblock, 0, st, a, dense_cells)
+        // the blocks read in full by one wave each, the others sampled 16 to a wave (tiny planes: one wave each throughout)
+        const int nb_dense = a.nij >= 64 ? (int)std::min<int64_t>(a.nblk, (dense_cells + kSampleBlock - 1) / kSampleBlock) : a.nblk;
+        const int nb_sparse = a.nblk - nb_dense;
+        const bool tiny = a.nij < 64;                              // (one wave per block, scalar loads)
+        const dim3 sgrid((unsigned)((a.nblk + 3) / 4), (unsigned)a.npk), sgrid16((unsigned)(nb_dense + (nb_sparse + 63) / 64), (unsigned)a.npk), sblock(256);
+#define CDFT_SAMPLE_LAUNCH(M8, FU, MX) do { \
+            if (tiny) hipLaunchKernelGGL((heatc_sample_kernel<M8, FU, MX>), sgrid, sblock, 0, st, a, dense_cells, a.nblk); \
+            else      hipLaunchKernelGGL((heatc_sample16_kernel<M8, FU, MX>), sgrid16, sblock, 0, st, a, nb_dense); } while (0)
         if (m8 && full)        { if (mx) CDFT_SAMPLE_LAUNCH(true, true, true);   else CDFT_SAMPLE_LAUNCH(true, true, false); }
         else if (m8 && !full)  { if (mx) CDFT_SAMPLE_LAUNCH(true, false, true);  else CDFT_SAMPLE_LAUNCH(true, false, false); }
         else if (!m8 && full)  { if (mx) CDFT_SAMPLE_LAUNCH(false, true, true);  else CDFT_SAMPLE_LAUNCH(false, true, false); }
@@ -1039,7 +1126,7 @@ int launch_seq_scan(HeatcArgs a, const float *carry, float *sums4, DevBuf &work,
 #undef CDFT_SAMPLE_LAUNCH
         CDFT_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(heatc_scan_est_kernel, dim3(a.npk), dim3(64), 0, st, a.partial, a.nblk, carry, est, lev, ctl);
+    hipLaunchKernelGGL(heatc_scan_est_kernel, dim3(a.npk), dim3(kEstThreads), 0, st, a.partial, a.nblk, carry, est, lev, ctl);
     int dev = 0, ncu = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
     const int64_t tickets = (int64_t)nsteps * a.npk;
