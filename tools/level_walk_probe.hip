@@ -16,7 +16,7 @@ struct Args { const float *f[3]; const uint8_t *m; int64_t nij; int npk; float *
 
 template <int NF, int VPT, bool MASK> struct Lev { f4 x[NF][VPT]; uint32_t m[VPT]; };
 
-template <int NF, int VPT, int D, bool MASK, bool NT>
+template <int NF, int VPT, int D, bool MASK, bool NT, bool ALWAYS = false>
 __global__ void __launch_bounds__(256) walk_kernel(Args a) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
@@ -49,13 +49,16 @@ __global__ void __launch_bounds__(256) walk_kernel(Args a) {
     };
     // the loop runs over groups of D+1 levels so that every buffer has a fixed name (registers, not scratch)
 #pragma unroll
-    for (int d = 0; d < D; ++d) if (d < a.npk) fetch(L[d], d);
+    for (int d = 0; d < D; ++d) fetch(L[d], d < a.npk ? d : a.npk - 1);
     for (int k0 = 0; k0 < a.npk; k0 += D + 1) {
 #pragma unroll
         for (int d = 0; d <= D; ++d) {
             const int k = k0 + d;
-            if (k < a.npk) {
-                if (k + D < a.npk) fetch(L[(d + D) % (D + 1)], k + D);
+            if (ALWAYS || k < a.npk) {
+                // ALWAYS: the request is made on every way through the loop (past the last level: that level again), so that the
+                // compiler's waits can count D levels of younger loads; otherwise they count none beyond the level itself
+                if (ALWAYS) fetch(L[(d + D) % (D + 1)], k + D < a.npk ? k + D : a.npk - 1);
+                else if (k + D < a.npk) fetch(L[(d + D) % (D + 1)], k + D);
                 use(L[d]);
             }
         }
@@ -63,27 +66,27 @@ __global__ void __launch_bounds__(256) walk_kernel(Args a) {
     if (acc == 12345.678f) a.out[0] = acc;
 }
 
-template <int NF, int VPT, int D, bool MASK, bool NT>
+template <int NF, int VPT, int D, bool MASK, bool NT, bool ALWAYS = false>
 void run(const Args &a, int reps) {
     const int64_t nv = a.nij / 4, nthr = (nv + VPT - 1) / VPT;
     const dim3 grid((unsigned)((nthr + 255) / 256)), block(256);
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((walk_kernel<NF, VPT, D, MASK, NT>), grid, block, 0, 0, a);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((walk_kernel<NF, VPT, D, MASK, NT, ALWAYS>), grid, block, 0, 0, a);
     CK(hipDeviceSynchronize());
     float best = 1e30f, sum = 0.f;
     for (int i = 0; i < reps; ++i) {
         CK(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL((walk_kernel<NF, VPT, D, MASK, NT>), grid, block, 0, 0, a);
+        hipLaunchKernelGGL((walk_kernel<NF, VPT, D, MASK, NT, ALWAYS>), grid, block, 0, 0, a);
         CK(hipEventRecord(e1, 0));
         CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         best = ms < best ? ms : best; sum += ms;
     }
     const double bytes = (double)a.nij * a.npk * (4.0 * NF + (MASK ? 1.0 : 0.0));
-    printf("{\"fields\": %d, \"byte_mask\": %d, \"vectors_per_lane\": %d, \"levels_ahead\": %d, \"nontemporal\": %d, \"workgroups\": %u, "
+    printf("{\"fields\": %d, \"byte_mask\": %d, \"vectors_per_lane\": %d, \"levels_ahead\": %d, \"nontemporal\": %d, \"unconditional_requests\": %d, \"workgroups\": %u, "
            "\"ms_avg\": %.4f, \"ms_min\": %.4f, \"TBps_avg\": %.3f, \"TBps_best\": %.3f}\n",
-           NF, (int)MASK, VPT, D, (int)NT, grid.x, sum / reps, best, bytes / (sum / reps * 1e-3) / 1e12, bytes / (best * 1e-3) / 1e12);
+           NF, (int)MASK, VPT, D, (int)NT, (int)ALWAYS, grid.x, sum / reps, best, bytes / (sum / reps * 1e-3) / 1e12, bytes / (best * 1e-3) / 1e12);
     fflush(stdout);
 }
 
@@ -105,5 +108,8 @@ int main(int argc, char **argv) {
     run<2, 4, 0, true, true>(a, R); run<2, 4, 1, true, true>(a, R); run<2, 4, 2, true, true>(a, R);
     run<2, 2, 0, true, true>(a, R); run<2, 2, 1, true, true>(a, R); run<2, 2, 3, true, true>(a, R); run<2, 8, 0, true, true>(a, R);
     run<3, 4, 1, false, false>(a, R); run<2, 4, 1, true, false>(a, R);
+    // the same with requests the compiler can count (npk must be a multiple of D + 1: 75 = 3 * 25 = 5 * 15)
+    run<2, 4, 2, false, true, true>(a, R); run<2, 4, 4, false, true, true>(a, R); run<3, 4, 2, false, true, true>(a, R); run<3, 2, 4, false, true, true>(a, R);
+    run<2, 4, 2, true, true, true>(a, R); run<2, 2, 4, true, true, true>(a, R); run<2, 2, 2, true, true, true>(a, R); run<3, 2, 2, false, true, true>(a, R);
     return 0;
 }
