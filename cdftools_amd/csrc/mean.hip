@@ -23,6 +23,8 @@ struct cdft_mean_plan {
     uint8_t *mask8 = nullptr;      // zmask as bytes when it holds only +0 and 1 (9 bytes per cell and level instead of 12)
     bool mask01 = false;
     int16_t *ib = nullptr;          // (nb,npi,npj), basin index fastest
+    uint8_t *ibits = nullptr;       // (npi,npj) bit b = ibmask(b) when every value is 0 or 1 (ib01): one byte per cell instead of nb values
+    bool ib01 = false;
     double *partial = nullptr;      // [npk][nblk][nb][4]
     int nblk = 0;
     int form = 0;                   // CDFT_MEAN_FORM_*
@@ -37,13 +39,15 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kVPT     = 2;     // vectors per lane of the scalar path; the 16-byte path takes 4.  The plan's partial sums are sized for 2
 constexpr int kMaxNB   = 8;
+constexpr int kRedStride = 65;  // doubles between the rows of the reduction scratch (64 lanes + 1: the reads of a sum's 8 lanes fall on different banks)
 
 struct MeanArgs {
     const float *e1, *e2, *e3, *e31d, *mask, *zv;
     const uint8_t *mask8;          // or null
     const int16_t *ib;
+    const uint8_t *ibits;          // or null
     int64_t nij;
-    int npk, nb, nblk, form, band;
+    int npk, nb, nblk, form, band, redoff;
     double *partial;
 };
 
@@ -58,6 +62,19 @@ __global__ void mean_mask8_kernel(const float *__restrict__ m, int64_t n, uint8_
     else { m8[p] = 0; if (!(v == 0.f) || signbit(v)) flag[0] = 1; }
 }
 
+// bits[p] = the basins cell p belongs to; flag[0] is raised by a basin value that is neither 0 nor 1
+__global__ void mean_ibits_kernel(const int16_t *__restrict__ ib, int64_t nij, int nb, uint8_t *__restrict__ bits, int *__restrict__ flag) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nij) return;
+    unsigned v = 0;
+    for (int b = 0; b < nb; ++b) {
+        const int x = ib[p * nb + b];
+        if (x == 1) v |= 1u << b;
+        else if (x != 0) flag[0] = 1;
+    }
+    bits[p] = (uint8_t)v;
+}
+
 // Two cells per vector instruction where the cells come four at a time (v_pk_mul_f32: each half the plain IEEE r4 product):
 // Lanes<4> works on pairs, Lanes<1> on single cells; the r8 sums take the cells in the same order either way.
 typedef float f2v __attribute__((ext_vector_type(2)));
@@ -66,11 +83,13 @@ template <> struct Lanes<4> {
     typedef f2v T; static constexpr int G = 2, W = 2;
     static __device__ __forceinline__ T mk(float a, float b) { return T{a, b}; }
     static __device__ __forceinline__ void add(double &s, T t) { s += (double)t.x; s += (double)t.y; }
+    static __device__ __forceinline__ float at(T t, int h) { return h ? t.y : t.x; }
 };
 template <> struct Lanes<1> {
     typedef float T; static constexpr int G = 1, W = 1;
     static __device__ __forceinline__ T mk(float a, float) { return a; }
     static __device__ __forceinline__ void add(double &s, T t) { s += (double)t; }
+    static __device__ __forceinline__ float at(T t, int) { return t; }
 };
 
 // PARK: the wave sums of every level stay in LDS [wave][level][nb*4] and the four waves are combined once, after the
@@ -78,16 +97,23 @@ template <> struct Lanes<1> {
 // npk * nb * 4 sums per wave do not fit): two barriers per level.
 // The form of the sums (cdfmean with / without the variance, cdfsum's two) picks one of four straight-line copies of the
 // cell loop by a uniform branch per level: no select and no scalar branch per cell.
-template <int VEC, bool FULL, int NB, bool PARK, int VPT, bool MASK8>
+// IB01: every basin value is 0 or 1 (the usual sub-basin file): a cell's basins are one byte in a register instead of NB r4
+// values, and a term reaches a basin's sum as fma(term, 0.d0 | 1.d0, sum) -- one instruction, the same r8 value as adding the
+// r4 product term * 1 or term * 0 (a zero of either sign leaves the sum, a NaN / Inf term gives NaN both ways).  Five basins:
+// 57 -> ~40 vector instructions per cell, and no NB x 16 registers of basin values.
+template <int VEC, bool FULL, int NB, bool PARK, int VPT, bool MASK8, bool IB01>
 __global__ void __launch_bounds__(kThreads) mean_level_kernel(MeanArgs a) {
-    extern __shared__ double wsum[];                   // PARK: [nwaves][npk][nb*4], else [nwaves][nb*4]
+    extern __shared__ double wsum[];                   // PARK: [nwaves][npk][nb*4], else [nwaves][nb*4]; then (NB >= 2) the reduction scratch
     typedef Lanes<VEC> LN;
     typedef typename LN::T T;
     constexpr int G = LN::G, W = LN::W;                // groups per vector, cells per group
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = kThreads / 64;
+    double *red = wsum + a.redoff;                     // [nwaves][8][kRedStride]
+    (void)red;
     const int64_t blk = xcd_band(a.band);              // (common.hpp)
     int64_t q[VPT];
-    T e1[VPT][G], e2[VPT][G], ar[VPT][G], fb[VPT][G][NB];
+    T e1[VPT][G], e2[VPT][G], ar[VPT][G], fb[IB01 ? 1 : VPT][G][IB01 ? 1 : NB];
+    uint32_t bb[VPT];                                  // IB01: the basin bytes of the vector's cells
     bool ok[VPT][VEC];
     bool edge = false;                                 // a lane of this wave holds a cell that is not its own
     // VEC = 4: vectors at cells 0, 4, 8, ... and, when the plane is not a multiple of 4 cells, one more anchored at
@@ -106,21 +132,32 @@ __global__ void __launch_bounds__(kThreads) mean_level_kernel(MeanArgs a) {
             const int64_t pc = ok[v][c] ? p : 0;
             x1[c] = ok[v][c] ? a.e1[pc] : 0.f;         // cells past the plane contribute exact zeros
             x2[c] = a.e2[pc];
+            if (IB01) {
+                if (c == 0) bb[v] = 0u;
+                bb[v] |= (ok[v][c] ? (uint32_t)a.ibits[pc] : 0u) << (8 * c);
+            } else {
 #pragma unroll
-            for (int b = 0; b < NB; ++b) xf[c][b] = (b < a.nb) ? (float)a.ib[pc * a.nb + min(b, a.nb - 1)] : 0.f;
+                for (int b = 0; b < NB; ++b) xf[c][b] = (b < a.nb) ? (float)a.ib[pc * a.nb + min(b, a.nb - 1)] : 0.f;
+            }
         }
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             e1[v][g] = LN::mk(x1[W * g], x1[W * g + W - 1]);
             e2[v][g] = LN::mk(x2[W * g], x2[W * g + W - 1]);
             ar[v][g] = e1[v][g] * e2[v][g];
+            if (!IB01) {
 #pragma unroll
-            for (int b = 0; b < NB; ++b) fb[v][g][b] = LN::mk(xf[W * g][b], xf[W * g + W - 1][b]);
+                for (int b = 0; b < NB; ++b) fb[v][g][b] = LN::mk(xf[W * g][b], xf[W * g + W - 1][b]);
+            }
         }
     }
     edge = __any(edge);                                // (wave-uniform)
     for (int k = 0; k < a.npk; ++k) {
         const int64_t base = (int64_t)k * a.nij;
+        if constexpr (IB01) {                              // (the 0.d0 / 1.d0 words are formed from the bytes at every level: hoisted out of
+#pragma unroll                                             //  the loop they are NB registers per cell again -- 196 VGPRs with five basins)
+            for (int v = 0; v < VPT; ++v) asm volatile("" : "+v"(bb[v]));
+        }
         T zv[VPT][G], e3[VPT][G], mk[VPT][G];
 #pragma unroll
         for (int v = 0; v < VPT; ++v) {
@@ -179,13 +216,32 @@ __global__ void __launch_bounds__(kThreads) mean_level_kernel(MeanArgs a) {
                     const T t_sum  = SF == 0 ? zee * e3[v][g] : (SF == 1 ? zee : zee * m);
                     T t_var = t_sum;
                     if (VAR) t_var = (((zm * zm) * e1[v][g]) * e2[v][g]) * e3[v][g];
+                    if constexpr (IB01) {
 #pragma unroll
-                    for (int b = 0; b < NB; ++b) {             // basins past nb have f = 0: they add exact zeros
-                        const T f = fb[v][g][b];
-                        LN::add(s[b][0], t_surf * f);
-                        LN::add(s[b][1], t_vol * f);
-                        LN::add(s[b][2], t_sum * f);
-                        if (VAR) LN::add(s[b][3], t_var * f);
+                        for (int h = 0; h < W; ++h) {           // the cells of the group in order
+                            const int c = W * g + h;
+                            const double d0 = (double)LN::at(t_surf, h), d1 = (double)LN::at(t_vol, h), d2 = (double)LN::at(t_sum, h);
+                            const double d3 = VAR ? (double)LN::at(t_var, h) : 0.0;
+#pragma unroll
+                            for (int b = 0; b < NB; ++b) {
+                                // 1.d0 where bit b of the cell's byte is set, else 0.d0: the high word is 0x3ff00000 or 0
+                                const int hi = ((int)(bb[v] << (31 - 8 * c - b)) >> 31) & 0x3ff00000;
+                                const double m = __hiloint2double(hi, 0);
+                                s[b][0] = __fma_rn(d0, m, s[b][0]);
+                                s[b][1] = __fma_rn(d1, m, s[b][1]);
+                                s[b][2] = __fma_rn(d2, m, s[b][2]);
+                                if (VAR) s[b][3] = __fma_rn(d3, m, s[b][3]);
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int b = 0; b < NB; ++b) {         // basins past nb have f = 0: they add exact zeros
+                            const T f = fb[v][g][b];
+                            LN::add(s[b][0], t_surf * f);
+                            LN::add(s[b][1], t_vol * f);
+                            LN::add(s[b][2], t_sum * f);
+                            if (VAR) LN::add(s[b][3], t_var * f);
+                        }
                     }
                 }
         };
@@ -196,13 +252,38 @@ __global__ void __launch_bounds__(kThreads) mean_level_kernel(MeanArgs a) {
         else if (a.form == CDFT_MEAN_FORM_MEAN_NOVAR) cells(F0{}, std::false_type{});
         else if (a.form == 1)                         cells(F1{}, std::false_type{});
         else                                          cells(F2{}, std::false_type{});
+        if constexpr (NB >= 2) {
+            // Two basins' four sums at a time through LDS: lane l adds 8 lanes' values of sum l / 8, three DPP steps add the 8
+            // lanes of a sum -- 33 instructions for 8 wave sums instead of 8 x 20 (five basins: 15 sums per level and wave were
+            // as much work as the level's cells).  A fixed order, like the DPP tree it replaces.
+            double *scr = red + wave * (8 * kRedStride);
 #pragma unroll
-        for (int b = 0; b < NB; ++b)
+            for (int b0 = 0; b0 < NB; b0 += 2) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const double t = (c < 3 || a.form == CDFT_MEAN_FORM_MEAN) ? wave_sum(s[b][c]) : 0.0;       // (uniform)
-                if (lane == 0 && b < a.nb) wsum[((PARK ? wave * a.npk + k : wave) * a.nb + b) * 4 + c] = t;
+                for (int j = 0; j < 8; ++j) scr[j * kRedStride + lane] = (b0 + (j >> 2) < NB) ? s[(b0 + (j >> 2)) < NB ? b0 + (j >> 2) : 0][j & 3] : 0.0;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const int n = lane >> 3, l8 = lane & 7;       // sum n of the batch, lanes 8 l8 .. 8 l8 + 7 of it
+                double t = 0.0;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) t += scr[n * kRedStride + l8 * 8 + i];
+                t = dpp_add<0xb1, 0xf>(t);                    // quad_perm:[1,0,3,2]
+                t = dpp_add<0x4e, 0xf>(t);                    // quad_perm:[2,3,0,1]
+                t = dpp_add<0x141, 0xf>(t);                   // row_half_mirror: the 8 lanes of a sum hold its total
+                const int b = b0 + (n >> 2), c = n & 3;
+                if (l8 == 0 && b < a.nb && b < NB) wsum[((PARK ? wave * a.npk + k : wave) * a.nb + b) * 4 + c] = (c < 3 || a.form == CDFT_MEAN_FORM_MEAN) ? t : 0.0;
+                __builtin_amdgcn_wave_barrier();              // scr is written again
             }
+        } else {
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const double t = (c < 3 || a.form == CDFT_MEAN_FORM_MEAN) ? wave_sum(s[b][c]) : 0.0;       // (uniform)
+                    if (lane == 0 && b < a.nb) wsum[((PARK ? wave * a.npk + k : wave) * a.nb + b) * 4 + c] = t;
+                }
+        }
         if (!PARK) {
             __syncthreads();
             if ((int)threadIdx.x < a.nb * 4) {
@@ -303,6 +384,18 @@ int cdft_mean_set_mesh(cdft_mean_plan *p, const float *e1, const float *e2, cons
     CDFT_HIP(hipMemcpyAsync(&not01, flag, 4, hipMemcpyDeviceToHost, st));
     CDFT_HIP(hipStreamSynchronize(st));
     p->mask01 = not01 == 0;
+    // the basin values as one byte per cell when they are all 0 or 1
+    if (!p->ibits && hipMalloc((void **)&p->ibits, nij + 64) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(CDFT_ERR_ALLOC, "cdft_mean_set_mesh: device allocation failed");
+    }
+    int ibnot01 = 0;
+    CDFT_HIP(hipMemsetAsync(flag, 0, 4, st));
+    hipLaunchKernelGGL(mean_ibits_kernel, dim3((unsigned)((nij + 255) / 256)), dim3(256), 0, st, p->ib, (int64_t)nij, p->nb, p->ibits, flag);
+    CDFT_LAUNCH_CHECK();
+    CDFT_HIP(hipMemcpyAsync(&ibnot01, flag, 4, hipMemcpyDeviceToHost, st));
+    CDFT_HIP(hipStreamSynchronize(st));
+    p->ib01 = ibnot01 == 0;
     p->mesh_set = true;
     return CDFT_OK;
 }
@@ -339,6 +432,8 @@ int cdft_mean_compute(cdft_mean_plan *p, const float *zv, int in_space, double *
     }
     MeanArgs a;
     a.e1 = p->e1; a.e2 = p->e2; a.e3 = p->e3; a.e31d = p->e31d; a.mask = p->mask; a.zv = (const float *)dz; a.ib = p->ib;
+    // (the byte form from two basins on: with one, the r4 value is a single register per cell anyway; CDFT_MEAN_IBVALUES: A/B hook)
+    a.ibits = (p->ib01 && p->nb >= 2 && !getenv("CDFT_MEAN_IBVALUES")) ? p->ibits : nullptr;
     a.nij = nij; a.npk = p->npk; a.nb = p->nb; a.partial = p->partial; a.form = p->form;
     {
         const char *e = getenv("CDFT_MEAN_R4MASK");              // test hook: the r4 mask
@@ -347,32 +442,39 @@ int cdft_mean_compute(cdft_mean_plan *p, const float *zv, int in_space, double *
     const bool vec4 = nij >= 4 && !getenv("CDFT_MEAN_SCALAR");         // (A/B hook: the scalar path)
     const int vec = vec4 ? 4 : 1;
     // vectors per lane: 4 (190 against 210 us at eORCA025, 1.72 against 1.73 ms at eORCA12); CDFT_MEAN_VPT = 2 | 4: A/B hook
-    int vpt = vec4 ? 4 : kVPT;
-    { const char *e = getenv("CDFT_MEAN_VPT"); if (e && atoi(e) == 2) vpt = 2; }
+    int vpt = (vec4 && (p->nb <= 2 || a.ibits)) ? 4 : kVPT;     // (the r4 basin VALUES of three basins and more: 16 x nb registers with four)
+    { const char *e = getenv("CDFT_MEAN_VPT"); if (e && atoi(e) == 2) vpt = 2; else if (e && atoi(e) == 4 && vec4) vpt = 4; }
     a.nblk = (int)(((nij + vec - 1) / vec + kThreads * vpt - 1) / (kThreads * vpt));
     a.band = xcd_bands_on();
     const dim3 grid(xcd_band_grid(a.nblk, a.band)), block(kThreads);
     const size_t park_bytes = (size_t)(kThreads / 64) * p->npk * nq * sizeof(double);
     const bool park = park_bytes <= 48 * 1024 && !getenv("CDFT_MEAN_NOPARK");     // (A/B hook: a barrier pair per level)
-    const size_t shmem = park ? park_bytes : (size_t)(kThreads / 64) * nq * sizeof(double);
+    const size_t wsum_bytes = park ? park_bytes : (size_t)(kThreads / 64) * nq * sizeof(double);
+    a.redoff = (int)(wsum_bytes / sizeof(double));
+    const size_t shmem = wsum_bytes + (p->nb >= 2 ? (size_t)(kThreads / 64) * 8 * kRedStride * sizeof(double) : 0);
     const bool full = p->e31d != nullptr;
+#define CDFT_MEAN4(NBC, PK, M8, IB) do { \
+        if (full && vpt == 4) hipLaunchKernelGGL((mean_level_kernel<4, true, NBC, PK, 4, M8, IB>), grid, block, shmem, st, a); \
+        else if (vpt == 4)    hipLaunchKernelGGL((mean_level_kernel<4, false, NBC, PK, 4, M8, IB>), grid, block, shmem, st, a); \
+        else if (full)        hipLaunchKernelGGL((mean_level_kernel<4, true, NBC, PK, kVPT, M8, IB>), grid, block, shmem, st, a); \
+        else                  hipLaunchKernelGGL((mean_level_kernel<4, false, NBC, PK, kVPT, M8, IB>), grid, block, shmem, st, a); } while (0)
 #define CDFT_MEAN3(NBC, PK, M8) do { \
-        if (vec4 && full && vpt == 4) hipLaunchKernelGGL((mean_level_kernel<4, true, NBC, PK, 4, M8>), grid, block, shmem, st, a); \
-        else if (vec4 && vpt == 4)    hipLaunchKernelGGL((mean_level_kernel<4, false, NBC, PK, 4, M8>), grid, block, shmem, st, a); \
-        else if (vec4 && full)  hipLaunchKernelGGL((mean_level_kernel<4, true, NBC, PK, kVPT, M8>), grid, block, shmem, st, a); \
-        else                    hipLaunchKernelGGL((mean_level_kernel<4, false, NBC, PK, kVPT, M8>), grid, block, shmem, st, a); } while (0)
+        if (NBC >= 2 && a.ibits) CDFT_MEAN4(NBC, PK, M8, (NBC >= 2)); \
+        else                     CDFT_MEAN4(NBC, PK, M8, false); } while (0)
 #define CDFT_MEAN2(NBC, PK) do { \
         if (vec4 && a.mask8)    CDFT_MEAN3(NBC, PK, true); \
         else if (vec4)          CDFT_MEAN3(NBC, PK, false); \
-        else if (full)          hipLaunchKernelGGL((mean_level_kernel<1, true, NBC, PK, kVPT, false>), grid, block, shmem, st, a); \
-        else                    hipLaunchKernelGGL((mean_level_kernel<1, false, NBC, PK, kVPT, false>), grid, block, shmem, st, a); } while (0)
+        else if (full)          hipLaunchKernelGGL((mean_level_kernel<1, true, NBC, PK, kVPT, false, false>), grid, block, shmem, st, a); \
+        else                    hipLaunchKernelGGL((mean_level_kernel<1, false, NBC, PK, kVPT, false, false>), grid, block, shmem, st, a); } while (0)
 #define CDFT_MEAN(NBC) do { if (park) CDFT_MEAN2(NBC, true); else CDFT_MEAN2(NBC, false); } while (0)
     if (p->nb == 1)      CDFT_MEAN(1);
     else if (p->nb == 2) CDFT_MEAN(2);
     else if (p->nb <= 4) CDFT_MEAN(4);
+    else if (p->nb == 5) CDFT_MEAN(5);                           // (the five sub-basins of a NEMO basin file)
     else                 CDFT_MEAN(8);
 #undef CDFT_MEAN2
 #undef CDFT_MEAN3
+#undef CDFT_MEAN4
 #undef CDFT_MEAN
     CDFT_LAUNCH_CHECK();
     hipLaunchKernelGGL(mean_final_kernel, dim3(p->npk), dim3(kThreads), 0, st, p->partial, a.nblk, nq, dout);
@@ -391,7 +493,7 @@ int cdft_mean_compute(cdft_mean_plan *p, const float *zv, int in_space, double *
 
 int cdft_mean_destroy(cdft_mean_plan *p) {
     if (!p) return CDFT_OK;
-    void *ptrs[] = {p->e1, p->e2, p->e3, p->e31d, p->mask, p->mask8, p->ib, p->partial};
+    void *ptrs[] = {p->e1, p->e2, p->e3, p->e31d, p->mask, p->mask8, p->ib, p->ibits, p->partial};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     if (p->hsums) (void)hipHostFree(p->hsums);
     p->st_zv.release(); p->st_out.release();

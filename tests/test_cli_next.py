@@ -156,6 +156,19 @@ def test_hip_mean_matches_oracle(gpu, monkeypatch, npi, npj, npk, nb):
         monkeypatch.setenv("CDFT_MEAN_R4MASK", "1")                                     # the 0/1 mask as r4 instead of bytes
         assert np.array_equal(plan.compute(zv), got)
         monkeypatch.delenv("CDFT_MEAN_R4MASK")
+        # two vectors per lane instead of four: other runs of cells per lane and block, the r8 sums regrouped within the bound
+        monkeypatch.setenv("CDFT_MEAN_VPT", "2")
+        got2 = plan.compute(zv)
+        assert np.all(np.abs(got2 - ref) <= 1e-13 * bound + 1e-300)
+        for form in (1, 2, 3):                                                          # cdfsum's two forms, cdfmean without -var
+            plan.set_form(form)
+            a2 = plan.compute(zv)
+            monkeypatch.setenv("CDFT_MEAN_VPT", "4")
+            a4 = plan.compute(zv)
+            monkeypatch.setenv("CDFT_MEAN_VPT", "2")
+            assert np.all(np.abs(a2 - a4) <= 2e-13 * bound + 1e-300) and np.array_equal(a2[..., 3], 0 * a2[..., 3])
+        plan.set_form(0)
+        monkeypatch.delenv("CDFT_MEAN_VPT")
     tm2 = tm * np.float32(0.5)                                                          # not 0/1: never packed
     plan.set_mesh(g["e1t"], g["e2t"], tm2, ib, e3=g["e3t_0"])
     got = plan.compute(zv)
