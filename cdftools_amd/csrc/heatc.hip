@@ -765,16 +765,19 @@ __global__ void __launch_bounds__(64 * kScanWaves, 3) heatc_scan_kernel(HeatcArg
         };
         // sums of chunk q under the hypotheses of each chain
         auto summarize = [&](const f2v (&x)[3][kScanNV][2], int q) {
-            uint32_t any = 0u;                                    // is there a cell with a term that is not 0?  (one answer for the three
-#pragma unroll                                                    // chains: "yes" for a chain of zeros only costs it the integer checks)
+            // Is there a cell with a term that is not 0?  One answer PER CHAIN: a chain that is still at 0 (no binade) has to look at
+            // every chunk that says yes -- with -mxloption the volume and heat terms are 0 below the mixed layer while the surface
+            // terms are not, and one answer for the three sent every chunk of 68 levels x 2 chains to the cells (12.5 ms at eORCA025).
+            uint32_t any[3] = {0u, 0u, 0u};
+#pragma unroll
             for (int v = 0; v < kScanNV; ++v)
 #pragma unroll
                 for (int p = 0; p < 2; ++p)
 #pragma unroll
-                    for (int ch = 0; ch < 3; ++ch) any |= __float_as_uint(x[ch][v][p].x) | __float_as_uint(x[ch][v][p].y);
-            const bool anz = __builtin_amdgcn_ballot_w64((any & 0x7fffffffu) != 0u) != 0;
+                    for (int ch = 0; ch < 3; ++ch) any[ch] |= __float_as_uint(x[ch][v][p].x) | __float_as_uint(x[ch][v][p].y);
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) {
+                const bool anz = __builtin_amdgcn_ballot_w64((any[ch] & 0x7fffffffu) != 0u) != 0;
                 for (int h = 0; h < 2; ++h) {
                     const int key = sm_key[h][q][ch];
                     if (h == 1 && key < 0) break;                 // (uniform)

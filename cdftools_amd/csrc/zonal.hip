@@ -554,7 +554,7 @@ int cdft_zonal_set_mesh(cdft_zonal_plan *p, const float *e1, const float *e2, co
     }
     // class kernel: number the bit patterns present (the empty one included), at most kZC of them
     p->nclass = 0;
-    if (p->binary && p->nb > 1) {
+    if (p->binary) {                                             // (one basin too: two patterns; the class kernel runs it at 0.65 where the byte-select kernel had 0.39)
         if (!p->cls && (hipMalloc((void **)&p->cls, nij + 64 + 256) != hipSuccess || hipMalloc((void **)&p->seen, 256 * sizeof(int)) != hipSuccess)) {
             (void)hipGetLastError();
             return fail(CDFT_ERR_ALLOC, "cdft_zonal_set_mesh: device allocation failed");
