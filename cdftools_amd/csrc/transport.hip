@@ -531,6 +531,118 @@ psi_scan_j_ring_kernel(const double *__restrict__ dtrp, double *__restrict__ dps
     }
 }
 
+// The same ring for the scan along i of the V path (src/cdfpsi.f90:380-383: dpsiv(npi,:) = 0 ; dpsiv(ji,:) = dpsiv(ji+1,:) -
+// dtrpv(ji,:), ji = npi-1 .. 1): a workgroup takes 32 ROWS, a pass is 112 columns from the east; a load or store instruction
+// moves 64 columns of one row (512 contiguous bytes), so the LDS slot is [column][row] with 33 doubles between columns: the
+// loaders write it along columns, the chain reads it along rows, both free of bank conflicts.  Eight waves load (two
+// instructions per row and pass, eight per wave), seven store.  (One wave per 64 rows, the round-2 kernel below, has 19 waves
+// on the whole chip at eORCA025: 0.5 ms.)
+constexpr int kRingIStr = kRingCW + 1, kRingIFeed = 8, kRingIDrain = 7, kRingILoads = 2 * kRingCW / kRingIFeed;
+
+__global__ void __launch_bounds__((1 + kRingIFeed + kRingIDrain) * 64)
+psi_scan_i_ring_kernel(const double *__restrict__ dtrp, double *__restrict__ dpsi, int npi, int npj) {
+    extern __shared__ double ring[];                              // [kRingSlots][kRingRows][kRingIStr], then the counters
+    constexpr int kSlot = kRingRows * kRingIStr;
+    int *filled = reinterpret_cast<int *>(ring + (size_t)kRingSlots * kSlot);
+    int *stored = filled + kRingCnt, *walked = stored + kRingCnt;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j0 = blockIdx.x * kRingCW;
+    const int npass = (npi + kRingRows - 1) / kRingRows;
+    if (threadIdx.x < 2 * kRingCnt + 1) filled[threadIdx.x] = 0;
+    __syncthreads();                                              // (the only one)
+    auto slot = [&](int p) { return ring + (size_t)(p % kRingSlots) * kSlot; };
+    if (wave == 0) {
+        // ---- the chain: lane c walks row j0 + c from the east ----
+        __builtin_amdgcn_s_setprio(3);
+        const int c = lane;
+        double acc = 0.0;
+        for (int p = 0; p < npass; ++p) {
+            ring_wait(filled + p % kRingCnt, (p / kRingCnt + 1) * kRingIFeed);
+            if (lane < kRingCW) {
+                double *rows = slot(p);
+                constexpr int BR = 14, NB = kRingRows / BR;       // (as in the scan along j)
+                double t[2][BR];
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+#pragma unroll
+                    for (int r = 0; r < BR; ++r) t[g][r] = rows[(g * BR + r) * kRingIStr + c];
+                if (p == 0) t[0][0] = 0.0;                        // the eastern column itself is 0: its transport is not used
+#pragma unroll
+                for (int g = 0; g < NB; ++g) {
+#pragma unroll
+                    for (int r = 0; r < BR; ++r) {
+                        acc = __dadd_rn(acc, -t[g % 2][r]);         // columns past the western end hold 0
+                        t[g % 2][r] = acc;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int r = 0; r < BR; ++r) rows[(g * BR + r) * kRingIStr + c] = t[g % 2][r];
+                    if (g + 2 < NB) {
+#pragma unroll
+                        for (int r = 0; r < BR; ++r) t[g % 2][r] = rows[((g + 2) * BR + r) * kRingIStr + c];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (lane == 0) ring_bump(walked);
+        }
+        return;
+    }
+    // item q = 0 .. 63 of a pass: row q / 2 of the workgroup, columns 64 (q % 2) + lane of the pass (the second half: 48)
+    auto col_of = [&](int p, int q) { return npi - 1 - (p * kRingRows + (q & 1) * 64 + lane); };
+    if (wave <= kRingIFeed) {
+        // ---- the loaders ----
+        const int lw = wave - 1;
+        auto fetch = [&](double (&x)[kRingILoads], int p) {       // (branch-free: clamped addresses, the value dropped in put)
+#pragma unroll
+            for (int r = 0; r < kRingILoads; ++r) {
+                const int q = lw * kRingILoads + r;
+                const int j = min(j0 + (q >> 1), npj - 1), i = min(max(col_of(p, q), 0), npi - 1);
+                x[r] = __builtin_nontemporal_load(dtrp + (int64_t)j * npi + i);
+            }
+        };
+        auto put = [&](const double (&x)[kRingILoads], int p) {
+            if (p >= npass) return;
+            if (p >= kRingSlots) ring_wait(stored + (p - kRingSlots) % kRingCnt, ((p - kRingSlots) / kRingCnt + 1) * kRingIDrain);
+            double *rows = slot(p);
+#pragma unroll
+            for (int r = 0; r < kRingILoads; ++r) {
+                const int q = lw * kRingILoads + r, step = (q & 1) * 64 + lane;
+                if (step < kRingRows) rows[step * kRingIStr + (q >> 1)] = (j0 + (q >> 1) < npj && col_of(p, q) >= 0) ? x[r] : 0.0;
+            }
+            if (lane == 0) ring_bump(filled + p % kRingCnt);
+        };
+        double x[kRingAhead][kRingILoads];
+#pragma unroll
+        for (int q = 0; q < kRingAhead; ++q) fetch(x[q], q);
+        for (int p = 0; p < npass; p += kRingAhead) {
+#pragma unroll
+            for (int d = 0; d < kRingAhead; ++d) { put(x[d], p + d); fetch(x[d], p + d + kRingAhead); }
+        }
+        return;
+    }
+    // ---- the storers ----
+    const int dw = wave - 1 - kRingIFeed;
+    for (int p = 0; p < npass; ++p) {
+        ring_wait(walked, p + 1);
+        const double *rows = slot(p);
+        constexpr int kMaxItems = (2 * kRingCW + kRingIDrain - 1) / kRingIDrain;
+        double y[kMaxItems];
+#pragma unroll
+        for (int r = 0; r < kMaxItems; ++r) {
+            const int q = dw + r * kRingIDrain, step = (q & 1) * 64 + lane;
+            y[r] = (q < 2 * kRingCW && step < kRingRows) ? rows[step * kRingIStr + (q >> 1)] : 0.0;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);                       // lgkmcnt(0): the slot has been read into registers ...
+        if (lane == 0) ring_bump(stored + p % kRingCnt);          // ... and may be written again
+#pragma unroll
+        for (int r = 0; r < kMaxItems; ++r) {
+            const int q = dw + r * kRingIDrain, step = (q & 1) * 64 + lane, i = col_of(p, q), j = j0 + (q >> 1);
+            if (q < 2 * kRingCW && step < kRingRows && i >= 0 && j < npj) dpsi[(int64_t)j * npi + i] = y[r];
+        }
+    }
+}
+
 // cdfpsi V path, src/cdfpsi.f90:380-383: dpsiv(npi,:) = 0 ; dpsiv(ji,:) = dpsiv(ji+1,:) - dtrpv(ji,:),
 // ji = npi-1..1.  The scan runs along i, the contiguous axis: one wave takes 64 rows, stages a
 // 64 x 64 tile through LDS with coalesced row segments, each lane scans its own row of the tile
@@ -1048,7 +1160,15 @@ int cdft_psi_integrate(cdft_psi_plan *p, const float *zu, const float *e2u, cons
     };
     if (lv) {                                            // the i-scan stays inside a row: local to a row block
         CDFT_TRY(integrate(zv, e1v, e3v, p->sv, p->se3v, p->sm1, p->dtrpv));
-        hipLaunchKernelGGL(psi_scan_i_kernel, dim3((p->npj + 63) / 64), dim3(64), 0, st, p->dtrpv, p->dpsiv, p->npi, p->npj);
+        const char *ew = getenv("CDFT_PSI_SCAN_WAVE");            // (1: the one-wave-per-64-rows scan, tests compare the two)
+        if (ew && ew[0] == '1') {
+            hipLaunchKernelGGL(psi_scan_i_kernel, dim3((p->npj + 63) / 64), dim3(64), 0, st, p->dtrpv, p->dpsiv, p->npi, p->npj);
+        } else {
+            const size_t shmem = sizeof(double) * kRingSlots * kRingRows * kRingIStr + sizeof(int) * (2 * kRingCnt + 2);
+            CDFT_HIP(hipFuncSetAttribute((const void *)psi_scan_i_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+            hipLaunchKernelGGL(psi_scan_i_ring_kernel, dim3((p->npj + kRingCW - 1) / kRingCW), dim3((1 + kRingIFeed + kRingIDrain) * 64), shmem, st,
+                               p->dtrpv, p->dpsiv, p->npi, p->npj);
+        }
         CDFT_LAUNCH_CHECK();
     }
     if (lu) CDFT_TRY(integrate(zu, e2u, e3u, p->su, p->se3u, p->sm0, p->dtrpu));
