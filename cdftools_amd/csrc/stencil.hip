@@ -189,7 +189,8 @@ struct CurlArgs {
     int npi, npj, nlev, ntx, lperio;
     int band;                                 // curl_tile_kernel: rows of a band (0: the whole eighth of an XCD), see there
     void *out;                                // (npi,npj,nlev) r8 or r4
-    double *work;                             // F-point curl for the T-point pass
+    float *work;                              // F-point curl for the T-point pass: the r4 value the reference widens into dl_rotn (:282), widened when read
+    uint8_t *fmk;                             // ... and its fmask (0 / 1), so that the T-point pass does not form it again from u and v
 };
 
 // one F point from scalar loads (periodic column, T-point pass); un/vn point at the level
@@ -262,6 +263,7 @@ __global__ void __launch_bounds__(kThreads) curl_kernel(CurlArgs a) {
         if (nv <= 0) continue;
         const float vnx = lv[buf][tid + 1];
         double r[4];
+        uint8_t fk[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int i = i0 + c;
@@ -271,6 +273,7 @@ __global__ void __launch_bounds__(kThreads) curl_kernel(CurlArgs a) {
                     const float ve = (c < 3) ? v[c < 3 ? c + 1 : 3] : vnx, ee = (c < 3) ? e2v[c < 3 ? c + 1 : 3] : enx;
                     float f = __fmul_rn(__fmul_rn(__fmul_rn(u[c], un1[c]), v[c]), ve);
                     f = (f != 0.f) ? 1.f : 0.f;
+                    fk[c] = (uint8_t)f;
                     const float num = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(ee, ve), -__fmul_rn(e2v[c], v[c])),
                                                           -__fmul_rn(e1un[c], un1[c])), __fmul_rn(e1u[c], u[c]));
                     val = __fdiv_rn(__fmul_rn(num, f), den[c]);
@@ -279,7 +282,7 @@ __global__ void __launch_bounds__(kThreads) curl_kernel(CurlArgs a) {
                 }
             }
             r[c] = (double)val;
-            if (KEEP && c < nv) a.work[(int64_t)lev * nij + p2 + c] = r[c];
+            if (KEEP && c < nv) { a.work[(int64_t)lev * nij + p2 + c] = val; a.fmk[(int64_t)lev * nij + p2 + c] = fk[c]; }
             if (!KEEP && a.ff && ffv[c] != 0.0) r[c] = __ddiv_rn(r[c], ffv[c]);   // -overf, :299-301
         }
         if (!KEEP) store4((OUT *)a.out + (int64_t)lev * nij + p2, nv, r);
@@ -376,15 +379,18 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6
                 if (halo) vnx = q[k].hv;
                 if (act) {
                     double res[4];
+                    uint8_t fk[4];
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         const int i = i0 + c;
                         float val = 0.f;                                          // drotn(:,:) = 0.d0, :275
+                        fk[c] = 0;
                         if (north) {
                             if (i < a.npi - 1) {
                                 const float ve = (c < 3) ? v[c < 3 ? c + 1 : 3] : vnx, ee = (c < 3) ? e2v[c < 3 ? c + 1 : 3] : enx;
                                 float f = __fmul_rn(__fmul_rn(__fmul_rn(u[c], un1[c]), v[c]), ve);
                                 f = (f != 0.f) ? 1.f : 0.f;
+                                fk[c] = (uint8_t)f;
                                 const float num = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(ee, ve), -__fmul_rn(e2v[c], v[c])),
                                                                       -__fmul_rn(e1un[c], un1[c])), __fmul_rn(e1u[c], u[c]));
                                 val = __fdiv_rn(__fmul_rn(num, f), den[c]);
@@ -393,7 +399,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6
                             }
                         }
                         res[c] = (double)val;
-                        if (KEEP) a.work[(int64_t)lev * nij + p2 + c] = res[c];
+                        if (KEEP) { a.work[(int64_t)lev * nij + p2 + c] = val; a.fmk[(int64_t)lev * nij + p2 + c] = fk[c]; }
                         if (!KEEP && a.ff) {                                          // -overf, :299-301 (ff re-read per level:
                             const double f = a.ff[p2 + c];                            // 8 registers fewer for every other run)
                             if (f != 0.0) res[c] = __ddiv_rn(res[c], f);
@@ -449,37 +455,62 @@ int resident_workgroups(K kernel, int threads) {
 }
 
 // -T: 4-point mean of the F-point curl to T points with the product of the 4 fmask (:286-297).
-// fmask(npiglo,:) and fmask(:,npjglo) are never assigned by the reference; taken as 0.
+// fmask(npiglo,:) and fmask(:,npjglo) are never assigned by the reference; taken as 0 (the F-point pass writes 0 there).
+// A lane takes four cells of a row: the F-point values and masks of its row and the row to the south, columns i0-1 .. i0+3,
+// are 2 x (an r4 value, a 16-byte vector; a byte, a 4-byte word) -- one thread per cell with its four masks formed again from
+// u and v and the F-point values kept in r8 was 21 loads per cell and 16 bytes more: 1.0 ms at eORCA025.
 template <typename OUT>
-__global__ void curl_tpoint_kernel(CurlArgs a) {
+__global__ void __launch_bounds__(256) curl_tpoint_kernel(CurlArgs a) {
     const int64_t nij = (int64_t)a.npi * a.npj;
-    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= nij * a.nlev) return;
-    const int lev = (int)(g / nij);
-    const int64_t p = g - (int64_t)lev * nij;
-    const int j = (int)(p / a.npi), i = (int)(p - (int64_t)j * a.npi);
-    const float *un = a.un + (int64_t)lev * nij, *vn = a.vn + (int64_t)lev * nij;
-    const double *w = a.work + (int64_t)lev * nij;
-    auto fm = [&](int ii, int jj) -> float {
-        if (ii >= a.npi - 1 || jj >= a.npj - 1) return 0.f;
-        float f;
-        (void)curl_at(a, un, vn, ii, jj, &f);
-        return f;
-    };
-    auto tval = [&](int ii, int jj) -> double {                  // dl_rotn(ii,jj), ii >= 1, jj >= 1
-        const float zm = __fmul_rn(__fmul_rn(__fmul_rn(fm(ii, jj), fm(ii, jj - 1)), fm(ii - 1, jj)), fm(ii - 1, jj - 1));
-        const double s4 = __dadd_rn(__dadd_rn(__dadd_rn(w[(int64_t)jj * a.npi + ii], w[(int64_t)(jj - 1) * a.npi + ii]),
-                                              w[(int64_t)jj * a.npi + ii - 1]), w[(int64_t)(jj - 1) * a.npi + ii - 1]);
+    const int i0 = 4 * (blockIdx.x * blockDim.x + threadIdx.x), j = blockIdx.y, lev = blockIdx.z;
+    if (i0 >= a.npi) return;
+    const float *w = a.work + (int64_t)lev * nij;
+    const uint8_t *fk = a.fmk + (int64_t)lev * nij;
+    OUT *out = (OUT *)a.out + (int64_t)lev * nij + (int64_t)j * a.npi;
+    auto tval = [&](int ii, int jj) -> double {                  // dl_rotn(ii,jj), ii >= 1, jj >= 1: one cell from scalar loads
+        const int64_t q = (int64_t)jj * a.npi + ii;
+        const float zm = __fmul_rn(__fmul_rn(__fmul_rn((float)fk[q], (float)fk[q - a.npi]), (float)fk[q - 1]), (float)fk[q - a.npi - 1]);
+        const double s4 = __dadd_rn(__dadd_rn(__dadd_rn((double)w[q], (double)w[q - a.npi]), (double)w[q - 1]), (double)w[q - a.npi - 1]);
         return __dmul_rn(__dmul_rn(0.25, s4), (double)zm);
     };
-    double r = 0.0;
-    if (i >= 1 && j >= 1) r = tval(i, j);
-    else if (i == 0 && a.lperio && j >= 1 && a.npi > 1) r = tval(a.npi - 1, j);   // dl_rotn(1,:) = dl_rotn(npiglo,:)
-    if (a.ff) {
-        const double f = a.ff[p];
-        if (f != 0.0) r = __ddiv_rn(r, f);
+    double r[4] = {0.0, 0.0, 0.0, 0.0};
+    const int nv = min(4, a.npi - i0);
+    if (j >= 1) {
+        if (nv == 4 && i0 >= 1) {                                 // the usual lane: columns i0-1 .. i0+3 of rows j and j-1
+            double wn[5], ws[5];
+            float fn[5], fs[5];
+            const int64_t q = (int64_t)j * a.npi + i0;
+            typedef uint32_t u32u __attribute__((aligned(1)));
+            wn[0] = (double)w[q - 1]; ws[0] = (double)w[q - a.npi - 1];
+            const f4u n4 = *reinterpret_cast<const f4u *>(w + q), s4v = *reinterpret_cast<const f4u *>(w + q - a.npi);
+            wn[1] = (double)n4.x; wn[2] = (double)n4.y; wn[3] = (double)n4.z; wn[4] = (double)n4.w;
+            ws[1] = (double)s4v.x; ws[2] = (double)s4v.y; ws[3] = (double)s4v.z; ws[4] = (double)s4v.w;
+            const uint32_t bn = *reinterpret_cast<const u32u *>(fk + q), bs = *reinterpret_cast<const u32u *>(fk + q - a.npi);
+            fn[0] = (float)fk[q - 1]; fs[0] = (float)fk[q - a.npi - 1];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { fn[c + 1] = (float)((bn >> (8 * c)) & 0xffu); fs[c + 1] = (float)((bs >> (8 * c)) & 0xffu); }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {                         // the reference's order: (ii,jj), (ii,jj-1), (ii-1,jj), (ii-1,jj-1)
+                const float zm = __fmul_rn(__fmul_rn(__fmul_rn(fn[c + 1], fs[c + 1]), fn[c]), fs[c]);
+                const double s4 = __dadd_rn(__dadd_rn(__dadd_rn(wn[c + 1], ws[c + 1]), wn[c]), ws[c]);
+                r[c] = __dmul_rn(__dmul_rn(0.25, s4), (double)zm);
+            }
+        } else {                                                  // the first lane of a row, the last one of a row that is not a multiple of 4
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int i = i0 + c;
+                if (c >= nv) continue;
+                if (i >= 1) r[c] = tval(i, j);
+                else if (a.lperio && a.npi > 1) r[c] = tval(a.npi - 1, j);    // dl_rotn(1,:) = dl_rotn(npiglo,:)
+            }
+        }
     }
-    ((OUT *)a.out)[g] = (OUT)r;
+    if (a.ff) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c < nv) { const double f = a.ff[(int64_t)j * a.npi + i0 + c]; if (f != 0.0) r[c] = __ddiv_rn(r[c], f); }
+    }
+    store4(out + i0, nv, r);
 }
 
 // e1f*e2f in r4, the divisor of src/cdfcurl.f90:276-282, once per mesh
@@ -663,10 +694,11 @@ int cdft_curl_compute(cdft_curl_plan *p, const float *un, const float *vn, int n
     CurlArgs a;
     a.un = (const float *)du; a.vn = (const float *)dv; a.e1u = p->e1u; a.e2v = p->e2v; a.e1f = p->e1f; a.e2f = p->e2f; a.den = p->den;
     a.ff = p->ff; a.npi = p->npi; a.npj = p->npj; a.nlev = nlev;
-    a.lperio = p->lperio; a.out = dout; a.work = nullptr; a.band = 0;
+    a.lperio = p->lperio; a.out = dout; a.work = nullptr; a.fmk = nullptr; a.band = 0;
     if (ltpoint) {
-        CDFT_TRY(p->work.reserve(n3 * 8));
-        a.work = (double *)p->work.ptr;
+        CDFT_TRY(p->work.reserve(n3 * 5));
+        a.work = (float *)p->work.ptr;
+        a.fmk = (uint8_t *)p->work.ptr + n3 * 4;
     }
     const char *env = getenv("CDFT_CURL_ROWTILE");                // the one-row-tile kernel (tests compare the two)
     if (p->npi >= 4 && !(env && env[0] == '1')) {
@@ -714,7 +746,7 @@ int cdft_curl_compute(cdft_curl_plan *p, const float *un, const float *vn, int n
     }
     if (ltpoint) {
         CDFT_LAUNCH_CHECK();
-        const dim3 g2((unsigned)((n3 + 255) / 256));
+        const dim3 g2((unsigned)((p->npi + 1023) / 1024), (unsigned)p->npj, (unsigned)nlev);
         if (out_is_r8) hipLaunchKernelGGL((curl_tpoint_kernel<double>), g2, dim3(256), 0, st, a);
         else           hipLaunchKernelGGL((curl_tpoint_kernel<float>), g2, dim3(256), 0, st, a);
     }
