@@ -39,7 +39,6 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kVPT     = 2;     // vectors per lane of the scalar path; the 16-byte path takes 4.  The plan's partial sums are sized for 2
 constexpr int kMaxNB   = 8;
-constexpr int kRedStride = 65;  // doubles between the rows of the reduction scratch (64 lanes + 1: the reads of a sum's 8 lanes fall on different banks)
 
 struct MeanArgs {
     const float *e1, *e2, *e3, *e31d, *mask, *zv;
@@ -108,7 +107,7 @@ __global__ void __launch_bounds__(kThreads) mean_level_kernel(MeanArgs a) {
     typedef typename LN::T T;
     constexpr int G = LN::G, W = LN::W;                // groups per vector, cells per group
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = kThreads / 64;
-    double *red = wsum + a.redoff;                     // [nwaves][8][kRedStride]
+    double *red = wsum + a.redoff;                     // [nwaves][8][kSum8Stride] (reduce.hpp)
     (void)red;
     const int64_t blk = xcd_band(a.band);              // (common.hpp)
     int64_t q[VPT];
@@ -256,24 +255,15 @@ __global__ void __launch_bounds__(kThreads) mean_level_kernel(MeanArgs a) {
             // Two basins' four sums at a time through LDS: lane l adds 8 lanes' values of sum l / 8, three DPP steps add the 8
             // lanes of a sum -- 33 instructions for 8 wave sums instead of 8 x 20 (five basins: 15 sums per level and wave were
             // as much work as the level's cells).  A fixed order, like the DPP tree it replaces.
-            double *scr = red + wave * (8 * kRedStride);
+            double *scr = red + wave * (8 * kSum8Stride);
 #pragma unroll
             for (int b0 = 0; b0 < NB; b0 += 2) {
+                double v8[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) scr[j * kRedStride + lane] = (b0 + (j >> 2) < NB) ? s[(b0 + (j >> 2)) < NB ? b0 + (j >> 2) : 0][j & 3] : 0.0;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const int n = lane >> 3, l8 = lane & 7;       // sum n of the batch, lanes 8 l8 .. 8 l8 + 7 of it
-                double t = 0.0;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) t += scr[n * kRedStride + l8 * 8 + i];
-                t = dpp_add<0xb1, 0xf>(t);                    // quad_perm:[1,0,3,2]
-                t = dpp_add<0x4e, 0xf>(t);                    // quad_perm:[2,3,0,1]
-                t = dpp_add<0x141, 0xf>(t);                   // row_half_mirror: the 8 lanes of a sum hold its total
-                const int b = b0 + (n >> 2), c = n & 3;
-                if (l8 == 0 && b < a.nb && b < NB) wsum[((PARK ? wave * a.npk + k : wave) * a.nb + b) * 4 + c] = (c < 3 || a.form == CDFT_MEAN_FORM_MEAN) ? t : 0.0;
-                __builtin_amdgcn_wave_barrier();              // scr is written again
+                for (int j = 0; j < 8; ++j) v8[j] = (b0 + (j >> 2) < NB) ? s[(b0 + (j >> 2)) < NB ? b0 + (j >> 2) : 0][j & 3] : 0.0;
+                const double t = wave_sum8(v8, scr, lane);        // (reduce.hpp: the total of sum n in the lanes 8 n .. 8 n + 7)
+                const int n = lane >> 3, b = b0 + (n >> 2), c = n & 3;
+                if ((lane & 7) == 0 && b < a.nb && b < NB) wsum[((PARK ? wave * a.npk + k : wave) * a.nb + b) * 4 + c] = (c < 3 || a.form == CDFT_MEAN_FORM_MEAN) ? t : 0.0;
             }
         } else {
 #pragma unroll
@@ -451,7 +441,7 @@ int cdft_mean_compute(cdft_mean_plan *p, const float *zv, int in_space, double *
     const bool park = park_bytes <= 48 * 1024 && !getenv("CDFT_MEAN_NOPARK");     // (A/B hook: a barrier pair per level)
     const size_t wsum_bytes = park ? park_bytes : (size_t)(kThreads / 64) * nq * sizeof(double);
     a.redoff = (int)(wsum_bytes / sizeof(double));
-    const size_t shmem = wsum_bytes + (p->nb >= 2 ? (size_t)(kThreads / 64) * 8 * kRedStride * sizeof(double) : 0);
+    const size_t shmem = wsum_bytes + (p->nb >= 2 ? (size_t)(kThreads / 64) * 8 * kSum8Stride * sizeof(double) : 0);
     const bool full = p->e31d != nullptr;
 #define CDFT_MEAN4(NBC, PK, M8, IB) do { \
         if (full && vpt == 4) hipLaunchKernelGGL((mean_level_kernel<4, true, NBC, PK, 4, M8, IB>), grid, block, shmem, st, a); \

@@ -296,6 +296,78 @@ mhst_zonal_bits_kernel(const double *__restrict__ dtrph, const double *__restric
     }
 }
 
+// cdfmhst -Zdim from a VT file: the running totals after every level (src/cdfmhst.f90:332-367 inside the level loop).  One
+// workgroup (256 threads, 512 for rows beyond 1536 cells) = one row jj for ALL levels: a thread keeps the two running r8 sums of
+// its cells (i = tid, tid + T, ...: at most 9 -- 17 per thread of 256, or 5 per thread of 1024 with their 128 registers, went to
+// scratch memory at eORCA12: 32 ms) in
+// registers, adds level k exactly as vint_kernel does, and the row's zonal sums of the totals so far -- every basin, heat
+// and salt -- leave through wave_sum8 and one barrier per level.  (Until round 4: a vertical-integral launch and a zonal
+// launch per level with the running sums going through memory, 61 bytes per cell and level: 2.3 ms at eORCA025.)
+template <int NC, bool FULL, int T>
+__global__ void __launch_bounds__(T)
+mhst_zdim_kernel(const float *__restrict__ vt, const float *__restrict__ vs, const float *__restrict__ e1v, const float *__restrict__ e3v,
+                 const float *__restrict__ e31d, const uint8_t *__restrict__ bits, int npi, int npj, int npk, int nb,
+                 double *__restrict__ heat, double *__restrict__ salt) {
+    __shared__ double scr[T / 64][8 * kSum8Stride];
+    __shared__ double part[2][T / 64][16];
+    const int jj = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t nij = (int64_t)npi * npj, row = (int64_t)jj * npi;
+    float m[NC];
+    unsigned bb[NC];
+    double s0[NC], s1[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int i = tid + c * T;
+        const bool in = i < npi;
+        m[c] = in ? e1v[row + i] : 0.f;
+        bb[c] = in ? bits[row + i] : 0u;
+        if (in && (i == 0 || i == npi - 1)) bb[c] &= ~1u;       // basin 0 (global) runs over ji = 2 .. npi-1 (:340-367)
+        s0[c] = 0.0; s1[c] = 0.0;
+    }
+    for (int k = 0; k < npk; ++k) {
+        const int64_t base = (int64_t)k * nij + row;
+        const float e3k = FULL ? e31d[k] : 0.f;
+        float x0[NC], x1[NC], e3[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) asm volatile("" : "+v"(bb[c]));   // (the 0.d0 / 1.d0 factors are formed from the bytes at every
+                                                                    //  level: hoisted out of the loop they are 16 registers per cell)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int i = min(tid + c * T, npi - 1);       // (clamped: every load unconditional; the clamped cells have m = 0, bits = 0)
+            x0[c] = ld_stream(vt + base + i); x1[c] = ld_stream(vs + base + i);
+            e3[c] = FULL ? e3k : ld_stream(e3v + base + i);
+        }
+        double hv[8], sv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { hv[q] = 0.0; sv[q] = 0.0; }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const bool in = tid + c * T < npi;
+            // (field*metric)*e3 in r4, then widened: src/cdfmhst.f90:332-337 -- as vint_kernel<kMhstVt>
+            const double d0 = (double)__fmul_rn(__fmul_rn(x0[c], m[c]), e3[c]);
+            if (in) {
+                s0[c] = __dadd_rn(s0[c], __dmul_rn(__dmul_rn(d0, 1000.0), 4000.0));
+                s1[c] = __dadd_rn(s1[c], (double)__fmul_rn(__fmul_rn(x1[c], m[c]), e3[c]));
+            }
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {                         // as mhst_zonal_bits_kernel: h * (0.d0 | 1.d0), a thread's cells in order
+                const double zm = ((bb[c] >> b) & 1u) ? 1.0 : 0.0;
+                hv[b] += s0[c] * zm;
+                sv[b] += s1[c] * zm;
+            }
+        }
+        const double th = wave_sum8(hv, scr[wave], lane), ts = wave_sum8(sv, scr[wave], lane);
+        if ((lane & 7) == 0) { part[k & 1][wave][lane >> 3] = th; part[k & 1][wave][8 + (lane >> 3)] = ts; }
+        __syncthreads();                                          // (one per level: part is double-buffered)
+        if (tid < 16) {
+            double t = 0.0;
+            for (int w = 0; w < T / 64; ++w) t += part[k & 1][w][tid];   // waves in order
+            const int b = tid & 7;
+            if (b < nb) (tid < 8 ? heat : salt)[((int64_t)k * npj + jj) * nb + b] = t;
+        }
+    }
+}
+
 // cdfpsi U path, src/cdfpsi.f90:395-398: dpsiu(:,1) = 0 ; dpsiu(:,jj) = dpsiu(:,jj-1) - dtrpu(:,jj)
 // Row-block sharding: a block that does not hold global row 1 continues the running difference of
 // the block south of it: it starts from that block's last row (carry) and its first row is an
@@ -907,7 +979,21 @@ int cdft_mhst_compute(cdft_mhst_plan *p, const float *vt, const float *vs, const
         a.k0 = 0; a.k1 = p->npk; a.init = 1;
         CDFT_TRY(sep ? launch_vint<kMhstSep>(a, st) : launch_vint<kMhstVt>(a, st));
         CDFT_TRY(zonal(oh, os));
-    } else {                                            // -Zdim: running totals after every level
+    } else if (!sep && p->use_bits && p->npi <= 9 * 512 && !getenv("CDFT_MHST_ZDIM_LEVELS")) {
+        // -Zdim from a VT file with 0/1 masks: one kernel, a row per workgroup, the running sums in registers
+        const float *fvt = (const float *)d0, *fvs = (const float *)d1;
+        const bool full = p->e31d != nullptr;
+        const int threads = p->npi <= 6 * kThreads ? kThreads : 512, nc = (p->npi + threads - 1) / threads;
+#define CDFT_ZDIM2(NCC, TT) do { \
+            if (full) hipLaunchKernelGGL((mhst_zdim_kernel<NCC, true, TT>), dim3(p->npj), dim3(TT), 0, st, fvt, fvs, p->e1v, p->e3v, p->e31d, \
+                                         p->mbits, p->npi, p->npj, p->npk, p->nb, oh, os); \
+            else      hipLaunchKernelGGL((mhst_zdim_kernel<NCC, false, TT>), dim3(p->npj), dim3(TT), 0, st, fvt, fvs, p->e1v, p->e3v, p->e31d, \
+                                         p->mbits, p->npi, p->npj, p->npk, p->nb, oh, os); } while (0)
+        if (threads == kThreads) { if (nc <= 2) CDFT_ZDIM2(2, 256); else CDFT_ZDIM2(6, 256); }
+        else                     { if (nc <= 6) CDFT_ZDIM2(6, 512); else CDFT_ZDIM2(9, 512); }
+#undef CDFT_ZDIM2
+        CDFT_LAUNCH_CHECK();
+    } else {                                            // -Zdim: running totals after every level, a launch pair per level
         for (int k = 0; k < p->npk; ++k) {
             a.k0 = k; a.k1 = k + 1; a.init = (k == 0);
             CDFT_TRY(sep ? launch_vint<kMhstSep>(a, st) : launch_vint<kMhstVt>(a, st));
