@@ -183,7 +183,7 @@ def test_oracle_decomp_matches_numpy_restatement(npi, npj, npk, nb, teos):
 @pytest.mark.gpu
 @pytest.mark.parametrize("npi,npj,npk,nb,teos", [(24, 18, 7, 5, False), (182, 149, 31, 5, False), (31, 11, 5, 1, True),
                                                  (3, 3, 3, 5, False), (1031, 9, 6, 5, True), (130, 40, 4, 8, False)])
-def test_hip_decomp_matches_oracle(gpu, npi, npj, npk, nb, teos):
+def test_hip_decomp_matches_oracle(gpu, monkeypatch, npi, npj, npk, nb, teos):
     a = decomp_inputs(npi, npj, npk, nb, seed=npi + 7)
     plan = gpu.MocPlan(npi, npj, npk, nb)
     plan.set_mesh(a["e1v"], a["e3v"], a["ibmask"])
@@ -197,6 +197,12 @@ def test_hip_decomp_matches_oracle(gpu, npi, npj, npk, nb, teos):
     within_bounds(got2, ref2, decomp_bounds(a, teos, dmoc_sh=ref["sh"]))
     again = plan.decomp(a["zv"], a["ztemp"], a["zsal"], eos=eos)
     assert all(np.array_equal(again[k], got[k]) for k in got)            # fixed order: run-to-run identical
+    # one sigmai launch over all levels + one kernel that walks the columns (what runs) against a launch of each per level:
+    # the same statements per cell and level, the same bits
+    monkeypatch.setenv("CDFT_MOC_DECOMP_LEVELS", "1")
+    by_level = plan.decomp(a["zv"], a["ztemp"], a["zsal"], eos=eos)
+    monkeypatch.delenv("CDFT_MOC_DECOMP_LEVELS")
+    assert all(np.array_equal(by_level[k], got[k]) for k in got)
     plan.close()
 
 
