@@ -100,6 +100,16 @@ def main():
     line("cdfzonalmean -max, 1 basin", args.grid, n3, 5.0, T(lambda: p.compute(t, mean_form=True, minmax=True, device_out=True)))
     del p
 
+    # ---- the EOS members in their library forms (r8 result), the per-point reference depth, JMD94, the neutral density
+    te, se = -2 + 32 * rnd(n3), 30 + 8 * rnd(n3)
+    o8 = torch.empty(n3, dtype=torch.float64, device=dev)
+    pr = 4000 * rnd(n3)
+    for name, fn in (("sigma0, r8 result", lambda: hip.sigma0(te, se, out=o8)), ("sigmai 2000 m, r8 result", lambda: hip.sigmai(te, se, 2000.0, out=o8)),
+                     ("sigmai, reference depth per point", lambda: hip.sigmai(te, se, pref2d=pr, out=o8)),
+                     ("sigmai 2000 m, JMD94", lambda: hip.sigmai(te, se, 2000.0, eos=hip.EOS_JMD94, out=o8)),
+                     ("sigmantr", lambda: hip.sigmai(te, se, 0.0, eos=hip.EOS_NTR, out=o8))):
+        line(name, args.grid, n3, 16.0, T(fn), "T 4 + S 4 + out 8 B per point; bound by the r8 vector pipeline, not by HBM")
+
 
 if __name__ == "__main__":
     main()
