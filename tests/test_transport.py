@@ -217,6 +217,35 @@ def test_hip_mhst_matches_oracle(gpu, npi, npj, npk, nb):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("npi,npj,npk,nb", [(2000, 5, 4, 5), (4322, 4, 3, 5), (1537, 3, 2, 1), (300, 7, 5, 8), (4700, 3, 2, 2)])
+def test_hip_mhst_zdim_one_kernel_against_the_level_by_level_launches(gpu, monkeypatch, npi, npj, npk, nb):
+    """-Zdim from a VT file runs as ONE kernel (a row per workgroup of 256 or 512 threads, the running sums in registers;
+    rows beyond 4608 cells keep the launch pair per level).  Against the oracle, against the level-by-level path
+    (CDFT_MHST_ZDIM_LEVELS=1: the zonal sums are grouped differently, the same bound), with e3v and with -full."""
+    g = synth.make_grid(npi, npj, npk, seed=npi + 5)
+    t, s, _, v = tracer_fields(g, 3)
+    m = mhst_masks(g, nb)
+    vt = ((np.float32(0.5) * (t + np.roll(t, -1, axis=1))).astype(np.float32) * v).astype(np.float32)
+    vs = ((np.float32(0.5) * (s + np.roll(s, -1, axis=1))).astype(np.float32) * v).astype(np.float32)
+    plan = gpu.MhstPlan(npi, npj, npk, nb)
+    for mesh in (dict(e3v=g["e3v_0"]), dict(e31d=g["e3t_1d"])):
+        plan.set_mesh(g["e1v"], m, **mesh)
+        ref = oracle_tools.mhst(g["e1v"], m, vt=vt, vs=vs, zdim=True, **mesh)
+        bound = oracle_tools.mhst(g["e1v"], m, vt=np.abs(vt), vs=np.abs(vs), zdim=True, **mesh)
+        got = plan.compute(vt=vt, vs=vs, zdim=True)
+        monkeypatch.setenv("CDFT_MHST_ZDIM_LEVELS", "1")
+        lev = plan.compute(vt=vt, vs=vs, zdim=True)
+        monkeypatch.delenv("CDFT_MHST_ZDIM_LEVELS")
+        for k in (0, 1):
+            assert np.all(np.abs(got[k] - ref[k]) <= 1e-13 * bound[k] + 1e-300)
+            assert np.all(np.abs(lev[k] - ref[k]) <= 1e-13 * bound[k] + 1e-300)
+            assert np.array_equal(plan.compute(vt=vt, vs=vs, zdim=True)[k], got[k])       # run-to-run identical
+        flat = plan.compute(vt=vt, vs=vs)                                               # the last level of -Zdim = the totals
+        for k in (0, 1):
+            assert np.all(np.abs(got[k][-1] - flat[k]) <= 1e-13 * bound[k][-1] + 1e-300)
+
+
+@pytest.mark.gpu
 def test_hip_mhst_packed_masks_equal_the_r4_masks_bitwise(gpu, monkeypatch):
     """0/1 basin masks are packed to a byte per cell for the zonal sums; CDFT_MHST_R4MASKS=1 keeps the r4 masks.  Same
     products (x*1.d0, x*0.d0), same order: identical bits, a NaN under a zero mask included (0*NaN = NaN in the reference's
