@@ -137,7 +137,8 @@ __global__ void zonal_bits_kernel(const float *__restrict__ bmask, uint8_t *__re
 // each basin only selects: bit-identical terms to the general kernel.  A workgroup owns a row jj for all
 // levels; every thread keeps the surface and the basin bits of its M cells (i = tid, tid+T, ...) in
 // registers and streams the field and its mask past them: 8 bytes per cell and level from HBM.
-template <int NB, int M, bool MEAN, bool MINMAX, int T>
+// M8: the level mask as one byte per cell (it holds only 0 and 1: the same m * z products), 5 bytes per cell and level instead of 8
+template <int NB, int M, bool MEAN, bool MINMAX, int T, bool M8>
 __global__ void __launch_bounds__(T) zonal_row_fast_kernel(ZonalArgs2 a, const uint8_t *__restrict__ bits,
                                                             int *__restrict__ rowflag) {
     extern __shared__ double lds[];                     // [nlev][nwaves][NB][4]
@@ -159,7 +160,8 @@ __global__ void __launch_bounds__(T) zonal_row_fast_kernel(ZonalArgs2 a, const u
 #pragma unroll
         for (int m = 0; m < M; ++m) {
             const int i = min((int)threadIdx.x + m * T, a.npi - 1);   // clamped: cells past the row have no bit set
-            z[m] = ld_stream(zv + i); mk[m] = ld_stream(mv + i);
+            z[m] = ld_stream(zv + i);
+            mk[m] = M8 ? (float)ld_stream(a.mask8 + (int64_t)k * nij + r2 + i) : ld_stream(mv + i);
         }
     };
     fetch(zc, mc, 0);
@@ -225,9 +227,15 @@ template <int NB, int M, int T>
 int launch_fast(const ZonalArgs2 &a, const uint8_t *bits, int *rowflag, bool mean, bool minmax, hipStream_t st) {
     const size_t shmem = (size_t)a.nlev * (T / 64) * NB * 4 * sizeof(double);
     const dim3 grid(a.npj), block(T);
-    if (mean && minmax)  hipLaunchKernelGGL((zonal_row_fast_kernel<NB, M, true, true, T>), grid, block, shmem, st, a, bits, rowflag);
-    else if (mean)       hipLaunchKernelGGL((zonal_row_fast_kernel<NB, M, true, false, T>), grid, block, shmem, st, a, bits, rowflag);
-    else                 hipLaunchKernelGGL((zonal_row_fast_kernel<NB, M, false, false, T>), grid, block, shmem, st, a, bits, rowflag);
+    if (a.mask8) {
+        if (mean && minmax)  hipLaunchKernelGGL((zonal_row_fast_kernel<NB, M, true, true, T, true>), grid, block, shmem, st, a, bits, rowflag);
+        else if (mean)       hipLaunchKernelGGL((zonal_row_fast_kernel<NB, M, true, false, T, true>), grid, block, shmem, st, a, bits, rowflag);
+        else                 hipLaunchKernelGGL((zonal_row_fast_kernel<NB, M, false, false, T, true>), grid, block, shmem, st, a, bits, rowflag);
+    } else {
+        if (mean && minmax)  hipLaunchKernelGGL((zonal_row_fast_kernel<NB, M, true, true, T, false>), grid, block, shmem, st, a, bits, rowflag);
+        else if (mean)       hipLaunchKernelGGL((zonal_row_fast_kernel<NB, M, true, false, T, false>), grid, block, shmem, st, a, bits, rowflag);
+        else                 hipLaunchKernelGGL((zonal_row_fast_kernel<NB, M, false, false, T, false>), grid, block, shmem, st, a, bits, rowflag);
+    }
     CDFT_LAUNCH_CHECK();
     return CDFT_OK;
 }
