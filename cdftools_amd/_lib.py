@@ -51,10 +51,12 @@ SIGNATURES = {
     "cdft_shard_get_collective": (_i, [C.POINTER(_i)]),
     "cdft_host_alloc": (_i, [_pvp, _sz]),
     "cdft_host_free": (_i, [_vp]),
+    "cdft_mem_info": (_i, [C.POINTER(_sz), C.POINTER(_sz)]),
     "cdft_feed_create": (_i, [_pvp, _sz, _i]),
     "cdft_feed_resize": (_i, [_vp, _sz, _i]),
     "cdft_feed_slot": (_i, [_vp, _pvp, C.POINTER(_sz)]),
     "cdft_feed_push": (_i, [_vp, _vp, _sz, _sz]),
+    "cdft_feed_push_rows": (_i, [_vp, _vp, _sz, _sz, _sz, _sz]),
     "cdft_feed_stream": (_i, [_vp, _pvp]),
     "cdft_feed_wait": (_i, [_vp]),
     "cdft_feed_destroy": (_i, [_vp]),
@@ -74,6 +76,11 @@ SIGNATURES = {
     "cdft_moc_reserve": (_i, [_vp, _i, _vp]),
     "cdft_moc_stage": (_i, [_vp, _vp, _i64, _i, _i, _vp]),
     "cdft_moc_compute_staged": (_i, [_vp, _vp, _i, _vp]),
+    "cdft_moc_stage_open": (_i, [_vp, _i, _vp]),
+    "cdft_moc_stage_dest": (_i, [_vp, _i, _i, _pvp, C.POINTER(_sz)]),
+    "cdft_moc_stage_close": (_i, [_vp]),
+    "cdft_moc_release_staged": (_i, [_vp]),
+    "cdft_moc_stats": (_i, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "cdft_moc_stage_rows": (_i, [_vp, _vp, _i64, _i64, _i, _i, _vp]),
     "cdft_moc_compute_pitched": (_i, [_vp, _vp, _i64, _i64, _i, _vp, _i, _vp]),
     "cdft_moc_destroy": (_i, [_vp]),

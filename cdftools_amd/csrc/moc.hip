@@ -56,6 +56,8 @@ struct cdft_moc_plan {
     int64_t pool_P = 0;        // slot length (elements)
     int pool_npt = 0;          // records the pool is laid out for (0: nothing staged in it)
     bool pool_w = false;       // the weights of the current mesh are in the pool
+    int open_npt = 0;          // cdft_moc_stage_open ... _close: records being written into the pool by the caller's own copies
+    int64_t n_launch = 0, n_launch_rec = 0;   // zonal launches so far and the records they covered (cdft_moc_stats)
 };
 
 static int moc_compute_on(cdft_moc_plan *p, const float *d_zv, int64_t rec_stride, int npt, double *dmoc, int dmoc_space,
@@ -436,6 +438,7 @@ static int zonal_launch(cdft_moc_plan *p, const float *w, int64_t w_row, const f
     else if (p->nbasins <= 5) CDFT_TRY(launch_zonal_nb5(a, k, v, aligned, md, st));
     else                      CDFT_TRY(launch_zonal_nb8(a, k, v, aligned, md, st));
     if (ev1) CDFT_HIP(hipEventRecord(ev1, st));
+    p->n_launch += 1; p->n_launch_rec += npt;
 
     return CDFT_OK;
 }
@@ -605,8 +608,7 @@ int cdft_moc_compute(cdft_moc_plan *p, const float *zv, int64_t rec_stride, int 
                     npt, (long long)rec_stride, (long long)n3);
     if (p->sh) {                                                                 // any memory spaces; returns when done
         if (zv_space == CDFT_MEM_DEVICE) CDFT_HIP(hipStreamSynchronize(as_stream(stream)));
-        p->staged_npt = 0;                                   // (the blocks' pools now hold THIS call's records)
-        return shard::moc_compute(*p->sh, zv, rec_stride, npt, dmoc);
+        return shard::moc_compute(*p->sh, zv, rec_stride, npt, dmoc);   // (dense arrays per block: the blocks' pools are not touched)
     }
     hipStream_t st = as_stream(stream);
     const void *d_zv;
@@ -703,12 +705,15 @@ static int pool_prepare(cdft_moc_plan *p, int npt, hipStream_t st) {
 int cdft_moc_reserve(cdft_moc_plan *p, int npt, void *stream) {
     if (!p || npt < 1) return fail(CDFT_ERR_ARG, "cdft_moc_reserve: bad argument");
     if (p->sh) {
-        for (size_t b = 0; b < p->sh->part.size(); ++b) {
-            CDFT_HIP(hipSetDevice(p->sh->dev[b]));
-            CDFT_TRY(cdft_moc_reserve((cdft_moc_plan *)p->sh->part[b], npt, p->sh->st[b]));
-            CDFT_HIP(hipStreamSynchronize(p->sh->st[b]));
+        int cur = 0, rc = CDFT_OK;
+        (void)hipGetDevice(&cur);
+        for (size_t b = 0; b < p->sh->part.size() && rc == CDFT_OK; ++b) {
+            if (hipSetDevice(p->sh->dev[b]) != hipSuccess) { rc = fail(CDFT_ERR_HIP, "cdft_moc_reserve: hipSetDevice(%d) failed", p->sh->dev[b]); break; }
+            rc = cdft_moc_reserve((cdft_moc_plan *)p->sh->part[b], npt, p->sh->st[b]);
+            if (rc == CDFT_OK && hipStreamSynchronize(p->sh->st[b]) != hipSuccess) rc = fail(CDFT_ERR_HIP, "cdft_moc_reserve: stream of block %zu", b);
         }
-        return CDFT_OK;
+        (void)hipSetDevice(cur);
+        return rc;
     }
     if (!pool_wanted()) return CDFT_OK;
     return pool_layout(p, npt, as_stream(stream));
@@ -728,7 +733,7 @@ int cdft_moc_stage(cdft_moc_plan *p, const float *zv, int64_t rec_stride, int np
     }
     if (!p->mesh_set) return fail(CDFT_ERR_STATE, "cdft_moc_stage: cdft_moc_set_mesh has not succeeded (the weights are staged with the records)");
     hipStream_t st = as_stream(stream);
-    p->staged = nullptr; p->staged_npt = 0;
+    p->staged = nullptr; p->staged_npt = 0; p->open_npt = 0;
     if (!pool_wanted()) {
         const void *d_zv;
         CDFT_TRY(to_device(zv, ((size_t)(npt - 1) * rec_stride + n3) * sizeof(float), zv_space, p->st_zv, st, &d_zv));
@@ -762,6 +767,68 @@ int cdft_moc_stage_rows(cdft_moc_plan *p, const float *zv, int64_t rec_stride, i
             CDFT_TRY(pool_put(p, 1 + t, (int64_t)k * p->npj, zv + (int64_t)t * rec_stride + (int64_t)k * lev_stride, p->npi, p->npj, st));
     if (zv_space == CDFT_MEM_HOST) CDFT_HIP(hipStreamSynchronize(st));
     p->staged_npt = npt;
+    return CDFT_OK;
+}
+
+// The caller writes the records into the pool itself (a host feed whose H2D copies ARE the staging): _open lays the pool out
+// and brings the weights in, _dest says where record t's rows start and how far apart they lie, _close declares them staged.
+int cdft_moc_stage_open(cdft_moc_plan *p, int npt, void *stream) {
+    TraceRange trace_("cdft_moc_stage_open");
+    if (!p || npt < 1) return fail(CDFT_ERR_ARG, "cdft_moc_stage_open: bad argument");
+    if (p->sh) return fail(CDFT_ERR_STATE, "cdft_moc_stage_open: single-device plans only (a sharded plan cuts the domain itself: cdft_moc_stage)");
+    if (!p->mesh_set) return fail(CDFT_ERR_STATE, "cdft_moc_stage_open: cdft_moc_set_mesh has not succeeded (the weights are staged with the records)");
+    p->staged = nullptr; p->staged_npt = 0; p->open_npt = 0;
+    CDFT_TRY(pool_prepare(p, npt, as_stream(stream)));
+    p->open_npt = npt;
+    return CDFT_OK;
+}
+
+int cdft_moc_stage_dest(cdft_moc_plan *p, int record, int level, void **dst, size_t *row_pitch_bytes) {
+    if (!p || !dst || !row_pitch_bytes) return fail(CDFT_ERR_ARG, "cdft_moc_stage_dest: NULL argument");
+    if (p->sh || p->open_npt < 1) return fail(CDFT_ERR_STATE, "cdft_moc_stage_dest: cdft_moc_stage_open has not succeeded");
+    if (record < 0 || record >= p->open_npt || level < 0 || level >= p->npk)
+        return fail(CDFT_ERR_ARG, "cdft_moc_stage_dest: record %d of %d, level %d of %d", record, p->open_npt, level, p->npk);
+    const int64_t R = (int64_t)(p->pool_npt + 1) * p->pool_P;
+    *dst = (float *)p->pool.ptr + (int64_t)level * p->npj * R + (int64_t)(1 + record) * p->pool_P;
+    *row_pitch_bytes = (size_t)R * 4;
+    return CDFT_OK;
+}
+
+int cdft_moc_stage_close(cdft_moc_plan *p) {
+    if (!p) return fail(CDFT_ERR_ARG, "cdft_moc_stage_close: NULL plan");
+    if (p->sh || p->open_npt < 1) return fail(CDFT_ERR_STATE, "cdft_moc_stage_close: cdft_moc_stage_open has not succeeded");
+    p->staged_npt = p->open_npt;
+    p->open_npt = 0;
+    return CDFT_OK;
+}
+
+int cdft_moc_release_staged(cdft_moc_plan *p) {
+    if (!p) return fail(CDFT_ERR_ARG, "cdft_moc_release_staged: NULL plan");
+    p->staged = nullptr; p->staged_npt = 0; p->open_npt = 0;
+    if (p->sh) {
+        int cur = 0, rc = CDFT_OK;
+        (void)hipGetDevice(&cur);
+        for (size_t b = 0; b < p->sh->part.size() && rc == CDFT_OK; ++b) {
+            if (hipSetDevice(p->sh->dev[b]) != hipSuccess) rc = fail(CDFT_ERR_HIP, "cdft_moc_release_staged: hipSetDevice(%d) failed", p->sh->dev[b]);
+            else rc = cdft_moc_release_staged((cdft_moc_plan *)p->sh->part[b]);
+        }
+        (void)hipSetDevice(cur);
+        return rc;
+    }
+    p->pool.release();
+    p->pool_npt = 0; p->pool_P = 0; p->pool_w = false;
+    return CDFT_OK;
+}
+
+int cdft_moc_stats(cdft_moc_plan *p, int64_t *zonal_launches, int64_t *records) {
+    if (!p) return fail(CDFT_ERR_ARG, "cdft_moc_stats: NULL plan");
+    int64_t nl = p->n_launch, nr = p->n_launch_rec;
+    if (p->sh) {                       // a call on a sharded plan is one launch per block: block 0 speaks for the call
+        cdft_moc_plan *q = (cdft_moc_plan *)p->sh->part[0];
+        nl = q->n_launch; nr = q->n_launch_rec;
+    }
+    if (zonal_launches) *zonal_launches = nl;
+    if (records) *records = nr;
     return CDFT_OK;
 }
 

@@ -25,6 +25,7 @@ MODULE cdffeed
   TYPE(C_PTR)         :: hfeed = C_NULL_PTR
   INTEGER(KIND=8)     :: nslot_bytes = 0
 
+  PUBLIC :: feed_moc_record
   PUBLIC :: feed_wanted, feed_open, feed_close, feed_field, feed_mask, feed_host, feed_device, feed_release, feed_sig_record, feed_mean_mesh
 
   ! feed_sig_record's slab buffers (kept from record to record): T and S of a slab in HBM, two page-locked result slabs
@@ -132,6 +133,32 @@ CONTAINS
             &         'cdft_feed_push')
     END DO
   END SUBROUTINE feed_field
+
+  SUBROUTINE feed_moc_record(cdfile, cdvar, plan, krec, kpi, kpj, kpk, ktime)
+    !! cdfmoc: levels 1 .. kpk of record ktime of the velocity file (the reference's getvar per level, src/cdfmoc.f90:357)
+    !! straight into the slots of record krec (1-based) of the plan's pool (cdft_moc_stage_open before, cdft_moc_stage_close
+    !! after): the H2D copy of a slab IS its staging, rows spread to the pool's pitch on the way (cdft_feed_push_rows).
+    CHARACTER(LEN=*), INTENT(in) :: cdfile, cdvar
+    TYPE(C_PTR),      INTENT(in) :: plan
+    INTEGER(KIND=4),  INTENT(in) :: krec, kpi, kpj, kpk, ktime
+    INTEGER(KIND=4) :: ik0, inl, inlmax
+    INTEGER(KIND=8) :: islab
+    INTEGER(C_SIZE_T) :: ibytes, ipitch
+    TYPE(C_PTR) :: pslot, pdst
+    REAL(KIND=4), POINTER :: zslab(:,:,:)
+    islab = 4_8 * kpi * kpj
+    CALL feed_size(islab, islab * kpk)
+    inlmax = INT(MAX(1_8, nslot_bytes / islab), 4)
+    DO ik0 = 1, kpk, inlmax
+       inl = MIN(inlmax, kpk - ik0 + 1)
+       CALL hip_check(cdft_feed_slot(hfeed, pslot, ibytes), 'cdft_feed_slot')
+       CALL C_F_POINTER(pslot, zslab, (/ kpi, kpj, inl /))
+       CALL readvar3d(cdfile, cdvar, zslab, ktime=ktime, kkmin=ik0)
+       CALL hip_check(cdft_moc_stage_dest(plan, INT(krec - 1, C_INT), INT(ik0 - 1, C_INT), pdst, ipitch), 'cdft_moc_stage_dest')
+       CALL hip_check(cdft_feed_push_rows(hfeed, pdst, 0_C_SIZE_T, ipitch, INT(4_8 * kpi, C_SIZE_T), INT(kpj, C_SIZE_T) * inl), &
+            &         'cdft_feed_push_rows')
+    END DO
+  END SUBROUTINE feed_moc_record
 
   SUBROUTINE feed_mask(cdfile, cdvar, pdev, kpi, kpj, kpk, ktime)
     !! a (kpi,kpj,kpk) mask as bytes into the device array pdev, the same way

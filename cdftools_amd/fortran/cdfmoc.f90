@@ -60,6 +60,12 @@ PROGRAM cdfmoc
   INTEGER(KIND=2), POINTER :: ib_d(:)
   INTEGER(KIND=8) :: nij8, n38
   LOGICAL :: lfeed
+  LOGICAL :: lpool = .FALSE.                                  ! the records of a batch go into the plan's pool: one zonal launch for all
+  INTEGER(C_SIZE_T) :: ifree, itotal
+  INTEGER(C_INT64_T) :: ilaunch, irecs
+  REAL(KIND=8) :: dl_field
+  CHARACTER(KIND=C_CHAR) :: cl_plan(512)
+  CHARACTER(LEN=512) :: cplan
   LOGICAL :: lbas, lfull = .FALSE., lchk = .FALSE., ldec = .FALSE., lrap = .FALSE., ll_teos10 = .FALSE.
   !!----------------------------------------------------------------------
   CALL ReadCdfNames()
@@ -179,6 +185,22 @@ PROGRAM cdfmoc
   CALL hip_shard(ngpu, igpus)                                ! CDFT_GPUS / CDFT_GPU_MAP: row blocks over the node's GPUs
   lfeed = feed_wanted(4_8 * npiglo * npjglo * npk) .AND. ngpu == 1 .AND. .NOT. ( ldec .OR. lfull )
   IF ( lfeed ) nbatch = 1                                 ! a record is computed on as soon as its last slab has left
+  ! ... unless the run's records fit the device beside the weights: then every slab goes from the ring straight into the
+  ! plan's pool (feed_moc_record: the H2D copy is the staging) and ONE zonal launch streams all the records of a batch past
+  ! the weights (cdft_moc_compute_staged) -- 4*(1+1/npt) bytes per cell and record instead of 8 (DESIGN 4.1).  The batch is
+  ! what HBM holds: the pool is (1 + nbatch) fields, beside the plan's weights and the mesh fields on their way through.
+  ! CDFT_MOC_BATCH=n sets it (1: the record-by-record way).
+  IF ( lfeed .AND. npt > 1 .AND. .NOT. lg_vvl ) THEN
+     CALL hip_check(cdft_mem_info(ifree, itotal), 'cdft_mem_info')
+     dl_field = 4.d0 * ( ( npiglo + 3 ) / 4 * 4 ) * REAL(npjglo, 8) * npk
+     nbatch = MIN(npt, INT(MIN(1.d6, ( 0.92d0 * REAL(ifree, 8) - 2.3d0 * dl_field ) / dl_field)) - 1)
+     CALL GET_ENVIRONMENT_VARIABLE('CDFT_MOC_BATCH', cldum)
+     IF ( LEN_TRIM(cldum) > 0 ) THEN
+        READ(cldum, *) nbatch ; nbatch = MIN(npt, nbatch)
+     ENDIF
+     lpool = nbatch >= 2
+     nbatch = MAX(1, nbatch)
+  ENDIF
   ! -decomp: V, T and S of a record go through the ring too (the mesh of the decomposition stays a host array: once per run)
   lfeed_dec = ldec .AND. .NOT. lfull .AND. ngpu == 1 .AND. feed_wanted(4_8 * npiglo * npjglo * npk)
   nij8 = INT(npiglo, 8) * npjglo ; n38 = nij8 * npk
@@ -239,6 +261,13 @@ PROGRAM cdfmoc
   ELSE
      CALL hip_check(cdft_moc_create(plan, npiglo, npjglo, npk, nbasins), 'cdft_moc_create')
   ENDIF
+  IF ( lpool ) THEN                                        ! the one large allocation first, while HBM is in one piece
+     CALL feed_open()
+     IF ( cdft_moc_reserve(plan, nbatch, feed_stream) /= CDFT_OK ) THEN
+        WRITE(0, '(a,i0,a)') ' cdfmoc: no room in HBM for a pool of ', nbatch, ' records: working record by record'
+        lpool = .FALSE. ; nbatch = 1
+     ENDIF
+  ENDIF
 
   it0 = 1
   DO WHILE ( it0 <= npt )
@@ -248,10 +277,12 @@ PROGRAM cdfmoc
         IF ( lfeed ) THEN                                ! file -> HBM through the ring, get_e3v's product on the device
            IF ( it0 == 1 ) THEN
               pd_e1v = feed_device(4 * nij8) ; pd_ib = feed_device(2 * nbasins * nij8)
-              pd_vm  = feed_device(n38)      ; pd_e3v = feed_device(4 * n38) ; pd_zv = feed_device(4 * n38)
+              pd_vm  = feed_device(n38)      ; pd_e3v = feed_device(4 * n38)
               CALL C_F_POINTER(pd_e1v, e1v_d, (/ nij8 /))   ; CALL C_F_POINTER(pd_ib, ib_d, (/ nbasins * nij8 /))
               CALL C_F_POINTER(pd_vm, ivm_d, (/ n38 /))     ; CALL C_F_POINTER(pd_e3v, e3v_d, (/ n38 /))
-              CALL C_F_POINTER(pd_zv, zv_d, (/ n38 /))
+              IF ( .NOT. lpool ) THEN                       ! (the pool route has no dense record in HBM)
+                 pd_zv = feed_device(4 * n38) ; CALL C_F_POINTER(pd_zv, zv_d, (/ n38 /))
+              ENDIF
               CALL feed_host(C_LOC(e1v), 4 * nij8, pd_e1v)
               CALL feed_host(C_LOC(ibmask), 2 * nbasins * nij8, pd_ib)
               CALL feed_mask(cn_fmsk, cn_vmask, pd_vm, npiglo, npjglo, npk)
@@ -309,7 +340,15 @@ PROGRAM cdfmoc
         CYCLE
      ENDIF
      CALL tick(5)
-     IF ( lfeed ) THEN                                    ! the record's slabs leave for HBM as they are read
+     IF ( lpool ) THEN                                    ! the batch's slabs leave for their pool slots as they are read
+        CALL hip_check(cdft_moc_stage_open(plan, nrec, feed_stream), 'cdft_moc_stage_open')
+        DO jr = 1, nrec                                   ! levels 1 .. npk-1, as the reference reads them (:357)
+           CALL feed_moc_record(cf_vfil, cn_vomecrty, plan, jr, npiglo, npjglo, npk - 1, it0 + jr - 1)
+        END DO
+        CALL hip_check(cdft_moc_stage_close(plan), 'cdft_moc_stage_close')
+        CALL tick(3)
+        CALL hip_check(cdft_moc_compute_staged(plan, dmoc, CDFT_MEM_HOST, feed_stream), 'cdft_moc_compute_staged')
+     ELSE IF ( lfeed ) THEN                               ! the record's slabs leave for HBM as they are read
         CALL feed_field(cf_vfil, cn_vomecrty, pd_zv, npiglo, npjglo, npk, ktime=it0)
         CALL tick(3)
         CALL hip_check(cdft_moc_compute(plan, zv_d, INT(n38, C_INT64_T), 1, CDFT_MEM_DEVICE, dmoc, CDFT_MEM_HOST, feed_stream), &
@@ -341,6 +380,16 @@ PROGRAM cdfmoc
      it0 = it0 + nrec
   END DO
 
+  IF ( ltiming ) THEN                                      ! which kernel read which layout, in how many launches (stderr)
+     ierr = cdft_moc_describe(plan, cl_plan, 512_C_SIZE_T)
+     ierr = cdft_moc_stats(plan, ilaunch, irecs)
+     cplan = ' '
+     DO ii = 1, 512
+        IF ( cl_plan(ii) == C_NULL_CHAR ) EXIT
+        cplan(ii:ii) = cl_plan(ii)
+     END DO
+     WRITE(0, '(a,a,a,i0,a,i0)') ' CDFT_PLAN cdfmoc: ', TRIM(cplan), ' zonal_launches=', ilaunch, ' records=', irecs
+  ENDIF
   ierr = cdft_moc_destroy(plan)
   IF ( lfeed_dec .AND. C_ASSOCIATED(pd_t) ) THEN
      CALL feed_release(pd_zv) ; CALL feed_release(pd_t) ; CALL feed_release(pd_s) ; CALL feed_close()

@@ -55,6 +55,9 @@ MODULE cdftools_hip
      INTEGER(C_INT) FUNCTION cdft_shard_get_collective(mode) BIND(C, name='cdft_shard_get_collective')
        IMPORT ; INTEGER(C_INT), INTENT(out) :: mode
      END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_mem_info(free_bytes, total_bytes) BIND(C, name='cdft_mem_info')
+       IMPORT ; INTEGER(C_SIZE_T), INTENT(out) :: free_bytes, total_bytes
+     END FUNCTION
      INTEGER(C_INT) FUNCTION cdft_host_alloc(ptr, bytes) BIND(C, name='cdft_host_alloc')
        IMPORT ; TYPE(C_PTR), INTENT(out) :: ptr ; INTEGER(C_SIZE_T), VALUE :: bytes
      END FUNCTION
@@ -72,6 +75,9 @@ MODULE cdftools_hip
      END FUNCTION
      INTEGER(C_INT) FUNCTION cdft_feed_push(feed, dst, dst_offset, bytes) BIND(C, name='cdft_feed_push')
        IMPORT ; TYPE(C_PTR), VALUE :: feed, dst ; INTEGER(C_SIZE_T), VALUE :: dst_offset, bytes
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_feed_push_rows(feed, dst, dst_offset, dst_pitch, row_bytes, nrows) BIND(C, name='cdft_feed_push_rows')
+       IMPORT ; TYPE(C_PTR), VALUE :: feed, dst ; INTEGER(C_SIZE_T), VALUE :: dst_offset, dst_pitch, row_bytes, nrows
      END FUNCTION
      INTEGER(C_INT) FUNCTION cdft_feed_stream(feed, stream) BIND(C, name='cdft_feed_stream')
        IMPORT ; TYPE(C_PTR), VALUE :: feed ; TYPE(C_PTR), INTENT(out) :: stream
@@ -134,6 +140,25 @@ MODULE cdftools_hip
      END FUNCTION
      INTEGER(C_INT) FUNCTION cdft_moc_compute_staged(plan, dmoc, dmoc_space, stream) BIND(C, name='cdft_moc_compute_staged')
        IMPORT ; TYPE(C_PTR), VALUE :: plan, stream ; INTEGER(C_INT), VALUE :: dmoc_space ; REAL(C_DOUBLE), INTENT(out) :: dmoc(*)
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_moc_describe(plan, buf, buflen) BIND(C, name='cdft_moc_describe')
+       IMPORT ; TYPE(C_PTR), VALUE :: plan ; CHARACTER(KIND=C_CHAR), INTENT(out) :: buf(*) ; INTEGER(C_SIZE_T), VALUE :: buflen
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_moc_stage_open(plan, npt, stream) BIND(C, name='cdft_moc_stage_open')
+       IMPORT ; TYPE(C_PTR), VALUE :: plan, stream ; INTEGER(C_INT), VALUE :: npt
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_moc_stage_dest(plan, record, level, dst, row_pitch_bytes) BIND(C, name='cdft_moc_stage_dest')
+       IMPORT ; TYPE(C_PTR), VALUE :: plan ; INTEGER(C_INT), VALUE :: record, level
+       TYPE(C_PTR), INTENT(out) :: dst ; INTEGER(C_SIZE_T), INTENT(out) :: row_pitch_bytes
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_moc_stage_close(plan) BIND(C, name='cdft_moc_stage_close')
+       IMPORT ; TYPE(C_PTR), VALUE :: plan
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_moc_release_staged(plan) BIND(C, name='cdft_moc_release_staged')
+       IMPORT ; TYPE(C_PTR), VALUE :: plan
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_moc_stats(plan, zonal_launches, records) BIND(C, name='cdft_moc_stats')
+       IMPORT ; TYPE(C_PTR), VALUE :: plan ; INTEGER(C_INT64_T), INTENT(out) :: zonal_launches, records
      END FUNCTION
      INTEGER(C_INT) FUNCTION cdft_moc_reserve(plan, npt, stream) BIND(C, name='cdft_moc_reserve')
        IMPORT ; TYPE(C_PTR), VALUE :: plan, stream ; INTEGER(C_INT), VALUE :: npt

@@ -257,6 +257,30 @@ class MocPlan:
         base = C.c_void_p(pz.value + 4 * self.npi * j0)
         check(_lib.load().cdft_moc_stage_rows(self._h, base, lev * self.npk, lev, npt, sz, stream or current_stream_ptr()))
 
+    def stage_open(self, npt, stream=None):
+        """cdft_moc_stage_open: the pool laid out for npt records the caller will write itself (weights brought in)."""
+        check(_lib.load().cdft_moc_stage_open(self._h, int(npt), stream or current_stream_ptr()))
+
+    def stage_dest(self, record, level):
+        """cdft_moc_stage_dest -> (device address of row 1 of `level` of `record` (both 0-based), bytes between rows)."""
+        d, pitch = C.c_void_p(), C.c_size_t(0)
+        check(_lib.load().cdft_moc_stage_dest(self._h, int(record), int(level), C.byref(d), C.byref(pitch)))
+        return d.value, pitch.value
+
+    def stage_close(self):
+        check(_lib.load().cdft_moc_stage_close(self._h))
+
+    def release_staged(self):
+        """cdft_moc_release_staged: forget the staged records and give the pool's memory back."""
+        self._staged = None
+        check(_lib.load().cdft_moc_release_staged(self._h))
+
+    def stats(self):
+        """cdft_moc_stats -> (zonal-kernel launches so far, records they covered)."""
+        nl, nr = C.c_int64(0), C.c_int64(0)
+        check(_lib.load().cdft_moc_stats(self._h, C.byref(nl), C.byref(nr)))
+        return nl.value, nr.value
+
     def compute_pitched(self, zv_ptr, rec_stride, row_stride, npt, out, stream=None):
         """Records in a pitched layout in HBM (cdft_moc_compute_pitched): zv_ptr a device address (int), strides in elements."""
         po, so, ko = _arg(out, np.float64, "dmoc")

@@ -56,6 +56,7 @@ int         cdft_device_count(int *count);            /* never fails on a box wi
 int         cdft_set_device(int device);
 int         cdft_malloc(void **ptr, size_t bytes);    /* HBM allocation */
 int         cdft_free(void *ptr);
+int         cdft_mem_info(size_t *free_bytes, size_t *total_bytes);   /* HBM of the current device (hipMemGetInfo) */
 /* Host feed without stalls.  The reference reads a slab and consumes it (src/cdfmoc.f90:355-379: getvar, then the loops);
  * a GPU is fed through PCIe, and a program that reads record t+1 while record t travels needs (a) page-locked memory, so
  * that the copy is a DMA the host does not take part in, and (b) calls that return once their work is QUEUED:
@@ -77,6 +78,11 @@ int         cdft_feed_create(cdft_feed **feed, size_t slot_bytes, int nslots);
 int         cdft_feed_resize(cdft_feed *feed, size_t slot_bytes, int nslots);   /* other slots, the same stream (waits for it) */
 int         cdft_feed_slot(cdft_feed *feed, void **host, size_t *slot_bytes);
 int         cdft_feed_push(cdft_feed *feed, void *dst, size_t dst_offset, size_t bytes);
+/* cdft_feed_push for a destination whose rows are not dense: the slot holds nrows rows of row_bytes bytes back to back (the
+ * (npiglo,npjglo) slabs getvar returns, src/cdfio.F90:1425-1609); they go to dst + dst_offset with dst_pitch bytes between row
+ * starts -- e.g. straight into the slots of cdfmoc's pool (cdft_moc_stage_dest), so that the H2D copy IS the staging.  One
+ * linear DMA into HBM and a row-spreading kernel behind it on the feed's stream; CDFT_FEED_ROWS=2d: one hipMemcpy2DAsync. */
+int         cdft_feed_push_rows(cdft_feed *feed, void *dst, size_t dst_offset, size_t dst_pitch, size_t row_bytes, size_t nrows);
 int         cdft_feed_stream(cdft_feed *feed, void **stream);
 int         cdft_feed_wait(cdft_feed *feed);
 int         cdft_feed_destroy(cdft_feed *feed);
@@ -179,7 +185,17 @@ int cdft_moc_compute(cdft_moc_plan *plan, const float *zv, int64_t rec_stride, i
  * (cdft_moc_set_mesh) keeps the staged records and brings its weights into the pool at the next cdft_moc_compute_staged.
  * cdft_moc_stage_rows: the same for records whose LEVELS are lev_stride elements apart (>= npiglo*npjglo; rows dense): a
  * row block of a larger domain, taken where it lies (single-device plans).
- * CDFT_MOC_POOL=0 (A/B hook): keep the records as they came instead (a device array is then borrowed, not copied).
+ * cdft_moc_stage_open / _dest / _close: the caller writes the records into the pool ITSELF -- a program that reads its file slab
+ * by slab (src/cdfmoc.f90:357, one getvar per level) and whose H2D copies then ARE the staging (cdft_feed_push_rows): _open
+ * lays the pool out for npt records and brings the weights in (on `stream`), _dest gives the address of row jj = 1 of level
+ * `level` (0-based) of record `record` (0-based) and the distance in bytes between consecutive rows (rows of a level, then
+ * of the next level, follow at that pitch), _close declares the npt records staged once every copy has been QUEUED on the
+ * stream the compute call is given.  Single-device plans.
+ * Lifetime: staged records stay until the next cdft_moc_stage* call, cdft_moc_release_staged (which gives the pool's memory
+ * back: 61 GB at eORCA12 for 12 records) or cdft_moc_destroy; cdft_moc_compute on other records does not touch them, on
+ * single-device and sharded plans alike.
+ * CDFT_MOC_POOL=0 (A/B hook of cdft_moc_stage): keep the records as they came instead (a device array is then borrowed, not
+ * copied, and a later cdft_moc_compute from host memory forgets them).
  * cdft_moc_reserve: make the pool for npt records now (optional: cdft_moc_stage makes it when it is not there).  A program
  * that knows its record count asks for the pool before it allocates anything else in HBM: the one large allocation then gets
  * the device's memory while it is still in one piece. */
@@ -187,7 +203,14 @@ int cdft_moc_reserve(cdft_moc_plan *plan, int npt, void *stream);
 int cdft_moc_stage(cdft_moc_plan *plan, const float *zv, int64_t rec_stride, int npt, int zv_space, void *stream);
 int cdft_moc_stage_rows(cdft_moc_plan *plan, const float *zv, int64_t rec_stride, int64_t lev_stride, int npt, int zv_space,
                         void *stream);
+int cdft_moc_stage_open(cdft_moc_plan *plan, int npt, void *stream);
+int cdft_moc_stage_dest(cdft_moc_plan *plan, int record, int level, void **dst, size_t *row_pitch_bytes);
+int cdft_moc_stage_close(cdft_moc_plan *plan);
+int cdft_moc_release_staged(cdft_moc_plan *plan);
 int cdft_moc_compute_staged(cdft_moc_plan *plan, double *dmoc, int dmoc_space, void *stream);
+/* zonal-kernel launches this plan has made and the records they covered (12 records in 1 launch: every input byte read once;
+ * 12 launches: the weights read 12 times) -- what a program prints under CDFT_TIMING and what the tests assert */
+int cdft_moc_stats(cdft_moc_plan *plan, int64_t *zonal_launches, int64_t *records);
 
 /* Records the CALLER keeps in a pitched layout in HBM.  The reference's zv(npiglo,npjglo) slab per (level, record) is
  * dense (src/cdfmoc.f90:357 getvar); in HBM the rows of a field need not be: element (ji,jj,jk) of record t lies at

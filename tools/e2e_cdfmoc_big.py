@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--npt", type=int, default=2)
     ap.add_argument("--rows", type=int, default=5)
     ap.add_argument("--keep", action="store_true")
+    ap.add_argument("--rocprof", default="", help="directory: also run the program once under rocprofv3 --kernel-trace --stats")
     args = ap.parse_args()
     npi, npj, npk = GRIDS[args.grid]
     npt = args.npt
@@ -164,12 +165,15 @@ def main():
 
     exe = os.path.join(ROOT, "cdftools_amd", "bin", "cdfmoc")
 
-    def run_program(feed, out):
+    plan_lines = {}
+
+    def run_program(feed, out, more=None, key=None):
         """-> wall time, the phases line, stdout without it, the phases as numbers"""
-        env = dict(os.environ, CDFT_TIMING="1", CDFT_FEED="1" if feed else "0")
+        env = dict(os.environ, CDFT_TIMING="1", CDFT_FEED="1" if feed else "0", **(more or {}))
         t0 = time.perf_counter()
         r = subprocess.run([exe, "-v", "V.nc", "-o", out], cwd=d, env=env, capture_output=True, text=True)
         wall = time.perf_counter() - t0
+        plan_lines[key or ("feed" if feed else "whole_records")] = [ln.strip() for ln in r.stderr.splitlines() if "CDFT_PLAN" in ln or "cdft_moc" in ln]
         if r.returncode != 0:
             print("cdfmoc failed with code", r.returncode)
             print(r.stdout[-3000:], r.stderr[-2000:])
@@ -194,6 +198,31 @@ def main():
         e2e["feed" if feed else "whole_records"] = {
             "wall_s": wall, "phases_s": ph, "per_record_s": round((ph["data_reads"] + ph["gpu_calls"] - (0 if feed else 0)) / npt, 4),
             "grid_cells_per_s": npi * npj * npk * npt / wall, "phases_line": line}
+    # the feed record by record (CDFT_MOC_BATCH=1: a launch per record on a dense record, the weights read again every time)
+    # beside the feed into the pool (the default: one launch for all records)
+    best = None
+    for i in range(2):
+        wall, line, rest, ph = run_program(True, "moc_feed_rec.nc", {"CDFT_MOC_BATCH": "1"}, "feed_record_by_record")
+        if best is None or wall < best[0]:
+            best = (wall, line, ph)
+    e2e["feed_record_by_record"] = {"wall_s": best[0], "phases_s": best[2], "phases_line": best[1]}
+    wall, line, rest, ph = run_program(True, "moc_feed_2d.nc", {"CDFT_FEED_ROWS": "2d"}, "feed_pitched_copies")   # hipMemcpy2DAsync per slab
+    e2e["feed_pitched_copies"] = {"wall_s": wall, "phases_s": ph, "phases_line": line,
+                                  "file_identical_to_feed": open(os.path.join(d, "moc_feed_2d.nc"), "rb").read() == open(os.path.join(d, "moc_feed.nc"), "rb").read()}
+    e2e["plan_lines"] = plan_lines
+    if args.rocprof:                                       # the PROGRAM under rocprofv3: the zonal kernel's launches and durations
+        import csv
+        import glob
+        os.makedirs(args.rocprof, exist_ok=True)
+        env = dict(os.environ, CDFT_FEED="1", TMPDIR="/tmp")
+        r = subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", args.rocprof, "--", exe, "-v", "V.nc", "-o",
+                            "moc_prof.nc"], cwd=d, env=env, capture_output=True, text=True)
+        ks = {}
+        for f in glob.glob(os.path.join(args.rocprof, "**", "*kernel_stats.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                ks[row["Name"][:120]] = {"calls": int(row["Calls"]), "total_ms": float(row["TotalDurationNs"]) / 1e6,
+                                         "avg_ms": float(row["AverageNs"]) / 1e6}
+        e2e["rocprof_of_the_program"] = {"rc": r.returncode, "kernels": ks}
     e2e["stdout_identical"] = outs[False] == outs[True].replace("moc_feed.nc", "moc.nc")
     e2e["moc_files_identical"] = open(os.path.join(d, "moc.nc"), "rb").read() == open(os.path.join(d, "moc_feed.nc"), "rb").read()
     walls, phases = [e2e["whole_records"]["wall_s"], e2e["feed"]["wall_s"]], e2e["feed"]["phases_line"]
