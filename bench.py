@@ -138,10 +138,73 @@ def cpu_baseline(e1v, e3v, ib, zv, npi, npk, npt, target_s=12.0):
         reps += 1
     cells = float(npi) * rows * npk * npt
     return {"value": cells * reps / total, "unit": "grid-cells/s", "cores": oracle_lib.num_threads(),
-            "kind": "port",
+            "kind": "port", **host_description(),
             "sample": f"rows 1..{rows} of the rank-0 block x {npk} levels x {npt} records = {cells:.3e} cells, "
                       f"{reps} passes in {total:.1f} s, OpenMP over jj as src/cdfmoc.f90:369,382, the fastest of "
                       f"five thread counts up to {nmax if target_s > 0 else oracle_lib.num_threads()}"}, rows, out
+
+
+def host_description():
+    """the box the CPU legs ran on: logical CPUs (nproc), those this process may use, and the CPU's model name"""
+    model = None
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        usable = os.cpu_count()
+    return {"host_nproc": os.cpu_count(), "host_cpus_usable": usable, "host_cpu_model": model}
+
+
+def tools_leg(args):
+    """The other BASELINE configs and the other 8(a) tools on THIS box, after the timed region (rank 0, N = 1): child processes
+    (this one has let go of its memory) run tools/bench_tools.py at eORCA025 -- cdfheatc in both sum modes (config 2), cdfmhst,
+    cdfpsi, cdfvT, cdfcurl, sigma0 / sigma2 -- and this script on the eorca025 workload (config 3: cdfmoc, 12 records).
+    -> a list of {tool, grid, ms, alg_bytes, frac, ...}: ms = one call through the C ABI (HIP events on the launch stream),
+    frac = alg_bytes / ms / 8 TB/s; kernels_only_* where a call also returns a host result."""
+    out = []
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "LOCAL_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE",
+              "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_tools.py"), "--grid", "eorca025", "--reps", "20", "--tools",
+                            "heatc,mhst,psi,vt,curl,eos", "--land", "none"], capture_output=True, text=True, timeout=args.tools_timeout, env=env)
+        for ln in r.stdout.splitlines():
+            if not ln.startswith("{"):
+                continue
+            t = json.loads(ln)
+            e = {"tool": t["tool"], "grid": t["grid"], "ms": t["ms"], "alg_bytes": t["cells"] * t["algorithmic_bytes_per_cell"],
+                 "frac": t["frac_of_hbm_peak"]}
+            if "kernels_only_ms" in t:
+                e.update(kernels_only_ms=t["kernels_only_ms"], kernels_only_frac=t["kernels_only_frac"])
+            if "roofline" in t:                                   # bound by the r8 issue rate, not by HBM
+                e.update(bound="fp64", frac_of_r8_issue_peak=t["roofline"]["frac"])
+            out.append(e)
+        if r.returncode != 0:
+            out.append({"error": f"tools/bench_tools.py rc {r.returncode}: " + r.stderr[-300:]})
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "eorca025", "--steps", "100", "--warmup", "5", "--no-cpu-baseline",
+                            "--no-inprocess", "--no-tools"], capture_output=True, text=True, timeout=args.tools_timeout, env=env)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode == 0 and len(lines) == 1:
+            t = json.loads(lines[0])
+            rf = t["roofline"]
+            out.append({"tool": "cdfmoc, 12 records (BASELINE config 3)", "grid": "eorca025", "ms": t["ms_per_step"],
+                        "alg_bytes": rf["algorithmic_bytes_per_launch"], "frac": rf["algorithmic_bytes_per_launch"] / (t["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "kernels_only_ms": rf["avg_launch_ms"], "kernels_only_frac": rf["frac"], "kernel": rf["kernel"],
+                        "dense_arrays_ms": (rf.get("dense_arrays") or {}).get("avg_launch_ms")})
+        else:
+            out.append({"error": f"bench.py --workload eorca025 rc {r.returncode}: " + (r.stderr or r.stdout)[-300:]})
+    except subprocess.TimeoutExpired:
+        out.append({"error": f"no result within {args.tools_timeout} s"})
+    except (OSError, ValueError, KeyError) as exc:
+        out.append({"error": str(exc)[:300]})
+    return out
 
 
 def reference_baseline(e1v, e3v, ib, zv, npi, npk, npt, got, rows=32, target_s=6.0):
@@ -425,6 +488,8 @@ def main():
                     help="ranks: one process per GPU over RCCL (the contract); inprocess: one process, the sharded plan over N devices")
     ap.add_argument("--no-inprocess", action="store_true", help="ranks mode: do not run the in-process leg afterwards")
     ap.add_argument("--inprocess-timeout", type=int, default=240)
+    ap.add_argument("--no-tools", action="store_true", help="N = 1: do not run the per-tool lines (BASELINE configs 2 and 3, the other 8(a) tools) afterwards")
+    ap.add_argument("--tools-timeout", type=int, default=240)
     args = ap.parse_args()
     if args.steps <= 0:
         args.steps = 250 * max(args.gpus, 1) if args.mode == "ranks" else 50
@@ -555,7 +620,7 @@ def main():
     traffic, traffic_note = pmc_traffic(describe, npi, nloc, npk, npt)
     dense_ms = float(dense_each.mean()) if dense_each.size else None
     roofline = {"bound": "hbm", "kernel": describe, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source_builders_pmc_run": traffic_note,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source_builders_pmc_run": traffic_note, "traffic_source": traffic_note,
                 "dense_arrays": {"kernel": dense_desc, "avg_launch_ms": dense_ms, "launches": int(dense_each.size),
                                  "frac": alg_bytes / (dense_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if dense_ms else None,
                                  "max_abs_diff_Sv_vs_staged": dense_err,
@@ -596,7 +661,14 @@ def main():
                 raise SystemExit(f"bench: HIP result differs from the reference's statements (rel {cpu_ref['hip_vs_reference_rel_err']:.3e})")
 
     inproc = None
+    tools = None
     gathers = pipe.gathers
+    if world == 1 and not args.no_tools and args.workload == "eorca12":
+        plan.close()                                                # the children need the device's memory
+        del pipe, plan, zv, e1v, ib, result
+        pipe = plan = zv = e1v = ib = result = None
+        torch.cuda.empty_cache()
+        tools = tools_leg(args)
     if not args.no_inprocess:
         # the in-process leg: every rank lets go of its memory, rank 0's child uses the N devices, the others wait
         del pipe, plan, zv, e1v, ib, result
@@ -624,7 +696,7 @@ def main():
                        "cells_per_step": cells_per_step,
                        "result_gathers": gathers if world > 1 else 0},
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_reference": cpu_ref, "oracle_check_rel_err": check,
-            "comm": comm, "per_rank": per_rank, "inprocess": inproc,
+            "comm": comm, "per_rank": per_rank, "inprocess": inproc, "tools": tools,
         }
         if one_gpu or backend != "nccl":
             line["test_hooks"] = {"one_gpu": one_gpu, "backend": backend}

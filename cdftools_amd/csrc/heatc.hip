@@ -1106,6 +1106,12 @@ int launch_seq_scan(HeatcArgs a, const float *carry, float *sums4, DevBuf &work,
     const int align = getenv("CDFT_HEATC_SCAN_NOALIGN") ? 0 : 1;          // (A/B hook)
     // timing experiments only (the sums are then wrong): 1 = no chain waits, 2 = no chunk sums, 4 = no cell-by-cell resolution
     const int dbg = getenv("CDFT_HEATC_SCAN_DEBUG") ? atoi(getenv("CDFT_HEATC_SCAN_DEBUG")) : 0;
+    if (dbg) {                                                    // never silently: the r4 sums of this call are not the reference's
+        static bool told = false;
+        if (!told) fprintf(stderr, "libcdftools_hip: CDFT_HEATC_SCAN_DEBUG=%d is a timing experiment -- parts of the reference-order scan are "
+                                   "switched off and the sums cdft_heatc_compute returns are WRONG\n", dbg);
+        told = true;
+    }
     const size_t head = (sizeof(ScanLevel) * (size_t)a.npk + sizeof(ScanCtl) + 15) / 16 * 16;
     CDFT_TRY(work.reserve(head + sizeof(double) * (size_t)a.npk * (a.nblk + 1) * 3));
     ScanLevel *lev = (ScanLevel *)work.ptr;

@@ -438,10 +438,13 @@ int cdft_mean_compute(cdft_mean_plan *p, const float *zv, int in_space, double *
     a.band = xcd_bands_on();
     const dim3 grid(xcd_band_grid(a.nblk, a.band)), block(kThreads);
     const size_t park_bytes = (size_t)(kThreads / 64) * p->npk * nq * sizeof(double);
-    const bool park = park_bytes <= 48 * 1024 && !getenv("CDFT_MEAN_NOPARK");     // (A/B hook: a barrier pair per level)
+    // (the parked sums AND the wave-sum scratch must fit the 64 KB a launch gets without asking for more: npk * nb = 384 --
+    // 4 basins x 96 levels -- parks 48 KB and would ask for 65 792 bytes with the scratch)
+    const size_t red_bytes = p->nb >= 2 ? (size_t)(kThreads / 64) * 8 * kSum8Stride * sizeof(double) : 0;
+    const bool park = park_bytes <= 48 * 1024 && park_bytes + red_bytes <= 64 * 1024 && !getenv("CDFT_MEAN_NOPARK");     // (A/B hook: a barrier pair per level)
     const size_t wsum_bytes = park ? park_bytes : (size_t)(kThreads / 64) * nq * sizeof(double);
     a.redoff = (int)(wsum_bytes / sizeof(double));
-    const size_t shmem = wsum_bytes + (p->nb >= 2 ? (size_t)(kThreads / 64) * 8 * kSum8Stride * sizeof(double) : 0);
+    const size_t shmem = wsum_bytes + red_bytes;
     const bool full = p->e31d != nullptr;
 #define CDFT_MEAN4(NBC, PK, M8, IB) do { \
         if (full && vpt == 4) hipLaunchKernelGGL((mean_level_kernel<4, true, NBC, PK, 4, M8, IB>), grid, block, shmem, st, a); \

@@ -4,6 +4,8 @@
 #include "rccl_dl.hpp"
 #include <dlfcn.h>
 #include <atomic>
+#include <chrono>
+#include <string>
 #include <cstdlib>
 #include <mutex>
 #include <thread>
@@ -203,7 +205,8 @@ void destroy(ShardSet *sh) {
     delete sh;
 }
 
-int for_blocks(ShardSet &sh, const std::function<int(int)> &fn) {
+// early_fail(b): called (on block b's thread) when the block fails before fn(b) could run -- for_blocks_collective's hook
+static int for_blocks_impl(ShardSet &sh, const std::function<int(int)> &fn, const std::function<void(int)> *early_fail) {
     const int n = sh.nblk();
     std::vector<int> rc(n, CDFT_OK);
     std::vector<std::string> msg(n);
@@ -213,6 +216,7 @@ int for_blocks(ShardSet &sh, const std::function<int(int)> &fn) {
             (void)hipGetLastError();
             rc[b] = CDFT_ERR_HIP;
             msg[b] = "hipSetDevice failed";
+            if (early_fail) (*early_fail)(b);
             return;
         }
         rc[b] = fn(b);
@@ -233,20 +237,53 @@ int for_blocks(ShardSet &sh, const std::function<int(int)> &fn) {
     return CDFT_OK;
 }
 
+int for_blocks(ShardSet &sh, const std::function<int(int)> &fn) { return for_blocks_impl(sh, fn, nullptr); }
+
 // The collectives of an operation, issued from the blocks' threads: every block must reach its call, or the others wait for
 // the missing rank for ever.  So (1) the fallible per-block work -- reserves, copies, kernels -- runs in a for_blocks pass of
-// its own whose status is checked BEFORE this one starts, and (2) if a block fails here all the same (the enqueue itself, or
-// what follows it on the stream), every communicator is aborted: the blocks already waiting come back with an error instead
-// of hanging, the set is left without communicators and the next sharded RCCL call reports that.
-static int for_blocks_collective(ShardSet &sh, const std::function<int(int)> &fn) {
-    std::atomic<int> failed{0};
-    const int rc = for_blocks(sh, [&](int b) {
-        const int r = fn(b);
-        if (r != CDFT_OK && !failed.exchange(1) && rccl::api())
+// its own whose status is checked BEFORE this one starts, and (2) if a block fails here all the same -- its hipSetDevice, the
+// enqueue itself (`enqueue`: the block's ONE RCCL call), or what follows it on the stream (`finish`) -- every communicator
+// is aborted: the blocks already waiting on their streams come back with an error instead of hanging, the set is left
+// without communicators and the next sharded RCCL call reports that.
+// The abort is made by the first failing block, and only once EVERY block is past its enqueue point (has returned from its
+// RCCL call, or has seen the `failed` flag and skipped it): no thread can then hand an aborted -- freed -- communicator to
+// RCCL.  A block that fails early raises the flag first, so the blocks not yet at their call skip it; a block already inside
+// its call returns from it (an enqueue does not wait for the other ranks' kernels).  Should a call not return all the same,
+// the abort goes ahead after kAbortWaitMs: ncclCommAbort is what RCCL offers against a blocked call.
+static int for_blocks_collective(ShardSet &sh, const std::function<int(int)> &enqueue, const std::function<int(int)> &finish) {
+    constexpr int kAbortWaitMs = 10000;
+    const int n = sh.nblk();
+    std::atomic<int> failed{0}, passed{0}, aborted{0};
+    auto abort_all = [&]() {
+        if (failed.exchange(1)) return;                          // (another block is already doing it)
+        for (int waited = 0; passed.load() < n && waited < kAbortWaitMs; ++waited) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        if (rccl::api())
             for (void *c : sh.comm) if (c) (void)rccl::api()->CommAbort(c);
+        aborted.store(1);
+    };
+    const std::function<void(int)> early = [&](int) { passed.fetch_add(1); abort_all(); };
+    const int rc = for_blocks_impl(sh, [&](int b) {
+        if (failed.load()) {                                     // another block has failed: this one never issues its call
+            passed.fetch_add(1);
+            return fail(CDFT_ERR_HIP, "collective not issued: another row block failed first");
+        }
+        // CDFT_SHARD_TEST_FAIL=enqueue|finish (test hook, tests/test_sharded_plans.py): block 0 fails there
+        const char *hook = getenv("CDFT_SHARD_TEST_FAIL");
+        int r = (b == 0 && hook && hook[0] == 'e') ? fail(CDFT_ERR_HIP, "CDFT_SHARD_TEST_FAIL: enqueue of block 0") : enqueue(b);
+        passed.fetch_add(1);
+        if (r == CDFT_OK) r = finish(b);
+        if (r == CDFT_OK && b == 0 && hook && hook[0] == 'f') r = fail(CDFT_ERR_HIP, "CDFT_SHARD_TEST_FAIL: after the collective of block 0");
+        if (r != CDFT_OK) {
+            const std::string keep = cdft_last_error();          // (abort_all may wait; keep this block's own message)
+            abort_all();
+            set_error("%s", keep.c_str());
+        }
         return r;
-    });
-    if (failed.load()) sh.comm.assign(sh.comm.size(), nullptr);
+    }, &early);
+    if (failed.load()) {
+        while (!aborted.load()) std::this_thread::sleep_for(std::chrono::milliseconds(1));   // (the aborting thread has been joined: set already)
+        sh.comm.assign(sh.comm.size(), nullptr);
+    }
     return rc;
 }
 static int comms_alive(const ShardSet &sh, const char *who) {
@@ -493,10 +530,12 @@ int heatc_compute(ShardSet &sh, const float *temp, const float *rmxldep, const f
     // levels); block 0's copy comes to the host, where they are added as below
     if (sh.rccl())
         CDFT_TRY(for_blocks_collective(sh, [&](int b) {
-            hipStream_t st = sh.st[b];
             DevBuf *B = sh.buf[b].data();
-            CDFT_RCCL(rccl::api()->AllGather(B[7].ptr, B[8].ptr, nsum, rccl::kDouble, sh.comm[b], st));
-            if (b == 0) CDFT_HIP(hipMemcpyAsync(gathered.data(), B[8].ptr, nsum * 8 * n, hipMemcpyDeviceToHost, st));
+            CDFT_RCCL(rccl::api()->AllGather(B[7].ptr, B[8].ptr, nsum, rccl::kDouble, sh.comm[b], sh.st[b]));
+            return CDFT_OK;
+        }, [&](int b) {
+            hipStream_t st = sh.st[b];
+            if (b == 0) CDFT_HIP(hipMemcpyAsync(gathered.data(), sh.buf[b][8].ptr, nsum * 8 * n, hipMemcpyDeviceToHost, st));
             CDFT_HIP(hipStreamSynchronize(st));
             return CDFT_OK;
         }));
@@ -705,9 +744,11 @@ int psi_finish(ShardSet &sh, int use_ref, double ref_value, int iiref, int ijref
         std::vector<double> refs((size_t)sh.nblk(), 0.0);
         CDFT_TRY(for_blocks_collective(sh, [&](int b) {
             DevBuf *B = sh.buf[b].data();
+            CDFT_RCCL(rccl::api()->Broadcast(B[12].ptr, B[12].ptr, 1, rccl::kDouble, owner, sh.comm[b], sh.st[b]));
+            return CDFT_OK;
+        }, [&](int b) {
             hipStream_t st = sh.st[b];
-            CDFT_RCCL(rccl::api()->Broadcast(B[12].ptr, B[12].ptr, 1, rccl::kDouble, owner, sh.comm[b], st));
-            CDFT_HIP(hipMemcpyAsync(&refs[b], B[12].ptr, 8, hipMemcpyDeviceToHost, st));
+            CDFT_HIP(hipMemcpyAsync(&refs[b], sh.buf[b][12].ptr, 8, hipMemcpyDeviceToHost, st));
             CDFT_HIP(hipStreamSynchronize(st));
             return CDFT_OK;
         }));

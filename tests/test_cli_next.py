@@ -139,7 +139,8 @@ def test_oracle_mean_matches_numpy_restatement():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("npi,npj,npk,nb", [(24, 18, 7, 4), (182, 149, 31, 1), (1, 1, 1, 1), (5, 3, 2, 8), (1023, 7, 3, 3), (64, 64, 2, 2)])
+@pytest.mark.parametrize("npi,npj,npk,nb", [(24, 18, 7, 4), (182, 149, 31, 1), (1, 1, 1, 1), (5, 3, 2, 8), (1023, 7, 3, 3), (64, 64, 2, 2),
+                                            (40, 9, 96, 4), (33, 5, 48, 8), (21, 4, 192, 2), (30, 6, 95, 4)])   # npk * nb = 384: the LDS budget's edge
 def test_hip_mean_matches_oracle(gpu, monkeypatch, npi, npj, npk, nb):
     g, zv, ib = mean_inputs(npi, npj, npk, min(nb, 4), seed=npi + 1)
     if nb > 4:

@@ -472,3 +472,43 @@ def test_hip_properties_at_full_size(gpu, npi, npj, npk, nb, npt):
     # indo-pacific = indian + pacific (disjoint masks), to r8 rounding
     a = d1.cpu().numpy()
     assert np.allclose(a[..., 2], a[..., 3] + a[..., 4], rtol=0, atol=1e-11 * np.abs(a).max())
+
+
+@pytest.mark.gpu
+def test_hip_headline_shape_on_the_pool(gpu):
+    """The shape bench.py times -- eORCA12 4322 x 3606 x 75, 12 records, 5 basins, the records staged into the plan's pool
+    (reserve -> stage -> compute_staged) -- on bench.py's own synthetic dataset (its build_inputs): sampled rows against the
+    oracle at 1e-13 * sum|terms| (src/cdfmoc.f90:355-388), level npk zero, the same bits from call to call, one launch for the
+    12 records on layout=pool, and what moc.nc would hold (REAL(dmoc)) within 1 ulp(r4) of the dense-array path.  61 GB of
+    records + 61 GB of pool of the 288."""
+    import os
+    import sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench
+    npi, npj, npk, npt, nb = bench.WORKLOADS["eorca12"]
+    plan = gpu.MocPlan(npi, npj, npk, nb)
+    plan.reserve(npt)
+    e1v, e3v, ib, zv = bench.build_inputs(npi, npj, npk, npt, nb, 0, npj, torch.device("cuda", 0))
+    plan.set_mesh(e1v, e3v, ib)
+    plan.stage(zv)
+    n0 = plan.stats()
+    a = plan.compute_staged(torch.full((npt, npk, npj, nb), float("nan"), dtype=torch.float64, device="cuda"))
+    b = plan.compute_staged(torch.zeros((npt, npk, npj, nb), dtype=torch.float64, device="cuda"))
+    torch.cuda.synchronize()
+    assert plan.stats() == (n0[0] + 2, n0[1] + 2 * npt) and "layout=pool" in plan.describe() and "moc_zonal_class_kernel" in plan.describe()
+    assert torch.equal(a, b) and bool((a[:, npk - 1] == 0).all()) and bool(torch.isfinite(a).all())
+    rows = np.sort(np.random.default_rng(12).choice(npj, 16, replace=False))
+    r = torch.from_numpy(rows).cuda()
+    e1s, e3s, ibs, zvs = e1v[r].cpu().numpy(), e3v[:, r].cpu().numpy(), ib[r].cpu().numpy(), zv[:, :, r].cpu().numpy()
+    ref = oracle_lib.moc(e1s, e3s, ibs, zvs)
+    assert_moc_close(a[:, :, r].cpu().numpy(), ref, abs_bound(e1s, e3s, ibs, zvs))
+    del e3v
+    dense = plan.compute(zv)                                       # the same records where they were generated, 4.7 GB apart
+    a4, d4 = a.float(), dense.float()
+    ulp = torch.from_numpy(np.spacing(np.abs(d4.cpu().numpy()))).cuda()
+    assert bool(((a4 - d4).abs() <= ulp).all())
+    assert torch.equal(plan.compute_staged(torch.zeros_like(a)), a)   # (the dense call did not touch the pool)
+    plan.close()

@@ -249,6 +249,14 @@ def test_staged_records_and_per_block_probes(gpu, devices):
         assert p.profile_read_block(nblk - 1).size == 0           # read and reset
         if nblk > 1:
             assert p.profile_read_block(0).size == 2              # (the other blocks keep theirs)
+    # lifetime (include/cdftools_hip.h): cdft_moc_compute on other records leaves the staged ones alone, on one device and on
+    # row blocks alike; cdft_moc_release_staged gives the pools back
+    assert np.array_equal(p.compute(zv), dense) and np.array_equal(p.compute_staged(np.zeros_like(ref)), ref)
+    p.release_staged()
+    with pytest.raises(gpu.CdftError):
+        p.compute_staged(np.zeros_like(ref))
+    p.stage(zv)
+    assert np.array_equal(p.compute_staged(np.zeros_like(ref)), ref)
     with pytest.raises(gpu.CdftError):
         p.block_info(7)
     with pytest.raises(gpu.CdftError):
@@ -291,6 +299,39 @@ def test_rccl_collectives_inside_the_library_on_one_device(gpu):
     assert np.array_equal(one[0], r4) and np.array_equal(one[1], r8)
     with pytest.raises(gpu.CdftError):
         gpu.set_collective(7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("where", ["enqueue", "finish"])
+def test_a_failed_collective_aborts_the_communicators_and_says_so(gpu, monkeypatch, where):
+    """a block that fails at its RCCL call or behind it (CDFT_SHARD_TEST_FAIL, a test hook): the call returns that block's error
+    (it does not hang), the communicators are aborted once every block is past its call, the plan then says they are gone
+    instead of handing freed handles to RCCL, and a new plan works"""
+    npi, npj, npk = 61, 33, 7
+    g = synth.make_grid(npi, npj, npk, seed=19)
+    rng = np.random.default_rng(20)
+    temp = ((-2 + 30 * rng.random((npk, npj, npi), dtype=f32)) * g["tmask"]).astype(f32)
+    tm = g["tmask"].astype(np.uint8)
+    gpu.set_collective(gpu.COLLECTIVE_RCCL)
+    try:
+        h = gpu.HeatcPlan(npi, npj, npk, devices=[0])
+        h.set_sum_mode(False)
+        h.set_mesh(g["e1t"], g["e2t"], tm, e3t=g["e3t_0"])
+        good = h.compute(temp)
+        monkeypatch.setenv("CDFT_SHARD_TEST_FAIL", where)
+        with pytest.raises(gpu.CdftError) as e:
+            h.compute(temp)
+        assert "CDFT_SHARD_TEST_FAIL" in str(e.value)
+        monkeypatch.delenv("CDFT_SHARD_TEST_FAIL")
+        with pytest.raises(gpu.CdftError) as e:
+            h.compute(temp)
+        assert "aborted by an earlier failure" in str(e.value)
+        h2 = gpu.HeatcPlan(npi, npj, npk, devices=[0])
+        h2.set_sum_mode(False)
+        h2.set_mesh(g["e1t"], g["e2t"], tm, e3t=g["e3t_0"])
+        assert np.array_equal(h2.compute(temp), good)
+    finally:
+        gpu.set_collective(gpu.COLLECTIVE_PEER)
 
 
 @pytest.mark.gpu
