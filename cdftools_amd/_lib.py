@@ -76,6 +76,12 @@ SIGNATURES = {
     "cdft_moc_reserve": (_i, [_vp, _i, _vp]),
     "cdft_moc_stage": (_i, [_vp, _vp, _i64, _i, _i, _vp]),
     "cdft_moc_compute_staged": (_i, [_vp, _vp, _i, _vp]),
+    "cdft_moc_set_basins": (_i, [_vp, _vp, _vp, _i, _vp]),
+    "cdft_moc_stream_begin": (_i, [_vp, _i, _i, _vp]),
+    "cdft_moc_stream_dest": (_i, [_vp, _i, _i, _pvp, C.POINTER(_sz)]),
+    "cdft_moc_stream_vmask_dest": (_i, [_vp, _i, _pvp]),
+    "cdft_moc_stream_compute": (_i, [_vp, _i, _i, _i, _vp]),
+    "cdft_moc_stream_end": (_i, [_vp, _vp, _i, _vp]),
     "cdft_moc_stage_open": (_i, [_vp, _i, _vp]),
     "cdft_moc_stage_dest": (_i, [_vp, _i, _i, _pvp, C.POINTER(_sz)]),
     "cdft_moc_stage_close": (_i, [_vp]),

@@ -56,12 +56,21 @@ struct cdft_moc_plan {
     int64_t pool_P = 0;        // slot length (elements)
     int pool_npt = 0;          // records the pool is laid out for (0: nothing staged in it)
     bool pool_w = false;       // the weights of the current mesh are in the pool
+    // The stream route (cdft_moc_stream_*): the domain goes through HBM a WINDOW of levels at a time -- the window's rows laid out
+    // like the pool's (a row's metric / weights, then its npt records, in one run) -- and nothing 3-D is resident: `win` is the
+    // window, `win_vm` the window's vmask bytes (dense), `e1v2d` the 2-D e1v; the raw sums of every window land in st_out.
+    DevBuf win, win_vm, e1v2d;
+    int win_npt = 0, win_nlev = 0;
+    int64_t win_P = 0;
+    bool basins_set = false;   // bits / cls / e1v2d are there (cdft_moc_set_basins, or cdft_moc_set_mesh*)
+    int64_t last_slot = 0;     // slot length of the layout the last launch read (cdft_moc_describe)
     int open_npt = 0;          // cdft_moc_stage_open ... _close: records being written into the pool by the caller's own copies
     int64_t n_launch = 0, n_launch_rec = 0;   // zonal launches so far and the records they covered (cdft_moc_stats)
 };
 
 static int moc_compute_on(cdft_moc_plan *p, const float *d_zv, int64_t rec_stride, int npt, double *dmoc, int dmoc_space,
                           hipStream_t st, int64_t z_row = 0, const float *w = nullptr, int64_t w_row = 0);
+static int basins_from(cdft_moc_plan *p, const int16_t *d_msk, hipStream_t st);
 
 namespace {
 
@@ -386,14 +395,16 @@ static int zonal_xcd_map(int npj) {
 
 // levels 1..npk-1 (level npk is left to the caller)
 // w_row / z_row: elements between consecutive (jj,jk) rows of the weights / of a record (npi: dense arrays)
+// nlev >= 0: a window of nlev levels (w / d_zv are the window's, d_out is shifted to its first level by the caller)
 static int zonal_launch(cdft_moc_plan *p, const float *w, int64_t w_row, const float *d_zv, int64_t rec_stride, int64_t z_row, int npt,
-                        double *d_out, hipStream_t st, bool profile) {
+                        double *d_out, hipStream_t st, bool profile, int nlev = -1) {
     ZonalArgs a;
     a.w = w; a.bits = p->bits; a.cls = p->cls; a.nclass = p->nclass;
     for (int c = 0; c < kMaxClass; ++c) a.pat[c] = p->pat[c];
     a.zv = d_zv; a.rec_stride = rec_stride; a.npt = npt;
     a.w_row = w_row; a.z_row = z_row;
     a.out = d_out; a.npi = p->npi; a.npj = p->npj; a.npk = p->npk; a.nbasins = p->nbasins;
+    a.nlev = nlev >= 0 ? nlev : p->npk - 1;
     a.rows_per_wg = 1;            // (2, 4, 8, 16 measured at eORCA025 and eORCA12: no gain, the kernel is not launch-bound)
     a.xcd_map = zonal_xcd_map(p->npj);
     // vectors aligned to the arrays: every record 16-byte aligned, and a row begins the same number of cells past a
@@ -405,6 +416,7 @@ static int zonal_launch(cdft_moc_plan *p, const float *w, int64_t w_row, const f
     choose_shape(p, aligned, &k, &v, &md);
     p->last_aligned = aligned;
     p->last_pool = (w != p->w);
+    p->last_slot = rec_stride;
     if (k > kMaxWaves || v > kMaxNV)
         return fail(CDFT_ERR_ARG, "cdft_moc_compute: a row of %d cells needs %d waves x %d vectors of the %s kernel (rows this long "
                     "take basin masks with at most %d bit patterns: the class kernel)", p->npi, k, v, md == kModeFma ? "fma" : "select",
@@ -461,14 +473,15 @@ int cdft_moc_create(cdft_moc_plan **plan, int npiglo, int npjglo, int npk, int n
     cdft_moc_plan *p = new cdft_moc_plan;
     p->npi = npiglo; p->npj = npjglo; p->npk = npk; p->nbasins = nbasins;
     const size_t n3 = (size_t)npiglo * npjglo * npk;
-    if (hipMalloc((void **)&p->w, n3 * sizeof(float) + 64) != hipSuccess ||
-        hipMalloc((void **)&p->bits, (size_t)npiglo * npjglo + 64) != hipSuccess ||
+    // (the 3-D weights come with the first cdft_moc_set_mesh*: a program on the stream route never holds them)
+    (void)n3;
+    if (hipMalloc((void **)&p->bits, (size_t)npiglo * npjglo + 64) != hipSuccess ||
         hipMalloc((void **)&p->cls, (size_t)npiglo * npjglo + 64 + 256) != hipSuccess ||
         hipMalloc((void **)&p->flag, 257 * sizeof(int)) != hipSuccess) {
         (void)hipGetLastError();
         cdft_moc_destroy(p);
         return fail(CDFT_ERR_ALLOC, "cdft_moc_create: device allocation of %zu bytes failed",
-                    n3 * sizeof(float));
+                    (size_t)npiglo * npjglo * 2);
     }
     *plan = p;
     return CDFT_OK;
@@ -505,12 +518,16 @@ int cdft_moc_set_mesh_vmask(cdft_moc_plan *p, const float *e1v, const float *e3v
     }
     hipStream_t st = as_stream(stream);
     const int64_t nij = (int64_t)p->npi * p->npj, n3 = nij * p->npk;
+    if (!p->w && hipMalloc((void **)&p->w, n3 * sizeof(float) + 64) != hipSuccess) {
+        (void)hipGetLastError();
+        p->w = nullptr;
+        return fail(CDFT_ERR_ALLOC, "cdft_moc_set_mesh: device allocation of %zu bytes (the weights) failed", (size_t)n3 * sizeof(float));
+    }
     const void *d_e1v, *d_e3v, *d_msk, *d_vm = nullptr;
     CDFT_TRY(to_device(e1v, nij * sizeof(float), memspace, p->st_e1v, st, &d_e1v));
     CDFT_TRY(to_device(e3v, n3 * sizeof(float), memspace, p->st_e3v, st, &d_e3v));
     if (vmask) CDFT_TRY(to_device(vmask, (size_t)n3, memspace, p->st_vm, st, &d_vm));
     CDFT_TRY(to_device(ibmask, nij * p->nbasins * sizeof(int16_t), memspace, p->st_mask, st, &d_msk));
-    CDFT_HIP(hipMemsetAsync(p->flag, 0, 257 * sizeof(int), st));
     CDFT_HIP(hipMemsetAsync(p->w + n3, 0, 64, st));
     p->pool_w = false;                                    // (the pool's copy of the weights is the old mesh's)
     const int threads = 256;
@@ -519,10 +536,24 @@ int cdft_moc_set_mesh_vmask(cdft_moc_plan *p, const float *e1v, const float *e3v
     hipLaunchKernelGGL(moc_weight_kernel, dim3(blocks), dim3(threads), 0, st, (const float *)d_e1v,
                        (const float *)d_e3v, (const int8_t *)d_vm, p->w, nij, n3, p->npi, (int64_t)p->npi);
     CDFT_LAUNCH_CHECK();
-    blocks = (int)((nij + threads - 1) / threads);
+    CDFT_TRY(p->e1v2d.reserve((size_t)nij * 4));                       // (kept for the stream route, 62 MB at eORCA12)
+    CDFT_HIP(hipMemcpyAsync(p->e1v2d.ptr, d_e1v, (size_t)nij * 4, hipMemcpyDeviceToDevice, st));
+    const int rc_b = basins_from(p, (const int16_t *)d_msk, st);
+    // the staged copies of host arrays are no longer needed (e3v is as large as the weight)
+    p->st_e1v.release(); p->st_e3v.release(); p->st_mask.release(); p->st_vm.release();
+    p->mesh_set = (rc_b == CDFT_OK);
+    return rc_b;
+}
+
+// bits, classes and their table from ibmask (nbasins,npi,npj) i2 in HBM; p->basins_set says whether it held 0/1 only
+static int basins_from(cdft_moc_plan *p, const int16_t *d_msk, hipStream_t st) {
+    const int64_t nij = (int64_t)p->npi * p->npj;
+    const int threads = 256;
+    int blocks = (int)((nij + threads - 1) / threads);
     if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(moc_bits_kernel, dim3(blocks), dim3(threads), 0, st, (const int16_t *)d_msk,
-                       p->bits, p->nbasins, nij, p->flag);
+    p->basins_set = false;
+    CDFT_HIP(hipMemsetAsync(p->flag, 0, 257 * sizeof(int), st));
+    hipLaunchKernelGGL(moc_bits_kernel, dim3(blocks), dim3(threads), 0, st, d_msk, p->bits, p->nbasins, nij, p->flag);
     CDFT_LAUNCH_CHECK();
     int flags[257];
     CDFT_HIP(hipMemcpyAsync(flags, p->flag, sizeof(flags), hipMemcpyDeviceToHost, st));
@@ -546,14 +577,25 @@ int cdft_moc_set_mesh_vmask(cdft_moc_plan *p, const float *e1v, const float *e3v
         CDFT_LAUNCH_CHECK();
         CDFT_HIP(hipStreamSynchronize(st));                      // lut[] is a stack array
     }
-    // the staged copies of host arrays are no longer needed (e3v is as large as the weight)
-    p->st_e1v.release(); p->st_e3v.release(); p->st_mask.release(); p->st_vm.release();
-    if (flag) {
-        p->mesh_set = false;
-        return fail(CDFT_ERR_ARG, "cdft_moc_set_mesh: ibmask holds values other than 0/1");
-    }
-    p->mesh_set = true;
+    if (flag) return fail(CDFT_ERR_ARG, "cdft_moc_set_mesh: ibmask holds values other than 0/1");
+    p->basins_set = true;
     return CDFT_OK;
+}
+
+extern "C" int cdft_moc_set_basins(cdft_moc_plan *p, const float *e1v, const int16_t *ibmask, int memspace, void *stream) {
+    TraceRange trace_("cdft_moc_set_basins");
+    if (!p || !e1v || !ibmask) return fail(CDFT_ERR_ARG, "cdft_moc_set_basins: NULL argument");
+    if (p->sh) return fail(CDFT_ERR_STATE, "cdft_moc_set_basins: single-device plans only (the stream route)");
+    hipStream_t st = as_stream(stream);
+    const int64_t nij = (int64_t)p->npi * p->npj;
+    const void *d_e1v, *d_msk;
+    CDFT_TRY(to_device(e1v, nij * sizeof(float), memspace, p->st_e1v, st, &d_e1v));
+    CDFT_TRY(to_device(ibmask, nij * p->nbasins * sizeof(int16_t), memspace, p->st_mask, st, &d_msk));
+    CDFT_TRY(p->e1v2d.reserve((size_t)nij * 4));
+    CDFT_HIP(hipMemcpyAsync(p->e1v2d.ptr, d_e1v, (size_t)nij * 4, hipMemcpyDeviceToDevice, st));
+    const int rc = basins_from(p, (const int16_t *)d_msk, st);
+    p->st_e1v.release(); p->st_mask.release();
+    return rc;
 }
 
 int cdft_moc_set_tuning(cdft_moc_plan *p, int waves_per_row, int vec_per_lane, int mode) {
@@ -592,7 +634,7 @@ int cdft_moc_describe(cdft_moc_plan *p, char *buf, size_t buflen) {
                  md == kModeFma ? "fma" : "select", k);
     if (p->last_pool) {                                   // the layout the launch read: dense arrays (nothing said) or the pool
         const size_t n = strlen(buf);
-        if (n + 1 < buflen) snprintf(buf + n, buflen - n, " layout=pool(slot=%lld)", (long long)p->pool_P);
+        if (n + 1 < buflen) snprintf(buf + n, buflen - n, " layout=pool(slot=%lld)", (long long)p->last_slot);
     }
     return CDFT_OK;
 }
@@ -802,6 +844,104 @@ int cdft_moc_stage_close(cdft_moc_plan *p) {
     return CDFT_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ the stream route
+// The window's slot 0 holds the raw metric e3v of its rows (as read from the file); in place it becomes the weight
+// e1v * (e3v * vmask), the reference's products in the reference's order (src/cdfmoc.f90:581-593, :374).
+__global__ void __launch_bounds__(256) moc_window_weight_kernel(float *__restrict__ win, int64_t R, const float *__restrict__ e1v,
+                                                                const int8_t *__restrict__ vm, int npi, int npj, int64_t nrows) {
+    for (int64_t r = blockIdx.x; r < nrows; r += gridDim.x) {
+        const int64_t lev = r / npj, jj = r - lev * npj;
+        float *w = win + r * R;
+        const float *e1 = e1v + jj * npi;
+        const int8_t *m = vm ? vm + r * (int64_t)npi : nullptr;      // (the window's vmask is dense: rows npi bytes apart)
+        for (int i = threadIdx.x; i < npi; i += 256) {
+            const float e3 = m ? __fmul_rn(w[i], (float)m[i]) : w[i];
+            w[i] = __fmul_rn(e1[i], e3);
+        }
+    }
+}
+
+int cdft_moc_stream_begin(cdft_moc_plan *p, int npt, int nlev, void *stream) {
+    TraceRange trace_("cdft_moc_stream_begin");
+    if (!p || npt < 1 || nlev < 1) return fail(CDFT_ERR_ARG, "cdft_moc_stream_begin: bad argument");
+    if (p->sh) return fail(CDFT_ERR_STATE, "cdft_moc_stream_begin: single-device plans only");
+    if (!p->basins_set) return fail(CDFT_ERR_STATE, "cdft_moc_stream_begin: cdft_moc_set_basins (or cdft_moc_set_mesh) has not succeeded");
+    hipStream_t st = as_stream(stream);
+    if (nlev > p->npk - 1) nlev = p->npk - 1;
+    const int64_t P = ((int64_t)p->npi + 3) & ~(int64_t)3, rows = (int64_t)p->npj * nlev;
+    const size_t bytes = (size_t)(rows * (npt + 1) * P) * 4 + 64;
+    p->win_npt = 0;
+    CDFT_TRY(p->win.reserve(bytes));
+    CDFT_TRY(p->win_vm.reserve((size_t)rows * p->npi + 64));
+    const size_t out_bytes = (size_t)p->nbasins * p->npj * p->npk * npt * sizeof(double);
+    CDFT_TRY(p->st_out.reserve(out_bytes));
+    // the cells between npi and P and the bytes behind the last row are read (and masked): never uninitialised memory
+    CDFT_HIP(hipMemsetAsync(p->win.ptr, 0, bytes, st));
+    CDFT_HIP(hipMemsetAsync(p->st_out.ptr, 0, out_bytes, st));
+    p->win_npt = npt; p->win_nlev = nlev; p->win_P = P;
+    return CDFT_OK;
+}
+
+int cdft_moc_stream_dest(cdft_moc_plan *p, int slot, int level, void **dst, size_t *row_pitch_bytes) {
+    if (!p || !dst || !row_pitch_bytes) return fail(CDFT_ERR_ARG, "cdft_moc_stream_dest: NULL argument");
+    if (p->win_npt < 1) return fail(CDFT_ERR_STATE, "cdft_moc_stream_dest: cdft_moc_stream_begin has not succeeded");
+    if (slot < 0 || slot > p->win_npt || level < 0 || level >= p->win_nlev)
+        return fail(CDFT_ERR_ARG, "cdft_moc_stream_dest: slot %d of 0..%d, level %d of a window of %d", slot, p->win_npt, level, p->win_nlev);
+    const int64_t R = (int64_t)(p->win_npt + 1) * p->win_P;
+    *dst = (float *)p->win.ptr + (int64_t)level * p->npj * R + (int64_t)slot * p->win_P;
+    *row_pitch_bytes = (size_t)R * 4;
+    return CDFT_OK;
+}
+
+int cdft_moc_stream_vmask_dest(cdft_moc_plan *p, int level, void **dst) {
+    if (!p || !dst) return fail(CDFT_ERR_ARG, "cdft_moc_stream_vmask_dest: NULL argument");
+    if (p->win_npt < 1) return fail(CDFT_ERR_STATE, "cdft_moc_stream_vmask_dest: cdft_moc_stream_begin has not succeeded");
+    if (level < 0 || level >= p->win_nlev) return fail(CDFT_ERR_ARG, "cdft_moc_stream_vmask_dest: level %d of a window of %d", level, p->win_nlev);
+    *dst = (int8_t *)p->win_vm.ptr + (int64_t)level * p->npj * p->npi;
+    return CDFT_OK;
+}
+
+int cdft_moc_stream_compute(cdft_moc_plan *p, int k0, int nlev, int with_vmask, void *stream) {
+    TraceRange trace_("cdft_moc_stream_compute");
+    if (!p) return fail(CDFT_ERR_ARG, "cdft_moc_stream_compute: NULL plan");
+    if (p->win_npt < 1) return fail(CDFT_ERR_STATE, "cdft_moc_stream_compute: cdft_moc_stream_begin has not succeeded");
+    if (k0 < 0 || nlev < 1 || nlev > p->win_nlev || k0 + nlev > p->npk - 1)
+        return fail(CDFT_ERR_ARG, "cdft_moc_stream_compute: levels %d .. %d of 0 .. %d, a window of %d", k0, k0 + nlev - 1, p->npk - 2, p->win_nlev);
+    hipStream_t st = as_stream(stream);
+    float *win = (float *)p->win.ptr;
+    const int64_t R = (int64_t)(p->win_npt + 1) * p->win_P, rows = (int64_t)p->npj * nlev;
+    const unsigned grid = (unsigned)(rows < 65536 ? rows : 65536);
+    hipLaunchKernelGGL(moc_window_weight_kernel, dim3(grid), dim3(256), 0, st, win, R, (const float *)p->e1v2d.ptr,
+                       with_vmask ? (const int8_t *)p->win_vm.ptr : nullptr, p->npi, p->npj, rows);
+    CDFT_LAUNCH_CHECK();
+    double *out = (double *)p->st_out.ptr + (int64_t)k0 * p->npj * p->nbasins;
+    return zonal_launch(p, win, R, win + p->win_P, p->win_P, R, p->win_npt, out, st, true, nlev);
+}
+
+int cdft_moc_stream_end(cdft_moc_plan *p, double *dmoc, int dmoc_space, void *stream) {
+    TraceRange trace_("cdft_moc_stream_end");
+    if (!p || !dmoc) return fail(CDFT_ERR_ARG, "cdft_moc_stream_end: NULL argument");
+    if (p->win_npt < 1) return fail(CDFT_ERR_STATE, "cdft_moc_stream_end: cdft_moc_stream_begin has not succeeded");
+    hipStream_t st = as_stream(stream);
+    const int npt = p->win_npt;
+    const size_t out_bytes = (size_t)p->nbasins * p->npj * p->npk * npt * sizeof(double);
+    double *d_out = (double *)p->st_out.ptr;
+    const int nbj = p->nbasins * p->npj;
+    const int64_t nthr = (int64_t)nbj * npt;
+    hipLaunchKernelGGL(moc_cumsum_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, d_out, nbj, p->npk, npt);
+    CDFT_LAUNCH_CHECK();
+    if (dmoc_space == CDFT_MEM_DEVICE) {
+        CDFT_HIP(hipMemcpyAsync(dmoc, d_out, out_bytes, hipMemcpyDeviceToDevice, st));
+    } else if (dmoc_space == CDFT_MEM_HOST || dmoc_space == CDFT_MEM_PINNED) {
+        CDFT_HIP(hipMemcpyAsync(dmoc, d_out, out_bytes, hipMemcpyDeviceToHost, st));
+        if (dmoc_space == CDFT_MEM_HOST) CDFT_HIP(hipStreamSynchronize(st));
+    } else {
+        return fail(CDFT_ERR_ARG, "cdft_moc_stream_end: bad memory-space tag %d", dmoc_space);
+    }
+    p->win_npt = 0;                                           // (the window and the sums stay allocated for the next batch)
+    return CDFT_OK;
+}
+
 int cdft_moc_release_staged(cdft_moc_plan *p) {
     if (!p) return fail(CDFT_ERR_ARG, "cdft_moc_release_staged: NULL plan");
     p->staged = nullptr; p->staged_npt = 0; p->open_npt = 0;
@@ -815,8 +955,8 @@ int cdft_moc_release_staged(cdft_moc_plan *p) {
         (void)hipSetDevice(cur);
         return rc;
     }
-    p->pool.release();
-    p->pool_npt = 0; p->pool_P = 0; p->pool_w = false;
+    p->pool.release(); p->win.release(); p->win_vm.release();
+    p->pool_npt = 0; p->pool_P = 0; p->pool_w = false; p->win_npt = 0;
     return CDFT_OK;
 }
 
@@ -1116,7 +1256,7 @@ int cdft_moc_destroy(cdft_moc_plan *p) {
     if (p->cls) (void)hipFree(p->cls);
     if (p->flag) (void)hipFree(p->flag);
     p->st_e1v.release(); p->st_e3v.release(); p->st_mask.release(); p->st_vm.release(); p->st_zv.release(); p->st_out.release(); p->seg_out.release();
-    p->pool.release();
+    p->pool.release(); p->win.release(); p->win_vm.release(); p->e1v2d.release();
     DevBuf *dec[] = {&p->d_e3v, &p->d_e1u, &p->d_zcoef, &p->d_tmask, &p->d_umask, &p->d_t, &p->d_s, &p->d_zvgeo, &p->d_sig8,
                      &p->d_dvbt, &p->d_hdep, &p->d_dvgeo, &p->d_raw, &p->d_o4, &p->d_pref3d};
     for (DevBuf *b : dec) b->release();

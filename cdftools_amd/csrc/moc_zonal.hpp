@@ -53,8 +53,10 @@ struct ZonalArgs {
     int64_t        w_row;       // elements between consecutive (jj,jk) rows of w   (npi: the reference's dense arrays)
     int64_t        z_row;       // the same for every record of zv (aligned kernels: w_row and z_row equal modulo 4)
     int            npt;
-    double        *out;         // (nbasins,npj,npk,npt): -(zonal sum), levels 1..npk-1
+    double        *out;         // (nbasins,npj,npk,npt): -(zonal sum), levels 1..nlev (of the window)
     int            npi, npj, npk, nbasins;
+    int            nlev;        // levels this launch covers: rows 0 .. npj*nlev-1 of w / zv; npk-1 for a whole domain.  A launch on a
+                                // window of levels k0 .. k0+nlev-1 passes w / zv of the window and out + k0*npj*nbasins.
     int            rows_per_wg; // class kernel: consecutive rows one workgroup works through (>= 1)
     int            xcd_map;     // class kernel: workgroup -> row so that each XCD takes an eighth of the rows of every level
     int            aligned;     // class kernel: record base and stride are multiples of 16 bytes
@@ -270,7 +272,7 @@ template <int NV, int NB, bool ALIGNED, int MODE, int LB>
 static int launch_lb(const ZonalArgs &a, int nwaves, hipStream_t st) {
     const size_t shmem =
         sizeof(double) * ((size_t)nwaves * NB * kScrStride + (size_t)kTChunk * NB * nwaves);
-    const unsigned grid = (unsigned)a.npj * (unsigned)(a.npk - 1);
+    const unsigned grid = (unsigned)a.npj * (unsigned)a.nlev;
     hipLaunchKernelGGL((moc_zonal_kernel<NV, NB, ALIGNED, MODE, LB>), dim3(grid),
                        dim3(kWave * nwaves), shmem, st, a);
     CDFT_LAUNCH_CHECK();
@@ -522,7 +524,7 @@ template <int NV, int KC, int LB, bool ALIGNED>
 __global__ void __launch_bounds__(LB)
 moc_zonal_class_kernel(ZonalArgs a) {
     extern __shared__ double smem[];
-    const int nitems = a.npj * (a.npk - 1) * a.nseg;              // item = row * nseg + segment
+    const int nitems = a.npj * a.nlev * a.nseg;              // item = row * nseg + segment
     int wg = blockIdx.x;
     if (a.xcd_map) {
         // Workgroups go round the 8 XCDs in launch order (workgroup b runs on XCD b % 8).  Mapped like this, XCD x takes the
@@ -536,7 +538,7 @@ moc_zonal_class_kernel(ZonalArgs a) {
         const int j0 = (int)((int64_t)x * a.npj / 8), nrows = (int)((int64_t)(x + 1) * a.npj / 8) - j0;
         if (nrows <= 0) return;
         const int lev = s / nrows;
-        if (lev >= a.npk - 1) return;
+        if (lev >= a.nlev) return;
         wg = lev * a.npj + j0 + (s - lev * nrows);
     }
     const int r0 = wg * a.rows_per_wg, r1 = min(nitems, r0 + a.rows_per_wg);
@@ -549,9 +551,9 @@ moc_zonal_class_kernel(ZonalArgs a) {
 // out = the segments' sums added in segment order (levels 1..npk-1 of every record; level npk is not theirs)
 __global__ void moc_seg_sum_kernel(ZonalArgs a) {
     const int64_t per_level = (int64_t)a.npj * a.nbasins, per_rec = per_level * a.npk;
-    const int64_t n = (int64_t)a.npt * (a.npk - 1) * per_level;
+    const int64_t n = (int64_t)a.npt * a.nlev * per_level;
     for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t t = q / ((a.npk - 1) * per_level), e = t * per_rec + (q - t * (a.npk - 1) * per_level);
+        const int64_t t = q / (a.nlev * per_level), e = t * per_rec + (q - t * a.nlev * per_level);
         double s = a.seg_out[e];
         for (int g = 1; g < a.nseg; ++g) s += a.seg_out[(int64_t)g * a.seg_stride + e];
         a.out[e] = s;
@@ -561,9 +563,9 @@ __global__ void moc_seg_sum_kernel(ZonalArgs a) {
 template <int NV, int KC, int LB>
 static int launch_class_lb(const ZonalArgs &a, int nwaves, hipStream_t st) {
     const size_t shmem = sizeof(double) * ((size_t)nwaves * (KC + 1) * kScrStride + (size_t)kTChunk * KC * nwaves + (kTChunk + 2) / 2 + 1);
-    const unsigned nrows = (unsigned)a.npj * (unsigned)(a.npk - 1) * (unsigned)a.nseg;
+    const unsigned nrows = (unsigned)a.npj * (unsigned)a.nlev * (unsigned)a.nseg;
     unsigned grid = (nrows + (unsigned)a.rows_per_wg - 1) / (unsigned)a.rows_per_wg;
-    if (a.xcd_map) grid = 8u * (unsigned)((a.npj + 7) / 8) * (unsigned)(a.npk - 1);      // (an XCD's rows x levels; a few workgroups find nothing to do)
+    if (a.xcd_map) grid = 8u * (unsigned)((a.npj + 7) / 8) * (unsigned)a.nlev;      // (an XCD's rows x levels; a few workgroups find nothing to do)
     if (a.aligned) hipLaunchKernelGGL((moc_zonal_class_kernel<NV, KC, LB, true>), dim3(grid), dim3(kWave * nwaves), shmem, st, a);
     else           hipLaunchKernelGGL((moc_zonal_class_kernel<NV, KC, LB, false>), dim3(grid), dim3(kWave * nwaves), shmem, st, a);
     CDFT_LAUNCH_CHECK();

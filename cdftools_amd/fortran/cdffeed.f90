@@ -25,7 +25,7 @@ MODULE cdffeed
   TYPE(C_PTR)         :: hfeed = C_NULL_PTR
   INTEGER(KIND=8)     :: nslot_bytes = 0
 
-  PUBLIC :: feed_moc_record
+  PUBLIC :: feed_moc_record, feed_moc_window, feed_moc_window_mask, feed_levels
   PUBLIC :: feed_wanted, feed_open, feed_close, feed_field, feed_mask, feed_host, feed_device, feed_release, feed_sig_record, feed_mean_mesh
 
   ! feed_sig_record's slab buffers (kept from record to record): T and S of a slab in HBM, two page-locked result slabs
@@ -159,6 +159,65 @@ CONTAINS
             &         'cdft_feed_push_rows')
     END DO
   END SUBROUTINE feed_moc_record
+
+  INTEGER(KIND=4) FUNCTION feed_levels(kpi, kpj, kpk)
+    !! the levels of a (kpi,kpj,kpk) r4 field that one slot of the ring holds (the ring is made for such fields if it is not there)
+    INTEGER(KIND=4), INTENT(in) :: kpi, kpj, kpk
+    INTEGER(KIND=8) :: islab
+    islab = 4_8 * kpi * kpj
+    CALL feed_size(islab, islab * kpk)
+    feed_levels = INT(MAX(1_8, nslot_bytes / islab), 4)
+  END FUNCTION feed_levels
+
+  SUBROUTINE feed_moc_window(cdfile, cdvar, plan, kslot, kpi, kpj, klev0, knlev, ktime, ldiom)
+    !! cdfmoc, the stream route: levels klev0 .. klev0+knlev-1 of record ktime of cdvar (the reference's getvar per level,
+    !! src/cdfmoc.f90:357; kslot = 0: the metric e3v, :343-348) into slot kslot of the plan's window of levels, a ring slot at a
+    !! time: the H2D copy spreads the rows to the window's pitch (cdft_feed_push_rows)
+    CHARACTER(LEN=*),  INTENT(in) :: cdfile, cdvar
+    TYPE(C_PTR),       INTENT(in) :: plan
+    INTEGER(KIND=4),   INTENT(in) :: kslot, kpi, kpj, klev0, knlev, ktime
+    LOGICAL, OPTIONAL, INTENT(in) :: ldiom
+    INTEGER(KIND=4) :: ik0, inl, inlmax
+    INTEGER(KIND=8) :: islab
+    INTEGER(C_SIZE_T) :: ibytes, ipitch
+    TYPE(C_PTR) :: pslot, pdst
+    REAL(KIND=4), POINTER :: zslab(:,:,:)
+    islab = 4_8 * kpi * kpj
+    CALL feed_size(islab, islab * knlev)
+    inlmax = INT(MAX(1_8, nslot_bytes / islab), 4)
+    DO ik0 = 1, knlev, inlmax
+       inl = MIN(inlmax, knlev - ik0 + 1)
+       CALL hip_check(cdft_feed_slot(hfeed, pslot, ibytes), 'cdft_feed_slot')
+       CALL C_F_POINTER(pslot, zslab, (/ kpi, kpj, inl /))
+       CALL readvar3d(cdfile, cdvar, zslab, ktime=ktime, ldiom=ldiom, kkmin=klev0 + ik0 - 1)
+       CALL hip_check(cdft_moc_stream_dest(plan, INT(kslot, C_INT), INT(ik0 - 1, C_INT), pdst, ipitch), 'cdft_moc_stream_dest')
+       CALL hip_check(cdft_feed_push_rows(hfeed, pdst, 0_C_SIZE_T, ipitch, INT(4_8 * kpi, C_SIZE_T), INT(kpj, C_SIZE_T) * inl), &
+            &         'cdft_feed_push_rows')
+    END DO
+  END SUBROUTINE feed_moc_window
+
+  SUBROUTINE feed_moc_window_mask(cdfile, cdvar, plan, kpi, kpj, klev0, knlev)
+    !! the same for the window's mask, as bytes (dense in HBM: a plain copy)
+    CHARACTER(LEN=*), INTENT(in) :: cdfile, cdvar
+    TYPE(C_PTR),      INTENT(in) :: plan
+    INTEGER(KIND=4),  INTENT(in) :: kpi, kpj, klev0, knlev
+    INTEGER(KIND=4) :: ik0, inl, inlmax
+    INTEGER(KIND=8) :: islab
+    INTEGER(C_SIZE_T) :: ibytes
+    TYPE(C_PTR) :: pslot, pdst
+    INTEGER(KIND=1), POINTER :: islabs(:,:,:)
+    islab = 1_8 * kpi * kpj
+    CALL feed_size(4 * islab, 4 * islab * knlev)
+    inlmax = INT(MAX(1_8, nslot_bytes / islab), 4)
+    DO ik0 = 1, knlev, inlmax
+       inl = MIN(inlmax, knlev - ik0 + 1)
+       CALL hip_check(cdft_feed_slot(hfeed, pslot, ibytes), 'cdft_feed_slot')
+       CALL C_F_POINTER(pslot, islabs, (/ kpi, kpj, inl /))
+       CALL readvar3d_i1(cdfile, cdvar, islabs, kkmin=klev0 + ik0 - 1)
+       CALL hip_check(cdft_moc_stream_vmask_dest(plan, INT(ik0 - 1, C_INT), pdst), 'cdft_moc_stream_vmask_dest')
+       CALL hip_check(cdft_feed_push(hfeed, pdst, 0_C_SIZE_T, INT(islab * inl, C_SIZE_T)), 'cdft_feed_push')
+    END DO
+  END SUBROUTINE feed_moc_window_mask
 
   SUBROUTINE feed_mask(cdfile, cdvar, pdev, kpi, kpj, kpk, ktime)
     !! a (kpi,kpj,kpk) mask as bytes into the device array pdev, the same way

@@ -16,6 +16,13 @@ PROGRAM cdfmoc
   !! Host feed (module cdffeed): on one device, without -decomp / -full, nothing 3-D is held in host memory -- the metric,
   !! its mask and every velocity record go from the file to HBM slab by slab through a page-locked ring, the copy of one
   !! slab under the read of the next, so a record costs its read, not its read plus its transfer (CDFT_FEED=0: the old way).
+  !! With the feed on (and no -vvl) nothing 3-D is held in HBM either: the STREAM route (run_stream below) takes the domain
+  !! through HBM a window of levels at a time -- the window's e3v, vmask and the same levels of EVERY record of the run, each
+  !! (jj,jk) row's metric and records in one run -- and one launch per window streams all the records past the row's weights:
+  !! every byte read from the files is read from HBM once, 4*(1+1/npt) bytes per cell and record as on bench.py's resident
+  !! pool, with 1.6 GB of HBM instead of 61 GB at eORCA12 x 12 (allocating HBM costs about what reading the file does).
+  !! CDFT_MOC_ROUTE = stream (default) | pool (all records resident in the plan's pool, ONE launch: bench.py's very call)
+  !! | record (a launch per record on dense arrays, the weights read again for each).
   !!======================================================================
   USE ISO_C_BINDING
   USE cdfio
@@ -61,6 +68,9 @@ PROGRAM cdfmoc
   INTEGER(KIND=8) :: nij8, n38
   LOGICAL :: lfeed
   LOGICAL :: lpool = .FALSE.                                  ! the records of a batch go into the plan's pool: one zonal launch for all
+  LOGICAL :: lstream = .FALSE.                                ! the stream route: windows of levels, nothing 3-D resident
+  INTEGER(KIND=4) :: nlevw = 1                                ! levels per window
+  CHARACTER(LEN=16) :: croute
   INTEGER(C_SIZE_T) :: ifree, itotal
   INTEGER(C_INT64_T) :: ilaunch, irecs
   REAL(KIND=8) :: dl_field
@@ -190,15 +200,24 @@ PROGRAM cdfmoc
   ! the weights (cdft_moc_compute_staged) -- 4*(1+1/npt) bytes per cell and record instead of 8 (DESIGN 4.1).  The batch is
   ! what HBM holds: the pool is (1 + nbatch) fields, beside the plan's weights and the mesh fields on their way through.
   ! CDFT_MOC_BATCH=n sets it (1: the record-by-record way).
-  IF ( lfeed .AND. npt > 1 .AND. .NOT. lg_vvl ) THEN
+  croute = 'stream'
+  CALL GET_ENVIRONMENT_VARIABLE('CDFT_MOC_ROUTE', cldum)
+  IF ( LEN_TRIM(cldum) > 0 ) croute = cldum(1:16)
+  IF ( lfeed .AND. .NOT. lg_vvl .AND. croute /= 'record' ) THEN
      CALL hip_check(cdft_mem_info(ifree, itotal), 'cdft_mem_info')
      dl_field = 4.d0 * ( ( npiglo + 3 ) / 4 * 4 ) * REAL(npjglo, 8) * npk
-     nbatch = MIN(npt, INT(MIN(1.d6, ( 0.92d0 * REAL(ifree, 8) - 2.3d0 * dl_field ) / dl_field)) - 1)
+     IF ( croute == 'pool' ) THEN                          ! every record of a batch resident: (1 + nbatch) fields + weights + mesh
+        nbatch = MIN(npt, INT(MIN(1.d6, ( 0.92d0 * REAL(ifree, 8) - 2.3d0 * dl_field ) / dl_field)) - 1)
+     ELSE                                                  ! a window of nlevw levels of 1 + nbatch slabs in half of what is free
+        nlevw  = MAX(1, MIN(npk - 1, feed_levels(npiglo, npjglo, npk)))
+        nbatch = MIN(npt, INT(MIN(1.d6, 0.5d0 * REAL(ifree, 8) / ( dl_field / npk * nlevw ))) - 1)
+     ENDIF
      CALL GET_ENVIRONMENT_VARIABLE('CDFT_MOC_BATCH', cldum)
      IF ( LEN_TRIM(cldum) > 0 ) THEN
         READ(cldum, *) nbatch ; nbatch = MIN(npt, nbatch)
      ENDIF
-     lpool = nbatch >= 2
+     lpool   = croute == 'pool' .AND. nbatch >= 2
+     lstream = croute /= 'pool' .AND. nbatch >= 1
      nbatch = MAX(1, nbatch)
   ENDIF
   ! -decomp: V, T and S of a record go through the ring too (the mesh of the decomposition stays a host array: once per run)
@@ -270,6 +289,10 @@ PROGRAM cdfmoc
   ENDIF
 
   it0 = 1
+  IF ( lstream ) THEN
+     CALL run_stream
+     it0 = npt + 1                                        ! (the record loop below has nothing left to do)
+  ENDIF
   DO WHILE ( it0 <= npt )
      nrec = MIN(nbatch, npt - it0 + 1)
      IF ( it0 == 1 .OR. lg_vvl ) THEN                     ! e3v masked by vmask, every level (get_e3v)
@@ -362,21 +385,7 @@ PROGRAM cdfmoc
              &                          CDFT_MEM_HOST, C_NULL_PTR), 'cdft_moc_compute')
      ENDIF
      CALL tick(4)
-     DO jr = 1, nrec
-        jt = it0 + jr - 1
-        ijvar = 1
-        DO jbasin = 1, nbasins
-           DO jk = 1, npk
-              ierr = putvar(ncout, id_varout(ijvar), REAL(dmoc(jbasin,:,jk,jr)), jk, 1, npjglo, ktime=jt)
-           END DO
-           ijvar = ijvar + 1
-        END DO
-        IF ( lbas ) THEN                                  ! net Indo-Pacific = global - Atlantic
-           DO jk = 1, npk
-              ierr = putvar(ncout, id_varout(ijvar), REAL(dmoc(npglo,:,jk,jr) - dmoc(npatl,:,jk,jr)), jk, 1, npjglo, ktime=jt)
-           END DO
-        ENDIF
-     END DO
+     CALL put_batch
      it0 = it0 + nrec
   END DO
 
@@ -394,7 +403,7 @@ PROGRAM cdfmoc
   IF ( lfeed_dec .AND. C_ASSOCIATED(pd_t) ) THEN
      CALL feed_release(pd_zv) ; CALL feed_release(pd_t) ; CALL feed_release(pd_s) ; CALL feed_close()
   ENDIF
-  IF ( lfeed ) THEN
+  IF ( lfeed .AND. .NOT. lstream ) THEN
      CALL feed_release(pd_zv) ; CALL feed_release(pd_e3v) ; CALL feed_release(pd_vm) ; CALL feed_release(pd_e1v) ; CALL feed_release(pd_ib)
      CALL feed_close()
   ENDIF
@@ -404,6 +413,57 @@ PROGRAM cdfmoc
        &                                 '  GPU calls (H2D + kernels + D2H)', dl_t(4), '  output', dl_t(5)
 
 CONTAINS
+
+  SUBROUTINE put_batch
+    !! the nrec records of dmoc, from record it0 on, into moc.nc (src/cdfmoc.f90:520-551)
+    DO jr = 1, nrec
+       jt = it0 + jr - 1
+       ijvar = 1
+       DO jbasin = 1, nbasins
+          DO jk = 1, npk
+             ierr = putvar(ncout, id_varout(ijvar), REAL(dmoc(jbasin,:,jk,jr)), jk, 1, npjglo, ktime=jt)
+          END DO
+          ijvar = ijvar + 1
+       END DO
+       IF ( lbas ) THEN                                  ! net Indo-Pacific = global - Atlantic
+          DO jk = 1, npk
+             ierr = putvar(ncout, id_varout(ijvar), REAL(dmoc(npglo,:,jk,jr) - dmoc(npatl,:,jk,jr)), jk, 1, npjglo, ktime=jt)
+          END DO
+       ENDIF
+    END DO
+  END SUBROUTINE put_batch
+
+  SUBROUTINE run_stream
+    !! The stream route.  The reference's loops are record { level { read zv(:,:) ; basin { jj { ji } } } } (:338-379); a sum
+    !! over ji of one (jj,jk) row of one record depends on nothing else, so here the order is batch of records { window of
+    !! levels { read e3v, vmask of the window ; record { read the window's levels } ; ONE launch } }, then the cumulated sums
+    !! (:382-388) of every record of the batch and their output.  Each file byte is read once per batch (the metric once per
+    !! batch: once per run when the records fit one batch), each HBM byte once.
+    INTEGER(KIND=4) :: ik0, inl
+    CALL tick(1)
+    CALL hip_check(cdft_moc_set_basins(plan, e1v, ibmask, CDFT_MEM_HOST, C_NULL_PTR), 'cdft_moc_set_basins')
+    CALL feed_open()
+    DO WHILE ( it0 <= npt )
+       nrec = MIN(nbatch, npt - it0 + 1)
+       CALL hip_check(cdft_moc_stream_begin(plan, nrec, nlevw, feed_stream), 'cdft_moc_stream_begin')
+       DO ik0 = 1, npk - 1, nlevw                           ! levels 1 .. npk-1, as the reference reads them (:355)
+          inl = MIN(nlevw, npk - ik0)
+          CALL feed_moc_window_mask(cn_fmsk, cn_vmask, plan, npiglo, npjglo, ik0, inl)
+          CALL feed_moc_window(cn_fe3v, cn_ve3v, plan, 0, npiglo, npjglo, ik0, inl, ktime=1, ldiom=.TRUE.)
+          DO jr = 1, nrec
+             CALL feed_moc_window(cf_vfil, cn_vomecrty, plan, jr, npiglo, npjglo, ik0, inl, ktime=it0 + jr - 1)
+          END DO
+          CALL hip_check(cdft_moc_stream_compute(plan, INT(ik0 - 1, C_INT), INT(inl, C_INT), 1_C_INT, feed_stream), 'cdft_moc_stream_compute')
+       END DO
+       CALL tick(3)
+       CALL hip_check(cdft_moc_stream_end(plan, dmoc, CDFT_MEM_HOST, feed_stream), 'cdft_moc_stream_end')
+       CALL tick(4)
+       CALL put_batch
+       CALL tick(5)
+       it0 = it0 + nrec
+    END DO
+    CALL feed_close()
+  END SUBROUTINE run_stream
 
   SUBROUTINE tick(kphase)
     !! the time since the last call goes to phase kphase

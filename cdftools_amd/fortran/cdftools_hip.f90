@@ -144,6 +144,26 @@ MODULE cdftools_hip
      INTEGER(C_INT) FUNCTION cdft_moc_describe(plan, buf, buflen) BIND(C, name='cdft_moc_describe')
        IMPORT ; TYPE(C_PTR), VALUE :: plan ; CHARACTER(KIND=C_CHAR), INTENT(out) :: buf(*) ; INTEGER(C_SIZE_T), VALUE :: buflen
      END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_moc_set_basins(plan, e1v, ibmask, memspace, stream) BIND(C, name='cdft_moc_set_basins')
+       IMPORT ; TYPE(C_PTR), VALUE :: plan, stream ; REAL(C_FLOAT), INTENT(in) :: e1v(*)
+       INTEGER(C_INT16_T), INTENT(in) :: ibmask(*) ; INTEGER(C_INT), VALUE :: memspace
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_moc_stream_begin(plan, npt, nlev, stream) BIND(C, name='cdft_moc_stream_begin')
+       IMPORT ; TYPE(C_PTR), VALUE :: plan, stream ; INTEGER(C_INT), VALUE :: npt, nlev
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_moc_stream_dest(plan, slot, level, dst, row_pitch_bytes) BIND(C, name='cdft_moc_stream_dest')
+       IMPORT ; TYPE(C_PTR), VALUE :: plan ; INTEGER(C_INT), VALUE :: slot, level
+       TYPE(C_PTR), INTENT(out) :: dst ; INTEGER(C_SIZE_T), INTENT(out) :: row_pitch_bytes
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_moc_stream_vmask_dest(plan, level, dst) BIND(C, name='cdft_moc_stream_vmask_dest')
+       IMPORT ; TYPE(C_PTR), VALUE :: plan ; INTEGER(C_INT), VALUE :: level ; TYPE(C_PTR), INTENT(out) :: dst
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_moc_stream_compute(plan, k0, nlev, with_vmask, stream) BIND(C, name='cdft_moc_stream_compute')
+       IMPORT ; TYPE(C_PTR), VALUE :: plan, stream ; INTEGER(C_INT), VALUE :: k0, nlev, with_vmask
+     END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_moc_stream_end(plan, dmoc, dmoc_space, stream) BIND(C, name='cdft_moc_stream_end')
+       IMPORT ; TYPE(C_PTR), VALUE :: plan, stream ; INTEGER(C_INT), VALUE :: dmoc_space ; REAL(C_DOUBLE), INTENT(out) :: dmoc(*)
+     END FUNCTION
      INTEGER(C_INT) FUNCTION cdft_moc_stage_open(plan, npt, stream) BIND(C, name='cdft_moc_stage_open')
        IMPORT ; TYPE(C_PTR), VALUE :: plan, stream ; INTEGER(C_INT), VALUE :: npt
      END FUNCTION

@@ -257,6 +257,37 @@ class MocPlan:
         base = C.c_void_p(pz.value + 4 * self.npi * j0)
         check(_lib.load().cdft_moc_stage_rows(self._h, base, lev * self.npk, lev, npt, sz, stream or current_stream_ptr()))
 
+    # ---- the stream route (cdft_moc_stream_*): a window of levels at a time, nothing 3-D resident
+    def set_basins(self, e1v, ibmask, stream=None):
+        p1, s1, k1 = _arg(e1v, np.float32, "e1v")
+        pm, sm, km = _arg(ibmask, np.int16, "ibmask")
+        if s1 != sm:
+            raise ValueError("e1v and ibmask must live in the same memory space")
+        self._mesh_keep = (k1, km)
+        check(_lib.load().cdft_moc_set_basins(self._h, p1, pm, s1, stream or current_stream_ptr()))
+
+    def stream_begin(self, npt, nlev, stream=None):
+        check(_lib.load().cdft_moc_stream_begin(self._h, int(npt), int(nlev), stream or current_stream_ptr()))
+
+    def stream_dest(self, slot, level):
+        """-> (device address of row 1 of `level` of the window in slot `slot` (0: metric, 1..npt: records), bytes between rows)"""
+        d, pitch = C.c_void_p(), C.c_size_t(0)
+        check(_lib.load().cdft_moc_stream_dest(self._h, int(slot), int(level), C.byref(d), C.byref(pitch)))
+        return d.value, pitch.value
+
+    def stream_vmask_dest(self, level):
+        d = C.c_void_p()
+        check(_lib.load().cdft_moc_stream_vmask_dest(self._h, int(level), C.byref(d)))
+        return d.value
+
+    def stream_compute(self, k0, nlev, with_vmask=True, stream=None):
+        check(_lib.load().cdft_moc_stream_compute(self._h, int(k0), int(nlev), 1 if with_vmask else 0, stream or current_stream_ptr()))
+
+    def stream_end(self, out, stream=None):
+        po, so, ko = _arg(out, np.float64, "dmoc")
+        check(_lib.load().cdft_moc_stream_end(self._h, po, so, stream or current_stream_ptr()))
+        return out
+
     def stage_open(self, npt, stream=None):
         """cdft_moc_stage_open: the pool laid out for npt records the caller will write itself (weights brought in)."""
         check(_lib.load().cdft_moc_stage_open(self._h, int(npt), stream or current_stream_ptr()))

@@ -208,6 +208,29 @@ int cdft_moc_stage_dest(cdft_moc_plan *plan, int record, int level, void **dst, 
 int cdft_moc_stage_close(cdft_moc_plan *plan);
 int cdft_moc_release_staged(cdft_moc_plan *plan);
 int cdft_moc_compute_staged(cdft_moc_plan *plan, double *dmoc, int dmoc_space, void *stream);
+/* The stream route: cdfmoc with NOTHING 3-D resident -- what the cdfmoc program does when its fields are large.  The reference
+ * reads one (npiglo,npjglo) slab per level and record and works on it (src/cdfmoc.f90:355-379); here the domain goes through
+ * HBM a WINDOW of nlev levels at a time, every record of the run beside the window's metric, laid out like the pool: row
+ * (jj,jk) of the window owns one run of 1+npt slots -- slot 0 the raw e3v of the row (src/cdfmoc.f90:343-348), slots 1..npt
+ * the row of records 1..npt -- so that one launch per window streams all the records past the weights and every byte that
+ * came from the files is read from HBM once: the same 4*(1+1/npt) bytes per cell and record as the resident pool, with
+ * (1+npt) * nlev slabs of HBM instead of (1+npt) * npk (1.6 GB instead of 61 GB at eORCA12 with 12 records and nlev = 2:
+ * hipMalloc costs about as much per byte as reading the file does).  The caller reads its files level-window by
+ * level-window (records inner) and writes each slab where _dest says (cdft_feed_push_rows).
+ *   cdft_moc_set_basins   the 2-D part of cdft_moc_set_mesh: e1v (npiglo,npjglo) r4 and ibmask (nbasins,npiglo,npjglo) i2
+ *   cdft_moc_stream_begin the window for npt records and nlev levels (allocated once, zeroed), the sums of the run zeroed
+ *   cdft_moc_stream_dest  slot 0..npt, level 0..nlev-1 of the window -> address of its row jj = 1 and the pitch between rows
+ *   cdft_moc_stream_vmask_dest  where the vmask bytes (npiglo,npjglo) of level `level` of the window go (dense)
+ *   cdft_moc_stream_compute     the window holds levels k0 .. k0+nlev-1 (0-based, < npk-1): slot 0 becomes the weight
+ *                         e1v*(e3v*vmask) in place (with_vmask = 0: e3v arrives masked), then the zonal kernel of the window;
+ *                         queued on `stream` -- the stream the copies were queued on -- so the next window's copies follow it
+ *   cdft_moc_stream_end   the cumulated sums (src/cdfmoc.f90:382-388) and dmoc (nbasins,npjglo,npk,npt) as cdft_moc_compute's */
+int cdft_moc_set_basins(cdft_moc_plan *plan, const float *e1v, const int16_t *ibmask, int memspace, void *stream);
+int cdft_moc_stream_begin(cdft_moc_plan *plan, int npt, int nlev, void *stream);
+int cdft_moc_stream_dest(cdft_moc_plan *plan, int slot, int level, void **dst, size_t *row_pitch_bytes);
+int cdft_moc_stream_vmask_dest(cdft_moc_plan *plan, int level, void **dst);
+int cdft_moc_stream_compute(cdft_moc_plan *plan, int k0, int nlev, int with_vmask, void *stream);
+int cdft_moc_stream_end(cdft_moc_plan *plan, double *dmoc, int dmoc_space, void *stream);
 /* zonal-kernel launches this plan has made and the records they covered (12 records in 1 launch: every input byte read once;
  * 12 launches: the weights read 12 times) -- what a program prints under CDFT_TIMING and what the tests assert */
 int cdft_moc_stats(cdft_moc_plan *plan, int64_t *zonal_launches, int64_t *records);

@@ -31,9 +31,10 @@ def case(tools, tmp_path_factory):  # noqa: F811
 
 V, U, T = "SYN_y0001_gridV.nc", "SYN_y0001_gridU.nc", "SYN_y0001_gridT.nc"
 RUNS = [
-    # (record by record: with several records the feed writes them into the plan's pool and ONE launch reads them all -- other
-    # r8 additions along i than the dense records of the pageable route, within 1 ulp(r4) in the file: tests/test_moc_pool_feed.py)
-    ("cdfmoc", ["-v", V], ["moc.nc"], {"CDFT_MOC_BATCH": "1"}),
+    # (record by record: by default the feed takes the domain through HBM in windows of levels laid out like the plan's pool --
+    # other r8 additions along i than the dense records of the pageable route, within 1 ulp(r4) in the file:
+    # tests/test_moc_pool_feed.py)
+    ("cdfmoc", ["-v", V], ["moc.nc"], {"CDFT_MOC_ROUTE": "record"}),
     ("cdfmoc", ["-v", "VVL_y0001_gridV.nc", "-vvl"], ["moc.nc"]),
     ("cdfheatc", ["-f", T], ["heatc.nc"]),
     ("cdfheatc", ["-f", T, "-full"], ["heatc.nc"]),

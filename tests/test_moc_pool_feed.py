@@ -115,6 +115,65 @@ def test_records_written_into_the_pool_by_the_feed_equal_staged_records(gpu, npi
     plan.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("npi,npj,npk,nb,npt,nlev", [(24, 18, 7, 5, 2, 2), (182, 29, 9, 5, 3, 3), (65, 5, 4, 1, 2, 1), (4322, 3, 5, 5, 12, 2),
+                                                     (1442, 5, 3, 5, 4, 5), (12960, 2, 3, 5, 2, 1)])
+def test_the_stream_route_equals_the_resident_pool(gpu, npi, npj, npk, nb, npt, nlev):
+    """cdft_moc_set_basins + cdft_moc_stream_begin / _dest / _vmask_dest / _compute / _end: the domain a window of nlev levels
+    at a time (raw e3v, vmask bytes and every record's levels pushed through the ring, the weights formed in the window),
+    no 3-D array resident == cdft_moc_set_mesh_vmask + cdft_moc_stage + cdft_moc_compute_staged, bit for bit (the same rows
+    in the same layout); one launch per window, every launch covering all npt records; two runs on one plan alike"""
+    from cdftools_amd import _lib
+    lib = _lib.load()
+    g = synth.make_grid(npi, npj, npk, seed=2 * npi + npj, nbasins=nb)
+    e1v, e3v, ib = synth.moc_inputs(g)
+    vm = (e3v != 0).astype(np.int8)
+    raw = (e3v + (1 - vm) * np.float32(7.5)).astype(np.float32)          # the file's e3v: not masked
+    zv = synth.velocity(g, npt, seed=9)
+    ref = oracle_lib.moc(e1v, e3v, ib, zv)
+    a_plan = gpu.MocPlan(npi, npj, npk, nb)
+    a_plan.set_mesh(e1v, raw, ib, vmask=vm)
+    a_plan.stage(zv)
+    a = a_plan.compute_staged(np.zeros_like(ref))
+    a_plan.close()
+    assert np.all(np.abs(a - ref) <= 1e-13 * -oracle_lib.moc(e1v, e3v, ib, np.abs(zv)) + 1e-300)
+
+    plan = gpu.MocPlan(npi, npj, npk, nb)
+    with pytest.raises(gpu.CdftError):
+        plan.stream_begin(npt, nlev)                          # no basins yet
+    plan.set_basins(e1v, ib)
+    feed, st = C.c_void_p(), C.c_void_p()
+    gpu.check(lib.cdft_feed_create(C.byref(feed), nlev * npj * npi * 4, 3))
+    gpu.check(lib.cdft_feed_stream(feed, C.byref(st)))
+    for run_ in range(2):
+        plan.stream_begin(npt, nlev, stream=st)
+        n0 = plan.stats()
+        nwin = 0
+        for k0 in range(0, npk - 1, nlev):
+            k1 = min(k0 + nlev, npk - 1)
+            host, nbytes = C.c_void_p(), C.c_size_t(0)
+            gpu.check(lib.cdft_feed_slot(feed, C.byref(host), C.byref(nbytes)))
+            n = (k1 - k0) * npj * npi
+            np.frombuffer((C.c_char * n).from_address(host.value), dtype=np.int8)[:] = vm[k0:k1].ravel()
+            gpu.check(lib.cdft_feed_push(feed, C.c_void_p(plan.stream_vmask_dest(0)), 0, n))
+            for slot in range(npt + 1):
+                src = raw[k0:k1] if slot == 0 else zv[slot - 1, k0:k1]
+                dst, pitch = plan.stream_dest(slot, 0)
+                assert pitch == 4 * (npt + 1) * ((npi + 3) // 4 * 4) and dst % 16 == 0
+                _push_rows(gpu, lib, feed, dst, pitch, src.reshape(-1, npi), (k1 - k0) * npj)
+            plan.stream_compute(k0, k1 - k0, stream=st)
+            nwin += 1
+        with pytest.raises(gpu.CdftError):
+            plan.stream_compute(npk - 1, 1, stream=st)        # level npk is never read (src/cdfmoc.f90:355)
+        b = plan.stream_end(np.full(ref.shape, np.nan), stream=st)
+        assert np.array_equal(a, b)
+        assert plan.stats() == (n0[0] + nwin, n0[1] + nwin * npt) and "layout=pool" in plan.describe()
+    with pytest.raises(gpu.CdftError):
+        plan.stream_dest(0, 0)                                # ended: begin again first
+    gpu.check(lib.cdft_feed_destroy(feed))
+    plan.close()
+
+
 def _plan_line(err):
     m = PLAN_LINE.search(err)
     assert m, err[-600:]
@@ -133,39 +192,55 @@ def test_the_program_runs_one_launch_on_the_pool_and_writes_the_reference_progra
     got, got_arr = pc.run_case(BIN, case, d, env={"CDFT_FEED": "1"})
     bad = [x for x in diff_case(case, ref, ref_arr, got, got_arr) if not explained(case[0], x[0], x[1])]
     assert not bad, bad[:10]
+    npt, npk = rec_["v"].shape[0], rec_["v"].shape[1]
+    # the default, the stream route: windows of levels, EVERY launch covers all the run's records, in the pool layout
     rc, out, err = run("cdfmoc", case[2], d, env={"CDFT_FEED": "1", "CDFT_TIMING": "1"})
     assert rc == 0, out + err
     desc, launches, records = _plan_line(err)
-    assert "layout=pool" in desc and (launches, records) == (1, rec_["v"].shape[0]), err[-400:]
-    # record by record (CDFT_MOC_BATCH=1): as many launches as records, on the dense record
-    rc, out, err = run("cdfmoc", case[2], d, env={"CDFT_FEED": "1", "CDFT_TIMING": "1", "CDFT_MOC_BATCH": "1"})
+    assert "layout=pool" in desc and records == launches * npt and 1 <= launches <= npk - 1, err[-400:]
+    # CDFT_MOC_ROUTE=pool: all records resident in the plan's pool, ONE launch -- bench.py's very call
+    got, got_arr = pc.run_case(BIN, case, d, env={"CDFT_FEED": "1", "CDFT_MOC_ROUTE": "pool"})
+    bad = [x for x in diff_case(case, ref, ref_arr, got, got_arr) if not explained(case[0], x[0], x[1])]
+    assert not bad, bad[:10]
+    rc, out, err = run("cdfmoc", case[2], d, env={"CDFT_FEED": "1", "CDFT_TIMING": "1", "CDFT_MOC_ROUTE": "pool"})
     desc, launches, records = _plan_line(err)
-    assert rc == 0 and "layout=pool" not in desc and launches == records == rec_["v"].shape[0]
+    assert rc == 0 and "layout=pool" in desc and (launches, records) == (1, npt), err[-400:]
+    # record by record: as many launches as records, on the dense record
+    rc, out, err = run("cdfmoc", case[2], d, env={"CDFT_FEED": "1", "CDFT_TIMING": "1", "CDFT_MOC_ROUTE": "record"})
+    desc, launches, records = _plan_line(err)
+    assert rc == 0 and "layout=pool" not in desc and launches == records == npt
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("ring", [{}, {"CDFT_FEED_MB": "0.0001", "CDFT_FEED_SLOTS": "2"}, {"CDFT_FEED_ROWS": "2d"}],
                          ids=["default_ring", "one_plane_two_slots", "pitched_copies"])
 def test_the_program_in_batches_of_records(tools, tmp_path, ring):  # noqa: F811
-    """five records in batches of 2 (CDFT_MOC_BATCH: 2 + 2 + 1 -- the pool is laid out anew for the last one), of 5 and record
-    by record: the same moc.nc within 1 ulp(r4) of the oracle whichever way, the batched ways byte-identical to each other"""
+    """five records, the three routes (CDFT_MOC_ROUTE), in batches of 2 (CDFT_MOC_BATCH: 2 + 2 + 1 -- the pool / the window is
+    laid out anew for the last one), of 5, of 1: the same moc.nc within 1 ulp(r4) of the oracle whichever way, and the same bits
+    from every way that reads the pool layout (a row's sums depend on nothing but the row there)"""
     d = str(tmp_path)
     g, rec = nemo_files.make_case(d, npi=70, npj=23, npk=9, npt=5)
     e1v, e3v, ib = synth.moc_inputs(g, nbasins=5)
     ref = oracle_lib.moc(e1v, e3v, ib, rec["v"])
     files = {}
-    for batch, want in (("2", (3, 5)), ("5", (1, 5)), ("1", (5, 5)), ("", (1, 5))):
-        env = dict(ring, CDFT_FEED="1", CDFT_TIMING="1")
+    one_plane = "CDFT_FEED_MB" in ring
+    nwin = 8 if one_plane else 1                            # windows of one level (a slot holds one plane) or of all eight
+    for route, batch, want in (("pool", "2", (3, 5)), ("pool", "5", (1, 5)), ("pool", "", (1, 5)), ("record", "", (5, 5)),
+                               ("stream", "", (nwin, 5 * nwin)), ("stream", "2", (3 * nwin, 5 * nwin)), ("stream", "1", (5 * nwin, 5 * nwin))):
+        env = dict(ring, CDFT_FEED="1", CDFT_TIMING="1", CDFT_MOC_ROUTE=route)
         if batch:
             env["CDFT_MOC_BATCH"] = batch
-        rc, out, err = run("cdfmoc", ["-v", "SYN_y0001_gridV.nc", "-o", f"moc{batch}.nc"], d, env=env)
+        key = route + batch
+        rc, out, err = run("cdfmoc", ["-v", "SYN_y0001_gridV.nc", "-o", f"moc{key}.nc"], d, env=env)
         assert rc == 0, out + err
         desc, launches, records = _plan_line(err)
-        assert (launches, records) == want and ("layout=pool" in desc) == (batch != "1"), (batch, err[-300:])
-        var, _, _ = read_nc(os.path.join(d, f"moc{batch}.nc"))
+        assert (launches, records) == want and ("layout=pool" in desc) == (route != "record"), (key, err[-300:])
+        var, _, _ = read_nc(os.path.join(d, f"moc{key}.nc"))
         for b, nm in enumerate(["zomsfglo", "zomsfatl", "zomsfinp", "zomsfind", "zomsfpac"]):
             w = ref[..., b].astype(np.float32)
-            assert np.all(np.abs(var[nm][:, :, :, 0] - w) <= np.spacing(np.abs(w))), (batch, nm)
-        files[batch] = {k: v for k, v in var.items()}
-    for k in files["2"]:
-        assert np.array_equal(files["2"][k], files["5"][k]) and np.array_equal(files["5"][k], files[""][k]), k
+            assert np.all(np.abs(var[nm][:, :, :, 0] - w) <= np.spacing(np.abs(w))), (key, nm)
+        files[key] = {k: v for k, v in var.items()}
+    for key in files:                                       # every route that reads the pool layout: the same bits
+        if key != "record":
+            for k in files["pool"]:
+                assert np.array_equal(files[key][k], files["pool"][k]), (key, k)

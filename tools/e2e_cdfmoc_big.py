@@ -198,14 +198,17 @@ def main():
         e2e["feed" if feed else "whole_records"] = {
             "wall_s": wall, "phases_s": ph, "per_record_s": round((ph["data_reads"] + ph["gpu_calls"] - (0 if feed else 0)) / npt, 4),
             "grid_cells_per_s": npi * npj * npk * npt / wall, "phases_line": line}
-    # the feed record by record (CDFT_MOC_BATCH=1: a launch per record on a dense record, the weights read again every time)
-    # beside the feed into the pool (the default: one launch for all records)
-    best = None
-    for i in range(2):
-        wall, line, rest, ph = run_program(True, "moc_feed_rec.nc", {"CDFT_MOC_BATCH": "1"}, "feed_record_by_record")
-        if best is None or wall < best[0]:
-            best = (wall, line, ph)
-    e2e["feed_record_by_record"] = {"wall_s": best[0], "phases_s": best[2], "phases_line": best[1]}
+    # the feed's other routes beside the default (stream: windows of levels, every record of the run per launch, nothing 3-D
+    # resident): record by record (a launch per record on a dense record, the weights read again every time) and the resident
+    # pool (all records in HBM, ONE launch: bench.py's call -- and a 61 GB allocation at eORCA12 x 12)
+    for key, more in (("feed_record_by_record", {"CDFT_MOC_ROUTE": "record"}), ("feed_resident_pool", {"CDFT_MOC_ROUTE": "pool"})):
+        best = None
+        for i in range(2):
+            wall, line, rest, ph = run_program(True, f"moc_{key}.nc", more, key)
+            if best is None or wall < best[0]:
+                best = (wall, line, ph)
+        e2e[key] = {"wall_s": best[0], "phases_s": best[2], "phases_line": best[1], "grid_cells_per_s": npi * npj * npk * npt / best[0],
+                    "file_identical_to_feed": open(os.path.join(d, f"moc_{key}.nc"), "rb").read() == open(os.path.join(d, "moc_feed.nc"), "rb").read()}
     wall, line, rest, ph = run_program(True, "moc_feed_2d.nc", {"CDFT_FEED_ROWS": "2d"}, "feed_pitched_copies")   # hipMemcpy2DAsync per slab
     e2e["feed_pitched_copies"] = {"wall_s": wall, "phases_s": ph, "phases_line": line,
                                   "file_identical_to_feed": open(os.path.join(d, "moc_feed_2d.nc"), "rb").read() == open(os.path.join(d, "moc_feed.nc"), "rb").read()}
@@ -214,15 +217,26 @@ def main():
         import csv
         import glob
         os.makedirs(args.rocprof, exist_ok=True)
-        env = dict(os.environ, CDFT_FEED="1", TMPDIR="/tmp")
-        r = subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", args.rocprof, "--", exe, "-v", "V.nc", "-o",
-                            "moc_prof.nc"], cwd=d, env=env, capture_output=True, text=True)
-        ks = {}
-        for f in glob.glob(os.path.join(args.rocprof, "**", "*kernel_stats.csv"), recursive=True):
-            for row in csv.DictReader(open(f)):
-                ks[row["Name"][:120]] = {"calls": int(row["Calls"]), "total_ms": float(row["TotalDurationNs"]) / 1e6,
-                                         "avg_ms": float(row["AverageNs"]) / 1e6}
-        e2e["rocprof_of_the_program"] = {"rc": r.returncode, "kernels": ks}
+        e2e["rocprof_of_the_program"] = {}
+        touched = float(npi) * npj * (npk - 1) * npt
+        for route in ("stream", "pool", "record"):
+            out_dir = os.path.join(args.rocprof, route)
+            env = dict(os.environ, CDFT_FEED="1", TMPDIR="/tmp", CDFT_MOC_ROUTE=route)
+            r = subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", out_dir, "--", exe, "-v", "V.nc", "-o",
+                                "moc_prof.nc"], cwd=d, env=env, capture_output=True, text=True)
+            ks = {}
+            for f in glob.glob(os.path.join(out_dir, "**", "*kernel_stats.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    ks[row["Name"][:120]] = {"calls": int(row["Calls"]), "total_ms": float(row["TotalDurationNs"]) / 1e6,
+                                             "avg_ms": float(row["AverageNs"]) / 1e6}
+            zon = [v for k, v in ks.items() if "moc_zonal" in k]
+            zms = sum(v["total_ms"] for v in zon)
+            # algorithmic bytes of the run's zonal launches: the records once, the weights once per launch that reads them
+            wreads = 1 if route != "record" else npt
+            alg = 4.0 * touched * (1.0 + wreads / npt)
+            e2e["rocprof_of_the_program"][route] = {"rc": r.returncode, "kernels": ks, "zonal_launches": sum(v["calls"] for v in zon),
+                                                    "zonal_total_ms": zms, "algorithmic_GB_of_the_launches": alg / 1e9,
+                                                    "zonal_frac_of_8TBps": (alg / (zms * 1e-3) / 8e12) if zms > 0 else None}
     e2e["stdout_identical"] = outs[False] == outs[True].replace("moc_feed.nc", "moc.nc")
     e2e["moc_files_identical"] = open(os.path.join(d, "moc.nc"), "rb").read() == open(os.path.join(d, "moc_feed.nc"), "rb").read()
     walls, phases = [e2e["whole_records"]["wall_s"], e2e["feed"]["wall_s"]], e2e["feed"]["phases_line"]
