@@ -32,6 +32,10 @@ struct DevBuf {
 int to_device(const void *src, size_t n, int memspace, DevBuf &stage, hipStream_t st,
               const void **dev);
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) made once per kernel and device instead of before every launch (the call
+// goes to the runtime under its lock every time; a launch that follows it cannot have been queued behind the previous kernel).
+int dyn_lds_once(const void *kernel, int bytes);
+
 // A named range around a C-ABI call.  CDFT_ROCTX=1: a roctx range for rocprofv3 --marker-trace (the roctx library is looked
 // up at run time: no link dependency, nothing when it is absent).  CDFT_TIMING=1: the wall time of the call (as the caller
 // sees it: a call that returns host results includes its stream synchronisation) is added to a per-entry total, printed

@@ -317,8 +317,7 @@ size_t sig_class_shmem(int nq, int nclass, int nb, int nbins) {
 template <int NV, int KIND, int DEPTH, int OPT>
 int launch_sig_class_opt(const SigArgs &a, const SigClassArgs &ca, size_t shmem, hipStream_t st) {
     if (shmem > 64 * 1024)
-        CDFT_HIP(hipFuncSetAttribute((const void *)mocsig_class_kernel<NV, KIND, kSigT, DEPTH, OPT>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        CDFT_TRY(dyn_lds_once((const void *)mocsig_class_kernel<NV, KIND, kSigT, DEPTH, OPT>, (int)shmem));
     hipLaunchKernelGGL((mocsig_class_kernel<NV, KIND, kSigT, DEPTH, OPT>), dim3(a.npj), dim3(kSigT), shmem, st, a, ca);
     CDFT_LAUNCH_CHECK();
     return CDFT_OK;

@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include <mutex>
 #include "common.hpp"
+#include <utility>
 #include <vector>
 
 namespace cdft {
@@ -35,6 +36,24 @@ int require_device() {
                     "libcdftools_hip has no CPU fallback",
                     hipGetErrorString(e), n);
     }
+    return CDFT_OK;
+}
+
+int dyn_lds_once(const void *kernel, int bytes) {
+    static std::mutex mu;
+    static std::vector<std::pair<std::pair<const void *, int>, int>> done;      // ((kernel, device), bytes asked for)
+    int dev = 0;
+    CDFT_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    for (auto &d : done)
+        if (d.first.first == kernel && d.first.second == dev) {
+            if (d.second >= bytes) return CDFT_OK;
+            CDFT_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+            d.second = bytes;
+            return CDFT_OK;
+        }
+    CDFT_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done.push_back({{kernel, dev}, bytes});
     return CDFT_OK;
 }
 

@@ -1251,7 +1251,7 @@ int cdft_psi_integrate(cdft_psi_plan *p, const float *zu, const float *e2u, cons
             hipLaunchKernelGGL(psi_scan_i_kernel, dim3((p->npj + 63) / 64), dim3(64), 0, st, p->dtrpv, p->dpsiv, p->npi, p->npj);
         } else {
             const size_t shmem = sizeof(double) * kRingSlots * kRingRows * kRingIStr + sizeof(int) * (2 * kRingCnt + 2);
-            CDFT_HIP(hipFuncSetAttribute((const void *)psi_scan_i_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+            CDFT_TRY(dyn_lds_once((const void *)psi_scan_i_ring_kernel, (int)shmem));
             hipLaunchKernelGGL(psi_scan_i_ring_kernel, dim3((p->npj + kRingCW - 1) / kRingCW), dim3((1 + kRingIFeed + kRingIDrain) * 64), shmem, st,
                                p->dtrpv, p->dpsiv, p->npi, p->npj);
         }
@@ -1285,7 +1285,7 @@ int cdft_psi_scan_u(cdft_psi_plan *p, const double *carry, int carry_space, int 
     else {
         const size_t shmem = sizeof(double) * kRingSlots * kRingRows * kRingCW + sizeof(int) * (2 * kRingCnt + 2);
         // (more than 64 KB of dynamic LDS has to be asked for, on the device the plan lives on)
-        CDFT_HIP(hipFuncSetAttribute((const void *)psi_scan_j_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        CDFT_TRY(dyn_lds_once((const void *)psi_scan_j_ring_kernel, (int)shmem));
         hipLaunchKernelGGL(psi_scan_j_ring_kernel, dim3((p->npi + kRingCW - 1) / kRingCW), dim3((1 + kRingFeed + kRingDrain) * 64), shmem, st,
                            p->dtrpu, p->dpsiu, p->npi, p->npj, (const double *)dc, first_block ? 1 : 0);
     }
