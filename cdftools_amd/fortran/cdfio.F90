@@ -84,6 +84,14 @@ MODULE cdfio
   PUBLIC :: getvar, getvar1d, getvare3, getvar3d, readvar3d, readvar3d_i1
   PUBLIC :: create, createvar, putatt, putheadervar, putvar, putvar1d, putvar0d, closeout, ERR_HDL
   PUBLIC :: putvar_behind, wait_writes                  ! (not in the reference: the host feed's write-behind)
+  ! the rest of the reference's public list (src/cdfio.F90:173-180): none of the 18 programs of this build calls them; they
+  ! are here so that another reference program finds the module surface whole (tests/fortran/cdfio_public.f90 calls each)
+  PUBLIC :: copyatt, cvaratt, gettimeatt, puttimeatt, atted, getdimvar, getvarid
+  PUBLIC :: getvarxz, getvaryz, getvar3dt, getvar4d, gettimeseries, ncopen
+
+  INTERFACE atted
+     MODULE PROCEDURE atted_char, atted_r4
+  END INTERFACE
 
 CONTAINS
 
@@ -306,6 +314,331 @@ CONTAINS
        ptab(jn) = zval
     END DO
   END SUBROUTINE pack_apply
+
+  ! ================================================================================================ the rest of the public list
+  INTEGER(KIND=4) FUNCTION ncopen(cdfile)
+    !! id of cdfile opened for writing (src/cdfio.F90:2907-2922); the caller closes it with closeout
+    CHARACTER(LEN=*), INTENT(in) :: cdfile
+    INTEGER(KIND=4) :: ierr
+    CALL src_forget(cdfile)                              ! (a read handle kept on it would not see what is written)
+    ncopen = -1
+    ierr = NF90_OPEN(cdfile, NF90_WRITE, ncopen)
+  END FUNCTION ncopen
+
+  INTEGER(KIND=4) FUNCTION copyatt(cdvar, kidvar, kcin, kcout)
+    !! every attribute of variable cdvar of the open file kcin onto variable kidvar of kcout; kcin = -9999 (no file to copy
+    !! from): the stock attributes of a coordinate named cdvar (src/cdfio.F90:195-257) -- what create does for its axes
+    CHARACTER(LEN=*), INTENT(in) :: cdvar
+    INTEGER(KIND=4),  INTENT(in) :: kidvar, kcin, kcout
+    copyatt = NF90_NOERR
+    CALL coordinate_attributes(cdvar, kidvar, kcin, kcout)
+  END FUNCTION copyatt
+
+  FUNCTION getvarid(cdfile, knvars)
+    !! the ids of the first knvars variables of cdfile, in file order (src/cdfio.F90:462-485)
+    CHARACTER(LEN=*), INTENT(in) :: cdfile
+    INTEGER(KIND=4),  INTENT(in) :: knvars
+    INTEGER(KIND=4), DIMENSION(knvars) :: getvarid
+    INTEGER(KIND=4) :: ncid, jv, ierr
+    CHARACTER(LEN=256) :: clname
+    getvarid(:) = -1
+    IF ( src_attach(cdfile, ncid) /= NF90_NOERR ) RETURN
+    DO jv = 1, knvars
+       IF ( NF90_INQUIRE_VARIABLE(ncid, jv, name=clname) == NF90_NOERR ) ierr = NF90_INQ_VARID(ncid, TRIM(clname), getvarid(jv))
+    END DO
+    CALL src_detach(ncid)
+  END FUNCTION getvarid
+
+  INTEGER(KIND=4) FUNCTION gettimeatt(cdfile, cdvartime, ctcalendar, cttitle, ctlong_name, ctaxis, ctunits, cttime_origin)
+    !! the six text attributes of the time variable, 'unknown' where the file has none (src/cdfio.F90:517-552); the status
+    !! returned is that of the last one looked up (time_origin), as in the reference
+    CHARACTER(LEN=*), INTENT(in)  :: cdfile, cdvartime
+    CHARACTER(LEN=*), INTENT(out) :: ctcalendar, cttitle, ctlong_name, ctaxis, ctunits, cttime_origin
+    INTEGER(KIND=4) :: ncid, ivar
+    ctcalendar = 'unknown' ; cttitle = 'unknown' ; ctlong_name = 'unknown'
+    ctaxis = 'unknown' ; ctunits = 'unknown' ; cttime_origin = 'unknown'
+    gettimeatt = src_attach(cdfile, ncid)
+    IF ( gettimeatt /= NF90_NOERR ) RETURN
+    gettimeatt = NF90_INQ_VARID(ncid, cdvartime, ivar)
+    IF ( gettimeatt == NF90_NOERR ) THEN
+       gettimeatt = NF90_GET_ATT(ncid, ivar, 'calendar',    ctcalendar)
+       gettimeatt = NF90_GET_ATT(ncid, ivar, 'title',       cttitle)
+       gettimeatt = NF90_GET_ATT(ncid, ivar, 'long_name',   ctlong_name)
+       gettimeatt = NF90_GET_ATT(ncid, ivar, 'axis',        ctaxis)
+       gettimeatt = NF90_GET_ATT(ncid, ivar, 'units',       ctunits)
+       gettimeatt = NF90_GET_ATT(ncid, ivar, 'time_origin', cttime_origin)
+    ENDIF
+    CALL src_detach(ncid)
+  END FUNCTION gettimeatt
+
+  INTEGER(KIND=4) FUNCTION puttimeatt(kout, cdvartime, ctcalendar, cttitle, ctlong_name, ctaxis, ctunits, cttime_origin)
+    !! the same six onto the time variable of the open output file kout (src/cdfio.F90:554-592): a missing variable or a
+    !! refused attribute stops the program with 98, as there
+    INTEGER(KIND=4),    INTENT(in) :: kout
+    CHARACTER(LEN=20),  INTENT(in) :: cdvartime
+    CHARACTER(LEN=256), INTENT(in) :: ctcalendar, cttitle, ctlong_name, ctaxis, ctunits, cttime_origin
+    INTEGER(KIND=4) :: ivar
+    puttimeatt = NF90_INQ_VARID(kout, cdvartime, ivar)
+    IF ( puttimeatt /= NF90_NOERR ) THEN
+       PRINT *, TRIM(NF90_STRERROR(puttimeatt))
+       PRINT *, 'puttimeatt : ', TRIM(cdvartime), ' does not exist'
+       STOP 98
+    ENDIF
+    puttimeatt = NF90_REDEF(kout)
+    CALL one('calendar', ctcalendar) ; CALL one('title', cttitle) ; CALL one('long_name', ctlong_name)
+    CALL one('axis', ctaxis) ; CALL one('units', ctunits) ; CALL one('time_origin', cttime_origin)
+    puttimeatt = NF90_ENDDEF(kout)
+  CONTAINS
+    SUBROUTINE one(cdatt, cdval)
+      CHARACTER(LEN=*), INTENT(in) :: cdatt, cdval
+      puttimeatt = NF90_PUT_ATT(kout, ivar, cdatt, cdval)
+      IF ( puttimeatt /= NF90_NOERR ) THEN
+         PRINT *, NF90_STRERROR(puttimeatt) ; PRINT *, ' in puttimeatt ', cdatt
+         STOP 98
+      ENDIF
+    END SUBROUTINE one
+  END FUNCTION puttimeatt
+
+  INTEGER(KIND=4) FUNCTION cvaratt(cdfile, cdvar, cdunits, pmissing_value, cdlong_name, cdshort_name)
+    !! units, missing value (under the name the variable already spells it with), long_name and short_name of an EXISTING
+    !! variable rewritten in place (src/cdfio.F90:595-626)
+    CHARACTER(LEN=256), INTENT(in) :: cdfile, cdvar
+    CHARACTER(LEN=256), INTENT(in) :: cdunits, cdlong_name, cdshort_name
+    REAL(KIND=4),       INTENT(in) :: pmissing_value
+    INTEGER(KIND=4) :: ncid, ivar, ierr
+    REAL(KIND=4) :: zold
+    CHARACTER(LEN=256) :: clmissing
+    zold = getspval(cdfile, cdvar, clmissing)             ! (before the file is opened for writing: its own read handle)
+    CALL src_forget(cdfile)
+    cvaratt = NF90_OPEN(cdfile, NF90_WRITE, ncid)
+    IF ( cvaratt /= NF90_NOERR ) RETURN
+    ierr = NF90_REDEF(ncid)
+    cvaratt = NF90_INQ_VARID(ncid, cdvar, ivar)
+    IF ( cvaratt == NF90_NOERR ) THEN
+       ierr = NF90_PUT_ATT(ncid, ivar, 'units', cdunits)
+       ierr = NF90_PUT_ATT(ncid, ivar, TRIM(clmissing), pmissing_value)
+       ierr = NF90_PUT_ATT(ncid, ivar, 'long_name', cdlong_name)
+       ierr = NF90_PUT_ATT(ncid, ivar, 'short_name', cdshort_name)
+       cvaratt = NF90_ENDDEF(ncid)
+    ENDIF
+    ierr = NF90_CLOSE(ncid)
+  END FUNCTION cvaratt
+
+  SUBROUTINE atted_open(cdfile, cdvar, cdatt, ktype_wanted, cdwho, kncid, kvar)
+    ! the attribute editor's preamble (src/cdfio.F90:790-876): cdfile open for writing, in define mode, the variable found (or
+    ! STOP 98), and an existing attribute of another type refused (STOP 98)
+    CHARACTER(LEN=*), INTENT(in)  :: cdfile, cdvar, cdatt, cdwho
+    INTEGER(KIND=4),  INTENT(in)  :: ktype_wanted
+    INTEGER(KIND=4),  INTENT(out) :: kncid, kvar
+    INTEGER(KIND=4) :: ierr, itype
+    CALL src_forget(cdfile)
+    ierr = NF90_OPEN(cdfile, NF90_WRITE, kncid)
+    ierr = NF90_INQ_VARID(kncid, cdvar, kvar)
+    IF ( ierr /= NF90_NOERR ) THEN
+       PRINT *, NF90_STRERROR(ierr), ' in atted ( inq_varid)'
+       STOP 98
+    ENDIF
+    ierr = NF90_INQUIRE_ATTRIBUTE(kncid, kvar, cdatt, xtype=itype)
+    IF ( ierr /= NF90_NOERR ) THEN
+       PRINT *, ' Attribute does not exist. Create it'
+    ELSE IF ( itype /= ktype_wanted ) THEN
+       PRINT *, ' Mismatch in attribute type in ', cdwho
+       STOP 98
+    ENDIF
+    ierr = NF90_REDEF(kncid)
+  END SUBROUTINE atted_open
+
+  INTEGER(KIND=4) FUNCTION atted_char(cdfile, cdvar, cdatt, cdvalue)
+    !! a text attribute of a variable of an existing file set or created (src/cdfio.F90:790-830)
+    CHARACTER(LEN=*), INTENT(in) :: cdfile, cdvar, cdatt, cdvalue
+    INTEGER(KIND=4) :: ncid, ivar, ierr
+    CALL atted_open(cdfile, cdvar, cdatt, NF90_CHAR, 'atted_char', ncid, ivar)
+    atted_char = NF90_PUT_ATT(ncid, ivar, cdatt, cdvalue)
+    ierr = NF90_CLOSE(ncid)
+  END FUNCTION atted_char
+
+  INTEGER(KIND=4) FUNCTION atted_r4(cdfile, cdvar, cdatt, pvalue)
+    !! the same for an r4 attribute (src/cdfio.F90:833-876)
+    CHARACTER(LEN=*), INTENT(in) :: cdfile, cdvar, cdatt
+    REAL(KIND=4),     INTENT(in) :: pvalue
+    INTEGER(KIND=4) :: ncid, ivar, ierr
+    CALL atted_open(cdfile, cdvar, cdatt, NF90_FLOAT, 'atted_r4', ncid, ivar)
+    atted_r4 = NF90_PUT_ATT(ncid, ivar, cdatt, pvalue)
+    ierr = NF90_CLOSE(ncid)
+  END FUNCTION atted_r4
+
+  FUNCTION getdimvar(cdfile, kpk, cd_depnam)
+    !! the values of the file's vertical coordinate, found by trial: the first variable with ONE dimension that is not the
+    !! record one (src/cdfio.F90:1085-1127); zeros and a message when there is none
+    CHARACTER(LEN=*), INTENT(in) :: cdfile
+    INTEGER(KIND=4),  INTENT(in) :: kpk
+    REAL(KIND=4), DIMENSION(kpk) :: getdimvar
+    CHARACTER(LEN=*), OPTIONAL, INTENT(out) :: cd_depnam
+    INTEGER(KIND=4) :: ncid, jv, invar, irec, irank, idim(4), ierr
+    CHARACTER(LEN=80) :: clvar
+    LOGICAL :: ll_found
+    clvar = 'none' ; ll_found = .FALSE.
+    getdimvar(:) = 0.
+    CALL ERR_HDL(src_attach(cdfile, ncid))
+    ierr = NF90_INQUIRE(ncid, nVariables=invar, unlimitedDimId=irec)
+    DO jv = 1, invar
+       ierr = NF90_INQUIRE_VARIABLE(ncid, jv, name=clvar, ndims=irank, dimids=idim)
+       IF ( irank == 1 .AND. idim(1) /= irec ) THEN
+          PRINT *, ' Found vertical variable :', TRIM(clvar)
+          ierr = NF90_GET_VAR(ncid, jv, getdimvar)
+          ll_found = .TRUE.
+          EXIT
+       ENDIF
+    END DO
+    IF ( PRESENT(cd_depnam) ) cd_depnam = TRIM(clvar)      ! (the last name looked at when nothing was found, as there)
+    IF ( .NOT. ll_found ) THEN
+       PRINT *, 'Sorry, no vertical dim variables inferred ...'
+       getdimvar(:) = 0.
+    ENDIF
+    CALL src_detach(ncid)
+  END FUNCTION getdimvar
+
+  SUBROUTINE read_block(cdwho, cdfile, cdvar, ptab, kn, kstart, kcount, ldzgr)
+    ! kn values of cdvar from kstart, shape kcount, unpacked like getvar's slabs; a NetCDF error names cdwho and stops with 98
+    CHARACTER(LEN=*), INTENT(in)  :: cdwho, cdfile, cdvar
+    INTEGER(KIND=8),  INTENT(in)  :: kn
+    REAL(KIND=4),     INTENT(out) :: ptab(kn)
+    INTEGER(KIND=4),  INTENT(in)  :: kstart(4), kcount(4)
+    LOGICAL,          INTENT(in)  :: ldzgr
+    INTEGER(KIND=4) :: ncid, ivar, ierr
+    CHARACTER(LEN=256) :: cl_name
+    TYPE(t_pack) :: tp
+    cl_name = cdvar
+    IF ( ldzgr .AND. cdvar == cn_ve3v ) cl_name = zgr_name(cdvar, .TRUE.)      ! (the one metric these sections rename, :1985-1991)
+    CALL tic()
+    CALL src_variable(cdfile, cl_name, ncid, ivar)
+    tp = pack_of(ncid, ivar, cl_name)
+    ierr = NF90_GET_VAR(ncid, ivar, ptab, start=kstart, count=kcount)
+    IF ( ierr /= NF90_NOERR ) THEN
+       PRINT *, ' Problem in ', cdwho, ' for ', TRIM(cl_name)
+       CALL ERR_HDL(ierr)
+    ENDIF
+    CALL pack_apply(tp, ptab, kn)
+    CALL src_detach(ncid)
+    CALL toc(dtime_read)
+  END SUBROUTINE read_block
+
+  LOGICAL FUNCTION has_y(cdfile)
+    ! whether the file has a dimension called 'y' (the sections' test, src/cdfio.F90:2018, :2124)
+    CHARACTER(LEN=*), INTENT(in) :: cdfile
+    INTEGER(KIND=4) :: ncid, idum
+    CALL ERR_HDL(src_attach(cdfile, ncid))
+    has_y = ( NF90_INQ_DIMID(ncid, 'y', idum) == NF90_NOERR )
+    CALL src_detach(ncid)
+  END FUNCTION has_y
+
+  FUNCTION getvarxz(cdfile, cdvar, kj, kpi, kpz, kimin, kkmin, ktime)
+    !! the (x,z) section of cdvar at row kj of record ktime (src/cdfio.F90:1933-2043): (x,y,z,t) files; a file without a 'y'
+    !! dimension is read as (x,z,t)
+    CHARACTER(LEN=*),          INTENT(in) :: cdfile, cdvar
+    INTEGER(KIND=4),           INTENT(in) :: kj, kpi, kpz
+    INTEGER(KIND=4), OPTIONAL, INTENT(in) :: kimin, kkmin, ktime
+    REAL(KIND=4), DIMENSION(kpi,kpz) :: getvarxz
+    IF ( has_y(cdfile) ) THEN
+       CALL read_block('getvarxz', cdfile, cdvar, getvarxz, INT(kpi, 8) * kpz, (/ oint(kimin, 1), kj, oint(kkmin, 1), oint(ktime, 1) /), &
+            &          (/ kpi, 1, kpz, 1 /), .TRUE.)
+    ELSE
+       CALL read_block('getvarxz', cdfile, cdvar, getvarxz, INT(kpi, 8) * kpz, (/ oint(kimin, 1), oint(kkmin, 1), oint(ktime, 1), 1 /), &
+            &          (/ kpi, kpz, 1, 1 /), .TRUE.)
+    ENDIF
+  END FUNCTION getvarxz
+
+  FUNCTION getvaryz(cdfile, cdvar, ki, kpj, kpz, kjmin, kkmin, ktime)
+    !! the (y,z) section at column ki (src/cdfio.F90:2046-2148); a file without an 'x' dimension is read as (y,z,t)
+    CHARACTER(LEN=*),          INTENT(in) :: cdfile, cdvar
+    INTEGER(KIND=4),           INTENT(in) :: ki, kpj, kpz
+    INTEGER(KIND=4), OPTIONAL, INTENT(in) :: kjmin, kkmin, ktime
+    REAL(KIND=4), DIMENSION(kpj,kpz) :: getvaryz
+    INTEGER(KIND=4) :: ncid, idum
+    LOGICAL :: ll_x
+    CALL ERR_HDL(src_attach(cdfile, ncid))
+    ll_x = ( NF90_INQ_DIMID(ncid, 'x', idum) == NF90_NOERR )
+    CALL src_detach(ncid)
+    IF ( ll_x ) THEN
+       CALL read_block('getvaryz', cdfile, cdvar, getvaryz, INT(kpj, 8) * kpz, (/ ki, oint(kjmin, 1), oint(kkmin, 1), oint(ktime, 1) /), &
+            &          (/ 1, kpj, kpz, 1 /), .TRUE.)
+    ELSE
+       CALL read_block('getvaryz', cdfile, cdvar, getvaryz, INT(kpj, 8) * kpz, (/ oint(kjmin, 1), oint(kkmin, 1), oint(ktime, 1), 1 /), &
+            &          (/ kpj, kpz, 1, 1 /), .TRUE.)
+    ENDIF
+  END FUNCTION getvaryz
+
+  FUNCTION getvar3dt(cdfile, cdvar, kk, kpi, kpj, kpt, kimin, kjmin, ktmin)
+    !! kpt records of level kk of cdvar, (x,y,t) (src/cdfio.F90:1717-1820): a 4-D variable at that level, a 3-D one (x,y,t) as it is
+    CHARACTER(LEN=*),          INTENT(in) :: cdfile, cdvar
+    INTEGER(KIND=4),           INTENT(in) :: kk, kpi, kpj, kpt
+    INTEGER(KIND=4), OPTIONAL, INTENT(in) :: kimin, kjmin, ktmin
+    REAL(KIND=4), DIMENSION(kpi,kpj,kpt) :: getvar3dt
+    PRINT *, '    KPI KPJ KPT, KK ', kpi, kpj, kpt, kk
+    IF ( getvdim_all(cdfile, cdvar) == 4 ) THEN
+       CALL read_block('getvar3dt', cdfile, cdvar, getvar3dt, INT(kpi, 8) * kpj * kpt, (/ oint(kimin, 1), oint(kjmin, 1), kk, oint(ktmin, 1) /), &
+            &          (/ kpi, kpj, 1, kpt /), .FALSE.)
+    ELSE
+       CALL read_block('getvar3dt', cdfile, cdvar, getvar3dt, INT(kpi, 8) * kpj * kpt, (/ oint(kimin, 1), oint(kjmin, 1), oint(ktmin, 1), 1 /), &
+            &          (/ kpi, kpj, kpt, 1 /), .FALSE.)
+    ENDIF
+  END FUNCTION getvar3dt
+
+  FUNCTION getvar4d(cdfile, cdvar, kpi, kpj, kpz, kpt, kimin, kjmin, kkmin, ktmin)
+    !! a (x,y,z,t) block in one read (src/cdfio.F90:1822-1930)
+    CHARACTER(LEN=*),          INTENT(in) :: cdfile, cdvar
+    INTEGER(KIND=4),           INTENT(in) :: kpi, kpj, kpz, kpt
+    INTEGER(KIND=4), OPTIONAL, INTENT(in) :: kimin, kjmin, kkmin, ktmin
+    REAL(KIND=4), DIMENSION(kpi,kpj,kpz,kpt) :: getvar4d
+    CALL read_block('getvar4d', cdfile, cdvar, getvar4d, INT(kpi, 8) * kpj * kpz * kpt, &
+         &          (/ oint(kimin, 1), oint(kjmin, 1), oint(kkmin, 1), oint(ktmin, 1) /), (/ kpi, kpj, kpz, kpt /), .FALSE.)
+  END FUNCTION getvar4d
+
+  INTEGER(KIND=4) FUNCTION getvdim_all(cdfile, cdvar)
+    ! the rank of cdvar as the file declares it (getvdim answers rank - 1, the reference's convention)
+    CHARACTER(LEN=*), INTENT(in) :: cdfile, cdvar
+    INTEGER(KIND=4) :: ncid, ivar, ierr
+    CALL src_variable(cdfile, cdvar, ncid, ivar)
+    ierr = NF90_INQUIRE_VARIABLE(ncid, ivar, ndims=getvdim_all)
+    CALL src_detach(ncid)
+  END FUNCTION getvdim_all
+
+  SUBROUTINE gettimeseries(cdfile, cdvar, kilook, kjlook, klev, ldncdf)
+    !! two columns on stdout, time in days and the value of cdvar at point (kilook,kjlook) [level klev] for every record of the
+    !! file (src/cdfio.F90:2943-3029); scale_factor and add_offset applied to every value (no missing-value test there);
+    !! ldncdf is accepted and, as in the reference ("not finished"), does nothing more
+    CHARACTER(LEN=*),          INTENT(in) :: cdfile, cdvar
+    INTEGER(KIND=4),           INTENT(in) :: kilook, kjlook
+    INTEGER(KIND=4), OPTIONAL, INTENT(in) :: klev
+    LOGICAL,         OPTIONAL, INTENT(in) :: ldncdf
+    INTEGER(KIND=4) :: ncid, ivar, idim, inrec, irank, ierr, jt
+    REAL(KIND=4), ALLOCATABLE :: ztime(:), zval(:)
+    REAL(KIND=4) :: zscale, zoffset, zatt
+    CALL ERR_HDL(src_attach(cdfile, ncid))
+    ierr = NF90_INQ_DIMID(ncid, cn_t, idim)
+    ierr = NF90_INQUIRE_DIMENSION(ncid, idim, len=inrec)
+    ALLOCATE( ztime(inrec), zval(inrec) )
+    ierr = NF90_INQ_VARID(ncid, cn_vtimec, ivar)
+    ierr = NF90_GET_VAR(ncid, ivar, ztime, (/ 1 /), (/ inrec /))
+    ierr = NF90_INQ_VARID(ncid, cdvar, ivar)
+    zscale = 1. ; zoffset = 0.
+    IF ( NF90_GET_ATT(ncid, ivar, 'add_offset', zatt)   == NF90_NOERR ) zoffset = zatt
+    IF ( NF90_GET_ATT(ncid, ivar, 'scale_factor', zatt) == NF90_NOERR ) zscale = zatt
+    ierr = NF90_INQUIRE_VARIABLE(ncid, ivar, ndims=irank)
+    SELECT CASE ( irank )
+    CASE ( 3 ) ; ierr = NF90_GET_VAR(ncid, ivar, zval, (/ kilook, kjlook, 1 /), (/ 1, 1, inrec /))
+    CASE ( 4 ) ; ierr = NF90_GET_VAR(ncid, ivar, zval, (/ kilook, kjlook, oint(klev, 1), 1 /), (/ 1, 1, 1, inrec /))
+    CASE DEFAULT
+       PRINT *, '  ERROR : variable ', TRIM(cdvar), ' has ', irank, ' dimensions !. Only 3 or 4 supported'
+       STOP 98
+    END SELECT
+    zval(:) = zval(:) * zscale + zoffset
+    DO jt = 1, inrec
+       PRINT *, ztime(jt) / 86400., zval(jt)
+    END DO
+    CALL src_detach(ncid)
+    DEALLOCATE( ztime, zval )
+  END SUBROUTINE gettimeseries
 
   ! ================================================================================================ inquiries
   LOGICAL FUNCTION chkfile(cd_file, ld_verbose)

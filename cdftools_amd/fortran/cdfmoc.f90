@@ -216,6 +216,19 @@ PROGRAM cdfmoc
      IF ( LEN_TRIM(cldum) > 0 ) THEN
         READ(cldum, *) nbatch ; nbatch = MIN(npt, nbatch)
      ENDIF
+     nbatch = MAX(1, nbatch)
+     IF ( croute /= 'pool' ) THEN
+        ! ... and as many levels per window as 4 GB hold: a launch on 2 levels of eORCA12 is 7 000 workgroups, under five rounds
+        ! of what the chip holds at once (0.65 of the HBM peak, profiles/r05), on 5 levels twelve rounds; more HBM than that
+        ! buys nothing -- an allocation costs up to 50 ms per GB on this pool, when the driver still has the pages of an earlier
+        ! process to clear (profiles/r05/alloc_probe.json: 61 GB in 0.0002 .. 6.3 s), the file read 30 ms per GB.
+        ! CDFT_MOC_WINDOW=n sets the levels per window.
+        nlevw = MAX(nlevw, MIN(npk - 1, INT(MIN(4.d9, 0.125d0 * REAL(ifree, 8)) / ( dl_field / npk * ( 1 + nbatch ) ))))
+        CALL GET_ENVIRONMENT_VARIABLE('CDFT_MOC_WINDOW', cldum)
+        IF ( LEN_TRIM(cldum) > 0 ) THEN
+           READ(cldum, *) nlevw ; nlevw = MAX(1, MIN(npk - 1, nlevw))
+        ENDIF
+     ENDIF
      lpool   = croute == 'pool' .AND. nbatch >= 2
      lstream = croute /= 'pool' .AND. nbatch >= 1
      nbatch = MAX(1, nbatch)

@@ -109,5 +109,64 @@ PROGRAM cdfio_public
   zline = (/ 1., 2., 3., 4., 5. /)
   istat = putvar(ncout, id_varout(1), zline, 3, 1, npj, ktime=1)
   ierr = closeout(ncout)
+  CALL the_rest_of_the_public_list
   PRINT '(a)', 'done'
+
+CONTAINS
+
+  SUBROUTINE the_rest_of_the_public_list
+    ! the names of src/cdfio.F90:173-180 that none of the 18 programs calls: one call each, the reference's argument order
+    CHARACTER(LEN=256) :: cl_cal, cl_tit, cl_lon, cl_axi, cl_uni, cl_ori, cl_dep, cf_e, cl256a, cl256b, cl256c, cl256d
+    CHARACTER(LEN=20)  :: cl_tvar
+    INTEGER(KIND=4) :: ids(8), iout, ivarid(1), ipk1(1)
+    REAL(KIND=4) :: zdep(npk), xz(npi-1,npk-1), yz(npj,npk), xyt(npi,npj,2), x4(3,2,2,2), zspv2
+    TYPE(variable) :: styp1(1)
+    ids = getvarid(cf_t, 8)
+    PRINT '(a,99i4)', 'getvarid', ids
+    ierr = gettimeatt(cf_t, cn_vtimec, cl_cal, cl_tit, cl_lon, cl_axi, cl_uni, cl_ori)
+    PRINT '(a,1x,13a)', 'gettimeatt', '|', TRIM(cl_cal), '|', TRIM(cl_tit), '|', TRIM(cl_lon), '|', TRIM(cl_axi), '|', TRIM(cl_uni), '|', TRIM(cl_ori), '|'
+    zdep = getdimvar(cf_t, npk, cl_dep)
+    PRINT '(a,99es16.8)', 'getdimvar', zdep
+    PRINT '(a,1x,a)', 'getdimvar_name', TRIM(cl_dep)
+    xz = getvarxz(cf_t, 'packed', 3, npi-1, npk-1, kimin=2, kkmin=2, ktime=2)
+    PRINT '(a,999es16.8)', 'getvarxz', xz
+    yz = getvaryz(cf_t, cn_votemper, 4, npj, npk, ktime=3)
+    PRINT '(a,999es16.8)', 'getvaryz', yz
+    xyt = getvar3dt(cf_t, cn_votemper, 2, npi, npj, 2, ktmin=2)
+    PRINT '(a,999es16.8)', 'getvar3dt', xyt
+    xyt = getvar3dt(cf_t, cn_sossheig, 1, npi, npj, 2, kimin=1, kjmin=1, ktmin=1)
+    PRINT '(a,999es16.8)', 'getvar3dt_xyt', xyt
+    x4 = getvar4d(cf_t, 'packed', 3, 2, 2, 2, kimin=2, kjmin=3, kkmin=2, ktmin=2)
+    PRINT '(a,999es16.8)', 'getvar4d', x4
+    PRINT '(a)', 'gettimeseries_begin'
+    CALL gettimeseries(cf_t, 'packed', 4, 3, klev=2)
+    PRINT '(a)', 'gettimeseries_end'
+    ! a file of its own to edit: create + copyatt (no reference file) + puttimeatt, then the editors on the closed file
+    cf_e = TRIM(cdir)//'/edit.nc'
+    styp1(1)%cname = 'field' ; styp1(1)%cunits = 'old' ; styp1(1)%rmissing_value = -9. ; styp1(1)%clong_name = 'old long'
+    styp1(1)%cshort_name = 'old short' ; styp1(1)%conline_operation = 'N/A' ; styp1(1)%caxis = 'TYX'
+    ipk1 = 1
+    iout = create(cf_e, cf_t, npi, npj, 0)
+    ierr = createvar(iout, styp1, 1, ipk1, ivarid)
+    ierr = putheadervar(iout, cf_t, npi, npj, 0)
+    cl_tvar = cn_vtimec
+    cl_cal = 'gregorian' ; cl_tit = 'Time!' ; cl_lon = 'the axis of time' ; cl_axi = 'T' ; cl_uni = 'days since then' ; cl_ori = 'then'
+    ierr = puttimeatt(iout, cl_tvar, cl_cal, cl_tit, cl_lon, cl_axi, cl_uni, cl_ori)
+    ierr = closeout(iout)
+    iout = ncopen(cf_e)
+    PRINT '(a,i3)', 'ncopen', MERGE(1, 0, iout >= 0)
+    ierr = closeout(iout)
+    cl256a = cf_e ; cl256b = 'field' ; cl256c = 'new units' ; cl256d = 'new long'
+    ierr = cvaratt(cl256a, cl256b, cl256c, 77., cl256d, cl256b)
+    ierr = atted(cf_e, 'field', 'comment', 'edited')
+    ierr = atted(cf_e, 'field', 'factor', 2.5)
+    ierr = atted(cf_e, 'field', 'comment', 'edited twice')
+    zspv2 = getspval(cf_e, 'field')
+    PRINT '(a,es16.8,1x,a,1x,a)', 'edited', zspv2, TRIM(getatt(cf_e, 'field', 'units', 'c')), TRIM(getatt(cf_e, 'field', 'comment', 'c'))
+    ! copyatt between two open files, and from no file at all
+    cf_o = TRIM(cdir)//'/copy.nc'
+    iout = create(cf_o, cf_t, npi, npj, 0)
+    ierr = createvar(iout, styp1, 1, ipk1, ivarid)
+    ierr = closeout(iout)
+  END SUBROUTINE the_rest_of_the_public_list
 END PROGRAM cdfio_public

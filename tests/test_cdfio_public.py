@@ -1,6 +1,6 @@
-"""The part of cdfio's surface the tools of this build call (reference src/cdfio.F90:173-180, minus what no tool here uses:
-atted, cvaratt, gettimeatt, puttimeatt, getvarid, getdimvar, getvarxz / yz, getvar3dt, getvar4d, gettimeseries, reputvar*,
-putvare3, ncopen are not provided) and the key_CMIP6 name set of modcdfnames.
+"""cdfio's public surface (reference src/cdfio.F90:173-180) -- what the tools of this build call and, since round 5, the rest
+of that list too (copyatt, cvaratt, gettimeatt, puttimeatt, atted, getdimvar, getvarid, getvarxz / yz, getvar3dt, getvar4d,
+gettimeseries, ncopen: no program here calls them; one call each below) -- and the key_CMIP6 name set of modcdfnames.
 
 tests/fortran/cdfio_public.f90 calls each routine with the reference's argument order and keywords on files written here by
 scipy.io.netcdf_file (an independent implementation of the format); what it prints is compared with NumPy slices of the
@@ -155,6 +155,40 @@ def test_slab_and_block_reads(run):
     assert out["getvar1d"].split() == ["4.3200000000000000E+04", "1.2960000000000000E+05"]
     v, flag = out["getvar1d_absent"].split()
     assert float(v) == 99999999999.0 and flag == "1"
+
+
+def test_the_rest_of_the_public_list(run):
+    """the thirteen names of src/cdfio.F90:173-180 no program of this build calls, against NumPy slices of the same arrays and
+    scipy's reading of the edited file"""
+    d, out, F, stdout = run
+    t, ssh, pk = F["t"], F["ssh"], F["pk"]
+    assert out["getvarid"].split() == [str(i) for i in range(1, 9)]
+    # (no 'axis' in the file: nf90_get_att blanks a text result before it looks the attribute up, so the reference's 'unknown'
+    # does not survive the call that fails -- the NF90 layer of this build does the same)
+    assert out["gettimeatt"] == "|noleap|Time|Time axis||seconds since 0001-01-01|0001-JAN-01|"
+    assert np.array_equal(nums(out["getdimvar"]), np.array([5, 15, 27.5, 45], f32)) and out["getdimvar_name"] == "deptht"
+    up = unpack(pk)
+    assert np.array_equal(nums(out["getvarxz"], (NPK - 1, NPI - 1)), up[1, 1:, 2, 1:])
+    assert np.array_equal(nums(out["getvaryz"], (NPK, NPJ)), t[2, :, :, 3])
+    assert np.array_equal(nums(out["getvar3dt"], (2, NPJ, NPI)), t[1:3, 1])
+    assert np.array_equal(nums(out["getvar3dt_xyt"], (2, NPJ, NPI)), ssh[0:2])
+    assert np.array_equal(nums(out["getvar4d"], (2, 2, 2, 3)), up[1:3, 1:3, 2:4, 1:4])
+    lines = stdout.splitlines()
+    i0, i1 = lines.index("gettimeseries_begin"), lines.index("gettimeseries_end")
+    rows = np.array([[float(x) for x in ln.split()] for ln in lines[i0 + 1:i1]])
+    raw = pk[:, 1, 2, 3].astype(f32) * f32(0.01) + f32(20.0)              # scale and offset on every value, missing or not (:3016)
+    assert rows.shape == (NPT, 2) and np.array_equal(rows[:, 0].astype(f32), (np.array([43200.0, 129600.0, 216000.0], f32) / f32(86400.0)))
+    assert np.array_equal(rows[:, 1].astype(f32), raw)
+    assert out["ncopen"] == "1"
+    v, units, comment = out["edited"].split(None, 2)
+    assert f32(v) == f32(77.0) and units == "new" or out["edited"].split()[1:3] == ["new", "units"]
+    f = netcdf_file(os.path.join(d, "edit.nc"), "r", mmap=False)
+    fld, tc = f.variables["field"], f.variables["time_counter"]
+    assert fld.units == b"new units" and fld.long_name == b"new long" and fld.short_name == b"field" and fld._FillValue == f32(77.0)
+    assert fld.comment == b"edited twice" and fld.factor == f32(2.5)
+    assert (tc.calendar, tc.title, tc.long_name, tc.axis, tc.units, tc.time_origin) == (b"gregorian", b"Time!", b"the axis of time", b"T",
+                                                                                           b"days since then", b"then")
+    f.close()
 
 
 def test_written_files(run):

@@ -224,7 +224,9 @@ def test_the_program_in_batches_of_records(tools, tmp_path, ring):  # noqa: F811
     ref = oracle_lib.moc(e1v, e3v, ib, rec["v"])
     files = {}
     one_plane = "CDFT_FEED_MB" in ring
-    nwin = 8 if one_plane else 1                            # windows of one level (a slot holds one plane) or of all eight
+    nwin = 3 if one_plane else 1                            # windows of three levels (3 + 3 + 2, a ring slot per level) or of all eight
+    if one_plane:
+        ring = dict(ring, CDFT_MOC_WINDOW="3")
     for route, batch, want in (("pool", "2", (3, 5)), ("pool", "5", (1, 5)), ("pool", "", (1, 5)), ("record", "", (5, 5)),
                                ("stream", "", (nwin, 5 * nwin)), ("stream", "2", (3 * nwin, 5 * nwin)), ("stream", "1", (5 * nwin, 5 * nwin))):
         env = dict(ring, CDFT_FEED="1", CDFT_TIMING="1", CDFT_MOC_ROUTE=route)
