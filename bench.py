@@ -589,6 +589,21 @@ def main():
         dense_desc = plan.describe()
         dense_err = float((dense_out - pipe.local[(pipe.i - 1) % pipe.nbuf]).abs().max().item())
         del dense_out
+    # the same pool read a window of levels per launch -- the launches the cdfmoc PROGRAM's stream route makes (4 GB windows:
+    # five levels at eORCA12 x 12 records), on resident data: outside the timed region
+    win_each, win_levels, win_err = np.zeros(0), None, None
+    if not args.no_dense:
+        slab = 4.0 * ((npi + 3) // 4 * 4) * nloc * (npt + 1)
+        win_levels = max(1, min(npk - 1, int(4.0e9 / slab)))
+        win_out = torch.empty_like(pipe.local[0])
+        plan.compute_staged_windows(win_levels, win_out)
+        plan.profile_enable(True)
+        for _ in range(min(10, args.steps)):
+            plan.compute_staged_windows(win_levels, win_out)
+        plan.profile_enable(False)
+        win_each = plan.profile_read_each()
+        win_err = float((win_out - pipe.local[(pipe.i - 1) % pipe.nbuf]).abs().max().item())
+        del win_out
     comm = None
     per_rank = None
     if world > 1:
@@ -625,6 +640,13 @@ def main():
                                  "frac": alg_bytes / (dense_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if dense_ms else None,
                                  "max_abs_diff_Sv_vs_staged": dense_err,
                                  "note": "cdft_moc_compute on the records as generated, 4.7 GB apart; not the timed path"},
+                "level_windows": None if not win_each.size else {
+                    "levels_per_launch": win_levels, "launches_per_pass": -(-(npk - 1) // win_levels),
+                    "ms_per_pass": float(win_each.sum()) / min(10, args.steps),
+                    "frac": alg_bytes / (float(win_each.sum()) / min(10, args.steps) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "max_abs_diff_Sv_vs_one_launch": win_err,
+                    "note": "cdft_moc_compute_staged_windows: the launches of the cdfmoc program's stream route (CDFT_MOC_ROUTE=stream), "
+                            "on the resident pool; not the timed path"},
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms, "launches": launches,
                 "min_launch_ms": float(each.min()) if launches else None,
                 "median_launch_ms": float(np.median(each)) if launches else None,

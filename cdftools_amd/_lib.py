@@ -82,6 +82,7 @@ SIGNATURES = {
     "cdft_moc_stream_vmask_dest": (_i, [_vp, _i, _pvp]),
     "cdft_moc_stream_compute": (_i, [_vp, _i, _i, _i, _vp]),
     "cdft_moc_stream_end": (_i, [_vp, _vp, _i, _vp]),
+    "cdft_moc_compute_staged_windows": (_i, [_vp, _i, _vp, _i, _vp]),
     "cdft_moc_stage_open": (_i, [_vp, _i, _vp]),
     "cdft_moc_stage_dest": (_i, [_vp, _i, _i, _pvp, C.POINTER(_sz)]),
     "cdft_moc_stage_close": (_i, [_vp]),

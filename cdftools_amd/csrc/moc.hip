@@ -1,6 +1,7 @@
 // moc.hip -- cdfmoc plan: mesh preparation, zonal-kernel dispatch, bottom-to-surface cumsum.
 // C ABI: include/cdftools_hip.h ("cdfmoc").  Reference loops: src/cdfmoc.f90:325-336 (masks),
 // :343-348,:576-596 (e3v), :355-379 (zonal sum), :382-388 (vertical cumulated sum).
+#include <algorithm>
 #include <cstdlib>
 #include <vector>
 #include "moc_zonal.hpp"
@@ -983,6 +984,42 @@ int cdft_moc_compute_staged(cdft_moc_plan *p, double *dmoc, int dmoc_space, void
     const float *pool = (const float *)p->pool.ptr;
     const int64_t R = (int64_t)(p->pool_npt + 1) * p->pool_P;
     return moc_compute_on(p, pool + p->pool_P, p->pool_P, p->staged_npt, dmoc, dmoc_space, as_stream(stream), R, pool, R);
+}
+
+// the staged pool computed a window of nlev levels per launch: the launches the stream route makes, on resident data
+int cdft_moc_compute_staged_windows(cdft_moc_plan *p, int nlev, double *dmoc, int dmoc_space, void *stream) {
+    TraceRange trace_("cdft_moc_compute_staged_windows");
+    if (!p || !dmoc || nlev < 1) return fail(CDFT_ERR_ARG, "cdft_moc_compute_staged_windows: bad argument");
+    if (p->sh) return fail(CDFT_ERR_STATE, "cdft_moc_compute_staged_windows: single-device plans only");
+    if (!p->mesh_set) return fail(CDFT_ERR_STATE, "cdft_moc_compute_staged_windows: cdft_moc_set_mesh has not succeeded");
+    if (p->staged_npt < 1 || p->staged) return fail(CDFT_ERR_STATE, "cdft_moc_compute_staged_windows: no records staged in the pool");
+    hipStream_t st = as_stream(stream);
+    if (!p->pool_w) CDFT_TRY(pool_prepare(p, p->pool_npt, st));
+    const int npt = p->staged_npt;
+    const size_t out_bytes = (size_t)p->nbasins * p->npj * p->npk * npt * sizeof(double);
+    double *d_out = dmoc;
+    if (dmoc_space == CDFT_MEM_HOST || dmoc_space == CDFT_MEM_PINNED) {
+        CDFT_TRY(p->st_out.reserve(out_bytes));
+        d_out = (double *)p->st_out.ptr;
+    } else if (dmoc_space != CDFT_MEM_DEVICE) {
+        return fail(CDFT_ERR_ARG, "cdft_moc_compute_staged_windows: bad memory-space tag %d", dmoc_space);
+    }
+    const float *pool = (const float *)p->pool.ptr;
+    const int64_t R = (int64_t)(p->pool_npt + 1) * p->pool_P;
+    for (int k0 = 0; k0 < p->npk - 1; k0 += nlev) {
+        const int n = std::min(nlev, p->npk - 1 - k0);
+        const float *w = pool + (int64_t)k0 * p->npj * R;
+        CDFT_TRY(zonal_launch(p, w, R, w + p->pool_P, p->pool_P, R, npt, d_out + (int64_t)k0 * p->npj * p->nbasins, st, true, n));
+    }
+    const int nbj = p->nbasins * p->npj;
+    const int64_t nthr = (int64_t)nbj * npt;
+    hipLaunchKernelGGL(moc_cumsum_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, d_out, nbj, p->npk, npt);
+    CDFT_LAUNCH_CHECK();
+    if (dmoc_space != CDFT_MEM_DEVICE) {
+        CDFT_HIP(hipMemcpyAsync(dmoc, d_out, out_bytes, hipMemcpyDeviceToHost, st));
+        if (dmoc_space == CDFT_MEM_HOST) CDFT_HIP(hipStreamSynchronize(st));
+    }
+    return CDFT_OK;
 }
 
 int cdft_moc_compute_pitched(cdft_moc_plan *p, const float *zv, int64_t rec_stride, int64_t row_stride, int npt, double *dmoc,

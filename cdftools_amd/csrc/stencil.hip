@@ -308,7 +308,21 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6
     const int lane = threadIdx.x & 63;
     const int64_t tiles = (int64_t)a.ntx * a.npj, total = tiles * lc;
     int chunk, jj, tx;
-    if (a.band > 0) {
+    // Persistent order (a.band < 0; CDFT_CURL_PERSIST): the grid is what the chip holds at once, XCD x owns the x-th eighth of the
+    // rows, and workgroup w of an XCD's W takes the tiles w, w + W, w + 2W, ... of that eighth in (row, tile) order, each for ALL
+    // levels: the metrics are read once per tile, every workgroup of the chip starts its tile at level 0 at the same moment and
+    // they walk the levels side by side -- a level of W consecutive tiles is one contiguous run per XCD and field.
+    const int W = (int)(gridDim.x >> 3);
+    const int px = blockIdx.x & 7, pw = (int)(blockIdx.x >> 3);
+    const int pj0 = (int)((int64_t)px * a.npj / 8), pnrows = (int)((int64_t)(px + 1) * a.npj / 8) - pj0;
+    const int64_t ptiles = (int64_t)pnrows * a.ntx;
+    for (int64_t pt = pw; ; pt += W) {
+    if (a.band < 0) {
+        if (pt >= ptiles) return;
+        chunk = 0;
+        jj = pj0 + (int)(pt / a.ntx);
+        tx = (int)(pt - (int64_t)(pt / a.ntx) * a.ntx);
+    } else if (a.band > 0) {
         // Row bands (A/B hook CDFT_CURL_BAND): XCD x owns the x-th eighth of the rows and works through it band by band --
         // a band = a.band rows, all their level chunks (chunk-major), then the next band -- so that the metric planes of a
         // band (3 x 17 KB per row) are asked for again while they are still in L2 / Infinity Cache, with short level chunks.
@@ -409,6 +423,8 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6
                 }
             }
         }
+    }
+    if (a.band >= 0) return;                                      // (one tile per workgroup in the other orders)
     }
 }
 
@@ -731,6 +747,18 @@ int cdft_curl_compute(cdft_curl_plan *p, const float *un, const float *vn, int n
         }
         if (const char *elc = getenv("CDFT_CURL_CHUNKS")) lc = std::max(1, std::min(nlev, atoi(elc)));
         dim3 grid((unsigned)(((tiles * lc + 7) / 8) * 8)), block(sh.threads);
+        if (const char *ep = getenv("CDFT_CURL_PERSIST")) {       // A/B hook: the persistent order, n workgroups per CU (0: what fits)
+            const int percu = atoi(ep);
+            if (percu >= 0 && ep[0] != '-') {
+                int ncu = 256;
+                hipDeviceProp_t prop;
+                int dev = 0;
+                if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+                a.band = -1;
+                lc = 1;
+                grid = dim3((unsigned)(percu > 0 ? ((ncu * percu + 7) / 8) * 8 : res));
+            }
+        }
         if (a.band > 0) {
             const int nb = (rows_x + a.band - 1) / a.band;
             grid = dim3((unsigned)(8 * (int64_t)nb * a.band * a.ntx * lc));

@@ -68,10 +68,10 @@ MODULE cdfio
   END TYPE t_pack
 
   INTERFACE putvar
-     MODULE PROCEDURE putvarr8, putvarr4, putvari2, putvarzo
+     MODULE PROCEDURE putvarr8, putvarr4, putvari2, putvarzo, reputvarr4, putvare3
   END INTERFACE
   INTERFACE putvar1d
-     MODULE PROCEDURE putvar1d4, putvar1d8
+     MODULE PROCEDURE putvar1d4, putvar1d8, reputvar1d4, reputvar1d8
   END INTERFACE
   INTERFACE putvar0d
      MODULE PROCEDURE putvar0dt, putvar0ds
@@ -602,6 +602,92 @@ CONTAINS
     ierr = NF90_INQUIRE_VARIABLE(ncid, ivar, ndims=getvdim_all)
     CALL src_detach(ncid)
   END FUNCTION getvdim_all
+
+  SUBROUTINE last_dim_is_record(kncid, kvar, krank, ldrec)
+    ! rank of a variable and whether its LAST dimension is the record one (the re-writers' test, src/cdfio.F90:2623, :2534)
+    INTEGER(KIND=4), INTENT(in)  :: kncid, kvar
+    INTEGER(KIND=4), INTENT(out) :: krank
+    LOGICAL,         INTENT(out) :: ldrec
+    INTEGER(KIND=4) :: ierr, irec, idim(4)
+    idim = 0 ; krank = 0
+    ierr = NF90_INQUIRE(kncid, unlimitedDimId=irec)
+    ierr = NF90_INQUIRE_VARIABLE(kncid, kvar, ndims=krank, dimids=idim)
+    ldrec = .FALSE.
+    IF ( krank >= 1 .AND. krank <= 4 ) ldrec = ( idim(krank) == irec )
+  END SUBROUTINE last_dim_is_record
+
+  INTEGER(KIND=4) FUNCTION reputvarr4(cdfile, cdvar, klev, kpi, kpj, kimin, kjmin, ktime, ptab, kwght)
+    !! putvar given a FILE NAME: a (kpi,kpj) r4 slab written over what variable cdvar of the existing file holds at level klev,
+    !! record ktime, window origin (kimin,kjmin) (src/cdfio.F90:2591-2639)
+    CHARACTER(LEN=*),                 INTENT(in) :: cdfile, cdvar
+    INTEGER(KIND=4), OPTIONAL,        INTENT(in) :: klev
+    INTEGER(KIND=4),                  INTENT(in) :: kpi, kpj
+    INTEGER(KIND=4), OPTIONAL,        INTENT(in) :: kimin, kjmin, ktime
+    REAL(KIND=4), DIMENSION(kpi,kpj), INTENT(in) :: ptab
+    INTEGER(KIND=4), OPTIONAL,        INTENT(in) :: kwght
+    INTEGER(KIND=4) :: ncid, ivar, ierr, irank, ifirst(4), ishape(4)
+    LOGICAL :: ll_rec
+    CALL src_forget(cdfile)
+    reputvarr4 = NF90_OPEN(cdfile, NF90_WRITE, ncid)
+    IF ( reputvarr4 /= NF90_NOERR ) RETURN
+    reputvarr4 = NF90_INQ_VARID(ncid, cdvar, ivar)
+    IF ( reputvarr4 == NF90_NOERR ) THEN
+       CALL last_dim_is_record(ncid, ivar, irank, ll_rec)
+       ifirst = (/ oint(kimin, 1), oint(kjmin, 1), 1, 1 /) ; ishape = (/ kpi, kpj, 1, 1 /)
+       IF ( ll_rec )     ifirst(irank) = oint(ktime, 1)
+       IF ( irank == 4 ) ifirst(3) = oint(klev, 1)
+       reputvarr4 = NF90_PUT_VAR(ncid, ivar, ptab, start=ifirst, count=ishape)
+       IF ( PRESENT(kwght) ) THEN
+          ierr = NF90_REDEF(ncid)
+          reputvarr4 = NF90_PUT_ATT(ncid, ivar, 'iweight', kwght)
+       ENDIF
+    ENDIF
+    ierr = NF90_CLOSE(ncid)
+  END FUNCTION reputvarr4
+
+  INTEGER(KIND=4) FUNCTION putvare3(kout, kid, ptab, kmax, cd_vert, ktime, kwght)
+    !! a vertical profile of kmax values into variable kid (1,1,kmax[,t]) of the open file kout; cd_vert only tells this
+    !! specific of putvar from the others (src/cdfio.F90:2501-2543)
+    INTEGER(KIND=4),               INTENT(in) :: kout, kid, kmax
+    REAL(KIND=4), DIMENSION(kmax), INTENT(in) :: ptab
+    CHARACTER(LEN=*),              INTENT(in) :: cd_vert
+    INTEGER(KIND=4), OPTIONAL,     INTENT(in) :: ktime, kwght
+    INTEGER(KIND=4) :: irank, ifirst(4), ishape(4)
+    LOGICAL :: ll_rec
+    CALL last_dim_is_record(kout, kid, irank, ll_rec)
+    ifirst = 1 ; ishape = (/ 1, 1, kmax, 1 /)
+    IF ( ll_rec ) ifirst(irank) = oint(ktime, 1)
+    putvare3 = NF90_PUT_VAR(kout, kid, ptab, start=ifirst, count=ishape)
+    IF ( PRESENT(kwght) ) putvare3 = NF90_PUT_ATT(kout, kid, 'iweight', kwght)
+  END FUNCTION putvare3
+
+  INTEGER(KIND=4) FUNCTION reputvar1d4(cdfile, cdvar, ptab, kk)
+    !! kk r4 values over the 1-D variable cdvar of an existing file (src/cdfio.F90:2758-2781)
+    CHARACTER(LEN=*),            INTENT(in) :: cdfile, cdvar
+    INTEGER(KIND=4),             INTENT(in) :: kk
+    REAL(KIND=4), DIMENSION(kk), INTENT(in) :: ptab
+    INTEGER(KIND=4) :: ncid, ivar, ierr
+    CALL src_forget(cdfile)
+    reputvar1d4 = NF90_OPEN(cdfile, NF90_WRITE, ncid)
+    IF ( reputvar1d4 /= NF90_NOERR ) RETURN
+    reputvar1d4 = NF90_INQ_VARID(ncid, cdvar, ivar)
+    IF ( reputvar1d4 == NF90_NOERR ) reputvar1d4 = NF90_PUT_VAR(ncid, ivar, ptab, start=(/ 1 /), count=(/ kk /))
+    ierr = NF90_CLOSE(ncid)
+  END FUNCTION reputvar1d4
+
+  INTEGER(KIND=4) FUNCTION reputvar1d8(cdfile, cdvar, ddtab, kk)
+    !! the same for r8 values (src/cdfio.F90:2783-2806)
+    CHARACTER(LEN=*),            INTENT(in) :: cdfile, cdvar
+    INTEGER(KIND=4),             INTENT(in) :: kk
+    REAL(KIND=8), DIMENSION(kk), INTENT(in) :: ddtab
+    INTEGER(KIND=4) :: ncid, ivar, ierr
+    CALL src_forget(cdfile)
+    reputvar1d8 = NF90_OPEN(cdfile, NF90_WRITE, ncid)
+    IF ( reputvar1d8 /= NF90_NOERR ) RETURN
+    reputvar1d8 = NF90_INQ_VARID(ncid, cdvar, ivar)
+    IF ( reputvar1d8 == NF90_NOERR ) reputvar1d8 = NF90_PUT_VAR(ncid, ivar, ddtab, start=(/ 1 /), count=(/ kk /))
+    ierr = NF90_CLOSE(ncid)
+  END FUNCTION reputvar1d8
 
   SUBROUTINE gettimeseries(cdfile, cdvar, kilook, kjlook, klev, ldncdf)
     !! two columns on stdout, time in days and the value of cdvar at point (kilook,kjlook) [level klev] for every record of the

@@ -42,35 +42,35 @@ PROGRAM cdfmhst
   CALL ReadCdfNames()
   narg = COMMAND_ARGUMENT_COUNT()
   IF ( narg == 0 ) THEN
-     PRINT *, ' usage : cdfmhst  -vt VT-file | (-v V-file -t T-file [-s S-file]) [-MST] [-full] ...'
-     PRINT *, '          ... [-Zdim] [-b BASIN-file] [-o OUT-file] [-vtvar VT-var VS-var] [-vvl]'
-     PRINT *, '      '
-     PRINT *, '     PURPOSE :'
-     PRINT *, '       Compute the meridional heat transport (and, with -MST, the salt transport) as a function'
-     PRINT *, '       of latitude, for the global ocean and for the sub-basins of ', TRIM(cn_fbasins), ' when'
-     PRINT *, '       that file exists.  MI355X build: integration and zonal sums run on the GPU.'
-     PRINT *, '      '
-     PRINT *, '     ARGUMENTS :'
-     PRINT *, '       -vt VT-file : file with the mean products V.T and V.S (from cdfvT), or'
-     PRINT *, '       -v V-file -t T-file [-s S-file] : separate velocity and tracer files.'
-     PRINT *, '      '
-     PRINT *, '     OPTIONS :'
-     PRINT *, '       [-MST ]   : also output the meridional salt transport'
-     PRINT *, '       [-full ]  : full step'
-     PRINT *, '       [-Zdim ]  : output the cumulated transport of every level (variables get a depth axis)'
-     PRINT *, '       [-b BASIN-file] : sub-basin mask file instead of ', TRIM(cn_fbasins)
-     PRINT *, '       [-vtvar VT-var VS-var] : names of the product variables instead of ', TRIM(cn_vomevt), ' ', TRIM(cn_vomevs)
-     PRINT *, '       [-vvl ]   : time-varying vertical metrics'
-     PRINT *, '       [-o OUT-file ] : change name of the output file. Default:', TRIM(cf_outnc)
-     PRINT *, '      '
-     PRINT *, '     REQUIRED FILES :'
-     PRINT *, '       ', TRIM(cn_fhgr), ', ', TRIM(cn_fzgr), ' and ', TRIM(cn_fmsk)
-     PRINT *, '      '
-     PRINT *, '     OUTPUT : '
-     PRINT *, '       ASCII files : ', TRIM(cf_outh), ' : Meridional Heat Transport'
-     PRINT *, '                     ', TRIM(cf_outs), ' : Meridional Salt Transport'
-     PRINT *, '       netcdf file : ', TRIM(cf_outnc), ' unless -o option is used.'
-     PRINT *, '         variables : ', TRIM(cv_zomht), '_glo [_atl _inp _ind _pac _inp0], and ', TRIM(cv_zomst), '_* with -MST'
+     PRINT '(99a)', ' ', ' usage : cdfmhst  -vt VT-file | (-v V-file -t T-file [-s S-file]) [-MST] [-full] ...'
+     PRINT '(99a)', ' ', '          ... [-Zdim] [-b BASIN-file] [-o OUT-file] [-vtvar VT-var VS-var] [-vvl]'
+     PRINT '(99a)', ' ', '      '
+     PRINT '(99a)', ' ', '     PURPOSE :'
+     PRINT '(99a)', ' ', '       Compute the meridional heat transport (and, with -MST, the salt transport) as a function'
+     PRINT '(99a)', ' ', '       of latitude, for the global ocean and for the sub-basins of ', TRIM(cn_fbasins), ' when'
+     PRINT '(99a)', ' ', '       that file exists.  MI355X build: integration and zonal sums run on the GPU.'
+     PRINT '(99a)', ' ', '      '
+     PRINT '(99a)', ' ', '     ARGUMENTS :'
+     PRINT '(99a)', ' ', '       -vt VT-file : file with the mean products V.T and V.S (from cdfvT), or'
+     PRINT '(99a)', ' ', '       -v V-file -t T-file [-s S-file] : separate velocity and tracer files.'
+     PRINT '(99a)', ' ', '      '
+     PRINT '(99a)', ' ', '     OPTIONS :'
+     PRINT '(99a)', ' ', '       [-MST ]   : also output the meridional salt transport'
+     PRINT '(99a)', ' ', '       [-full ]  : full step'
+     PRINT '(99a)', ' ', '       [-Zdim ]  : output the cumulated transport of every level (variables get a depth axis)'
+     PRINT '(99a)', ' ', '       [-b BASIN-file] : sub-basin mask file instead of ', TRIM(cn_fbasins)
+     PRINT '(99a)', ' ', '       [-vtvar VT-var VS-var] : names of the product variables instead of ', TRIM(cn_vomevt), ' ', TRIM(cn_vomevs)
+     PRINT '(99a)', ' ', '       [-vvl ]   : time-varying vertical metrics'
+     PRINT '(99a)', ' ', '       [-o OUT-file ] : change name of the output file. Default:', TRIM(cf_outnc)
+     PRINT '(99a)', ' ', '      '
+     PRINT '(99a)', ' ', '     REQUIRED FILES :'
+     PRINT '(99a)', ' ', '       ', TRIM(cn_fhgr), ', ', TRIM(cn_fzgr), ' and ', TRIM(cn_fmsk)
+     PRINT '(99a)', ' ', '      '
+     PRINT '(99a)', ' ', '     OUTPUT : '
+     PRINT '(99a)', ' ', '       ASCII files : ', TRIM(cf_outh), ' : Meridional Heat Transport'
+     PRINT '(99a)', ' ', '                     ', TRIM(cf_outs), ' : Meridional Salt Transport'
+     PRINT '(99a)', ' ', '       netcdf file : ', TRIM(cf_outnc), ' unless -o option is used.'
+     PRINT '(99a)', ' ', '         variables : ', TRIM(cv_zomht), '_glo [_atl _inp _ind _pac _inp0], and ', TRIM(cv_zomst), '_* with -MST'
      STOP
   ENDIF
 

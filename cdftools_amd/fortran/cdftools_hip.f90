@@ -180,6 +180,10 @@ MODULE cdftools_hip
      INTEGER(C_INT) FUNCTION cdft_moc_stats(plan, zonal_launches, records) BIND(C, name='cdft_moc_stats')
        IMPORT ; TYPE(C_PTR), VALUE :: plan ; INTEGER(C_INT64_T), INTENT(out) :: zonal_launches, records
      END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_moc_compute_staged_windows(plan, nlev, dmoc, dmoc_space, stream) &
+          &         BIND(C, name='cdft_moc_compute_staged_windows')
+       IMPORT ; TYPE(C_PTR), VALUE :: plan, stream ; INTEGER(C_INT), VALUE :: nlev, dmoc_space ; REAL(C_DOUBLE), INTENT(out) :: dmoc(*)
+     END FUNCTION
      INTEGER(C_INT) FUNCTION cdft_moc_reserve(plan, npt, stream) BIND(C, name='cdft_moc_reserve')
        IMPORT ; TYPE(C_PTR), VALUE :: plan, stream ; INTEGER(C_INT), VALUE :: npt
      END FUNCTION

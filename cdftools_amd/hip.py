@@ -325,6 +325,12 @@ class MocPlan:
         check(_lib.load().cdft_moc_compute_staged(self._h, po, so, stream or current_stream_ptr()))
         return out
 
+    def compute_staged_windows(self, nlev, out, stream=None):
+        """cdft_moc_compute_staged_windows: the staged pool, one launch per window of nlev levels (the stream route's launches)."""
+        po, so, ko = _arg(out, np.float64, "dmoc")
+        check(_lib.load().cdft_moc_compute_staged_windows(self._h, int(nlev), po, so, stream or current_stream_ptr()))
+        return out
+
     def compute(self, zv, out=None, rec_stride=None, npt=None, stream=None):
         """zv (npt,npk,npj,npi) r4 -> dmoc (npt,npk,npj,nb) r8 in Sv (same memory space as zv
         unless `out` is given)."""

@@ -208,6 +208,9 @@ int cdft_moc_stage_dest(cdft_moc_plan *plan, int record, int level, void **dst, 
 int cdft_moc_stage_close(cdft_moc_plan *plan);
 int cdft_moc_release_staged(cdft_moc_plan *plan);
 int cdft_moc_compute_staged(cdft_moc_plan *plan, double *dmoc, int dmoc_space, void *stream);
+/* the same result from the same resident pool with one launch per window of nlev levels instead of one for all: the launches
+ * the stream route (below) makes, on resident data -- what bench.py reports as roofline.level_windows */
+int cdft_moc_compute_staged_windows(cdft_moc_plan *plan, int nlev, double *dmoc, int dmoc_space, void *stream);
 /* The stream route: cdfmoc with NOTHING 3-D resident -- what the cdfmoc program does when its fields are large.  The reference
  * reads one (npiglo,npjglo) slab per level and record and works on it (src/cdfmoc.f90:355-379); here the domain goes through
  * HBM a WINDOW of nlev levels at a time, every record of the run beside the window's metric, laid out like the pool: row

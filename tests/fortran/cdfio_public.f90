@@ -163,6 +163,13 @@ CONTAINS
     ierr = atted(cf_e, 'field', 'comment', 'edited twice')
     zspv2 = getspval(cf_e, 'field')
     PRINT '(a,es16.8,1x,a,1x,a)', 'edited', zspv2, TRIM(getatt(cf_e, 'field', 'units', 'c')), TRIM(getatt(cf_e, 'field', 'comment', 'c'))
+    ! the specifics of putvar / putvar1d that take a file NAME (reputvarr4, reputvar1d4 / 8) and the profile one (putvare3)
+    z2 = 7.
+    ierr = putvar(cf_e, 'field', 1, 2, 2, kimin=3, kjmin=2, ktime=1, ptab=z2(1:2,1:2), kwght=9)
+    ierr = putvar1d(cf_e, cn_vtimec, (/ 5.d0 /), 1)
+    z2 = getvar(cf_e, 'field', 1, npi, npj)
+    PRINT '(a,999es16.8)', 'reputvar', z2
+    PRINT '(a,i4,es16.8)', 'reputvar_att', getatt(cf_e, 'field', 'iweight', 1), REAL(getvar1d(cf_e, cn_vtimec, 1), 4)
     ! copyatt between two open files, and from no file at all
     cf_o = TRIM(cdir)//'/copy.nc'
     iout = create(cf_o, cf_t, npi, npj, 0)

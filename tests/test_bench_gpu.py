@@ -32,6 +32,8 @@ def test_bench_n1_line_small_workload(gpu):
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and r["cpu_baseline"]["cores"] >= 1
     assert r["cpu_baseline"]["kind"] == "port" and r["cpu_baseline"]["value"] > 0
     assert rf["traffic"] is None and "measured" in rf["traffic_source_builders_pmc_run"]       # the PMC passes are another kernel shape's (eORCA12), not this run's
+    lw = rf["level_windows"]                         # the stream route's launches on the resident pool: the same sums, 0 < frac < 1
+    assert lw["launches_per_pass"] * lw["levels_per_launch"] >= 74 and lw["max_abs_diff_Sv_vs_one_launch"] == 0.0 and 0 < lw["frac"] < 1
     assert r["comm"] is None and r["per_rank"] is None and r["tools"] is None          # (the per-tool lines ride with the eorca12 line only)
     cb = r["cpu_baseline"]                           # the box is named: logical CPUs, those usable, the model; cores = threads used
     assert cb["host_nproc"] >= cb["host_cpus_usable"] >= 1 and cb["cores"] <= cb["host_nproc"] and isinstance(cb["host_cpu_model"], str)

@@ -182,6 +182,8 @@ def test_the_rest_of_the_public_list(run):
     assert out["ncopen"] == "1"
     v, units, comment = out["edited"].split(None, 2)
     assert f32(v) == f32(77.0) and units == "new" or out["edited"].split()[1:3] == ["new", "units"]
+    rp = nums(out["reputvar"], (NPJ, NPI))                           # a 2 x 2 window of sevens over a field never written before
+    assert np.all(rp[1:3, 2:4] == 7) and out["reputvar_att"].split()[0] == "9" and f32(out["reputvar_att"].split()[1]) == f32(5.0)
     f = netcdf_file(os.path.join(d, "edit.nc"), "r", mmap=False)
     fld, tc = f.variables["field"], f.variables["time_counter"]
     assert fld.units == b"new units" and fld.long_name == b"new long" and fld.short_name == b"field" and fld._FillValue == f32(77.0)

@@ -42,6 +42,8 @@ def test_usage_unknown_option_and_missing_file(tools, tmp_path, tool):
     rc, out, _ = run(tool, [], tmp_path)
     first = out.strip().splitlines()[0]
     assert rc == 0 and "usage :" in first and tool in first            # README.md:49 of the reference
+    # every line as it was written: list-directed output would fold a line at column 80, mid-word ("integ / ration")
+    assert all(ln.startswith("  ") for ln in out.splitlines() if ln.strip()), [ln for ln in out.splitlines() if ln.strip() and not ln.startswith("  ")][:3]
     rc, out, _ = run(tool, ["-thisisnotanoption"], tmp_path)
     assert rc == 99 and "unknown option" in out                      # e.g. src/cdfmoc.f90:232
     first = {"cdfmoc": "-v", "cdfheatc": "-f", "cdfcurl": "-u", "cdfsig0": "-t", "cdfsigi": "-t", "cdfpsi": "-u",

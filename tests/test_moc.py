@@ -511,4 +511,8 @@ def test_hip_headline_shape_on_the_pool(gpu):
     ulp = torch.from_numpy(np.spacing(np.abs(d4.cpu().numpy()))).cuda()
     assert bool(((a4 - d4).abs() <= ulp).all())
     assert torch.equal(plan.compute_staged(torch.zeros_like(a)), a)   # (the dense call did not touch the pool)
+    # the same pool a window of five levels per launch (what the program's stream route launches): the same bits
+    n1 = plan.stats()
+    assert torch.equal(plan.compute_staged_windows(5, torch.zeros_like(a)), a)
+    assert plan.stats() == (n1[0] + 15, n1[1] + 15 * npt)
     plan.close()

@@ -117,6 +117,24 @@ def test_hip_curl_equals_oracle_bitwise(gpu, monkeypatch, kernel, npi, npj, nlev
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("percu", [0, 1, 3])
+@pytest.mark.parametrize("npi,npj,nlev", [(70, 37, 7), (1025, 9, 3), (24, 8, 2), (4322, 70, 5), (1442, 300, 4)])
+def test_hip_curl_persistent_order(gpu, monkeypatch, percu, npi, npj, nlev):
+    """The persistent order of curl_tile_kernel (CDFT_CURL_PERSIST: the grid is what the chip holds, a workgroup takes every
+    W-th tile of its XCD's rows for all levels): more tiles than workgroups, fewer, XCDs without rows.  Bitwise against the oracle."""
+    monkeypatch.setenv("CDFT_CURL_PERSIST", str(percu))
+    g = synth.make_grid(npi, npj, max(nlev, 2), seed=npi + percu)
+    u, v, _, _, _, _ = frames(g, 1, seed=28)
+    un, vn = u[0, :nlev], v[0, :nlev]
+    plan = gpu.CurlPlan(npi, npj)
+    for lperio, ltpoint in ((False, False), (True, True)):
+        plan.set_mesh(g["e1u"], g["e2v"], g["e1f"], g["e2f"], lperio=lperio)
+        got = plan.compute(un, vn, ltpoint=ltpoint)
+        ref = np.stack([oracle_tools.curl(un[k], vn[k], g["e1u"], g["e2v"], g["e1f"], g["e2f"], lperio, ltpoint) for k in range(nlev)])
+        assert np.array_equal(got, ref), (lperio, ltpoint)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("band,chunks", [(1, 1), (3, 2), (7, 5), (64, 3), (5, 7)])
 @pytest.mark.parametrize("npi,npj,nlev", [(70, 37, 7), (1025, 9, 3), (24, 8, 2)])
 def test_hip_curl_row_bands_any_band_and_chunk_count(gpu, monkeypatch, band, chunks, npi, npj, nlev):

@@ -17,3 +17,5 @@ run() {  # label, env...
 run "default" CDFT_NOOP=1
 for lc in 1 3 5 8 15 25 38 75; do run "band=0 chunks=$lc" CDFT_CURL_BAND=0 CDFT_CURL_CHUNKS=$lc; done
 for b in 32 64 128 256; do for lc in 5 15 25 75; do run "band=$b chunks=$lc" CDFT_CURL_BAND=$b CDFT_CURL_CHUNKS=$lc; done; done
+# the persistent order: n workgroups per CU (0: what the occupancy calculator says fits)
+for n in 0 2 4 6 8; do run "persist=$n" CDFT_CURL_PERSIST=$n; done
