@@ -174,7 +174,7 @@ def tools_leg(args):
         env.pop(k, None)
     try:
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_tools.py"), "--grid", "eorca025", "--reps", "20", "--tools",
-                            "heatc,mhst,psi,vt,curl,eos", "--land", "none"], capture_output=True, text=True, timeout=args.tools_timeout, env=env)
+                            "heatc,mhst,psi,vt,curl,eos", "--land", "none", "--warm", "0.3"], capture_output=True, text=True, timeout=args.tools_timeout, env=env)
         for ln in r.stdout.splitlines():
             if not ln.startswith("{"):
                 continue
@@ -663,34 +663,40 @@ def main():
     cpu = None
     cpu_ref = None
     check = None
-    if rank == 0 and not args.no_cpu_baseline:
+    tools = None
+    gathers = pipe.gathers
+    sample = None
+    if rank == 0 and not args.no_cpu_baseline:                       # the row sample of the CPU legs, taken to the host now
+        sample = (e1v[:keep_rows].cpu(), e3v_s.cpu(), ib[:keep_rows].cpu(), zv[:, :, :keep_rows].cpu(), result[:, :, :keep_rows].cpu())
+    if world == 1 and not args.no_tools and args.workload == "eorca12":
+        # the per-tool lines FIRST, while the GPU is still warm from the timed region (after the 18 s of CPU legs it has gone
+        # back to its idle clocks, and the short tool kernels read 3-8 % slower): the children need the device's memory
+        plan.close()
+        del pipe, plan, zv, e1v, ib, result
+        pipe = plan = zv = e1v = ib = result = None
+        torch.cuda.empty_cache()
+        tools = tools_leg(args)
+    if sample is not None:
         # rank 0's first rows are rows 1..keep_rows of the global result for any N: the same check at every N
         target = 12.0 if world == 1 else 0.0                         # the timed CPU baseline is an N = 1 item
-        cpu, rows, ref = cpu_baseline(e1v[:keep_rows], e3v_s, ib[:keep_rows], zv[:, :, :keep_rows], npi, npk, npt, target_s=target)
+        s_e1v, s_e3v, s_ib, s_zv, s_res = sample
+        cpu, rows, ref = cpu_baseline(s_e1v, s_e3v, s_ib, s_zv, npi, npk, npt, target_s=target)
         if world > 1:
             cpu = None
-        got = result[:, :, :rows].cpu().numpy()
+        got = s_res[:, :, :rows].numpy()
         bound = np.abs(ref).max() + 1e-300
         check = float(np.abs(got - ref).max() / bound)
         if not check < 1e-11:
             raise SystemExit(f"bench: HIP result differs from the oracle on the sampled rows (rel {check:.3e})")
         if world == 1 and nb == 5:
             try:
-                cpu_ref = reference_baseline(e1v[:keep_rows], e3v_s, ib[:keep_rows], zv[:, :, :keep_rows], npi, npk, npt, got)
+                cpu_ref = reference_baseline(s_e1v, s_e3v, s_ib, s_zv, npi, npk, npt, got)
             except (OSError, subprocess.SubprocessError, ValueError) as exc:        # no room in the temporary directory, ...:
                 cpu_ref = {"kind": "reference", "error": str(exc)[:300]}               # an optional leg, never the bench's failure
             if cpu_ref is not None and "error" not in cpu_ref and not cpu_ref["hip_vs_reference_rel_err"] < 1e-11:
                 raise SystemExit(f"bench: HIP result differs from the reference's statements (rel {cpu_ref['hip_vs_reference_rel_err']:.3e})")
 
     inproc = None
-    tools = None
-    gathers = pipe.gathers
-    if world == 1 and not args.no_tools and args.workload == "eorca12":
-        plan.close()                                                # the children need the device's memory
-        del pipe, plan, zv, e1v, ib, result
-        pipe = plan = zv = e1v = ib = result = None
-        torch.cuda.empty_cache()
-        tools = tools_leg(args)
     if not args.no_inprocess:
         # the in-process leg: every rank lets go of its memory, rank 0's child uses the N devices, the others wait
         del pipe, plan, zv, e1v, ib, result

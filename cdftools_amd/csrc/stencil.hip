@@ -308,21 +308,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6
     const int lane = threadIdx.x & 63;
     const int64_t tiles = (int64_t)a.ntx * a.npj, total = tiles * lc;
     int chunk, jj, tx;
-    // Persistent order (a.band < 0; CDFT_CURL_PERSIST): the grid is what the chip holds at once, XCD x owns the x-th eighth of the
-    // rows, and workgroup w of an XCD's W takes the tiles w, w + W, w + 2W, ... of that eighth in (row, tile) order, each for ALL
-    // levels: the metrics are read once per tile, every workgroup of the chip starts its tile at level 0 at the same moment and
-    // they walk the levels side by side -- a level of W consecutive tiles is one contiguous run per XCD and field.
-    const int W = (int)(gridDim.x >> 3);
-    const int px = blockIdx.x & 7, pw = (int)(blockIdx.x >> 3);
-    const int pj0 = (int)((int64_t)px * a.npj / 8), pnrows = (int)((int64_t)(px + 1) * a.npj / 8) - pj0;
-    const int64_t ptiles = (int64_t)pnrows * a.ntx;
-    for (int64_t pt = pw; ; pt += W) {
-    if (a.band < 0) {
-        if (pt >= ptiles) return;
-        chunk = 0;
-        jj = pj0 + (int)(pt / a.ntx);
-        tx = (int)(pt - (int64_t)(pt / a.ntx) * a.ntx);
-    } else if (a.band > 0) {
+    if (a.band > 0) {
         // Row bands (A/B hook CDFT_CURL_BAND): XCD x owns the x-th eighth of the rows and works through it band by band --
         // a band = a.band rows, all their level chunks (chunk-major), then the next band -- so that the metric planes of a
         // band (3 x 17 KB per row) are asked for again while they are still in L2 / Infinity Cache, with short level chunks.
@@ -349,82 +335,25 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6
     const int64_t nij = (int64_t)a.npi * a.npj;
     {
         const int lev0 = (int)((int64_t)chunk * a.nlev / lc), lev1 = (int)((int64_t)(chunk + 1) * a.nlev / lc);
-        const bool north = jj < a.npj - 1;
-        const int it = (int)threadIdx.x * 4, ic = tx * tw + it;   // first column before anchoring
-        const bool act = it < tw && ic < a.npi;                   // lanes past the tile or the row do nothing
-        const int i0 = min(ic, a.npi - 4);
-        const int sh = act ? ic - i0 : 0;                         // cells of this vector that repeat the previous lane's
-        const bool halo = act && (lane == 63 || it + 4 >= tw) && ic + 4 < a.npi;   // east neighbour: next wave / tile
-        const int64_t p2 = (int64_t)jj * a.npi + i0;
-        float e1u[4] = {0, 0, 0, 0}, e1un[4] = {0, 0, 0, 0}, e2v[4] = {0, 0, 0, 0}, den[4] = {1, 1, 1, 1}, enx = 0.f;
-        if (act) {
-            load4(a.e1u + p2, 4, e1u); load4(a.e2v + p2, 4, e2v); load4(a.den + p2, 4, den);     // den = e1f*e2f, formed once per mesh
-            if (north) load4(a.e1u + p2 + a.npi, 4, e1un);
-            if (i0 + 4 < a.npi) enx = a.e2v[p2 + 4];
-        }
-        struct Level { float u[4], v[4], un1[4], hv; };
-        auto fetch = [&](Level &x, int lev) {
-            const float *un = a.un + (int64_t)lev * nij, *vn = a.vn + (int64_t)lev * nij;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { x.u[c] = x.v[c] = x.un1[c] = 0.f; }
-            if (act) {
-                load4(un + p2, 4, x.u); load4s(vn + p2, 4, x.v);
-                if (north) load4(un + p2 + a.npi, 4, x.un1);
-            }
-            x.hv = halo ? vn[p2 + 4] : 0.f;
-        };
-        Level q[kCurlPF];
-#pragma unroll
-        for (int k = 0; k < kCurlPF - 1; ++k)
-            if (lev0 + k < lev1) fetch(q[k], lev0 + k);
-        for (int levb = lev0; levb < lev1; levb += kCurlPF) {
-#pragma unroll
-            for (int k = 0; k < kCurlPF; ++k) {
-                const int lev = levb + k;
-                if (lev >= lev1) break;
-                if (lev + kCurlPF - 1 < lev1) fetch(q[(k + kCurlPF - 1) % kCurlPF], lev + kCurlPF - 1);
-                float u[4], un1[4], v[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) { u[c] = q[k].u[c]; un1[c] = q[k].un1[c]; v[c] = q[k].v[c]; }
-                const float mine = sh == 0 ? v[0] : sh == 1 ? v[1] : sh == 2 ? v[2] : v[3];   // column ic of this row
-                __syncthreads();            // nothing is shared: it keeps the waves of the tile at the same level, and their
-                                            // loads one contiguous run (measured: 8 % faster at eORCA12 than free-running waves)
-                float vnx = __shfl_down(mine, 1);
-                if (halo) vnx = q[k].hv;
-                if (act) {
-                    double res[4];
-                    uint8_t fk[4];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const int i = i0 + c;
-                        float val = 0.f;                                          // drotn(:,:) = 0.d0, :275
-                        fk[c] = 0;
-                        if (north) {
-                            if (i < a.npi - 1) {
-                                const float ve = (c < 3) ? v[c < 3 ? c + 1 : 3] : vnx, ee = (c < 3) ? e2v[c < 3 ? c + 1 : 3] : enx;
-                                float f = __fmul_rn(__fmul_rn(__fmul_rn(u[c], un1[c]), v[c]), ve);
-                                f = (f != 0.f) ? 1.f : 0.f;
-                                fk[c] = (uint8_t)f;
-                                const float num = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(ee, ve), -__fmul_rn(e2v[c], v[c])),
-                                                                      -__fmul_rn(e1un[c], un1[c])), __fmul_rn(e1u[c], u[c]));
-                                val = __fdiv_rn(__fmul_rn(num, f), den[c]);
-                            } else if (a.lperio && a.npi > 2) {                   // drotn(npiglo,:) = drotn(2,:), :285
-                                val = curl_at(a, a.un + (int64_t)lev * nij, a.vn + (int64_t)lev * nij, 1, jj, nullptr);
-                            }
-                        }
-                        res[c] = (double)val;
-                        if (KEEP) { a.work[(int64_t)lev * nij + p2 + c] = val; a.fmk[(int64_t)lev * nij + p2 + c] = fk[c]; }
-                        if (!KEEP && a.ff) {                                          // -overf, :299-301 (ff re-read per level:
-                            const double f = a.ff[p2 + c];                            // 8 registers fewer for every other run)
-                            if (f != 0.0) res[c] = __ddiv_rn(res[c], f);
-                        }
-                    }
-                    if (!KEEP) store4((OUT *)a.out + (int64_t)lev * nij + p2, 4, res);
-                }
-            }
-        }
+#include "curl_tile_body.inc"
     }
-    if (a.band >= 0) return;                                      // (one tile per workgroup in the other orders)
+}
+
+// The persistent order (CDFT_CURL_PERSIST; a kernel of its own so that the orders above keep their registers): the grid is what the
+// chip holds at once, XCD x owns the x-th eighth of the rows, and workgroup w of an XCD's W takes the tiles w, w + W, w + 2W, ...
+// of that eighth in (row, tile) order, each for ALL levels: the metrics are read once per tile, every workgroup of the chip starts
+// its tile at level 0 at the same moment and they walk the levels side by side -- a level of W consecutive tiles is one
+// contiguous run per XCD and field.
+template <typename OUT, bool KEEP>
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 8))) curl_tile_persist_kernel(CurlArgs a, int tw) {
+    const int lane = threadIdx.x & 63;
+    const int64_t nij = (int64_t)a.npi * a.npj;
+    const int W = (int)(gridDim.x >> 3), px = blockIdx.x & 7;
+    const int pj0 = (int)((int64_t)px * a.npj / 8), ntiles = ((int)((int64_t)(px + 1) * a.npj / 8) - pj0) * a.ntx;
+    const int lev0 = 0, lev1 = a.nlev;
+    for (int pt = (int)(blockIdx.x >> 3); pt < ntiles; pt += W) {
+        const int jj = pj0 + pt / a.ntx, tx = pt % a.ntx;
+#include "curl_tile_body.inc"
     }
 }
 
@@ -763,6 +692,12 @@ int cdft_curl_compute(cdft_curl_plan *p, const float *un, const float *vn, int n
             const int nb = (rows_x + a.band - 1) / a.band;
             grid = dim3((unsigned)(8 * (int64_t)nb * a.band * a.ntx * lc));
         }
+        if (a.band < 0) {
+            typedef void (*CurlPersist)(CurlArgs, int);
+            static const CurlPersist ptable[3] = {curl_tile_persist_kernel<double, true>, curl_tile_persist_kernel<double, false>,
+                                                  curl_tile_persist_kernel<float, false>};
+            hipLaunchKernelGGL(ptable[variant], grid, block, 0, st, a, sh.tw);
+        } else
         hipLaunchKernelGGL(table[variant], grid, block, 0, st, a, sh.tw, lc);
     } else {
         a.ntx = (p->npi + kTile - 1) / kTile;

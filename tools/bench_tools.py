@@ -112,11 +112,14 @@ def fp64_ops(case, grid, kernel):
     return None, None
 
 
+WARM_S = 0.05      # seconds of calls before the timed ones (--warm)
+
+
 def timed(fn, reps):
     # warm for 50 ms of calls at least: after host-side set-up the GPU's clocks take tens of milliseconds to come back up,
     # and a tool measured first read 4-6 % slower than the same tool measured again (cdfzonalsum / cdfzonalmean, swapped)
     t0, n = time.perf_counter(), 0
-    while n < 3 or time.perf_counter() - t0 < 0.05:
+    while n < 3 or time.perf_counter() - t0 < WARM_S:
         fn()
         torch.cuda.synchronize()
         n += 1
@@ -161,7 +164,10 @@ def main():
     ap.add_argument("--frames", type=int, default=6)
     ap.add_argument("--tools", default="heatc,mean,zonal,mhst,psi,vt,curl,eos")
     ap.add_argument("--land", default="noise,contiguous", help="land of the fp64-bound lines (eos, mocsig): none | noise | contiguous, comma separated")
+    ap.add_argument("--warm", type=float, default=0.05, help="seconds of untimed calls before every timed loop")
     args = ap.parse_args()
+    global WARM_S
+    WARM_S = args.warm
     npi, npj, npk = GRIDS[args.grid]
     dev = torch.device("cuda", 0)
     g = torch.Generator(device=dev).manual_seed(1)
