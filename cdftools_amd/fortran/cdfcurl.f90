@@ -39,34 +39,7 @@ PROGRAM cdfcurl
   CALL ReadCdfNames()
   narg = COMMAND_ARGUMENT_COUNT()
   IF ( narg == 0 ) THEN
-     PRINT '(99a)', ' ', ' usage : cdfcurl -u U-file U-var -v V-file V-var -l levlist [-T] [-8]...'
-     PRINT '(99a)', ' ', '           ... [-surf] [-overf] [-nc4] [-o OUT-file ] [-nometric]'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     PURPOSE :'
-     PRINT '(99a)', ' ', '       Compute the curl of a vector field at the specified levels (at F points, or at T points'
-     PRINT '(99a)', ' ', '       with -T).  MI355X build: the stencil runs on the GPU.'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     ARGUMENTS :'
-     PRINT '(99a)', ' ', '       -u U-file U-var : file and variable of the zonal component.'
-     PRINT '(99a)', ' ', '       -v V-file V-var : file and variable of the meridional component.'
-     PRINT '(99a)', ' ', '       -l levlist      : levels, e.g. 1  or  1,3,5  or  1-20  or  1-3,10-12.'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     OPTIONS :'
-     PRINT '(99a)', ' ', '       [-T]        : curl at T points instead of F points'
-     PRINT '(99a)', ' ', '       [-8]        : double precision output'
-     PRINT '(99a)', ' ', '       [-surf]     : single-level C-grid files (no vertical dimension)'
-     PRINT '(99a)', ' ', '       [-overf]    : curl normalised by the local Coriolis parameter'
-     PRINT '(99a)', ' ', '       [-nometric] : unit metrics (output ', 'curl_grid.nc', ')'
-     PRINT '(99a)', ' ', '       [-nc4]      : NetCDF-4 output with chunking and deflation (needs the HDF5 plug-in)'
-     PRINT '(99a)', ' ', '       [-o OUT-file] : output file instead of ', TRIM(cf_out)
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     REQUIRED FILES :'
-     PRINT '(99a)', ' ', '       ', TRIM(cn_fhgr)
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     OUTPUT : '
-     PRINT '(99a)', ' ', '       netcdf file : ', TRIM(cf_out)
-     PRINT '(99a)', ' ', '         variables : socurl or socurlt (if -T option), units : s^-1'
-     PRINT '(99a)', ' ', '            or socurloverf, no units (if -overf option)'
+#include "usage/cdfcurl.inc"
      STOP
   ENDIF
 

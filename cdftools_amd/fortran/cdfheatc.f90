@@ -41,38 +41,7 @@ PROGRAM cdfheatc
   CALL ReadCdfNames()
   narg = COMMAND_ARGUMENT_COUNT()
   IF ( narg == 0 ) THEN
-     PRINT '(99a)', ' ', ' usage :  cdfheatc  -f T-file [-mxloption option] [-mxlf MXL-file] ...'
-     PRINT '(99a)', ' ', '     [-zoom imin imax jmin jmax kmin kmax] [-full] [-o OUT-file]'
-     PRINT '(99a)', ' ', '     [-M MSK-file VAR-mask ] [-vvl ]'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     PURPOSE :'
-     PRINT '(99a)', ' ', '       Compute the heat content of the ocean in the specified area (global by default).'
-     PRINT '(99a)', ' ', '       MI355X build: the masked volume integrals of every level run on the GPU.'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     ARGUMENTS :'
-     PRINT '(99a)', ' ', '       -f T-file : netcdf file with temperature.'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     OPTIONS :'
-     PRINT '(99a)', ' ', '       [-zoom imin imax jmin jmax kmin kmax] : sub-domain; a 0 pair means the full range.'
-     PRINT '(99a)', ' ', '       [-full ]             : full step instead of the default partial step'
-     PRINT '(99a)', ' ', '       [-mxloption option]  : 1: only in the mixed layer, -1: only below it, 0: ignore (default)'
-     PRINT '(99a)', ' ', '       [-mxlf MXL-file ]    : file with the mixed layer depth when it is not in T-file'
-     PRINT '(99a)', ' ', '       [-o OUT-file ]       : output file instead of ', TRIM(cf_out)
-     PRINT '(99a)', ' ', '       [-M MSK-file VAR-mask] : mask file and variable instead of ', TRIM(cn_fmsk), ' and ', TRIM(cv_msk)
-     PRINT '(99a)', ' ', '       [-vvl ]              : time-varying vertical metrics (read from T-file)'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     REQUIRED FILES :'
-     PRINT '(99a)', ' ', '       Files ', TRIM(cn_fhgr), ', ', TRIM(cn_fzgr), ' and ', TRIM(cn_fmsk)
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     OUTPUT : '
-     PRINT '(99a)', ' ', '       Netcdf file : ', TRIM(cf_out), ' with variables heatc3d, heatc2d and heatc3dpervol'
-     PRINT '(99a)', ' ', '       Standard output : heat content per level and total'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     MI355X BUILD :'
-     PRINT '(99a)', ' ', '       By default the level sums are the sequential REAL*4 SUMs of the reference, bit for bit'
-     PRINT '(99a)', ' ', '       (the value a gfortran / flang build of it prints).  CDFT_HEATC_SUM=r8 in the environment'
-     PRINT '(99a)', ' ', '       adds them up in REAL*8 instead: more accurate (the r4 chain is 1e-4 away at eORCA025,'
-     PRINT '(99a)', ' ', '       per cents at eORCA12) and 2.5 times faster (at the memory roofline of the GPU).'
+#include "usage/cdfheatc.inc"
      STOP
   ENDIF
 

@@ -25,27 +25,7 @@ PROGRAM cdfmaxmoc
   CALL ReadCdfNames()
   narg = COMMAND_ARGUMENT_COUNT()
   IF ( narg == 0 ) THEN
-     PRINT '(99a)', ' ', ' usage : cdfmaxmoc -f OVT-file -b BASIN-name -w latmin latmax depmin depmax ...'
-     PRINT '(99a)', ' ', '                 ... [-o OUT-file]'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     PURPOSE :'
-     PRINT '(99a)', ' ', '        Compute the maximum and minimum of the overturning, from OVT-file, for the specified'
-     PRINT '(99a)', ' ', '        oceanic basin, in the window given by a range of latitudes and depths.'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     ARGUMENTS :'
-     PRINT '(99a)', ' ', '        -f OVT-file   : overturning file from cdfmoc, with or w/o sub basins.'
-     PRINT '(99a)', ' ', '        -b BASIN-name : one of atl, glo, inp, ind or pac (glo: no subbasins).'
-     PRINT '(99a)', ' ', '        -w latmin latmax depmin depmax : limits in latitude (deg N) and depth (meters).'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     OPTIONS :'
-     PRINT '(99a)', ' ', '        [-o OUT-file] : output file name instead of ', TRIM(cf_ncout)
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     REQUIRED FILES :'
-     PRINT '(99a)', ' ', '        none'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     OUTPUT : '
-     PRINT '(99a)', ' ', '       netcdf file : ', TRIM(cf_ncout)
-     PRINT '(99a)', ' ', '         6 variables : maxmoc, minmoc (Sv), latmaxmoc, latminmoc (deg), depthmaxmoc, depthminmoc (m)'
+#include "usage/cdfmaxmoc.inc"
      STOP
   ENDIF
 

@@ -45,43 +45,7 @@ PROGRAM cdfmean
   CALL ReadCdfNames()
   narg = COMMAND_ARGUMENT_COUNT()
   IF ( narg == 0 ) THEN
-     PRINT '(99a)', ' ', ' usage : cdfmean -f IN-file -v IN-var -p C-point  ...'
-     PRINT '(99a)', ' ', '       ... [-w imin imax jmin jmax kmin kmax] [-full] [-var] [-zeromean]...'
-     PRINT '(99a)', ' ', '       ... [-M MSK-file VAR-mask ] [-B BASIN-mask LST-basins] [-P OUT-prefix]'
-     PRINT '(99a)', ' ', '       ... [-o OUT-file] [ -ot OUTASCII-file] [-oz ZEROMEAN-file] '
-     PRINT '(99a)', ' ', '       ... [-ov VAR-file] [-os SUM-file][ -vvl ] [-S]'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     PURPOSE :'
-     PRINT '(99a)', ' ', '        Compute the weighted mean value of the field: a horizontal mean for each level and'
-     PRINT '(99a)', ' ', '        the mean over the volume, optionally in a window, with a non standard mask or per'
-     PRINT '(99a)', ' ', '        sub-basin.  MI355X build: the weighted sums run on the GPU.'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     ARGUMENTS :'
-     PRINT '(99a)', ' ', '       -f IN-file : input netcdf file.'
-     PRINT '(99a)', ' ', '       -v IN-var  : name of netcdf variable to work with.'
-     PRINT '(99a)', ' ', '       -p C-point : one of T|U|V|F|W, the position of IN-var on the C-grid.'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     OPTIONS :'
-     PRINT '(99a)', ' ', '       [-w imin imax jmin jmax kmin kmax] : spatial window (0 for a whole direction)'
-     PRINT '(99a)', ' ', '       [-full ] : full steps instead of partial steps.'
-     PRINT '(99a)', ' ', '       [-var ]  : also compute the spatial variance of IN-var.'
-     PRINT '(99a)', ' ', '       [-S ]    : also save the weighted sums.'
-     PRINT '(99a)', ' ', '       [-M MSK-file VAR-mask] : non standard mask file and variable'
-     PRINT '(99a)', ' ', '       [-B BASIN-mask LST-basins] : means for the sub-basins of the blank separated list'
-     PRINT '(99a)', ' ', '       [-P OUT-prefix] : prepended to every output file name.'
-     PRINT '(99a)', ' ', '       [-o OUT-file] [-ot OUTASCII-file] [-ov VAR-file] [-os SUM-file] : output names instead of'
-     PRINT '(99a)', ' ', '              ', TRIM(cf_ncout), ' ', TRIM(cf_out), ' ', TRIM(cf_var), ' ', TRIM(cf_sum)
-     PRINT '(99a)', ' ', '       [-vvl ] : time-varying vertical metrics.'
-     PRINT '(99a)', ' ', '       [-zeromean ] : also write the field minus its 3-D mean (per basin), masked, to ', TRIM(cf_zerom)
-     PRINT '(99a)', ' ', '       [-oz ZEROMEAN-file] : name of that file'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     REQUIRED FILES :'
-     PRINT '(99a)', ' ', '       Files ', TRIM(cn_fhgr), ', ', TRIM(cn_fzgr), ', ', TRIM(cn_fmsk)
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     OUTPUT : '
-     PRINT '(99a)', ' ', '       - netcdf file : ', TRIM(cf_ncout)
-     PRINT '(99a)', ' ', '           variables : mean_<IN-var>, mean_3D_<IN-var> [var_, var_3D with -var] [sum_, sum_3D with -S]'
-     PRINT '(99a)', ' ', '       - ASCII files : ', TRIM(cf_out), ' [', TRIM(cf_var), '] [', TRIM(cf_sum), '], also sent to standard output.'
+#include "usage/cdfmean.inc"
      STOP
   ENDIF
 

@@ -28,6 +28,7 @@ PROGRAM cdfmhst
   CHARACTER(LEN=256) :: cf_outh = 'zonal_heat_trp.dat', cf_outs = 'zonal_salt_trp.dat', cf_outnc = 'mhst.nc'
   CHARACTER(LEN=256) :: cv_zomht = 'zomht', cv_zomst = 'zomst', cldimension, cldum
   CHARACTER(LEN=5)   :: cbasin(6) = (/ '_glo ', '_atl ', '_inp ', '_ind ', '_pac ', '_inp0' /)
+  INTEGER(KIND=4) :: jbasins                               ! (the usage text lists the basins' variables)
   TYPE(variable), ALLOCATABLE :: stypvar(:)
   TYPE(C_PTR) :: plan, pe3v, pe31d, p1, p2, p3, p4, p5
   LOGICAL :: llglo, lchk = .FALSE., lfull = .FALSE., lsepf = .TRUE., lzdim = .FALSE.
@@ -42,35 +43,7 @@ PROGRAM cdfmhst
   CALL ReadCdfNames()
   narg = COMMAND_ARGUMENT_COUNT()
   IF ( narg == 0 ) THEN
-     PRINT '(99a)', ' ', ' usage : cdfmhst  -vt VT-file | (-v V-file -t T-file [-s S-file]) [-MST] [-full] ...'
-     PRINT '(99a)', ' ', '          ... [-Zdim] [-b BASIN-file] [-o OUT-file] [-vtvar VT-var VS-var] [-vvl]'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     PURPOSE :'
-     PRINT '(99a)', ' ', '       Compute the meridional heat transport (and, with -MST, the salt transport) as a function'
-     PRINT '(99a)', ' ', '       of latitude, for the global ocean and for the sub-basins of ', TRIM(cn_fbasins), ' when'
-     PRINT '(99a)', ' ', '       that file exists.  MI355X build: integration and zonal sums run on the GPU.'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     ARGUMENTS :'
-     PRINT '(99a)', ' ', '       -vt VT-file : file with the mean products V.T and V.S (from cdfvT), or'
-     PRINT '(99a)', ' ', '       -v V-file -t T-file [-s S-file] : separate velocity and tracer files.'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     OPTIONS :'
-     PRINT '(99a)', ' ', '       [-MST ]   : also output the meridional salt transport'
-     PRINT '(99a)', ' ', '       [-full ]  : full step'
-     PRINT '(99a)', ' ', '       [-Zdim ]  : output the cumulated transport of every level (variables get a depth axis)'
-     PRINT '(99a)', ' ', '       [-b BASIN-file] : sub-basin mask file instead of ', TRIM(cn_fbasins)
-     PRINT '(99a)', ' ', '       [-vtvar VT-var VS-var] : names of the product variables instead of ', TRIM(cn_vomevt), ' ', TRIM(cn_vomevs)
-     PRINT '(99a)', ' ', '       [-vvl ]   : time-varying vertical metrics'
-     PRINT '(99a)', ' ', '       [-o OUT-file ] : change name of the output file. Default:', TRIM(cf_outnc)
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     REQUIRED FILES :'
-     PRINT '(99a)', ' ', '       ', TRIM(cn_fhgr), ', ', TRIM(cn_fzgr), ' and ', TRIM(cn_fmsk)
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     OUTPUT : '
-     PRINT '(99a)', ' ', '       ASCII files : ', TRIM(cf_outh), ' : Meridional Heat Transport'
-     PRINT '(99a)', ' ', '                     ', TRIM(cf_outs), ' : Meridional Salt Transport'
-     PRINT '(99a)', ' ', '       netcdf file : ', TRIM(cf_outnc), ' unless -o option is used.'
-     PRINT '(99a)', ' ', '         variables : ', TRIM(cv_zomht), '_glo [_atl _inp _ind _pac _inp0], and ', TRIM(cv_zomst), '_* with -MST'
+#include "usage/cdfmhst.inc"
      STOP
   ENDIF
 

@@ -82,51 +82,7 @@ PROGRAM cdfmoc
 
   narg = COMMAND_ARGUMENT_COUNT()
   IF ( narg == 0 ) THEN
-     PRINT '(99a)', ' ', ' usage : cdfmoc  -v V-file  [-decomp] [-rapid] [-t T-file] [-s S-file] ...'
-     PRINT '(99a)', ' ', '                  ... [-u U-file] [-full] [-vvl ] [-o OUT-file] [-teos] '
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     PURPOSE :'
-     PRINT '(99a)', ' ', '       Compute the meridional overturning stream function (MOC) of the global ocean and,'
-     PRINT '(99a)', ' ', '       when the sub-basin file ', TRIM(cn_fbasins), ' is present, of the Atlantic,'
-     PRINT '(99a)', ' ', '       Indo-Pacific, Indian and Pacific basins.  MI355X build: the zonal integration and'
-     PRINT '(99a)', ' ', '       the bottom-to-surface accumulation run on the GPU.'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     ARGUMENTS :'
-     PRINT '(99a)', ' ', '       -v V-file : file with the meridional velocity component (mandatory).'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     OPTIONS :'
-     PRINT '(99a)', ' ', '       [-full ]      : full step instead of the default partial step'
-     PRINT '(99a)', ' ', '       [-vvl  ]      : time-varying vertical metrics (read from V-file)'
-     PRINT '(99a)', ' ', '       [-o OUT-file] : output file instead of ', TRIM(cf_moc)
-     PRINT '(99a)', ' ', '       [-decomp ]    : decompose the MOC in 3 components: geostrophic shear (_sh),'
-     PRINT '(99a)', ' ', '                       barotropic (_bt) and ageostrophic (_ag); needs -t (and -s)'
-     PRINT '(99a)', ' ', '       [-t T-file]   : temperature (and salinity) file, for -decomp'
-     PRINT '(99a)', ' ', '       [-s S-file]   : salinity file if not the T-file'
-     PRINT '(99a)', ' ', '       [-teos10]     : TEOS10 equation of state instead of the default EOS80'
-     PRINT '(99a)', ' ', '       [-rapid ]     : the AMOC at 26.5 N and its components as the RAPID-MOCHA array gives'
-     PRINT '(99a)', ' ', '                       them (output rapid_', TRIM(cf_moc), '); needs -t, (-s) and -u'
-     PRINT '(99a)', ' ', '       [-u U-file]   : file with the zonal wind stress, for the Ekman transport of -rapid'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     REQUIRED FILES :'
-     PRINT '(99a)', ' ', '       ', TRIM(cn_fhgr), ' ', TRIM(cn_fzgr), ' and ', TRIM(cn_fmsk)
-     PRINT '(99a)', ' ', '       ', TRIM(cn_fbasins), ' (optional): without it only the global MOC is computed'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     OPENMP SUPPORT : not needed (GPU) '
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     MI355X BUILD :'
-     PRINT '(99a)', ' ', '       Large files go through the GPU a window of levels at a time, all the records of the run'
-     PRINT '(99a)', ' ', '       in one launch per window (CDFT_MOC_ROUTE=stream, the default; pool: every record resident,'
-     PRINT '(99a)', ' ', '       one launch; record: a launch per record).  CDFT_TIMING=1 reports the route on stderr.'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     OUTPUT : '
-     PRINT '(99a)', ' ', '       netcdf file : ', TRIM(cf_moc)
-     PRINT '(99a)', ' ', '       variables ', TRIM(cn_zomsfglo), ' : Global ocean '
-     PRINT '(99a)', ' ', '       variables ', TRIM(cn_zomsfatl), ' : Atlantic Ocean '
-     PRINT '(99a)', ' ', '       variables ', TRIM(cn_zomsfinp), ' : Indo Pacific '
-     PRINT '(99a)', ' ', '       variables ', TRIM(cn_zomsfind), ' : Indian Ocean alone'
-     PRINT '(99a)', ' ', '       variables ', TRIM(cn_zomsfpac), ' : Pacific Ocean alone'
-     PRINT '(99a)', ' ', '       variables ', TRIM(cn_zomsfinp0), ' : Indo Pacific Net'
-     PRINT '(99a)', ' ', '      '
+#include "usage/cdfmoc.inc"
      STOP
   ENDIF
 

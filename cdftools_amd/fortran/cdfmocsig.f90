@@ -46,43 +46,7 @@ PROGRAM cdfmocsig
   CALL ReadCdfNames()
   narg = COMMAND_ARGUMENT_COUNT()
   IF ( narg == 0 ) THEN
-     PRINT '(99a)', ' ', ' usage : cdfmocsig  -v V-file -t T-file -r REF-depth | -ntr [-s S-file] [-eiv] [-full] ...'
-     PRINT '(99a)', ' ', '         ...  [-sigmin sigmin] [-sigstp sigstp] [-nbins nbins] [-isodep] [-o OUT-file]...'
-     PRINT '(99a)', ' ', '         ...  [-vvl] [-verbose] [-teos10]'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     PURPOSE :'
-     PRINT '(99a)', ' ', '       Compute the MOC in density-latitude coordinates: the meridional transport of each cell is'
-     PRINT '(99a)', ' ', '       binned by its potential density referred to REF-depth and integrated zonally, then'
-     PRINT '(99a)', ' ', '       cumulated from the densest class up.  MI355X build: all of it runs on the GPU.'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     ARGUMENTS :'
-     PRINT '(99a)', ' ', '        -v V-file  : Netcdf gridV file.'
-     PRINT '(99a)', ' ', '        -t T-file  : Netcdf gridT file with temperature and salinity (else -s).'
-     PRINT '(99a)', ' ', '        -r ref-depth : reference depth for density; 0, 1000 and 2000 m have pre-defined classes,'
-     PRINT '(99a)', ' ', '            other depths need -sigmin, -sigstp and -nbins.'
-     PRINT '(99a)', ' ', '        or -ntr : neutral density (McDougall and Jackett, 2005) instead of a reference depth.'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     OPTIONS :'
-     PRINT '(99a)', ' ', '       [-s S-file   ] : salinity file if not T-file.'
-     PRINT '(99a)', ' ', '       [-eiv ] : add the meridional eddy induced velocity.'
-     PRINT '(99a)', ' ', '       [-full       ] : full step instead of partial steps.'
-     PRINT '(99a)', ' ', '       [-sigmin     ] : minimum of density for bining.'
-     PRINT '(99a)', ' ', '       [-sigstp     ] : density step for bining.'
-     PRINT '(99a)', ' ', '       [-nbins      ] : number of density bins.'
-     PRINT '(99a)', ' ', '       [-isodep     ] : also the zonal mean of the isopycnal depths.'
-     PRINT '(99a)', ' ', '       [-o OUT-file ] : output file name instead of ', TRIM(cf_moc)
-     PRINT '(99a)', ' ', '       [-vvl        ] : time-varying vertical metrics.'
-     PRINT '(99a)', ' ', '       [-verbose    ] : more info during execution.'
-     PRINT '(99a)', ' ', '       [-teos10     ] : TEOS10 equation of state instead of default EOS80'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     REQUIRED FILES :'
-     PRINT '(99a)', ' ', '        Files ', TRIM(cn_fzgr), ', ', TRIM(cn_fhgr), ', ', TRIM(cn_fmsk)
-     PRINT '(99a)', ' ', '        File ', TRIM(cn_fbasins), ' is optional [sub basins masks]'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     OUTPUT : '
-     PRINT '(99a)', ' ', '       netcdf file : ', TRIM(cf_moc)
-     PRINT '(99a)', ' ', '       variables ', TRIM(cn_zomsfglo), ' [', TRIM(cn_zomsfatl), ' ', TRIM(cn_zomsfinp), ' ', TRIM(cn_zomsfind), ' ', &
-          &   TRIM(cn_zomsfpac), '] and with -isodep ', TRIM(cn_zoisoglo), ' ...'
+#include "usage/cdfmocsig.inc"
      STOP
   ENDIF
 

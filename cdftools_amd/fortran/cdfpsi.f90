@@ -45,37 +45,7 @@ PROGRAM cdfpsi
   CALL ReadCdfNames()
   narg = COMMAND_ARGUMENT_COUNT()
   IF ( narg == 0 ) THEN
-     PRINT '(99a)', ' ', ' usage : cdfpsi -u U-file -v V-file [-V] [-full ] [-mask ] [-mean] [-nc4] ...'
-     PRINT '(99a)', ' ', '          ... [--ssh-file SSH-file] [-open ] [-ref iref jref ] [-o OUT-file] [-vvl] [-lev]'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     PURPOSE :'
-     PRINT '(99a)', ' ', '       Compute the barotropic stream function (at F points) by integrating the zonal transport'
-     PRINT '(99a)', ' ', '       from south to north (default) or the meridional transport from east to west (-V).'
-     PRINT '(99a)', ' ', '       MI355X build: integration and scans run on the GPU.'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     ARGUMENTS :'
-     PRINT '(99a)', ' ', '       -u U-file  : netcdf file with the zonal velocity.'
-     PRINT '(99a)', ' ', '       -v V-file  : netcdf file with the meridional velocity.'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     OPTIONS :'
-     PRINT '(99a)', ' ', '       [-V ]      : use the meridional component (default: zonal component)'
-     PRINT '(99a)', ' ', '       [-full ]   : full step'
-     PRINT '(99a)', ' ', '       [-mask ]   : mask the output with fmask'
-     PRINT '(99a)', ' ', '       [-mean ]   : average of the U and V estimates'
-     PRINT '(99a)', ' ', '       [-ref iref jref] : point where psi is set to 0 (default: upper right corner)'
-     PRINT '(99a)', ' ', '       [-vvl ]    : time-varying vertical metrics'
-     PRINT '(99a)', ' ', '       [-nc4 ]    : NetCDF-4 output with chunking and deflation (needs the HDF5 plug-in)'
-     PRINT '(99a)', ' ', '       [-o OUT-file] : output file instead of ', TRIM(cf_out)
-     PRINT '(99a)', ' ', '       [-open ]   : open domain: psi is built from the row npjglo-2 (implies both components)'
-     PRINT '(99a)', ' ', '       [--ssh-file SSH-file] : add the contribution of the SSH (2 more variables)'
-     PRINT '(99a)', ' ', '       [-lev ]    : psi of each level instead of the vertical integral (variable vobarstf)'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     REQUIRED FILES :'
-     PRINT '(99a)', ' ', '       ', TRIM(cn_fhgr), ' and ', TRIM(cn_fzgr), ' (', TRIM(cn_fmsk), ' with -mask)'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     OUTPUT : '
-     PRINT '(99a)', ' ', '       netcdf file : ', TRIM(cf_out)
-     PRINT '(99a)', ' ', '         variables : ', TRIM(cv_out), ' (m3/s )'
+#include "usage/cdfpsi.inc"
      STOP
   ENDIF
 

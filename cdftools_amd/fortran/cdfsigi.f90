@@ -28,31 +28,7 @@ PROGRAM cdfsigi
   CALL ReadCdfNames()
   narg = COMMAND_ARGUMENT_COUNT()
   IF ( narg == 0 ) THEN
-     PRINT '(99a)', ' ', ' usage : cdfsigi -t T-file -r REF-dep(m) [-s S-file] [-nc4] ...'
-     PRINT '(99a)', ' ', '              ... [-o OUT-file] [-teos10] '
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     PURPOSE :'
-     PRINT '(99a)', ' ', '       Compute potential density refered to the depth given in argument.  MI355X build: the'
-     PRINT '(99a)', ' ', '       equation of state is evaluated on the GPU.'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     ARGUMENTS :'
-     PRINT '(99a)', ' ', '       -t T-file  : netcdf file with temperature and salinity.'
-     PRINT '(99a)', ' ', '       -r REF-dep : reference depth in meters.'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     OPTIONS :'
-     PRINT '(99a)', ' ', '       [-s S-file ]      : salinity file if it differs from T-file.'
-     PRINT '(99a)', ' ', '       [-nc4]            : NetCDF-4 output with chunking and deflation (needs the HDF5 plug-in)'
-     PRINT '(99a)', ' ', '       [-o OUT-file]     : output file instead of ', TRIM(cf_out)
-     PRINT '(99a)', ' ', '       [-teos10]         : TEOS10 equation of state (CT, SA) instead of EOS80'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     REQUIRED FILES :'
-     PRINT '(99a)', ' ', '       none'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     OPENMP SUPPORT : not needed (GPU) '
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     OUTPUT : '
-     PRINT '(99a)', ' ', '       netcdf file : ', TRIM(cf_out)
-     PRINT '(99a)', ' ', '         variables : ', TRIM(cn_vosigmai), ' ( kg/m3 - 1000 )'
+#include "usage/cdfsigi.inc"
      STOP
   ENDIF
 

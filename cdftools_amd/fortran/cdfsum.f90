@@ -40,39 +40,7 @@ PROGRAM cdfsum
   CALL ReadCdfNames()
   narg = COMMAND_ARGUMENT_COUNT()
   IF ( narg == 0 ) THEN
-     PRINT '(99a)', ' ', ' usage : cdfsum -f IN-file -v IN-var -p C-type [-nowght] [-nomsk]... '
-     PRINT '(99a)', ' ', '          ... [-w imin imax jmin jmax kmin kmax] [-full ] ...'
-     PRINT '(99a)', ' ', '          ... [-o OUT-file] [-nc4] [-M MSK-file VAR-mask ] [-vvl] '
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     PURPOSE :'
-     PRINT '(99a)', ' ', '       Compute the sum value of the field (3D weighted, unless -nowght used), optionally'
-     PRINT '(99a)', ' ', '       limited to a 3D sub-area.  MI355X build: the sums of a record run on the GPU.'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     ARGUMENTS :'
-     PRINT '(99a)', ' ', '       -f IN-file : netcdf input file.'
-     PRINT '(99a)', ' ', '       -v IN-var  : netcdf variable to work with.'
-     PRINT '(99a)', ' ', '       -p C-type  : one of T|U|V|F|W, the C-grid point where IN-var is located.'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     OPTIONS :'
-     PRINT '(99a)', ' ', '       [-w imin imax jmin jmax kmin kmax]: the 3D window (a 0 minimum takes the whole direction)'
-     PRINT '(99a)', ' ', '       [-nowght] : arithmetic sum over the grid points, not the area weighted sum.'
-     PRINT '(99a)', ' ', '       [-nomsk] : do not use a mask file '
-     PRINT '(99a)', ' ', '       [-full ]:  Use full steps instead of default partial steps'
-     PRINT '(99a)', ' ', '       [-vvl  ]:  use time -varying  vertical metrics'
-     PRINT '(99a)', ' ', '       [-o OUT-file ] : name of the output file instead of ', TRIM(cf_out)
-     PRINT '(99a)', ' ', '       [-nc4 ] : NetCDF-4 output with chunking and deflation (needs the HDF5 plug-in)'
-     PRINT '(99a)', ' ', '       [-M MSK-file VAR-mask] : non standard mask file and variable, instead of ', TRIM(cn_fmsk)
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     REQUIRED FILES :'
-     PRINT '(99a)', ' ', '      ', TRIM(cn_fhgr), ', ', TRIM(cn_fzgr), ' and ', TRIM(cn_fmsk), ' (or the -M file).'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     OUTPUT : '
-     PRINT '(99a)', ' ', '       Standard output.'
-     PRINT '(99a)', ' ', '       netcdf file : ', TRIM(cf_out), ' unless modified with -o option. '
-     PRINT '(99a)', ' ', '           variables : sum_<varname> (vertical profile), sum_3D<varname>, sum_3D_t<varname>.'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     SEE ALSO: '
-     PRINT '(99a)', ' ', '       cdfmean '
+#include "usage/cdfsum.inc"
      STOP
   ENDIF
 

@@ -40,26 +40,7 @@ PROGRAM cdfvT
   CALL ReadCdfNames()
   narg = COMMAND_ARGUMENT_COUNT()
   IF ( narg == 0 ) THEN
-     PRINT '(99a)', ' ', ' usage : cdfvT -c CONFIG-CASE -l LST-tags [-o OUT-file ] [-nc4 ] [-vvl]'
-     PRINT '(99a)', ' ', '          ... [-namT TEMP-name] [-namU U-name] [-namV V-name]'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     PURPOSE :'
-     PRINT '(99a)', ' ', '       Compute the time average of the products U.T, U.S, V.T and V.S over the model outputs'
-     PRINT '(99a)', ' ', '       identified by the list of tags.  MI355X build: the products are formed on the GPU.'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     ARGUMENTS :'
-     PRINT '(99a)', ' ', '       -c CONFIG-CASE : configuration and case, e.g. ORCA025-G70'
-     PRINT '(99a)', ' ', '       -l LST-tags    : blank-separated list of time tags; files are CONFIG-CASE_tag_grid[_]{T,U,V,S}.nc'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     OPTIONS :'
-     PRINT '(99a)', ' ', '       [-o OUT-file ] : output file instead of ', TRIM(cf_out)
-     PRINT '(99a)', ' ', '       [-nc4 ]        : NetCDF-4 output with chunking and deflation (needs the HDF5 plug-in)'
-     PRINT '(99a)', ' ', '       [-vvl ]        : time-varying vertical metrics (e3u, e3v read from the U and V files)'
-     PRINT '(99a)', ' ', '       [-namT/-namU/-namV name] : variable names instead of the defaults'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     OUTPUT : '
-     PRINT '(99a)', ' ', '       netcdf file : ', TRIM(cf_out)
-     PRINT '(99a)', ' ', '         variables : ', TRIM(cn_vozout), ', ', TRIM(cn_vozous), ', ', TRIM(cn_vomevt), ' and ', TRIM(cn_vomevs)
+#include "usage/cdfvT.inc"
      STOP
   ENDIF
 

@@ -36,34 +36,7 @@ PROGRAM cdfvertmean
   CALL ReadCdfNames()
   narg = COMMAND_ARGUMENT_COUNT()
   IF ( narg == 0 ) THEN
-     PRINT '(99a)', ' ', ' usage :  cdfvertmean -f IN-file -l LST-var -p C-type -zlim dep1 dep2'
-     PRINT '(99a)', ' ', '              ... [-w imin imax jmin jmax ] '
-     PRINT '(99a)', ' ', '              ... [-full] [-o OUT-file] [-nc4] [-vvl] [-debug]'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     PURPOSE :'
-     PRINT '(99a)', ' ', '       Compute the vertical mean between dep1 and dep2 (m, positive, from top to bottom) of the'
-     PRINT '(99a)', ' ', '       variables of LST-var in the input file.  MI355X build: the integration runs on the GPU.'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     ARGUMENTS :'
-     PRINT '(99a)', ' ', '       -f IN-file  : netcdf input file.'
-     PRINT '(99a)', ' ', '       -l LST-var : comma separated list of input variables to process.'
-     PRINT '(99a)', ' ', '       -p C-type  : one of T U V W, the position of the variables on the C-grid'
-     PRINT '(99a)', ' ', '       -zlim dep1 dep2 : depth limits of the vertical integration'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     OPTIONS :'
-     PRINT '(99a)', ' ', '       [ -w imin imax jmin jmax ] : subarea of the input domain'
-     PRINT '(99a)', ' ', '       [-full  ] : full step configurations (default: partial step).'
-     PRINT '(99a)', ' ', '       [-debug ] : print some extra informations.'
-     PRINT '(99a)', ' ', '       [-vvl ] : time-varying vertical metrics.'
-     PRINT '(99a)', ' ', '       [-o OUT-file ] : output file instead of ', TRIM(cf_out)
-     PRINT '(99a)', ' ', '       [-nc4 ]: NetCDF-4 output with chunking and deflation (needs the HDF5 plug-in)'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     REQUIRED FILES :'
-     PRINT '(99a)', ' ', '       ', TRIM(cn_fzgr), ' and ', TRIM(cn_fmsk)
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     OUTPUT : '
-     PRINT '(99a)', ' ', '       netcdf file : ', TRIM(cf_out)
-     PRINT '(99a)', ' ', '         variables : varin_vert_mean (same units as input variable)'
+#include "usage/cdfvertmean.inc"
      STOP
   ENDIF
 

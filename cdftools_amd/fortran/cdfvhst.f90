@@ -32,27 +32,7 @@ PROGRAM cdfvhst
   CALL ReadCdfNames()
   narg = COMMAND_ARGUMENT_COUNT()
   IF ( narg == 0 ) THEN
-     PRINT '(99a)', ' ', ' usage : cdfvhst  -f VT-file [-full] [-vvl] [-o OUT-file] [-nc4] '
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     PURPOSE :'
-     PRINT '(99a)', ' ', '         Compute the vertically integrated heat and salt transports at each grid cell:'
-     PRINT '(99a)', ' ', '         the vertical integral of the VT-file.  MI355X build: the integration runs on the GPU.'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     ARGUMENTS :'
-     PRINT '(99a)', ' ', '         -f VT-file : file which contains UT, VT, US, VS quantities (produced by cdfvT)'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     OPTIONS :'
-     PRINT '(99a)', ' ', '         [-full ] : full step computation (default is partial steps).'
-     PRINT '(99a)', ' ', '         [-vvl  ] : time-varying vertical metrics.'
-     PRINT '(99a)', ' ', '         [-o OUT-file ] : output file name instead of ', TRIM(cf_out)
-     PRINT '(99a)', ' ', '         [-nc4  ] : NetCDF-4 output with chunking and deflation (needs the HDF5 plug-in)'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     REQUIRED FILES :'
-     PRINT '(99a)', ' ', '         Files ', TRIM(cn_fhgr), ', ', TRIM(cn_fzgr)
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     OUTPUT : '
-     PRINT '(99a)', ' ', '         Netcdf file : ', TRIM(cf_out), ' unless -o option is used.'
-     PRINT '(99a)', ' ', '         Variables : ', TRIM(cn_somevt), ', ', TRIM(cn_somevs), ', ', TRIM(cn_sozout), ' and  ', TRIM(cn_sozous)
+#include "usage/cdfvhst.inc"
      STOP
   ENDIF
 

@@ -40,36 +40,7 @@ PROGRAM cdfvint
   cv_in = cn_votemper
   narg = COMMAND_ARGUMENT_COUNT()
   IF ( narg == 0 ) THEN
-     PRINT '(99a)', ' ', ' usage : cdfvint -f T-file [-v IN-var] [-GSOP] [-OCCI] [-full] [-vvl] ...'
-     PRINT '(99a)', ' ', '              ... [-w imin imax jmin jmax ] ...'
-     PRINT '(99a)', ' ', '              ... [-tmean] [-smean] [-o OUT-file] [-nc4]'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     PURPOSE :'
-     PRINT '(99a)', ' ', '       Compute the vertical integral of the variable from top to bottom and save the cumulated'
-     PRINT '(99a)', ' ', '       values level by level: heat content (10^6 J/m2) for temperature, PSU.m for salinity.'
-     PRINT '(99a)', ' ', '       MI355X build: the integration runs on the GPU.'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     ARGUMENTS :'
-     PRINT '(99a)', ' ', '         -f T-file : gridT file holding either temperature or salinity '
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     OPTIONS :'
-     PRINT '(99a)', ' ', '        [-v IN-var ] : input variable, default ', TRIM(cn_votemper), ', or ', TRIM(cn_vosaline)
-     PRINT '(99a)', ' ', '        [-GSOP] : 7 GSOP standard levels for the output (default: the model levels)'
-     PRINT '(99a)', ' ', '        [-OCCI] : 3 levels for the output: 700m, 2000m and bottom'
-     PRINT '(99a)', ' ', '        [-full] : full step computation '
-     PRINT '(99a)', ' ', '        [-vvl]  : time-varying vertical metrics'
-     PRINT '(99a)', ' ', '        [-w imin imax jmin jmax ] : limit the computation to a subdomain'
-     PRINT '(99a)', ' ', '        [-tmean] : output mean temperature instead of heat content'
-     PRINT '(99a)', ' ', '        [-smean] : output mean salinity instead of PSU.m'
-     PRINT '(99a)', ' ', '        [-o OUT-file] : output file instead of <IN-var>.nc'
-     PRINT '(99a)', ' ', '        [-nc4]  : NetCDF-4 output with chunking and deflation (needs the HDF5 plug-in)'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     REQUIRED FILES :'
-     PRINT '(99a)', ' ', '       ', TRIM(cn_fmsk), ', ', TRIM(cn_fhgr), ' and ', TRIM(cn_fzgr)
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     OUTPUT : '
-     PRINT '(99a)', ' ', '       netcdf file :  VAR-name.nc (or specified with -o option)'
-     PRINT '(99a)', ' ', '         variables :  voheatc or vohsalt, ', TRIM(cn_votemper), ' or ', TRIM(cn_vosaline), ' with -tmean / -smean'
+#include "usage/cdfvint.inc"
      STOP
   ENDIF
 

@@ -36,38 +36,7 @@ PROGRAM cdfvtrp
   CALL ReadCdfNames()
   narg = COMMAND_ARGUMENT_COUNT()
   IF ( narg == 0 ) THEN
-     PRINT '(99a)', ' ', ' usage : cdfvtrp -u U-file -v V-file [-full] [-bathy] [-vvl] ...'
-     PRINT '(99a)', ' ', '               ... [-o OUT-file] [-nc4]'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     PURPOSE :'
-     PRINT '(99a)', ' ', '       Compute the vertically integrated transports at each grid cell.'
-     PRINT '(99a)', ' ', '       MI355X build: the integration runs on the GPU.'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     ARGUMENTS :'
-     PRINT '(99a)', ' ', '       -u U-file : netcdf gridU file'
-     PRINT '(99a)', ' ', '       -v V-file : netcdf gridV file'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     OPTIONS :'
-     PRINT '(99a)', ' ', '       [-full ]  : full step configuration (default is partial steps).'
-     PRINT '(99a)', ' ', '       [-bathy ] : also compute the along slope and cross slope transport components;'
-     PRINT '(99a)', ' ', '                bathymetry is read from ', TRIM(cn_fzgr), ' file.'
-     PRINT '(99a)', ' ', '       [-vvl  ] : time-varying vertical metrics'
-     PRINT '(99a)', ' ', '       [-o OUT-file  ] : output file name instead of ', TRIM(cf_out)
-     PRINT '(99a)', ' ', '       [-nc4 ]     : NetCDF-4 output with chunking and deflation (needs the HDF5 plug-in)'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     REQUIRED FILES :'
-     PRINT '(99a)', ' ', '        ', TRIM(cn_fhgr), ' and ', TRIM(cn_fzgr)
-     PRINT '(99a)', ' ', '        ', TRIM(cn_fmsk), ' is required only with -bathy option.'
-     PRINT '(99a)', ' ', '      '
-     PRINT '(99a)', ' ', '     OUTPUT : '
-     PRINT '(99a)', ' ', '       netcdf file : ', TRIM(cf_out)
-     PRINT '(99a)', ' ', '       variables : '
-     PRINT '(99a)', ' ', '           ', TRIM(cn_sozoutrp), ' : zonal transport.'
-     PRINT '(99a)', ' ', '           ', TRIM(cn_somevtrp), ' : meridional transport.'
-     PRINT '(99a)', ' ', '          If option -bathy is used :'
-     PRINT '(99a)', ' ', '           ', TRIM(cv_soastrp), ' : along slope transport'
-     PRINT '(99a)', ' ', '           ', TRIM(cv_socstrp), ' : cross slope transport'
-     PRINT '(99a)', ' ', '      '
+#include "usage/cdfvtrp.inc"
      STOP
   ENDIF
 

@@ -34,7 +34,7 @@ def main():
     with tempfile.TemporaryDirectory(prefix="cdft_prog_") as d:
         g_, rec_ = nemo_files.make_case(d)
         pc.extra_files(d, g_, rec_)
-        for case in pc.CASES:
+        for case in pc.CASES + pc.USAGE_CASES:
             meta, arrays = pc.run_case(bindir, case, d)
             path = os.path.join(gold, f"prog_{case[0]}.npz")
             missing = [o for o, s in meta["files"].items() if s is None]
@@ -62,7 +62,7 @@ def main():
         print("all equal" if not bad and same else f"{bad} case(s) differ" + ("" if same else "; the list of cases left out differs"))
         raise SystemExit(1 if bad or not same else 0)
     json.dump(skipped, open(spath, "w"), indent=1)
-    print(f"{len(pc.CASES) - len(skipped)} goldens written, {len(skipped)} cases left out ({', '.join(skipped) or 'none'})")
+    print(f"{len(pc.CASES) + len(pc.USAGE_CASES) - len(skipped)} goldens written, {len(skipped)} cases left out ({', '.join(skipped) or 'none'})")
 
 
 if __name__ == "__main__":

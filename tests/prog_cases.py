@@ -103,6 +103,25 @@ CASES = [
 ]
 
 
+# the programs called without an argument: the usage text, the reference's own (src/cdfmoc.f90:130-210 ...), then this build's
+# "MI355X BUILD" lines.  No GPU, no input file: compared on the CPU (tests/test_prog_diff.py::test_usage_texts...)
+USAGE_CASES = [(p + "_usage", p, [], []) for p in
+               ("cdfmoc", "cdfmhst", "cdfvT", "cdfheatc", "cdfpsi", "cdfcurl", "cdfsig0", "cdfsigi", "cdfvhst", "cdfvtrp", "cdfmean", "cdfsum",
+                "cdfzonalsum", "cdfzonalmean", "cdfvint", "cdfvertmean", "cdfmocsig", "cdfmaxmoc")]
+
+
+def fold_like_list_directed_output(text, width=79):
+    """what flang's list-directed PRINT makes of records longer than `width` characters: cut at `width`, the rest on the next line
+    behind one blank (the reference's usage is PRINT *: its own build folds "transport and th / e")"""
+    out = []
+    for ln in text.split("\n"):
+        while len(ln) > width:
+            out.append(ln[:width])
+            ln = " " + ln[width:]
+        out.append(ln)
+    return "\n".join(out)
+
+
 def extra_files(d, g, rec):
     """the files the second-tier cases need beside those of nemo_files.make_case: a mixed-layer depth and a sea-surface height"""
     import nemo_files

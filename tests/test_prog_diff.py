@@ -170,6 +170,22 @@ def test_programs_against_the_reference_programs(tmp_path):
     assert not unexplained, "\n".join(unexplained[:60])
 
 
+@pytest.mark.parametrize("case", pc.USAGE_CASES, ids=[c[0] for c in pc.USAGE_CASES])
+def test_usage_texts_are_the_reference_programs(case):
+    """A program called without an argument prints the reference program's usage text (tests/golden/prog_<program>_usage.npz:
+    the stdout of the reference's own binary), then this build's "MI355X BUILD" lines; exit status 0.  This build writes every
+    line whole (PRINT '(99a)'); the reference's PRINT * under flang cuts records at column 79, so the golden is compared with
+    this build's text cut the same way.  CPU: no device is touched before the usage."""
+    ref, _ = pc.load_golden(os.path.join(GOLD, f"prog_{case[0]}.npz"))
+    p = subprocess.run([case[1]], executable=os.path.join(BIN, case[1]), capture_output=True, text=True, timeout=120)
+    assert p.returncode == ref["rc"] == 0
+    ours = p.stdout.rstrip("\n").split("\n")
+    k = next(i for i, ln in enumerate(ours) if "MI355X BUILD :" in ln)
+    assert k >= 2 and len(ours) > k + 1 and not ours[k - 1].strip()                 # a blank line, the heading, at least one line
+    assert all(ln.startswith("  ") for ln in ours if ln.strip())                   # nothing folded in this build's output
+    assert pc.fold_like_list_directed_output("\n".join(ours[:k - 1])) == ref["stdout"].rstrip("\n")
+
+
 def test_goldens_are_there_for_every_case():
     out_of_it = pc.left_out()
     assert set(out_of_it) <= {c[0] for c in pc.CASES} and len(out_of_it) <= 4
