@@ -75,6 +75,12 @@ while time.time() < stop:
         plan.stage(zv if rng.random() < 0.5 else torch.from_numpy(zv).cuda())
         got_pool = plan.compute_staged(np.zeros(got.shape))
         desc_pool = plan.describe()
+        # ... and read a window of levels per launch (the cdfmoc program's stream route): the same bits, NaNs included
+        nlev = int(rng.integers(1, npk + 1))
+        got_win = plan.compute_staged_windows(nlev, np.zeros(got.shape))
+        if not np.array_equal(got_win, got_pool, equal_nan=True):
+            print(f"FAIL seed={seed} case={n} npi={npi} npj={npj} npk={npk} npt={npt} nb={nb} windows of {nlev} levels differ from one launch\n  {desc_pool}", flush=True)
+            sys.exit(1)
     except CdftError:                                          # (the tuned shape may not cover a pool row either)
         pass
     plan.close()
