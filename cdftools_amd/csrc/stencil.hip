@@ -188,6 +188,7 @@ struct CurlArgs {
     const double *ff;                         // (npi,npj) or null
     int npi, npj, nlev, ntx, lperio;
     int band;                                 // curl_tile_kernel: rows of a band (0: the whole eighth of an XCD), see there
+    int fast;                                 // curl_tile_kernel: the branch-free level loop for inner tiles (CDFT_CURL_FAST=0: A/B hook)
     void *out;                                // (npi,npj,nlev) r8 or r4
     float *work;                              // F-point curl for the T-point pass: the r4 value the reference widens into dl_rotn (:282), widened when read
     uint8_t *fmk;                             // ... and its fmask (0 / 1), so that the T-point pass does not form it again from u and v
@@ -335,7 +336,9 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6
     const int64_t nij = (int64_t)a.npi * a.npj;
     {
         const int lev0 = (int)((int64_t)chunk * a.nlev / lc), lev1 = (int)((int64_t)(chunk + 1) * a.nlev / lc);
+#define CURL_TILE_FAST 1
 #include "curl_tile_body.inc"
+#undef CURL_TILE_FAST
     }
 }
 
@@ -639,7 +642,7 @@ int cdft_curl_compute(cdft_curl_plan *p, const float *un, const float *vn, int n
     CurlArgs a;
     a.un = (const float *)du; a.vn = (const float *)dv; a.e1u = p->e1u; a.e2v = p->e2v; a.e1f = p->e1f; a.e2f = p->e2f; a.den = p->den;
     a.ff = p->ff; a.npi = p->npi; a.npj = p->npj; a.nlev = nlev;
-    a.lperio = p->lperio; a.out = dout; a.work = nullptr; a.fmk = nullptr; a.band = 0;
+    a.lperio = p->lperio; a.out = dout; a.work = nullptr; a.fmk = nullptr; a.band = 0; a.fast = 1;
     if (ltpoint) {
         CDFT_TRY(p->work.reserve(n3 * 5));
         a.work = (float *)p->work.ptr;
@@ -667,6 +670,7 @@ int cdft_curl_compute(cdft_curl_plan *p, const float *un, const float *vn, int n
         // CDFT_CURL_BAND (0: off) and CDFT_CURL_CHUNKS are A/B hooks.
         const int rows_x = (p->npj + 7) / 8;
         a.band = rows_x >= 128 ? 128 : 0;
+        { const char *ef = getenv("CDFT_CURL_FAST"); a.fast = (ef && ef[0] == '0') ? 0 : 1; }
         if (const char *eb = getenv("CDFT_CURL_BAND")) a.band = std::max(0, atoi(eb));
         int lc = curl_level_chunks(tiles, nlev, res);
         if (a.band > 0) {
