@@ -117,6 +117,31 @@ def test_hip_curl_equals_oracle_bitwise(gpu, monkeypatch, kernel, npi, npj, nlev
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fast", ["0", "1"])
+@pytest.mark.parametrize("npi,npj,nlev", [(4322, 12, 5), (1442, 9, 4), (70, 37, 7), (1025, 9, 3), (2900, 6, 2), (2049, 5, 1), (9, 4, 3), (7, 3, 2)])
+def test_hip_curl_inner_tile_loop(gpu, monkeypatch, fast, npi, npj, nlev):
+    """The branch-free level loop of curl_tile_kernel's inner tiles (every lane reads whole vectors at clamped addresses, the east
+    neighbour as one more word; on by itself from three tiles per row, CDFT_CURL_FAST forces it on or off): rows of one to five tiles,
+    an odd and an even number of levels, one level; r4 results and (the other loop) r8, -T, -overf.  Bitwise against the oracle."""
+    monkeypatch.setenv("CDFT_CURL_FAST", fast)
+    g = synth.make_grid(npi, npj, max(nlev, 2), seed=npi + 11)
+    u, v, _, _, _, _ = frames(g, 1, seed=38)
+    un, vn = u[0, :nlev], v[0, :nlev]
+    ff = (2 * (2 * np.pi / 86400.0) * np.sin(g["gphif"].astype(np.float64) * np.pi / 180.0))
+    plan = gpu.CurlPlan(npi, npj)
+    for lperio, ltpoint, use_ff in ((False, False, False), (True, False, False), (True, True, False), (False, False, True)):
+        plan.set_mesh(g["e1u"], g["e2v"], g["e1f"], g["e2f"], ff=ff if use_ff else None, lperio=lperio)
+        ref = np.stack([oracle_tools.curl(un[k], vn[k], g["e1u"], g["e2v"], g["e1f"], g["e2f"], lperio, ltpoint, ff=ff if use_ff else None)
+                        for k in range(nlev)])
+        got = plan.compute(un, vn, ltpoint=ltpoint)
+        assert np.array_equal(got, ref), (lperio, ltpoint, use_ff)
+        if not ltpoint:
+            import torch
+            d = plan.compute(torch.from_numpy(un).cuda(), torch.from_numpy(vn).cuda(), ltpoint=False, out_r8=False)
+            assert np.array_equal(d.cpu().numpy(), ref.astype(np.float32)), (lperio, use_ff)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("percu", [0, 1, 3])
 @pytest.mark.parametrize("npi,npj,nlev", [(70, 37, 7), (1025, 9, 3), (24, 8, 2), (4322, 70, 5), (1442, 300, 4)])
 def test_hip_curl_persistent_order(gpu, monkeypatch, percu, npi, npj, nlev):
