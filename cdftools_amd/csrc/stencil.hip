@@ -642,7 +642,7 @@ int cdft_curl_compute(cdft_curl_plan *p, const float *un, const float *vn, int n
     CurlArgs a;
     a.un = (const float *)du; a.vn = (const float *)dv; a.e1u = p->e1u; a.e2v = p->e2v; a.e1f = p->e1f; a.e2f = p->e2f; a.den = p->den;
     a.ff = p->ff; a.npi = p->npi; a.npj = p->npj; a.nlev = nlev;
-    a.lperio = p->lperio; a.out = dout; a.work = nullptr; a.fmk = nullptr; a.band = 0; a.fast = 2;
+    a.lperio = p->lperio; a.out = dout; a.work = nullptr; a.fmk = nullptr; a.band = 0; a.fast = 1;
     if (ltpoint) {
         CDFT_TRY(p->work.reserve(n3 * 5));
         a.work = (float *)p->work.ptr;
@@ -672,7 +672,7 @@ int cdft_curl_compute(cdft_curl_plan *p, const float *un, const float *vn, int n
         a.band = rows_x >= 128 ? 128 : 0;
         // the branch-free level loop of the inner tiles: 2.72 against 2.82-2.91 ms at eORCA12 (five tiles of six), nothing at
         // eORCA025 where one tile of two is inner (0.332 against 0.327 ms): on from three tiles per row (CDFT_CURL_FAST=0 / 1: A/B hook)
-        { const char *ef = getenv("CDFT_CURL_FAST"); a.fast = ef ? atoi(ef) : 2; }      // 0: off, 1: inner tiles only, 2: every tile (A/B hook)
+        { const char *ef = getenv("CDFT_CURL_FAST"); a.fast = ef ? (ef[0] == '0' ? 0 : 1) : (sh.ntx >= 3 ? 1 : 0); }
         if (const char *eb = getenv("CDFT_CURL_BAND")) a.band = std::max(0, atoi(eb));
         int lc = curl_level_chunks(tiles, nlev, res);
         if (a.band > 0) {
