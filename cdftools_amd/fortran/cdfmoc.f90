@@ -16,7 +16,7 @@ PROGRAM cdfmoc
   !! Host feed (module cdffeed): on one device, without -decomp / -full, nothing 3-D is held in host memory -- the metric,
   !! its mask and every velocity record go from the file to HBM slab by slab through a page-locked ring, the copy of one
   !! slab under the read of the next, so a record costs its read, not its read plus its transfer (CDFT_FEED=0: the old way).
-  !! With the feed on (and no -vvl) nothing 3-D is held in HBM either: the STREAM route (run_stream below) takes the domain
+  !! With the feed on nothing 3-D is held in HBM either (-vvl: a window holds the metric and the velocity of one record): the STREAM route (run_stream below) takes the domain
   !! through HBM a window of levels at a time -- the window's e3v, vmask and the same levels of EVERY record of the run, each
   !! (jj,jk) row's metric and records in one run -- and one launch per window streams all the records past the row's weights:
   !! every byte read from the files is read from HBM once, 4*(1+1/npt) bytes per cell and record as on bench.py's resident
@@ -164,7 +164,8 @@ PROGRAM cdfmoc
   croute = 'stream'
   CALL GET_ENVIRONMENT_VARIABLE('CDFT_MOC_ROUTE', cldum)
   IF ( LEN_TRIM(cldum) > 0 ) croute = cldum(1:16)
-  IF ( lfeed .AND. .NOT. lg_vvl .AND. croute /= 'record' ) THEN
+  IF ( lg_vvl .AND. croute == 'pool' ) croute = 'stream'     ! (a pool holds ONE set of weights: with -vvl every record has its own)
+  IF ( lfeed .AND. croute /= 'record' ) THEN
      CALL hip_check(cdft_mem_info(ifree, itotal), 'cdft_mem_info')
      dl_field = 4.d0 * ( ( npiglo + 3 ) / 4 * 4 ) * REAL(npjglo, 8) * npk
      IF ( croute == 'pool' ) THEN                          ! every record of a batch resident: (1 + nbatch) fields + weights + mesh
@@ -178,6 +179,7 @@ PROGRAM cdfmoc
         READ(cldum, *) nbatch ; nbatch = MIN(npt, nbatch)
      ENDIF
      nbatch = MAX(1, nbatch)
+     IF ( lg_vvl ) nbatch = 1                             ! the metric changes with every record: a window holds e3v and v of ONE
      IF ( croute /= 'pool' ) THEN
         ! ... and as many levels per window as 4 GB hold: a launch on 2 levels of eORCA12 is 7 000 workgroups, under five rounds
         ! of what the chip holds at once (0.65 of the HBM peak, profiles/r05), on 5 levels twelve rounds; more HBM than that
@@ -423,7 +425,7 @@ CONTAINS
        DO ik0 = 1, npk - 1, nlevw                           ! levels 1 .. npk-1, as the reference reads them (:355)
           inl = MIN(nlevw, npk - ik0)
           CALL feed_moc_window_mask(cn_fmsk, cn_vmask, plan, npiglo, npjglo, ik0, inl)
-          CALL feed_moc_window(cn_fe3v, cn_ve3v, plan, 0, npiglo, npjglo, ik0, inl, ktime=1, ldiom=.TRUE.)
+          CALL feed_moc_window(cn_fe3v, cn_ve3v, plan, 0, npiglo, npjglo, ik0, inl, ktime=MERGE(it0, 1, lg_vvl), ldiom=.NOT. lg_vvl)
           DO jr = 1, nrec
              CALL feed_moc_window(cf_vfil, cn_vomecrty, plan, jr, npiglo, npjglo, ik0, inl, ktime=it0 + jr - 1)
           END DO

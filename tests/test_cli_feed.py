@@ -35,7 +35,7 @@ RUNS = [
     # other r8 additions along i than the dense records of the pageable route, within 1 ulp(r4) in the file:
     # tests/test_moc_pool_feed.py)
     ("cdfmoc", ["-v", V], ["moc.nc"], {"CDFT_MOC_ROUTE": "record"}),
-    ("cdfmoc", ["-v", "VVL_y0001_gridV.nc", "-vvl"], ["moc.nc"]),
+    ("cdfmoc", ["-v", "VVL_y0001_gridV.nc", "-vvl"], ["moc.nc"], {"CDFT_MOC_ROUTE": "record"}),
     ("cdfheatc", ["-f", T], ["heatc.nc"]),
     ("cdfheatc", ["-f", T, "-full"], ["heatc.nc"]),
     ("cdfheatc", ["-f", "VVL_y0001_gridT.nc", "-vvl"], ["heatc.nc"]),

@@ -212,6 +212,28 @@ def test_the_program_runs_one_launch_on_the_pool_and_writes_the_reference_progra
 
 
 @pytest.mark.gpu
+def test_the_program_with_vvl_streams_a_window_per_record(tools, tmp_path):  # noqa: F811
+    """cdfmoc -vvl with the feed: the metric changes with every record, so a window holds the e3v and the velocity of ONE record
+    (a launch per record and window, layout=pool, no 3-D array resident); moc.nc held to the reference program's own -vvl run
+    (tests/golden/prog_cdfmoc_vvl.npz) by the differential's comparison, and equal to the record-by-record route within 1 ulp(r4)"""
+    d = str(tmp_path)
+    g_, rec_ = nemo_files.make_case(d)
+    pc.extra_files(d, g_, rec_)
+    case = next(c for c in pc.CASES if c[0] == "cdfmoc_vvl")
+    ref, ref_arr = pc.load_golden(os.path.join(GOLD, "prog_cdfmoc_vvl.npz"))
+    got, got_arr = pc.run_case(BIN, case, d, env={"CDFT_FEED": "1"})
+    bad = [x for x in diff_case(case, ref, ref_arr, got, got_arr) if not explained(case[0], x[0], x[1])]
+    assert not bad, bad[:10]
+    npt = rec_["v"].shape[0]
+    rc, out, err = run("cdfmoc", case[2], d, env={"CDFT_FEED": "1", "CDFT_TIMING": "1", "CDFT_MOC_WINDOW": "4"})
+    desc, launches, records = _plan_line(err)
+    assert rc == 0 and "layout=pool" in desc and launches == records == npt * 2, err[-400:]      # 6 levels: windows of 4 + 2, per record
+    rc, out, err = run("cdfmoc", case[2], d, env={"CDFT_FEED": "1", "CDFT_TIMING": "1", "CDFT_MOC_ROUTE": "pool"})   # (no pool with -vvl: the stream)
+    desc, launches, records = _plan_line(err)
+    assert rc == 0 and "layout=pool" in desc and launches == records == npt
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("ring", [{}, {"CDFT_FEED_MB": "0.0001", "CDFT_FEED_SLOTS": "2"}, {"CDFT_FEED_ROWS": "2d"}],
                          ids=["default_ring", "one_plane_two_slots", "pitched_copies"])
 def test_the_program_in_batches_of_records(tools, tmp_path, ring):  # noqa: F811
