@@ -4,7 +4,7 @@
 Build container only (needs /root/reference): `make -C oracle refprog` compiles the unmodified reference sources into
 oracle/_ref/prog/ over this repository's NetCDF layer (oracle/ref_prog_build.sh says what that is worth: a differential of
 the program level -- option parsers, CreateOutput, cdfio's packing and headers, stdout -- not a parity pin), this script runs
-the sixteen cases of tests/prog_cases.py and stores exit status, stdout, and every output file's dimensions, variables,
+the cases of tests/prog_cases.py and stores exit status, stdout, and every output file's dimensions, variables,
 attributes (in file order) and data.  Only inputs' seeds and the programs' OUTPUTS are committed; no reference text.
 
     python3 tests/make_golden_prog.py            (re)write the goldens

@@ -98,8 +98,11 @@ CASES = [
     ("cdfmocsig_ntr_isodep", "cdfmocsig", ["-v", "SYN_y0001_gridV.nc", "-t", "SYN_y0001_gridT.nc", "-ntr", "-isodep"], ["mocsig.nc"]),
     ("cdfmocsig_ntr", "cdfmocsig", ["-v", "SYN_y0001_gridV.nc", "-t", "SYN_y0001_gridT.nc", "-ntr", "-sigmin", "19", "-sigstp", "0.25", "-nbins", "60",
                        "-o", "ntr.nc"], ["ntr.nc"]),
-    ("cdfmaxmoc_atl", "cdfmaxmoc", ["-f", "moc.nc", "-b", "atl", "-w", "-30", "60", "-5000", "-20"], ["maxmoc.nc"]),
-    ("cdfmaxmoc_glo_other_window", "cdfmaxmoc", ["-f", "moc.nc", "-b", "glo", "-w", "-60", "20", "-3000", "-100", "-o", "maxmoc2.nc"], ["maxmoc2.nc"]),
+    # (depths of the window as the reference takes them: positive, metres -- it flips the sign of depthw when it reads moc.nc
+    # (src/cdfmaxmoc.f90:123) and a window of negative depths leaves its ikmin / ikmax without a value: that, not the compiler, was
+    # the segmentation fault that kept these two cases out of the differential in round 4)
+    ("cdfmaxmoc_atl", "cdfmaxmoc", ["-f", "moc.nc", "-b", "atl", "-w", "-30", "60", "20", "5000"], ["maxmoc.nc"]),
+    ("cdfmaxmoc_glo_other_window", "cdfmaxmoc", ["-f", "moc.nc", "-b", "glo", "-w", "-60", "20", "100", "3000", "-o", "maxmoc2.nc"], ["maxmoc2.nc"]),
 ]
 
 

@@ -23,7 +23,7 @@ T, U, V = "SYN_y0001_gridT.nc", "SYN_y0001_gridU.nc", "SYN_y0001_gridV.nc"
 RUNS = [
     ("cdfmoc", ["-v", V]),
     ("cdfmoc", ["-v", V, "-t", T, "-decomp", "-o", "dec.nc"]),
-    ("cdfmaxmoc", ["-f", "moc.nc", "-b", "atl", "-w", "-30", "60", "-5000", "-20"]),
+    ("cdfmaxmoc", ["-f", "moc.nc", "-b", "atl", "-w", "-30", "60", "20", "5000"]),
     ("cdfheatc", ["-f", T]),
     ("cdfsig0", ["-t", T]),
     ("cdfsigi", ["-t", T, "-r", "2000", "-nc4", "-o", "sigi4.nc"]),
