@@ -170,8 +170,16 @@ def test_programs_against_the_reference_programs(tmp_path):
     assert not unexplained, "\n".join(unexplained[:60])
 
 
+@pytest.fixture(scope="module")
+def programs_built():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "cdftools_amd", "netcdf")], stdout=subprocess.DEVNULL)
+    if not os.path.exists(os.path.join(ROOT, "cdftools_amd", "lib", "libcdftools_hip.so")):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "cdftools_amd", "csrc"), "-j8"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "cdftools_amd", "fortran")], stdout=subprocess.DEVNULL)
+
+
 @pytest.mark.parametrize("case", pc.USAGE_CASES, ids=[c[0] for c in pc.USAGE_CASES])
-def test_usage_texts_are_the_reference_programs(case):
+def test_usage_texts_are_the_reference_programs(programs_built, case):
     """A program called without an argument prints the reference program's usage text (tests/golden/prog_<program>_usage.npz:
     the stdout of the reference's own binary), then this build's "MI355X BUILD" lines; exit status 0.  This build writes every
     line whole (PRINT '(99a)'); the reference's PRINT * under flang cuts records at column 79, so the golden is compared with
