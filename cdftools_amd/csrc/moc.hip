@@ -289,6 +289,67 @@ __global__ void __launch_bounds__(256) dec_shear_all_kernel(const double *__rest
     dvbt_out[p] = dvbt;
 }
 
+// The same walk with the stencil's neighbours taken from the neighbouring LANES instead of loaded (round 5).  In the kernel
+// above a cell and level is 18 vector memory instructions -- six r8 and six byte loads of the neighbours' density and tmask,
+// four byte loads of umask, e3v, the store -- for 18 algorithmic bytes: the address units bound it (requesting a level ahead
+// changed nothing, profiles/r05).  Here a lane loads sigma and tmask of ITS column on rows jj and jj+1 and umask there, forms
+// the two r4 values REAL(sig8 * itmask) (:443) and hands them and its umask bytes east and west through the lanes: 8 memory
+// instructions.  A wave covers 62 columns; its lanes 0 and 63 stand on the columns next to them and only give.  Every
+// statement on a cell is the one above, in its order.
+constexpr int kShearCols = 62;
+__global__ void __launch_bounds__(256) dec_shear_share_kernel(const double *__restrict__ sig8, const uint8_t *__restrict__ tm,
+                                                              const uint8_t *__restrict__ um, const float *__restrict__ e1u,
+                                                              const float *__restrict__ zcoef, const uint8_t *__restrict__ bits,
+                                                              const float *__restrict__ e3v, const float *__restrict__ zvlast, int npi, int npj,
+                                                              int npk, double *__restrict__ dvgeo_out, float *__restrict__ zvgeo,
+                                                              double *__restrict__ dvbt_out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int jj = blockIdx.y;
+    const int c0 = (blockIdx.x * 4 + wave) * kShearCols;           // the wave's first column
+    if (c0 >= npi) return;                                           // (whole wave: the lanes only talk inside a wave)
+    const int ji = c0 - 1 + lane;                                    // this lane's column; lanes 0 and 63: the neighbours'
+    const int jic = min(max(ji, 0), npi - 1);                        // (an address inside the row for the lanes that stand outside it)
+    const bool owns = lane >= 1 && lane <= kShearCols && ji < npi;   // the lane writes its column
+    const bool rowin = jj >= 1 && jj < npj - 1;                      // (uniform) the row has cells of the stencil
+    const bool inner = rowin && ji >= 1 && ji < npi - 1;
+    const int64_t nij = (int64_t)npi * npj, p = (int64_t)jj * npi + jic, pn = rowin ? p + npi : p;
+    const float zl = zvlast[p];
+    float e_nw = 1.f, e_n = 1.f, e_w = 1.f, e_c = 1.f;
+    double coef = 0.0, bit0 = 0.0;
+    if (inner) { e_nw = e1u[pn - 1]; e_n = e1u[pn]; e_w = e1u[p - 1]; e_c = e1u[p]; coef = (double)zcoef[p]; bit0 = (double)(bits[p] & 1u); }
+    double dvgeo = 0.0, dvbt = 0.0;
+    for (int jk = npk - 2; jk >= 0; --jk) {
+        const int64_t o = (int64_t)jk * nij;
+        const float e3 = e3v[o + p];
+        float zv = zl;
+        if (rowin) {                                                 // (uniform: every lane of the block takes it, the lanes talk)
+            const float zc = (float)__dmul_rn(sig8[o + p], (double)tm[o + p]);       // :443, this column on row jj ...
+            const float zn = (float)__dmul_rn(sig8[o + pn], (double)tm[o + pn]);     // ... and on row jj+1
+            const int uc = (int)um[o + p], un = (int)um[o + pn];
+            const float zc_w = __shfl_up(zc, 1), zc_e = __shfl_down(zc, 1), zn_w = __shfl_up(zn, 1), zn_e = __shfl_down(zn, 1);
+            const int uc_w = __shfl_up(uc, 1), un_w = __shfl_up(un, 1);
+            if (inner) {
+                const int isum = max(1, un_w + un + uc_w + uc);
+                const float zmsv = __fdiv_rn(1.f, (float)isum);                                      // :449
+                float g = __fdiv_rn(__fmul_rn(__fsub_rn(zn, zn_w), (float)un_w), e_nw);
+                g = __fadd_rn(g, __fdiv_rn(__fmul_rn(__fsub_rn(zn_e, zn), (float)un), e_n));
+                g = __fadd_rn(g, __fdiv_rn(__fmul_rn(__fsub_rn(zc, zc_w), (float)uc_w), e_w));
+                g = __fadd_rn(g, __fdiv_rn(__fmul_rn(__fsub_rn(zc_e, zc), (float)uc), e_c));       // :450-453
+                double inc = __dmul_rn(coef, (double)g);
+                inc = __dmul_rn(inc, (double)zmsv);
+                inc = __dmul_rn(inc, bit0);                                                          // ibmask(npglo,ji,jj)
+                inc = __dmul_rn(inc, (double)e3);
+                const double old = dvgeo, now = __dadd_rn(old, inc);                                 // :457
+                dvgeo = now;
+                zv = (float)__dmul_rn(0.5, __dadd_rn(now, old));                                     // :459
+            }
+        }
+        if (owns) zvgeo[o + p] = zv;
+        dvbt = __dadd_rn(dvbt, (double)__fmul_rn(e3, zv));                                           // :466
+    }
+    if (owns) { dvgeo_out[p] = dvgeo; dvbt_out[p] = dvbt; }
+}
+
 // :416-419, :505-516 per (basin,jj) column: cumulated sums of the barotropic and shear parts and the
 // ageostrophic remainder.  sh is IN/OUT (the reference accumulates onto what the array holds, :471).
 __global__ void dec_finish_kernel(const double *__restrict__ tot, const double *__restrict__ raw_bt,
@@ -1148,9 +1209,15 @@ int cdft_moc_decomp(cdft_moc_plan *p, const float *zv, const float *ztemp, const
         }
         CDFT_TRY(cdft_eos_sigmai2d((const float *)dt, (const float *)ds, (const float *)p->d_pref3d.ptr, nlow, eos, 0, sig8,
                                    CDFT_MEM_DEVICE, CDFT_MEM_DEVICE, stream));
-        hipLaunchKernelGGL(dec_shear_all_kernel, dim3((unsigned)((npi + 255) / 256), (unsigned)npj), dim3(256), 0, st, sig8, tm, um,
-                           (const float *)p->d_e1u.ptr, (const float *)p->d_zcoef.ptr, p->bits, e3v, fzv + (int64_t)(npk - 2) * nij, npi, npj,
-                           npk, dvgeo, zvgeo, dvbt);
+        const char *esh = getenv("CDFT_DEC_SHEAR");                  // A/B hook: "load" = every neighbour loaded (the round-4 kernel)
+        if (esh && esh[0] == 'l')
+            hipLaunchKernelGGL(dec_shear_all_kernel, dim3((unsigned)((npi + 255) / 256), (unsigned)npj), dim3(256), 0, st, sig8, tm, um,
+                               (const float *)p->d_e1u.ptr, (const float *)p->d_zcoef.ptr, p->bits, e3v, fzv + (int64_t)(npk - 2) * nij, npi, npj,
+                               npk, dvgeo, zvgeo, dvbt);
+        else
+            hipLaunchKernelGGL(dec_shear_share_kernel, dim3((unsigned)((npi + 4 * kShearCols - 1) / (4 * kShearCols)), (unsigned)npj), dim3(256), 0, st,
+                               sig8, tm, um, (const float *)p->d_e1u.ptr, (const float *)p->d_zcoef.ptr, p->bits, e3v,
+                               fzv + (int64_t)(npk - 2) * nij, npi, npj, npk, dvgeo, zvgeo, dvbt);
         CDFT_LAUNCH_CHECK();
     } else
     for (int jk = npk - 2; jk >= 0; --jk) {

@@ -92,3 +92,19 @@ def test_bench_tools_leg(gpu):
     for e in out:
         assert e["grid"] == "eorca025" and e["ms"] > 0 and e["alg_bytes"] > 0 and 0 < e["frac"] < 1, e
         assert abs(e["frac"] - e["alg_bytes"] / (e["ms"] * 1e-3) / 8e12) < 2e-4 * max(1.0, e["frac"]) + 1e-4, e
+
+
+@pytest.mark.gpu
+def test_headline_meets_the_north_star_target(gpu):
+    """BASELINE.json's target, as a test: cdfmoc on the synthetic eORCA12 75-level 12-record dataset at 1 GPU at >= 70 % of the HBM
+    roofline (ten fresh leases of round 4 and five of round 5 read 0.83-0.86), the pool read in the program's windows of levels
+    within a few per cent of it, the same sums, and the line's own consistency (kernel time <= step time, fraction = bytes / time / peak)."""
+    r = run_bench(["--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-inprocess", "--no-tools"])
+    rf = r["roofline"]
+    assert r["config"]["workload"].startswith("cdfmoc eorca12 4322x3606x75, 12 records") and r["n_gpus"] == 1
+    assert rf["frac"] >= 0.70, rf["frac"]
+    assert abs(rf["frac"] - rf["algorithmic_bytes_per_launch"] / (rf["avg_launch_ms"] * 1e-3) / 8e12) < 1e-9
+    assert rf["avg_launch_ms"] <= r["ms_per_step"] and rf["launches"] == 20
+    lw = rf["level_windows"]
+    assert lw["frac"] >= 0.65 and lw["frac"] <= rf["frac"] * 1.02 and lw["max_abs_diff_Sv_vs_one_launch"] == 0.0
+    assert rf["dense_arrays"]["frac"] >= 0.65 and rf["dense_arrays"]["max_abs_diff_Sv_vs_staged"] < 1e-9
