@@ -196,72 +196,6 @@ __global__ void __launch_bounds__(256) dec_zonal_r8_kernel(const float *__restri
     }
 }
 
-// The same sums with a workgroup per ROW jj for all its levels (round 5): the r8 field and the basin bits of the row do not depend
-// on the level -- they come from L1 / L2 after the first -- and a lane takes four cells at a time with 16-byte loads of the
-// weight: one vector memory instruction per cell instead of three, 90 000 launches of 6 KB of work fewer (0.31 -> ms at
-// eORCA025).  The r8 additions along i are regrouped again (a lane's four cells of each 1024, then the lanes, then
-// the waves, all in a fixed order): the stated 1e-13 * sum|terms| of these sums.
-template <int NB>
-__global__ void __launch_bounds__(256) dec_zonal_r8_rows_kernel(const float *__restrict__ w, const uint8_t *__restrict__ bits,
-                                                                 const double *__restrict__ field, int npi, int npj, int npk,
-                                                                 int nb, double *__restrict__ raw, int64_t w_row, int lch) {
-    typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
-    typedef uint32_t u32u __attribute__((aligned(1)));
-    __shared__ double scratch[2][NB][4];
-    const int jj = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t r2 = (int64_t)jj * npi;
-    const int k0 = blockIdx.y * lch, k1 = min(npk - 1, k0 + lch);  // this workgroup's levels (the grid's y cuts them into chunks of lch)
-    for (int jk = k0; jk < k1; ++jk) {
-        const int64_t r3 = ((int64_t)jk * npj + jj) * w_row;
-        double acc[NB];
-#pragma unroll
-        for (int b = 0; b < NB; ++b) acc[b] = 0.0;
-        for (int i0 = 4 * (int)threadIdx.x; i0 < npi; i0 += 1024) {
-            float wv[4];
-            double fv[4];
-            uint32_t bv;
-            if (i0 + 4 <= npi) {
-                const f4u q = ld_stream4u(w + r3 + i0);
-                wv[0] = q.x; wv[1] = q.y; wv[2] = q.z; wv[3] = q.w;
-                const d2u f0 = *reinterpret_cast<const d2u *>(field + r2 + i0), f1 = *reinterpret_cast<const d2u *>(field + r2 + i0 + 2);
-                fv[0] = f0.x; fv[1] = f0.y; fv[2] = f1.x; fv[3] = f1.y;
-                bv = *reinterpret_cast<const u32u *>(bits + r2 + i0);
-            } else {
-                bv = 0u;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const bool in = i0 + c < npi;
-                    wv[c] = in ? w[r3 + i0 + c] : 0.f;
-                    fv[c] = in ? field[r2 + i0 + c] : 0.0;
-                    if (in) bv |= (uint32_t)bits[r2 + i0 + c] << (8 * c);
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const double t = __dmul_rn((double)wv[c], fv[c]);
-                const double tz = __dmul_rn(t, 0.0);          // ibmask = 0: a zero, or the NaN of 0*NaN / 0*Inf
-                const uint32_t bb = (bv >> (8 * c)) & 255u;
-#pragma unroll
-                for (int b = 0; b < NB; ++b) acc[b] += ((bb >> b) & 1u) ? t : tz;
-            }
-        }
-        const int buf = (jk - k0) & 1;
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            double sm = acc[b];
-            for (int o = 32; o > 0; o >>= 1) sm += __shfl_down(sm, o, 64);
-            if (lane == 0) scratch[buf][b][wave] = sm;
-        }
-        __syncthreads();                                      // (one per level: the scratch of level jk+1 is the other one)
-        if ((int)threadIdx.x < nb) {
-            const int b = threadIdx.x;
-            const double sm = ((scratch[buf][b][0] + scratch[buf][b][1]) + scratch[buf][b][2]) + scratch[buf][b][3];
-            raw[((int64_t)jk * npj + jj) * nb + b] = -sm;
-        }
-    }
-    if (blockIdx.y == 0 && (int)threadIdx.x < nb) raw[((int64_t)(npk - 1) * npj + jj) * nb + threadIdx.x] = -0.0;   // level npk: the zero the other kernel writes
-}
-
 // :439-466 for ONE level jk (launched from the bottom level up, in order).  sig8 = sigmai(T,S,gdept(jk))
 // of the level (r8); zsig0 = REAL(sig8 * itmask) is formed on the fly for the six points of the stencil.
 // dvgeo is updated in place (the reference's iup/ido pair collapses: each cell only reads its own
@@ -1241,19 +1175,7 @@ int cdft_moc_decomp(cdft_moc_plan *p, const float *zv, const float *ztemp, const
     double *dvbt = (double *)p->d_dvbt.ptr, *dvgeo = (double *)p->d_dvgeo.ptr, *sig8 = (double *)p->d_sig8.ptr;   // (sig8: one level, or all of them below)
     float *hdep = (float *)p->d_hdep.ptr, *zvgeo = (float *)p->d_zvgeo.ptr;
     const dim3 g2((unsigned)((nij + 255) / 256)), b2(256), grow((unsigned)npj * (unsigned)npk);
-    const char *ezr = getenv("CDFT_DEC_ZONAL");                     // A/B hook: "row" = a workgroup per (jj,jk) row (the round-2 kernel)
-    const bool zonal_rows = !(ezr && ezr[0] == 'r');
     auto zonal_r8 = [&](const double *field, double *raw) -> int {
-        if (zonal_rows) {
-            // level chunks: enough workgroups (16 384) to fill the chip several times over, each with a few levels of its row
-            const int nch = std::max(1, std::min(npk - 1, (16384 + npj - 1) / npj)), lch = (npk - 1 + nch - 1) / nch;
-            const dim3 gj((unsigned)npj, (unsigned)((npk - 1 + lch - 1) / lch));
-            if (nb == 1)      hipLaunchKernelGGL((dec_zonal_r8_rows_kernel<1>), gj, b2, 0, st, p->w, p->bits, field, npi, npj, npk, nb, raw, (int64_t)npi, lch);
-            else if (nb <= 5) hipLaunchKernelGGL((dec_zonal_r8_rows_kernel<5>), gj, b2, 0, st, p->w, p->bits, field, npi, npj, npk, nb, raw, (int64_t)npi, lch);
-            else              hipLaunchKernelGGL((dec_zonal_r8_rows_kernel<8>), gj, b2, 0, st, p->w, p->bits, field, npi, npj, npk, nb, raw, (int64_t)npi, lch);
-            CDFT_LAUNCH_CHECK();
-            return CDFT_OK;
-        }
         if (nb == 1)      hipLaunchKernelGGL((dec_zonal_r8_kernel<1>), grow, b2, 0, st, p->w, p->bits, field, npi, npj, npk, nb, raw, (int64_t)npi);
         else if (nb <= 5) hipLaunchKernelGGL((dec_zonal_r8_kernel<5>), grow, b2, 0, st, p->w, p->bits, field, npi, npj, npk, nb, raw, (int64_t)npi);
         else              hipLaunchKernelGGL((dec_zonal_r8_kernel<8>), grow, b2, 0, st, p->w, p->bits, field, npi, npj, npk, nb, raw, (int64_t)npi);
