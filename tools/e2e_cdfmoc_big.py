@@ -8,7 +8,6 @@ new_maskglo.nc, V.nc (--npt records).  Sampled rows of moc.nc are checked agains
     python tools/e2e_cdfmoc_big.py [--grid eorca12] [--npt 2]      # on the GPU box; ~25 GB of scratch files
 """
 import argparse
-import ctypes as C
 import json
 import os
 import shutil
@@ -26,49 +25,8 @@ import synth  # noqa: E402
 from test_cli import read_nc  # noqa: E402
 
 GRIDS = {"tiny": (64, 40, 7), "eorca025": (1442, 1207, 75), "eorca12": (4322, 3606, 75)}
-BYTE, CHAR, FLOAT, DOUBLE = 1, 2, 5, 6
-nc = C.CDLL(os.path.join(ROOT, "cdftools_amd", "lib", "libncclassic.so"))
-nc.ncc_strerror.restype = C.c_char_p
-
-
-def ok(rc):
-    if rc != 0:
-        raise RuntimeError(nc.ncc_strerror(rc).decode())
-
-
-class Writer:
-    def __init__(self, path, dims):
-        self.id = C.c_int()
-        ok(nc.ncc_create(path.encode(), 5, 1, C.byref(self.id)))
-        self.dim = {}
-        for name, n in dims:
-            d = C.c_int()
-            ok(nc.ncc_def_dim(self.id, name.encode(), C.c_size_t(n or 0), C.byref(d)))
-            self.dim[name] = d.value
-        self.var = {}
-
-    def define(self, name, xtype, dims, **atts):
-        ids = (C.c_int * len(dims))(*[self.dim[d] for d in dims])
-        v = C.c_int()
-        ok(nc.ncc_def_var(self.id, name.encode(), xtype, len(dims), ids, C.byref(v)))
-        for k, val in atts.items():
-            b = val.encode()
-            ok(nc.ncc_put_att(self.id, v, k.encode(), CHAR, C.c_size_t(len(b)), CHAR, b))
-        self.var[name] = (v.value, xtype, len(dims))
-
-    def enddef(self):
-        ok(nc.ncc_enddef(self.id))
-
-    def put(self, name, start, a):
-        v, xtype, nd = self.var[name]
-        a = np.ascontiguousarray(a)
-        mt = {np.dtype(np.int8): BYTE, np.dtype(np.float32): FLOAT, np.dtype(np.float64): DOUBLE}[a.dtype]
-        st = (C.c_size_t * nd)(*start)
-        ct = (C.c_size_t * nd)(*([1] * (nd - a.ndim) + list(a.shape)))
-        ok(nc.ncc_put_vara(self.id, v, st, ct, mt, a.ctypes.data_as(C.c_void_p)))
-
-    def close(self):
-        ok(nc.ncc_close(self.id))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from big_files import BYTE, CHAR, FLOAT, DOUBLE, Writer  # noqa: E402
 
 
 def main():
