@@ -65,6 +65,7 @@ SIGNATURES = {
     "cdft_moc_set_mesh_vmask": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "cdft_moc_compute": (_i, [_vp, _vp, _i64, _i, _i, _vp, _i, _vp]),
     "cdft_moc_decomp_set_mesh": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "cdft_moc_mask_e3v": (_i, [_vp, _vp, C.c_int64, _vp]),
     "cdft_moc_decomp": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "cdft_moc_set_tuning": (_i, [_vp, _i, _i, _i]),
     "cdft_moc_describe": (_i, [_vp, C.c_char_p, _sz]),

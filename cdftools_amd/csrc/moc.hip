@@ -1109,6 +1109,22 @@ int cdft_moc_compute_pitched(cdft_moc_plan *p, const float *zv, int64_t rec_stri
 
 }  // extern "C"
 
+// get_e3v (src/cdfmoc.f90:576-596): e3v * vmask, the mask converted as the reference's INTEGER(2) is
+__global__ void __launch_bounds__(256) moc_mask_e3v_kernel(float *__restrict__ e3v, const int8_t *__restrict__ vmask, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        e3v[i] = __fmul_rn(e3v[i], (float)(int)vmask[i]);
+}
+
+int cdft_moc_mask_e3v(float *e3v, const int8_t *vmask, int64_t n, void *stream) {
+    if (!e3v || !vmask || n < 0) return fail(CDFT_ERR_ARG, "cdft_moc_mask_e3v: NULL argument or negative size");
+    CDFT_TRY(require_device());
+    if (n == 0) return CDFT_OK;
+    const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, 65536);
+    hipLaunchKernelGGL(moc_mask_e3v_kernel, dim3(grid), dim3(256), 0, as_stream(stream), e3v, vmask, n);
+    CDFT_LAUNCH_CHECK();
+    return CDFT_OK;
+}
+
 int cdft_moc_decomp_set_mesh(cdft_moc_plan *p, const float *e3v, const float *e1u, const float *zcoef,
                              const float *gdept, const uint8_t *tmask, const uint8_t *umask, int memspace,
                              void *stream) {

@@ -51,7 +51,7 @@ PROGRAM cdfmoc
   LOGICAL :: ltiming = .FALSE.
   ! -decomp
   INTEGER(KIND=1), ALLOCATABLE, TARGET :: itmask(:,:,:), iumask(:,:,:)   ! (npiglo, npjglo, npk) 0/1
-  REAL(KIND=4),    ALLOCATABLE :: e1u(:,:), zcoef(:,:), gdept(:), ztemp(:,:,:), zsal(:,:,:)
+  REAL(KIND=4),    ALLOCATABLE, TARGET :: e1u(:,:), zcoef(:,:), gdept(:), ztemp(:,:,:), zsal(:,:,:)
   REAL(KIND=8),    ALLOCATABLE :: dmoc_sh(:,:,:), dmoc_bt(:,:,:), dmoc_ag(:,:,:)   ! (nbasins, npjglo, npk)
   REAL(KIND=4) :: rpi, grav = 9.81, rau0 = 1025.
   CHARACTER(LEN=256) :: cf_vfil = 'none', cf_tfil = 'none', cf_sfil = 'none', cf_ufil = 'none'
@@ -202,7 +202,7 @@ PROGRAM cdfmoc
 
   ALLOCATE( ibmask(nbasins, npiglo, npjglo), zmsk(npiglo, npjglo) )
   ALLOCATE( e1v(npiglo, npjglo), gphiv(npiglo, npjglo), dmoc(nbasins, npjglo, npk, nbatch) )
-  IF ( .NOT. lfeed ) ALLOCATE( e3v(npiglo, npjglo, npk), zv(npiglo, npjglo, npk, nbatch) )
+  IF ( .NOT. ( lfeed .OR. lfeed_dec ) ) ALLOCATE( e3v(npiglo, npjglo, npk), zv(npiglo, npjglo, npk, nbatch) )
   ALLOCATE( rdumlon(1, npjglo), rdumlat(1, npjglo), gdepw(npk), e31d(npk), dtim(npt) )
   ALLOCATE( stypvar(nvarout), ipk(nvarout), id_varout(nvarout) )
 
@@ -213,7 +213,7 @@ PROGRAM cdfmoc
   IF ( lfull ) e31d(:) = getvare3(cn_fzgr, cn_ve3t1d, npk)
   IF ( ldec ) THEN
      ALLOCATE( e1u(npiglo, npjglo), zcoef(npiglo, npjglo), gdept(npk) )
-     ALLOCATE( itmask(npiglo, npjglo, npk), iumask(npiglo, npjglo, npk) )
+     IF ( .NOT. lfeed_dec ) ALLOCATE( itmask(npiglo, npjglo, npk), iumask(npiglo, npjglo, npk) )
      IF ( .NOT. lfeed_dec ) ALLOCATE( ztemp(npiglo, npjglo, npk), zsal(npiglo, npjglo, npk) )
      ALLOCATE( dmoc_sh(nbasins, npjglo, npk), dmoc_bt(nbasins, npjglo, npk), dmoc_ag(nbasins, npjglo, npk) )
      gdept(:) = getvare3(cn_fzgr, cn_gdept, npk)
@@ -226,10 +226,10 @@ PROGRAM cdfmoc
      ELSEWHERE
         zcoef(:,:) = 0.
      END WHERE
-     DO jk = 1, npk
-        zmsk(:,:) = getvar(cn_fmsk, cn_tmask, jk, npiglo, npjglo) ; itmask(:,:,jk) = INT(zmsk, 1)
-        zmsk(:,:) = getvar(cn_fmsk, cn_umask, jk, npiglo, npjglo) ; iumask(:,:,jk) = INT(zmsk, 1)
-     END DO
+     IF ( .NOT. lfeed_dec ) THEN                            ! (through the feed: file -> HBM, below)
+        CALL readvar3d_i1(cn_fmsk, cn_tmask, itmask)        ! (bytes in the file, bytes here: a level at a time through getvar's r4
+        CALL readvar3d_i1(cn_fmsk, cn_umask, iumask)        !  slab and back was 3 of the 3.7 s this program spent before its first record at eORCA12)
+     ENDIF
      dmoc_sh(:,:,:) = 0.d0            ! the reference never clears it: a fresh allocation (zero pages) for
   ENDIF                               ! the first record, then each record accumulates onto the last (:471)
 
@@ -294,6 +294,8 @@ PROGRAM cdfmoc
            IF ( .NOT. lg_vvl ) THEN                       ! the plan keeps its own weights and classes: these can go
               CALL feed_release(pd_e3v) ; CALL feed_release(pd_vm) ; CALL feed_release(pd_e1v) ; CALL feed_release(pd_ib)
            ENDIF
+        ELSE IF ( lfeed_dec ) THEN                       ! -decomp on large fields: the mesh of both plans file -> HBM, nothing 3-D here
+           CALL set_mesh_decomp_fed(it0)
         ELSE IF ( ldec .OR. lfull ) THEN                 ! the masked metric is needed on the host as well
            CALL get_e3v_all(it0)
            CALL tick(2)
@@ -307,7 +309,7 @@ PROGRAM cdfmoc
                 &         'cdft_moc_set_mesh_vmask')
         ENDIF
         CALL tick(4)
-        IF ( ldec ) CALL hip_check(cdft_moc_decomp_set_mesh(plan, e3v, e1u, zcoef, gdept, C_LOC(itmask), C_LOC(iumask), &
+        IF ( ldec .AND. .NOT. lfeed_dec ) CALL hip_check(cdft_moc_decomp_set_mesh(plan, e3v, e1u, zcoef, gdept, C_LOC(itmask), C_LOC(iumask), &
              &                     CDFT_MEM_HOST, C_NULL_PTR), 'cdft_moc_decomp_set_mesh')
      ENDIF
      IF ( ldec ) THEN                                     ! one record: total + the three components
@@ -462,6 +464,33 @@ CONTAINS
     DO ik = 1, npk ; ierr = putvar(ncout, id_varout(ijvar), REAL(dd_ag(:,ik)), ik, 1, npjglo, ktime=jt) ; END DO
     ijvar = ijvar + 1
   END SUBROUTINE put4
+
+  SUBROUTINE set_mesh_decomp_fed(kt)
+    !! cdft_moc_set_mesh + cdft_moc_decomp_set_mesh of record kt with every 3-D array going from its file to HBM through the
+    !! ring: e3v and vmask (get_e3v's product formed there, cdft_moc_mask_e3v), tmask, umask; the plan keeps its own copies.
+    !! At eORCA12 the host way (whole fields read, multiplied and handed over from pageable arrays) was 3 of the program's 4.6 s.
+    INTEGER(KIND=4), INTENT(in) :: kt
+    TYPE(C_PTR) :: pd_tm, pd_um, pd_e1u, pd_zc
+    REAL(KIND=4), POINTER :: e1u_d(:), zc_d(:)
+    pd_e1v = feed_device(4 * nij8) ; pd_ib = feed_device(2 * nbasins * nij8) ; pd_vm = feed_device(n38) ; pd_e3v = feed_device(4 * n38)
+    pd_tm  = feed_device(n38) ; pd_um = feed_device(n38) ; pd_e1u = feed_device(4 * nij8) ; pd_zc = feed_device(4 * nij8)
+    CALL C_F_POINTER(pd_e1v, e1v_d, (/ nij8 /)) ; CALL C_F_POINTER(pd_ib, ib_d, (/ nbasins * nij8 /))
+    CALL C_F_POINTER(pd_e3v, e3v_d, (/ n38 /))  ; CALL C_F_POINTER(pd_e1u, e1u_d, (/ nij8 /)) ; CALL C_F_POINTER(pd_zc, zc_d, (/ nij8 /))
+    CALL feed_host(C_LOC(e1v), 4 * nij8, pd_e1v) ; CALL feed_host(C_LOC(ibmask), 2 * nbasins * nij8, pd_ib)
+    CALL feed_host(C_LOC(e1u), 4 * nij8, pd_e1u) ; CALL feed_host(C_LOC(zcoef), 4 * nij8, pd_zc)
+    CALL feed_mask(cn_fmsk, cn_vmask, pd_vm, npiglo, npjglo, npk)
+    CALL feed_field(cn_fe3v, cn_ve3v, pd_e3v, npiglo, npjglo, npk, ktime=kt, ldiom=.NOT. lg_vvl)
+    CALL feed_mask(cn_fmsk, cn_tmask, pd_tm, npiglo, npjglo, npk)
+    CALL feed_mask(cn_fmsk, cn_umask, pd_um, npiglo, npjglo, npk)
+    CALL tick(2)
+    CALL hip_check(cdft_moc_mask_e3v(pd_e3v, pd_vm, n38, feed_stream), 'cdft_moc_mask_e3v')
+    CALL hip_check(cdft_moc_set_mesh(plan, e1v_d, e3v_d, ib_d, CDFT_MEM_DEVICE, feed_stream), 'cdft_moc_set_mesh')
+    CALL hip_check(cdft_moc_decomp_set_mesh(plan, e3v_d, e1u_d, zc_d, gdept, pd_tm, pd_um, CDFT_MEM_DEVICE, feed_stream), &
+         &         'cdft_moc_decomp_set_mesh')
+    CALL hip_check(cdft_stream_sync(feed_stream), 'cdft_stream_sync')
+    CALL feed_release(pd_e3v) ; CALL feed_release(pd_vm) ; CALL feed_release(pd_e1v) ; CALL feed_release(pd_ib)
+    CALL feed_release(pd_tm)  ; CALL feed_release(pd_um) ; CALL feed_release(pd_e1u) ; CALL feed_release(pd_zc)
+  END SUBROUTINE set_mesh_decomp_fed
 
   SUBROUTINE get_e3v_all(kt)
     !! e3v of every level (or e31d with -full) times vmask of that level (src/cdfmoc.f90:576-596, get_e3v), read as

@@ -211,6 +211,9 @@ MODULE cdftools_hip
        IMPORT ; TYPE(C_PTR), VALUE :: plan, stream, tmask, umask
        REAL(C_FLOAT), INTENT(in) :: e3v(*), e1u(*), zcoef(*), gdept(*) ; INTEGER(C_INT), VALUE :: memspace
      END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_moc_mask_e3v(e3v, vmask, n, stream) BIND(C, name='cdft_moc_mask_e3v')
+       IMPORT ; TYPE(C_PTR), VALUE :: e3v, vmask, stream ; INTEGER(C_INT64_T), VALUE :: n
+     END FUNCTION
      INTEGER(C_INT) FUNCTION cdft_moc_decomp(plan, zv, ztemp, zsal, eos, in_space, dmoc, dmoc_sh, dmoc_bt, dmoc_ag, &
           &                                  out_space, stream) BIND(C, name='cdft_moc_decomp')
        IMPORT ; TYPE(C_PTR), VALUE :: plan, stream ; REAL(C_FLOAT), INTENT(in) :: zv(*), ztemp(*), zsal(*)

@@ -93,7 +93,10 @@ PROGRAM cdfvT
   END DO
 
   CALL hip_shard(ngpu, igpus)                                ! CDFT_GPUS / CDFT_GPU_MAP
-  lfeed = feed_wanted(4_8 * npiglo * npjglo * ntframe) .AND. ngpu == 1                      ! one device: every slab file -> HBM through the ring (module cdffeed)
+  ! one device: every slab file -> HBM through the ring (module cdffeed).  What decides is what the RUN moves -- a field's frames of
+  ! every level -- not a level's frames: one frame of eORCA12 is 62 MB a level, and the level loop below it (pageable arrays
+  ! in, r8 means out) took 8.0 s for what the ring does in ... (profiles/r05/e2e_all_eorca12.txt)
+  lfeed = feed_wanted(4_8 * npiglo * npjglo * ntframe * npk) .AND. ngpu == 1
   nfr8 = 4_8 * npiglo * npjglo * ntframe
   IF ( lfeed ) THEN
      pd_u = feed_device(nfr8) ; pd_v = feed_device(nfr8) ; pd_t = feed_device(nfr8) ; pd_s = feed_device(nfr8)

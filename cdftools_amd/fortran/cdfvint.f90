@@ -33,6 +33,8 @@ PROGRAM cdfvint
   INTEGER(KIND=4) :: il, ib
   INTEGER(KIND=8) :: n38
   LOGICAL :: lfeed
+  INTEGER(KIND=8) :: iclk(4), iclk_rate
+  REAL(KIND=8) :: dl_ph(3) = 0.d0                                   ! CDFT_TIMING: the three steps of a level on its way out
   LOGICAL :: lfull = .FALSE., lgsop = .FALSE., locci = .FALSE., lchk, lout, ltmean = .FALSE., lsmean = .FALSE.
   LOGICAL :: lnc4 = .FALSE., lfout = .FALSE.
   !!----------------------------------------------------------------------
@@ -197,10 +199,15 @@ PROGRAM cdfvint
         DO jk = 1, npk
            IF ( kout(jk) < 0 ) CYCLE
            il = il + 1 ; ib = 1 + MOD(il - 1, 2)
+           CALL SYSTEM_CLOCK(iclk(1), iclk_rate)
            CALL wait_writes(ncout)                        ! (the page-locked array of this parity is in the file)
+           CALL SYSTEM_CLOCK(iclk(2))
            CALL hip_check(cdft_memcpy_d2h(ph_lev(ib), C_LOC(zout_d(1 + INT(kout(jk), 8) * npiglo * npjglo)),  &
                 &         INT(4_8 * npiglo * npjglo, C_SIZE_T), feed_stream), 'cdft_memcpy_d2h')
+           CALL SYSTEM_CLOCK(iclk(3))
            ierr = putvar_behind(ncout, id_varout(1), ph_lev(ib), .FALSE., kout(jk) + 1, npiglo, npjglo, ktime=jt)
+           CALL SYSTEM_CLOCK(iclk(4))
+           dl_ph(1:3) = dl_ph(1:3) + REAL(iclk(2:4) - iclk(1:3), 8) / iclk_rate
         END DO
         CYCLE
      ELSE IF ( lfull ) THEN
@@ -219,6 +226,8 @@ PROGRAM cdfvint
      END DO
   END DO
   IF ( lfeed ) CALL wait_writes(ncout)                    ! the last levels of the last record (a failed write stops here)
+  CALL GET_ENVIRONMENT_VARIABLE('CDFT_TIMING', cldum)
+  IF ( lfeed .AND. LEN_TRIM(cldum) > 0 ) WRITE(0, '(a,3f9.3)') ' CDFT_TIMING cdfvint levels out (s): wait for the file, D2H, queue', dl_ph
   ierr = closeout(ncout)
   IF ( lfeed ) THEN
      CALL feed_release(pd_zt) ; CALL feed_release(pd_msk) ; CALL feed_release(pd_e3) ; CALL feed_release(pd_e31) ; CALL feed_release(pd_out)

@@ -372,6 +372,19 @@ EOS_80, EOS_TEOS10, EOS_JMD94, EOS_NTR = 0, 1, 2, 3
 EOS_FAST_FMA = 1
 
 
+def moc_mask_e3v(e3v, vmask, stream=None):
+    """get_e3v's product (src/cdfmoc.f90:576-596) in place on device tensors: e3v (r4) *= vmask (int8), cdft_moc_mask_e3v."""
+    import torch
+    if not (_is_tensor(e3v) and _is_tensor(vmask) and e3v.is_cuda and vmask.is_cuda):
+        raise TypeError("moc_mask_e3v: device tensors only (a host caller multiplies its own arrays)")
+    if e3v.dtype != torch.float32 or vmask.dtype not in (torch.int8, torch.uint8) or not e3v.is_contiguous() or not vmask.is_contiguous():
+        raise TypeError("moc_mask_e3v: e3v contiguous float32, vmask contiguous int8 / uint8")
+    if e3v.numel() != vmask.numel():
+        raise ValueError("moc_mask_e3v: %d cells of e3v, %d of vmask" % (e3v.numel(), vmask.numel()))
+    check(_lib.load().cdft_moc_mask_e3v(C.c_void_p(e3v.data_ptr()), C.c_void_p(vmask.data_ptr()), e3v.numel(), stream or current_stream_ptr()))
+    return e3v
+
+
 def _out_like(x, dtype_np, dtype_t):
     if _is_tensor(x) and x.is_cuda:
         return torch.empty(x.shape, dtype=dtype_t, device=x.device)

@@ -32,6 +32,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include "ncmodel.h"
@@ -44,6 +45,17 @@
 static unsigned long g_chunks_read, g_chunks_written;
 unsigned long nch5_chunks_inflated(void) { return g_chunks_read; }
 unsigned long nch5_chunks_deflated(void) { return g_chunks_written; }
+
+/* threads that inflate / deflate chunks: CDFT_IO_THREADS, else half the cores between 8 and 32 (deflate of a 2 MB chunk of
+ * floats is ~25 ms: a level of eORCA12 is 31 of them) */
+static int filter_threads(void) {
+    int n = 8;
+    const long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+    if (ncpu / 2 > n) n = ncpu / 2 > 32 ? 32 : (int)(ncpu / 2);
+    const char *e = getenv("CDFT_IO_THREADS");
+    if (e && atoi(e) >= 1) n = atoi(e);
+    return n > 64 ? 64 : n;
+}
 
 /* what the chunk-at-a-time writer needs to know about an output variable */
 typedef struct {
@@ -516,10 +528,7 @@ static int get_by_chunks(hid_t d, int nd, const hsize_t *st, const hsize_t *ct, 
     }
     if (ok) {
         pthread_mutex_init(&j.lock, NULL);
-        int nthreads = 8;
-        const char *e = getenv("CDFT_IO_THREADS");
-        if (e && atoi(e) >= 1) nthreads = atoi(e);
-        if (nthreads > 64) nthreads = 64;
+        int nthreads = filter_threads();
         if ((size_t)nthreads > j.nchunks) nthreads = (int)j.nchunks;
         pthread_t th[64];
         int started = 0;
@@ -747,7 +756,7 @@ int nch5_create(const char *path, NcH5 **hout, int ndims, const Dim *dims, int n
 /* ---- deflated variables, whole chunks at a time ----------------------------------------------------------------
  * H5Dwrite runs the shuffle + deflate filters of every chunk on the calling thread (about 80 MB/s: the -nc4 output
  * of cdfsigi at eORCA025 took 6 s).  When a write covers whole chunks and needs no type conversion, the chunks are
- * shuffled and deflated here by CDFT_IO_THREADS threads (default 8) and handed over with H5Dwrite_chunk: the bytes in
+ * shuffled and deflated here by CDFT_IO_THREADS threads (default: half the cores, 8 to 32) and handed over with H5Dwrite_chunk: the bytes in
  * the file are what the library's own filters would have produced, any NetCDF-4 reader inflates them. */
 typedef struct {
     const VarOut *vo;
@@ -845,10 +854,7 @@ static int put_whole_chunks(NcH5 *h, int varid, int nd, const hsize_t *st, const
     j.out_bytes = (size_t *)calloc(j.nchunks, sizeof *j.out_bytes);
     if (!j.out || !j.out_bytes) { free(j.out); free(j.out_bytes); return NCC_ENOMEM; }
     pthread_mutex_init(&j.lock, NULL);
-    int nthreads = 8;
-    const char *e = getenv("CDFT_IO_THREADS");
-    if (e && atoi(e) >= 1) nthreads = atoi(e);
-    if (nthreads > 64) nthreads = 64;
+    int nthreads = filter_threads();
     if ((size_t)nthreads > j.nchunks) nthreads = (int)j.nchunks;
     pthread_t th[64];
     int started = 0;

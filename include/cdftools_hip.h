@@ -260,6 +260,10 @@ int cdft_moc_compute_pitched(cdft_moc_plan *plan, const float *zv, int64_t rec_s
 int cdft_moc_decomp_set_mesh(cdft_moc_plan *plan, const float *e3v, const float *e1u, const float *zcoef,
                              const float *gdept, const uint8_t *tmask, const uint8_t *umask, int memspace,
                              void *stream);
+/* get_e3v's product (src/cdfmoc.f90:576-596) in place on DEVICE arrays: e3v(i) = e3v(i) * vmask(i), n cells, the mask as bytes
+ * (the reference multiplies by its INTEGER(2) mask: the same r4 product).  For a caller whose raw e3v and vmask went from their
+ * files to HBM through the feed and who needs the masked metric for cdft_moc_set_mesh + cdft_moc_decomp_set_mesh. */
+int cdft_moc_mask_e3v(float *e3v, const int8_t *vmask, int64_t n, void *stream);
 /* zv, ztemp, zsal (npiglo,npjglo,npk) r4 of one record; eos = CDFT_EOS_80 | CDFT_EOS_TEOS10 (-teos10).
  * dmoc, dmoc_bt, dmoc_ag (nbasins,npjglo,npk) r8 out.
  * dmoc_sh (nbasins,npjglo,npk) r8 IN/OUT: the reference never clears it and accumulates each record

@@ -43,6 +43,7 @@ RUNS = [
     ("cdfheatc", ["-f", T, "-mxloption", "1", "-mxlf", "mxl.nc"], ["heatc.nc"]),
     ("cdfmoc", ["-v", V, "-t", T, "-decomp", "-o", "dec.nc"], ["dec.nc"]),                        # V, T and S of a record through the ring
     ("cdfmoc", ["-v", V, "-t", T, "-decomp", "-teos10", "-o", "dec.nc"], ["dec.nc"]),
+    ("cdfmoc", ["-v", "VVL_y0001_gridV.nc", "-t", "VVL_y0001_gridT.nc", "-decomp", "-vvl", "-o", "dec.nc"], ["dec.nc"]),   # the mesh of every record fed too
     ("cdfpsi", ["-u", U, "-v", V], ["psi.nc"]),
     ("cdfpsi", ["-u", U, "-v", V, "-V"], ["psi.nc"]),
     ("cdfpsi", ["-u", U, "-v", V, "-mean", "-mask", "-ref", "5", "4"], ["psi.nc"]),

@@ -217,3 +217,22 @@ def test_hip_decomp_needs_its_mesh_and_a_domain_of_3_by_3(gpu):
     with pytest.raises(gpu.CdftError):
         small.decomp_set_mesh(np.zeros((3, 5, 2), f32), np.ones((5, 2), f32), np.ones((5, 2), f32), np.ones(3, f32),
                               np.ones((3, 5, 2), np.uint8), np.ones((3, 5, 2), np.uint8))
+
+
+@pytest.mark.gpu
+def test_mask_e3v_on_the_device_is_get_e3v(gpu):
+    """cdft_moc_mask_e3v = e3v * INTEGER(2) mask of src/cdfmoc.f90:576-596, bit for bit: a NaN of the metric under a 0 of the
+    mask stays a NaN (0 * NaN), a negative value becomes -0."""
+    import torch
+    rng = np.random.default_rng(5)
+    n = 3 * 257 * 131 + 3
+    e3 = (1 + 200 * rng.random(n)).astype(np.float32)
+    e3[::97] = -e3[::97]
+    e3[5::1001] = np.nan
+    m = (rng.random(n) > 0.4).astype(np.int8)
+    want = e3 * m.astype(np.int16).astype(np.float32)
+    got = gpu.moc_mask_e3v(torch.from_numpy(e3).cuda(), torch.from_numpy(m).cuda()).cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    with pytest.raises(TypeError):
+        gpu.moc_mask_e3v(torch.from_numpy(e3), torch.from_numpy(m))
+

@@ -54,18 +54,29 @@ def main():
     ap.add_argument("--keep", action="store_true")
     ap.add_argument("--big", action="store_true", help="the CDF-5 generator and one run per program (always at eorca12)")
     ap.add_argument("--only", default="", help="comma-separated program names")
+    ap.add_argument("--dir", default="", help="keep the files there, and use the ones a former run left (implies --keep)")
     args = ap.parse_args()
     big = args.big or args.grid == "eorca12"
     npi, npj, npk = GRIDS[args.grid]
-    d = tempfile.mkdtemp(prefix="cdft_e2e_", dir=os.environ.get("TMPDIR", "/tmp"))
+    if args.dir:
+        d = os.path.abspath(args.dir)
+        os.makedirs(d, exist_ok=True)
+        args.keep = True
+    else:
+        d = tempfile.mkdtemp(prefix="cdft_e2e_", dir=os.environ.get("TMPDIR", "/tmp"))
     t0 = time.perf_counter()
     stats = None
-    if big:
+    made = os.path.join(d, "generated.json")
+    if os.path.exists(made):
+        stats = json.load(open(made))
+    elif big:
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import big_files
         stats = big_files.make_big_case(d, npi, npj, npk, npt=args.npt)
     else:
         nemo_files.make_case(d, npi=npi, npj=npj, npk=npk, npt=args.npt)
+    if args.dir and not os.path.exists(made):
+        json.dump(stats or {}, open(made, "w"))
     gen = time.perf_counter() - t0
     bad = 0
 
