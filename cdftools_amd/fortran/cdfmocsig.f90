@@ -20,7 +20,7 @@ PROGRAM cdfmocsig
   USE cdffeed
   IMPLICIT NONE
 
-  INTEGER(KIND=4) :: ji, jt, jbasin, jbin, it, npiglo, npjglo, npk, npt, nbins, narg, ijarg, ii, ncout, nbasins, nvaro, ierr
+  INTEGER(KIND=4) :: ji, jk, jt, jbasin, jbin, it, npiglo, npjglo, npk, npt, nbins, narg, ijarg, ii, ncout, nbasins, nvaro, ierr
   INTEGER(KIND=4) :: npglo = 1, npatl = 2, npinp = 3, npind = 4, nppac = 5, iloc(2)
   INTEGER(KIND=4), ALLOCATABLE :: ipk(:), id_varout(:)
   INTEGER(KIND=2), ALLOCATABLE, TARGET :: ibmask(:,:,:)
@@ -173,6 +173,12 @@ PROGRAM cdfmocsig
 
   DO jt = 1, npt
      it = 1 ; IF ( lg_vvl ) it = jt
+     IF ( lprint ) THEN                                     ! -verbose: the reference's two lines per level of its loop (src/cdfmocsig.f90:372, :412)
+        DO jk = 1, npk - 1
+           PRINT *, ' working at depth ', jk
+           PRINT *, ' Entering main J loop '
+        END DO
+     ENDIF
      IF ( lfeed ) THEN                                      ! file -> HBM through the ring, the compute call ordered behind it
         pe3 = C_NULL_PTR ; pe31d = C_NULL_PTR ; peiv = C_NULL_PTR ; pgdep = C_NULL_PTR ; pdepi = C_NULL_PTR
         IF ( jt == 1 ) THEN

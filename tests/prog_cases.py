@@ -98,6 +98,23 @@ CASES = [
     ("cdfmocsig_ntr_isodep", "cdfmocsig", ["-v", "SYN_y0001_gridV.nc", "-t", "SYN_y0001_gridT.nc", "-ntr", "-isodep"], ["mocsig.nc"]),
     ("cdfmocsig_ntr", "cdfmocsig", ["-v", "SYN_y0001_gridV.nc", "-t", "SYN_y0001_gridT.nc", "-ntr", "-sigmin", "19", "-sigstp", "0.25", "-nbins", "60",
                        "-o", "ntr.nc"], ["ntr.nc"]),
+    # fourth tier (round 5): the options no case had yet -- other file and variable names (-s, -b, -vtvar, -namU, -namV), -nometric,
+    # cdfvT -vvl, -debug, -pdep / -ndep_in, a window of cdfvertmean, cdfmocsig -eiv / -teos10 / -verbose (with -ntr: see above)
+    ("cdfmoc_decomp_sfile", "cdfmoc", ["-v", "SYN_y0001_gridV.nc", "-t", "SYN_y0001_gridT.nc", "-s", "salinity_alt.nc", "-decomp", "-o", "moc_ds.nc"],
+     ["moc_ds.nc"]),
+    ("cdfcurl_nometric", "cdfcurl", ["-u", "SYN_y0001_gridU.nc", "vozocrtx", "-v", "SYN_y0001_gridV.nc", "vomecrty", "-l", "1", "-nometric"], ["curl_grid.nc"]),
+    ("cdfmhst_sfile_basin_file", "cdfmhst", ["-v", "SYN_y0001_gridV.nc", "-t", "SYN_y0001_gridT.nc", "-s", "salinity_alt.nc", "-b", "basins_alt.nc", "-MST",
+                                  "-o", "mhst_b.nc"], ["mhst_b.nc", "zonal_heat_trp.dat", "zonal_salt_trp.dat"]),
+    ("cdfmhst_vtvar", "cdfmhst", ["-vt", "ALT_vt.nc", "-vtvar", "vt_alt", "vs_alt", "-o", "mhst_a.nc"], ["mhst_a.nc", "zonal_heat_trp.dat", "zonal_salt_trp.dat"]),
+    ("cdfvT_namU_namV", "cdfvT", ["-c", "ALT", "-l", "y0001", "-namU", "uoce", "-namV", "voce", "-o", "vt_alt.nc"], ["vt_alt.nc"]),
+    ("cdfvT_vvl", "cdfvT", ["-c", "VVL", "-l", "y0001", "-vvl", "-o", "vt_vvl2.nc"], ["vt_vvl2.nc"]),
+    ("cdfzonalmean_pdep_ndep_in_debug", "cdfzonalmean", ["-f", "SYN_y0001_gridT.nc", "-p", "T", "-pdep", "-ndep_in", "-debug", "-o", "zm3.nc"], ["zm3.nc"]),
+    ("cdfzonalsum_debug", "cdfzonalsum", ["-f", "SYN_y0001_gridT.nc", "-p", "T", "-debug", "-o", "zs3.nc"], ["zs3.nc"]),
+    ("cdfvertmean_window_debug", "cdfvertmean", ["-f", "SYN_y0001_gridT.nc", "-l", "votemper", "-p", "T", "-zlim", "15", "120", "-w", "3", "20", "2", "15",
+                                  "-debug", "-o", "vm_w.nc"], ["vm_w.nc"]),
+    ("cdfmocsig_ntr_eiv_sfile_verbose", "cdfmocsig", ["-v", "EIV_y0001_gridV.nc", "-t", "SYN_y0001_gridT.nc", "-s", "salinity_alt.nc", "-ntr", "-eiv",
+                                         "-verbose", "-o", "ms_e.nc"], ["ms_e.nc"]),
+    ("cdfmocsig_ntr_teos10", "cdfmocsig", ["-v", "SYN_y0001_gridV.nc", "-t", "SYN_y0001_gridT.nc", "-ntr", "-teos10", "-o", "ms_t.nc"], ["ms_t.nc"]),
     # (depths of the window as the reference takes them: positive, metres -- it flips the sign of depthw when it reads moc.nc
     # (src/cdfmaxmoc.f90:123) and a window of negative depths leaves its ikmin / ikmax without a value: that, not the compiler, was
     # the segmentation fault that kept these two cases out of the differential in round 4)
@@ -145,6 +162,16 @@ def extra_files(d, g, rec):
     vt = {"vomevt": (rec["t"] * rec["v"]).astype(f32), "vomevs": (rec["s"] * rec["v"]).astype(f32),
           "vozout": (rec["t"] * rec["u"]).astype(f32), "vozous": (rec["s"] * rec["u"]).astype(f32)}
     nemo_files.write_data(os.path.join(d, "VVL_vt.nc"), g, "deptht", dict(vt, e3u=e3["u"], e3v=e3["v"]))
+    # fourth tier: the same fields under other file and variable names
+    import shutil
+    nemo_files.write_data(os.path.join(d, "salinity_alt.nc"), g, "deptht", {"vosaline": (rec["s"] * f32(0.97) * g["tmask"][None]).astype(f32)}, fill=0.0)
+    shutil.copy(os.path.join(d, "new_maskglo.nc"), os.path.join(d, "basins_alt.nc"))
+    nemo_files.write_data(os.path.join(d, "ALT_vt.nc"), g, "deptht", {"vt_alt": vt["vomevt"][:, ::-1].copy(), "vs_alt": vt["vomevs"][:, ::-1].copy()})
+    nemo_files.write_data(os.path.join(d, "ALT_y0001_gridT.nc"), g, "deptht", {"votemper": rec["t"], "vosaline": rec["s"]}, fill=0.0)
+    nemo_files.write_data(os.path.join(d, "ALT_y0001_gridU.nc"), g, "depthu", {"uoce": rec["u"][::-1].copy()})
+    nemo_files.write_data(os.path.join(d, "ALT_y0001_gridV.nc"), g, "depthv", {"voce": rec["v"][::-1].copy()})
+    veiv = (np.random.default_rng(79).standard_normal(rec["v"].shape).astype(f32) * f32(0.05) * g["vmask"][None]).astype(f32)
+    nemo_files.write_data(os.path.join(d, "EIV_y0001_gridV.nc"), g, "depthv", {"vomecrty": rec["v"], "vomeeivv": veiv})
 
 
 def _att(v):
