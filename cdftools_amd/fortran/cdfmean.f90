@@ -394,12 +394,16 @@ CONTAINS
     DO jbasin = 1, nbasin
        cl_suffix = '' ; IF ( lbas ) cl_suffix = '_'//TRIM(cbasins(jbasin))
        ipkz(jbasin)                          = nvpk
+       ! The reference appends to the UNtrimmed 256-character strings (src/cdfmean.f90:647-653): what it appends falls off the end
+       ! on assignment.  Its long_name is therefore the input's, unchanged -- kept, the reference program's own file says so
+       ! (tests/golden/prog_cdfmean_zeromean.npz).  Its variable NAMES lose their basin suffix the same way, so that with -B every
+       ! basin defines the same <IN-var> again and one variable is left in the file: not kept -- the names carry the suffix here.
        stypvarzero(jbasin)%cname             = TRIM(cv_nam)//TRIM(cl_suffix)
        stypvarzero(jbasin)%cunits            = stypvarin(ivar0)%cunits
        stypvarzero(jbasin)%rmissing_value    = stypvarin(ivar0)%rmissing_value
        stypvarzero(jbasin)%valid_min         = stypvarin(ivar0)%valid_min - MAXVAL(dvmeanout3d)
        stypvarzero(jbasin)%valid_max         = stypvarin(ivar0)%valid_max - MINVAL(dvmeanout3d)
-       stypvarzero(jbasin)%clong_name        = TRIM(stypvarin(ivar0)%clong_name)//TRIM(cl_suffix)//' zero mean '
+       stypvarzero(jbasin)%clong_name        = stypvarin(ivar0)%clong_name
        stypvarzero(jbasin)%cshort_name       = TRIM(cv_nam)//TRIM(cl_suffix)
        stypvarzero(jbasin)%conline_operation = 'N/A'
        stypvarzero(jbasin)%caxis             = stypvarin(ivar0)%caxis

@@ -115,6 +115,15 @@ CASES = [
     ("cdfmocsig_ntr_eiv_sfile_verbose", "cdfmocsig", ["-v", "EIV_y0001_gridV.nc", "-t", "SYN_y0001_gridT.nc", "-s", "salinity_alt.nc", "-ntr", "-eiv",
                                          "-verbose", "-o", "ms_e.nc"], ["ms_e.nc"]),
     ("cdfmocsig_ntr_teos10", "cdfmocsig", ["-v", "SYN_y0001_gridV.nc", "-t", "SYN_y0001_gridT.nc", "-ntr", "-teos10", "-o", "ms_t.nc"], ["ms_t.nc"]),
+    # cdfmean's other options (round 5: the reference program runs once it is built with its own gfortran spelling of line 194,
+    # oracle/ref_prog_build.sh)
+    ("cdfmean_M_names", "cdfmean", ["-f", "SYN_y0001_gridV.nc", "-v", "vomecrty", "-p", "V", "-M", "mask.nc", "umask", "-var", "-S", "-o", "mm.nc", "-ot", "mm.txt",
+                          "-ov", "mv.txt", "-os", "ms.txt"], ["mm.nc", "mm.txt", "mv.txt", "ms.txt"]),
+    ("cdfmean_zeromean", "cdfmean", ["-f", "SYN_y0001_gridT.nc", "-v", "votemper", "-p", "T", "-zeromean", "-oz", "zm0.nc", "-o", "mz.nc"],
+     ["mz.nc", "zm0.nc", "cdfmean.txt"]),
+    ("cdfmean_vvl", "cdfmean", ["-f", "VVL_y0001_gridT.nc", "-v", "votemper", "-p", "T", "-vvl", "-o", "mvvl.nc"], ["mvvl.nc", "cdfmean.txt"]),
+    ("cdfmean_U_window_k", "cdfmean", ["-f", "SYN_y0001_gridU.nc", "-v", "vozocrtx", "-p", "U", "-w", "0", "0", "4", "12", "2", "5", "-o", "mu.nc"],
+     ["mu.nc", "cdfmean.txt"]),
     # (depths of the window as the reference takes them: positive, metres -- it flips the sign of depthw when it reads moc.nc
     # (src/cdfmaxmoc.f90:123) and a window of negative depths leaves its ikmin / ikmax without a value: that, not the compiler, was
     # the segmentation fault that kept these two cases out of the differential in round 4)

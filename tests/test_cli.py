@@ -29,7 +29,13 @@ def tools():
 def run(tool, args, cwd, env=None):
     e = dict(os.environ)
     e.update(env or {})
-    p = subprocess.run([os.path.join(BIN, tool)] + args, cwd=cwd, env=e, capture_output=True, text=True, timeout=600)
+    try:
+        p = subprocess.run([os.path.join(BIN, tool)] + args, cwd=cwd, env=e, capture_output=True, text=True, timeout=120)
+    except subprocess.TimeoutExpired as t:                   # (a program of a test grid takes a fraction of a second: name the one that hangs)
+        so = t.stdout.decode("latin-1") if isinstance(t.stdout, bytes) else (t.stdout or "")
+        se = t.stderr.decode("latin-1") if isinstance(t.stderr, bytes) else (t.stderr or "")
+        raise AssertionError("HUNG after 120 s: %s %s  env %s\n--- stdout so far\n%s\n--- stderr so far\n%s" % (
+            tool, " ".join(args), {k: v for k, v in (env or {}).items()}, so[-1500:], se[-1500:]))
     return p.returncode, p.stdout, p.stderr
 
 
