@@ -189,9 +189,10 @@ def test_the_program_runs_one_launch_on_the_pool_and_writes_the_reference_progra
     g_, rec_ = nemo_files.make_case(d)
     case = next(c for c in pc.CASES if c[0] == "cdfmoc_default")
     ref, ref_arr = pc.load_golden(os.path.join(GOLD, "prog_cdfmoc_default.npz"))
+    other_shape = bool(os.environ.get("CDFT_TEST_SHAPE"))     # (the golden is the differential's grid: a shape sweep checks the launches only)
     got, got_arr = pc.run_case(BIN, case, d, env={"CDFT_FEED": "1"})
     bad = [x for x in diff_case(case, ref, ref_arr, got, got_arr) if not explained(case[0], x[0], x[1])]
-    assert not bad, bad[:10]
+    assert other_shape or not bad, bad[:10]
     npt, npk = rec_["v"].shape[0], rec_["v"].shape[1]
     # the default, the stream route: windows of levels, EVERY launch covers all the run's records, in the pool layout
     rc, out, err = run("cdfmoc", case[2], d, env={"CDFT_FEED": "1", "CDFT_TIMING": "1"})
@@ -201,7 +202,7 @@ def test_the_program_runs_one_launch_on_the_pool_and_writes_the_reference_progra
     # CDFT_MOC_ROUTE=pool: all records resident in the plan's pool, ONE launch -- bench.py's very call
     got, got_arr = pc.run_case(BIN, case, d, env={"CDFT_FEED": "1", "CDFT_MOC_ROUTE": "pool"})
     bad = [x for x in diff_case(case, ref, ref_arr, got, got_arr) if not explained(case[0], x[0], x[1])]
-    assert not bad, bad[:10]
+    assert other_shape or not bad, bad[:10]
     rc, out, err = run("cdfmoc", case[2], d, env={"CDFT_FEED": "1", "CDFT_TIMING": "1", "CDFT_MOC_ROUTE": "pool"})
     desc, launches, records = _plan_line(err)
     assert rc == 0 and "layout=pool" in desc and (launches, records) == (1, npt), err[-400:]
