@@ -164,7 +164,8 @@ def host_description():
 def tools_leg(args):
     """The other BASELINE configs and the other 8(a) tools on THIS box, after the timed region (rank 0, N = 1): child processes
     (this one has let go of its memory) run tools/bench_tools.py at eORCA025 -- cdfheatc in both sum modes (config 2), cdfmhst,
-    cdfpsi, cdfvT, cdfcurl, sigma0 / sigma2 -- and this script on the eorca025 workload (config 3: cdfmoc, 12 records).
+    cdfpsi, cdfvT, cdfcurl, sigma0 / sigma2 -- and at eORCA12 (the same and cdfmean / cdfsum / cdfzonalsum / cdfzonalmean), and this
+    script on the eorca025 workload (config 3: cdfmoc, 12 records).
     -> a list of {tool, grid, ms, alg_bytes, frac, ...}: ms = one call through the C ABI (HIP events on the launch stream),
     frac = alg_bytes / ms / 8 TB/s; kernels_only_* where a call also returns a host result."""
     out = []
@@ -173,21 +174,24 @@ def tools_leg(args):
               "TORCHELASTIC_RUN_ID"):
         env.pop(k, None)
     try:
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_tools.py"), "--grid", "eorca025", "--reps", "20", "--tools",
-                            "heatc,mhst,psi,vt,curl,eos", "--land", "none", "--warm", "0.3"], capture_output=True, text=True, timeout=args.tools_timeout, env=env)
-        for ln in r.stdout.splitlines():
-            if not ln.startswith("{"):
-                continue
-            t = json.loads(ln)
-            e = {"tool": t["tool"], "grid": t["grid"], "ms": t["ms"], "alg_bytes": t["cells"] * t["algorithmic_bytes_per_cell"],
-                 "frac": t["frac_of_hbm_peak"]}
-            if "kernels_only_ms" in t:
-                e.update(kernels_only_ms=t["kernels_only_ms"], kernels_only_frac=t["kernels_only_frac"])
-            if "roofline" in t:                                   # bound by the r8 issue rate, not by HBM
-                e.update(bound="fp64", frac_of_r8_issue_peak=t["roofline"]["frac"])
-            out.append(e)
-        if r.returncode != 0:
-            out.append({"error": f"tools/bench_tools.py rc {r.returncode}: " + r.stderr[-300:]})
+        # eORCA025: BASELINE configs 2 and 3 are quoted there; eORCA12: the grid of the headline and of DESIGN 4's table (since
+        # round 5: 14 s more, so that the table's fractions are numbers of the driver's box too), with the 8(f) reductions
+        for grid, reps, which in (("eorca025", "20", "heatc,mhst,psi,vt,curl,eos"), ("eorca12", "10", "heatc,mean,zonal,mhst,psi,vt,curl,eos")):
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_tools.py"), "--grid", grid, "--reps", reps, "--tools", which,
+                                "--land", "none", "--warm", "0.3"], capture_output=True, text=True, timeout=args.tools_timeout, env=env)
+            for ln in r.stdout.splitlines():
+                if not ln.startswith("{"):
+                    continue
+                t = json.loads(ln)
+                e = {"tool": t["tool"], "grid": t["grid"], "ms": t["ms"], "alg_bytes": t["cells"] * t["algorithmic_bytes_per_cell"],
+                     "frac": t["frac_of_hbm_peak"]}
+                if "kernels_only_ms" in t:
+                    e.update(kernels_only_ms=t["kernels_only_ms"], kernels_only_frac=t["kernels_only_frac"])
+                if "roofline" in t:                                   # bound by the r8 issue rate, not by HBM
+                    e.update(bound="fp64", frac_of_r8_issue_peak=t["roofline"]["frac"])
+                out.append(e)
+            if r.returncode != 0:
+                out.append({"error": f"tools/bench_tools.py --grid {grid} rc {r.returncode}: " + r.stderr[-300:]})
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "eorca025", "--steps", "100", "--warmup", "5", "--no-cpu-baseline",
                             "--no-inprocess", "--no-tools"], capture_output=True, text=True, timeout=args.tools_timeout, env=env)
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

@@ -78,7 +78,7 @@ def test_bench_inprocess_mode_alone(gpu):
 
 @pytest.mark.gpu
 def test_bench_tools_leg(gpu):
-    """the "tools" block of the eorca12 line (BASELINE configs 2 and 3 and the other 8(a) tools at eORCA025, child processes of
+    """the "tools" block of the eorca12 line (BASELINE configs 2 and 3 and the other 8(a) tools at eORCA025, the 8(a) and 8(f) tools at eORCA12, child processes of
     bench.py after its timed region): every entry a measured call with its algorithmic bytes and fraction of the HBM peak"""
     import argparse
     sys.path.insert(0, ROOT)
@@ -89,8 +89,11 @@ def test_bench_tools_leg(gpu):
     for want in ("cdfheatc", "cdfheatc, reference-order r4 sums", "cdfmhst -vt", "cdfpsi (U path)", "cdfvT", "cdfcurl", "cdfmoc, 12 records (BASELINE config 3)"):
         assert want in names, names
     assert any(n.startswith("sigma0 tool form, exact") for n in names)
+    big = [e["tool"] for e in out if e["grid"] == "eorca12"]              # since round 5: the grid of DESIGN 4's table too
+    for want in ("cdfheatc", "cdfmean (1 basin)", "cdfzonalsum (5 basins)", "cdfmhst -vt", "cdfpsi (U path)", "cdfvT", "cdfcurl"):
+        assert want in big, big
     for e in out:
-        assert e["grid"] == "eorca025" and e["ms"] > 0 and e["alg_bytes"] > 0 and 0 < e["frac"] < 1, e
+        assert e["grid"] in ("eorca025", "eorca12") and e["ms"] > 0 and e["alg_bytes"] > 0 and 0 < e["frac"] < 1, e
         assert abs(e["frac"] - e["alg_bytes"] / (e["ms"] * 1e-3) / 8e12) < 2e-4 * max(1.0, e["frac"]) + 1e-4, e
 
 
