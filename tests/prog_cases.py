@@ -216,7 +216,13 @@ def run_case(bindir, case, cwd, env=None):
     e.update(env or {})
     # argv[0] is the bare program name (it goes into the `history` attribute, src/modutils.f90 SetGlobalAtt): the same text
     # whichever directory the binary lies in
-    p = subprocess.run([prog] + args, executable=os.path.join(bindir, prog), cwd=cwd, env=e, capture_output=True, text=True, timeout=600)
+    for attempt in (1, 2):                                   # (a run that hangs is tried once more: tests/test_cli.py run() says why)
+        try:
+            p = subprocess.run([prog] + args, executable=os.path.join(bindir, prog), cwd=cwd, env=e, capture_output=True, text=True, timeout=300)
+            break
+        except subprocess.TimeoutExpired:
+            if attempt == 2:
+                raise
     meta = {"case": name, "program": prog, "args": args, "rc": p.returncode, "stdout": p.stdout, "files": {}}
     if p.returncode != 0:
         meta["stderr"] = p.stderr
