@@ -69,7 +69,9 @@ CONTAINS
     CHARACTER(LEN=16) :: cl
     CALL feed_open()
     IF ( nslot_bytes >= kplane ) RETURN
-    dl_mb = 128.d0 ; islots = 4
+    ! two slots: the copy of one leaves faster than the next is read (57 against 30-35 GB/s), and page-locking costs 0.12 s per GB
+    ! to make and as much to undo -- four slots of 124 MB were 0.1 s of every program's 0.7-1.1 s at eORCA12 (profiles/r05 §10)
+    dl_mb = 128.d0 ; islots = 2
     CALL GET_ENVIRONMENT_VARIABLE('CDFT_FEED_MB', cl)    ; IF ( LEN_TRIM(cl) > 0 ) READ(cl, *) dl_mb
     CALL GET_ENVIRONMENT_VARIABLE('CDFT_FEED_SLOTS', cl) ; IF ( LEN_TRIM(cl) > 0 ) READ(cl, *) islots
     iwant = MIN(INT(dl_mb * 1048576.d0, 8), MAX(kfield / 16, 4194304_8))
