@@ -9,7 +9,7 @@ MODULE cdffeed
   !! the copies.  Unpacking (scale_factor ...), windows and the mesh_zgr names are readvar3d's, unchanged.
   !! The ring is made when the first field goes through it, sized for that field: page-locked memory costs 0.17 s per GB to
   !! get and 0.10 s per GB to give back on this pool (tools/pin_probe.hip), so the slots hold a sixteenth of the field, at
-  !! least one plane and at most CDFT_FEED_MB (default 128) MB, CDFT_FEED_SLOTS (default 4) of them.  A program takes this
+  !! least one plane and at most CDFT_FEED_MB (default 128) MB, CDFT_FEED_SLOTS (default 2) of them.  A program takes this
   !! route when its fields are large enough for it to pay (feed_wanted: CDFT_FEED=0 / 1 decide for it).
   !! Beyond feed_field: feed_mean_mesh (the mesh of cdfmean / cdfsum without a 3-D host array) and feed_sig_record (cdfsig0 /
   !! cdfsigi, whose result is as large as their input: slabs in through the ring, results out through two page-locked arrays,
