@@ -269,6 +269,8 @@ struct ZonalClassArgs {
     uint8_t pat[kZC];
     int nclass;
     int lc;                       // level chunks: workgroup = (chunk, row)
+    int lev_max;                  // levels of the longest chunk (the LDS layout behind the slots)
+    int *rowflag;                 // MINMAX: rows holding a NaN / Inf (zeroed before the launch)
     int xcd_map;                  // workgroup -> (chunk, row) so that each XCD takes an eighth of the rows
 };
 
@@ -277,7 +279,12 @@ struct ZonalClassArgs {
 // vector's and are sent to an unread slot -- so every load is a full vector inside the row, without a branch.
 typedef uint32_t u32u __attribute__((aligned(1)));               // 4 mask bytes at any address
 
-template <int NV, bool MEAN, int T, bool M8>
+// MINMAX (cdfzonalmean -max, src/cdfzonalmean.f90:316-326): the zonal maximum and minimum by class too -- two more slots per lane and
+// class, r4 (the reference keeps its extrema in r4: MAX(r4, r8) rounded back at every cell, which is the r4 rounding of the r8
+// extremum because rounding is monotone), updated by ds_max_f32 / ds_min_f32; a cell outside a basin enters its maximum as 0
+// (dtmp = 0 there) and never its minimum (dtmp /= 0).  A row that holds a NaN / Inf is flagged for the general kernel, as the
+// select kernel does (fmax / fmin drop a NaN the reference's MAX keeps or not by position).
+template <int NV, bool MEAN, int T, bool M8, bool MINMAX>
 __global__ void __launch_bounds__(T) zonal_row_class_kernel(ZonalArgs2 a, ZonalClassArgs ca) {
     extern __shared__ double lds[];
     constexpr int nwaves = T / 64;
@@ -297,6 +304,11 @@ __global__ void __launch_bounds__(T) zonal_row_class_kernel(ZonalArgs2 a, ZonalC
     const int k0 = (int)((int64_t)chunk * a.nlev / ca.lc), k1 = (int)((int64_t)(chunk + 1) * a.nlev / ca.lc);
     double *scr  = lds + wave * ((kZC + 1) * kZStride);              // slot [class][lane]; class kZC = cells not owned
     double *part = lds + nwaves * ((kZC + 1) * kZStride);            // [k1-k0][kZC][nwaves]
+    // MINMAX: behind part ([lev_max][kZC][nwaves] doubles), r4 slots [wave][max | min][class][lane] and their per-level results
+    float *xscr  = reinterpret_cast<float *>(part + (size_t)ca.lev_max * kZC * nwaves) + wave * (2 * (kZC + 1) * kZStride);
+    float *xpart = reinterpret_cast<float *>(part + (size_t)ca.lev_max * kZC * nwaves) + nwaves * (2 * (kZC + 1) * kZStride);   // [k1-k0][kZC][nwaves][2]
+    uint32_t present = 0u;                                           // classes this lane owns a cell of
+    float nonfinite = 0.f;
     const int64_t nij = (int64_t)a.npi * a.npj, r2 = (int64_t)jj * a.npi;
     const int nfull = a.npi >> 2;                                    // vectors 0..nfull-1 start at 4v
     double sf[NV][4];
@@ -314,11 +326,18 @@ __global__ void __launch_bounds__(T) zonal_row_class_kernel(ZonalArgs2 a, ZonalC
             const int i = i0 + c;
             const bool own = v < nfull || (v == nfull && i >= 4 * nfull);
             sf[r][c] = a.surf[r2 + i];
-            cpk[r] |= (uint32_t)(own ? min((int)ca.cls[r2 + i], kZC) : kZC) << (8 * c);      // slot kZC is never read
+            const int cl = own ? min((int)ca.cls[r2 + i], kZC) : kZC;
+            cpk[r] |= (uint32_t)cl << (8 * c);      // slot kZC is never read
+            if (MINMAX && cl < kZC) present |= 1u << cl;
         }
     }
 #pragma unroll
     for (int c = 0; c <= kZC; ++c) scr[c * kZStride + lane] = 0.0;
+    if (MINMAX) {
+#pragma unroll
+        for (int c = 0; c <= kZC; ++c) { xscr[c * kZStride + lane] = -1.e20f; xscr[(kZC + 1 + c) * kZStride + lane] = 1.e20f; }
+        for (int o = 32; o > 0; o >>= 1) present |= __shfl_xor(present, o, 64);
+    }
     // the level mask: r4 as given (M8 = false), or one byte per cell when it holds only 0 and 1 (the same m*z products)
     struct Mask { f4u v; uint32_t b; };
     f4u zc[NV], zn[NV];
@@ -355,8 +374,16 @@ __global__ void __launch_bounds__(T) zonal_row_class_kernel(ZonalArgs2 a, ZonalC
             for (int c = 0; c < 4; ++c) {
                 // zmask = 1: sum form (1.f*m)*z = m*z in r4; mean form ((1.d0*1)*m)*z = m*z in r8
                 const double dt = MEAN ? __dmul_rn((double)m4[c], (double)z4[c]) : (double)__fmul_rn(m4[c], z4[c]);
-                (void)__hip_atomic_fetch_add(&scr[((pk >> (8 * c)) & 0xffu) * kZStride + lane], __dmul_rn(sf[r][c], dt), __ATOMIC_RELAXED,
+                const uint32_t cl = (pk >> (8 * c)) & 0xffu;
+                (void)__hip_atomic_fetch_add(&scr[cl * kZStride + lane], __dmul_rn(sf[r][c], dt), __ATOMIC_RELAXED,
                                              __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (MINMAX) {
+                    const float ft = (float)dt;
+                    nonfinite = __fmaf_rn(z4[c], 0.f, nonfinite);
+                    (void)__hip_atomic_fetch_max(&xscr[cl * kZStride + lane], ft, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    (void)__hip_atomic_fetch_min(&xscr[(kZC + 1 + (dt != 0.0 ? cl : (uint32_t)kZC)) * kZStride + lane], ft, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -371,16 +398,45 @@ __global__ void __launch_bounds__(T) zonal_row_class_kernel(ZonalArgs2 a, ZonalC
         s += __shfl_xor(s, 1, 64);
         s += __shfl_xor(s, 2, 64);
         s += __shfl_xor(s, 4, 64);
+        float fx = -1.e20f, fn = 1.e20f;
+        if (MINMAX) {                                   // the same transposition for the extrema: lane c*8+q takes 8 lanes of class c
+            const float *qx = xscr + (lane >> 3) * kZStride + (lane & 7), *qn = qx + (kZC + 1) * kZStride;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { fx = fmaxf(fx, qx[8 * j]); fn = fminf(fn, qn[8 * j]); }
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) { fx = fmaxf(fx, __shfl_xor(fx, o, 64)); fn = fminf(fn, __shfl_xor(fn, o, 64)); }
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();                // every lane has read before the slots are cleared
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
         for (int c = 0; c < kZC; ++c) scr[c * kZStride + lane] = 0.0;
-        if ((lane & 7) == 0) part[((int64_t)(k - k0) * kZC + (lane >> 3)) * nwaves + wave] = s;
+        if (MINMAX) {
+#pragma unroll
+            for (int c = 0; c <= kZC; ++c) { xscr[c * kZStride + lane] = -1.e20f; xscr[(kZC + 1 + c) * kZStride + lane] = 1.e20f; }
+        }
+        if ((lane & 7) == 0) {
+            part[((int64_t)(k - k0) * kZC + (lane >> 3)) * nwaves + wave] = s;
+            if (MINMAX) {
+                float *xp = xpart + (((int64_t)(k - k0) * kZC + (lane >> 3)) * nwaves + wave) * 2;
+                xp[0] = fx; xp[1] = fn;
+            }
+        }
 #pragma unroll
         for (int r = 0; r < NV; ++r) { zc[r] = zn[r]; mc[r] = mn_[r]; }
     }
-    __syncthreads();
+    if (MINMAX) {                                       // a NaN / Inf in the row: the general kernel recomputes it (all its levels)
+        const int redo = __syncthreads_or(!__builtin_isfinite(nonfinite));
+        if (threadIdx.x == 0 && redo) atomicOr(ca.rowflag + jj, 1);
+        __shared__ uint32_t pres[nwaves];
+        if (lane == 0) pres[wave] = present;
+        __syncthreads();
+        present = 0u;
+#pragma unroll
+        for (int w = 0; w < nwaves; ++w) present |= pres[w];
+    } else {
+        __syncthreads();
+    }
     for (int t = threadIdx.x; t < (k1 - k0) * a.nb; t += T) {
         const int kk = t / a.nb, b = t - kk * a.nb, k = k0 + kk;
         double s = 0.0, z = 0.0;
@@ -393,21 +449,43 @@ __global__ void __launch_bounds__(T) zonal_row_class_kernel(ZonalArgs2 a, ZonalC
             }
         }
         a.dsum[((int64_t)b * a.nlev + k) * a.npj + jj] = s + __dmul_rn(z, 0.0);
+        if (MINMAX) {
+            float tx = -1.e20f, tn = 1.e20f;
+            for (int c = 0; c < ca.nclass; ++c) {
+                if ((ca.pat[c] >> b) & 1) {
+                    for (int w = 0; w < nwaves; ++w) {
+                        const float *xp = xpart + (((int64_t)kk * kZC + c) * nwaves + w) * 2;
+                        tx = fmaxf(tx, xp[0]); tn = fminf(tn, xp[1]);
+                    }
+                } else if ((present >> c) & 1u) {
+                    tx = fmaxf(tx, 0.f);                       // a cell of the row outside the basin: dtmp = 0
+                }
+            }
+            a.rmax[((int64_t)b * a.nlev + k) * a.npj + jj] = tx;
+            a.rmin[((int64_t)b * a.nlev + k) * a.npj + jj] = tn;
+        }
     }
 }
 
 constexpr int kClassT = 256, kClassMaxNV = 5;
 
 template <int NV, int T = kClassT>
-int launch_class_nv(const ZonalArgs2 &a, const ZonalClassArgs &ca, bool mean, hipStream_t st) {
-    const size_t shmem = ((size_t)(T / 64) * (kZC + 1) * kZStride + (size_t)a.nlev * kZC * (T / 64)) * sizeof(double);
+int launch_class_nv(const ZonalArgs2 &a, const ZonalClassArgs &ca, bool mean, bool minmax, hipStream_t st) {
+    constexpr int nw = T / 64;
+    size_t shmem = ((size_t)nw * (kZC + 1) * kZStride + (size_t)ca.lev_max * kZC * nw) * sizeof(double);
+    if (minmax) shmem += ((size_t)nw * 2 * (kZC + 1) * kZStride + (size_t)ca.lev_max * kZC * nw * 2) * sizeof(float);
     const dim3 grid(ca.xcd_map ? 8 * ((a.npj + 7) / 8) * ca.lc : a.npj * ca.lc);
-    if (a.mask8) {
-        if (mean) hipLaunchKernelGGL((zonal_row_class_kernel<NV, true, T, true>), grid, dim3(T), shmem, st, a, ca);
-        else      hipLaunchKernelGGL((zonal_row_class_kernel<NV, false, T, true>), grid, dim3(T), shmem, st, a, ca);
+    if (minmax) {                                                 // (-max is an option of the MEAN form, src/cdfzonalmean.f90:147)
+        const void *kf = a.mask8 ? (const void *)zonal_row_class_kernel<NV, true, T, true, true> : (const void *)zonal_row_class_kernel<NV, true, T, false, true>;
+        if (shmem > 48 * 1024) CDFT_TRY(dyn_lds_once(kf, (int)shmem));
+        if (a.mask8) hipLaunchKernelGGL((zonal_row_class_kernel<NV, true, T, true, true>), grid, dim3(T), shmem, st, a, ca);
+        else         hipLaunchKernelGGL((zonal_row_class_kernel<NV, true, T, false, true>), grid, dim3(T), shmem, st, a, ca);
+    } else if (a.mask8) {
+        if (mean) hipLaunchKernelGGL((zonal_row_class_kernel<NV, true, T, true, false>), grid, dim3(T), shmem, st, a, ca);
+        else      hipLaunchKernelGGL((zonal_row_class_kernel<NV, false, T, true, false>), grid, dim3(T), shmem, st, a, ca);
     } else {
-        if (mean) hipLaunchKernelGGL((zonal_row_class_kernel<NV, true, T, false>), grid, dim3(T), shmem, st, a, ca);
-        else      hipLaunchKernelGGL((zonal_row_class_kernel<NV, false, T, false>), grid, dim3(T), shmem, st, a, ca);
+        if (mean) hipLaunchKernelGGL((zonal_row_class_kernel<NV, true, T, false, false>), grid, dim3(T), shmem, st, a, ca);
+        else      hipLaunchKernelGGL((zonal_row_class_kernel<NV, false, T, false, false>), grid, dim3(T), shmem, st, a, ca);
     }
     CDFT_LAUNCH_CHECK();
     return CDFT_OK;
@@ -416,12 +494,16 @@ int launch_class_nv(const ZonalArgs2 &a, const ZonalClassArgs &ca, bool mean, hi
 // rows of 4 .. 5116 cells
 inline bool class_fits(int npi) { return npi >= 4 && (npi / 4 + 1 + kClassT - 1) / kClassT <= kClassMaxNV; }
 
-int launch_class(const ZonalArgs2 &a, ZonalClassArgs ca, bool mean, hipStream_t st) {
+int launch_class(const ZonalArgs2 &a, ZonalClassArgs ca, bool mean, bool minmax, hipStream_t st) {
     const char *e = getenv("CDFT_ZONAL_CHUNKS");                  // A/B hook
     // one workgroup per row for all levels is 1207 workgroups at eORCA025, less than the chip holds: the levels are cut
     // so that there are about 4096 (measured: 238 -> 209 us there, nothing lost at eORCA12)
     ca.lc = e ? std::max(1, std::min(a.nlev, atoi(e))) : std::max(1, std::min(std::min(a.nlev, 8), (4096 + a.npj - 1) / a.npj));
+    // -max: its r4 slots double the workgroup's LDS, and a chunk's per-level results are the rest of it -- at least four chunks keep three
+    // workgroups on a CU instead of two (eORCA12: 1.77 -> 1.51 ms; profiles/r05 section 11)
+    if (minmax && !e) ca.lc = std::max(ca.lc, std::min(a.nlev, 4));
     { const char *x = getenv("CDFT_ZONAL_XCDMAP"); ca.xcd_map = (a.npj >= 64 && !(x && x[0] == '0')) ? 1 : 0; }
+    ca.lev_max = (a.nlev + ca.lc - 1) / ca.lc;
     // Workgroups of 128 lanes where they waste fewer lanes on the end of the row than 256 do (a row of 1442 cells is 362
     // vectors: 2 x 256 slots leave 29 % of the lanes idle, 3 x 128 leave 6 %); CDFT_ZONAL_T = 128 | 256: A/B hook
     {
@@ -430,19 +512,19 @@ int launch_class(const ZonalArgs2 &a, ZonalClassArgs ca, bool mean, hipStream_t 
         const bool small = t ? atoi(t) == 128 : nv128 * 128 < nv256 * 256;
         if (small && nv128 <= kClassMaxNV)                        // (rows of up to 2556 cells; at 4322 cells 9 x 128 was measured: 3 % slower than 5 x 256)
             switch (nv128) {
-                case 1: return launch_class_nv<1, 128>(a, ca, mean, st);
-                case 2: return launch_class_nv<2, 128>(a, ca, mean, st);
-                case 3: return launch_class_nv<3, 128>(a, ca, mean, st);
-                case 4: return launch_class_nv<4, 128>(a, ca, mean, st);
-                default: return launch_class_nv<5, 128>(a, ca, mean, st);
+                case 1: return launch_class_nv<1, 128>(a, ca, mean, minmax, st);
+                case 2: return launch_class_nv<2, 128>(a, ca, mean, minmax, st);
+                case 3: return launch_class_nv<3, 128>(a, ca, mean, minmax, st);
+                case 4: return launch_class_nv<4, 128>(a, ca, mean, minmax, st);
+                default: return launch_class_nv<5, 128>(a, ca, mean, minmax, st);
             }
     }
     switch ((a.npi / 4 + 1 + kClassT - 1) / kClassT) {
-        case 1: return launch_class_nv<1>(a, ca, mean, st);
-        case 2: return launch_class_nv<2>(a, ca, mean, st);
-        case 3: return launch_class_nv<3>(a, ca, mean, st);
-        case 4: return launch_class_nv<4>(a, ca, mean, st);
-        default: return launch_class_nv<5>(a, ca, mean, st);
+        case 1: return launch_class_nv<1>(a, ca, mean, minmax, st);
+        case 2: return launch_class_nv<2>(a, ca, mean, minmax, st);
+        case 3: return launch_class_nv<3>(a, ca, mean, minmax, st);
+        case 4: return launch_class_nv<4>(a, ca, mean, minmax, st);
+        default: return launch_class_nv<5>(a, ca, mean, minmax, st);
     }
 }
 
@@ -651,11 +733,18 @@ int cdft_zonal_compute(cdft_zonal_plan *p, const float *zv, int nlev, int in_spa
     bool done = false;
     const bool force_general = getenv("CDFT_ZONAL_GENERAL") != nullptr;            // A/B and test hooks
     const bool no_class = getenv("CDFT_ZONAL_NOCLASS") != nullptr;
-    if (p->binary && !force_general && !no_class && !minmax && p->nclass > 0 && class_fits(p->npi)) {
+    const bool class_minmax = !(getenv("CDFT_ZONAL_MAX_SELECT"));                    // A/B hook: -max on the select kernel (rounds 2-4)
+    if (p->binary && !force_general && !no_class && (!minmax || class_minmax) && p->nclass > 0 && class_fits(p->npi)) {
         ZonalClassArgs ca;
-        ca.cls = p->cls; ca.nclass = p->nclass;
+        ca.cls = p->cls; ca.nclass = p->nclass; ca.rowflag = p->rowflag;
         for (int c = 0; c < kZC; ++c) ca.pat[c] = p->pat[c];
-        CDFT_TRY(launch_class(a, ca, mean_form != 0, st));
+        if (minmax) CDFT_HIP(hipMemsetAsync(p->rowflag, 0, (size_t)p->npj * sizeof(int), st));
+        CDFT_TRY(launch_class(a, ca, mean_form != 0, minmax, st));
+        if (minmax) {                                             // the rows it flagged (a NaN / Inf met): the general kernel
+            if (p->nb == 1)      CDFT_TRY(launch_rows<1>(a, p->rowflag, true, true, st));
+            else if (p->nb <= 5) CDFT_TRY(launch_rows<5>(a, p->rowflag, true, true, st));
+            else                 CDFT_TRY(launch_rows<8>(a, p->rowflag, true, true, st));
+        }
     } else {
     if (p->binary && !force_general) {
         if (p->nb == 1)      CDFT_TRY(launch_fast_nb<1>(a, p->bits, p->rowflag, mean_form != 0, minmax, st, &done));

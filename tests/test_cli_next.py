@@ -382,7 +382,7 @@ def test_oracle_zonal_matches_numpy_restatement():
 @pytest.mark.parametrize("npi,npj,npk,nb", [(24, 18, 7, 5), (182, 149, 31, 5), (1, 1, 1, 1), (300, 5, 2, 1), (1031, 4, 3, 5),
                                             (1537, 3, 2, 5), (4322, 2, 3, 5)])
 def test_hip_zonal_matches_oracle(gpu, monkeypatch, npi, npj, npk, nb, kernel):
-    """The three kernels behind cdft_zonal_compute: LDS class accumulators (0/1 masks, several basins, no -max), the
+    """The three kernels behind cdft_zonal_compute: LDS class accumulators (0/1 masks, up to 8 basin patterns), the
     select kernel (0/1 masks) and the general one (any mask values); the environment hooks force the latter two."""
     if kernel != "class":
         monkeypatch.setenv("CDFT_ZONAL_GENERAL" if kernel == "general" else "CDFT_ZONAL_NOCLASS", "1")
@@ -390,7 +390,7 @@ def test_hip_zonal_matches_oracle(gpu, monkeypatch, npi, npj, npk, nb, kernel):
     tm = g["tmask"].astype(np.float32)
     plan = gpu.ZonalPlan(npi, npj, npk, nb)
     plan.set_mesh(g["e1t"], g["e2t"], tm, zm)
-    for mean_form, minmax in ((False, False), (True, True), (True, False)):      # -max keeps the select kernel
+    for mean_form, minmax in ((False, False), (True, True), (True, False)):      # (-max: the class kernel too since round 5)
         got = plan.compute(zv, mean_form=mean_form, minmax=minmax)
         ref = oracle_tools.zonal(g["e1t"], g["e2t"], tm, zm, zv, mean_form=mean_form)
         bound = oracle_tools.zonal(g["e1t"], g["e2t"], tm, zm, np.abs(zv), mean_form=mean_form)["sum"]
@@ -417,6 +417,45 @@ def test_hip_zonal_matches_oracle(gpu, monkeypatch, npi, npj, npk, nb, kernel):
         ref = oracle_tools.zonal(g["e1t"], g["e2t"], tm2, zm, zv, mean_form=mean_form)
         bound = oracle_tools.zonal(g["e1t"], g["e2t"], tm2, zm, np.abs(zv), mean_form=mean_form)["sum"]
         assert np.all(np.abs(got["sum"] - ref["sum"]) <= 1e-13 * bound + 1e-300)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("npi,npj,npk,nb", [(24, 18, 7, 5), (1442, 9, 5, 5), (1031, 4, 3, 1), (4322, 3, 4, 5), (130, 70, 9, 8)])
+def test_hip_zonal_max_on_the_class_kernel_equals_the_select_kernel(gpu, monkeypatch, npi, npj, npk, nb):
+    """cdfzonalmean -max (src/cdfzonalmean.f90:316-326) on the class kernel (round 5: r4 extrema per lane and class in LDS,
+    ds_max_f32 / ds_min_f32) against the select kernel (CDFT_ZONAL_MAX_SELECT) and the oracle: the same bits -- rows in one
+    basin only, rows of land, values that round to the same r4, tiny values (the minimum skips an exact zero, not a denormal),
+    negative zeros, and rows with a NaN or an Inf, which both hand to the general kernel"""
+    g, zv, zm = zonal_inputs(npi, npj, npk, min(nb, 5), seed=npi + 31)
+    if nb > 5:
+        more = np.stack([(g["tmask"][0] * ((np.arange(npi) + b) % 3 == 0)[None, :]).astype(np.float32) for b in range(nb - 5)], axis=2)
+        zm = np.concatenate([zm, more], axis=2)
+    tm = g["tmask"].astype(np.float32)
+    rng = np.random.default_rng(npi)
+    zv = zv.copy()
+    zv[0, 0, :] = 0.0                                                     # a row of zeros: max 0 (or -1e20 on land), min 1e20
+    zv[-1, -1, ::3] = np.float32(1e-42)                                   # denormal r4 values
+    zv[0, 1, ::2] = -0.0
+    if npj > 2:
+        zv[:, 2, :] = np.abs(zv[:, 2, :]) + 1                             # a strictly positive row: the 0 of a cell outside a basin is its minimum's rival, never taken
+    plan = gpu.ZonalPlan(npi, npj, npk, nb)
+    plan.set_mesh(g["e1t"], g["e2t"], tm, zm)
+    for poison in (None, np.nan, np.inf):
+        z = zv.copy()
+        if poison is not None:
+            z[npk // 2, npj // 2, int(rng.integers(npi))] = poison
+            z[0, 0, 0] = poison
+        got = plan.compute(z, mean_form=True, minmax=True)
+        monkeypatch.setenv("CDFT_ZONAL_MAX_SELECT", "1")
+        sel = plan.compute(z, mean_form=True, minmax=True)
+        monkeypatch.delenv("CDFT_ZONAL_MAX_SELECT")
+        for k in ("max", "min"):
+            assert np.array_equal(got[k].view(np.uint32), sel[k].view(np.uint32)), (k, poison)
+        assert np.array_equal(np.isnan(got["sum"]), np.isnan(sel["sum"]))
+        if poison is None:
+            ref = oracle_tools.zonal(g["e1t"], g["e2t"], tm, zm, z, mean_form=True)
+            assert np.array_equal(got["max"], ref["max"]) and np.array_equal(got["min"], ref["min"])
+        assert all(np.array_equal(plan.compute(z, mean_form=True, minmax=True)[k], got[k], equal_nan=True) for k in got)
 
 
 @pytest.mark.parametrize("tool", ["cdfzonalsum", "cdfzonalmean", "cdfmean"])

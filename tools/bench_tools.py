@@ -233,6 +233,8 @@ def main():
             ms = timed(lambda: p.compute(zv, mean_form=mf, pinned=True, want_area=False), args.reps)
             report(name + ", result to the host, page-locked", args.grid, n3, 5.0, ms, "what the programs do: the result into page-locked"
                    " arrays that are reused (CDFT_MEM_PINNED), the area of the mean form taken once per mesh (cdft_zonal_area)")
+        ms = timed(lambda: p.compute(zv, mean_form=True, minmax=True, device_out=True), args.reps)
+        report("cdfzonalmean -max (5 basins)", args.grid, n3, 5.0, ms, "the zonal sums and the zonal maximum and minimum (src/cdfzonalmean.f90:316-326); result left in HBM")
         del p, zv
 
     if "mocsig" in tools:
