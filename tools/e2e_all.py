@@ -85,7 +85,7 @@ def main():
         import hashlib
         before = {f: os.path.getmtime(os.path.join(d, f)) for f in os.listdir(d)}
         t0 = time.perf_counter()
-        r = subprocess.run([os.path.join(ROOT, "cdftools_amd", "bin", tool)] + a, cwd=d, capture_output=True, text=True, env=env)
+        r = subprocess.run([os.path.join(os.environ.get("CDFT_BIN", os.path.join(ROOT, "cdftools_amd", "bin")), tool)] + a, cwd=d, capture_output=True, text=True, env=env)
         wall = time.perf_counter() - t0
         wrote = {}
         for f in sorted(os.listdir(d)):
