@@ -55,6 +55,26 @@ def main():
                 bad += not same
             else:
                 pc.save_golden(path, meta, arrays)
+    with tempfile.TemporaryDirectory(prefix="cdft_prog_rapid_") as d:          # cdfmoc -rapid: its own grid (tests/test_cli_rapid.py)
+        import test_cli_rapid as tr
+        tr.make_rapid_case(d)
+        for case in pc.RAPID_CASES:
+            meta, arrays = pc.run_case(bindir, case, d)
+            path = os.path.join(gold, f"prog_{case[0]}.npz")
+            missing = [o for o, s in meta["files"].items() if s is None]
+            print(f"{case[0]:28s} rc={meta['rc']} files={list(meta['files'])} missing={missing} stdout={len(meta['stdout'].splitlines())} lines")
+            if meta["rc"] != 99 or missing:
+                print("    -> NOT the outcome the reference's -rapid has (STOP 99 after its file):", meta.get("stderr", "")[-300:])
+                bad += 1
+                continue
+            meta.pop("stderr", None)                            # ("Fortran STOP: code 99": the runtime's line, not the program's)
+            if check:
+                m0, a0 = pc.load_golden(path)
+                same = m0 == meta and sorted(a0) == sorted(arrays) and all(np.array_equal(a0[k], arrays[k], equal_nan=True) for k in a0)
+                print("   ", "equal" if same else "DIFFERENT")
+                bad += not same
+            else:
+                pc.save_golden(path, meta, arrays)
     import json
     spath = os.path.join(gold, "prog_left_out.json")
     if check:

@@ -132,6 +132,14 @@ CASES = [
 ]
 
 
+# cdfmoc -rapid (src/cdfmoc.f90:598-1004) needs a grid on which cdf_findij finds its 26.5 N section: the files of
+# tests/test_cli_rapid.make_rapid_case, in a directory of their own.  The reference ends the option with STOP 99 (:255) AFTER it has
+# written rapid_moc.nc: exit status 99 with the file is the outcome to equal.
+RAPID_CASES = [
+    ("cdfmoc_rapid", "cdfmoc", ["-v", "V.nc", "-t", "T.nc", "-u", "U.nc", "-rapid"], ["rapid_moc.nc"]),
+    ("cdfmoc_rapid_full_sfile", "cdfmoc", ["-v", "V.nc", "-t", "T.nc", "-s", "T.nc", "-u", "U.nc", "-rapid", "-full", "-o", "m.nc"], ["rapid_m.nc"]),   # (the name the reference derives, src/cdfmoc.f90:1202)
+]
+
 # the programs called without an argument: the usage text, the reference's own (src/cdfmoc.f90:130-210 ...), then this build's
 # "MI355X BUILD" lines.  No GPU, no input file: compared on the CPU (tests/test_prog_diff.py::test_usage_texts...)
 USAGE_CASES = [(p + "_usage", p, [], []) for p in

@@ -241,3 +241,21 @@ def test_numpy_rapid_equals_the_reference_statements(name):
             if nm.startswith("tr_") and float(np.ravel(want)[0]) != 0.0:
                 met.add(nm)
     assert {"tr_THERM", "tr_AIW", "tr_UNADW", "tr_LNADW"} <= met      # the depth classes of the section are not empty
+
+
+@pytest.mark.parametrize("case", __import__("prog_cases").RAPID_CASES, ids=lambda c: c[0])
+def test_cdfmoc_rapid_against_the_reference_program(tools, tmp_path, case):  # noqa: F811
+    """The program differential of tests/test_prog_diff.py for -rapid: what the reference's own cdfmoc (unmodified, built in the build
+    container over this repository's NetCDF layer) left behind on these files -- exit status 99, every line of stdout, rapid_moc.nc with its
+    33 variables, their attributes in file order and their values -- against this build's.  Host code on both sides: no GPU needed."""
+    import prog_cases as pc
+    from test_prog_diff import BIN, GOLD, diff_case, explained
+    d = str(tmp_path)
+    make_rapid_case(d)
+    ref, ref_arr = pc.load_golden(os.path.join(GOLD, f"prog_{case[0]}.npz"))
+    got, got_arr = pc.run_case(BIN, case, d)
+    got.pop("stderr", None)
+    assert ref["rc"] == 99
+    bad = [x for x in diff_case(case, ref, ref_arr, got, got_arr) if not explained(case[0], x[0], x[1])]
+    assert not bad, bad[:20]
+
