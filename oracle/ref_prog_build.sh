@@ -53,4 +53,4 @@ for p in cdfmoc cdfmhst cdfvT cdfheatc cdfpsi cdfcurl cdfsig0 cdfsigi \
         -L$LIBDIR -lncclassic -Wl,-rpath,$LIBDIR
   fi
 done
-echo "oracle/_ref/prog: the 18 reference programs of SURVEY 8(a) and 8(f), unmodified, over this repository's NetCDF layer (a differential, not a pin)"
+echo "oracle/_ref/prog: the 18 reference programs of SURVEY 8(a) and 8(f), unmodified (cdfmean: its own gfortran spelling of one OPEN), over this repository's NetCDF layer (a differential, not a pin)"
