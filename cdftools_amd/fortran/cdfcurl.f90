@@ -115,6 +115,7 @@ PROGRAM cdfcurl
   END DO
   PRINT *, 'NLEV', nlev
 
+  CALL cdf_phase('start -> arguments, dimensions')
   ALLOCATE( e1u(npiglo,npjglo), e1f(npiglo,npjglo), e2v(npiglo,npjglo), e2f(npiglo,npjglo) )
   ! large fields: a level at a time through the page-locked ring (module cdffeed), nothing of nlev levels on the host
   nij8 = INT(npiglo, 8) * npjglo
@@ -135,6 +136,7 @@ PROGRAM cdfcurl
   ELSE
      e1u = 1. ; e1f = 1. ; e2v = 1. ; e2f = 1. ; zlon = 10. ; zlat = 10.
   ENDIF
+  CALL cdf_phase('allocations, metric and coordinates read')
   pff = C_NULL_PTR
   IF ( loverf ) THEN                                         ! src/cdfcurl.f90:224-227
      ALLOCATE( dl_ff(npiglo,npjglo) )
@@ -153,11 +155,14 @@ PROGRAM cdfcurl
   ENDIF
   IF ( zlon(1,1) == zlon(npiglo-1,1) ) lperio = .TRUE.       ! E-W periodicity, :238
 
+  CALL cdf_phase('depths, periodicity')
   CALL CreateOutput
+  CALL cdf_phase('CreateOutput')
   CALL hip_check(cdft_curl_create(plan, npiglo, npjglo), 'cdft_curl_create')
   CALL hip_check(cdft_curl_set_mesh(plan, e1u, e2v, e1f, e2f, pff, MERGE(1_C_INT, 0_C_INT, lperio), CDFT_MEM_HOST, &
        &         C_NULL_PTR), 'cdft_curl_set_mesh')
 
+  CALL cdf_phase('plan, mesh to the device')
   IF ( lfeed ) THEN
      pd_u = feed_device(4 * nij8) ; pd_v = feed_device(4 * nij8)
      CALL C_F_POINTER(pd_u, un_d, (/ nij8 /)) ; CALL C_F_POINTER(pd_v, vn_d, (/ nij8 /))
@@ -165,6 +170,7 @@ PROGRAM cdfcurl
      CALL hip_check(cdft_host_alloc(ph_rot(2), INT(MERGE(8, 4, ldblpr) * nij8, C_SIZE_T)), 'cdft_host_alloc')
   ENDIF
 
+  CALL cdf_phase('device and page-locked arrays')
   DO jt = 1, npt
      IF ( MOD(jt, 100) == 0 ) PRINT *, jt, '/', npt
      IF ( lfeed ) THEN      ! level jk+1 is read and computed while level jk is on its way to the host and to the file
@@ -205,6 +211,7 @@ PROGRAM cdfcurl
         ENDIF
      END DO
   END DO
+  CALL cdf_phase('records')
   ierr = cdft_curl_destroy(plan)
   ierr = closeout(ncout)
   IF ( lfeed ) THEN
@@ -212,6 +219,7 @@ PROGRAM cdfcurl
      ierr = cdft_host_free(ph_rot(1)) ; ierr = cdft_host_free(ph_rot(2))
      CALL feed_close()
   ENDIF
+  CALL cdf_phase('destroy, close, release')
 
 CONTAINS
 

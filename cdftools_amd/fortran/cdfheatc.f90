@@ -93,9 +93,11 @@ PROGRAM cdfheatc
   PRINT *, 'npt    = ', npt
   PRINT *, 'nvpk   = ', nvpk
 
+  CALL cdf_phase('start -> arguments, dimensions')
   CALL hip_shard(ngpu, igpus)                                ! CDFT_GPUS / CDFT_GPU_MAP: row blocks over the node's GPUs
   lfeed = feed_wanted(4_8 * npiglo * npjglo * nvpk) .AND. ngpu == 1                      ! one device: file -> HBM through the ring (module cdffeed)
   nij8 = INT(npiglo, 8) * npjglo ; n38 = nij8 * nvpk
+  CALL cdf_phase('device count (the HIP runtime comes up)')
   ALLOCATE( e1t(npiglo,npjglo), e2t(npiglo,npjglo), gdepw(npk), gdepw_sel(nvpk), dtim(npt), dsums(3,nvpk) )
   IF ( .NOT. lfeed ) ALLOCATE( temp(npiglo,npjglo,nvpk), tmask(npiglo,npjglo,nvpk) )
   IF ( mxloption /= 0 ) ALLOCATE( rmxldep(npiglo,npjglo) )
@@ -109,6 +111,7 @@ PROGRAM cdfheatc
      e31d(:) = getvare3(cn_fzgr, cn_ve3t1d, npk)
      e31d_sel(:) = e31d(ikmin:ikmin + nvpk - 1)
   ENDIF
+  CALL cdf_phase('allocations, e1t e2t gdepw read')
   IF ( lfeed ) THEN
      pd_e1 = feed_device(4 * nij8) ; pd_e2 = feed_device(4 * nij8) ; pd_msk = feed_device(4 * n38) ; pd_t = feed_device(4 * n38)
      CALL C_F_POINTER(pd_e1, e1_d, (/ nij8 /)) ; CALL C_F_POINTER(pd_e2, e2_d, (/ nij8 /)) ; CALL C_F_POINTER(pd_t, temp_d, (/ n38 /))
@@ -124,18 +127,21 @@ PROGRAM cdfheatc
      CALL readvar3d(cn_fmsk, cv_msk, tmask, kimin=iimin, kjmin=ijmin, kkmin=ikmin)      ! (every level in one read)
   ENDIF
 
+  CALL cdf_phase('device arrays, ring, mask file -> HBM')
   CALL CreateOutput
   IF ( ngpu > 1 ) THEN
      CALL hip_check(cdft_heatc_create_sharded(plan, npiglo, npjglo, nvpk, ngpu, igpus), 'cdft_heatc_create_sharded')
   ELSE
      CALL hip_check(cdft_heatc_create(plan, npiglo, npjglo, nvpk), 'cdft_heatc_create')
   ENDIF
+  CALL cdf_phase('CreateOutput, plan')
   ! The reference's SUMs are REAL(KIND=4), added sequentially in memory order (src/cdfheatc.f90:225-229 as gfortran -O and
   ! flang -O1 compile them): the program returns exactly those values.  CDFT_HEATC_SUM=r8 asks for r8 sums instead -- the
   ! more accurate number (the two differ by 1e-4 relative at eORCA025) at the HBM roofline.
   CALL GET_ENVIRONMENT_VARIABLE('CDFT_HEATC_SUM', cldum)
   IF ( TRIM(cldum) /= 'r8' ) CALL hip_check(cdft_heatc_set_sum_mode(plan, CDFT_HEATC_SUM_R4SEQ), 'cdft_heatc_set_sum_mode')
 
+  CALL cdf_phase('sum mode')
   DO jt = 1, npt
      it = 1 ; IF ( lg_vvl ) it = jt
      dvol = 0.d0
@@ -191,6 +197,7 @@ PROGRAM cdfheatc
      dl_dum(1,1) = dl_dum(1,1) / dvol
      ierr = putvar(ncout, id_varout(jp_hcvol), dl_dum(:,:), 1, 1, 1, ktime=jt)
   END DO
+  CALL cdf_phase('records')
   ierr = cdft_heatc_destroy(plan)
   IF ( lfeed ) THEN
      CALL feed_release(pd_e1) ; CALL feed_release(pd_e2) ; CALL feed_release(pd_msk) ; CALL feed_release(pd_t)
@@ -198,6 +205,7 @@ PROGRAM cdfheatc
      CALL feed_close()
   ENDIF
   ierr = closeout(ncout)
+  CALL cdf_phase('destroy, release, close')
 
 CONTAINS
 

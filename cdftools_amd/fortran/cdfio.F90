@@ -84,6 +84,7 @@ MODULE cdfio
   PUBLIC :: getvar, getvar1d, getvare3, getvar3d, readvar3d, readvar3d_i1
   PUBLIC :: create, createvar, putatt, putheadervar, putvar, putvar1d, putvar0d, closeout, ERR_HDL
   PUBLIC :: putvar_behind, wait_writes                  ! (not in the reference: the host feed's write-behind)
+  PUBLIC :: cdf_phase                                   ! (not in the reference: CDFT_TIMING's phase lines)
   ! the rest of the reference's public list (src/cdfio.F90:173-180): none of the 18 programs of this build calls them; they
   ! are here so that another reference program finds the module surface whole (tests/fortran/cdfio_public.f90 calls each)
   PUBLIC :: copyatt, cvaratt, gettimeatt, puttimeatt, atted, getdimvar, getvarid
@@ -147,6 +148,19 @@ CONTAINS
     IF ( ntiming < 0 ) ntiming = MERGE(1, 0, env_is_one('CDFT_TIMING'))
     IF ( ntiming == 1 ) CALL SYSTEM_CLOCK(nclock0)
   END SUBROUTINE tic
+
+  SUBROUTINE cdf_phase(cdwhat)
+    !! CDFT_TIMING=1: one line on stderr per call, ' CDFT_PHASE <what> <seconds since the previous call (or the first cdfio timing call)>'
+    !! -- where a program's wall clock goes outside its reads, writes and library calls (not in the reference)
+    CHARACTER(LEN=*), INTENT(in) :: cdwhat
+    INTEGER(KIND=8), SAVE :: ilast = -1
+    INTEGER(KIND=8) :: inow, irate
+    IF ( ntiming < 0 ) ntiming = MERGE(1, 0, env_is_one('CDFT_TIMING'))
+    IF ( ntiming /= 1 ) RETURN
+    CALL SYSTEM_CLOCK(inow, irate)
+    IF ( ilast >= 0 ) WRITE(0,'(a,a,f9.3)') ' CDFT_PHASE ', cdwhat, DBLE(inow - ilast) / DBLE(irate)
+    ilast = inow
+  END SUBROUTINE cdf_phase
 
   SUBROUTINE toc(dtotal)
     REAL(KIND=8), INTENT(inout) :: dtotal

@@ -20,14 +20,14 @@ PROGRAM cdfmocsig
   USE cdffeed
   IMPLICIT NONE
 
-  INTEGER(KIND=4) :: ji, jk, jt, jbasin, jbin, it, npiglo, npjglo, npk, npt, nbins, narg, ijarg, ii, ncout, nbasins, nvaro, ierr
+  INTEGER(KIND=4) :: ji, jj, jk, jt, jbasin, jbin, it, npiglo, npjglo, npk, npt, nbins, narg, ijarg, ii, ncout, nbasins, nvaro, ierr
   INTEGER(KIND=4) :: npglo = 1, npatl = 2, npinp = 3, npind = 4, nppac = 5, iloc(2)
   INTEGER(KIND=4), ALLOCATABLE :: ipk(:), id_varout(:)
   INTEGER(KIND=2), ALLOCATABLE, TARGET :: ibmask(:,:,:)
   REAL(KIND=4) :: pref = 0., sigmin, sigstp, zsps, zspt, zspv, rp_spval = 99999.
   REAL(KIND=4), ALLOCATABLE, TARGET :: e3v(:,:,:), e31d(:), gdep(:), zveiv(:,:,:)
   REAL(KIND=4), ALLOCATABLE, TARGET :: e1v(:,:)
-  REAL(KIND=4), ALLOCATABLE :: gphiv(:,:), zv(:,:,:), zt(:,:,:), zs(:,:,:), rdumlon(:,:), rdumlat(:,:), sigma(:), zwk(:,:)
+  REAL(KIND=4), ALLOCATABLE :: gphiv(:,:), zv(:,:,:), zt(:,:,:), zs(:,:,:), rdumlon(:,:), rdumlat(:,:), sigma(:), zwk(:,:), zbas(:,:,:)
   REAL(KIND=8), ALLOCATABLE :: dtim(:)
   REAL(KIND=8), ALLOCATABLE, TARGET :: dmoc(:,:,:), depi(:,:,:)            ! (nbasins, nbins, npjglo)
   CHARACTER(LEN=256) :: cf_vfil, cf_tfil, cf_sfil, cf_moc = 'mocsig.nc', cldum, cglobal
@@ -160,13 +160,25 @@ PROGRAM cdfmocsig
   rdumlon(:,:) = 0.
   CALL CreateOutputFile
 
-  zwk(:,:) = getvar(cn_fmsk, cn_vmask, 1, npiglo, npjglo) ; ibmask(npglo,:,:) = INT(zwk, 2)
+  ! (the same values as the reference's five strided assignments and its WHERE, in one pass with the basin index innermost: cdfmoc.f90)
+  zwk(:,:) = getvar(cn_fmsk, cn_vmask, 1, npiglo, npjglo)
+  IF ( .NOT. lbas ) ibmask(npglo,:,:) = INT(zwk, 2)
   IF ( lbas ) THEN
-     zwk(:,:) = getvar(cn_fbasins, cn_tmaskatl, 1, npiglo, npjglo) ; ibmask(npatl,:,:) = INT(zwk, 2)
-     zwk(:,:) = getvar(cn_fbasins, cn_tmaskind, 1, npiglo, npjglo) ; ibmask(npind,:,:) = INT(zwk, 2)
-     zwk(:,:) = getvar(cn_fbasins, cn_tmaskpac, 1, npiglo, npjglo) ; ibmask(nppac,:,:) = INT(zwk, 2)
-     ibmask(npinp,:,:) = ibmask(nppac,:,:) + ibmask(npind,:,:)
-     WHERE ( ibmask(npinp,:,:) > 0 ) ibmask(npinp,:,:) = 1
+     ALLOCATE( zbas(npiglo, npjglo, 3) )
+     zbas(:,:,1) = getvar(cn_fbasins, cn_tmaskatl, 1, npiglo, npjglo)
+     zbas(:,:,2) = getvar(cn_fbasins, cn_tmaskind, 1, npiglo, npjglo)
+     zbas(:,:,3) = getvar(cn_fbasins, cn_tmaskpac, 1, npiglo, npjglo)
+     DO jj = 1, npjglo
+        DO ji = 1, npiglo
+           ibmask(npglo,ji,jj) = INT(zwk(ji,jj), 2)
+           ibmask(npatl,ji,jj) = INT(zbas(ji,jj,1), 2)
+           ibmask(npind,ji,jj) = INT(zbas(ji,jj,2), 2)
+           ibmask(nppac,ji,jj) = INT(zbas(ji,jj,3), 2)
+           ibmask(npinp,ji,jj) = ibmask(nppac,ji,jj) + ibmask(npind,ji,jj)
+           IF ( ibmask(npinp,ji,jj) > 0 ) ibmask(npinp,ji,jj) = 1
+        END DO
+     END DO
+     DEALLOCATE( zbas )
      ibmask(1,1,     :) = 0                                 ! global periodic condition (only with the basin file, :357-358)
      ibmask(1,npiglo,:) = 0
   ENDIF
