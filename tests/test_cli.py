@@ -30,7 +30,7 @@ def run(tool, args, cwd, env=None):
     e = dict(os.environ)
     e.update(env or {})
     # A program of a test grid takes a third of a second.  One run in several thousand did not end within 600 s once in round 5 and
-    # never again (tools/stress_feed.py: 1 869 runs in a row without one): a run that hangs is written down where the round's
+    # never again (tools/stress_feed.py: 1 869 runs through the ring and 1 403 on whole records in a row without one): a run that hangs is written down where the round's
     # outputs are kept and tried ONCE more -- two in a row fail the test with the program's name and what it had printed.
     for attempt in (1, 2):
         try:

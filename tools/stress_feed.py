@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Every program run of tests/test_cli_feed.py (the feed on, a ring of two one-plane slots: every slot wraps many times per field), over
-and over for STRESS_SECONDS (default 240), each with a 30 s limit.  A run that does not end is described -- the state and the
+and over for STRESS_SECONDS (default 240), each with a 30 s limit (STRESS_FEED=0: the same calls on whole records in pageable memory).  A run that does not end is described -- the state and the
 system call of each of its threads from /proc, a backtrace when rocgdb may attach -- before it is killed: a rare hang (one program
 run in about a thousand, seen once in round 5) names itself here.       python tools/stress_feed.py        (on the GPU box)"""
 import glob
@@ -54,7 +54,7 @@ def main():
     t0, runs, hung, slowest = time.time(), 0, [], (0.0, None)
     while time.time() - t0 < seconds:
         for tool, args, files, *more in tf.RUNS:
-            env = dict(os.environ, CDFT_FEED="1", **ring, **(more[0] if more else {}))
+            env = dict(os.environ, CDFT_FEED=os.environ.get("STRESS_FEED", "1"), **ring, **(more[0] if more else {}))
             p = subprocess.Popen([os.path.join(BIN, tool)] + args, cwd=d, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             t1 = time.time()
             try:
@@ -71,7 +71,7 @@ def main():
             if time.time() - t0 >= seconds:
                 break
     print(json.dumps({"program_runs": runs, "seconds": round(time.time() - t0, 1), "hung": hung, "slowest_s": round(slowest[0], 2), "slowest": slowest[1],
-                      "ring": ring}))
+                      "ring": ring, "feed": os.environ.get("STRESS_FEED", "1")}))
     sys.exit(1 if hung else 0)
 
 
