@@ -57,6 +57,7 @@ SIGNATURES = {
     "cdft_feed_slot": (_i, [_vp, _pvp, C.POINTER(_sz)]),
     "cdft_feed_push": (_i, [_vp, _vp, _sz, _sz]),
     "cdft_feed_push_rows": (_i, [_vp, _vp, _sz, _sz, _sz, _sz]),
+    "cdft_feed_push_i1_as_r4": (_i, [_vp, _vp, _sz, _sz]),
     "cdft_feed_stream": (_i, [_vp, _pvp]),
     "cdft_feed_wait": (_i, [_vp]),
     "cdft_feed_destroy": (_i, [_vp]),

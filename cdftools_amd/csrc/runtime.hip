@@ -249,6 +249,20 @@ __global__ void __launch_bounds__(256) feed_rows_kernel(const uint32_t *__restri
     }
 }
 
+// n signed bytes (what a NetCDF byte variable holds) widened to r4 at dst: the conversion netCDF's nf90_get_var makes on the host
+__global__ void __launch_bounds__(256) feed_i1_r4_kernel(const int8_t *__restrict__ src, float *__restrict__ dst, int64_t n) {
+    const int64_t n4 = n >> 2;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < n4; q += (int64_t)gridDim.x * 256) {
+        const uint32_t w = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(src) + q);
+        float4 v;
+        v.x = (float)(int8_t)(w & 0xffu); v.y = (float)(int8_t)((w >> 8) & 0xffu); v.z = (float)(int8_t)((w >> 16) & 0xffu); v.w = (float)(int8_t)(w >> 24);
+        float *o = dst + 4 * q;
+        if ((reinterpret_cast<uintptr_t>(o) & 15u) == 0) *reinterpret_cast<float4 *>(o) = v;
+        else { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+    }
+    if (blockIdx.x == 0 && (int64_t)threadIdx.x < n - 4 * n4) dst[4 * n4 + threadIdx.x] = (float)src[4 * n4 + threadIdx.x];
+}
+
 int cdft_feed_create(cdft_feed **feed, size_t slot_bytes, int nslots) {
     if (!feed) return fail(CDFT_ERR_ARG, "cdft_feed_create: NULL argument");
     *feed = nullptr;
@@ -354,6 +368,23 @@ int cdft_feed_push_rows(cdft_feed *f, void *dst, size_t dst_offset, size_t dst_p
                            (int64_t)(row_bytes / 4), (int64_t)(dst_pitch / 4), (int64_t)nrows);
         CDFT_LAUNCH_CHECK();
     }
+    CDFT_HIP(hipEventRecord(f->done[f->cur], f->st));
+    f->busy[f->cur] = 1;
+    f->cur = (f->cur + 1) % (int)f->slot.size();
+    return CDFT_OK;
+}
+
+int cdft_feed_push_i1_as_r4(cdft_feed *f, float *dst, size_t dst_offset, size_t n) {
+    if (!f || !dst) return fail(CDFT_ERR_ARG, "cdft_feed_push_i1_as_r4: NULL argument");
+    if (n == 0 || n > f->slot_bytes) return fail(CDFT_ERR_ARG, "cdft_feed_push_i1_as_r4: %zu bytes for a slot of %zu", n, f->slot_bytes);
+    if (f->slot.empty()) return fail(CDFT_ERR_STATE, "cdft_feed_push_i1_as_r4: the ring has no slots");
+    DevBuf &b = f->bounce[f->bcur];                              // (the two buffers of cdft_feed_push_rows: stream order keeps them apart)
+    f->bcur ^= 1;
+    CDFT_TRY(b.reserve(f->slot_bytes));
+    CDFT_HIP(hipMemcpyAsync(b.ptr, f->slot[f->cur], n, hipMemcpyHostToDevice, f->st));
+    const unsigned grid = (unsigned)std::min<size_t>((n / 4 + 255) / 256 + 1, 16384);
+    hipLaunchKernelGGL(feed_i1_r4_kernel, dim3(grid), dim3(256), 0, f->st, (const int8_t *)b.ptr, dst + dst_offset, (int64_t)n);
+    CDFT_LAUNCH_CHECK();
     CDFT_HIP(hipEventRecord(f->done[f->cur], f->st));
     f->busy[f->cur] = 1;
     f->cur = (f->cur + 1) % (int)f->slot.size();

@@ -17,6 +17,7 @@ MODULE cdffeed
   !!======================================================================
   USE ISO_C_BINDING
   USE cdfio
+  USE modcdfnames, ONLY : cn_x, cn_y
   USE cdftools_hip
   IMPLICIT NONE
   PRIVATE
@@ -50,6 +51,12 @@ CONTAINS
     CALL GET_ENVIRONMENT_VARIABLE('CDFT_FEED_MIN_MB', cl) ; IF ( LEN_TRIM(cl) > 0 ) READ(cl, *) imin
     feed_wanted = ( kfield >= INT(imin, 8) * 1048576_8 )
   END FUNCTION feed_wanted
+
+  LOGICAL FUNCTION feed_bytes_wanted()
+    CHARACTER(LEN=16) :: cl
+    CALL GET_ENVIRONMENT_VARIABLE('CDFT_FEED_BYTES', cl)
+    feed_bytes_wanted = ( cl(1:1) /= '0' )
+  END FUNCTION feed_bytes_wanted
 
   SUBROUTINE feed_open()
     !! the feed's stream, with a ring of token size: the slots proper come with the first field (feed_size)
@@ -121,11 +128,37 @@ CONTAINS
     INTEGER(C_SIZE_T) :: ibytes
     TYPE(C_PTR) :: pslot
     REAL(KIND=4), POINTER :: zslab(:,:,:)
+    INTEGER(KIND=1), POINTER :: islabs(:,:,:)
+    LOGICAL :: ll_whole, ll_bytes
+    ll_bytes = .FALSE.
     islab = 4_8 * kpi * kpj
     CALL feed_size(islab, islab * kpk)
-    inlmax = INT(MAX(1_8, nslot_bytes / islab), 4)
     ikfirst = 1 ; IF ( PRESENT(kkmin) ) ikfirst = kkmin
     iplane = 1  ; IF ( PRESENT(kplane) ) iplane = kplane
+    ! A field the file holds as bytes (the masks of mask.nc), read whole in i and j: the bytes go through the ring and are widened to
+    ! r4 in HBM (cdft_feed_push_i1_as_r4) -- a quarter of the host conversion and of the PCIe transfer of a 4.7 GB r4 mask at eORCA12.
+    ! CDFT_FEED_BYTES=0: the r4 way.
+    ll_whole = .NOT. PRESENT(ldiom) .AND. kpk >= 1
+    IF ( PRESENT(kimin) ) ll_whole = ll_whole .AND. kimin == 1
+    IF ( PRESENT(kjmin) ) ll_whole = ll_whole .AND. kjmin == 1
+    IF ( ll_whole ) THEN
+       IF ( feed_bytes_wanted() ) THEN
+          IF ( var_is_plain_bytes(cdfile, cdvar) ) ll_bytes = getdim(cdfile, cn_x, ldexact=.TRUE.) == kpi .AND. getdim(cdfile, cn_y) == kpj
+          IF ( ll_bytes ) THEN
+             inlmax = INT(MAX(1_8, nslot_bytes / ( islab / 4 )), 4)
+             DO ik0 = 1, kpk, inlmax
+                inl = MIN(inlmax, kpk - ik0 + 1)
+                CALL hip_check(cdft_feed_slot(hfeed, pslot, ibytes), 'cdft_feed_slot')
+                CALL C_F_POINTER(pslot, islabs, (/ kpi, kpj, inl /))
+                CALL readvar3d_i1(cdfile, cdvar, islabs, ktime=ktime, kkmin=ikfirst + ik0 - 1)
+                CALL hip_check(cdft_feed_push_i1_as_r4(hfeed, pdev, INT(( islab / 4 ) * (iplane + ik0 - 2), C_SIZE_T),  &
+                     &         INT(( islab / 4 ) * inl, C_SIZE_T)), 'cdft_feed_push_i1_as_r4')
+             END DO
+             RETURN
+          ENDIF
+       ENDIF
+    ENDIF
+    inlmax = INT(MAX(1_8, nslot_bytes / islab), 4)
     DO ik0 = 1, kpk, inlmax
        inl = MIN(inlmax, kpk - ik0 + 1)
        CALL hip_check(cdft_feed_slot(hfeed, pslot, ibytes), 'cdft_feed_slot')

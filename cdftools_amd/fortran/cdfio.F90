@@ -81,7 +81,7 @@ MODULE cdfio
   END INTERFACE
 
   PUBLIC :: chkfile, chkvar, getdim, getvdim, getspval, getatt, getvaratt, getnvar, getvarname, getipk
-  PUBLIC :: getvar, getvar1d, getvare3, getvar3d, readvar3d, readvar3d_i1
+  PUBLIC :: getvar, getvar1d, getvare3, getvar3d, readvar3d, readvar3d_i1, var_is_plain_bytes
   PUBLIC :: create, createvar, putatt, putheadervar, putvar, putvar1d, putvar0d, closeout, ERR_HDL
   PUBLIC :: putvar_behind, wait_writes                  ! (not in the reference: the host feed's write-behind)
   PUBLIC :: cdf_phase                                   ! (not in the reference: CDFT_TIMING's phase lines)
@@ -1141,6 +1141,28 @@ CONTAINS
     CALL src_detach(ncid)
     CALL toc(dtime_read)
   END SUBROUTINE readvar3d
+
+  LOGICAL FUNCTION var_is_plain_bytes(cdfile, cdvar)
+    !! whether cdvar of cdfile is stored as bytes with levels and without scale_factor / add_offset / savelog10: its values are what
+    !! readvar3d_i1 returns, widened -- so that a caller may move the bytes and widen them where they are used (module cdffeed)
+    CHARACTER(LEN=*), INTENT(in) :: cdfile, cdvar
+    INTEGER(KIND=4) :: ncid, ivar, itype, indims, ifirst(4)
+    LOGICAL :: ll_levels
+    TYPE(t_pack) :: tp
+    var_is_plain_bytes = .FALSE.
+    IF ( src_attach(cdfile, ncid) /= NF90_NOERR ) RETURN
+    IF ( NF90_INQ_VARID(ncid, cdvar, ivar) == NF90_NOERR ) THEN
+       IF ( NF90_INQUIRE_VARIABLE(ncid, ivar, xtype=itype, ndims=indims) == NF90_NOERR ) THEN
+          IF ( itype == NF90_BYTE .AND. indims >= 3 ) THEN
+             tp = pack_of(ncid, ivar, cdvar)
+             ifirst = 1
+             CALL place_slab(ncid, ivar, 1, 1, ifirst, ll_levels)
+             var_is_plain_bytes = ll_levels .AND. .NOT. ( tp%lscale .OR. tp%loffset .OR. tp%llog10 )
+          ENDIF
+       ENDIF
+    ENDIF
+    CALL src_detach(ncid)
+  END FUNCTION var_is_plain_bytes
 
   SUBROUTINE readvar3d_i1(cdfile, cdvar, ktab, ktime, kkmin)
     !! a whole 3-D mask (or its levels from kkmin on) as bytes (the backend converts when the file holds another type); a

@@ -79,6 +79,9 @@ MODULE cdftools_hip
      INTEGER(C_INT) FUNCTION cdft_feed_push_rows(feed, dst, dst_offset, dst_pitch, row_bytes, nrows) BIND(C, name='cdft_feed_push_rows')
        IMPORT ; TYPE(C_PTR), VALUE :: feed, dst ; INTEGER(C_SIZE_T), VALUE :: dst_offset, dst_pitch, row_bytes, nrows
      END FUNCTION
+     INTEGER(C_INT) FUNCTION cdft_feed_push_i1_as_r4(feed, dst, dst_offset, n) BIND(C, name='cdft_feed_push_i1_as_r4')
+       IMPORT ; TYPE(C_PTR), VALUE :: feed, dst ; INTEGER(C_SIZE_T), VALUE :: dst_offset, n
+     END FUNCTION
      INTEGER(C_INT) FUNCTION cdft_feed_stream(feed, stream) BIND(C, name='cdft_feed_stream')
        IMPORT ; TYPE(C_PTR), VALUE :: feed ; TYPE(C_PTR), INTENT(out) :: stream
      END FUNCTION

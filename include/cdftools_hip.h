@@ -83,6 +83,10 @@ int         cdft_feed_push(cdft_feed *feed, void *dst, size_t dst_offset, size_t
  * starts -- e.g. straight into the slots of cdfmoc's pool (cdft_moc_stage_dest), so that the H2D copy IS the staging.  One
  * linear DMA into HBM and a row-spreading kernel behind it on the feed's stream; CDFT_FEED_ROWS=2d: one hipMemcpy2DAsync. */
 int         cdft_feed_push_rows(cdft_feed *feed, void *dst, size_t dst_offset, size_t dst_pitch, size_t row_bytes, size_t nrows);
+/* cdft_feed_push for a field the file holds as BYTES (the masks of mask.nc) and the kernels want as r4: the slot holds n signed bytes;
+ * they cross PCIe as bytes and are widened to r4 at dst + dst_offset ELEMENTS by a kernel on the feed's stream -- the conversion
+ * nf90_get_var makes on the host when the reference reads a byte mask into its r4 slab (src/cdfio.F90:1593), a quarter of the transfer. */
+int         cdft_feed_push_i1_as_r4(cdft_feed *feed, float *dst, size_t dst_offset, size_t n);
 int         cdft_feed_stream(cdft_feed *feed, void **stream);
 int         cdft_feed_wait(cdft_feed *feed);
 int         cdft_feed_destroy(cdft_feed *feed);

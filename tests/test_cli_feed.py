@@ -172,3 +172,35 @@ def test_eos_results_into_page_locked_arrays(gpu):
     assert np.array_equal(got[0], want) and np.array_equal(got[1], want0) and not np.array_equal(want, want0)
     for p in bufs:
         gpu.check(lib.cdft_host_free(p))
+
+
+@pytest.mark.gpu
+def test_bytes_through_the_ring_widened_to_r4_in_hbm(gpu):
+    """cdft_feed_push_i1_as_r4: a slot of signed bytes (a NetCDF byte mask) arrives in HBM as the r4 values nf90_get_var would have made of
+    them on the host -- any count (tails that are not a multiple of 4), any element offset (stores that are not 16-byte aligned)"""
+    import ctypes as C
+
+    import numpy as np
+    import torch
+    from cdftools_amd import _lib
+    lib = _lib.load()
+    feed = C.c_void_p()
+    gpu.check(lib.cdft_feed_create(C.byref(feed), 1 << 16, 2))
+    rng = np.random.default_rng(3)
+    dst = torch.full((300000,), -7.0, dtype=torch.float32, device="cuda")
+    want = np.full(300000, -7.0, np.float32)
+    off = 0
+    for n in (1, 2, 3, 4, 5, 63, 64, 65, 1023, 4097, 65536, 7, 40001):
+        host, nb = C.c_void_p(), C.c_size_t()
+        gpu.check(lib.cdft_feed_slot(feed, C.byref(host), C.byref(nb)))
+        b = rng.integers(-128, 128, n, dtype=np.int8)
+        np.frombuffer((C.c_char * n).from_address(host.value), dtype=np.int8)[:] = b
+        gpu.check(lib.cdft_feed_push_i1_as_r4(feed, C.c_void_p(dst.data_ptr()), off, n))
+        want[off:off + n] = b.astype(np.float32)
+        off += n + (n % 3)                                         # (gaps: what lies between two pushes is not touched)
+    gpu.check(lib.cdft_feed_wait(feed))
+    torch.cuda.synchronize()
+    assert np.array_equal(dst.cpu().numpy(), want)
+    assert lib.cdft_feed_push_i1_as_r4(feed, C.c_void_p(dst.data_ptr()), 0, (1 << 16) + 1) != 0       # more than a slot holds
+    gpu.check(lib.cdft_feed_destroy(feed))
+
