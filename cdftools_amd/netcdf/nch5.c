@@ -46,12 +46,12 @@ static unsigned long g_chunks_read, g_chunks_written;
 unsigned long nch5_chunks_inflated(void) { return g_chunks_read; }
 unsigned long nch5_chunks_deflated(void) { return g_chunks_written; }
 
-/* threads that inflate / deflate chunks: CDFT_IO_THREADS, else half the cores between 8 and 32 (deflate of a 2 MB chunk of
- * floats is ~25 ms: a level of eORCA12 is 31 of them) */
+/* threads that inflate / deflate chunks: CDFT_IO_THREADS, else half the cores between 8 and 64 (deflate of a 2 MB chunk of
+ * floats is ~25 ms: a level of eORCA12 is 31 of them, a slab of the feed 62) */
 static int filter_threads(void) {
     int n = 8;
     const long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
-    if (ncpu / 2 > n) n = ncpu / 2 > 32 ? 32 : (int)(ncpu / 2);
+    if (ncpu / 2 > n) n = ncpu / 2 > 64 ? 64 : (int)(ncpu / 2);
     const char *e = getenv("CDFT_IO_THREADS");
     if (e && atoi(e) >= 1) n = atoi(e);
     return n > 64 ? 64 : n;
