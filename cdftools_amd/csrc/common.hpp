@@ -36,6 +36,11 @@ int to_device(const void *src, size_t n, int memspace, DevBuf &stage, hipStream_
 // goes to the runtime under its lock every time; a launch that follows it cannot have been queued behind the previous kernel).
 int dyn_lds_once(const void *kernel, int bytes);
 
+// cdfmoc -decomp's r8 zonal sums on the zonal class kernel (zonal.hip): see there
+bool zonal_class_fits_moc(int npi, int nclass);
+int zonal_class_moc_r8(const float *w, const double *field, const uint8_t *cls, const uint8_t *pat, int nclass, int npi, int npj, int nlev, int nb,
+                       double *raw, hipStream_t st);
+
 // A named range around a C-ABI call.  CDFT_ROCTX=1: a roctx range for rocprofv3 --marker-trace (the roctx library is looked
 // up at run time: no link dependency, nothing when it is absent).  CDFT_TIMING=1: the wall time of the call (as the caller
 // sees it: a call that returns host results includes its stream synchronisation) is added to a per-entry total, printed

@@ -1192,6 +1192,13 @@ int cdft_moc_decomp(cdft_moc_plan *p, const float *zv, const float *ztemp, const
     float *hdep = (float *)p->d_hdep.ptr, *zvgeo = (float *)p->d_zvgeo.ptr;
     const dim3 g2((unsigned)((nij + 255) / 256)), b2(256), grow((unsigned)npj * (unsigned)npk);
     auto zonal_r8 = [&](const double *field, double *raw) -> int {
+        // the class kernel of cdfzonalsum (a term added to ONE slot instead of nb select-adds and a five-sum wave reduction per row);
+        // CDFT_DEC_ZONAL=select: the round-2 kernel (A/B and test hook)
+        {
+            const char *ez = getenv("CDFT_DEC_ZONAL");
+            if (!(ez && ez[0] == 's') && npk >= 2 && zonal_class_fits_moc(npi, p->nclass))
+                return zonal_class_moc_r8(p->w, field, p->cls, p->pat, p->nclass, npi, npj, npk - 1, nb, raw, st);
+        }
         if (nb == 1)      hipLaunchKernelGGL((dec_zonal_r8_kernel<1>), grow, b2, 0, st, p->w, p->bits, field, npi, npj, npk, nb, raw, (int64_t)npi);
         else if (nb <= 5) hipLaunchKernelGGL((dec_zonal_r8_kernel<5>), grow, b2, 0, st, p->w, p->bits, field, npi, npj, npk, nb, raw, (int64_t)npi);
         else              hipLaunchKernelGGL((dec_zonal_r8_kernel<8>), grow, b2, 0, st, p->w, p->bits, field, npi, npj, npk, nb, raw, (int64_t)npi);

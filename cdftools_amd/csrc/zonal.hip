@@ -271,6 +271,7 @@ struct ZonalClassArgs {
     int lc;                       // level chunks: workgroup = (chunk, row)
     int lev_max;                  // levels of the longest chunk (the LDS layout behind the slots)
     int *rowflag;                 // MINMAX: rows holding a NaN / Inf (zeroed before the launch)
+    double *moc_out;              // NOMASK: (nb, npj, nlev + 1) r8, the negated sums in cdfmoc's order
     int xcd_map;                  // workgroup -> (chunk, row) so that each XCD takes an eighth of the rows
 };
 
@@ -284,7 +285,10 @@ typedef uint32_t u32u __attribute__((aligned(1)));               // 4 mask bytes
 // extremum because rounding is monotone), updated by ds_max_f32 / ds_min_f32; a cell outside a basin enters its maximum as 0
 // (dtmp = 0 there) and never its minimum (dtmp /= 0).  A row that holds a NaN / Inf is flagged for the general kernel, as the
 // select kernel does (fmax / fmin drop a NaN the reference's MAX keeps or not by position).
-template <int NV, bool MEAN, int T, bool M8, bool MINMAX>
+// NOMASK (cdfmoc -decomp, src/cdfmoc.f90:397-419, :472-478): no level mask -- the streamed field IS the masked weight e1v*e3v of
+// cdfmoc and `surf` the r8 field of the row (the barotropic or the shear velocity): the term is surf * (double)z, and the result goes out
+// negated in cdfmoc's (basin, row, level) order (ca.moc_out), level nlev + 1 written as -0.
+template <int NV, bool MEAN, int T, bool M8, bool MINMAX, bool NOMASK = false>
 __global__ void __launch_bounds__(T) zonal_row_class_kernel(ZonalArgs2 a, ZonalClassArgs ca) {
     extern __shared__ double lds[];
     constexpr int nwaves = T / 64;
@@ -350,6 +354,7 @@ __global__ void __launch_bounds__(T) zonal_row_class_kernel(ZonalArgs2 a, ZonalC
         for (int r = 0; r < NV; ++r) {
             const int i0 = i0_of(r, tx);
             z[r] = ld_stream4u(zv + i0);
+            if (NOMASK) continue;
             if (M8) mk[r].b = __builtin_nontemporal_load(reinterpret_cast<const u32u *>(a.mask8 + (int64_t)k * nij + r2 + i0));
             else    mk[r].v = ld_stream4u(a.mask3 + (int64_t)k * nij + r2 + i0);
         }
@@ -363,8 +368,9 @@ __global__ void __launch_bounds__(T) zonal_row_class_kernel(ZonalArgs2 a, ZonalC
             const float z4[4] = {zc[r].x, zc[r].y, zc[r].z, zc[r].w};
             uint32_t pk = cpk[r];
             asm volatile("" : "+v"(pk));                // (or the 4 * NV slot addresses are hoisted into registers)
-            float m4[4];
-            if (M8) {
+            float m4[4] = {1.f, 1.f, 1.f, 1.f};
+            if (NOMASK) {
+            } else if (M8) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) m4[c] = (float)((mc[r].b >> (8 * c)) & 0xffu);
             } else {
@@ -373,7 +379,7 @@ __global__ void __launch_bounds__(T) zonal_row_class_kernel(ZonalArgs2 a, ZonalC
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 // zmask = 1: sum form (1.f*m)*z = m*z in r4; mean form ((1.d0*1)*m)*z = m*z in r8
-                const double dt = MEAN ? __dmul_rn((double)m4[c], (double)z4[c]) : (double)__fmul_rn(m4[c], z4[c]);
+                const double dt = NOMASK ? (double)z4[c] : MEAN ? __dmul_rn((double)m4[c], (double)z4[c]) : (double)__fmul_rn(m4[c], z4[c]);
                 const uint32_t cl = (pk >> (8 * c)) & 0xffu;
                 (void)__hip_atomic_fetch_add(&scr[cl * kZStride + lane], __dmul_rn(sf[r][c], dt), __ATOMIC_RELAXED,
                                              __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -437,6 +443,7 @@ __global__ void __launch_bounds__(T) zonal_row_class_kernel(ZonalArgs2 a, ZonalC
     } else {
         __syncthreads();
     }
+    if (NOMASK && chunk == 0 && (int)threadIdx.x < a.nb) ca.moc_out[((int64_t)a.nlev * a.npj + jj) * a.nb + threadIdx.x] = -0.0;
     for (int t = threadIdx.x; t < (k1 - k0) * a.nb; t += T) {
         const int kk = t / a.nb, b = t - kk * a.nb, k = k0 + kk;
         double s = 0.0, z = 0.0;
@@ -448,7 +455,8 @@ __global__ void __launch_bounds__(T) zonal_row_class_kernel(ZonalArgs2 a, ZonalC
                 else    z += v;
             }
         }
-        a.dsum[((int64_t)b * a.nlev + k) * a.npj + jj] = s + __dmul_rn(z, 0.0);
+        if (NOMASK) ca.moc_out[((int64_t)k * a.npj + jj) * a.nb + b] = -(s + __dmul_rn(z, 0.0));
+        else        a.dsum[((int64_t)b * a.nlev + k) * a.npj + jj] = s + __dmul_rn(z, 0.0);
         if (MINMAX) {
             float tx = -1.e20f, tn = 1.e20f;
             for (int c = 0; c < ca.nclass; ++c) {
@@ -475,6 +483,11 @@ int launch_class_nv(const ZonalArgs2 &a, const ZonalClassArgs &ca, bool mean, bo
     size_t shmem = ((size_t)nw * (kZC + 1) * kZStride + (size_t)ca.lev_max * kZC * nw) * sizeof(double);
     if (minmax) shmem += ((size_t)nw * 2 * (kZC + 1) * kZStride + (size_t)ca.lev_max * kZC * nw * 2) * sizeof(float);
     const dim3 grid(ca.xcd_map ? 8 * ((a.npj + 7) / 8) * ca.lc : a.npj * ca.lc);
+    if (ca.moc_out) {                                             // cdfmoc -decomp: the weight streamed past an r8 field, no level mask
+        hipLaunchKernelGGL((zonal_row_class_kernel<NV, false, T, false, false, true>), grid, dim3(T), shmem, st, a, ca);
+        CDFT_LAUNCH_CHECK();
+        return CDFT_OK;
+    }
     if (minmax) {                                                 // (-max is an option of the MEAN form, src/cdfzonalmean.f90:147)
         const void *kf = a.mask8 ? (const void *)zonal_row_class_kernel<NV, true, T, true, true> : (const void *)zonal_row_class_kernel<NV, true, T, false, true>;
         if (shmem > 48 * 1024) CDFT_TRY(dyn_lds_once(kf, (int)shmem));
@@ -578,6 +591,24 @@ int launch_area(const ZonalArgs2 &a, hipStream_t st) {
 }
 
 }  // namespace
+
+namespace cdft {
+// cdfmoc -decomp's r8 zonal sums (moc.hip) on this file's class kernel: raw(b, jj, jk) = -sum_i (double)w(i, jj, jk) * field(i, jj) over the cells of
+// basin b, jk < nlev; raw(b, jj, nlev) = -0.  cls / pat / nclass: the plan's classes of basin-bit patterns (moc.hip).  false: the shape does not fit
+// (rows under 4 or over 5116 cells, more than 8 patterns): the caller keeps its select kernel.
+bool zonal_class_fits_moc(int npi, int nclass) { return nclass > 0 && nclass <= kZC && class_fits(npi); }
+int zonal_class_moc_r8(const float *w, const double *field, const uint8_t *cls, const uint8_t *pat, int nclass, int npi, int npj, int nlev, int nb,
+                       double *raw, hipStream_t st) {
+    ZonalArgs2 a;
+    a.surf = field; a.mask3 = nullptr; a.bmask = nullptr; a.zv = w; a.mask8 = nullptr;
+    a.npi = npi; a.npj = npj; a.nlev = nlev; a.nb = nb;
+    a.dsum = nullptr; a.darea = nullptr; a.rmax = nullptr; a.rmin = nullptr;
+    ZonalClassArgs ca;
+    ca.cls = cls; ca.nclass = nclass; ca.rowflag = nullptr; ca.moc_out = raw;
+    for (int c = 0; c < kZC; ++c) ca.pat[c] = c < nclass ? pat[c] : 0;
+    return launch_class(a, ca, false, false, st);
+}
+}  // namespace cdft
 
 extern "C" {
 
@@ -736,7 +767,7 @@ int cdft_zonal_compute(cdft_zonal_plan *p, const float *zv, int nlev, int in_spa
     const bool class_minmax = !(getenv("CDFT_ZONAL_MAX_SELECT"));                    // A/B hook: -max on the select kernel (rounds 2-4)
     if (p->binary && !force_general && !no_class && (!minmax || class_minmax) && p->nclass > 0 && class_fits(p->npi)) {
         ZonalClassArgs ca;
-        ca.cls = p->cls; ca.nclass = p->nclass; ca.rowflag = p->rowflag;
+        ca.cls = p->cls; ca.nclass = p->nclass; ca.rowflag = p->rowflag; ca.moc_out = nullptr;
         for (int c = 0; c < kZC; ++c) ca.pat[c] = p->pat[c];
         if (minmax) CDFT_HIP(hipMemsetAsync(p->rowflag, 0, (size_t)p->npj * sizeof(int), st));
         CDFT_TRY(launch_class(a, ca, mean_form != 0, minmax, st));
