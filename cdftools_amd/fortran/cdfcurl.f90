@@ -127,12 +127,12 @@ PROGRAM cdfcurl
   ENDIF
 
   IF ( l_metric ) THEN
-     e1u  = getvar(cn_fhgr, cn_ve1u, 1, npiglo, npjglo)
-     e1f  = getvar(cn_fhgr, cn_ve1f, 1, npiglo, npjglo)
-     e2v  = getvar(cn_fhgr, cn_ve2v, 1, npiglo, npjglo)
-     e2f  = getvar(cn_fhgr, cn_ve2f, 1, npiglo, npjglo)
-     zlon = getvar(cn_fhgr, cn_glamf, 1, npiglo, npjglo)
-     zlat = getvar(cn_fhgr, cn_gphif, 1, npiglo, npjglo)
+     CALL getvar_to(cn_fhgr, cn_ve1u, 1, e1u)
+     CALL getvar_to(cn_fhgr, cn_ve1f, 1, e1f)
+     CALL getvar_to(cn_fhgr, cn_ve2v, 1, e2v)
+     CALL getvar_to(cn_fhgr, cn_ve2f, 1, e2f)
+     CALL getvar_to(cn_fhgr, cn_glamf, 1, zlon)
+     CALL getvar_to(cn_fhgr, cn_gphif, 1, zlat)
   ELSE
      e1u = 1. ; e1f = 1. ; e2v = 1. ; e2f = 1. ; zlon = 10. ; zlat = 10.
   ENDIF
@@ -187,8 +187,8 @@ PROGRAM cdfcurl
      ENDIF
      DO jk = 1, nlev
         PRINT *, TRIM(cf_ufil), ' ', TRIM(cv_u), ' ', jk, nilev(jk), npiglo, npjglo, jt
-        un(:,:,jk) = getvar(cf_ufil, cv_u, nilev(jk), npiglo, npjglo, ktime=jt)
-        vn(:,:,jk) = getvar(cf_vfil, cv_v, nilev(jk), npiglo, npjglo, ktime=jt)
+        CALL getvar_to(cf_ufil, cv_u, nilev(jk), un(:,:,jk), ktime=jt)
+        CALL getvar_to(cf_vfil, cv_v, nilev(jk), vn(:,:,jk), ktime=jt)
         IF ( lforcing ) THEN                                 ! A grid -> U and V points (:250-258); the last
            DO ji = 1, npiglo - 1                             ! column of un / row of vn is not used by the stencil
               un(ji,:,jk) = 0.5*( un(ji,:,jk) + un(ji+1,:,jk) )

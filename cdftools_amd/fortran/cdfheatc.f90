@@ -103,8 +103,8 @@ PROGRAM cdfheatc
   IF ( mxloption /= 0 ) ALLOCATE( rmxldep(npiglo,npjglo) )
   IF ( lfull ) THEN ; ALLOCATE( e31d(npk), e31d_sel(nvpk) ) ; ELSE IF ( .NOT. lfeed ) THEN ; ALLOCATE( e3t(npiglo,npjglo,nvpk) ) ; ENDIF
 
-  e1t(:,:) = getvar(cn_fhgr, cn_ve1t, 1, npiglo, npjglo, kimin=iimin, kjmin=ijmin)
-  e2t(:,:) = getvar(cn_fhgr, cn_ve2t, 1, npiglo, npjglo, kimin=iimin, kjmin=ijmin)
+  CALL getvar_to(cn_fhgr, cn_ve1t, 1, e1t(:,:), kimin=iimin, kjmin=ijmin)
+  CALL getvar_to(cn_fhgr, cn_ve2t, 1, e2t(:,:), kimin=iimin, kjmin=ijmin)
   gdepw(:) = getvare3(cn_fzgr, cn_gdepw, npk)
   gdepw_sel(:) = gdepw(ikmin:ikmin + nvpk - 1)
   IF ( lfull ) THEN
@@ -149,7 +149,7 @@ PROGRAM cdfheatc
      PRINT *, 'TIME : ', dtim(jt)
      pmxl = C_NULL_PTR ; pdepw = C_NULL_PTR
      IF ( mxloption /= 0 ) THEN
-        rmxldep(:,:) = getvar(cf_mfil, cn_somxl010, 1, npiglo, npjglo, kimin=iimin, kjmin=ijmin, ktime=jt)
+        CALL getvar_to(cf_mfil, cn_somxl010, 1, rmxldep(:,:), kimin=iimin, kjmin=ijmin, ktime=jt)
         pmxl = C_LOC(rmxldep) ; pdepw = C_LOC(gdepw_sel)
         IF ( lfeed ) THEN ; CALL feed_host(pmxl, 4 * nij8, pd_mxl) ; pmxl = pd_mxl ; ENDIF
      ENDIF

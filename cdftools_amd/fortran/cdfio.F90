@@ -81,7 +81,7 @@ MODULE cdfio
   END INTERFACE
 
   PUBLIC :: chkfile, chkvar, getdim, getvdim, getspval, getatt, getvaratt, getnvar, getvarname, getipk
-  PUBLIC :: getvar, getvar1d, getvare3, getvar3d, readvar3d, readvar3d_i1, var_is_plain_bytes
+  PUBLIC :: getvar, getvar1d, getvare3, getvar3d, readvar3d, readvar3d_i1, var_is_plain_bytes, getvar_to
   PUBLIC :: create, createvar, putatt, putheadervar, putvar, putvar1d, putvar0d, closeout, ERR_HDL
   PUBLIC :: putvar_behind, wait_writes                  ! (not in the reference: the host feed's write-behind)
   PUBLIC :: cdf_phase                                   ! (not in the reference: CDFT_TIMING's phase lines)
@@ -1052,9 +1052,21 @@ CONTAINS
     INTEGER(KIND=4), OPTIONAL, INTENT(in) :: kimin, kjmin, ktime
     LOGICAL,         OPTIONAL, INTENT(in) :: ldiom
     REAL(KIND=4), DIMENSION(kpi,kpj) :: getvar
-    INTEGER(KIND=4) :: ncid, ivar, ierr, iwest, ifirst(4), ishape(4)
+    CALL getvar_to(cdfile, cdvar, klev, getvar, kimin, kjmin, ktime, ldiom)
+  END FUNCTION getvar
+
+  SUBROUTINE getvar_to(cdfile, cdvar, klev, ptab, kimin, kjmin, ktime, ldiom)
+    !! getvar's slab read straight into the caller's array ptab (its shape is the window): what getvar returns, without the function
+    !! result -- 62 MB at eORCA12, whose allocation, first touch and copy cost twice the read itself (not in the reference's cdfio).
+    CHARACTER(LEN=*),          INTENT(in)  :: cdfile, cdvar
+    INTEGER(KIND=4), OPTIONAL, INTENT(in)  :: klev
+    REAL(KIND=4), CONTIGUOUS,  INTENT(out) :: ptab(:,:)
+    INTEGER(KIND=4), OPTIONAL, INTENT(in)  :: kimin, kjmin, ktime
+    LOGICAL,         OPTIONAL, INTENT(in)  :: ldiom
+    INTEGER(KIND=4) :: ncid, ivar, ierr, iwest, ifirst(4), ishape(4), kpi, kpj
     CHARACTER(LEN=256) :: cl_name
     TYPE(t_pack) :: tp
+    kpi = SIZE(ptab, 1) ; kpj = SIZE(ptab, 2)
     cl_name = zgr_name(cdvar, ldiom)
     iwest = kpi                                         ! columns taken before the eastern edge (kpi: the window does not wrap)
     IF ( PRESENT(kimin) ) iwest = MIN(kpi, getdim(cdfile, cn_x, ldexact=.TRUE.) - kimin)
@@ -1069,17 +1081,17 @@ CONTAINS
     IF ( iwest < kpi ) THEN
        ierr = NF90_NOERR
        ishape(1) = iwest
-       IF ( iwest > 0 ) ierr = NF90_GET_VAR(ncid, ivar, getvar(1:iwest,:), start=ifirst, count=ishape)
+       IF ( iwest > 0 ) ierr = NF90_GET_VAR(ncid, ivar, ptab(1:iwest,:), start=ifirst, count=ishape)
        ifirst(1) = 2 ; ishape(1) = kpi - iwest
-       IF ( ierr == NF90_NOERR ) ierr = NF90_GET_VAR(ncid, ivar, getvar(iwest+1:kpi,:), start=ifirst, count=ishape)
+       IF ( ierr == NF90_NOERR ) ierr = NF90_GET_VAR(ncid, ivar, ptab(iwest+1:kpi,:), start=ifirst, count=ishape)
     ELSE
-       ierr = NF90_GET_VAR(ncid, ivar, getvar, start=ifirst, count=ishape)
+       ierr = NF90_GET_VAR(ncid, ivar, ptab, start=ifirst, count=ishape)
     ENDIF
     CALL give_up(ierr, 'getvar', cl_name)
-    CALL pack_apply(tp, getvar, INT(kpi, 8) * kpj)
+    CALL pack_apply(tp, ptab, INT(kpi, 8) * kpj)
     CALL src_detach(ncid)
     CALL toc(dtime_read)
-  END FUNCTION getvar
+  END SUBROUTINE getvar_to
 
   FUNCTION getvar3d(cdfile, cdvar, kpi, kpj, kpk, kimin, kjmin, kkmin, ktime, ldiom)
     !! A (kpi,kpj,kpk) block of one record, window origin (kimin,kjmin,kkmin), as a function result

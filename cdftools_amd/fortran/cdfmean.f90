@@ -148,8 +148,8 @@ PROGRAM cdfmean
      STOP 99
   END SELECT
 
-  e1(:,:) = getvar(cn_fhgr, cv_e1, 1, npiglo, npjglo, kimin=iimin, kjmin=ijmin)
-  e2(:,:) = getvar(cn_fhgr, cv_e2, 1, npiglo, npjglo, kimin=iimin, kjmin=ijmin)
+  CALL getvar_to(cn_fhgr, cv_e1, 1, e1(:,:), kimin=iimin, kjmin=ijmin)
+  CALL getvar_to(cn_fhgr, cv_e2, 1, e2(:,:), kimin=iimin, kjmin=ijmin)
   IF ( lfull ) e31d(:) = getvare3(cn_fzgr, cv_e31d, npk)
   zdep(:) = getvare3(cn_fzgr, cv_dep, npk_fi)
   gdep(:) = zdep(ikmin:npk - ikmin + 1)
@@ -166,7 +166,7 @@ PROGRAM cdfmean
 
   IF ( lbas ) THEN
      DO jbasin = 1, nbasin
-        zwk(:,:) = getvar(cn_fbasins, cbasins(jbasin), 1, npiglo, npjglo, kimin=iimin, kjmin=ijmin)
+        CALL getvar_to(cn_fbasins, cbasins(jbasin), 1, zwk(:,:), kimin=iimin, kjmin=ijmin)
         ibmask(jbasin,:,:) = INT(zwk(:,:), 2)
      END DO
   ELSE
@@ -419,7 +419,7 @@ CONTAINS
     ierr  = putvar1d(ncout, dtim, npt, 'T')
     IF ( lbas ) THEN
        DO jbasin = 1, nbasin
-          zvf(:,:) = getvar(cn_fbasins, cbasins(jbasin), 1, npiglo, npjglo)
+          CALL getvar_to(cn_fbasins, cbasins(jbasin), 1, zvf(:,:))
           ibfull(jbasin,:,:) = INT(zvf(:,:), 2)
        END DO
     ELSE
@@ -428,8 +428,8 @@ CONTAINS
     DO jt = 1, npt
        DO jk = 1, nvpk
           ik = jk + ikmin - 1
-          zvf(:,:) = getvar(cf_in,   cv_nam, ik, npiglo, npjglo, ktime=jt)
-          zmf(:,:) = getvar(cn_fmsk, cv_msk, ik, npiglo, npjglo)
+          CALL getvar_to(cf_in, cv_nam, ik, zvf(:,:), ktime=jt)
+          CALL getvar_to(cn_fmsk, cv_msk, ik, zmf(:,:))
           DO jbasin = 1, nbasin
              zvzm(:,:) = (zvf(:,:) - dvmeanout3d(jbasin,jt)) * zmf(:,:) * ibfull(jbasin,:,:)
              ierr = putvar(ncout, id_varz(jbasin), zvzm, ik, npiglo, npjglo, ktime=jt)

@@ -123,8 +123,8 @@ PROGRAM cdfmhst
   ALLOCATE( dheat(nmask,npjglo,nlevo), dsalt(nmask,npjglo,nlevo) )
   ALLOCATE( stypvar(nbasinso*npvar), ipk(nbasinso*npvar), id_varout(nbasinso*npvar) )
 
-  e1v(:,:)   = getvar(cn_fhgr, cn_ve1v,  1, npiglo, npjglo)
-  gphiv(:,:) = getvar(cn_fhgr, cn_gphiv, 1, npiglo, npjglo)
+  CALL getvar_to(cn_fhgr, cn_ve1v, 1, e1v(:,:))
+  CALL getvar_to(cn_fhgr, cn_gphiv, 1, gphiv(:,:))
   IF ( lzdim ) THEN ; gdep(:) = getvare3(cn_fzgr, cn_gdept, npk)
   ELSE              ; gdep(:) = 0.
   ENDIF
@@ -135,11 +135,11 @@ PROGRAM cdfmhst
   CALL CreateOutput
 
   ! masks: slab 1 global (vmask level 1), then Atlantic, Pacific, Indian (src/cdfmhst.f90:340-363)
-  zmasks(:,:,1) = getvar(cn_fmsk, cn_vmask, 1, npiglo, npjglo)
+  CALL getvar_to(cn_fmsk, cn_vmask, 1, zmasks(:,:,1))
   IF ( llglo ) THEN
-     zmasks(:,:,2) = getvar(cn_fbasins, cn_tmaskatl, 1, npiglo, npjglo)
-     zmasks(:,:,3) = getvar(cn_fbasins, cn_tmaskpac, 1, npiglo, npjglo)
-     zmasks(:,:,4) = getvar(cn_fbasins, cn_tmaskind, 1, npiglo, npjglo)
+     CALL getvar_to(cn_fbasins, cn_tmaskatl, 1, zmasks(:,:,2))
+     CALL getvar_to(cn_fbasins, cn_tmaskpac, 1, zmasks(:,:,3))
+     CALL getvar_to(cn_fbasins, cn_tmaskind, 1, zmasks(:,:,4))
   ENDIF
 
   OPEN(numouth, FILE=cf_outh, FORM='FORMATTED', RECL=256)

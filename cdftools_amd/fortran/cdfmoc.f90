@@ -208,8 +208,8 @@ PROGRAM cdfmoc
   ALLOCATE( rdumlon(1, npjglo), rdumlat(1, npjglo), gdepw(npk), e31d(npk), dtim(npt) )
   ALLOCATE( stypvar(nvarout), ipk(nvarout), id_varout(nvarout) )
 
-  e1v(:,:)   = getvar(cn_fhgr, cn_ve1v,  1, npiglo, npjglo)
-  gphiv(:,:) = getvar(cn_fhgr, cn_gphiv, 1, npiglo, npjglo)
+  CALL getvar_to(cn_fhgr, cn_ve1v, 1, e1v(:,:))
+  CALL getvar_to(cn_fhgr, cn_gphiv, 1, gphiv(:,:))
   gdepw(:)   = getvare3(cn_fzgr, cn_gdepw, npk)
   gdepw(:)   = -1. * gdepw(:)
   IF ( lfull ) e31d(:) = getvare3(cn_fzgr, cn_ve3t1d, npk)
@@ -219,7 +219,7 @@ PROGRAM cdfmoc
      IF ( .NOT. lfeed_dec ) ALLOCATE( ztemp(npiglo, npjglo, npk), zsal(npiglo, npjglo, npk) )
      ALLOCATE( dmoc_sh(nbasins, npjglo, npk), dmoc_bt(nbasins, npjglo, npk), dmoc_ag(nbasins, npjglo, npk) )
      gdept(:) = getvare3(cn_fzgr, cn_gdept, npk)
-     e1u(:,:) = getvar(cn_fhgr, cn_ve1u, 1, npiglo, npjglo)
+     CALL getvar_to(cn_fhgr, cn_ve1u, 1, e1u(:,:))
      ! f at V points, then -g/rau0/f, in r4 as the reference writes it (src/cdfmoc.f90:425-433)
      rpi = ACOS( -1. )
      zcoef(:,:) = 2*2*rpi/( 24.0 * 3600. )* SIN ( rpi * gphiv(:,:) /180.0)
@@ -249,10 +249,10 @@ PROGRAM cdfmoc
   !  index innermost, as ibmask lies in memory: 0.13 s instead of 0.33 s of host time at eORCA12 on the build container's cores)
   IF ( lbas ) THEN
      ALLOCATE( zbas(npiglo, npjglo, 3) )
-     zmsk(:,:)   = getvar(cn_fmsk,    cn_vmask,    1, npiglo, npjglo)
-     zbas(:,:,1) = getvar(cn_fbasins, cn_tmaskatl, 1, npiglo, npjglo)
-     zbas(:,:,2) = getvar(cn_fbasins, cn_tmaskind, 1, npiglo, npjglo)
-     zbas(:,:,3) = getvar(cn_fbasins, cn_tmaskpac, 1, npiglo, npjglo)
+     CALL getvar_to(cn_fmsk, cn_vmask, 1, zmsk(:,:))
+     CALL getvar_to(cn_fbasins, cn_tmaskatl, 1, zbas(:,:,1))
+     CALL getvar_to(cn_fbasins, cn_tmaskind, 1, zbas(:,:,2))
+     CALL getvar_to(cn_fbasins, cn_tmaskpac, 1, zbas(:,:,3))
      DO jj = 1, npjglo
         DO ji = 1, npiglo
            ibmask(npglo,ji,jj) = INT(zmsk(ji,jj), 2)
@@ -265,7 +265,7 @@ PROGRAM cdfmoc
      END DO
      DEALLOCATE( zbas )
   ELSE
-     zmsk(:,:) = getvar(cn_fmsk, cn_vmask, 1, npiglo, npjglo) ; ibmask(npglo,:,:) = INT(zmsk, 2)
+     CALL getvar_to(cn_fmsk, cn_vmask, 1, zmsk(:,:)); ibmask(npglo,:,:) = INT(zmsk, 2)
   ENDIF
   ibmask(npglo, 1,      :) = 0                            ! E-W periodic overlap, global basin only
   ibmask(npglo, npiglo, :) = 0

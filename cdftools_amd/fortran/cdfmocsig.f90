@@ -147,11 +147,11 @@ PROGRAM cdfmocsig
   IF ( lisodep ) ALLOCATE( depi(nbasins,nbins,npjglo) )
   IF ( leiv .AND. .NOT. lfeed ) ALLOCATE( zveiv(npiglo,npjglo,npk) )
   IF ( .NOT. ( lfull .OR. lfeed ) ) ALLOCATE( e3v(npiglo,npjglo,npk) )
-  e1v(:,:) = getvar(cn_fhgr, cn_ve1v, 1, npiglo, npjglo)
+  CALL getvar_to(cn_fhgr, cn_ve1v, 1, e1v(:,:))
   IF ( lfull   ) e31d(:) = getvare3(cn_fzgr, cn_ve3t1d, npk)
   IF ( lisodep ) gdep(:) = -getvare3(cn_fzgr, cn_gdept, npk)
   IF ( npjglo > 1 ) THEN
-     gphiv(:,:)   = getvar(cn_fhgr, cn_gphiv, 1, npiglo, npjglo)
+     CALL getvar_to(cn_fhgr, cn_gphiv, 1, gphiv(:,:))
      iloc         = MAXLOC(gphiv)
      rdumlat(1,:) = gphiv(iloc(1),:)
   ELSE
@@ -161,13 +161,13 @@ PROGRAM cdfmocsig
   CALL CreateOutputFile
 
   ! (the same values as the reference's five strided assignments and its WHERE, in one pass with the basin index innermost: cdfmoc.f90)
-  zwk(:,:) = getvar(cn_fmsk, cn_vmask, 1, npiglo, npjglo)
+  CALL getvar_to(cn_fmsk, cn_vmask, 1, zwk(:,:))
   IF ( .NOT. lbas ) ibmask(npglo,:,:) = INT(zwk, 2)
   IF ( lbas ) THEN
      ALLOCATE( zbas(npiglo, npjglo, 3) )
-     zbas(:,:,1) = getvar(cn_fbasins, cn_tmaskatl, 1, npiglo, npjglo)
-     zbas(:,:,2) = getvar(cn_fbasins, cn_tmaskind, 1, npiglo, npjglo)
-     zbas(:,:,3) = getvar(cn_fbasins, cn_tmaskpac, 1, npiglo, npjglo)
+     CALL getvar_to(cn_fbasins, cn_tmaskatl, 1, zbas(:,:,1))
+     CALL getvar_to(cn_fbasins, cn_tmaskind, 1, zbas(:,:,2))
+     CALL getvar_to(cn_fbasins, cn_tmaskpac, 1, zbas(:,:,3))
      DO jj = 1, npjglo
         DO ji = 1, npiglo
            ibmask(npglo,ji,jj) = INT(zwk(ji,jj), 2)
@@ -231,7 +231,7 @@ PROGRAM cdfmocsig
         ELSE
            IF ( jt == 1 .OR. lg_vvl ) THEN
               DO ji = 1, npk
-                 e3v(:,:,ji) = getvar(cn_fe3v, cn_ve3v, ji, npiglo, npjglo, ktime=it, ldiom=.NOT. lg_vvl)
+                 CALL getvar_to(cn_fe3v, cn_ve3v, ji, e3v(:,:,ji), ktime=it, ldiom=.NOT. lg_vvl)
               END DO
            ENDIF
            pe3 = C_LOC(e3v)

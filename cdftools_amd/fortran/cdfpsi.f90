@@ -136,15 +136,15 @@ PROGRAM cdfpsi
      IF ( ll_v ) ALLOCATE( e3v(npiglo,npjglo,npk) )
   ENDIF
 
-  glamf(:,:) = getvar(cn_fhgr, cn_glamf, 1, npiglo, npjglo)
-  gphif(:,:) = getvar(cn_fhgr, cn_gphif, 1, npiglo, npjglo)
+  CALL getvar_to(cn_fhgr, cn_glamf, 1, glamf(:,:))
+  CALL getvar_to(cn_fhgr, cn_gphif, 1, gphif(:,:))
   CALL CreateOutput
-  e1v(:,:) = getvar(cn_fhgr, cn_ve1v, 1, npiglo, npjglo)
-  e2u(:,:) = getvar(cn_fhgr, cn_ve2u, 1, npiglo, npjglo)
+  CALL getvar_to(cn_fhgr, cn_ve1v, 1, e1v(:,:))
+  CALL getvar_to(cn_fhgr, cn_ve2u, 1, e2u(:,:))
   pmask = C_NULL_PTR
   IF ( lmask ) THEN
      ALLOCATE( zmask(npiglo,npjglo) )
-     zmask(:,:) = getvar(cn_fmsk, cn_fmask, 1, npiglo, npjglo)
+     CALL getvar_to(cn_fmsk, cn_fmask, 1, zmask(:,:))
      WHERE ( zmask >= 2 ) zmask = 1                       ! get rid of the free-slip / no-slip coding
      pmask = C_LOC(zmask)
   ENDIF
@@ -229,14 +229,14 @@ PROGRAM cdfpsi
      ENDIF
      ierr = putvar(ncout, id_varout(1), zpsi, 1, npiglo, npjglo, ktime=jt)
      IF ( lssh ) THEN                                     ! :260-267, :280, :299, :323-333, :386-408
-        zssh(:,:) = getvar(cf_sshfil, cn_sossheig, 1, npiglo, npjglo, ktime=jt)
+        CALL getvar_to(cf_sshfil, cn_sossheig, 1, zssh(:,:), ktime=jt)
         zsshu(:,:) = 0.0 ; zsshv(:,:) = 0.0
         zsshu(1:npiglo-1, :) = 0.5*( zssh(2:npiglo,:) + zssh(1:npiglo-1,:) )
         zsshv(:, 1:npjglo-1) = 0.5*( zssh(:,2:npjglo) + zssh(:,1:npjglo-1) )
         ! the reference multiplies BOTH contributions by zv(:,:), the meridional velocity of level 1
         ! (:299 uses zv where zu was meant); zv is never assigned without the V component: taken as 0
         zvel1(:,:) = 0.0
-        IF ( ll_v .AND. lfeed ) THEN ; zvel1(:,:) = getvar(cf_vfil, cn_vomecrty, 1, npiglo, npjglo, ktime=jt)
+        IF ( ll_v .AND. lfeed ) THEN ; CALL getvar_to(cf_vfil, cn_vomecrty, 1, zvel1(:,:), ktime=jt)
         ELSE IF ( ll_v )        THEN ; zvel1(:,:) = zv(:,:,1)
         ENDIF
         pzu = C_NULL_PTR ; pe2u = C_NULL_PTR ; pe3u = C_NULL_PTR ; pzv = C_NULL_PTR ; pe1v = C_NULL_PTR ; pe3v = C_NULL_PTR
@@ -285,11 +285,11 @@ CONTAINS
     CHARACTER(LEN=*), INTENT(in) :: cd_file, cd_var, cd_fe3, cd_ve3
     LOGICAL,          INTENT(in) :: ld_u
     TYPE(C_PTR) :: pl_e3, pl_1d
-    zlev(:,:) = getvar(cd_file, cd_var, jk, npiglo, npjglo, ktime=jt)
+    CALL getvar_to(cd_file, cd_var, jk, zlev(:,:), ktime=jt)
     pl_e3 = C_NULL_PTR ; pl_1d = C_NULL_PTR
     IF ( lfull ) THEN ; pl_1d = C_LOC(e31d(jk))
     ELSE
-       ze3(:,:) = getvar(cd_fe3, cd_ve3, jk, npiglo, npjglo, ktime=it, ldiom=.NOT. lg_vvl)
+       CALL getvar_to(cd_fe3, cd_ve3, jk, ze3(:,:), ktime=it, ldiom=.NOT. lg_vvl)
        pl_e3 = C_LOC(ze3)
     ENDIF
     IF ( ld_u ) THEN

@@ -135,8 +135,8 @@ PROGRAM cdfsum
      e1(:,:) = 1 ; e2(:,:) = 1
      gdep(:) = (/ (jk, jk = 1, npk) /)
   ELSE
-     e1(:,:) = getvar(cn_fhgr, cv_e1, 1, npiglo, npjglo, kimin=iimin, kjmin=ijmin)
-     e2(:,:) = getvar(cn_fhgr, cv_e2, 1, npiglo, npjglo, kimin=iimin, kjmin=ijmin)
+     CALL getvar_to(cn_fhgr, cv_e1, 1, e1(:,:), kimin=iimin, kjmin=ijmin)
+     CALL getvar_to(cn_fhgr, cv_e2, 1, e2(:,:), kimin=iimin, kjmin=ijmin)
      gdep(:) = getvare3(cn_fzgr, cv_dep, npk)
   ENDIF
 

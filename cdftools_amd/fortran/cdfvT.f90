@@ -165,13 +165,13 @@ PROGRAM cdfvT
         cf_vfil = SetFileName(config, ctag_lst(jt), 'V')
         DO jtt = 1, nptag(jt)
            ifr = ifr + 1
-           zu(:,:,ifr) = getvar(cf_ufil, cn_vozocrtx, jk, npiglo, npjglo, ktime=jtt)
-           zv(:,:,ifr) = getvar(cf_vfil, cn_vomecrty, jk, npiglo, npjglo, ktime=jtt)
-           zt(:,:,ifr) = getvar(cf_tfil, cn_votemper, jk, npiglo, npjglo, ktime=jtt)
-           zs(:,:,ifr) = getvar(cf_sfil, cn_vosaline, jk, npiglo, npjglo, ktime=jtt)
+           CALL getvar_to(cf_ufil, cn_vozocrtx, jk, zu(:,:,ifr), ktime=jtt)
+           CALL getvar_to(cf_vfil, cn_vomecrty, jk, zv(:,:,ifr), ktime=jtt)
+           CALL getvar_to(cf_tfil, cn_votemper, jk, zt(:,:,ifr), ktime=jtt)
+           CALL getvar_to(cf_sfil, cn_vosaline, jk, zs(:,:,ifr), ktime=jtt)
            IF ( lg_vvl ) THEN
-              e3u(:,:,ifr) = getvar(cf_ufil, cn_ve3u, jk, npiglo, npjglo, ktime=jtt)
-              e3v(:,:,ifr) = getvar(cf_vfil, cn_ve3v, jk, npiglo, npjglo, ktime=jtt)
+              CALL getvar_to(cf_ufil, cn_ve3u, jk, e3u(:,:,ifr), ktime=jtt)
+              CALL getvar_to(cf_vfil, cn_ve3v, jk, e3v(:,:,ifr), ktime=jtt)
            ENDIF
         END DO
      END DO

@@ -92,8 +92,8 @@ PROGRAM cdfvertmean
   END DO
   ALLOCATE( dvertmean(npiglo,npjglo), rlon(npiglo,npjglo), rlat(npiglo,npjglo), gdep(npk), dtim(npt) )
   IF ( lfull ) ALLOCATE( e31d(npk) )
-  rlon = getvar(cf_in, cn_vlon2d, 1, npiglo, npjglo, kimin=iimin, kjmin=ijmin)
-  rlat = getvar(cf_in, cn_vlat2d, 1, npiglo, npjglo, kimin=iimin, kjmin=ijmin)
+  CALL getvar_to(cf_in, cn_vlon2d, 1, rlon, kimin=iimin, kjmin=ijmin)
+  CALL getvar_to(cf_in, cn_vlat2d, 1, rlat, kimin=iimin, kjmin=ijmin)
   CALL CreateOutput
 
   SELECT CASE ( ctype )
@@ -136,7 +136,7 @@ PROGRAM cdfvertmean
      ALLOCATE( zv(npiglo,npjglo,nlev), zmask(npiglo,npjglo,nlev) )
      IF ( .NOT. lfull ) ALLOCATE( e3(npiglo,npjglo,nlev) )
      DO jk = ik1, ik2
-        zmask(:,:,jk-ik1+1) = getvar(cn_fmsk, cv_msk, jk, npiglo, npjglo, kimin=iimin, kjmin=ijmin)
+        CALL getvar_to(cn_fmsk, cv_msk, jk, zmask(:,:,jk-ik1+1), kimin=iimin, kjmin=ijmin)
      END DO
   ENDIF
 
@@ -159,7 +159,7 @@ PROGRAM cdfvertmean
      ELSE
         IF ( jt == 1 .OR. lg_vvl ) THEN
            DO jk = ik1, ik2
-              e3(:,:,jk-ik1+1) = getvar(cf_e3, cv_e3, jk, npiglo, npjglo, kimin=iimin, kjmin=ijmin, ktime=it, ldiom=.NOT. lg_vvl)
+              CALL getvar_to(cf_e3, cv_e3, jk, e3(:,:,jk-ik1+1), kimin=iimin, kjmin=ijmin, ktime=it, ldiom=.NOT. lg_vvl)
            END DO
         ENDIF
         pe3 = C_LOC(e3)
@@ -167,7 +167,7 @@ PROGRAM cdfvertmean
      DO jvar = 1, nvaro
         cv_cur = cv_in(jvar)
         DO jk = ik1, ik2
-           zv(:,:,jk-ik1+1) = getvar(cf_in, cv_cur, jk, npiglo, npjglo, kimin=iimin, kjmin=ijmin, ktime=jt)
+           CALL getvar_to(cf_in, cv_cur, jk, zv(:,:,jk-ik1+1), kimin=iimin, kjmin=ijmin, ktime=jt)
         END DO
         CALL hip_check(cdft_vertmean(zv, pe3, pe31d, zmask, npiglo, npjglo, nlev, gdep(ik1), gdep(ik2), rdep_up, rdep_down, &
              &         CDFT_MEM_HOST, dvertmean, CDFT_MEM_HOST, C_NULL_PTR), 'cdft_vertmean')

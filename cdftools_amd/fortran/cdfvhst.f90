@@ -81,8 +81,8 @@ PROGRAM cdfvhst
   ALLOCATE( dtrpt(npiglo,npjglo), dtrps(npiglo,npjglo), dtim(npt), e31d(npk) )
   IF ( .NOT. ( lfull .OR. lfeed ) ) ALLOCATE( e3u(npiglo,npjglo,npk), e3v(npiglo,npjglo,npk) )
   CALL CreateOutput
-  e1v(:,:) = getvar(cn_fhgr, cn_ve1v, 1, npiglo, npjglo)
-  e2u(:,:) = getvar(cn_fhgr, cn_ve2u, 1, npiglo, npjglo)
+  CALL getvar_to(cn_fhgr, cn_ve1v, 1, e1v(:,:))
+  CALL getvar_to(cn_fhgr, cn_ve2u, 1, e2u(:,:))
   e31d(:)  = getvare3(cn_fzgr, cn_ve3t1d, npk)
 
   IF ( lfeed ) THEN

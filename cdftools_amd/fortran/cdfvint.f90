@@ -143,8 +143,8 @@ PROGRAM cdfvint
      gdepo(1:npk-1) = gdepw(2:npk)
      gdepo(npk)     = 6000.
   ENDIF
-  rlon = getvar(cf_in, cn_vlon2d, 1, npiglo, npjglo, kimin=iimin, kjmin=ijmin)
-  rlat = getvar(cf_in, cn_vlat2d, 1, npiglo, npjglo, kimin=iimin, kjmin=ijmin)
+  CALL getvar_to(cf_in, cn_vlon2d, 1, rlon, kimin=iimin, kjmin=ijmin)
+  CALL getvar_to(cf_in, cn_vlat2d, 1, rlat, kimin=iimin, kjmin=ijmin)
   CALL CreateOutput
   PRINT *, 'OUTPUT DEPTHS ARE : ', gdepo
 

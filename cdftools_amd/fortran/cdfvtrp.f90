@@ -87,14 +87,14 @@ PROGRAM cdfvtrp
      ALLOCATE( e1u(npiglo,npjglo), e2v(npiglo,npjglo), tmask(npiglo,npjglo), hdepw(npiglo,npjglo) )
   ENDIF
   CALL CreateOutput
-  e1v(:,:) = getvar(cn_fhgr, cn_ve1v, 1, npiglo, npjglo)
-  e2u(:,:) = getvar(cn_fhgr, cn_ve2u, 1, npiglo, npjglo)
+  CALL getvar_to(cn_fhgr, cn_ve1v, 1, e1v(:,:))
+  CALL getvar_to(cn_fhgr, cn_ve2u, 1, e2u(:,:))
   IF ( lfull ) e31d(:) = getvare3(cn_fzgr, cn_ve3t1d, npk)
   IF ( lbathy ) THEN
-     e1u(:,:)   = getvar(cn_fhgr, cn_ve1u,  1, npiglo, npjglo)
-     e2v(:,:)   = getvar(cn_fhgr, cn_ve2v,  1, npiglo, npjglo)
-     tmask(:,:) = getvar(cn_fmsk, cn_tmask, 1, npiglo, npjglo)
-     hdepw(:,:) = getvar(cn_fzgr, cn_hdepw, 1, npiglo, npjglo)
+     CALL getvar_to(cn_fhgr, cn_ve1u, 1, e1u(:,:))
+     CALL getvar_to(cn_fhgr, cn_ve2v, 1, e2v(:,:))
+     CALL getvar_to(cn_fmsk, cn_tmask, 1, tmask(:,:))
+     CALL getvar_to(cn_fzgr, cn_hdepw, 1, hdepw(:,:))
   ENDIF
 
   IF ( lfeed ) THEN
