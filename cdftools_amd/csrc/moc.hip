@@ -657,6 +657,8 @@ extern "C" int cdft_moc_set_basins(cdft_moc_plan *p, const float *e1v, const int
     CDFT_HIP(hipMemcpyAsync(p->e1v2d.ptr, d_e1v, (size_t)nij * 4, hipMemcpyDeviceToDevice, st));
     const int rc = basins_from(p, (const int16_t *)d_msk, st);
     p->st_e1v.release(); p->st_mask.release();
+    // a rejected mask has already overwritten bits / cls / pat: a mesh set before must not let a later compute run on them
+    if (rc != CDFT_OK) p->mesh_set = false;
     return rc;
 }
 

@@ -756,7 +756,7 @@ int nch5_create(const char *path, NcH5 **hout, int ndims, const Dim *dims, int n
 /* ---- deflated variables, whole chunks at a time ----------------------------------------------------------------
  * H5Dwrite runs the shuffle + deflate filters of every chunk on the calling thread (about 80 MB/s: the -nc4 output
  * of cdfsigi at eORCA025 took 6 s).  When a write covers whole chunks and needs no type conversion, the chunks are
- * shuffled and deflated here by CDFT_IO_THREADS threads (default: half the cores, 8 to 32) and handed over with H5Dwrite_chunk: the bytes in
+ * shuffled and deflated here by CDFT_IO_THREADS threads (default: half the cores, 8 to 64: each holds one chunk buffer of its own, so a 128-core host runs 64 threads on 64 chunks at a time) and handed over with H5Dwrite_chunk: the bytes in
  * the file are what the library's own filters would have produced, any NetCDF-4 reader inflates them. */
 typedef struct {
     const VarOut *vo;

@@ -11,6 +11,8 @@ import subprocess
 import numpy as np
 from scipy.io import netcdf_file
 
+import run_program
+
 UV = ["-u", "SYN_y0001_gridU.nc", "-v", "SYN_y0001_gridV.nc"]
 
 # (case name, program, arguments, output files)
@@ -224,13 +226,8 @@ def run_case(bindir, case, cwd, env=None):
     e.update(env or {})
     # argv[0] is the bare program name (it goes into the `history` attribute, src/modutils.f90 SetGlobalAtt): the same text
     # whichever directory the binary lies in
-    for attempt in (1, 2):                                   # (a run that hangs is tried once more: tests/test_cli.py run() says why)
-        try:
-            p = subprocess.run([prog] + args, executable=os.path.join(bindir, prog), cwd=cwd, env=e, capture_output=True, text=True, timeout=300)
-            break
-        except subprocess.TimeoutExpired:
-            if attempt == 2:
-                raise
+    # (a run that does not end fails at once, described: tests/run_program.py)
+    p = run_program.run_watched([prog] + args, executable=os.path.join(bindir, prog), cwd=cwd, env=e, timeout=300)
     meta = {"case": name, "program": prog, "args": args, "rc": p.returncode, "stdout": p.stdout, "files": {}}
     if p.returncode != 0:
         meta["stderr"] = p.stderr

@@ -11,6 +11,7 @@ from scipy.io import netcdf_file
 
 import nemo_files
 import oracle_lib
+import run_program
 import synth
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -29,25 +30,8 @@ def tools():
 def run(tool, args, cwd, env=None):
     e = dict(os.environ)
     e.update(env or {})
-    # A program of a test grid takes a third of a second.  One run in several thousand did not end within 600 s once in round 5 and
-    # never again (tools/stress_feed.py: 1 869 runs through the ring and 1 403 on whole records in a row without one): a run that hangs is written down where the round's
-    # outputs are kept and tried ONCE more -- two in a row fail the test with the program's name and what it had printed.
-    for attempt in (1, 2):
-        try:
-            p = subprocess.run([os.path.join(BIN, tool)] + args, cwd=cwd, env=e, capture_output=True, text=True, timeout=120)
-            break
-        except subprocess.TimeoutExpired as t:
-            so = t.stdout.decode("latin-1") if isinstance(t.stdout, bytes) else (t.stdout or "")
-            se = t.stderr.decode("latin-1") if isinstance(t.stderr, bytes) else (t.stderr or "")
-            what = "HUNG after 120 s (attempt %d): %s %s  env %s\n--- stdout so far\n%s\n--- stderr so far\n%s\n" % (
-                attempt, tool, " ".join(args), {k: v for k, v in (env or {}).items()}, so[-1500:], se[-1500:])
-            try:
-                os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-                open(os.path.join(ROOT, "gpurun_out", "hung_programs.txt"), "a").write(what)
-            except OSError:
-                pass
-            if attempt == 2:
-                raise AssertionError(what)
+    # a run that does not end within 120 s fails the test at once, with what each of its threads was doing (tests/run_program.py)
+    p = run_program.run_watched([os.path.join(BIN, tool)] + args, cwd=cwd, env=e, timeout=120)
     return p.returncode, p.stdout, p.stderr
 
 

@@ -9,6 +9,7 @@ import subprocess
 import pytest
 
 import nemo_files
+import run_program
 from test_cli import BIN, tools  # noqa: F401
 
 T, U, V = "SYN_y0001_gridT.nc", "SYN_y0001_gridU.nc", "SYN_y0001_gridV.nc"
@@ -44,7 +45,7 @@ def test_programs_run_with_a_stack_smaller_than_one_slab(tools, tmp_path):  # no
     nemo_files.make_case(d, npi=768, npj=512, npk=4, npt=1)               # one r4 slab = 1.5 MB
     bad = []
     for tool, args in RUNS:
-        p = subprocess.run([os.path.join(BIN, tool)] + args, cwd=d, capture_output=True, text=True, timeout=600, preexec_fn=small_stack)
+        p = run_program.run_watched([os.path.join(BIN, tool)] + args, cwd=d, env=None, timeout=600, preexec_fn=small_stack)
         if p.returncode != 0:
             bad.append((tool, p.returncode, (p.stdout + p.stderr)[-300:]))
     assert not bad, bad

@@ -20,22 +20,7 @@ import test_cli_feed as tf  # noqa: E402
 BIN = os.path.join(ROOT, "cdftools_amd", "bin")
 
 
-def describe(pid):
-    out = []
-    for t in sorted(glob.glob(f"/proc/{pid}/task/*")):
-        def rd(name):
-            try:
-                return open(os.path.join(t, name)).read().strip()
-            except OSError as e:
-                return f"<{e.strerror}>"
-        st = [ln for ln in rd("status").splitlines() if ln.startswith(("Name", "State"))]
-        out.append(f"thread {os.path.basename(t)}: {' '.join(st)} wchan={rd('wchan')} syscall={rd('syscall')[:60]}")
-    try:
-        r = subprocess.run(["rocgdb", "-p", str(pid), "-batch", "-ex", "thread apply all bt 12"], capture_output=True, text=True, timeout=120)
-        out.append("--- rocgdb\n" + (r.stdout + r.stderr)[-6000:])
-    except (OSError, subprocess.TimeoutExpired) as e:
-        out.append(f"(rocgdb: {e})")
-    return "\n".join(out)
+from run_program import describe  # noqa: E402  (what every thread of a live process is doing)
 
 
 def main():
