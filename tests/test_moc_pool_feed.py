@@ -174,6 +174,28 @@ def test_the_stream_route_equals_the_resident_pool(gpu, npi, npj, npk, nb, npt, 
     plan.close()
 
 
+@pytest.mark.gpu
+def test_a_rejected_basin_mask_withdraws_the_mesh(gpu):
+    """cdft_moc_set_basins with values other than 0/1 overwrites the plan's bits and classes before it refuses the mask: a mesh set
+    before must not let cdft_moc_compute run on them (round-5 advisor) -- the compute is refused until a mesh or mask is accepted"""
+    g = synth.make_grid(24, 18, 7, seed=5, nbasins=5)
+    e1v, e3v, ib = synth.moc_inputs(g)
+    zv = synth.velocity(g, 2, seed=3)
+    ref = oracle_lib.moc(e1v, e3v, ib, zv)
+    plan = gpu.MocPlan(24, 18, 7, 5)
+    plan.set_mesh(e1v, e3v, ib)
+    a = plan.compute(zv, np.zeros_like(ref))
+    bad = ib.copy()
+    bad.flat[7] = 2
+    with pytest.raises(gpu.CdftError, match="other than 0/1"):
+        plan.set_basins(e1v, bad)
+    with pytest.raises(gpu.CdftError, match="has not succeeded"):
+        plan.compute(zv, np.zeros_like(ref))
+    plan.set_mesh(e1v, e3v, ib)
+    assert np.array_equal(plan.compute(zv, np.zeros_like(ref)), a)
+    plan.close()
+
+
 def _plan_line(err):
     m = PLAN_LINE.search(err)
     assert m, err[-600:]
