@@ -435,7 +435,10 @@ __device__ __forceinline__ int wave_iscan_incl(int v, int lane) {
 struct ScanLevel { unsigned long long word[3]; unsigned long long pad; };
 __device__ __forceinline__ unsigned long long scan_word(int step, float s) { return ((unsigned long long)(uint32_t)step << 32) | __float_as_uint(s); }
 constexpr int kScanMaxLanes = 8;
-struct ScanCtl   { int ticket; int error; int nfallback, nunguessed, nslow, nstolen; int lane_next[kScanMaxLanes]; };   // (nfallback ...: statistics)
+struct ScanCtl   { int ticket; int error; int nfallback, nunguessed, nslow, nstolen; int lane_next[kScanMaxLanes];   // (nfallback ...: statistics)
+                   // round 6, 100 MHz ticks summed over the walker waves (wk_*: waiting for a parked ticket, loading its sums, walking it)
+                   // and over the streaming workgroups (st_*: waiting for a ring slot, parking, the whole ticket); t_first / t_last: the kernel's span
+                   unsigned long long wk_wait, wk_load, wk_walk, st_ring, st_park, st_all, t_first, t_last; };
 
 // the binade of a chain value: sign and exponent, or -1 when the integer picture does not apply (0, denormal, Inf, NaN,
 // or an exponent whose ulp does not scale exactly)
@@ -565,7 +568,8 @@ __global__ void __launch_bounds__(256) heatc_sample16_kernel(HeatcArgs a, int b0
 // 60 blocks at eORCA12: 48 us).
 constexpr int kEstThreads = 1024;
 __global__ void __launch_bounds__(kEstThreads) heatc_scan_est_kernel(const double *__restrict__ partial, int nblk, const float *__restrict__ carry,
-                                                                     double *__restrict__ est, ScanLevel *lev, ScanCtl *ctl) {
+                                                                     double *__restrict__ est, ScanLevel *lev, ScanCtl *ctl,
+                                                                     int *__restrict__ parked, int nsteps) {
     __shared__ double wtot[3][kEstThreads / 64];
     const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double *ek = est + (int64_t)k * (nblk + 1) * 3;
@@ -590,8 +594,10 @@ __global__ void __launch_bounds__(kEstThreads) heatc_scan_est_kernel(const doubl
         for (int b = b0; b < b1; ++b) { run += pk[(int64_t)b * 3 + c]; ek[(int64_t)(b + 1) * 3 + c] = run; }
     }
     if (tid < 3) lev[k].word[tid] = scan_word(0, carry ? carry[k * 3 + tid] : 0.f);
+    if (parked) for (int i = tid; i < nsteps; i += kEstThreads) parked[(int64_t)k * nsteps + i] = 0;     // no ticket of the level is parked yet
     if (k == 0 && tid == 0) {
         ctl->ticket = 0; ctl->error = 0; ctl->nfallback = 0; ctl->nunguessed = 0; ctl->nslow = 0; ctl->nstolen = 0;
+        ctl->wk_wait = ctl->wk_load = ctl->wk_walk = ctl->st_ring = ctl->st_park = ctl->st_all = ctl->t_last = 0ull; ctl->t_first = ~0ull;
         for (int x = 0; x < kScanMaxLanes; ++x) ctl->lane_next[x] = 0;
     }
 }
@@ -600,287 +606,192 @@ template <bool MASK8, bool FULL, bool MXL>
 // (four workgroups per CU -- 128 VGPRs, no spill in the byte-mask form -- were measured in round 4: no faster, 2.27 against 2.20 ms)
 __global__ void __launch_bounds__(64 * kScanWaves, 3) heatc_scan_kernel(HeatcArgs a, ScanLevel *__restrict__ lev, ScanCtl *__restrict__ ctl,
                                                                      const double *__restrict__ est, int block_cells, int nchunk, int nsteps,
-                                                                     float *__restrict__ sums4, long long scan_wait_ticks, int nlanes, int align, int dbg) {
+                                                                     float *__restrict__ sums4, long long scan_wait_ticks, int nlanes, int align, int dbg,
+                                                                     int *__restrict__ parked, int *__restrict__ park, int ring) {
     __shared__ int sm_K[2][kScanMaxChunks][3], sm_pos[2][kScanMaxChunks][3], sm_flag[2][kScanMaxChunks][3], sm_key[2][kScanMaxChunks][3];
     __shared__ int tick;
     __shared__ __attribute__((aligned(16))) float xs[3][kScanChunk];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // (w in a scalar register: what depends on it alone stays scalar)
     const int64_t ticket_cells = (int64_t)nchunk * kScanChunk;
 
+    // Round 6: WALKERS.  With `ring` > 0 the first npk workgroups stream nothing: workgroup k is the chains of level k -- wave ch
+    // takes chain ch through the level's tickets in order, from the sums the streaming workgroups have PARKED in HBM
+    // (park: `ring` slots per level, a ticket in slot step % ring; parked[k * nsteps + step] = 1 once its sums are there).  A
+    // streaming workgroup never waits for a chain any more (round 5: a third of the workgroup slots of an eORCA025 run were held
+    // by tickets waiting for their start value while 21 cell-by-cell resolutions per level went by, profiles/r04/
+    // heatc_scan_timeline_eorca025.txt); it waits only when its ring slot is still unread, i.e. when a level's chains are
+    // `ring` tickets behind.  No deadlock: a walker waits for tickets that were dealt (held by workgroups that run and wait, if
+    // at all, for a walker to pass tickets parked long before); the walkers, first in the grid, are resident before any of them.
+    const bool walker = ring > 0 && (int)blockIdx.x < a.npk;
+    if (walker && w >= 3) return;                                 // (a walker has no workgroup barrier)
+    const int park_ints = 24 * nchunk;                            // a ticket's sums: [chain][hypothesis][K, pos, flag, key][chunk]
+
     // the XCD this workgroup runs on (HW_REG_XCC_ID, bits 3:0)
     const int my_lane = nlanes > 1 ? (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u) % nlanes : 0;
 
     struct Raw { float ar[4], e3[4], tt[4], mk[4], mx[4]; uint32_t mkb; };      // (mkb: the four mask bytes as loaded, MASK8)
-    for (;;) {
-        // Dealing.  Lane x of `nlanes` holds the steps x, x + nlanes, ... of every level, in that order; a workgroup draws from
-        // the lane of the XCD it runs on, and from the next lanes once its own is empty.  The 75 levels of a step multiply
-        // the SAME 131072 values of e1t*e2t: drawn by one XCD they find them in its L2 after the first (dealt from one
-        // counter the levels of a step spread over the eight L2s and the plane was fetched eight times, 0.4 B per cell).
-        // No deadlock: every lane deals in increasing order, so the smallest ticket not yet finished is either held by a
-        // workgroup that runs (all it waits for is finished) or the next one of its lane, whose workgroups all hold
-        // finished-or-running smaller tickets and come back for it.
-        if (threadIdx.x == 0) {
-            int t = -1;
-            for (int o = 0; o < nlanes && t < 0; ++o) {
-                const int x = (my_lane + o) % nlanes;
-                const int steps_x = (nsteps - x + nlanes - 1) / nlanes;            // steps x, x + nlanes, ... < nsteps
-                if (steps_x <= 0 || __hip_atomic_load(&ctl->lane_next[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= steps_x * a.npk) continue;
-                const int i = __hip_atomic_fetch_add(&ctl->lane_next[x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (i < steps_x * a.npk) {
-                    t = (x + nlanes * (i / a.npk)) * a.npk + i % a.npk;
-                    if (o) atomicAdd(&ctl->nstolen, 1);
-                }
-            }
-            if (t >= 0) atomicAdd(&ctl->ticket, 1);
-            tick = t;
-        }
-        __syncthreads();
-        const int ticket = tick;
-        if (ticket < 0) break;                                    // (uniform)
-        const int step = ticket / a.npk, k = ticket - step * a.npk;
-        // A level is walked in VIRTUAL cells: `pad` cells that do not exist (terms of -0.0, the one value that changes no sum,
-        // not even a sum of -0.0) stand before its first one, so that every chunk of 512 starts on a 128-byte line of temp,
-        // e3t and the byte mask alike whatever k * nij is -- a line split between two chunks is fetched by both (two waves,
-        // two moments): 0.35 B per cell of 9.1 at eORCA12, where a level starts 48 bytes into a line.
-        const int64_t base = (int64_t)k * a.nij, t0 = (int64_t)step * ticket_cells;
-        const int pad = align ? (int)((base + (int64_t)((reinterpret_cast<uintptr_t>(a.temp) >> 2) & 127u)) & 127) : 0;
-        const int64_t nijv = a.nij + pad;
-        const float e3k = FULL ? a.e31d[k] : 0.f;
-        const float dw  = MXL ? a.gdepw[k] : 0.f;
-        if (w < 3) {
-            // The hypotheses of chunk `lane`, chain w: the binades of the chain's estimated value at both ends of the
-            // level-kernel block the chunk lies in.  Estimated = the last EXACT value the level has published (a few
-            // tickets back) + the r8 sum of the blocks since: the r4 chain drifts away from the r8 sums (by 1e-4 at
-            // eORCA025, by per cents at eORCA12 where x is of the order of ulp(s)), but not over a handful of tickets.
-            const unsigned long long pub = __hip_atomic_load(&lev[k].word[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int sp = min(step, (int)(pub >> 32));
-            const float sv = __uint_as_float((uint32_t)pub);
-            const double *el = est + (int64_t)k * (a.nblk + 1) * 3 + w;
-            const int64_t ab = min((int64_t)a.nblk, max((int64_t)0, (int64_t)sp * ticket_cells - pad) / block_cells);
-            for (int q = lane; q < nchunk; q += 64) {
-                const int64_t c0 = t0 + (int64_t)q * kScanChunk;
-                int k0 = -1, k1 = -1;
-                if (c0 < nijv) {
-                    const int64_t c0r = max((int64_t)0, c0 - pad), cb = c0r / block_cells;
-                    const double b0 = el[cb * 3] - el[ab * 3], b1 = el[(cb + 1) * 3] - el[ab * 3];      // growth since the published value
-                    const double per = (b1 - b0) / (double)block_cells;
-                    const double g0 = b0 + per * (double)(c0r - cb * block_cells), g1 = g0 + per * (double)kScanChunk;
-                    const double d0 = (double)sv + g0, d1 = (double)sv + g1;
-                    k0 = scan_key((float)d0); k1 = scan_key((float)d1);
-                    if (k0 < 0) { k0 = k1; k1 = -1; }
-                    if (k1 == k0) k1 = -1;
-                    if (k1 < 0 && k0 >= 0) {                      // the estimate may be off by a share of what it added to the exact value
-                        const double u = 0.25 * fabs(g0);
-                        const int ku = scan_key((float)(d0 + u)), kd = scan_key((float)(d0 - u));
-                        k1 = (ku >= 0 && ku != k0) ? ku : (kd >= 0 && kd != k0) ? kd : -1;
-                    }
-                }
-                sm_key[0][q][w] = k0; sm_key[1][q][w] = k1;
-            }
-        }
-        __syncthreads();
-
-        auto fetch = [&](Raw (&raw)[kScanNV], int64_t c0) {       // 512 cells from c0 on: lane l takes cells 4l..4l+3 of each 256
-            if (c0 >= pad && c0 + kScanChunk <= nijv) {           // (uniform) every cell exists: four 16-byte loads per field and lane, nothing else
-                // wave-uniform bases (scalar registers) + one 32-bit lane offset: the loads need no 64-bit vector address arithmetic
-                const int64_t u0 = c0 - pad;
-                const float *ap = a.area + u0, *tp = a.temp + base + u0, *ep = FULL ? nullptr : a.e3t + base + u0;
-                const float *mp4 = MASK8 ? nullptr : a.mask4 + base + u0, *xp = MXL ? a.mxl + u0 : nullptr;
-                const uint8_t *mp8 = MASK8 ? a.mask8 + base + u0 : nullptr;
-#pragma unroll
-                for (int v = 0; v < kScanNV; ++v) {
-                    Raw &x = raw[v];
-                    const unsigned p = (unsigned)(v * 256 + 4 * lane);
-                    const f4u av = *reinterpret_cast<const f4u *>(ap + p);
-                    x.ar[0] = av.x; x.ar[1] = av.y; x.ar[2] = av.z; x.ar[3] = av.w;
-                    const f4u tv = ld_stream4u(tp + p);
-                    x.tt[0] = tv.x; x.tt[1] = tv.y; x.tt[2] = tv.z; x.tt[3] = tv.w;
-                    if (!FULL) { const f4u ev = ld_stream4u(ep + p); x.e3[0] = ev.x; x.e3[1] = ev.y; x.e3[2] = ev.z; x.e3[3] = ev.w; }
-                    else       { x.e3[0] = x.e3[1] = x.e3[2] = x.e3[3] = 0.f; }
-                    if (MASK8) { typedef uint32_t u32u __attribute__((aligned(1))); x.mkb = __builtin_nontemporal_load(reinterpret_cast<const u32u *>(mp8 + p)); }
-                    else       { const f4u m = ld_stream4u(mp4 + p); x.mk[0] = m.x; x.mk[1] = m.y; x.mk[2] = m.z; x.mk[3] = m.w; }
-                    if (MXL) { const f4u mv = *reinterpret_cast<const f4u *>(xp + p); x.mx[0] = mv.x; x.mx[1] = mv.y; x.mx[2] = mv.z; x.mx[3] = mv.w; }
-                    else     { x.mx[0] = x.mx[1] = x.mx[2] = x.mx[3] = 0.f; }
-                }
-                return;
-            }
-#pragma unroll
-            for (int v = 0; v < kScanNV; ++v) {                   // the first and the last chunk of a level: cell by cell, zeros where there is none
-                Raw &x = raw[v];
-                const int64_t p = c0 + v * 256 + 4 * lane - pad;
-                x.mkb = 0u;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    x.ar[c] = x.e3[c] = x.tt[c] = x.mk[c] = x.mx[c] = 0.f;
-                    if (p + c >= 0 && p + c < a.nij) {
-                        x.ar[c] = a.area[p + c];
-                        x.tt[c] = a.temp[base + p + c];
-                        if (!FULL) x.e3[c] = a.e3t[base + p + c];
-                        if (MASK8) x.mkb |= (uint32_t)a.mask8[base + p + c] << (8 * c);
-                        else       x.mk[c] = a.mask4[base + p + c];
-                        if (MXL) x.mx[c] = a.mxl[p + c];
-                    }
-                }
-            }
-        };
-        // the three r4 products of every cell in `raw`, exactly as the reference forms them (:225-229); zeros past the end.
-        // Two cells per instruction (v_pk_mul_f32: the same IEEE r4 product in each half): x[chain][vector][pair]
-        auto products = [&](const Raw (&raw)[kScanNV], int64_t c0, f2v (&x)[3][kScanNV][2]) {
-            const bool whole = c0 >= pad && c0 + kScanChunk <= nijv;     // (uniform) every cell of the chunk exists
+    // The ticket at hand (set_ticket): what the lambdas below read.
+    // A level is walked in VIRTUAL cells: `pad` cells that do not exist (terms of -0.0, the one value that changes no sum,
+    // not even a sum of -0.0) stand before its first one, so that every chunk of 512 starts on a 128-byte line of temp,
+    // e3t and the byte mask alike whatever k * nij is -- a line split between two chunks is fetched by both (two waves,
+    // two moments): 0.35 B per cell of 9.1 at eORCA12, where a level starts 48 bytes into a line.
+    int k = 0, step = 0, pad = 0;
+    int64_t base = 0, t0 = 0, nijv = 0;
+    float e3k = 0.f, dw = 0.f;
+    auto set_ticket = [&](int kk, int ss) {
+        k = kk; step = ss;
+        base = (int64_t)k * a.nij; t0 = (int64_t)step * ticket_cells;
+        pad = align ? (int)((base + (int64_t)((reinterpret_cast<uintptr_t>(a.temp) >> 2) & 127u)) & 127) : 0;
+        nijv = a.nij + pad;
+        e3k = FULL ? a.e31d[k] : 0.f;
+        dw  = MXL ? a.gdepw[k] : 0.f;
+    };
+    auto fetch = [&](Raw (&raw)[kScanNV], int64_t c0) {       // 512 cells from c0 on: lane l takes cells 4l..4l+3 of each 256
+        if (c0 >= pad && c0 + kScanChunk <= nijv) {           // (uniform) every cell exists: four 16-byte loads per field and lane, nothing else
+            // wave-uniform bases (scalar registers) + one 32-bit lane offset: the loads need no 64-bit vector address arithmetic
+            const int64_t u0 = c0 - pad;
+            const float *ap = a.area + u0, *tp = a.temp + base + u0, *ep = FULL ? nullptr : a.e3t + base + u0;
+            const float *mp4 = MASK8 ? nullptr : a.mask4 + base + u0, *xp = MXL ? a.mxl + u0 : nullptr;
+            const uint8_t *mp8 = MASK8 ? a.mask8 + base + u0 : nullptr;
 #pragma unroll
             for (int v = 0; v < kScanNV; ++v) {
-                const Raw &r = raw[v];
+                Raw &x = raw[v];
+                const unsigned p = (unsigned)(v * 256 + 4 * lane);
+                const f4u av = *reinterpret_cast<const f4u *>(ap + p);
+                x.ar[0] = av.x; x.ar[1] = av.y; x.ar[2] = av.z; x.ar[3] = av.w;
+                const f4u tv = ld_stream4u(tp + p);
+                x.tt[0] = tv.x; x.tt[1] = tv.y; x.tt[2] = tv.z; x.tt[3] = tv.w;
+                if (!FULL) { const f4u ev = ld_stream4u(ep + p); x.e3[0] = ev.x; x.e3[1] = ev.y; x.e3[2] = ev.z; x.e3[3] = ev.w; }
+                else       { x.e3[0] = x.e3[1] = x.e3[2] = x.e3[3] = 0.f; }
+                if (MASK8) { typedef uint32_t u32u __attribute__((aligned(1))); x.mkb = __builtin_nontemporal_load(reinterpret_cast<const u32u *>(mp8 + p)); }
+                else       { const f4u m = ld_stream4u(mp4 + p); x.mk[0] = m.x; x.mk[1] = m.y; x.mk[2] = m.z; x.mk[3] = m.w; }
+                if (MXL) { const f4u mv = *reinterpret_cast<const f4u *>(xp + p); x.mx[0] = mv.x; x.mx[1] = mv.y; x.mx[2] = mv.z; x.mx[3] = mv.w; }
+                else     { x.mx[0] = x.mx[1] = x.mx[2] = x.mx[3] = 0.f; }
+            }
+            return;
+        }
 #pragma unroll
-                for (int p = 0; p < 2; ++p) {
-                    float e[2], mk[2];
+        for (int v = 0; v < kScanNV; ++v) {                   // the first and the last chunk of a level: cell by cell, zeros where there is none
+            Raw &x = raw[v];
+            const int64_t p = c0 + v * 256 + 4 * lane - pad;
+            x.mkb = 0u;
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const int c = 2 * p + h;
-                        e[h] = FULL ? e3k : r.e3[c];
-                        if (MXL) {
-                            if (a.mxlopt == 1) e[h] = fmaxf(0.f, fminf(e[h], __fsub_rn(r.mx[c], dw)));                   // :220
-                            else               e[h] = fminf(e[h], fmaxf(0.f, __fsub_rn(__fadd_rn(dw, e[h]), r.mx[c])));  // :222
-                        }
-                        mk[h] = MASK8 ? (float)((r.mkb >> (8 * c)) & 0xffu) : r.mk[c];
-                    }
-                    const f2v ar = {r.ar[2 * p], r.ar[2 * p + 1]}, tt = {r.tt[2 * p], r.tt[2 * p + 1]};
-                    const f2v e2 = {e[0], e[1]}, mk2 = {mk[0], mk[1]};
-                    const f2v pv = pk_mul(ar, e2);
-                    x[0][v][p] = pk_mul(ar, mk2);
-                    x[1][v][p] = pk_mul(pv, mk2);
-                    x[2][v][p] = pk_mul(pk_mul(pv, tt), mk2);
+            for (int c = 0; c < 4; ++c) {
+                x.ar[c] = x.e3[c] = x.tt[c] = x.mk[c] = x.mx[c] = 0.f;
+                if (p + c >= 0 && p + c < a.nij) {
+                    x.ar[c] = a.area[p + c];
+                    x.tt[c] = a.temp[base + p + c];
+                    if (!FULL) x.e3[c] = a.e3t[base + p + c];
+                    if (MASK8) x.mkb |= (uint32_t)a.mask8[base + p + c] << (8 * c);
+                    else       x.mk[c] = a.mask4[base + p + c];
+                    if (MXL) x.mx[c] = a.mxl[p + c];
                 }
             }
-            if (!whole) {                                         // (uniform: only the first and the last chunk of a level take this branch)
+        }
+    };
+    // the three r4 products of every cell in `raw`, exactly as the reference forms them (:225-229); zeros past the end.
+    // Two cells per instruction (v_pk_mul_f32: the same IEEE r4 product in each half): x[chain][vector][pair]
+    auto products = [&](const Raw (&raw)[kScanNV], int64_t c0, f2v (&x)[3][kScanNV][2]) {
+        const bool whole = c0 >= pad && c0 + kScanChunk <= nijv;     // (uniform) every cell of the chunk exists
 #pragma unroll
-                for (int v = 0; v < kScanNV; ++v)
+        for (int v = 0; v < kScanNV; ++v) {
+            const Raw &r = raw[v];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const int64_t id = c0 + v * 256 + 4 * lane + c;
-                        if (id < pad || id >= nijv)
+            for (int p = 0; p < 2; ++p) {
+                float e[2], mk[2];
 #pragma unroll
-                            for (int ch = 0; ch < 3; ++ch) { if (c & 1) x[ch][v][c >> 1].y = -0.f; else x[ch][v][c >> 1].x = -0.f; }
+                for (int h = 0; h < 2; ++h) {
+                    const int c = 2 * p + h;
+                    e[h] = FULL ? e3k : r.e3[c];
+                    if (MXL) {
+                        if (a.mxlopt == 1) e[h] = fmaxf(0.f, fminf(e[h], __fsub_rn(r.mx[c], dw)));                   // :220
+                        else               e[h] = fminf(e[h], fmaxf(0.f, __fsub_rn(__fadd_rn(dw, e[h]), r.mx[c])));  // :222
                     }
+                    mk[h] = MASK8 ? (float)((r.mkb >> (8 * c)) & 0xffu) : r.mk[c];
+                }
+                const f2v ar = {r.ar[2 * p], r.ar[2 * p + 1]}, tt = {r.tt[2 * p], r.tt[2 * p + 1]};
+                const f2v e2 = {e[0], e[1]}, mk2 = {mk[0], mk[1]};
+                const f2v pv = pk_mul(ar, e2);
+                x[0][v][p] = pk_mul(ar, mk2);
+                x[1][v][p] = pk_mul(pv, mk2);
+                x[2][v][p] = pk_mul(pk_mul(pv, tt), mk2);
             }
-        };
-        // sums of chunk q under the hypotheses of each chain
-        auto summarize = [&](const f2v (&x)[3][kScanNV][2], int q) {
-            // Is there a cell with a term that is not 0?  One answer PER CHAIN: a chain that is still at 0 (no binade) has to look at
-            // every chunk that says yes -- with -mxloption the volume and heat terms are 0 below the mixed layer while the surface
-            // terms are not, and one answer for the three sent every chunk of 68 levels x 2 chains to the cells (12.5 ms at eORCA025).
-            uint32_t any[3] = {0u, 0u, 0u};
+        }
+        if (!whole) {                                         // (uniform: only the first and the last chunk of a level take this branch)
 #pragma unroll
             for (int v = 0; v < kScanNV; ++v)
 #pragma unroll
-                for (int p = 0; p < 2; ++p)
+                for (int c = 0; c < 4; ++c) {
+                    const int64_t id = c0 + v * 256 + 4 * lane + c;
+                    if (id < pad || id >= nijv)
 #pragma unroll
-                    for (int ch = 0; ch < 3; ++ch) any[ch] |= __float_as_uint(x[ch][v][p].x) | __float_as_uint(x[ch][v][p].y);
-#pragma unroll
-            for (int ch = 0; ch < 3; ++ch) {
-                const bool anz = __builtin_amdgcn_ballot_w64((any[ch] & 0x7fffffffu) != 0u) != 0;
-                for (int h = 0; h < 2; ++h) {
-                    const int key = sm_key[h][q][ch];
-                    if (h == 1 && key < 0) break;                 // (uniform)
-                    int Kl = 0, Al = 0;                           // this lane's sum of k and of |k| (chain 2; the others: Al = Kl)
-                    bool bad = key < 0;
-                    uint32_t sgn = 0u;
-                    if (key >= 0 && anz) {
-                        const float scale = scan_scale(key);
-                        const f2v sc = {scale, scale};
-                        // A lane's eight k's are added as floats, two at a time (v_pk_add_f32).  The guard is the lane's sum of
-                        // |k|: while it stays below 2^23 every partial sum is an integer below 2^24, hence exact, and the chunk's
-                        // 64 lane sums fit 32 bits with room for the walk's prefix sums; a sum that reaches 2^23 or is not a
-                        // number (a NaN / Inf term, or an x far above the chain's ulp) sends the chunk to the cells.  The surface
-                        // and the volume have no negative term on a real mesh: their sum of |k| IS their sum of k, and a sign
-                        // bit anywhere (a negative weight of -M, a negative start value) sends the chunk to the cells as well.
-                        f2v Kf = {0.f, 0.f};
-                        float Af = 0.f, far = 0.f;                // far: the largest |q - rint(q)|, 0.5 exactly = a tie
-#pragma unroll
-                        for (int v = 0; v < kScanNV; ++v)
-#pragma unroll
-                            for (int p = 0; p < 2; ++p) {
-                                const f2v qq = pk_mul(x[ch][v][p], sc);                       // exact (a power of two), or Inf / NaN
-                                const f2v kf = {rintf(qq.x), rintf(qq.y)};
-                                Kf = pk_add(Kf, kf);
-                                const f2v d = pk_sub(qq, kf);                                 // exact
-                                far = fmaxf(far, fmaxf(fabsf(d.x), fabsf(d.y)));              // (v_max3_f32)
-                                sgn |= __float_as_uint(qq.x) | __float_as_uint(qq.y);         // (v_or3_b32)
-                                if (ch == 2) { Af = __fadd_rn(Af, fabsf(kf.x)); Af = __fadd_rn(Af, fabsf(kf.y)); }
-                            }
-                        const float Ks = __fadd_rn(Kf.x, Kf.y);
-                        if (ch != 2) Af = Ks;
-                        bad = far == 0.5f || !(Af < 8388608.f) || (ch != 2 && (sgn >> 31) != 0u);
-                        Kl = bad ? 0 : (int)Ks;
-                        Al = bad ? 0 : (int)Af;
-                    }
-                    // the chunk's sums: in lane 63 of the accumulating registers, which writes them (no trip through a scalar)
-                    const int Kw = wave_isum_top(Kl);
-                    const int Aw = ch == 2 ? wave_isum_top(Al) : Kw;
-                    const bool abad = __builtin_amdgcn_ballot_w64(bad) != 0, ang = __builtin_amdgcn_ballot_w64((sgn >> 31) != 0u) != 0;
-                    if (lane == 63) {
-                        sm_K[h][q][ch] = Kw; sm_pos[h][q][ch] = ch == 2 ? (Aw + Kw) / 2 : Kw;      // pos = sum of max(k,0) = (sum|k| + sum k) / 2
-                        sm_flag[h][q][ch] = (anz ? 1 : 0) | (abad ? 2 : 0) | (ang ? 4 : 0);
-                    }
+                        for (int ch = 0; ch < 3; ++ch) { if (c & 1) x[ch][v][c >> 1].y = -0.f; else x[ch][v][c >> 1].x = -0.f; }
                 }
-            }
-        };
-        {   // Every chunk of the ticket; the loads run TWO sub-blocks ahead (two register sets, the loop unrolled by two so that
-            // neither is ever copied): counters showed the waves waiting for memory 61 % of their time with one sub-block ahead
-            // -- a chunk's vector work (~2 us with three waves on the SIMD) is about the latency of its loads under load.
-            // Round 4: THREE sub-blocks ahead (AHEAD register sets, the loop unrolled by as many): the skeleton alone -- loads and
-            // products, no sums -- ran at the pace of a wave's load round trips, not of HBM.
-            constexpr int AHEAD = (MASK8 && !MXL) ? kScanAhead : 2;       // (the r4-mask and mixed-layer forms would spill with three sets)
-            Raw rawA[kScanNV], rawB[kScanNV], rawC[kScanNV];
-            f2v x[3][kScanNV][2];
-            auto chunk = [&](Raw (&raw)[kScanNV], int q) {        // sums chunk q from `raw`, then asks for chunk q + AHEAD * kScanWaves into it
-                if (q >= nchunk) return;                          // (AHEAD = 3 does not divide the chunks of a wave)
-                const int64_t c0 = t0 + (int64_t)q * kScanChunk;
-                if (c0 >= nijv) {                                 // past the end of the level: nothing there
-                    if (lane == 63) for (int ch = 0; ch < 3; ++ch) sm_flag[0][q][ch] = sm_flag[1][q][ch] = 0;
-                    return;
+        }
+    };
+    // sums of chunk q under the hypotheses of each chain
+    auto summarize = [&](const f2v (&x)[3][kScanNV][2], int q) {
+        // Is there a cell with a term that is not 0?  One answer PER CHAIN: a chain that is still at 0 (no binade) has to look at
+        // every chunk that says yes -- with -mxloption the volume and heat terms are 0 below the mixed layer while the surface
+        // terms are not, and one answer for the three sent every chunk of 68 levels x 2 chains to the cells (12.5 ms at eORCA025).
+        uint32_t any[3] = {0u, 0u, 0u};
+#pragma unroll
+        for (int v = 0; v < kScanNV; ++v)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) any[ch] |= __float_as_uint(x[ch][v][p].x) | __float_as_uint(x[ch][v][p].y);
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const bool anz = __builtin_amdgcn_ballot_w64((any[ch] & 0x7fffffffu) != 0u) != 0;
+            for (int h = 0; h < 2; ++h) {
+                const int key = sm_key[h][q][ch];
+                if (h == 1 && key < 0) break;                 // (uniform)
+                int Kl = 0, Al = 0;                           // this lane's sum of k and of |k| (chain 2; the others: Al = Kl)
+                bool bad = key < 0;
+                uint32_t sgn = 0u;
+                if (key >= 0 && anz) {
+                    const float scale = scan_scale(key);
+                    const f2v sc = {scale, scale};
+                    // A lane's eight k's are added as floats, two at a time (v_pk_add_f32).  The guard is the lane's sum of
+                    // |k|: while it stays below 2^23 every partial sum is an integer below 2^24, hence exact, and the chunk's
+                    // 64 lane sums fit 32 bits with room for the walk's prefix sums; a sum that reaches 2^23 or is not a
+                    // number (a NaN / Inf term, or an x far above the chain's ulp) sends the chunk to the cells.  The surface
+                    // and the volume have no negative term on a real mesh: their sum of |k| IS their sum of k, and a sign
+                    // bit anywhere (a negative weight of -M, a negative start value) sends the chunk to the cells as well.
+                    f2v Kf = {0.f, 0.f};
+                    float Af = 0.f, far = 0.f;                // far: the largest |q - rint(q)|, 0.5 exactly = a tie
+#pragma unroll
+                    for (int v = 0; v < kScanNV; ++v)
+#pragma unroll
+                        for (int p = 0; p < 2; ++p) {
+                            const f2v qq = pk_mul(x[ch][v][p], sc);                       // exact (a power of two), or Inf / NaN
+                            const f2v kf = {rintf(qq.x), rintf(qq.y)};
+                            Kf = pk_add(Kf, kf);
+                            const f2v d = pk_sub(qq, kf);                                 // exact
+                            far = fmaxf(far, fmaxf(fabsf(d.x), fabsf(d.y)));              // (v_max3_f32)
+                            sgn |= __float_as_uint(qq.x) | __float_as_uint(qq.y);         // (v_or3_b32)
+                            if (ch == 2) { Af = __fadd_rn(Af, fabsf(kf.x)); Af = __fadd_rn(Af, fabsf(kf.y)); }
+                        }
+                    const float Ks = __fadd_rn(Kf.x, Kf.y);
+                    if (ch != 2) Af = Ks;
+                    bad = far == 0.5f || !(Af < 8388608.f) || (ch != 2 && (sgn >> 31) != 0u);
+                    Kl = bad ? 0 : (int)Ks;
+                    Al = bad ? 0 : (int)Af;
                 }
-                products(raw, c0, x);
-                if (q + AHEAD * kScanWaves < nchunk && c0 + (int64_t)AHEAD * kScanSub < nijv) fetch(raw, c0 + (int64_t)AHEAD * kScanSub);
-                if (!(dbg & 2)) summarize(x, q);      // (dbg: timing experiments of tools/, results then meaningless)
-            };
-            auto first = [&](Raw (&raw)[kScanNV], int q) {
-                if (q < nchunk && t0 + (int64_t)q * kScanChunk < nijv) fetch(raw, t0 + (int64_t)q * kScanChunk);
-            };
-            first(rawA, w);
-            first(rawB, w + kScanWaves);
-            if (AHEAD == 3) first(rawC, w + 2 * kScanWaves);
-#pragma clang loop unroll(disable)
-            for (int q = w; q < nchunk; q += AHEAD * kScanWaves) {
-                chunk(rawA, q);
-                chunk(rawB, q + kScanWaves);
-                if (AHEAD == 3) chunk(rawC, q + 2 * kScanWaves);
+                // the chunk's sums: in lane 63 of the accumulating registers, which writes them (no trip through a scalar)
+                const int Kw = wave_isum_top(Kl);
+                const int Aw = ch == 2 ? wave_isum_top(Al) : Kw;
+                const bool abad = __builtin_amdgcn_ballot_w64(bad) != 0, ang = __builtin_amdgcn_ballot_w64((sgn >> 31) != 0u) != 0;
+                if (lane == 63) {
+                    sm_K[h][q][ch] = Kw; sm_pos[h][q][ch] = ch == 2 ? (Aw + Kw) / 2 : Kw;      // pos = sum of max(k,0) = (sum|k| + sum k) / 2
+                    sm_flag[h][q][ch] = (anz ? 1 : 0) | (abad ? 2 : 0) | (ang ? 4 : 0);
+                }
             }
         }
-        __syncthreads();                                          // the sums of every chunk are in LDS
-        // ---- wave ch takes chain ch through the ticket on its own: no workgroup barrier, no other chain waited for
-        if (w < 3) {
-            const int ch = w;
-            // the exact value where this ticket starts: published by the step before (tag == step)
-            unsigned long long pub = 0;
-            if (lane == 0) {
-                // (the step waited for was dealt before this one: it is held by a workgroup that runs.  Two seconds of the
-                // 100 MHz wall clock without it -- a preempted queue, a fault -- raise the error flag; every other wait sees the
-                // flag and gives up too, the kernel ends and the host takes the plain chain instead)
-                long long t_start = 0;
-                int spins = 0;
-                while (!(dbg & 1) && (int)((pub = __hip_atomic_load(&lev[k].word[ch], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != step) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if ((++spins & 1023) == 0 || scan_wait_ticks == 0) {
-                        const long long now = wall_clock64();
-                        if (!t_start) t_start = now;
-                        if (now - t_start >= scan_wait_ticks || __hip_atomic_load(&ctl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                            __hip_atomic_store(&ctl->error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            break;
-                        }
-                    }
-                }
-            }
-            float s = __uint_as_float((uint32_t)__shfl((int)(uint32_t)pub, 0, 64));
+    };
+    // chain ch through the ticket whose sums are in LDS, from the value s where the ticket starts: the value where it ends
+    auto walk_chain = [&](const int ch, float s) __attribute__((always_inline)) -> float {
             int from = 0;
             for (;;) {
                 // the chunks in order, 64 at a time, one per lane
@@ -916,13 +827,13 @@ __global__ void __launch_bounds__(64 * kScanWaves, 3) heatc_scan_kernel(HeatcArg
                 fetch(raw, c0);
                 products(raw, c0, x3);
                 float xv[kScanNV][4];
+                auto take = [&](const f2v (&xc)[kScanNV][2]) {         // (a branch per chain, each with constant indices: nothing in scratch)
 #pragma unroll
-                for (int v = 0; v < kScanNV; ++v)
+                    for (int v = 0; v < kScanNV; ++v)
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const f2v t = ch == 0 ? x3[0][v][c >> 1] : ch == 1 ? x3[1][v][c >> 1] : x3[2][v][c >> 1];
-                        xv[v][c] = (c & 1) ? t.y : t.x;
-                    }
+                        for (int c = 0; c < 4; ++c) xv[v][c] = (c & 1) ? xc[v][c >> 1].y : xc[v][c >> 1].x;
+                };
+                if (ch == 0) take(x3[0]); else if (ch == 1) take(x3[1]); else take(x3[2]);
                 if (lane == 0) atomicAdd(&ctl->nfallback, 1);
                 int next = 0, rounds = 0;                         // cells [0, next) of the chunk are in s
                 while (next < nvalid && rounds < 6) {
@@ -1025,6 +936,256 @@ __global__ void __launch_bounds__(64 * kScanWaves, 3) heatc_scan_kernel(HeatcArg
                 }
                 from = q + 1;
             }
+        return s;
+    };
+
+    if (walker) {
+        // ---- the chains of level blockIdx.x: wave ch takes chain ch through the level's tickets, as they are parked
+        const int ch = w;
+        __builtin_amdgcn_s_setprio(2);
+        float s = __uint_as_float((uint32_t)__hip_atomic_load(&lev[blockIdx.x].word[ch], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));   // the carry
+        unsigned long long tw = 0, tl = 0, tk = 0;
+        for (int ws = 0; ws < nsteps; ++ws) {
+            set_ticket((int)blockIdx.x, ws);
+            const long long c0w = (dbg & 8) ? wall_clock64() : 0;
+            // the ticket's sums: parked by the workgroup that streamed it
+            int there = 0;
+            if (lane == 0) {
+                long long t_start = 0;
+                int spins = 0;
+                // (relaxed, like every load of the sums below: an agent-scope ACQUIRE is an invalidation of this XCD's L2 -- in a polling
+                // loop of 225 waves it took the e1t*e2t plane away from the streaming workgroups again and again, 2.1 -> 3.1 ms at
+                // eORCA12.  The loads below are issued after the flag has come back, and are agent-scope loads themselves.)
+                while (!(there = __hip_atomic_load(&parked[(int64_t)k * nsteps + step], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if ((++spins & 1023) == 0 || scan_wait_ticks == 0) {
+                        const long long now = wall_clock64();
+                        if (!t_start) t_start = now;
+                        // (a walker waits for the streaming itself, the whole kernel long if it must: ten times the limit of a hand-over)
+                        // (CDFT_HEATC_SCAN_WAIT_US=0, the tests' hook, still makes the first wait that is not over at once give up)
+                        if (now - t_start >= (scan_wait_ticks ? 10 * scan_wait_ticks + 100000000LL : 0LL) ||
+                            __hip_atomic_load(&ctl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                            __hip_atomic_store(&ctl->error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            break;
+                        }
+                    }
+                }
+            }
+            there = __shfl(there, 0, 64);
+            if (!there) return;                                // (the error flag is up: the host takes the plain chain)
+            const long long c1w = (dbg & 8) ? wall_clock64() : 0;
+            // every load of the ticket's sums is issued before the first is used (the compiler waits for an atomic load where its
+            // value is needed: a load and an LDS write in turns were 32 memory round trips a ticket, 25 us of a walker's step)
+            const unsigned long long *slot = reinterpret_cast<const unsigned long long *>(park + ((int64_t)k * ring + step % ring) * park_ints) +
+                                             (int64_t)ch * nchunk * 4;
+            unsigned long long pw[kScanMaxChunks / 64][4];
+#pragma unroll
+            for (int i = 0; i < kScanMaxChunks / 64; ++i) {
+                const unsigned long long *o = slot + (int64_t)min(lane + 64 * i, nchunk - 1) * 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pw[i][j] = __hip_atomic_load(o + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int i = 0; i < kScanMaxChunks / 64; ++i) {
+                const int q = lane + 64 * i;
+                if (q < nchunk) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        sm_K[h][q][ch]    = (int)(uint32_t)pw[i][2 * h];
+                        sm_pos[h][q][ch]  = (int)(uint32_t)(pw[i][2 * h] >> 32);
+                        sm_flag[h][q][ch] = (int)(uint32_t)pw[i][2 * h + 1];
+                        sm_key[h][q][ch]  = (int)(uint32_t)(pw[i][2 * h + 1] >> 32);
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const long long c2w = (dbg & 8) ? wall_clock64() : 0;
+            s = walk_chain(ch, s);
+            if (lane == 0) {
+                __hip_atomic_store(&lev[k].word[ch], scan_word(step + 1, s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the streaming workgroups: hypotheses, ring)
+                if (step == nsteps - 1) sums4[k * 3 + ch] = s;
+            }
+            if (dbg & 8) { const long long c3w = wall_clock64(); tw += c1w - c0w; tl += c2w - c1w; tk += c3w - c2w; }
+        }
+        if ((dbg & 8) && lane == 0) {
+            atomicAdd(&ctl->wk_wait, tw); atomicAdd(&ctl->wk_load, tl); atomicAdd(&ctl->wk_walk, tk);
+            atomicMax(&ctl->t_last, (unsigned long long)wall_clock64());
+        }
+        return;
+    }
+
+    for (;;) {
+        // Dealing.  Lane x of `nlanes` holds the steps x, x + nlanes, ... of every level, in that order; a workgroup draws from
+        // the lane of the XCD it runs on, and from the next lanes once its own is empty.  The 75 levels of a step multiply
+        // the SAME 131072 values of e1t*e2t: drawn by one XCD they find them in its L2 after the first (dealt from one
+        // counter the levels of a step spread over the eight L2s and the plane was fetched eight times, 0.4 B per cell).
+        // No deadlock: every lane deals in increasing order, so the smallest ticket not yet finished is either held by a
+        // workgroup that runs (all it waits for is finished) or the next one of its lane, whose workgroups all hold
+        // finished-or-running smaller tickets and come back for it.
+        if (threadIdx.x == 0) {
+            int t = -1;
+            for (int o = 0; o < nlanes && t < 0; ++o) {
+                const int x = (my_lane + o) % nlanes;
+                const int steps_x = (nsteps - x + nlanes - 1) / nlanes;            // steps x, x + nlanes, ... < nsteps
+                if (steps_x <= 0 || __hip_atomic_load(&ctl->lane_next[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= steps_x * a.npk) continue;
+                const int i = __hip_atomic_fetch_add(&ctl->lane_next[x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (i < steps_x * a.npk) {
+                    t = (x + nlanes * (i / a.npk)) * a.npk + i % a.npk;
+                    if (o) atomicAdd(&ctl->nstolen, 1);
+                }
+            }
+            if (t >= 0) atomicAdd(&ctl->ticket, 1);
+            tick = t;
+        }
+        __syncthreads();
+        const int ticket = tick;
+        if (ticket < 0) break;                                    // (uniform)
+        set_ticket(ticket % a.npk, ticket / a.npk);
+        if ((dbg & 8) && threadIdx.x == 0) atomicMin(&ctl->t_first, (unsigned long long)wall_clock64());
+        if (w < 3) {
+            // The hypotheses of chunk `lane`, chain w: the binades of the chain's estimated value at both ends of the
+            // level-kernel block the chunk lies in.  Estimated = the last EXACT value the level has published (a few
+            // tickets back) + the r8 sum of the blocks since: the r4 chain drifts away from the r8 sums (by 1e-4 at
+            // eORCA025, by per cents at eORCA12 where x is of the order of ulp(s)), but not over a handful of tickets.
+            const unsigned long long pub = __hip_atomic_load(&lev[k].word[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int sp = min(step, (int)(pub >> 32));
+            const float sv = __uint_as_float((uint32_t)pub);
+            const double *el = est + (int64_t)k * (a.nblk + 1) * 3 + w;
+            const int64_t ab = min((int64_t)a.nblk, max((int64_t)0, (int64_t)sp * ticket_cells - pad) / block_cells);
+            for (int q = lane; q < nchunk; q += 64) {
+                const int64_t c0 = t0 + (int64_t)q * kScanChunk;
+                int k0 = -1, k1 = -1;
+                if (c0 < nijv) {
+                    const int64_t c0r = max((int64_t)0, c0 - pad), cb = c0r / block_cells;
+                    const double b0 = el[cb * 3] - el[ab * 3], b1 = el[(cb + 1) * 3] - el[ab * 3];      // growth since the published value
+                    const double per = (b1 - b0) / (double)block_cells;
+                    const double g0 = b0 + per * (double)(c0r - cb * block_cells), g1 = g0 + per * (double)kScanChunk;
+                    const double d0 = (double)sv + g0, d1 = (double)sv + g1;
+                    k0 = scan_key((float)d0); k1 = scan_key((float)d1);
+                    if (k0 < 0) { k0 = k1; k1 = -1; }
+                    if (k1 == k0) k1 = -1;
+                    if (k1 < 0 && k0 >= 0) {                      // the estimate may be off by a share of what it added to the exact value
+                        const double u = 0.25 * fabs(g0);
+                        const int ku = scan_key((float)(d0 + u)), kd = scan_key((float)(d0 - u));
+                        k1 = (ku >= 0 && ku != k0) ? ku : (kd >= 0 && kd != k0) ? kd : -1;
+                    }
+                }
+                sm_key[0][q][w] = k0; sm_key[1][q][w] = k1;
+            }
+        }
+        __syncthreads();
+        {   // Every chunk of the ticket; the loads run TWO sub-blocks ahead (two register sets, the loop unrolled by two so that
+            // neither is ever copied): counters showed the waves waiting for memory 61 % of their time with one sub-block ahead
+            // -- a chunk's vector work (~2 us with three waves on the SIMD) is about the latency of its loads under load.
+            // Round 4: THREE sub-blocks ahead (AHEAD register sets, the loop unrolled by as many): the skeleton alone -- loads and
+            // products, no sums -- ran at the pace of a wave's load round trips, not of HBM.
+            constexpr int AHEAD = (MASK8 && !MXL) ? kScanAhead : 2;       // (the r4-mask and mixed-layer forms would spill with three sets)
+            Raw rawA[kScanNV], rawB[kScanNV], rawC[kScanNV];
+            f2v x[3][kScanNV][2];
+            auto chunk = [&](Raw (&raw)[kScanNV], int q) {        // sums chunk q from `raw`, then asks for chunk q + AHEAD * kScanWaves into it
+                if (q >= nchunk) return;                          // (AHEAD = 3 does not divide the chunks of a wave)
+                const int64_t c0 = t0 + (int64_t)q * kScanChunk;
+                if (c0 >= nijv) {                                 // past the end of the level: nothing there
+                    if (lane == 63) for (int ch = 0; ch < 3; ++ch) sm_flag[0][q][ch] = sm_flag[1][q][ch] = 0;
+                    return;
+                }
+                products(raw, c0, x);
+                if (q + AHEAD * kScanWaves < nchunk && c0 + (int64_t)AHEAD * kScanSub < nijv) fetch(raw, c0 + (int64_t)AHEAD * kScanSub);
+                if (!(dbg & 2)) summarize(x, q);      // (dbg: timing experiments of tools/, results then meaningless)
+                else if (lane == 63) for (int ch = 0; ch < 3; ++ch) sm_flag[0][q][ch] = sm_flag[1][q][ch] = 0;     // (chunks of zeros: the walk passes them)
+            };
+            auto first = [&](Raw (&raw)[kScanNV], int q) {
+                if (q < nchunk && t0 + (int64_t)q * kScanChunk < nijv) fetch(raw, t0 + (int64_t)q * kScanChunk);
+            };
+            first(rawA, w);
+            first(rawB, w + kScanWaves);
+            if (AHEAD == 3) first(rawC, w + 2 * kScanWaves);
+#pragma clang loop unroll(disable)
+            for (int q = w; q < nchunk; q += AHEAD * kScanWaves) {
+                chunk(rawA, q);
+                chunk(rawB, q + kScanWaves);
+                if (AHEAD == 3) chunk(rawC, q + 2 * kScanWaves);
+            }
+        }
+        __syncthreads();                                          // the sums of every chunk are in LDS
+        if (ring > 0) {
+            // ---- park the ticket's sums for the level's walker and go on streaming
+            const long long ts1 = ((dbg & 8) && threadIdx.x == 0) ? wall_clock64() : 0;
+            if (threadIdx.x == 0 && step >= ring) {
+                // the slot still holds ticket step - ring until the three chains have passed it (their published tags say so)
+                long long t_start = 0;
+                int spins = 0;
+                for (;;) {
+                    int done = 0x7fffffff;
+                    for (int c = 0; c < 3; ++c)
+                        done = min(done, (int)(__hip_atomic_load(&lev[k].word[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32));
+                    if (done > step - ring) break;
+                    __builtin_amdgcn_s_sleep(2);
+                    if ((++spins & 1023) == 0 || scan_wait_ticks == 0) {
+                        const long long now = wall_clock64();
+                        if (!t_start) t_start = now;
+                        if (now - t_start >= scan_wait_ticks || __hip_atomic_load(&ctl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                            __hip_atomic_store(&ctl->error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            break;
+                        }
+                    }
+                }
+            }
+            if (step >= ring) __syncthreads();
+            const long long ts2 = ((dbg & 8) && threadIdx.x == 0) ? wall_clock64() : 0;
+            // [chain][chunk][4] 64-bit words: (K, pos) and (flag, key) of the first hypothesis, then of the second
+            unsigned long long *slot = reinterpret_cast<unsigned long long *>(park + ((int64_t)k * ring + step % ring) * park_ints);
+            // (agent-scope stores and loads: the slot's lines are written and read by workgroups on different XCDs, ring after ring)
+            auto two = [](int lo, int hi) { return (unsigned long long)(uint32_t)lo | ((unsigned long long)(uint32_t)hi << 32); };
+            for (int idx = threadIdx.x; idx < 3 * nchunk; idx += 64 * kScanWaves) {
+                const int c = idx / nchunk, q = idx - c * nchunk;
+                unsigned long long *o = slot + (int64_t)idx * 4;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    __hip_atomic_store(o + 2 * h, two(sm_K[h][q][c], sm_pos[h][q][c]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(o + 2 * h + 1, two(sm_flag[h][q][c], sm_key[h][q][c]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            // Every wave's stores have been acknowledged (vmcnt(0): they are agent-scope stores, written through this XCD's L2;
+            // the barrier itself only waits for LDS) before the barrier, the ticket is said to be there after it.  (A RELEASE on
+            // the flag would wait for the storing wave's own stores only, and write back the L2 on top.)
+            __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0)
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                __hip_atomic_store(&parked[(int64_t)k * nsteps + step], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (dbg & 8) {
+                    const long long ts3 = wall_clock64();
+                    atomicAdd(&ctl->st_ring, (unsigned long long)(ts2 - ts1)); atomicAdd(&ctl->st_park, (unsigned long long)(ts3 - ts2));
+                    atomicAdd(&ctl->st_all, 1ull);                  // (tickets parked)
+                }
+            }
+        } else
+        // ---- wave ch takes chain ch through the ticket on its own: no workgroup barrier, no other chain waited for
+        if (w < 3) {
+            const int ch = w;
+            // the exact value where this ticket starts: published by the step before (tag == step)
+            unsigned long long pub = 0;
+            if (lane == 0) {
+                // (the step waited for was dealt before this one: it is held by a workgroup that runs.  Two seconds of the
+                // 100 MHz wall clock without it -- a preempted queue, a fault -- raise the error flag; every other wait sees the
+                // flag and gives up too, the kernel ends and the host takes the plain chain instead)
+                long long t_start = 0;
+                int spins = 0;
+                while (!(dbg & 1) && (int)((pub = __hip_atomic_load(&lev[k].word[ch], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != step) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if ((++spins & 1023) == 0 || scan_wait_ticks == 0) {
+                        const long long now = wall_clock64();
+                        if (!t_start) t_start = now;
+                        if (now - t_start >= scan_wait_ticks || __hip_atomic_load(&ctl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                            __hip_atomic_store(&ctl->error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            break;
+                        }
+                    }
+                }
+            }
+            const float s = walk_chain(ch, __uint_as_float((uint32_t)__shfl((int)(uint32_t)pub, 0, 64)));
             // publish: the value where the next step of this level starts
             if (lane == 0) {
                 __hip_atomic_store(&lev[k].word[ch], scan_word(step + 1, s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1083,11 +1244,14 @@ __global__ void heatc_seq_out_kernel(const float *__restrict__ s4, int n, const 
     if (threadIdx.x == 0) {
         ScanCtl c = {};
         if (ctl) { c.ticket = ctl->ticket; c.error = ctl->error; c.nfallback = ctl->nfallback; c.nunguessed = ctl->nunguessed;
-                   c.nslow = ctl->nslow; c.nstolen = ctl->nstolen; }
+                   c.nslow = ctl->nslow; c.nstolen = ctl->nstolen;
+                   c.wk_wait = ctl->wk_wait; c.wk_load = ctl->wk_load; c.wk_walk = ctl->wk_walk; c.st_ring = ctl->st_ring; c.st_park = ctl->st_park;
+                   c.st_all = ctl->st_all; c.t_first = ctl->t_first; c.t_last = ctl->t_last; }
         *hctl = c;
     }
 }
 
+inline bool dbg_stats_on() { const char *e = getenv("CDFT_HEATC_SCAN_DEBUG"); return e && (atoi(e) & 8); }
 // the sampled estimates (heatc_sample_kernel: blocks of kSampleBlock cells -- a multiple of a chunk, a divisor of a ticket), then the scan
 int launch_seq_scan(HeatcArgs a, const float *carry, float *sums4, DevBuf &work, hipStream_t st) {
     const bool m8 = a.mask8 != nullptr, full = a.e31d != nullptr, mx = a.mxlopt != 0;
@@ -1112,11 +1276,25 @@ int launch_seq_scan(HeatcArgs a, const float *carry, float *sums4, DevBuf &work,
                                    "switched off and the sums cdft_heatc_compute returns are WRONG\n", dbg);
         told = true;
     }
+    int dev = 0, ncu = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    const int per_cu = 3;                                       // (the kernel's launch bounds)
+    // Walkers (round 6, see the kernel): on when the levels' walker workgroups leave most of the chip to the streaming ones;
+    // a ring of up to 48 parked tickets per level (59 MB at eORCA12).  CDFT_HEATC_SCAN_WALKERS=0: the round-5 kernel, every
+    // workgroup walking its own ticket (A/B and test hook); CDFT_HEATC_SCAN_RING=n: the ring (tests: 1 and 2)
+    int ring = 4 * a.npk <= per_cu * ncu ? std::min(nsteps, 48) : 0;
+    if (const char *e = getenv("CDFT_HEATC_SCAN_WALKERS")) { if (e[0] == '0') ring = 0; }
+    if (ring > 0) { if (const char *e = getenv("CDFT_HEATC_SCAN_RING")) ring = std::max(1, std::min(nsteps, atoi(e))); }
     const size_t head = (sizeof(ScanLevel) * (size_t)a.npk + sizeof(ScanCtl) + 15) / 16 * 16;
-    CDFT_TRY(work.reserve(head + sizeof(double) * (size_t)a.npk * (a.nblk + 1) * 3));
+    const size_t est_bytes = sizeof(double) * (size_t)a.npk * (a.nblk + 1) * 3;
+    const size_t parked_bytes = ring > 0 ? (sizeof(int) * (size_t)a.npk * nsteps + 15) / 16 * 16 : 0;
+    const size_t park_bytes = ring > 0 ? sizeof(int) * (size_t)a.npk * ring * 24 * nchunk : 0;
+    CDFT_TRY(work.reserve(head + est_bytes + parked_bytes + park_bytes));
     ScanLevel *lev = (ScanLevel *)work.ptr;
     ScanCtl *ctl = (ScanCtl *)(lev + a.npk);
     double *est = (double *)((char *)work.ptr + head);
+    int *parked = ring > 0 ? (int *)((char *)work.ptr + head + est_bytes) : nullptr;
+    int *park = ring > 0 ? (int *)((char *)work.ptr + head + est_bytes + parked_bytes) : nullptr;
     {
         int64_t dense_cells = 32768;                              // read in full: where a chain grows from nothing
         if (const char *e = getenv("CDFT_HEATC_SCAN_DENSE")) dense_cells = std::max(0LL, atoll(e));           // (tuning hook)
@@ -1135,13 +1313,12 @@ int launch_seq_scan(HeatcArgs a, const float *carry, float *sums4, DevBuf &work,
 #undef CDFT_SAMPLE_LAUNCH
         CDFT_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(heatc_scan_est_kernel, dim3(a.npk), dim3(kEstThreads), 0, st, a.partial, a.nblk, carry, est, lev, ctl);
-    int dev = 0, ncu = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    hipLaunchKernelGGL(heatc_scan_est_kernel, dim3(a.npk), dim3(kEstThreads), 0, st, a.partial, a.nblk, carry, est, lev, ctl, parked, nsteps);
     const int64_t tickets = (int64_t)nsteps * a.npk;
-    const int per_cu = 3;                                       // (the kernel's launch bounds)
-    dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>(tickets, per_cu * (int64_t)ncu))), block(64 * kScanWaves);
-#define CDFT_SCAN_LAUNCH(M8, FU, MX) hipLaunchKernelGGL((heatc_scan_kernel<M8, FU, MX>), grid, block, 0, st, a, lev, ctl, est, block_cells, nchunk, nsteps, sums4, wait_ticks, nlanes, align, dbg)
+    // (walkers: the first npk workgroups; with them the grid is what the chip holds at once, so that they all are resident)
+    const int64_t streamers = std::max<int64_t>(1, std::min<int64_t>(tickets, per_cu * (int64_t)ncu - (ring > 0 ? a.npk : 0)));
+    dim3 grid((unsigned)(streamers + (ring > 0 ? a.npk : 0))), block(64 * kScanWaves);
+#define CDFT_SCAN_LAUNCH(M8, FU, MX) hipLaunchKernelGGL((heatc_scan_kernel<M8, FU, MX>), grid, block, 0, st, a, lev, ctl, est, block_cells, nchunk, nsteps, sums4, wait_ticks, nlanes, align, dbg, parked, park, ring)
     if (m8 && full)        { if (mx) CDFT_SCAN_LAUNCH(true, true, true);   else CDFT_SCAN_LAUNCH(true, true, false); }
     else if (m8 && !full)  { if (mx) CDFT_SCAN_LAUNCH(true, false, true);  else CDFT_SCAN_LAUNCH(true, false, false); }
     else if (!m8 && full)  { if (mx) CDFT_SCAN_LAUNCH(false, true, true);  else CDFT_SCAN_LAUNCH(false, true, false); }
@@ -1353,6 +1530,10 @@ int cdft_heatc_compute(cdft_heatc_plan *p, const float *temp, int temp_space, co
             fprintf(stderr, "heatc_scan_kernel: %d tickets, %d chunks resolved cell by cell (%d of them finished by the sequential loop), "
                     "%d times in a binade neither estimate named; %d tickets drawn from another XCD's lane\n", ctl.ticket, ctl.nfallback, ctl.nslow,
                     ctl.nunguessed, ctl.nstolen);
+        if (!chain && getenv("CDFT_HEATC_SCAN_STATS") && (dbg_stats_on()))
+            fprintf(stderr, "heatc_scan_kernel timing (us; CDFT_HEATC_SCAN_DEBUG=8): span %.1f; walker waves: waiting %.1f, loading %.1f, walking %.1f (sums over the waves); "
+                    "streaming workgroups: ring waits %.1f, parking %.1f (sums over the workgroups), %.0f tickets parked\n", (double)(ctl.t_last - ctl.t_first) / 100.0,
+                    ctl.wk_wait / 100.0, ctl.wk_load / 100.0, ctl.wk_walk / 100.0, ctl.st_ring / 100.0, ctl.st_park / 100.0, (double)ctl.st_all);
         if (ctl.error) {
             // a wait that did not end (heatc_scan_kernel): its results are discarded and the plain chain of v_add_f32 --
             // no workgroup waits for another there -- gives the same bits, 25 times slower

@@ -258,6 +258,30 @@ def test_hip_reference_order_scan_that_gives_up_hands_over_to_the_chain(gpu, mon
     assert "plain chain" not in capfd.readouterr().err
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"CDFT_HEATC_SCAN_WALKERS": "0"}, {"CDFT_HEATC_SCAN_RING": "1"}, {"CDFT_HEATC_SCAN_RING": "2"},
+                                 {"CDFT_HEATC_SCAN_RING": "5", "CDFT_HEATC_SCAN_CHUNKS": "64"}, {}],
+                         ids=["no_walkers", "ring1", "ring2", "ring5_small_tickets", "default"])
+def test_hip_reference_order_scan_with_and_without_walkers(gpu, monkeypatch, env):
+    """Round 6: the chains of a level are walked by a workgroup of their own from sums the streaming workgroups park in a ring
+    of slots per level.  The round-5 form (every workgroup walks its own ticket: CDFT_HEATC_SCAN_WALKERS=0), rings of one,
+    two and five slots (a streaming workgroup then waits for its slot to be read) and the default ring: the plain chain's bits,
+    twice in a row on one plan."""
+    npi, npj, npk = 1442, 400, 9
+    g, temp, _ = fields(npi, npj, npk, seed=77)
+    plan = gpu.HeatcPlan(npi, npj, npk)
+    plan.set_mesh(g["e1t"], g["e2t"], g["tmask"].astype(np.uint8), e3t=g["e3t_0"])
+    plan.set_sum_mode(True)
+    monkeypatch.setenv("CDFT_HEATC_SEQ", "chain")
+    want = plan.compute(temp).view(np.uint64)
+    monkeypatch.delenv("CDFT_HEATC_SEQ")
+    for k_, v_ in env.items():
+        monkeypatch.setenv(k_, v_)
+    for _ in range(2):
+        assert np.array_equal(plan.compute(temp).view(np.uint64), want)
+    assert np.array_equal(want.view(np.float64), oracle_tools.heatc(g["e1t"], g["e2t"], g["tmask"], temp, e3t=g["e3t_0"], r4sum=True))
+
+
 FUZZ_SHAPES = [(1, 1, 1), (511, 1, 2), (512, 1, 1), (513, 1, 3), (4, 127, 2), (4096, 8, 1), (4097, 8, 2), (257, 255, 3), (1023, 33, 2),
                (32768, 1, 2), (32769, 1, 1), (181, 181, 5), (65536, 2, 1), (1442, 91, 2), (977, 269, 4), (3, 3, 7)]
 
