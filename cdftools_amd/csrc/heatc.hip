@@ -622,6 +622,15 @@ __global__ void __launch_bounds__(64 * kScanWaves, 3) heatc_scan_kernel(HeatcArg
     // heatc_scan_timeline_eorca025.txt); it waits only when its ring slot is still unread, i.e. when a level's chains are
     // `ring` tickets behind.  No deadlock: a walker waits for tickets that were dealt (held by workgroups that run and wait, if
     // at all, for a walker to pass tickets parked long before); the walkers, first in the grid, are resident before any of them.
+    // Measured (profiles/r06/README.md): 0.50 -> 0.38-0.40 ms per call at eORCA025, 2.10-2.17 -> 2.12-2.26 at eORCA12 (there the
+    // streaming itself, 39 vector instructions a cell beside 9.1 bytes, is the whole time either way).  What it took, each a
+    // measured step: the walker's loads of a ticket's sums all issued before the first is used (the compiler waits for an
+    // atomic load where its value is needed: 32 round trips a ticket, 25 us); no agent-scope ACQUIRE in the polling loop (an
+    // L2 invalidation each: it took the e1t*e2t plane from the streaming workgroups, 2.1 -> 3.1 ms); no RELEASE on the flag
+    // (a write-back of the L2 per ticket: 2.1 -> 2.4 ms; vmcnt(0) in every wave before the barrier instead).  Tried and not
+    // kept: a chunk's sums stored to HBM as they are formed (a wave's loads and stores share one in-order counter: 2.75 ms);
+    // the next ticket drawn while this one streams (a ticket held for a whole ticket's time before it is begun: 0.39 -> 0.44 ms
+    // at eORCA025); the first loads requested before the hypotheses are formed (no difference).
     const bool walker = ring > 0 && (int)blockIdx.x < a.npk;
     if (walker && w >= 3) return;                                 // (a walker has no workgroup barrier)
     const int park_ints = 24 * nchunk;                            // a ticket's sums: [chain][hypothesis][K, pos, flag, key][chunk]
