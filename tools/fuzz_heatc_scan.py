@@ -72,6 +72,17 @@ while time.time() < stop:
     plan.set_sum_mode(True)
     kw = dict(rmxldep=mxl if opt else None, gdepw=gdepw, mxloption=opt)
     os.environ.pop("CDFT_HEATC_SEQ", None)
+    # round 6: the level walkers with their default ring, with rings of 1..3 slots (the streaming workgroups then wait for slots),
+    # with small tickets, and off (every workgroup walks its own ticket)
+    for key in ("CDFT_HEATC_SCAN_WALKERS", "CDFT_HEATC_SCAN_RING", "CDFT_HEATC_SCAN_CHUNKS"):
+        os.environ.pop(key, None)
+    form = rng.random()
+    if form < 0.15:
+        os.environ["CDFT_HEATC_SCAN_WALKERS"] = "0"
+    elif form < 0.45:
+        os.environ["CDFT_HEATC_SCAN_RING"] = str(int(rng.integers(1, 4)))
+    if rng.random() < 0.3:
+        os.environ["CDFT_HEATC_SCAN_CHUNKS"] = "64"
     plan.chain(carry_in=carry)
     a = plan.compute(temp, **kw).view(np.uint64)
     os.environ["CDFT_HEATC_SEQ"] = "chain"
@@ -85,7 +96,7 @@ while time.time() < stop:
     fa, fb = a.view(np.float64), b.view(np.float64)
     same = np.array_equal(np.isnan(fa), np.isnan(fb)) and np.array_equal(a[~np.isnan(fa)], b[~np.isnan(fb)])
     if not same:
-        print(f"MISMATCH seed={seed} case={n} kind={kind} shape={shape} full={full} m8={m8} opt={opt}", flush=True)
+        print(f"MISMATCH seed={seed} case={n} kind={kind} shape={shape} full={full} m8={m8} opt={opt} env={ {k: v for k, v in os.environ.items() if k.startswith('CDFT_HEATC')} }", flush=True)
         print(a, b)
         sys.exit(1)
 print(f"fuzz_heatc_scan: seed {seed}: {n} cases, {cells:.3e} cells, scan kernel == chain bit for bit on all")
