@@ -812,7 +812,7 @@ __global__ void __launch_bounds__(64 * kScanWaves, 3) heatc_scan_kernel(HeatcArg
                 for (int g = from & ~63; g < nchunk && stop < 0; g += 64) {
                     const int q = g + lane;
                     const int f0 = sm_flag[0][q][ch];
-                    const bool live = q >= from && ((f0 & 1) || (minus0 && t0 + (int64_t)q * kScanChunk < nijv));   // zeros: s + 0 = s
+                    const bool live = q >= from && q < nchunk && ((f0 & 1) || (minus0 && t0 + (int64_t)q * kScanChunk < nijv));   // zeros: s + 0 = s
                     const int h = (ks >= 0 && ks == sm_key[0][q][ch]) ? 0 : (ks >= 0 && ks == sm_key[1][q][ch]) ? 1 : -1;
                     const int hh = h < 0 ? 0 : h;
                     const int f = sm_flag[hh][q][ch];
@@ -1272,7 +1272,7 @@ int launch_seq_scan(HeatcArgs a, const float *carry, float *sums4, DevBuf &work,
     // about 32 tickets per level: enough of them in flight for every CU, few enough steps in a level's chain of waits
     int nchunk = 64;
     while (nchunk < kScanMaxChunks && a.nij > (int64_t)nchunk * kScanChunk * 32) nchunk *= 2;
-    if (const char *e = getenv("CDFT_HEATC_SCAN_CHUNKS")) { const int v = atoi(e); if (v == 64 || v == 128 || v == 256) nchunk = v; }   // (tuning hook)
+    if (const char *e = getenv("CDFT_HEATC_SCAN_CHUNKS")) { const int v = atoi(e); if (v >= 8 && v <= kScanMaxChunks && v % 8 == 0) nchunk = v; }   // (tuning hook: a multiple of 8)
     const int64_t ticket_cells = (int64_t)nchunk * kScanChunk;
     const int nsteps = (int)((a.nij + 127 + ticket_cells - 1) / ticket_cells);   // (a level is walked with up to 127 cells of padding in front)
     const int nlanes = scan_lanes(st);
