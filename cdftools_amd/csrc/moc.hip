@@ -125,10 +125,23 @@ __global__ void moc_cumsum_kernel(double *__restrict__ dmoc, int nbj, int npk, i
     double *base = dmoc + t * (int64_t)npk * nbj + q;
     double below = 0.0;
     base[(int64_t)(npk - 1) * nbj] = 0.0;
-    for (int jk = npk - 2; jk >= 0; --jk) {
-        const double v = base[(int64_t)jk * nbj];
-        below = below + v / 1.0e6;
-        base[(int64_t)jk * nbj] = below;
+    // Sixteen levels at a time: their loads first, then the chain, then the stores (round 6).  Level by level -- load, divide,
+    // add, store, and the next load only then, the stores being to the array the loads read -- a thread made 74 memory round
+    // trips: 43 us at any grid size, 4 % of a cdfmoc call at eORCA025.  The same operations in the same order.
+    constexpr int B = 16;
+    for (int j0 = npk - 2; j0 >= 0; j0 -= B) {
+        double v[B];
+#pragma unroll
+        for (int i = 0; i < B; ++i) v[i] = base[(int64_t)max(j0 - i, 0) * nbj];
+#pragma unroll
+        for (int i = 0; i < B; ++i)
+            if (j0 - i >= 0) {                                    // (uniform)
+                below = below + v[i] / 1.0e6;
+                v[i] = below;
+            }
+#pragma unroll
+        for (int i = 0; i < B; ++i)
+            if (j0 - i >= 0) base[(int64_t)(j0 - i) * nbj] = v[i];
     }
 }
 
