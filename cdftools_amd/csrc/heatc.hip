@@ -633,7 +633,7 @@ __global__ void __launch_bounds__(64 * kScanWaves, 3) heatc_scan_kernel(HeatcArg
     // at eORCA025); the first loads requested before the hypotheses are formed (no difference).
     const bool walker = ring > 0 && (int)blockIdx.x < a.npk;
     if (walker && w >= 3) return;                                 // (a walker has no workgroup barrier)
-    const int park_ints = 24 * nchunk;                            // a ticket's sums: [chain][hypothesis][K, pos, flag, key][chunk]
+    const int park_ints = 24 * nchunk;                            // a ticket's slot: [chain][chunk] x 4 64-bit words -- (K, pos), (flag, key) of each hypothesis
 
     // the XCD this workgroup runs on (HW_REG_XCC_ID, bits 3:0)
     const int my_lane = nlanes > 1 ? (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u) % nlanes : 0;
