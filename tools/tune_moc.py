@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--variants", default="")
     ap.add_argument("--npt", type=int, default=0)
     ap.add_argument("--nb", type=int, default=0, help="number of basins (default: the workload's)")
+    ap.add_argument("--staged", action="store_true", help="the records staged into the plan's pool (what bench.py and the program's routes read)")
     args = ap.parse_args()
     npi, npj, npk, npt, nb = bench.WORKLOADS[args.workload]
     if args.npt:
@@ -35,6 +36,9 @@ def main():
     del e3v
     torch.cuda.empty_cache()
     out = torch.empty((npt, npk, npj, nb), dtype=torch.float64, device=dev)
+    if args.staged:
+        plan.stage(zv)
+    run = (lambda: plan.compute_staged(out)) if args.staged else (lambda: plan.compute(zv, out=out))
     if args.variants:
         variants = [tuple(int(x) for x in v.split(",")) for v in args.variants.split(";")]
     else:
@@ -52,14 +56,14 @@ def main():
         for v in variants:
             try:
                 plan.set_tuning(*v)
-                plan.compute(zv, out=out)          # warm
+                run()                              # warm
             except Exception as e:                 # a shape this row length or mode does not allow
                 if rnd == 0:
                     print(json.dumps({"variant": v, "refused": str(e)}), flush=True)
                 continue
             plan.profile_enable(True)
-            for _ in range(3):
-                plan.compute(zv, out=out)
+            for _ in range(5 if args.staged else 3):
+                run()
             plan.profile_enable(False)
             ms, n = plan.profile_read()
             ms /= n
