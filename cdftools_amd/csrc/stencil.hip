@@ -303,9 +303,16 @@ __global__ void __launch_bounds__(kThreads) curl_kernel(CurlArgs a) {
 #define CDFT_CURL_PF 2
 #endif
 constexpr int kCurlPF = CDFT_CURL_PF;                             // level buffers in registers (kCurlPF-1 in flight)
+#ifndef CDFT_CURL_FPF
+#define CDFT_CURL_FPF 2
+#endif
+constexpr int kCurlFPF = CDFT_CURL_FPF;                           // the same for the inner tiles' loop
+#ifndef CDFT_CURL_WPE
+#define CDFT_CURL_WPE 6
+#endif
 
 template <typename OUT, bool KEEP>
-__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 8))) curl_tile_kernel(CurlArgs a, int tw, int lc) {
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(CDFT_CURL_WPE, 8))) curl_tile_kernel(CurlArgs a, int tw, int lc) {
     const int lane = threadIdx.x & 63;
     const int64_t tiles = (int64_t)a.ntx * a.npj, total = tiles * lc;
     int chunk, jj, tx;
