@@ -1025,6 +1025,9 @@ __global__ void __launch_bounds__(64 * kScanWaves, 3) heatc_scan_kernel(HeatcArg
         return;
     }
 
+    __shared__ int own_empty;                                     // (thread 0's) this XCD's lane has come back empty once
+    if (threadIdx.x == 0) own_empty = 0;
+    int pending = -1;                                             // the ticket parked last, not yet said to be there (index into `parked`)
     for (;;) {
         // Dealing.  Lane x of `nlanes` holds the steps x, x + nlanes, ... of every level, in that order; a workgroup draws from
         // the lane of the XCD it runs on, and from the next lanes once its own is empty.  The 75 levels of a step multiply
@@ -1038,17 +1041,34 @@ __global__ void __launch_bounds__(64 * kScanWaves, 3) heatc_scan_kernel(HeatcArg
             for (int o = 0; o < nlanes && t < 0; ++o) {
                 const int x = (my_lane + o) % nlanes;
                 const int steps_x = (nsteps - x + nlanes - 1) / nlanes;            // steps x, x + nlanes, ... < nsteps
-                if (steps_x <= 0 || __hip_atomic_load(&ctl->lane_next[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= steps_x * a.npk) continue;
+                // (the workgroup's own lane is drawn from without a look first -- one round trip instead of two -- until it has
+                // once come back empty)
+                if (steps_x <= 0 || ((o > 0 || own_empty) &&
+                                     __hip_atomic_load(&ctl->lane_next[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= steps_x * a.npk)) continue;
                 const int i = __hip_atomic_fetch_add(&ctl->lane_next[x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (i < steps_x * a.npk) {
                     t = (x + nlanes * (i / a.npk)) * a.npk + i % a.npk;
                     if (o) atomicAdd(&ctl->nstolen, 1);
+                } else if (o == 0) {
+                    own_empty = 1;
                 }
             }
             if (t >= 0) atomicAdd(&ctl->ticket, 1);
             tick = t;
         }
+        // (walkers) the stores that parked the ticket before have been acknowledged -- vmcnt(0) in every wave: agent-scope stores,
+        // written through this XCD's L2; the barrier itself only waits for LDS -- before the barrier, that ticket is said to be
+        // there after it: the stores' way to memory goes by under the drawing of this ticket.  (A RELEASE on the flag would wait
+        // for the storing wave's own stores only, and write back the L2 on top: 2.1 -> 2.4 ms at eORCA12.)
+        if (pending >= 0) __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0)
         __syncthreads();
+        if (pending >= 0) {
+            if (threadIdx.x == 0) {
+                __hip_atomic_store(&parked[pending], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (dbg & 8) atomicAdd(&ctl->st_all, 1ull);       // (tickets parked)
+            }
+            pending = -1;
+        }
         const int ticket = tick;
         if (ticket < 0) break;                                    // (uniform)
         set_ticket(ticket % a.npk, ticket / a.npk);
@@ -1157,19 +1177,8 @@ __global__ void __launch_bounds__(64 * kScanWaves, 3) heatc_scan_kernel(HeatcArg
                     __hip_atomic_store(o + 2 * h + 1, two(sm_flag[h][q][c], sm_key[h][q][c]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
-            // Every wave's stores have been acknowledged (vmcnt(0): they are agent-scope stores, written through this XCD's L2;
-            // the barrier itself only waits for LDS) before the barrier, the ticket is said to be there after it.  (A RELEASE on
-            // the flag would wait for the storing wave's own stores only, and write back the L2 on top.)
-            __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0)
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                __hip_atomic_store(&parked[(int64_t)k * nsteps + step], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (dbg & 8) {
-                    const long long ts3 = wall_clock64();
-                    atomicAdd(&ctl->st_ring, (unsigned long long)(ts2 - ts1)); atomicAdd(&ctl->st_park, (unsigned long long)(ts3 - ts2));
-                    atomicAdd(&ctl->st_all, 1ull);                  // (tickets parked)
-                }
-            }
+            pending = k * nsteps + step;                          // (said to be there at the next drawing, above)
+            if ((dbg & 8) && threadIdx.x == 0) { atomicAdd(&ctl->st_ring, (unsigned long long)(ts2 - ts1)); atomicAdd(&ctl->st_park, (unsigned long long)(wall_clock64() - ts2)); }
         } else
         // ---- wave ch takes chain ch through the ticket on its own: no workgroup barrier, no other chain waited for
         if (w < 3) {
@@ -1201,7 +1210,7 @@ __global__ void __launch_bounds__(64 * kScanWaves, 3) heatc_scan_kernel(HeatcArg
                 if (step == nsteps - 1) sums4[k * 3 + ch] = s;
             }
         }
-        __syncthreads();                                          // (the LDS arrays are written again by the next ticket)
+        if (ring == 0) __syncthreads();                           // (the LDS arrays are written again by the next ticket; with walkers the barrier of the next drawing stands between)
     }
 }
 
