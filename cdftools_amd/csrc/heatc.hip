@@ -371,6 +371,10 @@ __global__ void __launch_bounds__(64) heatc_seq_kernel(HeatcArgs a, const float 
 // a workgroup waits for was dealt before its own, it is held by a workgroup that already runs: no deadlock whatever
 // else shares the GPU; a wait that lasts over a second raises an error flag instead of hanging.  Bit-identical to
 // heatc_seq_kernel (tests/test_heatc.py compares the two on adversarial fields and at size).
+// Since round 6 that paragraph describes the form without WALKERS (CDFT_HEATC_SCAN_WALKERS=0, and launches of more
+// levels than a quarter of the chip's workgroup slots): by default the workgroup that formed a ticket's sums does not
+// wait and does not walk -- it parks the sums in HBM for the level's walker workgroup and draws the next ticket; see the
+// kernel.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kScanWaves = 4, kScanNV = 2, kScanChunk = kScanNV * 256, kScanSub = kScanWaves * kScanChunk;
 #ifndef CDFT_SCAN_AHEAD
