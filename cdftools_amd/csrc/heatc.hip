@@ -637,7 +637,7 @@ __global__ void __launch_bounds__(64 * kScanWaves, 3) heatc_scan_kernel(HeatcArg
     // at eORCA025); the first loads requested before the hypotheses are formed (no difference).
     const bool walker = ring > 0 && (int)blockIdx.x < a.npk;
     if (walker && w >= 3) return;                                 // (a walker has no workgroup barrier)
-    const int park_ints = 24 * nchunk;                            // a ticket's slot: [chain][chunk] x 4 64-bit words -- (K, pos), (flag, key) of each hypothesis
+    const int park_ints = 24 * nchunk;                            // a ticket's slot: [chain][4 64-bit words][chunk] -- (K, pos), (flag, key) of each hypothesis
 
     // the XCD this workgroup runs on (HW_REG_XCC_ID, bits 3:0)
     const int my_lane = nlanes > 1 ? (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u) % nlanes : 0;
@@ -992,11 +992,14 @@ __global__ void __launch_bounds__(64 * kScanWaves, 3) heatc_scan_kernel(HeatcArg
             const unsigned long long *slot = reinterpret_cast<const unsigned long long *>(park + ((int64_t)k * ring + step % ring) * park_ints) +
                                              (int64_t)ch * nchunk * 4;
             unsigned long long pw[kScanMaxChunks / 64][4];
+            const bool second = (there >> (1 + ch)) & 1;         // (uniform) the ticket has second hypotheses for this chain
 #pragma unroll
             for (int i = 0; i < kScanMaxChunks / 64; ++i) {
-                const unsigned long long *o = slot + (int64_t)min(lane + 64 * i, nchunk - 1) * 4;
+                const unsigned long long *o = slot + min(lane + 64 * i, nchunk - 1);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) pw[i][j] = __hip_atomic_load(o + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int j = 0; j < 4; ++j)
+                    pw[i][j] = (j < 2 || second) ? __hip_atomic_load(o + j * nchunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                                 : (j == 3 ? 0xffffffff00000000ull : 0ull);      // (flag 0, key -1: no such hypothesis)
             }
 #pragma unroll
             for (int i = 0; i < kScanMaxChunks / 64; ++i) {
@@ -1031,7 +1034,8 @@ __global__ void __launch_bounds__(64 * kScanWaves, 3) heatc_scan_kernel(HeatcArg
 
     __shared__ int own_empty;                                     // (thread 0's) this XCD's lane has come back empty once
     if (threadIdx.x == 0) own_empty = 0;
-    int pending = -1;                                             // the ticket parked last, not yet said to be there (index into `parked`)
+    int pending = -1, pending_val = 0;                            // the ticket parked last, not yet said to be there (index into `parked`), and its flag
+    __shared__ int sm_has1;
     for (;;) {
         // Dealing.  Lane x of `nlanes` holds the steps x, x + nlanes, ... of every level, in that order; a workgroup draws from
         // the lane of the XCD it runs on, and from the next lanes once its own is empty.  The 75 levels of a step multiply
@@ -1059,6 +1063,7 @@ __global__ void __launch_bounds__(64 * kScanWaves, 3) heatc_scan_kernel(HeatcArg
             }
             if (t >= 0) atomicAdd(&ctl->ticket, 1);
             tick = t;
+            sm_has1 = 0;
         }
         // (walkers) the stores that parked the ticket before have been acknowledged -- vmcnt(0) in every wave: agent-scope stores,
         // written through this XCD's L2; the barrier itself only waits for LDS -- before the barrier, that ticket is said to be
@@ -1068,7 +1073,7 @@ __global__ void __launch_bounds__(64 * kScanWaves, 3) heatc_scan_kernel(HeatcArg
         __syncthreads();
         if (pending >= 0) {
             if (threadIdx.x == 0) {
-                __hip_atomic_store(&parked[pending], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&parked[pending], pending_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // 1 | chains with second words << 1
                 if (dbg & 8) atomicAdd(&ctl->st_all, 1ull);       // (tickets parked)
             }
             pending = -1;
@@ -1168,19 +1173,37 @@ __global__ void __launch_bounds__(64 * kScanWaves, 3) heatc_scan_kernel(HeatcArg
             }
             if (step >= ring) __syncthreads();
             const long long ts2 = ((dbg & 8) && threadIdx.x == 0) ? wall_clock64() : 0;
-            // [chain][chunk][4] 64-bit words: (K, pos) and (flag, key) of the first hypothesis, then of the second
+            // [chain][word 0..3][chunk], 64-bit words: (K, pos) and (flag, key) of the first hypothesis, then of the second -- the chunk
+            // innermost, so that a store instruction of a wave writes 512 contiguous bytes (with the four words of a chunk side by
+            // side each instruction wrote 8 bytes of every 32: counters had 0.75 B per cell written for 0.19 parked)
             unsigned long long *slot = reinterpret_cast<unsigned long long *>(park + ((int64_t)k * ring + step % ring) * park_ints);
             // (agent-scope stores and loads: the slot's lines are written and read by workgroups on different XCDs, ring after ring)
             auto two = [](int lo, int hi) { return (unsigned long long)(uint32_t)lo | ((unsigned long long)(uint32_t)hi << 32); };
+            // which chains have a chunk with a second hypothesis at all (few tickets do: the ones near a power of two): the others'
+            // second words are neither stored nor, by the walker, loaded -- half the parked bytes
+            {
+                int mine = 0;
+                for (int idx = threadIdx.x; idx < 3 * nchunk; idx += 64 * kScanWaves) {
+                    const int c = idx / nchunk, q = idx - c * nchunk;
+                    if (sm_key[1][q][c] >= 0) mine |= 1 << c;
+                }
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    if (__builtin_amdgcn_ballot_w64((mine >> c) & 1) != 0 && lane == 0) atomicOr(&sm_has1, 1 << c);
+            }
+            __syncthreads();
+            const int has1 = sm_has1;
             for (int idx = threadIdx.x; idx < 3 * nchunk; idx += 64 * kScanWaves) {
                 const int c = idx / nchunk, q = idx - c * nchunk;
-                unsigned long long *o = slot + (int64_t)idx * 4;
+                unsigned long long *o = slot + (int64_t)c * 4 * nchunk + q;
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    __hip_atomic_store(o + 2 * h, two(sm_K[h][q][c], sm_pos[h][q][c]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(o + 2 * h + 1, two(sm_flag[h][q][c], sm_key[h][q][c]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (h == 1 && !((has1 >> c) & 1)) continue;
+                    __hip_atomic_store(o + (2 * h) * nchunk, two(sm_K[h][q][c], sm_pos[h][q][c]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(o + (2 * h + 1) * nchunk, two(sm_flag[h][q][c], sm_key[h][q][c]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
+            pending_val = 1 | (has1 << 1);
             pending = k * nsteps + step;                          // (said to be there at the next drawing, above)
             if ((dbg & 8) && threadIdx.x == 0) { atomicAdd(&ctl->st_ring, (unsigned long long)(ts2 - ts1)); atomicAdd(&ctl->st_park, (unsigned long long)(wall_clock64() - ts2)); }
         } else
