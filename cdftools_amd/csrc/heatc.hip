@@ -380,6 +380,9 @@ constexpr int kScanWaves = 4, kScanNV = 2, kScanChunk = kScanNV * 256, kScanSub 
 #ifndef CDFT_SCAN_AHEAD
 #define CDFT_SCAN_AHEAD 3
 #endif
+#ifndef CDFT_SCAN_WGS
+#define CDFT_SCAN_WGS 3
+#endif
 constexpr int kScanAhead = CDFT_SCAN_AHEAD;                       // sub-blocks of loads in flight ahead of the one being summed: 2 or 3
 constexpr int kScanMaxChunks = 256;                               // chunks per ticket: 64, 128 or 256 (32768 .. 131072 cells)
 
@@ -608,7 +611,7 @@ __global__ void __launch_bounds__(kEstThreads) heatc_scan_est_kernel(const doubl
 
 template <bool MASK8, bool FULL, bool MXL>
 // (four workgroups per CU -- 128 VGPRs, no spill in the byte-mask form -- were measured in round 4: no faster, 2.27 against 2.20 ms)
-__global__ void __launch_bounds__(64 * kScanWaves, 3) heatc_scan_kernel(HeatcArgs a, ScanLevel *__restrict__ lev, ScanCtl *__restrict__ ctl,
+__global__ void __launch_bounds__(64 * kScanWaves, CDFT_SCAN_WGS) heatc_scan_kernel(HeatcArgs a, ScanLevel *__restrict__ lev, ScanCtl *__restrict__ ctl,
                                                                      const double *__restrict__ est, int block_cells, int nchunk, int nsteps,
                                                                      float *__restrict__ sums4, long long scan_wait_ticks, int nlanes, int align, int dbg,
                                                                      int *__restrict__ parked, int *__restrict__ park, int ring) {
@@ -1323,7 +1326,7 @@ int launch_seq_scan(HeatcArgs a, const float *carry, float *sums4, DevBuf &work,
     }
     int dev = 0, ncu = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-    const int per_cu = 3;                                       // (the kernel's launch bounds)
+    const int per_cu = CDFT_SCAN_WGS;                           // (the kernel's launch bounds)
     // Walkers (round 6, see the kernel): on when the levels' walker workgroups leave most of the chip to the streaming ones;
     // a ring of up to 48 parked tickets per level (59 MB at eORCA12).  CDFT_HEATC_SCAN_WALKERS=0: the round-5 kernel, every
     // workgroup walking its own ticket (A/B and test hook); CDFT_HEATC_SCAN_RING=n: the ring (tests: 1 and 2)
