@@ -1066,7 +1066,6 @@ __global__ void __launch_bounds__(64 * kScanWaves, CDFT_SCAN_WGS) heatc_scan_ker
             }
             if (t >= 0) atomicAdd(&ctl->ticket, 1);
             tick = t;
-            sm_has1 = 0;
         }
         // (walkers) the stores that parked the ticket before have been acknowledged -- vmcnt(0) in every wave: agent-scope stores,
         // written through this XCD's L2; the barrier itself only waits for LDS -- before the barrier, that ticket is said to be
@@ -1083,6 +1082,7 @@ __global__ void __launch_bounds__(64 * kScanWaves, CDFT_SCAN_WGS) heatc_scan_ker
         }
         const int ticket = tick;
         if (ticket < 0) break;                                    // (uniform)
+        if (threadIdx.x == 0) sm_has1 = 0;                        // (every wave is past its last reading of it: the barrier above; next written after two more)
         set_ticket(ticket % a.npk, ticket / a.npk);
         if ((dbg & 8) && threadIdx.x == 0) atomicMin(&ctl->t_first, (unsigned long long)wall_clock64());
         if (w < 3) {
