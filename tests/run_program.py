@@ -1,12 +1,18 @@
-"""One program run under a time limit, for every test that starts one of cdftools_amd/bin.  A run that does not end is a FAILURE, at
-once (a program of a test grid takes a third of a second): before it is killed, the state, wait channel and system call of each of
-its threads are read from /proc, a backtrace of every thread is taken when rocgdb may attach, and the whole goes to
-gpurun_out/hung_programs.txt (what travels back from the GPU box) and into the assertion.  Round 5 saw one run in several thousand not
-end and could not make it happen again (tools/stress_feed.py: 4 196 runs in a row without one); its tests tried such a run once
-more, which would have let a deadlock in the ring, the events or the I/O threads through -- the round-5 advisor's finding."""
+"""One program run under a time limit, for every test that starts one of cdftools_amd/bin.  A run that does not end is never tried
+again and never passes: before it is killed, the state, wait channel and system call of each of its threads are read from /proc,
+a backtrace of every thread is taken when rocgdb may attach, and the whole goes to gpurun_out/hung_programs.txt (what travels
+back from the GPU box), to stderr and into the test's outcome -- XFAILED with the report as its reason (`pytest -rx` prints it; the
+summary line counts it), or FAILED when CDFT_TEST_HANG=fail (the builder's stress runs).  Round 5 saw one run in several
+thousand not end and could not make it happen again (some 25 000 program runs since, round 6's 9 000 included, without one:
+profiles/r06/README.md, section 5); its tests tried such a run once more, which would have let a deadlock in the ring, the events or
+the I/O threads through unseen -- the round-5 advisor's finding, who asked for a failure "or at least a loud xfail" with the
+threads' state captured.  The xfail is the default because nothing is known of where the one occurrence so far stood (it may as
+well have been the HIP runtime's start or end of a process as this repository's code): a suite run must not go red on it, and
+must not hide it either."""
 import glob
 import os
 import subprocess
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -49,5 +55,9 @@ def run_watched(argv, cwd, env, timeout, executable=None, preexec_fn=None):
                 f.write(report)
         except OSError:
             pass
-        raise AssertionError(report)
+        sys.stderr.write(report)
+        if os.environ.get("CDFT_TEST_HANG", "xfail") == "fail":
+            raise AssertionError(report)
+        import pytest
+        pytest.xfail("a program run did not end (described in gpurun_out/hung_programs.txt):\n" + report)
     return subprocess.CompletedProcess(argv, p.returncode, so, se)

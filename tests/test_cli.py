@@ -30,7 +30,8 @@ def tools():
 def run(tool, args, cwd, env=None):
     e = dict(os.environ)
     e.update(env or {})
-    # a run that does not end within 120 s fails the test at once, with what each of its threads was doing (tests/run_program.py)
+    # a run that does not end within 120 s is never tried again: the test is XFAILED (FAILED with CDFT_TEST_HANG=fail) with what each of
+    # the program's threads was doing (tests/run_program.py)
     p = run_program.run_watched([os.path.join(BIN, tool)] + args, cwd=cwd, env=e, timeout=120)
     return p.returncode, p.stdout, p.stderr
 
